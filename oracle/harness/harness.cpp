@@ -1,0 +1,387 @@
+// Headless step-and-dump harness with a plain C ABI (TEST INFRASTRUCTURE, not product).
+//
+// Compiled twice from this one source (see oracle/Makefile and box2d-mt_amd/Makefile):
+//   -DB2H_BACKEND_REF  against /root/reference (sources compiled where they lie) -> oracle/_ref/libb2ref_harness.so
+//   -DB2H_BACKEND_AMD  against this repo's drop-in Box2D headers + libb2hip.so   -> box2d-mt_amd/libb2amd_harness.so
+// The harness pattern follows the reference's own batch runner (Testbed/Framework/TestMT.cpp:50-132):
+// build a scene, step it with a b2ThreadPoolTaskExecutor, read back every body in creation order.
+#include "scenes.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <map>
+
+#if !defined(B2H_BACKEND_REF) && !defined(B2H_BACKEND_AMD)
+#error "define B2H_BACKEND_REF or B2H_BACKEND_AMD"
+#endif
+
+struct b2h_world
+{
+	b2World* world;
+	b2ThreadPoolTaskExecutor* executor;
+	b2h::Scene scene;
+	std::map<const b2Body*, int> bodyIndex;
+	float profileSum[13];
+	int profileSteps;
+};
+
+enum
+{
+	B2H_FLAG_CONTINUOUS = 1,
+	B2H_FLAG_ALLOW_SLEEP = 2,
+	B2H_FLAG_WARM_START = 4,
+	B2H_FLAG_SUBSTEPPING = 8
+};
+
+extern "C"
+{
+
+const char* b2h_backend()
+{
+#ifdef B2H_BACKEND_REF
+	return "reference";
+#else
+	return "amd";
+#endif
+}
+
+b2h_world* b2h_create(int scene, int p0, int p1, float f0, float f1, unsigned seed, int flags, int threads)
+{
+	b2h_world* h = new b2h_world;
+	b2ThreadPoolOptions opt;
+	opt.totalThreadCount = threads;
+	h->executor = new b2ThreadPoolTaskExecutor(opt);
+	h->world = new b2World(b2Vec2(0.0f, -10.0f));
+	h->world->SetContinuousPhysics((flags & B2H_FLAG_CONTINUOUS) != 0);
+	h->world->SetAllowSleeping((flags & B2H_FLAG_ALLOW_SLEEP) != 0);
+	h->world->SetWarmStarting((flags & B2H_FLAG_WARM_START) != 0);
+	h->world->SetSubStepping((flags & B2H_FLAG_SUBSTEPPING) != 0);
+	b2h::SceneParams p;
+	p.scene = scene;
+	p.p0 = p0;
+	p.p1 = p1;
+	p.f0 = f0;
+	p.f1 = f1;
+	p.seed = seed;
+	b2h::BuildScene(h->scene, h->world, p);
+	for (size_t i = 0; i < h->scene.bodies.size(); ++i)
+	{
+		h->bodyIndex[h->scene.bodies[i]] = (int)i;
+	}
+	memset(h->profileSum, 0, sizeof(h->profileSum));
+	h->profileSteps = 0;
+	return h;
+}
+
+void b2h_destroy(b2h_world* h)
+{
+	if (h == NULL) return;
+	delete h->world;
+	delete h->executor;
+	delete h;
+}
+
+void b2h_default_iters(b2h_world* h, int* velIters, int* posIters)
+{
+	*velIters = h->scene.velIters;
+	*posIters = h->scene.posIters;
+}
+
+void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
+{
+	for (int i = 0; i < steps; ++i)
+	{
+		h->world->Step(dt, velIters, posIters, *h->executor);
+		const b2Profile& p = h->world->GetProfile();
+		const float v[13] = { p.step, p.collide, p.solve, p.solveTraversal, p.solveInit, p.solveVelocity,
+			p.solvePosition, p.solveTOI, p.solveTOIFindMinContact, p.broadphase, p.broadphaseSyncFixtures,
+			p.broadphaseFindContacts, p.locking };
+		for (int k = 0; k < 13; ++k) h->profileSum[k] += v[k];
+		h->profileSteps += 1;
+	}
+}
+
+int b2h_body_count(b2h_world* h)
+{
+	return (int)h->scene.bodies.size();
+}
+
+// 8 floats per body, creation order: x, y, angle, vx, vy, w, awake(0/1), type
+void b2h_get_bodies(b2h_world* h, float* out)
+{
+	for (size_t i = 0; i < h->scene.bodies.size(); ++i)
+	{
+		const b2Body* b = h->scene.bodies[i];
+		float* o = out + 8 * i;
+		o[0] = b->GetPosition().x;
+		o[1] = b->GetPosition().y;
+		o[2] = b->GetAngle();
+		o[3] = b->GetLinearVelocity().x;
+		o[4] = b->GetLinearVelocity().y;
+		o[5] = b->GetAngularVelocity();
+		o[6] = b->IsAwake() ? 1.0f : 0.0f;
+		o[7] = (float)b->GetType();
+	}
+}
+
+// 6 floats per body: mass, inertia (about center), local center x,y, world center x,y
+void b2h_get_mass(b2h_world* h, float* out)
+{
+	for (size_t i = 0; i < h->scene.bodies.size(); ++i)
+	{
+		const b2Body* b = h->scene.bodies[i];
+		float* o = out + 6 * i;
+		o[0] = b->GetMass();
+		o[1] = b->GetInertia();
+		o[2] = b->GetLocalCenter().x;
+		o[3] = b->GetLocalCenter().y;
+		o[4] = b->GetWorldCenter().x;
+		o[5] = b->GetWorldCenter().y;
+	}
+}
+
+int b2h_contact_count(b2h_world* h)
+{
+	return h->world->GetContactCount();
+}
+
+static int FixtureIndexInBody(const b2Fixture* f)
+{
+	// The fixture list is newest-first (b2Body.cpp:210-211); index = creation order within the body.
+	const b2Body* b = f->GetBody();
+	int total = 0, pos = -1;
+	for (const b2Fixture* g = b->GetFixtureList(); g; g = g->GetNext())
+	{
+		if (g == f) pos = total;
+		++total;
+	}
+	return total - 1 - pos;
+}
+
+// Dumps every contact of the world's contact list.
+//   ids:      4 ints  per contact: bodyA, fixtureA (index within body), bodyB, fixtureB
+//   flags:    1 int   per contact: bit0 touching, bit1 enabled
+//   manifold: 16 floats per contact: type, pointCount, localNormal.xy, localPoint.xy,
+//             then per point (2x): localPoint.xy, normalImpulse, tangentImpulse, id.key (bit pattern as float)
+// Returns the number of contacts written (<= cap). Order is the list order of the backend and is
+// NOT comparable between backends: sort by ids on the caller's side.
+int b2h_get_contacts(b2h_world* h, int cap, int* ids, int* flags, float* manifold)
+{
+	int n = 0;
+	for (const b2Contact* c = h->world->GetContactList(); c && n < cap; c = c->GetNext())
+	{
+		const b2Fixture* fA = c->GetFixtureA();
+		const b2Fixture* fB = c->GetFixtureB();
+		ids[4 * n + 0] = h->bodyIndex[fA->GetBody()];
+		ids[4 * n + 1] = FixtureIndexInBody(fA);
+		ids[4 * n + 2] = h->bodyIndex[fB->GetBody()];
+		ids[4 * n + 3] = FixtureIndexInBody(fB);
+		flags[n] = (c->IsTouching() ? 1 : 0) | (c->IsEnabled() ? 2 : 0);
+		const b2Manifold* m = c->GetManifold();
+		float* o = manifold + 16 * n;
+		memset(o, 0, 16 * sizeof(float));
+		o[0] = (float)m->type;
+		o[1] = (float)m->pointCount;
+		if (m->pointCount > 0)
+		{
+			o[2] = m->localNormal.x;
+			o[3] = m->localNormal.y;
+			o[4] = m->localPoint.x;
+			o[5] = m->localPoint.y;
+			for (int k = 0; k < m->pointCount; ++k)
+			{
+				float* q = o + 6 + 5 * k;
+				q[0] = m->points[k].localPoint.x;
+				q[1] = m->points[k].localPoint.y;
+				q[2] = m->points[k].normalImpulse;
+				q[3] = m->points[k].tangentImpulse;
+				uint32 key = m->points[k].id.key;
+				memcpy(q + 4, &key, 4);
+			}
+		}
+		++n;
+	}
+	return n;
+}
+
+// Mean of the 13 b2Profile fields (b2TimeStep.h:25-40, in declaration order) over the steps taken so far.
+// Returns the number of steps averaged.
+int b2h_get_profile(b2h_world* h, float* out)
+{
+	float inv = h->profileSteps > 0 ? 1.0f / (float)h->profileSteps : 0.0f;
+	for (int k = 0; k < 13; ++k) out[k] = h->profileSum[k] * inv;
+	return h->profileSteps;
+}
+
+void b2h_reset_profile(b2h_world* h)
+{
+	memset(h->profileSum, 0, sizeof(h->profileSum));
+	h->profileSteps = 0;
+}
+
+// --- per-function probes (shape-level narrow phase and trig), used to pin the C restatement and
+// --- the device math bit-for-bit. Polygons are passed as count + 8 vertices (hull is rebuilt by Set()).
+
+static void FillPolygon(b2PolygonShape& poly, int count, const float* verts, int asBox)
+{
+	if (asBox)
+	{
+		poly.SetAsBox(verts[0], verts[1]);
+	}
+	else
+	{
+		b2Vec2 v[b2_maxPolygonVertices];
+		for (int i = 0; i < count; ++i) v[i].Set(verts[2 * i], verts[2 * i + 1]);
+		poly.Set(v, count);
+	}
+}
+
+static void DumpManifold(const b2Manifold& m, float* o)
+{
+	memset(o, 0, 16 * sizeof(float));
+	o[0] = (float)m.type;
+	o[1] = (float)m.pointCount;
+	if (m.pointCount == 0) return;
+	o[2] = m.localNormal.x;
+	o[3] = m.localNormal.y;
+	o[4] = m.localPoint.x;
+	o[5] = m.localPoint.y;
+	for (int k = 0; k < m.pointCount; ++k)
+	{
+		float* q = o + 6 + 5 * k;
+		q[0] = m.points[k].localPoint.x;
+		q[1] = m.points[k].localPoint.y;
+		uint32 key = m.points[k].id.key;
+		memcpy(q + 4, &key, 4);
+	}
+}
+
+static b2Transform MakeXf(const float* xf)
+{
+	b2Transform t;
+	t.p.Set(xf[0], xf[1]);
+	t.q.Set(xf[2]);
+	return t;
+}
+
+// xf = {px, py, angle}
+void b2h_probe_collide_polygons(int countA, const float* vertsA, int boxA, const float* xfA,
+	int countB, const float* vertsB, int boxB, const float* xfB, float* manifold16)
+{
+	b2PolygonShape a, b;
+	FillPolygon(a, countA, vertsA, boxA);
+	FillPolygon(b, countB, vertsB, boxB);
+	b2Manifold m;
+	memset(&m, 0, sizeof(m));
+	b2CollidePolygons(&m, &a, MakeXf(xfA), &b, MakeXf(xfB));
+	DumpManifold(m, manifold16);
+}
+
+void b2h_probe_collide_polygon_circle(int countA, const float* vertsA, int boxA, const float* xfA,
+	const float* circleB /* px, py, r */, const float* xfB, float* manifold16)
+{
+	b2PolygonShape a;
+	FillPolygon(a, countA, vertsA, boxA);
+	b2CircleShape c;
+	c.m_p.Set(circleB[0], circleB[1]);
+	c.m_radius = circleB[2];
+	b2Manifold m;
+	memset(&m, 0, sizeof(m));
+	b2CollidePolygonAndCircle(&m, &a, MakeXf(xfA), &c, MakeXf(xfB));
+	DumpManifold(m, manifold16);
+}
+
+void b2h_probe_collide_circles(const float* circleA, const float* xfA, const float* circleB, const float* xfB,
+	float* manifold16)
+{
+	b2CircleShape a, b;
+	a.m_p.Set(circleA[0], circleA[1]);
+	a.m_radius = circleA[2];
+	b.m_p.Set(circleB[0], circleB[1]);
+	b.m_radius = circleB[2];
+	b2Manifold m;
+	memset(&m, 0, sizeof(m));
+	b2CollideCircles(&m, &a, MakeXf(xfA), &b, MakeXf(xfB));
+	DumpManifold(m, manifold16);
+}
+
+// edge = {v1x, v1y, v2x, v2y, hasV0, v0x, v0y, hasV3, v3x, v3y}
+static void FillEdge(b2EdgeShape& e, const float* edge)
+{
+	e.Set(b2Vec2(edge[0], edge[1]), b2Vec2(edge[2], edge[3]));
+	if (edge[4] != 0.0f)
+	{
+		e.m_hasVertex0 = true;
+		e.m_vertex0.Set(edge[5], edge[6]);
+	}
+	if (edge[7] != 0.0f)
+	{
+		e.m_hasVertex3 = true;
+		e.m_vertex3.Set(edge[8], edge[9]);
+	}
+}
+
+void b2h_probe_collide_edge_polygon(const float* edgeA, const float* xfA,
+	int countB, const float* vertsB, int boxB, const float* xfB, float* manifold16)
+{
+	b2EdgeShape e;
+	FillEdge(e, edgeA);
+	b2PolygonShape b;
+	FillPolygon(b, countB, vertsB, boxB);
+	b2Manifold m;
+	memset(&m, 0, sizeof(m));
+	b2CollideEdgeAndPolygon(&m, &e, MakeXf(xfA), &b, MakeXf(xfB));
+	DumpManifold(m, manifold16);
+}
+
+void b2h_probe_collide_edge_circle(const float* edgeA, const float* xfA, const float* circleB, const float* xfB,
+	float* manifold16)
+{
+	b2EdgeShape e;
+	FillEdge(e, edgeA);
+	b2CircleShape c;
+	c.m_p.Set(circleB[0], circleB[1]);
+	c.m_radius = circleB[2];
+	b2Manifold m;
+	memset(&m, 0, sizeof(m));
+	b2CollideEdgeAndCircle(&m, &e, MakeXf(xfA), &c, MakeXf(xfB));
+	DumpManifold(m, manifold16);
+}
+
+// Polygon build probe: returns count, then vertices[8], normals[8], centroid, and mass data for `density`.
+// out = 1 + 16 + 16 + 2 + 4 floats = 39
+void b2h_probe_polygon(int count, const float* verts, float density, float* out39)
+{
+	b2PolygonShape p;
+	FillPolygon(p, count, verts, 0);
+	memset(out39, 0, 39 * sizeof(float));
+	out39[0] = (float)p.m_count;
+	for (int i = 0; i < p.m_count; ++i)
+	{
+		out39[1 + 2 * i] = p.m_vertices[i].x;
+		out39[2 + 2 * i] = p.m_vertices[i].y;
+		out39[17 + 2 * i] = p.m_normals[i].x;
+		out39[18 + 2 * i] = p.m_normals[i].y;
+	}
+	out39[33] = p.m_centroid.x;
+	out39[34] = p.m_centroid.y;
+	b2MassData md;
+	p.ComputeMass(&md, density);
+	out39[35] = md.mass;
+	out39[36] = md.center.x;
+	out39[37] = md.center.y;
+	out39[38] = md.I;
+}
+
+// sin/cos exactly as b2Rot::Set evaluates them (b2Math.h:294-299).
+void b2h_probe_sincos(int n, const float* angles, float* sinOut, float* cosOut)
+{
+	for (int i = 0; i < n; ++i)
+	{
+		b2Rot q(angles[i]);
+		sinOut[i] = q.s;
+		cosOut[i] = q.c;
+	}
+}
+
+} // extern "C"

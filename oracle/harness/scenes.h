@@ -1,0 +1,463 @@
+// Scene recipes used by the parity harness and the bench.
+//
+// TEST INFRASTRUCTURE. This file is written against the PUBLIC Box2D-MT API only
+// (b2World / b2Body / b2Fixture / shapes / b2RevoluteJointDef), so the very same source is
+// compiled twice:
+//   * against the reference headers + sources under /root/reference  -> oracle/_ref/libb2ref_harness.so
+//   * against this repo's drop-in headers (box2d-mt_amd/host)         -> libb2amd_harness.so
+// which makes "identical inputs" true by construction and doubles as the drop-in proof.
+//
+// Recipes restate (not copy) the reference's Testbed scenes:
+//   HelloWorld        HelloWorld/HelloWorld.cpp:27-108
+//   Pyramid           Testbed/Tests/Pyramid.h:30-69
+//   Tumbler           Testbed/Tests/Tumbler.h:31-87     (boxes pre-placed on a grid)
+//   Field             Testbed/Tests/ManyBodies.h:203-313 (explicit PCG32 instead of glibc rand)
+//   Piles / Rain      small-island and mixed-shape stress scenes of our own
+#ifndef B2H_SCENES_H
+#define B2H_SCENES_H
+
+#include "Box2D/Box2D.h"
+#include <stdint.h>
+#include <vector>
+
+namespace b2h
+{
+
+// PCG32 (O'Neill), fixed increment: deterministic on every platform.
+struct Pcg32
+{
+	uint64_t state;
+	explicit Pcg32(uint64_t seed) : state(0)
+	{
+		Next();
+		state += seed;
+		Next();
+	}
+	uint32_t Next()
+	{
+		uint64_t old = state;
+		state = old * 6364136223846793005ULL + 1442695040888963407ULL;
+		uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+		uint32_t rot = (uint32_t)(old >> 59u);
+		return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+	}
+	// 15-bit resolution like the Testbed's RandomFloat (Testbed/Framework/Test.h:45-60).
+	float Unit()
+	{
+		float r = (float)(Next() & 32767u);
+		r /= 32767.0f;
+		return r;
+	}
+	float Range(float lo, float hi)
+	{
+		return (hi - lo) * Unit() + lo;
+	}
+	float Signed()
+	{
+		return 2.0f * Unit() - 1.0f;
+	}
+};
+
+enum SceneId
+{
+	e_helloWorld = 0,
+	e_pyramid = 1,       // p0 = rows, p1 = number of pyramids (side by side)
+	e_tumbler = 2,       // p0 = boxes per side of the pre-placed grid, p1 = unused ; f0 = half size S (0 -> auto)
+	e_field = 3,         // p0 = bodies, p1 = bullet count ; f0 = arena half length R (0 -> auto density), f1 = max radius
+	e_piles = 4,         // p0 = piles, p1 = boxes per pile
+	e_rain = 5,          // p0 = bodies (mixed circles / boxes / polygons dropped on a box ground)
+	e_circleStack = 6    // p0 = columns, p1 = circles per column, on an edge ground
+};
+
+struct SceneParams
+{
+	int scene;
+	int p0, p1;
+	float f0, f1;
+	uint32_t seed;
+};
+
+struct Scene
+{
+	std::vector<b2Body*> bodies; // creation order == body index used by every dump
+	b2Joint* joint;
+	float dtDefault;
+	int velIters, posIters;
+	Scene() : joint(NULL), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
+};
+
+inline b2Body* AddBody(Scene& s, b2World* w, const b2BodyDef& bd)
+{
+	b2Body* b = w->CreateBody(&bd);
+	s.bodies.push_back(b);
+	return b;
+}
+
+inline void BuildHelloWorld(Scene& s, b2World* w)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	b2BodyDef groundBodyDef;
+	groundBodyDef.position.Set(0.0f, -10.0f);
+	b2Body* groundBody = AddBody(s, w, groundBodyDef);
+	b2PolygonShape groundBox;
+	groundBox.SetAsBox(50.0f, 10.0f);
+	groundBody->CreateFixture(&groundBox, 0.0f);
+
+	b2BodyDef bodyDef;
+	bodyDef.type = b2_dynamicBody;
+	bodyDef.position.Set(0.0f, 4.0f);
+	b2Body* body = AddBody(s, w, bodyDef);
+	b2PolygonShape dynamicBox;
+	dynamicBox.SetAsBox(1.0f, 1.0f);
+	b2FixtureDef fixtureDef;
+	fixtureDef.shape = &dynamicBox;
+	fixtureDef.density = 1.0f;
+	fixtureDef.friction = 0.3f;
+	body->CreateFixture(&fixtureDef);
+	s.velIters = 6;
+	s.posIters = 2;
+}
+
+// rows -> rows*(rows+1)/2 boxes per pyramid; `count` pyramids side by side on one ground edge.
+inline void BuildPyramid(Scene& s, b2World* w, int rows, int count)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	if (count < 1) count = 1;
+	float width = 1.125f * (float)rows + 10.0f;
+	float L = 0.5f * width * (float)count + 40.0f;
+	{
+		b2BodyDef bd;
+		b2Body* ground = AddBody(s, w, bd);
+		b2EdgeShape shape;
+		shape.Set(b2Vec2(-L, 0.0f), b2Vec2(L, 0.0f));
+		ground->CreateFixture(&shape, 0.0f);
+	}
+	float a = 0.5f;
+	b2PolygonShape shape;
+	shape.SetAsBox(a, a);
+	for (int k = 0; k < count; ++k)
+	{
+		float x0 = -0.5f * width * (float)count + width * (float)k + 5.0f;
+		b2Vec2 x(x0, 0.75f);
+		b2Vec2 y;
+		b2Vec2 deltaX(0.5625f, 1.25f);
+		b2Vec2 deltaY(1.125f, 0.0f);
+		for (int i = 0; i < rows; ++i)
+		{
+			y = x;
+			for (int j = i; j < rows; ++j)
+			{
+				b2BodyDef bd;
+				bd.type = b2_dynamicBody;
+				bd.position = y;
+				b2Body* body = AddBody(s, w, bd);
+				body->CreateFixture(&shape, 5.0f);
+				y += deltaY;
+			}
+			x += deltaX;
+		}
+	}
+}
+
+// Hollow square container driven by a revolute motor, n*n small boxes pre-placed on a grid.
+inline void BuildTumbler(Scene& s, b2World* w, int n, float S)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	const float pitch = 0.3f;
+	if (S <= 0.0f)
+	{
+		S = 0.5f * pitch * (float)n + 1.0f;
+		if (S < 10.0f) S = 10.0f;
+	}
+	b2Body* ground;
+	{
+		b2BodyDef bd;
+		ground = AddBody(s, w, bd);
+	}
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.allowSleep = false;
+		bd.position.Set(0.0f, S);
+		b2Body* body = AddBody(s, w, bd);
+		b2PolygonShape shape;
+		shape.SetAsBox(0.5f, S, b2Vec2(S, 0.0f), 0.0f);
+		body->CreateFixture(&shape, 5.0f);
+		shape.SetAsBox(0.5f, S, b2Vec2(-S, 0.0f), 0.0f);
+		body->CreateFixture(&shape, 5.0f);
+		shape.SetAsBox(S, 0.5f, b2Vec2(0.0f, S), 0.0f);
+		body->CreateFixture(&shape, 5.0f);
+		shape.SetAsBox(S, 0.5f, b2Vec2(0.0f, -S), 0.0f);
+		body->CreateFixture(&shape, 5.0f);
+
+		b2RevoluteJointDef jd;
+		jd.bodyA = ground;
+		jd.bodyB = body;
+		jd.localAnchorA.Set(0.0f, S);
+		jd.localAnchorB.Set(0.0f, 0.0f);
+		jd.referenceAngle = 0.0f;
+		jd.motorSpeed = 0.05f * b2_pi;
+		jd.maxMotorTorque = 1e8f;
+		jd.enableMotor = true;
+		s.joint = w->CreateJoint(&jd);
+	}
+	b2PolygonShape box;
+	box.SetAsBox(0.125f, 0.125f);
+	float start = -0.5f * pitch * (float)(n - 1);
+	for (int i = 0; i < n; ++i)
+	{
+		for (int j = 0; j < n; ++j)
+		{
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(start + pitch * (float)j, S + start + pitch * (float)i);
+			b2Body* body = AddBody(s, w, bd);
+			body->CreateFixture(&box, 1.0f);
+		}
+	}
+}
+
+// Zero-gravity random field of alternating circles / regular polygons inside 4 thick static walls.
+inline void BuildField(Scene& s, b2World* w, int count, int bullets, float R, float maxRadius, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, 0.0f));
+	const float kMinRadius = 0.5f;
+	if (maxRadius < kMinRadius) maxRadius = 5.0f;
+	if (R <= 0.0f)
+	{
+		// reference density: 20000 bodies in R = 2000 (ManyBodies.h) -> area per body 800
+		R = 0.5f * sqrtf(800.0f * (float)count);
+		if (R < 50.0f) R = 50.0f;
+	}
+	const float wallHalf = 5.0f;
+	{
+		b2BodyDef bd;
+		b2Body* ground = AddBody(s, w, bd);
+		b2PolygonShape wall;
+		b2FixtureDef fd;
+		fd.shape = &wall;
+		fd.thickShape = true;
+		wall.SetAsBox(R, wallHalf, b2Vec2(0.0f, -R), 0.0f);
+		ground->CreateFixture(&fd);
+		wall.SetAsBox(R, wallHalf, b2Vec2(0.0f, R), 0.0f);
+		ground->CreateFixture(&fd);
+		wall.SetAsBox(wallHalf, R, b2Vec2(-R, 0.0f), 0.0f);
+		ground->CreateFixture(&fd);
+		wall.SetAsBox(wallHalf, R, b2Vec2(R, 0.0f), 0.0f);
+		ground->CreateFixture(&fd);
+	}
+	Pcg32 rng(seed);
+	const float range = R - wallHalf - maxRadius;
+	b2PolygonShape polygon;
+	b2CircleShape circle;
+	for (int i = 0; i < count; ++i)
+	{
+		float radius = rng.Range(kMinRadius, maxRadius);
+		float speed = 8.0f * radius;
+		float x = rng.Range(-range, range);
+		float y = rng.Range(-range, range);
+		float a = rng.Range(0.0f, 2.0f * b2_pi);
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		b2FixtureDef fd;
+		fd.density = 1.0f;
+		if (i < bullets)
+		{
+			speed = 120.0f;
+			radius = kMinRadius;
+			bd.bullet = true;
+			fd.density = 25.0f;
+		}
+		bd.position = b2Vec2(x, y);
+		bd.angle = a;
+		bd.angularDamping = 0.25f;
+		b2Vec2 n(rng.Signed(), rng.Signed());
+		n.Normalize();
+		bd.linearVelocity = speed * n;
+		b2Body* body = AddBody(s, w, bd);
+		if ((i & 1) == 0)
+		{
+			circle.m_radius = radius;
+			fd.shape = &circle;
+		}
+		else
+		{
+			b2Vec2 vertices[b2_maxPolygonVertices];
+			int vc = i % b2_maxPolygonVertices;
+			if (vc < 3) vc = 3;
+			float arc = 2.0f * b2_pi / (float)vc;
+			for (int v = 0; v < vc; ++v)
+			{
+				float ang = ((float)v + 1.0f) * arc;
+				b2Rot q(ang);
+				vertices[v] = b2Mul(q, b2Vec2(radius, 0.0f));
+			}
+			polygon.Set(vertices, vc);
+			fd.shape = &polygon;
+		}
+		if (radius > 1.0f)
+		{
+			fd.thickShape = true;
+		}
+		body->CreateFixture(&fd);
+	}
+}
+
+// Many independent small stacks on one polygon ground: many small multi-contact islands under gravity.
+inline void BuildPiles(Scene& s, b2World* w, int piles, int height, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	float L = 2.0f * (float)piles + 10.0f;
+	{
+		b2BodyDef bd;
+		bd.position.Set(0.0f, -1.0f);
+		b2Body* ground = AddBody(s, w, bd);
+		b2PolygonShape shape;
+		shape.SetAsBox(L, 1.0f);
+		ground->CreateFixture(&shape, 0.0f);
+	}
+	Pcg32 rng(seed);
+	b2PolygonShape box;
+	b2CircleShape ball;
+	for (int p = 0; p < piles; ++p)
+	{
+		float x = -2.0f * (float)piles + 4.0f * (float)p + 2.0f;
+		float y = 0.0f;
+		for (int k = 0; k < height; ++k)
+		{
+			float hw = rng.Range(0.3f, 0.6f);
+			float hh = rng.Range(0.2f, 0.4f);
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(x + rng.Range(-0.15f, 0.15f), y + hh + 0.02f);
+			bd.angle = rng.Range(-0.05f, 0.05f);
+			b2Body* body = AddBody(s, w, bd);
+			b2FixtureDef fd;
+			fd.density = rng.Range(0.5f, 3.0f);
+			fd.friction = rng.Range(0.1f, 0.9f);
+			fd.restitution = (k % 3 == 0) ? 0.3f : 0.0f;
+			if ((p + k) % 4 == 3)
+			{
+				ball.m_radius = hh;
+				fd.shape = &ball;
+			}
+			else
+			{
+				box.SetAsBox(hw, hh);
+				fd.shape = &box;
+			}
+			body->CreateFixture(&fd);
+			y += 2.0f * hh + 0.04f;
+		}
+	}
+}
+
+// Mixed shapes falling on a box ground with side walls.
+inline void BuildRain(Scene& s, b2World* w, int count, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	int cols = 1;
+	while (cols * cols < count) ++cols;
+	float W = 1.5f * (float)cols * 0.5f + 3.0f;
+	{
+		b2BodyDef bd;
+		b2Body* ground = AddBody(s, w, bd);
+		b2PolygonShape shape;
+		shape.SetAsBox(W, 1.0f, b2Vec2(0.0f, -1.0f), 0.0f);
+		ground->CreateFixture(&shape, 0.0f);
+		shape.SetAsBox(1.0f, 4.0f * W, b2Vec2(-W - 1.0f, 4.0f * W - 2.0f), 0.0f);
+		ground->CreateFixture(&shape, 0.0f);
+		shape.SetAsBox(1.0f, 4.0f * W, b2Vec2(W + 1.0f, 4.0f * W - 2.0f), 0.0f);
+		ground->CreateFixture(&shape, 0.0f);
+	}
+	Pcg32 rng(seed);
+	b2PolygonShape poly;
+	b2CircleShape ball;
+	for (int i = 0; i < count; ++i)
+	{
+		int cx = i % cols, cy = i / cols;
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(-W + 2.0f + 1.5f * (float)cx + rng.Range(-0.2f, 0.2f), 1.0f + 1.5f * (float)cy);
+		bd.angle = rng.Range(0.0f, 2.0f * b2_pi);
+		bd.linearVelocity.Set(rng.Range(-1.0f, 1.0f), rng.Range(-2.0f, 0.0f));
+		bd.angularVelocity = rng.Range(-1.0f, 1.0f);
+		b2Body* body = AddBody(s, w, bd);
+		b2FixtureDef fd;
+		fd.density = rng.Range(0.5f, 4.0f);
+		fd.friction = rng.Range(0.0f, 1.0f);
+		fd.restitution = rng.Range(0.0f, 0.5f);
+		int kind = i % 3;
+		if (kind == 0)
+		{
+			ball.m_radius = rng.Range(0.2f, 0.5f);
+			fd.shape = &ball;
+		}
+		else if (kind == 1)
+		{
+			poly.SetAsBox(rng.Range(0.2f, 0.5f), rng.Range(0.2f, 0.5f));
+			fd.shape = &poly;
+		}
+		else
+		{
+			b2Vec2 vertices[b2_maxPolygonVertices];
+			int vc = 3 + (i / 3) % 6;
+			float r = rng.Range(0.25f, 0.5f);
+			float arc = 2.0f * b2_pi / (float)vc;
+			for (int v = 0; v < vc; ++v)
+			{
+				b2Rot q(((float)v + 0.5f) * arc);
+				vertices[v] = b2Mul(q, b2Vec2(r, 0.0f));
+			}
+			poly.Set(vertices, vc);
+			fd.shape = &poly;
+		}
+		body->CreateFixture(&fd);
+	}
+}
+
+// Columns of circles resting on an edge: edge-circle + circle-circle manifolds.
+inline void BuildCircleStack(Scene& s, b2World* w, int columns, int height)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	float L = 1.5f * (float)columns + 10.0f;
+	{
+		b2BodyDef bd;
+		b2Body* ground = AddBody(s, w, bd);
+		b2EdgeShape shape;
+		shape.Set(b2Vec2(-L, 0.0f), b2Vec2(L, 0.0f));
+		ground->CreateFixture(&shape, 0.0f);
+	}
+	b2CircleShape ball;
+	ball.m_radius = 0.5f;
+	for (int c = 0; c < columns; ++c)
+	{
+		for (int k = 0; k < height; ++k)
+		{
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(-1.5f * (float)columns + 3.0f * (float)c, 0.55f + 1.05f * (float)k);
+			b2Body* body = AddBody(s, w, bd);
+			body->CreateFixture(&ball, 1.0f + 0.25f * (float)(k & 3));
+		}
+	}
+}
+
+inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
+{
+	switch (p.scene)
+	{
+	case e_helloWorld: BuildHelloWorld(s, w); break;
+	case e_pyramid: BuildPyramid(s, w, p.p0, p.p1); break;
+	case e_tumbler: BuildTumbler(s, w, p.p0, p.f0); break;
+	case e_field: BuildField(s, w, p.p0, p.p1, p.f0, p.f1, p.seed); break;
+	case e_piles: BuildPiles(s, w, p.p0, p.p1, p.seed); break;
+	case e_rain: BuildRain(s, w, p.p0, p.seed); break;
+	case e_circleStack: BuildCircleStack(s, w, p.p0, p.p1); break;
+	default: break;
+	}
+}
+
+} // namespace b2h
+
+#endif

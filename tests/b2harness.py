@@ -1,0 +1,217 @@
+"""ctypes binding of the headless harness C ABI (oracle/harness/harness.cpp).
+
+TEST INFRASTRUCTURE.  The same ABI is exported by two shared libraries built from one source:
+  oracle/_ref/libb2ref_harness.so      the real reference (skitzoid/Box2D-MT) compiled where it lies
+  box2d-mt_amd/libb2amd_harness.so     this repo's drop-in Box2D API on top of the HIP C-ABI (libb2hip.so)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libb2ref_harness.so")
+AMD_LIB = os.path.join(ROOT, "box2d-mt_amd", "libb2amd_harness.so")
+
+HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK = range(7)
+F_CONTINUOUS, F_SLEEP, F_WARM, F_SUBSTEP = 1, 2, 4, 8
+DEFAULT_FLAGS = F_SLEEP | F_WARM  # CCD off unless a test asks for it
+
+PROFILE_FIELDS = ["step", "collide", "solve", "solveTraversal", "solveInit", "solveVelocity",
+                  "solvePosition", "solveTOI", "solveTOIFindMinContact", "broadphase",
+                  "broadphaseSyncFixtures", "broadphaseFindContacts", "locking"]
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+class Harness:
+    """One loaded backend library."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        L = self.lib
+        L.b2h_backend.restype = C.c_char_p
+        L.b2h_create.restype = C.c_void_p
+        L.b2h_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint, C.c_int, C.c_int]
+        L.b2h_destroy.argtypes = [C.c_void_p]
+        L.b2h_default_iters.argtypes = [C.c_void_p, _ip, _ip]
+        L.b2h_step.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int]
+        L.b2h_body_count.argtypes = [C.c_void_p]
+        L.b2h_get_bodies.argtypes = [C.c_void_p, _fp]
+        L.b2h_get_mass.argtypes = [C.c_void_p, _fp]
+        L.b2h_contact_count.argtypes = [C.c_void_p]
+        L.b2h_get_contacts.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _fp]
+        L.b2h_get_profile.argtypes = [C.c_void_p, _fp]
+        L.b2h_reset_profile.argtypes = [C.c_void_p]
+
+    @property
+    def backend(self):
+        return self.lib.b2h_backend().decode()
+
+    def world(self, scene, p0=0, p1=0, f0=0.0, f1=0.0, seed=1, flags=DEFAULT_FLAGS, threads=1):
+        return World(self, scene, p0, p1, f0, f1, seed, flags, threads)
+
+    # ---- per-function probes -------------------------------------------------------------
+    def _poly_args(self, poly):
+        """poly = ('box', hx, hy) or ('verts', [(x,y)...])"""
+        v = np.zeros(16, np.float32)
+        if poly[0] == "box":
+            v[0], v[1] = poly[1], poly[2]
+            return 4, v, 1
+        pts = np.asarray(poly[1], np.float32).reshape(-1)
+        v[:pts.size] = pts
+        return pts.size // 2, v, 0
+
+    def collide_polygons(self, polyA, xfA, polyB, xfB):
+        ca, va, ba = self._poly_args(polyA)
+        cb, vb, bb = self._poly_args(polyB)
+        out = np.zeros(16, np.float32)
+        a = np.asarray(xfA, np.float32)
+        b = np.asarray(xfB, np.float32)
+        self.lib.b2h_probe_collide_polygons(ca, _fptr(va), ba, _fptr(a), cb, _fptr(vb), bb, _fptr(b), _fptr(out))
+        return out
+
+    def collide_polygon_circle(self, polyA, xfA, circleB, xfB):
+        ca, va, ba = self._poly_args(polyA)
+        out = np.zeros(16, np.float32)
+        a = np.asarray(xfA, np.float32)
+        b = np.asarray(xfB, np.float32)
+        c = np.asarray(circleB, np.float32)
+        self.lib.b2h_probe_collide_polygon_circle(ca, _fptr(va), ba, _fptr(a), _fptr(c), _fptr(b), _fptr(out))
+        return out
+
+    def collide_circles(self, circleA, xfA, circleB, xfB):
+        out = np.zeros(16, np.float32)
+        ca = np.asarray(circleA, np.float32)
+        cb = np.asarray(circleB, np.float32)
+        a = np.asarray(xfA, np.float32)
+        b = np.asarray(xfB, np.float32)
+        self.lib.b2h_probe_collide_circles(_fptr(ca), _fptr(a), _fptr(cb), _fptr(b), _fptr(out))
+        return out
+
+    def collide_edge_polygon(self, edgeA, xfA, polyB, xfB):
+        cb, vb, bb = self._poly_args(polyB)
+        out = np.zeros(16, np.float32)
+        e = np.asarray(edgeA, np.float32)
+        a = np.asarray(xfA, np.float32)
+        b = np.asarray(xfB, np.float32)
+        self.lib.b2h_probe_collide_edge_polygon(_fptr(e), _fptr(a), cb, _fptr(vb), bb, _fptr(b), _fptr(out))
+        return out
+
+    def collide_edge_circle(self, edgeA, xfA, circleB, xfB):
+        out = np.zeros(16, np.float32)
+        e = np.asarray(edgeA, np.float32)
+        a = np.asarray(xfA, np.float32)
+        b = np.asarray(xfB, np.float32)
+        c = np.asarray(circleB, np.float32)
+        self.lib.b2h_probe_collide_edge_circle(_fptr(e), _fptr(a), _fptr(c), _fptr(b), _fptr(out))
+        return out
+
+    def polygon(self, verts, density=1.0):
+        pts = np.zeros(16, np.float32)
+        flat = np.asarray(verts, np.float32).reshape(-1)
+        pts[:flat.size] = flat
+        out = np.zeros(39, np.float32)
+        self.lib.b2h_probe_polygon(flat.size // 2, _fptr(pts), C.c_float(density), _fptr(out))
+        return out
+
+    def sincos(self, angles):
+        a = np.ascontiguousarray(angles, np.float32)
+        s = np.empty_like(a)
+        c = np.empty_like(a)
+        self.lib.b2h_probe_sincos(a.size, _fptr(a), _fptr(s), _fptr(c))
+        return s, c
+
+
+class World:
+    def __init__(self, h, scene, p0, p1, f0, f1, seed, flags, threads):
+        self.h = h
+        self.L = h.lib
+        self.ptr = self.L.b2h_create(scene, p0, p1, C.c_float(f0), C.c_float(f1), seed, flags, threads)
+        if not self.ptr:
+            raise RuntimeError("b2h_create failed")
+        vi, pi = C.c_int(), C.c_int()
+        self.L.b2h_default_iters(self.ptr, C.byref(vi), C.byref(pi))
+        self.vel_iters, self.pos_iters = vi.value, pi.value
+
+    def close(self):
+        if self.ptr:
+            self.L.b2h_destroy(self.ptr)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def step(self, n=1, dt=1.0 / 60.0, vel_iters=None, pos_iters=None):
+        self.L.b2h_step(self.ptr, n, C.c_float(dt), vel_iters or self.vel_iters, pos_iters or self.pos_iters)
+
+    @property
+    def body_count(self):
+        return self.L.b2h_body_count(self.ptr)
+
+    def bodies(self):
+        out = np.zeros((self.body_count, 8), np.float32)
+        self.L.b2h_get_bodies(self.ptr, _fptr(out))
+        return out
+
+    def mass(self):
+        out = np.zeros((self.body_count, 6), np.float32)
+        self.L.b2h_get_mass(self.ptr, _fptr(out))
+        return out
+
+    @property
+    def contact_count(self):
+        return self.L.b2h_contact_count(self.ptr)
+
+    def contacts(self):
+        """Returns (ids[n,4], flags[n], manifold[n,16]) sorted by ids so backends are comparable."""
+        cap = max(self.contact_count, 1)
+        ids = np.zeros((cap, 4), np.int32)
+        flags = np.zeros(cap, np.int32)
+        man = np.zeros((cap, 16), np.float32)
+        n = self.L.b2h_get_contacts(self.ptr, cap, _iptr(ids), _iptr(flags), _fptr(man))
+        ids, flags, man = ids[:n], flags[:n], man[:n]
+        order = np.lexsort((ids[:, 3], ids[:, 2], ids[:, 1], ids[:, 0]))
+        return ids[order], flags[order], man[order]
+
+    def profile(self):
+        out = np.zeros(13, np.float32)
+        n = self.L.b2h_get_profile(self.ptr, _fptr(out))
+        d = dict(zip(PROFILE_FIELDS, out.tolist()))
+        d["steps"] = n
+        return d
+
+    def reset_profile(self):
+        self.L.b2h_reset_profile(self.ptr)
+
+
+def fnv1a64(arr):
+    """FNV-1a over the raw bytes of an array (pose hashes in the fixtures)."""
+    h = 0xcbf29ce484222325
+    for b in np.ascontiguousarray(arr).view(np.uint8).reshape(-1).tolist():
+        h ^= b
+        h = (h * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+def have_amd():
+    return os.path.exists(AMD_LIB)
