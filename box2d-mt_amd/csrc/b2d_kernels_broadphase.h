@@ -1,0 +1,404 @@
+// b2d_kernels_broadphase.h - fat-AABB broad-phase on the device.
+//
+// Pair EXISTENCE in the reference is a pure function of the per-proxy fat AABBs and the move list
+// (b2BroadPhase::UpdatePairs, b2BroadPhase.h:211-267): the dynamic tree is only an index. We keep
+// the same per-proxy fat-AABB state machine (b2DynamicTree::MoveProxy, b2DynamicTree.cpp:130-174)
+// and replace the tree by a hashed uniform grid rebuilt on the device, so the pair SET is identical;
+// creation ORDER is then fixed by sorting on (proxyKeyLow, proxyKeyHigh) exactly like
+// b2ContactManager::FinishFindNewContacts (b2ContactManager.cpp:366-386).
+#ifndef B2D_KERNELS_BROADPHASE_H
+#define B2D_KERNELS_BROADPHASE_H
+
+#include "b2d_kernels_solve_large.h"
+
+// b2ContactManager::SynchronizeFixtures (:315-364) + FinishSynchronizeFixtures (:441-452) +
+// b2DynamicTree::MoveProxy, one lane per proxy.
+__global__ __launch_bounds__(256) void k_sync_fixtures(DW W)
+{
+	DState* S = W.st;
+	const int n = W.nProxies;
+	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
+	{
+		const int body = W.p_body[p];
+		if (body < 0) continue;
+		uint32_t f = W.b_flags[body];
+		// If a body was not in an island then it did not move.
+		if ((f & BF_ISLAND) == 0) continue;
+		float4 m = W.b_mass[body];
+		float4 p0 = W.b_pos0[body];
+		Xf xf1 = b2dXfFromSweep(v2(p0.x, p0.y), p0.z, v2(m.z, m.w));
+		Xf xf2 = loadXf(W.b_xf, body);
+		const ShapeRec* shape = W.shapes + W.p_shape[p];
+		AABB aabb = b2dAabbCombine(b2dShapeAABB(shape, xf1), b2dShapeAABB(shape, xf2));
+		AABB fat = loadAabb(W.p_fat, p);
+		if (b2dAabbContains(fat, aabb)) continue;
+		V2 displacement = xf2.p - xf1.p;
+		AABB b = aabb;
+		b.lo = v2(b.lo.x - B2D_AABB_EXTENSION, b.lo.y - B2D_AABB_EXTENSION);
+		b.hi = v2(b.hi.x + B2D_AABB_EXTENSION, b.hi.y + B2D_AABB_EXTENSION);
+		V2 d = B2D_AABB_MULTIPLIER * displacement;
+		if (d.x < 0.0f) b.lo.x += d.x; else b.hi.x += d.x;
+		if (d.y < 0.0f) b.lo.y += d.y; else b.hi.y += d.y;
+		W.p_fat[p] = make_float4(b.lo.x, b.lo.y, b.hi.x, b.hi.y);
+		int k = atomicAdd(&S->c.nMoves, 1);
+		if (k < W.capMoves) W.moveBuf[k] = p; else atomicOr(&S->c.overflow, 8);
+	}
+}
+
+// ---- hashed uniform grid over ALL proxies ----------------------------------------------------------
+__device__ __forceinline__ uint32_t cellHash(int ix, int iy, uint32_t mask)
+{
+	return ((uint32_t)ix * 73856093u ^ (uint32_t)iy * 19349663u) & mask;
+}
+
+__device__ __forceinline__ bool proxyIsLarge(const DW& W, float4 a)
+{
+	return (a.z - a.x) > W.cellSize || (a.w - a.y) > W.cellSize;
+}
+
+__device__ __forceinline__ void proxyCell(const DW& W, float4 a, int* ix, int* iy)
+{
+	*ix = (int)floorf(0.5f * (a.x + a.z) * W.invCellSize);
+	*iy = (int)floorf(0.5f * (a.y + a.w) * W.invCellSize);
+}
+
+__global__ __launch_bounds__(256) void k_grid_clear(DW W)
+{
+	DState* S = W.st;
+	// always reset the pair census, also when nothing moved: the ordering / creation kernels that
+	// follow key off nPairs and must see 0 then
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		S->c.nLargeProxies = 0;
+		S->c.nPairs = 0;
+		S->c.nNewContacts = 0;
+	}
+	if (S->c.nMoves == 0) return;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= W.gridMask; i += gridDim.x * blockDim.x)
+	{
+		W.gridCount[i] = 0;
+		W.gridCursor[i] = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_grid_count(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nMoves == 0) return;
+	const int n = W.nProxies;
+	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
+	{
+		if (W.p_body[p] < 0) continue;
+		float4 a = W.p_fat[p];
+		if (proxyIsLarge(W, a))
+		{
+			int k = atomicAdd(&S->c.nLargeProxies, 1);
+			W.largeProxies[k] = p;
+		}
+		else
+		{
+			int ix, iy;
+			proxyCell(W, a, &ix, &iy);
+			atomicAdd(&W.gridCount[cellHash(ix, iy, W.gridMask)], 1);
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_grid_fill(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nMoves == 0) return;
+	const int n = W.nProxies;
+	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
+	{
+		if (W.p_body[p] < 0) continue;
+		float4 a = W.p_fat[p];
+		if (proxyIsLarge(W, a)) continue;
+		int ix, iy;
+		proxyCell(W, a, &ix, &iy);
+		uint32_t h = cellHash(ix, iy, W.gridMask);
+		W.gridItems[W.gridStart[h] + atomicAdd(&W.gridCursor[h], 1)] = p;
+	}
+}
+
+// b2ContactManager::AddPair filters (:237-312) evaluated before the pair is even stored.
+__device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q)
+{
+	const int bodyP = W.p_body[p], bodyQ = W.p_body[q];
+	if (bodyP == bodyQ) return;
+	const int keyP = W.p_key[p], keyQ = W.p_key[q];
+	const int lo = keyP < keyQ ? p : q;
+	const int hi = keyP < keyQ ? q : p;
+	const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
+	if (htContains(W, key + 1ull)) return;
+	// bodyB->ShouldCollide(bodyA) with A = lower proxy id
+	if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
+	if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
+	if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return;
+	int k = atomicAdd(&S->c.nPairs, 1);
+	if (k < W.capPairs)
+	{
+		W.pairKey[k] = key;
+		W.pairProxy[k] = make_int2(lo, hi);
+	}
+	else
+	{
+		atomicOr(&S->c.overflow, 2);
+	}
+}
+
+// One lane per moved SMALL proxy: 3x3 cells + every large proxy.
+__global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
+{
+	DState* S = W.st;
+	const int nm = S->c.nMoves < W.capMoves ? S->c.nMoves : W.capMoves;
+	const int nLarge = S->c.nLargeProxies;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nm; k += gridDim.x * blockDim.x)
+	{
+		const int p = W.moveBuf[k];
+		if (p < 0 || W.p_body[p] < 0) continue;
+		float4 a4 = W.p_fat[p];
+		if (proxyIsLarge(W, a4)) continue;
+		AABB a;
+		a.lo = v2(a4.x, a4.y);
+		a.hi = v2(a4.z, a4.w);
+		int ix, iy;
+		proxyCell(W, a4, &ix, &iy);
+		uint32_t seen[9];
+		int nSeen = 0;
+		for (int dy = -1; dy <= 1; ++dy)
+		{
+			for (int dx = -1; dx <= 1; ++dx)
+			{
+				uint32_t h = cellHash(ix + dx, iy + dy, W.gridMask);
+				bool dup = false;
+				for (int t = 0; t < nSeen; ++t) dup = dup || seen[t] == h;
+				if (dup) continue;
+				seen[nSeen++] = h;
+				const int s = W.gridStart[h], e = s + W.gridCount[h];
+				for (int t = s; t < e; ++t)
+				{
+					const int q = W.gridItems[t];
+					if (q == p) continue;
+					if (!b2dAabbOverlap(a, loadAabb(W.p_fat, q))) continue;
+					tryEmitPair(W, S, p, q);
+				}
+			}
+		}
+		for (int t = 0; t < nLarge; ++t)
+		{
+			const int q = W.largeProxies[t];
+			if (!b2dAabbOverlap(a, loadAabb(W.p_fat, q))) continue;
+			tryEmitPair(W, S, p, q);
+		}
+	}
+}
+
+// One workgroup per moved LARGE proxy: brute force over every proxy.
+__global__ __launch_bounds__(256) void k_find_pairs_large(DW W)
+{
+	DState* S = W.st;
+	const int nm = S->c.nMoves < W.capMoves ? S->c.nMoves : W.capMoves;
+	for (int k = blockIdx.x; k < nm; k += gridDim.x)
+	{
+		const int p = W.moveBuf[k];
+		if (p < 0 || W.p_body[p] < 0) continue;
+		float4 a4 = W.p_fat[p];
+		if (!proxyIsLarge(W, a4)) continue;
+		AABB a;
+		a.lo = v2(a4.x, a4.y);
+		a.hi = v2(a4.z, a4.w);
+		for (int q = threadIdx.x; q < W.nProxies; q += blockDim.x)
+		{
+			if (q == p || W.p_body[q] < 0) continue;
+			if (!b2dAabbOverlap(a, loadAabb(W.p_fat, q))) continue;
+			tryEmitPair(W, S, p, q);
+		}
+	}
+}
+
+// ---- ordering of the new pairs ---------------------------------------------------------------------
+// Small sets (<= COUNT_RANK_MAX): rank by counting, tiles of keys staged through LDS.
+__global__ __launch_bounds__(256) void k_pairs_first(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
+	if (n == 0 || n > COUNT_RANK_MAX) return;
+	__shared__ uint64_t tile[256];
+	const int rounds = (n + 255) / 256;
+	for (int base = blockIdx.x * 256; base < rounds * 256; base += gridDim.x * 256)
+	{
+		const int i = base + threadIdx.x;
+		const uint64_t key = i < n ? W.pairKey[i] : 0;
+		int first = 1;
+		for (int t0 = 0; t0 < n; t0 += 256)
+		{
+			__syncthreads();
+			if (t0 + threadIdx.x < n) tile[threadIdx.x] = W.pairKey[t0 + threadIdx.x];
+			__syncthreads();
+			const int m = n - t0 < 256 ? n - t0 : 256;
+			for (int t = 0; t < m; ++t)
+			{
+				if (tile[t] == key && t0 + t < i) first = 0;
+			}
+		}
+		if (i < n) W.pairFirst[i] = first;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_pairs_rank(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
+	if (n == 0 || n > COUNT_RANK_MAX) return;
+	__shared__ uint64_t tile[256];
+	__shared__ int tfirst[256];
+	const int rounds = (n + 255) / 256;
+	for (int base = blockIdx.x * 256; base < rounds * 256; base += gridDim.x * 256)
+	{
+		const int i = base + threadIdx.x;
+		const uint64_t key = i < n ? W.pairKey[i] : 0;
+		int rank = 0;
+		for (int t0 = 0; t0 < n; t0 += 256)
+		{
+			__syncthreads();
+			if (t0 + threadIdx.x < n)
+			{
+				tile[threadIdx.x] = W.pairKey[t0 + threadIdx.x];
+				tfirst[threadIdx.x] = W.pairFirst[t0 + threadIdx.x];
+			}
+			__syncthreads();
+			const int m = n - t0 < 256 ? n - t0 : 256;
+			for (int t = 0; t < m; ++t)
+			{
+				if (tfirst[t] && tile[t] < key) ++rank;
+			}
+		}
+		if (i < n)
+		{
+			W.pairRank[i] = rank;
+			if (W.pairFirst[i]) atomicAdd(&S->c.nNewContacts, 1);
+		}
+	}
+}
+
+// Large sets: after the radix sort the keys are ordered; first-of-run flags + scan give the ranks.
+__global__ __launch_bounds__(256) void k_pairs_sorted_first(DW W, const uint64_t* keys, int* nOut)
+{
+	DState* S = W.st;
+	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *nOut = n > COUNT_RANK_MAX ? n : 0;
+	if (n <= COUNT_RANK_MAX) return;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		W.pairFirst[i] = (i == 0 || keys[i - 1] != keys[i]) ? 1 : 0;
+	}
+}
+
+__global__ void k_pairs_sorted_total(DW W, const int* n2)
+{
+	DState* S = W.st;
+	if (*n2 > 0) S->c.nNewContacts = W.pairRank[*n2];
+}
+
+// b2ContactManager::ConsumeCreate / OnContactCreate (:488-564) + b2Contact::b2Contact (b2Contact.cpp:125-159)
+// smallPath: ranks came from the counting kernels, which only run for n <= COUNT_RANK_MAX; a larger set is
+// left untouched (moves stay buffered) and the host finishes it with the radix path after its read-back.
+__global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* keys, const int2* proxies, int smallPath)
+{
+	DState* S = W.st;
+	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
+	if (smallPath && n > COUNT_RANK_MAX) return;
+	const int base = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		if (!W.pairFirst[i]) continue;
+		const int dst = base + W.pairRank[i];
+		if (dst >= W.capContacts)
+		{
+			atomicOr(&S->c.overflow, 1);
+			continue;
+		}
+		int2 pr = proxies[i];
+		int pA = pr.x, pB = pr.y; // A = lower proxy id (b2ContactManager.cpp:254)
+		if (b2dContactSwap(W.shapes[W.p_shape[pA]].type, W.shapes[W.p_shape[pB]].type) == 1)
+		{
+			int t = pA;
+			pA = pB;
+			pB = t;
+		}
+		const int bodyA = W.p_body[pA], bodyB = W.p_body[pB];
+		const bool sensor = ((W.p_filter1[pA] | W.p_filter1[pB]) & PF_SENSOR) != 0;
+		uint32_t flags = CF_ENABLED | (sensor ? CF_SENSOR : 0u);
+		float2 mA = W.p_mat[pA], mB = W.p_mat[pB];
+		// b2MixFriction / b2MixRestitution (b2Contact.h:40-50)
+		float friction = b2dSqrt(mA.x * mB.x);
+		float restitution = mA.y > mB.y ? mA.y : mB.y;
+		C.ids[dst] = make_int4(pA, pB, bodyA, bodyB);
+		C.key[dst] = keys[i];
+		C.flags[dst] = flags;
+		C.mat[dst] = make_float4(friction, restitution, 0.0f, 1.0f);
+		C.man0[dst] = make_float4(0, 0, 0, 0);
+		C.man1[dst] = make_float4(0, 0, 0, 0);
+		C.imp[dst] = make_float4(0, 0, 0, 0);
+		C.man3[dst] = make_int4(0, 0, 0, 0);
+		if (!sensor)
+		{
+			// SetAwake(true) on both bodies (:525-529), applied by k_apply_wake
+			W.b_wake[bodyA] = 1;
+			W.b_wake[bodyB] = 1;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
+{
+	DState* S = W.st;
+	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return;
+	// apply the wake requests of contact creation now (the next user of the flags is the next step)
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		if (W.b_wake[i])
+		{
+			W.b_flags[i] |= BF_AWAKE;
+			W.b_pos[i].w = 0.0f;
+			W.b_wake[i] = 0;
+		}
+	}
+}
+
+__global__ void k_create_commit(DW W, int smallPath)
+{
+	DState* S = W.st;
+	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return;
+	int total = S->c.nContacts + S->c.nNewContacts;
+	if (total > W.capContacts) total = W.capContacts;
+	S->c.nContacts = total;
+	S->c.nMoves = 0; // b2BroadPhase::ResetBuffers
+}
+
+// ---- end of step -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces)
+{
+	const int n = W.nBodies;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint32_t f = W.b_flags[i];
+		if (clearForces) W.b_force[i] = make_float4(0, 0, 0, 0);
+		float4 xf = W.b_xf[i], p = W.b_pos[i], v = W.b_vel[i];
+		float* o = W.stateOut + (size_t)i * 10;
+		o[0] = xf.x;
+		o[1] = xf.y;
+		o[2] = p.z;
+		o[3] = v.x;
+		o[4] = v.y;
+		o[5] = v.z;
+		o[6] = p.x;
+		o[7] = p.y;
+		o[8] = __uint_as_float(f & 0x7fu);
+		o[9] = p.w;
+	}
+}
+
+#endif

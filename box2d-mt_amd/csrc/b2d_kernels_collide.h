@@ -1,0 +1,281 @@
+// b2d_kernels_collide.h - narrow phase: one lane per contact (b2ContactManager::Collide +
+// b2Contact::UpdateImpl), then the stable compaction that plays the role of the reference's
+// sorted destroy list (b2ContactManager.cpp:388-439).
+#ifndef B2D_KERNELS_COLLIDE_H
+#define B2D_KERNELS_COLLIDE_H
+
+#include "b2d_world.h"
+
+__device__ __forceinline__ Xf loadXf(const float4* b_xf, int body)
+{
+	float4 t = b_xf[body];
+	Xf xf;
+	xf.p = v2(t.x, t.y);
+	xf.q.s = t.z;
+	xf.q.c = t.w;
+	return xf;
+}
+
+__device__ __forceinline__ AABB loadAabb(const float4* p_fat, int proxy)
+{
+	float4 t = p_fat[proxy];
+	AABB a;
+	a.lo = v2(t.x, t.y);
+	a.hi = v2(t.z, t.w);
+	return a;
+}
+
+__device__ __forceinline__ bool bodyActiveForContact(uint32_t f)
+{
+	// b2ContactManager::IsContactActive (b2ContactManager.cpp:94-107)
+	return (f & BF_AWAKE) != 0 && (f & BF_TYPE_MASK) != BT_STATIC;
+}
+
+// b2ContactFilter::ShouldCollide (b2WorldCallbacks.cpp:24-38)
+__device__ __forceinline__ bool filterShouldCollide(uint32_t f0A, int f1A, uint32_t f0B, int f1B)
+{
+	int groupA = (int)(short)(f1A & 0xffff);
+	int groupB = (int)(short)(f1B & 0xffff);
+	if (groupA == groupB && groupA != 0)
+	{
+		return groupA > 0;
+	}
+	uint32_t catA = f0A & 0xffffu, maskA = f0A >> 16;
+	uint32_t catB = f0B & 0xffffu, maskB = f0B >> 16;
+	return (maskA & catB) != 0 && (catA & maskB) != 0;
+}
+
+// b2Body::ShouldCollide (b2Body.cpp:428-449): at least one dynamic body, and no joint between
+// the two bodies with collideConnected == false.
+__device__ __forceinline__ bool bodiesShouldCollide(const DW& W, int bodyA, int bodyB)
+{
+	uint32_t tA = W.b_flags[bodyA] & BF_TYPE_MASK;
+	uint32_t tB = W.b_flags[bodyB] & BF_TYPE_MASK;
+	if (tA != BT_DYNAMIC && tB != BT_DYNAMIC) return false;
+	for (int j = 0; j < W.nJoints; ++j)
+	{
+		const RevoluteJoint& jn = W.joints[j];
+		if ((jn.bodyA == bodyA && jn.bodyB == bodyB) || (jn.bodyA == bodyB && jn.bodyB == bodyA))
+		{
+			if (jn.collideConnected == 0) return false;
+		}
+	}
+	return true;
+}
+
+__global__ __launch_bounds__(256) void k_collide(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	int nDestroy = 0, nTouch = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		int4 ids = C.ids[i];
+		uint32_t flags = C.flags[i];
+		const int proxyA = ids.x, proxyB = ids.y, bodyA = ids.z, bodyB = ids.w;
+		uint32_t bfA = W.b_flags[bodyA], bfB = W.b_flags[bodyB];
+		int keep = 1;
+
+		if (flags & CF_FILTER)
+		{
+			bool ok = bodiesShouldCollide(W, bodyB, bodyA) &&
+				filterShouldCollide(W.p_filter0[proxyA], W.p_filter1[proxyA], W.p_filter0[proxyB], W.p_filter1[proxyB]);
+			if (!ok)
+			{
+				keep = 0;
+			}
+			else
+			{
+				flags &= ~CF_FILTER;
+			}
+		}
+
+		bool active = bodyActiveForContact(bfA) || bodyActiveForContact(bfB);
+		if (keep && active)
+		{
+			bool overlap = b2dAabbOverlap(loadAabb(W.p_fat, proxyA), loadAabb(W.p_fat, proxyB));
+			if (!overlap)
+			{
+				keep = 0;
+			}
+			else
+			{
+				// b2Contact::UpdateImpl (b2Contact.cpp:173-298)
+				int4 m3 = C.man3[i];
+				float4 oldImp = C.imp[i];
+				const uint32_t oldId0 = (uint32_t)m3.x, oldId1 = (uint32_t)m3.y;
+				const int oldCount = m3.w;
+				flags |= CF_ENABLED;
+				bool wasTouching = (flags & CF_TOUCHING) != 0;
+				bool touching = false;
+				bool sensor = (flags & CF_SENSOR) != 0;
+				Manifold mf;
+				mf.pointCount = 0;
+				mf.type = m3.z;
+				if (sensor)
+				{
+					// TODO(next): GJK b2TestOverlap for sensors; sensors never enter the solver.
+					touching = false;
+					mf.pointCount = 0;
+				}
+				else
+				{
+					const ShapeRec* sA = W.shapes + W.p_shape[proxyA];
+					const ShapeRec* sB = W.shapes + W.p_shape[proxyB];
+					// stale fields survive an early-out exactly like the reference's persistent manifold
+					float4 o0 = C.man0[i], o1 = C.man1[i];
+					mf.localNormal = v2(o0.x, o0.y);
+					mf.localPoint = v2(o0.z, o0.w);
+					mf.p[0] = v2(o1.x, o1.y);
+					mf.p[1] = v2(o1.z, o1.w);
+					mf.id[0] = oldId0;
+					mf.id[1] = oldId1;
+					b2dEvaluate(&mf, sA, loadXf(W.b_xf, bodyA), sB, loadXf(W.b_xf, bodyB));
+					touching = mf.pointCount > 0;
+					float ni[2], ti[2];
+					ni[0] = oldImp.x; ti[0] = oldImp.y; ni[1] = oldImp.z; ti[1] = oldImp.w;
+					for (int k = 0; k < mf.pointCount; ++k)
+					{
+						mf.ni[k] = 0.0f;
+						mf.ti[k] = 0.0f;
+						uint32_t id2 = mf.id[k];
+						if (oldCount > 0 && oldId0 == id2)
+						{
+							mf.ni[k] = oldImp.x;
+							mf.ti[k] = oldImp.y;
+						}
+						else if (oldCount > 1 && oldId1 == id2)
+						{
+							mf.ni[k] = oldImp.z;
+							mf.ti[k] = oldImp.w;
+						}
+						ni[k] = mf.ni[k];
+						ti[k] = mf.ti[k];
+					}
+					if (touching != wasTouching)
+					{
+						// quirk kept: only fixture A's body is woken (b2ContactManager.cpp:472-485)
+						W.b_wake[bodyA] = 1;
+					}
+					C.man0[i] = make_float4(mf.localNormal.x, mf.localNormal.y, mf.localPoint.x, mf.localPoint.y);
+					C.man1[i] = make_float4(mf.p[0].x, mf.p[0].y, mf.p[1].x, mf.p[1].y);
+					C.imp[i] = make_float4(ni[0], ti[0], ni[1], ti[1]);
+				}
+				C.man3[i] = make_int4((int)mf.id[0], (int)mf.id[1], mf.type, mf.pointCount);
+				if (touching) flags |= CF_TOUCHING; else flags &= ~CF_TOUCHING;
+			}
+		}
+
+		if (!keep)
+		{
+			flags |= CF_DESTROY;
+			++nDestroy;
+			// b2Contact::Destroy (b2Contact.cpp:100-113): wake both bodies if the manifold had points
+			int pc = C.man3[i].w;
+			if (pc > 0 && (flags & CF_SENSOR) == 0)
+			{
+				W.b_wake[bodyA] = 1;
+				W.b_wake[bodyB] = 1;
+			}
+		}
+		else if ((flags & CF_TOUCHING) != 0)
+		{
+			++nTouch;
+		}
+		C.flags[i] = flags;
+		W.keepFlag[i] = keep;
+	}
+	if (nDestroy) atomicAdd(&S->c.nDestroy, nDestroy);
+	if (nTouch) atomicAdd(&S->c.nTouching, nTouch);
+}
+
+// Stable compaction (creation order is preserved). keepScan = exclusive scan of keepFlag.
+__global__ __launch_bounds__(256) void k_compact_contacts(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nDestroy == 0) return;
+	const int n = S->c.nContacts;
+	const ContactArrays& A = W.ca[S->cur];
+	const ContactArrays& B = W.ca[1 - S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		if (W.keepFlag[i])
+		{
+			int j = W.keepScan[i];
+			B.ids[j] = A.ids[i];
+			B.key[j] = A.key[i];
+			B.flags[j] = A.flags[i];
+			B.mat[j] = A.mat[i];
+			B.man0[j] = A.man0[i];
+			B.man1[j] = A.man1[i];
+			B.imp[j] = A.imp[i];
+			B.man3[j] = A.man3[i];
+		}
+	}
+}
+
+__global__ void k_compact_finish(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nDestroy == 0) return;
+	S->c.nContacts = W.keepScan[S->c.nContacts];
+	S->cur = 1 - S->cur;
+}
+
+// ---- contact key hash set ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hashKey(uint64_t k)
+{
+	k ^= k >> 33;
+	k *= 0xff51afd7ed558ccdULL;
+	k ^= k >> 33;
+	k *= 0xc4ceb9fe1a85ec53ULL;
+	k ^= k >> 33;
+	return (uint32_t)k;
+}
+
+__device__ __forceinline__ void htInsert(const DW& W, uint64_t key)
+{
+	uint32_t h = hashKey(key) & W.htMask;
+	for (;;)
+	{
+		unsigned long long old = atomicCAS((unsigned long long*)&W.ht_keys[h], 0ull, (unsigned long long)key);
+		if (old == 0ull || old == key) return;
+		h = (h + 1) & W.htMask;
+	}
+}
+
+__device__ __forceinline__ bool htContains(const DW& W, uint64_t key)
+{
+	uint32_t h = hashKey(key) & W.htMask;
+	for (;;)
+	{
+		uint64_t v = W.ht_keys[h];
+		if (v == key) return true;
+		if (v == 0) return false;
+		h = (h + 1) & W.htMask;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_ht_clear(DW W)
+{
+	if (W.st->c.nMoves == 0) return;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= W.htMask; i += gridDim.x * blockDim.x)
+	{
+		W.ht_keys[i] = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_ht_build(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nMoves == 0) return;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		htInsert(W, C.key[i] + 1ull); // +1 so that key 0 (proxies 0,0 never pair) cannot collide with "empty"
+	}
+}
+
+#endif

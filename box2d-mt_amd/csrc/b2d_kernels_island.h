@@ -1,0 +1,366 @@
+// b2d_kernels_island.h - island construction on the device.
+//
+// The reference finds islands with a serial DFS on the user thread (b2World.cpp:1207-1371). Here:
+//  1. connected components by lock-free union-find over the touching-contact graph (membership is
+//     order independent, so this is exact),
+//  2. components are classified: SMALL (max(bodies, contacts) <= 128, no joints) or LARGE,
+//  3. every SMALL island gets one lane that replays the reference's DFS from the reference's seed,
+//     which yields the reference's body order and constraint order for that island, plus the
+//     dependency level of every constraint (so the solver can run independent constraints of one
+//     level in parallel and still be bit-identical to the sequential sweep),
+//  4. LARGE islands only need membership (they are solved by graph colouring).
+#ifndef B2D_KERNELS_ISLAND_H
+#define B2D_KERNELS_ISLAND_H
+
+#include "b2d_kernels_collide.h"
+
+#define ROOT_NONE 0
+#define ROOT_SMALL 1
+#define ROOT_LARGE 2
+
+__device__ __forceinline__ bool contactSolid(uint32_t flags)
+{
+	// b2World.cpp:1261-1273: enabled, touching, not a sensor
+	return (flags & (CF_ENABLED | CF_TOUCHING | CF_SENSOR | CF_DESTROY)) == (CF_ENABLED | CF_TOUCHING);
+}
+
+__device__ __forceinline__ int ufFind(int* parent, int i)
+{
+	int r = i;
+	for (;;)
+	{
+		int p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (p == r) break;
+		r = p;
+	}
+	return r;
+}
+
+// Link the larger root under the smaller one: the final representative of a component is its
+// smallest body id whatever the interleaving, which makes labels deterministic.
+__device__ __forceinline__ void ufUnion(int* parent, int a, int b)
+{
+	for (;;)
+	{
+		a = ufFind(parent, a);
+		b = ufFind(parent, b);
+		if (a == b) return;
+		if (a > b)
+		{
+			int t = a;
+			a = b;
+			b = t;
+		}
+		// a < b : try to hang b under a
+		int old = atomicCAS(&parent[b], b, a);
+		if (old == b) return;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_island_init(DW W)
+{
+	DState* S = W.st;
+	const int n = W.nBodies;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		W.parent[i] = i;
+		W.rootSeed[i] = 0x7fffffff;
+		W.rootBodies[i] = 0;
+		W.rootContacts[i] = 0;
+		W.rootJoints[i] = 0;
+		W.rootIsland[i] = ROOT_NONE;
+		W.deg[i] = 0;
+		W.adjCursor[i] = 0;
+		W.b_slot[i] = -1;
+		W.b_island[i] = -1;
+		W.rootPen[i] = 0;
+		W.rootDone[i] = 0;
+		W.rootSleepMin[i] = 0x7f7fffffu; // b2_maxFloat
+		W.bodyClaim[i] = 0;
+		W.bodyColorMask[i] = 0;
+		uint32_t f = W.b_flags[i] & ~(BF_ISLAND | BF_LARGE);
+		// ConsumeAwakes / b2Contact::Destroy wake-ups gathered by collide: SetAwake(true) also
+		// resets the sleep timer of bodies that are already awake (b2Body.h:699-703).
+		if (W.b_wake[i])
+		{
+			f |= BF_AWAKE;
+			W.b_pos[i].w = 0.0f;
+			W.b_wake[i] = 0;
+		}
+		W.b_flags[i] = f;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		S->c.nSIslands = S->c.nSBodies = S->c.nSContacts = S->c.nSW = S->c.nChunks = 0;
+		S->c.nLIslands = S->c.nLBodies = S->c.nLContacts = 0;
+		S->c.nColors = 0;
+		S->c.nIslands = 0;
+		S->c.posItersLarge = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_island_union(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint32_t flags = C.flags[i] & ~CF_ISLAND;
+		C.flags[i] = flags;
+		if (!contactSolid(flags)) continue;
+		int4 ids = C.ids[i];
+		bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+		bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+		if (nsA) atomicAdd(&W.deg[ids.z], 1);
+		if (nsB) atomicAdd(&W.deg[ids.w], 1);
+		if (nsA && nsB) ufUnion(W.parent, ids.z, ids.w);
+	}
+	// joints connect bodies too (b2World.cpp:1292-1318)
+	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
+	{
+		const RevoluteJoint& jn = W.joints[j];
+		bool nsA = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC;
+		bool nsB = (W.b_flags[jn.bodyB] & BF_TYPE_MASK) != BT_STATIC;
+		if (nsA && nsB) ufUnion(W.parent, jn.bodyA, jn.bodyB);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_island_flatten(DW W)
+{
+	const int n = W.nBodies;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint32_t f = W.b_flags[i];
+		if ((f & BF_TYPE_MASK) == BT_STATIC) continue;
+		if ((f & BF_ACTIVE) == 0) continue;
+		int r = ufFind(W.parent, i);
+		__hip_atomic_store(&W.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		atomicAdd(&W.rootBodies[r], 1);
+		// seeds are taken in m_nonStaticBodies order (b2World.cpp:1207-1221): first awake, active body
+		if (f & BF_AWAKE) atomicMin(&W.rootSeed[r], i);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_island_count(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		if (!contactSolid(C.flags[i])) continue;
+		int4 ids = C.ids[i];
+		int b = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC ? ids.z : ids.w;
+		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
+		atomicAdd(&W.rootContacts[W.parent[b]], 1);
+	}
+	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
+	{
+		const RevoluteJoint& jn = W.joints[j];
+		int b = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC ? jn.bodyA : jn.bodyB;
+		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
+		atomicAdd(&W.rootJoints[W.parent[b]], 1);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
+{
+	DState* S = W.st;
+	const int n = W.nBodies;
+	int nIslands = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		int4 in = make_int4(0, 0, 0, 0);
+		uint32_t f = W.b_flags[i];
+		if ((f & BF_TYPE_MASK) != BT_STATIC && (f & BF_ACTIVE) && W.parent[i] == i)
+		{
+			bool solved = W.rootSeed[i] != 0x7fffffff;
+			if (solved)
+			{
+				++nIslands;
+				int nb = W.rootBodies[i], nc = W.rootContacts[i], nj = W.rootJoints[i];
+				int w = nb > nc ? nb : nc;
+				if (w < 1) w = 1;
+				if (nj == 0 && ((w <= SMALL_ISLAND_MAX_W && forceLarge == 0) || forceLarge == 2))
+				{
+					W.rootIsland[i] = ROOT_SMALL;
+					in = make_int4(nb, nc, w, 1);
+				}
+				else
+				{
+					W.rootIsland[i] = ROOT_LARGE;
+					int k = atomicAdd(&S->c.nLIslands, 1);
+					W.li_roots[k] = i;
+				}
+			}
+		}
+		W.rootScanIn[i] = in;
+	}
+	if (nIslands) atomicAdd(&S->c.nIslands, nIslands);
+}
+
+__global__ __launch_bounds__(256) void k_island_assign(DW W)
+{
+	DState* S = W.st;
+	const int n = W.nBodies;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint32_t f = W.b_flags[i];
+		if ((f & BF_TYPE_MASK) == BT_STATIC || (f & BF_ACTIVE) == 0) continue;
+		int r = W.parent[i];
+		int tier = W.rootIsland[r];
+		if (tier == ROOT_NONE) continue;
+		// the DFS makes every visited body awake without touching its sleep timer (b2World.cpp:1243-1244)
+		f |= BF_ISLAND | BF_AWAKE;
+		if (tier == ROOT_LARGE)
+		{
+			f |= BF_LARGE;
+			int k = atomicAdd(&S->c.nLBodies, 1);
+			W.li_bodies[k] = i;
+		}
+		W.b_flags[i] = f;
+		if (r == i && tier == ROOT_SMALL)
+		{
+			int4 sc = W.rootScanOut[i];
+			int idx = sc.w;
+			W.si_root[idx] = i;
+			W.si_bodyStart[idx] = sc.x;
+			W.si_contactStart[idx] = sc.y;
+			W.si_wStart[idx] = sc.z;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		int4 tot = W.rootScanOut[n];
+		S->c.nSBodies = tot.x;
+		S->c.nSContacts = tot.y;
+		S->c.nSW = tot.z;
+		S->c.nSIslands = tot.w;
+		W.si_bodyStart[tot.w] = tot.x;
+		W.si_contactStart[tot.w] = tot.y;
+		W.si_wStart[tot.w] = tot.z;
+		S->c.nChunks = tot.w > 0 ? (tot.z - 1) / SMALL_ISLAND_MAX_W + 1 : 0;
+	}
+}
+
+// Adjacency (small islands) and the large-island contact list.
+__global__ __launch_bounds__(256) void k_island_edges(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		if (!contactSolid(C.flags[i])) continue;
+		int4 ids = C.ids[i];
+		bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+		bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+		int b = nsA ? ids.z : ids.w;
+		if (!nsA && !nsB) continue;
+		int tier = W.rootIsland[W.parent[b]];
+		if (tier == ROOT_SMALL)
+		{
+			if (nsA) W.adj[W.adjStart[ids.z] + atomicAdd(&W.adjCursor[ids.z], 1)] = i;
+			if (nsB) W.adj[W.adjStart[ids.w] + atomicAdd(&W.adjCursor[ids.w], 1)] = i;
+		}
+		else if (tier == ROOT_LARGE)
+		{
+			int k = atomicAdd(&S->c.nLContacts, 1);
+			W.li_contacts[k] = i;
+		}
+	}
+}
+
+// One lane per small island: the reference's DFS (b2World.cpp:1223-1319), restricted to what can
+// change the outcome: static bodies are never pushed (they would be popped and skipped without
+// changing the relative order of anything else) and non-solid contacts are not in the adjacency.
+__global__ __launch_bounds__(64) void k_island_dfs(DW W)
+{
+	DState* S = W.st;
+	const int nS = S->c.nSIslands;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nS; idx += gridDim.x * blockDim.x)
+	{
+		const int root = W.si_root[idx];
+		const int seed = W.rootSeed[root];
+		const int bStart = W.si_bodyStart[idx];
+		const int cStart = W.si_contactStart[idx];
+		int* stack = W.si_stack + bStart;
+		int sp = 0, nb = 0, nc = 0;
+		stack[sp++] = seed;
+		W.b_slot[seed] = -2;
+		while (sp > 0)
+		{
+			const int b = stack[--sp];
+			const int slot = bStart + nb;
+			W.si_bodies[slot] = b;
+			W.b_slot[b] = slot;
+			W.b_island[b] = idx;
+			W.si_lastLevel[slot] = 0;
+			++nb;
+			const int s = W.adjStart[b];
+			const int e = s + W.adjCursor[b];
+			// the contact list is newest first (b2ContactManager.cpp:531-553) == descending index
+			for (int k = s + 1; k < e; ++k)
+			{
+				int v = W.adj[k];
+				int j = k - 1;
+				while (j >= s && W.adj[j] < v)
+				{
+					W.adj[j + 1] = W.adj[j];
+					--j;
+				}
+				W.adj[j + 1] = v;
+			}
+			for (int k = s; k < e; ++k)
+			{
+				const int ci = W.adj[k];
+				uint32_t cf = C.flags[ci];
+				if (cf & CF_ISLAND) continue;
+				W.si_contacts[cStart + nc] = ci;
+				++nc;
+				C.flags[ci] = cf | CF_ISLAND;
+				int4 ids = C.ids[ci];
+				const int other = ids.z == b ? ids.w : ids.z;
+				if ((W.b_flags[other] & BF_TYPE_MASK) == BT_STATIC) continue;
+				if (W.b_slot[other] != -1) continue;
+				stack[sp++] = other;
+				W.b_slot[other] = -2;
+			}
+		}
+		// dependency levels of the sequential constraint sweep
+		int maxLevel = 0;
+		for (int j = 0; j < nc; ++j)
+		{
+			int4 ids = C.ids[W.si_contacts[cStart + j]];
+			int sa = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC ? W.b_slot[ids.z] : -1;
+			int sb = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC ? W.b_slot[ids.w] : -1;
+			int la = sa >= 0 ? W.si_lastLevel[sa] : 0;
+			int lb = sb >= 0 ? W.si_lastLevel[sb] : 0;
+			int level = 1 + (la > lb ? la : lb);
+			W.si_level[cStart + j] = level;
+			if (sa >= 0) W.si_lastLevel[sa] = level;
+			if (sb >= 0) W.si_lastLevel[sb] = level;
+			if (level > maxLevel) maxLevel = level;
+		}
+		W.si_maxLevel[idx] = maxLevel;
+	}
+}
+
+// chunkFirst[c] = first small island whose weight prefix falls into [128 c, 128 (c+1))
+__global__ __launch_bounds__(256) void k_island_chunks(DW W)
+{
+	DState* S = W.st;
+	const int nS = S->c.nSIslands;
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nS; idx += gridDim.x * blockDim.x)
+	{
+		int c = W.si_wStart[idx] / SMALL_ISLAND_MAX_W;
+		if (idx == 0 || W.si_wStart[idx - 1] / SMALL_ISLAND_MAX_W != c)
+		{
+			W.chunkFirst[c] = idx;
+		}
+	}
+}
+
+#endif

@@ -1,0 +1,475 @@
+// b2d_kernels_solve_large.h - the island solver for LARGE islands (one pyramid, the tumbler pile).
+//
+// A large island cannot be walked by one lane, so its constraints are coloured (no two constraints
+// of a colour share a non-static body) and each colour is one data-parallel phase; phases are
+// separate launches on the world's stream (a kernel boundary is the cheapest grid-wide barrier on
+// MI355X). Within a Gauss-Seidel sweep this visits constraints in a different order than the
+// reference's DFS order: the iterates differ at the level the reference itself differs between two
+// valid orders, which is why poses of large islands are compared with a tolerance, while contact
+// counts and island membership stay exact.
+//
+// Constraint rows are field-major in HBM (lc[field * cap + row]) and rows are ordered by colour,
+// so a wave reads every field with fully coalesced 256-byte requests.
+#ifndef B2D_KERNELS_SOLVE_LARGE_H
+#define B2D_KERNELS_SOLVE_LARGE_H
+
+#include "b2d_kernels_solve_small.h"
+
+#define LC_WORDS ((int)(sizeof(ContactConstraint) / 4))
+#define LC_VEL_WORDS 36   // words [0, 36) = velocity part incl. pointCount
+#define LC_IMP_FIRST 10   // normalImpulse[2], tangentImpulse[2] = words 10..13
+#define LC_MASS_FIRST 28  // invMassA, invMassB, invIA, invIB
+#define LC_POS_FIRST 36
+
+// The constraint is moved between registers and its field-major HBM row through a word image
+// (memcpy keeps this free of aliasing games; it compiles to plain register moves).
+__device__ __forceinline__ void lcStore(const DW& W, int row, const ContactConstraint& cc, int first, int last)
+{
+	uint32_t words[LC_WORDS];
+	memcpy(words, &cc, sizeof(ContactConstraint));
+	uint32_t* dst = (uint32_t*)W.lc;
+#pragma unroll
+	for (int f = 0; f < LC_WORDS; ++f)
+	{
+		if (f >= first && f < last) dst[(size_t)f * W.capContacts + row] = words[f];
+	}
+}
+
+__device__ __forceinline__ void lcLoad(const DW& W, int row, ContactConstraint& cc, int first, int last)
+{
+	uint32_t words[LC_WORDS];
+	memcpy(words, &cc, sizeof(ContactConstraint));
+	const uint32_t* src = (const uint32_t*)W.lc;
+#pragma unroll
+	for (int f = 0; f < LC_WORDS; ++f)
+	{
+		if (f >= first && f < last) words[f] = src[(size_t)f * W.capContacts + row];
+	}
+	memcpy(&cc, words, sizeof(ContactConstraint));
+}
+
+// ---- bodies --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_large_integrate(DW W, StepParams sp)
+{
+	DState* S = W.st;
+	const int n = S->c.nLBodies;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int body = W.li_bodies[k];
+		float4 pos = W.b_pos[body];
+		W.b_pos0[body] = make_float4(pos.x, pos.y, pos.z, 0.0f);
+		uint32_t f = W.b_flags[body];
+		if ((f & BF_TYPE_MASK) == BT_DYNAMIC)
+		{
+			float4 vel = W.b_vel[body];
+			float4 m = W.b_mass[body], damp = W.b_damp[body], force = W.b_force[body];
+			V2 v = v2(vel.x, vel.y);
+			float w = vel.z;
+			b2dIntegrateVelocity(&v, &w, sp.dt, sp.gravity, damp.z, m.x, m.y, v2(force.x, force.y), force.z, damp.x, damp.y);
+			W.b_vel[body] = make_float4(v.x, v.y, w, 0.0f);
+		}
+	}
+}
+
+// ---- colouring (Jones-Plassmann by claims; deterministic: priorities are a bijection of the contact index)
+__device__ __forceinline__ uint32_t colorPriority(int contactIndex)
+{
+	return ((uint32_t)contactIndex + 1u) * 2654435761u;
+}
+
+__global__ __launch_bounds__(256) void k_color_begin(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nLContacts;
+	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+	{
+		W.li_color[s] = -1;
+	}
+	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS)
+	{
+		W.colorCount[threadIdx.x] = 0;
+		W.colorCursor[threadIdx.x] = 0;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		S->c.nUncolored = n;
+		S->c.colorRounds = 0;
+		S->c.nColors = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_color_claim(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nUncolored == 0) return;
+	const int n = S->c.nLContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+	{
+		if (W.li_color[s] >= 0) continue;
+		const int ci = W.li_contacts[s];
+		int4 ids = C.ids[ci];
+		uint32_t pr = colorPriority(ci);
+		if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC) atomicMax(&W.bodyClaim[ids.z], pr);
+		if ((W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC) atomicMax(&W.bodyClaim[ids.w], pr);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_color_resolve(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nUncolored == 0) return;
+	const int n = S->c.nLContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	int colored = 0;
+	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+	{
+		if (W.li_color[s] >= 0) continue;
+		const int ci = W.li_contacts[s];
+		int4 ids = C.ids[ci];
+		uint32_t pr = colorPriority(ci);
+		const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+		const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+		bool win = true;
+		if (nsA && __hip_atomic_load(&W.bodyClaim[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
+		if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
+		if (!win) continue;
+		// this lane is the only winner on both bodies this round: plain read-modify-write is safe
+		uint64_t used = 0;
+		if (nsA) used |= W.bodyColorMask[ids.z];
+		if (nsB) used |= W.bodyColorMask[ids.w];
+		int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
+		if (used == ~0ull) atomicOr(&S->c.overflow, 4);
+		uint64_t bit = 1ull << color;
+		if (nsA) { W.bodyColorMask[ids.z] |= bit; W.bodyClaim[ids.z] = 0; }
+		if (nsB) { W.bodyColorMask[ids.w] |= bit; W.bodyClaim[ids.w] = 0; }
+		W.li_color[s] = color;
+		atomicAdd(&W.colorCount[color], 1);
+		atomicMax(&S->c.nColors, color + 1);
+		++colored;
+	}
+	if (colored) atomicSub(&S->c.nUncolored, colored);
+}
+
+__global__ void k_color_scan(DW W)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		const int nc = W.st->c.nColors;
+		int run = 0;
+		for (int c = 0; c <= nc; ++c)
+		{
+			W.colorStart[c] = run;
+			if (c < nc) run += W.colorCount[c];
+		}
+	}
+}
+
+// ---- exact-order mode (validation / bit-exact large islands) ------------------------------------
+// Every island was walked by the DFS lane (k_island_dfs), so each constraint has its dependency
+// level in the reference's sequential order. Using the LEVEL as the colour makes the phased solver
+// below visit constraints in an order that commutes exactly with the reference's sweep, for any
+// island size (at the price of as many phases as the deepest dependency chain).
+__global__ __launch_bounds__(256) void k_exact_begin(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nSContacts;
+	for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n; c += gridDim.x * blockDim.x)
+	{
+		W.colorCount[c] = 0;
+		W.colorCursor[c] = 0;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.nColors = 0;
+}
+
+__global__ __launch_bounds__(256) void k_exact_convert(DW W)
+{
+	DState* S = W.st;
+	const int nC = S->c.nSContacts, nB = S->c.nSBodies, nI = S->c.nSIslands;
+	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nC; j += gridDim.x * blockDim.x)
+	{
+		W.li_contacts[j] = W.si_contacts[j];
+		const int color = W.si_level[j] - 1;
+		W.li_color[j] = color;
+		atomicAdd(&W.colorCount[color], 1);
+		atomicMax(&S->c.nColors, color + 1);
+	}
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nB; k += gridDim.x * blockDim.x)
+	{
+		const int body = W.si_bodies[k];
+		W.li_bodies[k] = body;
+		W.b_flags[body] |= BF_LARGE;
+	}
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nI; i += gridDim.x * blockDim.x)
+	{
+		W.li_roots[i] = W.si_root[i];
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		S->c.nLContacts = nC;
+		S->c.nLBodies = nB;
+		S->c.nLIslands = nI;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_color_fill(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nLContacts;
+	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+	{
+		int color = W.li_color[s];
+		if (color < 0) continue;
+		int p = W.colorStart[color] + atomicAdd(&W.colorCursor[color], 1);
+		W.li_sorted[p] = s;
+	}
+}
+
+// ---- constraints -----------------------------------------------------------------------------------
+struct LargeRef
+{
+	int ci, bodyA, bodyB, root;
+	bool nsA, nsB;
+};
+
+__device__ __forceinline__ LargeRef largeRef(const DW& W, const ContactArrays& C, int row)
+{
+	LargeRef r;
+	r.ci = W.li_contacts[W.li_sorted[row]];
+	int4 ids = C.ids[r.ci];
+	r.bodyA = ids.z;
+	r.bodyB = ids.w;
+	r.nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+	r.nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+	r.root = W.parent[r.nsA ? ids.z : ids.w];
+	return r;
+}
+
+__global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)
+{
+	DState* S = W.st;
+	const int n = S->c.nLContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x)
+	{
+		LargeRef r = largeRef(W, C, row);
+		int4 ids = C.ids[r.ci];
+		float4 pa = W.b_pos[r.bodyA], pb = W.b_pos[r.bodyB];
+		float4 va = W.b_vel[r.bodyA], vb = W.b_vel[r.bodyB];
+		float4 mA4 = W.b_mass[r.bodyA], mB4 = W.b_mass[r.bodyB];
+		BodyPos pA, pB;
+		BodyVel vA, vB;
+		pA.c = v2(pa.x, pa.y); pA.a = pa.z;
+		pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+		vA.v = r.nsA ? v2(va.x, va.y) : v2(0, 0); vA.w = r.nsA ? va.z : 0.0f;
+		vB.v = r.nsB ? v2(vb.x, vb.y) : v2(0, 0); vB.w = r.nsB ? vb.z : 0.0f;
+		float4 cmat = C.mat[r.ci];
+		float4 m0 = C.man0[r.ci], m1 = C.man1[r.ci], im = C.imp[r.ci];
+		int4 m3 = C.man3[r.ci];
+		Manifold mf;
+		mf.localNormal = v2(m0.x, m0.y);
+		mf.localPoint = v2(m0.z, m0.w);
+		mf.p[0] = v2(m1.x, m1.y);
+		mf.p[1] = v2(m1.z, m1.w);
+		mf.ni[0] = im.x; mf.ti[0] = im.y; mf.ni[1] = im.z; mf.ti[1] = im.w;
+		mf.id[0] = (uint32_t)m3.x; mf.id[1] = (uint32_t)m3.y;
+		mf.type = m3.z;
+		mf.pointCount = m3.w;
+		ContactConstraint cc;
+		b2dInitConstraint(&cc, &mf, cmat.x, cmat.y, cmat.z,
+			mA4.x, mA4.y, v2(mA4.z, mA4.w), W.shapes[W.p_shape[ids.x]].radius,
+			mB4.x, mB4.y, v2(mB4.z, mB4.w), W.shapes[W.p_shape[ids.y]].radius,
+			pA, vA, pB, vB, sp.warmStarting != 0, sp.dtRatio);
+		lcStore(W, row, cc, 0, LC_WORDS);
+	}
+}
+
+// mode 0 = warm start, 1 = velocity iteration
+__global__ __launch_bounds__(256) void k_large_velocity(DW W, int color, int mode)
+{
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	const int begin = W.colorStart[color], end = W.colorStart[color + 1];
+	for (int row = begin + blockIdx.x * blockDim.x + threadIdx.x; row < end; row += gridDim.x * blockDim.x)
+	{
+		LargeRef r = largeRef(W, C, row);
+		ContactConstraint cc;
+		memset(&cc, 0, sizeof(cc));
+		lcLoad(W, row, cc, 0, LC_VEL_WORDS);
+		BodyVel vA, vB;
+		vA.v = v2(0, 0); vA.w = 0; vB = vA;
+		if (r.nsA) { float4 v = W.b_vel[r.bodyA]; vA.v = v2(v.x, v.y); vA.w = v.z; }
+		if (r.nsB) { float4 v = W.b_vel[r.bodyB]; vB.v = v2(v.x, v.y); vB.w = v.z; }
+		if (mode == 0)
+		{
+			b2dWarmStart(&cc, &vA, &vB);
+		}
+		else
+		{
+			b2dSolveVelocity(&cc, &vA, &vB);
+			lcStore(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
+		}
+		if (r.nsA) W.b_vel[r.bodyA] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
+		if (r.nsB) W.b_vel[r.bodyB] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_large_store_impulses(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nLContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x)
+	{
+		const int ci = W.li_contacts[W.li_sorted[row]];
+		ContactConstraint cc;
+		memset(&cc, 0, sizeof(cc));
+		lcLoad(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
+		lcLoad(W, row, cc, 35, 36);
+		float4 im = C.imp[ci];
+		if (cc.pointCount > 0) { im.x = cc.normalImpulse[0]; im.y = cc.tangentImpulse[0]; }
+		if (cc.pointCount > 1) { im.z = cc.normalImpulse[1]; im.w = cc.tangentImpulse[1]; }
+		C.imp[ci] = im;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_large_integrate_positions(DW W, StepParams sp)
+{
+	DState* S = W.st;
+	const int n = S->c.nLBodies;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int body = W.li_bodies[k];
+		float4 p = W.b_pos[body], v = W.b_vel[body];
+		V2 c = v2(p.x, p.y), vv = v2(v.x, v.y);
+		float a = p.z, w = v.z;
+		b2dIntegratePosition(&c, &a, &vv, &w, sp.dt);
+		W.b_pos[body] = make_float4(c.x, c.y, a, p.w);
+		W.b_vel[body] = make_float4(vv.x, vv.y, w, 0.0f);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.allLargeDone = 0;
+}
+
+__global__ __launch_bounds__(256) void k_large_pos_begin(DW W)
+{
+	DState* S = W.st;
+	if (S->c.allLargeDone) return;
+	const int n = S->c.nLIslands;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		W.rootPen[W.li_roots[k]] = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_large_position(DW W, int color)
+{
+	DState* S = W.st;
+	if (S->c.allLargeDone) return;
+	const ContactArrays& C = W.ca[S->cur];
+	const int begin = W.colorStart[color], end = W.colorStart[color + 1];
+	for (int row = begin + blockIdx.x * blockDim.x + threadIdx.x; row < end; row += gridDim.x * blockDim.x)
+	{
+		LargeRef r = largeRef(W, C, row);
+		if (W.rootDone[r.root]) continue;
+		ContactConstraint cc;
+		memset(&cc, 0, sizeof(cc));
+		lcLoad(W, row, cc, LC_MASS_FIRST, LC_MASS_FIRST + 4);
+		lcLoad(W, row, cc, LC_POS_FIRST, LC_WORDS);
+		float4 pa = W.b_pos[r.bodyA], pb = W.b_pos[r.bodyB];
+		BodyPos pA, pB;
+		pA.c = v2(pa.x, pa.y); pA.a = pa.z;
+		pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+		float minSep = 0.0f;
+		b2dSolvePosition(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
+		if (r.nsA) W.b_pos[r.bodyA] = make_float4(pA.c.x, pA.c.y, pA.a, pa.w);
+		if (r.nsB) W.b_pos[r.bodyB] = make_float4(pB.c.x, pB.c.y, pB.a, pb.w);
+		atomicMax(&W.rootPen[r.root], floatBits(0.0f - minSep));
+	}
+}
+
+// After all colours of one position iteration: per-island early out (b2Island.cpp:329-334).
+__global__ __launch_bounds__(256) void k_large_pos_end(DW W)
+{
+	DState* S = W.st;
+	if (S->c.allLargeDone) return;
+	__shared__ int s_open;
+	if (threadIdx.x == 0) s_open = 0;
+	__syncthreads();
+	const int n = S->c.nLIslands;
+	int open = 0;
+	for (int k = threadIdx.x; k < n; k += blockDim.x)
+	{
+		const int root = W.li_roots[k];
+		if (W.rootDone[root]) continue;
+		float minSeparation = -__uint_as_float(W.rootPen[root]);
+		if (minSeparation >= -3.0f * B2D_LINEAR_SLOP && W.rootJoints[root] == 0)
+		{
+			W.rootDone[root] = 1;
+		}
+		else
+		{
+			++open;
+		}
+	}
+	if (open) atomicAdd(&s_open, open);
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		S->c.posItersLarge += 1;
+		if (s_open == 0) S->c.allLargeDone = 1;
+	}
+}
+
+// Write back + SynchronizeTransform + sleep timers (b2Island.cpp:338-382)
+__global__ __launch_bounds__(256) void k_large_finalize(DW W, StepParams sp)
+{
+	DState* S = W.st;
+	const int n = S->c.nLBodies;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int body = W.li_bodies[k];
+		float4 p = W.b_pos[body], v = W.b_vel[body], m = W.b_mass[body];
+		Xf xf = b2dXfFromSweep(v2(p.x, p.y), p.z, v2(m.z, m.w));
+		W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
+		if (sp.allowSleep)
+		{
+			const float linTolSqr = B2D_LINEAR_SLEEP_TOL * B2D_LINEAR_SLEEP_TOL;
+			const float angTolSqr = B2D_ANGULAR_SLEEP_TOL * B2D_ANGULAR_SLEEP_TOL;
+			uint32_t f = W.b_flags[body];
+			float sleepTime = p.w;
+			if ((f & BF_AUTOSLEEP) == 0 || v.z * v.z > angTolSqr || b2dDot(v2(v.x, v.y), v2(v.x, v.y)) > linTolSqr)
+			{
+				sleepTime = 0.0f;
+			}
+			else
+			{
+				sleepTime += sp.dt;
+			}
+			W.b_pos[body] = make_float4(p.x, p.y, p.z, sleepTime);
+			atomicMin(&W.rootSleepMin[W.parent[body]], floatBits(sleepTime));
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_large_sleep(DW W, StepParams sp)
+{
+	DState* S = W.st;
+	if (!sp.allowSleep) return;
+	const int n = S->c.nLBodies;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int body = W.li_bodies[k];
+		const int root = W.parent[body];
+		float minSleepTime = __uint_as_float(W.rootSleepMin[root]);
+		if (minSleepTime >= B2D_TIME_TO_SLEEP && W.rootDone[root])
+		{
+			float4 p = W.b_pos[body];
+			W.b_flags[body] &= ~BF_AWAKE;
+			W.b_pos[body] = make_float4(p.x, p.y, p.z, 0.0f);
+			W.b_vel[body] = make_float4(0, 0, 0, 0);
+			W.b_force[body] = make_float4(0, 0, 0, 0);
+		}
+	}
+}
+
+#endif

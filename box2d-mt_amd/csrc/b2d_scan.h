@@ -1,0 +1,232 @@
+// b2d_scan.h - device-wide exclusive scan and stable LSD radix sort, hand-written for wave64.
+// Element counts live in device memory (the host never learns them mid-step), so every launch is
+// sized by a capacity and blocks beyond the live count exit immediately.
+#ifndef B2D_SCAN_H
+#define B2D_SCAN_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 4
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ __forceinline__ int scanAdd(int a, int b) { return a + b; }
+__device__ __forceinline__ int4 scanAdd(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ void scanZero(int& a) { a = 0; }
+__device__ __forceinline__ void scanZero(int4& a) { a = make_int4(0, 0, 0, 0); }
+
+// Exclusive scan of one value per thread across a 256-thread block (Hillis-Steele through LDS).
+template <typename T>
+__device__ __forceinline__ T blockExclusiveScan(T val, T* total, T* lds /* [2 * SCAN_THREADS] */)
+{
+	int tid = threadIdx.x;
+	int pin = 0;
+	lds[tid] = val;
+	__syncthreads();
+	for (int off = 1; off < SCAN_THREADS; off <<= 1)
+	{
+		T v = lds[pin * SCAN_THREADS + tid];
+		if (tid >= off) v = scanAdd(v, lds[pin * SCAN_THREADS + tid - off]);
+		lds[(1 - pin) * SCAN_THREADS + tid] = v;
+		pin = 1 - pin;
+		__syncthreads();
+	}
+	T incl = lds[pin * SCAN_THREADS + tid];
+	*total = lds[pin * SCAN_THREADS + SCAN_THREADS - 1];
+	T excl;
+	scanZero(excl);
+	if (tid > 0) excl = lds[pin * SCAN_THREADS + tid - 1];
+	__syncthreads();
+	(void)incl;
+	return excl;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const T* __restrict__ in, T* __restrict__ blockSums, const int* nPtr)
+{
+	__shared__ T lds[2 * SCAN_THREADS];
+	int n = *nPtr;
+	int base = blockIdx.x * SCAN_TILE;
+	if (base >= n) return;
+	T sum;
+	scanZero(sum);
+	for (int k = 0; k < SCAN_ITEMS; ++k)
+	{
+		int i = base + threadIdx.x * SCAN_ITEMS + k;
+		if (i < n) sum = scanAdd(sum, in[i]);
+	}
+	T total;
+	blockExclusiveScan(sum, &total, lds);
+	if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(T* __restrict__ blockSums, const int* nPtr, T* totalOut)
+{
+	__shared__ T lds[2 * SCAN_THREADS];
+	int n = *nPtr;
+	int numBlocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+	T carry;
+	scanZero(carry);
+	for (int base = 0; base < numBlocks; base += SCAN_THREADS)
+	{
+		int i = base + threadIdx.x;
+		T v;
+		scanZero(v);
+		if (i < numBlocks) v = blockSums[i];
+		T total;
+		T excl = blockExclusiveScan(v, &total, lds);
+		if (i < numBlocks) blockSums[i] = scanAdd(carry, excl);
+		carry = scanAdd(carry, total);
+	}
+	if (threadIdx.x == 0 && totalOut) *totalOut = carry;
+}
+
+// out[i] = sum of in[0..i) ; out[n] = total (out must hold n + 1 entries)
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ blockSums, const int* nPtr)
+{
+	__shared__ T lds[2 * SCAN_THREADS];
+	int n = *nPtr;
+	int base = blockIdx.x * SCAN_TILE;
+	if (n == 0)
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+		{
+			T z;
+			scanZero(z);
+			out[0] = z;
+		}
+		return;
+	}
+	if (base >= n) return;
+	T v[SCAN_ITEMS];
+	T sum;
+	scanZero(sum);
+	for (int k = 0; k < SCAN_ITEMS; ++k)
+	{
+		int i = base + threadIdx.x * SCAN_ITEMS + k;
+		scanZero(v[k]);
+		if (i < n) v[k] = in[i];
+		sum = scanAdd(sum, v[k]);
+	}
+	T total;
+	T excl = blockExclusiveScan(sum, &total, lds);
+	T run = scanAdd(blockSums[blockIdx.x], excl);
+	for (int k = 0; k < SCAN_ITEMS; ++k)
+	{
+		int i = base + threadIdx.x * SCAN_ITEMS + k;
+		if (i < n) out[i] = run;
+		run = scanAdd(run, v[k]);
+		if (i == n - 1) out[n] = run;
+	}
+}
+
+// Host helper: three launches on `stream`. capN bounds the grid; nPtr is the live count in device memory.
+template <typename T>
+static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, T* blockSums, const int* nPtr, int capN)
+{
+	int blocks = (capN + SCAN_TILE - 1) / SCAN_TILE;
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(k_scan_reduce<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, blockSums, nPtr);
+	hipLaunchKernelGGL(k_scan_blocksums<T>, dim3(1), dim3(SCAN_THREADS), 0, stream, blockSums, nPtr, (T*)nullptr);
+	hipLaunchKernelGGL(k_scan_final<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, blockSums, nPtr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stable LSD radix sort of (uint64 key, int2 payload), 8 bits per pass.
+// Per pass: (1) per-tile digit histogram, (2) scan of the digit-major histogram matrix,
+// (3) stable scatter using wave64 ballots to rank equal digits inside a wave.
+#define RADIX_THREADS 256
+#define RADIX_ITEMS 8
+#define RADIX_TILE (RADIX_THREADS * RADIX_ITEMS)
+
+__global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(const uint64_t* __restrict__ keys, int* __restrict__ hist,
+	const int* nPtr, int minN, int shift, int numTilesCap)
+{
+	__shared__ int lh[256];
+	int n = *nPtr;
+	if (n <= minN) return;
+	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+	int tile = blockIdx.x;
+	if (tile >= numTiles) return;
+	lh[threadIdx.x] = 0;
+	__syncthreads();
+	int base = tile * RADIX_TILE;
+	for (int k = 0; k < RADIX_ITEMS; ++k)
+	{
+		int i = base + k * RADIX_THREADS + threadIdx.x;
+		if (i < n)
+		{
+			int d = (int)((keys[i] >> shift) & 0xffu);
+			atomicAdd(&lh[d], 1);
+		}
+	}
+	__syncthreads();
+	// digit-major so that a plain scan yields global offsets
+	hist[threadIdx.x * numTiles + tile] = lh[threadIdx.x];
+	(void)numTilesCap;
+}
+
+// histCount = 256 * numTiles, written to device memory for the scan utility
+__global__ void k_radix_count(const int* nPtr, int minN, int* histCount)
+{
+	int n = *nPtr;
+	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+	*histCount = (n <= minN) ? 0 : 256 * numTiles;
+}
+
+__global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(const uint64_t* __restrict__ keysIn, const int2* __restrict__ valsIn,
+	uint64_t* __restrict__ keysOut, int2* __restrict__ valsOut, const int* __restrict__ histScan, const int* nPtr, int minN, int shift)
+{
+	__shared__ int waveCount[4][256]; // per wave digit counts of the current round
+	__shared__ int digitBase[256];    // running global offset per digit for this tile
+	int n = *nPtr;
+	if (n <= minN) return;
+	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+	int tile = blockIdx.x;
+	if (tile >= numTiles) return;
+	int tid = threadIdx.x;
+	int lane = tid & 63;
+	int wave = tid >> 6;
+	digitBase[tid] = histScan[tid * numTiles + tile];
+	int base = tile * RADIX_TILE;
+	for (int k = 0; k < RADIX_ITEMS; ++k)
+	{
+		for (int w = 0; w < 4; ++w) waveCount[w][tid] = 0;
+		__syncthreads();
+		int i = base + k * RADIX_THREADS + tid;
+		bool valid = i < n;
+		uint64_t key = valid ? keysIn[i] : 0;
+		int d = valid ? (int)((key >> shift) & 0xffu) : -1;
+		// lanes of this wave holding the same digit
+		unsigned long long peers = __ballot(valid);
+		for (int b = 0; b < 8; ++b)
+		{
+			unsigned long long m = __ballot(valid && ((d >> b) & 1));
+			peers &= ((d >> b) & 1) ? m : ~m;
+		}
+		if (!valid) peers = 0;
+		unsigned long long lower = peers & ((1ull << lane) - 1ull);
+		int rankInWave = __popcll(lower);
+		if (valid && lower == 0)
+		{
+			waveCount[wave][d] = __popcll(peers); // first lane of each digit group
+		}
+		__syncthreads();
+		if (valid)
+		{
+			int off = digitBase[d];
+			for (int w = 0; w < wave; ++w) off += waveCount[w][d];
+			int dst = off + rankInWave;
+			keysOut[dst] = key;
+			valsOut[dst] = valsIn[i];
+		}
+		__syncthreads();
+		digitBase[tid] += waveCount[0][tid] + waveCount[1][tid] + waveCount[2][tid] + waveCount[3][tid];
+		__syncthreads();
+	}
+}
+
+#endif

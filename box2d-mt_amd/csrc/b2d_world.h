@@ -1,0 +1,214 @@
+// b2d_world.h - HBM layout of one simulated world (structure of arrays) and the per-step
+// device-side state block. Every kernel receives a `DW` by value (kernarg, scalar loads): the
+// pointers below, plus a pointer to the mutable `DState` (counters, current contact buffer).
+//
+// Layout rationale (MI355X): every per-body / per-contact field group is a 16-byte vector so a
+// wave reads it with one global_load_dwordx4 per lane (1 KiB per wave-instruction, fully
+// coalesced when lanes walk consecutive indices). Contacts are kept dense and in creation order
+// (stable compaction on destroy), because creation order is what defines the reference's
+// per-body contact-list order and therefore its Gauss-Seidel order (b2ContactManager.cpp:531-553).
+#ifndef B2D_WORLD_H
+#define B2D_WORLD_H
+
+#include "b2d_solver.h"
+
+// body flag bits (device). Bits 0-1 hold the b2BodyType.
+#define BF_TYPE_MASK 0x3u
+#define BF_AWAKE 0x4u
+#define BF_AUTOSLEEP 0x8u
+#define BF_BULLET 0x10u
+#define BF_FIXEDROT 0x20u
+#define BF_ACTIVE 0x40u
+#define BF_ISLAND 0x80u      // was in a solved island this step (b2Body::e_islandFlag)
+#define BF_LARGE 0x100u      // its island is solved by the coloured (large island) path this step
+
+#define BT_STATIC 0u
+#define BT_KINEMATIC 1u
+#define BT_DYNAMIC 2u
+
+// contact flag bits (b2Contact.h:178-203 restated)
+#define CF_TOUCHING 0x1u
+#define CF_ENABLED 0x2u
+#define CF_FILTER 0x4u
+#define CF_TOI_CANDIDATE 0x8u
+#define CF_SENSOR 0x10u      // either fixture is a sensor (cached at creation)
+#define CF_DESTROY 0x20u     // marked by collide, removed by the compaction that follows
+#define CF_ISLAND 0x40u      // already added to an island by the DFS
+
+// proxy filter1 packing: low 16 = groupIndex (int16), bit16 = sensor, bit17 = thick
+#define PF_SENSOR 0x10000
+#define PF_THICK 0x20000
+
+#define SMALL_ISLAND_MAX_W 128   // an island is "small" if max(bodies, contacts, 1) <= this
+#define SMALL_CHUNK_LANES 256    // one workgroup solves one chunk of small islands (<= 256 bodies, <= 256 contacts)
+#define MAX_COLORS 64
+#define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
+
+struct ContactArrays
+{
+	int4* ids;        // proxyA, proxyB, bodyA, bodyB  (A/B after the type-table swap of b2Contact::Create)
+	uint64_t* key;    // (min proxyKey << 32) | max proxyKey : b2ContactProxyIds ordering key
+	uint32_t* flags;
+	float4* mat;      // friction, restitution, tangentSpeed, toi
+	float4* man0;     // localNormal.xy, localPoint.xy
+	float4* man1;     // points[0].localPoint.xy, points[1].localPoint.xy
+	float4* imp;      // normalImpulse0, tangentImpulse0, normalImpulse1, tangentImpulse1
+	int4* man3;       // id0.key, id1.key, manifold type, pointCount
+};
+
+struct RevoluteJoint
+{
+	int bodyA, bodyB;
+	V2 localAnchorA, localAnchorB;
+	float referenceAngle;
+	int enableLimit;
+	float lowerAngle, upperAngle;
+	int enableMotor;
+	float motorSpeed, maxMotorTorque;
+	int collideConnected;
+	// persistent solver state (b2RevoluteJoint.h:190-199)
+	float impulseX, impulseY, impulseZ;
+	float motorImpulse;
+	int limitState;
+};
+
+struct Counters
+{
+	int nContacts;       // live contacts
+	int nDestroy;        // marked by collide this step
+	int nTouching;
+	int nMoves;          // entries of the move buffer
+	int nPairs;          // candidate pairs emitted by the pair finder
+	int nNewContacts;    // unique new contacts created
+	int nRoots;
+	int nSIslands, nSBodies, nSContacts, nSW, nChunks;
+	int nLIslands, nLBodies, nLContacts;
+	int nColors, nUncolored, colorRounds;
+	int nLargeProxies;
+	int posItersLarge;
+	int allLargeDone;
+	int overflow;        // bit0 contacts, bit1 pairs, bit2 colours, bit3 moves
+	int nIslands;
+	int pad[8];
+};
+
+struct DState
+{
+	Counters c;
+	int cur;             // which ContactArrays is live
+	int pad[15];
+};
+
+struct StepParams
+{
+	float dt, inv_dt, dtRatio;
+	int velIters, posIters;
+	int warmStarting, allowSleep;
+	V2 gravity;
+};
+
+struct DW
+{
+	DState* st;
+	int nBodies, nProxies, nJoints, nShapes;
+	int capContacts, capPairs, capMoves;
+	uint32_t htMask;      // contact-key hash table size - 1
+	uint32_t gridMask;    // broad-phase hash grid size - 1
+	float cellSize, invCellSize;
+
+	// ---- bodies [nBodies], index = creation order ------------------------------------------
+	float4* b_pos;    // sweep.c.xy, sweep.a, sleepTime
+	float4* b_pos0;   // sweep.c0.xy, sweep.a0, alpha0
+	float4* b_vel;    // v.xy, w, -
+	float4* b_xf;     // xf.p.xy, xf.q.s, xf.q.c
+	float4* b_mass;   // invMass, invI, localCenter.xy        (constant between edits)
+	float4* b_damp;   // linearDamping, angularDamping, gravityScale, -
+	float4* b_force;  // force.xy, torque, -
+	uint32_t* b_flags;
+	int* b_wake;      // wake requests gathered during collide / contact creation
+
+	// ---- proxies [nProxies], one per fixture (circle / edge / polygon) -----------------------
+	float4* p_fat;    // fat AABB lower.xy, upper.xy (b2DynamicTree node aabb)
+	int* p_body;
+	int* p_shape;
+	int* p_key;       // proxy id the reference's tree would hand out: the deterministic ordering key
+	uint32_t* p_filter0; // categoryBits | maskBits << 16
+	int* p_filter1;      // groupIndex | sensor / thick bits
+	float2* p_mat;       // friction, restitution
+	const ShapeRec* shapes;
+
+	// ---- contacts ---------------------------------------------------------------------------
+	ContactArrays ca[2];
+	uint64_t* ht_keys;   // open-addressing set of live contact keys
+
+	// ---- joints -----------------------------------------------------------------------------
+	RevoluteJoint* joints;
+
+	// ---- island build -----------------------------------------------------------------------
+	int* parent;         // union-find over non-static bodies; after flatten: island root per body
+	int* rootSeed;       // per root: min awake body id (INT_MAX = island asleep)
+	int* rootBodies;     // per root: non-static body count
+	int* rootContacts;   // per root: solid touching contact count
+	int* rootJoints;
+	int4* rootScanIn;    // per body slot: (nb, nc, w, 1) for small solved roots else 0
+	int4* rootScanOut;
+	int* rootIsland;     // per root: small-island index, or -2 for large, -1 not solved
+	int* deg;            // per body: number of solid touching contacts (CSR)
+	int* adjStart;       // exclusive scan of deg
+	int* adjCursor;
+	int* adj;            // contact indices grouped by body
+	// small islands
+	int* si_root;        // [nSIslands]
+	int* si_bodyStart;   // [nSIslands + 1]
+	int* si_contactStart;
+	int* si_wStart;
+	int* si_maxLevel;
+	int* si_bodies;      // body ids in the reference's DFS order, island after island
+	int* si_contacts;    // contact indices in the reference's discovery order
+	int* si_level;       // dependency level of each contact inside its island (1-based)
+	int* si_stack;       // DFS stack scratch (same segmentation as si_bodies)
+	int* si_lastLevel;   // per island-body slot scratch
+	int* b_slot;         // per body: slot in si_bodies (small islands)
+	int* b_island;       // per body: small island index
+	int* chunkFirst;     // [nChunks] first small island of each solver chunk
+	// large islands
+	int* li_bodies;      // body ids (any order)
+	int* li_contacts;    // contact indices (any order)
+	int* li_roots;
+	int* li_color;       // per large contact slot
+	int* colorCount;     // [MAX_COLORS + 1]
+	int* colorStart;     // [MAX_COLORS + 1]
+	int* colorCursor;
+	int* li_sorted;      // large contact slots grouped by colour
+	uint32_t* bodyClaim;
+	uint64_t* bodyColorMask;
+	float* lc;           // large-island constraint rows, field-major: lc[field * capContacts + slot]
+	uint32_t* rootPen;   // per root: max penetration of the running position iteration (bits of -minSeparation)
+	int* rootDone;       // per root: positionSolved
+	uint32_t* rootSleepMin;
+
+	// ---- broad-phase ------------------------------------------------------------------------
+	int* moveBuf;        // proxy indices whose fat AABB changed / were created
+	int* gridCount;      // per hash cell
+	int* gridStart;
+	int* gridCursor;
+	int* gridItems;      // proxy indices grouped by cell
+	int* largeProxies;   // proxies larger than a cell
+	uint64_t* pairKey;   // candidate pairs: key
+	int2* pairProxy;     // proxy indices (lo-key proxy, hi-key proxy)
+	uint64_t* pairKey2;  // sort double buffer
+	int2* pairProxy2;
+	int* pairFirst;      // 1 if first occurrence of its key
+	int* pairRank;       // rank among unique keys
+
+	// ---- generic scratch ----------------------------------------------------------------------
+	int* scanTmp;        // block sums for the scan utility
+	int* radixHist;
+	int* keepFlag;       // contact compaction
+	int* keepScan;
+
+	// ---- read-back ------------------------------------------------------------------------------
+	float* stateOut;     // 10 x 4 bytes per body (b2hip_body_state)
+};
+
+#endif

@@ -1,0 +1,1466 @@
+// b2hip.hip - libb2hip.so: host bookkeeping + step orchestration + the C ABI declared in include/b2hip.h.
+//
+// The world lives in HBM (b2d_world.h). The host keeps (a) the immutable per-body / per-fixture
+// parameters it was given, (b) a mirror of the dynamic body state refreshed by the mandatory
+// read-back at the end of each step, and (c) the deterministic proxy-id allocator that reproduces
+// the ids the reference's dynamic tree would hand out (they define every deterministic ordering,
+// b2ContactManager.cpp:64-92). All physics runs in HIP kernels; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/b2hip.h"
+#include "b2d_kernels_broadphase.h"
+#include "b2d_scan.h"
+
+static thread_local std::string g_lastError;
+
+static int setError(int code, const std::string& msg)
+{
+	g_lastError = msg;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+	do                                                                                                  \
+	{                                                                                                   \
+		hipError_t _e = (expr);                                                                         \
+		if (_e != hipSuccess)                                                                           \
+		{                                                                                               \
+			return setError(B2HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+		}                                                                                               \
+	} while (0)
+
+// Device array that keeps its content when it grows.
+template <typename T>
+struct DevArray
+{
+	T* p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t n, hipStream_t stream, bool keep = true, bool zeroNew = true)
+	{
+		if (n <= cap) return 0;
+		size_t ncap = cap ? cap : 64;
+		while (ncap < n) ncap *= 2;
+		T* np = nullptr;
+		HIP_TRY(hipMalloc((void**)&np, ncap * sizeof(T)));
+		if (zeroNew) HIP_TRY(hipMemsetAsync(np, 0, ncap * sizeof(T), stream));
+		if (keep && p && cap) HIP_TRY(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream));
+		if (p)
+		{
+			HIP_TRY(hipStreamSynchronize(stream));
+			HIP_TRY(hipFree(p));
+		}
+		p = np;
+		cap = ncap;
+		return 0;
+	}
+	void release()
+	{
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+struct HostBody
+{
+	int type;
+	uint32_t flags;
+	float px, py, qs, qc;   // m_xf
+	float cx, cy, a;        // m_sweep.c, a
+	float c0x, c0y, a0;
+	float lcx, lcy;         // m_sweep.localCenter
+	float vx, vy, w;
+	float fx, fy, torque;
+	float mass, I, invMass, invI;
+	float linearDamping, angularDamping, gravityScale;
+	float sleepTime;
+	std::vector<int> fixtures; // creation order (the reference's list is newest first)
+	bool dirty;
+};
+
+struct HostFixture
+{
+	int body;
+	int shape;
+	float density, friction, restitution;
+	uint16_t categoryBits, maskBits;
+	int16_t groupIndex;
+	bool isSensor, thick;
+	int proxyKey;
+	float fat[4];
+};
+
+struct FreeUnit
+{
+	int leaf;
+};
+
+struct b2hip_world
+{
+	b2hip_world_def def;
+	int device;
+	hipStream_t stream;
+	bool debugSync;
+
+	std::vector<HostBody> bodies;
+	std::vector<HostFixture> fixtures;
+	std::vector<ShapeRec> shapes;
+	std::map<std::string, int> shapeIndex;
+	std::vector<RevoluteJoint> joints;
+
+	// proxy id allocator (b2DynamicTree::AllocateNode / FreeNode, b2DynamicTree.cpp:53-99)
+	int nextNode;
+	int leafCount;
+	std::vector<FreeUnit> freeUnits;
+
+	// what has been uploaded so far
+	size_t upBodies, upFixtures, upShapes, upJoints;
+	std::vector<int> pendingMoves;
+	bool newFixture;
+	float inv_dt0;
+	bool stepActive;
+	StepParams sp;
+
+	// device
+	DW dw;
+	DevArray<DState> d_state;
+	DevArray<float4> b_pos, b_pos0, b_vel, b_xf, b_mass, b_damp, b_force;
+	DevArray<uint32_t> b_flags;
+	DevArray<int> b_wake;
+	DevArray<float4> p_fat;
+	DevArray<int> p_body, p_shape, p_key, p_filter1;
+	DevArray<uint32_t> p_filter0;
+	DevArray<float2> p_mat;
+	DevArray<ShapeRec> d_shapes;
+	DevArray<int4> c_ids[2];
+	DevArray<uint64_t> c_key[2];
+	DevArray<uint32_t> c_flags[2];
+	DevArray<float4> c_mat[2], c_man0[2], c_man1[2], c_imp[2];
+	DevArray<int4> c_man3[2];
+	DevArray<uint64_t> ht_keys;
+	DevArray<RevoluteJoint> d_joints;
+	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
+	DevArray<int4> rootScanIn, rootScanOut;
+	DevArray<int> si_root, si_bodyStart, si_contactStart, si_wStart, si_maxLevel, si_bodies, si_contacts, si_level,
+		si_stack, si_lastLevel, b_slot, b_island, chunkFirst;
+	DevArray<int> li_bodies, li_contacts, li_roots, li_color, colorCount, colorStart, colorCursor, li_sorted;
+	DevArray<uint32_t> bodyClaim, rootPen, rootSleepMin;
+	DevArray<uint64_t> bodyColorMask;
+	DevArray<int> rootDone;
+	DevArray<float> lc;
+	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies;
+	DevArray<uint64_t> pairKey, pairKey2;
+	DevArray<int2> pairProxy, pairProxy2;
+	DevArray<int> pairFirst, pairRank;
+	DevArray<int> scanTmp, radixHist, radixHistScan, keepFlag, keepScan;
+	DevArray<int4> scanTmp4;
+	DevArray<float> stateOut;
+	DevArray<int> consts; // [0] nBodies, [1] gridSize, [2] radix hist count, [3] sorted-pair count
+
+	// pinned host buffers
+	float* h_state;
+	size_t h_stateCap;
+	DState* h_dstate;
+
+	Counters last;        // counters of the last completed step
+	int lastContacts;
+	float profile[13];
+	hipEvent_t ev[12];
+	float solverMs;
+	double solverBytes;
+	int solverConstraints, solverBodies;
+	int forceLarge;
+};
+
+// ------------------------------------------------------------------------------------------------
+static int nextPow2(size_t n)
+{
+	size_t p = 64;
+	while (p < n) p <<= 1;
+	return (int)p;
+}
+
+static int allocProxyKey(b2hip_world* w)
+{
+	int key;
+	if (!w->freeUnits.empty())
+	{
+		key = w->freeUnits.back().leaf;
+		w->freeUnits.pop_back();
+	}
+	else
+	{
+		key = w->nextNode++;
+		if (w->leafCount > 0) w->nextNode++; // the internal parent node InsertLeaf allocates
+	}
+	w->leafCount++;
+	return key;
+}
+
+static int internShape(b2hip_world* w, const ShapeRec& s)
+{
+	std::string bytes((const char*)&s, sizeof(ShapeRec));
+	std::map<std::string, int>::iterator it = w->shapeIndex.find(bytes);
+	if (it != w->shapeIndex.end()) return it->second;
+	int idx = (int)w->shapes.size();
+	w->shapes.push_back(s);
+	w->shapeIndex[bytes] = idx;
+	return idx;
+}
+
+// Host evaluation of shape AABB / mass uses the same header the kernels use (b2d_collide.h), built
+// for the host by hipcc; host libm sinf/cosf == b2dSin/b2dCos bit for bit (see b2d_math.h).
+static Xf hostXf(const HostBody& b)
+{
+	Xf xf;
+	xf.p = v2(b.px, b.py);
+	xf.q.s = b.qs;
+	xf.q.c = b.qc;
+	return xf;
+}
+
+// b2PolygonShape::ComputeMass (b2PolygonShape.cpp:359-440), b2CircleShape::ComputeMass (b2CircleShape.cpp:92-100),
+// b2EdgeShape::ComputeMass (b2EdgeShape.cpp:131-138)
+static void shapeMass(const ShapeRec& s, float density, float* massOut, V2* centerOut, float* IOut)
+{
+	if (s.type == B2D_SHAPE_CIRCLE)
+	{
+		float mass = density * B2D_PI * s.radius * s.radius;
+		*massOut = mass;
+		*centerOut = s.verts[0];
+		*IOut = mass * (0.5f * s.radius * s.radius + b2dDot(s.verts[0], s.verts[0]));
+		return;
+	}
+	if (s.type == B2D_SHAPE_EDGE)
+	{
+		*massOut = 0.0f;
+		*centerOut = 0.5f * (s.verts[0] + s.verts[1]);
+		*IOut = 0.0f;
+		return;
+	}
+	V2 center = v2(0.0f, 0.0f);
+	float area = 0.0f;
+	float I = 0.0f;
+	V2 sref = v2(0.0f, 0.0f);
+	for (int i = 0; i < s.count; ++i) sref += s.verts[i];
+	sref *= 1.0f / s.count;
+	const float k_inv3 = 1.0f / 3.0f;
+	for (int i = 0; i < s.count; ++i)
+	{
+		V2 e1 = s.verts[i] - sref;
+		V2 e2 = i + 1 < s.count ? s.verts[i + 1] - sref : s.verts[0] - sref;
+		float D = b2dCross(e1, e2);
+		float triangleArea = 0.5f * D;
+		area += triangleArea;
+		center += triangleArea * k_inv3 * (e1 + e2);
+		float ex1 = e1.x, ey1 = e1.y;
+		float ex2 = e2.x, ey2 = e2.y;
+		float intx2 = ex1 * ex1 + ex2 * ex1 + ex2 * ex2;
+		float inty2 = ey1 * ey1 + ey2 * ey1 + ey2 * ey2;
+		I += (0.25f * k_inv3 * D) * (intx2 + inty2);
+	}
+	*massOut = density * area;
+	center *= 1.0f / area;
+	*centerOut = center + sref;
+	float Iout = density * I;
+	Iout += (*massOut) * (b2dDot(*centerOut, *centerOut) - b2dDot(center, center));
+	*IOut = Iout;
+}
+
+// b2Body::ResetMassData (b2Body.cpp:310-385)
+static void resetMassData(b2hip_world* w, HostBody& b)
+{
+	b.mass = 0.0f;
+	b.invMass = 0.0f;
+	b.I = 0.0f;
+	b.invI = 0.0f;
+	b.lcx = b.lcy = 0.0f;
+	if (b.type == B2HIP_STATIC_BODY || b.type == B2HIP_KINEMATIC_BODY)
+	{
+		b.c0x = b.cx = b.px;
+		b.c0y = b.cy = b.py;
+		b.a0 = b.a;
+		return;
+	}
+	V2 localCenter = v2(0.0f, 0.0f);
+	// the reference walks its fixture list newest first
+	for (int k = (int)b.fixtures.size() - 1; k >= 0; --k)
+	{
+		const HostFixture& f = w->fixtures[b.fixtures[k]];
+		if (f.density == 0.0f) continue;
+		float mass, I;
+		V2 center;
+		shapeMass(w->shapes[f.shape], f.density, &mass, &center, &I);
+		b.mass += mass;
+		localCenter += mass * center;
+		b.I += I;
+	}
+	if (b.mass > 0.0f)
+	{
+		b.invMass = 1.0f / b.mass;
+		localCenter *= b.invMass;
+	}
+	else
+	{
+		b.mass = 1.0f;
+		b.invMass = 1.0f;
+	}
+	if (b.I > 0.0f && (b.flags & BF_FIXEDROT) == 0)
+	{
+		b.I -= b.mass * b2dDot(localCenter, localCenter);
+		b.invI = 1.0f / b.I;
+	}
+	else
+	{
+		b.I = 0.0f;
+		b.invI = 0.0f;
+	}
+	V2 oldCenter = v2(b.cx, b.cy);
+	b.lcx = localCenter.x;
+	b.lcy = localCenter.y;
+	V2 c = b2dMulXV(hostXf(b), localCenter);
+	b.c0x = b.cx = c.x;
+	b.c0y = b.cy = c.y;
+	V2 dv = b2dCrossSV(b.w, c - oldCenter);
+	b.vx += dv.x;
+	b.vy += dv.y;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int syncCheck(b2hip_world* w, const char* what)
+{
+	if (!w->debugSync) return 0;
+	hipError_t e = hipStreamSynchronize(w->stream);
+	if (e == hipSuccess) e = hipGetLastError();
+	if (e != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+	return 0;
+}
+
+#define LAUNCH(w, kernel, grid, block, ...)                                                   \
+	do                                                                                        \
+	{                                                                                         \
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__);     \
+		int _rc = syncCheck((w), #kernel);                                                    \
+		if (_rc) return _rc;                                                                  \
+	} while (0)
+
+static int gridFor(size_t n, int block = 256, int maxBlocks = 2048)
+{
+	size_t g = (n + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > (size_t)maxBlocks) g = maxBlocks;
+	return (int)g;
+}
+
+static int readState(b2hip_world* w)
+{
+	HIP_TRY(hipMemcpyAsync(w->h_dstate, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	return 0;
+}
+
+// Size every buffer for the current topology and a contact / pair budget; refresh the kernarg block.
+static int ensureCapacity(b2hip_world* w, size_t needContacts)
+{
+	hipStream_t s = w->stream;
+	const size_t nb = std::max<size_t>(w->bodies.size(), 1);
+	const size_t np = std::max<size_t>(w->fixtures.size(), 1);
+	int rc = 0;
+#define ENS(arr, n) do { rc = w->arr.ensure((n), s); if (rc) return rc; } while (0)
+	ENS(d_state, 1);
+	ENS(b_pos, nb); ENS(b_pos0, nb); ENS(b_vel, nb); ENS(b_xf, nb); ENS(b_mass, nb); ENS(b_damp, nb); ENS(b_force, nb);
+	ENS(b_flags, nb); ENS(b_wake, nb);
+	ENS(p_fat, np); ENS(p_body, np); ENS(p_shape, np); ENS(p_key, np); ENS(p_filter0, np); ENS(p_filter1, np); ENS(p_mat, np);
+	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
+	ENS(d_joints, std::max<size_t>(w->joints.size(), 1));
+	const size_t capPairs = std::max<size_t>(8 * np + 4096, w->pairKey.cap);
+	const size_t capContacts = std::max<size_t>(needContacts + capPairs, 1024);
+	for (int k = 0; k < 2; ++k)
+	{
+		ENS(c_ids[k], capContacts); ENS(c_key[k], capContacts); ENS(c_flags[k], capContacts); ENS(c_mat[k], capContacts);
+		ENS(c_man0[k], capContacts); ENS(c_man1[k], capContacts); ENS(c_imp[k], capContacts); ENS(c_man3[k], capContacts);
+	}
+	const size_t cc = w->c_ids[0].cap; // actual (power of two) capacity
+	// hash set: at most 50 % load
+	{
+		size_t want = (size_t)nextPow2(2 * cc);
+		if (w->ht_keys.cap < want)
+		{
+			rc = w->ht_keys.ensure(want, s, false);
+			if (rc) return rc;
+		}
+	}
+	ENS(parent, nb); ENS(rootSeed, nb); ENS(rootBodies, nb); ENS(rootContacts, nb); ENS(rootJoints, nb); ENS(rootIsland, nb);
+	ENS(deg, nb + 1); ENS(adjStart, nb + 2); ENS(adjCursor, nb); ENS(adj, 2 * cc);
+	ENS(rootScanIn, nb + 1); ENS(rootScanOut, nb + 2);
+	ENS(si_root, nb + 1); ENS(si_bodyStart, nb + 2); ENS(si_contactStart, nb + 2); ENS(si_wStart, nb + 2); ENS(si_maxLevel, nb + 1);
+	ENS(si_bodies, nb); ENS(si_contacts, cc); ENS(si_level, cc); ENS(si_stack, nb); ENS(si_lastLevel, nb);
+	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / SMALL_ISLAND_MAX_W + 4);
+	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
+	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	if (w->lc.cap < (size_t)LC_WORDS * cc)
+	{
+		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
+		if (rc) return rc;
+	}
+	ENS(moveBuf, 2 * np + 64);
+	const size_t gridSize = (size_t)nextPow2(2 * np);
+	ENS(gridCount, gridSize); ENS(gridStart, gridSize + 2); ENS(gridCursor, gridSize); ENS(gridItems, np); ENS(largeProxies, np);
+	ENS(pairKey, capPairs); ENS(pairKey2, capPairs); ENS(pairProxy, capPairs); ENS(pairProxy2, capPairs);
+	ENS(pairFirst, capPairs + 1); ENS(pairRank, capPairs + 2);
+	const size_t maxScanN = std::max(std::max(nb + 2, gridSize + 2), std::max(cc + 2, capPairs + 2));
+	const size_t radixTiles = capPairs / RADIX_TILE + 2;
+	ENS(radixHist, 256 * radixTiles + 2); ENS(radixHistScan, 256 * radixTiles + 4);
+	ENS(scanTmp, std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 4);
+	ENS(scanTmp4, maxScanN / SCAN_TILE + 4);
+	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
+	ENS(stateOut, 12 * nb);
+	ENS(consts, 16);
+#undef ENS
+	if (w->h_stateCap < 12 * nb)
+	{
+		if (w->h_state) (void)hipHostFree(w->h_state);
+		w->h_stateCap = 12 * nb * 2;
+		HIP_TRY(hipHostMalloc((void**)&w->h_state, w->h_stateCap * sizeof(float), hipHostMallocDefault));
+	}
+
+	DW& d = w->dw;
+	d.st = w->d_state.p;
+	d.nBodies = (int)w->bodies.size();
+	d.nProxies = (int)w->fixtures.size();
+	d.nJoints = (int)w->joints.size();
+	d.nShapes = (int)w->shapes.size();
+	d.capContacts = (int)cc;
+	d.capPairs = (int)w->pairKey.cap;
+	d.capMoves = (int)w->moveBuf.cap;
+	d.htMask = (uint32_t)(w->ht_keys.cap - 1);
+	d.gridMask = (uint32_t)(gridSize - 1);
+	d.b_pos = w->b_pos.p; d.b_pos0 = w->b_pos0.p; d.b_vel = w->b_vel.p; d.b_xf = w->b_xf.p; d.b_mass = w->b_mass.p;
+	d.b_damp = w->b_damp.p; d.b_force = w->b_force.p; d.b_flags = w->b_flags.p; d.b_wake = w->b_wake.p;
+	d.p_fat = w->p_fat.p; d.p_body = w->p_body.p; d.p_shape = w->p_shape.p; d.p_key = w->p_key.p;
+	d.p_filter0 = w->p_filter0.p; d.p_filter1 = w->p_filter1.p; d.p_mat = w->p_mat.p; d.shapes = w->d_shapes.p;
+	for (int k = 0; k < 2; ++k)
+	{
+		d.ca[k].ids = w->c_ids[k].p; d.ca[k].key = w->c_key[k].p; d.ca[k].flags = w->c_flags[k].p; d.ca[k].mat = w->c_mat[k].p;
+		d.ca[k].man0 = w->c_man0[k].p; d.ca[k].man1 = w->c_man1[k].p; d.ca[k].imp = w->c_imp[k].p; d.ca[k].man3 = w->c_man3[k].p;
+	}
+	d.ht_keys = w->ht_keys.p;
+	d.joints = w->d_joints.p;
+	d.parent = w->parent.p; d.rootSeed = w->rootSeed.p; d.rootBodies = w->rootBodies.p; d.rootContacts = w->rootContacts.p;
+	d.rootJoints = w->rootJoints.p; d.rootScanIn = w->rootScanIn.p; d.rootScanOut = w->rootScanOut.p; d.rootIsland = w->rootIsland.p;
+	d.deg = w->deg.p; d.adjStart = w->adjStart.p; d.adjCursor = w->adjCursor.p; d.adj = w->adj.p;
+	d.si_root = w->si_root.p; d.si_bodyStart = w->si_bodyStart.p; d.si_contactStart = w->si_contactStart.p; d.si_wStart = w->si_wStart.p;
+	d.si_maxLevel = w->si_maxLevel.p; d.si_bodies = w->si_bodies.p; d.si_contacts = w->si_contacts.p; d.si_level = w->si_level.p;
+	d.si_stack = w->si_stack.p; d.si_lastLevel = w->si_lastLevel.p; d.b_slot = w->b_slot.p; d.b_island = w->b_island.p;
+	d.chunkFirst = w->chunkFirst.p;
+	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
+	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
+	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
+	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
+	d.pairKey = w->pairKey.p; d.pairProxy = w->pairProxy.p; d.pairKey2 = w->pairKey2.p; d.pairProxy2 = w->pairProxy2.p;
+	d.pairFirst = w->pairFirst.p; d.pairRank = w->pairRank.p;
+	d.scanTmp = w->scanTmp.p; d.radixHist = w->radixHist.p; d.keepFlag = w->keepFlag.p; d.keepScan = w->keepScan.p;
+	d.stateOut = w->stateOut.p;
+	return 0;
+}
+
+// Upload bodies / fixtures / shapes / joints created or edited since the last step.
+static int flushEdits(b2hip_world* w)
+{
+	hipStream_t s = w->stream;
+	int rc = ensureCapacity(w, (size_t)w->lastContacts);
+	if (rc) return rc;
+
+	// ---- bodies: every dirty body gets all its rows rewritten from the host mirror ---------------
+	const size_t nb = w->bodies.size();
+	size_t i = 0;
+	std::vector<float4> pos, pos0, vel, xf, mass, damp, force;
+	std::vector<uint32_t> flags;
+	while (i < nb)
+	{
+		if (!w->bodies[i].dirty) { ++i; continue; }
+		size_t j = i;
+		pos.clear(); pos0.clear(); vel.clear(); xf.clear(); mass.clear(); damp.clear(); force.clear(); flags.clear();
+		while (j < nb && w->bodies[j].dirty)
+		{
+			HostBody& b = w->bodies[j];
+			pos.push_back(make_float4(b.cx, b.cy, b.a, b.sleepTime));
+			pos0.push_back(make_float4(b.c0x, b.c0y, b.a0, 0.0f));
+			vel.push_back(make_float4(b.vx, b.vy, b.w, 0.0f));
+			xf.push_back(make_float4(b.px, b.py, b.qs, b.qc));
+			mass.push_back(make_float4(b.invMass, b.invI, b.lcx, b.lcy));
+			damp.push_back(make_float4(b.linearDamping, b.angularDamping, b.gravityScale, 0.0f));
+			force.push_back(make_float4(b.fx, b.fy, b.torque, 0.0f));
+			flags.push_back((b.flags & ~BF_TYPE_MASK) | (uint32_t)b.type);
+			b.dirty = false;
+			++j;
+		}
+		const size_t cnt = j - i;
+		HIP_TRY(hipMemcpyAsync(w->b_pos.p + i, pos.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->b_pos0.p + i, pos0.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->b_vel.p + i, vel.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->b_xf.p + i, xf.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->b_mass.p + i, mass.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->b_damp.p + i, damp.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->b_force.p + i, force.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->b_flags.p + i, flags.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s)); // staging vectors are reused
+		i = j;
+	}
+	w->upBodies = nb;
+
+	// ---- shapes / joints: small tables, rewritten whole when they grew -----------------------------
+	if (w->upShapes != w->shapes.size())
+	{
+		HIP_TRY(hipMemcpyAsync(w->d_shapes.p, w->shapes.data(), w->shapes.size() * sizeof(ShapeRec), hipMemcpyHostToDevice, s));
+		w->upShapes = w->shapes.size();
+	}
+	if (w->upJoints != w->joints.size())
+	{
+		HIP_TRY(hipMemcpyAsync(w->d_joints.p, w->joints.data(), w->joints.size() * sizeof(RevoluteJoint), hipMemcpyHostToDevice, s));
+		w->upJoints = w->joints.size();
+	}
+
+	// ---- new proxies -----------------------------------------------------------------------------
+	const size_t np = w->fixtures.size();
+	if (w->upFixtures < np)
+	{
+		const size_t first = w->upFixtures, cnt = np - first;
+		std::vector<float4> fat(cnt);
+		std::vector<int> body(cnt), shape(cnt), key(cnt), f1(cnt);
+		std::vector<uint32_t> f0(cnt);
+		std::vector<float2> mat(cnt);
+		for (size_t k = 0; k < cnt; ++k)
+		{
+			const HostFixture& f = w->fixtures[first + k];
+			fat[k] = make_float4(f.fat[0], f.fat[1], f.fat[2], f.fat[3]);
+			body[k] = f.body;
+			shape[k] = f.shape;
+			key[k] = f.proxyKey;
+			f0[k] = (uint32_t)f.categoryBits | ((uint32_t)f.maskBits << 16);
+			f1[k] = ((int)(uint16_t)f.groupIndex) | (f.isSensor ? PF_SENSOR : 0) | (f.thick ? PF_THICK : 0);
+			mat[k] = make_float2(f.friction, f.restitution);
+		}
+		HIP_TRY(hipMemcpyAsync(w->p_fat.p + first, fat.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_body.p + first, body.data(), cnt * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_shape.p + first, shape.data(), cnt * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_key.p + first, key.data(), cnt * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_filter0.p + first, f0.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_filter1.p + first, f1.data(), cnt * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_mat.p + first, mat.data(), cnt * sizeof(float2), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		w->upFixtures = np;
+
+		// Broad-phase cell: 1.5 x the largest fat extent among non-static proxies, ignoring outliers
+		// (> 8 x median), which are handled by the brute-force "large proxy" path.
+		std::vector<float> ext;
+		for (size_t k = 0; k < np; ++k)
+		{
+			const HostFixture& f = w->fixtures[k];
+			if (w->bodies[f.body].type == B2HIP_STATIC_BODY) continue;
+			ext.push_back(std::max(f.fat[2] - f.fat[0], f.fat[3] - f.fat[1]));
+		}
+		float cell = 1.0f;
+		if (!ext.empty())
+		{
+			std::sort(ext.begin(), ext.end());
+			float median = ext[ext.size() / 2];
+			float mx = median;
+			for (size_t k = 0; k < ext.size(); ++k)
+			{
+				if (ext[k] <= 8.0f * median) mx = std::max(mx, ext[k]);
+			}
+			cell = 1.5f * mx;
+		}
+		w->dw.cellSize = cell;
+		w->dw.invCellSize = 1.0f / cell;
+	}
+
+	// ---- move buffer: proxies created since the last step (b2BroadPhase::CreateProxy buffers a move)
+	if (!w->pendingMoves.empty())
+	{
+		rc = readState(w);
+		if (rc) return rc;
+		int have = w->h_dstate->c.nMoves;
+		HIP_TRY(hipMemcpyAsync(w->moveBuf.p + have, w->pendingMoves.data(), w->pendingMoves.size() * sizeof(int), hipMemcpyHostToDevice, s));
+		int total = have + (int)w->pendingMoves.size();
+		HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.nMoves, &total, sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		w->pendingMoves.clear();
+	}
+	int consts[4] = { (int)w->bodies.size(), (int)(w->dw.gridMask + 1), 0, 0 };
+	HIP_TRY(hipMemcpyAsync(w->consts.p, consts, sizeof(int) * 2, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phases
+// ------------------------------------------------------------------------------------------------
+static int radixBits(int maxKey)
+{
+	int bits = 1;
+	while ((1 << bits) <= maxKey && bits < 31) ++bits;
+	return bits;
+}
+
+// b2World::FindNewContacts. `sync` = the host may block on the pair count to pick the sort path
+// (top-of-step call after fixtures were added); otherwise the small path runs optimistically and
+// the caller checks Counters::nPairs at the end-of-step read-back.
+static int runSortAndCreate(b2hip_world* w, bool largePath)
+{
+	DW& d = w->dw;
+	const uint64_t* sortedKeys = d.pairKey;
+	const int2* sortedProxies = d.pairProxy;
+	if (largePath)
+	{
+		// LSD radix sort on the two key halves
+		int bits = radixBits(w->nextNode + 1);
+		std::vector<int> shifts;
+		for (int sft = 0; sft < bits; sft += 8) shifts.push_back(sft);
+		for (int sft = 0; sft < bits; sft += 8) shifts.push_back(32 + sft);
+		uint64_t* kin = d.pairKey;
+		uint64_t* kout = d.pairKey2;
+		int2* vin = d.pairProxy;
+		int2* vout = d.pairProxy2;
+		const int tilesCap = d.capPairs / RADIX_TILE + 1;
+		for (size_t p = 0; p < shifts.size(); ++p)
+		{
+			LAUNCH(w, k_radix_count, 1, 1, &d.st->c.nPairs, 0, w->consts.p + 2);
+			LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, &d.st->c.nPairs, 0, shifts[p], tilesCap);
+			deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->consts.p + 2, 256 * tilesCap);
+			LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, &d.st->c.nPairs, 0, shifts[p]);
+			std::swap(kin, kout);
+			std::swap(vin, vout);
+		}
+		sortedKeys = kin;
+		sortedProxies = vin;
+		LAUNCH(w, k_pairs_sorted_first, gridFor(d.capPairs), 256, d, sortedKeys, w->consts.p + 3);
+		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->consts.p + 3, d.capPairs);
+		LAUNCH(w, k_pairs_sorted_total, 1, 1, d, w->consts.p + 3);
+	}
+	else
+	{
+		LAUNCH(w, k_pairs_first, 16, 256, d);
+		LAUNCH(w, k_pairs_rank, 16, 256, d);
+	}
+	const int smallPath = largePath ? 0 : 1;
+	LAUNCH(w, k_create_contacts, gridFor(largePath ? d.capPairs : COUNT_RANK_MAX), 256, d, sortedKeys, sortedProxies, smallPath);
+	LAUNCH(w, k_create_finish, gridFor(d.nBodies), 256, d, smallPath);
+	LAUNCH(w, k_create_commit, 1, 1, d, smallPath);
+	return 0;
+}
+
+static int findNewContacts(b2hip_world* w, bool sync)
+{
+	DW& d = w->dw;
+	LAUNCH(w, k_ht_clear, gridFor(d.htMask + 1), 256, d);
+	LAUNCH(w, k_ht_build, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d);
+	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d);
+	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
+	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d);
+	LAUNCH(w, k_find_pairs_small, gridFor(d.capMoves, 256, 4096), 256, d);
+	LAUNCH(w, k_find_pairs_large, 1024, 256, d);
+	bool large = false;
+	if (sync)
+	{
+		int rc = readState(w);
+		if (rc) return rc;
+		if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+		if (w->h_dstate->c.nMoves == 0) return 0;
+		large = w->h_dstate->c.nPairs > COUNT_RANK_MAX;
+	}
+	return runSortAndCreate(w, large);
+}
+
+static int phaseCollide(b2hip_world* w)
+{
+	DW& d = w->dw;
+	LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
+	deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+	LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_compact_finish, 1, 1, d);
+	return 0;
+}
+
+static int phaseSolve(b2hip_world* w)
+{
+	DW& d = w->dw;
+	const StepParams& sp = w->sp;
+	LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
+	LAUNCH(w, k_island_union, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
+	LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, w->forceLarge);
+	{
+		int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
+		if (blocks < 1) blocks = 1;
+		hipLaunchKernelGGL(k_scan_reduce<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, w->scanTmp4.p, w->consts.p);
+		hipLaunchKernelGGL(k_scan_blocksums<int4>, dim3(1), dim3(SCAN_THREADS), 0, w->stream, w->scanTmp4.p, w->consts.p, (int4*)nullptr);
+		hipLaunchKernelGGL(k_scan_final<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->consts.p);
+	}
+	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p, d.nBodies);
+	LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
+	LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
+
+	// the host needs the island census to size the solver launches
+	int rc = readState(w);
+	if (rc) return rc;
+	const Counters c = w->h_dstate->c;
+
+	HIP_TRY(hipEventRecord(w->ev[4], w->stream));
+	const bool exactLarge = w->forceLarge == 2;
+	if (c.nSIslands > 0)
+	{
+		LAUNCH(w, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
+		LAUNCH(w, k_island_chunks, gridFor(c.nSIslands), 256, d);
+		HIP_TRY(hipEventRecord(w->ev[5], w->stream));
+		if (!exactLarge) LAUNCH(w, k_solve_small, c.nChunks, SMALL_CHUNK_LANES, d, sp);
+		HIP_TRY(hipEventRecord(w->ev[6], w->stream));
+	}
+	else
+	{
+		HIP_TRY(hipEventRecord(w->ev[5], w->stream));
+		HIP_TRY(hipEventRecord(w->ev[6], w->stream));
+	}
+	int nColors = 0;
+	int nLIslands = c.nLIslands, nLBodies = c.nLBodies, nLContacts = c.nLContacts;
+	if (exactLarge && c.nSIslands > 0)
+	{
+		// exact-order mode: colours := dependency levels of the reference's own constraint order
+		LAUNCH(w, k_exact_begin, gridFor(c.nSContacts + 1), 256, d);
+		LAUNCH(w, k_exact_convert, gridFor(std::max(c.nSContacts, c.nSBodies)), 256, d);
+		rc = readState(w);
+		if (rc) return rc;
+		nColors = w->h_dstate->c.nColors;
+		nLIslands = c.nSIslands;
+		nLBodies = c.nSBodies;
+		nLContacts = c.nSContacts;
+	}
+	if (nLIslands > 0)
+	{
+		const int gB = gridFor(nLBodies), gC = gridFor(std::max(nLContacts, 1));
+		if (!exactLarge)
+		{
+			LAUNCH(w, k_color_begin, gC, 256, d);
+			int uncolored = nLContacts;
+			while (uncolored > 0)
+			{
+				for (int r = 0; r < 8; ++r)
+				{
+					LAUNCH(w, k_color_claim, gC, 256, d);
+					LAUNCH(w, k_color_resolve, gC, 256, d);
+				}
+				rc = readState(w);
+				if (rc) return rc;
+				uncolored = w->h_dstate->c.nUncolored;
+				nColors = w->h_dstate->c.nColors;
+				if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
+			}
+		}
+		LAUNCH(w, k_color_scan, 1, 1, d);
+		LAUNCH(w, k_color_fill, gC, 256, d);
+		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
+		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
+		LAUNCH(w, k_large_integrate, gB, 256, d, sp);
+		LAUNCH(w, k_large_init, gC, 256, d, sp);
+		if (sp.warmStarting)
+		{
+			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
+		}
+		for (int it = 0; it < sp.velIters; ++it)
+		{
+			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_velocity, gK, 256, d, col, 1);
+		}
+		LAUNCH(w, k_large_store_impulses, gC, 256, d);
+		LAUNCH(w, k_large_integrate_positions, gB, 256, d, sp);
+		for (int it = 0; it < sp.posIters; ++it)
+		{
+			LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
+			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_position, gK, 256, d, col);
+			LAUNCH(w, k_large_pos_end, 1, 256, d);
+		}
+		LAUNCH(w, k_large_finalize, gB, 256, d, sp);
+		LAUNCH(w, k_large_sleep, gB, 256, d, sp);
+		HIP_TRY(hipEventRecord(w->ev[8], w->stream));
+	}
+	else
+	{
+		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
+		HIP_TRY(hipEventRecord(w->ev[8], w->stream));
+	}
+	w->last.nSIslands = c.nSIslands;
+	w->last.nSBodies = c.nSBodies;
+	w->last.nSContacts = c.nSContacts;
+	w->last.nChunks = c.nChunks;
+	w->last.nLIslands = nLIslands;
+	w->last.nLBodies = nLBodies;
+	w->last.nLContacts = nLContacts;
+	w->last.nIslands = c.nIslands;
+	w->last.nColors = nColors;
+	w->last.nTouching = c.nTouching;
+	w->last.nDestroy = c.nDestroy;
+	return 0;
+}
+
+static int phaseSyncFixtures(b2hip_world* w)
+{
+	DW& d = w->dw;
+	LAUNCH(w, k_sync_fixtures, gridFor(d.nProxies), 256, d);
+	return 0;
+}
+
+static int downloadState(b2hip_world* w)
+{
+	DW& d = w->dw;
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, w->def.auto_clear_forces);
+	const size_t nb = w->bodies.size();
+	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipMemcpyAsync(w->h_dstate, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	return 0;
+}
+
+static void refreshMirror(b2hip_world* w)
+{
+	const size_t nb = w->bodies.size();
+	for (size_t i = 0; i < nb; ++i)
+	{
+		HostBody& b = w->bodies[i];
+		const float* o = w->h_state + 10 * i;
+		b.px = o[0]; b.py = o[1]; b.a = o[2];
+		b.vx = o[3]; b.vy = o[4]; b.w = o[5];
+		b.cx = o[6]; b.cy = o[7];
+		uint32_t f;
+		memcpy(&f, o + 8, 4);
+		b.flags = (b.flags & ~0x7fu) | (f & 0x7fu);
+		b.sleepTime = o[9];
+		b.c0x = b.cx; b.c0y = b.cy; b.a0 = b.a;
+		if (w->def.auto_clear_forces) { b.fx = b.fy = b.torque = 0.0f; }
+	}
+}
+
+extern "C"
+{
+
+const char* b2hip_last_error(void)
+{
+	return g_lastError.c_str();
+}
+
+const char* b2hip_version(void)
+{
+	return "b2hip 0.1 (gfx950)";
+}
+
+int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
+{
+	if (!def || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0)
+	{
+		return setError(B2HIP_ERR_NO_DEVICE, "no HIP device available: the b2hip Step() path has no CPU fallback");
+	}
+	b2hip_world* w = new b2hip_world();
+	w->def = *def;
+	w->device = def->device;
+	if (w->device >= 0)
+	{
+		e = hipSetDevice(w->device);
+		if (e != hipSuccess)
+		{
+			delete w;
+			return setError(B2HIP_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+		}
+	}
+	e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+	if (e != hipSuccess)
+	{
+		delete w;
+		return setError(B2HIP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+	}
+	w->debugSync = getenv("B2HIP_DEBUG") != nullptr;
+	w->forceLarge = getenv("B2HIP_FORCE_LARGE") ? atoi(getenv("B2HIP_FORCE_LARGE")) : 0;
+	w->nextNode = 0;
+	w->leafCount = 0;
+	w->upBodies = w->upFixtures = w->upShapes = w->upJoints = 0;
+	w->newFixture = false;
+	w->inv_dt0 = 0.0f;
+	w->stepActive = false;
+	w->h_state = nullptr;
+	w->h_stateCap = 0;
+	w->lastContacts = 0;
+	memset(&w->last, 0, sizeof(w->last));
+	memset(&w->dw, 0, sizeof(w->dw));
+	memset(w->profile, 0, sizeof(w->profile));
+	w->solverMs = 0.0f;
+	w->solverBytes = 0.0;
+	w->solverConstraints = w->solverBodies = 0;
+	w->dw.cellSize = 1.0f;
+	w->dw.invCellSize = 1.0f;
+	for (int i = 0; i < 12; ++i)
+	{
+		if (hipEventCreate(&w->ev[i]) != hipSuccess)
+		{
+			return setError(B2HIP_ERR_HIP, "hipEventCreate failed");
+		}
+	}
+	if (hipHostMalloc((void**)&w->h_dstate, sizeof(DState), hipHostMallocDefault) != hipSuccess)
+	{
+		return setError(B2HIP_ERR_HIP, "hipHostMalloc failed");
+	}
+	int rc = ensureCapacity(w, 0);
+	if (rc)
+	{
+		return rc;
+	}
+	if (hipStreamSynchronize(w->stream) != hipSuccess) return setError(B2HIP_ERR_HIP, "stream sync failed");
+	*out = w;
+	return B2HIP_OK;
+}
+
+void b2hip_world_destroy(b2hip_world* w)
+{
+	if (!w) return;
+	(void)hipStreamSynchronize(w->stream);
+	w->d_state.release();
+	w->b_pos.release(); w->b_pos0.release(); w->b_vel.release(); w->b_xf.release(); w->b_mass.release(); w->b_damp.release();
+	w->b_force.release(); w->b_flags.release(); w->b_wake.release();
+	w->p_fat.release(); w->p_body.release(); w->p_shape.release(); w->p_key.release(); w->p_filter0.release(); w->p_filter1.release();
+	w->p_mat.release(); w->d_shapes.release();
+	for (int k = 0; k < 2; ++k)
+	{
+		w->c_ids[k].release(); w->c_key[k].release(); w->c_flags[k].release(); w->c_mat[k].release(); w->c_man0[k].release();
+		w->c_man1[k].release(); w->c_imp[k].release(); w->c_man3[k].release();
+	}
+	w->ht_keys.release(); w->d_joints.release();
+	w->parent.release(); w->rootSeed.release(); w->rootBodies.release(); w->rootContacts.release(); w->rootJoints.release();
+	w->rootIsland.release(); w->deg.release(); w->adjStart.release(); w->adjCursor.release(); w->adj.release();
+	w->rootScanIn.release(); w->rootScanOut.release();
+	w->si_root.release(); w->si_bodyStart.release(); w->si_contactStart.release(); w->si_wStart.release(); w->si_maxLevel.release();
+	w->si_bodies.release(); w->si_contacts.release(); w->si_level.release(); w->si_stack.release(); w->si_lastLevel.release();
+	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
+	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
+	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
+	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
+	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
+	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
+	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
+	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->stateOut.release(); w->consts.release();
+	if (w->h_state) (void)hipHostFree(w->h_state);
+	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
+	for (int i = 0; i < 12; ++i) (void)hipEventDestroy(w->ev[i]);
+	(void)hipStreamDestroy(w->stream);
+	delete w;
+}
+
+int b2hip_set_gravity(b2hip_world* w, float gx, float gy)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	w->def.gravity_x = gx;
+	w->def.gravity_y = gy;
+	return 0;
+}
+
+int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int continuous, int sub_stepping)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	w->def.allow_sleep = allow_sleep;
+	w->def.warm_starting = warm_starting;
+	w->def.continuous = continuous;
+	w->def.sub_stepping = sub_stepping;
+	return 0;
+}
+
+int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def)
+{
+	if (!w || !def) return setError(B2HIP_ERR_INVALID, "null argument");
+	HostBody b{};
+	b.type = def->type;
+	b.flags = 0;
+	if (def->bullet) b.flags |= BF_BULLET;
+	if (def->fixed_rotation) b.flags |= BF_FIXEDROT;
+	if (def->allow_sleep) b.flags |= BF_AUTOSLEEP;
+	if (def->awake) b.flags |= BF_AWAKE;
+	if (def->active) b.flags |= BF_ACTIVE;
+	b.px = def->px;
+	b.py = def->py;
+	b.qs = sinf(def->angle); // b2Rot::Set (b2Math.h:294-299)
+	b.qc = cosf(def->angle);
+	b.lcx = b.lcy = 0.0f;
+	b.c0x = b.cx = def->px;
+	b.c0y = b.cy = def->py;
+	b.a0 = b.a = def->angle;
+	b.vx = def->vx;
+	b.vy = def->vy;
+	b.w = def->w;
+	b.linearDamping = def->linear_damping;
+	b.angularDamping = def->angular_damping;
+	b.gravityScale = def->gravity_scale;
+	b.fx = b.fy = b.torque = 0.0f;
+	b.sleepTime = 0.0f;
+	if (def->type == B2HIP_DYNAMIC_BODY)
+	{
+		b.mass = 1.0f;
+		b.invMass = 1.0f;
+	}
+	else
+	{
+		b.mass = 0.0f;
+		b.invMass = 0.0f;
+	}
+	b.I = 0.0f;
+	b.invI = 0.0f;
+	b.dirty = true;
+	w->bodies.push_back(b);
+	return (int)w->bodies.size() - 1;
+}
+
+int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def, const b2hip_shape* shape)
+{
+	if (!w || !def || !shape) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad body id");
+	if (shape->type != B2HIP_SHAPE_CIRCLE && shape->type != B2HIP_SHAPE_EDGE && shape->type != B2HIP_SHAPE_POLYGON)
+	{
+		return setError(B2HIP_ERR_UNSUPPORTED, "shape type is not on the device path (chain shapes)");
+	}
+	ShapeRec rec;
+	memset(&rec, 0, sizeof(rec));
+	rec.type = shape->type;
+	rec.count = shape->count;
+	rec.radius = shape->radius;
+	rec.centroid = v2(shape->centroid[0], shape->centroid[1]);
+	int nv = shape->type == B2HIP_SHAPE_POLYGON ? shape->count : (shape->type == B2HIP_SHAPE_EDGE ? 4 : 1);
+	if (nv > B2D_MAX_POLY_VERTS) return setError(B2HIP_ERR_INVALID, "too many polygon vertices");
+	for (int i = 0; i < nv; ++i)
+	{
+		rec.verts[i] = v2(shape->verts[2 * i], shape->verts[2 * i + 1]);
+		if (shape->type == B2HIP_SHAPE_POLYGON) rec.normals[i] = v2(shape->normals[2 * i], shape->normals[2 * i + 1]);
+	}
+	HostBody& b = w->bodies[body];
+	HostFixture f;
+	f.body = body;
+	f.shape = internShape(w, rec);
+	f.density = def->density;
+	f.friction = def->friction;
+	f.restitution = def->restitution;
+	f.categoryBits = def->category_bits;
+	f.maskBits = def->mask_bits;
+	f.groupIndex = def->group_index;
+	f.isSensor = def->is_sensor != 0;
+	f.thick = def->thick_shape != 0;
+	// b2Fixture::CreateProxies (b2Fixture.cpp:126-141) + b2DynamicTree::CreateProxy (b2DynamicTree.cpp:105-119)
+	AABB aabb = b2dShapeAABB(&rec, hostXf(b));
+	f.fat[0] = aabb.lo.x - B2D_AABB_EXTENSION;
+	f.fat[1] = aabb.lo.y - B2D_AABB_EXTENSION;
+	f.fat[2] = aabb.hi.x + B2D_AABB_EXTENSION;
+	f.fat[3] = aabb.hi.y + B2D_AABB_EXTENSION;
+	f.proxyKey = allocProxyKey(w);
+	const int id = (int)w->fixtures.size();
+	w->fixtures.push_back(f);
+	b.fixtures.push_back(id);
+	w->pendingMoves.push_back(id);
+	if (f.density > 0.0f)
+	{
+		resetMassData(w, b);
+	}
+	b.dirty = true;
+	w->newFixture = true;
+	return id;
+}
+
+int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* def)
+{
+	if (!w || !def) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int nb = (int)w->bodies.size();
+	if (def->body_a < 0 || def->body_a >= nb || def->body_b < 0 || def->body_b >= nb) return setError(B2HIP_ERR_INVALID, "bad body id");
+	RevoluteJoint j;
+	memset(&j, 0, sizeof(j));
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.referenceAngle = def->reference_angle;
+	j.enableLimit = def->enable_limit;
+	j.lowerAngle = def->lower_angle;
+	j.upperAngle = def->upper_angle;
+	j.enableMotor = def->enable_motor;
+	j.motorSpeed = def->motor_speed;
+	j.maxMotorTorque = def->max_motor_torque;
+	j.collideConnected = def->collide_connected;
+	w->joints.push_back(j);
+	return (int)w->joints.size() - 1;
+}
+
+int b2hip_body_count(const b2hip_world* w)
+{
+	return w ? (int)w->bodies.size() : 0;
+}
+
+int b2hip_fixture_count(const b2hip_world* w)
+{
+	return w ? (int)w->fixtures.size() : 0;
+}
+
+int b2hip_get_mass_data(const b2hip_world* w, int body, b2hip_mass_data* out)
+{
+	if (!w || !out || body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad argument");
+	const HostBody& b = w->bodies[body];
+	out->mass = b.mass;
+	// b2Body::GetInertia (b2Body.h:585-588)
+	out->inertia = b.I + b.mass * (b.lcx * b.lcx + b.lcy * b.lcy);
+	out->local_center[0] = b.lcx;
+	out->local_center[1] = b.lcy;
+	out->inv_mass = b.invMass;
+	out->inv_inertia = b.invI;
+	return 0;
+}
+
+int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque, int wake)
+{
+	if (!w || body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad argument");
+	HostBody& b = w->bodies[body];
+	if (b.type != B2HIP_DYNAMIC_BODY) return 0;
+	if (wake && (b.flags & BF_AWAKE) == 0)
+	{
+		b.flags |= BF_AWAKE;
+		b.sleepTime = 0.0f;
+	}
+	if (b.flags & BF_AWAKE)
+	{
+		b.fx += fx;
+		b.fy += fy;
+		b.torque += torque;
+	}
+	b.dirty = true;
+	return 0;
+}
+
+int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega)
+{
+	if (!w || body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad argument");
+	HostBody& b = w->bodies[body];
+	if (b.type == B2HIP_STATIC_BODY) return 0;
+	if (vx * vx + vy * vy > 0.0f || omega * omega > 0.0f)
+	{
+		b.flags |= BF_AWAKE;
+		b.sleepTime = 0.0f;
+	}
+	b.vx = vx;
+	b.vy = vy;
+	b.w = omega;
+	b.dirty = true;
+	return 0;
+}
+
+int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	int rc = flushEdits(w);
+	if (rc) return rc;
+	StepParams& sp = w->sp;
+	sp.dt = dt;
+	sp.inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
+	sp.dtRatio = w->inv_dt0 * dt;
+	sp.velIters = velocity_iterations;
+	sp.posIters = position_iterations;
+	sp.warmStarting = w->def.warm_starting;
+	sp.allowSleep = w->def.allow_sleep;
+	sp.gravity = v2(w->def.gravity_x, w->def.gravity_y);
+	w->stepActive = true;
+	// zero the per-step counters (keep nContacts / nMoves / cur)
+	Counters zero;
+	memset(&zero, 0, sizeof(zero));
+	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nDestroy, 0, sizeof(int) * 2, w->stream));
+	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nPairs, 0, sizeof(int) * 2, w->stream));
+	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
+	// b2World.cpp:1628-1639: new fixtures -> find their contacts before colliding
+	if (w->newFixture)
+	{
+		rc = findNewContacts(w, true);
+		if (rc) return rc;
+		w->newFixture = false;
+	}
+	HIP_TRY(hipEventRecord(w->ev[1], w->stream));
+	return 0;
+}
+
+int b2hip_collide(b2hip_world* w)
+{
+	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_collide outside a step");
+	int rc = phaseCollide(w);
+	if (rc) return rc;
+	HIP_TRY(hipEventRecord(w->ev[2], w->stream));
+	return 0;
+}
+
+int b2hip_solve(b2hip_world* w)
+{
+	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve outside a step");
+	if (w->sp.dt > 0.0f)
+	{
+		int rc = phaseSolve(w);
+		if (rc) return rc;
+	}
+	else
+	{
+		for (int k = 4; k <= 8; ++k) HIP_TRY(hipEventRecord(w->ev[k], w->stream));
+	}
+	HIP_TRY(hipEventRecord(w->ev[3], w->stream));
+	return 0;
+}
+
+int b2hip_sync_fixtures(b2hip_world* w)
+{
+	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_sync_fixtures outside a step");
+	if (w->sp.dt > 0.0f)
+	{
+		int rc = phaseSyncFixtures(w);
+		if (rc) return rc;
+	}
+	HIP_TRY(hipEventRecord(w->ev[9], w->stream));
+	return 0;
+}
+
+int b2hip_find_new_contacts(b2hip_world* w)
+{
+	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_find_new_contacts outside a step");
+	if (w->sp.dt > 0.0f)
+	{
+		int rc = findNewContacts(w, false);
+		if (rc) return rc;
+	}
+	HIP_TRY(hipEventRecord(w->ev[10], w->stream));
+	return 0;
+}
+
+int b2hip_step_end(b2hip_world* w)
+{
+	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_end outside a step");
+	int rc = downloadState(w);
+	if (rc) return rc;
+	// optimistic small-sort path overflowed: finish the pair update with the radix path, then read back again
+	if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+	if (w->h_dstate->c.nMoves != 0 && w->sp.dt > 0.0f)
+	{
+		if (w->h_dstate->c.nPairs > COUNT_RANK_MAX)
+		{
+			rc = runSortAndCreate(w, true);
+			if (rc) return rc;
+			rc = downloadState(w);
+			if (rc) return rc;
+		}
+	}
+	HIP_TRY(hipEventRecord(w->ev[11], w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	refreshMirror(w);
+	const Counters& c = w->h_dstate->c;
+	w->lastContacts = c.nContacts;
+	w->last.nContacts = c.nContacts;
+	w->last.nMoves = c.nMoves;
+	w->last.nNewContacts = c.nNewContacts;
+	w->last.nPairs = c.nPairs;
+	w->last.overflow = c.overflow;
+	w->last.posItersLarge = c.posItersLarge;
+	if (w->sp.dt > 0.0f) w->inv_dt0 = w->sp.inv_dt;
+	w->stepActive = false;
+
+	// b2Profile from events (milliseconds)
+	float ms = 0.0f;
+	float* p = w->profile;
+	memset(p, 0, sizeof(float) * 13);
+	(void)hipEventElapsedTime(&ms, w->ev[0], w->ev[11]); p[0] = ms;                  // step
+	(void)hipEventElapsedTime(&ms, w->ev[1], w->ev[2]); p[1] = ms;                   // collide
+	(void)hipEventElapsedTime(&ms, w->ev[2], w->ev[3]); p[2] = ms;                   // solve (islands + solver)
+	(void)hipEventElapsedTime(&ms, w->ev[2], w->ev[4]); p[3] = ms;                   // solveTraversal = island build
+	float small = 0.0f, large = 0.0f, dfs = 0.0f, color = 0.0f;
+	(void)hipEventElapsedTime(&dfs, w->ev[4], w->ev[5]);
+	(void)hipEventElapsedTime(&small, w->ev[5], w->ev[6]);
+	(void)hipEventElapsedTime(&color, w->ev[6], w->ev[7]);
+	(void)hipEventElapsedTime(&large, w->ev[7], w->ev[8]);
+	p[3] += dfs + color;
+	p[5] = small + large;                                                        // solver kernels (init+velocity+position)
+	float bp0 = 0.0f, bp1 = 0.0f, bpTop = 0.0f;
+	(void)hipEventElapsedTime(&bpTop, w->ev[0], w->ev[1]);
+	(void)hipEventElapsedTime(&bp0, w->ev[3], w->ev[9]);
+	(void)hipEventElapsedTime(&bp1, w->ev[9], w->ev[10]);
+	p[10] = bp0;                                                                 // broadphaseSyncFixtures
+	p[11] = bp1 + bpTop;                                                         // broadphaseFindContacts
+	p[9] = bp0 + bp1 + bpTop;                                                    // broadphase
+	w->solverMs = small + large;
+	const int Ct = w->last.nSContacts + w->last.nLContacts;
+	const int B = w->last.nSBodies + w->last.nLBodies;
+	w->solverConstraints = Ct;
+	w->solverBodies = B;
+	// Ct*(Nv*220 + Np*136 + 488) + B*240 with Np = configured position iterations
+	w->solverBytes = (double)Ct * (w->sp.velIters * 220.0 + w->sp.posIters * 136.0 + 488.0) + (double)B * 240.0;
+	return 0;
+}
+
+int b2hip_step(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)
+{
+	int rc = b2hip_step_begin(w, dt, velocity_iterations, position_iterations);
+	if (rc) return rc;
+	rc = b2hip_collide(w);
+	if (rc) return rc;
+	rc = b2hip_solve(w);
+	if (rc) return rc;
+	rc = b2hip_sync_fixtures(w);
+	if (rc) return rc;
+	rc = b2hip_find_new_contacts(w);
+	if (rc) return rc;
+	return b2hip_step_end(w);
+}
+
+int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state* out)
+{
+	if (!w || !out || first < 0 || count < 0 || first + count > (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad range");
+	for (int i = 0; i < count; ++i)
+	{
+		const HostBody& b = w->bodies[first + i];
+		b2hip_body_state& s = out[i];
+		s.px = b.px; s.py = b.py; s.angle = b.a;
+		s.vx = b.vx; s.vy = b.vy; s.w = b.w;
+		s.cx = b.cx; s.cy = b.cy;
+		s.flags = (b.flags & 0x7cu) | (uint32_t)b.type;
+		s.sleep_time = b.sleepTime;
+	}
+	return 0;
+}
+
+int b2hip_contact_count(b2hip_world* w)
+{
+	return w ? w->lastContacts : 0;
+}
+
+int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	int rc = readState(w);
+	if (rc) return rc;
+	const int n = std::min(cap, w->h_dstate->c.nContacts);
+	const int cur = w->h_dstate->cur;
+	if (n <= 0) return 0;
+	std::vector<int4> ids(n), m3(n);
+	std::vector<uint32_t> flags(n);
+	std::vector<float4> mat(n), m0(n), m1(n), imp(n);
+	HIP_TRY(hipMemcpy(ids.data(), w->c_ids[cur].p, n * sizeof(int4), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(m3.data(), w->c_man3[cur].p, n * sizeof(int4), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(flags.data(), w->c_flags[cur].p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(mat.data(), w->c_mat[cur].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(m0.data(), w->c_man0[cur].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(m1.data(), w->c_man1[cur].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(imp.data(), w->c_imp[cur].p, n * sizeof(float4), hipMemcpyDeviceToHost));
+	for (int i = 0; i < n; ++i)
+	{
+		b2hip_contact& c = out[i];
+		c.fixture_a = ids[i].x;
+		c.fixture_b = ids[i].y;
+		c.body_a = ids[i].z;
+		c.body_b = ids[i].w;
+		c.flags = ((flags[i] & CF_TOUCHING) ? 1u : 0u) | ((flags[i] & CF_ENABLED) ? 2u : 0u);
+		c.manifold_type = m3[i].z;
+		c.point_count = m3[i].w;
+		c.local_normal[0] = m0[i].x; c.local_normal[1] = m0[i].y;
+		c.local_point[0] = m0[i].z; c.local_point[1] = m0[i].w;
+		c.point_local[0][0] = m1[i].x; c.point_local[0][1] = m1[i].y;
+		c.point_local[1][0] = m1[i].z; c.point_local[1][1] = m1[i].w;
+		c.normal_impulse[0] = imp[i].x; c.tangent_impulse[0] = imp[i].y;
+		c.normal_impulse[1] = imp[i].z; c.tangent_impulse[1] = imp[i].w;
+		c.id_key[0] = (uint32_t)m3[i].x;
+		c.id_key[1] = (uint32_t)m3[i].y;
+		c.friction = mat[i].x;
+		c.restitution = mat[i].y;
+	}
+	return n;
+}
+
+int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out)
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int n = std::min(cap, (int)w->bodies.size());
+	if (n <= 0) return 0;
+	std::vector<int> parent(n), tier(n);
+	HIP_TRY(hipMemcpy(parent.data(), w->parent.p, n * sizeof(int), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(tier.data(), w->rootIsland.p, n * sizeof(int), hipMemcpyDeviceToHost));
+	for (int i = 0; i < n; ++i)
+	{
+		const HostBody& b = w->bodies[i];
+		if (b.type == B2HIP_STATIC_BODY) { out[i] = -1; continue; }
+		int r = parent[i];
+		out[i] = (r >= 0 && r < n && tier[r] != ROOT_NONE) ? r : -1;
+	}
+	return n;
+}
+
+int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4])
+{
+	if (!w || !out4 || fixture < 0 || fixture >= (int)w->fixtures.size()) return setError(B2HIP_ERR_INVALID, "bad fixture id");
+	if ((size_t)fixture >= w->upFixtures)
+	{
+		memcpy(out4, w->fixtures[fixture].fat, 16);
+		return 0;
+	}
+	HIP_TRY(hipMemcpy(out4, w->p_fat.p + fixture, 16, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int b2hip_get_profile(b2hip_world* w, float ms[13])
+{
+	if (!w || !ms) return setError(B2HIP_ERR_INVALID, "null argument");
+	memcpy(ms, w->profile, sizeof(float) * 13);
+	return 0;
+}
+
+int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	memset(out, 0, sizeof(*out));
+	out->bodies = (int)w->bodies.size();
+	out->proxies = (int)w->fixtures.size();
+	out->contacts = w->last.nContacts;
+	out->touching_contacts = w->last.nTouching;
+	out->islands = w->last.nIslands;
+	out->small_islands = w->last.nSIslands;
+	out->large_islands = w->last.nLIslands;
+	out->small_island_bodies = w->last.nSBodies;
+	out->small_island_contacts = w->last.nSContacts;
+	out->large_island_bodies = w->last.nLBodies;
+	out->large_island_contacts = w->last.nLContacts;
+	out->colors = w->last.nColors;
+	out->moved_proxies = w->last.nMoves;
+	out->new_contacts = w->last.nNewContacts;
+	out->destroyed_contacts = w->last.nDestroy;
+	out->solver_chunks = w->last.nChunks;
+	out->pos_iterations_large = w->last.posItersLarge;
+	out->overflow_flags = w->last.overflow;
+	return 0;
+}
+
+int b2hip_get_solver_timing(b2hip_world* w, float* ms, double* algorithmic_bytes, int* constraints, int* bodies)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	if (ms) *ms = w->solverMs;
+	if (algorithmic_bytes) *algorithmic_bytes = w->solverBytes;
+	if (constraints) *constraints = w->solverConstraints;
+	if (bodies) *bodies = w->solverBodies;
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,31 @@
+// Drop-in umbrella header (reference: Box2D/Box2D.h:34-68): MI355X-native Step() hot path behind
+// the Box2D-MT public API.
+#ifndef BOX2D_H
+#define BOX2D_H
+
+#include "Box2D/Common/b2Settings.h"
+#include "Box2D/Common/b2Math.h"
+#include "Box2D/Common/b2Timer.h"
+#include "Box2D/Common/b2BlockAllocator.h"
+#include "Box2D/Common/b2StackAllocator.h"
+
+#include "Box2D/Collision/b2Collision.h"
+#include "Box2D/Collision/Shapes/b2CircleShape.h"
+#include "Box2D/Collision/Shapes/b2EdgeShape.h"
+#include "Box2D/Collision/Shapes/b2PolygonShape.h"
+
+#include "Box2D/Dynamics/b2Body.h"
+#include "Box2D/Dynamics/b2Fixture.h"
+#include "Box2D/Dynamics/b2WorldCallbacks.h"
+#include "Box2D/Dynamics/b2TimeStep.h"
+#include "Box2D/Dynamics/b2World.h"
+#include "Box2D/Dynamics/Contacts/b2Contact.h"
+#include "Box2D/Dynamics/Joints/b2Joint.h"
+#include "Box2D/Dynamics/Joints/b2RevoluteJoint.h"
+
+#include "Box2D/MT/b2Task.h"
+#include "Box2D/MT/b2TaskExecutor.h"
+#include "Box2D/MT/b2ThreadPool.h"
+#include "Box2D/MT/b2MtUtil.h"
+
+#endif

@@ -1,0 +1,54 @@
+// Drop-in header: read-only b2Contact view (reference: Box2D/Dynamics/Contacts/b2Contact.h:36-420).
+// Contacts live in HBM; b2World::GetContactList() materialises this host view on demand from one
+// device-to-host copy (b2hip_get_contacts).
+#ifndef B2_CONTACT_H
+#define B2_CONTACT_H
+
+#include "Box2D/Common/b2Math.h"
+#include "Box2D/Collision/b2Collision.h"
+#include "Box2D/Dynamics/b2Fixture.h"
+
+class b2Body;
+class b2World;
+
+inline float32 b2MixFriction(float32 friction1, float32 friction2) { return b2Sqrt(friction1 * friction2); }
+inline float32 b2MixRestitution(float32 restitution1, float32 restitution2) { return restitution1 > restitution2 ? restitution1 : restitution2; }
+
+struct b2ContactEdge
+{
+	b2Body* other;
+	b2Contact* contact;
+	b2ContactEdge* prev;
+	b2ContactEdge* next;
+};
+
+class b2Contact
+{
+public:
+	b2Manifold* GetManifold() { return &m_manifold; }
+	const b2Manifold* GetManifold() const { return &m_manifold; }
+	void GetWorldManifold(b2WorldManifold* worldManifold) const;
+	bool IsTouching() const { return m_touching; }
+	bool IsEnabled() const { return m_enabled; }
+	b2Contact* GetNext() { return m_next; }
+	const b2Contact* GetNext() const { return m_next; }
+	b2Fixture* GetFixtureA() { return m_fixtureA; }
+	const b2Fixture* GetFixtureA() const { return m_fixtureA; }
+	int32 GetChildIndexA() const { return 0; }
+	b2Fixture* GetFixtureB() { return m_fixtureB; }
+	const b2Fixture* GetFixtureB() const { return m_fixtureB; }
+	int32 GetChildIndexB() const { return 0; }
+	float32 GetFriction() const { return m_friction; }
+	float32 GetRestitution() const { return m_restitution; }
+
+private:
+	friend class b2World;
+	b2Manifold m_manifold;
+	b2Fixture* m_fixtureA;
+	b2Fixture* m_fixtureB;
+	b2Contact* m_next;
+	float32 m_friction, m_restitution;
+	bool m_touching, m_enabled;
+};
+
+#endif

@@ -1,0 +1,84 @@
+// Drop-in header: joint base types (reference: Box2D/Dynamics/Joints/b2Joint.h:31-232).
+// Device path: revolute joints (Tumbler). Other joint types are API-compat declarations only.
+#ifndef B2_JOINT_H
+#define B2_JOINT_H
+
+#include "Box2D/Common/b2Math.h"
+
+class b2Body;
+class b2Joint;
+class b2World;
+
+enum b2JointType
+{
+	e_unknownJoint,
+	e_revoluteJoint,
+	e_prismaticJoint,
+	e_distanceJoint,
+	e_pulleyJoint,
+	e_mouseJoint,
+	e_gearJoint,
+	e_wheelJoint,
+	e_weldJoint,
+	e_frictionJoint,
+	e_ropeJoint,
+	e_motorJoint
+};
+
+enum b2LimitState { e_inactiveLimit, e_atLowerLimit, e_atUpperLimit, e_equalLimits };
+
+struct b2JointEdge
+{
+	b2Body* other;
+	b2Joint* joint;
+	b2JointEdge* prev;
+	b2JointEdge* next;
+};
+
+struct b2JointDef
+{
+	b2JointDef()
+	{
+		type = e_unknownJoint;
+		userData = nullptr;
+		bodyA = nullptr;
+		bodyB = nullptr;
+		collideConnected = false;
+	}
+	b2JointType type;
+	void* userData;
+	b2Body* bodyA;
+	b2Body* bodyB;
+	bool collideConnected;
+};
+
+class b2Joint
+{
+public:
+	virtual ~b2Joint() {}
+	b2JointType GetType() const { return m_type; }
+	b2Body* GetBodyA() { return m_bodyA; }
+	b2Body* GetBodyB() { return m_bodyB; }
+	b2Joint* GetNext() { return m_next; }
+	const b2Joint* GetNext() const { return m_next; }
+	void* GetUserData() const { return m_userData; }
+	void SetUserData(void* data) { m_userData = data; }
+	bool GetCollideConnected() const { return m_collideConnected; }
+	int32 GetDeviceId() const { return m_id; }
+
+protected:
+	friend class b2World;
+	b2Joint(const b2JointDef* def) : m_type(def->type), m_prev(nullptr), m_next(nullptr), m_bodyA(def->bodyA),
+		m_bodyB(def->bodyB), m_collideConnected(def->collideConnected), m_userData(def->userData), m_id(-1) {}
+
+	b2JointType m_type;
+	b2Joint* m_prev;
+	b2Joint* m_next;
+	b2Body* m_bodyA;
+	b2Body* m_bodyB;
+	bool m_collideConnected;
+	void* m_userData;
+	int32 m_id;
+};
+
+#endif

@@ -1,0 +1,108 @@
+// Drop-in header: b2World (reference: Box2D/Dynamics/b2World.h:46-470).
+//
+// Same construction, body / joint factory and Step(dt, velocityIterations, positionIterations,
+// b2TaskExecutor&) signature as the reference (b2World.h:105-108). Step() runs the whole hot path
+// on one MI355X through the C ABI of libb2hip.so (include/b2hip.h) and returns with every body's
+// pose / velocity / awake state readable on the host. There is no CPU implementation of Step here:
+// if no HIP device is present the constructor reports it and Step does nothing but assert.
+#ifndef B2_WORLD_H
+#define B2_WORLD_H
+
+#include "Box2D/Common/b2Math.h"
+#include "Box2D/Common/b2BlockAllocator.h"
+#include "Box2D/Common/b2StackAllocator.h"
+#include "Box2D/Dynamics/b2TimeStep.h"
+#include "Box2D/Dynamics/b2WorldCallbacks.h"
+#include "Box2D/MT/b2TaskExecutor.h"
+
+#include <vector>
+
+struct b2AABB;
+struct b2BodyDef;
+struct b2JointDef;
+class b2Body;
+class b2Fixture;
+class b2Joint;
+class b2Contact;
+struct b2hip_world;
+struct b2hip_body_state;
+
+class b2World
+{
+public:
+	b2World(const b2Vec2& gravity);
+	~b2World();
+
+	void SetDestructionListener(b2DestructionListener* listener) { m_destructionListener = listener; }
+	void SetContactFilter(b2ContactFilter* filter) { m_contactFilter = filter; }
+	void SetContactListener(b2ContactListener* listener) { m_contactListener = listener; }
+
+	b2Body* CreateBody(const b2BodyDef* def);
+	b2Joint* CreateJoint(const b2JointDef* def);
+
+	/// Take a time step: collide, solve islands, update the broad-phase - all on the device.
+	void Step(float32 timeStep, int32 velocityIterations, int32 positionIterations, b2TaskExecutor& executor);
+
+	void ClearForces();
+
+	b2Body* GetBodyList() { return m_bodyList; }
+	const b2Body* GetBodyList() const { return m_bodyList; }
+	b2Joint* GetJointList() { return m_jointList; }
+	const b2Joint* GetJointList() const { return m_jointList; }
+	/// Materialises the contact list from the device (one copy per call after a step).
+	b2Contact* GetContactList();
+	const b2Contact* GetContactList() const { return const_cast<b2World*>(this)->GetContactList(); }
+
+	void SetAllowSleeping(bool flag);
+	bool GetAllowSleeping() const { return m_allowSleep; }
+	void SetWarmStarting(bool flag);
+	bool GetWarmStarting() const { return m_warmStarting; }
+	void SetContinuousPhysics(bool flag);
+	bool GetContinuousPhysics() const { return m_continuousPhysics; }
+	void SetSubStepping(bool flag);
+	bool GetSubStepping() const { return m_subStepping; }
+
+	int32 GetProxyCount() const;
+	int32 GetBodyCount() const { return m_bodyCount; }
+	int32 GetJointCount() const { return m_jointCount; }
+	int32 GetContactCount() const;
+
+	void SetGravity(const b2Vec2& gravity);
+	b2Vec2 GetGravity() const { return m_gravity; }
+	bool IsLocked() const { return m_locked; }
+	void SetAutoClearForces(bool flag) { m_autoClearForces = flag; }
+	bool GetAutoClearForces() const { return m_autoClearForces; }
+	const b2Profile& GetProfile() const { return m_profile; }
+
+	/// The C-ABI world this object wraps (include/b2hip.h).
+	b2hip_world* GetDeviceWorld() { return m_hip; }
+
+private:
+	friend class b2Body;
+	friend class b2Fixture;
+	friend class b2Contact;
+
+	void PushFlags();
+	const b2hip_body_state& State(int32 id) const;
+	void RefreshStates() const;
+
+	b2hip_world* m_hip;
+	b2Vec2 m_gravity;
+	bool m_allowSleep, m_warmStarting, m_continuousPhysics, m_subStepping, m_autoClearForces, m_locked;
+	b2Body* m_bodyList;
+	b2Joint* m_jointList;
+	int32 m_bodyCount, m_jointCount;
+	std::vector<b2Body*> m_bodies;     // by device id
+	std::vector<b2Fixture*> m_fixtures; // by device id
+	b2DestructionListener* m_destructionListener;
+	b2ContactFilter* m_contactFilter;
+	b2ContactListener* m_contactListener;
+	b2Profile m_profile;
+	b2BlockAllocator m_blockAllocator;
+	mutable std::vector<b2hip_body_state> m_states;
+	mutable bool m_statesValid;
+	std::vector<b2Contact> m_contactViews;
+	bool m_contactsValid;
+};
+
+#endif

@@ -1,0 +1,646 @@
+// Host-side implementation of the drop-in b2World / b2Body / b2Fixture / b2Contact: thin binding onto
+// the C ABI of libb2hip.so (include/b2hip.h). No physics is computed here: bodies and fixtures are
+// forwarded to the device world at creation, Step() is one b2hip_step, getters read the host mirror.
+#include "Box2D/Box2D.h"
+
+#include "b2hip.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+// ---- b2World ------------------------------------------------------------------------------------
+b2World::b2World(const b2Vec2& gravity)
+{
+	m_gravity = gravity;
+	m_allowSleep = true;
+	m_warmStarting = true;
+	m_continuousPhysics = true;
+	m_subStepping = false;
+	m_autoClearForces = true;
+	m_locked = false;
+	m_bodyList = nullptr;
+	m_jointList = nullptr;
+	m_bodyCount = 0;
+	m_jointCount = 0;
+	m_destructionListener = nullptr;
+	m_contactFilter = nullptr;
+	m_contactListener = nullptr;
+	memset(&m_profile, 0, sizeof(m_profile));
+	m_statesValid = false;
+	m_contactsValid = false;
+	m_hip = nullptr;
+
+	b2hip_world_def def;
+	def.gravity_x = gravity.x;
+	def.gravity_y = gravity.y;
+	def.allow_sleep = 1;
+	def.warm_starting = 1;
+	def.continuous = 1;
+	def.sub_stepping = 0;
+	def.auto_clear_forces = 1;
+	def.device = -1;
+	int rc = b2hip_world_create(&def, &m_hip);
+	if (rc != B2HIP_OK)
+	{
+		// Loud failure: there is no CPU implementation of Step() behind this API.
+		fprintf(stderr, "b2World: cannot create the HIP world (%d): %s\n", rc, b2hip_last_error());
+		m_hip = nullptr;
+	}
+}
+
+b2World::~b2World()
+{
+	b2Body* b = m_bodyList;
+	while (b)
+	{
+		b2Body* next = b->m_next;
+		b2Fixture* f = b->m_fixtureList;
+		while (f)
+		{
+			b2Fixture* fn = f->m_next;
+			if (f->m_shape)
+			{
+				f->m_shape->~b2Shape();
+				b2Free(f->m_shape);
+			}
+			f->~b2Fixture();
+			b2Free(f);
+			f = fn;
+		}
+		b->~b2Body();
+		b2Free(b);
+		b = next;
+	}
+	b2Joint* j = m_jointList;
+	while (j)
+	{
+		b2Joint* next = j->m_next;
+		j->~b2Joint();
+		b2Free(j);
+		j = next;
+	}
+	if (m_hip) b2hip_world_destroy(m_hip);
+}
+
+void b2World::PushFlags()
+{
+	if (m_hip) b2hip_set_flags(m_hip, m_allowSleep, m_warmStarting, m_continuousPhysics, m_subStepping);
+}
+
+void b2World::SetAllowSleeping(bool flag)
+{
+	m_allowSleep = flag;
+	PushFlags();
+}
+
+void b2World::SetWarmStarting(bool flag)
+{
+	m_warmStarting = flag;
+	PushFlags();
+}
+
+void b2World::SetContinuousPhysics(bool flag)
+{
+	m_continuousPhysics = flag;
+	PushFlags();
+}
+
+void b2World::SetSubStepping(bool flag)
+{
+	m_subStepping = flag;
+	PushFlags();
+}
+
+void b2World::SetGravity(const b2Vec2& gravity)
+{
+	m_gravity = gravity;
+	if (m_hip) b2hip_set_gravity(m_hip, gravity.x, gravity.y);
+}
+
+b2Body* b2World::CreateBody(const b2BodyDef* def)
+{
+	if (IsLocked() || !m_hip) return nullptr;
+	b2hip_body_def d;
+	d.type = (int)def->type;
+	d.px = def->position.x;
+	d.py = def->position.y;
+	d.angle = def->angle;
+	d.vx = def->linearVelocity.x;
+	d.vy = def->linearVelocity.y;
+	d.w = def->angularVelocity;
+	d.linear_damping = def->linearDamping;
+	d.angular_damping = def->angularDamping;
+	d.gravity_scale = def->gravityScale;
+	d.allow_sleep = def->allowSleep;
+	d.awake = def->awake;
+	d.fixed_rotation = def->fixedRotation;
+	d.bullet = def->bullet;
+	d.active = def->active;
+	int id = b2hip_create_body(m_hip, &d);
+	if (id < 0)
+	{
+		fprintf(stderr, "b2World::CreateBody: %s\n", b2hip_last_error());
+		return nullptr;
+	}
+	void* mem = b2Alloc(sizeof(b2Body));
+	b2Body* b = new (mem) b2Body(def, this, id);
+	b->m_prev = nullptr;
+	b->m_next = m_bodyList;
+	if (m_bodyList) m_bodyList->m_prev = b;
+	m_bodyList = b;
+	++m_bodyCount;
+	m_bodies.push_back(b);
+	m_statesValid = false;
+	return b;
+}
+
+b2Joint* b2World::CreateJoint(const b2JointDef* def)
+{
+	if (IsLocked() || !m_hip) return nullptr;
+	if (def->type != e_revoluteJoint)
+	{
+		fprintf(stderr, "b2World::CreateJoint: joint type %d is not on the device path yet\n", (int)def->type);
+		return nullptr;
+	}
+	const b2RevoluteJointDef* rd = static_cast<const b2RevoluteJointDef*>(def);
+	b2hip_revolute_joint_def d;
+	d.body_a = rd->bodyA->GetDeviceId();
+	d.body_b = rd->bodyB->GetDeviceId();
+	d.local_anchor_a[0] = rd->localAnchorA.x;
+	d.local_anchor_a[1] = rd->localAnchorA.y;
+	d.local_anchor_b[0] = rd->localAnchorB.x;
+	d.local_anchor_b[1] = rd->localAnchorB.y;
+	d.reference_angle = rd->referenceAngle;
+	d.enable_limit = rd->enableLimit;
+	d.lower_angle = rd->lowerAngle;
+	d.upper_angle = rd->upperAngle;
+	d.enable_motor = rd->enableMotor;
+	d.motor_speed = rd->motorSpeed;
+	d.max_motor_torque = rd->maxMotorTorque;
+	d.collide_connected = rd->collideConnected;
+	int id = b2hip_create_revolute_joint(m_hip, &d);
+	if (id < 0)
+	{
+		fprintf(stderr, "b2World::CreateJoint: %s\n", b2hip_last_error());
+		return nullptr;
+	}
+	void* mem = b2Alloc(sizeof(b2RevoluteJoint));
+	b2RevoluteJoint* j = new (mem) b2RevoluteJoint(rd);
+	j->m_id = id;
+	j->m_prev = nullptr;
+	j->m_next = m_jointList;
+	if (m_jointList) m_jointList->m_prev = j;
+	m_jointList = j;
+	++m_jointCount;
+	return j;
+}
+
+void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIterations, b2TaskExecutor& executor)
+{
+	// The executor stays part of the signature (plugin surface); the device runs the physics phases.
+	B2_NOT_USED(executor);
+	if (!m_hip)
+	{
+		fprintf(stderr, "b2World::Step: no HIP world (no device): nothing can be stepped\n");
+		return;
+	}
+	m_locked = true;
+	int rc = b2hip_step(m_hip, dt, velocityIterations, positionIterations);
+	m_locked = false;
+	if (rc != B2HIP_OK)
+	{
+		fprintf(stderr, "b2World::Step: b2hip_step failed (%d): %s\n", rc, b2hip_last_error());
+	}
+	m_statesValid = false;
+	m_contactsValid = false;
+	float ms[13];
+	if (b2hip_get_profile(m_hip, ms) == B2HIP_OK)
+	{
+		m_profile.step = ms[0];
+		m_profile.collide = ms[1];
+		m_profile.solve = ms[2];
+		m_profile.solveTraversal = ms[3];
+		m_profile.solveInit = ms[4];
+		m_profile.solveVelocity = ms[5];
+		m_profile.solvePosition = ms[6];
+		m_profile.solveTOI = ms[7];
+		m_profile.solveTOIFindMinContact = ms[8];
+		m_profile.broadphase = ms[9];
+		m_profile.broadphaseSyncFixtures = ms[10];
+		m_profile.broadphaseFindContacts = ms[11];
+		m_profile.locking = ms[12];
+	}
+}
+
+void b2World::ClearForces()
+{
+	// forces are cleared on the device at the end of Step when auto-clear is on (default)
+}
+
+int32 b2World::GetProxyCount() const
+{
+	return m_hip ? b2hip_fixture_count(m_hip) : 0;
+}
+
+int32 b2World::GetContactCount() const
+{
+	return m_hip ? b2hip_contact_count(m_hip) : 0;
+}
+
+void b2World::RefreshStates() const
+{
+	if (m_statesValid) return;
+	m_states.resize(m_bodies.size());
+	if (m_hip && !m_bodies.empty())
+	{
+		b2hip_get_body_states(m_hip, 0, (int)m_bodies.size(), m_states.data());
+	}
+	m_statesValid = true;
+}
+
+const b2hip_body_state& b2World::State(int32 id) const
+{
+	RefreshStates();
+	return m_states[id];
+}
+
+b2Contact* b2World::GetContactList()
+{
+	if (!m_hip) return nullptr;
+	if (!m_contactsValid)
+	{
+		int n = b2hip_contact_count(m_hip);
+		std::vector<b2hip_contact> raw(n > 0 ? n : 1);
+		n = n > 0 ? b2hip_get_contacts(m_hip, n, raw.data()) : 0;
+		if (n < 0) n = 0;
+		m_contactViews.assign(n, b2Contact());
+		// the reference's list is newest first (b2ContactManager.cpp:715-724)
+		for (int i = 0; i < n; ++i)
+		{
+			const b2hip_contact& r = raw[n - 1 - i];
+			b2Contact& c = m_contactViews[i];
+			memset(&c.m_manifold, 0, sizeof(c.m_manifold));
+			c.m_manifold.type = (b2Manifold::Type)r.manifold_type;
+			c.m_manifold.pointCount = r.point_count;
+			c.m_manifold.localNormal.Set(r.local_normal[0], r.local_normal[1]);
+			c.m_manifold.localPoint.Set(r.local_point[0], r.local_point[1]);
+			for (int k = 0; k < 2; ++k)
+			{
+				c.m_manifold.points[k].localPoint.Set(r.point_local[k][0], r.point_local[k][1]);
+				c.m_manifold.points[k].normalImpulse = r.normal_impulse[k];
+				c.m_manifold.points[k].tangentImpulse = r.tangent_impulse[k];
+				c.m_manifold.points[k].id.key = r.id_key[k];
+			}
+			c.m_fixtureA = m_fixtures[r.fixture_a];
+			c.m_fixtureB = m_fixtures[r.fixture_b];
+			c.m_friction = r.friction;
+			c.m_restitution = r.restitution;
+			c.m_touching = (r.flags & 1u) != 0;
+			c.m_enabled = (r.flags & 2u) != 0;
+			c.m_next = nullptr;
+		}
+		for (int i = 0; i + 1 < n; ++i) m_contactViews[i].m_next = &m_contactViews[i + 1];
+		m_contactsValid = true;
+	}
+	return m_contactViews.empty() ? nullptr : &m_contactViews[0];
+}
+
+// ---- b2Body -------------------------------------------------------------------------------------
+b2Body::b2Body(const b2BodyDef* bd, b2World* world, int32 id)
+{
+	m_world = world;
+	m_id = id;
+	m_type = bd->type;
+	m_bullet = bd->bullet;
+	m_allowSleep = bd->allowSleep;
+	m_active = bd->active;
+	m_fixedRotation = bd->fixedRotation;
+	m_linearDamping = bd->linearDamping;
+	m_angularDamping = bd->angularDamping;
+	m_gravityScale = bd->gravityScale;
+	m_prev = nullptr;
+	m_next = nullptr;
+	m_fixtureList = nullptr;
+	m_fixtureCount = 0;
+	m_userData = bd->userData;
+}
+
+b2Body::~b2Body()
+{
+}
+
+b2Fixture* b2Body::CreateFixture(const b2FixtureDef* def)
+{
+	if (m_world->IsLocked() || !m_world->m_hip) return nullptr;
+	const b2Shape* shape = def->shape;
+	b2hip_shape hs;
+	memset(&hs, 0, sizeof(hs));
+	hs.type = (int32_t)shape->GetType();
+	hs.radius = shape->m_radius;
+	switch (shape->GetType())
+	{
+	case b2Shape::e_circle:
+	{
+		const b2CircleShape* c = static_cast<const b2CircleShape*>(shape);
+		hs.verts[0] = c->m_p.x;
+		hs.verts[1] = c->m_p.y;
+		break;
+	}
+	case b2Shape::e_edge:
+	{
+		const b2EdgeShape* e = static_cast<const b2EdgeShape*>(shape);
+		hs.verts[0] = e->m_vertex1.x; hs.verts[1] = e->m_vertex1.y;
+		hs.verts[2] = e->m_vertex2.x; hs.verts[3] = e->m_vertex2.y;
+		hs.verts[4] = e->m_vertex0.x; hs.verts[5] = e->m_vertex0.y;
+		hs.verts[6] = e->m_vertex3.x; hs.verts[7] = e->m_vertex3.y;
+		hs.count = (e->m_hasVertex0 ? 1 : 0) | (e->m_hasVertex3 ? 2 : 0);
+		break;
+	}
+	case b2Shape::e_polygon:
+	{
+		const b2PolygonShape* p = static_cast<const b2PolygonShape*>(shape);
+		hs.count = p->m_count;
+		hs.centroid[0] = p->m_centroid.x;
+		hs.centroid[1] = p->m_centroid.y;
+		for (int32 i = 0; i < p->m_count; ++i)
+		{
+			hs.verts[2 * i] = p->m_vertices[i].x;
+			hs.verts[2 * i + 1] = p->m_vertices[i].y;
+			hs.normals[2 * i] = p->m_normals[i].x;
+			hs.normals[2 * i + 1] = p->m_normals[i].y;
+		}
+		break;
+	}
+	default:
+		fprintf(stderr, "b2Body::CreateFixture: shape type %d is not on the device path\n", (int)shape->GetType());
+		return nullptr;
+	}
+	b2hip_fixture_def fd;
+	memset(&fd, 0, sizeof(fd));
+	fd.density = def->density;
+	fd.friction = def->friction;
+	fd.restitution = def->restitution;
+	fd.category_bits = def->filter.categoryBits;
+	fd.mask_bits = def->filter.maskBits;
+	fd.group_index = def->filter.groupIndex;
+	fd.is_sensor = def->isSensor;
+	fd.thick_shape = def->thickShape;
+	int id = b2hip_create_fixture(m_world->m_hip, m_id, &fd, &hs);
+	if (id < 0)
+	{
+		fprintf(stderr, "b2Body::CreateFixture: %s\n", b2hip_last_error());
+		return nullptr;
+	}
+	void* mem = b2Alloc(sizeof(b2Fixture));
+	b2Fixture* f = new (mem) b2Fixture;
+	f->m_id = id;
+	f->m_body = this;
+	f->m_density = def->density;
+	f->m_friction = def->friction;
+	f->m_restitution = def->restitution;
+	f->m_filter = def->filter;
+	f->m_isSensor = def->isSensor;
+	f->m_isThickShape = def->thickShape;
+	f->m_userData = def->userData;
+	f->m_shape = shape->Clone(&m_world->m_blockAllocator);
+	f->m_next = m_fixtureList;
+	m_fixtureList = f;
+	++m_fixtureCount;
+	if ((int)m_world->m_fixtures.size() <= id) m_world->m_fixtures.resize(id + 1, nullptr);
+	m_world->m_fixtures[id] = f;
+	m_world->m_statesValid = false;
+	return f;
+}
+
+b2Fixture* b2Body::CreateFixture(const b2Shape* shape, float32 density)
+{
+	b2FixtureDef def;
+	def.shape = shape;
+	def.density = density;
+	return CreateFixture(&def);
+}
+
+const b2Transform& b2Body::GetTransform() const
+{
+	const b2hip_body_state& s = m_world->State(m_id);
+	m_xfCache.p.Set(s.px, s.py);
+	m_xfCache.q.Set(s.angle);
+	return m_xfCache;
+}
+
+const b2Vec2& b2Body::GetPosition() const
+{
+	const b2hip_body_state& s = m_world->State(m_id);
+	m_vecCache[0].Set(s.px, s.py);
+	return m_vecCache[0];
+}
+
+float32 b2Body::GetAngle() const
+{
+	return m_world->State(m_id).angle;
+}
+
+const b2Vec2& b2Body::GetWorldCenter() const
+{
+	const b2hip_body_state& s = m_world->State(m_id);
+	m_vecCache[1].Set(s.cx, s.cy);
+	return m_vecCache[1];
+}
+
+const b2Vec2& b2Body::GetLocalCenter() const
+{
+	b2hip_mass_data md;
+	b2hip_get_mass_data(m_world->m_hip, m_id, &md);
+	m_vecCache[2].Set(md.local_center[0], md.local_center[1]);
+	return m_vecCache[2];
+}
+
+const b2Vec2& b2Body::GetLinearVelocity() const
+{
+	const b2hip_body_state& s = m_world->State(m_id);
+	m_vecCache[2].Set(s.vx, s.vy);
+	return m_vecCache[2];
+}
+
+float32 b2Body::GetAngularVelocity() const
+{
+	return m_world->State(m_id).w;
+}
+
+bool b2Body::IsAwake() const
+{
+	return (m_world->State(m_id).flags & B2HIP_BODY_AWAKE) != 0;
+}
+
+void b2Body::SetLinearVelocity(const b2Vec2& v)
+{
+	if (m_type == b2_staticBody) return;
+	const b2hip_body_state& s = m_world->State(m_id);
+	b2hip_set_velocity(m_world->m_hip, m_id, v.x, v.y, s.w);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::SetAngularVelocity(float32 omega)
+{
+	if (m_type == b2_staticBody) return;
+	const b2hip_body_state& s = m_world->State(m_id);
+	b2hip_set_velocity(m_world->m_hip, m_id, s.vx, s.vy, omega);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::ApplyForce(const b2Vec2& force, const b2Vec2& point, bool wake)
+{
+	const b2hip_body_state& s = m_world->State(m_id);
+	float32 torque = b2Cross(point - b2Vec2(s.cx, s.cy), force);
+	b2hip_apply_force(m_world->m_hip, m_id, force.x, force.y, torque, wake);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::ApplyForceToCenter(const b2Vec2& force, bool wake)
+{
+	b2hip_apply_force(m_world->m_hip, m_id, force.x, force.y, 0.0f, wake);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::ApplyTorque(float32 torque, bool wake)
+{
+	b2hip_apply_force(m_world->m_hip, m_id, 0.0f, 0.0f, torque, wake);
+	m_world->m_statesValid = false;
+}
+
+float32 b2Body::GetMass() const
+{
+	b2hip_mass_data md;
+	b2hip_get_mass_data(m_world->m_hip, m_id, &md);
+	return md.mass;
+}
+
+float32 b2Body::GetInertia() const
+{
+	b2hip_mass_data md;
+	b2hip_get_mass_data(m_world->m_hip, m_id, &md);
+	return md.inertia;
+}
+
+void b2Body::GetMassData(b2MassData* data) const
+{
+	b2hip_mass_data md;
+	b2hip_get_mass_data(m_world->m_hip, m_id, &md);
+	data->mass = md.mass;
+	data->I = md.inertia;
+	data->center.Set(md.local_center[0], md.local_center[1]);
+}
+
+// ---- b2Fixture ------------------------------------------------------------------------------------
+bool b2Fixture::TestPoint(const b2Vec2& p) const
+{
+	return m_shape->TestPoint(m_body->GetTransform(), p);
+}
+
+const b2AABB& b2Fixture::GetAABB(int32 childIndex) const
+{
+	B2_NOT_USED(childIndex);
+	float a[4] = { 0, 0, 0, 0 };
+	b2hip_get_fat_aabb(m_body->m_world->m_hip, m_id, a);
+	m_aabbCache.lowerBound.Set(a[0], a[1]);
+	m_aabbCache.upperBound.Set(a[2], a[3]);
+	return m_aabbCache;
+}
+
+// ---- b2Contact ------------------------------------------------------------------------------------
+void b2Contact::GetWorldManifold(b2WorldManifold* worldManifold) const
+{
+	const b2Body* bodyA = m_fixtureA->GetBody();
+	const b2Body* bodyB = m_fixtureB->GetBody();
+	b2Transform xfA = bodyA->GetTransform();
+	b2Transform xfB = bodyB->GetTransform();
+	worldManifold->Initialize(&m_manifold, xfA, m_fixtureA->GetShape()->m_radius, xfB, m_fixtureB->GetShape()->m_radius);
+}
+
+// ---- joints ---------------------------------------------------------------------------------------
+void b2RevoluteJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor)
+{
+	bodyA = bA;
+	bodyB = bB;
+	localAnchorA = bodyA->GetLocalPoint(anchor);
+	localAnchorB = bodyB->GetLocalPoint(anchor);
+	referenceAngle = bodyB->GetAngle() - bodyA->GetAngle();
+}
+
+// ---- callbacks / collision helpers ----------------------------------------------------------------
+bool b2ContactFilter::ShouldCollide(b2Fixture* fixtureA, b2Fixture* fixtureB, uint32 threadId)
+{
+	B2_NOT_USED(threadId);
+	const b2Filter& filterA = fixtureA->GetFilterData();
+	const b2Filter& filterB = fixtureB->GetFilterData();
+	if (filterA.groupIndex == filterB.groupIndex && filterA.groupIndex != 0)
+	{
+		return filterA.groupIndex > 0;
+	}
+	return (filterA.maskBits & filterB.categoryBits) != 0 && (filterA.categoryBits & filterB.maskBits) != 0;
+}
+
+void b2WorldManifold::Initialize(const b2Manifold* manifold, const b2Transform& xfA, float32 radiusA,
+	const b2Transform& xfB, float32 radiusB)
+{
+	if (manifold->pointCount == 0) return;
+	if (manifold->type == b2Manifold::e_circles)
+	{
+		normal.Set(1.0f, 0.0f);
+		b2Vec2 pointA = b2Mul(xfA, manifold->localPoint);
+		b2Vec2 pointB = b2Mul(xfB, manifold->points[0].localPoint);
+		if (b2DistanceSquared(pointA, pointB) > b2_epsilon * b2_epsilon)
+		{
+			normal = pointB - pointA;
+			normal.Normalize();
+		}
+		b2Vec2 cA = pointA + radiusA * normal;
+		b2Vec2 cB = pointB - radiusB * normal;
+		points[0] = 0.5f * (cA + cB);
+		separations[0] = b2Dot(cB - cA, normal);
+		return;
+	}
+	const bool faceA = manifold->type == b2Manifold::e_faceA;
+	const b2Transform& xfRef = faceA ? xfA : xfB;
+	const b2Transform& xfInc = faceA ? xfB : xfA;
+	const float32 radiusRef = faceA ? radiusA : radiusB;
+	const float32 radiusInc = faceA ? radiusB : radiusA;
+	normal = b2Mul(xfRef.q, manifold->localNormal);
+	b2Vec2 planePoint = b2Mul(xfRef, manifold->localPoint);
+	for (int32 i = 0; i < manifold->pointCount; ++i)
+	{
+		b2Vec2 clipPoint = b2Mul(xfInc, manifold->points[i].localPoint);
+		b2Vec2 cRef = clipPoint + (radiusRef - b2Dot(clipPoint - planePoint, normal)) * normal;
+		b2Vec2 cInc = clipPoint - radiusInc * normal;
+		points[i] = 0.5f * (cRef + cInc);
+		separations[i] = b2Dot(cInc - cRef, normal);
+	}
+	if (!faceA) normal = -normal;
+}
+
+void b2GetPointStates(b2PointState state1[b2_maxManifoldPoints], b2PointState state2[b2_maxManifoldPoints],
+	const b2Manifold* manifold1, const b2Manifold* manifold2)
+{
+	for (int32 i = 0; i < b2_maxManifoldPoints; ++i)
+	{
+		state1[i] = b2_nullState;
+		state2[i] = b2_nullState;
+	}
+	for (int32 i = 0; i < manifold1->pointCount; ++i)
+	{
+		state1[i] = b2_removeState;
+		for (int32 j = 0; j < manifold2->pointCount; ++j)
+		{
+			if (manifold2->points[j].id.key == manifold1->points[i].id.key) state1[i] = b2_persistState;
+		}
+	}
+	for (int32 i = 0; i < manifold2->pointCount; ++i)
+	{
+		state2[i] = b2_addState;
+		for (int32 j = 0; j < manifold1->pointCount; ++j)
+		{
+			if (manifold1->points[j].id.key == manifold2->points[i].id.key) state2[i] = b2_persistState;
+		}
+	}
+}

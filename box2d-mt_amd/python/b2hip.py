@@ -1,0 +1,226 @@
+"""ctypes binding of include/b2hip.h (libb2hip.so).
+
+Plumbing only: every call goes straight to the C ABI; there is no Python or CPU implementation of the
+step behind it.  Loading fails loudly if the HIP library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libb2hip.so")
+
+STATIC, KINEMATIC, DYNAMIC = 0, 1, 2
+CIRCLE, EDGE, POLYGON = 0, 1, 2
+POLYGON_RADIUS = np.float32(2.0) * np.float32(0.005)
+
+
+class WorldDef(C.Structure):
+    _fields_ = [("gravity_x", C.c_float), ("gravity_y", C.c_float), ("allow_sleep", C.c_int),
+                ("warm_starting", C.c_int), ("continuous", C.c_int), ("sub_stepping", C.c_int),
+                ("auto_clear_forces", C.c_int), ("device", C.c_int)]
+
+
+class BodyDef(C.Structure):
+    _fields_ = [("type", C.c_int), ("px", C.c_float), ("py", C.c_float), ("angle", C.c_float),
+                ("vx", C.c_float), ("vy", C.c_float), ("w", C.c_float),
+                ("linear_damping", C.c_float), ("angular_damping", C.c_float), ("gravity_scale", C.c_float),
+                ("allow_sleep", C.c_int), ("awake", C.c_int), ("fixed_rotation", C.c_int),
+                ("bullet", C.c_int), ("active", C.c_int)]
+
+
+class Shape(C.Structure):
+    _fields_ = [("type", C.c_int32), ("count", C.c_int32), ("radius", C.c_float), ("pad", C.c_float),
+                ("centroid", C.c_float * 2), ("verts", C.c_float * 16), ("normals", C.c_float * 16)]
+
+
+class FixtureDef(C.Structure):
+    _fields_ = [("density", C.c_float), ("friction", C.c_float), ("restitution", C.c_float),
+                ("category_bits", C.c_uint16), ("mask_bits", C.c_uint16), ("group_index", C.c_int16),
+                ("pad", C.c_int16), ("is_sensor", C.c_int), ("thick_shape", C.c_int)]
+
+
+class RevoluteJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("local_anchor_a", C.c_float * 2),
+                ("local_anchor_b", C.c_float * 2), ("reference_angle", C.c_float), ("enable_limit", C.c_int),
+                ("lower_angle", C.c_float), ("upper_angle", C.c_float), ("enable_motor", C.c_int),
+                ("motor_speed", C.c_float), ("max_motor_torque", C.c_float), ("collide_connected", C.c_int)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
+        "small_island_bodies", "small_island_contacts", "large_island_bodies", "large_island_contacts",
+        "colors", "moved_proxies", "new_contacts", "destroyed_contacts", "solver_chunks",
+        "pos_iterations_large", "overflow_flags")]
+
+
+BODY_STATE_DTYPE = np.dtype([("px", "f4"), ("py", "f4"), ("angle", "f4"), ("vx", "f4"), ("vy", "f4"), ("w", "f4"),
+                             ("cx", "f4"), ("cy", "f4"), ("flags", "u4"), ("sleep_time", "f4")])
+
+CONTACT_DTYPE = np.dtype([("fixture_a", "i4"), ("fixture_b", "i4"), ("body_a", "i4"), ("body_b", "i4"),
+                          ("flags", "u4"), ("manifold_type", "i4"), ("point_count", "i4"),
+                          ("local_normal", "f4", 2), ("local_point", "f4", 2), ("point_local", "f4", (2, 2)),
+                          ("normal_impulse", "f4", 2), ("tangent_impulse", "f4", 2), ("id_key", "u4", 2),
+                          ("friction", "f4"), ("restitution", "f4")])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libb2hip.so is not built (%s): run __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.b2hip_last_error.restype = C.c_char_p
+        L.b2hip_version.restype = C.c_char_p
+        L.b2hip_world_create.argtypes = [C.POINTER(WorldDef), C.POINTER(C.c_void_p)]
+        L.b2hip_world_destroy.argtypes = [C.c_void_p]
+        L.b2hip_set_gravity.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.b2hip_set_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.b2hip_create_body.argtypes = [C.c_void_p, C.POINTER(BodyDef)]
+        L.b2hip_create_fixture.argtypes = [C.c_void_p, C.c_int, C.POINTER(FixtureDef), C.POINTER(Shape)]
+        L.b2hip_create_revolute_joint.argtypes = [C.c_void_p, C.POINTER(RevoluteJointDef)]
+        L.b2hip_body_count.argtypes = [C.c_void_p]
+        L.b2hip_fixture_count.argtypes = [C.c_void_p]
+        L.b2hip_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
+        L.b2hip_step_begin.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
+        for name in ("b2hip_collide", "b2hip_solve", "b2hip_sync_fixtures", "b2hip_find_new_contacts", "b2hip_step_end"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.b2hip_get_body_states.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.b2hip_contact_count.argtypes = [C.c_void_p]
+        L.b2hip_get_contacts.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.b2hip_get_island_labels.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.b2hip_get_fat_aabb.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.b2hip_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.b2hip_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.b2hip_get_solver_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.b2hip_apply_force.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+        L.b2hip_set_velocity.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
+        _lib = L
+    return _lib
+
+
+class B2HipError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc < 0:
+        raise B2HipError("b2hip error %d: %s" % (rc, lib().b2hip_last_error().decode()))
+    return rc
+
+
+def box_shape(hx, hy):
+    s = Shape()
+    s.type, s.count, s.radius = POLYGON, 4, POLYGON_RADIUS
+    hx, hy = np.float32(hx), np.float32(hy)
+    v = [-hx, -hy, hx, -hy, hx, hy, -hx, hy]
+    n = [0, -1, 1, 0, 0, 1, -1, 0]
+    for i in range(8):
+        s.verts[i] = v[i]
+        s.normals[i] = n[i]
+    return s
+
+
+def circle_shape(radius, px=0.0, py=0.0):
+    s = Shape()
+    s.type, s.count, s.radius = CIRCLE, 0, radius
+    s.verts[0], s.verts[1] = px, py
+    return s
+
+
+def edge_shape(v1, v2):
+    s = Shape()
+    s.type, s.count, s.radius = EDGE, 0, POLYGON_RADIUS
+    s.verts[0], s.verts[1], s.verts[2], s.verts[3] = v1[0], v1[1], v2[0], v2[1]
+    return s
+
+
+class World:
+    def __init__(self, gravity=(0.0, -10.0), allow_sleep=True, warm_starting=True, continuous=False, device=-1):
+        self.L = lib()
+        d = WorldDef(gravity[0], gravity[1], int(allow_sleep), int(warm_starting), int(continuous), 0, 1, device)
+        p = C.c_void_p()
+        _check(self.L.b2hip_world_create(C.byref(d), C.byref(p)))
+        self.p = p
+
+    def close(self):
+        if self.p:
+            self.L.b2hip_world_destroy(self.p)
+            self.p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def create_body(self, type=STATIC, position=(0.0, 0.0), angle=0.0, velocity=(0.0, 0.0), omega=0.0,
+                    linear_damping=0.0, angular_damping=0.0, gravity_scale=1.0, allow_sleep=True, awake=True,
+                    fixed_rotation=False, bullet=False):
+        d = BodyDef(type, position[0], position[1], angle, velocity[0], velocity[1], omega, linear_damping,
+                    angular_damping, gravity_scale, int(allow_sleep), int(awake), int(fixed_rotation), int(bullet), 1)
+        return _check(self.L.b2hip_create_body(self.p, C.byref(d)))
+
+    def create_fixture(self, body, shape, density=0.0, friction=0.2, restitution=0.0, category=1, mask=0xFFFF,
+                       group=0, sensor=False, thick=False):
+        d = FixtureDef(density, friction, restitution, category, mask, group, 0, int(sensor), int(thick))
+        return _check(self.L.b2hip_create_fixture(self.p, body, C.byref(d), C.byref(shape)))
+
+    def step(self, dt=1.0 / 60.0, vel_iters=8, pos_iters=3):
+        _check(self.L.b2hip_step(self.p, dt, vel_iters, pos_iters))
+
+    @property
+    def body_count(self):
+        return self.L.b2hip_body_count(self.p)
+
+    def body_states(self):
+        n = self.body_count
+        out = np.zeros(n, BODY_STATE_DTYPE)
+        _check(self.L.b2hip_get_body_states(self.p, 0, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def bodies8(self):
+        """Same 8-column layout as the harness: x, y, angle, vx, vy, w, awake, type."""
+        s = self.body_states()
+        out = np.zeros((s.size, 8), np.float32)
+        out[:, 0], out[:, 1], out[:, 2] = s["px"], s["py"], s["angle"]
+        out[:, 3], out[:, 4], out[:, 5] = s["vx"], s["vy"], s["w"]
+        out[:, 6] = (s["flags"] & 4) != 0
+        out[:, 7] = s["flags"] & 3
+        return out
+
+    @property
+    def contact_count(self):
+        return self.L.b2hip_contact_count(self.p)
+
+    def contacts(self):
+        cap = max(self.contact_count, 1)
+        out = np.zeros(cap, CONTACT_DTYPE)
+        n = _check(self.L.b2hip_get_contacts(self.p, cap, out.ctypes.data_as(C.c_void_p)))
+        return out[:n]
+
+    def island_labels(self):
+        n = self.body_count
+        out = np.zeros(n, np.int32)
+        _check(self.L.b2hip_get_island_labels(self.p, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def counters(self):
+        c = Counters()
+        _check(self.L.b2hip_get_counters(self.p, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def profile(self):
+        ms = (C.c_float * 13)()
+        _check(self.L.b2hip_get_profile(self.p, ms))
+        return list(ms)
+
+    def solver_timing(self):
+        ms, by, ct, b = C.c_float(), C.c_double(), C.c_int(), C.c_int()
+        _check(self.L.b2hip_get_solver_timing(self.p, C.byref(ms), C.byref(by), C.byref(ct), C.byref(b)))
+        return ms.value, by.value, ct.value, b.value

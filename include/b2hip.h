@@ -1,0 +1,223 @@
+/* b2hip.h - C ABI of the MI355X-native b2World::Step() hot path (libb2hip.so).
+ *
+ * This is the drop-in boundary: plain C structs, pointers and sizes, no C++ and no torch types.
+ * The host-side Box2D API mirror (box2d-mt_amd/host/Box2D/...) is a thin C++ layer that binds
+ * exactly these entry points; INTEGRATION.md shows the binding a maintainer of the reference
+ * would add inside b2World / b2Body.
+ *
+ * Reference interfaces replaced (all paths relative to the reference tree):
+ *   b2hip_world_create / destroy     b2World::b2World, ~b2World            Box2D/Dynamics/b2World.cpp:446-520
+ *   b2hip_create_body                b2World::CreateBody + b2Body::b2Body   b2World.cpp:548-582, b2Body.cpp:26-112
+ *   b2hip_create_fixture             b2Body::CreateFixture, b2Fixture::Create/CreateProxies,
+ *                                    b2Body::ResetMassData                  b2Body.cpp:182-226,310-385; b2Fixture.cpp:42-141
+ *   b2hip_create_revolute_joint      b2World::CreateJoint (revolute)        b2World.cpp:672-760, Joints/b2RevoluteJoint.cpp:47-63
+ *   b2hip_step                       b2World::Step                          b2World.cpp:1613-1710
+ *   b2hip_collide                    b2World::Collide / b2ContactManager::Collide      b2World.cpp:1120-1141, b2ContactManager.cpp:177-230
+ *   b2hip_solve                      b2World::Solve (islands + b2Island::Solve)        b2World.cpp:1166-1431, b2Island.cpp:184-396
+ *   b2hip_sync_fixtures              b2World::SynchronizeFixtures                      b2World.cpp:1143-1164, b2ContactManager.cpp:315-364,441-452
+ *   b2hip_find_new_contacts          b2World::FindNewContacts / b2BroadPhase::UpdatePairs / AddPair
+ *                                                                                       b2World.cpp:1095-1118, b2BroadPhase.h:211-267, b2ContactManager.cpp:237-312,366-386
+ *   b2hip_get_body_states            b2Body::GetPosition/GetAngle/GetLinearVelocity/GetAngularVelocity/IsAwake  b2Body.h:516-700
+ *   b2hip_get_contacts               b2World::GetContactList + b2Contact::GetManifold  b2World.h:352-360, b2Contact.h:95-163
+ *   b2hip_get_profile                b2World::GetProfile                    b2World.h:196-197, b2TimeStep.h:25-40
+ *
+ * Conventions: every function returns 0 on success and a negative b2hip_status on failure
+ * (b2hip_last_error() gives the text); no exceptions cross the boundary; host buffers are owned by
+ * the caller, device buffers by the world; all calls for one world come from one thread; work is
+ * stream-ordered on the world's HIP stream and only the download / step calls block.
+ * There is NO CPU fallback: if no HIP device is usable, b2hip_world_create fails.
+ */
+#ifndef B2HIP_H
+#define B2HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct b2hip_world b2hip_world;
+
+typedef enum b2hip_status
+{
+	B2HIP_OK = 0,
+	B2HIP_ERR_INVALID = -1,     /* bad argument / unknown id */
+	B2HIP_ERR_HIP = -2,         /* a HIP runtime call failed */
+	B2HIP_ERR_NO_DEVICE = -3,   /* no usable gfx950 device */
+	B2HIP_ERR_UNSUPPORTED = -4, /* feature outside the device path (e.g. chain shapes) */
+	B2HIP_ERR_CAPACITY = -5     /* a device buffer overflowed and could not be regrown */
+} b2hip_status;
+
+enum { B2HIP_STATIC_BODY = 0, B2HIP_KINEMATIC_BODY = 1, B2HIP_DYNAMIC_BODY = 2 }; /* b2BodyType, b2Body.h:36-47 */
+enum { B2HIP_SHAPE_CIRCLE = 0, B2HIP_SHAPE_EDGE = 1, B2HIP_SHAPE_POLYGON = 2 };    /* b2Shape::Type, b2Shape.h:53-60 */
+
+typedef struct b2hip_world_def
+{
+	float gravity_x, gravity_y;
+	int allow_sleep;      /* b2World::SetAllowSleeping      default 1 */
+	int warm_starting;    /* b2World::SetWarmStarting       default 1 */
+	int continuous;       /* b2World::SetContinuousPhysics  default 1 in the reference; TOI is not on the device path yet */
+	int sub_stepping;     /* b2World::SetSubStepping        default 0 */
+	int auto_clear_forces;/* b2World::SetAutoClearForces    default 1 */
+	int device;           /* HIP device ordinal, -1 = current */
+} b2hip_world_def;
+
+/* b2BodyDef (b2Body.h:52-129) */
+typedef struct b2hip_body_def
+{
+	int type;
+	float px, py, angle;
+	float vx, vy, w;
+	float linear_damping, angular_damping, gravity_scale;
+	int allow_sleep, awake, fixed_rotation, bullet, active;
+} b2hip_body_def;
+
+/* A finished collision shape (what b2Shape::Clone would copy). Layout == device ShapeRec.
+ *   circle : verts[0..1] = m_p, radius = m_radius
+ *   edge   : verts[0..1] = m_vertex1, [2..3] = m_vertex2, [4..5] = m_vertex0, [6..7] = m_vertex3,
+ *            count bit0 = m_hasVertex0, bit1 = m_hasVertex3, radius = b2_polygonRadius
+ *   polygon: count, verts[2*count], normals[2*count], centroid, radius = b2_polygonRadius */
+typedef struct b2hip_shape
+{
+	int32_t type;
+	int32_t count;
+	float radius;
+	float pad;
+	float centroid[2];
+	float verts[16];
+	float normals[16];
+} b2hip_shape;
+
+/* b2FixtureDef (b2Fixture.h:56-94) */
+typedef struct b2hip_fixture_def
+{
+	float density, friction, restitution;
+	uint16_t category_bits, mask_bits;
+	int16_t group_index;
+	int16_t pad;
+	int is_sensor;
+	int thick_shape;
+} b2hip_fixture_def;
+
+/* b2RevoluteJointDef (Joints/b2RevoluteJoint.h:35-85) */
+typedef struct b2hip_revolute_joint_def
+{
+	int body_a, body_b;
+	float local_anchor_a[2], local_anchor_b[2];
+	float reference_angle;
+	int enable_limit;
+	float lower_angle, upper_angle;
+	int enable_motor;
+	float motor_speed, max_motor_torque;
+	int collide_connected;
+} b2hip_revolute_joint_def;
+
+/* Host-visible body state after a step (40 bytes per body, one coalesced device->host copy). */
+typedef struct b2hip_body_state
+{
+	float px, py;      /* b2Body::GetPosition  (m_xf.p)   */
+	float angle;       /* b2Body::GetAngle     (m_sweep.a) */
+	float vx, vy, w;   /* linear / angular velocity        */
+	float cx, cy;      /* b2Body::GetWorldCenter (m_sweep.c) */
+	uint32_t flags;    /* bit0-1 type, bit2 awake, bit3 autoSleep, bit4 bullet, bit5 fixedRotation, bit6 active */
+	float sleep_time;
+} b2hip_body_state;
+
+#define B2HIP_BODY_AWAKE 0x4u
+
+/* b2MassData + centre (b2Body::GetMass/GetInertia/GetLocalCenter) */
+typedef struct b2hip_mass_data
+{
+	float mass, inertia;      /* inertia about the local origin, as b2Body::GetInertia returns it */
+	float local_center[2];
+	float inv_mass, inv_inertia;
+} b2hip_mass_data;
+
+/* One contact (b2Contact): fixture ids are the ids b2hip_create_fixture returned. */
+typedef struct b2hip_contact
+{
+	int32_t fixture_a, fixture_b;
+	int32_t body_a, body_b;
+	uint32_t flags;            /* bit0 touching, bit1 enabled */
+	int32_t manifold_type;     /* b2Manifold::Type */
+	int32_t point_count;
+	float local_normal[2];
+	float local_point[2];
+	float point_local[2][2];
+	float normal_impulse[2];
+	float tangent_impulse[2];
+	uint32_t id_key[2];
+	float friction, restitution;
+} b2hip_contact;
+
+/* Counters of the last step (device truth, read back with the body states). */
+typedef struct b2hip_counters
+{
+	int32_t bodies, proxies, contacts, touching_contacts;
+	int32_t islands, small_islands, large_islands;
+	int32_t small_island_bodies, small_island_contacts, large_island_bodies, large_island_contacts;
+	int32_t colors, moved_proxies, new_contacts, destroyed_contacts;
+	int32_t solver_chunks;
+	int32_t pos_iterations_large;
+	int32_t overflow_flags;
+} b2hip_counters;
+
+const char* b2hip_last_error(void);
+const char* b2hip_version(void);
+
+int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out);
+void b2hip_world_destroy(b2hip_world* w);
+
+int b2hip_set_gravity(b2hip_world* w, float gx, float gy);
+int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int continuous, int sub_stepping);
+
+/* Returns the new body / fixture / joint id (>= 0) or a negative status. */
+int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def);
+int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def, const b2hip_shape* shape);
+int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* def);
+
+int b2hip_body_count(const b2hip_world* w);
+int b2hip_fixture_count(const b2hip_world* w);
+int b2hip_get_mass_data(const b2hip_world* w, int body, b2hip_mass_data* out);
+
+/* Force / impulse staging between steps (b2Body::ApplyForceToCenter, ApplyTorque, SetLinearVelocity ...). */
+int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque, int wake);
+int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega);
+
+/* One full b2World::Step on the device, then the body-state read-back. Blocking. */
+int b2hip_step(b2hip_world* w, float dt, int velocity_iterations, int position_iterations);
+
+/* The phases of Step as separate entry points (each blocks until its kernels are done) so that every
+ * phase can be parity-tested and profiled alone. b2hip_step == begin, [find_new_contacts], collide,
+ * solve, sync_fixtures, find_new_contacts, end. */
+int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int position_iterations);
+int b2hip_collide(b2hip_world* w);
+int b2hip_solve(b2hip_world* w);
+int b2hip_sync_fixtures(b2hip_world* w);
+int b2hip_find_new_contacts(b2hip_world* w);
+int b2hip_step_end(b2hip_world* w);
+
+/* Host mirror of the last read-back; valid until the next step. */
+int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state* out);
+int b2hip_contact_count(b2hip_world* w);
+int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out);
+/* Island label per body for the last step: -1 = not solved (asleep / static), else the smallest body id
+ * of the island (island membership is compared as a set partition). */
+int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out);
+/* Fat AABB of a fixture's proxy (b2BroadPhase::GetFatAABB). */
+int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4]);
+
+/* 13 floats in b2Profile declaration order (b2TimeStep.h:25-40), milliseconds, from HIP events. */
+int b2hip_get_profile(b2hip_world* w, float ms[13]);
+int b2hip_get_counters(b2hip_world* w, b2hip_counters* out);
+
+/* Measurement hooks used by bench.py: mean duration (ms) of the solver kernel launches of the last
+ * step measured with HIP events on the world's stream, and the algorithmic bytes they processed
+ * (Ct*(Nv*220 + Np*136 + 488) + B*240). */
+int b2hip_get_solver_timing(b2hip_world* w, float* ms, double* algorithmic_bytes, int* constraints, int* bodies);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

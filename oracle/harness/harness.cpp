@@ -219,9 +219,6 @@ void b2h_reset_profile(b2h_world* h)
 	h->profileSteps = 0;
 }
 
-// --- per-function probes (shape-level narrow phase and trig), used to pin the C restatement and
-// --- the device math bit-for-bit. Polygons are passed as count + 8 vertices (hull is rebuilt by Set()).
-
 static void FillPolygon(b2PolygonShape& poly, int count, const float* verts, int asBox)
 {
 	if (asBox)
@@ -235,6 +232,10 @@ static void FillPolygon(b2PolygonShape& poly, int count, const float* verts, int
 		poly.Set(v, count);
 	}
 }
+
+#ifdef B2H_BACKEND_REF
+// --- per-function probes (shape-level narrow phase and trig), used to pin the C restatement and
+// --- the device math bit-for-bit. Polygons are passed as count + 8 vertices (hull is rebuilt by Set()).
 
 static void DumpManifold(const b2Manifold& m, float* o)
 {
@@ -347,6 +348,8 @@ void b2h_probe_collide_edge_circle(const float* edgeA, const float* xfA, const f
 	b2CollideEdgeAndCircle(&m, &e, MakeXf(xfA), &c, MakeXf(xfB));
 	DumpManifold(m, manifold16);
 }
+
+#endif // B2H_BACKEND_REF (narrow-phase probes call the reference's free functions)
 
 // Polygon build probe: returns count, then vertices[8], normals[8], centroid, and mass data for `density`.
 // out = 1 + 16 + 16 + 2 + 4 floats = 39

@@ -1,0 +1,75 @@
+// CPU compile of the device math headers (box2d-mt_amd/csrc/b2d_*.h) for bit-level checks against
+// oracle/_ref WITHOUT a GPU.  TEST INFRASTRUCTURE: nothing in the product links this file.
+#include "b2d_solver.h"
+#include <math.h>
+
+extern "C"
+{
+
+void probe_sincos(int n, const float* a, float* s, float* c)
+{
+	for (int i = 0; i < n; ++i)
+	{
+		s[i] = b2dSin(a[i]);
+		c[i] = b2dCos(a[i]);
+	}
+}
+
+// exhaustive-ish check against this machine's libm over [lo, hi] bit patterns; returns mismatches
+long probe_sincos_vs_libm(unsigned lo, unsigned hi, unsigned stride)
+{
+	long bad = 0;
+	for (unsigned long u = lo; u <= hi; u += stride)
+	{
+		float f = b2dAsFloat((unsigned)u);
+		if (f != f || f - f != 0.0f) continue;
+		if (b2dAsUint(sinf(f)) != b2dAsUint(b2dSin(f))) ++bad;
+		if (b2dAsUint(cosf(f)) != b2dAsUint(b2dCos(f))) ++bad;
+	}
+	return bad;
+}
+
+// shape = ShapeRec as 38 floats/ints: type, count, radius, pad, centroid(2), verts(16), normals(16)
+// xf = px, py, angle ; out = 16 floats in the harness manifold layout
+void probe_collide(const void* shapeA, const float* xfA, const void* shapeB, const float* xfB, float* out)
+{
+	const ShapeRec* sA = (const ShapeRec*)shapeA;
+	const ShapeRec* sB = (const ShapeRec*)shapeB;
+	Xf a, b;
+	a.p = v2(xfA[0], xfA[1]);
+	a.q = b2dRot(xfA[2]);
+	b.p = v2(xfB[0], xfB[1]);
+	b.q = b2dRot(xfB[2]);
+	Manifold m;
+	memset(&m, 0, sizeof(m));
+	b2dEvaluate(&m, sA, a, sB, b);
+	for (int i = 0; i < 16; ++i) out[i] = 0.0f;
+	out[0] = (float)m.type;
+	out[1] = (float)m.pointCount;
+	if (m.pointCount == 0) return;
+	out[2] = m.localNormal.x;
+	out[3] = m.localNormal.y;
+	out[4] = m.localPoint.x;
+	out[5] = m.localPoint.y;
+	for (int k = 0; k < m.pointCount; ++k)
+	{
+		float* q = out + 6 + 5 * k;
+		q[0] = m.p[k].x;
+		q[1] = m.p[k].y;
+		memcpy(q + 4, &m.id[k], 4);
+	}
+}
+
+void probe_shape_aabb(const void* shape, const float* xf, float* out4)
+{
+	Xf a;
+	a.p = v2(xf[0], xf[1]);
+	a.q = b2dRot(xf[2]);
+	AABB r = b2dShapeAABB((const ShapeRec*)shape, a);
+	out4[0] = r.lo.x;
+	out4[1] = r.lo.y;
+	out4[2] = r.hi.x;
+	out4[3] = r.hi.y;
+}
+
+} // extern "C"
