@@ -91,13 +91,12 @@ B2D_HD float b2dCross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
 B2D_HD V2 b2dCrossVS(V2 a, float s) { return v2(s * a.y, -s * a.x); }
 B2D_HD V2 b2dCrossSV(float s, V2 a) { return v2(-s * a.y, s * a.x); }
 
+// Correctly rounded sqrt on both sides: on gfx950 __builtin_sqrtf lowers to v_sqrt_f32 plus the FMA
+// fix-up sequence (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt). NOT __fsqrt_rn, which HIP
+// maps to the approximate native sqrt unless OCML_BASIC_ROUNDED_OPERATIONS is defined.
 B2D_HD float b2dSqrt(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-	return __fsqrt_rn(x);
-#else
 	return __builtin_sqrtf(x);
-#endif
 }
 
 // b2Vec2::Length / Normalize (b2Math.h:84-108): below epsilon the vector is left untouched.

@@ -1,0 +1,96 @@
+/* b2o.h - CPU oracle: a plain-C, serial restatement of the reference's b2World::Step() hot path.
+ *
+ * TEST INFRASTRUCTURE. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker - never as the thing measured or shipped. The product
+ * (libb2hip.so) does not link, include or call anything in oracle/.
+ *
+ * Pinned against the real reference: oracle/_ref/libb2ref_harness.so (skitzoid/Box2D-MT compiled from
+ * /root/reference by oracle/Makefile) and the golden vectors in tests/golden/ that it generated;
+ * tests/test_oracle.py requires bit-identical body states, contact sets and manifolds.
+ *
+ * The entry points deliberately have the same shape as the product's C ABI (include/b2hip.h) so the
+ * same scene-building code can drive either; every function cites the reference lines it follows in
+ * b2o_step.c.
+ */
+#ifndef B2O_H
+#define B2O_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct b2o_world b2o_world;
+
+typedef struct b2o_shape
+{
+	int32_t type;   /* 0 circle, 1 edge, 2 polygon */
+	int32_t count;  /* polygon: vertex count; edge: bit0 hasVertex0, bit1 hasVertex3 */
+	float radius;
+	float pad;
+	float centroid[2];
+	float verts[16];   /* circle: p ; edge: v1, v2, v0, v3 ; polygon: vertices */
+	float normals[16];
+} b2o_shape;
+
+typedef struct b2o_body_def
+{
+	int type; /* 0 static, 1 kinematic, 2 dynamic */
+	float px, py, angle;
+	float vx, vy, w;
+	float linear_damping, angular_damping, gravity_scale;
+	int allow_sleep, awake, fixed_rotation, bullet, active;
+} b2o_body_def;
+
+typedef struct b2o_fixture_def
+{
+	float density, friction, restitution;
+	uint16_t category_bits, mask_bits;
+	int16_t group_index;
+	int16_t pad;
+	int is_sensor;
+	int thick_shape;
+} b2o_fixture_def;
+
+typedef struct b2o_contact
+{
+	int32_t fixture_a, fixture_b;
+	int32_t body_a, body_b;
+	uint32_t flags; /* bit0 touching, bit1 enabled */
+	int32_t manifold_type;
+	int32_t point_count;
+	float local_normal[2];
+	float local_point[2];
+	float point_local[2][2];
+	float normal_impulse[2];
+	float tangent_impulse[2];
+	uint32_t id_key[2];
+	float friction, restitution;
+} b2o_contact;
+
+b2o_world* b2o_world_create(float gx, float gy, int allow_sleep, int warm_starting, int continuous);
+void b2o_world_destroy(b2o_world* w);
+void b2o_set_gravity(b2o_world* w, float gx, float gy);
+void b2o_set_flags(b2o_world* w, int allow_sleep, int warm_starting, int continuous);
+int b2o_create_body(b2o_world* w, const b2o_body_def* def);
+int b2o_create_fixture(b2o_world* w, int body, const b2o_fixture_def* def, const b2o_shape* shape);
+void b2o_step(b2o_world* w, float dt, int velocity_iterations, int position_iterations);
+int b2o_body_count(const b2o_world* w);
+/* 10 floats per body: px, py, angle, vx, vy, w, cx, cy, flags(bits), sleepTime  (== b2hip_body_state) */
+void b2o_get_body_states(const b2o_world* w, float* out10);
+void b2o_get_mass(const b2o_world* w, int body, float* mass, float* inertia, float* lcx, float* lcy);
+int b2o_contact_count(const b2o_world* w);
+int b2o_get_contacts(const b2o_world* w, int cap, b2o_contact* out);
+/* island label per body of the last step (-1 = not solved): smallest body id of its island */
+void b2o_get_island_labels(const b2o_world* w, int32_t* out);
+void b2o_get_fat_aabb(const b2o_world* w, int fixture, float out4[4]);
+
+/* per-function probes (same layouts as the harness probes) */
+void b2o_collide(const b2o_shape* shapeA, const float* xfA3, const b2o_shape* shapeB, const float* xfB3, float* manifold16);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

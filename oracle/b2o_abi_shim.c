@@ -1,0 +1,131 @@
+/* b2o_abi_shim.c - TEST INFRASTRUCTURE. Exposes the CPU oracle (b2o_*) under the product's C-ABI
+ * symbol names (include/b2hip.h) so that the SAME drop-in Box2D host layer and the SAME scene
+ * harness (oracle/harness) can be linked against the oracle instead of libb2hip.so:
+ *   oracle/libb2oracle_harness.so = harness.cpp + box2d-mt_amd/host/src/*.cpp + this shim + b2o_*.c
+ * Nothing in the product links this file. */
+#include "b2o.h"
+#include "../include/b2hip.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+struct b2hip_world
+{
+	b2o_world* o;
+	int fixtures;
+};
+
+const char* b2hip_last_error(void) { return "cpu oracle shim"; }
+const char* b2hip_version(void) { return "b2o oracle shim"; }
+
+int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
+{
+	b2hip_world* w = (b2hip_world*)calloc(1, sizeof(b2hip_world));
+	w->o = b2o_world_create(def->gravity_x, def->gravity_y, def->allow_sleep, def->warm_starting, def->continuous);
+	*out = w;
+	return 0;
+}
+
+void b2hip_world_destroy(b2hip_world* w)
+{
+	if (!w) return;
+	b2o_world_destroy(w->o);
+	free(w);
+}
+
+int b2hip_set_gravity(b2hip_world* w, float gx, float gy) { b2o_set_gravity(w->o, gx, gy); return 0; }
+
+int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int continuous, int sub_stepping)
+{
+	(void)sub_stepping;
+	b2o_set_flags(w->o, allow_sleep, warm_starting, continuous);
+	return 0;
+}
+
+int b2hip_create_body(b2hip_world* w, const b2hip_body_def* d)
+{
+	b2o_body_def o;
+	memcpy(&o, d, sizeof(o)); /* identical field order */
+	return b2o_create_body(w->o, &o);
+}
+
+int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* d, const b2hip_shape* s)
+{
+	b2o_fixture_def fd;
+	b2o_shape sh;
+	memcpy(&fd, d, sizeof(fd));
+	memcpy(&sh, s, sizeof(sh));
+	w->fixtures++;
+	return b2o_create_fixture(w->o, body, &fd, &sh);
+}
+
+int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* def)
+{
+	(void)w; (void)def;
+	return B2HIP_ERR_UNSUPPORTED;
+}
+
+int b2hip_body_count(const b2hip_world* w) { return b2o_body_count(w->o); }
+int b2hip_fixture_count(const b2hip_world* w) { return w->fixtures; }
+
+int b2hip_get_mass_data(const b2hip_world* w, int body, b2hip_mass_data* out)
+{
+	memset(out, 0, sizeof(*out));
+	b2o_get_mass(w->o, body, &out->mass, &out->inertia, &out->local_center[0], &out->local_center[1]);
+	return 0;
+}
+
+int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque, int wake)
+{
+	(void)w; (void)body; (void)fx; (void)fy; (void)torque; (void)wake;
+	return B2HIP_ERR_UNSUPPORTED;
+}
+
+int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega)
+{
+	(void)w; (void)body; (void)vx; (void)vy; (void)omega;
+	return B2HIP_ERR_UNSUPPORTED;
+}
+
+int b2hip_step(b2hip_world* w, float dt, int vi, int pi)
+{
+	b2o_step(w->o, dt, vi, pi);
+	return 0;
+}
+
+int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state* out)
+{
+	int n = b2o_body_count(w->o);
+	float* tmp = (float*)malloc(sizeof(float) * 10 * (size_t)(n + 1));
+	b2o_get_body_states(w->o, tmp);
+	memcpy(out, tmp + 10 * first, sizeof(float) * 10 * (size_t)count);
+	free(tmp);
+	return 0;
+}
+
+int b2hip_contact_count(b2hip_world* w) { return b2o_contact_count(w->o); }
+
+int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
+{
+	return b2o_get_contacts(w->o, cap, (b2o_contact*)out); /* identical layout */
+}
+
+int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out)
+{
+	(void)cap;
+	b2o_get_island_labels(w->o, out);
+	return b2o_body_count(w->o);
+}
+
+int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4])
+{
+	b2o_get_fat_aabb(w->o, fixture, out4);
+	return 0;
+}
+
+int b2hip_get_profile(b2hip_world* w, float ms[13])
+{
+	(void)w;
+	memset(ms, 0, sizeof(float) * 13);
+	return 0;
+}

@@ -1,0 +1,1243 @@
+/* b2o_step.c - CPU oracle: serial, plain-C restatement of b2World::Step() (TEST INFRASTRUCTURE, see b2o.h).
+ *
+ * Follows the reference's data flow and ORDER literally: per-body contact lists with new contacts at
+ * the front (b2ContactManager.cpp:531-553), DFS islands seeded in creation order
+ * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
+ * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
+ * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
+ * (b2ContactManager.cpp:366-386). Not covered (same as the device path): joints other than none,
+ * chain shapes, sensors' GJK overlap, TOI.
+ */
+#include "b2o_internal.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define BF_AWAKE 0x4u
+#define BF_AUTOSLEEP 0x8u
+#define BF_BULLET 0x10u
+#define BF_FIXEDROT 0x20u
+#define BF_ACTIVE 0x40u
+#define BF_ISLAND 0x80u
+
+#define CF_TOUCHING 0x1u
+#define CF_ENABLED 0x2u
+#define CF_FILTER 0x4u
+#define CF_ISLAND 0x8u
+
+typedef struct
+{
+	int type;
+	uint32_t flags;
+	xform xf;
+	vec2 localCenter, c0, c;
+	float a0, a;
+	vec2 v;
+	float w;
+	vec2 force;
+	float torque;
+	float mass, invMass, I, invI;
+	float linearDamping, angularDamping, gravityScale, sleepTime;
+	int fixtureHead;   /* newest fixture first */
+	int contactHead;   /* edge id = contact * 2 + side, newest first */
+	int islandIndex;
+	int label;
+} body_t;
+
+typedef struct
+{
+	int body;
+	b2o_shape shape;
+	float density, friction, restitution;
+	uint16_t categoryBits, maskBits;
+	int16_t groupIndex;
+	int isSensor, thick;
+	int proxyId;
+	float fat[4];
+	int nextInBody;
+} fixture_t;
+
+typedef struct
+{
+	int alive;
+	int fixtureA, fixtureB;
+	int bodyA, bodyB;
+	uint32_t flags;
+	int proxyLo, proxyHi;
+	manifold m;
+	float friction, restitution, tangentSpeed;
+	int prev[2], next[2]; /* edge links: side 0 lives in bodyA's list, side 1 in bodyB's list */
+	uint64_t seq;
+} contact_t;
+
+/* b2VelocityConstraintPoint / b2ContactVelocityConstraint / b2ContactPositionConstraint
+ * (b2ContactSolver.h:31-57, b2ContactSolver.cpp:32-45) */
+typedef struct
+{
+	vec2 rA[2], rB[2];
+	float normalImpulse[2], tangentImpulse[2], normalMass[2], tangentMass[2], velocityBias[2];
+	vec2 normal;
+	float nm[4], K[4]; /* ex.x, ex.y, ey.x, ey.y */
+	int indexA, indexB;
+	float invMassA, invMassB, invIA, invIB;
+	float friction, restitution, tangentSpeed;
+	int pointCount, contact;
+	/* position part */
+	vec2 localPoints[2], localNormal, localPoint, localCenterA, localCenterB;
+	float radiusA, radiusB;
+	int type, pcPointCount;
+} constraint_t;
+
+struct b2o_world
+{
+	vec2 gravity;
+	int allowSleep, warmStarting, continuous;
+	float inv_dt0;
+	int newFixture;
+	body_t* bodies; int nBodies, capBodies;
+	fixture_t* fixtures; int nFixtures, capFixtures;
+	contact_t* contacts; int nContactSlots, capContacts, liveContacts;
+	int* freeContacts; int nFreeContacts, capFreeContacts;
+	int* moves; int nMoves, capMoves;
+	uint64_t nextSeq;
+	/* proxy id allocator (b2DynamicTree free list) */
+	int nextNode, leafCount;
+	int* freeLeaves; int nFreeLeaves, capFreeLeaves;
+};
+
+#define GROW(ptr, cap, need, type)                                            \
+	do                                                                        \
+	{                                                                         \
+		if ((need) > (cap))                                                   \
+		{                                                                     \
+			int ncap = (cap) ? (cap) * 2 : 64;                                \
+			while (ncap < (need)) ncap *= 2;                                  \
+			(ptr) = (type*)realloc((ptr), (size_t)ncap * sizeof(type));       \
+			(cap) = ncap;                                                     \
+		}                                                                     \
+	} while (0)
+
+b2o_world* b2o_world_create(float gx, float gy, int allow_sleep, int warm_starting, int continuous)
+{
+	b2o_world* w = (b2o_world*)calloc(1, sizeof(b2o_world));
+	w->gravity = v_make(gx, gy);
+	w->allowSleep = allow_sleep;
+	w->warmStarting = warm_starting;
+	w->continuous = continuous;
+	return w;
+}
+
+void b2o_world_destroy(b2o_world* w)
+{
+	if (!w) return;
+	free(w->bodies);
+	free(w->fixtures);
+	free(w->contacts);
+	free(w->freeContacts);
+	free(w->moves);
+	free(w->freeLeaves);
+	free(w);
+}
+
+void b2o_set_gravity(b2o_world* w, float gx, float gy) { w->gravity = v_make(gx, gy); }
+
+void b2o_set_flags(b2o_world* w, int allow_sleep, int warm_starting, int continuous)
+{
+	w->allowSleep = allow_sleep;
+	w->warmStarting = warm_starting;
+	w->continuous = continuous;
+}
+
+/* b2Body::b2Body  Box2D/Dynamics/b2Body.cpp:26-112 */
+int b2o_create_body(b2o_world* w, const b2o_body_def* d)
+{
+	GROW(w->bodies, w->capBodies, w->nBodies + 1, body_t);
+	body_t* b = &w->bodies[w->nBodies];
+	memset(b, 0, sizeof(*b));
+	b->type = d->type;
+	if (d->bullet) b->flags |= BF_BULLET;
+	if (d->fixed_rotation) b->flags |= BF_FIXEDROT;
+	if (d->allow_sleep) b->flags |= BF_AUTOSLEEP;
+	if (d->awake) b->flags |= BF_AWAKE;
+	if (d->active) b->flags |= BF_ACTIVE;
+	b->xf.p = v_make(d->px, d->py);
+	b->xf.q = r_make(d->angle);
+	b->c0 = b->c = b->xf.p;
+	b->a0 = b->a = d->angle;
+	b->v = v_make(d->vx, d->vy);
+	b->w = d->w;
+	b->linearDamping = d->linear_damping;
+	b->angularDamping = d->angular_damping;
+	b->gravityScale = d->gravity_scale;
+	if (d->type == 2) { b->mass = 1.0f; b->invMass = 1.0f; }
+	b->fixtureHead = -1;
+	b->contactHead = -1;
+	b->label = -1;
+	return w->nBodies++;
+}
+
+/* b2PolygonShape::ComputeMass b2PolygonShape.cpp:359-440; b2CircleShape::ComputeMass b2CircleShape.cpp:92-100;
+ * b2EdgeShape::ComputeMass b2EdgeShape.cpp:131-138 */
+static void shape_mass(const b2o_shape* s, float density, float* mass, vec2* center, float* I)
+{
+	if (s->type == SHAPE_CIRCLE)
+	{
+		vec2 p = shape_vert(s, 0);
+		*mass = density * B2O_PI * s->radius * s->radius;
+		*center = p;
+		*I = (*mass) * (0.5f * s->radius * s->radius + v_dot(p, p));
+		return;
+	}
+	if (s->type == SHAPE_EDGE)
+	{
+		*mass = 0.0f;
+		*center = v_scale(0.5f, v_add(shape_vert(s, 0), shape_vert(s, 1)));
+		*I = 0.0f;
+		return;
+	}
+	vec2 c = v_make(0.0f, 0.0f);
+	float area = 0.0f, inertia = 0.0f;
+	vec2 ref = v_make(0.0f, 0.0f);
+	for (int i = 0; i < s->count; ++i) ref = v_add(ref, shape_vert(s, i));
+	ref = v_scale(1.0f / s->count, ref);
+	const float k_inv3 = 1.0f / 3.0f;
+	for (int i = 0; i < s->count; ++i)
+	{
+		vec2 e1 = v_sub(shape_vert(s, i), ref);
+		vec2 e2 = i + 1 < s->count ? v_sub(shape_vert(s, i + 1), ref) : v_sub(shape_vert(s, 0), ref);
+		float D = v_cross(e1, e2);
+		float tri = 0.5f * D;
+		area += tri;
+		c = v_add(c, v_scale(tri * k_inv3, v_add(e1, e2)));
+		float intx2 = e1.x * e1.x + e2.x * e1.x + e2.x * e2.x;
+		float inty2 = e1.y * e1.y + e2.y * e1.y + e2.y * e2.y;
+		inertia += (0.25f * k_inv3 * D) * (intx2 + inty2);
+	}
+	*mass = density * area;
+	c = v_scale(1.0f / area, c);
+	*center = v_add(c, ref);
+	*I = density * inertia;
+	*I += (*mass) * (v_dot(*center, *center) - v_dot(c, c));
+}
+
+/* shape AABBs: b2PolygonShape.cpp:340-357, b2CircleShape.cpp:83-90, b2EdgeShape.cpp:116-129 */
+static void shape_aabb(const b2o_shape* s, xform xf, float out[4])
+{
+	vec2 lower, upper;
+	if (s->type == SHAPE_CIRCLE)
+	{
+		vec2 q = r_mul(xf.q, shape_vert(s, 0));
+		vec2 p = v_make(xf.p.x + q.x, xf.p.y + q.y);
+		out[0] = p.x - s->radius; out[1] = p.y - s->radius;
+		out[2] = p.x + s->radius; out[3] = p.y + s->radius;
+		return;
+	}
+	if (s->type == SHAPE_EDGE)
+	{
+		vec2 a = xf_mul(xf, shape_vert(s, 0)), b = xf_mul(xf, shape_vert(s, 1));
+		lower = v_min(a, b);
+		upper = v_max(a, b);
+	}
+	else
+	{
+		lower = xf_mul(xf, shape_vert(s, 0));
+		upper = lower;
+		for (int i = 1; i < s->count; ++i)
+		{
+			vec2 v = xf_mul(xf, shape_vert(s, i));
+			lower = v_min(lower, v);
+			upper = v_max(upper, v);
+		}
+	}
+	out[0] = lower.x - s->radius; out[1] = lower.y - s->radius;
+	out[2] = upper.x + s->radius; out[3] = upper.y + s->radius;
+}
+
+/* b2Body::ResetMassData  b2Body.cpp:310-385 */
+static void reset_mass(b2o_world* w, body_t* b)
+{
+	b->mass = b->invMass = b->I = b->invI = 0.0f;
+	b->localCenter = v_make(0.0f, 0.0f);
+	if (b->type != 2)
+	{
+		b->c0 = b->c = b->xf.p;
+		b->a0 = b->a;
+		return;
+	}
+	vec2 lc = v_make(0.0f, 0.0f);
+	for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
+	{
+		fixture_t* fx = &w->fixtures[f];
+		if (fx->density == 0.0f) continue;
+		float mass, I;
+		vec2 center;
+		shape_mass(&fx->shape, fx->density, &mass, &center, &I);
+		b->mass += mass;
+		lc = v_add(lc, v_scale(mass, center));
+		b->I += I;
+	}
+	if (b->mass > 0.0f)
+	{
+		b->invMass = 1.0f / b->mass;
+		lc = v_scale(b->invMass, lc);
+	}
+	else
+	{
+		b->mass = 1.0f;
+		b->invMass = 1.0f;
+	}
+	if (b->I > 0.0f && (b->flags & BF_FIXEDROT) == 0)
+	{
+		b->I -= b->mass * v_dot(lc, lc);
+		b->invI = 1.0f / b->I;
+	}
+	else
+	{
+		b->I = 0.0f;
+		b->invI = 0.0f;
+	}
+	vec2 oldCenter = b->c;
+	b->localCenter = lc;
+	b->c0 = b->c = xf_mul(b->xf, lc);
+	b->v = v_add(b->v, v_cross_sv(b->w, v_sub(b->c, oldCenter)));
+}
+
+/* b2DynamicTree::AllocateNode / FreeNode (b2DynamicTree.cpp:53-99): leaf ids depend only on the
+ * create / destroy sequence; an internal parent node is consumed whenever the tree is not empty. */
+static int alloc_proxy_id(b2o_world* w)
+{
+	int id;
+	if (w->nFreeLeaves > 0)
+	{
+		id = w->freeLeaves[--w->nFreeLeaves];
+	}
+	else
+	{
+		id = w->nextNode++;
+		if (w->leafCount > 0) w->nextNode++;
+	}
+	w->leafCount++;
+	return id;
+}
+
+/* b2Body::CreateFixture b2Body.cpp:182-226, b2Fixture::Create/CreateProxies b2Fixture.cpp:42-141,
+ * b2DynamicTree::CreateProxy b2DynamicTree.cpp:105-119, b2BroadPhase::CreateProxy b2BroadPhase.cpp:46-52 */
+int b2o_create_fixture(b2o_world* w, int body, const b2o_fixture_def* d, const b2o_shape* shape)
+{
+	GROW(w->fixtures, w->capFixtures, w->nFixtures + 1, fixture_t);
+	fixture_t* f = &w->fixtures[w->nFixtures];
+	memset(f, 0, sizeof(*f));
+	body_t* b = &w->bodies[body];
+	f->body = body;
+	f->shape = *shape;
+	f->density = d->density;
+	f->friction = d->friction;
+	f->restitution = d->restitution;
+	f->categoryBits = d->category_bits;
+	f->maskBits = d->mask_bits;
+	f->groupIndex = d->group_index;
+	f->isSensor = d->is_sensor;
+	f->thick = d->thick_shape;
+	float aabb[4];
+	shape_aabb(shape, b->xf, aabb);
+	f->fat[0] = aabb[0] - B2O_AABB_EXTENSION;
+	f->fat[1] = aabb[1] - B2O_AABB_EXTENSION;
+	f->fat[2] = aabb[2] + B2O_AABB_EXTENSION;
+	f->fat[3] = aabb[3] + B2O_AABB_EXTENSION;
+	f->proxyId = alloc_proxy_id(w);
+	f->nextInBody = b->fixtureHead;
+	int id = w->nFixtures++;
+	b->fixtureHead = id;
+	GROW(w->moves, w->capMoves, w->nMoves + 1, int);
+	w->moves[w->nMoves++] = id;
+	if (f->density > 0.0f) reset_mass(w, b);
+	w->newFixture = 1;
+	return id;
+}
+
+/* ---- contacts ------------------------------------------------------------------------------------ */
+static int body_active_for_contact(const body_t* b) { return (b->flags & BF_AWAKE) != 0 && b->type != 0; }
+
+/* b2Body::SetAwake(true)  b2Body.h:690-718 */
+static void set_awake(body_t* b)
+{
+	b->flags |= BF_AWAKE;
+	b->sleepTime = 0.0f;
+}
+
+/* b2ContactFilter::ShouldCollide  b2WorldCallbacks.cpp:24-38 */
+static int filter_should_collide(const fixture_t* a, const fixture_t* b)
+{
+	if (a->groupIndex == b->groupIndex && a->groupIndex != 0) return a->groupIndex > 0;
+	return (a->maskBits & b->categoryBits) != 0 && (a->categoryBits & b->maskBits) != 0;
+}
+
+/* which fixture becomes A: b2Contact::Create register table (b2Contact.cpp:42-52, 72-98) */
+static int contact_swap(int t1, int t2)
+{
+	if (t1 == SHAPE_CIRCLE && t2 == SHAPE_CIRCLE) return 0;
+	if (t1 == SHAPE_POLYGON && t2 == SHAPE_CIRCLE) return 0;
+	if (t1 == SHAPE_CIRCLE && t2 == SHAPE_POLYGON) return 1;
+	if (t1 == SHAPE_POLYGON && t2 == SHAPE_POLYGON) return 0;
+	if (t1 == SHAPE_EDGE && t2 == SHAPE_CIRCLE) return 0;
+	if (t1 == SHAPE_CIRCLE && t2 == SHAPE_EDGE) return 1;
+	if (t1 == SHAPE_EDGE && t2 == SHAPE_POLYGON) return 0;
+	if (t1 == SHAPE_POLYGON && t2 == SHAPE_EDGE) return 1;
+	return -1;
+}
+
+static int* edge_head(b2o_world* w, int contact, int side)
+{
+	contact_t* c = &w->contacts[contact];
+	return &w->bodies[side == 0 ? c->bodyA : c->bodyB].contactHead;
+}
+
+/* b2ContactManager::OnContactCreate (:507-564) + b2Contact::b2Contact (b2Contact.cpp:125-159) */
+static void create_contact(b2o_world* w, int fLo, int fHi)
+{
+	int fA = fLo, fB = fHi;
+	int sw = contact_swap(w->fixtures[fA].shape.type, w->fixtures[fB].shape.type);
+	if (sw < 0) return;
+	if (sw == 1) { int t = fA; fA = fB; fB = t; }
+	int slot;
+	if (w->nFreeContacts > 0) slot = w->freeContacts[--w->nFreeContacts];
+	else
+	{
+		GROW(w->contacts, w->capContacts, w->nContactSlots + 1, contact_t);
+		slot = w->nContactSlots++;
+	}
+	contact_t* c = &w->contacts[slot];
+	memset(c, 0, sizeof(*c));
+	c->alive = 1;
+	c->fixtureA = fA;
+	c->fixtureB = fB;
+	c->bodyA = w->fixtures[fA].body;
+	c->bodyB = w->fixtures[fB].body;
+	c->flags = CF_ENABLED;
+	c->proxyLo = w->fixtures[fLo].proxyId;
+	c->proxyHi = w->fixtures[fHi].proxyId;
+	c->friction = sqrtf(w->fixtures[fA].friction * w->fixtures[fB].friction);
+	c->restitution = w->fixtures[fA].restitution > w->fixtures[fB].restitution ? w->fixtures[fA].restitution : w->fixtures[fB].restitution;
+	c->tangentSpeed = 0.0f;
+	c->seq = w->nextSeq++;
+	if (!w->fixtures[fA].isSensor && !w->fixtures[fB].isSensor)
+	{
+		set_awake(&w->bodies[c->bodyA]);
+		set_awake(&w->bodies[c->bodyB]);
+	}
+	for (int side = 0; side < 2; ++side)
+	{
+		int* head = edge_head(w, slot, side);
+		c->prev[side] = -1;
+		c->next[side] = *head;
+		if (*head >= 0) w->contacts[*head >> 1].prev[*head & 1] = slot * 2 + side;
+		*head = slot * 2 + side;
+	}
+	w->liveContacts++;
+}
+
+/* b2ContactManager::Destroy (:120-172) + b2Contact::Destroy (b2Contact.cpp:100-123) */
+static void destroy_contact(b2o_world* w, int slot)
+{
+	contact_t* c = &w->contacts[slot];
+	if (c->m.pointCount > 0 && !w->fixtures[c->fixtureA].isSensor && !w->fixtures[c->fixtureB].isSensor)
+	{
+		set_awake(&w->bodies[c->bodyA]);
+		set_awake(&w->bodies[c->bodyB]);
+	}
+	for (int side = 0; side < 2; ++side)
+	{
+		int p = c->prev[side], n = c->next[side];
+		if (p >= 0) w->contacts[p >> 1].next[p & 1] = n;
+		if (n >= 0) w->contacts[n >> 1].prev[n & 1] = p;
+		int* head = edge_head(w, slot, side);
+		if (*head == slot * 2 + side) *head = n;
+	}
+	c->alive = 0;
+	GROW(w->freeContacts, w->capFreeContacts, w->nFreeContacts + 1, int);
+	w->freeContacts[w->nFreeContacts++] = slot;
+	w->liveContacts--;
+}
+
+static int fat_overlap(const float a[4], const float b[4])
+{
+	/* b2TestOverlap(b2AABB)  b2Collision.h:273-286 */
+	float d1x = b[0] - a[2], d1y = b[1] - a[3];
+	float d2x = a[0] - b[2], d2y = a[1] - b[3];
+	if (d1x > 0.0f || d1y > 0.0f) return 0;
+	if (d2x > 0.0f || d2y > 0.0f) return 0;
+	return 1;
+}
+
+/* b2Body::ShouldCollide  b2Body.cpp:428-449 (no joints in the oracle) */
+static int bodies_should_collide(const body_t* a, const body_t* b)
+{
+	return a->type == 2 || b->type == 2;
+}
+
+/* b2ContactManager::Collide (:177-230) + b2Contact::UpdateImpl (b2Contact.cpp:173-298) + FinishCollide (:388-439) */
+static void collide(b2o_world* w)
+{
+	int nSlots = w->nContactSlots;
+	int* destroys = (int*)malloc(sizeof(int) * (size_t)(nSlots + 1));
+	int* awakes = (int*)malloc(sizeof(int) * (size_t)(nSlots + 1));
+	int nDestroy = 0, nAwake = 0;
+	for (int i = 0; i < nSlots; ++i)
+	{
+		contact_t* c = &w->contacts[i];
+		if (!c->alive) continue;
+		fixture_t* fA = &w->fixtures[c->fixtureA];
+		fixture_t* fB = &w->fixtures[c->fixtureB];
+		body_t* bA = &w->bodies[c->bodyA];
+		body_t* bB = &w->bodies[c->bodyB];
+		if (c->flags & CF_FILTER)
+		{
+			if (!bodies_should_collide(bB, bA) || !filter_should_collide(fA, fB))
+			{
+				destroys[nDestroy++] = i;
+				continue;
+			}
+			c->flags &= ~CF_FILTER;
+		}
+		if (!body_active_for_contact(bA) && !body_active_for_contact(bB)) continue; /* e_inactiveFlag */
+		if (!fat_overlap(fA->fat, fB->fat))
+		{
+			destroys[nDestroy++] = i;
+			continue;
+		}
+		manifold old = c->m;
+		c->flags |= CF_ENABLED;
+		int wasTouching = (c->flags & CF_TOUCHING) != 0;
+		int touching = 0;
+		int sensor = fA->isSensor || fB->isSensor;
+		if (sensor)
+		{
+			touching = 0; /* GJK overlap for sensors is outside the oracle's scope */
+			c->m.pointCount = 0;
+		}
+		else
+		{
+			b2o_evaluate(&c->m, &fA->shape, bA->xf, &fB->shape, bB->xf);
+			touching = c->m.pointCount > 0;
+			for (int k = 0; k < c->m.pointCount; ++k)
+			{
+				c->m.ni[k] = 0.0f;
+				c->m.ti[k] = 0.0f;
+				for (int j = 0; j < old.pointCount; ++j)
+				{
+					if (old.id[j] == c->m.id[k])
+					{
+						c->m.ni[k] = old.ni[j];
+						c->m.ti[k] = old.ti[j];
+						break;
+					}
+				}
+			}
+			if (touching != wasTouching) awakes[nAwake++] = i;
+		}
+		if (touching) c->flags |= CF_TOUCHING; else c->flags &= ~CF_TOUCHING;
+	}
+	/* ConsumeAwakes (:472-485): only fixture A's body (m_nodeB.other twice) */
+	for (int k = 0; k < nAwake; ++k) set_awake(&w->bodies[w->contacts[awakes[k]].bodyA]);
+	for (int k = 0; k < nDestroy; ++k) destroy_contact(w, destroys[k]);
+	free(destroys);
+	free(awakes);
+}
+
+/* ---- broad-phase --------------------------------------------------------------------------------- */
+typedef struct { int lo, hi; int fLo, fHi; } pair_t;
+
+static int pair_cmp(const void* a, const void* b)
+{
+	const pair_t* p = (const pair_t*)a;
+	const pair_t* q = (const pair_t*)b;
+	if (p->lo != q->lo) return p->lo < q->lo ? -1 : 1;
+	if (p->hi != q->hi) return p->hi < q->hi ? -1 : 1;
+	return 0;
+}
+
+/* b2BroadPhase::UpdatePairs (b2BroadPhase.h:211-267) + b2ContactManager::AddPair (:237-312) +
+ * FinishFindNewContacts (:366-386) */
+static void find_new_contacts(b2o_world* w)
+{
+	if (w->nMoves == 0) return;
+	int cap = 1024, n = 0;
+	pair_t* pairs = (pair_t*)malloc(sizeof(pair_t) * (size_t)cap);
+	for (int k = 0; k < w->nMoves; ++k)
+	{
+		int p = w->moves[k];
+		const fixture_t* fp = &w->fixtures[p];
+		for (int q = 0; q < w->nFixtures; ++q)
+		{
+			if (q == p) continue;
+			const fixture_t* fq = &w->fixtures[q];
+			if (!fat_overlap(fp->fat, fq->fat)) continue;
+			if (n == cap)
+			{
+				cap *= 2;
+				pairs = (pair_t*)realloc(pairs, sizeof(pair_t) * (size_t)cap);
+			}
+			pair_t pr;
+			if (fp->proxyId < fq->proxyId) { pr.lo = fp->proxyId; pr.hi = fq->proxyId; pr.fLo = p; pr.fHi = q; }
+			else { pr.lo = fq->proxyId; pr.hi = fp->proxyId; pr.fLo = q; pr.fHi = p; }
+			pairs[n++] = pr;
+		}
+	}
+	qsort(pairs, (size_t)n, sizeof(pair_t), pair_cmp);
+	int prevLo = -1, prevHi = -1;
+	for (int i = 0; i < n; ++i)
+	{
+		if (pairs[i].lo == prevLo && pairs[i].hi == prevHi) continue;
+		prevLo = pairs[i].lo;
+		prevHi = pairs[i].hi;
+		const fixture_t* fA = &w->fixtures[pairs[i].fLo];
+		const fixture_t* fB = &w->fixtures[pairs[i].fHi];
+		if (fA->body == fB->body) continue;
+		/* does a contact already exist? scan bodyB's list like the reference */
+		int exists = 0;
+		for (int e = w->bodies[fB->body].contactHead; e >= 0; e = w->contacts[e >> 1].next[e & 1])
+		{
+			const contact_t* c = &w->contacts[e >> 1];
+			if (c->proxyLo == pairs[i].lo && c->proxyHi == pairs[i].hi)
+			{
+				exists = 1;
+				break;
+			}
+		}
+		if (exists) continue;
+		if (!bodies_should_collide(&w->bodies[fB->body], &w->bodies[fA->body])) continue;
+		if (!filter_should_collide(fA, fB)) continue;
+		create_contact(w, pairs[i].fLo, pairs[i].fHi);
+	}
+	free(pairs);
+	w->nMoves = 0;
+}
+
+/* b2ContactManager::SynchronizeFixtures (:315-364) + FinishSynchronizeFixtures (:441-452) +
+ * b2DynamicTree::MoveProxy (b2DynamicTree.cpp:130-174) */
+static void synchronize_fixtures(b2o_world* w)
+{
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		body_t* b = &w->bodies[i];
+		if (b->type == 0) continue;
+		if ((b->flags & BF_ISLAND) == 0) continue;
+		xform xf1;
+		xf1.q = r_make(b->a0);
+		xf1.p = v_sub(b->c0, r_mul(xf1.q, b->localCenter));
+		for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
+		{
+			fixture_t* fx = &w->fixtures[f];
+			float a1[4], a2[4], aabb[4];
+			shape_aabb(&fx->shape, xf1, a1);
+			shape_aabb(&fx->shape, b->xf, a2);
+			aabb[0] = f_min(a1[0], a2[0]); aabb[1] = f_min(a1[1], a2[1]);
+			aabb[2] = f_max(a1[2], a2[2]); aabb[3] = f_max(a1[3], a2[3]);
+			int contains = fx->fat[0] <= aabb[0] && fx->fat[1] <= aabb[1] && aabb[2] <= fx->fat[2] && aabb[3] <= fx->fat[3];
+			if (contains) continue;
+			vec2 disp = v_sub(b->xf.p, xf1.p);
+			float lo0 = aabb[0] - B2O_AABB_EXTENSION, lo1 = aabb[1] - B2O_AABB_EXTENSION;
+			float hi0 = aabb[2] + B2O_AABB_EXTENSION, hi1 = aabb[3] + B2O_AABB_EXTENSION;
+			vec2 d = v_scale(B2O_AABB_MULTIPLIER, disp);
+			if (d.x < 0.0f) lo0 += d.x; else hi0 += d.x;
+			if (d.y < 0.0f) lo1 += d.y; else hi1 += d.y;
+			fx->fat[0] = lo0; fx->fat[1] = lo1; fx->fat[2] = hi0; fx->fat[3] = hi1;
+			GROW(w->moves, w->capMoves, w->nMoves + 1, int);
+			w->moves[w->nMoves++] = f;
+		}
+	}
+}
+
+/* ---- island solve -------------------------------------------------------------------------------- */
+typedef struct { vec2 c; float a; } pos_t;
+typedef struct { vec2 v; float w; } vel_t;
+
+/* b2ContactSolver::b2ContactSolver (:47-133) + InitializeVelocityConstraints (:142-251) */
+static void init_constraint(b2o_world* w, constraint_t* cc, int contact, const pos_t* positions, const vel_t* velocities,
+	float dtRatio)
+{
+	contact_t* c = &w->contacts[contact];
+	body_t* bA = &w->bodies[c->bodyA];
+	body_t* bB = &w->bodies[c->bodyB];
+	const manifold* mf = &c->m;
+	memset(cc, 0, sizeof(*cc));
+	cc->contact = contact;
+	cc->friction = c->friction;
+	cc->restitution = c->restitution;
+	cc->tangentSpeed = c->tangentSpeed;
+	cc->indexA = bA->islandIndex;
+	cc->indexB = bB->islandIndex;
+	cc->invMassA = bA->invMass; cc->invMassB = bB->invMass;
+	cc->invIA = bA->invI; cc->invIB = bB->invI;
+	cc->pointCount = mf->pointCount;
+	cc->localCenterA = bA->localCenter; cc->localCenterB = bB->localCenter;
+	cc->localNormal = mf->localNormal; cc->localPoint = mf->localPoint;
+	cc->pcPointCount = mf->pointCount;
+	cc->radiusA = w->fixtures[c->fixtureA].shape.radius;
+	cc->radiusB = w->fixtures[c->fixtureB].shape.radius;
+	cc->type = mf->type;
+	for (int j = 0; j < mf->pointCount; ++j)
+	{
+		if (w->warmStarting)
+		{
+			cc->normalImpulse[j] = dtRatio * mf->ni[j];
+			cc->tangentImpulse[j] = dtRatio * mf->ti[j];
+		}
+		cc->localPoints[j] = mf->p[j];
+	}
+	float mA = cc->invMassA, mB = cc->invMassB, iA = cc->invIA, iB = cc->invIB;
+	vec2 cA = positions[cc->indexA].c, cB = positions[cc->indexB].c;
+	float aA = positions[cc->indexA].a, aB = positions[cc->indexB].a;
+	vec2 vA = velocities[cc->indexA].v, vB = velocities[cc->indexB].v;
+	float wA = velocities[cc->indexA].w, wB = velocities[cc->indexB].w;
+	xform xfA, xfB;
+	xfA.q = r_make(aA);
+	xfB.q = r_make(aB);
+	xfA.p = v_sub(cA, r_mul(xfA.q, cc->localCenterA));
+	xfB.p = v_sub(cB, r_mul(xfB.q, cc->localCenterB));
+	/* b2WorldManifold::Initialize  b2Collision.cpp:22-86 */
+	vec2 normal = v_make(0, 0), points[2];
+	points[0] = points[1] = v_make(0, 0);
+	if (mf->type == MANIFOLD_CIRCLES)
+	{
+		normal = v_make(1.0f, 0.0f);
+		vec2 pointA = xf_mul(xfA, mf->localPoint);
+		vec2 pointB = xf_mul(xfB, mf->p[0]);
+		if (v_dist_sq(pointA, pointB) > B2O_EPSILON * B2O_EPSILON)
+		{
+			normal = v_sub(pointB, pointA);
+			v_normalize(&normal);
+		}
+		vec2 ca = v_add(pointA, v_scale(cc->radiusA, normal));
+		vec2 cb = v_sub(pointB, v_scale(cc->radiusB, normal));
+		points[0] = v_scale(0.5f, v_add(ca, cb));
+	}
+	else if (mf->type == MANIFOLD_FACE_A)
+	{
+		normal = r_mul(xfA.q, mf->localNormal);
+		vec2 planePoint = xf_mul(xfA, mf->localPoint);
+		for (int i = 0; i < mf->pointCount; ++i)
+		{
+			vec2 clip = xf_mul(xfB, mf->p[i]);
+			vec2 ca = v_add(clip, v_scale(cc->radiusA - v_dot(v_sub(clip, planePoint), normal), normal));
+			vec2 cb = v_sub(clip, v_scale(cc->radiusB, normal));
+			points[i] = v_scale(0.5f, v_add(ca, cb));
+		}
+	}
+	else
+	{
+		normal = r_mul(xfB.q, mf->localNormal);
+		vec2 planePoint = xf_mul(xfB, mf->localPoint);
+		for (int i = 0; i < mf->pointCount; ++i)
+		{
+			vec2 clip = xf_mul(xfA, mf->p[i]);
+			vec2 cb = v_add(clip, v_scale(cc->radiusB - v_dot(v_sub(clip, planePoint), normal), normal));
+			vec2 ca = v_sub(clip, v_scale(cc->radiusA, normal));
+			points[i] = v_scale(0.5f, v_add(ca, cb));
+		}
+		normal = v_neg(normal);
+	}
+	cc->normal = normal;
+	for (int j = 0; j < cc->pointCount; ++j)
+	{
+		cc->rA[j] = v_sub(points[j], cA);
+		cc->rB[j] = v_sub(points[j], cB);
+		float rnA = v_cross(cc->rA[j], normal), rnB = v_cross(cc->rB[j], normal);
+		float kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+		cc->normalMass[j] = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+		vec2 tangent = v_cross_vs(normal, 1.0f);
+		float rtA = v_cross(cc->rA[j], tangent), rtB = v_cross(cc->rB[j], tangent);
+		float kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+		cc->tangentMass[j] = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+		cc->velocityBias[j] = 0.0f;
+		vec2 rel = v_sub(v_sub(v_add(vB, v_cross_sv(wB, cc->rB[j])), vA), v_cross_sv(wA, cc->rA[j]));
+		float vRel = v_dot(normal, rel);
+		if (vRel < -B2O_VELOCITY_THRESHOLD) cc->velocityBias[j] = -cc->restitution * vRel;
+	}
+	if (cc->pointCount == 2)
+	{
+		float rn1A = v_cross(cc->rA[0], normal), rn1B = v_cross(cc->rB[0], normal);
+		float rn2A = v_cross(cc->rA[1], normal), rn2B = v_cross(cc->rB[1], normal);
+		float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
+		float k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+		float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+		if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12))
+		{
+			cc->K[0] = k11; cc->K[1] = k12; cc->K[2] = k12; cc->K[3] = k22;
+			float a = k11, b = k12, c2 = k12, d = k22;
+			float det = a * d - b * c2;
+			if (det != 0.0f) det = 1.0f / det;
+			cc->nm[0] = det * d;   /* ex.x */
+			cc->nm[2] = -det * b;  /* ey.x */
+			cc->nm[1] = -det * c2; /* ex.y */
+			cc->nm[3] = det * a;   /* ey.y */
+		}
+		else
+		{
+			cc->pointCount = 1;
+		}
+	}
+}
+
+/* b2ContactSolver::WarmStart  :253-291 */
+static void warm_start(const constraint_t* cc, vel_t* vel)
+{
+	float mA = cc->invMassA, iA = cc->invIA, mB = cc->invMassB, iB = cc->invIB;
+	vec2 vA = vel[cc->indexA].v, vB = vel[cc->indexB].v;
+	float wA = vel[cc->indexA].w, wB = vel[cc->indexB].w;
+	vec2 normal = cc->normal, tangent = v_cross_vs(normal, 1.0f);
+	for (int j = 0; j < cc->pointCount; ++j)
+	{
+		vec2 P = v_add(v_scale(cc->normalImpulse[j], normal), v_scale(cc->tangentImpulse[j], tangent));
+		wA -= iA * v_cross(cc->rA[j], P);
+		vA = v_sub(vA, v_scale(mA, P));
+		wB += iB * v_cross(cc->rB[j], P);
+		vB = v_add(vB, v_scale(mB, P));
+	}
+	vel[cc->indexA].v = vA; vel[cc->indexA].w = wA;
+	vel[cc->indexB].v = vB; vel[cc->indexB].w = wB;
+}
+
+static vec2 rel_vel(vec2 vA, float wA, vec2 vB, float wB, vec2 rA, vec2 rB)
+{
+	return v_sub(v_sub(v_add(vB, v_cross_sv(wB, rB)), vA), v_cross_sv(wA, rA));
+}
+
+/* b2ContactSolver::SolveVelocityConstraints  :293-603 */
+static void solve_velocity(constraint_t* cc, vel_t* vel)
+{
+	float mA = cc->invMassA, iA = cc->invIA, mB = cc->invMassB, iB = cc->invIB;
+	vec2 vA = vel[cc->indexA].v, vB = vel[cc->indexB].v;
+	float wA = vel[cc->indexA].w, wB = vel[cc->indexB].w;
+	vec2 normal = cc->normal, tangent = v_cross_vs(normal, 1.0f);
+	for (int j = 0; j < cc->pointCount; ++j)
+	{
+		vec2 dv = rel_vel(vA, wA, vB, wB, cc->rA[j], cc->rB[j]);
+		float vt = v_dot(dv, tangent) - cc->tangentSpeed;
+		float lambda = cc->tangentMass[j] * (-vt);
+		float maxFriction = cc->friction * cc->normalImpulse[j];
+		float newImpulse = f_clamp(cc->tangentImpulse[j] + lambda, -maxFriction, maxFriction);
+		lambda = newImpulse - cc->tangentImpulse[j];
+		cc->tangentImpulse[j] = newImpulse;
+		vec2 P = v_scale(lambda, tangent);
+		vA = v_sub(vA, v_scale(mA, P));
+		wA -= iA * v_cross(cc->rA[j], P);
+		vB = v_add(vB, v_scale(mB, P));
+		wB += iB * v_cross(cc->rB[j], P);
+	}
+	if (cc->pointCount == 1)
+	{
+		vec2 dv = rel_vel(vA, wA, vB, wB, cc->rA[0], cc->rB[0]);
+		float vn = v_dot(dv, normal);
+		float lambda = -cc->normalMass[0] * (vn - cc->velocityBias[0]);
+		float newImpulse = f_max(cc->normalImpulse[0] + lambda, 0.0f);
+		lambda = newImpulse - cc->normalImpulse[0];
+		cc->normalImpulse[0] = newImpulse;
+		vec2 P = v_scale(lambda, normal);
+		vA = v_sub(vA, v_scale(mA, P));
+		wA -= iA * v_cross(cc->rA[0], P);
+		vB = v_add(vB, v_scale(mB, P));
+		wB += iB * v_cross(cc->rB[0], P);
+	}
+	else
+	{
+		vec2 a = v_make(cc->normalImpulse[0], cc->normalImpulse[1]);
+		vec2 dv1 = rel_vel(vA, wA, vB, wB, cc->rA[0], cc->rB[0]);
+		vec2 dv2 = rel_vel(vA, wA, vB, wB, cc->rA[1], cc->rB[1]);
+		float vn1 = v_dot(dv1, normal), vn2 = v_dot(dv2, normal);
+		vec2 b = v_make(vn1 - cc->velocityBias[0], vn2 - cc->velocityBias[1]);
+		b.x -= cc->K[0] * a.x + cc->K[2] * a.y;
+		b.y -= cc->K[1] * a.x + cc->K[3] * a.y;
+		vec2 x;
+		int found = 0;
+		x = v_make(-(cc->nm[0] * b.x + cc->nm[2] * b.y), -(cc->nm[1] * b.x + cc->nm[3] * b.y));
+		if (x.x >= 0.0f && x.y >= 0.0f) found = 1;
+		if (!found)
+		{
+			x.x = -cc->normalMass[0] * b.x;
+			x.y = 0.0f;
+			vn2 = cc->K[1] * x.x + b.y;
+			if (x.x >= 0.0f && vn2 >= 0.0f) found = 1;
+		}
+		if (!found)
+		{
+			x.x = 0.0f;
+			x.y = -cc->normalMass[1] * b.y;
+			vn1 = cc->K[2] * x.y + b.x;
+			if (x.y >= 0.0f && vn1 >= 0.0f) found = 1;
+		}
+		if (!found)
+		{
+			x.x = 0.0f;
+			x.y = 0.0f;
+			vn1 = b.x;
+			vn2 = b.y;
+			if (vn1 >= 0.0f && vn2 >= 0.0f) found = 1;
+		}
+		if (found)
+		{
+			vec2 d = v_sub(x, a);
+			vec2 P1 = v_scale(d.x, normal), P2 = v_scale(d.y, normal);
+			vA = v_sub(vA, v_scale(mA, v_add(P1, P2)));
+			wA -= iA * (v_cross(cc->rA[0], P1) + v_cross(cc->rA[1], P2));
+			vB = v_add(vB, v_scale(mB, v_add(P1, P2)));
+			wB += iB * (v_cross(cc->rB[0], P1) + v_cross(cc->rB[1], P2));
+			cc->normalImpulse[0] = x.x;
+			cc->normalImpulse[1] = x.y;
+		}
+	}
+	vel[cc->indexA].v = vA; vel[cc->indexA].w = wA;
+	vel[cc->indexB].v = vB; vel[cc->indexB].w = wB;
+}
+
+/* b2ContactSolver::SolvePositionConstraints (:676-752) with b2PositionSolverManifold (:620-673), one constraint */
+static float solve_position(const constraint_t* cc, pos_t* pos, float minSeparation)
+{
+	float mA = cc->invMassA, iA = cc->invIA, mB = cc->invMassB, iB = cc->invIB;
+	vec2 cA = pos[cc->indexA].c, cB = pos[cc->indexB].c;
+	float aA = pos[cc->indexA].a, aB = pos[cc->indexB].a;
+	for (int j = 0; j < cc->pcPointCount; ++j)
+	{
+		xform xfA, xfB;
+		xfA.q = r_make(aA);
+		xfB.q = r_make(aB);
+		xfA.p = v_sub(cA, r_mul(xfA.q, cc->localCenterA));
+		xfB.p = v_sub(cB, r_mul(xfB.q, cc->localCenterB));
+		vec2 normal, point;
+		float separation;
+		if (cc->type == MANIFOLD_CIRCLES)
+		{
+			vec2 pointA = xf_mul(xfA, cc->localPoint);
+			vec2 pointB = xf_mul(xfB, cc->localPoints[0]);
+			normal = v_sub(pointB, pointA);
+			v_normalize(&normal);
+			point = v_scale(0.5f, v_add(pointA, pointB));
+			separation = v_dot(v_sub(pointB, pointA), normal) - cc->radiusA - cc->radiusB;
+		}
+		else if (cc->type == MANIFOLD_FACE_A)
+		{
+			normal = r_mul(xfA.q, cc->localNormal);
+			vec2 planePoint = xf_mul(xfA, cc->localPoint);
+			vec2 clip = xf_mul(xfB, cc->localPoints[j]);
+			separation = v_dot(v_sub(clip, planePoint), normal) - cc->radiusA - cc->radiusB;
+			point = clip;
+		}
+		else
+		{
+			normal = r_mul(xfB.q, cc->localNormal);
+			vec2 planePoint = xf_mul(xfB, cc->localPoint);
+			vec2 clip = xf_mul(xfA, cc->localPoints[j]);
+			separation = v_dot(v_sub(clip, planePoint), normal) - cc->radiusA - cc->radiusB;
+			point = clip;
+			normal = v_neg(normal);
+		}
+		vec2 rA = v_sub(point, cA), rB = v_sub(point, cB);
+		minSeparation = f_min(minSeparation, separation);
+		float C = f_clamp(B2O_BAUMGARTE * (separation + B2O_LINEAR_SLOP), -B2O_MAX_LINEAR_CORRECTION, 0.0f);
+		float rnA = v_cross(rA, normal), rnB = v_cross(rB, normal);
+		float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+		float impulse = K > 0.0f ? -C / K : 0.0f;
+		vec2 P = v_scale(impulse, normal);
+		cA = v_sub(cA, v_scale(mA, P));
+		aA -= iA * v_cross(rA, P);
+		cB = v_add(cB, v_scale(mB, P));
+		aB += iB * v_cross(rB, P);
+	}
+	pos[cc->indexA].c = cA; pos[cc->indexA].a = aA;
+	pos[cc->indexB].c = cB; pos[cc->indexB].a = aB;
+	return minSeparation;
+}
+
+/* b2Island::Solve  b2Island.cpp:184-396 */
+static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* islandContacts, int contactCount,
+	float h, float dtRatio, int velIters, int posIters)
+{
+	pos_t* positions = (pos_t*)malloc(sizeof(pos_t) * (size_t)(bodyCount + 1));
+	vel_t* velocities = (vel_t*)malloc(sizeof(vel_t) * (size_t)(bodyCount + 1));
+	constraint_t* cs = (constraint_t*)malloc(sizeof(constraint_t) * (size_t)(contactCount + 1));
+	for (int i = 0; i < bodyCount; ++i)
+	{
+		body_t* b = &w->bodies[islandBodies[i]];
+		b->islandIndex = i;
+		vec2 c = b->c;
+		float a = b->a;
+		vec2 v = b->v;
+		float ww = b->w;
+		if (b->type != 0)
+		{
+			b->c0 = b->c;
+			b->a0 = b->a;
+		}
+		if (b->type == 2)
+		{
+			vec2 acc = v_add(v_scale(b->gravityScale, w->gravity), v_scale(b->invMass, b->force));
+			v = v_add(v, v_scale(h, acc));
+			ww += h * b->invI * b->torque;
+			v = v_scale(1.0f / (1.0f + h * b->linearDamping), v);
+			ww *= 1.0f / (1.0f + h * b->angularDamping);
+		}
+		positions[i].c = c; positions[i].a = a;
+		velocities[i].v = v; velocities[i].w = ww;
+	}
+	for (int i = 0; i < contactCount; ++i) init_constraint(w, &cs[i], islandContacts[i], positions, velocities, dtRatio);
+	if (w->warmStarting)
+	{
+		for (int i = 0; i < contactCount; ++i) warm_start(&cs[i], velocities);
+	}
+	for (int it = 0; it < velIters; ++it)
+	{
+		for (int i = 0; i < contactCount; ++i) solve_velocity(&cs[i], velocities);
+	}
+	/* StoreImpulses :605-618 */
+	for (int i = 0; i < contactCount; ++i)
+	{
+		manifold* m = &w->contacts[cs[i].contact].m;
+		for (int j = 0; j < cs[i].pointCount; ++j)
+		{
+			m->ni[j] = cs[i].normalImpulse[j];
+			m->ti[j] = cs[i].tangentImpulse[j];
+		}
+	}
+	for (int i = 0; i < bodyCount; ++i)
+	{
+		vec2 c = positions[i].c, v = velocities[i].v;
+		float a = positions[i].a, ww = velocities[i].w;
+		vec2 translation = v_scale(h, v);
+		if (v_dot(translation, translation) > B2O_MAX_TRANSLATION_SQ)
+		{
+			float ratio = B2O_MAX_TRANSLATION / v_length(translation);
+			v = v_scale(ratio, v);
+		}
+		float rotation = h * ww;
+		if (rotation * rotation > B2O_MAX_ROTATION_SQ)
+		{
+			float ratio = B2O_MAX_ROTATION / f_abs(rotation);
+			ww *= ratio;
+		}
+		c = v_add(c, v_scale(h, v));
+		a += h * ww;
+		positions[i].c = c; positions[i].a = a;
+		velocities[i].v = v; velocities[i].w = ww;
+	}
+	int positionSolved = 0;
+	for (int it = 0; it < posIters; ++it)
+	{
+		float minSeparation = 0.0f;
+		for (int i = 0; i < contactCount; ++i) minSeparation = solve_position(&cs[i], positions, minSeparation);
+		if (minSeparation >= -3.0f * B2O_LINEAR_SLOP)
+		{
+			positionSolved = 1;
+			break;
+		}
+	}
+	for (int i = 0; i < bodyCount; ++i)
+	{
+		body_t* b = &w->bodies[islandBodies[i]];
+		if (b->type == 0) continue;
+		b->c = positions[i].c;
+		b->a = positions[i].a;
+		b->v = velocities[i].v;
+		b->w = velocities[i].w;
+		b->xf.q = r_make(b->a);
+		b->xf.p = v_sub(b->c, r_mul(b->xf.q, b->localCenter));
+	}
+	if (w->allowSleep)
+	{
+		float minSleepTime = B2O_MAXFLOAT;
+		const float linTolSqr = B2O_LINEAR_SLEEP_TOL * B2O_LINEAR_SLEEP_TOL;
+		const float angTolSqr = B2O_ANGULAR_SLEEP_TOL * B2O_ANGULAR_SLEEP_TOL;
+		for (int i = 0; i < bodyCount; ++i)
+		{
+			body_t* b = &w->bodies[islandBodies[i]];
+			if (b->type == 0) continue;
+			if ((b->flags & BF_AUTOSLEEP) == 0 || b->w * b->w > angTolSqr || v_dot(b->v, b->v) > linTolSqr)
+			{
+				b->sleepTime = 0.0f;
+				minSleepTime = 0.0f;
+			}
+			else
+			{
+				b->sleepTime += h;
+				minSleepTime = f_min(minSleepTime, b->sleepTime);
+			}
+		}
+		if (minSleepTime >= B2O_TIME_TO_SLEEP && positionSolved)
+		{
+			for (int i = 0; i < bodyCount; ++i)
+			{
+				body_t* b = &w->bodies[islandBodies[i]];
+				if (b->type == 0) continue;
+				/* SetAwake(false)  b2Body.h:704-712 */
+				b->flags &= ~BF_AWAKE;
+				b->sleepTime = 0.0f;
+				b->v = v_make(0.0f, 0.0f);
+				b->w = 0.0f;
+				b->force = v_make(0.0f, 0.0f);
+				b->torque = 0.0f;
+			}
+		}
+	}
+	free(positions);
+	free(velocities);
+	free(cs);
+}
+
+/* b2World::Solve  b2World.cpp:1166-1431 */
+static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIters)
+{
+	int nb = w->nBodies;
+	int* islandBodies = (int*)malloc(sizeof(int) * (size_t)(nb + w->liveContacts + 2));
+	int* islandContacts = (int*)malloc(sizeof(int) * (size_t)(w->liveContacts + 1));
+	int* stack = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
+	for (int i = 0; i < nb; ++i) w->bodies[i].label = -1;
+	for (int seedIdx = 0; seedIdx < nb; ++seedIdx)
+	{
+		body_t* seed = &w->bodies[seedIdx];
+		if (seed->type == 0) continue;
+		if (seed->flags & BF_ISLAND) continue;
+		if ((seed->flags & BF_AWAKE) == 0 || (seed->flags & BF_ACTIVE) == 0) continue;
+		int bodyCount = 0, contactCount = 0, sp = 0;
+		stack[sp++] = seedIdx;
+		seed->flags |= BF_ISLAND;
+		while (sp > 0)
+		{
+			int bi = stack[--sp];
+			body_t* b = &w->bodies[bi];
+			islandBodies[bodyCount++] = bi;
+			if (b->type == 0) continue;
+			b->flags |= BF_AWAKE;
+			for (int e = b->contactHead; e >= 0; e = w->contacts[e >> 1].next[e & 1])
+			{
+				contact_t* c = &w->contacts[e >> 1];
+				if (c->flags & CF_ISLAND) continue;
+				if ((c->flags & CF_ENABLED) == 0 || (c->flags & CF_TOUCHING) == 0) continue;
+				if (w->fixtures[c->fixtureA].isSensor || w->fixtures[c->fixtureB].isSensor) continue;
+				islandContacts[contactCount++] = e >> 1;
+				c->flags |= CF_ISLAND;
+				int other = (e & 1) == 0 ? c->bodyB : c->bodyA;
+				if (w->bodies[other].flags & BF_ISLAND) continue;
+				stack[sp++] = other;
+				w->bodies[other].flags |= BF_ISLAND;
+			}
+		}
+		int label = 0x7fffffff;
+		for (int j = 0; j < bodyCount; ++j)
+		{
+			body_t* b = &w->bodies[islandBodies[j]];
+			if (b->type == 0) b->flags &= ~BF_ISLAND;
+			else if (islandBodies[j] < label) label = islandBodies[j];
+		}
+		for (int j = 0; j < bodyCount; ++j)
+		{
+			body_t* b = &w->bodies[islandBodies[j]];
+			if (b->type != 0) b->label = label;
+		}
+		solve_island(w, islandBodies, bodyCount, islandContacts, contactCount, h, dtRatio, velIters, posIters);
+	}
+	free(islandBodies);
+	free(islandContacts);
+	free(stack);
+	synchronize_fixtures(w);
+	find_new_contacts(w);
+	/* ClearPostSolve  b2World.cpp:1433-1465 */
+	for (int i = 0; i < w->nContactSlots; ++i) w->contacts[i].flags &= ~CF_ISLAND;
+	for (int i = 0; i < nb; ++i) w->bodies[i].flags &= ~BF_ISLAND;
+}
+
+/* b2World::Step  b2World.cpp:1613-1710 */
+void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
+{
+	if (w->newFixture)
+	{
+		find_new_contacts(w);
+		w->newFixture = 0;
+	}
+	collide(w);
+	float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
+	float dtRatio = w->inv_dt0 * dt;
+	if (dt > 0.0f) solve(w, dt, dtRatio, velIters, posIters);
+	if (dt > 0.0f) w->inv_dt0 = inv_dt;
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		w->bodies[i].force = v_make(0.0f, 0.0f);
+		w->bodies[i].torque = 0.0f;
+	}
+}
+
+int b2o_body_count(const b2o_world* w) { return w->nBodies; }
+
+void b2o_get_body_states(const b2o_world* w, float* out)
+{
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		const body_t* b = &w->bodies[i];
+		float* o = out + 10 * i;
+		o[0] = b->xf.p.x; o[1] = b->xf.p.y; o[2] = b->a;
+		o[3] = b->v.x; o[4] = b->v.y; o[5] = b->w;
+		o[6] = b->c.x; o[7] = b->c.y;
+		uint32_t f = (b->flags & 0x7cu) | (uint32_t)b->type;
+		memcpy(o + 8, &f, 4);
+		o[9] = b->sleepTime;
+	}
+}
+
+void b2o_get_mass(const b2o_world* w, int body, float* mass, float* inertia, float* lcx, float* lcy)
+{
+	const body_t* b = &w->bodies[body];
+	*mass = b->mass;
+	*inertia = b->I + b->mass * v_dot(b->localCenter, b->localCenter);
+	*lcx = b->localCenter.x;
+	*lcy = b->localCenter.y;
+}
+
+int b2o_contact_count(const b2o_world* w) { return w->liveContacts; }
+
+static int seq_cmp(const void* a, const void* b)
+{
+	const contact_t* p = *(const contact_t* const*)a;
+	const contact_t* q = *(const contact_t* const*)b;
+	return p->seq < q->seq ? -1 : (p->seq > q->seq ? 1 : 0);
+}
+
+/* contacts in creation order (oldest first), like the device array */
+int b2o_get_contacts(const b2o_world* w, int cap, b2o_contact* out)
+{
+	const contact_t** live = (const contact_t**)malloc(sizeof(void*) * (size_t)(w->liveContacts + 1));
+	int n = 0;
+	for (int i = 0; i < w->nContactSlots; ++i) if (w->contacts[i].alive) live[n++] = &w->contacts[i];
+	qsort(live, (size_t)n, sizeof(void*), seq_cmp);
+	if (n > cap) n = cap;
+	for (int i = 0; i < n; ++i)
+	{
+		const contact_t* c = live[i];
+		b2o_contact* o = &out[i];
+		memset(o, 0, sizeof(*o));
+		o->fixture_a = c->fixtureA; o->fixture_b = c->fixtureB;
+		o->body_a = c->bodyA; o->body_b = c->bodyB;
+		o->flags = ((c->flags & CF_TOUCHING) ? 1u : 0u) | ((c->flags & CF_ENABLED) ? 2u : 0u);
+		o->manifold_type = c->m.type;
+		o->point_count = c->m.pointCount;
+		o->local_normal[0] = c->m.localNormal.x; o->local_normal[1] = c->m.localNormal.y;
+		o->local_point[0] = c->m.localPoint.x; o->local_point[1] = c->m.localPoint.y;
+		for (int k = 0; k < 2; ++k)
+		{
+			o->point_local[k][0] = c->m.p[k].x; o->point_local[k][1] = c->m.p[k].y;
+			o->normal_impulse[k] = c->m.ni[k]; o->tangent_impulse[k] = c->m.ti[k];
+			o->id_key[k] = c->m.id[k];
+		}
+		o->friction = c->friction;
+		o->restitution = c->restitution;
+	}
+	free(live);
+	return n;
+}
+
+void b2o_get_island_labels(const b2o_world* w, int32_t* out)
+{
+	for (int i = 0; i < w->nBodies; ++i) out[i] = w->bodies[i].label;
+}
+
+void b2o_get_fat_aabb(const b2o_world* w, int fixture, float out4[4])
+{
+	memcpy(out4, w->fixtures[fixture].fat, 16);
+}

@@ -38,7 +38,9 @@ extern "C"
 
 const char* b2h_backend()
 {
-#ifdef B2H_BACKEND_REF
+#if defined(B2H_BACKEND_NAME)
+	return B2H_BACKEND_NAME;
+#elif defined(B2H_BACKEND_REF)
 	return "reference";
 #else
 	return "amd";
@@ -180,10 +182,12 @@ int b2h_get_contacts(b2h_world* h, int cap, int* ids, int* flags, float* manifol
 		const b2Manifold* m = c->GetManifold();
 		float* o = manifold + 16 * n;
 		memset(o, 0, 16 * sizeof(float));
-		o[0] = (float)m->type;
 		o[1] = (float)m->pointCount;
 		if (m->pointCount > 0)
 		{
+			// type / normal / points are only defined while the manifold has points (the reference never
+			// initialises m_manifold.type of a contact that has not touched yet, b2Contact.cpp:125-159)
+			o[0] = (float)m->type;
 			o[2] = m->localNormal.x;
 			o[3] = m->localNormal.y;
 			o[4] = m->localPoint.x;

@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libb2ref_harness.so")
 AMD_LIB = os.path.join(ROOT, "box2d-mt_amd", "libb2amd_harness.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libb2oracle_harness.so")
 
 HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK = range(7)
 F_CONTINUOUS, F_SLEEP, F_WARM, F_SUBSTEP = 1, 2, 4, 8
@@ -211,6 +212,10 @@ def fnv1a64(arr):
 
 def have_ref():
     return os.path.exists(REF_LIB)
+
+
+def have_oracle():
+    return os.path.exists(ORACLE_LIB)
 
 
 def have_amd():
