@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - world steps/sec of the MI355X-native b2World::Step() hot path.
+
+A "step" is one full Step(1/60 s, 8 velocity / 3 position iterations) of the workload, including the
+mandatory host-visible body-state read-back. The N=1 workload is BASELINE.json
+configs[1]: the Pyramid recipe with 141 rows = 10 011 dynamic boxes on a ground edge (one island),
+CCD off, sleeping and warm starting on, measured in steady state after the warm-up steps. For N>1
+(configs[3]-style sharding) every rank owns one such pyramid island: islands never exchange data, so
+there is no data-path collective ("weak" scaling); `value` counts island-steps of all ranks.
+
+One JSON line is printed by rank 0. Extra objects:
+  roofline      dominant solver kernel: algorithmic bytes per launch / mean launch duration (HIP events
+                on the world's stream), against the 8 TB/s HBM3E peak
+  cpu_baseline  the reference build (oracle/_ref, kind "reference") or the C oracle (kind "port") stepping
+                the same workload on the host cores, bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+
+
+def cpu_baseline(rows, warmup, max_seconds):
+    """Times the reference (or, without it, the C oracle) on the same scene: bounded CPU sample."""
+    import b2harness as bh
+    if bh.have_ref():
+        h, kind = bh.Harness(bh.REF_LIB), "reference"
+    elif bh.have_oracle():
+        h, kind = bh.Harness(bh.ORACLE_LIB), "port"
+        rows = min(rows, 60)  # the oracle's brute-force broad-phase is quadratic
+    else:
+        return None
+    out = {}
+    for threads in (1, 8) if kind == "reference" else (1,):
+        w = h.world(bh.PYRAMID, rows, 1, threads=threads)
+        w.step(warmup)
+        w.reset_profile()
+        t0 = time.perf_counter()
+        steps = 0
+        while steps < 200 and time.perf_counter() - t0 < max_seconds:
+            w.step(10)
+            steps += 10
+        dt = time.perf_counter() - t0
+        out[threads] = (steps / dt, steps, w.body_count, w.profile())
+        w.close()
+    sps1, steps, bodies, prof = out[1]
+    res = {"value": sps1, "unit": "steps/s", "cores": 1, "kind": kind,
+           "sample": "Pyramid %d rows (%d bodies), %d warm-up + %d timed steps, 1 thread" % (rows, bodies, warmup, steps),
+           "ms_per_step": 1000.0 / sps1,
+           "profile_ms": {k: round(v, 4) for k, v in prof.items() if k not in ("steps",)}}
+    if 8 in out:
+        res["value_8_threads"] = out[8][0]
+        res["host_cores"] = os.cpu_count()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=120)
+    ap.add_argument("--rows", type=int, default=141, help="pyramid rows (141 -> 10 011 boxes, BASELINE configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the Step() path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import b2harness as bh
+    import b2hip
+    if not bh.have_amd():
+        raise SystemExit("box2d-mt_amd/libb2amd_harness.so missing: run `python __graft_entry__.py` first")
+    amd = bh.Harness(bh.AMD_LIB)
+    hipL = b2hip.lib()
+
+    # one pyramid island per rank (hipSetDevice above selects this rank's GPU for the world's stream)
+    w = amd.world(bh.PYRAMID, args.rows, 1)
+    nbodies = w.body_count
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    w.step(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    w.step(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- solver roofline: per-launch HIP-event timing of the dominant kernel, separate pass ----------
+    roof = None
+    try:
+        amd.lib.b2h_device_world.restype = C.c_void_p
+        amd.lib.b2h_device_world.argtypes = [C.c_void_p]
+        dev = amd.lib.b2h_device_world(w.ptr)
+        hipL.b2hip_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        hipL.b2hip_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char), C.c_int, C.POINTER(C.c_float),
+                                                 C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        hipL.b2hip_set_kernel_timing(dev, 1)
+        names = {}
+        for _ in range(20):
+            w.step(1)
+            buf = C.create_string_buffer(64)
+            ms, launches, nbytes = C.c_float(), C.c_int(), C.c_double()
+            hipL.b2hip_get_kernel_timing(dev, buf, 64, C.byref(ms), C.byref(launches), C.byref(nbytes))
+            k = buf.value.decode()
+            acc = names.setdefault(k, [0.0, 0, 0.0])
+            acc[0] += ms.value
+            acc[1] += launches.value
+            acc[2] += nbytes.value
+        hipL.b2hip_set_kernel_timing(dev, 0)
+        kname, (tot_ms, launches, tot_bytes) = max(names.items(), key=lambda kv: kv[1][0])
+        ctr = b2hip.Counters()
+        hipL.b2hip_get_counters(dev, C.byref(ctr))
+        if launches > 0 and tot_ms > 0:
+            achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "launches_per_step": launches / 20.0, "mean_launch_us": 1000.0 * tot_ms / launches,
+                    "algorithmic_bytes_per_launch": tot_bytes / launches,
+                    "constraints": ctr.large_island_contacts + ctr.small_island_contacts,
+                    "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors}
+        smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
+        hipL.b2hip_get_solver_timing(dev, C.byref(smsv), C.byref(sbytes), C.byref(sct), C.byref(sb))
+        if roof is not None and smsv.value > 0:
+            roof["solver_phase"] = {"ms": smsv.value, "algorithmic_bytes": sbytes.value,
+                                    "achieved": sbytes.value / (smsv.value * 1e-3) / 1e9,
+                                    "frac": sbytes.value / (smsv.value * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    except Exception as e:  # the timing hooks are best effort; the headline number does not depend on them
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "error": str(e)}
+
+    prof = w.profile()
+    contacts = w.contact_count
+    w.close()
+
+    if rank == 0:
+        total_steps = args.steps * world_size
+        line = {
+            "metric": "world steps/sec (Step = collide + island solve + broad-phase + state read-back), 10 011-body pyramid island per GPU",
+            "value": total_steps / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Pyramid %d rows: %d bodies, %d contacts per GPU, dt 1/60, 8 vel / 3 pos iterations, CCD off, sleep + warm start on"
+                                   % (args.rows, nbodies, contacts),
+                       "bodies_total": nbodies * world_size, "parallelism": "one island shard per GPU, no data-path collective"},
+            "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if world_size == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.rows, min(args.warmup, 120), args.cpu_seconds)
+            if cb is not None:
+                line["cpu_baseline"] = cb
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

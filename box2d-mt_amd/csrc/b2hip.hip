@@ -180,6 +180,14 @@ struct b2hip_world
 	double solverBytes;
 	int solverConstraints, solverBodies;
 	int forceLarge;
+	// optional per-launch timing of the dominant solver kernel
+	int kernelTiming;
+	std::vector<hipEvent_t> ktEvents;
+	int ktUsed;          // events recorded this step (pairs)
+	int ktKind;          // 0 none, 1 k_large_velocity, 2 k_solve_small
+	float ktMs;
+	int ktLaunches;
+	double ktBytes;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -353,6 +361,19 @@ static int syncCheck(b2hip_world* w, const char* what)
 		int _rc = syncCheck((w), #kernel);                                                    \
 		if (_rc) return _rc;                                                                  \
 	} while (0)
+
+static int ktRecord(b2hip_world* w)
+{
+	if (!w->kernelTiming) return 0;
+	if ((size_t)w->ktUsed >= w->ktEvents.size())
+	{
+		hipEvent_t e;
+		HIP_TRY(hipEventCreate(&e));
+		w->ktEvents.push_back(e);
+	}
+	HIP_TRY(hipEventRecord(w->ktEvents[w->ktUsed++], w->stream));
+	return 0;
+}
 
 static int gridFor(size_t n, int block = 256, int maxBlocks = 2048)
 {
@@ -701,6 +722,8 @@ static int phaseSolve(b2hip_world* w)
 {
 	DW& d = w->dw;
 	const StepParams& sp = w->sp;
+	w->ktUsed = 0;
+	w->ktKind = 0;
 	LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_island_union, gridFor(d.capContacts), 256, d);
 	LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
@@ -729,7 +752,13 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
 		LAUNCH(w, k_island_chunks, gridFor(c.nSIslands), 256, d);
 		HIP_TRY(hipEventRecord(w->ev[5], w->stream));
-		if (!exactLarge) LAUNCH(w, k_solve_small, c.nChunks, SMALL_CHUNK_LANES, d, sp);
+		if (!exactLarge)
+		{
+			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
+			if (timeIt) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 2; }
+			LAUNCH(w, k_solve_small, c.nChunks, SMALL_CHUNK_LANES, d, sp);
+			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
+		}
 		HIP_TRY(hipEventRecord(w->ev[6], w->stream));
 	}
 	else
@@ -784,7 +813,12 @@ static int phaseSolve(b2hip_world* w)
 		}
 		for (int it = 0; it < sp.velIters; ++it)
 		{
-			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_velocity, gK, 256, d, col, 1);
+			for (int col = 0; col < nColors; ++col)
+			{
+				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
+				LAUNCH(w, k_large_velocity, gK, 256, d, col, 1);
+				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
+			}
 		}
 		LAUNCH(w, k_large_store_impulses, gC, 256, d);
 		LAUNCH(w, k_large_integrate_positions, gB, 256, d, sp);
@@ -911,6 +945,12 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverMs = 0.0f;
 	w->solverBytes = 0.0;
 	w->solverConstraints = w->solverBodies = 0;
+	w->kernelTiming = 0;
+	w->ktUsed = 0;
+	w->ktKind = 0;
+	w->ktMs = 0.0f;
+	w->ktLaunches = 0;
+	w->ktBytes = 0.0;
 	w->dw.cellSize = 1.0f;
 	w->dw.invCellSize = 1.0f;
 	for (int i = 0; i < 12; ++i)
@@ -1310,6 +1350,21 @@ int b2hip_step_end(b2hip_world* w)
 	w->solverBodies = B;
 	// Ct*(Nv*220 + Np*136 + 488) + B*240 with Np = configured position iterations
 	w->solverBytes = (double)Ct * (w->sp.velIters * 220.0 + w->sp.posIters * 136.0 + 488.0) + (double)B * 240.0;
+	w->ktMs = 0.0f;
+	w->ktLaunches = 0;
+	w->ktBytes = 0.0;
+	if (w->kernelTiming && w->ktUsed >= 2)
+	{
+		for (int k = 0; k + 1 < w->ktUsed; k += 2)
+		{
+			float t = 0.0f;
+			(void)hipEventElapsedTime(&t, w->ktEvents[k], w->ktEvents[k + 1]);
+			w->ktMs += t;
+			w->ktLaunches += 1;
+		}
+		if (w->ktKind == 1) w->ktBytes = (double)w->last.nLContacts * 220.0 * w->sp.velIters;
+		else w->ktBytes = (double)w->last.nSContacts * (w->sp.velIters * 220.0 + w->sp.posIters * 136.0 + 488.0) + (double)w->last.nSBodies * 240.0;
+	}
 	return 0;
 }
 
@@ -1460,6 +1515,28 @@ int b2hip_get_solver_timing(b2hip_world* w, float* ms, double* algorithmic_bytes
 	if (algorithmic_bytes) *algorithmic_bytes = w->solverBytes;
 	if (constraints) *constraints = w->solverConstraints;
 	if (bodies) *bodies = w->solverBodies;
+	return 0;
+}
+
+int b2hip_set_kernel_timing(b2hip_world* w, int enable)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	w->kernelTiming = enable;
+	return 0;
+}
+
+int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : "");
+	if (name && name_cap > 0)
+	{
+		strncpy(name, n, (size_t)name_cap - 1);
+		name[name_cap - 1] = 0;
+	}
+	if (total_ms) *total_ms = w->ktMs;
+	if (launches) *launches = w->ktLaunches;
+	if (algorithmic_bytes) *algorithmic_bytes = w->ktBytes;
 	return 0;
 }
 

@@ -216,6 +216,15 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out);
  * (Ct*(Nv*220 + Np*136 + 488) + B*240). */
 int b2hip_get_solver_timing(b2hip_world* w, float* ms, double* algorithmic_bytes, int* constraints, int* bodies);
 
+/* Per-launch timing of the dominant solver kernel (k_large_velocity for coloured large islands, k_solve_small
+ * for in-LDS small islands): when enabled, every launch of it is bracketed by a HIP event pair on the world's
+ * stream. b2hip_get_kernel_timing reports, for the last step, the kernel's name, the SUM of its launch
+ * durations (ms), the launch count and the algorithmic bytes those launches processed (220 B per constraint
+ * per velocity sweep, resp. the whole 8d formula for the fused small-island kernel). Off by default: the event
+ * pairs cost host time, so the timed region of bench.py runs without them. */
+int b2hip_set_kernel_timing(b2hip_world* w, int enable);
+int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes);
+
 #ifdef __cplusplus
 }
 #endif

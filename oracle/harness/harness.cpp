@@ -103,6 +103,18 @@ void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
 	}
 }
 
+// The C-ABI world behind the drop-in b2World (NULL for the reference backend): lets bench.py reach the
+// measurement hooks of include/b2hip.h without going around the public API for stepping.
+void* b2h_device_world(b2h_world* h)
+{
+#if defined(B2H_BACKEND_AMD)
+	return (void*)h->world->GetDeviceWorld();
+#else
+	(void)h;
+	return NULL;
+#endif
+}
+
 int b2h_body_count(b2h_world* h)
 {
 	return (int)h->scene.bodies.size();

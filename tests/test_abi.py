@@ -1,0 +1,65 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/b2hip.h
+declares, and refuses to run without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "box2d-mt_amd", "libb2hip.so")
+HDR = os.path.join(ROOT, "include", "b2hip.h")
+
+
+def declared_symbols():
+    text = open(HDR).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(b2hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_step_path():
+    syms = declared_symbols()
+    for must in ("b2hip_world_create", "b2hip_step", "b2hip_collide", "b2hip_solve", "b2hip_sync_fixtures",
+                 "b2hip_find_new_contacts", "b2hip_get_body_states", "b2hip_get_contacts", "b2hip_get_profile"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        pytest.fail("libb2hip.so missing: run __graft_entry__.build()")
+    lib = C.CDLL(LIB)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert missing == []
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU, world creation must fail loudly with B2HIP_ERR_NO_DEVICE (never silently step on the CPU)."""
+    import b2hip
+    L = b2hip.lib()
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    d = b2hip.WorldDef(0.0, -10.0, 1, 1, 0, 0, 1, -1)
+    p = C.c_void_p()
+    rc = L.b2hip_world_create(C.byref(d), C.byref(p))
+    if has_gpu:
+        assert rc == 0
+        L.b2hip_world_destroy(p)
+    else:
+        assert rc == -3, "expected B2HIP_ERR_NO_DEVICE, got %d" % rc
+        assert b"no CPU fallback" in L.b2hip_last_error()
+
+
+def test_product_does_not_link_the_oracle():
+    """The shipped libraries must not depend on anything under oracle/."""
+    import subprocess
+    for so in ("libb2hip.so", "libb2amd_harness.so"):
+        path = os.path.join(ROOT, "box2d-mt_amd", so)
+        if not os.path.exists(path):
+            pytest.fail(so + " missing")
+        out = subprocess.check_output(["ldd", path]).decode()
+        assert "oracle" not in out
+        syms = subprocess.check_output(["nm", "-D", path]).decode()
+        assert "b2o_" not in syms
