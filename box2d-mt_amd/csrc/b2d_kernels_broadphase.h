@@ -147,49 +147,66 @@ __device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q
 	}
 }
 
-// One lane per moved SMALL proxy: 3x3 cells + every large proxy.
+// One WAVE per moved SMALL proxy. The candidates of its 3x3 cell neighbourhood are flattened into one
+// index space so that 64 candidates are fetched and tested at once (the per-candidate chain
+// item -> fat AABB -> filters -> hash probe is then paid once per wave, not once per candidate).
 __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 {
 	DState* S = W.st;
 	const int nm = S->c.nMoves < W.capMoves ? S->c.nMoves : W.capMoves;
 	const int nLarge = S->c.nLargeProxies;
-	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nm; k += gridDim.x * blockDim.x)
+	const int lane = (int)(threadIdx.x & 63u);
+	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
+	for (int k = waveId; k < nm; k += nWaves)
 	{
 		const int p = W.moveBuf[k];
 		if (p < 0 || W.p_body[p] < 0) continue;
-		float4 a4 = W.p_fat[p];
+		const float4 a4 = W.p_fat[p];
 		if (proxyIsLarge(W, a4)) continue;
 		AABB a;
 		a.lo = v2(a4.x, a4.y);
 		a.hi = v2(a4.z, a4.w);
 		int ix, iy;
 		proxyCell(W, a4, &ix, &iy);
-		uint32_t seen[9];
-		int nSeen = 0;
-		for (int dy = -1; dy <= 1; ++dy)
+		// lanes 0..8 own one neighbour cell each; cells that hash to an already seen bucket are dropped
+		uint32_t h = lane < 9 ? cellHash(ix + (lane % 3) - 1, iy + (lane / 3) - 1, W.gridMask) : 0xffffffffu;
+		bool dup = false;
+		for (int j = 0; j < 9; ++j)
 		{
-			for (int dx = -1; dx <= 1; ++dx)
+			uint32_t hj = (uint32_t)__shfl((int)h, j);
+			if (j < lane && lane < 9 && hj == h) dup = true;
+		}
+		const int cnt = (lane < 9 && !dup) ? W.gridCount[h] : 0;
+		const int start = lane < 9 ? W.gridStart[h] : 0;
+		int incl = cnt;
+		for (int off = 1; off < 16; off <<= 1)
+		{
+			int v = __shfl_up(incl, off);
+			if (lane >= off) incl += v;
+		}
+		const int excl = incl - cnt;
+		const int total = __shfl(incl, 8);
+		for (int base = 0; base < total; base += 64)
+		{
+			const int idx = base + lane;
+			const bool valid = idx < total;
+			int t = -1;
+			for (int c = 0; c < 9; ++c)
 			{
-				uint32_t h = cellHash(ix + dx, iy + dy, W.gridMask);
-				bool dup = false;
-				for (int t = 0; t < nSeen; ++t) dup = dup || seen[t] == h;
-				if (dup) continue;
-				seen[nSeen++] = h;
-				const int s = W.gridStart[h], e = s + W.gridCount[h];
-				for (int t = s; t < e; ++t)
-				{
-					const int q = W.gridItems[t];
-					if (q == p) continue;
-					if (!b2dAabbOverlap(a, loadAabb(W.p_fat, q))) continue;
-					tryEmitPair(W, S, p, q);
-				}
+				const int ec = __shfl(excl, c), cc = __shfl(cnt, c), sc = __shfl(start, c);
+				if (valid && idx >= ec && idx < ec + cc) t = sc + (idx - ec);
+			}
+			if (t >= 0)
+			{
+				const int q = W.gridItems[t];
+				if (q != p && b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 			}
 		}
-		for (int t = 0; t < nLarge; ++t)
+		for (int t = lane; t < nLarge; t += 64)
 		{
 			const int q = W.largeProxies[t];
-			if (!b2dAabbOverlap(a, loadAabb(W.p_fat, q))) continue;
-			tryEmitPair(W, S, p, q);
+			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
 }
@@ -343,6 +360,7 @@ __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* k
 		C.man1[dst] = make_float4(0, 0, 0, 0);
 		C.imp[dst] = make_float4(0, 0, 0, 0);
 		C.man3[dst] = make_int4(0, 0, 0, 0);
+		C.color[dst] = -1;
 		if (!sensor)
 		{
 			// SetAwake(true) on both bodies (:525-529), applied by k_apply_wake

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 			B.man1[j] = A.man1[i];
 			B.imp[j] = A.imp[i];
 			B.man3[j] = A.man3[i];
+			B.color[j] = A.color[i];
 		}
 	}
 }

@@ -13,6 +13,7 @@
 #define B2D_KERNELS_ISLAND_H
 
 #include "b2d_kernels_collide.h"
+#include "b2d_wave.h"
 
 #define ROOT_NONE 0
 #define ROOT_SMALL 1
@@ -26,11 +27,16 @@ __device__ __forceinline__ bool contactSolid(uint32_t flags)
 
 __device__ __forceinline__ int ufFind(int* parent, int i)
 {
+	// find with path halving: every visited node is re-pointed at its grandparent. Any ancestor is a valid
+	// parent at any time (links only ever go from a root to a smaller id), so this is safe under concurrency
+	// and keeps chains short when ten thousand bodies collapse into one component.
 	int r = i;
 	for (;;)
 	{
 		int p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (p == r) break;
+		int g = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (g != p) __hip_atomic_store(&parent[r], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		r = p;
 	}
 	return r;
@@ -129,16 +135,21 @@ __global__ __launch_bounds__(256) void k_island_union(DW W)
 __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 {
 	const int n = W.nBodies;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
-		uint32_t f = W.b_flags[i];
-		if ((f & BF_TYPE_MASK) == BT_STATIC) continue;
-		if ((f & BF_ACTIVE) == 0) continue;
-		int r = ufFind(W.parent, i);
-		__hip_atomic_store(&W.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		atomicAdd(&W.rootBodies[r], 1);
+		const int i = base + threadIdx.x;
+		bool valid = i < n;
+		uint32_t f = valid ? W.b_flags[i] : 0u;
+		valid = valid && (f & BF_TYPE_MASK) != BT_STATIC && (f & BF_ACTIVE) != 0;
+		int r = 0;
+		if (valid)
+		{
+			r = ufFind(W.parent, i);
+			__hip_atomic_store(&W.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		waveAtomicAddInt(W.rootBodies, r, 1, valid);
 		// seeds are taken in m_nonStaticBodies order (b2World.cpp:1207-1221): first awake, active body
-		if (f & BF_AWAKE) atomicMin(&W.rootSeed[r], i);
+		waveAtomicMinInt(W.rootSeed, r, i, valid && (f & BF_AWAKE) != 0);
 	}
 }
 
@@ -147,13 +158,19 @@ __global__ __launch_bounds__(256) void k_island_count(DW W)
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
-		if (!contactSolid(C.flags[i])) continue;
-		int4 ids = C.ids[i];
-		int b = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC ? ids.z : ids.w;
-		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
-		atomicAdd(&W.rootContacts[W.parent[b]], 1);
+		const int i = base + threadIdx.x;
+		bool valid = i < n && contactSolid(C.flags[i]);
+		int root = 0;
+		if (valid)
+		{
+			int4 ids = C.ids[i];
+			int b = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC ? ids.z : ids.w;
+			valid = (W.b_flags[b] & BF_TYPE_MASK) != BT_STATIC;
+			if (valid) root = W.parent[b];
+		}
+		waveAtomicAddInt(W.rootContacts, root, 1, valid);
 	}
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
 	{

@@ -90,11 +90,98 @@ __global__ __launch_bounds__(256) void k_color_begin(DW W)
 		W.colorCount[threadIdx.x] = 0;
 		W.colorCursor[threadIdx.x] = 0;
 	}
+	// a full recolour forgets every stored colour (also those of non-touching contacts)
+	{
+		const ContactArrays& C = W.ca[S->cur];
+		const int nAll = S->c.nContacts;
+		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAll; i += gridDim.x * blockDim.x) C.color[i] = -1;
+	}
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		W.bodyColorMask[i] = 0;
+		W.bodyClaim[i] = 0;
+	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		S->c.nUncolored = n;
 		S->c.colorRounds = 0;
 		S->c.nColors = 0;
+	}
+}
+
+// Colours persist with the contact (ContactArrays::color). A step can reuse them if every constraint of
+// the large islands already has one and no two constraints on a body share a colour; otherwise the host
+// runs the colouring rounds again. Also builds the per-colour census for the reuse case.
+__global__ __launch_bounds__(256) void k_color_check(DW W)
+{
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	int bad = 0;
+	int uncolored = 0;
+	int maxColor = 0;
+	// (1) every contact that owns a colour - touching or not, large island or not - reserves it on its
+	// bodies, so a constraint that stops touching for a few steps finds its colour still free when it
+	// comes back and colours handed out meanwhile can never clash with it
+	const int nAll = S->c.nContacts;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAll; i += gridDim.x * blockDim.x)
+	{
+		const int col = C.color[i];
+		if (col < 0 || col >= MAX_COLORS) continue;
+		int4 ids = C.ids[i];
+		const unsigned long long bit = 1ull << col;
+		if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC)
+		{
+			unsigned long long old = atomicOr((unsigned long long*)&W.bodyColorMask[ids.z], bit);
+			if (old & bit) bad = 1;
+		}
+		if ((W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC)
+		{
+			unsigned long long old = atomicOr((unsigned long long*)&W.bodyColorMask[ids.w], bit);
+			if (old & bit) bad = 1;
+		}
+	}
+	// (2) census of the large-island constraints by colour
+	const int n = S->c.nLContacts;
+	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
+	{
+		const int s = base + threadIdx.x;
+		const bool valid = s < n;
+		int col = -1;
+		if (valid)
+		{
+			col = C.color[W.li_contacts[s]];
+			if (col < 0 || col >= MAX_COLORS)
+			{
+				++uncolored;
+				col = -1;
+			}
+			else if (col + 1 > maxColor)
+			{
+				maxColor = col + 1;
+			}
+			W.li_color[s] = col;
+		}
+		(void)waveKeyedAlloc(W.colorCount, col < 0 ? 0 : col, valid && col >= 0);
+	}
+	// needRecolor bit0: two constraints on one body share a colour -> colour everything again;
+	// nUncolored: constraints without a colour yet -> incremental rounds on top of the existing masks
+	if (bad) atomicOr(&S->c.needRecolor, 1);
+	if (uncolored) atomicAdd(&S->c.nUncolored, uncolored);
+	if (maxColor) atomicMax(&S->c.nColors, maxColor);
+}
+
+__global__ void k_color_check_begin(DW W)
+{
+	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS)
+	{
+		W.colorCount[threadIdx.x] = 0;
+		W.colorCursor[threadIdx.x] = 0;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		W.st->c.needRecolor = 0;
+		W.st->c.nColors = 0;
+		W.st->c.nUncolored = 0;
 	}
 }
 
@@ -144,6 +231,7 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 		if (nsA) { W.bodyColorMask[ids.z] |= bit; W.bodyClaim[ids.z] = 0; }
 		if (nsB) { W.bodyColorMask[ids.w] |= bit; W.bodyClaim[ids.w] = 0; }
 		W.li_color[s] = color;
+		C.color[ci] = color;
 		atomicAdd(&W.colorCount[color], 1);
 		atomicMax(&S->c.nColors, color + 1);
 		++colored;
@@ -216,12 +304,23 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 {
 	DState* S = W.st;
 	const int n = S->c.nLContacts;
-	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+	const ContactArrays& C = W.ca[S->cur];
+	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
-		int color = W.li_color[s];
-		if (color < 0) continue;
-		int p = W.colorStart[color] + atomicAdd(&W.colorCursor[color], 1);
-		W.li_sorted[p] = s;
+		const int s = base + threadIdx.x;
+		const bool valid = s < n && W.li_color[s] >= 0;
+		const int color = valid ? W.li_color[s] : 0;
+		const int slot = waveKeyedAlloc(W.colorCursor, color, valid);
+		if (valid)
+		{
+			const int p = W.colorStart[color] + slot;
+			const int ci = W.li_contacts[s];
+			int4 ids = C.ids[ci];
+			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			W.li_sorted[p] = s;
+			W.li_ref[p] = make_int4(ci, nsA ? ids.z : -(ids.z + 1), nsB ? ids.w : -(ids.w + 1), W.parent[nsA ? ids.z : ids.w]);
+		}
 	}
 }
 
@@ -234,14 +333,15 @@ struct LargeRef
 
 __device__ __forceinline__ LargeRef largeRef(const DW& W, const ContactArrays& C, int row)
 {
+	(void)C;
+	const int4 q = W.li_ref[row];
 	LargeRef r;
-	r.ci = W.li_contacts[W.li_sorted[row]];
-	int4 ids = C.ids[r.ci];
-	r.bodyA = ids.z;
-	r.bodyB = ids.w;
-	r.nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
-	r.nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-	r.root = W.parent[r.nsA ? ids.z : ids.w];
+	r.ci = q.x;
+	r.nsA = q.y >= 0;
+	r.nsB = q.z >= 0;
+	r.bodyA = r.nsA ? q.y : -(q.y + 1);
+	r.bodyB = r.nsB ? q.z : -(q.z + 1);
+	r.root = q.w;
 	return r;
 }
 
@@ -321,7 +421,7 @@ __global__ __launch_bounds__(256) void k_large_store_impulses(DW W)
 	const ContactArrays& C = W.ca[S->cur];
 	for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x)
 	{
-		const int ci = W.li_contacts[W.li_sorted[row]];
+		const int ci = W.li_ref[row].x;
 		ContactConstraint cc;
 		memset(&cc, 0, sizeof(cc));
 		lcLoad(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
@@ -367,23 +467,33 @@ __global__ __launch_bounds__(256) void k_large_position(DW W, int color)
 	if (S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];
 	const int begin = W.colorStart[color], end = W.colorStart[color + 1];
-	for (int row = begin + blockIdx.x * blockDim.x + threadIdx.x; row < end; row += gridDim.x * blockDim.x)
+	for (int base = begin + blockIdx.x * blockDim.x; base < end; base += gridDim.x * blockDim.x)
 	{
-		LargeRef r = largeRef(W, C, row);
-		if (W.rootDone[r.root]) continue;
-		ContactConstraint cc;
-		memset(&cc, 0, sizeof(cc));
-		lcLoad(W, row, cc, LC_MASS_FIRST, LC_MASS_FIRST + 4);
-		lcLoad(W, row, cc, LC_POS_FIRST, LC_WORDS);
-		float4 pa = W.b_pos[r.bodyA], pb = W.b_pos[r.bodyB];
-		BodyPos pA, pB;
-		pA.c = v2(pa.x, pa.y); pA.a = pa.z;
-		pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+		const int row = base + threadIdx.x;
+		bool valid = row < end;
+		LargeRef r;
+		r.root = 0;
+		if (valid)
+		{
+			r = largeRef(W, C, row);
+			valid = W.rootDone[r.root] == 0;
+		}
 		float minSep = 0.0f;
-		b2dSolvePosition(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
-		if (r.nsA) W.b_pos[r.bodyA] = make_float4(pA.c.x, pA.c.y, pA.a, pa.w);
-		if (r.nsB) W.b_pos[r.bodyB] = make_float4(pB.c.x, pB.c.y, pB.a, pb.w);
-		atomicMax(&W.rootPen[r.root], floatBits(0.0f - minSep));
+		if (valid)
+		{
+			ContactConstraint cc;
+			memset(&cc, 0, sizeof(cc));
+			lcLoad(W, row, cc, LC_MASS_FIRST, LC_MASS_FIRST + 4);
+			lcLoad(W, row, cc, LC_POS_FIRST, LC_WORDS);
+			float4 pa = W.b_pos[r.bodyA], pb = W.b_pos[r.bodyB];
+			BodyPos pA, pB;
+			pA.c = v2(pa.x, pa.y); pA.a = pa.z;
+			pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+			b2dSolvePosition(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
+			if (r.nsA) W.b_pos[r.bodyA] = make_float4(pA.c.x, pA.c.y, pA.a, pa.w);
+			if (r.nsB) W.b_pos[r.bodyB] = make_float4(pB.c.x, pB.c.y, pB.a, pb.w);
+		}
+		waveAtomicMaxU32(W.rootPen, r.root, floatBits(0.0f - minSep), valid);
 	}
 }
 
@@ -425,29 +535,37 @@ __global__ __launch_bounds__(256) void k_large_finalize(DW W, StepParams sp)
 {
 	DState* S = W.st;
 	const int n = S->c.nLBodies;
-	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
-		const int body = W.li_bodies[k];
-		float4 p = W.b_pos[body], v = W.b_vel[body], m = W.b_mass[body];
-		Xf xf = b2dXfFromSweep(v2(p.x, p.y), p.z, v2(m.z, m.w));
-		W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
-		if (sp.allowSleep)
+		const int k = base + threadIdx.x;
+		const bool valid = k < n;
+		int root = 0;
+		float sleepTime = 0.0f;
+		if (valid)
 		{
-			const float linTolSqr = B2D_LINEAR_SLEEP_TOL * B2D_LINEAR_SLEEP_TOL;
-			const float angTolSqr = B2D_ANGULAR_SLEEP_TOL * B2D_ANGULAR_SLEEP_TOL;
-			uint32_t f = W.b_flags[body];
-			float sleepTime = p.w;
-			if ((f & BF_AUTOSLEEP) == 0 || v.z * v.z > angTolSqr || b2dDot(v2(v.x, v.y), v2(v.x, v.y)) > linTolSqr)
+			const int body = W.li_bodies[k];
+			float4 p = W.b_pos[body], v = W.b_vel[body], m = W.b_mass[body];
+			Xf xf = b2dXfFromSweep(v2(p.x, p.y), p.z, v2(m.z, m.w));
+			W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
+			root = W.parent[body];
+			if (sp.allowSleep)
 			{
-				sleepTime = 0.0f;
+				const float linTolSqr = B2D_LINEAR_SLEEP_TOL * B2D_LINEAR_SLEEP_TOL;
+				const float angTolSqr = B2D_ANGULAR_SLEEP_TOL * B2D_ANGULAR_SLEEP_TOL;
+				uint32_t f = W.b_flags[body];
+				sleepTime = p.w;
+				if ((f & BF_AUTOSLEEP) == 0 || v.z * v.z > angTolSqr || b2dDot(v2(v.x, v.y), v2(v.x, v.y)) > linTolSqr)
+				{
+					sleepTime = 0.0f;
+				}
+				else
+				{
+					sleepTime += sp.dt;
+				}
+				W.b_pos[body] = make_float4(p.x, p.y, p.z, sleepTime);
 			}
-			else
-			{
-				sleepTime += sp.dt;
-			}
-			W.b_pos[body] = make_float4(p.x, p.y, p.z, sleepTime);
-			atomicMin(&W.rootSleepMin[W.parent[body]], floatBits(sleepTime));
 		}
+		if (sp.allowSleep) waveAtomicMinU32(W.rootSleepMin, root, floatBits(sleepTime), valid);
 	}
 }
 

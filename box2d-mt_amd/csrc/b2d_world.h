@@ -54,6 +54,7 @@ struct ContactArrays
 	float4* man1;     // points[0].localPoint.xy, points[1].localPoint.xy
 	float4* imp;      // normalImpulse0, tangentImpulse0, normalImpulse1, tangentImpulse1
 	int4* man3;       // id0.key, id1.key, manifold type, pointCount
+	int* color;       // persistent constraint colour (large-island solver), -1 = none yet
 };
 
 struct RevoluteJoint
@@ -87,9 +88,10 @@ struct Counters
 	int nLargeProxies;
 	int posItersLarge;
 	int allLargeDone;
+	int needRecolor;
 	int overflow;        // bit0 contacts, bit1 pairs, bit2 colours, bit3 moves
 	int nIslands;
-	int pad[8];
+	int pad[7];
 };
 
 struct DState
@@ -180,6 +182,7 @@ struct DW
 	int* colorStart;     // [MAX_COLORS + 1]
 	int* colorCursor;
 	int* li_sorted;      // large contact slots grouped by colour
+	int4* li_ref;        // per colour-sorted row: contact index, bodyA, bodyB (static bodies as -(id+1)), island root
 	uint32_t* bodyClaim;
 	uint64_t* bodyColorMask;
 	float* lc;           // large-island constraint rows, field-major: lc[field * capContacts + slot]

@@ -147,6 +147,8 @@ struct b2hip_world
 	DevArray<uint32_t> c_flags[2];
 	DevArray<float4> c_mat[2], c_man0[2], c_man1[2], c_imp[2];
 	DevArray<int4> c_man3[2];
+	DevArray<int> c_color[2];
+	DevArray<int4> li_ref;
 	DevArray<uint64_t> ht_keys;
 	DevArray<RevoluteJoint> d_joints;
 	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
@@ -410,6 +412,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	{
 		ENS(c_ids[k], capContacts); ENS(c_key[k], capContacts); ENS(c_flags[k], capContacts); ENS(c_mat[k], capContacts);
 		ENS(c_man0[k], capContacts); ENS(c_man1[k], capContacts); ENS(c_imp[k], capContacts); ENS(c_man3[k], capContacts);
+		ENS(c_color[k], capContacts);
 	}
 	const size_t cc = w->c_ids[0].cap; // actual (power of two) capacity
 	// hash set: at most 50 % load
@@ -428,7 +431,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(si_bodies, nb); ENS(si_contacts, cc); ENS(si_level, cc); ENS(si_stack, nb); ENS(si_lastLevel, nb);
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / SMALL_ISLAND_MAX_W + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
-	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc);
+	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
 	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
@@ -475,6 +478,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	{
 		d.ca[k].ids = w->c_ids[k].p; d.ca[k].key = w->c_key[k].p; d.ca[k].flags = w->c_flags[k].p; d.ca[k].mat = w->c_mat[k].p;
 		d.ca[k].man0 = w->c_man0[k].p; d.ca[k].man1 = w->c_man1[k].p; d.ca[k].imp = w->c_imp[k].p; d.ca[k].man3 = w->c_man3[k].p;
+		d.ca[k].color = w->c_color[k].p;
 	}
 	d.ht_keys = w->ht_keys.p;
 	d.joints = w->d_joints.p;
@@ -486,7 +490,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.si_stack = w->si_stack.p; d.si_lastLevel = w->si_lastLevel.p; d.b_slot = w->b_slot.p; d.b_island = w->b_island.p;
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
-	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p;
+	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
 	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
@@ -694,7 +698,7 @@ static int findNewContacts(b2hip_world* w, bool sync)
 	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d);
 	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
 	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d);
-	LAUNCH(w, k_find_pairs_small, gridFor(d.capMoves, 256, 4096), 256, d);
+	LAUNCH(w, k_find_pairs_small, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
 	LAUNCH(w, k_find_pairs_large, 1024, 256, d);
 	bool large = false;
 	if (sync)
@@ -739,6 +743,8 @@ static int phaseSolve(b2hip_world* w)
 	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p, d.nBodies);
 	LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_color_check_begin, 1, 128, d);
+	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
 
 	// the host needs the island census to size the solver launches
 	int rc = readState(w);
@@ -783,13 +789,21 @@ static int phaseSolve(b2hip_world* w)
 	if (nLIslands > 0)
 	{
 		const int gB = gridFor(nLBodies), gC = gridFor(std::max(nLContacts, 1));
-		if (!exactLarge)
+		nColors = exactLarge ? nColors : c.nColors;
+		if (!exactLarge && (c.needRecolor || c.nUncolored > 0))
 		{
-			LAUNCH(w, k_color_begin, gC, 256, d);
-			int uncolored = nLContacts;
+			// a colour clash on some body -> colour the large islands from scratch; otherwise only the
+			// constraints that have no colour yet join the Jones-Plassmann rounds (existing masks stay)
+			int uncolored = c.nUncolored;
+			if (c.needRecolor)
+			{
+				LAUNCH(w, k_color_begin, gridFor(d.capContacts), 256, d);
+				uncolored = nLContacts;
+			}
+			int batch = c.needRecolor ? 8 : 2;
 			while (uncolored > 0)
 			{
-				for (int r = 0; r < 8; ++r)
+				for (int r = 0; r < batch; ++r)
 				{
 					LAUNCH(w, k_color_claim, gC, 256, d);
 					LAUNCH(w, k_color_resolve, gC, 256, d);
@@ -799,6 +813,7 @@ static int phaseSolve(b2hip_world* w)
 				uncolored = w->h_dstate->c.nUncolored;
 				nColors = w->h_dstate->c.nColors;
 				if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
+				batch = 8;
 			}
 		}
 		LAUNCH(w, k_color_scan, 1, 1, d);
@@ -986,9 +1001,9 @@ void b2hip_world_destroy(b2hip_world* w)
 	for (int k = 0; k < 2; ++k)
 	{
 		w->c_ids[k].release(); w->c_key[k].release(); w->c_flags[k].release(); w->c_mat[k].release(); w->c_man0[k].release();
-		w->c_man1[k].release(); w->c_imp[k].release(); w->c_man3[k].release();
+		w->c_man1[k].release(); w->c_imp[k].release(); w->c_man3[k].release(); w->c_color[k].release();
 	}
-	w->ht_keys.release(); w->d_joints.release();
+	w->ht_keys.release(); w->d_joints.release(); w->li_ref.release();
 	w->parent.release(); w->rootSeed.release(); w->rootBodies.release(); w->rootContacts.release(); w->rootJoints.release();
 	w->rootIsland.release(); w->deg.release(); w->adjStart.release(); w->adjCursor.release(); w->adj.release();
 	w->rootScanIn.release(); w->rootScanOut.release();
