@@ -190,6 +190,20 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 	if (nTouch) atomicAdd(&S->c.nTouching, nTouch);
 }
 
+// b2World::CreateJoint with collideConnected == false flags the contacts between the two bodies for
+// re-filtering at the next step (b2World.cpp:716-732).
+__global__ __launch_bounds__(256) void k_flag_filter(DW W, int bodyA, int bodyB)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		int4 ids = C.ids[i];
+		if ((ids.z == bodyA && ids.w == bodyB) || (ids.z == bodyB && ids.w == bodyA)) C.flags[i] |= CF_FILTER;
+	}
+}
+
 // Stable compaction (creation order is preserved). keepScan = exclusive scan of keepFlag.
 __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 {

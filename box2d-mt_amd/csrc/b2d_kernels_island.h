@@ -82,6 +82,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		W.rootPen[i] = 0;
 		W.rootDone[i] = 0;
 		W.rootSleepMin[i] = 0x7f7fffffu; // b2_maxFloat
+		W.rootJointCursor[i] = 0;
+		W.rootJointOkay[i] = 1;
 		W.bodyClaim[i] = 0;
 		W.bodyColorMask[i] = 0;
 		uint32_t f = W.b_flags[i] & ~(BF_ISLAND | BF_LARGE);
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		}
 		W.b_flags[i] = f;
 	}
+	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x) W.joints[j].islandFlag = 0;
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		S->c.nSIslands = S->c.nSBodies = S->c.nSContacts = S->c.nSW = S->c.nChunks = 0;
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 				int nb = W.rootBodies[i], nc = W.rootContacts[i], nj = W.rootJoints[i];
 				int w = nb > nc ? nb : nc;
 				if (w < 1) w = 1;
-				if (nj == 0 && ((w <= SMALL_ISLAND_MAX_W && forceLarge == 0) || forceLarge == 2))
+				if ((nj == 0 && w <= SMALL_ISLAND_MAX_W && forceLarge == 0) || forceLarge == 2)
 				{
 					W.rootIsland[i] = ROOT_SMALL;
 					in = make_int4(nb, nc, w, 1);
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 		const int bStart = W.si_bodyStart[idx];
 		const int cStart = W.si_contactStart[idx];
 		int* stack = W.si_stack + bStart;
-		int sp = 0, nb = 0, nc = 0;
+		int sp = 0, nb = 0, nc = 0, nj = 0;
 		stack[sp++] = seed;
 		W.b_slot[seed] = -2;
 		while (sp > 0)
@@ -345,6 +348,22 @@ __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 				stack[sp++] = other;
 				W.b_slot[other] = -2;
 			}
+			// joints of b, newest first (b2World.cpp:1292-1318)
+			for (int k = W.jadjStart[b]; k < W.jadjStart[b + 1]; ++k)
+			{
+				const int ji = W.jadj[k];
+				RevoluteJoint& jn = W.joints[ji];
+				if (jn.islandFlag) continue;
+				const int other = jn.bodyA == b ? jn.bodyB : jn.bodyA;
+				if ((W.b_flags[other] & BF_ACTIVE) == 0) continue;
+				W.lj_list[W.rootJointStart[root] + nj] = ji;
+				++nj;
+				jn.islandFlag = 1;
+				if ((W.b_flags[other] & BF_TYPE_MASK) == BT_STATIC) continue;
+				if (W.b_slot[other] != -1) continue;
+				stack[sp++] = other;
+				W.b_slot[other] = -2;
+			}
 		}
 		// dependency levels of the sequential constraint sweep
 		int maxLevel = 0;
@@ -362,6 +381,42 @@ __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 			if (level > maxLevel) maxLevel = level;
 		}
 		W.si_maxLevel[idx] = maxLevel;
+	}
+}
+
+// Joint lists of the LARGE (coloured) islands: grouped per root, ascending joint id inside an island.
+__global__ __launch_bounds__(256) void k_joints_fill(DW W)
+{
+	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
+	{
+		const RevoluteJoint& jn = W.joints[j];
+		int b = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC ? jn.bodyA : jn.bodyB;
+		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
+		const int root = W.parent[b];
+		if (W.rootIsland[root] != ROOT_LARGE) continue;
+		W.lj_list[W.rootJointStart[root] + atomicAdd(&W.rootJointCursor[root], 1)] = j;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_joints_sort(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nLIslands;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int root = W.li_roots[k];
+		const int s = W.rootJointStart[root], e = s + W.rootJoints[root];
+		for (int a = s + 1; a < e; ++a)
+		{
+			int v = W.lj_list[a];
+			int b = a - 1;
+			while (b >= s && W.lj_list[b] > v)
+			{
+				W.lj_list[b + 1] = W.lj_list[b];
+				--b;
+			}
+			W.lj_list[b + 1] = v;
+		}
 	}
 }
 

@@ -414,6 +414,63 @@ __global__ __launch_bounds__(256) void k_large_velocity(DW W, int color, int mod
 	}
 }
 
+// Joints of the large islands: one lane per island walks its joints in order (they are solved before the
+// contacts in every velocity iteration and after them in every position iteration, b2Island.cpp:259-335).
+// mode 0 = InitVelocityConstraints (+ joint warm start), 1 = velocity, 2 = position
+__global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mode)
+{
+	DState* S = W.st;
+	if (mode == 2 && S->c.allLargeDone) return;
+	const int n = S->c.nLIslands;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int root = W.li_roots[k];
+		const int nj = W.rootJoints[root];
+		if (nj == 0) continue;
+		if (mode == 2 && W.rootDone[root]) continue;
+		const int start = W.rootJointStart[root];
+		int okay = 1;
+		for (int t = 0; t < nj; ++t)
+		{
+			RevoluteJoint* j = &W.joints[W.lj_list[start + t]];
+			const int bA = j->bodyA, bB = j->bodyB;
+			const bool nsA = (W.b_flags[bA] & BF_TYPE_MASK) != BT_STATIC;
+			const bool nsB = (W.b_flags[bB] & BF_TYPE_MASK) != BT_STATIC;
+			float4 pa = W.b_pos[bA], pb = W.b_pos[bB];
+			if (mode == 2)
+			{
+				BodyPos pA, pB;
+				pA.c = v2(pa.x, pa.y); pA.a = pa.z;
+				pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+				bool ok = b2dRevoluteSolvePosition(j, &pA, &pB);
+				okay = okay && ok;
+				if (nsA) W.b_pos[bA] = make_float4(pA.c.x, pA.c.y, pA.a, pa.w);
+				if (nsB) W.b_pos[bB] = make_float4(pB.c.x, pB.c.y, pB.a, pb.w);
+			}
+			else
+			{
+				float4 va = W.b_vel[bA], vb = W.b_vel[bB];
+				BodyVel vA, vB;
+				vA.v = nsA ? v2(va.x, va.y) : v2(0, 0); vA.w = nsA ? va.z : 0.0f;
+				vB.v = nsB ? v2(vb.x, vb.y) : v2(0, 0); vB.w = nsB ? vb.z : 0.0f;
+				if (mode == 0)
+				{
+					float4 mA = W.b_mass[bA], mB = W.b_mass[bB];
+					b2dRevoluteInit(j, mA.x, mA.y, v2(mA.z, mA.w), mB.x, mB.y, v2(mB.z, mB.w), pa.z, &vA, pb.z, &vB,
+						sp.warmStarting != 0, sp.dtRatio);
+				}
+				else
+				{
+					b2dRevoluteSolveVelocity(j, &vA, &vB, sp.dt);
+				}
+				if (nsA) W.b_vel[bA] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
+				if (nsB) W.b_vel[bB] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
+			}
+		}
+		if (mode == 2) W.rootJointOkay[root] = okay;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_large_store_impulses(DW W)
 {
 	DState* S = W.st;
@@ -458,6 +515,7 @@ __global__ __launch_bounds__(256) void k_large_pos_begin(DW W)
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
 	{
 		W.rootPen[W.li_roots[k]] = 0;
+		W.rootJointOkay[W.li_roots[k]] = 1;
 	}
 }
 
@@ -512,7 +570,7 @@ __global__ __launch_bounds__(256) void k_large_pos_end(DW W)
 		const int root = W.li_roots[k];
 		if (W.rootDone[root]) continue;
 		float minSeparation = -__uint_as_float(W.rootPen[root]);
-		if (minSeparation >= -3.0f * B2D_LINEAR_SLOP && W.rootJoints[root] == 0)
+		if (minSeparation >= -3.0f * B2D_LINEAR_SLOP && W.rootJointOkay[root])
 		{
 			W.rootDone[root] = 1;
 		}

@@ -11,6 +11,7 @@
 #define B2D_WORLD_H
 
 #include "b2d_solver.h"
+#include "b2d_joint.h"
 
 // body flag bits (device). Bits 0-1 hold the b2BodyType.
 #define BF_TYPE_MASK 0x3u
@@ -55,22 +56,6 @@ struct ContactArrays
 	float4* imp;      // normalImpulse0, tangentImpulse0, normalImpulse1, tangentImpulse1
 	int4* man3;       // id0.key, id1.key, manifold type, pointCount
 	int* color;       // persistent constraint colour (large-island solver), -1 = none yet
-};
-
-struct RevoluteJoint
-{
-	int bodyA, bodyB;
-	V2 localAnchorA, localAnchorB;
-	float referenceAngle;
-	int enableLimit;
-	float lowerAngle, upperAngle;
-	int enableMotor;
-	float motorSpeed, maxMotorTorque;
-	int collideConnected;
-	// persistent solver state (b2RevoluteJoint.h:190-199)
-	float impulseX, impulseY, impulseZ;
-	float motorImpulse;
-	int limitState;
 };
 
 struct Counters
@@ -145,6 +130,12 @@ struct DW
 
 	// ---- joints -----------------------------------------------------------------------------
 	RevoluteJoint* joints;
+	int* jadjStart;      // per body: its joint edges, newest first (b2World::CreateJoint pushes at the list head)
+	int* jadj;
+	int* rootJointStart; // per root: segment of lj_list (exclusive scan of rootJoints)
+	int* rootJointCursor;
+	int* lj_list;        // joint ids grouped by island, in the island's solve order
+	int* rootJointOkay;  // per root: AND of the joints' position-solve results of the running iteration
 
 	// ---- island build -----------------------------------------------------------------------
 	int* parent;         // union-find over non-static bodies; after flatten: island root per body

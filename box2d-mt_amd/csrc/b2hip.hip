@@ -151,6 +151,8 @@ struct b2hip_world
 	DevArray<int4> li_ref;
 	DevArray<uint64_t> ht_keys;
 	DevArray<RevoluteJoint> d_joints;
+	DevArray<int> jadjStart, jadj, rootJointStart, rootJointCursor, lj_list, rootJointOkay;
+	std::vector<std::pair<int, int> > pendingFilter; // body pairs whose contacts must be re-filtered (new joint)
 	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
 	DevArray<int4> rootScanIn, rootScanOut;
 	DevArray<int> si_root, si_bodyStart, si_contactStart, si_wStart, si_maxLevel, si_bodies, si_contacts, si_level,
@@ -406,6 +408,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(p_fat, np); ENS(p_body, np); ENS(p_shape, np); ENS(p_key, np); ENS(p_filter0, np); ENS(p_filter1, np); ENS(p_mat, np);
 	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
 	ENS(d_joints, std::max<size_t>(w->joints.size(), 1));
+	ENS(jadjStart, nb + 2); ENS(jadj, 2 * w->joints.size() + 2); ENS(rootJointStart, nb + 2); ENS(rootJointCursor, nb);
+	ENS(lj_list, w->joints.size() + 2); ENS(rootJointOkay, nb);
 	const size_t capPairs = std::max<size_t>(8 * np + 4096, w->pairKey.cap);
 	const size_t capContacts = std::max<size_t>(needContacts + capPairs, 1024);
 	for (int k = 0; k < 2; ++k)
@@ -482,6 +486,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	}
 	d.ht_keys = w->ht_keys.p;
 	d.joints = w->d_joints.p;
+	d.jadjStart = w->jadjStart.p; d.jadj = w->jadj.p; d.rootJointStart = w->rootJointStart.p;
+	d.rootJointCursor = w->rootJointCursor.p; d.lj_list = w->lj_list.p; d.rootJointOkay = w->rootJointOkay.p;
 	d.parent = w->parent.p; d.rootSeed = w->rootSeed.p; d.rootBodies = w->rootBodies.p; d.rootContacts = w->rootContacts.p;
 	d.rootJoints = w->rootJoints.p; d.rootScanIn = w->rootScanIn.p; d.rootScanOut = w->rootScanOut.p; d.rootIsland = w->rootIsland.p;
 	d.deg = w->deg.p; d.adjStart = w->adjStart.p; d.adjCursor = w->adjCursor.p; d.adj = w->adj.p;
@@ -555,8 +561,30 @@ static int flushEdits(b2hip_world* w)
 	}
 	if (w->upJoints != w->joints.size())
 	{
-		HIP_TRY(hipMemcpyAsync(w->d_joints.p, w->joints.data(), w->joints.size() * sizeof(RevoluteJoint), hipMemcpyHostToDevice, s));
+		// new joints are appended; the device keeps the persistent impulses of the ones it already has
+		const size_t first = w->upJoints, cnt = w->joints.size() - first;
+		HIP_TRY(hipMemcpyAsync(w->d_joints.p + first, w->joints.data() + first, cnt * sizeof(RevoluteJoint), hipMemcpyHostToDevice, s));
 		w->upJoints = w->joints.size();
+	}
+	{
+		// per-body joint edges, newest first (b2World.cpp:697-710); tiny, rebuilt every flush
+		const size_t nbod = w->bodies.size();
+		std::vector<int> start(nbod + 1, 0), adj;
+		std::vector<std::vector<int> > per(nbod);
+		for (int j = (int)w->joints.size() - 1; j >= 0; --j)
+		{
+			per[w->joints[j].bodyA].push_back(j);
+			if (w->joints[j].bodyB != w->joints[j].bodyA) per[w->joints[j].bodyB].push_back(j);
+		}
+		for (size_t b = 0; b < nbod; ++b)
+		{
+			start[b] = (int)adj.size();
+			adj.insert(adj.end(), per[b].begin(), per[b].end());
+		}
+		start[nbod] = (int)adj.size();
+		HIP_TRY(hipMemcpyAsync(w->jadjStart.p, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice, s));
+		if (!adj.empty()) HIP_TRY(hipMemcpyAsync(w->jadj.p, adj.data(), adj.size() * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
 	}
 
 	// ---- new proxies -----------------------------------------------------------------------------
@@ -741,8 +769,13 @@ static int phaseSolve(b2hip_world* w)
 		hipLaunchKernelGGL(k_scan_final<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->consts.p);
 	}
 	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p, d.nBodies);
+	if (d.nJoints > 0)
+	{
+		deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->consts.p, d.nBodies);
+	}
 	LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
+	if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
 	LAUNCH(w, k_color_check_begin, 1, 128, d);
 	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
 
@@ -821,13 +854,18 @@ static int phaseSolve(b2hip_world* w)
 		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
 		LAUNCH(w, k_large_integrate, gB, 256, d, sp);
+		const bool hasJoints = d.nJoints > 0;
+		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
+		if (hasJoints && !exactLarge) LAUNCH(w, k_joints_sort, gJ, 64, d);
 		LAUNCH(w, k_large_init, gC, 256, d, sp);
 		if (sp.warmStarting)
 		{
 			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
 		}
+		if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 0);
 		for (int it = 0; it < sp.velIters; ++it)
 		{
+			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 1);
 			for (int col = 0; col < nColors; ++col)
 			{
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
@@ -841,6 +879,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
 			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_position, gK, 256, d, col);
+			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
 			LAUNCH(w, k_large_pos_end, 1, 256, d);
 		}
 		LAUNCH(w, k_large_finalize, gB, 256, d, sp);
@@ -1004,6 +1043,8 @@ void b2hip_world_destroy(b2hip_world* w)
 		w->c_man1[k].release(); w->c_imp[k].release(); w->c_man3[k].release(); w->c_color[k].release();
 	}
 	w->ht_keys.release(); w->d_joints.release(); w->li_ref.release();
+	w->jadjStart.release(); w->jadj.release(); w->rootJointStart.release(); w->rootJointCursor.release();
+	w->lj_list.release(); w->rootJointOkay.release();
 	w->parent.release(); w->rootSeed.release(); w->rootBodies.release(); w->rootContacts.release(); w->rootJoints.release();
 	w->rootIsland.release(); w->deg.release(); w->adjStart.release(); w->adjCursor.release(); w->adj.release();
 	w->rootScanIn.release(); w->rootScanOut.release();
@@ -1159,6 +1200,8 @@ int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* 
 	j.maxMotorTorque = def->max_motor_torque;
 	j.collideConnected = def->collide_connected;
 	w->joints.push_back(j);
+	// b2World::CreateJoint (b2World.cpp:716-732): contacts between the two bodies are re-filtered
+	if (def->collide_connected == 0) w->pendingFilter.push_back(std::make_pair(def->body_a, def->body_b));
 	return (int)w->joints.size() - 1;
 }
 
@@ -1244,6 +1287,11 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nDestroy, 0, sizeof(int) * 2, w->stream));
 	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nPairs, 0, sizeof(int) * 2, w->stream));
 	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+	for (size_t k = 0; k < w->pendingFilter.size(); ++k)
+	{
+		LAUNCH(w, k_flag_filter, gridFor(w->dw.capContacts), 256, w->dw, w->pendingFilter[k].first, w->pendingFilter[k].second);
+	}
+	w->pendingFilter.clear();
 	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
 	// b2World.cpp:1628-1639: new fixtures -> find their contacts before colliding
 	if (w->newFixture)

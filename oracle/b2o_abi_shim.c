@@ -61,8 +61,9 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* d, c
 
 int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* def)
 {
-	(void)w; (void)def;
-	return B2HIP_ERR_UNSUPPORTED;
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	return b2o_create_revolute_joint(w->o, def->body_a, def->body_b, anchors, def->reference_angle, def->enable_limit,
+		def->lower_angle, def->upper_angle, def->enable_motor, def->motor_speed, def->max_motor_torque, def->collide_connected);
 }
 
 int b2hip_body_count(const b2hip_world* w) { return b2o_body_count(w->o); }

@@ -1,0 +1,31 @@
+/* b2o_joint.h - CPU oracle, revolute joint state (TEST INFRASTRUCTURE, see b2o.h). */
+#ifndef B2O_JOINT_H
+#define B2O_JOINT_H
+
+#include "b2o_internal.h"
+
+typedef struct
+{
+	int bodyA, bodyB;
+	vec2 localAnchorA, localAnchorB;
+	float referenceAngle;
+	int enableLimit;
+	float lowerAngle, upperAngle;
+	int enableMotor;
+	float motorSpeed, maxMotorTorque;
+	int collideConnected;
+	float impulse[3], motorImpulse;
+	int limitState; /* 0 inactive, 1 at lower, 2 at upper, 3 equal */
+	vec2 rA, rB, localCenterA, localCenterB;
+	float invMassA, invMassB, invIA, invIB;
+	float ex[3], ey[3], ez[3], motorMass;
+	int islandFlag;
+	int nextA, nextB; /* per-body joint lists, newest first: edge id = joint * 2 + side */
+} revolute_t;
+
+void b2o_revolute_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	float aA, vec2* vA, float* wA, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
+void b2o_revolute_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt);
+int b2o_revolute_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+#endif

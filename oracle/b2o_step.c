@@ -5,10 +5,11 @@
  * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
- * (b2ContactManager.cpp:366-386). Not covered (same as the device path): joints other than none,
- * chain shapes, sensors' GJK overlap, TOI.
+ * (b2ContactManager.cpp:366-386). Joints: revolute (b2o_joint.c). Not covered (same as the device
+ * path): other joint types, chain shapes, sensors' GJK overlap, TOI.
  */
 #include "b2o_internal.h"
+#include "b2o_joint.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -39,6 +40,7 @@ typedef struct
 	float mass, invMass, I, invI;
 	float linearDamping, angularDamping, gravityScale, sleepTime;
 	int fixtureHead;   /* newest fixture first */
+	int jointHead;     /* joint edge id = joint * 2 + side, newest first */
 	int contactHead;   /* edge id = contact * 2 + side, newest first */
 	int islandIndex;
 	int label;
@@ -103,6 +105,7 @@ struct b2o_world
 	/* proxy id allocator (b2DynamicTree free list) */
 	int nextNode, leafCount;
 	int* freeLeaves; int nFreeLeaves, capFreeLeaves;
+	revolute_t* joints; int nJoints, capJoints;
 };
 
 #define GROW(ptr, cap, need, type)                                            \
@@ -136,6 +139,7 @@ void b2o_world_destroy(b2o_world* w)
 	free(w->freeContacts);
 	free(w->moves);
 	free(w->freeLeaves);
+	free(w->joints);
 	free(w);
 }
 
@@ -171,6 +175,7 @@ int b2o_create_body(b2o_world* w, const b2o_body_def* d)
 	b->gravityScale = d->gravity_scale;
 	if (d->type == 2) { b->mass = 1.0f; b->invMass = 1.0f; }
 	b->fixtureHead = -1;
+	b->jointHead = -1;
 	b->contactHead = -1;
 	b->label = -1;
 	return w->nBodies++;
@@ -355,6 +360,42 @@ int b2o_create_fixture(b2o_world* w, int body, const b2o_fixture_def* d, const b
 	return id;
 }
 
+/* b2World::CreateJoint (b2World.cpp:679-735) + b2RevoluteJoint::b2RevoluteJoint (b2RevoluteJoint.cpp:46-63) */
+int b2o_create_revolute_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float referenceAngle,
+	int enableLimit, float lower, float upper, int enableMotor, float motorSpeed, float maxMotorTorque, int collideConnected)
+{
+	GROW(w->joints, w->capJoints, w->nJoints + 1, revolute_t);
+	revolute_t* j = &w->joints[w->nJoints];
+	memset(j, 0, sizeof(*j));
+	j->bodyA = bodyA;
+	j->bodyB = bodyB;
+	j->localAnchorA = v_make(anchors4[0], anchors4[1]);
+	j->localAnchorB = v_make(anchors4[2], anchors4[3]);
+	j->referenceAngle = referenceAngle;
+	j->enableLimit = enableLimit;
+	j->lowerAngle = lower;
+	j->upperAngle = upper;
+	j->enableMotor = enableMotor;
+	j->motorSpeed = motorSpeed;
+	j->maxMotorTorque = maxMotorTorque;
+	j->collideConnected = collideConnected;
+	int id = w->nJoints++;
+	j->nextA = w->bodies[bodyA].jointHead;
+	w->bodies[bodyA].jointHead = id * 2;
+	j->nextB = w->bodies[bodyB].jointHead;
+	w->bodies[bodyB].jointHead = id * 2 + 1;
+	if (!collideConnected)
+	{
+		for (int e = w->bodies[bodyB].contactHead; e >= 0; e = w->contacts[e >> 1].next[e & 1])
+		{
+			contact_t* c = &w->contacts[e >> 1];
+			int other = (e & 1) == 0 ? c->bodyB : c->bodyA;
+			if (other == bodyA) c->flags |= CF_FILTER;
+		}
+	}
+	return id;
+}
+
 /* ---- contacts ------------------------------------------------------------------------------------ */
 static int body_active_for_contact(const body_t* b) { return (b->flags & BF_AWAKE) != 0 && b->type != 0; }
 
@@ -469,10 +510,20 @@ static int fat_overlap(const float a[4], const float b[4])
 	return 1;
 }
 
-/* b2Body::ShouldCollide  b2Body.cpp:428-449 (no joints in the oracle) */
-static int bodies_should_collide(const body_t* a, const body_t* b)
+/* b2Body::ShouldCollide  b2Body.cpp:428-449 */
+static int bodies_should_collide_w(const b2o_world* w, int ia, int ib)
 {
-	return a->type == 2 || b->type == 2;
+	const body_t* a = &w->bodies[ia];
+	const body_t* b = &w->bodies[ib];
+	if (a->type != 2 && b->type != 2) return 0;
+	for (int e = a->jointHead; e >= 0; )
+	{
+		const revolute_t* j = &w->joints[e >> 1];
+		int other = (e & 1) == 0 ? j->bodyB : j->bodyA;
+		if (other == ib && j->collideConnected == 0) return 0;
+		e = (e & 1) == 0 ? j->nextA : j->nextB;
+	}
+	return 1;
 }
 
 /* b2ContactManager::Collide (:177-230) + b2Contact::UpdateImpl (b2Contact.cpp:173-298) + FinishCollide (:388-439) */
@@ -492,7 +543,7 @@ static void collide(b2o_world* w)
 		body_t* bB = &w->bodies[c->bodyB];
 		if (c->flags & CF_FILTER)
 		{
-			if (!bodies_should_collide(bB, bA) || !filter_should_collide(fA, fB))
+			if (!bodies_should_collide_w(w, c->bodyB, c->bodyA) || !filter_should_collide(fA, fB))
 			{
 				destroys[nDestroy++] = i;
 				continue;
@@ -605,7 +656,7 @@ static void find_new_contacts(b2o_world* w)
 			}
 		}
 		if (exists) continue;
-		if (!bodies_should_collide(&w->bodies[fB->body], &w->bodies[fA->body])) continue;
+		if (!bodies_should_collide_w(w, fB->body, fA->body)) continue;
 		if (!filter_should_collide(fA, fB)) continue;
 		create_contact(w, pairs[i].fLo, pairs[i].fHi);
 	}
@@ -950,7 +1001,7 @@ static float solve_position(const constraint_t* cc, pos_t* pos, float minSeparat
 
 /* b2Island::Solve  b2Island.cpp:184-396 */
 static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* islandContacts, int contactCount,
-	float h, float dtRatio, int velIters, int posIters)
+	int* islandJoints, int jointCount, float h, float dtRatio, int velIters, int posIters)
 {
 	pos_t* positions = (pos_t*)malloc(sizeof(pos_t) * (size_t)(bodyCount + 1));
 	vel_t* velocities = (vel_t*)malloc(sizeof(vel_t) * (size_t)(bodyCount + 1));
@@ -984,8 +1035,24 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 	{
 		for (int i = 0; i < contactCount; ++i) warm_start(&cs[i], velocities);
 	}
+	for (int i = 0; i < jointCount; ++i)
+	{
+		revolute_t* j = &w->joints[islandJoints[i]];
+		body_t* bA = &w->bodies[j->bodyA];
+		body_t* bB = &w->bodies[j->bodyB];
+		int ia = bA->islandIndex, ib = bB->islandIndex;
+		b2o_revolute_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+			positions[ia].a, &velocities[ia].v, &velocities[ia].w, positions[ib].a, &velocities[ib].v, &velocities[ib].w,
+			w->warmStarting, dtRatio);
+	}
 	for (int it = 0; it < velIters; ++it)
 	{
+		for (int i = 0; i < jointCount; ++i)
+		{
+			revolute_t* j = &w->joints[islandJoints[i]];
+			int ia = w->bodies[j->bodyA].islandIndex, ib = w->bodies[j->bodyB].islandIndex;
+			b2o_revolute_velocity(j, &velocities[ia].v, &velocities[ia].w, &velocities[ib].v, &velocities[ib].w, h);
+		}
 		for (int i = 0; i < contactCount; ++i) solve_velocity(&cs[i], velocities);
 	}
 	/* StoreImpulses :605-618 */
@@ -1024,7 +1091,15 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 	{
 		float minSeparation = 0.0f;
 		for (int i = 0; i < contactCount; ++i) minSeparation = solve_position(&cs[i], positions, minSeparation);
-		if (minSeparation >= -3.0f * B2O_LINEAR_SLOP)
+		int jointsOkay = 1;
+		for (int i = 0; i < jointCount; ++i)
+		{
+			revolute_t* j = &w->joints[islandJoints[i]];
+			int ia = w->bodies[j->bodyA].islandIndex, ib = w->bodies[j->bodyB].islandIndex;
+			int ok = b2o_revolute_position(j, &positions[ia].c, &positions[ia].a, &positions[ib].c, &positions[ib].a);
+			jointsOkay = jointsOkay && ok;
+		}
+		if (minSeparation >= -3.0f * B2O_LINEAR_SLOP && jointsOkay)
 		{
 			positionSolved = 1;
 			break;
@@ -1089,14 +1164,16 @@ static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIte
 	int* islandBodies = (int*)malloc(sizeof(int) * (size_t)(nb + w->liveContacts + 2));
 	int* islandContacts = (int*)malloc(sizeof(int) * (size_t)(w->liveContacts + 1));
 	int* stack = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
+	int* islandJoints = (int*)malloc(sizeof(int) * (size_t)(w->nJoints + 1));
 	for (int i = 0; i < nb; ++i) w->bodies[i].label = -1;
+	for (int i = 0; i < w->nJoints; ++i) w->joints[i].islandFlag = 0;
 	for (int seedIdx = 0; seedIdx < nb; ++seedIdx)
 	{
 		body_t* seed = &w->bodies[seedIdx];
 		if (seed->type == 0) continue;
 		if (seed->flags & BF_ISLAND) continue;
 		if ((seed->flags & BF_AWAKE) == 0 || (seed->flags & BF_ACTIVE) == 0) continue;
-		int bodyCount = 0, contactCount = 0, sp = 0;
+		int bodyCount = 0, contactCount = 0, jointCount = 0, sp = 0;
 		stack[sp++] = seedIdx;
 		seed->flags |= BF_ISLAND;
 		while (sp > 0)
@@ -1119,6 +1196,21 @@ static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIte
 				stack[sp++] = other;
 				w->bodies[other].flags |= BF_ISLAND;
 			}
+			/* joints (b2World.cpp:1292-1318) */
+			for (int e = b->jointHead; e >= 0; )
+			{
+				revolute_t* j = &w->joints[e >> 1];
+				int other = (e & 1) == 0 ? j->bodyB : j->bodyA;
+				int next = (e & 1) == 0 ? j->nextA : j->nextB;
+				e = next;
+				if (j->islandFlag) continue;
+				if ((w->bodies[other].flags & BF_ACTIVE) == 0) continue;
+				islandJoints[jointCount++] = (int)(j - w->joints);
+				j->islandFlag = 1;
+				if (w->bodies[other].flags & BF_ISLAND) continue;
+				stack[sp++] = other;
+				w->bodies[other].flags |= BF_ISLAND;
+			}
 		}
 		int label = 0x7fffffff;
 		for (int j = 0; j < bodyCount; ++j)
@@ -1132,11 +1224,12 @@ static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIte
 			body_t* b = &w->bodies[islandBodies[j]];
 			if (b->type != 0) b->label = label;
 		}
-		solve_island(w, islandBodies, bodyCount, islandContacts, contactCount, h, dtRatio, velIters, posIters);
+		solve_island(w, islandBodies, bodyCount, islandContacts, contactCount, islandJoints, jointCount, h, dtRatio, velIters, posIters);
 	}
 	free(islandBodies);
 	free(islandContacts);
 	free(stack);
+	free(islandJoints);
 	synchronize_fixtures(w);
 	find_new_contacts(w);
 	/* ClearPostSolve  b2World.cpp:1433-1465 */

@@ -32,6 +32,8 @@ SCENES = [
     ("rain", bh.RAIN, 200, 0, 0.0, 0.0, 7, 200),
     ("circlestack", bh.CIRCLE_STACK, 8, 4, 0.0, 0.0, 1, 200),
     ("field", bh.FIELD, 1500, 0, 0.0, 0.0, 7, 100),
+    ("tumbler6", bh.TUMBLER, 6, 0, 0.0, 0.0, 1, 300),
+    ("tumbler20", bh.TUMBLER, 20, 0, 0.0, 0.0, 1, 150),
     ("pyramid141", bh.PYRAMID, 141, 1, 0.0, 0.0, 1, 30),
 ]
 

@@ -21,7 +21,7 @@ import b2harness as bh
 pytestmark = pytest.mark.gpu
 
 SMALL_ISLAND_SCENES = ["helloworld", "pyramid5x3", "piles", "circlestack", "field"]
-ALL_SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field"]
+ALL_SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20"]
 
 # coloured large islands: |pose - reference| / scene_scale after COLORED_HORIZON steps of a settling
 # 30-row pyramid (466 bodies, one island). Measured 4e-4 .. 3e-3 (impact transient); bound with margin.
@@ -239,5 +239,28 @@ def test_sleeping_and_waking_match(amd, oracle, default_mode):
         assert np.array_equal(A.view(np.uint32), O.view(np.uint32)), "state differs at step %d" % s
         slept = slept or (A[1:, 6] == 0).any()
     assert slept, "scene never put an island to sleep: test is vacuous"
+    a.close()
+    o.close()
+
+
+def test_tumbler_colored_mode_runs_and_stays_bounded(amd, oracle, default_mode):
+    """Config 3 shape (revolute motor + container + boxes) in the default coloured mode: one large island with
+    a joint. Floats differ from the reference order; the container angle is driven by the motor and must match
+    closely, boxes must stay inside the container, contact counts stay close."""
+    a = amd.world(bh.TUMBLER, 20)
+    o = oracle.world(bh.TUMBLER, 20)
+    for s in range(120):
+        a.step(1)
+        o.step(1)
+    A, O = a.bodies(), o.bodies()
+    assert np.isfinite(A).all()
+    assert abs(A[1, 2] - O[1, 2]) < 1e-3, "tumbler angle %g vs %g" % (A[1, 2], O[1, 2])
+    # box centres expressed in the container's frame must stay inside its walls (half size 10)
+    ang = float(A[1, 2])
+    dx, dy = A[2:, 0] - A[1, 0], A[2:, 1] - A[1, 1]
+    lx = np.cos(ang) * dx + np.sin(ang) * dy
+    ly = -np.sin(ang) * dx + np.cos(ang) * dy
+    assert (np.abs(lx) < 10.0).all() and (np.abs(ly) < 10.0).all(), "a box left the container"
+    assert abs(a.contact_count - o.contact_count) <= 0.15 * o.contact_count  # chaotic pile: AABB-pair count only roughly comparable
     a.close()
     o.close()

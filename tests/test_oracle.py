@@ -11,7 +11,7 @@ import b2harness as bh
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field"]
+SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20"]
 
 
 def run_scene(h, golden, name, check_every_step=True):
@@ -105,7 +105,7 @@ def test_oracle_determinism(oracle):
 
 
 @pytest.mark.parametrize("scene,p0,p1,steps", [(bh.PYRAMID, 20, 1, 120), (bh.PILES, 25, 6, 150), (bh.RAIN, 300, 0, 150),
-                                               (bh.FIELD, 800, 0, 80), (bh.CIRCLE_STACK, 6, 5, 150)])
+                                               (bh.FIELD, 800, 0, 80), (bh.CIRCLE_STACK, 6, 5, 150), (bh.TUMBLER, 12, 0, 200)])
 def test_oracle_matches_reference_build(oracle, ref, scene, p0, p1, steps):
     """Direct A/B against skitzoid/Box2D-MT compiled from /root/reference (skipped where it is absent)."""
     a = oracle.world(scene, p0, p1, seed=11)
