@@ -92,8 +92,9 @@ def main():
     amd = bh.Harness(bh.AMD_LIB)
     hipL = b2hip.lib()
 
-    # one pyramid island per rank (hipSetDevice above selects this rank's GPU for the world's stream)
-    w = amd.world(bh.PYRAMID, args.rows, 1)
+    # config-4 layout: `world_size` disjoint pyramids on one ground, rank r builds and steps pyramid r
+    # (hipSetDevice above selects this rank's GPU for the world's stream)
+    w = amd.world(bh.PYRAMID, args.rows, world_size, float(rank), float(world_size))
     nbodies = w.body_count
 
     def barrier():
@@ -158,6 +159,17 @@ def main():
                 "error": str(e)}
 
     contacts = w.contact_count
+    # Untimed: assemble the host-visible state of the WHOLE world on every rank with one all-gather over
+    # RCCL/xGMI (the only exchange a sharded world of disjoint islands needs; not part of `value`).
+    gather_ms = None
+    if dist is not None:
+        import sharding
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        full = sharding.gather_world_state(w.bodies(), args.rows, world_size, rank, world_size, dist=dist, device="cuda")
+        torch.cuda.synchronize()
+        gather_ms = 1000.0 * (time.perf_counter() - g0)
+        assert full.shape[0] == 1 + world_size * sharding.pyramid_bodies(args.rows)
     w.close()
 
     if rank == 0:
@@ -180,6 +192,8 @@ def main():
                        "bodies_total": nbodies * world_size, "parallelism": "one island shard per GPU, no data-path collective"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
+        if gather_ms is not None:
+            line["world_state_allgather_ms"] = gather_ms
         if roof is not None:
             line["roofline"] = roof
         if world_size == 1 and not args.no_cpu_baseline:

@@ -61,7 +61,8 @@ struct Pcg32
 enum SceneId
 {
 	e_helloWorld = 0,
-	e_pyramid = 1,       // p0 = rows, p1 = number of pyramids (side by side)
+	e_pyramid = 1,       // p0 = rows, p1 = number of pyramids (side by side); f0 = shard index, f1 = shard count
+	                     //   (f1 >= 2: build only the pyramids k with k % f1 == f0, at the positions of the full scene)
 	e_tumbler = 2,       // p0 = boxes per side of the pre-placed grid, p1 = unused ; f0 = half size S (0 -> auto)
 	e_field = 3,         // p0 = bodies, p1 = bullet count ; f0 = arena half length R (0 -> auto density), f1 = max radius
 	e_piles = 4,         // p0 = piles, p1 = boxes per pile
@@ -119,7 +120,7 @@ inline void BuildHelloWorld(Scene& s, b2World* w)
 }
 
 // rows -> rows*(rows+1)/2 boxes per pyramid; `count` pyramids side by side on one ground edge.
-inline void BuildPyramid(Scene& s, b2World* w, int rows, int count)
+inline void BuildPyramid(Scene& s, b2World* w, int rows, int count, int shard = 0, int shardCount = 1)
 {
 	w->SetGravity(b2Vec2(0.0f, -10.0f));
 	if (count < 1) count = 1;
@@ -137,6 +138,7 @@ inline void BuildPyramid(Scene& s, b2World* w, int rows, int count)
 	shape.SetAsBox(a, a);
 	for (int k = 0; k < count; ++k)
 	{
+		if (shardCount > 1 && (k % shardCount) != shard) continue;
 		float x0 = -0.5f * width * (float)count + width * (float)k + 5.0f;
 		b2Vec2 x(x0, 0.75f);
 		b2Vec2 y;
@@ -448,7 +450,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	switch (p.scene)
 	{
 	case e_helloWorld: BuildHelloWorld(s, w); break;
-	case e_pyramid: BuildPyramid(s, w, p.p0, p.p1); break;
+	case e_pyramid: BuildPyramid(s, w, p.p0, p.p1, (int)p.f0, p.f1 >= 2.0f ? (int)p.f1 : 1); break;
 	case e_tumbler: BuildTumbler(s, w, p.p0, p.f0); break;
 	case e_field: BuildField(s, w, p.p0, p.p1, p.f0, p.f1, p.seed); break;
 	case e_piles: BuildPiles(s, w, p.p0, p.p1, p.seed); break;
