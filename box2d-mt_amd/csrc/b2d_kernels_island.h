@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.nColors = 0;
 		S->c.nIslands = 0;
 		S->c.posItersLarge = 0;
+		S->c.maxSmallW = 0;
+		S->c.chunkW = SMALL_ISLAND_MAX_W;
 	}
 }
 
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 				{
 					W.rootIsland[i] = ROOT_SMALL;
 					in = make_int4(nb, nc, w, 1);
+					atomicMax(&S->c.maxSmallW, w);
 				}
 				else
 				{
@@ -260,7 +263,9 @@ __global__ __launch_bounds__(256) void k_island_assign(DW W)
 		W.si_bodyStart[tot.w] = tot.x;
 		W.si_contactStart[tot.w] = tot.y;
 		W.si_wStart[tot.w] = tot.z;
-		S->c.nChunks = tot.w > 0 ? (tot.z - 1) / SMALL_ISLAND_MAX_W + 1 : 0;
+		const int chunkW = S->c.maxSmallW <= TINY_ISLAND_MAX_W ? TINY_ISLAND_MAX_W : SMALL_ISLAND_MAX_W;
+		S->c.chunkW = chunkW;
+		S->c.nChunks = tot.w > 0 ? (tot.z - 1) / chunkW + 1 : 0;
 	}
 }
 
@@ -427,8 +432,9 @@ __global__ __launch_bounds__(256) void k_island_chunks(DW W)
 	const int nS = S->c.nSIslands;
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nS; idx += gridDim.x * blockDim.x)
 	{
-		int c = W.si_wStart[idx] / SMALL_ISLAND_MAX_W;
-		if (idx == 0 || W.si_wStart[idx - 1] / SMALL_ISLAND_MAX_W != c)
+		const int chunkW = S->c.chunkW;
+		int c = W.si_wStart[idx] / chunkW;
+		if (idx == 0 || W.si_wStart[idx - 1] / chunkW != c)
 		{
 			W.chunkFirst[c] = idx;
 		}

@@ -16,7 +16,8 @@
 
 __device__ __forceinline__ uint32_t floatBits(float f) { return __float_as_uint(f); }
 
-__global__ __launch_bounds__(SMALL_CHUNK_LANES) void k_solve_small(DW W, StepParams sp)
+template <int LANES>
+__global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 {
 	DState* S = W.st;
 	const int chunk = blockIdx.x;
@@ -33,11 +34,11 @@ __global__ __launch_bounds__(SMALL_CHUNK_LANES) void k_solve_small(DW W, StepPar
 	const int tid = threadIdx.x;
 	const float h = sp.dt;
 
-	__shared__ float4 s_vel[SMALL_CHUNK_LANES];     // v.xy, w
-	__shared__ float4 s_pos[SMALL_CHUNK_LANES];     // c.xy, a
-	__shared__ uint32_t s_pen[SMALL_CHUNK_LANES];   // per island: bits of max penetration (= -minSeparation)
-	__shared__ int s_done[SMALL_CHUNK_LANES];       // per island: positionSolved
-	__shared__ uint32_t s_sleepMin[SMALL_CHUNK_LANES];
+	__shared__ float4 s_vel[LANES];     // v.xy, w
+	__shared__ float4 s_pos[LANES];     // c.xy, a
+	__shared__ uint32_t s_pen[LANES];   // per island: bits of max penetration (= -minSeparation)
+	__shared__ int s_done[LANES];       // per island: positionSolved
+	__shared__ uint32_t s_sleepMin[LANES];
 	__shared__ int s_maxLevel;
 	__shared__ int s_notDone;
 
@@ -222,7 +223,11 @@ __global__ __launch_bounds__(SMALL_CHUNK_LANES) void k_solve_small(DW W, StepPar
 			}
 		}
 		__syncthreads();
-		if (s_notDone == 0) break;
+		// read the verdict, THEN barrier again: the next iteration's reset of s_notDone must not
+		// overtake a slower wave that has not looked at it yet (it would leave the loop alone)
+		const int notDone = s_notDone;
+		__syncthreads();
+		if (notDone == 0) break;
 	}
 	__syncthreads();
 

@@ -40,8 +40,10 @@
 #define PF_SENSOR 0x10000
 #define PF_THICK 0x20000
 
-#define SMALL_ISLAND_MAX_W 128   // an island is "small" if max(bodies, contacts, 1) <= this
-#define SMALL_CHUNK_LANES 256    // one workgroup solves one chunk of small islands (<= 256 bodies, <= 256 contacts)
+#define SMALL_ISLAND_MAX_W 512   // an island is "small" if max(bodies, contacts, 1) <= this
+#define SMALL_CHUNK_LANES 1024   // one workgroup solves one chunk of small islands (<= 1024 bodies, <= 1024 contacts)
+#define TINY_ISLAND_MAX_W 128    // if every small island of the step is <= this, chunks are 256 lanes (lighter barriers)
+#define TINY_CHUNK_LANES 256
 #define MAX_COLORS 64
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
 
@@ -74,9 +76,11 @@ struct Counters
 	int posItersLarge;
 	int allLargeDone;
 	int needRecolor;
+	int maxSmallW;       // largest max(bodies, contacts) among the small islands of this step
+	int chunkW;          // chunk granularity chosen for this step (TINY_ISLAND_MAX_W or SMALL_ISLAND_MAX_W)
 	int overflow;        // bit0 contacts, bit1 pairs, bit2 colours, bit3 moves
 	int nIslands;
-	int pad[7];
+	int pad[5];
 };
 
 struct DState

@@ -126,6 +126,8 @@ struct b2hip_world
 	// what has been uploaded so far
 	size_t upBodies, upFixtures, upShapes, upJoints;
 	std::vector<int> pendingMoves;
+	std::vector<int> dirtyList;   // bodies whose host mirror is newer than the device rows
+	size_t stateCount;            // bodies covered by the last read-back in h_state
 	bool newFixture;
 	float inv_dt0;
 	bool stepActive;
@@ -200,6 +202,35 @@ static int nextPow2(size_t n)
 	size_t p = 64;
 	while (p < n) p <<= 1;
 	return (int)p;
+}
+
+// The read-back buffer h_state IS the host mirror of the dynamic state; a HostBody is refreshed from it only
+// when the host is about to edit that body (no O(bodies) host loop per step).
+static void pullBody(b2hip_world* w, int i)
+{
+	if ((size_t)i >= w->stateCount || w->h_state == nullptr) return;
+	HostBody& b = w->bodies[i];
+	const float* o = w->h_state + 10 * (size_t)i;
+	b.px = o[0]; b.py = o[1]; b.a = o[2];
+	b.vx = o[3]; b.vy = o[4]; b.w = o[5];
+	b.cx = o[6]; b.cy = o[7];
+	uint32_t f;
+	memcpy(&f, o + 8, 4);
+	b.flags = (b.flags & ~0x7fu) | (f & 0x7fu);
+	b.sleepTime = o[9];
+	b.c0x = b.cx; b.c0y = b.cy; b.a0 = b.a;
+	b.qs = sinf(b.a);
+	b.qc = cosf(b.a);
+	if (w->def.auto_clear_forces) { b.fx = b.fy = b.torque = 0.0f; }
+}
+
+static void markDirty(b2hip_world* w, int i)
+{
+	HostBody& b = w->bodies[i];
+	if (b.dirty) return;
+	pullBody(w, i);
+	b.dirty = true;
+	w->dirtyList.push_back(i);
 }
 
 static int allocProxyKey(b2hip_world* w)
@@ -433,7 +464,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(rootScanIn, nb + 1); ENS(rootScanOut, nb + 2);
 	ENS(si_root, nb + 1); ENS(si_bodyStart, nb + 2); ENS(si_contactStart, nb + 2); ENS(si_wStart, nb + 2); ENS(si_maxLevel, nb + 1);
 	ENS(si_bodies, nb); ENS(si_contacts, cc); ENS(si_level, cc); ENS(si_stack, nb); ENS(si_lastLevel, nb);
-	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / SMALL_ISLAND_MAX_W + 4);
+	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / TINY_ISLAND_MAX_W + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
 	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
@@ -517,15 +548,17 @@ static int flushEdits(b2hip_world* w)
 
 	// ---- bodies: every dirty body gets all its rows rewritten from the host mirror ---------------
 	const size_t nb = w->bodies.size();
-	size_t i = 0;
+	std::sort(w->dirtyList.begin(), w->dirtyList.end());
+	w->dirtyList.erase(std::unique(w->dirtyList.begin(), w->dirtyList.end()), w->dirtyList.end());
 	std::vector<float4> pos, pos0, vel, xf, mass, damp, force;
 	std::vector<uint32_t> flags;
-	while (i < nb)
+	size_t di = 0;
+	while (di < w->dirtyList.size())
 	{
-		if (!w->bodies[i].dirty) { ++i; continue; }
+		const size_t i = (size_t)w->dirtyList[di];
 		size_t j = i;
 		pos.clear(); pos0.clear(); vel.clear(); xf.clear(); mass.clear(); damp.clear(); force.clear(); flags.clear();
-		while (j < nb && w->bodies[j].dirty)
+		while (di < w->dirtyList.size() && (size_t)w->dirtyList[di] == j)
 		{
 			HostBody& b = w->bodies[j];
 			pos.push_back(make_float4(b.cx, b.cy, b.a, b.sleepTime));
@@ -538,6 +571,7 @@ static int flushEdits(b2hip_world* w)
 			flags.push_back((b.flags & ~BF_TYPE_MASK) | (uint32_t)b.type);
 			b.dirty = false;
 			++j;
+			++di;
 		}
 		const size_t cnt = j - i;
 		HIP_TRY(hipMemcpyAsync(w->b_pos.p + i, pos.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
@@ -549,8 +583,8 @@ static int flushEdits(b2hip_world* w)
 		HIP_TRY(hipMemcpyAsync(w->b_force.p + i, force.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(w->b_flags.p + i, flags.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s)); // staging vectors are reused
-		i = j;
 	}
+	w->dirtyList.clear();
 	w->upBodies = nb;
 
 	// ---- shapes / joints: small tables, rewritten whole when they grew -----------------------------
@@ -795,7 +829,8 @@ static int phaseSolve(b2hip_world* w)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 2; }
-			LAUNCH(w, k_solve_small, c.nChunks, SMALL_CHUNK_LANES, d, sp);
+			if (c.chunkW == TINY_ISLAND_MAX_W) LAUNCH(w, k_solve_small<TINY_CHUNK_LANES>, c.nChunks, TINY_CHUNK_LANES, d, sp);
+			else LAUNCH(w, k_solve_small<SMALL_CHUNK_LANES>, c.nChunks, SMALL_CHUNK_LANES, d, sp);
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
 		}
 		HIP_TRY(hipEventRecord(w->ev[6], w->stream));
@@ -925,21 +960,8 @@ static int downloadState(b2hip_world* w)
 
 static void refreshMirror(b2hip_world* w)
 {
-	const size_t nb = w->bodies.size();
-	for (size_t i = 0; i < nb; ++i)
-	{
-		HostBody& b = w->bodies[i];
-		const float* o = w->h_state + 10 * i;
-		b.px = o[0]; b.py = o[1]; b.a = o[2];
-		b.vx = o[3]; b.vy = o[4]; b.w = o[5];
-		b.cx = o[6]; b.cy = o[7];
-		uint32_t f;
-		memcpy(&f, o + 8, 4);
-		b.flags = (b.flags & ~0x7fu) | (f & 0x7fu);
-		b.sleepTime = o[9];
-		b.c0x = b.cx; b.c0y = b.cy; b.a0 = b.a;
-		if (w->def.auto_clear_forces) { b.fx = b.fy = b.torque = 0.0f; }
-	}
+	// h_state now holds the state of every body; HostBody rows are pulled from it on demand (pullBody)
+	w->stateCount = w->bodies.size();
 }
 
 extern "C"
@@ -987,6 +1009,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->nextNode = 0;
 	w->leafCount = 0;
 	w->upBodies = w->upFixtures = w->upShapes = w->upJoints = 0;
+	w->stateCount = 0;
 	w->newFixture = false;
 	w->inv_dt0 = 0.0f;
 	w->stepActive = false;
@@ -1124,6 +1147,7 @@ int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def)
 	b.invI = 0.0f;
 	b.dirty = true;
 	w->bodies.push_back(b);
+	w->dirtyList.push_back((int)w->bodies.size() - 1);
 	return (int)w->bodies.size() - 1;
 }
 
@@ -1148,6 +1172,7 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def,
 		rec.verts[i] = v2(shape->verts[2 * i], shape->verts[2 * i + 1]);
 		if (shape->type == B2HIP_SHAPE_POLYGON) rec.normals[i] = v2(shape->normals[2 * i], shape->normals[2 * i + 1]);
 	}
+	markDirty(w, body);
 	HostBody& b = w->bodies[body];
 	HostFixture f;
 	f.body = body;
@@ -1175,7 +1200,6 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def,
 	{
 		resetMassData(w, b);
 	}
-	b.dirty = true;
 	w->newFixture = true;
 	return id;
 }
@@ -1232,8 +1256,9 @@ int b2hip_get_mass_data(const b2hip_world* w, int body, b2hip_mass_data* out)
 int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque, int wake)
 {
 	if (!w || body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad argument");
+	if (w->bodies[body].type != B2HIP_DYNAMIC_BODY) return 0;
+	markDirty(w, body);
 	HostBody& b = w->bodies[body];
-	if (b.type != B2HIP_DYNAMIC_BODY) return 0;
 	if (wake && (b.flags & BF_AWAKE) == 0)
 	{
 		b.flags |= BF_AWAKE;
@@ -1245,15 +1270,15 @@ int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque
 		b.fy += fy;
 		b.torque += torque;
 	}
-	b.dirty = true;
 	return 0;
 }
 
 int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega)
 {
 	if (!w || body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad argument");
+	if (w->bodies[body].type == B2HIP_STATIC_BODY) return 0;
+	markDirty(w, body);
 	HostBody& b = w->bodies[body];
-	if (b.type == B2HIP_STATIC_BODY) return 0;
 	if (vx * vx + vy * vy > 0.0f || omega * omega > 0.0f)
 	{
 		b.flags |= BF_AWAKE;
@@ -1262,7 +1287,6 @@ int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega
 	b.vx = vx;
 	b.vy = vy;
 	b.w = omega;
-	b.dirty = true;
 	return 0;
 }
 
@@ -1453,6 +1477,13 @@ int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state
 	{
 		const HostBody& b = w->bodies[first + i];
 		b2hip_body_state& s = out[i];
+		if (!b.dirty && (size_t)(first + i) < w->stateCount)
+		{
+			// straight from the pinned read-back buffer (same 40-byte layout)
+			memcpy(&s, w->h_state + 10 * (size_t)(first + i), sizeof(b2hip_body_state));
+			s.flags = (s.flags & 0x7cu) | (uint32_t)b.type;
+			continue;
+		}
 		s.px = b.px; s.py = b.py; s.angle = b.a;
 		s.vx = b.vx; s.vy = b.vy; s.w = b.w;
 		s.cx = b.cx; s.cy = b.cy;

@@ -264,3 +264,31 @@ def test_tumbler_colored_mode_runs_and_stays_bounded(amd, oracle, default_mode):
     assert abs(a.contact_count - o.contact_count) <= 0.15 * o.contact_count  # chaotic pile: AABB-pair count only roughly comparable
     a.close()
     o.close()
+
+
+def test_many_small_islands_at_scale_vs_reference_build(amd, ref, default_mode):
+    """20 k bodies in ~10 k islands (hundreds of islands per solver chunk): the default path must stay
+    bit-identical to the reference build, every step."""
+    for scene, p0, p1, steps in [(bh.PILES, 4000, 5, 80), (bh.FIELD, 20000, 0, 40)]:
+        a = amd.world(scene, p0, p1, seed=21)
+        r = ref.world(scene, p0, p1, seed=21)
+        for s in range(steps):
+            a.step(1)
+            r.step(1)
+            assert a.contact_count == r.contact_count, "scene %d step %d" % (scene, s)
+            assert np.array_equal(a.bodies().view(np.uint32), r.bodies().view(np.uint32)), "scene %d step %d" % (scene, s)
+        a.close()
+        r.close()
+
+
+def test_determinism_at_scale(amd, default_mode):
+    """The reference's consistency rule (TestMT.cpp:91-110) on 100 k bodies: two runs, bitwise equal."""
+    a = amd.world(bh.PILES, 20000, 5, seed=4)
+    b = amd.world(bh.PILES, 20000, 5, seed=4)
+    for s in range(50):
+        a.step(1)
+        b.step(1)
+    assert a.contact_count == b.contact_count
+    assert np.array_equal(a.bodies().view(np.uint32), b.bodies().view(np.uint32))
+    a.close()
+    b.close()
