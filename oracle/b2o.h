@@ -90,6 +90,14 @@ void b2o_get_fat_aabb(const b2o_world* w, int fixture, float out4[4]);
 
 /* per-function probes (same layouts as the harness probes) */
 void b2o_collide(const b2o_shape* shapeA, const float* xfA3, const b2o_shape* shapeB, const float* xfB3, float* manifold16);
+/* b2Distance / b2TimeOfImpact on raw vertex proxies; sweep9 = {localCenter, c0, c, a0, a, alpha0};
+ * out6 = {pointA, pointB, distance, iterations}; out2 = {state, t} */
+void b2o_probe_distance(int countA, const float* vertsA, float radiusA, const float* xfA3, int countB, const float* vertsB,
+	float radiusB, const float* xfB3, int useRadii, float* out6);
+void b2o_probe_toi(int countA, const float* vertsA, float radiusA, const float* sweepA9, int countB, const float* vertsB,
+	float radiusB, const float* sweepB9, float tMax, float* out2);
+/* continuous-collision diagnostics: out[0] = TOI sub-steps solved, out[1] = b2TimeOfImpact calls, since creation */
+void b2o_get_toi_stats(const b2o_world* w, int32_t out[2]);
 
 #ifdef __cplusplus
 }

@@ -6,10 +6,12 @@
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
  * (b2ContactManager.cpp:366-386). Joints: revolute (b2o_joint.c). Not covered (same as the device
- * path): other joint types, chain shapes, sensors' GJK overlap, TOI.
+ * path): other joint types, chain shapes, sensors' GJK overlap. Continuous collision: b2o_toi.c
+ * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
 #include "b2o_internal.h"
 #include "b2o_joint.h"
+#include "b2o_toi.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +27,13 @@
 #define CF_ENABLED 0x2u
 #define CF_FILTER 0x4u
 #define CF_ISLAND 0x8u
+#define CF_TOI 0x10u           /* e_toiFlag: m_toi is valid */
+#define CF_TOI_CANDIDATE 0x20u /* e_toiCandidateFlag */
+
+#define B2O_MAX_SUB_STEPS 8
+#define B2O_TOI_CONTACT_CAP 32
+#define B2O_TOI_BODY_CAP 64
+#define B2O_TOI_BAUMGARTE 0.75f
 
 typedef struct
 {
@@ -32,7 +41,7 @@ typedef struct
 	uint32_t flags;
 	xform xf;
 	vec2 localCenter, c0, c;
-	float a0, a;
+	float a0, a, alpha0;
 	vec2 v;
 	float w;
 	vec2 force;
@@ -70,6 +79,9 @@ typedef struct
 	float friction, restitution, tangentSpeed;
 	int prev[2], next[2]; /* edge links: side 0 lives in bodyA's list, side 1 in bodyB's list */
 	uint64_t seq;
+	float toi;
+	int toiCount;
+	int managerIndex; /* position in b2o_world::carray (b2Contact::m_managerIndex) */
 } contact_t;
 
 /* b2VelocityConstraintPoint / b2ContactVelocityConstraint / b2ContactPositionConstraint
@@ -106,6 +118,9 @@ struct b2o_world
 	int nextNode, leafCount;
 	int* freeLeaves; int nFreeLeaves, capFreeLeaves;
 	revolute_t* joints; int nJoints, capJoints;
+	/* b2ContactManager::m_contacts: TOI candidates first ([0, toiCount)), maintained by swaps */
+	int* carray; int nArr, capArr, toiCount;
+	int toiEvents, toiCalls; /* TOI sub-steps solved / b2TimeOfImpact calls so far (diagnostics) */
 };
 
 #define GROW(ptr, cap, need, type)                                            \
@@ -140,6 +155,7 @@ void b2o_world_destroy(b2o_world* w)
 	free(w->moves);
 	free(w->freeLeaves);
 	free(w->joints);
+	free(w->carray);
 	free(w);
 }
 
@@ -433,6 +449,66 @@ static int* edge_head(b2o_world* w, int contact, int side)
 	return &w->bodies[side == 0 ? c->bodyA : c->bodyB].contactHead;
 }
 
+/* b2Contact::IsToiCandidate  b2Contact.cpp:300-324 */
+static int is_toi_candidate(const b2o_world* w, const fixture_t* fA, const fixture_t* fB)
+{
+	if (fA->isSensor || fB->isSensor) return 0;
+	const body_t* bA = &w->bodies[fA->body];
+	const body_t* bB = &w->bodies[fB->body];
+	if ((bA->flags & BF_BULLET) || (bB->flags & BF_BULLET)) return 1;
+	int includesNonDynamic = bA->type != 2 || bB->type != 2;
+	int neitherThick = !fA->thick && !fB->thick;
+	return includesNonDynamic && neitherThick;
+}
+
+/* b2ContactManager::AddToContactArray  b2ContactManager.cpp:659-686 */
+static void carray_add(b2o_world* w, int slot)
+{
+	GROW(w->carray, w->capArr, w->nArr + 1, int);
+	contact_t* c = &w->contacts[slot];
+	if ((c->flags & CF_TOI_CANDIDATE) && w->toiCount < w->nArr)
+	{
+		int moved = w->carray[w->toiCount];
+		w->contacts[moved].managerIndex = w->nArr;
+		w->carray[w->nArr++] = moved;
+		w->carray[w->toiCount] = slot;
+		c->managerIndex = w->toiCount++;
+		return;
+	}
+	c->managerIndex = w->nArr;
+	w->carray[w->nArr++] = slot;
+	if (c->flags & CF_TOI_CANDIDATE) w->toiCount++;
+}
+
+/* b2ContactManager::RemoveFromContactArray  b2ContactManager.cpp:688-714 */
+static void carray_remove(b2o_world* w, int slot)
+{
+	contact_t* c = &w->contacts[slot];
+	if (c->managerIndex < w->toiCount)
+	{
+		--w->toiCount;
+		int lastToi = w->carray[w->toiCount];
+		w->contacts[lastToi].managerIndex = c->managerIndex;
+		w->carray[c->managerIndex] = lastToi;
+		int back = w->carray[--w->nArr];
+		if (w->nArr > w->toiCount)
+		{
+			w->carray[w->toiCount] = back;
+			w->contacts[back].managerIndex = w->toiCount;
+		}
+	}
+	else
+	{
+		int back = w->carray[--w->nArr];
+		if (c->managerIndex < w->nArr)
+		{
+			w->contacts[back].managerIndex = c->managerIndex;
+			w->carray[c->managerIndex] = back;
+		}
+	}
+	c->managerIndex = -1;
+}
+
 /* b2ContactManager::OnContactCreate (:507-564) + b2Contact::b2Contact (b2Contact.cpp:125-159) */
 static void create_contact(b2o_world* w, int fLo, int fHi)
 {
@@ -455,6 +531,10 @@ static void create_contact(b2o_world* w, int fLo, int fHi)
 	c->bodyA = w->fixtures[fA].body;
 	c->bodyB = w->fixtures[fB].body;
 	c->flags = CF_ENABLED;
+	if (is_toi_candidate(w, &w->fixtures[fA], &w->fixtures[fB])) c->flags |= CF_TOI_CANDIDATE;
+	c->toi = 1.0f;
+	c->toiCount = 0;
+	c->managerIndex = -1;
 	c->proxyLo = w->fixtures[fLo].proxyId;
 	c->proxyHi = w->fixtures[fHi].proxyId;
 	c->friction = sqrtf(w->fixtures[fA].friction * w->fixtures[fB].friction);
@@ -474,6 +554,7 @@ static void create_contact(b2o_world* w, int fLo, int fHi)
 		if (*head >= 0) w->contacts[*head >> 1].prev[*head & 1] = slot * 2 + side;
 		*head = slot * 2 + side;
 	}
+	carray_add(w, slot);
 	w->liveContacts++;
 }
 
@@ -494,6 +575,7 @@ static void destroy_contact(b2o_world* w, int slot)
 		int* head = edge_head(w, slot, side);
 		if (*head == slot * 2 + side) *head = n;
 	}
+	carray_remove(w, slot);
 	c->alive = 0;
 	GROW(w->freeContacts, w->capFreeContacts, w->nFreeContacts + 1, int);
 	w->freeContacts[w->nFreeContacts++] = slot;
@@ -526,7 +608,52 @@ static int bodies_should_collide_w(const b2o_world* w, int ia, int ib)
 	return 1;
 }
 
-/* b2ContactManager::Collide (:177-230) + b2Contact::UpdateImpl (b2Contact.cpp:173-298) + FinishCollide (:388-439) */
+/* b2Contact::UpdateImpl (b2Contact.cpp:173-298) without the wake-up, which differs between the
+ * multi-threaded Collide (deferred, body A only) and the single-threaded TOI path (both bodies) */
+static void contact_update(b2o_world* w, contact_t* c)
+{
+	const fixture_t* fA = &w->fixtures[c->fixtureA];
+	const fixture_t* fB = &w->fixtures[c->fixtureB];
+	manifold old = c->m;
+	c->flags |= CF_ENABLED;
+	int touching = 0;
+	if (fA->isSensor || fB->isSensor)
+	{
+		c->m.pointCount = 0; /* GJK overlap for sensors is outside the oracle's scope */
+	}
+	else
+	{
+		b2o_evaluate(&c->m, &fA->shape, w->bodies[c->bodyA].xf, &fB->shape, w->bodies[c->bodyB].xf);
+		touching = c->m.pointCount > 0;
+		for (int k = 0; k < c->m.pointCount; ++k)
+		{
+			c->m.ni[k] = 0.0f;
+			c->m.ti[k] = 0.0f;
+			for (int j = 0; j < old.pointCount; ++j)
+			{
+				if (old.id[j] == c->m.id[k])
+				{
+					c->m.ni[k] = old.ni[j];
+					c->m.ti[k] = old.ti[j];
+					break;
+				}
+			}
+		}
+	}
+	if (touching) c->flags |= CF_TOUCHING; else c->flags &= ~CF_TOUCHING;
+}
+
+static const b2o_world* destroy_cmp_world;
+static int destroy_cmp(const void* a, const void* b)
+{
+	const contact_t* p = &destroy_cmp_world->contacts[*(const int*)a];
+	const contact_t* q = &destroy_cmp_world->contacts[*(const int*)b];
+	if (p->proxyLo != q->proxyLo) return p->proxyLo < q->proxyLo ? -1 : 1;
+	if (p->proxyHi != q->proxyHi) return p->proxyHi < q->proxyHi ? -1 : 1;
+	return 0;
+}
+
+/* b2ContactManager::Collide (:177-230) + FinishCollide (:388-439: destroys sorted by proxy ids) */
 static void collide(b2o_world* w)
 {
 	int nSlots = w->nContactSlots;
@@ -556,40 +683,15 @@ static void collide(b2o_world* w)
 			destroys[nDestroy++] = i;
 			continue;
 		}
-		manifold old = c->m;
-		c->flags |= CF_ENABLED;
 		int wasTouching = (c->flags & CF_TOUCHING) != 0;
-		int touching = 0;
+		contact_update(w, c);
 		int sensor = fA->isSensor || fB->isSensor;
-		if (sensor)
-		{
-			touching = 0; /* GJK overlap for sensors is outside the oracle's scope */
-			c->m.pointCount = 0;
-		}
-		else
-		{
-			b2o_evaluate(&c->m, &fA->shape, bA->xf, &fB->shape, bB->xf);
-			touching = c->m.pointCount > 0;
-			for (int k = 0; k < c->m.pointCount; ++k)
-			{
-				c->m.ni[k] = 0.0f;
-				c->m.ti[k] = 0.0f;
-				for (int j = 0; j < old.pointCount; ++j)
-				{
-					if (old.id[j] == c->m.id[k])
-					{
-						c->m.ni[k] = old.ni[j];
-						c->m.ti[k] = old.ti[j];
-						break;
-					}
-				}
-			}
-			if (touching != wasTouching) awakes[nAwake++] = i;
-		}
-		if (touching) c->flags |= CF_TOUCHING; else c->flags &= ~CF_TOUCHING;
+		if (!sensor && ((c->flags & CF_TOUCHING) != 0) != wasTouching) awakes[nAwake++] = i;
 	}
 	/* ConsumeAwakes (:472-485): only fixture A's body (m_nodeB.other twice) */
 	for (int k = 0; k < nAwake; ++k) set_awake(&w->bodies[w->contacts[awakes[k]].bodyA]);
+	destroy_cmp_world = w;
+	qsort(destroys, (size_t)nDestroy, sizeof(int), destroy_cmp);
 	for (int k = 0; k < nDestroy; ++k) destroy_contact(w, destroys[k]);
 	free(destroys);
 	free(awakes);
@@ -664,8 +766,36 @@ static void find_new_contacts(b2o_world* w)
 	w->nMoves = 0;
 }
 
-/* b2ContactManager::SynchronizeFixtures (:315-364) + FinishSynchronizeFixtures (:441-452) +
+/* b2Body::SynchronizeFixtures (b2Body.cpp:475-489) + b2Fixture::Synchronize (b2Fixture.cpp:143-163) +
  * b2DynamicTree::MoveProxy (b2DynamicTree.cpp:130-174) */
+static void sync_body_fixtures(b2o_world* w, body_t* b)
+{
+	xform xf1;
+	xf1.q = r_make(b->a0);
+	xf1.p = v_sub(b->c0, r_mul(xf1.q, b->localCenter));
+	for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
+	{
+		fixture_t* fx = &w->fixtures[f];
+		float a1[4], a2[4], aabb[4];
+		shape_aabb(&fx->shape, xf1, a1);
+		shape_aabb(&fx->shape, b->xf, a2);
+		aabb[0] = f_min(a1[0], a2[0]); aabb[1] = f_min(a1[1], a2[1]);
+		aabb[2] = f_max(a1[2], a2[2]); aabb[3] = f_max(a1[3], a2[3]);
+		int contains = fx->fat[0] <= aabb[0] && fx->fat[1] <= aabb[1] && aabb[2] <= fx->fat[2] && aabb[3] <= fx->fat[3];
+		if (contains) continue;
+		vec2 disp = v_sub(b->xf.p, xf1.p);
+		float lo0 = aabb[0] - B2O_AABB_EXTENSION, lo1 = aabb[1] - B2O_AABB_EXTENSION;
+		float hi0 = aabb[2] + B2O_AABB_EXTENSION, hi1 = aabb[3] + B2O_AABB_EXTENSION;
+		vec2 d = v_scale(B2O_AABB_MULTIPLIER, disp);
+		if (d.x < 0.0f) lo0 += d.x; else hi0 += d.x;
+		if (d.y < 0.0f) lo1 += d.y; else hi1 += d.y;
+		fx->fat[0] = lo0; fx->fat[1] = lo1; fx->fat[2] = hi0; fx->fat[3] = hi1;
+		GROW(w->moves, w->capMoves, w->nMoves + 1, int);
+		w->moves[w->nMoves++] = f;
+	}
+}
+
+/* b2ContactManager::SynchronizeFixtures (:315-364) + FinishSynchronizeFixtures (:441-452) */
 static void synchronize_fixtures(b2o_world* w)
 {
 	for (int i = 0; i < w->nBodies; ++i)
@@ -673,29 +803,7 @@ static void synchronize_fixtures(b2o_world* w)
 		body_t* b = &w->bodies[i];
 		if (b->type == 0) continue;
 		if ((b->flags & BF_ISLAND) == 0) continue;
-		xform xf1;
-		xf1.q = r_make(b->a0);
-		xf1.p = v_sub(b->c0, r_mul(xf1.q, b->localCenter));
-		for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
-		{
-			fixture_t* fx = &w->fixtures[f];
-			float a1[4], a2[4], aabb[4];
-			shape_aabb(&fx->shape, xf1, a1);
-			shape_aabb(&fx->shape, b->xf, a2);
-			aabb[0] = f_min(a1[0], a2[0]); aabb[1] = f_min(a1[1], a2[1]);
-			aabb[2] = f_max(a1[2], a2[2]); aabb[3] = f_max(a1[3], a2[3]);
-			int contains = fx->fat[0] <= aabb[0] && fx->fat[1] <= aabb[1] && aabb[2] <= fx->fat[2] && aabb[3] <= fx->fat[3];
-			if (contains) continue;
-			vec2 disp = v_sub(b->xf.p, xf1.p);
-			float lo0 = aabb[0] - B2O_AABB_EXTENSION, lo1 = aabb[1] - B2O_AABB_EXTENSION;
-			float hi0 = aabb[2] + B2O_AABB_EXTENSION, hi1 = aabb[3] + B2O_AABB_EXTENSION;
-			vec2 d = v_scale(B2O_AABB_MULTIPLIER, disp);
-			if (d.x < 0.0f) lo0 += d.x; else hi0 += d.x;
-			if (d.y < 0.0f) lo1 += d.y; else hi1 += d.y;
-			fx->fat[0] = lo0; fx->fat[1] = lo1; fx->fat[2] = hi0; fx->fat[3] = hi1;
-			GROW(w->moves, w->capMoves, w->nMoves + 1, int);
-			w->moves[w->nMoves++] = f;
-		}
+		sync_body_fixtures(w, b);
 	}
 }
 
@@ -1237,6 +1345,353 @@ static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIte
 	for (int i = 0; i < nb; ++i) w->bodies[i].flags &= ~BF_ISLAND;
 }
 
+/* ---- continuous collision (TOI) ------------------------------------------------------------------ */
+static sweep_t body_sweep(const body_t* b)
+{
+	sweep_t s;
+	s.localCenter = b->localCenter;
+	s.c0 = b->c0; s.c = b->c;
+	s.a0 = b->a0; s.a = b->a;
+	s.alpha0 = b->alpha0;
+	return s;
+}
+
+static void body_set_sweep(body_t* b, const sweep_t* s)
+{
+	b->c0 = s->c0; b->c = s->c;
+	b->a0 = s->a0; b->a = s->a;
+	b->alpha0 = s->alpha0;
+}
+
+/* b2Body::SynchronizeTransform  b2Body.h:958-962 */
+static void body_sync_transform(body_t* b)
+{
+	b->xf.q = r_make(b->a);
+	b->xf.p = v_sub(b->c, r_mul(b->xf.q, b->localCenter));
+}
+
+/* b2Body::Advance  b2Body.h:964-972 */
+static void body_advance(body_t* b, float alpha)
+{
+	sweep_t s = body_sweep(b);
+	b2o_sweep_advance(&s, alpha);
+	s.c = s.c0;
+	s.a = s.a0;
+	body_set_sweep(b, &s);
+	body_sync_transform(b);
+}
+
+/* b2World::ComputeToi  b2World.cpp:362-444 */
+static float compute_toi(b2o_world* w, contact_t* c)
+{
+	if (c->flags & CF_TOI) return c->toi;
+	body_t* bA = &w->bodies[c->bodyA];
+	body_t* bB = &w->bodies[c->bodyB];
+	float alpha0 = bA->alpha0;
+	if (bA->alpha0 < bB->alpha0)
+	{
+		alpha0 = bB->alpha0;
+		sweep_t s = body_sweep(bA);
+		b2o_sweep_advance(&s, alpha0);
+		body_set_sweep(bA, &s);
+	}
+	else if (bB->alpha0 < bA->alpha0)
+	{
+		alpha0 = bA->alpha0;
+		sweep_t s = body_sweep(bB);
+		b2o_sweep_advance(&s, alpha0);
+		body_set_sweep(bB, &s);
+	}
+	gjk_proxy pA, pB;
+	b2o_proxy_set(&pA, &w->fixtures[c->fixtureA].shape);
+	b2o_proxy_set(&pB, &w->fixtures[c->fixtureB].shape);
+	sweep_t sA = body_sweep(bA), sB = body_sweep(bB);
+	toi_output out;
+	b2o_time_of_impact(&out, &pA, &sA, &pB, &sB, 1.0f);
+	float alpha = 1.0f;
+	if (out.state == TOI_TOUCHING) alpha = f_min(alpha0 + (1.0f - alpha0) * out.t, 1.0f);
+	c->toi = alpha;
+	c->flags |= CF_TOI;
+	w->toiCalls++;
+	return alpha;
+}
+
+/* b2World::FindMinToiContact (b2World.cpp:1525-1611). The multi-threaded first pass and the serial
+ * later passes both reduce to: lexicographic minimum of (alpha, proxyLo, proxyHi) over the active,
+ * enabled TOI candidates (b2Contact::ToiLessThan b2Contact.cpp:326-334), visiting the candidates in
+ * contact-array order, which fixes the order of the sweep side effects inside ComputeToi. */
+static int find_min_toi(b2o_world* w, float* alphaOut)
+{
+	int minContact = -1;
+	float minAlpha = 1.0f;
+	for (int i = 0; i < w->toiCount; ++i)
+	{
+		int slot = w->carray[i];
+		contact_t* c = &w->contacts[slot];
+		if (!body_active_for_contact(&w->bodies[c->bodyA]) && !body_active_for_contact(&w->bodies[c->bodyB])) continue;
+		if ((c->flags & CF_ENABLED) == 0 || c->toiCount > B2O_MAX_SUB_STEPS) continue; /* IsMinToiCandidate */
+		float alpha = compute_toi(w, c);
+		int less;
+		if (minContact < 0) less = 1;
+		else if (alpha == minAlpha)
+		{
+			const contact_t* m = &w->contacts[minContact];
+			less = c->proxyLo != m->proxyLo ? c->proxyLo < m->proxyLo : c->proxyHi < m->proxyHi;
+		}
+		else less = alpha < minAlpha;
+		if (less)
+		{
+			minContact = slot;
+			minAlpha = alpha;
+		}
+	}
+	*alphaOut = minAlpha;
+	return minContact;
+}
+
+/* b2Contact::Update(listener) - the single-threaded variant wakes both bodies when the touching state flips */
+static void contact_update_st(b2o_world* w, contact_t* c)
+{
+	int wasTouching = (c->flags & CF_TOUCHING) != 0;
+	contact_update(w, c);
+	int sensor = w->fixtures[c->fixtureA].isSensor || w->fixtures[c->fixtureB].isSensor;
+	if (!sensor && ((c->flags & CF_TOUCHING) != 0) != wasTouching)
+	{
+		set_awake(&w->bodies[c->bodyA]);
+		set_awake(&w->bodies[c->bodyB]);
+	}
+}
+
+/* b2ContactSolver::SolveTOIPositionConstraints  b2ContactSolver.cpp:755-843, one constraint */
+static float solve_position_toi(const constraint_t* cc, pos_t* pos, float minSeparation, int toiIndexA, int toiIndexB)
+{
+	float mA = 0.0f, iA = 0.0f, mB = 0.0f, iB = 0.0f;
+	if (cc->indexA == toiIndexA || cc->indexA == toiIndexB) { mA = cc->invMassA; iA = cc->invIA; }
+	if (cc->indexB == toiIndexA || cc->indexB == toiIndexB) { mB = cc->invMassB; iB = cc->invIB; }
+	vec2 cA = pos[cc->indexA].c, cB = pos[cc->indexB].c;
+	float aA = pos[cc->indexA].a, aB = pos[cc->indexB].a;
+	for (int j = 0; j < cc->pcPointCount; ++j)
+	{
+		xform xfA, xfB;
+		xfA.q = r_make(aA);
+		xfB.q = r_make(aB);
+		xfA.p = v_sub(cA, r_mul(xfA.q, cc->localCenterA));
+		xfB.p = v_sub(cB, r_mul(xfB.q, cc->localCenterB));
+		vec2 normal, point;
+		float separation;
+		if (cc->type == MANIFOLD_CIRCLES)
+		{
+			vec2 pointA = xf_mul(xfA, cc->localPoint);
+			vec2 pointB = xf_mul(xfB, cc->localPoints[0]);
+			normal = v_sub(pointB, pointA);
+			v_normalize(&normal);
+			point = v_scale(0.5f, v_add(pointA, pointB));
+			separation = v_dot(v_sub(pointB, pointA), normal) - cc->radiusA - cc->radiusB;
+		}
+		else if (cc->type == MANIFOLD_FACE_A)
+		{
+			normal = r_mul(xfA.q, cc->localNormal);
+			vec2 planePoint = xf_mul(xfA, cc->localPoint);
+			vec2 clip = xf_mul(xfB, cc->localPoints[j]);
+			separation = v_dot(v_sub(clip, planePoint), normal) - cc->radiusA - cc->radiusB;
+			point = clip;
+		}
+		else
+		{
+			normal = r_mul(xfB.q, cc->localNormal);
+			vec2 planePoint = xf_mul(xfB, cc->localPoint);
+			vec2 clip = xf_mul(xfA, cc->localPoints[j]);
+			separation = v_dot(v_sub(clip, planePoint), normal) - cc->radiusA - cc->radiusB;
+			point = clip;
+			normal = v_neg(normal);
+		}
+		vec2 rA = v_sub(point, cA), rB = v_sub(point, cB);
+		minSeparation = f_min(minSeparation, separation);
+		float C = f_clamp(B2O_TOI_BAUMGARTE * (separation + B2O_LINEAR_SLOP), -B2O_MAX_LINEAR_CORRECTION, 0.0f);
+		float rnA = v_cross(rA, normal), rnB = v_cross(rB, normal);
+		float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+		float impulse = K > 0.0f ? -C / K : 0.0f;
+		vec2 P = v_scale(impulse, normal);
+		cA = v_sub(cA, v_scale(mA, P));
+		aA -= iA * v_cross(rA, P);
+		cB = v_add(cB, v_scale(mB, P));
+		aB += iB * v_cross(rB, P);
+	}
+	pos[cc->indexA].c = cA; pos[cc->indexA].a = aA;
+	pos[cc->indexB].c = cB; pos[cc->indexB].a = aB;
+	return minSeparation;
+}
+
+/* b2Island::SolveTOI  b2Island.cpp:398-530 */
+static void solve_toi_island(b2o_world* w, const int* bodies, int bodyCount, const int* contacts, int contactCount,
+	float h, int velIters, int toiIndexA, int toiIndexB)
+{
+	pos_t positions[B2O_TOI_BODY_CAP];
+	vel_t velocities[B2O_TOI_BODY_CAP];
+	constraint_t cs[B2O_TOI_CONTACT_CAP];
+	for (int i = 0; i < bodyCount; ++i)
+	{
+		body_t* b = &w->bodies[bodies[i]];
+		b->islandIndex = i;
+		positions[i].c = b->c; positions[i].a = b->a;
+		velocities[i].v = b->v; velocities[i].w = b->w;
+	}
+	/* no warm starting in TOI sub-steps (b2World.cpp:995) */
+	int warm = w->warmStarting;
+	w->warmStarting = 0;
+	for (int i = 0; i < contactCount; ++i) init_constraint(w, &cs[i], contacts[i], positions, velocities, 1.0f);
+	for (int it = 0; it < 20; ++it)
+	{
+		float minSeparation = 0.0f;
+		for (int i = 0; i < contactCount; ++i) minSeparation = solve_position_toi(&cs[i], positions, minSeparation, toiIndexA, toiIndexB);
+		if (minSeparation >= -1.5f * B2O_LINEAR_SLOP) break;
+	}
+	/* leap of faith to the new safe state */
+	w->bodies[bodies[toiIndexA]].c0 = positions[toiIndexA].c;
+	w->bodies[bodies[toiIndexA]].a0 = positions[toiIndexA].a;
+	w->bodies[bodies[toiIndexB]].c0 = positions[toiIndexB].c;
+	w->bodies[bodies[toiIndexB]].a0 = positions[toiIndexB].a;
+	/* InitializeVelocityConstraints at the corrected positions */
+	for (int i = 0; i < contactCount; ++i) init_constraint(w, &cs[i], contacts[i], positions, velocities, 1.0f);
+	w->warmStarting = warm;
+	for (int it = 0; it < velIters; ++it)
+		for (int i = 0; i < contactCount; ++i) solve_velocity(&cs[i], velocities);
+	/* impulses are not stored back */
+	for (int i = 0; i < bodyCount; ++i)
+	{
+		vec2 c = positions[i].c, v = velocities[i].v;
+		float a = positions[i].a, ww = velocities[i].w;
+		vec2 translation = v_scale(h, v);
+		if (v_dot(translation, translation) > B2O_MAX_TRANSLATION_SQ)
+		{
+			float ratio = B2O_MAX_TRANSLATION / v_length(translation);
+			v = v_scale(ratio, v);
+		}
+		float rotation = h * ww;
+		if (rotation * rotation > B2O_MAX_ROTATION_SQ)
+		{
+			float ratio = B2O_MAX_ROTATION / f_abs(rotation);
+			ww *= ratio;
+		}
+		c = v_add(c, v_scale(h, v));
+		a += h * ww;
+		body_t* b = &w->bodies[bodies[i]];
+		b->c = c;
+		b->a = a;
+		b->v = v;
+		b->w = ww;
+		body_sync_transform(b);
+	}
+}
+
+/* b2World::StepSolveTOI  b2World.cpp:851-1024 */
+static void step_solve_toi(b2o_world* w, float dt, int velIters, int minSlot, float minAlpha)
+{
+	contact_t* mc = &w->contacts[minSlot];
+	int ia = mc->bodyA, ib = mc->bodyB;
+	body_t* bA = &w->bodies[ia];
+	body_t* bB = &w->bodies[ib];
+	sweep_t backup1 = body_sweep(bA), backup2 = body_sweep(bB);
+	body_advance(bA, minAlpha);
+	body_advance(bB, minAlpha);
+	contact_update_st(w, mc);
+	mc->flags &= ~CF_TOI;
+	++mc->toiCount;
+	if ((mc->flags & CF_ENABLED) == 0 || (mc->flags & CF_TOUCHING) == 0)
+	{
+		mc->flags &= ~CF_ENABLED;
+		body_set_sweep(bA, &backup1);
+		body_set_sweep(bB, &backup2);
+		body_sync_transform(bA);
+		body_sync_transform(bB);
+		return;
+	}
+	set_awake(bA);
+	set_awake(bB);
+	int bodies[B2O_TOI_BODY_CAP], contacts[B2O_TOI_CONTACT_CAP];
+	int bodyCount = 0, contactCount = 0;
+	bodies[bodyCount++] = ia;
+	bodies[bodyCount++] = ib;
+	contacts[contactCount++] = minSlot;
+	bA->flags |= BF_ISLAND;
+	bB->flags |= BF_ISLAND;
+	mc->flags |= CF_ISLAND;
+	const int seeds[2] = { ia, ib };
+	for (int k = 0; k < 2; ++k)
+	{
+		body_t* body = &w->bodies[seeds[k]];
+		if (body->type != 2) continue;
+		for (int e = body->contactHead; e >= 0; e = w->contacts[e >> 1].next[e & 1])
+		{
+			if (bodyCount == B2O_TOI_BODY_CAP) break;
+			if (contactCount == B2O_TOI_CONTACT_CAP) break;
+			contact_t* c = &w->contacts[e >> 1];
+			if (c->flags & CF_ISLAND) continue;
+			int oi = (e & 1) == 0 ? c->bodyB : c->bodyA;
+			body_t* other = &w->bodies[oi];
+			if (other->type == 2 && (body->flags & BF_BULLET) == 0 && (other->flags & BF_BULLET) == 0) continue;
+			if (w->fixtures[c->fixtureA].isSensor || w->fixtures[c->fixtureB].isSensor) continue;
+			sweep_t backup = body_sweep(other);
+			if ((other->flags & BF_ISLAND) == 0) body_advance(other, minAlpha);
+			contact_update_st(w, c);
+			if ((c->flags & CF_ENABLED) == 0 || (c->flags & CF_TOUCHING) == 0)
+			{
+				body_set_sweep(other, &backup);
+				body_sync_transform(other);
+				continue;
+			}
+			c->flags |= CF_ISLAND;
+			contacts[contactCount++] = e >> 1;
+			if (other->flags & BF_ISLAND) continue;
+			other->flags |= BF_ISLAND;
+			if (other->type != 0) set_awake(other);
+			bodies[bodyCount++] = oi;
+		}
+	}
+	float subDt = (1.0f - minAlpha) * dt;
+	solve_toi_island(w, bodies, bodyCount, contacts, contactCount, subDt, velIters, 0, 1);
+	for (int i = 0; i < bodyCount; ++i)
+	{
+		body_t* body = &w->bodies[bodies[i]];
+		body->flags &= ~BF_ISLAND;
+		if (body->type != 2) continue;
+		sync_body_fixtures(w, body);
+		for (int e = body->contactHead; e >= 0; e = w->contacts[e >> 1].next[e & 1])
+			w->contacts[e >> 1].flags &= ~(CF_ISLAND | CF_TOI);
+	}
+	find_new_contacts(w);
+	w->toiEvents++;
+}
+
+/* b2World::SolveTOI (b2World.cpp:1026-1093) + ClearPostSolveTOI (:1467-1523) */
+static void solve_toi(b2o_world* w, float dt, int velIters)
+{
+	int clearPost = 0, first = 1;
+	for (;;)
+	{
+		float minAlpha = 1.0f;
+		int minSlot = find_min_toi(w, &minAlpha);
+		if (first && minSlot >= 0) clearPost = 1;
+		first = 0;
+		if (minSlot < 0 || 1.0f - 10.0f * B2O_EPSILON < minAlpha) break;
+		step_solve_toi(w, dt, velIters, minSlot, minAlpha);
+	}
+	if (!clearPost) return;
+	for (int i = 0; i < w->nContactSlots; ++i)
+	{
+		contact_t* c = &w->contacts[i];
+		if (!c->alive) continue;
+		c->flags &= ~(CF_TOI | CF_ISLAND);
+		c->toiCount = 0;
+		c->toi = 1.0f;
+	}
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		w->bodies[i].flags &= ~BF_ISLAND;
+		w->bodies[i].alpha0 = 0.0f;
+	}
+}
+
 /* b2World::Step  b2World.cpp:1613-1710 */
 void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 {
@@ -1249,6 +1704,7 @@ void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 	float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
 	float dtRatio = w->inv_dt0 * dt;
 	if (dt > 0.0f) solve(w, dt, dtRatio, velIters, posIters);
+	if (w->continuous && dt > 0.0f) solve_toi(w, dt, velIters);
 	if (dt > 0.0f) w->inv_dt0 = inv_dt;
 	for (int i = 0; i < w->nBodies; ++i)
 	{
@@ -1333,4 +1789,10 @@ void b2o_get_island_labels(const b2o_world* w, int32_t* out)
 void b2o_get_fat_aabb(const b2o_world* w, int fixture, float out4[4])
 {
 	memcpy(out4, w->fixtures[fixture].fat, 16);
+}
+
+void b2o_get_toi_stats(const b2o_world* w, int32_t out[2])
+{
+	out[0] = w->toiEvents;
+	out[1] = w->toiCalls;
 }

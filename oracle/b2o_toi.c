@@ -1,0 +1,601 @@
+/* b2o_toi.c - CPU oracle: GJK distance and conservative-advancement time of impact
+ * (TEST INFRASTRUCTURE, see b2o.h).
+ *
+ * Restates, operation for operation, the reference's
+ *   b2Distance          Box2D/Collision/b2Distance.cpp:103-604   (simplex cache, Solve2/Solve3, main loop)
+ *   b2TimeOfImpact      Box2D/Collision/b2TimeOfImpact.cpp:45-486 (separation function + root finder)
+ *   b2Sweep             Box2D/Common/b2Math.h:679-705
+ * Every float expression keeps the reference's operand order; build with -ffp-contract=off.
+ */
+#include "b2o_toi.h"
+
+#include <string.h>
+
+/* ---- sweep ----------------------------------------------------------------------------------------- */
+/* b2Sweep::GetTransform  b2Math.h:679-687 */
+xform b2o_sweep_xf(const sweep_t* s, float beta)
+{
+	xform xf;
+	float om = 1.0f - beta;
+	xf.p = v_add(v_scale(om, s->c0), v_scale(beta, s->c));
+	float angle = om * s->a0 + beta * s->a;
+	xf.q = r_make(angle);
+	xf.p = v_sub(xf.p, r_mul(xf.q, s->localCenter));
+	return xf;
+}
+
+/* b2Sweep::Advance  b2Math.h:689-696 */
+void b2o_sweep_advance(sweep_t* s, float alpha)
+{
+	float beta = (alpha - s->alpha0) / (1.0f - s->alpha0);
+	s->c0 = v_add(s->c0, v_scale(beta, v_sub(s->c, s->c0)));
+	s->a0 += beta * (s->a - s->a0);
+	s->alpha0 = alpha;
+}
+
+/* b2Sweep::Normalize  b2Math.h:699-705 */
+static void sweep_normalize(sweep_t* s)
+{
+	float twoPi = 2.0f * B2O_PI;
+	float d = twoPi * floorf(s->a0 / twoPi);
+	s->a0 -= d;
+	s->a -= d;
+}
+
+/* ---- distance proxy -------------------------------------------------------------------------------- */
+/* b2DistanceProxy::Set  b2Distance.cpp:31-83 : circle = 1 vertex, edge = 2, polygon = m_count */
+void b2o_proxy_set(gjk_proxy* p, const b2o_shape* s)
+{
+	p->verts = s->verts;
+	p->radius = s->radius;
+	if (s->type == SHAPE_CIRCLE) p->count = 1;
+	else if (s->type == SHAPE_EDGE) p->count = 2;
+	else p->count = s->count;
+}
+
+static inline vec2 proxy_vertex(const gjk_proxy* p, int i) { return v_make(p->verts[2 * i], p->verts[2 * i + 1]); }
+
+/* b2DistanceProxy::GetSupport  b2Distance.h:132-147 : first maximum wins (strict >) */
+static int proxy_support(const gjk_proxy* p, vec2 d)
+{
+	int best = 0;
+	float bestValue = v_dot(proxy_vertex(p, 0), d);
+	for (int i = 1; i < p->count; ++i)
+	{
+		float value = v_dot(proxy_vertex(p, i), d);
+		if (value > bestValue)
+		{
+			best = i;
+			bestValue = value;
+		}
+	}
+	return best;
+}
+
+/* ---- simplex --------------------------------------------------------------------------------------- */
+typedef struct
+{
+	vec2 wA, wB, w;
+	float a;
+	int indexA, indexB;
+} sv_t;
+
+typedef struct
+{
+	sv_t v[3];
+	int count;
+} simplex_t;
+
+/* b2Simplex::GetMetric  b2Distance.cpp:241-264 */
+static float simplex_metric(const simplex_t* s)
+{
+	if (s->count == 2) return v_length(v_sub(s->v[0].w, s->v[1].w));
+	if (s->count == 3) return v_cross(v_sub(s->v[1].w, s->v[0].w), v_sub(s->v[2].w, s->v[0].w));
+	return 0.0f;
+}
+
+static void simplex_vertex(sv_t* v, const gjk_proxy* pA, xform xfA, int ia, const gjk_proxy* pB, xform xfB, int ib)
+{
+	v->indexA = ia;
+	v->indexB = ib;
+	v->wA = xf_mul(xfA, proxy_vertex(pA, ia));
+	v->wB = xf_mul(xfB, proxy_vertex(pB, ib));
+	v->w = v_sub(v->wB, v->wA);
+}
+
+/* b2Simplex::ReadCache  b2Distance.cpp:105-158 */
+static void simplex_read(simplex_t* s, const gjk_cache* cache, const gjk_proxy* pA, xform xfA, const gjk_proxy* pB, xform xfB)
+{
+	s->count = cache->count;
+	for (int i = 0; i < s->count; ++i)
+	{
+		simplex_vertex(&s->v[i], pA, xfA, cache->indexA[i], pB, xfB, cache->indexB[i]);
+		s->v[i].a = 0.0f;
+	}
+	if (s->count > 1)
+	{
+		float metric1 = cache->metric;
+		float metric2 = simplex_metric(s);
+		if (metric2 < 0.5f * metric1 || 2.0f * metric1 < metric2 || metric2 < B2O_EPSILON) s->count = 0;
+	}
+	if (s->count == 0)
+	{
+		simplex_vertex(&s->v[0], pA, xfA, 0, pB, xfB, 0);
+		s->v[0].a = 1.0f;
+		s->count = 1;
+	}
+}
+
+/* b2Simplex::WriteCache  b2Distance.cpp:160-170 */
+static void simplex_write(const simplex_t* s, gjk_cache* cache)
+{
+	cache->metric = simplex_metric(s);
+	cache->count = s->count;
+	for (int i = 0; i < s->count; ++i)
+	{
+		cache->indexA[i] = (uint8_t)s->v[i].indexA;
+		cache->indexB[i] = (uint8_t)s->v[i].indexB;
+	}
+}
+
+/* b2Simplex::GetSearchDirection  b2Distance.cpp:172-199 */
+static vec2 simplex_direction(const simplex_t* s)
+{
+	if (s->count == 1) return v_neg(s->v[0].w);
+	vec2 e12 = v_sub(s->v[1].w, s->v[0].w);
+	float sgn = v_cross(e12, v_neg(s->v[0].w));
+	if (sgn > 0.0f) return v_cross_sv(1.0f, e12);
+	return v_cross_vs(e12, 1.0f);
+}
+
+/* b2Simplex::GetWitnessPoints  b2Distance.cpp:214-239 */
+static void simplex_witness(const simplex_t* s, vec2* pA, vec2* pB)
+{
+	const sv_t* v = s->v;
+	if (s->count == 1)
+	{
+		*pA = v[0].wA;
+		*pB = v[0].wB;
+	}
+	else if (s->count == 2)
+	{
+		*pA = v_add(v_scale(v[0].a, v[0].wA), v_scale(v[1].a, v[1].wA));
+		*pB = v_add(v_scale(v[0].a, v[0].wB), v_scale(v[1].a, v[1].wB));
+	}
+	else
+	{
+		*pA = v_add(v_add(v_scale(v[0].a, v[0].wA), v_scale(v[1].a, v[1].wA)), v_scale(v[2].a, v[2].wA));
+		*pB = *pA;
+	}
+}
+
+/* b2Simplex::Solve2  b2Distance.cpp:297-330 */
+static void simplex_solve2(simplex_t* s)
+{
+	vec2 w1 = s->v[0].w, w2 = s->v[1].w;
+	vec2 e12 = v_sub(w2, w1);
+	float d12_2 = -v_dot(w1, e12);
+	if (d12_2 <= 0.0f)
+	{
+		s->v[0].a = 1.0f;
+		s->count = 1;
+		return;
+	}
+	float d12_1 = v_dot(w2, e12);
+	if (d12_1 <= 0.0f)
+	{
+		s->v[1].a = 1.0f;
+		s->count = 1;
+		s->v[0] = s->v[1];
+		return;
+	}
+	float inv = 1.0f / (d12_1 + d12_2);
+	s->v[0].a = d12_1 * inv;
+	s->v[1].a = d12_2 * inv;
+	s->count = 2;
+}
+
+/* b2Simplex::Solve3  b2Distance.cpp:338-440 */
+static void simplex_solve3(simplex_t* s)
+{
+	vec2 w1 = s->v[0].w, w2 = s->v[1].w, w3 = s->v[2].w;
+	vec2 e12 = v_sub(w2, w1);
+	float d12_1 = v_dot(w2, e12);
+	float d12_2 = -v_dot(w1, e12);
+	vec2 e13 = v_sub(w3, w1);
+	float d13_1 = v_dot(w3, e13);
+	float d13_2 = -v_dot(w1, e13);
+	vec2 e23 = v_sub(w3, w2);
+	float d23_1 = v_dot(w3, e23);
+	float d23_2 = -v_dot(w2, e23);
+	float n123 = v_cross(e12, e13);
+	float d123_1 = n123 * v_cross(w2, w3);
+	float d123_2 = n123 * v_cross(w3, w1);
+	float d123_3 = n123 * v_cross(w1, w2);
+	if (d12_2 <= 0.0f && d13_2 <= 0.0f)
+	{
+		s->v[0].a = 1.0f;
+		s->count = 1;
+		return;
+	}
+	if (d12_1 > 0.0f && d12_2 > 0.0f && d123_3 <= 0.0f)
+	{
+		float inv = 1.0f / (d12_1 + d12_2);
+		s->v[0].a = d12_1 * inv;
+		s->v[1].a = d12_2 * inv;
+		s->count = 2;
+		return;
+	}
+	if (d13_1 > 0.0f && d13_2 > 0.0f && d123_2 <= 0.0f)
+	{
+		float inv = 1.0f / (d13_1 + d13_2);
+		s->v[0].a = d13_1 * inv;
+		s->v[2].a = d13_2 * inv;
+		s->count = 2;
+		s->v[1] = s->v[2];
+		return;
+	}
+	if (d12_1 <= 0.0f && d23_2 <= 0.0f)
+	{
+		s->v[1].a = 1.0f;
+		s->count = 1;
+		s->v[0] = s->v[1];
+		return;
+	}
+	if (d13_1 <= 0.0f && d23_1 <= 0.0f)
+	{
+		s->v[2].a = 1.0f;
+		s->count = 1;
+		s->v[0] = s->v[2];
+		return;
+	}
+	if (d23_1 > 0.0f && d23_2 > 0.0f && d123_1 <= 0.0f)
+	{
+		float inv = 1.0f / (d23_1 + d23_2);
+		s->v[1].a = d23_1 * inv;
+		s->v[2].a = d23_2 * inv;
+		s->count = 2;
+		s->v[0] = s->v[2];
+		return;
+	}
+	float inv = 1.0f / (d123_1 + d123_2 + d123_3);
+	s->v[0].a = d123_1 * inv;
+	s->v[1].a = d123_2 * inv;
+	s->v[2].a = d123_3 * inv;
+	s->count = 3;
+}
+
+/* b2Distance  b2Distance.cpp:444-604 */
+void b2o_distance(gjk_output* out, gjk_cache* cache, const gjk_proxy* pA, xform xfA, const gjk_proxy* pB, xform xfB, int useRadii)
+{
+	simplex_t simplex;
+	memset(&simplex, 0, sizeof(simplex));
+	simplex_read(&simplex, cache, pA, xfA, pB, xfB);
+	int saveA[3], saveB[3];
+	int iter = 0;
+	while (iter < 20)
+	{
+		int saveCount = simplex.count;
+		for (int i = 0; i < saveCount; ++i)
+		{
+			saveA[i] = simplex.v[i].indexA;
+			saveB[i] = simplex.v[i].indexB;
+		}
+		if (simplex.count == 2) simplex_solve2(&simplex);
+		else if (simplex.count == 3) simplex_solve3(&simplex);
+		if (simplex.count == 3) break;
+		vec2 d = simplex_direction(&simplex);
+		if (v_dot(d, d) < B2O_EPSILON * B2O_EPSILON) break;
+		sv_t* nv = &simplex.v[simplex.count];
+		int ia = proxy_support(pA, r_mul_t(xfA.q, v_neg(d)));
+		int ib = proxy_support(pB, r_mul_t(xfB.q, d));
+		simplex_vertex(nv, pA, xfA, ia, pB, xfB, ib);
+		++iter;
+		int duplicate = 0;
+		for (int i = 0; i < saveCount; ++i)
+		{
+			if (ia == saveA[i] && ib == saveB[i])
+			{
+				duplicate = 1;
+				break;
+			}
+		}
+		if (duplicate) break;
+		++simplex.count;
+	}
+	simplex_witness(&simplex, &out->pointA, &out->pointB);
+	out->distance = v_length(v_sub(out->pointA, out->pointB));
+	out->iterations = iter;
+	simplex_write(&simplex, cache);
+	if (useRadii)
+	{
+		float rA = pA->radius, rB = pB->radius;
+		if (out->distance > rA + rB && out->distance > B2O_EPSILON)
+		{
+			out->distance -= rA + rB;
+			vec2 normal = v_sub(out->pointB, out->pointA);
+			v_normalize(&normal);
+			out->pointA = v_add(out->pointA, v_scale(rA, normal));
+			out->pointB = v_sub(out->pointB, v_scale(rB, normal));
+		}
+		else
+		{
+			vec2 p = v_scale(0.5f, v_add(out->pointA, out->pointB));
+			out->pointA = p;
+			out->pointB = p;
+			out->distance = 0.0f;
+		}
+	}
+}
+
+/* ---- separation function --------------------------------------------------------------------------- */
+enum { SEP_POINTS = 0, SEP_FACE_A = 1, SEP_FACE_B = 2 };
+
+typedef struct
+{
+	const gjk_proxy* pA;
+	const gjk_proxy* pB;
+	sweep_t sweepA, sweepB;
+	int type;
+	vec2 localPoint, axis;
+} sepfn_t;
+
+/* b2SeparationFunction::Initialize  b2TimeOfImpact.cpp:45-129 */
+static void sep_init(sepfn_t* f, const gjk_cache* cache, const gjk_proxy* pA, const sweep_t* sweepA, const gjk_proxy* pB,
+	const sweep_t* sweepB, float t1)
+{
+	f->pA = pA;
+	f->pB = pB;
+	f->sweepA = *sweepA;
+	f->sweepB = *sweepB;
+	f->localPoint = v_make(0.0f, 0.0f);
+	xform xfA = b2o_sweep_xf(&f->sweepA, t1);
+	xform xfB = b2o_sweep_xf(&f->sweepB, t1);
+	if (cache->count == 1)
+	{
+		f->type = SEP_POINTS;
+		vec2 pointA = xf_mul(xfA, proxy_vertex(pA, cache->indexA[0]));
+		vec2 pointB = xf_mul(xfB, proxy_vertex(pB, cache->indexB[0]));
+		f->axis = v_sub(pointB, pointA);
+		v_normalize(&f->axis);
+	}
+	else if (cache->indexA[0] == cache->indexA[1])
+	{
+		f->type = SEP_FACE_B;
+		vec2 b1 = proxy_vertex(pB, cache->indexB[0]);
+		vec2 b2 = proxy_vertex(pB, cache->indexB[1]);
+		f->axis = v_cross_vs(v_sub(b2, b1), 1.0f);
+		v_normalize(&f->axis);
+		vec2 normal = r_mul(xfB.q, f->axis);
+		f->localPoint = v_scale(0.5f, v_add(b1, b2));
+		vec2 pointB = xf_mul(xfB, f->localPoint);
+		vec2 pointA = xf_mul(xfA, proxy_vertex(pA, cache->indexA[0]));
+		float s = v_dot(v_sub(pointA, pointB), normal);
+		if (s < 0.0f) f->axis = v_neg(f->axis);
+	}
+	else
+	{
+		f->type = SEP_FACE_A;
+		vec2 a1 = proxy_vertex(pA, cache->indexA[0]);
+		vec2 a2 = proxy_vertex(pA, cache->indexA[1]);
+		f->axis = v_cross_vs(v_sub(a2, a1), 1.0f);
+		v_normalize(&f->axis);
+		vec2 normal = r_mul(xfA.q, f->axis);
+		f->localPoint = v_scale(0.5f, v_add(a1, a2));
+		vec2 pointA = xf_mul(xfA, f->localPoint);
+		vec2 pointB = xf_mul(xfB, proxy_vertex(pB, cache->indexB[0]));
+		float s = v_dot(v_sub(pointB, pointA), normal);
+		if (s < 0.0f) f->axis = v_neg(f->axis);
+	}
+}
+
+/* b2SeparationFunction::Evaluate  b2TimeOfImpact.cpp:193-245 */
+static float sep_eval_xf(const sepfn_t* f, xform xfA, xform xfB, int indexA, int indexB)
+{
+	if (f->type == SEP_POINTS)
+	{
+		vec2 pointA = xf_mul(xfA, proxy_vertex(f->pA, indexA));
+		vec2 pointB = xf_mul(xfB, proxy_vertex(f->pB, indexB));
+		return v_dot(v_sub(pointB, pointA), f->axis);
+	}
+	if (f->type == SEP_FACE_A)
+	{
+		vec2 normal = r_mul(xfA.q, f->axis);
+		vec2 pointA = xf_mul(xfA, f->localPoint);
+		vec2 pointB = xf_mul(xfB, proxy_vertex(f->pB, indexB));
+		return v_dot(v_sub(pointB, pointA), normal);
+	}
+	vec2 normal = r_mul(xfB.q, f->axis);
+	vec2 pointB = xf_mul(xfB, f->localPoint);
+	vec2 pointA = xf_mul(xfA, proxy_vertex(f->pA, indexA));
+	return v_dot(v_sub(pointA, pointB), normal);
+}
+
+static float sep_eval(const sepfn_t* f, int indexA, int indexB, float t)
+{
+	xform xfA = b2o_sweep_xf(&f->sweepA, t);
+	xform xfB = b2o_sweep_xf(&f->sweepB, t);
+	return sep_eval_xf(f, xfA, xfB, indexA, indexB);
+}
+
+/* b2SeparationFunction::FindMinSeparation  b2TimeOfImpact.cpp:132-190 */
+static float sep_find_min(const sepfn_t* f, int* indexA, int* indexB, float t)
+{
+	xform xfA = b2o_sweep_xf(&f->sweepA, t);
+	xform xfB = b2o_sweep_xf(&f->sweepB, t);
+	if (f->type == SEP_POINTS)
+	{
+		*indexA = proxy_support(f->pA, r_mul_t(xfA.q, f->axis));
+		*indexB = proxy_support(f->pB, r_mul_t(xfB.q, v_neg(f->axis)));
+	}
+	else if (f->type == SEP_FACE_A)
+	{
+		vec2 normal = r_mul(xfA.q, f->axis);
+		*indexA = -1;
+		*indexB = proxy_support(f->pB, r_mul_t(xfB.q, v_neg(normal)));
+	}
+	else
+	{
+		vec2 normal = r_mul(xfB.q, f->axis);
+		*indexB = -1;
+		*indexA = proxy_support(f->pA, r_mul_t(xfA.q, v_neg(normal)));
+	}
+	return sep_eval_xf(f, xfA, xfB, *indexA, *indexB);
+}
+
+/* b2TimeOfImpact  b2TimeOfImpact.cpp:253-486 */
+void b2o_time_of_impact(toi_output* out, const gjk_proxy* pA, const sweep_t* sweepAIn, const gjk_proxy* pB,
+	const sweep_t* sweepBIn, float tMax)
+{
+	out->state = TOI_UNKNOWN;
+	out->t = tMax;
+	sweep_t sweepA = *sweepAIn, sweepB = *sweepBIn;
+	sweep_normalize(&sweepA);
+	sweep_normalize(&sweepB);
+	float totalRadius = pA->radius + pB->radius;
+	float target = f_max(B2O_LINEAR_SLOP, totalRadius - 3.0f * B2O_LINEAR_SLOP);
+	float tolerance = 0.25f * B2O_LINEAR_SLOP;
+	float t1 = 0.0f;
+	int iter = 0;
+	gjk_cache cache;
+	memset(&cache, 0, sizeof(cache));
+	for (;;)
+	{
+		xform xfA = b2o_sweep_xf(&sweepA, t1);
+		xform xfB = b2o_sweep_xf(&sweepB, t1);
+		gjk_output dist;
+		b2o_distance(&dist, &cache, pA, xfA, pB, xfB, 0);
+		if (dist.distance <= 0.0f)
+		{
+			out->state = TOI_OVERLAPPED;
+			out->t = 0.0f;
+			break;
+		}
+		if (dist.distance < target + tolerance)
+		{
+			out->state = TOI_TOUCHING;
+			out->t = t1;
+			break;
+		}
+		sepfn_t fcn;
+		sep_init(&fcn, &cache, pA, &sweepA, pB, &sweepB, t1);
+		int done = 0;
+		float t2 = tMax;
+		int pushBackIter = 0;
+		for (;;)
+		{
+			int indexA, indexB;
+			float s2 = sep_find_min(&fcn, &indexA, &indexB, t2);
+			if (s2 > target + tolerance)
+			{
+				out->state = TOI_SEPARATED;
+				out->t = tMax;
+				done = 1;
+				break;
+			}
+			if (s2 > target - tolerance)
+			{
+				t1 = t2;
+				break;
+			}
+			float s1 = sep_eval(&fcn, indexA, indexB, t1);
+			if (s1 < target - tolerance)
+			{
+				out->state = TOI_FAILED;
+				out->t = t1;
+				done = 1;
+				break;
+			}
+			if (s1 <= target + tolerance)
+			{
+				out->state = TOI_TOUCHING;
+				out->t = t1;
+				done = 1;
+				break;
+			}
+			int rootIter = 0;
+			float a1 = t1, a2 = t2;
+			for (;;)
+			{
+				float t;
+				if (rootIter & 1) t = a1 + (target - s1) * (a2 - a1) / (s2 - s1);
+				else t = 0.5f * (a1 + a2);
+				++rootIter;
+				float s = sep_eval(&fcn, indexA, indexB, t);
+				if (f_abs(s - target) < tolerance)
+				{
+					t2 = t;
+					break;
+				}
+				if (s > target)
+				{
+					a1 = t;
+					s1 = s;
+				}
+				else
+				{
+					a2 = t;
+					s2 = s;
+				}
+				if (rootIter == 50) break;
+			}
+			++pushBackIter;
+			if (pushBackIter == 8) break; /* b2_maxPolygonVertices */
+		}
+		++iter;
+		if (done) break;
+		if (iter == 20)
+		{
+			out->state = TOI_FAILED;
+			out->t = t1;
+			break;
+		}
+	}
+	out->iterations = iter;
+}
+
+/* ---- probes (same layouts as oracle/harness/harness.cpp b2h_probe_distance / b2h_probe_toi) -------- */
+static sweep_t sweep_from9(const float* s9)
+{
+	sweep_t s;
+	s.localCenter = v_make(s9[0], s9[1]);
+	s.c0 = v_make(s9[2], s9[3]);
+	s.c = v_make(s9[4], s9[5]);
+	s.a0 = s9[6];
+	s.a = s9[7];
+	s.alpha0 = s9[8];
+	return s;
+}
+
+static xform xf_from3(const float* xf3)
+{
+	xform t;
+	t.p = v_make(xf3[0], xf3[1]);
+	t.q = r_make(xf3[2]);
+	return t;
+}
+
+void b2o_probe_distance(int countA, const float* vertsA, float radiusA, const float* xfA, int countB, const float* vertsB,
+	float radiusB, const float* xfB, int useRadii, float* out6)
+{
+	gjk_proxy pA = { vertsA, countA, radiusA }, pB = { vertsB, countB, radiusB };
+	gjk_cache cache;
+	memset(&cache, 0, sizeof(cache));
+	gjk_output out;
+	b2o_distance(&out, &cache, &pA, xf_from3(xfA), &pB, xf_from3(xfB), useRadii);
+	out6[0] = out.pointA.x; out6[1] = out.pointA.y;
+	out6[2] = out.pointB.x; out6[3] = out.pointB.y;
+	out6[4] = out.distance;
+	out6[5] = (float)out.iterations;
+}
+
+void b2o_probe_toi(int countA, const float* vertsA, float radiusA, const float* sweepA9, int countB, const float* vertsB,
+	float radiusB, const float* sweepB9, float tMax, float* out2)
+{
+	gjk_proxy pA = { vertsA, countA, radiusA }, pB = { vertsB, countB, radiusB };
+	sweep_t sA = sweep_from9(sweepA9), sB = sweep_from9(sweepB9);
+	toi_output out;
+	b2o_time_of_impact(&out, &pA, &sA, &pB, &sB, tMax);
+	out2[0] = (float)out.state;
+	out2[1] = out.t;
+}

@@ -403,4 +403,64 @@ void b2h_probe_sincos(int n, const float* angles, float* sinOut, float* cosOut)
 	}
 }
 
+#ifdef B2H_BACKEND_REF
+// --- continuous-collision probes: b2Distance and b2TimeOfImpact on raw vertex proxies.
+// sweep9 = {localCenter.x, .y, c0.x, c0.y, c.x, c.y, a0, a, alpha0}
+static void FillProxy(b2DistanceProxy& p, b2Vec2* store, int count, const float* verts, float radius)
+{
+	for (int i = 0; i < count; ++i) store[i].Set(verts[2 * i], verts[2 * i + 1]);
+	p.Set(store, count, radius);
+}
+
+static b2Sweep MakeSweep(const float* s9)
+{
+	b2Sweep s;
+	s.localCenter.Set(s9[0], s9[1]);
+	s.c0.Set(s9[2], s9[3]);
+	s.c.Set(s9[4], s9[5]);
+	s.a0 = s9[6];
+	s.a = s9[7];
+	s.alpha0 = s9[8];
+	return s;
+}
+
+// out6 = {pointA.x, pointA.y, pointB.x, pointB.y, distance, iterations}
+void b2h_probe_distance(int countA, const float* vertsA, float radiusA, const float* xfA,
+	int countB, const float* vertsB, float radiusB, const float* xfB, int useRadii, float* out6)
+{
+	b2Vec2 storeA[b2_maxPolygonVertices], storeB[b2_maxPolygonVertices];
+	b2DistanceInput in;
+	FillProxy(in.proxyA, storeA, countA, vertsA, radiusA);
+	FillProxy(in.proxyB, storeB, countB, vertsB, radiusB);
+	in.transformA = MakeXf(xfA);
+	in.transformB = MakeXf(xfB);
+	in.useRadii = useRadii != 0;
+	b2SimplexCache cache;
+	cache.count = 0;
+	b2DistanceOutput out;
+	b2Distance(&out, &cache, &in);
+	out6[0] = out.pointA.x; out6[1] = out.pointA.y;
+	out6[2] = out.pointB.x; out6[3] = out.pointB.y;
+	out6[4] = out.distance;
+	out6[5] = (float)out.iterations;
+}
+
+// out2 = {state (b2TOIOutput::State), t}
+void b2h_probe_toi(int countA, const float* vertsA, float radiusA, const float* sweepA9,
+	int countB, const float* vertsB, float radiusB, const float* sweepB9, float tMax, float* out2)
+{
+	b2Vec2 storeA[b2_maxPolygonVertices], storeB[b2_maxPolygonVertices];
+	b2TOIInput in;
+	FillProxy(in.proxyA, storeA, countA, vertsA, radiusA);
+	FillProxy(in.proxyB, storeB, countB, vertsB, radiusB);
+	in.sweepA = MakeSweep(sweepA9);
+	in.sweepB = MakeSweep(sweepB9);
+	in.tMax = tMax;
+	b2TOIOutput out;
+	b2TimeOfImpact(&out, &in);
+	out2[0] = (float)out.state;
+	out2[1] = out.t;
+}
+#endif
+
 } // extern "C"

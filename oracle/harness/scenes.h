@@ -67,7 +67,9 @@ enum SceneId
 	e_field = 3,         // p0 = bodies, p1 = bullet count ; f0 = arena half length R (0 -> auto density), f1 = max radius
 	e_piles = 4,         // p0 = piles, p1 = boxes per pile
 	e_rain = 5,          // p0 = bodies (mixed circles / boxes / polygons dropped on a box ground)
-	e_circleStack = 6    // p0 = columns, p1 = circles per column, on an edge ground
+	e_circleStack = 6,   // p0 = columns, p1 = circles per column, on an edge ground
+	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
+	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
 
 struct SceneParams
@@ -445,6 +447,76 @@ inline void BuildCircleStack(Scene& s, b2World* w, int columns, int height)
 	}
 }
 
+// Continuous-collision stress: a 40 x 30 room made of an edge floor and thin (0.1 wide) polygon walls, a few
+// box stacks inside, and fast small projectiles (polygons and circles; every other one is a bullet body)
+// fired through it. Fast non-bullet bodies still get TOI against the static walls; bullets also against the stacks.
+inline void BuildBullets(Scene& s, b2World* w, int projectiles, int stackHeight, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	{
+		b2BodyDef bd;
+		b2Body* room = AddBody(s, w, bd);
+		b2EdgeShape floor;
+		floor.Set(b2Vec2(-20.0f, 0.0f), b2Vec2(20.0f, 0.0f));
+		room->CreateFixture(&floor, 0.0f);
+		b2PolygonShape wall;
+		wall.SetAsBox(0.05f, 15.0f, b2Vec2(-20.0f, 15.0f), 0.0f);
+		room->CreateFixture(&wall, 0.0f);
+		wall.SetAsBox(0.05f, 15.0f, b2Vec2(20.0f, 15.0f), 0.0f);
+		room->CreateFixture(&wall, 0.0f);
+		wall.SetAsBox(20.0f, 0.05f, b2Vec2(0.0f, 30.0f), 0.0f);
+		room->CreateFixture(&wall, 0.0f);
+		// a slanted thin divider
+		wall.SetAsBox(0.05f, 4.0f, b2Vec2(6.0f, 4.0f), 0.3f);
+		room->CreateFixture(&wall, 0.0f);
+	}
+	Pcg32 rng(seed);
+	b2PolygonShape box;
+	box.SetAsBox(0.5f, 0.5f);
+	for (int k = 0; k < 3; ++k)
+	{
+		float x = -10.0f + 5.0f * (float)k;
+		for (int i = 0; i < stackHeight; ++i)
+		{
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(x + 0.02f * rng.Signed(), 0.5f + 1.0f * (float)i);
+			b2Body* body = AddBody(s, w, bd);
+			body->CreateFixture(&box, 1.0f);
+		}
+	}
+	b2CircleShape ball;
+	b2PolygonShape dart;
+	for (int i = 0; i < projectiles; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.bullet = (i & 1) == 0;
+		bd.position.Set(rng.Range(-18.0f, 18.0f), rng.Range(12.0f, 28.0f));
+		bd.angle = rng.Range(0.0f, 2.0f * b2_pi);
+		float speed = rng.Range(60.0f, 250.0f);
+		b2Vec2 n(rng.Signed(), rng.Signed() - 0.5f);
+		n.Normalize();
+		bd.linearVelocity = speed * n;
+		bd.angularVelocity = rng.Range(-20.0f, 20.0f);
+		b2Body* body = AddBody(s, w, bd);
+		b2FixtureDef fd;
+		fd.density = 5.0f;
+		fd.restitution = (i % 3 == 0) ? 0.5f : 0.0f;
+		if (i % 4 < 2)
+		{
+			ball.m_radius = rng.Range(0.1f, 0.3f);
+			fd.shape = &ball;
+		}
+		else
+		{
+			dart.SetAsBox(rng.Range(0.1f, 0.4f), rng.Range(0.05f, 0.15f));
+			fd.shape = &dart;
+		}
+		body->CreateFixture(&fd);
+	}
+}
+
 inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 {
 	switch (p.scene)
@@ -456,6 +528,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_piles: BuildPiles(s, w, p.p0, p.p1, p.seed); break;
 	case e_rain: BuildRain(s, w, p.p0, p.seed); break;
 	case e_circleStack: BuildCircleStack(s, w, p.p0, p.p1); break;
+	case e_bullets: BuildBullets(s, w, p.p0, p.p1, p.seed); break;
 	default: break;
 	}
 }

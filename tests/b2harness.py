@@ -14,7 +14,7 @@ REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libb2ref_harness.so")
 AMD_LIB = os.path.join(ROOT, "box2d-mt_amd", "libb2amd_harness.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libb2oracle_harness.so")
 
-HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK = range(7)
+HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS = range(8)
 F_CONTINUOUS, F_SLEEP, F_WARM, F_SUBSTEP = 1, 2, 4, 8
 DEFAULT_FLAGS = F_SLEEP | F_WARM  # CCD off unless a test asks for it
 
@@ -126,6 +126,29 @@ class Harness:
         pts[:flat.size] = flat
         out = np.zeros(39, np.float32)
         self.lib.b2h_probe_polygon(flat.size // 2, _fptr(pts), C.c_float(density), _fptr(out))
+        return out
+
+    # ---- continuous-collision probes (reference build only) ---------------------------------
+    def distance(self, vertsA, radiusA, xfA, vertsB, radiusB, xfB, use_radii=False):
+        """b2Distance on raw vertex proxies -> [pointA.x, pointA.y, pointB.x, pointB.y, distance, iterations]"""
+        va = np.ascontiguousarray(vertsA, np.float32).reshape(-1)
+        vb = np.ascontiguousarray(vertsB, np.float32).reshape(-1)
+        a = np.asarray(xfA, np.float32)
+        b = np.asarray(xfB, np.float32)
+        out = np.zeros(6, np.float32)
+        self.lib.b2h_probe_distance(va.size // 2, _fptr(va), C.c_float(radiusA), _fptr(a), vb.size // 2, _fptr(vb),
+                                    C.c_float(radiusB), _fptr(b), int(use_radii), _fptr(out))
+        return out
+
+    def toi(self, vertsA, radiusA, sweepA, vertsB, radiusB, sweepB, t_max=1.0):
+        """b2TimeOfImpact on raw vertex proxies; sweep = [lcx, lcy, c0x, c0y, cx, cy, a0, a, alpha0] -> [state, t]"""
+        va = np.ascontiguousarray(vertsA, np.float32).reshape(-1)
+        vb = np.ascontiguousarray(vertsB, np.float32).reshape(-1)
+        a = np.ascontiguousarray(sweepA, np.float32)
+        b = np.ascontiguousarray(sweepB, np.float32)
+        out = np.zeros(2, np.float32)
+        self.lib.b2h_probe_toi(va.size // 2, _fptr(va), C.c_float(radiusA), _fptr(a), vb.size // 2, _fptr(vb),
+                               C.c_float(radiusB), _fptr(b), C.c_float(t_max), _fptr(out))
         return out
 
     def sincos(self, angles):
