@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* k
 		const int bodyA = W.p_body[pA], bodyB = W.p_body[pB];
 		const bool sensor = ((W.p_filter1[pA] | W.p_filter1[pB]) & PF_SENSOR) != 0;
 		uint32_t flags = CF_ENABLED | (sensor ? CF_SENSOR : 0u);
+		if (isToiCandidate(W, pA, pB, bodyA, bodyB)) flags |= CF_TOI_CANDIDATE;
 		float2 mA = W.p_mat[pA], mB = W.p_mat[pB];
 		// b2MixFriction / b2MixRestitution (b2Contact.h:40-50)
 		float friction = b2dSqrt(mA.x * mB.x);
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* k
 		C.imp[dst] = make_float4(0, 0, 0, 0);
 		C.man3[dst] = make_int4(0, 0, 0, 0);
 		C.color[dst] = -1;
+		C.mgr[dst] = -1;
 		if (!sensor)
 		{
 			// SetAwake(true) on both bodies (:525-529), applied by k_apply_wake
@@ -384,6 +386,48 @@ __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 			W.b_wake[i] = 0;
 		}
 	}
+}
+
+// b2ContactManager::AddToContactArray (:659-686): a new TOI candidate takes the slot after the last
+// candidate, in creation order. One workgroup, block scan over the new contacts.
+__global__ __launch_bounds__(256) void k_toi_order_create(DW W, int smallPath)
+{
+	DState* S = W.st;
+	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return;
+	const int nNew = S->c.nNewContacts;
+	if (nNew == 0) return;
+	const int base = S->c.nContacts;
+	const int cap = W.capContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	__shared__ int s_scan[256];
+	__shared__ int s_count;
+	if (threadIdx.x == 0) s_count = S->c.nToiOrder;
+	__syncthreads();
+	for (int i0 = 0; i0 < nNew; i0 += 256)
+	{
+		const int i = base + i0 + threadIdx.x;
+		const int flag = (i0 + threadIdx.x < nNew && i < cap && (C.flags[i] & CF_TOI_CANDIDATE)) ? 1 : 0;
+		s_scan[threadIdx.x] = flag;
+		__syncthreads();
+		for (int off = 1; off < 256; off <<= 1)
+		{
+			const int v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+			__syncthreads();
+			s_scan[threadIdx.x] += v;
+			__syncthreads();
+		}
+		const int start = s_count;
+		if (flag)
+		{
+			const int slot = start + s_scan[threadIdx.x] - 1;
+			C.mgr[i] = slot;
+			W.toiPos2c[slot] = i;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) s_count = start + s_scan[255];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) S->c.nToiOrder = s_count;
 }
 
 __global__ void k_create_commit(DW W, int smallPath)

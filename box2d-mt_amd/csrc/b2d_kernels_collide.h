@@ -63,6 +63,18 @@ __device__ __forceinline__ bool bodiesShouldCollide(const DW& W, int bodyA, int 
 	return true;
 }
 
+// b2Contact::IsToiCandidate (b2Contact.cpp:300-324)
+__device__ __forceinline__ bool isToiCandidate(const DW& W, int proxyA, int proxyB, int bodyA, int bodyB)
+{
+	const int fA = W.p_filter1[proxyA], fB = W.p_filter1[proxyB];
+	if ((fA | fB) & PF_SENSOR) return false;
+	const uint32_t bfA = W.b_flags[bodyA], bfB = W.b_flags[bodyB];
+	if ((bfA | bfB) & BF_BULLET) return true;
+	const bool includesNonDynamic = (bfA & BF_TYPE_MASK) != BT_DYNAMIC || (bfB & BF_TYPE_MASK) != BT_DYNAMIC;
+	const bool neitherThick = ((fA | fB) & PF_THICK) == 0;
+	return includesNonDynamic && neitherThick;
+}
+
 __global__ __launch_bounds__(256) void k_collide(DW W)
 {
 	DState* S = W.st;
@@ -171,6 +183,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 		{
 			flags |= CF_DESTROY;
 			++nDestroy;
+			if (flags & CF_TOI_CANDIDATE) W.toiDestroyList[atomicAdd(&S->c.nToiDestroy, 1)] = i;
 			// b2Contact::Destroy (b2Contact.cpp:100-113): wake both bodies if the manifold had points
 			int pc = C.man3[i].w;
 			if (pc > 0 && (flags & CF_SENSOR) == 0)
@@ -204,6 +217,49 @@ __global__ __launch_bounds__(256) void k_flag_filter(DW W, int bodyA, int bodyB)
 	}
 }
 
+// The reference keeps its TOI-candidate contacts in the first m_toiCount slots of one array and removes a
+// contact by moving the LAST candidate into its slot (b2ContactManager::RemoveFromContactArray, :688-714),
+// destroying in (proxyLow, proxyHigh) order (FinishCollide :388-439). That slot order is the order in which
+// b2World::FindMinToiContact re-synchronises sweeps, so it is mirrored here: ContactArrays::mgr is the slot,
+// toiPos2c its inverse. Few candidates die per step; one lane replays the removals.
+#define TOI_ORDER_SORT_MAX 2048
+__global__ __launch_bounds__(256) void k_toi_order_destroy(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nToiDestroy;
+	if (n == 0) return;
+	const ContactArrays& C = W.ca[S->cur];
+	__shared__ int s_sorted[TOI_ORDER_SORT_MAX];
+	const int m = n < TOI_ORDER_SORT_MAX ? n : TOI_ORDER_SORT_MAX;
+	// rank by key (keys are unique)
+	for (int i = threadIdx.x; i < m; i += blockDim.x)
+	{
+		const int ci = W.toiDestroyList[i];
+		const uint64_t key = C.key[ci];
+		int rank = 0;
+		for (int j = 0; j < m; ++j) rank += C.key[W.toiDestroyList[j]] < key ? 1 : 0;
+		s_sorted[rank] = ci;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		int count = S->c.nToiOrder;
+		for (int k = 0; k < m; ++k)
+		{
+			const int ci = s_sorted[k];
+			const int slot = C.mgr[ci];
+			--count;
+			const int last = W.toiPos2c[count];
+			W.toiPos2c[slot] = last;
+			C.mgr[last] = slot;
+			C.mgr[ci] = -1;
+		}
+		S->c.nToiOrder = count;
+		S->c.nToiDestroy = 0;
+		if (n > TOI_ORDER_SORT_MAX) atomicOr(&S->c.overflow, 16);
+	}
+}
+
 // Stable compaction (creation order is preserved). keepScan = exclusive scan of keepFlag.
 __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 {
@@ -226,6 +282,9 @@ __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 			B.imp[j] = A.imp[i];
 			B.man3[j] = A.man3[i];
 			B.color[j] = A.color[i];
+			const int m = A.mgr[i];
+			B.mgr[j] = m;
+			if (m >= 0) W.toiPos2c[m] = j;
 		}
 	}
 }

@@ -42,6 +42,20 @@ __device__ __forceinline__ int ufFind(int* parent, int i)
 	return r;
 }
 
+// Read-only find for the flatten pass. It must NOT halve paths: a concurrent halving store parent[i] = grandparent
+// could land after the owner's final parent[i] = root and leave a non-root there (the body would then look like
+// it belongs to no island). Without halving the only writer of parent[i] in that pass is lane i itself.
+__device__ __forceinline__ int ufFindReadOnly(const int* parent, int i)
+{
+	int r = i;
+	for (;;)
+	{
+		const int p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (p == r) return r;
+		r = p;
+	}
+}
+
 // Link the larger root under the smaller one: the final representative of a component is its
 // smallest body id whatever the interleaving, which makes labels deterministic.
 __device__ __forceinline__ void ufUnion(int* parent, int a, int b)
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 		int r = 0;
 		if (valid)
 		{
-			r = ufFind(W.parent, i);
+			r = ufFindReadOnly(W.parent, i);
 			__hip_atomic_store(&W.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		waveAtomicAddInt(W.rootBodies, r, 1, valid);

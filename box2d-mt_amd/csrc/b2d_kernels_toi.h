@@ -1,0 +1,1009 @@
+// b2d_kernels_toi.h - continuous collision on the device: b2World::SolveTOI (b2World.cpp:1026-1093).
+//
+// Shape of the work in the reference: (1) one time-of-impact evaluation per TOI-candidate contact,
+// embarrassingly parallel (b2FindMinToiContactTask, b2World.cpp:283-360); (2) a strictly serial event
+// loop: take the earliest impact, advance the two bodies, build a mini island (<= 64 bodies, <= 32
+// contacts), solve it, re-sync its proxies, create the contacts that movement produced, recompute the
+// invalidated impacts, repeat (StepSolveTOI :851-1024).
+//
+// Mapping here: (1) is k_toi_first, one lane per contact over the whole contact array. (2) runs inside
+// ONE persistent workgroup (k_toi_loop) so that an event costs no launch and no host round trip; inside
+// an event everything that commutes is done by all lanes (candidate manifolds, proxy re-sync, pair
+// search, impact recomputation) and only the order-defining decisions (which candidate enters the
+// mini island, capacity cut-offs) are taken by one lane, in the reference's order: a body's contact list
+// is newest first = descending contact index here (contacts live in creation order).
+// The arg-min uses b2Contact::ToiLessThan (b2Contact.cpp:326-334): (alpha, proxyLow, proxyHigh).
+#ifndef B2D_KERNELS_TOI_H
+#define B2D_KERNELS_TOI_H
+
+#include "b2d_kernels_broadphase.h"
+#include "b2d_toi.h"
+
+#define TOI_LANES 256
+#define TOI_CAND_MAX 256     // candidate contacts of the two seed bodies in one event (one lane each)
+#define TOI_MOVES_MAX 128
+#define TOI_PAIRS_MAX 512
+#define TOI_RECOMP_MAX 512
+#define TOI_WOKEN_MAX 256
+#define TOI_EVENTS_MAX 100000
+
+// Flags are updated with L2 atomics (wake-ups, claims, invalidation) inside the event loop; a plain load could
+// be served from a stale L1 line of the same CU, so flag reads in this file go to L2 as relaxed atomic loads.
+__device__ __forceinline__ uint32_t ldFlags(const uint32_t* p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ Sweep loadSweep(const DW& W, int body)
+{
+	const float4 p0 = W.b_pos0[body], p = W.b_pos[body], m = W.b_mass[body];
+	Sweep s;
+	s.localCenter = v2(m.z, m.w);
+	s.c0 = v2(p0.x, p0.y);
+	s.a0 = p0.z;
+	s.alpha0 = p0.w;
+	s.c = v2(p.x, p.y);
+	s.a = p.z;
+	return s;
+}
+
+// b2World::ComputeToi(c, alpha0) (b2World.cpp:401-444): the sweeps are already on the same interval.
+__device__ __forceinline__ float computeToi(const DW& W, int4 ids, const Sweep& sA, const Sweep& sB)
+{
+	const GjkProxy pA = b2dProxy(W.shapes + W.p_shape[ids.x]);
+	const GjkProxy pB = b2dProxy(W.shapes + W.p_shape[ids.y]);
+	float t = 1.0f;
+	const int state = b2dTimeOfImpact(&t, pA, sA, pB, sB, 1.0f);
+	const float alpha0 = sA.alpha0;
+	return state == TOI_TOUCHING ? b2dMin(alpha0 + (1.0f - alpha0) * t, 1.0f) : 1.0f;
+}
+
+// IsMinToiCandidate (b2Contact.h:403-418) + !e_inactiveFlag: may this contact take part in the arg-min?
+__device__ __forceinline__ bool toiEligible(const DW& W, uint32_t flags, int4 ids)
+{
+	if ((flags & CF_TOI_CANDIDATE) == 0 || (flags & CF_ENABLED) == 0) return false;
+	if ((int)((flags & CF_TOI_COUNT_MASK) >> CF_TOI_COUNT_SHIFT) > B2D_MAX_SUB_STEPS) return false;
+	return bodyActiveForContact(ldFlags(&W.b_flags[ids.z])) || bodyActiveForContact(ldFlags(&W.b_flags[ids.w]));
+}
+
+// First pass of b2World::FindMinToiContact: every sweep starts the step at alpha0 = 0, so no contact
+// needs the out-of-sync path and all of them are independent.
+__global__ __launch_bounds__(256) void k_toi_first(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	int calls = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint32_t flags = C.flags[i] & ~CF_TOI_STATE_MASK;
+		const int4 ids = C.ids[i];
+		if (toiEligible(W, flags, ids))
+		{
+			const Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
+			const float alpha = computeToi(W, ids, sA, sB);
+			++calls;
+			float4 mat = C.mat[i];
+			mat.w = alpha;
+			C.mat[i] = mat;
+			flags |= CF_TOI;
+			if (alpha < 1.0f)
+			{
+				flags |= CF_TOI_LISTED;
+				const int k = atomicAdd(&S->c.nToiList, 1);
+				if (k < W.capContacts) W.toiList[k] = i;
+			}
+		}
+		C.flags[i] = flags;
+	}
+	if (calls) atomicAdd(&S->c.nToiCalls, calls);
+}
+
+// ---- adjacency of ALL contacts by non-static body (the island CSR only holds solid touching ones) ----
+__global__ __launch_bounds__(256) void k_toi_adj_clear(DW W)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		W.deg[i] = 0;
+		if (i < W.nBodies) W.adjCursor[i] = 0;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) W.st->c.toiBase = W.st->c.nContacts;
+}
+
+__global__ __launch_bounds__(256) void k_toi_adj_count(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		const int4 ids = C.ids[i];
+		if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC) atomicAdd(&W.deg[ids.z], 1);
+		if ((W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC) atomicAdd(&W.deg[ids.w], 1);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_toi_adj_fill(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		const int4 ids = C.ids[i];
+		if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC) W.adj[W.adjStart[ids.z] + atomicAdd(&W.adjCursor[ids.z], 1)] = i;
+		if ((W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC) W.adj[W.adjStart[ids.w] + atomicAdd(&W.adjCursor[ids.w], 1)] = i;
+	}
+}
+
+// b2ClearBodySolveTOIFlags (b2World.cpp:239-259): sweeps go back to alpha0 = 0 for the next step
+__global__ __launch_bounds__(256) void k_toi_clear(DW W)
+{
+	if (W.st->c.nToiEvents == 0) return;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		W.b_pos0[i].w = 0.0f;
+	}
+}
+
+// ---- the event loop ----------------------------------------------------------------------------------
+struct ToiCand
+{
+	int contact;
+	int other;     // body on the far side
+	int side;      // 0: from seed A's list, 1: from seed B's list
+	int info;      // bit0 touching after the update, bit1 was touching, bit2 visited, bit3 adds `other` to the island
+};
+
+struct ToiPair
+{
+	uint64_t key;
+	int lo, hi;
+};
+
+// b2Contact::UpdateImpl (b2Contact.cpp:173-298) for a non-sensor contact, evaluated at given transforms.
+struct ToiUpdate
+{
+	float4 man0, man1, imp;
+	int4 man3;
+	bool touching, wasTouching;
+};
+
+__device__ __forceinline__ void toiEvaluate(const DW& W, const ContactArrays& C, int i, int4 ids, Xf xfA, Xf xfB, ToiUpdate* u)
+{
+	const int4 m3 = C.man3[i];
+	const float4 oldImp = C.imp[i];
+	const float4 o0 = C.man0[i], o1 = C.man1[i];
+	const uint32_t oldId0 = (uint32_t)m3.x, oldId1 = (uint32_t)m3.y;
+	const int oldCount = m3.w;
+	Manifold mf;
+	mf.pointCount = 0;
+	mf.type = m3.z;
+	mf.localNormal = v2(o0.x, o0.y);
+	mf.localPoint = v2(o0.z, o0.w);
+	mf.p[0] = v2(o1.x, o1.y);
+	mf.p[1] = v2(o1.z, o1.w);
+	mf.id[0] = oldId0;
+	mf.id[1] = oldId1;
+	b2dEvaluate(&mf, W.shapes + W.p_shape[ids.x], xfA, W.shapes + W.p_shape[ids.y], xfB);
+	float ni[2], ti[2];
+	ni[0] = oldImp.x; ti[0] = oldImp.y; ni[1] = oldImp.z; ti[1] = oldImp.w;
+	for (int k = 0; k < mf.pointCount; ++k)
+	{
+		float n = 0.0f, t = 0.0f;
+		const uint32_t id2 = mf.id[k];
+		if (oldCount > 0 && oldId0 == id2) { n = oldImp.x; t = oldImp.y; }
+		else if (oldCount > 1 && oldId1 == id2) { n = oldImp.z; t = oldImp.w; }
+		ni[k] = n;
+		ti[k] = t;
+	}
+	u->man0 = make_float4(mf.localNormal.x, mf.localNormal.y, mf.localPoint.x, mf.localPoint.y);
+	u->man1 = make_float4(mf.p[0].x, mf.p[0].y, mf.p[1].x, mf.p[1].y);
+	u->imp = make_float4(ni[0], ti[0], ni[1], ti[1]);
+	u->man3 = make_int4((int)mf.id[0], (int)mf.id[1], mf.type, mf.pointCount);
+	u->touching = mf.pointCount > 0;
+}
+
+__device__ __forceinline__ void toiCommitUpdate(const ContactArrays& C, int i, const ToiUpdate& u)
+{
+	C.man0[i] = u.man0;
+	C.man1[i] = u.man1;
+	C.imp[i] = u.imp;
+	C.man3[i] = u.man3;
+	if (u.touching) atomicOr(&C.flags[i], CF_TOUCHING | CF_ENABLED);
+	else
+	{
+		atomicAnd(&C.flags[i], ~CF_TOUCHING);
+		atomicOr(&C.flags[i], CF_ENABLED);
+	}
+}
+
+// Pose of a body advanced to `alpha` (b2Body::Advance, b2Body.h:964-972) without storing it.
+__device__ __forceinline__ Sweep advancedSweep(const DW& W, int body, float alpha)
+{
+	Sweep s = loadSweep(W, body);
+	b2dSweepAdvance(s, alpha);
+	s.c = s.c0;
+	s.a = s.a0;
+	return s;
+}
+
+__device__ __forceinline__ void storeAdvanced(const DW& W, int body, const Sweep& s)
+{
+	const float sleepTime = W.b_pos[body].w;
+	W.b_pos0[body] = make_float4(s.c0.x, s.c0.y, s.a0, s.alpha0);
+	W.b_pos[body] = make_float4(s.c.x, s.c.y, s.a, sleepTime);
+	const Xf xf = b2dXfFromSweep(s.c, s.a, s.localCenter);
+	W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
+}
+
+__global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
+{
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	const int tid = threadIdx.x;
+	const int nC0 = S->c.toiBase; // contacts covered by the adjacency; [nC0, s_nC) is the tail created by events
+
+	__shared__ int s_nC, s_nL, s_events, s_calls, s_overflow;
+	__shared__ int s_minIdx;
+	__shared__ float s_minAlpha;
+	__shared__ unsigned long long s_best[TOI_LANES];
+	__shared__ uint32_t s_bestAlpha[TOI_LANES];
+	__shared__ int s_bestIdx[TOI_LANES];
+	__shared__ int s_solid;
+	__shared__ int s_bodies[B2D_MAX_TOI_BODIES], s_nBodies;
+	__shared__ int s_contacts[B2D_MAX_TOI_CONTACTS], s_nContacts;
+	__shared__ int s_level[B2D_MAX_TOI_CONTACTS], s_maxLevel;
+	__shared__ float4 s_pos[B2D_MAX_TOI_BODIES], s_vel[B2D_MAX_TOI_BODIES];
+	__shared__ uint32_t s_pen;
+	__shared__ ToiCand s_cand[TOI_CAND_MAX], s_sorted[TOI_CAND_MAX];
+	__shared__ int s_nCand;
+	__shared__ int s_moves[TOI_MOVES_MAX], s_nMoves;
+	__shared__ ToiPair s_pairs[TOI_PAIRS_MAX];
+	__shared__ int s_pairFirst[TOI_PAIRS_MAX], s_pairRank[TOI_PAIRS_MAX];
+	__shared__ int s_nPairs, s_nNew;
+	__shared__ int s_recomp[TOI_RECOMP_MAX], s_nRecomp;
+	__shared__ int s_rSorted[TOI_RECOMP_MAX], s_rSlot[TOI_RECOMP_MAX];
+	__shared__ int s_flatBody[2 * TOI_RECOMP_MAX], s_flatFirst[2 * TOI_RECOMP_MAX];
+	__shared__ float s_flatAlpha[2 * TOI_RECOMP_MAX];
+	__shared__ int s_advFlat[TOI_RECOMP_MAX], s_nAdv;
+	__shared__ float s_advAlpha[TOI_RECOMP_MAX];
+	__shared__ int s_pairCand[TOI_PAIRS_MAX];
+	__shared__ int s_toiOrder;
+	__shared__ int s_woken[TOI_WOKEN_MAX], s_nWoken;
+
+	if (tid == 0)
+	{
+		s_nC = S->c.nContacts;
+		s_nL = S->c.nToiList < W.capContacts ? S->c.nToiList : W.capContacts;
+		s_events = 0;
+		s_calls = 0;
+		s_overflow = 0;
+		s_toiOrder = S->c.nToiOrder;
+	}
+	__syncthreads();
+
+	// SetAwake(true) (b2Body.h:690-718) + remember bodies that were asleep: their dormant contacts become eligible
+	auto wake = [&](int body)
+	{
+		const uint32_t old = atomicOr(&W.b_flags[body], BF_AWAKE);
+		W.b_pos[body].w = 0.0f;
+		if ((old & BF_AWAKE) == 0)
+		{
+			const int k = atomicAdd(&s_nWoken, 1);
+			if (k < TOI_WOKEN_MAX) s_woken[k] = body; else atomicOr(&s_overflow, 8);
+		}
+	};
+
+	for (;;)
+	{
+		// ---- FindMinToiContact: lexicographic min of (alpha, proxyLow, proxyHigh) over the pending list ----
+		{
+			uint32_t bestA = 0xffffffffu;
+			unsigned long long bestK = ~0ull;
+			int bestI = -1;
+			const int nL = s_nL;
+			for (int k = tid; k < nL; k += TOI_LANES)
+			{
+				const int i = W.toiList[k];
+				const uint32_t flags = ldFlags(&C.flags[i]);
+				const int4 ids = C.ids[i];
+				if ((flags & CF_TOI) == 0 || !toiEligible(W, flags, ids)) continue;
+				const uint32_t a = __float_as_uint(C.mat[i].w); // alpha >= 0: bit order == value order
+				const unsigned long long key = C.key[i];
+				if (a < bestA || (a == bestA && key < bestK))
+				{
+					bestA = a;
+					bestK = key;
+					bestI = i;
+				}
+			}
+			s_bestAlpha[tid] = bestA;
+			s_best[tid] = bestK;
+			s_bestIdx[tid] = bestI;
+			__syncthreads();
+			for (int off = TOI_LANES / 2; off > 0; off >>= 1)
+			{
+				if (tid < off)
+				{
+					const uint32_t a = s_bestAlpha[tid + off];
+					const unsigned long long k2 = s_best[tid + off];
+					if (a < s_bestAlpha[tid] || (a == s_bestAlpha[tid] && k2 < s_best[tid]))
+					{
+						s_bestAlpha[tid] = a;
+						s_best[tid] = k2;
+						s_bestIdx[tid] = s_bestIdx[tid + off];
+					}
+				}
+				__syncthreads();
+			}
+			if (tid == 0)
+			{
+				s_minIdx = s_bestIdx[0];
+				s_minAlpha = s_bestIdx[0] >= 0 ? __uint_as_float(s_bestAlpha[0]) : 1.0f;
+			}
+			__syncthreads();
+		}
+		const int minIdx = s_minIdx;
+		const float minAlpha = s_minAlpha;
+		if (minIdx < 0 || 1.0f - 10.0f * B2D_EPSILON < minAlpha) break;
+		if (s_events >= TOI_EVENTS_MAX)
+		{
+			// safety net against a runaway loop (the reference bounds it through b2_maxSubSteps per contact)
+			if (tid == 0) s_overflow |= 32;
+			break;
+		}
+
+		// ---- StepSolveTOI (b2World.cpp:851-1024) ------------------------------------------------------------
+		const int4 minIds = C.ids[minIdx];
+		const int seedA = minIds.z, seedB = minIds.w;
+		if (tid == 0)
+		{
+			s_nWoken = 0;
+			s_nCand = 0;
+			s_nMoves = 0;
+			s_nPairs = 0;
+			s_nNew = 0;
+			s_nRecomp = 0;
+			Sweep a = loadSweep(W, seedA), b = loadSweep(W, seedB);
+			b2dSweepAdvance(a, minAlpha); a.c = a.c0; a.a = a.a0;
+			b2dSweepAdvance(b, minAlpha); b.c = b.c0; b.a = b.a0;
+			const Xf xfA = b2dXfFromSweep(a.c, a.a, a.localCenter), xfB = b2dXfFromSweep(b.c, b.a, b.localCenter);
+			// the TOI contact likely has some new contact points
+			ToiUpdate u;
+			u.wasTouching = (ldFlags(&C.flags[minIdx]) & CF_TOUCHING) != 0;
+			toiEvaluate(W, C, minIdx, minIds, xfA, xfB, &u);
+			toiCommitUpdate(C, minIdx, u);
+			uint32_t f = ldFlags(&C.flags[minIdx]);
+			const uint32_t cnt = ((f & CF_TOI_COUNT_MASK) >> CF_TOI_COUNT_SHIFT) + 1u;
+			f = (f & ~(CF_TOI | CF_TOI_COUNT_MASK)) | (cnt << CF_TOI_COUNT_SHIFT);
+			if (u.touching != u.wasTouching)
+			{
+				wake(seedA);
+				wake(seedB);
+			}
+			if (!u.touching)
+			{
+				// not solid: disable the contact and restore the sweeps (xf was derived from the same c, a)
+				f &= ~CF_ENABLED;
+				s_solid = 0;
+			}
+			else
+			{
+				s_solid = 1;
+				storeAdvanced(W, seedA, a);
+				storeAdvanced(W, seedB, b);
+				wake(seedA);
+				wake(seedB);
+				s_bodies[0] = seedA;
+				s_bodies[1] = seedB;
+				s_nBodies = 2;
+				s_contacts[0] = minIdx;
+				s_nContacts = 1;
+			}
+			C.flags[minIdx] = f;
+		}
+		__syncthreads();
+		// A contact that is not solid at its time of impact (no manifold points) is disabled and its bodies keep
+		// their sweeps; only the wake-ups of that update remain to be accounted for below.
+		const bool solid = s_solid != 0;
+		if (solid)
+		{
+
+		// ---- gather the candidate contacts of the two seeds (dynamic seeds only) -------------------------------
+		for (int side = 0; side < 2; ++side)
+		{
+			const int X = side == 0 ? seedA : seedB;
+			const uint32_t fX = ldFlags(&W.b_flags[X]);
+			if ((fX & BF_TYPE_MASK) != BT_DYNAMIC) continue;
+			const int e0 = W.adjStart[X], e1 = W.adjStart[X + 1];
+			const int nTail = s_nC - nC0;
+			for (int e = tid; e < (e1 - e0) + nTail; e += TOI_LANES)
+			{
+				int c;
+				if (e < e1 - e0) c = W.adj[e0 + e];
+				else c = nC0 + (e - (e1 - e0));
+				if (c == minIdx) continue;
+				const int4 ids = C.ids[c];
+				if (ids.z != X && ids.w != X) continue;
+				const int other = ids.z == X ? ids.w : ids.z;
+				const uint32_t fO = ldFlags(&W.b_flags[other]);
+				// only static, kinematic or bullet bodies join
+				if ((fO & BF_TYPE_MASK) == BT_DYNAMIC && ((fX | fO) & BF_BULLET) == 0) continue;
+				if (ldFlags(&C.flags[c]) & CF_SENSOR) continue;
+				const int k = atomicAdd(&s_nCand, 1);
+				if (k < TOI_CAND_MAX)
+				{
+					s_cand[k].contact = c;
+					s_cand[k].other = other;
+					s_cand[k].side = side;
+					s_cand[k].info = 0;
+				}
+				else atomicOr(&s_overflow, 1);
+			}
+		}
+		__syncthreads();
+		const int nCand = s_nCand < TOI_CAND_MAX ? s_nCand : TOI_CAND_MAX;
+		// order: seed A's list first, each list newest contact first
+		if (tid < nCand)
+		{
+			const ToiCand me = s_cand[tid];
+			int rank = 0;
+			for (int j = 0; j < nCand; ++j)
+			{
+				const ToiCand o = s_cand[j];
+				if (o.side < me.side || (o.side == me.side && o.contact > me.contact)) ++rank;
+			}
+			s_sorted[rank] = me;
+		}
+		__syncthreads();
+
+		// ---- tentative update of every candidate with both bodies at the time of impact ------------------------
+		ToiUpdate upd;
+		Sweep otherAdv;
+		int myContact = -1, myOther = -1;
+		if (tid < nCand)
+		{
+			const ToiCand me = s_sorted[tid];
+			myContact = me.contact;
+			myOther = me.other;
+			const int4 ids = C.ids[myContact];
+			const int X = me.side == 0 ? seedA : seedB;
+			const bool otherIsSeed = myOther == seedA || myOther == seedB;
+			Xf xfX = loadXf(W.b_xf, X), xfO;
+			if (otherIsSeed)
+			{
+				xfO = loadXf(W.b_xf, myOther);
+				otherAdv = loadSweep(W, myOther);
+			}
+			else
+			{
+				otherAdv = advancedSweep(W, myOther, minAlpha);
+				xfO = b2dXfFromSweep(otherAdv.c, otherAdv.a, otherAdv.localCenter);
+			}
+			upd.wasTouching = (ldFlags(&C.flags[myContact]) & CF_TOUCHING) != 0;
+			toiEvaluate(W, C, myContact, ids, ids.z == X ? xfX : xfO, ids.z == X ? xfO : xfX, &upd);
+			s_sorted[tid].info = (upd.touching ? 1 : 0) | (upd.wasTouching ? 2 : 0);
+		}
+		__syncthreads();
+
+		// ---- the order-defining walk (b2World.cpp:899-985) -------------------------------------------------------
+		if (tid == 0)
+		{
+			int nB = s_nBodies, nK = s_nContacts;
+			int blockedSide = -1;
+			for (int r = 0; r < nCand; ++r)
+			{
+				ToiCand cd = s_sorted[r];
+				if (cd.side == blockedSide) continue;
+				if (nB == B2D_MAX_TOI_BODIES || nK == B2D_MAX_TOI_CONTACTS)
+				{
+					blockedSide = cd.side;
+					continue;
+				}
+				bool inIsland = false;
+				for (int j = 0; j < nK; ++j) inIsland = inIsland || s_contacts[j] == cd.contact;
+				if (inIsland) continue;
+				cd.info |= 4; // visited: its update is committed
+				if (cd.info & 1)
+				{
+					s_contacts[nK++] = cd.contact;
+					bool bodyIn = false;
+					for (int j = 0; j < nB; ++j) bodyIn = bodyIn || s_bodies[j] == cd.other;
+					if (!bodyIn)
+					{
+						s_bodies[nB++] = cd.other;
+						cd.info |= 8;
+					}
+				}
+				s_sorted[r].info = cd.info;
+			}
+			s_nBodies = nB;
+			s_nContacts = nK;
+		}
+		__syncthreads();
+		if (tid < nCand)
+		{
+			const int info = s_sorted[tid].info;
+			if (info & 4)
+			{
+				toiCommitUpdate(C, myContact, upd);
+				if (upd.touching != upd.wasTouching)
+				{
+					const int4 ids = C.ids[myContact];
+					wake(ids.z);
+					wake(ids.w);
+				}
+			}
+		}
+		__syncthreads();
+		if (tid < nCand)
+		{
+			const int info = s_sorted[tid].info;
+			if (info & 8)
+			{
+				storeAdvanced(W, myOther, otherAdv);
+				if ((ldFlags(&W.b_flags[myOther]) & BF_TYPE_MASK) != BT_STATIC) wake(myOther);
+			}
+		}
+		__syncthreads();
+
+		// ---- b2Island::SolveTOI (b2Island.cpp:398-530): one constraint per lane, dependency levels -------------
+		const int nB = s_nBodies, nK = s_nContacts; // (shadows nothing: the outer nB is declared after this block)
+		const float h = (1.0f - minAlpha) * sp.dt;
+		if (tid < nB)
+		{
+			const int b = s_bodies[tid];
+			const float4 p = W.b_pos[b], v = W.b_vel[b];
+			s_pos[tid] = make_float4(p.x, p.y, p.z, 0.0f);
+			s_vel[tid] = make_float4(v.x, v.y, v.z, 0.0f);
+		}
+		if (tid == 0)
+		{
+			int maxLevel = 0;
+			for (int i = 0; i < nK; ++i)
+			{
+				const int4 a = C.ids[s_contacts[i]];
+				int lv = 1;
+				for (int j = 0; j < i; ++j)
+				{
+					const int4 b = C.ids[s_contacts[j]];
+					const bool share = a.z == b.z || a.z == b.w || a.w == b.z || a.w == b.w;
+					if (share && s_level[j] + 1 > lv) lv = s_level[j] + 1;
+				}
+				s_level[i] = lv;
+				if (lv > maxLevel) maxLevel = lv;
+			}
+			s_maxLevel = maxLevel;
+		}
+		__syncthreads();
+		ContactConstraint cc;
+		int ci = -1, la = 0, lb = 0, level = 0;
+		Manifold mf;
+		float4 cmat = make_float4(0, 0, 0, 0), mA4 = cmat, mB4 = cmat;
+		float radiusA = 0.0f, radiusB = 0.0f;
+		if (tid < nK)
+		{
+			ci = s_contacts[tid];
+			level = s_level[tid];
+			const int4 ids = C.ids[ci];
+			for (int j = 0; j < nB; ++j)
+			{
+				if (s_bodies[j] == ids.z) la = j;
+				if (s_bodies[j] == ids.w) lb = j;
+			}
+			mA4 = W.b_mass[ids.z];
+			mB4 = W.b_mass[ids.w];
+			radiusA = W.shapes[W.p_shape[ids.x]].radius;
+			radiusB = W.shapes[W.p_shape[ids.y]].radius;
+			cmat = C.mat[ci];
+			const float4 m0 = C.man0[ci], m1 = C.man1[ci], im = C.imp[ci];
+			const int4 m3 = C.man3[ci];
+			mf.localNormal = v2(m0.x, m0.y);
+			mf.localPoint = v2(m0.z, m0.w);
+			mf.p[0] = v2(m1.x, m1.y);
+			mf.p[1] = v2(m1.z, m1.w);
+			mf.ni[0] = im.x; mf.ti[0] = im.y; mf.ni[1] = im.z; mf.ti[1] = im.w;
+			mf.id[0] = (uint32_t)m3.x; mf.id[1] = (uint32_t)m3.y;
+			mf.type = m3.z;
+			mf.pointCount = m3.w;
+		}
+		const int maxLevel = s_maxLevel;
+		auto initConstraint = [&]()
+		{
+			BodyPos pA, pB;
+			BodyVel vA, vB;
+			const float4 pa = s_pos[la], va = s_vel[la], pb = s_pos[lb], vb = s_vel[lb];
+			pA.c = v2(pa.x, pa.y); pA.a = pa.z; vA.v = v2(va.x, va.y); vA.w = va.z;
+			pB.c = v2(pb.x, pb.y); pB.a = pb.z; vB.v = v2(vb.x, vb.y); vB.w = vb.z;
+			b2dInitConstraint(&cc, &mf, cmat.x, cmat.y, cmat.z,
+				mA4.x, mA4.y, v2(mA4.z, mA4.w), radiusA,
+				mB4.x, mB4.y, v2(mB4.z, mB4.w), radiusB,
+				pA, vA, pB, vB, false, 1.0f);
+		};
+		if (ci >= 0) initConstraint();
+		__syncthreads();
+		// SolveTOIPositionConstraints (b2ContactSolver.cpp:755-843): only the two TOI bodies (island slots 0, 1) move
+		for (int it = 0; it < 20; ++it)
+		{
+			if (tid == 0) s_pen = 0;
+			__syncthreads();
+			for (int L = 1; L <= maxLevel; ++L)
+			{
+				if (ci >= 0 && level == L)
+				{
+					ContactConstraint pc = cc;
+					if (la > 1) { pc.invMassA = 0.0f; pc.invIA = 0.0f; }
+					if (lb > 1) { pc.invMassB = 0.0f; pc.invIB = 0.0f; }
+					BodyPos pA, pB;
+					const float4 pa = s_pos[la], pb = s_pos[lb];
+					pA.c = v2(pa.x, pa.y); pA.a = pa.z;
+					pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+					float minSep = 0.0f;
+					b2dSolvePosition(&pc, &pA, &pB, B2D_TOI_BAUMGARTE, &minSep);
+					s_pos[la] = make_float4(pA.c.x, pA.c.y, pA.a, 0.0f);
+					s_pos[lb] = make_float4(pB.c.x, pB.c.y, pB.a, 0.0f);
+					atomicMax(&s_pen, floatBits(0.0f - minSep));
+				}
+				__syncthreads();
+			}
+			const float minSeparation = -__uint_as_float(s_pen);
+			__syncthreads();
+			if (minSeparation >= -1.5f * B2D_LINEAR_SLOP) break;
+		}
+		// leap of faith to the new safe state (b2Island.cpp:466-470)
+		if (tid < 2)
+		{
+			const int b = s_bodies[tid];
+			const float4 p = s_pos[tid];
+			W.b_pos0[b] = make_float4(p.x, p.y, p.z, minAlpha);
+		}
+		if (ci >= 0) initConstraint();
+		__syncthreads();
+		for (int it = 0; it < sp.velIters; ++it)
+		{
+			for (int L = 1; L <= maxLevel; ++L)
+			{
+				if (ci >= 0 && level == L)
+				{
+					BodyVel vA, vB;
+					const float4 va = s_vel[la], vb = s_vel[lb];
+					vA.v = v2(va.x, va.y); vA.w = va.z;
+					vB.v = v2(vb.x, vb.y); vB.w = vb.z;
+					b2dSolveVelocity(&cc, &vA, &vB);
+					s_vel[la] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
+					s_vel[lb] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
+				}
+				__syncthreads();
+			}
+		}
+		// integrate positions, sync bodies (b2Island.cpp:483-527); TOI impulses are not stored
+		if (tid < nB)
+		{
+			const int b = s_bodies[tid];
+			const float4 p = s_pos[tid], v = s_vel[tid];
+			V2 c = v2(p.x, p.y), vv = v2(v.x, v.y);
+			float a = p.z, w = v.z;
+			b2dIntegratePosition(&c, &a, &vv, &w, h);
+			const float4 m = W.b_mass[b];
+			const float sleepTime = W.b_pos[b].w;
+			W.b_pos[b] = make_float4(c.x, c.y, a, sleepTime);
+			W.b_vel[b] = make_float4(vv.x, vv.y, w, 0.0f);
+			const Xf xf = b2dXfFromSweep(c, a, v2(m.z, m.w));
+			W.b_xf[b] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
+		}
+		__syncthreads();
+
+		// ---- b2Body::SynchronizeFixtures of the island's dynamic bodies (b2World.cpp:1000-1011) -----------------
+		if (tid < nB)
+		{
+			const int b = s_bodies[tid];
+			if ((ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) == BT_DYNAMIC)
+			{
+				const float4 m = W.b_mass[b], p0 = W.b_pos0[b];
+				const Xf xf1 = b2dXfFromSweep(v2(p0.x, p0.y), p0.z, v2(m.z, m.w));
+				const Xf xf2 = loadXf(W.b_xf, b);
+				for (int p = W.b_proxyHead[b]; p >= 0; p = W.p_next[p])
+				{
+					const ShapeRec* shape = W.shapes + W.p_shape[p];
+					const AABB aabb = b2dAabbCombine(b2dShapeAABB(shape, xf1), b2dShapeAABB(shape, xf2));
+					if (b2dAabbContains(loadAabb(W.p_fat, p), aabb)) continue;
+					const V2 d = B2D_AABB_MULTIPLIER * (xf2.p - xf1.p);
+					AABB f = aabb;
+					f.lo = v2(f.lo.x - B2D_AABB_EXTENSION, f.lo.y - B2D_AABB_EXTENSION);
+					f.hi = v2(f.hi.x + B2D_AABB_EXTENSION, f.hi.y + B2D_AABB_EXTENSION);
+					if (d.x < 0.0f) f.lo.x += d.x; else f.hi.x += d.x;
+					if (d.y < 0.0f) f.lo.y += d.y; else f.hi.y += d.y;
+					W.p_fat[p] = make_float4(f.lo.x, f.lo.y, f.hi.x, f.hi.y);
+					const int k = atomicAdd(&s_nMoves, 1);
+					if (k < TOI_MOVES_MAX) s_moves[k] = p; else atomicOr(&s_overflow, 2);
+				}
+			}
+		}
+		__syncthreads();
+
+		// ---- FindNewContacts for the moved proxies (b2World.cpp:1013-1023): brute force over all proxies ----------
+		const int nMoves = s_nMoves < TOI_MOVES_MAX ? s_nMoves : TOI_MOVES_MAX;
+		if (nMoves > 0)
+		{
+			for (int q = tid; q < W.nProxies; q += TOI_LANES)
+			{
+				const int bodyQ = W.p_body[q];
+				if (bodyQ < 0) continue;
+				const AABB fq = loadAabb(W.p_fat, q);
+				for (int mI = 0; mI < nMoves; ++mI)
+				{
+					const int p = s_moves[mI];
+					if (p == q) continue;
+					if (!b2dAabbOverlap(loadAabb(W.p_fat, p), fq)) continue;
+					const int bodyP = W.p_body[p];
+					if (bodyP == bodyQ) continue;
+					const int keyP = W.p_key[p], keyQ = W.p_key[q];
+					const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
+					const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
+					// does a contact already exist? (b2ContactManager.cpp:262-287) p's body is dynamic: walk its adjacency
+					bool exists = false;
+					const int e0 = W.adjStart[bodyP], e1 = W.adjStart[bodyP + 1];
+					for (int e = e0; e < e1 && !exists; ++e) exists = C.key[W.adj[e]] == key;
+					for (int c = nC0; c < s_nC && !exists; ++c) exists = C.key[c] == key;
+					if (exists) continue;
+					if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) continue;
+					if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) continue;
+					if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) continue;
+					const int k = atomicAdd(&s_nPairs, 1);
+					if (k < TOI_PAIRS_MAX)
+					{
+						s_pairs[k].key = key;
+						s_pairs[k].lo = lo;
+						s_pairs[k].hi = hi;
+					}
+					else atomicOr(&s_overflow, 4);
+				}
+			}
+		}
+		__syncthreads();
+		const int nPairs = s_nPairs < TOI_PAIRS_MAX ? s_nPairs : TOI_PAIRS_MAX;
+		for (int i = tid; i < nPairs; i += TOI_LANES)
+		{
+			const uint64_t key = s_pairs[i].key;
+			int first = 1;
+			for (int j = 0; j < i; ++j) if (s_pairs[j].key == key) first = 0;
+			s_pairFirst[i] = first;
+		}
+		__syncthreads();
+		for (int i = tid; i < nPairs; i += TOI_LANES)
+		{
+			const uint64_t key = s_pairs[i].key;
+			int rank = 0;
+			for (int j = 0; j < nPairs; ++j) if (s_pairFirst[j] && s_pairs[j].key < key) ++rank;
+			s_pairRank[i] = rank;
+			if (s_pairFirst[i]) atomicAdd(&s_nNew, 1);
+		}
+		__syncthreads();
+		// OnContactCreate (b2ContactManager.cpp:507-564), in (proxyLow, proxyHigh) order at the end of the array
+		const int base = s_nC;
+		for (int i = tid; i < nPairs; i += TOI_LANES)
+		{
+			if (!s_pairFirst[i]) continue;
+			const int dst = base + s_pairRank[i];
+			if (dst >= W.capContacts)
+			{
+				atomicOr(&S->c.overflow, 1);
+				continue;
+			}
+			int pA = s_pairs[i].lo, pB = s_pairs[i].hi;
+			if (b2dContactSwap(W.shapes[W.p_shape[pA]].type, W.shapes[W.p_shape[pB]].type) == 1)
+			{
+				const int t = pA;
+				pA = pB;
+				pB = t;
+			}
+			const int bodyA = W.p_body[pA], bodyB = W.p_body[pB];
+			const bool sensor = ((W.p_filter1[pA] | W.p_filter1[pB]) & PF_SENSOR) != 0;
+			uint32_t flags = CF_ENABLED | (sensor ? CF_SENSOR : 0u);
+			const bool cand = isToiCandidate(W, pA, pB, bodyA, bodyB);
+			if (cand) flags |= CF_TOI_CANDIDATE;
+			s_pairCand[i] = cand ? 1 : 0;
+			const float2 mA = W.p_mat[pA], mB = W.p_mat[pB];
+			C.ids[dst] = make_int4(pA, pB, bodyA, bodyB);
+			C.key[dst] = s_pairs[i].key;
+			C.flags[dst] = flags;
+			C.mat[dst] = make_float4(b2dSqrt(mA.x * mB.x), mA.y > mB.y ? mA.y : mB.y, 0.0f, 1.0f);
+			C.man0[dst] = make_float4(0, 0, 0, 0);
+			C.man1[dst] = make_float4(0, 0, 0, 0);
+			C.imp[dst] = make_float4(0, 0, 0, 0);
+			C.man3[dst] = make_int4(0, 0, 0, 0);
+			C.color[dst] = -1;
+			C.mgr[dst] = -1;
+			if (!sensor)
+			{
+				wake(bodyA);
+				wake(bodyB);
+			}
+		}
+		__syncthreads();
+		// b2ContactManager::AddToContactArray: new TOI candidates take the next slots in creation order
+		for (int i = tid; i < nPairs; i += TOI_LANES)
+		{
+			if (!s_pairFirst[i] || !s_pairCand[i] || base + s_pairRank[i] >= W.capContacts) continue;
+			int before = 0;
+			for (int j = 0; j < nPairs; ++j)
+			{
+				if (s_pairFirst[j] && s_pairCand[j] && s_pairRank[j] < s_pairRank[i]) ++before;
+			}
+			const int slot = s_toiOrder + before;
+			C.mgr[base + s_pairRank[i]] = slot;
+			W.toiPos2c[slot] = base + s_pairRank[i];
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			int total = s_nC + s_nNew;
+			if (total > W.capContacts) total = W.capContacts;
+			s_nC = total;
+			s_events += 1;
+			int cands = 0;
+			for (int j = 0; j < nPairs; ++j) cands += (s_pairFirst[j] && s_pairCand[j] && base + s_pairRank[j] < W.capContacts) ? 1 : 0;
+			s_toiOrder += cands;
+		}
+		__syncthreads();
+
+		} // solid
+		const int nB = solid ? s_nBodies : 0;
+		// ---- invalidate the impacts of the displaced bodies (b2World.cpp:1005-1010) ---------------------------------
+		const int nTail = s_nC - nC0;
+		for (int bi = 0; bi < nB; ++bi)
+		{
+			const int b = s_bodies[bi];
+			if ((ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) != BT_DYNAMIC) continue;
+			const int e0 = W.adjStart[b], e1 = W.adjStart[b + 1];
+			for (int e = tid; e < (e1 - e0) + nTail; e += TOI_LANES)
+			{
+				int c;
+				if (e < e1 - e0) c = W.adj[e0 + e];
+				else
+				{
+					c = nC0 + (e - (e1 - e0));
+					const int4 ids = C.ids[c];
+					if (ids.z != b && ids.w != b) continue;
+				}
+				atomicAnd(&C.flags[c], ~CF_TOI);
+			}
+		}
+		__syncthreads();
+		// ---- contacts that the next FindMinToiContact would have to (re)compute ----------------------------------------
+		const int nWoken = s_nWoken < TOI_WOKEN_MAX ? s_nWoken : TOI_WOKEN_MAX;
+		for (int bi = 0; bi < nB + nWoken; ++bi)
+		{
+			const int b = bi < nB ? s_bodies[bi] : s_woken[bi - nB];
+			if ((ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) == BT_STATIC) continue;
+			const int e0 = W.adjStart[b], e1 = W.adjStart[b + 1];
+			for (int e = tid; e < (e1 - e0) + nTail; e += TOI_LANES)
+			{
+				int c;
+				if (e < e1 - e0) c = W.adj[e0 + e];
+				else c = nC0 + (e - (e1 - e0));
+				const int4 ids = C.ids[c];
+				if (ids.z != b && ids.w != b) continue;
+				const uint32_t flags = ldFlags(&C.flags[c]);
+				if ((flags & (CF_TOI | CF_TOI_PENDING)) != 0 || !toiEligible(W, flags, ids)) continue;
+				const uint32_t old = atomicOr(&C.flags[c], CF_TOI_PENDING);
+				if (old & CF_TOI_PENDING) continue;
+				const int k = atomicAdd(&s_nRecomp, 1);
+				if (k < TOI_RECOMP_MAX) s_recomp[k] = c; else atomicOr(&s_overflow, 8);
+			}
+		}
+		__syncthreads();
+		const int nRecomp = s_nRecomp < TOI_RECOMP_MAX ? s_nRecomp : TOI_RECOMP_MAX;
+		// Put the sweeps of each pair on the same interval (b2World.cpp:385-396): the lagging body advances to
+		// the other's alpha0. A body can meet partners at different times within one pass, so the advances are
+		// replayed in the reference's visiting order: the slot order of its contact array (ContactArrays::mgr).
+		for (int r = tid; r < nRecomp; r += TOI_LANES) s_rSlot[r] = C.mgr[s_recomp[r]];
+		__syncthreads();
+		for (int r = tid; r < nRecomp; r += TOI_LANES)
+		{
+			const int m = s_rSlot[r];
+			int rank = 0;
+			for (int j = 0; j < nRecomp; ++j) rank += s_rSlot[j] < m ? 1 : 0;
+			s_rSorted[rank] = s_recomp[r];
+		}
+		__syncthreads();
+		for (int r = tid; r < nRecomp; r += TOI_LANES)
+		{
+			const int4 ids = C.ids[s_rSorted[r]];
+			s_flatBody[2 * r] = ids.z;
+			s_flatBody[2 * r + 1] = ids.w;
+		}
+		if (tid == 0) s_nAdv = 0;
+		__syncthreads();
+		for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
+		{
+			const int b = s_flatBody[q];
+			int first = q;
+			for (int j = 0; j < q; ++j)
+			{
+				if (s_flatBody[j] == b)
+				{
+					first = j;
+					break;
+				}
+			}
+			s_flatFirst[q] = first;
+			if (first == q) s_flatAlpha[q] = W.b_pos0[b].w;
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			int nAdv = 0;
+			for (int r = 0; r < nRecomp; ++r)
+			{
+				const int fa = s_flatFirst[2 * r], fb = s_flatFirst[2 * r + 1];
+				const float aA = s_flatAlpha[fa], aB = s_flatAlpha[fb];
+				if (aA < aB)
+				{
+					s_advFlat[nAdv] = fa;
+					s_advAlpha[nAdv++] = aB;
+					s_flatAlpha[fa] = aB;
+				}
+				else if (aB < aA)
+				{
+					s_advFlat[nAdv] = fb;
+					s_advAlpha[nAdv++] = aA;
+					s_flatAlpha[fb] = aA;
+				}
+			}
+			s_nAdv = nAdv;
+		}
+		__syncthreads();
+		for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
+		{
+			if (s_flatFirst[q] != q) continue;
+			const int nAdv = s_nAdv;
+			bool any = false;
+			Sweep sw;
+			for (int k = 0; k < nAdv; ++k)
+			{
+				if (s_advFlat[k] != q) continue;
+				if (!any) sw = loadSweep(W, s_flatBody[q]);
+				any = true;
+				b2dSweepAdvance(sw, s_advAlpha[k]);
+			}
+			if (any) W.b_pos0[s_flatBody[q]] = make_float4(sw.c0.x, sw.c0.y, sw.a0, sw.alpha0);
+		}
+		__syncthreads();
+		for (int r = tid; r < nRecomp; r += TOI_LANES)
+		{
+			const int c = s_rSorted[r];
+			const int4 ids = C.ids[c];
+			const Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
+			const float alpha = computeToi(W, ids, sA, sB);
+			atomicAdd(&s_calls, 1);
+			float4 mat = C.mat[c];
+			mat.w = alpha;
+			C.mat[c] = mat;
+			uint32_t flags = (ldFlags(&C.flags[c]) & ~CF_TOI_PENDING) | CF_TOI;
+			if (alpha < 1.0f && (flags & CF_TOI_LISTED) == 0)
+			{
+				flags |= CF_TOI_LISTED;
+				const int k = atomicAdd(&s_nL, 1);
+				if (k < W.capContacts) W.toiList[k] = c; else atomicOr(&s_overflow, 16);
+			}
+			C.flags[c] = flags;
+		}
+		__syncthreads();
+		if (tid == 0 && s_nL > W.capContacts) s_nL = W.capContacts;
+		__syncthreads();
+	}
+
+	if (tid == 0)
+	{
+		S->c.nContacts = s_nC;
+		S->c.nToiList = s_nL;
+		S->c.nToiEvents = s_events;
+		atomicAdd(&S->c.nToiCalls, s_calls);
+		S->c.toiOverflow = s_overflow;
+		S->c.nToiOrder = s_toiOrder;
+	}
+}
+
+#endif

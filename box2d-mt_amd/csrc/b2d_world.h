@@ -35,6 +35,13 @@
 #define CF_SENSOR 0x10u      // either fixture is a sensor (cached at creation)
 #define CF_DESTROY 0x20u     // marked by collide, removed by the compaction that follows
 #define CF_ISLAND 0x40u      // already added to an island by the DFS
+// continuous collision (b2Contact::e_toiFlag, m_toiCount; valid only inside one step's TOI phase)
+#define CF_TOI 0x80u           // ContactArrays::mat.w holds a valid time of impact
+#define CF_TOI_LISTED 0x100u   // already in DW::toiList
+#define CF_TOI_PENDING 0x200u  // claimed for recomputation by the running TOI pass
+#define CF_TOI_COUNT_SHIFT 12  // bits 12..15: m_toiCount (0..9)
+#define CF_TOI_COUNT_MASK 0xf000u
+#define CF_TOI_STATE_MASK (CF_TOI | CF_TOI_LISTED | CF_TOI_PENDING | CF_TOI_COUNT_MASK)
 
 // proxy filter1 packing: low 16 = groupIndex (int16), bit16 = sensor, bit17 = thick
 #define PF_SENSOR 0x10000
@@ -58,6 +65,7 @@ struct ContactArrays
 	float4* imp;      // normalImpulse0, tangentImpulse0, normalImpulse1, tangentImpulse1
 	int4* man3;       // id0.key, id1.key, manifold type, pointCount
 	int* color;       // persistent constraint colour (large-island solver), -1 = none yet
+	int* mgr;         // TOI candidates: slot in the reference's contact array (b2Contact::m_managerIndex), else -1
 };
 
 struct Counters
@@ -80,14 +88,20 @@ struct Counters
 	int chunkW;          // chunk granularity chosen for this step (TINY_ISLAND_MAX_W or SMALL_ISLAND_MAX_W)
 	int overflow;        // bit0 contacts, bit1 pairs, bit2 colours, bit3 moves
 	int nIslands;
-	int pad[5];
+	int nToiList;        // contacts with a cached time of impact < 1 (pending TOI events)
+	int nToiEvents;      // TOI sub-steps solved this step
+	int nToiCalls;       // b2TimeOfImpact evaluations this step
+	int toiBase;         // contact count when the TOI adjacency was built (later contacts form the tail)
+	int toiOverflow;     // bit0 candidates, bit1 moves, bit2 pairs, bit3 recompute list, bit4 TOI list
+	int nToiOrder;       // persistent: TOI-candidate contacts alive (b2ContactManager::m_toiCount)
+	int nToiDestroy;     // TOI candidates destroyed by the running collide
 };
 
 struct DState
 {
 	Counters c;
 	int cur;             // which ContactArrays is live
-	int pad[15];
+	int pad[13];
 };
 
 struct StepParams
@@ -127,6 +141,8 @@ struct DW
 	int* p_filter1;      // groupIndex | sensor / thick bits
 	float2* p_mat;       // friction, restitution
 	const ShapeRec* shapes;
+	int* b_proxyHead;    // per body: its newest proxy (b2Body::m_fixtureList), -1 = none
+	int* p_next;         // next older proxy of the same body
 
 	// ---- contacts ---------------------------------------------------------------------------
 	ContactArrays ca[2];
@@ -198,6 +214,11 @@ struct DW
 	int2* pairProxy2;
 	int* pairFirst;      // 1 if first occurrence of its key
 	int* pairRank;       // rank among unique keys
+
+	// ---- continuous collision ----------------------------------------------------------------
+	int* toiList;        // contact indices whose cached TOI is < 1
+	int* toiPos2c;       // slot of the reference's TOI partition -> contact index (inverse of ContactArrays::mgr)
+	int* toiDestroyList; // TOI candidates marked for destruction by collide
 
 	// ---- generic scratch ----------------------------------------------------------------------
 	int* scanTmp;        // block sums for the scan utility

@@ -18,7 +18,7 @@
 #include <vector>
 
 #include "../../include/b2hip.h"
-#include "b2d_kernels_broadphase.h"
+#include "b2d_kernels_toi.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -143,13 +143,14 @@ struct b2hip_world
 	DevArray<int> p_body, p_shape, p_key, p_filter1;
 	DevArray<uint32_t> p_filter0;
 	DevArray<float2> p_mat;
+	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList;
 	DevArray<ShapeRec> d_shapes;
 	DevArray<int4> c_ids[2];
 	DevArray<uint64_t> c_key[2];
 	DevArray<uint32_t> c_flags[2];
 	DevArray<float4> c_mat[2], c_man0[2], c_man1[2], c_imp[2];
 	DevArray<int4> c_man3[2];
-	DevArray<int> c_color[2];
+	DevArray<int> c_color[2], c_mgr[2];
 	DevArray<int4> li_ref;
 	DevArray<uint64_t> ht_keys;
 	DevArray<RevoluteJoint> d_joints;
@@ -181,12 +182,17 @@ struct b2hip_world
 	Counters last;        // counters of the last completed step
 	int lastContacts;
 	float profile[13];
-	hipEvent_t ev[12];
+	hipEvent_t ev[13];
 	float solverMs;
 	double solverBytes;
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
+	bool toiRan, toiEventValid;
+	bool debugTrace;                                   // B2HIP_TRACE=1: hash the body state after every solver stage
+	std::vector<std::pair<std::string, uint64_t> > trace;
+	DevArray<float4> dbgPreVel, dbgVel;
+	DevArray<int> dbgLi;
 	int kernelTiming;
 	std::vector<hipEvent_t> ktEvents;
 	int ktUsed;          // events recorded this step (pairs)
@@ -437,6 +443,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_pos, nb); ENS(b_pos0, nb); ENS(b_vel, nb); ENS(b_xf, nb); ENS(b_mass, nb); ENS(b_damp, nb); ENS(b_force, nb);
 	ENS(b_flags, nb); ENS(b_wake, nb);
 	ENS(p_fat, np); ENS(p_body, np); ENS(p_shape, np); ENS(p_key, np); ENS(p_filter0, np); ENS(p_filter1, np); ENS(p_mat, np);
+	ENS(b_proxyHead, nb); ENS(p_next, np);
 	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
 	ENS(d_joints, std::max<size_t>(w->joints.size(), 1));
 	ENS(jadjStart, nb + 2); ENS(jadj, 2 * w->joints.size() + 2); ENS(rootJointStart, nb + 2); ENS(rootJointCursor, nb);
@@ -447,7 +454,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	{
 		ENS(c_ids[k], capContacts); ENS(c_key[k], capContacts); ENS(c_flags[k], capContacts); ENS(c_mat[k], capContacts);
 		ENS(c_man0[k], capContacts); ENS(c_man1[k], capContacts); ENS(c_imp[k], capContacts); ENS(c_man3[k], capContacts);
-		ENS(c_color[k], capContacts);
+		ENS(c_color[k], capContacts); ENS(c_mgr[k], capContacts);
 	}
 	const size_t cc = w->c_ids[0].cap; // actual (power of two) capacity
 	// hash set: at most 50 % load
@@ -484,6 +491,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(scanTmp, std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 4);
 	ENS(scanTmp4, maxScanN / SCAN_TILE + 4);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
+	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
 #undef ENS
@@ -513,7 +521,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	{
 		d.ca[k].ids = w->c_ids[k].p; d.ca[k].key = w->c_key[k].p; d.ca[k].flags = w->c_flags[k].p; d.ca[k].mat = w->c_mat[k].p;
 		d.ca[k].man0 = w->c_man0[k].p; d.ca[k].man1 = w->c_man1[k].p; d.ca[k].imp = w->c_imp[k].p; d.ca[k].man3 = w->c_man3[k].p;
-		d.ca[k].color = w->c_color[k].p;
+		d.ca[k].color = w->c_color[k].p; d.ca[k].mgr = w->c_mgr[k].p;
 	}
 	d.ht_keys = w->ht_keys.p;
 	d.joints = w->d_joints.p;
@@ -536,6 +544,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.pairFirst = w->pairFirst.p; d.pairRank = w->pairRank.p;
 	d.scanTmp = w->scanTmp.p; d.radixHist = w->radixHist.p; d.keepFlag = w->keepFlag.p; d.keepScan = w->keepScan.p;
 	d.stateOut = w->stateOut.p;
+	d.b_proxyHead = w->b_proxyHead.p; d.p_next = w->p_next.p; d.toiList = w->toiList.p;
+	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
 	return 0;
 }
 
@@ -648,6 +658,16 @@ static int flushEdits(b2hip_world* w)
 		HIP_TRY(hipMemcpyAsync(w->p_filter0.p + first, f0.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(w->p_filter1.p + first, f1.data(), cnt * sizeof(int), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(w->p_mat.p + first, mat.data(), cnt * sizeof(float2), hipMemcpyHostToDevice, s));
+		// per-body proxy lists, newest first like b2Body::m_fixtureList (b2Body.cpp:203-205)
+		std::vector<int> head(w->bodies.size(), -1), next(np, -1);
+		for (size_t k = 0; k < np; ++k)
+		{
+			const int b = w->fixtures[k].body;
+			next[k] = head[b];
+			head[b] = (int)k;
+		}
+		HIP_TRY(hipMemcpyAsync(w->b_proxyHead.p, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_next.p, next.data(), np * sizeof(int), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		w->upFixtures = np;
 
@@ -690,6 +710,8 @@ static int flushEdits(b2hip_world* w)
 	}
 	int consts[4] = { (int)w->bodies.size(), (int)(w->dw.gridMask + 1), 0, 0 };
 	HIP_TRY(hipMemcpyAsync(w->consts.p, consts, sizeof(int) * 2, hipMemcpyHostToDevice, s));
+	int nb1 = (int)w->bodies.size() + 1; // scan length of the TOI adjacency (nBodies + 1 so that adjStart[nBodies] is the total)
+	HIP_TRY(hipMemcpyAsync(w->consts.p + 4, &nb1, sizeof(int), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	return 0;
 }
@@ -747,6 +769,7 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 	const int smallPath = largePath ? 0 : 1;
 	LAUNCH(w, k_create_contacts, gridFor(largePath ? d.capPairs : COUNT_RANK_MAX), 256, d, sortedKeys, sortedProxies, smallPath);
 	LAUNCH(w, k_create_finish, gridFor(d.nBodies), 256, d, smallPath);
+	LAUNCH(w, k_toi_order_create, 1, 256, d, smallPath);
 	LAUNCH(w, k_create_commit, 1, 1, d, smallPath);
 	return 0;
 }
@@ -778,14 +801,27 @@ static int phaseCollide(b2hip_world* w)
 {
 	DW& d = w->dw;
 	LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_toi_order_destroy, 1, 256, d);
 	deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
 	LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
 	LAUNCH(w, k_compact_finish, 1, 1, d);
 	return 0;
 }
 
+int b2hip_debug_hash(b2hip_world* w, int which, uint64_t* out);
+static void tracePoint(b2hip_world* w, const char* label)
+{
+	if (!w->debugTrace) return;
+	uint64_t hb = 0, hi = 0;
+	(void)b2hip_debug_hash(w, 0, &hb);
+	(void)b2hip_debug_hash(w, 3, &hi);
+	w->trace.push_back(std::make_pair(std::string(label), hb ^ (hi * 0x9E3779B97F4A7C15ull)));
+}
+#define TRACE(label) tracePoint(w, label)
+
 static int phaseSolve(b2hip_world* w)
 {
+	w->trace.clear();
 	DW& d = w->dw;
 	const StepParams& sp = w->sp;
 	w->ktUsed = 0;
@@ -888,15 +924,28 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_color_fill, gC, 256, d);
 		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
+		TRACE("before_integrate");
+		if (w->debugTrace)
+		{
+			const size_t nb = w->bodies.size();
+			(void)w->dbgPreVel.ensure(nb, w->stream); (void)w->dbgVel.ensure(nb, w->stream); (void)w->dbgLi.ensure(nb + 64, w->stream);
+			HIP_TRY(hipMemcpyAsync(w->dbgPreVel.p, w->b_vel.p, nb * 16, hipMemcpyDeviceToDevice, w->stream));
+			HIP_TRY(hipMemcpyAsync(w->dbgLi.p, w->li_bodies.p, nb * 4, hipMemcpyDeviceToDevice, w->stream));
+			HIP_TRY(hipMemcpyAsync(w->dbgLi.p + nb, &w->d_state.p->c, 64 * 4 > sizeof(Counters) ? sizeof(Counters) : 64 * 4, hipMemcpyDeviceToDevice, w->stream));
+		}
 		LAUNCH(w, k_large_integrate, gB, 256, d, sp);
+		if (w->debugTrace) HIP_TRY(hipMemcpyAsync(w->dbgVel.p, w->b_vel.p, w->bodies.size() * 16, hipMemcpyDeviceToDevice, w->stream));
+		TRACE("integrate");
 		const bool hasJoints = d.nJoints > 0;
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
 		if (hasJoints && !exactLarge) LAUNCH(w, k_joints_sort, gJ, 64, d);
 		LAUNCH(w, k_large_init, gC, 256, d, sp);
+		TRACE("init");
 		if (sp.warmStarting)
 		{
 			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
 		}
+		TRACE("warmstart");
 		if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 0);
 		for (int it = 0; it < sp.velIters; ++it)
 		{
@@ -906,19 +955,28 @@ static int phaseSolve(b2hip_world* w)
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
 				LAUNCH(w, k_large_velocity, gK, 256, d, col, 1);
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
+				if (w->debugTrace) TRACE(("vel" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
 		}
 		LAUNCH(w, k_large_store_impulses, gC, 256, d);
+		TRACE("store_impulses");
 		LAUNCH(w, k_large_integrate_positions, gB, 256, d, sp);
+		TRACE("integrate_positions");
 		for (int it = 0; it < sp.posIters; ++it)
 		{
 			LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
-			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_position, gK, 256, d, col);
+			for (int col = 0; col < nColors; ++col)
+			{
+				LAUNCH(w, k_large_position, gK, 256, d, col);
+				if (w->debugTrace) TRACE(("pos" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
+			}
 			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
 			LAUNCH(w, k_large_pos_end, 1, 256, d);
 		}
 		LAUNCH(w, k_large_finalize, gB, 256, d, sp);
+		TRACE("finalize");
 		LAUNCH(w, k_large_sleep, gB, 256, d, sp);
+		TRACE("sleep");
 		HIP_TRY(hipEventRecord(w->ev[8], w->stream));
 	}
 	else
@@ -944,6 +1002,40 @@ static int phaseSyncFixtures(b2hip_world* w)
 {
 	DW& d = w->dw;
 	LAUNCH(w, k_sync_fixtures, gridFor(d.nProxies), 256, d);
+	return 0;
+}
+
+// b2World::SolveTOI (b2World.cpp:1026-1093). The first arg-min pass runs over the whole contact array; the
+// event loop only runs (one persistent workgroup) when some impact lies inside the step.
+static int phaseToi(b2hip_world* w)
+{
+	DW& d = w->dw;
+	int rc = readState(w);
+	if (rc) return rc;
+	if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+	if (w->h_dstate->c.nMoves != 0 && w->h_dstate->c.nPairs > COUNT_RANK_MAX)
+	{
+		// the optimistic small-sort path of the end-of-step pair update did not apply: finish it first,
+		// the TOI phase must see every contact
+		rc = runSortAndCreate(w, true);
+		if (rc) return rc;
+	}
+	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nToiList, 0, sizeof(int) * 5, w->stream));
+	LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
+	rc = readState(w);
+	if (rc) return rc;
+	w->last.nToiList = w->h_dstate->c.nToiList;
+	w->last.nToiCalls = w->h_dstate->c.nToiCalls;
+	w->last.nToiEvents = 0;
+	if (w->h_dstate->c.nToiList == 0) return 0;
+	if (w->h_dstate->c.nToiList > d.capContacts) return setError(B2HIP_ERR_CAPACITY, "TOI list overflow");
+	LAUNCH(w, k_toi_adj_clear, gridFor(d.nBodies + 1), 256, d);
+	LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
+	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p + 4, d.nBodies + 1);
+	LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_toi_loop, 1, TOI_LANES, d, w->sp);
+	LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+	w->toiRan = true;
 	return 0;
 }
 
@@ -1030,7 +1122,10 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->ktBytes = 0.0;
 	w->dw.cellSize = 1.0f;
 	w->dw.invCellSize = 1.0f;
-	for (int i = 0; i < 12; ++i)
+	w->toiRan = false;
+	w->toiEventValid = false;
+	w->debugTrace = getenv("B2HIP_TRACE") != nullptr;
+	for (int i = 0; i < 13; ++i)
 	{
 		if (hipEventCreate(&w->ev[i]) != hipSuccess)
 		{
@@ -1083,7 +1178,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->stateOut.release(); w->consts.release();
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
-	for (int i = 0; i < 12; ++i) (void)hipEventDestroy(w->ev[i]);
+	for (int i = 0; i < 13; ++i) (void)hipEventDestroy(w->ev[i]);
 	(void)hipStreamDestroy(w->stream);
 	delete w;
 }
@@ -1377,6 +1472,21 @@ int b2hip_find_new_contacts(b2hip_world* w)
 	return 0;
 }
 
+int b2hip_solve_toi(b2hip_world* w)
+{
+	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve_toi outside a step");
+	w->toiRan = false;
+	w->last.nToiList = w->last.nToiCalls = w->last.nToiEvents = 0;
+	if (w->def.continuous && w->sp.dt > 0.0f)
+	{
+		int rc = phaseToi(w);
+		if (rc) return rc;
+	}
+	HIP_TRY(hipEventRecord(w->ev[12], w->stream));
+	w->toiEventValid = true;
+	return 0;
+}
+
 int b2hip_step_end(b2hip_world* w)
 {
 	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_end outside a step");
@@ -1405,6 +1515,13 @@ int b2hip_step_end(b2hip_world* w)
 	w->last.nPairs = c.nPairs;
 	w->last.overflow = c.overflow;
 	w->last.posItersLarge = c.posItersLarge;
+	if (w->toiRan)
+	{
+		w->last.nToiEvents = c.nToiEvents;
+		w->last.nToiCalls = c.nToiCalls;
+		w->last.toiOverflow = c.toiOverflow;
+		if (c.toiOverflow) return setError(B2HIP_ERR_CAPACITY, "TOI event scratch overflow (flags " + std::to_string(c.toiOverflow) + ")");
+	}
 	if (w->sp.dt > 0.0f) w->inv_dt0 = w->sp.inv_dt;
 	w->stepActive = false;
 
@@ -1430,6 +1547,7 @@ int b2hip_step_end(b2hip_world* w)
 	p[10] = bp0;                                                                 // broadphaseSyncFixtures
 	p[11] = bp1 + bpTop;                                                         // broadphaseFindContacts
 	p[9] = bp0 + bp1 + bpTop;                                                    // broadphase
+	if (w->toiEventValid) { (void)hipEventElapsedTime(&ms, w->ev[10], w->ev[12]); p[7] = ms; }  // solveTOI
 	w->solverMs = small + large;
 	const int Ct = w->last.nSContacts + w->last.nLContacts;
 	const int B = w->last.nSBodies + w->last.nLBodies;
@@ -1466,6 +1584,8 @@ int b2hip_step(b2hip_world* w, float dt, int velocity_iterations, int position_i
 	rc = b2hip_sync_fixtures(w);
 	if (rc) return rc;
 	rc = b2hip_find_new_contacts(w);
+	if (rc) return rc;
+	rc = b2hip_solve_toi(w);
 	if (rc) return rc;
 	return b2hip_step_end(w);
 }
@@ -1570,6 +1690,113 @@ int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4])
 	return 0;
 }
 
+// Debug / test hook: FNV-1a over a group of device arrays, read back after a stream sync. Valid between
+// phase calls (b2hip_collide ... b2hip_step_end), so two worlds can be compared phase by phase.
+//   which 0: bodies (pos, pos0, vel, xf, flags)   1: contacts (ids, key, flags & 0x7f, manifold, impulses)
+//         2: proxies (fat AABBs)                  3: contact impulses only
+static uint64_t fnv(uint64_t h, const void* data, size_t n)
+{
+	const unsigned char* p = (const unsigned char*)data;
+	for (size_t i = 0; i < n; ++i)
+	{
+		h ^= p[i];
+		h *= 1099511628211ull;
+	}
+	return h;
+}
+
+int b2hip_debug_hash(b2hip_world* w, int which, uint64_t* out)
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	DState st;
+	HIP_TRY(hipMemcpy(&st, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost));
+	uint64_t h = 1469598103934665603ull;
+	std::vector<unsigned char> buf;
+	auto pull = [&](const void* dev, size_t bytes) -> int
+	{
+		buf.resize(bytes);
+		if (bytes == 0) return 0;
+		if (hipMemcpy(buf.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+		h = fnv(h, buf.data(), bytes);
+		return 0;
+	};
+	const size_t nb = w->upBodies, np = w->upFixtures, nc = (size_t)st.c.nContacts;
+	const int cur = st.cur;
+	int bad = 0;
+	if (which == 0)
+	{
+		bad |= pull(w->b_pos.p, nb * 16); bad |= pull(w->b_pos0.p, nb * 16); bad |= pull(w->b_vel.p, nb * 16);
+		bad |= pull(w->b_xf.p, nb * 16);
+		std::vector<uint32_t> f(nb);
+		if (nb && hipMemcpy(f.data(), w->b_flags.p, nb * 4, hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+		for (size_t i = 0; i < nb; ++i) f[i] &= 0x7fu;
+		h = fnv(h, f.data(), nb * 4);
+	}
+	else if (which == 1)
+	{
+		bad |= pull(w->c_ids[cur].p, nc * 16); bad |= pull(w->c_key[cur].p, nc * 8);
+		std::vector<uint32_t> f(nc);
+		if (nc && hipMemcpy(f.data(), w->c_flags[cur].p, nc * 4, hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+		for (size_t i = 0; i < nc; ++i) f[i] &= 0x1fu;
+		h = fnv(h, f.data(), nc * 4);
+		bad |= pull(w->c_man0[cur].p, nc * 16); bad |= pull(w->c_man1[cur].p, nc * 16);
+		bad |= pull(w->c_imp[cur].p, nc * 16); bad |= pull(w->c_man3[cur].p, nc * 16);
+	}
+	else if (which == 2)
+	{
+		bad |= pull(w->p_fat.p, np * 16);
+	}
+	else
+	{
+		bad |= pull(w->c_imp[cur].p, nc * 16);
+	}
+	if (bad) return setError(B2HIP_ERR_HIP, "debug hash read-back failed");
+	*out = h;
+	return 0;
+}
+
+// Debug hook: raw read of a device array (0 b_pos, 1 b_vel, 2 li_bodies, 3 b_force, 4 b_flags, 5 b_damp, 6 b_mass,
+// 7 counters as ints) into `out` (bytes).
+int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	const void* src = nullptr;
+	size_t elem = 16;
+	switch (which)
+	{
+	case 0: src = w->b_pos.p; break;
+	case 1: src = w->b_vel.p; break;
+	case 2: src = w->li_bodies.p; elem = 4; break;
+	case 3: src = w->b_force.p; break;
+	case 4: src = w->b_flags.p; elem = 4; break;
+	case 5: src = w->b_damp.p; break;
+	case 6: src = w->b_mass.p; break;
+	case 7: src = w->d_state.p; elem = 4; break;
+	case 8: src = w->dbgPreVel.p; break;
+	case 9: src = w->dbgVel.p; break;
+	case 10: src = w->dbgLi.p; elem = 4; break;
+	default: return setError(B2HIP_ERR_INVALID, "bad array id");
+	}
+	HIP_TRY(hipMemcpy(out, (const char*)src + (size_t)first * elem, (size_t)count * elem, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// Debug hook (B2HIP_TRACE=1): stage labels + state hashes recorded by the last b2hip_solve.
+int b2hip_debug_trace(b2hip_world* w, int index, char* label, int label_cap, uint64_t* hash)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	if (index < 0 || index >= (int)w->trace.size()) return 1;
+	if (label && label_cap > 0)
+	{
+		strncpy(label, w->trace[index].first.c_str(), (size_t)label_cap - 1);
+		label[label_cap - 1] = 0;
+	}
+	if (hash) *hash = w->trace[index].second;
+	return 0;
+}
+
 int b2hip_get_profile(b2hip_world* w, float ms[13])
 {
 	if (!w || !ms) return setError(B2HIP_ERR_INVALID, "null argument");
@@ -1599,6 +1826,9 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->solver_chunks = w->last.nChunks;
 	out->pos_iterations_large = w->last.posItersLarge;
 	out->overflow_flags = w->last.overflow;
+	out->toi_events = w->last.nToiEvents;
+	out->toi_calls = w->last.nToiCalls;
+	out->toi_pending_first_pass = w->last.nToiList;
 	return 0;
 }
 

@@ -53,7 +53,7 @@ class Counters(C.Structure):
         "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
         "small_island_bodies", "small_island_contacts", "large_island_bodies", "large_island_contacts",
         "colors", "moved_proxies", "new_contacts", "destroyed_contacts", "solver_chunks",
-        "pos_iterations_large", "overflow_flags")]
+        "pos_iterations_large", "overflow_flags", "toi_events", "toi_calls", "toi_pending_first_pass")]
 
 
 BODY_STATE_DTYPE = np.dtype([("px", "f4"), ("py", "f4"), ("angle", "f4"), ("vx", "f4"), ("vy", "f4"), ("w", "f4"),
@@ -87,7 +87,7 @@ def lib():
         L.b2hip_fixture_count.argtypes = [C.c_void_p]
         L.b2hip_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         L.b2hip_step_begin.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
-        for name in ("b2hip_collide", "b2hip_solve", "b2hip_sync_fixtures", "b2hip_find_new_contacts", "b2hip_step_end"):
+        for name in ("b2hip_collide", "b2hip_solve", "b2hip_sync_fixtures", "b2hip_find_new_contacts", "b2hip_solve_toi", "b2hip_step_end"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.b2hip_get_body_states.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.b2hip_contact_count.argtypes = [C.c_void_p]

@@ -56,7 +56,7 @@ typedef struct b2hip_world_def
 	float gravity_x, gravity_y;
 	int allow_sleep;      /* b2World::SetAllowSleeping      default 1 */
 	int warm_starting;    /* b2World::SetWarmStarting       default 1 */
-	int continuous;       /* b2World::SetContinuousPhysics  default 1 in the reference; TOI is not on the device path yet */
+	int continuous;       /* b2World::SetContinuousPhysics  default 1 in the reference; continuous collision (TOI) runs on the device: b2hip_solve_toi */
 	int sub_stepping;     /* b2World::SetSubStepping        default 0 */
 	int auto_clear_forces;/* b2World::SetAutoClearForces    default 1 */
 	int device;           /* HIP device ordinal, -1 = current */
@@ -160,6 +160,9 @@ typedef struct b2hip_counters
 	int32_t solver_chunks;
 	int32_t pos_iterations_large;
 	int32_t overflow_flags;
+	int32_t toi_events;              /* TOI sub-steps solved in the last step (b2World::StepSolveTOI calls) */
+	int32_t toi_calls;               /* b2TimeOfImpact evaluations in the last step */
+	int32_t toi_pending_first_pass;  /* contacts whose first-pass time of impact was < 1 */
 } b2hip_counters;
 
 const char* b2hip_last_error(void);
@@ -195,6 +198,9 @@ int b2hip_collide(b2hip_world* w);
 int b2hip_solve(b2hip_world* w);
 int b2hip_sync_fixtures(b2hip_world* w);
 int b2hip_find_new_contacts(b2hip_world* w);
+/* b2World::SolveTOI (b2World.cpp:1026-1093): continuous collision, after the end-of-step pair update.
+ * No-op unless the world was created / flagged with continuous = 1. */
+int b2hip_solve_toi(b2hip_world* w);
 int b2hip_step_end(b2hip_world* w);
 
 /* Host mirror of the last read-back; valid until the next step. */
@@ -206,6 +212,15 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out);
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out);
 /* Fat AABB of a fixture's proxy (b2BroadPhase::GetFatAABB). */
 int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4]);
+
+/* Test hook: FNV-1a hash of a group of device arrays (0 bodies, 1 contacts, 2 proxy AABBs, 3 contact impulses),
+ * usable between phase calls to compare two worlds phase by phase. */
+int b2hip_debug_hash(b2hip_world* w, int which, uint64_t* out);
+/* With B2HIP_TRACE=1 in the environment at world creation, b2hip_solve records a (stage label, state hash)
+ * per solver stage; returns 1 past the end. */
+int b2hip_debug_trace(b2hip_world* w, int index, char* label, int label_cap, uint64_t* hash);
+/* Raw read-back of one device array (see b2hip.hip for the ids); test / debugging only. */
+int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out);
 
 /* 13 floats in b2Profile declaration order (b2TimeStep.h:25-40), milliseconds, from HIP events. */
 int b2hip_get_profile(b2hip_world* w, float ms[13]);

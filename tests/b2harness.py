@@ -213,6 +213,12 @@ class World:
         order = np.lexsort((ids[:, 3], ids[:, 2], ids[:, 1], ids[:, 0]))
         return ids[order], flags[order], man[order]
 
+    def device_world(self):
+        """b2hip_world* behind the drop-in b2World (AMD backend only), for the C-ABI measurement hooks."""
+        self.L.b2h_device_world.restype = C.c_void_p
+        self.L.b2h_device_world.argtypes = [C.c_void_p]
+        return self.L.b2h_device_world(self.ptr)
+
     def profile(self):
         out = np.zeros(13, np.float32)
         n = self.L.b2h_get_profile(self.ptr, _fptr(out))

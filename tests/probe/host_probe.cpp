@@ -1,6 +1,7 @@
 // CPU compile of the device math headers (box2d-mt_amd/csrc/b2d_*.h) for bit-level checks against
 // oracle/_ref WITHOUT a GPU.  TEST INFRASTRUCTURE: nothing in the product links this file.
 #include "b2d_solver.h"
+#include "b2d_toi.h"
 #include <math.h>
 
 extern "C"
@@ -70,6 +71,49 @@ void probe_shape_aabb(const void* shape, const float* xf, float* out4)
 	out4[1] = r.lo.y;
 	out4[2] = r.hi.x;
 	out4[3] = r.hi.y;
+}
+
+// Same layouts as the harness probes b2h_probe_distance / b2h_probe_toi (oracle/harness/harness.cpp).
+static Sweep SweepFrom9(const float* s9)
+{
+	Sweep s;
+	s.localCenter = v2(s9[0], s9[1]);
+	s.c0 = v2(s9[2], s9[3]);
+	s.c = v2(s9[4], s9[5]);
+	s.a0 = s9[6];
+	s.a = s9[7];
+	s.alpha0 = s9[8];
+	return s;
+}
+
+void probe_distance(int countA, const float* vertsA, float radiusA, const float* xfA, int countB, const float* vertsB,
+	float radiusB, const float* xfB, int useRadii, float* out6)
+{
+	GjkProxy pA = { (const V2*)vertsA, countA, radiusA }, pB = { (const V2*)vertsB, countB, radiusB };
+	Xf a, b;
+	a.p = v2(xfA[0], xfA[1]);
+	a.q = b2dRot(xfA[2]);
+	b.p = v2(xfB[0], xfB[1]);
+	b.q = b2dRot(xfB[2]);
+	GjkCache cache;
+	memset(&cache, 0, sizeof(cache));
+	GjkOutput out;
+	b2dDistance(out, cache, pA, a, pB, b, useRadii != 0);
+	out6[0] = out.pointA.x; out6[1] = out.pointA.y;
+	out6[2] = out.pointB.x; out6[3] = out.pointB.y;
+	out6[4] = out.distance;
+	out6[5] = (float)out.iterations;
+}
+
+void probe_toi(int countA, const float* vertsA, float radiusA, const float* sweepA9, int countB, const float* vertsB,
+	float radiusB, const float* sweepB9, float tMax, float* out2)
+{
+	GjkProxy pA = { (const V2*)vertsA, countA, radiusA }, pB = { (const V2*)vertsB, countB, radiusB };
+	Sweep sA = SweepFrom9(sweepA9), sB = SweepFrom9(sweepB9);
+	float t = 0.0f;
+	int state = b2dTimeOfImpact(&t, pA, sA, pB, sB, tMax);
+	out2[0] = (float)state;
+	out2[1] = t;
 }
 
 } // extern "C"

@@ -13,7 +13,7 @@ CIRCLE, EDGE, POLYGON = 0, 1, 2
 
 
 def build_probe():
-    hdrs = [os.path.join(ROOT, "box2d-mt_amd", "csrc", h) for h in ("b2d_math.h", "b2d_collide.h", "b2d_solver.h")]
+    hdrs = [os.path.join(ROOT, "box2d-mt_amd", "csrc", h) for h in ("b2d_math.h", "b2d_collide.h", "b2d_solver.h", "b2d_toi.h")]
     newest = max(os.path.getmtime(p) for p in hdrs + [PROBE_SRC])
     if not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_LIB) < newest:
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared",

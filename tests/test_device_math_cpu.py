@@ -47,3 +47,39 @@ def test_device_sincos_matches_libm_dense_sample():
     P.probe_sincos_vs_libm.restype = C.c_long
     bad = P.probe_sincos_vs_libm(C.c_uint(0), C.c_uint(0xFFFFFFFF), C.c_uint(4099))
     assert bad == 0
+
+
+def _toi_vectors():
+    return np.load(os.path.join(GOLD, "toi_vectors.npz"))
+
+
+def test_device_distance_header_matches_golden():
+    """b2d_toi.h b2dDistance (GJK) against the reference's b2Distance outputs."""
+    P = pu.build_probe()
+    v = _toi_vectors()
+    bad = 0
+    for i in range(len(v["d_out"])):
+        out = np.zeros(6, np.float32)
+        a = np.ascontiguousarray(v["d_vertsA"][i]); b = np.ascontiguousarray(v["d_vertsB"][i])
+        xa = np.ascontiguousarray(v["d_xfA"][i]); xb = np.ascontiguousarray(v["d_xfB"][i])
+        P.probe_distance(int(v["d_countA"][i]), a.ctypes.data_as(fp), C.c_float(v["d_radiusA"][i]), xa.ctypes.data_as(fp),
+                         int(v["d_countB"][i]), b.ctypes.data_as(fp), C.c_float(v["d_radiusB"][i]), xb.ctypes.data_as(fp),
+                         int(v["d_useRadii"][i]), out.ctypes.data_as(fp))
+        bad += not np.array_equal(out.view(np.uint32), v["d_out"][i].view(np.uint32))
+    assert bad == 0
+
+
+def test_device_toi_header_matches_golden():
+    """b2d_toi.h b2dTimeOfImpact against the reference's b2TimeOfImpact outputs (state and t, bitwise)."""
+    P = pu.build_probe()
+    v = _toi_vectors()
+    bad = 0
+    for i in range(len(v["t_out"])):
+        out = np.zeros(2, np.float32)
+        a = np.ascontiguousarray(v["t_vertsA"][i]); b = np.ascontiguousarray(v["t_vertsB"][i])
+        sa = np.ascontiguousarray(v["t_sweepA"][i]); sb = np.ascontiguousarray(v["t_sweepB"][i])
+        P.probe_toi(int(v["t_countA"][i]), a.ctypes.data_as(fp), C.c_float(v["t_radiusA"][i]), sa.ctypes.data_as(fp),
+                    int(v["t_countB"][i]), b.ctypes.data_as(fp), C.c_float(v["t_radiusB"][i]), sb.ctypes.data_as(fp),
+                    C.c_float(1.0), out.ctypes.data_as(fp))
+        bad += not np.array_equal(out.view(np.uint32), v["t_out"][i].view(np.uint32))
+    assert bad == 0

@@ -1,0 +1,112 @@
+"""GPU parity tests of the continuous-collision path (b2World::SolveTOI on the device: k_toi_first,
+k_toi_loop), driven through the drop-in Box2D API + C ABI with continuous physics ON.
+
+Bars: contact counts, contact sets, feature ids and awake flags bit-exact; floats bit-exact wherever the
+discrete solver walks the reference's constraint order (small islands in default mode, every island in
+exact-order mode) - the TOI sub-steps themselves always follow the reference's order.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import b2harness as bh
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CCD = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
+SMALL_ISLAND_SCENES = ["ccd_helloworld", "ccd_bullets", "ccd_field", "ccd_rain"]
+ALL_SCENES = SMALL_ISLAND_SCENES + ["ccd_pyramid12", "ccd_tumbler6"]
+
+
+@pytest.fixture(scope="module")
+def toi_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "toi_scenes.npz"))
+
+
+@pytest.fixture()
+def exact_mode():
+    os.environ["B2HIP_FORCE_LARGE"] = "2"
+    yield
+    os.environ.pop("B2HIP_FORCE_LARGE", None)
+
+
+@pytest.fixture()
+def default_mode():
+    os.environ.pop("B2HIP_FORCE_LARGE", None)
+    yield
+
+
+def check_golden(h, g, name):
+    sc, p0, p1, seed, steps = [int(x) for x in g[name + "/params"]]
+    f0, f1 = [float(x) for x in g[name + "/fparams"]]
+    w = h.world(sc, p0, p1, f0, f1, seed, flags=CCD)
+    for s in range(steps):
+        w.step(1)
+        assert w.contact_count == g[name + "/contact_counts"][s], "contact count differs at step %d" % s
+        assert bh.fnv1a64(w.bodies()[:, :3]) == g[name + "/hashes"][s], "pose hash differs at step %d" % s
+    assert np.array_equal(w.bodies().view(np.uint32), g[name + "/bodies"].view(np.uint32))
+    ids, flags, man = w.contacts()
+    assert np.array_equal(ids, g[name + "/contact_ids"])
+    assert np.array_equal(flags, g[name + "/contact_flags"])
+    assert np.array_equal(man.view(np.uint32), g[name + "/contact_manifolds"].view(np.uint32))
+    w.close()
+
+
+@pytest.mark.parametrize("name", SMALL_ISLAND_SCENES)
+def test_ccd_small_island_scenes_bit_exact_vs_golden(amd, toi_golden, default_mode, name):
+    check_golden(amd, toi_golden, name)
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_ccd_exact_order_mode_bit_exact_vs_golden(amd, toi_golden, exact_mode, name):
+    check_golden(amd, toi_golden, name)
+
+
+@pytest.mark.parametrize("scene,p0,p1,f0,f1,steps", [(bh.BULLETS, 150, 8, 0.0, 0.0, 200), (bh.FIELD, 800, 200, 50.0, 3.0, 120),
+                                                      (bh.PILES, 30, 6, 0.0, 0.0, 100)])
+def test_ccd_side_by_side_with_c_oracle(amd, oracle, exact_mode, scene, p0, p1, f0, f1, steps):
+    """Fresh seeds: HIP path vs the C oracle next to it with continuous physics on, every step, bitwise."""
+    a = amd.world(scene, p0, p1, f0, f1, seed=29, flags=CCD)
+    o = oracle.world(scene, p0, p1, f0, f1, seed=29, flags=CCD)
+    for s in range(steps):
+        a.step(1)
+        o.step(1)
+        assert a.contact_count == o.contact_count, "step %d" % s
+        assert np.array_equal(a.bodies().view(np.uint32), o.bodies().view(np.uint32)), "step %d" % s
+    ia, fa, ma = a.contacts()
+    io, fo, mo = o.contacts()
+    assert np.array_equal(ia, io) and np.array_equal(fa, fo)
+    assert np.array_equal(ma.view(np.uint32), mo.view(np.uint32))
+
+
+def test_ccd_keeps_projectiles_inside_on_device(amd, default_mode):
+    """The point of the TOI phase: no projectile tunnels through the 0.1-wide walls; with it off many do."""
+    def escaped(flags):
+        w = amd.world(bh.BULLETS, 40, 6, seed=2, flags=flags)
+        w.step(60)
+        b = w.bodies()
+        w.close()
+        return int(((np.abs(b[:, 0]) > 20.5) | (b[:, 1] < -0.5) | (b[:, 1] > 30.5)).sum())
+    assert escaped(CCD) == 0
+    assert escaped(bh.F_SLEEP | bh.F_WARM) > 5
+
+
+def test_ccd_events_are_counted(amd, default_mode):
+    """b2hip_get_counters reports the TOI activity of the last step (events happen in the first steps of the scene)."""
+    w = amd.world(bh.BULLETS, 80, 6, seed=5, flags=CCD)
+    dev = C.c_void_p(w.device_world())
+    hip = C.CDLL(os.path.join(ROOT, "box2d-mt_amd", "libb2hip.so"))
+    import b2hip
+    events = calls = 0
+    for _ in range(30):
+        w.step(1)
+        ctr = b2hip.Counters()
+        assert hip.b2hip_get_counters(dev, C.byref(ctr)) == 0
+        events += ctr.toi_events
+        calls += ctr.toi_calls
+        assert ctr.toi_calls >= ctr.toi_pending_first_pass
+    assert events > 10 and calls > events
+    w.close()

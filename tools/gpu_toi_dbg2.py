@@ -1,0 +1,32 @@
+import os, sys, ctypes as C
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
+import b2harness as H, b2hip
+amd = H.Harness(H.AMD_LIB); orc = H.Harness(H.ORACLE_LIB)
+hip = C.CDLL(os.path.join(ROOT, "box2d-mt_amd", "libb2hip.so"))
+FL = H.F_CONTINUOUS | H.F_SLEEP | H.F_WARM
+kw = dict(p0=400, p1=60, f0=40.0, f1=3.0, seed=5)
+a = amd.world(H.FIELD, flags=FL, **kw); o = orc.world(H.FIELD, flags=FL, **kw)
+dev = C.c_void_p(a.device_world())
+for s in range(150):
+    a.step(); o.step()
+    ctr = b2hip.Counters(); hip.b2hip_get_counters(dev, C.byref(ctr))
+    A = a.bodies(); O = o.bodies()
+    ia, fa, ma = a.contacts(); io, fo, mo = o.contacts()
+    sa = set(map(tuple, ia.tolist())); so = set(map(tuple, io.tolist()))
+    ok = A.tobytes() == O.tobytes() and sa == so
+    if ok:
+        ok = not ((ma.view(np.uint32) != mo.view(np.uint32)).any(axis=1) | (fa != fo)).any()
+    if not ok or s % 25 == 0:
+        print("step", s + 1, "contacts", a.contact_count, o.contact_count, "bodies equal", A.tobytes() == O.tobytes(), "sets equal", sa == so,
+              {n: getattr(ctr, n) for n, _ in b2hip.Counters._fields_})
+    if not ok:
+        print("  only oracle:", sorted(so - sa)[:10], " only amd:", sorted(sa - so)[:10])
+        d = np.argwhere(A != O)
+        print("  body diffs", d[:12].tolist())
+        if sa == so:
+            bad = np.argwhere((ma.view(np.uint32) != mo.view(np.uint32)).any(axis=1) | (fa != fo)).reshape(-1)
+            for k in bad[:4]:
+                print("   ", ia[k].tolist(), "flags", fa[k], fo[k], "\n     amd", ma[k].tolist(), "\n     orc", mo[k].tolist())
+        break
