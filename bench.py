@@ -4,9 +4,11 @@
 A "step" is one full Step(1/60 s, 8 velocity / 3 position iterations) of the workload, including the
 mandatory host-visible body-state read-back. The N=1 workload is BASELINE.json
 configs[1]: the Pyramid recipe with 141 rows = 10 011 dynamic boxes on a ground edge (one island),
-CCD off, sleeping and warm starting on, measured in steady state after the warm-up steps. For N>1
+measured in steady state after the warm-up steps. For N>1
 (configs[3]-style sharding) every rank owns one such pyramid island: islands never exchange data, so
 there is no data-path collective ("weak" scaling); `value` counts island-steps of all ranks.
+World flags are the reference's defaults (b2World.cpp:75-79): continuous physics (TOI) ON, sleeping ON,
+warm starting ON - on the GPU path and on the CPU baseline alike (--no-ccd turns TOI off on both).
 
 One JSON line is printed by rank 0. Extra objects:
   roofline      dominant solver kernel: algorithmic bytes per launch / mean launch duration (HIP events
@@ -28,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
 
-def cpu_baseline(rows, warmup, max_seconds):
+def cpu_baseline(rows, warmup, max_seconds, flags):
     """Times the reference (or, without it, the C oracle) on the same scene: bounded CPU sample."""
     import b2harness as bh
     if bh.have_ref():
@@ -40,7 +42,7 @@ def cpu_baseline(rows, warmup, max_seconds):
         return None
     out = {}
     for threads in (1, 8) if kind == "reference" else (1,):
-        w = h.world(bh.PYRAMID, rows, 1, threads=threads)
+        w = h.world(bh.PYRAMID, rows, 1, threads=threads, flags=flags)
         w.step(warmup)
         w.reset_profile()
         t0 = time.perf_counter()
@@ -69,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=120)
     ap.add_argument("--rows", type=int, default=141, help="pyramid rows (141 -> 10 011 boxes, BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ccd", action="store_true", help="turn continuous physics (TOI) off on both sides")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -94,7 +97,8 @@ def main():
 
     # config-4 layout: `world_size` disjoint pyramids on one ground, rank r builds and steps pyramid r
     # (hipSetDevice above selects this rank's GPU for the world's stream)
-    w = amd.world(bh.PYRAMID, args.rows, world_size, float(rank), float(world_size))
+    flags = bh.F_SLEEP | bh.F_WARM | (0 if args.no_ccd else bh.F_CONTINUOUS)
+    w = amd.world(bh.PYRAMID, args.rows, world_size, float(rank), float(world_size), flags=flags)
     nbodies = w.body_count
 
     def barrier():
@@ -147,7 +151,8 @@ def main():
                     "launches_per_step": launches / 20.0, "mean_launch_us": 1000.0 * tot_ms / launches,
                     "algorithmic_bytes_per_launch": tot_bytes / launches,
                     "constraints": ctr.large_island_contacts + ctr.small_island_contacts,
-                    "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors}
+                    "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors,
+                    "toi_calls_per_step": ctr.toi_calls, "toi_events_last_step": ctr.toi_events}
         smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
         hipL.b2hip_get_solver_timing(dev, C.byref(smsv), C.byref(sbytes), C.byref(sct), C.byref(sb))
         if roof is not None and smsv.value > 0:
@@ -187,8 +192,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Pyramid %d rows: %d bodies, %d contacts per GPU, dt 1/60, 8 vel / 3 pos iterations, CCD off, sleep + warm start on"
-                                   % (args.rows, nbodies, contacts),
+            "config": {"workload": "Pyramid %d rows: %d bodies, %d contacts per GPU, dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
+                                   % (args.rows, nbodies, contacts, "off" if args.no_ccd else "on (reference default)"),
                        "bodies_total": nbodies * world_size, "parallelism": "one island shard per GPU, no data-path collective"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
@@ -197,7 +202,7 @@ def main():
         if roof is not None:
             line["roofline"] = roof
         if world_size == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.rows, min(args.warmup, 120), args.cpu_seconds)
+            cb = cpu_baseline(args.rows, min(args.warmup, 120), args.cpu_seconds, flags)
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line))

@@ -92,6 +92,11 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 				flags |= CF_TOI_LISTED;
 				const int k = atomicAdd(&S->c.nToiList, 1);
 				if (k < W.capContacts) W.toiList[k] = i;
+				// the parallel chains need (dynamic, static) pairs; bullets / kinematic partners go to the serial loop
+				const uint32_t fA = W.b_flags[ids.z], fB = W.b_flags[ids.w];
+				const uint32_t tA = fA & BF_TYPE_MASK, tB = fB & BF_TYPE_MASK;
+				const bool simple = ((tA == BT_DYNAMIC && tB == BT_STATIC) || (tB == BT_DYNAMIC && tA == BT_STATIC)) && ((fA | fB) & BF_BULLET) == 0;
+				if (!simple) atomicOr(&S->c.toiUnsafe, 1);
 			}
 		}
 		C.flags[i] = flags;

@@ -1,0 +1,579 @@
+// b2d_kernels_toi_chains.h - the common case of b2World::SolveTOI in parallel.
+//
+// In a world without bullets / kinematic bodies every TOI candidate pairs ONE dynamic body D with a static
+// body, and everything a TOI event on such a contact reads or writes is owned by D: D's sweep and velocity,
+// D's contacts with static bodies (manifold update, mini island, impact recomputation) and D's proxies.
+// Static bodies are only read (the reference also "advances" them, which changes nothing but their alpha0
+// bookkeeping, and that only ever makes them in-sync with D again - see DESIGN.md). Events of different dynamic
+// bodies therefore commute, unless one of them
+//   * creates a contact (the creation ORDER across bodies is defined by the global event order), or
+//   * wakes a sleeping body (its dormant contacts join the global arg-min), or
+//   * involves a non-static partner (bullet, kinematic).
+// k_toi_chains runs the whole event chain of each such body in its own wave; any of the conditions above raises
+// Counters::toiUnsafe, in which case the host restores the snapshot taken before the chains (k_toi_snapshot /
+// k_toi_restore) and lets the serial event loop (k_toi_loop) redo the phase. Nothing is approximated: either the
+// chains are provably order independent, or the reference's sequential order is replayed.
+#ifndef B2D_KERNELS_TOI_CHAINS_H
+#define B2D_KERNELS_TOI_CHAINS_H
+
+#include "b2d_kernels_toi.h"
+
+#define CHAIN_LANES 64
+#define CHAIN_CAND_MAX 64
+#define CHAIN_EVENTS_MAX 4096
+#define TOI_MOVED_MAX 4096
+
+// unsafe bits
+#define TOI_UNSAFE_PARTNER 1    // a pending impact involves a non-static partner
+#define TOI_UNSAFE_WOKE 2       // a sleeping body was woken
+#define TOI_UNSAFE_PAIR 4       // a moved proxy found a new pair
+#define TOI_UNSAFE_CAPACITY 8   // a per-chain capacity was exceeded
+#define TOI_UNSAFE_MOVED 16     // two moved proxies of different chains overlap without a contact
+
+// One entry per dynamic body that owns at least one pending impact.
+__global__ __launch_bounds__(256) void k_toi_groups_begin(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nToiList < W.capContacts ? S->c.nToiList : W.capContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int4 ids = C.ids[W.toiList[k]];
+		const uint32_t tA = W.b_flags[ids.z] & BF_TYPE_MASK, tB = W.b_flags[ids.w] & BF_TYPE_MASK;
+		int D = -1;
+		if (tA == BT_DYNAMIC && tB == BT_STATIC) D = ids.z;
+		else if (tB == BT_DYNAMIC && tA == BT_STATIC) D = ids.w;
+		if (D < 0 || ((W.b_flags[ids.z] | W.b_flags[ids.w]) & BF_BULLET))
+		{
+			atomicOr(&S->c.toiUnsafe, TOI_UNSAFE_PARTNER);
+			continue;
+		}
+		if (atomicCAS(&W.b_toiGroup[D], 0, 1) == 0)
+		{
+			const int g = atomicAdd(&S->c.nToiGroups, 1);
+			W.toiGroups[g] = D;
+		}
+	}
+}
+
+// Everything the chains may touch, copied once (contacts go to the idle half of the double buffer).
+__global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
+{
+	DState* S = W.st;
+	const int nC = S->c.nContacts;
+	const ContactArrays& A = W.ca[S->cur];
+	const ContactArrays& B = W.ca[1 - S->cur];
+	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	if (!restore)
+	{
+		for (int i = t0; i < W.nBodies; i += stride)
+		{
+			W.snapBody[5 * (size_t)i + 0] = W.b_pos[i];
+			W.snapBody[5 * (size_t)i + 1] = W.b_pos0[i];
+			W.snapBody[5 * (size_t)i + 2] = W.b_vel[i];
+			W.snapBody[5 * (size_t)i + 3] = W.b_xf[i];
+			W.snapBody[5 * (size_t)i + 4] = make_float4(__uint_as_float(W.b_flags[i]), 0, 0, 0);
+		}
+		for (int p = t0; p < W.nProxies; p += stride) W.snapFat[p] = W.p_fat[p];
+		for (int i = t0; i < nC; i += stride)
+		{
+			B.flags[i] = A.flags[i];
+			B.mat[i] = A.mat[i];
+			B.man0[i] = A.man0[i];
+			B.man1[i] = A.man1[i];
+			B.imp[i] = A.imp[i];
+			B.man3[i] = A.man3[i];
+		}
+	}
+	else
+	{
+		for (int i = t0; i < W.nBodies; i += stride)
+		{
+			W.b_pos[i] = W.snapBody[5 * (size_t)i + 0];
+			W.b_pos0[i] = W.snapBody[5 * (size_t)i + 1];
+			W.b_vel[i] = W.snapBody[5 * (size_t)i + 2];
+			W.b_xf[i] = W.snapBody[5 * (size_t)i + 3];
+			W.b_flags[i] = __float_as_uint(W.snapBody[5 * (size_t)i + 4].x);
+			W.b_toiGroup[i] = 0;
+		}
+		for (int p = t0; p < W.nProxies; p += stride) W.p_fat[p] = W.snapFat[p];
+		for (int i = t0; i < nC; i += stride)
+		{
+			A.flags[i] = B.flags[i];
+			A.mat[i] = B.mat[i];
+			A.man0[i] = B.man0[i];
+			A.man1[i] = B.man1[i];
+			A.imp[i] = B.imp[i];
+			A.man3[i] = B.man3[i];
+		}
+		if (t0 == 0)
+		{
+			S->c.nToiEvents = 0;
+			S->c.nToiMoved = 0;
+		}
+	}
+}
+
+// The event chain of one dynamic body: b2World::SolveTOI restricted to the contacts of D (all with static partners).
+__global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
+{
+	DState* S = W.st;
+	if ((int)blockIdx.x >= S->c.nToiGroups || (S->c.toiUnsafe & TOI_UNSAFE_PARTNER)) return;
+	const ContactArrays& C = W.ca[S->cur];
+	const int lane = threadIdx.x;
+	const int D = W.toiGroups[blockIdx.x];
+	const int e0 = W.adjStart[D], e1 = W.adjStart[D + 1];
+	const int nAdj = e1 - e0;
+	const float4 massD = W.b_mass[D];
+
+	__shared__ int s_cand[CHAIN_CAND_MAX], s_sorted[CHAIN_CAND_MAX], s_info[CHAIN_CAND_MAX];
+	__shared__ int s_nCand;
+	__shared__ int s_contacts[B2D_MAX_TOI_CONTACTS], s_cBodyA[B2D_MAX_TOI_CONTACTS], s_cBodyB[B2D_MAX_TOI_CONTACTS], s_nK;
+	__shared__ int s_bodies[B2D_MAX_TOI_BODIES], s_nB;
+	__shared__ float4 s_pos[B2D_MAX_TOI_BODIES], s_vel[B2D_MAX_TOI_BODIES];
+	__shared__ uint32_t s_pen;
+	__shared__ int s_unsafe, s_events, s_calls, s_solid, s_minIdx;
+	__shared__ float s_minAlpha;
+	__shared__ int s_moved[16], s_nMoved;
+	if (lane == 0)
+	{
+		s_unsafe = 0;
+		s_events = 0;
+		s_calls = 0;
+	}
+	__syncthreads();
+
+	// SetAwake(true); a body that really was asleep changes the eligibility of contacts outside this chain
+	auto wake = [&](int body)
+	{
+		const uint32_t old = atomicOr(&W.b_flags[body], BF_AWAKE);
+		W.b_pos[body].w = 0.0f;
+		if ((old & BF_AWAKE) == 0 && (old & BF_TYPE_MASK) != BT_STATIC) atomicOr(&s_unsafe, TOI_UNSAFE_WOKE);
+	};
+	// static partners are always in sync with D (see the header): give both sweeps D's alpha0
+	auto chainToi = [&](int c, int4 ids) -> float
+	{
+		Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
+		const float a0 = ids.z == D ? sA.alpha0 : sB.alpha0;
+		sA.alpha0 = a0;
+		sB.alpha0 = a0;
+		(void)c;
+		return computeToi(W, ids, sA, sB);
+	};
+
+	for (;;)
+	{
+		// ---- arg-min over D's candidate contacts -----------------------------------------------------------------
+		uint32_t bestA = 0xffffffffu;
+		unsigned long long bestK = ~0ull;
+		int bestI = -1;
+		for (int e = lane; e < nAdj; e += CHAIN_LANES)
+		{
+			const int c = W.adj[e0 + e];
+			const uint32_t flags = ldFlags(&C.flags[c]);
+			if ((flags & CF_TOI) == 0) continue;
+			const int4 ids = C.ids[c];
+			if (!toiEligible(W, flags, ids)) continue;
+			const uint32_t a = __float_as_uint(C.mat[c].w);
+			const unsigned long long key = C.key[c];
+			if (a < bestA || (a == bestA && key < bestK))
+			{
+				bestA = a;
+				bestK = key;
+				bestI = c;
+			}
+		}
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			const uint32_t oa = (uint32_t)__shfl_xor((int)bestA, off);
+			const unsigned long long ok = ((unsigned long long)(uint32_t)__shfl_xor((int)(bestK >> 32), off) << 32) |
+				(uint32_t)__shfl_xor((int)(uint32_t)bestK, off);
+			const int oi = __shfl_xor(bestI, off);
+			if (oa < bestA || (oa == bestA && ok < bestK))
+			{
+				bestA = oa;
+				bestK = ok;
+				bestI = oi;
+			}
+		}
+		const int minIdx = bestI;
+		const float minAlpha = bestI >= 0 ? __uint_as_float(bestA) : 1.0f;
+		if (minIdx < 0 || 1.0f - 10.0f * B2D_EPSILON < minAlpha) break;
+		if (s_unsafe) break;
+		if (s_events >= CHAIN_EVENTS_MAX)
+		{
+			if (lane == 0) s_unsafe |= TOI_UNSAFE_CAPACITY;
+			break;
+		}
+
+		// ---- StepSolveTOI for (static, D) ----------------------------------------------------------------------------
+		const int4 minIds = C.ids[minIdx];
+		const int partner = minIds.z == D ? minIds.w : minIds.z;
+		if (lane == 0)
+		{
+			s_nCand = 0;
+			s_nMoved = 0;
+			if ((ldFlags(&W.b_flags[partner]) & BF_TYPE_MASK) != BT_STATIC) s_unsafe |= TOI_UNSAFE_PARTNER;
+			Sweep d = loadSweep(W, D);
+			b2dSweepAdvance(d, minAlpha);
+			d.c = d.c0;
+			d.a = d.a0;
+			const Xf xfD = b2dXfFromSweep(d.c, d.a, d.localCenter);
+			const Xf xfS = loadXf(W.b_xf, partner);
+			ToiUpdate u;
+			u.wasTouching = (ldFlags(&C.flags[minIdx]) & CF_TOUCHING) != 0;
+			toiEvaluate(W, C, minIdx, minIds, minIds.z == D ? xfD : xfS, minIds.z == D ? xfS : xfD, &u);
+			toiCommitUpdate(C, minIdx, u);
+			uint32_t f = ldFlags(&C.flags[minIdx]);
+			const uint32_t cnt = ((f & CF_TOI_COUNT_MASK) >> CF_TOI_COUNT_SHIFT) + 1u;
+			f = (f & ~(CF_TOI | CF_TOI_COUNT_MASK)) | (cnt << CF_TOI_COUNT_SHIFT);
+			if (u.touching != u.wasTouching)
+			{
+				wake(minIds.z);
+				wake(minIds.w);
+			}
+			if (!u.touching)
+			{
+				f &= ~CF_ENABLED;
+				s_solid = 0;
+			}
+			else
+			{
+				s_solid = 1;
+				storeAdvanced(W, D, d);
+				wake(minIds.z);
+				wake(minIds.w);
+				s_bodies[0] = minIds.z;
+				s_bodies[1] = minIds.w;
+				s_nB = 2;
+				s_contacts[0] = minIdx;
+				s_nK = 1;
+			}
+			C.flags[minIdx] = f;
+		}
+		__syncthreads();
+		if (s_unsafe) break;
+		if (!s_solid) continue;
+
+		// ---- D's other contacts with non-dynamic partners, newest first --------------------------------------------------
+		for (int e = lane; e < nAdj; e += CHAIN_LANES)
+		{
+			const int c = W.adj[e0 + e];
+			if (c == minIdx) continue;
+			const int4 ids = C.ids[c];
+			const int other = ids.z == D ? ids.w : ids.z;
+			const uint32_t fO = ldFlags(&W.b_flags[other]);
+			if ((fO & BF_TYPE_MASK) == BT_DYNAMIC) continue; // neither is a bullet in this mode
+			if (ldFlags(&C.flags[c]) & CF_SENSOR) continue;
+			if ((fO & BF_TYPE_MASK) != BT_STATIC)
+			{
+				atomicOr(&s_unsafe, TOI_UNSAFE_PARTNER);
+				continue;
+			}
+			const int k = atomicAdd(&s_nCand, 1);
+			if (k < CHAIN_CAND_MAX) s_cand[k] = c; else atomicOr(&s_unsafe, TOI_UNSAFE_CAPACITY);
+		}
+		__syncthreads();
+		if (s_unsafe) break;
+		const int nCand = s_nCand;
+		if (lane < nCand)
+		{
+			const int me = s_cand[lane];
+			int rank = 0;
+			for (int j = 0; j < nCand; ++j) rank += s_cand[j] > me ? 1 : 0;
+			s_sorted[rank] = me;
+		}
+		__syncthreads();
+		ToiUpdate upd;
+		int myContact = -1;
+		if (lane < nCand)
+		{
+			myContact = s_sorted[lane];
+			const int4 ids = C.ids[myContact];
+			const int other = ids.z == D ? ids.w : ids.z;
+			const Xf xfD = loadXf(W.b_xf, D), xfO = loadXf(W.b_xf, other);
+			upd.wasTouching = (ldFlags(&C.flags[myContact]) & CF_TOUCHING) != 0;
+			toiEvaluate(W, C, myContact, ids, ids.z == D ? xfD : xfO, ids.z == D ? xfO : xfD, &upd);
+			s_info[lane] = upd.touching ? 1 : 0;
+		}
+		__syncthreads();
+		if (lane == 0)
+		{
+			int nB = s_nB, nK = s_nK;
+			bool blocked = false;
+			for (int r = 0; r < nCand; ++r)
+			{
+				if (blocked) break;
+				if (nB == B2D_MAX_TOI_BODIES || nK == B2D_MAX_TOI_CONTACTS)
+				{
+					blocked = true;
+					break;
+				}
+				int info = s_info[r] | 4;
+				if (info & 1)
+				{
+					const int c = s_sorted[r];
+					s_contacts[nK++] = c;
+					const int4 ids = C.ids[c];
+					const int other = ids.z == D ? ids.w : ids.z;
+					bool bodyIn = false;
+					for (int j = 0; j < nB; ++j) bodyIn = bodyIn || s_bodies[j] == other;
+					if (!bodyIn) s_bodies[nB++] = other;
+				}
+				s_info[r] = info;
+			}
+			s_nB = nB;
+			s_nK = nK;
+		}
+		__syncthreads();
+		if (lane < nCand && (s_info[lane] & 4))
+		{
+			toiCommitUpdate(C, myContact, upd);
+			if (upd.touching != upd.wasTouching)
+			{
+				const int4 ids = C.ids[myContact];
+				wake(ids.z);
+				wake(ids.w);
+			}
+		}
+		__syncthreads();
+
+		// ---- b2Island::SolveTOI: every constraint involves D, so the sweep is one constraint after the other -----------------
+		const int nB = s_nB, nK = s_nK;
+		const float h = (1.0f - minAlpha) * sp.dt;
+		if (lane < nB)
+		{
+			const int b = s_bodies[lane];
+			const float4 p = W.b_pos[b], v = W.b_vel[b];
+			s_pos[lane] = make_float4(p.x, p.y, p.z, 0.0f);
+			s_vel[lane] = make_float4(v.x, v.y, v.z, 0.0f);
+		}
+		ContactConstraint cc;
+		int ci = -1, la = 0, lb = 0;
+		Manifold mf;
+		float4 cmat = make_float4(0, 0, 0, 0), mA4 = cmat, mB4 = cmat;
+		float radiusA = 0.0f, radiusB = 0.0f;
+		if (lane < nK)
+		{
+			ci = s_contacts[lane];
+			const int4 ids = C.ids[ci];
+			for (int j = 0; j < nB; ++j)
+			{
+				if (s_bodies[j] == ids.z) la = j;
+				if (s_bodies[j] == ids.w) lb = j;
+			}
+			mA4 = W.b_mass[ids.z];
+			mB4 = W.b_mass[ids.w];
+			radiusA = W.shapes[W.p_shape[ids.x]].radius;
+			radiusB = W.shapes[W.p_shape[ids.y]].radius;
+			cmat = C.mat[ci];
+			const float4 m0 = C.man0[ci], m1 = C.man1[ci], im = C.imp[ci];
+			const int4 m3 = C.man3[ci];
+			mf.localNormal = v2(m0.x, m0.y);
+			mf.localPoint = v2(m0.z, m0.w);
+			mf.p[0] = v2(m1.x, m1.y);
+			mf.p[1] = v2(m1.z, m1.w);
+			mf.ni[0] = im.x; mf.ti[0] = im.y; mf.ni[1] = im.z; mf.ti[1] = im.w;
+			mf.id[0] = (uint32_t)m3.x; mf.id[1] = (uint32_t)m3.y;
+			mf.type = m3.z;
+			mf.pointCount = m3.w;
+		}
+		__syncthreads();
+		auto initConstraint = [&]()
+		{
+			BodyPos pA, pB;
+			BodyVel vA, vB;
+			const float4 pa = s_pos[la], va = s_vel[la], pb = s_pos[lb], vb = s_vel[lb];
+			pA.c = v2(pa.x, pa.y); pA.a = pa.z; vA.v = v2(va.x, va.y); vA.w = va.z;
+			pB.c = v2(pb.x, pb.y); pB.a = pb.z; vB.v = v2(vb.x, vb.y); vB.w = vb.z;
+			b2dInitConstraint(&cc, &mf, cmat.x, cmat.y, cmat.z,
+				mA4.x, mA4.y, v2(mA4.z, mA4.w), radiusA,
+				mB4.x, mB4.y, v2(mB4.z, mB4.w), radiusB,
+				pA, vA, pB, vB, false, 1.0f);
+		};
+		if (ci >= 0) initConstraint();
+		__syncthreads();
+		for (int it = 0; it < 20; ++it)
+		{
+			if (lane == 0) s_pen = 0;
+			__syncthreads();
+			for (int L = 0; L < nK; ++L)
+			{
+				if (lane == L)
+				{
+					ContactConstraint pc = cc;
+					if (la > 1) { pc.invMassA = 0.0f; pc.invIA = 0.0f; }
+					if (lb > 1) { pc.invMassB = 0.0f; pc.invIB = 0.0f; }
+					BodyPos pA, pB;
+					const float4 pa = s_pos[la], pb = s_pos[lb];
+					pA.c = v2(pa.x, pa.y); pA.a = pa.z;
+					pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+					float minSep = 0.0f;
+					b2dSolvePosition(&pc, &pA, &pB, B2D_TOI_BAUMGARTE, &minSep);
+					s_pos[la] = make_float4(pA.c.x, pA.c.y, pA.a, 0.0f);
+					s_pos[lb] = make_float4(pB.c.x, pB.c.y, pB.a, 0.0f);
+					atomicMax(&s_pen, floatBits(0.0f - minSep));
+				}
+				__syncthreads();
+			}
+			const float minSeparation = -__uint_as_float(s_pen);
+			__syncthreads();
+			if (minSeparation >= -1.5f * B2D_LINEAR_SLOP) break;
+		}
+		// leap of faith: only D moves (the static seed keeps c0 = c)
+		if (lane < 2 && s_bodies[lane] == D)
+		{
+			const float4 p = s_pos[lane];
+			W.b_pos0[D] = make_float4(p.x, p.y, p.z, minAlpha);
+		}
+		if (ci >= 0) initConstraint();
+		__syncthreads();
+		for (int it = 0; it < sp.velIters; ++it)
+		{
+			for (int L = 0; L < nK; ++L)
+			{
+				if (lane == L)
+				{
+					BodyVel vA, vB;
+					const float4 va = s_vel[la], vb = s_vel[lb];
+					vA.v = v2(va.x, va.y); vA.w = va.z;
+					vB.v = v2(vb.x, vb.y); vB.w = vb.z;
+					b2dSolveVelocity(&cc, &vA, &vB);
+					s_vel[la] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
+					s_vel[lb] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
+				}
+				__syncthreads();
+			}
+		}
+		if (lane < nB && s_bodies[lane] == D)
+		{
+			const float4 p = s_pos[lane], v = s_vel[lane];
+			V2 c = v2(p.x, p.y), vv = v2(v.x, v.y);
+			float a = p.z, w = v.z;
+			b2dIntegratePosition(&c, &a, &vv, &w, h);
+			const float sleepTime = W.b_pos[D].w;
+			W.b_pos[D] = make_float4(c.x, c.y, a, sleepTime);
+			W.b_vel[D] = make_float4(vv.x, vv.y, w, 0.0f);
+			const Xf xf = b2dXfFromSweep(c, a, v2(massD.z, massD.w));
+			W.b_xf[D] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
+		}
+		__syncthreads();
+
+		// ---- SynchronizeFixtures(D) + pair search -----------------------------------------------------------------------------
+		if (lane == 0)
+		{
+			const float4 p0 = W.b_pos0[D];
+			const Xf xf1 = b2dXfFromSweep(v2(p0.x, p0.y), p0.z, v2(massD.z, massD.w));
+			const Xf xf2 = loadXf(W.b_xf, D);
+			for (int p = W.b_proxyHead[D]; p >= 0; p = W.p_next[p])
+			{
+				const ShapeRec* shape = W.shapes + W.p_shape[p];
+				const AABB aabb = b2dAabbCombine(b2dShapeAABB(shape, xf1), b2dShapeAABB(shape, xf2));
+				if (b2dAabbContains(loadAabb(W.p_fat, p), aabb)) continue;
+				const V2 d = B2D_AABB_MULTIPLIER * (xf2.p - xf1.p);
+				AABB f = aabb;
+				f.lo = v2(f.lo.x - B2D_AABB_EXTENSION, f.lo.y - B2D_AABB_EXTENSION);
+				f.hi = v2(f.hi.x + B2D_AABB_EXTENSION, f.hi.y + B2D_AABB_EXTENSION);
+				if (d.x < 0.0f) f.lo.x += d.x; else f.hi.x += d.x;
+				if (d.y < 0.0f) f.lo.y += d.y; else f.hi.y += d.y;
+				W.p_fat[p] = make_float4(f.lo.x, f.lo.y, f.hi.x, f.hi.y);
+				if (s_nMoved < 16) s_moved[s_nMoved++] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
+				const int k = atomicAdd(&S->c.nToiMoved, 1);
+				if (k < TOI_MOVED_MAX) W.toiMoved[k] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
+			}
+		}
+		__syncthreads();
+		const int nMoved = s_nMoved;
+		if (nMoved > 0)
+		{
+			// against the fat AABBs as they were before the chains started (other chains move theirs concurrently);
+			// moved-vs-moved across chains is checked afterwards by k_toi_chains_end
+			for (int q = lane; q < W.nProxies; q += CHAIN_LANES)
+			{
+				const int bodyQ = W.p_body[q];
+				if (bodyQ < 0 || bodyQ == D) continue;
+				const AABB fq = loadAabb(W.snapFat, q);
+				for (int mI = 0; mI < nMoved; ++mI)
+				{
+					const int p = s_moved[mI];
+					if (!b2dAabbOverlap(loadAabb(W.p_fat, p), fq)) continue;
+					const int keyP = W.p_key[p], keyQ = W.p_key[q];
+					const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
+					const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
+					bool exists = false;
+					for (int e = e0; e < e1 && !exists; ++e) exists = C.key[W.adj[e]] == key;
+					if (exists) continue;
+					if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) continue;
+					if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) continue;
+					if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) continue;
+					atomicOr(&s_unsafe, TOI_UNSAFE_PAIR);
+				}
+			}
+		}
+		__syncthreads();
+		if (lane == 0) s_events += 1;
+
+		// ---- invalidate + recompute the impacts of D's contacts ------------------------------------------------------------------
+		for (int e = lane; e < nAdj; e += CHAIN_LANES) atomicAnd(&C.flags[W.adj[e0 + e]], ~CF_TOI);
+		__syncthreads();
+		if (s_unsafe) break;
+		for (int e = lane; e < nAdj; e += CHAIN_LANES)
+		{
+			const int c = W.adj[e0 + e];
+			const uint32_t flags = ldFlags(&C.flags[c]);
+			const int4 ids = C.ids[c];
+			if (!toiEligible(W, flags, ids)) continue;
+			if ((ldFlags(&W.b_flags[ids.z == D ? ids.w : ids.z]) & BF_TYPE_MASK) != BT_STATIC)
+			{
+				atomicOr(&s_unsafe, TOI_UNSAFE_PARTNER);
+				continue;
+			}
+			const float alpha = chainToi(c, ids);
+			atomicAdd(&s_calls, 1);
+			float4 mat = C.mat[c];
+			mat.w = alpha;
+			C.mat[c] = mat;
+			C.flags[c] = flags | CF_TOI;
+		}
+		__syncthreads();
+	}
+
+	__syncthreads();
+	if (lane == 0)
+	{
+		W.b_toiGroup[D] = 0;
+		if (s_events) atomicAdd(&S->c.nToiEvents, s_events);
+		if (s_calls) atomicAdd(&S->c.nToiCalls, s_calls);
+		if (s_unsafe) atomicOr(&S->c.toiUnsafe, s_unsafe);
+	}
+}
+
+// Two proxies moved by different chains may have come to overlap without either chain seeing it.
+__global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nToiMoved < TOI_MOVED_MAX ? S->c.nToiMoved : TOI_MOVED_MAX;
+	if (n < 2 || S->c.toiUnsafe) return;
+	for (int i = threadIdx.x; i < n; i += blockDim.x)
+	{
+		const int p = W.toiMoved[i];
+		const AABB fp = loadAabb(W.p_fat, p);
+		for (int j = i + 1; j < n; ++j)
+		{
+			const int q = W.toiMoved[j];
+			if (q == p || W.p_body[p] == W.p_body[q]) continue;
+			if (!b2dAabbOverlap(fp, loadAabb(W.p_fat, q))) continue;
+			// an existing contact makes the overlap harmless: look it up on p's (dynamic) body
+			const int keyP = W.p_key[p], keyQ = W.p_key[q];
+			const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
+			const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
+			const ContactArrays& C = W.ca[S->cur];
+			const int b = W.p_body[p];
+			bool exists = false;
+			for (int e = W.adjStart[b]; e < W.adjStart[b + 1] && !exists; ++e) exists = C.key[W.adj[e]] == key;
+			if (!exists) atomicOr(&S->c.toiUnsafe, TOI_UNSAFE_MOVED);
+		}
+	}
+}
+
+#endif

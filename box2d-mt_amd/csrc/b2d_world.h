@@ -95,13 +95,16 @@ struct Counters
 	int toiOverflow;     // bit0 candidates, bit1 moves, bit2 pairs, bit3 recompute list, bit4 TOI list
 	int nToiOrder;       // persistent: TOI-candidate contacts alive (b2ContactManager::m_toiCount)
 	int nToiDestroy;     // TOI candidates destroyed by the running collide
+	int toiUnsafe;       // the parallel TOI chains met a case only the serial event loop reproduces (bits: b2d_kernels_toi_chains.h)
+	int nToiGroups;      // dynamic bodies with a pending impact
+	int nToiMoved;       // proxies re-inserted by the TOI chains
 };
 
 struct DState
 {
 	Counters c;
 	int cur;             // which ContactArrays is live
-	int pad[13];
+	int pad[10];
 };
 
 struct StepParams
@@ -219,6 +222,11 @@ struct DW
 	int* toiList;        // contact indices whose cached TOI is < 1
 	int* toiPos2c;       // slot of the reference's TOI partition -> contact index (inverse of ContactArrays::mgr)
 	int* toiDestroyList; // TOI candidates marked for destruction by collide
+	int* b_toiGroup;     // per body: 1 while it owns a TOI chain
+	int* toiGroups;      // dynamic bodies with a pending impact
+	int* toiMoved;       // proxies re-inserted by the chains
+	float4* snapBody;    // 5 rows per body: pos, pos0, vel, xf, flags (state before the chains)
+	float4* snapFat;     // fat AABBs before the chains
 
 	// ---- generic scratch ----------------------------------------------------------------------
 	int* scanTmp;        // block sums for the scan utility

@@ -18,7 +18,7 @@
 #include <vector>
 
 #include "../../include/b2hip.h"
-#include "b2d_kernels_toi.h"
+#include "b2d_kernels_toi_chains.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -143,7 +143,8 @@ struct b2hip_world
 	DevArray<int> p_body, p_shape, p_key, p_filter1;
 	DevArray<uint32_t> p_filter0;
 	DevArray<float2> p_mat;
-	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList;
+	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiMoved;
+	DevArray<float4> snapBody, snapFat;
 	DevArray<ShapeRec> d_shapes;
 	DevArray<int4> c_ids[2];
 	DevArray<uint64_t> c_key[2];
@@ -188,7 +189,8 @@ struct b2hip_world
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
-	bool toiRan, toiEventValid;
+	bool toiRan, toiEventValid, toiChains, toiSerialOnly;
+	int toiFallbacks;                                  // steps whose TOI chains had to be redone serially
 	bool debugTrace;                                   // B2HIP_TRACE=1: hash the body state after every solver stage
 	std::vector<std::pair<std::string, uint64_t> > trace;
 	DevArray<float4> dbgPreVel, dbgVel;
@@ -492,6 +494,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(scanTmp4, maxScanN / SCAN_TILE + 4);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
+	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiMoved, TOI_MOVED_MAX); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
 #undef ENS
@@ -546,6 +549,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.stateOut = w->stateOut.p;
 	d.b_proxyHead = w->b_proxyHead.p; d.p_next = w->p_next.p; d.toiList = w->toiList.p;
 	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
+	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiMoved = w->toiMoved.p;
+	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	return 0;
 }
 
@@ -1005,25 +1010,36 @@ static int phaseSyncFixtures(b2hip_world* w)
 	return 0;
 }
 
+static int toiSerial(b2hip_world* w)
+{
+	DW& d = w->dw;
+	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
+	LAUNCH(w, k_toi_loop, 1, TOI_LANES, d, w->sp);
+	LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+	w->toiChains = false;
+	return 0;
+}
+
 // b2World::SolveTOI (b2World.cpp:1026-1093). The first arg-min pass runs over the whole contact array; the
 // event loop only runs (one persistent workgroup) when some impact lies inside the step.
 static int phaseToi(b2hip_world* w)
 {
 	DW& d = w->dw;
-	int rc = readState(w);
-	if (rc) return rc;
-	if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
-	if (w->h_dstate->c.nMoves != 0 && w->h_dstate->c.nPairs > COUNT_RANK_MAX)
+	// one read-back serves both questions: did the optimistic small-sort path of the end-of-step pair update
+	// apply (else finish it first: the TOI phase must see every contact), and is any impact pending
+	int rc = 0;
+	for (int pass = 0; pass < 2; ++pass)
 	{
-		// the optimistic small-sort path of the end-of-step pair update did not apply: finish it first,
-		// the TOI phase must see every contact
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nToiList, 0, sizeof(int) * 5, w->stream));
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
+		LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
+		rc = readState(w);
+		if (rc) return rc;
+		if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+		if (pass == 1 || w->h_dstate->c.nMoves == 0 || w->h_dstate->c.nPairs <= COUNT_RANK_MAX) break;
 		rc = runSortAndCreate(w, true);
 		if (rc) return rc;
 	}
-	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nToiList, 0, sizeof(int) * 5, w->stream));
-	LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
-	rc = readState(w);
-	if (rc) return rc;
 	w->last.nToiList = w->h_dstate->c.nToiList;
 	w->last.nToiCalls = w->h_dstate->c.nToiCalls;
 	w->last.nToiEvents = 0;
@@ -1033,10 +1049,21 @@ static int phaseToi(b2hip_world* w)
 	LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
 	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p + 4, d.nBodies + 1);
 	LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_toi_loop, 1, TOI_LANES, d, w->sp);
-	LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
 	w->toiRan = true;
-	return 0;
+	if (w->h_dstate->c.toiUnsafe == 0 && !w->toiSerialOnly)
+	{
+		// every pending impact pairs a dynamic body with a static one: one wave per dynamic body, verified afterwards
+		// (b2hip_step_end falls back to the serial loop from the snapshot if a chain met a case that is order dependent)
+		const int groups = std::min(w->h_dstate->c.nToiList, d.nBodies);
+		LAUNCH(w, k_toi_groups_begin, gridFor(w->h_dstate->c.nToiList), 256, d);
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+		LAUNCH(w, k_toi_chains, groups, CHAIN_LANES, d, w->sp);
+		LAUNCH(w, k_toi_chains_end, 1, 256, d);
+		LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+		w->toiChains = true;
+		return 0;
+	}
+	return toiSerial(w);
 }
 
 static int downloadState(b2hip_world* w)
@@ -1125,6 +1152,9 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->toiRan = false;
 	w->toiEventValid = false;
 	w->debugTrace = getenv("B2HIP_TRACE") != nullptr;
+	w->toiChains = false;
+	w->toiSerialOnly = getenv("B2HIP_TOI_SERIAL") != nullptr;
+	w->toiFallbacks = 0;
 	for (int i = 0; i < 13; ++i)
 	{
 		if (hipEventCreate(&w->ev[i]) != hipSuccess)
@@ -1476,6 +1506,7 @@ int b2hip_solve_toi(b2hip_world* w)
 {
 	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve_toi outside a step");
 	w->toiRan = false;
+	w->toiChains = false;
 	w->last.nToiList = w->last.nToiCalls = w->last.nToiEvents = 0;
 	if (w->def.continuous && w->sp.dt > 0.0f)
 	{
@@ -1504,6 +1535,16 @@ int b2hip_step_end(b2hip_world* w)
 			if (rc) return rc;
 		}
 	}
+	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
+	{
+		// a chain met an order-dependent case: back to the state before the chains, then the reference's serial order
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		rc = toiSerial(w);
+		if (rc) return rc;
+		w->toiFallbacks += 1;
+		rc = downloadState(w);
+		if (rc) return rc;
+	}
 	HIP_TRY(hipEventRecord(w->ev[11], w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	refreshMirror(w);
@@ -1517,6 +1558,7 @@ int b2hip_step_end(b2hip_world* w)
 	w->last.posItersLarge = c.posItersLarge;
 	if (w->toiRan)
 	{
+		w->last.toiUnsafe = c.toiUnsafe;
 		w->last.nToiEvents = c.nToiEvents;
 		w->last.nToiCalls = c.nToiCalls;
 		w->last.toiOverflow = c.toiOverflow;
@@ -1829,6 +1871,7 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->toi_events = w->last.nToiEvents;
 	out->toi_calls = w->last.nToiCalls;
 	out->toi_pending_first_pass = w->last.nToiList;
+	out->toi_serial_fallbacks = w->toiFallbacks;
 	return 0;
 }
 

@@ -163,6 +163,7 @@ typedef struct b2hip_counters
 	int32_t toi_events;              /* TOI sub-steps solved in the last step (b2World::StepSolveTOI calls) */
 	int32_t toi_calls;               /* b2TimeOfImpact evaluations in the last step */
 	int32_t toi_pending_first_pass;  /* contacts whose first-pass time of impact was < 1 */
+	int32_t toi_serial_fallbacks;    /* steps (since creation) whose parallel TOI chains were redone by the serial event loop */
 } b2hip_counters;
 
 const char* b2hip_last_error(void);
