@@ -19,6 +19,7 @@
 
 #include "../../include/b2hip.h"
 #include "b2d_kernels_toi_chains.h"
+#include "b2d_kernels_solve_persist.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -173,6 +174,9 @@ struct b2hip_world
 	DevArray<int> scanTmp, radixHist, radixHistScan, keepFlag, keepScan;
 	DevArray<int4> scanTmp4;
 	DevArray<float> stateOut;
+	DevArray<int> gridBar;       // grid barrier state of the persistent solver
+	int persistMaxWG;            // co-resident workgroups of k_solve_persistent on this device (0 = do not use it)
+	int persistSteps;            // steps solved by the persistent kernel (diagnostics)
 	DevArray<int> consts; // [0] nBodies, [1] gridSize, [2] radix hist count, [3] sorted-pair count
 
 	// pinned host buffers
@@ -189,7 +193,7 @@ struct b2hip_world
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
-	bool toiRan, toiEventValid, toiChains, toiSerialOnly;
+	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches;
 	int toiFallbacks;                                  // steps whose TOI chains had to be redone serially
 	bool debugTrace;                                   // B2HIP_TRACE=1: hash the body state after every solver stage
 	std::vector<std::pair<std::string, uint64_t> > trace;
@@ -497,6 +501,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiMoved, TOI_MOVED_MAX); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
+	ENS(gridBar, 16);
 #undef ENS
 	if (w->h_stateCap < 12 * nb)
 	{
@@ -929,6 +934,22 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_color_fill, gC, 256, d);
 		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
+		const bool hasJoints = d.nJoints > 0;
+		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
+		const int persistWG = (nLContacts + PERSIST_LANES - 1) / PERSIST_LANES;
+		const bool usePersistent = !exactLarge && !hasJoints && !w->debugTrace && !w->kernelTimingLaunches &&
+			w->persistMaxWG > 0 && persistWG <= w->persistMaxWG && nColors <= MAX_COLORS;
+		if (usePersistent)
+		{
+			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (b2d_kernels_solve_persist.h)
+			HIP_TRY(hipMemsetAsync(w->gridBar.p, 0, 16 * sizeof(int), w->stream));
+			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 3; }
+			LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColors, w->gridBar.p);
+			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
+			w->persistSteps += 1;
+		}
+		else
+		{
 		TRACE("before_integrate");
 		if (w->debugTrace)
 		{
@@ -941,8 +962,6 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_large_integrate, gB, 256, d, sp);
 		if (w->debugTrace) HIP_TRY(hipMemcpyAsync(w->dbgVel.p, w->b_vel.p, w->bodies.size() * 16, hipMemcpyDeviceToDevice, w->stream));
 		TRACE("integrate");
-		const bool hasJoints = d.nJoints > 0;
-		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
 		if (hasJoints && !exactLarge) LAUNCH(w, k_joints_sort, gJ, 64, d);
 		LAUNCH(w, k_large_init, gC, 256, d, sp);
 		TRACE("init");
@@ -977,6 +996,7 @@ static int phaseSolve(b2hip_world* w)
 			}
 			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
 			LAUNCH(w, k_large_pos_end, 1, 256, d);
+		}
 		}
 		LAUNCH(w, k_large_finalize, gB, 256, d, sp);
 		TRACE("finalize");
@@ -1152,6 +1172,20 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->toiRan = false;
 	w->toiEventValid = false;
 	w->debugTrace = getenv("B2HIP_TRACE") != nullptr;
+	w->kernelTimingLaunches = getenv("B2HIP_SOLVER_LAUNCHES") != nullptr; // force the launch-per-colour solver
+	w->persistSteps = 0;
+	w->persistMaxWG = 0;
+	{
+		int perCU = 0;
+		hipDeviceProp_t prop;
+		int devId = 0;
+		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess &&
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_persistent, PERSIST_LANES, 0) == hipSuccess)
+		{
+			// the occupancy query can be one block per CU high (sgpr_count 81-112, MI355X_MICROARCH.md): keep a margin
+			w->persistMaxWG = std::max(0, std::min(perCU - 1, 4)) * prop.multiProcessorCount;
+		}
+	}
 	w->toiChains = false;
 	w->toiSerialOnly = getenv("B2HIP_TOI_SERIAL") != nullptr;
 	w->toiFallbacks = 0;
@@ -1555,6 +1589,7 @@ int b2hip_step_end(b2hip_world* w)
 	w->last.nNewContacts = c.nNewContacts;
 	w->last.nPairs = c.nPairs;
 	w->last.overflow = c.overflow;
+	if (c.overflow & 64) return setError(B2HIP_ERR_HIP, "grid barrier of k_solve_persistent timed out (a workgroup was not resident)");
 	w->last.posItersLarge = c.posItersLarge;
 	if (w->toiRan)
 	{
@@ -1610,6 +1645,7 @@ int b2hip_step_end(b2hip_world* w)
 			w->ktLaunches += 1;
 		}
 		if (w->ktKind == 1) w->ktBytes = (double)w->last.nLContacts * 220.0 * w->sp.velIters;
+		else if (w->ktKind == 3) w->ktBytes = (double)w->last.nLContacts * (w->sp.velIters * 220.0 + w->last.posItersLarge * 136.0 + 488.0) + (double)w->last.nLBodies * 240.0;
 		else w->ktBytes = (double)w->last.nSContacts * (w->sp.velIters * 220.0 + w->sp.posIters * 136.0 + 488.0) + (double)w->last.nSBodies * 240.0;
 	}
 	return 0;
@@ -1895,7 +1931,7 @@ int b2hip_set_kernel_timing(b2hip_world* w, int enable)
 int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes)
 {
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
-	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : "");
+	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? "k_solve_persistent" : ""));
 	if (name && name_cap > 0)
 	{
 		strncpy(name, n, (size_t)name_cap - 1);
