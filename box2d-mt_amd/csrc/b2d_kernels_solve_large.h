@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			{
 				++uncolored;
 				col = -1;
+				// short list for the in-kernel incremental colouring (k_color_small)
+				const int u = atomicAdd(&S->c.nUncolList, 1);
+				if (u < COLOR_SMALL_MAX) W.uncolList[u] = s;
 			}
 			else if (col + 1 > maxColor)
 			{
@@ -182,6 +185,7 @@ __global__ void k_color_check_begin(DW W)
 		W.st->c.needRecolor = 0;
 		W.st->c.nColors = 0;
 		W.st->c.nUncolored = 0;
+		W.st->c.nUncolList = 0;
 	}
 }
 
@@ -237,6 +241,76 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 		++colored;
 	}
 	if (colored) atomicSub(&S->c.nUncolored, colored);
+}
+
+// Incremental colouring without a host round trip: the few constraints that have no colour yet (new contacts of a
+// settled island) are listed by k_color_check; one workgroup runs the Jones-Plassmann rounds over that list only.
+// Same claims, same priorities, same "lowest free colour" rule as k_color_claim / k_color_resolve, so the colours are
+// the ones the grid-wide rounds would hand out.
+__global__ __launch_bounds__(1024) void k_color_small(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nUncolList;
+	if (n == 0 || n > COLOR_SMALL_MAX || S->c.needRecolor) return;
+	const ContactArrays& C = W.ca[S->cur];
+	__shared__ int s_left, s_colored, s_maxColor;
+	if (threadIdx.x == 0)
+	{
+		s_left = n;
+		s_maxColor = 0;
+	}
+	__syncthreads();
+	for (int round = 0; round < 4 * MAX_COLORS && s_left > 0; ++round)
+	{
+		if (threadIdx.x == 0) s_colored = 0;
+		for (int k = threadIdx.x; k < n; k += blockDim.x)
+		{
+			const int s = W.uncolList[k];
+			if (W.li_color[s] >= 0) continue;
+			const int ci = W.li_contacts[s];
+			const int4 ids = C.ids[ci];
+			const uint32_t pr = colorPriority(ci);
+			if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC) atomicMax(&W.bodyClaim[ids.z], pr);
+			if ((W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC) atomicMax(&W.bodyClaim[ids.w], pr);
+		}
+		__syncthreads();
+		for (int k = threadIdx.x; k < n; k += blockDim.x)
+		{
+			const int s = W.uncolList[k];
+			if (W.li_color[s] >= 0) continue;
+			const int ci = W.li_contacts[s];
+			const int4 ids = C.ids[ci];
+			const uint32_t pr = colorPriority(ci);
+			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			bool win = true;
+			if (nsA && __hip_atomic_load(&W.bodyClaim[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
+			if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
+			if (!win) continue;
+			uint64_t used = 0;
+			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
+			if (used == ~0ull) atomicOr(&S->c.overflow, 4);
+			const unsigned long long bit = 1ull << color;
+			if (nsA) { atomicOr((unsigned long long*)&W.bodyColorMask[ids.z], bit); __hip_atomic_store(&W.bodyClaim[ids.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			if (nsB) { atomicOr((unsigned long long*)&W.bodyColorMask[ids.w], bit); __hip_atomic_store(&W.bodyClaim[ids.w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			W.li_color[s] = color;
+			C.color[ci] = color;
+			atomicAdd(&W.colorCount[color], 1);
+			atomicMax(&s_maxColor, color + 1);
+			atomicAdd(&s_colored, 1);
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) s_left -= s_colored;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+	{
+		atomicMax(&S->c.nColors, s_maxColor);
+		S->c.nUncolored = s_left;
+		S->c.colorRounds += 1;
+	}
 }
 
 __global__ void k_color_scan(DW W)

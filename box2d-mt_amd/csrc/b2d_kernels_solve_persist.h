@@ -95,9 +95,10 @@ __device__ __forceinline__ bool gridBarrier(const GridBarrier& gb)
 	return s_ok != 0;
 }
 
-__global__ __launch_bounds__(PERSIST_LANES) void k_solve_persistent(DW W, StepParams sp, int nColors, int* bar)
+__global__ __launch_bounds__(PERSIST_LANES) void k_solve_persistent(DW W, StepParams sp, int nColorsArg, int* bar)
 {
 	DState* S = W.st;
+	const int nColors = nColorsArg >= 0 ? nColorsArg : (S->c.nColors < MAX_COLORS ? S->c.nColors : MAX_COLORS);
 	const ContactArrays& C = W.ca[S->cur];
 	GridBarrier gb;
 	gb.bar = bar;

@@ -52,6 +52,7 @@
 #define TINY_ISLAND_MAX_W 128    // if every small island of the step is <= this, chunks are 256 lanes (lighter barriers)
 #define TINY_CHUNK_LANES 256
 #define MAX_COLORS 64
+#define COLOR_SMALL_MAX 4096     // uncoloured constraints up to this many are coloured by one workgroup without a host round trip
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
 
 struct ContactArrays
@@ -98,13 +99,14 @@ struct Counters
 	int toiUnsafe;       // the parallel TOI chains met a case only the serial event loop reproduces (bits: b2d_kernels_toi_chains.h)
 	int nToiGroups;      // dynamic bodies with a pending impact
 	int nToiMoved;       // proxies re-inserted by the TOI chains
+	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
 };
 
 struct DState
 {
 	Counters c;
 	int cur;             // which ContactArrays is live
-	int pad[10];
+	int pad[9];
 };
 
 struct StepParams
@@ -195,10 +197,13 @@ struct DW
 	int* colorCount;     // [MAX_COLORS + 1]
 	int* colorStart;     // [MAX_COLORS + 1]
 	int* colorCursor;
+	int* uncolList;      // large contact slots that have no colour yet (at most COLOR_SMALL_MAX listed)
 	int* li_sorted;      // large contact slots grouped by colour
 	int4* li_ref;        // per colour-sorted row: contact index, bodyA, bodyB (static bodies as -(id+1)), island root
 	uint32_t* bodyClaim;
 	uint64_t* bodyColorMask;
+	uint64_t* bodyActive;   // per body: colours of its constraints in THIS step's large-island solve (dataflow solver)
+	float4* b_posv;         // per body: (c.xy, a, version) rows of the dataflow solver's position phase
 	float* lc;           // large-island constraint rows, field-major: lc[field * capContacts + slot]
 	uint32_t* rootPen;   // per root: max penetration of the running position iteration (bits of -minSeparation)
 	int* rootDone;       // per root: positionSolved

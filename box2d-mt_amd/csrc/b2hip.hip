@@ -19,7 +19,7 @@
 
 #include "../../include/b2hip.h"
 #include "b2d_kernels_toi_chains.h"
-#include "b2d_kernels_solve_persist.h"
+#include "b2d_kernels_solve_dataflow.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -164,7 +164,9 @@ struct b2hip_world
 		si_stack, si_lastLevel, b_slot, b_island, chunkFirst;
 	DevArray<int> li_bodies, li_contacts, li_roots, li_color, colorCount, colorStart, colorCursor, li_sorted;
 	DevArray<uint32_t> bodyClaim, rootPen, rootSleepMin;
-	DevArray<uint64_t> bodyColorMask;
+	DevArray<uint64_t> bodyColorMask, bodyActive;
+	DevArray<float4> b_posv;
+	DevArray<int> uncolList;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
 	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies;
@@ -193,7 +195,7 @@ struct b2hip_world
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
-	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches;
+	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	int toiFallbacks;                                  // steps whose TOI chains had to be redone serially
 	bool debugTrace;                                   // B2HIP_TRACE=1: hash the body state after every solver stage
 	std::vector<std::pair<std::string, uint64_t> > trace;
@@ -480,7 +482,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / TINY_ISLAND_MAX_W + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(uncolList, COLOR_SMALL_MAX); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -544,7 +546,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.uncolList = w->uncolList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
@@ -904,8 +906,23 @@ static int phaseSolve(b2hip_world* w)
 	{
 		const int gB = gridFor(nLBodies), gC = gridFor(std::max(nLContacts, 1));
 		nColors = exactLarge ? nColors : c.nColors;
+		const bool hasJoints = d.nJoints > 0;
+		const int persistWG = (nLContacts + PERSIST_LANES - 1) / PERSIST_LANES;
+		const bool usePersistent = !exactLarge && !hasJoints && !w->debugTrace && !w->kernelTimingLaunches &&
+			w->persistMaxWG > 0 && persistWG <= w->persistMaxWG;
+		bool colorsOnDevice = false;
 		if (!exactLarge && (c.needRecolor || c.nUncolored > 0))
 		{
+			if (usePersistent && !c.needRecolor && c.nUncolored <= COLOR_SMALL_MAX)
+			{
+				// the usual case (a few new contacts on a settled island): one workgroup colours them, no host round trip;
+				// the resident solver reads the colour count from the device
+				LAUNCH(w, k_color_small, 1, 1024, d);
+				colorsOnDevice = true;
+				w->colorSmallPending = true;
+			}
+			else
+			{
 			// a colour clash on some body -> colour the large islands from scratch; otherwise only the
 			// constraints that have no colour yet join the Jones-Plassmann rounds (existing masks stay)
 			int uncolored = c.nUncolored;
@@ -929,22 +946,21 @@ static int phaseSolve(b2hip_world* w)
 				if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
 				batch = 8;
 			}
+			}
 		}
 		LAUNCH(w, k_color_scan, 1, 1, d);
 		LAUNCH(w, k_color_fill, gC, 256, d);
 		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
-		const bool hasJoints = d.nJoints > 0;
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
-		const int persistWG = (nLContacts + PERSIST_LANES - 1) / PERSIST_LANES;
-		const bool usePersistent = !exactLarge && !hasJoints && !w->debugTrace && !w->kernelTimingLaunches &&
-			w->persistMaxWG > 0 && persistWG <= w->persistMaxWG && nColors <= MAX_COLORS;
 		if (usePersistent)
 		{
 			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (b2d_kernels_solve_persist.h)
 			HIP_TRY(hipMemsetAsync(w->gridBar.p, 0, 16 * sizeof(int), w->stream));
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 3; }
-			LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColors, w->gridBar.p);
+			const int nColorsArg = colorsOnDevice ? -1 : nColors; // -1: read Counters::nColors on the device
+			if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
+			else LAUNCH(w, k_solve_dataflow, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 			w->persistSteps += 1;
 		}
@@ -1173,14 +1189,16 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->toiEventValid = false;
 	w->debugTrace = getenv("B2HIP_TRACE") != nullptr;
 	w->kernelTimingLaunches = getenv("B2HIP_SOLVER_LAUNCHES") != nullptr; // force the launch-per-colour solver
+	w->solverBarriers = getenv("B2HIP_SOLVER_BARRIERS") != nullptr;       // persistent kernel with a grid barrier per colour instead of body-level dataflow
 	w->persistSteps = 0;
+	w->colorSmallPending = false;
 	w->persistMaxWG = 0;
 	{
 		int perCU = 0;
 		hipDeviceProp_t prop;
 		int devId = 0;
 		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_persistent, PERSIST_LANES, 0) == hipSuccess)
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_dataflow, PERSIST_LANES, 0) == hipSuccess)
 		{
 			// the occupancy query can be one block per CU high (sgpr_count 81-112, MI355X_MICROARCH.md): keep a margin
 			w->persistMaxWG = std::max(0, std::min(perCU - 1, 4)) * prop.multiProcessorCount;
@@ -1589,6 +1607,13 @@ int b2hip_step_end(b2hip_world* w)
 	w->last.nNewContacts = c.nNewContacts;
 	w->last.nPairs = c.nPairs;
 	w->last.overflow = c.overflow;
+	if (w->colorSmallPending)
+	{
+		w->colorSmallPending = false;
+		w->last.nColors = c.nColors;
+		if (c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
+		if (c.nUncolored != 0) return setError(B2HIP_ERR_CAPACITY, "incremental colouring did not converge");
+	}
 	if (c.overflow & 64) return setError(B2HIP_ERR_HIP, "grid barrier of k_solve_persistent timed out (a workgroup was not resident)");
 	w->last.posItersLarge = c.posItersLarge;
 	if (w->toiRan)
@@ -1931,7 +1956,7 @@ int b2hip_set_kernel_timing(b2hip_world* w, int enable)
 int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes)
 {
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
-	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? "k_solve_persistent" : ""));
+	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : "k_solve_dataflow") : ""));
 	if (name && name_cap > 0)
 	{
 		strncpy(name, n, (size_t)name_cap - 1);

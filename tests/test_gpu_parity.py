@@ -328,12 +328,14 @@ def test_persistent_solver_matches_launch_per_colour(amd, default_mode):
 
     for scene, steps, kw in [(bh.PYRAMID, 90, dict(p0=40)), (bh.FIELD, 40, dict(p0=800, p1=200, f0=50.0, f1=3.0, seed=29))]:
         os.environ.pop("B2HIP_SOLVER_LAUNCHES", None)
-        a = run(scene, steps, **kw)
-        os.environ["B2HIP_SOLVER_LAUNCHES"] = "1"
-        try:
-            b = run(scene, steps, **kw)
-        finally:
-            os.environ.pop("B2HIP_SOLVER_LAUNCHES", None)
-        first_bad = next((i for i, (x, y) in enumerate(zip(a[0], b[0])) if x != y), None)
-        assert first_bad is None, "persistent and per-colour solvers diverge at step %s" % first_bad
-        assert a[1] == b[1]
+        os.environ.pop("B2HIP_SOLVER_BARRIERS", None)
+        a = run(scene, steps, **kw)  # default: body-level dataflow (k_solve_dataflow)
+        for var in ("B2HIP_SOLVER_BARRIERS", "B2HIP_SOLVER_LAUNCHES"):
+            os.environ[var] = "1"
+            try:
+                b = run(scene, steps, **kw)
+            finally:
+                os.environ.pop(var, None)
+            first_bad = next((i for i, (x, y) in enumerate(zip(a[0], b[0])) if x != y), None)
+            assert first_bad is None, "dataflow solver and %s diverge at step %s" % (var, first_bad)
+            assert a[1] == b[1]
