@@ -107,6 +107,10 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 	__shared__ int s_colorStart[MAX_COLORS + 2];
 	if ((int)threadIdx.x <= nColors && threadIdx.x <= MAX_COLORS) s_colorStart[threadIdx.x] = W.colorStart[threadIdx.x];
 	if (gtid == 0) S->c.allLargeDone = 0;
+	// phase timestamps of workgroup 0 (100 MHz ticks since kernel start) in bar[8..15]: a debugging aid read by
+	// b2hip_debug_read(11); one scalar store per phase
+	const unsigned long long t0 = wall_clock64();
+#define DF_STAMP(k) do { if (gtid == 0) bar[8 + (k)] = (int)(wall_clock64() - t0); } while (0)
 
 	// ---- integrate velocities (b2Island.cpp:192-230); velocity rows start at version 0 ---------------------------------
 	for (int k = gtid; k < nBodies; k += gsize)
@@ -127,6 +131,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 		stRow(&W.b_vel[body], v.x, v.y, w, 0);
 	}
 	if (!gridBarrier(gb)) return;
+	DF_STAMP(0);
 
 	// ---- my constraint: row = gtid ------------------------------------------------------------------------------------
 	const bool have = gtid < nRows;
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 			pA, vA, pB, vB, sp.warmStarting != 0, sp.dtRatio);
 	}
 	if (!gridBarrier(gb)) return; // all constructors have read the pre-warm-start velocities; the colour masks are complete
+	DF_STAMP(1);
 
 	// ---- my place in the update order of my two bodies --------------------------------------------------------------------
 	int degA = 0, rankA = 0, degB = 0, rankB = 0;
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 		if (!ok) return;
 	}
 
+	DF_STAMP(2);
 	// ---- StoreImpulses (b2ContactSolver.cpp:605-618) ----------------------------------------------------------------------
 	if (have)
 	{
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 		C.imp[r.ci] = im;
 	}
 	if (!gridBarrier(gb)) return; // every body has its final velocity
+	DF_STAMP(3);
 
 	// ---- integrate positions (b2Island.cpp:283-313); position rows start at version 0 -------------------------------------------
 	for (int k = gtid; k < nBodies; k += gsize)
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 	}
 	if (!gridBarrier(gb)) return;
 
+	DF_STAMP(4);
 	// ---- position iterations (b2Island.cpp:316-335): dataflow inside an iteration, island verdicts between iterations ------------
 	int executed = 0; // iterations in which my island was still open = version epochs of my bodies
 	for (int it = 0; it < sp.posIters; ++it)
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 		}
 	}
 
+	DF_STAMP(5);
 	// ---- positions back into the body table (sleepTime in the 4th word is untouched) -----------------------------------------------------
 	for (int k = gtid; k < nBodies; k += gsize)
 	{
@@ -303,6 +313,8 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 		const float sleepTime = W.b_pos[body].w;
 		W.b_pos[body] = make_float4(p.x, p.y, p.z, sleepTime);
 	}
+	DF_STAMP(6);
+#undef DF_STAMP
 }
 
 #endif
