@@ -153,6 +153,16 @@ def main():
                     "constraints": ctr.large_island_contacts + ctr.small_island_contacts,
                     "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors,
                     "toi_calls_per_step": ctr.toi_calls, "toi_events_last_step": ctr.toi_events}
+        # HBM traffic of that kernel: PMC counters cannot be sampled from inside this process; the per-launch figure
+        # measured with rocprofv3 --pmc on this same command is committed under profiles/ and quoted here when the
+        # workload and the kernel match (null otherwise)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+            if roof is not None and pmc.get("kernel") == kname and args.rows == 141 and not args.no_ccd:
+                roof["traffic"] = pmc["hbm_bytes_per_dispatch"]
+                roof["traffic_source"] = "profiles/r01_d_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
         hipL.b2hip_get_solver_timing(dev, C.byref(smsv), C.byref(sbytes), C.byref(sct), C.byref(sb))
         if roof is not None and smsv.value > 0:
