@@ -1253,6 +1253,10 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
+	w->bodyActive.release(); w->b_posv.release(); w->uncolList.release(); w->gridBar.release();
+	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
+	w->b_toiGroup.release(); w->toiGroups.release(); w->toiMoved.release(); w->snapBody.release(); w->snapFat.release();
+	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
 	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
