@@ -62,7 +62,9 @@ __device__ __forceinline__ void proxyCell(const DW& W, float4 a, int* ix, int* i
 	*iy = (int)floorf(0.5f * (a.y + a.w) * W.invCellSize);
 }
 
-__global__ __launch_bounds__(256) void k_grid_clear(DW W)
+// force = 1: rebuild the grid although the move buffer is empty (the TOI phase queries it and needs it to reflect
+// every fat AABB as of now; the pair census of the finished pair update is left alone)
+__global__ __launch_bounds__(256) void k_grid_clear(DW W, int force)
 {
 	DState* S = W.st;
 	// always reset the pair census, also when nothing moved: the ordering / creation kernels that
@@ -70,10 +72,13 @@ __global__ __launch_bounds__(256) void k_grid_clear(DW W)
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		S->c.nLargeProxies = 0;
-		S->c.nPairs = 0;
-		S->c.nNewContacts = 0;
+		if (!force)
+		{
+			S->c.nPairs = 0;
+			S->c.nNewContacts = 0;
+		}
 	}
-	if (S->c.nMoves == 0) return;
+	if (S->c.nMoves == 0 && !force) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= W.gridMask; i += gridDim.x * blockDim.x)
 	{
 		W.gridCount[i] = 0;
@@ -81,10 +86,10 @@ __global__ __launch_bounds__(256) void k_grid_clear(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_grid_count(DW W)
+__global__ __launch_bounds__(256) void k_grid_count(DW W, int force)
 {
 	DState* S = W.st;
-	if (S->c.nMoves == 0) return;
+	if (S->c.nMoves == 0 && !force) return;
 	const int n = W.nProxies;
 	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
 	{
@@ -104,10 +109,10 @@ __global__ __launch_bounds__(256) void k_grid_count(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_grid_fill(DW W)
+__global__ __launch_bounds__(256) void k_grid_fill(DW W, int force)
 {
 	DState* S = W.st;
-	if (S->c.nMoves == 0) return;
+	if (S->c.nMoves == 0 && !force) return;
 	const int n = W.nProxies;
 	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
 	{

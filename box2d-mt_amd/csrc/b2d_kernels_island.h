@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.nIslands = 0;
 		S->c.posItersLarge = 0;
 		S->c.maxSmallW = 0;
+		S->c.maxDegree = 0;
 		S->c.chunkW = SMALL_ISLAND_MAX_W;
 	}
 }
@@ -165,6 +166,16 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 		{
 			r = ufFindReadOnly(W.parent, i);
 			__hip_atomic_store(&W.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		{
+			// census of the largest contact degree (k_island_union counted deg[])
+			int dg = valid ? W.deg[i] : 0;
+			for (int off = 32; off > 0; off >>= 1)
+			{
+				const int o = __shfl_xor(dg, off);
+				dg = o > dg ? o : dg;
+			}
+			if (waveLane() == 0 && dg > 0) atomicMax(&W.st->c.maxDegree, dg);
 		}
 		waveAtomicAddInt(W.rootBodies, r, 1, valid);
 		// seeds are taken in m_nonStaticBodies order (b2World.cpp:1207-1221): first awake, active body

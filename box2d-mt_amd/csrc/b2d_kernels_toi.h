@@ -26,6 +26,7 @@
 #define TOI_RECOMP_MAX 512
 #define TOI_WOKEN_MAX 256
 #define TOI_EVENTS_MAX 100000
+#define TOI_MOVED_ALL_MAX 4096  // proxies re-inserted during one TOI phase (their grid bins are stale): DW::toiMoved
 
 // Flags are updated with L2 atomics (wake-ups, claims, invalidation) inside the event loop; a plain load could
 // be served from a stale L1 line of the same CU, so flag reads in this file go to L2 as relaxed atomic loads.
@@ -45,6 +46,34 @@ __device__ __forceinline__ Sweep loadSweep(const DW& W, int body)
 	s.c = v2(p.x, p.y);
 	s.a = p.z;
 	return s;
+}
+
+// Candidate partners of a re-inserted proxy: every proxy whose fat AABB can overlap `a`, found through the hash grid
+// (proxies are binned by the cell of their centre and are at most one cell wide, so the centres of all partners lie in
+// `a` grown by half a cell), plus the proxies that are wider than a cell, plus the proxies whose fat AABB changed since the
+// grid was built (`moved`: their bin is stale). f(q) may be called more than once for the same q.
+template <typename F>
+__device__ __forceinline__ void toiForEachCandidate(const DW& W, AABB a, int lane, int nLanes, const int* moved, int nMoved, F f)
+{
+	const float half = 0.5f * W.cellSize;
+	const float fx0 = floorf((a.lo.x - half) * W.invCellSize), fx1 = floorf((a.hi.x + half) * W.invCellSize);
+	const float fy0 = floorf((a.lo.y - half) * W.invCellSize), fy1 = floorf((a.hi.y + half) * W.invCellSize);
+	const float cells = (fx1 - fx0 + 1.0f) * (fy1 - fy0 + 1.0f);
+	if (!(cells >= 1.0f && cells <= 4096.0f))
+	{
+		for (int q = lane; q < W.nProxies; q += nLanes) f(q); // degenerate or huge query: look at everything
+		return;
+	}
+	const int ix0 = (int)fx0, iy0 = (int)fy0, nx = (int)(fx1 - fx0) + 1, nCells = (int)cells;
+	for (int c = lane; c < nCells; c += nLanes)
+	{
+		const uint32_t h = cellHash(ix0 + c % nx, iy0 + c / nx, W.gridMask);
+		const int start = W.gridStart[h], n = W.gridCount[h];
+		for (int t = 0; t < n; ++t) f(W.gridItems[start + t]);
+	}
+	const int nLarge = W.st->c.nLargeProxies;
+	for (int t = lane; t < nLarge; t += nLanes) f(W.largeProxies[t]);
+	for (int t = lane; t < nMoved; t += nLanes) f(moved[t]);
 }
 
 // b2World::ComputeToi(c, alpha0) (b2World.cpp:401-444): the sweeps are already on the same interval.
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 	__shared__ int s_advFlat[TOI_RECOMP_MAX], s_nAdv;
 	__shared__ float s_advAlpha[TOI_RECOMP_MAX];
 	__shared__ int s_pairCand[TOI_PAIRS_MAX];
-	__shared__ int s_toiOrder;
+	__shared__ int s_toiOrder, s_nMovedAll;
 	__shared__ int s_woken[TOI_WOKEN_MAX], s_nWoken;
 
 	if (tid == 0)
@@ -285,6 +314,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		s_calls = 0;
 		s_overflow = 0;
 		s_toiOrder = S->c.nToiOrder;
+		s_nMovedAll = 0;
 	}
 	__syncthreads();
 
@@ -727,44 +757,49 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		}
 		__syncthreads();
 
-		// ---- FindNewContacts for the moved proxies (b2World.cpp:1013-1023): brute force over all proxies ----------
+		// ---- FindNewContacts for the moved proxies (b2World.cpp:1013-1023) through the hash grid -------------------------
 		const int nMoves = s_nMoves < TOI_MOVES_MAX ? s_nMoves : TOI_MOVES_MAX;
-		if (nMoves > 0)
+		if (tid == 0)
 		{
-			for (int q = tid; q < W.nProxies; q += TOI_LANES)
+			// every proxy re-inserted during this TOI phase has a stale grid bin from now on
+			for (int mI = 0; mI < nMoves; ++mI)
+			{
+				if (s_nMovedAll < TOI_MOVED_ALL_MAX) W.toiMoved[s_nMovedAll++] = s_moves[mI]; else s_overflow |= 64;
+			}
+		}
+		__syncthreads();
+		const int nMovedAll = s_nMovedAll;
+		for (int mI = 0; mI < nMoves; ++mI)
+		{
+			const int p = s_moves[mI];
+			const AABB fp = loadAabb(W.p_fat, p);
+			const int bodyP = W.p_body[p];
+			toiForEachCandidate(W, fp, tid, TOI_LANES, W.toiMoved, nMovedAll, [&](int q)
 			{
 				const int bodyQ = W.p_body[q];
-				if (bodyQ < 0) continue;
-				const AABB fq = loadAabb(W.p_fat, q);
-				for (int mI = 0; mI < nMoves; ++mI)
+				if (bodyQ < 0 || p == q || bodyP == bodyQ) return;
+				if (!b2dAabbOverlap(fp, loadAabb(W.p_fat, q))) return;
+				const int keyP = W.p_key[p], keyQ = W.p_key[q];
+				const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
+				const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
+				// does a contact already exist? (b2ContactManager.cpp:262-287) p's body is dynamic: walk its adjacency
+				bool exists = false;
+				const int e0 = W.adjStart[bodyP], e1 = W.adjStart[bodyP + 1];
+				for (int e = e0; e < e1 && !exists; ++e) exists = C.key[W.adj[e]] == key;
+				for (int c = nC0; c < s_nC && !exists; ++c) exists = C.key[c] == key;
+				if (exists) return;
+				if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
+				if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
+				if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return;
+				const int k = atomicAdd(&s_nPairs, 1);
+				if (k < TOI_PAIRS_MAX)
 				{
-					const int p = s_moves[mI];
-					if (p == q) continue;
-					if (!b2dAabbOverlap(loadAabb(W.p_fat, p), fq)) continue;
-					const int bodyP = W.p_body[p];
-					if (bodyP == bodyQ) continue;
-					const int keyP = W.p_key[p], keyQ = W.p_key[q];
-					const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
-					const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
-					// does a contact already exist? (b2ContactManager.cpp:262-287) p's body is dynamic: walk its adjacency
-					bool exists = false;
-					const int e0 = W.adjStart[bodyP], e1 = W.adjStart[bodyP + 1];
-					for (int e = e0; e < e1 && !exists; ++e) exists = C.key[W.adj[e]] == key;
-					for (int c = nC0; c < s_nC && !exists; ++c) exists = C.key[c] == key;
-					if (exists) continue;
-					if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) continue;
-					if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) continue;
-					if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) continue;
-					const int k = atomicAdd(&s_nPairs, 1);
-					if (k < TOI_PAIRS_MAX)
-					{
-						s_pairs[k].key = key;
-						s_pairs[k].lo = lo;
-						s_pairs[k].hi = hi;
-					}
-					else atomicOr(&s_overflow, 4);
+					s_pairs[k].key = key;
+					s_pairs[k].lo = lo;
+					s_pairs[k].hi = hi;
 				}
-			}
+				else atomicOr(&s_overflow, 4);
+			});
 		}
 		__syncthreads();
 		const int nPairs = s_nPairs < TOI_PAIRS_MAX ? s_nPairs : TOI_PAIRS_MAX;

@@ -486,28 +486,28 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
 		const int nMoved = s_nMoved;
 		if (nMoved > 0)
 		{
-			// against the fat AABBs as they were before the chains started (other chains move theirs concurrently);
-			// moved-vs-moved across chains is checked afterwards by k_toi_chains_end
-			for (int q = lane; q < W.nProxies; q += CHAIN_LANES)
+			// against the fat AABBs as they were before the chains started (other chains move theirs concurrently; the grid was
+			// built from exactly those); moved-vs-moved across chains is checked afterwards by k_toi_chains_end
+			for (int mI = 0; mI < nMoved; ++mI)
 			{
-				const int bodyQ = W.p_body[q];
-				if (bodyQ < 0 || bodyQ == D) continue;
-				const AABB fq = loadAabb(W.snapFat, q);
-				for (int mI = 0; mI < nMoved; ++mI)
+				const int p = s_moved[mI];
+				const AABB fp = loadAabb(W.p_fat, p);
+				toiForEachCandidate(W, fp, lane, CHAIN_LANES, W.toiMoved, 0, [&](int q)
 				{
-					const int p = s_moved[mI];
-					if (!b2dAabbOverlap(loadAabb(W.p_fat, p), fq)) continue;
+					const int bodyQ = W.p_body[q];
+					if (bodyQ < 0 || bodyQ == D) return;
+					if (!b2dAabbOverlap(fp, loadAabb(W.snapFat, q))) return;
 					const int keyP = W.p_key[p], keyQ = W.p_key[q];
 					const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
 					const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
 					bool exists = false;
 					for (int e = e0; e < e1 && !exists; ++e) exists = C.key[W.adj[e]] == key;
-					if (exists) continue;
-					if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) continue;
-					if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) continue;
-					if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) continue;
+					if (exists) return;
+					if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
+					if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
+					if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return;
 					atomicOr(&s_unsafe, TOI_UNSAFE_PAIR);
-				}
+				});
 			}
 		}
 		__syncthreads();

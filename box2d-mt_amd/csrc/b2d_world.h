@@ -52,6 +52,8 @@
 #define TINY_ISLAND_MAX_W 128    // if every small island of the step is <= this, chunks are 256 lanes (lighter barriers)
 #define TINY_CHUNK_LANES 256
 #define MAX_COLORS 64
+#define HUB_DEGREE 30            // a body with more solid contacts than this cannot be coloured safely with 64 colours (two such
+                                 // bodies in contact may need deg + deg - 1): such steps use the exact-order (level) path
 #define COLOR_SMALL_MAX 4096     // uncoloured constraints up to this many are coloured by one workgroup without a host round trip
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
 
@@ -100,13 +102,14 @@ struct Counters
 	int nToiGroups;      // dynamic bodies with a pending impact
 	int nToiMoved;       // proxies re-inserted by the TOI chains
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
+	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
 };
 
 struct DState
 {
 	Counters c;
 	int cur;             // which ContactArrays is live
-	int pad[9];
+	int pad[8];
 };
 
 struct StepParams

@@ -196,6 +196,8 @@ struct b2hip_world
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
+	bool hubExact;               // the last step had a body of very large contact degree: solve on the exact-order path
+	int hubSteps;
 	int toiFallbacks;                                  // steps whose TOI chains had to be redone serially
 	bool debugTrace;                                   // B2HIP_TRACE=1: hash the body state after every solver stage
 	std::vector<std::pair<std::string, uint64_t> > trace;
@@ -791,10 +793,10 @@ static int findNewContacts(b2hip_world* w, bool sync)
 	DW& d = w->dw;
 	LAUNCH(w, k_ht_clear, gridFor(d.htMask + 1), 256, d);
 	LAUNCH(w, k_ht_build, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d);
-	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d);
+	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 0);
+	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 0);
 	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
-	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d);
+	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 0);
 	LAUNCH(w, k_find_pairs_small, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
 	LAUNCH(w, k_find_pairs_large, 1024, 256, d);
 	bool large = false;
@@ -831,8 +833,27 @@ static void tracePoint(b2hip_world* w, const char* label)
 }
 #define TRACE(label) tracePoint(w, label)
 
+static int phaseSolveOnce(b2hip_world* w, bool* redoExact);
+
+// b2World::Solve. A body with a very large contact degree (the Tumbler's container) cannot be edge-coloured with 64
+// colours: such steps are solved on the exact-order (dependency level) path, which has no degree limit and reproduces the
+// reference bit for bit. The decision is sticky from step to step so the island build is not repeated every step.
 static int phaseSolve(b2hip_world* w)
 {
+	bool redo = false;
+	int rc = phaseSolveOnce(w, &redo);
+	if (rc) return rc;
+	if (redo)
+	{
+		w->hubSteps += 1;
+		rc = phaseSolveOnce(w, &redo);
+	}
+	return rc;
+}
+
+static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
+{
+	*redoExact = false;
 	w->trace.clear();
 	DW& d = w->dw;
 	const StepParams& sp = w->sp;
@@ -842,7 +863,8 @@ static int phaseSolve(b2hip_world* w)
 	LAUNCH(w, k_island_union, gridFor(d.capContacts), 256, d);
 	LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, w->forceLarge);
+	const int forceLarge = (w->forceLarge == 0 && w->hubExact) ? 2 : w->forceLarge;
+	LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge);
 	{
 		int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
 		if (blocks < 1) blocks = 1;
@@ -867,7 +889,19 @@ static int phaseSolve(b2hip_world* w)
 	const Counters c = w->h_dstate->c;
 
 	HIP_TRY(hipEventRecord(w->ev[4], w->stream));
-	const bool exactLarge = w->forceLarge == 2;
+	const bool exactLarge = forceLarge == 2;
+	if (w->forceLarge == 0)
+	{
+		const bool hub = c.maxDegree > HUB_DEGREE;
+		if (hub && !w->hubExact)
+		{
+			// found out too late for this island build: classify again with every island on the exact-order path
+			w->hubExact = true;
+			*redoExact = true;
+			return 0;
+		}
+		w->hubExact = hub;
+	}
 	if (c.nSIslands > 0)
 	{
 		LAUNCH(w, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
@@ -1085,6 +1119,12 @@ static int phaseToi(b2hip_world* w)
 	LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
 	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p + 4, d.nBodies + 1);
 	LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
+	// the events search new pairs through the hash grid: make it reflect every fat AABB as of now (the end-of-step
+	// pair update skips the rebuild when nothing moved, and TOI moves of earlier steps never enter the move buffer)
+	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
+	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
+	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
+	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 1);
 	w->toiRan = true;
 	if (w->h_dstate->c.toiUnsafe == 0 && !w->toiSerialOnly)
 	{
@@ -1192,6 +1232,8 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverBarriers = getenv("B2HIP_SOLVER_BARRIERS") != nullptr;       // persistent kernel with a grid barrier per colour instead of body-level dataflow
 	w->persistSteps = 0;
 	w->colorSmallPending = false;
+	w->hubExact = false;
+	w->hubSteps = 0;
 	w->persistMaxWG = 0;
 	{
 		int perCU = 0;
