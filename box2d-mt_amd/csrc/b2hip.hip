@@ -101,6 +101,13 @@ struct HostFixture
 	float fat[4];
 };
 
+struct GraphSeg
+{
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t exec = nullptr;
+	uint64_t sig = 0;
+};
+
 struct FreeUnit
 {
 	int leaf;
@@ -196,6 +203,9 @@ struct b2hip_world
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
+	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
+	int graphCaptures;
+	GraphSeg segCollide, segIslands, segPairs;
 	bool hubExact;               // the last step had a body of very large contact degree: solve on the exact-order path
 	int hubSteps;
 	int toiFallbacks;                                  // steps whose TOI chains had to be redone serially
@@ -412,6 +422,50 @@ static int syncCheck(b2hip_world* w, const char* what)
 		int _rc = syncCheck((w), #kernel);                                                    \
 		if (_rc) return _rc;                                                                  \
 	} while (0)
+
+// ---- hipGraph segments ------------------------------------------------------------------------------
+// The step is ~55 kernels of 2-5 us: issued one by one the host (~3.5 us per launch) is the bottleneck between two
+// read-backs. The three launch sequences that contain no host decision (collide + compaction, island build up to the
+// census read-back, end-of-step pair update) are captured once per world layout and replayed as one graph launch each.
+// A segment is re-captured when anything baked into the kernel arguments changes (the DW pointer block, capacities).
+static uint64_t segSignature(const b2hip_world* w, uint64_t extra)
+{
+	uint64_t h = 1469598103934665603ull ^ extra;
+	h = (h ^ (uint64_t)(uintptr_t)w->scanTmp4.p) * 1099511628211ull;
+	h = (h ^ (uint64_t)(uintptr_t)w->consts.p) * 1099511628211ull;
+	h = (h ^ (uint64_t)(uintptr_t)w->stream) * 1099511628211ull;
+	const unsigned char* p = (const unsigned char*)&w->dw;
+	for (size_t i = 0; i < sizeof(DW); ++i)
+	{
+		h ^= p[i];
+		h *= 1099511628211ull;
+	}
+	return h;
+}
+
+template <typename F>
+static int runSegment(b2hip_world* w, GraphSeg& seg, uint64_t extra, F launches)
+{
+	if (!w->useGraphs || w->debugSync || w->debugTrace) return launches();
+	const uint64_t sig = segSignature(w, extra);
+	if (!seg.exec || seg.sig != sig)
+	{
+		if (seg.exec) (void)hipGraphExecDestroy(seg.exec);
+		if (seg.graph) (void)hipGraphDestroy(seg.graph);
+		seg.exec = nullptr;
+		seg.graph = nullptr;
+		HIP_TRY(hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
+		const int rc = launches();
+		hipError_t e = hipStreamEndCapture(w->stream, &seg.graph);
+		if (rc) return rc;
+		if (e != hipSuccess) return setError(B2HIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+		HIP_TRY(hipGraphInstantiate(&seg.exec, seg.graph, nullptr, nullptr, 0));
+		seg.sig = sig;
+		w->graphCaptures += 1;
+	}
+	HIP_TRY(hipGraphLaunch(seg.exec, w->stream));
+	return 0;
+}
 
 static int ktRecord(b2hip_world* w)
 {
@@ -788,6 +842,12 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 	return 0;
 }
 
+static int findNewContacts(b2hip_world* w, bool sync);
+static int findNewContactsGraph(b2hip_world* w)
+{
+	return runSegment(w, w->segPairs, 3, [w]() -> int { return findNewContacts(w, false); });
+}
+
 static int findNewContacts(b2hip_world* w, bool sync)
 {
 	DW& d = w->dw;
@@ -813,13 +873,16 @@ static int findNewContacts(b2hip_world* w, bool sync)
 
 static int phaseCollide(b2hip_world* w)
 {
-	DW& d = w->dw;
-	LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_toi_order_destroy, 1, 256, d);
-	deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
-	LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_compact_finish, 1, 1, d);
-	return 0;
+	return runSegment(w, w->segCollide, 1, [w]() -> int
+	{
+		DW& d = w->dw;
+		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_toi_order_destroy, 1, 256, d);
+		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_compact_finish, 1, 1, d);
+		return 0;
+	});
 }
 
 int b2hip_debug_hash(b2hip_world* w, int which, uint64_t* out);
@@ -859,32 +922,38 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 	const StepParams& sp = w->sp;
 	w->ktUsed = 0;
 	w->ktKind = 0;
-	LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
-	LAUNCH(w, k_island_union, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
-	LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
 	const int forceLarge = (w->forceLarge == 0 && w->hubExact) ? 2 : w->forceLarge;
-	LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge);
+	int rc = runSegment(w, w->segIslands, 2 + 16ull * (uint64_t)forceLarge, [w, forceLarge]() -> int
 	{
-		int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
-		if (blocks < 1) blocks = 1;
-		hipLaunchKernelGGL(k_scan_reduce<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, w->scanTmp4.p, w->consts.p);
-		hipLaunchKernelGGL(k_scan_blocksums<int4>, dim3(1), dim3(SCAN_THREADS), 0, w->stream, w->scanTmp4.p, w->consts.p, (int4*)nullptr);
-		hipLaunchKernelGGL(k_scan_final<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->consts.p);
-	}
-	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p, d.nBodies);
-	if (d.nJoints > 0)
-	{
-		deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->consts.p, d.nBodies);
-	}
-	LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
-	LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
-	if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
-	LAUNCH(w, k_color_check_begin, 1, 128, d);
-	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+		DW& d = w->dw;
+		LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
+		LAUNCH(w, k_island_union, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
+		LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge);
+		{
+			int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
+			if (blocks < 1) blocks = 1;
+			hipLaunchKernelGGL(k_scan_reduce<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, w->scanTmp4.p, w->consts.p);
+			hipLaunchKernelGGL(k_scan_blocksums<int4>, dim3(1), dim3(SCAN_THREADS), 0, w->stream, w->scanTmp4.p, w->consts.p, (int4*)nullptr);
+			hipLaunchKernelGGL(k_scan_final<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->consts.p);
+		}
+		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p, d.nBodies);
+		if (d.nJoints > 0)
+		{
+			deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->consts.p, d.nBodies);
+		}
+		LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
+		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
+		if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
+		LAUNCH(w, k_color_check_begin, 1, 128, d);
+		LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+		return 0;
+	});
+	if (rc) return rc;
 
 	// the host needs the island census to size the solver launches
-	int rc = readState(w);
+	rc = readState(w);
 	if (rc) return rc;
 	const Counters c = w->h_dstate->c;
 
@@ -1234,6 +1303,8 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->colorSmallPending = false;
 	w->hubExact = false;
 	w->hubSteps = 0;
+	w->useGraphs = getenv("B2HIP_GRAPHS") != nullptr; // opt-in: measured no gain on MI355X (the step is not host-bound), see DESIGN.md
+	w->graphCaptures = 0;
 	w->persistMaxWG = 0;
 	{
 		int perCU = 0;
@@ -1307,6 +1378,14 @@ void b2hip_world_destroy(b2hip_world* w)
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
 	for (int i = 0; i < 13; ++i) (void)hipEventDestroy(w->ev[i]);
+	{
+		GraphSeg* segs[3] = { &w->segCollide, &w->segIslands, &w->segPairs };
+		for (int i = 0; i < 3; ++i)
+		{
+			if (segs[i]->exec) (void)hipGraphExecDestroy(segs[i]->exec);
+			if (segs[i]->graph) (void)hipGraphDestroy(segs[i]->graph);
+		}
+	}
 	(void)hipStreamDestroy(w->stream);
 	delete w;
 }
@@ -1593,7 +1672,7 @@ int b2hip_find_new_contacts(b2hip_world* w)
 	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_find_new_contacts outside a step");
 	if (w->sp.dt > 0.0f)
 	{
-		int rc = findNewContacts(w, false);
+		int rc = findNewContactsGraph(w);
 		if (rc) return rc;
 	}
 	HIP_TRY(hipEventRecord(w->ev[10], w->stream));
