@@ -288,8 +288,14 @@ __global__ __launch_bounds__(256) void k_island_assign(DW W)
 		W.si_bodyStart[tot.w] = tot.x;
 		W.si_contactStart[tot.w] = tot.y;
 		W.si_wStart[tot.w] = tot.z;
-		const int chunkW = S->c.maxSmallW <= TINY_ISLAND_MAX_W ? TINY_ISLAND_MAX_W : SMALL_ISLAND_MAX_W;
+		// A chunk takes the islands whose weight prefix falls into one window of chunkW; it can overshoot the window
+		// by at most one island, so chunkW = lanes - largest island packs the workgroup as full as possible (the more
+		// islands a chunk holds, the more lanes each dependency level keeps busy).
+		const int lanes = (S->c.maxSmallW <= TINY_ISLAND_MAX_W && !W.bigChunks) ? TINY_CHUNK_LANES : SMALL_CHUNK_LANES;
+		int chunkW = lanes - S->c.maxSmallW;
+		if (chunkW < lanes / 2) chunkW = lanes / 2;
 		S->c.chunkW = chunkW;
+		S->c.chunkLanes = lanes;
 		S->c.nChunks = tot.w > 0 ? (tot.z - 1) / chunkW + 1 : 0;
 	}
 }
@@ -463,6 +469,9 @@ __global__ __launch_bounds__(256) void k_island_chunks(DW W)
 		{
 			W.chunkFirst[c] = idx;
 		}
+		// The census counted windows up to the END of the last island; a window in which no island STARTS has no chunk
+		// (its chunkFirst entry would be stale). Only the trailing window can be empty (islands are at most one window wide).
+		if (idx == nS - 1) S->c.nChunks = c + 1;
 	}
 }
 

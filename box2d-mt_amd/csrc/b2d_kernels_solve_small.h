@@ -79,6 +79,35 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 		s_pos[tid] = make_float4(pos.x, pos.y, pos.z, 0.0f);
 	}
 
+	// ---- lanes are re-dealt so that constraints of one dependency level sit in consecutive lanes: at level L only the
+	// waves that hold level-L constraints execute the solver body, the others branch over it (a stack is a chain: with
+	// the discovery order every wave would run every level for a handful of active lanes) ---------------------------
+	__shared__ int s_levelStart[LANES + 2];
+	__shared__ int s_perm[LANES];
+	for (int i = tid; i <= LANES + 1; i += LANES) s_levelStart[i] = 0;
+	__syncthreads();
+	int myLevel0 = 0;
+	if (tid < nC)
+	{
+		myLevel0 = W.si_level[cStart + tid];
+		if (myLevel0 > LANES) myLevel0 = LANES;
+		atomicAdd(&s_levelStart[myLevel0 + 1], 1);
+	}
+	__syncthreads();
+	if (tid == 0)
+	{
+		int run = 0;
+		for (int L = 0; L <= LANES + 1; ++L)
+		{
+			const int c = s_levelStart[L];
+			s_levelStart[L] = run;
+			run += c;
+		}
+	}
+	__syncthreads();
+	if (tid < nC) s_perm[atomicAdd(&s_levelStart[myLevel0 + 1], 1)] = tid;
+	__syncthreads();
+
 	// ---- per-constraint: gather ------------------------------------------------------------------
 	ContactConstraint cc;
 	int ci = -1, la = -1, lb = -1, level = 0, myIsland = 0;
@@ -91,8 +120,9 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 	float radiusA = 0, radiusB = 0;
 	if (tid < nC)
 	{
-		ci = W.si_contacts[cStart + tid];
-		level = W.si_level[cStart + tid];
+		const int mine = s_perm[tid];
+		ci = W.si_contacts[cStart + mine];
+		level = W.si_level[cStart + mine];
 		int4 ids = C.ids[ci];
 		const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
 		const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;

@@ -103,13 +103,14 @@ struct Counters
 	int nToiMoved;       // proxies re-inserted by the TOI chains
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
+	int chunkLanes;      // workgroup size of the small-island solver chosen for this step (TINY_CHUNK_LANES or SMALL_CHUNK_LANES)
 };
 
 struct DState
 {
 	Counters c;
 	int cur;             // which ContactArrays is live
-	int pad[8];
+	int pad[7];
 };
 
 struct StepParams
@@ -125,6 +126,7 @@ struct DW
 	DState* st;
 	int nBodies, nProxies, nJoints, nShapes;
 	int capContacts, capPairs, capMoves;
+	int bigChunks;        // 1: always use 1024-lane chunks for the small-island solver (B2HIP_BIG_CHUNKS)
 	uint32_t htMask;      // contact-key hash table size - 1
 	uint32_t gridMask;    // broad-phase hash grid size - 1
 	float cellSize, invCellSize;

@@ -535,7 +535,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(rootScanIn, nb + 1); ENS(rootScanOut, nb + 2);
 	ENS(si_root, nb + 1); ENS(si_bodyStart, nb + 2); ENS(si_contactStart, nb + 2); ENS(si_wStart, nb + 2); ENS(si_maxLevel, nb + 1);
 	ENS(si_bodies, nb); ENS(si_contacts, cc); ENS(si_level, cc); ENS(si_stack, nb); ENS(si_lastLevel, nb);
-	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / TINY_ISLAND_MAX_W + 4);
+	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
 	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(uncolList, COLOR_SMALL_MAX); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
@@ -574,6 +574,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.nProxies = (int)w->fixtures.size();
 	d.nJoints = (int)w->joints.size();
 	d.nShapes = (int)w->shapes.size();
+	d.bigChunks = getenv("B2HIP_BIG_CHUNKS") != nullptr ? 1 : 0;
 	d.capContacts = (int)cc;
 	d.capPairs = (int)w->pairKey.cap;
 	d.capMoves = (int)w->moveBuf.cap;
@@ -980,7 +981,7 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 2; }
-			if (c.chunkW == TINY_ISLAND_MAX_W) LAUNCH(w, k_solve_small<TINY_CHUNK_LANES>, c.nChunks, TINY_CHUNK_LANES, d, sp);
+			if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH(w, k_solve_small<TINY_CHUNK_LANES>, c.nChunks, TINY_CHUNK_LANES, d, sp);
 			else LAUNCH(w, k_solve_small<SMALL_CHUNK_LANES>, c.nChunks, SMALL_CHUNK_LANES, d, sp);
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
 		}
