@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 				Manifold mf;
 				mf.pointCount = 0;
 				mf.type = m3.z;
+				mf.id[0] = oldId0; // a sensor keeps whatever the manifold held (the reference leaves it untouched)
+				mf.id[1] = oldId1;
 				if (sensor)
 				{
 					// TODO(next): GJK b2TestOverlap for sensors; sensors never enter the solver.

@@ -654,7 +654,13 @@ static int flushEdits(b2hip_world* w)
 		}
 		const size_t cnt = j - i;
 		HIP_TRY(hipMemcpyAsync(w->b_pos.p + i, pos.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
-		HIP_TRY(hipMemcpyAsync(w->b_pos0.p + i, pos0.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+		// the sweep origin (c0, a0, alpha0) is device-owned state: only NEW bodies get it from the host mirror, an edited
+		// body keeps the one the last solve left (the read-back does not carry it, and TOI needs the true one)
+		if (i + cnt > w->upBodies)
+		{
+			const size_t first = std::max(i, w->upBodies);
+			HIP_TRY(hipMemcpyAsync(w->b_pos0.p + first, pos0.data() + (first - i), (i + cnt - first) * sizeof(float4), hipMemcpyHostToDevice, s));
+		}
 		HIP_TRY(hipMemcpyAsync(w->b_vel.p + i, vel.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(w->b_xf.p + i, xf.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(w->b_mass.p + i, mass.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));

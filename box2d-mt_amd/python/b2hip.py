@@ -68,39 +68,56 @@ CONTACT_DTYPE = np.dtype([("fixture_a", "i4"), ("fixture_b", "i4"), ("body_a", "
 _lib = None
 
 
+def _configure(L, optional_ok=False):
+    """Declares the C-ABI signatures on a loaded library. `optional_ok`: the library may lack the measurement / phase
+    entry points (the oracle's ABI shim used by the tests exports the world-building and stepping calls only)."""
+    L.b2hip_last_error.restype = C.c_char_p
+    L.b2hip_version.restype = C.c_char_p
+    sigs = {
+        "b2hip_world_create": [C.POINTER(WorldDef), C.POINTER(C.c_void_p)],
+        "b2hip_world_destroy": [C.c_void_p],
+        "b2hip_set_gravity": [C.c_void_p, C.c_float, C.c_float],
+        "b2hip_set_flags": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
+        "b2hip_create_body": [C.c_void_p, C.POINTER(BodyDef)],
+        "b2hip_create_fixture": [C.c_void_p, C.c_int, C.POINTER(FixtureDef), C.POINTER(Shape)],
+        "b2hip_create_revolute_joint": [C.c_void_p, C.POINTER(RevoluteJointDef)],
+        "b2hip_body_count": [C.c_void_p],
+        "b2hip_fixture_count": [C.c_void_p],
+        "b2hip_step": [C.c_void_p, C.c_float, C.c_int, C.c_int],
+        "b2hip_step_begin": [C.c_void_p, C.c_float, C.c_int, C.c_int],
+        "b2hip_collide": [C.c_void_p], "b2hip_solve": [C.c_void_p], "b2hip_sync_fixtures": [C.c_void_p],
+        "b2hip_find_new_contacts": [C.c_void_p], "b2hip_solve_toi": [C.c_void_p], "b2hip_step_end": [C.c_void_p],
+        "b2hip_get_body_states": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+        "b2hip_contact_count": [C.c_void_p],
+        "b2hip_get_contacts": [C.c_void_p, C.c_int, C.c_void_p],
+        "b2hip_get_island_labels": [C.c_void_p, C.c_int, C.c_void_p],
+        "b2hip_get_fat_aabb": [C.c_void_p, C.c_int, C.POINTER(C.c_float)],
+        "b2hip_get_profile": [C.c_void_p, C.POINTER(C.c_float)],
+        "b2hip_get_counters": [C.c_void_p, C.POINTER(Counters)],
+        "b2hip_get_solver_timing": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "b2hip_apply_force": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int],
+        "b2hip_set_velocity": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
+    }
+    for name, argtypes in sigs.items():
+        try:
+            getattr(L, name).argtypes = argtypes
+        except AttributeError:
+            if not optional_ok:
+                raise
+    return L
+
+
+def load(path, optional_ok=False):
+    """Any library that exports the b2hip C ABI (the product, or the tests' oracle shim)."""
+    return _configure(C.CDLL(path), optional_ok)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libb2hip.so is not built (%s): run __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
-        L.b2hip_last_error.restype = C.c_char_p
-        L.b2hip_version.restype = C.c_char_p
-        L.b2hip_world_create.argtypes = [C.POINTER(WorldDef), C.POINTER(C.c_void_p)]
-        L.b2hip_world_destroy.argtypes = [C.c_void_p]
-        L.b2hip_set_gravity.argtypes = [C.c_void_p, C.c_float, C.c_float]
-        L.b2hip_set_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
-        L.b2hip_create_body.argtypes = [C.c_void_p, C.POINTER(BodyDef)]
-        L.b2hip_create_fixture.argtypes = [C.c_void_p, C.c_int, C.POINTER(FixtureDef), C.POINTER(Shape)]
-        L.b2hip_create_revolute_joint.argtypes = [C.c_void_p, C.POINTER(RevoluteJointDef)]
-        L.b2hip_body_count.argtypes = [C.c_void_p]
-        L.b2hip_fixture_count.argtypes = [C.c_void_p]
-        L.b2hip_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
-        L.b2hip_step_begin.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
-        for name in ("b2hip_collide", "b2hip_solve", "b2hip_sync_fixtures", "b2hip_find_new_contacts", "b2hip_solve_toi", "b2hip_step_end"):
-            getattr(L, name).argtypes = [C.c_void_p]
-        L.b2hip_get_body_states.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        L.b2hip_contact_count.argtypes = [C.c_void_p]
-        L.b2hip_get_contacts.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.b2hip_get_island_labels.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.b2hip_get_fat_aabb.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
-        L.b2hip_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-        L.b2hip_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
-        L.b2hip_get_solver_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double),
-                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        L.b2hip_apply_force.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
-        L.b2hip_set_velocity.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
-        _lib = L
+        _lib = load(LIB_PATH)
     return _lib
 
 
@@ -110,7 +127,7 @@ class B2HipError(RuntimeError):
 
 def _check(rc):
     if rc < 0:
-        raise B2HipError("b2hip error %d: %s" % (rc, lib().b2hip_last_error().decode()))
+        raise B2HipError("b2hip error %d: %s" % (rc, (_lib.b2hip_last_error().decode() if _lib is not None else "?")))
     return rc
 
 
@@ -141,8 +158,8 @@ def edge_shape(v1, v2):
 
 
 class World:
-    def __init__(self, gravity=(0.0, -10.0), allow_sleep=True, warm_starting=True, continuous=False, device=-1):
-        self.L = lib()
+    def __init__(self, gravity=(0.0, -10.0), allow_sleep=True, warm_starting=True, continuous=False, device=-1, library=None):
+        self.L = library if library is not None else lib()
         d = WorldDef(gravity[0], gravity[1], int(allow_sleep), int(warm_starting), int(continuous), 0, 1, device)
         p = C.c_void_p()
         _check(self.L.b2hip_world_create(C.byref(d), C.byref(p)))
@@ -170,6 +187,25 @@ class World:
                        group=0, sensor=False, thick=False):
         d = FixtureDef(density, friction, restitution, category, mask, group, 0, int(sensor), int(thick))
         return _check(self.L.b2hip_create_fixture(self.p, body, C.byref(d), C.byref(shape)))
+
+    def create_revolute_joint(self, body_a, body_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), reference_angle=0.0,
+                              enable_limit=False, lower=0.0, upper=0.0, enable_motor=False, motor_speed=0.0,
+                              max_motor_torque=0.0, collide_connected=False):
+        d = RevoluteJointDef()
+        d.body_a, d.body_b = body_a, body_b
+        d.local_anchor_a[0], d.local_anchor_a[1] = anchor_a
+        d.local_anchor_b[0], d.local_anchor_b[1] = anchor_b
+        d.reference_angle = reference_angle
+        d.enable_limit, d.lower_angle, d.upper_angle = int(enable_limit), lower, upper
+        d.enable_motor, d.motor_speed, d.max_motor_torque = int(enable_motor), motor_speed, max_motor_torque
+        d.collide_connected = int(collide_connected)
+        return _check(self.L.b2hip_create_revolute_joint(self.p, C.byref(d)))
+
+    def apply_force(self, body, force=(0.0, 0.0), torque=0.0, wake=True):
+        _check(self.L.b2hip_apply_force(self.p, body, force[0], force[1], torque, int(wake)))
+
+    def set_velocity(self, body, velocity=(0.0, 0.0), omega=0.0):
+        _check(self.L.b2hip_set_velocity(self.p, body, velocity[0], velocity[1], omega))
 
     def step(self, dt=1.0 / 60.0, vel_iters=8, pos_iters=3):
         _check(self.L.b2hip_step(self.p, dt, vel_iters, pos_iters))

@@ -78,14 +78,14 @@ int b2hip_get_mass_data(const b2hip_world* w, int body, b2hip_mass_data* out)
 
 int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque, int wake)
 {
-	(void)w; (void)body; (void)fx; (void)fy; (void)torque; (void)wake;
-	return B2HIP_ERR_UNSUPPORTED;
+	b2o_apply_force(w->o, body, fx, fy, torque, wake);
+	return 0;
 }
 
 int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega)
 {
-	(void)w; (void)body; (void)vx; (void)vy; (void)omega;
-	return B2HIP_ERR_UNSUPPORTED;
+	b2o_set_velocity(w->o, body, vx, vy, omega);
+	return 0;
 }
 
 int b2hip_step(b2hip_world* w, float dt, int vi, int pi)

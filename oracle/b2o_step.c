@@ -1713,6 +1713,30 @@ void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 	}
 }
 
+/* b2Body::ApplyForceToCenter + ApplyTorque  b2Body.h:740-775 */
+void b2o_apply_force(b2o_world* w, int body, float fx, float fy, float torque, int wake)
+{
+	body_t* b = &w->bodies[body];
+	if (b->type != 2) return;
+	if (wake && (b->flags & BF_AWAKE) == 0) set_awake(b);
+	if (b->flags & BF_AWAKE)
+	{
+		b->force = v_add(b->force, v_make(fx, fy));
+		b->torque += torque;
+	}
+}
+
+/* b2Body::SetLinearVelocity / SetAngularVelocity  b2Body.h:575-611 */
+void b2o_set_velocity(b2o_world* w, int body, float vx, float vy, float omega)
+{
+	body_t* b = &w->bodies[body];
+	if (b->type == 0) return;
+	if (vx * vx + vy * vy > 0.0f) set_awake(b);
+	b->v = v_make(vx, vy);
+	if (omega * omega > 0.0f) set_awake(b);
+	b->w = omega;
+}
+
 int b2o_body_count(const b2o_world* w) { return w->nBodies; }
 
 void b2o_get_body_states(const b2o_world* w, float* out)

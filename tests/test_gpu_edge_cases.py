@@ -1,0 +1,181 @@
+"""GPU edge cases through the plain C ABI (include/b2hip.h): the same world is built twice with the same calls, once on
+libb2hip.so (HIP) and once on the oracle's ABI shim, and every step is compared bitwise. Covers what the scene harness
+does not: empty and static-only worlds, dt = 0, bodies without fixtures, forces / velocities set between steps, waking a
+sleeping pile, sensors, collision filters, fixed rotation, damping, gravity scale, bullets, zero iterations."""
+import os
+
+import numpy as np
+import pytest
+
+import b2harness as bh
+import b2hip
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libs(built_libs):
+    if not bh.have_amd():
+        pytest.fail("libb2hip.so missing (no CPU fallback)")
+    return b2hip.lib(), b2hip.load(bh.ORACLE_LIB, optional_ok=True)
+
+
+def both(libs, **kw):
+    return b2hip.World(library=libs[0], **kw), b2hip.World(library=libs[1], **kw)
+
+
+def same(a, b, what=""):
+    sa, sb = a.body_states(), b.body_states()
+    for f in ("px", "py", "angle", "vx", "vy", "w", "cx", "cy", "sleep_time"):
+        assert np.array_equal(sa[f].view(np.uint32), sb[f].view(np.uint32)), "%s: %s differs" % (what, f)
+    assert np.array_equal(sa["flags"] & 0x7f, sb["flags"] & 0x7f), "%s: flags differ" % what
+    assert a.contact_count == b.contact_count, "%s: contact count" % what
+    ca, cb = a.contacts(), b.contacts()
+    for f in ("fixture_a", "fixture_b", "flags", "point_count", "id_key", "normal_impulse", "tangent_impulse"):
+        assert np.array_equal(ca[f].view(np.uint32) if ca[f].dtype.kind == "f" else ca[f],
+                              cb[f].view(np.uint32) if cb[f].dtype.kind == "f" else cb[f]), "%s: contact %s differs" % (what, f)
+
+
+def run(a, b, steps, what, dt=1.0 / 60.0, vi=8, pi=3, between=None):
+    for s in range(steps):
+        if between:
+            between(s, a)
+            between(s, b)
+        a.step(dt, vi, pi)
+        b.step(dt, vi, pi)
+        same(a, b, "%s step %d" % (what, s))
+
+
+def test_empty_and_static_only_worlds(libs):
+    a, b = both(libs)
+    run(a, b, 3, "empty")
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, -1.0))
+        w.create_fixture(g, b2hip.box_shape(10.0, 1.0))
+        g2 = w.create_body(b2hip.STATIC, (3.0, 0.5), angle=0.3)
+        w.create_fixture(g2, b2hip.circle_shape(0.5))
+    run(a, b, 3, "static only")
+    assert a.contact_count == 0
+    a.close(); b.close()
+
+
+def test_zero_dt_and_zero_iterations(libs):
+    a, b = both(libs)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, -1.0))
+        w.create_fixture(g, b2hip.box_shape(10.0, 1.0))
+        d = w.create_body(b2hip.DYNAMIC, (0.0, 0.4), velocity=(1.0, 0.0))
+        w.create_fixture(d, b2hip.box_shape(0.5, 0.5), density=1.0)
+    run(a, b, 2, "dt=0", dt=0.0)
+    run(a, b, 20, "normal")
+    run(a, b, 2, "dt=0 again", dt=0.0)
+    run(a, b, 10, "no iterations", vi=0, pi=0)
+    run(a, b, 10, "one iteration", vi=1, pi=1)
+    a.close(); b.close()
+
+
+def test_body_without_fixture_and_body_options(libs):
+    a, b = both(libs)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, -1.0))
+        w.create_fixture(g, b2hip.box_shape(20.0, 1.0), friction=0.6)
+        w.create_body(b2hip.DYNAMIC, (5.0, 5.0))                      # no fixture: unit mass, falls forever
+        d1 = w.create_body(b2hip.DYNAMIC, (-3.0, 2.0), angle=0.4, fixed_rotation=True)
+        w.create_fixture(d1, b2hip.box_shape(0.4, 0.7), density=2.0, friction=0.1)
+        d2 = w.create_body(b2hip.DYNAMIC, (-1.0, 3.0), linear_damping=0.8, angular_damping=0.5, omega=5.0)
+        w.create_fixture(d2, b2hip.circle_shape(0.3), density=1.0, restitution=0.6)
+        d3 = w.create_body(b2hip.DYNAMIC, (1.0, 3.0), gravity_scale=0.25, allow_sleep=False)
+        w.create_fixture(d3, b2hip.box_shape(0.3, 0.3), density=1.0)
+        d4 = w.create_body(b2hip.DYNAMIC, (3.0, 2.0), gravity_scale=-0.5)   # floats upwards
+        w.create_fixture(d4, b2hip.circle_shape(0.2, 0.1, 0.0), density=1.0)  # off-centre circle: non-zero local centre
+        k = w.create_body(b2hip.KINEMATIC, (0.0, 1.0), velocity=(0.5, 0.0), omega=0.3)
+        w.create_fixture(k, b2hip.box_shape(1.0, 0.1))
+    run(a, b, 150, "options")
+    a.close(); b.close()
+
+
+def test_sensor_and_filters(libs):
+    a, b = both(libs)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, -1.0))
+        w.create_fixture(g, b2hip.box_shape(20.0, 1.0))
+        s = w.create_body(b2hip.STATIC, (0.0, 1.0))
+        w.create_fixture(s, b2hip.box_shape(2.0, 0.2), sensor=True)                    # bodies fall through
+        for i in range(6):
+            d = w.create_body(b2hip.DYNAMIC, (-2.5 + i, 3.0 + 0.3 * i))
+            # categories: even boxes ignore odd boxes (mask), group -1 never collides within the group
+            w.create_fixture(d, b2hip.box_shape(0.45, 0.45), density=1.0, category=1 << (i & 1), mask=0xFFFF ^ (2 >> (i & 1)) if i < 4 else 0xFFFF,
+                             group=-1 if i >= 4 else 0)
+    run(a, b, 120, "sensor/filter")
+    a.close(); b.close()
+
+
+def test_forces_velocities_and_waking(libs):
+    a, b = both(libs)
+    ids = {}
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, -1.0))
+        w.create_fixture(g, b2hip.box_shape(20.0, 1.0))
+        ids[w] = []
+        for i in range(4):
+            d = w.create_body(b2hip.DYNAMIC, (0.0, 0.5 + 1.0 * i))
+            w.create_fixture(d, b2hip.box_shape(0.5, 0.5), density=1.0)
+            ids[w].append(d)
+
+    def between(s, w):
+        top = ids[w][3]
+        if 5 <= s < 15:
+            w.apply_force(top, (30.0, 0.0), torque=2.0)
+        if s == 200:
+            w.apply_force(ids[w][0], (0.0, 0.0), torque=0.0, wake=False)   # no-op on a sleeping body
+        if s == 220:
+            w.set_velocity(ids[w][1], (0.0, 4.0), omega=1.0)                # wakes the pile
+
+    run(a, b, 300, "forces", between=between)
+    a.close(); b.close()
+
+
+def test_pile_falls_asleep_and_all_flags_match(libs):
+    a, b = both(libs)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+        w.create_fixture(g, b2hip.edge_shape((-10.0, 0.0), (10.0, 0.0)))
+        for i in range(5):
+            d = w.create_body(b2hip.DYNAMIC, (0.01 * i, 0.51 + 1.01 * i))
+            w.create_fixture(d, b2hip.box_shape(0.5, 0.5), density=1.0, friction=0.5)
+    run(a, b, 260, "sleep")
+    assert (a.body_states()["flags"][1:] & 4).sum() == 0, "the settled pile must be asleep"
+    a.close(); b.close()
+
+
+def test_bullet_through_thin_wall_with_ccd(libs):
+    a, b = both(libs, continuous=True, gravity=(0.0, 0.0))
+    for w in (a, b):
+        wall = w.create_body(b2hip.STATIC, (5.0, 0.0))
+        w.create_fixture(wall, b2hip.box_shape(0.05, 5.0))
+        for i in range(5):
+            d = w.create_body(b2hip.DYNAMIC, (0.0, -2.0 + i), velocity=(150.0 + 20.0 * i, 3.0 * i), bullet=(i % 2 == 0))
+            w.create_fixture(d, b2hip.circle_shape(0.1) if i % 2 else b2hip.box_shape(0.1, 0.1), density=1.0, restitution=0.3)
+    run(a, b, 60, "ccd")
+    assert (a.body_states()["px"][1:] < 5.0).all(), "nothing may tunnel through the wall with continuous physics on"
+    a.close(); b.close()
+
+
+def test_revolute_pendulum_chain(libs, monkeypatch):
+    """Several joints in one island, limit and motor rows: exact-order mode (islands with joints take the coloured path by
+    default, where joints are visited in id order instead of the reference's traversal order)."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 10.0))
+        prev = g
+        for i in range(4):
+            d = w.create_body(b2hip.DYNAMIC, (0.5 + i, 10.0))
+            w.create_fixture(d, b2hip.box_shape(0.5, 0.1), density=2.0)
+            w.create_revolute_joint(prev, d, anchor_a=(0.0, 0.0) if i == 0 else (0.5, 0.0), anchor_b=(-0.5, 0.0),
+                                    enable_limit=(i == 2), lower=-0.5, upper=0.5, enable_motor=(i == 0), motor_speed=1.0, max_motor_torque=50.0)
+            prev = d
+    run(a, b, 200, "pendulum")
+    a.close(); b.close()
