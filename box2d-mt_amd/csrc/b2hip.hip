@@ -2013,6 +2013,9 @@ int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
 	case 9: src = w->dbgVel.p; break;
 	case 10: src = w->dbgLi.p; elem = 4; break;
 	case 11: src = w->gridBar.p; elem = 4; break;
+	case 12: src = w->colorCount.p; elem = 4; break;
+	case 13: src = w->bodyColorMask.p; elem = 8; break;
+	case 14: src = w->deg.p; elem = 4; break;
 	default: return setError(B2HIP_ERR_INVALID, "bad array id");
 	}
 	HIP_TRY(hipMemcpy(out, (const char*)src + (size_t)first * elem, (size_t)count * elem, hipMemcpyDeviceToHost));
