@@ -83,11 +83,11 @@ __global__ __launch_bounds__(256) void k_color_begin(DW W)
 	const int n = S->c.nLContacts;
 	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
 	{
-		W.li_color[s] = -1;
+		if (W.li_color[s] != HUB_COLOR) W.li_color[s] = -1; // hub constraints are never coloured (k_color_check marked them)
 	}
 	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS)
 	{
-		W.colorCount[threadIdx.x] = 0;
+		if (threadIdx.x != HUB_COLOR) W.colorCount[threadIdx.x] = 0;
 		W.colorCursor[threadIdx.x] = 0;
 	}
 	// a full recolour forgets every stored colour (also those of non-touching contacts)
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_color_begin(DW W)
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
-		S->c.nUncolored = n;
+		S->c.nUncolored = n - W.colorCount[HUB_COLOR];
 		S->c.colorRounds = 0;
 		S->c.nColors = 0;
 	}
@@ -149,7 +149,18 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		int col = -1;
 		if (valid)
 		{
-			col = C.color[W.li_contacts[s]];
+			const int ci = W.li_contacts[s];
+			const int4 ids = C.ids[ci];
+			const bool hubA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC && W.deg[ids.z] > HUB_DEGREE;
+			const bool hubB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC && W.deg[ids.w] > HUB_DEGREE;
+			col = C.color[ci];
+			if (hubA || hubB)
+			{
+				// a hub constraint owns no colour (and reserves none from the next step on)
+				col = HUB_COLOR;
+				C.color[ci] = -1;
+			}
+			else if (col == HUB_COLOR) col = -1;
 			if (col < 0 || col >= MAX_COLORS)
 			{
 				++uncolored;
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 				const int u = atomicAdd(&S->c.nUncolList, 1);
 				if (u < COLOR_SMALL_MAX) W.uncolList[u] = s;
 			}
-			else if (col + 1 > maxColor)
+			else if (col != HUB_COLOR && col + 1 > maxColor)
 			{
 				maxColor = col + 1;
 			}
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 		if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 		if (!win) continue;
 		// this lane is the only winner on both bodies this round: plain read-modify-write is safe
-		uint64_t used = 0;
+		uint64_t used = 1ull << HUB_COLOR;
 		if (nsA) used |= W.bodyColorMask[ids.z];
 		if (nsB) used |= W.bodyColorMask[ids.w];
 		int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W)
 			if (nsA && __hip_atomic_load(&W.bodyClaim[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 			if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 			if (!win) continue;
-			uint64_t used = 0;
+			uint64_t used = 1ull << HUB_COLOR;
 			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
@@ -317,13 +328,16 @@ __global__ void k_color_scan(DW W)
 {
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
-		const int nc = W.st->c.nColors;
+		// all MAX_COLORS groups: the regular colours [0, nColors) first, the hub group (HUB_COLOR) last
+		// (exact-order mode uses one group per dependency level, possibly thousands)
+		const int nc = W.st->c.nColors > MAX_COLORS ? W.st->c.nColors : MAX_COLORS;
 		int run = 0;
 		for (int c = 0; c <= nc; ++c)
 		{
 			W.colorStart[c] = run;
 			if (c < nc) run += W.colorCount[c];
 		}
+		W.st->c.nHubRows = W.colorCount[HUB_COLOR];
 	}
 }
 
@@ -393,6 +407,7 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
 			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
 			W.li_sorted[p] = s;
+			if (color == HUB_COLOR) W.hubRowOf[ci] = p;
 			W.li_ref[p] = make_int4(ci, nsA ? ids.z : -(ids.z + 1), nsB ? ids.w : -(ids.w + 1), W.parent[nsA ? ids.z : ids.w]);
 		}
 	}
@@ -417,6 +432,163 @@ __device__ __forceinline__ LargeRef largeRef(const DW& W, const ContactArrays& C
 	r.bodyB = r.nsB ? q.z : -(q.z + 1);
 	r.root = q.w;
 	return r;
+}
+
+// ---- hub bodies ---------------------------------------------------------------------------------------
+// The constraints of a body with a very large contact degree are inherently serial in a Gauss-Seidel sweep (each one
+// reads the velocity the previous one wrote). They are visited in contact-index order by ONE wave after the coloured
+// constraints of every sweep: the lanes fetch 64 rows and 64 partner bodies in parallel, then the hub-dependent solves
+// run one lane at a time with the hub's state handed on through wave shuffles.
+__global__ __launch_bounds__(256) void k_hub_flag(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		int f = 0;
+		if ((C.flags[i] & (CF_ENABLED | CF_TOUCHING | CF_SENSOR | CF_DESTROY)) == (CF_ENABLED | CF_TOUCHING))
+		{
+			const int4 ids = C.ids[i];
+			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			const int b = nsA ? ids.z : ids.w;
+			if ((nsA || nsB) && W.rootIsland[W.parent[b]] == ROOT_LARGE)
+			{
+				f = ((nsA && W.deg[ids.z] > HUB_DEGREE) || (nsB && W.deg[ids.w] > HUB_DEGREE)) ? 1 : 0;
+			}
+		}
+		W.keepFlag[i] = f;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_hub_fill(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		if (W.keepFlag[i]) W.hubList[W.keepScan[i]] = W.hubRowOf[i];
+	}
+}
+
+// mode 0 warm start, 1 velocity, 2 position. One wave; rows in hubList order.
+// Per chunk of 64 rows: every lane fetches its constraint and its non-hub body in parallel; then the lanes take turns.
+// The hub's row (velocity or position) travels from turn to turn in registers (wave shuffle) as long as consecutive
+// constraints sit on the same hub; a partner body that occurs twice in a chunk is re-read at its turn.
+__global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
+{
+	DState* S = W.st;
+	if (mode == 2 && S->c.allLargeDone) return;
+	const ContactArrays& C = W.ca[S->cur];
+	const int n = S->c.nHubRows;
+	const int lane = threadIdx.x;
+	const float4* rows = mode == 2 ? W.b_pos : W.b_vel;
+	float4* rowsOut = mode == 2 ? W.b_pos : W.b_vel;
+	int carryBody = -1;
+	float4 carry = make_float4(0, 0, 0, 0);
+	for (int base = 0; base < n; base += 64)
+	{
+		const int k = base + lane;
+		const bool have = k < n;
+		LargeRef r;
+		r.ci = 0; r.bodyA = 0; r.bodyB = 0; r.root = 0; r.nsA = false; r.nsB = false;
+		ContactConstraint cc;
+		memset(&cc, 0, sizeof(cc));
+		int row = 0;
+		bool active = have;
+		int hubBody = -1, otherBody = -1;
+		bool hubIsA = true, otherDynamic = false;
+		float4 other = make_float4(0, 0, 0, 0);
+		if (have)
+		{
+			row = W.hubList[k];
+			r = largeRef(W, C, row);
+			hubIsA = r.nsA && W.deg[r.bodyA] > HUB_DEGREE;
+			hubBody = hubIsA ? r.bodyA : r.bodyB;
+			otherBody = hubIsA ? r.bodyB : r.bodyA;
+			otherDynamic = hubIsA ? r.nsB : r.nsA;
+			if (mode == 2)
+			{
+				active = W.rootDone[r.root] == 0;
+				lcLoad(W, row, cc, LC_MASS_FIRST, LC_MASS_FIRST + 4);
+				lcLoad(W, row, cc, LC_POS_FIRST, LC_WORDS);
+				other = rows[otherBody]; // static partners have a position too
+			}
+			else
+			{
+				lcLoad(W, row, cc, 0, LC_VEL_WORDS);
+				if (otherDynamic) other = rows[otherBody];
+			}
+		}
+		// does my partner body occur earlier in this chunk (as partner or as hub)? then my copy may be stale at my turn
+		bool reload = have && otherBody == carryBody; // its memory row is stale while it is carried
+		for (int t = 0; t < 64; ++t)
+		{
+			const int ob = __shfl(otherBody, t), hb = __shfl(hubBody, t);
+			if (t < lane && have && (ob == otherBody || hb == otherBody)) reload = true;
+		}
+		float minSep = 0.0f;
+		const int cnt = n - base < 64 ? n - base : 64;
+		for (int t = 0; t < cnt; ++t)
+		{
+			float4 hubOut = carry;
+			int hubOutBody = carryBody;
+			if (lane == t && active)
+			{
+				int cb = carryBody;
+				if (cb >= 0 && cb == otherBody)
+				{
+					// hub-to-hub contact: the partner is the body being carried; put it back first
+					rowsOut[cb] = carry;
+					cb = -1;
+				}
+				float4 hubRow = cb == hubBody ? carry : rows[hubBody];
+				if (reload && (mode == 2 || otherDynamic)) other = rows[otherBody];
+				if (mode == 2)
+				{
+					BodyPos pH, pO;
+					pH.c = v2(hubRow.x, hubRow.y); pH.a = hubRow.z;
+					pO.c = v2(other.x, other.y); pO.a = other.z;
+					if (hubIsA) b2dSolvePosition(&cc, &pH, &pO, B2D_BAUMGARTE, &minSep);
+					else b2dSolvePosition(&cc, &pO, &pH, B2D_BAUMGARTE, &minSep);
+					hubRow = make_float4(pH.c.x, pH.c.y, pH.a, hubRow.w);
+					if (otherDynamic) rowsOut[otherBody] = make_float4(pO.c.x, pO.c.y, pO.a, other.w);
+				}
+				else
+				{
+					BodyVel vH, vO;
+					vH.v = v2(hubRow.x, hubRow.y); vH.w = hubRow.z;
+					vO.v = v2(other.x, other.y); vO.w = other.z;
+					if (!otherDynamic) { vO.v = v2(0, 0); vO.w = 0; }
+					if (mode == 0)
+					{
+						if (hubIsA) b2dWarmStart(&cc, &vH, &vO); else b2dWarmStart(&cc, &vO, &vH);
+					}
+					else
+					{
+						if (hubIsA) b2dSolveVelocity(&cc, &vH, &vO); else b2dSolveVelocity(&cc, &vO, &vH);
+					}
+					hubRow = make_float4(vH.v.x, vH.v.y, vH.w, 0.0f);
+					if (otherDynamic) rowsOut[otherBody] = make_float4(vO.v.x, vO.v.y, vO.w, 0.0f);
+				}
+				// a different hub was being carried: its row goes back to memory now
+				if (cb >= 0 && cb != hubBody) rowsOut[cb] = carry;
+				hubOut = hubRow;
+				hubOutBody = hubBody;
+			}
+			// hand the hub row to the next turn; order this lane's stores before the next lane's loads
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			carry.x = __shfl(hubOut.x, t);
+			carry.y = __shfl(hubOut.y, t);
+			carry.z = __shfl(hubOut.z, t);
+			carry.w = __shfl(hubOut.w, t);
+			carryBody = __shfl(hubOutBody, t);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+		if (mode == 1 && have) lcStore(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
+		if (mode == 2) waveAtomicMaxU32(W.rootPen, r.root, floatBits(0.0f - minSep), have && active);
+	}
+	if (lane == 0 && carryBody >= 0) rowsOut[carryBody] = carry;
 }
 
 __global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)

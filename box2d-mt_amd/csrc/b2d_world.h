@@ -52,8 +52,10 @@
 #define TINY_ISLAND_MAX_W 128    // if every small island of the step is <= this, chunks are 256 lanes (lighter barriers)
 #define TINY_CHUNK_LANES 256
 #define MAX_COLORS 64
-#define HUB_DEGREE 30            // a body with more solid contacts than this cannot be coloured safely with 64 colours (two such
-                                 // bodies in contact may need deg + deg - 1): such steps use the exact-order (level) path
+#define HUB_DEGREE 30            // a body with more solid contacts than this is a "hub" (the Tumbler's container): its constraints
+                                 // are not coloured (two such bodies in contact could need deg + deg - 1 > 64 colours) but solved
+                                 // one after the other by k_large_hub after the coloured constraints of every sweep
+#define HUB_COLOR (MAX_COLORS - 1) // row group of the hub constraints
 #define COLOR_SMALL_MAX 4096     // uncoloured constraints up to this many are coloured by one workgroup without a host round trip
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
 
@@ -103,6 +105,7 @@ struct Counters
 	int nToiMoved;       // proxies re-inserted by the TOI chains
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
+	int nHubRows;        // hub constraints of this step
 	int chunkLanes;      // workgroup size of the small-island solver chosen for this step (TINY_CHUNK_LANES or SMALL_CHUNK_LANES)
 };
 
@@ -110,7 +113,7 @@ struct DState
 {
 	Counters c;
 	int cur;             // which ContactArrays is live
-	int pad[7];
+	int pad[6];
 };
 
 struct StepParams
@@ -203,6 +206,8 @@ struct DW
 	int* colorStart;     // [MAX_COLORS + 1]
 	int* colorCursor;
 	int* uncolList;      // large contact slots that have no colour yet (at most COLOR_SMALL_MAX listed)
+	int* hubRowOf;       // per contact: its constraint row if it is a hub constraint this step
+	int* hubList;        // hub constraint rows in contact-index order (the deterministic visiting order of k_large_hub)
 	int* li_sorted;      // large contact slots grouped by colour
 	int4* li_ref;        // per colour-sorted row: contact index, bodyA, bodyB (static bodies as -(id+1)), island root
 	uint32_t* bodyClaim;

@@ -173,7 +173,7 @@ struct b2hip_world
 	DevArray<uint32_t> bodyClaim, rootPen, rootSleepMin;
 	DevArray<uint64_t> bodyColorMask, bodyActive;
 	DevArray<float4> b_posv;
-	DevArray<int> uncolList;
+	DevArray<int> uncolList, hubRowOf, hubList;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
 	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies;
@@ -538,7 +538,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(uncolList, COLOR_SMALL_MAX); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(uncolList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -603,7 +603,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.uncolList = w->uncolList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.uncolList = w->uncolList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
@@ -929,7 +929,7 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 	const StepParams& sp = w->sp;
 	w->ktUsed = 0;
 	w->ktKind = 0;
-	const int forceLarge = (w->forceLarge == 0 && w->hubExact) ? 2 : w->forceLarge;
+	const int forceLarge = w->forceLarge;
 	int rc = runSegment(w, w->segIslands, 2 + 16ull * (uint64_t)forceLarge, [w, forceLarge]() -> int
 	{
 		DW& d = w->dw;
@@ -966,18 +966,8 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 
 	HIP_TRY(hipEventRecord(w->ev[4], w->stream));
 	const bool exactLarge = forceLarge == 2;
-	if (w->forceLarge == 0)
-	{
-		const bool hub = c.maxDegree > HUB_DEGREE;
-		if (hub && !w->hubExact)
-		{
-			// found out too late for this island build: classify again with every island on the exact-order path
-			w->hubExact = true;
-			*redoExact = true;
-			return 0;
-		}
-		w->hubExact = hub;
-	}
+	const bool hasHubs = !exactLarge && c.maxDegree > HUB_DEGREE;
+	(void)redoExact;
 	if (c.nSIslands > 0)
 	{
 		LAUNCH(w, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
@@ -1018,7 +1008,7 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 		nColors = exactLarge ? nColors : c.nColors;
 		const bool hasJoints = d.nJoints > 0;
 		const int persistWG = (nLContacts + PERSIST_LANES - 1) / PERSIST_LANES;
-		const bool usePersistent = !exactLarge && !hasJoints && !w->debugTrace && !w->kernelTimingLaunches &&
+		const bool usePersistent = !exactLarge && !hasJoints && !hasHubs && !w->debugTrace && !w->kernelTimingLaunches &&
 			w->persistMaxWG > 0 && persistWG <= w->persistMaxWG;
 		bool colorsOnDevice = false;
 		if (!exactLarge && (c.needRecolor || c.nUncolored > 0))
@@ -1039,7 +1029,7 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 			if (c.needRecolor)
 			{
 				LAUNCH(w, k_color_begin, gridFor(d.capContacts), 256, d);
-				uncolored = nLContacts;
+				uncolored = nLContacts; // upper bound (hub constraints excluded on the device); refreshed by the read-back below
 			}
 			int batch = c.needRecolor ? 8 : 2;
 			while (uncolored > 0)
@@ -1060,6 +1050,14 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 		}
 		LAUNCH(w, k_color_scan, 1, 1, d);
 		LAUNCH(w, k_color_fill, gC, 256, d);
+		if (hasHubs)
+		{
+			// the hub constraints in contact-index order (deterministic whatever the atomics of k_color_fill did)
+			LAUNCH(w, k_hub_flag, gridFor(d.capContacts), 256, d);
+			deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+			LAUNCH(w, k_hub_fill, gridFor(d.capContacts), 256, d);
+			w->hubSteps += 1;
+		}
 		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
@@ -1094,6 +1092,7 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 		if (sp.warmStarting)
 		{
 			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
+			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 0);
 		}
 		TRACE("warmstart");
 		if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 0);
@@ -1107,6 +1106,7 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 				if (w->debugTrace) TRACE(("vel" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
+			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 1);
 		}
 		LAUNCH(w, k_large_store_impulses, gC, 256, d);
 		TRACE("store_impulses");
@@ -1120,6 +1120,7 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 				LAUNCH(w, k_large_position, gK, 256, d, col);
 				if (w->debugTrace) TRACE(("pos" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
+			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 2);
 			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
 			LAUNCH(w, k_large_pos_end, 1, 256, d);
 		}

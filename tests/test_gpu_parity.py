@@ -339,3 +339,28 @@ def test_persistent_solver_matches_launch_per_colour(amd, default_mode):
             first_bad = next((i for i, (x, y) in enumerate(zip(a[0], b[0])) if x != y), None)
             assert first_bad is None, "dataflow solver and %s diverge at step %s" % (var, first_bad)
             assert a[1] == b[1]
+
+
+def test_hub_body_path_runs_deterministically(amd, default_mode):
+    """A body with hundreds of contacts (the Tumbler's container over 3 600 boxes) cannot be edge-coloured with 64 colours:
+    its constraints take the sequential hub lane (k_large_hub) after the coloured ones. The step must stay deterministic
+    (the hub constraints are visited in contact-index order), finite and inside the container."""
+    def run():
+        w = amd.world(bh.TUMBLER, 60, 0)
+        trace = []
+        for s in range(160):
+            w.step(1)
+            if s % 20 == 19:
+                trace.append((bh.fnv1a64(w.bodies()), w.contact_count))
+        b = w.bodies()
+        w.close()
+        return trace, b
+    t1, b1 = run()
+    t2, b2 = run()
+    assert t1 == t2, "hub path is not run-to-run deterministic"
+    assert np.isfinite(b1).all()
+    # boxes stay inside the rotating container: within its circumscribed circle around the joint anchor
+    centre = b1[1, :2]
+    r = np.linalg.norm(b1[2:, :2] - centre, axis=1)
+    half = np.abs(b1[2:, :2] - centre).max()
+    assert r.max() < 1.5 * half + 1.0 and half < 40.0
