@@ -330,6 +330,11 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		}
 	};
 
+	// phase timers (100 MHz ticks, accumulated by lane 0; written to DW::hubList[0..15], which is idle during the TOI phase)
+	__shared__ unsigned long long s_t[12];
+	unsigned long long tPrev = wall_clock64();
+	if (tid < 12) s_t[tid] = 0;
+#define TOI_T(k) do { if (tid == 0) { const unsigned long long now = wall_clock64(); s_t[k] += now - tPrev; tPrev = now; } } while (0)
 	for (;;)
 	{
 		// ---- FindMinToiContact: lexicographic min of (alpha, proxyLow, proxyHigh) over the pending list ----
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			break;
 		}
 
+		TOI_T(0);
 		// ---- StepSolveTOI (b2World.cpp:851-1024) ------------------------------------------------------------
 		const int4 minIds = C.ids[minIdx];
 		const int seedA = minIds.z, seedB = minIds.w;
@@ -445,6 +451,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		if (solid)
 		{
 
+		TOI_T(1);
 		// ---- gather the candidate contacts of the two seeds (dynamic seeds only) -------------------------------
 		for (int side = 0; side < 2; ++side)
 		{
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		}
 		__syncthreads();
 
+		TOI_T(2);
 		// ---- tentative update of every candidate with both bodies at the time of impact ------------------------
 		ToiUpdate upd;
 		Sweep otherAdv;
@@ -522,6 +530,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		}
 		__syncthreads();
 
+		TOI_T(3);
 		// ---- the order-defining walk (b2World.cpp:899-985) -------------------------------------------------------
 		if (tid == 0)
 		{
@@ -583,6 +592,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		}
 		__syncthreads();
 
+		TOI_T(4);
 		// ---- b2Island::SolveTOI (b2Island.cpp:398-530): one constraint per lane, dependency levels -------------
 		const int nB = s_nBodies, nK = s_nContacts; // (shadows nothing: the outer nB is declared after this block)
 		const float h = (1.0f - minAlpha) * sp.dt;
@@ -729,6 +739,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		}
 		__syncthreads();
 
+		TOI_T(5);
 		// ---- b2Body::SynchronizeFixtures of the island's dynamic bodies (b2World.cpp:1000-1011) -----------------
 		if (tid < nB)
 		{
@@ -757,6 +768,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		}
 		__syncthreads();
 
+		TOI_T(6);
 		// ---- FindNewContacts for the moved proxies (b2World.cpp:1013-1023) through the hash grid -------------------------
 		const int nMoves = s_nMoves < TOI_MOVES_MAX ? s_nMoves : TOI_MOVES_MAX;
 		if (tid == 0)
@@ -890,6 +902,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 
 		} // solid
 		const int nB = solid ? s_nBodies : 0;
+		TOI_T(7);
 		// ---- invalidate the impacts of the displaced bodies (b2World.cpp:1005-1010) ---------------------------------
 		const int nTail = s_nC - nC0;
 		for (int bi = 0; bi < nB; ++bi)
@@ -911,6 +924,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			}
 		}
 		__syncthreads();
+		TOI_T(8);
 		// ---- contacts that the next FindMinToiContact would have to (re)compute ----------------------------------------
 		const int nWoken = s_nWoken < TOI_WOKEN_MAX ? s_nWoken : TOI_WOKEN_MAX;
 		for (int bi = 0; bi < nB + nWoken; ++bi)
@@ -1033,7 +1047,10 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		__syncthreads();
 		if (tid == 0 && s_nL > W.capContacts) s_nL = W.capContacts;
 		__syncthreads();
+		TOI_T(9);
 	}
+	if (tid < 12) W.hubList[tid] = (int)s_t[tid];
+#undef TOI_T
 
 	if (tid == 0)
 	{

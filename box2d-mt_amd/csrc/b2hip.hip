@@ -206,7 +206,6 @@ struct b2hip_world
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
 	int graphCaptures;
 	GraphSeg segCollide, segIslands, segPairs;
-	bool hubExact;               // the last step had a body of very large contact degree: solve on the exact-order path
 	int hubSteps;
 	int toiFallbacks;                                  // steps whose TOI chains had to be redone serially
 	bool debugTrace;                                   // B2HIP_TRACE=1: hash the body state after every solver stage
@@ -903,27 +902,9 @@ static void tracePoint(b2hip_world* w, const char* label)
 }
 #define TRACE(label) tracePoint(w, label)
 
-static int phaseSolveOnce(b2hip_world* w, bool* redoExact);
-
-// b2World::Solve. A body with a very large contact degree (the Tumbler's container) cannot be edge-coloured with 64
-// colours: such steps are solved on the exact-order (dependency level) path, which has no degree limit and reproduces the
-// reference bit for bit. The decision is sticky from step to step so the island build is not repeated every step.
+// b2World::Solve (b2World.cpp:1166-1431): island build, census read-back, then the solver tier of each island.
 static int phaseSolve(b2hip_world* w)
 {
-	bool redo = false;
-	int rc = phaseSolveOnce(w, &redo);
-	if (rc) return rc;
-	if (redo)
-	{
-		w->hubSteps += 1;
-		rc = phaseSolveOnce(w, &redo);
-	}
-	return rc;
-}
-
-static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
-{
-	*redoExact = false;
 	w->trace.clear();
 	DW& d = w->dw;
 	const StepParams& sp = w->sp;
@@ -967,7 +948,6 @@ static int phaseSolveOnce(b2hip_world* w, bool* redoExact)
 	HIP_TRY(hipEventRecord(w->ev[4], w->stream));
 	const bool exactLarge = forceLarge == 2;
 	const bool hasHubs = !exactLarge && c.maxDegree > HUB_DEGREE;
-	(void)redoExact;
 	if (c.nSIslands > 0)
 	{
 		LAUNCH(w, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
@@ -1309,7 +1289,6 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverBarriers = getenv("B2HIP_SOLVER_BARRIERS") != nullptr;       // persistent kernel with a grid barrier per colour instead of body-level dataflow
 	w->persistSteps = 0;
 	w->colorSmallPending = false;
-	w->hubExact = false;
 	w->hubSteps = 0;
 	w->useGraphs = getenv("B2HIP_GRAPHS") != nullptr; // opt-in: measured no gain on MI355X (the step is not host-bound), see DESIGN.md
 	w->graphCaptures = 0;
@@ -2017,6 +1996,7 @@ int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
 	case 12: src = w->colorCount.p; elem = 4; break;
 	case 13: src = w->bodyColorMask.p; elem = 8; break;
 	case 14: src = w->deg.p; elem = 4; break;
+	case 15: src = w->hubList.p; elem = 4; break;
 	default: return setError(B2HIP_ERR_INVALID, "bad array id");
 	}
 	HIP_TRY(hipMemcpy(out, (const char*)src + (size_t)first * elem, (size_t)count * elem, hipMemcpyDeviceToHost));
