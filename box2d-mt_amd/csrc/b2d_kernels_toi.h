@@ -666,13 +666,18 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 				mB4.x, mB4.y, v2(mB4.z, mB4.w), radiusB,
 				pA, vA, pB, vB, false, 1.0f);
 		};
+		// The mini island has at most 64 bodies and 32 constraints: everything below runs in the first wave, with wave-level
+		// ordering instead of workgroup barriers (the LDS executes one wave's instructions in order); the other waves wait.
+#define TOI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+		if (tid < 64)
+		{
 		if (ci >= 0) initConstraint();
-		__syncthreads();
+		TOI_WAVE_SYNC();
 		// SolveTOIPositionConstraints (b2ContactSolver.cpp:755-843): only the two TOI bodies (island slots 0, 1) move
 		for (int it = 0; it < 20; ++it)
 		{
 			if (tid == 0) s_pen = 0;
-			__syncthreads();
+			TOI_WAVE_SYNC();
 			for (int L = 1; L <= maxLevel; ++L)
 			{
 				if (ci >= 0 && level == L)
@@ -690,10 +695,10 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 					s_pos[lb] = make_float4(pB.c.x, pB.c.y, pB.a, 0.0f);
 					atomicMax(&s_pen, floatBits(0.0f - minSep));
 				}
-				__syncthreads();
+				TOI_WAVE_SYNC();
 			}
 			const float minSeparation = -__uint_as_float(s_pen);
-			__syncthreads();
+			TOI_WAVE_SYNC();
 			if (minSeparation >= -1.5f * B2D_LINEAR_SLOP) break;
 		}
 		// leap of faith to the new safe state (b2Island.cpp:466-470)
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			W.b_pos0[b] = make_float4(p.x, p.y, p.z, minAlpha);
 		}
 		if (ci >= 0) initConstraint();
-		__syncthreads();
+		TOI_WAVE_SYNC();
 		for (int it = 0; it < sp.velIters; ++it)
 		{
 			for (int L = 1; L <= maxLevel; ++L)
@@ -719,9 +724,12 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 					s_vel[la] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
 					s_vel[lb] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
 				}
-				__syncthreads();
+				TOI_WAVE_SYNC();
 			}
 		}
+		} // first wave
+#undef TOI_WAVE_SYNC
+		__syncthreads();
 		// integrate positions, sync bodies (b2Island.cpp:483-527); TOI impulses are not stored
 		if (tid < nB)
 		{
