@@ -21,6 +21,8 @@
 #define CHAIN_LANES 64
 #define CHAIN_CAND_MAX 64
 #define CHAIN_EVENTS_MAX 4096
+#define CHAIN_ADJ_MAX 32        // contacts of one chain body (more: serial loop)
+#define TOI_GROUPS_MAX 262144   // chains per step (more: serial loop)
 #define TOI_MOVED_MAX 4096
 
 // unsafe bits
@@ -48,10 +50,37 @@ __global__ __launch_bounds__(256) void k_toi_groups_begin(DW W)
 			atomicOr(&S->c.toiUnsafe, TOI_UNSAFE_PARTNER);
 			continue;
 		}
-		if (atomicCAS(&W.b_toiGroup[D], 0, 1) == 0)
+		if (atomicCAS(&W.b_toiGroup[D], 0, -1) == 0)
 		{
 			const int g = atomicAdd(&S->c.nToiGroups, 1);
-			W.toiGroups[g] = D;
+			if (g < TOI_GROUPS_MAX)
+			{
+				W.toiGroups[g] = D;
+				W.toiGroupCount[g] = 0;
+				atomicExch(&W.b_toiGroup[D], g + 1);
+			}
+			else atomicOr(&S->c.toiUnsafe, TOI_UNSAFE_CAPACITY);
+		}
+	}
+}
+
+// The contacts of every chain body, gathered in one pass over the contact array (b_toiGroup = chain index + 1).
+__global__ __launch_bounds__(256) void k_toi_group_contacts(DW W)
+{
+	DState* S = W.st;
+	if (S->c.toiUnsafe) return;
+	const int nC = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nC; i += gridDim.x * blockDim.x)
+	{
+		const int4 ids = C.ids[i];
+		for (int side = 0; side < 2; ++side)
+		{
+			const int g = W.b_toiGroup[side ? ids.w : ids.z] - 1;
+			if (g < 0) continue;
+			const int k = atomicAdd(&W.toiGroupCount[g], 1);
+			if (k < CHAIN_ADJ_MAX) W.toiGroupList[(size_t)g * CHAIN_ADJ_MAX + k] = i;
+			else atomicOr(&S->c.toiUnsafe, TOI_UNSAFE_CAPACITY);
 		}
 	}
 }
@@ -115,15 +144,16 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 }
 
 // The event chain of one dynamic body: b2World::SolveTOI restricted to the contacts of D (all with static partners).
-__global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
+// haveGrid = 0: the hash grid was not rebuilt for this phase, so a proxy leaving its fat AABB sends the phase to the serial loop.
+__global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp, int haveGrid)
 {
 	DState* S = W.st;
-	if ((int)blockIdx.x >= S->c.nToiGroups || (S->c.toiUnsafe & TOI_UNSAFE_PARTNER)) return;
+	if ((int)blockIdx.x >= S->c.nToiGroups || (S->c.toiUnsafe & (TOI_UNSAFE_PARTNER | TOI_UNSAFE_CAPACITY))) return;
 	const ContactArrays& C = W.ca[S->cur];
 	const int lane = threadIdx.x;
 	const int D = W.toiGroups[blockIdx.x];
-	const int e0 = W.adjStart[D], e1 = W.adjStart[D + 1];
-	const int nAdj = e1 - e0;
+	const int* adjL = W.toiGroupList + (size_t)blockIdx.x * CHAIN_ADJ_MAX;
+	const int nAdj = W.toiGroupCount[blockIdx.x] < CHAIN_ADJ_MAX ? W.toiGroupCount[blockIdx.x] : CHAIN_ADJ_MAX;
 	const float4 massD = W.b_mass[D];
 
 	__shared__ int s_cand[CHAIN_CAND_MAX], s_sorted[CHAIN_CAND_MAX], s_info[CHAIN_CAND_MAX];
@@ -169,7 +199,7 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
 		int bestI = -1;
 		for (int e = lane; e < nAdj; e += CHAIN_LANES)
 		{
-			const int c = W.adj[e0 + e];
+			const int c = adjL[e];
 			const uint32_t flags = ldFlags(&C.flags[c]);
 			if ((flags & CF_TOI) == 0) continue;
 			const int4 ids = C.ids[c];
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
 		// ---- D's other contacts with non-dynamic partners, newest first --------------------------------------------------
 		for (int e = lane; e < nAdj; e += CHAIN_LANES)
 		{
-			const int c = W.adj[e0 + e];
+			const int c = adjL[e];
 			if (c == minIdx) continue;
 			const int4 ids = C.ids[c];
 			const int other = ids.z == D ? ids.w : ids.z;
@@ -484,7 +514,11 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
 		}
 		__syncthreads();
 		const int nMoved = s_nMoved;
-		if (nMoved > 0)
+		if (nMoved > 0 && !haveGrid)
+		{
+			if (lane == 0) s_unsafe |= TOI_UNSAFE_PAIR;
+		}
+		else if (nMoved > 0)
 		{
 			// against the fat AABBs as they were before the chains started (other chains move theirs concurrently; the grid was
 			// built from exactly those); moved-vs-moved across chains is checked afterwards by k_toi_chains_end
@@ -501,7 +535,7 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
 					const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
 					const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
 					bool exists = false;
-					for (int e = e0; e < e1 && !exists; ++e) exists = C.key[W.adj[e]] == key;
+					for (int e = 0; e < nAdj && !exists; ++e) exists = C.key[adjL[e]] == key;
 					if (exists) return;
 					if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
 					if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
@@ -514,12 +548,12 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
 		if (lane == 0) s_events += 1;
 
 		// ---- invalidate + recompute the impacts of D's contacts ------------------------------------------------------------------
-		for (int e = lane; e < nAdj; e += CHAIN_LANES) atomicAnd(&C.flags[W.adj[e0 + e]], ~CF_TOI);
+		for (int e = lane; e < nAdj; e += CHAIN_LANES) atomicAnd(&C.flags[adjL[e]], ~CF_TOI);
 		__syncthreads();
 		if (s_unsafe) break;
 		for (int e = lane; e < nAdj; e += CHAIN_LANES)
 		{
-			const int c = W.adj[e0 + e];
+			const int c = adjL[e];
 			const uint32_t flags = ldFlags(&C.flags[c]);
 			const int4 ids = C.ids[c];
 			if (!toiEligible(W, flags, ids)) continue;
@@ -541,7 +575,6 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp)
 	__syncthreads();
 	if (lane == 0)
 	{
-		W.b_toiGroup[D] = 0;
 		if (s_events) atomicAdd(&S->c.nToiEvents, s_events);
 		if (s_calls) atomicAdd(&S->c.nToiCalls, s_calls);
 		if (s_unsafe) atomicOr(&S->c.toiUnsafe, s_unsafe);
@@ -553,8 +586,8 @@ __global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
 {
 	DState* S = W.st;
 	const int n = S->c.nToiMoved < TOI_MOVED_MAX ? S->c.nToiMoved : TOI_MOVED_MAX;
-	if (n < 2 || S->c.toiUnsafe) return;
-	for (int i = threadIdx.x; i < n; i += blockDim.x)
+	const int nG = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
+	for (int i = threadIdx.x; i < n && n >= 2 && !S->c.toiUnsafe; i += blockDim.x)
 	{
 		const int p = W.toiMoved[i];
 		const AABB fp = loadAabb(W.p_fat, p);
@@ -568,12 +601,18 @@ __global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
 			const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
 			const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
 			const ContactArrays& C = W.ca[S->cur];
-			const int b = W.p_body[p];
+			const int g = W.b_toiGroup[W.p_body[p]] - 1;
 			bool exists = false;
-			for (int e = W.adjStart[b]; e < W.adjStart[b + 1] && !exists; ++e) exists = C.key[W.adj[e]] == key;
+			if (g >= 0)
+			{
+				const int cnt = W.toiGroupCount[g] < CHAIN_ADJ_MAX ? W.toiGroupCount[g] : CHAIN_ADJ_MAX;
+				for (int e = 0; e < cnt && !exists; ++e) exists = C.key[W.toiGroupList[(size_t)g * CHAIN_ADJ_MAX + e]] == key;
+			}
 			if (!exists) atomicOr(&S->c.toiUnsafe, TOI_UNSAFE_MOVED);
 		}
 	}
+	__syncthreads();
+	for (int g = threadIdx.x; g < nG; g += blockDim.x) W.b_toiGroup[W.toiGroups[g]] = 0;
 }
 
 #endif

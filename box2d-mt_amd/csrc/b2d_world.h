@@ -237,8 +237,10 @@ struct DW
 	int* toiList;        // contact indices whose cached TOI is < 1
 	int* toiPos2c;       // slot of the reference's TOI partition -> contact index (inverse of ContactArrays::mgr)
 	int* toiDestroyList; // TOI candidates marked for destruction by collide
-	int* b_toiGroup;     // per body: 1 while it owns a TOI chain
+	int* b_toiGroup;     // per body: chain index + 1 while it owns a TOI chain
 	int* toiGroups;      // dynamic bodies with a pending impact
+	int* toiGroupCount;  // per chain: contacts gathered for it
+	int* toiGroupList;   // per chain: CHAIN_ADJ_MAX contact indices
 	int* toiMoved;       // proxies re-inserted by the chains
 	float4* snapBody;    // 5 rows per body: pos, pos0, vel, xf, flags (state before the chains)
 	float4* snapFat;     // fat AABBs before the chains

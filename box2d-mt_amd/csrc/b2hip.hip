@@ -151,7 +151,7 @@ struct b2hip_world
 	DevArray<int> p_body, p_shape, p_key, p_filter1;
 	DevArray<uint32_t> p_filter0;
 	DevArray<float2> p_mat;
-	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiMoved;
+	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiGroupCount, toiGroupList, toiMoved;
 	DevArray<float4> snapBody, snapFat;
 	DevArray<ShapeRec> d_shapes;
 	DevArray<int4> c_ids[2];
@@ -202,6 +202,7 @@ struct b2hip_world
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
+	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
 	int graphCaptures;
@@ -555,7 +556,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(scanTmp4, maxScanN / SCAN_TILE + 4);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
-	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiMoved, TOI_MOVED_MAX); ENS(snapBody, 5 * nb); ENS(snapFat, np);
+	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_MAX); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
 	ENS(gridBar, 16);
@@ -612,7 +613,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.stateOut = w->stateOut.p;
 	d.b_proxyHead = w->b_proxyHead.p; d.p_next = w->p_next.p; d.toiList = w->toiList.p;
 	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
-	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiMoved = w->toiMoved.p;
+	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p;
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	return 0;
 }
@@ -1137,9 +1138,31 @@ static int phaseSyncFixtures(b2hip_world* w)
 	return 0;
 }
 
+// The serial event loop walks contacts by body (CSR) and searches new pairs through the hash grid.
+static int toiBuildIndexes(b2hip_world* w, bool csr)
+{
+	DW& d = w->dw;
+	if (csr)
+	{
+		LAUNCH(w, k_toi_adj_clear, gridFor(d.nBodies + 1), 256, d);
+		LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
+		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p + 4, d.nBodies + 1);
+		LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
+	}
+	// make the grid reflect every fat AABB as of now (the end-of-step pair update skips the rebuild when nothing
+	// moved, and TOI moves of earlier steps never enter the move buffer)
+	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
+	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
+	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
+	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 1);
+	return 0;
+}
+
 static int toiSerial(b2hip_world* w)
 {
 	DW& d = w->dw;
+	int rc = toiBuildIndexes(w, true);
+	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
 	LAUNCH(w, k_toi_loop, 1, TOI_LANES, d, w->sp);
 	LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
@@ -1172,25 +1195,24 @@ static int phaseToi(b2hip_world* w)
 	w->last.nToiEvents = 0;
 	if (w->h_dstate->c.nToiList == 0) return 0;
 	if (w->h_dstate->c.nToiList > d.capContacts) return setError(B2HIP_ERR_CAPACITY, "TOI list overflow");
-	LAUNCH(w, k_toi_adj_clear, gridFor(d.nBodies + 1), 256, d);
-	LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
-	deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p + 4, d.nBodies + 1);
-	LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
-	// the events search new pairs through the hash grid: make it reflect every fat AABB as of now (the end-of-step
-	// pair update skips the rebuild when nothing moved, and TOI moves of earlier steps never enter the move buffer)
-	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
-	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
-	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
-	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 1);
 	w->toiRan = true;
 	if (w->h_dstate->c.toiUnsafe == 0 && !w->toiSerialOnly)
 	{
 		// every pending impact pairs a dynamic body with a static one: one wave per dynamic body, verified afterwards
 		// (b2hip_step_end falls back to the serial loop from the snapshot if a chain met a case that is order dependent)
-		const int groups = std::min(w->h_dstate->c.nToiList, d.nBodies);
+		// The hash grid is only needed when a chain moves a proxy out of its fat AABB: it is rebuilt while that has
+		// happened recently, otherwise such a move sends the phase to the serial loop (which rebuilds it).
+		const int groups = std::min(std::min(w->h_dstate->c.nToiList, d.nBodies), (int)TOI_GROUPS_MAX);
+		const int haveGrid = w->toiGridSticky > 0 ? 1 : 0;
 		LAUNCH(w, k_toi_groups_begin, gridFor(w->h_dstate->c.nToiList), 256, d);
+		LAUNCH(w, k_toi_group_contacts, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
-		LAUNCH(w, k_toi_chains, groups, CHAIN_LANES, d, w->sp);
+		if (haveGrid)
+		{
+			rc = toiBuildIndexes(w, false);
+			if (rc) return rc;
+		}
+		LAUNCH(w, k_toi_chains, groups, CHAIN_LANES, d, w->sp, haveGrid);
 		LAUNCH(w, k_toi_chains_end, 1, 256, d);
 		LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
 		w->toiChains = true;
@@ -1355,7 +1377,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
 	w->bodyActive.release(); w->b_posv.release(); w->uncolList.release(); w->gridBar.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
-	w->b_toiGroup.release(); w->toiGroups.release(); w->toiMoved.release(); w->snapBody.release(); w->snapFat.release();
+	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
@@ -1698,6 +1720,11 @@ int b2hip_step_end(b2hip_world* w)
 			rc = downloadState(w);
 			if (rc) return rc;
 		}
+	}
+	if (w->toiChains)
+	{
+		if (w->h_dstate->c.nToiMoved > 0) w->toiGridSticky = 16;
+		else if (w->toiGridSticky > 0) w->toiGridSticky -= 1;
 	}
 	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
 	{
