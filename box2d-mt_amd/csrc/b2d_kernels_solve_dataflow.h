@@ -61,7 +61,7 @@ __device__ __forceinline__ void atomicOr64(uint64_t* p, uint64_t v)
 // One dataflow phase for this lane's constraint: wait until both rows show the expected versions, then run `body(ra, rb)`.
 // rowA / rowB are null for static bodies (nothing to wait for, nothing to publish). Returns false if the wait was abandoned.
 template <typename F>
-__device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, int needA, const float4* rowB, int needB, int* bar, int* overflow, F body)
+__device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, int needA, const float4* rowB, int needB, int* bar, int* overflow, int pollSleep, F body)
 {
 	int spins = 0;
 	while (__any(pending))
@@ -87,12 +87,17 @@ __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, in
 			atomicOr(overflow, 64);
 			return false;
 		}
-		if (__any(pending)) __builtin_amdgcn_s_sleep(1);
+		if (__any(pending))
+		{
+			if (pollSleep == 1) __builtin_amdgcn_s_sleep(1);
+			else if (pollSleep == 2) __builtin_amdgcn_s_sleep(4);
+			else if (pollSleep == 3) __builtin_amdgcn_s_sleep(12);
+		}
 	}
 	return true;
 }
 
-__global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepParams sp, int nColorsArg, int* bar)
+__global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepParams sp, int nColorsArg, int* bar, int pollSleep)
 {
 	DState* S = W.st;
 	const int nColors = nColorsArg >= 0 ? nColorsArg : (S->c.nColors < MAX_COLORS ? S->c.nColors : MAX_COLORS);
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 	{
 		const bool warm = sp.warmStarting && sweep == 0;
 		const int needA = sweep * degA + rankA, needB = sweep * degB + rankB;
-		const bool ok = dataflowRun(have, velA, needA, velB, needB, bar, gb.overflow, [&](f4v ra, f4v rb)
+		const bool ok = dataflowRun(have, velA, needA, velB, needB, bar, gb.overflow, pollSleep, [&](f4v ra, f4v rb)
 		{
 			BodyVel vA, vB;
 			vA.v = v2(ra.x, ra.y); vA.w = ra.z;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 		sA.c = v2(0, 0); sA.a = 0; sB = sA;
 		if (active && !r.nsA) { const float4 p = W.b_pos[r.bodyA]; sA.c = v2(p.x, p.y); sA.a = p.z; }
 		if (active && !r.nsB) { const float4 p = W.b_pos[r.bodyB]; sB.c = v2(p.x, p.y); sB.a = p.z; }
-		const bool ok = dataflowRun(active, posA, needA, posB, needB, bar, gb.overflow, [&](f4v ra, f4v rb)
+		const bool ok = dataflowRun(active, posA, needA, posB, needB, bar, gb.overflow, pollSleep, [&](f4v ra, f4v rb)
 		{
 			BodyPos pA, pB;
 			if (posA) { pA.c = v2(ra.x, ra.y); pA.a = ra.z; } else pA = sA;

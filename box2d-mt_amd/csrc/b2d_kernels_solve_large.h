@@ -119,14 +119,19 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	int bad = 0;
 	int uncolored = 0;
 	int maxColor = 0;
-	// (1) every contact that owns a colour - touching or not, large island or not - reserves it on its
-	// bodies, so a constraint that stops touching for a few steps finds its colour still free when it
-	// comes back and colours handed out meanwhile can never clash with it
+	// (1) every touching contact that owns a colour - large island or not, asleep or not - reserves it on its bodies.
+	// A contact that stopped touching gives its colour back: reservations of idle neighbours (a pyramid box has two of
+	// them) would push new constraints to ever higher colours, and the depth of a sweep is the number of colours.
 	const int nAll = S->c.nContacts;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAll; i += gridDim.x * blockDim.x)
 	{
 		const int col = C.color[i];
 		if (col < 0 || col >= MAX_COLORS) continue;
+		if ((C.flags[i] & (CF_TOUCHING | CF_SENSOR)) != CF_TOUCHING)
+		{
+			C.color[i] = -1;
+			continue;
+		}
 		int4 ids = C.ids[i];
 		const unsigned long long bit = 1ull << col;
 		if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC)
@@ -169,9 +174,15 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 				const int u = atomicAdd(&S->c.nUncolList, 1);
 				if (u < COLOR_SMALL_MAX) W.uncolList[u] = s;
 			}
-			else if (col != HUB_COLOR && col + 1 > maxColor)
+			else if (col != HUB_COLOR)
 			{
-				maxColor = col + 1;
+				if (col + 1 > maxColor) maxColor = col + 1;
+				if (col == S->c.compactClass && col > 0)
+				{
+					// candidates of this step's compaction class (k_color_small moves them down if a lower colour is free)
+					const int u = atomicAdd(&S->c.nCompact, 1);
+					if (u < COLOR_SMALL_MAX) W.compactList[u] = s;
+				}
 			}
 			W.li_color[s] = col;
 		}
@@ -193,6 +204,12 @@ __global__ void k_color_check_begin(DW W)
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
+		// colour compaction visits one class per step, from the highest down to 1, then starts over
+		const int prev = W.st->c.nColors < MAX_COLORS ? W.st->c.nColors : MAX_COLORS;
+		int t = W.st->c.compactClass - 1;
+		if (t < 1 || t >= prev) t = prev - 1;
+		W.st->c.compactClass = t > 0 ? t : 0;
+		W.st->c.nCompact = 0;
 		W.st->c.needRecolor = 0;
 		W.st->c.nColors = 0;
 		W.st->c.nUncolored = 0;
@@ -261,15 +278,48 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 __global__ __launch_bounds__(1024) void k_color_small(DW W)
 {
 	DState* S = W.st;
-	const int n = S->c.nUncolList;
-	if (n == 0 || n > COLOR_SMALL_MAX || S->c.needRecolor) return;
+	if (S->c.nUncolList > COLOR_SMALL_MAX || S->c.needRecolor) return;
 	const ContactArrays& C = W.ca[S->cur];
-	__shared__ int s_left, s_colored, s_maxColor;
+	__shared__ int s_left, s_colored, s_maxColor, s_n;
 	if (threadIdx.x == 0)
 	{
-		s_left = n;
+		s_n = S->c.nUncolList;
 		s_maxColor = 0;
 	}
+	__syncthreads();
+	// Colour compaction: a constraint of this step's class gives its colour up when a lower one is free on both bodies,
+	// and takes the lowest free colour in the rounds below. Constraints of one class never share a body, so each
+	// decision reads masks nobody else is changing: deterministic. Over the steps the colouring becomes greedy-minimal
+	// (colour <= (degA - 1) + (degB - 1)), whatever the order in which the contacts appeared.
+	{
+		const int nc = S->c.nCompact < COLOR_SMALL_MAX ? S->c.nCompact : COLOR_SMALL_MAX;
+		for (int k = threadIdx.x; k < nc; k += blockDim.x)
+		{
+			const int s = W.compactList[k];
+			const int c = W.li_color[s];
+			if (c <= 0 || c >= MAX_COLORS) continue;
+			const int ci = W.li_contacts[s];
+			const int4 ids = C.ids[ci];
+			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			uint64_t used = 1ull << HUB_COLOR;
+			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (used == ~0ull || __ffsll((long long)~used) - 1 >= c) continue;
+			const int slot = atomicAdd(&s_n, 1);
+			if (slot >= COLOR_SMALL_MAX) continue;
+			const unsigned long long bit = 1ull << c;
+			if (nsA) atomicAnd((unsigned long long*)&W.bodyColorMask[ids.z], ~bit);
+			if (nsB) atomicAnd((unsigned long long*)&W.bodyColorMask[ids.w], ~bit);
+			W.li_color[s] = -1;
+			C.color[ci] = -1;
+			atomicSub(&W.colorCount[c], 1);
+			W.uncolList[slot] = s;
+		}
+	}
+	__syncthreads();
+	const int n = s_n < COLOR_SMALL_MAX ? s_n : COLOR_SMALL_MAX;
+	if (threadIdx.x == 0) s_left = n;
 	__syncthreads();
 	for (int round = 0; round < 4 * MAX_COLORS && s_left > 0; ++round)
 	{
@@ -318,7 +368,10 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W)
 	}
 	if (threadIdx.x == 0)
 	{
-		atomicMax(&S->c.nColors, s_maxColor);
+		int nc = S->c.nColors > s_maxColor ? S->c.nColors : s_maxColor;
+		if (nc > MAX_COLORS) nc = MAX_COLORS;
+		while (nc > 0 && __hip_atomic_load(&W.colorCount[nc - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) --nc;
+		S->c.nColors = nc;
 		S->c.nUncolored = s_left;
 		S->c.colorRounds += 1;
 	}

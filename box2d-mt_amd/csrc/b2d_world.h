@@ -104,6 +104,8 @@ struct Counters
 	int nToiGroups;      // dynamic bodies with a pending impact
 	int nToiMoved;       // proxies re-inserted by the TOI chains
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
+	int nCompact;        // entries of DW::compactList (constraints of the colour class under compaction this step)
+	int compactClass;    // persistent: colour class whose constraints may move to a lower free colour this step
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
 	int nHubRows;        // hub constraints of this step
 	int chunkLanes;      // workgroup size of the small-island solver chosen for this step (TINY_CHUNK_LANES or SMALL_CHUNK_LANES)
@@ -205,6 +207,7 @@ struct DW
 	int* colorCount;     // [MAX_COLORS + 1]
 	int* colorStart;     // [MAX_COLORS + 1]
 	int* colorCursor;
+	int* compactList;    // large contact slots of colour Counters::compactClass (at most COLOR_SMALL_MAX listed)
 	int* uncolList;      // large contact slots that have no colour yet (at most COLOR_SMALL_MAX listed)
 	int* hubRowOf;       // per contact: its constraint row if it is a hub constraint this step
 	int* hubList;        // hub constraint rows in contact-index order (the deterministic visiting order of k_large_hub)

@@ -173,7 +173,7 @@ struct b2hip_world
 	DevArray<uint32_t> bodyClaim, rootPen, rootSleepMin;
 	DevArray<uint64_t> bodyColorMask, bodyActive;
 	DevArray<float4> b_posv;
-	DevArray<int> uncolList, hubRowOf, hubList;
+	DevArray<int> uncolList, compactList, hubRowOf, hubList;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
 	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies;
@@ -184,6 +184,7 @@ struct b2hip_world
 	DevArray<int4> scanTmp4;
 	DevArray<float> stateOut;
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
+	int dfLanesForced, dfSleep, nCU; // k_solve_dataflow: workgroup size, poll back-off, co-resident workgroups
 	int persistMaxWG;            // co-resident workgroups of k_solve_persistent on this device (0 = do not use it)
 	int persistSteps;            // steps solved by the persistent kernel (diagnostics)
 	DevArray<int> consts; // [0] nBodies, [1] gridSize, [2] radix hist count, [3] sorted-pair count
@@ -538,7 +539,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(uncolList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -603,7 +604,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.uncolList = w->uncolList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
@@ -988,19 +989,36 @@ static int phaseSolve(b2hip_world* w)
 		const int gB = gridFor(nLBodies), gC = gridFor(std::max(nLContacts, 1));
 		nColors = exactLarge ? nColors : c.nColors;
 		const bool hasJoints = d.nJoints > 0;
-		const int persistWG = (nLContacts + PERSIST_LANES - 1) / PERSIST_LANES;
+		// k_solve_dataflow: two waves per workgroup while that still leaves at most ~2 workgroups per CU (a hand-off is
+		// priced by the consumer CU's memory queue: 256 -> 128 lanes took the 10k-body pyramid from 464 to 409 us; 64 lanes
+		// lost it again to the grid barriers), four waves for bigger islands
+		const int dfLanes = w->dfLanesForced ? w->dfLanesForced : (nLContacts <= 128 * 2 * w->nCU ? 128 : PERSIST_LANES);
+		const int persistLanes = w->solverBarriers ? PERSIST_LANES : dfLanes;
+		const int persistWG = (nLContacts + persistLanes - 1) / persistLanes;
+		const int persistMaxWG = w->persistMaxWG * (PERSIST_LANES / persistLanes);
 		const bool usePersistent = !exactLarge && !hasJoints && !hasHubs && !w->debugTrace && !w->kernelTimingLaunches &&
-			w->persistMaxWG > 0 && persistWG <= w->persistMaxWG;
+			persistMaxWG > 0 && persistWG <= persistMaxWG;
 		bool colorsOnDevice = false;
-		if (!exactLarge && (c.needRecolor || c.nUncolored > 0))
+		if (!exactLarge && (c.needRecolor || c.nUncolored > 0 || c.nCompact > 0))
 		{
-			if (usePersistent && !c.needRecolor && c.nUncolored <= COLOR_SMALL_MAX)
+			if (!c.needRecolor && c.nUncolored <= COLOR_SMALL_MAX)
 			{
-				// the usual case (a few new contacts on a settled island): one workgroup colours them, no host round trip;
-				// the resident solver reads the colour count from the device
+				// the usual case (a few new contacts on a settled island, a colour class to compact): one workgroup colours
+				// them; the resident solver reads the colour count from the device, the launch-per-colour path reads it back
 				LAUNCH(w, k_color_small, 1, 1024, d);
-				colorsOnDevice = true;
-				w->colorSmallPending = true;
+				if (usePersistent)
+				{
+					colorsOnDevice = true;
+					w->colorSmallPending = true;
+				}
+				else
+				{
+					rc = readState(w);
+					if (rc) return rc;
+					nColors = w->h_dstate->c.nColors;
+					if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
+					if (w->h_dstate->c.nUncolored != 0) return setError(B2HIP_ERR_CAPACITY, "incremental colouring did not converge");
+				}
 			}
 			else
 			{
@@ -1049,7 +1067,7 @@ static int phaseSolve(b2hip_world* w)
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 3; }
 			const int nColorsArg = colorsOnDevice ? -1 : nColors; // -1: read Counters::nColors on the device
 			if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
-			else LAUNCH(w, k_solve_dataflow, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
+			else LAUNCH(w, k_solve_dataflow, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfSleep);
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 			w->persistSteps += 1;
 		}
@@ -1315,6 +1333,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->useGraphs = getenv("B2HIP_GRAPHS") != nullptr; // opt-in: measured no gain on MI355X (the step is not host-bound), see DESIGN.md
 	w->graphCaptures = 0;
 	w->persistMaxWG = 0;
+	w->nCU = 256;
 	{
 		int perCU = 0;
 		hipDeviceProp_t prop;
@@ -1324,8 +1343,13 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 		{
 			// the occupancy query can be one block per CU high (sgpr_count 81-112, MI355X_MICROARCH.md): keep a margin
 			w->persistMaxWG = std::max(0, std::min(perCU - 1, 4)) * prop.multiProcessorCount;
+			w->nCU = prop.multiProcessorCount;
 		}
 	}
+	w->dfLanesForced = 0;
+	w->dfSleep = 1;
+	if (const char* e = getenv("B2HIP_DF_LANES")) w->dfLanesForced = std::max(64, std::min(256, atoi(e) / 64 * 64));
+	if (const char* e = getenv("B2HIP_DF_SLEEP")) w->dfSleep = atoi(e);
 	w->toiChains = false;
 	w->toiSerialOnly = getenv("B2HIP_TOI_SERIAL") != nullptr;
 	w->toiFallbacks = 0;
@@ -1375,7 +1399,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
-	w->bodyActive.release(); w->b_posv.release(); w->uncolList.release(); w->gridBar.release();
+	w->bodyActive.release(); w->b_posv.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
