@@ -207,6 +207,30 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 
 // b2World::CreateJoint with collideConnected == false flags the contacts between the two bodies for
 // re-filtering at the next step (b2World.cpp:716-732).
+// Per-step counters back to zero (one launch instead of a handful of memsets); `bar` = the resident solver's grid barrier.
+__global__ void k_step_begin(DW W, int* bar)
+{
+	Counters& c = W.st->c;
+	const int t = threadIdx.x;
+	if (t == 0)
+	{
+		c.nDestroy = 0;
+		(&c.nDestroy)[1] = 0;
+		c.nPairs = 0;
+		(&c.nPairs)[1] = 0;
+		c.overflow = 0;
+		c.nToiList = 0;
+		c.nToiEvents = 0;
+		c.nToiCalls = 0;
+		c.toiBase = 0;
+		c.toiOverflow = 0;
+		c.toiUnsafe = 0;
+		c.nToiGroups = 0;
+		c.nToiMoved = 0;
+	}
+	if (t < 16) bar[t] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_flag_filter(DW W, int bodyA, int bodyB)
 {
 	DState* S = W.st;

@@ -77,9 +77,33 @@ __device__ __forceinline__ void ufUnion(int* parent, int a, int b)
 	}
 }
 
+// Called by block 0 of k_island_init (one launch less than a kernel of its own).
+__device__ __forceinline__ void colorCheckBegin(const DW& W)
+{
+	if (threadIdx.x <= MAX_COLORS)
+	{
+		W.colorCount[threadIdx.x] = 0;
+		W.colorCursor[threadIdx.x] = 0;
+	}
+	if (threadIdx.x == 0)
+	{
+		// colour compaction visits one class per step, from the highest down to 1, then starts over
+		const int prev = W.st->c.nColors < MAX_COLORS ? W.st->c.nColors : MAX_COLORS;
+		int t = W.st->c.compactClass - 1;
+		if (t < 1 || t >= prev) t = prev - 1;
+		W.st->c.compactClass = t > 0 ? t : 0;
+		W.st->c.nCompact = 0;
+		W.st->c.needRecolor = 0;
+		W.st->c.nColors = 0;
+		W.st->c.nUncolored = 0;
+		W.st->c.nUncolList = 0;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_island_init(DW W)
 {
 	DState* S = W.st;
+	if (blockIdx.x == 0) colorCheckBegin(W);
 	const int n = W.nBodies;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{

@@ -195,28 +195,6 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	if (maxColor) atomicMax(&S->c.nColors, maxColor);
 }
 
-__global__ void k_color_check_begin(DW W)
-{
-	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS)
-	{
-		W.colorCount[threadIdx.x] = 0;
-		W.colorCursor[threadIdx.x] = 0;
-	}
-	if (blockIdx.x == 0 && threadIdx.x == 0)
-	{
-		// colour compaction visits one class per step, from the highest down to 1, then starts over
-		const int prev = W.st->c.nColors < MAX_COLORS ? W.st->c.nColors : MAX_COLORS;
-		int t = W.st->c.compactClass - 1;
-		if (t < 1 || t >= prev) t = prev - 1;
-		W.st->c.compactClass = t > 0 ? t : 0;
-		W.st->c.nCompact = 0;
-		W.st->c.needRecolor = 0;
-		W.st->c.nColors = 0;
-		W.st->c.nUncolored = 0;
-		W.st->c.nUncolList = 0;
-	}
-}
-
 __global__ __launch_bounds__(256) void k_color_claim(DW W)
 {
 	DState* S = W.st;

@@ -615,4 +615,53 @@ __global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
 	for (int g = threadIdx.x; g < nG; g += blockDim.x) W.b_toiGroup[W.toiGroups[g]] = 0;
 }
 
+// ---- fused front of the pair update: (hash table of contact keys + spatial grid) cleared, then built -----------------
+// Same bodies as k_ht_clear + k_grid_clear(force 0) and k_ht_build + k_grid_count(force 0): independent arrays, one
+// launch each instead of two.
+__global__ __launch_bounds__(256) void k_bp_clear(DW W)
+{
+	DState* S = W.st;
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		S->c.nLargeProxies = 0;
+		S->c.nPairs = 0;
+		S->c.nNewContacts = 0;
+	}
+	if (S->c.nMoves == 0) return;
+	const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	for (uint32_t i = t0; i <= W.gridMask; i += stride)
+	{
+		W.gridCount[i] = 0;
+		W.gridCursor[i] = 0;
+	}
+	for (uint32_t i = t0; i <= W.htMask; i += stride) W.ht_keys[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_bp_build(DW W)
+{
+	DState* S = W.st;
+	if (S->c.nMoves == 0) return;
+	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	const int nC = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = t0; i < nC; i += stride) htInsert(W, C.key[i] + 1ull);
+	const int n = W.nProxies;
+	for (int p = t0; p < n; p += stride)
+	{
+		if (W.p_body[p] < 0) continue;
+		const float4 a = W.p_fat[p];
+		if (proxyIsLarge(W, a))
+		{
+			const int k = atomicAdd(&S->c.nLargeProxies, 1);
+			W.largeProxies[k] = p;
+		}
+		else
+		{
+			int ix, iy;
+			proxyCell(W, a, &ix, &iy);
+			atomicAdd(&W.gridCount[cellHash(ix, iy, W.gridMask)], 1);
+		}
+	}
+}
+
 #endif

@@ -204,6 +204,7 @@ struct b2hip_world
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
+	bool toiCountersFresh = false;
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
 	int graphCaptures;
@@ -859,10 +860,8 @@ static int findNewContactsGraph(b2hip_world* w)
 static int findNewContacts(b2hip_world* w, bool sync)
 {
 	DW& d = w->dw;
-	LAUNCH(w, k_ht_clear, gridFor(d.htMask + 1), 256, d);
-	LAUNCH(w, k_ht_build, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 0);
-	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 0);
+	LAUNCH(w, k_bp_clear, gridFor(std::max(d.htMask, d.gridMask) + 1), 256, d);
+	LAUNCH(w, k_bp_build, gridFor(std::max(d.capContacts, d.nProxies)), 256, d);
 	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
 	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 0);
 	LAUNCH(w, k_find_pairs_small, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
@@ -936,7 +935,6 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
 		if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
-		LAUNCH(w, k_color_check_begin, 1, 128, d);
 		LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
 		return 0;
 	});
@@ -1063,7 +1061,7 @@ static int phaseSolve(b2hip_world* w)
 		if (usePersistent)
 		{
 			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (b2d_kernels_solve_persist.h)
-			HIP_TRY(hipMemsetAsync(w->gridBar.p, 0, 16 * sizeof(int), w->stream));
+			// (the barrier words were zeroed by k_step_begin: one resident launch per step)
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 3; }
 			const int nColorsArg = colorsOnDevice ? -1 : nColors; // -1: read Counters::nColors on the device
 			if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
@@ -1198,8 +1196,13 @@ static int phaseToi(b2hip_world* w)
 	int rc = 0;
 	for (int pass = 0; pass < 2; ++pass)
 	{
-		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nToiList, 0, sizeof(int) * 5, w->stream));
-		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
+		if (pass == 1 || !w->toiCountersFresh)
+		{
+			// (the first pass of a step starts from the zeros of k_step_begin)
+			HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nToiList, 0, sizeof(int) * 5, w->stream));
+			HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
+		}
+		w->toiCountersFresh = false;
 		LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
 		rc = readState(w);
 		if (rc) return rc;
@@ -1643,9 +1646,8 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 	// zero the per-step counters (keep nContacts / nMoves / cur)
 	Counters zero;
 	memset(&zero, 0, sizeof(zero));
-	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nDestroy, 0, sizeof(int) * 2, w->stream));
-	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nPairs, 0, sizeof(int) * 2, w->stream));
-	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+	LAUNCH(w, k_step_begin, 1, 64, w->dw, w->gridBar.p);
+	w->toiCountersFresh = true;
 	for (size_t k = 0; k < w->pendingFilter.size(); ++k)
 	{
 		LAUNCH(w, k_flag_filter, gridFor(w->dw.capContacts), 256, w->dw, w->pendingFilter[k].first, w->pendingFilter[k].second);
