@@ -82,27 +82,34 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 	// ---- lanes are re-dealt so that constraints of one dependency level sit in consecutive lanes: at level L only the
 	// waves that hold level-L constraints execute the solver body, the others branch over it (a stack is a chain: with
 	// the discovery order every wave would run every level for a handful of active lanes) ---------------------------
-	__shared__ int s_levelStart[LANES + 2];
+	__shared__ int s_levelStart[LANES];
 	__shared__ int s_perm[LANES];
-	for (int i = tid; i <= LANES + 1; i += LANES) s_levelStart[i] = 0;
+	__shared__ int s_waveSum[LANES / 64];
+	s_levelStart[tid] = 0;
 	__syncthreads();
 	int myLevel0 = 0;
 	if (tid < nC)
 	{
+		// (the clamp only affects which lane a constraint sits in, never the order it is solved in)
 		myLevel0 = W.si_level[cStart + tid];
-		if (myLevel0 > LANES) myLevel0 = LANES;
+		if (myLevel0 > LANES - 2) myLevel0 = LANES - 2;
 		atomicAdd(&s_levelStart[myLevel0 + 1], 1);
 	}
 	__syncthreads();
-	if (tid == 0)
 	{
-		int run = 0;
-		for (int L = 0; L <= LANES + 1; ++L)
+		// exclusive scan of the level census, one entry per lane
+		const int v = s_levelStart[tid];
+		int incl = v;
+		for (int off = 1; off < 64; off <<= 1)
 		{
-			const int c = s_levelStart[L];
-			s_levelStart[L] = run;
-			run += c;
+			const int n = __shfl_up(incl, off);
+			if ((tid & 63) >= off) incl += n;
 		}
+		if ((tid & 63) == 63) s_waveSum[tid >> 6] = incl;
+		__syncthreads();
+		int base = 0;
+		for (int wv = 0; wv < (tid >> 6); ++wv) base += s_waveSum[wv];
+		s_levelStart[tid] = base + incl - v;
 	}
 	__syncthreads();
 	if (tid < nC) s_perm[atomicAdd(&s_levelStart[myLevel0 + 1], 1)] = tid;

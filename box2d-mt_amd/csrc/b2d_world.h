@@ -216,6 +216,8 @@ struct DW
 	uint32_t* bodyClaim;
 	uint64_t* bodyColorMask;
 	uint64_t* bodyActive;   // per body: colours of its constraints in THIS step's large-island solve (dataflow solver)
+	int* dfRank;            // per body: DF_RANKS mailbox slots, [rank] = slot of the body's rank-th constraint (k_solve_mailbox)
+	float4* dfInbox;        // per large-island constraint row: two tagged 16-byte slots (body A, body B)
 	float4* b_posv;         // per body: (c.xy, a, version) rows of the dataflow solver's position phase
 	float* lc;           // large-island constraint rows, field-major: lc[field * capContacts + slot]
 	uint32_t* rootPen;   // per root: max penetration of the running position iteration (bits of -minSeparation)

@@ -20,6 +20,7 @@
 #include "../../include/b2hip.h"
 #include "b2d_kernels_toi_chains.h"
 #include "b2d_kernels_solve_dataflow.h"
+#include "b2d_kernels_solve_mailbox.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -172,7 +173,8 @@ struct b2hip_world
 	DevArray<int> li_bodies, li_contacts, li_roots, li_color, colorCount, colorStart, colorCursor, li_sorted;
 	DevArray<uint32_t> bodyClaim, rootPen, rootSleepMin;
 	DevArray<uint64_t> bodyColorMask, bodyActive;
-	DevArray<float4> b_posv;
+	DevArray<float4> b_posv, dfInbox;
+	DevArray<int> dfRank;
 	DevArray<int> uncolList, compactList, hubRowOf, hubList;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
@@ -184,6 +186,10 @@ struct b2hip_world
 	DevArray<int4> scanTmp4;
 	DevArray<float> stateOut;
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
+	int dfEpoch;
+	bool solverRows, solverLocal, noSideStream;
+	hipStream_t stream2 = nullptr; // small-island solver beside the large-island one
+	hipEvent_t evFork = nullptr, evJoin = nullptr;
 	int dfLanesForced, dfSleep, nCU; // k_solve_dataflow: workgroup size, poll back-off, co-resident workgroups
 	int persistMaxWG;            // co-resident workgroups of k_solve_persistent on this device (0 = do not use it)
 	int persistSteps;            // steps solved by the persistent kernel (diagnostics)
@@ -425,6 +431,19 @@ static int syncCheck(b2hip_world* w, const char* what)
 		if (_rc) return _rc;                                                                  \
 	} while (0)
 
+// Same on an explicit stream (the small-island side stream, see phaseSolve).
+#define LAUNCH_ON(w, strm, kernel, grid, block, ...)                                          \
+	do                                                                                        \
+	{                                                                                         \
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (strm), __VA_ARGS__);          \
+		if ((w)->debugSync)                                                                   \
+		{                                                                                     \
+			hipError_t _e = hipStreamSynchronize(strm);                                       \
+			if (_e == hipSuccess) _e = hipGetLastError();                                     \
+			if (_e != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(#kernel) + ": " + hipGetErrorString(_e)); \
+		}                                                                                     \
+	} while (0)
+
 // ---- hipGraph segments ------------------------------------------------------------------------------
 // The step is ~55 kernels of 2-5 us: issued one by one the host (~3.5 us per launch) is the bottleneck between two
 // read-backs. The three launch sequences that contain no host decision (collide + compaction, island build up to the
@@ -540,7 +559,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -605,7 +624,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
@@ -948,19 +967,34 @@ static int phaseSolve(b2hip_world* w)
 	HIP_TRY(hipEventRecord(w->ev[4], w->stream));
 	const bool exactLarge = forceLarge == 2;
 	const bool hasHubs = !exactLarge && c.maxDegree > HUB_DEGREE;
+	// Small and large islands share nothing (different bodies, contacts, island tables): when both tiers are present the
+	// small-island chain (DFS order, chunking, k_solve_small) runs on a side stream beside the large-island solver and
+	// joins before SynchronizeFixtures. With a handful of small islands that chain is one or two workgroups of big kernels
+	// whose cost is instruction fetch from a cold cache (~2 us per KB of code executed: 83 us for a dozen free bodies next
+	// to the 10k-body pyramid) - time the large solver's resident grid leaves plenty of idle CUs for.
+	bool sideStream = false;
 	if (c.nSIslands > 0)
 	{
-		LAUNCH(w, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
-		LAUNCH(w, k_island_chunks, gridFor(c.nSIslands), 256, d);
+		sideStream = !exactLarge && c.nLIslands > 0 && !w->debugTrace && !w->kernelTimingLaunches && !w->noSideStream;
+		hipStream_t ss = w->stream;
+		if (sideStream)
+		{
+			ss = w->stream2;
+			HIP_TRY(hipEventRecord(w->evFork, w->stream));
+			HIP_TRY(hipStreamWaitEvent(ss, w->evFork, 0));
+		}
+		LAUNCH_ON(w, ss, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
+		LAUNCH_ON(w, ss, k_island_chunks, gridFor(c.nSIslands), 256, d);
 		HIP_TRY(hipEventRecord(w->ev[5], w->stream));
 		if (!exactLarge)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 2; }
-			if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH(w, k_solve_small<TINY_CHUNK_LANES>, c.nChunks, TINY_CHUNK_LANES, d, sp);
-			else LAUNCH(w, k_solve_small<SMALL_CHUNK_LANES>, c.nChunks, SMALL_CHUNK_LANES, d, sp);
+			if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH_ON(w, ss, k_solve_small<TINY_CHUNK_LANES>, c.nChunks, TINY_CHUNK_LANES, d, sp);
+			else LAUNCH_ON(w, ss, k_solve_small<SMALL_CHUNK_LANES>, c.nChunks, SMALL_CHUNK_LANES, d, sp);
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
 		}
+		if (sideStream) HIP_TRY(hipEventRecord(w->evJoin, ss));
 		HIP_TRY(hipEventRecord(w->ev[6], w->stream));
 	}
 	else
@@ -1065,7 +1099,18 @@ static int phaseSolve(b2hip_world* w)
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 3; }
 			const int nColorsArg = colorsOnDevice ? -1 : nColors; // -1: read Counters::nColors on the device
 			if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
-			else LAUNCH(w, k_solve_dataflow, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfSleep);
+			else if (w->solverRows || (sp.velIters + 2) * DF_RANKS >= 65536 || (sp.posIters + 1) * DF_RANKS >= 65536)
+				LAUNCH(w, k_solve_dataflow, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfSleep);
+			else
+			{
+				// optional single-XCD attempt first when the island fits one XCD's CUs (k_solve_mailbox<true>), then the ordinary
+				// launch, which returns at once if the attempt took the step
+				const int xcdWG = persistMaxWG / 8;
+				const bool tryLocal = w->solverLocal && persistWG <= xcdWG;
+				if (tryLocal) LAUNCH(w, k_solve_mailbox<true>, 8 * persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfEpoch, persistWG, 0);
+				LAUNCH(w, k_solve_mailbox<false>, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfEpoch, persistWG, tryLocal ? 1 : 0);
+				w->dfEpoch += 1;
+			}
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 			w->persistSteps += 1;
 		}
@@ -1126,6 +1171,7 @@ static int phaseSolve(b2hip_world* w)
 		TRACE("finalize");
 		LAUNCH(w, k_large_sleep, gB, 256, d, sp);
 		TRACE("sleep");
+		if (sideStream) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
 		HIP_TRY(hipEventRecord(w->ev[8], w->stream));
 	}
 	else
@@ -1293,7 +1339,10 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 			return setError(B2HIP_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
 		}
 	}
-	e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+	e = hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&w->evFork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&w->evJoin, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
 	if (e != hipSuccess)
 	{
 		delete w;
@@ -1338,18 +1387,27 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->persistMaxWG = 0;
 	w->nCU = 256;
 	{
-		int perCU = 0;
+		int perCU = 0, perCU2 = 0;
 		hipDeviceProp_t prop;
 		int devId = 0;
 		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_dataflow, PERSIST_LANES, 0) == hipSuccess)
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_dataflow, PERSIST_LANES, 0) == hipSuccess &&
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU2, k_solve_mailbox<true>, PERSIST_LANES, 0) == hipSuccess)
 		{
+			perCU = std::min(perCU, perCU2);
 			// the occupancy query can be one block per CU high (sgpr_count 81-112, MI355X_MICROARCH.md): keep a margin
 			w->persistMaxWG = std::max(0, std::min(perCU - 1, 4)) * prop.multiProcessorCount;
 			w->nCU = prop.multiProcessorCount;
 		}
 	}
 	w->dfLanesForced = 0;
+	w->noSideStream = getenv("B2HIP_NO_SIDE_STREAM") != nullptr;
+	w->dfEpoch = 0;
+	// single-XCD attempt of k_solve_mailbox: opt-in. Measured on the 10k-body pyramid it LOSES (launch 500 us against 368):
+	// 334 waves polling on 32 CUs load the consumer CUs' memory queues, which is where a hand-off is priced; L2 locality
+	// buys only 0.1-0.3 us of it (MI355X_MICROARCH.md, handoff-1to1)
+	w->solverLocal = getenv("B2HIP_SOLVER_SINGLE_XCD") != nullptr;
+	w->solverRows = getenv("B2HIP_SOLVER_ROWS") != nullptr; // polled body rows (k_solve_dataflow) instead of pushed mailboxes
 	w->dfSleep = 1;
 	if (const char* e = getenv("B2HIP_DF_LANES")) w->dfLanesForced = std::max(64, std::min(256, atoi(e) / 64 * 64));
 	if (const char* e = getenv("B2HIP_DF_SLEEP")) w->dfSleep = atoi(e);
@@ -1402,7 +1460,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
-	w->bodyActive.release(); w->b_posv.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release();
+	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
@@ -1423,6 +1481,9 @@ void b2hip_world_destroy(b2hip_world* w)
 		}
 	}
 	(void)hipStreamDestroy(w->stream);
+	(void)hipStreamDestroy(w->stream2);
+	(void)hipEventDestroy(w->evFork);
+	(void)hipEventDestroy(w->evJoin);
 	delete w;
 }
 
@@ -2126,7 +2187,7 @@ int b2hip_set_kernel_timing(b2hip_world* w, int enable)
 int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes)
 {
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
-	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : "k_solve_dataflow") : ""));
+	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : (w->solverRows ? "k_solve_dataflow" : "k_solve_mailbox")) : ""));
 	if (name && name_cap > 0)
 	{
 		strncpy(name, n, (size_t)name_cap - 1);

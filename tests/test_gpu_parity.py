@@ -327,10 +327,10 @@ def test_persistent_solver_matches_launch_per_colour(amd, default_mode):
         return out, man.tobytes()
 
     for scene, steps, kw in [(bh.PYRAMID, 90, dict(p0=40)), (bh.FIELD, 40, dict(p0=800, p1=200, f0=50.0, f1=3.0, seed=29))]:
-        os.environ.pop("B2HIP_SOLVER_LAUNCHES", None)
-        os.environ.pop("B2HIP_SOLVER_BARRIERS", None)
-        a = run(scene, steps, **kw)  # default: body-level dataflow (k_solve_dataflow)
-        for var in ("B2HIP_SOLVER_BARRIERS", "B2HIP_SOLVER_LAUNCHES"):
+        for var in ("B2HIP_SOLVER_LAUNCHES", "B2HIP_SOLVER_BARRIERS", "B2HIP_SOLVER_ROWS"):
+            os.environ.pop(var, None)
+        a = run(scene, steps, **kw)  # default: body-level dataflow with pushed hand-offs (k_solve_mailbox)
+        for var in ("B2HIP_SOLVER_ROWS", "B2HIP_SOLVER_BARRIERS", "B2HIP_SOLVER_LAUNCHES"):
             os.environ[var] = "1"
             try:
                 b = run(scene, steps, **kw)
