@@ -254,13 +254,29 @@ B2D_HD float b2dSinCosImpl(float y, int which)
 B2D_HD float b2dSin(float y) { return b2dSinCosImpl(y, 0); }
 B2D_HD float b2dCos(float y) { return b2dSinCosImpl(y, 1); }
 
-// b2Rot::Set (b2Math.h:294-299)
-B2D_HD Rot b2dRot(float angle)
+// b2Rot::Set (b2Math.h:294-299). On the device this is ONE out-of-line copy: the glibc-exact sinf/cosf pair is ~3 KB of
+// code, and inlined at every transform (ten sites in the time-of-impact root finder alone) it made the TOI kernels
+// 60-200 KB - far beyond the 64 KB instruction cache, where a wave pays ~2 us per KB of cold code it walks through.
+#if defined(__HIPCC__)
+__device__ __noinline__ static Rot b2dRotOutOfLine(float angle)
 {
 	Rot q;
 	q.s = b2dSin(angle);
 	q.c = b2dCos(angle);
 	return q;
+}
+#endif
+
+B2D_HD Rot b2dRot(float angle)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return b2dRotOutOfLine(angle);
+#else
+	Rot q;
+	q.s = b2dSin(angle);
+	q.c = b2dCos(angle);
+	return q;
+#endif
 }
 
 // b2Math.h:553-600
