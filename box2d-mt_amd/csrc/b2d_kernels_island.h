@@ -28,7 +28,7 @@ __device__ __forceinline__ bool contactSolid(uint32_t flags)
 __device__ __forceinline__ int ufFind(int* parent, int i)
 {
 	// find with path halving: every visited node is re-pointed at its grandparent. Any ancestor is a valid
-	// parent at any time (links only ever go from a root to a smaller id), so this is safe under concurrency
+	// parent at any time (links only ever go from a root to a body of lower ufPriority), so this is safe under concurrency
 	// and keeps chains short when ten thousand bodies collapse into one component.
 	int r = i;
 	for (;;)
@@ -56,8 +56,12 @@ __device__ __forceinline__ int ufFindReadOnly(const int* parent, int i)
 	}
 }
 
-// Link the larger root under the smaller one: the final representative of a component is its
-// smallest body id whatever the interleaving, which makes labels deterministic.
+// Link by a fixed pseudo-random priority (a bijective hash of the body id): the root of a component is its member of
+// lowest priority whatever the interleaving, so labels are deterministic, and the expected tree depth is logarithmic.
+// Linking by the id itself made the pyramid's trees as deep as the pyramid is high (every box links under a box of the
+// row below, which was created earlier): 58 us of pointer chasing for 22k unions.
+__device__ __forceinline__ uint32_t ufPriority(int i) { return (uint32_t)i * 2654435761u; }
+
 __device__ __forceinline__ void ufUnion(int* parent, int a, int b)
 {
 	for (;;)
@@ -65,13 +69,13 @@ __device__ __forceinline__ void ufUnion(int* parent, int a, int b)
 		a = ufFind(parent, a);
 		b = ufFind(parent, b);
 		if (a == b) return;
-		if (a > b)
+		if (ufPriority(a) > ufPriority(b))
 		{
 			int t = a;
 			a = b;
 			b = t;
 		}
-		// a < b : try to hang b under a
+		// a has the lower priority value: try to hang b under a
 		int old = atomicCAS(&parent[b], b, a);
 		if (old == b) return;
 	}

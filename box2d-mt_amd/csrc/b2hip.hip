@@ -187,7 +187,7 @@ struct b2hip_world
 	DevArray<float> stateOut;
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
 	int dfEpoch;
-	bool solverRows, solverLocal, noSideStream;
+	bool solverRows, solverLocal, noSideStream, profileDetail;
 	hipStream_t stream2 = nullptr; // small-island solver beside the large-island one
 	hipEvent_t evFork = nullptr, evJoin = nullptr;
 	int dfLanesForced, dfSleep, nCU; // k_solve_dataflow: workgroup size, poll back-off, co-resident workgroups
@@ -964,7 +964,7 @@ static int phaseSolve(b2hip_world* w)
 	if (rc) return rc;
 	const Counters c = w->h_dstate->c;
 
-	HIP_TRY(hipEventRecord(w->ev[4], w->stream));
+	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[4], w->stream));
 	const bool exactLarge = forceLarge == 2;
 	const bool hasHubs = !exactLarge && c.maxDegree > HUB_DEGREE;
 	// Small and large islands share nothing (different bodies, contacts, island tables): when both tiers are present the
@@ -985,7 +985,7 @@ static int phaseSolve(b2hip_world* w)
 		}
 		LAUNCH_ON(w, ss, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
 		LAUNCH_ON(w, ss, k_island_chunks, gridFor(c.nSIslands), 256, d);
-		HIP_TRY(hipEventRecord(w->ev[5], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[5], w->stream));
 		if (!exactLarge)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
@@ -995,12 +995,12 @@ static int phaseSolve(b2hip_world* w)
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
 		}
 		if (sideStream) HIP_TRY(hipEventRecord(w->evJoin, ss));
-		HIP_TRY(hipEventRecord(w->ev[6], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[6], w->stream));
 	}
 	else
 	{
-		HIP_TRY(hipEventRecord(w->ev[5], w->stream));
-		HIP_TRY(hipEventRecord(w->ev[6], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[5], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[6], w->stream));
 	}
 	int nColors = 0;
 	int nLIslands = c.nLIslands, nLBodies = c.nLBodies, nLContacts = c.nLContacts;
@@ -1089,7 +1089,7 @@ static int phaseSolve(b2hip_world* w)
 			LAUNCH(w, k_hub_fill, gridFor(d.capContacts), 256, d);
 			w->hubSteps += 1;
 		}
-		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[7], w->stream));
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
 		if (usePersistent)
@@ -1172,12 +1172,12 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_large_sleep, gB, 256, d, sp);
 		TRACE("sleep");
 		if (sideStream) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
-		HIP_TRY(hipEventRecord(w->ev[8], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[8], w->stream));
 	}
 	else
 	{
-		HIP_TRY(hipEventRecord(w->ev[7], w->stream));
-		HIP_TRY(hipEventRecord(w->ev[8], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[7], w->stream));
+		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[8], w->stream));
 	}
 	w->last.nSIslands = c.nSIslands;
 	w->last.nSBodies = c.nSBodies;
@@ -1402,6 +1402,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	}
 	w->dfLanesForced = 0;
 	w->noSideStream = getenv("B2HIP_NO_SIDE_STREAM") != nullptr;
+	w->profileDetail = !(getenv("B2HIP_PROFILE_DETAIL") && atoi(getenv("B2HIP_PROFILE_DETAIL")) == 0);
 	w->dfEpoch = 0;
 	// single-XCD attempt of k_solve_mailbox: opt-in. Measured on the 10k-body pyramid it LOSES (launch 500 us against 368):
 	// 334 waves polling on 32 CUs load the consumer CUs' memory queues, which is where a hand-off is priced; L2 locality
@@ -1722,7 +1723,7 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 		if (rc) return rc;
 		w->newFixture = false;
 	}
-	HIP_TRY(hipEventRecord(w->ev[1], w->stream));
+	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[1], w->stream));
 	return 0;
 }
 
@@ -1731,7 +1732,7 @@ int b2hip_collide(b2hip_world* w)
 	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_collide outside a step");
 	int rc = phaseCollide(w);
 	if (rc) return rc;
-	HIP_TRY(hipEventRecord(w->ev[2], w->stream));
+	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[2], w->stream));
 	return 0;
 }
 
@@ -1745,9 +1746,9 @@ int b2hip_solve(b2hip_world* w)
 	}
 	else
 	{
-		for (int k = 4; k <= 8; ++k) HIP_TRY(hipEventRecord(w->ev[k], w->stream));
+		for (int k = 4; k <= 8 && w->profileDetail; ++k) HIP_TRY(hipEventRecord(w->ev[k], w->stream));
 	}
-	HIP_TRY(hipEventRecord(w->ev[3], w->stream));
+	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[3], w->stream));
 	return 0;
 }
 
@@ -1759,7 +1760,7 @@ int b2hip_sync_fixtures(b2hip_world* w)
 		int rc = phaseSyncFixtures(w);
 		if (rc) return rc;
 	}
-	HIP_TRY(hipEventRecord(w->ev[9], w->stream));
+	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[9], w->stream));
 	return 0;
 }
 
@@ -1771,7 +1772,7 @@ int b2hip_find_new_contacts(b2hip_world* w)
 		int rc = findNewContactsGraph(w);
 		if (rc) return rc;
 	}
-	HIP_TRY(hipEventRecord(w->ev[10], w->stream));
+	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[10], w->stream));
 	return 0;
 }
 
@@ -1786,7 +1787,7 @@ int b2hip_solve_toi(b2hip_world* w)
 		int rc = phaseToi(w);
 		if (rc) return rc;
 	}
-	HIP_TRY(hipEventRecord(w->ev[12], w->stream));
+	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[12], w->stream));
 	w->toiEventValid = true;
 	return 0;
 }
@@ -1858,6 +1859,8 @@ int b2hip_step_end(b2hip_world* w)
 	float* p = w->profile;
 	memset(p, 0, sizeof(float) * 13);
 	(void)hipEventElapsedTime(&ms, w->ev[0], w->ev[11]); p[0] = ms;                  // step
+	if (w->profileDetail)
+	{
 	(void)hipEventElapsedTime(&ms, w->ev[1], w->ev[2]); p[1] = ms;                   // collide
 	(void)hipEventElapsedTime(&ms, w->ev[2], w->ev[3]); p[2] = ms;                   // solve (islands + solver)
 	(void)hipEventElapsedTime(&ms, w->ev[2], w->ev[4]); p[3] = ms;                   // solveTraversal = island build
@@ -1877,6 +1880,7 @@ int b2hip_step_end(b2hip_world* w)
 	p[9] = bp0 + bp1 + bpTop;                                                    // broadphase
 	if (w->toiEventValid) { (void)hipEventElapsedTime(&ms, w->ev[10], w->ev[12]); p[7] = ms; }  // solveTOI
 	w->solverMs = small + large;
+	}
 	const int Ct = w->last.nSContacts + w->last.nLContacts;
 	const int B = w->last.nSBodies + w->last.nLBodies;
 	w->solverConstraints = Ct;
