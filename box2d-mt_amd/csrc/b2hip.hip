@@ -1107,6 +1107,9 @@ static int phaseSolve(b2hip_world* w)
 				// launch, which returns at once if the attempt took the step
 				const int xcdWG = persistMaxWG / 8;
 				const bool tryLocal = w->solverLocal && persistWG <= xcdWG;
+				// the 15-bit epoch of the mailbox tags comes round every 16 384 steps: wipe the slots then, so that a slot
+				// nobody has written since cannot carry a matching tag
+				if (w->dfEpoch != 0 && (w->dfEpoch & 0x3fff) == 0) HIP_TRY(hipMemsetAsync(w->dfInbox.p, 0, w->dfInbox.cap * sizeof(float4), w->stream));
 				if (tryLocal) LAUNCH(w, k_solve_mailbox<true>, 8 * persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfEpoch, persistWG, 0);
 				LAUNCH(w, k_solve_mailbox<false>, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfEpoch, persistWG, tryLocal ? 1 : 0);
 				w->dfEpoch += 1;
