@@ -230,11 +230,31 @@ __global__ __launch_bounds__(256) void k_find_pairs_large(DW W)
 		AABB a;
 		a.lo = v2(a4.x, a4.y);
 		a.hi = v2(a4.z, a4.w);
-		for (int q = threadIdx.x; q < W.nProxies; q += blockDim.x)
+		// four candidates per lane and trip: their loads are issued together (the emit path contains atomics, which the
+		// compiler will not move loads across; one candidate per trip made this loop a chain of dependent round trips)
+		for (int q0 = threadIdx.x; q0 < W.nProxies; q0 += 4 * blockDim.x)
 		{
-			if (q == p || W.p_body[q] < 0) continue;
-			if (!b2dAabbOverlap(a, loadAabb(W.p_fat, q))) continue;
-			tryEmitPair(W, S, p, q);
+			int body[4];
+			float4 fat[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+			{
+				const int q = q0 + u * blockDim.x;
+				const bool in = q < W.nProxies;
+				body[u] = in ? W.p_body[q] : -1;
+				fat[u] = in ? W.p_fat[q] : make_float4(0, 0, 0, 0);
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+			{
+				const int q = q0 + u * blockDim.x;
+				if (q == p || body[u] < 0) continue;
+				AABB b;
+				b.lo = v2(fat[u].x, fat[u].y);
+				b.hi = v2(fat[u].z, fat[u].w);
+				if (!b2dAabbOverlap(a, b)) continue;
+				tryEmitPair(W, S, p, q);
+			}
 		}
 	}
 }
@@ -256,10 +276,12 @@ __global__ __launch_bounds__(256) void k_pairs_first(DW W)
 		for (int t0 = 0; t0 < n; t0 += 256)
 		{
 			__syncthreads();
-			if (t0 + threadIdx.x < n) tile[threadIdx.x] = W.pairKey[t0 + threadIdx.x];
+			// the tail of the last tile is padded with a key no pair can have: every tile is a full, unrolled 256-compare
+			// loop (16 LDS reads in flight instead of one 64-cycle round trip per compare)
+			tile[threadIdx.x] = t0 + threadIdx.x < n ? W.pairKey[t0 + threadIdx.x] : ~0ull;
 			__syncthreads();
-			const int m = n - t0 < 256 ? n - t0 : 256;
-			for (int t = 0; t < m; ++t)
+#pragma unroll 16
+			for (int t = 0; t < 256; ++t)
 			{
 				if (tile[t] == key && t0 + t < i) first = 0;
 			}
@@ -274,7 +296,6 @@ __global__ __launch_bounds__(256) void k_pairs_rank(DW W)
 	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
 	if (n == 0 || n > COUNT_RANK_MAX) return;
 	__shared__ uint64_t tile[256];
-	__shared__ int tfirst[256];
 	const int rounds = (n + 255) / 256;
 	for (int base = blockIdx.x * 256; base < rounds * 256; base += gridDim.x * 256)
 	{
@@ -284,22 +305,18 @@ __global__ __launch_bounds__(256) void k_pairs_rank(DW W)
 		for (int t0 = 0; t0 < n; t0 += 256)
 		{
 			__syncthreads();
-			if (t0 + threadIdx.x < n)
-			{
-				tile[threadIdx.x] = W.pairKey[t0 + threadIdx.x];
-				tfirst[threadIdx.x] = W.pairFirst[t0 + threadIdx.x];
-			}
+			// only first occurrences count; the others and the tail padding carry a key that is never smaller
+			const bool in = t0 + threadIdx.x < n && W.pairFirst[t0 + threadIdx.x] != 0;
+			tile[threadIdx.x] = in ? W.pairKey[t0 + threadIdx.x] : ~0ull;
 			__syncthreads();
-			const int m = n - t0 < 256 ? n - t0 : 256;
-			for (int t = 0; t < m; ++t)
-			{
-				if (tfirst[t] && tile[t] < key) ++rank;
-			}
+#pragma unroll 16
+			for (int t = 0; t < 256; ++t) rank += tile[t] < key ? 1 : 0;
 		}
-		if (i < n)
+		if (i < n) W.pairRank[i] = rank;
+		// one add per wave, not per pair (hundreds of same-address atomics were most of this kernel's time)
 		{
-			W.pairRank[i] = rank;
-			if (W.pairFirst[i]) atomicAdd(&S->c.nNewContacts, 1);
+			const unsigned long long firsts = __ballot(i < n && W.pairFirst[i] != 0);
+			if (waveLane() == 0 && firsts) atomicAdd(&S->c.nNewContacts, __popcll(firsts));
 		}
 	}
 }

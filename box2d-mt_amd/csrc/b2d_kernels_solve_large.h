@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			}
 			W.li_color[s] = col;
 		}
-		(void)waveKeyedAlloc(W.colorCount, col < 0 ? 0 : col, valid && col >= 0);
+		(void)blockKeyedAlloc65(W.colorCount, col < 0 ? 0 : col, valid && col >= 0, false);
 	}
 	// needRecolor bit0: two constraints on one body share a colour -> colour everything again;
 	// nUncolored: constraints without a colour yet -> incremental rounds on top of the existing masks
@@ -429,7 +429,8 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 		const int s = base + threadIdx.x;
 		const bool valid = s < n && W.li_color[s] >= 0;
 		const int color = valid ? W.li_color[s] : 0;
-		const int slot = waveKeyedAlloc(W.colorCursor, color, valid);
+		// (exact-order mode has one group per dependency level, possibly thousands: keys beyond the LDS histogram)
+		const int slot = S->c.nColors > MAX_COLORS ? waveKeyedAlloc(W.colorCursor, color, valid) : blockKeyedAlloc65(W.colorCursor, color, valid, true);
 		if (valid)
 		{
 			const int p = W.colorStart[color] + slot;

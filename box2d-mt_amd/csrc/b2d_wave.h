@@ -146,4 +146,31 @@ __device__ __forceinline__ int waveKeyedAlloc(int* counter, int key, bool valid)
 	return result;
 }
 
+// The same for a whole 256-lane workgroup and keys in [0, 64]: ranks through an LDS histogram, then ONE global atomicAdd
+// per key that occurs, all of them in flight together (waveKeyedAlloc pays one atomic round trip per distinct key and
+// wave, one after the other: seven colours on the 10k-body pyramid made k_color_fill 24 us). Every thread of the
+// workgroup must call it (it contains barriers). `fetch` = false: only count (no slot returned).
+__device__ __forceinline__ int blockKeyedAlloc65(int* counter, int key, bool valid, bool fetch)
+{
+	__shared__ int s_cnt[65], s_base[65];
+	__syncthreads(); // a previous call's readers are done
+	if (threadIdx.x < 65) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	int local = 0;
+	if (valid) local = atomicAdd(&s_cnt[key], 1);
+	__syncthreads();
+	if (threadIdx.x < 65)
+	{
+		const int c = s_cnt[threadIdx.x];
+		if (c > 0)
+		{
+			if (fetch) s_base[threadIdx.x] = atomicAdd(&counter[threadIdx.x], c);
+			else atomicAdd(&counter[threadIdx.x], c);
+		}
+	}
+	if (!fetch) return 0;
+	__syncthreads();
+	return valid ? s_base[key] + local : 0;
+}
+
 #endif
