@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_toi_groups_begin(DW W)
 __global__ __launch_bounds__(256) void k_toi_group_contacts(DW W)
 {
 	DState* S = W.st;
-	if (S->c.toiUnsafe) return;
+	if (S->c.toiUnsafe || S->c.nToiGroups == 0) return;
 	const int nC = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nC; i += gridDim.x * blockDim.x)
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 	const ContactArrays& A = W.ca[S->cur];
 	const ContactArrays& B = W.ca[1 - S->cur];
 	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	if (!restore && S->c.nToiList == 0) return; // launched before the host knows whether any impact is pending
 	if (!restore)
 	{
 		for (int i = t0; i < W.nBodies; i += stride)
@@ -145,15 +146,14 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 
 // The event chain of one dynamic body: b2World::SolveTOI restricted to the contacts of D (all with static partners).
 // haveGrid = 0: the hash grid was not rebuilt for this phase, so a proxy leaving its fat AABB sends the phase to the serial loop.
-__global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp, int haveGrid)
+__device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, int haveGrid, int group)
 {
 	DState* S = W.st;
-	if ((int)blockIdx.x >= S->c.nToiGroups || (S->c.toiUnsafe & (TOI_UNSAFE_PARTNER | TOI_UNSAFE_CAPACITY))) return;
 	const ContactArrays& C = W.ca[S->cur];
 	const int lane = threadIdx.x;
-	const int D = W.toiGroups[blockIdx.x];
-	const int* adjL = W.toiGroupList + (size_t)blockIdx.x * CHAIN_ADJ_MAX;
-	const int nAdj = W.toiGroupCount[blockIdx.x] < CHAIN_ADJ_MAX ? W.toiGroupCount[blockIdx.x] : CHAIN_ADJ_MAX;
+	const int D = W.toiGroups[group];
+	const int* adjL = W.toiGroupList + (size_t)group * CHAIN_ADJ_MAX;
+	const int nAdj = W.toiGroupCount[group] < CHAIN_ADJ_MAX ? W.toiGroupCount[group] : CHAIN_ADJ_MAX;
 	const float4 massD = W.b_mass[D];
 
 	__shared__ int s_cand[CHAIN_CAND_MAX], s_sorted[CHAIN_CAND_MAX], s_info[CHAIN_CAND_MAX];
@@ -578,6 +578,20 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp,
 		if (s_events) atomicAdd(&S->c.nToiEvents, s_events);
 		if (s_calls) atomicAdd(&S->c.nToiCalls, s_calls);
 		if (s_unsafe) atomicOr(&S->c.toiUnsafe, s_unsafe);
+	}
+}
+
+// The launch does not know the number of chains (the host no longer waits for the census of k_toi_first): a fixed grid
+// of waves takes them in turn.
+__global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp, int haveGrid)
+{
+	DState* S = W.st;
+	if (S->c.toiUnsafe & (TOI_UNSAFE_PARTNER | TOI_UNSAFE_CAPACITY)) return;
+	const int nGroups = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
+	for (int group = blockIdx.x; group < nGroups; group += gridDim.x)
+	{
+		toiChainRun(W, sp, haveGrid, group);
+		__syncthreads();
 	}
 }
 

@@ -209,8 +209,9 @@ struct b2hip_world
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
+	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
-	bool toiCountersFresh = false;
+	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false;
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
 	int graphCaptures;
@@ -1237,7 +1238,52 @@ static int toiSerial(b2hip_world* w)
 
 // b2World::SolveTOI (b2World.cpp:1026-1093). The first arg-min pass runs over the whole contact array; the
 // event loop only runs (one persistent workgroup) when some impact lies inside the step.
+static int phaseToiSync(b2hip_world* w);
+
+// The phase without a host round trip: k_toi_first, then the chain kernels at once. Each of them leaves immediately if no
+// impact is pending (or if k_toi_first saw a bullet / kinematic partner: toiUnsafe), so the host learns the outcome from
+// the read-back b2hip_step_end makes anyway, and falls back there (snapshot restore + serial loop, or - when the pair
+// update had overflowed its optimistic small-sort path, so this phase did not see every contact - restore, finish the
+// contacts, and the synchronous phase). One read-back and ~45 us less per step with continuous physics on.
 static int phaseToi(b2hip_world* w)
+{
+	if (w->toiSerialOnly || w->toiSyncOnly) return phaseToiSync(w);
+	if (w->toiSyncSticky > 0)
+	{
+		// the serial loop was needed recently (bullets, kinematic partners, contact-creating events): decide from the
+		// read-back again instead of paying a wasted snapshot + state download per step
+		int rc = phaseToiSync(w);
+		if (rc) return rc;
+		if (w->h_dstate->c.nToiList == 0 || (w->toiChains && w->h_dstate->c.toiUnsafe == 0)) w->toiSyncSticky -= 1;
+		else w->toiSyncSticky = 16;
+		return 0;
+	}
+	DW& d = w->dw;
+	if (!w->toiCountersFresh)
+	{
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nToiList, 0, sizeof(int) * 5, w->stream));
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
+	}
+	w->toiCountersFresh = false;
+	LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
+	const int haveGrid = w->toiGridSticky > 0 ? 1 : 0;
+	LAUNCH(w, k_toi_groups_begin, gridFor(std::min(d.capContacts, 1 << 16)), 256, d);
+	LAUNCH(w, k_toi_group_contacts, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+	if (haveGrid)
+	{
+		int rc = toiBuildIndexes(w, false);
+		if (rc) return rc;
+	}
+	LAUNCH(w, k_toi_chains, 1024, CHAIN_LANES, d, w->sp, haveGrid);
+	LAUNCH(w, k_toi_chains_end, 1, 256, d);
+	LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+	w->toiChains = true;
+	w->toiSpeculative = true;
+	return 0;
+}
+
+static int phaseToiSync(b2hip_world* w)
 {
 	DW& d = w->dw;
 	// one read-back serves both questions: did the optimistic small-sort path of the end-of-step pair update
@@ -1282,7 +1328,7 @@ static int phaseToi(b2hip_world* w)
 			rc = toiBuildIndexes(w, false);
 			if (rc) return rc;
 		}
-		LAUNCH(w, k_toi_chains, groups, CHAIN_LANES, d, w->sp, haveGrid);
+		LAUNCH(w, k_toi_chains, std::min(groups, 1024), CHAIN_LANES, d, w->sp, haveGrid);
 		LAUNCH(w, k_toi_chains_end, 1, 256, d);
 		LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
 		w->toiChains = true;
@@ -1417,6 +1463,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	if (const char* e = getenv("B2HIP_DF_SLEEP")) w->dfSleep = atoi(e);
 	w->toiChains = false;
 	w->toiSerialOnly = getenv("B2HIP_TOI_SERIAL") != nullptr;
+	w->toiSyncOnly = getenv("B2HIP_TOI_SYNC") != nullptr; // decide chains / serial loop from a read-back after k_toi_first (the older flow)
 	w->toiFallbacks = 0;
 	for (int i = 0; i < 13; ++i)
 	{
@@ -1784,6 +1831,7 @@ int b2hip_solve_toi(b2hip_world* w)
 	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve_toi outside a step");
 	w->toiRan = false;
 	w->toiChains = false;
+	w->toiSpeculative = false;
 	w->last.nToiList = w->last.nToiCalls = w->last.nToiEvents = 0;
 	if (w->def.continuous && w->sp.dt > 0.0f)
 	{
@@ -1806,11 +1854,33 @@ int b2hip_step_end(b2hip_world* w)
 	{
 		if (w->h_dstate->c.nPairs > COUNT_RANK_MAX)
 		{
+			const bool redoToi = w->toiSpeculative;
+			if (redoToi && w->h_dstate->c.nToiList > 0)
+			{
+				// the TOI phase ran without the contacts that are created only now: undo it
+				LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+			}
 			rc = runSortAndCreate(w, true);
 			if (rc) return rc;
+			if (redoToi)
+			{
+				w->toiChains = false;
+				w->toiSpeculative = false;
+				rc = phaseToiSync(w);
+				if (rc) return rc;
+			}
 			rc = downloadState(w);
 			if (rc) return rc;
 		}
+	}
+	if (w->toiSpeculative)
+	{
+		const Counters& tc = w->h_dstate->c;
+		if (tc.nToiList > w->dw.capContacts) return setError(B2HIP_ERR_CAPACITY, "TOI list overflow");
+		w->last.nToiList = tc.nToiList;
+		w->last.nToiCalls = tc.nToiCalls;
+		w->toiRan = tc.nToiList > 0;
+		if (tc.nToiList == 0) w->toiChains = false;
 	}
 	if (w->toiChains)
 	{
@@ -1824,6 +1894,7 @@ int b2hip_step_end(b2hip_world* w)
 		rc = toiSerial(w);
 		if (rc) return rc;
 		w->toiFallbacks += 1;
+		w->toiSyncSticky = 16;
 		rc = downloadState(w);
 		if (rc) return rc;
 	}
