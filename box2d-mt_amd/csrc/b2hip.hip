@@ -209,6 +209,8 @@ struct b2hip_world
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
+	int constsUploaded[2] = { -1, -1 };
+	int* constsUploadedAt = nullptr;
 	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
 	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false;
@@ -805,11 +807,18 @@ static int flushEdits(b2hip_world* w)
 		HIP_TRY(hipStreamSynchronize(s));
 		w->pendingMoves.clear();
 	}
-	int consts[4] = { (int)w->bodies.size(), (int)(w->dw.gridMask + 1), 0, 0 };
-	HIP_TRY(hipMemcpyAsync(w->consts.p, consts, sizeof(int) * 2, hipMemcpyHostToDevice, s));
-	int nb1 = (int)w->bodies.size() + 1; // scan length of the TOI adjacency (nBodies + 1 so that adjStart[nBodies] is the total)
-	HIP_TRY(hipMemcpyAsync(w->consts.p + 4, &nb1, sizeof(int), hipMemcpyHostToDevice, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	// scan lengths that live on the device: uploaded when they change, not every step
+	const int consts[3] = { (int)w->bodies.size(), (int)(w->dw.gridMask + 1), (int)w->bodies.size() + 1 };
+	if (consts[0] != w->constsUploaded[0] || consts[1] != w->constsUploaded[1] || w->consts.p != w->constsUploadedAt)
+	{
+		HIP_TRY(hipMemcpyAsync(w->consts.p, consts, sizeof(int) * 2, hipMemcpyHostToDevice, s));
+		// [4]: scan length of the TOI adjacency (nBodies + 1 so that adjStart[nBodies] is the total)
+		HIP_TRY(hipMemcpyAsync(w->consts.p + 4, &consts[2], sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		w->constsUploaded[0] = consts[0];
+		w->constsUploaded[1] = consts[1];
+		w->constsUploadedAt = w->consts.p;
+	}
 	return 0;
 }
 
