@@ -176,7 +176,7 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 		else { pA = staticPosA; vA.v = v2(0, 0); vA.w = 0; }
 		if (lb >= 0) { float4 p = s_pos[lb], v = s_vel[lb]; pB.c = v2(p.x, p.y); pB.a = p.z; vB.v = v2(v.x, v.y); vB.w = v.z; }
 		else { pB = staticPosB; vB.v = v2(0, 0); vB.w = 0; }
-		b2dInitConstraint(&cc, &mf, cmat.x, cmat.y, cmat.z,
+		b2dInitConstraint<true>(&cc, &mf, cmat.x, cmat.y, cmat.z,
 			mA4.x, mA4.y, v2(mA4.z, mA4.w), radiusA,
 			mB4.x, mB4.y, v2(mB4.z, mB4.w), radiusB,
 			pA, vA, pB, vB, sp.warmStarting != 0, sp.dtRatio);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 				if (la >= 0) { float4 p = s_pos[la]; pA.c = v2(p.x, p.y); pA.a = p.z; } else pA = staticPosA;
 				if (lb >= 0) { float4 p = s_pos[lb]; pB.c = v2(p.x, p.y); pB.a = p.z; } else pB = staticPosB;
 				float minSep = 0.0f;
-				b2dSolvePosition(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
+				b2dSolvePosition<true>(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
 				if (la >= 0) s_pos[la] = make_float4(pA.c.x, pA.c.y, pA.a, 0.0f);
 				if (lb >= 0) s_pos[lb] = make_float4(pB.c.x, pB.c.y, pB.a, 0.0f);
 				// minSep <= 0: track max of (0 - minSep) as unsigned bits (monotone for non-negative floats;

@@ -267,6 +267,15 @@ __device__ __noinline__ static Rot b2dRotOutOfLine(float angle)
 }
 #endif
 
+// The inlined form, for the one place where throughput matters more than code size (k_solve_small's position sweeps).
+B2D_HD Rot b2dRotInline(float angle)
+{
+	Rot q;
+	q.s = b2dSin(angle);
+	q.c = b2dCos(angle);
+	return q;
+}
+
 B2D_HD Rot b2dRot(float angle)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -45,6 +45,7 @@ struct ContactConstraint
 
 // b2ContactSolver::b2ContactSolver (b2ContactSolver.cpp:47-133) + InitializeVelocityConstraints (:142-251)
 // posA/posB, velA/velB are the island state AFTER velocity integration and BEFORE warm starting.
+template <bool INLINE_ROT = false>
 B2D_HD void b2dInitConstraint(ContactConstraint* cc, const Manifold* mf,
 	float friction, float restitution, float tangentSpeed,
 	float invMassA, float invIA, V2 localCenterA, float radiusA,
@@ -99,8 +100,8 @@ B2D_HD void b2dInitConstraint(ContactConstraint* cc, const Manifold* mf,
 	float wA = velA.w, wB = velB.w;
 
 	Xf xfA, xfB;
-	xfA.q = b2dRot(aA);
-	xfB.q = b2dRot(aB);
+	xfA.q = INLINE_ROT ? b2dRotInline(aA) : b2dRot(aA);
+	xfB.q = INLINE_ROT ? b2dRotInline(aB) : b2dRot(aB);
 	xfA.p = cA - b2dMulRV(xfA.q, localCenterA);
 	xfB.p = cB - b2dMulRV(xfB.q, localCenterB);
 
@@ -347,6 +348,8 @@ B2D_HD void b2dSolveVelocity(ContactConstraint* cc, BodyVel* A, BodyVel* B)
 // b2ContactSolver::SolvePositionConstraints (b2ContactSolver.cpp:676-752) with
 // b2PositionSolverManifold::Initialize (:620-673), one constraint. Returns its min separation
 // (starting from 0, as the reference's running minimum does).
+// INLINE_ROT: expand the sin/cos pair in place instead of calling the out-of-line copy (see b2dRot).
+template <bool INLINE_ROT = false>
 B2D_HD float b2dSolvePosition(const ContactConstraint* cc, BodyPos* A, BodyPos* B, float baumgarte, float* minSepInOut)
 {
 	V2 localCenterA = cc->localCenterA, localCenterB = cc->localCenterB;
@@ -359,8 +362,8 @@ B2D_HD float b2dSolvePosition(const ContactConstraint* cc, BodyPos* A, BodyPos* 
 	for (int j = 0; j < pointCount; ++j)
 	{
 		Xf xfA, xfB;
-		xfA.q = b2dRot(aA);
-		xfB.q = b2dRot(aB);
+		xfA.q = INLINE_ROT ? b2dRotInline(aA) : b2dRot(aA);
+		xfB.q = INLINE_ROT ? b2dRotInline(aB) : b2dRot(aB);
 		xfA.p = cA - b2dMulRV(xfA.q, localCenterA);
 		xfB.p = cB - b2dMulRV(xfB.q, localCenterB);
 
