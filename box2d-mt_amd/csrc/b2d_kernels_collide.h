@@ -5,6 +5,7 @@
 #define B2D_KERNELS_COLLIDE_H
 
 #include "b2d_world.h"
+#include "b2d_toi.h"
 
 __device__ __forceinline__ Xf loadXf(const float4* b_xf, int body)
 {
@@ -129,8 +130,17 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 				mf.id[1] = oldId1;
 				if (sensor)
 				{
-					// TODO(next): GJK b2TestOverlap for sensors; sensors never enter the solver.
-					touching = false;
+					// b2Contact::Update, sensor branch (b2Contact.cpp:193-202): touching = b2TestOverlap (b2Collision.cpp:233-252),
+					// GJK distance with the shape radii below 10 epsilon; no manifold. Sensors never enter the solver.
+					const GjkProxy pA = b2dProxy(W.shapes + W.p_shape[proxyA]);
+					const GjkProxy pB = b2dProxy(W.shapes + W.p_shape[proxyB]);
+					GjkCache cache;
+					cache.count = 0;
+					cache.metric = 0.0f;
+					for (int k = 0; k < 3; ++k) cache.indexA[k] = cache.indexB[k] = 0;
+					GjkOutput dist;
+					b2dDistance(dist, cache, pA, loadXf(W.b_xf, bodyA), pB, loadXf(W.b_xf, bodyB), true);
+					touching = dist.distance < 10.0f * B2D_EPSILON;
 					mf.pointCount = 0;
 				}
 				else

@@ -6,7 +6,7 @@
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
  * (b2ContactManager.cpp:366-386). Joints: revolute (b2o_joint.c). Not covered (same as the device
- * path): other joint types, chain shapes, sensors' GJK overlap. Continuous collision: b2o_toi.c
+ * path): other joint types, chain shapes. Continuous collision: b2o_toi.c
  * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
 #include "b2o_internal.h"
@@ -619,7 +619,17 @@ static void contact_update(b2o_world* w, contact_t* c)
 	int touching = 0;
 	if (fA->isSensor || fB->isSensor)
 	{
-		c->m.pointCount = 0; /* GJK overlap for sensors is outside the oracle's scope */
+		/* b2Contact::Update, sensor branch (b2Contact.cpp:193-202): touching = b2TestOverlap (b2Collision.cpp:233-252),
+		 * i.e. GJK distance with the shape radii < 10 * epsilon; sensors generate no manifold */
+		gjk_proxy pA, pB;
+		b2o_proxy_set(&pA, &fA->shape);
+		b2o_proxy_set(&pB, &fB->shape);
+		gjk_cache cache;
+		memset(&cache, 0, sizeof(cache));
+		gjk_output out;
+		b2o_distance(&out, &cache, &pA, w->bodies[c->bodyA].xf, &pB, w->bodies[c->bodyB].xf, 1);
+		touching = out.distance < 10.0f * B2O_EPSILON;
+		c->m.pointCount = 0;
 	}
 	else
 	{

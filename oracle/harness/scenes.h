@@ -68,6 +68,8 @@ enum SceneId
 	e_piles = 4,         // p0 = piles, p1 = boxes per pile
 	e_rain = 5,          // p0 = bodies (mixed circles / boxes / polygons dropped on a box ground)
 	e_circleStack = 6,   // p0 = columns, p1 = circles per column, on an edge ground
+	e_sensors = 8,       // p0 = falling bodies ; static sensor regions (box, circle, polygon) + one dynamic body that carries
+	                     //   a proximity sensor: exercises b2Contact::Update's sensor branch (b2TestOverlap = GJK with radii)
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -447,6 +449,75 @@ inline void BuildCircleStack(Scene& s, b2World* w, int columns, int height)
 	}
 }
 
+// Sensors: bodies rain through static sensor regions onto an edge ground; one dynamic "probe" carries a solid box and a
+// larger circular proximity sensor. Sensor contacts never enter the solver; their touching flag is b2TestOverlap.
+inline void BuildSensors(Scene& s, b2World* w, int count, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	Pcg32 rng(seed ? seed : 11u);
+	{
+		b2BodyDef bd;
+		b2Body* ground = AddBody(s, w, bd);
+		b2EdgeShape edge;
+		edge.Set(b2Vec2(-30.0f, 0.0f), b2Vec2(30.0f, 0.0f));
+		ground->CreateFixture(&edge, 0.0f);
+		b2FixtureDef fd;
+		fd.isSensor = true;
+		b2PolygonShape zone;
+		zone.SetAsBox(6.0f, 1.0f, b2Vec2(-8.0f, 6.0f), 0.2f);
+		fd.shape = &zone;
+		ground->CreateFixture(&fd);
+		b2CircleShape disc;
+		disc.m_radius = 2.5f;
+		disc.m_p.Set(6.0f, 5.0f);
+		fd.shape = &disc;
+		ground->CreateFixture(&fd);
+		b2Vec2 tri[3] = { b2Vec2(-2.0f, 1.0f), b2Vec2(3.0f, 1.5f), b2Vec2(0.5f, 4.0f) };
+		b2PolygonShape wedge;
+		wedge.Set(tri, 3);
+		fd.shape = &wedge;
+		ground->CreateFixture(&fd);
+	}
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(0.0f, 9.0f);
+		bd.angularVelocity = 1.0f;
+		b2Body* probe = AddBody(s, w, bd);
+		b2PolygonShape core;
+		core.SetAsBox(0.4f, 0.4f);
+		probe->CreateFixture(&core, 2.0f);
+		b2CircleShape halo;
+		halo.m_radius = 1.5f;
+		b2FixtureDef fd;
+		fd.shape = &halo;
+		fd.isSensor = true;
+		fd.density = 0.0f;
+		probe->CreateFixture(&fd);
+	}
+	for (int i = 0; i < count; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(rng.Range(-14.0f, 10.0f), 8.0f + 1.2f * (float)(i / 6) + rng.Range(0.0f, 0.5f));
+		bd.angle = rng.Range(0.0f, 2.0f * b2_pi);
+		bd.linearVelocity.Set(rng.Range(-2.0f, 2.0f), rng.Range(-3.0f, 0.0f));
+		b2Body* body = AddBody(s, w, bd);
+		if (i % 3 == 0)
+		{
+			b2CircleShape ball;
+			ball.m_radius = rng.Range(0.2f, 0.45f);
+			body->CreateFixture(&ball, 1.0f);
+		}
+		else
+		{
+			b2PolygonShape box;
+			box.SetAsBox(rng.Range(0.2f, 0.5f), rng.Range(0.2f, 0.4f));
+			body->CreateFixture(&box, 1.0f);
+		}
+	}
+}
+
 // Continuous-collision stress: a 40 x 30 room made of an edge floor and thin (0.1 wide) polygon walls, a few
 // box stacks inside, and fast small projectiles (polygons and circles; every other one is a bullet body)
 // fired through it. Fast non-bullet bodies still get TOI against the static walls; bullets also against the stacks.
@@ -529,6 +600,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_rain: BuildRain(s, w, p.p0, p.seed); break;
 	case e_circleStack: BuildCircleStack(s, w, p.p0, p.p1); break;
 	case e_bullets: BuildBullets(s, w, p.p0, p.p1, p.seed); break;
+	case e_sensors: BuildSensors(s, w, p.p0, p.seed); break;
 	default: break;
 	}
 }

@@ -34,6 +34,7 @@ SCENES = [
     ("field", bh.FIELD, 1500, 0, 0.0, 0.0, 7, 100),
     ("tumbler6", bh.TUMBLER, 6, 0, 0.0, 0.0, 1, 300),
     ("tumbler20", bh.TUMBLER, 20, 0, 0.0, 0.0, 1, 150),
+    ("sensors", bh.SENSORS, 40, 0, 0.0, 0.0, 5, 240),
     ("pyramid141", bh.PYRAMID, 141, 1, 0.0, 0.0, 1, 30),
 ]
 
