@@ -193,6 +193,16 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 
 		if (!keep)
 		{
+			if (W.eventsOn && (flags & CF_REPORTED))
+			{
+				// b2ContactManager::Destroy (b2ContactManager.cpp:104-107): a touching contact ends when it is destroyed
+				const int e = atomicAdd(&S->c.nEvents, 1);
+				if (e < W.capContacts)
+				{
+					W.evKey[e] = C.key[i];
+					W.evInfo[e] = make_int4(proxyA, proxyB, 1, -1);
+				}
+			}
 			flags |= CF_DESTROY;
 			++nDestroy;
 			if (flags & CF_TOI_CANDIDATE) W.toiDestroyList[atomicAdd(&S->c.nToiDestroy, 1)] = i;
@@ -217,6 +227,32 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 
 // b2World::CreateJoint with collideConnected == false flags the contacts between the two bodies for
 // re-filtering at the next step (b2World.cpp:716-732).
+// Contact events (the begin / end half of the b2ContactListener bridge): once per step, after the last
+// phase, every contact whose touching state differs from what the host was last told yields one event and flips its
+// CF_REPORTED bit; contacts destroyed while reported yield their end event in k_collide. The host sorts them by proxy-key
+// pair, begins first (the order of b2ContactManager::Collide's deferred callbacks, b2ContactManager.cpp:420-438). One
+// net event per contact and step: a begin + end inside one step (possible through TOI sub-steps) cancels out.
+__global__ __launch_bounds__(256) void k_contact_events(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		const uint32_t flags = C.flags[i];
+		const bool touching = (flags & CF_TOUCHING) != 0, reported = (flags & CF_REPORTED) != 0;
+		if (touching == reported) continue;
+		C.flags[i] = flags ^ CF_REPORTED;
+		const int e = atomicAdd(&S->c.nEvents, 1);
+		if (e < W.capContacts)
+		{
+			const int4 ids = C.ids[i];
+			W.evKey[e] = C.key[i];
+			W.evInfo[e] = make_int4(ids.x, ids.y, touching ? 0 : 1, i);
+		}
+	}
+}
+
 // Per-step counters back to zero (one launch instead of a handful of memsets); `bar` = the resident solver's grid barrier.
 __global__ void k_step_begin(DW W, int* bar)
 {
@@ -229,6 +265,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.nPairs = 0;
 		(&c.nPairs)[1] = 0;
 		c.overflow = 0;
+		c.nEvents = 0;
 		c.nToiList = 0;
 		c.nToiEvents = 0;
 		c.nToiCalls = 0;

@@ -39,6 +39,7 @@
 #define CF_TOI 0x80u           // ContactArrays::mat.w holds a valid time of impact
 #define CF_TOI_LISTED 0x100u   // already in DW::toiList
 #define CF_TOI_PENDING 0x200u  // claimed for recomputation by the running TOI pass
+#define CF_REPORTED 0x400u     // contact events on: the host has been told that this contact touches (k_contact_events)
 #define CF_TOI_COUNT_SHIFT 12  // bits 12..15: m_toiCount (0..9)
 #define CF_TOI_COUNT_MASK 0xf000u
 #define CF_TOI_STATE_MASK (CF_TOI | CF_TOI_LISTED | CF_TOI_PENDING | CF_TOI_COUNT_MASK)
@@ -103,6 +104,7 @@ struct Counters
 	int toiUnsafe;       // the parallel TOI chains met a case only the serial event loop reproduces (bits: b2d_kernels_toi_chains.h)
 	int nToiGroups;      // dynamic bodies with a pending impact
 	int nToiMoved;       // proxies re-inserted by the TOI chains
+	int nEvents;         // contact events of this step (DW::evKey / evInfo), see k_contact_events
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
 	int nCompact;        // entries of DW::compactList (constraints of the colour class under compaction this step)
 	int compactClass;    // persistent: colour class whose constraints may move to a lower free colour this step
@@ -216,6 +218,9 @@ struct DW
 	uint32_t* bodyClaim;
 	uint64_t* bodyColorMask;
 	uint64_t* bodyActive;   // per body: colours of its constraints in THIS step's large-island solve (dataflow solver)
+	int eventsOn;           // contact events requested by the host (b2hip_enable_contact_events)
+	unsigned long long* evKey; // per event: proxy-key pair of the contact (the reference's deferred-callback sort key)
+	int4* evInfo;           // per event: (fixtureA, fixtureB, kind 0 = begin / 1 = end, contact index or -1 if destroyed)
 	int* dfRank;            // per body: DF_RANKS mailbox slots, [rank] = slot of the body's rank-th constraint (k_solve_mailbox)
 	float4* dfInbox;        // per large-island constraint row: two tagged 16-byte slots (body A, body B)
 	float4* b_posv;         // per body: (c.xy, a, version) rows of the dataflow solver's position phase

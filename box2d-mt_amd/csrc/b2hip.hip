@@ -175,6 +175,10 @@ struct b2hip_world
 	DevArray<uint64_t> bodyColorMask, bodyActive;
 	DevArray<float4> b_posv, dfInbox;
 	DevArray<int> dfRank;
+	DevArray<unsigned long long> evKey;
+	DevArray<int4> evInfo;
+	bool eventsOn = false;
+	std::vector<b2hip_contact_event> events; // of the last step, in delivery order
 	DevArray<int> uncolList, compactList, hubRowOf, hubList;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
@@ -562,7 +566,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -627,7 +631,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
@@ -1520,7 +1524,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
-	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release();
+	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
@@ -1907,6 +1911,40 @@ int b2hip_step_end(b2hip_world* w)
 		rc = downloadState(w);
 		if (rc) return rc;
 	}
+	w->events.clear();
+	if (w->eventsOn)
+	{
+		// after every fallback has had its say: one pass over the contacts, then the (usually short) list comes back
+		LAUNCH(w, k_contact_events, gridFor(w->dw.capContacts), 256, w->dw);
+		int nEv = 0;
+		HIP_TRY(hipMemcpyAsync(&nEv, &w->d_state.p->c.nEvents, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		if (nEv > w->dw.capContacts) return setError(B2HIP_ERR_CAPACITY, "contact event buffer overflow");
+		if (nEv > 0)
+		{
+			std::vector<unsigned long long> keys(nEv);
+			std::vector<int4> info(nEv);
+			HIP_TRY(hipMemcpy(keys.data(), w->evKey.p, nEv * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(info.data(), w->evInfo.p, nEv * sizeof(int4), hipMemcpyDeviceToHost));
+			std::vector<int> order(nEv);
+			for (int i = 0; i < nEv; ++i) order[i] = i;
+			// begins before ends, each group by proxy-id pair (b2ContactManager.cpp:420-438, b2ContactPointerLessThan :64-67)
+			std::sort(order.begin(), order.end(), [&](int a, int b)
+			{
+				if (info[a].z != info[b].z) return info[a].z < info[b].z;
+				return keys[a] < keys[b];
+			});
+			w->events.resize(nEv);
+			for (int i = 0; i < nEv; ++i)
+			{
+				const int4 q = info[order[i]];
+				w->events[i].fixture_a = q.x;
+				w->events[i].fixture_b = q.y;
+				w->events[i].kind = q.z;
+				w->events[i].contact_index = q.w;
+			}
+		}
+	}
 	HIP_TRY(hipEventRecord(w->ev[11], w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	refreshMirror(w);
@@ -2032,6 +2070,24 @@ int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state
 int b2hip_contact_count(b2hip_world* w)
 {
 	return w ? w->lastContacts : 0;
+}
+
+int b2hip_enable_contact_events(b2hip_world* w, int enable)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_enable_contact_events inside a step");
+	w->eventsOn = enable != 0;
+	w->dw.eventsOn = w->eventsOn ? 1 : 0;
+	w->events.clear();
+	return B2HIP_OK;
+}
+
+int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
+{
+	if (!w || (cap > 0 && !out)) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int n = (int)w->events.size();
+	for (int i = 0; i < n && i < cap; ++i) out[i] = w->events[i];
+	return n;
 }
 
 int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)

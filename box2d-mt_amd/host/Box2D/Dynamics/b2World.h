@@ -35,7 +35,9 @@ public:
 
 	void SetDestructionListener(b2DestructionListener* listener) { m_destructionListener = listener; }
 	void SetContactFilter(b2ContactFilter* filter) { m_contactFilter = filter; }
-	void SetContactListener(b2ContactListener* listener) { m_contactListener = listener; }
+	/// BeginContact / EndContact are delivered at the end of Step() (one net event per contact and step, begins before
+	/// ends, each in proxy-id order); PreSolve / PostSolve are not bridged yet.
+	void SetContactListener(b2ContactListener* listener);
 
 	b2Body* CreateBody(const b2BodyDef* def);
 	b2Joint* CreateJoint(const b2JointDef* def);
@@ -81,6 +83,7 @@ private:
 	friend class b2Body;
 	friend class b2Fixture;
 	friend class b2Contact;
+	void DeliverContactEvents();
 
 	void PushFlags();
 	const b2hip_body_state& State(int32 id) const;

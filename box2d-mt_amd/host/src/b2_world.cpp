@@ -214,6 +214,7 @@ void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIteration
 	}
 	m_statesValid = false;
 	m_contactsValid = false;
+	DeliverContactEvents();
 	float ms[13];
 	if (b2hip_get_profile(m_hip, ms) == B2HIP_OK)
 	{
@@ -230,6 +231,51 @@ void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIteration
 		m_profile.broadphaseSyncFixtures = ms[10];
 		m_profile.broadphaseFindContacts = ms[11];
 		m_profile.locking = ms[12];
+	}
+}
+
+void b2World::SetContactListener(b2ContactListener* listener)
+{
+	m_contactListener = listener;
+	if (m_hip) (void)b2hip_enable_contact_events(m_hip, listener != nullptr ? 1 : 0);
+}
+
+// b2ContactManager::Collide's deferred callbacks (b2ContactManager.cpp:420-438), fed from the device's event list.
+void b2World::DeliverContactEvents()
+{
+	if (!m_hip || !m_contactListener) return;
+	int count = b2hip_get_contact_events(m_hip, 0, nullptr);
+	if (count <= 0) return;
+	std::vector<b2hip_contact_event> ev(count);
+	count = b2hip_get_contact_events(m_hip, count, ev.data());
+	(void)GetContactList(); // views of this step's contacts, newest first
+	const int n = (int)m_contactViews.size();
+	for (int i = 0; i < count; ++i)
+	{
+		const b2hip_contact_event& e = ev[i];
+		b2Contact gone; // the view of a contact that no longer exists (its end event)
+		b2Contact* c = nullptr;
+		if (e.contact_index >= 0 && e.contact_index < n) c = &m_contactViews[n - 1 - e.contact_index];
+		else
+		{
+			memset(&gone.m_manifold, 0, sizeof(gone.m_manifold));
+			gone.m_fixtureA = m_fixtures[e.fixture_a];
+			gone.m_fixtureB = m_fixtures[e.fixture_b];
+			gone.m_next = nullptr;
+			gone.m_friction = 0.0f;
+			gone.m_restitution = 0.0f;
+			gone.m_touching = false;
+			gone.m_enabled = true;
+			c = &gone;
+		}
+		if (e.kind == 0)
+		{
+			if (m_contactListener->BeginContactImmediate(c, 0)) m_contactListener->BeginContact(c);
+		}
+		else
+		{
+			if (m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
+		}
 	}
 }
 

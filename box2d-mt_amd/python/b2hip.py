@@ -90,6 +90,8 @@ def _configure(L, optional_ok=False):
         "b2hip_get_body_states": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
         "b2hip_contact_count": [C.c_void_p],
         "b2hip_get_contacts": [C.c_void_p, C.c_int, C.c_void_p],
+        "b2hip_enable_contact_events": [C.c_void_p, C.c_int],
+        "b2hip_get_contact_events": [C.c_void_p, C.c_int, C.c_void_p],
         "b2hip_get_island_labels": [C.c_void_p, C.c_int, C.c_void_p],
         "b2hip_get_fat_aabb": [C.c_void_p, C.c_int, C.POINTER(C.c_float)],
         "b2hip_get_profile": [C.c_void_p, C.POINTER(C.c_float)],
@@ -238,6 +240,16 @@ class World:
         cap = max(self.contact_count, 1)
         out = np.zeros(cap, CONTACT_DTYPE)
         n = _check(self.L.b2hip_get_contacts(self.p, cap, out.ctypes.data_as(C.c_void_p)))
+        return out[:n]
+
+    def enable_contact_events(self, enable=True):
+        _check(self.L.b2hip_enable_contact_events(self.p, 1 if enable else 0))
+
+    def contact_events(self):
+        """Begin / end events of the last step: rows (fixture_a, fixture_b, kind 0 begin / 1 end, contact_index or -1)."""
+        n = _check(self.L.b2hip_get_contact_events(self.p, 0, None))
+        out = np.zeros((max(n, 1), 4), np.int32)
+        n = _check(self.L.b2hip_get_contact_events(self.p, n, out.ctypes.data_as(C.c_void_p)))
         return out[:n]
 
     def island_labels(self):

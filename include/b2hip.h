@@ -18,6 +18,7 @@
  *   b2hip_find_new_contacts          b2World::FindNewContacts / b2BroadPhase::UpdatePairs / AddPair
  *                                                                                       b2World.cpp:1095-1118, b2BroadPhase.h:211-267, b2ContactManager.cpp:237-312,366-386
  *   b2hip_get_body_states            b2Body::GetPosition/GetAngle/GetLinearVelocity/GetAngularVelocity/IsAwake  b2Body.h:516-700
+ *   b2hip_enable/get_contact_events  b2ContactListener::BeginContact / EndContact     b2WorldCallbacks.h:88-104, b2ContactManager.cpp:420-438
  *   b2hip_get_contacts               b2World::GetContactList + b2Contact::GetManifold  b2World.h:352-360, b2Contact.h:95-163
  *   b2hip_get_profile                b2World::GetProfile                    b2World.h:196-197, b2TimeStep.h:25-40
  *
@@ -208,6 +209,23 @@ int b2hip_step_end(b2hip_world* w);
 int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state* out);
 int b2hip_contact_count(b2hip_world* w);
 int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out);
+
+/* Contact events: the BeginContact / EndContact half of b2ContactListener (b2WorldCallbacks.h:88-174; generation sites
+ * b2Contact.cpp:253-297, b2ContactManager.cpp:104-107; delivery order b2ContactManager.cpp:420-438). When enabled, every
+ * step ends with the list of contacts whose touching state changed since the host was last told: all begins in
+ * proxy-id-pair order, then all ends in proxy-id-pair order (the order in which the reference delivers its deferred
+ * callbacks). One net event per contact and step: a contact that begins AND ends inside one step (continuous-collision
+ * sub-steps) produces none, where the reference may call both. `contact_index` = index into b2hip_get_contacts of the
+ * same step, or -1 when the contact was destroyed (its end event). Sensors report like any contact. */
+typedef struct b2hip_contact_event
+{
+	int32_t fixture_a, fixture_b;
+	int32_t kind;              /* 0 = begin, 1 = end */
+	int32_t contact_index;
+} b2hip_contact_event;
+int b2hip_enable_contact_events(b2hip_world* w, int enable);
+/* returns the number of events of the last step (negative on error); at most `cap` are written */
+int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out);
 /* Island label per body for the last step: -1 = not solved (asleep / static), else the smallest body id
  * of the island (island membership is compared as a set partition). */
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out);

@@ -86,6 +86,16 @@ void b2o_get_body_states(const b2o_world* w, float* out10);
 void b2o_get_mass(const b2o_world* w, int body, float* mass, float* inertia, float* lcx, float* lcy);
 int b2o_contact_count(const b2o_world* w);
 int b2o_get_contacts(const b2o_world* w, int cap, b2o_contact* out);
+
+/* BeginContact / EndContact events of the last step (same layout and semantics as b2hip_contact_event, include/b2hip.h) */
+typedef struct b2o_contact_event
+{
+	int32_t fixture_a, fixture_b;
+	int32_t kind;          /* 0 = begin, 1 = end */
+	int32_t contact_index; /* into b2o_get_contacts of the same step, -1 = destroyed */
+} b2o_contact_event;
+void b2o_enable_contact_events(b2o_world* w, int enable);
+int b2o_get_contact_events(const b2o_world* w, int cap, b2o_contact_event* out);
 /* island label per body of the last step (-1 = not solved): smallest body id of its island */
 void b2o_get_island_labels(const b2o_world* w, int32_t* out);
 void b2o_get_fat_aabb(const b2o_world* w, int fixture, float out4[4]);

@@ -111,6 +111,17 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 	return b2o_get_contacts(w->o, cap, (b2o_contact*)out); /* identical layout */
 }
 
+int b2hip_enable_contact_events(b2hip_world* w, int enable)
+{
+	b2o_enable_contact_events(w->o, enable);
+	return 0;
+}
+
+int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
+{
+	return b2o_get_contact_events(w->o, cap, (b2o_contact_event*)out); /* identical layout */
+}
+
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out)
 {
 	(void)cap;

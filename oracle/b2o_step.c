@@ -82,6 +82,7 @@ typedef struct
 	float toi;
 	int toiCount;
 	int managerIndex; /* position in b2o_world::carray (b2Contact::m_managerIndex) */
+	int reported;     /* contact events: the host has been told that this contact touches */
 } contact_t;
 
 /* b2VelocityConstraintPoint / b2ContactVelocityConstraint / b2ContactPositionConstraint
@@ -121,6 +122,10 @@ struct b2o_world
 	/* b2ContactManager::m_contacts: TOI candidates first ([0, toiCount)), maintained by swaps */
 	int* carray; int nArr, capArr, toiCount;
 	int toiEvents, toiCalls; /* TOI sub-steps solved / b2TimeOfImpact calls so far (diagnostics) */
+	/* contact events of the last step (b2ContactListener::BeginContact / EndContact, one net event per contact and step) */
+	int eventsOn;
+	b2o_contact_event* events; int nEvents, capEvents;
+	uint64_t* eventKeys; int capEventKeys;
 };
 
 #define GROW(ptr, cap, need, type)                                            \
@@ -559,9 +564,25 @@ static void create_contact(b2o_world* w, int fLo, int fHi)
 }
 
 /* b2ContactManager::Destroy (:120-172) + b2Contact::Destroy (b2Contact.cpp:100-123) */
+static void push_event(b2o_world* w, const contact_t* c, int kind, int index)
+{
+	GROW(w->events, w->capEvents, w->nEvents + 1, b2o_contact_event);
+	GROW(w->eventKeys, w->capEventKeys, w->nEvents + 1, uint64_t);
+	b2o_contact_event* e = &w->events[w->nEvents];
+	e->fixture_a = c->fixtureA;
+	e->fixture_b = c->fixtureB;
+	e->kind = kind;
+	e->contact_index = index;
+	w->eventKeys[w->nEvents] = ((uint64_t)(uint32_t)c->proxyLo << 32) | (uint32_t)c->proxyHi;
+	w->nEvents++;
+}
+
 static void destroy_contact(b2o_world* w, int slot)
 {
 	contact_t* c = &w->contacts[slot];
+	/* b2ContactManager::Destroy (b2ContactManager.cpp:104-107): a touching contact ends when it is destroyed */
+	if (w->eventsOn && c->reported) push_event(w, c, 1, -1);
+	c->reported = 0;
 	if (c->m.pointCount > 0 && !w->fixtures[c->fixtureA].isSensor && !w->fixtures[c->fixtureB].isSensor)
 	{
 		set_awake(&w->bodies[c->bodyA]);
@@ -1703,8 +1724,58 @@ static void solve_toi(b2o_world* w, float dt, int velIters)
 }
 
 /* b2World::Step  b2World.cpp:1613-1710 */
+static int seq_cmp(const void* a, const void* b);
+
+/* Events of the step: every contact whose touching state differs from what the host was last told, begins first, each
+ * group by proxy-id pair (the order of the reference's deferred callbacks, b2ContactManager.cpp:420-438, :64-67). */
+static void collect_contact_events(b2o_world* w)
+{
+	/* indices refer to b2o_get_contacts' creation order */
+	const contact_t** live = (const contact_t**)malloc(sizeof(void*) * (size_t)(w->liveContacts + 1));
+	int n = 0;
+	for (int i = 0; i < w->nContactSlots; ++i) if (w->contacts[i].alive) live[n++] = &w->contacts[i];
+	qsort(live, (size_t)n, sizeof(void*), seq_cmp);
+	for (int i = 0; i < n; ++i)
+	{
+		contact_t* c = (contact_t*)live[i];
+		const int touching = (c->flags & CF_TOUCHING) != 0;
+		if (touching == c->reported) continue;
+		c->reported = touching;
+		push_event(w, c, touching ? 0 : 1, i);
+	}
+	free(live);
+	/* insertion sort by (kind, key): the lists are short */
+	for (int i = 1; i < w->nEvents; ++i)
+	{
+		b2o_contact_event e = w->events[i];
+		uint64_t k = w->eventKeys[i];
+		int j = i - 1;
+		while (j >= 0 && (w->events[j].kind > e.kind || (w->events[j].kind == e.kind && w->eventKeys[j] > k)))
+		{
+			w->events[j + 1] = w->events[j];
+			w->eventKeys[j + 1] = w->eventKeys[j];
+			--j;
+		}
+		w->events[j + 1] = e;
+		w->eventKeys[j + 1] = k;
+	}
+}
+
+void b2o_enable_contact_events(b2o_world* w, int enable)
+{
+	w->eventsOn = enable != 0;
+	w->nEvents = 0;
+}
+
+int b2o_get_contact_events(const b2o_world* w, int cap, b2o_contact_event* out)
+{
+	for (int i = 0; i < w->nEvents && i < cap; ++i) out[i] = w->events[i];
+	return w->nEvents;
+}
+
 void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 {
+	w->nEvents = 0;
 	if (w->newFixture)
 	{
 		find_new_contacts(w);
@@ -1721,6 +1792,7 @@ void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 		w->bodies[i].force = v_make(0.0f, 0.0f);
 		w->bodies[i].torque = 0.0f;
 	}
+	if (w->eventsOn) collect_contact_events(w);
 }
 
 /* b2Body::ApplyForceToCenter + ApplyTorque  b2Body.h:740-775 */

@@ -15,8 +15,28 @@
 #error "define B2H_BACKEND_REF or B2H_BACKEND_AMD"
 #endif
 
+struct b2h_world;
+
+// Records BeginContact / EndContact (the deferred, deterministic callbacks) since the last b2h_get_events call.
+class b2hEventRecorder : public b2ContactListener
+{
+public:
+	explicit b2hEventRecorder(b2h_world* owner) : m_owner(owner) {}
+	void BeginContact(b2Contact* contact) override { Record(0, contact); }
+	void EndContact(b2Contact* contact) override { Record(1, contact); }
+	bool BeginContactImmediate(b2Contact*, uint32) override { return true; }
+	bool EndContactImmediate(b2Contact*, uint32) override { return true; }
+	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32) override { return false; }
+	bool PostSolveImmediate(b2Contact*, const b2ContactImpulse*, uint32) override { return false; }
+	void Record(int kind, b2Contact* contact);
+	std::vector<int> log; // 5 ints per event: kind, bodyA, fixtureA, bodyB, fixtureB
+private:
+	b2h_world* m_owner;
+};
+
 struct b2h_world
 {
+	b2hEventRecorder* recorder;
 	b2World* world;
 	b2ThreadPoolTaskExecutor* executor;
 	b2h::Scene scene;
@@ -72,6 +92,7 @@ b2h_world* b2h_create(int scene, int p0, int p1, float f0, float f1, unsigned se
 	}
 	memset(h->profileSum, 0, sizeof(h->profileSum));
 	h->profileSteps = 0;
+	h->recorder = nullptr;
 	return h;
 }
 
@@ -79,6 +100,7 @@ void b2h_destroy(b2h_world* h)
 {
 	if (h == NULL) return;
 	delete h->world;
+	delete h->recorder;
 	delete h->executor;
 	delete h;
 }
@@ -170,6 +192,48 @@ static int FixtureIndexInBody(const b2Fixture* f)
 		++total;
 	}
 	return total - 1 - pos;
+}
+
+} // extern "C" (reopened below): the recorder needs FixtureIndexInBody
+
+void b2hEventRecorder::Record(int kind, b2Contact* contact)
+{
+	const b2Fixture* fA = contact->GetFixtureA();
+	const b2Fixture* fB = contact->GetFixtureB();
+	log.push_back(kind);
+	log.push_back(m_owner->bodyIndex[fA->GetBody()]);
+	log.push_back(FixtureIndexInBody(fA));
+	log.push_back(m_owner->bodyIndex[fB->GetBody()]);
+	log.push_back(FixtureIndexInBody(fB));
+}
+
+extern "C"
+{
+
+// Contact events: install the recording listener / fetch what it has logged since the last call
+// (5 ints per event: kind 0 begin / 1 end, bodyA, fixtureA, bodyB, fixtureB; returns the number of events).
+void b2h_record_events(b2h_world* h, int enable)
+{
+	if (enable && !h->recorder)
+	{
+		h->recorder = new b2hEventRecorder(h);
+		h->world->SetContactListener(h->recorder);
+	}
+	else if (!enable && h->recorder)
+	{
+		h->world->SetContactListener(nullptr);
+		delete h->recorder;
+		h->recorder = nullptr;
+	}
+}
+
+int b2h_get_events(b2h_world* h, int cap, int* out)
+{
+	if (!h->recorder) return 0;
+	const int n = (int)h->recorder->log.size() / 5;
+	for (int i = 0; i < n && i < cap; ++i) memcpy(out + 5 * i, h->recorder->log.data() + 5 * i, 5 * sizeof(int));
+	h->recorder->log.clear();
+	return n;
 }
 
 // Dumps every contact of the world's contact list.

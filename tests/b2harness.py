@@ -56,6 +56,9 @@ class Harness:
         L.b2h_get_contacts.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _fp]
         L.b2h_get_profile.argtypes = [C.c_void_p, _fp]
         L.b2h_reset_profile.argtypes = [C.c_void_p]
+        L.b2h_record_events.argtypes = [C.c_void_p, C.c_int]
+        L.b2h_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.b2h_get_events.restype = C.c_int
 
     @property
     def backend(self):
@@ -225,6 +228,16 @@ class World:
         d = dict(zip(PROFILE_FIELDS, out.tolist()))
         d["steps"] = n
         return d
+
+    def record_events(self, enable=True):
+        """Install (or remove) the harness's recording b2ContactListener."""
+        self.L.b2h_record_events(self.ptr, 1 if enable else 0)
+
+    def events(self, cap=1 << 16):
+        """BeginContact / EndContact callbacks since the last call, in call order: rows (kind, bodyA, fixtureA, bodyB, fixtureB)."""
+        out = np.zeros((cap, 5), np.int32)
+        n = self.L.b2h_get_events(self.ptr, cap, _iptr(out))
+        return out[:min(n, cap)].copy()
 
     def reset_profile(self):
         self.L.b2h_reset_profile(self.ptr)
