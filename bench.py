@@ -19,6 +19,8 @@ One JSON line is printed by rank 0. Extra objects:
 import argparse
 import ctypes as C
 import json
+
+import numpy as np
 import os
 import sys
 import time
@@ -110,10 +112,17 @@ def main():
     w.step(args.warmup)
     w.reset_profile()
     barrier()
+    # one Step() per call so that the per-step distribution can be reported as well (Step() returns after its read-back,
+    # so a call is one complete step; the loop adds ~1 us of Python per step to the timed region)
+    stamps = np.empty(args.steps + 1)
     t0 = time.perf_counter()
-    w.step(args.steps)
+    stamps[0] = t0
+    for k in range(args.steps):
+        w.step(1)
+        stamps[k + 1] = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step_ms = 1000.0 * np.diff(stamps)
     prof = w.profile()  # device phase times (HIP events) averaged over the timed steps only
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -158,10 +167,10 @@ def main():
         # measured with rocprofv3 --pmc on this same command is committed under profiles/ and quoted here when the
         # workload and the kernel match (null otherwise)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")))
             if roof is not None and pmc.get("kernel") == kname and args.rows == 141 and not args.no_ccd:
                 roof["traffic"] = pmc["hbm_bytes_per_dispatch"]
-                roof["traffic_source"] = "profiles/r01_f_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roof["traffic_source"] = "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except Exception:
             pass
         smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
@@ -228,6 +237,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps,
+            "ms_per_step_p50": float(np.percentile(per_step_ms, 50)),
+            "ms_per_step_p99": float(np.percentile(per_step_ms, 99)),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
