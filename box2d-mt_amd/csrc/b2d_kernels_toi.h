@@ -271,12 +271,35 @@ __device__ __forceinline__ void storeAdvanced(const DW& W, int body, const Sweep
 	W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
 }
 
-__global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
+#define TOI_MOVED_MAX 4096     // proxies re-inserted by the parallel TOI paths in one step (more: serial loop)
+
+// unsafe bits of the domain mode (shared with the chains: b2d_kernels_toi_chains.h)
+#define TOI_DOM_UNSAFE_WOKE 2
+#define TOI_DOM_UNSAFE_PAIR 4
+#define TOI_DOM_UNSAFE_CAPACITY 8
+#define TOI_DOM_MOVED_LOCAL 64
+
+// The event loop of b2World::SolveTOI. DOMAIN = false: the whole world in one workgroup (k_toi_loop), the reference's
+// order replayed event by event. DOMAIN = true: the same loop restricted to ONE connected component of the graph
+// {non-static bodies, contacts between them} (k_toi_domains runs the components side by side, see
+// b2d_kernels_toi_domains.h): its pending list is the component's slice of DW::toiDomList, static bodies are read-only
+// partners that are always "in sync" (their alpha0 is neither read nor written), and the three things that would couple
+// components - a new contact, a sleeping body woken, a capacity cut - raise Counters::toiUnsafe instead of being done.
+// partial (DOMAIN = false only): the serial loop over the components that could not finish on their own (see
+// k_toi_dom_rollback): its pending list is DW::toiDomList[0, nToiPartial), the proxies the finished components moved
+// are already in DW::toiMoved, and a contact created with a body of a finished component means that component did not
+// see it in time: Counters::toiUnsafe, and the whole phase is redone serially.
+template <bool DOMAIN>
+__device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, int domain, int partial)
 {
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int tid = threadIdx.x;
 	const int nC0 = S->c.toiBase; // contacts covered by the adjacency; [nC0, s_nC) is the tail created by events
+	int* const list = DOMAIN ? W.toiDomList + W.toiDomBase[domain] : (partial ? W.toiDomList : W.toiList);
+	const int listCap = DOMAIN ? W.toiDomCount[domain] : W.capContacts;
+	const int myRoot = DOMAIN ? W.toiDomRoot[domain] : -1;
+	__shared__ int s_unsafe, s_failed, s_movedLocal[TOI_DOM_MOVED_LOCAL], s_nMovedLocal;
 
 	__shared__ int s_nC, s_nL, s_events, s_calls, s_overflow;
 	__shared__ int s_minIdx;
@@ -309,12 +332,16 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 	if (tid == 0)
 	{
 		s_nC = S->c.nContacts;
-		s_nL = S->c.nToiList < W.capContacts ? S->c.nToiList : W.capContacts;
+		const int nPending = partial ? S->c.nToiPartial : S->c.nToiList;
+		s_nL = DOMAIN ? (W.toiDomFill[domain] < listCap ? W.toiDomFill[domain] : listCap) : (nPending < W.capContacts ? nPending : W.capContacts);
+		s_unsafe = 0;
+		s_failed = 0;
+		s_nMovedLocal = 0;
 		s_events = 0;
 		s_calls = 0;
 		s_overflow = 0;
 		s_toiOrder = S->c.nToiOrder;
-		s_nMovedAll = 0;
+		s_nMovedAll = partial ? (S->c.nToiMoved < TOI_MOVED_ALL_MAX ? S->c.nToiMoved : TOI_MOVED_ALL_MAX) : 0;
 	}
 	__syncthreads();
 
@@ -325,6 +352,9 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		W.b_pos[body].w = 0.0f;
 		if ((old & BF_AWAKE) == 0)
 		{
+			// (a woken body resting on a static one would read that body's alpha0, which other components also advance)
+			if (DOMAIN) atomicOr(&s_unsafe, TOI_DOM_UNSAFE_WOKE);
+			else if (partial) atomicOr(&S->c.toiUnsafe, TOI_DOM_UNSAFE_WOKE);
 			const int k = atomicAdd(&s_nWoken, 1);
 			if (k < TOI_WOKEN_MAX) s_woken[k] = body; else atomicOr(&s_overflow, 8);
 		}
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			const int nL = s_nL;
 			for (int k = tid; k < nL; k += TOI_LANES)
 			{
-				const int i = W.toiList[k];
+				const int i = list[k];
 				const uint32_t flags = ldFlags(&C.flags[i]);
 				const int4 ids = C.ids[i];
 				if ((flags & CF_TOI) == 0 || !toiEligible(W, flags, ids)) continue;
@@ -387,6 +417,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		const int minIdx = s_minIdx;
 		const float minAlpha = s_minAlpha;
 		if (minIdx < 0 || 1.0f - 10.0f * B2D_EPSILON < minAlpha) break;
+		if (DOMAIN && (s_unsafe || s_overflow || s_failed)) break;
 		if (s_events >= TOI_EVENTS_MAX)
 		{
 			// safety net against a runaway loop (the reference bounds it through b2_maxSubSteps per contact)
@@ -432,8 +463,8 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			else
 			{
 				s_solid = 1;
-				storeAdvanced(W, seedA, a);
-				storeAdvanced(W, seedB, b);
+				if (!DOMAIN || (ldFlags(&W.b_flags[seedA]) & BF_TYPE_MASK) != BT_STATIC) storeAdvanced(W, seedA, a);
+				if (!DOMAIN || (ldFlags(&W.b_flags[seedB]) & BF_TYPE_MASK) != BT_STATIC) storeAdvanced(W, seedB, b);
 				wake(seedA);
 				wake(seedB);
 				s_bodies[0] = seedA;
@@ -586,8 +617,9 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			const int info = s_sorted[tid].info;
 			if (info & 8)
 			{
-				storeAdvanced(W, myOther, otherAdv);
-				if ((ldFlags(&W.b_flags[myOther]) & BF_TYPE_MASK) != BT_STATIC) wake(myOther);
+				const bool otherStatic = (ldFlags(&W.b_flags[myOther]) & BF_TYPE_MASK) == BT_STATIC;
+				if (!DOMAIN || !otherStatic) storeAdvanced(W, myOther, otherAdv);
+				if (!otherStatic) wake(myOther);
 			}
 		}
 		__syncthreads();
@@ -706,7 +738,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		{
 			const int b = s_bodies[tid];
 			const float4 p = s_pos[tid];
-			W.b_pos0[b] = make_float4(p.x, p.y, p.z, minAlpha);
+			if (!DOMAIN || (ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) != BT_STATIC) W.b_pos0[b] = make_float4(p.x, p.y, p.z, minAlpha);
 		}
 		if (ci >= 0) initConstraint();
 		TOI_WAVE_SYNC();
@@ -784,21 +816,44 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			// every proxy re-inserted during this TOI phase has a stale grid bin from now on
 			for (int mI = 0; mI < nMoves; ++mI)
 			{
-				if (s_nMovedAll < TOI_MOVED_ALL_MAX) W.toiMoved[s_nMovedAll++] = s_moves[mI]; else s_overflow |= 64;
+				if (!DOMAIN)
+				{
+					if (s_nMovedAll < TOI_MOVED_ALL_MAX) W.toiMoved[s_nMovedAll++] = s_moves[mI]; else s_overflow |= 64;
+					continue;
+				}
+				// component mode: the proxies this component has moved (for its own searches) ...
+				const int p = s_moves[mI];
+				bool mine = false;
+				for (int j = 0; j < s_nMovedLocal; ++j) mine = mine || s_movedLocal[j] == p;
+				if (!mine)
+				{
+					if (s_nMovedLocal < TOI_DOM_MOVED_LOCAL) s_movedLocal[s_nMovedLocal++] = p; else s_unsafe |= TOI_DOM_UNSAFE_CAPACITY;
+					// ... and the world-wide list with the hull of every fat AABB the proxy has had in this phase, for the
+					// cross-component check afterwards (k_toi_domains_end)
+					const int k = atomicAdd(&S->c.nToiMoved, 1);
+					if (k < TOI_MOVED_MAX) W.toiMoved[k] = p; else s_unsafe |= TOI_DOM_UNSAFE_CAPACITY;
+					W.toiHull[p] = W.snapFat[p];
+				}
+				const float4 f = W.p_fat[p], hcur = W.toiHull[p];
+				W.toiHull[p] = make_float4(fminf(hcur.x, f.x), fminf(hcur.y, f.y), fmaxf(hcur.z, f.z), fmaxf(hcur.w, f.w));
 			}
 		}
 		__syncthreads();
-		const int nMovedAll = s_nMovedAll;
+		const int nMovedAll = DOMAIN ? s_nMovedLocal : s_nMovedAll;
+		const int* const movedList = DOMAIN ? s_movedLocal : W.toiMoved;
 		for (int mI = 0; mI < nMoves; ++mI)
 		{
 			const int p = s_moves[mI];
 			const AABB fp = loadAabb(W.p_fat, p);
 			const int bodyP = W.p_body[p];
-			toiForEachCandidate(W, fp, tid, TOI_LANES, W.toiMoved, nMovedAll, [&](int q)
+			toiForEachCandidate(W, fp, tid, TOI_LANES, movedList, nMovedAll, [&](int q)
 			{
 				const int bodyQ = W.p_body[q];
 				if (bodyQ < 0 || p == q || bodyP == bodyQ) return;
-				if (!b2dAabbOverlap(fp, loadAabb(W.p_fat, q))) return;
+				// component mode: a proxy of another component (or a static one) is compared as it was when the phase began -
+				// the grid was built from exactly those boxes; what the others move meanwhile is k_toi_domains_end's business
+				const bool foreign = DOMAIN && W.toiParent[bodyQ] != myRoot;
+				if (!b2dAabbOverlap(fp, loadAabb(foreign ? W.snapFat : W.p_fat, q))) return;
 				const int keyP = W.p_key[p], keyQ = W.p_key[q];
 				const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
 				const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
@@ -811,6 +866,16 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 				if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
 				if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
 				if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return;
+				if (DOMAIN)
+				{
+					// the new contact ties this component to q's: neither can finish on its own (k_toi_dom_rollback)
+					if (foreign && (ldFlags(&W.b_flags[bodyQ]) & BF_TYPE_MASK) != BT_STATIC)
+					{
+						const int d2 = W.toiDomOf[W.toiParent[bodyQ]] - 1;
+						if (d2 >= 0) W.toiDomFailed[d2] = 1;
+					}
+					s_failed = 1;
+				}
 				const int k = atomicAdd(&s_nPairs, 1);
 				if (k < TOI_PAIRS_MAX)
 				{
@@ -822,6 +887,12 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			});
 		}
 		__syncthreads();
+		if (DOMAIN && s_nPairs > 0)
+		{
+			// the creation ORDER of contacts is defined by the global event order: not for a component to decide. The
+			// component is put back to the snapshot and replayed by the serial loop together with the others like it.
+			break;
+		}
 		const int nPairs = s_nPairs < TOI_PAIRS_MAX ? s_nPairs : TOI_PAIRS_MAX;
 		for (int i = tid; i < nPairs; i += TOI_LANES)
 		{
@@ -859,6 +930,16 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 				pB = t;
 			}
 			const int bodyA = W.p_body[pA], bodyB = W.p_body[pB];
+			if (partial)
+			{
+				for (int side = 0; side < 2; ++side)
+				{
+					const int b = side ? bodyB : bodyA;
+					if ((ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) == BT_STATIC) continue;
+					const int d2 = W.toiDomOf[W.toiParent[b]] - 1;
+					if (d2 >= 0 && W.toiDomFailed[d2] == 0) atomicOr(&S->c.toiUnsafe, TOI_DOM_UNSAFE_PAIR);
+				}
+			}
 			const bool sensor = ((W.p_filter1[pA] | W.p_filter1[pB]) & PF_SENSOR) != 0;
 			uint32_t flags = CF_ENABLED | (sensor ? CF_SENSOR : 0u);
 			const bool cand = isToiCandidate(W, pA, pB, bodyA, bodyB);
@@ -1000,6 +1081,14 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			for (int r = 0; r < nRecomp; ++r)
 			{
 				const int fa = s_flatFirst[2 * r], fb = s_flatFirst[2 * r + 1];
+				if (DOMAIN)
+				{
+					// a static partner is always level with or behind the body it is paired with here (every body of the mini
+					// island was advanced to the event time, and event times never decrease): advancing it changes nothing
+					const bool stA = (ldFlags(&W.b_flags[s_flatBody[fa]]) & BF_TYPE_MASK) == BT_STATIC;
+					const bool stB = (ldFlags(&W.b_flags[s_flatBody[fb]]) & BF_TYPE_MASK) == BT_STATIC;
+					if (stA || stB) continue;
+				}
 				const float aA = s_flatAlpha[fa], aB = s_flatAlpha[fb];
 				if (aA < aB)
 				{
@@ -1037,7 +1126,12 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 		{
 			const int c = s_rSorted[r];
 			const int4 ids = C.ids[c];
-			const Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
+			Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
+			if (DOMAIN)
+			{
+				if ((ldFlags(&W.b_flags[ids.z]) & BF_TYPE_MASK) == BT_STATIC) sA.alpha0 = sB.alpha0;
+				else if ((ldFlags(&W.b_flags[ids.w]) & BF_TYPE_MASK) == BT_STATIC) sB.alpha0 = sA.alpha0;
+			}
 			const float alpha = computeToi(W, ids, sA, sB);
 			atomicAdd(&s_calls, 1);
 			float4 mat = C.mat[c];
@@ -1048,27 +1142,54 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 			{
 				flags |= CF_TOI_LISTED;
 				const int k = atomicAdd(&s_nL, 1);
-				if (k < W.capContacts) W.toiList[k] = c; else atomicOr(&s_overflow, 16);
+				if (k < listCap) list[k] = c; else atomicOr(&s_overflow, 16);
 			}
 			C.flags[c] = flags;
 		}
 		__syncthreads();
-		if (tid == 0 && s_nL > W.capContacts) s_nL = W.capContacts;
+		if (tid == 0 && s_nL > listCap) s_nL = listCap;
 		__syncthreads();
 		TOI_T(9);
 	}
-	if (tid < 12) W.hubList[tid] = (int)s_t[tid];
+	if (!DOMAIN && !partial && tid < 12) W.hubList[tid] = (int)s_t[tid];
 #undef TOI_T
 
 	if (tid == 0)
 	{
-		S->c.nContacts = s_nC;
-		S->c.nToiList = s_nL;
-		S->c.nToiEvents = s_events;
-		atomicAdd(&S->c.nToiCalls, s_calls);
-		S->c.toiOverflow = s_overflow;
-		S->c.nToiOrder = s_toiOrder;
+		if (DOMAIN)
+		{
+			if (s_failed) W.toiDomFailed[domain] = 1;
+			W.toiDomEvents[domain] = s_events;
+			if (s_events) atomicAdd(&S->c.nToiEvents, s_events);
+			if (s_calls) atomicAdd(&S->c.nToiCalls, s_calls);
+			// a capacity cut inside a component is not an error yet: the serial loop gets the phase (and reports it if it
+			// hits the same limit)
+			const int unsafe = s_unsafe | (s_overflow ? TOI_DOM_UNSAFE_CAPACITY : 0);
+			if (unsafe) atomicOr(&S->c.toiUnsafe, unsafe);
+		}
+		else
+		{
+			S->c.nContacts = s_nC;
+			if (!partial) S->c.nToiList = s_nL;
+			S->c.nToiEvents = (partial ? S->c.nToiEvents : 0) + s_events;
+			atomicAdd(&S->c.nToiCalls, s_calls);
+			S->c.toiOverflow = s_overflow;
+			S->c.nToiOrder = s_toiOrder;
+		}
 	}
+}
+
+// The whole world in one persistent workgroup: the reference's serial order.
+__global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
+{
+	toiLoopRun<false>(W, sp, 0, 0);
+}
+
+// The components that met a new contact (or each other), replayed in the reference's global order by one workgroup.
+__global__ __launch_bounds__(TOI_LANES) void k_toi_loop_partial(DW W, StepParams sp)
+{
+	if (W.st->c.nToiPartial == 0 || W.st->c.toiUnsafe != 0) return;
+	toiLoopRun<false>(W, sp, 0, 1);
 }
 
 #endif

@@ -23,7 +23,6 @@
 #define CHAIN_EVENTS_MAX 4096
 #define CHAIN_ADJ_MAX 32        // contacts of one chain body (more: serial loop)
 #define TOI_GROUPS_MAX 262144   // chains per step (more: serial loop)
-#define TOI_MOVED_MAX 4096
 
 // unsafe bits
 #define TOI_UNSAFE_PARTNER 1    // a pending impact involves a non-static partner
@@ -96,6 +95,11 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 	if (!restore && S->c.nToiList == 0) return; // launched before the host knows whether any impact is pending
 	if (!restore)
 	{
+		if (t0 == 0)
+		{
+			S->c.nContactsSnap = S->c.nContacts;
+			S->c.nToiOrderSnap = S->c.nToiOrder;
+		}
 		for (int i = t0; i < W.nBodies; i += stride)
 		{
 			W.snapBody[5 * (size_t)i + 0] = W.b_pos[i];
@@ -140,6 +144,9 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 		{
 			S->c.nToiEvents = 0;
 			S->c.nToiMoved = 0;
+			// (the serial replay of tied components may have created contacts)
+			S->c.nContacts = S->c.nContactsSnap;
+			S->c.nToiOrder = S->c.nToiOrderSnap;
 		}
 	}
 }

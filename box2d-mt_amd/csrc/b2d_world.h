@@ -103,7 +103,10 @@ struct Counters
 	int nToiDestroy;     // TOI candidates destroyed by the running collide
 	int toiUnsafe;       // the parallel TOI chains met a case only the serial event loop reproduces (bits: b2d_kernels_toi_chains.h)
 	int nToiGroups;      // dynamic bodies with a pending impact
-	int nToiMoved;       // proxies re-inserted by the TOI chains
+	int nToiMoved;       // proxies re-inserted by the TOI chains / components
+	int nToiDomains;     // components with a pending impact
+	int nToiPartial;     // pending impacts of the components that are replayed serially (DW::toiDomList)
+	int nContactsSnap, nToiOrderSnap; // contact count / TOI slot count when k_toi_snapshot was taken
 	int nEvents;         // contact events of this step (DW::evKey / evInfo), see k_contact_events
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
 	int nCompact;        // entries of DW::compactList (constraints of the colour class under compaction this step)
@@ -249,6 +252,17 @@ struct DW
 	int* toiDestroyList; // TOI candidates marked for destruction by collide
 	int* b_toiGroup;     // per body: chain index + 1 while it owns a TOI chain
 	int* toiGroups;      // dynamic bodies with a pending impact
+	// TOI components (b2d_kernels_toi_domains.h): connected components of {non-static bodies, contacts between them}
+	int* toiParent;      // per body: component label (union-find, flattened)
+	int* toiDomOf;       // per body (label): component index + 1 while the component has a pending impact, else 0
+	int* toiDomRoot;     // per component: its label
+	int* toiDomCount;    // per component: contacts in it = capacity of its pending list
+	int* toiDomBase;     // per component: start of its slice of toiDomList
+	int* toiDomFill;     // per component: pending impacts listed so far
+	int* toiDomList;     // pending lists of all components, back to back; afterwards the list of the serial replay
+	int* toiDomFailed;   // per component: it met a new contact / another component and has to be replayed serially
+	int* toiDomEvents;   // per component: events it counted (taken back if it is replayed)
+	float4* toiHull;     // per proxy: hull of the fat AABBs it has had in this TOI phase (valid for proxies in toiMoved)
 	int* toiGroupCount;  // per chain: contacts gathered for it
 	int* toiGroupList;   // per chain: CHAIN_ADJ_MAX contact indices
 	int* toiMoved;       // proxies re-inserted by the chains

@@ -19,6 +19,7 @@
 
 #include "../../include/b2hip.h"
 #include "b2d_kernels_toi_chains.h"
+#include "b2d_kernels_toi_domains.h"
 #include "b2d_kernels_solve_dataflow.h"
 #include "b2d_kernels_solve_mailbox.h"
 #include "b2d_scan.h"
@@ -152,7 +153,8 @@ struct b2hip_world
 	DevArray<int> p_body, p_shape, p_key, p_filter1;
 	DevArray<uint32_t> p_filter0;
 	DevArray<float2> p_mat;
-	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiGroupCount, toiGroupList, toiMoved;
+	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiGroupCount, toiGroupList, toiMoved, toiParent, toiDomOf, toiDomRoot, toiDomCount, toiDomBase, toiDomFill, toiDomList, toiDomFailed, toiDomEvents;
+	DevArray<float4> toiHull;
 	DevArray<float4> snapBody, snapFat;
 	DevArray<ShapeRec> d_shapes;
 	DevArray<int4> c_ids[2];
@@ -217,7 +219,7 @@ struct b2hip_world
 	int* constsUploadedAt = nullptr;
 	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
-	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false;
+	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false, toiNoDomains = false;
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
 	int graphCaptures;
@@ -584,7 +586,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(scanTmp4, maxScanN / SCAN_TILE + 4);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
-	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_MAX); ENS(snapBody, 5 * nb); ENS(snapFat, np);
+	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
 	ENS(gridBar, 16);
@@ -641,7 +643,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.stateOut = w->stateOut.p;
 	d.b_proxyHead = w->b_proxyHead.p; d.p_next = w->p_next.p; d.toiList = w->toiList.p;
 	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
-	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p;
+	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p; d.toiParent = w->toiParent.p; d.toiDomOf = w->toiDomOf.p; d.toiDomRoot = w->toiDomRoot.p; d.toiDomCount = w->toiDomCount.p; d.toiDomBase = w->toiDomBase.p; d.toiDomFill = w->toiDomFill.p; d.toiDomFailed = w->toiDomFailed.p; d.toiDomEvents = w->toiDomEvents.p; d.toiDomList = w->toiDomList.p; d.toiHull = w->toiHull.p;
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	return 0;
 }
@@ -1347,6 +1349,31 @@ static int phaseToiSync(b2hip_world* w)
 		w->toiChains = true;
 		return 0;
 	}
+	if (!w->toiSerialOnly && !w->toiNoDomains)
+	{
+		// bullets / kinematic partners: the event loop runs per connected component of the contact graph, side by side
+		// (b2d_kernels_toi_domains.h); b2hip_step_end falls back to the serial loop from the snapshot if a component met
+		// something that couples it to another one
+		rc = toiBuildIndexes(w, true);
+		if (rc) return rc;
+		LAUNCH(w, k_toi_dom_init, gridFor(d.nBodies), 256, d);
+		LAUNCH(w, k_toi_dom_union, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int), w->stream)); // (k_toi_first's "not chains" bit)
+		LAUNCH(w, k_toi_dom_mark, gridFor(w->h_dstate->c.nToiList), 256, d);
+		LAUNCH(w, k_toi_dom_count, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_toi_dom_scan, 1, 1024, d);
+		LAUNCH(w, k_toi_dom_fill, gridFor(w->h_dstate->c.nToiList), 256, d);
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+		LAUNCH(w, k_toi_domains, std::min(w->h_dstate->c.nToiList, 2048), TOI_LANES, d, w->sp);
+		LAUNCH(w, k_toi_domains_end, std::min(std::max(w->h_dstate->c.nToiList, 1), 1024), 256, d);
+		// components tied together by a new contact: back to the snapshot, then the serial loop over just those
+		LAUNCH(w, k_toi_dom_rollback, gridFor(std::max(std::max(d.nBodies, d.nProxies), d.capContacts)), 256, d);
+		LAUNCH(w, k_toi_loop_partial, 1, TOI_LANES, d, w->sp);
+		LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+		w->toiChains = true;
+		return 0;
+	}
 	return toiSerial(w);
 }
 
@@ -1476,7 +1503,8 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	if (const char* e = getenv("B2HIP_DF_SLEEP")) w->dfSleep = atoi(e);
 	w->toiChains = false;
 	w->toiSerialOnly = getenv("B2HIP_TOI_SERIAL") != nullptr;
-	w->toiSyncOnly = getenv("B2HIP_TOI_SYNC") != nullptr; // decide chains / serial loop from a read-back after k_toi_first (the older flow)
+	w->toiSyncOnly = getenv("B2HIP_TOI_SYNC") != nullptr;
+	w->toiNoDomains = getenv("B2HIP_TOI_NO_DOMAINS") != nullptr; // bullets / kinematic partners through the serial loop only // decide chains / serial loop from a read-back after k_toi_first (the older flow)
 	w->toiFallbacks = 0;
 	for (int i = 0; i < 13; ++i)
 	{
@@ -1526,7 +1554,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
 	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
-	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->snapBody.release(); w->snapFat.release();
+	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
@@ -1904,6 +1932,7 @@ int b2hip_step_end(b2hip_world* w)
 	{
 		// a chain met an order-dependent case: back to the state before the chains, then the reference's serial order
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		if (getenv("B2HIP_TOI_WHY")) fprintf(stderr, "b2hip: TOI fallback to the serial loop, unsafe bits 0x%x (1 partner, 2 woke, 4 new pair, 8 capacity, 16 moved proxies), %d pending, %d components\n", w->h_dstate->c.toiUnsafe, w->h_dstate->c.nToiList, w->h_dstate->c.nToiDomains);
 		rc = toiSerial(w);
 		if (rc) return rc;
 		w->toiFallbacks += 1;
