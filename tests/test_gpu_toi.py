@@ -110,3 +110,34 @@ def test_ccd_events_are_counted(amd, default_mode):
         assert ctr.toi_calls >= ctr.toi_pending_first_pass
     assert events > 10 and calls > events
     w.close()
+
+
+def test_ccd_components_run_side_by_side_and_stay_bit_exact(amd, oracle, default_mode, monkeypatch):
+    """Bullets among free bodies: the event loop runs per connected component of the contact graph (k_toi_domains),
+    components tied by a new contact are replayed serially (k_toi_loop_partial). Bitwise equal to the oracle every step,
+    with and without that path, and the path really is the one that ran (few whole-phase fallbacks)."""
+    hip = C.CDLL(os.path.join(ROOT, "box2d-mt_amd", "libb2hip.so"))
+    import b2hip
+    kw = dict(p0=2500, p1=300, f0=0.0, f1=0.0, seed=11, flags=CCD)
+    o = oracle.world(bh.FIELD, **kw)
+    want = []
+    for _ in range(25):
+        o.step(1)
+        want.append((bh.fnv1a64(o.bodies()), o.contact_count))
+    o.close()
+    for no_domains in (False, True):
+        if no_domains:
+            monkeypatch.setenv("B2HIP_TOI_NO_DOMAINS", "1")
+        w = amd.world(bh.FIELD, **kw)
+        dev = C.c_void_p(w.device_world())
+        events = 0
+        for s in range(25):
+            w.step(1)
+            assert (bh.fnv1a64(w.bodies()), w.contact_count) == want[s], "step %d differs (no_domains=%s)" % (s, no_domains)
+            ctr = b2hip.Counters()
+            assert hip.b2hip_get_counters(dev, C.byref(ctr)) == 0
+            events += ctr.toi_events
+        assert events > 50
+        if not no_domains:
+            assert ctr.toi_serial_fallbacks <= 5, "the component path fell back to the serial loop in most steps"
+        w.close()
