@@ -172,11 +172,13 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 	__shared__ int s_unsafe, s_events, s_calls, s_solid, s_minIdx;
 	__shared__ float s_minAlpha;
 	__shared__ int s_moved[16], s_nMoved;
+	__shared__ int s_listed[16], s_nListed;
 	if (lane == 0)
 	{
 		s_unsafe = 0;
 		s_events = 0;
 		s_calls = 0;
+		s_nListed = 0;
 	}
 	__syncthreads();
 
@@ -515,8 +517,18 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 				if (d.y < 0.0f) f.lo.y += d.y; else f.hi.y += d.y;
 				W.p_fat[p] = make_float4(f.lo.x, f.lo.y, f.hi.x, f.hi.y);
 				if (s_nMoved < 16) s_moved[s_nMoved++] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
-				const int k = atomicAdd(&S->c.nToiMoved, 1);
-				if (k < TOI_MOVED_MAX) W.toiMoved[k] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
+				// world-wide list (once per proxy) with the hull of every box the proxy has had in this phase, for k_toi_chains_end
+				bool listed = false;
+				for (int j = 0; j < s_nListed; ++j) listed = listed || s_listed[j] == p;
+				if (!listed)
+				{
+					if (s_nListed < 16) s_listed[s_nListed++] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
+					const int k = atomicAdd(&S->c.nToiMoved, 1);
+					if (k < TOI_MOVED_MAX) W.toiMoved[k] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
+					W.toiHull[p] = W.snapFat[p];
+				}
+				const float4 hcur = W.toiHull[p];
+				W.toiHull[p] = make_float4(fminf(hcur.x, f.lo.x), fminf(hcur.y, f.lo.y), fmaxf(hcur.z, f.hi.x), fmaxf(hcur.w, f.hi.y));
 			}
 		}
 		__syncthreads();
@@ -611,12 +623,12 @@ __global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
 	for (int i = threadIdx.x; i < n && n >= 2 && !S->c.toiUnsafe; i += blockDim.x)
 	{
 		const int p = W.toiMoved[i];
-		const AABB fp = loadAabb(W.p_fat, p);
+		const AABB fp = loadAabb(W.toiHull, p); // every box p has had in this phase: covers momentary overlaps too
 		for (int j = i + 1; j < n; ++j)
 		{
 			const int q = W.toiMoved[j];
 			if (q == p || W.p_body[p] == W.p_body[q]) continue;
-			if (!b2dAabbOverlap(fp, loadAabb(W.p_fat, q))) continue;
+			if (!b2dAabbOverlap(fp, loadAabb(W.toiHull, q))) continue;
 			// an existing contact makes the overlap harmless: look it up on p's (dynamic) body
 			const int keyP = W.p_key[p], keyQ = W.p_key[q];
 			const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
