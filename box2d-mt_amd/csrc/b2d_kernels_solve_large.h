@@ -270,7 +270,9 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W)
 	// decision reads masks nobody else is changing: deterministic. Over the steps the colouring becomes greedy-minimal
 	// (colour <= (degA - 1) + (degB - 1)), whatever the order in which the contacts appeared.
 	{
-		const int nc = S->c.nCompact < COLOR_SMALL_MAX ? S->c.nCompact : COLOR_SMALL_MAX;
+		// all of the class or none of it: a class that does not fit the list (together with the new constraints) would be
+		// cut at an arbitrary member - which ones were listed depends on the order of the atomics in k_color_check
+		const int nc = S->c.nCompact + S->c.nUncolList <= COLOR_SMALL_MAX ? S->c.nCompact : 0;
 		for (int k = threadIdx.x; k < nc; k += blockDim.x)
 		{
 			const int s = W.compactList[k];

@@ -313,6 +313,23 @@ def test_dense_scene_run_to_run_determinism(amd, default_mode):
             assert first_bad is None, "run %d diverges from run 0 at step %s" % (rep, first_bad)
 
 
+def test_bench_scene_run_to_run_determinism(amd, default_mode):
+    """The bench workload itself (10 011-box pyramid, continuous physics on) twice, 320 steps: every 20th state hash and the
+    contact counts must agree. (Colour compaction once listed an arbitrary 4 096 members of a larger colour class: the
+    runs parted around step 150.)"""
+    def run():
+        w = amd.world(bh.PYRAMID, 141, 1, flags=bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM)
+        trace = []
+        for s in range(16):
+            w.step(20)
+            trace.append((bh.fnv1a64(w.bodies()), w.contact_count))
+        w.close()
+        return trace
+    a, b = run(), run()
+    first_bad = next((20 * (i + 1) for i, (x, y) in enumerate(zip(a, b)) if x != y), None)
+    assert first_bad is None, "two runs of the bench scene differ by step %s" % first_bad
+
+
 def test_persistent_solver_matches_launch_per_colour(amd, default_mode):
     """The persistent coloured solver (one resident grid, grid barriers between colours) must reproduce the
     launch-per-colour solver bit for bit: same colours, same sweep structure, same arithmetic."""
