@@ -6,6 +6,7 @@ reference (oracle/_ref/libb2ref_harness.so). Run in the build container:
 Outputs (committed, small):
   toi_scenes.npz    scenes stepped with continuous physics ON: final body states, per-step contact
                     counts and pose hashes, final contact ids / flags / manifolds
+  toi_scale.npz     at-scale traces (per-step contact counts and full-state hashes only)
   toi_vectors.npz   b2Distance and b2TimeOfImpact inputs (vertex proxies, transforms / sweeps) and the
                     reference's outputs
 Fixtures are data (inputs and expected outputs); no reference source text is stored.
@@ -29,6 +30,12 @@ SCENES = [
     ("ccd_pyramid12", bh.PYRAMID, 12, 1, 0.0, 0.0, 1, 120),
     ("ccd_rain", bh.RAIN, 150, 0, 0.0, 0.0, 7, 150),
     ("ccd_tumbler6", bh.TUMBLER, 6, 0, 0.0, 0.0, 1, 200),
+]
+
+# at-scale traces (hashes and contact counts only): thousands of bullets among free bodies, the workload of the
+# per-component TOI path
+SCALE_SCENES = [
+    ("ccd_field30k", bh.FIELD, 30000, 3000, 0.0, 0.0, 17, 30),
 ]
 
 POLY_RADIUS = 0.01
@@ -72,6 +79,23 @@ def main():
         print(name, w.body_count, counts[-1], hashes[-1], "solveTOI ms", w.profile()["solveTOI"])
         w.close()
     np.savez_compressed(os.path.join(HERE, "toi_scenes.npz"), **out)
+
+    big = {}
+    for name, sc, p0, p1, f0, f1, seed, steps in SCALE_SCENES:
+        w = ref.world(sc, p0, p1, f0, f1, seed, flags=CCD, threads=8)
+        counts = np.zeros(steps, np.int32)
+        hashes = []
+        for s in range(steps):
+            w.step(1)
+            counts[s] = w.contact_count
+            hashes.append(bh.fnv1a64(w.bodies()))
+        big[name + "/params"] = np.array([sc, p0, p1, seed, steps], np.int64)
+        big[name + "/fparams"] = np.array([f0, f1], np.float32)
+        big[name + "/contact_counts"] = counts
+        big[name + "/hashes"] = np.array(hashes)
+        print(name, w.body_count, counts[-1], hashes[-1], "solveTOI ms", w.profile()["solveTOI"])
+        w.close()
+    np.savez_compressed(os.path.join(HERE, "toi_scale.npz"), **big)
 
     rng = np.random.default_rng(20240917)
     # ---- b2Distance ---------------------------------------------------------------------------

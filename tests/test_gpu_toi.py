@@ -141,3 +141,18 @@ def test_ccd_components_run_side_by_side_and_stay_bit_exact(amd, oracle, default
         if not no_domains:
             assert ctr.toi_serial_fallbacks <= 5, "the component path fell back to the serial loop in most steps"
         w.close()
+
+
+def test_ccd_at_scale_matches_reference_trace(amd, default_mode):
+    """30 000 free bodies with 3 000 bullets, 30 steps: per-step contact counts and full-state hashes recorded from the
+    reference build (tests/golden/toi_scale.npz). Hundreds of TOI events per step go through the per-component path."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "toi_scale.npz"))
+    name = "ccd_field30k"
+    sc, p0, p1, seed, steps = [int(x) for x in g[name + "/params"]]
+    f0, f1 = [float(x) for x in g[name + "/fparams"]]
+    w = amd.world(sc, p0, p1, f0, f1, seed, flags=CCD)
+    for s in range(steps):
+        w.step(1)
+        assert w.contact_count == int(g[name + "/contact_counts"][s]), "contact count differs at step %d" % s
+        assert bh.fnv1a64(w.bodies()) == str(g[name + "/hashes"][s]), "state hash differs at step %d" % s
+    w.close()
