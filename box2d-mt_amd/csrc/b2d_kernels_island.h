@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 				int nb = W.rootBodies[i], nc = W.rootContacts[i], nj = W.rootJoints[i];
 				int w = nb > nc ? nb : nc;
 				if (w < 1) w = 1;
-				if ((nj == 0 && w <= SMALL_ISLAND_MAX_W && forceLarge == 0) || forceLarge == 2)
+				if ((nj == 0 && w <= W.smallMaxW && forceLarge == 0) || forceLarge == 2)
 				{
 					W.rootIsland[i] = ROOT_SMALL;
 					in = make_int4(nb, nc, w, 1);

@@ -136,6 +136,7 @@ struct DW
 	DState* st;
 	int nBodies, nProxies, nJoints, nShapes;
 	int capContacts, capPairs, capMoves;
+	int smallMaxW;        // islands up to this size take the exact-order in-LDS solver (default SMALL_ISLAND_MAX_W; B2HIP_SMALL_MAX_W)
 	int bigChunks;        // 1: always use 1024-lane chunks for the small-island solver (B2HIP_BIG_CHUNKS)
 	uint32_t htMask;      // contact-key hash table size - 1
 	uint32_t gridMask;    // broad-phase hash grid size - 1

@@ -605,6 +605,11 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.nJoints = (int)w->joints.size();
 	d.nShapes = (int)w->shapes.size();
 	d.bigChunks = getenv("B2HIP_BIG_CHUNKS") != nullptr ? 1 : 0;
+	// Exact order costs ~1 us per DEPENDENT constraint (a GPU lane against a CPU core on a chain): a 210-box pyramid is
+	// ~300 levels x 12 sweeps = 4.8 ms in k_solve_small, 0.5 ms through the coloured solver. The default keeps islands up
+	// to 512 bit-exact; B2HIP_SMALL_MAX_W=128 trades that for latency on mid-size stacks.
+	d.smallMaxW = SMALL_ISLAND_MAX_W;
+	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
 	d.capContacts = (int)cc;
 	d.capPairs = (int)w->pairKey.cap;
 	d.capMoves = (int)w->moveBuf.cap;
