@@ -1,5 +1,6 @@
-// Drop-in header: profile block (reference: Box2D/Dynamics/b2TimeStep.h:25-40). Times in ms.
-// In the MI355X build the fields are filled from HIP events around the device phases.
+// Drop-in header: the profile block callers read through b2World::GetProfile() (reference interface:
+// Box2D/Dynamics/b2TimeStep.h:25-40, b2AddProfile :76-91). Milliseconds. In the MI355X build the thirteen values come
+// from HIP events around the device phases (b2hip_get_profile fills them in this declaration order).
 #ifndef B2_TIME_STEP_H
 #define B2_TIME_STEP_H
 
@@ -7,41 +8,21 @@
 
 struct b2Profile
 {
-	float32 step;
-	float32 collide;
-	float32 solve;
-	float32 solveTraversal;
-	float32 solveInit;
-	float32 solveVelocity;
-	float32 solvePosition;
-	float32 solveTOI;
-	float32 solveTOIFindMinContact;
-	float32 broadphase;
-	float32 broadphaseSyncFixtures;
-	float32 broadphaseFindContacts;
-	float32 locking;
+	float32 step, collide;                                           // whole step; contact update
+	float32 solve, solveTraversal, solveInit, solveVelocity, solvePosition; // island build and solver phases
+	float32 solveTOI, solveTOIFindMinContact;                        // continuous collision
+	float32 broadphase, broadphaseSyncFixtures, broadphaseFindContacts;
+	float32 locking;                                                 // always 0 here: no locks on the device path
 };
 
-struct b2TimeStep
-{
-	float32 dt;
-	float32 inv_dt;
-	float32 dtRatio;
-	int32 velocityIterations;
-	int32 positionIterations;
-	bool warmStarting;
-};
+static_assert(sizeof(b2Profile) == 13 * sizeof(float32), "b2Profile is thirteen floats, in b2hip_get_profile's order");
 
-struct b2Position
+// dest += scale * src, field by field (the Testbed averages profiles with it).
+inline void b2AddProfile(b2Profile& dest, const b2Profile& src, float32 scale)
 {
-	b2Vec2 c;
-	float32 a;
-};
-
-struct b2Velocity
-{
-	b2Vec2 v;
-	float32 w;
-};
+	float32* d = &dest.step;
+	const float32* s = &src.step;
+	for (int i = 0; i < 13; ++i) d[i] += scale * s[i];
+}
 
 #endif
