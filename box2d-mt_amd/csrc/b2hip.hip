@@ -2196,6 +2196,16 @@ int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4])
 	return 0;
 }
 
+int b2hip_get_fat_aabbs(b2hip_world* w, int first, int count, float* out4n)
+{
+	if (!w || (count > 0 && !out4n) || first < 0 || count < 0 || (size_t)(first + count) > w->fixtures.size())
+		return setError(B2HIP_ERR_INVALID, "bad fixture range");
+	const int onDevice = std::max(0, std::min(first + count, (int)w->upFixtures) - first);
+	if (onDevice > 0) HIP_TRY(hipMemcpy(out4n, w->p_fat.p + first, (size_t)onDevice * 16, hipMemcpyDeviceToHost));
+	for (int i = onDevice; i < count; ++i) memcpy(out4n + 4 * (size_t)i, w->fixtures[first + i].fat, 16); // not uploaded yet
+	return 0;
+}
+
 // Debug / test hook: FNV-1a over a group of device arrays, read back after a stream sync. Valid between
 // phase calls (b2hip_collide ... b2hip_step_end), so two worlds can be compared phase by phase.
 //   which 0: bodies (pos, pos0, vel, xf, flags)   1: contacts (ids, key, flags & 0x7f, manifold, impulses)

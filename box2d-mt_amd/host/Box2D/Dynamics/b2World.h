@@ -47,6 +47,13 @@ public:
 
 	void ClearForces();
 
+	/// Every fixture whose fat AABB overlaps `aabb` (b2World.cpp:1751-1757), in fixture creation order (the reference walks
+	/// its dynamic tree: same set, other order); the callback returns false to stop.
+	void QueryAABB(b2QueryCallback* callback, const b2AABB& aabb);
+	/// Ray cast with the reference's callback protocol (b2World.cpp:1785-1795, b2DynamicTree.h:203-287): return 0 to stop,
+	/// a fraction to clip the ray, 1 to go on unclipped; fixtures are visited in creation order.
+	void RayCast(b2RayCastCallback* callback, const b2Vec2& point1, const b2Vec2& point2);
+
 	b2Body* GetBodyList() { return m_bodyList; }
 	const b2Body* GetBodyList() const { return m_bodyList; }
 	b2Joint* GetJointList() { return m_jointList; }
@@ -84,6 +91,7 @@ private:
 	friend class b2Fixture;
 	friend class b2Contact;
 	void DeliverContactEvents();
+	const std::vector<b2AABB>& FatAABBs();
 
 	void PushFlags();
 	const b2hip_body_state& State(int32 id) const;
@@ -97,6 +105,8 @@ private:
 	int32 m_bodyCount, m_jointCount;
 	std::vector<b2Body*> m_bodies;     // by device id
 	std::vector<b2Fixture*> m_fixtures; // by device id
+	std::vector<b2AABB> m_fatAABBs;    // one read-back per step, on demand (QueryAABB / RayCast)
+	bool m_fatValid;
 	b2DestructionListener* m_destructionListener;
 	b2ContactFilter* m_contactFilter;
 	b2ContactListener* m_contactListener;

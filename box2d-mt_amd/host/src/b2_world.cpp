@@ -29,6 +29,7 @@ b2World::b2World(const b2Vec2& gravity)
 	memset(&m_profile, 0, sizeof(m_profile));
 	m_statesValid = false;
 	m_contactsValid = false;
+	m_fatValid = false;
 	m_hip = nullptr;
 
 	b2hip_world_def def;
@@ -214,6 +215,7 @@ void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIteration
 	}
 	m_statesValid = false;
 	m_contactsValid = false;
+	m_fatValid = false;
 	DeliverContactEvents();
 	float ms[13];
 	if (b2hip_get_profile(m_hip, ms) == B2HIP_OK)
@@ -275,6 +277,76 @@ void b2World::DeliverContactEvents()
 		else
 		{
 			if (m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
+		}
+	}
+}
+
+const std::vector<b2AABB>& b2World::FatAABBs()
+{
+	if (!m_fatValid)
+	{
+		const int n = (int)m_fixtures.size();
+		m_fatAABBs.resize(n);
+		std::vector<float> raw(4 * (size_t)(n > 0 ? n : 1));
+		if (m_hip && n > 0 && b2hip_get_fat_aabbs(m_hip, 0, n, raw.data()) == B2HIP_OK)
+		{
+			for (int i = 0; i < n; ++i)
+			{
+				m_fatAABBs[i].lowerBound.Set(raw[4 * i + 0], raw[4 * i + 1]);
+				m_fatAABBs[i].upperBound.Set(raw[4 * i + 2], raw[4 * i + 3]);
+			}
+		}
+		m_fatValid = true;
+	}
+	return m_fatAABBs;
+}
+
+void b2World::QueryAABB(b2QueryCallback* callback, const b2AABB& aabb)
+{
+	const std::vector<b2AABB>& fat = FatAABBs();
+	for (size_t i = 0; i < fat.size(); ++i)
+	{
+		if (m_fixtures[i] == nullptr || !b2TestOverlap(fat[i], aabb)) continue;
+		if (!callback->ReportFixture(m_fixtures[i])) return;
+	}
+}
+
+void b2World::RayCast(b2RayCastCallback* callback, const b2Vec2& point1, const b2Vec2& point2)
+{
+	const std::vector<b2AABB>& fat = FatAABBs();
+	b2Vec2 r = point2 - point1;
+	if (r.LengthSquared() <= 0.0f) return;
+	r.Normalize();
+	// v is perpendicular to the segment: |dot(v, p1 - c)| > dot(|v|, h) separates a box from it
+	const b2Vec2 v = b2Cross(1.0f, r);
+	const b2Vec2 abs_v = b2Abs(v);
+	float32 maxFraction = 1.0f;
+	b2AABB segment;
+	b2Vec2 t = point1 + maxFraction * (point2 - point1);
+	segment.lowerBound = b2Min(point1, t);
+	segment.upperBound = b2Max(point1, t);
+	for (size_t i = 0; i < fat.size(); ++i)
+	{
+		b2Fixture* fixture = m_fixtures[i];
+		if (fixture == nullptr || !b2TestOverlap(fat[i], segment)) continue;
+		const b2Vec2 c = fat[i].GetCenter(), h = fat[i].GetExtents();
+		if (b2Abs(b2Dot(v, point1 - c)) - b2Dot(abs_v, h) > 0.0f) continue;
+		b2RayCastInput input;
+		input.p1 = point1;
+		input.p2 = point2;
+		input.maxFraction = maxFraction;
+		b2RayCastOutput output;
+		if (!fixture->GetShape()->RayCast(&output, input, fixture->GetBody()->GetTransform(), 0)) continue;
+		const float32 fraction = output.fraction;
+		const b2Vec2 point = (1.0f - fraction) * point1 + fraction * point2;
+		const float32 value = callback->ReportFixture(fixture, point, output.normal, fraction);
+		if (value == 0.0f) return;
+		if (value > 0.0f)
+		{
+			maxFraction = value;
+			t = point1 + maxFraction * (point2 - point1);
+			segment.lowerBound = b2Min(point1, t);
+			segment.upperBound = b2Max(point1, t);
 		}
 	}
 }
@@ -455,6 +527,7 @@ b2Fixture* b2Body::CreateFixture(const b2FixtureDef* def)
 	++m_fixtureCount;
 	if ((int)m_world->m_fixtures.size() <= id) m_world->m_fixtures.resize(id + 1, nullptr);
 	m_world->m_fixtures[id] = f;
+	m_world->m_fatValid = false;
 	m_world->m_statesValid = false;
 	return f;
 }

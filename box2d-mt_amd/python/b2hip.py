@@ -94,6 +94,7 @@ def _configure(L, optional_ok=False):
         "b2hip_get_contact_events": [C.c_void_p, C.c_int, C.c_void_p],
         "b2hip_get_island_labels": [C.c_void_p, C.c_int, C.c_void_p],
         "b2hip_get_fat_aabb": [C.c_void_p, C.c_int, C.POINTER(C.c_float)],
+        "b2hip_get_fat_aabbs": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
         "b2hip_get_profile": [C.c_void_p, C.POINTER(C.c_float)],
         "b2hip_get_counters": [C.c_void_p, C.POINTER(Counters)],
         "b2hip_get_solver_timing": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)],

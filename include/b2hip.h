@@ -231,6 +231,9 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out);
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out);
 /* Fat AABB of a fixture's proxy (b2BroadPhase::GetFatAABB). */
 int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4]);
+/* The fat AABBs of fixtures [first, first + count) in one copy: what b2World::QueryAABB / RayCast walk
+ * (b2World.cpp:1740-1795; the reference asks its dynamic tree, b2DynamicTree.h:168-287 - same boxes, other order). */
+int b2hip_get_fat_aabbs(b2hip_world* w, int first, int count, float* out4n);
 
 /* Test hook: FNV-1a hash of a group of device arrays (0 bodies, 1 contacts, 2 proxy AABBs, 3 contact impulses),
  * usable between phase calls to compare two worlds phase by phase. */

@@ -135,6 +135,12 @@ int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4])
 	return 0;
 }
 
+int b2hip_get_fat_aabbs(b2hip_world* w, int first, int count, float* out4n)
+{
+	for (int i = 0; i < count; ++i) b2o_get_fat_aabb(w->o, first + i, out4n + 4 * i);
+	return 0;
+}
+
 int b2hip_get_profile(b2hip_world* w, float ms[13])
 {
 	(void)w;

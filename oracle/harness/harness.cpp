@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <algorithm>
 
 #if !defined(B2H_BACKEND_REF) && !defined(B2H_BACKEND_AMD)
 #error "define B2H_BACKEND_REF or B2H_BACKEND_AMD"
@@ -234,6 +235,64 @@ int b2h_get_events(b2h_world* h, int cap, int* out)
 	for (int i = 0; i < n && i < cap; ++i) memcpy(out + 5 * i, h->recorder->log.data() + 5 * i, 5 * sizeof(int));
 	h->recorder->log.clear();
 	return n;
+}
+
+} // extern "C": the query callbacks below are C++ classes
+
+namespace
+{
+struct AllFixtures : b2QueryCallback
+{
+	std::vector<const b2Fixture*> hits;
+	bool ReportFixture(b2Fixture* fixture) override { hits.push_back(fixture); return true; }
+};
+struct ClosestHit : b2RayCastCallback
+{
+	const b2Fixture* fixture = nullptr;
+	b2Vec2 point, normal;
+	float32 fraction = 1.0f;
+	float32 ReportFixture(b2Fixture* f, const b2Vec2& p, const b2Vec2& n, float32 fr) override
+	{
+		fixture = f; point = p; normal = n; fraction = fr;
+		return fr; // clip the ray to this hit: the last report is the closest one, whatever the visiting order
+	}
+};
+}
+
+extern "C"
+{
+
+// b2World::QueryAABB: (body, fixture index in body) of every reported fixture, sorted; returns the count.
+int b2h_query_aabb(b2h_world* h, float lx, float ly, float ux, float uy, int cap, int* out)
+{
+	AllFixtures cb;
+	b2AABB aabb;
+	aabb.lowerBound.Set(lx, ly);
+	aabb.upperBound.Set(ux, uy);
+	h->world->QueryAABB(&cb, aabb);
+	std::vector<std::pair<int, int> > ids;
+	for (size_t i = 0; i < cb.hits.size(); ++i) ids.push_back(std::make_pair(h->bodyIndex[cb.hits[i]->GetBody()], FixtureIndexInBody(cb.hits[i])));
+	std::sort(ids.begin(), ids.end());
+	for (size_t i = 0; i < ids.size() && (int)i < cap; ++i)
+	{
+		out[2 * i] = ids[i].first;
+		out[2 * i + 1] = ids[i].second;
+	}
+	return (int)ids.size();
+}
+
+// b2World::RayCast with a closest-hit callback: out7 = body, fixture index, point.xy, normal.xy, fraction; returns 1 on a hit.
+int b2h_raycast_closest(b2h_world* h, float x1, float y1, float x2, float y2, float* out7)
+{
+	ClosestHit cb;
+	h->world->RayCast(&cb, b2Vec2(x1, y1), b2Vec2(x2, y2));
+	if (!cb.fixture) return 0;
+	out7[0] = (float)h->bodyIndex[cb.fixture->GetBody()];
+	out7[1] = (float)FixtureIndexInBody(cb.fixture);
+	out7[2] = cb.point.x; out7[3] = cb.point.y;
+	out7[4] = cb.normal.x; out7[5] = cb.normal.y;
+	out7[6] = cb.fraction;
+	return 1;
 }
 
 // Dumps every contact of the world's contact list.

@@ -56,6 +56,10 @@ class Harness:
         L.b2h_get_contacts.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _fp]
         L.b2h_get_profile.argtypes = [C.c_void_p, _fp]
         L.b2h_reset_profile.argtypes = [C.c_void_p]
+        L.b2h_query_aabb.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_int)]
+        L.b2h_query_aabb.restype = C.c_int
+        L.b2h_raycast_closest.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.b2h_raycast_closest.restype = C.c_int
         L.b2h_record_events.argtypes = [C.c_void_p, C.c_int]
         L.b2h_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.b2h_get_events.restype = C.c_int
@@ -228,6 +232,19 @@ class World:
         d = dict(zip(PROFILE_FIELDS, out.tolist()))
         d["steps"] = n
         return d
+
+    def query_aabb(self, lo, hi, cap=1 << 16):
+        """b2World::QueryAABB: sorted rows (body, fixture index in body) of every fixture whose fat AABB overlaps the box."""
+        out = np.zeros((cap, 2), np.int32)
+        n = self.L.b2h_query_aabb(self.ptr, lo[0], lo[1], hi[0], hi[1], cap, _iptr(out))
+        return out[:min(n, cap)].copy()
+
+    def raycast_closest(self, p1, p2):
+        """b2World::RayCast with a closest-hit callback: None, or (body, fixture, point.xy, normal.xy, fraction)."""
+        out = np.zeros(7, np.float32)
+        if not self.L.b2h_raycast_closest(self.ptr, p1[0], p1[1], p2[0], p2[1], _fptr(out)):
+            return None
+        return out
 
     def record_events(self, enable=True):
         """Install (or remove) the harness's recording b2ContactListener."""
