@@ -215,6 +215,7 @@ struct b2hip_world
 	int solverConstraints, solverBodies;
 	int forceLarge;
 	// optional per-launch timing of the dominant solver kernel
+	size_t pairCapHint = 0; // pair-buffer size asked for after an overflow (growPairBuffers)
 	int constsUploaded[2] = { -1, -1 };
 	int* constsUploadedAt = nullptr;
 	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
@@ -542,7 +543,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(d_joints, std::max<size_t>(w->joints.size(), 1));
 	ENS(jadjStart, nb + 2); ENS(jadj, 2 * w->joints.size() + 2); ENS(rootJointStart, nb + 2); ENS(rootJointCursor, nb);
 	ENS(lj_list, w->joints.size() + 2); ENS(rootJointOkay, nb);
-	const size_t capPairs = std::max<size_t>(8 * np + 4096, w->pairKey.cap);
+	const size_t capPairs = std::max<size_t>(std::max<size_t>(8 * np + 4096, w->pairKey.cap), w->pairCapHint);
 	const size_t capContacts = std::max<size_t>(needContacts + capPairs, 1024);
 	for (int k = 0; k < 2; ++k)
 	{
@@ -892,12 +893,36 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 }
 
 static int findNewContacts(b2hip_world* w, bool sync);
+static int findNewContactsOnce(b2hip_world* w, bool sync);
 static int findNewContactsGraph(b2hip_world* w)
 {
 	return runSegment(w, w->segPairs, 3, [w]() -> int { return findNewContacts(w, false); });
 }
 
+// The pair finder met more candidate pairs than the buffer holds (a dense start: every proxy is "moved" and overlaps dozens
+// of others). Counters::nPairs counted all of them: size the buffers for that and let the caller run the search again
+// (nothing was consumed: the creation kernels leave an overflowed set alone and the moves stay buffered).
+static int growPairBuffers(b2hip_world* w)
+{
+	w->pairCapHint = 2 * (size_t)w->h_dstate->c.nPairs + 4096;
+	int rc = ensureCapacity(w, (size_t)w->h_dstate->c.nContacts);
+	if (rc) return rc;
+	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+	return 0;
+}
+
 static int findNewContacts(b2hip_world* w, bool sync)
+{
+	for (int attempt = 0; sync && attempt < 4; ++attempt)
+	{
+		int rc = findNewContactsOnce(w, true);
+		if (rc != 1) return rc; // 1 = pair buffer overflow, buffers grown: search again
+	}
+	if (sync) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+	return findNewContactsOnce(w, false);
+}
+
+static int findNewContactsOnce(b2hip_world* w, bool sync)
 {
 	DW& d = w->dw;
 	LAUNCH(w, k_bp_clear, gridFor(std::max(d.htMask, d.gridMask) + 1), 256, d);
@@ -911,7 +936,11 @@ static int findNewContacts(b2hip_world* w, bool sync)
 	{
 		int rc = readState(w);
 		if (rc) return rc;
-		if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+		if (w->h_dstate->c.overflow & 2)
+		{
+			rc = growPairBuffers(w);
+			return rc ? rc : 1;
+		}
 		if (w->h_dstate->c.nMoves == 0) return 0;
 		large = w->h_dstate->c.nPairs > COUNT_RANK_MAX;
 	}
@@ -1321,7 +1350,16 @@ static int phaseToiSync(b2hip_world* w)
 		LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
 		rc = readState(w);
 		if (rc) return rc;
-		if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+		if (w->h_dstate->c.overflow & 2)
+		{
+			// the end-of-step pair update overflowed its buffer: grow it, run the whole update again, then look again
+			if (pass == 1) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+			rc = growPairBuffers(w);
+			if (rc) return rc;
+			rc = findNewContacts(w, true);
+			if (rc) return rc;
+			continue;
+		}
 		if (pass == 1 || w->h_dstate->c.nMoves == 0 || w->h_dstate->c.nPairs <= COUNT_RANK_MAX) break;
 		rc = runSortAndCreate(w, true);
 		if (rc) return rc;
@@ -1894,11 +1932,13 @@ int b2hip_step_end(b2hip_world* w)
 	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_end outside a step");
 	int rc = downloadState(w);
 	if (rc) return rc;
-	// optimistic small-sort path overflowed: finish the pair update with the radix path, then read back again
-	if (w->h_dstate->c.overflow & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
-	if (w->h_dstate->c.nMoves != 0 && w->sp.dt > 0.0f)
+	// optimistic small-sort path overflowed (or the pair buffer itself): finish the pair update with the radix path (after
+	// growing the buffer and searching again), then read back again
+	const bool pairOverflow = (w->h_dstate->c.overflow & 2) != 0;
+	if (pairOverflow && w->sp.dt <= 0.0f) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+	if ((w->h_dstate->c.nMoves != 0 || pairOverflow) && w->sp.dt > 0.0f)
 	{
-		if (w->h_dstate->c.nPairs > COUNT_RANK_MAX)
+		if (w->h_dstate->c.nPairs > COUNT_RANK_MAX || pairOverflow)
 		{
 			const bool redoToi = w->toiSpeculative;
 			if (redoToi && w->h_dstate->c.nToiList > 0)
@@ -1906,7 +1946,13 @@ int b2hip_step_end(b2hip_world* w)
 				// the TOI phase ran without the contacts that are created only now: undo it
 				LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
 			}
-			rc = runSortAndCreate(w, true);
+			if (pairOverflow)
+			{
+				rc = growPairBuffers(w);
+				if (rc) return rc;
+				rc = findNewContacts(w, true);
+			}
+			else rc = runSortAndCreate(w, true);
 			if (rc) return rc;
 			if (redoToi)
 			{

@@ -179,3 +179,21 @@ def test_revolute_pendulum_chain(libs, monkeypatch):
             prev = d
     run(a, b, 200, "pendulum")
     a.close(); b.close()
+
+
+def test_dense_start_grows_the_pair_buffer(monkeypatch):
+    """1 400 bodies and 450 bullets crammed into a 70 x 70 arena: the first pair update finds several times more candidate
+    pairs than the buffer was sized for (21 000 contacts on step one). The buffers grow and the search runs again - no
+    capacity error - and the result is still the oracle's, bit for bit (exact-order mode: the islands are huge)."""
+    import b2harness as bh
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    amd, orc = bh.Harness(bh.AMD_LIB), bh.Harness(bh.ORACLE_LIB)
+    kw = dict(p0=1406, p1=456, f0=35.0, f1=2.0, seed=2623, flags=bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM)
+    a, o = amd.world(bh.FIELD, **kw), orc.world(bh.FIELD, **kw)
+    for s in range(3):
+        a.step(1)
+        o.step(1)
+        assert a.contact_count == o.contact_count and a.contact_count > 15000, "step %d" % s
+        assert np.array_equal(a.bodies().view(np.uint32), o.bodies().view(np.uint32)), "step %d" % s
+    a.close()
+    o.close()
