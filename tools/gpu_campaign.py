@@ -5,7 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
 import b2harness as H
-os.environ["B2HIP_FORCE_LARGE"] = "2"
+DEFAULT = os.environ.get("MODE") == "default"  # coloured order for large islands: compare loosely, look for errors
+if not DEFAULT: os.environ["B2HIP_FORCE_LARGE"] = "2"
 amd, orc = H.Harness(H.AMD_LIB), H.Harness(H.ORACLE_LIB)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -26,8 +27,17 @@ for k in range(cases):
     first = None
     for s in range(steps):
         a.step(1); o.step(1)
+        if DEFAULT:
+            x, y = a.bodies(), o.bodies()
+            if not np.isfinite(x).all() or a.contact_count == 0 and o.contact_count > 10: first = "error at %d" % s; break
+            continue
         if a.contact_count != o.contact_count or not np.array_equal(a.bodies(), o.bodies()):
             first = s; break
+    if DEFAULT and first is None:
+        x, y = a.bodies(), o.bodies()
+        dev = float(np.abs(x[:, :2] - y[:, :2]).max())
+        print("         default mode: max position deviation from the oracle after %d steps %.4f, contacts %d vs %d" % (steps, dev, a.contact_count, o.contact_count))
+        a.close(); o.close(); continue
     if first is None:
         ia, fa, ma = a.contacts(); io, fo, mo = o.contacts()
         if not (np.array_equal(ia, io) and np.array_equal(fa, fo) and np.array_equal(ma.view(np.uint32), mo.view(np.uint32))): first = "contacts"
