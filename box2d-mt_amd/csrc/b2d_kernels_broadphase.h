@@ -51,15 +51,28 @@ __device__ __forceinline__ uint32_t cellHash(int ix, int iy, uint32_t mask)
 	return ((uint32_t)ix * 73856093u ^ (uint32_t)iy * 19349663u) & mask;
 }
 
+// The cell of the hashed grid. DW::cellSize is sized from the fixtures as they were created; fat AABBs of fast bodies
+// stretch (b2DynamicTree::MoveProxy adds twice the displacement), and a proxy wider than a cell takes the brute-force
+// "large proxy" path: thousands of falling boxes did in the Tumbler. So the cell follows the widest proxy of this pair
+// update (k_bp_clear reduces it into Counters::cellExtBits), capped at 4 x the static size - beyond that a proxy is an
+// outlier (a ground box) and stays on the large path. The pair SET does not depend on the cell.
+__device__ __forceinline__ float gridCellSize(const DW& W)
+{
+	const float dyn = 1.05f * __uint_as_float(W.st->c.cellExtBits);
+	return dyn > W.cellSize ? dyn : W.cellSize;
+}
+
 __device__ __forceinline__ bool proxyIsLarge(const DW& W, float4 a)
 {
-	return (a.z - a.x) > W.cellSize || (a.w - a.y) > W.cellSize;
+	const float cell = gridCellSize(W);
+	return (a.z - a.x) > cell || (a.w - a.y) > cell;
 }
 
 __device__ __forceinline__ void proxyCell(const DW& W, float4 a, int* ix, int* iy)
 {
-	*ix = (int)floorf(0.5f * (a.x + a.z) * W.invCellSize);
-	*iy = (int)floorf(0.5f * (a.y + a.w) * W.invCellSize);
+	const float inv = 1.0f / gridCellSize(W);
+	*ix = (int)floorf(0.5f * (a.x + a.z) * inv);
+	*iy = (int)floorf(0.5f * (a.y + a.w) * inv);
 }
 
 // force = 1: rebuild the grid although the move buffer is empty (the TOI phase queries it and needs it to reflect

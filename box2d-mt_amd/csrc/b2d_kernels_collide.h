@@ -265,6 +265,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.nPairs = 0;
 		(&c.nPairs)[1] = 0;
 		c.overflow = 0;
+		c.cellExtBits = 0;
 		c.nEvents = 0;
 		c.nToiList = 0;
 		c.nToiEvents = 0;

@@ -55,9 +55,10 @@ __device__ __forceinline__ Sweep loadSweep(const DW& W, int body)
 template <typename F>
 __device__ __forceinline__ void toiForEachCandidate(const DW& W, AABB a, int lane, int nLanes, const int* moved, int nMoved, F f)
 {
-	const float half = 0.5f * W.cellSize;
-	const float fx0 = floorf((a.lo.x - half) * W.invCellSize), fx1 = floorf((a.hi.x + half) * W.invCellSize);
-	const float fy0 = floorf((a.lo.y - half) * W.invCellSize), fy1 = floorf((a.hi.y + half) * W.invCellSize);
+	const float cell = gridCellSize(W), inv = 1.0f / cell;
+	const float half = 0.5f * cell;
+	const float fx0 = floorf((a.lo.x - half) * inv), fx1 = floorf((a.hi.x + half) * inv);
+	const float fy0 = floorf((a.lo.y - half) * inv), fy1 = floorf((a.hi.y + half) * inv);
 	const float cells = (fx1 - fx0 + 1.0f) * (fy1 - fy0 + 1.0f);
 	if (!(cells >= 1.0f && cells <= 4096.0f))
 	{

@@ -662,6 +662,20 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 	}
 	if (S->c.nMoves == 0) return;
 	const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	// widest proxy that should still go through the grid (see gridCellSize): complete when this kernel ends
+	{
+		const float cap = 4.0f * W.cellSize;
+		float ext = 0.0f;
+		for (uint32_t p = t0; p < (uint32_t)W.nProxies; p += stride)
+		{
+			if (W.p_body[p] < 0) continue;
+			const float4 a = W.p_fat[p];
+			const float e = fmaxf(a.z - a.x, a.w - a.y);
+			if (e <= cap && e > ext) ext = e;
+		}
+		for (int off = 32; off > 0; off >>= 1) ext = fmaxf(ext, __shfl_xor(ext, off));
+		if ((threadIdx.x & 63u) == 0 && ext > 0.0f) atomicMax(&S->c.cellExtBits, __float_as_uint(ext));
+	}
 	for (uint32_t i = t0; i <= W.gridMask; i += stride)
 	{
 		W.gridCount[i] = 0;

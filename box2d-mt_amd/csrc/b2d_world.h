@@ -104,6 +104,7 @@ struct Counters
 	int toiUnsafe;       // the parallel TOI chains met a case only the serial event loop reproduces (bits: b2d_kernels_toi_chains.h)
 	int nToiGroups;      // dynamic bodies with a pending impact
 	int nToiMoved;       // proxies re-inserted by the TOI chains / components
+	uint32_t cellExtBits; // float bits of the largest fat-AABB extent among the grid-sized proxies, see gridCellSize()
 	int nToiDomains;     // components with a pending impact
 	int nToiPartial;     // pending impacts of the components that are replayed serially (DW::toiDomList)
 	int nContactsSnap, nToiOrderSnap; // contact count / TOI slot count when k_toi_snapshot was taken
