@@ -2170,6 +2170,190 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
 	return n;
 }
 
+// ---- snapshot -----------------------------------------------------------------------------------------
+namespace
+{
+struct SnapHeader
+{
+	char magic[8];
+	uint32_t version, szDState, szHostBody, szHostFixture, szShape, szJoint;
+	uint32_t nBodies, nFixtures, nShapes, nJoints, nFree, nContacts, nToiOrder, nMoves;
+	uint32_t stateCount, cur;
+	int32_t nextNode, leafCount, lastContacts, newFixture;
+	float inv_dt0, cellSize;
+};
+const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
+
+struct SnapWriter
+{
+	std::vector<char> out;
+	void host(const void* p, size_t n) { const char* c = (const char*)p; out.insert(out.end(), c, c + n); }
+	int dev(const void* p, size_t n)
+	{
+		const size_t at = out.size();
+		out.resize(at + n);
+		if (n == 0) return 0;
+		HIP_TRY(hipMemcpy(out.data() + at, p, n, hipMemcpyDeviceToHost));
+		return 0;
+	}
+};
+
+struct SnapReader
+{
+	const char* p;
+	size_t left;
+	bool ok;
+	const void* take(size_t n)
+	{
+		if (n > left) { ok = false; return nullptr; }
+		const void* r = p;
+		p += n;
+		left -= n;
+		return r;
+	}
+	void host(void* dst, size_t n) { const void* s = take(n); if (s && n) memcpy(dst, s, n); }
+	int dev(void* dst, size_t n)
+	{
+		const void* s = take(n);
+		if (!s) return setError(B2HIP_ERR_INVALID, "snapshot truncated");
+		if (n) HIP_TRY(hipMemcpy(dst, s, n, hipMemcpyHostToDevice));
+		return 0;
+	}
+};
+} // namespace
+
+int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed)
+{
+	if (!w || !needed || (cap > 0 && !buffer)) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_save_snapshot inside a step");
+	int rc = flushEdits(w); // everything the host has created or edited is on the device now
+	if (rc) return rc;
+	rc = readState(w);
+	if (rc) return rc;
+	const DState& ds = *w->h_dstate;
+	const size_t nb = w->bodies.size(), np = w->fixtures.size();
+	const size_t nC = (size_t)std::max(ds.c.nContacts, 0), nM = (size_t)std::max(std::min(ds.c.nMoves, w->dw.capMoves), 0);
+	const size_t nT = (size_t)std::max(ds.c.nToiOrder, 0);
+	SnapHeader h;
+	memset(&h, 0, sizeof(h));
+	memcpy(h.magic, kSnapMagic, 8);
+	h.version = 1;
+	h.szDState = sizeof(DState); h.szHostBody = (uint32_t)offsetof(HostBody, fixtures); h.szHostFixture = sizeof(HostFixture);
+	h.szShape = sizeof(ShapeRec); h.szJoint = sizeof(RevoluteJoint);
+	h.nBodies = (uint32_t)nb; h.nFixtures = (uint32_t)np; h.nShapes = (uint32_t)w->shapes.size(); h.nJoints = (uint32_t)w->joints.size();
+	h.nFree = (uint32_t)w->freeUnits.size(); h.nContacts = (uint32_t)nC; h.nToiOrder = (uint32_t)nT; h.nMoves = (uint32_t)nM;
+	h.stateCount = (uint32_t)std::min(w->stateCount, nb); h.cur = (uint32_t)ds.cur;
+	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
+	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
+	SnapWriter o;
+	o.host(&h, sizeof(h));
+	o.host(&w->def, sizeof(w->def));
+	for (size_t i = 0; i < nb; ++i)
+	{
+		o.host(&w->bodies[i], offsetof(HostBody, fixtures));
+		const char dirty = w->bodies[i].dirty ? 1 : 0;
+		o.host(&dirty, 1);
+	}
+	o.host(w->fixtures.data(), np * sizeof(HostFixture));
+	o.host(w->shapes.data(), w->shapes.size() * sizeof(ShapeRec));
+	o.host(w->freeUnits.data(), w->freeUnits.size() * sizeof(FreeUnit));
+	o.host(w->h_state, (size_t)h.stateCount * 10 * sizeof(float));
+	o.host(&ds, sizeof(DState));
+#define SNAP_DEV(arr, n) do { rc = o.dev(w->arr.p, (size_t)(n) * sizeof(*w->arr.p)); if (rc) return rc; } while (0)
+	SNAP_DEV(d_joints, w->joints.size()); // the device copy carries the accumulated impulses
+	SNAP_DEV(b_pos, nb); SNAP_DEV(b_pos0, nb); SNAP_DEV(b_vel, nb); SNAP_DEV(b_xf, nb); SNAP_DEV(b_mass, nb); SNAP_DEV(b_damp, nb);
+	SNAP_DEV(b_force, nb); SNAP_DEV(b_flags, nb); SNAP_DEV(b_wake, nb); SNAP_DEV(b_proxyHead, nb);
+	SNAP_DEV(p_fat, np); SNAP_DEV(p_body, np); SNAP_DEV(p_shape, np); SNAP_DEV(p_key, np); SNAP_DEV(p_filter0, np); SNAP_DEV(p_filter1, np);
+	SNAP_DEV(p_mat, np); SNAP_DEV(p_next, np);
+	const int cur = ds.cur;
+	SNAP_DEV(c_ids[cur], nC); SNAP_DEV(c_key[cur], nC); SNAP_DEV(c_flags[cur], nC); SNAP_DEV(c_mat[cur], nC); SNAP_DEV(c_man0[cur], nC);
+	SNAP_DEV(c_man1[cur], nC); SNAP_DEV(c_imp[cur], nC); SNAP_DEV(c_man3[cur], nC); SNAP_DEV(c_color[cur], nC); SNAP_DEV(c_mgr[cur], nC);
+	SNAP_DEV(toiPos2c, nT); SNAP_DEV(moveBuf, nM);
+#undef SNAP_DEV
+	*needed = o.out.size();
+	if (cap >= o.out.size()) memcpy(buffer, o.out.data(), o.out.size());
+	else if (cap > 0) return setError(B2HIP_ERR_CAPACITY, "snapshot buffer too small");
+	return B2HIP_OK;
+}
+
+int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world** out)
+{
+	if (!buffer || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	SnapReader in = { (const char*)buffer, size, true };
+	SnapHeader h;
+	in.host(&h, sizeof(h));
+	if (!in.ok || memcmp(h.magic, kSnapMagic, 8) != 0 || h.version != 1 || h.szDState != sizeof(DState) ||
+		h.szHostBody != offsetof(HostBody, fixtures) || h.szHostFixture != sizeof(HostFixture) || h.szShape != sizeof(ShapeRec) ||
+		h.szJoint != sizeof(RevoluteJoint))
+		return setError(B2HIP_ERR_INVALID, "not a snapshot of this build of libb2hip");
+	b2hip_world_def def;
+	in.host(&def, sizeof(def));
+	if (!in.ok) return setError(B2HIP_ERR_INVALID, "snapshot truncated");
+	def.device = device;
+	b2hip_world* w = nullptr;
+	int rc = b2hip_world_create(&def, &w);
+	if (rc) return rc;
+	auto fail = [&](int code) { b2hip_world_destroy(w); return code; };
+	w->bodies.resize(h.nBodies);
+	for (size_t i = 0; i < h.nBodies; ++i)
+	{
+		in.host(&w->bodies[i], offsetof(HostBody, fixtures));
+		char dirty = 0;
+		in.host(&dirty, 1);
+		w->bodies[i].dirty = dirty != 0;
+		if (dirty) w->dirtyList.push_back((int)i);
+	}
+	w->fixtures.resize(h.nFixtures);
+	in.host(w->fixtures.data(), (size_t)h.nFixtures * sizeof(HostFixture));
+	w->shapes.resize(h.nShapes);
+	in.host(w->shapes.data(), (size_t)h.nShapes * sizeof(ShapeRec));
+	w->freeUnits.resize(h.nFree);
+	in.host(w->freeUnits.data(), (size_t)h.nFree * sizeof(FreeUnit));
+	if (!in.ok) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
+	for (size_t f = 0; f < w->fixtures.size(); ++f)
+	{
+		if (w->fixtures[f].body < 0 || (size_t)w->fixtures[f].body >= w->bodies.size()) return fail(setError(B2HIP_ERR_INVALID, "snapshot corrupt"));
+		w->bodies[w->fixtures[f].body].fixtures.push_back((int)f);
+	}
+	for (size_t k = 0; k < w->shapes.size(); ++k) w->shapeIndex[std::string((const char*)&w->shapes[k], sizeof(ShapeRec))] = (int)k;
+	w->joints.resize(h.nJoints);
+	w->nextNode = h.nextNode; w->leafCount = h.leafCount; w->lastContacts = h.lastContacts; w->newFixture = h.newFixture != 0;
+	w->inv_dt0 = h.inv_dt0;
+	rc = ensureCapacity(w, (size_t)h.nContacts);
+	if (rc) return fail(rc);
+	const size_t nb = h.nBodies, np = h.nFixtures, nC = h.nContacts;
+	in.host(w->h_state, (size_t)h.stateCount * 10 * sizeof(float));
+	w->stateCount = h.stateCount;
+	DState ds;
+	in.host(&ds, sizeof(DState));
+	if (!in.ok) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
+	HIP_TRY(hipMemcpy(w->d_state.p, &ds, sizeof(DState), hipMemcpyHostToDevice));
+	*w->h_dstate = ds;
+#define SNAP_DEV(arr, n) do { rc = in.dev(w->arr.p, (size_t)(n) * sizeof(*w->arr.p)); if (rc) return fail(rc); } while (0)
+	{
+		// joints: the device copy is the truth (accumulated impulses); the host vector mirrors it and is uploaded, with the
+		// per-body joint lists, by the next flushEdits
+		const void* src = in.take((size_t)h.nJoints * sizeof(RevoluteJoint));
+		if (!src) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
+		if (h.nJoints) memcpy(w->joints.data(), src, (size_t)h.nJoints * sizeof(RevoluteJoint));
+	}
+	SNAP_DEV(b_pos, nb); SNAP_DEV(b_pos0, nb); SNAP_DEV(b_vel, nb); SNAP_DEV(b_xf, nb); SNAP_DEV(b_mass, nb); SNAP_DEV(b_damp, nb);
+	SNAP_DEV(b_force, nb); SNAP_DEV(b_flags, nb); SNAP_DEV(b_wake, nb); SNAP_DEV(b_proxyHead, nb);
+	SNAP_DEV(p_fat, np); SNAP_DEV(p_body, np); SNAP_DEV(p_shape, np); SNAP_DEV(p_key, np); SNAP_DEV(p_filter0, np); SNAP_DEV(p_filter1, np);
+	SNAP_DEV(p_mat, np); SNAP_DEV(p_next, np);
+	const int cur = (int)h.cur & 1;
+	SNAP_DEV(c_ids[cur], nC); SNAP_DEV(c_key[cur], nC); SNAP_DEV(c_flags[cur], nC); SNAP_DEV(c_mat[cur], nC); SNAP_DEV(c_man0[cur], nC);
+	SNAP_DEV(c_man1[cur], nC); SNAP_DEV(c_imp[cur], nC); SNAP_DEV(c_man3[cur], nC); SNAP_DEV(c_color[cur], nC); SNAP_DEV(c_mgr[cur], nC);
+	SNAP_DEV(toiPos2c, h.nToiOrder); SNAP_DEV(moveBuf, h.nMoves);
+#undef SNAP_DEV
+	HIP_TRY(hipMemcpy(w->d_shapes.p, w->shapes.data(), w->shapes.size() * sizeof(ShapeRec), hipMemcpyHostToDevice));
+	w->upBodies = nb; w->upFixtures = np; w->upShapes = w->shapes.size(); w->upJoints = 0;
+	w->dw.cellSize = h.cellSize;
+	w->dw.invCellSize = 1.0f / h.cellSize;
+	*out = w;
+	return B2HIP_OK;
+}
+
 int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 {
 	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");

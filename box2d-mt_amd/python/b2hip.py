@@ -90,6 +90,8 @@ def _configure(L, optional_ok=False):
         "b2hip_get_body_states": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
         "b2hip_contact_count": [C.c_void_p],
         "b2hip_get_contacts": [C.c_void_p, C.c_int, C.c_void_p],
+        "b2hip_save_snapshot": [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
+        "b2hip_load_snapshot": [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)],
         "b2hip_enable_contact_events": [C.c_void_p, C.c_int],
         "b2hip_get_contact_events": [C.c_void_p, C.c_int, C.c_void_p],
         "b2hip_get_island_labels": [C.c_void_p, C.c_int, C.c_void_p],
@@ -167,6 +169,23 @@ class World:
         p = C.c_void_p()
         _check(self.L.b2hip_world_create(C.byref(d), C.byref(p)))
         self.p = p
+
+    def save_snapshot(self):
+        """The world as bytes (b2hip_save_snapshot): bodies, fixtures, joints, contacts with warm-start state, counters."""
+        need = C.c_size_t(0)
+        _check(self.L.b2hip_save_snapshot(self.p, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        _check(self.L.b2hip_save_snapshot(self.p, buf, need.value, C.byref(need)))
+        return buf.raw[:need.value]
+
+    @classmethod
+    def from_snapshot(cls, blob, device=-1, library=None):
+        self = cls.__new__(cls)
+        self.L = library if library is not None else lib()
+        p = C.c_void_p()
+        _check(self.L.b2hip_load_snapshot(blob, len(blob), device, C.byref(p)))
+        self.p = p
+        return self
 
     def close(self):
         if self.p:

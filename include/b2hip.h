@@ -19,6 +19,7 @@
  *                                                                                       b2World.cpp:1095-1118, b2BroadPhase.h:211-267, b2ContactManager.cpp:237-312,366-386
  *   b2hip_get_body_states            b2Body::GetPosition/GetAngle/GetLinearVelocity/GetAngularVelocity/IsAwake  b2Body.h:516-700
  *   b2hip_enable/get_contact_events  b2ContactListener::BeginContact / EndContact     b2WorldCallbacks.h:88-104, b2ContactManager.cpp:420-438
+ *   b2hip_save / load_snapshot       (new: binary checkpoint; cf. b2World::Dump          b2World.cpp:2107-2164)
  *   b2hip_get_contacts               b2World::GetContactList + b2Contact::GetManifold  b2World.h:352-360, b2Contact.h:95-163
  *   b2hip_get_profile                b2World::GetProfile                    b2World.h:196-197, b2TimeStep.h:25-40
  *
@@ -243,6 +244,16 @@ int b2hip_debug_hash(b2hip_world* w, int which, uint64_t* out);
 int b2hip_debug_trace(b2hip_world* w, int index, char* label, int label_cap, uint64_t* hash);
 /* Raw read-back of one device array (see b2hip.hip for the ids); test / debugging only. */
 int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out);
+
+/* World snapshot (checkpoint / resume; the reference only has the lossy text b2World::Dump, b2World.cpp:2107-2164).
+ * Everything that survives a step: bodies, shapes, fixtures with their proxy ids and fat AABBs, joints with their
+ * accumulated impulses, the contact array in creation order with manifolds, warm-start impulses, cached impacts,
+ * colours and TOI slots, the move buffer and the counters. A world loaded from it continues bit for bit like the world
+ * it was taken from. The blob is only meaningful to the same build of the library.
+ *   b2hip_save_snapshot: writes at most `cap` bytes; *needed receives the snapshot's size (call with cap 0 to ask).
+ *   b2hip_load_snapshot: creates a NEW world (destroy it with b2hip_world_destroy); `device` as in b2hip_world_def. */
+int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed);
+int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world** out);
 
 /* 13 floats in b2Profile declaration order (b2TimeStep.h:25-40), milliseconds, from HIP events. */
 int b2hip_get_profile(b2hip_world* w, float ms[13]);

@@ -1,0 +1,66 @@
+"""World snapshot (second half): save after N steps, load into a NEW world, continue - the loaded world
+must go on bit for bit like the one it was taken from (bodies, contact array, warm-start impulses, cached impacts, colours)."""
+import numpy as np
+import pytest
+
+import b2hip
+
+pytestmark = pytest.mark.gpu
+
+
+def build(continuous):
+    w = b2hip.World(gravity=(0.0, -10.0), continuous=continuous)
+    ground = w.create_body(b2hip.STATIC)
+    w.create_fixture(ground, b2hip.edge_shape((-40.0, 0.0), (40.0, 0.0)))
+    w.create_fixture(ground, b2hip.box_shape(0.5, 6.0), friction=0.4)
+    rng = np.random.default_rng(3)
+    for i in range(260):
+        b = w.create_body(b2hip.DYNAMIC, position=(float(rng.uniform(-12, 12)), 1.0 + 0.55 * (i // 8) + float(rng.uniform(0, 0.2))),
+                          angle=float(rng.uniform(0, 6.28)), velocity=(float(rng.uniform(-2, 2)), 0.0), bullet=(i % 37 == 0))
+        shape = b2hip.circle_shape(float(rng.uniform(0.15, 0.35))) if i % 3 == 0 else b2hip.box_shape(float(rng.uniform(0.15, 0.4)), float(rng.uniform(0.15, 0.3)))
+        w.create_fixture(b, shape, density=1.0, friction=0.3, restitution=0.1 if i % 5 == 0 else 0.0)
+    arm = w.create_body(b2hip.DYNAMIC, position=(20.0, 6.0))
+    w.create_fixture(arm, b2hip.box_shape(2.0, 0.2), density=2.0)
+    w.create_revolute_joint(ground, arm, anchor_a=(18.0, 6.0), anchor_b=(-2.0, 0.0), enable_motor=True, motor_speed=1.5, max_motor_torque=500.0)
+    return w
+
+
+def state(w):
+    s = w.body_states()
+    c = w.contacts()
+    return s.tobytes(), w.contact_count, c.tobytes()
+
+
+@pytest.mark.parametrize("continuous", [False, True])
+def test_snapshot_resume_is_bit_exact(continuous):
+    a = build(continuous)
+    for _ in range(90):
+        a.step()
+    blob = a.save_snapshot()
+    assert len(blob) > 10000
+    b = b2hip.World.from_snapshot(blob)
+    assert b.body_count == a.body_count
+    assert state(a) == state(b), "the loaded world does not show the state it was saved from"
+    for s in range(80):
+        a.step()
+        b.step()
+        assert state(a) == state(b), "the loaded world parts from the original at step %d after the snapshot" % s
+    # edits after the load go through the same mirrors
+    a.apply_force(5, (30.0, 10.0), 1.0)
+    b.apply_force(5, (30.0, 10.0), 1.0)
+    na = a.create_body(b2hip.DYNAMIC, position=(0.0, 30.0))
+    nb = b.create_body(b2hip.DYNAMIC, position=(0.0, 30.0))
+    assert na == nb
+    a.create_fixture(na, b2hip.box_shape(0.3, 0.3), density=1.0)
+    b.create_fixture(nb, b2hip.box_shape(0.3, 0.3), density=1.0)
+    for s in range(40):
+        a.step()
+        b.step()
+        assert state(a) == state(b), "after edits: step %d" % s
+    a.close()
+    b.close()
+
+
+def test_snapshot_rejects_garbage():
+    with pytest.raises(b2hip.B2HipError):
+        b2hip.World.from_snapshot(b"not a snapshot at all" * 10)
