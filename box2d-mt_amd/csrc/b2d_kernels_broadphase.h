@@ -353,6 +353,15 @@ __global__ void k_pairs_sorted_total(DW W, const int* n2)
 	if (*n2 > 0) S->c.nNewContacts = W.pairRank[*n2];
 }
 
+// Creation is all or nothing: if the new contacts of this update do not fit the contact array (or the counting path was
+// given a set it does not handle), nothing is created, the moves stay buffered and Counters::overflow tells the host, which
+// grows the arrays and runs the pair update again - the contacts then appear in one piece, in proxy-key order.
+__device__ __forceinline__ bool createBlocked(const DW& W, const DState* S, int smallPath)
+{
+	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return true;
+	return S->c.nContacts + S->c.nNewContacts > W.capContacts;
+}
+
 // b2ContactManager::ConsumeCreate / OnContactCreate (:488-564) + b2Contact::b2Contact (b2Contact.cpp:125-159)
 // smallPath: ranks came from the counting kernels, which only run for n <= COUNT_RANK_MAX; a larger set is
 // left untouched (moves stay buffered) and the host finishes it with the radix path after its read-back.
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* k
 {
 	DState* S = W.st;
 	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
-	if (smallPath && n > COUNT_RANK_MAX) return;
+	if (createBlocked(W, S, smallPath)) return;
 	const int base = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* k
 __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 {
 	DState* S = W.st;
-	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return;
+	if (createBlocked(W, S, smallPath)) return;
 	// apply the wake requests of contact creation now (the next user of the flags is the next step)
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 __global__ __launch_bounds__(256) void k_toi_order_create(DW W, int smallPath)
 {
 	DState* S = W.st;
-	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return;
+	if (createBlocked(W, S, smallPath)) return;
 	const int nNew = S->c.nNewContacts;
 	if (nNew == 0) return;
 	const int base = S->c.nContacts;
@@ -468,10 +477,12 @@ __global__ __launch_bounds__(256) void k_toi_order_create(DW W, int smallPath)
 __global__ void k_create_commit(DW W, int smallPath)
 {
 	DState* S = W.st;
-	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return;
-	int total = S->c.nContacts + S->c.nNewContacts;
-	if (total > W.capContacts) total = W.capContacts;
-	S->c.nContacts = total;
+	if (createBlocked(W, S, smallPath))
+	{
+		if (S->c.nContacts + S->c.nNewContacts > W.capContacts) atomicOr(&S->c.overflow, 1);
+		return;
+	}
+	S->c.nContacts = S->c.nContacts + S->c.nNewContacts;
 	S->c.nMoves = 0; // b2BroadPhase::ResetBuffers
 }
 

@@ -26,7 +26,7 @@
 #define TOI_RECOMP_MAX 512
 #define TOI_WOKEN_MAX 256
 #define TOI_EVENTS_MAX 100000
-#define TOI_MOVED_ALL_MAX 4096  // proxies re-inserted during one TOI phase (their grid bins are stale): DW::toiMoved
+#define TOI_MOVED_ALL_MAX 32768  // proxies re-inserted during one TOI phase (their grid bins are stale): DW::toiMoved
 
 // Flags are updated with L2 atomics (wake-ups, claims, invalidation) inside the event loop; a plain load could
 // be served from a stale L1 line of the same CU, so flag reads in this file go to L2 as relaxed atomic loads.
@@ -272,7 +272,7 @@ __device__ __forceinline__ void storeAdvanced(const DW& W, int body, const Sweep
 	W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
 }
 
-#define TOI_MOVED_MAX 4096     // proxies re-inserted by the parallel TOI paths in one step (more: serial loop)
+#define TOI_MOVED_MAX 32768     // proxies re-inserted by the parallel TOI paths in one step (more: serial loop)
 
 // unsafe bits of the domain mode (shared with the chains: b2d_kernels_toi_chains.h)
 #define TOI_DOM_UNSAFE_WOKE 2

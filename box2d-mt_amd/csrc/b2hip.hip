@@ -220,6 +220,7 @@ struct b2hip_world
 	int* constsUploadedAt = nullptr;
 	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
+	bool toiSnapshotTaken = false; // this step's TOI phase saved the state it started from (k_toi_snapshot)
 	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false, toiNoDomains = false;
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
@@ -904,8 +905,10 @@ static int findNewContactsGraph(b2hip_world* w)
 // (nothing was consumed: the creation kernels leave an overflowed set alone and the moves stay buffered).
 static int growPairBuffers(b2hip_world* w)
 {
-	w->pairCapHint = 2 * (size_t)w->h_dstate->c.nPairs + 4096;
-	int rc = ensureCapacity(w, (size_t)w->h_dstate->c.nContacts);
+	const Counters& c = w->h_dstate->c;
+	if (c.overflow & 2) w->pairCapHint = 2 * (size_t)c.nPairs + 4096;
+	// (bit 0: the new contacts did not fit the contact array - creation was skipped as a whole, see createBlocked)
+	int rc = ensureCapacity(w, (size_t)c.nContacts + (size_t)std::max(c.nNewContacts, 0) + 1024);
 	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
 	return 0;
@@ -936,7 +939,7 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 	{
 		int rc = readState(w);
 		if (rc) return rc;
-		if (w->h_dstate->c.overflow & 2)
+		if (w->h_dstate->c.overflow & 3)
 		{
 			rc = growPairBuffers(w);
 			return rc ? rc : 1;
@@ -1319,6 +1322,7 @@ static int phaseToi(b2hip_world* w)
 	LAUNCH(w, k_toi_groups_begin, gridFor(std::min(d.capContacts, 1 << 16)), 256, d);
 	LAUNCH(w, k_toi_group_contacts, gridFor(d.capContacts), 256, d);
 	LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+		w->toiSnapshotTaken = true;
 	if (haveGrid)
 	{
 		int rc = toiBuildIndexes(w, false);
@@ -1350,9 +1354,9 @@ static int phaseToiSync(b2hip_world* w)
 		LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
 		rc = readState(w);
 		if (rc) return rc;
-		if (w->h_dstate->c.overflow & 2)
+		if (w->h_dstate->c.overflow & 3)
 		{
-			// the end-of-step pair update overflowed its buffer: grow it, run the whole update again, then look again
+			// the end-of-step pair update overflowed its buffer (or the contact array): grow, run the whole update again, look again
 			if (pass == 1) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
 			rc = growPairBuffers(w);
 			if (rc) return rc;
@@ -1381,6 +1385,7 @@ static int phaseToiSync(b2hip_world* w)
 		LAUNCH(w, k_toi_groups_begin, gridFor(w->h_dstate->c.nToiList), 256, d);
 		LAUNCH(w, k_toi_group_contacts, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+		w->toiSnapshotTaken = true;
 		if (haveGrid)
 		{
 			rc = toiBuildIndexes(w, false);
@@ -1408,6 +1413,7 @@ static int phaseToiSync(b2hip_world* w)
 		LAUNCH(w, k_toi_dom_scan, 1, 1024, d);
 		LAUNCH(w, k_toi_dom_fill, gridFor(w->h_dstate->c.nToiList), 256, d);
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+		w->toiSnapshotTaken = true;
 		LAUNCH(w, k_toi_domains, std::min(w->h_dstate->c.nToiList, 2048), TOI_LANES, d, w->sp);
 		LAUNCH(w, k_toi_domains_end, std::min(std::max(w->h_dstate->c.nToiList, 1), 1024), 256, d);
 		// components tied together by a new contact: back to the snapshot, then the serial loop over just those
@@ -1916,6 +1922,7 @@ int b2hip_solve_toi(b2hip_world* w)
 	w->toiRan = false;
 	w->toiChains = false;
 	w->toiSpeculative = false;
+	w->toiSnapshotTaken = false;
 	w->last.nToiList = w->last.nToiCalls = w->last.nToiEvents = 0;
 	if (w->def.continuous && w->sp.dt > 0.0f)
 	{
@@ -1934,7 +1941,11 @@ int b2hip_step_end(b2hip_world* w)
 	if (rc) return rc;
 	// optimistic small-sort path overflowed (or the pair buffer itself): finish the pair update with the radix path (after
 	// growing the buffer and searching again), then read back again
-	const bool pairOverflow = (w->h_dstate->c.overflow & 2) != 0;
+	// bit 1: candidate-pair buffer; bit 0 with moves still buffered: the new contacts did not fit and creation was skipped
+	// as a whole (createBlocked) - both are cured by growing and running the pair update again. Bit 0 without buffered
+	// moves comes from a contact created inside a TOI sub-step: that one is lost.
+	const bool pairOverflow = (w->h_dstate->c.overflow & 2) != 0 || ((w->h_dstate->c.overflow & 1) != 0 && w->h_dstate->c.nMoves != 0);
+	if ((w->h_dstate->c.overflow & 1) != 0 && !pairOverflow) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step");
 	if (pairOverflow && w->sp.dt <= 0.0f) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
 	if ((w->h_dstate->c.nMoves != 0 || pairOverflow) && w->sp.dt > 0.0f)
 	{
@@ -1988,6 +1999,36 @@ int b2hip_step_end(b2hip_world* w)
 		if (rc) return rc;
 		w->toiFallbacks += 1;
 		w->toiSyncSticky = 16;
+		rc = downloadState(w);
+		if (rc) return rc;
+	}
+	// A contact created inside a TOI sub-step did not fit the array (whatever path ran last, fallbacks included): never a
+	// silent drop. With the snapshot of this step's TOI phase at hand the phase is undone, the array doubled and the phase
+	// run again; without one (serial-only mode) it is an error.
+	for (int attempt = 0; (w->h_dstate->c.overflow & 1) != 0; ++attempt)
+	{
+		if (!w->toiSnapshotTaken || attempt == 3) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step");
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		rc = ensureCapacity(w, 2 * (size_t)w->dw.capContacts);
+		if (rc) return rc;
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+		w->toiChains = false;
+		w->toiSpeculative = false;
+		rc = phaseToiSync(w);
+		if (rc) return rc;
+		if (w->toiChains)
+		{
+			// (the parallel paths report through toiUnsafe: take their serial fallback here as well)
+			rc = downloadState(w);
+			if (rc) return rc;
+			if (w->h_dstate->c.toiUnsafe != 0)
+			{
+				LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+				rc = toiSerial(w);
+				if (rc) return rc;
+				w->toiFallbacks += 1;
+			}
+		}
 		rc = downloadState(w);
 		if (rc) return rc;
 	}
