@@ -272,7 +272,7 @@ __device__ __forceinline__ void storeAdvanced(const DW& W, int body, const Sweep
 	W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
 }
 
-#define TOI_MOVED_MAX 32768     // proxies re-inserted by the parallel TOI paths in one step (more: serial loop)
+#define TOI_MOVED_MAX 4096     // proxies re-inserted by the parallel TOI paths in one step (more: serial loop)
 
 // unsafe bits of the domain mode (shared with the chains: b2d_kernels_toi_chains.h)
 #define TOI_DOM_UNSAFE_WOKE 2

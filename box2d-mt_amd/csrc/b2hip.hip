@@ -588,7 +588,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(scanTmp4, maxScanN / SCAN_TILE + 4);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
-	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
+	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
 	ENS(gridBar, 16);
