@@ -17,6 +17,8 @@
  *   b2hip_sync_fixtures              b2World::SynchronizeFixtures                      b2World.cpp:1143-1164, b2ContactManager.cpp:315-364,441-452
  *   b2hip_find_new_contacts          b2World::FindNewContacts / b2BroadPhase::UpdatePairs / AddPair
  *                                                                                       b2World.cpp:1095-1118, b2BroadPhase.h:211-267, b2ContactManager.cpp:237-312,366-386
+ *   b2hip_solve_toi                  b2World::SolveTOI                                 b2World.cpp:1026-1093, 851-1024
+ *   b2hip_get_fat_aabbs              (served to) b2World::QueryAABB / RayCast          b2World.cpp:1740-1795, b2DynamicTree.h:168-287
  *   b2hip_get_body_states            b2Body::GetPosition/GetAngle/GetLinearVelocity/GetAngularVelocity/IsAwake  b2Body.h:516-700
  *   b2hip_enable/get_contact_events  b2ContactListener::BeginContact / EndContact     b2WorldCallbacks.h:88-104, b2ContactManager.cpp:420-438
  *   b2hip_save / load_snapshot       (new: binary checkpoint; cf. b2World::Dump          b2World.cpp:2107-2164)
