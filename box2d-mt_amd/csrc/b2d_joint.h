@@ -1,7 +1,10 @@
-// b2d_joint.h - revolute joint constraint (the joint type on the device path: Tumbler's motor).
-// Restates b2RevoluteJoint::{InitVelocityConstraints, SolveVelocityConstraints,
-// SolvePositionConstraints} (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376) in the reference's
-// operand order; b2Mat33::Solve33 / Solve22 as in Box2D/Common/b2Math.cpp:25-53.
+// b2d_joint.h - joint constraints on the device path: revolute (Tumbler's motor) and distance (rigid rods and
+// soft springs). One fixed-size record per joint whatever its type (the type-specific members share storage), so
+// the island kernels, the upload and the snapshot handle one array.
+// Restates b2RevoluteJoint::{InitVelocityConstraints, SolveVelocityConstraints, SolvePositionConstraints}
+// (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376) and the same three of b2DistanceJoint
+// (Joints/b2DistanceJoint.cpp:65-236) in the reference's operand order; b2Mat33::Solve33 / Solve22 as in
+// Box2D/Common/b2Math.cpp:25-53.
 #ifndef B2D_JOINT_H
 #define B2D_JOINT_H
 
@@ -17,29 +20,43 @@ enum
 	B2D_LIMIT_EQUAL = 3
 };
 
-struct RevoluteJoint
+enum
 {
-	// definition (b2RevoluteJointDef)
+	B2D_JOINT_REVOLUTE = 0, // e_revoluteJoint
+	B2D_JOINT_DISTANCE = 1  // e_distanceJoint
+};
+
+struct JointRec
+{
+	// definition (b2RevoluteJointDef / b2DistanceJointDef)
 	int bodyA, bodyB;
 	V2 localAnchorA, localAnchorB;
-	float referenceAngle;
+	union { float referenceAngle; float length; };
 	int enableLimit;
-	float lowerAngle, upperAngle;
+	union { float lowerAngle; float frequencyHz; };
+	union { float upperAngle; float dampingRatio; };
 	int enableMotor;
 	float motorSpeed, maxMotorTorque;
 	int collideConnected;
-	// persistent solver state (b2RevoluteJoint.h:190-199)
-	float impulseX, impulseY, impulseZ;
+	// persistent solver state (b2RevoluteJoint.h:190-199, b2DistanceJoint.h:148-150)
+	union { float impulseX; float impulse; };
+	float impulseY, impulseZ;
 	float motorImpulse;
 	int limitState;
 	// per-step scratch written by init
 	V2 rA, rB, localCenterA, localCenterB;
 	float invMassA, invMassB, invIA, invIB;
-	float m_exx, m_exy, m_exz, m_eyx, m_eyy, m_eyz, m_ezx, m_ezy, m_ezz; // m_mass
+	union { float m_exx; float mass; };  // revolute: m_mass (3x3) ; distance: m_mass, m_gamma, m_bias, m_u
+	union { float m_exy; float gamma; };
+	union { float m_exz; float bias; };
+	union { float m_eyx; float ux; };
+	union { float m_eyy; float uy; };
+	float m_eyz, m_ezx, m_ezy, m_ezz;
 	float motorMass;
 	int islandFlag;
-	int pad;
+	int type;
 };
+typedef JointRec RevoluteJoint;
 
 struct V3
 {
@@ -310,6 +327,144 @@ B2D_HD bool b2dRevoluteSolvePosition(const RevoluteJoint* j, BodyPos* A, BodyPos
 	A->c = cA; A->a = aA;
 	B->c = cB; B->a = aB;
 	return positionError <= B2D_LINEAR_SLOP && angularError <= B2D_ANGULAR_SLOP;
+}
+
+// ---- distance joint ---------------------------------------------------------------------------------
+// InitVelocityConstraints (b2DistanceJoint.cpp:65-157)
+B2D_HD void b2dDistanceInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
+{
+	j->localCenterA = lcA;
+	j->localCenterB = lcB;
+	j->invMassA = invMassA;
+	j->invMassB = invMassB;
+	j->invIA = invIA;
+	j->invIB = invIB;
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - lcA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	j->rA = rA;
+	j->rB = rB;
+	V2 u = pB.c + rB - pA.c - rA;
+	float length = b2dLength(u);
+	if (length > B2D_LINEAR_SLOP)
+	{
+		u = (1.0f / length) * u;
+	}
+	else
+	{
+		u = v2(0.0f, 0.0f);
+	}
+	float crAu = b2dCross(rA, u);
+	float crBu = b2dCross(rB, u);
+	float invMass = invMassA + invIA * crAu * crAu + invMassB + invIB * crBu * crBu;
+	float mass = invMass != 0.0f ? 1.0f / invMass : 0.0f;
+	if (j->frequencyHz > 0.0f)
+	{
+		float C = length - j->length;
+		float omega = 2.0f * B2D_PI * j->frequencyHz;
+		float d = 2.0f * mass * j->dampingRatio * omega;
+		float k = mass * omega * omega;
+		float gamma = dt * (d + dt * k);
+		gamma = gamma != 0.0f ? 1.0f / gamma : 0.0f;
+		j->gamma = gamma;
+		j->bias = C * dt * k * gamma;
+		invMass += gamma;
+		mass = invMass != 0.0f ? 1.0f / invMass : 0.0f;
+	}
+	else
+	{
+		j->gamma = 0.0f;
+		j->bias = 0.0f;
+	}
+	j->mass = mass;
+	j->ux = u.x;
+	j->uy = u.y;
+	if (warmStarting)
+	{
+		j->impulse *= dtRatio;
+		V2 P = j->impulse * u;
+		vA -= invMassA * P;
+		wA -= invIA * b2dCross(rA, P);
+		vB += invMassB * P;
+		wB += invIB * b2dCross(rB, P);
+	}
+	else
+	{
+		j->impulse = 0.0f;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolveVelocityConstraints (b2DistanceJoint.cpp:159-184)
+B2D_HD void b2dDistanceSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	V2 rA = j->rA, rB = j->rB, u = v2(j->ux, j->uy);
+	V2 vpA = vA + b2dCrossSV(wA, rA);
+	V2 vpB = vB + b2dCrossSV(wB, rB);
+	float Cdot = b2dDot(u, vpB - vpA);
+	float impulse = -j->mass * (Cdot + j->bias + j->gamma * j->impulse);
+	j->impulse += impulse;
+	V2 P = impulse * u;
+	vA -= j->invMassA * P;
+	wA -= j->invIA * b2dCross(rA, P);
+	vB += j->invMassB * P;
+	wB += j->invIB * b2dCross(rB, P);
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolvePositionConstraints (b2DistanceJoint.cpp:186-225): soft joints have no position correction.
+B2D_HD bool b2dDistanceSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
+{
+	if (j->frequencyHz > 0.0f) return true;
+	V2 cA = A->c, cB = B->c;
+	float aA = A->a, aB = B->a;
+	Rot qA = b2dRot(aA), qB = b2dRot(aB);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - j->localCenterA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - j->localCenterB);
+	V2 u = cB + rB - cA - rA;
+	float length = b2dNormalize(u);
+	float C = length - j->length;
+	C = b2dClamp(C, -B2D_MAX_LINEAR_CORRECTION, B2D_MAX_LINEAR_CORRECTION);
+	float impulse = -j->mass * C;
+	V2 P = impulse * u;
+	cA -= j->invMassA * P;
+	aA -= j->invIA * b2dCross(rA, P);
+	cB += j->invMassB * P;
+	aB += j->invIB * b2dCross(rB, P);
+	A->c = cA; A->a = aA;
+	B->c = cB; B->a = aB;
+	return b2dAbs(C) < B2D_LINEAR_SLOP;
+}
+
+// ---- dispatch on the joint type (b2Joint's virtual calls, b2Island.cpp:235-318) -------------------------
+B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
+{
+	if (j->type == B2D_JOINT_DISTANCE)
+		b2dDistanceInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio, dt);
+	else
+		b2dRevoluteInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA.a, A, pB.a, B, warmStarting, dtRatio);
+}
+
+B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt)
+{
+	if (j->type == B2D_JOINT_DISTANCE)
+		b2dDistanceSolveVelocity(j, A, B);
+	else
+		b2dRevoluteSolveVelocity(j, A, B, dt);
+}
+
+B2D_HD bool b2dJointSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
+{
+	if (j->type == B2D_JOINT_DISTANCE) return b2dDistanceSolvePosition(j, A, B);
+	return b2dRevoluteSolvePosition(j, A, B);
 }
 
 #endif

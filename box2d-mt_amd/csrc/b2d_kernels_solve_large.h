@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mo
 		int okay = 1;
 		for (int t = 0; t < nj; ++t)
 		{
-			RevoluteJoint* j = &W.joints[W.lj_list[start + t]];
+			JointRec* j = &W.joints[W.lj_list[start + t]];
 			const int bA = j->bodyA, bB = j->bodyB;
 			const bool nsA = (W.b_flags[bA] & BF_TYPE_MASK) != BT_STATIC;
 			const bool nsB = (W.b_flags[bB] & BF_TYPE_MASK) != BT_STATIC;
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mo
 				BodyPos pA, pB;
 				pA.c = v2(pa.x, pa.y); pA.a = pa.z;
 				pB.c = v2(pb.x, pb.y); pB.a = pb.z;
-				bool ok = b2dRevoluteSolvePosition(j, &pA, &pB);
+				bool ok = b2dJointSolvePosition(j, &pA, &pB);
 				okay = okay && ok;
 				if (nsA) W.b_pos[bA] = make_float4(pA.c.x, pA.c.y, pA.a, pa.w);
 				if (nsB) W.b_pos[bB] = make_float4(pB.c.x, pB.c.y, pB.a, pb.w);
@@ -736,12 +736,15 @@ __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mo
 				if (mode == 0)
 				{
 					float4 mA = W.b_mass[bA], mB = W.b_mass[bB];
-					b2dRevoluteInit(j, mA.x, mA.y, v2(mA.z, mA.w), mB.x, mB.y, v2(mB.z, mB.w), pa.z, &vA, pb.z, &vB,
-						sp.warmStarting != 0, sp.dtRatio);
+					BodyPos pA, pB;
+					pA.c = v2(pa.x, pa.y); pA.a = pa.z;
+					pB.c = v2(pb.x, pb.y); pB.a = pb.z;
+					b2dJointInit(j, mA.x, mA.y, v2(mA.z, mA.w), mB.x, mB.y, v2(mB.z, mB.w), pA, &vA, pB, &vB,
+						sp.warmStarting != 0, sp.dtRatio, sp.dt);
 				}
 				else
 				{
-					b2dRevoluteSolveVelocity(j, &vA, &vB, sp.dt);
+					b2dJointSolveVelocity(j, &vA, &vB, sp.dt);
 				}
 				if (nsA) W.b_vel[bA] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
 				if (nsB) W.b_vel[bB] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);

@@ -1769,6 +1769,27 @@ int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* 
 	return (int)w->joints.size() - 1;
 }
 
+int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* def)
+{
+	if (!w || !def) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int nb = (int)w->bodies.size();
+	if (def->body_a < 0 || def->body_a >= nb || def->body_b < 0 || def->body_b >= nb) return setError(B2HIP_ERR_INVALID, "bad body id");
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_DISTANCE;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.length = def->length;
+	j.frequencyHz = def->frequency_hz;
+	j.dampingRatio = def->damping_ratio;
+	j.collideConnected = def->collide_connected;
+	w->joints.push_back(j);
+	if (def->collide_connected == 0) w->pendingFilter.push_back(std::make_pair(def->body_a, def->body_b));
+	return (int)w->joints.size() - 1;
+}
+
 int b2hip_body_count(const b2hip_world* w)
 {
 	return w ? (int)w->bodies.size() : 0;

@@ -22,6 +22,7 @@
 #include "Box2D/Dynamics/Contacts/b2Contact.h"
 #include "Box2D/Dynamics/Joints/b2Joint.h"
 #include "Box2D/Dynamics/Joints/b2RevoluteJoint.h"
+#include "Box2D/Dynamics/Joints/b2DistanceJoint.h"
 
 #include "Box2D/MT/b2Task.h"
 #include "Box2D/MT/b2TaskExecutor.h"

@@ -159,35 +159,56 @@ b2Body* b2World::CreateBody(const b2BodyDef* def)
 b2Joint* b2World::CreateJoint(const b2JointDef* def)
 {
 	if (IsLocked() || !m_hip) return nullptr;
-	if (def->type != e_revoluteJoint)
+	int id = -1;
+	b2Joint* j = nullptr;
+	if (def->type == e_revoluteJoint)
+	{
+		const b2RevoluteJointDef* rd = static_cast<const b2RevoluteJointDef*>(def);
+		b2hip_revolute_joint_def d;
+		d.body_a = rd->bodyA->GetDeviceId();
+		d.body_b = rd->bodyB->GetDeviceId();
+		d.local_anchor_a[0] = rd->localAnchorA.x;
+		d.local_anchor_a[1] = rd->localAnchorA.y;
+		d.local_anchor_b[0] = rd->localAnchorB.x;
+		d.local_anchor_b[1] = rd->localAnchorB.y;
+		d.reference_angle = rd->referenceAngle;
+		d.enable_limit = rd->enableLimit;
+		d.lower_angle = rd->lowerAngle;
+		d.upper_angle = rd->upperAngle;
+		d.enable_motor = rd->enableMotor;
+		d.motor_speed = rd->motorSpeed;
+		d.max_motor_torque = rd->maxMotorTorque;
+		d.collide_connected = rd->collideConnected;
+		id = b2hip_create_revolute_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2RevoluteJoint))) b2RevoluteJoint(rd);
+	}
+	else if (def->type == e_distanceJoint)
+	{
+		const b2DistanceJointDef* dd = static_cast<const b2DistanceJointDef*>(def);
+		b2hip_distance_joint_def d;
+		d.body_a = dd->bodyA->GetDeviceId();
+		d.body_b = dd->bodyB->GetDeviceId();
+		d.local_anchor_a[0] = dd->localAnchorA.x;
+		d.local_anchor_a[1] = dd->localAnchorA.y;
+		d.local_anchor_b[0] = dd->localAnchorB.x;
+		d.local_anchor_b[1] = dd->localAnchorB.y;
+		d.length = dd->length;
+		d.frequency_hz = dd->frequencyHz;
+		d.damping_ratio = dd->dampingRatio;
+		d.collide_connected = dd->collideConnected;
+		id = b2hip_create_distance_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2DistanceJoint))) b2DistanceJoint(dd);
+	}
+	else
 	{
 		fprintf(stderr, "b2World::CreateJoint: joint type %d is not on the device path yet\n", (int)def->type);
 		return nullptr;
 	}
-	const b2RevoluteJointDef* rd = static_cast<const b2RevoluteJointDef*>(def);
-	b2hip_revolute_joint_def d;
-	d.body_a = rd->bodyA->GetDeviceId();
-	d.body_b = rd->bodyB->GetDeviceId();
-	d.local_anchor_a[0] = rd->localAnchorA.x;
-	d.local_anchor_a[1] = rd->localAnchorA.y;
-	d.local_anchor_b[0] = rd->localAnchorB.x;
-	d.local_anchor_b[1] = rd->localAnchorB.y;
-	d.reference_angle = rd->referenceAngle;
-	d.enable_limit = rd->enableLimit;
-	d.lower_angle = rd->lowerAngle;
-	d.upper_angle = rd->upperAngle;
-	d.enable_motor = rd->enableMotor;
-	d.motor_speed = rd->motorSpeed;
-	d.max_motor_torque = rd->maxMotorTorque;
-	d.collide_connected = rd->collideConnected;
-	int id = b2hip_create_revolute_joint(m_hip, &d);
 	if (id < 0)
 	{
 		fprintf(stderr, "b2World::CreateJoint: %s\n", b2hip_last_error());
 		return nullptr;
 	}
-	void* mem = b2Alloc(sizeof(b2RevoluteJoint));
-	b2RevoluteJoint* j = new (mem) b2RevoluteJoint(rd);
 	j->m_id = id;
 	j->m_prev = nullptr;
 	j->m_next = m_jointList;
@@ -685,6 +706,15 @@ void b2RevoluteJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor
 	localAnchorA = bodyA->GetLocalPoint(anchor);
 	localAnchorB = bodyB->GetLocalPoint(anchor);
 	referenceAngle = bodyB->GetAngle() - bodyA->GetAngle();
+}
+
+void b2DistanceJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchorA, const b2Vec2& anchorB)
+{
+	bodyA = bA;
+	bodyB = bB;
+	localAnchorA = bodyA->GetLocalPoint(anchorA);
+	localAnchorB = bodyB->GetLocalPoint(anchorB);
+	length = (anchorB - anchorA).Length();
 }
 
 // ---- callbacks / collision helpers ----------------------------------------------------------------

@@ -48,6 +48,12 @@ class RevoluteJointDef(C.Structure):
                 ("motor_speed", C.c_float), ("max_motor_torque", C.c_float), ("collide_connected", C.c_int)]
 
 
+class DistanceJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("local_anchor_a", C.c_float * 2),
+                ("local_anchor_b", C.c_float * 2), ("length", C.c_float), ("frequency_hz", C.c_float),
+                ("damping_ratio", C.c_float), ("collide_connected", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
@@ -81,6 +87,7 @@ def _configure(L, optional_ok=False):
         "b2hip_create_body": [C.c_void_p, C.POINTER(BodyDef)],
         "b2hip_create_fixture": [C.c_void_p, C.c_int, C.POINTER(FixtureDef), C.POINTER(Shape)],
         "b2hip_create_revolute_joint": [C.c_void_p, C.POINTER(RevoluteJointDef)],
+        "b2hip_create_distance_joint": [C.c_void_p, C.POINTER(DistanceJointDef)],
         "b2hip_body_count": [C.c_void_p],
         "b2hip_fixture_count": [C.c_void_p],
         "b2hip_step": [C.c_void_p, C.c_float, C.c_int, C.c_int],
@@ -222,6 +229,16 @@ class World:
         d.enable_motor, d.motor_speed, d.max_motor_torque = int(enable_motor), motor_speed, max_motor_torque
         d.collide_connected = int(collide_connected)
         return _check(self.L.b2hip_create_revolute_joint(self.p, C.byref(d)))
+
+    def create_distance_joint(self, body_a, body_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), length=1.0,
+                              frequency_hz=0.0, damping_ratio=0.0, collide_connected=False):
+        d = DistanceJointDef()
+        d.body_a, d.body_b = body_a, body_b
+        d.local_anchor_a[0], d.local_anchor_a[1] = anchor_a
+        d.local_anchor_b[0], d.local_anchor_b[1] = anchor_b
+        d.length, d.frequency_hz, d.damping_ratio = length, frequency_hz, damping_ratio
+        d.collide_connected = int(collide_connected)
+        return _check(self.L.b2hip_create_distance_joint(self.p, C.byref(d)))
 
     def apply_force(self, body, force=(0.0, 0.0), torque=0.0, wake=True):
         _check(self.L.b2hip_apply_force(self.p, body, force[0], force[1], torque, int(wake)))

@@ -11,6 +11,7 @@
  *   b2hip_create_fixture             b2Body::CreateFixture, b2Fixture::Create/CreateProxies,
  *                                    b2Body::ResetMassData                  b2Body.cpp:182-226,310-385; b2Fixture.cpp:42-141
  *   b2hip_create_revolute_joint      b2World::CreateJoint (revolute)        b2World.cpp:672-760, Joints/b2RevoluteJoint.cpp:47-63
+ *   b2hip_create_distance_joint      b2World::CreateJoint (distance)        b2World.cpp:672-760, Joints/b2DistanceJoint.cpp:51-63
  *   b2hip_step                       b2World::Step                          b2World.cpp:1613-1710
  *   b2hip_collide                    b2World::Collide / b2ContactManager::Collide      b2World.cpp:1120-1141, b2ContactManager.cpp:177-230
  *   b2hip_solve                      b2World::Solve (islands + b2Island::Solve)        b2World.cpp:1166-1431, b2Island.cpp:184-396
@@ -34,6 +35,7 @@
 #ifndef B2HIP_H
 #define B2HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -116,6 +118,16 @@ typedef struct b2hip_revolute_joint_def
 	int collide_connected;
 } b2hip_revolute_joint_def;
 
+/* b2DistanceJointDef (Joints/b2DistanceJoint.h:31-68): rigid rod when frequency_hz == 0, damped spring otherwise */
+typedef struct b2hip_distance_joint_def
+{
+	int body_a, body_b;
+	float local_anchor_a[2], local_anchor_b[2];
+	float length;
+	float frequency_hz, damping_ratio;
+	int collide_connected;
+} b2hip_distance_joint_def;
+
 /* Host-visible body state after a step (40 bytes per body, one coalesced device->host copy). */
 typedef struct b2hip_body_state
 {
@@ -183,6 +195,7 @@ int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int cont
 int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def);
 int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def, const b2hip_shape* shape);
 int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* def);
+int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* def);
 
 int b2hip_body_count(const b2hip_world* w);
 int b2hip_fixture_count(const b2hip_world* w);

@@ -77,6 +77,8 @@ int b2o_create_body(b2o_world* w, const b2o_body_def* def);
 int b2o_create_fixture(b2o_world* w, int body, const b2o_fixture_def* def, const b2o_shape* shape);
 int b2o_create_revolute_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float referenceAngle,
 	int enableLimit, float lower, float upper, int enableMotor, float motorSpeed, float maxMotorTorque, int collideConnected);
+int b2o_create_distance_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float length,
+	float frequencyHz, float dampingRatio, int collideConnected);
 void b2o_apply_force(b2o_world* w, int body, float fx, float fy, float torque, int wake);
 void b2o_set_velocity(b2o_world* w, int body, float vx, float vy, float omega);
 void b2o_step(b2o_world* w, float dt, int velocity_iterations, int position_iterations);

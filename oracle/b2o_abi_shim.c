@@ -66,6 +66,13 @@ int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* 
 		def->lower_angle, def->upper_angle, def->enable_motor, def->motor_speed, def->max_motor_torque, def->collide_connected);
 }
 
+int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* def)
+{
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	return b2o_create_distance_joint(w->o, def->body_a, def->body_b, anchors, def->length, def->frequency_hz, def->damping_ratio,
+		def->collide_connected);
+}
+
 int b2hip_body_count(const b2hip_world* w) { return b2o_body_count(w->o); }
 int b2hip_fixture_count(const b2hip_world* w) { return w->fixtures; }
 

@@ -1,5 +1,6 @@
-/* b2o_joint.c - CPU oracle, revolute joint: plain-C restatement of b2RevoluteJoint
- * (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376; b2Mat33::Solve33/Solve22 b2Math.cpp:25-53).
+/* b2o_joint.c - CPU oracle, joints: plain-C restatement of b2RevoluteJoint
+ * (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376; b2Mat33::Solve33/Solve22 b2Math.cpp:25-53) and of
+ * b2DistanceJoint (Joints/b2DistanceJoint.cpp:65-225).
  * TEST INFRASTRUCTURE (see b2o.h). */
 #include "b2o_joint.h"
 
@@ -225,4 +226,89 @@ int b2o_revolute_position(const revolute_t* j, vec2* pcA, float* paA, vec2* pcB,
 	}
 	*pcA = cA; *paA = aA; *pcB = cB; *paB = aB;
 	return positionError <= B2O_LINEAR_SLOP && angularError <= B2O_ANGULAR_SLOP;
+}
+
+/* ---- distance joint ---------------------------------------------------------------------------- */
+/* InitVelocityConstraints b2DistanceJoint.cpp:65-157 */
+void b2o_distance_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	j->rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	j->rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	j->u = v_sub(v_sub(v_add(cB, j->rB), cA), j->rA);
+	float length = v_length(j->u);
+	if (length > B2O_LINEAR_SLOP) j->u = v_scale(1.0f / length, j->u);
+	else j->u = v_make(0.0f, 0.0f);
+	float crAu = v_cross(j->rA, j->u);
+	float crBu = v_cross(j->rB, j->u);
+	float invMass = mA + iA * crAu * crAu + mB + iB * crBu * crBu;
+	j->mass = invMass != 0.0f ? 1.0f / invMass : 0.0f;
+	if (j->frequencyHz > 0.0f)
+	{
+		float C = length - j->length;
+		float omega = 2.0f * B2O_PI * j->frequencyHz;
+		float d = 2.0f * j->mass * j->dampingRatio * omega;
+		float k = j->mass * omega * omega;
+		j->gamma = dt * (d + dt * k);
+		j->gamma = j->gamma != 0.0f ? 1.0f / j->gamma : 0.0f;
+		j->bias = C * dt * k * j->gamma;
+		invMass += j->gamma;
+		j->mass = invMass != 0.0f ? 1.0f / invMass : 0.0f;
+	}
+	else
+	{
+		j->gamma = 0.0f;
+		j->bias = 0.0f;
+	}
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio;
+		vec2 P = v_scale(j->impulse[0], j->u);
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * v_cross(j->rA, P);
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * v_cross(j->rB, P);
+	}
+	else
+	{
+		j->impulse[0] = 0.0f;
+	}
+}
+
+/* SolveVelocityConstraints :159-184 */
+void b2o_distance_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB)
+{
+	vec2 vpA = v_add(*vA, v_cross_sv(*wA, j->rA));
+	vec2 vpB = v_add(*vB, v_cross_sv(*wB, j->rB));
+	float Cdot = v_dot(j->u, v_sub(vpB, vpA));
+	float impulse = -j->mass * (Cdot + j->bias + j->gamma * j->impulse[0]);
+	j->impulse[0] += impulse;
+	vec2 P = v_scale(impulse, j->u);
+	*vA = v_sub(*vA, v_scale(j->invMassA, P));
+	*wA -= j->invIA * v_cross(j->rA, P);
+	*vB = v_add(*vB, v_scale(j->invMassB, P));
+	*wB += j->invIB * v_cross(j->rB, P);
+}
+
+/* SolvePositionConstraints :186-225 */
+int b2o_distance_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB)
+{
+	if (j->frequencyHz > 0.0f) return 1;
+	rot qA = r_make(*aA), qB = r_make(*aB);
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, j->localCenterA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, j->localCenterB));
+	vec2 u = v_sub(v_sub(v_add(*cB, rB), *cA), rA);
+	float length = v_normalize(&u);
+	float C = length - j->length;
+	C = f_clamp(C, -B2O_MAX_LINEAR_CORRECTION, B2O_MAX_LINEAR_CORRECTION);
+	float impulse = -j->mass * C;
+	vec2 P = v_scale(impulse, u);
+	*cA = v_sub(*cA, v_scale(j->invMassA, P));
+	*aA -= j->invIA * v_cross(rA, P);
+	*cB = v_add(*cB, v_scale(j->invMassB, P));
+	*aB += j->invIB * v_cross(rB, P);
+	return f_abs(C) < B2O_LINEAR_SLOP;
 }

@@ -1,11 +1,14 @@
-/* b2o_joint.h - CPU oracle, revolute joint state (TEST INFRASTRUCTURE, see b2o.h). */
+/* b2o_joint.h - CPU oracle, joint state: revolute and distance (TEST INFRASTRUCTURE, see b2o.h). */
 #ifndef B2O_JOINT_H
 #define B2O_JOINT_H
 
 #include "b2o_internal.h"
 
+enum { B2O_JOINT_REVOLUTE = 0, B2O_JOINT_DISTANCE = 1 };
+
 typedef struct
 {
+	int type;
 	int bodyA, bodyB;
 	vec2 localAnchorA, localAnchorB;
 	float referenceAngle;
@@ -19,6 +22,10 @@ typedef struct
 	vec2 rA, rB, localCenterA, localCenterB;
 	float invMassA, invMassB, invIA, invIB;
 	float ex[3], ey[3], ez[3], motorMass;
+	/* distance joint (b2DistanceJoint.h:137-163); its accumulated impulse is impulse[0] */
+	float length, frequencyHz, dampingRatio;
+	float gamma, bias, mass;
+	vec2 u;
 	int islandFlag;
 	int nextA, nextB; /* per-body joint lists, newest first: edge id = joint * 2 + side */
 } revolute_t;
@@ -27,5 +34,10 @@ void b2o_revolute_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, fl
 	float aA, vec2* vA, float* wA, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
 void b2o_revolute_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt);
 int b2o_revolute_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+void b2o_distance_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt);
+void b2o_distance_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB);
+int b2o_distance_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
 
 #endif

@@ -5,7 +5,7 @@
  * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
- * (b2ContactManager.cpp:366-386). Joints: revolute (b2o_joint.c). Not covered (same as the device
+ * (b2ContactManager.cpp:366-386). Joints: revolute, distance (b2o_joint.c). Not covered (same as the device
  * path): other joint types, chain shapes. Continuous collision: b2o_toi.c
  * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
@@ -414,6 +414,20 @@ int b2o_create_revolute_joint(b2o_world* w, int bodyA, int bodyB, const float* a
 			if (other == bodyA) c->flags |= CF_FILTER;
 		}
 	}
+	return id;
+}
+
+/* b2World::CreateJoint + b2DistanceJoint::b2DistanceJoint (b2DistanceJoint.cpp:51-63): same list linking and
+ * re-filtering as above, distance-specific definition members. */
+int b2o_create_distance_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float length,
+	float frequencyHz, float dampingRatio, int collideConnected)
+{
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors4, 0.0f, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_DISTANCE;
+	j->length = length;
+	j->frequencyHz = frequencyHz;
+	j->dampingRatio = dampingRatio;
 	return id;
 }
 
@@ -1180,9 +1194,14 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		body_t* bA = &w->bodies[j->bodyA];
 		body_t* bB = &w->bodies[j->bodyB];
 		int ia = bA->islandIndex, ib = bB->islandIndex;
-		b2o_revolute_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
-			positions[ia].a, &velocities[ia].v, &velocities[ia].w, positions[ib].a, &velocities[ib].v, &velocities[ib].w,
-			w->warmStarting, dtRatio);
+		if (j->type == B2O_JOINT_DISTANCE)
+			b2o_distance_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].c, positions[ia].a, &velocities[ia].v, &velocities[ia].w,
+				positions[ib].c, positions[ib].a, &velocities[ib].v, &velocities[ib].w, w->warmStarting, dtRatio, h);
+		else
+			b2o_revolute_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].a, &velocities[ia].v, &velocities[ia].w, positions[ib].a, &velocities[ib].v, &velocities[ib].w,
+				w->warmStarting, dtRatio);
 	}
 	for (int it = 0; it < velIters; ++it)
 	{
@@ -1190,7 +1209,10 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		{
 			revolute_t* j = &w->joints[islandJoints[i]];
 			int ia = w->bodies[j->bodyA].islandIndex, ib = w->bodies[j->bodyB].islandIndex;
-			b2o_revolute_velocity(j, &velocities[ia].v, &velocities[ia].w, &velocities[ib].v, &velocities[ib].w, h);
+			if (j->type == B2O_JOINT_DISTANCE)
+				b2o_distance_velocity(j, &velocities[ia].v, &velocities[ia].w, &velocities[ib].v, &velocities[ib].w);
+			else
+				b2o_revolute_velocity(j, &velocities[ia].v, &velocities[ia].w, &velocities[ib].v, &velocities[ib].w, h);
 		}
 		for (int i = 0; i < contactCount; ++i) solve_velocity(&cs[i], velocities);
 	}
@@ -1235,7 +1257,9 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		{
 			revolute_t* j = &w->joints[islandJoints[i]];
 			int ia = w->bodies[j->bodyA].islandIndex, ib = w->bodies[j->bodyB].islandIndex;
-			int ok = b2o_revolute_position(j, &positions[ia].c, &positions[ia].a, &positions[ib].c, &positions[ib].a);
+			int ok = j->type == B2O_JOINT_DISTANCE
+				? b2o_distance_position(j, &positions[ia].c, &positions[ia].a, &positions[ib].c, &positions[ib].a)
+				: b2o_revolute_position(j, &positions[ia].c, &positions[ia].a, &positions[ib].c, &positions[ib].a);
 			jointsOkay = jointsOkay && ok;
 		}
 		if (minSeparation >= -3.0f * B2O_LINEAR_SLOP && jointsOkay)

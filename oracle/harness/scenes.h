@@ -1,7 +1,7 @@
 // Scene recipes used by the parity harness and the bench.
 //
 // TEST INFRASTRUCTURE. This file is written against the PUBLIC Box2D-MT API only
-// (b2World / b2Body / b2Fixture / shapes / b2RevoluteJointDef), so the very same source is
+// (b2World / b2Body / b2Fixture / shapes / b2RevoluteJointDef / b2DistanceJointDef), so the very same source is
 // compiled twice:
 //   * against the reference headers + sources under /root/reference  -> oracle/_ref/libb2ref_harness.so
 //   * against this repo's drop-in headers (box2d-mt_amd/host)         -> libb2amd_harness.so
@@ -70,6 +70,8 @@ enum SceneId
 	e_circleStack = 6,   // p0 = columns, p1 = circles per column, on an edge ground
 	e_sensors = 8,       // p0 = falling bodies ; static sensor regions (box, circle, polygon) + one dynamic body that carries
 	                     //   a proximity sensor: exercises b2Contact::Update's sensor branch (b2TestOverlap = GJK with radii)
+	e_ropes = 9,         // p0 = falling bodies, p1 = planks ; distance joints: a plank bridge hung by rigid rods between its
+	                     //   planks and the ground, a soft web of four boxes on damped springs, bodies dropped on both
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -521,6 +523,106 @@ inline void BuildSensors(Scene& s, b2World* w, int count, uint32_t seed)
 // Continuous-collision stress: a 40 x 30 room made of an edge floor and thin (0.1 wide) polygon walls, a few
 // box stacks inside, and fast small projectiles (polygons and circles; every other one is a bullet body)
 // fired through it. Fast non-bullet bodies still get TOI against the static walls; bullets also against the stacks.
+// Distance joints in both regimes (rigid rod: frequencyHz = 0, spring: > 0) mixed with contacts in the same islands.
+inline void BuildRopes(Scene& s, b2World* w, int count, int planks, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	Pcg32 rng(seed ? seed : 23u);
+	if (planks < 2) planks = 2;
+	b2Body* ground;
+	{
+		b2BodyDef bd;
+		ground = AddBody(s, w, bd);
+		b2EdgeShape edge;
+		edge.Set(b2Vec2(-40.0f, 0.0f), b2Vec2(40.0f, 0.0f));
+		ground->CreateFixture(&edge, 0.0f);
+	}
+	// bridge: planks of half length 0.35, 1.1 apart along a parabola that sags 2.5 below its two ground anchors; neighbours
+	// are tied end to end by rods whose rest length is the initial gap
+	{
+		b2PolygonShape plank;
+		const float hx = 0.35f;
+		plank.SetAsBox(hx, 0.125f);
+		b2FixtureDef fd;
+		fd.shape = &plank;
+		fd.density = 4.0f;
+		fd.friction = 0.4f;
+		const float pitch = 1.1f, top = 8.0f, sag = 2.5f;
+		const float x0 = -20.0f;
+		b2Body* prev = ground;
+		b2Vec2 prevAnchor(x0 - pitch + hx, top);
+		for (int i = 0; i < planks; ++i)
+		{
+			const float t = (float)(2 * i - (planks - 1)) / (float)(planks + 1);
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(x0 + pitch * (float)i, top - sag * (1.0f - t * t));
+			b2Body* body = AddBody(s, w, bd);
+			body->CreateFixture(&fd);
+			b2DistanceJointDef jd;
+			jd.Initialize(prev, body, prevAnchor, b2Vec2(bd.position.x - hx, bd.position.y));
+			w->CreateJoint(&jd);
+			prev = body;
+			prevAnchor.Set(bd.position.x + hx, bd.position.y);
+		}
+		b2DistanceJointDef jd;
+		jd.Initialize(prev, ground, prevAnchor, b2Vec2(prevAnchor.x + pitch - hx, top));
+		w->CreateJoint(&jd);
+	}
+	// web: four boxes on springs to each other and to four ground anchors (frequencies 2..4 Hz)
+	{
+		b2PolygonShape box;
+		box.SetAsBox(0.5f, 0.5f);
+		b2Body* web[4];
+		const float cx = 12.0f, cy = 10.0f;
+		const float ox[4] = { -3.0f, 3.0f, 3.0f, -3.0f }, oy[4] = { -3.0f, -3.0f, 3.0f, 3.0f };
+		for (int i = 0; i < 4; ++i)
+		{
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(cx + ox[i], cy + oy[i]);
+			web[i] = AddBody(s, w, bd);
+			web[i]->CreateFixture(&box, 5.0f);
+		}
+		for (int i = 0; i < 4; ++i)
+		{
+			b2DistanceJointDef jd;
+			jd.frequencyHz = 2.0f + 0.5f * (float)i;
+			jd.dampingRatio = 0.1f * (float)i;
+			jd.Initialize(ground, web[i], b2Vec2(cx + 2.5f * ox[i], cy + 2.5f * oy[i]), web[i]->GetWorldPoint(b2Vec2(0.17f * ox[i], 0.17f * oy[i])));
+			w->CreateJoint(&jd);
+			const int k = (i + 1) & 3;
+			jd.frequencyHz = 4.0f;
+			jd.dampingRatio = 0.5f;
+			jd.collideConnected = (i & 1) != 0;
+			jd.Initialize(web[i], web[k], web[i]->GetWorldPoint(b2Vec2(0.5f * (ox[k] - ox[i]) / 6.0f, 0.5f * (oy[k] - oy[i]) / 6.0f)),
+				web[k]->GetWorldPoint(b2Vec2(0.5f * (ox[i] - ox[k]) / 6.0f, 0.5f * (oy[i] - oy[k]) / 6.0f)));
+			w->CreateJoint(&jd);
+		}
+	}
+	// bodies dropped over the bridge and the web
+	for (int i = 0; i < count; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(rng.Range(-20.0f, 16.0f), rng.Range(8.0f, 30.0f));
+		bd.angle = rng.Range(-1.0f, 1.0f);
+		b2Body* body = AddBody(s, w, bd);
+		if (i & 1)
+		{
+			b2CircleShape c;
+			c.m_radius = rng.Range(0.15f, 0.4f);
+			body->CreateFixture(&c, 1.0f);
+		}
+		else
+		{
+			b2PolygonShape b;
+			b.SetAsBox(rng.Range(0.15f, 0.45f), rng.Range(0.15f, 0.45f));
+			body->CreateFixture(&b, 1.0f);
+		}
+	}
+}
+
 inline void BuildBullets(Scene& s, b2World* w, int projectiles, int stackHeight, uint32_t seed)
 {
 	w->SetGravity(b2Vec2(0.0f, -10.0f));
@@ -601,6 +703,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_circleStack: BuildCircleStack(s, w, p.p0, p.p1); break;
 	case e_bullets: BuildBullets(s, w, p.p0, p.p1, p.seed); break;
 	case e_sensors: BuildSensors(s, w, p.p0, p.seed); break;
+	case e_ropes: BuildRopes(s, w, p.p0, p.p1, p.seed); break;
 	default: break;
 	}
 }

@@ -35,6 +35,7 @@ SCENES = [
     ("tumbler6", bh.TUMBLER, 6, 0, 0.0, 0.0, 1, 300),
     ("tumbler20", bh.TUMBLER, 20, 0, 0.0, 0.0, 1, 150),
     ("sensors", bh.SENSORS, 40, 0, 0.0, 0.0, 5, 240),
+    ("ropes", bh.ROPES, 80, 14, 0.0, 0.0, 9, 240),
     ("pyramid141", bh.PYRAMID, 141, 1, 0.0, 0.0, 1, 30),
 ]
 

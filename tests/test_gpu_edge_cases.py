@@ -181,6 +181,51 @@ def test_revolute_pendulum_chain(libs, monkeypatch):
     a.close(); b.close()
 
 
+def test_distance_joints_rods_and_springs(libs, monkeypatch):
+    """Distance joints (b2DistanceJoint.cpp): a rope of circles on rigid rods swinging into a wall, a weight on a soft
+    spring, and a box held by a rod and a revolute joint at once (two joint types in one island), collide_connected both
+    ways. Exact-order mode, as for every island with joints."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+        w.create_fixture(g, b2hip.box_shape(30.0, 0.5))
+        wall = w.create_body(b2hip.STATIC, (6.0, 6.0))
+        w.create_fixture(wall, b2hip.box_shape(0.5, 6.0))
+        prev, prev_anchor = g, (0.0, 12.0)
+        for i in range(8):
+            d = w.create_body(b2hip.DYNAMIC, (-1.0 - i, 12.0))
+            w.create_fixture(d, b2hip.circle_shape(0.3), density=1.0 + 0.5 * i, restitution=0.2)
+            w.create_distance_joint(prev, d, anchor_a=prev_anchor, anchor_b=(0.0, 0.0), length=1.0, collide_connected=bool(i & 1))
+            prev, prev_anchor = d, (0.0, 0.0)
+        m = w.create_body(b2hip.DYNAMIC, (12.0, 6.0))
+        w.create_fixture(m, b2hip.box_shape(0.5, 0.5), density=3.0)
+        w.create_distance_joint(g, m, anchor_a=(12.0, 12.0), anchor_b=(0.2, 0.5), length=4.0, frequency_hz=1.5, damping_ratio=0.2)
+        k = w.create_body(b2hip.DYNAMIC, (16.0, 8.0), angle=0.4)
+        w.create_fixture(k, b2hip.box_shape(1.0, 0.25), density=1.0)
+        w.create_revolute_joint(g, k, anchor_a=(15.0, 8.0), anchor_b=(-1.0, 0.0))
+        w.create_distance_joint(m, k, anchor_a=(0.0, 0.0), anchor_b=(1.0, 0.0), length=5.0, frequency_hz=3.0, damping_ratio=0.7,
+                                collide_connected=True)
+    run(a, b, 300, "distance joints")
+    a.close(); b.close()
+
+
+def test_distance_joints_without_warm_starting(libs, monkeypatch):
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs, warm_starting=False)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+        w.create_fixture(g, b2hip.box_shape(10.0, 0.5))
+        d = w.create_body(b2hip.DYNAMIC, (3.0, 5.0))
+        w.create_fixture(d, b2hip.box_shape(0.4, 0.4), density=1.0)
+        w.create_distance_joint(g, d, anchor_a=(0.0, 5.0), anchor_b=(0.0, 0.0), length=3.0)
+        e = w.create_body(b2hip.DYNAMIC, (3.0, 3.0))
+        w.create_fixture(e, b2hip.circle_shape(0.3), density=1.0)
+        w.create_distance_joint(d, e, anchor_a=(0.0, -0.4), anchor_b=(0.0, 0.0), length=1.6, frequency_hz=5.0, damping_ratio=0.1)
+    run(a, b, 150, "distance joints, no warm start")
+    a.close(); b.close()
+
+
 def test_dense_start_grows_the_pair_buffer(monkeypatch):
     """1 400 bodies and 450 bullets crammed into a 70 x 70 arena: the first pair update finds several times more candidate
     pairs than the buffer was sized for (21 000 contacts on step one). The buffers grow and the search runs again - no

@@ -21,7 +21,7 @@ import b2harness as bh
 pytestmark = pytest.mark.gpu
 
 SMALL_ISLAND_SCENES = ["helloworld", "pyramid5x3", "piles", "circlestack", "field", "sensors"]
-ALL_SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20", "sensors"]
+ALL_SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20", "sensors", "ropes"]
 
 # coloured large islands: |pose - reference| / scene_scale after COLORED_HORIZON steps of a settling
 # 30-row pyramid (466 bodies, one island). Measured 4e-4 .. 3e-3 (impact transient); bound with margin.
@@ -262,6 +262,34 @@ def test_tumbler_colored_mode_runs_and_stays_bounded(amd, oracle, default_mode):
     ly = -np.sin(ang) * dx + np.cos(ang) * dy
     assert (np.abs(lx) < 10.0).all() and (np.abs(ly) < 10.0).all(), "a box left the container"
     assert abs(a.contact_count - o.contact_count) <= 0.15 * o.contact_count  # chaotic pile: AABB-pair count only roughly comparable
+    a.close()
+    o.close()
+
+
+def test_ropes_colored_mode_keeps_the_joints_tight(amd, oracle, default_mode):
+    """Distance joints in the default (coloured) mode: the plank bridge of the ropes scene is one island of rigid rods with
+    bodies landing on it. Floats differ from the reference order, so check the constraint itself: every rod keeps its rest
+    length about as well as the oracle's does (it stretches by up to 0.03 there), and the bridge hangs where the oracle's does."""
+    n = 14
+    a = amd.world(bh.ROPES, 80, n, seed=9)
+    o = oracle.world(bh.ROPES, 80, n, seed=9)
+
+    def gaps(B):
+        p = B[1:1 + n]
+        d = 0.35 * np.stack([np.cos(p[:, 2]), np.sin(p[:, 2])], 1)
+        return np.linalg.norm((p[1:, :2] - d[1:]) - (p[:-1, :2] + d[:-1]), axis=1)
+
+    rest = gaps(a.bodies())
+    worst = 0.0
+    for s in range(240):
+        a.step(1)
+        o.step(1)
+        worst = max(worst, float(np.abs(gaps(a.bodies()) - rest).max()))
+    A, O = a.bodies(), o.bodies()
+    assert np.isfinite(A).all()
+    assert worst < 0.08, "a rod stretched by %g" % worst
+    assert np.abs(gaps(A) - rest).max() < 0.01, "the settled bridge still has stretched rods"
+    assert np.abs(A[1:1 + n, :2] - O[1:1 + n, :2]).max() < 0.25, "bridge shape far from the oracle's"
     a.close()
     o.close()
 
