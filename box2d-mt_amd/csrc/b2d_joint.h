@@ -1,10 +1,11 @@
-// b2d_joint.h - joint constraints on the device path: revolute (Tumbler's motor) and distance (rigid rods and
-// soft springs). One fixed-size record per joint whatever its type (the type-specific members share storage), so
+// b2d_joint.h - joint constraints on the device path: revolute (Tumbler's motor), distance (rigid rods and
+// soft springs), prismatic (MultithreadDemo's slider: axis, limits, motor) and weld (rigid or soft). One fixed-size record per joint whatever its type (the type-specific members share storage), so
 // the island kernels, the upload and the snapshot handle one array.
 // Restates b2RevoluteJoint::{InitVelocityConstraints, SolveVelocityConstraints, SolvePositionConstraints}
 // (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376) and the same three of b2DistanceJoint
-// (Joints/b2DistanceJoint.cpp:65-236) in the reference's operand order; b2Mat33::Solve33 / Solve22 as in
-// Box2D/Common/b2Math.cpp:25-53.
+// (Joints/b2DistanceJoint.cpp:65-236), b2PrismaticJoint (Joints/b2PrismaticJoint.cpp:130-478) and b2WeldJoint
+// (Joints/b2WeldJoint.cpp:58-303) in the reference's operand order; b2Mat33::Solve33 / Solve22 / GetInverse22 /
+// GetSymInverse33 as in Box2D/Common/b2Math.cpp:25-94.
 #ifndef B2D_JOINT_H
 #define B2D_JOINT_H
 
@@ -23,20 +24,23 @@ enum
 enum
 {
 	B2D_JOINT_REVOLUTE = 0, // e_revoluteJoint
-	B2D_JOINT_DISTANCE = 1  // e_distanceJoint
+	B2D_JOINT_DISTANCE = 1, // e_distanceJoint
+	B2D_JOINT_PRISMATIC = 2, // e_prismaticJoint
+	B2D_JOINT_WELD = 3      // e_weldJoint
 };
 
 struct JointRec
 {
-	// definition (b2RevoluteJointDef / b2DistanceJointDef)
+	// definition (b2RevoluteJointDef / b2DistanceJointDef / b2PrismaticJointDef / b2WeldJointDef)
 	int bodyA, bodyB;
 	V2 localAnchorA, localAnchorB;
 	union { float referenceAngle; float length; };
 	int enableLimit;
-	union { float lowerAngle; float frequencyHz; };
-	union { float upperAngle; float dampingRatio; };
+	union { float lowerAngle; float frequencyHz; float lowerTranslation; };
+	union { float upperAngle; float dampingRatio; float upperTranslation; };
 	int enableMotor;
-	float motorSpeed, maxMotorTorque;
+	float motorSpeed;
+	union { float maxMotorTorque; float maxMotorForce; };
 	int collideConnected;
 	// persistent solver state (b2RevoluteJoint.h:190-199, b2DistanceJoint.h:148-150)
 	union { float impulseX; float impulse; };
@@ -55,6 +59,10 @@ struct JointRec
 	float motorMass;
 	int islandFlag;
 	int type;
+	V2 localAxisA;                        // prismatic: m_localXAxisA (normalised at creation)
+	union { float s1; float wGamma; };    // prismatic: m_s1, m_s2, m_a1, m_a2 ; weld: m_gamma, m_bias
+	union { float s2; float wBias; };
+	float a1, a2;
 };
 typedef JointRec RevoluteJoint;
 
@@ -72,6 +80,90 @@ B2D_HD V3 b2dCross3(V3 a, V3 b)
 	return r;
 }
 B2D_HD float b2dDot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+B2D_HD V3 v3(float x, float y, float z)
+{
+	V3 r;
+	r.x = x; r.y = y; r.z = z;
+	return r;
+}
+
+// b2Mat33 (b2Math.h:237-291) as three columns
+struct M33
+{
+	V3 ex, ey, ez;
+};
+
+B2D_HD M33 b2dJointMatrix(const struct JointRec* j);
+
+B2D_HD V3 b2dM33Solve33(const M33& K, V3 b)
+{
+	float det = b2dDot3(K.ex, b2dCross3(K.ey, K.ez));
+	if (det != 0.0f) det = 1.0f / det;
+	V3 x;
+	x.x = det * b2dDot3(b, b2dCross3(K.ey, K.ez));
+	x.y = det * b2dDot3(K.ex, b2dCross3(b, K.ez));
+	x.z = det * b2dDot3(K.ex, b2dCross3(K.ey, b));
+	return x;
+}
+
+B2D_HD V2 b2dM33Solve22(const M33& K, V2 b)
+{
+	float a11 = K.ex.x, a12 = K.ey.x, a21 = K.ex.y, a22 = K.ey.y;
+	float det = a11 * a22 - a12 * a21;
+	if (det != 0.0f) det = 1.0f / det;
+	V2 x;
+	x.x = det * (a22 * b.x - a12 * b.y);
+	x.y = det * (a11 * b.y - a21 * b.x);
+	return x;
+}
+
+// b2Mat33::GetInverse22 (b2Math.cpp:56-68)
+B2D_HD M33 b2dM33Inverse22(const M33& K)
+{
+	float a = K.ex.x, b = K.ey.x, c = K.ex.y, d = K.ey.y;
+	float det = a * d - b * c;
+	if (det != 0.0f) det = 1.0f / det;
+	M33 M;
+	M.ex = v3(det * d, -det * c, 0.0f);
+	M.ey = v3(-det * b, det * a, 0.0f);
+	M.ez = v3(0.0f, 0.0f, 0.0f);
+	return M;
+}
+
+// b2Mat33::GetSymInverse33 (b2Math.cpp:71-94)
+B2D_HD M33 b2dM33SymInverse33(const M33& K)
+{
+	float det = b2dDot3(K.ex, b2dCross3(K.ey, K.ez));
+	if (det != 0.0f) det = 1.0f / det;
+	float a11 = K.ex.x, a12 = K.ey.x, a13 = K.ez.x;
+	float a22 = K.ey.y, a23 = K.ez.y;
+	float a33 = K.ez.z;
+	M33 M;
+	M.ex.x = det * (a22 * a33 - a23 * a23);
+	M.ex.y = det * (a13 * a23 - a12 * a33);
+	M.ex.z = det * (a12 * a23 - a13 * a22);
+	M.ey.x = M.ex.y;
+	M.ey.y = det * (a11 * a33 - a13 * a13);
+	M.ey.z = det * (a13 * a12 - a11 * a23);
+	M.ez.x = M.ex.z;
+	M.ez.y = M.ey.z;
+	M.ez.z = det * (a11 * a22 - a12 * a12);
+	return M;
+}
+
+// b2Mul(b2Mat33, b2Vec3) (b2Math.h:515-518): v.x * ex + v.y * ey + v.z * ez
+B2D_HD V3 b2dM33Mul(const M33& A, V3 v)
+{
+	return v3(v.x * A.ex.x + v.y * A.ey.x + v.z * A.ez.x, v.x * A.ex.y + v.y * A.ey.y + v.z * A.ez.y,
+		v.x * A.ex.z + v.y * A.ey.z + v.z * A.ez.z);
+}
+
+// b2Mul22(b2Mat33, b2Vec2) (b2Math.h:521-524)
+B2D_HD V2 b2dM33Mul22(const M33& A, V2 v)
+{
+	return v2(A.ex.x * v.x + A.ey.x * v.y, A.ex.y * v.x + A.ey.y * v.y);
+}
 
 B2D_HD V3 b2dSolve33(const RevoluteJoint* j, V3 b)
 {
@@ -443,12 +535,469 @@ B2D_HD bool b2dDistanceSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 	return b2dAbs(C) < B2D_LINEAR_SLOP;
 }
 
+B2D_HD M33 b2dJointMatrix(const JointRec* j)
+{
+	M33 K;
+	K.ex = v3(j->m_exx, j->m_exy, j->m_exz);
+	K.ey = v3(j->m_eyx, j->m_eyy, j->m_eyz);
+	K.ez = v3(j->m_ezx, j->m_ezy, j->m_ezz);
+	return K;
+}
+
+B2D_HD void b2dJointSetMatrix(JointRec* j, const M33& K)
+{
+	j->m_exx = K.ex.x; j->m_exy = K.ex.y; j->m_exz = K.ex.z;
+	j->m_eyx = K.ey.x; j->m_eyy = K.ey.y; j->m_eyz = K.ey.z;
+	j->m_ezx = K.ez.x; j->m_ezy = K.ez.y; j->m_ezz = K.ez.z;
+}
+
+B2D_HD void b2dJointStoreBodies(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB)
+{
+	j->localCenterA = lcA;
+	j->localCenterB = lcB;
+	j->invMassA = invMassA;
+	j->invMassB = invMassB;
+	j->invIA = invIA;
+	j->invIB = invIB;
+}
+
+// ---- prismatic joint --------------------------------------------------------------------------------
+// The record keeps m_axis in rA and m_perp in rB (the lever arms themselves are not needed after init).
+// InitVelocityConstraints (b2PrismaticJoint.cpp:130-257)
+B2D_HD void b2dPrismaticInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio)
+{
+	b2dJointStoreBodies(j, invMassA, invIA, lcA, invMassB, invIB, lcB);
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - lcA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	V2 d = (pB.c - pA.c) + rB - rA;
+	float mA = invMassA, mB = invMassB, iA = invIA, iB = invIB;
+	V2 axis = b2dMulRV(qA, j->localAxisA);
+	float a1 = b2dCross(d + rA, axis);
+	float a2 = b2dCross(rB, axis);
+	float motorMass = mA + mB + iA * a1 * a1 + iB * a2 * a2;
+	if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
+	V2 perp = b2dMulRV(qA, b2dCrossSV(1.0f, j->localAxisA));
+	float s1 = b2dCross(d + rA, perp);
+	float s2 = b2dCross(rB, perp);
+	{
+		float k11 = mA + mB + iA * s1 * s1 + iB * s2 * s2;
+		float k12 = iA * s1 + iB * s2;
+		float k13 = iA * s1 * a1 + iB * s2 * a2;
+		float k22 = iA + iB;
+		if (k22 == 0.0f) k22 = 1.0f; // bodies with fixed rotation
+		float k23 = iA * a1 + iB * a2;
+		float k33 = mA + mB + iA * a1 * a1 + iB * a2 * a2;
+		M33 K;
+		K.ex = v3(k11, k12, k13);
+		K.ey = v3(k12, k22, k23);
+		K.ez = v3(k13, k23, k33);
+		b2dJointSetMatrix(j, K);
+	}
+	j->rA = axis;
+	j->rB = perp;
+	j->a1 = a1; j->a2 = a2; j->s1 = s1; j->s2 = s2;
+	j->motorMass = motorMass;
+	if (j->enableLimit)
+	{
+		float jointTranslation = b2dDot(axis, d);
+		if (b2dAbs(j->upperTranslation - j->lowerTranslation) < 2.0f * B2D_LINEAR_SLOP)
+		{
+			j->limitState = B2D_LIMIT_EQUAL;
+		}
+		else if (jointTranslation <= j->lowerTranslation)
+		{
+			if (j->limitState != B2D_LIMIT_AT_LOWER)
+			{
+				j->limitState = B2D_LIMIT_AT_LOWER;
+				j->impulseZ = 0.0f;
+			}
+		}
+		else if (jointTranslation >= j->upperTranslation)
+		{
+			if (j->limitState != B2D_LIMIT_AT_UPPER)
+			{
+				j->limitState = B2D_LIMIT_AT_UPPER;
+				j->impulseZ = 0.0f;
+			}
+		}
+		else
+		{
+			j->limitState = B2D_LIMIT_INACTIVE;
+			j->impulseZ = 0.0f;
+		}
+	}
+	else
+	{
+		j->limitState = B2D_LIMIT_INACTIVE;
+		j->impulseZ = 0.0f;
+	}
+	if (j->enableMotor == 0) j->motorImpulse = 0.0f;
+	if (warmStarting)
+	{
+		j->impulseX *= dtRatio;
+		j->impulseY *= dtRatio;
+		j->impulseZ *= dtRatio;
+		j->motorImpulse *= dtRatio;
+		V2 P = j->impulseX * perp + (j->motorImpulse + j->impulseZ) * axis;
+		float LA = j->impulseX * s1 + j->impulseY + (j->motorImpulse + j->impulseZ) * a1;
+		float LB = j->impulseX * s2 + j->impulseY + (j->motorImpulse + j->impulseZ) * a2;
+		vA -= mA * P;
+		wA -= iA * LA;
+		vB += mB * P;
+		wB += iB * LB;
+	}
+	else
+	{
+		j->impulseX = j->impulseY = j->impulseZ = 0.0f;
+		j->motorImpulse = 0.0f;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolveVelocityConstraints (b2PrismaticJoint.cpp:259-350)
+B2D_HD void b2dPrismaticSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	const V2 axis = j->rA, perp = j->rB;
+	const float a1 = j->a1, a2 = j->a2, s1 = j->s1, s2 = j->s2;
+	if (j->enableMotor && j->limitState != B2D_LIMIT_EQUAL)
+	{
+		float Cdot = b2dDot(axis, vB - vA) + a2 * wB - a1 * wA;
+		float impulse = j->motorMass * (j->motorSpeed - Cdot);
+		float oldImpulse = j->motorImpulse;
+		float maxImpulse = dt * j->maxMotorForce;
+		j->motorImpulse = b2dClamp(j->motorImpulse + impulse, -maxImpulse, maxImpulse);
+		impulse = j->motorImpulse - oldImpulse;
+		V2 P = impulse * axis;
+		float LA = impulse * a1;
+		float LB = impulse * a2;
+		vA -= mA * P;
+		wA -= iA * LA;
+		vB += mB * P;
+		wB += iB * LB;
+	}
+	V2 Cdot1;
+	Cdot1.x = b2dDot(perp, vB - vA) + s2 * wB - s1 * wA;
+	Cdot1.y = wB - wA;
+	const M33 K = b2dJointMatrix(j);
+	if (j->enableLimit && j->limitState != B2D_LIMIT_INACTIVE)
+	{
+		float Cdot2 = b2dDot(axis, vB - vA) + a2 * wB - a1 * wA;
+		V3 f1 = v3(j->impulseX, j->impulseY, j->impulseZ);
+		V3 df = b2dM33Solve33(K, v3(-Cdot1.x, -Cdot1.y, -Cdot2));
+		V3 imp = v3(f1.x + df.x, f1.y + df.y, f1.z + df.z);
+		if (j->limitState == B2D_LIMIT_AT_LOWER)
+		{
+			imp.z = b2dMax(imp.z, 0.0f);
+		}
+		else if (j->limitState == B2D_LIMIT_AT_UPPER)
+		{
+			imp.z = b2dMin(imp.z, 0.0f);
+		}
+		// the two unlimited rows again with the limit impulse fixed
+		V2 b = -Cdot1 - (imp.z - f1.z) * v2(K.ez.x, K.ez.y);
+		V2 f2r = b2dM33Solve22(K, b) + v2(f1.x, f1.y);
+		imp.x = f2r.x;
+		imp.y = f2r.y;
+		df = v3(imp.x - f1.x, imp.y - f1.y, imp.z - f1.z);
+		j->impulseX = imp.x; j->impulseY = imp.y; j->impulseZ = imp.z;
+		V2 P = df.x * perp + df.z * axis;
+		float LA = df.x * s1 + df.y + df.z * a1;
+		float LB = df.x * s2 + df.y + df.z * a2;
+		vA -= mA * P;
+		wA -= iA * LA;
+		vB += mB * P;
+		wB += iB * LB;
+	}
+	else
+	{
+		V2 df = b2dM33Solve22(K, -Cdot1);
+		j->impulseX += df.x;
+		j->impulseY += df.y;
+		V2 P = df.x * perp;
+		float LA = df.x * s1 + df.y;
+		float LB = df.x * s2 + df.y;
+		vA -= mA * P;
+		wA -= iA * LA;
+		vB += mB * P;
+		wB += iB * LB;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolvePositionConstraints (b2PrismaticJoint.cpp:352-478)
+B2D_HD bool b2dPrismaticSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
+{
+	V2 cA = A->c, cB = B->c;
+	float aA = A->a, aB = B->a;
+	Rot qA = b2dRot(aA), qB = b2dRot(aB);
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	V2 rA = b2dMulRV(qA, j->localAnchorA - j->localCenterA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - j->localCenterB);
+	V2 d = cB + rB - cA - rA;
+	V2 axis = b2dMulRV(qA, j->localAxisA);
+	float a1 = b2dCross(d + rA, axis);
+	float a2 = b2dCross(rB, axis);
+	V2 perp = b2dMulRV(qA, b2dCrossSV(1.0f, j->localAxisA));
+	float s1 = b2dCross(d + rA, perp);
+	float s2 = b2dCross(rB, perp);
+	V3 impulse;
+	V2 C1;
+	C1.x = b2dDot(perp, d);
+	C1.y = aB - aA - j->referenceAngle;
+	float linearError = b2dAbs(C1.x);
+	float angularError = b2dAbs(C1.y);
+	bool active = false;
+	float C2 = 0.0f;
+	if (j->enableLimit)
+	{
+		float translation = b2dDot(axis, d);
+		if (b2dAbs(j->upperTranslation - j->lowerTranslation) < 2.0f * B2D_LINEAR_SLOP)
+		{
+			C2 = b2dClamp(translation, -B2D_MAX_LINEAR_CORRECTION, B2D_MAX_LINEAR_CORRECTION);
+			linearError = b2dMax(linearError, b2dAbs(translation));
+			active = true;
+		}
+		else if (translation <= j->lowerTranslation)
+		{
+			C2 = b2dClamp(translation - j->lowerTranslation + B2D_LINEAR_SLOP, -B2D_MAX_LINEAR_CORRECTION, 0.0f);
+			linearError = b2dMax(linearError, j->lowerTranslation - translation);
+			active = true;
+		}
+		else if (translation >= j->upperTranslation)
+		{
+			C2 = b2dClamp(translation - j->upperTranslation - B2D_LINEAR_SLOP, 0.0f, B2D_MAX_LINEAR_CORRECTION);
+			linearError = b2dMax(linearError, translation - j->upperTranslation);
+			active = true;
+		}
+	}
+	float k11 = mA + mB + iA * s1 * s1 + iB * s2 * s2;
+	float k12 = iA * s1 + iB * s2;
+	float k22 = iA + iB;
+	if (k22 == 0.0f) k22 = 1.0f;
+	if (active)
+	{
+		float k13 = iA * s1 * a1 + iB * s2 * a2;
+		float k23 = iA * a1 + iB * a2;
+		float k33 = mA + mB + iA * a1 * a1 + iB * a2 * a2;
+		M33 K;
+		K.ex = v3(k11, k12, k13);
+		K.ey = v3(k12, k22, k23);
+		K.ez = v3(k13, k23, k33);
+		impulse = b2dM33Solve33(K, v3(-C1.x, -C1.y, -C2));
+	}
+	else
+	{
+		// b2Mat22::Solve (b2Math.h:221-233)
+		float a11 = k11, a12 = k12, a21 = k12, a22 = k22;
+		float det = a11 * a22 - a12 * a21;
+		if (det != 0.0f) det = 1.0f / det;
+		V2 nb = -C1;
+		impulse = v3(det * (a22 * nb.x - a12 * nb.y), det * (a11 * nb.y - a21 * nb.x), 0.0f);
+	}
+	V2 P = impulse.x * perp + impulse.z * axis;
+	float LA = impulse.x * s1 + impulse.y + impulse.z * a1;
+	float LB = impulse.x * s2 + impulse.y + impulse.z * a2;
+	cA -= mA * P;
+	aA -= iA * LA;
+	cB += mB * P;
+	aB += iB * LB;
+	A->c = cA; A->a = aA;
+	B->c = cB; B->a = aB;
+	return linearError <= B2D_LINEAR_SLOP && angularError <= B2D_ANGULAR_SLOP;
+}
+
+// ---- weld joint -------------------------------------------------------------------------------------
+B2D_HD M33 b2dWeldK(V2 rA, V2 rB, float mA, float mB, float iA, float iB)
+{
+	M33 K;
+	K.ex.x = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+	K.ey.x = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+	K.ez.x = -rA.y * iA - rB.y * iB;
+	K.ex.y = K.ey.x;
+	K.ey.y = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+	K.ez.y = rA.x * iA + rB.x * iB;
+	K.ex.z = K.ez.x;
+	K.ey.z = K.ez.y;
+	K.ez.z = iA + iB;
+	return K;
+}
+
+// InitVelocityConstraints (b2WeldJoint.cpp:58-155); the record's matrix holds m_mass (the inverse)
+B2D_HD void b2dWeldInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
+{
+	b2dJointStoreBodies(j, invMassA, invIA, lcA, invMassB, invIB, lcB);
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - lcA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	j->rA = rA;
+	j->rB = rB;
+	float mA = invMassA, mB = invMassB, iA = invIA, iB = invIB;
+	M33 K = b2dWeldK(rA, rB, mA, mB, iA, iB);
+	M33 mass;
+	if (j->frequencyHz > 0.0f)
+	{
+		mass = b2dM33Inverse22(K);
+		float invM = iA + iB;
+		float m = invM > 0.0f ? 1.0f / invM : 0.0f;
+		float C = pB.a - pA.a - j->referenceAngle;
+		float omega = 2.0f * B2D_PI * j->frequencyHz;
+		float d = 2.0f * m * j->dampingRatio * omega;
+		float k = m * omega * omega;
+		float gamma = dt * (d + dt * k);
+		gamma = gamma != 0.0f ? 1.0f / gamma : 0.0f;
+		j->wGamma = gamma;
+		j->wBias = C * dt * k * gamma;
+		invM += gamma;
+		mass.ez.z = invM != 0.0f ? 1.0f / invM : 0.0f;
+	}
+	else if (K.ez.z == 0.0f)
+	{
+		mass = b2dM33Inverse22(K);
+		j->wGamma = 0.0f;
+		j->wBias = 0.0f;
+	}
+	else
+	{
+		mass = b2dM33SymInverse33(K);
+		j->wGamma = 0.0f;
+		j->wBias = 0.0f;
+	}
+	b2dJointSetMatrix(j, mass);
+	if (warmStarting)
+	{
+		j->impulseX *= dtRatio;
+		j->impulseY *= dtRatio;
+		j->impulseZ *= dtRatio;
+		V2 P = v2(j->impulseX, j->impulseY);
+		vA -= mA * P;
+		wA -= iA * (b2dCross(rA, P) + j->impulseZ);
+		vB += mB * P;
+		wB += iB * (b2dCross(rB, P) + j->impulseZ);
+	}
+	else
+	{
+		j->impulseX = j->impulseY = j->impulseZ = 0.0f;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolveVelocityConstraints (b2WeldJoint.cpp:157-216)
+B2D_HD void b2dWeldSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	const V2 rA = j->rA, rB = j->rB;
+	const M33 mass = b2dJointMatrix(j);
+	if (j->frequencyHz > 0.0f)
+	{
+		float Cdot2 = wB - wA;
+		float impulse2 = -mass.ez.z * (Cdot2 + j->wBias + j->wGamma * j->impulseZ);
+		j->impulseZ += impulse2;
+		wA -= iA * impulse2;
+		wB += iB * impulse2;
+		V2 Cdot1 = vB + b2dCrossSV(wB, rB) - vA - b2dCrossSV(wA, rA);
+		V2 impulse1 = -b2dM33Mul22(mass, Cdot1);
+		j->impulseX += impulse1.x;
+		j->impulseY += impulse1.y;
+		V2 P = impulse1;
+		vA -= mA * P;
+		wA -= iA * b2dCross(rA, P);
+		vB += mB * P;
+		wB += iB * b2dCross(rB, P);
+	}
+	else
+	{
+		V2 Cdot1 = vB + b2dCrossSV(wB, rB) - vA - b2dCrossSV(wA, rA);
+		float Cdot2 = wB - wA;
+		V3 m = b2dM33Mul(mass, v3(Cdot1.x, Cdot1.y, Cdot2));
+		V3 impulse = v3(-m.x, -m.y, -m.z);
+		j->impulseX += impulse.x;
+		j->impulseY += impulse.y;
+		j->impulseZ += impulse.z;
+		V2 P = v2(impulse.x, impulse.y);
+		vA -= mA * P;
+		wA -= iA * (b2dCross(rA, P) + impulse.z);
+		vB += mB * P;
+		wB += iB * (b2dCross(rB, P) + impulse.z);
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolvePositionConstraints (b2WeldJoint.cpp:218-303)
+B2D_HD bool b2dWeldSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
+{
+	V2 cA = A->c, cB = B->c;
+	float aA = A->a, aB = B->a;
+	Rot qA = b2dRot(aA), qB = b2dRot(aB);
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	V2 rA = b2dMulRV(qA, j->localAnchorA - j->localCenterA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - j->localCenterB);
+	float positionError, angularError;
+	M33 K = b2dWeldK(rA, rB, mA, mB, iA, iB);
+	if (j->frequencyHz > 0.0f)
+	{
+		V2 C1 = cB + rB - cA - rA;
+		positionError = b2dLength(C1);
+		angularError = 0.0f;
+		V2 P = -b2dM33Solve22(K, C1);
+		cA -= mA * P;
+		aA -= iA * b2dCross(rA, P);
+		cB += mB * P;
+		aB += iB * b2dCross(rB, P);
+	}
+	else
+	{
+		V2 C1 = cB + rB - cA - rA;
+		float C2 = aB - aA - j->referenceAngle;
+		positionError = b2dLength(C1);
+		angularError = b2dAbs(C2);
+		V3 impulse;
+		if (K.ez.z > 0.0f)
+		{
+			V3 x = b2dM33Solve33(K, v3(C1.x, C1.y, C2));
+			impulse = v3(-x.x, -x.y, -x.z);
+		}
+		else
+		{
+			V2 impulse2 = -b2dM33Solve22(K, C1);
+			impulse = v3(impulse2.x, impulse2.y, 0.0f);
+		}
+		V2 P = v2(impulse.x, impulse.y);
+		cA -= mA * P;
+		aA -= iA * (b2dCross(rA, P) + impulse.z);
+		cB += mB * P;
+		aB += iB * (b2dCross(rB, P) + impulse.z);
+	}
+	A->c = cA; A->a = aA;
+	B->c = cB; B->a = aB;
+	return positionError <= B2D_LINEAR_SLOP && angularError <= B2D_ANGULAR_SLOP;
+}
+
 // ---- dispatch on the joint type (b2Joint's virtual calls, b2Island.cpp:235-318) -------------------------
 B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
 	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
 {
 	if (j->type == B2D_JOINT_DISTANCE)
 		b2dDistanceInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio, dt);
+	else if (j->type == B2D_JOINT_PRISMATIC)
+		b2dPrismaticInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
+	else if (j->type == B2D_JOINT_WELD)
+		b2dWeldInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio, dt);
 	else
 		b2dRevoluteInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA.a, A, pB.a, B, warmStarting, dtRatio);
 }
@@ -457,6 +1006,10 @@ B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt)
 {
 	if (j->type == B2D_JOINT_DISTANCE)
 		b2dDistanceSolveVelocity(j, A, B);
+	else if (j->type == B2D_JOINT_PRISMATIC)
+		b2dPrismaticSolveVelocity(j, A, B, dt);
+	else if (j->type == B2D_JOINT_WELD)
+		b2dWeldSolveVelocity(j, A, B);
 	else
 		b2dRevoluteSolveVelocity(j, A, B, dt);
 }
@@ -464,6 +1017,8 @@ B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt)
 B2D_HD bool b2dJointSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 {
 	if (j->type == B2D_JOINT_DISTANCE) return b2dDistanceSolvePosition(j, A, B);
+	if (j->type == B2D_JOINT_PRISMATIC) return b2dPrismaticSolvePosition(j, A, B);
+	if (j->type == B2D_JOINT_WELD) return b2dWeldSolvePosition(j, A, B);
 	return b2dRevoluteSolvePosition(j, A, B);
 }
 

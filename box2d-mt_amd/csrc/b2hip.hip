@@ -168,6 +168,7 @@ struct b2hip_world
 	DevArray<RevoluteJoint> d_joints;
 	DevArray<int> jadjStart, jadj, rootJointStart, rootJointCursor, lj_list, rootJointOkay;
 	std::vector<std::pair<int, int> > pendingFilter; // body pairs whose contacts must be re-filtered (new joint)
+	std::vector<std::pair<int, int> > jointEdits;    // (joint, 1 = also clear the limit impulse): definition members changed by a setter
 	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
 	DevArray<int4> rootScanIn, rootScanOut;
 	DevArray<int> si_root, si_bodyStart, si_contactStart, si_wStart, si_maxLevel, si_bodies, si_contacts, si_level,
@@ -722,6 +723,19 @@ static int flushEdits(b2hip_world* w)
 		HIP_TRY(hipMemcpyAsync(w->d_joints.p + first, w->joints.data() + first, cnt * sizeof(RevoluteJoint), hipMemcpyHostToDevice, s));
 		w->upJoints = w->joints.size();
 	}
+	for (size_t k = 0; k < w->jointEdits.size(); ++k)
+	{
+		// setters touch the six limit / motor members only (contiguous); everything else in the device record is solver state
+		const int id = w->jointEdits[k].first;
+		const size_t off = offsetof(JointRec, enableLimit), len = offsetof(JointRec, collideConnected) - off;
+		HIP_TRY(hipMemcpyAsync((char*)(w->d_joints.p + id) + off, (const char*)&w->joints[id] + off, len, hipMemcpyHostToDevice, s));
+		if (w->jointEdits[k].second)
+		{
+			static const float zero = 0.0f;
+			HIP_TRY(hipMemcpyAsync((char*)(w->d_joints.p + id) + offsetof(JointRec, impulseZ), &zero, sizeof(float), hipMemcpyHostToDevice, s));
+		}
+	}
+	w->jointEdits.clear();
 	{
 		// per-body joint edges, newest first (b2World.cpp:697-710); tiny, rebuilt every flush
 		const size_t nbod = w->bodies.size();
@@ -1788,6 +1802,104 @@ int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* 
 	w->joints.push_back(j);
 	if (def->collide_connected == 0) w->pendingFilter.push_back(std::make_pair(def->body_a, def->body_b));
 	return (int)w->joints.size() - 1;
+}
+
+static int addJoint(b2hip_world* w, const JointRec& j)
+{
+	w->joints.push_back(j);
+	// b2World::CreateJoint (b2World.cpp:716-732): contacts between the two bodies are re-filtered
+	if (j.collideConnected == 0) w->pendingFilter.push_back(std::make_pair(j.bodyA, j.bodyB));
+	return (int)w->joints.size() - 1;
+}
+
+int b2hip_create_prismatic_joint(b2hip_world* w, const b2hip_prismatic_joint_def* def)
+{
+	if (!w || !def) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int nb = (int)w->bodies.size();
+	if (def->body_a < 0 || def->body_a >= nb || def->body_b < 0 || def->body_b >= nb) return setError(B2HIP_ERR_INVALID, "bad body id");
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_PRISMATIC;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.localAxisA = v2(def->local_axis_a[0], def->local_axis_a[1]);
+	b2dNormalize(j.localAxisA); // b2PrismaticJoint.cpp:104
+	j.referenceAngle = def->reference_angle;
+	j.enableLimit = def->enable_limit;
+	j.lowerTranslation = def->lower_translation;
+	j.upperTranslation = def->upper_translation;
+	j.enableMotor = def->enable_motor;
+	j.motorSpeed = def->motor_speed;
+	j.maxMotorForce = def->max_motor_force;
+	j.collideConnected = def->collide_connected;
+	return addJoint(w, j);
+}
+
+int b2hip_create_weld_joint(b2hip_world* w, const b2hip_weld_joint_def* def)
+{
+	if (!w || !def) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int nb = (int)w->bodies.size();
+	if (def->body_a < 0 || def->body_a >= nb || def->body_b < 0 || def->body_b >= nb) return setError(B2HIP_ERR_INVALID, "bad body id");
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_WELD;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.referenceAngle = def->reference_angle;
+	j.frequencyHz = def->frequency_hz;
+	j.dampingRatio = def->damping_ratio;
+	j.collideConnected = def->collide_connected;
+	return addJoint(w, j);
+}
+
+// b2Body::SetAwake(true) on both bodies of a joint whose definition changed (b2RevoluteJoint.cpp:418-500)
+static void wakeJointBodies(b2hip_world* w, const JointRec& j)
+{
+	const int ids[2] = { j.bodyA, j.bodyB };
+	for (int k = 0; k < 2; ++k)
+	{
+		if (w->bodies[ids[k]].type == B2HIP_STATIC_BODY) continue;
+		markDirty(w, ids[k]);
+		HostBody& b = w->bodies[ids[k]];
+		if ((b.flags & BF_AWAKE) == 0)
+		{
+			b.flags |= BF_AWAKE;
+			b.sleepTime = 0.0f;
+		}
+	}
+}
+
+int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor)
+{
+	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	JointRec& j = w->joints[joint];
+	if (j.type != B2D_JOINT_REVOLUTE && j.type != B2D_JOINT_PRISMATIC) return setError(B2HIP_ERR_INVALID, "joint type has no motor");
+	if ((enable_motor != 0) == (j.enableMotor != 0) && motor_speed == j.motorSpeed && max_motor == j.maxMotorTorque) return 0;
+	wakeJointBodies(w, j);
+	j.enableMotor = enable_motor != 0;
+	j.motorSpeed = motor_speed;
+	j.maxMotorTorque = max_motor;
+	w->jointEdits.push_back(std::make_pair(joint, 0));
+	return 0;
+}
+
+int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lower, float upper)
+{
+	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	JointRec& j = w->joints[joint];
+	if (j.type != B2D_JOINT_REVOLUTE && j.type != B2D_JOINT_PRISMATIC) return setError(B2HIP_ERR_INVALID, "joint type has no limits");
+	if (lower > upper) return setError(B2HIP_ERR_INVALID, "lower limit above upper limit");
+	if ((enable_limit != 0) == (j.enableLimit != 0) && lower == j.lowerAngle && upper == j.upperAngle) return 0;
+	wakeJointBodies(w, j);
+	j.enableLimit = enable_limit != 0;
+	j.lowerAngle = lower;
+	j.upperAngle = upper;
+	w->jointEdits.push_back(std::make_pair(joint, 1)); // the limit impulse restarts from zero
+	return 0;
 }
 
 int b2hip_body_count(const b2hip_world* w)

@@ -23,6 +23,8 @@
 #include "Box2D/Dynamics/Joints/b2Joint.h"
 #include "Box2D/Dynamics/Joints/b2RevoluteJoint.h"
 #include "Box2D/Dynamics/Joints/b2DistanceJoint.h"
+#include "Box2D/Dynamics/Joints/b2PrismaticJoint.h"
+#include "Box2D/Dynamics/Joints/b2WeldJoint.h"
 
 #include "Box2D/MT/b2Task.h"
 #include "Box2D/MT/b2TaskExecutor.h"

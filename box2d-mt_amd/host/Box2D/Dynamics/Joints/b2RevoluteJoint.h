@@ -42,9 +42,22 @@ public:
 	float32 GetMotorSpeed() const { return m_motorSpeed; }
 	float32 GetMaxMotorTorque() const { return m_maxMotorTorque; }
 	bool IsLimitEnabled() const { return m_enableLimit; }
+	float32 GetLowerLimit() const { return m_lowerAngle; }
+	float32 GetUpperLimit() const { return m_upperAngle; }
+	// computed from the body states of the last step (reference: b2RevoluteJoint.cpp:399-411)
+	float32 GetJointAngle() const;
+	float32 GetJointSpeed() const;
+	// setters forward to the device record; like the reference's they wake both bodies when something changes
+	void EnableLimit(bool flag);
+	void SetLimits(float32 lower, float32 upper);
+	void EnableMotor(bool flag);
+	void SetMotorSpeed(float32 speed);
+	void SetMaxMotorTorque(float32 torque);
 
 protected:
 	friend class b2World;
+	void PushMotor();
+	void PushLimits();
 	b2RevoluteJoint(const b2RevoluteJointDef* def) : b2Joint(def), m_localAnchorA(def->localAnchorA),
 		m_localAnchorB(def->localAnchorB), m_referenceAngle(def->referenceAngle), m_enableLimit(def->enableLimit),
 		m_lowerAngle(def->lowerAngle), m_upperAngle(def->upperAngle), m_enableMotor(def->enableMotor),

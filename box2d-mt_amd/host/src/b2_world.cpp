@@ -199,6 +199,46 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 		id = b2hip_create_distance_joint(m_hip, &d);
 		if (id >= 0) j = new (b2Alloc(sizeof(b2DistanceJoint))) b2DistanceJoint(dd);
 	}
+	else if (def->type == e_prismaticJoint)
+	{
+		const b2PrismaticJointDef* pd = static_cast<const b2PrismaticJointDef*>(def);
+		b2hip_prismatic_joint_def d;
+		d.body_a = pd->bodyA->GetDeviceId();
+		d.body_b = pd->bodyB->GetDeviceId();
+		d.local_anchor_a[0] = pd->localAnchorA.x;
+		d.local_anchor_a[1] = pd->localAnchorA.y;
+		d.local_anchor_b[0] = pd->localAnchorB.x;
+		d.local_anchor_b[1] = pd->localAnchorB.y;
+		d.local_axis_a[0] = pd->localAxisA.x;
+		d.local_axis_a[1] = pd->localAxisA.y;
+		d.reference_angle = pd->referenceAngle;
+		d.enable_limit = pd->enableLimit;
+		d.lower_translation = pd->lowerTranslation;
+		d.upper_translation = pd->upperTranslation;
+		d.enable_motor = pd->enableMotor;
+		d.motor_speed = pd->motorSpeed;
+		d.max_motor_force = pd->maxMotorForce;
+		d.collide_connected = pd->collideConnected;
+		id = b2hip_create_prismatic_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2PrismaticJoint))) b2PrismaticJoint(pd);
+	}
+	else if (def->type == e_weldJoint)
+	{
+		const b2WeldJointDef* wd = static_cast<const b2WeldJointDef*>(def);
+		b2hip_weld_joint_def d;
+		d.body_a = wd->bodyA->GetDeviceId();
+		d.body_b = wd->bodyB->GetDeviceId();
+		d.local_anchor_a[0] = wd->localAnchorA.x;
+		d.local_anchor_a[1] = wd->localAnchorA.y;
+		d.local_anchor_b[0] = wd->localAnchorB.x;
+		d.local_anchor_b[1] = wd->localAnchorB.y;
+		d.reference_angle = wd->referenceAngle;
+		d.frequency_hz = wd->frequencyHz;
+		d.damping_ratio = wd->dampingRatio;
+		d.collide_connected = wd->collideConnected;
+		id = b2hip_create_weld_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2WeldJoint))) b2WeldJoint(wd);
+	}
 	else
 	{
 		fprintf(stderr, "b2World::CreateJoint: joint type %d is not on the device path yet\n", (int)def->type);
@@ -715,6 +755,74 @@ void b2DistanceJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor
 	localAnchorA = bodyA->GetLocalPoint(anchorA);
 	localAnchorB = bodyB->GetLocalPoint(anchorB);
 	length = (anchorB - anchorA).Length();
+}
+
+void b2PrismaticJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor, const b2Vec2& axis)
+{
+	bodyA = bA;
+	bodyB = bB;
+	localAnchorA = bodyA->GetLocalPoint(anchor);
+	localAnchorB = bodyB->GetLocalPoint(anchor);
+	localAxisA = bodyA->GetLocalVector(axis);
+	referenceAngle = bodyB->GetAngle() - bodyA->GetAngle();
+}
+
+void b2WeldJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor)
+{
+	bodyA = bA;
+	bodyB = bB;
+	localAnchorA = bodyA->GetLocalPoint(anchor);
+	localAnchorB = bodyB->GetLocalPoint(anchor);
+	referenceAngle = bodyB->GetAngle() - bodyA->GetAngle();
+}
+
+// Joint setters between steps: the definition lives in the device record (b2hip_joint_set_motor / _set_limits).
+void b2RevoluteJoint::PushMotor()
+{
+	b2hip_joint_set_motor(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_enableMotor, m_motorSpeed, m_maxMotorTorque);
+}
+void b2RevoluteJoint::PushLimits()
+{
+	b2hip_joint_set_limits(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_enableLimit, m_lowerAngle, m_upperAngle);
+}
+void b2RevoluteJoint::EnableMotor(bool flag) { m_enableMotor = flag; PushMotor(); }
+void b2RevoluteJoint::SetMotorSpeed(float32 speed) { m_motorSpeed = speed; PushMotor(); }
+void b2RevoluteJoint::SetMaxMotorTorque(float32 torque) { m_maxMotorTorque = torque; PushMotor(); }
+void b2RevoluteJoint::EnableLimit(bool flag) { m_enableLimit = flag; PushLimits(); }
+void b2RevoluteJoint::SetLimits(float32 lower, float32 upper) { m_lowerAngle = lower; m_upperAngle = upper; PushLimits(); }
+float32 b2RevoluteJoint::GetJointAngle() const { return m_bodyB->GetAngle() - m_bodyA->GetAngle() - m_referenceAngle; }
+float32 b2RevoluteJoint::GetJointSpeed() const { return m_bodyB->GetAngularVelocity() - m_bodyA->GetAngularVelocity(); }
+
+void b2PrismaticJoint::PushMotor()
+{
+	b2hip_joint_set_motor(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_enableMotor, m_motorSpeed, m_maxMotorForce);
+}
+void b2PrismaticJoint::PushLimits()
+{
+	b2hip_joint_set_limits(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_enableLimit, m_lowerTranslation, m_upperTranslation);
+}
+void b2PrismaticJoint::EnableMotor(bool flag) { m_enableMotor = flag; PushMotor(); }
+void b2PrismaticJoint::SetMotorSpeed(float32 speed) { m_motorSpeed = speed; PushMotor(); }
+void b2PrismaticJoint::SetMaxMotorForce(float32 force) { m_maxMotorForce = force; PushMotor(); }
+void b2PrismaticJoint::EnableLimit(bool flag) { m_enableLimit = flag; PushLimits(); }
+void b2PrismaticJoint::SetLimits(float32 lower, float32 upper) { m_lowerTranslation = lower; m_upperTranslation = upper; PushLimits(); }
+
+float32 b2PrismaticJoint::GetJointTranslation() const
+{
+	b2Vec2 d = m_bodyB->GetWorldPoint(m_localAnchorB) - m_bodyA->GetWorldPoint(m_localAnchorA);
+	return b2Dot(d, m_bodyA->GetWorldVector(m_localAxisA));
+}
+
+float32 b2PrismaticJoint::GetJointSpeed() const
+{
+	const b2Rot qA = m_bodyA->GetTransform().q, qB = m_bodyB->GetTransform().q;
+	b2Vec2 rA = b2Mul(qA, m_localAnchorA - m_bodyA->GetLocalCenter());
+	b2Vec2 rB = b2Mul(qB, m_localAnchorB - m_bodyB->GetLocalCenter());
+	b2Vec2 d = (m_bodyB->GetWorldCenter() + rB) - (m_bodyA->GetWorldCenter() + rA);
+	b2Vec2 axis = b2Mul(qA, m_localAxisA);
+	b2Vec2 vA = m_bodyA->GetLinearVelocity(), vB = m_bodyB->GetLinearVelocity();
+	float32 wA = m_bodyA->GetAngularVelocity(), wB = m_bodyB->GetAngularVelocity();
+	return b2Dot(d, b2Cross(wA, axis)) + b2Dot(axis, vB + b2Cross(wB, rB) - vA - b2Cross(wA, rA));
 }
 
 // ---- callbacks / collision helpers ----------------------------------------------------------------

@@ -54,6 +54,20 @@ class DistanceJointDef(C.Structure):
                 ("damping_ratio", C.c_float), ("collide_connected", C.c_int)]
 
 
+class PrismaticJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("local_anchor_a", C.c_float * 2),
+                ("local_anchor_b", C.c_float * 2), ("local_axis_a", C.c_float * 2), ("reference_angle", C.c_float),
+                ("enable_limit", C.c_int), ("lower_translation", C.c_float), ("upper_translation", C.c_float),
+                ("enable_motor", C.c_int), ("motor_speed", C.c_float), ("max_motor_force", C.c_float),
+                ("collide_connected", C.c_int)]
+
+
+class WeldJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("local_anchor_a", C.c_float * 2),
+                ("local_anchor_b", C.c_float * 2), ("reference_angle", C.c_float), ("frequency_hz", C.c_float),
+                ("damping_ratio", C.c_float), ("collide_connected", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
@@ -88,6 +102,10 @@ def _configure(L, optional_ok=False):
         "b2hip_create_fixture": [C.c_void_p, C.c_int, C.POINTER(FixtureDef), C.POINTER(Shape)],
         "b2hip_create_revolute_joint": [C.c_void_p, C.POINTER(RevoluteJointDef)],
         "b2hip_create_distance_joint": [C.c_void_p, C.POINTER(DistanceJointDef)],
+        "b2hip_create_prismatic_joint": [C.c_void_p, C.POINTER(PrismaticJointDef)],
+        "b2hip_create_weld_joint": [C.c_void_p, C.POINTER(WeldJointDef)],
+        "b2hip_joint_set_motor": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
+        "b2hip_joint_set_limits": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
         "b2hip_body_count": [C.c_void_p],
         "b2hip_fixture_count": [C.c_void_p],
         "b2hip_step": [C.c_void_p, C.c_float, C.c_int, C.c_int],
@@ -239,6 +257,36 @@ class World:
         d.length, d.frequency_hz, d.damping_ratio = length, frequency_hz, damping_ratio
         d.collide_connected = int(collide_connected)
         return _check(self.L.b2hip_create_distance_joint(self.p, C.byref(d)))
+
+    def create_prismatic_joint(self, body_a, body_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), axis=(1.0, 0.0),
+                               reference_angle=0.0, enable_limit=False, lower=0.0, upper=0.0, enable_motor=False,
+                               motor_speed=0.0, max_motor_force=0.0, collide_connected=False):
+        d = PrismaticJointDef()
+        d.body_a, d.body_b = body_a, body_b
+        d.local_anchor_a[0], d.local_anchor_a[1] = anchor_a
+        d.local_anchor_b[0], d.local_anchor_b[1] = anchor_b
+        d.local_axis_a[0], d.local_axis_a[1] = axis
+        d.reference_angle = reference_angle
+        d.enable_limit, d.lower_translation, d.upper_translation = int(enable_limit), lower, upper
+        d.enable_motor, d.motor_speed, d.max_motor_force = int(enable_motor), motor_speed, max_motor_force
+        d.collide_connected = int(collide_connected)
+        return _check(self.L.b2hip_create_prismatic_joint(self.p, C.byref(d)))
+
+    def create_weld_joint(self, body_a, body_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), reference_angle=0.0,
+                          frequency_hz=0.0, damping_ratio=0.0, collide_connected=False):
+        d = WeldJointDef()
+        d.body_a, d.body_b = body_a, body_b
+        d.local_anchor_a[0], d.local_anchor_a[1] = anchor_a
+        d.local_anchor_b[0], d.local_anchor_b[1] = anchor_b
+        d.reference_angle, d.frequency_hz, d.damping_ratio = reference_angle, frequency_hz, damping_ratio
+        d.collide_connected = int(collide_connected)
+        return _check(self.L.b2hip_create_weld_joint(self.p, C.byref(d)))
+
+    def joint_set_motor(self, joint, enable_motor, motor_speed, max_motor):
+        _check(self.L.b2hip_joint_set_motor(self.p, joint, int(enable_motor), motor_speed, max_motor))
+
+    def joint_set_limits(self, joint, enable_limit, lower, upper):
+        _check(self.L.b2hip_joint_set_limits(self.p, joint, int(enable_limit), lower, upper))
 
     def apply_force(self, body, force=(0.0, 0.0), torque=0.0, wake=True):
         _check(self.L.b2hip_apply_force(self.p, body, force[0], force[1], torque, int(wake)))

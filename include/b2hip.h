@@ -12,6 +12,12 @@
  *                                    b2Body::ResetMassData                  b2Body.cpp:182-226,310-385; b2Fixture.cpp:42-141
  *   b2hip_create_revolute_joint      b2World::CreateJoint (revolute)        b2World.cpp:672-760, Joints/b2RevoluteJoint.cpp:47-63
  *   b2hip_create_distance_joint      b2World::CreateJoint (distance)        b2World.cpp:672-760, Joints/b2DistanceJoint.cpp:51-63
+ *   b2hip_create_prismatic_joint     b2World::CreateJoint (prismatic)       b2World.cpp:672-760, Joints/b2PrismaticJoint.cpp:98-128
+ *   b2hip_create_weld_joint          b2World::CreateJoint (weld)            b2World.cpp:672-760, Joints/b2WeldJoint.cpp:46-56
+ *   b2hip_joint_set_motor            b2{Revolute,Prismatic}Joint::EnableMotor / SetMotorSpeed / SetMaxMotor{Torque,Force}
+ *                                                                           Joints/b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616
+ *   b2hip_joint_set_limits           b2{Revolute,Prismatic}Joint::EnableLimit / SetLimits
+ *                                                                           Joints/b2RevoluteJoint.cpp:459-500, b2PrismaticJoint.cpp:549-581
  *   b2hip_step                       b2World::Step                          b2World.cpp:1613-1710
  *   b2hip_collide                    b2World::Collide / b2ContactManager::Collide      b2World.cpp:1120-1141, b2ContactManager.cpp:177-230
  *   b2hip_solve                      b2World::Solve (islands + b2Island::Solve)        b2World.cpp:1166-1431, b2Island.cpp:184-396
@@ -128,6 +134,30 @@ typedef struct b2hip_distance_joint_def
 	int collide_connected;
 } b2hip_distance_joint_def;
 
+/* b2PrismaticJointDef (Joints/b2PrismaticJoint.h:31-85): bodyB slides along local_axis_a of bodyA, no relative rotation */
+typedef struct b2hip_prismatic_joint_def
+{
+	int body_a, body_b;
+	float local_anchor_a[2], local_anchor_b[2];
+	float local_axis_a[2];          /* normalised at creation, like b2PrismaticJoint's constructor does */
+	float reference_angle;
+	int enable_limit;
+	float lower_translation, upper_translation;
+	int enable_motor;
+	float motor_speed, max_motor_force;
+	int collide_connected;
+} b2hip_prismatic_joint_def;
+
+/* b2WeldJointDef (Joints/b2WeldJoint.h:28-60): rigid when frequency_hz == 0, else a soft angular spring */
+typedef struct b2hip_weld_joint_def
+{
+	int body_a, body_b;
+	float local_anchor_a[2], local_anchor_b[2];
+	float reference_angle;
+	float frequency_hz, damping_ratio;
+	int collide_connected;
+} b2hip_weld_joint_def;
+
 /* Host-visible body state after a step (40 bytes per body, one coalesced device->host copy). */
 typedef struct b2hip_body_state
 {
@@ -196,6 +226,13 @@ int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def);
 int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def, const b2hip_shape* shape);
 int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* def);
 int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* def);
+int b2hip_create_prismatic_joint(b2hip_world* w, const b2hip_prismatic_joint_def* def);
+int b2hip_create_weld_joint(b2hip_world* w, const b2hip_weld_joint_def* def);
+/* Revolute / prismatic joints between steps: EnableMotor + SetMotorSpeed + SetMaxMotorTorque|Force in one call, and
+ * EnableLimit + SetLimits in one call. Like the reference's setters, a call that changes something wakes both bodies and
+ * (limits) restarts the limit impulse from zero; a call that changes nothing does nothing. */
+int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor);
+int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lower, float upper);
 
 int b2hip_body_count(const b2hip_world* w);
 int b2hip_fixture_count(const b2hip_world* w);

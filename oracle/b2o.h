@@ -79,6 +79,12 @@ int b2o_create_revolute_joint(b2o_world* w, int bodyA, int bodyB, const float* a
 	int enableLimit, float lower, float upper, int enableMotor, float motorSpeed, float maxMotorTorque, int collideConnected);
 int b2o_create_distance_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float length,
 	float frequencyHz, float dampingRatio, int collideConnected);
+int b2o_create_prismatic_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, const float* axis2, float referenceAngle,
+	int enableLimit, float lower, float upper, int enableMotor, float motorSpeed, float maxMotorForce, int collideConnected);
+int b2o_create_weld_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float referenceAngle,
+	float frequencyHz, float dampingRatio, int collideConnected);
+void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor);
+void b2o_joint_set_limits(b2o_world* w, int joint, int enableLimit, float lower, float upper);
 void b2o_apply_force(b2o_world* w, int body, float fx, float fy, float torque, int wake);
 void b2o_set_velocity(b2o_world* w, int body, float vx, float vy, float omega);
 void b2o_step(b2o_world* w, float dt, int velocity_iterations, int position_iterations);

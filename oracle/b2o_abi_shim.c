@@ -73,6 +73,33 @@ int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* 
 		def->collide_connected);
 }
 
+int b2hip_create_prismatic_joint(b2hip_world* w, const b2hip_prismatic_joint_def* def)
+{
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	return b2o_create_prismatic_joint(w->o, def->body_a, def->body_b, anchors, def->local_axis_a, def->reference_angle,
+		def->enable_limit, def->lower_translation, def->upper_translation, def->enable_motor, def->motor_speed,
+		def->max_motor_force, def->collide_connected);
+}
+
+int b2hip_create_weld_joint(b2hip_world* w, const b2hip_weld_joint_def* def)
+{
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	return b2o_create_weld_joint(w->o, def->body_a, def->body_b, anchors, def->reference_angle, def->frequency_hz,
+		def->damping_ratio, def->collide_connected);
+}
+
+int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor)
+{
+	b2o_joint_set_motor(w->o, joint, enable_motor, motor_speed, max_motor);
+	return 0;
+}
+
+int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lower, float upper)
+{
+	b2o_joint_set_limits(w->o, joint, enable_limit, lower, upper);
+	return 0;
+}
+
 int b2hip_body_count(const b2hip_world* w) { return b2o_body_count(w->o); }
 int b2hip_fixture_count(const b2hip_world* w) { return w->fixtures; }
 

@@ -1,6 +1,7 @@
 /* b2o_joint.c - CPU oracle, joints: plain-C restatement of b2RevoluteJoint
  * (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376; b2Mat33::Solve33/Solve22 b2Math.cpp:25-53) and of
- * b2DistanceJoint (Joints/b2DistanceJoint.cpp:65-225).
+ * b2DistanceJoint (Joints/b2DistanceJoint.cpp:65-225), b2PrismaticJoint (Joints/b2PrismaticJoint.cpp:130-478),
+ * b2WeldJoint (Joints/b2WeldJoint.cpp:58-303); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
  * TEST INFRASTRUCTURE (see b2o.h). */
 #include "b2o_joint.h"
 
@@ -311,4 +312,416 @@ int b2o_distance_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, fl
 	*cB = v_add(*cB, v_scale(j->invMassB, P));
 	*aB += j->invIB * v_cross(rB, P);
 	return f_abs(C) < B2O_LINEAR_SLOP;
+}
+
+/* ---- 3x3 helpers on column arrays (b2Mat33, b2Math.cpp:25-94) ------------------------------------ */
+static void m_solve33(const float ex[3], const float ey[3], const float ez[3], const float b[3], float x[3])
+{
+	float c[3];
+	cross3(ey, ez, c);
+	float det = dot3(ex, c);
+	if (det != 0.0f) det = 1.0f / det;
+	x[0] = det * dot3(b, c);
+	cross3(b, ez, c);
+	x[1] = det * dot3(ex, c);
+	cross3(ey, b, c);
+	x[2] = det * dot3(ex, c);
+}
+
+static vec2 m_solve22(const float ex[3], const float ey[3], vec2 b)
+{
+	float a11 = ex[0], a12 = ey[0], a21 = ex[1], a22 = ey[1];
+	float det = a11 * a22 - a12 * a21;
+	if (det != 0.0f) det = 1.0f / det;
+	return v_make(det * (a22 * b.x - a12 * b.y), det * (a11 * b.y - a21 * b.x));
+}
+
+static void m_inverse22(const float ex[3], const float ey[3], float ox[3], float oy[3], float oz[3])
+{
+	float a = ex[0], b = ey[0], c = ex[1], d = ey[1];
+	float det = a * d - b * c;
+	if (det != 0.0f) det = 1.0f / det;
+	ox[0] = det * d; oy[0] = -det * b; ox[2] = 0.0f;
+	ox[1] = -det * c; oy[1] = det * a; oy[2] = 0.0f;
+	oz[0] = 0.0f; oz[1] = 0.0f; oz[2] = 0.0f;
+}
+
+static void m_sym_inverse33(const float ex[3], const float ey[3], const float ez[3], float ox[3], float oy[3], float oz[3])
+{
+	float c[3];
+	cross3(ey, ez, c);
+	float det = dot3(ex, c);
+	if (det != 0.0f) det = 1.0f / det;
+	float a11 = ex[0], a12 = ey[0], a13 = ez[0];
+	float a22 = ey[1], a23 = ez[1];
+	float a33 = ez[2];
+	ox[0] = det * (a22 * a33 - a23 * a23);
+	ox[1] = det * (a13 * a23 - a12 * a33);
+	ox[2] = det * (a12 * a23 - a13 * a22);
+	oy[0] = ox[1];
+	oy[1] = det * (a11 * a33 - a13 * a13);
+	oy[2] = det * (a13 * a12 - a11 * a23);
+	oz[0] = ox[2];
+	oz[1] = oy[2];
+	oz[2] = det * (a11 * a22 - a12 * a12);
+}
+
+/* ---- prismatic joint ---------------------------------------------------------------------------- */
+static void prismatic_k(float mA, float mB, float iA, float iB, float s1, float s2, float a1, float a2,
+	float ex[3], float ey[3], float ez[3])
+{
+	float k11 = mA + mB + iA * s1 * s1 + iB * s2 * s2;
+	float k12 = iA * s1 + iB * s2;
+	float k13 = iA * s1 * a1 + iB * s2 * a2;
+	float k22 = iA + iB;
+	if (k22 == 0.0f) k22 = 1.0f;
+	float k23 = iA * a1 + iB * a2;
+	float k33 = mA + mB + iA * a1 * a1 + iB * a2 * a2;
+	ex[0] = k11; ex[1] = k12; ex[2] = k13;
+	ey[0] = k12; ey[1] = k22; ey[2] = k23;
+	ez[0] = k13; ez[1] = k23; ez[2] = k33;
+}
+
+/* InitVelocityConstraints b2PrismaticJoint.cpp:130-257 */
+void b2o_prismatic_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	vec2 d = v_sub(v_add(v_sub(cB, cA), rB), rA);
+	j->axis = r_mul(qA, j->localXAxisA);
+	j->a1 = v_cross(v_add(d, rA), j->axis);
+	j->a2 = v_cross(rB, j->axis);
+	j->motorMass = mA + mB + iA * j->a1 * j->a1 + iB * j->a2 * j->a2;
+	if (j->motorMass > 0.0f) j->motorMass = 1.0f / j->motorMass;
+	j->perp = r_mul(qA, j->localYAxisA);
+	j->s1 = v_cross(v_add(d, rA), j->perp);
+	j->s2 = v_cross(rB, j->perp);
+	prismatic_k(mA, mB, iA, iB, j->s1, j->s2, j->a1, j->a2, j->ex, j->ey, j->ez);
+	if (j->enableLimit)
+	{
+		float jointTranslation = v_dot(j->axis, d);
+		if (f_abs(j->upperAngle - j->lowerAngle) < 2.0f * B2O_LINEAR_SLOP)
+		{
+			j->limitState = 3;
+		}
+		else if (jointTranslation <= j->lowerAngle)
+		{
+			if (j->limitState != 1) { j->limitState = 1; j->impulse[2] = 0.0f; }
+		}
+		else if (jointTranslation >= j->upperAngle)
+		{
+			if (j->limitState != 2) { j->limitState = 2; j->impulse[2] = 0.0f; }
+		}
+		else
+		{
+			j->limitState = 0;
+			j->impulse[2] = 0.0f;
+		}
+	}
+	else
+	{
+		j->limitState = 0;
+		j->impulse[2] = 0.0f;
+	}
+	if (!j->enableMotor) j->motorImpulse = 0.0f;
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio; j->impulse[1] *= dtRatio; j->impulse[2] *= dtRatio;
+		j->motorImpulse *= dtRatio;
+		vec2 P = v_add(v_scale(j->impulse[0], j->perp), v_scale(j->motorImpulse + j->impulse[2], j->axis));
+		float LA = j->impulse[0] * j->s1 + j->impulse[1] + (j->motorImpulse + j->impulse[2]) * j->a1;
+		float LB = j->impulse[0] * j->s2 + j->impulse[1] + (j->motorImpulse + j->impulse[2]) * j->a2;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * LA;
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * LB;
+	}
+	else
+	{
+		j->impulse[0] = j->impulse[1] = j->impulse[2] = 0.0f;
+		j->motorImpulse = 0.0f;
+	}
+}
+
+/* SolveVelocityConstraints :259-350 */
+void b2o_prismatic_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt)
+{
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	if (j->enableMotor && j->limitState != 3)
+	{
+		float Cdot = v_dot(j->axis, v_sub(*vB, *vA)) + j->a2 * *wB - j->a1 * *wA;
+		float impulse = j->motorMass * (j->motorSpeed - Cdot);
+		float oldImpulse = j->motorImpulse;
+		float maxImpulse = dt * j->maxMotorTorque;
+		j->motorImpulse = f_clamp(j->motorImpulse + impulse, -maxImpulse, maxImpulse);
+		impulse = j->motorImpulse - oldImpulse;
+		vec2 P = v_scale(impulse, j->axis);
+		float LA = impulse * j->a1;
+		float LB = impulse * j->a2;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * LA;
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * LB;
+	}
+	vec2 Cdot1;
+	Cdot1.x = v_dot(j->perp, v_sub(*vB, *vA)) + j->s2 * *wB - j->s1 * *wA;
+	Cdot1.y = *wB - *wA;
+	if (j->enableLimit && j->limitState != 0)
+	{
+		float Cdot2 = v_dot(j->axis, v_sub(*vB, *vA)) + j->a2 * *wB - j->a1 * *wA;
+		float nC[3] = { -Cdot1.x, -Cdot1.y, -Cdot2 };
+		float f1[3] = { j->impulse[0], j->impulse[1], j->impulse[2] };
+		float df[3];
+		m_solve33(j->ex, j->ey, j->ez, nC, df);
+		j->impulse[0] += df[0]; j->impulse[1] += df[1]; j->impulse[2] += df[2];
+		if (j->limitState == 1) j->impulse[2] = f_max(j->impulse[2], 0.0f);
+		else if (j->limitState == 2) j->impulse[2] = f_min(j->impulse[2], 0.0f);
+		vec2 b = v_sub(v_neg(Cdot1), v_scale(j->impulse[2] - f1[2], v_make(j->ez[0], j->ez[1])));
+		vec2 f2r = v_add(m_solve22(j->ex, j->ey, b), v_make(f1[0], f1[1]));
+		j->impulse[0] = f2r.x;
+		j->impulse[1] = f2r.y;
+		df[0] = j->impulse[0] - f1[0]; df[1] = j->impulse[1] - f1[1]; df[2] = j->impulse[2] - f1[2];
+		vec2 P = v_add(v_scale(df[0], j->perp), v_scale(df[2], j->axis));
+		float LA = df[0] * j->s1 + df[1] + df[2] * j->a1;
+		float LB = df[0] * j->s2 + df[1] + df[2] * j->a2;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * LA;
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * LB;
+	}
+	else
+	{
+		vec2 df = m_solve22(j->ex, j->ey, v_neg(Cdot1));
+		j->impulse[0] += df.x;
+		j->impulse[1] += df.y;
+		vec2 P = v_scale(df.x, j->perp);
+		float LA = df.x * j->s1 + df.y;
+		float LB = df.x * j->s2 + df.y;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * LA;
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * LB;
+	}
+}
+
+/* SolvePositionConstraints :352-478 */
+int b2o_prismatic_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB)
+{
+	rot qA = r_make(*aA), qB = r_make(*aB);
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, j->localCenterA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, j->localCenterB));
+	vec2 d = v_sub(v_sub(v_add(*cB, rB), *cA), rA);
+	vec2 axis = r_mul(qA, j->localXAxisA);
+	float a1 = v_cross(v_add(d, rA), axis);
+	float a2 = v_cross(rB, axis);
+	vec2 perp = r_mul(qA, j->localYAxisA);
+	float s1 = v_cross(v_add(d, rA), perp);
+	float s2 = v_cross(rB, perp);
+	float impulse[3];
+	vec2 C1;
+	C1.x = v_dot(perp, d);
+	C1.y = *aB - *aA - j->referenceAngle;
+	float linearError = f_abs(C1.x);
+	float angularError = f_abs(C1.y);
+	int active = 0;
+	float C2 = 0.0f;
+	if (j->enableLimit)
+	{
+		float translation = v_dot(axis, d);
+		if (f_abs(j->upperAngle - j->lowerAngle) < 2.0f * B2O_LINEAR_SLOP)
+		{
+			C2 = f_clamp(translation, -B2O_MAX_LINEAR_CORRECTION, B2O_MAX_LINEAR_CORRECTION);
+			linearError = f_max(linearError, f_abs(translation));
+			active = 1;
+		}
+		else if (translation <= j->lowerAngle)
+		{
+			C2 = f_clamp(translation - j->lowerAngle + B2O_LINEAR_SLOP, -B2O_MAX_LINEAR_CORRECTION, 0.0f);
+			linearError = f_max(linearError, j->lowerAngle - translation);
+			active = 1;
+		}
+		else if (translation >= j->upperAngle)
+		{
+			C2 = f_clamp(translation - j->upperAngle - B2O_LINEAR_SLOP, 0.0f, B2O_MAX_LINEAR_CORRECTION);
+			linearError = f_max(linearError, translation - j->upperAngle);
+			active = 1;
+		}
+	}
+	float ex[3], ey[3], ez[3];
+	prismatic_k(mA, mB, iA, iB, s1, s2, a1, a2, ex, ey, ez);
+	if (active)
+	{
+		float nC[3] = { -C1.x, -C1.y, -C2 };
+		m_solve33(ex, ey, ez, nC, impulse);
+	}
+	else
+	{
+		vec2 i1 = m_solve22(ex, ey, v_neg(C1)); /* b2Mat22::Solve has the same form (b2Math.h:221-233) */
+		impulse[0] = i1.x; impulse[1] = i1.y; impulse[2] = 0.0f;
+	}
+	vec2 P = v_add(v_scale(impulse[0], perp), v_scale(impulse[2], axis));
+	float LA = impulse[0] * s1 + impulse[1] + impulse[2] * a1;
+	float LB = impulse[0] * s2 + impulse[1] + impulse[2] * a2;
+	*cA = v_sub(*cA, v_scale(mA, P));
+	*aA -= iA * LA;
+	*cB = v_add(*cB, v_scale(mB, P));
+	*aB += iB * LB;
+	return linearError <= B2O_LINEAR_SLOP && angularError <= B2O_ANGULAR_SLOP;
+}
+
+/* ---- weld joint --------------------------------------------------------------------------------- */
+static void weld_k(vec2 rA, vec2 rB, float mA, float mB, float iA, float iB, float ex[3], float ey[3], float ez[3])
+{
+	ex[0] = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+	ey[0] = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+	ez[0] = -rA.y * iA - rB.y * iB;
+	ex[1] = ey[0];
+	ey[1] = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+	ez[1] = rA.x * iA + rB.x * iB;
+	ex[2] = ez[0];
+	ey[2] = ez[1];
+	ez[2] = iA + iB;
+}
+
+/* InitVelocityConstraints b2WeldJoint.cpp:58-155 */
+void b2o_weld_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	float aA, vec2* vA, float* wA, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	j->rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	j->rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	float kx[3], ky[3], kz[3];
+	weld_k(j->rA, j->rB, mA, mB, iA, iB, kx, ky, kz);
+	if (j->frequencyHz > 0.0f)
+	{
+		m_inverse22(kx, ky, j->ex, j->ey, j->ez);
+		float invM = iA + iB;
+		float m = invM > 0.0f ? 1.0f / invM : 0.0f;
+		float C = aB - aA - j->referenceAngle;
+		float omega = 2.0f * B2O_PI * j->frequencyHz;
+		float d = 2.0f * m * j->dampingRatio * omega;
+		float k = m * omega * omega;
+		j->gamma = dt * (d + dt * k);
+		j->gamma = j->gamma != 0.0f ? 1.0f / j->gamma : 0.0f;
+		j->bias = C * dt * k * j->gamma;
+		invM += j->gamma;
+		j->ez[2] = invM != 0.0f ? 1.0f / invM : 0.0f;
+	}
+	else if (kz[2] == 0.0f)
+	{
+		m_inverse22(kx, ky, j->ex, j->ey, j->ez);
+		j->gamma = 0.0f;
+		j->bias = 0.0f;
+	}
+	else
+	{
+		m_sym_inverse33(kx, ky, kz, j->ex, j->ey, j->ez);
+		j->gamma = 0.0f;
+		j->bias = 0.0f;
+	}
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio; j->impulse[1] *= dtRatio; j->impulse[2] *= dtRatio;
+		vec2 P = v_make(j->impulse[0], j->impulse[1]);
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * (v_cross(j->rA, P) + j->impulse[2]);
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * (v_cross(j->rB, P) + j->impulse[2]);
+	}
+	else
+	{
+		j->impulse[0] = j->impulse[1] = j->impulse[2] = 0.0f;
+	}
+}
+
+/* SolveVelocityConstraints :157-216 */
+void b2o_weld_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB)
+{
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	if (j->frequencyHz > 0.0f)
+	{
+		float Cdot2 = *wB - *wA;
+		float impulse2 = -j->ez[2] * (Cdot2 + j->bias + j->gamma * j->impulse[2]);
+		j->impulse[2] += impulse2;
+		*wA -= iA * impulse2;
+		*wB += iB * impulse2;
+		vec2 Cdot1 = v_sub(v_sub(v_add(*vB, v_cross_sv(*wB, j->rB)), *vA), v_cross_sv(*wA, j->rA));
+		/* b2Mul22 b2Math.h:521-524 */
+		vec2 impulse1 = v_neg(v_make(j->ex[0] * Cdot1.x + j->ey[0] * Cdot1.y, j->ex[1] * Cdot1.x + j->ey[1] * Cdot1.y));
+		j->impulse[0] += impulse1.x;
+		j->impulse[1] += impulse1.y;
+		vec2 P = impulse1;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * v_cross(j->rA, P);
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * v_cross(j->rB, P);
+	}
+	else
+	{
+		vec2 Cdot1 = v_sub(v_sub(v_add(*vB, v_cross_sv(*wB, j->rB)), *vA), v_cross_sv(*wA, j->rA));
+		float Cdot2 = *wB - *wA;
+		/* b2Mul(b2Mat33, b2Vec3) b2Math.h:515-518 */
+		float impulse[3];
+		for (int k = 0; k < 3; ++k) impulse[k] = -(Cdot1.x * j->ex[k] + Cdot1.y * j->ey[k] + Cdot2 * j->ez[k]);
+		j->impulse[0] += impulse[0]; j->impulse[1] += impulse[1]; j->impulse[2] += impulse[2];
+		vec2 P = v_make(impulse[0], impulse[1]);
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * (v_cross(j->rA, P) + impulse[2]);
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * (v_cross(j->rB, P) + impulse[2]);
+	}
+}
+
+/* SolvePositionConstraints :218-303 */
+int b2o_weld_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB)
+{
+	rot qA = r_make(*aA), qB = r_make(*aB);
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, j->localCenterA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, j->localCenterB));
+	float positionError, angularError;
+	float kx[3], ky[3], kz[3];
+	weld_k(rA, rB, mA, mB, iA, iB, kx, ky, kz);
+	vec2 C1 = v_sub(v_sub(v_add(*cB, rB), *cA), rA);
+	if (j->frequencyHz > 0.0f)
+	{
+		positionError = v_length(C1);
+		angularError = 0.0f;
+		vec2 P = v_neg(m_solve22(kx, ky, C1));
+		*cA = v_sub(*cA, v_scale(mA, P));
+		*aA -= iA * v_cross(rA, P);
+		*cB = v_add(*cB, v_scale(mB, P));
+		*aB += iB * v_cross(rB, P);
+	}
+	else
+	{
+		float C2 = *aB - *aA - j->referenceAngle;
+		positionError = v_length(C1);
+		angularError = f_abs(C2);
+		float impulse[3];
+		if (kz[2] > 0.0f)
+		{
+			float C[3] = { C1.x, C1.y, C2 };
+			m_solve33(kx, ky, kz, C, impulse);
+			impulse[0] = -impulse[0]; impulse[1] = -impulse[1]; impulse[2] = -impulse[2];
+		}
+		else
+		{
+			vec2 i2 = v_neg(m_solve22(kx, ky, C1));
+			impulse[0] = i2.x; impulse[1] = i2.y; impulse[2] = 0.0f;
+		}
+		vec2 P = v_make(impulse[0], impulse[1]);
+		*cA = v_sub(*cA, v_scale(mA, P));
+		*aA -= iA * (v_cross(rA, P) + impulse[2]);
+		*cB = v_add(*cB, v_scale(mB, P));
+		*aB += iB * (v_cross(rB, P) + impulse[2]);
+	}
+	return positionError <= B2O_LINEAR_SLOP && angularError <= B2O_ANGULAR_SLOP;
 }

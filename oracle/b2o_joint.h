@@ -1,10 +1,10 @@
-/* b2o_joint.h - CPU oracle, joint state: revolute and distance (TEST INFRASTRUCTURE, see b2o.h). */
+/* b2o_joint.h - CPU oracle, joint state: revolute, distance, prismatic, weld (TEST INFRASTRUCTURE, see b2o.h). */
 #ifndef B2O_JOINT_H
 #define B2O_JOINT_H
 
 #include "b2o_internal.h"
 
-enum { B2O_JOINT_REVOLUTE = 0, B2O_JOINT_DISTANCE = 1 };
+enum { B2O_JOINT_REVOLUTE = 0, B2O_JOINT_DISTANCE = 1, B2O_JOINT_PRISMATIC = 2, B2O_JOINT_WELD = 3 };
 
 typedef struct
 {
@@ -26,6 +26,10 @@ typedef struct
 	float length, frequencyHz, dampingRatio;
 	float gamma, bias, mass;
 	vec2 u;
+	/* prismatic joint (b2PrismaticJoint.h:170-196): limits in lowerAngle / upperAngle, motor force in maxMotorTorque,
+	 * m_K in ex / ey / ez ; weld joint (b2WeldJoint.h:97-123): m_mass in ex / ey / ez, gamma / bias above */
+	vec2 localXAxisA, localYAxisA, axis, perp;
+	float s1, s2, a1, a2;
 	int islandFlag;
 	int nextA, nextB; /* per-body joint lists, newest first: edge id = joint * 2 + side */
 } revolute_t;
@@ -39,5 +43,15 @@ void b2o_distance_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, fl
 	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt);
 void b2o_distance_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB);
 int b2o_distance_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+void b2o_prismatic_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
+void b2o_prismatic_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt);
+int b2o_prismatic_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+void b2o_weld_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	float aA, vec2* vA, float* wA, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt);
+void b2o_weld_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB);
+int b2o_weld_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
 
 #endif

@@ -5,7 +5,7 @@
  * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
- * (b2ContactManager.cpp:366-386). Joints: revolute, distance (b2o_joint.c). Not covered (same as the device
+ * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld (b2o_joint.c). Not covered (same as the device
  * path): other joint types, chain shapes. Continuous collision: b2o_toi.c
  * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
@@ -429,6 +429,59 @@ int b2o_create_distance_joint(b2o_world* w, int bodyA, int bodyB, const float* a
 	j->frequencyHz = frequencyHz;
 	j->dampingRatio = dampingRatio;
 	return id;
+}
+
+/* b2PrismaticJoint::b2PrismaticJoint (b2PrismaticJoint.cpp:98-128): the axis is normalised, the y axis is cross(1, x) */
+int b2o_create_prismatic_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, const float* axis2, float referenceAngle,
+	int enableLimit, float lower, float upper, int enableMotor, float motorSpeed, float maxMotorForce, int collideConnected)
+{
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors4, referenceAngle, enableLimit, lower, upper, enableMotor,
+		motorSpeed, maxMotorForce, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_PRISMATIC;
+	j->localXAxisA = v_make(axis2[0], axis2[1]);
+	v_normalize(&j->localXAxisA);
+	j->localYAxisA = v_cross_sv(1.0f, j->localXAxisA);
+	return id;
+}
+
+/* b2WeldJoint::b2WeldJoint (b2WeldJoint.cpp:46-56) */
+int b2o_create_weld_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float referenceAngle,
+	float frequencyHz, float dampingRatio, int collideConnected)
+{
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors4, referenceAngle, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_WELD;
+	j->frequencyHz = frequencyHz;
+	j->dampingRatio = dampingRatio;
+	return id;
+}
+
+static void set_awake(body_t* b);
+
+/* EnableMotor / SetMotorSpeed / SetMaxMotorTorque|Force (b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616) */
+void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor)
+{
+	revolute_t* j = &w->joints[joint];
+	if ((enableMotor != 0) == (j->enableMotor != 0) && motorSpeed == j->motorSpeed && maxMotor == j->maxMotorTorque) return;
+	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
+	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	j->enableMotor = enableMotor != 0;
+	j->motorSpeed = motorSpeed;
+	j->maxMotorTorque = maxMotor;
+}
+
+/* EnableLimit / SetLimits (b2RevoluteJoint.cpp:459-500, b2PrismaticJoint.cpp:549-581) */
+void b2o_joint_set_limits(b2o_world* w, int joint, int enableLimit, float lower, float upper)
+{
+	revolute_t* j = &w->joints[joint];
+	if ((enableLimit != 0) == (j->enableLimit != 0) && lower == j->lowerAngle && upper == j->upperAngle) return;
+	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
+	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	j->enableLimit = enableLimit != 0;
+	j->lowerAngle = lower;
+	j->upperAngle = upper;
+	j->impulse[2] = 0.0f;
 }
 
 /* ---- contacts ------------------------------------------------------------------------------------ */
@@ -1194,14 +1247,26 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		body_t* bA = &w->bodies[j->bodyA];
 		body_t* bB = &w->bodies[j->bodyB];
 		int ia = bA->islandIndex, ib = bB->islandIndex;
-		if (j->type == B2O_JOINT_DISTANCE)
+		vec2* vA = &velocities[ia].v; float* wA = &velocities[ia].w;
+		vec2* vB = &velocities[ib].v; float* wB = &velocities[ib].w;
+		switch (j->type)
+		{
+		case B2O_JOINT_DISTANCE:
 			b2o_distance_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
-				positions[ia].c, positions[ia].a, &velocities[ia].v, &velocities[ia].w,
-				positions[ib].c, positions[ib].a, &velocities[ib].v, &velocities[ib].w, w->warmStarting, dtRatio, h);
-		else
+				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio, h);
+			break;
+		case B2O_JOINT_PRISMATIC:
+			b2o_prismatic_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
+			break;
+		case B2O_JOINT_WELD:
+			b2o_weld_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].a, vA, wA, positions[ib].a, vB, wB, w->warmStarting, dtRatio, h);
+			break;
+		default:
 			b2o_revolute_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
-				positions[ia].a, &velocities[ia].v, &velocities[ia].w, positions[ib].a, &velocities[ib].v, &velocities[ib].w,
-				w->warmStarting, dtRatio);
+				positions[ia].a, vA, wA, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
+		}
 	}
 	for (int it = 0; it < velIters; ++it)
 	{
@@ -1209,10 +1274,15 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		{
 			revolute_t* j = &w->joints[islandJoints[i]];
 			int ia = w->bodies[j->bodyA].islandIndex, ib = w->bodies[j->bodyB].islandIndex;
-			if (j->type == B2O_JOINT_DISTANCE)
-				b2o_distance_velocity(j, &velocities[ia].v, &velocities[ia].w, &velocities[ib].v, &velocities[ib].w);
-			else
-				b2o_revolute_velocity(j, &velocities[ia].v, &velocities[ia].w, &velocities[ib].v, &velocities[ib].w, h);
+			vec2* vA = &velocities[ia].v; float* wA = &velocities[ia].w;
+			vec2* vB = &velocities[ib].v; float* wB = &velocities[ib].w;
+			switch (j->type)
+			{
+			case B2O_JOINT_DISTANCE: b2o_distance_velocity(j, vA, wA, vB, wB); break;
+			case B2O_JOINT_PRISMATIC: b2o_prismatic_velocity(j, vA, wA, vB, wB, h); break;
+			case B2O_JOINT_WELD: b2o_weld_velocity(j, vA, wA, vB, wB); break;
+			default: b2o_revolute_velocity(j, vA, wA, vB, wB, h);
+			}
 		}
 		for (int i = 0; i < contactCount; ++i) solve_velocity(&cs[i], velocities);
 	}
@@ -1257,9 +1327,16 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		{
 			revolute_t* j = &w->joints[islandJoints[i]];
 			int ia = w->bodies[j->bodyA].islandIndex, ib = w->bodies[j->bodyB].islandIndex;
-			int ok = j->type == B2O_JOINT_DISTANCE
-				? b2o_distance_position(j, &positions[ia].c, &positions[ia].a, &positions[ib].c, &positions[ib].a)
-				: b2o_revolute_position(j, &positions[ia].c, &positions[ia].a, &positions[ib].c, &positions[ib].a);
+			vec2* cA = &positions[ia].c; float* aA = &positions[ia].a;
+			vec2* cB = &positions[ib].c; float* aB = &positions[ib].a;
+			int ok;
+			switch (j->type)
+			{
+			case B2O_JOINT_DISTANCE: ok = b2o_distance_position(j, cA, aA, cB, aB); break;
+			case B2O_JOINT_PRISMATIC: ok = b2o_prismatic_position(j, cA, aA, cB, aB); break;
+			case B2O_JOINT_WELD: ok = b2o_weld_position(j, cA, aA, cB, aB); break;
+			default: ok = b2o_revolute_position(j, cA, aA, cB, aB);
+			}
 			jointsOkay = jointsOkay && ok;
 		}
 		if (minSeparation >= -3.0f * B2O_LINEAR_SLOP && jointsOkay)

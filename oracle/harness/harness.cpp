@@ -116,6 +116,15 @@ void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
 {
 	for (int i = 0; i < steps; ++i)
 	{
+		if (h->scene.sliderBounces && h->scene.joint != NULL)
+		{
+			// between steps, through the public joint API: turn the motor round once the slider has reached the limit it runs at
+			b2PrismaticJoint* slider = static_cast<b2PrismaticJoint*>(h->scene.joint);
+			const float speed = slider->GetJointSpeed(), at = slider->GetJointTranslation();
+			const bool atUpper = speed > 0.0f && at >= slider->GetUpperLimit() - b2_epsilon;
+			const bool atLower = speed < 0.0f && at <= slider->GetLowerLimit() + b2_epsilon;
+			if (atUpper || atLower) slider->SetMotorSpeed(-slider->GetMotorSpeed());
+		}
 		h->world->Step(dt, velIters, posIters, *h->executor);
 		const b2Profile& p = h->world->GetProfile();
 		const float v[13] = { p.step, p.collide, p.solve, p.solveTraversal, p.solveInit, p.solveVelocity,

@@ -1,7 +1,7 @@
 // Scene recipes used by the parity harness and the bench.
 //
 // TEST INFRASTRUCTURE. This file is written against the PUBLIC Box2D-MT API only
-// (b2World / b2Body / b2Fixture / shapes / b2RevoluteJointDef / b2DistanceJointDef), so the very same source is
+// (b2World / b2Body / b2Fixture / shapes / b2RevoluteJointDef / b2DistanceJointDef / b2PrismaticJointDef / b2WeldJointDef), so the very same source is
 // compiled twice:
 //   * against the reference headers + sources under /root/reference  -> oracle/_ref/libb2ref_harness.so
 //   * against this repo's drop-in headers (box2d-mt_amd/host)         -> libb2amd_harness.so
@@ -72,6 +72,9 @@ enum SceneId
 	                     //   a proximity sensor: exercises b2Contact::Update's sensor branch (b2TestOverlap = GJK with radii)
 	e_ropes = 9,         // p0 = falling bodies, p1 = planks ; distance joints: a plank bridge hung by rigid rods between its
 	                     //   planks and the ground, a soft web of four boxes on damped springs, bodies dropped on both
+	e_machines = 10,     // p0 = falling bodies, p1 = cantilever segments ; prismatic joints (motor slider between limits, a free
+	                     //   vertical slider resting on its lower limit, a locked one) and weld joints (rigid and soft cantilevers,
+	                     //   a welded free-falling pair), bodies dropped over all of them
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -88,9 +91,10 @@ struct Scene
 {
 	std::vector<b2Body*> bodies; // creation order == body index used by every dump
 	b2Joint* joint;
+	bool sliderBounces; // joint is a prismatic motor slider whose motor is reversed by the step loop at either limit
 	float dtDefault;
 	int velIters, posIters;
-	Scene() : joint(NULL), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
+	Scene() : joint(NULL), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
 };
 
 inline b2Body* AddBody(Scene& s, b2World* w, const b2BodyDef& bd)
@@ -623,6 +627,146 @@ inline void BuildRopes(Scene& s, b2World* w, int count, int planks, uint32_t see
 	}
 }
 
+// Prismatic and weld joints, every limit / motor / softness branch, sharing islands with contacts.
+inline void BuildMachines(Scene& s, b2World* w, int count, int segments, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	Pcg32 rng(seed ? seed : 31u);
+	if (segments < 1) segments = 1;
+	b2Body* ground;
+	{
+		b2BodyDef bd;
+		ground = AddBody(s, w, bd);
+		b2PolygonShape slab;
+		slab.SetAsBox(40.0f, 0.5f, b2Vec2(0.0f, -0.5f), 0.0f);
+		ground->CreateFixture(&slab, 0.0f);
+	}
+	b2PolygonShape block;
+	block.SetAsBox(1.0f, 1.0f);
+	// motor slider along x between -12 and 12, reversed at either limit by the step loop (as MultithreadDemo.h:153-160
+	// drives its slider), pushing whatever lies in the way
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(-6.0f, 1.0f);
+		bd.allowSleep = false;
+		b2Body* body = AddBody(s, w, bd);
+		body->CreateFixture(&block, 5.0f);
+		b2PrismaticJointDef jd;
+		jd.Initialize(ground, body, b2Vec2(0.0f, 1.0f), b2Vec2(1.0f, 0.0f));
+		jd.motorSpeed = 6.0f;
+		jd.maxMotorForce = 5000.0f;
+		jd.enableMotor = true;
+		jd.lowerTranslation = -12.0f;
+		jd.upperTranslation = 12.0f;
+		jd.enableLimit = true;
+		s.joint = w->CreateJoint(&jd);
+		s.sliderBounces = true;
+	}
+	// free slider on a tilted axis: falls to its lower limit and stays there under the bodies that land on it
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(-20.0f, 8.0f);
+		bd.angle = 0.25f;
+		b2Body* body = AddBody(s, w, bd);
+		body->CreateFixture(&block, 2.0f);
+		b2PrismaticJointDef jd;
+		jd.Initialize(ground, body, bd.position, b2Vec2(0.3f, 2.0f)); // not normalised on purpose
+		jd.lowerTranslation = -3.0f;
+		jd.upperTranslation = 2.0f;
+		jd.enableLimit = true;
+		w->CreateJoint(&jd);
+	}
+	// locked slider (equal limits) holding a shelf, and an unlimited one with a weak motor working against gravity
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(22.0f, 6.0f);
+		b2Body* body = AddBody(s, w, bd);
+		b2PolygonShape shelf;
+		shelf.SetAsBox(3.0f, 0.25f);
+		body->CreateFixture(&shelf, 1.0f);
+		b2PrismaticJointDef jd;
+		jd.Initialize(ground, body, bd.position, b2Vec2(0.0f, 1.0f));
+		jd.lowerTranslation = 0.0f;
+		jd.upperTranslation = 0.0f;
+		jd.enableLimit = true;
+		jd.enableMotor = true;
+		jd.motorSpeed = 1.0f;
+		jd.maxMotorForce = 100.0f;
+		w->CreateJoint(&jd);
+
+		bd.position.Set(30.0f, 4.0f);
+		b2Body* lift = AddBody(s, w, bd);
+		lift->CreateFixture(&shelf, 1.0f);
+		jd.Initialize(ground, lift, bd.position, b2Vec2(0.0f, 1.0f));
+		jd.enableLimit = false;
+		jd.motorSpeed = 0.5f;
+		jd.maxMotorForce = 40.0f;
+		w->CreateJoint(&jd);
+	}
+	// cantilevers: rigid welds from a ground post at y = 10, soft welds at y = 14
+	for (int soft = 0; soft < 2; ++soft)
+	{
+		b2PolygonShape seg;
+		seg.SetAsBox(0.5f, 0.125f);
+		b2Body* prev = ground;
+		const float y = soft ? 14.0f : 10.0f;
+		for (int i = 0; i < segments; ++i)
+		{
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(4.5f + (float)i, y);
+			b2Body* body = AddBody(s, w, bd);
+			body->CreateFixture(&seg, 20.0f);
+			b2WeldJointDef jd;
+			jd.frequencyHz = soft ? 5.0f : 0.0f;
+			jd.dampingRatio = soft ? 0.7f : 0.0f;
+			jd.Initialize(prev, body, b2Vec2(4.0f + (float)i, y));
+			w->CreateJoint(&jd);
+			prev = body;
+		}
+	}
+	// a welded pair in free fall (circle + box), fixed-rotation partner welded to a rotating one
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(14.0f, 20.0f);
+		b2Body* a = AddBody(s, w, bd);
+		a->CreateFixture(&block, 1.0f);
+		bd.position.Set(16.0f, 20.5f);
+		bd.fixedRotation = true;
+		b2Body* b = AddBody(s, w, bd);
+		b2CircleShape c;
+		c.m_radius = 0.75f;
+		b->CreateFixture(&c, 1.0f);
+		b2WeldJointDef jd;
+		jd.Initialize(a, b, b2Vec2(15.0f, 20.0f));
+		w->CreateJoint(&jd);
+	}
+	for (int i = 0; i < count; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(rng.Range(-24.0f, 32.0f), rng.Range(16.0f, 40.0f));
+		bd.angle = rng.Range(-1.0f, 1.0f);
+		b2Body* body = AddBody(s, w, bd);
+		if (i % 3 == 0)
+		{
+			b2CircleShape c;
+			c.m_radius = rng.Range(0.15f, 0.4f);
+			body->CreateFixture(&c, 1.0f);
+		}
+		else
+		{
+			b2PolygonShape b;
+			b.SetAsBox(rng.Range(0.15f, 0.45f), rng.Range(0.15f, 0.45f));
+			body->CreateFixture(&b, 1.0f);
+		}
+	}
+}
+
 inline void BuildBullets(Scene& s, b2World* w, int projectiles, int stackHeight, uint32_t seed)
 {
 	w->SetGravity(b2Vec2(0.0f, -10.0f));
@@ -704,6 +848,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_bullets: BuildBullets(s, w, p.p0, p.p1, p.seed); break;
 	case e_sensors: BuildSensors(s, w, p.p0, p.seed); break;
 	case e_ropes: BuildRopes(s, w, p.p0, p.p1, p.seed); break;
+	case e_machines: BuildMachines(s, w, p.p0, p.p1, p.seed); break;
 	default: break;
 	}
 }

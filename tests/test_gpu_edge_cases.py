@@ -226,6 +226,80 @@ def test_distance_joints_without_warm_starting(libs, monkeypatch):
     a.close(); b.close()
 
 
+def test_prismatic_and_weld_joints(libs, monkeypatch):
+    """Prismatic joints (b2PrismaticJoint.cpp) in each limit state with and without motor, on a moving (dynamic) parent
+    too, and weld joints (b2WeldJoint.cpp) rigid, soft and with a fixed-rotation pair (singular angular row). Exact-order mode."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs)
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+        w.create_fixture(g, b2hip.box_shape(40.0, 0.5))
+        cart = w.create_body(b2hip.DYNAMIC, (0.0, 1.5))
+        w.create_fixture(cart, b2hip.box_shape(2.0, 0.5), density=2.0, friction=0.1)
+        w.create_prismatic_joint(g, cart, anchor_a=(0.0, 1.5), anchor_b=(0.0, 0.0), axis=(2.0, 0.0), enable_limit=True, lower=-5.0,
+                                 upper=5.0, enable_motor=True, motor_speed=4.0, max_motor_force=400.0)
+        mast = w.create_body(b2hip.DYNAMIC, (0.0, 4.0))
+        w.create_fixture(mast, b2hip.box_shape(0.2, 2.0), density=0.5)
+        w.create_weld_joint(cart, mast, anchor_a=(0.0, 0.5), anchor_b=(0.0, -2.0))
+        flag = w.create_body(b2hip.DYNAMIC, (1.0, 6.0))
+        w.create_fixture(flag, b2hip.box_shape(0.8, 0.1), density=0.5)
+        w.create_weld_joint(mast, flag, anchor_a=(0.2, 2.0), anchor_b=(-0.8, 0.0), frequency_hz=3.0, damping_ratio=0.3)
+        bob = w.create_body(b2hip.DYNAMIC, (3.0, 3.0))
+        w.create_fixture(bob, b2hip.circle_shape(0.4), density=1.0)
+        w.create_prismatic_joint(cart, bob, anchor_a=(1.5, 0.5), anchor_b=(0.0, -1.0), axis=(0.5, 1.0), reference_angle=0.1,
+                                 enable_limit=True, lower=-0.5, upper=1.5)
+        pin = w.create_body(b2hip.DYNAMIC, (-10.0, 5.0), fixed_rotation=True)
+        w.create_fixture(pin, b2hip.box_shape(0.3, 0.3), density=1.0)
+        nail = w.create_body(b2hip.DYNAMIC, (-10.0, 6.0), fixed_rotation=True)
+        w.create_fixture(nail, b2hip.circle_shape(0.3), density=1.0)
+        w.create_weld_joint(pin, nail, anchor_a=(0.0, 0.5), anchor_b=(0.0, -0.5))
+        w.create_prismatic_joint(g, pin, anchor_a=(-10.0, 5.0), anchor_b=(0.0, 0.0), axis=(0.0, 1.0), enable_limit=True,
+                                 lower=-0.001, upper=0.001)
+        for i in range(20):
+            d = w.create_body(b2hip.DYNAMIC, (-4.0 + 0.45 * i, 9.0 + 0.7 * (i % 5)), angle=0.1 * i)
+            w.create_fixture(d, b2hip.box_shape(0.2, 0.2) if i % 2 else b2hip.circle_shape(0.2), density=1.0)
+    run(a, b, 250, "prismatic + weld")
+    a.close(); b.close()
+
+
+def test_joint_setters_between_steps(libs, monkeypatch):
+    """b2hip_joint_set_motor / b2hip_joint_set_limits: reverse a slider's motor, switch motors off and on, move and drop the
+    limits of a revolute arm while everything has gone to sleep (the setters wake both bodies, as the reference's do), and
+    calls that change nothing (no wake-up)."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs)
+    ids = {}
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+        w.create_fixture(g, b2hip.box_shape(40.0, 0.5))
+        cart = w.create_body(b2hip.DYNAMIC, (0.0, 1.5))
+        w.create_fixture(cart, b2hip.box_shape(1.0, 0.5), density=2.0, friction=0.2)
+        ids["slider"] = w.create_prismatic_joint(g, cart, anchor_a=(0.0, 1.5), axis=(1.0, 0.0), enable_limit=True, lower=-3.0, upper=3.0,
+                                                 enable_motor=True, motor_speed=3.0, max_motor_force=300.0)
+        arm = w.create_body(b2hip.DYNAMIC, (10.0, 5.0))
+        w.create_fixture(arm, b2hip.box_shape(2.0, 0.2), density=1.0)
+        ids["hinge"] = w.create_revolute_joint(g, arm, anchor_a=(8.0, 5.0), anchor_b=(-2.0, 0.0), enable_limit=True, lower=-0.3, upper=0.3)
+        for i in range(6):
+            d = w.create_body(b2hip.DYNAMIC, (-1.0 + 0.4 * i, 2.5 + 0.5 * i))
+            w.create_fixture(d, b2hip.box_shape(0.2, 0.2), density=1.0)
+
+    def between(s, w):
+        if s == 60:
+            w.joint_set_motor(ids["slider"], True, -3.0, 300.0)
+        if s == 100:
+            w.joint_set_motor(ids["slider"], False, -3.0, 300.0)
+        if s in (250, 251):
+            w.joint_set_limits(ids["hinge"], True, -1.2, -0.6)     # asleep by now: wakes the arm (251: no change, no-op)
+        if s == 330:
+            w.joint_set_limits(ids["hinge"], False, -1.2, -0.6)
+            w.joint_set_motor(ids["hinge"], True, 2.0, 80.0)
+            w.joint_set_motor(ids["slider"], True, 1.0, 50.0)
+            w.joint_set_limits(ids["slider"], True, -6.0, 0.5)
+
+    run(a, b, 420, "joint setters", between=between)
+    a.close(); b.close()
+
+
 def test_dense_start_grows_the_pair_buffer(monkeypatch):
     """1 400 bodies and 450 bullets crammed into a 70 x 70 arena: the first pair update finds several times more candidate
     pairs than the buffer was sized for (21 000 contacts on step one). The buffers grow and the search runs again - no
