@@ -1,11 +1,14 @@
 // b2d_joint.h - joint constraints on the device path: revolute (Tumbler's motor), distance (rigid rods and
-// soft springs), prismatic (MultithreadDemo's slider: axis, limits, motor) and weld (rigid or soft). One fixed-size record per joint whatever its type (the type-specific members share storage), so
+// soft springs), prismatic (MultithreadDemo's slider: axis, limits, motor), weld (rigid or soft), wheel (suspension
+// spring + axle motor), rope (maximum distance), friction and motor (top-down drag / pose servo). One fixed-size record per joint whatever its type (the type-specific members share storage), so
 // the island kernels, the upload and the snapshot handle one array.
 // Restates b2RevoluteJoint::{InitVelocityConstraints, SolveVelocityConstraints, SolvePositionConstraints}
 // (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376) and the same three of b2DistanceJoint
 // (Joints/b2DistanceJoint.cpp:65-236), b2PrismaticJoint (Joints/b2PrismaticJoint.cpp:130-478) and b2WeldJoint
 // (Joints/b2WeldJoint.cpp:58-303) in the reference's operand order; b2Mat33::Solve33 / Solve22 / GetInverse22 /
-// GetSymInverse33 as in Box2D/Common/b2Math.cpp:25-94.
+// GetSymInverse33 as in Box2D/Common/b2Math.cpp:25-94. Also b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
+// (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint
+// (Joints/b2MotorJoint.cpp:62-203).
 #ifndef B2D_JOINT_H
 #define B2D_JOINT_H
 
@@ -26,33 +29,40 @@ enum
 	B2D_JOINT_REVOLUTE = 0, // e_revoluteJoint
 	B2D_JOINT_DISTANCE = 1, // e_distanceJoint
 	B2D_JOINT_PRISMATIC = 2, // e_prismaticJoint
-	B2D_JOINT_WELD = 3      // e_weldJoint
+	B2D_JOINT_WELD = 3,     // e_weldJoint
+	B2D_JOINT_WHEEL = 4,    // e_wheelJoint
+	B2D_JOINT_ROPE = 5,     // e_ropeJoint
+	B2D_JOINT_FRICTION = 6, // e_frictionJoint
+	B2D_JOINT_MOTOR = 7     // e_motorJoint
 };
 
 struct JointRec
 {
 	// definition (b2RevoluteJointDef / b2DistanceJointDef / b2PrismaticJointDef / b2WeldJointDef)
 	int bodyA, bodyB;
-	V2 localAnchorA, localAnchorB;
-	union { float referenceAngle; float length; };
+	union { V2 localAnchorA; V2 linearOffset; };   // motor joint: m_linearOffset
+	V2 localAnchorB;
+	union { float referenceAngle; float length; float maxLength; float angularOffset; };
 	int enableLimit;
-	union { float lowerAngle; float frequencyHz; float lowerTranslation; };
+	union { float lowerAngle; float frequencyHz; float lowerTranslation; float correctionFactor; };
 	union { float upperAngle; float dampingRatio; float upperTranslation; };
 	int enableMotor;
-	float motorSpeed;
-	union { float maxMotorTorque; float maxMotorForce; };
+	union { float motorSpeed; float maxTorque; };  // friction / motor joint: m_maxTorque
+	union { float maxMotorTorque; float maxMotorForce; float maxForce; };
 	int collideConnected;
 	// persistent solver state (b2RevoluteJoint.h:190-199, b2DistanceJoint.h:148-150)
-	union { float impulseX; float impulse; };
-	float impulseY, impulseZ;
+	union { float impulseX; float impulse; };      // wheel: m_impulse ; friction / motor: m_linearImpulse.x
+	union { float impulseY; float springImpulse; }; // friction / motor: m_linearImpulse.y
+	union { float impulseZ; float angularImpulse; };
 	float motorImpulse;
 	int limitState;
 	// per-step scratch written by init
 	V2 rA, rB, localCenterA, localCenterB;
 	float invMassA, invMassB, invIA, invIB;
 	union { float m_exx; float mass; };  // revolute: m_mass (3x3) ; distance: m_mass, m_gamma, m_bias, m_u
-	union { float m_exy; float gamma; };
-	union { float m_exz; float bias; };
+	union { float m_exy; float gamma; float springMass; float curLength; }; // wheel: m_springMass, m_bias, m_gamma in exy, exz, eyx
+	union { float m_exz; float bias; };                                     // rope: m_length in exy ; friction / motor: m_linearMass
+	                                                                         //   in exx, exy (ex) and eyx, eyy (ey)
 	union { float m_eyx; float ux; };
 	union { float m_eyy; float uy; };
 	float m_eyz, m_ezx, m_ezy, m_ezz;
@@ -60,9 +70,10 @@ struct JointRec
 	int islandFlag;
 	int type;
 	V2 localAxisA;                        // prismatic: m_localXAxisA (normalised at creation)
-	union { float s1; float wGamma; };    // prismatic: m_s1, m_s2, m_a1, m_a2 ; weld: m_gamma, m_bias
-	union { float s2; float wBias; };
-	float a1, a2;
+	union { float s1; float wGamma; float sAx; float linErrX; };  // prismatic: m_s1, m_s2, m_a1, m_a2 ; weld: m_gamma, m_bias
+	union { float s2; float wBias; float sBx; float linErrY; };   // wheel: m_sAx, m_sBx, m_sAy, m_sBy ; motor: m_linearError,
+	union { float a1; float sAy; float angErr; };                 //   m_angularError
+	union { float a2; float sBy; };
 };
 typedef JointRec RevoluteJoint;
 
@@ -988,6 +999,381 @@ B2D_HD bool b2dWeldSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 	return positionError <= B2D_LINEAR_SLOP && angularError <= B2D_ANGULAR_SLOP;
 }
 
+// ---- wheel joint ------------------------------------------------------------------------------------
+// The record keeps m_ax in rA and m_ay in rB. InitVelocityConstraints (b2WheelJoint.cpp:79-198)
+B2D_HD void b2dWheelInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
+{
+	b2dJointStoreBodies(j, invMassA, invIA, lcA, invMassB, invIB, lcB);
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	float mA = invMassA, mB = invMassB, iA = invIA, iB = invIB;
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - lcA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	V2 d = pB.c + rB - pA.c - rA;
+	// point to line constraint
+	V2 ay = b2dMulRV(qA, b2dCrossSV(1.0f, j->localAxisA));
+	j->rB = ay;
+	j->sAy = b2dCross(d + rA, ay);
+	j->sBy = b2dCross(rB, ay);
+	j->mass = mA + mB + iA * j->sAy * j->sAy + iB * j->sBy * j->sBy;
+	if (j->mass > 0.0f) j->mass = 1.0f / j->mass;
+	// spring constraint
+	j->springMass = 0.0f;
+	j->bias = 0.0f;
+	float gamma = 0.0f;
+	if (j->frequencyHz > 0.0f)
+	{
+		V2 ax = b2dMulRV(qA, j->localAxisA);
+		j->rA = ax;
+		j->sAx = b2dCross(d + rA, ax);
+		j->sBx = b2dCross(rB, ax);
+		float invMass = mA + mB + iA * j->sAx * j->sAx + iB * j->sBx * j->sBx;
+		if (invMass > 0.0f)
+		{
+			j->springMass = 1.0f / invMass;
+			float C = b2dDot(d, ax);
+			float omega = 2.0f * B2D_PI * j->frequencyHz;
+			float damp = 2.0f * j->springMass * j->dampingRatio * omega;
+			float k = j->springMass * omega * omega;
+			gamma = dt * (damp + dt * k);
+			if (gamma > 0.0f) gamma = 1.0f / gamma;
+			j->bias = C * dt * k * gamma;
+			j->springMass = invMass + gamma;
+			if (j->springMass > 0.0f) j->springMass = 1.0f / j->springMass;
+		}
+	}
+	else
+	{
+		j->springImpulse = 0.0f;
+	}
+	j->m_eyx = gamma;
+	if (j->enableMotor)
+	{
+		j->motorMass = iA + iB;
+		if (j->motorMass > 0.0f) j->motorMass = 1.0f / j->motorMass;
+	}
+	else
+	{
+		j->motorMass = 0.0f;
+		j->motorImpulse = 0.0f;
+	}
+	if (warmStarting)
+	{
+		j->impulse *= dtRatio;
+		j->springImpulse *= dtRatio;
+		j->motorImpulse *= dtRatio;
+		const V2 ax = j->rA;
+		V2 P = j->impulse * ay + j->springImpulse * ax;
+		float LA = j->impulse * j->sAy + j->springImpulse * j->sAx + j->motorImpulse;
+		float LB = j->impulse * j->sBy + j->springImpulse * j->sBx + j->motorImpulse;
+		vA -= mA * P;
+		wA -= iA * LA;
+		vB += mB * P;
+		wB += iB * LB;
+	}
+	else
+	{
+		j->impulse = 0.0f;
+		j->springImpulse = 0.0f;
+		j->motorImpulse = 0.0f;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolveVelocityConstraints (b2WheelJoint.cpp:200-257): spring, motor, then the line constraint
+B2D_HD void b2dWheelSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	const V2 ax = j->rA, ay = j->rB;
+	{
+		float Cdot = b2dDot(ax, vB - vA) + j->sBx * wB - j->sAx * wA;
+		float impulse = -j->springMass * (Cdot + j->bias + j->m_eyx * j->springImpulse);
+		j->springImpulse += impulse;
+		V2 P = impulse * ax;
+		float LA = impulse * j->sAx;
+		float LB = impulse * j->sBx;
+		vA -= mA * P;
+		wA -= iA * LA;
+		vB += mB * P;
+		wB += iB * LB;
+	}
+	{
+		float Cdot = wB - wA - j->motorSpeed;
+		float impulse = -j->motorMass * Cdot;
+		float oldImpulse = j->motorImpulse;
+		float maxImpulse = dt * j->maxMotorTorque;
+		j->motorImpulse = b2dClamp(j->motorImpulse + impulse, -maxImpulse, maxImpulse);
+		impulse = j->motorImpulse - oldImpulse;
+		wA -= iA * impulse;
+		wB += iB * impulse;
+	}
+	{
+		float Cdot = b2dDot(ay, vB - vA) + j->sBy * wB - j->sAy * wA;
+		float impulse = -j->mass * Cdot;
+		j->impulse += impulse;
+		V2 P = impulse * ay;
+		float LA = impulse * j->sAy;
+		float LB = impulse * j->sBy;
+		vA -= mA * P;
+		wA -= iA * LA;
+		vB += mB * P;
+		wB += iB * LB;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolvePositionConstraints (b2WheelJoint.cpp:259-292). The effective mass there is built from the lever arms stored
+// by InitVelocityConstraints (m_sAy, m_sBy), not from the ones of the current positions - kept.
+B2D_HD bool b2dWheelSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
+{
+	V2 cA = A->c, cB = B->c;
+	float aA = A->a, aB = B->a;
+	Rot qA = b2dRot(aA), qB = b2dRot(aB);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - j->localCenterA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - j->localCenterB);
+	V2 d = (cB - cA) + rB - rA;
+	V2 ay = b2dMulRV(qA, b2dCrossSV(1.0f, j->localAxisA));
+	float sAy = b2dCross(d + rA, ay);
+	float sBy = b2dCross(rB, ay);
+	float C = b2dDot(d, ay);
+	float k = j->invMassA + j->invMassB + j->invIA * j->sAy * j->sAy + j->invIB * j->sBy * j->sBy;
+	float impulse;
+	if (k != 0.0f)
+	{
+		impulse = -C / k;
+	}
+	else
+	{
+		impulse = 0.0f;
+	}
+	V2 P = impulse * ay;
+	float LA = impulse * sAy;
+	float LB = impulse * sBy;
+	cA -= j->invMassA * P;
+	aA -= j->invIA * LA;
+	cB += j->invMassB * P;
+	aB += j->invIB * LB;
+	A->c = cA; A->a = aA;
+	B->c = cB; B->a = aB;
+	return b2dAbs(C) <= B2D_LINEAR_SLOP;
+}
+
+// ---- rope joint -------------------------------------------------------------------------------------
+// InitVelocityConstraints (b2RopeJoint.cpp:48-115); limitState holds m_state, curLength m_length
+B2D_HD void b2dRopeInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio)
+{
+	b2dJointStoreBodies(j, invMassA, invIA, lcA, invMassB, invIB, lcB);
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - lcA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	j->rA = rA;
+	j->rB = rB;
+	V2 u = pB.c + rB - pA.c - rA;
+	j->curLength = b2dLength(u);
+	float C = j->curLength - j->maxLength;
+	j->limitState = C > 0.0f ? B2D_LIMIT_AT_UPPER : B2D_LIMIT_INACTIVE;
+	if (j->curLength > B2D_LINEAR_SLOP)
+	{
+		u = (1.0f / j->curLength) * u;
+	}
+	else
+	{
+		j->ux = 0.0f;
+		j->uy = 0.0f;
+		j->mass = 0.0f;
+		j->impulse = 0.0f;
+		return;
+	}
+	j->ux = u.x;
+	j->uy = u.y;
+	float crA = b2dCross(rA, u);
+	float crB = b2dCross(rB, u);
+	float invMass = invMassA + invIA * crA * crA + invMassB + invIB * crB * crB;
+	j->mass = invMass != 0.0f ? 1.0f / invMass : 0.0f;
+	if (warmStarting)
+	{
+		j->impulse *= dtRatio;
+		V2 P = j->impulse * u;
+		vA -= invMassA * P;
+		wA -= invIA * b2dCross(rA, P);
+		vB += invMassB * P;
+		wB += invIB * b2dCross(rB, P);
+	}
+	else
+	{
+		j->impulse = 0.0f;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolveVelocityConstraints (b2RopeJoint.cpp:117-149): predictive when the rope is still slack
+B2D_HD void b2dRopeSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float inv_dt)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	const V2 rA = j->rA, rB = j->rB, u = v2(j->ux, j->uy);
+	V2 vpA = vA + b2dCrossSV(wA, rA);
+	V2 vpB = vB + b2dCrossSV(wB, rB);
+	float C = j->curLength - j->maxLength;
+	float Cdot = b2dDot(u, vpB - vpA);
+	if (C < 0.0f) Cdot += inv_dt * C;
+	float impulse = -j->mass * Cdot;
+	float oldImpulse = j->impulse;
+	j->impulse = b2dMin(0.0f, j->impulse + impulse);
+	impulse = j->impulse - oldImpulse;
+	V2 P = impulse * u;
+	vA -= j->invMassA * P;
+	wA -= j->invIA * b2dCross(rA, P);
+	vB += j->invMassB * P;
+	wB += j->invIB * b2dCross(rB, P);
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolvePositionConstraints (b2RopeJoint.cpp:151-182)
+B2D_HD bool b2dRopeSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
+{
+	V2 cA = A->c, cB = B->c;
+	float aA = A->a, aB = B->a;
+	Rot qA = b2dRot(aA), qB = b2dRot(aB);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - j->localCenterA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - j->localCenterB);
+	V2 u = cB + rB - cA - rA;
+	float length = b2dNormalize(u);
+	float C = length - j->maxLength;
+	C = b2dClamp(C, 0.0f, B2D_MAX_LINEAR_CORRECTION);
+	float impulse = -j->mass * C;
+	V2 P = impulse * u;
+	cA -= j->invMassA * P;
+	aA -= j->invIA * b2dCross(rA, P);
+	cB += j->invMassB * P;
+	aB += j->invIB * b2dCross(rB, P);
+	A->c = cA; A->a = aA;
+	B->c = cB; B->a = aB;
+	return length - j->maxLength < B2D_LINEAR_SLOP;
+}
+
+// ---- friction and motor joints: a clamped 2-D linear row pair + a clamped angular row ------------------
+// m_linearMass = K.GetInverse() (b2Math.h:205-217), stored as ex = (exx, exy), ey = (eyx, eyy)
+B2D_HD void b2dJointLinearMass(JointRec* j, V2 rA, V2 rB, float mA, float mB, float iA, float iB)
+{
+	float kxx = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
+	float kxy = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+	float kyy = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+	float a = kxx, b = kxy, c = kxy, d = kyy;
+	float det = a * d - b * c;
+	if (det != 0.0f) det = 1.0f / det;
+	j->m_exx = det * d; j->m_eyx = -det * b;
+	j->m_exy = -det * c; j->m_eyy = det * a;
+	j->motorMass = iA + iB; // m_angularMass
+	if (j->motorMass > 0.0f) j->motorMass = 1.0f / j->motorMass;
+}
+
+B2D_HD void b2dJointWarmStartLinearAngular(JointRec* j, V2 rA, V2 rB, BodyVel* A, BodyVel* B, bool warmStarting, float dtRatio)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	if (warmStarting)
+	{
+		j->impulseX *= dtRatio;
+		j->impulseY *= dtRatio;
+		j->angularImpulse *= dtRatio;
+		V2 P = v2(j->impulseX, j->impulseY);
+		vA -= j->invMassA * P;
+		wA -= j->invIA * (b2dCross(rA, P) + j->angularImpulse);
+		vB += j->invMassB * P;
+		wB += j->invIB * (b2dCross(rB, P) + j->angularImpulse);
+	}
+	else
+	{
+		j->impulseX = j->impulseY = 0.0f;
+		j->angularImpulse = 0.0f;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// angular row then linear rows, each clamped to dt * max (b2FrictionJoint.cpp:124-171, b2MotorJoint.cpp:136-189);
+// angBias / linBias are zero for the friction joint
+B2D_HD void b2dJointSolveLinearAngular(JointRec* j, BodyVel* A, BodyVel* B, float dt, float angBias, V2 linBias, bool biased)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	const V2 rA = j->rA, rB = j->rB;
+	{
+		float Cdot = wB - wA;
+		if (biased) Cdot = Cdot + angBias;
+		float impulse = -j->motorMass * Cdot;
+		float oldImpulse = j->angularImpulse;
+		float maxImpulse = dt * j->maxTorque;
+		j->angularImpulse = b2dClamp(j->angularImpulse + impulse, -maxImpulse, maxImpulse);
+		impulse = j->angularImpulse - oldImpulse;
+		wA -= iA * impulse;
+		wB += iB * impulse;
+	}
+	{
+		V2 Cdot = vB + b2dCrossSV(wB, rB) - vA - b2dCrossSV(wA, rA);
+		if (biased) Cdot = Cdot + linBias;
+		V2 impulse = -v2(j->m_exx * Cdot.x + j->m_eyx * Cdot.y, j->m_exy * Cdot.x + j->m_eyy * Cdot.y);
+		V2 oldImpulse = v2(j->impulseX, j->impulseY);
+		V2 acc = oldImpulse + impulse;
+		float maxImpulse = dt * j->maxForce;
+		if (acc.x * acc.x + acc.y * acc.y > maxImpulse * maxImpulse)
+		{
+			b2dNormalize(acc);
+			acc *= maxImpulse;
+		}
+		j->impulseX = acc.x;
+		j->impulseY = acc.y;
+		impulse = acc - oldImpulse;
+		vA -= mA * impulse;
+		wA -= iA * b2dCross(rA, impulse);
+		vB += mB * impulse;
+		wB += iB * b2dCross(rB, impulse);
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// b2FrictionJoint::InitVelocityConstraints (b2FrictionJoint.cpp:58-122)
+B2D_HD void b2dFrictionInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio)
+{
+	b2dJointStoreBodies(j, invMassA, invIA, lcA, invMassB, invIB, lcB);
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	j->rA = b2dMulRV(qA, j->localAnchorA - lcA);
+	j->rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	b2dJointLinearMass(j, j->rA, j->rB, invMassA, invMassB, invIA, invIB);
+	b2dJointWarmStartLinearAngular(j, j->rA, j->rB, A, B, warmStarting, dtRatio);
+}
+
+// b2MotorJoint::InitVelocityConstraints (b2MotorJoint.cpp:62-134)
+B2D_HD void b2dMotorInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio)
+{
+	b2dJointStoreBodies(j, invMassA, invIA, lcA, invMassB, invIB, lcB);
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	j->rA = b2dMulRV(qA, j->linearOffset - lcA);
+	j->rB = b2dMulRV(qB, -lcB);
+	b2dJointLinearMass(j, j->rA, j->rB, invMassA, invMassB, invIA, invIB);
+	V2 linearError = pB.c + j->rB - pA.c - j->rA;
+	j->linErrX = linearError.x;
+	j->linErrY = linearError.y;
+	j->angErr = pB.a - pA.a - j->angularOffset;
+	b2dJointWarmStartLinearAngular(j, j->rA, j->rB, A, B, warmStarting, dtRatio);
+}
+
 // ---- dispatch on the joint type (b2Joint's virtual calls, b2Island.cpp:235-318) -------------------------
 B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
 	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
@@ -998,11 +1384,19 @@ B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float
 		b2dPrismaticInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
 	else if (j->type == B2D_JOINT_WELD)
 		b2dWeldInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio, dt);
+	else if (j->type == B2D_JOINT_WHEEL)
+		b2dWheelInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio, dt);
+	else if (j->type == B2D_JOINT_ROPE)
+		b2dRopeInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
+	else if (j->type == B2D_JOINT_FRICTION)
+		b2dFrictionInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
+	else if (j->type == B2D_JOINT_MOTOR)
+		b2dMotorInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
 	else
 		b2dRevoluteInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA.a, A, pB.a, B, warmStarting, dtRatio);
 }
 
-B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt)
+B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt, float inv_dt)
 {
 	if (j->type == B2D_JOINT_DISTANCE)
 		b2dDistanceSolveVelocity(j, A, B);
@@ -1010,6 +1404,15 @@ B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt)
 		b2dPrismaticSolveVelocity(j, A, B, dt);
 	else if (j->type == B2D_JOINT_WELD)
 		b2dWeldSolveVelocity(j, A, B);
+	else if (j->type == B2D_JOINT_WHEEL)
+		b2dWheelSolveVelocity(j, A, B, dt);
+	else if (j->type == B2D_JOINT_ROPE)
+		b2dRopeSolveVelocity(j, A, B, inv_dt);
+	else if (j->type == B2D_JOINT_FRICTION)
+		b2dJointSolveLinearAngular(j, A, B, dt, 0.0f, v2(0.0f, 0.0f), false);
+	else if (j->type == B2D_JOINT_MOTOR)
+		b2dJointSolveLinearAngular(j, A, B, dt, inv_dt * j->correctionFactor * j->angErr,
+			(inv_dt * j->correctionFactor) * v2(j->linErrX, j->linErrY), true);
 	else
 		b2dRevoluteSolveVelocity(j, A, B, dt);
 }
@@ -1019,6 +1422,9 @@ B2D_HD bool b2dJointSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 	if (j->type == B2D_JOINT_DISTANCE) return b2dDistanceSolvePosition(j, A, B);
 	if (j->type == B2D_JOINT_PRISMATIC) return b2dPrismaticSolvePosition(j, A, B);
 	if (j->type == B2D_JOINT_WELD) return b2dWeldSolvePosition(j, A, B);
+	if (j->type == B2D_JOINT_WHEEL) return b2dWheelSolvePosition(j, A, B);
+	if (j->type == B2D_JOINT_ROPE) return b2dRopeSolvePosition(j, A, B);
+	if (j->type == B2D_JOINT_FRICTION || j->type == B2D_JOINT_MOTOR) return true;
 	return b2dRevoluteSolvePosition(j, A, B);
 }
 

@@ -744,7 +744,7 @@ __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mo
 				}
 				else
 				{
-					b2dJointSolveVelocity(j, &vA, &vB, sp.dt);
+					b2dJointSolveVelocity(j, &vA, &vB, sp.dt, sp.inv_dt);
 				}
 				if (nsA) W.b_vel[bA] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
 				if (nsB) W.b_vel[bB] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);

@@ -168,7 +168,7 @@ struct b2hip_world
 	DevArray<RevoluteJoint> d_joints;
 	DevArray<int> jadjStart, jadj, rootJointStart, rootJointCursor, lj_list, rootJointOkay;
 	std::vector<std::pair<int, int> > pendingFilter; // body pairs whose contacts must be re-filtered (new joint)
-	std::vector<std::pair<int, int> > jointEdits;    // (joint, 1 = also clear the limit impulse): definition members changed by a setter
+	std::vector<std::pair<int, int> > jointEdits;    // (joint, 1 = also clear the limit impulse, 2 = also the anchors / offsets): members changed by a setter
 	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
 	DevArray<int4> rootScanIn, rootScanOut;
 	DevArray<int> si_root, si_bodyStart, si_contactStart, si_wStart, si_maxLevel, si_bodies, si_contacts, si_level,
@@ -729,7 +729,12 @@ static int flushEdits(b2hip_world* w)
 		const int id = w->jointEdits[k].first;
 		const size_t off = offsetof(JointRec, enableLimit), len = offsetof(JointRec, collideConnected) - off;
 		HIP_TRY(hipMemcpyAsync((char*)(w->d_joints.p + id) + off, (const char*)&w->joints[id] + off, len, hipMemcpyHostToDevice, s));
-		if (w->jointEdits[k].second)
+		if (w->jointEdits[k].second == 2)
+		{
+			const size_t o2 = offsetof(JointRec, localAnchorA), l2 = offsetof(JointRec, enableLimit) - o2;
+			HIP_TRY(hipMemcpyAsync((char*)(w->d_joints.p + id) + o2, (const char*)&w->joints[id] + o2, l2, hipMemcpyHostToDevice, s));
+		}
+		if (w->jointEdits[k].second == 1)
 		{
 			static const float zero = 0.0f;
 			HIP_TRY(hipMemcpyAsync((char*)(w->d_joints.p + id) + offsetof(JointRec, impulseZ), &zero, sizeof(float), hipMemcpyHostToDevice, s));
@@ -1856,6 +1861,86 @@ int b2hip_create_weld_joint(b2hip_world* w, const b2hip_weld_joint_def* def)
 	return addJoint(w, j);
 }
 
+static int checkJointBodies(b2hip_world* w, int a, int b)
+{
+	const int nb = w ? (int)w->bodies.size() : 0;
+	if (!w) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (a < 0 || a >= nb || b < 0 || b >= nb) return setError(B2HIP_ERR_INVALID, "bad body id");
+	return 0;
+}
+
+int b2hip_create_wheel_joint(b2hip_world* w, const b2hip_wheel_joint_def* def)
+{
+	if (!def) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rc = checkJointBodies(w, def->body_a, def->body_b)) return rc;
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_WHEEL;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.localAxisA = v2(def->local_axis_a[0], def->local_axis_a[1]);
+	j.frequencyHz = def->frequency_hz;
+	j.dampingRatio = def->damping_ratio;
+	j.enableMotor = def->enable_motor;
+	j.motorSpeed = def->motor_speed;
+	j.maxMotorTorque = def->max_motor_torque;
+	j.collideConnected = def->collide_connected;
+	return addJoint(w, j);
+}
+
+int b2hip_create_rope_joint(b2hip_world* w, const b2hip_rope_joint_def* def)
+{
+	if (!def) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rc = checkJointBodies(w, def->body_a, def->body_b)) return rc;
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_ROPE;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.maxLength = def->max_length;
+	j.collideConnected = def->collide_connected;
+	return addJoint(w, j);
+}
+
+int b2hip_create_friction_joint(b2hip_world* w, const b2hip_friction_joint_def* def)
+{
+	if (!def) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rc = checkJointBodies(w, def->body_a, def->body_b)) return rc;
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_FRICTION;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.maxForce = def->max_force;
+	j.maxTorque = def->max_torque;
+	j.collideConnected = def->collide_connected;
+	return addJoint(w, j);
+}
+
+int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def)
+{
+	if (!def) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rc = checkJointBodies(w, def->body_a, def->body_b)) return rc;
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_MOTOR;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.linearOffset = v2(def->linear_offset[0], def->linear_offset[1]);
+	j.angularOffset = def->angular_offset;
+	j.maxForce = def->max_force;
+	j.maxTorque = def->max_torque;
+	j.correctionFactor = def->correction_factor;
+	j.collideConnected = def->collide_connected;
+	return addJoint(w, j);
+}
+
 // b2Body::SetAwake(true) on both bodies of a joint whose definition changed (b2RevoluteJoint.cpp:418-500)
 static void wakeJointBodies(b2hip_world* w, const JointRec& j)
 {
@@ -1877,13 +1962,27 @@ int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float mot
 {
 	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
 	JointRec& j = w->joints[joint];
-	if (j.type != B2D_JOINT_REVOLUTE && j.type != B2D_JOINT_PRISMATIC) return setError(B2HIP_ERR_INVALID, "joint type has no motor");
+	if (j.type != B2D_JOINT_REVOLUTE && j.type != B2D_JOINT_PRISMATIC && j.type != B2D_JOINT_WHEEL)
+		return setError(B2HIP_ERR_INVALID, "joint type has no motor");
 	if ((enable_motor != 0) == (j.enableMotor != 0) && motor_speed == j.motorSpeed && max_motor == j.maxMotorTorque) return 0;
 	wakeJointBodies(w, j);
 	j.enableMotor = enable_motor != 0;
 	j.motorSpeed = motor_speed;
 	j.maxMotorTorque = max_motor;
 	w->jointEdits.push_back(std::make_pair(joint, 0));
+	return 0;
+}
+
+int b2hip_joint_set_offsets(b2hip_world* w, int joint, float linear_x, float linear_y, float angular)
+{
+	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	JointRec& j = w->joints[joint];
+	if (j.type != B2D_JOINT_MOTOR) return setError(B2HIP_ERR_INVALID, "not a motor joint");
+	if (linear_x == j.linearOffset.x && linear_y == j.linearOffset.y && angular == j.angularOffset) return 0;
+	wakeJointBodies(w, j);
+	j.linearOffset = v2(linear_x, linear_y);
+	j.angularOffset = angular;
+	w->jointEdits.push_back(std::make_pair(joint, 2)); // rewrite the anchor / offset members
 	return 0;
 }
 

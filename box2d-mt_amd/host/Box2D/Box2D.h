@@ -25,6 +25,10 @@
 #include "Box2D/Dynamics/Joints/b2DistanceJoint.h"
 #include "Box2D/Dynamics/Joints/b2PrismaticJoint.h"
 #include "Box2D/Dynamics/Joints/b2WeldJoint.h"
+#include "Box2D/Dynamics/Joints/b2WheelJoint.h"
+#include "Box2D/Dynamics/Joints/b2RopeJoint.h"
+#include "Box2D/Dynamics/Joints/b2FrictionJoint.h"
+#include "Box2D/Dynamics/Joints/b2MotorJoint.h"
 
 #include "Box2D/MT/b2Task.h"
 #include "Box2D/MT/b2TaskExecutor.h"

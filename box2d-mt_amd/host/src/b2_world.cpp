@@ -239,6 +239,74 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 		id = b2hip_create_weld_joint(m_hip, &d);
 		if (id >= 0) j = new (b2Alloc(sizeof(b2WeldJoint))) b2WeldJoint(wd);
 	}
+	else if (def->type == e_wheelJoint)
+	{
+		const b2WheelJointDef* wd = static_cast<const b2WheelJointDef*>(def);
+		b2hip_wheel_joint_def d;
+		d.body_a = wd->bodyA->GetDeviceId();
+		d.body_b = wd->bodyB->GetDeviceId();
+		d.local_anchor_a[0] = wd->localAnchorA.x;
+		d.local_anchor_a[1] = wd->localAnchorA.y;
+		d.local_anchor_b[0] = wd->localAnchorB.x;
+		d.local_anchor_b[1] = wd->localAnchorB.y;
+		d.local_axis_a[0] = wd->localAxisA.x;
+		d.local_axis_a[1] = wd->localAxisA.y;
+		d.frequency_hz = wd->frequencyHz;
+		d.damping_ratio = wd->dampingRatio;
+		d.enable_motor = wd->enableMotor;
+		d.motor_speed = wd->motorSpeed;
+		d.max_motor_torque = wd->maxMotorTorque;
+		d.collide_connected = wd->collideConnected;
+		id = b2hip_create_wheel_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2WheelJoint))) b2WheelJoint(wd);
+	}
+	else if (def->type == e_ropeJoint)
+	{
+		const b2RopeJointDef* rd = static_cast<const b2RopeJointDef*>(def);
+		b2hip_rope_joint_def d;
+		d.body_a = rd->bodyA->GetDeviceId();
+		d.body_b = rd->bodyB->GetDeviceId();
+		d.local_anchor_a[0] = rd->localAnchorA.x;
+		d.local_anchor_a[1] = rd->localAnchorA.y;
+		d.local_anchor_b[0] = rd->localAnchorB.x;
+		d.local_anchor_b[1] = rd->localAnchorB.y;
+		d.max_length = rd->maxLength;
+		d.collide_connected = rd->collideConnected;
+		id = b2hip_create_rope_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2RopeJoint))) b2RopeJoint(rd);
+	}
+	else if (def->type == e_frictionJoint)
+	{
+		const b2FrictionJointDef* fd = static_cast<const b2FrictionJointDef*>(def);
+		b2hip_friction_joint_def d;
+		d.body_a = fd->bodyA->GetDeviceId();
+		d.body_b = fd->bodyB->GetDeviceId();
+		d.local_anchor_a[0] = fd->localAnchorA.x;
+		d.local_anchor_a[1] = fd->localAnchorA.y;
+		d.local_anchor_b[0] = fd->localAnchorB.x;
+		d.local_anchor_b[1] = fd->localAnchorB.y;
+		d.max_force = fd->maxForce;
+		d.max_torque = fd->maxTorque;
+		d.collide_connected = fd->collideConnected;
+		id = b2hip_create_friction_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2FrictionJoint))) b2FrictionJoint(fd);
+	}
+	else if (def->type == e_motorJoint)
+	{
+		const b2MotorJointDef* md = static_cast<const b2MotorJointDef*>(def);
+		b2hip_motor_joint_def d;
+		d.body_a = md->bodyA->GetDeviceId();
+		d.body_b = md->bodyB->GetDeviceId();
+		d.linear_offset[0] = md->linearOffset.x;
+		d.linear_offset[1] = md->linearOffset.y;
+		d.angular_offset = md->angularOffset;
+		d.max_force = md->maxForce;
+		d.max_torque = md->maxTorque;
+		d.correction_factor = md->correctionFactor;
+		d.collide_connected = md->collideConnected;
+		id = b2hip_create_motor_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2MotorJoint))) b2MotorJoint(md);
+	}
 	else
 	{
 		fprintf(stderr, "b2World::CreateJoint: joint type %d is not on the device path yet\n", (int)def->type);
@@ -823,6 +891,51 @@ float32 b2PrismaticJoint::GetJointSpeed() const
 	b2Vec2 vA = m_bodyA->GetLinearVelocity(), vB = m_bodyB->GetLinearVelocity();
 	float32 wA = m_bodyA->GetAngularVelocity(), wB = m_bodyB->GetAngularVelocity();
 	return b2Dot(d, b2Cross(wA, axis)) + b2Dot(axis, vB + b2Cross(wB, rB) - vA - b2Cross(wA, rA));
+}
+
+void b2WheelJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor, const b2Vec2& axis)
+{
+	bodyA = bA;
+	bodyB = bB;
+	localAnchorA = bodyA->GetLocalPoint(anchor);
+	localAnchorB = bodyB->GetLocalPoint(anchor);
+	localAxisA = bodyA->GetLocalVector(axis);
+}
+
+void b2WheelJoint::PushMotor()
+{
+	b2hip_joint_set_motor(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_enableMotor, m_motorSpeed, m_maxMotorTorque);
+}
+void b2WheelJoint::EnableMotor(bool flag) { m_enableMotor = flag; PushMotor(); }
+void b2WheelJoint::SetMotorSpeed(float32 speed) { m_motorSpeed = speed; PushMotor(); }
+void b2WheelJoint::SetMaxMotorTorque(float32 torque) { m_maxMotorTorque = torque; PushMotor(); }
+
+void b2FrictionJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor)
+{
+	bodyA = bA;
+	bodyB = bB;
+	localAnchorA = bodyA->GetLocalPoint(anchor);
+	localAnchorB = bodyB->GetLocalPoint(anchor);
+}
+
+void b2MotorJointDef::Initialize(b2Body* bA, b2Body* bB)
+{
+	bodyA = bA;
+	bodyB = bB;
+	linearOffset = bodyA->GetLocalPoint(bodyB->GetPosition());
+	angularOffset = bodyB->GetAngle() - bodyA->GetAngle();
+}
+
+void b2MotorJoint::SetLinearOffset(const b2Vec2& linearOffset)
+{
+	m_linearOffset = linearOffset;
+	b2hip_joint_set_offsets(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_linearOffset.x, m_linearOffset.y, m_angularOffset);
+}
+
+void b2MotorJoint::SetAngularOffset(float32 angularOffset)
+{
+	m_angularOffset = angularOffset;
+	b2hip_joint_set_offsets(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_linearOffset.x, m_linearOffset.y, m_angularOffset);
 }
 
 // ---- callbacks / collision helpers ----------------------------------------------------------------

@@ -68,6 +68,30 @@ class WeldJointDef(C.Structure):
                 ("damping_ratio", C.c_float), ("collide_connected", C.c_int)]
 
 
+class WheelJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("local_anchor_a", C.c_float * 2),
+                ("local_anchor_b", C.c_float * 2), ("local_axis_a", C.c_float * 2), ("frequency_hz", C.c_float),
+                ("damping_ratio", C.c_float), ("enable_motor", C.c_int), ("motor_speed", C.c_float),
+                ("max_motor_torque", C.c_float), ("collide_connected", C.c_int)]
+
+
+class RopeJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("local_anchor_a", C.c_float * 2),
+                ("local_anchor_b", C.c_float * 2), ("max_length", C.c_float), ("collide_connected", C.c_int)]
+
+
+class FrictionJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("local_anchor_a", C.c_float * 2),
+                ("local_anchor_b", C.c_float * 2), ("max_force", C.c_float), ("max_torque", C.c_float),
+                ("collide_connected", C.c_int)]
+
+
+class MotorJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("linear_offset", C.c_float * 2), ("angular_offset", C.c_float),
+                ("max_force", C.c_float), ("max_torque", C.c_float), ("correction_factor", C.c_float),
+                ("collide_connected", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
@@ -104,6 +128,11 @@ def _configure(L, optional_ok=False):
         "b2hip_create_distance_joint": [C.c_void_p, C.POINTER(DistanceJointDef)],
         "b2hip_create_prismatic_joint": [C.c_void_p, C.POINTER(PrismaticJointDef)],
         "b2hip_create_weld_joint": [C.c_void_p, C.POINTER(WeldJointDef)],
+        "b2hip_create_wheel_joint": [C.c_void_p, C.POINTER(WheelJointDef)],
+        "b2hip_create_rope_joint": [C.c_void_p, C.POINTER(RopeJointDef)],
+        "b2hip_create_friction_joint": [C.c_void_p, C.POINTER(FrictionJointDef)],
+        "b2hip_create_motor_joint": [C.c_void_p, C.POINTER(MotorJointDef)],
+        "b2hip_joint_set_offsets": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
         "b2hip_joint_set_motor": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
         "b2hip_joint_set_limits": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
         "b2hip_body_count": [C.c_void_p],
@@ -282,6 +311,45 @@ class World:
         d.collide_connected = int(collide_connected)
         return _check(self.L.b2hip_create_weld_joint(self.p, C.byref(d)))
 
+    def _joint_def(self, cls, body_a, body_b, anchor_a, anchor_b, collide_connected):
+        d = cls()
+        d.body_a, d.body_b = body_a, body_b
+        if anchor_a is not None:
+            d.local_anchor_a[0], d.local_anchor_a[1] = anchor_a
+            d.local_anchor_b[0], d.local_anchor_b[1] = anchor_b
+        d.collide_connected = int(collide_connected)
+        return d
+
+    def create_wheel_joint(self, body_a, body_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), axis=(1.0, 0.0), frequency_hz=2.0,
+                           damping_ratio=0.7, enable_motor=False, motor_speed=0.0, max_motor_torque=0.0, collide_connected=False):
+        d = self._joint_def(WheelJointDef, body_a, body_b, anchor_a, anchor_b, collide_connected)
+        d.local_axis_a[0], d.local_axis_a[1] = axis
+        d.frequency_hz, d.damping_ratio = frequency_hz, damping_ratio
+        d.enable_motor, d.motor_speed, d.max_motor_torque = int(enable_motor), motor_speed, max_motor_torque
+        return _check(self.L.b2hip_create_wheel_joint(self.p, C.byref(d)))
+
+    def create_rope_joint(self, body_a, body_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), max_length=1.0, collide_connected=False):
+        d = self._joint_def(RopeJointDef, body_a, body_b, anchor_a, anchor_b, collide_connected)
+        d.max_length = max_length
+        return _check(self.L.b2hip_create_rope_joint(self.p, C.byref(d)))
+
+    def create_friction_joint(self, body_a, body_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), max_force=0.0, max_torque=0.0,
+                              collide_connected=False):
+        d = self._joint_def(FrictionJointDef, body_a, body_b, anchor_a, anchor_b, collide_connected)
+        d.max_force, d.max_torque = max_force, max_torque
+        return _check(self.L.b2hip_create_friction_joint(self.p, C.byref(d)))
+
+    def create_motor_joint(self, body_a, body_b, linear_offset=(0.0, 0.0), angular_offset=0.0, max_force=1.0, max_torque=1.0,
+                           correction_factor=0.3, collide_connected=False):
+        d = self._joint_def(MotorJointDef, body_a, body_b, None, None, collide_connected)
+        d.linear_offset[0], d.linear_offset[1] = linear_offset
+        d.angular_offset = angular_offset
+        d.max_force, d.max_torque, d.correction_factor = max_force, max_torque, correction_factor
+        return _check(self.L.b2hip_create_motor_joint(self.p, C.byref(d)))
+
+    def joint_set_offsets(self, joint, linear_offset, angular_offset):
+        _check(self.L.b2hip_joint_set_offsets(self.p, joint, linear_offset[0], linear_offset[1], angular_offset))
+
     def joint_set_motor(self, joint, enable_motor, motor_speed, max_motor):
         _check(self.L.b2hip_joint_set_motor(self.p, joint, int(enable_motor), motor_speed, max_motor))
 
@@ -290,6 +358,9 @@ class World:
 
     def apply_force(self, body, force=(0.0, 0.0), torque=0.0, wake=True):
         _check(self.L.b2hip_apply_force(self.p, body, force[0], force[1], torque, int(wake)))
+
+    def set_flags(self, allow_sleep=True, warm_starting=True, continuous=False, sub_stepping=False):
+        _check(self.L.b2hip_set_flags(self.p, int(allow_sleep), int(warm_starting), int(continuous), int(sub_stepping)))
 
     def set_velocity(self, body, velocity=(0.0, 0.0), omega=0.0):
         _check(self.L.b2hip_set_velocity(self.p, body, velocity[0], velocity[1], omega))

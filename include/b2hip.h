@@ -14,7 +14,12 @@
  *   b2hip_create_distance_joint      b2World::CreateJoint (distance)        b2World.cpp:672-760, Joints/b2DistanceJoint.cpp:51-63
  *   b2hip_create_prismatic_joint     b2World::CreateJoint (prismatic)       b2World.cpp:672-760, Joints/b2PrismaticJoint.cpp:98-128
  *   b2hip_create_weld_joint          b2World::CreateJoint (weld)            b2World.cpp:672-760, Joints/b2WeldJoint.cpp:46-56
- *   b2hip_joint_set_motor            b2{Revolute,Prismatic}Joint::EnableMotor / SetMotorSpeed / SetMaxMotor{Torque,Force}
+ *   b2hip_create_wheel_joint         b2World::CreateJoint (wheel)           Joints/b2WheelJoint.cpp:47-77
+ *   b2hip_create_rope_joint          b2World::CreateJoint (rope)            Joints/b2RopeJoint.cpp:34-46
+ *   b2hip_create_friction_joint      b2World::CreateJoint (friction)        Joints/b2FrictionJoint.cpp:45-56
+ *   b2hip_create_motor_joint         b2World::CreateJoint (motor)           Joints/b2MotorJoint.cpp:48-60
+ *   b2hip_joint_set_offsets          b2MotorJoint::SetLinearOffset / SetAngularOffset   Joints/b2MotorJoint.cpp:253-281
+ *   b2hip_joint_set_motor            b2{Revolute,Prismatic,Wheel}Joint::EnableMotor / SetMotorSpeed / SetMaxMotor{Torque,Force}
  *                                                                           Joints/b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616
  *   b2hip_joint_set_limits           b2{Revolute,Prismatic}Joint::EnableLimit / SetLimits
  *                                                                           Joints/b2RevoluteJoint.cpp:459-500, b2PrismaticJoint.cpp:549-581
@@ -158,6 +163,48 @@ typedef struct b2hip_weld_joint_def
 	int collide_connected;
 } b2hip_weld_joint_def;
 
+/* b2WheelJointDef (Joints/b2WheelJoint.h:31-76): point-on-line along local_axis_a (used as given), suspension spring
+ * along the axis (frequency_hz > 0) and a rotational motor */
+typedef struct b2hip_wheel_joint_def
+{
+	int body_a, body_b;
+	float local_anchor_a[2], local_anchor_b[2];
+	float local_axis_a[2];
+	float frequency_hz, damping_ratio;
+	int enable_motor;
+	float motor_speed, max_motor_torque;
+	int collide_connected;
+} b2hip_wheel_joint_def;
+
+/* b2RopeJointDef (Joints/b2RopeJoint.h:28-52): the anchors may not get further apart than max_length */
+typedef struct b2hip_rope_joint_def
+{
+	int body_a, body_b;
+	float local_anchor_a[2], local_anchor_b[2];
+	float max_length;
+	int collide_connected;
+} b2hip_rope_joint_def;
+
+/* b2FrictionJointDef (Joints/b2FrictionJoint.h:26-51): top-down friction, force and torque capped */
+typedef struct b2hip_friction_joint_def
+{
+	int body_a, body_b;
+	float local_anchor_a[2], local_anchor_b[2];
+	float max_force, max_torque;
+	int collide_connected;
+} b2hip_friction_joint_def;
+
+/* b2MotorJointDef (Joints/b2MotorJoint.h:26-57): drives bodyB to linear_offset / angular_offset in bodyA's frame */
+typedef struct b2hip_motor_joint_def
+{
+	int body_a, body_b;
+	float linear_offset[2];
+	float angular_offset;
+	float max_force, max_torque;
+	float correction_factor;
+	int collide_connected;
+} b2hip_motor_joint_def;
+
 /* Host-visible body state after a step (40 bytes per body, one coalesced device->host copy). */
 typedef struct b2hip_body_state
 {
@@ -228,7 +275,13 @@ int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* 
 int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* def);
 int b2hip_create_prismatic_joint(b2hip_world* w, const b2hip_prismatic_joint_def* def);
 int b2hip_create_weld_joint(b2hip_world* w, const b2hip_weld_joint_def* def);
-/* Revolute / prismatic joints between steps: EnableMotor + SetMotorSpeed + SetMaxMotorTorque|Force in one call, and
+int b2hip_create_wheel_joint(b2hip_world* w, const b2hip_wheel_joint_def* def);
+int b2hip_create_rope_joint(b2hip_world* w, const b2hip_rope_joint_def* def);
+int b2hip_create_friction_joint(b2hip_world* w, const b2hip_friction_joint_def* def);
+int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def);
+/* b2MotorJoint::SetLinearOffset + SetAngularOffset (b2MotorJoint.cpp:253-281): wakes both bodies when something changes */
+int b2hip_joint_set_offsets(b2hip_world* w, int joint, float linear_x, float linear_y, float angular);
+/* Revolute / prismatic / wheel (motor only) joints between steps: EnableMotor + SetMotorSpeed + SetMaxMotorTorque|Force in one call, and
  * EnableLimit + SetLimits in one call. Like the reference's setters, a call that changes something wakes both bodies and
  * (limits) restarts the limit impulse from zero; a call that changes nothing does nothing. */
 int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor);

@@ -83,6 +83,13 @@ int b2o_create_prismatic_joint(b2o_world* w, int bodyA, int bodyB, const float* 
 	int enableLimit, float lower, float upper, int enableMotor, float motorSpeed, float maxMotorForce, int collideConnected);
 int b2o_create_weld_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float referenceAngle,
 	float frequencyHz, float dampingRatio, int collideConnected);
+int b2o_create_wheel_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, const float* axis2, float frequencyHz,
+	float dampingRatio, int enableMotor, float motorSpeed, float maxMotorTorque, int collideConnected);
+int b2o_create_rope_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float maxLength, int collideConnected);
+int b2o_create_friction_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float maxForce, float maxTorque, int collideConnected);
+int b2o_create_motor_joint(b2o_world* w, int bodyA, int bodyB, const float* linearOffset2, float angularOffset, float maxForce,
+	float maxTorque, float correctionFactor, int collideConnected);
+void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float angular);
 void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor);
 void b2o_joint_set_limits(b2o_world* w, int joint, int enableLimit, float lower, float upper);
 void b2o_apply_force(b2o_world* w, int body, float fx, float fy, float torque, int wake);

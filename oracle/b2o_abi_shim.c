@@ -88,6 +88,37 @@ int b2hip_create_weld_joint(b2hip_world* w, const b2hip_weld_joint_def* def)
 		def->damping_ratio, def->collide_connected);
 }
 
+int b2hip_create_wheel_joint(b2hip_world* w, const b2hip_wheel_joint_def* def)
+{
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	return b2o_create_wheel_joint(w->o, def->body_a, def->body_b, anchors, def->local_axis_a, def->frequency_hz, def->damping_ratio,
+		def->enable_motor, def->motor_speed, def->max_motor_torque, def->collide_connected);
+}
+
+int b2hip_create_rope_joint(b2hip_world* w, const b2hip_rope_joint_def* def)
+{
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	return b2o_create_rope_joint(w->o, def->body_a, def->body_b, anchors, def->max_length, def->collide_connected);
+}
+
+int b2hip_create_friction_joint(b2hip_world* w, const b2hip_friction_joint_def* def)
+{
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	return b2o_create_friction_joint(w->o, def->body_a, def->body_b, anchors, def->max_force, def->max_torque, def->collide_connected);
+}
+
+int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def)
+{
+	return b2o_create_motor_joint(w->o, def->body_a, def->body_b, def->linear_offset, def->angular_offset, def->max_force,
+		def->max_torque, def->correction_factor, def->collide_connected);
+}
+
+int b2hip_joint_set_offsets(b2hip_world* w, int joint, float lx, float ly, float angular)
+{
+	b2o_joint_set_offsets(w->o, joint, lx, ly, angular);
+	return 0;
+}
+
 int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor)
 {
 	b2o_joint_set_motor(w->o, joint, enable_motor, motor_speed, max_motor);

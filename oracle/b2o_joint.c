@@ -1,7 +1,8 @@
 /* b2o_joint.c - CPU oracle, joints: plain-C restatement of b2RevoluteJoint
  * (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376; b2Mat33::Solve33/Solve22 b2Math.cpp:25-53) and of
  * b2DistanceJoint (Joints/b2DistanceJoint.cpp:65-225), b2PrismaticJoint (Joints/b2PrismaticJoint.cpp:130-478),
- * b2WeldJoint (Joints/b2WeldJoint.cpp:58-303); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
+ * b2WeldJoint (Joints/b2WeldJoint.cpp:58-303), b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
+ * (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint (Joints/b2MotorJoint.cpp:62-203); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
  * TEST INFRASTRUCTURE (see b2o.h). */
 #include "b2o_joint.h"
 
@@ -724,4 +725,337 @@ int b2o_weld_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float*
 		*aB += iB * (v_cross(rB, P) + impulse[2]);
 	}
 	return positionError <= B2O_LINEAR_SLOP && angularError <= B2O_ANGULAR_SLOP;
+}
+
+/* ---- wheel joint -------------------------------------------------------------------------------- */
+/* InitVelocityConstraints b2WheelJoint.cpp:79-198 */
+void b2o_wheel_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	vec2 d = v_sub(v_sub(v_add(cB, rB), cA), rA);
+	j->perp = r_mul(qA, j->localYAxisA);
+	j->a1 = v_cross(v_add(d, rA), j->perp);
+	j->a2 = v_cross(rB, j->perp);
+	j->mass = mA + mB + iA * j->a1 * j->a1 + iB * j->a2 * j->a2;
+	if (j->mass > 0.0f) j->mass = 1.0f / j->mass;
+	j->springMass = 0.0f;
+	j->bias = 0.0f;
+	j->gamma = 0.0f;
+	if (j->frequencyHz > 0.0f)
+	{
+		j->axis = r_mul(qA, j->localXAxisA);
+		j->s1 = v_cross(v_add(d, rA), j->axis);
+		j->s2 = v_cross(rB, j->axis);
+		float invMass = mA + mB + iA * j->s1 * j->s1 + iB * j->s2 * j->s2;
+		if (invMass > 0.0f)
+		{
+			j->springMass = 1.0f / invMass;
+			float C = v_dot(d, j->axis);
+			float omega = 2.0f * B2O_PI * j->frequencyHz;
+			float damp = 2.0f * j->springMass * j->dampingRatio * omega;
+			float k = j->springMass * omega * omega;
+			j->gamma = dt * (damp + dt * k);
+			if (j->gamma > 0.0f) j->gamma = 1.0f / j->gamma;
+			j->bias = C * dt * k * j->gamma;
+			j->springMass = invMass + j->gamma;
+			if (j->springMass > 0.0f) j->springMass = 1.0f / j->springMass;
+		}
+	}
+	else
+	{
+		j->springImpulse = 0.0f;
+	}
+	if (j->enableMotor)
+	{
+		j->motorMass = iA + iB;
+		if (j->motorMass > 0.0f) j->motorMass = 1.0f / j->motorMass;
+	}
+	else
+	{
+		j->motorMass = 0.0f;
+		j->motorImpulse = 0.0f;
+	}
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio;
+		j->springImpulse *= dtRatio;
+		j->motorImpulse *= dtRatio;
+		vec2 P = v_add(v_scale(j->impulse[0], j->perp), v_scale(j->springImpulse, j->axis));
+		float LA = j->impulse[0] * j->a1 + j->springImpulse * j->s1 + j->motorImpulse;
+		float LB = j->impulse[0] * j->a2 + j->springImpulse * j->s2 + j->motorImpulse;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * LA;
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * LB;
+	}
+	else
+	{
+		j->impulse[0] = 0.0f;
+		j->springImpulse = 0.0f;
+		j->motorImpulse = 0.0f;
+	}
+}
+
+/* SolveVelocityConstraints :200-257 */
+void b2o_wheel_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt)
+{
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	{
+		float Cdot = v_dot(j->axis, v_sub(*vB, *vA)) + j->s2 * *wB - j->s1 * *wA;
+		float impulse = -j->springMass * (Cdot + j->bias + j->gamma * j->springImpulse);
+		j->springImpulse += impulse;
+		vec2 P = v_scale(impulse, j->axis);
+		float LA = impulse * j->s1;
+		float LB = impulse * j->s2;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * LA;
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * LB;
+	}
+	{
+		float Cdot = *wB - *wA - j->motorSpeed;
+		float impulse = -j->motorMass * Cdot;
+		float oldImpulse = j->motorImpulse;
+		float maxImpulse = dt * j->maxMotorTorque;
+		j->motorImpulse = f_clamp(j->motorImpulse + impulse, -maxImpulse, maxImpulse);
+		impulse = j->motorImpulse - oldImpulse;
+		*wA -= iA * impulse;
+		*wB += iB * impulse;
+	}
+	{
+		float Cdot = v_dot(j->perp, v_sub(*vB, *vA)) + j->a2 * *wB - j->a1 * *wA;
+		float impulse = -j->mass * Cdot;
+		j->impulse[0] += impulse;
+		vec2 P = v_scale(impulse, j->perp);
+		float LA = impulse * j->a1;
+		float LB = impulse * j->a2;
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * LA;
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * LB;
+	}
+}
+
+/* SolvePositionConstraints :259-292 (k is built from the stored m_sAy / m_sBy, as there) */
+int b2o_wheel_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB)
+{
+	rot qA = r_make(*aA), qB = r_make(*aB);
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, j->localCenterA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, j->localCenterB));
+	vec2 d = v_sub(v_add(v_sub(*cB, *cA), rB), rA);
+	vec2 ay = r_mul(qA, j->localYAxisA);
+	float sAy = v_cross(v_add(d, rA), ay);
+	float sBy = v_cross(rB, ay);
+	float C = v_dot(d, ay);
+	float k = j->invMassA + j->invMassB + j->invIA * j->a1 * j->a1 + j->invIB * j->a2 * j->a2;
+	float impulse = k != 0.0f ? -C / k : 0.0f;
+	vec2 P = v_scale(impulse, ay);
+	float LA = impulse * sAy;
+	float LB = impulse * sBy;
+	*cA = v_sub(*cA, v_scale(j->invMassA, P));
+	*aA -= j->invIA * LA;
+	*cB = v_add(*cB, v_scale(j->invMassB, P));
+	*aB += j->invIB * LB;
+	return f_abs(C) <= B2O_LINEAR_SLOP;
+}
+
+/* ---- rope joint --------------------------------------------------------------------------------- */
+/* InitVelocityConstraints b2RopeJoint.cpp:48-115 */
+void b2o_rope_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	j->rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	j->rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	j->u = v_sub(v_sub(v_add(cB, j->rB), cA), j->rA);
+	j->curLength = v_length(j->u);
+	float C = j->curLength - j->length;
+	j->limitState = C > 0.0f ? 2 : 0;
+	if (j->curLength > B2O_LINEAR_SLOP)
+	{
+		j->u = v_scale(1.0f / j->curLength, j->u);
+	}
+	else
+	{
+		j->u = v_make(0.0f, 0.0f);
+		j->mass = 0.0f;
+		j->impulse[0] = 0.0f;
+		return;
+	}
+	float crA = v_cross(j->rA, j->u);
+	float crB = v_cross(j->rB, j->u);
+	float invMass = mA + iA * crA * crA + mB + iB * crB * crB;
+	j->mass = invMass != 0.0f ? 1.0f / invMass : 0.0f;
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio;
+		vec2 P = v_scale(j->impulse[0], j->u);
+		*vA = v_sub(*vA, v_scale(mA, P));
+		*wA -= iA * v_cross(j->rA, P);
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * v_cross(j->rB, P);
+	}
+	else
+	{
+		j->impulse[0] = 0.0f;
+	}
+}
+
+/* SolveVelocityConstraints :117-149 */
+void b2o_rope_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float inv_dt)
+{
+	vec2 vpA = v_add(*vA, v_cross_sv(*wA, j->rA));
+	vec2 vpB = v_add(*vB, v_cross_sv(*wB, j->rB));
+	float C = j->curLength - j->length;
+	float Cdot = v_dot(j->u, v_sub(vpB, vpA));
+	if (C < 0.0f) Cdot += inv_dt * C;
+	float impulse = -j->mass * Cdot;
+	float oldImpulse = j->impulse[0];
+	j->impulse[0] = f_min(0.0f, j->impulse[0] + impulse);
+	impulse = j->impulse[0] - oldImpulse;
+	vec2 P = v_scale(impulse, j->u);
+	*vA = v_sub(*vA, v_scale(j->invMassA, P));
+	*wA -= j->invIA * v_cross(j->rA, P);
+	*vB = v_add(*vB, v_scale(j->invMassB, P));
+	*wB += j->invIB * v_cross(j->rB, P);
+}
+
+/* SolvePositionConstraints :151-182 */
+int b2o_rope_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB)
+{
+	rot qA = r_make(*aA), qB = r_make(*aB);
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, j->localCenterA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, j->localCenterB));
+	vec2 u = v_sub(v_sub(v_add(*cB, rB), *cA), rA);
+	float length = v_normalize(&u);
+	float C = length - j->length;
+	C = f_clamp(C, 0.0f, B2O_MAX_LINEAR_CORRECTION);
+	float impulse = -j->mass * C;
+	vec2 P = v_scale(impulse, u);
+	*cA = v_sub(*cA, v_scale(j->invMassA, P));
+	*aA -= j->invIA * v_cross(rA, P);
+	*cB = v_add(*cB, v_scale(j->invMassB, P));
+	*aB += j->invIB * v_cross(rB, P);
+	return length - j->length < B2O_LINEAR_SLOP;
+}
+
+/* ---- friction / motor joints -------------------------------------------------------------------- */
+/* K and its inverse (b2FrictionJoint.cpp:86-100 = b2MotorJoint.cpp:90-104; b2Mat22::GetInverse b2Math.h:205-217) */
+static void linear_angular_mass(revolute_t* j)
+{
+	float mA = j->invMassA, mB = j->invMassB, iA = j->invIA, iB = j->invIB;
+	float kxx = mA + mB + iA * j->rA.y * j->rA.y + iB * j->rB.y * j->rB.y;
+	float kxy = -iA * j->rA.x * j->rA.y - iB * j->rB.x * j->rB.y;
+	float kyy = mA + mB + iA * j->rA.x * j->rA.x + iB * j->rB.x * j->rB.x;
+	float a = kxx, b = kxy, c = kxy, d = kyy;
+	float det = a * d - b * c;
+	if (det != 0.0f) det = 1.0f / det;
+	j->linearMass[0] = det * d; j->linearMass[2] = -det * b;
+	j->linearMass[1] = -det * c; j->linearMass[3] = det * a;
+	j->angularMass = iA + iB;
+	if (j->angularMass > 0.0f) j->angularMass = 1.0f / j->angularMass;
+}
+
+static void linear_angular_warm_start(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, int warmStarting, float dtRatio)
+{
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio; j->impulse[1] *= dtRatio;
+		j->impulse[2] *= dtRatio;
+		vec2 P = v_make(j->impulse[0], j->impulse[1]);
+		*vA = v_sub(*vA, v_scale(j->invMassA, P));
+		*wA -= j->invIA * (v_cross(j->rA, P) + j->impulse[2]);
+		*vB = v_add(*vB, v_scale(j->invMassB, P));
+		*wB += j->invIB * (v_cross(j->rB, P) + j->impulse[2]);
+	}
+	else
+	{
+		j->impulse[0] = j->impulse[1] = 0.0f;
+		j->impulse[2] = 0.0f;
+	}
+}
+
+/* the clamped linear rows shared by both (b2FrictionJoint.cpp:145-170, b2MotorJoint.cpp:163-188) */
+static void linear_rows(revolute_t* j, vec2 Cdot, vec2* vA, float* wA, vec2* vB, float* wB, float dt)
+{
+	vec2 impulse = v_neg(v_make(j->linearMass[0] * Cdot.x + j->linearMass[2] * Cdot.y, j->linearMass[1] * Cdot.x + j->linearMass[3] * Cdot.y));
+	vec2 oldImpulse = v_make(j->impulse[0], j->impulse[1]);
+	vec2 acc = v_add(oldImpulse, impulse);
+	float maxImpulse = dt * j->maxForce;
+	if (v_dot(acc, acc) > maxImpulse * maxImpulse)
+	{
+		v_normalize(&acc);
+		acc.x *= maxImpulse;
+		acc.y *= maxImpulse;
+	}
+	j->impulse[0] = acc.x;
+	j->impulse[1] = acc.y;
+	impulse = v_sub(acc, oldImpulse);
+	*vA = v_sub(*vA, v_scale(j->invMassA, impulse));
+	*wA -= j->invIA * v_cross(j->rA, impulse);
+	*vB = v_add(*vB, v_scale(j->invMassB, impulse));
+	*wB += j->invIB * v_cross(j->rB, impulse);
+}
+
+static void angular_row(revolute_t* j, float Cdot, float* wA, float* wB, float dt)
+{
+	float impulse = -j->angularMass * Cdot;
+	float oldImpulse = j->impulse[2];
+	float maxImpulse = dt * j->maxTorque;
+	j->impulse[2] = f_clamp(j->impulse[2] + impulse, -maxImpulse, maxImpulse);
+	impulse = j->impulse[2] - oldImpulse;
+	*wA -= j->invIA * impulse;
+	*wB += j->invIB * impulse;
+}
+
+/* b2FrictionJoint::InitVelocityConstraints b2FrictionJoint.cpp:58-122 */
+void b2o_friction_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	float aA, vec2* vA, float* wA, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	j->rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	j->rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	linear_angular_mass(j);
+	linear_angular_warm_start(j, vA, wA, vB, wB, warmStarting, dtRatio);
+}
+
+/* b2FrictionJoint::SolveVelocityConstraints :124-171 */
+void b2o_friction_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt)
+{
+	angular_row(j, *wB - *wA, wA, wB, dt);
+	vec2 Cdot = v_sub(v_sub(v_add(*vB, v_cross_sv(*wB, j->rB)), *vA), v_cross_sv(*wA, j->rA));
+	linear_rows(j, Cdot, vA, wA, vB, wB, dt);
+}
+
+/* b2MotorJoint::InitVelocityConstraints b2MotorJoint.cpp:62-134 */
+void b2o_motor_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	j->rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	j->rB = r_mul(qB, v_neg(lcB));
+	linear_angular_mass(j);
+	j->linearError = v_sub(v_sub(v_add(cB, j->rB), cA), j->rA);
+	j->angularError = aB - aA - j->referenceAngle;
+	linear_angular_warm_start(j, vA, wA, vB, wB, warmStarting, dtRatio);
+}
+
+/* b2MotorJoint::SolveVelocityConstraints :136-189 */
+void b2o_motor_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt, float inv_dt)
+{
+	angular_row(j, *wB - *wA + inv_dt * j->correctionFactor * j->angularError, wA, wB, dt);
+	vec2 Cdot = v_add(v_sub(v_sub(v_add(*vB, v_cross_sv(*wB, j->rB)), *vA), v_cross_sv(*wA, j->rA)),
+		v_scale(inv_dt * j->correctionFactor, j->linearError));
+	linear_rows(j, Cdot, vA, wA, vB, wB, dt);
 }

@@ -1,10 +1,11 @@
-/* b2o_joint.h - CPU oracle, joint state: revolute, distance, prismatic, weld (TEST INFRASTRUCTURE, see b2o.h). */
+/* b2o_joint.h - CPU oracle, joint state: revolute, distance, prismatic, weld, wheel, rope, friction, motor (TEST INFRASTRUCTURE, see b2o.h). */
 #ifndef B2O_JOINT_H
 #define B2O_JOINT_H
 
 #include "b2o_internal.h"
 
-enum { B2O_JOINT_REVOLUTE = 0, B2O_JOINT_DISTANCE = 1, B2O_JOINT_PRISMATIC = 2, B2O_JOINT_WELD = 3 };
+enum { B2O_JOINT_REVOLUTE = 0, B2O_JOINT_DISTANCE = 1, B2O_JOINT_PRISMATIC = 2, B2O_JOINT_WELD = 3,
+	B2O_JOINT_WHEEL = 4, B2O_JOINT_ROPE = 5, B2O_JOINT_FRICTION = 6, B2O_JOINT_MOTOR = 7 };
 
 typedef struct
 {
@@ -30,6 +31,17 @@ typedef struct
 	 * m_K in ex / ey / ez ; weld joint (b2WeldJoint.h:97-123): m_mass in ex / ey / ez, gamma / bias above */
 	vec2 localXAxisA, localYAxisA, axis, perp;
 	float s1, s2, a1, a2;
+	/* wheel joint (b2WheelJoint.h:170-211): m_ax / m_ay in axis / perp, m_sAx, m_sBx, m_sAy, m_sBy in s1, s2, a1, a2,
+	 * m_impulse = impulse[0], m_mass = mass, spring state below ; rope joint (b2RopeJoint.h:97-117): m_maxLength = length,
+	 * m_state = limitState ; friction / motor joints (b2FrictionJoint.h:93-117, b2MotorJoint.h:107-133): linear impulse
+	 * impulse[0..1], angular impulse impulse[2], linearOffset = localAnchorA, angularOffset = referenceAngle */
+	float springImpulse, springMass;
+	float curLength;
+	float maxForce, maxTorque, correctionFactor;
+	float linearMass[4]; /* ex.x, ex.y, ey.x, ey.y */
+	float angularMass;
+	vec2 linearError;
+	float angularError;
 	int islandFlag;
 	int nextA, nextB; /* per-body joint lists, newest first: edge id = joint * 2 + side */
 } revolute_t;
@@ -53,5 +65,23 @@ void b2o_weld_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float 
 	float aA, vec2* vA, float* wA, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt);
 void b2o_weld_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB);
 int b2o_weld_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+void b2o_wheel_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio, float dt);
+void b2o_wheel_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt);
+int b2o_wheel_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+void b2o_rope_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
+void b2o_rope_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float inv_dt);
+int b2o_rope_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+/* friction and motor joints have no position step (b2FrictionJoint.cpp:173-178, b2MotorJoint.cpp:191-196) */
+void b2o_friction_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	float aA, vec2* vA, float* wA, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
+void b2o_friction_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt);
+void b2o_motor_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
+void b2o_motor_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB, float dt, float inv_dt);
 
 #endif

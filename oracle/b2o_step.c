@@ -5,7 +5,7 @@
  * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
- * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld (b2o_joint.c). Not covered (same as the device
+ * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld, wheel, rope, friction, motor (b2o_joint.c). Not covered (same as the device
  * path): other joint types, chain shapes. Continuous collision: b2o_toi.c
  * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
@@ -457,7 +457,67 @@ int b2o_create_weld_joint(b2o_world* w, int bodyA, int bodyB, const float* ancho
 	return id;
 }
 
+/* b2WheelJoint::b2WheelJoint (b2WheelJoint.cpp:47-77): the axis is taken as given (not normalised) */
+int b2o_create_wheel_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, const float* axis2, float frequencyHz,
+	float dampingRatio, int enableMotor, float motorSpeed, float maxMotorTorque, int collideConnected)
+{
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors4, 0.0f, 0, 0.0f, 0.0f, enableMotor, motorSpeed, maxMotorTorque, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_WHEEL;
+	j->localXAxisA = v_make(axis2[0], axis2[1]);
+	j->localYAxisA = v_cross_sv(1.0f, j->localXAxisA);
+	j->frequencyHz = frequencyHz;
+	j->dampingRatio = dampingRatio;
+	return id;
+}
+
+/* b2RopeJoint::b2RopeJoint (b2RopeJoint.cpp:34-46) */
+int b2o_create_rope_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float maxLength, int collideConnected)
+{
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors4, 0.0f, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_ROPE;
+	j->length = maxLength;
+	return id;
+}
+
+/* b2FrictionJoint::b2FrictionJoint (b2FrictionJoint.cpp:45-56) */
+int b2o_create_friction_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float maxForce, float maxTorque, int collideConnected)
+{
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors4, 0.0f, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_FRICTION;
+	j->maxForce = maxForce;
+	j->maxTorque = maxTorque;
+	return id;
+}
+
+/* b2MotorJoint::b2MotorJoint (b2MotorJoint.cpp:48-60) */
+int b2o_create_motor_joint(b2o_world* w, int bodyA, int bodyB, const float* linearOffset2, float angularOffset, float maxForce,
+	float maxTorque, float correctionFactor, int collideConnected)
+{
+	float anchors[4] = { linearOffset2[0], linearOffset2[1], 0.0f, 0.0f };
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors, angularOffset, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_MOTOR;
+	j->maxForce = maxForce;
+	j->maxTorque = maxTorque;
+	j->correctionFactor = correctionFactor;
+	return id;
+}
+
 static void set_awake(body_t* b);
+
+/* b2MotorJoint::SetLinearOffset / SetAngularOffset (b2MotorJoint.cpp:253-281) */
+void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float angular)
+{
+	revolute_t* j = &w->joints[joint];
+	if (lx == j->localAnchorA.x && ly == j->localAnchorA.y && angular == j->referenceAngle) return;
+	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
+	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	j->localAnchorA = v_make(lx, ly);
+	j->referenceAngle = angular;
+}
 
 /* EnableMotor / SetMotorSpeed / SetMaxMotorTorque|Force (b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616) */
 void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor)
@@ -1263,6 +1323,22 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			b2o_weld_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
 				positions[ia].a, vA, wA, positions[ib].a, vB, wB, w->warmStarting, dtRatio, h);
 			break;
+		case B2O_JOINT_WHEEL:
+			b2o_wheel_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio, h);
+			break;
+		case B2O_JOINT_ROPE:
+			b2o_rope_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
+			break;
+		case B2O_JOINT_FRICTION:
+			b2o_friction_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].a, vA, wA, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
+			break;
+		case B2O_JOINT_MOTOR:
+			b2o_motor_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
+			break;
 		default:
 			b2o_revolute_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
 				positions[ia].a, vA, wA, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
@@ -1281,6 +1357,10 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			case B2O_JOINT_DISTANCE: b2o_distance_velocity(j, vA, wA, vB, wB); break;
 			case B2O_JOINT_PRISMATIC: b2o_prismatic_velocity(j, vA, wA, vB, wB, h); break;
 			case B2O_JOINT_WELD: b2o_weld_velocity(j, vA, wA, vB, wB); break;
+			case B2O_JOINT_WHEEL: b2o_wheel_velocity(j, vA, wA, vB, wB, h); break;
+			case B2O_JOINT_ROPE: b2o_rope_velocity(j, vA, wA, vB, wB, 1.0f / h); break;
+			case B2O_JOINT_FRICTION: b2o_friction_velocity(j, vA, wA, vB, wB, h); break;
+			case B2O_JOINT_MOTOR: b2o_motor_velocity(j, vA, wA, vB, wB, h, 1.0f / h); break;
 			default: b2o_revolute_velocity(j, vA, wA, vB, wB, h);
 			}
 		}
@@ -1335,6 +1415,9 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			case B2O_JOINT_DISTANCE: ok = b2o_distance_position(j, cA, aA, cB, aB); break;
 			case B2O_JOINT_PRISMATIC: ok = b2o_prismatic_position(j, cA, aA, cB, aB); break;
 			case B2O_JOINT_WELD: ok = b2o_weld_position(j, cA, aA, cB, aB); break;
+			case B2O_JOINT_WHEEL: ok = b2o_wheel_position(j, cA, aA, cB, aB); break;
+			case B2O_JOINT_ROPE: ok = b2o_rope_position(j, cA, aA, cB, aB); break;
+			case B2O_JOINT_FRICTION: case B2O_JOINT_MOTOR: ok = 1; break;
 			default: ok = b2o_revolute_position(j, cA, aA, cB, aB);
 			}
 			jointsOkay = jointsOkay && ok;

@@ -125,6 +125,18 @@ void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
 			const bool atLower = speed < 0.0f && at <= slider->GetLowerLimit() + b2_epsilon;
 			if (atUpper || atLower) slider->SetMotorSpeed(-slider->GetMotorSpeed());
 		}
+		if (!h->scene.servos.empty())
+		{
+			// motor-joint targets move on a figure of eight (the way the Testbed's MotorJoint scene drives its own: new offsets each step)
+			const float t = 0.05f * (float)h->scene.servoStep++;
+			for (size_t k = 0; k < h->scene.servos.size(); ++k)
+			{
+				b2MotorJoint* servo = static_cast<b2MotorJoint*>(h->scene.servos[k]);
+				b2Vec2 offset(40.0f + 6.0f * (float)k + 3.0f * sinf(2.0f * t), 8.0f + 2.0f * sinf(t));
+				servo->SetLinearOffset(offset);
+				servo->SetAngularOffset(0.3f * (float)(k + 1) * sinf(0.5f * t));
+			}
+		}
 		h->world->Step(dt, velIters, posIters, *h->executor);
 		const b2Profile& p = h->world->GetProfile();
 		const float v[13] = { p.step, p.collide, p.solve, p.solveTraversal, p.solveInit, p.solveVelocity,

@@ -75,6 +75,9 @@ enum SceneId
 	e_machines = 10,     // p0 = falling bodies, p1 = cantilever segments ; prismatic joints (motor slider between limits, a free
 	                     //   vertical slider resting on its lower limit, a locked one) and weld joints (rigid and soft cantilevers,
 	                     //   a welded free-falling pair), bodies dropped over all of them
+	e_vehicles = 11,     // p0 = falling bodies, p1 = cars ; wheel joints (cars with sprung, motor-driven wheels over bumps, one
+	                     //   with a rigid axle), rope joints (weights on slack and taut tethers), friction joints (pucks braked
+	                     //   against the ground) and motor joints (platforms servoed to a pose the step loop keeps moving)
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -91,10 +94,12 @@ struct Scene
 {
 	std::vector<b2Body*> bodies; // creation order == body index used by every dump
 	b2Joint* joint;
+	std::vector<b2Joint*> servos; // motor joints whose linear / angular offset the step loop moves along a fixed path
+	int servoStep;
 	bool sliderBounces; // joint is a prismatic motor slider whose motor is reversed by the step loop at either limit
 	float dtDefault;
 	int velIters, posIters;
-	Scene() : joint(NULL), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
+	Scene() : joint(NULL), servoStep(0), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
 };
 
 inline b2Body* AddBody(Scene& s, b2World* w, const b2BodyDef& bd)
@@ -767,6 +772,141 @@ inline void BuildMachines(Scene& s, b2World* w, int count, int segments, uint32_
 	}
 }
 
+// Wheel, rope, friction and motor joints sharing islands with contacts.
+inline void BuildVehicles(Scene& s, b2World* w, int count, int cars, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	Pcg32 rng(seed ? seed : 41u);
+	if (cars < 1) cars = 1;
+	b2Body* ground;
+	{
+		b2BodyDef bd;
+		ground = AddBody(s, w, bd);
+		b2EdgeShape edge;
+		edge.Set(b2Vec2(-60.0f, 0.0f), b2Vec2(60.0f, 0.0f));
+		ground->CreateFixture(&edge, 0.0f);
+		// bumps the cars drive over
+		for (int i = 0; i < 12; ++i)
+		{
+			b2PolygonShape bump;
+			bump.SetAsBox(0.6f, 0.15f, b2Vec2(-30.0f + 5.0f * (float)i, 0.15f), (i & 1) ? 0.2f : -0.15f);
+			ground->CreateFixture(&bump, 0.0f);
+		}
+	}
+	for (int c = 0; c < cars; ++c)
+	{
+		const float x = -40.0f + 9.0f * (float)c, y = 1.0f;
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(x, y);
+		b2Body* chassis = AddBody(s, w, bd);
+		b2PolygonShape hull;
+		b2Vec2 pts[6] = { b2Vec2(-1.5f, -0.5f), b2Vec2(1.5f, -0.5f), b2Vec2(1.5f, 0.0f), b2Vec2(0.0f, 0.9f), b2Vec2(-1.15f, 0.9f), b2Vec2(-1.5f, 0.2f) };
+		hull.Set(pts, 6);
+		chassis->CreateFixture(&hull, 1.0f);
+		b2CircleShape tyre;
+		tyre.m_radius = 0.4f;
+		b2FixtureDef fd;
+		fd.shape = &tyre;
+		fd.density = 1.0f;
+		fd.friction = 0.9f;
+		for (int k = 0; k < 2; ++k)
+		{
+			bd.position.Set(x + (k ? 1.0f : -1.0f), y - 0.65f);
+			b2Body* wheel = AddBody(s, w, bd);
+			wheel->CreateFixture(&fd);
+			b2WheelJointDef jd;
+			jd.Initialize(chassis, wheel, wheel->GetPosition(), b2Vec2(0.1f * (float)(c % 3), 1.0f));
+			jd.motorSpeed = k ? 0.0f : -12.0f - 2.0f * (float)c;
+			jd.maxMotorTorque = k ? 10.0f : 20.0f;
+			jd.enableMotor = (k == 0) || (c & 1);
+			jd.frequencyHz = (c % 4 == 3) ? 0.0f : 4.0f; // every fourth car: rigid axle (no spring row)
+			jd.dampingRatio = 0.7f;
+			w->CreateJoint(&jd);
+		}
+	}
+	// tethered weights: anchors on a static beam 12 up, ropes longer (slack) and shorter (taut from the start) than the drop
+	for (int i = 0; i < 6; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(20.0f + 2.0f * (float)i, 9.0f);
+		b2Body* weight = AddBody(s, w, bd);
+		b2PolygonShape box;
+		box.SetAsBox(0.4f, 0.4f);
+		weight->CreateFixture(&box, 2.0f + (float)i);
+		b2RopeJointDef jd;
+		jd.bodyA = ground;
+		jd.bodyB = weight;
+		jd.localAnchorA.Set(20.0f + 2.0f * (float)i + ((i & 1) ? 1.5f : 0.0f), 12.0f);
+		jd.localAnchorB.Set(0.0f, 0.4f);
+		jd.maxLength = (i < 2) ? 2.0f : 4.0f + 0.5f * (float)i;
+		jd.collideConnected = true;
+		w->CreateJoint(&jd);
+	}
+	// pucks thrown along the ground plane of a top-down table (no gravity on them), braked by friction joints
+	for (int i = 0; i < 5; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.gravityScale = 0.0f;
+		bd.position.Set(-50.0f + 3.0f * (float)i, 20.0f + 1.5f * (float)i);
+		bd.linearVelocity.Set(6.0f + (float)i, 1.0f - 0.5f * (float)i);
+		bd.angularVelocity = 3.0f - (float)i;
+		b2Body* puck = AddBody(s, w, bd);
+		b2PolygonShape box;
+		box.SetAsBox(0.5f, 0.3f);
+		puck->CreateFixture(&box, 1.0f);
+		b2FrictionJointDef jd;
+		jd.Initialize(ground, puck, puck->GetPosition());
+		jd.maxForce = 1.0f + 2.0f * (float)i;
+		jd.maxTorque = 0.2f * (float)(i + 1);
+		jd.collideConnected = true;
+		w->CreateJoint(&jd);
+	}
+	// servo platforms: motor joints towards a pose that the step loop moves on a figure of eight
+	for (int i = 0; i < 3; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(40.0f + 6.0f * (float)i, 8.0f);
+		b2Body* plat = AddBody(s, w, bd);
+		b2PolygonShape box;
+		box.SetAsBox(2.0f, 0.25f);
+		b2FixtureDef fd;
+		fd.shape = &box;
+		fd.friction = 0.6f;
+		fd.density = 2.0f;
+		plat->CreateFixture(&fd);
+		b2MotorJointDef jd;
+		jd.Initialize(ground, plat);
+		jd.maxForce = 1000.0f;
+		jd.maxTorque = 1000.0f;
+		jd.correctionFactor = 0.3f + 0.2f * (float)i;
+		s.servos.push_back(w->CreateJoint(&jd));
+	}
+	for (int i = 0; i < count; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(rng.Range(-45.0f, 56.0f), rng.Range(14.0f, 34.0f));
+		bd.angle = rng.Range(-1.0f, 1.0f);
+		b2Body* body = AddBody(s, w, bd);
+		if (i % 3 == 0)
+		{
+			b2CircleShape c;
+			c.m_radius = rng.Range(0.15f, 0.4f);
+			body->CreateFixture(&c, 1.0f);
+		}
+		else
+		{
+			b2PolygonShape b;
+			b.SetAsBox(rng.Range(0.15f, 0.45f), rng.Range(0.15f, 0.45f));
+			body->CreateFixture(&b, 1.0f);
+		}
+	}
+}
+
 inline void BuildBullets(Scene& s, b2World* w, int projectiles, int stackHeight, uint32_t seed)
 {
 	w->SetGravity(b2Vec2(0.0f, -10.0f));
@@ -849,6 +989,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_sensors: BuildSensors(s, w, p.p0, p.seed); break;
 	case e_ropes: BuildRopes(s, w, p.p0, p.p1, p.seed); break;
 	case e_machines: BuildMachines(s, w, p.p0, p.p1, p.seed); break;
+	case e_vehicles: BuildVehicles(s, w, p.p0, p.p1, p.seed); break;
 	default: break;
 	}
 }

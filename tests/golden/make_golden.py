@@ -37,6 +37,7 @@ SCENES = [
     ("sensors", bh.SENSORS, 40, 0, 0.0, 0.0, 5, 240),
     ("ropes", bh.ROPES, 80, 14, 0.0, 0.0, 9, 240),
     ("machines", bh.MACHINES, 120, 6, 0.0, 0.0, 3, 300),
+    ("vehicles", bh.VEHICLES, 150, 5, 0.0, 0.0, 3, 300),
     ("pyramid141", bh.PYRAMID, 141, 1, 0.0, 0.0, 1, 30),
 ]
 

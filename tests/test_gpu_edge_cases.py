@@ -262,6 +262,56 @@ def test_prismatic_and_weld_joints(libs, monkeypatch):
     a.close(); b.close()
 
 
+def test_wheel_rope_friction_motor_joints(libs, monkeypatch):
+    """The four remaining simple joint types through the plain C ABI: a cart on sprung / rigid wheel joints whose motor is
+    reversed mid-run, a rope that goes taut, a friction joint between two dynamic bodies, a motor joint whose target offsets
+    are moved between steps and one between two dynamic bodies. Warm starting off for the second half (set_flags)."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs)
+    ids = {}
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+        w.create_fixture(g, b2hip.box_shape(60.0, 0.5))
+        cart = w.create_body(b2hip.DYNAMIC, (0.0, 1.6))
+        w.create_fixture(cart, b2hip.box_shape(1.5, 0.3), density=1.0)
+        for k, x in enumerate((-1.0, 1.0)):
+            wh = w.create_body(b2hip.DYNAMIC, (x, 0.95))
+            w.create_fixture(wh, b2hip.circle_shape(0.45), density=1.0, friction=0.9)
+            ids["wheel%d" % k] = w.create_wheel_joint(cart, wh, anchor_a=(x, -0.65), anchor_b=(0.0, 0.0), axis=(0.0, 1.0),
+                                                      frequency_hz=4.0 if k == 0 else 0.0, damping_ratio=0.7, enable_motor=(k == 0),
+                                                      motor_speed=-8.0, max_motor_torque=15.0)
+        bob = w.create_body(b2hip.DYNAMIC, (10.0, 8.0))
+        w.create_fixture(bob, b2hip.circle_shape(0.3), density=2.0)
+        w.create_rope_joint(g, bob, anchor_a=(10.0, 10.0), anchor_b=(0.0, 0.3), max_length=4.0)
+        w.set_velocity(bob, (5.0, 0.0), 0.0)
+        sled = w.create_body(b2hip.DYNAMIC, (-10.0, 1.0))
+        w.create_fixture(sled, b2hip.box_shape(2.0, 0.5), density=1.0, friction=0.0)
+        rider = w.create_body(b2hip.DYNAMIC, (-10.0, 1.9))
+        w.create_fixture(rider, b2hip.box_shape(0.5, 0.4), density=1.0, friction=0.0)
+        w.create_friction_joint(sled, rider, anchor_a=(0.0, 0.9), anchor_b=(0.0, 0.0), max_force=3.0, max_torque=1.0, collide_connected=True)
+        w.set_velocity(rider, (4.0, 0.0), 0.0)
+        plat = w.create_body(b2hip.DYNAMIC, (20.0, 5.0))
+        w.create_fixture(plat, b2hip.box_shape(1.5, 0.2), density=1.0)
+        ids["servo"] = w.create_motor_joint(g, plat, linear_offset=(20.0, 5.0), max_force=500.0, max_torque=200.0)
+        tail = w.create_body(b2hip.DYNAMIC, (23.0, 5.0))
+        w.create_fixture(tail, b2hip.box_shape(0.5, 0.2), density=0.5)
+        w.create_motor_joint(plat, tail, linear_offset=(3.0, 0.5), angular_offset=0.5, max_force=50.0, max_torque=20.0, correction_factor=0.8)
+        for i in range(12):
+            d = w.create_body(b2hip.DYNAMIC, (18.0 + 0.4 * i, 8.0 + 0.6 * (i % 4)))
+            w.create_fixture(d, b2hip.box_shape(0.2, 0.2) if i % 2 else b2hip.circle_shape(0.2), density=1.0)
+
+    def between(s, w):
+        import math
+        w.joint_set_offsets(ids["servo"], (20.0 + 2.0 * math.sin(0.05 * s), 5.0 + math.sin(0.1 * s)), 0.2 * math.sin(0.03 * s))
+        if s == 120:
+            w.joint_set_motor(ids["wheel0"], True, 8.0, 15.0)
+        if s == 150:
+            w.set_flags(allow_sleep=True, warm_starting=False, continuous=False)
+
+    run(a, b, 260, "wheel/rope/friction/motor", between=between)
+    a.close(); b.close()
+
+
 def test_joint_setters_between_steps(libs, monkeypatch):
     """b2hip_joint_set_motor / b2hip_joint_set_limits: reverse a slider's motor, switch motors off and on, move and drop the
     limits of a revolute arm while everything has gone to sleep (the setters wake both bodies, as the reference's do), and

@@ -21,7 +21,7 @@ import b2harness as bh
 pytestmark = pytest.mark.gpu
 
 SMALL_ISLAND_SCENES = ["helloworld", "pyramid5x3", "piles", "circlestack", "field", "sensors"]
-ALL_SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20", "sensors", "ropes", "machines"]
+ALL_SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20", "sensors", "ropes", "machines", "vehicles"]
 
 # coloured large islands: |pose - reference| / scene_scale after COLORED_HORIZON steps of a settling
 # 30-row pyramid (466 bodies, one island). Measured 4e-4 .. 3e-3 (impact transient); bound with margin.

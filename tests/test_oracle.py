@@ -11,7 +11,7 @@ import b2harness as bh
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20", "sensors", "ropes", "machines"]
+SCENES = ["helloworld", "pyramid12", "pyramid5x3", "pyramid30", "piles", "rain", "circlestack", "field", "tumbler6", "tumbler20", "sensors", "ropes", "machines", "vehicles"]
 
 
 def run_scene(h, golden, name, check_every_step=True):
