@@ -294,6 +294,73 @@ def test_ropes_colored_mode_keeps_the_joints_tight(amd, oracle, default_mode):
     o.close()
 
 
+def _world_point(b, local):
+    c, s_ = np.cos(b[2]), np.sin(b[2])
+    return np.array([b[0] + c * local[0] - s_ * local[1], b[1] + s_ * local[0] + c * local[1]])
+
+
+def _machines_errors(B, segments):
+    """Constraint errors of the machines scene read off the body states (scene geometry: oracle/harness/scenes.h)."""
+    e = {}
+    e["slider off axis"] = max(abs(B[1, 1] - 1.0), abs(B[1, 2]))
+    e["slider past limits"] = max(0.0, abs(B[1, 0] + 6.0) - 12.0)
+    axis = np.array([0.3, 2.0]) / np.hypot(0.3, 2.0)
+    d = B[2, :2] - np.array([-20.0, 8.0])
+    e["free slider off axis"] = max(abs(d[0] * axis[1] - d[1] * axis[0]), abs(B[2, 2] - 0.25))
+    e["locked slider moved"] = float(np.abs(B[3, :3] - np.array([22.0, 6.0, 0.0])).max())
+    first = 5
+    worst = 0.0
+    for i in range(segments):  # rigid cantilever: consecutive segments share the weld point (left end of i = right end of i - 1)
+        left = _world_point(B[first + i], (-0.5, 0.0))
+        prev = np.array([4.0, 10.0]) if i == 0 else _world_point(B[first + i - 1], (0.5, 0.0))
+        worst = max(worst, float(np.abs(left - prev).max()))
+    e["weld point gap"] = worst
+    return e
+
+
+def _vehicles_errors(B, cars):
+    e = {"wheel off its line": 0.0, "rope stretched": 0.0}
+    for c in range(cars):
+        chassis = B[1 + 3 * c]
+        axis = np.array([0.1 * (c % 3), 1.0])
+        axis = axis / np.hypot(axis[0], axis[1])
+        ca, sa = np.cos(chassis[2]), np.sin(chassis[2])
+        waxis = np.array([ca * axis[0] - sa * axis[1], sa * axis[0] + ca * axis[1]])
+        for k, lx in enumerate((-1.0, 1.0)):
+            d = B[2 + 3 * c + k, :2] - _world_point(chassis, (lx, -0.65))
+            e["wheel off its line"] = max(e["wheel off its line"], abs(d[0] * waxis[1] - d[1] * waxis[0]))
+    for i in range(6):
+        wgt = B[1 + 3 * cars + i]
+        anchor = np.array([20.0 + 2.0 * i + (1.5 if i & 1 else 0.0), 12.0])
+        length = np.linalg.norm(_world_point(wgt, (0.0, 0.4)) - anchor)
+        e["rope stretched"] = max(e["rope stretched"], length - (2.0 if i < 2 else 4.0 + 0.5 * i))
+    return e
+
+
+@pytest.mark.parametrize("scene", ["machines", "vehicles"])
+def test_joint_scenes_colored_mode_hold_their_constraints(amd, oracle, default_mode, scene):
+    """Default (coloured) mode on the joint scenes: the floats differ from the reference order and these scenes are chaotic
+    (bodies raining on moving machinery), so poses are not compared; the joints' own constraint errors are, every step,
+    against what the oracle reaches with the same iteration counts."""
+    sc, p1, errs = (bh.MACHINES, 6, _machines_errors) if scene == "machines" else (bh.VEHICLES, 5, _vehicles_errors)
+    a = amd.world(sc, 150, p1, seed=3)
+    o = oracle.world(sc, 150, p1, seed=3)
+    worst_a, worst_o = {}, {}
+    for s in range(240):
+        a.step(1)
+        o.step(1)
+        A = a.bodies()
+        assert np.isfinite(A).all(), "step %d" % s
+        for k, v in errs(A, p1).items():
+            worst_a[k] = max(worst_a.get(k, 0.0), float(v))
+        for k, v in errs(o.bodies(), p1).items():
+            worst_o[k] = max(worst_o.get(k, 0.0), float(v))
+    for k in worst_a:
+        assert worst_a[k] <= 3.0 * worst_o[k] + 0.03, "%s: %g on the device, %g on the oracle" % (k, worst_a[k], worst_o[k])
+    a.close()
+    o.close()
+
+
 def test_many_small_islands_at_scale_vs_reference_build(amd, ref, default_mode):
     """20 k bodies in ~10 k islands (hundreds of islands per solver chunk): the default path must stay
     bit-identical to the reference build, every step."""

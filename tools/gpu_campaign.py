@@ -13,7 +13,7 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 bad = 0
 for k in range(cases):
-    fam = int(rng.integers(0, 7))
+    fam = int(rng.integers(0, 10)) if os.environ.get("FAMILIES") != "joints" else int(rng.integers(7, 10))
     seed = int(rng.integers(1, 100000))
     if fam == 0: name, scene, kw = "rain", H.RAIN, dict(p0=int(rng.integers(50, 1200)), seed=seed)
     elif fam == 1: name, scene, kw = "piles", H.PILES, dict(p0=int(rng.integers(5, 300)), p1=int(rng.integers(2, 9)), seed=seed)
@@ -21,6 +21,9 @@ for k in range(cases):
     elif fam == 3: name, scene, kw = "circles", H.CIRCLE_STACK, dict(p0=int(rng.integers(2, 20)), p1=int(rng.integers(2, 10)))
     elif fam == 4: name, scene, kw = "tumbler", H.TUMBLER, dict(p0=int(rng.integers(4, 22)), p1=0)
     elif fam == 5: name, scene, kw = "sensors", H.SENSORS, dict(p0=int(rng.integers(10, 250)), seed=seed)
+    elif fam == 7: name, scene, kw = "ropes", H.ROPES, dict(p0=int(rng.integers(0, 300)), p1=int(rng.integers(2, 18)), seed=seed)
+    elif fam == 8: name, scene, kw = "machines", H.MACHINES, dict(p0=int(rng.integers(0, 300)), p1=int(rng.integers(1, 9)), seed=seed)
+    elif fam == 9: name, scene, kw = "vehicles", H.VEHICLES, dict(p0=int(rng.integers(0, 300)), p1=int(rng.integers(1, 9)), seed=seed)
     else: name, scene, kw = "bullets", H.BULLETS, dict(p0=int(rng.integers(10, 200)), p1=int(rng.integers(2, 10)), seed=seed)
     flags = (H.F_CONTINUOUS if rng.random() < 0.6 else 0) | (H.F_SLEEP if rng.random() < 0.8 else 0) | (H.F_WARM if rng.random() < 0.85 else 0)
     a, o = amd.world(scene, flags=flags, **kw), orc.world(scene, flags=flags, **kw)
