@@ -1,6 +1,6 @@
 // b2d_joint.h - joint constraints on the device path: revolute (Tumbler's motor), distance (rigid rods and
 // soft springs), prismatic (MultithreadDemo's slider: axis, limits, motor), weld (rigid or soft), wheel (suspension
-// spring + axle motor), rope (maximum distance), friction and motor (top-down drag / pose servo). One fixed-size record per joint whatever its type (the type-specific members share storage), so
+// spring + axle motor), rope (maximum distance), friction and motor (top-down drag / pose servo), pulley. One fixed-size record per joint whatever its type (the type-specific members share storage), so
 // the island kernels, the upload and the snapshot handle one array.
 // Restates b2RevoluteJoint::{InitVelocityConstraints, SolveVelocityConstraints, SolvePositionConstraints}
 // (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376) and the same three of b2DistanceJoint
@@ -8,7 +8,7 @@
 // (Joints/b2WeldJoint.cpp:58-303) in the reference's operand order; b2Mat33::Solve33 / Solve22 / GetInverse22 /
 // GetSymInverse33 as in Box2D/Common/b2Math.cpp:25-94. Also b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
 // (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint
-// (Joints/b2MotorJoint.cpp:62-203).
+// (Joints/b2MotorJoint.cpp:62-203), b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253).
 #ifndef B2D_JOINT_H
 #define B2D_JOINT_H
 
@@ -33,7 +33,8 @@ enum
 	B2D_JOINT_WHEEL = 4,    // e_wheelJoint
 	B2D_JOINT_ROPE = 5,     // e_ropeJoint
 	B2D_JOINT_FRICTION = 6, // e_frictionJoint
-	B2D_JOINT_MOTOR = 7     // e_motorJoint
+	B2D_JOINT_MOTOR = 7,    // e_motorJoint
+	B2D_JOINT_PULLEY = 8    // e_pulleyJoint
 };
 
 struct JointRec
@@ -44,8 +45,8 @@ struct JointRec
 	V2 localAnchorB;
 	union { float referenceAngle; float length; float maxLength; float angularOffset; };
 	int enableLimit;
-	union { float lowerAngle; float frequencyHz; float lowerTranslation; float correctionFactor; };
-	union { float upperAngle; float dampingRatio; float upperTranslation; };
+	union { float lowerAngle; float frequencyHz; float lowerTranslation; float correctionFactor; float ratio; };
+	union { float upperAngle; float dampingRatio; float upperTranslation; float constant; };  // pulley: m_ratio, m_constant
 	int enableMotor;
 	union { float motorSpeed; float maxTorque; };  // friction / motor joint: m_maxTorque
 	union { float maxMotorTorque; float maxMotorForce; float maxForce; };
@@ -69,7 +70,7 @@ struct JointRec
 	float motorMass;
 	int islandFlag;
 	int type;
-	V2 localAxisA;                        // prismatic: m_localXAxisA (normalised at creation)
+	union { V2 localAxisA; V2 groundAnchorA; };  // prismatic / wheel: m_localXAxisA ; pulley: ground anchors here and in s1, s2
 	union { float s1; float wGamma; float sAx; float linErrX; };  // prismatic: m_s1, m_s2, m_a1, m_a2 ; weld: m_gamma, m_bias
 	union { float s2; float wBias; float sBx; float linErrY; };   // wheel: m_sAx, m_sBx, m_sAy, m_sBy ; motor: m_linearError,
 	union { float a1; float sAy; float angErr; };                 //   m_angularError
@@ -1374,6 +1375,108 @@ B2D_HD void b2dMotorInit(JointRec* j, float invMassA, float invIA, V2 lcA, float
 	b2dJointWarmStartLinearAngular(j, j->rA, j->rB, A, B, warmStarting, dtRatio);
 }
 
+// ---- pulley joint -----------------------------------------------------------------------------------
+// length1 + ratio * length2 = constant. m_uA is kept in (m_eyx, m_eyy), m_uB in (m_eyz, m_ezx), ground anchor B in (s1, s2).
+B2D_HD V2 b2dPulleyDir(V2 u, float* length)
+{
+	*length = b2dLength(u);
+	if (*length > 10.0f * B2D_LINEAR_SLOP) return (1.0f / *length) * u;
+	return v2(0.0f, 0.0f);
+}
+
+// InitVelocityConstraints (b2PulleyJoint.cpp:81-156)
+B2D_HD void b2dPulleyInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
+	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio)
+{
+	b2dJointStoreBodies(j, invMassA, invIA, lcA, invMassB, invIB, lcB);
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	Rot qA = b2dRot(pA.a), qB = b2dRot(pB.a);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - lcA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	j->rA = rA;
+	j->rB = rB;
+	float lengthA, lengthB;
+	V2 uA = b2dPulleyDir(pA.c + rA - j->groundAnchorA, &lengthA);
+	V2 uB = b2dPulleyDir(pB.c + rB - v2(j->s1, j->s2), &lengthB);
+	j->m_eyx = uA.x; j->m_eyy = uA.y;
+	j->m_eyz = uB.x; j->m_ezx = uB.y;
+	float ruA = b2dCross(rA, uA);
+	float ruB = b2dCross(rB, uB);
+	float mA = invMassA + invIA * ruA * ruA;
+	float mB = invMassB + invIB * ruB * ruB;
+	j->mass = mA + j->ratio * j->ratio * mB;
+	if (j->mass > 0.0f) j->mass = 1.0f / j->mass;
+	if (warmStarting)
+	{
+		j->impulse *= dtRatio;
+		V2 PA = -(j->impulse) * uA;
+		V2 PB = (-j->ratio * j->impulse) * uB;
+		vA += invMassA * PA;
+		wA += invIA * b2dCross(rA, PA);
+		vB += invMassB * PB;
+		wB += invIB * b2dCross(rB, PB);
+	}
+	else
+	{
+		j->impulse = 0.0f;
+	}
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolveVelocityConstraints (b2PulleyJoint.cpp:158-183)
+B2D_HD void b2dPulleySolveVelocity(JointRec* j, BodyVel* A, BodyVel* B)
+{
+	V2 vA = A->v, vB = B->v;
+	float wA = A->w, wB = B->w;
+	const V2 rA = j->rA, rB = j->rB, uA = v2(j->m_eyx, j->m_eyy), uB = v2(j->m_eyz, j->m_ezx);
+	V2 vpA = vA + b2dCrossSV(wA, rA);
+	V2 vpB = vB + b2dCrossSV(wB, rB);
+	float Cdot = -b2dDot(uA, vpA) - j->ratio * b2dDot(uB, vpB);
+	float impulse = -j->mass * Cdot;
+	j->impulse += impulse;
+	V2 PA = -impulse * uA;
+	V2 PB = -j->ratio * impulse * uB;
+	vA += j->invMassA * PA;
+	wA += j->invIA * b2dCross(rA, PA);
+	vB += j->invMassB * PB;
+	wB += j->invIB * b2dCross(rB, PB);
+	A->v = vA; A->w = wA;
+	B->v = vB; B->w = wB;
+}
+
+// SolvePositionConstraints (b2PulleyJoint.cpp:185-253)
+B2D_HD bool b2dPulleySolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
+{
+	V2 cA = A->c, cB = B->c;
+	float aA = A->a, aB = B->a;
+	Rot qA = b2dRot(aA), qB = b2dRot(aB);
+	V2 rA = b2dMulRV(qA, j->localAnchorA - j->localCenterA);
+	V2 rB = b2dMulRV(qB, j->localAnchorB - j->localCenterB);
+	float lengthA, lengthB;
+	V2 uA = b2dPulleyDir(cA + rA - j->groundAnchorA, &lengthA);
+	V2 uB = b2dPulleyDir(cB + rB - v2(j->s1, j->s2), &lengthB);
+	float ruA = b2dCross(rA, uA);
+	float ruB = b2dCross(rB, uB);
+	float mA = j->invMassA + j->invIA * ruA * ruA;
+	float mB = j->invMassB + j->invIB * ruB * ruB;
+	float mass = mA + j->ratio * j->ratio * mB;
+	if (mass > 0.0f) mass = 1.0f / mass;
+	float C = j->constant - lengthA - j->ratio * lengthB;
+	float linearError = b2dAbs(C);
+	float impulse = -mass * C;
+	V2 PA = -impulse * uA;
+	V2 PB = -j->ratio * impulse * uB;
+	cA += j->invMassA * PA;
+	aA += j->invIA * b2dCross(rA, PA);
+	cB += j->invMassB * PB;
+	aB += j->invIB * b2dCross(rB, PB);
+	A->c = cA; A->a = aA;
+	B->c = cB; B->a = aB;
+	return linearError < B2D_LINEAR_SLOP;
+}
+
 // ---- dispatch on the joint type (b2Joint's virtual calls, b2Island.cpp:235-318) -------------------------
 B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
 	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
@@ -1392,6 +1495,8 @@ B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float
 		b2dFrictionInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
 	else if (j->type == B2D_JOINT_MOTOR)
 		b2dMotorInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
+	else if (j->type == B2D_JOINT_PULLEY)
+		b2dPulleyInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
 	else
 		b2dRevoluteInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA.a, A, pB.a, B, warmStarting, dtRatio);
 }
@@ -1408,6 +1513,8 @@ B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt,
 		b2dWheelSolveVelocity(j, A, B, dt);
 	else if (j->type == B2D_JOINT_ROPE)
 		b2dRopeSolveVelocity(j, A, B, inv_dt);
+	else if (j->type == B2D_JOINT_PULLEY)
+		b2dPulleySolveVelocity(j, A, B);
 	else if (j->type == B2D_JOINT_FRICTION)
 		b2dJointSolveLinearAngular(j, A, B, dt, 0.0f, v2(0.0f, 0.0f), false);
 	else if (j->type == B2D_JOINT_MOTOR)
@@ -1424,6 +1531,7 @@ B2D_HD bool b2dJointSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 	if (j->type == B2D_JOINT_WELD) return b2dWeldSolvePosition(j, A, B);
 	if (j->type == B2D_JOINT_WHEEL) return b2dWheelSolvePosition(j, A, B);
 	if (j->type == B2D_JOINT_ROPE) return b2dRopeSolvePosition(j, A, B);
+	if (j->type == B2D_JOINT_PULLEY) return b2dPulleySolvePosition(j, A, B);
 	if (j->type == B2D_JOINT_FRICTION || j->type == B2D_JOINT_MOTOR) return true;
 	return b2dRevoluteSolvePosition(j, A, B);
 }

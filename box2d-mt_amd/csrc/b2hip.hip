@@ -1941,6 +1941,27 @@ int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def)
 	return addJoint(w, j);
 }
 
+int b2hip_create_pulley_joint(b2hip_world* w, const b2hip_pulley_joint_def* def)
+{
+	if (!def) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rc = checkJointBodies(w, def->body_a, def->body_b)) return rc;
+	if (def->ratio == 0.0f) return setError(B2HIP_ERR_INVALID, "pulley ratio must not be zero");
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_PULLEY;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.localAnchorA = v2(def->local_anchor_a[0], def->local_anchor_a[1]);
+	j.localAnchorB = v2(def->local_anchor_b[0], def->local_anchor_b[1]);
+	j.groundAnchorA = v2(def->ground_anchor_a[0], def->ground_anchor_a[1]);
+	j.s1 = def->ground_anchor_b[0];
+	j.s2 = def->ground_anchor_b[1];
+	j.ratio = def->ratio;
+	j.constant = def->length_a + def->ratio * def->length_b; // b2PulleyJoint.cpp:75
+	j.collideConnected = def->collide_connected;
+	return addJoint(w, j);
+}
+
 // b2Body::SetAwake(true) on both bodies of a joint whose definition changed (b2RevoluteJoint.cpp:418-500)
 static void wakeJointBodies(b2hip_world* w, const JointRec& j)
 {

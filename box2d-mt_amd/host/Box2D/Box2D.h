@@ -29,6 +29,7 @@
 #include "Box2D/Dynamics/Joints/b2RopeJoint.h"
 #include "Box2D/Dynamics/Joints/b2FrictionJoint.h"
 #include "Box2D/Dynamics/Joints/b2MotorJoint.h"
+#include "Box2D/Dynamics/Joints/b2PulleyJoint.h"
 
 #include "Box2D/MT/b2Task.h"
 #include "Box2D/MT/b2TaskExecutor.h"

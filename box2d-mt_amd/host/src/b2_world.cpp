@@ -307,6 +307,27 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 		id = b2hip_create_motor_joint(m_hip, &d);
 		if (id >= 0) j = new (b2Alloc(sizeof(b2MotorJoint))) b2MotorJoint(md);
 	}
+	else if (def->type == e_pulleyJoint)
+	{
+		const b2PulleyJointDef* pd = static_cast<const b2PulleyJointDef*>(def);
+		b2hip_pulley_joint_def d;
+		d.body_a = pd->bodyA->GetDeviceId();
+		d.body_b = pd->bodyB->GetDeviceId();
+		d.ground_anchor_a[0] = pd->groundAnchorA.x;
+		d.ground_anchor_a[1] = pd->groundAnchorA.y;
+		d.ground_anchor_b[0] = pd->groundAnchorB.x;
+		d.ground_anchor_b[1] = pd->groundAnchorB.y;
+		d.local_anchor_a[0] = pd->localAnchorA.x;
+		d.local_anchor_a[1] = pd->localAnchorA.y;
+		d.local_anchor_b[0] = pd->localAnchorB.x;
+		d.local_anchor_b[1] = pd->localAnchorB.y;
+		d.length_a = pd->lengthA;
+		d.length_b = pd->lengthB;
+		d.ratio = pd->ratio;
+		d.collide_connected = pd->collideConnected;
+		id = b2hip_create_pulley_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2PulleyJoint))) b2PulleyJoint(pd);
+	}
 	else
 	{
 		fprintf(stderr, "b2World::CreateJoint: joint type %d is not on the device path yet\n", (int)def->type);
@@ -936,6 +957,20 @@ void b2MotorJoint::SetAngularOffset(float32 angularOffset)
 {
 	m_angularOffset = angularOffset;
 	b2hip_joint_set_offsets(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_linearOffset.x, m_linearOffset.y, m_angularOffset);
+}
+
+void b2PulleyJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& groundA, const b2Vec2& groundB, const b2Vec2& anchorA,
+	const b2Vec2& anchorB, float32 r)
+{
+	bodyA = bA;
+	bodyB = bB;
+	groundAnchorA = groundA;
+	groundAnchorB = groundB;
+	localAnchorA = bodyA->GetLocalPoint(anchorA);
+	localAnchorB = bodyB->GetLocalPoint(anchorB);
+	lengthA = (anchorA - groundA).Length();
+	lengthB = (anchorB - groundB).Length();
+	ratio = r;
 }
 
 // ---- callbacks / collision helpers ----------------------------------------------------------------

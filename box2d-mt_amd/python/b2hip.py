@@ -92,6 +92,12 @@ class MotorJointDef(C.Structure):
                 ("collide_connected", C.c_int)]
 
 
+class PulleyJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("ground_anchor_a", C.c_float * 2), ("ground_anchor_b", C.c_float * 2),
+                ("local_anchor_a", C.c_float * 2), ("local_anchor_b", C.c_float * 2), ("length_a", C.c_float),
+                ("length_b", C.c_float), ("ratio", C.c_float), ("collide_connected", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
@@ -132,6 +138,7 @@ def _configure(L, optional_ok=False):
         "b2hip_create_rope_joint": [C.c_void_p, C.POINTER(RopeJointDef)],
         "b2hip_create_friction_joint": [C.c_void_p, C.POINTER(FrictionJointDef)],
         "b2hip_create_motor_joint": [C.c_void_p, C.POINTER(MotorJointDef)],
+        "b2hip_create_pulley_joint": [C.c_void_p, C.POINTER(PulleyJointDef)],
         "b2hip_joint_set_offsets": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
         "b2hip_joint_set_motor": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
         "b2hip_joint_set_limits": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
@@ -346,6 +353,14 @@ class World:
         d.angular_offset = angular_offset
         d.max_force, d.max_torque, d.correction_factor = max_force, max_torque, correction_factor
         return _check(self.L.b2hip_create_motor_joint(self.p, C.byref(d)))
+
+    def create_pulley_joint(self, body_a, body_b, ground_a, ground_b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), length_a=1.0,
+                            length_b=1.0, ratio=1.0, collide_connected=True):
+        d = self._joint_def(PulleyJointDef, body_a, body_b, anchor_a, anchor_b, collide_connected)
+        d.ground_anchor_a[0], d.ground_anchor_a[1] = ground_a
+        d.ground_anchor_b[0], d.ground_anchor_b[1] = ground_b
+        d.length_a, d.length_b, d.ratio = length_a, length_b, ratio
+        return _check(self.L.b2hip_create_pulley_joint(self.p, C.byref(d)))
 
     def joint_set_offsets(self, joint, linear_offset, angular_offset):
         _check(self.L.b2hip_joint_set_offsets(self.p, joint, linear_offset[0], linear_offset[1], angular_offset))

@@ -18,6 +18,7 @@
  *   b2hip_create_rope_joint          b2World::CreateJoint (rope)            Joints/b2RopeJoint.cpp:34-46
  *   b2hip_create_friction_joint      b2World::CreateJoint (friction)        Joints/b2FrictionJoint.cpp:45-56
  *   b2hip_create_motor_joint         b2World::CreateJoint (motor)           Joints/b2MotorJoint.cpp:48-60
+ *   b2hip_create_pulley_joint        b2World::CreateJoint (pulley)          Joints/b2PulleyJoint.cpp:62-79
  *   b2hip_joint_set_offsets          b2MotorJoint::SetLinearOffset / SetAngularOffset   Joints/b2MotorJoint.cpp:253-281
  *   b2hip_joint_set_motor            b2{Revolute,Prismatic,Wheel}Joint::EnableMotor / SetMotorSpeed / SetMaxMotor{Torque,Force}
  *                                                                           Joints/b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616
@@ -194,6 +195,17 @@ typedef struct b2hip_friction_joint_def
 	int collide_connected;
 } b2hip_friction_joint_def;
 
+/* b2PulleyJointDef (Joints/b2PulleyJoint.h:28-76): length_a + ratio * length_b stays constant; ground anchors in world space */
+typedef struct b2hip_pulley_joint_def
+{
+	int body_a, body_b;
+	float ground_anchor_a[2], ground_anchor_b[2];
+	float local_anchor_a[2], local_anchor_b[2];
+	float length_a, length_b;
+	float ratio;
+	int collide_connected;
+} b2hip_pulley_joint_def;
+
 /* b2MotorJointDef (Joints/b2MotorJoint.h:26-57): drives bodyB to linear_offset / angular_offset in bodyA's frame */
 typedef struct b2hip_motor_joint_def
 {
@@ -279,6 +291,7 @@ int b2hip_create_wheel_joint(b2hip_world* w, const b2hip_wheel_joint_def* def);
 int b2hip_create_rope_joint(b2hip_world* w, const b2hip_rope_joint_def* def);
 int b2hip_create_friction_joint(b2hip_world* w, const b2hip_friction_joint_def* def);
 int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def);
+int b2hip_create_pulley_joint(b2hip_world* w, const b2hip_pulley_joint_def* def);
 /* b2MotorJoint::SetLinearOffset + SetAngularOffset (b2MotorJoint.cpp:253-281): wakes both bodies when something changes */
 int b2hip_joint_set_offsets(b2hip_world* w, int joint, float linear_x, float linear_y, float angular);
 /* Revolute / prismatic / wheel (motor only) joints between steps: EnableMotor + SetMotorSpeed + SetMaxMotorTorque|Force in one call, and

@@ -113,6 +113,14 @@ int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def)
 		def->max_torque, def->correction_factor, def->collide_connected);
 }
 
+int b2hip_create_pulley_joint(b2hip_world* w, const b2hip_pulley_joint_def* def)
+{
+	float anchors[4] = { def->local_anchor_a[0], def->local_anchor_a[1], def->local_anchor_b[0], def->local_anchor_b[1] };
+	float grounds[4] = { def->ground_anchor_a[0], def->ground_anchor_a[1], def->ground_anchor_b[0], def->ground_anchor_b[1] };
+	return b2o_create_pulley_joint(w->o, def->body_a, def->body_b, anchors, grounds, def->length_a, def->length_b, def->ratio,
+		def->collide_connected);
+}
+
 int b2hip_joint_set_offsets(b2hip_world* w, int joint, float lx, float ly, float angular)
 {
 	b2o_joint_set_offsets(w->o, joint, lx, ly, angular);

@@ -2,7 +2,8 @@
  * (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376; b2Mat33::Solve33/Solve22 b2Math.cpp:25-53) and of
  * b2DistanceJoint (Joints/b2DistanceJoint.cpp:65-225), b2PrismaticJoint (Joints/b2PrismaticJoint.cpp:130-478),
  * b2WeldJoint (Joints/b2WeldJoint.cpp:58-303), b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
- * (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint (Joints/b2MotorJoint.cpp:62-203); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
+ * (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint (Joints/b2MotorJoint.cpp:62-203),
+ * b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
  * TEST INFRASTRUCTURE (see b2o.h). */
 #include "b2o_joint.h"
 
@@ -1058,4 +1059,89 @@ void b2o_motor_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB,
 	vec2 Cdot = v_add(v_sub(v_sub(v_add(*vB, v_cross_sv(*wB, j->rB)), *vA), v_cross_sv(*wA, j->rA)),
 		v_scale(inv_dt * j->correctionFactor, j->linearError));
 	linear_rows(j, Cdot, vA, wA, vB, wB, dt);
+}
+
+/* ---- pulley joint ------------------------------------------------------------------------------- */
+static vec2 pulley_dir(vec2 u, float* length)
+{
+	*length = v_length(u);
+	if (*length > 10.0f * B2O_LINEAR_SLOP) return v_scale(1.0f / *length, u);
+	return v_make(0.0f, 0.0f);
+}
+
+/* InitVelocityConstraints b2PulleyJoint.cpp:81-156 */
+void b2o_pulley_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, float iB, vec2 lcB,
+	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio)
+{
+	j->localCenterA = lcA; j->localCenterB = lcB;
+	j->invMassA = mA; j->invMassB = mB; j->invIA = iA; j->invIB = iB;
+	rot qA = r_make(aA), qB = r_make(aB);
+	j->rA = r_mul(qA, v_sub(j->localAnchorA, lcA));
+	j->rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	float lengthA, lengthB;
+	j->uA = pulley_dir(v_sub(v_add(cA, j->rA), j->groundAnchorA), &lengthA);
+	j->uB = pulley_dir(v_sub(v_add(cB, j->rB), j->groundAnchorB), &lengthB);
+	float ruA = v_cross(j->rA, j->uA);
+	float ruB = v_cross(j->rB, j->uB);
+	float effA = mA + iA * ruA * ruA;
+	float effB = mB + iB * ruB * ruB;
+	j->mass = effA + j->ratio * j->ratio * effB;
+	if (j->mass > 0.0f) j->mass = 1.0f / j->mass;
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio;
+		vec2 PA = v_scale(-(j->impulse[0]), j->uA);
+		vec2 PB = v_scale(-j->ratio * j->impulse[0], j->uB);
+		*vA = v_add(*vA, v_scale(mA, PA));
+		*wA += iA * v_cross(j->rA, PA);
+		*vB = v_add(*vB, v_scale(mB, PB));
+		*wB += iB * v_cross(j->rB, PB);
+	}
+	else
+	{
+		j->impulse[0] = 0.0f;
+	}
+}
+
+/* SolveVelocityConstraints :158-183 */
+void b2o_pulley_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB)
+{
+	vec2 vpA = v_add(*vA, v_cross_sv(*wA, j->rA));
+	vec2 vpB = v_add(*vB, v_cross_sv(*wB, j->rB));
+	float Cdot = -v_dot(j->uA, vpA) - j->ratio * v_dot(j->uB, vpB);
+	float impulse = -j->mass * Cdot;
+	j->impulse[0] += impulse;
+	vec2 PA = v_scale(-impulse, j->uA);
+	vec2 PB = v_scale(-j->ratio * impulse, j->uB);
+	*vA = v_add(*vA, v_scale(j->invMassA, PA));
+	*wA += j->invIA * v_cross(j->rA, PA);
+	*vB = v_add(*vB, v_scale(j->invMassB, PB));
+	*wB += j->invIB * v_cross(j->rB, PB);
+}
+
+/* SolvePositionConstraints :185-253 */
+int b2o_pulley_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB)
+{
+	rot qA = r_make(*aA), qB = r_make(*aB);
+	vec2 rA = r_mul(qA, v_sub(j->localAnchorA, j->localCenterA));
+	vec2 rB = r_mul(qB, v_sub(j->localAnchorB, j->localCenterB));
+	float lengthA, lengthB;
+	vec2 uA = pulley_dir(v_sub(v_add(*cA, rA), j->groundAnchorA), &lengthA);
+	vec2 uB = pulley_dir(v_sub(v_add(*cB, rB), j->groundAnchorB), &lengthB);
+	float ruA = v_cross(rA, uA);
+	float ruB = v_cross(rB, uB);
+	float effA = j->invMassA + j->invIA * ruA * ruA;
+	float effB = j->invMassB + j->invIB * ruB * ruB;
+	float mass = effA + j->ratio * j->ratio * effB;
+	if (mass > 0.0f) mass = 1.0f / mass;
+	float C = j->constant - lengthA - j->ratio * lengthB;
+	float linearError = f_abs(C);
+	float impulse = -mass * C;
+	vec2 PA = v_scale(-impulse, uA);
+	vec2 PB = v_scale(-j->ratio * impulse, uB);
+	*cA = v_add(*cA, v_scale(j->invMassA, PA));
+	*aA += j->invIA * v_cross(rA, PA);
+	*cB = v_add(*cB, v_scale(j->invMassB, PB));
+	*aB += j->invIB * v_cross(rB, PB);
+	return linearError < B2O_LINEAR_SLOP;
 }

@@ -5,7 +5,7 @@
  * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
- * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld, wheel, rope, friction, motor (b2o_joint.c). Not covered (same as the device
+ * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley (b2o_joint.c). Not covered (same as the device
  * path): other joint types, chain shapes. Continuous collision: b2o_toi.c
  * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
@@ -503,6 +503,20 @@ int b2o_create_motor_joint(b2o_world* w, int bodyA, int bodyB, const float* line
 	j->maxForce = maxForce;
 	j->maxTorque = maxTorque;
 	j->correctionFactor = correctionFactor;
+	return id;
+}
+
+/* b2PulleyJoint::b2PulleyJoint (b2PulleyJoint.cpp:62-79) */
+int b2o_create_pulley_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, const float* groundAnchors4, float lengthA,
+	float lengthB, float ratio, int collideConnected)
+{
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors4, 0.0f, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_PULLEY;
+	j->groundAnchorA = v_make(groundAnchors4[0], groundAnchors4[1]);
+	j->groundAnchorB = v_make(groundAnchors4[2], groundAnchors4[3]);
+	j->ratio = ratio;
+	j->constant = lengthA + ratio * lengthB;
 	return id;
 }
 
@@ -1335,6 +1349,10 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			b2o_friction_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
 				positions[ia].a, vA, wA, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
 			break;
+		case B2O_JOINT_PULLEY:
+			b2o_pulley_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
+				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
+			break;
 		case B2O_JOINT_MOTOR:
 			b2o_motor_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
 				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
@@ -1359,6 +1377,7 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			case B2O_JOINT_WELD: b2o_weld_velocity(j, vA, wA, vB, wB); break;
 			case B2O_JOINT_WHEEL: b2o_wheel_velocity(j, vA, wA, vB, wB, h); break;
 			case B2O_JOINT_ROPE: b2o_rope_velocity(j, vA, wA, vB, wB, 1.0f / h); break;
+			case B2O_JOINT_PULLEY: b2o_pulley_velocity(j, vA, wA, vB, wB); break;
 			case B2O_JOINT_FRICTION: b2o_friction_velocity(j, vA, wA, vB, wB, h); break;
 			case B2O_JOINT_MOTOR: b2o_motor_velocity(j, vA, wA, vB, wB, h, 1.0f / h); break;
 			default: b2o_revolute_velocity(j, vA, wA, vB, wB, h);
@@ -1417,6 +1436,7 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			case B2O_JOINT_WELD: ok = b2o_weld_position(j, cA, aA, cB, aB); break;
 			case B2O_JOINT_WHEEL: ok = b2o_wheel_position(j, cA, aA, cB, aB); break;
 			case B2O_JOINT_ROPE: ok = b2o_rope_position(j, cA, aA, cB, aB); break;
+			case B2O_JOINT_PULLEY: ok = b2o_pulley_position(j, cA, aA, cB, aB); break;
 			case B2O_JOINT_FRICTION: case B2O_JOINT_MOTOR: ok = 1; break;
 			default: ok = b2o_revolute_position(j, cA, aA, cB, aB);
 			}

@@ -74,7 +74,7 @@ enum SceneId
 	                     //   planks and the ground, a soft web of four boxes on damped springs, bodies dropped on both
 	e_machines = 10,     // p0 = falling bodies, p1 = cantilever segments ; prismatic joints (motor slider between limits, a free
 	                     //   vertical slider resting on its lower limit, a locked one) and weld joints (rigid and soft cantilevers,
-	                     //   a welded free-falling pair), bodies dropped over all of them
+	                     //   a welded free-falling pair), two pulleys, bodies dropped over all of them
 	e_vehicles = 11,     // p0 = falling bodies, p1 = cars ; wheel joints (cars with sprung, motor-driven wheels over bumps, one
 	                     //   with a rigid axle), rope joints (weights on slack and taut tethers), friction joints (pucks braked
 	                     //   against the ground) and motor joints (platforms servoed to a pose the step loop keeps moving)
@@ -748,6 +748,25 @@ inline void BuildMachines(Scene& s, b2World* w, int count, int segments, uint32_
 		b->CreateFixture(&c, 1.0f);
 		b2WeldJointDef jd;
 		jd.Initialize(a, b, b2Vec2(15.0f, 20.0f));
+		w->CreateJoint(&jd);
+	}
+	// pulleys: two pairs of unequal weights over ground points, ratios 1 and 2.5 (the second pair starts out of balance)
+	for (int i = 0; i < 2; ++i)
+	{
+		const float x = -34.0f + 6.0f * (float)i, y = 8.0f;
+		b2PolygonShape wgt;
+		wgt.SetAsBox(0.6f, 0.8f);
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(x - 1.5f, y);
+		b2Body* left = AddBody(s, w, bd);
+		left->CreateFixture(&wgt, 3.0f);
+		bd.position.Set(x + 1.5f, y - (float)i);
+		b2Body* right = AddBody(s, w, bd);
+		right->CreateFixture(&wgt, 3.0f + 2.0f * (float)i);
+		b2PulleyJointDef jd;
+		jd.Initialize(left, right, b2Vec2(x - 1.5f, y + 6.0f), b2Vec2(x + 1.5f, y + 6.0f), b2Vec2(x - 1.5f, y + 0.8f),
+			b2Vec2(x + 1.5f, y - (float)i + 0.8f), i ? 2.5f : 1.0f);
 		w->CreateJoint(&jd);
 	}
 	for (int i = 0; i < count; ++i)
