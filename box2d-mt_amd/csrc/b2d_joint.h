@@ -1,6 +1,6 @@
 // b2d_joint.h - joint constraints on the device path: revolute (Tumbler's motor), distance (rigid rods and
 // soft springs), prismatic (MultithreadDemo's slider: axis, limits, motor), weld (rigid or soft), wheel (suspension
-// spring + axle motor), rope (maximum distance), friction and motor (top-down drag / pose servo), pulley. One fixed-size record per joint whatever its type (the type-specific members share storage), so
+// spring + axle motor), rope (maximum distance), friction and motor (top-down drag / pose servo), pulley, mouse (drag a body to a target). One fixed-size record per joint whatever its type (the type-specific members share storage), so
 // the island kernels, the upload and the snapshot handle one array.
 // Restates b2RevoluteJoint::{InitVelocityConstraints, SolveVelocityConstraints, SolvePositionConstraints}
 // (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376) and the same three of b2DistanceJoint
@@ -8,7 +8,8 @@
 // (Joints/b2WeldJoint.cpp:58-303) in the reference's operand order; b2Mat33::Solve33 / Solve22 / GetInverse22 /
 // GetSymInverse33 as in Box2D/Common/b2Math.cpp:25-94. Also b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
 // (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint
-// (Joints/b2MotorJoint.cpp:62-203), b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253).
+// (Joints/b2MotorJoint.cpp:62-203), b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253),
+// b2MouseJoint (Joints/b2MouseJoint.cpp:99-198).
 #ifndef B2D_JOINT_H
 #define B2D_JOINT_H
 
@@ -34,16 +35,17 @@ enum
 	B2D_JOINT_ROPE = 5,     // e_ropeJoint
 	B2D_JOINT_FRICTION = 6, // e_frictionJoint
 	B2D_JOINT_MOTOR = 7,    // e_motorJoint
-	B2D_JOINT_PULLEY = 8    // e_pulleyJoint
+	B2D_JOINT_PULLEY = 8,   // e_pulleyJoint
+	B2D_JOINT_MOUSE = 9     // e_mouseJoint
 };
 
 struct JointRec
 {
 	// definition (b2RevoluteJointDef / b2DistanceJointDef / b2PrismaticJointDef / b2WeldJointDef)
 	int bodyA, bodyB;
-	union { V2 localAnchorA; V2 linearOffset; };   // motor joint: m_linearOffset
+	union { V2 localAnchorA; V2 linearOffset; V2 targetA; };   // motor joint: m_linearOffset ; mouse joint: m_targetA (world)
 	V2 localAnchorB;
-	union { float referenceAngle; float length; float maxLength; float angularOffset; };
+	union { float referenceAngle; float length; float maxLength; float angularOffset; float bodyMass; }; // mouse: bodyB's mass
 	int enableLimit;
 	union { float lowerAngle; float frequencyHz; float lowerTranslation; float correctionFactor; float ratio; };
 	union { float upperAngle; float dampingRatio; float upperTranslation; float constant; };  // pulley: m_ratio, m_constant
@@ -1477,6 +1479,81 @@ B2D_HD bool b2dPulleySolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 	return linearError < B2D_LINEAR_SLOP;
 }
 
+// ---- mouse joint ------------------------------------------------------------------------------------
+// Acts on bodyB only. m_mass (2x2) in exx, exy (ex) and eyx, eyy (ey); m_C in (s1, s2); m_beta in a1, m_gamma in a2.
+// InitVelocityConstraints (b2MouseJoint.cpp:99-163)
+B2D_HD void b2dMouseInit(JointRec* j, float invMassB, float invIB, V2 lcB, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio,
+	float dt)
+{
+	j->localCenterB = lcB;
+	j->invMassB = invMassB;
+	j->invIB = invIB;
+	V2 vB = B->v;
+	float wB = B->w;
+	Rot qB = b2dRot(pB.a);
+	float mass = j->bodyMass;
+	float omega = 2.0f * B2D_PI * j->frequencyHz;
+	float d = 2.0f * mass * j->dampingRatio * omega;
+	float k = mass * (omega * omega);
+	float gamma = dt * (d + dt * k);
+	if (gamma != 0.0f) gamma = 1.0f / gamma;
+	float beta = dt * k * gamma;
+	j->a1 = beta;
+	j->a2 = gamma;
+	V2 rB = b2dMulRV(qB, j->localAnchorB - lcB);
+	j->rB = rB;
+	float kxx = invMassB + invIB * rB.y * rB.y + gamma;
+	float kxy = -invIB * rB.x * rB.y;
+	float kyy = invMassB + invIB * rB.x * rB.x + gamma;
+	float a = kxx, b = kxy, c = kxy, dd = kyy;
+	float det = a * dd - b * c;
+	if (det != 0.0f) det = 1.0f / det;
+	j->m_exx = det * dd; j->m_eyx = -det * b;
+	j->m_exy = -det * c; j->m_eyy = det * a;
+	V2 C = pB.c + rB - j->targetA;
+	C *= beta;
+	j->s1 = C.x;
+	j->s2 = C.y;
+	wB *= 0.98f; // the reference's built-in damping
+	if (warmStarting)
+	{
+		j->impulseX *= dtRatio;
+		j->impulseY *= dtRatio;
+		V2 P = v2(j->impulseX, j->impulseY);
+		vB += invMassB * P;
+		wB += invIB * b2dCross(rB, P);
+	}
+	else
+	{
+		j->impulseX = j->impulseY = 0.0f;
+	}
+	B->v = vB; B->w = wB;
+}
+
+// SolveVelocityConstraints (b2MouseJoint.cpp:165-192)
+B2D_HD void b2dMouseSolveVelocity(JointRec* j, BodyVel* B, float dt)
+{
+	V2 vB = B->v;
+	float wB = B->w;
+	const V2 rB = j->rB;
+	V2 Cdot = vB + b2dCrossSV(wB, rB);
+	V2 oldImpulse = v2(j->impulseX, j->impulseY);
+	V2 rhs = -(Cdot + v2(j->s1, j->s2) + j->a2 * oldImpulse);
+	V2 impulse = v2(j->m_exx * rhs.x + j->m_eyx * rhs.y, j->m_exy * rhs.x + j->m_eyy * rhs.y);
+	V2 acc = oldImpulse + impulse;
+	float maxImpulse = dt * j->maxForce;
+	if (acc.x * acc.x + acc.y * acc.y > maxImpulse * maxImpulse)
+	{
+		acc *= maxImpulse / b2dLength(acc);
+	}
+	j->impulseX = acc.x;
+	j->impulseY = acc.y;
+	impulse = acc - oldImpulse;
+	vB += j->invMassB * impulse;
+	wB += j->invIB * b2dCross(rB, impulse);
+	B->v = vB; B->w = wB;
+}
+
 // ---- dispatch on the joint type (b2Joint's virtual calls, b2Island.cpp:235-318) -------------------------
 B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float invMassB, float invIB, V2 lcB,
 	BodyPos pA, BodyVel* A, BodyPos pB, BodyVel* B, bool warmStarting, float dtRatio, float dt)
@@ -1497,6 +1574,8 @@ B2D_HD void b2dJointInit(JointRec* j, float invMassA, float invIA, V2 lcA, float
 		b2dMotorInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
 	else if (j->type == B2D_JOINT_PULLEY)
 		b2dPulleyInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA, A, pB, B, warmStarting, dtRatio);
+	else if (j->type == B2D_JOINT_MOUSE)
+		b2dMouseInit(j, invMassB, invIB, lcB, pB, B, warmStarting, dtRatio, dt);
 	else
 		b2dRevoluteInit(j, invMassA, invIA, lcA, invMassB, invIB, lcB, pA.a, A, pB.a, B, warmStarting, dtRatio);
 }
@@ -1515,6 +1594,8 @@ B2D_HD void b2dJointSolveVelocity(JointRec* j, BodyVel* A, BodyVel* B, float dt,
 		b2dRopeSolveVelocity(j, A, B, inv_dt);
 	else if (j->type == B2D_JOINT_PULLEY)
 		b2dPulleySolveVelocity(j, A, B);
+	else if (j->type == B2D_JOINT_MOUSE)
+		b2dMouseSolveVelocity(j, B, dt);
 	else if (j->type == B2D_JOINT_FRICTION)
 		b2dJointSolveLinearAngular(j, A, B, dt, 0.0f, v2(0.0f, 0.0f), false);
 	else if (j->type == B2D_JOINT_MOTOR)
@@ -1532,7 +1613,7 @@ B2D_HD bool b2dJointSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 	if (j->type == B2D_JOINT_WHEEL) return b2dWheelSolvePosition(j, A, B);
 	if (j->type == B2D_JOINT_ROPE) return b2dRopeSolvePosition(j, A, B);
 	if (j->type == B2D_JOINT_PULLEY) return b2dPulleySolvePosition(j, A, B);
-	if (j->type == B2D_JOINT_FRICTION || j->type == B2D_JOINT_MOTOR) return true;
+	if (j->type == B2D_JOINT_FRICTION || j->type == B2D_JOINT_MOTOR || j->type == B2D_JOINT_MOUSE) return true;
 	return b2dRevoluteSolvePosition(j, A, B);
 }
 

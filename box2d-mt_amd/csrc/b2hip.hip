@@ -168,6 +168,7 @@ struct b2hip_world
 	DevArray<RevoluteJoint> d_joints;
 	DevArray<int> jadjStart, jadj, rootJointStart, rootJointCursor, lj_list, rootJointOkay;
 	std::vector<std::pair<int, int> > pendingFilter; // body pairs whose contacts must be re-filtered (new joint)
+	int nMouseJoints = 0;
 	std::vector<std::pair<int, int> > jointEdits;    // (joint, 1 = also clear the limit impulse, 2 = also the anchors / offsets): members changed by a setter
 	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
 	DevArray<int4> rootScanIn, rootScanOut;
@@ -722,6 +723,19 @@ static int flushEdits(b2hip_world* w)
 		const size_t first = w->upJoints, cnt = w->joints.size() - first;
 		HIP_TRY(hipMemcpyAsync(w->d_joints.p + first, w->joints.data() + first, cnt * sizeof(RevoluteJoint), hipMemcpyHostToDevice, s));
 		w->upJoints = w->joints.size();
+	}
+	if (w->nMouseJoints > 0)
+	{
+		// a mouse joint reads bodyB's mass (b2MouseJoint.cpp:110), which a fixture added later changes
+		for (size_t k = 0; k < w->upJoints; ++k)
+		{
+			JointRec& j = w->joints[k];
+			if (j.type == B2D_JOINT_MOUSE && j.bodyMass != w->bodies[j.bodyB].mass)
+			{
+				j.bodyMass = w->bodies[j.bodyB].mass;
+				w->jointEdits.push_back(std::make_pair((int)k, 2));
+			}
+		}
 	}
 	for (size_t k = 0; k < w->jointEdits.size(); ++k)
 	{
@@ -1960,6 +1974,51 @@ int b2hip_create_pulley_joint(b2hip_world* w, const b2hip_pulley_joint_def* def)
 	j.constant = def->length_a + def->ratio * def->length_b; // b2PulleyJoint.cpp:75
 	j.collideConnected = def->collide_connected;
 	return addJoint(w, j);
+}
+
+int b2hip_create_mouse_joint(b2hip_world* w, const b2hip_mouse_joint_def* def)
+{
+	if (!def) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rc = checkJointBodies(w, def->body_a, def->body_b)) return rc;
+	HostBody& bB = w->bodies[def->body_b];
+	if (!bB.dirty) pullBody(w, def->body_b); // current transform of bodyB
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_MOUSE;
+	j.bodyA = def->body_a;
+	j.bodyB = def->body_b;
+	j.targetA = v2(def->target[0], def->target[1]);
+	// m_localAnchorB = b2MulT(bodyB transform, target) (b2MouseJoint.cpp:45)
+	const float px = def->target[0] - bB.px, py = def->target[1] - bB.py;
+	j.localAnchorB = v2(bB.qc * px + bB.qs * py, -bB.qs * px + bB.qc * py);
+	j.bodyMass = bB.mass;
+	j.maxForce = def->max_force;
+	j.frequencyHz = def->frequency_hz;
+	j.dampingRatio = def->damping_ratio;
+	j.collideConnected = def->collide_connected;
+	w->nMouseJoints += 1;
+	return addJoint(w, j);
+}
+
+int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y)
+{
+	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	JointRec& j = w->joints[joint];
+	if (j.type != B2D_JOINT_MOUSE) return setError(B2HIP_ERR_INVALID, "not a mouse joint");
+	if (x == j.targetA.x && y == j.targetA.y) return 0;
+	if (w->bodies[j.bodyB].type != B2HIP_STATIC_BODY)
+	{
+		markDirty(w, j.bodyB);
+		HostBody& b = w->bodies[j.bodyB];
+		if ((b.flags & BF_AWAKE) == 0)
+		{
+			b.flags |= BF_AWAKE;
+			b.sleepTime = 0.0f;
+		}
+	}
+	j.targetA = v2(x, y);
+	w->jointEdits.push_back(std::make_pair(joint, 2));
+	return 0;
 }
 
 // b2Body::SetAwake(true) on both bodies of a joint whose definition changed (b2RevoluteJoint.cpp:418-500)

@@ -30,6 +30,7 @@
 #include "Box2D/Dynamics/Joints/b2FrictionJoint.h"
 #include "Box2D/Dynamics/Joints/b2MotorJoint.h"
 #include "Box2D/Dynamics/Joints/b2PulleyJoint.h"
+#include "Box2D/Dynamics/Joints/b2MouseJoint.h"
 
 #include "Box2D/MT/b2Task.h"
 #include "Box2D/MT/b2TaskExecutor.h"

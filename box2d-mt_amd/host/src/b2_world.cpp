@@ -328,6 +328,21 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 		id = b2hip_create_pulley_joint(m_hip, &d);
 		if (id >= 0) j = new (b2Alloc(sizeof(b2PulleyJoint))) b2PulleyJoint(pd);
 	}
+	else if (def->type == e_mouseJoint)
+	{
+		const b2MouseJointDef* md = static_cast<const b2MouseJointDef*>(def);
+		b2hip_mouse_joint_def d;
+		d.body_a = md->bodyA->GetDeviceId();
+		d.body_b = md->bodyB->GetDeviceId();
+		d.target[0] = md->target.x;
+		d.target[1] = md->target.y;
+		d.max_force = md->maxForce;
+		d.frequency_hz = md->frequencyHz;
+		d.damping_ratio = md->dampingRatio;
+		d.collide_connected = md->collideConnected;
+		id = b2hip_create_mouse_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2MouseJoint))) b2MouseJoint(md);
+	}
 	else
 	{
 		fprintf(stderr, "b2World::CreateJoint: joint type %d is not on the device path yet\n", (int)def->type);
@@ -971,6 +986,12 @@ void b2PulleyJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& groundA,
 	lengthA = (anchorA - groundA).Length();
 	lengthB = (anchorB - groundB).Length();
 	ratio = r;
+}
+
+void b2MouseJoint::SetTarget(const b2Vec2& target)
+{
+	m_targetA = target;
+	b2hip_joint_set_target(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, target.x, target.y);
 }
 
 // ---- callbacks / collision helpers ----------------------------------------------------------------

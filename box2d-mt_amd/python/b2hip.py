@@ -98,6 +98,11 @@ class PulleyJointDef(C.Structure):
                 ("length_b", C.c_float), ("ratio", C.c_float), ("collide_connected", C.c_int)]
 
 
+class MouseJointDef(C.Structure):
+    _fields_ = [("body_a", C.c_int), ("body_b", C.c_int), ("target", C.c_float * 2), ("max_force", C.c_float),
+                ("frequency_hz", C.c_float), ("damping_ratio", C.c_float), ("collide_connected", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
@@ -139,6 +144,8 @@ def _configure(L, optional_ok=False):
         "b2hip_create_friction_joint": [C.c_void_p, C.POINTER(FrictionJointDef)],
         "b2hip_create_motor_joint": [C.c_void_p, C.POINTER(MotorJointDef)],
         "b2hip_create_pulley_joint": [C.c_void_p, C.POINTER(PulleyJointDef)],
+        "b2hip_create_mouse_joint": [C.c_void_p, C.POINTER(MouseJointDef)],
+        "b2hip_joint_set_target": [C.c_void_p, C.c_int, C.c_float, C.c_float],
         "b2hip_joint_set_offsets": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
         "b2hip_joint_set_motor": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
         "b2hip_joint_set_limits": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
@@ -361,6 +368,15 @@ class World:
         d.ground_anchor_b[0], d.ground_anchor_b[1] = ground_b
         d.length_a, d.length_b, d.ratio = length_a, length_b, ratio
         return _check(self.L.b2hip_create_pulley_joint(self.p, C.byref(d)))
+
+    def create_mouse_joint(self, body_a, body_b, target, max_force, frequency_hz=5.0, damping_ratio=0.7, collide_connected=False):
+        d = self._joint_def(MouseJointDef, body_a, body_b, None, None, collide_connected)
+        d.target[0], d.target[1] = target
+        d.max_force, d.frequency_hz, d.damping_ratio = max_force, frequency_hz, damping_ratio
+        return _check(self.L.b2hip_create_mouse_joint(self.p, C.byref(d)))
+
+    def joint_set_target(self, joint, target):
+        _check(self.L.b2hip_joint_set_target(self.p, joint, target[0], target[1]))
 
     def joint_set_offsets(self, joint, linear_offset, angular_offset):
         _check(self.L.b2hip_joint_set_offsets(self.p, joint, linear_offset[0], linear_offset[1], angular_offset))

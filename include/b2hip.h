@@ -19,6 +19,8 @@
  *   b2hip_create_friction_joint      b2World::CreateJoint (friction)        Joints/b2FrictionJoint.cpp:45-56
  *   b2hip_create_motor_joint         b2World::CreateJoint (motor)           Joints/b2MotorJoint.cpp:48-60
  *   b2hip_create_pulley_joint        b2World::CreateJoint (pulley)          Joints/b2PulleyJoint.cpp:62-79
+ *   b2hip_create_mouse_joint         b2World::CreateJoint (mouse)           Joints/b2MouseJoint.cpp:36-55
+ *   b2hip_joint_set_target           b2MouseJoint::SetTarget                Joints/b2MouseJoint.cpp:57-64
  *   b2hip_joint_set_offsets          b2MotorJoint::SetLinearOffset / SetAngularOffset   Joints/b2MotorJoint.cpp:253-281
  *   b2hip_joint_set_motor            b2{Revolute,Prismatic,Wheel}Joint::EnableMotor / SetMotorSpeed / SetMaxMotor{Torque,Force}
  *                                                                           Joints/b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616
@@ -206,6 +208,17 @@ typedef struct b2hip_pulley_joint_def
 	int collide_connected;
 } b2hip_pulley_joint_def;
 
+/* b2MouseJointDef (Joints/b2MouseJoint.h:27-57): pulls the point of bodyB that lies at `target` (world) when the joint is
+ * created towards wherever the target is moved; bodyA is only bookkeeping (the Testbed passes the ground body) */
+typedef struct b2hip_mouse_joint_def
+{
+	int body_a, body_b;
+	float target[2];
+	float max_force;
+	float frequency_hz, damping_ratio;
+	int collide_connected;
+} b2hip_mouse_joint_def;
+
 /* b2MotorJointDef (Joints/b2MotorJoint.h:26-57): drives bodyB to linear_offset / angular_offset in bodyA's frame */
 typedef struct b2hip_motor_joint_def
 {
@@ -292,6 +305,9 @@ int b2hip_create_rope_joint(b2hip_world* w, const b2hip_rope_joint_def* def);
 int b2hip_create_friction_joint(b2hip_world* w, const b2hip_friction_joint_def* def);
 int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def);
 int b2hip_create_pulley_joint(b2hip_world* w, const b2hip_pulley_joint_def* def);
+int b2hip_create_mouse_joint(b2hip_world* w, const b2hip_mouse_joint_def* def);
+/* b2MouseJoint::SetTarget (b2MouseJoint.cpp:57-64): wakes bodyB when the target moves */
+int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y);
 /* b2MotorJoint::SetLinearOffset + SetAngularOffset (b2MotorJoint.cpp:253-281): wakes both bodies when something changes */
 int b2hip_joint_set_offsets(b2hip_world* w, int joint, float linear_x, float linear_y, float angular);
 /* Revolute / prismatic / wheel (motor only) joints between steps: EnableMotor + SetMotorSpeed + SetMaxMotorTorque|Force in one call, and

@@ -91,6 +91,9 @@ int b2o_create_motor_joint(b2o_world* w, int bodyA, int bodyB, const float* line
 	float maxTorque, float correctionFactor, int collideConnected);
 int b2o_create_pulley_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, const float* groundAnchors4, float lengthA,
 	float lengthB, float ratio, int collideConnected);
+int b2o_create_mouse_joint(b2o_world* w, int bodyA, int bodyB, float tx, float ty, float maxForce, float frequencyHz,
+	float dampingRatio, int collideConnected);
+void b2o_joint_set_target(b2o_world* w, int joint, float tx, float ty);
 void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float angular);
 void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor);
 void b2o_joint_set_limits(b2o_world* w, int joint, int enableLimit, float lower, float upper);

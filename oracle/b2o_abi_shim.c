@@ -121,6 +121,18 @@ int b2hip_create_pulley_joint(b2hip_world* w, const b2hip_pulley_joint_def* def)
 		def->collide_connected);
 }
 
+int b2hip_create_mouse_joint(b2hip_world* w, const b2hip_mouse_joint_def* def)
+{
+	return b2o_create_mouse_joint(w->o, def->body_a, def->body_b, def->target[0], def->target[1], def->max_force, def->frequency_hz,
+		def->damping_ratio, def->collide_connected);
+}
+
+int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y)
+{
+	b2o_joint_set_target(w->o, joint, x, y);
+	return 0;
+}
+
 int b2hip_joint_set_offsets(b2hip_world* w, int joint, float lx, float ly, float angular)
 {
 	b2o_joint_set_offsets(w->o, joint, lx, ly, angular);

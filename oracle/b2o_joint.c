@@ -3,7 +3,7 @@
  * b2DistanceJoint (Joints/b2DistanceJoint.cpp:65-225), b2PrismaticJoint (Joints/b2PrismaticJoint.cpp:130-478),
  * b2WeldJoint (Joints/b2WeldJoint.cpp:58-303), b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
  * (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint (Joints/b2MotorJoint.cpp:62-203),
- * b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
+ * b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253), b2MouseJoint (Joints/b2MouseJoint.cpp:99-198); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
  * TEST INFRASTRUCTURE (see b2o.h). */
 #include "b2o_joint.h"
 
@@ -1144,4 +1144,66 @@ int b2o_pulley_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, floa
 	*cB = v_add(*cB, v_scale(j->invMassB, PB));
 	*aB += j->invIB * v_cross(rB, PB);
 	return linearError < B2O_LINEAR_SLOP;
+}
+
+/* ---- mouse joint -------------------------------------------------------------------------------- */
+/* InitVelocityConstraints b2MouseJoint.cpp:99-163 */
+void b2o_mouse_init(revolute_t* j, float massB, float mB, float iB, vec2 lcB, vec2 cB, float aB, vec2* vB, float* wB,
+	int warmStarting, float dtRatio, float dt)
+{
+	j->localCenterB = lcB;
+	j->invMassB = mB; j->invIB = iB;
+	rot qB = r_make(aB);
+	float omega = 2.0f * B2O_PI * j->frequencyHz;
+	float d = 2.0f * massB * j->dampingRatio * omega;
+	float k = massB * (omega * omega);
+	j->gamma = dt * (d + dt * k);
+	if (j->gamma != 0.0f) j->gamma = 1.0f / j->gamma;
+	j->beta = dt * k * j->gamma;
+	j->rB = r_mul(qB, v_sub(j->localAnchorB, lcB));
+	float kxx = mB + iB * j->rB.y * j->rB.y + j->gamma;
+	float kxy = -iB * j->rB.x * j->rB.y;
+	float kyy = mB + iB * j->rB.x * j->rB.x + j->gamma;
+	float a = kxx, b = kxy, c = kxy, dd = kyy;
+	float det = a * dd - b * c;
+	if (det != 0.0f) det = 1.0f / det;
+	j->linearMass[0] = det * dd; j->linearMass[2] = -det * b;
+	j->linearMass[1] = -det * c; j->linearMass[3] = det * a;
+	j->mouseC = v_sub(v_add(cB, j->rB), j->localAnchorA);
+	j->mouseC.x *= j->beta;
+	j->mouseC.y *= j->beta;
+	*wB *= 0.98f;
+	if (warmStarting)
+	{
+		j->impulse[0] *= dtRatio; j->impulse[1] *= dtRatio;
+		vec2 P = v_make(j->impulse[0], j->impulse[1]);
+		*vB = v_add(*vB, v_scale(mB, P));
+		*wB += iB * v_cross(j->rB, P);
+	}
+	else
+	{
+		j->impulse[0] = j->impulse[1] = 0.0f;
+	}
+}
+
+/* SolveVelocityConstraints :165-192 */
+void b2o_mouse_velocity(revolute_t* j, vec2* vB, float* wB, float dt)
+{
+	vec2 Cdot = v_add(*vB, v_cross_sv(*wB, j->rB));
+	vec2 old = v_make(j->impulse[0], j->impulse[1]);
+	vec2 rhs = v_neg(v_add(v_add(Cdot, j->mouseC), v_scale(j->gamma, old)));
+	vec2 impulse = v_make(j->linearMass[0] * rhs.x + j->linearMass[2] * rhs.y, j->linearMass[1] * rhs.x + j->linearMass[3] * rhs.y);
+	vec2 acc = v_add(old, impulse);
+	float maxImpulse = dt * j->maxForce;
+	if (v_dot(acc, acc) > maxImpulse * maxImpulse)
+	{
+		float s = maxImpulse / v_length(acc);
+		acc.x *= s;
+		acc.y *= s;
+	}
+	j->impulse[0] = acc.x;
+	j->impulse[1] = acc.y;
+	impulse = v_sub(acc, old);
+	*vB = v_add(*vB, v_scale(j->invMassB, impulse));
+	*wB += j->invIB * v_cross(j->rB, impulse);
 }

@@ -1,11 +1,11 @@
-/* b2o_joint.h - CPU oracle, joint state: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley (TEST INFRASTRUCTURE, see b2o.h). */
+/* b2o_joint.h - CPU oracle, joint state: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley, mouse (TEST INFRASTRUCTURE, see b2o.h). */
 #ifndef B2O_JOINT_H
 #define B2O_JOINT_H
 
 #include "b2o_internal.h"
 
 enum { B2O_JOINT_REVOLUTE = 0, B2O_JOINT_DISTANCE = 1, B2O_JOINT_PRISMATIC = 2, B2O_JOINT_WELD = 3,
-	B2O_JOINT_WHEEL = 4, B2O_JOINT_ROPE = 5, B2O_JOINT_FRICTION = 6, B2O_JOINT_MOTOR = 7, B2O_JOINT_PULLEY = 8 };
+	B2O_JOINT_WHEEL = 4, B2O_JOINT_ROPE = 5, B2O_JOINT_FRICTION = 6, B2O_JOINT_MOTOR = 7, B2O_JOINT_PULLEY = 8, B2O_JOINT_MOUSE = 9 };
 
 typedef struct
 {
@@ -45,6 +45,9 @@ typedef struct
 	/* pulley joint (b2PulleyJoint.h:118-150): impulse[0], mass */
 	vec2 groundAnchorA, groundAnchorB, uA, uB;
 	float ratio, constant;
+	/* mouse joint (b2MouseJoint.h:101-126): m_targetA = localAnchorA, impulse[0..1], m_mass in linearMass, m_C, m_beta; gamma above */
+	vec2 mouseC;
+	float beta;
 	int islandFlag;
 	int nextA, nextB; /* per-body joint lists, newest first: edge id = joint * 2 + side */
 } revolute_t;
@@ -91,5 +94,10 @@ void b2o_pulley_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, floa
 	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
 void b2o_pulley_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB);
 int b2o_pulley_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+/* acts on bodyB only; no position step (b2MouseJoint.cpp:194-198) */
+void b2o_mouse_init(revolute_t* j, float massB, float mB, float iB, vec2 lcB, vec2 cB, float aB, vec2* vB, float* wB,
+	int warmStarting, float dtRatio, float dt);
+void b2o_mouse_velocity(revolute_t* j, vec2* vB, float* wB, float dt);
 
 #endif

@@ -5,7 +5,7 @@
  * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
- * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley (b2o_joint.c). Not covered (same as the device
+ * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley, mouse (b2o_joint.c). Not covered (same as the device
  * path): other joint types, chain shapes. Continuous collision: b2o_toi.c
  * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
@@ -520,7 +520,32 @@ int b2o_create_pulley_joint(b2o_world* w, int bodyA, int bodyB, const float* anc
 	return id;
 }
 
+/* b2MouseJoint::b2MouseJoint (b2MouseJoint.cpp:36-55): the anchor on bodyB is where the target lies at creation */
+int b2o_create_mouse_joint(b2o_world* w, int bodyA, int bodyB, float tx, float ty, float maxForce, float frequencyHz,
+	float dampingRatio, int collideConnected)
+{
+	vec2 target = v_make(tx, ty);
+	vec2 local = xf_mul_tv(w->bodies[bodyB].xf, target);
+	float anchors[4] = { tx, ty, local.x, local.y };
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors, 0.0f, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	j->type = B2O_JOINT_MOUSE;
+	j->maxForce = maxForce;
+	j->frequencyHz = frequencyHz;
+	j->dampingRatio = dampingRatio;
+	return id;
+}
+
 static void set_awake(body_t* b);
+
+/* b2MouseJoint::SetTarget (b2MouseJoint.cpp:57-64): wakes bodyB only */
+void b2o_joint_set_target(b2o_world* w, int joint, float tx, float ty)
+{
+	revolute_t* j = &w->joints[joint];
+	if (tx == j->localAnchorA.x && ty == j->localAnchorA.y) return;
+	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	j->localAnchorA = v_make(tx, ty);
+}
 
 /* b2MotorJoint::SetLinearOffset / SetAngularOffset (b2MotorJoint.cpp:253-281) */
 void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float angular)
@@ -1349,6 +1374,10 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			b2o_friction_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
 				positions[ia].a, vA, wA, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
 			break;
+		case B2O_JOINT_MOUSE:
+			b2o_mouse_init(j, bB->mass, bB->invMass, bB->invI, bB->localCenter, positions[ib].c, positions[ib].a, vB, wB,
+				w->warmStarting, dtRatio, h);
+			break;
 		case B2O_JOINT_PULLEY:
 			b2o_pulley_init(j, bA->invMass, bA->invI, bA->localCenter, bB->invMass, bB->invI, bB->localCenter,
 				positions[ia].c, positions[ia].a, vA, wA, positions[ib].c, positions[ib].a, vB, wB, w->warmStarting, dtRatio);
@@ -1378,6 +1407,7 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			case B2O_JOINT_WHEEL: b2o_wheel_velocity(j, vA, wA, vB, wB, h); break;
 			case B2O_JOINT_ROPE: b2o_rope_velocity(j, vA, wA, vB, wB, 1.0f / h); break;
 			case B2O_JOINT_PULLEY: b2o_pulley_velocity(j, vA, wA, vB, wB); break;
+			case B2O_JOINT_MOUSE: b2o_mouse_velocity(j, vB, wB, h); break;
 			case B2O_JOINT_FRICTION: b2o_friction_velocity(j, vA, wA, vB, wB, h); break;
 			case B2O_JOINT_MOTOR: b2o_motor_velocity(j, vA, wA, vB, wB, h, 1.0f / h); break;
 			default: b2o_revolute_velocity(j, vA, wA, vB, wB, h);
@@ -1437,7 +1467,7 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			case B2O_JOINT_WHEEL: ok = b2o_wheel_position(j, cA, aA, cB, aB); break;
 			case B2O_JOINT_ROPE: ok = b2o_rope_position(j, cA, aA, cB, aB); break;
 			case B2O_JOINT_PULLEY: ok = b2o_pulley_position(j, cA, aA, cB, aB); break;
-			case B2O_JOINT_FRICTION: case B2O_JOINT_MOTOR: ok = 1; break;
+			case B2O_JOINT_FRICTION: case B2O_JOINT_MOTOR: case B2O_JOINT_MOUSE: ok = 1; break;
 			default: ok = b2o_revolute_position(j, cA, aA, cB, aB);
 			}
 			jointsOkay = jointsOkay && ok;

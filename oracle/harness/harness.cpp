@@ -125,6 +125,11 @@ void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
 			const bool atLower = speed < 0.0f && at <= slider->GetLowerLimit() + b2_epsilon;
 			if (atUpper || atLower) slider->SetMotorSpeed(-slider->GetMotorSpeed());
 		}
+		if (h->scene.drag != NULL)
+		{
+			const float t = 0.04f * (float)h->scene.servoStep;
+			static_cast<b2MouseJoint*>(h->scene.drag)->SetTarget(b2Vec2(10.5f + 4.0f * sinf(t), 5.0f + 2.0f * sinf(2.0f * t + 1.0f)));
+		}
 		if (!h->scene.servos.empty())
 		{
 			// motor-joint targets move on a figure of eight (the way the Testbed's MotorJoint scene drives its own: new offsets each step)

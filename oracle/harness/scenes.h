@@ -77,7 +77,8 @@ enum SceneId
 	                     //   a welded free-falling pair), two pulleys, bodies dropped over all of them
 	e_vehicles = 11,     // p0 = falling bodies, p1 = cars ; wheel joints (cars with sprung, motor-driven wheels over bumps, one
 	                     //   with a rigid axle), rope joints (weights on slack and taut tethers), friction joints (pucks braked
-	                     //   against the ground) and motor joints (platforms servoed to a pose the step loop keeps moving)
+	                     //   against the ground), motor joints (platforms servoed to a pose the step loop keeps moving) and a
+	                     //   mouse joint dragging a crate round a circle
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -94,12 +95,13 @@ struct Scene
 {
 	std::vector<b2Body*> bodies; // creation order == body index used by every dump
 	b2Joint* joint;
+	b2Joint* drag;                // mouse joint whose target the step loop moves on a circle
 	std::vector<b2Joint*> servos; // motor joints whose linear / angular offset the step loop moves along a fixed path
 	int servoStep;
 	bool sliderBounces; // joint is a prismatic motor slider whose motor is reversed by the step loop at either limit
 	float dtDefault;
 	int velIters, posIters;
-	Scene() : joint(NULL), servoStep(0), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
+	Scene() : joint(NULL), drag(NULL), servoStep(0), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
 };
 
 inline b2Body* AddBody(Scene& s, b2World* w, const b2BodyDef& bd)
@@ -903,6 +905,23 @@ inline void BuildVehicles(Scene& s, b2World* w, int count, int cars, uint32_t se
 		jd.maxTorque = 1000.0f;
 		jd.correctionFactor = 0.3f + 0.2f * (float)i;
 		s.servos.push_back(w->CreateJoint(&jd));
+	}
+	// a crate picked up off-centre by a mouse joint (as Test::MouseDown does: ground as bodyA, force cap 1000 x mass)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(10.0f, 3.0f);
+		bd.angle = 0.3f;
+		b2Body* crate = AddBody(s, w, bd);
+		b2PolygonShape box;
+		box.SetAsBox(0.8f, 0.6f);
+		crate->CreateFixture(&box, 2.0f);
+		b2MouseJointDef jd;
+		jd.bodyA = ground;
+		jd.bodyB = crate;
+		jd.target.Set(10.5f, 3.3f);
+		jd.maxForce = 1000.0f * crate->GetMass();
+		s.drag = w->CreateJoint(&jd);
 	}
 	for (int i = 0; i < count; ++i)
 	{
