@@ -1,6 +1,6 @@
 // b2d_joint.h - joint constraints on the device path: revolute (Tumbler's motor), distance (rigid rods and
 // soft springs), prismatic (MultithreadDemo's slider: axis, limits, motor), weld (rigid or soft), wheel (suspension
-// spring + axle motor), rope (maximum distance), friction and motor (top-down drag / pose servo), pulley, mouse (drag a body to a target). One fixed-size record per joint whatever its type (the type-specific members share storage), so
+// spring + axle motor), rope (maximum distance), friction and motor (top-down drag / pose servo), pulley, mouse (drag a body to a target), gear (couples two revolute / prismatic joints: four bodies, own record). One fixed-size record per joint whatever its type (the type-specific members share storage), so
 // the island kernels, the upload and the snapshot handle one array.
 // Restates b2RevoluteJoint::{InitVelocityConstraints, SolveVelocityConstraints, SolvePositionConstraints}
 // (Box2D/Dynamics/Joints/b2RevoluteJoint.cpp:65-376) and the same three of b2DistanceJoint
@@ -9,7 +9,7 @@
 // GetSymInverse33 as in Box2D/Common/b2Math.cpp:25-94. Also b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
 // (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint
 // (Joints/b2MotorJoint.cpp:62-203), b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253),
-// b2MouseJoint (Joints/b2MouseJoint.cpp:99-198).
+// b2MouseJoint (Joints/b2MouseJoint.cpp:99-198), b2GearJoint (Joints/b2GearJoint.cpp:131-390).
 #ifndef B2D_JOINT_H
 #define B2D_JOINT_H
 
@@ -36,7 +36,8 @@ enum
 	B2D_JOINT_FRICTION = 6, // e_frictionJoint
 	B2D_JOINT_MOTOR = 7,    // e_motorJoint
 	B2D_JOINT_PULLEY = 8,   // e_pulleyJoint
-	B2D_JOINT_MOUSE = 9     // e_mouseJoint
+	B2D_JOINT_MOUSE = 9,    // e_mouseJoint
+	B2D_JOINT_GEAR = 10     // e_gearJoint: the JointRec carries bodyA / bodyB and, in enableLimit, the index of its GearRec
 };
 
 struct JointRec
@@ -1552,6 +1553,150 @@ B2D_HD void b2dMouseSolveVelocity(JointRec* j, BodyVel* B, float dt)
 	vB += j->invMassB * impulse;
 	wB += j->invIB * b2dCross(rB, impulse);
 	B->v = vB; B->w = wB;
+}
+
+// ---- gear joint -------------------------------------------------------------------------------------
+// coordinateA + ratio * coordinateB = constant, where a coordinate is the angle of a revolute joint or the translation of a
+// prismatic joint. Bodies A and B are the moving bodies of the two joints, C and D the bodies they are attached to.
+struct GearRec
+{
+	// definition, derived from the two joints at creation (b2GearJoint.cpp:50-129)
+	int bodyC, bodyD;
+	int typeA, typeB;                 // B2D_JOINT_REVOLUTE or B2D_JOINT_PRISMATIC
+	V2 localAnchorA, localAnchorB, localAnchorC, localAnchorD;
+	V2 localAxisC, localAxisD;
+	float referenceAngleA, referenceAngleB;
+	float ratio, constant;
+	// persistent
+	float impulse;
+	// per-step scratch written by init
+	V2 lcA, lcB, lcC, lcD;
+	float mA, mB, mC, mD, iA, iB, iC, iD;
+	V2 JvAC, JvBD;
+	float JwA, JwB, JwC, JwD;
+	float mass;
+};
+
+struct GearBodies
+{
+	BodyPos pA, pB, pC, pD;
+	BodyVel vA, vB, vC, vD;
+};
+
+// the Jacobian of one side (b2GearJoint.cpp:159-195 and again :276-331); returns the side's share of the effective mass
+B2D_HD float b2dGearSide(int type, float scale, V2 localAxis, V2 localAnchorFixed, V2 lcFixed, V2 localAnchorMoving, V2 lcMoving,
+	float aFixed, float aMoving, float mFixed, float mMoving, float iFixed, float iMoving, V2* Jv, float* JwMoving, float* JwFixed,
+	bool isB)
+{
+	if (type == B2D_JOINT_REVOLUTE)
+	{
+		*Jv = v2(0.0f, 0.0f);
+		*JwMoving = scale;
+		*JwFixed = scale;
+		return isB ? scale * scale * (iMoving + iFixed) : iMoving + iFixed;
+	}
+	Rot qF = b2dRot(aFixed), qM = b2dRot(aMoving);
+	V2 u = b2dMulRV(qF, localAxis);
+	V2 rF = b2dMulRV(qF, localAnchorFixed - lcFixed);
+	V2 rM = b2dMulRV(qM, localAnchorMoving - lcMoving);
+	if (isB)
+	{
+		*Jv = scale * u;
+		*JwFixed = scale * b2dCross(rF, u);
+		*JwMoving = scale * b2dCross(rM, u);
+		return scale * scale * (mFixed + mMoving) + iFixed * *JwFixed * *JwFixed + iMoving * *JwMoving * *JwMoving;
+	}
+	*Jv = u;
+	*JwFixed = b2dCross(rF, u);
+	*JwMoving = b2dCross(rM, u);
+	return mFixed + mMoving + iFixed * *JwFixed * *JwFixed + iMoving * *JwMoving * *JwMoving;
+}
+
+// InitVelocityConstraints (b2GearJoint.cpp:131-222)
+B2D_HD void b2dGearInit(GearRec* g, GearBodies* b, float4 massA, float4 massB, float4 massC, float4 massD, bool warmStarting)
+{
+	g->mA = massA.x; g->iA = massA.y; g->lcA = v2(massA.z, massA.w);
+	g->mB = massB.x; g->iB = massB.y; g->lcB = v2(massB.z, massB.w);
+	g->mC = massC.x; g->iC = massC.y; g->lcC = v2(massC.z, massC.w);
+	g->mD = massD.x; g->iD = massD.y; g->lcD = v2(massD.z, massD.w);
+	float mass = 0.0f;
+	mass += b2dGearSide(g->typeA, 1.0f, g->localAxisC, g->localAnchorC, g->lcC, g->localAnchorA, g->lcA, b->pC.a, b->pA.a,
+		g->mC, g->mA, g->iC, g->iA, &g->JvAC, &g->JwA, &g->JwC, false);
+	mass += b2dGearSide(g->typeB, g->ratio, g->localAxisD, g->localAnchorD, g->lcD, g->localAnchorB, g->lcB, b->pD.a, b->pB.a,
+		g->mD, g->mB, g->iD, g->iB, &g->JvBD, &g->JwB, &g->JwD, true);
+	g->mass = mass > 0.0f ? 1.0f / mass : 0.0f;
+	if (warmStarting)
+	{
+		b->vA.v += (g->mA * g->impulse) * g->JvAC;
+		b->vA.w += g->iA * g->impulse * g->JwA;
+		b->vB.v += (g->mB * g->impulse) * g->JvBD;
+		b->vB.w += g->iB * g->impulse * g->JwB;
+		b->vC.v -= (g->mC * g->impulse) * g->JvAC;
+		b->vC.w -= g->iC * g->impulse * g->JwC;
+		b->vD.v -= (g->mD * g->impulse) * g->JvBD;
+		b->vD.w -= g->iD * g->impulse * g->JwD;
+	}
+	else
+	{
+		g->impulse = 0.0f;
+	}
+}
+
+// SolveVelocityConstraints (b2GearJoint.cpp:224-258)
+B2D_HD void b2dGearSolveVelocity(GearRec* g, GearBodies* b)
+{
+	float Cdot = b2dDot(g->JvAC, b->vA.v - b->vC.v) + b2dDot(g->JvBD, b->vB.v - b->vD.v);
+	Cdot += (g->JwA * b->vA.w - g->JwC * b->vC.w) + (g->JwB * b->vB.w - g->JwD * b->vD.w);
+	float impulse = -g->mass * Cdot;
+	g->impulse += impulse;
+	b->vA.v += (g->mA * impulse) * g->JvAC;
+	b->vA.w += g->iA * impulse * g->JwA;
+	b->vB.v += (g->mB * impulse) * g->JvBD;
+	b->vB.w += g->iB * impulse * g->JwB;
+	b->vC.v -= (g->mC * impulse) * g->JvAC;
+	b->vC.w -= g->iC * impulse * g->JwC;
+	b->vD.v -= (g->mD * impulse) * g->JvBD;
+	b->vD.w -= g->iD * impulse * g->JwD;
+}
+
+// one side's coordinate at the current positions (b2GearJoint.cpp:284-305, :313-334)
+B2D_HD float b2dGearCoordinate(int type, V2 localAxis, V2 localAnchorFixed, V2 lcFixed, V2 localAnchorMoving, V2 lcMoving, BodyPos pF,
+	BodyPos pM, float referenceAngle)
+{
+	if (type == B2D_JOINT_REVOLUTE) return pM.a - pF.a - referenceAngle;
+	Rot qF = b2dRot(pF.a), qM = b2dRot(pM.a);
+	V2 rM = b2dMulRV(qM, localAnchorMoving - lcMoving);
+	V2 pFix = localAnchorFixed - lcFixed;
+	V2 pMov = b2dMulTRV(qF, rM + (pM.c - pF.c));
+	return b2dDot(pMov - pFix, localAxis);
+}
+
+// SolvePositionConstraints (b2GearJoint.cpp:260-362); its linear error is never updated from zero, so it always reports success
+B2D_HD bool b2dGearSolvePosition(const GearRec* g, GearBodies* b)
+{
+	V2 JvAC, JvBD;
+	float JwA, JwB, JwC, JwD;
+	float mass = 0.0f;
+	mass += b2dGearSide(g->typeA, 1.0f, g->localAxisC, g->localAnchorC, g->lcC, g->localAnchorA, g->lcA, b->pC.a, b->pA.a,
+		g->mC, g->mA, g->iC, g->iA, &JvAC, &JwA, &JwC, false);
+	float coordinateA = b2dGearCoordinate(g->typeA, g->localAxisC, g->localAnchorC, g->lcC, g->localAnchorA, g->lcA, b->pC, b->pA,
+		g->referenceAngleA);
+	mass += b2dGearSide(g->typeB, g->ratio, g->localAxisD, g->localAnchorD, g->lcD, g->localAnchorB, g->lcB, b->pD.a, b->pB.a,
+		g->mD, g->mB, g->iD, g->iB, &JvBD, &JwB, &JwD, true);
+	float coordinateB = b2dGearCoordinate(g->typeB, g->localAxisD, g->localAnchorD, g->lcD, g->localAnchorB, g->lcB, b->pD, b->pB,
+		g->referenceAngleB);
+	float C = (coordinateA + g->ratio * coordinateB) - g->constant;
+	float impulse = 0.0f;
+	if (mass > 0.0f) impulse = -C / mass;
+	b->pA.c += g->mA * impulse * JvAC;
+	b->pA.a += g->iA * impulse * JwA;
+	b->pB.c += g->mB * impulse * JvBD;
+	b->pB.a += g->iB * impulse * JwB;
+	b->pC.c -= g->mC * impulse * JvAC;
+	b->pC.a -= g->iC * impulse * JwC;
+	b->pD.c -= g->mD * impulse * JvBD;
+	b->pD.a -= g->iD * impulse * JwD;
+	return true;
 }
 
 // ---- dispatch on the joint type (b2Joint's virtual calls, b2Island.cpp:235-318) -------------------------

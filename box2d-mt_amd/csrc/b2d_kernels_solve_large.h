@@ -713,6 +713,41 @@ __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mo
 		for (int t = 0; t < nj; ++t)
 		{
 			JointRec* j = &W.joints[W.lj_list[start + t]];
+			if (j->type == B2D_JOINT_GEAR)
+			{
+				// four bodies; loaded into separate copies and written back A, B, C, D like the reference does
+				GearRec* g = &W.gears[j->enableLimit];
+				const int ids[4] = { j->bodyA, j->bodyB, g->bodyC, g->bodyD };
+				bool ns[4];
+				float4 p4[4], v4[4];
+				GearBodies gb;
+				BodyPos* gp[4] = { &gb.pA, &gb.pB, &gb.pC, &gb.pD };
+				BodyVel* gv[4] = { &gb.vA, &gb.vB, &gb.vC, &gb.vD };
+				for (int q = 0; q < 4; ++q)
+				{
+					ns[q] = (W.b_flags[ids[q]] & BF_TYPE_MASK) != BT_STATIC;
+					p4[q] = W.b_pos[ids[q]];
+					v4[q] = W.b_vel[ids[q]];
+					gp[q]->c = v2(p4[q].x, p4[q].y); gp[q]->a = p4[q].z;
+					gv[q]->v = ns[q] ? v2(v4[q].x, v4[q].y) : v2(0, 0); gv[q]->w = ns[q] ? v4[q].z : 0.0f;
+				}
+				if (mode == 2)
+				{
+					b2dGearSolvePosition(g, &gb);
+					for (int q = 0; q < 4; ++q)
+						if (ns[q]) W.b_pos[ids[q]] = make_float4(gp[q]->c.x, gp[q]->c.y, gp[q]->a, p4[q].w);
+				}
+				else
+				{
+					if (mode == 0)
+						b2dGearInit(g, &gb, W.b_mass[ids[0]], W.b_mass[ids[1]], W.b_mass[ids[2]], W.b_mass[ids[3]], sp.warmStarting != 0);
+					else
+						b2dGearSolveVelocity(g, &gb);
+					for (int q = 0; q < 4; ++q)
+						if (ns[q]) W.b_vel[ids[q]] = make_float4(gv[q]->v.x, gv[q]->v.y, gv[q]->w, 0.0f);
+				}
+				continue;
+			}
 			const int bA = j->bodyA, bB = j->bodyB;
 			const bool nsA = (W.b_flags[bA] & BF_TYPE_MASK) != BT_STATIC;
 			const bool nsB = (W.b_flags[bB] & BF_TYPE_MASK) != BT_STATIC;

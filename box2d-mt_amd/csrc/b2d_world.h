@@ -172,6 +172,7 @@ struct DW
 
 	// ---- joints -----------------------------------------------------------------------------
 	RevoluteJoint* joints;
+	GearRec* gears;      // gear joints' own records (JointRec::enableLimit indexes it)
 	int* jadjStart;      // per body: its joint edges, newest first (b2World::CreateJoint pushes at the list head)
 	int* jadj;
 	int* rootJointStart; // per root: segment of lj_list (exclusive scan of rootJoints)

@@ -166,9 +166,12 @@ struct b2hip_world
 	DevArray<int4> li_ref;
 	DevArray<uint64_t> ht_keys;
 	DevArray<RevoluteJoint> d_joints;
+	DevArray<GearRec> d_gears;
 	DevArray<int> jadjStart, jadj, rootJointStart, rootJointCursor, lj_list, rootJointOkay;
 	std::vector<std::pair<int, int> > pendingFilter; // body pairs whose contacts must be re-filtered (new joint)
 	int nMouseJoints = 0;
+	std::vector<GearRec> gears;   // gear joints' own records, appended like joints (the device copy keeps the impulses)
+	size_t upGears = 0;
 	std::vector<std::pair<int, int> > jointEdits;    // (joint, 1 = also clear the limit impulse, 2 = also the anchors / offsets): members changed by a setter
 	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
 	DevArray<int4> rootScanIn, rootScanOut;
@@ -544,6 +547,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_proxyHead, nb); ENS(p_next, np);
 	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
 	ENS(d_joints, std::max<size_t>(w->joints.size(), 1));
+	ENS(d_gears, std::max<size_t>(w->gears.size(), 1));
 	ENS(jadjStart, nb + 2); ENS(jadj, 2 * w->joints.size() + 2); ENS(rootJointStart, nb + 2); ENS(rootJointCursor, nb);
 	ENS(lj_list, w->joints.size() + 2); ENS(rootJointOkay, nb);
 	const size_t capPairs = std::max<size_t>(std::max<size_t>(8 * np + 4096, w->pairKey.cap), w->pairCapHint);
@@ -631,6 +635,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	}
 	d.ht_keys = w->ht_keys.p;
 	d.joints = w->d_joints.p;
+	d.gears = w->d_gears.p;
 	d.jadjStart = w->jadjStart.p; d.jadj = w->jadj.p; d.rootJointStart = w->rootJointStart.p;
 	d.rootJointCursor = w->rootJointCursor.p; d.lj_list = w->lj_list.p; d.rootJointOkay = w->rootJointOkay.p;
 	d.parent = w->parent.p; d.rootSeed = w->rootSeed.p; d.rootBodies = w->rootBodies.p; d.rootContacts = w->rootContacts.p;
@@ -723,6 +728,12 @@ static int flushEdits(b2hip_world* w)
 		const size_t first = w->upJoints, cnt = w->joints.size() - first;
 		HIP_TRY(hipMemcpyAsync(w->d_joints.p + first, w->joints.data() + first, cnt * sizeof(RevoluteJoint), hipMemcpyHostToDevice, s));
 		w->upJoints = w->joints.size();
+	}
+	if (w->upGears != w->gears.size())
+	{
+		const size_t first = w->upGears, cnt = w->gears.size() - first;
+		HIP_TRY(hipMemcpyAsync(w->d_gears.p + first, w->gears.data() + first, cnt * sizeof(GearRec), hipMemcpyHostToDevice, s));
+		w->upGears = w->gears.size();
 	}
 	if (w->nMouseJoints > 0)
 	{
@@ -1623,7 +1634,7 @@ void b2hip_world_destroy(b2hip_world* w)
 		w->c_ids[k].release(); w->c_key[k].release(); w->c_flags[k].release(); w->c_mat[k].release(); w->c_man0[k].release();
 		w->c_man1[k].release(); w->c_imp[k].release(); w->c_man3[k].release(); w->c_color[k].release();
 	}
-	w->ht_keys.release(); w->d_joints.release(); w->li_ref.release();
+	w->ht_keys.release(); w->d_joints.release(); w->d_gears.release(); w->li_ref.release();
 	w->jadjStart.release(); w->jadj.release(); w->rootJointStart.release(); w->rootJointCursor.release();
 	w->lj_list.release(); w->rootJointOkay.release();
 	w->parent.release(); w->rootSeed.release(); w->rootBodies.release(); w->rootContacts.release(); w->rootJoints.release();
@@ -2019,6 +2030,55 @@ int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y)
 	j.targetA = v2(x, y);
 	w->jointEdits.push_back(std::make_pair(joint, 2));
 	return 0;
+}
+
+// b2GearJoint::b2GearJoint (b2GearJoint.cpp:50-129): everything is derived from the two joints and the bodies' current poses
+static float gearCoordinate(b2hip_world* w, const JointRec& jt, int moving, int fixed)
+{
+	const HostBody& bm = w->bodies[moving];
+	const HostBody& bf = w->bodies[fixed];
+	if (jt.type == B2D_JOINT_REVOLUTE) return bm.a - bf.a - jt.referenceAngle;
+	// pA = b2MulT(xfC.q, b2Mul(xfA.q, m_localAnchorA) + (xfA.p - xfC.p)); coordinate = b2Dot(pA - pC, m_localAxisC)
+	const V2 la = jt.localAnchorB, lc = jt.localAnchorA;
+	const V2 wa = v2(bm.qc * la.x - bm.qs * la.y, bm.qs * la.x + bm.qc * la.y) + v2(bm.px - bf.px, bm.py - bf.py);
+	const V2 pa = v2(bf.qc * wa.x + bf.qs * wa.y, -bf.qs * wa.x + bf.qc * wa.y);
+	return b2dDot(pa - lc, jt.localAxisA);
+}
+
+int b2hip_create_gear_joint(b2hip_world* w, const b2hip_gear_joint_def* def)
+{
+	if (!w || !def) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int nj = (int)w->joints.size();
+	if (def->joint1 < 0 || def->joint1 >= nj || def->joint2 < 0 || def->joint2 >= nj) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	const JointRec j1 = w->joints[def->joint1], j2 = w->joints[def->joint2];
+	if ((j1.type != B2D_JOINT_REVOLUTE && j1.type != B2D_JOINT_PRISMATIC) || (j2.type != B2D_JOINT_REVOLUTE && j2.type != B2D_JOINT_PRISMATIC))
+		return setError(B2HIP_ERR_INVALID, "a gear joint connects revolute and / or prismatic joints");
+	const int ids[4] = { j1.bodyB, j2.bodyB, j1.bodyA, j2.bodyA }; // A, B, C, D
+	for (int k = 0; k < 4; ++k)
+		if (!w->bodies[ids[k]].dirty) pullBody(w, ids[k]);
+	GearRec g;
+	memset(&g, 0, sizeof(g));
+	g.bodyC = ids[2];
+	g.bodyD = ids[3];
+	g.typeA = j1.type;
+	g.typeB = j2.type;
+	g.localAnchorC = j1.localAnchorA; g.localAnchorA = j1.localAnchorB; g.referenceAngleA = j1.referenceAngle;
+	g.localAxisC = j1.type == B2D_JOINT_PRISMATIC ? j1.localAxisA : v2(0.0f, 0.0f);
+	g.localAnchorD = j2.localAnchorA; g.localAnchorB = j2.localAnchorB; g.referenceAngleB = j2.referenceAngle;
+	g.localAxisD = j2.type == B2D_JOINT_PRISMATIC ? j2.localAxisA : v2(0.0f, 0.0f);
+	const float coordinateA = gearCoordinate(w, j1, ids[0], ids[2]);
+	const float coordinateB = gearCoordinate(w, j2, ids[1], ids[3]);
+	g.ratio = def->ratio;
+	g.constant = coordinateA + g.ratio * coordinateB;
+	JointRec j;
+	memset(&j, 0, sizeof(j));
+	j.type = B2D_JOINT_GEAR;
+	j.bodyA = ids[0];
+	j.bodyB = ids[1];
+	j.enableLimit = (int)w->gears.size();
+	j.collideConnected = def->collide_connected;
+	w->gears.push_back(g);
+	return addJoint(w, j);
 }
 
 // b2Body::SetAwake(true) on both bodies of a joint whose definition changed (b2RevoluteJoint.cpp:418-500)
@@ -2622,6 +2682,12 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	SNAP_DEV(c_ids[cur], nC); SNAP_DEV(c_key[cur], nC); SNAP_DEV(c_flags[cur], nC); SNAP_DEV(c_mat[cur], nC); SNAP_DEV(c_man0[cur], nC);
 	SNAP_DEV(c_man1[cur], nC); SNAP_DEV(c_imp[cur], nC); SNAP_DEV(c_man3[cur], nC); SNAP_DEV(c_color[cur], nC); SNAP_DEV(c_mgr[cur], nC);
 	SNAP_DEV(toiPos2c, nT); SNAP_DEV(moveBuf, nM);
+	{
+		// trailing section (absent in snapshots of worlds saved before gear joints existed): the gear records
+		const uint32_t tail[2] = { (uint32_t)w->gears.size(), (uint32_t)sizeof(GearRec) };
+		o.host(tail, sizeof(tail));
+		SNAP_DEV(d_gears, w->gears.size());
+	}
 #undef SNAP_DEV
 	*needed = o.out.size();
 	if (cap >= o.out.size()) memcpy(buffer, o.out.data(), o.out.size());
@@ -2689,6 +2755,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 		const void* src = in.take((size_t)h.nJoints * sizeof(RevoluteJoint));
 		if (!src) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
 		if (h.nJoints) memcpy(w->joints.data(), src, (size_t)h.nJoints * sizeof(RevoluteJoint));
+		for (size_t k = 0; k < w->joints.size(); ++k) w->nMouseJoints += w->joints[k].type == B2D_JOINT_MOUSE;
 	}
 	SNAP_DEV(b_pos, nb); SNAP_DEV(b_pos0, nb); SNAP_DEV(b_vel, nb); SNAP_DEV(b_xf, nb); SNAP_DEV(b_mass, nb); SNAP_DEV(b_damp, nb);
 	SNAP_DEV(b_force, nb); SNAP_DEV(b_flags, nb); SNAP_DEV(b_wake, nb); SNAP_DEV(b_proxyHead, nb);
@@ -2698,6 +2765,16 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	SNAP_DEV(c_ids[cur], nC); SNAP_DEV(c_key[cur], nC); SNAP_DEV(c_flags[cur], nC); SNAP_DEV(c_mat[cur], nC); SNAP_DEV(c_man0[cur], nC);
 	SNAP_DEV(c_man1[cur], nC); SNAP_DEV(c_imp[cur], nC); SNAP_DEV(c_man3[cur], nC); SNAP_DEV(c_color[cur], nC); SNAP_DEV(c_mgr[cur], nC);
 	SNAP_DEV(toiPos2c, h.nToiOrder); SNAP_DEV(moveBuf, h.nMoves);
+	if (in.left >= 2 * sizeof(uint32_t))
+	{
+		uint32_t tail[2];
+		in.host(tail, sizeof(tail));
+		if (tail[1] != sizeof(GearRec)) return fail(setError(B2HIP_ERR_INVALID, "snapshot: gear record layout differs"));
+		const void* src = in.take((size_t)tail[0] * sizeof(GearRec));
+		if (!src) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
+		w->gears.resize(tail[0]);
+		if (tail[0]) memcpy(w->gears.data(), src, (size_t)tail[0] * sizeof(GearRec)); // re-uploaded by the next flushEdits, like the joints
+	}
 #undef SNAP_DEV
 	HIP_TRY(hipMemcpy(w->d_shapes.p, w->shapes.data(), w->shapes.size() * sizeof(ShapeRec), hipMemcpyHostToDevice));
 	w->upBodies = nb; w->upFixtures = np; w->upShapes = w->shapes.size(); w->upJoints = 0;

@@ -31,6 +31,7 @@
 #include "Box2D/Dynamics/Joints/b2MotorJoint.h"
 #include "Box2D/Dynamics/Joints/b2PulleyJoint.h"
 #include "Box2D/Dynamics/Joints/b2MouseJoint.h"
+#include "Box2D/Dynamics/Joints/b2GearJoint.h"
 
 #include "Box2D/MT/b2Task.h"
 #include "Box2D/MT/b2TaskExecutor.h"

@@ -1,5 +1,5 @@
 // Drop-in header: joint base types (reference: Box2D/Dynamics/Joints/b2Joint.h:31-232).
-// Device path: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley and mouse joints. Other joint types are API-compat declarations only.
+// Device path: all eleven joint types (revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley, mouse, gear).
 #ifndef B2_JOINT_H
 #define B2_JOINT_H
 

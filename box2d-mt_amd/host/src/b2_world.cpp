@@ -343,9 +343,20 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 		id = b2hip_create_mouse_joint(m_hip, &d);
 		if (id >= 0) j = new (b2Alloc(sizeof(b2MouseJoint))) b2MouseJoint(md);
 	}
+	else if (def->type == e_gearJoint)
+	{
+		const b2GearJointDef* gd = static_cast<const b2GearJointDef*>(def);
+		b2hip_gear_joint_def d;
+		d.joint1 = gd->joint1->GetDeviceId();
+		d.joint2 = gd->joint2->GetDeviceId();
+		d.ratio = gd->ratio;
+		d.collide_connected = gd->collideConnected;
+		id = b2hip_create_gear_joint(m_hip, &d);
+		if (id >= 0) j = new (b2Alloc(sizeof(b2GearJoint))) b2GearJoint(gd);
+	}
 	else
 	{
-		fprintf(stderr, "b2World::CreateJoint: joint type %d is not on the device path yet\n", (int)def->type);
+		fprintf(stderr, "b2World::CreateJoint: unknown joint type %d\n", (int)def->type);
 		return nullptr;
 	}
 	if (id < 0)

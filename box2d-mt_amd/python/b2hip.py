@@ -103,6 +103,10 @@ class MouseJointDef(C.Structure):
                 ("frequency_hz", C.c_float), ("damping_ratio", C.c_float), ("collide_connected", C.c_int)]
 
 
+class GearJointDef(C.Structure):
+    _fields_ = [("joint1", C.c_int), ("joint2", C.c_int), ("ratio", C.c_float), ("collide_connected", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "bodies", "proxies", "contacts", "touching_contacts", "islands", "small_islands", "large_islands",
@@ -145,6 +149,7 @@ def _configure(L, optional_ok=False):
         "b2hip_create_motor_joint": [C.c_void_p, C.POINTER(MotorJointDef)],
         "b2hip_create_pulley_joint": [C.c_void_p, C.POINTER(PulleyJointDef)],
         "b2hip_create_mouse_joint": [C.c_void_p, C.POINTER(MouseJointDef)],
+        "b2hip_create_gear_joint": [C.c_void_p, C.POINTER(GearJointDef)],
         "b2hip_joint_set_target": [C.c_void_p, C.c_int, C.c_float, C.c_float],
         "b2hip_joint_set_offsets": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
         "b2hip_joint_set_motor": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
@@ -374,6 +379,10 @@ class World:
         d.target[0], d.target[1] = target
         d.max_force, d.frequency_hz, d.damping_ratio = max_force, frequency_hz, damping_ratio
         return _check(self.L.b2hip_create_mouse_joint(self.p, C.byref(d)))
+
+    def create_gear_joint(self, joint1, joint2, ratio=1.0, collide_connected=False):
+        d = GearJointDef(joint1, joint2, ratio, int(collide_connected))
+        return _check(self.L.b2hip_create_gear_joint(self.p, C.byref(d)))
 
     def joint_set_target(self, joint, target):
         _check(self.L.b2hip_joint_set_target(self.p, joint, target[0], target[1]))

@@ -20,6 +20,7 @@
  *   b2hip_create_motor_joint         b2World::CreateJoint (motor)           Joints/b2MotorJoint.cpp:48-60
  *   b2hip_create_pulley_joint        b2World::CreateJoint (pulley)          Joints/b2PulleyJoint.cpp:62-79
  *   b2hip_create_mouse_joint         b2World::CreateJoint (mouse)           Joints/b2MouseJoint.cpp:36-55
+ *   b2hip_create_gear_joint          b2World::CreateJoint (gear)            Joints/b2GearJoint.cpp:50-129
  *   b2hip_joint_set_target           b2MouseJoint::SetTarget                Joints/b2MouseJoint.cpp:57-64
  *   b2hip_joint_set_offsets          b2MotorJoint::SetLinearOffset / SetAngularOffset   Joints/b2MotorJoint.cpp:253-281
  *   b2hip_joint_set_motor            b2{Revolute,Prismatic,Wheel}Joint::EnableMotor / SetMotorSpeed / SetMaxMotor{Torque,Force}
@@ -219,6 +220,16 @@ typedef struct b2hip_mouse_joint_def
 	int collide_connected;
 } b2hip_mouse_joint_def;
 
+/* b2GearJointDef (Joints/b2GearJoint.h:28-48): couples two existing revolute / prismatic joints (ids returned by their
+ * create calls): coordinate1 + ratio * coordinate2 stays what it is at creation. The joint's bodies are the second bodies of the
+ * two joints, as in the reference's constructor; the two joints must outlive the gear. */
+typedef struct b2hip_gear_joint_def
+{
+	int joint1, joint2;
+	float ratio;
+	int collide_connected;
+} b2hip_gear_joint_def;
+
 /* b2MotorJointDef (Joints/b2MotorJoint.h:26-57): drives bodyB to linear_offset / angular_offset in bodyA's frame */
 typedef struct b2hip_motor_joint_def
 {
@@ -306,6 +317,7 @@ int b2hip_create_friction_joint(b2hip_world* w, const b2hip_friction_joint_def* 
 int b2hip_create_motor_joint(b2hip_world* w, const b2hip_motor_joint_def* def);
 int b2hip_create_pulley_joint(b2hip_world* w, const b2hip_pulley_joint_def* def);
 int b2hip_create_mouse_joint(b2hip_world* w, const b2hip_mouse_joint_def* def);
+int b2hip_create_gear_joint(b2hip_world* w, const b2hip_gear_joint_def* def);
 /* b2MouseJoint::SetTarget (b2MouseJoint.cpp:57-64): wakes bodyB when the target moves */
 int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y);
 /* b2MotorJoint::SetLinearOffset + SetAngularOffset (b2MotorJoint.cpp:253-281): wakes both bodies when something changes */

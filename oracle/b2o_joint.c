@@ -3,7 +3,8 @@
  * b2DistanceJoint (Joints/b2DistanceJoint.cpp:65-225), b2PrismaticJoint (Joints/b2PrismaticJoint.cpp:130-478),
  * b2WeldJoint (Joints/b2WeldJoint.cpp:58-303), b2WheelJoint (Joints/b2WheelJoint.cpp:79-292), b2RopeJoint
  * (Joints/b2RopeJoint.cpp:48-182), b2FrictionJoint (Joints/b2FrictionJoint.cpp:58-185), b2MotorJoint (Joints/b2MotorJoint.cpp:62-203),
- * b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253), b2MouseJoint (Joints/b2MouseJoint.cpp:99-198); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
+ * b2PulleyJoint (Joints/b2PulleyJoint.cpp:81-253), b2MouseJoint (Joints/b2MouseJoint.cpp:99-198),
+ * b2GearJoint (Joints/b2GearJoint.cpp:131-390); b2Mat33::GetInverse22 / GetSymInverse33 b2Math.cpp:56-94.
  * TEST INFRASTRUCTURE (see b2o.h). */
 #include "b2o_joint.h"
 
@@ -1206,4 +1207,129 @@ void b2o_mouse_velocity(revolute_t* j, vec2* vB, float* wB, float dt)
 	impulse = v_sub(acc, old);
 	*vB = v_add(*vB, v_scale(j->invMassB, impulse));
 	*wB += j->invIB * v_cross(j->rB, impulse);
+}
+
+/* ---- gear joint --------------------------------------------------------------------------------- */
+enum { GA = 0, GB = 1, GC = 2, GD = 3 };
+
+/* Jacobian rows of the two sides at the given angles (b2GearJoint.cpp:159-195, :276-331); returns the effective inverse mass */
+static float gear_jacobian(const revolute_t* j, const float a[4], vec2* JvAC, vec2* JvBD, float* JwA, float* JwB, float* JwC, float* JwD)
+{
+	float mass = 0.0f;
+	if (j->typeA == B2O_JOINT_REVOLUTE)
+	{
+		*JvAC = v_make(0.0f, 0.0f);
+		*JwA = 1.0f;
+		*JwC = 1.0f;
+		mass += j->giA + j->giC;
+	}
+	else
+	{
+		rot qA = r_make(a[GA]), qC = r_make(a[GC]);
+		vec2 u = r_mul(qC, j->localAxisC);
+		vec2 rC = r_mul(qC, v_sub(j->gLocalAnchorC, j->lcC));
+		vec2 rA = r_mul(qA, v_sub(j->gLocalAnchorA, j->lcA));
+		*JvAC = u;
+		*JwC = v_cross(rC, u);
+		*JwA = v_cross(rA, u);
+		mass += j->gmC + j->gmA + j->giC * *JwC * *JwC + j->giA * *JwA * *JwA;
+	}
+	if (j->typeB == B2O_JOINT_REVOLUTE)
+	{
+		*JvBD = v_make(0.0f, 0.0f);
+		*JwB = j->ratio;
+		*JwD = j->ratio;
+		mass += j->ratio * j->ratio * (j->giB + j->giD);
+	}
+	else
+	{
+		rot qB = r_make(a[GB]), qD = r_make(a[GD]);
+		vec2 u = r_mul(qD, j->localAxisD);
+		vec2 rD = r_mul(qD, v_sub(j->gLocalAnchorD, j->lcD));
+		vec2 rB = r_mul(qB, v_sub(j->gLocalAnchorB, j->lcB));
+		*JvBD = v_scale(j->ratio, u);
+		*JwD = j->ratio * v_cross(rD, u);
+		*JwB = j->ratio * v_cross(rB, u);
+		mass += j->ratio * j->ratio * (j->gmD + j->gmB) + j->giD * *JwD * *JwD + j->giB * *JwB * *JwB;
+	}
+	return mass;
+}
+
+static void gear_apply(const revolute_t* j, gear_bodies* b, float impulse)
+{
+	b->v[GA] = v_add(b->v[GA], v_scale(j->gmA * impulse, j->JvAC));
+	b->w[GA] += j->giA * impulse * j->JwA;
+	b->v[GB] = v_add(b->v[GB], v_scale(j->gmB * impulse, j->JvBD));
+	b->w[GB] += j->giB * impulse * j->JwB;
+	b->v[GC] = v_sub(b->v[GC], v_scale(j->gmC * impulse, j->JvAC));
+	b->w[GC] -= j->giC * impulse * j->JwC;
+	b->v[GD] = v_sub(b->v[GD], v_scale(j->gmD * impulse, j->JvBD));
+	b->w[GD] -= j->giD * impulse * j->JwD;
+}
+
+/* InitVelocityConstraints b2GearJoint.cpp:131-222 */
+void b2o_gear_init(revolute_t* j, gear_bodies* b, const float invMass[4], const float invI[4], const vec2 lc[4], int warmStarting)
+{
+	j->lcA = lc[GA]; j->lcB = lc[GB]; j->lcC = lc[GC]; j->lcD = lc[GD];
+	j->gmA = invMass[GA]; j->gmB = invMass[GB]; j->gmC = invMass[GC]; j->gmD = invMass[GD];
+	j->giA = invI[GA]; j->giB = invI[GB]; j->giC = invI[GC]; j->giD = invI[GD];
+	float mass = gear_jacobian(j, b->a, &j->JvAC, &j->JvBD, &j->JwA, &j->JwB, &j->JwC, &j->JwD);
+	j->mass = mass > 0.0f ? 1.0f / mass : 0.0f;
+	if (warmStarting) gear_apply(j, b, j->impulse[0]);
+	else j->impulse[0] = 0.0f;
+}
+
+/* SolveVelocityConstraints :224-258 */
+void b2o_gear_velocity(revolute_t* j, gear_bodies* b)
+{
+	float Cdot = v_dot(j->JvAC, v_sub(b->v[GA], b->v[GC])) + v_dot(j->JvBD, v_sub(b->v[GB], b->v[GD]));
+	Cdot += (j->JwA * b->w[GA] - j->JwC * b->w[GC]) + (j->JwB * b->w[GB] - j->JwD * b->w[GD]);
+	float impulse = -j->mass * Cdot;
+	j->impulse[0] += impulse;
+	gear_apply(j, b, impulse);
+}
+
+/* SolvePositionConstraints :260-362 (its linearError stays zero: always "solved") */
+int b2o_gear_position(const revolute_t* j, gear_bodies* b)
+{
+	vec2 JvAC, JvBD;
+	float JwA, JwB, JwC, JwD;
+	float mass = gear_jacobian(j, b->a, &JvAC, &JvBD, &JwA, &JwB, &JwC, &JwD);
+	float coordinateA, coordinateB;
+	if (j->typeA == B2O_JOINT_REVOLUTE)
+	{
+		coordinateA = b->a[GA] - b->a[GC] - j->referenceAngleA;
+	}
+	else
+	{
+		rot qA = r_make(b->a[GA]), qC = r_make(b->a[GC]);
+		vec2 rA = r_mul(qA, v_sub(j->gLocalAnchorA, j->lcA));
+		vec2 pC = v_sub(j->gLocalAnchorC, j->lcC);
+		vec2 pA = r_mul_t(qC, v_add(rA, v_sub(b->c[GA], b->c[GC])));
+		coordinateA = v_dot(v_sub(pA, pC), j->localAxisC);
+	}
+	if (j->typeB == B2O_JOINT_REVOLUTE)
+	{
+		coordinateB = b->a[GB] - b->a[GD] - j->referenceAngleB;
+	}
+	else
+	{
+		rot qB = r_make(b->a[GB]), qD = r_make(b->a[GD]);
+		vec2 rB = r_mul(qB, v_sub(j->gLocalAnchorB, j->lcB));
+		vec2 pD = v_sub(j->gLocalAnchorD, j->lcD);
+		vec2 pB = r_mul_t(qD, v_add(rB, v_sub(b->c[GB], b->c[GD])));
+		coordinateB = v_dot(v_sub(pB, pD), j->localAxisD);
+	}
+	float C = (coordinateA + j->ratio * coordinateB) - j->constant;
+	float impulse = 0.0f;
+	if (mass > 0.0f) impulse = -C / mass;
+	b->c[GA] = v_add(b->c[GA], v_scale(j->gmA * impulse, JvAC));
+	b->a[GA] += j->giA * impulse * JwA;
+	b->c[GB] = v_add(b->c[GB], v_scale(j->gmB * impulse, JvBD));
+	b->a[GB] += j->giB * impulse * JwB;
+	b->c[GC] = v_sub(b->c[GC], v_scale(j->gmC * impulse, JvAC));
+	b->a[GC] -= j->giC * impulse * JwC;
+	b->c[GD] = v_sub(b->c[GD], v_scale(j->gmD * impulse, JvBD));
+	b->a[GD] -= j->giD * impulse * JwD;
+	return 1;
 }

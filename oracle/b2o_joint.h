@@ -1,11 +1,11 @@
-/* b2o_joint.h - CPU oracle, joint state: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley, mouse (TEST INFRASTRUCTURE, see b2o.h). */
+/* b2o_joint.h - CPU oracle, joint state: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley, mouse, gear (TEST INFRASTRUCTURE, see b2o.h). */
 #ifndef B2O_JOINT_H
 #define B2O_JOINT_H
 
 #include "b2o_internal.h"
 
 enum { B2O_JOINT_REVOLUTE = 0, B2O_JOINT_DISTANCE = 1, B2O_JOINT_PRISMATIC = 2, B2O_JOINT_WELD = 3,
-	B2O_JOINT_WHEEL = 4, B2O_JOINT_ROPE = 5, B2O_JOINT_FRICTION = 6, B2O_JOINT_MOTOR = 7, B2O_JOINT_PULLEY = 8, B2O_JOINT_MOUSE = 9 };
+	B2O_JOINT_WHEEL = 4, B2O_JOINT_ROPE = 5, B2O_JOINT_FRICTION = 6, B2O_JOINT_MOTOR = 7, B2O_JOINT_PULLEY = 8, B2O_JOINT_MOUSE = 9, B2O_JOINT_GEAR = 10 };
 
 typedef struct
 {
@@ -48,6 +48,14 @@ typedef struct
 	/* mouse joint (b2MouseJoint.h:101-126): m_targetA = localAnchorA, impulse[0..1], m_mass in linearMass, m_C, m_beta; gamma above */
 	vec2 mouseC;
 	float beta;
+	/* gear joint (b2GearJoint.h:84-122): impulse[0], mass, ratio, constant above */
+	int bodyC, bodyD, typeA, typeB;
+	vec2 gLocalAnchorA, gLocalAnchorB, gLocalAnchorC, gLocalAnchorD, localAxisC, localAxisD;
+	float referenceAngleA, referenceAngleB;
+	vec2 lcA, lcB, lcC, lcD;
+	float gmA, gmB, gmC, gmD, giA, giB, giC, giD;
+	vec2 JvAC, JvBD;
+	float JwA, JwB, JwC, JwD;
 	int islandFlag;
 	int nextA, nextB; /* per-body joint lists, newest first: edge id = joint * 2 + side */
 } revolute_t;
@@ -94,6 +102,12 @@ void b2o_pulley_init(revolute_t* j, float mA, float iA, vec2 lcA, float mB, floa
 	vec2 cA, float aA, vec2* vA, float* wA, vec2 cB, float aB, vec2* vB, float* wB, int warmStarting, float dtRatio);
 void b2o_pulley_velocity(revolute_t* j, vec2* vA, float* wA, vec2* vB, float* wB);
 int b2o_pulley_position(const revolute_t* j, vec2* cA, float* aA, vec2* cB, float* aB);
+
+/* four bodies: positions / velocities as arrays in the order A, B, C, D */
+typedef struct { vec2 c[4]; float a[4]; vec2 v[4]; float w[4]; } gear_bodies;
+void b2o_gear_init(revolute_t* j, gear_bodies* b, const float invMass[4], const float invI[4], const vec2 lc[4], int warmStarting);
+void b2o_gear_velocity(revolute_t* j, gear_bodies* b);
+int b2o_gear_position(const revolute_t* j, gear_bodies* b);
 
 /* acts on bodyB only; no position step (b2MouseJoint.cpp:194-198) */
 void b2o_mouse_init(revolute_t* j, float massB, float mB, float iB, vec2 lcB, vec2 cB, float aB, vec2* vB, float* wB,

@@ -5,8 +5,8 @@
  * (b2World.cpp:1207-1371), sequential-impulse sweeps in island order (b2ContactSolver.cpp), fat-AABB
  * broad-phase semantics (b2DynamicTree.cpp:130-174) with a brute-force overlap query in place of the
  * tree (the pair set does not depend on the index structure), creation sorted by proxy ids
- * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley, mouse (b2o_joint.c). Not covered (same as the device
- * path): other joint types, chain shapes. Continuous collision: b2o_toi.c
+ * (b2ContactManager.cpp:366-386). Joints: revolute, distance, prismatic, weld, wheel, rope, friction, motor, pulley, mouse, gear (b2o_joint.c). Not covered (same as the device
+ * path): chain shapes. Continuous collision: b2o_toi.c
  * (GJK + time of impact) and the TOI event loop at the end of this file.
  */
 #include "b2o_internal.h"
@@ -533,6 +533,39 @@ int b2o_create_mouse_joint(b2o_world* w, int bodyA, int bodyB, float tx, float t
 	j->maxForce = maxForce;
 	j->frequencyHz = frequencyHz;
 	j->dampingRatio = dampingRatio;
+	return id;
+}
+
+/* b2GearJoint::b2GearJoint (b2GearJoint.cpp:50-129) */
+static float gear_coordinate(const b2o_world* w, const revolute_t* jt)
+{
+	const body_t* bm = &w->bodies[jt->bodyB];
+	const body_t* bf = &w->bodies[jt->bodyA];
+	if (jt->type == B2O_JOINT_REVOLUTE) return bm->a - bf->a - jt->referenceAngle;
+	vec2 pC = jt->localAnchorA;
+	vec2 pA = r_mul_t(bf->xf.q, v_add(r_mul(bm->xf.q, jt->localAnchorB), v_sub(bm->xf.p, bf->xf.p)));
+	return v_dot(v_sub(pA, pC), jt->localXAxisA);
+}
+
+int b2o_create_gear_joint(b2o_world* w, int joint1, int joint2, float ratio, int collideConnected)
+{
+	float coordinateA = gear_coordinate(w, &w->joints[joint1]);
+	float coordinateB = gear_coordinate(w, &w->joints[joint2]);
+	int bodyA = w->joints[joint1].bodyB, bodyB = w->joints[joint2].bodyB;
+	float anchors[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	int id = b2o_create_revolute_joint(w, bodyA, bodyB, anchors, 0.0f, 0, 0.0f, 0.0f, 0, 0.0f, 0.0f, collideConnected);
+	revolute_t* j = &w->joints[id];
+	const revolute_t* j1 = &w->joints[joint1];
+	const revolute_t* j2 = &w->joints[joint2];
+	j->type = B2O_JOINT_GEAR;
+	j->bodyC = j1->bodyA; j->bodyD = j2->bodyA;
+	j->typeA = j1->type; j->typeB = j2->type;
+	j->gLocalAnchorC = j1->localAnchorA; j->gLocalAnchorA = j1->localAnchorB; j->referenceAngleA = j1->referenceAngle;
+	j->localAxisC = j1->type == B2O_JOINT_PRISMATIC ? j1->localXAxisA : v_make(0.0f, 0.0f);
+	j->gLocalAnchorD = j2->localAnchorA; j->gLocalAnchorB = j2->localAnchorB; j->referenceAngleB = j2->referenceAngle;
+	j->localAxisD = j2->type == B2O_JOINT_PRISMATIC ? j2->localXAxisA : v_make(0.0f, 0.0f);
+	j->ratio = ratio;
+	j->constant = coordinateA + ratio * coordinateB;
 	return id;
 }
 
@@ -1305,6 +1338,18 @@ static float solve_position(const constraint_t* cc, pos_t* pos, float minSeparat
 }
 
 /* b2Island::Solve  b2Island.cpp:184-396 */
+/* the gear joint's four bodies in island arrays, A, B, C, D (copies, written back in that order: b2GearJoint.cpp:215-222) */
+static void gear_gather(b2o_world* w, const revolute_t* j, const pos_t* positions, const vel_t* velocities, int idx[4], gear_bodies* g)
+{
+	idx[0] = w->bodies[j->bodyA].islandIndex; idx[1] = w->bodies[j->bodyB].islandIndex;
+	idx[2] = w->bodies[j->bodyC].islandIndex; idx[3] = w->bodies[j->bodyD].islandIndex;
+	for (int k = 0; k < 4; ++k)
+	{
+		g->c[k] = positions[idx[k]].c; g->a[k] = positions[idx[k]].a;
+		g->v[k] = velocities[idx[k]].v; g->w[k] = velocities[idx[k]].w;
+	}
+}
+
 static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* islandContacts, int contactCount,
 	int* islandJoints, int jointCount, float h, float dtRatio, int velIters, int posIters)
 {
@@ -1348,6 +1393,19 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		int ia = bA->islandIndex, ib = bB->islandIndex;
 		vec2* vA = &velocities[ia].v; float* wA = &velocities[ia].w;
 		vec2* vB = &velocities[ib].v; float* wB = &velocities[ib].w;
+		if (j->type == B2O_JOINT_GEAR)
+		{
+			int idx[4];
+			gear_bodies g;
+			gear_gather(w, j, positions, velocities, idx, &g);
+			const int ids[4] = { j->bodyA, j->bodyB, j->bodyC, j->bodyD };
+			float im[4], ii[4];
+			vec2 lc[4];
+			for (int k = 0; k < 4; ++k) { im[k] = w->bodies[ids[k]].invMass; ii[k] = w->bodies[ids[k]].invI; lc[k] = w->bodies[ids[k]].localCenter; }
+			b2o_gear_init(j, &g, im, ii, lc, w->warmStarting);
+			for (int k = 0; k < 4; ++k) { velocities[idx[k]].v = g.v[k]; velocities[idx[k]].w = g.w[k]; }
+			continue;
+		}
 		switch (j->type)
 		{
 		case B2O_JOINT_DISTANCE:
@@ -1399,6 +1457,15 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			int ia = w->bodies[j->bodyA].islandIndex, ib = w->bodies[j->bodyB].islandIndex;
 			vec2* vA = &velocities[ia].v; float* wA = &velocities[ia].w;
 			vec2* vB = &velocities[ib].v; float* wB = &velocities[ib].w;
+			if (j->type == B2O_JOINT_GEAR)
+			{
+				int idx[4];
+				gear_bodies g;
+				gear_gather(w, j, positions, velocities, idx, &g);
+				b2o_gear_velocity(j, &g);
+				for (int k = 0; k < 4; ++k) { velocities[idx[k]].v = g.v[k]; velocities[idx[k]].w = g.w[k]; }
+				continue;
+			}
 			switch (j->type)
 			{
 			case B2O_JOINT_DISTANCE: b2o_distance_velocity(j, vA, wA, vB, wB); break;
@@ -1459,6 +1526,16 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 			vec2* cA = &positions[ia].c; float* aA = &positions[ia].a;
 			vec2* cB = &positions[ib].c; float* aB = &positions[ib].a;
 			int ok;
+			if (j->type == B2O_JOINT_GEAR)
+			{
+				int idx[4];
+				gear_bodies g;
+				gear_gather(w, j, positions, velocities, idx, &g);
+				ok = b2o_gear_position(j, &g);
+				for (int k = 0; k < 4; ++k) { positions[idx[k]].c = g.c[k]; positions[idx[k]].a = g.a[k]; }
+				jointsOkay = jointsOkay && ok;
+				continue;
+			}
 			switch (j->type)
 			{
 			case B2O_JOINT_DISTANCE: ok = b2o_distance_position(j, cA, aA, cB, aB); break;

@@ -1,7 +1,7 @@
 // Scene recipes used by the parity harness and the bench.
 //
 // TEST INFRASTRUCTURE. This file is written against the PUBLIC Box2D-MT API only
-// (b2World / b2Body / b2Fixture / shapes / b2RevoluteJointDef / b2DistanceJointDef / b2PrismaticJointDef / b2WeldJointDef), so the very same source is
+// (b2World / b2Body / b2Fixture / shapes / b2RevoluteJointDef / b2DistanceJointDef / b2PrismaticJointDef / b2WeldJointDef / ...), so the very same source is
 // compiled twice:
 //   * against the reference headers + sources under /root/reference  -> oracle/_ref/libb2ref_harness.so
 //   * against this repo's drop-in headers (box2d-mt_amd/host)         -> libb2amd_harness.so
@@ -74,7 +74,7 @@ enum SceneId
 	                     //   planks and the ground, a soft web of four boxes on damped springs, bodies dropped on both
 	e_machines = 10,     // p0 = falling bodies, p1 = cantilever segments ; prismatic joints (motor slider between limits, a free
 	                     //   vertical slider resting on its lower limit, a locked one) and weld joints (rigid and soft cantilevers,
-	                     //   a welded free-falling pair), two pulleys, bodies dropped over all of them
+	                     //   a welded free-falling pair), a gear train, two pulleys, bodies dropped over all of them
 	e_vehicles = 11,     // p0 = falling bodies, p1 = cars ; wheel joints (cars with sprung, motor-driven wheels over bumps, one
 	                     //   with a rigid axle), rope joints (weights on slack and taut tethers), friction joints (pucks braked
 	                     //   against the ground), motor joints (platforms servoed to a pose the step loop keeps moving) and a
@@ -751,6 +751,55 @@ inline void BuildMachines(Scene& s, b2World* w, int count, int segments, uint32_
 		b2WeldJointDef jd;
 		jd.Initialize(a, b, b2Vec2(15.0f, 20.0f));
 		w->CreateJoint(&jd);
+	}
+	// gear train: a small motorised disc drives a big one (revolute - revolute gear) which lifts a rack on a prismatic
+	// joint (revolute - prismatic gear); the three bodies are spaced so that they do not touch
+	{
+		const float y = 12.0f;
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		b2CircleShape disc;
+		bd.position.Set(-44.0f, y);
+		b2Body* small = AddBody(s, w, bd);
+		disc.m_radius = 1.0f;
+		small->CreateFixture(&disc, 5.0f);
+		b2RevoluteJointDef r1;
+		r1.Initialize(ground, small, bd.position);
+		r1.enableMotor = true;
+		r1.motorSpeed = 1.0f;
+		r1.maxMotorTorque = 400.0f;
+		b2Joint* j1 = w->CreateJoint(&r1);
+		bd.position.Set(-40.9f, y);
+		b2Body* big = AddBody(s, w, bd);
+		disc.m_radius = 2.0f;
+		big->CreateFixture(&disc, 5.0f);
+		b2RevoluteJointDef r2;
+		r2.Initialize(ground, big, bd.position);
+		b2Joint* j2 = w->CreateJoint(&r2);
+		bd.position.Set(-38.3f, y);
+		b2Body* rack = AddBody(s, w, bd);
+		b2PolygonShape bar;
+		bar.SetAsBox(0.5f, 5.0f);
+		rack->CreateFixture(&bar, 5.0f);
+		b2PrismaticJointDef p3;
+		p3.Initialize(ground, rack, bd.position, b2Vec2(0.0f, 1.0f));
+		p3.lowerTranslation = -5.0f;
+		p3.upperTranslation = 5.0f;
+		p3.enableLimit = true;
+		b2Joint* j3 = w->CreateJoint(&p3);
+		b2GearJointDef g;
+		g.bodyA = small;
+		g.bodyB = big;
+		g.joint1 = j1;
+		g.joint2 = j2;
+		g.ratio = 2.0f;
+		w->CreateJoint(&g);
+		g.bodyA = big;
+		g.bodyB = rack;
+		g.joint1 = j2;
+		g.joint2 = j3;
+		g.ratio = -1.0f / 2.0f;
+		w->CreateJoint(&g);
 	}
 	// pulleys: two pairs of unequal weights over ground points, ratios 1 and 2.5 (the second pair starts out of balance)
 	for (int i = 0; i < 2; ++i)

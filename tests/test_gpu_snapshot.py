@@ -22,6 +22,31 @@ def build(continuous):
     arm = w.create_body(b2hip.DYNAMIC, position=(20.0, 6.0))
     w.create_fixture(arm, b2hip.box_shape(2.0, 0.2), density=2.0)
     w.create_revolute_joint(ground, arm, anchor_a=(18.0, 6.0), anchor_b=(-2.0, 0.0), enable_motor=True, motor_speed=1.5, max_motor_torque=500.0)
+    # one of each remaining stateful joint family: spring (wheel), clamped rows (motor), soft target (mouse), unilateral (rope)
+    cart = w.create_body(b2hip.DYNAMIC, position=(28.0, 1.5))
+    w.create_fixture(cart, b2hip.box_shape(1.5, 0.3), density=1.0)
+    for x in (-1.0, 1.0):
+        wheel = w.create_body(b2hip.DYNAMIC, position=(28.0 + x, 0.9))
+        w.create_fixture(wheel, b2hip.circle_shape(0.4), density=1.0, friction=0.9)
+        w.create_wheel_joint(cart, wheel, anchor_a=(x, -0.6), axis=(0.0, 1.0), frequency_hz=4.0, damping_ratio=0.7, enable_motor=x < 0,
+                             motor_speed=-3.0, max_motor_torque=10.0)
+    plat = w.create_body(b2hip.DYNAMIC, position=(-25.0, 6.0))
+    w.create_fixture(plat, b2hip.box_shape(1.5, 0.2), density=1.0)
+    w.create_motor_joint(ground, plat, linear_offset=(-24.0, 7.0), angular_offset=0.3, max_force=300.0, max_torque=100.0)
+    crate = w.create_body(b2hip.DYNAMIC, position=(-32.0, 3.0))
+    w.create_fixture(crate, b2hip.box_shape(0.6, 0.6), density=1.0)
+    w.mouse = w.create_mouse_joint(ground, crate, target=(-31.7, 3.2), max_force=1500.0)
+    w.joint_set_target(w.mouse, (-30.0, 6.0))
+    bob = w.create_body(b2hip.DYNAMIC, position=(-36.0, 5.0), velocity=(3.0, 0.0))
+    w.create_fixture(bob, b2hip.circle_shape(0.3), density=1.0)
+    w.create_rope_joint(ground, bob, anchor_a=(-36.0, 8.0), anchor_b=(0.0, 0.0), max_length=3.5)
+    # a gear between two hinged discs (its record lives in its own device array: trailing snapshot section)
+    hinges = []
+    for x, r in ((34.0, 0.8), (36.5, 1.6)):
+        disc = w.create_body(b2hip.DYNAMIC, position=(x, 9.0))
+        w.create_fixture(disc, b2hip.circle_shape(r), density=2.0)
+        hinges.append(w.create_revolute_joint(ground, disc, anchor_a=(x, 9.0), enable_motor=(r < 1.0), motor_speed=2.0, max_motor_torque=60.0))
+    w.create_gear_joint(hinges[0], hinges[1], ratio=2.0)
     return w
 
 
@@ -48,6 +73,8 @@ def test_snapshot_resume_is_bit_exact(continuous):
     # edits after the load go through the same mirrors
     a.apply_force(5, (30.0, 10.0), 1.0)
     b.apply_force(5, (30.0, 10.0), 1.0)
+    a.joint_set_target(a.mouse, (-33.0, 4.0))
+    b.joint_set_target(a.mouse, (-33.0, 4.0))
     na = a.create_body(b2hip.DYNAMIC, position=(0.0, 30.0))
     nb = b.create_body(b2hip.DYNAMIC, position=(0.0, 30.0))
     assert na == nb
