@@ -1613,12 +1613,12 @@ B2D_HD float b2dGearSide(int type, float scale, V2 localAxis, V2 localAnchorFixe
 }
 
 // InitVelocityConstraints (b2GearJoint.cpp:131-222)
-B2D_HD void b2dGearInit(GearRec* g, GearBodies* b, float4 massA, float4 massB, float4 massC, float4 massD, bool warmStarting)
+B2D_HD void b2dGearInit(GearRec* g, GearBodies* b, const float invMass[4], const float invI[4], const V2 lc[4], bool warmStarting)
 {
-	g->mA = massA.x; g->iA = massA.y; g->lcA = v2(massA.z, massA.w);
-	g->mB = massB.x; g->iB = massB.y; g->lcB = v2(massB.z, massB.w);
-	g->mC = massC.x; g->iC = massC.y; g->lcC = v2(massC.z, massC.w);
-	g->mD = massD.x; g->iD = massD.y; g->lcD = v2(massD.z, massD.w);
+	g->mA = invMass[0]; g->iA = invI[0]; g->lcA = lc[0];
+	g->mB = invMass[1]; g->iB = invI[1]; g->lcB = lc[1];
+	g->mC = invMass[2]; g->iC = invI[2]; g->lcC = lc[2];
+	g->mD = invMass[3]; g->iD = invI[3]; g->lcD = lc[3];
 	float mass = 0.0f;
 	mass += b2dGearSide(g->typeA, 1.0f, g->localAxisC, g->localAnchorC, g->lcC, g->localAnchorA, g->lcA, b->pC.a, b->pA.a,
 		g->mC, g->mA, g->iC, g->iA, &g->JvAC, &g->JwA, &g->JwC, false);

@@ -740,7 +740,16 @@ __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mo
 				else
 				{
 					if (mode == 0)
-						b2dGearInit(g, &gb, W.b_mass[ids[0]], W.b_mass[ids[1]], W.b_mass[ids[2]], W.b_mass[ids[3]], sp.warmStarting != 0);
+					{
+						float im[4], ii[4];
+						V2 lc[4];
+						for (int q = 0; q < 4; ++q)
+						{
+							const float4 m = W.b_mass[ids[q]];
+							im[q] = m.x; ii[q] = m.y; lc[q] = v2(m.z, m.w);
+						}
+						b2dGearInit(g, &gb, im, ii, lc, sp.warmStarting != 0);
+					}
 					else
 						b2dGearSolveVelocity(g, &gb);
 					for (int q = 0; q < 4; ++q)
