@@ -170,6 +170,7 @@ struct b2hip_world
 	DevArray<int> jadjStart, jadj, rootJointStart, rootJointCursor, lj_list, rootJointOkay;
 	std::vector<std::pair<int, int> > pendingFilter; // body pairs whose contacts must be re-filtered (new joint)
 	int nMouseJoints = 0;
+	size_t jadjBodies = (size_t)-1, jadjJoints = (size_t)-1; // what the device's per-body joint lists were last built for
 	std::vector<GearRec> gears;   // gear joints' own records, appended like joints (the device copy keeps the impulses)
 	size_t upGears = 0;
 	std::vector<std::pair<int, int> > jointEdits;    // (joint, 1 = also clear the limit impulse, 2 = also the anchors / offsets): members changed by a setter
@@ -766,22 +767,26 @@ static int flushEdits(b2hip_world* w)
 		}
 	}
 	w->jointEdits.clear();
+	if (w->jadjBodies != w->bodies.size() || w->jadjJoints != w->joints.size())
 	{
-		// per-body joint edges, newest first (b2World.cpp:697-710); tiny, rebuilt every flush
+		// per-body joint edges, newest first (b2World.cpp:697-710): CSR by counting, rebuilt only when bodies or joints were added
 		const size_t nbod = w->bodies.size();
+		w->jadjBodies = nbod;
+		w->jadjJoints = w->joints.size();
 		std::vector<int> start(nbod + 1, 0), adj;
-		std::vector<std::vector<int> > per(nbod);
+		for (size_t j = 0; j < w->joints.size(); ++j)
+		{
+			start[w->joints[j].bodyA + 1] += 1;
+			if (w->joints[j].bodyB != w->joints[j].bodyA) start[w->joints[j].bodyB + 1] += 1;
+		}
+		for (size_t b = 0; b < nbod; ++b) start[b + 1] += start[b];
+		adj.resize((size_t)start[nbod]);
+		std::vector<int> cursor(start.begin(), start.end() - 1);
 		for (int j = (int)w->joints.size() - 1; j >= 0; --j)
 		{
-			per[w->joints[j].bodyA].push_back(j);
-			if (w->joints[j].bodyB != w->joints[j].bodyA) per[w->joints[j].bodyB].push_back(j);
+			adj[(size_t)cursor[w->joints[j].bodyA]++] = j;
+			if (w->joints[j].bodyB != w->joints[j].bodyA) adj[(size_t)cursor[w->joints[j].bodyB]++] = j;
 		}
-		for (size_t b = 0; b < nbod; ++b)
-		{
-			start[b] = (int)adj.size();
-			adj.insert(adj.end(), per[b].begin(), per[b].end());
-		}
-		start[nbod] = (int)adj.size();
 		HIP_TRY(hipMemcpyAsync(w->jadjStart.p, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice, s));
 		if (!adj.empty()) HIP_TRY(hipMemcpyAsync(w->jadj.p, adj.data(), adj.size() * sizeof(int), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));
