@@ -48,7 +48,16 @@ __global__ __launch_bounds__(256) void k_sync_fixtures(DW W)
 // ---- hashed uniform grid over ALL proxies ----------------------------------------------------------
 __device__ __forceinline__ uint32_t cellHash(int ix, int iy, uint32_t mask)
 {
-	return ((uint32_t)ix * 73856093u ^ (uint32_t)iy * 19349663u) & mask;
+	// two odd multipliers, then an avalanche before the power-of-two mask: bodies laid out on a regular lattice (tile
+	// maps, rows of vehicles) otherwise land in a small fraction of the buckets (measured: 10 000 cars on a 12 x 10 m
+	// lattice, 3.1 ms in k_find_pairs_small with the plain xor of products)
+	uint32_t h = (uint32_t)ix * 73856093u ^ (uint32_t)iy * 19349663u;
+	h ^= h >> 15;
+	h *= 0x2c1b3c6du;
+	h ^= h >> 12;
+	h *= 0x297a2d39u;
+	h ^= h >> 15;
+	return h & mask;
 }
 
 // The cell of the hashed grid. DW::cellSize is sized from the fixtures as they were created; fat AABBs of fast bodies

@@ -53,10 +53,13 @@ __device__ __forceinline__ bool bodiesShouldCollide(const DW& W, int bodyA, int 
 	uint32_t tA = W.b_flags[bodyA] & BF_TYPE_MASK;
 	uint32_t tB = W.b_flags[bodyB] & BF_TYPE_MASK;
 	if (tA != BT_DYNAMIC && tB != BT_DYNAMIC) return false;
-	for (int j = 0; j < W.nJoints; ++j)
+	if (W.nJoints == 0) return true;
+	// the joint edges of ONE of the two bodies (the reference walks bodyA's joint list too); the per-body lists are the ones
+	// island building uses. A scan of every joint of the world here cost 3 ms per step with 20 000 joints.
+	for (int e = W.jadjStart[bodyA], end = W.jadjStart[bodyA + 1]; e < end; ++e)
 	{
-		const RevoluteJoint& jn = W.joints[j];
-		if ((jn.bodyA == bodyA && jn.bodyB == bodyB) || (jn.bodyA == bodyB && jn.bodyB == bodyA))
+		const JointRec& jn = W.joints[W.jadj[e]];
+		if (jn.bodyA == bodyB || jn.bodyB == bodyB)
 		{
 			if (jn.collideConnected == 0) return false;
 		}

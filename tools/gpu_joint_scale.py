@@ -36,3 +36,16 @@ print("cars %d bodies %d joints %d: %.3f ms/step; islands %d (small %d, large %d
 names = ["step", "collide", "solve", "solveTraversal", "solveInit", "solveVelocity", "solvePosition", "solveTOI", "solveTOIFindMinContact",
          "broadphase", "broadphaseSyncFixtures", "broadphaseFindContacts", "locking"]
 print("  last step, ms: " + ", ".join("%s %.3f" % (n, v) for n, v in zip(names, w.profile()) if v > 0.0005))
+# host wall-clock per phase call (the calls enqueue asynchronously; a phase that waits for the device shows it here)
+import ctypes as C
+L, p = w.L, w.p
+acc = {}
+for _ in range(40):
+    for name, call in (("step_begin", lambda: L.b2hip_step_begin(p, C.c_float(1.0 / 60.0), 8, 3)), ("collide", lambda: L.b2hip_collide(p)),
+                       ("solve", lambda: L.b2hip_solve(p)), ("sync_fixtures", lambda: L.b2hip_sync_fixtures(p)),
+                       ("find_new_contacts", lambda: L.b2hip_find_new_contacts(p)), ("step_end", lambda: L.b2hip_step_end(p))):
+        t = time.perf_counter()
+        rc = call()
+        acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+        assert rc == 0, (name, rc)
+print("  host wall-clock per phase call, ms: " + ", ".join("%s %.3f" % (k, 1e3 * v / 40) for k, v in acc.items()))
