@@ -167,10 +167,10 @@ def main():
         # measured with rocprofv3 --pmc on this same command is committed under profiles/ and quoted here when the
         # workload and the kernel match (null otherwise)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")))
             if roof is not None and pmc.get("kernel") == kname and args.rows == 141 and not args.no_ccd:
                 roof["traffic"] = pmc["hbm_bytes_per_dispatch"]
-                roof["traffic_source"] = "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roof["traffic_source"] = "profiles/r01_h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except Exception:
             pass
         smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
