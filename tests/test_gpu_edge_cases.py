@@ -312,6 +312,35 @@ def test_wheel_rope_friction_motor_joints(libs, monkeypatch):
     a.close(); b.close()
 
 
+def test_many_jointed_islands(libs, monkeypatch):
+    """240 cars (chassis + two wheels on wheel joints, one driven) on three static strips: 240 separate islands that all
+    carry joints (per-island joint lists, joint-aware pair filtering between every chassis and its wheels), a revolute
+    trailer hitched to every fourth car. Exact-order mode, bitwise against the oracle."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs)
+    for w in (a, b):
+        for r in range(3):
+            g = w.create_body(b2hip.STATIC, (480.0, 10.0 * r - 0.25))
+            w.create_fixture(g, b2hip.box_shape(500.0, 0.25))
+        for r in range(3):
+            for c in range(80):
+                x, y = 12.0 * c + 2.0, 10.0 * r + 1.0
+                ch = w.create_body(b2hip.DYNAMIC, (x, y))
+                w.create_fixture(ch, b2hip.box_shape(1.5, 0.4), density=1.0)
+                for k, dx in enumerate((-1.0, 1.0)):
+                    wh = w.create_body(b2hip.DYNAMIC, (x + dx, y - 0.6))
+                    w.create_fixture(wh, b2hip.circle_shape(0.4), density=1.0, friction=0.9)
+                    w.create_wheel_joint(ch, wh, anchor_a=(dx, -0.6), axis=(0.0, 1.0), frequency_hz=4.0, damping_ratio=0.7,
+                                         enable_motor=(k == 0), motor_speed=-2.0 - 0.05 * c, max_motor_torque=20.0)
+                if c % 4 == 0:
+                    tr = w.create_body(b2hip.DYNAMIC, (x + 3.2, y - 0.3))
+                    w.create_fixture(tr, b2hip.box_shape(1.0, 0.2), density=0.5, friction=0.1)
+                    w.create_revolute_joint(ch, tr, anchor_a=(1.8, -0.3), anchor_b=(-1.4, 0.0), collide_connected=(c % 8 == 0))
+    run(a, b, 120, "many jointed islands")
+    assert a.counters()["islands"] >= 240
+    a.close(); b.close()
+
+
 def test_joint_setters_between_steps(libs, monkeypatch):
     """b2hip_joint_set_motor / b2hip_joint_set_limits: reverse a slider's motor, switch motors off and on, move and drop the
     limits of a revolute arm while everything has gone to sleep (the setters wake both bodies, as the reference's do), and
