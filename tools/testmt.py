@@ -25,6 +25,9 @@ ENTRIES = [
     ("Field 100k + 5k bullets", H.FIELD, dict(p0=100000, p1=5000, seed=3, flags=CCD), 60, False),
     ("Bullets room", H.BULLETS, dict(p0=80, p1=6, seed=5, flags=CCD), 200, True),
     ("Sensors", H.SENSORS, dict(p0=40, seed=5, flags=CCD), 240, True),
+    ("Ropes (distance joints)", H.ROPES, dict(p0=200, p1=14, seed=9, flags=CCD), 240, True),
+    ("Machines (prismatic, weld, gear, pulley)", H.MACHINES, dict(p0=200, p1=6, seed=3, flags=CCD), 300, True),
+    ("Vehicles (wheel, rope, friction, motor, mouse)", H.VEHICLES, dict(p0=200, p1=6, seed=3, flags=CCD), 300, True),
     ("Tumbler 20", H.TUMBLER, dict(p0=20, p1=0, flags=H.F_SLEEP | H.F_WARM), 200, True),
     ("Tumbler 100", H.TUMBLER, dict(p0=100, p1=0, flags=H.F_SLEEP | H.F_WARM), 120, False),
 ]
