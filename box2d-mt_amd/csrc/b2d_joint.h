@@ -27,6 +27,7 @@ enum
 
 enum
 {
+	B2D_JOINT_DEAD = -1,    // destroyed (b2World::DestroyJoint): ids stay stable, every walk over the joints skips it
 	B2D_JOINT_REVOLUTE = 0, // e_revoluteJoint
 	B2D_JOINT_DISTANCE = 1, // e_distanceJoint
 	B2D_JOINT_PRISMATIC = 2, // e_prismaticJoint

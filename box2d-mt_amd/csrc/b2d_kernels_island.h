@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void k_island_union(DW W)
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
 	{
 		const RevoluteJoint& jn = W.joints[j];
+		if (jn.type == B2D_JOINT_DEAD) continue;
 		bool nsA = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC;
 		bool nsB = (W.b_flags[jn.bodyB] & BF_TYPE_MASK) != BT_STATIC;
 		if (nsA && nsB) ufUnion(W.parent, jn.bodyA, jn.bodyB);
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void k_island_count(DW W)
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
 	{
 		const RevoluteJoint& jn = W.joints[j];
+		if (jn.type == B2D_JOINT_DEAD) continue;
 		int b = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC ? jn.bodyA : jn.bodyB;
 		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
 		atomicAdd(&W.rootJoints[W.parent[b]], 1);
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(256) void k_joints_fill(DW W)
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
 	{
 		const RevoluteJoint& jn = W.joints[j];
+		if (jn.type == B2D_JOINT_DEAD) continue;
 		int b = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC ? jn.bodyA : jn.bodyB;
 		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
 		const int root = W.parent[b];

@@ -760,6 +760,10 @@ static int flushEdits(b2hip_world* w)
 			const size_t o2 = offsetof(JointRec, localAnchorA), l2 = offsetof(JointRec, enableLimit) - o2;
 			HIP_TRY(hipMemcpyAsync((char*)(w->d_joints.p + id) + o2, (const char*)&w->joints[id] + o2, l2, hipMemcpyHostToDevice, s));
 		}
+		if (w->jointEdits[k].second == 3)
+		{
+			HIP_TRY(hipMemcpyAsync((char*)(w->d_joints.p + id) + offsetof(JointRec, type), &w->joints[id].type, sizeof(int), hipMemcpyHostToDevice, s));
+		}
 		if (w->jointEdits[k].second == 1)
 		{
 			static const float zero = 0.0f;
@@ -776,6 +780,7 @@ static int flushEdits(b2hip_world* w)
 		std::vector<int> start(nbod + 1, 0), adj;
 		for (size_t j = 0; j < w->joints.size(); ++j)
 		{
+			if (w->joints[j].type == B2D_JOINT_DEAD) continue;
 			start[w->joints[j].bodyA + 1] += 1;
 			if (w->joints[j].bodyB != w->joints[j].bodyA) start[w->joints[j].bodyB + 1] += 1;
 		}
@@ -784,6 +789,7 @@ static int flushEdits(b2hip_world* w)
 		std::vector<int> cursor(start.begin(), start.end() - 1);
 		for (int j = (int)w->joints.size() - 1; j >= 0; --j)
 		{
+			if (w->joints[j].type == B2D_JOINT_DEAD) continue;
 			adj[(size_t)cursor[w->joints[j].bodyA]++] = j;
 			if (w->joints[j].bodyB != w->joints[j].bodyA) adj[(size_t)cursor[w->joints[j].bodyB]++] = j;
 		}
@@ -2101,6 +2107,23 @@ static void wakeJointBodies(b2hip_world* w, const JointRec& j)
 			b.sleepTime = 0.0f;
 		}
 	}
+}
+
+int b2hip_destroy_joint(b2hip_world* w, int joint)
+{
+	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_destroy_joint inside a step");
+	JointRec& j = w->joints[joint];
+	if (j.type == B2D_JOINT_DEAD) return setError(B2HIP_ERR_INVALID, "joint already destroyed");
+	// (a gear joint must be destroyed before the joints it couples, as in the reference)
+	wakeJointBodies(w, j);
+	// contacts between the two bodies are filtered again when the joint kept them from colliding (b2World.cpp:833-845)
+	if (j.collideConnected == 0) w->pendingFilter.push_back(std::make_pair(j.bodyA, j.bodyB));
+	if (j.type == B2D_JOINT_MOUSE) w->nMouseJoints -= 1;
+	j.type = B2D_JOINT_DEAD;
+	w->jadjJoints = (size_t)-1; // per-body joint lists are rebuilt without it
+	w->jointEdits.push_back(std::make_pair(joint, 3));
+	return 0;
 }
 
 int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor)

@@ -41,6 +41,7 @@ public:
 
 	b2Body* CreateBody(const b2BodyDef* def);
 	b2Joint* CreateJoint(const b2JointDef* def);
+	void DestroyJoint(b2Joint* joint);   // reference: b2World.cpp:762-846 (destroy a gear joint before the joints it couples)
 
 	/// Take a time step: collide, solve islands, update the broad-phase - all on the device.
 	void Step(float32 timeStep, int32 velocityIterations, int32 positionIterations, b2TaskExecutor& executor);

@@ -373,6 +373,22 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 	return j;
 }
 
+void b2World::DestroyJoint(b2Joint* j)
+{
+	if (IsLocked() || !m_hip || j == nullptr) return;
+	if (b2hip_destroy_joint(m_hip, j->m_id) != B2HIP_OK)
+	{
+		fprintf(stderr, "b2World::DestroyJoint: %s\n", b2hip_last_error());
+		return;
+	}
+	if (j->m_prev) j->m_prev->m_next = j->m_next;
+	if (j->m_next) j->m_next->m_prev = j->m_prev;
+	if (j == m_jointList) m_jointList = j->m_next;
+	--m_jointCount;
+	j->~b2Joint();
+	b2Free(j);
+}
+
 void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIterations, b2TaskExecutor& executor)
 {
 	// The executor stays part of the signature (plugin surface); the device runs the physics phases.

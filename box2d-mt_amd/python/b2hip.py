@@ -150,6 +150,7 @@ def _configure(L, optional_ok=False):
         "b2hip_create_pulley_joint": [C.c_void_p, C.POINTER(PulleyJointDef)],
         "b2hip_create_mouse_joint": [C.c_void_p, C.POINTER(MouseJointDef)],
         "b2hip_create_gear_joint": [C.c_void_p, C.POINTER(GearJointDef)],
+        "b2hip_destroy_joint": [C.c_void_p, C.c_int],
         "b2hip_joint_set_target": [C.c_void_p, C.c_int, C.c_float, C.c_float],
         "b2hip_joint_set_offsets": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
         "b2hip_joint_set_motor": [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float],
@@ -383,6 +384,9 @@ class World:
     def create_gear_joint(self, joint1, joint2, ratio=1.0, collide_connected=False):
         d = GearJointDef(joint1, joint2, ratio, int(collide_connected))
         return _check(self.L.b2hip_create_gear_joint(self.p, C.byref(d)))
+
+    def destroy_joint(self, joint):
+        _check(self.L.b2hip_destroy_joint(self.p, joint))
 
     def joint_set_target(self, joint, target):
         _check(self.L.b2hip_joint_set_target(self.p, joint, target[0], target[1]))

@@ -23,6 +23,7 @@
  *   b2hip_create_gear_joint          b2World::CreateJoint (gear)            Joints/b2GearJoint.cpp:50-129
  *   b2hip_joint_set_target           b2MouseJoint::SetTarget                Joints/b2MouseJoint.cpp:57-64
  *   b2hip_joint_set_offsets          b2MotorJoint::SetLinearOffset / SetAngularOffset   Joints/b2MotorJoint.cpp:253-281
+ *   b2hip_destroy_joint              b2World::DestroyJoint                  b2World.cpp:762-846
  *   b2hip_joint_set_motor            b2{Revolute,Prismatic,Wheel}Joint::EnableMotor / SetMotorSpeed / SetMaxMotor{Torque,Force}
  *                                                                           Joints/b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616
  *   b2hip_joint_set_limits           b2{Revolute,Prismatic}Joint::EnableLimit / SetLimits
@@ -322,6 +323,10 @@ int b2hip_create_gear_joint(b2hip_world* w, const b2hip_gear_joint_def* def);
 int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y);
 /* b2MotorJoint::SetLinearOffset + SetAngularOffset (b2MotorJoint.cpp:253-281): wakes both bodies when something changes */
 int b2hip_joint_set_offsets(b2hip_world* w, int joint, float linear_x, float linear_y, float angular);
+/* b2World::DestroyJoint (b2World.cpp:762-846): wakes both bodies; contacts between them are filtered again if the joint
+ * kept them from colliding. Joint ids are never reused (the id of a destroyed joint stays invalid). Destroy a gear joint
+ * before the joints it couples. */
+int b2hip_destroy_joint(b2hip_world* w, int joint);
 /* Revolute / prismatic / wheel (motor only) joints between steps: EnableMotor + SetMotorSpeed + SetMaxMotorTorque|Force in one call, and
  * EnableLimit + SetLimits in one call. Like the reference's setters, a call that changes something wakes both bodies and
  * (limits) restarts the limit impulse from zero; a call that changes nothing does nothing. */

@@ -94,6 +94,7 @@ int b2o_create_pulley_joint(b2o_world* w, int bodyA, int bodyB, const float* anc
 int b2o_create_mouse_joint(b2o_world* w, int bodyA, int bodyB, float tx, float ty, float maxForce, float frequencyHz,
 	float dampingRatio, int collideConnected);
 int b2o_create_gear_joint(b2o_world* w, int joint1, int joint2, float ratio, int collideConnected);
+void b2o_destroy_joint(b2o_world* w, int joint);
 void b2o_joint_set_target(b2o_world* w, int joint, float tx, float ty);
 void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float angular);
 void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor);

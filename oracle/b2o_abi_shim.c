@@ -132,6 +132,12 @@ int b2hip_create_gear_joint(b2hip_world* w, const b2hip_gear_joint_def* def)
 	return b2o_create_gear_joint(w->o, def->joint1, def->joint2, def->ratio, def->collide_connected);
 }
 
+int b2hip_destroy_joint(b2hip_world* w, int joint)
+{
+	b2o_destroy_joint(w->o, joint);
+	return 0;
+}
+
 int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y)
 {
 	b2o_joint_set_target(w->o, joint, x, y);

@@ -591,6 +591,42 @@ void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float an
 	j->referenceAngle = angular;
 }
 
+/* b2World::DestroyJoint (b2World.cpp:762-846) */
+static void unlink_joint_edge(b2o_world* w, int body, int edge)
+{
+	int* link = &w->bodies[body].jointHead;
+	while (*link >= 0 && *link != edge)
+	{
+		revolute_t* o = &w->joints[*link >> 1];
+		link = (*link & 1) ? &o->nextB : &o->nextA;
+	}
+	if (*link == edge)
+	{
+		revolute_t* me = &w->joints[edge >> 1];
+		*link = (edge & 1) ? me->nextB : me->nextA;
+	}
+}
+
+void b2o_destroy_joint(b2o_world* w, int joint)
+{
+	revolute_t* j = &w->joints[joint];
+	if (j->type < 0) return;
+	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
+	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	unlink_joint_edge(w, j->bodyA, joint * 2);
+	unlink_joint_edge(w, j->bodyB, joint * 2 + 1);
+	if (!j->collideConnected)
+	{
+		for (int e = w->bodies[j->bodyB].contactHead; e >= 0; e = w->contacts[e >> 1].next[e & 1])
+		{
+			contact_t* c = &w->contacts[e >> 1];
+			int other = (e & 1) == 0 ? c->bodyB : c->bodyA;
+			if (other == j->bodyA) c->flags |= CF_FILTER;
+		}
+	}
+	j->type = -1;
+}
+
 /* EnableMotor / SetMotorSpeed / SetMaxMotorTorque|Force (b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616) */
 void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor)
 {

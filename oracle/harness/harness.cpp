@@ -125,6 +125,12 @@ void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
 			const bool atLower = speed < 0.0f && at <= slider->GetLowerLimit() + b2_epsilon;
 			if (atUpper || atLower) slider->SetMotorSpeed(-slider->GetMotorSpeed());
 		}
+		if (h->scene.drag != NULL && h->scene.servoStep == 170)
+		{
+			// mouse up (Test::MouseUp, Testbed/Framework/Test.cpp:203-215): the crate is let go in mid-air
+			h->world->DestroyJoint(h->scene.drag);
+			h->scene.drag = NULL;
+		}
 		if (h->scene.drag != NULL)
 		{
 			const float t = 0.04f * (float)h->scene.servoStep;

@@ -341,6 +341,51 @@ def test_many_jointed_islands(libs, monkeypatch):
     a.close(); b.close()
 
 
+def test_destroy_joint(libs, monkeypatch):
+    """b2hip_destroy_joint (b2World::DestroyJoint): a pendulum chain cut in the middle, a welded pair whose members may collide
+    only once the weld (collide_connected = false) is gone, a joint destroyed while its bodies sleep (they wake), the second of
+    two joints between the same bodies, and creating new joints afterwards (ids are not reused)."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = both(libs)
+    ids = {}
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+        w.create_fixture(g, b2hip.box_shape(40.0, 0.5))
+        prev = g
+        for i in range(6):
+            d = w.create_body(b2hip.DYNAMIC, (0.5 + i, 12.0))
+            w.create_fixture(d, b2hip.box_shape(0.5, 0.1), density=2.0)
+            ids["link%d" % i] = w.create_revolute_joint(prev, d, anchor_a=(0.0, 12.0) if i == 0 else (0.5, 0.0), anchor_b=(-0.5, 0.0))
+            prev = d
+        p = w.create_body(b2hip.DYNAMIC, (-10.0, 3.0))
+        w.create_fixture(p, b2hip.box_shape(1.0, 0.5), density=1.0)
+        q = w.create_body(b2hip.DYNAMIC, (-10.0, 3.6))
+        w.create_fixture(q, b2hip.box_shape(0.5, 0.5), density=1.0)
+        ids["weld"] = w.create_weld_joint(p, q, anchor_a=(0.0, 0.5), anchor_b=(0.0, -0.1))   # overlapping boxes, no contact while welded
+        ids["rod"] = w.create_distance_joint(p, q, anchor_a=(0.9, 0.0), anchor_b=(0.4, 0.0), length=0.8, collide_connected=True)
+        s_ = w.create_body(b2hip.DYNAMIC, (15.0, 1.0))
+        w.create_fixture(s_, b2hip.box_shape(0.5, 0.5), density=1.0)
+        ids["tether"] = w.create_rope_joint(g, s_, anchor_a=(15.0, 6.0), anchor_b=(0.0, 0.5), max_length=6.0)
+        ids["bodies"] = (p, q, s_, prev)
+
+    def between(s, w):
+        if s == 90:
+            w.destroy_joint(ids["link3"])
+        if s == 140:
+            w.destroy_joint(ids["weld"])
+        if s == 200:
+            w.destroy_joint(ids["rod"])
+        if s == 260:
+            w.destroy_joint(ids["tether"])          # its body has been asleep on the ground for a while
+            n = w.create_revolute_joint(ids["bodies"][0], ids["bodies"][1], anchor_a=(1.0, 0.5), anchor_b=(0.5, -0.5))
+            assert n > ids["tether"]
+
+    run(a, b, 330, "destroy joint", between=between)
+    with pytest.raises(b2hip.B2HipError):
+        a.destroy_joint(ids["weld"])
+    a.close(); b.close()
+
+
 def test_joint_setters_between_steps(libs, monkeypatch):
     """b2hip_joint_set_motor / b2hip_joint_set_limits: reverse a slider's motor, switch motors off and on, move and drop the
     limits of a revolute arm while everything has gone to sleep (the setters wake both bodies, as the reference's do), and
