@@ -1,0 +1,223 @@
+"""The default (coloured-order) solver pinned to north_star's tolerance from IDENTICAL inputs.
+
+A reordered Gauss-Seidel sweep cannot follow the reference's trajectory for long, but ONE step from
+the same state must land within 1e-4 of it. So: a world in exact-order mode (bit-equal to the CPU oracle, asserted on the
+way) is stepped to step k of the scene, `b2hip_save_snapshot` is taken, `b2hip_load_snapshot` brings it up as a world in
+the DEFAULT mode (the solver the bench times), that world takes ONE step, and the result is compared with the oracle's
+step k + 1:
+
+  * island labels (set partition), awake flags, contact set, touching flags: exact;
+  * positions, angles: |d| <= ONE_STEP_REL_TOL x scene scale;  velocities: |d| <= ONE_STEP_REL_TOL x scene scale per second.
+
+Scenes: config 2 at full size (Pyramid 141 rows = 10 011 boxes, one island: the resident large-island solver), a Tumbler
+(hub body + revolute motor joint: hub lane and joint rows) and a fleet of cars on wheel joints (jointed islands).
+Reference: b2Island.cpp:184-396 (b2Island::Solve), b2World.cpp:1207-1371 (island build).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import b2harness as bh
+import b2hip
+
+pytestmark = pytest.mark.gpu
+
+ONE_STEP_REL_TOL = 1e-4  # north_star: "results within 1e-4 rel of CPU reference"
+
+
+@pytest.fixture(scope="module")
+def libs(built_libs):
+    if not bh.have_amd():
+        pytest.fail("libb2hip.so missing (no CPU fallback)")
+    return b2hip.lib(), b2hip.load(bh.ORACLE_LIB, optional_ok=True)
+
+
+def offset_box(hx, hy, cx, cy):
+    """b2PolygonShape::SetAsBox(hx, hy, center, 0) (b2PolygonShape.cpp:44-66)"""
+    s = b2hip.box_shape(hx, hy)
+    for i in range(4):
+        s.verts[2 * i] = np.float32(s.verts[2 * i]) + np.float32(cx)
+        s.verts[2 * i + 1] = np.float32(s.verts[2 * i + 1]) + np.float32(cy)
+    s.centroid[0], s.centroid[1] = cx, cy
+    return s
+
+
+def build_pyramid(w, rows):
+    """Testbed/Tests/Pyramid.h:30-69 with e_count = rows (float32 accumulation as the loop does it)."""
+    g = w.create_body(b2hip.STATIC)
+    w.create_fixture(g, b2hip.edge_shape((-200.0, 0.0), (200.0, 0.0)))
+    box = b2hip.box_shape(0.5, 0.5)
+    x = np.array([-7.0, 0.75], np.float32)
+    dx = np.array([0.5625, 1.25], np.float32)
+    dy = np.array([1.125, 0.0], np.float32)
+    for i in range(rows):
+        y = x.copy()
+        for j in range(i, rows):
+            b = w.create_body(b2hip.DYNAMIC, (float(y[0]), float(y[1])))
+            w.create_fixture(b, box, density=5.0)
+            y = y + dy
+        x = x + dx
+
+
+def build_tumbler(w, boxes):
+    """Testbed/Tests/Tumbler.h:31-68: hollow square on a revolute motor, boxes on a grid inside."""
+    g = w.create_body(b2hip.STATIC)
+    t = w.create_body(b2hip.DYNAMIC, (0.0, 10.0), allow_sleep=False)
+    for hx, hy, cx, cy in ((0.5, 10.0, 10.0, 0.0), (0.5, 10.0, -10.0, 0.0), (10.0, 0.5, 0.0, 10.0), (10.0, 0.5, 0.0, -10.0)):
+        w.create_fixture(t, offset_box(hx, hy, cx, cy), density=5.0)
+    w.create_revolute_joint(g, t, anchor_a=(0.0, 10.0), anchor_b=(0.0, 0.0), enable_motor=True,
+                            motor_speed=0.05 * np.pi, max_motor_torque=1e8)
+    side = int(np.ceil(np.sqrt(boxes)))
+    small = b2hip.box_shape(0.125, 0.125)
+    for i in range(boxes):
+        px = -0.3 * side / 2 + 0.3 * (i % side)
+        py = 10.0 - 9.0 + 0.3 * (i // side)
+        b = w.create_body(b2hip.DYNAMIC, (px, py))
+        w.create_fixture(b, small, density=1.0)
+
+
+def build_cars(w, cars):
+    """Chassis + two wheels on wheel joints (one driven), a revolute trailer behind every third car, on a long strip
+    (cf. Testbed/Tests/Car.h:146-221)."""
+    g = w.create_body(b2hip.STATIC, (6.0 * cars, -0.25))
+    w.create_fixture(g, b2hip.box_shape(6.0 * cars + 20.0, 0.25))
+    for c in range(cars):
+        x, y = 12.0 * c + 2.0, 1.0
+        ch = w.create_body(b2hip.DYNAMIC, (x, y))
+        w.create_fixture(ch, b2hip.box_shape(1.5, 0.4), density=1.0)
+        for k, dx in enumerate((-1.0, 1.0)):
+            wh = w.create_body(b2hip.DYNAMIC, (x + dx, y - 0.6))
+            w.create_fixture(wh, b2hip.circle_shape(0.4), density=1.0, friction=0.9)
+            w.create_wheel_joint(ch, wh, anchor_a=(dx, -0.6), axis=(0.0, 1.0), frequency_hz=4.0, damping_ratio=0.7,
+                                 enable_motor=(k == 0), motor_speed=-2.0 - 0.05 * c, max_motor_torque=20.0)
+        if c % 3 == 0:
+            tr = w.create_body(b2hip.DYNAMIC, (x + 3.2, y - 0.3))
+            w.create_fixture(tr, b2hip.box_shape(1.0, 0.2), density=0.5, friction=0.1)
+            w.create_revolute_joint(ch, tr, anchor_a=(1.8, -0.3), anchor_b=(-1.4, 0.0))
+
+
+def partition(labels):
+    """Island labels as a canonical set partition: every body gets the smallest body id carrying its label (-1 stays -1)."""
+    labels = np.asarray(labels)
+    out = np.full(labels.shape, -1, np.int64)
+    solved = labels >= 0
+    if solved.any():
+        ids = np.nonzero(solved)[0]
+        lab = labels[solved]
+        order = np.lexsort((ids, lab))
+        first = np.ones(lab.size, bool)
+        first[1:] = lab[order][1:] != lab[order][:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(lab.size), 0))
+        out[ids[order]] = ids[order][start]
+    return out
+
+
+def contact_table(w):
+    c = w.contacts()
+    order = np.lexsort((c["fixture_b"], c["fixture_a"]))
+    return c[order]
+
+
+def bitwise_same(a, o, what):
+    sa, so = a.body_states(), o.body_states()
+    for f in ("px", "py", "angle", "vx", "vy", "w"):
+        assert np.array_equal(sa[f].view(np.uint32), so[f].view(np.uint32)), "%s: %s differs (exact-order world vs oracle)" % (what, f)
+    assert a.contact_count == o.contact_count, what
+
+
+def one_step_deviation(b, o):
+    """Relative deviations of the default-mode world `b` from the oracle `o` after the one step, plus the exact checks."""
+    sb, so = b.body_states(), o.body_states()
+    scale = float(max(np.abs(so["px"]).max(), np.abs(so["py"]).max(), 1.0))
+    pos = max(float(np.abs(sb[f] - so[f]).max()) for f in ("px", "py"))
+    ang = float(np.abs(sb["angle"] - so["angle"]).max())
+    vel = max(float(np.abs(sb[f] - so[f]).max()) for f in ("vx", "vy"))
+    spin = float(np.abs(sb["w"] - so["w"]).max())
+    assert np.isfinite(sb["px"]).all() and np.isfinite(sb["vx"]).all()
+    assert np.array_equal(sb["flags"] & 0x7f, so["flags"] & 0x7f), "body flags (awake / type) differ after one step"
+    return {"scale": scale, "pos": pos / scale, "angle": ang, "vel": vel / scale, "spin": spin}
+
+
+SCENES = {
+    # name: (builder, size, steps at which a one-step comparison is made, continuous physics)
+    "pyramid141": (build_pyramid, 141, (20, 60, 130), True),
+    "tumbler2000": (build_tumbler, 2000, (40, 100), False),
+    "cars60": (build_cars, 60, (30, 90), True),
+}
+
+
+def run_scene(libs, name, report=None):
+    builder, size, ks, continuous = SCENES[name]
+    os.environ["B2HIP_FORCE_LARGE"] = "2"  # read at world creation: every island in the reference's constraint order
+    try:
+        a = b2hip.World(library=libs[0], continuous=continuous)
+    finally:
+        os.environ.pop("B2HIP_FORCE_LARGE", None)
+    o = b2hip.World(library=libs[1], continuous=continuous)
+    builder(a, size)
+    builder(o, size)
+    step = 0
+    worst = {}
+    for k in ks:
+        while step < k:
+            a.step()
+            o.step()
+            step += 1
+        bitwise_same(a, o, "%s step %d" % (name, step))
+        blob = a.save_snapshot()
+        b = b2hip.World.from_snapshot(blob, library=libs[0])  # default mode: B2HIP_FORCE_LARGE is not set any more
+        a.step()
+        o.step()
+        step += 1
+        bitwise_same(a, o, "%s step %d" % (name, step))
+        b.step()
+        # exact: islands of the step just solved, contact set and touching flags after it
+        assert np.array_equal(partition(b.island_labels()), partition(o.island_labels())), "%s step %d: island membership" % (name, step)
+        cb, co = contact_table(b), contact_table(o)
+        assert b.contact_count == o.contact_count, "%s step %d: contact count %d vs %d" % (name, step, b.contact_count, o.contact_count)
+        assert np.array_equal(cb["fixture_a"], co["fixture_a"]) and np.array_equal(cb["fixture_b"], co["fixture_b"]), "%s step %d: contact set" % (name, step)
+        assert np.array_equal(cb["flags"] & 1, co["flags"] & 1), "%s step %d: touching flags" % (name, step)
+        dev = one_step_deviation(b, o)
+        cnt = b.counters()
+        dev["large_island_contacts"] = cnt["large_island_contacts"]
+        if report is not None:
+            report.append((name, step, dev))
+        for key in ("pos", "angle", "vel", "spin"):
+            worst[key] = max(worst.get(key, 0.0), dev[key])
+        b.close()
+    a.close()
+    o.close()
+    return worst
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_default_solver_one_step_from_identical_state(libs, name):
+    worst = run_scene(libs, name)
+    for key in ("pos", "angle", "vel", "spin"):
+        assert worst[key] <= ONE_STEP_REL_TOL, "%s: %s deviates by %.3g (relative to scene scale) after one step" % (name, key, worst[key])
+
+
+@pytest.mark.parametrize("scene,p0,p1,seed,steps", [(bh.RAIN, 400, 0, 7, 120), (bh.FIELD, 2500, 0, 8, 80), (bh.PILES, 80, 6, 9, 160)])
+def test_island_labels_match_the_oracle_every_step(amd, oracle, scene, p0, p1, seed, steps):
+    """a11: the device's union-find labels (b2hip_get_island_labels) against the labels of the oracle's DFS
+    (b2o_get_island_labels, b2World.cpp:1207-1371), as set partitions, after every step. Default mode: these scenes are
+    bit-exact, so both see the same contact graph at every step."""
+    L = b2hip.lib()
+    O = b2hip.load(bh.ORACLE_LIB, optional_ok=True)
+    a = amd.world(scene, p0, p1, seed=seed)
+    o = oracle.world(scene, p0, p1, seed=seed)
+    n = a.body_count
+    la, lo = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    multi = 0
+    for s in range(steps):
+        a.step(1)
+        o.step(1)
+        assert L.b2hip_get_island_labels(a.device_world(), n, la.ctypes.data) == n
+        assert O.b2hip_get_island_labels(o.device_world(), n, lo.ctypes.data) == n
+        pa, po = partition(la), partition(lo)
+        assert np.array_equal(pa, po), "island membership differs at step %d" % s
+        multi = max(multi, int(np.bincount(pa[pa >= 0]).max()) if (pa >= 0).any() else 0)
+    assert multi > 1, "no island with more than one body ever formed: test is vacuous"
+    a.close()
+    o.close()
