@@ -4,7 +4,9 @@
 A "step" is one full Step(1/60 s, 8 velocity / 3 position iterations) of the workload, including the
 mandatory host-visible body-state read-back. The N=1 workload is BASELINE.json
 configs[1]: the Pyramid recipe with 141 rows = 10 011 dynamic boxes on a ground edge (one island),
-measured in steady state after the warm-up steps. For N>1
+measured in STEADY STATE: the scene is first settled for SETTLE_STEPS (120) untimed steps as part of building the
+workload, whatever --warmup says (the free-fall / first-impact transient of those steps is reported separately
+under "transient"), then --warmup untimed steps, then the timed steps. For N>1
 (configs[3]-style sharding) every rank owns one such pyramid island: islands never exchange data, so
 there is no data-path collective ("weak" scaling); `value` counts island-steps of all ranks.
 World flags are the reference's defaults (b2World.cpp:75-79): continuous physics (TOI) ON, sleeping ON,
@@ -30,6 +32,50 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+SETTLE_STEPS = 120     # "measure steady state (after >= 120 warm-up steps) and first-contact transient separately"
+
+
+def committed_pmc_traffic(kernel, workload_key):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE profile of THIS command in
+    THIS state (profiles/*_pmc_traffic.json: {"kernel", "workload", "state": "steady", "hbm_bytes_per_dispatch"}); PMC counters
+    cannot be sampled from inside the process. None when no committed profile matches kernel, workload and state."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            pmc = json.load(open(path))
+        except Exception:
+            continue
+        if pmc.get("kernel") == kernel and pmc.get("workload") == workload_key and pmc.get("state") == "steady":
+            best = (pmc["hbm_bytes_per_dispatch"], os.path.relpath(path, ROOT))
+    return best
+
+
+def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, seed=3):
+    """One of the other BASELINE configs on this GPU, short: settle, then `steps` timed steps (read-back included)."""
+    import b2harness as bh  # noqa: F401
+    import b2hip
+    t0 = time.perf_counter()
+    w = amd.world(scene, p0, p1, seed=seed, flags=flags)
+    build_s = time.perf_counter() - t0
+    w.step(settle)
+    w.reset_profile()
+    stamps = np.empty(steps + 1)
+    stamps[0] = time.perf_counter()
+    for k in range(steps):
+        w.step(1)
+        stamps[k + 1] = time.perf_counter()
+    per = 1000.0 * np.diff(stamps)
+    ctr = b2hip.Counters()
+    hipL.b2hip_get_counters(C.c_void_p(w.device_world()), C.byref(ctr))
+    out = {"workload": name, "bodies": w.body_count, "contacts": w.contact_count, "settle_steps": settle, "timed_steps": steps,
+           "ms_per_step": float(per.mean()), "ms_per_step_p50": float(np.percentile(per, 50)), "ms_per_step_max": float(per.max()),
+           "steps_per_s": 1000.0 / float(per.mean()), "build_s": round(build_s, 2),
+           "islands": ctr.islands, "large_island_constraints": ctr.large_island_contacts, "small_island_constraints": ctr.small_island_contacts,
+           "toi_events_last_step": ctr.toi_events,
+           "device_profile_ms": {k: round(v, 4) for k, v in w.profile().items() if k != "steps"}}
+    w.close()
+    return out
 
 
 def cpu_baseline(rows, warmup, max_seconds, flags):
@@ -75,6 +121,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ccd", action="store_true", help="turn continuous physics (TOI) off on both sides")
     ap.add_argument("--no-secondary", action="store_true", help="skip the multi-island roofline sample (500 k bodies in 100 k piles)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other BASELINE configs (Tumbler 100 k, 1 M field, 50 k pyramid)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -109,6 +156,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # workload construction: settle the pile (untimed, always), keeping the cost of the transient for the report
+    settle_ms = np.empty(SETTLE_STEPS)
+    for k in range(SETTLE_STEPS):
+        ts = time.perf_counter()
+        w.step(1)
+        settle_ms[k] = 1000.0 * (time.perf_counter() - ts)
     w.step(args.warmup)
     w.reset_profile()
     barrier()
@@ -163,16 +216,14 @@ def main():
                     "constraints": ctr.large_island_contacts + ctr.small_island_contacts,
                     "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors,
                     "toi_calls_per_step": ctr.toi_calls, "toi_events_last_step": ctr.toi_events}
-        # HBM traffic of that kernel: PMC counters cannot be sampled from inside this process; the per-launch figure
-        # measured with rocprofv3 --pmc on this same command is committed under profiles/ and quoted here when the
-        # workload and the kernel match (null otherwise)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")))
-            if roof is not None and pmc.get("kernel") == kname and args.rows == 141 and not args.no_ccd:
-                roof["traffic"] = pmc["hbm_bytes_per_dispatch"]
-                roof["traffic_source"] = "profiles/r01_h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
+        # HBM traffic of that kernel: null unless a committed rocprofv3 --pmc profile of this command matches the kernel,
+        # the workload and the (steady) state this run measured
+        if roof is not None:
+            hit = committed_pmc_traffic(kname, "pyramid%d%s" % (args.rows, "" if not args.no_ccd else "_noccd"))
+            if hit is not None:
+                roof["traffic"] = hit[0]
+                roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, steady state)" % hit[1]
+                roof["traffic_GBps"] = hit[0] / (1e-3 * tot_ms / launches) / 1e9
         smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
         hipL.b2hip_get_solver_timing(dev, C.byref(smsv), C.byref(sbytes), C.byref(sct), C.byref(sb))
         if roof is not None and smsv.value > 0:
@@ -208,10 +259,38 @@ def main():
                 ach = tot_b2 / (tot_ms2 * 1e-3) / 1e9
                 secondary = {"workload": "100 000 piles of 5 boxes (%d bodies, %d contacts), same step parameters" % (w2.body_count, w2.contact_count),
                              "bound": "hbm", "kernel": k2, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "achieved_is": "algorithmic (reference-layout) bytes / launch time; the kernel keeps rows in LDS / registers, so counter traffic is lower",
+                             "traffic": None,
                              "mean_launch_us": 1000.0 * tot_ms2 / n2, "algorithmic_bytes_per_launch": tot_b2 / n2}
+                hit = committed_pmc_traffic(k2, "piles100000x5")
+                if hit is not None:
+                    secondary["traffic"] = hit[0]
+                    secondary["traffic_source"] = hit[1]
+                    secondary["traffic_GBps"] = hit[0] / (1e-3 * tot_ms2 / n2) / 1e9
             w2.close()
         except Exception as e:
             secondary = {"error": str(e)}
+
+    # ---- the other BASELINE configs, short (not part of `value`): config 3, the 1-GPU form of config 5, config 4's share ----
+    extras = None
+    if not args.no_extras:
+        extras = []
+        jobs = []
+        if world_size == 1:
+            jobs.append(("config 3: Tumbler 316 x 316 = 99 856 boxes in a revolving container, CCD off (Tumbler.h)", bh.TUMBLER, 316, 0, bh.F_SLEEP | bh.F_WARM, 60, 20))
+            jobs.append(("config 5 on ONE GPU: 1 M mixed circles + boxes random field, 10 000 bullets, CCD on", bh.FIELD, 1000000, 10000, flags | bh.F_CONTINUOUS, 10, 10))
+        jobs.append(("config 4, one GPU's share: Pyramid 316 rows = 50 086 boxes, CCD on", bh.PYRAMID, 316, 1, flags, 60, 20))
+        for job in jobs:
+            try:
+                extras.append(time_extra(amd, hipL, *job))
+            except Exception as e:
+                extras.append({"workload": job[0], "error": str(e)})
+        if dist is not None:
+            # config 4 as stated: every rank steps its own 50 086-box pyramid; whole-job rate over the slowest rank
+            t = torch.tensor([extras[-1].get("ms_per_step", 0.0)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            extras[-1]["ms_per_step_max_over_ranks"] = float(t.item())
+            extras[-1]["island_steps_per_s_all_ranks"] = world_size * 1000.0 / float(t.item()) if t.item() > 0 else None
 
     contacts = w.contact_count
     # Untimed: assemble the host-visible state of the WHOLE world on every rank with one all-gather over
@@ -244,11 +323,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Pyramid %d rows: %d bodies, %d contacts per GPU, dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
-                                   % (args.rows, nbodies, contacts, "off" if args.no_ccd else "on (reference default)"),
+            "config": {"workload": "Pyramid %d rows: %d bodies, %d contacts per GPU, settled for %d untimed steps (steady state), dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
+                                   % (args.rows, nbodies, contacts, SETTLE_STEPS, "off" if args.no_ccd else "on (reference default)"),
+                       "settle_steps": SETTLE_STEPS,
                        "bodies_total": nbodies * world_size, "parallelism": "one island shard per GPU, no data-path collective"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
+        # the free-fall / first-impact transient the settle steps went through (rank 0), never part of `value`
+        line["transient"] = {"steps": "0..%d (workload construction, untimed)" % (SETTLE_STEPS - 1), "ms_per_step": float(settle_ms.mean()),
+                             "ms_per_step_p50": float(np.percentile(settle_ms, 50)), "ms_per_step_p99": float(np.percentile(settle_ms, 99)),
+                             "ms_per_step_max": float(settle_ms.max())}
+        if extras is not None:
+            line["extra_configs"] = extras
         if gather_ms is not None:
             line["world_state_allgather_ms"] = gather_ms
         if roof is not None:

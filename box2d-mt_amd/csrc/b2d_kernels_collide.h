@@ -282,15 +282,27 @@ __global__ void k_step_begin(DW W, int* bar)
 	if (t < 16) bar[t] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_flag_filter(DW W, int bodyA, int bodyB)
+// b2World::CreateJoint / DestroyJoint (b2World.cpp:716-732, 833-845): contacts between the two bodies of a joint that does
+// not let them collide (or no longer keeps them from it) are filtered again by the next Collide. `pairs` = the body pairs of
+// every joint created or destroyed since the last step, as sorted (low body << 32 | high body) keys: one launch whatever
+// their number (a world built with 20 000 joints used to issue 20 000 launches in its first step).
+__global__ __launch_bounds__(256) void k_flag_filter(DW W, const unsigned long long* pairs, int nPairs)
 {
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
-		int4 ids = C.ids[i];
-		if ((ids.z == bodyA && ids.w == bodyB) || (ids.z == bodyB && ids.w == bodyA)) C.flags[i] |= CF_FILTER;
+		const int4 ids = C.ids[i];
+		const unsigned lo = (unsigned)(ids.z < ids.w ? ids.z : ids.w), hi = (unsigned)(ids.z < ids.w ? ids.w : ids.z);
+		const unsigned long long key = ((unsigned long long)lo << 32) | hi;
+		int a = 0, b = nPairs;
+		while (a < b)
+		{
+			const int m = (a + b) >> 1;
+			if (pairs[m] < key) a = m + 1; else b = m;
+		}
+		if (a < nPairs && pairs[a] == key) C.flags[i] |= CF_FILTER;
 	}
 }
 

@@ -141,6 +141,8 @@ struct b2hip_world
 	bool newFixture;
 	float inv_dt0;
 	bool stepActive;
+	bool failed = false;          // a step failed half-way: the device state is inconsistent, every later call says so
+	std::string failedWhy;
 	StepParams sp;
 
 	// device
@@ -206,6 +208,7 @@ struct b2hip_world
 	int persistMaxWG;            // co-resident workgroups of k_solve_persistent on this device (0 = do not use it)
 	int persistSteps;            // steps solved by the persistent kernel (diagnostics)
 	DevArray<int> consts; // [0] nBodies, [1] gridSize, [2] radix hist count, [3] sorted-pair count
+	DevArray<unsigned long long> filterPairs; // sorted body-pair keys of the joints created / destroyed since the last step
 
 	// pinned host buffers
 	float* h_state;
@@ -247,6 +250,26 @@ struct b2hip_world
 	double ktBytes;
 };
 
+// Every entry point that touches the device runs with the world's device current and puts the caller's device back
+// afterwards: two worlds on different GPUs in one process, or a step from another thread, stay on their own device.
+struct DeviceGuard
+{
+	int prev = -1;
+	bool switched = false;
+	explicit DeviceGuard(int device)
+	{
+		if (device < 0 || hipGetDevice(&prev) != hipSuccess || prev == device) return;
+		switched = hipSetDevice(device) == hipSuccess;
+	}
+	~DeviceGuard()
+	{
+		if (switched) (void)hipSetDevice(prev);
+	}
+	DeviceGuard(const DeviceGuard&) = delete;
+	DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVICE_GUARD(w) DeviceGuard _deviceGuard((w)->device)
+
 // ------------------------------------------------------------------------------------------------
 static int nextPow2(size_t n)
 {
@@ -282,6 +305,17 @@ static void markDirty(b2hip_world* w, int i)
 	pullBody(w, i);
 	b.dirty = true;
 	w->dirtyList.push_back(i);
+}
+
+// b2Body::SetAwake(true) (b2Body.h:690-718): the flag is set and the sleep timer restarts whether the body was asleep or not
+// (a slowly dragged mouse joint keeps its body awake this way). A static body's timer is never read: only its flag matters.
+static void setAwake(b2hip_world* w, int i)
+{
+	if (w->bodies[i].type == B2HIP_STATIC_BODY && (w->bodies[i].flags & BF_AWAKE) != 0) return;
+	markDirty(w, i);
+	HostBody& b = w->bodies[i];
+	b.flags |= BF_AWAKE;
+	b.sleepTime = 0.0f;
 }
 
 static int allocProxyKey(b2hip_world* w)
@@ -440,10 +474,14 @@ static int syncCheck(b2hip_world* w, const char* what)
 	return 0;
 }
 
+// A launch that the runtime refuses (bad configuration, wrong device current, lost context) is reported at once:
+// hipGetLastError needs no synchronisation. With B2HIP_DEBUG the stream is drained after every launch as well.
 #define LAUNCH(w, kernel, grid, block, ...)                                                   \
 	do                                                                                        \
 	{                                                                                         \
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__);     \
+		hipError_t _le = hipGetLastError();                                                   \
+		if (_le != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(#kernel) + " launch: " + hipGetErrorString(_le)); \
 		int _rc = syncCheck((w), #kernel);                                                    \
 		if (_rc) return _rc;                                                                  \
 	} while (0)
@@ -453,6 +491,8 @@ static int syncCheck(b2hip_world* w, const char* what)
 	do                                                                                        \
 	{                                                                                         \
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (strm), __VA_ARGS__);          \
+		hipError_t _le = hipGetLastError();                                                   \
+		if (_le != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(#kernel) + " launch: " + hipGetErrorString(_le)); \
 		if ((w)->debugSync)                                                                   \
 		{                                                                                     \
 			hipError_t _e = hipStreamSynchronize(strm);                                       \
@@ -890,6 +930,30 @@ static int flushEdits(b2hip_world* w)
 	return 0;
 }
 
+// Flags the contacts between the bodies of every joint created or destroyed since the last step for re-filtering
+// (b2World.cpp:716-732, 833-845): one upload of the sorted pair keys, one launch. Called by the step and by the snapshot
+// (so that a snapshot taken right after CreateJoint / DestroyJoint carries the flags).
+static int applyPendingFilters(b2hip_world* w)
+{
+	if (w->pendingFilter.empty()) return 0;
+	std::vector<unsigned long long> keys(w->pendingFilter.size());
+	for (size_t k = 0; k < keys.size(); ++k)
+	{
+		const unsigned a = (unsigned)std::min(w->pendingFilter[k].first, w->pendingFilter[k].second);
+		const unsigned b = (unsigned)std::max(w->pendingFilter[k].first, w->pendingFilter[k].second);
+		keys[k] = ((unsigned long long)a << 32) | b;
+	}
+	std::sort(keys.begin(), keys.end());
+	keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+	int rc = w->filterPairs.ensure(keys.size(), w->stream, false, false);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(w->filterPairs.p, keys.data(), keys.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, w->stream));
+	LAUNCH(w, k_flag_filter, gridFor(w->dw.capContacts), 256, w->dw, w->filterPairs.p, (int)keys.size());
+	HIP_TRY(hipStreamSynchronize(w->stream)); // `keys` is pageable host memory
+	w->pendingFilter.clear();
+	return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Phases
 // ------------------------------------------------------------------------------------------------
@@ -1053,6 +1117,7 @@ static int phaseSolve(b2hip_world* w)
 			hipLaunchKernelGGL(k_scan_reduce<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, w->scanTmp4.p, w->consts.p);
 			hipLaunchKernelGGL(k_scan_blocksums<int4>, dim3(1), dim3(SCAN_THREADS), 0, w->stream, w->scanTmp4.p, w->consts.p, (int4*)nullptr);
 			hipLaunchKernelGGL(k_scan_final<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->consts.p);
+			if (hipError_t le = hipGetLastError()) return setError(B2HIP_ERR_HIP, std::string("k_scan<int4> launch: ") + hipGetErrorString(le));
 		}
 		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p, d.nBodies);
 		if (d.nJoints > 0)
@@ -1498,6 +1563,36 @@ static void refreshMirror(b2hip_world* w)
 	w->stateCount = w->bodies.size();
 }
 
+// A phase that fails leaves the device state half-stepped: the world unlocks (so that it can still be inspected and
+// destroyed) and every later call reports the failure instead of stepping on.
+static int stepFailed(b2hip_world* w, int rc)
+{
+	if (rc)
+	{
+		w->stepActive = false;
+		w->failed = true;
+		w->failedWhy = g_lastError;
+	}
+	return rc;
+}
+
+static int checkUsable(b2hip_world* w, const char* what, bool mutator)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	if (w->failed) return setError(B2HIP_ERR_INVALID, std::string(what) + ": the world is in a failed state (" + w->failedWhy + ")");
+	if (mutator && w->stepActive) return setError(B2HIP_ERR_INVALID, std::string(what) + " inside a step");
+	return 0;
+}
+
+static int addJoint(b2hip_world* w, const JointRec& j)
+{
+	if (int rcu = checkUsable(w, "b2hip_create_joint", true)) return rcu;
+	w->joints.push_back(j);
+	// b2World::CreateJoint (b2World.cpp:716-732): contacts between the two bodies are re-filtered
+	if (j.collideConnected == 0) w->pendingFilter.push_back(std::make_pair(j.bodyA, j.bodyB));
+	return (int)w->joints.size() - 1;
+}
+
 extern "C"
 {
 
@@ -1520,16 +1615,20 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	{
 		return setError(B2HIP_ERR_NO_DEVICE, "no HIP device available: the b2hip Step() path has no CPU fallback");
 	}
+	int current = 0;
+	if (hipGetDevice(&current) != hipSuccess) current = 0;
+	const int device = def->device >= 0 ? def->device : current;
+	if (device >= count) return setError(B2HIP_ERR_NO_DEVICE, "no such HIP device");
 	b2hip_world* w = new b2hip_world();
 	w->def = *def;
-	w->device = def->device;
-	if (w->device >= 0)
+	w->device = device; // the ordinal itself, also when the caller asked for "current": later calls select it again
+	DEVICE_GUARD(w);
 	{
-		e = hipSetDevice(w->device);
-		if (e != hipSuccess)
+		int now = -1;
+		if (hipGetDevice(&now) != hipSuccess || now != device)
 		{
 			delete w;
-			return setError(B2HIP_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+			return setError(B2HIP_ERR_NO_DEVICE, "hipSetDevice failed");
 		}
 	}
 	e = hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking);
@@ -1610,23 +1709,29 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->toiSyncOnly = getenv("B2HIP_TOI_SYNC") != nullptr;
 	w->toiNoDomains = getenv("B2HIP_TOI_NO_DOMAINS") != nullptr; // bullets / kinematic partners through the serial loop only // decide chains / serial loop from a read-back after k_toi_first (the older flow)
 	w->toiFallbacks = 0;
+	for (int i = 0; i < 13; ++i) w->ev[i] = nullptr;
+	w->h_dstate = nullptr;
 	for (int i = 0; i < 13; ++i)
 	{
 		if (hipEventCreate(&w->ev[i]) != hipSuccess)
 		{
+			b2hip_world_destroy(w);
 			return setError(B2HIP_ERR_HIP, "hipEventCreate failed");
 		}
 	}
 	if (hipHostMalloc((void**)&w->h_dstate, sizeof(DState), hipHostMallocDefault) != hipSuccess)
 	{
+		b2hip_world_destroy(w);
 		return setError(B2HIP_ERR_HIP, "hipHostMalloc failed");
 	}
 	int rc = ensureCapacity(w, 0);
+	if (rc == 0 && hipStreamSynchronize(w->stream) != hipSuccess) rc = setError(B2HIP_ERR_HIP, "stream sync failed");
 	if (rc)
 	{
-		return rc;
+		const std::string why = g_lastError;
+		b2hip_world_destroy(w);
+		return setError(rc, why);
 	}
-	if (hipStreamSynchronize(w->stream) != hipSuccess) return setError(B2HIP_ERR_HIP, "stream sync failed");
 	*out = w;
 	return B2HIP_OK;
 }
@@ -1634,7 +1739,8 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 void b2hip_world_destroy(b2hip_world* w)
 {
 	if (!w) return;
-	(void)hipStreamSynchronize(w->stream);
+	DEVICE_GUARD(w);
+	if (w->stream) (void)hipStreamSynchronize(w->stream);
 	w->d_state.release();
 	w->b_pos.release(); w->b_pos0.release(); w->b_vel.release(); w->b_xf.release(); w->b_mass.release(); w->b_damp.release();
 	w->b_force.release(); w->b_flags.release(); w->b_wake.release();
@@ -1663,11 +1769,14 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
 	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
+	w->filterPairs.release();
 	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
 	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->stateOut.release(); w->consts.release();
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
-	for (int i = 0; i < 13; ++i) (void)hipEventDestroy(w->ev[i]);
+	for (int i = 0; i < 13; ++i)
+		if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
+	for (size_t i = 0; i < w->ktEvents.size(); ++i) (void)hipEventDestroy(w->ktEvents[i]);
 	{
 		GraphSeg* segs[3] = { &w->segCollide, &w->segIslands, &w->segPairs };
 		for (int i = 0; i < 3; ++i)
@@ -1676,15 +1785,16 @@ void b2hip_world_destroy(b2hip_world* w)
 			if (segs[i]->graph) (void)hipGraphDestroy(segs[i]->graph);
 		}
 	}
-	(void)hipStreamDestroy(w->stream);
-	(void)hipStreamDestroy(w->stream2);
-	(void)hipEventDestroy(w->evFork);
-	(void)hipEventDestroy(w->evJoin);
+	if (w->stream) (void)hipStreamDestroy(w->stream);
+	if (w->stream2) (void)hipStreamDestroy(w->stream2);
+	if (w->evFork) (void)hipEventDestroy(w->evFork);
+	if (w->evJoin) (void)hipEventDestroy(w->evJoin);
 	delete w;
 }
 
 int b2hip_set_gravity(b2hip_world* w, float gx, float gy)
 {
+	if (int rcu = checkUsable(w, "b2hip_set_gravity", true)) return rcu;
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
 	w->def.gravity_x = gx;
 	w->def.gravity_y = gy;
@@ -1693,6 +1803,7 @@ int b2hip_set_gravity(b2hip_world* w, float gx, float gy)
 
 int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int continuous, int sub_stepping)
 {
+	if (int rcu = checkUsable(w, "b2hip_set_flags", true)) return rcu;
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
 	w->def.allow_sleep = allow_sleep;
 	w->def.warm_starting = warm_starting;
@@ -1704,6 +1815,7 @@ int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int cont
 int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def)
 {
 	if (!w || !def) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rcu = checkUsable(w, "b2hip_create_body", true)) return rcu;
 	HostBody b{};
 	b.type = def->type;
 	b.flags = 0;
@@ -1749,6 +1861,7 @@ int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def)
 int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def, const b2hip_shape* shape)
 {
 	if (!w || !def || !shape) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (int rcu = checkUsable(w, "b2hip_create_fixture", true)) return rcu;
 	if (body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad body id");
 	if (shape->type != B2HIP_SHAPE_CIRCLE && shape->type != B2HIP_SHAPE_EDGE && shape->type != B2HIP_SHAPE_POLYGON)
 	{
@@ -1818,10 +1931,7 @@ int b2hip_create_revolute_joint(b2hip_world* w, const b2hip_revolute_joint_def* 
 	j.motorSpeed = def->motor_speed;
 	j.maxMotorTorque = def->max_motor_torque;
 	j.collideConnected = def->collide_connected;
-	w->joints.push_back(j);
-	// b2World::CreateJoint (b2World.cpp:716-732): contacts between the two bodies are re-filtered
-	if (def->collide_connected == 0) w->pendingFilter.push_back(std::make_pair(def->body_a, def->body_b));
-	return (int)w->joints.size() - 1;
+	return addJoint(w, j);
 }
 
 int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* def)
@@ -1840,17 +1950,7 @@ int b2hip_create_distance_joint(b2hip_world* w, const b2hip_distance_joint_def* 
 	j.frequencyHz = def->frequency_hz;
 	j.dampingRatio = def->damping_ratio;
 	j.collideConnected = def->collide_connected;
-	w->joints.push_back(j);
-	if (def->collide_connected == 0) w->pendingFilter.push_back(std::make_pair(def->body_a, def->body_b));
-	return (int)w->joints.size() - 1;
-}
-
-static int addJoint(b2hip_world* w, const JointRec& j)
-{
-	w->joints.push_back(j);
-	// b2World::CreateJoint (b2World.cpp:716-732): contacts between the two bodies are re-filtered
-	if (j.collideConnected == 0) w->pendingFilter.push_back(std::make_pair(j.bodyA, j.bodyB));
-	return (int)w->joints.size() - 1;
+	return addJoint(w, j);
 }
 
 int b2hip_create_prismatic_joint(b2hip_world* w, const b2hip_prismatic_joint_def* def)
@@ -2024,20 +2124,12 @@ int b2hip_create_mouse_joint(b2hip_world* w, const b2hip_mouse_joint_def* def)
 
 int b2hip_joint_set_target(b2hip_world* w, int joint, float x, float y)
 {
+	if (int rcu = checkUsable(w, "b2hip_joint_set_target", true)) return rcu;
 	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
 	JointRec& j = w->joints[joint];
 	if (j.type != B2D_JOINT_MOUSE) return setError(B2HIP_ERR_INVALID, "not a mouse joint");
 	if (x == j.targetA.x && y == j.targetA.y) return 0;
-	if (w->bodies[j.bodyB].type != B2HIP_STATIC_BODY)
-	{
-		markDirty(w, j.bodyB);
-		HostBody& b = w->bodies[j.bodyB];
-		if ((b.flags & BF_AWAKE) == 0)
-		{
-			b.flags |= BF_AWAKE;
-			b.sleepTime = 0.0f;
-		}
-	}
+	setAwake(w, j.bodyB);
 	j.targetA = v2(x, y);
 	w->jointEdits.push_back(std::make_pair(joint, 2));
 	return 0;
@@ -2095,24 +2187,14 @@ int b2hip_create_gear_joint(b2hip_world* w, const b2hip_gear_joint_def* def)
 // b2Body::SetAwake(true) on both bodies of a joint whose definition changed (b2RevoluteJoint.cpp:418-500)
 static void wakeJointBodies(b2hip_world* w, const JointRec& j)
 {
-	const int ids[2] = { j.bodyA, j.bodyB };
-	for (int k = 0; k < 2; ++k)
-	{
-		if (w->bodies[ids[k]].type == B2HIP_STATIC_BODY) continue;
-		markDirty(w, ids[k]);
-		HostBody& b = w->bodies[ids[k]];
-		if ((b.flags & BF_AWAKE) == 0)
-		{
-			b.flags |= BF_AWAKE;
-			b.sleepTime = 0.0f;
-		}
-	}
+	setAwake(w, j.bodyA);
+	setAwake(w, j.bodyB);
 }
 
 int b2hip_destroy_joint(b2hip_world* w, int joint)
 {
 	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
-	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_destroy_joint inside a step");
+	if (int rcu = checkUsable(w, "b2hip_destroy_joint", true)) return rcu;
 	JointRec& j = w->joints[joint];
 	if (j.type == B2D_JOINT_DEAD) return setError(B2HIP_ERR_INVALID, "joint already destroyed");
 	// (a gear joint must be destroyed before the joints it couples, as in the reference)
@@ -2128,6 +2210,7 @@ int b2hip_destroy_joint(b2hip_world* w, int joint)
 
 int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor)
 {
+	if (int rcu = checkUsable(w, "b2hip_joint_set_motor", true)) return rcu;
 	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
 	JointRec& j = w->joints[joint];
 	if (j.type != B2D_JOINT_REVOLUTE && j.type != B2D_JOINT_PRISMATIC && j.type != B2D_JOINT_WHEEL)
@@ -2143,6 +2226,7 @@ int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float mot
 
 int b2hip_joint_set_offsets(b2hip_world* w, int joint, float linear_x, float linear_y, float angular)
 {
+	if (int rcu = checkUsable(w, "b2hip_joint_set_offsets", true)) return rcu;
 	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
 	JointRec& j = w->joints[joint];
 	if (j.type != B2D_JOINT_MOTOR) return setError(B2HIP_ERR_INVALID, "not a motor joint");
@@ -2156,6 +2240,7 @@ int b2hip_joint_set_offsets(b2hip_world* w, int joint, float linear_x, float lin
 
 int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lower, float upper)
 {
+	if (int rcu = checkUsable(w, "b2hip_joint_set_limits", true)) return rcu;
 	if (!w || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
 	JointRec& j = w->joints[joint];
 	if (j.type != B2D_JOINT_REVOLUTE && j.type != B2D_JOINT_PRISMATIC) return setError(B2HIP_ERR_INVALID, "joint type has no limits");
@@ -2195,6 +2280,7 @@ int b2hip_get_mass_data(const b2hip_world* w, int body, b2hip_mass_data* out)
 
 int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque, int wake)
 {
+	if (int rcu = checkUsable(w, "b2hip_apply_force", true)) return rcu;
 	if (!w || body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad argument");
 	if (w->bodies[body].type != B2HIP_DYNAMIC_BODY) return 0;
 	markDirty(w, body);
@@ -2215,6 +2301,7 @@ int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque
 
 int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega)
 {
+	if (int rcu = checkUsable(w, "b2hip_set_velocity", true)) return rcu;
 	if (!w || body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad argument");
 	if (w->bodies[body].type == B2HIP_STATIC_BODY) return 0;
 	markDirty(w, body);
@@ -2230,9 +2317,8 @@ int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega
 	return 0;
 }
 
-int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)
+static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)
 {
-	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
 	int rc = flushEdits(w);
 	if (rc) return rc;
 	StepParams& sp = w->sp;
@@ -2250,11 +2336,8 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 	memset(&zero, 0, sizeof(zero));
 	LAUNCH(w, k_step_begin, 1, 64, w->dw, w->gridBar.p);
 	w->toiCountersFresh = true;
-	for (size_t k = 0; k < w->pendingFilter.size(); ++k)
-	{
-		LAUNCH(w, k_flag_filter, gridFor(w->dw.capContacts), 256, w->dw, w->pendingFilter[k].first, w->pendingFilter[k].second);
-	}
-	w->pendingFilter.clear();
+	rc = applyPendingFilters(w);
+	if (rc) return rc;
 	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
 	// b2World.cpp:1628-1639: new fixtures -> find their contacts before colliding
 	if (w->newFixture)
@@ -2267,18 +2350,32 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 	return 0;
 }
 
-int b2hip_collide(b2hip_world* w)
+int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)
 {
-	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_collide outside a step");
+	if (int rc = checkUsable(w, "b2hip_step_begin", false)) return rc;
+	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_begin inside a step (finish it with b2hip_step_end)");
+	DEVICE_GUARD(w);
+	return stepFailed(w, stepBeginImpl(w, dt, velocity_iterations, position_iterations));
+}
+
+static int collideImpl(b2hip_world* w)
+{
 	int rc = phaseCollide(w);
 	if (rc) return rc;
 	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[2], w->stream));
 	return 0;
 }
 
-int b2hip_solve(b2hip_world* w)
+int b2hip_collide(b2hip_world* w)
 {
-	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve outside a step");
+	if (int rc = checkUsable(w, "b2hip_collide", false)) return rc;
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_collide outside a step");
+	DEVICE_GUARD(w);
+	return stepFailed(w, collideImpl(w));
+}
+
+static int solveImpl(b2hip_world* w)
+{
 	if (w->sp.dt > 0.0f)
 	{
 		int rc = phaseSolve(w);
@@ -2292,9 +2389,16 @@ int b2hip_solve(b2hip_world* w)
 	return 0;
 }
 
-int b2hip_sync_fixtures(b2hip_world* w)
+int b2hip_solve(b2hip_world* w)
 {
-	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_sync_fixtures outside a step");
+	if (int rc = checkUsable(w, "b2hip_solve", false)) return rc;
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve outside a step");
+	DEVICE_GUARD(w);
+	return stepFailed(w, solveImpl(w));
+}
+
+static int syncFixturesImpl(b2hip_world* w)
+{
 	if (w->sp.dt > 0.0f)
 	{
 		int rc = phaseSyncFixtures(w);
@@ -2304,9 +2408,16 @@ int b2hip_sync_fixtures(b2hip_world* w)
 	return 0;
 }
 
-int b2hip_find_new_contacts(b2hip_world* w)
+int b2hip_sync_fixtures(b2hip_world* w)
 {
-	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_find_new_contacts outside a step");
+	if (int rc = checkUsable(w, "b2hip_sync_fixtures", false)) return rc;
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_sync_fixtures outside a step");
+	DEVICE_GUARD(w);
+	return stepFailed(w, syncFixturesImpl(w));
+}
+
+static int findNewContactsImpl(b2hip_world* w)
+{
 	if (w->sp.dt > 0.0f)
 	{
 		int rc = findNewContactsGraph(w);
@@ -2316,9 +2427,16 @@ int b2hip_find_new_contacts(b2hip_world* w)
 	return 0;
 }
 
-int b2hip_solve_toi(b2hip_world* w)
+int b2hip_find_new_contacts(b2hip_world* w)
 {
-	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve_toi outside a step");
+	if (int rc = checkUsable(w, "b2hip_find_new_contacts", false)) return rc;
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_find_new_contacts outside a step");
+	DEVICE_GUARD(w);
+	return stepFailed(w, findNewContactsImpl(w));
+}
+
+static int solveToiImpl(b2hip_world* w)
+{
 	w->toiRan = false;
 	w->toiChains = false;
 	w->toiSpeculative = false;
@@ -2334,9 +2452,16 @@ int b2hip_solve_toi(b2hip_world* w)
 	return 0;
 }
 
-int b2hip_step_end(b2hip_world* w)
+int b2hip_solve_toi(b2hip_world* w)
 {
-	if (!w || !w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_end outside a step");
+	if (int rc = checkUsable(w, "b2hip_solve_toi", false)) return rc;
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve_toi outside a step");
+	DEVICE_GUARD(w);
+	return stepFailed(w, solveToiImpl(w));
+}
+
+static int stepEndImpl(b2hip_world* w)
+{
 	int rc = downloadState(w);
 	if (rc) return rc;
 	// optimistic small-sort path overflowed (or the pair buffer itself): finish the pair update with the radix path (after
@@ -2548,6 +2673,14 @@ int b2hip_step_end(b2hip_world* w)
 	return 0;
 }
 
+int b2hip_step_end(b2hip_world* w)
+{
+	if (int rc = checkUsable(w, "b2hip_step_end", false)) return rc;
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_end outside a step");
+	DEVICE_GUARD(w);
+	return stepFailed(w, stepEndImpl(w));
+}
+
 int b2hip_step(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)
 {
 	int rc = b2hip_step_begin(w, dt, velocity_iterations, position_iterations);
@@ -2595,8 +2728,8 @@ int b2hip_contact_count(b2hip_world* w)
 
 int b2hip_enable_contact_events(b2hip_world* w, int enable)
 {
+	if (int rcu = checkUsable(w, "b2hip_enable_contact_events", true)) return rcu;
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
-	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_enable_contact_events inside a step");
 	w->eventsOn = enable != 0;
 	w->dw.eventsOn = w->eventsOn ? 1 : 0;
 	w->events.clear();
@@ -2622,7 +2755,9 @@ struct SnapHeader
 	uint32_t stateCount, cur;
 	int32_t nextNode, leafCount, lastContacts, newFixture;
 	float inv_dt0, cellSize;
+	int32_t eventsOn, reserved;
 };
+const uint32_t kSnapVersion = 2;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
 
 struct SnapWriter
@@ -2666,8 +2801,11 @@ struct SnapReader
 int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed)
 {
 	if (!w || !needed || (cap > 0 && !buffer)) return setError(B2HIP_ERR_INVALID, "null argument");
-	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_save_snapshot inside a step");
+	if (int rcu = checkUsable(w, "b2hip_save_snapshot", true)) return rcu;
+	DEVICE_GUARD(w);
 	int rc = flushEdits(w); // everything the host has created or edited is on the device now
+	if (rc) return rc;
+	rc = applyPendingFilters(w); // ... including the re-filter flags of joints created / destroyed since the last step
 	if (rc) return rc;
 	rc = readState(w);
 	if (rc) return rc;
@@ -2678,7 +2816,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	SnapHeader h;
 	memset(&h, 0, sizeof(h));
 	memcpy(h.magic, kSnapMagic, 8);
-	h.version = 1;
+	h.version = kSnapVersion;
 	h.szDState = sizeof(DState); h.szHostBody = (uint32_t)offsetof(HostBody, fixtures); h.szHostFixture = sizeof(HostFixture);
 	h.szShape = sizeof(ShapeRec); h.szJoint = sizeof(RevoluteJoint);
 	h.nBodies = (uint32_t)nb; h.nFixtures = (uint32_t)np; h.nShapes = (uint32_t)w->shapes.size(); h.nJoints = (uint32_t)w->joints.size();
@@ -2686,6 +2824,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	h.stateCount = (uint32_t)std::min(w->stateCount, nb); h.cur = (uint32_t)ds.cur;
 	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
 	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
+	h.eventsOn = w->eventsOn ? 1 : 0;
 	SnapWriter o;
 	o.host(&h, sizeof(h));
 	o.host(&w->def, sizeof(w->def));
@@ -2723,97 +2862,190 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	return B2HIP_OK;
 }
 
+// Everything in the blob is checked BEFORE anything is copied to the device or used as an index: the counts against each
+// other and against the blob's size, every body / fixture / shape / joint / gear / proxy / contact index against its range.
+// A truncated or bit-flipped snapshot is refused with B2HIP_ERR_INVALID; it never writes out of bounds.
 int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world** out)
 {
 	if (!buffer || !out) return setError(B2HIP_ERR_INVALID, "null argument");
 	SnapReader in = { (const char*)buffer, size, true };
 	SnapHeader h;
 	in.host(&h, sizeof(h));
-	if (!in.ok || memcmp(h.magic, kSnapMagic, 8) != 0 || h.version != 1 || h.szDState != sizeof(DState) ||
+	if (!in.ok || memcmp(h.magic, kSnapMagic, 8) != 0 || h.version != kSnapVersion || h.szDState != sizeof(DState) ||
 		h.szHostBody != offsetof(HostBody, fixtures) || h.szHostFixture != sizeof(HostFixture) || h.szShape != sizeof(ShapeRec) ||
 		h.szJoint != sizeof(RevoluteJoint))
 		return setError(B2HIP_ERR_INVALID, "not a snapshot of this build of libb2hip");
 	b2hip_world_def def;
 	in.host(&def, sizeof(def));
 	if (!in.ok) return setError(B2HIP_ERR_INVALID, "snapshot truncated");
-	def.device = device;
-	b2hip_world* w = nullptr;
-	int rc = b2hip_world_create(&def, &w);
-	if (rc) return rc;
-	auto fail = [&](int code) { b2hip_world_destroy(w); return code; };
-	w->bodies.resize(h.nBodies);
-	for (size_t i = 0; i < h.nBodies; ++i)
+	auto corrupt = [](const char* what) { return setError(B2HIP_ERR_INVALID, std::string("snapshot corrupt: ") + what); };
+	const size_t nb = h.nBodies, np = h.nFixtures, nC = h.nContacts, nS = h.nShapes, nJ = h.nJoints, nT = h.nToiOrder, nM = h.nMoves;
+	// no count can exceed what the blob could hold at all (this also keeps the size products below from overflowing)
+	if (nb > size || np > size || nC > size || nS > size || nJ > size || h.nFree > size || nT > size || nM > size || h.stateCount > size)
+		return corrupt("counts exceed the blob");
+	if (h.stateCount > nb || h.cur > 1u || nT > nC) return corrupt("header counts");
+	if (!(h.cellSize > 0.0f) || !std::isfinite(h.cellSize)) return corrupt("cell size");
+
+	// ---- host sections -------------------------------------------------------------------------------------------------
+	const size_t bodyBytes = offsetof(HostBody, fixtures) + 1;
+	const char* bodiesAt = (const char*)in.take(nb * bodyBytes);
+	const HostFixture* fixturesAt = (const HostFixture*)in.take(np * sizeof(HostFixture));
+	const ShapeRec* shapesAt = (const ShapeRec*)in.take(nS * sizeof(ShapeRec));
+	const FreeUnit* freeAt = (const FreeUnit*)in.take((size_t)h.nFree * sizeof(FreeUnit));
+	const float* stateAt = (const float*)in.take((size_t)h.stateCount * 10 * sizeof(float));
+	const DState* dsAt = (const DState*)in.take(sizeof(DState));
+	const RevoluteJoint* jointsAt = (const RevoluteJoint*)in.take(nJ * sizeof(RevoluteJoint));
+	if (!in.ok) return setError(B2HIP_ERR_INVALID, "snapshot truncated");
+	for (size_t i = 0; i < nb; ++i)
 	{
-		in.host(&w->bodies[i], offsetof(HostBody, fixtures));
-		char dirty = 0;
-		in.host(&dirty, 1);
-		w->bodies[i].dirty = dirty != 0;
-		if (dirty) w->dirtyList.push_back((int)i);
+		HostBody hb;
+		memcpy((void*)&hb, bodiesAt + i * bodyBytes, offsetof(HostBody, fixtures));
+		if (hb.type < 0 || hb.type > 2) return corrupt("body type");
 	}
-	w->fixtures.resize(h.nFixtures);
-	in.host(w->fixtures.data(), (size_t)h.nFixtures * sizeof(HostFixture));
-	w->shapes.resize(h.nShapes);
-	in.host(w->shapes.data(), (size_t)h.nShapes * sizeof(ShapeRec));
-	w->freeUnits.resize(h.nFree);
-	in.host(w->freeUnits.data(), (size_t)h.nFree * sizeof(FreeUnit));
-	if (!in.ok) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
-	for (size_t f = 0; f < w->fixtures.size(); ++f)
+	for (size_t f = 0; f < np; ++f)
 	{
-		if (w->fixtures[f].body < 0 || (size_t)w->fixtures[f].body >= w->bodies.size()) return fail(setError(B2HIP_ERR_INVALID, "snapshot corrupt"));
-		w->bodies[w->fixtures[f].body].fixtures.push_back((int)f);
+		HostFixture hf;
+		memcpy(&hf, fixturesAt + f, sizeof(hf));
+		if (hf.body < 0 || (size_t)hf.body >= nb || hf.shape < 0 || (size_t)hf.shape >= nS || hf.proxyKey < 0) return corrupt("fixture");
 	}
-	for (size_t k = 0; k < w->shapes.size(); ++k) w->shapeIndex[std::string((const char*)&w->shapes[k], sizeof(ShapeRec))] = (int)k;
-	w->joints.resize(h.nJoints);
-	w->nextNode = h.nextNode; w->leafCount = h.leafCount; w->lastContacts = h.lastContacts; w->newFixture = h.newFixture != 0;
-	w->inv_dt0 = h.inv_dt0;
-	rc = ensureCapacity(w, (size_t)h.nContacts);
-	if (rc) return fail(rc);
-	const size_t nb = h.nBodies, np = h.nFixtures, nC = h.nContacts;
-	in.host(w->h_state, (size_t)h.stateCount * 10 * sizeof(float));
-	w->stateCount = h.stateCount;
+	for (size_t k = 0; k < nS; ++k)
+	{
+		ShapeRec sr;
+		memcpy(&sr, shapesAt + k, sizeof(sr));
+		if (sr.type < 0 || sr.type > 2 || sr.count < 0 || sr.count > B2D_MAX_POLY_VERTS) return corrupt("shape");
+	}
+	for (size_t k = 0; k < h.nFree; ++k)
+	{
+		FreeUnit fu;
+		memcpy(&fu, freeAt + k, sizeof(fu));
+		if (fu.leaf < 0 || fu.leaf >= h.nextNode) return corrupt("proxy id free list");
+	}
 	DState ds;
-	in.host(&ds, sizeof(DState));
-	if (!in.ok) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
-	HIP_TRY(hipMemcpy(w->d_state.p, &ds, sizeof(DState), hipMemcpyHostToDevice));
-	*w->h_dstate = ds;
-#define SNAP_DEV(arr, n) do { rc = in.dev(w->arr.p, (size_t)(n) * sizeof(*w->arr.p)); if (rc) return fail(rc); } while (0)
+	memcpy(&ds, dsAt, sizeof(ds));
+	if (ds.cur != (int)h.cur || ds.c.nContacts != (int)nC || ds.c.nToiOrder != (int)nT || ds.c.nMoves < (int)nM) return corrupt("device state block");
+
+	// ---- device sections: located and range-checked in the blob, uploaded later ---------------------------------------------
+	struct Sec { const void* p; size_t bytes; };
+	auto sec = [&](size_t n, size_t elem) { Sec x = { in.take(n * elem), n * elem }; return x; };
+	const Sec sPos = sec(nb, 16), sPos0 = sec(nb, 16), sVel = sec(nb, 16), sXf = sec(nb, 16), sMass = sec(nb, 16), sDamp = sec(nb, 16), sForce = sec(nb, 16);
+	const Sec sFlags = sec(nb, 4), sWake = sec(nb, 4), sHead = sec(nb, 4);
+	const Sec sFat = sec(np, 16), sPBody = sec(np, 4), sPShape = sec(np, 4), sPKey = sec(np, 4), sF0 = sec(np, 4), sF1 = sec(np, 4), sPMat = sec(np, 8), sNext = sec(np, 4);
+	const Sec cIds = sec(nC, 16), cKey = sec(nC, 8), cFlags = sec(nC, 4), cMat = sec(nC, 16), cMan0 = sec(nC, 16), cMan1 = sec(nC, 16), cImp = sec(nC, 16),
+		cMan3 = sec(nC, 16), cColor = sec(nC, 4), cMgr = sec(nC, 4);
+	const Sec sToi = sec(nT, 4), sMoves = sec(nM, 4);
+	if (!in.ok) return setError(B2HIP_ERR_INVALID, "snapshot truncated");
+	auto inRange = [](const Sec& x, long long lo, long long hi) // every int of the section in [lo, hi)
 	{
-		// joints: the device copy is the truth (accumulated impulses); the host vector mirrors it and is uploaded, with the
-		// per-body joint lists, by the next flushEdits
-		const void* src = in.take((size_t)h.nJoints * sizeof(RevoluteJoint));
-		if (!src) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
-		if (h.nJoints) memcpy(w->joints.data(), src, (size_t)h.nJoints * sizeof(RevoluteJoint));
-		for (size_t k = 0; k < w->joints.size(); ++k) w->nMouseJoints += w->joints[k].type == B2D_JOINT_MOUSE;
+		const int* v = (const int*)x.p;
+		for (size_t i = 0; i < x.bytes / 4; ++i)
+		{
+			int q;
+			memcpy(&q, v + i, 4);
+			if (q < lo || q >= hi) return false;
+		}
+		return true;
+	};
+	if (!inRange(sHead, -1, (long long)np) || !inRange(sNext, -1, (long long)np)) return corrupt("per-body proxy lists");
+	if (!inRange(sPBody, 0, (long long)nb) || !inRange(sPShape, 0, (long long)nS)) return corrupt("proxy table");
+	if (!inRange(sToi, 0, (long long)nC) || !inRange(sMoves, 0, (long long)np)) return corrupt("TOI order / move buffer");
+	if (!inRange(cColor, -1, MAX_COLORS) || !inRange(cMgr, -1, (long long)std::max<size_t>(nT, 1))) return corrupt("contact colour / TOI slot");
+	for (size_t i = 0; i < nC; ++i)
+	{
+		int4 ids;
+		memcpy(&ids, (const char*)cIds.p + 16 * i, 16);
+		if (ids.x < 0 || (size_t)ids.x >= np || ids.y < 0 || (size_t)ids.y >= np || ids.z < 0 || (size_t)ids.z >= nb || ids.w < 0 || (size_t)ids.w >= nb)
+			return corrupt("contact ids");
 	}
-	SNAP_DEV(b_pos, nb); SNAP_DEV(b_pos0, nb); SNAP_DEV(b_vel, nb); SNAP_DEV(b_xf, nb); SNAP_DEV(b_mass, nb); SNAP_DEV(b_damp, nb);
-	SNAP_DEV(b_force, nb); SNAP_DEV(b_flags, nb); SNAP_DEV(b_wake, nb); SNAP_DEV(b_proxyHead, nb);
-	SNAP_DEV(p_fat, np); SNAP_DEV(p_body, np); SNAP_DEV(p_shape, np); SNAP_DEV(p_key, np); SNAP_DEV(p_filter0, np); SNAP_DEV(p_filter1, np);
-	SNAP_DEV(p_mat, np); SNAP_DEV(p_next, np);
-	const int cur = (int)h.cur & 1;
-	SNAP_DEV(c_ids[cur], nC); SNAP_DEV(c_key[cur], nC); SNAP_DEV(c_flags[cur], nC); SNAP_DEV(c_mat[cur], nC); SNAP_DEV(c_man0[cur], nC);
-	SNAP_DEV(c_man1[cur], nC); SNAP_DEV(c_imp[cur], nC); SNAP_DEV(c_man3[cur], nC); SNAP_DEV(c_color[cur], nC); SNAP_DEV(c_mgr[cur], nC);
-	SNAP_DEV(toiPos2c, h.nToiOrder); SNAP_DEV(moveBuf, h.nMoves);
+	// trailing section: the gear records (absent in snapshots of worlds that never had one)
+	size_t nG = 0;
+	const GearRec* gearsAt = nullptr;
 	if (in.left >= 2 * sizeof(uint32_t))
 	{
 		uint32_t tail[2];
 		in.host(tail, sizeof(tail));
-		if (tail[1] != sizeof(GearRec)) return fail(setError(B2HIP_ERR_INVALID, "snapshot: gear record layout differs"));
-		const void* src = in.take((size_t)tail[0] * sizeof(GearRec));
-		if (!src) return fail(setError(B2HIP_ERR_INVALID, "snapshot truncated"));
-		w->gears.resize(tail[0]);
-		if (tail[0]) memcpy(w->gears.data(), src, (size_t)tail[0] * sizeof(GearRec)); // re-uploaded by the next flushEdits, like the joints
+		if (tail[1] != sizeof(GearRec) || tail[0] > size) return corrupt("gear section");
+		nG = tail[0];
+		gearsAt = (const GearRec*)in.take(nG * sizeof(GearRec));
+		if (!gearsAt && nG) return setError(B2HIP_ERR_INVALID, "snapshot truncated");
 	}
-#undef SNAP_DEV
-	HIP_TRY(hipMemcpy(w->d_shapes.p, w->shapes.data(), w->shapes.size() * sizeof(ShapeRec), hipMemcpyHostToDevice));
-	w->upBodies = nb; w->upFixtures = np; w->upShapes = w->shapes.size(); w->upJoints = 0;
+	for (size_t k = 0; k < nJ; ++k)
+	{
+		RevoluteJoint j;
+		memcpy((void*)&j, jointsAt + k, sizeof(j));
+		if (j.type < B2D_JOINT_DEAD || j.type > B2D_JOINT_GEAR) return corrupt("joint type");
+		if (j.bodyA < 0 || (size_t)j.bodyA >= nb || j.bodyB < 0 || (size_t)j.bodyB >= nb) return corrupt("joint bodies");
+		if (j.type == B2D_JOINT_GEAR && (j.enableLimit < 0 || (size_t)j.enableLimit >= nG)) return corrupt("gear index");
+	}
+	for (size_t k = 0; k < nG; ++k)
+	{
+		GearRec g;
+		memcpy((void*)&g, gearsAt + k, sizeof(g));
+		if (g.bodyC < 0 || (size_t)g.bodyC >= nb || g.bodyD < 0 || (size_t)g.bodyD >= nb) return corrupt("gear bodies");
+	}
+
+	// ---- build the world ---------------------------------------------------------------------------------------------------------
+	def.device = device;
+	b2hip_world* w = nullptr;
+	int rc = b2hip_world_create(&def, &w);
+	if (rc) return rc;
+	DEVICE_GUARD(w);
+	auto fail = [&](int code) { const std::string why = g_lastError; b2hip_world_destroy(w); return setError(code, why); };
+	w->bodies.resize(nb);
+	for (size_t i = 0; i < nb; ++i)
+	{
+		memcpy((void*)&w->bodies[i], bodiesAt + i * bodyBytes, offsetof(HostBody, fixtures));
+		w->bodies[i].dirty = bodiesAt[i * bodyBytes + offsetof(HostBody, fixtures)] != 0;
+		if (w->bodies[i].dirty) w->dirtyList.push_back((int)i);
+	}
+	w->fixtures.resize(np);
+	if (np) memcpy(w->fixtures.data(), fixturesAt, np * sizeof(HostFixture));
+	w->shapes.resize(nS);
+	if (nS) memcpy((void*)w->shapes.data(), shapesAt, nS * sizeof(ShapeRec));
+	w->freeUnits.resize(h.nFree);
+	if (h.nFree) memcpy(w->freeUnits.data(), freeAt, (size_t)h.nFree * sizeof(FreeUnit));
+	for (size_t f = 0; f < np; ++f) w->bodies[w->fixtures[f].body].fixtures.push_back((int)f);
+	for (size_t k = 0; k < nS; ++k) w->shapeIndex[std::string((const char*)&w->shapes[k], sizeof(ShapeRec))] = (int)k;
+	// joints / gears: the device copy is the truth (accumulated impulses); the host vectors mirror it and are uploaded, with
+	// the per-body joint lists, by the next flushEdits
+	w->joints.resize(nJ);
+	if (nJ) memcpy((void*)w->joints.data(), jointsAt, nJ * sizeof(RevoluteJoint));
+	for (size_t k = 0; k < nJ; ++k) w->nMouseJoints += w->joints[k].type == B2D_JOINT_MOUSE;
+	w->gears.resize(nG);
+	if (nG) memcpy((void*)w->gears.data(), gearsAt, nG * sizeof(GearRec));
+	w->nextNode = h.nextNode; w->leafCount = h.leafCount; w->lastContacts = h.lastContacts; w->newFixture = h.newFixture != 0;
+	w->inv_dt0 = h.inv_dt0;
+	w->eventsOn = h.eventsOn != 0;
+	rc = ensureCapacity(w, nC);
+	if (rc) return fail(rc);
+	if (nM > w->moveBuf.cap || nC > (size_t)w->dw.capContacts || (size_t)h.stateCount * 10 > w->h_stateCap) return fail(corrupt("counts exceed the buffers sized for them"));
+	if (h.stateCount) memcpy(w->h_state, stateAt, (size_t)h.stateCount * 10 * sizeof(float));
+	w->stateCount = h.stateCount;
+	*w->h_dstate = ds;
+#define SNAP_UP(arr, s) do { if ((s).bytes && hipMemcpy(w->arr.p, (s).p, (s).bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (" #arr ")")); } while (0)
+	if (hipMemcpy(w->d_state.p, &ds, sizeof(DState), hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (state block)"));
+	SNAP_UP(b_pos, sPos); SNAP_UP(b_pos0, sPos0); SNAP_UP(b_vel, sVel); SNAP_UP(b_xf, sXf); SNAP_UP(b_mass, sMass); SNAP_UP(b_damp, sDamp);
+	SNAP_UP(b_force, sForce); SNAP_UP(b_flags, sFlags); SNAP_UP(b_wake, sWake); SNAP_UP(b_proxyHead, sHead);
+	SNAP_UP(p_fat, sFat); SNAP_UP(p_body, sPBody); SNAP_UP(p_shape, sPShape); SNAP_UP(p_key, sPKey); SNAP_UP(p_filter0, sF0); SNAP_UP(p_filter1, sF1);
+	SNAP_UP(p_mat, sPMat); SNAP_UP(p_next, sNext);
+	const int cur = (int)h.cur;
+	SNAP_UP(c_ids[cur], cIds); SNAP_UP(c_key[cur], cKey); SNAP_UP(c_flags[cur], cFlags); SNAP_UP(c_mat[cur], cMat); SNAP_UP(c_man0[cur], cMan0);
+	SNAP_UP(c_man1[cur], cMan1); SNAP_UP(c_imp[cur], cImp); SNAP_UP(c_man3[cur], cMan3); SNAP_UP(c_color[cur], cColor); SNAP_UP(c_mgr[cur], cMgr);
+	SNAP_UP(toiPos2c, sToi); SNAP_UP(moveBuf, sMoves);
+#undef SNAP_UP
+	if (nS && hipMemcpy(w->d_shapes.p, w->shapes.data(), nS * sizeof(ShapeRec), hipMemcpyHostToDevice) != hipSuccess)
+		return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (shapes)"));
+	w->upBodies = nb; w->upFixtures = np; w->upShapes = nS; w->upJoints = 0;
 	w->dw.cellSize = h.cellSize;
 	w->dw.invCellSize = 1.0f / h.cellSize;
+	w->dw.eventsOn = w->eventsOn ? 1 : 0;
 	*out = w;
 	return B2HIP_OK;
 }
 
 int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 {
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	DEVICE_GUARD(w);
 	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
 	int rc = readState(w);
 	if (rc) return rc;
@@ -2856,6 +3088,8 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out)
 {
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	DEVICE_GUARD(w);
 	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
 	const int n = std::min(cap, (int)w->bodies.size());
 	if (n <= 0) return 0;
@@ -2874,6 +3108,8 @@ int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out)
 
 int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4])
 {
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	DEVICE_GUARD(w);
 	if (!w || !out4 || fixture < 0 || fixture >= (int)w->fixtures.size()) return setError(B2HIP_ERR_INVALID, "bad fixture id");
 	if ((size_t)fixture >= w->upFixtures)
 	{
@@ -2886,6 +3122,8 @@ int b2hip_get_fat_aabb(b2hip_world* w, int fixture, float out4[4])
 
 int b2hip_get_fat_aabbs(b2hip_world* w, int first, int count, float* out4n)
 {
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	DEVICE_GUARD(w);
 	if (!w || (count > 0 && !out4n) || first < 0 || count < 0 || (size_t)(first + count) > w->fixtures.size())
 		return setError(B2HIP_ERR_INVALID, "bad fixture range");
 	const int onDevice = std::max(0, std::min(first + count, (int)w->upFixtures) - first);
@@ -2911,6 +3149,8 @@ static uint64_t fnv(uint64_t h, const void* data, size_t n)
 
 int b2hip_debug_hash(b2hip_world* w, int which, uint64_t* out)
 {
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	DEVICE_GUARD(w);
 	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	DState st;
@@ -2964,6 +3204,8 @@ int b2hip_debug_hash(b2hip_world* w, int which, uint64_t* out)
 // 7 counters as ints) into `out` (bytes).
 int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
 {
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	DEVICE_GUARD(w);
 	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	const void* src = nullptr;

@@ -576,7 +576,7 @@ void b2o_joint_set_target(b2o_world* w, int joint, float tx, float ty)
 {
 	revolute_t* j = &w->joints[joint];
 	if (tx == j->localAnchorA.x && ty == j->localAnchorA.y) return;
-	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	set_awake(&w->bodies[j->bodyB]);
 	j->localAnchorA = v_make(tx, ty);
 }
 
@@ -585,8 +585,8 @@ void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float an
 {
 	revolute_t* j = &w->joints[joint];
 	if (lx == j->localAnchorA.x && ly == j->localAnchorA.y && angular == j->referenceAngle) return;
-	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
-	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	set_awake(&w->bodies[j->bodyA]); /* b2Body::SetAwake(true) always restarts the sleep timer (b2Body.h:699-703) */
+	set_awake(&w->bodies[j->bodyB]);
 	j->localAnchorA = v_make(lx, ly);
 	j->referenceAngle = angular;
 }
@@ -611,8 +611,8 @@ void b2o_destroy_joint(b2o_world* w, int joint)
 {
 	revolute_t* j = &w->joints[joint];
 	if (j->type < 0) return;
-	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
-	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	set_awake(&w->bodies[j->bodyA]); /* b2Body::SetAwake(true) always restarts the sleep timer (b2Body.h:699-703) */
+	set_awake(&w->bodies[j->bodyB]);
 	unlink_joint_edge(w, j->bodyA, joint * 2);
 	unlink_joint_edge(w, j->bodyB, joint * 2 + 1);
 	if (!j->collideConnected)
@@ -632,8 +632,8 @@ void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSp
 {
 	revolute_t* j = &w->joints[joint];
 	if ((enableMotor != 0) == (j->enableMotor != 0) && motorSpeed == j->motorSpeed && maxMotor == j->maxMotorTorque) return;
-	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
-	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	set_awake(&w->bodies[j->bodyA]); /* b2Body::SetAwake(true) always restarts the sleep timer (b2Body.h:699-703) */
+	set_awake(&w->bodies[j->bodyB]);
 	j->enableMotor = enableMotor != 0;
 	j->motorSpeed = motorSpeed;
 	j->maxMotorTorque = maxMotor;
@@ -644,8 +644,8 @@ void b2o_joint_set_limits(b2o_world* w, int joint, int enableLimit, float lower,
 {
 	revolute_t* j = &w->joints[joint];
 	if ((enableLimit != 0) == (j->enableLimit != 0) && lower == j->lowerAngle && upper == j->upperAngle) return;
-	if ((w->bodies[j->bodyA].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyA]);
-	if ((w->bodies[j->bodyB].flags & BF_AWAKE) == 0) set_awake(&w->bodies[j->bodyB]);
+	set_awake(&w->bodies[j->bodyA]); /* b2Body::SetAwake(true) always restarts the sleep timer (b2Body.h:699-703) */
+	set_awake(&w->bodies[j->bodyB]);
 	j->enableLimit = enableLimit != 0;
 	j->lowerAngle = lower;
 	j->upperAngle = upper;

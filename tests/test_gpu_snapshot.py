@@ -91,3 +91,56 @@ def test_snapshot_resume_is_bit_exact(continuous):
 def test_snapshot_rejects_garbage():
     with pytest.raises(b2hip.B2HipError):
         b2hip.World.from_snapshot(b"not a snapshot at all" * 10)
+
+
+def test_snapshot_rejects_truncated_and_bit_flipped_blobs():
+    """A damaged snapshot is refused (B2HIP_ERR_INVALID) before anything is copied: every count is checked against the blob
+    and against the others, every index against its range. Truncations at many lengths, then single-byte damage at offsets
+    spread over the header, the host tables and the device sections: each load either fails cleanly or (damage that only
+    touched float payload) yields a world that can be stepped and destroyed."""
+    a = build(False)
+    for _ in range(30):
+        a.step()
+    blob = a.save_snapshot()
+    a.close()
+    n = len(blob)
+    for cut in [0, 7, 8, 40, 96, 97, 200, n // 7, n // 3, n // 2, n - 4097, n - 1]:
+        with pytest.raises(b2hip.B2HipError):
+            b2hip.World.from_snapshot(blob[:cut])
+    rng = np.random.default_rng(11)
+    refused = 0
+    offsets = list(range(8, 112, 4)) + [int(x) for x in rng.integers(112, n, 120)]
+    for off in offsets:
+        bad = bytearray(blob)
+        bad[off] ^= 0xFF
+        bad[min(off + 3, n - 1)] ^= 0x7F  # the high byte too: makes counts and indices wild, not off by one
+        try:
+            w = b2hip.World.from_snapshot(bytes(bad))
+        except b2hip.B2HipError:
+            refused += 1
+            continue
+        w.step()  # survived validation: payload damage only
+        w.close()
+    assert refused >= 20, "header damage must be refused (%d refusals)" % refused
+
+
+def test_snapshot_right_after_joint_edits_keeps_the_refilter_flags():
+    """a snapshot taken between CreateJoint / DestroyJoint and the next step must carry the pending contact
+    re-filter (b2World.cpp:716-732, 833-845), and the contact-event switch."""
+    a = build(False)
+    for _ in range(60):
+        a.step()
+    # weld two bodies that are touching right now (collide_connected = false): their contact must go at the next collide
+    c = a.contacts()
+    touching = c[(c["flags"] & 1) != 0]
+    pair = next((int(r["body_a"]), int(r["body_b"])) for r in touching if r["body_a"] > 1 and r["body_b"] > 1)
+    a.create_weld_joint(pair[0], pair[1])
+    a.enable_contact_events(True)
+    b = b2hip.World.from_snapshot(a.save_snapshot())
+    for s in range(30):
+        a.step()
+        b.step()
+        assert state(a) == state(b), "step %d after the snapshot" % s
+        assert np.array_equal(a.contact_events(), b.contact_events()), "contact events differ at step %d" % s
+    a.close()
+    b.close()

@@ -20,6 +20,7 @@ for name in (sys.argv[1:] or list(t.SCENES)):
     except AssertionError as e:
         print("%s: ASSERT %s" % (name, e))
     for n, step, dev in rep:
-        print("%s step %d: pos %.3g angle %.3g vel %.3g spin %.3g (scale %.1f, %d large-island constraints)" % (
-            n, step, dev["pos"], dev["angle"], dev["vel"], dev["spin"], dev["scale"], dev["large_island_contacts"]), flush=True)
+        print("%s step %d: pos %.3g angle %.3g vel %.3g spin %.3g (scale %.1f, max speed %.2f, %d large-island constraints); contacts %d, set diff %d, touching diff %d, flags differ %d" % (
+            n, step, dev["pos"], dev["angle"], dev["vel"], dev["spin"], dev["scale"], dev["speed_max"], dev["large_island_contacts"],
+            dev["contacts"], dev["contact_set_diff"], dev["touching_diff"], dev["flags_differ"]), flush=True)
     print("%s: %.1f s" % (name, time.time() - t0), flush=True)
