@@ -104,10 +104,23 @@ __device__ __forceinline__ void colorCheckBegin(const DW& W)
 	}
 }
 
+// Home block (+ 1) of a body this step: its own, or the one a neighbour offered it in k_island_edges (a body that joins a
+// partitioned island is adopted by the block next to it; k_block_census makes that permanent). 0 = none.
+__device__ __forceinline__ int effBlk(const DW& W, int body)
+{
+	const int b = W.b_blk1[body];
+	return b ? b : W.b_adopt[body];
+}
+
 __global__ __launch_bounds__(256) void k_island_init(DW W)
 {
 	DState* S = W.st;
 	if (blockIdx.x == 0) colorCheckBegin(W);
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_BLOCKS + 1; i += gridDim.x * blockDim.x)
+	{
+		W.blkRows[i] = 0;
+		W.blkCursor[i] = 0;
+	}
 	const int n = W.nBodies;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
@@ -128,6 +141,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		W.rootJointOkay[i] = 1;
 		W.bodyClaim[i] = 0;
 		W.bodyColorMask[i] = 0;
+		W.bodyActive[i] = 0;
+		W.b_adopt[i] = 0;
 		uint32_t f = W.b_flags[i] & ~(BF_ISLAND | BF_LARGE);
 		// ConsumeAwakes / b2Contact::Destroy wake-ups gathered by collide: SetAwake(true) also
 		// resets the sleep timer of bodies that are already awake (b2Body.h:699-703).
@@ -150,6 +165,13 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.maxSmallW = 0;
 		S->c.maxDegree = 0;
 		S->c.chunkW = SMALL_ISLAND_MAX_W;
+		S->c.partitionAge += 1;
+		if (S->c.partitionCooldown > 0) S->c.partitionCooldown -= 1;
+		S->c.nOrphanRows = 0;
+		S->c.blkMaxRows = 0;
+		S->c.blkMaxBodies = 0;
+		S->c.nCutRows = 0;
+		S->c.colorMaskLo = S->c.colorMaskHi = 0u;
 	}
 }
 
@@ -354,6 +376,13 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W)
 		{
 			int k = atomicAdd(&S->c.nLContacts, 1);
 			W.li_contacts[k] = i;
+			// a body without a home block is offered the block of its neighbour (the highest one, if several do: deterministic)
+			if (nsA && nsB)
+			{
+				const int ba = W.b_blk1[ids.z], bb = W.b_blk1[ids.w];
+				if (ba == 0 && bb != 0) atomicMax(&W.b_adopt[ids.z], bb);
+				if (bb == 0 && ba != 0) atomicMax(&W.b_adopt[ids.w], ba);
+			}
 		}
 	}
 }

@@ -77,6 +77,28 @@ __device__ __forceinline__ uint32_t colorPriority(int contactIndex)
 	return ((uint32_t)contactIndex + 1u) * 2654435761u;
 }
 
+// Colour classes of the block partition: a constraint between bodies of two blocks (a CUT constraint) takes its colour
+// from [CUT_COLOR_BASE, HUB_COLOR), every other one from [0, CUT_COLOR_BASE): a sweep in colour order then visits, on
+// every body, the constraints inside its block first and the ones that cross a block boundary last.
+#define COLOR_INTERIOR_BITS ((1ull << CUT_COLOR_BASE) - 1ull)
+__device__ __forceinline__ bool constraintIsCut(const DW& W, int bodyA, bool nsA, int bodyB, bool nsB)
+{
+	return nsA && nsB && effBlk(W, bodyA) != effBlk(W, bodyB);
+}
+// Colours a constraint of this class may NOT take. A cut constraint must sit in the upper range (k_solve_blocks hands the
+// bodies of upper-range constraints over through memory, and only those). An interior constraint takes the lowest free
+// colour, which lies in the lower range unless one of its bodies already holds 32 colours; it may spill into the upper
+// range then (it is handed over through memory like a cut constraint: correct, merely slower).
+__device__ __forceinline__ uint64_t colorClassMask(bool cut)
+{
+	return (cut ? COLOR_INTERIOR_BITS : 0ull) | (1ull << HUB_COLOR);
+}
+__device__ __forceinline__ void noteColorUsed(DState* S, int color)
+{
+	if (color < 32) atomicOr(&S->c.colorMaskLo, 1u << color);
+	else atomicOr(&S->c.colorMaskHi, 1u << (color - 32));
+}
+
 __global__ __launch_bounds__(256) void k_color_begin(DW W)
 {
 	DState* S = W.st;
@@ -106,6 +128,7 @@ __global__ __launch_bounds__(256) void k_color_begin(DW W)
 		S->c.nUncolored = n - W.colorCount[HUB_COLOR];
 		S->c.colorRounds = 0;
 		S->c.nColors = 0;
+		S->c.colorMaskLo = S->c.colorMaskHi = 0u;
 	}
 }
 
@@ -134,12 +157,19 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		}
 		int4 ids = C.ids[i];
 		const unsigned long long bit = 1ull << col;
-		if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC)
+		const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+		if (bit & colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))
+		{
+			// the constraint changed class (a body moved to another block, a new partition): its colour is void
+			C.color[i] = -1;
+			continue;
+		}
+		if (nsA)
 		{
 			unsigned long long old = atomicOr((unsigned long long*)&W.bodyColorMask[ids.z], bit);
 			if (old & bit) bad = 1;
 		}
-		if ((W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC)
+		if (nsB)
 		{
 			unsigned long long old = atomicOr((unsigned long long*)&W.bodyColorMask[ids.w], bit);
 			if (old & bit) bad = 1;
@@ -156,9 +186,19 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		{
 			const int ci = W.li_contacts[s];
 			const int4 ids = C.ids[ci];
-			const bool hubA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC && W.deg[ids.z] > HUB_DEGREE;
-			const bool hubB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC && W.deg[ids.w] > HUB_DEGREE;
+			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			const bool hubA = nsA && W.deg[ids.z] > HUB_DEGREE;
+			const bool hubB = nsB && W.deg[ids.w] > HUB_DEGREE;
+			{
+				// block census: the row belongs to the home block of its first non-static body
+				const int blkA = nsA ? effBlk(W, ids.z) : 0, blkB = nsB ? effBlk(W, ids.w) : 0;
+				const int owner = nsA ? blkA : blkB;
+				if (owner > 0 && owner <= MAX_BLOCKS) atomicAdd(&W.blkRows[owner - 1], 1);
+				if ((nsA && blkA == 0) || (nsB && blkB == 0)) atomicAdd(&S->c.nOrphanRows, 1);
+				if (nsA && nsB && blkA != blkB) atomicAdd(&S->c.nCutRows, 1);
+			}
 			col = C.color[ci];
+			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
 			if (hubA || hubB)
 			{
 				// a hub constraint owns no colour (and reserves none from the next step on)
@@ -177,6 +217,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			else if (col != HUB_COLOR)
 			{
 				if (col + 1 > maxColor) maxColor = col + 1;
+				noteColorUsed(S, col);
 				if (col == S->c.compactClass && col > 0)
 				{
 					// candidates of this step's compaction class (k_color_small moves them down if a lower colour is free)
@@ -232,7 +273,7 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 		if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 		if (!win) continue;
 		// this lane is the only winner on both bodies this round: plain read-modify-write is safe
-		uint64_t used = 1ull << HUB_COLOR;
+		uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
 		if (nsA) used |= W.bodyColorMask[ids.z];
 		if (nsB) used |= W.bodyColorMask[ids.w];
 		int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
@@ -244,6 +285,7 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 		C.color[ci] = color;
 		atomicAdd(&W.colorCount[color], 1);
 		atomicMax(&S->c.nColors, color + 1);
+		noteColorUsed(S, color);
 		++colored;
 	}
 	if (colored) atomicSub(&S->c.nUncolored, colored);
@@ -282,7 +324,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W)
 			const int4 ids = C.ids[ci];
 			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
 			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-			uint64_t used = 1ull << HUB_COLOR;
+			uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
 			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (used == ~0ull || __ffsll((long long)~used) - 1 >= c) continue;
@@ -328,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W)
 			if (nsA && __hip_atomic_load(&W.bodyClaim[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 			if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 			if (!win) continue;
-			uint64_t used = 1ull << HUB_COLOR;
+			uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
 			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
@@ -340,6 +382,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W)
 			C.color[ci] = color;
 			atomicAdd(&W.colorCount[color], 1);
 			atomicMax(&s_maxColor, color + 1);
+			noteColorUsed(S, color);
 			atomicAdd(&s_colored, 1);
 		}
 		__syncthreads();
@@ -431,18 +474,46 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 		const int s = base + threadIdx.x;
 		const bool valid = s < n && W.li_color[s] >= 0;
 		const int color = valid ? W.li_color[s] : 0;
-		// (exact-order mode has one group per dependency level, possibly thousands: keys beyond the LDS histogram)
-		const int slot = S->c.nColors > MAX_COLORS ? waveKeyedAlloc(W.colorCursor, color, valid) : blockKeyedAlloc65(W.colorCursor, color, valid, true);
+		int ci = 0;
+		int4 ids = make_int4(0, 0, 0, 0);
+		bool nsA = false, nsB = false;
 		if (valid)
 		{
-			const int p = W.colorStart[color] + slot;
-			const int ci = W.li_contacts[s];
-			int4 ids = C.ids[ci];
-			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
-			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			ci = W.li_contacts[s];
+			ids = C.ids[ci];
+			nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+			nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+		}
+		int p = 0;
+		if (W.blockSort)
+		{
+			// k_solve_blocks: rows grouped by the home block of their first non-static body (the workgroup sorts its rows by
+			// colour itself, in LDS); blkRowStart comes from the census of k_block_census
+			int owner = valid ? effBlk(W, nsA ? ids.z : ids.w) - 1 : 0;
+			const bool placed = valid && owner >= 0 && owner < MAX_BLOCKS;
+			if (!placed) owner = 0;
+			const int slot = waveKeyedAlloc(W.blkCursor, owner, placed);
+			p = W.blkRowStart[owner] + slot;
+			if (placed) W.rowColor[p] = color;
+			else if (valid) p = -1;
+		}
+		else
+		{
+			// (exact-order mode has one group per dependency level, possibly thousands: keys beyond the LDS histogram)
+			const int slot = S->c.nColors > MAX_COLORS ? waveKeyedAlloc(W.colorCursor, color, valid) : blockKeyedAlloc65(W.colorCursor, color, valid, true);
+			p = W.colorStart[color] + slot;
+		}
+		if (valid && p >= 0)
+		{
 			W.li_sorted[p] = s;
 			if (color == HUB_COLOR) W.hubRowOf[ci] = p;
 			W.li_ref[p] = make_int4(ci, nsA ? ids.z : -(ids.z + 1), nsB ? ids.w : -(ids.w + 1), W.parent[nsA ? ids.z : ids.w]);
+			// the upper-range colours of every body (its hand-overs through memory in k_solve_blocks, in this order)
+			if (color >= CUT_COLOR_BASE && color != HUB_COLOR && S->c.nColors <= MAX_COLORS)
+			{
+				if (nsA) atomicOr((unsigned long long*)&W.bodyActive[ids.z], 1ull << color);
+				if (nsB) atomicOr((unsigned long long*)&W.bodyActive[ids.w], 1ull << color);
+			}
 		}
 	}
 }

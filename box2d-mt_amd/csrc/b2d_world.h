@@ -59,6 +59,14 @@
 #define HUB_COLOR (MAX_COLORS - 1) // row group of the hub constraints
 #define COLOR_SMALL_MAX 4096     // uncoloured constraints up to this many are coloured by one workgroup without a host round trip
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
+// Block partition of the large islands (b2d_kernels_solve_blocks.h): every body of a large island has a home block, one
+// workgroup solves one block with its bodies in LDS. A constraint between bodies of two blocks is a CUT constraint: it owns
+// a colour of the upper range, so that on every body the cut constraints come last in a sweep.
+#define CUT_COLOR_BASE 32        // colours [0, 32) interior constraints, [32, 63) cut constraints, 63 = HUB_COLOR
+#define BLOCK_LANES 1024         // workgroup size of k_solve_blocks = rows (constraints) a block can hold
+#define BLOCK_MAX_BODIES 1024    // home bodies a block can hold (LDS rows)
+#define MAX_BLOCKS 1024          // blocks of one partition
+#define BLOCK_TARGET_DEG 1500    // a block is closed when the contact degrees of its bodies add up to this (rows ~ half of it)
 
 struct ContactArrays
 {
@@ -115,6 +123,17 @@ struct Counters
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
 	int nHubRows;        // hub constraints of this step
 	int chunkLanes;      // workgroup size of the small-island solver chosen for this step (TINY_CHUNK_LANES or SMALL_CHUNK_LANES)
+	// block partition (persistent: nBlocks, partitions; per step: the rest)
+	int nBlocks;         // blocks of the current partition (0 = none yet)
+	int partitions;      // partitions made so far (diagnostics)
+	int nOrphanRows;     // large-island constraints with a body that has no home block this step
+	int blkMaxRows;      // most rows owned by one block this step
+	int blkMaxBodies;    // most home bodies in one block this step
+	int nCutRows;        // cut constraints this step
+	int blkTargetDeg;    // degree budget per block the current partition was made with
+	int partitionAge;    // steps since the current partition was made (persistent; kept here so that a snapshot carries it)
+	int partitionCooldown; // steps for which no new partition is attempted (the last attempts did not fit); persistent
+	uint32_t colorMaskLo, colorMaskHi; // colours that own at least one large-island constraint this step
 };
 
 struct DState
@@ -234,6 +253,17 @@ struct DW
 	uint32_t* rootPen;   // per root: max penetration of the running position iteration (bits of -minSeparation)
 	int* rootDone;       // per root: positionSolved
 	uint32_t* rootSleepMin;
+	// block partition of the large islands
+	int* b_blk1;         // per body, persistent: home block + 1 (0 = none)
+	int* b_adopt;        // per body, per step: block + 1 offered to a body without one by a neighbour (max over the neighbours)
+	int* blkRows;        // per block: rows it owns this step
+	int* blkRowStart;    // [nBlocks + 1] exclusive scan of blkRows
+	int* blkCursor;      // per block: fill cursor of k_color_fill
+	int* blkBodyStart;   // [nBlocks + 1] home bodies of each block (segments of blkBodies)
+	int* blkBodies;      // large-island bodies grouped by home block
+	int* rowColor;       // per block-sorted row: its colour
+	float4* b_cutv;      // per body: (v.xy, w, tag) exchange row of the cut constraints, velocity phase (positions: b_posv)
+	int blockSort;       // k_color_fill groups the rows by owner block (k_solve_blocks) instead of by colour
 
 	// ---- broad-phase ------------------------------------------------------------------------
 	int* moveBuf;        // proxy indices whose fat AABB changed / were created

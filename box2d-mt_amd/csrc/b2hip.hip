@@ -22,6 +22,7 @@
 #include "b2d_kernels_toi_domains.h"
 #include "b2d_kernels_solve_dataflow.h"
 #include "b2d_kernels_solve_mailbox.h"
+#include "b2d_kernels_solve_blocks.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -201,7 +202,7 @@ struct b2hip_world
 	DevArray<float> stateOut;
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
 	int dfEpoch;
-	bool solverRows, solverLocal, noSideStream, profileDetail;
+	bool solverRows, solverLocal, solverMailbox, noSideStream, profileDetail;
 	hipStream_t stream2 = nullptr; // small-island solver beside the large-island one
 	hipEvent_t evFork = nullptr, evJoin = nullptr;
 	int dfLanesForced, dfSleep, nCU; // k_solve_dataflow: workgroup size, poll back-off, co-resident workgroups
@@ -209,6 +210,12 @@ struct b2hip_world
 	int persistSteps;            // steps solved by the persistent kernel (diagnostics)
 	DevArray<int> consts; // [0] nBodies, [1] gridSize, [2] radix hist count, [3] sorted-pair count
 	DevArray<unsigned long long> filterPairs; // sorted body-pair keys of the joints created / destroyed since the last step
+	// block partition of the large islands (b2d_kernels_solve_blocks.h)
+	DevArray<int> b_blk1, b_adopt, blkRows, blkRowStart, blkCursor, blkBodyStart, blkBodies, rowColor;
+	DevArray<float4> b_cutv;
+	int blocksMaxWG = 0;         // co-resident workgroups of k_solve_blocks on this device (0 = do not use it)
+	bool noBlocks = false;       // B2HIP_NO_BLOCKS=1: keep the large islands on k_solve_mailbox
+	int blockSteps = 0;          // steps solved by k_solve_blocks (diagnostics)
 
 	// pinned host buffers
 	float* h_state;
@@ -636,6 +643,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
 	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
+	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2);
+	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
 	ENS(gridBar, 16);
@@ -700,6 +709,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
 	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p; d.toiParent = w->toiParent.p; d.toiDomOf = w->toiDomOf.p; d.toiDomRoot = w->toiDomRoot.p; d.toiDomCount = w->toiDomCount.p; d.toiDomBase = w->toiDomBase.p; d.toiDomFill = w->toiDomFill.p; d.toiDomFailed = w->toiDomFailed.p; d.toiDomEvents = w->toiDomEvents.p; d.toiDomList = w->toiDomList.p; d.toiHull = w->toiHull.p;
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
+	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p;
+	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
 	return 0;
 }
 
@@ -1094,6 +1105,42 @@ static void tracePoint(b2hip_world* w, const char* label)
 }
 #define TRACE(label) tracePoint(w, label)
 
+// New block partition of the large-island bodies (b2d_kernels_solve_blocks.h): sort by Morton cell, cut the sorted sequence
+// where the contact degrees add up to `targetDeg`, then look at the colours and the census again (classes have changed).
+static int partitionLargeIslands(b2hip_world* w, int targetDeg)
+{
+	DW& d = w->dw;
+	HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.blkTargetDeg, &targetDeg, sizeof(int), hipMemcpyHostToDevice, w->stream));
+	uint64_t* kin = d.pairKey;
+	uint64_t* kout = d.pairKey2;
+	int2* vin = d.pairProxy;
+	int2* vout = d.pairProxy2;
+	LAUNCH(w, k_part_keys, gridFor(d.nBodies), 256, d, kin, vin);
+	// LSD radix sort: the body-id bits, then the 32 Morton bits (the pair buffers hold at least 8 entries per proxy)
+	std::vector<int> shifts;
+	const int idBits = radixBits(d.nBodies + 1);
+	for (int sft = 0; sft < idBits; sft += 8) shifts.push_back(sft);
+	for (int sft = 0; sft < 32; sft += 8) shifts.push_back(32 + sft);
+	const int tilesCap = d.capPairs / RADIX_TILE + 1;
+	const int* nPtr = &d.st->c.nLBodies;
+	for (size_t p = 0; p < shifts.size(); ++p)
+	{
+		LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
+		LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, nPtr, 0, shifts[p], tilesCap);
+		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->consts.p + 2, 256 * tilesCap);
+		LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, nPtr, 0, shifts[p]);
+		std::swap(kin, kout);
+		std::swap(vin, vout);
+	}
+	LAUNCH(w, k_part_weights, gridFor(d.nBodies), 256, d, vin, d.pairFirst);
+	deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, nPtr, d.nBodies);
+	LAUNCH(w, k_part_assign, gridFor(d.nBodies), 256, d, vin, d.pairRank);
+	LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
+	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_block_census, 1, 1024, d);
+	return 0;
+}
+
 // b2World::Solve (b2World.cpp:1166-1431): island build, census read-back, then the solver tier of each island.
 static int phaseSolve(b2hip_world* w)
 {
@@ -1128,6 +1175,7 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
 		if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
 		LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_block_census, 1, 1024, d);
 		return 0;
 	});
 	if (rc) return rc;
@@ -1135,7 +1183,34 @@ static int phaseSolve(b2hip_world* w)
 	// the host needs the island census to size the solver launches
 	rc = readState(w);
 	if (rc) return rc;
-	const Counters c = w->h_dstate->c;
+	Counters c = w->h_dstate->c;
+	// ---- block partition of the large islands: (re)made when bodies without a home block joined, when a block outgrew a
+	// workgroup, or when too many constraints cross block boundaries (the pile has moved since the partition was made)
+	const bool blockShape = forceLarge != 2 && !w->noBlocks && c.nLIslands > 0 && d.nJoints == 0 && c.maxDegree <= HUB_DEGREE &&
+		(sp.warmStarting ? 1 : 0) + sp.velIters > 0 && w->blocksMaxWG > 0;
+	if (blockShape && c.partitionCooldown == 0)
+	{
+		auto misfit = [](const Counters& k) { return k.nBlocks == 0 || k.nOrphanRows > 0 || k.blkMaxRows > BLOCK_LANES || k.blkMaxBodies > BLOCK_MAX_BODIES; };
+		bool need = misfit(c) || (4 * c.nCutRows > c.nLContacts && c.partitionAge > 240);
+		int target = BLOCK_TARGET_DEG;
+		for (int attempt = 0; need && attempt < 3; ++attempt)
+		{
+			rc = partitionLargeIslands(w, target);
+			if (rc) return rc;
+			rc = readState(w);
+			if (rc) return rc;
+			c = w->h_dstate->c;
+			need = misfit(c);
+			target = target * 2 / 3;
+		}
+		if (need)
+		{
+			// does not fit (e.g. more blocks than workgroups can be resident): back to the other solvers for a while
+			const int cooldown = 120;
+			HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.partitionCooldown, &cooldown, sizeof(int), hipMemcpyHostToDevice, w->stream));
+			HIP_TRY(hipStreamSynchronize(w->stream));
+		}
+	}
 
 	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[4], w->stream));
 	const bool exactLarge = forceLarge == 2;
@@ -1203,6 +1278,11 @@ static int phaseSolve(b2hip_world* w)
 		const int persistMaxWG = w->persistMaxWG * (PERSIST_LANES / persistLanes);
 		const bool usePersistent = !exactLarge && !hasJoints && !hasHubs && !w->debugTrace && !w->kernelTimingLaunches &&
 			persistMaxWG > 0 && persistWG <= persistMaxWG;
+		// the block solver (bodies in LDS, one workgroup per block of the partition): whenever the partition fits
+		const bool useBlocks = usePersistent && blockShape && !w->solverBarriers && !w->solverRows && !w->solverMailbox && c.nBlocks > 0 &&
+			c.nOrphanRows == 0 && c.blkMaxRows <= BLOCK_LANES && c.blkMaxBodies <= BLOCK_MAX_BODIES && c.nBlocks <= w->blocksMaxWG &&
+			(sp.velIters + 2) * (MAX_COLORS + 1) < 65536 && (sp.posIters + 1) * (MAX_COLORS + 1) < 65536;
+		d.blockSort = useBlocks ? 1 : 0;
 		bool colorsOnDevice = false;
 		if (!exactLarge && (c.needRecolor || c.nUncolored > 0 || c.nCompact > 0))
 		{
@@ -1269,9 +1349,22 @@ static int phaseSolve(b2hip_world* w)
 		{
 			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (b2d_kernels_solve_persist.h)
 			// (the barrier words were zeroed by k_step_begin: one resident launch per step)
-			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 3; }
+			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = useBlocks ? 4 : 3; }
 			const int nColorsArg = colorsOnDevice ? -1 : nColors; // -1: read Counters::nColors on the device
-			if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
+			if (useBlocks)
+			{
+				// (tags carry a 15-bit epoch: wipe the exchange rows when it comes round, like the mailbox slots below)
+				if (w->dfEpoch != 0 && (w->dfEpoch & 0x3fff) == 0)
+				{
+					HIP_TRY(hipMemsetAsync(w->b_cutv.p, 0, w->b_cutv.cap * sizeof(float4), w->stream));
+					HIP_TRY(hipMemsetAsync(w->b_posv.p, 0, w->b_posv.cap * sizeof(float4), w->stream));
+					HIP_TRY(hipMemsetAsync(w->dfInbox.p, 0, w->dfInbox.cap * sizeof(float4), w->stream));
+				}
+				LAUNCH(w, k_solve_blocks<BLOCK_LANES>, c.nBlocks, BLOCK_LANES, d, sp, w->gridBar.p, w->dfEpoch);
+				w->dfEpoch += 1;
+				w->blockSteps += 1;
+			}
+			else if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
 			else if (w->solverRows || (sp.velIters + 2) * DF_RANKS >= 65536 || (sp.posIters + 1) * DF_RANKS >= 65536)
 				LAUNCH(w, k_solve_dataflow, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfSleep);
 			else
@@ -1282,7 +1375,11 @@ static int phaseSolve(b2hip_world* w)
 				const bool tryLocal = w->solverLocal && persistWG <= xcdWG;
 				// the 15-bit epoch of the mailbox tags comes round every 16 384 steps: wipe the slots then, so that a slot
 				// nobody has written since cannot carry a matching tag
-				if (w->dfEpoch != 0 && (w->dfEpoch & 0x3fff) == 0) HIP_TRY(hipMemsetAsync(w->dfInbox.p, 0, w->dfInbox.cap * sizeof(float4), w->stream));
+				if (w->dfEpoch != 0 && (w->dfEpoch & 0x3fff) == 0)
+				{
+					HIP_TRY(hipMemsetAsync(w->dfInbox.p, 0, w->dfInbox.cap * sizeof(float4), w->stream));
+					HIP_TRY(hipMemsetAsync(w->b_cutv.p, 0, w->b_cutv.cap * sizeof(float4), w->stream));
+				}
 				if (tryLocal) LAUNCH(w, k_solve_mailbox<true>, 8 * persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfEpoch, persistWG, 0);
 				LAUNCH(w, k_solve_mailbox<false>, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfEpoch, persistWG, tryLocal ? 1 : 0);
 				w->dfEpoch += 1;
@@ -1307,9 +1404,13 @@ static int phaseSolve(b2hip_world* w)
 		if (hasJoints && !exactLarge) LAUNCH(w, k_joints_sort, gJ, 64, d);
 		LAUNCH(w, k_large_init, gC, 256, d, sp);
 		TRACE("init");
+		// colours that own no constraint (the partition keeps two colour ranges apart) are not launched
+		const uint64_t colorMask = exactLarge ? ~0ull : ((uint64_t)w->h_dstate->c.colorMaskLo | ((uint64_t)w->h_dstate->c.colorMaskHi << 32));
+		auto colorUsed = [&](int col) { return col >= 64 || ((colorMask >> col) & 1ull) != 0; };
 		if (sp.warmStarting)
 		{
-			for (int col = 0; col < nColors; ++col) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
+			for (int col = 0; col < nColors; ++col)
+				if (colorUsed(col)) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
 			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 0);
 		}
 		TRACE("warmstart");
@@ -1319,6 +1420,7 @@ static int phaseSolve(b2hip_world* w)
 			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 1);
 			for (int col = 0; col < nColors; ++col)
 			{
+				if (!colorUsed(col)) continue;
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
 				LAUNCH(w, k_large_velocity, gK, 256, d, col, 1);
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
@@ -1335,6 +1437,7 @@ static int phaseSolve(b2hip_world* w)
 			LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
 			for (int col = 0; col < nColors; ++col)
 			{
+				if (!colorUsed(col)) continue;
 				LAUNCH(w, k_large_position, gK, 256, d, col);
 				if (w->debugTrace) TRACE(("pos" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
@@ -1366,6 +1469,10 @@ static int phaseSolve(b2hip_world* w)
 	w->last.nColors = nColors;
 	w->last.nTouching = c.nTouching;
 	w->last.nDestroy = c.nDestroy;
+	w->last.nBlocks = c.nBlocks;
+	w->last.nCutRows = c.nCutRows;
+	w->last.blkMaxRows = c.blkMaxRows;
+	w->last.partitions = c.partitions;
 	return 0;
 }
 
@@ -1701,6 +1808,19 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	// buys only 0.1-0.3 us of it (MI355X_MICROARCH.md, handoff-1to1)
 	w->solverLocal = getenv("B2HIP_SOLVER_SINGLE_XCD") != nullptr;
 	w->solverRows = getenv("B2HIP_SOLVER_ROWS") != nullptr; // polled body rows (k_solve_dataflow) instead of pushed mailboxes
+	w->solverMailbox = getenv("B2HIP_SOLVER_MAILBOX") != nullptr; // pushed hand-offs for every constraint (k_solve_mailbox) instead of k_solve_blocks
+	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
+	{
+		int perCU = 0;
+		hipDeviceProp_t prop;
+		int devId = 0;
+		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess &&
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<BLOCK_LANES>, BLOCK_LANES, 0) == hipSuccess && perCU > 0)
+		{
+			// one block per CU is all this sizing relies on (the occupancy query can be one too high, MI355X_MICROARCH.md)
+			w->blocksMaxWG = prop.multiProcessorCount - 8;
+		}
+	}
 	w->dfSleep = 1;
 	if (const char* e = getenv("B2HIP_DF_LANES")) w->dfLanesForced = std::max(64, std::min(256, atoi(e) / 64 * 64));
 	if (const char* e = getenv("B2HIP_DF_SLEEP")) w->dfSleep = atoi(e);
@@ -1770,6 +1890,8 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
 	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
 	w->filterPairs.release();
+	w->b_blk1.release(); w->b_adopt.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release();
+	w->blkBodyStart.release(); w->blkBodies.release(); w->rowColor.release(); w->b_cutv.release();
 	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
 	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->stateOut.release(); w->consts.release();
 	if (w->h_state) (void)hipHostFree(w->h_state);
@@ -2667,7 +2789,7 @@ static int stepEndImpl(b2hip_world* w)
 			w->ktLaunches += 1;
 		}
 		if (w->ktKind == 1) w->ktBytes = (double)w->last.nLContacts * 220.0 * w->sp.velIters;
-		else if (w->ktKind == 3) w->ktBytes = (double)w->last.nLContacts * (w->sp.velIters * 220.0 + w->last.posItersLarge * 136.0 + 488.0) + (double)w->last.nLBodies * 240.0;
+		else if (w->ktKind == 3 || w->ktKind == 4) w->ktBytes = (double)w->last.nLContacts * (w->sp.velIters * 220.0 + w->last.posItersLarge * 136.0 + 488.0) + (double)w->last.nLBodies * 240.0;
 		else w->ktBytes = (double)w->last.nSContacts * (w->sp.velIters * 220.0 + w->sp.posIters * 136.0 + 488.0) + (double)w->last.nSBodies * 240.0;
 	}
 	return 0;
@@ -2757,7 +2879,7 @@ struct SnapHeader
 	float inv_dt0, cellSize;
 	int32_t eventsOn, reserved;
 };
-const uint32_t kSnapVersion = 2;
+const uint32_t kSnapVersion = 3;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
 
 struct SnapWriter
@@ -2842,7 +2964,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 #define SNAP_DEV(arr, n) do { rc = o.dev(w->arr.p, (size_t)(n) * sizeof(*w->arr.p)); if (rc) return rc; } while (0)
 	SNAP_DEV(d_joints, w->joints.size()); // the device copy carries the accumulated impulses
 	SNAP_DEV(b_pos, nb); SNAP_DEV(b_pos0, nb); SNAP_DEV(b_vel, nb); SNAP_DEV(b_xf, nb); SNAP_DEV(b_mass, nb); SNAP_DEV(b_damp, nb);
-	SNAP_DEV(b_force, nb); SNAP_DEV(b_flags, nb); SNAP_DEV(b_wake, nb); SNAP_DEV(b_proxyHead, nb);
+	SNAP_DEV(b_force, nb); SNAP_DEV(b_flags, nb); SNAP_DEV(b_wake, nb); SNAP_DEV(b_proxyHead, nb); SNAP_DEV(b_blk1, nb);
 	SNAP_DEV(p_fat, np); SNAP_DEV(p_body, np); SNAP_DEV(p_shape, np); SNAP_DEV(p_key, np); SNAP_DEV(p_filter0, np); SNAP_DEV(p_filter1, np);
 	SNAP_DEV(p_mat, np); SNAP_DEV(p_next, np);
 	const int cur = ds.cur;
@@ -2928,7 +3050,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	struct Sec { const void* p; size_t bytes; };
 	auto sec = [&](size_t n, size_t elem) { Sec x = { in.take(n * elem), n * elem }; return x; };
 	const Sec sPos = sec(nb, 16), sPos0 = sec(nb, 16), sVel = sec(nb, 16), sXf = sec(nb, 16), sMass = sec(nb, 16), sDamp = sec(nb, 16), sForce = sec(nb, 16);
-	const Sec sFlags = sec(nb, 4), sWake = sec(nb, 4), sHead = sec(nb, 4);
+	const Sec sFlags = sec(nb, 4), sWake = sec(nb, 4), sHead = sec(nb, 4), sBlk = sec(nb, 4);
 	const Sec sFat = sec(np, 16), sPBody = sec(np, 4), sPShape = sec(np, 4), sPKey = sec(np, 4), sF0 = sec(np, 4), sF1 = sec(np, 4), sPMat = sec(np, 8), sNext = sec(np, 4);
 	const Sec cIds = sec(nC, 16), cKey = sec(nC, 8), cFlags = sec(nC, 4), cMat = sec(nC, 16), cMan0 = sec(nC, 16), cMan1 = sec(nC, 16), cImp = sec(nC, 16),
 		cMan3 = sec(nC, 16), cColor = sec(nC, 4), cMgr = sec(nC, 4);
@@ -2946,6 +3068,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 		return true;
 	};
 	if (!inRange(sHead, -1, (long long)np) || !inRange(sNext, -1, (long long)np)) return corrupt("per-body proxy lists");
+	if (!inRange(sBlk, 0, MAX_BLOCKS + 1) || ds.c.nBlocks < 0 || ds.c.nBlocks > MAX_BLOCKS) return corrupt("block partition");
 	if (!inRange(sPBody, 0, (long long)nb) || !inRange(sPShape, 0, (long long)nS)) return corrupt("proxy table");
 	if (!inRange(sToi, 0, (long long)nC) || !inRange(sMoves, 0, (long long)np)) return corrupt("TOI order / move buffer");
 	if (!inRange(cColor, -1, MAX_COLORS) || !inRange(cMgr, -1, (long long)std::max<size_t>(nT, 1))) return corrupt("contact colour / TOI slot");
@@ -3024,7 +3147,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 #define SNAP_UP(arr, s) do { if ((s).bytes && hipMemcpy(w->arr.p, (s).p, (s).bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (" #arr ")")); } while (0)
 	if (hipMemcpy(w->d_state.p, &ds, sizeof(DState), hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (state block)"));
 	SNAP_UP(b_pos, sPos); SNAP_UP(b_pos0, sPos0); SNAP_UP(b_vel, sVel); SNAP_UP(b_xf, sXf); SNAP_UP(b_mass, sMass); SNAP_UP(b_damp, sDamp);
-	SNAP_UP(b_force, sForce); SNAP_UP(b_flags, sFlags); SNAP_UP(b_wake, sWake); SNAP_UP(b_proxyHead, sHead);
+	SNAP_UP(b_force, sForce); SNAP_UP(b_flags, sFlags); SNAP_UP(b_wake, sWake); SNAP_UP(b_proxyHead, sHead); SNAP_UP(b_blk1, sBlk);
 	SNAP_UP(p_fat, sFat); SNAP_UP(p_body, sPBody); SNAP_UP(p_shape, sPShape); SNAP_UP(p_key, sPKey); SNAP_UP(p_filter0, sF0); SNAP_UP(p_filter1, sF1);
 	SNAP_UP(p_mat, sPMat); SNAP_UP(p_next, sNext);
 	const int cur = (int)h.cur;
@@ -3281,6 +3404,11 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->toi_calls = w->last.nToiCalls;
 	out->toi_pending_first_pass = w->last.nToiList;
 	out->toi_serial_fallbacks = w->toiFallbacks;
+	out->blocks = w->last.nBlocks;
+	out->cut_constraints = w->last.nCutRows;
+	out->block_max_rows = w->last.blkMaxRows;
+	out->partitions = w->last.partitions;
+	out->block_solver_steps = w->blockSteps;
 	return 0;
 }
 
@@ -3304,7 +3432,7 @@ int b2hip_set_kernel_timing(b2hip_world* w, int enable)
 int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes)
 {
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
-	const char* n = w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : (w->solverRows ? "k_solve_dataflow" : "k_solve_mailbox")) : ""));
+	const char* n = w->ktKind == 4 ? "k_solve_blocks" : w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : (w->solverRows ? "k_solve_dataflow" : "k_solve_mailbox")) : ""));
 	if (name && name_cap > 0)
 	{
 		strncpy(name, n, (size_t)name_cap - 1);

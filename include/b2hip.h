@@ -294,6 +294,12 @@ typedef struct b2hip_counters
 	int32_t toi_calls;               /* b2TimeOfImpact evaluations in the last step */
 	int32_t toi_pending_first_pass;  /* contacts whose first-pass time of impact was < 1 */
 	int32_t toi_serial_fallbacks;    /* steps (since creation) whose parallel TOI chains were redone by the serial event loop */
+	/* block partition of the large islands (one workgroup solves one block with its bodies in LDS) */
+	int32_t blocks;                  /* blocks of the current partition */
+	int32_t cut_constraints;         /* constraints between bodies of two blocks in the last step */
+	int32_t block_max_rows;          /* most constraints owned by one block in the last step */
+	int32_t partitions;              /* partitions made since the world was created */
+	int32_t block_solver_steps;      /* steps whose large islands were solved by the block solver */
 } b2hip_counters;
 
 const char* b2hip_last_error(void);

@@ -389,9 +389,12 @@ def test_bench_scene_run_to_run_determinism(amd, default_mode):
     assert first_bad is None, "two runs of the bench scene differ by step %s" % first_bad
 
 
-def test_persistent_solver_matches_launch_per_colour(amd, default_mode):
-    """The persistent coloured solver (one resident grid, grid barriers between colours) must reproduce the
-    launch-per-colour solver bit for bit: same colours, same sweep structure, same arithmetic."""
+def test_block_solver_matches_launch_per_colour(amd, default_mode):
+    """The default large-island solver (k_solve_blocks: one workgroup per block of the partition, bodies in LDS, boundary
+    bodies handed over through memory) must reproduce the launch-per-colour solver bit for bit - same partition, same
+    colours, same sweep structure, same arithmetic - and so must the three older resident solvers kept for cross-checks
+    (pushed mailboxes, polled body rows, grid barrier per colour). Multi-block islands (Pyramid 90: 4 095 boxes, Pyramid 141:
+    the bench workload), single-block ones (Pyramid 40) and a dense field whose islands come and go."""
     def run(scene, steps, **kw):
         w = amd.world(scene, **kw)
         out = []
@@ -399,21 +402,31 @@ def test_persistent_solver_matches_launch_per_colour(amd, default_mode):
             w.step(1)
             out.append((bh.fnv1a64(w.bodies()), w.contact_count))
         ids, flags, man = w.contacts()
+        import ctypes as C
+        import b2hip
+        ctr = b2hip.Counters()
+        b2hip.lib().b2hip_get_counters(C.c_void_p(w.device_world()), C.byref(ctr))
         w.close()
-        return out, man.tobytes()
+        return out, man.tobytes(), ctr.block_solver_steps, ctr.blocks
 
-    for scene, steps, kw in [(bh.PYRAMID, 90, dict(p0=40)), (bh.FIELD, 40, dict(p0=800, p1=200, f0=50.0, f1=3.0, seed=29))]:
-        for var in ("B2HIP_SOLVER_LAUNCHES", "B2HIP_SOLVER_BARRIERS", "B2HIP_SOLVER_ROWS"):
+    variants = ("B2HIP_SOLVER_MAILBOX", "B2HIP_SOLVER_ROWS", "B2HIP_SOLVER_BARRIERS", "B2HIP_SOLVER_LAUNCHES")
+    ccd = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
+    for scene, steps, kw, check in [(bh.PYRAMID, 90, dict(p0=40), variants), (bh.PYRAMID, 100, dict(p0=90, flags=ccd), variants),
+                                    (bh.PYRAMID, 160, dict(p0=141, flags=ccd), ("B2HIP_SOLVER_LAUNCHES",)),
+                                    (bh.FIELD, 40, dict(p0=800, p1=200, f0=50.0, f1=3.0, seed=29), variants)]:
+        for var in variants:
             os.environ.pop(var, None)
-        a = run(scene, steps, **kw)  # default: body-level dataflow with pushed hand-offs (k_solve_mailbox)
-        for var in ("B2HIP_SOLVER_ROWS", "B2HIP_SOLVER_BARRIERS", "B2HIP_SOLVER_LAUNCHES"):
+        a = run(scene, steps, **kw)
+        assert a[2] > 0, "the block solver never ran on scene %d" % scene
+        for var in check:
             os.environ[var] = "1"
             try:
                 b = run(scene, steps, **kw)
             finally:
                 os.environ.pop(var, None)
+            assert b[2] == 0, "%s did not keep the world off the block solver" % var
             first_bad = next((i for i, (x, y) in enumerate(zip(a[0], b[0])) if x != y), None)
-            assert first_bad is None, "dataflow solver and %s diverge at step %s" % (var, first_bad)
+            assert first_bad is None, "block solver and %s diverge at step %s (scene %d, %d rows)" % (var, first_bad, scene, kw.get("p0", 0))
             assert a[1] == b[1]
 
 
