@@ -279,7 +279,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.nToiGroups = 0;
 		c.nToiMoved = 0;
 	}
-	if (t < 16) bar[t] = 0;
+	if (t < 32) bar[t] = 0;
 }
 
 // b2World::CreateJoint / DestroyJoint (b2World.cpp:716-732, 833-845): contacts between the two bodies of a joint that does

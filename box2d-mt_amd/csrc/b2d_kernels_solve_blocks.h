@@ -18,8 +18,8 @@
 //  -> the home lanes take the final rows of their boundary bodies back into LDS.
 // A sweep costs (interior colours) workgroup barriers + (upper-range colours on the busiest body + 1) memory hand-offs
 // instead of (all colours) memory hand-offs, and the hand-offs are few (the block surfaces), so the CUs' memory queues -
-// which price a hand-off - are nearly idle. No grid barrier in the velocity phase at all; one pair per position iteration
-// for the islands' convergence verdicts (b2Island.cpp:329-334).
+// which price a hand-off - are nearly idle. No grid barrier in the velocity phase at all; one per position iteration
+// for the islands' convergence verdicts (b2Island.cpp:329-334), none when the world's large islands fit one block.
 //
 // The visiting order is the colour order on every body (interior colours of different blocks never share a non-static body),
 // so the floats are bit-identical to the launch-per-colour path (k_large_velocity ...) under the same colouring
@@ -231,6 +231,16 @@ __device__ __forceinline__ void integratedVelocityOf(const DW& W, const StepPara
 	}
 }
 
+// Grid barrier of k_solve_blocks; with one workgroup (a mid-size island of its own) it is a workgroup barrier behind the
+// drain of this wave's memory operations (no-return atomics included).
+__device__ __forceinline__ bool blockBarrier(const GridBarrier& gb)
+{
+	if (gb.nWG > 1) return gridBarrier(gb);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	return true;
+}
+
 template <int LANES>
 __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int* bar, int epoch)
 {
@@ -248,6 +258,8 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	__shared__ int s_hist[MAX_COLORS], s_colStart[MAX_COLORS + 1];
 	__shared__ unsigned long long s_colMask;
 	if (gtid == 0) S->c.allLargeDone = 0;
+	// (penetration maxima: buffer 0 was wiped by k_island_init, buffer 2 is wiped after the first barrier, buffer 1 here)
+	for (int k = gtid; k < nIslands; k += gsize) stcU(&W.rootPen[(size_t)W.nBodies + W.li_roots[k]], 0u);
 	const unsigned long long t0 = wall_clock64();
 #define BLK_STAMP(k) do { if (gtid == 0) bar[8 + (k)] = (int)(wall_clock64() - t0); } while (0)
 	const int tagV = ((2 * epoch + 1) & 0x7fff) << 16, tagP = ((2 * epoch + 2) & 0x7fff) << 16;
@@ -473,13 +485,19 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	BLK_STAMP(2);
 
 	// ---- position iterations (b2Island.cpp:316-335, b2ContactSolver.cpp:676-752) -----------------------------------------------------------
-	int executed = 0, hExecuted = 0; // iterations in which my constraint's / my body's island was still open
+	// An island is closed once an iteration leaves its minimum separation >= -3 linearSlop (b2Island.cpp:329-334). ONE grid
+	// barrier per iteration: the penetration maxima of iteration `it` go to buffer it % 3 of rootPen (three buffers of
+	// nBodies words: the one of iteration it + 2 is wiped after barrier `it`, when nobody reads or adds to it), and after the
+	// barrier every lane reads the verdict of its own island itself. Whether ANY island is still open is known one barrier
+	// later (each workgroup reports its open rows to a counter of iteration it % 4): if none was, iteration it + 1 found
+	// every row inactive, and all workgroups leave after its barrier.
+	bool rowDone = false, hDone = false;
 	for (int it = 0; it < sp.posIters; ++it)
 	{
-		int* openNow = &gb.bar[2 + (it & 1)];
-		int* openNext = &gb.bar[2 + ((it + 1) & 1)];
-		const bool active = have && ldcI(&W.rootDone[r.root]) == 0;
-		const bool hActive = hBoundary && ldcI(&W.rootDone[hRoot]) == 0;
+		uint32_t* pen = W.rootPen + (size_t)(it % 3) * W.nBodies;
+		uint32_t* penWipe = W.rootPen + (size_t)((it + 2) % 3) * W.nBodies;
+		const bool active = have && !rowDone;
+		const bool hActive = hBoundary && !hDone;
 		float minSep = 0.0f;
 		for (unsigned long long m = colMask & COLOR_INTERIOR_BITS; m != 0ull; m &= m - 1ull)
 		{
@@ -492,7 +510,7 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 				if (nsB) qb = s_row[slotB];
 				pA.c = v2(qa.x, qa.y); pA.a = qa.z;
 				pB.c = v2(qb.x, qb.y); pB.a = qb.z;
-				b2dSolvePosition(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
+				b2dSolvePosition<true>(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
 				if (nsA) s_row[slotA] = make_float4(pA.c.x, pA.c.y, pA.a, 0.0f);
 				if (nsB) s_row[slotB] = make_float4(pB.c.x, pB.c.y, pB.a, 0.0f);
 			}
@@ -503,10 +521,10 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 			if (hActive)
 			{
 				const float4 q = s_row[tid];
-				stRow(&W.b_posv[hBody], q.x, q.y, q.z, tagP + hExecuted * (hCutDeg + 1) + 1);
+				stRow(&W.b_posv[hBody], q.x, q.y, q.z, tagP + it * (hCutDeg + 1) + 1);
 			}
 			{
-				const int needA = tagP + executed * (degA + 1) + 1 + rankA, needB = tagP + executed * (degB + 1) + 1 + rankB;
+				const int needA = tagP + it * (degA + 1) + 1 + rankA, needB = tagP + it * (degB + 1) + 1 + rankB;
 				const bool ok = dataflowRun(upper && active, posRowA, needA, posRowB, needB, bar, gb.overflow, 1, [&](f4v ra, f4v rb)
 				{
 					BodyPos pA, pB;
@@ -514,14 +532,14 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 					pB.c = v2(rb.x, rb.y); pB.a = rb.z;
 					if (!nsA) { pA.c = v2(statA.x, statA.y); pA.a = statA.z; }
 					if (!nsB) { pB.c = v2(statB.x, statB.y); pB.a = statB.z; }
-					b2dSolvePosition(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
+					b2dSolvePosition<true>(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
 					if (nsA) stRow(posRowA, pA.c.x, pA.c.y, pA.a, needA + 1);
 					if (nsB) stRow(posRowB, pB.c.x, pB.c.y, pB.a, needB + 1);
 				});
 				if (!ok) return;
 			}
 			{
-				const int need = tagP + (hExecuted + 1) * (hCutDeg + 1);
+				const int need = tagP + (it + 1) * (hCutDeg + 1);
 				const bool ok = dataflowRun(hActive, &W.b_posv[hBody], need, nullptr, 0, bar, gb.overflow, 1, [&](f4v ra, f4v)
 				{
 					s_row[tid] = make_float4(ra.x, ra.y, ra.z, 0.0f);
@@ -529,29 +547,30 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 				if (!ok) return;
 			}
 		}
-		if (active) ++executed;
-		if (hActive) ++hExecuted;
-		waveAtomicMaxU32(W.rootPen, r.root, floatBits(0.0f - minSep), active);
-		if (!gridBarrier(gb)) return;
-		// the islands' verdicts (minSeparation >= -3 linearSlop closes an island), as in k_solve_mailbox
-		if (gtid == 0) stcI(openNext, 0);
-		int open = 0;
+		waveAtomicMaxU32(pen, r.root, floatBits(0.0f - minSep), active);
+		if (!blockBarrier(gb)) return;
+		// after the barrier: verdicts; one lane per island records a closed island for k_large_sleep and wipes the buffer of
+		// the iteration after next
 		for (int k = gtid; k < nIslands; k += gsize)
 		{
 			const int root = W.li_roots[k];
-			if (ldcI(&W.rootDone[root])) continue;
-			const float minSeparation = -__uint_as_float(ldcU(&W.rootPen[root]));
-			if (minSeparation >= -3.0f * B2D_LINEAR_SLOP) stcI(&W.rootDone[root], 1); else ++open;
-			stcU(&W.rootPen[root], 0u);
+			if (ldcI(&W.rootDone[root]) == 0 && -__uint_as_float(ldcU(&pen[root])) >= -3.0f * B2D_LINEAR_SLOP) stcI(&W.rootDone[root], 1);
+			stcU(&penWipe[root], 0u);
 		}
-		if (open) __hip_atomic_fetch_add(openNow, open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (!gridBarrier(gb)) return;
-		if (gtid == 0) S->c.posItersLarge += 1;
-		if (ldcI(openNow) == 0)
+		const bool someOpenBefore = it == 0 || ldcI(&bar[16 + ((it - 1) & 3)]) != 0; // did iteration `it` have any open island?
+		if (gtid == 0)
+		{
+			stcI(&bar[16 + ((it + 2) & 3)], 0);
+			if (someOpenBefore) S->c.posItersLarge += 1;
+		}
+		if (!someOpenBefore)
 		{
 			if (gtid == 0) S->c.allLargeDone = 1;
 			break;
 		}
+		if (active) rowDone = -__uint_as_float(ldcU(&pen[r.root])) >= -3.0f * B2D_LINEAR_SLOP;
+		if (hActive) hDone = -__uint_as_float(ldcU(&pen[hRoot])) >= -3.0f * B2D_LINEAR_SLOP;
+		if (__syncthreads_or(have && !rowDone) && tid == 0) __hip_atomic_fetch_add(&bar[16 + (it & 3)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	BLK_STAMP(3);
 

@@ -254,6 +254,50 @@ B2D_HD float b2dSinCosImpl(float y, int which)
 B2D_HD float b2dSin(float y) { return b2dSinCosImpl(y, 0); }
 B2D_HD float b2dCos(float y) { return b2dSinCosImpl(y, 1); }
 
+// sinf(y) and cosf(y) together: ONE argument reduction feeds both polynomials. Every operation is the one b2dSin / b2dCos
+// perform on the same operands, so the two results are bit-identical to the separate calls (checked against them for all
+// 2^32 inputs by tests/probe, and a dense sample in tests/test_device_math_cpu.py); the pair costs about two thirds of them.
+B2D_HD void b2dSinCos(float y, float* sinOut, float* cosOut)
+{
+	double x = (double)y;
+	int n;
+	if (b2dAbsTop12(y) < b2dAbsTop12(0x1.921fb6p-1f))
+	{
+		if (b2dAbsTop12(y) < b2dAbsTop12(0x1p-12f))
+		{
+			*sinOut = y;
+			*cosOut = 1.0f;
+			return;
+		}
+		const double x2 = x * x;
+		*sinOut = b2dSinCosPoly(x, x2, 0, 0);
+		*cosOut = b2dSinCosPoly(x, x2, 0, 1);
+		return;
+	}
+	else if (b2dAbsTop12(y) < b2dAbsTop12(120.0f))
+	{
+		x = b2dReduceFast(x, &n);
+		const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+		const double xs = x * s, x2 = x * x;
+		*sinOut = b2dSinCosPoly(xs, x2, (n & 2) != 0, n);
+		*cosOut = b2dSinCosPoly(xs, x2, (n & 2) != 0, n ^ 1);
+		return;
+	}
+	else if (b2dAbsTop12(y) < 0x7f8u)
+	{
+		uint32_t xi = b2dAsUint(y);
+		int sign = (int)(xi >> 31);
+		x = b2dReduceLarge(xi, &n);
+		int m = n + sign;
+		const double s = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
+		const double xs = x * s, x2 = x * x;
+		*sinOut = b2dSinCosPoly(xs, x2, (m & 2) != 0, n);
+		*cosOut = b2dSinCosPoly(xs, x2, (m & 2) != 0, n ^ 1);
+		return;
+	}
+	*sinOut = *cosOut = y - y;
+}
+
 // b2Rot::Set (b2Math.h:294-299). On the device this is ONE out-of-line copy: the glibc-exact sinf/cosf pair is ~3 KB of
 // code, and inlined at every transform (ten sites in the time-of-impact root finder alone) it made the TOI kernels
 // 60-200 KB - far beyond the 64 KB instruction cache, where a wave pays ~2 us per KB of cold code it walks through.
@@ -261,8 +305,7 @@ B2D_HD float b2dCos(float y) { return b2dSinCosImpl(y, 1); }
 __device__ __noinline__ static Rot b2dRotOutOfLine(float angle)
 {
 	Rot q;
-	q.s = b2dSin(angle);
-	q.c = b2dCos(angle);
+	b2dSinCos(angle, &q.s, &q.c);
 	return q;
 }
 #endif
@@ -271,8 +314,7 @@ __device__ __noinline__ static Rot b2dRotOutOfLine(float angle)
 B2D_HD Rot b2dRotInline(float angle)
 {
 	Rot q;
-	q.s = b2dSin(angle);
-	q.c = b2dCos(angle);
+	b2dSinCos(angle, &q.s, &q.c);
 	return q;
 }
 
@@ -282,8 +324,7 @@ B2D_HD Rot b2dRot(float angle)
 	return b2dRotOutOfLine(angle);
 #else
 	Rot q;
-	q.s = b2dSin(angle);
-	q.c = b2dCos(angle);
+	b2dSinCos(angle, &q.s, &q.c);
 	return q;
 #endif
 }

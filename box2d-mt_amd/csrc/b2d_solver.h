@@ -9,6 +9,12 @@
 
 #include "b2d_collide.h"
 
+// A manifold has at most two points: loops over them are written with a constant trip count and a predicate, so that after
+// unrolling every index into the constraint's small arrays is a constant and the constraint can live in registers (a
+// data-dependent trip count made the compiler keep it in scratch memory: 240-300 bytes per lane, re-read at every solve).
+// Same operations in the same order: the floats do not change.
+#define B2D_FOR_POINTS(j, count) _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j < (count))
+
 struct BodyVel
 {
 	V2 v;
@@ -83,7 +89,7 @@ B2D_HD void b2dInitConstraint(ContactConstraint* cc, const Manifold* mf,
 		cc->velocityBias[j] = 0.0f;
 		cc->localPoints[j] = v2(0.0f, 0.0f);
 	}
-	for (int j = 0; j < pointCount; ++j)
+	B2D_FOR_POINTS(j, pointCount)
 	{
 		if (warmStarting)
 		{
@@ -128,7 +134,7 @@ B2D_HD void b2dInitConstraint(ContactConstraint* cc, const Manifold* mf,
 	{
 		wmNormal = b2dMulRV(xfA.q, mf->localNormal);
 		V2 planePoint = b2dMulXV(xfA, mf->localPoint);
-		for (int i = 0; i < pointCount; ++i)
+		B2D_FOR_POINTS(i, pointCount)
 		{
 			V2 clipPoint = b2dMulXV(xfB, mf->p[i]);
 			V2 ca = clipPoint + (radiusA - b2dDot(clipPoint - planePoint, wmNormal)) * wmNormal;
@@ -140,7 +146,7 @@ B2D_HD void b2dInitConstraint(ContactConstraint* cc, const Manifold* mf,
 	{
 		wmNormal = b2dMulRV(xfB.q, mf->localNormal);
 		V2 planePoint = b2dMulXV(xfB, mf->localPoint);
-		for (int i = 0; i < pointCount; ++i)
+		B2D_FOR_POINTS(i, pointCount)
 		{
 			V2 clipPoint = b2dMulXV(xfA, mf->p[i]);
 			V2 cb = clipPoint + (radiusB - b2dDot(clipPoint - planePoint, wmNormal)) * wmNormal;
@@ -152,7 +158,7 @@ B2D_HD void b2dInitConstraint(ContactConstraint* cc, const Manifold* mf,
 
 	cc->normal = wmNormal;
 
-	for (int j = 0; j < pointCount; ++j)
+	B2D_FOR_POINTS(j, pointCount)
 	{
 		cc->rA[j] = wmPoints[j] - cA;
 		cc->rB[j] = wmPoints[j] - cB;
@@ -221,7 +227,7 @@ B2D_HD void b2dWarmStart(const ContactConstraint* cc, BodyVel* A, BodyVel* B)
 	float wA = A->w, wB = B->w;
 	V2 normal = cc->normal;
 	V2 tangent = b2dCrossVS(normal, 1.0f);
-	for (int j = 0; j < cc->pointCount; ++j)
+	B2D_FOR_POINTS(j, cc->pointCount)
 	{
 		V2 P = cc->normalImpulse[j] * normal + cc->tangentImpulse[j] * tangent;
 		wA -= iA * b2dCross(cc->rA[j], P);
@@ -246,7 +252,7 @@ B2D_HD void b2dSolveVelocity(ContactConstraint* cc, BodyVel* A, BodyVel* B)
 	V2 tangent = b2dCrossVS(normal, 1.0f);
 	float friction = cc->friction;
 
-	for (int j = 0; j < pointCount; ++j)
+	B2D_FOR_POINTS(j, pointCount)
 	{
 		V2 dv = vB + b2dCrossSV(wB, cc->rB[j]) - vA - b2dCrossSV(wA, cc->rA[j]);
 		float vt = b2dDot(dv, tangent) - cc->tangentSpeed;
@@ -359,7 +365,7 @@ B2D_HD float b2dSolvePosition(const ContactConstraint* cc, BodyPos* A, BodyPos* 
 	float aA = A->a, aB = B->a;
 	float minSeparation = *minSepInOut;
 
-	for (int j = 0; j < pointCount; ++j)
+	B2D_FOR_POINTS(j, pointCount)
 	{
 		Xf xfA, xfB;
 		xfA.q = INLINE_ROT ? b2dRotInline(aA) : b2dRot(aA);

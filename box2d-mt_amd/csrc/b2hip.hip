@@ -214,6 +214,7 @@ struct b2hip_world
 	DevArray<int> b_blk1, b_adopt, blkRows, blkRowStart, blkCursor, blkBodyStart, blkBodies, rowColor;
 	DevArray<float4> b_cutv;
 	int blocksMaxWG = 0;         // co-resident workgroups of k_solve_blocks on this device (0 = do not use it)
+	int blockLanes = BLOCK_LANES; // workgroup size of k_solve_blocks = rows / home bodies a block may hold (B2HIP_BLOCK_LANES=512: half-size blocks)
 	bool noBlocks = false;       // B2HIP_NO_BLOCKS=1: keep the large islands on k_solve_mailbox
 	int blockSteps = 0;          // steps solved by k_solve_blocks (diagnostics)
 
@@ -624,7 +625,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, 3 * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -647,7 +648,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
-	ENS(gridBar, 16);
+	ENS(gridBar, 32);
 #undef ENS
 	if (w->h_stateCap < 12 * nb)
 	{
@@ -1190,9 +1191,10 @@ static int phaseSolve(b2hip_world* w)
 		(sp.warmStarting ? 1 : 0) + sp.velIters > 0 && w->blocksMaxWG > 0;
 	if (blockShape && c.partitionCooldown == 0)
 	{
-		auto misfit = [](const Counters& k) { return k.nBlocks == 0 || k.nOrphanRows > 0 || k.blkMaxRows > BLOCK_LANES || k.blkMaxBodies > BLOCK_MAX_BODIES; };
+		const int lanes = w->blockLanes;
+		auto misfit = [lanes](const Counters& k) { return k.nBlocks == 0 || k.nOrphanRows > 0 || k.blkMaxRows > lanes || k.blkMaxBodies > lanes; };
 		bool need = misfit(c) || (4 * c.nCutRows > c.nLContacts && c.partitionAge > 240);
-		int target = BLOCK_TARGET_DEG;
+		int target = BLOCK_TARGET_DEG * lanes / BLOCK_LANES;
 		for (int attempt = 0; need && attempt < 3; ++attempt)
 		{
 			rc = partitionLargeIslands(w, target);
@@ -1280,7 +1282,7 @@ static int phaseSolve(b2hip_world* w)
 			persistMaxWG > 0 && persistWG <= persistMaxWG;
 		// the block solver (bodies in LDS, one workgroup per block of the partition): whenever the partition fits
 		const bool useBlocks = usePersistent && blockShape && !w->solverBarriers && !w->solverRows && !w->solverMailbox && c.nBlocks > 0 &&
-			c.nOrphanRows == 0 && c.blkMaxRows <= BLOCK_LANES && c.blkMaxBodies <= BLOCK_MAX_BODIES && c.nBlocks <= w->blocksMaxWG &&
+			c.nOrphanRows == 0 && c.blkMaxRows <= w->blockLanes && c.blkMaxBodies <= w->blockLanes && c.nBlocks <= w->blocksMaxWG &&
 			(sp.velIters + 2) * (MAX_COLORS + 1) < 65536 && (sp.posIters + 1) * (MAX_COLORS + 1) < 65536;
 		d.blockSort = useBlocks ? 1 : 0;
 		bool colorsOnDevice = false;
@@ -1360,7 +1362,9 @@ static int phaseSolve(b2hip_world* w)
 					HIP_TRY(hipMemsetAsync(w->b_posv.p, 0, w->b_posv.cap * sizeof(float4), w->stream));
 					HIP_TRY(hipMemsetAsync(w->dfInbox.p, 0, w->dfInbox.cap * sizeof(float4), w->stream));
 				}
-				LAUNCH(w, k_solve_blocks<BLOCK_LANES>, c.nBlocks, BLOCK_LANES, d, sp, w->gridBar.p, w->dfEpoch);
+				if (w->blockLanes == 512) LAUNCH(w, k_solve_blocks<512>, c.nBlocks, 512, d, sp, w->gridBar.p, w->dfEpoch);
+				else if (w->blockLanes == 256) LAUNCH(w, k_solve_blocks<256>, c.nBlocks, 256, d, sp, w->gridBar.p, w->dfEpoch);
+				else LAUNCH(w, k_solve_blocks<BLOCK_LANES>, c.nBlocks, BLOCK_LANES, d, sp, w->gridBar.p, w->dfEpoch);
 				w->dfEpoch += 1;
 				w->blockSteps += 1;
 			}
@@ -1810,12 +1814,16 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverRows = getenv("B2HIP_SOLVER_ROWS") != nullptr; // polled body rows (k_solve_dataflow) instead of pushed mailboxes
 	w->solverMailbox = getenv("B2HIP_SOLVER_MAILBOX") != nullptr; // pushed hand-offs for every constraint (k_solve_mailbox) instead of k_solve_blocks
 	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
+	w->blockLanes = BLOCK_LANES;
+	if (const char* e = getenv("B2HIP_BLOCK_LANES")) w->blockLanes = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : BLOCK_LANES);
 	{
 		int perCU = 0;
 		hipDeviceProp_t prop;
 		int devId = 0;
 		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<BLOCK_LANES>, BLOCK_LANES, 0) == hipSuccess && perCU > 0)
+			(w->blockLanes == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<256>, 256, 0)
+			 : w->blockLanes == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<512>, 512, 0)
+			                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<BLOCK_LANES>, BLOCK_LANES, 0)) == hipSuccess && perCU > 0)
 		{
 			// one block per CU is all this sizing relies on (the occupancy query can be one too high, MI355X_MICROARCH.md)
 			w->blocksMaxWG = prop.multiProcessorCount - 8;
@@ -3351,6 +3359,11 @@ int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
 	case 13: src = w->bodyColorMask.p; elem = 8; break;
 	case 14: src = w->deg.p; elem = 4; break;
 	case 15: src = w->hubList.p; elem = 4; break;
+	case 16: src = w->bodyActive.p; elem = 8; break;
+	case 17: src = w->b_blk1.p; elem = 4; break;
+	case 18: src = w->li_ref.p; break;
+	case 19: src = w->rowColor.p; elem = 4; break;
+	case 20: src = w->blkRowStart.p; elem = 4; break;
 	default: return setError(B2HIP_ERR_INVALID, "bad array id");
 	}
 	HIP_TRY(hipMemcpy(out, (const char*)src + (size_t)first * elem, (size_t)count * elem, hipMemcpyDeviceToHost));

@@ -26,6 +26,10 @@ long probe_sincos_vs_libm(unsigned lo, unsigned hi, unsigned stride)
 		if (f != f || f - f != 0.0f) continue;
 		if (b2dAsUint(sinf(f)) != b2dAsUint(b2dSin(f))) ++bad;
 		if (b2dAsUint(cosf(f)) != b2dAsUint(b2dCos(f))) ++bad;
+		// the fused pair (one argument reduction for both) is what b2Rot::Set uses on the device
+		float s2, c2;
+		b2dSinCos(f, &s2, &c2);
+		if (b2dAsUint(s2) != b2dAsUint(sinf(f)) || b2dAsUint(c2) != b2dAsUint(cosf(f))) ++bad;
 	}
 	return bad;
 }

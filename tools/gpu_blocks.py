@@ -41,5 +41,20 @@ for s in range(steps):
             ctr.large_island_contacts, ctr.cut_constraints, ctr.blocks, ctr.block_max_rows, ctr.partitions, ctr.block_solver_steps, ctr.colors,
             ctr.pos_iterations_large, stamps[8:14].tolist()), flush=True)
         t_acc = 0.0
+# partition / colouring dump for offline analysis
+ctr = b2hip.Counters(); L.b2hip_get_counters(dev, C.byref(ctr))
+nb = w.body_count
+act = np.zeros(nb, np.uint64); L.b2hip_debug_read(dev, 16, 0, nb, act.ctypes.data)
+blk = np.zeros(nb, np.int32); L.b2hip_debug_read(dev, 17, 0, nb, blk.ctypes.data)
+cc = np.zeros(65, np.int32); L.b2hip_debug_read(dev, 12, 0, 65, cc.ctypes.data)
+nrows = ctr.large_island_contacts
+ref = np.zeros((max(nrows, 1), 4), np.int32); L.b2hip_debug_read(dev, 18, 0, nrows, ref.ctypes.data)
+rcol = np.zeros(max(nrows, 1), np.int32); L.b2hip_debug_read(dev, 19, 0, nrows, rcol.ctypes.data)
+rstart = np.zeros(ctr.blocks + 1, np.int32); L.b2hip_debug_read(dev, 20, 0, ctr.blocks + 1, rstart.ctypes.data)
+cutdeg = np.array([bin(int(x)).count("1") for x in act])
+print("colour census", {i: int(c) for i, c in enumerate(cc) if c})
+print("cut degree histogram of the bodies", np.bincount(cutdeg).tolist())
+os.makedirs(os.path.join(ROOT, "gpurun_out", "blocks"), exist_ok=True)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", "blocks", "dump_%d.npz" % rows), bodies=w.bodies(), act=act, blk=blk, colorCount=cc, ref=ref, rowColor=rcol, rowStart=rstart)
 b = w.bodies()
 print("finite", bool(np.isfinite(b).all()), "min y", float(b[1:, 1].min()))
