@@ -142,6 +142,13 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	int bad = 0;
 	int uncolored = 0;
 	int maxColor = 0;
+	int orphanRows = 0, cutRows = 0;
+	uint32_t usedLo = 0u, usedHi = 0u;
+	__shared__ int s_blkRows[MAX_BLOCKS];
+	__shared__ int s_sums[2];
+	for (int i = threadIdx.x; i < MAX_BLOCKS; i += blockDim.x) s_blkRows[i] = 0;
+	if (threadIdx.x < 2) s_sums[threadIdx.x] = 0;
+	__syncthreads();
 	// (1) every touching contact that owns a colour - large island or not, asleep or not - reserves it on its bodies.
 	// A contact that stopped touching gives its colour back: reservations of idle neighbours (a pyramid box has two of
 	// them) would push new constraints to ever higher colours, and the depth of a sweep is the number of colours.
@@ -190,12 +197,13 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			const bool hubA = nsA && W.deg[ids.z] > HUB_DEGREE;
 			const bool hubB = nsB && W.deg[ids.w] > HUB_DEGREE;
 			{
-				// block census: the row belongs to the home block of its first non-static body
+				// block census: the row belongs to the home block of its first non-static body (counted in LDS: ten
+				// thousand rows adding to a few dozen words of memory serialise in L2)
 				const int blkA = nsA ? effBlk(W, ids.z) : 0, blkB = nsB ? effBlk(W, ids.w) : 0;
 				const int owner = nsA ? blkA : blkB;
-				if (owner > 0 && owner <= MAX_BLOCKS) atomicAdd(&W.blkRows[owner - 1], 1);
-				if ((nsA && blkA == 0) || (nsB && blkB == 0)) atomicAdd(&S->c.nOrphanRows, 1);
-				if (nsA && nsB && blkA != blkB) atomicAdd(&S->c.nCutRows, 1);
+				if (owner > 0 && owner <= MAX_BLOCKS) atomicAdd(&s_blkRows[owner - 1], 1);
+				if ((nsA && blkA == 0) || (nsB && blkB == 0)) ++orphanRows;
+				if (nsA && nsB && blkA != blkB) ++cutRows;
 			}
 			col = C.color[ci];
 			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			else if (col != HUB_COLOR)
 			{
 				if (col + 1 > maxColor) maxColor = col + 1;
-				noteColorUsed(S, col);
+				if (col < 32) usedLo |= 1u << col; else usedHi |= 1u << (col - 32);
 				if (col == S->c.compactClass && col > 0)
 				{
 					// candidates of this step's compaction class (k_color_small moves them down if a lower colour is free)
@@ -234,6 +242,32 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	if (bad) atomicOr(&S->c.needRecolor, 1);
 	if (uncolored) atomicAdd(&S->c.nUncolored, uncolored);
 	if (maxColor) atomicMax(&S->c.nColors, maxColor);
+	// wave-combined: one atomic per wave and word instead of one per row
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		usedLo |= (uint32_t)__shfl_xor((int)usedLo, off);
+		usedHi |= (uint32_t)__shfl_xor((int)usedHi, off);
+	}
+	orphanRows = waveSumInt(orphanRows);
+	cutRows = waveSumInt(cutRows);
+	if (waveLane() == 0)
+	{
+		if (usedLo) atomicOr(&S->c.colorMaskLo, usedLo);
+		if (usedHi) atomicOr(&S->c.colorMaskHi, usedHi);
+		if (orphanRows) atomicAdd(&s_sums[0], orphanRows);
+		if (cutRows) atomicAdd(&s_sums[1], cutRows);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < MAX_BLOCKS; i += blockDim.x)
+	{
+		const int v = s_blkRows[i];
+		if (v) atomicAdd(&W.blkRows[i], v);
+	}
+	if (threadIdx.x == 0)
+	{
+		if (s_sums[0]) atomicAdd(&S->c.nOrphanRows, s_sums[0]);
+		if (s_sums[1]) atomicAdd(&S->c.nCutRows, s_sums[1]);
+	}
 }
 
 __global__ __launch_bounds__(256) void k_color_claim(DW W)

@@ -131,6 +131,7 @@ struct Counters
 	int blkMaxBodies;    // most home bodies in one block this step
 	int nCutRows;        // cut constraints this step
 	int blkTargetDeg;    // degree budget per block the current partition was made with
+	int blkLanes;        // workgroup size (= rows / home bodies a block may hold) the current partition was made for
 	int partitionAge;    // steps since the current partition was made (persistent; kept here so that a snapshot carries it)
 	int partitionCooldown; // steps for which no new partition is attempted (the last attempts did not fit); persistent
 	uint32_t colorMaskLo, colorMaskHi; // colours that own at least one large-island constraint this step

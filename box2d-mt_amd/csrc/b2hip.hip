@@ -214,7 +214,7 @@ struct b2hip_world
 	DevArray<int> b_blk1, b_adopt, blkRows, blkRowStart, blkCursor, blkBodyStart, blkBodies, rowColor;
 	DevArray<float4> b_cutv;
 	int blocksMaxWG = 0;         // co-resident workgroups of k_solve_blocks on this device (0 = do not use it)
-	int blockLanes = BLOCK_LANES; // workgroup size of k_solve_blocks = rows / home bodies a block may hold (B2HIP_BLOCK_LANES=512: half-size blocks)
+	int blockLanes = 0;          // forced workgroup size of k_solve_blocks (B2HIP_BLOCK_LANES), 0 = chosen per partition
 	bool noBlocks = false;       // B2HIP_NO_BLOCKS=1: keep the large islands on k_solve_mailbox
 	int blockSteps = 0;          // steps solved by k_solve_blocks (diagnostics)
 
@@ -1191,12 +1191,17 @@ static int phaseSolve(b2hip_world* w)
 		(sp.warmStarting ? 1 : 0) + sp.velIters > 0 && w->blocksMaxWG > 0;
 	if (blockShape && c.partitionCooldown == 0)
 	{
-		const int lanes = w->blockLanes;
-		auto misfit = [lanes](const Counters& k) { return k.nBlocks == 0 || k.nOrphanRows > 0 || k.blkMaxRows > lanes || k.blkMaxBodies > lanes; };
-		bool need = misfit(c) || (4 * c.nCutRows > c.nLContacts && c.partitionAge > 240);
+		// Block size: one 1024-lane block while the large islands fit it (nothing ever goes through memory then), else
+		// 256-lane blocks (measured on the 10 011-box pyramid: 215 us against 235 / 245 us with 512 / 1024 lanes - the
+		// workgroup barriers of the interior colours are cheaper and the position solves spread over more CUs)
+		auto lanesFor = [w](const Counters& k) { return w->blockLanes ? w->blockLanes : (k.nLContacts <= 900 ? 1024 : 256); };
+		auto misfit = [](const Counters& k) { return k.nBlocks == 0 || k.nOrphanRows > 0 || k.blkMaxRows > k.blkLanes || k.blkMaxBodies > k.blkLanes; };
+		bool need = misfit(c) || (c.partitionAge > 240 && (4 * c.nCutRows > c.nLContacts || (c.blkLanes != lanesFor(c) && 2 * c.nLContacts < 900)));
+		int lanes = lanesFor(c);
 		int target = BLOCK_TARGET_DEG * lanes / BLOCK_LANES;
 		for (int attempt = 0; need && attempt < 3; ++attempt)
 		{
+			HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.blkLanes, &lanes, sizeof(int), hipMemcpyHostToDevice, w->stream));
 			rc = partitionLargeIslands(w, target);
 			if (rc) return rc;
 			rc = readState(w);
@@ -1282,7 +1287,7 @@ static int phaseSolve(b2hip_world* w)
 			persistMaxWG > 0 && persistWG <= persistMaxWG;
 		// the block solver (bodies in LDS, one workgroup per block of the partition): whenever the partition fits
 		const bool useBlocks = usePersistent && blockShape && !w->solverBarriers && !w->solverRows && !w->solverMailbox && c.nBlocks > 0 &&
-			c.nOrphanRows == 0 && c.blkMaxRows <= w->blockLanes && c.blkMaxBodies <= w->blockLanes && c.nBlocks <= w->blocksMaxWG &&
+			c.nOrphanRows == 0 && c.blkMaxRows <= c.blkLanes && c.blkMaxBodies <= c.blkLanes && c.nBlocks <= w->blocksMaxWG &&
 			(sp.velIters + 2) * (MAX_COLORS + 1) < 65536 && (sp.posIters + 1) * (MAX_COLORS + 1) < 65536;
 		d.blockSort = useBlocks ? 1 : 0;
 		bool colorsOnDevice = false;
@@ -1334,7 +1339,7 @@ static int phaseSolve(b2hip_world* w)
 			}
 			}
 		}
-		LAUNCH(w, k_color_scan, 1, 1, d);
+		if (!useBlocks) LAUNCH(w, k_color_scan, 1, 1, d); // (segments by colour: the block solver sorts its rows itself)
 		LAUNCH(w, k_color_fill, gC, 256, d);
 		if (hasHubs)
 		{
@@ -1362,9 +1367,10 @@ static int phaseSolve(b2hip_world* w)
 					HIP_TRY(hipMemsetAsync(w->b_posv.p, 0, w->b_posv.cap * sizeof(float4), w->stream));
 					HIP_TRY(hipMemsetAsync(w->dfInbox.p, 0, w->dfInbox.cap * sizeof(float4), w->stream));
 				}
-				if (w->blockLanes == 512) LAUNCH(w, k_solve_blocks<512>, c.nBlocks, 512, d, sp, w->gridBar.p, w->dfEpoch);
-				else if (w->blockLanes == 256) LAUNCH(w, k_solve_blocks<256>, c.nBlocks, 256, d, sp, w->gridBar.p, w->dfEpoch);
-				else LAUNCH(w, k_solve_blocks<BLOCK_LANES>, c.nBlocks, BLOCK_LANES, d, sp, w->gridBar.p, w->dfEpoch);
+				if (c.blkLanes == 512) LAUNCH(w, k_solve_blocks<512>, c.nBlocks, 512, d, sp, w->gridBar.p, w->dfEpoch);
+				else if (c.blkLanes == 256) LAUNCH(w, k_solve_blocks<256>, c.nBlocks, 256, d, sp, w->gridBar.p, w->dfEpoch);
+				else if (c.blkLanes == BLOCK_LANES) LAUNCH(w, k_solve_blocks<BLOCK_LANES>, c.nBlocks, BLOCK_LANES, d, sp, w->gridBar.p, w->dfEpoch);
+				else return setError(B2HIP_ERR_INVALID, "block partition made for an unknown workgroup size");
 				w->dfEpoch += 1;
 				w->blockSteps += 1;
 			}
@@ -1814,16 +1820,17 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverRows = getenv("B2HIP_SOLVER_ROWS") != nullptr; // polled body rows (k_solve_dataflow) instead of pushed mailboxes
 	w->solverMailbox = getenv("B2HIP_SOLVER_MAILBOX") != nullptr; // pushed hand-offs for every constraint (k_solve_mailbox) instead of k_solve_blocks
 	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
-	w->blockLanes = BLOCK_LANES;
-	if (const char* e = getenv("B2HIP_BLOCK_LANES")) w->blockLanes = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : BLOCK_LANES);
+	w->blockLanes = 0; // chosen per partition (see phaseSolve); B2HIP_BLOCK_LANES = 256 | 512 | 1024 forces one size
+	if (const char* e = getenv("B2HIP_BLOCK_LANES")) w->blockLanes = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0));
 	{
-		int perCU = 0;
+		int perCU = 0, perCU2 = 0, perCU3 = 0;
 		hipDeviceProp_t prop;
 		int devId = 0;
 		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess &&
-			(w->blockLanes == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<256>, 256, 0)
-			 : w->blockLanes == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<512>, 512, 0)
-			                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<BLOCK_LANES>, BLOCK_LANES, 0)) == hipSuccess && perCU > 0)
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_blocks<256>, 256, 0) == hipSuccess &&
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU2, k_solve_blocks<512>, 512, 0) == hipSuccess &&
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU3, k_solve_blocks<BLOCK_LANES>, BLOCK_LANES, 0) == hipSuccess &&
+			perCU > 0 && perCU2 > 0 && perCU3 > 0)
 		{
 			// one block per CU is all this sizing relies on (the occupancy query can be one too high, MI355X_MICROARCH.md)
 			w->blocksMaxWG = prop.multiProcessorCount - 8;
