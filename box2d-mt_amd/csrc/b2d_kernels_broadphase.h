@@ -160,7 +160,8 @@ __device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q
 	if (htContains(W, key + 1ull)) return;
 	// bodyB->ShouldCollide(bodyA) with A = lower proxy id
 	if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
-	if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
+	// (a user contact filter replaces the built-in rule: it is asked on the host for every pair that gets this far)
+	if (!W.userFilter && !filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
 	if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return;
 	int k = atomicAdd(&S->c.nPairs, 1);
 	if (k < W.capPairs)

@@ -95,8 +95,11 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 
 		if (flags & CF_FILTER)
 		{
+			// (with a user contact filter the host has asked it already: k_filter_list / CF_USER_REJECT)
 			bool ok = bodiesShouldCollide(W, bodyB, bodyA) &&
-				filterShouldCollide(W.p_filter0[proxyA], W.p_filter1[proxyA], W.p_filter0[proxyB], W.p_filter1[proxyB]);
+				(W.userFilter ? (flags & CF_USER_REJECT) == 0
+				              : filterShouldCollide(W.p_filter0[proxyA], W.p_filter1[proxyA], W.p_filter0[proxyB], W.p_filter1[proxyB]));
+			flags &= ~CF_USER_REJECT;
 			if (!ok)
 			{
 				keep = 0;
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 			}
 		}
 
+		flags &= ~(CF_PRESOLVE | CF_VC_ONE_POINT);
 		bool active = bodyActiveForContact(bfA) || bodyActiveForContact(bfB);
 		if (keep && active)
 		{
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 				bool wasTouching = (flags & CF_TOUCHING) != 0;
 				bool touching = false;
 				bool sensor = (flags & CF_SENSOR) != 0;
+				float4 o0s = make_float4(0, 0, 0, 0), o1s = o0s; // the old manifold's vectors, for PreSolve
 				Manifold mf;
 				mf.pointCount = 0;
 				mf.type = m3.z;
@@ -152,6 +157,8 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 					const ShapeRec* sB = W.shapes + W.p_shape[proxyB];
 					// stale fields survive an early-out exactly like the reference's persistent manifold
 					float4 o0 = C.man0[i], o1 = C.man1[i];
+					o0s = o0;
+					o1s = o1;
 					mf.localNormal = v2(o0.x, o0.y);
 					mf.localPoint = v2(o0.z, o0.w);
 					mf.p[0] = v2(o1.x, o1.y);
@@ -188,6 +195,15 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 					C.man0[i] = make_float4(mf.localNormal.x, mf.localNormal.y, mf.localPoint.x, mf.localPoint.y);
 					C.man1[i] = make_float4(mf.p[0].x, mf.p[0].y, mf.p[1].x, mf.p[1].y);
 					C.imp[i] = make_float4(ni[0], ti[0], ni[1], ti[1]);
+				}
+				if (W.preSolveOn && !sensor && touching)
+				{
+					// what PreSolve is handed as the old manifold (the new one has just overwritten it above)
+					W.pre_o0[i] = o0s;
+					W.pre_o1[i] = o1s;
+					W.pre_oimp[i] = oldImp;
+					W.pre_o3[i] = m3;
+					flags |= CF_PRESOLVE;
 				}
 				C.man3[i] = make_int4((int)mf.id[0], (int)mf.id[1], mf.type, mf.pointCount);
 				if (touching) flags |= CF_TOUCHING; else flags &= ~CF_TOUCHING;
@@ -256,6 +272,99 @@ __global__ __launch_bounds__(256) void k_contact_events(DW W)
 	}
 }
 
+// b2ContactListener::PreSolve records (b2Contact.cpp:283-297): between the scan of the keep flags and the compaction, so
+// that the old manifolds saved by k_collide are still addressed by the contact's old index; the record carries the index
+// the contact has after the compaction.
+__global__ __launch_bounds__(256) void k_presolve_gather(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const bool compacting = S->c.nDestroy != 0;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		if (!W.keepFlag[i] || (C.flags[i] & CF_PRESOLVE) == 0) continue;
+		const int e = atomicAdd(&S->c.nPreSolve, 1);
+		if (e >= W.capContacts) continue;
+		const int4 ids = C.ids[i];
+		PreSolveRec r;
+		r.info = make_int4(compacting ? W.keepScan[i] : i, ids.x, ids.y, 0);
+		r.key = C.key[i];
+		r.pad = 0ull;
+		r.o0 = W.pre_o0[i]; r.o1 = W.pre_o1[i]; r.oimp = W.pre_oimp[i]; r.o3 = W.pre_o3[i];
+		r.n0 = C.man0[i]; r.n1 = C.man1[i]; r.nimp = C.imp[i]; r.n3 = C.man3[i];
+		W.preRecs[e] = r;
+	}
+}
+
+// b2Contact::SetEnabled(false) from PreSolve: the listed contacts sit out this step (the next Collide enables them again)
+__global__ __launch_bounds__(256) void k_presolve_disable(DW W, const int* list, int count)
+{
+	const ContactArrays& C = W.ca[W.st->cur];
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+	{
+		const int j = list[k];
+		if (j >= 0 && j < W.st->c.nContacts) C.flags[j] &= ~CF_ENABLED;
+	}
+}
+
+// b2ContactListener::PostSolve records (b2Island::Report, b2Island.cpp:532-570): every contact constraint of the islands
+// solved in this step = solid contacts with a non-static body that was in a solved island.
+__global__ __launch_bounds__(256) void k_postsolve_gather(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		const uint32_t flags = C.flags[i];
+		if ((flags & (CF_ENABLED | CF_TOUCHING | CF_SENSOR | CF_DESTROY)) != (CF_ENABLED | CF_TOUCHING)) continue;
+		const int4 ids = C.ids[i];
+		const uint32_t fA = W.b_flags[ids.z], fB = W.b_flags[ids.w];
+		const bool inIsland = ((fA & BF_TYPE_MASK) != BT_STATIC && (fA & BF_ISLAND)) || ((fB & BF_TYPE_MASK) != BT_STATIC && (fB & BF_ISLAND));
+		if (!inIsland) continue;
+		const int e = atomicAdd(&S->c.nPostSolve, 1);
+		if (e >= W.capContacts) continue;
+		PostSolveRec r;
+		const int pc = C.man3[i].w;
+		r.info = make_int4(i, ids.x, ids.y, (flags & CF_VC_ONE_POINT) != 0 && pc > 1 ? 1 : pc);
+		r.key = C.key[i];
+		r.pad = 0ull;
+		r.imp = C.imp[i];
+		W.postRecs[e] = r;
+	}
+}
+
+// Contacts flagged for re-filtering, listed for the user's contact filter (asked on the host before Collide)
+__global__ __launch_bounds__(256) void k_filter_list(DW W)
+{
+	DState* S = W.st;
+	const int n = S->c.nContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		if ((C.flags[i] & CF_FILTER) == 0) continue;
+		const int e = atomicAdd(&S->c.nFilterList, 1);
+		if (e < W.capContacts) W.filterList[e] = i;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_filter_reject(DW W, const int* list, int count)
+{
+	const ContactArrays& C = W.ca[W.st->cur];
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+	{
+		const int j = list[k];
+		if (j >= 0 && j < W.st->c.nContacts) C.flags[j] |= CF_USER_REJECT;
+	}
+}
+
+// Candidate pairs the user's contact filter refused: they are no first occurrences any more (nothing is created for them)
+__global__ __launch_bounds__(256) void k_pairs_reject(DW W, const int* list, int count)
+{
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) W.pairFirst[list[k]] = 0;
+}
+
 // Per-step counters back to zero (one launch instead of a handful of memsets); `bar` = the resident solver's grid barrier.
 __global__ void k_step_begin(DW W, int* bar)
 {
@@ -278,6 +387,9 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.toiUnsafe = 0;
 		c.nToiGroups = 0;
 		c.nToiMoved = 0;
+		c.nPreSolve = 0;
+		c.nPostSolve = 0;
+		c.nFilterList = 0;
 	}
 	if (t < 32) bar[t] = 0;
 }

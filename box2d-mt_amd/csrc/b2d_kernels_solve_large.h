@@ -915,6 +915,11 @@ __global__ __launch_bounds__(256) void k_large_store_impulses(DW W)
 		memset(&cc, 0, sizeof(cc));
 		lcLoad(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
 		lcLoad(W, row, cc, 35, 36);
+		if (W.postSolveOn)
+		{
+			lcLoad(W, row, cc, LC_WORDS - 1, LC_WORDS); // pcPointCount: the manifold's own count
+			if (cc.pointCount < cc.pcPointCount) C.flags[ci] |= CF_VC_ONE_POINT;
+		}
 		float4 im = C.imp[ci];
 		if (cc.pointCount > 0) { im.x = cc.normalImpulse[0]; im.y = cc.tangentImpulse[0]; }
 		if (cc.pointCount > 1) { im.z = cc.normalImpulse[1]; im.w = cc.tangentImpulse[1]; }

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_persistent(DW W, StepPa
 		if (cc.pointCount > 0) { im.x = cc.normalImpulse[0]; im.y = cc.tangentImpulse[0]; }
 		if (cc.pointCount > 1) { im.z = cc.normalImpulse[1]; im.w = cc.tangentImpulse[1]; }
 		C.imp[r.ci] = im;
+		if (W.postSolveOn && cc.pointCount < cc.pcPointCount) C.flags[r.ci] |= CF_VC_ONE_POINT; // PostSolve reports the solver's point count
 	}
 
 	// ---- integrate positions (b2Island.cpp:283-313) ---------------------------------------------------------------------------

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 		if (cc.pointCount > 0) { im.x = cc.normalImpulse[0]; im.y = cc.tangentImpulse[0]; }
 		if (cc.pointCount > 1) { im.z = cc.normalImpulse[1]; im.w = cc.tangentImpulse[1]; }
 		C.imp[ci] = im;
+		if (W.postSolveOn && cc.pointCount < cc.pcPointCount) C.flags[ci] |= CF_VC_ONE_POINT; // PostSolve reports the solver's point count
 	}
 
 	// ---- integrate positions (b2Island.cpp:283-313) ---------------------------------------------------

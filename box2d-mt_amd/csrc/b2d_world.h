@@ -40,6 +40,9 @@
 #define CF_TOI_LISTED 0x100u   // already in DW::toiList
 #define CF_TOI_PENDING 0x200u  // claimed for recomputation by the running TOI pass
 #define CF_REPORTED 0x400u     // contact events on: the host has been told that this contact touches (k_contact_events)
+#define CF_PRESOLVE 0x800u      // updated by this step's Collide, touching, not a sensor: b2ContactListener::PreSolve is due (b2Contact.cpp:283)
+#define CF_VC_ONE_POINT 0x10000u // the solver's conditioning guard dropped the second manifold point this step (b2ContactSolver.cpp:230-247)
+#define CF_USER_REJECT 0x20000u  // the user's contact filter refused this contact at its re-filtering (b2ContactManager.cpp:195-203)
 #define CF_TOI_COUNT_SHIFT 12  // bits 12..15: m_toiCount (0..9)
 #define CF_TOI_COUNT_MASK 0xf000u
 #define CF_TOI_STATE_MASK (CF_TOI | CF_TOI_LISTED | CF_TOI_PENDING | CF_TOI_COUNT_MASK)
@@ -135,6 +138,29 @@ struct Counters
 	int partitionAge;    // steps since the current partition was made (persistent; kept here so that a snapshot carries it)
 	int partitionCooldown; // steps for which no new partition is attempted (the last attempts did not fit); persistent
 	uint32_t colorMaskLo, colorMaskHi; // colours that own at least one large-island constraint this step
+	int nPreSolve;       // PreSolve records of this step's Collide (DW::preRecs)
+	int nPostSolve;      // PostSolve records of this step's Solve (DW::postRecs)
+	int nFilterList;     // contacts flagged for re-filtering, listed for the user's contact filter (DW::filterList)
+};
+
+// What b2ContactListener::PreSolve is told about one contact (gathered after Collide, before the compaction of destroyed
+// contacts: `info.x` is the contact's index AFTER it), and what PostSolve is told.
+struct PreSolveRec
+{
+	int4 info;               // contact index, proxy A, proxy B, -
+	unsigned long long key;  // proxy-id pair: the reference's deferred-callback order
+	unsigned long long pad;
+	float4 o0, o1, oimp;     // old manifold (as ContactArrays::man0 / man1 / imp)
+	int4 o3;
+	float4 n0, n1, nimp;     // new manifold
+	int4 n3;
+};
+struct PostSolveRec
+{
+	int4 info;               // contact index, proxy A, proxy B, solver point count
+	unsigned long long key;
+	unsigned long long pad;
+	float4 imp;              // normalImpulse0, tangentImpulse0, normalImpulse1, tangentImpulse1
 };
 
 struct DState
@@ -265,6 +291,16 @@ struct DW
 	int* rowColor;       // per block-sorted row: its colour
 	float4* b_cutv;      // per body: (v.xy, w, tag) exchange row of the cut constraints, velocity phase (positions: b_posv)
 	int blockSort;       // k_color_fill groups the rows by owner block (k_solve_blocks) instead of by colour
+	// listener / filter bridge (include/b2hip.h: b2hip_set_contact_filter, b2hip_set_pre_solve, b2hip_enable_post_solve)
+	int userFilter;      // a user contact filter is installed: the built-in category / mask / group rule is not applied
+	int preSolveOn, postSolveOn;
+	float4* pre_o0;      // per contact: the manifold before this step's Collide (valid where CF_PRESOLVE is set)
+	float4* pre_o1;
+	float4* pre_oimp;
+	int4* pre_o3;
+	PreSolveRec* preRecs;
+	PostSolveRec* postRecs;
+	int* filterList;     // contact indices flagged CF_FILTER (listed for the user's filter before Collide)
 
 	// ---- broad-phase ------------------------------------------------------------------------
 	int* moveBuf;        // proxy indices whose fat AABB changed / were created

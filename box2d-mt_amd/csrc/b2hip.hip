@@ -210,6 +210,19 @@ struct b2hip_world
 	int persistSteps;            // steps solved by the persistent kernel (diagnostics)
 	DevArray<int> consts; // [0] nBodies, [1] gridSize, [2] radix hist count, [3] sorted-pair count
 	DevArray<unsigned long long> filterPairs; // sorted body-pair keys of the joints created / destroyed since the last step
+	// listener / filter bridge: user callbacks in the middle of a step (include/b2hip.h)
+	b2hip_should_collide_fn filterFn = nullptr;
+	void* filterUser = nullptr;
+	bool refilterPending = false;   // some contact may carry CF_FILTER (joint created / destroyed, fixture re-filtered)
+	b2hip_pre_solve_fn preSolveFn = nullptr;
+	void* preSolveUser = nullptr;
+	bool postSolveOn = false;
+	std::vector<b2hip_contact_impulse> postSolve; // of the last step, in delivery order
+	DevArray<float4> pre_o0, pre_o1, pre_oimp;
+	DevArray<int4> pre_o3;
+	DevArray<PreSolveRec> preRecs;
+	DevArray<PostSolveRec> postRecs;
+	DevArray<int> filterList, hostList; // hostList: indices uploaded by the host (contacts to disable / reject, pairs to drop)
 	// block partition of the large islands (b2d_kernels_solve_blocks.h)
 	DevArray<int> b_blk1, b_adopt, blkRows, blkRowStart, blkCursor, blkBodyStart, blkBodies, rowColor;
 	DevArray<float4> b_cutv;
@@ -644,6 +657,13 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
 	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
+	{
+		// listener bridge buffers: contact-sized only while the callback that needs them is installed
+		const size_t nPre = w->preSolveFn ? cc : 1, nPost = w->postSolveOn ? cc : 1, nFil = w->filterFn ? cc : 1;
+		ENS(pre_o0, nPre); ENS(pre_o1, nPre); ENS(pre_oimp, nPre); ENS(pre_o3, nPre); ENS(preRecs, nPre);
+		ENS(postRecs, nPost); ENS(filterList, nFil);
+		ENS(hostList, std::max<size_t>(std::max(nPre, nFil), w->filterFn ? capPairs : 1));
+	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
 	ENS(stateOut, 12 * nb);
@@ -665,8 +685,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.nShapes = (int)w->shapes.size();
 	d.bigChunks = getenv("B2HIP_BIG_CHUNKS") != nullptr ? 1 : 0;
 	// Exact order costs ~1 us per DEPENDENT constraint (a GPU lane against a CPU core on a chain): a 210-box pyramid is
-	// ~300 levels x 12 sweeps = 4.8 ms in k_solve_small, 0.5 ms through the coloured solver. The default keeps islands up
-	// to 512 bit-exact; B2HIP_SMALL_MAX_W=128 trades that for latency on mid-size stacks.
+	// ~300 levels x 12 sweeps = 3.9 ms in k_solve_small, ~0.1 ms as one block of k_solve_blocks. Islands up to 128 (bodies
+	// or contacts) are walked in the reference's order, bit-exact; B2HIP_SMALL_MAX_W (<= 512) moves the line.
 	d.smallMaxW = SMALL_ISLAND_MAX_W;
 	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
 	d.capContacts = (int)cc;
@@ -712,6 +732,9 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p;
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
+	d.userFilter = w->filterFn ? 1 : 0; d.preSolveOn = w->preSolveFn ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
+	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
+	d.preRecs = w->preRecs.p; d.postRecs = w->postRecs.p; d.filterList = w->filterList.p;
 	return 0;
 }
 
@@ -963,6 +986,7 @@ static int applyPendingFilters(b2hip_world* w)
 	LAUNCH(w, k_flag_filter, gridFor(w->dw.capContacts), 256, w->dw, w->filterPairs.p, (int)keys.size());
 	HIP_TRY(hipStreamSynchronize(w->stream)); // `keys` is pageable host memory
 	w->pendingFilter.clear();
+	w->refilterPending = true;
 	return 0;
 }
 
@@ -974,6 +998,38 @@ static int radixBits(int maxKey)
 	int bits = 1;
 	while ((1 << bits) <= maxKey && bits < 31) ++bits;
 	return bits;
+}
+
+// Uploads `list` and runs `kernel(d, list, count)` (contacts to disable / reject, candidate pairs to drop)
+template <typename K>
+static int applyHostList(b2hip_world* w, K kernel, const std::vector<int>& list)
+{
+	if (list.empty()) return 0;
+	HIP_TRY(hipMemcpyAsync(w->hostList.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, w->stream));
+	LAUNCH(w, kernel, gridFor(list.size()), 256, w->dw, (const int*)w->hostList.p, (int)list.size());
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	return 0;
+}
+
+// b2ContactManager::AddPair's user filter (b2ContactManager.cpp:283-287): the first occurrence of every candidate pair is
+// shown to the user's b2hip_should_collide_fn (lower proxy id first, as AddPair passes them); refused pairs stop being
+// first occurrences, so nothing is created for them. Between the "first" flags and the ranks of either ordering path.
+static int userFilterPairs(b2hip_world* w, const int2* proxies)
+{
+	int rc = readState(w);
+	if (rc) return rc;
+	const int n = std::min(w->h_dstate->c.nPairs, w->dw.capPairs);
+	if (n <= 0 || (w->h_dstate->c.overflow & 3)) return 0;
+	std::vector<int> first(n);
+	std::vector<int2> pr(n);
+	HIP_TRY(hipMemcpy(first.data(), w->pairFirst.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(pr.data(), proxies, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+	std::vector<int> refused;
+	for (int i = 0; i < n; ++i)
+	{
+		if (first[i] && !w->filterFn(w->filterUser, pr[i].x, pr[i].y)) refused.push_back(i);
+	}
+	return applyHostList(w, k_pairs_reject, refused);
 }
 
 // b2World::FindNewContacts. `sync` = the host may block on the pair count to pick the sort path
@@ -1008,12 +1064,14 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		sortedKeys = kin;
 		sortedProxies = vin;
 		LAUNCH(w, k_pairs_sorted_first, gridFor(d.capPairs), 256, d, sortedKeys, w->consts.p + 3);
+		if (w->filterFn) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
 		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->consts.p + 3, d.capPairs);
 		LAUNCH(w, k_pairs_sorted_total, 1, 1, d, w->consts.p + 3);
 	}
 	else
 	{
 		LAUNCH(w, k_pairs_first, 16, 256, d);
+		if (w->filterFn) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
 		LAUNCH(w, k_pairs_rank, 16, 256, d);
 	}
 	const int smallPath = largePath ? 0 : 1;
@@ -1028,6 +1086,8 @@ static int findNewContacts(b2hip_world* w, bool sync);
 static int findNewContactsOnce(b2hip_world* w, bool sync);
 static int findNewContactsGraph(b2hip_world* w)
 {
+	// (a user contact filter is asked on the host in the middle of the update: synchronous, no graph)
+	if (w->filterFn) return findNewContacts(w, true);
 	return runSegment(w, w->segPairs, 3, [w]() -> int { return findNewContacts(w, false); });
 }
 
@@ -1083,12 +1143,13 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 
 static int phaseCollide(b2hip_world* w)
 {
-	return runSegment(w, w->segCollide, 1, [w]() -> int
+	return runSegment(w, w->segCollide, 1 + (w->dw.preSolveOn ? 32 : 0), [w]() -> int
 	{
 		DW& d = w->dw;
 		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_toi_order_destroy, 1, 256, d);
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_finish, 1, 1, d);
 		return 0;
@@ -1905,6 +1966,8 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
 	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
 	w->filterPairs.release();
+	w->pre_o0.release(); w->pre_o1.release(); w->pre_oimp.release(); w->pre_o3.release(); w->preRecs.release();
+	w->postRecs.release(); w->filterList.release(); w->hostList.release();
 	w->b_blk1.release(); w->b_adopt.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release();
 	w->blkBodyStart.release(); w->blkBodies.release(); w->rowColor.release(); w->b_cutv.release();
 	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
@@ -2495,10 +2558,78 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 	return stepFailed(w, stepBeginImpl(w, dt, velocity_iterations, position_iterations));
 }
 
+static bool keyLess(const std::pair<unsigned long long, int>& a, const std::pair<unsigned long long, int>& b) { return a < b; }
+
+static void toManifold(b2hip_manifold* m, float4 m0, float4 m1, float4 imp, int4 m3)
+{
+	m->type = m3.z;
+	m->point_count = m3.w;
+	m->local_normal[0] = m0.x; m->local_normal[1] = m0.y;
+	m->local_point[0] = m0.z; m->local_point[1] = m0.w;
+	m->point_local[0][0] = m1.x; m->point_local[0][1] = m1.y;
+	m->point_local[1][0] = m1.z; m->point_local[1][1] = m1.w;
+	m->normal_impulse[0] = imp.x; m->tangent_impulse[0] = imp.y;
+	m->normal_impulse[1] = imp.z; m->tangent_impulse[1] = imp.w;
+	m->id_key[0] = (uint32_t)m3.x;
+	m->id_key[1] = (uint32_t)m3.y;
+}
+
 static int collideImpl(b2hip_world* w)
 {
-	int rc = phaseCollide(w);
+	int rc = 0;
+	if (w->filterFn && w->refilterPending)
+	{
+		// b2ContactManager::Collide's re-filter (:195-203) with a user filter: the flagged contacts are shown to it first
+		LAUNCH(w, k_filter_list, gridFor(w->dw.capContacts), 256, w->dw);
+		rc = readState(w);
+		if (rc) return rc;
+		const int n = std::min(w->h_dstate->c.nFilterList, w->dw.capContacts);
+		if (n > 0)
+		{
+			std::vector<int> list(n), refused;
+			HIP_TRY(hipMemcpy(list.data(), w->filterList.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+			std::sort(list.begin(), list.end());
+			const int cur = w->h_dstate->cur;
+			for (int k = 0; k < n; ++k)
+			{
+				int4 ids;
+				HIP_TRY(hipMemcpy(&ids, w->c_ids[cur].p + list[k], sizeof(int4), hipMemcpyDeviceToHost));
+				if (!w->filterFn(w->filterUser, ids.x, ids.y)) refused.push_back(list[k]);
+			}
+			rc = applyHostList(w, k_filter_reject, refused);
+			if (rc) return rc;
+		}
+	}
+	w->refilterPending = false;
+	rc = phaseCollide(w);
 	if (rc) return rc;
+	if (w->preSolveFn)
+	{
+		// b2ContactListener::PreSolve: one record per touching, non-sensor contact this Collide updated; delivered in
+		// proxy-id-pair order (b2ContactManager.cpp:431-434); a zero return disables the contact for this step
+		rc = readState(w);
+		if (rc) return rc;
+		const int n = std::min(w->h_dstate->c.nPreSolve, w->dw.capContacts);
+		if (n > 0)
+		{
+			std::vector<PreSolveRec> recs(n);
+			HIP_TRY(hipMemcpy((void*)recs.data(), w->preRecs.p, (size_t)n * sizeof(PreSolveRec), hipMemcpyDeviceToHost));
+			std::vector<std::pair<unsigned long long, int> > order(n);
+			for (int i = 0; i < n; ++i) order[i] = std::make_pair(recs[i].key, i);
+			std::sort(order.begin(), order.end(), keyLess);
+			std::vector<int> disabled;
+			for (int k = 0; k < n; ++k)
+			{
+				const PreSolveRec& r = recs[order[k].second];
+				b2hip_manifold oldM, newM;
+				toManifold(&oldM, r.o0, r.o1, r.oimp, r.o3);
+				toManifold(&newM, r.n0, r.n1, r.nimp, r.n3);
+				if (!w->preSolveFn(w->preSolveUser, r.info.x, r.info.y, r.info.z, &oldM, &newM)) disabled.push_back(r.info.x);
+			}
+			rc = applyHostList(w, k_presolve_disable, disabled);
+			if (rc) return rc;
+		}
+	}
 	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[2], w->stream));
 	return 0;
 }
@@ -2522,6 +2653,7 @@ static int solveImpl(b2hip_world* w)
 	{
 		for (int k = 4; k <= 8 && w->profileDetail; ++k) HIP_TRY(hipEventRecord(w->ev[k], w->stream));
 	}
+	if (w->postSolveOn && w->sp.dt > 0.0f) LAUNCH(w, k_postsolve_gather, gridFor(w->dw.capContacts), 256, w->dw);
 	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[3], w->stream));
 	return 0;
 }
@@ -2693,6 +2825,31 @@ static int stepEndImpl(b2hip_world* w)
 		}
 		rc = downloadState(w);
 		if (rc) return rc;
+	}
+	w->postSolve.clear();
+	if (w->postSolveOn)
+	{
+		const int n = std::min(w->h_dstate->c.nPostSolve, w->dw.capContacts);
+		if (n > 0)
+		{
+			std::vector<PostSolveRec> recs(n);
+			HIP_TRY(hipMemcpy((void*)recs.data(), w->postRecs.p, (size_t)n * sizeof(PostSolveRec), hipMemcpyDeviceToHost));
+			std::vector<std::pair<unsigned long long, int> > order(n);
+			for (int i = 0; i < n; ++i) order[i] = std::make_pair(recs[i].key, i);
+			std::sort(order.begin(), order.end(), keyLess); // b2DeferredPostSolveLessThan: proxy-id pair
+			w->postSolve.resize(n);
+			for (int k = 0; k < n; ++k)
+			{
+				const PostSolveRec& r = recs[order[k].second];
+				b2hip_contact_impulse& o = w->postSolve[k];
+				o.contact_index = r.info.x;
+				o.fixture_a = r.info.y;
+				o.fixture_b = r.info.z;
+				o.count = r.info.w;
+				o.normal_impulses[0] = r.imp.x; o.tangent_impulses[0] = r.imp.y;
+				o.normal_impulses[1] = r.imp.z; o.tangent_impulses[1] = r.imp.w;
+			}
+		}
 	}
 	w->events.clear();
 	if (w->eventsOn)
@@ -3020,7 +3177,8 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	// no count can exceed what the blob could hold at all (this also keeps the size products below from overflowing)
 	if (nb > size || np > size || nC > size || nS > size || nJ > size || h.nFree > size || nT > size || nM > size || h.stateCount > size)
 		return corrupt("counts exceed the blob");
-	if (h.stateCount > nb || h.cur > 1u || nT > nC) return corrupt("header counts");
+	if (h.stateCount > nb || h.cur > 1u || nT > nC || h.lastContacts < 0 || (size_t)h.lastContacts > nC) return corrupt("header counts");
+	if (h.nextNode < 0 || h.leafCount < 0 || (size_t)h.leafCount > np || (size_t)h.nextNode > 2 * np + 2) return corrupt("proxy id allocator");
 	if (!(h.cellSize > 0.0f) || !std::isfinite(h.cellSize)) return corrupt("cell size");
 
 	// ---- host sections -------------------------------------------------------------------------------------------------
@@ -3221,6 +3379,52 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 		c.friction = mat[i].x;
 		c.restitution = mat[i].y;
 	}
+	return n;
+}
+
+int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* user)
+{
+	if (int rcu = checkUsable(w, "b2hip_set_contact_filter", true)) return rcu;
+	w->filterFn = fn;
+	w->filterUser = user;
+	w->dw.userFilter = fn ? 1 : 0;
+	return B2HIP_OK;
+}
+
+int b2hip_default_should_collide(b2hip_world* w, int fixture_a, int fixture_b)
+{
+	if (!w || fixture_a < 0 || fixture_b < 0 || fixture_a >= (int)w->fixtures.size() || fixture_b >= (int)w->fixtures.size())
+		return setError(B2HIP_ERR_INVALID, "bad fixture id");
+	// b2ContactFilter::ShouldCollide (b2WorldCallbacks.cpp:24-38)
+	const HostFixture& a = w->fixtures[fixture_a];
+	const HostFixture& b = w->fixtures[fixture_b];
+	if (a.groupIndex == b.groupIndex && a.groupIndex != 0) return a.groupIndex > 0 ? 1 : 0;
+	return ((a.maskBits & b.categoryBits) != 0 && (a.categoryBits & b.maskBits) != 0) ? 1 : 0;
+}
+
+int b2hip_set_pre_solve(b2hip_world* w, b2hip_pre_solve_fn fn, void* user)
+{
+	if (int rcu = checkUsable(w, "b2hip_set_pre_solve", true)) return rcu;
+	w->preSolveFn = fn;
+	w->preSolveUser = user;
+	w->dw.preSolveOn = fn ? 1 : 0;
+	return B2HIP_OK;
+}
+
+int b2hip_enable_post_solve(b2hip_world* w, int enable)
+{
+	if (int rcu = checkUsable(w, "b2hip_enable_post_solve", true)) return rcu;
+	w->postSolveOn = enable != 0;
+	w->dw.postSolveOn = enable ? 1 : 0;
+	w->postSolve.clear();
+	return B2HIP_OK;
+}
+
+int b2hip_get_post_solve(b2hip_world* w, int cap, b2hip_contact_impulse* out)
+{
+	if (!w || (cap > 0 && !out)) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int n = (int)w->postSolve.size();
+	for (int i = 0; i < n && i < cap; ++i) out[i] = w->postSolve[i];
 	return n;
 }
 

@@ -30,6 +30,9 @@ public:
 	void GetWorldManifold(b2WorldManifold* worldManifold) const;
 	bool IsTouching() const { return m_touching; }
 	bool IsEnabled() const { return m_enabled; }
+	/// Inside b2ContactListener::PreSolve: false leaves the contact out of this step's islands (b2Contact.h:117-123);
+	/// the next Collide enables it again. Anywhere else the call has no effect (the view is a copy).
+	void SetEnabled(bool flag) { m_enabled = flag; }
 	b2Contact* GetNext() { return m_next; }
 	const b2Contact* GetNext() const { return m_next; }
 	b2Fixture* GetFixtureA() { return m_fixtureA; }

@@ -34,9 +34,12 @@ public:
 	~b2World();
 
 	void SetDestructionListener(b2DestructionListener* listener) { m_destructionListener = listener; }
-	void SetContactFilter(b2ContactFilter* filter) { m_contactFilter = filter; }
+	/// A user filter replaces the built-in category / mask / group rule (b2World.h:69-72): it is asked on the stepping
+	/// thread for every new candidate pair and every contact flagged for re-filtering (b2ContactManager.cpp:283-287, 195-203).
+	void SetContactFilter(b2ContactFilter* filter);
 	/// BeginContact / EndContact are delivered at the end of Step() (one net event per contact and step, begins before
-	/// ends, each in proxy-id order); PreSolve / PostSolve are not bridged yet.
+	/// ends, each in proxy-id order); PreSolve between Collide and the island solve (SetEnabled(false) is honoured);
+	/// PostSolve at the end of Step() with the solver's final impulses. All on the stepping thread, threadId 0.
 	void SetContactListener(b2ContactListener* listener);
 
 	b2Body* CreateBody(const b2BodyDef* def);
@@ -92,6 +95,10 @@ private:
 	friend class b2Fixture;
 	friend class b2Contact;
 	void DeliverContactEvents();
+	void DeliverPostSolve();
+	static int FilterTrampoline(void* user, int fixtureA, int fixtureB);
+	static int PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int fixtureB, const struct b2hip_manifold* oldManifold,
+		const struct b2hip_manifold* manifold);
 	const std::vector<b2AABB>& FatAABBs();
 
 	void PushFlags();

@@ -408,7 +408,9 @@ void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIteration
 	m_statesValid = false;
 	m_contactsValid = false;
 	m_fatValid = false;
+	// the reference's order within a step: begin / end (Collide), [PreSolve: called by the step itself], PostSolve (Solve)
 	DeliverContactEvents();
+	DeliverPostSolve();
 	float ms[13];
 	if (b2hip_get_profile(m_hip, ms) == B2HIP_OK)
 	{
@@ -431,7 +433,89 @@ void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIteration
 void b2World::SetContactListener(b2ContactListener* listener)
 {
 	m_contactListener = listener;
-	if (m_hip) (void)b2hip_enable_contact_events(m_hip, listener != nullptr ? 1 : 0);
+	if (!m_hip) return;
+	(void)b2hip_enable_contact_events(m_hip, listener != nullptr ? 1 : 0);
+	(void)b2hip_set_pre_solve(m_hip, listener != nullptr ? &b2World::PreSolveTrampoline : nullptr, this);
+	(void)b2hip_enable_post_solve(m_hip, listener != nullptr ? 1 : 0);
+}
+
+void b2World::SetContactFilter(b2ContactFilter* filter)
+{
+	m_contactFilter = filter;
+	if (m_hip) (void)b2hip_set_contact_filter(m_hip, filter != nullptr ? &b2World::FilterTrampoline : nullptr, this);
+}
+
+// b2ContactManager::AddPair / Collide -> m_contactFilter->ShouldCollide (b2ContactManager.cpp:283-287, 195-203)
+int b2World::FilterTrampoline(void* user, int fixtureA, int fixtureB)
+{
+	b2World* self = static_cast<b2World*>(user);
+	if (!self->m_contactFilter) return 1;
+	return self->m_contactFilter->ShouldCollide(self->m_fixtures[fixtureA], self->m_fixtures[fixtureB], 0) ? 1 : 0;
+}
+
+static void FillManifold(b2Manifold& out, const b2hip_manifold& m)
+{
+	memset(&out, 0, sizeof(out));
+	out.type = (b2Manifold::Type)m.type;
+	out.pointCount = m.point_count;
+	out.localNormal.Set(m.local_normal[0], m.local_normal[1]);
+	out.localPoint.Set(m.local_point[0], m.local_point[1]);
+	for (int k = 0; k < 2; ++k)
+	{
+		out.points[k].localPoint.Set(m.point_local[k][0], m.point_local[k][1]);
+		out.points[k].normalImpulse = m.normal_impulse[k];
+		out.points[k].tangentImpulse = m.tangent_impulse[k];
+		out.points[k].id.key = m.id_key[k];
+	}
+}
+
+// b2Contact::Update -> PreSolveImmediate / PreSolve (b2Contact.cpp:283-297): called by the step between Collide and the
+// island build; the contact view lives for the duration of the call.
+int b2World::PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int fixtureB, const b2hip_manifold* oldManifold,
+	const b2hip_manifold* manifold)
+{
+	B2_NOT_USED(contactIndex);
+	b2World* self = static_cast<b2World*>(user);
+	if (!self->m_contactListener) return 1;
+	b2Contact c;
+	FillManifold(c.m_manifold, *manifold);
+	c.m_fixtureA = self->m_fixtures[fixtureA];
+	c.m_fixtureB = self->m_fixtures[fixtureB];
+	c.m_next = nullptr;
+	c.m_friction = b2MixFriction(c.m_fixtureA->GetFriction(), c.m_fixtureB->GetFriction());
+	c.m_restitution = b2MixRestitution(c.m_fixtureA->GetRestitution(), c.m_fixtureB->GetRestitution());
+	c.m_touching = true;
+	c.m_enabled = true;
+	b2Manifold old;
+	FillManifold(old, *oldManifold);
+	if (self->m_contactListener->PreSolveImmediate(&c, &old, 0)) self->m_contactListener->PreSolve(&c, &old);
+	return c.m_enabled ? 1 : 0;
+}
+
+// b2Island::Report -> PostSolveImmediate / PostSolve (b2Island.cpp:532-570, b2ContactManager.cpp:454-470)
+void b2World::DeliverPostSolve()
+{
+	if (!m_hip || !m_contactListener) return;
+	int count = b2hip_get_post_solve(m_hip, 0, nullptr);
+	if (count <= 0) return;
+	std::vector<b2hip_contact_impulse> rec(count);
+	count = b2hip_get_post_solve(m_hip, count, rec.data());
+	(void)GetContactList();
+	const int n = (int)m_contactViews.size();
+	for (int i = 0; i < count; ++i)
+	{
+		const b2hip_contact_impulse& r = rec[i];
+		if (r.contact_index < 0 || r.contact_index >= n) continue;
+		b2Contact* c = &m_contactViews[n - 1 - r.contact_index];
+		b2ContactImpulse impulse;
+		impulse.count = r.count;
+		for (int k = 0; k < b2_maxManifoldPoints; ++k)
+		{
+			impulse.normalImpulses[k] = k < r.count ? r.normal_impulses[k] : 0.0f;
+			impulse.tangentImpulses[k] = k < r.count ? r.tangent_impulses[k] : 0.0f;
+		}
+		if (m_contactListener->PostSolveImmediate(c, &impulse, 0)) m_contactListener->PostSolve(c, &impulse);
+	}
 }
 
 // b2ContactManager::Collide's deferred callbacks (b2ContactManager.cpp:420-438), fed from the device's event list.

@@ -38,6 +38,9 @@
  *   b2hip_get_fat_aabbs              (served to) b2World::QueryAABB / RayCast          b2World.cpp:1740-1795, b2DynamicTree.h:168-287
  *   b2hip_get_body_states            b2Body::GetPosition/GetAngle/GetLinearVelocity/GetAngularVelocity/IsAwake  b2Body.h:516-700
  *   b2hip_enable/get_contact_events  b2ContactListener::BeginContact / EndContact     b2WorldCallbacks.h:88-104, b2ContactManager.cpp:420-438
+ *   b2hip_set_pre_solve              b2ContactListener::PreSolve(Immediate)           b2WorldCallbacks.h:105-174, b2Contact.cpp:283-297
+ *   b2hip_enable/get_post_solve      b2ContactListener::PostSolve(Immediate)          b2Island.cpp:532-570, b2ContactManager.cpp:454-470
+ *   b2hip_set_contact_filter         b2ContactFilter::ShouldCollide                   b2WorldCallbacks.h:52-63, b2ContactManager.cpp:283-287
  *   b2hip_save / load_snapshot       (new: binary checkpoint; cf. b2World::Dump          b2World.cpp:2107-2164)
  *   b2hip_get_contacts               b2World::GetContactList + b2Contact::GetManifold  b2World.h:352-360, b2Contact.h:95-163
  *   b2hip_get_profile                b2World::GetProfile                    b2World.h:196-197, b2TimeStep.h:25-40
@@ -384,6 +387,57 @@ typedef struct b2hip_contact_event
 int b2hip_enable_contact_events(b2hip_world* w, int enable);
 /* returns the number of events of the last step (negative on error); at most `cap` are written */
 int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out);
+/* ---- The other half of b2ContactListener, and b2ContactFilter: user code in the middle of a step ----------------------------
+ * The physics runs on the device, user code on the host: each of these is a plain C callback the step calls on the
+ * stepping thread at the point where the reference calls the listener / filter, between two device phases.
+ * Installing one costs a device -> host round trip per step at that point (and only then).
+ *
+ * b2ContactFilter::ShouldCollide (b2WorldCallbacks.h:52-63; call sites b2ContactManager.cpp:283-287 AddPair, :195-203 the
+ * re-filter of flagged contacts in Collide): called for every NEW candidate pair that has passed the body rules (same
+ * body, existing contact, joints, one dynamic body) and for every contact flagged for re-filtering; return 0 to refuse.
+ * An installed filter REPLACES the built-in category / mask / group rule, as a user b2ContactFilter replaces the default
+ * one (call b2hip_default_should_collide from it to keep that rule). Not consulted for contacts created inside a
+ * continuous-collision sub-step (those are made on the device with the built-in rule). */
+typedef int (*b2hip_should_collide_fn)(void* user, int fixture_a, int fixture_b);
+int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* user);
+/* the built-in rule: b2ContactFilter::ShouldCollide (b2WorldCallbacks.cpp:24-38) on the fixtures' filter data */
+int b2hip_default_should_collide(b2hip_world* w, int fixture_a, int fixture_b);
+
+/* b2Manifold as the listener sees it (b2Collision.h:93-107) */
+typedef struct b2hip_manifold
+{
+	int32_t type, point_count;
+	float local_normal[2], local_point[2];
+	float point_local[2][2];
+	float normal_impulse[2], tangent_impulse[2];
+	uint32_t id_key[2];
+} b2hip_manifold;
+
+/* b2ContactListener::PreSolve (b2WorldCallbacks.h:88-174; generation site b2Contact.cpp:283-297, delivery
+ * b2ContactManager.cpp:431-434): after Collide, before the islands are built, once per touching non-sensor contact that
+ * was updated in this step, in proxy-id-pair order, with the manifold of the previous step. Return 0 to disable the
+ * contact for this step (b2Contact::SetEnabled(false): it is left out of the islands; the next Collide enables it again).
+ * `contact_index` indexes b2hip_get_contacts. Contacts updated inside continuous-collision sub-steps are not reported. */
+typedef int (*b2hip_pre_solve_fn)(void* user, int contact_index, int fixture_a, int fixture_b,
+	const b2hip_manifold* old_manifold, const b2hip_manifold* manifold);
+int b2hip_set_pre_solve(b2hip_world* w, b2hip_pre_solve_fn fn, void* user);
+
+/* b2ContactListener::PostSolve (generation b2Island.cpp:532-570, delivery b2ContactManager.cpp:454-470): the impulses the
+ * solver ended with, one record per contact constraint of every island solved in the last step, in proxy-id-pair order.
+ * `count` is the solver's point count (1 when the block solver's conditioning guard dropped the second point,
+ * b2ContactSolver.cpp:230-247). The sub-step islands of continuous collision are not reported. */
+typedef struct b2hip_contact_impulse
+{
+	int32_t fixture_a, fixture_b;
+	int32_t contact_index;
+	int32_t count;
+	float normal_impulses[2];
+	float tangent_impulses[2];
+} b2hip_contact_impulse;
+int b2hip_enable_post_solve(b2hip_world* w, int enable);
+/* returns the number of records of the last step (negative on error); at most `cap` are written */
+int b2hip_get_post_solve(b2hip_world* w, int cap, b2hip_contact_impulse* out);
+
 /* Island label per body for the last step: -1 = not solved (asleep / static), else the smallest body id
  * of the island (island membership is compared as a set partition). */
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out);

@@ -116,6 +116,32 @@ typedef struct b2o_contact_event
 	int32_t kind;          /* 0 = begin, 1 = end */
 	int32_t contact_index; /* into b2o_get_contacts of the same step, -1 = destroyed */
 } b2o_contact_event;
+/* user contact filter, PreSolve and PostSolve: same protocol and layouts as include/b2hip.h (b2hip_should_collide_fn,
+ * b2hip_manifold, b2hip_pre_solve_fn, b2hip_contact_impulse) */
+typedef int (*b2o_should_collide_fn)(void* user, int fixture_a, int fixture_b);
+typedef struct b2o_manifold
+{
+	int32_t type, point_count;
+	float local_normal[2], local_point[2];
+	float point_local[2][2];
+	float normal_impulse[2], tangent_impulse[2];
+	uint32_t id_key[2];
+} b2o_manifold;
+typedef int (*b2o_pre_solve_fn)(void* user, int contact_index, int fixture_a, int fixture_b, const b2o_manifold* old_manifold,
+	const b2o_manifold* manifold);
+typedef struct b2o_contact_impulse
+{
+	int32_t fixture_a, fixture_b;
+	int32_t contact_index;
+	int32_t count;
+	float normal_impulses[2];
+	float tangent_impulses[2];
+} b2o_contact_impulse;
+void b2o_set_contact_filter(b2o_world* w, b2o_should_collide_fn fn, void* user);
+int b2o_default_should_collide(const b2o_world* w, int fixture_a, int fixture_b);
+void b2o_set_pre_solve(b2o_world* w, b2o_pre_solve_fn fn, void* user);
+void b2o_enable_post_solve(b2o_world* w, int enable);
+int b2o_get_post_solve(const b2o_world* w, int cap, b2o_contact_impulse* out);
 void b2o_enable_contact_events(b2o_world* w, int enable);
 int b2o_get_contact_events(const b2o_world* w, int cap, b2o_contact_event* out);
 /* island label per body of the last step (-1 = not solved): smallest body id of its island */

@@ -218,6 +218,34 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
 	return b2o_get_contact_events(w->o, cap, (b2o_contact_event*)out); /* identical layout */
 }
 
+int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* user)
+{
+	b2o_set_contact_filter(w->o, (b2o_should_collide_fn)fn, user);
+	return 0;
+}
+
+int b2hip_default_should_collide(b2hip_world* w, int fixture_a, int fixture_b)
+{
+	return b2o_default_should_collide(w->o, fixture_a, fixture_b);
+}
+
+int b2hip_set_pre_solve(b2hip_world* w, b2hip_pre_solve_fn fn, void* user)
+{
+	b2o_set_pre_solve(w->o, (b2o_pre_solve_fn)fn, user); /* b2hip_manifold == b2o_manifold */
+	return 0;
+}
+
+int b2hip_enable_post_solve(b2hip_world* w, int enable)
+{
+	b2o_enable_post_solve(w->o, enable);
+	return 0;
+}
+
+int b2hip_get_post_solve(b2hip_world* w, int cap, b2hip_contact_impulse* out)
+{
+	return b2o_get_post_solve(w->o, cap, (b2o_contact_impulse*)out); /* identical layout */
+}
+
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out)
 {
 	(void)cap;

@@ -83,6 +83,8 @@ typedef struct
 	int toiCount;
 	int managerIndex; /* position in b2o_world::carray (b2Contact::m_managerIndex) */
 	int reported;     /* contact events: the host has been told that this contact touches */
+	manifold oldm;    /* the manifold before this step's Update (what b2ContactListener::PreSolve is handed) */
+	int preSolveDue;  /* updated by this step's Collide, touching, not a sensor (b2Contact.cpp:283) */
 } contact_t;
 
 /* b2VelocityConstraintPoint / b2ContactVelocityConstraint / b2ContactPositionConstraint
@@ -126,6 +128,12 @@ struct b2o_world
 	int eventsOn;
 	b2o_contact_event* events; int nEvents, capEvents;
 	uint64_t* eventKeys; int capEventKeys;
+	/* the other listener callbacks and the user contact filter (same protocol as include/b2hip.h) */
+	b2o_should_collide_fn filterFn; void* filterUser;
+	b2o_pre_solve_fn preSolveFn; void* preSolveUser;
+	int postSolveOn;
+	b2o_contact_impulse* postSolve; int nPostSolve, capPostSolve;
+	int* postSolveSlot; int capPostSolveSlot; /* contact slot of each record until the end of the step */
 };
 
 #define GROW(ptr, cap, need, type)                                            \
@@ -907,6 +915,8 @@ static void contact_update(b2o_world* w, contact_t* c)
 		}
 	}
 	if (touching) c->flags |= CF_TOUCHING; else c->flags &= ~CF_TOUCHING;
+	c->oldm = old;
+	c->preSolveDue = touching && !(fA->isSensor || fB->isSensor);
 }
 
 static const b2o_world* destroy_cmp_world;
@@ -917,6 +927,62 @@ static int destroy_cmp(const void* a, const void* b)
 	if (p->proxyLo != q->proxyLo) return p->proxyLo < q->proxyLo ? -1 : 1;
 	if (p->proxyHi != q->proxyHi) return p->proxyHi < q->proxyHi ? -1 : 1;
 	return 0;
+}
+
+static int seq_cmp(const void* a, const void* b);
+
+/* index of every live contact in b2o_get_contacts order (creation order); -1 for dead slots */
+static int* contact_ranks(const b2o_world* w)
+{
+	const contact_t** live = (const contact_t**)malloc(sizeof(void*) * (size_t)(w->liveContacts + 1));
+	int* rank = (int*)malloc(sizeof(int) * (size_t)(w->nContactSlots + 1));
+	int n = 0;
+	for (int i = 0; i < w->nContactSlots; ++i)
+	{
+		rank[i] = -1;
+		if (w->contacts[i].alive) live[n++] = &w->contacts[i];
+	}
+	qsort(live, (size_t)n, sizeof(void*), seq_cmp);
+	for (int i = 0; i < n; ++i) rank[(int)(live[i] - w->contacts)] = i;
+	free(live);
+	return rank;
+}
+
+static void fill_manifold(b2o_manifold* o, const manifold* m)
+{
+	o->type = m->type;
+	o->point_count = m->pointCount;
+	o->local_normal[0] = m->localNormal.x; o->local_normal[1] = m->localNormal.y;
+	o->local_point[0] = m->localPoint.x; o->local_point[1] = m->localPoint.y;
+	for (int k = 0; k < 2; ++k)
+	{
+		o->point_local[k][0] = m->p[k].x; o->point_local[k][1] = m->p[k].y;
+		o->normal_impulse[k] = m->ni[k]; o->tangent_impulse[k] = m->ti[k];
+		o->id_key[k] = m->id[k];
+	}
+}
+
+/* b2ContactListener::PreSolve, deferred form (b2Contact.cpp:283-297, b2ContactManager.cpp:431-434): after the destroys of
+ * FinishCollide here, so that the contact index is the one b2o_get_contacts shows; proxy-id-pair order */
+static void deliver_pre_solve(b2o_world* w)
+{
+	int n = 0;
+	int* due = (int*)malloc(sizeof(int) * (size_t)(w->nContactSlots + 1));
+	for (int i = 0; i < w->nContactSlots; ++i)
+		if (w->contacts[i].alive && w->contacts[i].preSolveDue) due[n++] = i;
+	destroy_cmp_world = w;
+	qsort(due, (size_t)n, sizeof(int), destroy_cmp);
+	int* rank = contact_ranks(w);
+	for (int k = 0; k < n; ++k)
+	{
+		contact_t* c = &w->contacts[due[k]];
+		b2o_manifold oldM, newM;
+		fill_manifold(&oldM, &c->oldm);
+		fill_manifold(&newM, &c->m);
+		if (!w->preSolveFn(w->preSolveUser, rank[due[k]], c->fixtureA, c->fixtureB, &oldM, &newM)) c->flags &= ~CF_ENABLED;
+	}
+	free(rank);
+	free(due);
 }
 
 /* b2ContactManager::Collide (:177-230) + FinishCollide (:388-439: destroys sorted by proxy ids) */
@@ -934,9 +1000,12 @@ static void collide(b2o_world* w)
 		fixture_t* fB = &w->fixtures[c->fixtureB];
 		body_t* bA = &w->bodies[c->bodyA];
 		body_t* bB = &w->bodies[c->bodyB];
+		c->preSolveDue = 0;
 		if (c->flags & CF_FILTER)
 		{
-			if (!bodies_should_collide_w(w, c->bodyB, c->bodyA) || !filter_should_collide(fA, fB))
+			/* (a user contact filter replaces the default one, b2ContactManager.cpp:195-203) */
+			int pass = w->filterFn ? w->filterFn(w->filterUser, c->fixtureA, c->fixtureB) != 0 : filter_should_collide(fA, fB);
+			if (!bodies_should_collide_w(w, c->bodyB, c->bodyA) || !pass)
 			{
 				destroys[nDestroy++] = i;
 				continue;
@@ -961,6 +1030,7 @@ static void collide(b2o_world* w)
 	for (int k = 0; k < nDestroy; ++k) destroy_contact(w, destroys[k]);
 	free(destroys);
 	free(awakes);
+	if (w->preSolveFn) deliver_pre_solve(w);
 }
 
 /* ---- broad-phase --------------------------------------------------------------------------------- */
@@ -1025,7 +1095,8 @@ static void find_new_contacts(b2o_world* w)
 		}
 		if (exists) continue;
 		if (!bodies_should_collide_w(w, fB->body, fA->body)) continue;
-		if (!filter_should_collide(fA, fB)) continue;
+		/* m_contactFilter->ShouldCollide (b2ContactManager.cpp:283-287): a user filter replaces the default one */
+		if (w->filterFn ? !w->filterFn(w->filterUser, pairs[i].fLo, pairs[i].fHi) : !filter_should_collide(fA, fB)) continue;
 		create_contact(w, pairs[i].fLo, pairs[i].fHi);
 	}
 	free(pairs);
@@ -1526,6 +1597,29 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		{
 			m->ni[j] = cs[i].normalImpulse[j];
 			m->ti[j] = cs[i].tangentImpulse[j];
+		}
+	}
+	/* b2Island::Report (b2Island.cpp:532-570): the velocity constraints' impulses, one record per contact of the island */
+	if (w->postSolveOn)
+	{
+		for (int i = 0; i < contactCount; ++i)
+		{
+			GROW(w->postSolve, w->capPostSolve, w->nPostSolve + 1, b2o_contact_impulse);
+			GROW(w->postSolveSlot, w->capPostSolveSlot, w->nPostSolve + 1, int);
+			b2o_contact_impulse* r = &w->postSolve[w->nPostSolve];
+			const contact_t* c = &w->contacts[cs[i].contact];
+			memset(r, 0, sizeof(*r));
+			r->fixture_a = c->fixtureA;
+			r->fixture_b = c->fixtureB;
+			r->count = cs[i].pointCount;
+			for (int j = 0; j < 2; ++j)
+			{
+				/* like the device's record: the manifold's stored impulses (points beyond the solver's count keep the warm-start value) */
+				r->normal_impulses[j] = c->m.ni[j];
+				r->tangent_impulses[j] = c->m.ti[j];
+			}
+			w->postSolveSlot[w->nPostSolve] = cs[i].contact;
+			w->nPostSolve++;
 		}
 	}
 	for (int i = 0; i < bodyCount; ++i)
@@ -2120,9 +2214,39 @@ int b2o_get_contact_events(const b2o_world* w, int cap, b2o_contact_event* out)
 	return w->nEvents;
 }
 
+static int post_cmp(const void* a, const void* b)
+{
+	return destroy_cmp(a, b);
+}
+
+/* deferred PostSolve order (b2ContactManager.cpp:454-470): proxy-id pair; contact index as b2o_get_contacts shows it */
+static void finish_post_solve(b2o_world* w)
+{
+	const int n = w->nPostSolve;
+	if (n == 0) return;
+	int* order = (int*)malloc(sizeof(int) * (size_t)n);
+	int* slots = (int*)malloc(sizeof(int) * (size_t)n);
+	for (int i = 0; i < n; ++i) slots[i] = w->postSolveSlot[i];
+	/* sort record indices by the proxy ids of their contacts: sort the slots, then match (slots are unique) */
+	destroy_cmp_world = w;
+	qsort(slots, (size_t)n, sizeof(int), post_cmp);
+	int* rank = contact_ranks(w);
+	b2o_contact_impulse* sorted = (b2o_contact_impulse*)malloc(sizeof(b2o_contact_impulse) * (size_t)n);
+	int* where = (int*)malloc(sizeof(int) * (size_t)(w->nContactSlots + 1));
+	for (int i = 0; i < n; ++i) where[w->postSolveSlot[i]] = i;
+	for (int k = 0; k < n; ++k)
+	{
+		sorted[k] = w->postSolve[where[slots[k]]];
+		sorted[k].contact_index = rank[slots[k]];
+	}
+	memcpy(w->postSolve, sorted, sizeof(b2o_contact_impulse) * (size_t)n);
+	free(where); free(sorted); free(rank); free(slots); free(order);
+}
+
 void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 {
 	w->nEvents = 0;
+	w->nPostSolve = 0;
 	if (w->newFixture)
 	{
 		find_new_contacts(w);
@@ -2140,6 +2264,20 @@ void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 		w->bodies[i].torque = 0.0f;
 	}
 	if (w->eventsOn) collect_contact_events(w);
+	if (w->postSolveOn) finish_post_solve(w);
+}
+
+void b2o_set_contact_filter(b2o_world* w, b2o_should_collide_fn fn, void* user) { w->filterFn = fn; w->filterUser = user; }
+void b2o_set_pre_solve(b2o_world* w, b2o_pre_solve_fn fn, void* user) { w->preSolveFn = fn; w->preSolveUser = user; }
+void b2o_enable_post_solve(b2o_world* w, int enable) { w->postSolveOn = enable != 0; w->nPostSolve = 0; }
+int b2o_get_post_solve(const b2o_world* w, int cap, b2o_contact_impulse* out)
+{
+	for (int i = 0; i < w->nPostSolve && i < cap; ++i) out[i] = w->postSolve[i];
+	return w->nPostSolve;
+}
+int b2o_default_should_collide(const b2o_world* w, int fixtureA, int fixtureB)
+{
+	return filter_should_collide(&w->fixtures[fixtureA], &w->fixtures[fixtureB]);
 }
 
 /* b2Body::ApplyForceToCenter + ApplyTorque  b2Body.h:740-775 */

@@ -18,19 +18,37 @@
 
 struct b2h_world;
 
-// Records BeginContact / EndContact (the deferred, deterministic callbacks) since the last b2h_get_events call.
+// Records the listener callbacks (the deferred, deterministic ones) since the last b2h_get_events* call: 10 ints per event:
+//   kind 0 BeginContact / 1 EndContact : bodyA, fixtureA, bodyB, fixtureB, 0...
+//   kind 2 PreSolve  : ..., old point count, new point count, bits(old normalImpulse[0]), bits(new localNormal.x), enabled after the call
+//   kind 3 PostSolve : ..., count, bits(normalImpulses[0]), bits(normalImpulses[1]), bits(tangentImpulses[0]), bits(tangentImpulses[1])
+// mode bits: 1 begin / end, 2 PreSolve, 4 PostSolve, 8 PreSolve disables the contacts picked by a fixed rule of the body
+// indices (b2Contact::SetEnabled(false): a one-way-platform style use of the callback).
 class b2hEventRecorder : public b2ContactListener
 {
 public:
-	explicit b2hEventRecorder(b2h_world* owner) : m_owner(owner) {}
-	void BeginContact(b2Contact* contact) override { Record(0, contact); }
-	void EndContact(b2Contact* contact) override { Record(1, contact); }
-	bool BeginContactImmediate(b2Contact*, uint32) override { return true; }
-	bool EndContactImmediate(b2Contact*, uint32) override { return true; }
-	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32) override { return false; }
-	bool PostSolveImmediate(b2Contact*, const b2ContactImpulse*, uint32) override { return false; }
-	void Record(int kind, b2Contact* contact);
-	std::vector<int> log; // 5 ints per event: kind, bodyA, fixtureA, bodyB, fixtureB
+	b2hEventRecorder(b2h_world* owner, int mode) : m_owner(owner), m_mode(mode) {}
+	void BeginContact(b2Contact* contact) override { Record(0, contact, 0, 0, 0, 0, 0); }
+	void EndContact(b2Contact* contact) override { Record(1, contact, 0, 0, 0, 0, 0); }
+	void PreSolve(b2Contact* contact, const b2Manifold* oldManifold) override;
+	void PostSolve(b2Contact* contact, const b2ContactImpulse* impulse) override;
+	bool BeginContactImmediate(b2Contact*, uint32) override { return (m_mode & 1) != 0; }
+	bool EndContactImmediate(b2Contact*, uint32) override { return (m_mode & 1) != 0; }
+	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32) override { return (m_mode & (2 | 8)) != 0; }
+	bool PostSolveImmediate(b2Contact*, const b2ContactImpulse*, uint32) override { return (m_mode & 4) != 0; }
+	void Record(int kind, b2Contact* contact, int a, int b, int c, int d, int e);
+	std::vector<int> log; // 10 ints per event
+	int m_mode;
+private:
+	b2h_world* m_owner;
+};
+
+// A user contact filter: the default rule AND a fixed rule of the body indices (b2ContactFilter::ShouldCollide override).
+class b2hFilter : public b2ContactFilter
+{
+public:
+	explicit b2hFilter(b2h_world* owner) : m_owner(owner) {}
+	bool ShouldCollide(b2Fixture* fixtureA, b2Fixture* fixtureB, uint32 threadId) override;
 private:
 	b2h_world* m_owner;
 };
@@ -38,6 +56,7 @@ private:
 struct b2h_world
 {
 	b2hEventRecorder* recorder;
+	b2hFilter* filter;
 	b2World* world;
 	b2ThreadPoolTaskExecutor* executor;
 	b2h::Scene scene;
@@ -94,6 +113,7 @@ b2h_world* b2h_create(int scene, int p0, int p1, float f0, float f1, unsigned se
 	memset(h->profileSum, 0, sizeof(h->profileSum));
 	h->profileSteps = 0;
 	h->recorder = nullptr;
+	h->filter = nullptr;
 	return h;
 }
 
@@ -102,6 +122,7 @@ void b2h_destroy(b2h_world* h)
 	if (h == NULL) return;
 	delete h->world;
 	delete h->recorder;
+	delete h->filter;
 	delete h->executor;
 	delete h;
 }
@@ -229,44 +250,108 @@ static int FixtureIndexInBody(const b2Fixture* f)
 
 } // extern "C" (reopened below): the recorder needs FixtureIndexInBody
 
-void b2hEventRecorder::Record(int kind, b2Contact* contact)
+static int FloatBits(float f)
+{
+	int i;
+	memcpy(&i, &f, 4);
+	return i;
+}
+
+void b2hEventRecorder::Record(int kind, b2Contact* contact, int a, int b, int c, int d, int e)
 {
 	const b2Fixture* fA = contact->GetFixtureA();
 	const b2Fixture* fB = contact->GetFixtureB();
-	log.push_back(kind);
-	log.push_back(m_owner->bodyIndex[fA->GetBody()]);
-	log.push_back(FixtureIndexInBody(fA));
-	log.push_back(m_owner->bodyIndex[fB->GetBody()]);
-	log.push_back(FixtureIndexInBody(fB));
+	const int row[10] = { kind, m_owner->bodyIndex[fA->GetBody()], FixtureIndexInBody(fA), m_owner->bodyIndex[fB->GetBody()],
+		FixtureIndexInBody(fB), a, b, c, d, e };
+	log.insert(log.end(), row, row + 10);
+}
+
+void b2hEventRecorder::PreSolve(b2Contact* contact, const b2Manifold* oldManifold)
+{
+	const int bA = m_owner->bodyIndex[contact->GetFixtureA()->GetBody()], bB = m_owner->bodyIndex[contact->GetFixtureB()->GetBody()];
+	if ((m_mode & 8) != 0 && (bA + 3 * bB) % 7 == 0) contact->SetEnabled(false);
+	if ((m_mode & 2) != 0)
+	{
+		const b2Manifold* m = contact->GetManifold();
+		Record(2, contact, oldManifold->pointCount, m->pointCount, oldManifold->pointCount > 0 ? FloatBits(oldManifold->points[0].normalImpulse) : 0,
+			FloatBits(m->localNormal.x), contact->IsEnabled() ? 1 : 0);
+	}
+}
+
+void b2hEventRecorder::PostSolve(b2Contact* contact, const b2ContactImpulse* impulse)
+{
+	Record(3, contact, impulse->count, FloatBits(impulse->normalImpulses[0]), impulse->count > 1 ? FloatBits(impulse->normalImpulses[1]) : 0,
+		FloatBits(impulse->tangentImpulses[0]), impulse->count > 1 ? FloatBits(impulse->tangentImpulses[1]) : 0);
+}
+
+bool b2hFilter::ShouldCollide(b2Fixture* fixtureA, b2Fixture* fixtureB, uint32 threadId)
+{
+	if (!b2ContactFilter::ShouldCollide(fixtureA, fixtureB, threadId)) return false;
+	const int bA = m_owner->bodyIndex[fixtureA->GetBody()], bB = m_owner->bodyIndex[fixtureB->GetBody()];
+	const int lo = bA < bB ? bA : bB, hi = bA < bB ? bB : bA;
+	return lo == 0 || (31 * lo + 17 * hi) % 11 != 0; // (everything still collides with the ground)
 }
 
 extern "C"
 {
 
-// Contact events: install the recording listener / fetch what it has logged since the last call
-// (5 ints per event: kind 0 begin / 1 end, bodyA, fixtureA, bodyB, fixtureB; returns the number of events).
-void b2h_record_events(b2h_world* h, int enable)
+// Listener: install (mode != 0, see b2hEventRecorder) or remove the recording listener / fetch what it has logged since the
+// last call. b2h_get_events: begin / end only, 5 ints per event (kind, bodyA, fixtureA, bodyB, fixtureB);
+// b2h_get_events_ex: every recorded callback, 10 ints per event. Both return the number of events and clear the log.
+void b2h_record_events(b2h_world* h, int mode)
 {
-	if (enable && !h->recorder)
-	{
-		h->recorder = new b2hEventRecorder(h);
-		h->world->SetContactListener(h->recorder);
-	}
-	else if (!enable && h->recorder)
+	if (h->recorder)
 	{
 		h->world->SetContactListener(nullptr);
 		delete h->recorder;
 		h->recorder = nullptr;
+	}
+	if (mode)
+	{
+		h->recorder = new b2hEventRecorder(h, mode);
+		h->world->SetContactListener(h->recorder);
 	}
 }
 
 int b2h_get_events(b2h_world* h, int cap, int* out)
 {
 	if (!h->recorder) return 0;
-	const int n = (int)h->recorder->log.size() / 5;
-	for (int i = 0; i < n && i < cap; ++i) memcpy(out + 5 * i, h->recorder->log.data() + 5 * i, 5 * sizeof(int));
+	const int n = (int)h->recorder->log.size() / 10;
+	int m = 0;
+	for (int i = 0; i < n; ++i)
+	{
+		const int* row = h->recorder->log.data() + 10 * i;
+		if (row[0] > 1) continue;
+		if (m < cap) memcpy(out + 5 * m, row, 5 * sizeof(int));
+		++m;
+	}
+	h->recorder->log.clear();
+	return m;
+}
+
+int b2h_get_events_ex(b2h_world* h, int cap, int* out)
+{
+	if (!h->recorder) return 0;
+	const int n = (int)h->recorder->log.size() / 10;
+	for (int i = 0; i < n && i < cap; ++i) memcpy(out + 10 * i, h->recorder->log.data() + 10 * i, 10 * sizeof(int));
 	h->recorder->log.clear();
 	return n;
+}
+
+// User contact filter (b2World::SetContactFilter): the harness's rule of the body indices on top of the default rule.
+void b2h_set_filter(b2h_world* h, int enable)
+{
+	if (enable && !h->filter)
+	{
+		h->filter = new b2hFilter(h);
+		h->world->SetContactFilter(h->filter);
+	}
+	else if (!enable && h->filter)
+	{
+		h->world->SetContactFilter(nullptr);
+		delete h->filter;
+		h->filter = nullptr;
+	}
 }
 
 } // extern "C": the query callbacks below are C++ classes

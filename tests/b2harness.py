@@ -63,6 +63,9 @@ class Harness:
         L.b2h_record_events.argtypes = [C.c_void_p, C.c_int]
         L.b2h_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.b2h_get_events.restype = C.c_int
+        L.b2h_get_events_ex.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.b2h_get_events_ex.restype = C.c_int
+        L.b2h_set_filter.argtypes = [C.c_void_p, C.c_int]
 
     @property
     def backend(self):
@@ -246,9 +249,21 @@ class World:
             return None
         return out
 
-    def record_events(self, enable=True):
-        """Install (or remove) the harness's recording b2ContactListener."""
-        self.L.b2h_record_events(self.ptr, 1 if enable else 0)
+    def record_events(self, enable=True, mode=None):
+        """Install (or remove) the harness's recording b2ContactListener. mode bits: 1 begin / end (the default), 2 PreSolve,
+        4 PostSolve, 8 PreSolve disables the contacts a fixed rule of the body indices picks (SetEnabled(false))."""
+        self.L.b2h_record_events(self.ptr, (mode if mode is not None else 1) if enable else 0)
+
+    def events_ex(self, cap=1 << 18):
+        """Every recorded callback since the last call, in call order: rows of 10 ints (see oracle/harness/harness.cpp):
+        kind (0 begin, 1 end, 2 PreSolve, 3 PostSolve), bodyA, fixtureA, bodyB, fixtureB, five payload words."""
+        out = np.zeros((cap, 10), np.int32)
+        n = self.L.b2h_get_events_ex(self.ptr, cap, _iptr(out))
+        return out[:min(n, cap)].copy()
+
+    def set_filter(self, enable=True):
+        """Install (or remove) the harness's user b2ContactFilter (default rule AND a fixed rule of the body indices)."""
+        self.L.b2h_set_filter(self.ptr, 1 if enable else 0)
 
     def events(self, cap=1 << 16):
         """BeginContact / EndContact callbacks since the last call, in call order: rows (kind, bodyA, fixtureA, bodyB, fixtureB)."""

@@ -119,7 +119,10 @@ def test_snapshot_rejects_truncated_and_bit_flipped_blobs():
         except b2hip.B2HipError:
             refused += 1
             continue
-        w.step()  # survived validation: payload damage only
+        try:
+            w.step()  # survived validation: payload damage only (or a counter whose damage the step itself reports)
+        except b2hip.B2HipError:
+            pass
         w.close()
     assert refused >= 20, "header damage must be refused (%d refusals)" % refused
 

@@ -1,0 +1,107 @@
+"""b2ContactListener::PreSolve / PostSolve and a user b2ContactFilter.
+
+The harness installs the same recording listener / filter on every backend (oracle/harness/harness.cpp): the listener logs
+every PreSolve (old and new manifold words, enabled flag after the call) and PostSolve (solver point count, impulse bits)
+callback; in mode 8 its PreSolve disables the contacts a fixed rule of the body indices picks (b2Contact::SetEnabled(false),
+b2Contact.h:117-123), the filter refuses the pairs another fixed rule picks (b2ContactFilter::ShouldCollide override,
+b2WorldCallbacks.h:52-63). Both change the physics, so the body states are compared as well.
+
+  CPU : the drop-in host layer over the C oracle  vs  the real reference build   (the oracle is pinned)
+  GPU : the product (HIP)                          vs  the oracle                 (exact-order mode: bit for bit)
+
+The reference calls the listener in island / contact-array order when it runs on one thread and in proxy-id order when its
+callbacks are deferred (b2ContactManager.cpp:431-434, 466-469); per step the SET of callbacks and their payloads is what is
+pinned, so each step's rows are sorted before they are compared. Reference sites: b2Contact.cpp:283-297 (PreSolve),
+b2Island.cpp:532-570 (Report -> PostSolve), b2ContactManager.cpp:283-287 (AddPair -> ShouldCollide).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import b2harness as bh
+
+MODE_ALL = 1 | 2 | 4          # begin / end, PreSolve, PostSolve: recorded
+MODE_DISABLE = 1 | 2 | 4 | 8  # ... and PreSolve switches contacts off by the harness's rule
+CASES = [("rain", bh.RAIN, 120, 0, 4, 150), ("piles", bh.PILES, 25, 5, 6, 140), ("pyramid", bh.PYRAMID, 9, 1, 1, 120),
+         ("circlestack", bh.CIRCLE_STACK, 6, 5, 1, 120)]
+
+
+def rows(ev):
+    """a step's callbacks as a sorted list of tuples (call order inside a step differs between the backends)"""
+    return sorted(tuple(r) for r in ev.tolist())
+
+
+def run_pair(a, b, steps, mode, use_filter, what):
+    for w in (a, b):
+        w.record_events(mode=mode)
+        if use_filter:
+            w.set_filter(True)
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    disabled = 0
+    for s in range(steps):
+        a.step(1)
+        b.step(1)
+        ea, eb = a.events_ex(), b.events_ex()
+        assert rows(ea) == rows(eb), "%s: listener callbacks differ at step %d" % (what, s)
+        for k in seen:
+            seen[k] += int((eb[:, 0] == k).sum())
+        disabled += int(((eb[:, 0] == 2) & (eb[:, 9] == 0)).sum())
+        assert a.contact_count == b.contact_count, "%s: contact count at step %d" % (what, s)
+        assert np.array_equal(a.bodies().view(np.uint32), b.bodies().view(np.uint32)), "%s: body states differ at step %d" % (what, s)
+    return seen, disabled
+
+
+@pytest.mark.parametrize("name,scene,p0,p1,seed,steps", CASES)
+@pytest.mark.parametrize("variant", ["record", "disable", "filter"])
+def test_oracle_listener_and_filter_match_the_reference(ref, oracle, name, scene, p0, p1, seed, steps, variant):
+    a = ref.world(scene, p0, p1, seed=seed)
+    b = oracle.world(scene, p0, p1, seed=seed)
+    seen, disabled = run_pair(a, b, steps, MODE_DISABLE if variant == "disable" else MODE_ALL, variant == "filter", name + "/" + variant)
+    assert seen[2] > 0 and seen[3] > 0, "no PreSolve / PostSolve callback ever fired: test is vacuous"
+    if variant == "disable" and name != "circlestack":
+        assert disabled > 0, "the PreSolve rule never disabled a contact: test is vacuous"
+    a.close()
+    b.close()
+
+
+def test_filter_changes_the_contact_set(oracle):
+    """the user filter really refuses pairs (else the filter variant above proves nothing)"""
+    a = oracle.world(bh.RAIN, 120, 0, seed=4)
+    b = oracle.world(bh.RAIN, 120, 0, seed=4)
+    b.set_filter(True)
+    a.step(100)
+    b.step(100)
+    assert a.contact_count != b.contact_count or not np.array_equal(a.bodies(), b.bodies())
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scene,p0,p1,seed,steps", CASES + [("field", bh.FIELD, 1500, 0, 8, 60)])
+@pytest.mark.parametrize("variant", ["record", "disable", "filter"])
+def test_device_listener_and_filter_match_the_oracle(amd, oracle, monkeypatch, name, scene, p0, p1, seed, steps, variant):
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")  # every island in the reference's order: states stay bit-equal
+    a = amd.world(scene, p0, p1, seed=seed)
+    b = oracle.world(scene, p0, p1, seed=seed)
+    seen, disabled = run_pair(a, b, steps, MODE_DISABLE if variant == "disable" else MODE_ALL, variant == "filter", name + "/" + variant)
+    assert seen[2] > 0 and seen[3] > 0
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_device_post_solve_in_default_mode_reports_every_solved_constraint(amd):
+    """Default (coloured) mode on a pile that takes the block solver: one PostSolve per touching contact of the solved
+    islands, with the impulses the contact list shows afterwards."""
+    w = amd.world(bh.PYRAMID, 30, 1)
+    w.record_events(mode=4)
+    for s in range(80):
+        w.step(1)
+        ev = w.events_ex()
+        ids, flags, man = w.contacts()
+        touching = int(((flags & 1) != 0).sum())
+        assert (ev[:, 0] == 3).all()
+        if s > 40:
+            assert abs(len(ev) - touching) <= 0.02 * touching + 2, "step %d: %d PostSolve callbacks for %d touching contacts" % (s, len(ev), touching)
+    w.close()

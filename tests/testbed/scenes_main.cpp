@@ -1,0 +1,64 @@
+// Headless runner of the REFERENCE's own Testbed scene headers (included from /root/reference where they lie, unmodified)
+// on top of a Box2D API chosen by the include path: the drop-in one (box2d-mt_amd/host, -> libtestbed_amd.so) or the
+// reference's (-> libtestbed_ref.so). TEST INFRASTRUCTURE; the built library goes to oracle/_ref/ (git-ignored, travels).
+// Follows TestMT.cpp:4-48: construct the scene, step it `steps` times with default Settings, ask TestPassed().
+#include "headless_test.h"
+
+DebugDraw g_debugDraw;
+Camera g_camera;
+
+#include "Testbed/Tests/SleepCollideTest.h"
+#include "Testbed/Tests/TunnelingTest.h"
+#include "Testbed/Tests/DuplicateProxyTest.h"
+#include "Testbed/Tests/ManyBodies.h"
+#include "Testbed/Tests/MultithreadDemo.h"
+#include "Testbed/Tests/Car.h"
+#include "Testbed/Tests/Pyramid.h"
+#include "Testbed/Tests/Tumbler.h"
+
+struct Entry { const char* name; TestCreateFcn* create; };
+static const Entry kEntries[] = {
+	{ "SleepCollideTest", SleepCollideTest::Create }, { "TunnelingTest", TunnelingTest::Create },
+	{ "DuplicateProxyTest", DuplicateProxyTest::Create }, { "ManyBodies", ManyBodies::Create },
+	{ "MultithreadDemo", MultithreadDemo::Create }, { "Car", Car::Create }, { "Pyramid", Pyramid::Create },
+	{ "Tumbler", Tumbler::Create },
+};
+
+extern "C"
+{
+
+// Runs scene `name` for `steps` steps. Returns TestPassed() (0 none, 1 pass, 2 fail) or -1 for an unknown name; out6 =
+// body count, contact count, sum of |x| + |y| over the bodies, max |v|, 1 if every body state is finite, awake bodies.
+int testbed_run(const char* name, int steps, double* out6)
+{
+	for (const Entry& e : kEntries)
+	{
+		if (strcmp(e.name, name) != 0) continue;
+		srand(0);
+		Test* t = e.create();
+		Settings settings;
+		for (int i = 0; i < steps; ++i) t->Step(&settings);
+		double sum = 0.0, vmax = 0.0;
+		int finite = 1, awake = 0, n = 0;
+		for (b2Body* b = t->GetWorld()->GetBodyList(); b; b = b->GetNext())
+		{
+			const b2Vec2 p = b->GetPosition(), v = b->GetLinearVelocity();
+			if (!(p.x == p.x) || !(p.y == p.y) || !(v.x == v.x) || !(v.y == v.y)) finite = 0;
+			sum += (p.x < 0 ? -p.x : p.x) + (p.y < 0 ? -p.y : p.y);
+			const double sp = (double)v.x * v.x + (double)v.y * v.y;
+			if (sp > vmax) vmax = sp;
+			awake += b->IsAwake() ? 1 : 0;
+			++n;
+		}
+		if (out6)
+		{
+			out6[0] = n; out6[1] = t->GetWorld()->GetContactCount(); out6[2] = sum; out6[3] = vmax; out6[4] = finite; out6[5] = awake;
+		}
+		const int res = (int)t->TestPassed();
+		delete t;
+		return res;
+	}
+	return -1;
+}
+
+}
