@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 		}
 		waveAtomicAddInt(W.rootBodies, r, 1, valid);
 		// seeds are taken in m_nonStaticBodies order (b2World.cpp:1207-1221): first awake, active body
-		waveAtomicMinInt(W.rootSeed, r, i, valid && (f & BF_AWAKE) != 0);
+		waveAtomicMinInt(W.rootSeed, r, valid ? W.b_order[i] : 0, valid && (f & BF_AWAKE) != 0);
 	}
 }
 
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nS; idx += gridDim.x * blockDim.x)
 	{
 		const int root = W.si_root[idx];
-		const int seed = W.rootSeed[root];
+		const int seed = W.orderBody[W.rootSeed[root]];
 		const int bStart = W.si_bodyStart[idx];
 		const int cStart = W.si_contactStart[idx];
 		int* stack = W.si_stack + bStart;

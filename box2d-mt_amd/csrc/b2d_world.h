@@ -183,7 +183,7 @@ struct DW
 	DState* st;
 	int nBodies, nProxies, nJoints, nShapes;
 	int capContacts, capPairs, capMoves;
-	int smallMaxW;        // islands up to this size take the exact-order in-LDS solver (default SMALL_ISLAND_MAX_W; B2HIP_SMALL_MAX_W)
+	int smallMaxW;        // islands up to this size take the exact-order in-LDS solver (default TINY_ISLAND_MAX_W = 128; B2HIP_SMALL_MAX_W up to 512)
 	int bigChunks;        // 1: always use 1024-lane chunks for the small-island solver (B2HIP_BIG_CHUNKS)
 	uint32_t htMask;      // contact-key hash table size - 1
 	uint32_t gridMask;    // broad-phase hash grid size - 1
@@ -199,6 +199,9 @@ struct DW
 	float4* b_force;  // force.xy, torque, -
 	uint32_t* b_flags;
 	int* b_wake;      // wake requests gathered during collide / contact creation
+	int* b_order;     // per body: its slot in the reference's m_nonStaticBodies (b2World.cpp:573, 662-667: appended at creation,
+	                  // the last one moves into the slot of a destroyed one) - island seeds are taken in that order (:1207-1221)
+	int* orderBody;   // slot -> body
 
 	// ---- proxies [nProxies], one per fixture (circle / edge / polygon) -----------------------
 	float4* p_fat;    // fat AABB lower.xy, upper.xy (b2DynamicTree node aabb)
@@ -228,7 +231,7 @@ struct DW
 
 	// ---- island build -----------------------------------------------------------------------
 	int* parent;         // union-find over non-static bodies; after flatten: island root per body
-	int* rootSeed;       // per root: min awake body id (INT_MAX = island asleep)
+	int* rootSeed;       // per root: lowest m_nonStaticBodies slot (b_order) among its awake bodies (INT_MAX = island asleep)
 	int* rootBodies;     // per root: non-static body count
 	int* rootContacts;   // per root: solid touching contact count
 	int* rootJoints;

@@ -23,6 +23,7 @@
 #include "b2d_kernels_solve_dataflow.h"
 #include "b2d_kernels_solve_mailbox.h"
 #include "b2d_kernels_solve_blocks.h"
+#include "b2d_kernels_edit.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -88,6 +89,9 @@ struct HostBody
 	float mass, I, invMass, invI;
 	float linearDamping, angularDamping, gravityScale;
 	float sleepTime;
+	int worldIndex;   // slot in b2hip_world::nonStatic (the reference's m_nonStaticBodies), -1 for static bodies
+	int dead;         // destroyed (b2World::DestroyBody): the id stays, the body takes no part in anything any more
+	int resetSweep;   // SetTransform: the sweep origin (c0, a0) is rewritten from the host mirror at the next upload
 	std::vector<int> fixtures; // creation order (the reference's list is newest first)
 	bool dirty;
 };
@@ -102,6 +106,7 @@ struct HostFixture
 	bool isSensor, thick;
 	int proxyKey;
 	float fat[4];
+	bool dead;        // destroyed (b2Body::DestroyFixture / DestroyBody): the id stays, the proxy is gone
 };
 
 struct GraphSeg
@@ -210,6 +215,14 @@ struct b2hip_world
 	int persistSteps;            // steps solved by the persistent kernel (diagnostics)
 	DevArray<int> consts; // [0] nBodies, [1] gridSize, [2] radix hist count, [3] sorted-pair count
 	DevArray<unsigned long long> filterPairs; // sorted body-pair keys of the joints created / destroyed since the last step
+	std::vector<int> nonStatic;       // the reference's m_nonStaticBodies: body ids in its order (island seed order)
+	bool orderDirty = false;
+	DevArray<int> b_order, orderBody;
+	// edits of existing fixtures / contacts between steps (b2d_kernels_edit.h)
+	std::vector<int2> editOps;        // queued contact-array ops, in call order
+	std::vector<int> proxyEdits;      // fixtures whose device proxy row (fat AABB, filter words, body) must be rewritten
+	bool proxyListsStale = false;     // a fixture was destroyed: b_proxyHead / p_next need a rebuild
+	DevArray<int2> d_editOps;
 	// listener / filter bridge: user callbacks in the middle of a step (include/b2hip.h)
 	b2hip_should_collide_fn filterFn = nullptr;
 	void* filterUser = nullptr;
@@ -339,13 +352,25 @@ static void setAwake(b2hip_world* w, int i)
 	b.sleepTime = 0.0f;
 }
 
+// The ids the reference's b2DynamicTree hands out (AllocateNode / FreeNode, b2DynamicTree.cpp:53-99): a LIFO free list of
+// node ids in front of a growing pool. CreateProxy takes one node for the leaf and - unless the tree is empty - InsertLeaf
+// one more for the new internal parent; DestroyProxy gives back the parent RemoveLeaf drops (unless the leaf was the root)
+// and then the leaf, so the next CreateProxy reuses exactly that leaf id. Which id the internal node had is never
+// observable (only leaves are proxies): it sits in the list as a marker (-1).
 static int allocProxyKey(b2hip_world* w)
 {
 	int key;
 	if (!w->freeUnits.empty())
 	{
 		key = w->freeUnits.back().leaf;
+		if (key < 0) return -1; // an internal node's id would become a leaf id (the tree was emptied and refilled): not modelled
 		w->freeUnits.pop_back();
+		if (w->leafCount > 0)
+		{
+			// InsertLeaf's parent node comes off the free list as well, or from the pool
+			if (!w->freeUnits.empty()) w->freeUnits.pop_back();
+			else w->nextNode++;
+		}
 	}
 	else
 	{
@@ -354,6 +379,20 @@ static int allocProxyKey(b2hip_world* w)
 	}
 	w->leafCount++;
 	return key;
+}
+
+// b2DynamicTree::DestroyProxy (b2DynamicTree.cpp:121-128): RemoveLeaf frees the parent (if the leaf is not the root), then the leaf
+static void freeProxyKey(b2hip_world* w, int key)
+{
+	FreeUnit u;
+	if (w->leafCount > 1)
+	{
+		u.leaf = -1;
+		w->freeUnits.push_back(u);
+	}
+	u.leaf = key;
+	w->freeUnits.push_back(u);
+	w->leafCount--;
 }
 
 static int internShape(b2hip_world* w, const ShapeRec& s)
@@ -604,7 +643,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 #define ENS(arr, n) do { rc = w->arr.ensure((n), s); if (rc) return rc; } while (0)
 	ENS(d_state, 1);
 	ENS(b_pos, nb); ENS(b_pos0, nb); ENS(b_vel, nb); ENS(b_xf, nb); ENS(b_mass, nb); ENS(b_damp, nb); ENS(b_force, nb);
-	ENS(b_flags, nb); ENS(b_wake, nb);
+	ENS(b_flags, nb); ENS(b_wake, nb); ENS(b_order, nb); ENS(orderBody, nb);
 	ENS(p_fat, np); ENS(p_body, np); ENS(p_shape, np); ENS(p_key, np); ENS(p_filter0, np); ENS(p_filter1, np); ENS(p_mat, np);
 	ENS(b_proxyHead, nb); ENS(p_next, np);
 	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
@@ -687,7 +726,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	// Exact order costs ~1 us per DEPENDENT constraint (a GPU lane against a CPU core on a chain): a 210-box pyramid is
 	// ~300 levels x 12 sweeps = 3.9 ms in k_solve_small, ~0.1 ms as one block of k_solve_blocks. Islands up to 128 (bodies
 	// or contacts) are walked in the reference's order, bit-exact; B2HIP_SMALL_MAX_W (<= 512) moves the line.
-	d.smallMaxW = SMALL_ISLAND_MAX_W;
+	d.smallMaxW = TINY_ISLAND_MAX_W;
 	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
 	d.capContacts = (int)cc;
 	d.capPairs = (int)w->pairKey.cap;
@@ -696,6 +735,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.gridMask = (uint32_t)(gridSize - 1);
 	d.b_pos = w->b_pos.p; d.b_pos0 = w->b_pos0.p; d.b_vel = w->b_vel.p; d.b_xf = w->b_xf.p; d.b_mass = w->b_mass.p;
 	d.b_damp = w->b_damp.p; d.b_force = w->b_force.p; d.b_flags = w->b_flags.p; d.b_wake = w->b_wake.p;
+	d.b_order = w->b_order.p; d.orderBody = w->orderBody.p;
 	d.p_fat = w->p_fat.p; d.p_body = w->p_body.p; d.p_shape = w->p_shape.p; d.p_key = w->p_key.p;
 	d.p_filter0 = w->p_filter0.p; d.p_filter1 = w->p_filter1.p; d.p_mat = w->p_mat.p; d.shapes = w->d_shapes.p;
 	for (int k = 0; k < 2; ++k)
@@ -781,6 +821,13 @@ static int flushEdits(b2hip_world* w)
 			const size_t first = std::max(i, w->upBodies);
 			HIP_TRY(hipMemcpyAsync(w->b_pos0.p + first, pos0.data() + (first - i), (i + cnt - first) * sizeof(float4), hipMemcpyHostToDevice, s));
 		}
+		for (size_t k = 0; k < cnt; ++k)
+		{
+			// b2Body::SetTransform moves the sweep origin too (b2Body.cpp:463-467)
+			if (w->bodies[i + k].resetSweep && i + k < w->upBodies)
+				HIP_TRY(hipMemcpyAsync(w->b_pos0.p + i + k, pos0.data() + k, sizeof(float4), hipMemcpyHostToDevice, s));
+			w->bodies[i + k].resetSweep = 0;
+		}
 		HIP_TRY(hipMemcpyAsync(w->b_vel.p + i, vel.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(w->b_xf.p + i, xf.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(w->b_mass.p + i, mass.data(), cnt * sizeof(float4), hipMemcpyHostToDevice, s));
@@ -791,6 +838,17 @@ static int flushEdits(b2hip_world* w)
 	}
 	w->dirtyList.clear();
 	w->upBodies = nb;
+
+	// ---- island seed order (m_nonStaticBodies): rewritten whole when a non-static body was created or destroyed
+	if (w->orderDirty)
+	{
+		std::vector<int> order(nb, 0x7fffffff);
+		for (size_t k = 0; k < w->nonStatic.size(); ++k) order[(size_t)w->nonStatic[k]] = (int)k;
+		HIP_TRY(hipMemcpyAsync(w->b_order.p, order.data(), nb * sizeof(int), hipMemcpyHostToDevice, s));
+		if (!w->nonStatic.empty()) HIP_TRY(hipMemcpyAsync(w->orderBody.p, w->nonStatic.data(), w->nonStatic.size() * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		w->orderDirty = false;
+	}
 
 	// ---- shapes / joints: small tables, rewritten whole when they grew -----------------------------
 	if (w->upShapes != w->shapes.size())
@@ -875,6 +933,22 @@ static int flushEdits(b2hip_world* w)
 
 	// ---- new proxies -----------------------------------------------------------------------------
 	const size_t np = w->fixtures.size();
+	if (w->proxyListsStale && w->upFixtures == np && np > 0)
+	{
+		// a fixture was destroyed: the per-body proxy lists (newest first) are rebuilt without it
+		std::vector<int> head(w->bodies.size(), -1), next(np, -1);
+		for (size_t k = 0; k < np; ++k)
+		{
+			if (w->fixtures[k].dead) continue;
+			const int b = w->fixtures[k].body;
+			next[k] = head[b];
+			head[b] = (int)k;
+		}
+		HIP_TRY(hipMemcpyAsync(w->b_proxyHead.p, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(w->p_next.p, next.data(), np * sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		w->proxyListsStale = false;
+	}
 	if (w->upFixtures < np)
 	{
 		const size_t first = w->upFixtures, cnt = np - first;
@@ -886,7 +960,7 @@ static int flushEdits(b2hip_world* w)
 		{
 			const HostFixture& f = w->fixtures[first + k];
 			fat[k] = make_float4(f.fat[0], f.fat[1], f.fat[2], f.fat[3]);
-			body[k] = f.body;
+			body[k] = f.dead ? -1 : f.body;
 			shape[k] = f.shape;
 			key[k] = f.proxyKey;
 			f0[k] = (uint32_t)f.categoryBits | ((uint32_t)f.maskBits << 16);
@@ -904,6 +978,7 @@ static int flushEdits(b2hip_world* w)
 		std::vector<int> head(w->bodies.size(), -1), next(np, -1);
 		for (size_t k = 0; k < np; ++k)
 		{
+			if (w->fixtures[k].dead) continue;
 			const int b = w->fixtures[k].body;
 			next[k] = head[b];
 			head[b] = (int)k;
@@ -912,6 +987,7 @@ static int flushEdits(b2hip_world* w)
 		HIP_TRY(hipMemcpyAsync(w->p_next.p, next.data(), np * sizeof(int), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		w->upFixtures = np;
+		w->proxyListsStale = false;
 
 		// Broad-phase cell: 1.5 x the largest fat extent among non-static proxies, ignoring outliers
 		// (> 8 x median), which are handled by the brute-force "large proxy" path.
@@ -919,7 +995,7 @@ static int flushEdits(b2hip_world* w)
 		for (size_t k = 0; k < np; ++k)
 		{
 			const HostFixture& f = w->fixtures[k];
-			if (w->bodies[f.body].type == B2HIP_STATIC_BODY) continue;
+			if (f.dead || w->bodies[f.body].type == B2HIP_STATIC_BODY) continue;
 			ext.push_back(std::max(f.fat[2] - f.fat[0], f.fat[3] - f.fat[1]));
 		}
 		float cell = 1.0f;
@@ -936,6 +1012,29 @@ static int flushEdits(b2hip_world* w)
 		}
 		w->dw.cellSize = cell;
 		w->dw.invCellSize = 1.0f / cell;
+	}
+
+	// ---- edited proxies of fixtures the device already has: fat AABB (SetTransform), filter words (SetFilterData,
+	// SetSensor, SetThickShape), owner (-1: the fixture was destroyed)
+	if (!w->proxyEdits.empty())
+	{
+		std::sort(w->proxyEdits.begin(), w->proxyEdits.end());
+		w->proxyEdits.erase(std::unique(w->proxyEdits.begin(), w->proxyEdits.end()), w->proxyEdits.end());
+		for (size_t k = 0; k < w->proxyEdits.size(); ++k)
+		{
+			const int id = w->proxyEdits[k];
+			if ((size_t)id >= w->upFixtures) continue; // (a new fixture: uploaded whole above)
+			const HostFixture& f = w->fixtures[id];
+			const float4 fat = make_float4(f.fat[0], f.fat[1], f.fat[2], f.fat[3]);
+			const int body = f.dead ? -1 : f.body;
+			const uint32_t f0 = (uint32_t)f.categoryBits | ((uint32_t)f.maskBits << 16);
+			const int f1 = ((int)(uint16_t)f.groupIndex) | (f.isSensor ? PF_SENSOR : 0) | (f.thick ? PF_THICK : 0);
+			HIP_TRY(hipMemcpy(w->p_fat.p + id, &fat, sizeof(float4), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(w->p_body.p + id, &body, sizeof(int), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(w->p_filter0.p + id, &f0, sizeof(uint32_t), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(w->p_filter1.p + id, &f1, sizeof(int), hipMemcpyHostToDevice));
+		}
+		w->proxyEdits.clear();
 	}
 
 	// ---- move buffer: proxies created since the last step (b2BroadPhase::CreateProxy buffers a move)
@@ -987,6 +1086,35 @@ static int applyPendingFilters(b2hip_world* w)
 	HIP_TRY(hipStreamSynchronize(w->stream)); // `keys` is pageable host memory
 	w->pendingFilter.clear();
 	w->refilterPending = true;
+	return 0;
+}
+
+// Applies the queued contact-array ops (b2d_kernels_edit.h) in call order, then compacts the contact array if contacts
+// were destroyed. Called by the step right after its counters are zeroed, and by whoever reads the contacts between steps.
+static int applyEditOps(b2hip_world* w)
+{
+	if (w->editOps.empty()) return 0;
+	bool destroys = false;
+	for (size_t k = 0; k < w->editOps.size(); ++k) destroys = destroys || w->editOps[k].x == EDIT_DESTROY_BODY || w->editOps[k].x == EDIT_DESTROY_FIXTURE;
+	int rc = w->d_editOps.ensure(w->editOps.size(), w->stream, false, false);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(w->d_editOps.p, w->editOps.data(), w->editOps.size() * sizeof(int2), hipMemcpyHostToDevice, w->stream));
+	DW& d = w->dw;
+	LAUNCH(w, k_apply_edits, 1, 1024, d, (const int2*)w->d_editOps.p, (int)w->editOps.size());
+	if (destroys)
+	{
+		LAUNCH(w, k_edit_keepflags, gridFor(d.capContacts), 256, d);
+		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_compact_finish, 1, 1, d);
+		LAUNCH(w, k_edit_finish, 1, 1, d);
+	}
+	rc = readState(w); // (also makes the staging vector reusable)
+	if (rc) return rc;
+	w->editOps.clear();
+	if (w->h_dstate->c.overflow & 128) return setError(B2HIP_ERR_CAPACITY, "more than 8192 contacts on one edited body / fixture");
+	w->lastContacts = w->h_dstate->c.nContacts;
+	w->last.nContacts = w->lastContacts;
 	return 0;
 }
 
@@ -1966,6 +2094,8 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
 	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
 	w->filterPairs.release();
+	w->d_editOps.release();
+	w->b_order.release(); w->orderBody.release();
 	w->pre_o0.release(); w->pre_o1.release(); w->pre_oimp.release(); w->pre_o3.release(); w->preRecs.release();
 	w->postRecs.release(); w->filterList.release(); w->hostList.release();
 	w->b_blk1.release(); w->b_adopt.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release();
@@ -2053,6 +2183,14 @@ int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def)
 	b.I = 0.0f;
 	b.invI = 0.0f;
 	b.dirty = true;
+	b.worldIndex = -1;
+	if (def->type != B2HIP_STATIC_BODY)
+	{
+		// b2World::CreateBody (b2World.cpp:571-575): appended to m_nonStaticBodies
+		b.worldIndex = (int)w->nonStatic.size();
+		w->nonStatic.push_back((int)w->bodies.size());
+		w->orderDirty = true;
+	}
 	w->bodies.push_back(b);
 	w->dirtyList.push_back((int)w->bodies.size() - 1);
 	return (int)w->bodies.size() - 1;
@@ -2083,6 +2221,7 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def,
 	markDirty(w, body);
 	HostBody& b = w->bodies[body];
 	HostFixture f;
+	memset(&f, 0, sizeof(f));
 	f.body = body;
 	f.shape = internShape(w, rec);
 	f.density = def->density;
@@ -2100,6 +2239,7 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def,
 	f.fat[2] = aabb.hi.x + B2D_AABB_EXTENSION;
 	f.fat[3] = aabb.hi.y + B2D_AABB_EXTENSION;
 	f.proxyKey = allocProxyKey(w);
+	if (f.proxyKey < 0) return setError(B2HIP_ERR_UNSUPPORTED, "proxy id reuse after the broad-phase tree was emptied is not modelled");
 	const int id = (int)w->fixtures.size();
 	w->fixtures.push_back(f);
 	b.fixtures.push_back(id);
@@ -2538,6 +2678,8 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	w->toiCountersFresh = true;
 	rc = applyPendingFilters(w);
 	if (rc) return rc;
+	rc = applyEditOps(w); // (after k_step_begin: the end events of destroyed contacts belong to this step's list)
+	if (rc) return rc;
 	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
 	// b2World.cpp:1628-1639: new fixtures -> find their contacts before colliding
 	if (w->newFixture)
@@ -2548,6 +2690,299 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	}
 	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[1], w->stream));
 	return 0;
+}
+
+// ---- life cycle and mutators ---------------------------------------------------------------------------------------------
+static int checkBody(b2hip_world* w, int body, const char* what)
+{
+	if (int rcu = checkUsable(w, what, true)) return rcu;
+	if (body < 0 || body >= (int)w->bodies.size() || w->bodies[body].dead) return setError(B2HIP_ERR_INVALID, std::string(what) + ": bad body id");
+	return 0;
+}
+
+static int checkFixture(b2hip_world* w, int fixture, const char* what)
+{
+	if (int rcu = checkUsable(w, what, true)) return rcu;
+	if (fixture < 0 || fixture >= (int)w->fixtures.size() || w->fixtures[fixture].dead) return setError(B2HIP_ERR_INVALID, std::string(what) + ": bad fixture id");
+	return 0;
+}
+
+static void queueOp(b2hip_world* w, int kind, int id)
+{
+	w->editOps.push_back(make_int2(kind, id));
+}
+
+// b2Fixture::DestroyProxies (b2Fixture.cpp:143-157) + the host bookkeeping of a fixture that is gone
+static void dropFixture(b2hip_world* w, int fixture)
+{
+	HostFixture& f = w->fixtures[fixture];
+	freeProxyKey(w, f.proxyKey);
+	f.dead = true;
+	w->proxyEdits.push_back(fixture);
+	w->proxyListsStale = true;
+	// (a proxy created since the last step and not yet buffered on the device leaves the pending moves too: UnBufferMove)
+	w->pendingMoves.erase(std::remove(w->pendingMoves.begin(), w->pendingMoves.end(), fixture), w->pendingMoves.end());
+}
+
+int b2hip_destroy_fixture(b2hip_world* w, int fixture)
+{
+	if (int rc = checkFixture(w, fixture, "b2hip_destroy_fixture")) return rc;
+	const int body = w->fixtures[fixture].body;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	queueOp(w, EDIT_DESTROY_FIXTURE, fixture);
+	b.fixtures.erase(std::remove(b.fixtures.begin(), b.fixtures.end(), fixture), b.fixtures.end());
+	dropFixture(w, fixture);
+	resetMassData(w, b);
+	return B2HIP_OK;
+}
+
+int b2hip_destroy_body(b2hip_world* w, int body)
+{
+	if (int rc = checkBody(w, body, "b2hip_destroy_body")) return rc;
+	// joints first, newest first (the body's joint list is newest first, b2World.cpp:697-710)
+	for (int j = (int)w->joints.size() - 1; j >= 0; --j)
+	{
+		if (w->joints[j].type == B2D_JOINT_DEAD) continue;
+		bool touches = w->joints[j].bodyA == body || w->joints[j].bodyB == body;
+		if (w->joints[j].type == B2D_JOINT_GEAR)
+		{
+			const GearRec& g = w->gears[w->joints[j].enableLimit];
+			touches = touches || g.bodyC == body || g.bodyD == body;
+		}
+		if (touches)
+		{
+			const int rc = b2hip_destroy_joint(w, j);
+			if (rc) return rc;
+		}
+	}
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	queueOp(w, EDIT_DESTROY_BODY, body);
+	for (int k = (int)b.fixtures.size() - 1; k >= 0; --k) dropFixture(w, b.fixtures[k]); // newest first
+	b.fixtures.clear();
+	if (b.worldIndex >= 0)
+	{
+		// b2RemoveAndSwapBack on m_nonStaticBodies (b2World.cpp:662-667)
+		const int slot = b.worldIndex, last = w->nonStatic.back();
+		w->nonStatic[(size_t)slot] = last;
+		w->bodies[last].worldIndex = slot;
+		w->nonStatic.pop_back();
+		b.worldIndex = -1;
+		w->orderDirty = true;
+	}
+	b.dead = 1;
+	b.type = B2HIP_STATIC_BODY;
+	b.flags &= ~(BF_ACTIVE | BF_AWAKE | BF_BULLET);
+	b.vx = b.vy = b.w = 0.0f;
+	b.fx = b.fy = b.torque = 0.0f;
+	b.invMass = b.invI = 0.0f;
+	return B2HIP_OK;
+}
+
+int b2hip_body_is_destroyed(const b2hip_world* w, int body)
+{
+	return w && body >= 0 && body < (int)w->bodies.size() && w->bodies[body].dead ? 1 : 0;
+}
+
+int b2hip_fixture_is_destroyed(const b2hip_world* w, int fixture)
+{
+	return w && fixture >= 0 && fixture < (int)w->fixtures.size() && w->fixtures[fixture].dead ? 1 : 0;
+}
+
+// The fat AABB a fixture's proxy has right now (the device owns it once the fixture is uploaded)
+static int currentFat(b2hip_world* w, int fixture, float out4[4])
+{
+	if ((size_t)fixture >= w->upFixtures || std::find(w->proxyEdits.begin(), w->proxyEdits.end(), fixture) != w->proxyEdits.end())
+	{
+		memcpy(out4, w->fixtures[fixture].fat, 16);
+		return 0;
+	}
+	DEVICE_GUARD(w);
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	HIP_TRY(hipMemcpy(out4, w->p_fat.p + fixture, 16, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_transform")) return rc;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	b.qs = sinf(angle);
+	b.qc = cosf(angle);
+	b.px = x;
+	b.py = y;
+	const V2 c = b2dMulXV(hostXf(b), v2(b.lcx, b.lcy));
+	b.cx = b.c0x = c.x;
+	b.cy = b.c0y = c.y;
+	b.a = b.a0 = angle;
+	b.resetSweep = 1;
+	// b2Fixture::Synchronize(broadPhase, xf, xf) for every fixture, newest first -> b2DynamicTree::MoveProxy with zero displacement
+	for (int k = (int)b.fixtures.size() - 1; k >= 0; --k)
+	{
+		const int id = b.fixtures[k];
+		HostFixture& f = w->fixtures[id];
+		float fat[4];
+		if (int rc = currentFat(w, id, fat)) return rc;
+		const AABB aabb = b2dShapeAABB(&w->shapes[f.shape], hostXf(b));
+		if (fat[0] <= aabb.lo.x && fat[1] <= aabb.lo.y && aabb.hi.x <= fat[2] && aabb.hi.y <= fat[3])
+		{
+			memcpy(f.fat, fat, 16);
+			continue;
+		}
+		f.fat[0] = aabb.lo.x - B2D_AABB_EXTENSION;
+		f.fat[1] = aabb.lo.y - B2D_AABB_EXTENSION;
+		f.fat[2] = aabb.hi.x + B2D_AABB_EXTENSION;
+		f.fat[3] = aabb.hi.y + B2D_AABB_EXTENSION;
+		w->proxyEdits.push_back(id);
+		if ((size_t)id < w->upFixtures || std::find(w->pendingMoves.begin(), w->pendingMoves.end(), id) == w->pendingMoves.end()) w->pendingMoves.push_back(id);
+		w->newFixture = w->newFixture; // (moves alone do not ask for the top-of-step pair update: the end-of-step one takes them)
+	}
+	return B2HIP_OK;
+}
+
+int b2hip_set_awake(b2hip_world* w, int body, int awake)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_awake")) return rc;
+	if (awake)
+	{
+		setAwake(w, body);
+		return B2HIP_OK;
+	}
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	b.flags &= ~BF_AWAKE;
+	b.sleepTime = 0.0f;
+	b.vx = b.vy = b.w = 0.0f;
+	b.fx = b.fy = b.torque = 0.0f;
+	return B2HIP_OK;
+}
+
+int b2hip_set_bullet(b2hip_world* w, int body, int bullet)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_bullet")) return rc;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	const bool was = (b.flags & BF_BULLET) != 0;
+	if (bullet) b.flags |= BF_BULLET; else b.flags &= ~BF_BULLET;
+	if (was != (bullet != 0)) queueOp(w, EDIT_RECALC_BODY, body);
+	return B2HIP_OK;
+}
+
+int b2hip_apply_linear_impulse(b2hip_world* w, int body, float ix, float iy, float px, float py, int wake)
+{
+	if (int rc = checkBody(w, body, "b2hip_apply_linear_impulse")) return rc;
+	if (w->bodies[body].type != B2HIP_DYNAMIC_BODY) return B2HIP_OK;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (wake && (b.flags & BF_AWAKE) == 0)
+	{
+		b.flags |= BF_AWAKE;
+		b.sleepTime = 0.0f;
+	}
+	if (b.flags & BF_AWAKE)
+	{
+		// b2Body.h:915-921
+		const float sx = b.invMass * ix, sy = b.invMass * iy;
+		b.vx += sx;
+		b.vy += sy;
+		b.w += b.invI * ((px - b.cx) * iy - (py - b.cy) * ix);
+	}
+	return B2HIP_OK;
+}
+
+int b2hip_apply_linear_impulse_to_center(b2hip_world* w, int body, float ix, float iy, int wake)
+{
+	if (int rc = checkBody(w, body, "b2hip_apply_linear_impulse_to_center")) return rc;
+	if (w->bodies[body].type != B2HIP_DYNAMIC_BODY) return B2HIP_OK;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (wake && (b.flags & BF_AWAKE) == 0)
+	{
+		b.flags |= BF_AWAKE;
+		b.sleepTime = 0.0f;
+	}
+	if (b.flags & BF_AWAKE)
+	{
+		const float sx = b.invMass * ix, sy = b.invMass * iy; // b2Body.h:923-942
+		b.vx += sx;
+		b.vy += sy;
+	}
+	return B2HIP_OK;
+}
+
+int b2hip_apply_angular_impulse(b2hip_world* w, int body, float impulse, int wake)
+{
+	if (int rc = checkBody(w, body, "b2hip_apply_angular_impulse")) return rc;
+	if (w->bodies[body].type != B2HIP_DYNAMIC_BODY) return B2HIP_OK;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (wake && (b.flags & BF_AWAKE) == 0)
+	{
+		b.flags |= BF_AWAKE;
+		b.sleepTime = 0.0f;
+	}
+	if (b.flags & BF_AWAKE) b.w += b.invI * impulse;
+	return B2HIP_OK;
+}
+
+int b2hip_fixture_set_sensor(b2hip_world* w, int fixture, int is_sensor)
+{
+	if (int rc = checkFixture(w, fixture, "b2hip_fixture_set_sensor")) return rc;
+	HostFixture& f = w->fixtures[fixture];
+	if (f.isSensor == (is_sensor != 0)) return B2HIP_OK;
+	setAwake(w, f.body);
+	f.isSensor = is_sensor != 0;
+	w->proxyEdits.push_back(fixture);
+	queueOp(w, EDIT_SENSOR_FIXTURE, fixture);
+	queueOp(w, EDIT_RECALC_FIXTURE, fixture);
+	return B2HIP_OK;
+}
+
+int b2hip_fixture_set_thick(b2hip_world* w, int fixture, int thick_shape)
+{
+	if (int rc = checkFixture(w, fixture, "b2hip_fixture_set_thick")) return rc;
+	HostFixture& f = w->fixtures[fixture];
+	if (f.thick == (thick_shape != 0)) return B2HIP_OK;
+	f.thick = thick_shape != 0;
+	w->proxyEdits.push_back(fixture);
+	queueOp(w, EDIT_RECALC_FIXTURE, fixture);
+	return B2HIP_OK;
+}
+
+int b2hip_fixture_refilter(b2hip_world* w, int fixture)
+{
+	if (int rc = checkFixture(w, fixture, "b2hip_fixture_refilter")) return rc;
+	queueOp(w, EDIT_REFILTER_FIXTURE, fixture);
+	w->refilterPending = true;
+	// TouchProxy (b2BroadPhase.cpp:70-73): the proxy is buffered as moved so that new pairs can form
+	if (w->bodies[w->fixtures[fixture].body].flags & BF_ACTIVE) w->pendingMoves.push_back(fixture);
+	return B2HIP_OK;
+}
+
+int b2hip_fixture_set_filter(b2hip_world* w, int fixture, uint16_t category_bits, uint16_t mask_bits, int16_t group_index)
+{
+	if (int rc = checkFixture(w, fixture, "b2hip_fixture_set_filter")) return rc;
+	HostFixture& f = w->fixtures[fixture];
+	f.categoryBits = category_bits;
+	f.maskBits = mask_bits;
+	f.groupIndex = group_index;
+	w->proxyEdits.push_back(fixture);
+	return b2hip_fixture_refilter(w, fixture);
+}
+
+int b2hip_joint_set_spring(b2hip_world* w, int joint, float frequency_hz, float damping_ratio)
+{
+	if (int rcu = checkUsable(w, "b2hip_joint_set_spring", true)) return rcu;
+	if (joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	JointRec& j = w->joints[joint];
+	if (j.type != B2D_JOINT_WHEEL && j.type != B2D_JOINT_DISTANCE && j.type != B2D_JOINT_WELD && j.type != B2D_JOINT_MOUSE)
+		return setError(B2HIP_ERR_INVALID, "joint type has no spring");
+	j.frequencyHz = frequency_hz;
+	j.dampingRatio = damping_ratio;
+	w->jointEdits.push_back(std::make_pair(joint, 0));
+	return B2HIP_OK;
 }
 
 int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)
@@ -3015,9 +3450,22 @@ int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state
 	return 0;
 }
 
+// Edits queued since the last step (destroyed bodies / fixtures ...) change the contact list at once in the reference:
+// whoever looks at the contacts between steps sees them applied.
+static int flushForRead(b2hip_world* w)
+{
+	if (w->editOps.empty() || w->stepActive || w->failed) return 0;
+	DEVICE_GUARD(w);
+	int rc = flushEdits(w);
+	if (rc) return rc;
+	return applyEditOps(w);
+}
+
 int b2hip_contact_count(b2hip_world* w)
 {
-	return w ? w->lastContacts : 0;
+	if (!w) return 0;
+	(void)flushForRead(w);
+	return w->lastContacts;
 }
 
 int b2hip_enable_contact_events(b2hip_world* w, int enable)
@@ -3100,6 +3548,8 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	int rc = flushEdits(w); // everything the host has created or edited is on the device now
 	if (rc) return rc;
 	rc = applyPendingFilters(w); // ... including the re-filter flags of joints created / destroyed since the last step
+	if (rc) return rc;
+	rc = applyEditOps(w);
 	if (rc) return rc;
 	rc = readState(w);
 	if (rc) return rc;
@@ -3213,7 +3663,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	{
 		FreeUnit fu;
 		memcpy(&fu, freeAt + k, sizeof(fu));
-		if (fu.leaf < 0 || fu.leaf >= h.nextNode) return corrupt("proxy id free list");
+		if (fu.leaf < -1 || fu.leaf >= h.nextNode) return corrupt("proxy id free list");
 	}
 	DState ds;
 	memcpy(&ds, dsAt, sizeof(ds));
@@ -3293,6 +3743,20 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 		w->bodies[i].dirty = bodiesAt[i * bodyBytes + offsetof(HostBody, fixtures)] != 0;
 		if (w->bodies[i].dirty) w->dirtyList.push_back((int)i);
 	}
+	{
+		// m_nonStaticBodies from the saved slots
+		size_t count = 0;
+		for (size_t i = 0; i < nb; ++i) count += w->bodies[i].worldIndex >= 0 ? 1 : 0;
+		w->nonStatic.assign(count, -1);
+		for (size_t i = 0; i < nb; ++i)
+		{
+			const int k = w->bodies[i].worldIndex;
+			if (k < 0) continue;
+			if ((size_t)k >= count || w->nonStatic[(size_t)k] != -1) return fail(corrupt("non-static body order"));
+			w->nonStatic[(size_t)k] = (int)i;
+		}
+		w->orderDirty = true;
+	}
 	w->fixtures.resize(np);
 	if (np) memcpy(w->fixtures.data(), fixturesAt, np * sizeof(HostFixture));
 	w->shapes.resize(nS);
@@ -3343,7 +3807,9 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
 	DEVICE_GUARD(w);
 	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
-	int rc = readState(w);
+	int rc = flushForRead(w);
+	if (rc) return rc;
+	rc = readState(w);
 	if (rc) return rc;
 	const int n = std::min(cap, w->h_dstate->c.nContacts);
 	const int cur = w->h_dstate->cur;

@@ -46,6 +46,8 @@ public:
 	void EnableMotor(bool flag);
 	void SetMotorSpeed(float32 speed);
 	void SetMaxMotorTorque(float32 torque);
+	void SetSpringFrequencyHz(float32 hz);
+	void SetSpringDampingRatio(float32 ratio);
 
 protected:
 	friend class b2World;

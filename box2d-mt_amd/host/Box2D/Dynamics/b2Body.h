@@ -57,6 +57,8 @@ struct b2BodyDef
 	float32 gravityScale;
 };
 
+struct b2ContactEdge;
+
 class b2Body
 {
 public:
@@ -75,6 +77,18 @@ public:
 	void ApplyForce(const b2Vec2& force, const b2Vec2& point, bool wake);
 	void ApplyForceToCenter(const b2Vec2& force, bool wake);
 	void ApplyTorque(float32 torque, bool wake);
+	void ApplyLinearImpulse(const b2Vec2& impulse, const b2Vec2& point, bool wake);
+	void ApplyLinearImpulseToCenter(const b2Vec2& impulse, bool wake);
+	void ApplyAngularImpulse(float32 impulse, bool wake);
+	/// b2Body.cpp:451-473: pose and sweep are set, the fixtures' proxies follow (a no-op while the world is locked)
+	void SetTransform(const b2Vec2& position, float32 angle);
+	void SetAwake(bool flag);
+	void SetBullet(bool flag);
+	/// b2Body.cpp:238-308; the fixture pointer is dead afterwards
+	void DestroyFixture(b2Fixture* fixture);
+	/// The body's contact edges, newest contact first (b2Body.h:431-436); valid until the next Step or edit.
+	b2ContactEdge* GetContactList();
+	const b2ContactEdge* GetContactList() const { return const_cast<b2Body*>(this)->GetContactList(); }
 	float32 GetMass() const;
 	float32 GetInertia() const;
 	void GetMassData(b2MassData* data) const;

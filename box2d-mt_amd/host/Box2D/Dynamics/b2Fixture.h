@@ -64,6 +64,11 @@ public:
 	bool IsSensor() const { return m_isSensor; }
 	bool IsThickShape() const { return m_isThickShape; }
 	const b2Filter& GetFilterData() const { return m_filter; }
+	/// b2Fixture.cpp:180-257: the next Collide filters the fixture's contacts again / TOI candidacy is re-evaluated
+	void SetFilterData(const b2Filter& filter);
+	void Refilter();
+	void SetSensor(bool sensor);
+	void SetThickShape(bool flag);
 	b2Body* GetBody() { return m_body; }
 	const b2Body* GetBody() const { return m_body; }
 	b2Fixture* GetNext() { return m_next; }

@@ -43,6 +43,10 @@ public:
 	void SetContactListener(b2ContactListener* listener);
 
 	b2Body* CreateBody(const b2BodyDef* def);
+	/// b2World.cpp:585-670: joints (SayGoodbye), contacts, fixtures (SayGoodbye) and the body; the pointer is dead afterwards
+	void DestroyBody(b2Body* body);
+	/// Box2D-MT's sub-tree broad-phase knob (b2World.h:199-206): accepted and ignored (the device broad-phase is a hash grid)
+	void SetSubTreeSize(float32 subTreeWidth, float32 subTreeHeight) { B2_NOT_USED(subTreeWidth); B2_NOT_USED(subTreeHeight); }
 	b2Joint* CreateJoint(const b2JointDef* def);
 	void DestroyJoint(b2Joint* joint);   // reference: b2World.cpp:762-846 (destroy a gear joint before the joints it couples)
 
@@ -124,6 +128,9 @@ private:
 	mutable bool m_statesValid;
 	std::vector<b2Contact> m_contactViews;
 	bool m_contactsValid;
+	std::vector<b2ContactEdge> m_edgeViews; // b2Body::GetContactList: edges of one body, rebuilt per call
+	void DestroyFixtureView(b2Fixture* f);
+	void EndContactsOf(b2Body* body, b2Fixture* fixture);
 };
 
 #endif

@@ -156,6 +156,78 @@ b2Body* b2World::CreateBody(const b2BodyDef* def)
 	return b;
 }
 
+// The host-side view of a fixture that is gone (its shape clone included); the id stays reserved on the device
+void b2World::DestroyFixtureView(b2Fixture* f)
+{
+	if (f->m_id >= 0 && f->m_id < (int32)m_fixtures.size()) m_fixtures[f->m_id] = nullptr;
+	if (f->m_shape)
+	{
+		f->m_shape->~b2Shape();
+		b2Free(f->m_shape);
+	}
+	f->~b2Fixture();
+	b2Free(f);
+}
+
+// b2ContactManager::Destroy (b2ContactManager.cpp:104-107) for the contacts that go with a body (fixture == nullptr) or a
+// fixture: a touching contact ends, and the listener hears it while the fixtures still exist.
+void b2World::EndContactsOf(b2Body* body, b2Fixture* fixture)
+{
+	if (!m_contactListener) return;
+	(void)GetContactList();
+	for (size_t i = 0; i < m_contactViews.size(); ++i)
+	{
+		b2Contact* c = &m_contactViews[i];
+		if (!c->m_touching) continue;
+		const bool mine = fixture ? (c->m_fixtureA == fixture || c->m_fixtureB == fixture)
+		                          : (c->m_fixtureA->GetBody() == body || c->m_fixtureB->GetBody() == body);
+		if (mine && m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
+	}
+}
+
+void b2World::DestroyBody(b2Body* b)
+{
+	if (IsLocked() || !m_hip || b == nullptr) return;
+	EndContactsOf(b, nullptr);
+	// joints attached to the body: SayGoodbye, then gone (b2World.cpp:595-611); b2hip_destroy_body destroys them on the device
+	for (b2Joint* j = m_jointList; j != nullptr;)
+	{
+		b2Joint* next = j->m_next;
+		if (j->m_bodyA == b || j->m_bodyB == b)
+		{
+			if (m_destructionListener) m_destructionListener->SayGoodbye(j);
+			DestroyJoint(j);
+		}
+		j = next;
+	}
+	for (b2Fixture* f = b->m_fixtureList; f != nullptr; f = f->m_next)
+	{
+		if (m_destructionListener) m_destructionListener->SayGoodbye(f);
+	}
+	if (b2hip_destroy_body(m_hip, b->m_id) != B2HIP_OK)
+	{
+		fprintf(stderr, "b2World::DestroyBody: %s\n", b2hip_last_error());
+		return;
+	}
+	for (b2Fixture* f = b->m_fixtureList; f != nullptr;)
+	{
+		b2Fixture* next = f->m_next;
+		DestroyFixtureView(f);
+		f = next;
+	}
+	b->m_fixtureList = nullptr;
+	if (b->m_prev) b->m_prev->m_next = b->m_next;
+	if (b->m_next) b->m_next->m_prev = b->m_prev;
+	if (b == m_bodyList) m_bodyList = b->m_next;
+	--m_bodyCount;
+	m_bodies[b->m_id] = nullptr;
+	b->~b2Body();
+	b2Free(b);
+	m_statesValid = false;
+	m_contactsValid = false;
+	m_fatValid = false;
+}
+
 b2Joint* b2World::CreateJoint(const b2JointDef* def)
 {
 	if (IsLocked() || !m_hip) return nullptr;
@@ -531,6 +603,8 @@ void b2World::DeliverContactEvents()
 	for (int i = 0; i < count; ++i)
 	{
 		const b2hip_contact_event& e = ev[i];
+		// (the end of a contact that went with its body or fixture was delivered by DestroyBody / DestroyFixture itself)
+		if (e.fixture_a >= (int)m_fixtures.size() || e.fixture_b >= (int)m_fixtures.size() || !m_fixtures[e.fixture_a] || !m_fixtures[e.fixture_b]) continue;
 		b2Contact gone; // the view of a contact that no longer exists (its end event)
 		b2Contact* c = nullptr;
 		if (e.contact_index >= 0 && e.contact_index < n) c = &m_contactViews[n - 1 - e.contact_index];
@@ -904,6 +978,117 @@ void b2Body::ApplyTorque(float32 torque, bool wake)
 	m_world->m_statesValid = false;
 }
 
+void b2Body::ApplyLinearImpulse(const b2Vec2& impulse, const b2Vec2& point, bool wake)
+{
+	b2hip_apply_linear_impulse(m_world->m_hip, m_id, impulse.x, impulse.y, point.x, point.y, wake);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::ApplyLinearImpulseToCenter(const b2Vec2& impulse, bool wake)
+{
+	b2hip_apply_linear_impulse_to_center(m_world->m_hip, m_id, impulse.x, impulse.y, wake);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::ApplyAngularImpulse(float32 impulse, bool wake)
+{
+	b2hip_apply_angular_impulse(m_world->m_hip, m_id, impulse, wake);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::SetTransform(const b2Vec2& position, float32 angle)
+{
+	if (m_world->IsLocked()) return;
+	if (b2hip_set_transform(m_world->m_hip, m_id, position.x, position.y, angle) != B2HIP_OK)
+		fprintf(stderr, "b2Body::SetTransform: %s\n", b2hip_last_error());
+	m_world->m_statesValid = false;
+	m_world->m_fatValid = false;
+}
+
+void b2Body::SetAwake(bool flag)
+{
+	b2hip_set_awake(m_world->m_hip, m_id, flag ? 1 : 0);
+	m_world->m_statesValid = false;
+}
+
+void b2Body::SetBullet(bool flag)
+{
+	m_bullet = flag;
+	b2hip_set_bullet(m_world->m_hip, m_id, flag ? 1 : 0);
+	m_world->m_contactsValid = false;
+}
+
+void b2Body::DestroyFixture(b2Fixture* fixture)
+{
+	if (fixture == nullptr || m_world->IsLocked() || fixture->m_body != this) return;
+	// the reference's order (b2Body.cpp:254-290): out of the body's list first, then its contacts end, then it is destroyed
+	b2Fixture** node = &m_fixtureList;
+	while (*node != nullptr && *node != fixture) node = &(*node)->m_next;
+	if (*node == fixture) *node = fixture->m_next;
+	--m_fixtureCount;
+	m_world->EndContactsOf(this, fixture);
+	if (b2hip_destroy_fixture(m_world->m_hip, fixture->m_id) != B2HIP_OK) fprintf(stderr, "b2Body::DestroyFixture: %s\n", b2hip_last_error());
+	m_world->DestroyFixtureView(fixture);
+	m_world->m_statesValid = false;
+	m_world->m_contactsValid = false;
+	m_world->m_fatValid = false;
+}
+
+b2ContactEdge* b2Body::GetContactList()
+{
+	// edges of this body over the world's contact views (newest contact first, like the reference's per-body list)
+	b2World* w = m_world;
+	(void)w->GetContactList();
+	std::vector<b2ContactEdge>& edges = w->m_edgeViews;
+	edges.clear();
+	for (size_t i = 0; i < w->m_contactViews.size(); ++i)
+	{
+		b2Contact& c = w->m_contactViews[i];
+		b2Body* bA = c.GetFixtureA()->GetBody();
+		b2Body* bB = c.GetFixtureB()->GetBody();
+		if (bA != this && bB != this) continue;
+		b2ContactEdge e;
+		e.other = bA == this ? bB : bA;
+		e.contact = &c;
+		e.prev = nullptr;
+		e.next = nullptr;
+		edges.push_back(e);
+	}
+	for (size_t i = 0; i < edges.size(); ++i)
+	{
+		edges[i].prev = i > 0 ? &edges[i - 1] : nullptr;
+		edges[i].next = i + 1 < edges.size() ? &edges[i + 1] : nullptr;
+	}
+	return edges.empty() ? nullptr : &edges[0];
+}
+
+void b2Fixture::SetFilterData(const b2Filter& filter)
+{
+	m_filter = filter;
+	b2hip_fixture_set_filter(m_body->GetWorld()->GetDeviceWorld(), m_id, filter.categoryBits, filter.maskBits, filter.groupIndex);
+}
+
+void b2Fixture::Refilter()
+{
+	if (m_body == nullptr) return;
+	b2hip_fixture_refilter(m_body->GetWorld()->GetDeviceWorld(), m_id);
+}
+
+void b2Fixture::SetSensor(bool sensor)
+{
+	if (sensor == m_isSensor) return;
+	m_isSensor = sensor;
+	b2hip_fixture_set_sensor(m_body->GetWorld()->GetDeviceWorld(), m_id, sensor ? 1 : 0);
+	m_body->m_world->m_statesValid = false;
+}
+
+void b2Fixture::SetThickShape(bool flag)
+{
+	if (flag == m_isThickShape) return;
+	m_isThickShape = flag;
+	b2hip_fixture_set_thick(m_body->GetWorld()->GetDeviceWorld(), m_id, flag ? 1 : 0);
+}
+
 float32 b2Body::GetMass() const
 {
 	b2hip_mass_data md;
@@ -1056,6 +1241,16 @@ void b2WheelJoint::PushMotor()
 void b2WheelJoint::EnableMotor(bool flag) { m_enableMotor = flag; PushMotor(); }
 void b2WheelJoint::SetMotorSpeed(float32 speed) { m_motorSpeed = speed; PushMotor(); }
 void b2WheelJoint::SetMaxMotorTorque(float32 torque) { m_maxMotorTorque = torque; PushMotor(); }
+void b2WheelJoint::SetSpringFrequencyHz(float32 hz)
+{
+	m_frequencyHz = hz;
+	b2hip_joint_set_spring(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_frequencyHz, m_dampingRatio);
+}
+void b2WheelJoint::SetSpringDampingRatio(float32 ratio)
+{
+	m_dampingRatio = ratio;
+	b2hip_joint_set_spring(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_frequencyHz, m_dampingRatio);
+}
 
 void b2FrictionJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor)
 {

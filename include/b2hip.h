@@ -28,6 +28,9 @@
  *                                                                           Joints/b2RevoluteJoint.cpp:418-452, b2PrismaticJoint.cpp:588-616
  *   b2hip_joint_set_limits           b2{Revolute,Prismatic}Joint::EnableLimit / SetLimits
  *                                                                           Joints/b2RevoluteJoint.cpp:459-500, b2PrismaticJoint.cpp:549-581
+ *   b2hip_destroy_body / _fixture    b2World::DestroyBody, b2Body::DestroyFixture  b2World.cpp:585-670, b2Body.cpp:238-308
+ *   b2hip_set_transform / _awake / _bullet, b2hip_apply_*_impulse           b2Body.cpp:451-473, 575-601; b2Body.h:690-718, 885-950
+ *   b2hip_fixture_set_sensor / _thick / _filter, b2hip_fixture_refilter     b2Fixture.cpp:180-257
  *   b2hip_step                       b2World::Step                          b2World.cpp:1613-1710
  *   b2hip_collide                    b2World::Collide / b2ContactManager::Collide      b2World.cpp:1120-1141, b2ContactManager.cpp:177-230
  *   b2hip_solve                      b2World::Solve (islands + b2Island::Solve)        b2World.cpp:1166-1431, b2Island.cpp:184-396
@@ -341,6 +344,43 @@ int b2hip_destroy_joint(b2hip_world* w, int joint);
  * (limits) restarts the limit impulse from zero; a call that changes nothing does nothing. */
 int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor);
 int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lower, float upper);
+
+/* ---- Life cycle and mutators between steps (all refused inside a step, like the reference's locked world) -------------------
+ * Ids are never reused: a destroyed body / fixture keeps its id (every getter reports it as destroyed), so ids handed
+ * out earlier stay valid. Edits that touch the contact array (destroys, TOI candidacy, re-filtering) are applied in call
+ * order by one device pass at the start of the next step, or when the contacts are read.
+ *
+ * b2World::DestroyBody (b2World.cpp:585-670): its joints (b2hip_destroy_joint each, newest first), then its contacts
+ * (newest first; a touching one reports its EndContact), then its fixtures and their broad-phase proxies (newest first:
+ * proxy ids are freed and reused exactly as the reference's tree does), then the body leaves m_nonStaticBodies (the last
+ * non-static body takes its slot, which is the order islands are seeded in). */
+int b2hip_destroy_body(b2hip_world* w, int body);
+/* b2Body::DestroyFixture (b2Body.cpp:238-308): the fixture's contacts, its proxy, then ResetMassData */
+int b2hip_destroy_fixture(b2hip_world* w, int fixture);
+/* b2Body::SetTransform (b2Body.cpp:451-473): pose and sweep (origin included) are set, every fixture is synchronised with
+ * zero displacement (a proxy that leaves its fat AABB is re-inserted and buffered as moved) */
+int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle);
+/* b2Body::SetAwake (b2Body.h:690-718): true restarts the sleep timer; false also zeroes velocities and forces */
+int b2hip_set_awake(b2hip_world* w, int body, int awake);
+/* b2Body::SetBullet (b2Body.cpp:575-601) + b2ContactManager::RecalculateToiCandidacy (b2ContactManager.cpp:566-640) */
+int b2hip_set_bullet(b2hip_world* w, int body, int bullet);
+/* b2Body::ApplyLinearImpulse / ApplyLinearImpulseToCenter (point = world centre) / ApplyAngularImpulse (b2Body.h:885-950) */
+int b2hip_apply_linear_impulse(b2hip_world* w, int body, float ix, float iy, float px, float py, int wake);
+int b2hip_apply_linear_impulse_to_center(b2hip_world* w, int body, float ix, float iy, int wake);
+int b2hip_apply_angular_impulse(b2hip_world* w, int body, float impulse, int wake);
+/* b2Fixture::SetSensor (b2Fixture.cpp:222-239: wakes the body, re-evaluates TOI candidacy), SetThickShape (:241-257),
+ * SetFilterData + Refilter (:180-220: contacts of the fixture are filtered again by the next Collide, the proxy is
+ * touched so that new pairs can form) */
+int b2hip_fixture_set_sensor(b2hip_world* w, int fixture, int is_sensor);
+int b2hip_fixture_set_thick(b2hip_world* w, int fixture, int thick_shape);
+int b2hip_fixture_set_filter(b2hip_world* w, int fixture, uint16_t category_bits, uint16_t mask_bits, int16_t group_index);
+int b2hip_fixture_refilter(b2hip_world* w, int fixture);
+/* b2WheelJoint / b2DistanceJoint / b2WeldJoint / b2MouseJoint ::SetFrequency / SetSpringFrequencyHz + SetDampingRatio
+ * (e.g. b2WheelJoint.h:125-131): plain member writes, nobody is woken */
+int b2hip_joint_set_spring(b2hip_world* w, int joint, float frequency_hz, float damping_ratio);
+/* 1 if the id names a body / fixture that has been destroyed */
+int b2hip_body_is_destroyed(const b2hip_world* w, int body);
+int b2hip_fixture_is_destroyed(const b2hip_world* w, int fixture);
 
 int b2hip_body_count(const b2hip_world* w);
 int b2hip_fixture_count(const b2hip_world* w);

@@ -116,6 +116,22 @@ typedef struct b2o_contact_event
 	int32_t kind;          /* 0 = begin, 1 = end */
 	int32_t contact_index; /* into b2o_get_contacts of the same step, -1 = destroyed */
 } b2o_contact_event;
+/* life cycle and mutators between steps (semantics and reference lines: include/b2hip.h) */
+void b2o_destroy_body(b2o_world* w, int body);
+void b2o_destroy_fixture(b2o_world* w, int fixture);
+void b2o_set_transform(b2o_world* w, int body, float x, float y, float angle);
+void b2o_set_awake(b2o_world* w, int body, int awake);
+void b2o_set_bullet(b2o_world* w, int body, int bullet);
+void b2o_apply_linear_impulse(b2o_world* w, int body, float ix, float iy, float px, float py, int to_center, int wake);
+void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake);
+void b2o_fixture_set_sensor(b2o_world* w, int fixture, int is_sensor);
+void b2o_fixture_set_thick(b2o_world* w, int fixture, int thick);
+void b2o_fixture_refilter(b2o_world* w, int fixture);
+void b2o_fixture_set_filter(b2o_world* w, int fixture, uint16_t category_bits, uint16_t mask_bits, int16_t group_index);
+void b2o_joint_set_spring(b2o_world* w, int joint, float frequency_hz, float damping_ratio);
+int b2o_body_is_destroyed(const b2o_world* w, int body);
+int b2o_fixture_is_destroyed(const b2o_world* w, int fixture);
+
 /* user contact filter, PreSolve and PostSolve: same protocol and layouts as include/b2hip.h (b2hip_should_collide_fn,
  * b2hip_manifold, b2hip_pre_solve_fn, b2hip_contact_impulse) */
 typedef int (*b2o_should_collide_fn)(void* user, int fixture_a, int fixture_b);

@@ -218,6 +218,38 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
 	return b2o_get_contact_events(w->o, cap, (b2o_contact_event*)out); /* identical layout */
 }
 
+int b2hip_destroy_body(b2hip_world* w, int body) { b2o_destroy_body(w->o, body); return 0; }
+int b2hip_destroy_fixture(b2hip_world* w, int fixture) { b2o_destroy_fixture(w->o, fixture); return 0; }
+int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle) { b2o_set_transform(w->o, body, x, y, angle); return 0; }
+int b2hip_set_awake(b2hip_world* w, int body, int awake) { b2o_set_awake(w->o, body, awake); return 0; }
+int b2hip_set_bullet(b2hip_world* w, int body, int bullet) { b2o_set_bullet(w->o, body, bullet); return 0; }
+int b2hip_apply_linear_impulse(b2hip_world* w, int body, float ix, float iy, float px, float py, int wake)
+{
+	b2o_apply_linear_impulse(w->o, body, ix, iy, px, py, 0, wake);
+	return 0;
+}
+int b2hip_apply_linear_impulse_to_center(b2hip_world* w, int body, float ix, float iy, int wake)
+{
+	b2o_apply_linear_impulse(w->o, body, ix, iy, 0.0f, 0.0f, 1, wake);
+	return 0;
+}
+int b2hip_apply_angular_impulse(b2hip_world* w, int body, float impulse, int wake) { b2o_apply_angular_impulse(w->o, body, impulse, wake); return 0; }
+int b2hip_fixture_set_sensor(b2hip_world* w, int fixture, int is_sensor) { b2o_fixture_set_sensor(w->o, fixture, is_sensor); return 0; }
+int b2hip_fixture_set_thick(b2hip_world* w, int fixture, int thick) { b2o_fixture_set_thick(w->o, fixture, thick); return 0; }
+int b2hip_fixture_refilter(b2hip_world* w, int fixture) { b2o_fixture_refilter(w->o, fixture); return 0; }
+int b2hip_fixture_set_filter(b2hip_world* w, int fixture, uint16_t category_bits, uint16_t mask_bits, int16_t group_index)
+{
+	b2o_fixture_set_filter(w->o, fixture, category_bits, mask_bits, group_index);
+	return 0;
+}
+int b2hip_joint_set_spring(b2hip_world* w, int joint, float frequency_hz, float damping_ratio)
+{
+	b2o_joint_set_spring(w->o, joint, frequency_hz, damping_ratio);
+	return 0;
+}
+int b2hip_body_is_destroyed(const b2hip_world* w, int body) { return b2o_body_is_destroyed(w->o, body); }
+int b2hip_fixture_is_destroyed(const b2hip_world* w, int fixture) { return b2o_fixture_is_destroyed(w->o, fixture); }
+
 int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* user)
 {
 	b2o_set_contact_filter(w->o, (b2o_should_collide_fn)fn, user);

@@ -53,6 +53,8 @@ typedef struct
 	int contactHead;   /* edge id = contact * 2 + side, newest first */
 	int islandIndex;
 	int label;
+	int worldIndex;    /* slot in b2o_world::nonStatic (m_nonStaticBodies), -1 for static bodies */
+	int dead;          /* destroyed: the id stays */
 } body_t;
 
 typedef struct
@@ -66,6 +68,7 @@ typedef struct
 	int proxyId;
 	float fat[4];
 	int nextInBody;
+	int dead;          /* destroyed: the id stays, the proxy is gone */
 } fixture_t;
 
 typedef struct
@@ -128,6 +131,8 @@ struct b2o_world
 	int eventsOn;
 	b2o_contact_event* events; int nEvents, capEvents;
 	uint64_t* eventKeys; int capEventKeys;
+	/* m_nonStaticBodies (b2World.cpp:573, 662-667): island seeds are taken in this order */
+	int* nonStatic; int nNonStatic, capNonStatic;
 	/* the other listener callbacks and the user contact filter (same protocol as include/b2hip.h) */
 	b2o_should_collide_fn filterFn; void* filterUser;
 	b2o_pre_solve_fn preSolveFn; void* preSolveUser;
@@ -207,6 +212,14 @@ int b2o_create_body(b2o_world* w, const b2o_body_def* d)
 	b->jointHead = -1;
 	b->contactHead = -1;
 	b->label = -1;
+	b->worldIndex = -1;
+	if (d->type != 0)
+	{
+		/* b2World::CreateBody (b2World.cpp:571-575) */
+		GROW(w->nonStatic, w->capNonStatic, w->nNonStatic + 1, int);
+		b->worldIndex = w->nNonStatic;
+		w->nonStatic[w->nNonStatic++] = w->nBodies;
+	}
 	return w->nBodies++;
 }
 
@@ -343,7 +356,13 @@ static int alloc_proxy_id(b2o_world* w)
 	int id;
 	if (w->nFreeLeaves > 0)
 	{
+		/* the free list is LIFO; -1 marks the internal node RemoveLeaf gave back under a freed leaf */
 		id = w->freeLeaves[--w->nFreeLeaves];
+		if (w->leafCount > 0)
+		{
+			if (w->nFreeLeaves > 0) --w->nFreeLeaves; /* InsertLeaf's parent node */
+			else w->nextNode++;
+		}
 	}
 	else
 	{
@@ -352,6 +371,15 @@ static int alloc_proxy_id(b2o_world* w)
 	}
 	w->leafCount++;
 	return id;
+}
+
+/* b2DynamicTree::DestroyProxy (b2DynamicTree.cpp:121-128): the parent RemoveLeaf drops, then the leaf */
+static void free_proxy_id(b2o_world* w, int id)
+{
+	GROW(w->freeLeaves, w->capFreeLeaves, w->nFreeLeaves + 2, int);
+	if (w->leafCount > 1) w->freeLeaves[w->nFreeLeaves++] = -1;
+	w->freeLeaves[w->nFreeLeaves++] = id;
+	w->leafCount--;
 }
 
 /* b2Body::CreateFixture b2Body.cpp:182-226, b2Fixture::Create/CreateProxies b2Fixture.cpp:42-141,
@@ -1056,10 +1084,12 @@ static void find_new_contacts(b2o_world* w)
 	{
 		int p = w->moves[k];
 		const fixture_t* fp = &w->fixtures[p];
+		if (fp->dead) continue;
 		for (int q = 0; q < w->nFixtures; ++q)
 		{
 			if (q == p) continue;
 			const fixture_t* fq = &w->fixtures[q];
+			if (fq->dead) continue;
 			if (!fat_overlap(fp->fat, fq->fat)) continue;
 			if (n == cap)
 			{
@@ -1747,8 +1777,10 @@ static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIte
 	int* islandJoints = (int*)malloc(sizeof(int) * (size_t)(w->nJoints + 1));
 	for (int i = 0; i < nb; ++i) w->bodies[i].label = -1;
 	for (int i = 0; i < w->nJoints; ++i) w->joints[i].islandFlag = 0;
-	for (int seedIdx = 0; seedIdx < nb; ++seedIdx)
+	for (int seedSlot = 0; seedSlot < w->nNonStatic; ++seedSlot)
 	{
+		/* seeds in m_nonStaticBodies order (b2World.cpp:1207-1221) */
+		const int seedIdx = w->nonStatic[seedSlot];
 		body_t* seed = &w->bodies[seedIdx];
 		if (seed->type == 0) continue;
 		if (seed->flags & BF_ISLAND) continue;
@@ -2387,3 +2419,254 @@ void b2o_get_toi_stats(const b2o_world* w, int32_t out[2])
 	out[0] = w->toiEvents;
 	out[1] = w->toiCalls;
 }
+
+
+/* ==== life cycle and mutators between steps (same semantics as include/b2hip.h; reference lines cited there) ============ */
+
+/* b2ContactManager::RecalculateToiCandidacy(b2Contact*) (b2ContactManager.cpp:590-640) */
+static void recalc_toi_candidacy(b2o_world* w, int slot)
+{
+	contact_t* c = &w->contacts[slot];
+	int cand = is_toi_candidate(w, &w->fixtures[c->fixtureA], &w->fixtures[c->fixtureB]);
+	if (cand == ((c->flags & CF_TOI_CANDIDATE) != 0)) return;
+	c->flags = (c->flags ^ CF_TOI_CANDIDATE) & ~CF_TOI;
+	c->toiCount = 0;
+	c->toi = 1.0f;
+	if (c->managerIndex < 0) return;
+	if (cand)
+	{
+		/* swap with the first non-candidate: the new candidate takes slot toiCount */
+		int other = w->carray[w->toiCount];
+		w->contacts[other].managerIndex = c->managerIndex;
+		w->carray[c->managerIndex] = other;
+		w->carray[w->toiCount] = slot;
+		c->managerIndex = w->toiCount;
+		w->toiCount++;
+	}
+	else
+	{
+		w->toiCount--;
+		int other = w->carray[w->toiCount];
+		w->contacts[other].managerIndex = c->managerIndex;
+		w->carray[c->managerIndex] = other;
+		w->carray[w->toiCount] = slot;
+		c->managerIndex = w->toiCount;
+	}
+}
+
+static void recalc_body(b2o_world* w, int body, int fixture /* -1: every contact of the body */)
+{
+	for (int e = w->bodies[body].contactHead; e >= 0; )
+	{
+		contact_t* c = &w->contacts[e >> 1];
+		int next = c->next[e & 1];
+		if (fixture < 0 || c->fixtureA == fixture || c->fixtureB == fixture) recalc_toi_candidacy(w, e >> 1);
+		e = next;
+	}
+}
+
+static void unbuffer_move(b2o_world* w, int fixture)
+{
+	int n = 0;
+	for (int k = 0; k < w->nMoves; ++k)
+		if (w->moves[k] != fixture) w->moves[n++] = w->moves[k];
+	w->nMoves = n;
+}
+
+static void buffer_move(b2o_world* w, int fixture)
+{
+	GROW(w->moves, w->capMoves, w->nMoves + 1, int);
+	w->moves[w->nMoves++] = fixture;
+}
+
+/* b2Fixture::DestroyProxies + the bookkeeping of a fixture that is gone */
+static void drop_fixture(b2o_world* w, int fixture)
+{
+	fixture_t* f = &w->fixtures[fixture];
+	free_proxy_id(w, f->proxyId);
+	unbuffer_move(w, fixture);
+	f->dead = 1;
+	f->fat[0] = f->fat[1] = 1e30f; /* overlaps nothing */
+	f->fat[2] = f->fat[3] = -1e30f;
+}
+
+void b2o_destroy_fixture(b2o_world* w, int fixture)
+{
+	fixture_t* f = &w->fixtures[fixture];
+	if (f->dead) return;
+	body_t* b = &w->bodies[f->body];
+	/* unlink from the body's fixture list */
+	int* link = &b->fixtureHead;
+	while (*link >= 0 && *link != fixture) link = &w->fixtures[*link].nextInBody;
+	if (*link == fixture) *link = f->nextInBody;
+	/* its contacts, in the body's contact-list order (b2Body.cpp:262-275) */
+	for (int e = b->contactHead; e >= 0; )
+	{
+		contact_t* c = &w->contacts[e >> 1];
+		int next = c->next[e & 1];
+		if (c->fixtureA == fixture || c->fixtureB == fixture) destroy_contact(w, e >> 1);
+		e = next;
+	}
+	drop_fixture(w, fixture);
+	reset_mass(w, b);
+}
+
+void b2o_destroy_body(b2o_world* w, int body)
+{
+	body_t* b = &w->bodies[body];
+	if (b->dead) return;
+	/* joints, newest first; a gear joint goes with a body of the joints it couples */
+	for (int j = w->nJoints - 1; j >= 0; --j)
+	{
+		revolute_t* jt = &w->joints[j];
+		if (jt->type < 0) continue;
+		int touches = jt->bodyA == body || jt->bodyB == body;
+		if (jt->type == B2O_JOINT_GEAR) touches = touches || jt->bodyC == body || jt->bodyD == body;
+		if (touches) b2o_destroy_joint(w, j);
+	}
+	for (int e = b->contactHead; e >= 0; )
+	{
+		int next = w->contacts[e >> 1].next[e & 1];
+		destroy_contact(w, e >> 1);
+		e = next;
+	}
+	for (int f = b->fixtureHead; f >= 0; )
+	{
+		int next = w->fixtures[f].nextInBody;
+		drop_fixture(w, f);
+		f = next;
+	}
+	b->fixtureHead = -1;
+	if (b->worldIndex >= 0)
+	{
+		/* b2RemoveAndSwapBack on m_nonStaticBodies (b2World.cpp:662-667) */
+		int slot = b->worldIndex, last = w->nonStatic[w->nNonStatic - 1];
+		w->nonStatic[slot] = last;
+		w->bodies[last].worldIndex = slot;
+		w->nNonStatic--;
+		b->worldIndex = -1;
+	}
+	b->dead = 1;
+	b->type = 0;
+	b->flags &= ~(BF_ACTIVE | BF_AWAKE | BF_BULLET);
+	b->v = v_make(0.0f, 0.0f);
+	b->w = 0.0f;
+	b->force = v_make(0.0f, 0.0f);
+	b->torque = 0.0f;
+	b->invMass = b->invI = 0.0f;
+}
+
+/* b2Body::SetTransform (b2Body.cpp:451-473) */
+void b2o_set_transform(b2o_world* w, int body, float x, float y, float angle)
+{
+	body_t* b = &w->bodies[body];
+	b->xf.q = r_make(angle);
+	b->xf.p = v_make(x, y);
+	b->c = xf_mul(b->xf, b->localCenter);
+	b->a = angle;
+	b->c0 = b->c;
+	b->a0 = angle;
+	for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
+	{
+		fixture_t* fx = &w->fixtures[f];
+		float aabb[4];
+		shape_aabb(&fx->shape, b->xf, aabb);
+		if (fx->fat[0] <= aabb[0] && fx->fat[1] <= aabb[1] && aabb[2] <= fx->fat[2] && aabb[3] <= fx->fat[3]) continue;
+		fx->fat[0] = aabb[0] - B2O_AABB_EXTENSION;
+		fx->fat[1] = aabb[1] - B2O_AABB_EXTENSION;
+		fx->fat[2] = aabb[2] + B2O_AABB_EXTENSION;
+		fx->fat[3] = aabb[3] + B2O_AABB_EXTENSION;
+		buffer_move(w, f);
+	}
+}
+
+/* b2Body::SetAwake (b2Body.h:690-718) */
+void b2o_set_awake(b2o_world* w, int body, int awake)
+{
+	body_t* b = &w->bodies[body];
+	if (awake) { set_awake(b); return; }
+	b->flags &= ~BF_AWAKE;
+	b->sleepTime = 0.0f;
+	b->v = v_make(0.0f, 0.0f);
+	b->w = 0.0f;
+	b->force = v_make(0.0f, 0.0f);
+	b->torque = 0.0f;
+}
+
+/* b2Body::SetBullet (b2Body.cpp:575-601) */
+void b2o_set_bullet(b2o_world* w, int body, int bullet)
+{
+	body_t* b = &w->bodies[body];
+	int was = (b->flags & BF_BULLET) != 0;
+	if (bullet) b->flags |= BF_BULLET; else b->flags &= ~BF_BULLET;
+	if (was != (bullet != 0)) recalc_body(w, body, -1);
+}
+
+/* b2Body::ApplyLinearImpulse / ToCenter / ApplyAngularImpulse (b2Body.h:885-950) */
+void b2o_apply_linear_impulse(b2o_world* w, int body, float ix, float iy, float px, float py, int toCenter, int wake)
+{
+	body_t* b = &w->bodies[body];
+	if (b->type != 2) return;
+	if (wake && (b->flags & BF_AWAKE) == 0) set_awake(b);
+	if ((b->flags & BF_AWAKE) == 0) return;
+	float sx = b->invMass * ix, sy = b->invMass * iy;
+	b->v.x += sx;
+	b->v.y += sy;
+	if (!toCenter) b->w += b->invI * ((px - b->c.x) * iy - (py - b->c.y) * ix);
+}
+
+void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake)
+{
+	body_t* b = &w->bodies[body];
+	if (b->type != 2) return;
+	if (wake && (b->flags & BF_AWAKE) == 0) set_awake(b);
+	if (b->flags & BF_AWAKE) b->w += b->invI * impulse;
+}
+
+/* b2Fixture::SetSensor / SetThickShape / Refilter / SetFilterData (b2Fixture.cpp:180-257) */
+void b2o_fixture_set_sensor(b2o_world* w, int fixture, int isSensor)
+{
+	fixture_t* f = &w->fixtures[fixture];
+	if ((f->isSensor != 0) == (isSensor != 0)) return;
+	set_awake(&w->bodies[f->body]);
+	f->isSensor = isSensor != 0;
+	recalc_body(w, f->body, fixture);
+}
+
+void b2o_fixture_set_thick(b2o_world* w, int fixture, int thick)
+{
+	fixture_t* f = &w->fixtures[fixture];
+	if ((f->thick != 0) == (thick != 0)) return;
+	f->thick = thick != 0;
+	recalc_body(w, f->body, fixture);
+}
+
+void b2o_fixture_refilter(b2o_world* w, int fixture)
+{
+	fixture_t* f = &w->fixtures[fixture];
+	for (int e = w->bodies[f->body].contactHead; e >= 0; e = w->contacts[e >> 1].next[e & 1])
+	{
+		contact_t* c = &w->contacts[e >> 1];
+		if (c->fixtureA == fixture || c->fixtureB == fixture) c->flags |= CF_FILTER;
+	}
+	if (w->bodies[f->body].flags & BF_ACTIVE) buffer_move(w, fixture); /* TouchProxy */
+}
+
+void b2o_fixture_set_filter(b2o_world* w, int fixture, uint16_t categoryBits, uint16_t maskBits, int16_t groupIndex)
+{
+	fixture_t* f = &w->fixtures[fixture];
+	f->categoryBits = categoryBits;
+	f->maskBits = maskBits;
+	f->groupIndex = groupIndex;
+	b2o_fixture_refilter(w, fixture);
+}
+
+void b2o_joint_set_spring(b2o_world* w, int joint, float frequencyHz, float dampingRatio)
+{
+	revolute_t* j = &w->joints[joint];
+	j->frequencyHz = frequencyHz;
+	j->dampingRatio = dampingRatio;
+}
+
+int b2o_body_is_destroyed(const b2o_world* w, int body) { return w->bodies[body].dead; }
+int b2o_fixture_is_destroyed(const b2o_world* w, int fixture) { return w->fixtures[fixture].dead; }

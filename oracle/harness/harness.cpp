@@ -157,6 +157,12 @@ void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
 			const float t = 0.04f * (float)h->scene.servoStep;
 			static_cast<b2MouseJoint*>(h->scene.drag)->SetTarget(b2Vec2(10.5f + 4.0f * sinf(t), 5.0f + 2.0f * sinf(2.0f * t + 1.0f)));
 		}
+		if (h->scene.lifecycle)
+		{
+			const size_t before = h->scene.bodies.size();
+			b2h::LifecycleEdits(h->scene, h->world);
+			for (size_t k = before; k < h->scene.bodies.size(); ++k) h->bodyIndex[h->scene.bodies[k]] = (int)k;
+		}
 		if (!h->scene.servos.empty())
 		{
 			// motor-joint targets move on a figure of eight (the way the Testbed's MotorJoint scene drives its own: new offsets each step)
@@ -203,6 +209,13 @@ void b2h_get_bodies(b2h_world* h, float* out)
 	{
 		const b2Body* b = h->scene.bodies[i];
 		float* o = out + 8 * i;
+		if (b == NULL)
+		{
+			// destroyed (life-cycle scene): the row stays, marked by type -1
+			for (int k = 0; k < 7; ++k) o[k] = 0.0f;
+			o[7] = -1.0f;
+			continue;
+		}
 		o[0] = b->GetPosition().x;
 		o[1] = b->GetPosition().y;
 		o[2] = b->GetAngle();
@@ -221,6 +234,11 @@ void b2h_get_mass(b2h_world* h, float* out)
 	{
 		const b2Body* b = h->scene.bodies[i];
 		float* o = out + 6 * i;
+		if (b == NULL)
+		{
+			for (int k = 0; k < 6; ++k) o[k] = 0.0f;
+			continue;
+		}
 		o[0] = b->GetMass();
 		o[1] = b->GetInertia();
 		o[2] = b->GetLocalCenter().x;

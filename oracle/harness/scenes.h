@@ -75,6 +75,11 @@ enum SceneId
 	e_machines = 10,     // p0 = falling bodies, p1 = cantilever segments ; prismatic joints (motor slider between limits, a free
 	                     //   vertical slider resting on its lower limit, a locked one) and weld joints (rigid and soft cantilevers,
 	                     //   a welded free-falling pair), a gear train, two pulleys, bodies dropped over all of them
+	e_lifecycle = 12,    // p0 = falling bodies ; a scripted tour of the life-cycle API and the mutators between steps: DestroyBody,
+	                     //   DestroyFixture, CreateBody / CreateFixture afterwards (proxy ids are reused), SetTransform, SetAwake,
+	                     //   SetBullet, ApplyLinearImpulse / ToCenter / ApplyAngularImpulse, SetSensor, SetThickShape,
+	                     //   SetFilterData, a wheel joint's spring retuned, and a mouse joint dragged more slowly than the sleep
+	                     //   tolerance for more than the time to sleep (the body must stay awake); see LifecycleEdits
 	e_vehicles = 11,     // p0 = falling bodies, p1 = cars ; wheel joints (cars with sprung, motor-driven wheels over bumps, one
 	                     //   with a rigid axle), rope joints (weights on slack and taut tethers), friction joints (pucks braked
 	                     //   against the ground), motor joints (platforms servoed to a pose the step loop keeps moving) and a
@@ -98,10 +103,15 @@ struct Scene
 	b2Joint* drag;                // mouse joint whose target the step loop moves on a circle
 	std::vector<b2Joint*> servos; // motor joints whose linear / angular offset the step loop moves along a fixed path
 	int servoStep;
+	bool lifecycle;     // the step loop runs LifecycleEdits before every step
+	int lifecycleStep;
+	b2Joint* slowDrag;  // lifecycle scene: mouse joint with a slowly moving target
+	b2Joint* spring;    // lifecycle scene: wheel joint whose spring is retuned
+	uint32_t lifecycleSeed;
 	bool sliderBounces; // joint is a prismatic motor slider whose motor is reversed by the step loop at either limit
 	float dtDefault;
 	int velIters, posIters;
-	Scene() : joint(NULL), drag(NULL), servoStep(0), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
+	Scene() : joint(NULL), drag(NULL), servoStep(0), lifecycle(false), lifecycleStep(0), slowDrag(NULL), spring(NULL), lifecycleSeed(1), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
 };
 
 inline b2Body* AddBody(Scene& s, b2World* w, const b2BodyDef& bd)
@@ -1061,6 +1071,273 @@ inline void BuildBullets(Scene& s, b2World* w, int projectiles, int stackHeight,
 	}
 }
 
+// ---- life cycle scene -----------------------------------------------------------------------------------------------------
+// Ground with two walls, a heap of boxes / discs / two-fixture "dumbbells", a cart on sprung wheel joints, a crate on a
+// mouse joint. The edits are made by LifecycleEdits, called by the step loop before every step.
+inline void BuildLifecycle(Scene& s, b2World* w, int count, uint32_t seed)
+{
+	Pcg32 rng(seed);
+	s.lifecycle = true;
+	s.lifecycleSeed = seed;
+	b2BodyDef gd;
+	b2Body* ground = AddBody(s, w, gd);
+	{
+		b2EdgeShape edge;
+		edge.Set(b2Vec2(-30.0f, 0.0f), b2Vec2(30.0f, 0.0f));
+		ground->CreateFixture(&edge, 0.0f);
+		b2PolygonShape wall;
+		wall.SetAsBox(0.25f, 4.0f, b2Vec2(-12.0f, 4.0f), 0.0f);
+		ground->CreateFixture(&wall, 0.0f);
+		wall.SetAsBox(0.05f, 4.0f, b2Vec2(12.0f, 4.0f), 0.0f); // thin wall: bullets test it
+		ground->CreateFixture(&wall, 0.0f);
+	}
+	for (int i = 0; i < count; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(rng.Range(-9.0f, 9.0f), 1.0f + 0.6f * (float)(i / 6) + rng.Range(0.0f, 0.2f));
+		bd.angle = rng.Range(0.0f, 2.0f * b2_pi);
+		b2Body* body = AddBody(s, w, bd);
+		b2FixtureDef fd;
+		fd.density = 1.0f + 0.5f * (float)(i % 3);
+		fd.friction = 0.3f;
+		if (i % 5 == 0)
+		{
+			b2CircleShape disc;
+			disc.m_radius = rng.Range(0.2f, 0.4f);
+			fd.shape = &disc;
+			body->CreateFixture(&fd);
+		}
+		else if (i % 5 == 1)
+		{
+			// dumbbell: two fixtures on one body
+			b2PolygonShape bar;
+			bar.SetAsBox(0.5f, 0.1f);
+			fd.shape = &bar;
+			body->CreateFixture(&fd);
+			b2CircleShape knob;
+			knob.m_radius = 0.25f;
+			knob.m_p.Set(0.5f, 0.0f);
+			fd.shape = &knob;
+			body->CreateFixture(&fd);
+		}
+		else
+		{
+			b2PolygonShape box;
+			box.SetAsBox(rng.Range(0.2f, 0.45f), rng.Range(0.2f, 0.35f));
+			fd.shape = &box;
+			body->CreateFixture(&fd);
+		}
+	}
+	// cart on two sprung wheels
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(-20.0f, 1.2f);
+		b2Body* chassis = AddBody(s, w, bd);
+		b2PolygonShape box;
+		box.SetAsBox(1.4f, 0.3f);
+		chassis->CreateFixture(&box, 1.0f);
+		for (int k = 0; k < 2; ++k)
+		{
+			bd.position.Set(-20.0f + (k == 0 ? -1.0f : 1.0f), 0.5f);
+			b2Body* wheel = AddBody(s, w, bd);
+			b2CircleShape disc;
+			disc.m_radius = 0.4f;
+			b2FixtureDef fd;
+			fd.shape = &disc;
+			fd.density = 1.0f;
+			fd.friction = 0.9f;
+			wheel->CreateFixture(&fd);
+			b2WheelJointDef jd;
+			jd.Initialize(chassis, wheel, wheel->GetPosition(), b2Vec2(0.0f, 1.0f));
+			jd.frequencyHz = 4.0f;
+			jd.dampingRatio = 0.7f;
+			jd.enableMotor = k == 0;
+			jd.motorSpeed = -3.0f;
+			jd.maxMotorTorque = 15.0f;
+			b2Joint* j = w->CreateJoint(&jd);
+			if (k == 0) s.spring = j;
+		}
+	}
+	// crate held by a mouse joint
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(20.0f, 3.0f);
+		b2Body* crate = AddBody(s, w, bd);
+		b2PolygonShape box;
+		box.SetAsBox(0.5f, 0.5f);
+		crate->CreateFixture(&box, 1.0f);
+		b2MouseJointDef jd;
+		jd.bodyA = ground;
+		jd.bodyB = crate;
+		jd.target.Set(20.0f, 3.0f);
+		jd.maxForce = 1000.0f * crate->GetMass();
+		s.slowDrag = w->CreateJoint(&jd);
+	}
+}
+
+// The script. `first` = index of the first heap body in s.bodies (1), `count` = heap bodies. Destroyed bodies leave a NULL
+// in s.bodies (indices stay what they were); bodies created later are appended.
+inline void LifecycleEdits(Scene& s, b2World* w)
+{
+	const int step = s.lifecycleStep++;
+	const int count = (int)s.bodies.size();
+	auto alive = [&](int i) -> b2Body* { return i >= 0 && i < count ? s.bodies[(size_t)i] : NULL; };
+	// impulses every step on a rotating subset (the ManyBodies floater pattern, ManyBodies.h:29-68)
+	for (int k = 0; k < 4; ++k)
+	{
+		b2Body* b = alive(1 + (step * 3 + k * 7) % 40);
+		if (b == NULL || b->GetType() != b2_dynamicBody) continue;
+		if (k == 0) b->ApplyLinearImpulseToCenter(b2Vec2(0.2f * b->GetMass(), 0.6f * b->GetMass()), step % 2 == 0);
+		else if (k == 1) b->ApplyAngularImpulse(0.05f * b->GetInertia(), true);
+		else if (k == 2) b->ApplyLinearImpulse(b2Vec2(-0.3f * b->GetMass(), 0.0f), b->GetWorldPoint(b2Vec2(0.1f, 0.2f)), true);
+	}
+	if (step == 25 || step == 26 || step == 60)
+	{
+		// destroy bodies out of the heap (touching contacts, TOI candidates against the ground among them)
+		const int victims[3] = { 1 + (step % 5), 9 + (step % 3), 17 };
+		for (int k = 0; k < 3; ++k)
+		{
+			b2Body* b = alive(victims[k]);
+			if (b == NULL) continue;
+			w->DestroyBody(b);
+			s.bodies[(size_t)victims[k]] = NULL;
+		}
+	}
+	if (step == 40)
+	{
+		// the cart loses a wheel: DestroyBody takes the wheel joint with it
+		b2Body* wheel = alive(count - 2);
+		if (wheel != NULL && s.spring != NULL)
+		{
+			s.spring = NULL;
+			w->DestroyBody(wheel);
+			s.bodies[(size_t)(count - 2)] = NULL;
+		}
+	}
+	if (step == 32 || step == 33)
+	{
+		// a dumbbell loses its knob (the newest fixture), another one its bar (the oldest)
+		for (int i = 1; i < count; ++i)
+		{
+			b2Body* b = alive(i);
+			if (b == NULL || b->GetFixtureList() == NULL || b->GetFixtureList()->GetNext() == NULL) continue;
+			if ((i / 5) % 2 == (step % 2))
+			{
+				b2Fixture* f = step == 32 ? b->GetFixtureList() : b->GetFixtureList()->GetNext();
+				b->DestroyFixture(f);
+			}
+		}
+	}
+	if (step == 45 || step == 70 || step == 71)
+	{
+		// new bodies after destroys: the freed proxy ids come back in the tree's LIFO order
+		for (int k = 0; k < (step == 45 ? 4 : 2); ++k)
+		{
+			b2BodyDef bd;
+			bd.type = b2_dynamicBody;
+			bd.position.Set(-6.0f + 3.0f * (float)k, 9.0f + 0.5f * (float)(step % 3));
+			b2Body* body = AddBody(s, w, bd);
+			b2PolygonShape box;
+			box.SetAsBox(0.3f, 0.3f);
+			body->CreateFixture(&box, 2.0f);
+			if (k == 1)
+			{
+				b2CircleShape disc;
+				disc.m_radius = 0.2f;
+				disc.m_p.Set(0.0f, 0.4f);
+				body->CreateFixture(&disc, 1.0f);
+			}
+		}
+	}
+	if (step == 50 || step == 51 || step == 90)
+	{
+		// teleports: onto the heap, far away (new fat AABB), and by a hair (stays inside its fat AABB)
+		b2Body* b = alive(5 + step % 7);
+		if (b != NULL) b->SetTransform(b2Vec2(step == 50 ? 0.0f : 6.0f, step == 90 ? 1.0f : 8.0f), 0.3f * (float)(step % 4));
+		b2Body* c = alive(20);
+		if (c != NULL) c->SetTransform(c->GetPosition() + b2Vec2(0.01f, 0.0f), c->GetAngle());
+	}
+	if (step == 55)
+	{
+		// bullets: three heap bodies are shot at the thin wall
+		for (int k = 0; k < 3; ++k)
+		{
+			b2Body* b = alive(22 + k);
+			if (b == NULL) continue;
+			b->SetBullet(true);
+			b->SetTransform(b2Vec2(4.0f, 2.0f + 1.5f * (float)k), 0.0f);
+			b->SetLinearVelocity(b2Vec2(150.0f, 0.0f));
+		}
+	}
+	if (step == 80)
+	{
+		for (int k = 0; k < 3; ++k)
+		{
+			b2Body* b = alive(22 + k);
+			if (b != NULL) b->SetBullet(false);
+		}
+	}
+	if (step == 65)
+	{
+		// put part of the heap to sleep by hand; one of them is woken again two steps later
+		for (int i = 26; i < 32; ++i)
+		{
+			b2Body* b = alive(i);
+			if (b != NULL) b->SetAwake(false);
+		}
+	}
+	if (step == 67)
+	{
+		b2Body* b = alive(27);
+		if (b != NULL) b->SetAwake(true);
+	}
+	if (step == 75 || step == 95)
+	{
+		// sensors on and off: the bodies fall through their neighbours while their fixture is a sensor
+		for (int i = 33; i < 37; ++i)
+		{
+			b2Body* b = alive(i);
+			if (b != NULL && b->GetFixtureList() != NULL) b->GetFixtureList()->SetSensor(step == 75);
+		}
+	}
+	if (step == 85)
+	{
+		// filter data: these bodies stop colliding with each other (their contacts are filtered again and go)
+		for (int i = 1; i < count; i += 3)
+		{
+			b2Body* b = alive(i);
+			if (b == NULL || b->GetFixtureList() == NULL || b->GetType() != b2_dynamicBody) continue;
+			b2Filter filter;
+			filter.categoryBits = 0x0002;
+			filter.maskBits = 0xFFFD;
+			b->GetFixtureList()->SetFilterData(filter);
+		}
+	}
+	if (step == 58 || step == 100)
+	{
+		// the thin wall becomes a thick shape (its contacts stop being TOI candidates) and thin again
+		b2Fixture* f = s.bodies[0]->GetFixtureList(); // newest ground fixture = the thin wall
+		f->SetThickShape(step == 58);
+	}
+	if (step == 62 && s.spring != NULL)
+	{
+		b2WheelJoint* wj = static_cast<b2WheelJoint*>(s.spring);
+		wj->SetSpringFrequencyHz(1.5f);
+		wj->SetSpringDampingRatio(0.2f);
+	}
+	if (s.slowDrag != NULL)
+	{
+		// steps 110..175: the target creeps at 0.3 mm per step (0.018 m/s: above the 0.01 m/s sleep tolerance it would not
+		// prove anything, so it creeps at 0.1 mm per step = 0.006 m/s), far longer than b2_timeToSleep; then it jumps
+		b2MouseJoint* mj = static_cast<b2MouseJoint*>(s.slowDrag);
+		if (step >= 110 && step < 176) mj->SetTarget(b2Vec2(20.0f + 0.0001f * (float)(step - 109), 3.0f));
+		else if (step == 176) mj->SetTarget(b2Vec2(22.0f, 4.0f));
+	}
+}
+
 inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 {
 	switch (p.scene)
@@ -1077,6 +1354,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_ropes: BuildRopes(s, w, p.p0, p.p1, p.seed); break;
 	case e_machines: BuildMachines(s, w, p.p0, p.p1, p.seed); break;
 	case e_vehicles: BuildVehicles(s, w, p.p0, p.p1, p.seed); break;
+	case e_lifecycle: BuildLifecycle(s, w, p.p0, p.seed); break;
 	default: break;
 	}
 }

@@ -14,7 +14,7 @@ REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libb2ref_harness.so")
 AMD_LIB = os.path.join(ROOT, "box2d-mt_amd", "libb2amd_harness.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libb2oracle_harness.so")
 
-HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS, SENSORS, ROPES, MACHINES, VEHICLES = range(12)
+HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS, SENSORS, ROPES, MACHINES, VEHICLES, LIFECYCLE = range(13)
 F_CONTINUOUS, F_SLEEP, F_WARM, F_SUBSTEP = 1, 2, 4, 8
 DEFAULT_FLAGS = F_SLEEP | F_WARM  # CCD off unless a test asks for it
 

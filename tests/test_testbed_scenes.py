@@ -1,0 +1,92 @@
+"""The reference's OWN Testbed scene headers, unmodified, on the drop-in API ("unmodified Testbed").
+
+oracle/Makefile compiles tests/testbed/scenes_main.cpp - a headless stand-in for Testbed/Framework/Test.h plus
+`#include "Testbed/Tests/<Scene>.h"` straight from /root/reference - three times into oracle/_ref/ (git-ignored, travels
+with the snapshot like the compiled reference): against the reference's Box2D (libtestbed_ref.so), against
+box2d-mt_amd/host over the C oracle (libtestbed_oracle.so) and against box2d-mt_amd/host over libb2hip.so
+(libtestbed_amd.so, the product). Scenes: SleepCollideTest, TunnelingTest, QueryTest (the three with a TestPassed
+predicate, TestMT.cpp:36,113-114), ManyBodies, MultithreadDemo, Car, Pyramid, Tumbler, SleepCollidePerf.
+
+  CPU : drop-in host layer over the oracle  ==  reference build, per-step summaries (body / contact counts, position sum,
+        top speed, awake count) over the whole run
+  GPU : the three TestPassed predicates pass on the product; the others run finite and, in exact-order mode, reproduce
+        the oracle-backed run step for step
+TunnelingTest edits the world from inside its listener callbacks; the bridge delivers begin / end / PostSolve after the
+step's device work and refuses edits from PreSolve (the world is locked mid-step), so its cells change configuration a
+step apart from the reference's: its predicate is pinned, its per-step trace is not.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NONE, PASS, FAIL = 0, 1, 2
+
+
+def load(kind):
+    path = os.path.join(ROOT, "oracle", "_ref", "libtestbed_%s.so" % kind)
+    if not os.path.exists(path):
+        pytest.skip("%s not built (needs /root/reference at build time: make -C oracle testbed)" % os.path.basename(path))
+    L = C.CDLL(path, mode=C.RTLD_LOCAL)
+    L.testbed_run.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    L.testbed_trace.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    return L
+
+
+def trace(L, name, steps):
+    out = np.zeros((steps, 6))
+    res = L.testbed_trace(name.encode(), steps, out.ctypes.data)
+    return res, out
+
+
+CPU_SCENES = [("SleepCollideTest", 700), ("QueryTest", 1), ("ManyBodies6", 160), ("MultithreadDemo", 240), ("Car", 240),
+              ("Pyramid", 240), ("Tumbler", 300), ("SleepCollidePerf", 120)]
+
+
+@pytest.mark.parametrize("name,steps", CPU_SCENES)
+def test_reference_scenes_on_the_drop_in_layer_match_the_reference(name, steps):
+    ra, ta = trace(load("ref"), name, steps)
+    rb, tb = trace(load("oracle"), name, steps)
+    assert ra == rb, "TestPassed differs"
+    bad = np.nonzero((ta != tb).any(axis=1))[0]
+    assert bad.size == 0, "%s: summaries differ first at step %d: %s vs %s" % (name, bad[0], ta[bad[0]], tb[bad[0]])
+    assert ta[-1, 4] == 1.0 and ta[-1, 0] > 0
+
+
+def test_tunneling_test_predicate_on_the_drop_in_layer():
+    ra, ta = trace(load("ref"), "TunnelingTest", 900)
+    rb, tb = trace(load("oracle"), "TunnelingTest", 900)
+    assert ra == PASS and rb == PASS
+    assert tb[-1, 4] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,steps", [("SleepCollideTest", 1800), ("TunnelingTest", 1800), ("QueryTest", 1)])
+def test_reference_test_passed_predicates_on_the_gpu(name, steps):
+    """TestMT.cpp:36,113-114: the three scenes that define TestPassed() must report PASS on the product (default mode)."""
+    out = np.zeros(6)
+    res = load("amd").testbed_run(name.encode(), steps, out.ctypes.data)
+    assert res == PASS, "%s: TestPassed = %d" % (name, res)
+    assert out[4] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,steps", [("ManyBodies6", 160), ("MultithreadDemo", 200), ("Car", 240), ("Pyramid", 200), ("Tumbler", 200)])
+def test_reference_scenes_on_the_gpu_match_the_oracle_backed_run(name, steps, monkeypatch):
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")  # every island in the reference's constraint order
+    ra, ta = trace(load("amd"), name, steps)
+    rb, tb = trace(load("oracle"), name, steps)
+    assert ra == rb
+    bad = np.nonzero((ta != tb).any(axis=1))[0]
+    assert bad.size == 0, "%s: summaries differ first at step %d: %s vs %s" % (name, bad[0], ta[bad[0]], tb[bad[0]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,steps", [("ManyBodies6", 240), ("MultithreadDemo", 300), ("Car", 240), ("SleepCollidePerf", 200)])
+def test_reference_scenes_run_in_default_mode(name, steps):
+    res, t = trace(load("amd"), name, steps)
+    assert res in (NONE, PASS)
+    assert (t[:, 4] == 1.0).all(), "non-finite body state"
+    assert t[-1, 0] > 0

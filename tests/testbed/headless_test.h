@@ -67,7 +67,6 @@ struct DebugDraw : public b2Draw
 	void DrawSolidPolygon(const b2Vec2*, int32, const b2Color&) override {}
 	void DrawCircle(const b2Vec2&, float32, const b2Color&) override {}
 	void DrawSolidCircle(const b2Vec2&, float32, const b2Vec2&, const b2Color&) override {}
-	void DrawParticles(const b2Vec2*, float32, const b2Color*, int32) override {}
 	void DrawSegment(const b2Vec2&, const b2Vec2&, const b2Color&) override {}
 	void DrawTransform(const b2Transform&) override {}
 	void DrawPoint(const b2Vec2&, float32, const b2Color&) override {}
@@ -91,6 +90,7 @@ public:
 		m_world->SetContactListener(this);
 		m_textLine = 30;
 		m_stepCount = 0;
+		m_timeStep = 0.0f;
 		m_mouseJoint = nullptr;
 		m_bomb = nullptr;
 		m_visible = false;
@@ -102,6 +102,7 @@ public:
 	virtual void Step(Settings* settings)
 	{
 		const float32 timeStep = settings->hz > 0.0f ? 1.0f / settings->hz : 0.0f;
+		m_timeStep = timeStep;
 		m_world->SetAllowSleeping(settings->enableSleep);
 		m_world->SetWarmStarting(settings->enableWarmStarting);
 		m_world->SetContinuousPhysics(settings->enableContinuous);
@@ -139,6 +140,7 @@ protected:
 	bool m_visible;
 	b2Vec2 m_mouseWorld;
 	int32 m_stepCount;
+	float32 m_timeStep;
 	b2ThreadPoolTaskExecutor m_threadPoolExec;
 };
 

@@ -15,13 +15,14 @@ Camera g_camera;
 #include "Testbed/Tests/Car.h"
 #include "Testbed/Tests/Pyramid.h"
 #include "Testbed/Tests/Tumbler.h"
+#include "Testbed/Tests/SleepCollidePerf.h"
 
 struct Entry { const char* name; TestCreateFcn* create; };
 static const Entry kEntries[] = {
 	{ "SleepCollideTest", SleepCollideTest::Create }, { "TunnelingTest", TunnelingTest::Create },
-	{ "DuplicateProxyTest", DuplicateProxyTest::Create }, { "ManyBodies", ManyBodies::Create },
+	{ "QueryTest", QueryTest::Create }, { "ManyBodies6", ManyBodies6::Create }, { "ManyBodies1", ManyBodies1::Create },
 	{ "MultithreadDemo", MultithreadDemo::Create }, { "Car", Car::Create }, { "Pyramid", Pyramid::Create },
-	{ "Tumbler", Tumbler::Create },
+	{ "Tumbler", Tumbler::Create }, { "SleepCollidePerf", SleepCollidePerf::Create },
 };
 
 extern "C"
@@ -29,6 +30,29 @@ extern "C"
 
 // Runs scene `name` for `steps` steps. Returns TestPassed() (0 none, 1 pass, 2 fail) or -1 for an unknown name; out6 =
 // body count, contact count, sum of |x| + |y| over the bodies, max |v|, 1 if every body state is finite, awake bodies.
+static void Summarise(Test* t, double* out6);
+
+// Same, with the six summary figures after EVERY step (trace = steps x 6 doubles): where two backends part.
+int testbed_trace(const char* name, int steps, double* trace)
+{
+	for (const Entry& e : kEntries)
+	{
+		if (strcmp(e.name, name) != 0) continue;
+		srand(0);
+		Test* t = e.create();
+		Settings settings;
+		for (int i = 0; i < steps; ++i)
+		{
+			t->Step(&settings);
+			Summarise(t, trace + 6 * i);
+		}
+		const int res = (int)t->TestPassed();
+		delete t;
+		return res;
+	}
+	return -1;
+}
+
 int testbed_run(const char* name, int steps, double* out6)
 {
 	for (const Entry& e : kEntries)
@@ -38,6 +62,20 @@ int testbed_run(const char* name, int steps, double* out6)
 		Test* t = e.create();
 		Settings settings;
 		for (int i = 0; i < steps; ++i) t->Step(&settings);
+		if (out6) Summarise(t, out6);
+		const int res = (int)t->TestPassed();
+		delete t;
+		return res;
+	}
+	return -1;
+}
+
+}
+
+static void Summarise(Test* t, double* out6)
+{
+	{
+		{
 		double sum = 0.0, vmax = 0.0;
 		int finite = 1, awake = 0, n = 0;
 		for (b2Body* b = t->GetWorld()->GetBodyList(); b; b = b->GetNext())
@@ -50,15 +88,7 @@ int testbed_run(const char* name, int steps, double* out6)
 			awake += b->IsAwake() ? 1 : 0;
 			++n;
 		}
-		if (out6)
-		{
-			out6[0] = n; out6[1] = t->GetWorld()->GetContactCount(); out6[2] = sum; out6[3] = vmax; out6[4] = finite; out6[5] = awake;
+		out6[0] = n; out6[1] = t->GetWorld()->GetContactCount(); out6[2] = sum; out6[3] = vmax; out6[4] = finite; out6[5] = awake;
 		}
-		const int res = (int)t->TestPassed();
-		delete t;
-		return res;
 	}
-	return -1;
-}
-
 }
