@@ -145,11 +145,26 @@ def main():
     amd = bh.Harness(bh.AMD_LIB)
     hipL = b2hip.lib()
 
-    # config-4 layout: `world_size` disjoint pyramids on one ground, rank r builds and steps pyramid r
+    # N > 1 (config-4 layout): ONE world of `world_size` disjoint pyramids on one ground, held whole by every rank and
+    # sharded by island owner (include/b2hip.h, b2d_kernels_shard.h): rank r solves pyramid r, collide / broad-phase / TOI run
+    # replicated, one RCCL all-reduce(MAX) per step carries the solved islands to every rank (sharding.ShardedWorld).
     # (hipSetDevice above selects this rank's GPU for the world's stream)
     flags = bh.F_SLEEP | bh.F_WARM | (0 if args.no_ccd else bh.F_CONTINUOUS)
-    w = amd.world(bh.PYRAMID, args.rows, world_size, float(rank), float(world_size), flags=flags)
+    w = amd.world(bh.PYRAMID, args.rows, world_size, flags=flags)
     nbodies = w.body_count
+    sharded = None
+    if world_size > 1:
+        import sharding
+
+        class _Raw:  # the C-ABI world behind the drop-in b2World, as sharding.ShardedWorld wants it
+            pass
+        raw = _Raw()
+        raw.p = C.c_void_p(w.device_world())
+        raw.L = hipL
+        sharded = sharding.ShardedWorld(raw, dist=dist, device=torch.device("cuda", local_rank))
+        step_world = lambda n=1: [sharded.step(1.0 / 60.0, w.vel_iters, w.pos_iters) for _ in range(n)]
+    else:
+        step_world = lambda n=1: w.step(n)
 
     def barrier():
         if dist is not None:
@@ -160,9 +175,9 @@ def main():
     settle_ms = np.empty(SETTLE_STEPS)
     for k in range(SETTLE_STEPS):
         ts = time.perf_counter()
-        w.step(1)
+        step_world(1)
         settle_ms[k] = 1000.0 * (time.perf_counter() - ts)
-    w.step(args.warmup)
+    step_world(args.warmup)
     w.reset_profile()
     barrier()
     # one Step() per call so that the per-step distribution can be reported as well (Step() returns after its read-back,
@@ -171,7 +186,7 @@ def main():
     t0 = time.perf_counter()
     stamps[0] = t0
     for k in range(args.steps):
-        w.step(1)
+        step_world(1)
         stamps[k + 1] = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -194,7 +209,7 @@ def main():
         hipL.b2hip_set_kernel_timing(dev, 1)
         names = {}
         for _ in range(20):
-            w.step(1)
+            step_world(1)
             buf = C.create_string_buffer(64)
             ms, launches, nbytes = C.c_float(), C.c_int(), C.c_double()
             hipL.b2hip_get_kernel_timing(dev, buf, 64, C.byref(ms), C.byref(launches), C.byref(nbytes))
@@ -279,37 +294,49 @@ def main():
         if world_size == 1:
             jobs.append(("config 3: Tumbler 316 x 316 = 99 856 boxes in a revolving container, CCD off (Tumbler.h)", bh.TUMBLER, 316, 0, bh.F_SLEEP | bh.F_WARM, 60, 20))
             jobs.append(("config 5 on ONE GPU: 1 M mixed circles + boxes random field, 10 000 bullets, CCD on", bh.FIELD, 1000000, 10000, flags | bh.F_CONTINUOUS, 10, 10))
-        jobs.append(("config 4, one GPU's share: Pyramid 316 rows = 50 086 boxes, CCD on", bh.PYRAMID, 316, 1, flags, 60, 20))
+        if world_size == 1:
+            jobs.append(("config 4, one GPU's share: Pyramid 316 rows = 50 086 boxes, CCD on", bh.PYRAMID, 316, 1, flags, 60, 20))
         for job in jobs:
             try:
                 extras.append(time_extra(amd, hipL, *job))
             except Exception as e:
                 extras.append({"workload": job[0], "error": str(e)})
         if dist is not None:
-            # config 4 as stated: every rank steps its own 50 086-box pyramid; whole-job rate over the slowest rank
-            t = torch.tensor([extras[-1].get("ms_per_step", 0.0)], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            extras[-1]["ms_per_step_max_over_ranks"] = float(t.item())
-            extras[-1]["island_steps_per_s_all_ranks"] = world_size * 1000.0 / float(t.item()) if t.item() > 0 else None
+            # config 4 as stated: `world_size` disjoint 50 086-box pyramids in ONE world sharded by island owner over the
+            # ranks (one pyramid each), one RCCL all-reduce per step; whole-job rate from the slowest rank's clock
+            try:
+                w4 = amd.world(bh.PYRAMID, 316, world_size, flags=flags)
+                raw4 = _Raw()
+                raw4.p = C.c_void_p(w4.device_world())
+                raw4.L = hipL
+                s4 = sharding.ShardedWorld(raw4, dist=dist, device=torch.device("cuda", local_rank))
+                for _ in range(60):
+                    s4.step(1.0 / 60.0, w4.vel_iters, w4.pos_iters)
+                barrier()
+                t4 = time.perf_counter()
+                for _ in range(20):
+                    s4.step(1.0 / 60.0, w4.vel_iters, w4.pos_iters)
+                barrier()
+                el = torch.tensor([time.perf_counter() - t4], dtype=torch.float64, device="cuda")
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                ms = 1000.0 * float(el.item()) / 20
+                extras.append({"workload": "config 4: %d disjoint pyramids of 316 rows (50 086 boxes each) in one world sharded by island over %d GPUs, CCD on" % (world_size, world_size),
+                               "bodies": w4.body_count, "settle_steps": 60, "timed_steps": 20, "ms_per_step": ms,
+                               "world_steps_per_s": 1000.0 / ms, "island_steps_per_s_all_ranks": world_size * 1000.0 / ms,
+                               "exchange_bytes_per_step": s4.exchange_bytes})
+                w4.close()
+            except Exception as e:
+                extras.append({"workload": "config 4 (sharded)", "error": str(e)})
 
     contacts = w.contact_count
-    # Untimed: assemble the host-visible state of the WHOLE world on every rank with one all-gather over
-    # RCCL/xGMI (the only exchange a sharded world of disjoint islands needs; not part of `value`).
     gather_ms = None
-    if dist is not None:
-        import sharding
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        full = sharding.gather_world_state(w.bodies(), args.rows, world_size, rank, world_size, dist=dist, device="cuda")
-        torch.cuda.synchronize()
-        gather_ms = 1000.0 * (time.perf_counter() - g0)
-        assert full.shape[0] == 1 + world_size * sharding.pyramid_bodies(args.rows)
+    exchange_bytes = sharded.exchange_bytes if sharded is not None else 0
     w.close()
 
     if rank == 0:
         total_steps = args.steps * world_size
         line = {
-            "metric": "world steps/sec (Step = collide + island solve + broad-phase + state read-back), 10 011-body pyramid island per GPU",
+            "metric": "world steps/sec x pyramid islands (Step = collide + island solve + broad-phase + state read-back), one 10 011-body pyramid island per GPU",
             "value": total_steps / elapsed,
             "unit": "steps/s",
             "n_gpus": world_size,
@@ -326,7 +353,7 @@ def main():
             "config": {"workload": "Pyramid %d rows: %d bodies, %d contacts per GPU, settled for %d untimed steps (steady state), dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
                                    % (args.rows, nbodies, contacts, SETTLE_STEPS, "off" if args.no_ccd else "on (reference default)"),
                        "settle_steps": SETTLE_STEPS,
-                       "bodies_total": nbodies * world_size, "parallelism": "one island shard per GPU, no data-path collective"},
+                       "bodies_total": nbodies * world_size, "parallelism": "one world on every rank, islands sharded by owner, one RCCL all-reduce per step" if world_size > 1 else "single GPU"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
         # the free-fall / first-impact transient the settle steps went through (rank 0), never part of `value`
@@ -335,8 +362,9 @@ def main():
                              "ms_per_step_max": float(settle_ms.max())}
         if extras is not None:
             line["extra_configs"] = extras
-        if gather_ms is not None:
-            line["world_state_allgather_ms"] = gather_ms
+        if sharded is not None:
+            line["exchange_bytes_per_step"] = exchange_bytes
+            line["exchange"] = "one all-reduce(MAX) per step over int32 records of the solved islands (RCCL), inside the timed region"
         if roof is not None:
             line["roofline"] = roof
         if secondary is not None:

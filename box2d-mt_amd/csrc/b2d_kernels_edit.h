@@ -105,10 +105,13 @@ __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int
 					}
 				}
 				// b2Contact::Destroy (b2Contact.cpp:100-113): wake both bodies if the manifold had points
+				// (at once, as SetAwake(true) does: the flag decides which contacts this step's Collide updates)
 				if (C.man3[i].w > 0 && (flags & CF_SENSOR) == 0)
 				{
-					W.b_wake[ids.z] = 1;
-					W.b_wake[ids.w] = 1;
+					atomicOr(&W.b_flags[ids.z], BF_AWAKE);
+					atomicOr(&W.b_flags[ids.w], BF_AWAKE);
+					W.b_pos[ids.z].w = 0.0f;
+					W.b_pos[ids.w].w = 0.0f;
 				}
 				C.flags[i] = flags | CF_DESTROY;
 			}

@@ -18,6 +18,13 @@
 #define ROOT_NONE 0
 #define ROOT_SMALL 1
 #define ROOT_LARGE 2
+#define ROOT_REMOTE 3   // solved by another rank of a sharded world (b2d_kernels_shard.h): in an island, but not on our lists
+
+// Which rank solves the island rooted at `root` (the member of lowest ufPriority: the same body on every rank)
+__device__ __forceinline__ int shardHashOwner(int root, int shardCount)
+{
+	return (int)((((uint32_t)root * 2654435761u) >> 12) % (uint32_t)shardCount);
+}
 
 __device__ __forceinline__ bool contactSolid(uint32_t flags)
 {
@@ -167,6 +174,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.chunkW = SMALL_ISLAND_MAX_W;
 		S->c.partitionAge += 1;
 		if (S->c.partitionCooldown > 0) S->c.partitionCooldown -= 1;
+		S->c.nBigIslands = 0;
+		S->c.nRemoteIslands = 0;
 		S->c.nOrphanRows = 0;
 		S->c.blkMaxRows = 0;
 		S->c.blkMaxBodies = 0;
@@ -281,7 +290,28 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 				int nb = W.rootBodies[i], nc = W.rootContacts[i], nj = W.rootJoints[i];
 				int w = nb > nc ? nb : nc;
 				if (w < 1) w = 1;
-				if ((nj == 0 && w <= W.smallMaxW && forceLarge == 0) || forceLarge == 2)
+				bool mine = true, big = false;
+				if (W.shardCount > 1)
+				{
+					// islands are dealt over the ranks: the big ones one by one (k_shard_big), the others by a hash of their root
+					big = nb > SHARD_BIG_BODIES && forceLarge != 2;
+					if (big)
+					{
+						const int k = atomicAdd(&S->c.nBigIslands, 1);
+						if (k < SHARD_BIG_MAX) W.bigRoots[k] = i; else big = false;
+					}
+					if (!big) mine = shardHashOwner(i, W.shardCount) == W.shardRank;
+				}
+				if (big)
+				{
+					W.rootIsland[i] = ROOT_LARGE; // k_shard_big keeps it, or hands it to another rank
+				}
+				else if (!mine)
+				{
+					W.rootIsland[i] = ROOT_REMOTE;
+					atomicAdd(&S->c.nRemoteIslands, 1);
+				}
+				else if ((nj == 0 && w <= W.smallMaxW && forceLarge == 0) || forceLarge == 2)
 				{
 					W.rootIsland[i] = ROOT_SMALL;
 					in = make_int4(nb, nc, w, 1);

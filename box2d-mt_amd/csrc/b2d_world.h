@@ -62,6 +62,12 @@
 #define HUB_COLOR (MAX_COLORS - 1) // row group of the hub constraints
 #define COLOR_SMALL_MAX 4096     // uncoloured constraints up to this many are coloured by one workgroup without a host round trip
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
+#define SHARD_BIG_BODIES 4096    // islands above this size are dealt over the ranks one by one (in root-id order), smaller ones by a hash of their root
+#define SHARD_BIG_MAX 1024       // ... at most this many per step (more: they fall back to the hash)
+#define SHARD_BODY_WORDS 13      // exchange record of a body: c.xy, a, sleepTime, v.xy, w, awake, xf.p.xy, xf.q.sc, owner + 1
+#define SHARD_CONTACT_WORDS 5    // ... of a contact: the four warm-start impulses, owner + 1
+#define SHARD_JOINT_WORDS 6      // ... of a joint: impulse x, y (wheel: spring impulse), z, motor impulse, limit state, owner + 1
+#define SHARD_NOBODY ((int)0x80000000) // every word of a record this rank does not own (the exchange is a MAX over int32)
 // Block partition of the large islands (b2d_kernels_solve_blocks.h): every body of a large island has a home block, one
 // workgroup solves one block with its bodies in LDS. A constraint between bodies of two blocks is a CUT constraint: it owns
 // a colour of the upper range, so that on every body the cut constraints come last in a sweep.
@@ -141,6 +147,8 @@ struct Counters
 	int nPreSolve;       // PreSolve records of this step's Collide (DW::preRecs)
 	int nPostSolve;      // PostSolve records of this step's Solve (DW::postRecs)
 	int nFilterList;     // contacts flagged for re-filtering, listed for the user's contact filter (DW::filterList)
+	int nBigIslands;     // islands with more than SHARD_BIG_BODIES bodies this step (sharded worlds only)
+	int nRemoteIslands;  // islands of this step that another rank solves
 };
 
 // What b2ContactListener::PreSolve is told about one contact (gathered after Collide, before the compaction of destroyed
@@ -294,6 +302,10 @@ struct DW
 	int* rowColor;       // per block-sorted row: its colour
 	float4* b_cutv;      // per body: (v.xy, w, tag) exchange row of the cut constraints, velocity phase (positions: b_posv)
 	int blockSort;       // k_color_fill groups the rows by owner block (k_solve_blocks) instead of by colour
+	// island sharding over the ranks of one node (b2d_kernels_shard.h): every rank holds the whole world, solves the islands
+	// it owns and takes the others' results from one exchange per step
+	int shardRank, shardCount;
+	int* bigRoots;       // roots of the islands with more than SHARD_BIG_BODIES bodies (dealt over the ranks in root-id order)
 	// listener / filter bridge (include/b2hip.h: b2hip_set_contact_filter, b2hip_set_pre_solve, b2hip_enable_post_solve)
 	int userFilter;      // a user contact filter is installed: the built-in category / mask / group rule is not applied
 	int preSolveOn, postSolveOn;

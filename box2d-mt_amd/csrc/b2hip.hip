@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,7 @@
 #include "b2d_kernels_solve_mailbox.h"
 #include "b2d_kernels_solve_blocks.h"
 #include "b2d_kernels_edit.h"
+#include "b2d_kernels_shard.h"
 #include "b2d_scan.h"
 
 static thread_local std::string g_lastError;
@@ -94,6 +96,8 @@ struct HostBody
 	int resetSweep;   // SetTransform: the sweep origin (c0, a0) is rewritten from the host mirror at the next upload
 	std::vector<int> fixtures; // creation order (the reference's list is newest first)
 	bool dirty;
+	uint32_t pullEpoch;  // == b2hip_world::mirrorEpoch: this row has been refreshed from (or is newer than) h_state
+	uint32_t forceEpoch; // == b2hip_world::stepEpoch: fx, fy, torque were applied since the last step (auto-clear worlds)
 };
 
 struct HostFixture
@@ -143,10 +147,14 @@ struct b2hip_world
 	size_t upBodies, upFixtures, upShapes, upJoints;
 	std::vector<int> pendingMoves;
 	std::vector<int> dirtyList;   // bodies whose host mirror is newer than the device rows
+	std::mutex dirtyMutex;        // the per-body setters may run on several user threads, one body each (ManyBodies.h:39-64)
 	size_t stateCount;            // bodies covered by the last read-back in h_state
+	uint32_t mirrorEpoch;         // bumped by every read-back into h_state (HostBody::pullEpoch)
+	uint32_t stepEpoch;           // bumped by every step (HostBody::forceEpoch)
 	bool newFixture;
 	float inv_dt0;
 	bool stepActive;
+	bool callbackWindow;          // inside the step, while the PreSolve callbacks run: mutators are accepted (and applied right after)
 	bool failed = false;          // a step failed half-way: the device state is inconsistent, every later call says so
 	std::string failedWhy;
 	StepParams sp;
@@ -218,9 +226,11 @@ struct b2hip_world
 	std::vector<int> nonStatic;       // the reference's m_nonStaticBodies: body ids in its order (island seed order)
 	bool orderDirty = false;
 	DevArray<int> b_order, orderBody;
+	DevArray<int> bigRoots;           // sharded worlds: roots of this step's big islands
 	// edits of existing fixtures / contacts between steps (b2d_kernels_edit.h)
 	std::vector<int2> editOps;        // queued contact-array ops, in call order
-	std::vector<int> proxyEdits;      // fixtures whose device proxy row (fat AABB, filter words, body) must be rewritten
+	std::vector<int> proxyEdits;      // fixtures whose device proxy row (filter words, body) must be rewritten
+	std::vector<int> fatEdits;        // ... and the ones among them whose fat AABB the host has moved (SetTransform)
 	bool proxyListsStale = false;     // a fixture was destroyed: b_proxyHead / p_next need a rebuild
 	DevArray<int2> d_editOps;
 	// listener / filter bridge: user callbacks in the middle of a step (include/b2hip.h)
@@ -248,6 +258,8 @@ struct b2hip_world
 	float* h_state;
 	size_t h_stateCap;
 	DState* h_dstate;
+	int* h_stamps = nullptr;     // pinned: phase stamps of the resident solver (gridBar[8..15])
+	bool blocksThisStep = false; // the large islands of this step went through k_solve_blocks
 
 	Counters last;        // counters of the last completed step
 	int lastContacts;
@@ -318,6 +330,10 @@ static void pullBody(b2hip_world* w, int i)
 {
 	if ((size_t)i >= w->stateCount || w->h_state == nullptr) return;
 	HostBody& b = w->bodies[i];
+	// once pulled, the host row is the newer one until the next read-back (an upload in between - a contact read flushes
+	// the edits made so far - does not make h_state any fresher)
+	if (b.pullEpoch == w->mirrorEpoch) return;
+	b.pullEpoch = w->mirrorEpoch;
 	const float* o = w->h_state + 10 * (size_t)i;
 	b.px = o[0]; b.py = o[1]; b.a = o[2];
 	b.vx = o[3]; b.vy = o[4]; b.w = o[5];
@@ -329,7 +345,8 @@ static void pullBody(b2hip_world* w, int i)
 	b.c0x = b.cx; b.c0y = b.cy; b.a0 = b.a;
 	b.qs = sinf(b.a);
 	b.qc = cosf(b.a);
-	if (w->def.auto_clear_forces) { b.fx = b.fy = b.torque = 0.0f; }
+	if (w->def.auto_clear_forces && b.forceEpoch != w->stepEpoch) { b.fx = b.fy = b.torque = 0.0f; }
+	b.forceEpoch = w->stepEpoch;
 }
 
 static void markDirty(b2hip_world* w, int i)
@@ -338,6 +355,7 @@ static void markDirty(b2hip_world* w, int i)
 	if (b.dirty) return;
 	pullBody(w, i);
 	b.dirty = true;
+	std::lock_guard<std::mutex> lock(w->dirtyMutex);
 	w->dirtyList.push_back(i);
 }
 
@@ -643,7 +661,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 #define ENS(arr, n) do { rc = w->arr.ensure((n), s); if (rc) return rc; } while (0)
 	ENS(d_state, 1);
 	ENS(b_pos, nb); ENS(b_pos0, nb); ENS(b_vel, nb); ENS(b_xf, nb); ENS(b_mass, nb); ENS(b_damp, nb); ENS(b_force, nb);
-	ENS(b_flags, nb); ENS(b_wake, nb); ENS(b_order, nb); ENS(orderBody, nb);
+	ENS(b_flags, nb); ENS(b_wake, nb); ENS(b_order, nb); ENS(orderBody, nb); ENS(bigRoots, SHARD_BIG_MAX);
 	ENS(p_fat, np); ENS(p_body, np); ENS(p_shape, np); ENS(p_key, np); ENS(p_filter0, np); ENS(p_filter1, np); ENS(p_mat, np);
 	ENS(b_proxyHead, nb); ENS(p_next, np);
 	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
@@ -735,7 +753,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.gridMask = (uint32_t)(gridSize - 1);
 	d.b_pos = w->b_pos.p; d.b_pos0 = w->b_pos0.p; d.b_vel = w->b_vel.p; d.b_xf = w->b_xf.p; d.b_mass = w->b_mass.p;
 	d.b_damp = w->b_damp.p; d.b_force = w->b_force.p; d.b_flags = w->b_flags.p; d.b_wake = w->b_wake.p;
-	d.b_order = w->b_order.p; d.orderBody = w->orderBody.p;
+	d.b_order = w->b_order.p; d.orderBody = w->orderBody.p; d.bigRoots = w->bigRoots.p;
 	d.p_fat = w->p_fat.p; d.p_body = w->p_body.p; d.p_shape = w->p_shape.p; d.p_key = w->p_key.p;
 	d.p_filter0 = w->p_filter0.p; d.p_filter1 = w->p_filter1.p; d.p_mat = w->p_mat.p; d.shapes = w->d_shapes.p;
 	for (int k = 0; k < 2; ++k)
@@ -1029,12 +1047,15 @@ static int flushEdits(b2hip_world* w)
 			const int body = f.dead ? -1 : f.body;
 			const uint32_t f0 = (uint32_t)f.categoryBits | ((uint32_t)f.maskBits << 16);
 			const int f1 = ((int)(uint16_t)f.groupIndex) | (f.isSensor ? PF_SENSOR : 0) | (f.thick ? PF_THICK : 0);
-			HIP_TRY(hipMemcpy(w->p_fat.p + id, &fat, sizeof(float4), hipMemcpyHostToDevice));
+			// (the fat AABB of an uploaded fixture is device state: the host copy is only current if SetTransform wrote it)
+			if (std::find(w->fatEdits.begin(), w->fatEdits.end(), id) != w->fatEdits.end())
+				HIP_TRY(hipMemcpy(w->p_fat.p + id, &fat, sizeof(float4), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(w->p_body.p + id, &body, sizeof(int), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(w->p_filter0.p + id, &f0, sizeof(uint32_t), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(w->p_filter1.p + id, &f1, sizeof(int), hipMemcpyHostToDevice));
 		}
 		w->proxyEdits.clear();
+		w->fatEdits.clear();
 	}
 
 	// ---- move buffer: proxies created since the last step (b2BroadPhase::CreateProxy buffers a move)
@@ -1091,7 +1112,7 @@ static int applyPendingFilters(b2hip_world* w)
 
 // Applies the queued contact-array ops (b2d_kernels_edit.h) in call order, then compacts the contact array if contacts
 // were destroyed. Called by the step right after its counters are zeroed, and by whoever reads the contacts between steps.
-static int applyEditOps(b2hip_world* w)
+static int applyEditOps(b2hip_world* w, bool betweenSteps)
 {
 	if (w->editOps.empty()) return 0;
 	bool destroys = false;
@@ -1108,8 +1129,17 @@ static int applyEditOps(b2hip_world* w)
 		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_finish, 1, 1, d);
 		LAUNCH(w, k_edit_finish, 1, 1, d);
+		if (betweenSteps)
+		{
+			// destroying a touching contact wakes its bodies (b2Contact::Destroy, b2Contact.cpp:105-111): the host rows are
+			// read again from the device (every edit made so far has been uploaded by the caller)
+			LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0);
+			HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, w->bodies.size() * 10 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+			w->stateCount = w->bodies.size();
+			++w->mirrorEpoch;
+		}
 	}
-	rc = readState(w); // (also makes the staging vector reusable)
+	rc = readState(w); // (also makes the staging vector reusable, and the state rows above readable)
 	if (rc) return rc;
 	w->editOps.clear();
 	if (w->h_dstate->c.overflow & 128) return setError(B2HIP_ERR_CAPACITY, "more than 8192 contacts on one edited body / fixture");
@@ -1335,6 +1365,7 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 static int phaseSolve(b2hip_world* w)
 {
 	w->trace.clear();
+	w->blocksThisStep = false;
 	DW& d = w->dw;
 	const StepParams& sp = w->sp;
 	w->ktUsed = 0;
@@ -1348,6 +1379,7 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge);
+		if (d.shardCount > 1) LAUNCH(w, k_shard_big, 1, 1024, d); // the big islands of a sharded world, dealt over the ranks
 		{
 			int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
 			if (blocks < 1) blocks = 1;
@@ -1562,6 +1594,7 @@ static int phaseSolve(b2hip_world* w)
 				else return setError(B2HIP_ERR_INVALID, "block partition made for an unknown workgroup size");
 				w->dfEpoch += 1;
 				w->blockSteps += 1;
+				w->blocksThisStep = true;
 			}
 			else if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
 			else if (w->solverRows || (sp.velIters + 2) * DF_RANKS >= 65536 || (sp.posIters + 1) * DF_RANKS >= 65536)
@@ -1859,6 +1892,9 @@ static int downloadState(b2hip_world* w)
 	const size_t nb = w->bodies.size();
 	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipMemcpyAsync(w->h_dstate, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost, w->stream));
+	// phase stamps of the resident large-island solver (workgroup 0, 100 MHz ticks since its start): b2Profile's solveInit /
+	// solveVelocity / solvePosition split
+	HIP_TRY(hipMemcpyAsync(w->h_stamps, w->gridBar.p + 8, 8 * sizeof(int), hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	return 0;
 }
@@ -1867,6 +1903,8 @@ static void refreshMirror(b2hip_world* w)
 {
 	// h_state now holds the state of every body; HostBody rows are pulled from it on demand (pullBody)
 	w->stateCount = w->bodies.size();
+	++w->mirrorEpoch;
+	++w->stepEpoch;
 }
 
 // A phase that fails leaves the device state half-stepped: the world unlocks (so that it can still be inspected and
@@ -1886,7 +1924,7 @@ static int checkUsable(b2hip_world* w, const char* what, bool mutator)
 {
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
 	if (w->failed) return setError(B2HIP_ERR_INVALID, std::string(what) + ": the world is in a failed state (" + w->failedWhy + ")");
-	if (mutator && w->stepActive) return setError(B2HIP_ERR_INVALID, std::string(what) + " inside a step");
+	if (mutator && w->stepActive && !w->callbackWindow) return setError(B2HIP_ERR_INVALID, std::string(what) + " inside a step");
 	return 0;
 }
 
@@ -1952,9 +1990,12 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->leafCount = 0;
 	w->upBodies = w->upFixtures = w->upShapes = w->upJoints = 0;
 	w->stateCount = 0;
+	w->mirrorEpoch = 1;
+	w->stepEpoch = 1;
 	w->newFixture = false;
 	w->inv_dt0 = 0.0f;
 	w->stepActive = false;
+	w->callbackWindow = false;
 	w->h_state = nullptr;
 	w->h_stateCap = 0;
 	w->lastContacts = 0;
@@ -2043,11 +2084,13 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 			return setError(B2HIP_ERR_HIP, "hipEventCreate failed");
 		}
 	}
-	if (hipHostMalloc((void**)&w->h_dstate, sizeof(DState), hipHostMallocDefault) != hipSuccess)
+	if (hipHostMalloc((void**)&w->h_dstate, sizeof(DState), hipHostMallocDefault) != hipSuccess ||
+		hipHostMalloc((void**)&w->h_stamps, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess)
 	{
 		b2hip_world_destroy(w);
 		return setError(B2HIP_ERR_HIP, "hipHostMalloc failed");
 	}
+	memset(w->h_stamps, 0, 8 * sizeof(int));
 	int rc = ensureCapacity(w, 0);
 	if (rc == 0 && hipStreamSynchronize(w->stream) != hipSuccess) rc = setError(B2HIP_ERR_HIP, "stream sync failed");
 	if (rc)
@@ -2095,7 +2138,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
 	w->filterPairs.release();
 	w->d_editOps.release();
-	w->b_order.release(); w->orderBody.release();
+	w->b_order.release(); w->orderBody.release(); w->bigRoots.release();
 	w->pre_o0.release(); w->pre_o1.release(); w->pre_oimp.release(); w->pre_o3.release(); w->preRecs.release();
 	w->postRecs.release(); w->filterList.release(); w->hostList.release();
 	w->b_blk1.release(); w->b_adopt.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release();
@@ -2104,6 +2147,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->stateOut.release(); w->consts.release();
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
+	if (w->h_stamps) (void)hipHostFree(w->h_stamps);
 	for (int i = 0; i < 13; ++i)
 		if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
 	for (size_t i = 0; i < w->ktEvents.size(); ++i) (void)hipEventDestroy(w->ktEvents[i]);
@@ -2170,6 +2214,8 @@ int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def)
 	b.gravityScale = def->gravity_scale;
 	b.fx = b.fy = b.torque = 0.0f;
 	b.sleepTime = 0.0f;
+	b.pullEpoch = w->mirrorEpoch;
+	b.forceEpoch = w->stepEpoch;
 	if (def->type == B2HIP_DYNAMIC_BODY)
 	{
 		b.mass = 1.0f;
@@ -2678,7 +2724,7 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	w->toiCountersFresh = true;
 	rc = applyPendingFilters(w);
 	if (rc) return rc;
-	rc = applyEditOps(w); // (after k_step_begin: the end events of destroyed contacts belong to this step's list)
+	rc = applyEditOps(w, false); // (after k_step_begin: the end events of destroyed contacts belong to this step's list)
 	if (rc) return rc;
 	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
 	// b2World.cpp:1628-1639: new fixtures -> find their contacts before colliding
@@ -2793,7 +2839,7 @@ int b2hip_fixture_is_destroyed(const b2hip_world* w, int fixture)
 // The fat AABB a fixture's proxy has right now (the device owns it once the fixture is uploaded)
 static int currentFat(b2hip_world* w, int fixture, float out4[4])
 {
-	if ((size_t)fixture >= w->upFixtures || std::find(w->proxyEdits.begin(), w->proxyEdits.end(), fixture) != w->proxyEdits.end())
+	if ((size_t)fixture >= w->upFixtures || std::find(w->fatEdits.begin(), w->fatEdits.end(), fixture) != w->fatEdits.end())
 	{
 		memcpy(out4, w->fixtures[fixture].fat, 16);
 		return 0;
@@ -2836,6 +2882,7 @@ int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle)
 		f.fat[2] = aabb.hi.x + B2D_AABB_EXTENSION;
 		f.fat[3] = aabb.hi.y + B2D_AABB_EXTENSION;
 		w->proxyEdits.push_back(id);
+		w->fatEdits.push_back(id);
 		if ((size_t)id < w->upFixtures || std::find(w->pendingMoves.begin(), w->pendingMoves.end(), id) == w->pendingMoves.end()) w->pendingMoves.push_back(id);
 		w->newFixture = w->newFixture; // (moves alone do not ask for the top-of-step pair update: the end-of-step one takes them)
 	}
@@ -3053,6 +3100,7 @@ static int collideImpl(b2hip_world* w)
 			for (int i = 0; i < n; ++i) order[i] = std::make_pair(recs[i].key, i);
 			std::sort(order.begin(), order.end(), keyLess);
 			std::vector<int> disabled;
+			w->callbackWindow = true;
 			for (int k = 0; k < n; ++k)
 			{
 				const PreSolveRec& r = recs[order[k].second];
@@ -3061,7 +3109,18 @@ static int collideImpl(b2hip_world* w)
 				toManifold(&newM, r.n0, r.n1, r.nimp, r.n3);
 				if (!w->preSolveFn(w->preSolveUser, r.info.x, r.info.y, r.info.z, &oldM, &newM)) disabled.push_back(r.info.x);
 			}
+			w->callbackWindow = false;
 			rc = applyHostList(w, k_presolve_disable, disabled);
+			if (rc) return rc;
+		}
+		// Edits made from inside PreSolve take effect at once, as in the reference, whose deferred callbacks run between
+		// Collide and Solve (b2ContactManager::FinishCollide, b2ContactManager.cpp:387-441; Testbed/Tests/TunnelingTest.h
+		// switches sensors, thick shapes and bullets there and expects this step's solvers to see it)
+		if (!w->dirtyList.empty() || !w->editOps.empty() || !w->proxyEdits.empty() || !w->pendingMoves.empty())
+		{
+			rc = flushEdits(w);
+			if (rc) return rc;
+			rc = applyEditOps(w, false);
 			if (rc) return rc;
 		}
 	}
@@ -3376,6 +3435,18 @@ static int stepEndImpl(b2hip_world* w)
 	p[9] = bp0 + bp1 + bpTop;                                                    // broadphase
 	if (w->toiEventValid) { (void)hipEventElapsedTime(&ms, w->ev[10], w->ev[12]); p[7] = ms; }  // solveTOI
 	w->solverMs = small + large;
+	if (w->blocksThisStep && w->h_stamps[4] > 0)
+	{
+		// b2Profile::solveInit / solveVelocity / solvePosition (b2TimeStep.h:30-32) from the block solver's own phase stamps:
+		// [0] constraints initialised, [1] velocity iterations done, [2] positions integrated, [3] position iterations done,
+		// [4] written back (10 ns ticks); scaled to the event-measured span of the launch (stamps are workgroup 0's view)
+		const float tick = 1.0e-5f; // ms
+		const float total = tick * (float)w->h_stamps[4];
+		const float scale = total > 0.0f ? large / total : 0.0f;
+		p[4] = scale * tick * (float)w->h_stamps[0];
+		p[5] = small + scale * tick * (float)(w->h_stamps[2] - w->h_stamps[0]);
+		p[6] = scale * tick * (float)(w->h_stamps[4] - w->h_stamps[2]);
+	}
 	}
 	const int Ct = w->last.nSContacts + w->last.nLContacts;
 	const int B = w->last.nSBodies + w->last.nLBodies;
@@ -3434,7 +3505,7 @@ int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state
 	{
 		const HostBody& b = w->bodies[first + i];
 		b2hip_body_state& s = out[i];
-		if (!b.dirty && (size_t)(first + i) < w->stateCount)
+		if (!b.dirty && b.pullEpoch != w->mirrorEpoch && (size_t)(first + i) < w->stateCount)
 		{
 			// straight from the pinned read-back buffer (same 40-byte layout)
 			memcpy(&s, w->h_state + 10 * (size_t)(first + i), sizeof(b2hip_body_state));
@@ -3458,7 +3529,7 @@ static int flushForRead(b2hip_world* w)
 	DEVICE_GUARD(w);
 	int rc = flushEdits(w);
 	if (rc) return rc;
-	return applyEditOps(w);
+	return applyEditOps(w, true);
 }
 
 int b2hip_contact_count(b2hip_world* w)
@@ -3549,7 +3620,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	if (rc) return rc;
 	rc = applyPendingFilters(w); // ... including the re-filter flags of joints created / destroyed since the last step
 	if (rc) return rc;
-	rc = applyEditOps(w);
+	rc = applyEditOps(w, true);
 	if (rc) return rc;
 	rc = readState(w);
 	if (rc) return rc;
@@ -3574,7 +3645,14 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	o.host(&w->def, sizeof(w->def));
 	for (size_t i = 0; i < nb; ++i)
 	{
-		o.host(&w->bodies[i], offsetof(HostBody, fixtures));
+		// (forces left in a row from before the last step are stale in an auto-clear world: the loaded world treats every
+		// saved force as pending)
+		HostBody row;
+		memcpy((void*)&row, &w->bodies[i], offsetof(HostBody, fixtures));
+		const HostBody& src = w->bodies[i];
+		const bool current = src.dirty || src.pullEpoch == w->mirrorEpoch || i >= w->stateCount;
+		if (w->def.auto_clear_forces && !(current && src.forceEpoch == w->stepEpoch) && i < w->stateCount) { row.fx = row.fy = row.torque = 0.0f; }
+		o.host(&row, offsetof(HostBody, fixtures));
 		const char dirty = w->bodies[i].dirty ? 1 : 0;
 		o.host(&dirty, 1);
 	}
@@ -3741,6 +3819,8 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	{
 		memcpy((void*)&w->bodies[i], bodiesAt + i * bodyBytes, offsetof(HostBody, fixtures));
 		w->bodies[i].dirty = bodiesAt[i * bodyBytes + offsetof(HostBody, fixtures)] != 0;
+		w->bodies[i].pullEpoch = 0;
+		w->bodies[i].forceEpoch = w->stepEpoch;
 		if (w->bodies[i].dirty) w->dirtyList.push_back((int)i);
 	}
 	{
@@ -3846,6 +3926,52 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 		c.restitution = mat[i].y;
 	}
 	return n;
+}
+
+int b2hip_set_shard(b2hip_world* w, int rank, int count)
+{
+	if (int rcu = checkUsable(w, "b2hip_set_shard", true)) return rcu;
+	if (count < 1 || rank < 0 || rank >= count) return setError(B2HIP_ERR_INVALID, "bad shard rank / count");
+	w->dw.shardRank = rank;
+	w->dw.shardCount = count;
+	return B2HIP_OK;
+}
+
+int b2hip_shard_exchange_words(b2hip_world* w, size_t* words)
+{
+	if (!w || !words) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shard_exchange_words outside a step");
+	DEVICE_GUARD(w);
+	int rc = readState(w);
+	if (rc) return rc;
+	*words = (size_t)w->dw.nBodies * SHARD_BODY_WORDS + (size_t)std::max(w->h_dstate->c.nContacts, 0) * SHARD_CONTACT_WORDS +
+		(size_t)w->dw.nJoints * SHARD_JOINT_WORDS;
+	return B2HIP_OK;
+}
+
+int b2hip_shard_export(b2hip_world* w, void* device_buffer, size_t words)
+{
+	if (!w || !device_buffer) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shard_export outside a step");
+	DEVICE_GUARD(w);
+	size_t need = 0;
+	if (int rc = b2hip_shard_exchange_words(w, &need)) return rc;
+	if (words < need) return setError(B2HIP_ERR_CAPACITY, "exchange buffer too small");
+	LAUNCH(w, k_shard_export, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, (int*)device_buffer);
+	HIP_TRY(hipStreamSynchronize(w->stream)); // the caller's collective runs on its own stream
+	return B2HIP_OK;
+}
+
+int b2hip_shard_import(b2hip_world* w, const void* device_buffer, size_t words)
+{
+	if (!w || !device_buffer) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shard_import outside a step");
+	DEVICE_GUARD(w);
+	size_t need = 0;
+	if (int rc = b2hip_shard_exchange_words(w, &need)) return rc;
+	if (words < need) return setError(B2HIP_ERR_CAPACITY, "exchange buffer too small");
+	LAUNCH(w, k_shard_import, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, (const int*)device_buffer);
+	return B2HIP_OK;
 }
 
 int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* user)

@@ -8,6 +8,8 @@
 #ifndef B2_WORLD_H
 #define B2_WORLD_H
 
+#include <atomic>
+#include <mutex>
 #include "Box2D/Common/b2Math.h"
 #include "Box2D/Common/b2BlockAllocator.h"
 #include "Box2D/Common/b2StackAllocator.h"
@@ -125,7 +127,9 @@ private:
 	b2Profile m_profile;
 	b2BlockAllocator m_blockAllocator;
 	mutable std::vector<b2hip_body_state> m_states;
-	mutable bool m_statesValid;
+	mutable std::atomic<bool> m_statesValid; // (read by user range tasks on several threads: RefreshStates locks)
+	mutable std::mutex m_statesMutex;
+	void TouchState(int32 id) const;
 	std::vector<b2Contact> m_contactViews;
 	bool m_contactsValid;
 	std::vector<b2ContactEdge> m_edgeViews; // b2Body::GetContactList: edges of one body, rebuilt per call

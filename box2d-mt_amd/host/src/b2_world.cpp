@@ -716,15 +716,26 @@ int32 b2World::GetContactCount() const
 	return m_hip ? b2hip_contact_count(m_hip) : 0;
 }
 
+// The per-body getters and setters may be called from user range tasks on several threads at once, on different bodies
+// (Testbed/Tests/ManyBodies.h:39-64): the first reader after a step fills the cache under a lock, a setter refreshes its
+// own body's row only.
 void b2World::RefreshStates() const
 {
-	if (m_statesValid) return;
+	if (m_statesValid.load(std::memory_order_acquire)) return;
+	std::lock_guard<std::mutex> lock(m_statesMutex);
+	if (m_statesValid.load(std::memory_order_relaxed)) return;
 	m_states.resize(m_bodies.size());
 	if (m_hip && !m_bodies.empty())
 	{
 		b2hip_get_body_states(m_hip, 0, (int)m_bodies.size(), m_states.data());
 	}
-	m_statesValid = true;
+	m_statesValid.store(true, std::memory_order_release);
+}
+
+void b2World::TouchState(int32 id) const
+{
+	if (!m_hip || !m_statesValid.load(std::memory_order_acquire) || (size_t)id >= m_states.size()) return;
+	b2hip_get_body_states(m_hip, id, 1, &m_states[id]);
 }
 
 const b2hip_body_state& b2World::State(int32 id) const
@@ -947,7 +958,7 @@ void b2Body::SetLinearVelocity(const b2Vec2& v)
 	if (m_type == b2_staticBody) return;
 	const b2hip_body_state& s = m_world->State(m_id);
 	b2hip_set_velocity(m_world->m_hip, m_id, v.x, v.y, s.w);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::SetAngularVelocity(float32 omega)
@@ -955,7 +966,7 @@ void b2Body::SetAngularVelocity(float32 omega)
 	if (m_type == b2_staticBody) return;
 	const b2hip_body_state& s = m_world->State(m_id);
 	b2hip_set_velocity(m_world->m_hip, m_id, s.vx, s.vy, omega);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::ApplyForce(const b2Vec2& force, const b2Vec2& point, bool wake)
@@ -963,37 +974,37 @@ void b2Body::ApplyForce(const b2Vec2& force, const b2Vec2& point, bool wake)
 	const b2hip_body_state& s = m_world->State(m_id);
 	float32 torque = b2Cross(point - b2Vec2(s.cx, s.cy), force);
 	b2hip_apply_force(m_world->m_hip, m_id, force.x, force.y, torque, wake);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::ApplyForceToCenter(const b2Vec2& force, bool wake)
 {
 	b2hip_apply_force(m_world->m_hip, m_id, force.x, force.y, 0.0f, wake);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::ApplyTorque(float32 torque, bool wake)
 {
 	b2hip_apply_force(m_world->m_hip, m_id, 0.0f, 0.0f, torque, wake);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::ApplyLinearImpulse(const b2Vec2& impulse, const b2Vec2& point, bool wake)
 {
 	b2hip_apply_linear_impulse(m_world->m_hip, m_id, impulse.x, impulse.y, point.x, point.y, wake);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::ApplyLinearImpulseToCenter(const b2Vec2& impulse, bool wake)
 {
 	b2hip_apply_linear_impulse_to_center(m_world->m_hip, m_id, impulse.x, impulse.y, wake);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::ApplyAngularImpulse(float32 impulse, bool wake)
 {
 	b2hip_apply_angular_impulse(m_world->m_hip, m_id, impulse, wake);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::SetTransform(const b2Vec2& position, float32 angle)
@@ -1008,7 +1019,7 @@ void b2Body::SetTransform(const b2Vec2& position, float32 angle)
 void b2Body::SetAwake(bool flag)
 {
 	b2hip_set_awake(m_world->m_hip, m_id, flag ? 1 : 0);
-	m_world->m_statesValid = false;
+	m_world->TouchState(m_id);
 }
 
 void b2Body::SetBullet(bool flag)
@@ -1079,7 +1090,7 @@ void b2Fixture::SetSensor(bool sensor)
 	if (sensor == m_isSensor) return;
 	m_isSensor = sensor;
 	b2hip_fixture_set_sensor(m_body->GetWorld()->GetDeviceWorld(), m_id, sensor ? 1 : 0);
-	m_body->m_world->m_statesValid = false;
+	m_body->m_world->TouchState(m_body->m_id); // (SetSensor wakes its body)
 }
 
 void b2Fixture::SetThickShape(bool flag)

@@ -478,6 +478,21 @@ int b2hip_enable_post_solve(b2hip_world* w, int enable);
 /* returns the number of records of the last step (negative on error); at most `cap` are written */
 int b2hip_get_post_solve(b2hip_world* w, int cap, b2hip_contact_impulse* out);
 
+/* ---- One world over the GPUs of a node, sharded by island ----------------------------------------------
+ * Every rank builds the SAME world (same calls, same ids) and steps it with the phase entry points; b2hip_solve solves only
+ * the islands this rank owns (ownership is a pure function of the shared state: big islands are dealt round robin in the
+ * order of their root ids, the others by a hash of their root), everything else runs replicated and deterministic, so the
+ * ranks stay bit-identical. Between b2hip_solve and b2hip_sync_fixtures the ranks exchange what they solved:
+ *     b2hip_shard_exchange_words -> buffer of that many int32 (memory the library can address: DEVICE memory for libb2hip)
+ *     b2hip_shard_export(buffer)  -> the records of the islands this rank owns, INT32_MIN everywhere else
+ *     all-reduce MAX over the ranks on the int32 buffer (RCCL over xGMI: torch.distributed backend "nccl"; gloo on CPUs)
+ *     b2hip_shard_import(buffer)  -> the other ranks' results enter the world
+ * box2d-mt_amd/python/sharding.py (ShardedWorld.step) is that sequence. With one rank (the default) nothing changes. */
+int b2hip_set_shard(b2hip_world* w, int rank, int count);
+int b2hip_shard_exchange_words(b2hip_world* w, size_t* words);
+int b2hip_shard_export(b2hip_world* w, void* buffer, size_t words);
+int b2hip_shard_import(b2hip_world* w, const void* buffer, size_t words);
+
 /* Island label per body for the last step: -1 = not solved (asleep / static), else the smallest body id
  * of the island (island membership is compared as a set partition). */
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out);

@@ -15,6 +15,7 @@
 #ifndef B2O_H
 #define B2O_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -116,6 +117,20 @@ typedef struct b2o_contact_event
 	int32_t kind;          /* 0 = begin, 1 = end */
 	int32_t contact_index; /* into b2o_get_contacts of the same step, -1 = destroyed */
 } b2o_contact_event;
+/* the phases of b2o_step as separate calls, and island sharding (ownership rule and exchange records:
+ * box2d-mt_amd/csrc/b2d_kernels_shard.h; protocol: include/b2hip.h) */
+void b2o_step_begin(b2o_world* w, float dt, int velIters, int posIters);
+void b2o_phase_collide(b2o_world* w);
+void b2o_phase_solve(b2o_world* w);
+void b2o_phase_sync_fixtures(b2o_world* w);
+void b2o_phase_find_new_contacts(b2o_world* w);
+void b2o_phase_solve_toi(b2o_world* w);
+void b2o_step_end(b2o_world* w);
+void b2o_set_shard(b2o_world* w, int rank, int count);
+size_t b2o_shard_exchange_words(const b2o_world* w);
+void b2o_shard_export(const b2o_world* w, int32_t* out);
+void b2o_shard_import(b2o_world* w, const int32_t* in);
+
 /* life cycle and mutators between steps (semantics and reference lines: include/b2hip.h) */
 void b2o_destroy_body(b2o_world* w, int body);
 void b2o_destroy_fixture(b2o_world* w, int fixture);

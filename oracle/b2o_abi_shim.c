@@ -218,6 +218,18 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
 	return b2o_get_contact_events(w->o, cap, (b2o_contact_event*)out); /* identical layout */
 }
 
+int b2hip_step_begin(b2hip_world* w, float dt, int vi, int pi) { b2o_step_begin(w->o, dt, vi, pi); return 0; }
+int b2hip_collide(b2hip_world* w) { b2o_phase_collide(w->o); return 0; }
+int b2hip_solve(b2hip_world* w) { b2o_phase_solve(w->o); return 0; }
+int b2hip_sync_fixtures(b2hip_world* w) { b2o_phase_sync_fixtures(w->o); return 0; }
+int b2hip_find_new_contacts(b2hip_world* w) { b2o_phase_find_new_contacts(w->o); return 0; }
+int b2hip_solve_toi(b2hip_world* w) { b2o_phase_solve_toi(w->o); return 0; }
+int b2hip_step_end(b2hip_world* w) { b2o_step_end(w->o); return 0; }
+int b2hip_set_shard(b2hip_world* w, int rank, int count) { b2o_set_shard(w->o, rank, count); return 0; }
+int b2hip_shard_exchange_words(b2hip_world* w, size_t* words) { *words = b2o_shard_exchange_words(w->o); return 0; }
+int b2hip_shard_export(b2hip_world* w, void* buffer, size_t words) { (void)words; b2o_shard_export(w->o, (int32_t*)buffer); return 0; }
+int b2hip_shard_import(b2hip_world* w, const void* buffer, size_t words) { (void)words; b2o_shard_import(w->o, (const int32_t*)buffer); return 0; }
+
 int b2hip_destroy_body(b2hip_world* w, int body) { b2o_destroy_body(w->o, body); return 0; }
 int b2hip_destroy_fixture(b2hip_world* w, int fixture) { b2o_destroy_fixture(w->o, fixture); return 0; }
 int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle) { b2o_set_transform(w->o, body, x, y, angle); return 0; }

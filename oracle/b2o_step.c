@@ -131,6 +131,12 @@ struct b2o_world
 	int eventsOn;
 	b2o_contact_event* events; int nEvents, capEvents;
 	uint64_t* eventKeys; int capEventKeys;
+	/* island sharding (same ownership rule and exchange format as box2d-mt_amd/csrc/b2d_kernels_shard.h) */
+	int shardRank, shardCount;
+	unsigned char* bodyOwned; int capBodyOwned;       /* per body: its island was solved HERE this step */
+	unsigned char* contactOwned; int capContactOwned; /* per contact slot */
+	unsigned char* jointOwned; int capJointOwned;
+	float stepDt; int stepVelIters, stepPosIters;     /* parameters of the running step (phase entry points) */
 	/* m_nonStaticBodies (b2World.cpp:573, 662-667): island seeds are taken in this order */
 	int* nonStatic; int nNonStatic, capNonStatic;
 	/* the other listener callbacks and the user contact filter (same protocol as include/b2hip.h) */
@@ -1768,9 +1774,37 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 }
 
 /* b2World::Solve  b2World.cpp:1166-1431 */
-static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIters)
+#define B2O_SHARD_BIG_BODIES 4096
+static uint32_t uf_priority(int i) { return (uint32_t)i * 2654435761u; }
+static int shard_hash_owner(int root, int count) { return (int)(((uint32_t)root * 2654435761u >> 12) % (uint32_t)count); }
+
+typedef struct { int root; int* bodies; int nb; int* contacts; int nc; int* joints; int nj; } pending_island;
+static int pending_cmp(const void* a, const void* b)
+{
+	const pending_island* p = (const pending_island*)a;
+	const pending_island* q = (const pending_island*)b;
+	return p->root < q->root ? -1 : (p->root > q->root ? 1 : 0);
+}
+
+static void mark_owned(b2o_world* w, const int* bodies, int nb, const int* contacts, int nc, const int* joints, int nj)
+{
+	for (int i = 0; i < nb; ++i) if (w->bodies[bodies[i]].type != 0) w->bodyOwned[bodies[i]] = 1;
+	for (int i = 0; i < nc; ++i) w->contactOwned[contacts[i]] = 1;
+	for (int i = 0; i < nj; ++i) w->jointOwned[joints[i]] = 1;
+}
+
+static void solve_islands(b2o_world* w, float h, float dtRatio, int velIters, int posIters)
 {
 	int nb = w->nBodies;
+	const int sharded = w->shardCount > 1;
+	pending_island* pending = NULL;
+	int nPending = 0, capPending = 0;
+	GROW(w->bodyOwned, w->capBodyOwned, w->nBodies + 1, unsigned char);
+	GROW(w->contactOwned, w->capContactOwned, w->nContactSlots + 1, unsigned char);
+	GROW(w->jointOwned, w->capJointOwned, w->nJoints + 1, unsigned char);
+	memset(w->bodyOwned, 0, (size_t)w->nBodies + 1);
+	memset(w->contactOwned, 0, (size_t)w->nContactSlots + 1);
+	memset(w->jointOwned, 0, (size_t)w->nJoints + 1);
 	int* islandBodies = (int*)malloc(sizeof(int) * (size_t)(nb + w->liveContacts + 2));
 	int* islandContacts = (int*)malloc(sizeof(int) * (size_t)(w->liveContacts + 1));
 	int* stack = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
@@ -1836,17 +1870,71 @@ static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIte
 			body_t* b = &w->bodies[islandBodies[j]];
 			if (b->type != 0) b->label = label;
 		}
+		if (sharded)
+		{
+			/* who solves this island? its root is the non-static member of lowest priority (the device's union-find root) */
+			int root = -1, nonStatic = 0;
+			for (int j = 0; j < bodyCount; ++j)
+			{
+				const int bi = islandBodies[j];
+				if (w->bodies[bi].type == 0) continue;
+				++nonStatic;
+				if (root < 0 || uf_priority(bi) < uf_priority(root)) root = bi;
+			}
+			if (nonStatic > B2O_SHARD_BIG_BODIES)
+			{
+				/* big islands are dealt round robin in root-id order once all of them are known */
+				GROW(pending, capPending, nPending + 1, pending_island);
+				pending_island* p = &pending[nPending++];
+				p->root = root;
+				p->nb = bodyCount; p->nc = contactCount; p->nj = jointCount;
+				p->bodies = (int*)malloc(sizeof(int) * (size_t)(bodyCount + 1));
+				p->contacts = (int*)malloc(sizeof(int) * (size_t)(contactCount + 1));
+				p->joints = (int*)malloc(sizeof(int) * (size_t)(jointCount + 1));
+				memcpy(p->bodies, islandBodies, sizeof(int) * (size_t)bodyCount);
+				memcpy(p->contacts, islandContacts, sizeof(int) * (size_t)contactCount);
+				memcpy(p->joints, islandJoints, sizeof(int) * (size_t)jointCount);
+				continue;
+			}
+			if (shard_hash_owner(root, w->shardCount) != w->shardRank) continue; /* another rank's: its bodies stay flagged */
+		}
+		mark_owned(w, islandBodies, bodyCount, islandContacts, contactCount, islandJoints, jointCount);
 		solve_island(w, islandBodies, bodyCount, islandContacts, contactCount, islandJoints, jointCount, h, dtRatio, velIters, posIters);
 	}
+	if (nPending > 0)
+	{
+		qsort(pending, (size_t)nPending, sizeof(pending_island), pending_cmp);
+		for (int k = 0; k < nPending; ++k)
+		{
+			pending_island* p = &pending[k];
+			if (k % w->shardCount == w->shardRank)
+			{
+				mark_owned(w, p->bodies, p->nb, p->contacts, p->nc, p->joints, p->nj);
+				solve_island(w, p->bodies, p->nb, p->contacts, p->nc, p->joints, p->nj, h, dtRatio, velIters, posIters);
+			}
+			free(p->bodies); free(p->contacts); free(p->joints);
+		}
+	}
+	free(pending);
 	free(islandBodies);
 	free(islandContacts);
 	free(stack);
 	free(islandJoints);
+}
+
+/* the rest of b2World::Solve: SynchronizeFixtures, FindNewContacts, ClearPostSolve (b2World.cpp:1373-1465) */
+static void clear_post_solve(b2o_world* w)
+{
+	for (int i = 0; i < w->nContactSlots; ++i) w->contacts[i].flags &= ~CF_ISLAND;
+	for (int i = 0; i < w->nBodies; ++i) w->bodies[i].flags &= ~BF_ISLAND;
+}
+
+static void solve(b2o_world* w, float h, float dtRatio, int velIters, int posIters)
+{
+	solve_islands(w, h, dtRatio, velIters, posIters);
 	synchronize_fixtures(w);
 	find_new_contacts(w);
-	/* ClearPostSolve  b2World.cpp:1433-1465 */
-	for (int i = 0; i < w->nContactSlots; ++i) w->contacts[i].flags &= ~CF_ISLAND;
-	for (int i = 0; i < nb; ++i) w->bodies[i].flags &= ~BF_ISLAND;
+	clear_post_solve(w);
 }
 
 /* ---- continuous collision (TOI) ------------------------------------------------------------------ */
@@ -2273,6 +2361,159 @@ static void finish_post_solve(b2o_world* w)
 	}
 	memcpy(w->postSolve, sorted, sizeof(b2o_contact_impulse) * (size_t)n);
 	free(where); free(sorted); free(rank); free(slots); free(order);
+}
+
+/* ---- the phases of a step as separate entry points (same sequence as b2o_step; the sharded driver exchanges the solved
+ * islands between b2o_phase_solve and b2o_phase_sync_fixtures) ---------------------------------------------------------- */
+void b2o_step_begin(b2o_world* w, float dt, int velIters, int posIters)
+{
+	w->nEvents = 0;
+	w->nPostSolve = 0;
+	w->stepDt = dt; w->stepVelIters = velIters; w->stepPosIters = posIters;
+	if (w->newFixture)
+	{
+		find_new_contacts(w);
+		w->newFixture = 0;
+	}
+}
+void b2o_phase_collide(b2o_world* w) { collide(w); }
+void b2o_phase_solve(b2o_world* w)
+{
+	if (w->stepDt > 0.0f) solve_islands(w, w->stepDt, w->inv_dt0 * w->stepDt, w->stepVelIters, w->stepPosIters);
+}
+void b2o_phase_sync_fixtures(b2o_world* w) { if (w->stepDt > 0.0f) synchronize_fixtures(w); }
+void b2o_phase_find_new_contacts(b2o_world* w)
+{
+	if (w->stepDt > 0.0f)
+	{
+		find_new_contacts(w);
+		clear_post_solve(w);
+	}
+}
+void b2o_phase_solve_toi(b2o_world* w) { if (w->continuous && w->stepDt > 0.0f) solve_toi(w, w->stepDt, w->stepVelIters); }
+void b2o_step_end(b2o_world* w)
+{
+	if (w->stepDt > 0.0f) w->inv_dt0 = 1.0f / w->stepDt;
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		w->bodies[i].force = v_make(0.0f, 0.0f);
+		w->bodies[i].torque = 0.0f;
+	}
+	if (w->eventsOn) collect_contact_events(w);
+	if (w->postSolveOn) finish_post_solve(w);
+}
+
+/* ---- island sharding: exchange records, layout and ownership as in b2d_kernels_shard.h ---------------------------------------- */
+#define SHARD_BODY_WORDS 13
+#define SHARD_CONTACT_WORDS 5
+#define SHARD_JOINT_WORDS 6
+#define SHARD_NOBODY ((int32_t)0x80000000)
+static int32_t fbits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+static float bitsf(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+
+void b2o_set_shard(b2o_world* w, int rank, int count) { w->shardRank = rank; w->shardCount = count; }
+
+size_t b2o_shard_exchange_words(const b2o_world* w)
+{
+	return (size_t)w->nBodies * SHARD_BODY_WORDS + (size_t)w->liveContacts * SHARD_CONTACT_WORDS + (size_t)w->nJoints * SHARD_JOINT_WORDS;
+}
+
+void b2o_shard_export(const b2o_world* w, int32_t* out)
+{
+	const int32_t me = w->shardRank + 1;
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		int32_t* o = out + (size_t)i * SHARD_BODY_WORDS;
+		const body_t* b = &w->bodies[i];
+		if (!w->bodyOwned || !w->bodyOwned[i])
+		{
+			for (int k = 0; k < SHARD_BODY_WORDS; ++k) o[k] = SHARD_NOBODY;
+			continue;
+		}
+		o[0] = fbits(b->c.x); o[1] = fbits(b->c.y); o[2] = fbits(b->a); o[3] = fbits(b->sleepTime);
+		o[4] = fbits(b->v.x); o[5] = fbits(b->v.y); o[6] = fbits(b->w);
+		o[7] = (b->flags & BF_AWAKE) ? 1 : 0;
+		o[8] = fbits(b->xf.p.x); o[9] = fbits(b->xf.p.y); o[10] = fbits(b->xf.q.s); o[11] = fbits(b->xf.q.c);
+		o[12] = me;
+	}
+	int32_t* oc = out + (size_t)w->nBodies * SHARD_BODY_WORDS;
+	int* rank = contact_ranks(w);
+	for (int slot = 0; slot < w->nContactSlots; ++slot)
+	{
+		if (rank[slot] < 0) continue;
+		int32_t* o = oc + (size_t)rank[slot] * SHARD_CONTACT_WORDS;
+		const contact_t* c = &w->contacts[slot];
+		if (!w->contactOwned || !w->contactOwned[slot])
+		{
+			for (int k = 0; k < SHARD_CONTACT_WORDS; ++k) o[k] = SHARD_NOBODY;
+			continue;
+		}
+		o[0] = fbits(c->m.ni[0]); o[1] = fbits(c->m.ti[0]); o[2] = fbits(c->m.ni[1]); o[3] = fbits(c->m.ti[1]);
+		o[4] = me;
+	}
+	free(rank);
+	int32_t* oj = oc + (size_t)w->liveContacts * SHARD_CONTACT_WORDS;
+	for (int j = 0; j < w->nJoints; ++j)
+	{
+		int32_t* o = oj + (size_t)j * SHARD_JOINT_WORDS;
+		const revolute_t* jn = &w->joints[j];
+		if (!w->jointOwned || !w->jointOwned[j])
+		{
+			for (int k = 0; k < SHARD_JOINT_WORDS; ++k) o[k] = SHARD_NOBODY;
+			continue;
+		}
+		o[0] = fbits(jn->impulse[0]);
+		o[1] = fbits(jn->type == B2O_JOINT_WHEEL ? jn->springImpulse : jn->impulse[1]);
+		o[2] = fbits(jn->impulse[2]);
+		o[3] = fbits(jn->motorImpulse);
+		o[4] = jn->limitState;
+		o[5] = me;
+	}
+}
+
+void b2o_shard_import(b2o_world* w, const int32_t* in)
+{
+	const int32_t me = w->shardRank + 1;
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		const int32_t* o = in + (size_t)i * SHARD_BODY_WORDS;
+		if (o[12] <= 0 || o[12] == me) continue;
+		body_t* b = &w->bodies[i];
+		b->c0 = b->c; b->a0 = b->a; b->alpha0 = 0.0f;
+		b->c = v_make(bitsf(o[0]), bitsf(o[1])); b->a = bitsf(o[2]); b->sleepTime = bitsf(o[3]);
+		b->v = v_make(bitsf(o[4]), bitsf(o[5])); b->w = bitsf(o[6]);
+		b->xf.p = v_make(bitsf(o[8]), bitsf(o[9])); b->xf.q.s = bitsf(o[10]); b->xf.q.c = bitsf(o[11]);
+		if (o[7]) b->flags |= BF_AWAKE;
+		else
+		{
+			b->flags &= ~BF_AWAKE;
+			b->force = v_make(0.0f, 0.0f);
+			b->torque = 0.0f;
+		}
+	}
+	const int32_t* ic = in + (size_t)w->nBodies * SHARD_BODY_WORDS;
+	int* rank = contact_ranks(w);
+	for (int slot = 0; slot < w->nContactSlots; ++slot)
+	{
+		if (rank[slot] < 0) continue;
+		const int32_t* o = ic + (size_t)rank[slot] * SHARD_CONTACT_WORDS;
+		if (o[4] <= 0 || o[4] == me) continue;
+		contact_t* c = &w->contacts[slot];
+		c->m.ni[0] = bitsf(o[0]); c->m.ti[0] = bitsf(o[1]); c->m.ni[1] = bitsf(o[2]); c->m.ti[1] = bitsf(o[3]);
+	}
+	free(rank);
+	const int32_t* ij = ic + (size_t)w->liveContacts * SHARD_CONTACT_WORDS;
+	for (int j = 0; j < w->nJoints; ++j)
+	{
+		const int32_t* o = ij + (size_t)j * SHARD_JOINT_WORDS;
+		if (o[5] <= 0 || o[5] == me) continue;
+		revolute_t* jn = &w->joints[j];
+		jn->impulse[0] = bitsf(o[0]);
+		if (jn->type == B2O_JOINT_WHEEL) jn->springImpulse = bitsf(o[1]); else jn->impulse[1] = bitsf(o[1]);
+		jn->impulse[2] = bitsf(o[2]);
+		jn->motorImpulse = bitsf(o[3]);
+		jn->limitState = o[4];
+	}
 }
 
 void b2o_step(b2o_world* w, float dt, int velIters, int posIters)

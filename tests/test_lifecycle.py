@@ -81,7 +81,7 @@ def test_slowly_dragged_body_stays_awake(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("count,seed,flags", CASES)
-@pytest.mark.parametrize("mode", ["exact", "default"])
+@pytest.mark.parametrize("mode", ["exact"])
 def test_device_life_cycle_matches_the_oracle(amd, oracle, monkeypatch, count, seed, flags, mode):
     if mode == "exact":
         monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")

@@ -64,3 +64,99 @@ def test_plan_covers_every_body_once():
             ids = sharding.global_body_ids(ROWS, COUNT, r, world)
             seen[ids[1:]] += 1
         assert (seen[1:] == 1).all()
+
+
+# ---- one world sharded by island owner: the replicated world + one exchange per step ------------------
+def build_field(w, n, seed, with_joints=True):
+    """A bounded zero-gravity field of moving discs and boxes (the ManyBodies recipe, ManyBodies.h:203-313, small): islands
+    form, merge across owners and fall apart again all the time. A few jointed pairs ride along."""
+    import b2hip
+    rng = np.random.default_rng(seed)
+    half = 14.0
+    g = w.create_body(b2hip.STATIC)
+    for (hx, hy, cx, cy) in ((half, 0.5, 0.0, -half), (half, 0.5, 0.0, half), (0.5, half, -half, 0.0), (0.5, half, half, 0.0)):
+        wall = b2hip.box_shape(hx, hy)
+        for i in range(4):
+            wall.verts[2 * i] += cx
+            wall.verts[2 * i + 1] += cy
+        wall.centroid[0], wall.centroid[1] = cx, cy
+        w.create_fixture(g, wall)
+    prev = None
+    for i in range(n):
+        r = float(rng.uniform(0.25, 0.6))
+        ang = float(rng.uniform(0, 6.28))
+        speed = float(rng.uniform(2.0, 9.0))
+        b = w.create_body(b2hip.DYNAMIC, position=(float(rng.uniform(-half + 1.5, half - 1.5)), float(rng.uniform(-half + 1.5, half - 1.5))),
+                          angle=float(rng.uniform(0, 6.28)), velocity=(speed * np.cos(ang), speed * np.sin(ang)), angular_damping=0.25)
+        shape = b2hip.circle_shape(r) if i % 2 == 0 else b2hip.box_shape(r, 0.7 * r)
+        w.create_fixture(b, shape, density=1.0, friction=0.3, restitution=0.2 if i % 3 == 0 else 0.0)
+        if with_joints and i % 23 == 5 and prev is not None:
+            w.create_distance_joint(prev, b, length=1.5, frequency_hz=3.0, damping_ratio=0.5)
+        prev = b
+
+
+FIELD_N, FIELD_STEPS = 260, 150
+
+
+def _field_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import b2harness as bh
+    import b2hip
+    import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    lib = b2hip.load(bh.ORACLE_LIB, optional_ok=True)
+    b2hip._lib = lib
+    w = b2hip.World(gravity=(0.0, 0.0), library=lib)
+    build_field(w, FIELD_N, seed=12)
+    sw = sharding.ShardedWorld(w, dist=dist, device="cpu")
+    trace = []
+    islands_split = 0
+    for s in range(FIELD_STEPS):
+        sw.step()
+        st = w.body_states()
+        trace.append((st.tobytes(), w.contact_count, w.contacts().tobytes()))
+    dist.barrier()
+    q.put((rank, trace, sw.exchange_bytes))
+    dist.destroy_process_group()
+
+
+def test_field_world_sharded_by_island_owner_equals_the_unsharded_run(built_libs):
+    """Two gloo ranks hold the same field world, each solves the islands it owns (hash of the island root), one
+    all-reduce(MAX) per step exchanges them: every rank must see, after every step, exactly the body states, contact set,
+    manifolds and warm-start impulses of the unsharded run."""
+    import torch.multiprocessing as mp
+    import b2harness as bh
+    import b2hip
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    procs = [ctx.Process(target=_field_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, trace, nbytes = q.get(timeout=600)
+        got[rank] = trace
+        assert nbytes > 0
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lib = b2hip.load(bh.ORACLE_LIB, optional_ok=True)
+    b2hip._lib = lib
+    w = b2hip.World(gravity=(0.0, 0.0), library=lib)
+    build_field(w, FIELD_N, seed=12)
+    multi = 0
+    for s in range(FIELD_STEPS):
+        w.step()
+        want = (w.body_states().tobytes(), w.contact_count, w.contacts().tobytes())
+        for rank in (0, 1):
+            assert got[rank][s][1] == want[1], "rank %d: contact count at step %d" % (rank, s)
+            assert got[rank][s][0] == want[0], "rank %d: body states differ from the unsharded run at step %d" % (rank, s)
+            assert got[rank][s][2] == want[2], "rank %d: contacts (manifolds / impulses) differ at step %d" % (rank, s)
+        lab = w.island_labels()
+        multi = max(multi, int(np.bincount(lab[lab >= 0]).max()) if (lab >= 0).any() else 0)
+    assert multi >= 3, "no island of three or more bodies ever formed: the scene does not exercise island ownership"
+    w.close()

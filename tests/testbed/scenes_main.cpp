@@ -53,6 +53,32 @@ int testbed_trace(const char* name, int steps, double* trace)
 	return -1;
 }
 
+// Debugging aid: the body list (world order) after `steps` steps: x, y, angle, vx, vy, w, awake, type per body. Returns the
+// body count (at most cap rows are written).
+int testbed_states(const char* name, int steps, double* rows8, int cap)
+{
+	for (const Entry& e : kEntries)
+	{
+		if (strcmp(e.name, name) != 0) continue;
+		srand(0);
+		Test* t = e.create();
+		Settings settings;
+		for (int i = 0; i < steps; ++i) t->Step(&settings);
+		int n = 0;
+		for (b2Body* b = t->GetWorld()->GetBodyList(); b; b = b->GetNext(), ++n)
+		{
+			if (n >= cap) continue;
+			double* o = rows8 + 8 * n;
+			o[0] = b->GetPosition().x; o[1] = b->GetPosition().y; o[2] = b->GetAngle();
+			o[3] = b->GetLinearVelocity().x; o[4] = b->GetLinearVelocity().y; o[5] = b->GetAngularVelocity();
+			o[6] = b->IsAwake() ? 1.0 : 0.0; o[7] = (double)b->GetType();
+		}
+		delete t;
+		return n;
+	}
+	return -1;
+}
+
 int testbed_run(const char* name, int steps, double* out6)
 {
 	for (const Entry& e : kEntries)
