@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		W.adjCursor[i] = 0;
 		W.b_slot[i] = -1;
 		W.b_island[i] = -1;
-		W.rootPen[i] = 0;
+		for (int k = 0; k < ROOT_PEN_SLOTS; ++k) W.rootPen[(size_t)k * W.nBodies + i] = 0;
 		W.rootDone[i] = 0;
 		W.rootSleepMin[i] = 0x7f7fffffu; // b2_maxFloat
 		W.rootJointCursor[i] = 0;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 					W.rootIsland[i] = ROOT_REMOTE;
 					atomicAdd(&S->c.nRemoteIslands, 1);
 				}
-				else if ((nj == 0 && w <= W.smallMaxW && forceLarge == 0) || forceLarge == 2)
+				else if ((nj <= SMALL_ISLAND_MAX_JOINTS && w <= W.smallMaxW && forceLarge == 0) || forceLarge == 2)
 				{
 					W.rootIsland[i] = ROOT_SMALL;
 					in = make_int4(nb, nc, w, 1);

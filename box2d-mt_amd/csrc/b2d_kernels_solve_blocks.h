@@ -258,8 +258,7 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	__shared__ int s_hist[MAX_COLORS], s_colStart[MAX_COLORS + 1];
 	__shared__ unsigned long long s_colMask;
 	if (gtid == 0) S->c.allLargeDone = 0;
-	// (penetration maxima: buffer 0 was wiped by k_island_init, buffer 2 is wiped after the first barrier, buffer 1 here)
-	for (int k = gtid; k < nIslands; k += gsize) stcU(&W.rootPen[(size_t)W.nBodies + W.li_roots[k]], 0u);
+	// (penetration maxima: every slot was wiped by k_island_init)
 	const unsigned long long t0 = wall_clock64();
 #define BLK_STAMP(k) do { if (gtid == 0) bar[8 + (k)] = (int)(wall_clock64() - t0); } while (0)
 	const int tagV = ((2 * epoch + 1) & 0x7fff) << 16, tagP = ((2 * epoch + 2) & 0x7fff) << 16;
@@ -486,19 +485,56 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	BLK_STAMP(2);
 
 	// ---- position iterations (b2Island.cpp:316-335, b2ContactSolver.cpp:676-752) -----------------------------------------------------------
-	// An island is closed once an iteration leaves its minimum separation >= -3 linearSlop (b2Island.cpp:329-334). ONE grid
-	// barrier per iteration: the penetration maxima of iteration `it` go to buffer it % 3 of rootPen (three buffers of
-	// nBodies words: the one of iteration it + 2 is wiped after barrier `it`, when nobody reads or adds to it), and after the
-	// barrier every lane reads the verdict of its own island itself. Whether ANY island is still open is known one barrier
-	// later (each workgroup reports its open rows to a counter of iteration it % 4): if none was, iteration it + 1 found
-	// every row inactive, and all workgroups leave after its barrier.
-	bool rowDone = false, hDone = false;
+	// An island is closed once an iteration leaves its minimum separation >= -3 linearSlop (b2Island.cpp:329-334): a verdict
+	// over ALL rows of the island, i.e. a grid barrier per iteration - which made a position iteration three times as long as
+	// a velocity sweep (the sweeps overlap between workgroups, an iteration behind a barrier pays the whole chain of
+	// hand-offs plus the slowest workgroup). So the verdict is taken ONE ITERATION LATE: iteration it + 1 starts without
+	// waiting for it, on every row not yet known to be closed; when the verdict of iteration `it` arrives (by then it almost
+	// always has: no stall), the home bodies of islands it closed are put back to the state iteration `it` left - nothing
+	// else has seen what the surplus iteration did to them (islands share no moving bodies, and a closed island's rows
+	// stay out of every later iteration). The result is the state the barrier-per-iteration form computes, bit for bit.
+	//   pen slots : the penetration maxima of iteration `it` go to slot it % ROOT_PEN_SLOTS of rootPen (all wiped by
+	//               k_island_init); a slot is wiped for re-use after wait(it + 2), before arrive(it + 3)
+	//   barriers  : arrive(it) after the rows of iteration `it`; wait(it - 1) right after it. bar[0] counts arrivals.
+	__shared__ float4 s_back[BLOCK_MAX_BODIES];
+	__shared__ int s_waitOk;
+	auto arrive = [&]()
+	{
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (gb.nWG > 1 && tid == 0) __hip_atomic_fetch_add(&bar[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	auto waitFor = [&](int g) -> bool
+	{
+		if (gb.nWG <= 1) return true;
+		if (tid == 0)
+		{
+			int ok = 1, spins = 0;
+			const int need = (g + 1) * gb.nWG;
+			while (__hip_atomic_load(&bar[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need)
+			{
+				if (++spins > PERSIST_SPIN_MAX || ldcI(&bar[4]) != 0)
+				{
+					stcI(&bar[4], 1);
+					atomicOr(gb.overflow, 64);
+					ok = 0;
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			s_waitOk = ok;
+		}
+		__syncthreads();
+		return s_waitOk != 0;
+	};
+	const float closedAt = -3.0f * B2D_LINEAR_SLOP;
+	bool rowDone = false, bodyDone = false;
+	int itDone = sp.posIters; // iterations run
 	for (int it = 0; it < sp.posIters; ++it)
 	{
-		uint32_t* pen = W.rootPen + (size_t)(it % 3) * W.nBodies;
-		uint32_t* penWipe = W.rootPen + (size_t)((it + 2) % 3) * W.nBodies;
+		uint32_t* pen = W.rootPen + (size_t)(it % ROOT_PEN_SLOTS) * W.nBodies;
 		const bool active = have && !rowDone;
-		const bool hActive = hBoundary && !hDone;
+		const bool hActive = hBoundary && !bodyDone;
 		float minSep = 0.0f;
 		for (unsigned long long m = colMask & COLOR_INTERIOR_BITS; m != 0ull; m &= m - 1ull)
 		{
@@ -549,29 +585,66 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 			}
 		}
 		waveAtomicMaxU32(pen, r.root, floatBits(0.0f - minSep), active);
-		if (!blockBarrier(gb)) return;
-		// after the barrier: verdicts; one lane per island records a closed island for k_large_sleep and wipes the buffer of
-		// the iteration after next
+		arrive();
+		if (it > 0)
+		{
+			// ---- the verdict of iteration it - 1 ----------------------------------------------------------------------------------
+			if (!waitFor(it - 1)) return;
+			const uint32_t* penPrev = W.rootPen + (size_t)((it - 1) % ROOT_PEN_SLOTS) * W.nBodies;
+			if (have && !rowDone) rowDone = -__uint_as_float(ldcU(&penPrev[r.root])) >= closedAt;
+			if (isBody && !bodyDone && -__uint_as_float(ldcU(&penPrev[hRoot])) >= closedAt)
+			{
+				bodyDone = true;
+				s_row[tid] = s_back[tid]; // what iteration it - 1 left: iteration `it` should not have touched this island
+			}
+			// one lane per island: the flag k_large_sleep reads, the census of open islands, the iteration count
+			int open = 0;
+			for (int k = gtid; k < nIslands; k += gsize)
+			{
+				const int root = W.li_roots[k];
+				if (ldcI(&W.rootDone[root]) != 0) continue;
+				if (-__uint_as_float(ldcU(&penPrev[root])) >= closedAt)
+				{
+					stcI(&W.rootDone[root], 1);
+					atomicMax(&S->c.posItersLarge, it); // iterations 0 .. it - 1 ran on it
+				}
+				else
+				{
+					++open;
+				}
+			}
+			if (open) __hip_atomic_fetch_add(&bar[16 + ((it - 1) & 7)], open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// slots for re-use (long iteration counts): everybody has read slot it - 3 before arriving at it - 1 ...
+			if (it >= 3)
+			{
+				uint32_t* wipe = W.rootPen + (size_t)((it - 3) % ROOT_PEN_SLOTS) * W.nBodies;
+				for (int k = gtid; k < nIslands; k += gsize) stcU(&wipe[W.li_roots[k]], 0u);
+			}
+			if (gtid == 0 && it >= 5) stcI(&bar[16 + ((it - 5) & 7)], 0);
+			// ... and the census of iteration it - 3 is complete: nothing open then = nothing to do since
+			if (it >= 3 && ldcI(&bar[16 + ((it - 3) & 7)]) == 0)
+			{
+				itDone = it + 1;
+				break;
+			}
+		}
+		// what this iteration left, for the islands the next verdict closes
+		if (isBody && !bodyDone) s_back[tid] = s_row[tid];
+		__syncthreads();
+	}
+	if (itDone == sp.posIters && sp.posIters > 0)
+	{
+		// the verdict of the last iteration (nothing ran after it: flags only)
+		const int it = sp.posIters;
+		if (!waitFor(it - 1)) return;
+		const uint32_t* penPrev = W.rootPen + (size_t)((it - 1) % ROOT_PEN_SLOTS) * W.nBodies;
 		for (int k = gtid; k < nIslands; k += gsize)
 		{
 			const int root = W.li_roots[k];
-			if (ldcI(&W.rootDone[root]) == 0 && -__uint_as_float(ldcU(&pen[root])) >= -3.0f * B2D_LINEAR_SLOP) stcI(&W.rootDone[root], 1);
-			stcU(&penWipe[root], 0u);
+			if (ldcI(&W.rootDone[root]) != 0) continue;
+			if (-__uint_as_float(ldcU(&penPrev[root])) >= closedAt) stcI(&W.rootDone[root], 1);
+			atomicMax(&S->c.posItersLarge, it);
 		}
-		const bool someOpenBefore = it == 0 || ldcI(&bar[16 + ((it - 1) & 3)]) != 0; // did iteration `it` have any open island?
-		if (gtid == 0)
-		{
-			stcI(&bar[16 + ((it + 2) & 3)], 0);
-			if (someOpenBefore) S->c.posItersLarge += 1;
-		}
-		if (!someOpenBefore)
-		{
-			if (gtid == 0) S->c.allLargeDone = 1;
-			break;
-		}
-		if (active) rowDone = -__uint_as_float(ldcU(&pen[r.root])) >= -3.0f * B2D_LINEAR_SLOP;
-		if (hActive) hDone = -__uint_as_float(ldcU(&pen[hRoot])) >= -3.0f * B2D_LINEAR_SLOP;
-		if (__syncthreads_or(have && !rowDone) && tid == 0) __hip_atomic_fetch_add(&bar[16 + (it & 3)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	BLK_STAMP(3);
 

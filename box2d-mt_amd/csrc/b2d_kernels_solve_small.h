@@ -12,11 +12,14 @@
 #ifndef B2D_KERNELS_SOLVE_SMALL_H
 #define B2D_KERNELS_SOLVE_SMALL_H
 
-#include "b2d_kernels_island.h"
+#include "b2d_island_joints.h"
 
 __device__ __forceinline__ uint32_t floatBits(float f) { return __float_as_uint(f); }
 
-template <int LANES>
+// JOINTS: the islands may hold joints (at most SMALL_ISLAND_MAX_JOINTS each): lane i of the chunk walks island i's joints in
+// the island's joint order (b2d_island_joints.h) on the LDS rows, between the contact sweeps where b2Island::Solve has them.
+// Worlds without joints run the lean instantiation.
+template <int LANES, bool JOINTS>
 __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 {
 	DState* S = W.st;
@@ -50,6 +53,14 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 	}
 	__syncthreads();
 	if (tid < nI) atomicMax(&s_maxLevel, W.si_maxLevel[i0 + tid]);
+	int jStart = 0, jCount = 0;
+	if (JOINTS && tid < nI)
+	{
+		const int root = W.si_root[i0 + tid];
+		jCount = W.rootJoints[root];
+		jStart = W.rootJointStart[root];
+	}
+	JointBodiesLds jointBodies(W, s_pos, s_vel, bStart, nB);
 
 	// ---- per-body: load, stash c0/a0, integrate velocities (b2Island.cpp:192-230) ---------------
 	int body = -1;
@@ -185,9 +196,20 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 
 	// ---- warm start + velocity iterations, level by level -----------------------------------------
 	const int sweeps = (sp.warmStarting ? 1 : 0) + sp.velIters;
+	if (JOINTS && !sp.warmStarting)
+	{
+		if (jCount > 0) b2dSolveIslandJoints(W, sp, JOINTS_INIT, jStart, jCount, jointBodies);
+		__syncthreads();
+	}
 	for (int sweep = 0; sweep < sweeps; ++sweep)
 	{
 		const bool warm = sp.warmStarting && sweep == 0;
+		if (JOINTS && !warm)
+		{
+			// joints before contacts in every velocity iteration (b2Island.cpp:268-276)
+			if (jCount > 0) b2dSolveIslandJoints(W, sp, JOINTS_VELOCITY, jStart, jCount, jointBodies);
+			__syncthreads();
+		}
 		for (int L = 1; L <= maxLevel; ++L)
 		{
 			if (ci >= 0 && level == L)
@@ -199,6 +221,12 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 				if (la >= 0) s_vel[la] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
 				if (lb >= 0) s_vel[lb] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
 			}
+			__syncthreads();
+		}
+		if (JOINTS && warm)
+		{
+			// InitVelocityConstraints of the joints (with their warm start) after the contacts' warm start (:251-259)
+			if (jCount > 0) b2dSolveIslandJoints(W, sp, JOINTS_INIT, jStart, jCount, jointBodies);
 			__syncthreads();
 		}
 	}
@@ -250,10 +278,12 @@ __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 		}
 		if (tid < nI && !s_done[tid])
 		{
+			int jointsOkay = 1;
+			if (JOINTS && jCount > 0) jointsOkay = b2dSolveIslandJoints(W, sp, JOINTS_POSITION, jStart, jCount, jointBodies);
 			float minSeparation = -__uint_as_float(s_pen[tid]);
-			if (minSeparation >= -3.0f * B2D_LINEAR_SLOP)
+			if (minSeparation >= -3.0f * B2D_LINEAR_SLOP && jointsOkay)
 			{
-				s_done[tid] = 1; // contactsOkay (no joints in small islands) -> positionSolved, break
+				s_done[tid] = 1; // contactsOkay && jointsOkay -> positionSolved, break
 			}
 			else
 			{

@@ -254,48 +254,75 @@ B2D_HD float b2dSinCosImpl(float y, int which)
 B2D_HD float b2dSin(float y) { return b2dSinCosImpl(y, 0); }
 B2D_HD float b2dCos(float y) { return b2dSinCosImpl(y, 1); }
 
-// sinf(y) and cosf(y) together: ONE argument reduction feeds both polynomials. Every operation is the one b2dSin / b2dCos
-// perform on the same operands, so the two results are bit-identical to the separate calls (checked against them for all
-// 2^32 inputs by tests/probe, and a dense sample in tests/test_device_math_cpu.py); the pair costs about two thirds of them.
-B2D_HD void b2dSinCos(float y, float* sinOut, float* cosOut)
+// |y| >= 120, infinities and NaN: the table-driven reduction. Cold (a body would have to spin 19 turns without its angle
+// ever being renormalised) and big: kept out of line so that the callers' loops stay small.
+struct SinCosPair { float s, c; };
+#if defined(__HIPCC__)
+__host__ __device__ __noinline__
+#endif
+static SinCosPair b2dSinCosLarge(float y)
 {
-	double x = (double)y;
-	int n;
-	if (b2dAbsTop12(y) < b2dAbsTop12(0x1.921fb6p-1f))
+	SinCosPair r;
+	if (b2dAbsTop12(y) < 0x7f8u)
 	{
-		if (b2dAbsTop12(y) < b2dAbsTop12(0x1p-12f))
-		{
-			*sinOut = y;
-			*cosOut = 1.0f;
-			return;
-		}
-		const double x2 = x * x;
-		*sinOut = b2dSinCosPoly(x, x2, 0, 0);
-		*cosOut = b2dSinCosPoly(x, x2, 0, 1);
-		return;
-	}
-	else if (b2dAbsTop12(y) < b2dAbsTop12(120.0f))
-	{
-		x = b2dReduceFast(x, &n);
-		const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
-		const double xs = x * s, x2 = x * x;
-		*sinOut = b2dSinCosPoly(xs, x2, (n & 2) != 0, n);
-		*cosOut = b2dSinCosPoly(xs, x2, (n & 2) != 0, n ^ 1);
-		return;
-	}
-	else if (b2dAbsTop12(y) < 0x7f8u)
-	{
+		int n;
 		uint32_t xi = b2dAsUint(y);
 		int sign = (int)(xi >> 31);
-		x = b2dReduceLarge(xi, &n);
+		double x = b2dReduceLarge(xi, &n);
 		int m = n + sign;
 		const double s = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
 		const double xs = x * s, x2 = x * x;
-		*sinOut = b2dSinCosPoly(xs, x2, (m & 2) != 0, n);
-		*cosOut = b2dSinCosPoly(xs, x2, (m & 2) != 0, n ^ 1);
+		r.s = b2dSinCosPoly(xs, x2, (m & 2) != 0, n);
+		r.c = b2dSinCosPoly(xs, x2, (m & 2) != 0, n ^ 1);
+		return r;
+	}
+	r.s = r.c = y - y;
+	return r;
+}
+
+// sinf(y) and cosf(y) together: ONE argument reduction feeds both polynomials, and ONE straight-line path serves every
+// |y| < 120. glibc's sincosf has three ranges below 120 - |y| < 2^-12 (returns y and 1), |y| < pi/4 (no reduction) and the
+// rest (reduce_fast) - but the third computes exactly what the first two return: for |y| < pi/4 reduce_fast finds n = 0 and
+// fma(-0, pi/2, x) = x, and for |y| < 2^-12 the polynomials round to y and 1 (x^3/6 and x^2/2 are below half an ulp of the
+// results). Every operation is the one b2dSin / b2dCos perform on the same operands; the pair is checked bit for bit
+// against libm's sinf / cosf for ALL 2^32 inputs (tests/test_device_math_cpu.py, exhaustive variant in tools/probe_sincos_all.py).
+// The straight line matters on the device: the position solver calls this four times per two-point contact, one wave per
+// SIMD, and with three diverging ranges inlined at every site the loop was 25 KB of code.
+B2D_HD void b2dSinCos(float y, float* sinOut, float* cosOut)
+{
+	if (b2dAbsTop12(y) < b2dAbsTop12(120.0f))
+	{
+		int n;
+		const double x = b2dReduceFast((double)y, &n);
+		const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+		const double xs = x * s, x2 = x * x;
+		const bool neg = (n & 2) != 0;
+		// both polynomials once (b2dSinCosPoly's two branches), then dealt by the parity of n
+		const double x3 = xs * x2;
+		const double sa = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+		const double x7 = x3 * x2;
+		const double sp = xs + x3 * -0x1.555545995a603p-3;
+		const float sinPoly = (float)(sp + x7 * sa);
+		const double c0 = neg ? -0x1p0 : 0x1p0;
+		const double c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2;
+		const double c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5;
+		const double c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10;
+		const double c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+		const double x4 = x2 * x2;
+		const double cb = c3 + x2 * c4;
+		const double ca = c0 + x2 * c1;
+		const double x6 = x4 * x2;
+		const double cp = ca + x4 * c2;
+		const float cosPoly = (float)(cp + x6 * cb);
+		// (|y| < 2^-12 returns y and 1 outright in glibc; the polynomials agree except for the sign of sin(-0): a select, not a branch)
+		const bool tiny = b2dAbsTop12(y) < b2dAbsTop12(0x1p-12f);
+		*sinOut = tiny ? y : ((n & 1) ? cosPoly : sinPoly);
+		*cosOut = tiny ? 1.0f : ((n & 1) ? sinPoly : cosPoly);
 		return;
 	}
-	*sinOut = *cosOut = y - y;
+	const SinCosPair big = b2dSinCosLarge(y);
+	*sinOut = big.s;
+	*cosOut = big.c;
 }
 
 // b2Rot::Set (b2Math.h:294-299). On the device this is ONE out-of-line copy: the glibc-exact sinf/cosf pair is ~3 KB of

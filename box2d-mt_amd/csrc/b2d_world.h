@@ -54,6 +54,7 @@
 #define SMALL_ISLAND_MAX_W 512   // an island is "small" if max(bodies, contacts, 1) <= this
 #define SMALL_CHUNK_LANES 1024   // one workgroup solves one chunk of small islands (<= 1024 bodies, <= 1024 contacts)
 #define TINY_ISLAND_MAX_W 128    // if every small island of the step is <= this, chunks are 256 lanes (lighter barriers)
+#define SMALL_ISLAND_MAX_JOINTS 64 // a small island holds at most this many joints (one lane walks them in order); more: the coloured solver
 #define TINY_CHUNK_LANES 256
 #define MAX_COLORS 64
 #define HUB_DEGREE 30            // a body with more solid contacts than this is a "hub" (the Tumbler's container): its constraints
@@ -73,6 +74,7 @@
 // a colour of the upper range, so that on every body the cut constraints come last in a sweep.
 #define CUT_COLOR_BASE 32        // colours [0, 32) interior constraints, [32, 63) cut constraints, 63 = HUB_COLOR
 #define BLOCK_LANES 1024         // workgroup size of k_solve_blocks = rows (constraints) a block can hold
+#define ROOT_PEN_SLOTS 5          // penetration maxima of the block solver's position iterations in flight (b2d_kernels_solve_blocks.h)
 #define BLOCK_MAX_BODIES 1024    // home bodies a block can hold (LDS rows)
 #define MAX_BLOCKS 1024          // blocks of one partition
 #define BLOCK_TARGET_DEG 1500    // a block is closed when the contact degrees of its bodies add up to this (rows ~ half of it)
@@ -191,6 +193,7 @@ struct DW
 	DState* st;
 	int nBodies, nProxies, nJoints, nShapes;
 	int capContacts, capPairs, capMoves;
+	int hubSerial;        // B2HIP_HUB_SERIAL=1: hub rows lane after lane only (validation of the fixed-point path)
 	int smallMaxW;        // islands up to this size take the exact-order in-LDS solver (default TINY_ISLAND_MAX_W = 128; B2HIP_SMALL_MAX_W up to 512)
 	int bigChunks;        // 1: always use 1024-lane chunks for the small-island solver (B2HIP_BIG_CHUNKS)
 	uint32_t htMask;      // contact-key hash table size - 1

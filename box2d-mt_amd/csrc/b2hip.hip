@@ -695,7 +695,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, 3 * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -745,6 +745,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	// ~300 levels x 12 sweeps = 3.9 ms in k_solve_small, ~0.1 ms as one block of k_solve_blocks. Islands up to 128 (bodies
 	// or contacts) are walked in the reference's order, bit-exact; B2HIP_SMALL_MAX_W (<= 512) moves the line.
 	d.smallMaxW = TINY_ISLAND_MAX_W;
+	d.hubSerial = getenv("B2HIP_HUB_SERIAL") && atoi(getenv("B2HIP_HUB_SERIAL")) ? 1 : 0;
 	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
 	d.capContacts = (int)cc;
 	d.capPairs = (int)w->pairKey.cap;
@@ -1466,8 +1467,13 @@ static int phaseSolve(b2hip_world* w)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 2; }
-			if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH_ON(w, ss, k_solve_small<TINY_CHUNK_LANES>, c.nChunks, TINY_CHUNK_LANES, d, sp);
-			else LAUNCH_ON(w, ss, k_solve_small<SMALL_CHUNK_LANES>, c.nChunks, SMALL_CHUNK_LANES, d, sp);
+			if (d.nJoints > 0)
+			{
+				if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH_ON(w, ss, (k_solve_small<TINY_CHUNK_LANES, true>), c.nChunks, TINY_CHUNK_LANES, d, sp);
+				else LAUNCH_ON(w, ss, (k_solve_small<SMALL_CHUNK_LANES, true>), c.nChunks, SMALL_CHUNK_LANES, d, sp);
+			}
+			else if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH_ON(w, ss, (k_solve_small<TINY_CHUNK_LANES, false>), c.nChunks, TINY_CHUNK_LANES, d, sp);
+			else LAUNCH_ON(w, ss, (k_solve_small<SMALL_CHUNK_LANES, false>), c.nChunks, SMALL_CHUNK_LANES, d, sp);
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
 		}
 		if (sideStream) HIP_TRY(hipEventRecord(w->evJoin, ss));

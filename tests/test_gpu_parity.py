@@ -89,6 +89,17 @@ def test_small_island_scenes_bit_exact_vs_golden(amd, golden, default_mode, name
     w.close()
 
 
+@pytest.mark.parametrize("name", ["machines", "vehicles", "ropes"])
+def test_jointed_small_islands_bit_exact_in_default_mode(amd, golden, default_mode, monkeypatch, name):
+    """Default mode, joint scenes: islands of up to 512 rows and 64 joints take the in-LDS solver, one lane walking the
+    island's joints in the reference's order between the contact sweeps (b2Island.cpp:256-335) - bit-exact like the
+    joint-free small islands. (The tier is widened from its default 128 rows to its limit for these goldens.)"""
+    monkeypatch.setenv("B2HIP_SMALL_MAX_W", "512")
+    w, counts, hashes = run_golden(amd, golden, name)
+    assert_matches_golden(w, counts, hashes, golden, name)
+    w.close()
+
+
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_exact_order_mode_bit_exact_vs_golden(amd, golden, exact_mode, name):
     """Exact-order mode: every island, whatever its size, is walked in the reference's constraint order."""
@@ -453,3 +464,25 @@ def test_hub_body_path_runs_deterministically(amd, default_mode):
     r = np.linalg.norm(b1[2:, :2] - centre, axis=1)
     half = np.abs(b1[2:, :2] - centre).max()
     assert r.max() < 1.5 * half + 1.0 and half < 40.0
+
+
+def test_hub_fixed_point_sweep_equals_the_lane_after_lane_sweep(amd, default_mode, monkeypatch):
+    """k_large_hub finds the sequential sweep through a hub body as a fixed point (all 64 lanes of a chunk evaluate, the
+    changes to the hub row are prefix-summed, repeat until nothing changes); B2HIP_HUB_SERIAL=1 keeps the lanes taking turns.
+    Both are the same sweep up to the rounding of the hub row: 40 steps of the Tumbler (3 600 boxes, the container is the
+    hub) must agree to 1e-3 of a box (0.25) - the scene is chaotic, a different ORDER would be off by whole boxes."""
+    def run(serial):
+        if serial:
+            monkeypatch.setenv("B2HIP_HUB_SERIAL", "1")
+        else:
+            monkeypatch.delenv("B2HIP_HUB_SERIAL", raising=False)
+        w = amd.world(bh.TUMBLER, 60, 0)
+        w.step(40)
+        b, n = w.bodies(), w.contact_count
+        w.close()
+        return b, n
+    b1, n1 = run(True)
+    b2, n2 = run(False)
+    assert np.isfinite(b2).all()
+    assert abs(n1 - n2) <= max(3, n1 // 500), "contact counts %d vs %d" % (n1, n2)
+    assert np.abs(b1[:, :2] - b2[:, :2]).max() < 2.5e-4, "poses differ by %g" % np.abs(b1[:, :2] - b2[:, :2]).max()

@@ -81,12 +81,14 @@ def test_slowly_dragged_body_stays_awake(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("count,seed,flags", CASES)
-@pytest.mark.parametrize("mode", ["exact"])
+@pytest.mark.parametrize("mode", ["exact", "default"])
 def test_device_life_cycle_matches_the_oracle(amd, oracle, monkeypatch, count, seed, flags, mode):
     if mode == "exact":
         monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
     else:
-        monkeypatch.setenv("B2HIP_SMALL_MAX_W", "512")  # the heap is one island of a few hundred contacts: keep it on the exact-order solver
+        monkeypatch.setenv("B2HIP_SMALL_MAX_W", "512")
+        # the heap is one island of a few hundred contacts: the exact-order in-LDS solver at its 512-row limit takes it, and the
+        # jointed islands (cart + wheels, the dragged crate) with it
     a = amd.world(bh.LIFECYCLE, count, 0, seed=seed, flags=flags)
     b = oracle.world(bh.LIFECYCLE, count, 0, seed=seed, flags=flags)
     compare(a, b, STEPS, "device (%s) vs oracle" % mode)  # (device and oracle share the bridge's definition: callbacks compared with CCD on as well)
