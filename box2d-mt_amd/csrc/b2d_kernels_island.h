@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		if (S->c.partitionCooldown > 0) S->c.partitionCooldown -= 1;
 		S->c.nBigIslands = 0;
 		S->c.nRemoteIslands = 0;
+		S->c.nSmallJointed = 0;
 		S->c.nOrphanRows = 0;
 		S->c.blkMaxRows = 0;
 		S->c.blkMaxBodies = 0;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 				else if ((nj <= SMALL_ISLAND_MAX_JOINTS && w <= W.smallMaxW && forceLarge == 0) || forceLarge == 2)
 				{
 					W.rootIsland[i] = ROOT_SMALL;
+					if (nj > 0) atomicAdd(&S->c.nSmallJointed, 1);
 					in = make_int4(nb, nc, w, 1);
 					atomicMax(&S->c.maxSmallW, w);
 				}

@@ -97,6 +97,7 @@ __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, in
 	return true;
 }
 
+#ifdef B2HIP_VALIDATION_SOLVERS // (cross-check solver: see b2hip.hip)
 __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepParams sp, int nColorsArg, int* bar, int pollSleep)
 {
 	DState* S = W.st;
@@ -322,5 +323,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepPara
 	DF_STAMP(6);
 #undef DF_STAMP
 }
+
+#endif // B2HIP_VALIDATION_SOLVERS
 
 #endif

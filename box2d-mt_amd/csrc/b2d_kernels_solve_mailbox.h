@@ -78,6 +78,7 @@ __device__ __forceinline__ bool mailboxRun(bool pending, const float4* box, bool
 	return true;
 }
 
+#ifdef B2HIP_VALIDATION_SOLVERS // (cross-check solver: see b2hip.hip)
 // LOCAL = true: the single-XCD form. The per-XCD L2s are not coherent with each other, which is why a cross-XCD hand-off
 // has to go through memory (~3.3 us a hop here). If all workgroups share one XCD the hand-offs stay in its L2. HIP
 // promises nothing about placement, so the launch asks for 8 x nWG workgroups (they are dealt round-robin over the 8 XCDs),
@@ -395,5 +396,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_mailbox(DW W, StepParam
 	DF_STAMP(6);
 #undef DF_STAMP
 }
+
+#endif // B2HIP_VALIDATION_SOLVERS
 
 #endif

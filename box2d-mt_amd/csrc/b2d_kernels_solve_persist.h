@@ -95,6 +95,7 @@ __device__ __forceinline__ bool gridBarrier(const GridBarrier& gb)
 	return s_ok != 0;
 }
 
+#ifdef B2HIP_VALIDATION_SOLVERS // (cross-check solver: see b2hip.hip)
 __global__ __launch_bounds__(PERSIST_LANES) void k_solve_persistent(DW W, StepParams sp, int nColorsArg, int* bar)
 {
 	DState* S = W.st;
@@ -264,5 +265,7 @@ __global__ __launch_bounds__(PERSIST_LANES) void k_solve_persistent(DW W, StepPa
 		}
 	}
 }
+
+#endif // B2HIP_VALIDATION_SOLVERS
 
 #endif

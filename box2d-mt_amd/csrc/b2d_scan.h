@@ -123,15 +123,111 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const T* __restrict
 	}
 }
 
-// Host helper: three launches on `stream`. capN bounds the grid; nPtr is the live count in device memory.
+// ---- single-pass scan (decoupled look-back) ---------------------------------------------------------------------------------
+// One launch instead of three: every tile publishes its aggregate, then walks back over its predecessors' status words
+// until it meets one whose inclusive prefix is known, and publishes its own. Status per tile in `work`:
+//   work[t]     aggregate of tile t          work[cap + t]   inclusive prefix up to and including tile t
+//   flags[t]    (epoch << 2) | state, state 1 = aggregate published, 2 = prefix published
+// `epoch` is unique per launch (the host counts them), so the flag words are never reset (they live in an array of their
+// own that only ever holds flag words: zeroed when allocated). Progress: workgroups are dispatched in
+// index order on every XCD, so the lowest unfinished tile is always running.
 template <typename T>
-static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, T* blockSums, const int* nPtr, int capN)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict__ in, T* __restrict__ out, T* work, int* flags, int cap, const int* nPtr, unsigned epoch)
+{
+	__shared__ T lds[2 * SCAN_THREADS];
+	__shared__ T s_prefix;
+	const int n = *nPtr;
+	const int tile = blockIdx.x;
+	const int base = tile * SCAN_TILE;
+	if (n == 0)
+	{
+		if (tile == 0 && threadIdx.x == 0)
+		{
+			T z;
+			scanZero(z);
+			out[0] = z;
+		}
+		return;
+	}
+	if (base >= n) return;
+	T v[SCAN_ITEMS];
+	T sum;
+	scanZero(sum);
+	for (int k = 0; k < SCAN_ITEMS; ++k)
+	{
+		const int i = base + threadIdx.x * SCAN_ITEMS + k;
+		scanZero(v[k]);
+		if (i < n) v[k] = in[i];
+		sum = scanAdd(sum, v[k]);
+	}
+	T total;
+	const T excl = blockExclusiveScan(sum, &total, lds);
+	if (threadIdx.x == 0)
+	{
+		T* agg = work;
+		T* pre = work + cap;
+		int* flagOfTile = flags + tile;
+		T running;
+		scanZero(running);
+		if (tile > 0)
+		{
+			agg[tile] = total;
+			__hip_atomic_store(flagOfTile, (int)((epoch << 2) | 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			int t = tile - 1;
+			while (true)
+			{
+				const int* f = flags + t;
+				const unsigned word = (unsigned)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+				if ((word >> 2) != epoch || (word & 3u) == 0u)
+				{
+					__builtin_amdgcn_s_sleep(1);
+					continue;
+				}
+				if ((word & 3u) == 2u)
+				{
+					running = scanAdd(running, pre[t]);
+					break;
+				}
+				running = scanAdd(running, agg[t]);
+				--t;
+			}
+		}
+		pre[tile] = scanAdd(running, total);
+		__hip_atomic_store(flagOfTile, (int)((epoch << 2) | 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		s_prefix = running;
+	}
+	__syncthreads();
+	T run = scanAdd(s_prefix, excl);
+	for (int k = 0; k < SCAN_ITEMS; ++k)
+	{
+		const int i = base + threadIdx.x * SCAN_ITEMS + k;
+		if (i < n) out[i] = run;
+		run = scanAdd(run, v[k]);
+		if (i == n - 1) out[n] = run;
+	}
+}
+
+// Host helper: ONE launch on `stream`. capN bounds the grid; nPtr is the live count in device memory; `work` holds
+// 2 * (capN / SCAN_TILE + 4) elements, `flags` capN / SCAN_TILE + 4 ints (zeroed when allocated, never reset).
+#include <atomic>
+static std::atomic<unsigned> g_scanEpoch{0};
+template <typename T>
+static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, T* work, int* flags, const int* nPtr, int capN)
 {
 	int blocks = (capN + SCAN_TILE - 1) / SCAN_TILE;
 	if (blocks < 1) blocks = 1;
-	hipLaunchKernelGGL(k_scan_reduce<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, blockSums, nPtr);
-	hipLaunchKernelGGL(k_scan_blocksums<T>, dim3(1), dim3(SCAN_THREADS), 0, stream, blockSums, nPtr, (T*)nullptr);
-	hipLaunchKernelGGL(k_scan_final<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, blockSums, nPtr);
+	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+	{
+		// a captured launch would replay its epoch: the three-kernel form (reduce, scan of the tile sums, final) has no state
+		hipLaunchKernelGGL(k_scan_reduce<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, work, nPtr);
+		hipLaunchKernelGGL(k_scan_blocksums<T>, dim3(1), dim3(SCAN_THREADS), 0, stream, work, nPtr, (T*)nullptr);
+		hipLaunchKernelGGL(k_scan_final<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, nPtr);
+		return;
+	}
+	unsigned epoch = (g_scanEpoch.fetch_add(1) + 1u) & 0x3fffffffu;
+	if (epoch == 0u) epoch = (g_scanEpoch.fetch_add(1) + 1u) & 0x3fffffffu;
+	hipLaunchKernelGGL(k_scan_chain<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, flags, blocks + 4, nPtr, epoch);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -384,22 +384,19 @@ B2D_HD float b2dSolvePosition(const ContactConstraint* cc, BodyPos* A, BodyPos* 
 			point = 0.5f * (pointA + pointB);
 			separation = b2dDot(pointB - pointA, normal) - cc->radiusA - cc->radiusB;
 		}
-		else if (cc->type == B2D_MANIFOLD_FACE_A)
-		{
-			normal = b2dMulRV(xfA.q, cc->localNormal);
-			V2 planePoint = b2dMulXV(xfA, cc->localPoint);
-			V2 clipPoint = b2dMulXV(xfB, cc->localPoints[j]);
-			separation = b2dDot(clipPoint - planePoint, normal) - cc->radiusA - cc->radiusB;
-			point = clipPoint;
-		}
 		else
 		{
-			normal = b2dMulRV(xfB.q, cc->localNormal);
-			V2 planePoint = b2dMulXV(xfB, cc->localPoint);
-			V2 clipPoint = b2dMulXV(xfA, cc->localPoints[j]);
+			// e_faceA and e_faceB (b2ContactSolver.cpp:645-671) are one computation with the two bodies' roles exchanged:
+			// selects instead of a branch (the rows of a wave are a mix of both)
+			const bool faceA = cc->type == B2D_MANIFOLD_FACE_A;
+			const Xf xfRef = faceA ? xfA : xfB;
+			const Xf xfInc = faceA ? xfB : xfA;
+			normal = b2dMulRV(xfRef.q, cc->localNormal);
+			V2 planePoint = b2dMulXV(xfRef, cc->localPoint);
+			V2 clipPoint = b2dMulXV(xfInc, cc->localPoints[j]);
 			separation = b2dDot(clipPoint - planePoint, normal) - cc->radiusA - cc->radiusB;
 			point = clipPoint;
-			normal = -normal;
+			if (!faceA) normal = -normal;
 		}
 
 		V2 rA = point - cA;

@@ -151,6 +151,7 @@ struct Counters
 	int nFilterList;     // contacts flagged for re-filtering, listed for the user's contact filter (DW::filterList)
 	int nBigIslands;     // islands with more than SHARD_BIG_BODIES bodies this step (sharded worlds only)
 	int nRemoteIslands;  // islands of this step that another rank solves
+	int nSmallJointed;   // small islands of this step that hold joints (none: the lean k_solve_small runs)
 };
 
 // What b2ContactListener::PreSolve is told about one contact (gathered after Collide, before the compaction of destroyed

@@ -21,8 +21,18 @@
 #include "../../include/b2hip.h"
 #include "b2d_kernels_toi_chains.h"
 #include "b2d_kernels_toi_domains.h"
+// The three earlier resident large-island solvers (grid barrier per colour, polled body rows, pushed mailboxes) are kept
+// for cross-checks only: built with -DB2HIP_VALIDATION_SOLVERS (make -C box2d-mt_amd validation -> libb2hip_validation.so,
+// used by tests/test_gpu_parity.py::test_block_solver_matches_launch_per_colour). The product has two large-island
+// solvers: k_solve_blocks and, where it does not apply (joints, hubs, exact-order mode, a partition that does not fit),
+// the launch-per-colour kernels.
 #include "b2d_kernels_solve_dataflow.h"
 #include "b2d_kernels_solve_mailbox.h"
+#ifdef B2HIP_VALIDATION_SOLVERS
+#define B2HIP_HAVE_VALIDATION_SOLVERS 1
+#else
+#define B2HIP_HAVE_VALIDATION_SOLVERS 0
+#endif
 #include "b2d_kernels_solve_blocks.h"
 #include "b2d_kernels_edit.h"
 #include "b2d_kernels_shard.h"
@@ -212,6 +222,7 @@ struct b2hip_world
 	DevArray<int> pairFirst, pairRank;
 	DevArray<int> scanTmp, radixHist, radixHistScan, keepFlag, keepScan;
 	DevArray<int4> scanTmp4;
+	DevArray<int> scanFlags;     // status words of the single-pass scans (b2d_scan.h)
 	DevArray<float> stateOut;
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
 	int dfEpoch;
@@ -709,8 +720,9 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	const size_t maxScanN = std::max(std::max(nb + 2, gridSize + 2), std::max(cc + 2, capPairs + 2));
 	const size_t radixTiles = capPairs / RADIX_TILE + 2;
 	ENS(radixHist, 256 * radixTiles + 2); ENS(radixHistScan, 256 * radixTiles + 4);
-	ENS(scanTmp, std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 4);
-	ENS(scanTmp4, maxScanN / SCAN_TILE + 4);
+	ENS(scanTmp, 3 * (std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 8));
+	ENS(scanTmp4, 3 * (maxScanN / SCAN_TILE + 8));
+	ENS(scanFlags, std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 8);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
 	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
@@ -1126,7 +1138,7 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 	if (destroys)
 	{
 		LAUNCH(w, k_edit_keepflags, gridFor(d.capContacts), 256, d);
-		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
 		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_finish, 1, 1, d);
 		LAUNCH(w, k_edit_finish, 1, 1, d);
@@ -1215,7 +1227,7 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		{
 			LAUNCH(w, k_radix_count, 1, 1, &d.st->c.nPairs, 0, w->consts.p + 2);
 			LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, &d.st->c.nPairs, 0, shifts[p], tilesCap);
-			deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->consts.p + 2, 256 * tilesCap);
+			deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanFlags.p, w->consts.p + 2, 256 * tilesCap);
 			LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, &d.st->c.nPairs, 0, shifts[p]);
 			std::swap(kin, kout);
 			std::swap(vin, vout);
@@ -1224,7 +1236,7 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		sortedProxies = vin;
 		LAUNCH(w, k_pairs_sorted_first, gridFor(d.capPairs), 256, d, sortedKeys, w->consts.p + 3);
 		if (w->filterFn) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
-		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->consts.p + 3, d.capPairs);
+		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanFlags.p, w->consts.p + 3, d.capPairs);
 		LAUNCH(w, k_pairs_sorted_total, 1, 1, d, w->consts.p + 3);
 	}
 	else
@@ -1280,7 +1292,7 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 	DW& d = w->dw;
 	LAUNCH(w, k_bp_clear, gridFor(std::max(d.htMask, d.gridMask) + 1), 256, d);
 	LAUNCH(w, k_bp_build, gridFor(std::max(d.capContacts, d.nProxies)), 256, d);
-	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
+	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanFlags.p, w->consts.p + 1, (int)(d.gridMask + 1));
 	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 0);
 	LAUNCH(w, k_find_pairs_small, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
 	LAUNCH(w, k_find_pairs_large, 1024, 256, d);
@@ -1307,7 +1319,7 @@ static int phaseCollide(b2hip_world* w)
 		DW& d = w->dw;
 		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_toi_order_destroy, 1, 256, d);
-		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_finish, 1, 1, d);
@@ -1348,13 +1360,13 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	{
 		LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
 		LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, nPtr, 0, shifts[p], tilesCap);
-		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->consts.p + 2, 256 * tilesCap);
+		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanFlags.p, w->consts.p + 2, 256 * tilesCap);
 		LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, nPtr, 0, shifts[p]);
 		std::swap(kin, kout);
 		std::swap(vin, vout);
 	}
 	LAUNCH(w, k_part_weights, gridFor(d.nBodies), 256, d, vin, d.pairFirst);
-	deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, nPtr, d.nBodies);
+	deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanFlags.p, nPtr, d.nBodies);
 	LAUNCH(w, k_part_assign, gridFor(d.nBodies), 256, d, vin, d.pairRank);
 	LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
@@ -1384,15 +1396,13 @@ static int phaseSolve(b2hip_world* w)
 		{
 			int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
 			if (blocks < 1) blocks = 1;
-			hipLaunchKernelGGL(k_scan_reduce<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, w->scanTmp4.p, w->consts.p);
-			hipLaunchKernelGGL(k_scan_blocksums<int4>, dim3(1), dim3(SCAN_THREADS), 0, w->stream, w->scanTmp4.p, w->consts.p, (int4*)nullptr);
-			hipLaunchKernelGGL(k_scan_final<int4>, dim3(blocks), dim3(SCAN_THREADS), 0, w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->consts.p);
+			deviceExclusiveScan<int4>(w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->scanFlags.p, w->consts.p, d.nBodies);
 			if (hipError_t le = hipGetLastError()) return setError(B2HIP_ERR_HIP, std::string("k_scan<int4> launch: ") + hipGetErrorString(le));
 		}
-		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p, d.nBodies);
+		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->scanFlags.p, w->consts.p, d.nBodies);
 		if (d.nJoints > 0)
 		{
-			deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->consts.p, d.nBodies);
+			deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->scanFlags.p, w->consts.p, d.nBodies);
 		}
 		LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
@@ -1467,7 +1477,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 2; }
-			if (d.nJoints > 0)
+			if (c.nSmallJointed > 0)
 			{
 				if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH_ON(w, ss, (k_solve_small<TINY_CHUNK_LANES, true>), c.nChunks, TINY_CHUNK_LANES, d, sp);
 				else LAUNCH_ON(w, ss, (k_solve_small<SMALL_CHUNK_LANES, true>), c.nChunks, SMALL_CHUNK_LANES, d, sp);
@@ -1517,6 +1527,7 @@ static int phaseSolve(b2hip_world* w)
 			c.nOrphanRows == 0 && c.blkMaxRows <= c.blkLanes && c.blkMaxBodies <= c.blkLanes && c.nBlocks <= w->blocksMaxWG &&
 			(sp.velIters + 2) * (MAX_COLORS + 1) < 65536 && (sp.posIters + 1) * (MAX_COLORS + 1) < 65536;
 		d.blockSort = useBlocks ? 1 : 0;
+		const bool useResident = usePersistent && (useBlocks || B2HIP_HAVE_VALIDATION_SOLVERS);
 		bool colorsOnDevice = false;
 		if (!exactLarge && (c.needRecolor || c.nUncolored > 0 || c.nCompact > 0))
 		{
@@ -1525,7 +1536,7 @@ static int phaseSolve(b2hip_world* w)
 				// the usual case (a few new contacts on a settled island, a colour class to compact): one workgroup colours
 				// them; the resident solver reads the colour count from the device, the launch-per-colour path reads it back
 				LAUNCH(w, k_color_small, 1, 1024, d);
-				if (usePersistent)
+				if (useResident)
 				{
 					colorsOnDevice = true;
 					w->colorSmallPending = true;
@@ -1572,14 +1583,14 @@ static int phaseSolve(b2hip_world* w)
 		{
 			// the hub constraints in contact-index order (deterministic whatever the atomics of k_color_fill did)
 			LAUNCH(w, k_hub_flag, gridFor(d.capContacts), 256, d);
-			deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, &d.st->c.nContacts, d.capContacts);
+			deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
 			LAUNCH(w, k_hub_fill, gridFor(d.capContacts), 256, d);
 			w->hubSteps += 1;
 		}
 		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[7], w->stream));
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
-		if (usePersistent)
+		if (useResident)
 		{
 			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (b2d_kernels_solve_persist.h)
 			// (the barrier words were zeroed by k_step_begin: one resident launch per step)
@@ -1602,6 +1613,7 @@ static int phaseSolve(b2hip_world* w)
 				w->blockSteps += 1;
 				w->blocksThisStep = true;
 			}
+#if B2HIP_HAVE_VALIDATION_SOLVERS
 			else if (w->solverBarriers) LAUNCH(w, k_solve_persistent, persistWG, PERSIST_LANES, d, sp, nColorsArg, w->gridBar.p);
 			else if (w->solverRows || (sp.velIters + 2) * DF_RANKS >= 65536 || (sp.posIters + 1) * DF_RANKS >= 65536)
 				LAUNCH(w, k_solve_dataflow, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfSleep);
@@ -1622,6 +1634,7 @@ static int phaseSolve(b2hip_world* w)
 				LAUNCH(w, k_solve_mailbox<false>, persistWG, persistLanes, d, sp, nColorsArg, w->gridBar.p, w->dfEpoch, persistWG, tryLocal ? 1 : 0);
 				w->dfEpoch += 1;
 			}
+#endif
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 			w->persistSteps += 1;
 		}
@@ -1729,14 +1742,14 @@ static int toiBuildIndexes(b2hip_world* w, bool csr)
 	{
 		LAUNCH(w, k_toi_adj_clear, gridFor(d.nBodies + 1), 256, d);
 		LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
-		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->consts.p + 4, d.nBodies + 1);
+		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->scanFlags.p, w->consts.p + 4, d.nBodies + 1);
 		LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
 	}
 	// make the grid reflect every fat AABB as of now (the end-of-step pair update skips the rebuild when nothing
 	// moved, and TOI moves of earlier steps never enter the move buffer)
 	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
 	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
-	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->consts.p + 1, (int)(d.gridMask + 1));
+	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanFlags.p, w->consts.p + 1, (int)(d.gridMask + 1));
 	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 1);
 	return 0;
 }
@@ -2032,17 +2045,23 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->persistMaxWG = 0;
 	w->nCU = 256;
 	{
-		int perCU = 0, perCU2 = 0;
 		hipDeviceProp_t prop;
 		int devId = 0;
-		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_dataflow, PERSIST_LANES, 0) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU2, k_solve_mailbox<true>, PERSIST_LANES, 0) == hipSuccess)
+		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess)
 		{
-			perCU = std::min(perCU, perCU2);
-			// the occupancy query can be one block per CU high (sgpr_count 81-112, MI355X_MICROARCH.md): keep a margin
-			w->persistMaxWG = std::max(0, std::min(perCU - 1, 4)) * prop.multiProcessorCount;
 			w->nCU = prop.multiProcessorCount;
+#if B2HIP_HAVE_VALIDATION_SOLVERS
+			int perCU = 0, perCU2 = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_solve_dataflow, PERSIST_LANES, 0) == hipSuccess &&
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU2, k_solve_mailbox<true>, PERSIST_LANES, 0) == hipSuccess)
+			{
+				perCU = std::min(perCU, perCU2);
+				// the occupancy query can be one block per CU high (sgpr_count 81-112, MI355X_MICROARCH.md): keep a margin
+				w->persistMaxWG = std::max(0, std::min(perCU - 1, 4)) * prop.multiProcessorCount;
+			}
+#else
+			w->persistMaxWG = 1 << 24; // (a limit of the cross-check solvers; k_solve_blocks has its own: blocksMaxWG)
+#endif
 		}
 	}
 	w->dfLanesForced = 0;
@@ -2150,7 +2169,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_blk1.release(); w->b_adopt.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release();
 	w->blkBodyStart.release(); w->blkBodies.release(); w->rowColor.release(); w->b_cutv.release();
 	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
-	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->stateOut.release(); w->consts.release();
+	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->scanFlags.release(); w->stateOut.release(); w->consts.release();
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
 	if (w->h_stamps) (void)hipHostFree(w->h_stamps);
