@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 
 // b2ContactManager::AddToContactArray (:659-686): a new TOI candidate takes the slot after the last
 // candidate, in creation order. One workgroup, block scan over the new contacts.
-__global__ __launch_bounds__(256) void k_toi_order_create(DW W, int smallPath)
+__global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 {
 	DState* S = W.st;
 	if (createBlocked(W, S, smallPath)) return;
@@ -453,35 +453,35 @@ __global__ __launch_bounds__(256) void k_toi_order_create(DW W, int smallPath)
 	const int base = S->c.nContacts;
 	const int cap = W.capContacts;
 	const ContactArrays& C = W.ca[S->cur];
-	__shared__ int s_scan[256];
-	__shared__ int s_count;
-	if (threadIdx.x == 0) s_count = S->c.nToiOrder;
-	__syncthreads();
-	for (int i0 = 0; i0 < nNew; i0 += 256)
+	// 1024 new contacts per round: wave ballots rank the candidates inside a wave, 16 wave totals are summed by every lane
+	__shared__ int s_wave[2][16];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	int count = S->c.nToiOrder;
+	int buf = 0;
+	for (int i0 = 0; i0 < nNew; i0 += 1024, buf ^= 1)
 	{
-		const int i = base + i0 + threadIdx.x;
-		const int flag = (i0 + threadIdx.x < nNew && i < cap && (C.flags[i] & CF_TOI_CANDIDATE)) ? 1 : 0;
-		s_scan[threadIdx.x] = flag;
+		const int i = base + i0 + tid;
+		const bool flag = i0 + tid < nNew && i < cap && (C.flags[i] & CF_TOI_CANDIDATE) != 0;
+		const unsigned long long m = __ballot(flag);
+		if (lane == 0) s_wave[buf][wave] = __popcll(m);
 		__syncthreads();
-		for (int off = 1; off < 256; off <<= 1)
+		int before = 0, total = 0;
+		for (int k = 0; k < 16; ++k)
 		{
-			const int v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
-			__syncthreads();
-			s_scan[threadIdx.x] += v;
-			__syncthreads();
+			const int v = s_wave[buf][k];
+			if (k < wave) before += v;
+			total += v;
 		}
-		const int start = s_count;
 		if (flag)
 		{
-			const int slot = start + s_scan[threadIdx.x] - 1;
+			const int slot = count + before + __popcll(m & ((1ull << lane) - 1ull));
 			C.mgr[i] = slot;
 			W.toiPos2c[slot] = i;
 		}
-		__syncthreads();
-		if (threadIdx.x == 0) s_count = start + s_scan[255];
-		__syncthreads();
+		count += total;
+		// (the other buffer is written in the next round: one barrier per round is enough)
 	}
-	if (threadIdx.x == 0) S->c.nToiOrder = s_count;
+	if (tid == 0) S->c.nToiOrder = count;
 }
 
 __global__ void k_create_commit(DW W, int smallPath)

@@ -177,6 +177,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.nBigIslands = 0;
 		S->c.nRemoteIslands = 0;
 		S->c.nSmallJointed = 0;
+		S->c.hubRounds = 0;
+		S->c.hubSerialChunks = 0;
 		S->c.nOrphanRows = 0;
 		S->c.blkMaxRows = 0;
 		S->c.blkMaxBodies = 0;

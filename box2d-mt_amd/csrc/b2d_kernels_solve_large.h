@@ -665,15 +665,15 @@ __device__ __forceinline__ HubTrial hubEvaluate(int mode, ContactConstraint& cc,
 //   * the common case - one hub, 64 different partners, none of them a hub itself: the sequential sweep through the hub is
 //     found as a FIXED POINT. Every lane evaluates its constraint from the hub row it assumes it will meet; the changes it
 //     makes to the hub row are prefix-summed over the lanes, which gives every lane a better assumption; repeat until no
-//     lane's assumption changes by a bit. Lane k's assumption only depends on lanes < k, so after k rounds it is final:
-//     the loop ends after at most 64 rounds with exactly the rows a lane-after-lane sweep meets (up to the rounding of
-//     "row + sum of changes" against "row changed step by step"), and in practice after a handful - a partner changes the
-//     hub's row by (its mass / the hub's mass), which is what an error shrinks by per round. 64 turns of one lane each
-//     become ~5 rounds of 64 lanes (Tumbler 100 k: 434 -> ~90 us per sweep);
+//     lane's assumption moves by more than 2^-21 of the row. Lane k's assumption only depends on lanes < k, so after k
+//     rounds it is final: the loop ends after at most 64 rounds with the rows a lane-after-lane sweep meets (up to that
+//     2^-21 and the rounding of "row + sum of changes" against "row changed step by step"), and in practice after two or
+//     three - a partner changes the hub's row by (its mass / the hub's mass), which is what an error shrinks by per round,
+//     and the first assumption is what the previous sweep found (hubDelta);
 //   * otherwise (or if HUB_FIXPOINT_ROUNDS were not enough) the lanes take turns: the hub's row travels from turn to turn
 //     in registers (wave shuffle) as long as consecutive constraints sit on the same hub; a partner body that occurs twice
 //     in a chunk is re-read at its turn.
-__global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
+__global__ __launch_bounds__(64) void k_large_hub(DW W, int mode, int useGuess)
 {
 	DState* S = W.st;
 	if (mode == 2 && S->c.allLargeDone) return;
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
 	float4* rowsOut = mode == 2 ? W.b_pos : W.b_vel;
 	int carryBody = -1;
 	float4 carry = make_float4(0, 0, 0, 0);
+	int statRounds = 0, statSerial = 0;
 	for (int base = 0; base < n; base += 64)
 	{
 		const int k = base + lane;
@@ -754,7 +755,22 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
 			const float4 u0 = carryBody == hub0 ? carry : rows[hub0];
 			float imp0[4] = { cc.normalImpulse[0], cc.tangentImpulse[0], cc.normalImpulse[1], cc.tangentImpulse[1] };
 			float4 incoming = u0;
+			if (useGuess)
+			{
+				// start from what the previous sweep of the same kind found: the changes this constraint made to the hub row
+				// then (they move little from sweep to sweep, so the first assumption is already close)
+				float4 g = make_float4(0, 0, 0, 0);
+				if (have) g = W.hubDelta[k];
+				float sx = g.x, sy = g.y, sz = g.z;
+				for (int off = 1; off < 64; off <<= 1)
+				{
+					const float ux = __shfl_up(sx, off), uy = __shfl_up(sy, off), uz = __shfl_up(sz, off);
+					if (lane >= off) { sx += ux; sy += uy; sz += uz; }
+				}
+				incoming = make_float4(u0.x + (sx - g.x), u0.y + (sy - g.y), u0.z + (sz - g.z), u0.w);
+			}
 			HubTrial tr;
+			float lastDx = 0.0f, lastDy = 0.0f, lastDz = 0.0f;
 			for (int round = 0; round < HUB_FIXPOINT_ROUNDS + 1 && !solved; ++round)
 			{
 				float dx = 0.0f, dy = 0.0f, dz = 0.0f;
@@ -777,9 +793,16 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
 					if (lane >= off) { sx += ux; sy += uy; sz += uz; }
 				}
 				const float4 next = make_float4(u0.x + (sx - dx), u0.y + (sy - dy), u0.z + (sz - dz), u0.w);
-				const bool changed = __float_as_uint(next.x) != __float_as_uint(incoming.x) || __float_as_uint(next.y) != __float_as_uint(incoming.y) ||
-					__float_as_uint(next.z) != __float_as_uint(incoming.z);
+				// settled = no lane's assumption moves by more than 2^-21 of the hub row (or of the sweep's total change to it, if
+				// that is larger). Not "by a bit": a lane's change is measured as (row after - row before), which carries the
+				// rounding of the row itself, so assumptions keep flickering in their last bit long after the sweep is decided
+				const float tx = 0x1p-21f * fmaxf(fabsf(u0.x), fabsf(__shfl(sx, 63)));
+				const float ty = 0x1p-21f * fmaxf(fabsf(u0.y), fabsf(__shfl(sy, 63)));
+				const float tz = 0x1p-21f * fmaxf(fabsf(u0.z), fabsf(__shfl(sz, 63)));
+				const bool changed = fabsf(next.x - incoming.x) > tx || fabsf(next.y - incoming.y) > ty || fabsf(next.z - incoming.z) > tz;
 				incoming = next;
+				lastDx = dx; lastDy = dy; lastDz = dz;
+				++statRounds;
 				if (__ballot(changed) == 0ull) solved = true;
 			}
 			if (solved)
@@ -795,6 +818,7 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
 					if (otherDynamic) rowsOut[otherBody] = tr.otherOut;
 					minSep = tr.minSep;
 				}
+				if (have) W.hubDelta[k] = make_float4(lastDx, lastDy, lastDz, 0.0f);
 				const float4 last = tr.hubOut; // (an inactive lane hands its assumption on)
 				carry.x = __shfl(last.x, cnt - 1);
 				carry.y = __shfl(last.y, cnt - 1);
@@ -812,6 +836,7 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
 			}
 		}
 		// ---- lanes take turns ----------------------------------------------------------------------------------------------
+		if (!solved) ++statSerial;
 		for (int t = 0; t < cnt && !solved; ++t)
 		{
 			float4 hubOut = carry;
@@ -872,6 +897,11 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode)
 		if (mode == 2) waveAtomicMaxU32(W.rootPen, r.root, floatBits(0.0f - minSep), have && active);
 	}
 	if (lane == 0 && carryBody >= 0) rowsOut[carryBody] = carry;
+	if (lane == 0)
+	{
+		atomicAdd(&S->c.hubRounds, statRounds);
+		atomicAdd(&S->c.hubSerialChunks, statSerial);
+	}
 }
 
 __global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)

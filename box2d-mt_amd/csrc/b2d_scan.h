@@ -10,6 +10,7 @@
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 4
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+#define SCAN_CHAIN_MAX_TILES 256 // single-pass scan up to 256 K elements, three kernels beyond
 
 __device__ __forceinline__ int scanAdd(int a, int b) { return a + b; }
 __device__ __forceinline__ int4 scanAdd(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -131,6 +132,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const T* __restrict
 // `epoch` is unique per launch (the host counts them), so the flag words are never reset (they live in an array of their
 // own that only ever holds flag words: zeroed when allocated). Progress: workgroups are dispatched in
 // index order on every XCD, so the lowest unfinished tile is always running.
+__device__ __forceinline__ int scanWaveSum(int v)
+{
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+	return v;
+}
+__device__ __forceinline__ int4 scanWaveSum(int4 v)
+{
+	return make_int4(scanWaveSum(v.x), scanWaveSum(v.y), scanWaveSum(v.z), scanWaveSum(v.w));
+}
+
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict__ in, T* __restrict__ out, T* work, int* flags, int cap, const int* nPtr, unsigned epoch)
 {
@@ -162,39 +173,53 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 	}
 	T total;
 	const T excl = blockExclusiveScan(sum, &total, lds);
-	if (threadIdx.x == 0)
+	if (threadIdx.x < 64)
 	{
+		// the first wave looks back over 64 predecessors at a time (one status word per lane)
+		const int lane = threadIdx.x;
 		T* agg = work;
 		T* pre = work + cap;
-		int* flagOfTile = flags + tile;
 		T running;
 		scanZero(running);
 		if (tile > 0)
 		{
-			agg[tile] = total;
-			__hip_atomic_store(flagOfTile, (int)((epoch << 2) | 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-			int t = tile - 1;
+			if (lane == 0)
+			{
+				agg[tile] = total;
+				__hip_atomic_store(flags + tile, (int)((epoch << 2) | 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			int hi = tile - 1; // nearest predecessor not yet accounted for
 			while (true)
 			{
-				const int* f = flags + t;
-				const unsigned word = (unsigned)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-				if ((word >> 2) != epoch || (word & 3u) == 0u)
+				const int t = hi - lane;
+				unsigned state = 2u; // (lanes before tile 0 count as "prefix known, zero")
+				T val;
+				scanZero(val);
+				if (t >= 0)
 				{
-					__builtin_amdgcn_s_sleep(1);
-					continue;
+					unsigned word;
+					do
+					{
+						word = (unsigned)__hip_atomic_load(flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+					} while ((word >> 2) != epoch || (word & 3u) == 0u);
+					state = word & 3u;
+					val = state == 2u ? pre[t] : agg[t];
 				}
-				if ((word & 3u) == 2u)
-				{
-					running = scanAdd(running, pre[t]);
-					break;
-				}
-				running = scanAdd(running, agg[t]);
-				--t;
+				// the nearest tile whose inclusive prefix is known ends the walk
+				const unsigned long long known = __ballot(state == 2u);
+				const int stop = known ? __ffsll((long long)known) - 1 : 64;
+				if (lane > stop) scanZero(val);
+				running = scanAdd(running, scanWaveSum(val));
+				if (stop < 64) break;
+				hi -= 64;
 			}
 		}
-		pre[tile] = scanAdd(running, total);
-		__hip_atomic_store(flagOfTile, (int)((epoch << 2) | 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-		s_prefix = running;
+		if (lane == 0)
+		{
+			pre[tile] = scanAdd(running, total);
+			__hip_atomic_store(flags + tile, (int)((epoch << 2) | 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			s_prefix = running;
+		}
 	}
 	__syncthreads();
 	T run = scanAdd(s_prefix, excl);
@@ -217,9 +242,11 @@ static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, 
 	int blocks = (capN + SCAN_TILE - 1) / SCAN_TILE;
 	if (blocks < 1) blocks = 1;
 	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-	if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+	(void)hipStreamIsCapturing(stream, &capturing);
+	if (capturing != hipStreamCaptureStatusNone || blocks > SCAN_CHAIN_MAX_TILES)
 	{
-		// a captured launch would replay its epoch: the three-kernel form (reduce, scan of the tile sums, final) has no state
+		// a captured launch would replay its epoch, and past a few hundred tiles the look-back chain costs more than the two
+		// launches it saves (1.4 M elements: 25 us against 15): the three-kernel form (reduce, scan of the tile sums, final)
 		hipLaunchKernelGGL(k_scan_reduce<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, work, nPtr);
 		hipLaunchKernelGGL(k_scan_blocksums<T>, dim3(1), dim3(SCAN_THREADS), 0, stream, work, nPtr, (T*)nullptr);
 		hipLaunchKernelGGL(k_scan_final<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, nPtr);

@@ -133,6 +133,8 @@ struct Counters
 	int compactClass;    // persistent: colour class whose constraints may move to a lower free colour this step
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
 	int nHubRows;        // hub constraints of this step
+	int hubRounds;       // fixed-point rounds k_large_hub ran this step (all sweeps, all chunks)
+	int hubSerialChunks; // chunks of 64 hub rows it solved lane after lane instead
 	int chunkLanes;      // workgroup size of the small-island solver chosen for this step (TINY_CHUNK_LANES or SMALL_CHUNK_LANES)
 	// block partition (persistent: nBlocks, partitions; per step: the rest)
 	int nBlocks;         // blocks of the current partition (0 = none yet)
@@ -279,6 +281,7 @@ struct DW
 	int* compactList;    // large contact slots of colour Counters::compactClass (at most COLOR_SMALL_MAX listed)
 	int* uncolList;      // large contact slots that have no colour yet (at most COLOR_SMALL_MAX listed)
 	int* hubRowOf;       // per contact: its constraint row if it is a hub constraint this step
+	float4* hubDelta;    // per hub constraint (hubList order): the change it made to its hub's row in the last sweep (k_large_hub's first guess)
 	int* hubList;        // hub constraint rows in contact-index order (the deterministic visiting order of k_large_hub)
 	int* li_sorted;      // large contact slots grouped by colour
 	int4* li_ref;        // per colour-sorted row: contact index, bodyA, bodyB (static bodies as -(id+1)), island root

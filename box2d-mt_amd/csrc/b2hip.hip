@@ -214,6 +214,7 @@ struct b2hip_world
 	bool eventsOn = false;
 	std::vector<b2hip_contact_event> events; // of the last step, in delivery order
 	DevArray<int> uncolList, compactList, hubRowOf, hubList;
+	DevArray<float4> hubDelta;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
 	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies;
@@ -706,7 +707,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -789,7 +790,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.hubDelta = w->hubDelta.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
@@ -1248,7 +1249,7 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 	const int smallPath = largePath ? 0 : 1;
 	LAUNCH(w, k_create_contacts, gridFor(largePath ? d.capPairs : COUNT_RANK_MAX), 256, d, sortedKeys, sortedProxies, smallPath);
 	LAUNCH(w, k_create_finish, gridFor(d.nBodies), 256, d, smallPath);
-	LAUNCH(w, k_toi_order_create, 1, 256, d, smallPath);
+	LAUNCH(w, k_toi_order_create, 1, 1024, d, smallPath);
 	LAUNCH(w, k_create_commit, 1, 1, d, smallPath);
 	return 0;
 }
@@ -1662,7 +1663,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			for (int col = 0; col < nColors; ++col)
 				if (colorUsed(col)) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
-			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 0);
+			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 0, 0);
 		}
 		TRACE("warmstart");
 		if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 0);
@@ -1677,7 +1678,7 @@ static int phaseSolve(b2hip_world* w)
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 				if (w->debugTrace) TRACE(("vel" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
-			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 1);
+			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 1, it > 0 ? 1 : 0);
 		}
 		LAUNCH(w, k_large_store_impulses, gC, 256, d);
 		TRACE("store_impulses");
@@ -1692,7 +1693,7 @@ static int phaseSolve(b2hip_world* w)
 				LAUNCH(w, k_large_position, gK, 256, d, col);
 				if (w->debugTrace) TRACE(("pos" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
-			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 2);
+			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 2, it > 0 ? 1 : 0);
 			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
 			LAUNCH(w, k_large_pos_end, 1, 256, d);
 		}
@@ -2154,7 +2155,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
-	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release();
+	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release(); w->hubRowOf.release(); w->hubList.release(); w->hubDelta.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
@@ -3423,6 +3424,9 @@ static int stepEndImpl(b2hip_world* w)
 	}
 	if (c.overflow & 64) return setError(B2HIP_ERR_HIP, "grid barrier of k_solve_persistent timed out (a workgroup was not resident)");
 	w->last.posItersLarge = c.posItersLarge;
+	w->last.nHubRows = c.nHubRows;
+	w->last.hubRounds = c.hubRounds;
+	w->last.hubSerialChunks = c.hubSerialChunks;
 	if (w->toiRan)
 	{
 		w->last.toiUnsafe = c.toiUnsafe;
@@ -4250,6 +4254,9 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->block_max_rows = w->last.blkMaxRows;
 	out->partitions = w->last.partitions;
 	out->block_solver_steps = w->blockSteps;
+	out->hub_constraints = w->last.nHubRows;
+	out->hub_fixpoint_rounds = w->last.hubRounds;
+	out->hub_serial_chunks = w->last.hubSerialChunks;
 	return 0;
 }
 

@@ -12,6 +12,6 @@ every = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 for s in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):
     t0 = time.time(); w.step(every); dt = (time.time() - t0) / every
     ctr = b2hip.Counters(); hip.b2hip_get_counters(dev, C.byref(ctr))
-    print("step", s, "%.1f ms" % (dt * 1e3), "contacts", w.contact_count, "touching", ctr.touching_contacts, "islands", ctr.islands, "L", ctr.large_islands, ctr.large_island_bodies, ctr.large_island_contacts, "colors", ctr.colors, flush=True)
+    print("step", s, "%.1f ms" % (dt * 1e3), "contacts", w.contact_count, "touching", ctr.touching_contacts, "islands", ctr.islands, "L", ctr.large_islands, ctr.large_island_bodies, ctr.large_island_contacts, "colors", ctr.colors, "hub rows", ctr.hub_constraints, "rounds", ctr.hub_fixpoint_rounds, "serial chunks", ctr.hub_serial_chunks, flush=True)
 b = w.bodies(); print("finite", bool(np.isfinite(b).all()))
 print({k: round(v, 2) for k, v in w.profile().items() if v and k != "steps"})
