@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		W.bodyColorMask[i] = 0;
 		W.bodyActive[i] = 0;
 		W.b_adopt[i] = 0;
+		for (int q = 0; q < 3; ++q) W.b_adoptStage[(size_t)q * W.nBodies + i] = 0;
 		uint32_t f = W.b_flags[i] & ~(BF_ISLAND | BF_LARGE);
 		// ConsumeAwakes / b2Contact::Destroy wake-ups gathered by collide: SetAwake(true) also
 		// resets the sleep timer of bodies that are already awake (b2Body.h:699-703).
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.nBigIslands = 0;
 		S->c.nRemoteIslands = 0;
 		S->c.nSmallJointed = 0;
+		S->c.nSerialOrphans = 0;
 		S->c.hubRounds = 0;
 		S->c.hubSerialChunks = 0;
 		S->c.nOrphanRows = 0;
@@ -413,10 +415,49 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W)
 			// a body without a home block is offered the block of its neighbour (the highest one, if several do: deterministic)
 			if (nsA && nsB)
 			{
+				// (the offers also go to the three stage buffers of k_block_adopt, which hands blocks on to bodies further away)
 				const int ba = W.b_blk1[ids.z], bb = W.b_blk1[ids.w];
-				if (ba == 0 && bb != 0) atomicMax(&W.b_adopt[ids.z], bb);
-				if (bb == 0 && ba != 0) atomicMax(&W.b_adopt[ids.w], ba);
+				if (ba == 0 && bb != 0)
+				{
+					atomicMax(&W.b_adopt[ids.z], bb);
+					for (int q = 0; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.z], bb);
+				}
+				if (bb == 0 && ba != 0)
+				{
+					atomicMax(&W.b_adopt[ids.w], ba);
+					for (int q = 0; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.w], ba);
+				}
 			}
+		}
+	}
+}
+
+// A body that joins a partitioned island without touching a body that has a home block - it landed on other newcomers -
+// gets no offer from k_island_edges; its constraints would be orphans and the island would have to be partitioned again
+// (every step, while a pile is growing). Stage `stage` (0, 1, 2) hands blocks on by one more contact: it reads what stage
+// - 1 knew (stage buffer `stage`; buffer 0 holds k_island_edges' offers) and adds its offers to every later buffer and to
+// b_adopt, so the outcome does not depend on which lane ran first.
+__global__ __launch_bounds__(256) void k_block_adopt(DW W, int stage)
+{
+	DState* S = W.st;
+	const int n = S->c.nLContacts;
+	const ContactArrays& C = W.ca[S->cur];
+	const int* known = W.b_adoptStage + (size_t)stage * W.nBodies;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int4 ids = C.ids[W.li_contacts[k]];
+		if ((W.b_flags[ids.z] & BF_TYPE_MASK) == BT_STATIC || (W.b_flags[ids.w] & BF_TYPE_MASK) == BT_STATIC) continue;
+		const int ba = W.b_blk1[ids.z] ? W.b_blk1[ids.z] : known[ids.z];
+		const int bb = W.b_blk1[ids.w] ? W.b_blk1[ids.w] : known[ids.w];
+		if (W.b_blk1[ids.z] == 0 && bb != 0 && bb > ba)
+		{
+			atomicMax(&W.b_adopt[ids.z], bb);
+			for (int q = stage + 1; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.z], bb);
+		}
+		if (W.b_blk1[ids.w] == 0 && ba != 0 && ba > bb)
+		{
+			atomicMax(&W.b_adopt[ids.w], ba);
+			for (int q = stage + 1; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.w], ba);
 		}
 	}
 }

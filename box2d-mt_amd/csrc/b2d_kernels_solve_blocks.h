@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void k_color_recheck_begin(DW W)
 		S->c.nUncolored = 0;
 		S->c.nUncolList = 0;
 		S->c.nOrphanRows = 0;
+		S->c.nSerialOrphans = 0;
 		S->c.blkMaxRows = 0;
 		S->c.blkMaxBodies = 0;
 		S->c.nCutRows = 0;
@@ -656,6 +657,221 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	}
 	BLK_STAMP(4);
 #undef BLK_STAMP
+}
+
+// ---- one sweep per launch ------------------------------------------------------------------------------------------------------
+// Islands with joints or hub bodies cannot stay inside one resident kernel: between the contact sweeps the island's joints are
+// walked in order (k_large_joints) and the hub constraints are swept by k_large_hub. Instead of one launch per COLOUR
+// (k_large_velocity / k_large_position: 17 colours x 12 sweeps = 200 launches of ~5 us for the 100 000-box Tumbler, each
+// bound by the launch itself) this kernel does one SWEEP per launch with the block machinery of k_solve_blocks: a workgroup
+// per block, its bodies' rows in LDS for the interior colours, the upper-range (cut) constraints handed over through
+// tagged rows in memory. The constraints live in the field-major rows k_large_init wrote (W.lc), the bodies in b_vel /
+// b_pos between launches, exactly as for the launch-per-colour kernels - whose result it reproduces bit for bit (same
+// colours, same order on every body: interior colours ascending, then upper colours ascending, then the hub sweep).
+//   mode 0 warm start, 1 velocity iteration, 2 position iteration
+template <int LANES>
+__global__ __launch_bounds__(LANES) void k_blocks_sweep(DW W, StepParams sp, int mode, int* bar, int epoch)
+{
+	DState* S = W.st;
+	if (mode == 2 && S->c.allLargeDone) return;
+	const ContactArrays& C = W.ca[S->cur];
+	const int tid = (int)threadIdx.x, blk = (int)blockIdx.x;
+	__shared__ float4 s_row[BLOCK_MAX_BODIES];
+	__shared__ int s_perm[LANES];
+	__shared__ int s_hist[MAX_COLORS], s_colStart[MAX_COLORS + 1];
+	__shared__ unsigned long long s_colMask;
+	const int tag = (epoch & 0x7fff) << 16;
+	const int rowStart = W.blkRowStart[blk];
+	int nR = W.blkRowStart[blk + 1] - rowStart;
+	const int bodyStart = W.blkBodyStart[blk];
+	int nB = W.blkBodyStart[blk + 1] - bodyStart;
+	if (nR > LANES || nB > BLOCK_MAX_BODIES || nB > LANES)
+	{
+		if (tid == 0) { stcI(&bar[4], 1); atomicOr(&S->c.overflow, 64); }
+		nR = nR > LANES ? LANES : nR;
+		nB = 0;
+	}
+	// ---- my rows, sorted by colour in LDS -------------------------------------------------------------------------------------
+	if (tid < MAX_COLORS) s_hist[tid] = 0;
+	__syncthreads();
+	int color0 = 0;
+	if (tid < nR)
+	{
+		color0 = W.rowColor[rowStart + tid] & (MAX_COLORS - 1);
+		atomicAdd(&s_hist[color0], 1);
+	}
+	__syncthreads();
+	if (tid == 0)
+	{
+		int run = 0;
+		unsigned long long mask = 0ull;
+		for (int c = 0; c < MAX_COLORS; ++c)
+		{
+			s_colStart[c] = run;
+			if (s_hist[c]) mask |= 1ull << c;
+			run += s_hist[c];
+			s_hist[c] = 0;
+		}
+		s_colStart[MAX_COLORS] = run;
+		s_colMask = mask;
+	}
+	__syncthreads();
+	if (tid < nR) s_perm[s_colStart[color0] + atomicAdd(&s_hist[color0], 1)] = tid;
+	__syncthreads();
+	const bool have = tid < nR;
+	const int row = have ? rowStart + s_perm[tid] : 0;
+	const int myColor = have ? (W.rowColor[row] & (MAX_COLORS - 1)) : -1;
+	const bool upper = have && myColor >= CUT_COLOR_BASE && myColor != HUB_COLOR;
+	const unsigned long long colMask = s_colMask;
+	float4* const rows = mode == 2 ? W.b_pos : W.b_vel;
+	float4* const xch = mode == 2 ? W.b_posv : W.b_cutv;
+
+	// ---- my home body into LDS ---------------------------------------------------------------------------------------------------
+	const bool isBody = tid < nB;
+	int hBody = 0, hCutDeg = 0;
+	float hW = 0.0f;
+	if (isBody)
+	{
+		hBody = W.blkBodies[bodyStart + tid];
+		hCutDeg = __popcll(W.bodyActive[hBody]);
+		const float4 q = rows[hBody];
+		hW = q.w;
+		s_row[tid] = make_float4(q.x, q.y, q.z, 0.0f);
+	}
+	// ---- my constraint -----------------------------------------------------------------------------------------------------------
+	LargeRef r;
+	r.ci = 0; r.bodyA = 0; r.bodyB = 0; r.root = 0; r.nsA = false; r.nsB = false;
+	ContactConstraint cc;
+	memset(&cc, 0, sizeof(cc));
+	int slotA = 0, slotB = 0, degA = 0, rankA = 0, degB = 0, rankB = 0;
+	float4 statA = make_float4(0, 0, 0, 0), statB = statA;
+	bool active = have && myColor != HUB_COLOR;
+	if (active)
+	{
+		r = largeRef(W, C, row);
+		if (mode == 2)
+		{
+			active = W.rootDone[r.root] == 0;
+			lcLoad(W, row, cc, LC_MASS_FIRST, LC_MASS_FIRST + 4);
+			lcLoad(W, row, cc, LC_POS_FIRST, LC_WORDS);
+			statA = W.b_pos[r.bodyA];
+			statB = W.b_pos[r.bodyB];
+		}
+		else
+		{
+			lcLoad(W, row, cc, 0, LC_VEL_WORDS);
+		}
+		if (!upper)
+		{
+			if (r.nsA) slotA = W.b_slot[r.bodyA];
+			if (r.nsB) slotB = W.b_slot[r.bodyB];
+		}
+		else
+		{
+			const unsigned long long below = (1ull << myColor) - 1ull;
+			if (r.nsA) { const unsigned long long m = W.bodyActive[r.bodyA]; degA = __popcll(m); rankA = __popcll(m & below); }
+			if (r.nsB) { const unsigned long long m = W.bodyActive[r.bodyB]; degB = __popcll(m); rankB = __popcll(m & below); }
+		}
+	}
+	const bool nsA = have && r.nsA, nsB = have && r.nsB;
+	// (a closed island's bodies take no part: its rows are inactive everywhere, so nobody waits for them either)
+	const bool hBoundary = isBody && hCutDeg > 0 && !(mode == 2 && W.rootDone[W.parent[hBody]] != 0);
+	float4* const xA = nsA ? &xch[r.bodyA] : nullptr;
+	float4* const xB = nsB ? &xch[r.bodyB] : nullptr;
+	const bool crossing = __syncthreads_or(hBoundary || (upper && active)) != 0;
+	float minSep = 0.0f;
+
+	// ---- interior colours ----------------------------------------------------------------------------------------------------------
+	for (unsigned long long m = colMask & COLOR_INTERIOR_BITS; m != 0ull; m &= m - 1ull)
+	{
+		const int c = __ffsll((long long)m) - 1;
+		if (myColor == c && active)
+		{
+			if (mode == 2)
+			{
+				float4 qa = statA, qb = statB;
+				if (nsA) qa = s_row[slotA];
+				if (nsB) qb = s_row[slotB];
+				BodyPos pA, pB;
+				pA.c = v2(qa.x, qa.y); pA.a = qa.z;
+				pB.c = v2(qb.x, qb.y); pB.a = qb.z;
+				b2dSolvePosition<true>(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
+				if (nsA) s_row[slotA] = make_float4(pA.c.x, pA.c.y, pA.a, 0.0f);
+				if (nsB) s_row[slotB] = make_float4(pB.c.x, pB.c.y, pB.a, 0.0f);
+			}
+			else
+			{
+				BodyVel vA, vB;
+				vA.v = v2(0, 0); vA.w = 0.0f;
+				vB = vA;
+				if (nsA) { const float4 q = s_row[slotA]; vA.v = v2(q.x, q.y); vA.w = q.z; }
+				if (nsB) { const float4 q = s_row[slotB]; vB.v = v2(q.x, q.y); vB.w = q.z; }
+				if (mode == 0) b2dWarmStart(&cc, &vA, &vB); else b2dSolveVelocity(&cc, &vA, &vB);
+				if (nsA) s_row[slotA] = make_float4(vA.v.x, vA.v.y, vA.w, 0.0f);
+				if (nsB) s_row[slotB] = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
+			}
+		}
+		__syncthreads();
+	}
+	// ---- upper colours through memory ------------------------------------------------------------------------------------------------
+	if (crossing)
+	{
+		if (hBoundary)
+		{
+			const float4 q = s_row[tid];
+			stRow(&xch[hBody], q.x, q.y, q.z, tag + 1);
+		}
+		{
+			const int needA = tag + 1 + rankA, needB = tag + 1 + rankB;
+			bool ok;
+			if (mode == 2)
+			{
+				ok = dataflowRun(upper && active, xA, needA, xB, needB, bar, &S->c.overflow, 1, [&](f4v ra, f4v rb)
+				{
+					BodyPos pA, pB;
+					pA.c = v2(ra.x, ra.y); pA.a = ra.z;
+					pB.c = v2(rb.x, rb.y); pB.a = rb.z;
+					if (!nsA) { pA.c = v2(statA.x, statA.y); pA.a = statA.z; }
+					if (!nsB) { pB.c = v2(statB.x, statB.y); pB.a = statB.z; }
+					b2dSolvePosition<true>(&cc, &pA, &pB, B2D_BAUMGARTE, &minSep);
+					if (nsA) stRow(xA, pA.c.x, pA.c.y, pA.a, needA + 1);
+					if (nsB) stRow(xB, pB.c.x, pB.c.y, pB.a, needB + 1);
+				});
+			}
+			else
+			{
+				ok = dataflowRun(upper && active, xA, needA, xB, needB, bar, &S->c.overflow, 1, [&](f4v ra, f4v rb)
+				{
+					BodyVel vA, vB;
+					vA.v = v2(ra.x, ra.y); vA.w = ra.z;
+					vB.v = v2(rb.x, rb.y); vB.w = rb.z;
+					if (!nsA) { vA.v = v2(0, 0); vA.w = 0.0f; }
+					if (!nsB) { vB.v = v2(0, 0); vB.w = 0.0f; }
+					if (mode == 0) b2dWarmStart(&cc, &vA, &vB); else b2dSolveVelocity(&cc, &vA, &vB);
+					if (nsA) stRow(xA, vA.v.x, vA.v.y, vA.w, needA + 1);
+					if (nsB) stRow(xB, vB.v.x, vB.v.y, vB.w, needB + 1);
+				});
+			}
+			if (!ok) return;
+		}
+		{
+			const int need = tag + (hCutDeg + 1);
+			const bool ok = dataflowRun(hBoundary, &xch[hBody], need, nullptr, 0, bar, &S->c.overflow, 1, [&](f4v ra, f4v)
+			{
+				s_row[tid] = make_float4(ra.x, ra.y, ra.z, 0.0f);
+			});
+			if (!ok) return;
+		}
+	}
+	(void)degA; (void)degB;
+	// ---- out ---------------------------------------------------------------------------------------------------------------------------
+	if (mode == 1 && active) lcStore(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
+	if (mode == 2) waveAtomicMaxU32(W.rootPen, r.root, floatBits(0.0f - minSep), active);
+	if (isBody)
+	{
+		const float4 q = s_row[tid];
+		rows[hBody] = make_float4(q.x, q.y, q.z, mode == 2 ? hW : 0.0f);
+	}
 }
 
 #endif

@@ -99,6 +99,21 @@ __device__ __forceinline__ void noteColorUsed(DState* S, int color)
 	else atomicOr(&S->c.colorMaskHi, 1u << (color - 32));
 }
 
+// A constraint that is not coloured but swept in order by k_large_hub after the coloured ones of every sweep: a hub's
+// (more constraints on one body than colours can separate), or - in islands that are swept block-wise between joint walks
+// and hub sweeps - one whose body has no home block yet (a newcomer that landed on other newcomers: the handful of such
+// constraints a step brings is cheaper swept in order than a new partition of the whole island).
+__device__ __forceinline__ bool rowIsHubs(const DW& W, bool nsA, int bodyA, bool nsB, int bodyB)
+{
+	return (nsA && W.deg[bodyA] > HUB_DEGREE) || (nsB && W.deg[bodyB] > HUB_DEGREE);
+}
+__device__ __forceinline__ bool rowIsSerial(const DW& W, bool nsA, int bodyA, bool nsB, int bodyB)
+{
+	if (rowIsHubs(W, nsA, bodyA, nsB, bodyB)) return true;
+	if (!W.serialOrphans) return false;
+	return (nsA && effBlk(W, bodyA) == 0) || (nsB && effBlk(W, bodyB) == 0);
+}
+
 __global__ __launch_bounds__(256) void k_color_begin(DW W)
 {
 	DState* S = W.st;
@@ -194,16 +209,20 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			const int ci = W.li_contacts[s];
 			const int4 ids = C.ids[ci];
 			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-			const bool hubA = nsA && W.deg[ids.z] > HUB_DEGREE;
-			const bool hubB = nsB && W.deg[ids.w] > HUB_DEGREE;
+			const bool hubA = rowIsSerial(W, nsA, ids.z, nsB, ids.w), hubB = false; // (swept in order: see rowIsSerial)
+			if (hubA && !rowIsHubs(W, nsA, ids.z, nsB, ids.w)) atomicAdd(&S->c.nSerialOrphans, 1);
 			{
 				// block census: the row belongs to the home block of its first non-static body (counted in LDS: ten
 				// thousand rows adding to a few dozen words of memory serialise in L2)
 				const int blkA = nsA ? effBlk(W, ids.z) : 0, blkB = nsB ? effBlk(W, ids.w) : 0;
+				// (a hub's constraints belong to no block: k_large_hub sweeps them, in a segment of their own behind the blocks' rows)
 				const int owner = nsA ? blkA : blkB;
-				if (owner > 0 && owner <= MAX_BLOCKS) atomicAdd(&s_blkRows[owner - 1], 1);
-				if ((nsA && blkA == 0) || (nsB && blkB == 0)) ++orphanRows;
-				if (nsA && nsB && blkA != blkB) ++cutRows;
+				if (!hubA && !hubB)
+				{
+					if (owner > 0 && owner <= MAX_BLOCKS) atomicAdd(&s_blkRows[owner - 1], 1);
+					if ((nsA && blkA == 0) || (nsB && blkB == 0)) ++orphanRows;
+					if (nsA && nsB && blkA != blkB) ++cutRows;
+				}
 			}
 			col = C.color[ci];
 			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
@@ -524,7 +543,8 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 			// k_solve_blocks: rows grouped by the home block of their first non-static body (the workgroup sorts its rows by
 			// colour itself, in LDS); blkRowStart comes from the census of k_block_census
 			int owner = valid ? effBlk(W, nsA ? ids.z : ids.w) - 1 : 0;
-			const bool placed = valid && owner >= 0 && owner < MAX_BLOCKS;
+			if (valid && color == HUB_COLOR) owner = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS; // the segment behind the last block
+			const bool placed = valid && owner >= 0 && owner <= MAX_BLOCKS;
 			if (!placed) owner = 0;
 			const int slot = waveKeyedAlloc(W.blkCursor, owner, placed);
 			p = W.blkRowStart[owner] + slot;
@@ -593,7 +613,10 @@ __global__ __launch_bounds__(256) void k_hub_flag(DW W)
 			const int b = nsA ? ids.z : ids.w;
 			if ((nsA || nsB) && W.rootIsland[W.parent[b]] == ROOT_LARGE)
 			{
-				f = ((nsA && W.deg[ids.z] > HUB_DEGREE) || (nsB && W.deg[ids.w] > HUB_DEGREE)) ? 1 : 0;
+				// a hub's constraints first (in contact order), then the others that are swept in order: two counts in one word
+				// (the scan that follows ranks both)
+				if (rowIsHubs(W, nsA, ids.z, nsB, ids.w)) f = 1;
+				else if (rowIsSerial(W, nsA, ids.z, nsB, ids.w)) f = 1 << 20;
 			}
 		}
 		W.keepFlag[i] = f;
@@ -606,8 +629,12 @@ __global__ __launch_bounds__(256) void k_hub_fill(DW W)
 	const int n = S->c.nContacts;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
-		if (W.keepFlag[i]) W.hubList[W.keepScan[i]] = W.hubRowOf[i];
+		const int f = W.keepFlag[i];
+		if (f == 1) W.hubList[W.keepScan[i] & 0xfffff] = W.hubRowOf[i];
+		else if (f) W.hubList[(W.keepScan[n] & 0xfffff) + (W.keepScan[i] >> 20)] = W.hubRowOf[i];
 	}
+	// (k_color_scan sets this for the launch-per-colour layout; with rows grouped by block it is not run)
+	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.nHubRows = W.colorCount[HUB_COLOR];
 }
 
 // One constraint of a hub chunk, evaluated from the hub row `hubIn` the lane assumes it will meet at its turn. Works on
@@ -673,19 +700,18 @@ __device__ __forceinline__ HubTrial hubEvaluate(int mode, ContactConstraint& cc,
 //   * otherwise (or if HUB_FIXPOINT_ROUNDS were not enough) the lanes take turns: the hub's row travels from turn to turn
 //     in registers (wave shuffle) as long as consecutive constraints sit on the same hub; a partner body that occurs twice
 //     in a chunk is re-read at its turn.
-__global__ __launch_bounds__(64) void k_large_hub(DW W, int mode, int useGuess)
+__device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGuess, int firstRow)
 {
 	DState* S = W.st;
-	if (mode == 2 && S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];
 	const int n = S->c.nHubRows;
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63;
 	const float4* rows = mode == 2 ? W.b_pos : W.b_vel;
 	float4* rowsOut = mode == 2 ? W.b_pos : W.b_vel;
 	int carryBody = -1;
 	float4 carry = make_float4(0, 0, 0, 0);
 	int statRounds = 0, statSerial = 0;
-	for (int base = 0; base < n; base += 64)
+	for (int base = firstRow; base < n; base += 64)
 	{
 		const int k = base + lane;
 		const bool have = k < n;
@@ -702,7 +728,9 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode, int useGuess)
 		{
 			row = W.hubList[k];
 			r = largeRef(W, C, row);
-			hubIsA = r.nsA && W.deg[r.bodyA] > HUB_DEGREE;
+			// the body whose row is carried from turn to turn: the hub; for a constraint that is here for another reason
+			// (rowIsSerial) any of its moving bodies
+			hubIsA = r.nsA && (W.deg[r.bodyA] > HUB_DEGREE || !r.nsB || W.deg[r.bodyB] <= HUB_DEGREE);
 			hubBody = hubIsA ? r.bodyA : r.bodyB;
 			otherBody = hubIsA ? r.bodyB : r.bodyA;
 			otherDynamic = hubIsA ? r.nsB : r.nsA;
@@ -793,7 +821,8 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode, int useGuess)
 					if (lane >= off) { sx += ux; sy += uy; sz += uz; }
 				}
 				const float4 next = make_float4(u0.x + (sx - dx), u0.y + (sy - dy), u0.z + (sz - dz), u0.w);
-				// settled = no lane's assumption moves by more than 2^-21 of the hub row (or of the sweep's total change to it, if
+				// settled = no lane's assumption moves by more than 2^-21 of the hub row - a 64th of the rounding a sweep over 500
+				// constraints accumulates in that row anyway (or of the sweep's total change to it, if
 				// that is larger). Not "by a bit": a lane's change is measured as (row after - row before), which carries the
 				// rounding of the row itself, so assumptions keep flickering in their last bit long after the sweep is decided
 				const float tx = 0x1p-21f * fmaxf(fabsf(u0.x), fabsf(__shfl(sx, 63)));
@@ -902,6 +931,12 @@ __global__ __launch_bounds__(64) void k_large_hub(DW W, int mode, int useGuess)
 		atomicAdd(&S->c.hubRounds, statRounds);
 		atomicAdd(&S->c.hubSerialChunks, statSerial);
 	}
+}
+
+__global__ __launch_bounds__(64) void k_large_hub(DW W, int mode, int useGuess)
+{
+	if (mode == 2 && W.st->c.allLargeDone) return;
+	hubSweepOneWave(W, mode, useGuess, 0);
 }
 
 __global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)

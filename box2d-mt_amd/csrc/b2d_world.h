@@ -153,6 +153,7 @@ struct Counters
 	int nFilterList;     // contacts flagged for re-filtering, listed for the user's contact filter (DW::filterList)
 	int nBigIslands;     // islands with more than SHARD_BIG_BODIES bodies this step (sharded worlds only)
 	int nRemoteIslands;  // islands of this step that another rank solves
+	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
 	int nSmallJointed;   // small islands of this step that hold joints (none: the lean k_solve_small runs)
 };
 
@@ -196,6 +197,7 @@ struct DW
 	DState* st;
 	int nBodies, nProxies, nJoints, nShapes;
 	int capContacts, capPairs, capMoves;
+	int serialOrphans;    // 1: constraints of bodies without a home block are swept in order with the hub constraints
 	int hubSerial;        // B2HIP_HUB_SERIAL=1: hub rows lane after lane only (validation of the fixed-point path)
 	int smallMaxW;        // islands up to this size take the exact-order in-LDS solver (default TINY_ISLAND_MAX_W = 128; B2HIP_SMALL_MAX_W up to 512)
 	int bigChunks;        // 1: always use 1024-lane chunks for the small-island solver (B2HIP_BIG_CHUNKS)
@@ -301,6 +303,7 @@ struct DW
 	// block partition of the large islands
 	int* b_blk1;         // per body, persistent: home block + 1 (0 = none)
 	int* b_adopt;        // per body, per step: block + 1 offered to a body without one by a neighbour (max over the neighbours)
+	int* b_adoptStage;   // three stage buffers of k_block_adopt (nBodies each)
 	int* blkRows;        // per block: rows it owns this step
 	int* blkRowStart;    // [nBlocks + 1] exclusive scan of blkRows
 	int* blkCursor;      // per block: fill cursor of k_color_fill

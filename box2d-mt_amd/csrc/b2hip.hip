@@ -259,9 +259,18 @@ struct b2hip_world
 	DevArray<PostSolveRec> postRecs;
 	DevArray<int> filterList, hostList; // hostList: indices uploaded by the host (contacts to disable / reject, pairs to drop)
 	// block partition of the large islands (b2d_kernels_solve_blocks.h)
+	DevArray<int> b_adoptStage;
 	DevArray<int> b_blk1, b_adopt, blkRows, blkRowStart, blkCursor, blkBodyStart, blkBodies, rowColor;
 	DevArray<float4> b_cutv;
 	int blocksMaxWG = 0;         // co-resident workgroups of k_solve_blocks on this device (0 = do not use it)
+	int sweepMaxWG[3] = { 0, 0, 0 }; // ... of k_blocks_sweep<256 / 512 / 1024>
+	int serialOrphansNext = 0;   // DW::serialOrphans of the next step
+	int adoptSticky = 0;
+	bool adoptPasses = false;    // the last step had orphan constraints (or made a partition): run k_block_adopt this step
+	bool tracePartition = false; // B2HIP_TRACE_PARTITION=1: why a partition was made, on stderr
+	bool noSweepBlocks = false;  // B2HIP_NO_SWEEP_BLOCKS=1: jointed / hub islands stay on the launch-per-colour kernels
+	int dfWipedAt = 0;           // dfEpoch >> 14 at the last wipe of the hand-over rows
+	int sweepSteps = 0;          // steps whose large islands went through k_blocks_sweep
 	int blockLanes = 0;          // forced workgroup size of k_solve_blocks (B2HIP_BLOCK_LANES), 0 = chosen per partition
 	bool noBlocks = false;       // B2HIP_NO_BLOCKS=1: keep the large islands on k_solve_mailbox
 	int blockSteps = 0;          // steps solved by k_solve_blocks (diagnostics)
@@ -734,7 +743,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		ENS(postRecs, nPost); ENS(filterList, nFil);
 		ENS(hostList, std::max<size_t>(std::max(nPre, nFil), w->filterFn ? capPairs : 1));
 	}
-	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2);
+	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
 	ENS(stateOut, 12 * nb);
 	ENS(consts, 16);
@@ -802,7 +811,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
 	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p; d.toiParent = w->toiParent.p; d.toiDomOf = w->toiDomOf.p; d.toiDomRoot = w->toiDomRoot.p; d.toiDomCount = w->toiDomCount.p; d.toiDomBase = w->toiDomBase.p; d.toiDomFill = w->toiDomFill.p; d.toiDomFailed = w->toiDomFailed.p; d.toiDomEvents = w->toiDomEvents.p; d.toiDomList = w->toiDomList.p; d.toiHull = w->toiHull.p;
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
-	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p;
+	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.b_adoptStage = w->b_adoptStage.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p;
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
 	d.userFilter = w->filterFn ? 1 : 0; d.preSolveOn = w->preSolveFn ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
 	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
@@ -1381,6 +1390,7 @@ static int phaseSolve(b2hip_world* w)
 	w->trace.clear();
 	w->blocksThisStep = false;
 	DW& d = w->dw;
+	d.serialOrphans = w->serialOrphansNext;
 	const StepParams& sp = w->sp;
 	w->ktUsed = 0;
 	w->ktKind = 0;
@@ -1407,6 +1417,9 @@ static int phaseSolve(b2hip_world* w)
 		}
 		LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
+		// (a growing pile: hand home blocks on to newcomers up to four contacts away instead of partitioning again)
+		if (w->adoptPasses)
+			for (int stage = 0; stage < 3; ++stage) LAUNCH(w, k_block_adopt, gridFor(d.capContacts), 256, d, stage);
 		if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
 		LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_block_census, 1, 1024, d);
@@ -1418,22 +1431,42 @@ static int phaseSolve(b2hip_world* w)
 	rc = readState(w);
 	if (rc) return rc;
 	Counters c = w->h_dstate->c;
+	// (newcomers without a home block: from the next step on k_block_adopt hands blocks further, for a while)
+	if (c.nOrphanRows > 0) w->adoptSticky = 16; else if (w->adoptSticky > 0) w->adoptSticky -= 1;
+	w->adoptPasses = w->adoptSticky > 0;
+	// (from the next step on: in islands with joints / hubs the constraints of such newcomers are swept in order instead)
+	w->serialOrphansNext = (forceLarge != 2 && !w->noBlocks && !w->noSweepBlocks && c.nBlocks > 0 && (d.nJoints > 0 || c.maxDegree > HUB_DEGREE)) ? 1 : 0;
 	// ---- block partition of the large islands: (re)made when bodies without a home block joined, when a block outgrew a
 	// workgroup, or when too many constraints cross block boundaries (the pile has moved since the partition was made)
-	const bool blockShape = forceLarge != 2 && !w->noBlocks && c.nLIslands > 0 && d.nJoints == 0 && c.maxDegree <= HUB_DEGREE &&
+	// (islands with joints or hub bodies are partitioned too: k_blocks_sweep does their contact sweeps block-wise, one launch
+	// per sweep, between the joint walks and the hub sweeps)
+	const bool plainIslands = d.nJoints == 0 && c.maxDegree <= HUB_DEGREE;
+	const bool blockShape = forceLarge != 2 && !w->noBlocks && c.nLIslands > 0 && (plainIslands || !w->noSweepBlocks) &&
 		(sp.warmStarting ? 1 : 0) + sp.velIters > 0 && w->blocksMaxWG > 0;
 	if (blockShape && c.partitionCooldown == 0)
 	{
 		// Block size: one 1024-lane block while the large islands fit it (nothing ever goes through memory then), else
 		// 256-lane blocks (measured on the 10 011-box pyramid: 215 us against 235 / 245 us with 512 / 1024 lanes - the
 		// workgroup barriers of the interior colours are cheaper and the position solves spread over more CUs)
-		auto lanesFor = [w](const Counters& k) { return w->blockLanes ? w->blockLanes : (k.nLContacts <= 900 ? 1024 : 256); };
-		auto misfit = [](const Counters& k) { return k.nBlocks == 0 || k.nOrphanRows > 0 || k.blkMaxRows > k.blkLanes || k.blkMaxBodies > k.blkLanes; };
+		// (512 lanes once 256-lane blocks would be more than fit the device together)
+		// (... and 1024 again once 512-lane blocks would not)
+		auto lanesFor = [w](const Counters& k) { return w->blockLanes ? w->blockLanes : (k.nLContacts <= 900 ? 1024 : (k.nLContacts > 400 * w->blocksMaxWG ? 1024 : (k.nLContacts > 200 * w->blocksMaxWG ? 512 : 256))); };
+		auto misfit = [](const Counters& k) { return k.nBlocks == 0 || k.nOrphanRows > 0 || k.blkMaxRows > k.blkLanes || k.blkMaxBodies > k.blkLanes || k.nSerialOrphans > 2048; };
 		bool need = misfit(c) || (c.partitionAge > 240 && (4 * c.nCutRows > c.nLContacts || (c.blkLanes != lanesFor(c) && 2 * c.nLContacts < 900)));
 		int lanes = lanesFor(c);
 		int target = BLOCK_TARGET_DEG * lanes / BLOCK_LANES;
+		// (the last partition did not last - a growing pile: leave the blocks room for the bodies they will adopt, if half as
+		// many blocks again still fit the device together)
+		{
+			const int cap = plainIslands ? w->blocksMaxWG : (lanes == 512 ? w->sweepMaxWG[1] : (lanes == BLOCK_LANES ? w->sweepMaxWG[2] : w->sweepMaxWG[0]));
+			if (c.nBlocks > 0 && c.partitionAge < 16 && c.nBlocks * 3 / 2 + 8 <= cap) target = target * 2 / 3;
+			if (w->tracePartition) fprintf(stderr, "[b2hip] capacity for %d-lane blocks: %d\n", lanes, cap);
+		}
 		for (int attempt = 0; need && attempt < 3; ++attempt)
 		{
+			if (w->tracePartition)
+				fprintf(stderr, "[b2hip] partition (attempt %d, target %d, lanes %d): blocks %d orphan rows %d max rows %d max bodies %d lanes %d age %d cut %d of %d\n",
+					attempt, target, lanes, c.nBlocks, c.nOrphanRows, c.blkMaxRows, c.blkMaxBodies, c.blkLanes, c.partitionAge, c.nCutRows, c.nLContacts);
 			HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.blkLanes, &lanes, sizeof(int), hipMemcpyHostToDevice, w->stream));
 			rc = partitionLargeIslands(w, target);
 			if (rc) return rc;
@@ -1454,7 +1487,7 @@ static int phaseSolve(b2hip_world* w)
 
 	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[4], w->stream));
 	const bool exactLarge = forceLarge == 2;
-	const bool hasHubs = !exactLarge && c.maxDegree > HUB_DEGREE;
+	const bool hasHubs = !exactLarge && (c.maxDegree > HUB_DEGREE || c.nSerialOrphans > 0); // (anything for k_large_hub)
 	// Small and large islands share nothing (different bodies, contacts, island tables): when both tiers are present the
 	// small-island chain (DFS order, chunking, k_solve_small) runs on a side stream beside the large-island solver and
 	// joins before SynchronizeFixtures. With a handful of small islands that chain is one or two workgroups of big kernels
@@ -1524,10 +1557,15 @@ static int phaseSolve(b2hip_world* w)
 		const bool usePersistent = !exactLarge && !hasJoints && !hasHubs && !w->debugTrace && !w->kernelTimingLaunches &&
 			persistMaxWG > 0 && persistWG <= persistMaxWG;
 		// the block solver (bodies in LDS, one workgroup per block of the partition): whenever the partition fits
-		const bool useBlocks = usePersistent && blockShape && !w->solverBarriers && !w->solverRows && !w->solverMailbox && c.nBlocks > 0 &&
-			c.nOrphanRows == 0 && c.blkMaxRows <= c.blkLanes && c.blkMaxBodies <= c.blkLanes && c.nBlocks <= w->blocksMaxWG &&
+		const bool partitionFits = blockShape && c.nBlocks > 0 && c.nOrphanRows == 0 && c.blkMaxRows <= c.blkLanes && c.blkMaxBodies <= c.blkLanes;
+		const bool useBlocks = usePersistent && partitionFits && plainIslands && !w->solverBarriers && !w->solverRows && !w->solverMailbox &&
+			c.nBlocks <= w->blocksMaxWG &&
 			(sp.velIters + 2) * (MAX_COLORS + 1) < 65536 && (sp.posIters + 1) * (MAX_COLORS + 1) < 65536;
-		d.blockSort = useBlocks ? 1 : 0;
+		// one launch per sweep over the same blocks for islands that need joint walks / hub sweeps in between
+		const int sweepMaxWG = c.blkLanes == 512 ? w->sweepMaxWG[1] : (c.blkLanes == BLOCK_LANES ? w->sweepMaxWG[2] : w->sweepMaxWG[0]);
+		const bool useSweep = !useBlocks && !exactLarge && partitionFits && !plainIslands && !w->debugTrace && !w->kernelTimingLaunches &&
+			c.nBlocks <= sweepMaxWG;
+		d.blockSort = (useBlocks || useSweep) ? 1 : 0;
 		const bool useResident = usePersistent && (useBlocks || B2HIP_HAVE_VALIDATION_SOLVERS);
 		bool colorsOnDevice = false;
 		if (!exactLarge && (c.needRecolor || c.nUncolored > 0 || c.nCompact > 0))
@@ -1578,7 +1616,7 @@ static int phaseSolve(b2hip_world* w)
 			}
 			}
 		}
-		if (!useBlocks) LAUNCH(w, k_color_scan, 1, 1, d); // (segments by colour: the block solver sorts its rows itself)
+		if (!d.blockSort) LAUNCH(w, k_color_scan, 1, 1, d); // (segments by colour: the block solvers sort their rows themselves)
 		LAUNCH(w, k_color_fill, gC, 256, d);
 		if (hasHubs)
 		{
@@ -1600,11 +1638,12 @@ static int phaseSolve(b2hip_world* w)
 			if (useBlocks)
 			{
 				// (tags carry a 15-bit epoch: wipe the exchange rows when it comes round, like the mailbox slots below)
-				if (w->dfEpoch != 0 && (w->dfEpoch & 0x3fff) == 0)
+				if ((w->dfEpoch >> 14) != w->dfWipedAt)
 				{
 					HIP_TRY(hipMemsetAsync(w->b_cutv.p, 0, w->b_cutv.cap * sizeof(float4), w->stream));
 					HIP_TRY(hipMemsetAsync(w->b_posv.p, 0, w->b_posv.cap * sizeof(float4), w->stream));
 					HIP_TRY(hipMemsetAsync(w->dfInbox.p, 0, w->dfInbox.cap * sizeof(float4), w->stream));
+					w->dfWipedAt = w->dfEpoch >> 14;
 				}
 				if (c.blkLanes == 512) LAUNCH(w, k_solve_blocks<512>, c.nBlocks, 512, d, sp, w->gridBar.p, w->dfEpoch);
 				else if (c.blkLanes == 256) LAUNCH(w, k_solve_blocks<256>, c.nBlocks, 256, d, sp, w->gridBar.p, w->dfEpoch);
@@ -1659,10 +1698,31 @@ static int phaseSolve(b2hip_world* w)
 		// colours that own no constraint (the partition keeps two colour ranges apart) are not launched
 		const uint64_t colorMask = exactLarge ? ~0ull : ((uint64_t)w->h_dstate->c.colorMaskLo | ((uint64_t)w->h_dstate->c.colorMaskHi << 32));
 		auto colorUsed = [&](int col) { return col >= 64 || ((colorMask >> col) & 1ull) != 0; };
+		// every launch of k_blocks_sweep tags its hand-over rows with an epoch of its own (15 bits: the rows are wiped twice per round)
+		auto sweep = [&](int mode) -> int
+		{
+			if ((w->dfEpoch >> 14) != w->dfWipedAt)
+			{
+				HIP_TRY(hipMemsetAsync(w->b_cutv.p, 0, w->b_cutv.cap * sizeof(float4), w->stream));
+				HIP_TRY(hipMemsetAsync(w->b_posv.p, 0, w->b_posv.cap * sizeof(float4), w->stream));
+				w->dfWipedAt = w->dfEpoch >> 14;
+			}
+			if (c.blkLanes == 512) LAUNCH(w, k_blocks_sweep<512>, c.nBlocks, 512, d, sp, mode, w->gridBar.p, w->dfEpoch);
+			else if (c.blkLanes == 256) LAUNCH(w, k_blocks_sweep<256>, c.nBlocks, 256, d, sp, mode, w->gridBar.p, w->dfEpoch);
+			else if (c.blkLanes == BLOCK_LANES) LAUNCH(w, k_blocks_sweep<BLOCK_LANES>, c.nBlocks, BLOCK_LANES, d, sp, mode, w->gridBar.p, w->dfEpoch);
+			else return setError(B2HIP_ERR_INVALID, "block partition made for an unknown workgroup size");
+			w->dfEpoch += 1;
+			return 0;
+		};
+		if (useSweep) w->sweepSteps += 1;
 		if (sp.warmStarting)
 		{
-			for (int col = 0; col < nColors; ++col)
-				if (colorUsed(col)) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
+			if (useSweep) { rc = sweep(0); if (rc) return rc; }
+			else
+			{
+				for (int col = 0; col < nColors; ++col)
+					if (colorUsed(col)) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
+			}
 			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 0, 0);
 		}
 		TRACE("warmstart");
@@ -1670,6 +1730,8 @@ static int phaseSolve(b2hip_world* w)
 		for (int it = 0; it < sp.velIters; ++it)
 		{
 			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 1);
+			if (useSweep) { rc = sweep(1); if (rc) return rc; }
+			else
 			for (int col = 0; col < nColors; ++col)
 			{
 				if (!colorUsed(col)) continue;
@@ -1687,6 +1749,8 @@ static int phaseSolve(b2hip_world* w)
 		for (int it = 0; it < sp.posIters; ++it)
 		{
 			LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
+			if (useSweep) { rc = sweep(2); if (rc) return rc; }
+			else
 			for (int col = 0; col < nColors; ++col)
 			{
 				if (!colorUsed(col)) continue;
@@ -2075,6 +2139,8 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverLocal = getenv("B2HIP_SOLVER_SINGLE_XCD") != nullptr;
 	w->solverRows = getenv("B2HIP_SOLVER_ROWS") != nullptr; // polled body rows (k_solve_dataflow) instead of pushed mailboxes
 	w->solverMailbox = getenv("B2HIP_SOLVER_MAILBOX") != nullptr; // pushed hand-offs for every constraint (k_solve_mailbox) instead of k_solve_blocks
+	w->noSweepBlocks = getenv("B2HIP_NO_SWEEP_BLOCKS") != nullptr;
+	w->tracePartition = getenv("B2HIP_TRACE_PARTITION") != nullptr;
 	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
 	w->blockLanes = 0; // chosen per partition (see phaseSolve); B2HIP_BLOCK_LANES = 256 | 512 | 1024 forces one size
 	if (const char* e = getenv("B2HIP_BLOCK_LANES")) w->blockLanes = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0));
@@ -2090,6 +2156,16 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 		{
 			// one block per CU is all this sizing relies on (the occupancy query can be one too high, MI355X_MICROARCH.md)
 			w->blocksMaxWG = prop.multiProcessorCount - 8;
+			int s0 = 0, s1 = 0, s2 = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&s0, k_blocks_sweep<256>, 256, 0) == hipSuccess &&
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&s1, k_blocks_sweep<512>, 512, 0) == hipSuccess &&
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&s2, k_blocks_sweep<BLOCK_LANES>, BLOCK_LANES, 0) == hipSuccess)
+			{
+				// (the blocks of a launch wait for one another: all of them must be resident together)
+				w->sweepMaxWG[0] = std::max(1, s0 - 1) * w->blocksMaxWG;
+				w->sweepMaxWG[1] = std::max(1, s1 - 1) * w->blocksMaxWG;
+				w->sweepMaxWG[2] = std::max(1, s2 - 1) * w->blocksMaxWG;
+			}
 		}
 	}
 	w->dfSleep = 1;
@@ -2167,7 +2243,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_order.release(); w->orderBody.release(); w->bigRoots.release();
 	w->pre_o0.release(); w->pre_o1.release(); w->pre_oimp.release(); w->pre_o3.release(); w->preRecs.release();
 	w->postRecs.release(); w->filterList.release(); w->hostList.release();
-	w->b_blk1.release(); w->b_adopt.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release();
+	w->b_blk1.release(); w->b_adopt.release(); w->b_adoptStage.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release();
 	w->blkBodyStart.release(); w->blkBodies.release(); w->rowColor.release(); w->b_cutv.release();
 	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
 	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->scanFlags.release(); w->stateOut.release(); w->consts.release();
@@ -3597,9 +3673,9 @@ struct SnapHeader
 	uint32_t stateCount, cur;
 	int32_t nextNode, leafCount, lastContacts, newFixture;
 	float inv_dt0, cellSize;
-	int32_t eventsOn, reserved;
+	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bits 8..15 adoptSticky (what the next island build is told)
 };
-const uint32_t kSnapVersion = 3;
+const uint32_t kSnapVersion = 4;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
 
 struct SnapWriter
@@ -3669,6 +3745,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
 	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
 	h.eventsOn = w->eventsOn ? 1 : 0;
+	h.solverHints = (w->serialOrphansNext ? 1 : 0) | ((w->adoptSticky & 0xff) << 8);
 	SnapWriter o;
 	o.host(&h, sizeof(h));
 	o.host(&w->def, sizeof(w->def));
@@ -3884,6 +3961,9 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	w->nextNode = h.nextNode; w->leafCount = h.leafCount; w->lastContacts = h.lastContacts; w->newFixture = h.newFixture != 0;
 	w->inv_dt0 = h.inv_dt0;
 	w->eventsOn = h.eventsOn != 0;
+	w->serialOrphansNext = h.solverHints & 1;
+	w->adoptSticky = (h.solverHints >> 8) & 0xff;
+	w->adoptPasses = w->adoptSticky > 0;
 	rc = ensureCapacity(w, nC);
 	if (rc) return fail(rc);
 	if (nM > w->moveBuf.cap || nC > (size_t)w->dw.capContacts || (size_t)h.stateCount * 10 > w->h_stateCap) return fail(corrupt("counts exceed the buffers sized for them"));
@@ -4254,6 +4334,7 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->block_max_rows = w->last.blkMaxRows;
 	out->partitions = w->last.partitions;
 	out->block_solver_steps = w->blockSteps;
+	out->sweep_solver_steps = w->sweepSteps;
 	out->hub_constraints = w->last.nHubRows;
 	out->hub_fixpoint_rounds = w->last.hubRounds;
 	out->hub_serial_chunks = w->last.hubSerialChunks;
