@@ -18,6 +18,7 @@
 #define ROOT_NONE 0
 #define ROOT_SMALL 1
 #define ROOT_LARGE 2
+#define ROOT_FREE 4     // one body, no contact, no joint: stepped on the spot by k_island_classify (freeBodyStep)
 #define ROOT_REMOTE 3   // solved by another rank of a sharded world (b2d_kernels_shard.h): in an island, but not on our lists
 
 // Which rank solves the island rooted at `root` (the member of lowest ufPriority: the same body on every rank)
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.nBigIslands = 0;
 		S->c.nRemoteIslands = 0;
 		S->c.nSmallJointed = 0;
+		S->c.nFreeIslands = 0;
 		S->c.nSerialOrphans = 0;
 		S->c.hubRounds = 0;
 		S->c.hubSerialChunks = 0;
@@ -277,7 +279,51 @@ __global__ __launch_bounds__(256) void k_island_count(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
+// An island of ONE body that touches nothing and hangs on no joint - most bodies of a sparse world (97 % of the islands of
+// the 1 M-body field, the boxes in flight in the Tumbler): b2Island::Solve (b2Island.cpp:184-396) reduces to integrating
+// the body and its sleep timer, done here with the arithmetic k_solve_small performs for such a body (same helpers, same
+// order), instead of sending it through the island traversal, the chunk tables and a lane of the LDS solver.
+__device__ __forceinline__ void freeBodyStep(const DW& W, const StepParams& sp, int body)
+{
+	const uint32_t bflags = W.b_flags[body];
+	const float4 pos = W.b_pos[body], vel = W.b_vel[body], massv = W.b_mass[body];
+	float sleepTime = pos.w;
+	W.b_pos0[body] = make_float4(pos.x, pos.y, pos.z, 0.0f);
+	V2 v = v2(vel.x, vel.y);
+	float w = vel.z;
+	if ((bflags & BF_TYPE_MASK) == BT_DYNAMIC)
+	{
+		const float4 damp = W.b_damp[body], force = W.b_force[body];
+		b2dIntegrateVelocity(&v, &w, sp.dt, sp.gravity, damp.z, massv.x, massv.y, v2(force.x, force.y), force.z, damp.x, damp.y);
+	}
+	V2 c = v2(pos.x, pos.y);
+	float a = pos.z;
+	b2dIntegratePosition(&c, &a, &v, &w, sp.dt);
+	const Xf xf = b2dXfFromSweep(c, a, v2(massv.z, massv.w));
+	W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
+	uint32_t f = bflags | BF_ISLAND | BF_AWAKE;
+	if (sp.allowSleep)
+	{
+		const float linTolSqr = B2D_LINEAR_SLEEP_TOL * B2D_LINEAR_SLEEP_TOL;
+		const float angTolSqr = B2D_ANGULAR_SLEEP_TOL * B2D_ANGULAR_SLEEP_TOL;
+		if ((bflags & BF_AUTOSLEEP) == 0 || w * w > angTolSqr || b2dDot(v, v) > linTolSqr) sleepTime = 0.0f;
+		else sleepTime += sp.dt;
+		// (no constraint: the first position iteration finds the island solved - if there is one)
+		if (sleepTime >= B2D_TIME_TO_SLEEP && sp.posIters > 0)
+		{
+			f &= ~BF_AWAKE;
+			sleepTime = 0.0f;
+			v = v2(0, 0);
+			w = 0.0f;
+			W.b_force[body] = make_float4(0, 0, 0, 0);
+		}
+	}
+	W.b_flags[body] = f;
+	W.b_pos[body] = make_float4(c.x, c.y, a, sleepTime);
+	W.b_vel[body] = make_float4(v.x, v.y, w, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, StepParams sp)
 {
 	DState* S = W.st;
 	const int n = W.nBodies;
@@ -296,6 +342,14 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 				int w = nb > nc ? nb : nc;
 				if (w < 1) w = 1;
 				bool mine = true, big = false;
+				if (nb == 1 && nc == 0 && nj == 0 && forceLarge != 2 && !W.noFreeBodies)
+				{
+					// (in a sharded world every rank steps these itself: nothing to exchange)
+					freeBodyStep(W, sp, i);
+					W.rootIsland[i] = ROOT_FREE;
+					atomicAdd(&S->c.nFreeIslands, 1);
+				}
+				else
 				if (W.shardCount > 1)
 				{
 					// islands are dealt over the ranks: the big ones one by one (k_shard_big), the others by a hash of their root
@@ -307,7 +361,10 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge)
 					}
 					if (!big) mine = shardHashOwner(i, W.shardCount) == W.shardRank;
 				}
-				if (big)
+				if (W.rootIsland[i] == ROOT_FREE)
+				{
+				}
+				else if (big)
 				{
 					W.rootIsland[i] = ROOT_LARGE; // k_shard_big keeps it, or hands it to another rank
 				}
@@ -346,7 +403,7 @@ __global__ __launch_bounds__(256) void k_island_assign(DW W)
 		if ((f & BF_TYPE_MASK) == BT_STATIC || (f & BF_ACTIVE) == 0) continue;
 		int r = W.parent[i];
 		int tier = W.rootIsland[r];
-		if (tier == ROOT_NONE) continue;
+		if (tier == ROOT_NONE || tier == ROOT_FREE) continue;
 		// the DFS makes every visited body awake without touching its sleep timer (b2World.cpp:1243-1244)
 		f |= BF_ISLAND | BF_AWAKE;
 		if (tier == ROOT_LARGE)

@@ -154,6 +154,7 @@ struct Counters
 	int nBigIslands;     // islands with more than SHARD_BIG_BODIES bodies this step (sharded worlds only)
 	int nRemoteIslands;  // islands of this step that another rank solves
 	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
+	int nFreeIslands;    // one-body islands without contacts or joints, stepped by k_island_classify itself
 	int nSmallJointed;   // small islands of this step that hold joints (none: the lean k_solve_small runs)
 };
 
@@ -198,6 +199,7 @@ struct DW
 	int nBodies, nProxies, nJoints, nShapes;
 	int capContacts, capPairs, capMoves;
 	int serialOrphans;    // 1: constraints of bodies without a home block are swept in order with the hub constraints
+	int noFreeBodies;     // B2HIP_NO_FREE_BODIES=1: one-body islands go through the small-island solver like any other
 	int hubSerial;        // B2HIP_HUB_SERIAL=1: hub rows lane after lane only (validation of the fixed-point path)
 	int smallMaxW;        // islands up to this size take the exact-order in-LDS solver (default TINY_ISLAND_MAX_W = 128; B2HIP_SMALL_MAX_W up to 512)
 	int bigChunks;        // 1: always use 1024-lane chunks for the small-island solver (B2HIP_BIG_CHUNKS)

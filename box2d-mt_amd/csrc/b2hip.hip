@@ -767,6 +767,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	// ~300 levels x 12 sweeps = 3.9 ms in k_solve_small, ~0.1 ms as one block of k_solve_blocks. Islands up to 128 (bodies
 	// or contacts) are walked in the reference's order, bit-exact; B2HIP_SMALL_MAX_W (<= 512) moves the line.
 	d.smallMaxW = TINY_ISLAND_MAX_W;
+	d.noFreeBodies = getenv("B2HIP_NO_FREE_BODIES") && atoi(getenv("B2HIP_NO_FREE_BODIES")) ? 1 : 0;
 	d.hubSerial = getenv("B2HIP_HUB_SERIAL") && atoi(getenv("B2HIP_HUB_SERIAL")) ? 1 : 0;
 	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
 	d.capContacts = (int)cc;
@@ -1395,14 +1396,18 @@ static int phaseSolve(b2hip_world* w)
 	w->ktUsed = 0;
 	w->ktKind = 0;
 	const int forceLarge = w->forceLarge;
-	int rc = runSegment(w, w->segIslands, 2 + 16ull * (uint64_t)forceLarge, [w, forceLarge]() -> int
+	// (the step parameters are kernel arguments of k_island_classify - it steps the free bodies - so a captured segment is
+	// only replayed for the same ones)
+	uint64_t spHash = 1469598103934665603ull;
+	for (size_t k = 0; k < sizeof(StepParams); ++k) spHash = (spHash ^ ((const unsigned char*)&sp)[k]) * 1099511628211ull;
+	int rc = runSegment(w, w->segIslands, (2 + 16ull * (uint64_t)forceLarge) ^ (spHash << 8), [w, forceLarge, sp]() -> int
 	{
 		DW& d = w->dw;
 		LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_union, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge);
+		LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge, sp);
 		if (d.shardCount > 1) LAUNCH(w, k_shard_big, 1, 1024, d); // the big islands of a sharded world, dealt over the ranks
 		{
 			int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
@@ -1775,6 +1780,7 @@ static int phaseSolve(b2hip_world* w)
 		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[8], w->stream));
 	}
 	w->last.nSIslands = c.nSIslands;
+	w->last.nFreeIslands = c.nFreeIslands;
 	w->last.nSBodies = c.nSBodies;
 	w->last.nSContacts = c.nSContacts;
 	w->last.nChunks = c.nChunks;
@@ -4334,6 +4340,7 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->block_max_rows = w->last.blkMaxRows;
 	out->partitions = w->last.partitions;
 	out->block_solver_steps = w->blockSteps;
+	out->free_islands = w->last.nFreeIslands;
 	out->sweep_solver_steps = w->sweepSteps;
 	out->hub_constraints = w->last.nHubRows;
 	out->hub_fixpoint_rounds = w->last.hubRounds;

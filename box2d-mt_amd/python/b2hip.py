@@ -113,7 +113,7 @@ class Counters(C.Structure):
         "small_island_bodies", "small_island_contacts", "large_island_bodies", "large_island_contacts",
         "colors", "moved_proxies", "new_contacts", "destroyed_contacts", "solver_chunks",
         "pos_iterations_large", "overflow_flags", "toi_events", "toi_calls", "toi_pending_first_pass", "toi_serial_fallbacks",
-        "blocks", "cut_constraints", "block_max_rows", "partitions", "block_solver_steps", "sweep_solver_steps",
+        "blocks", "cut_constraints", "block_max_rows", "partitions", "block_solver_steps", "free_islands", "sweep_solver_steps",
         "hub_constraints", "hub_fixpoint_rounds", "hub_serial_chunks")]
 
 

@@ -306,6 +306,7 @@ typedef struct b2hip_counters
 	int32_t block_max_rows;          /* most constraints owned by one block in the last step */
 	int32_t partitions;              /* partitions made since the world was created */
 	int32_t block_solver_steps;      /* steps whose large islands were solved by the block solver */
+	int32_t free_islands;            /* one-body islands without contact or joint in the last step (stepped without the island solver) */
 	int32_t sweep_solver_steps;      /* steps whose (jointed / hub) large islands took the one-launch-per-sweep block kernel */
 	/* hub bodies (more contacts than can be coloured): their constraints are swept in order by one wave (k_large_hub) */
 	int32_t hub_constraints;         /* hub constraints in the last step */
