@@ -447,59 +447,67 @@ __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 {
 	DState* S = W.st;
-	if (createBlocked(W, S, smallPath)) return;
-	const int nNew = S->c.nNewContacts;
-	if (nNew == 0) return;
-	const int base = S->c.nContacts;
-	const int cap = W.capContacts;
-	const ContactArrays& C = W.ca[S->cur];
-	// 1024 new contacts per round: wave ballots rank the candidates inside a wave, 16 wave totals are summed by every lane
-	__shared__ int s_wave[2][16];
-	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	int count = S->c.nToiOrder;
-	int buf = 0;
-	for (int i0 = 0; i0 < nNew; i0 += 1024, buf ^= 1)
+	const bool blocked = createBlocked(W, S, smallPath);
+	const int nNew = blocked ? 0 : S->c.nNewContacts;
+	if (nNew > 0)
 	{
-		const int i = base + i0 + tid;
-		const bool flag = i0 + tid < nNew && i < cap && (C.flags[i] & CF_TOI_CANDIDATE) != 0;
-		const unsigned long long m = __ballot(flag);
-		if (lane == 0) s_wave[buf][wave] = __popcll(m);
+		const int base = S->c.nContacts;
+		const int cap = W.capContacts;
+		const ContactArrays& C = W.ca[S->cur];
+		// 1024 new contacts per round: wave ballots rank the candidates inside a wave, 16 wave totals are summed by every lane
+		__shared__ int s_wave[2][16];
+		const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+		int count = S->c.nToiOrder;
+		int buf = 0;
+		for (int i0 = 0; i0 < nNew; i0 += 1024, buf ^= 1)
+		{
+			const int i = base + i0 + tid;
+			const bool flag = i0 + tid < nNew && i < cap && (C.flags[i] & CF_TOI_CANDIDATE) != 0;
+			const unsigned long long m = __ballot(flag);
+			if (lane == 0) s_wave[buf][wave] = __popcll(m);
+			__syncthreads();
+			int before = 0, total = 0;
+			for (int k = 0; k < 16; ++k)
+			{
+				const int v = s_wave[buf][k];
+				if (k < wave) before += v;
+				total += v;
+			}
+			if (flag)
+			{
+				const int slot = count + before + __popcll(m & ((1ull << lane) - 1ull));
+				C.mgr[i] = slot;
+				W.toiPos2c[slot] = i;
+			}
+			count += total;
+			// (the other buffer is written in the next round: one barrier per round is enough)
+		}
+		// (every lane has read Counters::nToiOrder and nContacts before lane 0 changes them below)
 		__syncthreads();
-		int before = 0, total = 0;
-		for (int k = 0; k < 16; ++k)
-		{
-			const int v = s_wave[buf][k];
-			if (k < wave) before += v;
-			total += v;
-		}
-		if (flag)
-		{
-			const int slot = count + before + __popcll(m & ((1ull << lane) - 1ull));
-			C.mgr[i] = slot;
-			W.toiPos2c[slot] = i;
-		}
-		count += total;
-		// (the other buffer is written in the next round: one barrier per round is enough)
+		if (tid == 0) S->c.nToiOrder = count;
 	}
-	if (tid == 0) S->c.nToiOrder = count;
-}
-
-__global__ void k_create_commit(DW W, int smallPath)
-{
-	DState* S = W.st;
-	if (createBlocked(W, S, smallPath))
+	// the commit of the pair update (was a kernel of its own): the new contacts join the array, the move buffer is reset
+	// (b2BroadPhase::ResetBuffers) - or nothing happens and the host is told to grow the arrays
+	if (threadIdx.x == 0)
 	{
-		if (S->c.nContacts + S->c.nNewContacts > W.capContacts) atomicOr(&S->c.overflow, 1);
-		return;
+		if (blocked)
+		{
+			if (S->c.nContacts + S->c.nNewContacts > W.capContacts) atomicOr(&S->c.overflow, 1);
+		}
+		else
+		{
+			S->c.nContacts = S->c.nContacts + S->c.nNewContacts;
+			S->c.nMoves = 0;
+		}
 	}
-	S->c.nContacts = S->c.nContacts + S->c.nNewContacts;
-	S->c.nMoves = 0; // b2BroadPhase::ResetBuffers
 }
 
 // ---- end of step -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces)
+__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar)
 {
 	const int n = W.nBodies;
+	// (the solver's phase stamps travel with the counters: one copy to the host less)
+	if (bar != nullptr && blockIdx.x == 0 && threadIdx.x < 6) W.st->stamps[threadIdx.x] = bar[8 + threadIdx.x];
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		uint32_t f = W.b_flags[i];

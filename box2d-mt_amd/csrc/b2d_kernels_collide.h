@@ -488,14 +488,19 @@ __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 			if (m >= 0) W.toiPos2c[m] = j;
 		}
 	}
-}
-
-__global__ void k_compact_finish(DW W)
-{
-	DState* S = W.st;
-	if (S->c.nDestroy == 0) return;
-	S->c.nContacts = W.keepScan[S->c.nContacts];
-	S->cur = 1 - S->cur;
+	// the workgroup that finishes last switches the buffers (was a kernel of its own): everybody has read the count and
+	// the live half by then
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		__threadfence();
+		if (atomicAdd(&S->c.compactBlocksDone, 1) == (int)gridDim.x - 1)
+		{
+			S->c.compactBlocksDone = 0;
+			S->c.nContacts = W.keepScan[n];
+			S->cur = 1 - S->cur;
+		}
+	}
 }
 
 // ---- contact key hash set ---------------------------------------------------------------------

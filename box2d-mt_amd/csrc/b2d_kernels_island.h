@@ -529,6 +529,16 @@ __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 	const ContactArrays& C = W.ca[S->cur];
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nS; idx += gridDim.x * blockDim.x)
 	{
+		{
+			// chunk table of the solver (was a kernel of its own): chunkFirst[c] = first small island whose weight prefix falls
+			// into window c of chunkW
+			const int chunkW = S->c.chunkW;
+			const int c = W.si_wStart[idx] / chunkW;
+			if (idx == 0 || W.si_wStart[idx - 1] / chunkW != c) W.chunkFirst[c] = idx;
+			// The census counted windows up to the END of the last island; a window in which no island STARTS has no chunk
+			// (its chunkFirst entry would be stale). Only the trailing window can be empty (islands are at most one window wide).
+			if (idx == nS - 1) S->c.nChunks = c + 1;
+		}
 		const int root = W.si_root[idx];
 		const int seed = W.orderBody[W.rootSeed[root]];
 		const int bStart = W.si_bodyStart[idx];
@@ -645,25 +655,6 @@ __global__ __launch_bounds__(64) void k_joints_sort(DW W)
 			}
 			W.lj_list[b + 1] = v;
 		}
-	}
-}
-
-// chunkFirst[c] = first small island whose weight prefix falls into [128 c, 128 (c+1))
-__global__ __launch_bounds__(256) void k_island_chunks(DW W)
-{
-	DState* S = W.st;
-	const int nS = S->c.nSIslands;
-	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nS; idx += gridDim.x * blockDim.x)
-	{
-		const int chunkW = S->c.chunkW;
-		int c = W.si_wStart[idx] / chunkW;
-		if (idx == 0 || W.si_wStart[idx - 1] / chunkW != c)
-		{
-			W.chunkFirst[c] = idx;
-		}
-		// The census counted windows up to the END of the last island; a window in which no island STARTS has no chunk
-		// (its chunkFirst entry would be stale). Only the trailing window can be empty (islands are at most one window wide).
-		if (idx == nS - 1) S->c.nChunks = c + 1;
 	}
 }
 

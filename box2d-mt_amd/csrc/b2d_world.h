@@ -154,6 +154,7 @@ struct Counters
 	int nBigIslands;     // islands with more than SHARD_BIG_BODIES bodies this step (sharded worlds only)
 	int nRemoteIslands;  // islands of this step that another rank solves
 	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
+	int compactBlocksDone; // workgroups of k_compact_contacts that have finished (the last one switches the contact buffers)
 	int nFreeIslands;    // one-body islands without contacts or joints, stepped by k_island_classify itself
 	int nSmallJointed;   // small islands of this step that hold joints (none: the lean k_solve_small runs)
 };
@@ -182,7 +183,7 @@ struct DState
 {
 	Counters c;
 	int cur;             // which ContactArrays is live
-	int pad[6];
+	int stamps[6];       // phase stamps of the resident large-island solver (copied from its barrier words by k_end_step)
 };
 
 struct StepParams

@@ -264,6 +264,7 @@ struct b2hip_world
 	DevArray<float4> b_cutv;
 	int blocksMaxWG = 0;         // co-resident workgroups of k_solve_blocks on this device (0 = do not use it)
 	int sweepMaxWG[3] = { 0, 0, 0 }; // ... of k_blocks_sweep<256 / 512 / 1024>
+	int largeHintSteps = 120;    // > 0: the world has had large islands lately (k_color_check / k_block_census run with the island build)
 	int serialOrphansNext = 0;   // DW::serialOrphans of the next step
 	int adoptSticky = 0;
 	bool adoptPasses = false;    // the last step had orphan constraints (or made a partition): run k_block_adopt this step
@@ -279,7 +280,6 @@ struct b2hip_world
 	float* h_state;
 	size_t h_stateCap;
 	DState* h_dstate;
-	int* h_stamps = nullptr;     // pinned: phase stamps of the resident solver (gridBar[8..15])
 	bool blocksThisStep = false; // the large islands of this step went through k_solve_blocks
 
 	Counters last;        // counters of the last completed step
@@ -1150,14 +1150,13 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 	{
 		LAUNCH(w, k_edit_keepflags, gridFor(d.capContacts), 256, d);
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
-		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_compact_finish, 1, 1, d);
+		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d); // (its last workgroup switches the buffers)
 		LAUNCH(w, k_edit_finish, 1, 1, d);
 		if (betweenSteps)
 		{
 			// destroying a touching contact wakes its bodies (b2Contact::Destroy, b2Contact.cpp:105-111): the host rows are
 			// read again from the device (every edit made so far has been uploaded by the caller)
-			LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0);
+			LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0, (const int*)nullptr);
 			HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, w->bodies.size() * 10 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
 			w->stateCount = w->bodies.size();
 			++w->mirrorEpoch;
@@ -1259,8 +1258,7 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 	const int smallPath = largePath ? 0 : 1;
 	LAUNCH(w, k_create_contacts, gridFor(largePath ? d.capPairs : COUNT_RANK_MAX), 256, d, sortedKeys, sortedProxies, smallPath);
 	LAUNCH(w, k_create_finish, gridFor(d.nBodies), 256, d, smallPath);
-	LAUNCH(w, k_toi_order_create, 1, 1024, d, smallPath);
-	LAUNCH(w, k_create_commit, 1, 1, d, smallPath);
+	LAUNCH(w, k_toi_order_create, 1, 1024, d, smallPath); // (+ the commit of the update)
 	return 0;
 }
 
@@ -1332,8 +1330,7 @@ static int phaseCollide(b2hip_world* w)
 		LAUNCH(w, k_toi_order_destroy, 1, 256, d);
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_compact_finish, 1, 1, d);
+		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d); // (its last workgroup switches the buffers)
 		return 0;
 	});
 }
@@ -1400,7 +1397,8 @@ static int phaseSolve(b2hip_world* w)
 	// only replayed for the same ones)
 	uint64_t spHash = 1469598103934665603ull;
 	for (size_t k = 0; k < sizeof(StepParams); ++k) spHash = (spHash ^ ((const unsigned char*)&sp)[k]) * 1099511628211ull;
-	int rc = runSegment(w, w->segIslands, (2 + 16ull * (uint64_t)forceLarge) ^ (spHash << 8), [w, forceLarge, sp]() -> int
+	const bool largeHint = w->largeHintSteps > 0;
+	int rc = runSegment(w, w->segIslands, (2 + 16ull * (uint64_t)forceLarge + (largeHint ? 8ull : 0ull)) ^ (spHash << 8), [w, forceLarge, sp, largeHint]() -> int
 	{
 		DW& d = w->dw;
 		LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
@@ -1426,8 +1424,12 @@ static int phaseSolve(b2hip_world* w)
 		if (w->adoptPasses)
 			for (int stage = 0; stage < 3; ++stage) LAUNCH(w, k_block_adopt, gridFor(d.capContacts), 256, d, stage);
 		if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
-		LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_block_census, 1, 1024, d);
+		// (colour bookkeeping and block census only matter to large islands: skipped while the world has had none lately)
+		if (largeHint)
+		{
+			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_block_census, 1, 1024, d);
+		}
 		return 0;
 	});
 	if (rc) return rc;
@@ -1436,6 +1438,20 @@ static int phaseSolve(b2hip_world* w)
 	rc = readState(w);
 	if (rc) return rc;
 	Counters c = w->h_dstate->c;
+	if (c.nLIslands > 0)
+	{
+		if (!largeHint)
+		{
+			// the first large island after a while: run what was skipped, look again
+			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_block_census, 1, 1024, d);
+			rc = readState(w);
+			if (rc) return rc;
+			c = w->h_dstate->c;
+		}
+		w->largeHintSteps = 120;
+	}
+	else if (w->largeHintSteps > 0) w->largeHintSteps -= 1;
 	// (newcomers without a home block: from the next step on k_block_adopt hands blocks further, for a while)
 	if (c.nOrphanRows > 0) w->adoptSticky = 16; else if (w->adoptSticky > 0) w->adoptSticky -= 1;
 	w->adoptPasses = w->adoptSticky > 0;
@@ -1510,7 +1526,6 @@ static int phaseSolve(b2hip_world* w)
 			HIP_TRY(hipStreamWaitEvent(ss, w->evFork, 0));
 		}
 		LAUNCH_ON(w, ss, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
-		LAUNCH_ON(w, ss, k_island_chunks, gridFor(c.nSIslands), 256, d);
 		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[5], w->stream));
 		if (!exactLarge)
 		{
@@ -1978,13 +1993,10 @@ static int phaseToiSync(b2hip_world* w)
 static int downloadState(b2hip_world* w)
 {
 	DW& d = w->dw;
-	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, w->def.auto_clear_forces);
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, w->def.auto_clear_forces, (const int*)w->gridBar.p);
 	const size_t nb = w->bodies.size();
 	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipMemcpyAsync(w->h_dstate, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost, w->stream));
-	// phase stamps of the resident large-island solver (workgroup 0, 100 MHz ticks since its start): b2Profile's solveInit /
-	// solveVelocity / solvePosition split
-	HIP_TRY(hipMemcpyAsync(w->h_stamps, w->gridBar.p + 8, 8 * sizeof(int), hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	return 0;
 }
@@ -2192,13 +2204,11 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 			return setError(B2HIP_ERR_HIP, "hipEventCreate failed");
 		}
 	}
-	if (hipHostMalloc((void**)&w->h_dstate, sizeof(DState), hipHostMallocDefault) != hipSuccess ||
-		hipHostMalloc((void**)&w->h_stamps, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+	if (hipHostMalloc((void**)&w->h_dstate, sizeof(DState), hipHostMallocDefault) != hipSuccess)
 	{
 		b2hip_world_destroy(w);
 		return setError(B2HIP_ERR_HIP, "hipHostMalloc failed");
 	}
-	memset(w->h_stamps, 0, 8 * sizeof(int));
 	int rc = ensureCapacity(w, 0);
 	if (rc == 0 && hipStreamSynchronize(w->stream) != hipSuccess) rc = setError(B2HIP_ERR_HIP, "stream sync failed");
 	if (rc)
@@ -2255,7 +2265,6 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->scanFlags.release(); w->stateOut.release(); w->consts.release();
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
-	if (w->h_stamps) (void)hipHostFree(w->h_stamps);
 	for (int i = 0; i < 13; ++i)
 		if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
 	for (size_t i = 0; i < w->ktEvents.size(); ++i) (void)hipEventDestroy(w->ktEvents[i]);
@@ -3546,17 +3555,17 @@ static int stepEndImpl(b2hip_world* w)
 	p[9] = bp0 + bp1 + bpTop;                                                    // broadphase
 	if (w->toiEventValid) { (void)hipEventElapsedTime(&ms, w->ev[10], w->ev[12]); p[7] = ms; }  // solveTOI
 	w->solverMs = small + large;
-	if (w->blocksThisStep && w->h_stamps[4] > 0)
+	if (w->blocksThisStep && w->h_dstate->stamps[4] > 0)
 	{
 		// b2Profile::solveInit / solveVelocity / solvePosition (b2TimeStep.h:30-32) from the block solver's own phase stamps:
 		// [0] constraints initialised, [1] velocity iterations done, [2] positions integrated, [3] position iterations done,
 		// [4] written back (10 ns ticks); scaled to the event-measured span of the launch (stamps are workgroup 0's view)
 		const float tick = 1.0e-5f; // ms
-		const float total = tick * (float)w->h_stamps[4];
+		const float total = tick * (float)w->h_dstate->stamps[4];
 		const float scale = total > 0.0f ? large / total : 0.0f;
-		p[4] = scale * tick * (float)w->h_stamps[0];
-		p[5] = small + scale * tick * (float)(w->h_stamps[2] - w->h_stamps[0]);
-		p[6] = scale * tick * (float)(w->h_stamps[4] - w->h_stamps[2]);
+		p[4] = scale * tick * (float)w->h_dstate->stamps[0];
+		p[5] = small + scale * tick * (float)(w->h_dstate->stamps[2] - w->h_dstate->stamps[0]);
+		p[6] = scale * tick * (float)(w->h_dstate->stamps[4] - w->h_dstate->stamps[2]);
 	}
 	}
 	const int Ct = w->last.nSContacts + w->last.nLContacts;
@@ -3679,7 +3688,7 @@ struct SnapHeader
 	uint32_t stateCount, cur;
 	int32_t nextNode, leafCount, lastContacts, newFixture;
 	float inv_dt0, cellSize;
-	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bits 8..15 adoptSticky (what the next island build is told)
+	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bits 8..15 adoptSticky, 16..23 largeHintSteps (what the next island build is told)
 };
 const uint32_t kSnapVersion = 4;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
@@ -3751,7 +3760,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
 	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
 	h.eventsOn = w->eventsOn ? 1 : 0;
-	h.solverHints = (w->serialOrphansNext ? 1 : 0) | ((w->adoptSticky & 0xff) << 8);
+	h.solverHints = (w->serialOrphansNext ? 1 : 0) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16);
 	SnapWriter o;
 	o.host(&h, sizeof(h));
 	o.host(&w->def, sizeof(w->def));
@@ -3969,6 +3978,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	w->eventsOn = h.eventsOn != 0;
 	w->serialOrphansNext = h.solverHints & 1;
 	w->adoptSticky = (h.solverHints >> 8) & 0xff;
+	w->largeHintSteps = (h.solverHints >> 16) & 0xff;
 	w->adoptPasses = w->adoptSticky > 0;
 	rc = ensureCapacity(w, nC);
 	if (rc) return fail(rc);
