@@ -273,7 +273,7 @@ struct b2hip_world
 	int dfWipedAt = 0;           // dfEpoch >> 14 at the last wipe of the hand-over rows
 	int sweepSteps = 0;          // steps whose large islands went through k_blocks_sweep
 	int blockLanes = 0;          // forced workgroup size of k_solve_blocks (B2HIP_BLOCK_LANES), 0 = chosen per partition
-	bool noBlocks = false;       // B2HIP_NO_BLOCKS=1: keep the large islands on k_solve_mailbox
+	bool noBlocks = false;       // B2HIP_NO_BLOCKS=1: no block partition (large islands through the launch-per-colour kernels)
 	int blockSteps = 0;          // steps solved by k_solve_blocks (diagnostics)
 
 	// pinned host buffers
