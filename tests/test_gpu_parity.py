@@ -5,12 +5,13 @@ and (c) the reference build itself when oracle/_ref travelled with the snapshot.
 Bars (written here, stated in DESIGN.md):
   * integer / index work - contact counts, contact sets, feature ids, island membership, awake flags:
     bit-exact, always;
-  * floats, islands the solver walks in the reference's constraint order (all islands with
-    max(bodies, contacts) <= SMALL_ISLAND_MAX_W, b2d_world.h, and every island in exact-order mode): bit-exact
+  * floats, islands the solver walks in the reference's constraint order (islands with max(bodies, contacts) <= 128 and
+    <= 64 joints by default - B2HIP_SMALL_MAX_W widens the tier to 512 - and every island in exact-order mode): bit-exact
     (x, y, angle, velocities, manifolds and warm-start impulses compared as raw 32-bit patterns);
-  * floats, large islands solved by graph colouring (a different Gauss-Seidel order than the reference's
-    DFS order): 1e-4 of the scene scale after ONE step from identical inputs (tests/test_gpu_onestep.py, at
-    full config-2 size), and the looser trajectory tolerance below on a stated horizon.
+  * floats, larger islands solved in coloured order (a different Gauss-Seidel order than the reference's DFS order):
+    the bounds measured after ONE step from identical inputs at full config-2 size (tests/test_gpu_onestep.py), the
+    looser trajectory tolerance below on a stated horizon, and bit-identity between the solvers that share the colouring
+    (k_solve_blocks, k_blocks_sweep, launch per colour, the three round-1 solvers of the test build).
 """
 import os
 

@@ -6,7 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
 import b2harness as H
 DEFAULT = os.environ.get("MODE") == "default"  # coloured order for large islands: compare loosely, look for errors
-if not DEFAULT: os.environ["B2HIP_FORCE_LARGE"] = "2"
+# MODE=tier: default mode with the reference-order tier at its 512-row limit; a case whose islands all stayed inside the
+# tier (no large island in any step) must be bitwise equal to the oracle - the in-LDS solver with joints, free bodies ...
+TIER = os.environ.get("MODE") == "tier"
+if TIER: os.environ["B2HIP_SMALL_MAX_W"] = "512"
+elif not DEFAULT: os.environ["B2HIP_FORCE_LARGE"] = "2"
+import b2hip
+hipL = b2hip.lib() if TIER else None
 amd, orc = H.Harness(H.AMD_LIB), H.Harness(H.ORACLE_LIB)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -28,8 +34,13 @@ for k in range(cases):
     flags = (H.F_CONTINUOUS if rng.random() < 0.6 else 0) | (H.F_SLEEP if rng.random() < 0.8 else 0) | (H.F_WARM if rng.random() < 0.85 else 0)
     a, o = amd.world(scene, flags=flags, **kw), orc.world(scene, flags=flags, **kw)
     first = None
+    large_seen = 0
     for s in range(steps):
         a.step(1); o.step(1)
+        if TIER:
+            ctr = b2hip.Counters(); hipL.b2hip_get_counters(C.c_void_p(a.device_world()), C.byref(ctr))
+            large_seen = max(large_seen, ctr.large_islands)
+            if large_seen: break
         if DEFAULT:
             x, y = a.bodies(), o.bodies()
             if not np.isfinite(x).all() or a.contact_count == 0 and o.contact_count > 10: first = "error at %d" % s; break
@@ -40,6 +51,9 @@ for k in range(cases):
         x, y = a.bodies(), o.bodies()
         dev = float(np.abs(x[:, :2] - y[:, :2]).max())
         print("         default mode: max position deviation from the oracle after %d steps %.4f, contacts %d vs %d" % (steps, dev, a.contact_count, o.contact_count))
+        a.close(); o.close(); continue
+    if TIER and large_seen:
+        print("case %2d %-8s %s: left the tier (large island), not compared" % (k, name, kw), flush=True)
         a.close(); o.close(); continue
     if first is None:
         ia, fa, ma = a.contacts(); io, fo, mo = o.contacts()
