@@ -132,11 +132,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the Step() path has no CPU fallback")
+    # (B2_BENCH_SHARE_GPU=1 + B2_BENCH_BACKEND=gloo: every rank on GPU 0, collectives over gloo - how the N > 1 path is
+    # exercised on a one-GPU box; the driver's runs use one GPU per rank and RCCL)
+    if os.environ.get("B2_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("B2_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import b2harness as bh
     import b2hip
@@ -192,6 +200,12 @@ def main():
     elapsed = time.perf_counter() - t0
     per_step_ms = 1000.0 * np.diff(stamps)
     prof = w.profile()  # device phase times (HIP events) averaged over the timed steps only
+    if sharded is not None:
+        # (the sharded loop drives the C-ABI phases itself, past the drop-in b2World that keeps the average: last step's times)
+        ms13 = (C.c_float * 13)()
+        hipL.b2hip_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        if hipL.b2hip_get_profile(C.c_void_p(w.device_world()), ms13) == 0:
+            prof = dict(zip(bh.PROFILE_FIELDS, [float(x) for x in ms13]))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,10 +364,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Pyramid %d rows: %d bodies, %d contacts per GPU, settled for %d untimed steps (steady state), dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
-                                   % (args.rows, nbodies, contacts, SETTLE_STEPS, "off" if args.no_ccd else "on (reference default)"),
+            "config": {"workload": ("Pyramid %d rows: %d bodies, %d contacts per GPU" % (args.rows, nbodies, contacts) if world_size == 1 else
+                                    "%d pyramids of %d rows in ONE world (%d bodies, %d contacts in all; every rank holds it whole and solves one pyramid island)"
+                                    % (world_size, args.rows, nbodies, contacts)) +
+                                   ", settled for %d untimed steps (steady state), dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
+                                   % (SETTLE_STEPS, "off" if args.no_ccd else "on (reference default)"),
                        "settle_steps": SETTLE_STEPS,
-                       "bodies_total": nbodies * world_size, "parallelism": "one world on every rank, islands sharded by owner, one RCCL all-reduce per step" if world_size > 1 else "single GPU"},
+                       "bodies_total": nbodies, "parallelism": "one world on every rank, islands sharded by owner, one RCCL all-reduce per step" if world_size > 1 else "single GPU"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
         # the free-fall / first-impact transient the settle steps went through (rank 0), never part of `value`

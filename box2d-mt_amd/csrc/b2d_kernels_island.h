@@ -213,6 +213,8 @@ __global__ __launch_bounds__(256) void k_island_union(DW W)
 	{
 		const RevoluteJoint& jn = W.joints[j];
 		if (jn.type == B2D_JOINT_DEAD) continue;
+		// (a joint to an inactive body is skipped by the traversal: b2World.cpp:1303-1307)
+		if (((W.b_flags[jn.bodyA] & W.b_flags[jn.bodyB]) & BF_ACTIVE) == 0) continue;
 		bool nsA = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC;
 		bool nsB = (W.b_flags[jn.bodyB] & BF_TYPE_MASK) != BT_STATIC;
 		if (nsA && nsB) ufUnion(W.parent, jn.bodyA, jn.bodyB);
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(256) void k_island_count(DW W)
 	{
 		const RevoluteJoint& jn = W.joints[j];
 		if (jn.type == B2D_JOINT_DEAD) continue;
+		if (((W.b_flags[jn.bodyA] & W.b_flags[jn.bodyB]) & BF_ACTIVE) == 0) continue;
 		int b = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC ? jn.bodyA : jn.bodyB;
 		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
 		atomicAdd(&W.rootJoints[W.parent[b]], 1);
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(256) void k_joints_fill(DW W)
 	{
 		const RevoluteJoint& jn = W.joints[j];
 		if (jn.type == B2D_JOINT_DEAD) continue;
+		if (((W.b_flags[jn.bodyA] & W.b_flags[jn.bodyB]) & BF_ACTIVE) == 0) continue;
 		int b = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC ? jn.bodyA : jn.bodyB;
 		if ((W.b_flags[b] & BF_TYPE_MASK) == BT_STATIC) continue;
 		const int root = W.parent[b];

@@ -121,6 +121,7 @@ struct HostFixture
 	int proxyKey;
 	float fat[4];
 	bool dead;        // destroyed (b2Body::DestroyFixture / DestroyBody): the id stays, the proxy is gone
+	bool noProxy;     // the body is inactive (b2Body::SetActive(false)): the fixture lives on without a broad-phase proxy
 };
 
 struct GraphSeg
@@ -981,7 +982,7 @@ static int flushEdits(b2hip_world* w)
 		std::vector<int> head(w->bodies.size(), -1), next(np, -1);
 		for (size_t k = 0; k < np; ++k)
 		{
-			if (w->fixtures[k].dead) continue;
+			if (w->fixtures[k].dead || w->fixtures[k].noProxy) continue;
 			const int b = w->fixtures[k].body;
 			next[k] = head[b];
 			head[b] = (int)k;
@@ -1002,7 +1003,7 @@ static int flushEdits(b2hip_world* w)
 		{
 			const HostFixture& f = w->fixtures[first + k];
 			fat[k] = make_float4(f.fat[0], f.fat[1], f.fat[2], f.fat[3]);
-			body[k] = f.dead ? -1 : f.body;
+			body[k] = (f.dead || f.noProxy) ? -1 : f.body;
 			shape[k] = f.shape;
 			key[k] = f.proxyKey;
 			f0[k] = (uint32_t)f.categoryBits | ((uint32_t)f.maskBits << 16);
@@ -1020,7 +1021,7 @@ static int flushEdits(b2hip_world* w)
 		std::vector<int> head(w->bodies.size(), -1), next(np, -1);
 		for (size_t k = 0; k < np; ++k)
 		{
-			if (w->fixtures[k].dead) continue;
+			if (w->fixtures[k].dead || w->fixtures[k].noProxy) continue;
 			const int b = w->fixtures[k].body;
 			next[k] = head[b];
 			head[b] = (int)k;
@@ -1037,7 +1038,7 @@ static int flushEdits(b2hip_world* w)
 		for (size_t k = 0; k < np; ++k)
 		{
 			const HostFixture& f = w->fixtures[k];
-			if (f.dead || w->bodies[f.body].type == B2HIP_STATIC_BODY) continue;
+			if (f.dead || f.noProxy || w->bodies[f.body].type == B2HIP_STATIC_BODY) continue;
 			ext.push_back(std::max(f.fat[2] - f.fat[0], f.fat[3] - f.fat[1]));
 		}
 		float cell = 1.0f;
@@ -1068,13 +1069,15 @@ static int flushEdits(b2hip_world* w)
 			if ((size_t)id >= w->upFixtures) continue; // (a new fixture: uploaded whole above)
 			const HostFixture& f = w->fixtures[id];
 			const float4 fat = make_float4(f.fat[0], f.fat[1], f.fat[2], f.fat[3]);
-			const int body = f.dead ? -1 : f.body;
+			const int body = (f.dead || f.noProxy) ? -1 : f.body;
+			const int key = f.proxyKey;
 			const uint32_t f0 = (uint32_t)f.categoryBits | ((uint32_t)f.maskBits << 16);
 			const int f1 = ((int)(uint16_t)f.groupIndex) | (f.isSensor ? PF_SENSOR : 0) | (f.thick ? PF_THICK : 0);
 			// (the fat AABB of an uploaded fixture is device state: the host copy is only current if SetTransform wrote it)
 			if (std::find(w->fatEdits.begin(), w->fatEdits.end(), id) != w->fatEdits.end())
 				HIP_TRY(hipMemcpy(w->p_fat.p + id, &fat, sizeof(float4), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(w->p_body.p + id, &body, sizeof(int), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(w->p_key.p + id, &key, sizeof(int), hipMemcpyHostToDevice)); // (a re-activated body's proxies have new ids)
 			HIP_TRY(hipMemcpy(w->p_filter0.p + id, &f0, sizeof(uint32_t), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(w->p_filter1.p + id, &f1, sizeof(int), hipMemcpyHostToDevice));
 		}
@@ -2401,12 +2404,22 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def,
 	f.fat[1] = aabb.lo.y - B2D_AABB_EXTENSION;
 	f.fat[2] = aabb.hi.x + B2D_AABB_EXTENSION;
 	f.fat[3] = aabb.hi.y + B2D_AABB_EXTENSION;
-	f.proxyKey = allocProxyKey(w);
-	if (f.proxyKey < 0) return setError(B2HIP_ERR_UNSUPPORTED, "proxy id reuse after the broad-phase tree was emptied is not modelled");
+	const bool bodyActive = (b.flags & BF_ACTIVE) != 0;
+	if (bodyActive)
+	{
+		f.proxyKey = allocProxyKey(w);
+		if (f.proxyKey < 0) return setError(B2HIP_ERR_UNSUPPORTED, "proxy id reuse after the broad-phase tree was emptied is not modelled");
+	}
+	else
+	{
+		// (b2Body.cpp:199-203: an inactive body's fixtures get their proxies when it is activated)
+		f.proxyKey = -1;
+		f.noProxy = true;
+	}
 	const int id = (int)w->fixtures.size();
 	w->fixtures.push_back(f);
 	b.fixtures.push_back(id);
-	w->pendingMoves.push_back(id);
+	if (bodyActive) w->pendingMoves.push_back(id);
 	if (f.density > 0.0f)
 	{
 		resetMassData(w, b);
@@ -3002,6 +3015,120 @@ int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle)
 		w->fatEdits.push_back(id);
 		if ((size_t)id < w->upFixtures || std::find(w->pendingMoves.begin(), w->pendingMoves.end(), id) == w->pendingMoves.end()) w->pendingMoves.push_back(id);
 		w->newFixture = w->newFixture; // (moves alone do not ask for the top-of-step pair update: the end-of-step one takes them)
+	}
+	return B2HIP_OK;
+}
+
+int b2hip_set_active(b2hip_world* w, int body, int active)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_active")) return rc;
+	if (((w->bodies[body].flags & BF_ACTIVE) != 0) == (active != 0)) return B2HIP_OK;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (active)
+	{
+		b.flags |= BF_ACTIVE;
+		// b2Fixture::CreateProxies for every fixture, newest first: fat AABB at the body's transform, a fresh proxy id, a buffered move
+		for (int k = (int)b.fixtures.size() - 1; k >= 0; --k)
+		{
+			const int id = b.fixtures[k];
+			HostFixture& f = w->fixtures[id];
+			const AABB aabb = b2dShapeAABB(&w->shapes[f.shape], hostXf(b));
+			f.fat[0] = aabb.lo.x - B2D_AABB_EXTENSION;
+			f.fat[1] = aabb.lo.y - B2D_AABB_EXTENSION;
+			f.fat[2] = aabb.hi.x + B2D_AABB_EXTENSION;
+			f.fat[3] = aabb.hi.y + B2D_AABB_EXTENSION;
+			f.proxyKey = allocProxyKey(w);
+			if (f.proxyKey < 0) return setError(B2HIP_ERR_UNSUPPORTED, "proxy id reuse after the broad-phase tree was emptied is not modelled");
+			f.noProxy = false;
+			w->proxyEdits.push_back(id);
+			w->fatEdits.push_back(id);
+			w->pendingMoves.push_back(id);
+		}
+		w->proxyListsStale = true;
+		return B2HIP_OK;
+	}
+	b.flags &= ~BF_ACTIVE;
+	// b2Fixture::DestroyProxies, newest fixture first, then the body's contacts in its contact-list order
+	for (int k = (int)b.fixtures.size() - 1; k >= 0; --k)
+	{
+		const int id = b.fixtures[k];
+		HostFixture& f = w->fixtures[id];
+		if (f.noProxy) continue;
+		freeProxyKey(w, f.proxyKey);
+		f.proxyKey = -1;
+		f.noProxy = true;
+		w->proxyEdits.push_back(id);
+		w->pendingMoves.erase(std::remove(w->pendingMoves.begin(), w->pendingMoves.end(), id), w->pendingMoves.end());
+	}
+	w->proxyListsStale = true;
+	queueOp(w, EDIT_DESTROY_BODY, body);
+	return B2HIP_OK;
+}
+
+int b2hip_set_type(b2hip_world* w, int body, int type)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_type")) return rc;
+	if (type < B2HIP_STATIC_BODY || type > B2HIP_DYNAMIC_BODY) return setError(B2HIP_ERR_INVALID, "b2hip_set_type: bad body type");
+	if (w->bodies[body].type == type) return B2HIP_OK;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (b.type == B2HIP_STATIC_BODY)
+	{
+		// out of m_staticBodies, to the end of m_nonStaticBodies (b2Body.cpp:131-140)
+		b.worldIndex = (int)w->nonStatic.size();
+		w->nonStatic.push_back(body);
+		w->orderDirty = true;
+	}
+	b.type = type;
+	resetMassData(w, b);
+	b.resetSweep = 1; // (the mass data moved the sweep origin with the centre)
+	if (type == B2HIP_STATIC_BODY)
+	{
+		b.vx = b.vy = b.w = 0.0f;
+		b.a0 = b.a;
+		b.c0x = b.cx;
+		b.c0y = b.cy;
+		b.resetSweep = 1;
+		// b2Body::SynchronizeFixtures with xf1 == xf (the sweep origin was just reset): MoveProxy with zero displacement
+		for (int k = (int)b.fixtures.size() - 1; k >= 0; --k)
+		{
+			const int id = b.fixtures[k];
+			HostFixture& f = w->fixtures[id];
+			if (f.noProxy) continue;
+			float fat[4];
+			if (int rc = currentFat(w, id, fat)) return rc;
+			const AABB aabb = b2dShapeAABB(&w->shapes[f.shape], hostXf(b));
+			if (fat[0] <= aabb.lo.x && fat[1] <= aabb.lo.y && aabb.hi.x <= fat[2] && aabb.hi.y <= fat[3])
+			{
+				memcpy(f.fat, fat, 16);
+				continue;
+			}
+			f.fat[0] = aabb.lo.x - B2D_AABB_EXTENSION;
+			f.fat[1] = aabb.lo.y - B2D_AABB_EXTENSION;
+			f.fat[2] = aabb.hi.x + B2D_AABB_EXTENSION;
+			f.fat[3] = aabb.hi.y + B2D_AABB_EXTENSION;
+			w->proxyEdits.push_back(id);
+			w->fatEdits.push_back(id);
+			w->pendingMoves.push_back(id);
+		}
+		// b2RemoveAndSwapBack on m_nonStaticBodies (b2Body.cpp:154-160)
+		const int slot = b.worldIndex, last = w->nonStatic.back();
+		w->nonStatic[(size_t)slot] = last;
+		w->bodies[(size_t)last].worldIndex = slot;
+		w->nonStatic.pop_back();
+		b.worldIndex = -1;
+		w->orderDirty = true;
+	}
+	b.flags |= BF_AWAKE;
+	b.sleepTime = 0.0f;
+	b.fx = b.fy = b.torque = 0.0f;
+	// every contact of the body goes, in its contact-list order; TouchProxy on every proxy, newest fixture first
+	queueOp(w, EDIT_DESTROY_BODY, body);
+	for (int k = (int)b.fixtures.size() - 1; k >= 0; --k)
+	{
+		const int id = b.fixtures[k];
+		if (!w->fixtures[id].noProxy) w->pendingMoves.push_back(id);
 	}
 	return B2HIP_OK;
 }

@@ -84,6 +84,8 @@ public:
 	void SetTransform(const b2Vec2& position, float32 angle);
 	void SetAwake(bool flag);
 	void SetBullet(bool flag);
+	void SetActive(bool flag);
+	void SetType(b2BodyType type);
 	/// b2Body.cpp:238-308; the fixture pointer is dead afterwards
 	void DestroyFixture(b2Fixture* fixture);
 	/// The body's contact edges, newest contact first (b2Body.h:431-436); valid until the next Step or edit.

@@ -9,6 +9,7 @@
 #define B2_WORLD_H
 
 #include <atomic>
+#include <utility>
 #include <mutex>
 #include "Box2D/Common/b2Math.h"
 #include "Box2D/Common/b2BlockAllocator.h"
@@ -132,6 +133,7 @@ private:
 	void TouchState(int32 id) const;
 	std::vector<b2Contact> m_contactViews;
 	bool m_contactsValid;
+	std::vector<std::pair<int32, int32> > m_endedEarly; // fixture pairs whose EndContact was delivered by an edit between steps
 	std::vector<b2ContactEdge> m_edgeViews; // b2Body::GetContactList: edges of one body, rebuilt per call
 	void DestroyFixtureView(b2Fixture* f);
 	void EndContactsOf(b2Body* body, b2Fixture* fixture);

@@ -181,7 +181,10 @@ void b2World::EndContactsOf(b2Body* body, b2Fixture* fixture)
 		if (!c->m_touching) continue;
 		const bool mine = fixture ? (c->m_fixtureA == fixture || c->m_fixtureB == fixture)
 		                          : (c->m_fixtureA->GetBody() == body || c->m_fixtureB->GetBody() == body);
-		if (mine && m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
+		if (!mine) continue;
+		// (the step's own event list will name this contact's end as well: remembered, so that it is delivered once)
+		m_endedEarly.push_back(std::make_pair(c->m_fixtureA->m_id, c->m_fixtureB->m_id));
+		if (m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
 	}
 }
 
@@ -595,7 +598,11 @@ void b2World::DeliverContactEvents()
 {
 	if (!m_hip || !m_contactListener) return;
 	int count = b2hip_get_contact_events(m_hip, 0, nullptr);
-	if (count <= 0) return;
+	if (count <= 0)
+	{
+		m_endedEarly.clear();
+		return;
+	}
 	std::vector<b2hip_contact_event> ev(count);
 	count = b2hip_get_contact_events(m_hip, count, ev.data());
 	(void)GetContactList(); // views of this step's contacts, newest first
@@ -605,6 +612,21 @@ void b2World::DeliverContactEvents()
 		const b2hip_contact_event& e = ev[i];
 		// (the end of a contact that went with its body or fixture was delivered by DestroyBody / DestroyFixture itself)
 		if (e.fixture_a >= (int)m_fixtures.size() || e.fixture_b >= (int)m_fixtures.size() || !m_fixtures[e.fixture_a] || !m_fixtures[e.fixture_b]) continue;
+		if (e.kind != 0)
+		{
+			// ... and so was the end of a contact that went when its body was switched off or changed type
+			bool early = false;
+			for (size_t k = 0; k < m_endedEarly.size() && !early; ++k)
+			{
+				if ((m_endedEarly[k].first == e.fixture_a && m_endedEarly[k].second == e.fixture_b) ||
+					(m_endedEarly[k].first == e.fixture_b && m_endedEarly[k].second == e.fixture_a))
+				{
+					m_endedEarly.erase(m_endedEarly.begin() + (long)k);
+					early = true;
+				}
+			}
+			if (early) continue;
+		}
 		b2Contact gone; // the view of a contact that no longer exists (its end event)
 		b2Contact* c = nullptr;
 		if (e.contact_index >= 0 && e.contact_index < n) c = &m_contactViews[n - 1 - e.contact_index];
@@ -629,6 +651,7 @@ void b2World::DeliverContactEvents()
 			if (m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
 		}
 	}
+	m_endedEarly.clear();
 }
 
 const std::vector<b2AABB>& b2World::FatAABBs()
@@ -656,7 +679,8 @@ void b2World::QueryAABB(b2QueryCallback* callback, const b2AABB& aabb)
 	const std::vector<b2AABB>& fat = FatAABBs();
 	for (size_t i = 0; i < fat.size(); ++i)
 	{
-		if (m_fixtures[i] == nullptr || !b2TestOverlap(fat[i], aabb)) continue;
+		// (an inactive body has no proxies in the reference's tree)
+		if (m_fixtures[i] == nullptr || !m_fixtures[i]->GetBody()->IsActive() || !b2TestOverlap(fat[i], aabb)) continue;
 		if (!callback->ReportFixture(m_fixtures[i])) return;
 	}
 }
@@ -678,7 +702,7 @@ void b2World::RayCast(b2RayCastCallback* callback, const b2Vec2& point1, const b
 	for (size_t i = 0; i < fat.size(); ++i)
 	{
 		b2Fixture* fixture = m_fixtures[i];
-		if (fixture == nullptr || !b2TestOverlap(fat[i], segment)) continue;
+		if (fixture == nullptr || !fixture->GetBody()->IsActive() || !b2TestOverlap(fat[i], segment)) continue;
 		const b2Vec2 c = fat[i].GetCenter(), h = fat[i].GetExtents();
 		if (b2Abs(b2Dot(v, point1 - c)) - b2Dot(abs_v, h) > 0.0f) continue;
 		b2RayCastInput input;
@@ -1027,6 +1051,31 @@ void b2Body::SetBullet(bool flag)
 	m_bullet = flag;
 	b2hip_set_bullet(m_world->m_hip, m_id, flag ? 1 : 0);
 	m_world->m_contactsValid = false;
+}
+
+// b2Body::SetActive (b2Body.cpp:496-544): the contacts of a body that is switched off end first (the listener hears it),
+// as when the body is destroyed
+void b2Body::SetActive(bool flag)
+{
+	if (m_world->IsLocked() || flag == m_active) return;
+	if (!flag) m_world->EndContactsOf(this, nullptr);
+	m_active = flag;
+	if (b2hip_set_active(m_world->m_hip, m_id, flag ? 1 : 0) != B2HIP_OK) fprintf(stderr, "b2Body::SetActive: %s\n", b2hip_last_error());
+	m_world->m_statesValid = false;
+	m_world->m_contactsValid = false;
+	m_world->m_fatValid = false;
+}
+
+// b2Body::SetType (b2Body.cpp:118-188)
+void b2Body::SetType(b2BodyType type)
+{
+	if (m_world->IsLocked() || type == m_type) return;
+	m_world->EndContactsOf(this, nullptr);
+	m_type = type;
+	if (b2hip_set_type(m_world->m_hip, m_id, (int)type) != B2HIP_OK) fprintf(stderr, "b2Body::SetType: %s\n", b2hip_last_error());
+	m_world->m_statesValid = false;
+	m_world->m_contactsValid = false;
+	m_world->m_fatValid = false;
 }
 
 void b2Body::DestroyFixture(b2Fixture* fixture)

@@ -368,6 +368,15 @@ int b2hip_destroy_fixture(b2hip_world* w, int fixture);
 int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle);
 /* b2Body::SetAwake (b2Body.h:690-718): true restarts the sleep timer; false also zeroes velocities and forces */
 int b2hip_set_awake(b2hip_world* w, int body, int awake);
+/* b2Body::SetActive (b2Body.cpp:496-544): an inactive body keeps its fixtures but has no broad-phase proxies and no contacts
+ * (they are destroyed in its contact-list order) and is skipped by the island build, joints to it included; activating it
+ * creates the proxies again, newest fixture first, with fresh proxy ids - contacts follow with the next pair update. */
+int b2hip_set_active(b2hip_world* w, int body, int active);
+/* b2Body::SetType (b2Body.cpp:118-188): type = B2HIP_STATIC_BODY / KINEMATIC / DYNAMIC. Mass data are recomputed, a body
+ * that becomes static stops and its proxies are synchronised, the body moves between the world's static and non-static
+ * lists (the island seed order follows), wakes, loses its forces and ALL its contacts; its proxies are touched so that
+ * the next pair update forms the contacts its new type allows. */
+int b2hip_set_type(b2hip_world* w, int body, int type);
 /* b2Body::SetBullet (b2Body.cpp:575-601) + b2ContactManager::RecalculateToiCandidacy (b2ContactManager.cpp:566-640) */
 int b2hip_set_bullet(b2hip_world* w, int body, int bullet);
 /* b2Body::ApplyLinearImpulse / ApplyLinearImpulseToCenter (point = world centre) / ApplyAngularImpulse (b2Body.h:885-950) */

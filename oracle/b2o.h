@@ -136,6 +136,8 @@ void b2o_destroy_body(b2o_world* w, int body);
 void b2o_destroy_fixture(b2o_world* w, int fixture);
 void b2o_set_transform(b2o_world* w, int body, float x, float y, float angle);
 void b2o_set_awake(b2o_world* w, int body, int awake);
+void b2o_set_active(b2o_world* w, int body, int active);   /* b2Body::SetActive (b2Body.cpp:496-544) */
+void b2o_set_type(b2o_world* w, int body, int type);       /* b2Body::SetType (b2Body.cpp:118-188); 0 static, 1 kinematic, 2 dynamic */
 void b2o_set_bullet(b2o_world* w, int body, int bullet);
 void b2o_apply_linear_impulse(b2o_world* w, int body, float ix, float iy, float px, float py, int to_center, int wake);
 void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake);

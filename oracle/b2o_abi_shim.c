@@ -234,6 +234,8 @@ int b2hip_destroy_body(b2hip_world* w, int body) { b2o_destroy_body(w->o, body);
 int b2hip_destroy_fixture(b2hip_world* w, int fixture) { b2o_destroy_fixture(w->o, fixture); return 0; }
 int b2hip_set_transform(b2hip_world* w, int body, float x, float y, float angle) { b2o_set_transform(w->o, body, x, y, angle); return 0; }
 int b2hip_set_awake(b2hip_world* w, int body, int awake) { b2o_set_awake(w->o, body, awake); return 0; }
+int b2hip_set_active(b2hip_world* w, int body, int active) { b2o_set_active(w->o, body, active); return 0; }
+int b2hip_set_type(b2hip_world* w, int body, int type) { b2o_set_type(w->o, body, type); return 0; }
 int b2hip_set_bullet(b2hip_world* w, int body, int bullet) { b2o_set_bullet(w->o, body, bullet); return 0; }
 int b2hip_apply_linear_impulse(b2hip_world* w, int body, float ix, float iy, float px, float py, int wake)
 {

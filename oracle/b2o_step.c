@@ -412,12 +412,22 @@ int b2o_create_fixture(b2o_world* w, int body, const b2o_fixture_def* d, const b
 	f->fat[1] = aabb[1] - B2O_AABB_EXTENSION;
 	f->fat[2] = aabb[2] + B2O_AABB_EXTENSION;
 	f->fat[3] = aabb[3] + B2O_AABB_EXTENSION;
-	f->proxyId = alloc_proxy_id(w);
 	f->nextInBody = b->fixtureHead;
 	int id = w->nFixtures++;
 	b->fixtureHead = id;
-	GROW(w->moves, w->capMoves, w->nMoves + 1, int);
-	w->moves[w->nMoves++] = id;
+	if (b->flags & BF_ACTIVE)
+	{
+		/* (b2Body.cpp:199-203: an inactive body's fixtures get their proxies when it is activated) */
+		f->proxyId = alloc_proxy_id(w);
+		GROW(w->moves, w->capMoves, w->nMoves + 1, int);
+		w->moves[w->nMoves++] = id;
+	}
+	else
+	{
+		f->proxyId = -1;
+		f->fat[0] = f->fat[1] = 1e30f;
+		f->fat[2] = f->fat[3] = -1e30f;
+	}
 	if (f->density > 0.0f) reset_mass(w, b);
 	w->newFixture = 1;
 	return id;
@@ -1149,6 +1159,7 @@ static void sync_body_fixtures(b2o_world* w, body_t* b)
 	for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
 	{
 		fixture_t* fx = &w->fixtures[f];
+		if (fx->proxyId < 0) continue; /* (an inactive body's fixtures have no proxies) */
 		float a1[4], a2[4], aabb[4];
 		shape_aabb(&fx->shape, xf1, a1);
 		shape_aabb(&fx->shape, b->xf, a2);
@@ -2720,15 +2731,23 @@ static void buffer_move(b2o_world* w, int fixture)
 	w->moves[w->nMoves++] = fixture;
 }
 
-/* b2Fixture::DestroyProxies + the bookkeeping of a fixture that is gone */
-static void drop_fixture(b2o_world* w, int fixture)
+/* b2Fixture::DestroyProxies (b2Fixture.cpp:143-157) */
+static void release_proxy(b2o_world* w, int fixture)
 {
 	fixture_t* f = &w->fixtures[fixture];
+	if (f->proxyId < 0) return;
 	free_proxy_id(w, f->proxyId);
+	f->proxyId = -1;
 	unbuffer_move(w, fixture);
-	f->dead = 1;
 	f->fat[0] = f->fat[1] = 1e30f; /* overlaps nothing */
 	f->fat[2] = f->fat[3] = -1e30f;
+}
+
+/* ... + the bookkeeping of a fixture that is gone */
+static void drop_fixture(b2o_world* w, int fixture)
+{
+	release_proxy(w, fixture);
+	w->fixtures[fixture].dead = 1;
 }
 
 void b2o_destroy_fixture(b2o_world* w, int fixture)
@@ -2810,6 +2829,7 @@ void b2o_set_transform(b2o_world* w, int body, float x, float y, float angle)
 	for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
 	{
 		fixture_t* fx = &w->fixtures[f];
+		if (fx->proxyId < 0) continue;
 		float aabb[4];
 		shape_aabb(&fx->shape, b->xf, aabb);
 		if (fx->fat[0] <= aabb[0] && fx->fat[1] <= aabb[1] && aabb[2] <= fx->fat[2] && aabb[3] <= fx->fat[3]) continue;
@@ -2819,6 +2839,81 @@ void b2o_set_transform(b2o_world* w, int body, float x, float y, float angle)
 		fx->fat[3] = aabb[3] + B2O_AABB_EXTENSION;
 		buffer_move(w, f);
 	}
+}
+
+/* b2Body::SetActive (b2Body.cpp:496-544) */
+void b2o_set_active(b2o_world* w, int body, int active)
+{
+	body_t* b = &w->bodies[body];
+	if (b->dead || ((b->flags & BF_ACTIVE) != 0) == (active != 0)) return;
+	if (active)
+	{
+		b->flags |= BF_ACTIVE;
+		/* proxies for all fixtures, newest first (b2Fixture::CreateProxies: fat AABB at the body's transform, the move is
+		 * buffered); contacts appear with the next pair update */
+		for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
+		{
+			fixture_t* fx = &w->fixtures[f];
+			float aabb[4];
+			shape_aabb(&fx->shape, b->xf, aabb);
+			fx->fat[0] = aabb[0] - B2O_AABB_EXTENSION;
+			fx->fat[1] = aabb[1] - B2O_AABB_EXTENSION;
+			fx->fat[2] = aabb[2] + B2O_AABB_EXTENSION;
+			fx->fat[3] = aabb[3] + B2O_AABB_EXTENSION;
+			fx->proxyId = alloc_proxy_id(w);
+			buffer_move(w, f);
+		}
+		return;
+	}
+	b->flags &= ~BF_ACTIVE;
+	for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody) release_proxy(w, f);
+	for (int e = b->contactHead; e >= 0; )
+	{
+		int next = w->contacts[e >> 1].next[e & 1];
+		destroy_contact(w, e >> 1);
+		e = next;
+	}
+}
+
+/* b2Body::SetType (b2Body.cpp:118-188) */
+void b2o_set_type(b2o_world* w, int body, int type)
+{
+	body_t* b = &w->bodies[body];
+	if (b->dead || b->type == type) return;
+	if (b->type == 0)
+	{
+		/* out of m_staticBodies (their order is never used), to the end of m_nonStaticBodies */
+		GROW(w->nonStatic, w->capNonStatic, w->nNonStatic + 1, int);
+		b->worldIndex = w->nNonStatic;
+		w->nonStatic[w->nNonStatic++] = body;
+	}
+	b->type = type;
+	reset_mass(w, b);
+	if (type == 0)
+	{
+		b->v = v_make(0.0f, 0.0f);
+		b->w = 0.0f;
+		b->a0 = b->a;
+		b->c0 = b->c;
+		sync_body_fixtures(w, b);
+		int slot = b->worldIndex, last = w->nonStatic[w->nNonStatic - 1];
+		w->nonStatic[slot] = last;
+		w->bodies[last].worldIndex = slot;
+		w->nNonStatic--;
+		b->worldIndex = -1;
+	}
+	set_awake(b);
+	b->force = v_make(0.0f, 0.0f);
+	b->torque = 0.0f;
+	for (int e = b->contactHead; e >= 0; )
+	{
+		int next = w->contacts[e >> 1].next[e & 1];
+		destroy_contact(w, e >> 1);
+		e = next;
+	}
+	/* TouchProxy on every proxy, newest fixture first: new contacts can form with the next pair update */
+	for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
+		if (w->fixtures[f].proxyId >= 0) buffer_move(w, f);
 }
 
 /* b2Body::SetAwake (b2Body.h:690-718) */

@@ -1316,6 +1316,51 @@ inline void LifecycleEdits(Scene& s, b2World* w)
 			b->GetFixtureList()->SetFilterData(filter);
 		}
 	}
+	if (step == 104 || step == 118)
+	{
+		// bodies switched off (their proxies and contacts go, b2Body.cpp:496-544) and on again (new proxy ids, contacts with
+		// the next pair update); one of them gets a fixture while it is off
+		for (int i = 6; i < 9; ++i)
+		{
+			b2Body* b = alive(i);
+			if (b != NULL) b->SetActive(step == 118);
+		}
+	}
+	if (step == 110)
+	{
+		b2Body* b = alive(7);
+		if (b != NULL && !b->IsActive())
+		{
+			b2CircleShape knob;
+			knob.m_radius = 0.15f;
+			knob.m_p.Set(0.0f, 0.35f);
+			b->CreateFixture(&knob, 1.5f);
+		}
+	}
+	if (step == 122 || step == 140)
+	{
+		// body types (b2Body.cpp:118-188): two heap bodies freeze (static), one becomes a kinematic mover; later they thaw
+		b2Body* a = alive(12);
+		b2Body* c = alive(13);
+		b2Body* k = alive(14);
+		if (step == 122)
+		{
+			if (a != NULL) a->SetType(b2_staticBody);
+			if (c != NULL) c->SetType(b2_staticBody);
+			if (k != NULL)
+			{
+				k->SetType(b2_kinematicBody);
+				k->SetLinearVelocity(b2Vec2(0.5f, 0.2f));
+				k->SetAngularVelocity(0.3f);
+			}
+		}
+		else
+		{
+			if (a != NULL) a->SetType(b2_dynamicBody);
+			if (c != NULL) c->SetType(b2_kinematicBody);
+			if (k != NULL) k->SetType(b2_dynamicBody);
+		}
+	}
 	if (step == 58 || step == 100)
 	{
 		// the thin wall becomes a thick shape (its contacts stop being TOI candidates) and thin again

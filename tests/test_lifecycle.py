@@ -7,7 +7,8 @@ order, b2DynamicTree.cpp:53-99, and the island seed order follows m_nonStaticBod
 teleports (SetTransform b2Body.cpp:451-473), puts to sleep and wakes (SetAwake b2Body.h:690-718), turns bodies into bullets
 and back (SetBullet + RecalculateToiCandidacy b2ContactManager.cpp:566-640), applies linear / angular impulses
 (b2Body.h:885-950), switches sensors, thick shapes and filter data (b2Fixture.cpp:180-257), retunes a wheel joint's spring,
-destroys a jointed body (its joint goes with it) and drags a mouse joint more slowly than the sleep tolerance for longer
+switches bodies off and on again (SetActive b2Body.cpp:496-544, a fixture created meanwhile) and changes body types
+(SetType b2Body.cpp:118-188: static, kinematic and back), destroys a jointed body (its joint goes with it) and drags a mouse joint more slowly than the sleep tolerance for longer
 than b2_timeToSleep (b2Body::SetAwake(true) restarts the sleep timer whether the body sleeps or not: ADVICE r1).
 
   CPU : host layer over the C oracle  vs  the real reference build: body states, contact sets, manifolds and the listener's
