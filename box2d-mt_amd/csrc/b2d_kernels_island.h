@@ -302,7 +302,10 @@ __device__ __forceinline__ void freeBodyStep(const DW& W, const StepParams& sp, 
 	V2 c = v2(pos.x, pos.y);
 	float a = pos.z;
 	b2dIntegratePosition(&c, &a, &v, &w, sp.dt);
-	const Xf xf = b2dXfFromSweep(c, a, v2(massv.z, massv.w));
+	// (b2dXfFromSweep with the rotation expanded in place: a call would give this streaming kernel a stack)
+	Xf xf;
+	xf.q = b2dRotInline(a);
+	xf.p = c - b2dMulRV(xf.q, v2(massv.z, massv.w));
 	W.b_xf[body] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
 	uint32_t f = bflags | BF_ISLAND | BF_AWAKE;
 	if (sp.allowSleep)
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 {
 	DState* S = W.st;
 	const int n = W.nBodies;
-	int nIslands = 0;
+	int nIslands = 0, nFree = 0;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		int4 in = make_int4(0, 0, 0, 0);
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 					// (in a sharded world every rank steps these itself: nothing to exchange)
 					freeBodyStep(W, sp, i);
 					W.rootIsland[i] = ROOT_FREE;
-					atomicAdd(&S->c.nFreeIslands, 1);
+					++nFree;
 				}
 				else
 				if (W.shardCount > 1)
@@ -393,7 +396,14 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 		}
 		W.rootScanIn[i] = in;
 	}
-	if (nIslands) atomicAdd(&S->c.nIslands, nIslands);
+	// (one add per wave: a million single-body islands adding to one word serialise in L2)
+	nIslands = waveSumInt(nIslands);
+	nFree = waveSumInt(nFree);
+	if (waveLane() == 0)
+	{
+		if (nIslands) atomicAdd(&S->c.nIslands, nIslands);
+		if (nFree) atomicAdd(&S->c.nFreeIslands, nFree);
+	}
 }
 
 __global__ __launch_bounds__(256) void k_island_assign(DW W)
