@@ -180,6 +180,14 @@ void b2o_world_destroy(b2o_world* w)
 	free(w->freeLeaves);
 	free(w->joints);
 	free(w->carray);
+	free(w->nonStatic);
+	free(w->events);
+	free(w->eventKeys);
+	free(w->postSolve);
+	free(w->postSolveSlot);
+	free(w->bodyOwned);
+	free(w->contactOwned);
+	free(w->jointOwned);
 	free(w);
 }
 
