@@ -341,6 +341,24 @@ def main():
                 w4.close()
             except Exception as e:
                 extras.append({"workload": "config 4 (sharded)", "error": str(e)})
+            # for comparison: the same islands as INDEPENDENT worlds, one pyramid world per rank and no collective at all (how
+            # round 1 measured N > 1). The gap to `value` is what the replicated phases of the one-world form cost.
+            try:
+                wi = amd.world(bh.PYRAMID, args.rows, 1, flags=flags)
+                wi.step(SETTLE_STEPS)
+                barrier()
+                ti = time.perf_counter()
+                wi.step(100)
+                barrier()
+                el = torch.tensor([time.perf_counter() - ti], dtype=torch.float64, device="cuda")
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                ms = 1000.0 * float(el.item()) / 100
+                extras.append({"workload": "independent worlds: one Pyramid %d world per rank, no collective (not the headline: DESIGN.md section 7)" % args.rows,
+                               "bodies_per_rank": wi.body_count, "settle_steps": SETTLE_STEPS, "timed_steps": 100, "ms_per_step": ms,
+                               "island_steps_per_s_all_ranks": world_size * 1000.0 / ms})
+                wi.close()
+            except Exception as e:
+                extras.append({"workload": "independent worlds", "error": str(e)})
 
     contacts = w.contact_count
     gather_ms = None
