@@ -22,12 +22,12 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tm
 python3 tools/pmc_summary.py /tmp/prof_fetch2 last 10 > $OUT/pmc_piles_fetch_size.csv
 python3 tools/pmc_summary.py /tmp/prof_write2 last 10 > $OUT/pmc_piles_write_size.csv
 python3 tools/pmc_traffic_json.py $OUT k_solve_blocks pyramid141 $OUT/pmc_fetch_size.csv $OUT/pmc_write_size.csv > $OUT/pmc_traffic.json
-python3 tools/pmc_traffic_json.py $OUT k_solve_small piles100000x5 $OUT/pmc_piles_fetch_size.csv $OUT/pmc_piles_write_size.csv > $OUT/pmc_piles_traffic.json
+python3 tools/pmc_traffic_json.py $OUT k_solve_small piles100000x5 $OUT/pmc_piles_fetch_size.csv $OUT/pmc_piles_write_size.csv > $OUT/piles_pmc_traffic.json
 # per-step budgets of HelloWorld (the floor) and of the Tumbler
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_hello -- python3 tools/gpu_one_scene.py 0 0 0 400 ccd > $OUT/hello.log 2>&1
 python3 tools/trace_steady.py /tmp/prof_hello 100 > $OUT/helloworld_steady_state_per_step.txt
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tumbler -- python3 tools/gpu_tumbler100k.py 316 80 > $OUT/tumbler.log 2>&1
 python3 tools/trace_steady.py /tmp/prof_tumbler 20 > $OUT/tumbler100k_steady_state_per_step.txt
 timeout 100 python3 tools/gpu_floor.py 3000 1 > $OUT/floor.txt 2>&1; timeout 100 python3 tools/gpu_floor.py 3000 0 >> $OUT/floor.txt 2>&1
-head -3 $OUT/pmc_fetch_size.csv; head -3 $OUT/pmc_write_size.csv; head -4 $OUT/steady_state_per_step.txt; cat $OUT/pmc_traffic.json $OUT/pmc_piles_traffic.json $OUT/floor.txt
+head -3 $OUT/pmc_fetch_size.csv; head -3 $OUT/pmc_write_size.csv; head -4 $OUT/steady_state_per_step.txt; cat $OUT/pmc_traffic.json $OUT/piles_pmc_traffic.json $OUT/floor.txt
 python3 tools/print_bench.py $OUT/bench.json
