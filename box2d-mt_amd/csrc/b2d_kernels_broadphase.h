@@ -15,6 +15,7 @@
 // b2DynamicTree::MoveProxy, one lane per proxy.
 __global__ __launch_bounds__(256) void k_sync_fixtures(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = W.nProxies;
 	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
@@ -88,6 +89,7 @@ __device__ __forceinline__ void proxyCell(const DW& W, float4 a, int* ix, int* i
 // every fat AABB as of now; the pair census of the finished pair update is left alone)
 __global__ __launch_bounds__(256) void k_grid_clear(DW W, int force)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	// always reset the pair census, also when nothing moved: the ordering / creation kernels that
 	// follow key off nPairs and must see 0 then
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void k_grid_clear(DW W, int force)
 
 __global__ __launch_bounds__(256) void k_grid_count(DW W, int force)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0 && !force) return;
 	const int n = W.nProxies;
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DW W, int force)
 
 __global__ __launch_bounds__(256) void k_grid_fill(DW W, int force)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0 && !force) return;
 	const int n = W.nProxies;
@@ -180,6 +184,7 @@ __device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q
 // item -> fat AABB -> filters -> hash probe is then paid once per wave, not once per candidate).
 __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int nm = S->c.nMoves < W.capMoves ? S->c.nMoves : W.capMoves;
 	const int nLarge = S->c.nLargeProxies;
@@ -191,7 +196,12 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 		const int p = W.moveBuf[k];
 		if (p < 0 || W.p_body[p] < 0) continue;
 		const float4 a4 = W.p_fat[p];
-		if (proxyIsLarge(W, a4)) continue;
+		if (proxyIsLarge(W, a4))
+		{
+			// (for k_find_pairs_large; the list is as long as the move buffer)
+			if (lane == 0) W.largeMoves[atomicAdd(&S->c.nLargeMoves, 1)] = p;
+			continue;
+		}
 		AABB a;
 		a.lo = v2(a4.x, a4.y);
 		a.hi = v2(a4.z, a4.w);
@@ -239,45 +249,47 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	}
 }
 
-// One workgroup per moved LARGE proxy: brute force over every proxy.
+// Moved LARGE proxies (listed by k_find_pairs_small): brute force over every proxy, a workgroup per (proxy, slice of 1024
+// candidates) - the four walls of the Tumbler's container move every step, and one workgroup per wall walking 100 000
+// proxies was 360 us of a 4.9 ms step with 252 CUs idle.
 __global__ __launch_bounds__(256) void k_find_pairs_large(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
-	const int nm = S->c.nMoves < W.capMoves ? S->c.nMoves : W.capMoves;
-	for (int k = blockIdx.x; k < nm; k += gridDim.x)
+	const int nLM = S->c.nLargeMoves;
+	const int slices = (W.nProxies + 1023) / 1024;
+	const long long units = (long long)nLM * slices;
+	for (long long u = blockIdx.x; u < units; u += gridDim.x)
 	{
-		const int p = W.moveBuf[k];
-		if (p < 0 || W.p_body[p] < 0) continue;
-		float4 a4 = W.p_fat[p];
-		if (!proxyIsLarge(W, a4)) continue;
+		const int k = (int)(u / slices), slice = (int)(u - (long long)k * slices);
+		const int p = W.largeMoves[k];
+		const float4 a4 = W.p_fat[p];
 		AABB a;
 		a.lo = v2(a4.x, a4.y);
 		a.hi = v2(a4.z, a4.w);
-		// four candidates per lane and trip: their loads are issued together (the emit path contains atomics, which the
-		// compiler will not move loads across; one candidate per trip made this loop a chain of dependent round trips)
-		for (int q0 = threadIdx.x; q0 < W.nProxies; q0 += 4 * blockDim.x)
+		// four candidates per lane: their loads are issued together (the emit path contains atomics, which the compiler
+		// will not move loads across; one candidate per trip made this a chain of dependent round trips)
+		const int q0 = slice * 1024 + (int)threadIdx.x;
+		int body[4];
+		float4 fat[4];
+#pragma unroll
+		for (int v = 0; v < 4; ++v)
 		{
-			int body[4];
-			float4 fat[4];
+			const int q = q0 + v * 256;
+			const bool in = q < W.nProxies;
+			body[v] = in ? W.p_body[q] : -1;
+			fat[v] = in ? W.p_fat[q] : make_float4(0, 0, 0, 0);
+		}
 #pragma unroll
-			for (int u = 0; u < 4; ++u)
-			{
-				const int q = q0 + u * blockDim.x;
-				const bool in = q < W.nProxies;
-				body[u] = in ? W.p_body[q] : -1;
-				fat[u] = in ? W.p_fat[q] : make_float4(0, 0, 0, 0);
-			}
-#pragma unroll
-			for (int u = 0; u < 4; ++u)
-			{
-				const int q = q0 + u * blockDim.x;
-				if (q == p || body[u] < 0) continue;
-				AABB b;
-				b.lo = v2(fat[u].x, fat[u].y);
-				b.hi = v2(fat[u].z, fat[u].w);
-				if (!b2dAabbOverlap(a, b)) continue;
-				tryEmitPair(W, S, p, q);
-			}
+		for (int v = 0; v < 4; ++v)
+		{
+			const int q = q0 + v * 256;
+			if (q == p || body[v] < 0) continue;
+			AABB b;
+			b.lo = v2(fat[v].x, fat[v].y);
+			b.hi = v2(fat[v].z, fat[v].w);
+			if (!b2dAabbOverlap(a, b)) continue;
+			tryEmitPair(W, S, p, q);
 		}
 	}
 }
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_large(DW W)
 // Small sets (<= COUNT_RANK_MAX): rank by counting, tiles of keys staged through LDS.
 __global__ __launch_bounds__(256) void k_pairs_first(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
 	if (n == 0 || n > COUNT_RANK_MAX) return;
@@ -315,6 +328,7 @@ __global__ __launch_bounds__(256) void k_pairs_first(DW W)
 
 __global__ __launch_bounds__(256) void k_pairs_rank(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
 	if (n == 0 || n > COUNT_RANK_MAX) return;
@@ -347,6 +361,7 @@ __global__ __launch_bounds__(256) void k_pairs_rank(DW W)
 // Large sets: after the radix sort the keys are ordered; first-of-run flags + scan give the ranks.
 __global__ __launch_bounds__(256) void k_pairs_sorted_first(DW W, const uint64_t* keys, int* nOut)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
 	if (blockIdx.x == 0 && threadIdx.x == 0) *nOut = n > COUNT_RANK_MAX ? n : 0;
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(256) void k_pairs_sorted_first(DW W, const uint64_t
 
 __global__ void k_pairs_sorted_total(DW W, const int* n2)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (*n2 > 0) S->c.nNewContacts = W.pairRank[*n2];
 }
@@ -377,6 +393,7 @@ __device__ __forceinline__ bool createBlocked(const DW& W, const DState* S, int 
 // left untouched (moves stay buffered) and the host finishes it with the radix path after its read-back.
 __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* keys, const int2* proxies, int smallPath)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
 	if (createBlocked(W, S, smallPath)) return;
@@ -428,6 +445,7 @@ __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* k
 
 __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (createBlocked(W, S, smallPath)) return;
 	// apply the wake requests of contact creation now (the next user of the flags is the next step)
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 // candidate, in creation order. One workgroup, block scan over the new contacts.
 __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const bool blocked = createBlocked(W, S, smallPath);
 	const int nNew = blocked ? 0 : S->c.nNewContacts;
@@ -505,9 +524,18 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 // ---- end of step -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar)
 {
+	b2dPhaseStamp(W);
 	const int n = W.nBodies;
 	// (the solver's phase stamps travel with the counters: one copy to the host less)
-	if (bar != nullptr && blockIdx.x == 0 && threadIdx.x < 6) W.st->stamps[threadIdx.x] = bar[8 + threadIdx.x];
+	if (blockIdx.x == 0)
+	{
+		if (bar != nullptr && threadIdx.x < 6) W.st->stamps[threadIdx.x] = bar[8 + threadIdx.x];
+		__syncthreads();
+		// the counters travel behind the state rows (nothing else runs in this step: they are final)
+		const int* src = (const int*)W.st;
+		int* dst = (int*)(W.stateOut + (size_t)n * 10);
+		for (int k = threadIdx.x; k < (int)(sizeof(DState) / sizeof(int)); k += blockDim.x) dst[k] = src[k];
+	}
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		uint32_t f = W.b_flags[i];

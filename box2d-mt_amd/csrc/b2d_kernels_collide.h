@@ -81,6 +81,7 @@ __device__ __forceinline__ bool isToiCandidate(const DW& W, int proxyA, int prox
 
 __global__ __launch_bounds__(256) void k_collide(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 // net event per contact and step: a begin + end inside one step (possible through TOI sub-steps) cancels out.
 __global__ __launch_bounds__(256) void k_contact_events(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void k_contact_events(DW W)
 // the contact has after the compaction.
 __global__ __launch_bounds__(256) void k_presolve_gather(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const bool compacting = S->c.nDestroy != 0;
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(256) void k_presolve_gather(DW W)
 // b2Contact::SetEnabled(false) from PreSolve: the listed contacts sit out this step (the next Collide enables them again)
 __global__ __launch_bounds__(256) void k_presolve_disable(DW W, const int* list, int count)
 {
+	b2dPhaseStamp(W);
 	const ContactArrays& C = W.ca[W.st->cur];
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
 	{
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(256) void k_presolve_disable(DW W, const int* list,
 // solved in this step = solid contacts with a non-static body that was in a solved island.
 __global__ __launch_bounds__(256) void k_postsolve_gather(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -338,6 +343,7 @@ __global__ __launch_bounds__(256) void k_postsolve_gather(DW W)
 // Contacts flagged for re-filtering, listed for the user's contact filter (asked on the host before Collide)
 __global__ __launch_bounds__(256) void k_filter_list(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(256) void k_filter_list(DW W)
 
 __global__ __launch_bounds__(256) void k_filter_reject(DW W, const int* list, int count)
 {
+	b2dPhaseStamp(W);
 	const ContactArrays& C = W.ca[W.st->cur];
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
 	{
@@ -362,12 +369,14 @@ __global__ __launch_bounds__(256) void k_filter_reject(DW W, const int* list, in
 // Candidate pairs the user's contact filter refused: they are no first occurrences any more (nothing is created for them)
 __global__ __launch_bounds__(256) void k_pairs_reject(DW W, const int* list, int count)
 {
+	b2dPhaseStamp(W);
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) W.pairFirst[list[k]] = 0;
 }
 
 // Per-step counters back to zero (one launch instead of a handful of memsets); `bar` = the resident solver's grid barrier.
 __global__ void k_step_begin(DW W, int* bar)
 {
+	b2dPhaseStamp(W);
 	Counters& c = W.st->c;
 	const int t = threadIdx.x;
 	if (t == 0)
@@ -400,6 +409,7 @@ __global__ void k_step_begin(DW W, int* bar)
 // their number (a world built with 20 000 joints used to issue 20 000 launches in its first step).
 __global__ __launch_bounds__(256) void k_flag_filter(DW W, const unsigned long long* pairs, int nPairs)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -426,6 +436,7 @@ __global__ __launch_bounds__(256) void k_flag_filter(DW W, const unsigned long l
 #define TOI_ORDER_SORT_MAX 2048
 __global__ __launch_bounds__(256) void k_toi_order_destroy(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nToiDestroy;
 	if (n == 0) return;
@@ -464,6 +475,7 @@ __global__ __launch_bounds__(256) void k_toi_order_destroy(DW W)
 // Stable compaction (creation order is preserved). keepScan = exclusive scan of keepFlag.
 __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nDestroy == 0) return;
 	const int n = S->c.nContacts;
@@ -539,6 +551,7 @@ __device__ __forceinline__ bool htContains(const DW& W, uint64_t key)
 
 __global__ __launch_bounds__(256) void k_ht_clear(DW W)
 {
+	b2dPhaseStamp(W);
 	if (W.st->c.nMoves == 0) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= W.htMask; i += gridDim.x * blockDim.x)
 	{
@@ -548,6 +561,7 @@ __global__ __launch_bounds__(256) void k_ht_clear(DW W)
 
 __global__ __launch_bounds__(256) void k_ht_build(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0) return;
 	const int n = S->c.nContacts;

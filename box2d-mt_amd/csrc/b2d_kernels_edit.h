@@ -30,6 +30,7 @@ enum
 
 __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int nOps)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	__shared__ int s_list[EDIT_LIST_MAX];
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int
 // After destroy ops: keep flags for the stable compaction that follows (the tail of phaseCollide)
 __global__ __launch_bounds__(256) void k_edit_keepflags(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void k_edit_keepflags(DW W)
 
 __global__ void k_edit_finish(DW W)
 {
+	b2dPhaseStamp(W);
 	// the per-step destroy census belongs to Collide
 	W.st->c.nDestroy = 0;
 }

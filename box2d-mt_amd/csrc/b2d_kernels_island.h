@@ -122,6 +122,7 @@ __device__ __forceinline__ int effBlk(const DW& W, int body)
 
 __global__ __launch_bounds__(256) void k_island_init(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (blockIdx.x == 0) colorCheckBegin(W);
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_BLOCKS + 1; i += gridDim.x * blockDim.x)
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 
 __global__ __launch_bounds__(256) void k_island_union(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256) void k_island_union(DW W)
 
 __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 {
+	b2dPhaseStamp(W);
 	const int n = W.nBodies;
 	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 
 __global__ __launch_bounds__(256) void k_island_count(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -331,6 +335,7 @@ __device__ __forceinline__ void freeBodyStep(const DW& W, const StepParams& sp, 
 
 __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = W.nBodies;
 	int nIslands = 0, nFree = 0;
@@ -408,6 +413,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 
 __global__ __launch_bounds__(256) void k_island_assign(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = W.nBodies;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -461,6 +467,7 @@ __global__ __launch_bounds__(256) void k_island_assign(DW W)
 // Adjacency (small islands) and the large-island contact list.
 __global__ __launch_bounds__(256) void k_island_edges(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -509,6 +516,7 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W)
 // b_adopt, so the outcome does not depend on which lane ran first.
 __global__ __launch_bounds__(256) void k_block_adopt(DW W, int stage)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -537,9 +545,11 @@ __global__ __launch_bounds__(256) void k_block_adopt(DW W, int stage)
 // changing the relative order of anything else) and non-solid contacts are not in the adjacency.
 __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int nS = S->c.nSIslands;
 	const ContactArrays& C = W.ca[S->cur];
+	if (blockIdx.x == 0 && threadIdx.x == 0) S->gapClock[1] = wall_clock64();
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nS; idx += gridDim.x * blockDim.x)
 	{
 		{
@@ -637,6 +647,7 @@ __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 // Joint lists of the LARGE (coloured) islands: grouped per root, ascending joint id inside an island.
 __global__ __launch_bounds__(256) void k_joints_fill(DW W)
 {
+	b2dPhaseStamp(W);
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
 	{
 		const RevoluteJoint& jn = W.joints[j];
@@ -652,6 +663,7 @@ __global__ __launch_bounds__(256) void k_joints_fill(DW W)
 
 __global__ __launch_bounds__(64) void k_joints_sort(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLIslands;
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)

@@ -22,6 +22,7 @@
 // One workgroup: rank the big islands by root id, deal them round robin, keep ours on the large-island list.
 __global__ __launch_bounds__(1024) void k_shard_big(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nBigIslands < SHARD_BIG_MAX ? S->c.nBigIslands : SHARD_BIG_MAX;
 	const int t = (int)threadIdx.x;
@@ -52,6 +53,7 @@ __device__ __forceinline__ bool shardOwnsBody(const DW& W, int body)
 // out: [nBodies x SHARD_BODY_WORDS][nContacts x SHARD_CONTACT_WORDS][nJoints x SHARD_JOINT_WORDS]
 __global__ __launch_bounds__(256) void k_shard_export(DW W, int* out)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int nb = W.nBodies, nc = S->c.nContacts, nj = W.nJoints;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256) void k_shard_export(DW W, int* out)
 // in: the MAX over the ranks of what k_shard_export wrote. Records owned by another rank are written into the world.
 __global__ __launch_bounds__(256) void k_shard_import(DW W, const int* in)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int nb = W.nBodies, nc = S->c.nContacts, nj = W.nJoints;

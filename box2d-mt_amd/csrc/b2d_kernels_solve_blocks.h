@@ -65,8 +65,9 @@ __device__ __forceinline__ int blockScan1024(int v, int* s_buf /* [2 * 1024] */,
 
 // After k_color_check's census (rows per block): row segments of the blocks, home bodies grouped by block (and each
 // body's slot in its block), adoptions made permanent, and the two capacity figures the host decides on.
-__global__ __launch_bounds__(1024) void k_block_census(DW W)
+__global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub, int pubSeq)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	__shared__ int s_buf[2048];
 	__shared__ int s_cnt[MAX_BLOCKS], s_start[MAX_BLOCKS];
@@ -117,6 +118,22 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W)
 			W.b_slot[body] = slot;
 		}
 	}
+	if (t == 0) S->gapClock[0] = wall_clock64();
+	// The island build ends here and the host is waiting for its census to size the solver launches: the counters go
+	// straight into host memory (pinned, coherent), the sequence number last - the host polls it (b2hip.hip: awaitCensus).
+	// Cheaper than a copy behind this kernel plus a stream synchronisation, and the stream can go on (k_color_small is
+	// already queued) while the host decides.
+	if (pub != nullptr)
+	{
+		__syncthreads();
+		const int* src = (const int*)S;
+		int* dst = (int*)pub;
+		for (int k = t; k < (int)(offsetof(DState, pubSeq) / sizeof(int)); k += 1024)
+			__hip_atomic_store(&dst[k], src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__threadfence_system();
+		__syncthreads();
+		if (t == 0) __hip_atomic_store(&pub->pubSeq, pubSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 // ---- partition ------------------------------------------------------------------------------------------------------------------
@@ -134,6 +151,7 @@ __device__ __forceinline__ uint32_t mortonSpread16(uint32_t x)
 // the large islands lose their block (a stale block id would make them a far-away member of it when they come back).
 __global__ __launch_bounds__(256) void k_part_keys(DW W, uint64_t* keys, int2* vals)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
@@ -156,6 +174,7 @@ __global__ __launch_bounds__(256) void k_part_keys(DW W, uint64_t* keys, int2* v
 
 __global__ __launch_bounds__(256) void k_part_weights(DW W, const int2* vals, int* weights)
 {
+	b2dPhaseStamp(W);
 	const int n = W.st->c.nLBodies;
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) weights[k] = vals[k].y;
 }
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(256) void k_part_weights(DW W, const int2* vals, in
 // Bodies in sorted order, `prefix` = exclusive scan of their degrees: a block is closed every blkTargetDeg.
 __global__ __launch_bounds__(256) void k_part_assign(DW W, const int2* vals, const int* prefix)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLBodies;
 	const int target = S->c.blkTargetDeg > 0 ? S->c.blkTargetDeg : BLOCK_TARGET_DEG;
@@ -184,6 +204,7 @@ __global__ __launch_bounds__(256) void k_part_assign(DW W, const int2* vals, con
 // Before k_color_check runs a second time in one step (after a new partition): what k_island_init had prepared for it.
 __global__ __launch_bounds__(256) void k_color_recheck_begin(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
@@ -245,6 +266,7 @@ __device__ __forceinline__ bool blockBarrier(const GridBarrier& gb)
 template <int LANES>
 __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int* bar, int epoch)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int tid = (int)threadIdx.x, blk = (int)blockIdx.x;
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	__shared__ int s_perm[LANES];
 	__shared__ int s_hist[MAX_COLORS], s_colStart[MAX_COLORS + 1];
 	__shared__ unsigned long long s_colMask;
-	if (gtid == 0) S->c.allLargeDone = 0;
+	if (gtid == 0) { S->c.allLargeDone = 0; S->gapClock[3] = wall_clock64(); }
 	// (penetration maxima: every slot was wiped by k_island_init)
 	const unsigned long long t0 = wall_clock64();
 #define BLK_STAMP(k) do { if (gtid == 0) bar[8 + (k)] = (int)(wall_clock64() - t0); } while (0)
@@ -672,6 +694,7 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 template <int LANES>
 __global__ __launch_bounds__(LANES) void k_blocks_sweep(DW W, StepParams sp, int mode, int* bar, int epoch)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (mode == 2 && S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];

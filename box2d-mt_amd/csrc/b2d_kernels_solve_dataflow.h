@@ -100,6 +100,7 @@ __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, in
 #ifdef B2HIP_VALIDATION_SOLVERS // (cross-check solver: see b2hip.hip)
 __global__ __launch_bounds__(PERSIST_LANES) void k_solve_dataflow(DW W, StepParams sp, int nColorsArg, int* bar, int pollSleep)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int nColors = nColorsArg >= 0 ? nColorsArg : (S->c.nColors < MAX_COLORS ? S->c.nColors : MAX_COLORS);
 	const ContactArrays& C = W.ca[S->cur];

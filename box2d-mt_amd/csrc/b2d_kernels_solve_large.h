@@ -51,6 +51,7 @@ __device__ __forceinline__ void lcLoad(const DW& W, int row, ContactConstraint& 
 // ---- bodies --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_large_integrate(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLBodies;
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
@@ -116,6 +117,7 @@ __device__ __forceinline__ bool rowIsSerial(const DW& W, bool nsA, int bodyA, bo
 
 __global__ __launch_bounds__(256) void k_color_begin(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLContacts;
 	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void k_color_begin(DW W)
 // runs the colouring rounds again. Also builds the per-colour census for the reuse case.
 __global__ __launch_bounds__(256) void k_color_check(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	int bad = 0;
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 
 __global__ __launch_bounds__(256) void k_color_claim(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nUncolored == 0) return;
 	const int n = S->c.nLContacts;
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(256) void k_color_claim(DW W)
 
 __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nUncolored == 0) return;
 	const int n = S->c.nLContacts;
@@ -348,9 +353,14 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 // settled island) are listed by k_color_check; one workgroup runs the Jones-Plassmann rounds over that list only.
 // Same claims, same priorities, same "lowest free colour" rule as k_color_claim / k_color_resolve, so the colours are
 // the ones the grid-wide rounds would hand out.
-__global__ __launch_bounds__(1024) void k_color_small(DW W)
+// `queuedAhead`: launched behind the census before the host has read it (it runs while the host sizes the solver launches):
+// only if the partition is certain to stay (b2dPartitionSettled), else the host launches it again in its usual place.
+__global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
+	if (threadIdx.x == 0) S->gapClock[2] = wall_clock64();
+	if (queuedAhead && !b2dPartitionSettled(S->c)) return;
 	if (S->c.nUncolList > COLOR_SMALL_MAX || S->c.needRecolor) return;
 	const ContactArrays& C = W.ca[S->cur];
 	__shared__ int s_left, s_colored, s_maxColor, s_n;
@@ -455,6 +465,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W)
 
 __global__ void k_color_scan(DW W)
 {
+	b2dPhaseStamp(W);
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		// all MAX_COLORS groups: the regular colours [0, nColors) first, the hub group (HUB_COLOR) last
@@ -477,6 +488,7 @@ __global__ void k_color_scan(DW W)
 // island size (at the price of as many phases as the deepest dependency chain).
 __global__ __launch_bounds__(256) void k_exact_begin(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nSContacts;
 	for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n; c += gridDim.x * blockDim.x)
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(256) void k_exact_begin(DW W)
 
 __global__ __launch_bounds__(256) void k_exact_convert(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int nC = S->c.nSContacts, nB = S->c.nSBodies, nI = S->c.nSIslands;
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nC; j += gridDim.x * blockDim.x)
@@ -519,6 +532,7 @@ __global__ __launch_bounds__(256) void k_exact_convert(DW W)
 
 __global__ __launch_bounds__(256) void k_color_fill(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -600,6 +614,7 @@ __device__ __forceinline__ LargeRef largeRef(const DW& W, const ContactArrays& C
 // run one lane at a time with the hub's state handed on through wave shuffles.
 __global__ __launch_bounds__(256) void k_hub_flag(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -625,6 +640,7 @@ __global__ __launch_bounds__(256) void k_hub_flag(DW W)
 
 __global__ __launch_bounds__(256) void k_hub_fill(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -687,8 +703,8 @@ __device__ __forceinline__ HubTrial hubEvaluate(int mode, ContactConstraint& cc,
 
 #define HUB_FIXPOINT_ROUNDS 24
 
-// mode 0 warm start, 1 velocity, 2 position. One wave; rows in hubList order.
-// Per chunk of 64 rows: every lane fetches its constraint and its non-hub body in parallel. Then
+// mode 0 warm start, 1 velocity, 2 position. Rows in hubList order, a chunk of 64 rows per wave.
+// Per chunk: every lane fetches its constraint and its non-hub body in parallel. Then
 //   * the common case - one hub, 64 different partners, none of them a hub itself: the sequential sweep through the hub is
 //     found as a FIXED POINT. Every lane evaluates its constraint from the hub row it assumes it will meet; the changes it
 //     makes to the hub row are prefix-summed over the lanes, which gives every lane a better assumption; repeat until no
@@ -700,19 +716,54 @@ __device__ __forceinline__ HubTrial hubEvaluate(int mode, ContactConstraint& cc,
 //   * otherwise (or if HUB_FIXPOINT_ROUNDS were not enough) the lanes take turns: the hub's row travels from turn to turn
 //     in registers (wave shuffle) as long as consecutive constraints sit on the same hub; a partner body that occurs twice
 //     in a chunk is re-read at its turn.
-__device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGuess, int firstRow)
+// The chunks themselves are a chain (the hub row goes from chunk to chunk), but only the rounds are: with NW waves in the
+// workgroup, wave w owns chunks w, w + NW, ... and FETCHES a chunk (three levels of dependent loads, ~6 us of the 13 us a
+// chunk took in the one-wave form) while the waves before it have their turn. The hub row is handed from wave to wave
+// through LDS (s_turn counts the chunks done); a wave that finds one of its prefetched partner rows was written by an
+// earlier chunk of this launch (s_dirty, a bitmap over body ids) waits until those stores have landed (s_landed) and
+// reads the row again. Every chunk computes from the same inputs as in the one-wave form: the result is the same bits
+// for any NW (tests/test_gpu_parity.py::test_hub_sweep_is_the_same_for_any_number_of_waves).
+#define HUB_DIRTY_WORDS 2048
+
+template <int NW>
+__device__ __forceinline__ void hubSweep(const DW& W, int mode, int useGuess)
 {
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int n = S->c.nHubRows;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
 	const float4* rows = mode == 2 ? W.b_pos : W.b_vel;
 	float4* rowsOut = mode == 2 ? W.b_pos : W.b_vel;
+	__shared__ float4 s_carry;
+	__shared__ int s_carryBody, s_turn, s_landed;
+	__shared__ uint32_t s_dirty[NW > 1 ? HUB_DIRTY_WORDS : 1];
+	if (NW > 1)
+	{
+		for (int i = threadIdx.x; i < HUB_DIRTY_WORDS; i += 64 * NW) s_dirty[i] = 0u;
+		if (threadIdx.x == 0)
+		{
+			s_carry = make_float4(0, 0, 0, 0);
+			s_carryBody = -1;
+			s_turn = 0;
+			s_landed = 0;
+		}
+		__syncthreads();
+	}
+	auto markDirty = [&](int body)
+	{
+		if (NW > 1) atomicOr(&s_dirty[((uint32_t)body >> 5) & (HUB_DIRTY_WORDS - 1)], 1u << (body & 31));
+	};
+	auto isDirty = [&](int body) -> bool
+	{
+		return NW > 1 && (s_dirty[((uint32_t)body >> 5) & (HUB_DIRTY_WORDS - 1)] >> (body & 31)) & 1u;
+	};
 	int carryBody = -1;
 	float4 carry = make_float4(0, 0, 0, 0);
 	int statRounds = 0, statSerial = 0;
-	for (int base = firstRow; base < n; base += 64)
+	const int nChunks = (n + 63) / 64;
+	for (int chunk = wave; chunk < nChunks; chunk += NW)
 	{
+		const int base = chunk * 64;
 		const int k = base + lane;
 		const bool have = k < n;
 		LargeRef r;
@@ -748,7 +799,7 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 			}
 		}
 		// does my partner body occur earlier in this chunk (as partner or as hub)? then my copy may be stale at my turn
-		bool reload = have && otherBody == carryBody; // its memory row is stale while it is carried
+		bool reload = false;
 		for (int t = 0; t < 64; ++t)
 		{
 			const int ob = __shfl(otherBody, t), hb = __shfl(hubBody, t);
@@ -770,16 +821,46 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 			}
 			if (__ballot(have && (hubBody != hub0 || partnerIsHub || dup || otherBody == hubBody)) != 0ull) simple = false;
 		}
+
+		// ---- my turn: the chunks before this one are through --------------------------------------------------------------------
+		bool landedWaited = false;
+		auto waitLanded = [&]()
+		{
+			// every store of the chunks before this one has reached memory (they may have written rows this chunk reads)
+			if (NW > 1 && !landedWaited)
+			{
+				while (__hip_atomic_load(&s_landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < chunk) __builtin_amdgcn_s_sleep(1);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				landedWaited = true;
+			}
+		};
+		if (NW > 1)
+		{
+			while (__hip_atomic_load(&s_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < chunk) __builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			carry = s_carry;
+			carryBody = s_carryBody;
+			// a partner row fetched ahead that an earlier chunk has written since: read it again
+			const bool stale = have && (mode == 2 || otherDynamic) && isDirty(otherBody);
+			if (__ballot(stale) != 0ull)
+			{
+				waitLanded();
+				if (stale) other = rows[otherBody];
+			}
+			if (!simple) waitLanded(); // (the turn-by-turn path reads rows as it goes)
+		}
+		if (have && otherBody == carryBody) reload = true; // its memory row is stale while it is carried
 		bool solved = false;
 		if (simple)
 		{
 			if (carryBody >= 0 && carryBody != hub0)
 			{
-				if (lane == 0) rowsOut[carryBody] = carry;
+				if (lane == 0) { rowsOut[carryBody] = carry; markDirty(carryBody); }
 				carryBody = -1;
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			}
+			if (carryBody != hub0) waitLanded(); // (the hub's row comes from memory: an earlier chunk may have put it there)
 			const float4 u0 = carryBody == hub0 ? carry : rows[hub0];
 			float imp0[4] = { cc.normalImpulse[0], cc.tangentImpulse[0], cc.normalImpulse[1], cc.tangentImpulse[1] };
 			float4 incoming = u0;
@@ -837,6 +918,20 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 			if (solved)
 			{
 				// every lane met the hub row it assumed: what it computed last stands
+				const float4 last = tr.hubOut; // (an inactive lane hands its assumption on)
+				carry.x = __shfl(last.x, cnt - 1);
+				carry.y = __shfl(last.y, cnt - 1);
+				carry.z = __shfl(last.z, cnt - 1);
+				carry.w = u0.w;
+				carryBody = hub0;
+				if (NW > 1)
+				{
+					// the next chunk can start its rounds: it needs the hub row, and to know which partner rows are on their way
+					if (active && otherDynamic) markDirty(otherBody);
+					if (lane == 0) { s_carry = carry; s_carryBody = carryBody; }
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					if (lane == 0) __hip_atomic_store(&s_turn, chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
 				if (active)
 				{
 					if (mode != 2)
@@ -848,12 +943,6 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 					minSep = tr.minSep;
 				}
 				if (have) W.hubDelta[k] = make_float4(lastDx, lastDy, lastDz, 0.0f);
-				const float4 last = tr.hubOut; // (an inactive lane hands its assumption on)
-				carry.x = __shfl(last.x, cnt - 1);
-				carry.y = __shfl(last.y, cnt - 1);
-				carry.z = __shfl(last.z, cnt - 1);
-				carry.w = u0.w;
-				carryBody = hub0;
 				// the partner rows written here may be read by the next chunk
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -865,7 +954,11 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 			}
 		}
 		// ---- lanes take turns ----------------------------------------------------------------------------------------------
-		if (!solved) ++statSerial;
+		if (!solved)
+		{
+			++statSerial;
+			waitLanded();
+		}
 		for (int t = 0; t < cnt && !solved; ++t)
 		{
 			float4 hubOut = carry;
@@ -877,6 +970,7 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 				{
 					// hub-to-hub contact: the partner is the body being carried; put it back first
 					rowsOut[cb] = carry;
+					markDirty(cb);
 					cb = -1;
 				}
 				float4 hubRow = cb == hubBody ? carry : rows[hubBody];
@@ -889,7 +983,7 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 					if (hubIsA) b2dSolvePosition(&cc, &pH, &pO, B2D_BAUMGARTE, &minSep);
 					else b2dSolvePosition(&cc, &pO, &pH, B2D_BAUMGARTE, &minSep);
 					hubRow = make_float4(pH.c.x, pH.c.y, pH.a, hubRow.w);
-					if (otherDynamic) rowsOut[otherBody] = make_float4(pO.c.x, pO.c.y, pO.a, other.w);
+					if (otherDynamic) { rowsOut[otherBody] = make_float4(pO.c.x, pO.c.y, pO.a, other.w); markDirty(otherBody); }
 				}
 				else
 				{
@@ -906,10 +1000,10 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 						if (hubIsA) b2dSolveVelocity(&cc, &vH, &vO); else b2dSolveVelocity(&cc, &vO, &vH);
 					}
 					hubRow = make_float4(vH.v.x, vH.v.y, vH.w, 0.0f);
-					if (otherDynamic) rowsOut[otherBody] = make_float4(vO.v.x, vO.v.y, vO.w, 0.0f);
+					if (otherDynamic) { rowsOut[otherBody] = make_float4(vO.v.x, vO.v.y, vO.w, 0.0f); markDirty(otherBody); }
 				}
 				// a different hub was being carried: its row goes back to memory now
-				if (cb >= 0 && cb != hubBody) rowsOut[cb] = carry;
+				if (cb >= 0 && cb != hubBody) { rowsOut[cb] = carry; markDirty(cb); }
 				hubOut = hubRow;
 				hubOutBody = hubBody;
 			}
@@ -922,25 +1016,47 @@ __device__ __forceinline__ void hubSweepOneWave(const DW& W, int mode, int useGu
 			carryBody = __shfl(hubOutBody, t);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		}
+		if (NW > 1 && !solved)
+		{
+			if (lane == 0) { s_carry = carry; s_carryBody = carryBody; }
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) __hip_atomic_store(&s_turn, chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
 		if (mode == 1 && have) lcStore(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
 		if (mode == 2) waveAtomicMaxU32(W.rootPen, r.root, floatBits(0.0f - minSep), have && active);
+		if (NW > 1)
+		{
+			// my stores have landed - and, in order, those of every chunk before mine
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			while (__hip_atomic_load(&s_landed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < chunk) __builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) __hip_atomic_store(&s_landed, chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
 	}
-	if (lane == 0 && carryBody >= 0) rowsOut[carryBody] = carry;
-	if (lane == 0)
+	if (NW > 1)
+	{
+		// the row still being carried goes back to memory: by the wave that had the last turn
+		if (nChunks > 0 && wave == (nChunks - 1) % NW && lane == 0 && carryBody >= 0) rowsOut[carryBody] = carry;
+	}
+	else if (lane == 0 && carryBody >= 0) rowsOut[carryBody] = carry;
+	if (lane == 0 && (statRounds | statSerial))
 	{
 		atomicAdd(&S->c.hubRounds, statRounds);
 		atomicAdd(&S->c.hubSerialChunks, statSerial);
 	}
 }
 
-__global__ __launch_bounds__(64) void k_large_hub(DW W, int mode, int useGuess)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_large_hub(DW W, int mode, int useGuess)
 {
+	b2dPhaseStamp(W);
 	if (mode == 2 && W.st->c.allLargeDone) return;
-	hubSweepOneWave(W, mode, useGuess, 0);
+	hubSweep<NW>(W, mode, useGuess);
 }
 
 __global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -981,6 +1097,7 @@ __global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)
 // mode 0 = warm start, 1 = velocity iteration
 __global__ __launch_bounds__(256) void k_large_velocity(DW W, int color, int mode)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int begin = W.colorStart[color], end = W.colorStart[color + 1];
@@ -1013,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_large_velocity(DW W, int color, int mod
 // mode 0 = InitVelocityConstraints (+ joint warm start), 1 = velocity, 2 = position
 __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mode)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (mode == 2 && S->c.allLargeDone) return;
 	const int n = S->c.nLIslands;
@@ -1031,6 +1149,7 @@ __global__ __launch_bounds__(64) void k_large_joints(DW W, StepParams sp, int mo
 
 __global__ __launch_bounds__(256) void k_large_store_impulses(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -1055,6 +1174,7 @@ __global__ __launch_bounds__(256) void k_large_store_impulses(DW W)
 
 __global__ __launch_bounds__(256) void k_large_integrate_positions(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLBodies;
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
@@ -1072,6 +1192,7 @@ __global__ __launch_bounds__(256) void k_large_integrate_positions(DW W, StepPar
 
 __global__ __launch_bounds__(256) void k_large_pos_begin(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.allLargeDone) return;
 	const int n = S->c.nLIslands;
@@ -1084,6 +1205,7 @@ __global__ __launch_bounds__(256) void k_large_pos_begin(DW W)
 
 __global__ __launch_bounds__(256) void k_large_position(DW W, int color)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];
@@ -1121,6 +1243,7 @@ __global__ __launch_bounds__(256) void k_large_position(DW W, int color)
 // After all colours of one position iteration: per-island early out (b2Island.cpp:329-334).
 __global__ __launch_bounds__(256) void k_large_pos_end(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.allLargeDone) return;
 	__shared__ int s_open;
@@ -1154,6 +1277,7 @@ __global__ __launch_bounds__(256) void k_large_pos_end(DW W)
 // Write back + SynchronizeTransform + sleep timers (b2Island.cpp:338-382)
 __global__ __launch_bounds__(256) void k_large_finalize(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nLBodies;
 	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
@@ -1192,6 +1316,7 @@ __global__ __launch_bounds__(256) void k_large_finalize(DW W, StepParams sp)
 
 __global__ __launch_bounds__(256) void k_large_sleep(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (!sp.allowSleep) return;
 	const int n = S->c.nLBodies;

@@ -89,6 +89,7 @@ __device__ __forceinline__ bool mailboxRun(bool pending, const float4* box, bool
 template <bool LOCAL>
 __global__ __launch_bounds__(PERSIST_LANES) void k_solve_mailbox(DW W, StepParams sp, int nColorsArg, int* bar, int epoch, int nWGArg, int skipIfDone)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	__shared__ int s_wg;
 	if (LOCAL)

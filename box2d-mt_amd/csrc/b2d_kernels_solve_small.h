@@ -22,6 +22,7 @@ __device__ __forceinline__ uint32_t floatBits(float f) { return __float_as_uint(
 template <int LANES, bool JOINTS>
 __global__ __launch_bounds__(LANES) void k_solve_small(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int chunk = blockIdx.x;
 	if (chunk >= S->c.nChunks) return;

@@ -100,6 +100,7 @@ __device__ __forceinline__ bool toiEligible(const DW& W, uint32_t flags, int4 id
 // needs the out-of-sync path and all of them are independent.
 __global__ __launch_bounds__(256) void k_toi_first(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 // ---- adjacency of ALL contacts by non-static body (the island CSR only holds solid touching ones) ----
 __global__ __launch_bounds__(256) void k_toi_adj_clear(DW W)
 {
+	b2dPhaseStamp(W);
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= W.nBodies; i += gridDim.x * blockDim.x)
 	{
 		W.deg[i] = 0;
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void k_toi_adj_clear(DW W)
 
 __global__ __launch_bounds__(256) void k_toi_adj_count(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256) void k_toi_adj_count(DW W)
 
 __global__ __launch_bounds__(256) void k_toi_adj_fill(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(256) void k_toi_adj_fill(DW W)
 // b2ClearBodySolveTOIFlags (b2World.cpp:239-259): sweeps go back to alpha0 = 0 for the next step
 __global__ __launch_bounds__(256) void k_toi_clear(DW W)
 {
+	b2dPhaseStamp(W);
 	if (W.st->c.nToiEvents == 0) return;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
@@ -1183,12 +1188,14 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 // The whole world in one persistent workgroup: the reference's serial order.
 __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	toiLoopRun<false>(W, sp, 0, 0);
 }
 
 // The components that met a new contact (or each other), replayed in the reference's global order by one workgroup.
 __global__ __launch_bounds__(TOI_LANES) void k_toi_loop_partial(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	if (W.st->c.nToiPartial == 0 || W.st->c.toiUnsafe != 0) return;
 	toiLoopRun<false>(W, sp, 0, 1);
 }

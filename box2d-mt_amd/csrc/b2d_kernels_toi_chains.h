@@ -34,6 +34,7 @@
 // One entry per dynamic body that owns at least one pending impact.
 __global__ __launch_bounds__(256) void k_toi_groups_begin(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nToiList < W.capContacts ? S->c.nToiList : W.capContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void k_toi_groups_begin(DW W)
 // The contacts of every chain body, gathered in one pass over the contact array (b_toiGroup = chain index + 1).
 __global__ __launch_bounds__(256) void k_toi_group_contacts(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.toiUnsafe || S->c.nToiGroups == 0) return;
 	const int nC = S->c.nContacts;
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void k_toi_group_contacts(DW W)
 // Everything the chains may touch, copied once (contacts go to the idle half of the double buffer).
 __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int nC = S->c.nContacts;
 	const ContactArrays& A = W.ca[S->cur];
@@ -604,6 +607,7 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 // of waves takes them in turn.
 __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp, int haveGrid)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.toiUnsafe & (TOI_UNSAFE_PARTNER | TOI_UNSAFE_CAPACITY)) return;
 	const int nGroups = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
@@ -617,6 +621,7 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp,
 // Two proxies moved by different chains may have come to overlap without either chain seeing it.
 __global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nToiMoved < TOI_MOVED_MAX ? S->c.nToiMoved : TOI_MOVED_MAX;
 	const int nG = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
@@ -653,10 +658,12 @@ __global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
 // launch each instead of two.
 __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		S->c.nLargeProxies = 0;
+		S->c.nLargeMoves = 0;
 		S->c.nPairs = 0;
 		S->c.nNewContacts = 0;
 	}
@@ -686,6 +693,7 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 
 __global__ __launch_bounds__(256) void k_bp_build(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0) return;
 	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;

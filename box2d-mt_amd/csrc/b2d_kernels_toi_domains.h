@@ -26,6 +26,7 @@
 
 __global__ __launch_bounds__(256) void k_toi_dom_init(DW W)
 {
+	b2dPhaseStamp(W);
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
 		W.toiParent[i] = i;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256) void k_toi_dom_init(DW W)
 
 __global__ __launch_bounds__(256) void k_toi_dom_union(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(256) void k_toi_dom_union(DW W)
 
 __global__ __launch_bounds__(256) void k_toi_dom_flatten(DW W)
 {
+	b2dPhaseStamp(W);
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
 		const int r = ufFindReadOnly(W.toiParent, i);
@@ -72,6 +75,7 @@ __device__ __forceinline__ int toiContactLabel(const DW& W, int4 ids)
 // One component per label that owns a pending impact.
 __global__ __launch_bounds__(256) void k_toi_dom_mark(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nToiList < W.capContacts ? S->c.nToiList : W.capContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(256) void k_toi_dom_mark(DW W)
 // Contacts per component = the capacity of its pending list (a contact is listed at most once).
 __global__ __launch_bounds__(256) void k_toi_dom_count(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nToiDomains == 0) return;
 	const int n = S->c.nContacts;
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(256) void k_toi_dom_count(DW W)
 // Slices of toiDomList (one workgroup: the number of components is small next to the number of contacts).
 __global__ __launch_bounds__(1024) void k_toi_dom_scan(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nToiDomains < TOI_DOMAINS_MAX ? S->c.nToiDomains : TOI_DOMAINS_MAX;
 	__shared__ int s_wave[16], s_carry;
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(1024) void k_toi_dom_scan(DW W)
 
 __global__ __launch_bounds__(256) void k_toi_dom_fill(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nToiList < W.capContacts ? S->c.nToiList : W.capContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(256) void k_toi_dom_fill(DW W)
 // The event loop of every component with a pending impact, one workgroup each (a fixed grid takes them in turn).
 __global__ __launch_bounds__(TOI_LANES) void k_toi_domains(DW W, StepParams sp)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.toiUnsafe & TOI_UNSAFE_CAPACITY) return;
 	const int n = S->c.nToiDomains < TOI_DOMAINS_MAX ? S->c.nToiDomains : TOI_DOMAINS_MAX;
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_domains(DW W, StepParams sp)
 // exists: compared on the hulls of all the fat AABBs each has had (a superset of every momentary overlap).
 __global__ __launch_bounds__(256) void k_toi_domains_end(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nToiMoved < TOI_MOVED_MAX ? S->c.nToiMoved : TOI_MOVED_MAX;
 	if (S->c.nToiMoved > TOI_MOVED_MAX) atomicOr(&S->c.toiUnsafe, TOI_UNSAFE_CAPACITY);
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(256) void k_toi_domains_end(DW W)
 // impacts form the list of the serial replay (k_toi_loop_partial); the events they had counted are taken back.
 __global__ __launch_bounds__(256) void k_toi_dom_rollback(DW W)
 {
+	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.toiUnsafe) return; // the whole phase is redone anyway
 	const int nD = S->c.nToiDomains < TOI_DOMAINS_MAX ? S->c.nToiDomains : TOI_DOMAINS_MAX;

@@ -106,6 +106,7 @@ struct Counters
 	int nLIslands, nLBodies, nLContacts;
 	int nColors, nUncolored, colorRounds;
 	int nLargeProxies;
+	int nLargeMoves;      // moved proxies wider than a grid cell (k_find_pairs_small lists them for k_find_pairs_large)
 	int posItersLarge;
 	int allLargeDone;
 	int needRecolor;
@@ -184,6 +185,14 @@ struct DState
 	Counters c;
 	int cur;             // which ContactArrays is live
 	int stamps[6];       // phase stamps of the resident large-island solver (copied from its barrier words by k_end_step)
+	// wall_clock64 (100 MHz) at: end of k_block_census, start of k_island_dfs / k_color_small / k_solve_blocks - what the host's
+	// census read-back in the middle of the step costs (tools/gpu_sync_gap.py)
+	unsigned long long gapClock[4];
+	// b2Profile: wall_clock64 at the start of the first kernel of each phase (slots = the PH_* points of b2hip.hip). Written
+	// by b2dPhaseStamp, which every kernel calls first: a time stamp costs nothing on the stream (a hipEventRecord between
+	// two kernels is a packet of its own - thirteen of them were 90 us of the 10 011-box pyramid's 760 us step)
+	unsigned long long phaseClock[16];
+	int pubSeq, pubPad;  // (host copy only: the sequence number k_block_census publishes the census under)
 };
 
 struct StepParams
@@ -197,6 +206,7 @@ struct StepParams
 struct DW
 {
 	DState* st;
+	uint32_t stampMask;   // phase stamps the next kernel on the main stream takes (b2dPhaseStamp); 0 for every other launch
 	int nBodies, nProxies, nJoints, nShapes;
 	int capContacts, capPairs, capMoves;
 	int serialOrphans;    // 1: constraints of bodies without a home block are swept in order with the hub constraints
@@ -337,6 +347,7 @@ struct DW
 	int* gridCursor;
 	int* gridItems;      // proxy indices grouped by cell
 	int* largeProxies;   // proxies larger than a cell
+	int* largeMoves;     // ... those of them in the move buffer
 	uint64_t* pairKey;   // candidate pairs: key
 	int2* pairProxy;     // proxy indices (lo-key proxy, hi-key proxy)
 	uint64_t* pairKey2;  // sort double buffer
@@ -376,5 +387,29 @@ struct DW
 	// ---- read-back ------------------------------------------------------------------------------
 	float* stateOut;     // 10 x 4 bytes per body (b2hip_body_state)
 };
+
+#if defined(__HIPCC__)
+// "The host will keep the block partition this step": what phaseSolve's test for a new partition comes to on the census
+// (slightly stricter: it does not know the workgroup size the host would choose). k_color_small, queued behind the census
+// before the host has seen it, only runs if this holds - colours handed out against a partition that is about to be
+// replaced would differ from the ones the host-ordered sequence (partition, check, colour) gives - and the host, which
+// evaluates the same function on the same counters, knows whether it ran.
+__host__ __device__ inline bool b2dPartitionSettled(const Counters& c)
+{
+	if (c.nBlocks == 0 || c.nOrphanRows > 0 || c.blkMaxRows > c.blkLanes || c.blkMaxBodies > c.blkLanes || c.nSerialOrphans > 2048) return false;
+	if (c.partitionAge > 240 && (4 * c.nCutRows > c.nLContacts || 2 * c.nLContacts < 900)) return false;
+	return true;
+}
+
+// First statement of every kernel: the start of this kernel is the boundary of the phases the host named in stampMask.
+__device__ __forceinline__ void b2dPhaseStamp(const DW& W)
+{
+	if (W.stampMask != 0u && blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		const unsigned long long t = wall_clock64();
+		for (uint32_t m = W.stampMask; m != 0u; m &= m - 1u) W.st->phaseClock[__ffs((int)m) - 1] = t;
+	}
+}
+#endif
 
 #endif

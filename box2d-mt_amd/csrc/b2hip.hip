@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -218,7 +220,7 @@ struct b2hip_world
 	DevArray<float4> hubDelta;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
-	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies;
+	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies, largeMoves;
 	DevArray<uint64_t> pairKey, pairKey2;
 	DevArray<int2> pairProxy, pairProxy2;
 	DevArray<int> pairFirst, pairRank;
@@ -265,6 +267,7 @@ struct b2hip_world
 	DevArray<float4> b_cutv;
 	int blocksMaxWG = 0;         // co-resident workgroups of k_solve_blocks on this device (0 = do not use it)
 	int sweepMaxWG[3] = { 0, 0, 0 }; // ... of k_blocks_sweep<256 / 512 / 1024>
+	int hubWaves = 8;            // waves of k_large_hub (B2HIP_HUB_WAVES=1: one)
 	int largeHintSteps = 120;    // > 0: the world has had large islands lately (k_color_check / k_block_census run with the island build)
 	int serialOrphansNext = 0;   // DW::serialOrphans of the next step
 	int adoptSticky = 0;
@@ -281,6 +284,10 @@ struct b2hip_world
 	float* h_state;
 	size_t h_stateCap;
 	DState* h_dstate;
+	DState* h_pub = nullptr;     // where k_block_census publishes the island census (pinned, coherent); polled by awaitCensus
+	DState* d_pub = nullptr;     // ... its device address
+	int pubSeq = 0;
+	bool noCensusPoll = false;   // B2HIP_NO_CENSUS_POLL=1: copy + stream synchronisation instead (for comparison)
 	bool blocksThisStep = false; // the large islands of this step went through k_solve_blocks
 
 	Counters last;        // counters of the last completed step
@@ -574,12 +581,26 @@ static int syncCheck(b2hip_world* w, const char* what)
 	return 0;
 }
 
+// b2Profile without events: stampPhase(w, k) asks the NEXT kernel launched on the main stream to note the device clock in
+// DState::phaseClock[k] as it starts (b2dPhaseStamp, first statement of every kernel that takes the DW block).
+static inline void stampPhase(b2hip_world* w, int slot)
+{
+	if (w->profileDetail) w->dw.stampMask |= 1u << slot;
+}
+
+template <typename A, typename... R>
+static inline void stampsTaken(b2hip_world* w, const A&, const R&...)
+{
+	if (std::is_same<typename std::decay<A>::type, DW>::value) w->dw.stampMask = 0u;
+}
+
 // A launch that the runtime refuses (bad configuration, wrong device current, lost context) is reported at once:
 // hipGetLastError needs no synchronisation. With B2HIP_DEBUG the stream is drained after every launch as well.
 #define LAUNCH(w, kernel, grid, block, ...)                                                   \
 	do                                                                                        \
 	{                                                                                         \
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__);     \
+		stampsTaken((w), __VA_ARGS__);                                                        \
 		hipError_t _le = hipGetLastError();                                                   \
 		if (_le != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(#kernel) + " launch: " + hipGetErrorString(_le)); \
 		int _rc = syncCheck((w), #kernel);                                                    \
@@ -590,7 +611,10 @@ static int syncCheck(b2hip_world* w, const char* what)
 #define LAUNCH_ON(w, strm, kernel, grid, block, ...)                                          \
 	do                                                                                        \
 	{                                                                                         \
+		const uint32_t _sm = (w)->dw.stampMask;                                               \
+		if ((strm) != (w)->stream) (w)->dw.stampMask = 0u; /* phase stamps belong to the main stream */ \
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (strm), __VA_ARGS__);          \
+		if ((strm) != (w)->stream) (w)->dw.stampMask = _sm; else stampsTaken((w), __VA_ARGS__); \
 		hipError_t _le = hipGetLastError();                                                   \
 		if (_le != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(#kernel) + " launch: " + hipGetErrorString(_le)); \
 		if ((w)->debugSync)                                                                   \
@@ -642,6 +666,7 @@ static int runSegment(b2hip_world* w, GraphSeg& seg, uint64_t extra, F launches)
 		w->graphCaptures += 1;
 	}
 	HIP_TRY(hipGraphLaunch(seg.exec, w->stream));
+	w->dw.stampMask = 0u; // (taken by the first kernel of the segment: the mask is part of the segment's signature)
 	return 0;
 }
 
@@ -670,6 +695,31 @@ static int readState(b2hip_world* w)
 {
 	HIP_TRY(hipMemcpyAsync(w->h_dstate, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
+	return 0;
+}
+
+// The island census as k_block_census published it under sequence number w->pubSeq (straight into pinned host memory):
+// the host polls the number instead of queueing a copy and synchronising the stream - which also lets the stream run on
+// (k_color_small, queued behind the census) while the host sizes the solver launches.
+static int awaitCensus(b2hip_world* w)
+{
+	volatile int* seq = (volatile int*)&w->h_pub->pubSeq;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (unsigned spins = 1; *seq != w->pubSeq; ++spins)
+	{
+		if ((spins & 0x3fff) == 0)
+		{
+			// (a failed launch or a dead device would leave us here for ever)
+			const hipError_t q = hipStreamQuery(w->stream);
+			if (q != hipSuccess && q != hipErrorNotReady) return setError(B2HIP_ERR_HIP, std::string("island census: ") + hipGetErrorString(q));
+			if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return setError(B2HIP_ERR_HIP, "island census was not published (20 s)");
+		}
+#if defined(__x86_64__)
+		__builtin_ia32_pause();
+#endif
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	memcpy(w->h_dstate, w->h_pub, offsetof(DState, pubSeq));
 	return 0;
 }
 
@@ -725,7 +775,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	}
 	ENS(moveBuf, 2 * np + 64);
 	const size_t gridSize = (size_t)nextPow2(2 * np);
-	ENS(gridCount, gridSize); ENS(gridStart, gridSize + 2); ENS(gridCursor, gridSize); ENS(gridItems, np); ENS(largeProxies, np);
+	ENS(gridCount, gridSize); ENS(gridStart, gridSize + 2); ENS(gridCursor, gridSize); ENS(gridItems, np); ENS(largeProxies, np); ENS(largeMoves, 2 * np + 64);
 	ENS(pairKey, capPairs); ENS(pairKey2, capPairs); ENS(pairProxy, capPairs); ENS(pairProxy2, capPairs);
 	ENS(pairFirst, capPairs + 1); ENS(pairRank, capPairs + 2);
 	const size_t maxScanN = std::max(std::max(nb + 2, gridSize + 2), std::max(cc + 2, capPairs + 2));
@@ -746,14 +796,14 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
-	ENS(stateOut, 12 * nb);
+	ENS(stateOut, 12 * nb + sizeof(DState) / sizeof(float) + 4); // (+ the counters, behind the rows: one copy to the host per step)
 	ENS(consts, 16);
 	ENS(gridBar, 32);
 #undef ENS
-	if (w->h_stateCap < 12 * nb)
+	if (w->h_stateCap < 12 * nb + sizeof(DState) / sizeof(float) + 4)
 	{
 		if (w->h_state) (void)hipHostFree(w->h_state);
-		w->h_stateCap = 12 * nb * 2;
+		w->h_stateCap = 12 * nb * 2 + sizeof(DState) / sizeof(float) + 4;
 		HIP_TRY(hipHostMalloc((void**)&w->h_state, w->h_stateCap * sizeof(float), hipHostMallocDefault));
 	}
 
@@ -770,6 +820,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.smallMaxW = TINY_ISLAND_MAX_W;
 	d.noFreeBodies = getenv("B2HIP_NO_FREE_BODIES") && atoi(getenv("B2HIP_NO_FREE_BODIES")) ? 1 : 0;
 	d.hubSerial = getenv("B2HIP_HUB_SERIAL") && atoi(getenv("B2HIP_HUB_SERIAL")) ? 1 : 0;
+	w->hubWaves = getenv("B2HIP_HUB_WAVES") && atoi(getenv("B2HIP_HUB_WAVES")) == 1 ? 1 : 8; // (1: the one-wave form, for comparison)
 	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
 	d.capContacts = (int)cc;
 	d.capPairs = (int)w->pairKey.cap;
@@ -804,7 +855,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.hubDelta = w->hubDelta.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
-	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p;
+	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p; d.largeMoves = w->largeMoves.p;
 	d.pairKey = w->pairKey.p; d.pairProxy = w->pairProxy.p; d.pairKey2 = w->pairKey2.p; d.pairProxy2 = w->pairProxy2.p;
 	d.pairFirst = w->pairFirst.p; d.pairRank = w->pairRank.p;
 	d.scanTmp = w->scanTmp.p; d.radixHist = w->radixHist.p; d.keepFlag = w->keepFlag.p; d.keepScan = w->keepScan.p;
@@ -1381,7 +1432,7 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	LAUNCH(w, k_part_assign, gridFor(d.nBodies), 256, d, vin, d.pairRank);
 	LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_block_census, 1, 1024, d);
+	LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr, 0);
 	return 0;
 }
 
@@ -1428,17 +1479,31 @@ static int phaseSolve(b2hip_world* w)
 			for (int stage = 0; stage < 3; ++stage) LAUNCH(w, k_block_adopt, gridFor(d.capContacts), 256, d, stage);
 		if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
 		// (colour bookkeeping and block census only matter to large islands: skipped while the world has had none lately)
-		if (largeHint)
-		{
-			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
-			LAUNCH(w, k_block_census, 1, 1024, d);
-		}
+		if (largeHint) LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
 		return 0;
 	});
 	if (rc) return rc;
 
 	// the host needs the island census to size the solver launches
-	rc = readState(w);
+	bool colorSmallQueued = false;
+	if (largeHint)
+	{
+		// (k_block_census is not part of the captured segment: it carries the sequence number of its publication)
+		const bool poll = !w->noCensusPoll;
+		w->pubSeq = (w->pubSeq + 1) & 0x3fffffff;
+		LAUNCH(w, k_block_census, 1, 1024, d, poll ? w->d_pub : (DState*)nullptr, w->pubSeq);
+		if (poll)
+		{
+			// what the host would launch next in the usual case (a few new contacts on a settled pile to colour, a colour class
+			// to compact) goes behind the census at once and runs while the host is busy with it; the kernel looks at the same
+			// counters and returns if the case is another one
+			if (forceLarge != 2) { LAUNCH(w, k_color_small, 1, 1024, d, 1); colorSmallQueued = true; }
+			rc = awaitCensus(w);
+			if (rc == 0 && !b2dPartitionSettled(w->h_dstate->c)) colorSmallQueued = false; // (it saw the same and returned)
+		}
+		else rc = readState(w);
+	}
+	else rc = readState(w);
 	if (rc) return rc;
 	Counters c = w->h_dstate->c;
 	if (c.nLIslands > 0)
@@ -1447,7 +1512,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			// the first large island after a while: run what was skipped, look again
 			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
-			LAUNCH(w, k_block_census, 1, 1024, d);
+			LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr, 0);
 			rc = readState(w);
 			if (rc) return rc;
 			c = w->h_dstate->c;
@@ -1494,6 +1559,7 @@ static int phaseSolve(b2hip_world* w)
 			HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.blkLanes, &lanes, sizeof(int), hipMemcpyHostToDevice, w->stream));
 			rc = partitionLargeIslands(w, target);
 			if (rc) return rc;
+			colorSmallQueued = false; // (the colours are checked against the new partition: what is open after that is new work)
 			rc = readState(w);
 			if (rc) return rc;
 			c = w->h_dstate->c;
@@ -1509,7 +1575,7 @@ static int phaseSolve(b2hip_world* w)
 		}
 	}
 
-	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[4], w->stream));
+	stampPhase(w, 4);
 	const bool exactLarge = forceLarge == 2;
 	const bool hasHubs = !exactLarge && (c.maxDegree > HUB_DEGREE || c.nSerialOrphans > 0); // (anything for k_large_hub)
 	// Small and large islands share nothing (different bodies, contacts, island tables): when both tiers are present the
@@ -1529,7 +1595,7 @@ static int phaseSolve(b2hip_world* w)
 			HIP_TRY(hipStreamWaitEvent(ss, w->evFork, 0));
 		}
 		LAUNCH_ON(w, ss, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[5], w->stream));
+		stampPhase(w, 5);
 		if (!exactLarge)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
@@ -1544,12 +1610,12 @@ static int phaseSolve(b2hip_world* w)
 			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
 		}
 		if (sideStream) HIP_TRY(hipEventRecord(w->evJoin, ss));
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[6], w->stream));
+		stampPhase(w, 6);
 	}
 	else
 	{
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[5], w->stream));
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[6], w->stream));
+		stampPhase(w, 5);
+		stampPhase(w, 6);
 	}
 	int nColors = 0;
 	int nLIslands = c.nLIslands, nLBodies = c.nLBodies, nLContacts = c.nLContacts;
@@ -1597,7 +1663,7 @@ static int phaseSolve(b2hip_world* w)
 			{
 				// the usual case (a few new contacts on a settled island, a colour class to compact): one workgroup colours
 				// them; the resident solver reads the colour count from the device, the launch-per-colour path reads it back
-				LAUNCH(w, k_color_small, 1, 1024, d);
+				if (!colorSmallQueued) LAUNCH(w, k_color_small, 1, 1024, d, 0); // (else: it went out behind the census)
 				if (useResident)
 				{
 					colorsOnDevice = true;
@@ -1649,7 +1715,7 @@ static int phaseSolve(b2hip_world* w)
 			LAUNCH(w, k_hub_fill, gridFor(d.capContacts), 256, d);
 			w->hubSteps += 1;
 		}
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[7], w->stream));
+		stampPhase(w, 7);
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
 		if (useResident)
@@ -1737,6 +1803,13 @@ static int phaseSolve(b2hip_world* w)
 			w->dfEpoch += 1;
 			return 0;
 		};
+		// the hub sweeps: eight waves that fetch their chunks of hub constraints ahead of their turn (one wave on request)
+		auto hubSweepLaunch = [&](int mode, int useGuess) -> int
+		{
+			if (w->hubWaves == 1) LAUNCH(w, k_large_hub<1>, 1, 64, d, mode, useGuess);
+			else LAUNCH(w, k_large_hub<8>, 1, 512, d, mode, useGuess);
+			return 0;
+		};
 		if (useSweep) w->sweepSteps += 1;
 		if (sp.warmStarting)
 		{
@@ -1746,7 +1819,7 @@ static int phaseSolve(b2hip_world* w)
 				for (int col = 0; col < nColors; ++col)
 					if (colorUsed(col)) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
 			}
-			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 0, 0);
+			if (hasHubs) { rc = hubSweepLaunch(0, 0); if (rc) return rc; }
 		}
 		TRACE("warmstart");
 		if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 0);
@@ -1763,7 +1836,7 @@ static int phaseSolve(b2hip_world* w)
 				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 				if (w->debugTrace) TRACE(("vel" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
-			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 1, it > 0 ? 1 : 0);
+			if (hasHubs) { rc = hubSweepLaunch(1, it > 0 ? 1 : 0); if (rc) return rc; }
 		}
 		LAUNCH(w, k_large_store_impulses, gC, 256, d);
 		TRACE("store_impulses");
@@ -1780,7 +1853,7 @@ static int phaseSolve(b2hip_world* w)
 				LAUNCH(w, k_large_position, gK, 256, d, col);
 				if (w->debugTrace) TRACE(("pos" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
-			if (hasHubs) LAUNCH(w, k_large_hub, 1, 64, d, 2, it > 0 ? 1 : 0);
+			if (hasHubs) { rc = hubSweepLaunch(2, it > 0 ? 1 : 0); if (rc) return rc; }
 			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
 			LAUNCH(w, k_large_pos_end, 1, 256, d);
 		}
@@ -1790,12 +1863,12 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_large_sleep, gB, 256, d, sp);
 		TRACE("sleep");
 		if (sideStream) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[8], w->stream));
+		stampPhase(w, 8);
 	}
 	else
 	{
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[7], w->stream));
-		if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[8], w->stream));
+		stampPhase(w, 7);
+		stampPhase(w, 8);
 	}
 	w->last.nSIslands = c.nSIslands;
 	w->last.nFreeIslands = c.nFreeIslands;
@@ -1998,9 +2071,10 @@ static int downloadState(b2hip_world* w)
 	DW& d = w->dw;
 	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, w->def.auto_clear_forces, (const int*)w->gridBar.p);
 	const size_t nb = w->bodies.size();
-	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-	HIP_TRY(hipMemcpyAsync(w->h_dstate, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost, w->stream));
+	// (k_end_step put the counters behind the state rows: one copy)
+	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
+	memcpy(w->h_dstate, w->h_state + nb * 10, sizeof(DState));
 	return 0;
 }
 
@@ -2212,6 +2286,15 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 		b2hip_world_destroy(w);
 		return setError(B2HIP_ERR_HIP, "hipHostMalloc failed");
 	}
+	// (written by a kernel, polled by the host: mapped and coherent)
+	if (hipHostMalloc((void**)&w->h_pub, sizeof(DState), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+		hipHostGetDevicePointer((void**)&w->d_pub, w->h_pub, 0) != hipSuccess)
+	{
+		b2hip_world_destroy(w);
+		return setError(B2HIP_ERR_HIP, "hipHostMalloc (coherent) failed");
+	}
+	memset(w->h_pub, 0, sizeof(DState));
+	w->noCensusPoll = getenv("B2HIP_NO_CENSUS_POLL") && atoi(getenv("B2HIP_NO_CENSUS_POLL"));
 	int rc = ensureCapacity(w, 0);
 	if (rc == 0 && hipStreamSynchronize(w->stream) != hipSuccess) rc = setError(B2HIP_ERR_HIP, "stream sync failed");
 	if (rc)
@@ -2256,7 +2339,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
-	w->largeProxies.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
+	w->largeProxies.release(); w->largeMoves.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
 	w->filterPairs.release();
 	w->d_editOps.release();
 	w->b_order.release(); w->orderBody.release(); w->bigRoots.release();
@@ -2268,6 +2351,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->keepFlag.release(); w->keepScan.release(); w->scanTmp4.release(); w->scanFlags.release(); w->stateOut.release(); w->consts.release();
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
+	if (w->h_pub) (void)hipHostFree(w->h_pub);
 	for (int i = 0; i < 13; ++i)
 		if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
 	for (size_t i = 0; i < w->ktEvents.size(); ++i) (void)hipEventDestroy(w->ktEvents[i]);
@@ -2850,13 +2934,16 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	// zero the per-step counters (keep nContacts / nMoves / cur)
 	Counters zero;
 	memset(&zero, 0, sizeof(zero));
+	// (b2Profile::step is the one figure that comes from events: it includes the read-back behind the last kernel)
+	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
+	w->dw.stampMask = 0u;
 	LAUNCH(w, k_step_begin, 1, 64, w->dw, w->gridBar.p);
 	w->toiCountersFresh = true;
 	rc = applyPendingFilters(w);
 	if (rc) return rc;
 	rc = applyEditOps(w, false); // (after k_step_begin: the end events of destroyed contacts belong to this step's list)
 	if (rc) return rc;
-	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
+	stampPhase(w, 0);
 	// b2World.cpp:1628-1639: new fixtures -> find their contacts before colliding
 	if (w->newFixture)
 	{
@@ -2864,7 +2951,7 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 		if (rc) return rc;
 		w->newFixture = false;
 	}
-	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[1], w->stream));
+	stampPhase(w, 1);
 	return 0;
 }
 
@@ -3368,7 +3455,7 @@ static int collideImpl(b2hip_world* w)
 			if (rc) return rc;
 		}
 	}
-	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[2], w->stream));
+	stampPhase(w, 2);
 	return 0;
 }
 
@@ -3389,10 +3476,10 @@ static int solveImpl(b2hip_world* w)
 	}
 	else
 	{
-		for (int k = 4; k <= 8 && w->profileDetail; ++k) HIP_TRY(hipEventRecord(w->ev[k], w->stream));
+		for (int k = 4; k <= 8; ++k) stampPhase(w, k);
 	}
 	if (w->postSolveOn && w->sp.dt > 0.0f) LAUNCH(w, k_postsolve_gather, gridFor(w->dw.capContacts), 256, w->dw);
-	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[3], w->stream));
+	stampPhase(w, 3);
 	return 0;
 }
 
@@ -3411,7 +3498,7 @@ static int syncFixturesImpl(b2hip_world* w)
 		int rc = phaseSyncFixtures(w);
 		if (rc) return rc;
 	}
-	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[9], w->stream));
+	stampPhase(w, 9);
 	return 0;
 }
 
@@ -3430,7 +3517,7 @@ static int findNewContactsImpl(b2hip_world* w)
 		int rc = findNewContactsGraph(w);
 		if (rc) return rc;
 	}
-	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[10], w->stream));
+	stampPhase(w, 10);
 	return 0;
 }
 
@@ -3454,7 +3541,7 @@ static int solveToiImpl(b2hip_world* w)
 		int rc = phaseToi(w);
 		if (rc) return rc;
 	}
-	if (w->profileDetail) HIP_TRY(hipEventRecord(w->ev[12], w->stream));
+	stampPhase(w, 12);
 	w->toiEventValid = true;
 	return 0;
 }
@@ -3663,24 +3750,20 @@ static int stepEndImpl(b2hip_world* w)
 	(void)hipEventElapsedTime(&ms, w->ev[0], w->ev[11]); p[0] = ms;                  // step
 	if (w->profileDetail)
 	{
-	(void)hipEventElapsedTime(&ms, w->ev[1], w->ev[2]); p[1] = ms;                   // collide
-	(void)hipEventElapsedTime(&ms, w->ev[2], w->ev[3]); p[2] = ms;                   // solve (islands + solver)
-	(void)hipEventElapsedTime(&ms, w->ev[2], w->ev[4]); p[3] = ms;                   // solveTraversal = island build
-	float small = 0.0f, large = 0.0f, dfs = 0.0f, color = 0.0f;
-	(void)hipEventElapsedTime(&dfs, w->ev[4], w->ev[5]);
-	(void)hipEventElapsedTime(&small, w->ev[5], w->ev[6]);
-	(void)hipEventElapsedTime(&color, w->ev[6], w->ev[7]);
-	(void)hipEventElapsedTime(&large, w->ev[7], w->ev[8]);
+	// the other figures: device clock (10 ns ticks) at the start of the first kernel of each phase (stampPhase)
+	const unsigned long long* pc = w->h_dstate->phaseClock;
+	auto span = [pc](int a, int b) -> float { return pc[b] > pc[a] ? 1.0e-5f * (float)(pc[b] - pc[a]) : 0.0f; };
+	p[1] = span(1, 2);                                                           // collide
+	p[2] = span(2, 3);                                                           // solve (islands + solver)
+	p[3] = span(2, 4);                                                           // solveTraversal = island build
+	const float dfs = span(4, 5), small = span(5, 6), color = span(6, 7), large = span(7, 8);
 	p[3] += dfs + color;
 	p[5] = small + large;                                                        // solver kernels (init+velocity+position)
-	float bp0 = 0.0f, bp1 = 0.0f, bpTop = 0.0f;
-	(void)hipEventElapsedTime(&bpTop, w->ev[0], w->ev[1]);
-	(void)hipEventElapsedTime(&bp0, w->ev[3], w->ev[9]);
-	(void)hipEventElapsedTime(&bp1, w->ev[9], w->ev[10]);
+	const float bpTop = span(0, 1), bp0 = span(3, 9), bp1 = span(9, 10);
 	p[10] = bp0;                                                                 // broadphaseSyncFixtures
 	p[11] = bp1 + bpTop;                                                         // broadphaseFindContacts
 	p[9] = bp0 + bp1 + bpTop;                                                    // broadphase
-	if (w->toiEventValid) { (void)hipEventElapsedTime(&ms, w->ev[10], w->ev[12]); p[7] = ms; }  // solveTOI
+	if (w->toiEventValid) p[7] = span(10, 12);                                   // solveTOI
 	w->solverMs = small + large;
 	if (w->blocksThisStep && w->h_dstate->stamps[4] > 0)
 	{
@@ -4514,6 +4597,14 @@ int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* tot
 	if (total_ms) *total_ms = w->ktMs;
 	if (launches) *launches = w->ktLaunches;
 	if (algorithmic_bytes) *algorithmic_bytes = w->ktBytes;
+	return 0;
+}
+
+// (diagnostics, not part of include/b2hip.h: the device clock stamps around the mid-step census read-back, in 10 ns ticks)
+int b2hip_debug_gap_clocks(b2hip_world* w, unsigned long long out[4])
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	for (int k = 0; k < 4; ++k) out[k] = w->h_dstate->gapClock[k];
 	return 0;
 }
 

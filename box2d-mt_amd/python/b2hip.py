@@ -268,6 +268,12 @@ class World:
             self.L.b2hip_world_destroy(self.p)
             self.p = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __enter__(self):
         return self
 

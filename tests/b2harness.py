@@ -188,6 +188,14 @@ class World:
             self.L.b2h_destroy(self.ptr)
             self.ptr = None
 
+    def __del__(self):
+        # a test that fails (or forgets) must not keep its world: on the GPU a world is two streams, and a pytest process
+        # that piles them up leaves the queues of other processes (the torchrun self-tests) waiting for a slot
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __enter__(self):
         return self
 

@@ -497,6 +497,32 @@ def test_hub_fixed_point_sweep_equals_the_lane_after_lane_sweep(amd, default_mod
     assert np.abs(b1[:, :2] - b2[:, :2]).max() < 1e-3, "poses differ by %g" % np.abs(b1[:, :2] - b2[:, :2]).max()
 
 
+def test_hub_sweep_is_the_same_for_any_number_of_waves(amd, default_mode, monkeypatch):
+    """k_large_hub<8>: eight waves fetch their chunks of 64 hub constraints ahead and take their turns on the hub row one
+    after the other (the row is handed on through LDS; a partner row written by an earlier chunk is read again). Every chunk
+    computes from the inputs the one-wave form (B2HIP_HUB_WAVES=1) gives it: bit-identical states, step by step. The Tumbler
+    with 3 600 boxes (two to four chunks per sweep, partners shared between chunks at the container's corners) and with
+    10 000 (a dozen chunks: every wave has a turn, some two); both in the fixed-point and in the lane-after-lane form."""
+    def run(n, steps, waves, serial):
+        monkeypatch.setenv("B2HIP_HUB_WAVES", str(waves))
+        if serial:
+            monkeypatch.setenv("B2HIP_HUB_SERIAL", "1")
+        else:
+            monkeypatch.delenv("B2HIP_HUB_SERIAL", raising=False)
+        w = amd.world(bh.TUMBLER, n, 0)
+        out = []
+        for _ in range(steps):
+            w.step(1)
+            out.append((bh.fnv1a64(w.bodies()), w.contact_count))
+        w.close()
+        return out
+    for n, steps, serial in [(60, 120, False), (100, 160, False), (60, 60, True)]:
+        one = run(n, steps, 1, serial)
+        eight = run(n, steps, 8, serial)
+        first = next((i for i in range(steps) if one[i] != eight[i]), None)
+        assert first is None, "Tumbler %d x %d (serial %s): eight waves differ from one at step %d" % (n, n, serial, first)
+
+
 def test_sweep_blocks_match_launch_per_colour(amd, default_mode):
     """Large islands with joints or hub bodies: k_blocks_sweep (one launch per sweep over the block partition, between the
     joint walks and the hub sweeps) must reproduce the launch-per-colour kernels bit for bit - same partition, same colours,

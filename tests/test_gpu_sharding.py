@@ -155,6 +155,17 @@ def test_big_islands_are_dealt_round_robin():
         w.close()
 
 
+def run_selftest(cmd, root, env):
+    """tools/shard_selftest.py under torchrun. It takes ~15 s; a rank that is still running after 150 s dumps the stack of
+    every thread and exits (B2_SELFTEST_WATCHDOG), so a hang shows where it hangs instead of eating the suite's time."""
+    import gc
+    import subprocess
+    gc.collect()  # (worlds of earlier tests that are only waiting for the collector: their streams go back first)
+    env = dict(env, B2_SELFTEST_WATCHDOG="150")
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0 and "SHARD-SELFTEST OK" in r.stdout, "stdout:\n%s\nstderr:\n%s" % (r.stdout[-3000:], r.stderr[-6000:])
+
+
 def test_sharded_world_over_a_process_group():
     """The driver bench.py --gpus N uses (sharding.ShardedWorld over torch.distributed), two ranks in two processes sharing
     this box's one GPU over gloo (RCCL wants a GPU per rank): every rank holds the unsharded world after every step."""
@@ -166,8 +177,7 @@ def test_sharded_world_over_a_process_group():
     # exact-order mode: what a rank computes for an island must not depend on which other islands it owns (in default mode
     # the block partition of the large islands spans the islands a rank holds, so only the ranks agree with each other)
     env = dict(os.environ, B2HIP_FORCE_LARGE="2")
-    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "SHARD-SELFTEST OK" in r.stdout, "stdout:\n%s\nstderr:\n%s" % (r.stdout[-3000:], r.stderr[-3000:])
+    run_selftest(cmd, root, env)
 
 
 def test_sharded_world_over_a_process_group_default_mode():
@@ -177,5 +187,4 @@ def test_sharded_world_over_a_process_group_default_mode():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29542", os.path.join(root, "tools", "shard_selftest.py"), "--backend", "gloo", "--rows", "40",
            "--pyramids", "5", "--steps", "50", "--no-reference"]
-    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "SHARD-SELFTEST OK" in r.stdout, "stdout:\n%s\nstderr:\n%s" % (r.stdout[-3000:], r.stderr[-3000:])
+    run_selftest(cmd, root, dict(os.environ))

@@ -37,6 +37,10 @@ def build(w, b2hip, rows, pyramids):
 
 
 def main():
+    if os.environ.get("B2_SELFTEST_WATCHDOG"):
+        # (debugging aid: where is every thread after N seconds?)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["B2_SELFTEST_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--rows", type=int, default=40)
