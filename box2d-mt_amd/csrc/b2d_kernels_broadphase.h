@@ -522,37 +522,64 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 }
 
 // ---- end of step -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar)
+// The read-back (b2hip_body_state rows, then the counters) goes straight into the host's pinned buffer `out` - no staging
+// array, no copy behind the kernel: the rows of a workgroup's 256 bodies are transposed through LDS and leave as contiguous
+// 16-byte stores; the workgroup that finishes last appends DState and, last of all, the sequence number the host polls
+// (b2hip.hip: awaitState). Nothing else runs in the step after this kernel: the counters are final.
+__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq)
 {
 	b2dPhaseStamp(W);
+	DState* S = W.st;
 	const int n = W.nBodies;
-	// (the solver's phase stamps travel with the counters: one copy to the host less)
-	if (blockIdx.x == 0)
+	const int tid = (int)threadIdx.x;
+	__shared__ __attribute__((aligned(16))) float s_out[2560];
+	__shared__ int s_last;
+	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256)
 	{
-		if (bar != nullptr && threadIdx.x < 6) W.st->stamps[threadIdx.x] = bar[8 + threadIdx.x];
+		const int i = base + tid;
+		if (i < n)
+		{
+			uint32_t f = W.b_flags[i];
+			if (clearForces) W.b_force[i] = make_float4(0, 0, 0, 0);
+			float4 xf = W.b_xf[i], p = W.b_pos[i], v = W.b_vel[i];
+			float* o = s_out + tid * 10;
+			o[0] = xf.x;
+			o[1] = xf.y;
+			o[2] = p.z;
+			o[3] = v.x;
+			o[4] = v.y;
+			o[5] = v.z;
+			o[6] = p.x;
+			o[7] = p.y;
+			o[8] = __uint_as_float(f & 0x7fu);
+			o[9] = p.w;
+		}
 		__syncthreads();
-		// the counters travel behind the state rows (nothing else runs in this step: they are final)
-		const int* src = (const int*)W.st;
-		int* dst = (int*)(W.stateOut + (size_t)n * 10);
-		for (int k = threadIdx.x; k < (int)(sizeof(DState) / sizeof(int)); k += blockDim.x) dst[k] = src[k];
+		const int cnt = (n - base < 256 ? n - base : 256) * 10; // floats of this tile; base * 40 bytes is 16-byte aligned
+		float* dst = out + (size_t)base * 10;
+		for (int q = tid; q < cnt / 4; q += 256) ((float4*)dst)[q] = ((const float4*)s_out)[q];
+		for (int q = (cnt / 4) * 4 + tid; q < cnt; q += 256) dst[q] = s_out[q];
+		__syncthreads();
 	}
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-	{
-		uint32_t f = W.b_flags[i];
-		if (clearForces) W.b_force[i] = make_float4(0, 0, 0, 0);
-		float4 xf = W.b_xf[i], p = W.b_pos[i], v = W.b_vel[i];
-		float* o = W.stateOut + (size_t)i * 10;
-		o[0] = xf.x;
-		o[1] = xf.y;
-		o[2] = p.z;
-		o[3] = v.x;
-		o[4] = v.y;
-		o[5] = v.z;
-		o[6] = p.x;
-		o[7] = p.y;
-		o[8] = __uint_as_float(f & 0x7fu);
-		o[9] = p.w;
-	}
+	// ---- the last workgroup: counters, then the sequence number ---------------------------------------------------------
+	__threadfence_system();
+	__syncthreads();
+	if (tid == 0) s_last = atomicAdd(&S->c.endBlocksDone, 1) == (int)gridDim.x - 1 ? 1 : 0;
+	__syncthreads();
+	if (!s_last) return;
+	if (tid == 0) S->c.endBlocksDone = 0;
+	// (the solver's phase stamps travel with the counters)
+	if (bar != nullptr && tid < 6) S->stamps[tid] = bar[8 + tid];
+	if (tid == 0) S->phaseClock[13] = wall_clock64(); // end of the step, read-back included
+	__threadfence();
+	__syncthreads();
+	const int* src = (const int*)S;
+	int* tail = (int*)(out + (size_t)n * 10);
+	for (int k = tid; k < (int)(offsetof(DState, pubSeq) / sizeof(int)); k += 256)
+		__hip_atomic_store(&tail[k], __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	__threadfence_system();
+	__syncthreads();
+	if (tid == 0) __hip_atomic_store(&tail[offsetof(DState, pubSeq) / sizeof(int)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 #endif

@@ -156,6 +156,7 @@ struct Counters
 	int nRemoteIslands;  // islands of this step that another rank solves
 	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
 	int compactBlocksDone; // workgroups of k_compact_contacts that have finished (the last one switches the contact buffers)
+	int endBlocksDone;     // ... of k_end_step (the last one appends the counters to the read-back)
 	int nFreeIslands;    // one-body islands without contacts or joints, stepped by k_island_classify itself
 	int nSmallJointed;   // small islands of this step that hold joints (none: the lean k_solve_small runs)
 };

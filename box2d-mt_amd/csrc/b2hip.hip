@@ -281,13 +281,16 @@ struct b2hip_world
 	int blockSteps = 0;          // steps solved by k_solve_blocks (diagnostics)
 
 	// pinned host buffers
-	float* h_state;
+	float* h_state;             // pinned, coherent: k_end_step writes the read-back into it (d_hstate = its device address)
+	float* d_hstate = nullptr;
+	int stateSeq = 0;            // sequence number of the last read-back asked for (awaitState)
 	size_t h_stateCap;
 	DState* h_dstate;
 	DState* h_pub = nullptr;     // where k_block_census publishes the island census (pinned, coherent); polled by awaitCensus
 	DState* d_pub = nullptr;     // ... its device address
 	int pubSeq = 0;
 	bool noCensusPoll = false;   // B2HIP_NO_CENSUS_POLL=1: copy + stream synchronisation instead (for comparison)
+	bool noStatePoll = false;    // B2HIP_NO_STATE_POLL=1: the same for the read-back at the end of the step
 	bool blocksThisStep = false; // the large islands of this step went through k_solve_blocks
 
 	Counters last;        // counters of the last completed step
@@ -804,7 +807,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	{
 		if (w->h_state) (void)hipHostFree(w->h_state);
 		w->h_stateCap = 12 * nb * 2 + sizeof(DState) / sizeof(float) + 4;
-		HIP_TRY(hipHostMalloc((void**)&w->h_state, w->h_stateCap * sizeof(float), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void**)&w->h_state, w->h_stateCap * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostGetDevicePointer((void**)&w->d_hstate, w->h_state, 0));
 	}
 
 	DW& d = w->dw;
@@ -1190,6 +1194,8 @@ static int applyPendingFilters(b2hip_world* w)
 
 // Applies the queued contact-array ops (b2d_kernels_edit.h) in call order, then compacts the contact array if contacts
 // were destroyed. Called by the step right after its counters are zeroed, and by whoever reads the contacts between steps.
+static int downloadState(b2hip_world* w, int clearForces);
+
 static int applyEditOps(b2hip_world* w, bool betweenSteps)
 {
 	if (w->editOps.empty()) return 0;
@@ -1210,8 +1216,8 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 		{
 			// destroying a touching contact wakes its bodies (b2Contact::Destroy, b2Contact.cpp:105-111): the host rows are
 			// read again from the device (every edit made so far has been uploaded by the caller)
-			LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0, (const int*)nullptr);
-			HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, w->bodies.size() * 10 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+			rc = downloadState(w, 0);
+			if (rc) return rc;
 			w->stateCount = w->bodies.size();
 			++w->mirrorEpoch;
 		}
@@ -1584,22 +1590,18 @@ static int phaseSolve(b2hip_world* w)
 	// whose cost is instruction fetch from a cold cache (~2 us per KB of code executed: 83 us for a dozen free bodies next
 	// to the 10k-body pyramid) - time the large solver's resident grid leaves plenty of idle CUs for.
 	bool sideStream = false;
-	if (c.nSIslands > 0)
+	bool smallDeferred = false;
+	// (the launches of the small-island chain; on the side stream they are issued AFTER the large-island solver's own
+	// launches - the solver is what the step waits for, and every launch the host makes first delays it by ~3 us)
+	auto launchSmallIslands = [&](hipStream_t ss) -> int
 	{
-		sideStream = !exactLarge && c.nLIslands > 0 && !w->debugTrace && !w->kernelTimingLaunches && !w->noSideStream;
-		hipStream_t ss = w->stream;
-		if (sideStream)
-		{
-			ss = w->stream2;
-			HIP_TRY(hipEventRecord(w->evFork, w->stream));
-			HIP_TRY(hipStreamWaitEvent(ss, w->evFork, 0));
-		}
+		if (sideStream) HIP_TRY(hipStreamWaitEvent(ss, w->evFork, 0));
 		LAUNCH_ON(w, ss, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
-		stampPhase(w, 5);
+		if (!sideStream) stampPhase(w, 5);
 		if (!exactLarge)
 		{
 			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
-			if (timeIt) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 2; }
+			if (timeIt) { int rck = ktRecord(w); if (rck) return rck; w->ktKind = 2; }
 			if (c.nSmallJointed > 0)
 			{
 				if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH_ON(w, ss, (k_solve_small<TINY_CHUNK_LANES, true>), c.nChunks, TINY_CHUNK_LANES, d, sp);
@@ -1607,10 +1609,28 @@ static int phaseSolve(b2hip_world* w)
 			}
 			else if (c.chunkLanes == TINY_CHUNK_LANES) LAUNCH_ON(w, ss, (k_solve_small<TINY_CHUNK_LANES, false>), c.nChunks, TINY_CHUNK_LANES, d, sp);
 			else LAUNCH_ON(w, ss, (k_solve_small<SMALL_CHUNK_LANES, false>), c.nChunks, SMALL_CHUNK_LANES, d, sp);
-			if (timeIt) { rc = ktRecord(w); if (rc) return rc; }
+			if (timeIt) { int rck = ktRecord(w); if (rck) return rck; }
 		}
 		if (sideStream) HIP_TRY(hipEventRecord(w->evJoin, ss));
-		stampPhase(w, 6);
+		else stampPhase(w, 6);
+		return 0;
+	};
+	if (c.nSIslands > 0)
+	{
+		sideStream = !exactLarge && c.nLIslands > 0 && !w->debugTrace && !w->kernelTimingLaunches && !w->noSideStream;
+		if (sideStream)
+		{
+			// fork here (the side stream needs the island build, nothing of the large-island solver); launches later
+			HIP_TRY(hipEventRecord(w->evFork, w->stream));
+			smallDeferred = true;
+			stampPhase(w, 5);
+			stampPhase(w, 6);
+		}
+		else
+		{
+			rc = launchSmallIslands(w->stream);
+			if (rc) return rc;
+		}
 	}
 	else
 	{
@@ -1766,9 +1786,11 @@ static int phaseSolve(b2hip_world* w)
 #endif
 			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
 			w->persistSteps += 1;
+			if (smallDeferred) { smallDeferred = false; rc = launchSmallIslands(w->stream2); if (rc) return rc; }
 		}
 		else
 		{
+		if (smallDeferred) { smallDeferred = false; rc = launchSmallIslands(w->stream2); if (rc) return rc; }
 		TRACE("before_integrate");
 		if (w->debugTrace)
 		{
@@ -2066,16 +2088,50 @@ static int phaseToiSync(b2hip_world* w)
 	return toiSerial(w);
 }
 
-static int downloadState(b2hip_world* w)
+// The read-back of a step (and of a between-step destroy): k_end_step writes the state rows and, behind them, the counters
+// straight into the pinned host buffer, its last workgroup the sequence number - which the host polls. No copy, no stream
+// synchronisation (the kernel is the last thing on the stream).
+static int awaitState(b2hip_world* w, size_t nb)
+{
+	const DState* tail = (const DState*)(w->h_state + nb * 10);
+	volatile const int* seq = (volatile const int*)&tail->pubSeq;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (unsigned spins = 1; *seq != w->stateSeq; ++spins)
+	{
+		if ((spins & 0x3fff) == 0)
+		{
+			const hipError_t q = hipStreamQuery(w->stream);
+			if (q != hipSuccess && q != hipErrorNotReady) return setError(B2HIP_ERR_HIP, std::string("state read-back: ") + hipGetErrorString(q));
+			if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return setError(B2HIP_ERR_HIP, "state read-back was not published (30 s)");
+		}
+#if defined(__x86_64__)
+		__builtin_ia32_pause();
+#endif
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	memcpy(w->h_dstate, (const void*)tail, offsetof(DState, pubSeq));
+	return 0;
+}
+
+static int downloadState(b2hip_world* w, int clearForces)
 {
 	DW& d = w->dw;
-	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, w->def.auto_clear_forces, (const int*)w->gridBar.p);
 	const size_t nb = w->bodies.size();
-	// (k_end_step put the counters behind the state rows: one copy)
-	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
-	HIP_TRY(hipStreamSynchronize(w->stream));
-	memcpy(w->h_dstate, w->h_state + nb * 10, sizeof(DState));
-	return 0;
+	w->stateSeq = (w->stateSeq + 1) & 0x3fffffff;
+	if (w->stateSeq == 0) w->stateSeq = 1;
+	((DState*)(w->h_state + nb * 10))->pubSeq = 0; // (whatever was there: not this number)
+	const int clear = clearForces < 0 ? w->def.auto_clear_forces : clearForces;
+	if (w->noStatePoll)
+	{
+		// B2HIP_NO_STATE_POLL=1, for comparison: into the device staging array, one copy, stream synchronisation
+		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq);
+		HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		memcpy(w->h_dstate, w->h_state + nb * 10, offsetof(DState, pubSeq));
+		return 0;
+	}
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq);
+	return awaitState(w, nb);
 }
 
 static void refreshMirror(b2hip_world* w)
@@ -2295,6 +2351,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	}
 	memset(w->h_pub, 0, sizeof(DState));
 	w->noCensusPoll = getenv("B2HIP_NO_CENSUS_POLL") && atoi(getenv("B2HIP_NO_CENSUS_POLL"));
+	w->noStatePoll = getenv("B2HIP_NO_STATE_POLL") && atoi(getenv("B2HIP_NO_STATE_POLL"));
 	int rc = ensureCapacity(w, 0);
 	if (rc == 0 && hipStreamSynchronize(w->stream) != hipSuccess) rc = setError(B2HIP_ERR_HIP, "stream sync failed");
 	if (rc)
@@ -2934,9 +2991,8 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	// zero the per-step counters (keep nContacts / nMoves / cur)
 	Counters zero;
 	memset(&zero, 0, sizeof(zero));
-	// (b2Profile::step is the one figure that comes from events: it includes the read-back behind the last kernel)
-	HIP_TRY(hipEventRecord(w->ev[0], w->stream));
-	w->dw.stampMask = 0u;
+	// (b2Profile::step: from the start of this kernel to the end of k_end_step, slots 14 and 13)
+	w->dw.stampMask = 1u << 14;
 	LAUNCH(w, k_step_begin, 1, 64, w->dw, w->gridBar.p);
 	w->toiCountersFresh = true;
 	rc = applyPendingFilters(w);
@@ -3556,7 +3612,7 @@ int b2hip_solve_toi(b2hip_world* w)
 
 static int stepEndImpl(b2hip_world* w)
 {
-	int rc = downloadState(w);
+	int rc = downloadState(w, -1);
 	if (rc) return rc;
 	// optimistic small-sort path overflowed (or the pair buffer itself): finish the pair update with the radix path (after
 	// growing the buffer and searching again), then read back again
@@ -3591,7 +3647,7 @@ static int stepEndImpl(b2hip_world* w)
 				rc = phaseToiSync(w);
 				if (rc) return rc;
 			}
-			rc = downloadState(w);
+			rc = downloadState(w, -1);
 			if (rc) return rc;
 		}
 	}
@@ -3618,7 +3674,7 @@ static int stepEndImpl(b2hip_world* w)
 		if (rc) return rc;
 		w->toiFallbacks += 1;
 		w->toiSyncSticky = 16;
-		rc = downloadState(w);
+		rc = downloadState(w, -1);
 		if (rc) return rc;
 	}
 	// A contact created inside a TOI sub-step did not fit the array (whatever path ran last, fallbacks included): never a
@@ -3638,7 +3694,7 @@ static int stepEndImpl(b2hip_world* w)
 		if (w->toiChains)
 		{
 			// (the parallel paths report through toiUnsafe: take their serial fallback here as well)
-			rc = downloadState(w);
+			rc = downloadState(w, -1);
 			if (rc) return rc;
 			if (w->h_dstate->c.toiUnsafe != 0)
 			{
@@ -3648,7 +3704,7 @@ static int stepEndImpl(b2hip_world* w)
 				w->toiFallbacks += 1;
 			}
 		}
-		rc = downloadState(w);
+		rc = downloadState(w, -1);
 		if (rc) return rc;
 	}
 	w->postSolve.clear();
@@ -3710,8 +3766,8 @@ static int stepEndImpl(b2hip_world* w)
 			}
 		}
 	}
-	HIP_TRY(hipEventRecord(w->ev[11], w->stream));
-	HIP_TRY(hipStreamSynchronize(w->stream));
+	// (no synchronisation here: the read-back has arrived - awaitState - and k_end_step was the last thing on the stream)
+	if (w->debugSync) HIP_TRY(hipStreamSynchronize(w->stream));
 	refreshMirror(w);
 	const Counters& c = w->h_dstate->c;
 	w->lastContacts = c.nContacts;
@@ -3747,7 +3803,10 @@ static int stepEndImpl(b2hip_world* w)
 	float ms = 0.0f;
 	float* p = w->profile;
 	memset(p, 0, sizeof(float) * 13);
-	(void)hipEventElapsedTime(&ms, w->ev[0], w->ev[11]); p[0] = ms;                  // step
+	{
+		const unsigned long long* pc0 = w->h_dstate->phaseClock;
+		p[0] = pc0[13] > pc0[14] ? 1.0e-5f * (float)(pc0[13] - pc0[14]) : 0.0f;      // step (device clock, read-back included)
+	}
 	if (w->profileDetail)
 	{
 	// the other figures: device clock (10 ns ticks) at the start of the first kernel of each phase (stampPhase)
