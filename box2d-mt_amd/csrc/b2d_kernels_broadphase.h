@@ -534,6 +534,7 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	const int tid = (int)threadIdx.x;
 	__shared__ __attribute__((aligned(16))) float s_out[2560];
 	__shared__ int s_last;
+	const bool toiEvents = S->c.nToiEvents != 0;
 	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256)
 	{
 		const int i = base + tid;
@@ -541,6 +542,8 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 		{
 			uint32_t f = W.b_flags[i];
 			if (clearForces) W.b_force[i] = make_float4(0, 0, 0, 0);
+			// b2ClearBodySolveTOIFlags (b2World.cpp:239-259, k_toi_clear): sweeps go back to alpha0 = 0 for the next step
+			if (toiEvents) W.b_pos0[i].w = 0.0f;
 			float4 xf = W.b_xf[i], p = W.b_pos[i], v = W.b_vel[i];
 			float* o = s_out + tid * 10;
 			o[0] = xf.x;

@@ -64,11 +64,46 @@ __global__ __launch_bounds__(256) void k_toi_groups_begin(DW W)
 	}
 }
 
+// Everything the chains may touch, copied once (contacts go to the idle half of the double buffer).
+__device__ __forceinline__ void toiSnapshotSave(const DW& W)
+{
+	DState* S = W.st;
+	const int nC = S->c.nContacts;
+	const ContactArrays& A = W.ca[S->cur];
+	const ContactArrays& B = W.ca[1 - S->cur];
+	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t0 == 0)
+	{
+		S->c.nContactsSnap = S->c.nContacts;
+		S->c.nToiOrderSnap = S->c.nToiOrder;
+	}
+	for (int i = t0; i < W.nBodies; i += stride)
+	{
+		W.snapBody[5 * (size_t)i + 0] = W.b_pos[i];
+		W.snapBody[5 * (size_t)i + 1] = W.b_pos0[i];
+		W.snapBody[5 * (size_t)i + 2] = W.b_vel[i];
+		W.snapBody[5 * (size_t)i + 3] = W.b_xf[i];
+		W.snapBody[5 * (size_t)i + 4] = make_float4(__uint_as_float(W.b_flags[i]), 0, 0, 0);
+	}
+	for (int p = t0; p < W.nProxies; p += stride) W.snapFat[p] = W.p_fat[p];
+	for (int i = t0; i < nC; i += stride)
+	{
+		B.flags[i] = A.flags[i];
+		B.mat[i] = A.mat[i];
+		B.man0[i] = A.man0[i];
+		B.man1[i] = A.man1[i];
+		B.imp[i] = A.imp[i];
+		B.man3[i] = A.man3[i];
+	}
+}
+
 // The contacts of every chain body, gathered in one pass over the contact array (b_toiGroup = chain index + 1).
-__global__ __launch_bounds__(256) void k_toi_group_contacts(DW W)
+// withSnapshot: the state the chains may touch is saved by the same launch (k_toi_snapshot, restore = 0, was one more).
+__global__ __launch_bounds__(256) void k_toi_group_contacts(DW W, int withSnapshot)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
+	if (withSnapshot && S->c.nToiList != 0) toiSnapshotSave(W);
 	if (S->c.toiUnsafe || S->c.nToiGroups == 0) return;
 	const int nC = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
@@ -86,7 +121,7 @@ __global__ __launch_bounds__(256) void k_toi_group_contacts(DW W)
 	}
 }
 
-// Everything the chains may touch, copied once (contacts go to the idle half of the double buffer).
+// restore = 0: toiSnapshotSave as a launch of its own; 1: everything back.
 __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 {
 	b2dPhaseStamp(W);
@@ -98,29 +133,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 	if (!restore && S->c.nToiList == 0) return; // launched before the host knows whether any impact is pending
 	if (!restore)
 	{
-		if (t0 == 0)
-		{
-			S->c.nContactsSnap = S->c.nContacts;
-			S->c.nToiOrderSnap = S->c.nToiOrder;
-		}
-		for (int i = t0; i < W.nBodies; i += stride)
-		{
-			W.snapBody[5 * (size_t)i + 0] = W.b_pos[i];
-			W.snapBody[5 * (size_t)i + 1] = W.b_pos0[i];
-			W.snapBody[5 * (size_t)i + 2] = W.b_vel[i];
-			W.snapBody[5 * (size_t)i + 3] = W.b_xf[i];
-			W.snapBody[5 * (size_t)i + 4] = make_float4(__uint_as_float(W.b_flags[i]), 0, 0, 0);
-		}
-		for (int p = t0; p < W.nProxies; p += stride) W.snapFat[p] = W.p_fat[p];
-		for (int i = t0; i < nC; i += stride)
-		{
-			B.flags[i] = A.flags[i];
-			B.mat[i] = A.mat[i];
-			B.man0[i] = A.man0[i];
-			B.man1[i] = A.man1[i];
-			B.imp[i] = A.imp[i];
-			B.man3[i] = A.man3[i];
-		}
+		toiSnapshotSave(W);
 	}
 	else
 	{

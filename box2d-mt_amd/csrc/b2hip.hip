@@ -1982,9 +1982,8 @@ static int phaseToi(b2hip_world* w)
 	LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
 	const int haveGrid = w->toiGridSticky > 0 ? 1 : 0;
 	LAUNCH(w, k_toi_groups_begin, gridFor(std::min(d.capContacts, 1 << 16)), 256, d);
-	LAUNCH(w, k_toi_group_contacts, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
-		w->toiSnapshotTaken = true;
+	LAUNCH(w, k_toi_group_contacts, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 1); // (+ the snapshot)
+	w->toiSnapshotTaken = true;
 	if (haveGrid)
 	{
 		int rc = toiBuildIndexes(w, false);
@@ -1992,7 +1991,7 @@ static int phaseToi(b2hip_world* w)
 	}
 	LAUNCH(w, k_toi_chains, 1024, CHAIN_LANES, d, w->sp, haveGrid);
 	LAUNCH(w, k_toi_chains_end, 1, 256, d);
-	LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+	// (k_toi_clear's work is done by k_end_step, which follows)
 	w->toiChains = true;
 	w->toiSpeculative = true;
 	return 0;
@@ -2045,7 +2044,7 @@ static int phaseToiSync(b2hip_world* w)
 		const int groups = std::min(std::min(w->h_dstate->c.nToiList, d.nBodies), (int)TOI_GROUPS_MAX);
 		const int haveGrid = w->toiGridSticky > 0 ? 1 : 0;
 		LAUNCH(w, k_toi_groups_begin, gridFor(w->h_dstate->c.nToiList), 256, d);
-		LAUNCH(w, k_toi_group_contacts, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_toi_group_contacts, gridFor(d.capContacts), 256, d, 0);
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
 		w->toiSnapshotTaken = true;
 		if (haveGrid)
