@@ -405,49 +405,75 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead)
 	__syncthreads();
 	const int n = s_n < COLOR_SMALL_MAX ? s_n : COLOR_SMALL_MAX;
 	if (threadIdx.x == 0) s_left = n;
+	// what a round needs of a constraint, read once (a round used to start with five dependent loads per constraint and pass:
+	// 200 us of the Tumbler's step, where a thousand contacts are new every step)
+	constexpr int PER = COLOR_SMALL_MAX / 1024;
+	int it_s[PER], it_ci[PER], it_a[PER], it_b[PER];
+	uint32_t it_pr[PER];
+	uint64_t it_class[PER];
+	bool it_open[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j)
+	{
+		const int k = (int)threadIdx.x + j * 1024;
+		it_open[j] = false;
+		it_s[j] = it_ci[j] = 0; it_a[j] = it_b[j] = -1; it_pr[j] = 0u; it_class[j] = 0ull;
+		if (k < n)
+		{
+			const int s = W.uncolList[k];
+			it_s[j] = s;
+			it_open[j] = W.li_color[s] < 0;
+			const int ci = W.li_contacts[s];
+			it_ci[j] = ci;
+			const int4 ids = C.ids[ci];
+			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			it_a[j] = nsA ? ids.z : -1;
+			it_b[j] = nsB ? ids.w : -1;
+			it_pr[j] = colorPriority(ci);
+			it_class[j] = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
+		}
+	}
 	__syncthreads();
 	for (int round = 0; round < 4 * MAX_COLORS && s_left > 0; ++round)
 	{
 		if (threadIdx.x == 0) s_colored = 0;
-		for (int k = threadIdx.x; k < n; k += blockDim.x)
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
 		{
-			const int s = W.uncolList[k];
-			if (W.li_color[s] >= 0) continue;
-			const int ci = W.li_contacts[s];
-			const int4 ids = C.ids[ci];
-			const uint32_t pr = colorPriority(ci);
-			if ((W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC) atomicMax(&W.bodyClaim[ids.z], pr);
-			if ((W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC) atomicMax(&W.bodyClaim[ids.w], pr);
+			if (!it_open[j]) continue;
+			if (it_a[j] >= 0) atomicMax(&W.bodyClaim[it_a[j]], it_pr[j]);
+			if (it_b[j] >= 0) atomicMax(&W.bodyClaim[it_b[j]], it_pr[j]);
 		}
 		__syncthreads();
-		for (int k = threadIdx.x; k < n; k += blockDim.x)
+		int colored = 0;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
 		{
-			const int s = W.uncolList[k];
-			if (W.li_color[s] >= 0) continue;
-			const int ci = W.li_contacts[s];
-			const int4 ids = C.ids[ci];
-			const uint32_t pr = colorPriority(ci);
-			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
-			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			if (!it_open[j]) continue;
+			const int A = it_a[j], B = it_b[j];
+			const uint32_t pr = it_pr[j];
 			bool win = true;
-			if (nsA && __hip_atomic_load(&W.bodyClaim[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
-			if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
+			if (A >= 0 && __hip_atomic_load(&W.bodyClaim[A], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
+			if (B >= 0 && __hip_atomic_load(&W.bodyClaim[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 			if (!win) continue;
-			uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
-			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			uint64_t used = it_class[j];
+			if (A >= 0) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[A], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (B >= 0) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
 			if (used == ~0ull) atomicOr(&S->c.overflow, 4);
 			const unsigned long long bit = 1ull << color;
-			if (nsA) { atomicOr((unsigned long long*)&W.bodyColorMask[ids.z], bit); __hip_atomic_store(&W.bodyClaim[ids.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-			if (nsB) { atomicOr((unsigned long long*)&W.bodyColorMask[ids.w], bit); __hip_atomic_store(&W.bodyClaim[ids.w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-			W.li_color[s] = color;
-			C.color[ci] = color;
+			if (A >= 0) { atomicOr((unsigned long long*)&W.bodyColorMask[A], bit); __hip_atomic_store(&W.bodyClaim[A], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			if (B >= 0) { atomicOr((unsigned long long*)&W.bodyColorMask[B], bit); __hip_atomic_store(&W.bodyClaim[B], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			W.li_color[it_s[j]] = color;
+			C.color[it_ci[j]] = color;
 			atomicAdd(&W.colorCount[color], 1);
 			atomicMax(&s_maxColor, color + 1);
 			noteColorUsed(S, color);
-			atomicAdd(&s_colored, 1);
+			it_open[j] = false;
+			++colored;
 		}
+		if (colored) atomicAdd(&s_colored, colored);
 		__syncthreads();
 		if (threadIdx.x == 0) s_left -= s_colored;
 		__syncthreads();
