@@ -565,9 +565,14 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 		__syncthreads();
 	}
 	// ---- the last workgroup: counters, then the sequence number ---------------------------------------------------------
-	__threadfence_system();
+	// (every wave's stores have left; ONE system-scope fence per workgroup - a fence writes the L2 back - then arrive)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
-	if (tid == 0) s_last = atomicAdd(&S->c.endBlocksDone, 1) == (int)gridDim.x - 1 ? 1 : 0;
+	if (tid == 0)
+	{
+		__threadfence_system();
+		s_last = atomicAdd(&S->c.endBlocksDone, 1) == (int)gridDim.x - 1 ? 1 : 0;
+	}
 	__syncthreads();
 	if (!s_last) return;
 	if (tid == 0) S->c.endBlocksDone = 0;

@@ -79,6 +79,50 @@ __device__ __forceinline__ bool isToiCandidate(const DW& W, int proxyA, int prox
 	return includesNonDynamic && neitherThick;
 }
 
+// The reference keeps its TOI-candidate contacts in the first m_toiCount slots of one array and removes a
+// contact by moving the LAST candidate into its slot (b2ContactManager::RemoveFromContactArray, :688-714),
+// destroying in (proxyLow, proxyHigh) order (FinishCollide :388-439). That slot order is the order in which
+// b2World::FindMinToiContact re-synchronises sweeps, so it is mirrored here: ContactArrays::mgr is the slot,
+// toiPos2c its inverse. Few candidates die per step; one lane replays the removals.
+#define TOI_ORDER_SORT_MAX 2048
+// Run by the last workgroup of k_collide (256 lanes; it was a launch of its own behind it).
+__device__ __forceinline__ void toiOrderDestroy(const DW& W)
+{
+	DState* S = W.st;
+	const int n = __hip_atomic_load(&S->c.nToiDestroy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (n == 0) return;
+	const ContactArrays& C = W.ca[S->cur];
+	__shared__ int s_sorted[TOI_ORDER_SORT_MAX];
+	const int m = n < TOI_ORDER_SORT_MAX ? n : TOI_ORDER_SORT_MAX;
+	// rank by key (keys are unique)
+	for (int i = threadIdx.x; i < m; i += blockDim.x)
+	{
+		const int ci = b2dLoadAgentI(&W.toiDestroyList[i]);
+		const uint64_t key = C.key[ci];
+		int rank = 0;
+		for (int j = 0; j < m; ++j) rank += C.key[b2dLoadAgentI(&W.toiDestroyList[j])] < key ? 1 : 0;
+		s_sorted[rank] = ci;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		int count = S->c.nToiOrder;
+		for (int k = 0; k < m; ++k)
+		{
+			const int ci = s_sorted[k];
+			const int slot = C.mgr[ci];
+			--count;
+			const int last = W.toiPos2c[count];
+			W.toiPos2c[slot] = last;
+			C.mgr[last] = slot;
+			C.mgr[ci] = -1;
+		}
+		S->c.nToiOrder = count;
+		S->c.nToiDestroy = 0;
+		if (n > TOI_ORDER_SORT_MAX) atomicOr(&S->c.overflow, 16);
+	}
+}
+
 __global__ __launch_bounds__(256) void k_collide(DW W)
 {
 	b2dPhaseStamp(W);
@@ -225,7 +269,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 			}
 			flags |= CF_DESTROY;
 			++nDestroy;
-			if (flags & CF_TOI_CANDIDATE) W.toiDestroyList[atomicAdd(&S->c.nToiDestroy, 1)] = i;
+			if (flags & CF_TOI_CANDIDATE) b2dStoreAgentI(&W.toiDestroyList[atomicAdd(&S->c.nToiDestroy, 1)], i); // (read by the last workgroup)
 			// b2Contact::Destroy (b2Contact.cpp:100-113): wake both bodies if the manifold had points
 			int pc = C.man3[i].w;
 			if (pc > 0 && (flags & CF_SENSOR) == 0)
@@ -243,6 +287,8 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 	}
 	if (nDestroy) atomicAdd(&S->c.nDestroy, nDestroy);
 	if (nTouch) atomicAdd(&S->c.nTouching, nTouch);
+	// the last workgroup to finish: the TOI candidates destroyed by this pass leave the manager's slot order
+	if (b2dLastBlockArrive(&S->c.collideBlocksDone)) toiOrderDestroy(W);
 }
 
 // b2World::CreateJoint with collideConnected == false flags the contacts between the two bodies for
@@ -425,50 +471,6 @@ __global__ __launch_bounds__(256) void k_flag_filter(DW W, const unsigned long l
 			if (pairs[m] < key) a = m + 1; else b = m;
 		}
 		if (a < nPairs && pairs[a] == key) C.flags[i] |= CF_FILTER;
-	}
-}
-
-// The reference keeps its TOI-candidate contacts in the first m_toiCount slots of one array and removes a
-// contact by moving the LAST candidate into its slot (b2ContactManager::RemoveFromContactArray, :688-714),
-// destroying in (proxyLow, proxyHigh) order (FinishCollide :388-439). That slot order is the order in which
-// b2World::FindMinToiContact re-synchronises sweeps, so it is mirrored here: ContactArrays::mgr is the slot,
-// toiPos2c its inverse. Few candidates die per step; one lane replays the removals.
-#define TOI_ORDER_SORT_MAX 2048
-__global__ __launch_bounds__(256) void k_toi_order_destroy(DW W)
-{
-	b2dPhaseStamp(W);
-	DState* S = W.st;
-	const int n = S->c.nToiDestroy;
-	if (n == 0) return;
-	const ContactArrays& C = W.ca[S->cur];
-	__shared__ int s_sorted[TOI_ORDER_SORT_MAX];
-	const int m = n < TOI_ORDER_SORT_MAX ? n : TOI_ORDER_SORT_MAX;
-	// rank by key (keys are unique)
-	for (int i = threadIdx.x; i < m; i += blockDim.x)
-	{
-		const int ci = W.toiDestroyList[i];
-		const uint64_t key = C.key[ci];
-		int rank = 0;
-		for (int j = 0; j < m; ++j) rank += C.key[W.toiDestroyList[j]] < key ? 1 : 0;
-		s_sorted[rank] = ci;
-	}
-	__syncthreads();
-	if (threadIdx.x == 0)
-	{
-		int count = S->c.nToiOrder;
-		for (int k = 0; k < m; ++k)
-		{
-			const int ci = s_sorted[k];
-			const int slot = C.mgr[ci];
-			--count;
-			const int last = W.toiPos2c[count];
-			W.toiPos2c[slot] = last;
-			C.mgr[last] = slot;
-			C.mgr[ci] = -1;
-		}
-		S->c.nToiOrder = count;
-		S->c.nToiDestroy = 0;
-		if (n > TOI_ORDER_SORT_MAX) atomicOr(&S->c.overflow, 16);
 	}
 }
 

@@ -464,8 +464,9 @@ __global__ __launch_bounds__(256) void k_island_assign(DW W)
 	}
 }
 
-// Adjacency (small islands) and the large-island contact list.
-__global__ __launch_bounds__(256) void k_island_edges(DW W)
+// Adjacency (small islands) and the large-island contact list. `pub`: this is the last kernel of the island build (no large
+// islands lately, no joints): its last workgroup publishes the census for the host (b2dPublishCensus).
+__global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -507,6 +508,15 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W)
 			}
 		}
 	}
+	// (the counters the census consists of are atomics' results: nothing of this workgroup's plain stores is read there)
+	if (pub != nullptr && b2dLastBlockArrive(&S->c.edgesBlocksDone)) b2dPublishCensus(W, pub);
+}
+
+// The census published by a launch of its own (the island build ends with another kernel than the two that can do it).
+__global__ __launch_bounds__(256) void k_publish_census(DW W, DState* pub)
+{
+	b2dPhaseStamp(W);
+	b2dPublishCensus(W, pub);
 }
 
 // A body that joins a partitioned island without touching a body that has a home block - it landed on other newcomers -

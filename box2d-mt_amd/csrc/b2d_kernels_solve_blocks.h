@@ -65,7 +65,7 @@ __device__ __forceinline__ int blockScan1024(int v, int* s_buf /* [2 * 1024] */,
 
 // After k_color_check's census (rows per block): row segments of the blocks, home bodies grouped by block (and each
 // body's slot in its block), adoptions made permanent, and the two capacity figures the host decides on.
-__global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub, int pubSeq)
+__global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -119,21 +119,8 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub, int pu
 		}
 	}
 	if (t == 0) S->gapClock[0] = wall_clock64();
-	// The island build ends here and the host is waiting for its census to size the solver launches: the counters go
-	// straight into host memory (pinned, coherent), the sequence number last - the host polls it (b2hip.hip: awaitCensus).
-	// Cheaper than a copy behind this kernel plus a stream synchronisation, and the stream can go on (k_color_small is
-	// already queued) while the host decides.
-	if (pub != nullptr)
-	{
-		__syncthreads();
-		const int* src = (const int*)S;
-		int* dst = (int*)pub;
-		for (int k = t; k < (int)(offsetof(DState, pubSeq) / sizeof(int)); k += 1024)
-			__hip_atomic_store(&dst[k], src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		__threadfence_system();
-		__syncthreads();
-		if (t == 0) __hip_atomic_store(&pub->pubSeq, pubSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
+	// the island build ends here and the host is waiting for its census to size the solver launches
+	if (pub != nullptr) b2dPublishCensus(W, pub);
 }
 
 // ---- partition ------------------------------------------------------------------------------------------------------------------

@@ -540,11 +540,12 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 				{
 					if (s_nListed < 16) s_listed[s_nListed++] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
 					const int k = atomicAdd(&S->c.nToiMoved, 1);
-					if (k < TOI_MOVED_MAX) W.toiMoved[k] = p; else s_unsafe |= TOI_UNSAFE_CAPACITY;
-					W.toiHull[p] = W.snapFat[p];
+					// (list and hulls are read by the workgroup of this launch that finishes last: past the L2, b2dStoreAgent*)
+					if (k < TOI_MOVED_MAX) b2dStoreAgentI(&W.toiMoved[k], p); else s_unsafe |= TOI_UNSAFE_CAPACITY;
+					b2dStoreAgent4(&W.toiHull[p], W.snapFat[p]);
 				}
-				const float4 hcur = W.toiHull[p];
-				W.toiHull[p] = make_float4(fminf(hcur.x, f.lo.x), fminf(hcur.y, f.lo.y), fmaxf(hcur.z, f.hi.x), fmaxf(hcur.w, f.hi.y));
+				const float4 hcur = b2dLoadAgent4(&W.toiHull[p]);
+				b2dStoreAgent4(&W.toiHull[p], make_float4(fminf(hcur.x, f.lo.x), fminf(hcur.y, f.lo.y), fmaxf(hcur.z, f.hi.x), fmaxf(hcur.w, f.hi.y)));
 			}
 		}
 		__syncthreads();
@@ -618,35 +619,30 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 
 // The launch does not know the number of chains (the host no longer waits for the census of k_toi_first): a fixed grid
 // of waves takes them in turn.
-__global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp, int haveGrid)
+// Two proxies moved by different chains may have come to overlap without either chain seeing it. Run by the last
+// workgroup of k_toi_chains to finish (it was a launch of its own behind it).
+__device__ __forceinline__ void toiChainsEnd(const DW& W)
 {
-	b2dPhaseStamp(W);
 	DState* S = W.st;
-	if (S->c.toiUnsafe & (TOI_UNSAFE_PARTNER | TOI_UNSAFE_CAPACITY)) return;
-	const int nGroups = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
-	for (int group = blockIdx.x; group < nGroups; group += gridDim.x)
-	{
-		toiChainRun(W, sp, haveGrid, group);
-		__syncthreads();
-	}
-}
-
-// Two proxies moved by different chains may have come to overlap without either chain seeing it.
-__global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
-{
-	b2dPhaseStamp(W);
-	DState* S = W.st;
-	const int n = S->c.nToiMoved < TOI_MOVED_MAX ? S->c.nToiMoved : TOI_MOVED_MAX;
+	const int nMovedAll = b2dLoadAgentI(&S->c.nToiMoved);
+	const int n = nMovedAll < TOI_MOVED_MAX ? nMovedAll : TOI_MOVED_MAX;
 	const int nG = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
-	for (int i = threadIdx.x; i < n && n >= 2 && !S->c.toiUnsafe; i += blockDim.x)
+	for (int i = threadIdx.x; i < n && n >= 2 && !b2dLoadAgentI(&S->c.toiUnsafe); i += blockDim.x)
 	{
-		const int p = W.toiMoved[i];
-		const AABB fp = loadAabb(W.toiHull, p); // every box p has had in this phase: covers momentary overlaps too
+		const int p = b2dLoadAgentI(&W.toiMoved[i]);
+		const float4 hp4 = b2dLoadAgent4(&W.toiHull[p]); // every box p has had in this phase: covers momentary overlaps too
+		AABB fp;
+		fp.lo = v2(hp4.x, hp4.y);
+		fp.hi = v2(hp4.z, hp4.w);
 		for (int j = i + 1; j < n; ++j)
 		{
-			const int q = W.toiMoved[j];
+			const int q = b2dLoadAgentI(&W.toiMoved[j]);
 			if (q == p || W.p_body[p] == W.p_body[q]) continue;
-			if (!b2dAabbOverlap(fp, loadAabb(W.toiHull, q))) continue;
+			const float4 hq4 = b2dLoadAgent4(&W.toiHull[q]);
+			AABB fq;
+			fq.lo = v2(hq4.x, hq4.y);
+			fq.hi = v2(hq4.z, hq4.w);
+			if (!b2dAabbOverlap(fp, fq)) continue;
 			// an existing contact makes the overlap harmless: look it up on p's (dynamic) body
 			const int keyP = W.p_key[p], keyQ = W.p_key[q];
 			const int lo = keyP < keyQ ? p : q, hi = keyP < keyQ ? q : p;
@@ -664,6 +660,23 @@ __global__ __launch_bounds__(256) void k_toi_chains_end(DW W)
 	}
 	__syncthreads();
 	for (int g = threadIdx.x; g < nG; g += blockDim.x) W.b_toiGroup[W.toiGroups[g]] = 0;
+}
+
+__global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp, int haveGrid)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	if ((S->c.toiUnsafe & (TOI_UNSAFE_PARTNER | TOI_UNSAFE_CAPACITY)) == 0)
+	{
+		const int nGroups = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
+		for (int group = blockIdx.x; group < nGroups; group += gridDim.x)
+		{
+			toiChainRun(W, sp, haveGrid, group);
+			__syncthreads();
+		}
+	}
+	// the last workgroup to finish closes the phase
+	if (b2dLastBlockArrive(&S->c.chainBlocksDone)) toiChainsEnd(W);
 }
 
 // ---- fused front of the pair update: (hash table of contact keys + spatial grid) cleared, then built -----------------

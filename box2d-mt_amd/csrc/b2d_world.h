@@ -157,6 +157,9 @@ struct Counters
 	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
 	int compactBlocksDone; // workgroups of k_compact_contacts that have finished (the last one switches the contact buffers)
 	int endBlocksDone;     // ... of k_end_step (the last one appends the counters to the read-back)
+	int collideBlocksDone; // ... of k_collide (the last one runs toiOrderDestroy)
+	int chainBlocksDone;   // ... of k_toi_chains (the last one runs toiChainsEnd)
+	int edgesBlocksDone;   // ... of k_island_edges (the last one publishes the census when it is the island build's last kernel)
 	int nFreeIslands;    // one-body islands without contacts or joints, stepped by k_island_classify itself
 	int nSmallJointed;   // small islands of this step that hold joints (none: the lean k_solve_small runs)
 };
@@ -193,7 +196,9 @@ struct DState
 	// by b2dPhaseStamp, which every kernel calls first: a time stamp costs nothing on the stream (a hipEventRecord between
 	// two kernels is a packet of its own - thirteen of them were 90 us of the 10 011-box pyramid's 760 us step)
 	unsigned long long phaseClock[16];
-	int pubSeq, pubPad;  // (host copy only: the sequence number k_block_census publishes the census under)
+	int pubCount;        // publications of the census so far (b2dPublishCensus; the host counts along)
+	int pubPad0;
+	int pubSeq, pubPad;  // (host copies only: the number of the publication / read-back this copy is)
 };
 
 struct StepParams
@@ -400,6 +405,65 @@ __host__ __device__ inline bool b2dPartitionSettled(const Counters& c)
 	if (c.nBlocks == 0 || c.nOrphanRows > 0 || c.blkMaxRows > c.blkLanes || c.blkMaxBodies > c.blkLanes || c.nSerialOrphans > 2048) return false;
 	if (c.partitionAge > 240 && (4 * c.nCutRows > c.nLContacts || 2 * c.nLContacts < 900)) return false;
 	return true;
+}
+
+// What one workgroup hands to another workgroup of the SAME launch (the "last workgroup finishes the job" kernels): stores
+// and loads that go past the XCD's L2 (sc1), so that no fence is needed - a release fence at agent scope writes the whole
+// L2 back (measured: a __threadfence per workgroup made k_collide 50 us longer on the 10 011-box pyramid).
+//   producer: b2dStoreAgent* ... then b2dLastBlockArrive() ;  the workgroup it elects reads with b2dLoadAgent*
+__device__ __forceinline__ void b2dStoreAgentI(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int b2dLoadAgentI(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void b2dStoreAgent4(float4* p, float4 v)
+{
+	typedef float f4 __attribute__((ext_vector_type(4)));
+	f4 q;
+	q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+	asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ float4 b2dLoadAgent4(const float4* p)
+{
+	typedef float f4 __attribute__((ext_vector_type(4)));
+	f4 r;
+	asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+	return make_float4(r.x, r.y, r.z, r.w);
+}
+// Every thread of the workgroup calls it at the end of its work; true in the workgroup that arrived last (all of them
+// have then completed the stores they made before arriving). `counter` goes back to 0 for the next launch.
+__device__ __forceinline__ bool b2dLastBlockArrive(int* counter)
+{
+	__shared__ int s_lastBlock;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		s_lastBlock = prev == (int)gridDim.x - 1 ? 1 : 0;
+		if (s_lastBlock) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__syncthreads();
+	return s_lastBlock != 0;
+}
+
+// The island census for the host, which is polling for it (b2hip.hip: awaitCensus): every counter goes straight into the
+// pinned host copy `pub`, the number of this publication last. Called by ALL threads of one workgroup, after everything
+// the counters depend on (the island build's last kernel, its last workgroup). Cheaper than a copy behind the kernel plus
+// a stream synchronisation, and the stream can go on (k_color_small is already queued) while the host decides.
+__device__ __forceinline__ void b2dPublishCensus(const DW& W, DState* pub)
+{
+	DState* S = W.st;
+	__syncthreads();
+	const int* src = (const int*)S;
+	int* dst = (int*)pub;
+	for (int k = (int)threadIdx.x; k < (int)(offsetof(DState, pubSeq) / sizeof(int)); k += (int)blockDim.x)
+		__hip_atomic_store(&dst[k], __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	__threadfence_system();
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		const int seq = (S->pubCount + 1) & 0x3fffffff;
+		S->pubCount = seq;
+		__hip_atomic_store(&pub->pubSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 // First statement of every kernel: the start of this kernel is the boundary of the phases the host named in stampMask.

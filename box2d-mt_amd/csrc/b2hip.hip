@@ -1387,7 +1387,6 @@ static int phaseCollide(b2hip_world* w)
 	{
 		DW& d = w->dw;
 		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_toi_order_destroy, 1, 256, d);
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d); // (its last workgroup switches the buffers)
@@ -1438,7 +1437,7 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	LAUNCH(w, k_part_assign, gridFor(d.nBodies), 256, d, vin, d.pairRank);
 	LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
-	LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr, 0);
+	LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr);
 	return 0;
 }
 
@@ -1458,7 +1457,12 @@ static int phaseSolve(b2hip_world* w)
 	uint64_t spHash = 1469598103934665603ull;
 	for (size_t k = 0; k < sizeof(StepParams); ++k) spHash = (spHash ^ ((const unsigned char*)&sp)[k]) * 1099511628211ull;
 	const bool largeHint = w->largeHintSteps > 0;
-	int rc = runSegment(w, w->segIslands, (2 + 16ull * (uint64_t)forceLarge + (largeHint ? 8ull : 0ull)) ^ (spHash << 8), [w, forceLarge, sp, largeHint]() -> int
+	// the island build ends with the publication of its census (b2dPublishCensus): by k_block_census, by k_island_edges when
+	// that is the last kernel, else by a launch of its own. B2HIP_NO_CENSUS_POLL=1: copy + stream synchronisation instead.
+	const bool poll = !w->noCensusPoll;
+	const bool adopt = w->adoptPasses;
+	const int pubBy = !poll ? 0 : (largeHint ? 1 : ((d.nJoints == 0 && !adopt) ? 2 : 3));
+	int rc = runSegment(w, w->segIslands, (2 + 16ull * (uint64_t)forceLarge + (largeHint ? 8ull : 0ull) + 64ull * (uint64_t)pubBy + (adopt ? 512ull : 0ull)) ^ (spHash << 12), [w, forceLarge, sp, largeHint, pubBy, adopt]() -> int
 	{
 		DW& d = w->dw;
 		LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
@@ -1479,35 +1483,33 @@ static int phaseSolve(b2hip_world* w)
 			deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->scanFlags.p, w->consts.p, d.nBodies);
 		}
 		LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
-		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d, pubBy == 2 ? w->d_pub : (DState*)nullptr);
 		// (a growing pile: hand home blocks on to newcomers up to four contacts away instead of partitioning again)
-		if (w->adoptPasses)
+		if (adopt)
 			for (int stage = 0; stage < 3; ++stage) LAUNCH(w, k_block_adopt, gridFor(d.capContacts), 256, d, stage);
 		if (d.nJoints > 0) LAUNCH(w, k_joints_fill, gridFor(d.nJoints), 256, d);
 		// (colour bookkeeping and block census only matter to large islands: skipped while the world has had none lately)
-		if (largeHint) LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+		if (largeHint)
+		{
+			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_block_census, 1, 1024, d, pubBy == 1 ? w->d_pub : (DState*)nullptr);
+		}
+		if (pubBy == 3) LAUNCH(w, k_publish_census, 1, 256, d, w->d_pub);
 		return 0;
 	});
 	if (rc) return rc;
 
 	// the host needs the island census to size the solver launches
 	bool colorSmallQueued = false;
-	if (largeHint)
+	if (poll)
 	{
-		// (k_block_census is not part of the captured segment: it carries the sequence number of its publication)
-		const bool poll = !w->noCensusPoll;
-		w->pubSeq = (w->pubSeq + 1) & 0x3fffffff;
-		LAUNCH(w, k_block_census, 1, 1024, d, poll ? w->d_pub : (DState*)nullptr, w->pubSeq);
-		if (poll)
-		{
-			// what the host would launch next in the usual case (a few new contacts on a settled pile to colour, a colour class
-			// to compact) goes behind the census at once and runs while the host is busy with it; the kernel looks at the same
-			// counters and returns if the case is another one
-			if (forceLarge != 2) { LAUNCH(w, k_color_small, 1, 1024, d, 1); colorSmallQueued = true; }
-			rc = awaitCensus(w);
-			if (rc == 0 && !b2dPartitionSettled(w->h_dstate->c)) colorSmallQueued = false; // (it saw the same and returned)
-		}
-		else rc = readState(w);
+		w->pubSeq = (w->pubSeq + 1) & 0x3fffffff; // (the device counts its publications the same way: DState::pubCount)
+		// what the host would launch next in the usual case (a few new contacts on a settled pile to colour, a colour class to
+		// compact) goes behind the census at once and runs while the host is busy with it; the kernel looks at the same
+		// counters and returns if the case is another one
+		if (largeHint && forceLarge != 2) { LAUNCH(w, k_color_small, 1, 1024, d, 1); colorSmallQueued = true; }
+		rc = awaitCensus(w);
+		if (rc == 0 && !b2dPartitionSettled(w->h_dstate->c)) colorSmallQueued = false; // (it saw the same and returned)
 	}
 	else rc = readState(w);
 	if (rc) return rc;
@@ -1518,7 +1520,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			// the first large island after a while: run what was skipped, look again
 			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
-			LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr, 0);
+			LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr);
 			rc = readState(w);
 			if (rc) return rc;
 			c = w->h_dstate->c;
@@ -1990,7 +1992,6 @@ static int phaseToi(b2hip_world* w)
 		if (rc) return rc;
 	}
 	LAUNCH(w, k_toi_chains, 1024, CHAIN_LANES, d, w->sp, haveGrid);
-	LAUNCH(w, k_toi_chains_end, 1, 256, d);
 	// (k_toi_clear's work is done by k_end_step, which follows)
 	w->toiChains = true;
 	w->toiSpeculative = true;
@@ -2053,8 +2054,7 @@ static int phaseToiSync(b2hip_world* w)
 			if (rc) return rc;
 		}
 		LAUNCH(w, k_toi_chains, std::min(groups, 1024), CHAIN_LANES, d, w->sp, haveGrid);
-		LAUNCH(w, k_toi_chains_end, 1, 256, d);
-		LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+			LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
 		w->toiChains = true;
 		return 0;
 	}
@@ -4256,6 +4256,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	*w->h_dstate = ds;
 #define SNAP_UP(arr, s) do { if ((s).bytes && hipMemcpy(w->arr.p, (s).p, (s).bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (" #arr ")")); } while (0)
 	if (hipMemcpy(w->d_state.p, &ds, sizeof(DState), hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (state block)"));
+	w->pubSeq = ds.pubCount; // (the device numbers its census publications; the host counts along)
 	SNAP_UP(b_pos, sPos); SNAP_UP(b_pos0, sPos0); SNAP_UP(b_vel, sVel); SNAP_UP(b_xf, sXf); SNAP_UP(b_mass, sMass); SNAP_UP(b_damp, sDamp);
 	SNAP_UP(b_force, sForce); SNAP_UP(b_flags, sFlags); SNAP_UP(b_wake, sWake); SNAP_UP(b_proxyHead, sHead); SNAP_UP(b_blk1, sBlk);
 	SNAP_UP(p_fat, sFat); SNAP_UP(p_body, sPBody); SNAP_UP(p_shape, sPShape); SNAP_UP(p_key, sPKey); SNAP_UP(p_filter0, sF0); SNAP_UP(p_filter1, sF1);
