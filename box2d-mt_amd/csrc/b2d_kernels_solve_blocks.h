@@ -512,7 +512,9 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	{
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
-		if (gb.nWG > 1 && tid == 0) __hip_atomic_fetch_add(&bar[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		// (relaxed: everything other workgroups read of this one - penetration maxima, flags, hand-over rows - was written with
+		// atomics or sc1 stores, complete by the s_waitcnt above; a release here would write the whole L2 back)
+		if (gb.nWG > 1 && tid == 0) __hip_atomic_fetch_add(&bar[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	};
 	auto waitFor = [&](int g) -> bool
 	{
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 		{
 			int ok = 1, spins = 0;
 			const int need = (g + 1) * gb.nWG;
-			while (__hip_atomic_load(&bar[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need)
+			while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) // (what follows reads past the L2: ldc*)
 			{
 				if (++spins > PERSIST_SPIN_MAX || ldcI(&bar[4]) != 0)
 				{

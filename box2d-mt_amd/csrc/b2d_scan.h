@@ -16,6 +16,25 @@ __device__ __forceinline__ int scanAdd(int a, int b) { return a + b; }
 __device__ __forceinline__ int4 scanAdd(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ void scanZero(int& a) { a = 0; }
 __device__ __forceinline__ void scanZero(int4& a) { a = make_int4(0, 0, 0, 0); }
+// Tile aggregates / prefixes handed from workgroup to workgroup of one launch: stores and loads that go past the XCD's L2
+// (sc1), so the status words need no release / acquire (an agent-scope release writes the whole L2 back, an acquire
+// invalidates it - per tile, and per spin of the look-back).
+__device__ __forceinline__ void scanStoreAgent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int scanLoadAgent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void scanStoreAgent(int4* p, int4 v)
+{
+	typedef int i4 __attribute__((ext_vector_type(4)));
+	i4 q;
+	q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+	asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ int4 scanLoadAgent(const int4* p)
+{
+	typedef int i4 __attribute__((ext_vector_type(4)));
+	i4 r;
+	asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+	return make_int4(r.x, r.y, r.z, r.w);
+}
 
 // Exclusive scan of one value per thread across a 256-thread block (Hillis-Steele through LDS).
 template <typename T>
@@ -185,8 +204,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 		{
 			if (lane == 0)
 			{
-				agg[tile] = total;
-				__hip_atomic_store(flags + tile, (int)((epoch << 2) | 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				scanStoreAgent(&agg[tile], total);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(flags + tile, (int)((epoch << 2) | 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			int hi = tile - 1; // nearest predecessor not yet accounted for
 			while (true)
@@ -200,10 +220,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 					unsigned word;
 					do
 					{
-						word = (unsigned)__hip_atomic_load(flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+						word = (unsigned)__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					} while ((word >> 2) != epoch || (word & 3u) == 0u);
 					state = word & 3u;
-					val = state == 2u ? pre[t] : agg[t];
+					val = scanLoadAgent(state == 2u ? &pre[t] : &agg[t]);
 				}
 				// the nearest tile whose inclusive prefix is known ends the walk
 				const unsigned long long known = __ballot(state == 2u);
@@ -216,8 +236,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 		}
 		if (lane == 0)
 		{
-			pre[tile] = scanAdd(running, total);
-			__hip_atomic_store(flags + tile, (int)((epoch << 2) | 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			scanStoreAgent(&pre[tile], scanAdd(running, total));
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__hip_atomic_store(flags + tile, (int)((epoch << 2) | 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			s_prefix = running;
 		}
 	}
