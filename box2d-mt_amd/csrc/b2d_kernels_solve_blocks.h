@@ -85,14 +85,23 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 	s_cnt[t] = 0;
 	__syncthreads();
 	const int nLB = S->c.nLBodies;
-	for (int k = t; k < nLB; k += 1024)
+	// (four bodies per lane and trip: the loads of a trip are issued together - one workgroup walks all bodies of the large
+	// islands here, and a trip is a chain of three dependent loads)
+	for (int k0 = t; k0 < nLB; k0 += 4 * 1024)
 	{
-		const int body = W.li_bodies[k];
-		const int e = effBlk(W, body);
-		if (e > 0 && e <= nb)
+		int body[4], e[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) body[u] = k0 + u * 1024 < nLB ? W.li_bodies[k0 + u * 1024] : -1;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) e[u] = body[u] >= 0 ? effBlk(W, body[u]) : 0;
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
 		{
-			W.b_blk1[body] = e;
-			atomicAdd(&s_cnt[e - 1], 1);
+			if (e[u] > 0 && e[u] <= nb)
+			{
+				W.b_blk1[body[u]] = e[u];
+				atomicAdd(&s_cnt[e[u] - 1], 1);
+			}
 		}
 	}
 	__syncthreads();
@@ -107,15 +116,22 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 	}
 	s_cnt[t] = 0;
 	__syncthreads();
-	for (int k = t; k < nLB; k += 1024)
+	for (int k0 = t; k0 < nLB; k0 += 4 * 1024)
 	{
-		const int body = W.li_bodies[k];
-		const int e = W.b_blk1[body];
-		if (e > 0 && e <= nb)
+		int body[4], e[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) body[u] = k0 + u * 1024 < nLB ? W.li_bodies[k0 + u * 1024] : -1;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) e[u] = body[u] >= 0 ? W.b_blk1[body[u]] : 0;
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
 		{
-			const int slot = atomicAdd(&s_cnt[e - 1], 1);
-			W.blkBodies[s_start[e - 1] + slot] = body;
-			W.b_slot[body] = slot;
+			if (e[u] > 0 && e[u] <= nb)
+			{
+				const int slot = atomicAdd(&s_cnt[e[u] - 1], 1);
+				W.blkBodies[s_start[e[u] - 1] + slot] = body[u];
+				W.b_slot[body[u]] = slot;
+			}
 		}
 	}
 	if (t == 0) S->gapClock[0] = wall_clock64();
