@@ -581,13 +581,13 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	if (tid == 0) S->phaseClock[13] = wall_clock64(); // end of the step, read-back included
 	__threadfence();
 	__syncthreads();
-	const int* src = (const int*)S;
-	int* tail = (int*)(out + (size_t)n * 10);
-	for (int k = tid; k < (int)(offsetof(DState, pubSeq) / sizeof(int)); k += 256)
-		__hip_atomic_store(&tail[k], __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	// (16 bytes per lane, as b2dPublishCensus does)
+	const float4* src = (const float4*)S;
+	float4* tail = (float4*)(out + B2D_STATE_TAIL(n));
+	for (int k = tid; k < (int)(offsetof(DState, pubSeq) / 16); k += 256) tail[k] = b2dLoadAgent4(&src[k]);
 	__threadfence_system();
 	__syncthreads();
-	if (tid == 0) __hip_atomic_store(&tail[offsetof(DState, pubSeq) / sizeof(int)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	if (tid == 0) __hip_atomic_store(&((DState*)tail)->pubSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 #endif

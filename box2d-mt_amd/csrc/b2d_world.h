@@ -197,9 +197,13 @@ struct DState
 	// two kernels is a packet of its own - thirteen of them were 90 us of the 10 011-box pyramid's 760 us step)
 	unsigned long long phaseClock[16];
 	int pubCount;        // publications of the census so far (b2dPublishCensus; the host counts along)
-	int pubPad0;
-	int pubSeq, pubPad;  // (host copies only: the number of the publication / read-back this copy is)
+	// (host copies only: the number of the publication / read-back this copy is; what lies before it is copied in 16-byte pieces)
+	alignas(16) int pubSeq;
+	int pubPad[3];
 };
+
+// Where DState sits behind the n state rows of a read-back (floats from the start of the buffer; 16-byte aligned).
+#define B2D_STATE_TAIL(n) ((((size_t)(n) * 10) + 3) & ~(size_t)3)
 
 struct StepParams
 {
@@ -452,10 +456,12 @@ __device__ __forceinline__ void b2dPublishCensus(const DW& W, DState* pub)
 {
 	DState* S = W.st;
 	__syncthreads();
-	const int* src = (const int*)S;
-	int* dst = (int*)pub;
-	for (int k = (int)threadIdx.x; k < (int)(offsetof(DState, pubSeq) / sizeof(int)); k += (int)blockDim.x)
-		__hip_atomic_store(&dst[k], __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	// (16 bytes per lane: the whole block leaves as one or two store instructions of the first wave - word by word it was
+	// two hundred separate writes across PCIe)
+	static_assert(offsetof(DState, pubSeq) % 16 == 0, "DState: the published part is copied in 16-byte pieces");
+	const float4* src = (const float4*)S;
+	float4* dst = (float4*)pub;
+	for (int k = (int)threadIdx.x; k < (int)(offsetof(DState, pubSeq) / 16); k += (int)blockDim.x) dst[k] = b2dLoadAgent4(&src[k]);
 	__threadfence_system();
 	__syncthreads();
 	if (threadIdx.x == 0)

@@ -2092,7 +2092,7 @@ static int phaseToiSync(b2hip_world* w)
 // synchronisation (the kernel is the last thing on the stream).
 static int awaitState(b2hip_world* w, size_t nb)
 {
-	const DState* tail = (const DState*)(w->h_state + nb * 10);
+	const DState* tail = (const DState*)(w->h_state + B2D_STATE_TAIL(nb));
 	volatile const int* seq = (volatile const int*)&tail->pubSeq;
 	const auto t0 = std::chrono::steady_clock::now();
 	for (unsigned spins = 1; *seq != w->stateSeq; ++spins)
@@ -2118,15 +2118,15 @@ static int downloadState(b2hip_world* w, int clearForces)
 	const size_t nb = w->bodies.size();
 	w->stateSeq = (w->stateSeq + 1) & 0x3fffffff;
 	if (w->stateSeq == 0) w->stateSeq = 1;
-	((DState*)(w->h_state + nb * 10))->pubSeq = 0; // (whatever was there: not this number)
+	((DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq = 0; // (whatever was there: not this number)
 	const int clear = clearForces < 0 ? w->def.auto_clear_forces : clearForces;
 	if (w->noStatePoll)
 	{
 		// B2HIP_NO_STATE_POLL=1, for comparison: into the device staging array, one copy, stream synchronisation
 		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq);
-		HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, nb * 10 * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, B2D_STATE_TAIL(nb) * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
-		memcpy(w->h_dstate, w->h_state + nb * 10, offsetof(DState, pubSeq));
+		memcpy(w->h_dstate, w->h_state + B2D_STATE_TAIL(nb), offsetof(DState, pubSeq));
 		return 0;
 	}
 	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq);
