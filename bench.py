@@ -179,13 +179,77 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- solver roofline: per-launch HIP-event timing of the dominant kernel ---------------------------------------
+    # A pass of its own (an event pair around the launch would perturb the timed region): the LAST 20 warm-up steps, i.e.
+    # the state the timed region starts from (after it only when there is no warm-up: the 141-row pyramid is not a stable
+    # pile, and a pass 300 steps later times a different one).
+    ROOF_STEPS = 20
+
+    def solver_roofline_pass():
+        roof = None
+        try:
+            amd.lib.b2h_device_world.restype = C.c_void_p
+            amd.lib.b2h_device_world.argtypes = [C.c_void_p]
+            dev = amd.lib.b2h_device_world(w.ptr)
+            hipL.b2hip_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+            hipL.b2hip_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char), C.c_int, C.POINTER(C.c_float),
+                                                     C.POINTER(C.c_int), C.POINTER(C.c_double)]
+            hipL.b2hip_set_kernel_timing(dev, 1)
+            names = {}
+            for _ in range(ROOF_STEPS):
+                step_world(1)
+                buf = C.create_string_buffer(64)
+                ms, launches, nbytes = C.c_float(), C.c_int(), C.c_double()
+                hipL.b2hip_get_kernel_timing(dev, buf, 64, C.byref(ms), C.byref(launches), C.byref(nbytes))
+                k = buf.value.decode()
+                acc = names.setdefault(k, [0.0, 0, 0.0])
+                acc[0] += ms.value
+                acc[1] += launches.value
+                acc[2] += nbytes.value
+            hipL.b2hip_set_kernel_timing(dev, 0)
+            kname, (tot_ms, launches, tot_bytes) = max(names.items(), key=lambda kv: kv[1][0])
+            ctr = b2hip.Counters()
+            hipL.b2hip_get_counters(dev, C.byref(ctr))
+            if launches > 0 and tot_ms > 0:
+                achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "launches_per_step": launches / float(ROOF_STEPS), "mean_launch_us": 1000.0 * tot_ms / launches,
+                        "algorithmic_bytes_per_launch": tot_bytes / launches,
+                        "constraints": ctr.large_island_contacts + ctr.small_island_contacts,
+                        "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors,
+                        "toi_calls_per_step": ctr.toi_calls, "toi_events_last_step": ctr.toi_events}
+            # HBM traffic of that kernel: null unless a committed rocprofv3 --pmc profile of this command matches the kernel,
+            # the workload and the (steady) state this run measured
+            if roof is not None:
+                hit = committed_pmc_traffic(kname, "pyramid%d%s" % (args.rows, "" if not args.no_ccd else "_noccd"))
+                if hit is not None:
+                    roof["traffic"] = hit[0]
+                    roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, steady state)" % hit[1]
+                    roof["traffic_GBps"] = hit[0] / (1e-3 * tot_ms / launches) / 1e9
+            smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
+            hipL.b2hip_get_solver_timing(dev, C.byref(smsv), C.byref(sbytes), C.byref(sct), C.byref(sb))
+            if roof is not None and smsv.value > 0:
+                roof["solver_phase"] = {"ms": smsv.value, "algorithmic_bytes": sbytes.value,
+                                        "achieved": sbytes.value / (smsv.value * 1e-3) / 1e9,
+                                        "frac": sbytes.value / (smsv.value * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:  # the timing hooks are best effort; the headline number does not depend on them
+            roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "error": str(e)}
+        return roof
+
     # workload construction: settle the pile (untimed, always), keeping the cost of the transient for the report
     settle_ms = np.empty(SETTLE_STEPS)
     for k in range(SETTLE_STEPS):
         ts = time.perf_counter()
         step_world(1)
         settle_ms[k] = 1000.0 * (time.perf_counter() - ts)
-    step_world(args.warmup)
+    roof = None
+    if args.warmup >= ROOF_STEPS:
+        step_world(args.warmup - ROOF_STEPS)
+        roof = solver_roofline_pass()  # (steps ROOF_STEPS warm-up steps)
+    else:
+        step_world(args.warmup)
     w.reset_profile()
     barrier()
     # one Step() per call so that the per-step distribution can be reported as well (Step() returns after its read-back,
@@ -211,57 +275,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- solver roofline: per-launch HIP-event timing of the dominant kernel, separate pass ----------
-    roof = None
-    try:
-        amd.lib.b2h_device_world.restype = C.c_void_p
-        amd.lib.b2h_device_world.argtypes = [C.c_void_p]
-        dev = amd.lib.b2h_device_world(w.ptr)
-        hipL.b2hip_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
-        hipL.b2hip_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char), C.c_int, C.POINTER(C.c_float),
-                                                 C.POINTER(C.c_int), C.POINTER(C.c_double)]
-        hipL.b2hip_set_kernel_timing(dev, 1)
-        names = {}
-        for _ in range(20):
-            step_world(1)
-            buf = C.create_string_buffer(64)
-            ms, launches, nbytes = C.c_float(), C.c_int(), C.c_double()
-            hipL.b2hip_get_kernel_timing(dev, buf, 64, C.byref(ms), C.byref(launches), C.byref(nbytes))
-            k = buf.value.decode()
-            acc = names.setdefault(k, [0.0, 0, 0.0])
-            acc[0] += ms.value
-            acc[1] += launches.value
-            acc[2] += nbytes.value
-        hipL.b2hip_set_kernel_timing(dev, 0)
-        kname, (tot_ms, launches, tot_bytes) = max(names.items(), key=lambda kv: kv[1][0])
-        ctr = b2hip.Counters()
-        hipL.b2hip_get_counters(dev, C.byref(ctr))
-        if launches > 0 and tot_ms > 0:
-            achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "launches_per_step": launches / 20.0, "mean_launch_us": 1000.0 * tot_ms / launches,
-                    "algorithmic_bytes_per_launch": tot_bytes / launches,
-                    "constraints": ctr.large_island_contacts + ctr.small_island_contacts,
-                    "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors,
-                    "toi_calls_per_step": ctr.toi_calls, "toi_events_last_step": ctr.toi_events}
-        # HBM traffic of that kernel: null unless a committed rocprofv3 --pmc profile of this command matches the kernel,
-        # the workload and the (steady) state this run measured
-        if roof is not None:
-            hit = committed_pmc_traffic(kname, "pyramid%d%s" % (args.rows, "" if not args.no_ccd else "_noccd"))
-            if hit is not None:
-                roof["traffic"] = hit[0]
-                roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, steady state)" % hit[1]
-                roof["traffic_GBps"] = hit[0] / (1e-3 * tot_ms / launches) / 1e9
-        smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
-        hipL.b2hip_get_solver_timing(dev, C.byref(smsv), C.byref(sbytes), C.byref(sct), C.byref(sb))
-        if roof is not None and smsv.value > 0:
-            roof["solver_phase"] = {"ms": smsv.value, "algorithmic_bytes": sbytes.value,
-                                    "achieved": sbytes.value / (smsv.value * 1e-3) / 1e9,
-                                    "frac": sbytes.value / (smsv.value * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    except Exception as e:  # the timing hooks are best effort; the headline number does not depend on them
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "error": str(e)}
+    if roof is None:
+        roof = solver_roofline_pass()
 
     # ---- secondary roofline: the in-LDS small-island kernel on a multi-island world (not part of `value`) ----------
     secondary = None
