@@ -526,7 +526,11 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 // array, no copy behind the kernel: the rows of a workgroup's 256 bodies are transposed through LDS and leave as contiguous
 // 16-byte stores; the workgroup that finishes last appends DState and, last of all, the sequence number the host polls
 // (b2hip.hip: awaitState). Nothing else runs in the step after this kernel: the counters are final.
-__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq)
+// skipIfRedo: the first read-back of b2hip_step_end. If the counters say that the host will finish the pair update with the
+// radix path and read back AGAIN (more new pairs than the counting path ranks, or a pair-buffer overflow: the test
+// stepEndImpl makes), only the counters travel now - the rows would be overwritten by the second read-back anyway, and at
+// 1 M bodies they are 40 MB of PCIe. Counters::rowsSkipped tells the host (which reads back in full before it returns).
+__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq, int skipIfRedo)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -535,7 +539,14 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	__shared__ __attribute__((aligned(16))) float s_out[2560];
 	__shared__ int s_last;
 	const bool toiEvents = S->c.nToiEvents != 0;
-	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256)
+	bool skipRows = false;
+	if (skipIfRedo)
+	{
+		const int ov = S->c.overflow, moves = S->c.nMoves;
+		const bool pairOverflow = (ov & 2) != 0 || ((ov & 1) != 0 && moves != 0);
+		skipRows = (moves != 0 || pairOverflow) && (S->c.nPairs > COUNT_RANK_MAX || pairOverflow);
+	}
+	for (int base = blockIdx.x * 256; base < n && !skipRows; base += gridDim.x * 256)
 	{
 		const int i = base + tid;
 		if (i < n)
@@ -578,7 +589,11 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	if (tid == 0) S->c.endBlocksDone = 0;
 	// (the solver's phase stamps travel with the counters)
 	if (bar != nullptr && tid < 6) S->stamps[tid] = bar[8 + tid];
-	if (tid == 0) S->phaseClock[13] = wall_clock64(); // end of the step, read-back included
+	if (tid == 0)
+	{
+		S->phaseClock[13] = wall_clock64(); // end of the step, read-back included
+		S->c.rowsSkipped = skipRows ? 1 : 0;
+	}
 	__threadfence();
 	__syncthreads();
 	// (16 bytes per lane, as b2dPublishCensus does)

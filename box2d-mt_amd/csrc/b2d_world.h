@@ -157,6 +157,7 @@ struct Counters
 	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
 	int compactBlocksDone; // workgroups of k_compact_contacts that have finished (the last one switches the contact buffers)
 	int endBlocksDone;     // ... of k_end_step (the last one appends the counters to the read-back)
+	int rowsSkipped;       // k_end_step left the state rows out: the host will finish the pair update and read back again
 	int collideBlocksDone; // ... of k_collide (the last one runs toiOrderDestroy)
 	int chainBlocksDone;   // ... of k_toi_chains (the last one runs toiChainsEnd)
 	int edgesBlocksDone;   // ... of k_island_edges (the last one publishes the census when it is the island build's last kernel)

@@ -1194,7 +1194,7 @@ static int applyPendingFilters(b2hip_world* w)
 
 // Applies the queued contact-array ops (b2d_kernels_edit.h) in call order, then compacts the contact array if contacts
 // were destroyed. Called by the step right after its counters are zeroed, and by whoever reads the contacts between steps.
-static int downloadState(b2hip_world* w, int clearForces);
+static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo = false);
 
 static int applyEditOps(b2hip_world* w, bool betweenSteps)
 {
@@ -2112,7 +2112,7 @@ static int awaitState(b2hip_world* w, size_t nb)
 	return 0;
 }
 
-static int downloadState(b2hip_world* w, int clearForces)
+static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 {
 	DW& d = w->dw;
 	const size_t nb = w->bodies.size();
@@ -2123,13 +2123,13 @@ static int downloadState(b2hip_world* w, int clearForces)
 	if (w->noStatePoll)
 	{
 		// B2HIP_NO_STATE_POLL=1, for comparison: into the device staging array, one copy, stream synchronisation
-		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq);
+		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq, 0);
 		HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, B2D_STATE_TAIL(nb) * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 		memcpy(w->h_dstate, w->h_state + B2D_STATE_TAIL(nb), offsetof(DState, pubSeq));
 		return 0;
 	}
-	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq);
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq, skipRowsIfRedo ? 1 : 0);
 	return awaitState(w, nb);
 }
 
@@ -3611,7 +3611,7 @@ int b2hip_solve_toi(b2hip_world* w)
 
 static int stepEndImpl(b2hip_world* w)
 {
-	int rc = downloadState(w, -1);
+	int rc = downloadState(w, -1, w->sp.dt > 0.0f); // (rows only if this is the last read-back of the step: k_end_step)
 	if (rc) return rc;
 	// optimistic small-sort path overflowed (or the pair buffer itself): finish the pair update with the radix path (after
 	// growing the buffer and searching again), then read back again
@@ -3732,6 +3732,12 @@ static int stepEndImpl(b2hip_world* w)
 		}
 	}
 	w->events.clear();
+	// (the rows were left out of a read-back because another one was due, and it did not come: safety net, never seen)
+	if (w->h_dstate->c.rowsSkipped)
+	{
+		rc = downloadState(w, -1);
+		if (rc) return rc;
+	}
 	if (w->eventsOn)
 	{
 		// after every fallback has had its say: one pass over the contacts, then the (usually short) list comes back
