@@ -504,16 +504,11 @@ __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 	}
 	// the workgroup that finishes last switches the buffers (was a kernel of its own): everybody has read the count and
 	// the live half by then
-	__syncthreads();
-	if (threadIdx.x == 0)
+	// (no fence: the last workgroup reads nothing the others wrote - a fence per workgroup writes the L2 back 256 times)
+	if (b2dLastBlockArrive(&S->c.compactBlocksDone) && threadIdx.x == 0)
 	{
-		__threadfence();
-		if (atomicAdd(&S->c.compactBlocksDone, 1) == (int)gridDim.x - 1)
-		{
-			S->c.compactBlocksDone = 0;
-			S->c.nContacts = W.keepScan[n];
-			S->cur = 1 - S->cur;
-		}
+		S->c.nContacts = W.keepScan[n];
+		S->cur = 1 - S->cur;
 	}
 }
 
