@@ -554,3 +554,39 @@ def test_sweep_blocks_match_launch_per_colour(amd, default_mode):
         assert swept_b == 0
         first_bad = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), None)
         assert first_bad is None, "k_blocks_sweep and launch-per-colour diverge at step %s (scene %d)" % (first_bad, scene)
+
+
+def test_host_device_handshakes_do_not_change_the_results(amd, default_mode, monkeypatch):
+    """The island census is published by a kernel to pinned host memory and polled (with k_color_small queued behind it before
+    the host has seen it), the read-back is written by k_end_step straight into the host's buffer and polled, the phase
+    times are device clock stamps. The comparison forms - copy + stream synchronisation (B2HIP_NO_CENSUS_POLL,
+    B2HIP_NO_STATE_POLL), no stamps (B2HIP_PROFILE_DETAIL=0) - must give the same bits step by step: a pile that grows
+    (partitions, adoption, colouring every step), the Tumbler (sweep solver, hubs, a second read-back per step) and a
+    field with bullets (continuous collision)."""
+    ccd = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
+
+    def run(scene, steps, env, **kw):
+        for k in ("B2HIP_NO_CENSUS_POLL", "B2HIP_NO_STATE_POLL", "B2HIP_PROFILE_DETAIL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        w = amd.world(scene, **kw)
+        out = []
+        for _ in range(steps):
+            w.step(1)
+            out.append((bh.fnv1a64(w.bodies()), w.contact_count))
+        prof = w.profile()
+        w.close()
+        return out, prof
+
+    for scene, steps, kw in [(bh.PYRAMID, 120, dict(p0=40, flags=ccd)), (bh.TUMBLER, 100, dict(p0=40)),
+                             (bh.FIELD, 40, dict(p0=2000, p1=200, f0=50.0, f1=3.0, seed=11, flags=ccd))]:
+        base, prof = run(scene, steps, {}, **kw)
+        # the profile is made of device clock differences: every figure finite and not negative, the phases inside the step
+        assert all(np.isfinite(v) and v >= 0.0 for k, v in prof.items() if k != "steps"), prof
+        assert prof["step"] > 0.0 and prof["collide"] + prof["solve"] <= 1.05 * prof["step"] + 0.01, prof
+        for env in ({"B2HIP_NO_CENSUS_POLL": "1"}, {"B2HIP_NO_STATE_POLL": "1"}, {"B2HIP_PROFILE_DETAIL": "0"},
+                    {"B2HIP_NO_CENSUS_POLL": "1", "B2HIP_NO_STATE_POLL": "1", "B2HIP_PROFILE_DETAIL": "0"}):
+            other, _ = run(scene, steps, env, **kw)
+            first = next((i for i in range(steps) if base[i] != other[i]), None)
+            assert first is None, "scene %d with %s differs from the default at step %d" % (scene, env, first)
