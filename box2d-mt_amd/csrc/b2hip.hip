@@ -1597,7 +1597,7 @@ static int phaseSolve(b2hip_world* w)
 	// launches - the solver is what the step waits for, and every launch the host makes first delays it by ~3 us)
 	auto launchSmallIslands = [&](hipStream_t ss) -> int
 	{
-		if (sideStream) HIP_TRY(hipStreamWaitEvent(ss, w->evFork, 0));
+		if (sideStream && !poll) HIP_TRY(hipStreamWaitEvent(ss, w->evFork, 0));
 		LAUNCH_ON(w, ss, k_island_dfs, gridFor(c.nSIslands, 64, 1 << 20), 64, d);
 		if (!sideStream) stampPhase(w, 5);
 		if (!exactLarge)
@@ -1622,8 +1622,11 @@ static int phaseSolve(b2hip_world* w)
 		sideStream = !exactLarge && c.nLIslands > 0 && !w->debugTrace && !w->kernelTimingLaunches && !w->noSideStream;
 		if (sideStream)
 		{
-			// fork here (the side stream needs the island build, nothing of the large-island solver); launches later
-			HIP_TRY(hipEventRecord(w->evFork, w->stream));
+			// fork here (the side stream needs the island build, nothing of the large-island solver); launches later.
+			// With the census polled the host has SEEN the island build finish (the publication is its last act): the side
+			// stream needs no event to wait for - an event record is a packet of its own on the main stream, ~6 us between
+			// the colouring and the solver
+			if (!poll) HIP_TRY(hipEventRecord(w->evFork, w->stream));
 			smallDeferred = true;
 			stampPhase(w, 5);
 			stampPhase(w, 6);
