@@ -72,20 +72,32 @@ __device__ __forceinline__ uint32_t ufPriority(int i) { return (uint32_t)i * 265
 
 __device__ __forceinline__ void ufUnion(int* parent, int a, int b)
 {
+	// Both walks in lockstep, ONE round of loads per level: a walk is a chain of dependent loads past the L2 (a dozen levels
+	// when ten thousand bodies collapse into one component), and one walk after the other, with parent and grandparent
+	// fetched in two rounds per level, made k_island_union 44 us on the 10 011-box pyramid. Path splitting: every body on
+	// the way is re-pointed at its grandparent (any ancestor is a valid parent at any time, see ufFind).
+	int pa = __hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	int pb = __hip_atomic_load(&parent[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	for (;;)
 	{
-		a = ufFind(parent, a);
-		b = ufFind(parent, b);
-		if (a == b) return;
-		if (ufPriority(a) > ufPriority(b))
+		for (;;)
 		{
-			int t = a;
-			a = b;
-			b = t;
+			if (pa == pb || pa == b || pb == a) return; // (the walks met: same component)
+			if (pa == a && pb == b) break;               // two roots
+			const int ga = __hip_atomic_load(&parent[pa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int gb = __hip_atomic_load(&parent[pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (pa != a && ga != pa) __hip_atomic_store(&parent[a], ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (pb != b && gb != pb) __hip_atomic_store(&parent[b], gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			a = pa; pa = ga;
+			b = pb; pb = gb;
 		}
-		// a has the lower priority value: try to hang b under a
-		int old = atomicCAS(&parent[b], b, a);
-		if (old == b) return;
+		// hang the root of higher priority value under the other
+		const bool swap = ufPriority(a) > ufPriority(b);
+		const int lo = swap ? b : a, hi = swap ? a : b;
+		const int old = atomicCAS(&parent[hi], hi, lo);
+		if (old == hi) return;
+		// somebody else linked `hi` meanwhile: go on from where it points now
+		if (swap) pa = old; else pb = old;
 	}
 }
 
