@@ -70,14 +70,21 @@ __device__ __forceinline__ int ufFindReadOnly(const int* parent, int i)
 // row below, which was created earlier): 58 us of pointer chasing for 22k unions.
 __device__ __forceinline__ uint32_t ufPriority(int i) { return (uint32_t)i * 2654435761u; }
 
+__device__ __forceinline__ void ufUnionFrom(int* parent, int a, int b, int pa, int pb);
+
 __device__ __forceinline__ void ufUnion(int* parent, int a, int b)
+{
+	ufUnionFrom(parent, a, b, __hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+		__hip_atomic_load(&parent[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// (pa, pb = parent[a], parent[b] as the caller has already read them - together with whatever else it had to fetch)
+__device__ __forceinline__ void ufUnionFrom(int* parent, int a, int b, int pa, int pb)
 {
 	// Both walks in lockstep, ONE round of loads per level: a walk is a chain of dependent loads past the L2 (a dozen levels
 	// when ten thousand bodies collapse into one component), and one walk after the other, with parent and grandparent
 	// fetched in two rounds per level, made k_island_union 44 us on the 10 011-box pyramid. Path splitting: every body on
 	// the way is re-pointed at its grandparent (any ancestor is a valid parent at any time, see ufFind).
-	int pa = __hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	int pb = __hip_atomic_load(&parent[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	for (;;)
 	{
 		for (;;)
@@ -216,11 +223,15 @@ __global__ __launch_bounds__(256) void k_island_union(DW W)
 		C.flags[i] = flags;
 		if (!contactSolid(flags)) continue;
 		int4 ids = C.ids[i];
-		bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
-		bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+		// (the first level of both walks is fetched together with the body flags: one round trip less in front of the walks)
+		const uint32_t bfA = W.b_flags[ids.z], bfB = W.b_flags[ids.w];
+		const int pa = __hip_atomic_load(&W.parent[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int pb = __hip_atomic_load(&W.parent[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		bool nsA = (bfA & BF_TYPE_MASK) != BT_STATIC;
+		bool nsB = (bfB & BF_TYPE_MASK) != BT_STATIC;
 		if (nsA) atomicAdd(&W.deg[ids.z], 1);
 		if (nsB) atomicAdd(&W.deg[ids.w], 1);
-		if (nsA && nsB) ufUnion(W.parent, ids.z, ids.w);
+		if (nsA && nsB) ufUnionFrom(W.parent, ids.z, ids.w, pa, pb);
 	}
 	// joints connect bodies too (b2World.cpp:1292-1318)
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
