@@ -120,9 +120,26 @@ __device__ __forceinline__ void colorCheckBegin(const DW& W)
 	{
 		// colour compaction visits one class per step, from the highest down to 1, then starts over
 		const int prev = W.st->c.nColors < MAX_COLORS ? W.st->c.nColors : MAX_COLORS;
-		int t = W.st->c.compactClass - 1;
+		int t = W.st->c.compactCursor - 1;
 		if (t < 1 || t >= prev) t = prev - 1;
-		W.st->c.compactClass = t > 0 ? t : 0;
+		if (t < 0) t = 0;
+		// a colouring that a whole round over its classes could not improve (a settled pile) is visited on every 8th step
+		// only: the visit reads every constraint of the class (k_color_check lists them, k_color_small tries them: ~15 us
+		// of the 10 011-box pyramid's step)
+		W.st->c.compactTick += 1;
+		// (the outcome of the last visit - whether or not k_color_small had anything to run for)
+		if (W.st->c.compactClass > 0) W.st->c.compactIdle = W.st->c.compactMoved > 0 ? 0 : W.st->c.compactIdle + 1;
+		W.st->c.compactMoved = 0;
+		const bool idle = W.st->c.compactIdle >= prev && prev > 1;
+		if (idle && (W.st->c.compactTick & 7) != 0)
+		{
+			W.st->c.compactClass = 0;
+		}
+		else
+		{
+			W.st->c.compactCursor = t;
+			W.st->c.compactClass = t;
+		}
 		W.st->c.nCompact = 0;
 		W.st->c.needRecolor = 0;
 		W.st->c.nColors = 0;

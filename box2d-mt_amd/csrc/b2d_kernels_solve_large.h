@@ -404,7 +404,12 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead)
 	}
 	__syncthreads();
 	const int n = s_n < COLOR_SMALL_MAX ? s_n : COLOR_SMALL_MAX;
-	if (threadIdx.x == 0) s_left = n;
+	if (threadIdx.x == 0)
+	{
+		s_left = n;
+		// (the next step's colorCheckBegin slows the visits down once a whole round of classes has moved nothing)
+		if (s_n > S->c.nUncolList) S->c.compactMoved = s_n - S->c.nUncolList;
+	}
 	// what a round needs of a constraint, read once (a round used to start with five dependent loads per constraint and pass:
 	// 200 us of the Tumbler's step, where a thousand contacts are new every step)
 	constexpr int PER = COLOR_SMALL_MAX / 1024;

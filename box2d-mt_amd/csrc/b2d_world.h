@@ -131,7 +131,11 @@ struct Counters
 	int nEvents;         // contact events of this step (DW::evKey / evInfo), see k_contact_events
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)
 	int nCompact;        // entries of DW::compactList (constraints of the colour class under compaction this step)
-	int compactClass;    // persistent: colour class whose constraints may move to a lower free colour this step
+	int compactClass;    // colour class whose constraints may move to a lower free colour this step (0: none)
+	int compactCursor;   // persistent: the class visited last (one per step, from the highest down to 1, then over again)
+	int compactIdle;     // persistent: classes visited in a row without a constraint moving
+	int compactMoved;    // constraints k_color_small moved down in this step's visit (read by the next step's colorCheckBegin)
+	int compactTick;     // persistent: steps, for the slow beat of an idle colouring
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
 	int nHubRows;        // hub constraints of this step
 	int hubRounds;       // fixed-point rounds k_large_hub ran this step (all sweeps, all chunks)
