@@ -134,8 +134,18 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 	{
 		int4 ids = C.ids[i];
 		uint32_t flags = C.flags[i];
+		// Everything the update of a live contact reads is fetched in TWO rounds - what hangs on the contact index with the
+		// ids, what hangs on the ids right after - instead of level by level behind the tests that need it (flags, then fat
+		// AABBs, then the old manifold and the shape indices, then shapes and transforms: five dependent round trips in front
+		// of the arithmetic). A contact that turns out inactive or out of its fat AABBs has read a few rows for nothing.
+		const int4 m3 = C.man3[i];
+		const float4 oldImp = C.imp[i];
+		const float4 o0 = C.man0[i], o1 = C.man1[i];
 		const int proxyA = ids.x, proxyB = ids.y, bodyA = ids.z, bodyB = ids.w;
 		uint32_t bfA = W.b_flags[bodyA], bfB = W.b_flags[bodyB];
+		const float4 fatA = W.p_fat[proxyA], fatB = W.p_fat[proxyB];
+		const int shapeA = W.p_shape[proxyA], shapeB = W.p_shape[proxyB];
+		const Xf xfA = loadXf(W.b_xf, bodyA), xfB = loadXf(W.b_xf, bodyB);
 		int keep = 1;
 
 		if (flags & CF_FILTER)
@@ -159,7 +169,10 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 		bool active = bodyActiveForContact(bfA) || bodyActiveForContact(bfB);
 		if (keep && active)
 		{
-			bool overlap = b2dAabbOverlap(loadAabb(W.p_fat, proxyA), loadAabb(W.p_fat, proxyB));
+			AABB boxA, boxB;
+			boxA.lo = v2(fatA.x, fatA.y); boxA.hi = v2(fatA.z, fatA.w);
+			boxB.lo = v2(fatB.x, fatB.y); boxB.hi = v2(fatB.z, fatB.w);
+			bool overlap = b2dAabbOverlap(boxA, boxB);
 			if (!overlap)
 			{
 				keep = 0;
@@ -167,8 +180,6 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 			else
 			{
 				// b2Contact::UpdateImpl (b2Contact.cpp:173-298)
-				int4 m3 = C.man3[i];
-				float4 oldImp = C.imp[i];
 				const uint32_t oldId0 = (uint32_t)m3.x, oldId1 = (uint32_t)m3.y;
 				const int oldCount = m3.w;
 				flags |= CF_ENABLED;
@@ -185,23 +196,22 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 				{
 					// b2Contact::Update, sensor branch (b2Contact.cpp:193-202): touching = b2TestOverlap (b2Collision.cpp:233-252),
 					// GJK distance with the shape radii below 10 epsilon; no manifold. Sensors never enter the solver.
-					const GjkProxy pA = b2dProxy(W.shapes + W.p_shape[proxyA]);
-					const GjkProxy pB = b2dProxy(W.shapes + W.p_shape[proxyB]);
+					const GjkProxy pA = b2dProxy(W.shapes + shapeA);
+					const GjkProxy pB = b2dProxy(W.shapes + shapeB);
 					GjkCache cache;
 					cache.count = 0;
 					cache.metric = 0.0f;
 					for (int k = 0; k < 3; ++k) cache.indexA[k] = cache.indexB[k] = 0;
 					GjkOutput dist;
-					b2dDistance(dist, cache, pA, loadXf(W.b_xf, bodyA), pB, loadXf(W.b_xf, bodyB), true);
+					b2dDistance(dist, cache, pA, xfA, pB, xfB, true);
 					touching = dist.distance < 10.0f * B2D_EPSILON;
 					mf.pointCount = 0;
 				}
 				else
 				{
-					const ShapeRec* sA = W.shapes + W.p_shape[proxyA];
-					const ShapeRec* sB = W.shapes + W.p_shape[proxyB];
+					const ShapeRec* sA = W.shapes + shapeA;
+					const ShapeRec* sB = W.shapes + shapeB;
 					// stale fields survive an early-out exactly like the reference's persistent manifold
-					float4 o0 = C.man0[i], o1 = C.man1[i];
 					o0s = o0;
 					o1s = o1;
 					mf.localNormal = v2(o0.x, o0.y);
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 					mf.p[1] = v2(o1.z, o1.w);
 					mf.id[0] = oldId0;
 					mf.id[1] = oldId1;
-					b2dEvaluate(&mf, sA, loadXf(W.b_xf, bodyA), sB, loadXf(W.b_xf, bodyB));
+					b2dEvaluate(&mf, sA, xfA, sB, xfB);
 					touching = mf.pointCount > 0;
 					float ni[2], ti[2];
 					ni[0] = oldImp.x; ti[0] = oldImp.y; ni[1] = oldImp.z; ti[1] = oldImp.w;
