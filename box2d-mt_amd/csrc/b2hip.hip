@@ -272,6 +272,7 @@ struct b2hip_world
 	int serialOrphansNext = 0;   // DW::serialOrphans of the next step
 	int adoptSticky = 0;
 	bool adoptPasses = false;    // the last step had orphan constraints (or made a partition): run k_block_adopt this step
+	bool traceLaunches = false;  // B2HIP_TRACE_LAUNCHES=1 (with B2HIP_DEBUG): every kernel's name before the stream is drained behind it
 	bool tracePartition = false; // B2HIP_TRACE_PARTITION=1: why a partition was made, on stderr
 	bool noSweepBlocks = false;  // B2HIP_NO_SWEEP_BLOCKS=1: jointed / hub islands stay on the launch-per-colour kernels
 	int dfWipedAt = 0;           // dfEpoch >> 14 at the last wipe of the hand-over rows
@@ -578,6 +579,7 @@ static void resetMassData(b2hip_world* w, HostBody& b)
 static int syncCheck(b2hip_world* w, const char* what)
 {
 	if (!w->debugSync) return 0;
+	if (w->traceLaunches) { fprintf(stderr, "[b2hip] %s\n", what); fflush(stderr); } // (B2HIP_TRACE_LAUNCHES=1: which launch hangs?)
 	hipError_t e = hipStreamSynchronize(w->stream);
 	if (e == hipSuccess) e = hipGetLastError();
 	if (e != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -704,24 +706,38 @@ static int readState(b2hip_world* w)
 // The island census as k_block_census published it under sequence number w->pubSeq (straight into pinned host memory):
 // the host polls the number instead of queueing a copy and synchronising the stream - which also lets the stream run on
 // (k_color_small, queued behind the census) while the host sizes the solver launches.
-static int awaitCensus(b2hip_world* w)
+// The polling loop of awaitCensus / awaitState: until *seq == want. Like hipStreamSynchronize it waits as long as the stream
+// is busy (a step of a pathological world can take a minute); it gives up only if the stream reports an error, or has
+// drained and the number still is not there two seconds later (the publishing kernel did not run: a bug, not a wait).
+static int pollPublished(b2hip_world* w, volatile const int* seq, int want, const char* what)
 {
-	volatile int* seq = (volatile int*)&w->h_pub->pubSeq;
-	const auto t0 = std::chrono::steady_clock::now();
-	for (unsigned spins = 1; *seq != w->pubSeq; ++spins)
+	bool drained = false;
+	std::chrono::steady_clock::time_point drainedAt;
+	for (unsigned spins = 1; *seq != want; ++spins)
 	{
 		if ((spins & 0x3fff) == 0)
 		{
-			// (a failed launch or a dead device would leave us here for ever)
 			const hipError_t q = hipStreamQuery(w->stream);
-			if (q != hipSuccess && q != hipErrorNotReady) return setError(B2HIP_ERR_HIP, std::string("island census: ") + hipGetErrorString(q));
-			if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return setError(B2HIP_ERR_HIP, "island census was not published (20 s)");
+			if (q != hipSuccess && q != hipErrorNotReady) return setError(B2HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(q));
+			if (q == hipSuccess)
+			{
+				const auto now = std::chrono::steady_clock::now();
+				if (!drained) { drained = true; drainedAt = now; }
+				else if (now - drainedAt > std::chrono::seconds(2)) return setError(B2HIP_ERR_HIP, std::string(what) + " was not published (the stream has drained)");
+			}
+			else drained = false;
 		}
 #if defined(__x86_64__)
 		__builtin_ia32_pause();
 #endif
 	}
 	std::atomic_thread_fence(std::memory_order_acquire);
+	return 0;
+}
+
+static int awaitCensus(b2hip_world* w)
+{
+	if (int rc = pollPublished(w, (volatile const int*)&w->h_pub->pubSeq, w->pubSeq, "island census")) return rc;
 	memcpy(w->h_dstate, w->h_pub, offsetof(DState, pubSeq));
 	return 0;
 }
@@ -2096,21 +2112,7 @@ static int phaseToiSync(b2hip_world* w)
 static int awaitState(b2hip_world* w, size_t nb)
 {
 	const DState* tail = (const DState*)(w->h_state + B2D_STATE_TAIL(nb));
-	volatile const int* seq = (volatile const int*)&tail->pubSeq;
-	const auto t0 = std::chrono::steady_clock::now();
-	for (unsigned spins = 1; *seq != w->stateSeq; ++spins)
-	{
-		if ((spins & 0x3fff) == 0)
-		{
-			const hipError_t q = hipStreamQuery(w->stream);
-			if (q != hipSuccess && q != hipErrorNotReady) return setError(B2HIP_ERR_HIP, std::string("state read-back: ") + hipGetErrorString(q));
-			if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return setError(B2HIP_ERR_HIP, "state read-back was not published (30 s)");
-		}
-#if defined(__x86_64__)
-		__builtin_ia32_pause();
-#endif
-	}
-	std::atomic_thread_fence(std::memory_order_acquire);
+	if (int rc = pollPublished(w, (volatile const int*)&tail->pubSeq, w->stateSeq, "state read-back")) return rc;
 	memcpy(w->h_dstate, (const void*)tail, offsetof(DState, pubSeq));
 	return 0;
 }
@@ -2294,6 +2296,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverMailbox = getenv("B2HIP_SOLVER_MAILBOX") != nullptr; // pushed hand-offs for every constraint (k_solve_mailbox) instead of k_solve_blocks
 	w->noSweepBlocks = getenv("B2HIP_NO_SWEEP_BLOCKS") != nullptr;
 	w->tracePartition = getenv("B2HIP_TRACE_PARTITION") != nullptr;
+	w->traceLaunches = getenv("B2HIP_TRACE_LAUNCHES") != nullptr;
 	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
 	w->blockLanes = 0; // chosen per partition (see phaseSolve); B2HIP_BLOCK_LANES = 256 | 512 | 1024 forces one size
 	if (const char* e = getenv("B2HIP_BLOCK_LANES")) w->blockLanes = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : (atoi(e) == 1024 ? 1024 : 0));
