@@ -165,6 +165,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 	{
 		W.blkRows[i] = 0;
 		W.blkCursor[i] = 0;
+		W.blkBodyCount[i] = 0;
+		W.blkBodyCursor[i] = 0;
 	}
 	const int n = W.nBodies;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)

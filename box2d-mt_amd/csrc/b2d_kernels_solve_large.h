@@ -290,6 +290,25 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		if (s_sums[0]) atomicAdd(&S->c.nOrphanRows, s_sums[0]);
 		if (s_sums[1]) atomicAdd(&S->c.nCutRows, s_sums[1]);
 	}
+	// the home bodies of every block, counted for k_block_census; an adoption (b_adopt: a neighbour's block, offered by
+	// k_island_edges / k_block_adopt) becomes the body's own block (small worlds: k_block_census does it itself)
+	if (S->c.nLBodies > CENSUS_WG_MAX_BODIES)
+	{
+		const int nLB = S->c.nLBodies;
+		const int nb = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS;
+		for (int base = blockIdx.x * blockDim.x; base < nLB; base += gridDim.x * blockDim.x)
+		{
+			const int k = base + threadIdx.x;
+			int e = 0;
+			if (k < nLB)
+			{
+				const int body = W.li_bodies[k];
+				e = effBlk(W, body);
+				if (e > 0 && e <= nb) W.b_blk1[body] = e; else e = 0;
+			}
+			if (e > 0) atomicAdd(&W.blkBodyCount[e - 1], 1);
+		}
+	}
 }
 
 __global__ __launch_bounds__(256) void k_color_claim(DW W)
@@ -612,6 +631,32 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 			{
 				if (nsA) atomicOr((unsigned long long*)&W.bodyActive[ids.z], 1ull << color);
 				if (nsB) atomicOr((unsigned long long*)&W.bodyActive[ids.w], 1ull << color);
+			}
+		}
+	}
+	// the home bodies of the blocks take their slots (blkBodyStart comes from k_block_census; which body gets which slot of
+	// its block does not matter to the arithmetic: a slot is an LDS address)
+	if (W.blockSort && S->c.nLBodies > CENSUS_WG_MAX_BODIES)
+	{
+		const int nLB = S->c.nLBodies;
+		const int nb = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS;
+		for (int base = blockIdx.x * blockDim.x; base < nLB; base += gridDim.x * blockDim.x)
+		{
+			const int k = base + threadIdx.x;
+			int body = 0, e = 0;
+			if (k < nLB)
+			{
+				body = W.li_bodies[k];
+				e = W.b_blk1[body];
+				if (e <= 0 || e > nb) e = 0;
+			}
+			if (e > 0)
+			{
+				// (one atomic per lane, all in flight together: the bodies of a wave belong to many blocks, and handing the slots out
+				// block after block - waveKeyedAlloc - is a round trip per block)
+				const int slot = atomicAdd(&W.blkBodyCursor[e - 1], 1);
+				W.blkBodies[W.blkBodyStart[e - 1] + slot] = body;
+				W.b_slot[body] = slot;
 			}
 		}
 	}

@@ -61,6 +61,7 @@
                                  // are not coloured (two such bodies in contact could need deg + deg - 1 > 64 colours) but solved
                                  // one after the other by k_large_hub after the coloured constraints of every sweep
 #define HUB_COLOR (MAX_COLORS - 1) // row group of the hub constraints
+#define CENSUS_WG_MAX_BODIES 16384 // large-island bodies up to this many are grouped by block by k_block_census itself (one workgroup)
 #define COLOR_SMALL_MAX 4096     // uncoloured constraints up to this many are coloured by one workgroup without a host round trip
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
 #define SHARD_BIG_BODIES 4096    // islands above this size are dealt over the ranks one by one (in root-id order), smaller ones by a hash of their root
@@ -335,6 +336,8 @@ struct DW
 	int* blkRows;        // per block: rows it owns this step
 	int* blkRowStart;    // [nBlocks + 1] exclusive scan of blkRows
 	int* blkCursor;      // per block: fill cursor of k_color_fill
+	int* blkBodyCount;   // home bodies per block (counted by k_color_check, scanned by k_block_census)
+	int* blkBodyCursor;  // ... slots handed out so far (k_color_fill)
 	int* blkBodyStart;   // [nBlocks + 1] home bodies of each block (segments of blkBodies)
 	int* blkBodies;      // large-island bodies grouped by home block
 	int* rowColor;       // per block-sorted row: its colour
