@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $OUT/pytest_gpu.txt
-timeout 900 python3 bench.py --steps 300 --warmup 120 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+timeout 900 python3 bench.py --steps 200 --warmup 60 2>$OUT/bench.err | tail -1 > $OUT/bench.json
 # kernel trace of the bench command in steady state (the 120 settle steps are part of workload construction)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --no-extras > $OUT/stats.log 2>&1
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
