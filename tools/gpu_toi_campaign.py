@@ -18,7 +18,9 @@ for k in range(cases):
     rmax = float(rng.choice([0.0, 2.0, 3.0])); seed = int(rng.integers(1, 10000)); steps = 30
     # (default radii in the smallest arena: every body overlaps a hundred others - 200 000 contacts among 2 000 bodies, half a
     # minute per step in the oracle itself and minutes in the device's serial TOI replay; keep that combination small)
-    if rmax == 0.0 and arena == 35.0: n = min(n, 700)
+    # (at 700 bodies it still runs into the documented scratch limit of a TOI event - 256 candidate contacts on the two seed
+    # bodies, B2HIP_ERR_CAPACITY - on some seeds)
+    if rmax == 0.0 and arena == 35.0: n = min(n, 400)
     kw = dict(p0=n, p1=bullets, f0=arena, f1=rmax, seed=seed, flags=FL)
     a, o = amd.world(H.FIELD, **kw), orc.world(H.FIELD, **kw)
     dev = C.c_void_p(a.device_world())
