@@ -463,6 +463,8 @@ __device__ __forceinline__ bool b2dLastBlockArrive(int* counter)
 __device__ __forceinline__ void b2dPublishCensus(const DW& W, DState* pub)
 {
 	DState* S = W.st;
+	// (what lane 0 has just stored into the counters with ordinary stores is written back before anybody reads it past the L2)
+	if (threadIdx.x == 0) __threadfence();
 	__syncthreads();
 	// (16 bytes per lane: the whole block leaves as one or two store instructions of the first wave - word by word it was
 	// two hundred separate writes across PCIe)
