@@ -13,8 +13,11 @@ enum
 	B2D_SHAPE_CIRCLE = 0, // b2Shape::Type order (b2Shape.h:53-60)
 	B2D_SHAPE_EDGE = 1,
 	B2D_SHAPE_POLYGON = 2,
-	B2D_SHAPE_CHAIN = 3
+	B2D_SHAPE_CHAIN = 3   // ONE child of a b2ChainShape: an edge record (ghost vertices = its neighbours) whose AABB has no radius
 };
+
+// an edge or a chain child: the same segment record for the narrow phase, the TOI proxy and the ray cast
+#define B2D_IS_SEGMENT(t) ((t) == B2D_SHAPE_EDGE || (t) == B2D_SHAPE_CHAIN)
 
 enum
 {
@@ -706,7 +709,9 @@ B2D_HD void b2dCollideEdgeAndPolygon(Manifold* m, const ShapeRec* edgeA, Xf xfA,
 // (b2Contact.cpp:42-52, 72-98): A/B already ordered so that typeA >= typeB ... see b2dOrderTypes.
 B2D_HD void b2dEvaluate(Manifold* m, const ShapeRec* sA, Xf xfA, const ShapeRec* sB, Xf xfB)
 {
-	int tA = sA->type, tB = sB->type;
+	// chain children collide as the edge b2ChainShape::GetChildEdge hands out (b2ChainAndPolygonContact.cpp:45-53,
+	// b2ChainAndCircleContact.cpp:45-53)
+	int tA = sA->type == B2D_SHAPE_CHAIN ? B2D_SHAPE_EDGE : sA->type, tB = sB->type;
 	if (tA == B2D_SHAPE_POLYGON && tB == B2D_SHAPE_POLYGON)
 		b2dCollidePolygons(m, sA, xfA, sB, xfB);
 	else if (tA == B2D_SHAPE_POLYGON && tB == B2D_SHAPE_CIRCLE)
@@ -726,6 +731,9 @@ B2D_HD void b2dEvaluate(Manifold* m, const ShapeRec* sA, Xf xfA, const ShapeRec*
 // edge-circle, edge-polygon. Returns 1 if (type1, type2) must be swapped, 0 if kept, -1 if no contact type.
 B2D_HD int b2dContactSwap(int type1, int type2)
 {
+	// chain-circle and chain-polygon are primary like their edge forms (b2Contact.cpp:47-52); chain-chain, chain-edge: none
+	if (type1 == B2D_SHAPE_CHAIN) type1 = B2D_SHAPE_EDGE;
+	if (type2 == B2D_SHAPE_CHAIN) type2 = B2D_SHAPE_EDGE;
 	if (type1 == B2D_SHAPE_CIRCLE && type2 == B2D_SHAPE_CIRCLE) return 0;
 	if (type1 == B2D_SHAPE_POLYGON && type2 == B2D_SHAPE_CIRCLE) return 0;
 	if (type1 == B2D_SHAPE_CIRCLE && type2 == B2D_SHAPE_POLYGON) return 1;
@@ -748,6 +756,15 @@ B2D_HD AABB b2dShapeAABB(const ShapeRec* s, Xf xf)
 		V2 p = v2(xf.p.x + q.x, xf.p.y + q.y);
 		r.lo = v2(p.x - s->radius, p.y - s->radius);
 		r.hi = v2(p.x + s->radius, p.y + s->radius);
+		return r;
+	}
+	if (s->type == B2D_SHAPE_CHAIN)
+	{
+		// b2ChainShape::ComputeAABB (b2ChainShape.cpp:174-189): the child's two vertices, NO radius
+		V2 a = b2dMulXV(xf, s->verts[0]);
+		V2 b = b2dMulXV(xf, s->verts[1]);
+		r.lo = b2dMinV(a, b);
+		r.hi = b2dMaxV(a, b);
 		return r;
 	}
 	if (s->type == B2D_SHAPE_EDGE)

@@ -68,7 +68,7 @@ B2D_HD GjkProxy b2dProxy(const ShapeRec* s)
 	GjkProxy p;
 	p.verts = s->verts;
 	p.radius = s->radius;
-	p.count = s->type == B2D_SHAPE_CIRCLE ? 1 : (s->type == B2D_SHAPE_EDGE ? 2 : s->count);
+	p.count = s->type == B2D_SHAPE_CIRCLE ? 1 : (B2D_IS_SEGMENT(s->type) ? 2 : s->count);
 	return p;
 }
 

@@ -39,6 +39,7 @@
 #include "b2d_kernels_edit.h"
 #include "b2d_kernels_shard.h"
 #include "b2d_scan.h"
+#include "b2d_shape_geom.h"
 
 static thread_local std::string g_lastError;
 
@@ -468,52 +469,13 @@ static Xf hostXf(const HostBody& b)
 	return xf;
 }
 
-// b2PolygonShape::ComputeMass (b2PolygonShape.cpp:359-440), b2CircleShape::ComputeMass (b2CircleShape.cpp:92-100),
-// b2EdgeShape::ComputeMass (b2EdgeShape.cpp:131-138)
+// fixture mass: the shared geometry module (b2d_shape_geom.h), the same routine the drop-in host shape classes call
 static void shapeMass(const ShapeRec& s, float density, float* massOut, V2* centerOut, float* IOut)
 {
-	if (s.type == B2D_SHAPE_CIRCLE)
-	{
-		float mass = density * B2D_PI * s.radius * s.radius;
-		*massOut = mass;
-		*centerOut = s.verts[0];
-		*IOut = mass * (0.5f * s.radius * s.radius + b2dDot(s.verts[0], s.verts[0]));
-		return;
-	}
-	if (s.type == B2D_SHAPE_EDGE)
-	{
-		*massOut = 0.0f;
-		*centerOut = 0.5f * (s.verts[0] + s.verts[1]);
-		*IOut = 0.0f;
-		return;
-	}
-	V2 center = v2(0.0f, 0.0f);
-	float area = 0.0f;
-	float I = 0.0f;
-	V2 sref = v2(0.0f, 0.0f);
-	for (int i = 0; i < s.count; ++i) sref += s.verts[i];
-	sref *= 1.0f / s.count;
-	const float k_inv3 = 1.0f / 3.0f;
-	for (int i = 0; i < s.count; ++i)
-	{
-		V2 e1 = s.verts[i] - sref;
-		V2 e2 = i + 1 < s.count ? s.verts[i + 1] - sref : s.verts[0] - sref;
-		float D = b2dCross(e1, e2);
-		float triangleArea = 0.5f * D;
-		area += triangleArea;
-		center += triangleArea * k_inv3 * (e1 + e2);
-		float ex1 = e1.x, ey1 = e1.y;
-		float ex2 = e2.x, ey2 = e2.y;
-		float intx2 = ex1 * ex1 + ex2 * ex1 + ex2 * ex2;
-		float inty2 = ey1 * ey1 + ey2 * ey1 + ey2 * ey2;
-		I += (0.25f * k_inv3 * D) * (intx2 + inty2);
-	}
-	*massOut = density * area;
-	center *= 1.0f / area;
-	*centerOut = center + sref;
-	float Iout = density * I;
-	Iout += (*massOut) * (b2dDot(*centerOut, *centerOut) - b2dDot(center, center));
-	*IOut = Iout;
+	const MassProps mp = b2dShapeMass(&s, density);
+	*massOut = mp.mass;
+	*centerOut = mp.center;
+	*IOut = mp.inertia;
 }
 
 // b2Body::ResetMassData (b2Body.cpp:310-385)
@@ -2513,9 +2475,9 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def,
 	if (!w || !def || !shape) return setError(B2HIP_ERR_INVALID, "null argument");
 	if (int rcu = checkUsable(w, "b2hip_create_fixture", true)) return rcu;
 	if (body < 0 || body >= (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad body id");
-	if (shape->type != B2HIP_SHAPE_CIRCLE && shape->type != B2HIP_SHAPE_EDGE && shape->type != B2HIP_SHAPE_POLYGON)
+	if (shape->type != B2HIP_SHAPE_CIRCLE && shape->type != B2HIP_SHAPE_EDGE && shape->type != B2HIP_SHAPE_POLYGON && shape->type != B2HIP_SHAPE_CHAIN)
 	{
-		return setError(B2HIP_ERR_UNSUPPORTED, "shape type is not on the device path (chain shapes)");
+		return setError(B2HIP_ERR_INVALID, "unknown shape type");
 	}
 	ShapeRec rec;
 	memset(&rec, 0, sizeof(rec));
@@ -2523,7 +2485,7 @@ int b2hip_create_fixture(b2hip_world* w, int body, const b2hip_fixture_def* def,
 	rec.count = shape->count;
 	rec.radius = shape->radius;
 	rec.centroid = v2(shape->centroid[0], shape->centroid[1]);
-	int nv = shape->type == B2HIP_SHAPE_POLYGON ? shape->count : (shape->type == B2HIP_SHAPE_EDGE ? 4 : 1);
+	int nv = shape->type == B2HIP_SHAPE_POLYGON ? shape->count : (B2D_IS_SEGMENT(shape->type) ? 4 : 1);
 	if (nv > B2D_MAX_POLY_VERTS) return setError(B2HIP_ERR_INVALID, "too many polygon vertices");
 	for (int i = 0; i < nv; ++i)
 	{

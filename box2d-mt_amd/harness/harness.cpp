@@ -445,9 +445,9 @@ int b2h_get_contacts(b2h_world* h, int cap, int* ids, int* flags, float* manifol
 		const b2Fixture* fA = c->GetFixtureA();
 		const b2Fixture* fB = c->GetFixtureB();
 		ids[4 * n + 0] = h->bodyIndex[fA->GetBody()];
-		ids[4 * n + 1] = FixtureIndexInBody(fA);
+		ids[4 * n + 1] = FixtureIndexInBody(fA) | (c->GetChildIndexA() << 16); // (child index of a chain shape in the high half)
 		ids[4 * n + 2] = h->bodyIndex[fB->GetBody()];
-		ids[4 * n + 3] = FixtureIndexInBody(fB);
+		ids[4 * n + 3] = FixtureIndexInBody(fB) | (c->GetChildIndexB() << 16);
 		flags[n] = (c->IsTouching() ? 1 : 0) | (c->IsEnabled() ? 2 : 0);
 		const b2Manifold* m = c->GetManifold();
 		float* o = manifold + 16 * n;

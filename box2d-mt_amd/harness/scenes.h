@@ -84,6 +84,9 @@ enum SceneId
 	                     //   with a rigid axle), rope joints (weights on slack and taut tethers), friction joints (pucks braked
 	                     //   against the ground), motor joints (platforms servoed to a pose the step loop keeps moving) and a
 	                     //   mouse joint dragging a crate round a circle
+	e_chains = 13,       // p0 = falling bodies (every fourth a bullet) ; chain shapes: a closed loop (an arena with a bumpy floor), an
+	                     //   open chain with ghost vertices set by hand (a ramp), one without, and a short chain on a kinematic
+	                     //   body that travels to and fro: b2ChainAndCircleContact / b2ChainAndPolygonContact, one proxy per child
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -537,6 +540,94 @@ inline void BuildSensors(Scene& s, b2World* w, int count, uint32_t seed)
 			b2PolygonShape box;
 			box.SetAsBox(rng.Range(0.2f, 0.5f), rng.Range(0.2f, 0.4f));
 			body->CreateFixture(&box, 1.0f);
+		}
+	}
+}
+
+// Chain shapes (b2ChainShape.h:32): every child segment is a proxy of its own with its neighbours as ghost vertices, so bodies
+// slide over the inner vertices without catching. Circles, boxes and polygons are dropped into a closed loop whose floor is
+// a saw-tooth, onto a ramp (open chain, ghost vertices given by SetPrevVertex / SetNextVertex) and onto a plain open chain;
+// a kinematic body carries a three-segment chain back and forth through the pile (its children move every step).
+inline void BuildChains(Scene& s, b2World* w, int count, uint32_t seed)
+{
+	w->SetGravity(b2Vec2(0.0f, -10.0f));
+	Pcg32 rng(seed ? seed : 17u);
+	{
+		b2BodyDef bd;
+		b2Body* ground = AddBody(s, w, bd);
+		b2Vec2 loop[14];
+		int n = 0;
+		loop[n++].Set(-20.0f, 0.0f);
+		for (int k = 0; k < 9; ++k) loop[n++].Set(-16.0f + 4.0f * (float)k, (k & 1) ? 0.9f : 0.0f);
+		loop[n++].Set(20.0f, 0.0f);
+		loop[n++].Set(21.0f, 18.0f);
+		loop[n++].Set(0.0f, 22.0f);
+		loop[n++].Set(-21.0f, 18.0f);
+		b2ChainShape arena;
+		arena.CreateLoop(loop, n);
+		b2FixtureDef fd;
+		fd.shape = &arena;
+		fd.friction = 0.4f;
+		ground->CreateFixture(&fd);
+
+		b2Vec2 ramp[4] = { b2Vec2(-15.0f, 9.0f), b2Vec2(-9.0f, 7.5f), b2Vec2(-4.0f, 7.0f), b2Vec2(-1.0f, 7.4f) };
+		b2ChainShape slide;
+		slide.CreateChain(ramp, 4);
+		slide.SetPrevVertex(b2Vec2(-18.0f, 11.0f));
+		slide.SetNextVertex(b2Vec2(1.0f, 8.5f));
+		ground->CreateFixture(&slide, 0.0f);
+
+		b2Vec2 shelf[3] = { b2Vec2(4.0f, 6.0f), b2Vec2(9.0f, 6.2f), b2Vec2(14.0f, 8.0f) };
+		b2ChainShape plain;
+		plain.CreateChain(shelf, 3);
+		ground->CreateFixture(&plain, 0.0f);
+	}
+	{
+		b2BodyDef bd;
+		bd.type = b2_kinematicBody;
+		bd.position.Set(-10.0f, 3.0f);
+		bd.linearVelocity.Set(2.5f, 0.0f);
+		bd.angularVelocity = 0.15f;
+		b2Body* cart = AddBody(s, w, bd);
+		b2Vec2 scoop[4] = { b2Vec2(-2.0f, 0.8f), b2Vec2(-1.0f, 0.0f), b2Vec2(1.0f, 0.0f), b2Vec2(2.0f, 0.8f) };
+		b2ChainShape bucket;
+		bucket.CreateChain(scoop, 4);
+		cart->CreateFixture(&bucket, 0.0f);
+	}
+	for (int i = 0; i < count; ++i)
+	{
+		b2BodyDef bd;
+		bd.type = b2_dynamicBody;
+		bd.position.Set(rng.Range(-16.0f, 16.0f), 9.0f + 1.1f * (float)(i / 8) + rng.Range(0.0f, 0.6f));
+		bd.angle = rng.Range(0.0f, 2.0f * b2_pi);
+		bd.linearVelocity.Set(rng.Range(-3.0f, 3.0f), rng.Range(-6.0f, 0.0f));
+		bd.bullet = (i % 4) == 3;
+		if (bd.bullet) bd.linearVelocity.Set(rng.Range(-30.0f, 30.0f), rng.Range(-60.0f, -30.0f));
+		b2Body* body = AddBody(s, w, bd);
+		if (i % 3 == 0)
+		{
+			b2CircleShape ball;
+			ball.m_radius = rng.Range(0.15f, 0.5f);
+			body->CreateFixture(&ball, 1.0f);
+		}
+		else if (i % 3 == 1)
+		{
+			b2PolygonShape box;
+			box.SetAsBox(rng.Range(0.2f, 0.55f), rng.Range(0.15f, 0.4f));
+			body->CreateFixture(&box, 1.0f);
+		}
+		else
+		{
+			b2Vec2 pts[5];
+			const float r = rng.Range(0.25f, 0.5f);
+			for (int k = 0; k < 5; ++k)
+			{
+				const float a = 2.0f * b2_pi * (float)k / 5.0f + rng.Range(-0.3f, 0.3f);
+				pts[k].Set(r * cosf(a), r * sinf(a));
+			}
+			b2PolygonShape poly;
+			poly.Set(pts, 5);
+			body->CreateFixture(&poly, 1.5f);
 		}
 	}
 }
@@ -1400,6 +1491,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_machines: BuildMachines(s, w, p.p0, p.p1, p.seed); break;
 	case e_vehicles: BuildVehicles(s, w, p.p0, p.p1, p.seed); break;
 	case e_lifecycle: BuildLifecycle(s, w, p.p0, p.seed); break;
+	case e_chains: BuildChains(s, w, p.p0, p.seed); break;
 	default: break;
 	}
 }

@@ -37,10 +37,10 @@ public:
 	const b2Contact* GetNext() const { return m_next; }
 	b2Fixture* GetFixtureA() { return m_fixtureA; }
 	const b2Fixture* GetFixtureA() const { return m_fixtureA; }
-	int32 GetChildIndexA() const { return 0; }
+	int32 GetChildIndexA() const { return m_indexA; }
 	b2Fixture* GetFixtureB() { return m_fixtureB; }
 	const b2Fixture* GetFixtureB() const { return m_fixtureB; }
-	int32 GetChildIndexB() const { return 0; }
+	int32 GetChildIndexB() const { return m_indexB; }
 	float32 GetFriction() const { return m_friction; }
 	float32 GetRestitution() const { return m_restitution; }
 
@@ -49,6 +49,7 @@ private:
 	b2Manifold m_manifold;
 	b2Fixture* m_fixtureA;
 	b2Fixture* m_fixtureB;
+	int32 m_indexA = 0, m_indexB = 0; // child indices (chain shapes)
 	b2Contact* m_next;
 	float32 m_friction, m_restitution;
 	bool m_touching, m_enabled;

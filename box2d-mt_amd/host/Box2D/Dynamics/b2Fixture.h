@@ -91,7 +91,7 @@ protected:
 	friend class b2Contact;
 
 	b2Fixture() : m_density(0.0f), m_next(nullptr), m_body(nullptr), m_shape(nullptr), m_friction(0.0f),
-		m_restitution(0.0f), m_isSensor(false), m_isThickShape(false), m_userData(nullptr), m_id(-1) {}
+		m_restitution(0.0f), m_isSensor(false), m_isThickShape(false), m_userData(nullptr), m_id(-1), m_childCount(1) {}
 
 	float32 m_density;
 	b2Fixture* m_next;
@@ -103,7 +103,8 @@ protected:
 	bool m_isSensor;
 	bool m_isThickShape;
 	void* m_userData;
-	int32 m_id;
+	int32 m_id;         // device id of child 0; a chain's children follow consecutively
+	int32 m_childCount;
 	mutable b2AABB m_aabbCache;
 };
 

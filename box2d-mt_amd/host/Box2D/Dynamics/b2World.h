@@ -136,6 +136,7 @@ private:
 	std::vector<std::pair<int32, int32> > m_endedEarly; // fixture pairs whose EndContact was delivered by an edit between steps
 	std::vector<b2ContactEdge> m_edgeViews; // b2Body::GetContactList: edges of one body, rebuilt per call
 	void DestroyFixtureView(b2Fixture* f);
+	void BindFixtures(b2Contact& c, int deviceFixtureA, int deviceFixtureB) const;
 	void EndContactsOf(b2Body* body, b2Fixture* fixture);
 };
 

@@ -2,6 +2,8 @@
 #include "Box2D/Common/b2Settings.h"
 #include "Box2D/Common/b2Math.h"
 
+#include "../../csrc/b2d_mat33.h"
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,59 +31,35 @@ void b2Log(const char* string, ...)
 	va_end(args);
 }
 
-// Cramer's rule, reference semantics (b2Math.cpp:25-53)
+// b2Mat33's out-of-line members (b2Math.h:237-291; b2Math.cpp:25-95): the arithmetic is stated once, in the header the device
+// joint solvers use (csrc/b2d_mat33.h); these are the host API's doors to it.
+static M33 columns(const b2Mat33& A)
+{
+	M33 K;
+	K.ex = v3(A.ex.x, A.ex.y, A.ex.z);
+	K.ey = v3(A.ey.x, A.ey.y, A.ey.z);
+	K.ez = v3(A.ez.x, A.ez.y, A.ez.z);
+	return K;
+}
+
+static void store(b2Mat33* out, const M33& K)
+{
+	out->ex.Set(K.ex.x, K.ex.y, K.ex.z);
+	out->ey.Set(K.ey.x, K.ey.y, K.ey.z);
+	out->ez.Set(K.ez.x, K.ez.y, K.ez.z);
+}
+
 b2Vec3 b2Mat33::Solve33(const b2Vec3& b) const
 {
-	float32 det = b2Dot(ex, b2Cross(ey, ez));
-	if (det != 0.0f) det = 1.0f / det;
-	b2Vec3 x;
-	x.x = det * b2Dot(b, b2Cross(ey, ez));
-	x.y = det * b2Dot(ex, b2Cross(b, ez));
-	x.z = det * b2Dot(ex, b2Cross(ey, b));
-	return x;
+	const V3 x = b2dM33Solve33(columns(*this), v3(b.x, b.y, b.z));
+	return b2Vec3(x.x, x.y, x.z);
 }
 
 b2Vec2 b2Mat33::Solve22(const b2Vec2& b) const
 {
-	float32 a11 = ex.x, a12 = ey.x, a21 = ex.y, a22 = ey.y;
-	float32 det = a11 * a22 - a12 * a21;
-	if (det != 0.0f) det = 1.0f / det;
-	b2Vec2 x;
-	x.x = det * (a22 * b.x - a12 * b.y);
-	x.y = det * (a11 * b.y - a21 * b.x);
-	return x;
+	const V2 x = b2dM33Solve22(columns(*this), v2(b.x, b.y));
+	return b2Vec2(x.x, x.y);
 }
 
-void b2Mat33::GetInverse22(b2Mat33* M) const
-{
-	float32 a = ex.x, b = ey.x, c = ex.y, d = ey.y;
-	float32 det = a * d - b * c;
-	if (det != 0.0f) det = 1.0f / det;
-	M->ex.x = det * d;
-	M->ey.x = -det * b;
-	M->ex.z = 0.0f;
-	M->ex.y = -det * c;
-	M->ey.y = det * a;
-	M->ey.z = 0.0f;
-	M->ez.x = 0.0f;
-	M->ez.y = 0.0f;
-	M->ez.z = 0.0f;
-}
-
-void b2Mat33::GetSymInverse33(b2Mat33* M) const
-{
-	float32 det = b2Dot(ex, b2Cross(ey, ez));
-	if (det != 0.0f) det = 1.0f / det;
-	float32 a11 = ex.x, a12 = ey.x, a13 = ez.x;
-	float32 a22 = ey.y, a23 = ez.y;
-	float32 a33 = ez.z;
-	M->ex.x = det * (a22 * a33 - a23 * a23);
-	M->ex.y = det * (a13 * a23 - a12 * a33);
-	M->ex.z = det * (a12 * a23 - a13 * a22);
-	M->ey.x = M->ex.y;
-	M->ey.y = det * (a11 * a33 - a13 * a13);
-	M->ey.z = det * (a13 * a12 - a11 * a23);
-	M->ez.x = M->ex.z;
-	M->ez.y = M->ey.z;
-	M->ez.z = det * (a11 * a22 - a12 * a12);
-}
+void b2Mat33::GetInverse22(b2Mat33* M) const { store(M, b2dM33Inverse22(columns(*this))); }
+void b2Mat33::GetSymInverse33(b2Mat33* M) const { store(M, b2dM33SymInverse33(columns(*this))); }

@@ -9,6 +9,9 @@
 #include <string.h>
 #include <new>
 
+// the 152-byte device record of a shape / of child `child` of a chain (host/src/b2_shapes.cpp)
+void b2ShapeToRecord(const b2Shape* shape, int32 child, void* record152);
+
 // ---- b2World ------------------------------------------------------------------------------------
 b2World::b2World(const b2Vec2& gravity)
 {
@@ -159,7 +162,11 @@ b2Body* b2World::CreateBody(const b2BodyDef* def)
 // The host-side view of a fixture that is gone (its shape clone included); the id stays reserved on the device
 void b2World::DestroyFixtureView(b2Fixture* f)
 {
-	if (f->m_id >= 0 && f->m_id < (int32)m_fixtures.size()) m_fixtures[f->m_id] = nullptr;
+	for (int32 child = 0; child < f->m_childCount; ++child)
+	{
+		const int32 id = f->m_id + child;
+		if (id >= 0 && id < (int32)m_fixtures.size()) m_fixtures[id] = nullptr;
+	}
 	if (f->m_shape)
 	{
 		f->m_shape->~b2Shape();
@@ -183,7 +190,7 @@ void b2World::EndContactsOf(b2Body* body, b2Fixture* fixture)
 		                          : (c->m_fixtureA->GetBody() == body || c->m_fixtureB->GetBody() == body);
 		if (!mine) continue;
 		// (the step's own event list will name this contact's end as well: remembered, so that it is delivered once)
-		m_endedEarly.push_back(std::make_pair(c->m_fixtureA->m_id, c->m_fixtureB->m_id));
+		m_endedEarly.push_back(std::make_pair(c->m_fixtureA->m_id + c->m_indexA, c->m_fixtureB->m_id + c->m_indexB));
 		if (m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
 	}
 }
@@ -528,6 +535,15 @@ int b2World::FilterTrampoline(void* user, int fixtureA, int fixtureB)
 	return self->m_contactFilter->ShouldCollide(self->m_fixtures[fixtureA], self->m_fixtures[fixtureB], 0) ? 1 : 0;
 }
 
+// A device fixture id is (b2Fixture, child): a chain's children are consecutive device fixtures (b2Body::CreateFixture)
+void b2World::BindFixtures(b2Contact& c, int deviceFixtureA, int deviceFixtureB) const
+{
+	c.m_fixtureA = m_fixtures[deviceFixtureA];
+	c.m_fixtureB = m_fixtures[deviceFixtureB];
+	c.m_indexA = c.m_fixtureA ? deviceFixtureA - c.m_fixtureA->m_id : 0;
+	c.m_indexB = c.m_fixtureB ? deviceFixtureB - c.m_fixtureB->m_id : 0;
+}
+
 static void FillManifold(b2Manifold& out, const b2hip_manifold& m)
 {
 	memset(&out, 0, sizeof(out));
@@ -554,8 +570,7 @@ int b2World::PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int 
 	if (!self->m_contactListener) return 1;
 	b2Contact c;
 	FillManifold(c.m_manifold, *manifold);
-	c.m_fixtureA = self->m_fixtures[fixtureA];
-	c.m_fixtureB = self->m_fixtures[fixtureB];
+	self->BindFixtures(c, fixtureA, fixtureB);
 	c.m_next = nullptr;
 	c.m_friction = b2MixFriction(c.m_fixtureA->GetFriction(), c.m_fixtureB->GetFriction());
 	c.m_restitution = b2MixRestitution(c.m_fixtureA->GetRestitution(), c.m_fixtureB->GetRestitution());
@@ -633,8 +648,7 @@ void b2World::DeliverContactEvents()
 		else
 		{
 			memset(&gone.m_manifold, 0, sizeof(gone.m_manifold));
-			gone.m_fixtureA = m_fixtures[e.fixture_a];
-			gone.m_fixtureB = m_fixtures[e.fixture_b];
+			BindFixtures(gone, e.fixture_a, e.fixture_b);
 			gone.m_next = nullptr;
 			gone.m_friction = 0.0f;
 			gone.m_restitution = 0.0f;
@@ -710,7 +724,7 @@ void b2World::RayCast(b2RayCastCallback* callback, const b2Vec2& point1, const b
 		input.p2 = point2;
 		input.maxFraction = maxFraction;
 		b2RayCastOutput output;
-		if (!fixture->GetShape()->RayCast(&output, input, fixture->GetBody()->GetTransform(), 0)) continue;
+		if (!fixture->GetShape()->RayCast(&output, input, fixture->GetBody()->GetTransform(), (int32)i - fixture->m_id)) continue;
 		const float32 fraction = output.fraction;
 		const b2Vec2 point = (1.0f - fraction) * point1 + fraction * point2;
 		const float32 value = callback->ReportFixture(fixture, point, output.normal, fraction);
@@ -795,8 +809,7 @@ b2Contact* b2World::GetContactList()
 				c.m_manifold.points[k].tangentImpulse = r.tangent_impulse[k];
 				c.m_manifold.points[k].id.key = r.id_key[k];
 			}
-			c.m_fixtureA = m_fixtures[r.fixture_a];
-			c.m_fixtureB = m_fixtures[r.fixture_b];
+			BindFixtures(c, r.fixture_a, r.fixture_b);
 			c.m_friction = r.friction;
 			c.m_restitution = r.restitution;
 			c.m_touching = (r.flags & 1u) != 0;
@@ -837,48 +850,6 @@ b2Fixture* b2Body::CreateFixture(const b2FixtureDef* def)
 {
 	if (m_world->IsLocked() || !m_world->m_hip) return nullptr;
 	const b2Shape* shape = def->shape;
-	b2hip_shape hs;
-	memset(&hs, 0, sizeof(hs));
-	hs.type = (int32_t)shape->GetType();
-	hs.radius = shape->m_radius;
-	switch (shape->GetType())
-	{
-	case b2Shape::e_circle:
-	{
-		const b2CircleShape* c = static_cast<const b2CircleShape*>(shape);
-		hs.verts[0] = c->m_p.x;
-		hs.verts[1] = c->m_p.y;
-		break;
-	}
-	case b2Shape::e_edge:
-	{
-		const b2EdgeShape* e = static_cast<const b2EdgeShape*>(shape);
-		hs.verts[0] = e->m_vertex1.x; hs.verts[1] = e->m_vertex1.y;
-		hs.verts[2] = e->m_vertex2.x; hs.verts[3] = e->m_vertex2.y;
-		hs.verts[4] = e->m_vertex0.x; hs.verts[5] = e->m_vertex0.y;
-		hs.verts[6] = e->m_vertex3.x; hs.verts[7] = e->m_vertex3.y;
-		hs.count = (e->m_hasVertex0 ? 1 : 0) | (e->m_hasVertex3 ? 2 : 0);
-		break;
-	}
-	case b2Shape::e_polygon:
-	{
-		const b2PolygonShape* p = static_cast<const b2PolygonShape*>(shape);
-		hs.count = p->m_count;
-		hs.centroid[0] = p->m_centroid.x;
-		hs.centroid[1] = p->m_centroid.y;
-		for (int32 i = 0; i < p->m_count; ++i)
-		{
-			hs.verts[2 * i] = p->m_vertices[i].x;
-			hs.verts[2 * i + 1] = p->m_vertices[i].y;
-			hs.normals[2 * i] = p->m_normals[i].x;
-			hs.normals[2 * i + 1] = p->m_normals[i].y;
-		}
-		break;
-	}
-	default:
-		fprintf(stderr, "b2Body::CreateFixture: shape type %d is not on the device path\n", (int)shape->GetType());
-		return nullptr;
-	}
 	b2hip_fixture_def fd;
 	memset(&fd, 0, sizeof(fd));
 	fd.density = def->density;
@@ -889,15 +860,27 @@ b2Fixture* b2Body::CreateFixture(const b2FixtureDef* def)
 	fd.group_index = def->filter.groupIndex;
 	fd.is_sensor = def->isSensor;
 	fd.thick_shape = def->thickShape;
-	int id = b2hip_create_fixture(m_world->m_hip, m_id, &fd, &hs);
-	if (id < 0)
+	// one device fixture (= one broad-phase proxy) per child, in child order like b2Fixture::CreateProxies
+	// (b2Fixture.cpp:126-141): a chain of n segments is n consecutive records of type "chain child"
+	const int32 children = shape->GetChildCount();
+	if (children < 1) return nullptr;
+	int id = -1;
+	for (int32 child = 0; child < children; ++child)
 	{
-		fprintf(stderr, "b2Body::CreateFixture: %s\n", b2hip_last_error());
-		return nullptr;
+		b2hip_shape hs;
+		b2ShapeToRecord(shape, child, &hs);
+		const int got = b2hip_create_fixture(m_world->m_hip, m_id, &fd, &hs);
+		if (got < 0 || (child > 0 && got != id + child))
+		{
+			fprintf(stderr, "b2Body::CreateFixture: %s\n", got < 0 ? b2hip_last_error() : "fixture ids of a chain are not consecutive");
+			return nullptr;
+		}
+		if (child == 0) id = got;
 	}
 	void* mem = b2Alloc(sizeof(b2Fixture));
 	b2Fixture* f = new (mem) b2Fixture;
 	f->m_id = id;
+	f->m_childCount = children;
 	f->m_body = this;
 	f->m_density = def->density;
 	f->m_friction = def->friction;
@@ -910,8 +893,8 @@ b2Fixture* b2Body::CreateFixture(const b2FixtureDef* def)
 	f->m_next = m_fixtureList;
 	m_fixtureList = f;
 	++m_fixtureCount;
-	if ((int)m_world->m_fixtures.size() <= id) m_world->m_fixtures.resize(id + 1, nullptr);
-	m_world->m_fixtures[id] = f;
+	if ((int)m_world->m_fixtures.size() < id + children) m_world->m_fixtures.resize(id + children, nullptr);
+	for (int32 child = 0; child < children; ++child) m_world->m_fixtures[id + child] = f;
 	m_world->m_fatValid = false;
 	m_world->m_statesValid = false;
 	return f;
@@ -1087,7 +1070,11 @@ void b2Body::DestroyFixture(b2Fixture* fixture)
 	if (*node == fixture) *node = fixture->m_next;
 	--m_fixtureCount;
 	m_world->EndContactsOf(this, fixture);
-	if (b2hip_destroy_fixture(m_world->m_hip, fixture->m_id) != B2HIP_OK) fprintf(stderr, "b2Body::DestroyFixture: %s\n", b2hip_last_error());
+	// (the proxies of a chain go in child order, b2Fixture::DestroyProxies b2Fixture.cpp:143-155)
+	for (int32 child = 0; child < fixture->m_childCount; ++child)
+	{
+		if (b2hip_destroy_fixture(m_world->m_hip, fixture->m_id + child) != B2HIP_OK) fprintf(stderr, "b2Body::DestroyFixture: %s\n", b2hip_last_error());
+	}
 	m_world->DestroyFixtureView(fixture);
 	m_world->m_statesValid = false;
 	m_world->m_contactsValid = false;
@@ -1125,20 +1112,20 @@ b2ContactEdge* b2Body::GetContactList()
 void b2Fixture::SetFilterData(const b2Filter& filter)
 {
 	m_filter = filter;
-	b2hip_fixture_set_filter(m_body->GetWorld()->GetDeviceWorld(), m_id, filter.categoryBits, filter.maskBits, filter.groupIndex);
+	for (int32 child = 0; child < m_childCount; ++child) b2hip_fixture_set_filter(m_body->GetWorld()->GetDeviceWorld(), m_id + child, filter.categoryBits, filter.maskBits, filter.groupIndex);
 }
 
 void b2Fixture::Refilter()
 {
 	if (m_body == nullptr) return;
-	b2hip_fixture_refilter(m_body->GetWorld()->GetDeviceWorld(), m_id);
+	for (int32 child = 0; child < m_childCount; ++child) b2hip_fixture_refilter(m_body->GetWorld()->GetDeviceWorld(), m_id + child);
 }
 
 void b2Fixture::SetSensor(bool sensor)
 {
 	if (sensor == m_isSensor) return;
 	m_isSensor = sensor;
-	b2hip_fixture_set_sensor(m_body->GetWorld()->GetDeviceWorld(), m_id, sensor ? 1 : 0);
+	for (int32 child = 0; child < m_childCount; ++child) b2hip_fixture_set_sensor(m_body->GetWorld()->GetDeviceWorld(), m_id + child, sensor ? 1 : 0);
 	m_body->m_world->TouchState(m_body->m_id); // (SetSensor wakes its body)
 }
 
@@ -1146,7 +1133,7 @@ void b2Fixture::SetThickShape(bool flag)
 {
 	if (flag == m_isThickShape) return;
 	m_isThickShape = flag;
-	b2hip_fixture_set_thick(m_body->GetWorld()->GetDeviceWorld(), m_id, flag ? 1 : 0);
+	for (int32 child = 0; child < m_childCount; ++child) b2hip_fixture_set_thick(m_body->GetWorld()->GetDeviceWorld(), m_id + child, flag ? 1 : 0);
 }
 
 float32 b2Body::GetMass() const
@@ -1180,9 +1167,8 @@ bool b2Fixture::TestPoint(const b2Vec2& p) const
 
 const b2AABB& b2Fixture::GetAABB(int32 childIndex) const
 {
-	B2_NOT_USED(childIndex);
 	float a[4] = { 0, 0, 0, 0 };
-	b2hip_get_fat_aabb(m_body->m_world->m_hip, m_id, a);
+	b2hip_get_fat_aabb(m_body->m_world->m_hip, m_id + (childIndex >= 0 && childIndex < m_childCount ? childIndex : 0), a);
 	m_aabbCache.lowerBound.Set(a[0], a[1]);
 	m_aabbCache.upperBound.Set(a[2], a[3]);
 	return m_aabbCache;

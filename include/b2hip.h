@@ -77,7 +77,12 @@ typedef enum b2hip_status
 } b2hip_status;
 
 enum { B2HIP_STATIC_BODY = 0, B2HIP_KINEMATIC_BODY = 1, B2HIP_DYNAMIC_BODY = 2 }; /* b2BodyType, b2Body.h:36-47 */
-enum { B2HIP_SHAPE_CIRCLE = 0, B2HIP_SHAPE_EDGE = 1, B2HIP_SHAPE_POLYGON = 2 };    /* b2Shape::Type, b2Shape.h:53-60 */
+enum { B2HIP_SHAPE_CIRCLE = 0, B2HIP_SHAPE_EDGE = 1, B2HIP_SHAPE_POLYGON = 2,          /* b2Shape::Type, b2Shape.h:53-60 */
+       /* ONE child of a b2ChainShape (b2ChainShape.h:32, GetChildEdge b2ChainShape.cpp:114-147): the record of an edge whose
+        * ghost vertices are the child's neighbours. It collides, sweeps and ray-casts as that edge; its broad-phase AABB has no
+        * radius (b2ChainShape.cpp:174-189). A chain fixture of n children is n consecutive fixtures of this type, created in
+        * child order (the reference creates one proxy per child in that order, b2Fixture.cpp:126-141). */
+       B2HIP_SHAPE_CHAIN = 3 };
 
 typedef struct b2hip_world_def
 {

@@ -1,6 +1,6 @@
 /* b2o_abi_shim.c - TEST INFRASTRUCTURE. Exposes the CPU oracle (b2o_*) under the product's C-ABI
  * symbol names (include/b2hip.h) so that the SAME drop-in Box2D host layer and the SAME scene
- * harness (in oracle/harness) can be linked against the oracle instead of libb2hip.so:
+ * harness (in box2d-mt_amd/harness) can be linked against the oracle instead of libb2hip.so:
  *   oracle/libb2oracle_harness.so = harness.cpp + box2d-mt_amd/host/src/ (all .cpp) + this shim + b2o_*.c
  * Nothing in the product links this file. */
 #include "b2o.h"

@@ -537,8 +537,9 @@ void b2o_evaluate(manifold* m, const b2o_shape* sA, xform xfA, const b2o_shape* 
 	if (sA->type == SHAPE_POLYGON && sB->type == SHAPE_POLYGON) b2o_collide_polygons(m, sA, xfA, sB, xfB);
 	else if (sA->type == SHAPE_POLYGON && sB->type == SHAPE_CIRCLE) b2o_collide_polygon_circle(m, sA, xfA, sB, xfB);
 	else if (sA->type == SHAPE_CIRCLE && sB->type == SHAPE_CIRCLE) b2o_collide_circles(m, sA, xfA, sB, xfB);
-	else if (sA->type == SHAPE_EDGE && sB->type == SHAPE_POLYGON) b2o_collide_edge_polygon(m, sA, xfA, sB, xfB);
-	else if (sA->type == SHAPE_EDGE && sB->type == SHAPE_CIRCLE) b2o_collide_edge_circle(m, sA, xfA, sB, xfB);
+	/* chain children: b2ChainAndPolygonContact.cpp:45-53, b2ChainAndCircleContact.cpp:45-53 evaluate the child edge */
+	else if (SHAPE_IS_SEGMENT(sA->type) && sB->type == SHAPE_POLYGON) b2o_collide_edge_polygon(m, sA, xfA, sB, xfB);
+	else if (SHAPE_IS_SEGMENT(sA->type) && sB->type == SHAPE_CIRCLE) b2o_collide_edge_circle(m, sA, xfA, sB, xfB);
 	else m->pointCount = 0;
 }
 

@@ -27,7 +27,10 @@
 #define B2O_LINEAR_SLEEP_TOL 0.01f
 #define B2O_ANGULAR_SLEEP_TOL (2.0f / 180.0f * B2O_PI)
 
-enum { SHAPE_CIRCLE = 0, SHAPE_EDGE = 1, SHAPE_POLYGON = 2 };
+/* SHAPE_CHAIN = one child of a b2ChainShape: the edge b2ChainShape::GetChildEdge hands out (b2ChainShape.cpp:114-147) for the
+ * narrow phase and the TOI proxy; its AABB has no radius (b2ChainShape.cpp:174-189) */
+enum { SHAPE_CIRCLE = 0, SHAPE_EDGE = 1, SHAPE_POLYGON = 2, SHAPE_CHAIN = 3 };
+#define SHAPE_IS_SEGMENT(t) ((t) == SHAPE_EDGE || (t) == SHAPE_CHAIN)
 enum { MANIFOLD_CIRCLES = 0, MANIFOLD_FACE_A = 1, MANIFOLD_FACE_B = 2 };
 #define CF_VERTEX 0u
 #define CF_FACE 1u

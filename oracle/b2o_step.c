@@ -249,7 +249,7 @@ static void shape_mass(const b2o_shape* s, float density, float* mass, vec2* cen
 		*I = (*mass) * (0.5f * s->radius * s->radius + v_dot(p, p));
 		return;
 	}
-	if (s->type == SHAPE_EDGE)
+	if (SHAPE_IS_SEGMENT(s->type))
 	{
 		*mass = 0.0f;
 		*center = v_scale(0.5f, v_add(shape_vert(s, 0), shape_vert(s, 1)));
@@ -291,6 +291,16 @@ static void shape_aabb(const b2o_shape* s, xform xf, float out[4])
 		vec2 p = v_make(xf.p.x + q.x, xf.p.y + q.y);
 		out[0] = p.x - s->radius; out[1] = p.y - s->radius;
 		out[2] = p.x + s->radius; out[3] = p.y + s->radius;
+		return;
+	}
+	if (s->type == SHAPE_CHAIN)
+	{
+		/* b2ChainShape::ComputeAABB  b2ChainShape.cpp:174-189 : no radius */
+		vec2 a = xf_mul(xf, shape_vert(s, 0)), b = xf_mul(xf, shape_vert(s, 1));
+		lower = v_min(a, b);
+		upper = v_max(a, b);
+		out[0] = lower.x; out[1] = lower.y;
+		out[2] = upper.x; out[3] = upper.y;
 		return;
 	}
 	if (s->type == SHAPE_EDGE)
@@ -732,6 +742,9 @@ static int filter_should_collide(const fixture_t* a, const fixture_t* b)
 /* which fixture becomes A: b2Contact::Create register table (b2Contact.cpp:42-52, 72-98) */
 static int contact_swap(int t1, int t2)
 {
+	/* b2ChainAndCircleContact / b2ChainAndPolygonContact are primary like the edge forms (b2Contact.cpp:47-52) */
+	if (t1 == SHAPE_CHAIN) t1 = SHAPE_EDGE;
+	if (t2 == SHAPE_CHAIN) t2 = SHAPE_EDGE;
 	if (t1 == SHAPE_CIRCLE && t2 == SHAPE_CIRCLE) return 0;
 	if (t1 == SHAPE_POLYGON && t2 == SHAPE_CIRCLE) return 0;
 	if (t1 == SHAPE_CIRCLE && t2 == SHAPE_POLYGON) return 1;

@@ -49,7 +49,7 @@ void b2o_proxy_set(gjk_proxy* p, const b2o_shape* s)
 	p->verts = s->verts;
 	p->radius = s->radius;
 	if (s->type == SHAPE_CIRCLE) p->count = 1;
-	else if (s->type == SHAPE_EDGE) p->count = 2;
+	else if (SHAPE_IS_SEGMENT(s->type)) p->count = 2; /* chain child: b2Distance.cpp:60-80 */
 	else p->count = s->count;
 }
 
@@ -554,7 +554,7 @@ void b2o_time_of_impact(toi_output* out, const gjk_proxy* pA, const sweep_t* swe
 	out->iterations = iter;
 }
 
-/* ---- probes (same layouts as oracle/harness/harness.cpp b2h_probe_distance / b2h_probe_toi) -------- */
+/* ---- probes (same layouts as box2d-mt_amd/harness/harness.cpp b2h_probe_distance / b2h_probe_toi) -------- */
 static sweep_t sweep_from9(const float* s9)
 {
 	sweep_t s;

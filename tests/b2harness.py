@@ -1,4 +1,4 @@
-"""ctypes binding of the headless harness C ABI (oracle/harness/harness.cpp).
+"""ctypes binding of the headless harness C ABI (box2d-mt_amd/harness/harness.cpp).
 
 TEST INFRASTRUCTURE.  The same ABI is exported by two shared libraries built from one source:
   oracle/_ref/libb2ref_harness.so      the real reference (skitzoid/Box2D-MT) compiled where it lies
@@ -17,7 +17,7 @@ ORACLE_LIB = os.path.join(ROOT, "oracle", "libb2oracle_harness.so")
 VALIDATION_LIB = os.path.join(ROOT, "box2d-mt_amd", "validation", "libb2amd_harness_validation.so")
 VALIDATION_CAPI = os.path.join(ROOT, "box2d-mt_amd", "validation", "libb2hip_validation.so")
 
-HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS, SENSORS, ROPES, MACHINES, VEHICLES, LIFECYCLE = range(13)
+HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS, SENSORS, ROPES, MACHINES, VEHICLES, LIFECYCLE, CHAINS = range(14)
 F_CONTINUOUS, F_SLEEP, F_WARM, F_SUBSTEP = 1, 2, 4, 8
 DEFAULT_FLAGS = F_SLEEP | F_WARM  # CCD off unless a test asks for it
 
@@ -266,7 +266,7 @@ class World:
         self.L.b2h_record_events(self.ptr, (mode if mode is not None else 1) if enable else 0)
 
     def events_ex(self, cap=1 << 18):
-        """Every recorded callback since the last call, in call order: rows of 10 ints (see oracle/harness/harness.cpp):
+        """Every recorded callback since the last call, in call order: rows of 10 ints (see box2d-mt_amd/harness/harness.cpp):
         kind (0 begin, 1 end, 2 PreSolve, 3 PostSolve), bodyA, fixtureA, bodyB, fixtureB, five payload words."""
         out = np.zeros((cap, 10), np.int32)
         n = self.L.b2h_get_events_ex(self.ptr, cap, _iptr(out))

@@ -77,7 +77,7 @@ void probe_shape_aabb(const void* shape, const float* xf, float* out4)
 	out4[3] = r.hi.y;
 }
 
-// Same layouts as the harness probes b2h_probe_distance / b2h_probe_toi (oracle/harness/harness.cpp).
+// Same layouts as the harness probes b2h_probe_distance / b2h_probe_toi (box2d-mt_amd/harness/harness.cpp).
 static Sweep SweepFrom9(const float* s9)
 {
 	Sweep s;

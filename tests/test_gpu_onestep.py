@@ -134,7 +134,18 @@ def one_step_deviation(b, o):
     dev["angle"] = float(np.abs(sb["angle"] - so["angle"]).max())
     dev["vel"] = max(float(np.abs(sb[f] - so[f]).max()) for f in ("vx", "vy")) / scale
     dev["spin"] = float(np.abs(sb["w"] - so["w"]).max())
-    dev["speed_max"] = float(np.sqrt(so["vx"] ** 2 + so["vy"] ** 2).max())
+    speed = np.sqrt(so["vx"] ** 2 + so["vy"] ** 2)
+    dev["speed_max"] = float(speed.max())
+    # the same deviations in absolute units and per body (a bound relative to the 176 m extent of the
+    # scene says little about 1 m boxes): metres, metres / body size, m/s, and |dv| of a body over max(|v| of that body, 1 m/s)
+    dp = np.sqrt((sb["px"] - so["px"]) ** 2 + (sb["py"] - so["py"]) ** 2)
+    dv = np.sqrt((sb["vx"] - so["vx"]) ** 2 + (sb["vy"] - so["vy"]) ** 2)
+    dev["pos_m"] = float(dp.max())
+    dev["pos_m_p99"] = float(np.percentile(dp, 99))
+    dev["pos_m_p50"] = float(np.percentile(dp, 50))
+    dev["vel_mps"] = float(dv.max())
+    dev["vel_mps_p99"] = float(np.percentile(dv, 99))
+    dev["vel_over_speed"] = float((dv / np.maximum(speed, 1.0)).max())
     dev["flags_differ"] = int(np.count_nonzero((sb["flags"] & 0x7f) != (so["flags"] & 0x7f)))
     cb, co = b.contacts(), o.contacts()
     tb = {(int(fa), int(fb)): int(fl) & 1 for fa, fb, fl in zip(cb["fixture_a"], cb["fixture_b"], cb["flags"])}

@@ -1,6 +1,6 @@
 """Body / fixture life cycle and the mutators between steps (the drop-in boundary beyond build-once scenes).
 
-One scripted scene (oracle/harness/scenes.h: BuildLifecycle + LifecycleEdits, written against the public Box2D API only)
+One scripted scene (box2d-mt_amd/harness/scenes.h: BuildLifecycle + LifecycleEdits, written against the public Box2D API only)
 destroys bodies and fixtures in the middle of a heap (b2World::DestroyBody b2World.cpp:585-670, b2Body::DestroyFixture
 b2Body.cpp:238-308), creates new ones afterwards (the freed broad-phase proxy ids are reused in the dynamic tree's LIFO
 order, b2DynamicTree.cpp:53-99, and the island seed order follows m_nonStaticBodies' swap-remove, b2World.cpp:662-667),

@@ -1,6 +1,6 @@
 """b2ContactListener::PreSolve / PostSolve and a user b2ContactFilter.
 
-The harness installs the same recording listener / filter on every backend (oracle/harness/harness.cpp): the listener logs
+The harness installs the same recording listener / filter on every backend (box2d-mt_amd/harness/harness.cpp): the listener logs
 every PreSolve (old and new manifold words, enabled flag after the call) and PostSolve (solver point count, impulse bits)
 callback; in mode 8 its PreSolve disables the contacts a fixed rule of the body indices picks (b2Contact::SetEnabled(false),
 b2Contact.h:117-123), the filter refuses the pairs another fixed rule picks (b2ContactFilter::ShouldCollide override,

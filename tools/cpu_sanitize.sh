@@ -10,8 +10,8 @@ O=$R/gpurun_out/asan
 mkdir -p $O && cd $O
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 for f in b2o_step b2o_collide b2o_joint b2o_toi b2o_abi_shim; do gcc $SAN -std=c11 -ffp-contract=off -fPIC -I$R/include -c $R/oracle/$f.c -o $f.o; done
-g++ $SAN -std=c++17 -ffp-contract=off -w -DB2H_BACKEND_AMD -I$R/box2d-mt_amd/host -I$R/include -I$R/oracle/harness -o harness_asan \
-    $R/tools/sanitize/harness_main.cpp $R/oracle/harness/harness.cpp $R/box2d-mt_amd/host/src/*.cpp b2o_*.o -lpthread -lm
+g++ $SAN -std=c++17 -ffp-contract=off -w -DB2H_BACKEND_AMD -I$R/box2d-mt_amd/host -I$R/include -I$R/box2d-mt_amd/harness -o harness_asan \
+    $R/tools/sanitize/harness_main.cpp $R/box2d-mt_amd/harness/harness.cpp $R/box2d-mt_amd/host/src/*.cpp b2o_*.o -lpthread -lm
 ASAN_OPTIONS=detect_leaks=1 ./harness_asan > harness.log 2>&1 || true
 bad=$(grep -c -E "ERROR|runtime error" harness.log || true)
 if [ -d /root/reference/Testbed ]; then
