@@ -7,8 +7,9 @@ configs[1]: the Pyramid recipe with 141 rows = 10 011 dynamic boxes on a ground 
 measured in STEADY STATE: the scene is first settled for SETTLE_STEPS (240) untimed steps as part of building the
 workload, whatever --warmup says (the free-fall / first-impact transient of those steps is reported separately
 under "transient"), then --warmup untimed steps, then the timed steps. For N>1
-(configs[3]-style sharding) every rank owns one such pyramid island: islands never exchange data, so
-there is no data-path collective ("weak" scaling); `value` counts island-steps of all ranks.
+(configs[3]-style sharding) ONE world holds N such pyramids and every rank solves one of them ("weak" scaling: one
+pyramid per GPU); `value` = pyramid-steps/s = world steps/s x pyramids (`world_steps_per_s` is reported beside it).
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run, one rank per GPU, RCCL).
 World flags are the reference's defaults (b2World.cpp:75-79): continuous physics (TOI) ON, sleeping ON,
 warm starting ON - on the GPU path and on the CPU baseline alike (--no-ccd turns TOI off on both).
 
@@ -16,7 +17,10 @@ One JSON line is printed by rank 0. Extra objects:
   roofline      dominant solver kernel: algorithmic bytes per launch / mean launch duration (HIP events
                 on the world's stream), against the 8 TB/s HBM3E peak
   cpu_baseline  the reference build (oracle/_ref, kind "reference") or the C oracle (kind "port") stepping
-                the same workload on the host cores, bounded sample
+                the same workload FROM THE SAME STATE (settled for the same steps) on the host cores, bounded sample
+  config.parity_class / exact_order   which parity class the timed solver is in (coloured order: tolerance measured one
+                step from identical state, tests/test_gpu_onestep.py) and what the bit-exact class costs on this workload:
+                ms/step of the same settled state in exact-order mode (B2HIP_FORCE_LARGE=2), from a snapshot
 """
 import argparse
 import ctypes as C
@@ -36,6 +40,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 # is still growing at step 120 (14 600 of its final 20 200 touching contacts, a new block partition every ten steps): the
 # contact count levels off at step ~200, so the workload is settled for 240 steps.
 SETTLE_STEPS = 240
+# Which parity class the timed solver belongs to ("Order, exactness and the tolerance"). The bounds are the
+# ones tests/test_gpu_onestep.py asserts at THIS state (steps 245 and 300 of the scene), measured on MI355X.
+PARITY_CLASS = ("coloured order (k_solve_blocks): integer results (island membership, awake flags) exact; floats differ from the "
+                "reference by the ORDER dependence of 8 + 3 Gauss-Seidel sweeps - ONE step from a bit-identical snapshot of the "
+                "timed state: |dp| <= 1.7 cm on 1 m boxes (1.13e-4 of the 150 m scene; median 1-2 mm), |dv| <= 0.30 m/s with "
+                "bodies at up to 18 m/s, 18 of 30 000 contacts differ (tests/test_gpu_onestep.py); the bit-exact class is "
+                "`exact_order` below")
 
 
 def committed_pmc_traffic(kernel, workload_key):
@@ -54,8 +65,52 @@ def committed_pmc_traffic(kernel, workload_key):
     return best
 
 
-def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, seed=3):
-    """One of the other BASELINE configs on this GPU, short: settle, then `steps` timed steps (read-back included)."""
+def kernel_roofline(hipL, dev, step_fn, mode, steps, units=None):
+    """HIP-event timing of one kernel family over `steps` steps (b2hip_set_kernel_timing modes: 1 dominant solver kernel,
+    2 k_collide, 3 k_sync_fixtures, 4 k_find_pairs_small): {"kernel", "achieved" GB/s of algorithmic bytes, "frac", ...}."""
+    hipL.b2hip_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    hipL.b2hip_set_kernel_timing_units.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong]
+    hipL.b2hip_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char), C.c_int, C.POINTER(C.c_float),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    if units is not None:
+        hipL.b2hip_set_kernel_timing_units(dev, int(units[0]), int(units[1]))
+    hipL.b2hip_set_kernel_timing(dev, mode)
+    names = {}
+    for _ in range(steps):
+        step_fn()
+        buf = C.create_string_buffer(64)
+        ms, launches, nbytes = C.c_float(), C.c_int(), C.c_double()
+        hipL.b2hip_get_kernel_timing(dev, buf, 64, C.byref(ms), C.byref(launches), C.byref(nbytes))
+        acc = names.setdefault(buf.value.decode(), [0.0, 0, 0.0])
+        acc[0] += ms.value
+        acc[1] += launches.value
+        acc[2] += nbytes.value
+    hipL.b2hip_set_kernel_timing(dev, 0)
+    kname, (tot_ms, launches, tot_bytes) = max(names.items(), key=lambda kv: kv[1][0])
+    if launches <= 0 or tot_ms <= 0:
+        return None
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "launches_per_step": launches / float(steps), "mean_launch_us": 1000.0 * tot_ms / launches,
+            "algorithmic_bytes_per_launch": tot_bytes / launches, "timed_steps": steps}
+
+
+def attach_committed_traffic(roof, workload_key):
+    """HBM-side bytes per launch are PMC counters, which cannot be sampled from inside the process: they come from a
+    committed rocprofv3 --pmc profile of the same command in the same state, and the key says so."""
+    if roof is None:
+        return
+    hit = committed_pmc_traffic(roof["kernel"], workload_key)
+    if hit is not None:
+        roof["traffic"] = hit[0]
+        roof["traffic_committed_profile"] = hit[0]
+        roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over the same command and state; NOT sampled in this run)" % hit[1]
+        roof["traffic_GBps"] = hit[0] / (1e-6 * roof["mean_launch_us"]) / 1e9
+
+
+def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, roof_mode, workload_key, seed=3):
+    """One of the other BASELINE configs on this GPU, short: settle (the window is stated in the entry), then `steps` timed
+    steps (read-back included), then a roofline pass over the configuration's dominant bandwidth kernel."""
     import b2harness as bh  # noqa: F401
     import b2hip
     t0 = time.perf_counter()
@@ -70,19 +125,30 @@ def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, seed=3):
         stamps[k + 1] = time.perf_counter()
     per = 1000.0 * np.diff(stamps)
     ctr = b2hip.Counters()
-    hipL.b2hip_get_counters(C.c_void_p(w.device_world()), C.byref(ctr))
+    dev = C.c_void_p(w.device_world())
+    hipL.b2hip_get_counters(dev, C.byref(ctr))
     out = {"workload": name, "bodies": w.body_count, "contacts": w.contact_count, "settle_steps": settle, "timed_steps": steps,
+           "timed_window": "steps %d..%d of the scene" % (settle, settle + steps - 1),
            "ms_per_step": float(per.mean()), "ms_per_step_p50": float(np.percentile(per, 50)), "ms_per_step_max": float(per.max()),
            "steps_per_s": 1000.0 / float(per.mean()), "build_s": round(build_s, 2),
            "islands": ctr.islands, "large_island_constraints": ctr.large_island_contacts, "small_island_constraints": ctr.small_island_contacts,
            "toi_events_last_step": ctr.toi_events,
            "device_profile_ms": {k: round(v, 4) for k, v in w.profile().items() if k != "steps"}}
+    try:
+        # algorithmic units: collide 480 B per polygon-polygon contact (the Tumbler has nothing else), sync fixtures 250 B per proxy
+        units = {2: (w.contact_count, 0), 3: (hipL.b2hip_fixture_count(dev), 0), 4: (hipL.b2hip_fixture_count(dev), 0)}.get(roof_mode)
+        roof = kernel_roofline(hipL, dev, lambda: w.step(1), roof_mode, 5, units)
+        attach_committed_traffic(roof, workload_key)
+        out["roofline"] = roof
+    except Exception as e:
+        out["roofline"] = {"error": str(e)}
     w.close()
     return out
 
 
 def cpu_baseline(rows, warmup, max_seconds, flags):
-    """Times the reference (or, without it, the C oracle) on the same scene: bounded CPU sample."""
+    """Times the reference (or, without it, the C oracle) on the same scene from the same state the GPU is timed at
+    (`warmup` = SETTLE_STEPS + --warmup untimed steps first): bounded CPU sample."""
     import b2harness as bh
     if bh.have_ref():
         h, kind = bh.Harness(bh.REF_LIB), "reference"
@@ -106,7 +172,8 @@ def cpu_baseline(rows, warmup, max_seconds, flags):
         w.close()
     sps1, steps, bodies, prof = out[1]
     res = {"value": sps1, "unit": "steps/s", "cores": 1, "kind": kind,
-           "sample": "Pyramid %d rows (%d bodies), %d warm-up + %d timed steps, 1 thread" % (rows, bodies, warmup, steps),
+           "sample": "Pyramid %d rows (%d bodies), %d untimed steps (the GPU side's settle + warm-up) + %d timed steps, 1 thread" % (rows, bodies, warmup, steps),
+           "timed_window": "steps %d..%d of the scene" % (warmup, warmup + steps - 1),
            "ms_per_step": 1000.0 / sps1,
            "profile_ms": {k: round(v, 4) for k, v in prof.items() if k not in ("steps",)}}
     if 8 in out:
@@ -125,16 +192,35 @@ def main():
     ap.add_argument("--no-ccd", action="store_true", help="turn continuous physics (TOI) off on both sides")
     ap.add_argument("--no-secondary", action="store_true", help="skip the multi-island roofline sample (500 k bodies in 100 k piles)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other BASELINE configs (Tumbler 100 k, 1 M field, 50 k pyramid)")
+    ap.add_argument("--no-exact-order", action="store_true", help="skip the exact-order (bit-exact parity class) cost sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) as children BEFORE this process
+        # touches a GPU and hand their exit code on; N = 1 stays the plain in-process path.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and args.gpus != world_size:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world_size))
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the Step() path has no CPU fallback")
+    if world_size > 1 and os.environ.get("B2_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < world_size:
+        raise SystemExit("bench.py: %d ranks but %d GPUs visible (B2_BENCH_SHARE_GPU=1 B2_BENCH_BACKEND=gloo shares one for a functional run)"
+                         % (world_size, torch.cuda.device_count()))
     # (B2_BENCH_SHARE_GPU=1 + B2_BENCH_BACKEND=gloo: every rank on GPU 0, collectives over gloo - how the N > 1 path is
     # exercised on a one-GPU box; the driver's runs use one GPU per rank and RCCL)
     if os.environ.get("B2_BENCH_SHARE_GPU") == "1":
@@ -187,49 +273,22 @@ def main():
     # the state the timed region starts from (after it only when there is no warm-up: the 141-row pyramid is not a stable
     # pile, and a pass 300 steps later times a different one).
     ROOF_STEPS = 20
+    EXACT_STEPS = 3
 
     def solver_roofline_pass():
         roof = None
         try:
-            amd.lib.b2h_device_world.restype = C.c_void_p
-            amd.lib.b2h_device_world.argtypes = [C.c_void_p]
-            dev = amd.lib.b2h_device_world(w.ptr)
-            hipL.b2hip_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
-            hipL.b2hip_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char), C.c_int, C.POINTER(C.c_float),
-                                                     C.POINTER(C.c_int), C.POINTER(C.c_double)]
-            hipL.b2hip_set_kernel_timing(dev, 1)
-            names = {}
-            for _ in range(ROOF_STEPS):
-                step_world(1)
-                buf = C.create_string_buffer(64)
-                ms, launches, nbytes = C.c_float(), C.c_int(), C.c_double()
-                hipL.b2hip_get_kernel_timing(dev, buf, 64, C.byref(ms), C.byref(launches), C.byref(nbytes))
-                k = buf.value.decode()
-                acc = names.setdefault(k, [0.0, 0, 0.0])
-                acc[0] += ms.value
-                acc[1] += launches.value
-                acc[2] += nbytes.value
-            hipL.b2hip_set_kernel_timing(dev, 0)
-            kname, (tot_ms, launches, tot_bytes) = max(names.items(), key=lambda kv: kv[1][0])
+            dev = C.c_void_p(w.device_world())
+            roof = kernel_roofline(hipL, dev, lambda: step_world(1), 1, ROOF_STEPS)
             ctr = b2hip.Counters()
             hipL.b2hip_get_counters(dev, C.byref(ctr))
-            if launches > 0 and tot_ms > 0:
-                achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "launches_per_step": launches / float(ROOF_STEPS), "mean_launch_us": 1000.0 * tot_ms / launches,
-                        "algorithmic_bytes_per_launch": tot_bytes / launches,
-                        "constraints": ctr.large_island_contacts + ctr.small_island_contacts,
-                        "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors,
-                        "toi_calls_per_step": ctr.toi_calls, "toi_events_last_step": ctr.toi_events}
-            # HBM traffic of that kernel: null unless a committed rocprofv3 --pmc profile of this command matches the kernel,
-            # the workload and the (steady) state this run measured
             if roof is not None:
-                hit = committed_pmc_traffic(kname, "pyramid%d%s" % (args.rows, "" if not args.no_ccd else "_noccd"))
-                if hit is not None:
-                    roof["traffic"] = hit[0]
-                    roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, steady state)" % hit[1]
-                    roof["traffic_GBps"] = hit[0] / (1e-3 * tot_ms / launches) / 1e9
+                roof.update({"constraints": ctr.large_island_contacts + ctr.small_island_contacts,
+                             "bodies": ctr.large_island_bodies + ctr.small_island_bodies, "colors": ctr.colors,
+                             "toi_calls_per_step": ctr.toi_calls, "toi_events_last_step": ctr.toi_events})
+                # HBM traffic of that kernel: null unless a committed rocprofv3 --pmc profile of this command matches the
+                # kernel, the workload and the (steady) state this run measured
+                attach_committed_traffic(roof, "pyramid%d%s" % (args.rows, "" if not args.no_ccd else "_noccd"))
             smsv, sbytes, sct, sb = C.c_float(), C.c_double(), C.c_int(), C.c_int()
             hipL.b2hip_get_solver_timing(dev, C.byref(smsv), C.byref(sbytes), C.byref(sct), C.byref(sb))
             if roof is not None and smsv.value > 0:
@@ -281,39 +340,46 @@ def main():
     if roof is None:
         roof = solver_roofline_pass()
 
+    # ---- what the bit-exact parity class costs on this workload: the state the timed region ended in, saved and loaded
+    # into a world in exact-order mode (every island walked in the reference's constraint order), a few steps timed
+    exact_order = None
+    if world_size == 1 and not args.no_exact_order:
+        try:
+            holder = b2hip.World.__new__(b2hip.World)  # (a view of the harness's device world for the snapshot call; not closed)
+            holder.L, holder.p = hipL, C.c_void_p(w.device_world())
+            blob = holder.save_snapshot()
+            holder.p = None
+            os.environ["B2HIP_FORCE_LARGE"] = "2"  # read when the world is created
+            try:
+                ex = b2hip.World.from_snapshot(blob, library=hipL)
+            finally:
+                os.environ.pop("B2HIP_FORCE_LARGE", None)
+            ex.step(1.0 / 60.0, w.vel_iters, w.pos_iters)  # (first step: allocations)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for _ in range(EXACT_STEPS):
+                ex.step(1.0 / 60.0, w.vel_iters, w.pos_iters)
+            torch.cuda.synchronize()
+            ems = 1000.0 * (time.perf_counter() - te) / EXACT_STEPS
+            exact_order = {"mode": "B2HIP_FORCE_LARGE=2: every island in the reference's constraint order, bit-identical to the reference build (tests/test_gpu_parity.py)",
+                           "state": "snapshot of the timed world after its last timed step", "timed_steps": EXACT_STEPS,
+                           "ms_per_step": ems, "steps_per_s": 1000.0 / ems}
+            ex.close()
+        except Exception as e:
+            exact_order = {"error": str(e)}
+
     # ---- secondary roofline: the in-LDS small-island kernel on a multi-island world (not part of `value`) ----------
     secondary = None
     if world_size == 1 and not args.no_secondary:
         try:
             w2 = amd.world(bh.PILES, 100000, 5, seed=3, flags=flags)
-            dev2 = amd.lib.b2h_device_world(w2.ptr)
+            dev2 = w2.device_world()
             w2.step(40)
-            hipL.b2hip_set_kernel_timing(dev2, 1)
-            tot_ms2 = tot_b2 = 0.0
-            n2 = 0
-            k2 = ""
-            for _ in range(10):
-                w2.step(1)
-                buf = C.create_string_buffer(64)
-                ms, launches, nbytes = C.c_float(), C.c_int(), C.c_double()
-                hipL.b2hip_get_kernel_timing(dev2, buf, 64, C.byref(ms), C.byref(launches), C.byref(nbytes))
-                k2 = buf.value.decode()
-                tot_ms2 += ms.value
-                tot_b2 += nbytes.value
-                n2 += launches.value
-            hipL.b2hip_set_kernel_timing(dev2, 0)
-            if n2 > 0 and tot_ms2 > 0:
-                ach = tot_b2 / (tot_ms2 * 1e-3) / 1e9
-                secondary = {"workload": "100 000 piles of 5 boxes (%d bodies, %d contacts), same step parameters" % (w2.body_count, w2.contact_count),
-                             "bound": "hbm", "kernel": k2, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                             "achieved_is": "algorithmic (reference-layout) bytes / launch time; the kernel keeps rows in LDS / registers, so counter traffic is lower",
-                             "traffic": None,
-                             "mean_launch_us": 1000.0 * tot_ms2 / n2, "algorithmic_bytes_per_launch": tot_b2 / n2}
-                hit = committed_pmc_traffic(k2, "piles100000x5")
-                if hit is not None:
-                    secondary["traffic"] = hit[0]
-                    secondary["traffic_source"] = hit[1]
-                    secondary["traffic_GBps"] = hit[0] / (1e-3 * tot_ms2 / n2) / 1e9
+            secondary = kernel_roofline(hipL, C.c_void_p(dev2), lambda: w2.step(1), 1, 10)
+            if secondary is not None:
+                secondary["workload"] = "100 000 piles of 5 boxes (%d bodies, %d contacts), same step parameters" % (w2.body_count, w2.contact_count)
+                secondary["achieved_is"] = "algorithmic (reference-layout) bytes / launch time; the kernel keeps rows in LDS / registers, so counter traffic is lower"
+                attach_committed_traffic(secondary, "piles100000x5")
             w2.close()
         except Exception as e:
             secondary = {"error": str(e)}
@@ -324,10 +390,12 @@ def main():
         extras = []
         jobs = []
         if world_size == 1:
-            jobs.append(("config 3: Tumbler 316 x 316 = 99 856 boxes in a revolving container, CCD off (Tumbler.h)", bh.TUMBLER, 316, 0, bh.F_SLEEP | bh.F_WARM, 60, 20))
-            jobs.append(("config 5 on ONE GPU: 1 M mixed circles + boxes random field, 10 000 bullets, CCD on", bh.FIELD, 1000000, 10000, flags | bh.F_CONTINUOUS, 10, 10))
+            # (settle windows: the Tumbler's boxes start on a grid that fills the container and have come down after ~400 steps;
+            #  the 316-row pyramid's top row lands after ~240 steps; the field is random from the start)
+            jobs.append(("config 3: Tumbler 316 x 316 = 99 856 boxes in a revolving container, CCD off (Tumbler.h)", bh.TUMBLER, 316, 0, bh.F_SLEEP | bh.F_WARM, 400, 20, 2, "tumbler316"))
+            jobs.append(("config 5 on ONE GPU: 1 M mixed circles + boxes random field, 10 000 bullets, CCD on", bh.FIELD, 1000000, 10000, flags | bh.F_CONTINUOUS, 30, 10, 3, "field1000000"))
         if world_size == 1:
-            jobs.append(("config 4, one GPU's share: Pyramid 316 rows = 50 086 boxes, CCD on", bh.PYRAMID, 316, 1, flags, 60, 20))
+            jobs.append(("config 4, one GPU's share: Pyramid 316 rows = 50 086 boxes, CCD on", bh.PYRAMID, 316, 1, flags, 320, 20, 1, "pyramid316"))
         for job in jobs:
             try:
                 extras.append(time_extra(amd, hipL, *job))
@@ -386,7 +454,8 @@ def main():
     if rank == 0:
         total_steps = args.steps * world_size
         line = {
-            "metric": "world steps/sec x pyramid islands (Step = collide + island solve + broad-phase + state read-back), one 10 011-body pyramid island per GPU",
+            "metric": "world steps/sec at 10 011 bodies per GPU (Step = collide + island solve + broad-phase + TOI + state read-back); for N > 1: pyramid-steps/s = world steps/s x N pyramids in the one sharded world",
+            "world_steps_per_s": args.steps / elapsed,
             "value": total_steps / elapsed,
             "unit": "steps/s",
             "n_gpus": world_size,
@@ -406,6 +475,8 @@ def main():
                                    ", settled for %d untimed steps (steady state), dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
                                    % (SETTLE_STEPS, "off" if args.no_ccd else "on (reference default)"),
                        "settle_steps": SETTLE_STEPS,
+                       "timed_window": "steps %d..%d of the scene" % (SETTLE_STEPS + args.warmup, SETTLE_STEPS + args.warmup + args.steps - 1),
+                       "parity_class": PARITY_CLASS,
                        "bodies_total": nbodies, "parallelism": "one world on every rank, islands sharded by owner, one RCCL all-reduce per step" if world_size > 1 else "single GPU"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
@@ -420,10 +491,12 @@ def main():
             line["exchange"] = "one all-reduce(MAX) per step over int32 records of the solved islands (RCCL), inside the timed region"
         if roof is not None:
             line["roofline"] = roof
+        if exact_order is not None:
+            line["exact_order"] = exact_order
         if secondary is not None:
             line["roofline_small_islands"] = secondary
         if world_size == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.rows, min(args.warmup, 120), args.cpu_seconds, flags)
+            cb = cpu_baseline(args.rows, SETTLE_STEPS + args.warmup, args.cpu_seconds, flags)
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line))

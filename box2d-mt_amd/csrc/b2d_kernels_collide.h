@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void k_presolve_gather(DW W)
 		r.pad = 0ull;
 		r.o0 = W.pre_o0[i]; r.o1 = W.pre_o1[i]; r.oimp = W.pre_oimp[i]; r.o3 = W.pre_o3[i];
 		r.n0 = C.man0[i]; r.n1 = C.man1[i]; r.nimp = C.imp[i]; r.n3 = C.man3[i];
+		r.mat = C.mat[i];
 		W.preRecs[e] = r;
 	}
 }
@@ -365,6 +366,25 @@ __global__ __launch_bounds__(256) void k_presolve_disable(DW W, const int* list,
 	{
 		const int j = list[k];
 		if (j >= 0 && j < W.st->c.nContacts) C.flags[j] &= ~CF_ENABLED;
+	}
+}
+
+// b2Contact::SetFriction / SetRestitution / SetTangentSpeed from PreSolve (b2Contact.h:129-160): the values stay with the
+// contact until they are set again (the conveyor belt of Testbed/Tests/ConveyorBelt.h sets its speed in every PreSolve).
+// list = count x {contact index, friction, restitution, tangent speed as bits}
+__global__ __launch_bounds__(256) void k_presolve_material(DW W, const int* list, int count)
+{
+	b2dPhaseStamp(W);
+	const ContactArrays& C = W.ca[W.st->cur];
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+	{
+		const int j = list[4 * k];
+		if (j < 0 || j >= W.st->c.nContacts) continue;
+		float4 m = C.mat[j];
+		m.x = __int_as_float(list[4 * k + 1]);
+		m.y = __int_as_float(list[4 * k + 2]);
+		m.z = __int_as_float(list[4 * k + 3]);
+		C.mat[j] = m;
 	}
 }
 

@@ -26,7 +26,7 @@ enum
 	EDIT_REFILTER_FIXTURE = 5,
 	EDIT_SENSOR_FIXTURE = 6
 };
-#define EDIT_LIST_MAX 8192
+#define EDIT_LIST_MAX 8192 // contacts per pass (LDS list); an op takes as many passes as it needs
 
 __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int nOps)
 {
@@ -41,10 +41,17 @@ __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int
 		const int kind = ops[o].x, id = ops[o].y;
 		const bool byBody = kind == EDIT_DESTROY_BODY || kind == EDIT_RECALC_BODY;
 		const int n = S->c.nContacts;
+		// The matching contacts are listed newest first and worked off in passes of at most EDIT_LIST_MAX (a ground body under
+		// a large pile, the Tumbler's container: the reference has no limit): a pass ends where the next chunk of 1024 might
+		// not fit any more, the op is applied to the listed contacts, and the next pass goes on below - the newest-first order
+		// of the whole walk is kept.
+		for (int passTop = n - 1; passTop >= 0;)
+		{
 		if (t == 0) s_n = 0;
 		__syncthreads();
-		// matching contacts, newest first: chunks of 1024 from the top, each lane one index, ordered append
-		for (int hi = n - 1; hi >= 0; hi -= 1024)
+		int hi = passTop;
+		// chunks of 1024 from the top, each lane one index, ordered append
+		for (; hi >= 0 && s_n + 1024 <= EDIT_LIST_MAX; hi -= 1024)
 		{
 			const int i = hi - t;
 			bool match = false;
@@ -59,10 +66,7 @@ __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int
 			int base = s_n;
 			for (int k = 0; k < wave; ++k) base += s_waveCount[k];
 			const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-			if (match)
-			{
-				if (pos < EDIT_LIST_MAX) s_list[pos] = i; else atomicOr(&S->c.overflow, 128);
-			}
+			if (match) s_list[pos] = i;
 			__syncthreads();
 			if (t == 0)
 			{
@@ -72,7 +76,8 @@ __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int
 			}
 			__syncthreads();
 		}
-		const int cnt = s_n < EDIT_LIST_MAX ? s_n : EDIT_LIST_MAX;
+		passTop = hi; // (uniform: every lane ran the same chunks)
+		const int cnt = s_n;
 		if (kind == EDIT_REFILTER_FIXTURE)
 		{
 			for (int k = t; k < cnt; k += 1024) C.flags[s_list[k]] |= CF_FILTER;
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(1024) void k_apply_edits(DW W, const int2* ops, int
 			}
 		}
 		__syncthreads();
+		} // passes
 	}
 }
 

@@ -161,8 +161,16 @@ __device__ __forceinline__ int4 scanWaveSum(int4 v)
 	return make_int4(scanWaveSum(v.x), scanWaveSum(v.y), scanWaveSum(v.z), scanWaveSum(v.w));
 }
 
+// The look-back spins on status words other workgroups publish: bounded. A tile that has waited SCAN_SPIN_MAX polls (seconds:
+// a poll is a memory round trip, ~1 us) for one word gives up, raises SCAN_ABORT_BIT in *abortWord and publishes a zero
+// prefix so that its successors end too; every other waiting lane leaves as soon as it sees the bit. The host finds the bit
+// with the step's read-back and fails the step (B2HIP_ERR_HIP) instead of hanging in it.
+#define SCAN_SPIN_MAX (1u << 23)
+#define SCAN_ABORT_BIT 256
+
 template <typename T>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict__ in, T* __restrict__ out, T* work, int* flags, int cap, const int* nPtr, unsigned epoch)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict__ in, T* __restrict__ out, T* work, int* flags, int cap, const int* nPtr, unsigned epoch,
+	int* abortWord)
 {
 	__shared__ T lds[2 * SCAN_THREADS];
 	__shared__ T s_prefix;
@@ -218,12 +226,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 				if (t >= 0)
 				{
 					unsigned word;
+					unsigned polls = 0;
+					bool gaveUp = false;
 					do
 					{
 						word = (unsigned)__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					} while ((word >> 2) != epoch || (word & 3u) == 0u);
-					state = word & 3u;
-					val = scanLoadAgent(state == 2u ? &pre[t] : &agg[t]);
+						if ((++polls & 0xfffu) == 0u)
+						{
+							if (polls >= SCAN_SPIN_MAX) atomicOr(abortWord, SCAN_ABORT_BIT);
+							gaveUp = (__hip_atomic_load(abortWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SCAN_ABORT_BIT) != 0;
+						}
+					} while (!gaveUp && ((word >> 2) != epoch || (word & 3u) == 0u));
+					state = gaveUp ? 2u : (word & 3u); // (aborted: pretend a zero prefix so that the walk ends)
+					if (!gaveUp) val = scanLoadAgent(state == 2u ? &pre[t] : &agg[t]);
 				}
 				// the nearest tile whose inclusive prefix is known ends the walk
 				const unsigned long long known = __ballot(state == 2u);
@@ -254,12 +269,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 }
 
 // Host helper: ONE launch on `stream`. capN bounds the grid; nPtr is the live count in device memory; `work` holds
-// 2 * (capN / SCAN_TILE + 4) elements, `flags` capN / SCAN_TILE + 4 ints (zeroed when allocated, never reset).
-#include <atomic>
-static std::atomic<unsigned> g_scanEpoch{0};
-template <typename T>
-static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, T* work, int* flags, const int* nPtr, int capN)
+// 2 * (capN / SCAN_TILE + 4) elements, `flags` capN / SCAN_TILE + 4 ints (zeroed when allocated).
+// The epoch belongs to the flag array (ScanFlags: one per world): it tags the array's status words, 30 bits wide, and when it
+// wraps the array is zeroed on the stream before the next scan, so that no word left behind by a scan 2^30 launches ago can
+// read as "published" (a process-wide counter over per-world arrays could alias in a rarely used tile).
+struct ScanFlags
 {
+	int* words = nullptr;   // device
+	size_t count = 0;
+	unsigned epoch = 0;     // of the last launch over `words`
+	int* abortWord = nullptr; // device: SCAN_ABORT_BIT is raised here when a look-back gives up
+};
+template <typename T>
+static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, T* work, ScanFlags& sf, const int* nPtr, int capN)
+{
+	int* flags = sf.words;
 	int blocks = (capN + SCAN_TILE - 1) / SCAN_TILE;
 	if (blocks < 1) blocks = 1;
 	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
@@ -273,9 +297,13 @@ static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, 
 		hipLaunchKernelGGL(k_scan_final<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, nPtr);
 		return;
 	}
-	unsigned epoch = (g_scanEpoch.fetch_add(1) + 1u) & 0x3fffffffu;
-	if (epoch == 0u) epoch = (g_scanEpoch.fetch_add(1) + 1u) & 0x3fffffffu;
-	hipLaunchKernelGGL(k_scan_chain<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, flags, blocks + 4, nPtr, epoch);
+	if (sf.epoch >= 0x3fffffffu)
+	{
+		(void)hipMemsetAsync(flags, 0, sf.count * sizeof(int), stream);
+		sf.epoch = 0u;
+	}
+	const unsigned epoch = ++sf.epoch;
+	hipLaunchKernelGGL(k_scan_chain<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, flags, blocks + 4, nPtr, epoch, sf.abortWord);
 }
 
 // ---------------------------------------------------------------------------------------------

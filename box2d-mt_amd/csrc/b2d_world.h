@@ -181,6 +181,7 @@ struct PreSolveRec
 	int4 o3;
 	float4 n0, n1, nimp;     // new manifold
 	int4 n3;
+	float4 mat;              // the contact's mixed friction, restitution, tangent speed (b2Contact.h:40-50, 157) as the callback may edit them
 };
 struct PostSolveRec
 {

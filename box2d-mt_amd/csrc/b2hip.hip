@@ -228,6 +228,7 @@ struct b2hip_world
 	DevArray<int> scanTmp, radixHist, radixHistScan, keepFlag, keepScan;
 	DevArray<int4> scanTmp4;
 	DevArray<int> scanFlags;     // status words of the single-pass scans (b2d_scan.h)
+	ScanFlags scanCtx;           // ... with their epoch and the abort word (refreshed by ensureCapacity)
 	DevArray<float> stateOut;
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
 	int dfEpoch;
@@ -322,6 +323,7 @@ struct b2hip_world
 	DevArray<float4> dbgPreVel, dbgVel;
 	DevArray<int> dbgLi;
 	int kernelTiming;
+	long long ktUnitsA, ktUnitsB; // units behind the bandwidth kernels' byte counts (set by b2hip_set_kernel_timing_units)
 	std::vector<hipEvent_t> ktEvents;
 	int ktUsed;          // events recorded this step (pairs)
 	int ktKind;          // 0 none, 1 k_large_velocity, 2 k_solve_small
@@ -650,6 +652,14 @@ static int ktRecord(b2hip_world* w)
 	return 0;
 }
 
+// b2hip_set_kernel_timing modes 2 / 3 / 4: an event pair around k_collide / k_sync_fixtures / k_find_pairs_small
+static int ktBracket(b2hip_world* w, int mode, int kind)
+{
+	if (w->kernelTiming != mode) return 0;
+	w->ktKind = kind;
+	return ktRecord(w);
+}
+
 static int gridFor(size_t n, int block = 256, int maxBlocks = 2048)
 {
 	size_t g = (n + block - 1) / block;
@@ -675,6 +685,11 @@ static int pollPublished(b2hip_world* w, volatile const int* seq, int want, cons
 {
 	bool drained = false;
 	std::chrono::steady_clock::time_point drainedAt;
+	// ... and, as a backstop, after a generous wall-clock deadline (B2HIP_STEP_DEADLINE_S, default 300 s): every device-side
+	// wait is bounded (PERSIST_SPIN_MAX, SCAN_SPIN_MAX), so a stream that stays busy that long is lost, and the caller gets an
+	// error and a failed world instead of a Step() that never returns.
+	static const double deadlineS = getenv("B2HIP_STEP_DEADLINE_S") ? atof(getenv("B2HIP_STEP_DEADLINE_S")) : 300.0;
+	const auto startedAt = std::chrono::steady_clock::now();
 	for (unsigned spins = 1; *seq != want; ++spins)
 	{
 		if ((spins & 0x3fff) == 0)
@@ -688,6 +703,8 @@ static int pollPublished(b2hip_world* w, volatile const int* seq, int want, cons
 				else if (now - drainedAt > std::chrono::seconds(2)) return setError(B2HIP_ERR_HIP, std::string(what) + " was not published (the stream has drained)");
 			}
 			else drained = false;
+			if (std::chrono::duration<double>(std::chrono::steady_clock::now() - startedAt).count() > deadlineS)
+				return setError(B2HIP_ERR_HIP, std::string(what) + ": the device did not finish the step within the deadline (B2HIP_STEP_DEADLINE_S)");
 		}
 #if defined(__x86_64__)
 		__builtin_ia32_pause();
@@ -773,7 +790,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		const size_t nPre = w->preSolveFn ? cc : 1, nPost = w->postSolveOn ? cc : 1, nFil = w->filterFn ? cc : 1;
 		ENS(pre_o0, nPre); ENS(pre_o1, nPre); ENS(pre_oimp, nPre); ENS(pre_o3, nPre); ENS(preRecs, nPre);
 		ENS(postRecs, nPost); ENS(filterList, nFil);
-		ENS(hostList, std::max<size_t>(std::max(nPre, nFil), w->filterFn ? capPairs : 1));
+		ENS(hostList, std::max<size_t>(std::max(4 * nPre, nFil), w->filterFn ? capPairs : 1)); // (PreSolve material edits: 4 words each)
 	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2); ENS(blkBodyCount, MAX_BLOCKS + 2); ENS(blkBodyCursor, MAX_BLOCKS + 2);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
@@ -781,6 +798,9 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(consts, 16);
 	ENS(gridBar, 32);
 #undef ENS
+	w->scanCtx.words = w->scanFlags.p; // (a grown array keeps its words: the epoch goes on)
+	w->scanCtx.count = w->scanFlags.cap;
+	w->scanCtx.abortWord = &w->d_state.p->c.overflow;
 	if (w->h_stateCap < 12 * nb + sizeof(DState) / sizeof(float) + 4)
 	{
 		if (w->h_state) (void)hipHostFree(w->h_state);
@@ -1187,7 +1207,7 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 	if (destroys)
 	{
 		LAUNCH(w, k_edit_keepflags, gridFor(d.capContacts), 256, d);
-		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
+		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d); // (its last workgroup switches the buffers)
 		LAUNCH(w, k_edit_finish, 1, 1, d);
 		if (betweenSteps)
@@ -1203,7 +1223,6 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 	rc = readState(w); // (also makes the staging vector reusable, and the state rows above readable)
 	if (rc) return rc;
 	w->editOps.clear();
-	if (w->h_dstate->c.overflow & 128) return setError(B2HIP_ERR_CAPACITY, "more than 8192 contacts on one edited body / fixture");
 	w->lastContacts = w->h_dstate->c.nContacts;
 	w->last.nContacts = w->lastContacts;
 	return 0;
@@ -1275,7 +1294,7 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		{
 			LAUNCH(w, k_radix_count, 1, 1, &d.st->c.nPairs, 0, w->consts.p + 2);
 			LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, &d.st->c.nPairs, 0, shifts[p], tilesCap);
-			deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanFlags.p, w->consts.p + 2, 256 * tilesCap);
+			deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanCtx, w->consts.p + 2, 256 * tilesCap);
 			LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, &d.st->c.nPairs, 0, shifts[p]);
 			std::swap(kin, kout);
 			std::swap(vin, vout);
@@ -1284,7 +1303,7 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		sortedProxies = vin;
 		LAUNCH(w, k_pairs_sorted_first, gridFor(d.capPairs), 256, d, sortedKeys, w->consts.p + 3);
 		if (w->filterFn) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
-		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanFlags.p, w->consts.p + 3, d.capPairs);
+		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanCtx, w->consts.p + 3, d.capPairs);
 		LAUNCH(w, k_pairs_sorted_total, 1, 1, d, w->consts.p + 3);
 	}
 	else
@@ -1339,9 +1358,11 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 	DW& d = w->dw;
 	LAUNCH(w, k_bp_clear, gridFor(std::max(d.htMask, d.gridMask) + 1), 256, d);
 	LAUNCH(w, k_bp_build, gridFor(std::max(d.capContacts, d.nProxies)), 256, d);
-	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanFlags.p, w->consts.p + 1, (int)(d.gridMask + 1));
+	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanCtx, w->consts.p + 1, (int)(d.gridMask + 1));
 	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 0);
+	if (int rk = ktBracket(w, 4, 7)) return rk;
 	LAUNCH(w, k_find_pairs_small, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
+	if (int rk = ktBracket(w, 4, 7)) return rk;
 	LAUNCH(w, k_find_pairs_large, 1024, 256, d);
 	bool large = false;
 	if (sync)
@@ -1364,8 +1385,10 @@ static int phaseCollide(b2hip_world* w)
 	return runSegment(w, w->segCollide, 1 + (w->dw.preSolveOn ? 32 : 0), [w]() -> int
 	{
 		DW& d = w->dw;
+		if (int rk = ktBracket(w, 2, 5)) return rk;
 		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
-		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
+		if (int rk = ktBracket(w, 2, 5)) return rk;
+		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_compact_contacts, gridFor(d.capContacts), 256, d); // (its last workgroup switches the buffers)
 		return 0;
@@ -1405,13 +1428,13 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	{
 		LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
 		LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, nPtr, 0, shifts[p], tilesCap);
-		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanFlags.p, w->consts.p + 2, 256 * tilesCap);
+		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanCtx, w->consts.p + 2, 256 * tilesCap);
 		LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, nPtr, 0, shifts[p]);
 		std::swap(kin, kout);
 		std::swap(vin, vout);
 	}
 	LAUNCH(w, k_part_weights, gridFor(d.nBodies), 256, d, vin, d.pairFirst);
-	deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanFlags.p, nPtr, d.nBodies);
+	deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanCtx, nPtr, d.nBodies);
 	LAUNCH(w, k_part_assign, gridFor(d.nBodies), 256, d, vin, d.pairRank);
 	LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
@@ -1427,8 +1450,13 @@ static int phaseSolve(b2hip_world* w)
 	DW& d = w->dw;
 	d.serialOrphans = w->serialOrphansNext;
 	const StepParams& sp = w->sp;
-	w->ktUsed = 0;
-	w->ktKind = 0;
+	if (w->kernelTiming <= 1)
+	{
+		// (the event pairs of the solver kernels belong to this phase; those of k_collide / k_sync_fixtures / k_find_pairs_small -
+		// timing modes 2 to 4 - are taken in other phases of the step and cleared by b2hip_step_begin)
+		w->ktUsed = 0;
+		w->ktKind = 0;
+	}
 	const int forceLarge = w->forceLarge;
 	// (the step parameters are kernel arguments of k_island_classify - it steps the free bodies - so a captured segment is
 	// only replayed for the same ones)
@@ -1452,13 +1480,13 @@ static int phaseSolve(b2hip_world* w)
 		{
 			int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
 			if (blocks < 1) blocks = 1;
-			deviceExclusiveScan<int4>(w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->scanFlags.p, w->consts.p, d.nBodies);
+			deviceExclusiveScan<int4>(w->stream, d.rootScanIn, d.rootScanOut, w->scanTmp4.p, w->scanCtx, w->consts.p, d.nBodies);
 			if (hipError_t le = hipGetLastError()) return setError(B2HIP_ERR_HIP, std::string("k_scan<int4> launch: ") + hipGetErrorString(le));
 		}
-		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->scanFlags.p, w->consts.p, d.nBodies);
+		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->scanCtx, w->consts.p, d.nBodies);
 		if (d.nJoints > 0)
 		{
-			deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->scanFlags.p, w->consts.p, d.nBodies);
+			deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->scanCtx, w->consts.p, d.nBodies);
 		}
 		LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d, pubBy == 2 ? w->d_pub : (DState*)nullptr);
@@ -1580,7 +1608,7 @@ static int phaseSolve(b2hip_world* w)
 		if (!sideStream) stampPhase(w, 5);
 		if (!exactLarge)
 		{
-			const bool timeIt = w->kernelTiming && c.nLIslands == 0;
+			const bool timeIt = w->kernelTiming == 1 && c.nLIslands == 0;
 			if (timeIt) { int rck = ktRecord(w); if (rck) return rck; w->ktKind = 2; }
 			if (c.nSmallJointed > 0)
 			{
@@ -1714,7 +1742,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			// the hub constraints in contact-index order (deterministic whatever the atomics of k_color_fill did)
 			LAUNCH(w, k_hub_flag, gridFor(d.capContacts), 256, d);
-			deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanFlags.p, &d.st->c.nContacts, d.capContacts);
+			deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 			LAUNCH(w, k_hub_fill, gridFor(d.capContacts), 256, d);
 			w->hubSteps += 1;
 		}
@@ -1725,7 +1753,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (b2d_kernels_solve_persist.h)
 			// (the barrier words were zeroed by k_step_begin: one resident launch per step)
-			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = useBlocks ? 4 : 3; }
+			if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; w->ktKind = useBlocks ? 4 : 3; }
 			const int nColorsArg = colorsOnDevice ? -1 : nColors; // -1: read Counters::nColors on the device
 			if (useBlocks)
 			{
@@ -1767,7 +1795,7 @@ static int phaseSolve(b2hip_world* w)
 				w->dfEpoch += 1;
 			}
 #endif
-			if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
+			if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; }
 			w->persistSteps += 1;
 			if (smallDeferred) { smallDeferred = false; rc = launchSmallIslands(w->stream2); if (rc) return rc; }
 		}
@@ -1836,9 +1864,9 @@ static int phaseSolve(b2hip_world* w)
 			for (int col = 0; col < nColors; ++col)
 			{
 				if (!colorUsed(col)) continue;
-				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
+				if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
 				LAUNCH(w, k_large_velocity, gK, 256, d, col, 1);
-				if (w->kernelTiming) { rc = ktRecord(w); if (rc) return rc; }
+				if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; }
 				if (w->debugTrace) TRACE(("vel" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
 			if (hasHubs) { rc = hubSweepLaunch(1, it > 0 ? 1 : 0); if (rc) return rc; }
@@ -1897,7 +1925,9 @@ static int phaseSolve(b2hip_world* w)
 static int phaseSyncFixtures(b2hip_world* w)
 {
 	DW& d = w->dw;
+	if (int rk = ktBracket(w, 3, 6)) return rk;
 	LAUNCH(w, k_sync_fixtures, gridFor(d.nProxies), 256, d);
+	if (int rk = ktBracket(w, 3, 6)) return rk;
 	return 0;
 }
 
@@ -1909,14 +1939,14 @@ static int toiBuildIndexes(b2hip_world* w, bool csr)
 	{
 		LAUNCH(w, k_toi_adj_clear, gridFor(d.nBodies + 1), 256, d);
 		LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
-		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->scanFlags.p, w->consts.p + 4, d.nBodies + 1);
+		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->scanCtx, w->consts.p + 4, d.nBodies + 1);
 		LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
 	}
 	// make the grid reflect every fat AABB as of now (the end-of-step pair update skips the rebuild when nothing
 	// moved, and TOI moves of earlier steps never enter the move buffer)
 	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
 	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
-	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanFlags.p, w->consts.p + 1, (int)(d.gridMask + 1));
+	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanCtx, w->consts.p + 1, (int)(d.gridMask + 1));
 	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 1);
 	return 0;
 }
@@ -2207,6 +2237,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverBytes = 0.0;
 	w->solverConstraints = w->solverBodies = 0;
 	w->kernelTiming = 0;
+	w->ktUnitsA = w->ktUnitsB = 0;
 	w->ktUsed = 0;
 	w->ktKind = 0;
 	w->ktMs = 0.0f;
@@ -2954,6 +2985,11 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	sp.warmStarting = w->def.warm_starting;
 	sp.allowSleep = w->def.allow_sleep;
 	sp.gravity = v2(w->def.gravity_x, w->def.gravity_y);
+	if (w->kernelTiming > 1)
+	{
+		w->ktUsed = 0;
+		w->ktKind = 0;
+	}
 	w->stepActive = true;
 	// zero the per-step counters (keep nContacts / nMoves / cur)
 	Counters zero;
@@ -3453,7 +3489,7 @@ static int collideImpl(b2hip_world* w)
 			std::vector<std::pair<unsigned long long, int> > order(n);
 			for (int i = 0; i < n; ++i) order[i] = std::make_pair(recs[i].key, i);
 			std::sort(order.begin(), order.end(), keyLess);
-			std::vector<int> disabled;
+			std::vector<int> disabled, materials;
 			w->callbackWindow = true;
 			for (int k = 0; k < n; ++k)
 			{
@@ -3461,11 +3497,25 @@ static int collideImpl(b2hip_world* w)
 				b2hip_manifold oldM, newM;
 				toManifold(&oldM, r.o0, r.o1, r.oimp, r.o3);
 				toManifold(&newM, r.n0, r.n1, r.nimp, r.n3);
-				if (!w->preSolveFn(w->preSolveUser, r.info.x, r.info.y, r.info.z, &oldM, &newM)) disabled.push_back(r.info.x);
+				b2hip_contact_material mat = { r.mat.x, r.mat.y, r.mat.z };
+				if (!w->preSolveFn(w->preSolveUser, r.info.x, r.info.y, r.info.z, &oldM, &newM, &mat)) disabled.push_back(r.info.x);
+				if (memcmp(&mat.friction, &r.mat.x, 4) != 0 || memcmp(&mat.restitution, &r.mat.y, 4) != 0 || memcmp(&mat.tangent_speed, &r.mat.z, 4) != 0)
+				{
+					int bits[3];
+					memcpy(bits, &mat, sizeof(bits));
+					materials.push_back(r.info.x);
+					materials.insert(materials.end(), bits, bits + 3);
+				}
 			}
 			w->callbackWindow = false;
 			rc = applyHostList(w, k_presolve_disable, disabled);
 			if (rc) return rc;
+			if (!materials.empty())
+			{
+				HIP_TRY(hipMemcpyAsync(w->hostList.p, materials.data(), materials.size() * sizeof(int), hipMemcpyHostToDevice, w->stream));
+				LAUNCH(w, k_presolve_material, gridFor(materials.size() / 4), 256, w->dw, (const int*)w->hostList.p, (int)(materials.size() / 4));
+				HIP_TRY(hipStreamSynchronize(w->stream));
+			}
 		}
 		// Edits made from inside PreSolve take effect at once, as in the reference, whose deferred callbacks run between
 		// Collide and Solve (b2ContactManager::FinishCollide, b2ContactManager.cpp:387-441; Testbed/Tests/TunnelingTest.h
@@ -3757,6 +3807,7 @@ static int stepEndImpl(b2hip_world* w)
 		if (c.nUncolored != 0) return setError(B2HIP_ERR_CAPACITY, "incremental colouring did not converge");
 	}
 	if (c.overflow & 64) return setError(B2HIP_ERR_HIP, "grid barrier of k_solve_persistent timed out (a workgroup was not resident)");
+	if (c.overflow & SCAN_ABORT_BIT) return setError(B2HIP_ERR_HIP, "a single-pass scan gave up waiting for a predecessor tile (k_scan_chain look-back)");
 	w->last.posItersLarge = c.posItersLarge;
 	w->last.nHubRows = c.nHubRows;
 	w->last.hubRounds = c.hubRounds;
@@ -3828,7 +3879,12 @@ static int stepEndImpl(b2hip_world* w)
 			w->ktMs += t;
 			w->ktLaunches += 1;
 		}
-		if (w->ktKind == 1) w->ktBytes = (double)w->last.nLContacts * 220.0 * w->sp.velIters;
+		// SURVEY.md 8d per-unit figures: collide 480 B per contact of two polygons (230 B otherwise: circles), sync fixtures
+		// 250 B per proxy, pair update 16 B per proxy read + 8 B per candidate pair written
+		if (w->ktKind == 5) w->ktBytes = (double)w->ktUnitsA * 480.0 + (double)w->ktUnitsB * 230.0;
+		else if (w->ktKind == 6) w->ktBytes = (double)w->ktUnitsA * 250.0;
+		else if (w->ktKind == 7) w->ktBytes = (double)w->ktUnitsA * 16.0 + (double)w->ktUnitsB * 8.0;
+		else if (w->ktKind == 1) w->ktBytes = (double)w->last.nLContacts * 220.0 * w->sp.velIters;
 		else if (w->ktKind == 3 || w->ktKind == 4) w->ktBytes = (double)w->last.nLContacts * (w->sp.velIters * 220.0 + w->last.posItersLarge * 136.0 + 488.0) + (double)w->last.nLBodies * 240.0;
 		else w->ktBytes = (double)w->last.nSContacts * (w->sp.velIters * 220.0 + w->sp.posIters * 136.0 + 488.0) + (double)w->last.nSBodies * 240.0;
 	}
@@ -4292,6 +4348,7 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 		c.id_key[1] = (uint32_t)m3[i].y;
 		c.friction = mat[i].x;
 		c.restitution = mat[i].y;
+		c.tangent_speed = mat[i].z;
 	}
 	return n;
 }
@@ -4618,10 +4675,18 @@ int b2hip_set_kernel_timing(b2hip_world* w, int enable)
 	return 0;
 }
 
+int b2hip_set_kernel_timing_units(b2hip_world* w, long long units_a, long long units_b)
+{
+	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
+	w->ktUnitsA = units_a;
+	w->ktUnitsB = units_b;
+	return 0;
+}
+
 int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes)
 {
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
-	const char* n = w->ktKind == 4 ? "k_solve_blocks" : w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : (w->solverRows ? "k_solve_dataflow" : "k_solve_mailbox")) : ""));
+	const char* n = w->ktKind == 5 ? "k_collide" : w->ktKind == 6 ? "k_sync_fixtures" : w->ktKind == 7 ? "k_find_pairs_small" : w->ktKind == 4 ? "k_solve_blocks" : w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : (w->solverRows ? "k_solve_dataflow" : "k_solve_mailbox")) : ""));
 	if (name && name_cap > 0)
 	{
 		strncpy(name, n, (size_t)name_cap - 1);

@@ -23,7 +23,9 @@ struct b2h_world;
 //   kind 2 PreSolve  : ..., old point count, new point count, bits(old normalImpulse[0]), bits(new localNormal.x), enabled after the call
 //   kind 3 PostSolve : ..., count, bits(normalImpulses[0]), bits(normalImpulses[1]), bits(tangentImpulses[0]), bits(tangentImpulses[1])
 // mode bits: 1 begin / end, 2 PreSolve, 4 PostSolve, 8 PreSolve disables the contacts picked by a fixed rule of the body
-// indices (b2Contact::SetEnabled(false): a one-way-platform style use of the callback).
+// indices (b2Contact::SetEnabled(false): a one-way-platform style use of the callback), 16 PreSolve edits the contact's
+// material by a fixed rule of the body indices: every contact of body 0 (the ground) becomes a conveyor belt
+// (SetTangentSpeed, as Testbed/Tests/ConveyorBelt.h does), some contacts get another friction / restitution and some are reset.
 class b2hEventRecorder : public b2ContactListener
 {
 public:
@@ -34,7 +36,7 @@ public:
 	void PostSolve(b2Contact* contact, const b2ContactImpulse* impulse) override;
 	bool BeginContactImmediate(b2Contact*, uint32) override { return (m_mode & 1) != 0; }
 	bool EndContactImmediate(b2Contact*, uint32) override { return (m_mode & 1) != 0; }
-	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32) override { return (m_mode & (2 | 8)) != 0; }
+	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32) override { return (m_mode & (2 | 8 | 16)) != 0; }
 	bool PostSolveImmediate(b2Contact*, const b2ContactImpulse*, uint32) override { return (m_mode & 4) != 0; }
 	void Record(int kind, b2Contact* contact, int a, int b, int c, int d, int e);
 	std::vector<int> log; // 10 ints per event
@@ -288,6 +290,15 @@ void b2hEventRecorder::PreSolve(b2Contact* contact, const b2Manifold* oldManifol
 {
 	const int bA = m_owner->bodyIndex[contact->GetFixtureA()->GetBody()], bB = m_owner->bodyIndex[contact->GetFixtureB()->GetBody()];
 	if ((m_mode & 8) != 0 && (bA + 3 * bB) % 7 == 0) contact->SetEnabled(false);
+	if ((m_mode & 16) != 0)
+	{
+		const int lo = bA < bB ? bA : bB, hi = bA < bB ? bB : bA;
+		if (lo == 0) contact->SetTangentSpeed((hi & 1) ? 1.5f : -0.75f);             // the ground carries everything sideways
+		else if ((lo + hi) % 5 == 0) contact->SetFriction(0.05f + 0.01f * (float)(hi % 7));
+		else if ((lo + hi) % 5 == 1) contact->SetRestitution(0.6f);
+		else if ((lo + hi) % 5 == 2 && contact->GetFriction() != 0.0f) contact->SetFriction(0.5f * contact->GetFriction()); // (persists: halves every step)
+		else if ((lo + 2 * hi) % 9 == 0) { contact->ResetFriction(); contact->ResetRestitution(); }
+	}
 	if ((m_mode & 2) != 0)
 	{
 		const b2Manifold* m = contact->GetManifold();

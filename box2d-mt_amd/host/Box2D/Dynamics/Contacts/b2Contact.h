@@ -41,8 +41,16 @@ public:
 	b2Fixture* GetFixtureB() { return m_fixtureB; }
 	const b2Fixture* GetFixtureB() const { return m_fixtureB; }
 	int32 GetChildIndexB() const { return m_indexB; }
+	/// Friction / restitution / tangent speed (b2Contact.h:129-160). Inside b2ContactListener::PreSolve the setters reach the
+	/// solver of this step and stay with the contact (the conveyor belt of the Testbed); anywhere else they change the view only.
+	void SetFriction(float32 friction) { m_friction = friction; }
 	float32 GetFriction() const { return m_friction; }
+	void ResetFriction() { m_friction = b2MixFriction(m_fixtureA->GetFriction(), m_fixtureB->GetFriction()); }
+	void SetRestitution(float32 restitution) { m_restitution = restitution; }
 	float32 GetRestitution() const { return m_restitution; }
+	void ResetRestitution() { m_restitution = b2MixRestitution(m_fixtureA->GetRestitution(), m_fixtureB->GetRestitution()); }
+	void SetTangentSpeed(float32 speed) { m_tangentSpeed = speed; }
+	float32 GetTangentSpeed() const { return m_tangentSpeed; }
 
 private:
 	friend class b2World;
@@ -52,6 +60,7 @@ private:
 	int32 m_indexA = 0, m_indexB = 0; // child indices (chain shapes)
 	b2Contact* m_next;
 	float32 m_friction, m_restitution;
+	float32 m_tangentSpeed = 0.0f;
 	bool m_touching, m_enabled;
 };
 

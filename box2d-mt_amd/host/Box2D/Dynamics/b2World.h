@@ -105,7 +105,7 @@ private:
 	void DeliverPostSolve();
 	static int FilterTrampoline(void* user, int fixtureA, int fixtureB);
 	static int PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int fixtureB, const struct b2hip_manifold* oldManifold,
-		const struct b2hip_manifold* manifold);
+		const struct b2hip_manifold* manifold, struct b2hip_contact_material* material);
 	const std::vector<b2AABB>& FatAABBs();
 
 	void PushFlags();

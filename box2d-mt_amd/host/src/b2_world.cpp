@@ -198,8 +198,10 @@ void b2World::EndContactsOf(b2Body* body, b2Fixture* fixture)
 void b2World::DestroyBody(b2Body* b)
 {
 	if (IsLocked() || !m_hip || b == nullptr) return;
-	EndContactsOf(b, nullptr);
-	// joints attached to the body: SayGoodbye, then gone (b2World.cpp:595-611); b2hip_destroy_body destroys them on the device
+	// nothing is torn down and no listener hears anything for a body the device does not know (any more)
+	if (b->m_world != this || b->m_id < 0 || b->m_id >= (int32)m_bodies.size() || m_bodies[b->m_id] != b || b2hip_body_is_destroyed(m_hip, b->m_id)) return;
+	// the reference's order (b2World.cpp:594-643): the attached joints go first (SayGoodbye, then destroyed), then the
+	// contacts end, then the fixtures say goodbye and go with the body
 	for (b2Joint* j = m_jointList; j != nullptr;)
 	{
 		b2Joint* next = j->m_next;
@@ -210,6 +212,7 @@ void b2World::DestroyBody(b2Body* b)
 		}
 		j = next;
 	}
+	EndContactsOf(b, nullptr);
 	for (b2Fixture* f = b->m_fixtureList; f != nullptr; f = f->m_next)
 	{
 		if (m_destructionListener) m_destructionListener->SayGoodbye(f);
@@ -563,7 +566,7 @@ static void FillManifold(b2Manifold& out, const b2hip_manifold& m)
 // b2Contact::Update -> PreSolveImmediate / PreSolve (b2Contact.cpp:283-297): called by the step between Collide and the
 // island build; the contact view lives for the duration of the call.
 int b2World::PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int fixtureB, const b2hip_manifold* oldManifold,
-	const b2hip_manifold* manifold)
+	const b2hip_manifold* manifold, b2hip_contact_material* material)
 {
 	B2_NOT_USED(contactIndex);
 	b2World* self = static_cast<b2World*>(user);
@@ -572,13 +575,19 @@ int b2World::PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int 
 	FillManifold(c.m_manifold, *manifold);
 	self->BindFixtures(c, fixtureA, fixtureB);
 	c.m_next = nullptr;
-	c.m_friction = b2MixFriction(c.m_fixtureA->GetFriction(), c.m_fixtureB->GetFriction());
-	c.m_restitution = b2MixRestitution(c.m_fixtureA->GetRestitution(), c.m_fixtureB->GetRestitution());
+	// the contact's own values (b2Contact::m_friction ...: a listener may have overridden the mixture in an earlier step)
+	c.m_friction = material->friction;
+	c.m_restitution = material->restitution;
+	c.m_tangentSpeed = material->tangent_speed;
 	c.m_touching = true;
 	c.m_enabled = true;
 	b2Manifold old;
 	FillManifold(old, *oldManifold);
 	if (self->m_contactListener->PreSolveImmediate(&c, &old, 0)) self->m_contactListener->PreSolve(&c, &old);
+	// SetFriction / SetRestitution / SetTangentSpeed / SetEnabled made on the view go back to the contact
+	material->friction = c.m_friction;
+	material->restitution = c.m_restitution;
+	material->tangent_speed = c.m_tangentSpeed;
 	return c.m_enabled ? 1 : 0;
 }
 
@@ -812,6 +821,7 @@ b2Contact* b2World::GetContactList()
 			BindFixtures(c, r.fixture_a, r.fixture_b);
 			c.m_friction = r.friction;
 			c.m_restitution = r.restitution;
+			c.m_tangentSpeed = r.tangent_speed;
 			c.m_touching = (r.flags & 1u) != 0;
 			c.m_enabled = (r.flags & 2u) != 0;
 			c.m_next = nullptr;

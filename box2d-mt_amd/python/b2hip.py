@@ -124,7 +124,7 @@ CONTACT_DTYPE = np.dtype([("fixture_a", "i4"), ("fixture_b", "i4"), ("body_a", "
                           ("flags", "u4"), ("manifold_type", "i4"), ("point_count", "i4"),
                           ("local_normal", "f4", 2), ("local_point", "f4", 2), ("point_local", "f4", (2, 2)),
                           ("normal_impulse", "f4", 2), ("tangent_impulse", "f4", 2), ("id_key", "u4", 2),
-                          ("friction", "f4"), ("restitution", "f4")])
+                          ("friction", "f4"), ("restitution", "f4"), ("tangent_speed", "f4")])
 
 _lib = None
 
@@ -178,6 +178,12 @@ def _configure(L, optional_ok=False):
         "b2hip_get_solver_timing": [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "b2hip_apply_force": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int],
         "b2hip_set_velocity": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
+        "b2hip_destroy_body": [C.c_void_p, C.c_int],
+        "b2hip_destroy_fixture": [C.c_void_p, C.c_int],
+        "b2hip_set_bullet": [C.c_void_p, C.c_int, C.c_int],
+        "b2hip_set_awake": [C.c_void_p, C.c_int, C.c_int],
+        "b2hip_fixture_set_sensor": [C.c_void_p, C.c_int, C.c_int],
+        "b2hip_fixture_refilter": [C.c_void_p, C.c_int],
     }
     for name, argtypes in sigs.items():
         try:
@@ -395,6 +401,25 @@ class World:
 
     def destroy_joint(self, joint):
         _check(self.L.b2hip_destroy_joint(self.p, joint))
+
+    def destroy_body(self, body):
+        """b2World::DestroyBody: the body, its fixtures, its joints and its contacts (ids are never reused)."""
+        _check(self.L.b2hip_destroy_body(self.p, body))
+
+    def destroy_fixture(self, fixture):
+        _check(self.L.b2hip_destroy_fixture(self.p, fixture))
+
+    def set_bullet(self, body, flag=True):
+        _check(self.L.b2hip_set_bullet(self.p, body, int(flag)))
+
+    def set_awake(self, body, flag=True):
+        _check(self.L.b2hip_set_awake(self.p, body, int(flag)))
+
+    def fixture_set_sensor(self, fixture, flag=True):
+        _check(self.L.b2hip_fixture_set_sensor(self.p, fixture, int(flag)))
+
+    def fixture_refilter(self, fixture):
+        _check(self.L.b2hip_fixture_refilter(self.p, fixture))
 
     def joint_set_target(self, joint, target):
         _check(self.L.b2hip_joint_set_target(self.p, joint, target[0], target[1]))

@@ -289,6 +289,7 @@ typedef struct b2hip_contact
 	float tangent_impulse[2];
 	uint32_t id_key[2];
 	float friction, restitution;
+	float tangent_speed;       /* b2Contact::GetTangentSpeed (b2Contact.h:157-160) */
 } b2hip_contact;
 
 /* Counters of the last step (device truth, read back with the body states). */
@@ -478,8 +479,15 @@ typedef struct b2hip_manifold
  * was updated in this step, in proxy-id-pair order, with the manifold of the previous step. Return 0 to disable the
  * contact for this step (b2Contact::SetEnabled(false): it is left out of the islands; the next Collide enables it again).
  * `contact_index` indexes b2hip_get_contacts. Contacts updated inside continuous-collision sub-steps are not reported. */
+/* `material` (in / out): the contact's mixed friction and restitution (b2Contact.h:40-50) and its tangent speed, as
+ * b2Contact::SetFriction / SetRestitution / SetTangentSpeed (b2Contact.h:129-160) may change them from inside the callback;
+ * what the callback leaves there stays with the contact (this step's solver and every later one, until it is set again). */
+typedef struct b2hip_contact_material
+{
+	float friction, restitution, tangent_speed;
+} b2hip_contact_material;
 typedef int (*b2hip_pre_solve_fn)(void* user, int contact_index, int fixture_a, int fixture_b,
-	const b2hip_manifold* old_manifold, const b2hip_manifold* manifold);
+	const b2hip_manifold* old_manifold, const b2hip_manifold* manifold, b2hip_contact_material* material);
 int b2hip_set_pre_solve(b2hip_world* w, b2hip_pre_solve_fn fn, void* user);
 
 /* b2ContactListener::PostSolve (generation b2Island.cpp:532-570, delivery b2ContactManager.cpp:454-470): the impulses the
@@ -556,7 +564,13 @@ int b2hip_get_solver_timing(b2hip_world* w, float* ms, double* algorithmic_bytes
  * durations (ms), the launch count and the algorithmic bytes those launches processed (220 B per constraint
  * per velocity sweep, resp. the whole 8d formula for the fused small-island kernel). Off by default: the event
  * pairs cost host time, so the timed region of bench.py runs without them. */
+/* `enable`: 0 off, 1 the dominant solver kernel (above); 2 k_collide, 3 k_sync_fixtures, 4 k_find_pairs_small - the bandwidth
+ * kernels of the other phases (one event pair per launch). Their algorithmic bytes are the SURVEY 8d per-unit figures times
+ * the units the caller states with b2hip_set_kernel_timing_units (it knows the scene: collide = 480 B x contacts between two
+ * polygons (units_a) + 230 B x other contacts (units_b); sync fixtures = 250 B x proxies (units_a); pair search = 16 B x proxies
+ * (units_a) + 8 B x candidate pairs (units_b)). */
 int b2hip_set_kernel_timing(b2hip_world* w, int enable);
+int b2hip_set_kernel_timing_units(b2hip_world* w, long long units_a, long long units_b);
 int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes);
 
 #ifdef __cplusplus

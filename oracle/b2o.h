@@ -68,6 +68,7 @@ typedef struct b2o_contact
 	float tangent_impulse[2];
 	uint32_t id_key[2];
 	float friction, restitution;
+	float tangent_speed;
 } b2o_contact;
 
 b2o_world* b2o_world_create(float gx, float gy, int allow_sleep, int warm_starting, int continuous);
@@ -160,8 +161,11 @@ typedef struct b2o_manifold
 	float normal_impulse[2], tangent_impulse[2];
 	uint32_t id_key[2];
 } b2o_manifold;
+/* material (in / out) = the contact's m_friction, m_restitution, m_tangentSpeed: b2Contact::SetFriction / SetRestitution /
+ * SetTangentSpeed from inside PreSolve (b2Contact.h:129-160); same layout as b2hip_contact_material */
+typedef struct b2o_contact_material { float friction, restitution, tangent_speed; } b2o_contact_material;
 typedef int (*b2o_pre_solve_fn)(void* user, int contact_index, int fixture_a, int fixture_b, const b2o_manifold* old_manifold,
-	const b2o_manifold* manifold);
+	const b2o_manifold* manifold, b2o_contact_material* material);
 typedef struct b2o_contact_impulse
 {
 	int32_t fixture_a, fixture_b;

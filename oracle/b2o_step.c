@@ -1044,7 +1044,11 @@ static void deliver_pre_solve(b2o_world* w)
 		b2o_manifold oldM, newM;
 		fill_manifold(&oldM, &c->oldm);
 		fill_manifold(&newM, &c->m);
-		if (!w->preSolveFn(w->preSolveUser, rank[due[k]], c->fixtureA, c->fixtureB, &oldM, &newM)) c->flags &= ~CF_ENABLED;
+		b2o_contact_material mat = { c->friction, c->restitution, c->tangentSpeed };
+		if (!w->preSolveFn(w->preSolveUser, rank[due[k]], c->fixtureA, c->fixtureB, &oldM, &newM, &mat)) c->flags &= ~CF_ENABLED;
+		c->friction = mat.friction; /* (the setters' values stay with the contact, b2Contact.h:129-160) */
+		c->restitution = mat.restitution;
+		c->tangentSpeed = mat.tangent_speed;
 	}
 	free(rank);
 	free(due);
@@ -1525,6 +1529,123 @@ static void gear_gather(b2o_world* w, const revolute_t* j, const pos_t* position
 	}
 }
 
+#ifdef B2O_ORDER_EXPERIMENT
+#include <stdio.h>
+/* ---- ORDER EXPERIMENT (compiled only with -DB2O_ORDER_EXPERIMENT by tools/order_experiment.py; never in liboracle.so) -----
+ * How much of the one-step deviation of a reordered Gauss-Seidel sweep can a better visiting order buy? With the environment
+ * variable B2O_ORDER = k the constraints of every island of more than 1 000 contacts are visited in another order than the
+ * reference's (b2Island.cpp:184-396 solves them in island order): 1 greedy colouring by hashed priority (what the device's
+ * coloured solver does), 2 bottom-up by contact height, 3 / 6 greedy colouring with a spatial priority, 4 the reference
+ * order's own dependency levels wrapped modulo B2O_ORDER_D (flips about 1 / D of the pairwise precedences), 5 the same on
+ * the bottom-up order. Result on Pyramid 141 at steps 245 / 300: DESIGN.md section 3. */
+static const b2o_world* exw;
+static float* exkey;
+static int ex_cmp(const void* a, const void* b)
+{
+	int ia = *(const int*)a, ib = *(const int*)b;
+	if (exkey[ia] < exkey[ib]) return -1;
+	if (exkey[ia] > exkey[ib]) return 1;
+	return ia - ib;
+}
+static float ex_y(const b2o_world* w, int slot)
+{
+	const contact_t* c = &w->contacts[slot];
+	const body_t* a = &w->bodies[c->bodyA];
+	const body_t* b = &w->bodies[c->bodyB];
+	if (a->type == 0) return b->c.y - 0.5f;
+	if (b->type == 0) return a->c.y - 0.5f;
+	return 0.5f * (a->c.y + b->c.y);
+}
+static float ex_x(const b2o_world* w, int slot)
+{
+	const contact_t* c = &w->contacts[slot];
+	const body_t* a = &w->bodies[c->bodyA];
+	const body_t* b = &w->bodies[c->bodyB];
+	if (a->type == 0) return b->c.x;
+	if (b->type == 0) return a->c.x;
+	return 0.5f * (a->c.x + b->c.x);
+}
+static void ex_reorder(b2o_world* w, int* ic, int n, int mode, int D)
+{
+	int* idx = (int*)malloc(sizeof(int) * n);
+	float* key = (float*)malloc(sizeof(float) * n);
+	int* out = (int*)malloc(sizeof(int) * n);
+	for (int i = 0; i < n; ++i) idx[i] = i;
+	exkey = key;
+	if (mode == 2)
+	{
+		for (int i = 0; i < n; ++i) key[i] = ex_y(w, ic[i]);
+	}
+	else if (mode == 1 || mode == 3 || mode == 6)
+	{
+		/* greedy colouring in priority order; colour classes ascending */
+		float* pri = (float*)malloc(sizeof(float) * n);
+		for (int i = 0; i < n; ++i) pri[i] = mode == 1 ? (float)(((uint32_t)ic[i] * 2654435761u) >> 8) : (mode == 3 ? ex_y(w, ic[i]) : ex_y(w, ic[i]) + 0.37f * ex_x(w, ic[i]));
+		exkey = pri;
+		qsort(idx, n, sizeof(int), ex_cmp);
+		uint64_t* used = (uint64_t*)calloc(w->nBodies, sizeof(uint64_t));
+		int maxc = 0;
+		for (int k = 0; k < n; ++k)
+		{
+			int i = idx[k];
+			const contact_t* c = &w->contacts[ic[i]];
+			uint64_t m = 0;
+			if (w->bodies[c->bodyA].type != 0) m |= used[c->bodyA];
+			if (w->bodies[c->bodyB].type != 0) m |= used[c->bodyB];
+			int col = 0;
+			while (m & (1ull << col)) ++col;
+			if (w->bodies[c->bodyA].type != 0) used[c->bodyA] |= 1ull << col;
+			if (w->bodies[c->bodyB].type != 0) used[c->bodyB] |= 1ull << col;
+			key[i] = (float)col;
+			if (col > maxc) maxc = col;
+		}
+		fprintf(stderr, "[ex] mode %d: %d colours\n", mode, maxc + 1);
+		free(used);
+		free(pri);
+		exkey = key;
+		for (int i = 0; i < n; ++i) idx[i] = i;
+	}
+	else if (mode == 4 || mode == 5)
+	{
+		/* DAG levels of the reference order (mode 4) or of the bottom-up order (mode 5), wrapped mod D */
+		if (mode == 5)
+		{
+			for (int i = 0; i < n; ++i) key[i] = ex_y(w, ic[i]) + 0.37f * ex_x(w, ic[i]);
+			qsort(idx, n, sizeof(int), ex_cmp);
+		}
+		int* last = (int*)calloc(w->nBodies, sizeof(int));
+		int maxl = 0;
+		int* lev = (int*)malloc(sizeof(int) * n);
+		for (int k = 0; k < n; ++k)
+		{
+			int i = idx[k];
+			const contact_t* c = &w->contacts[ic[i]];
+			int l = 0;
+			if (w->bodies[c->bodyA].type != 0 && last[c->bodyA] > l) l = last[c->bodyA];
+			if (w->bodies[c->bodyB].type != 0 && last[c->bodyB] > l) l = last[c->bodyB];
+			l += 1;
+			if (w->bodies[c->bodyA].type != 0) last[c->bodyA] = l;
+			if (w->bodies[c->bodyB].type != 0) last[c->bodyB] = l;
+			lev[i] = l;
+			if (l > maxl) maxl = l;
+		}
+		fprintf(stderr, "[ex] mode %d: %d levels, D %d\n", mode, maxl, D);
+		/* key = (level mod D), ties in the base order */
+		int* rank = (int*)malloc(sizeof(int) * n);
+		for (int k = 0; k < n; ++k) rank[idx[k]] = k;
+		for (int i = 0; i < n; ++i) key[i] = (float)((lev[i] - 1) % D) + (float)rank[i] / (float)(n + 1);
+		free(rank);
+		free(lev);
+		free(last);
+		for (int i = 0; i < n; ++i) idx[i] = i;
+	}
+	qsort(idx, n, sizeof(int), ex_cmp);
+	for (int k = 0; k < n; ++k) out[k] = ic[idx[k]];
+	memcpy(ic, out, sizeof(int) * n);
+	free(idx); free(key); free(out);
+}
+#endif
+
 static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* islandContacts, int contactCount,
 	int* islandJoints, int jointCount, float h, float dtRatio, int velIters, int posIters)
 {
@@ -1555,6 +1676,13 @@ static void solve_island(b2o_world* w, int* islandBodies, int bodyCount, int* is
 		positions[i].c = c; positions[i].a = a;
 		velocities[i].v = v; velocities[i].w = ww;
 	}
+#ifdef B2O_ORDER_EXPERIMENT
+	{
+		const char* ex = getenv("B2O_ORDER");
+		const char* exd = getenv("B2O_ORDER_D");
+		if (ex && atoi(ex) > 0 && contactCount > 1000) ex_reorder(w, islandContacts, contactCount, atoi(ex), exd ? atoi(exd) : 64);
+	}
+#endif
 	for (int i = 0; i < contactCount; ++i) init_constraint(w, &cs[i], islandContacts[i], positions, velocities, dtRatio);
 	if (w->warmStarting)
 	{
@@ -2672,6 +2800,7 @@ int b2o_get_contacts(const b2o_world* w, int cap, b2o_contact* out)
 		}
 		o->friction = c->friction;
 		o->restitution = c->restitution;
+		o->tangent_speed = c->tangentSpeed;
 	}
 	free(live);
 	return n;

@@ -424,6 +424,45 @@ def test_joint_setters_between_steps(libs, monkeypatch):
     a.close(); b.close()
 
 
+def test_edits_on_a_body_with_more_contacts_than_one_edit_pass(libs):
+    """The edit kernel lists the contacts of an edited body / fixture in an LDS list of 8 192 entries and works a longer
+    list off in passes (b2d_kernels_edit.h; the reference walks the body's contact list without a limit, b2World.cpp:617-625,
+    b2Fixture.cpp:187-210). A ground body under 9 000 boxes: its fixture is re-filtered and turned into a sensor and back,
+    then the body is destroyed with all 9 000 contacts at once; a second ground 0.2 below catches the boxes."""
+    a, b = both(libs, continuous=True)
+    ids = {}
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, -0.5))
+        ids["gfix"] = w.create_fixture(g, b2hip.box_shape(3000.0, 0.5))
+        g2 = w.create_body(b2hip.STATIC, (0.0, -1.2))
+        w.create_fixture(g2, b2hip.box_shape(3000.0, 0.5))
+        ids["ground"] = g
+        for i in range(9000):
+            body = w.create_body(b2hip.DYNAMIC, (-2700.0 + 0.6 * i, 0.26))
+            w.create_fixture(body, b2hip.box_shape(0.25, 0.25), density=1.0)
+
+    def between(s, w):
+        if s == 4:
+            w.fixture_refilter(ids["gfix"])
+        if s == 6:
+            w.fixture_set_sensor(ids["gfix"], True)
+        if s == 7:
+            w.fixture_set_sensor(ids["gfix"], False)
+        if s == 12:
+            w.destroy_body(ids["ground"])
+
+    run(a, b, 6, "wide ground", between=between)
+    assert a.contact_count >= 9000
+    for s in range(6, 30):
+        between(s, a)
+        between(s, b)
+        a.step()
+        b.step()
+        same(a, b, "wide ground step %d" % s)
+    assert a.contact_count >= 9000  # (on the lower ground now)
+    a.close(); b.close()
+
+
 def test_dense_start_grows_the_pair_buffer(monkeypatch):
     """1 400 bodies and 450 bullets crammed into a 70 x 70 arena: the first pair update finds several times more candidate
     pairs than the buffer was sized for (21 000 contacts on step one). The buffers grow and the search runs again - no

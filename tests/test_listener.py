@@ -23,6 +23,9 @@ import b2harness as bh
 
 MODE_ALL = 1 | 2 | 4          # begin / end, PreSolve, PostSolve: recorded
 MODE_DISABLE = 1 | 2 | 4 | 8  # ... and PreSolve switches contacts off by the harness's rule
+MODE_MATERIAL = 1 | 2 | 4 | 16  # ... and PreSolve edits the contacts' material: SetTangentSpeed on every ground contact (a conveyor
+#                                 belt, Testbed/Tests/ConveyorBelt.h:70-83), SetFriction / SetRestitution / Reset* on others (b2Contact.h:129-160)
+MODES = {"record": MODE_ALL, "filter": MODE_ALL, "disable": MODE_DISABLE, "material": MODE_MATERIAL}
 CASES = [("rain", bh.RAIN, 120, 0, 4, 150), ("piles", bh.PILES, 25, 5, 6, 140), ("pyramid", bh.PYRAMID, 9, 1, 1, 120),
          ("circlestack", bh.CIRCLE_STACK, 6, 5, 1, 120)]
 
@@ -53,14 +56,26 @@ def run_pair(a, b, steps, mode, use_filter, what):
 
 
 @pytest.mark.parametrize("name,scene,p0,p1,seed,steps", CASES)
-@pytest.mark.parametrize("variant", ["record", "disable", "filter"])
+@pytest.mark.parametrize("variant", ["record", "disable", "filter", "material"])
 def test_oracle_listener_and_filter_match_the_reference(ref, oracle, name, scene, p0, p1, seed, steps, variant):
     a = ref.world(scene, p0, p1, seed=seed)
     b = oracle.world(scene, p0, p1, seed=seed)
-    seen, disabled = run_pair(a, b, steps, MODE_DISABLE if variant == "disable" else MODE_ALL, variant == "filter", name + "/" + variant)
+    seen, disabled = run_pair(a, b, steps, MODES[variant], variant == "filter", name + "/" + variant)
     assert seen[2] > 0 and seen[3] > 0, "no PreSolve / PostSolve callback ever fired: test is vacuous"
     if variant == "disable" and name != "circlestack":
         assert disabled > 0, "the PreSolve rule never disabled a contact: test is vacuous"
+    a.close()
+    b.close()
+
+
+def test_material_edits_change_the_motion(oracle):
+    """the conveyor-belt rule really moves things (else the material variant above proves nothing)"""
+    a = oracle.world(bh.PILES, 25, 5, seed=6)
+    b = oracle.world(bh.PILES, 25, 5, seed=6)
+    b.record_events(mode=16)
+    a.step(100)
+    b.step(100)
+    assert np.abs(a.bodies()[:, 0] - b.bodies()[:, 0]).max() > 0.5  # carried sideways by the belt
     a.close()
     b.close()
 
@@ -79,12 +94,12 @@ def test_filter_changes_the_contact_set(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,scene,p0,p1,seed,steps", CASES + [("field", bh.FIELD, 1500, 0, 8, 60)])
-@pytest.mark.parametrize("variant", ["record", "disable", "filter"])
+@pytest.mark.parametrize("variant", ["record", "disable", "filter", "material"])
 def test_device_listener_and_filter_match_the_oracle(amd, oracle, monkeypatch, name, scene, p0, p1, seed, steps, variant):
     monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")  # every island in the reference's order: states stay bit-equal
     a = amd.world(scene, p0, p1, seed=seed)
     b = oracle.world(scene, p0, p1, seed=seed)
-    seen, disabled = run_pair(a, b, steps, MODE_DISABLE if variant == "disable" else MODE_ALL, variant == "filter", name + "/" + variant)
+    seen, disabled = run_pair(a, b, steps, MODES[variant], variant == "filter", name + "/" + variant)
     assert seen[2] > 0 and seen[3] > 0
     a.close()
     b.close()
