@@ -26,8 +26,12 @@ def both(libs, **kw):
     return b2hip.World(library=libs[0], **kw), b2hip.World(library=libs[1], **kw)
 
 
-def same(a, b, what=""):
+def same(a, b, what="", skip=()):
     sa, sb = a.body_states(), b.body_states()
+    if skip:  # (destroyed bodies: their ids stay, what their rows hold is not defined)
+        keep = np.ones(len(sa), bool)
+        keep[list(skip)] = False
+        sa, sb = sa[keep], sb[keep]
     for f in ("px", "py", "angle", "vx", "vy", "w", "cx", "cy", "sleep_time"):
         assert np.array_equal(sa[f].view(np.uint32), sb[f].view(np.uint32)), "%s: %s differs" % (what, f)
     assert np.array_equal(sa["flags"] & 0x7f, sb["flags"] & 0x7f), "%s: flags differ" % what
@@ -458,7 +462,7 @@ def test_edits_on_a_body_with_more_contacts_than_one_edit_pass(libs):
         between(s, b)
         a.step()
         b.step()
-        same(a, b, "wide ground step %d" % s)
+        same(a, b, "wide ground step %d" % s, skip=(ids["ground"],) if s >= 12 else ())
     assert a.contact_count >= 9000  # (on the lower ground now)
     a.close(); b.close()
 
