@@ -1668,4 +1668,76 @@ B2D_HD bool b2dJointSolvePosition(const JointRec* j, BodyPos* A, BodyPos* B)
 	return b2dRevoluteSolvePosition(j, A, B);
 }
 
+// ---- what a joint did in the last step: b2Joint::GetReactionForce / GetReactionTorque and the motor's share
+// (GetMotorTorque / GetMotorForce), from the record's accumulated impulses and the directions its init stored. Reference:
+// b2RevoluteJoint.cpp:439-456, b2DistanceJoint.cpp:236-247, b2PrismaticJoint.cpp:502-510,618-621, b2WeldJoint.cpp:316-325,
+// b2WheelJoint.cpp:340-348,434-437, b2RopeJoint.cpp:207-217, b2FrictionJoint.cpp:222-230, b2MotorJoint.cpp:236-244,
+// b2PulleyJoint.cpp:273-283, b2MouseJoint.cpp:210-218, b2GearJoint.cpp:381-391.
+struct JointReaction
+{
+	V2 force;     // on bodyB at the anchor, newtons
+	float torque; // on bodyB, N m
+	float motor;  // motor torque / force (revolute, prismatic, wheel), else 0
+};
+
+B2D_HD JointReaction b2dJointReaction(const JointRec* j, const GearRec* gear, float inv_dt)
+{
+	JointReaction r;
+	r.force = v2(0.0f, 0.0f);
+	r.torque = 0.0f;
+	r.motor = 0.0f;
+	switch (j->type)
+	{
+	case B2D_JOINT_REVOLUTE:
+	case B2D_JOINT_WELD:
+		r.force = inv_dt * v2(j->impulseX, j->impulseY);
+		r.torque = inv_dt * j->impulseZ;
+		if (j->type == B2D_JOINT_REVOLUTE) r.motor = inv_dt * j->motorImpulse;
+		break;
+	case B2D_JOINT_DISTANCE:
+	case B2D_JOINT_ROPE:
+		r.force = (inv_dt * j->impulse) * v2(j->ux, j->uy);
+		break;
+	case B2D_JOINT_PRISMATIC:
+		// (init keeps m_axis in rA and m_perp in rB)
+		r.force = inv_dt * (j->impulseX * j->rB + (j->motorImpulse + j->impulseZ) * j->rA);
+		r.torque = inv_dt * j->impulseY;
+		r.motor = inv_dt * j->motorImpulse;
+		break;
+	case B2D_JOINT_WHEEL:
+		// (m_ax in rA, m_ay in rB)
+		r.force = inv_dt * (j->impulse * j->rB + j->springImpulse * j->rA);
+		r.torque = inv_dt * j->motorImpulse;
+		r.motor = inv_dt * j->motorImpulse;
+		break;
+	case B2D_JOINT_FRICTION:
+	case B2D_JOINT_MOTOR:
+		r.force = inv_dt * v2(j->impulseX, j->impulseY);
+		r.torque = inv_dt * j->angularImpulse;
+		break;
+	case B2D_JOINT_PULLEY:
+	{
+		const V2 P = j->impulse * v2(j->m_eyz, j->m_ezx); // m_uB
+		r.force = inv_dt * P;
+		break;
+	}
+	case B2D_JOINT_MOUSE:
+		r.force = inv_dt * v2(j->impulseX, j->impulseY);
+		r.torque = inv_dt * 0.0f;
+		break;
+	case B2D_JOINT_GEAR:
+		if (gear != nullptr)
+		{
+			const V2 P = gear->impulse * gear->JvAC;
+			r.force = inv_dt * P;
+			const float L = gear->impulse * gear->JwA;
+			r.torque = inv_dt * L;
+		}
+		break;
+	default:
+		break;
+	}
+	return r;
+}
+
 #endif

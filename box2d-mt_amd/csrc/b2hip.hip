@@ -2909,6 +2909,30 @@ int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lo
 	return 0;
 }
 
+int b2hip_get_joint_reaction(b2hip_world* w, int joint, float inv_dt, float out4[4])
+{
+	if (int rcu = checkUsable(w, "b2hip_get_joint_reaction", true)) return rcu;
+	if (!w || !out4 || joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	DEVICE_GUARD(w);
+	JointRec rec = w->joints[joint];
+	GearRec gear;
+	memset(&gear, 0, sizeof(gear));
+	const bool isGear = rec.type == B2D_JOINT_GEAR;
+	// (the solver's state lives in the device copy; a joint the device has not seen yet has done nothing)
+	if ((size_t)joint < w->upJoints && w->d_joints.p != nullptr)
+	{
+		HIP_TRY(hipMemcpyAsync(&rec, w->d_joints.p + joint, sizeof(JointRec), hipMemcpyDeviceToHost, w->stream));
+		if (isGear && (size_t)rec.enableLimit < w->upGears) HIP_TRY(hipMemcpyAsync(&gear, w->d_gears.p + rec.enableLimit, sizeof(GearRec), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	}
+	const JointReaction r = b2dJointReaction(&rec, isGear ? &gear : nullptr, inv_dt);
+	out4[0] = r.force.x;
+	out4[1] = r.force.y;
+	out4[2] = r.torque;
+	out4[3] = r.motor;
+	return 0;
+}
+
 int b2hip_body_count(const b2hip_world* w)
 {
 	return w ? (int)w->bodies.size() : 0;
@@ -3426,6 +3450,10 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 {
 	if (int rc = checkUsable(w, "b2hip_step_begin", false)) return rc;
 	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_begin inside a step (finish it with b2hip_step_end)");
+	// b2World::SetSubStepping (b2World.h:183, b2World.cpp:1082: one TOI event per Step call, the step finished over several
+	// calls) is not implemented. A world that has it switched on is REFUSED a step - stepping it as if the flag were off would
+	// silently give other results than the reference. The world is untouched and steps again once the flag is cleared.
+	if (w->def.sub_stepping) return setError(B2HIP_ERR_UNSUPPORTED, "sub-stepping (b2World::SetSubStepping) is not implemented: the step was refused, clear the flag to step");
 	DEVICE_GUARD(w);
 	return stepFailed(w, stepBeginImpl(w, dt, velocity_iterations, position_iterations));
 }

@@ -518,7 +518,7 @@ static void FillPolygon(b2PolygonShape& poly, int count, const float* verts, int
 	}
 }
 
-#ifdef B2H_BACKEND_REF
+// (both backends: the drop-in API offers b2CollidePolygons & co. as well, on the CPU build of the device's manifold code)
 // --- per-function probes (shape-level narrow phase and trig), used to pin the C restatement and
 // --- the device math bit-for-bit. Polygons are passed as count + 8 vertices (hull is rebuilt by Set()).
 
@@ -634,7 +634,6 @@ void b2h_probe_collide_edge_circle(const float* edgeA, const float* xfA, const f
 	DumpManifold(m, manifold16);
 }
 
-#endif // B2H_BACKEND_REF (narrow-phase probes call the reference's free functions)
 
 // Polygon build probe: returns count, then vertices[8], normals[8], centroid, and mass data for `density`.
 // out = 1 + 16 + 16 + 2 + 4 floats = 39
@@ -672,8 +671,8 @@ void b2h_probe_sincos(int n, const float* angles, float* sinOut, float* cosOut)
 	}
 }
 
-#ifdef B2H_BACKEND_REF
-// --- continuous-collision probes: b2Distance and b2TimeOfImpact on raw vertex proxies.
+// --- continuous-collision probes (both backends: the drop-in API offers b2Distance / b2TimeOfImpact / b2ShapeCast as well)
+// ---: b2Distance and b2TimeOfImpact on raw vertex proxies.
 // sweep9 = {localCenter.x, .y, c0.x, c0.y, c.x, c.y, a0, a, alpha0}
 static void FillProxy(b2DistanceProxy& p, b2Vec2* store, int count, const float* verts, float radius)
 {
@@ -730,6 +729,156 @@ void b2h_probe_toi(int countA, const float* vertsA, float radiusA, const float* 
 	out2[0] = (float)out.state;
 	out2[1] = out.t;
 }
-#endif
+// out6 = {hit, point.x, point.y, normal.x, normal.y, lambda}; iterations in out6[6]
+void b2h_probe_shape_cast(int countA, const float* vertsA, float radiusA, const float* xfA,
+	int countB, const float* vertsB, float radiusB, const float* xfB, float tx, float ty, float* out7)
+{
+	b2Vec2 storeA[b2_maxPolygonVertices], storeB[b2_maxPolygonVertices];
+	b2ShapeCastInput in;
+	FillProxy(in.proxyA, storeA, countA, vertsA, radiusA);
+	FillProxy(in.proxyB, storeB, countB, vertsB, radiusB);
+	in.transformA = MakeXf(xfA);
+	in.transformB = MakeXf(xfB);
+	in.translationB.Set(tx, ty);
+	b2ShapeCastOutput out;
+	const bool hit = b2ShapeCast(&out, &in);
+	out7[0] = hit ? 1.0f : 0.0f;
+	out7[1] = out.point.x; out7[2] = out.point.y;
+	out7[3] = out.normal.x; out7[4] = out.normal.y;
+	out7[5] = out.lambda;
+	out7[6] = (float)out.iterations;
+}
+
+// b2AABB::RayCast: out3 = {fraction, normal.x, normal.y}; returns 1 on a hit
+int b2h_probe_aabb_raycast(const float* box4, const float* ray5, float* out3)
+{
+	b2AABB box;
+	box.lowerBound.Set(box4[0], box4[1]);
+	box.upperBound.Set(box4[2], box4[3]);
+	b2RayCastInput in;
+	in.p1.Set(ray5[0], ray5[1]);
+	in.p2.Set(ray5[2], ray5[3]);
+	in.maxFraction = ray5[4];
+	b2RayCastOutput out;
+	if (!box.RayCast(&out, in)) return 0;
+	out3[0] = out.fraction; out3[1] = out.normal.x; out3[2] = out.normal.y;
+	return 1;
+}
+
+// b2DynamicTree through its public interface: `ops` random create / move / destroy operations on `count` boxes, after each of
+// which an AABB query and a ray cast are compared with brute force over the stored fat boxes. Returns the number of
+// disagreements (0 expected); out3 = final height, max balance, area ratio.
+namespace
+{
+struct TreeProbe
+{
+	bool QueryCallback(int32 id) { hits.push_back(id); return true; }
+	float32 RayCastCallback(const b2RayCastInput& in, int32 id) { rayHits.push_back(id); return in.maxFraction; }
+	std::vector<int32> hits, rayHits;
+};
+}
+int b2h_probe_dynamic_tree(unsigned seed, int count, int ops, float* out3)
+{
+	b2h::Pcg32 rng(seed);
+	b2DynamicTree tree;
+	std::vector<int32> ids(count, b2_nullNode);
+	std::vector<b2AABB> tight(count);
+	int bad = 0;
+	for (int op = 0; op < ops; ++op)
+	{
+		const int k = (int)(rng.Unit() * (float)count) % count;
+		const float roll = rng.Unit();
+		if (ids[k] == b2_nullNode)
+		{
+			const b2Vec2 c(rng.Range(-40.0f, 40.0f), rng.Range(-40.0f, 40.0f));
+			const b2Vec2 h(rng.Range(0.1f, 3.0f), rng.Range(0.1f, 3.0f));
+			tight[k].lowerBound = c - h;
+			tight[k].upperBound = c + h;
+			ids[k] = tree.CreateProxy(tight[k], (void*)(intptr_t)k);
+		}
+		else if (roll < 0.2f)
+		{
+			tree.DestroyProxy(ids[k]);
+			ids[k] = b2_nullNode;
+		}
+		else
+		{
+			const b2Vec2 d(rng.Range(-2.0f, 2.0f), rng.Range(-2.0f, 2.0f));
+			tight[k].lowerBound += d;
+			tight[k].upperBound += d;
+			tree.MoveProxy(ids[k], tight[k], d);
+		}
+		if (op % 8 != 0) continue;
+		tree.Validate();
+		b2AABB q;
+		const b2Vec2 c(rng.Range(-40.0f, 40.0f), rng.Range(-40.0f, 40.0f));
+		q.lowerBound = c - b2Vec2(5.0f, 4.0f);
+		q.upperBound = c + b2Vec2(5.0f, 4.0f);
+		TreeProbe probe;
+		tree.Query(&probe, q);
+		b2RayCastInput ray;
+		ray.p1.Set(rng.Range(-45.0f, 45.0f), rng.Range(-45.0f, 45.0f));
+		ray.p2.Set(rng.Range(-45.0f, 45.0f), rng.Range(-45.0f, 45.0f));
+		ray.maxFraction = 1.0f;
+		tree.RayCast(&probe, ray);
+		std::sort(probe.hits.begin(), probe.hits.end());
+		std::sort(probe.rayHits.begin(), probe.rayHits.end());
+		std::vector<int32> want, wantRay;
+		for (int i = 0; i < count; ++i)
+		{
+			if (ids[i] == b2_nullNode) continue;
+			const b2AABB& fat = tree.GetFatAABB(ids[i]);
+			if (!fat.Contains(tight[i])) ++bad; // the stored box always holds the tight one
+			if ((intptr_t)tree.GetUserData(ids[i]) != i) ++bad;
+			if (b2TestOverlap(fat, q)) want.push_back(ids[i]);
+			b2RayCastOutput o;
+			// (a ray that starts inside a box is not a hit of b2AABB::RayCast but the tree visits the leaf: test the segment's box)
+			b2AABB seg;
+			seg.lowerBound = b2Min(ray.p1, ray.p2);
+			seg.upperBound = b2Max(ray.p1, ray.p2);
+			b2RayCastInput back = ray;
+			back.p1 = ray.p2;
+			back.p2 = ray.p1;
+			const bool inside = fat.lowerBound.x <= ray.p1.x && ray.p1.x <= fat.upperBound.x && fat.lowerBound.y <= ray.p1.y && ray.p1.y <= fat.upperBound.y;
+			if (b2TestOverlap(fat, seg) && (inside || fat.RayCast(&o, ray) || fat.RayCast(&o, back))) wantRay.push_back(ids[i]);
+		}
+		std::sort(want.begin(), want.end());
+		std::sort(wantRay.begin(), wantRay.end());
+		if (want != probe.hits) ++bad;
+		// every leaf the exact test names must have been visited (the tree's own test is conservative: it may visit more)
+		for (size_t i = 0; i < wantRay.size(); ++i)
+			if (!std::binary_search(probe.rayHits.begin(), probe.rayHits.end(), wantRay[i])) ++bad;
+	}
+	out3[0] = (float)tree.GetHeight();
+	out3[1] = (float)tree.GetMaxBalance();
+	out3[2] = tree.GetAreaRatio();
+	return bad;
+}
+
+// b2World::GetTreeHeight / GetTreeBalance / GetTreeQuality / GetProxyCount (b2World.h:199-206)
+void b2h_tree_stats(b2h_world* h, float* out4)
+{
+	out4[0] = (float)h->world->GetTreeHeight();
+	out4[1] = (float)h->world->GetTreeBalance();
+	out4[2] = h->world->GetTreeQuality();
+	out4[3] = (float)h->world->GetProxyCount();
+}
+
+// b2Joint::GetReactionForce / GetReactionTorque(inv_dt) of every joint, in creation order: rows of 3 floats; returns the joint count
+int b2h_joint_reactions(b2h_world* h, float inv_dt, int cap, float* out)
+{
+	std::vector<b2Joint*> joints;
+	for (b2Joint* j = h->world->GetJointList(); j; j = j->GetNext()) joints.push_back(j);
+	std::reverse(joints.begin(), joints.end()); // (the list is newest first)
+	for (size_t i = 0; i < joints.size() && (int)i < cap; ++i)
+	{
+		const b2Vec2 f = joints[i]->GetReactionForce(inv_dt);
+		out[3 * i] = f.x;
+		out[3 * i + 1] = f.y;
+		out[3 * i + 2] = joints[i]->GetReactionTorque(inv_dt);
+	}
+	return (int)joints.size();
+}
+
 
 } // extern "C"

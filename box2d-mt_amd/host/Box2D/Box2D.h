@@ -11,6 +11,10 @@
 
 #include "Box2D/Common/b2Draw.h"
 #include "Box2D/Collision/b2Collision.h"
+#include "Box2D/Collision/b2Distance.h"
+#include "Box2D/Collision/b2TimeOfImpact.h"
+#include "Box2D/Collision/b2DynamicTree.h"
+#include "Box2D/Collision/b2BroadPhase.h"
 #include "Box2D/Collision/Shapes/b2CircleShape.h"
 #include "Box2D/Collision/Shapes/b2EdgeShape.h"
 #include "Box2D/Collision/Shapes/b2PolygonShape.h"
@@ -21,6 +25,7 @@
 #include "Box2D/Dynamics/b2WorldCallbacks.h"
 #include "Box2D/Dynamics/b2TimeStep.h"
 #include "Box2D/Dynamics/b2World.h"
+#include "Box2D/Dynamics/b2ContactManager.h"
 #include "Box2D/Dynamics/Contacts/b2Contact.h"
 #include "Box2D/Dynamics/Joints/b2Joint.h"
 #include "Box2D/Dynamics/Joints/b2RevoluteJoint.h"

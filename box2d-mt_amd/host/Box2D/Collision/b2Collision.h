@@ -81,6 +81,8 @@ struct b2RayCastOutput
 
 struct b2AABB
 {
+	/// the segment p1 -> p2 of `input` against the box: entry fraction and face normal (b2Collision.cpp:133-198)
+	bool RayCast(b2RayCastOutput* output, const b2RayCastInput& input) const;
 	bool IsValid() const
 	{
 		b2Vec2 d = upperBound - lowerBound;
@@ -117,6 +119,17 @@ struct b2AABB
 	b2Vec2 lowerBound;
 	b2Vec2 upperBound;
 };
+
+// Narrow-phase routines on the host, with the reference's signatures (b2Collision.h:229-256): each packs its shapes into
+// the device's shape records and runs the CPU build of the manifold code the collide kernel runs (csrc/b2d_collide.h).
+void b2CollideCircles(b2Manifold* manifold, const b2CircleShape* circleA, const b2Transform& xfA, const b2CircleShape* circleB, const b2Transform& xfB);
+void b2CollidePolygonAndCircle(b2Manifold* manifold, const b2PolygonShape* polygonA, const b2Transform& xfA, const b2CircleShape* circleB, const b2Transform& xfB);
+void b2CollidePolygons(b2Manifold* manifold, const b2PolygonShape* polygonA, const b2Transform& xfA, const b2PolygonShape* polygonB, const b2Transform& xfB);
+void b2CollideEdgeAndCircle(b2Manifold* manifold, const b2EdgeShape* edgeA, const b2Transform& xfA, const b2CircleShape* circleB, const b2Transform& xfB);
+void b2CollideEdgeAndPolygon(b2Manifold* manifold, const b2EdgeShape* edgeA, const b2Transform& xfA, const b2PolygonShape* polygonB, const b2Transform& xfB);
+int32 b2ClipSegmentToLine(b2ClipVertex vOut[2], const b2ClipVertex vIn[2], const b2Vec2& normal, float32 offset, int32 vertexIndexA);
+/// do two shapes (children) overlap: GJK distance below 10 epsilon, radii included (b2Collision.cpp:233-252)
+bool b2TestOverlap(const b2Shape* shapeA, int32 indexA, const b2Shape* shapeB, int32 indexB, const b2Transform& xfA, const b2Transform& xfB);
 
 inline bool b2TestOverlap(const b2AABB& a, const b2AABB& b)
 {

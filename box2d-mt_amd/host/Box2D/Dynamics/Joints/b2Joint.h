@@ -65,9 +65,15 @@ public:
 	void SetUserData(void* data) { m_userData = data; }
 	bool GetCollideConnected() const { return m_collideConnected; }
 	int32 GetDeviceId() const { return m_id; }
+	/// The force / torque the joint put on bodyB in the last step, for every joint type (b2Joint.h:129-133): computed from the
+	/// device record's accumulated impulses (b2hip_get_joint_reaction).
+	b2Vec2 GetReactionForce(float32 inv_dt) const;
+	float32 GetReactionTorque(float32 inv_dt) const;
+	bool IsActive() const;
 
 protected:
 	friend class b2World;
+	float32 MotorReaction(float32 inv_dt) const; // the motor's share (GetMotorTorque / GetMotorForce of the types that have one)
 	b2Joint(const b2JointDef* def) : m_type(def->type), m_prev(nullptr), m_next(nullptr), m_bodyA(def->bodyA),
 		m_bodyB(def->bodyB), m_collideConnected(def->collideConnected), m_userData(def->userData), m_id(-1) {}
 

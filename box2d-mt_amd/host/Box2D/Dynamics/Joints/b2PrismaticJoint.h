@@ -48,6 +48,7 @@ public:
 	float32 GetLowerLimit() const { return m_lowerTranslation; }
 	float32 GetUpperLimit() const { return m_upperTranslation; }
 	bool IsMotorEnabled() const { return m_enableMotor; }
+	float32 GetMotorForce(float32 inv_dt) const { return MotorReaction(inv_dt); }
 	float32 GetMotorSpeed() const { return m_motorSpeed; }
 	float32 GetMaxMotorForce() const { return m_maxMotorForce; }
 	// computed from the body states of the last step (reference: b2PrismaticJoint.cpp:512-542)

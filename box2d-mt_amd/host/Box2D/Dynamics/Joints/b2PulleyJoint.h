@@ -43,6 +43,9 @@ public:
 	float32 GetLengthA() const { return m_lengthA; }
 	float32 GetLengthB() const { return m_lengthB; }
 	float32 GetRatio() const { return m_ratio; }
+	/// distance of each body anchor from its ground anchor, from the current poses (b2PulleyJoint.cpp:310-324)
+	float32 GetCurrentLengthA() const;
+	float32 GetCurrentLengthB() const;
 
 protected:
 	friend class b2World;

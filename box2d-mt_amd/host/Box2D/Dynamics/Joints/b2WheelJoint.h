@@ -39,6 +39,7 @@ public:
 	const b2Vec2& GetLocalAnchorB() const { return m_localAnchorB; }
 	const b2Vec2& GetLocalAxisA() const { return m_localAxisA; }
 	bool IsMotorEnabled() const { return m_enableMotor; }
+	float32 GetMotorTorque(float32 inv_dt) const { return MotorReaction(inv_dt); }
 	float32 GetMotorSpeed() const { return m_motorSpeed; }
 	float32 GetMaxMotorTorque() const { return m_maxMotorTorque; }
 	float32 GetSpringFrequencyHz() const { return m_frequencyHz; }

@@ -17,6 +17,8 @@
 #include "Box2D/Dynamics/b2TimeStep.h"
 #include "Box2D/Dynamics/b2WorldCallbacks.h"
 #include "Box2D/MT/b2TaskExecutor.h"
+#include "Box2D/Collision/b2DynamicTree.h"
+#include "Box2D/Dynamics/b2ContactManager.h"
 
 #include <vector>
 
@@ -58,12 +60,19 @@ public:
 
 	void ClearForces();
 
-	/// Every fixture whose fat AABB overlaps `aabb` (b2World.cpp:1751-1757), in fixture creation order (the reference walks
-	/// its dynamic tree: same set, other order); the callback returns false to stop.
+	/// Every fixture (once per child proxy) whose fat AABB overlaps `aabb` (b2World.cpp:1751-1757); the callback returns false
+	/// to stop. Served by a host-side tree over the device's fat AABBs (refitted on demand, O(log n) per query): the same SET
+	/// as the reference's tree reports, in this tree's traversal order.
 	void QueryAABB(b2QueryCallback* callback, const b2AABB& aabb);
 	/// Ray cast with the reference's callback protocol (b2World.cpp:1785-1795, b2DynamicTree.h:203-287): return 0 to stop,
-	/// a fraction to clip the ray, 1 to go on unclipped; fixtures are visited in creation order.
+	/// a fraction to clip the ray, 1 to go on unclipped, -1 to ignore the fixture.
 	void RayCast(b2RayCastCallback* callback, const b2Vec2& point1, const b2Vec2& point2);
+	/// Statistics of that tree (b2World.h:199-206 of the reference): it holds the same fat AABBs as the reference's
+	/// broad-phase tree but is built by this repo's insertion order, so the figures are of the same kind, not the same values.
+	int32 GetTreeHeight() const;
+	int32 GetTreeBalance() const;
+	float32 GetTreeQuality() const;
+	const b2ContactManager& GetContactManager() const { return m_contactManager; }
 
 	b2Body* GetBodyList() { return m_bodyList; }
 	const b2Body* GetBodyList() const { return m_bodyList; }
@@ -107,6 +116,12 @@ private:
 	static int PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int fixtureB, const struct b2hip_manifold* oldManifold,
 		const struct b2hip_manifold* manifold, struct b2hip_contact_material* material);
 	const std::vector<b2AABB>& FatAABBs();
+	friend class b2BroadPhase;
+	void SyncShadowTree();             // the tree's leaves follow the device's fat AABBs (one read-back per step, on demand)
+	b2DynamicTree m_shadowTree;
+	std::vector<int32> m_shadowLeaf;   // device fixture id -> leaf (b2_nullNode: no proxy)
+	bool m_shadowValid;
+	b2ContactManager m_contactManager;
 
 	void PushFlags();
 	const b2hip_body_state& State(int32 id) const;

@@ -63,3 +63,8 @@ b2Vec2 b2Mat33::Solve22(const b2Vec2& b) const
 
 void b2Mat33::GetInverse22(b2Mat33* M) const { store(M, b2dM33Inverse22(columns(*this))); }
 void b2Mat33::GetSymInverse33(b2Mat33* M) const { store(M, b2dM33SymInverse33(columns(*this))); }
+
+// The reference's debugging switch for the 2-point block solver (b2ContactSolver.cpp:30; Testbed/Tests/VerticalStack.h flips
+// it from the keyboard). The symbol exists so that such scenes link; the device solver always runs the block solver
+// (the reference's default) and does not read it.
+bool g_blockSolve = true;

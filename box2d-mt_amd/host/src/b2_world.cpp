@@ -8,12 +8,13 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <stdint.h>
 
 // the 152-byte device record of a shape / of child `child` of a chain (host/src/b2_shapes.cpp)
 void b2ShapeToRecord(const b2Shape* shape, int32 child, void* record152);
 
 // ---- b2World ------------------------------------------------------------------------------------
-b2World::b2World(const b2Vec2& gravity)
+b2World::b2World(const b2Vec2& gravity) : m_shadowValid(false), m_contactManager(this)
 {
 	m_gravity = gravity;
 	m_allowSleep = true;
@@ -693,59 +694,119 @@ const std::vector<b2AABB>& b2World::FatAABBs()
 			}
 		}
 		m_fatValid = true;
+		m_shadowValid = false;
 	}
 	return m_fatAABBs;
 }
 
-void b2World::QueryAABB(b2QueryCallback* callback, const b2AABB& aabb)
+// The shadow tree: one leaf per live proxy (device fixture id of an active body), its box = the device's fat AABB. After a
+// step the boxes are read back once (FatAABBs) and only the leaves whose box changed are re-inserted - the proxies that left
+// their fat AABB, which is what the reference's tree re-inserts as well (b2DynamicTree::MoveProxy).
+void b2World::SyncShadowTree()
 {
 	const std::vector<b2AABB>& fat = FatAABBs();
-	for (size_t i = 0; i < fat.size(); ++i)
+	if (m_shadowValid) return;
+	const size_t n = fat.size();
+	if (m_shadowLeaf.size() < n) m_shadowLeaf.resize(n, b2_nullNode);
+	for (size_t i = 0; i < m_shadowLeaf.size(); ++i)
 	{
-		// (an inactive body has no proxies in the reference's tree)
-		if (m_fixtures[i] == nullptr || !m_fixtures[i]->GetBody()->IsActive() || !b2TestOverlap(fat[i], aabb)) continue;
-		if (!callback->ReportFixture(m_fixtures[i])) return;
+		const bool live = i < n && m_fixtures[i] != nullptr && m_fixtures[i]->GetBody()->IsActive();
+		int32& leaf = m_shadowLeaf[i];
+		if (!live)
+		{
+			if (leaf != b2_nullNode)
+			{
+				m_shadowTree.RemoveFat(leaf);
+				leaf = b2_nullNode;
+			}
+			continue;
+		}
+		if (leaf == b2_nullNode) leaf = m_shadowTree.InsertFat(fat[i], (void*)(intptr_t)i);
+		else if (memcmp(&m_shadowTree.GetFatAABB(leaf), &fat[i], sizeof(b2AABB)) != 0) m_shadowTree.ReplaceFat(leaf, fat[i]);
 	}
+	m_shadowValid = true;
+}
+
+namespace
+{
+// b2WorldQueryWrapper / b2WorldRayCastWrapper of the reference (b2World.cpp:1740-1795): leaf -> fixture (+ child)
+struct ShadowQuery
+{
+	bool QueryCallback(int32 leaf)
+	{
+		const size_t id = (size_t)(intptr_t)tree->GetUserData(leaf);
+		return callback->ReportFixture((*fixtures)[id]);
+	}
+	const b2DynamicTree* tree;
+	const std::vector<b2Fixture*>* fixtures;
+	b2QueryCallback* callback;
+};
+
+struct ShadowRayCast
+{
+	float32 RayCastCallback(const b2RayCastInput& input, int32 leaf)
+	{
+		const size_t id = (size_t)(intptr_t)tree->GetUserData(leaf);
+		b2Fixture* fixture = (*fixtures)[id];
+		b2RayCastOutput output;
+		if (!fixture->GetShape()->RayCast(&output, input, fixture->GetBody()->GetTransform(), (int32)id - fixture->GetDeviceId())) return input.maxFraction;
+		const float32 fraction = output.fraction;
+		const b2Vec2 point = (1.0f - fraction) * input.p1 + fraction * input.p2;
+		return callback->ReportFixture(fixture, point, output.normal, fraction);
+	}
+	const b2DynamicTree* tree;
+	const std::vector<b2Fixture*>* fixtures;
+	b2RayCastCallback* callback;
+};
+}
+
+void b2World::QueryAABB(b2QueryCallback* callback, const b2AABB& aabb)
+{
+	SyncShadowTree();
+	ShadowQuery q = { &m_shadowTree, &m_fixtures, callback };
+	m_shadowTree.Query(&q, aabb);
 }
 
 void b2World::RayCast(b2RayCastCallback* callback, const b2Vec2& point1, const b2Vec2& point2)
 {
-	const std::vector<b2AABB>& fat = FatAABBs();
-	b2Vec2 r = point2 - point1;
-	if (r.LengthSquared() <= 0.0f) return;
-	r.Normalize();
-	// v is perpendicular to the segment: |dot(v, p1 - c)| > dot(|v|, h) separates a box from it
-	const b2Vec2 v = b2Cross(1.0f, r);
-	const b2Vec2 abs_v = b2Abs(v);
-	float32 maxFraction = 1.0f;
-	b2AABB segment;
-	b2Vec2 t = point1 + maxFraction * (point2 - point1);
-	segment.lowerBound = b2Min(point1, t);
-	segment.upperBound = b2Max(point1, t);
-	for (size_t i = 0; i < fat.size(); ++i)
-	{
-		b2Fixture* fixture = m_fixtures[i];
-		if (fixture == nullptr || !fixture->GetBody()->IsActive() || !b2TestOverlap(fat[i], segment)) continue;
-		const b2Vec2 c = fat[i].GetCenter(), h = fat[i].GetExtents();
-		if (b2Abs(b2Dot(v, point1 - c)) - b2Dot(abs_v, h) > 0.0f) continue;
-		b2RayCastInput input;
-		input.p1 = point1;
-		input.p2 = point2;
-		input.maxFraction = maxFraction;
-		b2RayCastOutput output;
-		if (!fixture->GetShape()->RayCast(&output, input, fixture->GetBody()->GetTransform(), (int32)i - fixture->m_id)) continue;
-		const float32 fraction = output.fraction;
-		const b2Vec2 point = (1.0f - fraction) * point1 + fraction * point2;
-		const float32 value = callback->ReportFixture(fixture, point, output.normal, fraction);
-		if (value == 0.0f) return;
-		if (value > 0.0f)
-		{
-			maxFraction = value;
-			t = point1 + maxFraction * (point2 - point1);
-			segment.lowerBound = b2Min(point1, t);
-			segment.upperBound = b2Max(point1, t);
-		}
-	}
+	SyncShadowTree();
+	ShadowRayCast q = { &m_shadowTree, &m_fixtures, callback };
+	b2RayCastInput input;
+	input.p1 = point1;
+	input.p2 = point2;
+	input.maxFraction = 1.0f;
+	m_shadowTree.RayCast(&q, input);
+}
+
+int32 b2World::GetTreeHeight() const
+{
+	const_cast<b2World*>(this)->SyncShadowTree();
+	return m_shadowTree.GetHeight();
+}
+
+int32 b2World::GetTreeBalance() const
+{
+	const_cast<b2World*>(this)->SyncShadowTree();
+	return m_shadowTree.GetMaxBalance();
+}
+
+float32 b2World::GetTreeQuality() const
+{
+	const_cast<b2World*>(this)->SyncShadowTree();
+	return m_shadowTree.GetAreaRatio();
+}
+
+int32 b2BroadPhase::GetProxyCount() const { return m_world->GetProxyCount(); }
+int32 b2BroadPhase::GetTreeHeight() const { return m_world->GetTreeHeight(); }
+int32 b2BroadPhase::GetTreeBalance() const { return m_world->GetTreeBalance(); }
+float32 b2BroadPhase::GetTreeQuality() const { return m_world->GetTreeQuality(); }
+const b2AABB& b2BroadPhase::GetFatAABB(int32 proxyId) const
+{
+	const std::vector<b2AABB>& fat = m_world->FatAABBs();
+	b2AABB& out = m_scratch[m_turn ^= 1];
+	if (proxyId >= 0 && proxyId < (int32)fat.size()) out = fat[proxyId];
+	else { out.lowerBound.SetZero(); out.upperBound.SetZero(); }
+	return out;
 }
 
 void b2World::ClearForces()
@@ -755,7 +816,13 @@ void b2World::ClearForces()
 
 int32 b2World::GetProxyCount() const
 {
-	return m_hip ? b2hip_fixture_count(m_hip) : 0;
+	// proxies in the broad-phase = live fixtures (children counted) of active bodies (b2BroadPhase::GetProxyCount)
+	int32 count = 0;
+	for (size_t i = 0; i < m_fixtures.size(); ++i)
+	{
+		if (m_fixtures[i] != nullptr && m_fixtures[i]->GetBody()->IsActive()) ++count;
+	}
+	return count;
 }
 
 int32 b2World::GetContactCount() const
@@ -1233,6 +1300,32 @@ void b2WeldJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor)
 }
 
 // Joint setters between steps: the definition lives in the device record (b2hip_joint_set_motor / _set_limits).
+b2Vec2 b2Joint::GetReactionForce(float32 inv_dt) const
+{
+	float r[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	b2hip_get_joint_reaction(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, inv_dt, r);
+	return b2Vec2(r[0], r[1]);
+}
+
+float32 b2Joint::GetReactionTorque(float32 inv_dt) const
+{
+	float r[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	b2hip_get_joint_reaction(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, inv_dt, r);
+	return r[2];
+}
+
+float32 b2Joint::MotorReaction(float32 inv_dt) const
+{
+	float r[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	b2hip_get_joint_reaction(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, inv_dt, r);
+	return r[3];
+}
+
+bool b2Joint::IsActive() const { return m_bodyA->IsActive() && m_bodyB->IsActive(); }
+
+float32 b2PulleyJoint::GetCurrentLengthA() const { return (m_bodyA->GetWorldPoint(m_localAnchorA) - m_groundAnchorA).Length(); }
+float32 b2PulleyJoint::GetCurrentLengthB() const { return (m_bodyB->GetWorldPoint(m_localAnchorB) - m_groundAnchorB).Length(); }
+
 void b2RevoluteJoint::PushMotor()
 {
 	b2hip_joint_set_motor(m_bodyA->GetWorld()->GetDeviceWorld(), m_id, m_enableMotor, m_motorSpeed, m_maxMotorTorque);

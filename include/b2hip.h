@@ -72,7 +72,7 @@ typedef enum b2hip_status
 	B2HIP_ERR_INVALID = -1,     /* bad argument / unknown id */
 	B2HIP_ERR_HIP = -2,         /* a HIP runtime call failed */
 	B2HIP_ERR_NO_DEVICE = -3,   /* no usable gfx950 device */
-	B2HIP_ERR_UNSUPPORTED = -4, /* feature outside the device path (e.g. chain shapes) */
+	B2HIP_ERR_UNSUPPORTED = -4, /* feature outside the device path: a step asked of a world with sub-stepping on is refused */
 	B2HIP_ERR_CAPACITY = -5     /* a device buffer overflowed and could not be regrown */
 } b2hip_status;
 
@@ -90,7 +90,7 @@ typedef struct b2hip_world_def
 	int allow_sleep;      /* b2World::SetAllowSleeping      default 1 */
 	int warm_starting;    /* b2World::SetWarmStarting       default 1 */
 	int continuous;       /* b2World::SetContinuousPhysics  default 1 in the reference; continuous collision (TOI) runs on the device: b2hip_solve_toi */
-	int sub_stepping;     /* b2World::SetSubStepping        default 0 */
+	int sub_stepping;     /* b2World::SetSubStepping        default 0 ; not implemented: while it is on, b2hip_step* refuses to step (B2HIP_ERR_UNSUPPORTED) */
 	int auto_clear_forces;/* b2World::SetAutoClearForces    default 1 */
 	int device;           /* HIP device ordinal, -1 = current */
 } b2hip_world_def;
@@ -356,6 +356,11 @@ int b2hip_destroy_joint(b2hip_world* w, int joint);
  * (limits) restarts the limit impulse from zero; a call that changes nothing does nothing. */
 int b2hip_joint_set_motor(b2hip_world* w, int joint, int enable_motor, float motor_speed, float max_motor);
 int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lower, float upper);
+/* b2Joint::GetReactionForce / GetReactionTorque(inv_dt) and the motor's share (b2RevoluteJoint::GetMotorTorque,
+ * b2PrismaticJoint::GetMotorForce, b2WheelJoint::GetMotorTorque) after the last step, from the joint's accumulated impulses
+ * (b2Joint.h:129-133; per type: b2RevoluteJoint.cpp:439-456, b2PrismaticJoint.cpp:502-510,618-621, ...).
+ * out4 = force.x, force.y, torque, motor. One small device read per call (between steps). */
+int b2hip_get_joint_reaction(b2hip_world* w, int joint, float inv_dt, float out4[4]);
 
 /* ---- Life cycle and mutators between steps (all refused inside a step, like the reference's locked world) -------------------
  * Ids are never reused: a destroyed body / fixture keeps its id (every getter reports it as destroyed), so ids handed

@@ -101,6 +101,8 @@ void b2o_joint_set_target(b2o_world* w, int joint, float tx, float ty);
 void b2o_joint_set_offsets(b2o_world* w, int joint, float lx, float ly, float angular);
 void b2o_joint_set_motor(b2o_world* w, int joint, int enableMotor, float motorSpeed, float maxMotor);
 void b2o_joint_set_limits(b2o_world* w, int joint, int enableLimit, float lower, float upper);
+/* b2Joint::GetReactionForce / GetReactionTorque / motor share after the last step: out4 = force.x, force.y, torque, motor */
+void b2o_get_joint_reaction(const b2o_world* w, int joint, float inv_dt, float out4[4]);
 void b2o_apply_force(b2o_world* w, int body, float fx, float fy, float torque, int wake);
 void b2o_set_velocity(b2o_world* w, int body, float vx, float vy, float omega);
 void b2o_step(b2o_world* w, float dt, int velocity_iterations, int position_iterations);

@@ -13,6 +13,7 @@ struct b2hip_world
 {
 	b2o_world* o;
 	int fixtures;
+	int sub_stepping;
 };
 
 const char* b2hip_last_error(void) { return "cpu oracle shim"; }
@@ -37,7 +38,7 @@ int b2hip_set_gravity(b2hip_world* w, float gx, float gy) { b2o_set_gravity(w->o
 
 int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int continuous, int sub_stepping)
 {
-	(void)sub_stepping;
+	w->sub_stepping = sub_stepping; /* not restated either: a step is refused while it is on, like the product does */
 	b2o_set_flags(w->o, allow_sleep, warm_starting, continuous);
 	return 0;
 }
@@ -162,6 +163,12 @@ int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lo
 	return 0;
 }
 
+int b2hip_get_joint_reaction(b2hip_world* w, int joint, float inv_dt, float out4[4])
+{
+	b2o_get_joint_reaction(w->o, joint, inv_dt, out4);
+	return 0;
+}
+
 int b2hip_body_count(const b2hip_world* w) { return b2o_body_count(w->o); }
 int b2hip_fixture_count(const b2hip_world* w) { return w->fixtures; }
 
@@ -186,6 +193,7 @@ int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega
 
 int b2hip_step(b2hip_world* w, float dt, int vi, int pi)
 {
+	if (w->sub_stepping) return -4; /* B2HIP_ERR_UNSUPPORTED */
 	b2o_step(w->o, dt, vi, pi);
 	return 0;
 }
@@ -218,7 +226,7 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
 	return b2o_get_contact_events(w->o, cap, (b2o_contact_event*)out); /* identical layout */
 }
 
-int b2hip_step_begin(b2hip_world* w, float dt, int vi, int pi) { b2o_step_begin(w->o, dt, vi, pi); return 0; }
+int b2hip_step_begin(b2hip_world* w, float dt, int vi, int pi) { if (w->sub_stepping) return -4; b2o_step_begin(w->o, dt, vi, pi); return 0; }
 int b2hip_collide(b2hip_world* w) { b2o_phase_collide(w->o); return 0; }
 int b2hip_solve(b2hip_world* w) { b2o_phase_solve(w->o); return 0; }
 int b2hip_sync_fixtures(b2hip_world* w) { b2o_phase_sync_fixtures(w->o); return 0; }

@@ -1333,3 +1333,56 @@ int b2o_gear_position(const revolute_t* j, gear_bodies* b)
 	b->a[GD] -= j->giD * impulse * JwD;
 	return 1;
 }
+
+/* ---- what a joint did in the last step: b2Joint::GetReactionForce / GetReactionTorque and the motor's share
+ * (b2RevoluteJoint.cpp:439-456, b2DistanceJoint.cpp:236-247, b2PrismaticJoint.cpp:502-510,618-621, b2WeldJoint.cpp:316-325,
+ * b2WheelJoint.cpp:340-348,434-437, b2RopeJoint.cpp:207-217, b2FrictionJoint.cpp:222-230, b2MotorJoint.cpp:236-244,
+ * b2PulleyJoint.cpp:273-283, b2MouseJoint.cpp:210-218, b2GearJoint.cpp:381-391). out4 = force.x, force.y, torque, motor ---- */
+void b2o_joint_reaction(const revolute_t* j, float inv_dt, float out4[4])
+{
+	vec2 F = v_make(0.0f, 0.0f);
+	float T = 0.0f, M = 0.0f;
+	switch (j->type)
+	{
+	case B2O_JOINT_REVOLUTE:
+	case B2O_JOINT_WELD:
+		F = v_scale(inv_dt, v_make(j->impulse[0], j->impulse[1]));
+		T = inv_dt * j->impulse[2];
+		if (j->type == B2O_JOINT_REVOLUTE) M = inv_dt * j->motorImpulse;
+		break;
+	case B2O_JOINT_DISTANCE:
+	case B2O_JOINT_ROPE:
+		F = v_scale(inv_dt * j->impulse[0], j->u);
+		break;
+	case B2O_JOINT_PRISMATIC:
+		F = v_scale(inv_dt, v_add(v_scale(j->impulse[0], j->perp), v_scale(j->motorImpulse + j->impulse[2], j->axis)));
+		T = inv_dt * j->impulse[1];
+		M = inv_dt * j->motorImpulse;
+		break;
+	case B2O_JOINT_WHEEL:
+		/* m_ax in axis, m_ay in perp */
+		F = v_scale(inv_dt, v_add(v_scale(j->impulse[0], j->perp), v_scale(j->springImpulse, j->axis)));
+		T = inv_dt * j->motorImpulse;
+		M = inv_dt * j->motorImpulse;
+		break;
+	case B2O_JOINT_FRICTION:
+	case B2O_JOINT_MOTOR:
+		F = v_scale(inv_dt, v_make(j->impulse[0], j->impulse[1]));
+		T = inv_dt * j->impulse[2];
+		break;
+	case B2O_JOINT_PULLEY:
+		F = v_scale(inv_dt, v_scale(j->impulse[0], j->uB));
+		break;
+	case B2O_JOINT_MOUSE:
+		F = v_scale(inv_dt, v_make(j->impulse[0], j->impulse[1]));
+		T = inv_dt * 0.0f;
+		break;
+	case B2O_JOINT_GEAR:
+		F = v_scale(inv_dt, v_scale(j->impulse[0], j->JvAC));
+		T = inv_dt * (j->impulse[0] * j->JwA);
+		break;
+	default:
+		break;
+	}
+	out4[0] = F.x; out4[1] = F.y; out4[2] = T; out4[3] = M;
+}

@@ -114,4 +114,6 @@ void b2o_mouse_init(revolute_t* j, float massB, float mB, float iB, vec2 lcB, ve
 	int warmStarting, float dtRatio, float dt);
 void b2o_mouse_velocity(revolute_t* j, vec2* vB, float* wB, float dt);
 
+void b2o_joint_reaction(const revolute_t* j, float inv_dt, float out4[4]);
+
 #endif

@@ -722,6 +722,8 @@ void b2o_joint_set_limits(b2o_world* w, int joint, int enableLimit, float lower,
 	j->impulse[2] = 0.0f;
 }
 
+void b2o_get_joint_reaction(const b2o_world* w, int joint, float inv_dt, float out4[4]) { b2o_joint_reaction(&w->joints[joint], inv_dt, out4); }
+
 /* ---- contacts ------------------------------------------------------------------------------------ */
 static int body_active_for_contact(const body_t* b) { return (b->flags & BF_AWAKE) != 0 && b->type != 0; }
 

@@ -63,3 +63,26 @@ def test_product_does_not_link_the_oracle():
         assert "oracle" not in out
         syms = subprocess.check_output(["nm", "-D", path]).decode()
         assert "b2o_" not in syms
+
+
+@pytest.mark.gpu
+def test_sub_stepping_is_refused_not_ignored():
+    """b2World::SetSubStepping (b2World.h:183) is not implemented: a world with the flag on must refuse to step, loudly, and
+    step again once the flag is cleared (never step as if the flag were off)."""
+    import b2hip
+    w = b2hip.World(continuous=True)
+    g = w.create_body(b2hip.STATIC, (0.0, -1.0))
+    w.create_fixture(g, b2hip.box_shape(10.0, 1.0))
+    b = w.create_body(b2hip.DYNAMIC, (0.0, 3.0))
+    w.create_fixture(b, b2hip.box_shape(0.5, 0.5), density=1.0)
+    w.step()
+    before = w.body_states().copy()
+    w.set_flags(continuous=True, sub_stepping=True)
+    with pytest.raises(b2hip.B2HipError) as err:
+        w.step()
+    assert "sub-stepping" in str(err.value)
+    assert w.body_states().tobytes() == before.tobytes()  # the refused step changed nothing
+    w.set_flags(continuous=True, sub_stepping=False)
+    w.step()
+    assert w.body_states()["py"][b] < before["py"][b]
+    w.close()

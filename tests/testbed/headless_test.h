@@ -25,7 +25,8 @@ enum
 	GLFW_KEY_H = 72, GLFW_KEY_I = 73, GLFW_KEY_J = 74, GLFW_KEY_K = 75, GLFW_KEY_L = 76, GLFW_KEY_M = 77, GLFW_KEY_N = 78,
 	GLFW_KEY_O = 79, GLFW_KEY_P = 80, GLFW_KEY_Q = 81, GLFW_KEY_R = 82, GLFW_KEY_S = 83, GLFW_KEY_T = 84, GLFW_KEY_U = 85,
 	GLFW_KEY_V = 86, GLFW_KEY_W = 87, GLFW_KEY_X = 88, GLFW_KEY_Y = 89, GLFW_KEY_Z = 90, GLFW_KEY_COMMA = 44, GLFW_KEY_PERIOD = 46,
-	GLFW_KEY_1 = 49, GLFW_KEY_2 = 50, GLFW_KEY_3 = 51, GLFW_KEY_4 = 52, GLFW_KEY_5 = 53
+	GLFW_KEY_0 = 48, GLFW_KEY_1 = 49, GLFW_KEY_2 = 50, GLFW_KEY_3 = 51, GLFW_KEY_4 = 52, GLFW_KEY_5 = 53, GLFW_KEY_6 = 54, GLFW_KEY_7 = 55,
+	GLFW_KEY_8 = 56, GLFW_KEY_9 = 57, GLFW_KEY_SPACE = 32, GLFW_KEY_MINUS = 45, GLFW_KEY_EQUAL = 61, GLFW_KEY_LEFT_BRACKET = 91, GLFW_KEY_RIGHT_BRACKET = 93
 };
 
 inline float32 RandomFloat()
@@ -81,6 +82,21 @@ extern Camera g_camera;
 
 enum class TestResult { NONE = 0, PASS, FAIL };
 
+// what Test::PreSolveImmediate keeps of every manifold point of a step, per calling thread (Test.h:141-153, 263-264): scenes
+// read it after the step (CollisionProcessing.h: which bodies touched)
+const int32 k_maxContactPoints = 8192;
+struct ContactPoint
+{
+	b2Fixture* fixtureA;
+	b2Fixture* fixtureB;
+	b2Vec2 normal;
+	b2Vec2 position;
+	b2PointState state;
+	float32 normalImpulse;
+	float32 tangentImpulse;
+	float32 separation;
+};
+
 class Test : public b2ContactListener
 {
 public:
@@ -94,6 +110,7 @@ public:
 		m_mouseJoint = nullptr;
 		m_bomb = nullptr;
 		m_visible = false;
+		for (uint32 t = 0; t < b2_maxThreads; ++t) m_pointCount[t] = 0;
 		b2BodyDef bodyDef;
 		m_groundBody = m_world->CreateBody(&bodyDef);
 	}
@@ -103,6 +120,7 @@ public:
 	{
 		const float32 timeStep = settings->hz > 0.0f ? 1.0f / settings->hz : 0.0f;
 		m_timeStep = timeStep;
+		for (uint32 t = 0; t < b2_maxThreads; ++t) m_pointCount[t] = 0; // (Test::Step, Test.cpp:292-295)
 		m_world->SetAllowSleeping(settings->enableSleep);
 		m_world->SetWarmStarting(settings->enableWarmStarting);
 		m_world->SetContinuousPhysics(settings->enableContinuous);
@@ -120,7 +138,29 @@ public:
 
 	bool BeginContactImmediate(b2Contact*, uint32) override { return false; }
 	bool EndContactImmediate(b2Contact*, uint32) override { return false; }
-	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32) override { return false; }
+	// Test.cpp:73-110: every point of every updated manifold goes into m_points of the calling thread
+	bool PreSolveImmediate(b2Contact* contact, const b2Manifold* oldManifold, uint32 threadId) override
+	{
+		const b2Manifold* now = contact->GetManifold();
+		if (now->pointCount == 0) return false;
+		b2PointState before[b2_maxManifoldPoints], after[b2_maxManifoldPoints];
+		b2GetPointStates(before, after, oldManifold, now);
+		b2WorldManifold wm;
+		contact->GetWorldManifold(&wm);
+		for (int32 i = 0; i < now->pointCount && m_pointCount[threadId] < k_maxContactPoints; ++i)
+		{
+			ContactPoint& cp = m_points[threadId][m_pointCount[threadId]++];
+			cp.fixtureA = contact->GetFixtureA();
+			cp.fixtureB = contact->GetFixtureB();
+			cp.position = wm.points[i];
+			cp.normal = wm.normal;
+			cp.state = after[i];
+			cp.normalImpulse = now->points[i].normalImpulse;
+			cp.tangentImpulse = now->points[i].tangentImpulse;
+			cp.separation = wm.separations[i];
+		}
+		return false;
+	}
 	bool PostSolveImmediate(b2Contact*, const b2ContactImpulse*, uint32) override { return false; }
 	void BeginContact(b2Contact*) override {}
 	void EndContact(b2Contact*) override {}
@@ -142,6 +182,8 @@ protected:
 	int32 m_stepCount;
 	float32 m_timeStep;
 	b2ThreadPoolTaskExecutor m_threadPoolExec;
+	ContactPoint m_points[b2_maxThreads][k_maxContactPoints];
+	int32 m_pointCount[b2_maxThreads];
 };
 
 #endif

@@ -7,22 +7,133 @@
 DebugDraw g_debugDraw;
 Camera g_camera;
 
-#include "Testbed/Tests/SleepCollideTest.h"
-#include "Testbed/Tests/TunnelingTest.h"
+#include "Testbed/Tests/AddPair.h"
+#include "Testbed/Tests/ApplyForce.h"
+#include "Testbed/Tests/BasicSliderCrank.h"
+#include "Testbed/Tests/BodyTypes.h"
+#include "Testbed/Tests/Breakable.h"
+#include "Testbed/Tests/Bridge.h"
+#include "Testbed/Tests/BulletTest.h"
+#include "Testbed/Tests/Cantilever.h"
+#include "Testbed/Tests/Car.h"
+#include "Testbed/Tests/ContinuousTest.h"
+#include "Testbed/Tests/Chain.h"
+#include "Testbed/Tests/CharacterCollision.h"
+#include "Testbed/Tests/CollisionFiltering.h"
+#include "Testbed/Tests/CollisionProcessing.h"
+#include "Testbed/Tests/CompoundShapes.h"
+#include "Testbed/Tests/Confined.h"
+#include "Testbed/Tests/ConvexHull.h"
+#include "Testbed/Tests/ConveyorBelt.h"
+#include "Testbed/Tests/DistanceTest.h"
+#include "Testbed/Tests/Dominos.h"
+#include "Testbed/Tests/DumpShell.h"
 #include "Testbed/Tests/DuplicateProxyTest.h"
+#include "Testbed/Tests/DynamicTreeTest.h"
+#include "Testbed/Tests/EdgeShapes.h"
+#include "Testbed/Tests/EdgeTest.h"
+#include "Testbed/Tests/Gears.h"
+#include "Testbed/Tests/HeavyOnLight.h"
+#include "Testbed/Tests/HeavyOnLightTwo.h"
+#include "Testbed/Tests/Mobile.h"
+#include "Testbed/Tests/MobileBalanced.h"
+#include "Testbed/Tests/MotorJoint.h"
 #include "Testbed/Tests/ManyBodies.h"
 #include "Testbed/Tests/MultithreadDemo.h"
-#include "Testbed/Tests/Car.h"
+#include "Testbed/Tests/OneSidedPlatform.h"
+#include "Testbed/Tests/Pinball.h"
+#include "Testbed/Tests/PolyCollision.h"
+#include "Testbed/Tests/PolyShapes.h"
+#include "Testbed/Tests/Prismatic.h"
+#include "Testbed/Tests/Pulleys.h"
 #include "Testbed/Tests/Pyramid.h"
-#include "Testbed/Tests/Tumbler.h"
+#include "Testbed/Tests/RayCast.h"
+#include "Testbed/Tests/Revolute.h"
+#include "Testbed/Tests/RopeJoint.h"
+#include "Testbed/Tests/SensorTest.h"
+#include "Testbed/Tests/ShapeCast.h"
+#include "Testbed/Tests/ShapeEditing.h"
 #include "Testbed/Tests/SleepCollidePerf.h"
+#include "Testbed/Tests/SleepCollideTest.h"
+#include "Testbed/Tests/SliderCrank.h"
+#include "Testbed/Tests/SphereStack.h"
+#include "Testbed/Tests/TheoJansen.h"
+#include "Testbed/Tests/Tiles.h"
+#include "Testbed/Tests/TimeOfImpact.h"
+#include "Testbed/Tests/TunnelingTest.h"
+#include "Testbed/Tests/Tumbler.h"
+#include "Testbed/Tests/VaryingFriction.h"
+#include "Testbed/Tests/VaryingRestitution.h"
+#include "Testbed/Tests/VerticalStack.h"
+#include "Testbed/Tests/Web.h"
 
 struct Entry { const char* name; TestCreateFcn* create; };
+// every scene of the reference's Testbed (Testbed/Tests/TestEntries.cpp) but Rope (Box2D/Rope is out of the hot path's scope)
 static const Entry kEntries[] = {
-	{ "SleepCollideTest", SleepCollideTest::Create }, { "TunnelingTest", TunnelingTest::Create },
-	{ "QueryTest", QueryTest::Create }, { "ManyBodies6", ManyBodies6::Create }, { "ManyBodies1", ManyBodies1::Create },
-	{ "MultithreadDemo", MultithreadDemo::Create }, { "Car", Car::Create }, { "Pyramid", Pyramid::Create },
-	{ "Tumbler", Tumbler::Create }, { "SleepCollidePerf", SleepCollidePerf::Create },
+	{ "MultithreadDemo", MultithreadDemo::Create },
+	{ "ManyBodies1", ManyBodies1::Create },
+	{ "ManyBodies2", ManyBodies2::Create },
+	{ "ManyBodies3", ManyBodies3::Create },
+	{ "ManyBodies4", ManyBodies4::Create },
+	{ "ManyBodies5", ManyBodies5::Create },
+	{ "ManyBodies6", ManyBodies6::Create },
+	{ "SleepCollidePerf", SleepCollidePerf::Create },
+	{ "SleepCollideTest", SleepCollideTest::Create },
+	{ "TunnelingTest", TunnelingTest::Create },
+	{ "QueryTest", QueryTest::Create },
+	{ "ShapeCast", ShapeCast::Create },
+	{ "TimeOfImpact", TimeOfImpact::Create },
+	{ "CharacterCollision", CharacterCollision::Create },
+	{ "Tiles", Tiles::Create },
+	{ "HeavyOnLight", HeavyOnLight::Create },
+	{ "HeavyOnLightTwo", HeavyOnLightTwo::Create },
+	{ "VerticalStack", VerticalStack::Create },
+	{ "BasicSliderCrank", BasicSliderCrank::Create },
+	{ "SliderCrank", SliderCrank::Create },
+	{ "SphereStack", SphereStack::Create },
+	{ "ConvexHull", ConvexHull::Create },
+	{ "Tumbler", Tumbler::Create },
+	{ "RayCast", RayCast::Create },
+	{ "DumpShell", DumpShell::Create },
+	{ "ApplyForce", ApplyForce::Create },
+	{ "ContinuousTest", ContinuousTest::Create },
+	{ "MotorJoint", MotorJoint::Create },
+	{ "OneSidedPlatform", OneSidedPlatform::Create },
+	{ "Mobile", Mobile::Create },
+	{ "MobileBalanced", MobileBalanced::Create },
+	{ "ConveyorBelt", ConveyorBelt::Create },
+	{ "Gears", Gears::Create },
+	{ "VaryingRestitution", VaryingRestitution::Create },
+	{ "Cantilever", Cantilever::Create },
+	{ "EdgeTest", EdgeTest::Create },
+	{ "BodyTypes", BodyTypes::Create },
+	{ "ShapeEditing", ShapeEditing::Create },
+	{ "Car", Car::Create },
+	{ "Prismatic", Prismatic::Create },
+	{ "Revolute", Revolute::Create },
+	{ "Pulleys", Pulleys::Create },
+	{ "PolyShapes", PolyShapes::Create },
+	{ "Web", Web::Create },
+	{ "RopeJoint", RopeJoint::Create },
+	{ "Pinball", Pinball::Create },
+	{ "BulletTest", BulletTest::Create },
+	{ "Confined", Confined::Create },
+	{ "Pyramid", Pyramid::Create },
+	{ "TheoJansen", TheoJansen::Create },
+	{ "EdgeShapes", EdgeShapes::Create },
+	{ "PolyCollision", PolyCollision::Create },
+	{ "Bridge", Bridge::Create },
+	{ "Breakable", Breakable::Create },
+	{ "Chain", Chain::Create },
+	{ "CollisionFiltering", CollisionFiltering::Create },
+	{ "CollisionProcessing", CollisionProcessing::Create },
+	{ "CompoundShapes", CompoundShapes::Create },
+	{ "DistanceTest", DistanceTest::Create },
+	{ "Dominos", Dominos::Create },
+	{ "DynamicTreeTest", DynamicTreeTest::Create },
+	{ "SensorTest", SensorTest::Create },
+	{ "VaryingFriction", VaryingFriction::Create },
+	{ "AddPair", AddPair::Create },
 };
 
 extern "C"
