@@ -19,8 +19,8 @@
 #include "b2d_kernels_broadphase.h"
 #include "b2d_toi.h"
 
-#define TOI_LANES 256
-#define TOI_CAND_MAX 256     // candidate contacts of the two seed bodies in one event (one lane each)
+#define TOI_LANES 512
+#define TOI_CAND_MAX 512     // candidate contacts of the two seed bodies in one event (one lane each)
 #define TOI_MOVES_MAX 128
 #define TOI_PAIRS_MAX 512
 #define TOI_RECOMP_MAX 512
