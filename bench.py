@@ -244,7 +244,8 @@ def main():
 
     # N > 1 (config-4 layout): ONE world of `world_size` disjoint pyramids on one ground, held whole by every rank and
     # sharded by island owner (include/b2hip.h, b2d_kernels_shard.h): rank r solves pyramid r, collide / broad-phase / TOI run
-    # replicated, one RCCL all-reduce(MAX) per step carries the solved islands to every rank (sharding.ShardedWorld).
+    # replicated, one RCCL all-gather of owner-sized slabs per step - issued by the library on the world's own stream
+    # (b2hip_shard_connect) - carries the solved islands to every rank (sharding.ShardedWorld).
     # (hipSetDevice above selects this rank's GPU for the world's stream)
     flags = bh.F_SLEEP | bh.F_WARM | (0 if args.no_ccd else bh.F_CONTINUOUS)
     w = amd.world(bh.PYRAMID, args.rows, world_size, flags=flags)
@@ -259,6 +260,8 @@ def main():
         raw.p = C.c_void_p(w.device_world())
         raw.L = hipL
         sharded = sharding.ShardedWorld(raw, dist=dist, device=torch.device("cuda", local_rank))
+        if dist.get_backend() == "nccl":
+            sharded.connect_rccl()
         step_world = lambda n=1: [sharded.step(1.0 / 60.0, w.vel_iters, w.pos_iters) for _ in range(n)]
     else:
         step_world = lambda n=1: w.step(n)
@@ -410,6 +413,8 @@ def main():
                 raw4.p = C.c_void_p(w4.device_world())
                 raw4.L = hipL
                 s4 = sharding.ShardedWorld(raw4, dist=dist, device=torch.device("cuda", local_rank))
+                if dist.get_backend() == "nccl":
+                    s4.connect_rccl()
                 for _ in range(60):
                     s4.step(1.0 / 60.0, w4.vel_iters, w4.pos_iters)
                 barrier()
@@ -477,7 +482,7 @@ def main():
                        "settle_steps": SETTLE_STEPS,
                        "timed_window": "steps %d..%d of the scene" % (SETTLE_STEPS + args.warmup, SETTLE_STEPS + args.warmup + args.steps - 1),
                        "parity_class": PARITY_CLASS,
-                       "bodies_total": nbodies, "parallelism": "one world on every rank, islands sharded by owner, one RCCL all-reduce per step" if world_size > 1 else "single GPU"},
+                       "bodies_total": nbodies, "parallelism": "one world on every rank, islands sharded by owner, one RCCL all-gather of owner-sized slabs per step" if world_size > 1 else "single GPU"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
         # the free-fall / first-impact transient the settle steps went through (rank 0), never part of `value`
@@ -488,7 +493,7 @@ def main():
             line["extra_configs"] = extras
         if sharded is not None:
             line["exchange_bytes_per_step"] = exchange_bytes
-            line["exchange"] = "one all-reduce(MAX) per step over int32 records of the solved islands (RCCL), inside the timed region"
+            line["exchange"] = "one all-gather per step of owner-sized slabs (records of the islands each rank solved), RCCL on the world's stream from inside the library, inside the timed region"
         if roof is not None:
             line["roofline"] = roof
         if exact_order is not None:

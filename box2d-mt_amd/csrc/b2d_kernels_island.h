@@ -216,6 +216,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.partitionAge += 1;
 		if (S->c.partitionCooldown > 0) S->c.partitionCooldown -= 1;
 		S->c.nBigIslands = 0;
+		for (int r = 0; r < SHARD_MAX_RANKS; ++r) S->c.shardBodies[r] = S->c.shardContacts[r] = S->c.shardJoints[r] = 0;
+		S->c.shardCursor[0] = S->c.shardCursor[1] = S->c.shardCursor[2] = 0;
 		S->c.nRemoteIslands = 0;
 		S->c.nSmallJointed = 0;
 		S->c.nFreeIslands = 0;
@@ -412,7 +414,15 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 						const int k = atomicAdd(&S->c.nBigIslands, 1);
 						if (k < SHARD_BIG_MAX) W.bigRoots[k] = i; else big = false;
 					}
-					if (!big) mine = shardHashOwner(i, W.shardCount) == W.shardRank;
+					if (!big)
+					{
+						const int owner = shardHashOwner(i, W.shardCount);
+						mine = owner == W.shardRank;
+						// (every rank keeps every rank's census: the slabs of the exchange are sized from it)
+						atomicAdd(&S->c.shardBodies[owner], nb);
+						if (nc) atomicAdd(&S->c.shardContacts[owner], nc);
+						if (nj) atomicAdd(&S->c.shardJoints[owner], nj);
+					}
 				}
 				if (W.rootIsland[i] == ROOT_FREE)
 				{

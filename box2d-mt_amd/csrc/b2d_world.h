@@ -66,10 +66,10 @@
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
 #define SHARD_BIG_BODIES 4096    // islands above this size are dealt over the ranks one by one (in root-id order), smaller ones by a hash of their root
 #define SHARD_BIG_MAX 1024       // ... at most this many per step (more: they fall back to the hash)
-#define SHARD_BODY_WORDS 13      // exchange record of a body: c.xy, a, sleepTime, v.xy, w, awake, xf.p.xy, xf.q.sc, owner + 1
-#define SHARD_CONTACT_WORDS 5    // ... of a contact: the four warm-start impulses, owner + 1
-#define SHARD_JOINT_WORDS 6      // ... of a joint: impulse x, y (wheel: spring impulse), z, motor impulse, limit state, owner + 1
-#define SHARD_NOBODY ((int)0x80000000) // every word of a record this rank does not own (the exchange is a MAX over int32)
+#define SHARD_MAX_RANKS 8        // GPUs of one node
+#define SHARD_BODY_WORDS 13      // exchange record of a body: its id, c.xy, a, sleepTime, v.xy, w, awake, xf.p.xy, xf.q.sc
+#define SHARD_CONTACT_WORDS 5    // ... of a contact: its index, the four warm-start impulses
+#define SHARD_JOINT_WORDS 6      // ... of a joint: its id, impulse x, y (wheel: spring impulse), z, motor impulse, limit state
 // Block partition of the large islands (b2d_kernels_solve_blocks.h): every body of a large island has a home block, one
 // workgroup solves one block with its bodies in LDS. A constraint between bodies of two blocks is a CUT constraint: it owns
 // a colour of the upper range, so that on every body the cut constraints come last in a sweep.
@@ -158,6 +158,10 @@ struct Counters
 	int nPostSolve;      // PostSolve records of this step's Solve (DW::postRecs)
 	int nFilterList;     // contacts flagged for re-filtering, listed for the user's contact filter (DW::filterList)
 	int nBigIslands;     // islands with more than SHARD_BIG_BODIES bodies this step (sharded worlds only)
+	// sharded worlds: what every rank's slab of the exchange holds this step - bodies, solid contacts, joints of the islands it
+	// owns. Every rank counts ALL ranks' (the island build is replicated), so the hosts size the all-gather without talking.
+	int shardBodies[SHARD_MAX_RANKS], shardContacts[SHARD_MAX_RANKS], shardJoints[SHARD_MAX_RANKS];
+	int shardCursor[3];  // append cursors of k_shard_export
 	int nRemoteIslands;  // islands of this step that another rank solves
 	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
 	int compactBlocksDone; // workgroups of k_compact_contacts that have finished (the last one switches the contact buffers)

@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // (types only: the library is opened with dlopen by b2hip_shard_connect)
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -60,6 +62,9 @@ static int setError(int code, const std::string& msg)
 	} while (0)
 
 // Device array that keeps its content when it grows.
+// (set when librccl is opened, b2hip_shard_connect: releases a world's communicator)
+static void (*g_rcclDestroy)(void* comm) = nullptr;
+
 template <typename T>
 struct DevArray
 {
@@ -227,6 +232,10 @@ struct b2hip_world
 	DevArray<int> pairFirst, pairRank;
 	DevArray<int> scanTmp, radixHist, radixHistScan, keepFlag, keepScan;
 	DevArray<int4> scanTmp4;
+	void* shardComm = nullptr;   // ncclComm_t of a connected sharded world (b2hip_shard_connect)
+	DevArray<int> shardSend, shardRecv; // this rank's slab / all ranks' slabs
+	size_t shardExchangeBytes = 0;
+	bool shardLoopback = false;  // B2HIP_SHARD_LOOPBACK=1: a communicator of ONE rank still runs export -> ncclAllGather -> import (self-test on a one-GPU box)
 	DevArray<int> scanFlags;     // status words of the single-pass scans (b2d_scan.h)
 	ScanFlags scanCtx;           // ... with their epoch and the abort word (refreshed by ensureCapacity)
 	DevArray<float> stateOut;
@@ -2367,6 +2376,9 @@ void b2hip_world_destroy(b2hip_world* w)
 	if (!w) return;
 	DEVICE_GUARD(w);
 	if (w->stream) (void)hipStreamSynchronize(w->stream);
+	if (w->shardComm != nullptr && g_rcclDestroy != nullptr) g_rcclDestroy(w->shardComm);
+	w->shardComm = nullptr;
+	w->shardSend.release(); w->shardRecv.release();
 	w->d_state.release();
 	w->b_pos.release(); w->b_pos0.release(); w->b_vel.release(); w->b_xf.release(); w->b_mass.release(); w->b_damp.release();
 	w->b_force.release(); w->b_flags.release(); w->b_wake.release();
@@ -3568,12 +3580,20 @@ int b2hip_collide(b2hip_world* w)
 	return stepFailed(w, collideImpl(w));
 }
 
+static int shardExchangeOnStream(b2hip_world* w);
+
 static int solveImpl(b2hip_world* w)
 {
 	if (w->sp.dt > 0.0f)
 	{
 		int rc = phaseSolve(w);
 		if (rc) return rc;
+		// a connected sharded world (b2hip_shard_connect): the islands the other ranks solved arrive here, on the stream
+		if (w->shardComm != nullptr && (w->dw.shardCount > 1 || w->shardLoopback))
+		{
+			rc = shardExchangeOnStream(w);
+			if (rc) return rc;
+		}
 	}
 	else
 	{
@@ -4390,15 +4410,21 @@ int b2hip_set_shard(b2hip_world* w, int rank, int count)
 	return B2HIP_OK;
 }
 
-int b2hip_shard_exchange_words(b2hip_world* w, size_t* words)
+// ---- the exchange of a sharded world (b2d_kernels_shard.h) -------------------------------------------------------------------
+// words of rank r's slab this step, from the island census every rank keeps of every rank (read with the census the solver
+// waited for anyway: no extra read-back)
+static size_t shardSlabWords(const b2hip_world* w, int r)
 {
-	if (!w || !words) return setError(B2HIP_ERR_INVALID, "null argument");
-	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shard_exchange_words outside a step");
-	DEVICE_GUARD(w);
-	int rc = readState(w);
-	if (rc) return rc;
-	*words = (size_t)w->dw.nBodies * SHARD_BODY_WORDS + (size_t)std::max(w->h_dstate->c.nContacts, 0) * SHARD_CONTACT_WORDS +
-		(size_t)w->dw.nJoints * SHARD_JOINT_WORDS;
+	const Counters& c = w->h_dstate->c;
+	return (size_t)c.shardBodies[r] * SHARD_BODY_WORDS + (size_t)c.shardContacts[r] * SHARD_CONTACT_WORDS + (size_t)c.shardJoints[r] * SHARD_JOINT_WORDS;
+}
+
+int b2hip_shard_slab_words(b2hip_world* w, size_t* words_per_rank, int ranks)
+{
+	if (!w || !words_per_rank) return setError(B2HIP_ERR_INVALID, "null argument");
+	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shard_slab_words outside a step");
+	if (ranks != w->dw.shardCount) return setError(B2HIP_ERR_INVALID, "rank count differs from b2hip_set_shard");
+	for (int r = 0; r < ranks; ++r) words_per_rank[r] = shardSlabWords(w, r);
 	return B2HIP_OK;
 }
 
@@ -4407,23 +4433,109 @@ int b2hip_shard_export(b2hip_world* w, void* device_buffer, size_t words)
 	if (!w || !device_buffer) return setError(B2HIP_ERR_INVALID, "null argument");
 	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shard_export outside a step");
 	DEVICE_GUARD(w);
-	size_t need = 0;
-	if (int rc = b2hip_shard_exchange_words(w, &need)) return rc;
-	if (words < need) return setError(B2HIP_ERR_CAPACITY, "exchange buffer too small");
+	if (words < shardSlabWords(w, w->dw.shardRank)) return setError(B2HIP_ERR_CAPACITY, "slab buffer too small");
 	LAUNCH(w, k_shard_export, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, (int*)device_buffer);
-	HIP_TRY(hipStreamSynchronize(w->stream)); // the caller's collective runs on its own stream
+	HIP_TRY(hipStreamSynchronize(w->stream)); // (the CALLER's collective runs on a stream of its own; b2hip_shard_connect avoids this)
 	return B2HIP_OK;
 }
 
-int b2hip_shard_import(b2hip_world* w, const void* device_buffer, size_t words)
+int b2hip_shard_import(b2hip_world* w, const void* device_buffer, size_t stride_words)
 {
 	if (!w || !device_buffer) return setError(B2HIP_ERR_INVALID, "null argument");
 	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shard_import outside a step");
 	DEVICE_GUARD(w);
-	size_t need = 0;
-	if (int rc = b2hip_shard_exchange_words(w, &need)) return rc;
-	if (words < need) return setError(B2HIP_ERR_CAPACITY, "exchange buffer too small");
-	LAUNCH(w, k_shard_import, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, (const int*)device_buffer);
+	for (int r = 0; r < w->dw.shardCount; ++r)
+		if (stride_words < shardSlabWords(w, r)) return setError(B2HIP_ERR_CAPACITY, "slab stride too small");
+	LAUNCH(w, k_shard_import, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, (const int*)device_buffer, stride_words);
+	return B2HIP_OK;
+}
+
+// ---- RCCL from inside the library: the all-gather of the slabs on the world's own stream --------------------------------------
+// librccl is opened when a world is connected (not a link-time dependency: a single-GPU user never loads it).
+namespace
+{
+struct RcclApi
+{
+	void* lib = nullptr;
+	ncclResult_t (*getUniqueId)(ncclUniqueId*) = nullptr;
+	ncclResult_t (*commInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*allGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	const char* (*errorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rcclLoad()
+{
+	if (g_rccl.lib) return 0;
+	void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+	if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	if (!lib) return setError(B2HIP_ERR_UNSUPPORTED, std::string("librccl could not be opened: ") + dlerror());
+	g_rccl.getUniqueId = (decltype(g_rccl.getUniqueId))dlsym(lib, "ncclGetUniqueId");
+	g_rccl.commInitRank = (decltype(g_rccl.commInitRank))dlsym(lib, "ncclCommInitRank");
+	g_rccl.commDestroy = (decltype(g_rccl.commDestroy))dlsym(lib, "ncclCommDestroy");
+	g_rccl.allGather = (decltype(g_rccl.allGather))dlsym(lib, "ncclAllGather");
+	g_rccl.errorString = (decltype(g_rccl.errorString))dlsym(lib, "ncclGetErrorString");
+	if (!g_rccl.getUniqueId || !g_rccl.commInitRank || !g_rccl.commDestroy || !g_rccl.allGather || !g_rccl.errorString)
+		return setError(B2HIP_ERR_UNSUPPORTED, "librccl lacks a collective entry point");
+	g_rccl.lib = lib;
+	g_rcclDestroy = [](void* comm) { (void)g_rccl.commDestroy((ncclComm_t)comm); };
+	return 0;
+}
+#define RCCL_TRY(call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) return setError(B2HIP_ERR_HIP, std::string(#call) + ": " + g_rccl.errorString(_r)); } while (0)
+}
+
+int b2hip_shard_unique_id(void* id128)
+{
+	if (!id128) return setError(B2HIP_ERR_INVALID, "null argument");
+	static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+	if (int rc = rcclLoad()) return rc;
+	ncclUniqueId id;
+	RCCL_TRY(g_rccl.getUniqueId(&id));
+	memcpy(id128, &id, sizeof(id));
+	return B2HIP_OK;
+}
+
+int b2hip_shard_connect(b2hip_world* w, const void* id128, int rank, int count)
+{
+	if (int rcu = checkUsable(w, "b2hip_shard_connect", true)) return rcu;
+	if (!id128 || count < 1 || count > SHARD_MAX_RANKS || rank < 0 || rank >= count) return setError(B2HIP_ERR_INVALID, "bad rank / count (at most 8 ranks)");
+	if (w->shardComm) return setError(B2HIP_ERR_INVALID, "the world is connected already");
+	if (int rc = rcclLoad()) return rc;
+	DEVICE_GUARD(w);
+	ncclUniqueId id;
+	memcpy(&id, id128, sizeof(id));
+	ncclComm_t comm = nullptr;
+	RCCL_TRY(g_rccl.commInitRank(&comm, count, id, rank));
+	w->shardComm = comm;
+	w->shardLoopback = getenv("B2HIP_SHARD_LOOPBACK") != nullptr && atoi(getenv("B2HIP_SHARD_LOOPBACK")) != 0;
+	w->dw.shardRank = rank;
+	w->dw.shardCount = count;
+	return B2HIP_OK;
+}
+
+// export -> ncclAllGather -> import, all queued on the world's stream: no event, no host synchronisation
+static int shardExchangeOnStream(b2hip_world* w)
+{
+	const int ranks = w->dw.shardCount;
+	size_t stride = 1;
+	for (int r = 0; r < ranks; ++r) stride = std::max(stride, shardSlabWords(w, r));
+	// (buffers grow by doubling; a grown buffer is new memory, the old one is freed behind a stream synchronisation by ensure)
+	int rc = w->shardSend.ensure(stride, w->stream, false, false);
+	if (rc) return rc;
+	rc = w->shardRecv.ensure(stride * (size_t)ranks, w->stream, false, false);
+	if (rc) return rc;
+	LAUNCH(w, k_shard_export, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, w->shardSend.p);
+	RCCL_TRY(g_rccl.allGather(w->shardSend.p, w->shardRecv.p, stride, ncclInt32, (ncclComm_t)w->shardComm, w->stream));
+	LAUNCH(w, k_shard_import, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, (const int*)w->shardRecv.p, stride);
+	w->shardExchangeBytes = 4 * stride * (size_t)ranks;
+	return 0;
+}
+
+int b2hip_shard_exchange_bytes(b2hip_world* w, size_t* bytes)
+{
+	if (!w || !bytes) return setError(B2HIP_ERR_INVALID, "null argument");
+	*bytes = w->shardExchangeBytes;
 	return B2HIP_OK;
 }
 

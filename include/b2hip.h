@@ -512,19 +512,31 @@ int b2hip_enable_post_solve(b2hip_world* w, int enable);
 int b2hip_get_post_solve(b2hip_world* w, int cap, b2hip_contact_impulse* out);
 
 /* ---- One world over the GPUs of a node, sharded by island ----------------------------------------------
- * Every rank builds the SAME world (same calls, same ids) and steps it with the phase entry points; b2hip_solve solves only
- * the islands this rank owns (ownership is a pure function of the shared state: big islands are dealt round robin in the
- * order of their root ids, the others by a hash of their root), everything else runs replicated and deterministic, so the
- * ranks stay bit-identical. Between b2hip_solve and b2hip_sync_fixtures the ranks exchange what they solved:
- *     b2hip_shard_exchange_words -> buffer of that many int32 (memory the library can address: DEVICE memory for libb2hip)
- *     b2hip_shard_export(buffer)  -> the records of the islands this rank owns, INT32_MIN everywhere else
- *     all-reduce MAX over the ranks on the int32 buffer (RCCL over xGMI: torch.distributed backend "nccl"; gloo on CPUs)
- *     b2hip_shard_import(buffer)  -> the other ranks' results enter the world
- * box2d-mt_amd/python/sharding.py (ShardedWorld.step) is that sequence. With one rank (the default) nothing changes. */
+ * Every rank builds the SAME world with the same calls and steps it; Collide, the island build, the broad-phase and the TOI
+ * phase run replicated, b2Island::Solve runs for the islands a rank owns (b2World.cpp:1236-1241: islands share only static
+ * bodies), and after the solve the ranks all-gather the records of what they own (a "slab" per rank: 52 B per body, 20 B per
+ * contact, 24 B per joint of ITS islands; every record carries its id).
+ *
+ * (1) Inside the library, RCCL over xGMI on the world's own stream - no host synchronisation, nothing to call per step:
+ *       rank 0: b2hip_shard_unique_id(id)  ->  hand the 128 bytes to every rank (any means: a file, MPI, torch.distributed)
+ *       every rank: b2hip_shard_connect(world, id, rank, count)   (one GPU per rank, at most 8 ranks; librccl is opened here)
+ *       ... b2hip_step as usual (the drop-in b2World::Step needs no change).
+ * (2) With a collective of the caller's (the CPU tests use gloo through torch.distributed), per step, inside
+ *     b2hip_step_begin .. b2hip_step_end, between b2hip_solve and b2hip_sync_fixtures:
+ *       b2hip_set_shard(world, rank, count) once;
+ *       b2hip_shard_slab_words(world, words[count], count): the slab sizes of ALL ranks (every rank knows them: the island
+ *         build is replicated) -> stride = max; b2hip_shard_export(slab, stride): this rank's slab (memory the library can
+ *         address: DEVICE memory for libb2hip); all-gather of `stride` int32 per rank;
+ *         b2hip_shard_import(all_slabs, stride): the other ranks' results enter the world.
+ * box2d-mt_amd/python/sharding.py (ShardedWorld) drives either. With one rank (the default) nothing changes. */
 int b2hip_set_shard(b2hip_world* w, int rank, int count);
-int b2hip_shard_exchange_words(b2hip_world* w, size_t* words);
-int b2hip_shard_export(b2hip_world* w, void* buffer, size_t words);
-int b2hip_shard_import(b2hip_world* w, const void* buffer, size_t words);
+int b2hip_shard_slab_words(b2hip_world* w, size_t* words_per_rank, int ranks);
+int b2hip_shard_export(b2hip_world* w, void* slab, size_t words);
+int b2hip_shard_import(b2hip_world* w, const void* all_slabs, size_t stride_words);
+int b2hip_shard_unique_id(void* id128);
+int b2hip_shard_connect(b2hip_world* w, const void* id128, int rank, int count);
+/* bytes the last step's all-gather moved into this rank (count x stride x 4) */
+int b2hip_shard_exchange_bytes(b2hip_world* w, size_t* bytes);
 
 /* Island label per body for the last step: -1 = not solved (asleep / static), else the smallest body id
  * of the island (island membership is compared as a set partition). */

@@ -130,9 +130,9 @@ void b2o_phase_find_new_contacts(b2o_world* w);
 void b2o_phase_solve_toi(b2o_world* w);
 void b2o_step_end(b2o_world* w);
 void b2o_set_shard(b2o_world* w, int rank, int count);
-size_t b2o_shard_exchange_words(const b2o_world* w);
-void b2o_shard_export(const b2o_world* w, int32_t* out);
-void b2o_shard_import(b2o_world* w, const int32_t* in);
+size_t b2o_shard_slab_words(const b2o_world* w, int rank); /* of ANY rank: every rank counts all during its island build */
+void b2o_shard_export(const b2o_world* w, int32_t* slab);
+void b2o_shard_import(b2o_world* w, const int32_t* all_slabs, size_t stride_words);
 
 /* life cycle and mutators between steps (semantics and reference lines: include/b2hip.h) */
 void b2o_destroy_body(b2o_world* w, int body);

@@ -234,9 +234,13 @@ int b2hip_find_new_contacts(b2hip_world* w) { b2o_phase_find_new_contacts(w->o);
 int b2hip_solve_toi(b2hip_world* w) { b2o_phase_solve_toi(w->o); return 0; }
 int b2hip_step_end(b2hip_world* w) { b2o_step_end(w->o); return 0; }
 int b2hip_set_shard(b2hip_world* w, int rank, int count) { b2o_set_shard(w->o, rank, count); return 0; }
-int b2hip_shard_exchange_words(b2hip_world* w, size_t* words) { *words = b2o_shard_exchange_words(w->o); return 0; }
-int b2hip_shard_export(b2hip_world* w, void* buffer, size_t words) { (void)words; b2o_shard_export(w->o, (int32_t*)buffer); return 0; }
-int b2hip_shard_import(b2hip_world* w, const void* buffer, size_t words) { (void)words; b2o_shard_import(w->o, (const int32_t*)buffer); return 0; }
+int b2hip_shard_slab_words(b2hip_world* w, size_t* words_per_rank, int ranks)
+{
+	for (int r = 0; r < ranks; ++r) words_per_rank[r] = b2o_shard_slab_words(w->o, r);
+	return 0;
+}
+int b2hip_shard_export(b2hip_world* w, void* slab, size_t words) { (void)words; b2o_shard_export(w->o, (int32_t*)slab); return 0; }
+int b2hip_shard_import(b2hip_world* w, const void* all_slabs, size_t stride_words) { b2o_shard_import(w->o, (const int32_t*)all_slabs, stride_words); return 0; }
 
 int b2hip_destroy_body(b2hip_world* w, int body) { b2o_destroy_body(w->o, body); return 0; }
 int b2hip_destroy_fixture(b2hip_world* w, int fixture) { b2o_destroy_fixture(w->o, fixture); return 0; }

@@ -133,6 +133,7 @@ struct b2o_world
 	uint64_t* eventKeys; int capEventKeys;
 	/* island sharding (same ownership rule and exchange format as box2d-mt_amd/csrc/b2d_kernels_shard.h) */
 	int shardRank, shardCount;
+	int shardBodies[8], shardContacts[8], shardJoints[8]; /* what every rank's slab of the exchange holds this step (every rank counts all) */
 	unsigned char* bodyOwned; int capBodyOwned;       /* per body: its island was solved HERE this step */
 	unsigned char* contactOwned; int capContactOwned; /* per contact slot */
 	unsigned char* jointOwned; int capJointOwned;
@@ -1967,6 +1968,9 @@ static void solve_islands(b2o_world* w, float h, float dtRatio, int velIters, in
 	memset(w->bodyOwned, 0, (size_t)w->nBodies + 1);
 	memset(w->contactOwned, 0, (size_t)w->nContactSlots + 1);
 	memset(w->jointOwned, 0, (size_t)w->nJoints + 1);
+	memset(w->shardBodies, 0, sizeof(w->shardBodies));
+	memset(w->shardContacts, 0, sizeof(w->shardContacts));
+	memset(w->shardJoints, 0, sizeof(w->shardJoints));
 	int* islandBodies = (int*)malloc(sizeof(int) * (size_t)(nb + w->liveContacts + 2));
 	int* islandContacts = (int*)malloc(sizeof(int) * (size_t)(w->liveContacts + 1));
 	int* stack = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
@@ -2058,7 +2062,13 @@ static void solve_islands(b2o_world* w, float h, float dtRatio, int velIters, in
 				memcpy(p->joints, islandJoints, sizeof(int) * (size_t)jointCount);
 				continue;
 			}
-			if (shard_hash_owner(root, w->shardCount) != w->shardRank) continue; /* another rank's: its bodies stay flagged */
+			{
+				const int owner = shard_hash_owner(root, w->shardCount);
+				w->shardBodies[owner] += nonStatic;
+				w->shardContacts[owner] += contactCount;
+				w->shardJoints[owner] += jointCount;
+				if (owner != w->shardRank) continue; /* another rank's: its bodies stay flagged */
+			}
 		}
 		mark_owned(w, islandBodies, bodyCount, islandContacts, contactCount, islandJoints, jointCount);
 		solve_island(w, islandBodies, bodyCount, islandContacts, contactCount, islandJoints, jointCount, h, dtRatio, velIters, posIters);
@@ -2069,6 +2079,13 @@ static void solve_islands(b2o_world* w, float h, float dtRatio, int velIters, in
 		for (int k = 0; k < nPending; ++k)
 		{
 			pending_island* p = &pending[k];
+			{
+				int nonStatic = 0;
+				for (int j = 0; j < p->nb; ++j) nonStatic += w->bodies[p->bodies[j]].type != 0;
+				w->shardBodies[k % w->shardCount] += nonStatic;
+				w->shardContacts[k % w->shardCount] += p->nc;
+				w->shardJoints[k % w->shardCount] += p->nj;
+			}
 			if (k % w->shardCount == w->shardRank)
 			{
 				mark_owned(w, p->bodies, p->nb, p->contacts, p->nc, p->joints, p->nj);
@@ -2565,117 +2582,110 @@ void b2o_step_end(b2o_world* w)
 	if (w->postSolveOn) finish_post_solve(w);
 }
 
-/* ---- island sharding: exchange records, layout and ownership as in b2d_kernels_shard.h ---------------------------------------- */
+/* ---- island sharding: every rank packs the records of the islands it solved (each record carries its id) into its SLAB,
+ * the slabs are all-gathered, every rank imports the others'. Layout and ownership as in b2d_kernels_shard.h; every rank
+ * has counted every rank's slab during its (replicated) island build. ------------------------------------------------------ */
 #define SHARD_BODY_WORDS 13
 #define SHARD_CONTACT_WORDS 5
 #define SHARD_JOINT_WORDS 6
-#define SHARD_NOBODY ((int32_t)0x80000000)
 static int32_t fbits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
 static float bitsf(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
 
 void b2o_set_shard(b2o_world* w, int rank, int count) { w->shardRank = rank; w->shardCount = count; }
 
-size_t b2o_shard_exchange_words(const b2o_world* w)
+size_t b2o_shard_slab_words(const b2o_world* w, int rank)
 {
-	return (size_t)w->nBodies * SHARD_BODY_WORDS + (size_t)w->liveContacts * SHARD_CONTACT_WORDS + (size_t)w->nJoints * SHARD_JOINT_WORDS;
+	return (size_t)w->shardBodies[rank] * SHARD_BODY_WORDS + (size_t)w->shardContacts[rank] * SHARD_CONTACT_WORDS + (size_t)w->shardJoints[rank] * SHARD_JOINT_WORDS;
 }
 
 void b2o_shard_export(const b2o_world* w, int32_t* out)
 {
-	const int32_t me = w->shardRank + 1;
-	for (int i = 0; i < w->nBodies; ++i)
+	const int me = w->shardRank;
+	int32_t* o = out;
+	int n = 0;
+	for (int i = 0; i < w->nBodies && w->bodyOwned; ++i)
 	{
-		int32_t* o = out + (size_t)i * SHARD_BODY_WORDS;
+		if (!w->bodyOwned[i]) continue;
 		const body_t* b = &w->bodies[i];
-		if (!w->bodyOwned || !w->bodyOwned[i])
-		{
-			for (int k = 0; k < SHARD_BODY_WORDS; ++k) o[k] = SHARD_NOBODY;
-			continue;
-		}
-		o[0] = fbits(b->c.x); o[1] = fbits(b->c.y); o[2] = fbits(b->a); o[3] = fbits(b->sleepTime);
-		o[4] = fbits(b->v.x); o[5] = fbits(b->v.y); o[6] = fbits(b->w);
-		o[7] = (b->flags & BF_AWAKE) ? 1 : 0;
-		o[8] = fbits(b->xf.p.x); o[9] = fbits(b->xf.p.y); o[10] = fbits(b->xf.q.s); o[11] = fbits(b->xf.q.c);
-		o[12] = me;
+		o[0] = i;
+		o[1] = fbits(b->c.x); o[2] = fbits(b->c.y); o[3] = fbits(b->a); o[4] = fbits(b->sleepTime);
+		o[5] = fbits(b->v.x); o[6] = fbits(b->v.y); o[7] = fbits(b->w);
+		o[8] = (b->flags & BF_AWAKE) ? 1 : 0;
+		o[9] = fbits(b->xf.p.x); o[10] = fbits(b->xf.p.y); o[11] = fbits(b->xf.q.s); o[12] = fbits(b->xf.q.c);
+		o += SHARD_BODY_WORDS;
+		++n;
 	}
-	int32_t* oc = out + (size_t)w->nBodies * SHARD_BODY_WORDS;
+	(void)n;
+	o = out + (size_t)w->shardBodies[me] * SHARD_BODY_WORDS;
 	int* rank = contact_ranks(w);
-	for (int slot = 0; slot < w->nContactSlots; ++slot)
+	for (int slot = 0; slot < w->nContactSlots && w->contactOwned; ++slot)
 	{
-		if (rank[slot] < 0) continue;
-		int32_t* o = oc + (size_t)rank[slot] * SHARD_CONTACT_WORDS;
+		if (rank[slot] < 0 || !w->contactOwned[slot]) continue;
 		const contact_t* c = &w->contacts[slot];
-		if (!w->contactOwned || !w->contactOwned[slot])
-		{
-			for (int k = 0; k < SHARD_CONTACT_WORDS; ++k) o[k] = SHARD_NOBODY;
-			continue;
-		}
-		o[0] = fbits(c->m.ni[0]); o[1] = fbits(c->m.ti[0]); o[2] = fbits(c->m.ni[1]); o[3] = fbits(c->m.ti[1]);
-		o[4] = me;
+		o[0] = rank[slot]; /* the contact's index in b2o_get_contacts order = every rank's index for it */
+		o[1] = fbits(c->m.ni[0]); o[2] = fbits(c->m.ti[0]); o[3] = fbits(c->m.ni[1]); o[4] = fbits(c->m.ti[1]);
+		o += SHARD_CONTACT_WORDS;
 	}
 	free(rank);
-	int32_t* oj = oc + (size_t)w->liveContacts * SHARD_CONTACT_WORDS;
-	for (int j = 0; j < w->nJoints; ++j)
+	o = out + (size_t)w->shardBodies[me] * SHARD_BODY_WORDS + (size_t)w->shardContacts[me] * SHARD_CONTACT_WORDS;
+	for (int j = 0; j < w->nJoints && w->jointOwned; ++j)
 	{
-		int32_t* o = oj + (size_t)j * SHARD_JOINT_WORDS;
+		if (!w->jointOwned[j]) continue;
 		const revolute_t* jn = &w->joints[j];
-		if (!w->jointOwned || !w->jointOwned[j])
-		{
-			for (int k = 0; k < SHARD_JOINT_WORDS; ++k) o[k] = SHARD_NOBODY;
-			continue;
-		}
-		o[0] = fbits(jn->impulse[0]);
-		o[1] = fbits(jn->type == B2O_JOINT_WHEEL ? jn->springImpulse : jn->impulse[1]);
-		o[2] = fbits(jn->impulse[2]);
-		o[3] = fbits(jn->motorImpulse);
-		o[4] = jn->limitState;
-		o[5] = me;
+		o[0] = j;
+		o[1] = fbits(jn->impulse[0]);
+		o[2] = fbits(jn->type == B2O_JOINT_WHEEL ? jn->springImpulse : jn->impulse[1]);
+		o[3] = fbits(jn->impulse[2]);
+		o[4] = fbits(jn->motorImpulse);
+		o[5] = jn->limitState;
+		o += SHARD_JOINT_WORDS;
 	}
 }
 
-void b2o_shard_import(b2o_world* w, const int32_t* in)
+void b2o_shard_import(b2o_world* w, const int32_t* in, size_t strideWords)
 {
-	const int32_t me = w->shardRank + 1;
-	for (int i = 0; i < w->nBodies; ++i)
+	int* slotOf = NULL; /* contact index (b2o_get_contacts order) -> slot */
 	{
-		const int32_t* o = in + (size_t)i * SHARD_BODY_WORDS;
-		if (o[12] <= 0 || o[12] == me) continue;
-		body_t* b = &w->bodies[i];
-		b->c0 = b->c; b->a0 = b->a; b->alpha0 = 0.0f;
-		b->c = v_make(bitsf(o[0]), bitsf(o[1])); b->a = bitsf(o[2]); b->sleepTime = bitsf(o[3]);
-		b->v = v_make(bitsf(o[4]), bitsf(o[5])); b->w = bitsf(o[6]);
-		b->xf.p = v_make(bitsf(o[8]), bitsf(o[9])); b->xf.q.s = bitsf(o[10]); b->xf.q.c = bitsf(o[11]);
-		if (o[7]) b->flags |= BF_AWAKE;
-		else
+		int* rank = contact_ranks(w);
+		slotOf = (int*)malloc(sizeof(int) * (size_t)(w->liveContacts + 1));
+		for (int slot = 0; slot < w->nContactSlots; ++slot) if (rank[slot] >= 0) slotOf[rank[slot]] = slot;
+		free(rank);
+	}
+	for (int r = 0; r < w->shardCount; ++r)
+	{
+		if (r == w->shardRank) continue;
+		const int32_t* o = in + (size_t)r * strideWords;
+		for (int k = 0; k < w->shardBodies[r]; ++k, o += SHARD_BODY_WORDS)
 		{
-			b->flags &= ~BF_AWAKE;
-			b->force = v_make(0.0f, 0.0f);
-			b->torque = 0.0f;
+			body_t* b = &w->bodies[o[0]];
+			b->c0 = b->c; b->a0 = b->a; b->alpha0 = 0.0f;
+			b->c = v_make(bitsf(o[1]), bitsf(o[2])); b->a = bitsf(o[3]); b->sleepTime = bitsf(o[4]);
+			b->v = v_make(bitsf(o[5]), bitsf(o[6])); b->w = bitsf(o[7]);
+			b->xf.p = v_make(bitsf(o[9]), bitsf(o[10])); b->xf.q.s = bitsf(o[11]); b->xf.q.c = bitsf(o[12]);
+			if (o[8]) b->flags |= BF_AWAKE;
+			else
+			{
+				b->flags &= ~BF_AWAKE;
+				b->force = v_make(0.0f, 0.0f);
+				b->torque = 0.0f;
+			}
+		}
+		for (int k = 0; k < w->shardContacts[r]; ++k, o += SHARD_CONTACT_WORDS)
+		{
+			contact_t* c = &w->contacts[slotOf[o[0]]];
+			c->m.ni[0] = bitsf(o[1]); c->m.ti[0] = bitsf(o[2]); c->m.ni[1] = bitsf(o[3]); c->m.ti[1] = bitsf(o[4]);
+		}
+		for (int k = 0; k < w->shardJoints[r]; ++k, o += SHARD_JOINT_WORDS)
+		{
+			revolute_t* jn = &w->joints[o[0]];
+			jn->impulse[0] = bitsf(o[1]);
+			if (jn->type == B2O_JOINT_WHEEL) jn->springImpulse = bitsf(o[2]); else jn->impulse[1] = bitsf(o[2]);
+			jn->impulse[2] = bitsf(o[3]);
+			jn->motorImpulse = bitsf(o[4]);
+			jn->limitState = o[5];
 		}
 	}
-	const int32_t* ic = in + (size_t)w->nBodies * SHARD_BODY_WORDS;
-	int* rank = contact_ranks(w);
-	for (int slot = 0; slot < w->nContactSlots; ++slot)
-	{
-		if (rank[slot] < 0) continue;
-		const int32_t* o = ic + (size_t)rank[slot] * SHARD_CONTACT_WORDS;
-		if (o[4] <= 0 || o[4] == me) continue;
-		contact_t* c = &w->contacts[slot];
-		c->m.ni[0] = bitsf(o[0]); c->m.ti[0] = bitsf(o[1]); c->m.ni[1] = bitsf(o[2]); c->m.ti[1] = bitsf(o[3]);
-	}
-	free(rank);
-	const int32_t* ij = ic + (size_t)w->liveContacts * SHARD_CONTACT_WORDS;
-	for (int j = 0; j < w->nJoints; ++j)
-	{
-		const int32_t* o = ij + (size_t)j * SHARD_JOINT_WORDS;
-		if (o[5] <= 0 || o[5] == me) continue;
-		revolute_t* jn = &w->joints[j];
-		jn->impulse[0] = bitsf(o[0]);
-		if (jn->type == B2O_JOINT_WHEEL) jn->springImpulse = bitsf(o[1]); else jn->impulse[1] = bitsf(o[1]);
-		jn->impulse[2] = bitsf(o[2]);
-		jn->motorImpulse = bitsf(o[3]);
-		jn->limitState = o[4];
-	}
+	free(slotOf);
 }
 
 void b2o_step(b2o_world* w, float dt, int velIters, int posIters)

@@ -45,7 +45,7 @@ class Hip:
 
 
 class TwoRanks:
-    """ShardedWorld.step for two worlds side by side; the collective is an element-wise maximum (numpy, through the host)."""
+    """ShardedWorld.step for two worlds side by side; the collective (an all-gather of the ranks' slabs) goes through the host."""
 
     def __init__(self, worlds):
         self.hip = Hip()
@@ -57,27 +57,33 @@ class TwoRanks:
             self.sw.append(s)
 
     def step(self):
-        bufs, host = [], []
+        n = len(self.sw)
         for s in self.sw:
             L, p = s.L, s.w.p
             s._check(L.b2hip_step_begin(p, 1.0 / 60.0, 8, 3))
             s._check(L.b2hip_collide(p))
             s._check(L.b2hip_solve(p))
-            words = C.c_size_t(0)
-            s._check(L.b2hip_shard_exchange_words(p, C.byref(words)))
-            n = int(words.value)
-            buf = self.hip.alloc(4 * n)
-            s._check(L.b2hip_shard_export(p, buf, n))
-            bufs.append(buf)
-            host.append(self.hip.to_host(buf, n))
-        assert len({h.size for h in host}) == 1, "the ranks disagree about the size of the world"
-        red = host[0]
-        for h in host[1:]:
-            red = np.maximum(red, h)
-        for s, buf in zip(self.sw, bufs):
+        # every rank has counted every rank's slab (the island build is replicated): they must agree
+        sizes = []
+        for s in self.sw:
+            words = (C.c_size_t * n)()
+            s._check(s.L.b2hip_shard_slab_words(s.w.p, words, n))
+            sizes.append(list(words))
+        assert all(sz == sizes[0] for sz in sizes), "the ranks disagree about the slab sizes: %s" % sizes
+        stride = max(max(sizes[0]), 1)
+        self.exchange_words = stride * n
+        slabs = []
+        for s in self.sw:
+            buf = self.hip.alloc(4 * stride)
+            s._check(s.L.b2hip_shard_export(s.w.p, buf, stride))
+            slabs.append(self.hip.to_host(buf, stride))
+            self.hip.free(buf)
+        gathered = np.concatenate(slabs)  # (the all-gather)
+        for s in self.sw:
             L, p = s.L, s.w.p
-            self.hip.to_device(buf, red)
-            s._check(L.b2hip_shard_import(p, buf, red.size))
+            buf = self.hip.alloc(4 * stride * n)
+            self.hip.to_device(buf, gathered)
+            s._check(L.b2hip_shard_import(p, buf, stride))
             s._check(L.b2hip_sync_fixtures(p))
             s._check(L.b2hip_find_new_contacts(p))
             s._check(L.b2hip_solve_toi(p))
@@ -153,6 +159,31 @@ def test_big_islands_are_dealt_round_robin():
     assert np.isfinite(st["px"]).all() and (st["py"][1:] > 0.3).all()
     for w in worlds:
         w.close()
+
+
+def test_rccl_all_gather_inside_the_library_on_one_rank(monkeypatch):
+    """b2hip_shard_connect opens librccl, makes a communicator and from then on b2hip_step queues export -> ncclAllGather ->
+    import on the world's own stream. A one-GPU box has no peer, but a communicator of ONE rank (B2HIP_SHARD_LOOPBACK=1)
+    runs the same calls: the world must step exactly like an unconnected one, and report the bytes it gathered."""
+    monkeypatch.setenv("B2HIP_SHARD_LOOPBACK", "1")
+    L = b2hip.lib()
+    L.b2hip_shard_unique_id.argtypes = [C.c_void_p]
+    L.b2hip_shard_connect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.b2hip_shard_exchange_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    a, b = b2hip.World(gravity=(0.0, 0.0), continuous=True), b2hip.World(gravity=(0.0, 0.0), continuous=True)
+    build_field(a, 600, seed=5)
+    build_field(b, 600, seed=5)
+    ident = (C.c_ubyte * 128)()
+    assert L.b2hip_shard_unique_id(ident) == 0, L.b2hip_last_error()
+    assert L.b2hip_shard_connect(b.p, ident, 0, 1) == 0, L.b2hip_last_error()
+    for s in range(60):
+        a.step()
+        b.step()
+        assert snapshot(a) == snapshot(b), "step %d" % s
+    n = C.c_size_t(0)
+    assert L.b2hip_shard_exchange_bytes(b.p, C.byref(n)) == 0 and n.value >= 4
+    a.close()
+    b.close()
 
 
 def run_selftest(cmd, root, env):

@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: two processes (gloo, world_size 2) each step their shard of a 4-pyramid world with the
-C oracle as the stepper, all-gather the body states and compare with the unsharded world: islands are
-independent, so the sharded result must be BIT-IDENTICAL to the unsharded one."""
+"""N > 1 path on CPU: two processes (gloo, world_size 2) hold the same world on the C oracle (through the C-ABI shim), each
+solves the islands it owns, the ranks all-gather their slabs every step (box2d-mt_amd/python/sharding.ShardedWorld, the
+driver bench.py --gpus N uses): islands are independent, so every rank must hold, after every step, exactly the
+unsharded world - bit for bit."""
 import os
 import sys
 
@@ -9,62 +10,6 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
-
-ROWS, COUNT, STEPS = 8, 4, 90
-
-
-def _worker(rank, world_size, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import b2harness as bh
-    import sharding
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
-    h = bh.Harness(bh.ORACLE_LIB)
-    w = h.world(bh.PYRAMID, ROWS, COUNT, float(rank), float(world_size))
-    assert w.body_count == len(sharding.global_body_ids(ROWS, COUNT, rank, world_size))
-    for _ in range(STEPS):
-        w.step(1)
-    full = sharding.gather_world_state(w.bodies(), ROWS, COUNT, rank, world_size, dist=dist)
-    dist.barrier()
-    if rank == 0:
-        q.put(full)
-    dist.destroy_process_group()
-
-
-def test_sharded_world_equals_unsharded_bitwise(built_libs):
-    import torch.multiprocessing as mp
-    import b2harness as bh
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    full = q.get(timeout=240)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    h = bh.Harness(bh.ORACLE_LIB)
-    w = h.world(bh.PYRAMID, ROWS, COUNT)
-    for _ in range(STEPS):
-        w.step(1)
-    want = w.bodies()
-    assert full.shape == want.shape
-    # the static ground is written by both shards with the same value
-    assert np.array_equal(full.view(np.uint32), want.view(np.uint32))
-
-
-def test_plan_covers_every_body_once():
-    import sharding
-    for world in (1, 2, 4, 8):
-        seen = np.zeros(1 + COUNT * sharding.pyramid_bodies(ROWS), int)
-        for r in range(world):
-            ids = sharding.global_body_ids(ROWS, COUNT, r, world)
-            seen[ids[1:]] += 1
-        assert (seen[1:] == 1).all()
-
 
 # ---- one world sharded by island owner: the replicated world + one exchange per step ------------------
 def build_field(w, n, seed, with_joints=True):
@@ -124,9 +69,9 @@ def _field_worker(rank, world_size, port, q):
 
 
 def test_field_world_sharded_by_island_owner_equals_the_unsharded_run(built_libs):
-    """Two gloo ranks hold the same field world, each solves the islands it owns (hash of the island root), one
-    all-reduce(MAX) per step exchanges them: every rank must see, after every step, exactly the body states, contact set,
-    manifolds and warm-start impulses of the unsharded run."""
+    """Two gloo ranks hold the same field world, each solves the islands it owns (hash of the island root), one all-gather of
+    owner-sized slabs per step exchanges them: every rank must see, after every step, exactly the body states, contact
+    set, manifolds and warm-start impulses of the unsharded run."""
     import torch.multiprocessing as mp
     import b2harness as bh
     import b2hip
@@ -140,7 +85,9 @@ def test_field_world_sharded_by_island_owner_equals_the_unsharded_run(built_libs
     for _ in range(2):
         rank, trace, nbytes = q.get(timeout=600)
         got[rank] = trace
-        assert nbytes > 0
+        # owner-sized slabs: both ranks' slabs together hold every solved body once (52 B) plus their contacts and joints -
+        # less than the 52 B x ALL bodies x ranks a world-sized exchange would move
+        assert 0 < nbytes < 52 * FIELD_N * 2
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -5,8 +5,9 @@ after every step every rank must hold the unsharded world bit for bit.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
         tools/shard_selftest.py [--backend gloo|nccl] [--rows 40] [--pyramids 5] [--steps 60]
 
-backend nccl (RCCL) wants one GPU per rank; gloo lets several ranks share one GPU (the exchange buffer is a device tensor
-either way), which is how tests/test_gpu_sharding.py runs it on a one-GPU box."""
+backend nccl (RCCL) wants one GPU per rank: the all-gather then runs inside the library on the world's stream
+(b2hip_shard_connect); gloo lets several ranks share one GPU (torch.distributed's all-gather over device tensors), which is
+how tests/test_gpu_sharding.py runs it on a one-GPU box."""
 import argparse
 import hashlib
 import os
@@ -46,6 +47,7 @@ def main():
     ap.add_argument("--rows", type=int, default=40)
     ap.add_argument("--pyramids", type=int, default=5)
     ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--torch-collective", action="store_true", help="with --backend nccl: torch.distributed's all-gather instead of the library's own RCCL")
     ap.add_argument("--no-reference", action="store_true", help="do not compare with an unsharded world (default mode: the "
                     "block partition of large islands depends on the islands a rank holds; set B2HIP_FORCE_LARGE=2 to compare)")
     a = ap.parse_args()
@@ -60,6 +62,8 @@ def main():
     w = b2hip.World(device=dev)
     build(w, b2hip, a.rows, a.pyramids)
     sw = sharding.ShardedWorld(w, dist=dist, device="cuda:%d" % dev)
+    if a.backend == "nccl" and not a.torch_collective:
+        sw.connect_rccl()  # the all-gather inside the library (RCCL on the world's stream), as bench.py --gpus N runs it
     ref = None
     if rank == 0 and not a.no_reference:
         ref = b2hip.World(device=dev)
@@ -75,7 +79,10 @@ def main():
         all_t = [torch.empty_like(t) for _ in range(size)]
         dist.all_gather(all_t, t)
         if any(bytes(x.numpy()) != mine for x in all_t):
-            print("rank %d: the ranks hold different worlds after step %d" % (rank, s), flush=True)
+            st, ct = w.body_states(), w.contacts()
+            parts = {f: hashlib.sha1(st[f].tobytes()).hexdigest()[:8] for f in st.dtype.names}
+            parts.update({"c:" + f: hashlib.sha1(ct[f].tobytes()).hexdigest()[:8] for f in ct.dtype.names})
+            print("rank %d: the ranks hold different worlds after step %d (%d contacts, counters %s)\n   %s" % (rank, s, len(ct), w.counters(), parts), flush=True)
             sys.exit(3)
         if ref is not None:
             ref.step()
