@@ -264,6 +264,8 @@ struct b2hip_world
 	void* filterUser = nullptr;
 	bool refilterPending = false;   // some contact may carry CF_FILTER (joint created / destroyed, fixture re-filtered)
 	b2hip_pre_solve_fn preSolveFn = nullptr;
+	b2hip_pre_solve_batch_fn preSolveBatchFn = nullptr;
+	b2hip_should_collide_batch_fn filterBatchFn = nullptr;
 	void* preSolveUser = nullptr;
 	bool postSolveOn = false;
 	std::vector<b2hip_contact_impulse> postSolve; // of the last step, in delivery order
@@ -648,6 +650,9 @@ static int runSegment(b2hip_world* w, GraphSeg& seg, uint64_t extra, F launches)
 	return 0;
 }
 
+static inline bool hasFilter(const b2hip_world* w) { return w->filterFn != nullptr || w->filterBatchFn != nullptr; }
+static inline bool hasPreSolve(const b2hip_world* w) { return w->preSolveFn != nullptr || w->preSolveBatchFn != nullptr; }
+
 static int ktRecord(b2hip_world* w)
 {
 	if (!w->kernelTiming) return 0;
@@ -796,10 +801,10 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	{
 		// listener bridge buffers: contact-sized only while the callback that needs them is installed
-		const size_t nPre = w->preSolveFn ? cc : 1, nPost = w->postSolveOn ? cc : 1, nFil = w->filterFn ? cc : 1;
+		const size_t nPre = hasPreSolve(w) ? cc : 1, nPost = w->postSolveOn ? cc : 1, nFil = hasFilter(w) ? cc : 1;
 		ENS(pre_o0, nPre); ENS(pre_o1, nPre); ENS(pre_oimp, nPre); ENS(pre_o3, nPre); ENS(preRecs, nPre);
 		ENS(postRecs, nPost); ENS(filterList, nFil);
-		ENS(hostList, std::max<size_t>(std::max(4 * nPre, nFil), w->filterFn ? capPairs : 1)); // (PreSolve material edits: 4 words each)
+		ENS(hostList, std::max<size_t>(std::max(4 * nPre, nFil), hasFilter(w) ? capPairs : 1)); // (PreSolve material edits: 4 words each)
 	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2); ENS(blkBodyCount, MAX_BLOCKS + 2); ENS(blkBodyCursor, MAX_BLOCKS + 2);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
@@ -877,7 +882,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.b_adoptStage = w->b_adoptStage.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p; d.blkBodyCount = w->blkBodyCount.p; d.blkBodyCursor = w->blkBodyCursor.p;
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
-	d.userFilter = w->filterFn ? 1 : 0; d.preSolveOn = w->preSolveFn ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
+	d.userFilter = hasFilter(w) ? 1 : 0; d.preSolveOn = hasPreSolve(w) ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
 	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
 	d.preRecs = w->preRecs.p; d.postRecs = w->postRecs.p; d.filterList = w->filterList.p;
 	return 0;
@@ -1261,6 +1266,16 @@ static int applyHostList(b2hip_world* w, K kernel, const std::vector<int>& list)
 // b2ContactManager::AddPair's user filter (b2ContactManager.cpp:283-287): the first occurrence of every candidate pair is
 // shown to the user's b2hip_should_collide_fn (lower proxy id first, as AddPair passes them); refused pairs stop being
 // first occurrences, so nothing is created for them. Between the "first" flags and the ranks of either ordering path.
+// the user's filter on a list of fixture pairs: one call with all of them (batch form) or one call per pair
+static void askFilter(b2hip_world* w, const std::vector<int>& pairs2, std::vector<int>& verdict)
+{
+	const int n = (int)pairs2.size() / 2;
+	verdict.assign((size_t)n, 1);
+	if (n == 0) return;
+	if (w->filterBatchFn) w->filterBatchFn(w->filterUser, n, pairs2.data(), verdict.data());
+	else for (int i = 0; i < n; ++i) verdict[i] = w->filterFn(w->filterUser, pairs2[2 * i], pairs2[2 * i + 1]) ? 1 : 0;
+}
+
 static int userFilterPairs(b2hip_world* w, const int2* proxies)
 {
 	int rc = readState(w);
@@ -1271,11 +1286,16 @@ static int userFilterPairs(b2hip_world* w, const int2* proxies)
 	std::vector<int2> pr(n);
 	HIP_TRY(hipMemcpy(first.data(), w->pairFirst.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(pr.data(), proxies, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
-	std::vector<int> refused;
+	std::vector<int> refused, asked, which, verdict;
 	for (int i = 0; i < n; ++i)
 	{
-		if (first[i] && !w->filterFn(w->filterUser, pr[i].x, pr[i].y)) refused.push_back(i);
+		if (!first[i]) continue;
+		asked.push_back(pr[i].x);
+		asked.push_back(pr[i].y);
+		which.push_back(i);
 	}
+	askFilter(w, asked, verdict);
+	for (size_t k = 0; k < which.size(); ++k) if (!verdict[k]) refused.push_back(which[k]);
 	return applyHostList(w, k_pairs_reject, refused);
 }
 
@@ -1311,14 +1331,14 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		sortedKeys = kin;
 		sortedProxies = vin;
 		LAUNCH(w, k_pairs_sorted_first, gridFor(d.capPairs), 256, d, sortedKeys, w->consts.p + 3);
-		if (w->filterFn) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
+		if (hasFilter(w)) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
 		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanCtx, w->consts.p + 3, d.capPairs);
 		LAUNCH(w, k_pairs_sorted_total, 1, 1, d, w->consts.p + 3);
 	}
 	else
 	{
 		LAUNCH(w, k_pairs_first, 16, 256, d);
-		if (w->filterFn) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
+		if (hasFilter(w)) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
 		LAUNCH(w, k_pairs_rank, 16, 256, d);
 	}
 	const int smallPath = largePath ? 0 : 1;
@@ -1333,7 +1353,7 @@ static int findNewContactsOnce(b2hip_world* w, bool sync);
 static int findNewContactsGraph(b2hip_world* w)
 {
 	// (a user contact filter is asked on the host in the middle of the update: synchronous, no graph)
-	if (w->filterFn) return findNewContacts(w, true);
+	if (hasFilter(w)) return findNewContacts(w, true);
 	return runSegment(w, w->segPairs, 3, [w]() -> int { return findNewContacts(w, false); });
 }
 
@@ -3489,7 +3509,7 @@ static void toManifold(b2hip_manifold* m, float4 m0, float4 m1, float4 imp, int4
 static int collideImpl(b2hip_world* w)
 {
 	int rc = 0;
-	if (w->filterFn && w->refilterPending)
+	if (hasFilter(w) && w->refilterPending)
 	{
 		// b2ContactManager::Collide's re-filter (:195-203) with a user filter: the flagged contacts are shown to it first
 		LAUNCH(w, k_filter_list, gridFor(w->dw.capContacts), 256, w->dw);
@@ -3502,12 +3522,16 @@ static int collideImpl(b2hip_world* w)
 			HIP_TRY(hipMemcpy(list.data(), w->filterList.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
 			std::sort(list.begin(), list.end());
 			const int cur = w->h_dstate->cur;
+			std::vector<int> asked, verdict;
 			for (int k = 0; k < n; ++k)
 			{
 				int4 ids;
 				HIP_TRY(hipMemcpy(&ids, w->c_ids[cur].p + list[k], sizeof(int4), hipMemcpyDeviceToHost));
-				if (!w->filterFn(w->filterUser, ids.x, ids.y)) refused.push_back(list[k]);
+				asked.push_back(ids.x);
+				asked.push_back(ids.y);
 			}
+			askFilter(w, asked, verdict);
+			for (int k = 0; k < n; ++k) if (!verdict[k]) refused.push_back(list[k]);
 			rc = applyHostList(w, k_filter_reject, refused);
 			if (rc) return rc;
 		}
@@ -3515,7 +3539,7 @@ static int collideImpl(b2hip_world* w)
 	w->refilterPending = false;
 	rc = phaseCollide(w);
 	if (rc) return rc;
-	if (w->preSolveFn)
+	if (hasPreSolve(w))
 	{
 		// b2ContactListener::PreSolve: one record per touching, non-sensor contact this Collide updated; delivered in
 		// proxy-id-pair order (b2ContactManager.cpp:431-434); a zero return disables the contact for this step
@@ -3531,14 +3555,32 @@ static int collideImpl(b2hip_world* w)
 			std::sort(order.begin(), order.end(), keyLess);
 			std::vector<int> disabled, materials;
 			w->callbackWindow = true;
+			std::vector<b2hip_pre_solve_record> batch((size_t)n);
 			for (int k = 0; k < n; ++k)
 			{
 				const PreSolveRec& r = recs[order[k].second];
-				b2hip_manifold oldM, newM;
-				toManifold(&oldM, r.o0, r.o1, r.oimp, r.o3);
-				toManifold(&newM, r.n0, r.n1, r.nimp, r.n3);
-				b2hip_contact_material mat = { r.mat.x, r.mat.y, r.mat.z };
-				if (!w->preSolveFn(w->preSolveUser, r.info.x, r.info.y, r.info.z, &oldM, &newM, &mat)) disabled.push_back(r.info.x);
+				b2hip_pre_solve_record& b = batch[k];
+				b.contact_index = r.info.x;
+				b.fixture_a = r.info.y;
+				b.fixture_b = r.info.z;
+				b.enabled = 1;
+				toManifold(&b.old_manifold, r.o0, r.o1, r.oimp, r.o3);
+				toManifold(&b.manifold, r.n0, r.n1, r.nimp, r.n3);
+				b.material.friction = r.mat.x;
+				b.material.restitution = r.mat.y;
+				b.material.tangent_speed = r.mat.z;
+			}
+			if (w->preSolveBatchFn) w->preSolveBatchFn(w->preSolveUser, n, batch.data());
+			else for (int k = 0; k < n; ++k)
+			{
+				b2hip_pre_solve_record& b = batch[k];
+				b.enabled = w->preSolveFn(w->preSolveUser, b.contact_index, b.fixture_a, b.fixture_b, &b.old_manifold, &b.manifold, &b.material) ? 1 : 0;
+			}
+			for (int k = 0; k < n; ++k)
+			{
+				const PreSolveRec& r = recs[order[k].second];
+				const b2hip_contact_material& mat = batch[k].material;
+				if (!batch[k].enabled) disabled.push_back(r.info.x);
 				if (memcmp(&mat.friction, &r.mat.x, 4) != 0 || memcmp(&mat.restitution, &r.mat.y, 4) != 0 || memcmp(&mat.tangent_speed, &r.mat.z, 4) != 0)
 				{
 					int bits[3];
@@ -4544,7 +4586,16 @@ int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* u
 	if (int rcu = checkUsable(w, "b2hip_set_contact_filter", true)) return rcu;
 	w->filterFn = fn;
 	w->filterUser = user;
-	w->dw.userFilter = fn ? 1 : 0;
+	w->dw.userFilter = hasFilter(w) ? 1 : 0;
+	return B2HIP_OK;
+}
+
+int b2hip_set_contact_filter_batch(b2hip_world* w, b2hip_should_collide_batch_fn fn, void* user)
+{
+	if (int rcu = checkUsable(w, "b2hip_set_contact_filter_batch", true)) return rcu;
+	w->filterBatchFn = fn;
+	if (fn) w->filterUser = user;
+	w->dw.userFilter = hasFilter(w) ? 1 : 0;
 	return B2HIP_OK;
 }
 
@@ -4564,7 +4615,16 @@ int b2hip_set_pre_solve(b2hip_world* w, b2hip_pre_solve_fn fn, void* user)
 	if (int rcu = checkUsable(w, "b2hip_set_pre_solve", true)) return rcu;
 	w->preSolveFn = fn;
 	w->preSolveUser = user;
-	w->dw.preSolveOn = fn ? 1 : 0;
+	w->dw.preSolveOn = hasPreSolve(w) ? 1 : 0;
+	return B2HIP_OK;
+}
+
+int b2hip_set_pre_solve_batch(b2hip_world* w, b2hip_pre_solve_batch_fn fn, void* user)
+{
+	if (int rcu = checkUsable(w, "b2hip_set_pre_solve_batch", true)) return rcu;
+	w->preSolveBatchFn = fn;
+	if (fn) w->preSolveUser = user;
+	w->dw.preSolveOn = hasPreSolve(w) ? 1 : 0;
 	return B2HIP_OK;
 }
 

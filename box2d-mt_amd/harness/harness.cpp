@@ -34,10 +34,14 @@ public:
 	void EndContact(b2Contact* contact) override { Record(1, contact, 0, 0, 0, 0, 0); }
 	void PreSolve(b2Contact* contact, const b2Manifold* oldManifold) override;
 	void PostSolve(b2Contact* contact, const b2ContactImpulse* impulse) override;
-	bool BeginContactImmediate(b2Contact*, uint32) override { return (m_mode & 1) != 0; }
-	bool EndContactImmediate(b2Contact*, uint32) override { return (m_mode & 1) != 0; }
-	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32) override { return (m_mode & (2 | 8 | 16)) != 0; }
-	bool PostSolveImmediate(b2Contact*, const b2ContactImpulse*, uint32) override { return (m_mode & 4) != 0; }
+	// (the *Immediate forms run on the executor's worker threads, each with its own threadId: counted per thread)
+	bool BeginContactImmediate(b2Contact*, uint32 t) override { Hit(t); return (m_mode & 1) != 0; }
+	bool EndContactImmediate(b2Contact*, uint32 t) override { Hit(t); return (m_mode & 1) != 0; }
+	bool PreSolveImmediate(b2Contact*, const b2Manifold*, uint32 t) override { Hit(t); return (m_mode & (2 | 8 | 16)) != 0; }
+	bool PostSolveImmediate(b2Contact*, const b2ContactImpulse*, uint32 t) override { Hit(t); return (m_mode & 4) != 0; }
+	void Hit(uint32 threadId) { if (threadId < b2_maxThreads) __atomic_fetch_add(&immediateCalls[threadId], 1, __ATOMIC_RELAXED); else __atomic_fetch_add(&badThreadIds, 1, __ATOMIC_RELAXED); }
+	int immediateCalls[b2_maxThreads] = {};
+	int badThreadIds = 0;
 	void Record(int kind, b2Contact* contact, int a, int b, int c, int d, int e);
 	std::vector<int> log; // 10 ints per event
 	int m_mode;
@@ -340,6 +344,19 @@ void b2h_record_events(b2h_world* h, int mode)
 		h->recorder = new b2hEventRecorder(h, mode);
 		h->world->SetContactListener(h->recorder);
 	}
+}
+
+// How often each thread id called an *Immediate callback since the listener was installed: out[b2_maxThreads], out[b2_maxThreads] =
+// calls with an id outside [0, b2_maxThreads). Returns b2_maxThreads.
+int b2h_immediate_calls_by_thread(b2h_world* h, int* out)
+{
+	for (int t = 0; t <= (int)b2_maxThreads; ++t) out[t] = 0;
+	if (h->recorder)
+	{
+		for (int t = 0; t < (int)b2_maxThreads; ++t) out[t] = h->recorder->immediateCalls[t];
+		out[b2_maxThreads] = h->recorder->badThreadIds;
+	}
+	return (int)b2_maxThreads;
 }
 
 int b2h_get_events(b2h_world* h, int cap, int* out)

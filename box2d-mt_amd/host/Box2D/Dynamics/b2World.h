@@ -21,6 +21,7 @@
 #include "Box2D/Dynamics/b2ContactManager.h"
 
 #include <vector>
+#include <stdint.h>
 
 struct b2AABB;
 struct b2BodyDef;
@@ -113,6 +114,12 @@ private:
 	void DeliverContactEvents();
 	void DeliverPostSolve();
 	static int FilterTrampoline(void* user, int fixtureA, int fixtureB);
+	static void FilterBatchTrampoline(void* user, int count, const int32_t* fixturePairs, int32_t* verdict);
+	static void PreSolveBatchTrampoline(void* user, int count, struct b2hip_pre_solve_record* records);
+	/// fn(index, threadId) for every index in [0, count): on the worker threads of the executor the running Step was given
+	/// (each with its own threadId < GetThreadCount(), as the reference's *Immediate callbacks see it), inline otherwise
+	void RunOnExecutor(uint32 count, void (*fn)(void* ctx, uint32 index, uint32 threadId), void* ctx);
+	b2TaskExecutor* m_stepExecutor;
 	static int PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int fixtureB, const struct b2hip_manifold* oldManifold,
 		const struct b2hip_manifold* manifold, struct b2hip_contact_material* material);
 	const std::vector<b2AABB>& FatAABBs();

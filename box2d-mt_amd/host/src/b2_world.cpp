@@ -14,7 +14,7 @@
 void b2ShapeToRecord(const b2Shape* shape, int32 child, void* record152);
 
 // ---- b2World ------------------------------------------------------------------------------------
-b2World::b2World(const b2Vec2& gravity) : m_shadowValid(false), m_contactManager(this)
+b2World::b2World(const b2Vec2& gravity) : m_stepExecutor(nullptr), m_shadowValid(false), m_contactManager(this)
 {
 	m_gravity = gravity;
 	m_allowSleep = true;
@@ -477,8 +477,9 @@ void b2World::DestroyJoint(b2Joint* j)
 
 void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIterations, b2TaskExecutor& executor)
 {
-	// The executor stays part of the signature (plugin surface); the device runs the physics phases.
-	B2_NOT_USED(executor);
+	// The physics phases are kernels; what is left on the host - the listener's *Immediate callbacks and the user's contact
+	// filter - runs on this executor's worker threads, as the reference runs them from its collide / solve tasks.
+	m_stepExecutor = &executor;
 	if (!m_hip)
 	{
 		fprintf(stderr, "b2World::Step: no HIP world (no device): nothing can be stepped\n");
@@ -497,6 +498,7 @@ void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIteration
 	// the reference's order within a step: begin / end (Collide), [PreSolve: called by the step itself], PostSolve (Solve)
 	DeliverContactEvents();
 	DeliverPostSolve();
+	m_stepExecutor = nullptr;
 	float ms[13];
 	if (b2hip_get_profile(m_hip, ms) == B2HIP_OK)
 	{
@@ -521,14 +523,14 @@ void b2World::SetContactListener(b2ContactListener* listener)
 	m_contactListener = listener;
 	if (!m_hip) return;
 	(void)b2hip_enable_contact_events(m_hip, listener != nullptr ? 1 : 0);
-	(void)b2hip_set_pre_solve(m_hip, listener != nullptr ? &b2World::PreSolveTrampoline : nullptr, this);
+	(void)b2hip_set_pre_solve_batch(m_hip, listener != nullptr ? &b2World::PreSolveBatchTrampoline : nullptr, this);
 	(void)b2hip_enable_post_solve(m_hip, listener != nullptr ? 1 : 0);
 }
 
 void b2World::SetContactFilter(b2ContactFilter* filter)
 {
 	m_contactFilter = filter;
-	if (m_hip) (void)b2hip_set_contact_filter(m_hip, filter != nullptr ? &b2World::FilterTrampoline : nullptr, this);
+	if (m_hip) (void)b2hip_set_contact_filter_batch(m_hip, filter != nullptr ? &b2World::FilterBatchTrampoline : nullptr, this);
 }
 
 // b2ContactManager::AddPair / Collide -> m_contactFilter->ShouldCollide (b2ContactManager.cpp:283-287, 195-203)
@@ -537,6 +539,50 @@ int b2World::FilterTrampoline(void* user, int fixtureA, int fixtureB)
 	b2World* self = static_cast<b2World*>(user);
 	if (!self->m_contactFilter) return 1;
 	return self->m_contactFilter->ShouldCollide(self->m_fixtures[fixtureA], self->m_fixtures[fixtureB], 0) ? 1 : 0;
+}
+
+// ---- host-side callbacks on the executor ------------------------------------------------------------------------------------
+namespace
+{
+struct CallbackRange : public b2RangeTask
+{
+	CallbackRange() : fn(nullptr), ctx(nullptr) {}
+	void Execute(const b2ThreadContext& tc, const b2RangeTaskRange& range) override
+	{
+		for (uint32 i = range.begin; i < range.end; ++i) fn(ctx, i, tc.threadId);
+	}
+	void (*fn)(void*, uint32, uint32);
+	void* ctx;
+};
+}
+
+void b2World::RunOnExecutor(uint32 count, void (*fn)(void* ctx, uint32 index, uint32 threadId), void* ctx)
+{
+	if (count == 0) return;
+	if (m_stepExecutor == nullptr || m_stepExecutor->GetThreadCount() < 2 || count < 2)
+	{
+		for (uint32 i = 0; i < count; ++i) fn(ctx, i, 0);
+		return;
+	}
+	CallbackRange task;
+	task.fn = fn;
+	task.ctx = ctx;
+	task.SetRange(b2RangeTaskRange(0, count));
+	b2ExecuteRangeTask(*m_stepExecutor, task);
+}
+
+// b2ContactFilter::ShouldCollide(fixtureA, fixtureB, threadId) for every pair of one decision point, from the worker threads
+// (b2WorldCallbacks.h:57-62: the reference asks from its find-contacts and collide tasks)
+void b2World::FilterBatchTrampoline(void* user, int count, const int32_t* pairs, int32_t* verdict)
+{
+	b2World* self = static_cast<b2World*>(user);
+	if (!self->m_contactFilter) return;
+	struct Ctx { b2World* w; const int32_t* pairs; int32_t* verdict; } c = { self, pairs, verdict };
+	self->RunOnExecutor((uint32)count, [](void* p, uint32 i, uint32 threadId)
+	{
+		Ctx* k = static_cast<Ctx*>(p);
+		k->verdict[i] = k->w->m_contactFilter->ShouldCollide(k->w->m_fixtures[k->pairs[2 * i]], k->w->m_fixtures[k->pairs[2 * i + 1]], threadId) ? 1 : 0;
+	}, &c);
 }
 
 // A device fixture id is (b2Fixture, child): a chain's children are consecutive device fixtures (b2Body::CreateFixture)
@@ -592,6 +638,53 @@ int b2World::PreSolveTrampoline(void* user, int contactIndex, int fixtureA, int 
 	return c.m_enabled ? 1 : 0;
 }
 
+// All PreSolve records of a step: PreSolveImmediate on the executor's threads (each contact view is a lane's own), then the
+// deferred PreSolve of the contacts that asked for it, on this thread, in the reference's deferred order (the records' order).
+void b2World::PreSolveBatchTrampoline(void* user, int count, b2hip_pre_solve_record* records)
+{
+	b2World* self = static_cast<b2World*>(user);
+	if (!self->m_contactListener || count <= 0) return;
+	struct Ctx
+	{
+		b2World* w;
+		b2hip_pre_solve_record* records;
+		std::vector<b2Contact> views;
+		std::vector<b2Manifold> olds;
+		std::vector<char> deferred;
+	} c;
+	c.w = self;
+	c.records = records;
+	c.views.resize((size_t)count);
+	c.olds.resize((size_t)count);
+	c.deferred.assign((size_t)count, 0);
+	for (int i = 0; i < count; ++i)
+	{
+		b2Contact& v = c.views[i];
+		FillManifold(v.m_manifold, records[i].manifold);
+		FillManifold(c.olds[i], records[i].old_manifold);
+		self->BindFixtures(v, records[i].fixture_a, records[i].fixture_b);
+		v.m_next = nullptr;
+		v.m_friction = records[i].material.friction;
+		v.m_restitution = records[i].material.restitution;
+		v.m_tangentSpeed = records[i].material.tangent_speed;
+		v.m_touching = true;
+		v.m_enabled = true;
+	}
+	self->RunOnExecutor((uint32)count, [](void* p, uint32 i, uint32 threadId)
+	{
+		Ctx* k = static_cast<Ctx*>(p);
+		k->deferred[i] = k->w->m_contactListener->PreSolveImmediate(&k->views[i], &k->olds[i], threadId) ? 1 : 0;
+	}, &c);
+	for (int i = 0; i < count; ++i)
+	{
+		if (c.deferred[i]) self->m_contactListener->PreSolve(&c.views[i], &c.olds[i]);
+		records[i].enabled = c.views[i].m_enabled ? 1 : 0;
+		records[i].material.friction = c.views[i].m_friction;
+		records[i].material.restitution = c.views[i].m_restitution;
+		records[i].material.tangent_speed = c.views[i].m_tangentSpeed;
+	}
+}
+
 // b2Island::Report -> PostSolveImmediate / PostSolve (b2Island.cpp:532-570, b2ContactManager.cpp:454-470)
 void b2World::DeliverPostSolve()
 {
@@ -602,11 +695,20 @@ void b2World::DeliverPostSolve()
 	count = b2hip_get_post_solve(m_hip, count, rec.data());
 	(void)GetContactList();
 	const int n = (int)m_contactViews.size();
+	// PostSolveImmediate on the executor's threads (the reference calls it from its solve tasks, b2Island.cpp:532-570), then the
+	// deferred PostSolve of the contacts that asked for it, in the records' (proxy-key) order (b2ContactManager.cpp:454-470)
+	struct Ctx
+	{
+		b2World* w;
+		std::vector<b2Contact*> contacts;
+		std::vector<b2ContactImpulse> impulses;
+		std::vector<char> deferred;
+	} c;
+	c.w = this;
 	for (int i = 0; i < count; ++i)
 	{
 		const b2hip_contact_impulse& r = rec[i];
 		if (r.contact_index < 0 || r.contact_index >= n) continue;
-		b2Contact* c = &m_contactViews[n - 1 - r.contact_index];
 		b2ContactImpulse impulse;
 		impulse.count = r.count;
 		for (int k = 0; k < b2_maxManifoldPoints; ++k)
@@ -614,7 +716,18 @@ void b2World::DeliverPostSolve()
 			impulse.normalImpulses[k] = k < r.count ? r.normal_impulses[k] : 0.0f;
 			impulse.tangentImpulses[k] = k < r.count ? r.tangent_impulses[k] : 0.0f;
 		}
-		if (m_contactListener->PostSolveImmediate(c, &impulse, 0)) m_contactListener->PostSolve(c, &impulse);
+		c.contacts.push_back(&m_contactViews[n - 1 - r.contact_index]);
+		c.impulses.push_back(impulse);
+	}
+	c.deferred.assign(c.contacts.size(), 0);
+	RunOnExecutor((uint32)c.contacts.size(), [](void* p, uint32 i, uint32 threadId)
+	{
+		Ctx* k = static_cast<Ctx*>(p);
+		k->deferred[i] = k->w->m_contactListener->PostSolveImmediate(k->contacts[i], &k->impulses[i], threadId) ? 1 : 0;
+	}, &c);
+	for (size_t i = 0; i < c.contacts.size(); ++i)
+	{
+		if (c.deferred[i]) m_contactListener->PostSolve(c.contacts[i], &c.impulses[i]);
 	}
 }
 
@@ -632,6 +745,17 @@ void b2World::DeliverContactEvents()
 	count = b2hip_get_contact_events(m_hip, count, ev.data());
 	(void)GetContactList(); // views of this step's contacts, newest first
 	const int n = (int)m_contactViews.size();
+	// Begin / EndContactImmediate on the executor's threads (the reference calls them from its collide tasks,
+	// b2Contact.cpp:253-281), then the deferred calls of the contacts that asked for them, in the list's order
+	struct Ctx
+	{
+		b2World* w;
+		std::vector<b2Contact*> contacts;
+		std::vector<char> ended, deferred;
+		std::vector<b2Contact> gone; // views of contacts that no longer exist (their end events)
+	} c;
+	c.w = this;
+	c.gone.reserve((size_t)count);
 	for (int i = 0; i < count; ++i)
 	{
 		const b2hip_contact_event& e = ev[i];
@@ -652,28 +776,35 @@ void b2World::DeliverContactEvents()
 			}
 			if (early) continue;
 		}
-		b2Contact gone; // the view of a contact that no longer exists (its end event)
-		b2Contact* c = nullptr;
-		if (e.contact_index >= 0 && e.contact_index < n) c = &m_contactViews[n - 1 - e.contact_index];
+		b2Contact* view = nullptr;
+		if (e.contact_index >= 0 && e.contact_index < n) view = &m_contactViews[n - 1 - e.contact_index];
 		else
 		{
-			memset(&gone.m_manifold, 0, sizeof(gone.m_manifold));
-			BindFixtures(gone, e.fixture_a, e.fixture_b);
-			gone.m_next = nullptr;
-			gone.m_friction = 0.0f;
-			gone.m_restitution = 0.0f;
-			gone.m_touching = false;
-			gone.m_enabled = true;
-			c = &gone;
+			c.gone.push_back(b2Contact());
+			b2Contact& g = c.gone.back();
+			memset(&g.m_manifold, 0, sizeof(g.m_manifold));
+			BindFixtures(g, e.fixture_a, e.fixture_b);
+			g.m_next = nullptr;
+			g.m_friction = 0.0f;
+			g.m_restitution = 0.0f;
+			g.m_touching = false;
+			g.m_enabled = true;
+			view = &g;
 		}
-		if (e.kind == 0)
-		{
-			if (m_contactListener->BeginContactImmediate(c, 0)) m_contactListener->BeginContact(c);
-		}
-		else
-		{
-			if (m_contactListener->EndContactImmediate(c, 0)) m_contactListener->EndContact(c);
-		}
+		c.contacts.push_back(view);
+		c.ended.push_back(e.kind != 0 ? 1 : 0);
+	}
+	c.deferred.assign(c.contacts.size(), 0);
+	RunOnExecutor((uint32)c.contacts.size(), [](void* p, uint32 i, uint32 threadId)
+	{
+		Ctx* k = static_cast<Ctx*>(p);
+		b2ContactListener* listener = k->w->m_contactListener;
+		k->deferred[i] = (k->ended[i] ? listener->EndContactImmediate(k->contacts[i], threadId) : listener->BeginContactImmediate(k->contacts[i], threadId)) ? 1 : 0;
+	}, &c);
+	for (size_t i = 0; i < c.contacts.size(); ++i)
+	{
+		if (!c.deferred[i]) continue;
+		if (c.ended[i]) m_contactListener->EndContact(c.contacts[i]); else m_contactListener->BeginContact(c.contacts[i]);
 	}
 	m_endedEarly.clear();
 }

@@ -466,6 +466,10 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out);
  * continuous-collision sub-step (those are made on the device with the built-in rule). */
 typedef int (*b2hip_should_collide_fn)(void* user, int fixture_a, int fixture_b);
 int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* user);
+/* ... or all pairs of one decision point in one call (fixture_pairs = count x {a, b}, verdict[i] = 0 refuses pair i): the
+ * form for a caller that asks b2ContactFilter::ShouldCollide(fA, fB, threadId) from several threads (b2WorldCallbacks.h:57-62). */
+typedef void (*b2hip_should_collide_batch_fn)(void* user, int count, const int32_t* fixture_pairs, int32_t* verdict);
+int b2hip_set_contact_filter_batch(b2hip_world* w, b2hip_should_collide_batch_fn fn, void* user);
 /* the built-in rule: b2ContactFilter::ShouldCollide (b2WorldCallbacks.cpp:24-38) on the fixtures' filter data */
 int b2hip_default_should_collide(b2hip_world* w, int fixture_a, int fixture_b);
 
@@ -494,6 +498,21 @@ typedef struct b2hip_contact_material
 typedef int (*b2hip_pre_solve_fn)(void* user, int contact_index, int fixture_a, int fixture_b,
 	const b2hip_manifold* old_manifold, const b2hip_manifold* manifold, b2hip_contact_material* material);
 int b2hip_set_pre_solve(b2hip_world* w, b2hip_pre_solve_fn fn, void* user);
+
+/* The same delivery as ONE call per step with all records (in the deferred order): the form a caller uses that wants to run
+ * b2ContactListener::PreSolveImmediate on the worker threads of its b2TaskExecutor, as the reference does during Collide
+ * (b2WorldCallbacks.h:135-173, b2Contact.cpp:283-297), and the deferred PreSolve afterwards in order. The callee fills
+ * `enabled` (in: 1) and `material` (in: the contact's values) of every record. Installing a batch function replaces the
+ * per-record one. */
+typedef struct b2hip_pre_solve_record
+{
+	int32_t contact_index, fixture_a, fixture_b;
+	int32_t enabled;
+	b2hip_manifold old_manifold, manifold;
+	b2hip_contact_material material;
+} b2hip_pre_solve_record;
+typedef void (*b2hip_pre_solve_batch_fn)(void* user, int count, b2hip_pre_solve_record* records);
+int b2hip_set_pre_solve_batch(b2hip_world* w, b2hip_pre_solve_batch_fn fn, void* user);
 
 /* b2ContactListener::PostSolve (generation b2Island.cpp:532-570, delivery b2ContactManager.cpp:454-470): the impulses the
  * solver ended with, one record per contact constraint of every island solved in the last step, in proxy-id-pair order.

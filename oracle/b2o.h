@@ -179,6 +179,16 @@ typedef struct b2o_contact_impulse
 void b2o_set_contact_filter(b2o_world* w, b2o_should_collide_fn fn, void* user);
 int b2o_default_should_collide(const b2o_world* w, int fixture_a, int fixture_b);
 void b2o_set_pre_solve(b2o_world* w, b2o_pre_solve_fn fn, void* user);
+/* all records of a step in one call (layout of b2hip_pre_solve_record): the callee fills enabled and material */
+typedef struct b2o_pre_solve_record
+{
+	int32_t contact_index, fixture_a, fixture_b;
+	int32_t enabled;
+	b2o_manifold old_manifold, manifold;
+	b2o_contact_material material;
+} b2o_pre_solve_record;
+typedef void (*b2o_pre_solve_batch_fn)(void* user, int count, b2o_pre_solve_record* records);
+void b2o_set_pre_solve_batch(b2o_world* w, b2o_pre_solve_batch_fn fn, void* user);
 void b2o_enable_post_solve(b2o_world* w, int enable);
 int b2o_get_post_solve(const b2o_world* w, int cap, b2o_contact_impulse* out);
 void b2o_enable_contact_events(b2o_world* w, int enable);

@@ -14,6 +14,8 @@ struct b2hip_world
 	b2o_world* o;
 	int fixtures;
 	int sub_stepping;
+	b2hip_should_collide_batch_fn filterBatch; /* asked pair by pair (the oracle decides inline): batches of one */
+	void* filterBatchUser;
 };
 
 const char* b2hip_last_error(void) { return "cpu oracle shim"; }
@@ -279,6 +281,29 @@ int b2hip_fixture_is_destroyed(const b2hip_world* w, int fixture) { return b2o_f
 int b2hip_set_contact_filter(b2hip_world* w, b2hip_should_collide_fn fn, void* user)
 {
 	b2o_set_contact_filter(w->o, (b2o_should_collide_fn)fn, user);
+	return 0;
+}
+
+static int filter_batch_of_one(void* user, int fixture_a, int fixture_b)
+{
+	b2hip_world* w = (b2hip_world*)user;
+	const int32_t pair[2] = { fixture_a, fixture_b };
+	int32_t verdict = 1;
+	w->filterBatch(w->filterBatchUser, 1, pair, &verdict);
+	return verdict;
+}
+
+int b2hip_set_contact_filter_batch(b2hip_world* w, b2hip_should_collide_batch_fn fn, void* user)
+{
+	w->filterBatch = fn;
+	w->filterBatchUser = user;
+	b2o_set_contact_filter(w->o, fn ? filter_batch_of_one : NULL, w);
+	return 0;
+}
+
+int b2hip_set_pre_solve_batch(b2hip_world* w, b2hip_pre_solve_batch_fn fn, void* user)
+{
+	b2o_set_pre_solve_batch(w->o, (b2o_pre_solve_batch_fn)fn, user); /* b2hip_pre_solve_record == b2o_pre_solve_record */
 	return 0;
 }
 

@@ -143,6 +143,7 @@ struct b2o_world
 	/* the other listener callbacks and the user contact filter (same protocol as include/b2hip.h) */
 	b2o_should_collide_fn filterFn; void* filterUser;
 	b2o_pre_solve_fn preSolveFn; void* preSolveUser;
+	b2o_pre_solve_batch_fn preSolveBatchFn;
 	int postSolveOn;
 	b2o_contact_impulse* postSolve; int nPostSolve, capPostSolve;
 	int* postSolveSlot; int capPostSolveSlot; /* contact slot of each record until the end of the step */
@@ -1041,18 +1042,36 @@ static void deliver_pre_solve(b2o_world* w)
 	destroy_cmp_world = w;
 	qsort(due, (size_t)n, sizeof(int), destroy_cmp);
 	int* rank = contact_ranks(w);
+	b2o_pre_solve_record* recs = (b2o_pre_solve_record*)malloc(sizeof(b2o_pre_solve_record) * (size_t)(n + 1));
 	for (int k = 0; k < n; ++k)
 	{
 		contact_t* c = &w->contacts[due[k]];
-		b2o_manifold oldM, newM;
-		fill_manifold(&oldM, &c->oldm);
-		fill_manifold(&newM, &c->m);
-		b2o_contact_material mat = { c->friction, c->restitution, c->tangentSpeed };
-		if (!w->preSolveFn(w->preSolveUser, rank[due[k]], c->fixtureA, c->fixtureB, &oldM, &newM, &mat)) c->flags &= ~CF_ENABLED;
-		c->friction = mat.friction; /* (the setters' values stay with the contact, b2Contact.h:129-160) */
-		c->restitution = mat.restitution;
-		c->tangentSpeed = mat.tangent_speed;
+		b2o_pre_solve_record* r = &recs[k];
+		r->contact_index = rank[due[k]];
+		r->fixture_a = c->fixtureA;
+		r->fixture_b = c->fixtureB;
+		r->enabled = 1;
+		fill_manifold(&r->old_manifold, &c->oldm);
+		fill_manifold(&r->manifold, &c->m);
+		r->material.friction = c->friction;
+		r->material.restitution = c->restitution;
+		r->material.tangent_speed = c->tangentSpeed;
 	}
+	if (w->preSolveBatchFn) w->preSolveBatchFn(w->preSolveUser, n, recs);
+	else for (int k = 0; k < n; ++k)
+	{
+		b2o_pre_solve_record* r = &recs[k];
+		r->enabled = w->preSolveFn(w->preSolveUser, r->contact_index, r->fixture_a, r->fixture_b, &r->old_manifold, &r->manifold, &r->material) != 0;
+	}
+	for (int k = 0; k < n; ++k)
+	{
+		contact_t* c = &w->contacts[due[k]];
+		if (!recs[k].enabled) c->flags &= ~CF_ENABLED;
+		c->friction = recs[k].material.friction; /* (the setters' values stay with the contact, b2Contact.h:129-160) */
+		c->restitution = recs[k].material.restitution;
+		c->tangentSpeed = recs[k].material.tangent_speed;
+	}
+	free(recs);
 	free(rank);
 	free(due);
 }
@@ -1102,7 +1121,7 @@ static void collide(b2o_world* w)
 	for (int k = 0; k < nDestroy; ++k) destroy_contact(w, destroys[k]);
 	free(destroys);
 	free(awakes);
-	if (w->preSolveFn) deliver_pre_solve(w);
+	if (w->preSolveFn || w->preSolveBatchFn) deliver_pre_solve(w);
 }
 
 /* ---- broad-phase --------------------------------------------------------------------------------- */
@@ -2714,6 +2733,7 @@ void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 
 void b2o_set_contact_filter(b2o_world* w, b2o_should_collide_fn fn, void* user) { w->filterFn = fn; w->filterUser = user; }
 void b2o_set_pre_solve(b2o_world* w, b2o_pre_solve_fn fn, void* user) { w->preSolveFn = fn; w->preSolveUser = user; }
+void b2o_set_pre_solve_batch(b2o_world* w, b2o_pre_solve_batch_fn fn, void* user) { w->preSolveBatchFn = fn; if (fn) w->preSolveUser = user; }
 void b2o_enable_post_solve(b2o_world* w, int enable) { w->postSolveOn = enable != 0; w->nPostSolve = 0; }
 int b2o_get_post_solve(const b2o_world* w, int cap, b2o_contact_impulse* out)
 {

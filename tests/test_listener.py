@@ -120,3 +120,54 @@ def test_device_post_solve_in_default_mode_reports_every_solved_constraint(amd):
         if s > 40:
             assert abs(len(ev) - touching) <= 0.02 * touching + 2, "step %d: %d PostSolve callbacks for %d touching contacts" % (s, len(ev), touching)
     w.close()
+
+
+def test_immediate_callbacks_run_on_the_executors_threads(oracle, ref):
+    """b2TaskExecutor use (b2TaskExecutor.h:27-79, b2WorldCallbacks.h:135-173): with a 4-thread executor the listener's
+    *Immediate callbacks are called from the worker threads, each with its own threadId < 4, and the deferred callbacks
+    afterwards on the stepping thread in the reference's order - the recorded callbacks and the physics (mode 8 disables
+    contacts from PreSolve) equal the reference build's run with 4 threads and the drop-in layer's own run with 1."""
+    import ctypes as C
+    worlds = {"drop-in x4": oracle.world(bh.RAIN, 200, 0, seed=4, threads=4), "drop-in x1": oracle.world(bh.RAIN, 200, 0, seed=4, threads=1),
+              "reference x4": ref.world(bh.RAIN, 200, 0, seed=4, threads=4)}
+    for w in worlds.values():
+        w.record_events(mode=MODE_DISABLE)
+    for s in range(120):
+        rows_ = {}
+        for name, w in worlds.items():
+            w.step(1)
+            rows_[name] = rows(w.events_ex())
+        assert rows_["drop-in x4"] == rows_["reference x4"] == rows_["drop-in x1"], "callbacks differ at step %d" % s
+    a = worlds["drop-in x4"].bodies()
+    for name in ("drop-in x1", "reference x4"):
+        assert np.array_equal(a.view(np.uint32), worlds[name].bodies().view(np.uint32)), name
+    hits = np.zeros(9, np.int32)
+    w = worlds["drop-in x4"]
+    w.L.b2h_immediate_calls_by_thread.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    w.L.b2h_immediate_calls_by_thread(w.ptr, hits.ctypes.data_as(C.POINTER(C.c_int)))
+    assert hits[8] == 0 and hits[4:8].sum() == 0, "a callback saw a thread id outside the executor's 4 threads: %s" % hits
+    assert np.count_nonzero(hits[:4]) >= 2, "every *Immediate callback ran on one thread: %s" % hits
+    one = np.zeros(9, np.int32)
+    w1 = worlds["drop-in x1"]
+    w1.L.b2h_immediate_calls_by_thread(w1.ptr, one.ctypes.data_as(C.POINTER(C.c_int)))
+    assert one[0] == hits[:4].sum() and one[1:].sum() == 0, "the same callbacks, all on thread 0: %s vs %s" % (one, hits)
+    for w in worlds.values():
+        w.close()
+
+
+@pytest.mark.gpu
+def test_device_callbacks_on_a_four_thread_executor_match_the_oracle(amd, oracle, monkeypatch):
+    """The product with a 4-thread b2ThreadPoolTaskExecutor: the filter's ShouldCollide and the *Immediate callbacks are
+    called in batches from the worker threads (b2hip_set_contact_filter_batch / b2hip_set_pre_solve_batch), the physics and
+    the deferred callbacks equal the oracle's single-threaded run, and more than one thread took part."""
+    import ctypes as C
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a = amd.world(bh.RAIN, 300, 0, seed=9, threads=4)
+    b = oracle.world(bh.RAIN, 300, 0, seed=9, threads=1)
+    run_pair(a, b, 120, MODE_DISABLE, True, "rain / 4 threads")
+    hits = np.zeros(9, np.int32)
+    a.L.b2h_immediate_calls_by_thread.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    a.L.b2h_immediate_calls_by_thread(a.ptr, hits.ctypes.data_as(C.POINTER(C.c_int)))
+    assert hits[4:].sum() == 0 and np.count_nonzero(hits[:4]) >= 2, hits
+    a.close()
+    b.close()
