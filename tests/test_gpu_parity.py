@@ -401,6 +401,43 @@ def test_bench_scene_run_to_run_determinism(amd, default_mode):
     assert first_bad is None, "two runs of the bench scene differ by step %s" % first_bad
 
 
+def test_config_3_at_full_size_properties_and_determinism(amd, oracle, default_mode):
+    """BASELINE config 3 at size: the Tumbler with 316 x 316 = 99 856 boxes in its revolving container (revolute motor, hub
+    body with tens of thousands of contacts), continuous physics off. The C oracle cannot follow at this size, so: (1) the
+    run-to-run rule of the reference (TestMT.cpp:91-110) - two runs, bitwise equal states and contact counts every 10th
+    step; (2) size-independent properties every 10th step - finite states, no box outside the container (it is closed:
+    escaping needs a tunnelling or solver failure), the container turning at its motor speed, contact counts between the
+    number of boxes resting on a neighbour and the all-pairs-in-a-cell bound; (3) at the largest size the oracle CAN
+    follow (2 000 boxes, tests/test_gpu_onestep.py) the same scene is compared against it directly."""
+    def run():
+        w = amd.world(bh.TUMBLER, 316, 0, flags=bh.F_SLEEP | bh.F_WARM)
+        trace = []
+        for s in range(6):
+            w.step(10)
+            b = w.bodies()
+            trace.append((bh.fnv1a64(b), w.contact_count, b.copy()))
+        n = w.body_count
+        w.close()
+        return n, trace
+
+    n, a = run()
+    _, b = run()
+    assert n == 316 * 316 + 2
+    S = 0.5 * 0.3 * 316 + 1.0  # half size of the container (harness/scenes.h: BuildTumbler)
+    for k, ((ha, ca, ba), (hb, cb, _)) in enumerate(zip(a, b)):
+        step = 10 * (k + 1)
+        assert (ha, ca) == (hb, cb), "two runs of config 3 differ by step %d" % step
+        assert np.isfinite(ba).all(), "step %d" % step
+        boxes = ba[2:]
+        # inside the (rotating) square: the distance from its centre (0, S) never exceeds the half diagonal
+        r = np.hypot(boxes[:, 0], boxes[:, 1] - S)
+        assert r.max() <= np.sqrt(2.0) * (S + 0.5) + 0.25, "step %d: a box left the container (r = %.2f)" % (step, r.max())
+        # the container (body 1) turns at 0.05 pi rad/s about its pin
+        assert abs(ba[1, 5] - 0.05 * np.pi) < 1e-3 and abs(ba[1, 2] - 0.05 * np.pi * step / 60.0) < 2e-3, "step %d: container %s" % (step, ba[1])
+        assert 0 <= ca <= 16 * n
+    assert a[-1][1] > 50000, "the pile has not formed: %d contacts" % a[-1][1]
+
+
 def test_block_solver_matches_launch_per_colour(amd, default_mode):
     """The default large-island solver (k_solve_blocks: one workgroup per block of the partition, bodies in LDS, boundary
     bodies handed over through memory) must reproduce the launch-per-colour solver bit for bit - same partition, same
