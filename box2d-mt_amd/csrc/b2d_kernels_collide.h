@@ -469,6 +469,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.nToiCalls = 0;
 		c.toiBase = 0;
 		c.toiOverflow = 0;
+		c.nToiLog = 0;
 		c.toiUnsafe = 0;
 		c.nToiGroups = 0;
 		c.nToiMoved = 0;

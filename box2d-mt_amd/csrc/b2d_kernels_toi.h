@@ -206,8 +206,32 @@ struct ToiUpdate
 {
 	float4 man0, man1, imp;
 	int4 man3;
+	float4 old0, old1, oldImp; // the manifold before the update (b2ContactListener::PreSolve is handed it)
+	int4 old3;
 	bool touching, wasTouching;
 };
+
+// The listener calls b2Contact::Update makes (b2Contact.cpp:253-297) as ONE log record: BeginContact when the contact starts
+// touching, EndContact when it stops, PreSolve while it touches (TOI candidates are never sensors). `slot` is the record's
+// place in DW::toiLog - the call order of the reference. The reported state (CF_REPORTED) follows what was logged.
+__device__ __forceinline__ void toiLogUpdate(const DW& W, const ContactArrays& C, int slot, int contact, int4 ids, const ToiUpdate& u)
+{
+	if (W.toiLog == nullptr || slot < 0 || slot >= W.capToiLog) return;
+	int kind = 0;
+	if (W.eventsOn && !u.wasTouching && u.touching) kind |= 1;
+	if (W.eventsOn && u.wasTouching && !u.touching) kind |= 2;
+	if (W.preSolveOn && u.touching) kind |= 4;
+	if (W.eventsOn)
+	{
+		if (u.touching) atomicOr(&C.flags[contact], CF_REPORTED); else atomicAnd(&C.flags[contact], ~CF_REPORTED);
+	}
+	ToiLogRec r;
+	r.info = make_int4(kind, contact, ids.x, ids.y);
+	r.o0 = u.old0; r.o1 = u.old1; r.oimp = u.oldImp; r.o3 = u.old3;
+	r.n0 = u.man0; r.n1 = u.man1; r.nimp = u.imp; r.n3 = u.man3;
+	r.mat = C.mat[contact];
+	W.toiLog[slot] = r;
+}
 
 __device__ __forceinline__ void toiEvaluate(const DW& W, const ContactArrays& C, int i, int4 ids, Xf xfA, Xf xfB, ToiUpdate* u)
 {
@@ -241,6 +265,7 @@ __device__ __forceinline__ void toiEvaluate(const DW& W, const ContactArrays& C,
 	u->man1 = make_float4(mf.p[0].x, mf.p[0].y, mf.p[1].x, mf.p[1].y);
 	u->imp = make_float4(ni[0], ti[0], ni[1], ti[1]);
 	u->man3 = make_int4((int)mf.id[0], (int)mf.id[1], mf.type, mf.pointCount);
+	u->old0 = o0; u->old1 = o1; u->oldImp = oldImp; u->old3 = m3;
 	u->touching = mf.pointCount > 0;
 }
 
@@ -308,6 +333,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 	__shared__ int s_unsafe, s_failed, s_movedLocal[TOI_DOM_MOVED_LOCAL], s_nMovedLocal;
 
 	__shared__ int s_nC, s_nL, s_events, s_calls, s_overflow;
+	__shared__ int s_logCursor; // next free record of DW::toiLog (listener calls of the sub-steps, in call order)
 	__shared__ int s_minIdx;
 	__shared__ float s_minAlpha;
 	__shared__ unsigned long long s_best[TOI_LANES];
@@ -343,6 +369,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		s_unsafe = 0;
 		s_failed = 0;
 		s_nMovedLocal = 0;
+		s_logCursor = S->c.nToiLog;
 		s_events = 0;
 		s_calls = 0;
 		s_overflow = 0;
@@ -452,6 +479,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			u.wasTouching = (ldFlags(&C.flags[minIdx]) & CF_TOUCHING) != 0;
 			toiEvaluate(W, C, minIdx, minIds, xfA, xfB, &u);
 			toiCommitUpdate(C, minIdx, u);
+			if (W.toiLog != nullptr) toiLogUpdate(W, C, s_logCursor++, minIdx, minIds, u);
 			uint32_t f = ldFlags(&C.flags[minIdx]);
 			const uint32_t cnt = ((f & CF_TOI_COUNT_MASK) >> CF_TOI_COUNT_SHIFT) + 1u;
 			f = (f & ~(CF_TOI | CF_TOI_COUNT_MASK)) | (cnt << CF_TOI_COUNT_SHIFT);
@@ -586,6 +614,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				for (int j = 0; j < nK; ++j) inIsland = inIsland || s_contacts[j] == cd.contact;
 				if (inIsland) continue;
 				cd.info |= 4; // visited: its update is committed
+				if (W.toiLog != nullptr) cd.info |= (s_logCursor++) << 8; // (... and its listener calls logged, in this order)
 				if (cd.info & 1)
 				{
 					s_contacts[nK++] = cd.contact;
@@ -609,6 +638,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			if (info & 4)
 			{
 				toiCommitUpdate(C, myContact, upd);
+				if (W.toiLog != nullptr) toiLogUpdate(W, C, info >> 8, myContact, C.ids[myContact], upd);
 				if (upd.touching != upd.wasTouching)
 				{
 					const int4 ids = C.ids[myContact];
@@ -765,9 +795,25 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				TOI_WAVE_SYNC();
 			}
 		}
+		// b2Island::Report (b2Island.cpp:527, 532-570): PostSolve with the sub-step's impulses, contact after contact
+		if (W.toiLog != nullptr && W.postSolveOn && ci >= 0 && s_logCursor + tid < W.capToiLog)
+		{
+			ToiLogRec r;
+			const int4 ids = C.ids[ci];
+			r.info = make_int4(8, ci, ids.x, ids.y);
+			r.o0 = r.o1 = r.oimp = make_float4(0, 0, 0, 0);
+			r.o3 = make_int4(0, 0, 0, 0);
+			r.n0 = C.man0[ci]; r.n1 = C.man1[ci];
+			r.nimp = make_float4(cc.normalImpulse[0], cc.tangentImpulse[0], cc.pointCount > 1 ? cc.normalImpulse[1] : 0.0f, cc.pointCount > 1 ? cc.tangentImpulse[1] : 0.0f);
+			r.n3 = C.man3[ci];
+			r.n3.w = cc.pointCount;
+			r.mat = cmat;
+			W.toiLog[s_logCursor + tid] = r;
+		}
 		} // first wave
 #undef TOI_WAVE_SYNC
 		__syncthreads();
+		if (tid == 0 && W.toiLog != nullptr && W.postSolveOn) s_logCursor += nK;
 		// integrate positions, sync bodies (b2Island.cpp:483-527); TOI impulses are not stored
 		if (tid < nB)
 		{
@@ -1179,8 +1225,9 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			if (!partial) S->c.nToiList = s_nL;
 			S->c.nToiEvents = (partial ? S->c.nToiEvents : 0) + s_events;
 			atomicAdd(&S->c.nToiCalls, s_calls);
-			S->c.toiOverflow = s_overflow;
+			S->c.toiOverflow = s_overflow | (s_logCursor > W.capToiLog && W.toiLog != nullptr ? 64 : 0);
 			S->c.nToiOrder = s_toiOrder;
+			S->c.nToiLog = s_logCursor < W.capToiLog ? s_logCursor : W.capToiLog;
 		}
 	}
 }

@@ -119,6 +119,7 @@ struct Counters
 	int nToiEvents;      // TOI sub-steps solved this step
 	int nToiCalls;       // b2TimeOfImpact evaluations this step
 	int toiBase;         // contact count when the TOI adjacency was built (later contacts form the tail)
+	int nToiLog;         // records in DW::toiLog this step
 	int toiOverflow;     // bit0 candidates, bit1 moves, bit2 pairs, bit3 recompute list, bit4 TOI list
 	int nToiOrder;       // persistent: TOI-candidate contacts alive (b2ContactManager::m_toiCount)
 	int nToiDestroy;     // TOI candidates destroyed by the running collide
@@ -186,6 +187,17 @@ struct PreSolveRec
 	float4 n0, n1, nimp;     // new manifold
 	int4 n3;
 	float4 mat;              // the contact's mixed friction, restitution, tangent speed (b2Contact.h:40-50, 157) as the callback may edit them
+};
+// One listener call the reference makes from a TOI sub-step (b2World.cpp:866,946: contact->Update(listener); b2Island.cpp:527 ->
+// Report), logged by the serial TOI loop in call order (DW::toiLog, Counters::nToiLog) while a listener is installed.
+struct ToiLogRec
+{
+	int4 info;               // kind bits (1 BeginContact, 2 EndContact, 4 PreSolve, 8 PostSolve), contact index, proxy A, proxy B
+	float4 o0, o1, oimp;     // old manifold (PreSolve)
+	int4 o3;
+	float4 n0, n1, nimp;     // new manifold ; PostSolve: nimp = the solver's impulses, n3.w = its point count
+	int4 n3;
+	float4 mat;
 };
 struct PostSolveRec
 {
@@ -361,6 +373,8 @@ struct DW
 	int4* pre_o3;
 	PreSolveRec* preRecs;
 	PostSolveRec* postRecs;
+	ToiLogRec* toiLog;      // listener calls from TOI sub-steps, in call order (null: no listener)
+	int capToiLog;
 	int* filterList;     // contact indices flagged CF_FILTER (listed for the user's filter before Collide)
 
 	// ---- broad-phase ------------------------------------------------------------------------

@@ -222,6 +222,8 @@ struct b2hip_world
 	DevArray<int4> evInfo;
 	bool eventsOn = false;
 	std::vector<b2hip_contact_event> events; // of the last step, in delivery order
+	std::vector<b2hip_toi_callback> toiCallbacks; // listener calls of the last step's TOI sub-steps, in call order
+	DevArray<ToiLogRec> toiLog;
 	DevArray<int> uncolList, compactList, hubRowOf, hubList;
 	DevArray<float4> hubDelta;
 	DevArray<int> rootDone;
@@ -652,6 +654,8 @@ static int runSegment(b2hip_world* w, GraphSeg& seg, uint64_t extra, F launches)
 
 static inline bool hasFilter(const b2hip_world* w) { return w->filterFn != nullptr || w->filterBatchFn != nullptr; }
 static inline bool hasPreSolve(const b2hip_world* w) { return w->preSolveFn != nullptr || w->preSolveBatchFn != nullptr; }
+// any listener callback switched on: the TOI sub-steps log their calls (b2hip_get_toi_callbacks) and run in serial order
+static inline bool listenerOn(const b2hip_world* w) { return w->eventsOn || hasPreSolve(w) || w->postSolveOn; }
 
 static int ktRecord(b2hip_world* w)
 {
@@ -804,6 +808,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		const size_t nPre = hasPreSolve(w) ? cc : 1, nPost = w->postSolveOn ? cc : 1, nFil = hasFilter(w) ? cc : 1;
 		ENS(pre_o0, nPre); ENS(pre_o1, nPre); ENS(pre_oimp, nPre); ENS(pre_o3, nPre); ENS(preRecs, nPre);
 		ENS(postRecs, nPost); ENS(filterList, nFil);
+		ENS(toiLog, listenerOn(w) && w->def.continuous ? cc : 1);
 		ENS(hostList, std::max<size_t>(std::max(4 * nPre, nFil), hasFilter(w) ? capPairs : 1)); // (PreSolve material edits: 4 words each)
 	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2); ENS(blkBodyCount, MAX_BLOCKS + 2); ENS(blkBodyCursor, MAX_BLOCKS + 2);
@@ -885,6 +890,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.userFilter = hasFilter(w) ? 1 : 0; d.preSolveOn = hasPreSolve(w) ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
 	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
 	d.preRecs = w->preRecs.p; d.postRecs = w->postRecs.p; d.filterList = w->filterList.p;
+	d.toiLog = listenerOn(w) && w->def.continuous ? w->toiLog.p : nullptr;
+	d.capToiLog = (int)std::min<size_t>(w->toiLog.cap, 0x7fffff);
 	return 0;
 }
 
@@ -2003,7 +2010,7 @@ static int phaseToiSync(b2hip_world* w);
 // contacts, and the synchronous phase). One read-back and ~45 us less per step with continuous physics on.
 static int phaseToi(b2hip_world* w)
 {
-	if (w->toiSerialOnly || w->toiSyncOnly) return phaseToiSync(w);
+	if (w->toiSerialOnly || w->toiSyncOnly || listenerOn(w)) return phaseToiSync(w);
 	if (w->toiSyncSticky > 0)
 	{
 		// the serial loop was needed recently (bullets, kinematic partners, contact-creating events): decide from the
@@ -2076,7 +2083,7 @@ static int phaseToiSync(b2hip_world* w)
 	if (w->h_dstate->c.nToiList == 0) return 0;
 	if (w->h_dstate->c.nToiList > d.capContacts) return setError(B2HIP_ERR_CAPACITY, "TOI list overflow");
 	w->toiRan = true;
-	if (w->h_dstate->c.toiUnsafe == 0 && !w->toiSerialOnly)
+	if (w->h_dstate->c.toiUnsafe == 0 && !w->toiSerialOnly && !listenerOn(w))
 	{
 		// every pending impact pairs a dynamic body with a static one: one wave per dynamic body, verified afterwards
 		// (b2hip_step_end falls back to the serial loop from the snapshot if a chain met a case that is order dependent)
@@ -2098,7 +2105,7 @@ static int phaseToiSync(b2hip_world* w)
 		w->toiChains = true;
 		return 0;
 	}
-	if (!w->toiSerialOnly && !w->toiNoDomains)
+	if (!w->toiSerialOnly && !w->toiNoDomains && !listenerOn(w))
 	{
 		// bullets / kinematic partners: the event loop runs per connected component of the contact graph, side by side
 		// (b2d_kernels_toi_domains.h); b2hip_step_end falls back to the serial loop from the snapshot if a component met
@@ -2431,7 +2438,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->d_editOps.release();
 	w->b_order.release(); w->orderBody.release(); w->bigRoots.release();
 	w->pre_o0.release(); w->pre_o1.release(); w->pre_oimp.release(); w->pre_o3.release(); w->preRecs.release();
-	w->postRecs.release(); w->filterList.release(); w->hostList.release();
+	w->postRecs.release(); w->filterList.release(); w->hostList.release(); w->toiLog.release();
 	w->b_blk1.release(); w->b_adopt.release(); w->b_adoptStage.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release(); w->blkBodyCount.release(); w->blkBodyCursor.release();
 	w->blkBodyStart.release(); w->blkBodies.release(); w->rowColor.release(); w->b_cutv.release();
 	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
@@ -3610,6 +3617,9 @@ static int collideImpl(b2hip_world* w)
 			if (rc) return rc;
 		}
 	}
+	// the begin / end events of THIS phase are listed now (k_contact_events compares touching with what the host was told and
+	// flips CF_REPORTED): what the TOI sub-steps change later in the step is logged by the sub-steps themselves, in order
+	if (w->eventsOn && w->def.continuous && w->sp.dt > 0.0f) LAUNCH(w, k_contact_events, gridFor(w->dw.capContacts), 256, w->dw);
 	stampPhase(w, 2);
 	return 0;
 }
@@ -3839,6 +3849,33 @@ static int stepEndImpl(b2hip_world* w)
 			}
 		}
 	}
+	w->toiCallbacks.clear();
+	if (w->dw.toiLog != nullptr)
+	{
+		const int n = std::min(w->h_dstate->c.nToiLog, w->dw.capToiLog);
+		if (n > 0)
+		{
+			std::vector<ToiLogRec> recs((size_t)n);
+			HIP_TRY(hipMemcpy((void*)recs.data(), w->toiLog.p, (size_t)n * sizeof(ToiLogRec), hipMemcpyDeviceToHost));
+			for (int k = 0; k < n; ++k)
+			{
+				const ToiLogRec& r = recs[k];
+				if (r.info.x == 0) continue; // (an Update that called nothing: the contact neither touched before nor after)
+				b2hip_toi_callback cb;
+				memset(&cb, 0, sizeof(cb));
+				cb.kind = r.info.x;
+				cb.contact_index = r.info.y;
+				cb.fixture_a = r.info.z;
+				cb.fixture_b = r.info.w;
+				toManifold(&cb.old_manifold, r.o0, r.o1, r.oimp, r.o3);
+				toManifold(&cb.manifold, r.n0, r.n1, r.nimp, r.n3);
+				cb.material.friction = r.mat.x;
+				cb.material.restitution = r.mat.y;
+				cb.material.tangent_speed = r.mat.z;
+				w->toiCallbacks.push_back(cb);
+			}
+		}
+	}
 	w->events.clear();
 	// (the rows were left out of a read-back because another one was due, and it did not come: safety net, never seen)
 	if (w->h_dstate->c.rowsSkipped)
@@ -4062,6 +4099,14 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
 	if (!w || (cap > 0 && !out)) return setError(B2HIP_ERR_INVALID, "null argument");
 	const int n = (int)w->events.size();
 	for (int i = 0; i < n && i < cap; ++i) out[i] = w->events[i];
+	return n;
+}
+
+int b2hip_get_toi_callbacks(b2hip_world* w, int cap, b2hip_toi_callback* out)
+{
+	if (!w || (cap > 0 && !out)) return setError(B2HIP_ERR_INVALID, "null argument");
+	const int n = (int)w->toiCallbacks.size();
+	for (int i = 0; i < n && i < cap; ++i) out[i] = w->toiCallbacks[i];
 	return n;
 }
 

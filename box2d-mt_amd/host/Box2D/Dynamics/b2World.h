@@ -113,6 +113,7 @@ private:
 	friend class b2Contact;
 	void DeliverContactEvents();
 	void DeliverPostSolve();
+	void DeliverToiCallbacks();
 	static int FilterTrampoline(void* user, int fixtureA, int fixtureB);
 	static void FilterBatchTrampoline(void* user, int count, const int32_t* fixturePairs, int32_t* verdict);
 	static void PreSolveBatchTrampoline(void* user, int count, struct b2hip_pre_solve_record* records);

@@ -498,6 +498,7 @@ void b2World::Step(float32 dt, int32 velocityIterations, int32 positionIteration
 	// the reference's order within a step: begin / end (Collide), [PreSolve: called by the step itself], PostSolve (Solve)
 	DeliverContactEvents();
 	DeliverPostSolve();
+	DeliverToiCallbacks();
 	m_stepExecutor = nullptr;
 	float ms[13];
 	if (b2hip_get_profile(m_hip, ms) == B2HIP_OK)
@@ -728,6 +729,56 @@ void b2World::DeliverPostSolve()
 	for (size_t i = 0; i < c.contacts.size(); ++i)
 	{
 		if (c.deferred[i]) m_contactListener->PostSolve(c.contacts[i], &c.impulses[i]);
+	}
+}
+
+// The listener calls the reference makes from inside its TOI sub-steps (b2World.cpp:866,946: contact->Update(listener);
+// b2Island.cpp:527: Report), replayed from the step's log in the reference's call order, after the Collide and Solve callbacks
+// like there. The sub-steps run on one thread in the reference: immediate and deferred form are called back to back, threadId 0.
+// (They are replayed after the fact: a PreSolve here cannot disable its contact for the sub-step that called it.)
+void b2World::DeliverToiCallbacks()
+{
+	if (!m_hip || !m_contactListener) return;
+	int count = b2hip_get_toi_callbacks(m_hip, 0, nullptr);
+	if (count <= 0) return;
+	std::vector<b2hip_toi_callback> rec((size_t)count);
+	count = b2hip_get_toi_callbacks(m_hip, count, rec.data());
+	for (int i = 0; i < count; ++i)
+	{
+		const b2hip_toi_callback& r = rec[i];
+		if (r.fixture_a < 0 || r.fixture_b < 0 || r.fixture_a >= (int)m_fixtures.size() || r.fixture_b >= (int)m_fixtures.size()) continue;
+		if (!m_fixtures[r.fixture_a] || !m_fixtures[r.fixture_b]) continue;
+		b2Contact c;
+		FillManifold(c.m_manifold, r.manifold);
+		BindFixtures(c, r.fixture_a, r.fixture_b);
+		c.m_next = nullptr;
+		c.m_friction = r.material.friction;
+		c.m_restitution = r.material.restitution;
+		c.m_tangentSpeed = r.material.tangent_speed;
+		c.m_enabled = true;
+		if (r.kind & 8)
+		{
+			// (the record's impulses are the sub-step solver's, its point count the solver's; the view shows the contact's manifold)
+			b2ContactImpulse impulse;
+			impulse.count = r.manifold.point_count;
+			for (int k = 0; k < b2_maxManifoldPoints; ++k)
+			{
+				impulse.normalImpulses[k] = k < impulse.count ? r.manifold.normal_impulse[k] : 0.0f;
+				impulse.tangentImpulses[k] = k < impulse.count ? r.manifold.tangent_impulse[k] : 0.0f;
+			}
+			c.m_touching = true;
+			if (m_contactListener->PostSolveImmediate(&c, &impulse, 0)) m_contactListener->PostSolve(&c, &impulse);
+			continue;
+		}
+		c.m_touching = (r.kind & 2) == 0;
+		if ((r.kind & 1) && m_contactListener->BeginContactImmediate(&c, 0)) m_contactListener->BeginContact(&c);
+		if ((r.kind & 2) && m_contactListener->EndContactImmediate(&c, 0)) m_contactListener->EndContact(&c);
+		if (r.kind & 4)
+		{
+			b2Manifold old;
+			FillManifold(old, r.old_manifold);
+			if (m_contactListener->PreSolveImmediate(&c, &old, 0)) m_contactListener->PreSolve(&c, &old);
+		}
 	}
 }
 

@@ -514,6 +514,27 @@ typedef struct b2hip_pre_solve_record
 typedef void (*b2hip_pre_solve_batch_fn)(void* user, int count, b2hip_pre_solve_record* records);
 int b2hip_set_pre_solve_batch(b2hip_world* w, b2hip_pre_solve_batch_fn fn, void* user);
 
+/* The listener calls the reference makes from INSIDE its TOI sub-steps (b2World::SolveTOI -> StepSolveTOI, b2World.cpp:866,946:
+ * contact->Update(listener) on the TOI contact and on every contact of the two bodies it visits; b2Island::SolveTOI ->
+ * Report, b2Island.cpp:527): the last step's calls in the reference's call order - event after event, inside an event the
+ * TOI contact's Update, the visited contacts' Updates in walk order, then PostSolve for the sub-step's island in island
+ * order. They come after the Collide / Solve callbacks of the step (b2hip_get_contact_events, PreSolve, b2hip_get_post_solve).
+ * One record per call site; `kind` says which callbacks it stands for (an Update can be BeginContact + PreSolve at once):
+ *   bit0 BeginContact, bit1 EndContact, bit2 PreSolve(old_manifold), bit3 PostSolve (manifold.normal_impulse / tangent_impulse
+ *   = the sub-step solver's impulses, manifold.point_count = its point count).
+ * Recorded while begin / end events, a PreSolve function or PostSolve records are switched on (each kind only if its
+ * callback is), and the TOI phase then runs through the serial event loop (the order IS the serial order). The records
+ * are made after the fact: what a PreSolve does to its contact (SetEnabled, SetFriction ...) cannot reach the sub-step
+ * that called it. */
+typedef struct b2hip_toi_callback
+{
+	int32_t kind;
+	int32_t contact_index, fixture_a, fixture_b;
+	b2hip_manifold old_manifold, manifold;
+	b2hip_contact_material material;
+} b2hip_toi_callback;
+int b2hip_get_toi_callbacks(b2hip_world* w, int cap, b2hip_toi_callback* out);
+
 /* b2ContactListener::PostSolve (generation b2Island.cpp:532-570, delivery b2ContactManager.cpp:454-470): the impulses the
  * solver ended with, one record per contact constraint of every island solved in the last step, in proxy-id-pair order.
  * `count` is the solver's point count (1 when the block solver's conditioning guard dropped the second point,

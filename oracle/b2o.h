@@ -180,6 +180,16 @@ void b2o_set_contact_filter(b2o_world* w, b2o_should_collide_fn fn, void* user);
 int b2o_default_should_collide(const b2o_world* w, int fixture_a, int fixture_b);
 void b2o_set_pre_solve(b2o_world* w, b2o_pre_solve_fn fn, void* user);
 /* all records of a step in one call (layout of b2hip_pre_solve_record): the callee fills enabled and material */
+/* the listener calls of the TOI sub-steps in call order (layout and meaning of b2hip_toi_callback, include/b2hip.h) */
+typedef struct b2o_toi_callback
+{
+	int32_t kind; /* bit0 BeginContact, bit1 EndContact, bit2 PreSolve, bit3 PostSolve */
+	int32_t contact_index, fixture_a, fixture_b;
+	b2o_manifold old_manifold, manifold;
+	b2o_contact_material material;
+} b2o_toi_callback;
+int b2o_get_toi_callbacks(const b2o_world* w, int cap, b2o_toi_callback* out);
+
 typedef struct b2o_pre_solve_record
 {
 	int32_t contact_index, fixture_a, fixture_b;

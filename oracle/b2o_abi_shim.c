@@ -318,6 +318,11 @@ int b2hip_set_pre_solve(b2hip_world* w, b2hip_pre_solve_fn fn, void* user)
 	return 0;
 }
 
+int b2hip_get_toi_callbacks(b2hip_world* w, int cap, b2hip_toi_callback* out)
+{
+	return b2o_get_toi_callbacks(w->o, cap, (b2o_toi_callback*)out); /* same layout */
+}
+
 int b2hip_enable_post_solve(b2hip_world* w, int enable)
 {
 	b2o_enable_post_solve(w->o, enable);

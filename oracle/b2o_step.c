@@ -144,6 +144,7 @@ struct b2o_world
 	b2o_should_collide_fn filterFn; void* filterUser;
 	b2o_pre_solve_fn preSolveFn; void* preSolveUser;
 	b2o_pre_solve_batch_fn preSolveBatchFn;
+	b2o_toi_callback* toiLog; int nToiLog, capToiLog; /* listener calls of this step's TOI sub-steps (contact_index = slot until read) */
 	int postSolveOn;
 	b2o_contact_impulse* postSolve; int nPostSolve, capPostSolve;
 	int* postSolveSlot; int capPostSolveSlot; /* contact slot of each record until the end of the step */
@@ -187,6 +188,7 @@ void b2o_world_destroy(b2o_world* w)
 	free(w->eventKeys);
 	free(w->postSolve);
 	free(w->postSolveSlot);
+	free(w->toiLog);
 	free(w->bodyOwned);
 	free(w->contactOwned);
 	free(w->jointOwned);
@@ -2240,10 +2242,44 @@ static int find_min_toi(b2o_world* w, float* alphaOut)
 }
 
 /* b2Contact::Update(listener) - the single-threaded variant wakes both bodies when the touching state flips */
+static int listener_on(const b2o_world* w) { return w->eventsOn || w->preSolveFn != NULL || w->preSolveBatchFn != NULL || w->postSolveOn; }
+
+static b2o_toi_callback* toi_log_push(b2o_world* w)
+{
+	GROW(w->toiLog, w->capToiLog, w->nToiLog + 1, b2o_toi_callback);
+	b2o_toi_callback* r = &w->toiLog[w->nToiLog++];
+	memset(r, 0, sizeof(*r));
+	return r;
+}
+
+/* b2Contact::Update(listener) in a TOI sub-step (b2World.cpp:866,946 -> b2Contact.cpp:253-297): the callbacks it makes,
+ * as one log record */
 static void contact_update_st(b2o_world* w, contact_t* c)
 {
 	int wasTouching = (c->flags & CF_TOUCHING) != 0;
 	contact_update(w, c);
+	if (listener_on(w))
+	{
+		const int touching = (c->flags & CF_TOUCHING) != 0;
+		int kind = 0;
+		if (w->eventsOn && !wasTouching && touching) kind |= 1;
+		if (w->eventsOn && wasTouching && !touching) kind |= 2;
+		if ((w->preSolveFn != NULL || w->preSolveBatchFn != NULL) && touching) kind |= 4;
+		if (w->eventsOn) c->reported = touching;
+		if (kind)
+		{
+			b2o_toi_callback* r = toi_log_push(w);
+			r->kind = kind;
+			r->contact_index = (int32_t)(c - w->contacts);
+			r->fixture_a = c->fixtureA;
+			r->fixture_b = c->fixtureB;
+			fill_manifold(&r->old_manifold, &c->oldm);
+			fill_manifold(&r->manifold, &c->m);
+			r->material.friction = c->friction;
+			r->material.restitution = c->restitution;
+			r->material.tangent_speed = c->tangentSpeed;
+		}
+	}
 	int sensor = w->fixtures[c->fixtureA].isSensor || w->fixtures[c->fixtureB].isSensor;
 	if (!sensor && ((c->flags & CF_TOUCHING) != 0) != wasTouching)
 	{
@@ -2346,7 +2382,29 @@ static void solve_toi_island(b2o_world* w, const int* bodies, int bodyCount, con
 	w->warmStarting = warm;
 	for (int it = 0; it < velIters; ++it)
 		for (int i = 0; i < contactCount; ++i) solve_velocity(&cs[i], velocities);
-	/* impulses are not stored back */
+	/* impulses are not stored back; b2Island::Report (b2Island.cpp:527, 532-570) shows them to PostSolve */
+	if (w->postSolveOn)
+	{
+		for (int i = 0; i < contactCount; ++i)
+		{
+			const contact_t* c = &w->contacts[contacts[i]];
+			b2o_toi_callback* r = toi_log_push(w);
+			r->kind = 8;
+			r->contact_index = contacts[i];
+			r->fixture_a = c->fixtureA;
+			r->fixture_b = c->fixtureB;
+			fill_manifold(&r->manifold, &c->m);
+			r->manifold.point_count = cs[i].pointCount;
+			for (int k = 0; k < 2; ++k)
+			{
+				r->manifold.normal_impulse[k] = k < cs[i].pointCount ? cs[i].normalImpulse[k] : 0.0f;
+				r->manifold.tangent_impulse[k] = k < cs[i].pointCount ? cs[i].tangentImpulse[k] : 0.0f;
+			}
+			r->material.friction = c->friction;
+			r->material.restitution = c->restitution;
+			r->material.tangent_speed = c->tangentSpeed;
+		}
+	}
 	for (int i = 0; i < bodyCount; ++i)
 	{
 		vec2 c = positions[i].c, v = velocities[i].v;
@@ -2520,6 +2578,18 @@ static void collect_contact_events(b2o_world* w)
 	}
 }
 
+int b2o_get_toi_callbacks(const b2o_world* w, int cap, b2o_toi_callback* out)
+{
+	int* rank = contact_ranks(w);
+	for (int i = 0; i < w->nToiLog && i < cap; ++i)
+	{
+		out[i] = w->toiLog[i];
+		out[i].contact_index = rank[w->toiLog[i].contact_index]; /* slot -> index in b2o_get_contacts order */
+	}
+	free(rank);
+	return w->nToiLog;
+}
+
 void b2o_enable_contact_events(b2o_world* w, int enable)
 {
 	w->eventsOn = enable != 0;
@@ -2567,6 +2637,7 @@ void b2o_step_begin(b2o_world* w, float dt, int velIters, int posIters)
 {
 	w->nEvents = 0;
 	w->nPostSolve = 0;
+	w->nToiLog = 0;
 	w->stepDt = dt; w->stepVelIters = velIters; w->stepPosIters = posIters;
 	if (w->newFixture)
 	{
@@ -2574,7 +2645,11 @@ void b2o_step_begin(b2o_world* w, float dt, int velIters, int posIters)
 		w->newFixture = 0;
 	}
 }
-void b2o_phase_collide(b2o_world* w) { collide(w); }
+void b2o_phase_collide(b2o_world* w)
+{
+	collide(w);
+	if (w->eventsOn && w->continuous && w->stepDt > 0.0f) collect_contact_events(w);
+}
 void b2o_phase_solve(b2o_world* w)
 {
 	if (w->stepDt > 0.0f) solve_islands(w, w->stepDt, w->inv_dt0 * w->stepDt, w->stepVelIters, w->stepPosIters);
@@ -2716,7 +2791,9 @@ void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 		find_new_contacts(w);
 		w->newFixture = 0;
 	}
+	w->nToiLog = 0;
 	collide(w);
+	if (w->eventsOn && w->continuous && dt > 0.0f) collect_contact_events(w);
 	float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
 	float dtRatio = w->inv_dt0 * dt;
 	if (dt > 0.0f) solve(w, dt, dtRatio, velIters, posIters);
