@@ -135,6 +135,19 @@ def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, roof_mode, 
            "toi_events_last_step": ctr.toi_events,
            "device_profile_ms": {k: round(v, 4) for k, v in w.profile().items() if k != "steps"}}
     try:
+        # the same window length once more with the read-back on demand (b2hip_set_lazy_readback): nobody looks at a body
+        # between these steps, the states come home once at the end (inside the timed region)
+        hipL.b2hip_set_lazy_readback.argtypes = [C.c_void_p, C.c_int]
+        if hipL.b2hip_set_lazy_readback(dev, 1) == 0:
+            tl = time.perf_counter()
+            w.step(steps)
+            w.bodies()
+            out["ms_per_step_lazy_readback"] = 1000.0 * (time.perf_counter() - tl) / steps
+            out["lazy_readback_window"] = "steps %d..%d, states fetched once after the last" % (settle + steps, settle + 2 * steps - 1)
+            hipL.b2hip_set_lazy_readback(dev, 0)
+    except Exception as e:
+        out["ms_per_step_lazy_readback"] = {"error": str(e)}
+    try:
         # algorithmic units: collide 480 B per polygon-polygon contact (the Tumbler has nothing else), sync fixtures 250 B per proxy
         units = {2: (w.contact_count, 0), 3: (hipL.b2hip_fixture_count(dev), 0), 4: (hipL.b2hip_fixture_count(dev), 0)}.get(roof_mode)
         roof = kernel_roofline(hipL, dev, lambda: w.step(1), roof_mode, 5, units)

@@ -530,7 +530,13 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 // radix path and read back AGAIN (more new pairs than the counting path ranks, or a pair-buffer overflow: the test
 // stepEndImpl makes), only the counters travel now - the rows would be overwritten by the second read-back anyway, and at
 // 1 M bodies they are 40 MB of PCIe. Counters::rowsSkipped tells the host (which reads back in full before it returns).
-__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq, int skipIfRedo)
+// mode END_STEP_LAZY (b2hip_set_lazy_readback): the step's house-keeping and the counters, but the rows stay on the device
+// until somebody asks for a body's state; mode END_STEP_ROWS is that later fetch: rows and counters, nothing else.
+#define END_STEP_FULL 0
+#define END_STEP_SKIP_IF_REDO 1
+#define END_STEP_LAZY 2
+#define END_STEP_ROWS 3
+__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq, int mode)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -540,7 +546,8 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	__shared__ int s_last;
 	const bool toiEvents = S->c.nToiEvents != 0;
 	bool skipRows = false;
-	if (skipIfRedo)
+	const bool storeRows = mode != END_STEP_LAZY, houseKeeping = mode != END_STEP_ROWS;
+	if (mode == END_STEP_SKIP_IF_REDO)
 	{
 		const int ov = S->c.overflow, moves = S->c.nMoves;
 		const bool pairOverflow = (ov & 2) != 0 || ((ov & 1) != 0 && moves != 0);
@@ -552,11 +559,11 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 		if (i < n)
 		{
 			uint32_t f = W.b_flags[i];
-			if (clearForces) W.b_force[i] = make_float4(0, 0, 0, 0);
+			if (clearForces && houseKeeping) W.b_force[i] = make_float4(0, 0, 0, 0);
 			// b2ClearBodySolveTOIFlags (b2World.cpp:239-259, k_toi_clear): sweeps go back to alpha0 = 0 for the next step
-			if (toiEvents) W.b_pos0[i].w = 0.0f;
+			if (toiEvents && houseKeeping) W.b_pos0[i].w = 0.0f;
 			float4 xf = W.b_xf[i], p = W.b_pos[i], v = W.b_vel[i];
-			float* o = s_out + tid * 10;
+			float* o = s_out + tid * 10; // (filled in every mode: cheaper than a second predicate around ten LDS stores)
 			o[0] = xf.x;
 			o[1] = xf.y;
 			o[2] = p.z;
@@ -568,6 +575,7 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 			o[8] = __uint_as_float(f & 0x7fu);
 			o[9] = p.w;
 		}
+		if (!storeRows) continue; // (uniform over the workgroup: every lane leaves the tile before its barriers)
 		__syncthreads();
 		const int cnt = (n - base < 256 ? n - base : 256) * 10; // floats of this tile; base * 40 bytes is 16-byte aligned
 		float* dst = out + (size_t)base * 10;
@@ -591,8 +599,8 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	if (bar != nullptr && tid < 6) S->stamps[tid] = bar[8 + tid];
 	if (tid == 0)
 	{
-		S->phaseClock[13] = wall_clock64(); // end of the step, read-back included
-		S->c.rowsSkipped = skipRows ? 1 : 0;
+		if (houseKeeping) S->phaseClock[13] = wall_clock64(); // end of the step, read-back included
+		S->c.rowsSkipped = skipRows ? 1 : (storeRows ? 0 : 2);
 	}
 	__threadfence();
 	__syncthreads();

@@ -307,6 +307,11 @@ struct b2hip_world
 	int pubSeq = 0;
 	bool noCensusPoll = false;   // B2HIP_NO_CENSUS_POLL=1: copy + stream synchronisation instead (for comparison)
 	bool noStatePoll = false;    // B2HIP_NO_STATE_POLL=1: the same for the read-back at the end of the step
+	// b2hip_set_lazy_readback: a step ends with the counters only; the 40 B per body stay on the device until a body's state
+	// is asked for (rowsPending: h_state's rows are older than the device's; fetched once, by whoever asks first)
+	bool lazyReadback = false;
+	std::atomic<bool> rowsPending{false};
+	std::mutex rowsMutex;
 	bool blocksThisStep = false; // the large islands of this step went through k_solve_blocks
 
 	Counters last;        // counters of the last completed step
@@ -375,10 +380,12 @@ static int nextPow2(size_t n)
 
 // The read-back buffer h_state IS the host mirror of the dynamic state; a HostBody is refreshed from it only
 // when the host is about to edit that body (no O(bodies) host loop per step).
+static void ensureRows(b2hip_world* w);
 static void pullBody(b2hip_world* w, int i)
 {
 	if ((size_t)i >= w->stateCount || w->h_state == nullptr) return;
 	HostBody& b = w->bodies[i];
+	if (b.pullEpoch != w->mirrorEpoch) ensureRows(w);
 	// once pulled, the host row is the newer one until the next read-back (an upload in between - a contact read flushes
 	// the edits made so far - does not make h_state any fresher)
 	if (b.pullEpoch == w->mirrorEpoch) return;
@@ -822,10 +829,18 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	w->scanCtx.abortWord = &w->d_state.p->c.overflow;
 	if (w->h_stateCap < 12 * nb + sizeof(DState) / sizeof(float) + 4)
 	{
-		if (w->h_state) (void)hipHostFree(w->h_state);
+		// (the rows of the last read-back are the host's mirror of every body it has not edited: they move along)
+		ensureRows(w);
+		float* old = w->h_state;
+		w->h_state = nullptr;
 		w->h_stateCap = 12 * nb * 2 + sizeof(DState) / sizeof(float) + 4;
 		HIP_TRY(hipHostMalloc((void**)&w->h_state, w->h_stateCap * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
 		HIP_TRY(hipHostGetDevicePointer((void**)&w->d_hstate, w->h_state, 0));
+		if (old)
+		{
+			memcpy(w->h_state, old, w->stateCount * 10 * sizeof(float));
+			(void)hipHostFree(old);
+		}
 	}
 
 	DW& d = w->dw;
@@ -2149,6 +2164,9 @@ static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 {
 	DW& d = w->dw;
 	const size_t nb = w->bodies.size();
+	// (lazy: every read-back of a step end leaves the rows where they are; a read-back outside a step is a full one)
+	const bool lazy = w->lazyReadback && w->stepActive && !w->noStatePoll;
+	w->rowsPending.store(lazy, std::memory_order_release);
 	w->stateSeq = (w->stateSeq + 1) & 0x3fffffff;
 	if (w->stateSeq == 0) w->stateSeq = 1;
 	((DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq = 0; // (whatever was there: not this number)
@@ -2162,8 +2180,37 @@ static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 		memcpy(w->h_dstate, w->h_state + B2D_STATE_TAIL(nb), offsetof(DState, pubSeq));
 		return 0;
 	}
-	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq, skipRowsIfRedo ? 1 : 0);
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq,
+		lazy ? END_STEP_LAZY : skipRowsIfRedo ? END_STEP_SKIP_IF_REDO : END_STEP_FULL);
 	return awaitState(w, nb);
+}
+
+// The rows a lazy step end left on the device (b2hip_set_lazy_readback), fetched when the first caller asks for a body's
+// state: the row half of k_end_step on its own. Several user threads may ask at once (b2Body getters from range tasks).
+static int fetchRows(b2hip_world* w)
+{
+	DEVICE_GUARD(w);
+	DW& d = w->dw;
+	const size_t nb = (size_t)d.nBodies; // (bodies created since the step are not on the device yet: the step's count)
+	w->stateSeq = (w->stateSeq + 1) & 0x3fffffff;
+	if (w->stateSeq == 0) w->stateSeq = 1;
+	((DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq = 0;
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0, (const int*)nullptr, w->d_hstate, w->stateSeq, END_STEP_ROWS);
+	return pollPublished(w, (volatile const int*)&((const DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq, w->stateSeq, "lazy state read-back");
+}
+
+static void ensureRows(b2hip_world* w)
+{
+	if (!w->rowsPending.load(std::memory_order_acquire)) return;
+	std::lock_guard<std::mutex> lock(w->rowsMutex);
+	if (!w->rowsPending.load(std::memory_order_relaxed)) return;
+	if (fetchRows(w) != 0)
+	{
+		// (the rows cannot be had: the world is as good as lost - every later call says why)
+		w->failed = true;
+		w->failedWhy = g_lastError;
+	}
+	w->rowsPending.store(false, std::memory_order_release);
 }
 
 static void refreshMirror(b2hip_world* w)
@@ -2386,6 +2433,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	memset(w->h_pub, 0, sizeof(DState));
 	w->noCensusPoll = getenv("B2HIP_NO_CENSUS_POLL") && atoi(getenv("B2HIP_NO_CENSUS_POLL"));
 	w->noStatePoll = getenv("B2HIP_NO_STATE_POLL") && atoi(getenv("B2HIP_NO_STATE_POLL"));
+	w->lazyReadback = getenv("B2HIP_LAZY_READBACK") && atoi(getenv("B2HIP_LAZY_READBACK"));
 	int rc = ensureCapacity(w, 0);
 	if (rc == 0 && hipStreamSynchronize(w->stream) != hipSuccess) rc = setError(B2HIP_ERR_HIP, "stream sync failed");
 	if (rc)
@@ -3878,7 +3926,7 @@ static int stepEndImpl(b2hip_world* w)
 	}
 	w->events.clear();
 	// (the rows were left out of a read-back because another one was due, and it did not come: safety net, never seen)
-	if (w->h_dstate->c.rowsSkipped)
+	if (w->h_dstate->c.rowsSkipped == 1)
 	{
 		rc = downloadState(w, -1);
 		if (rc) return rc;
@@ -4018,6 +4066,14 @@ static int stepEndImpl(b2hip_world* w)
 	return 0;
 }
 
+int b2hip_set_lazy_readback(b2hip_world* w, int enable)
+{
+	if (int rc = checkUsable(w, "b2hip_set_lazy_readback", true)) return rc;
+	ensureRows(w); // (switching off with rows outstanding: they come home now)
+	w->lazyReadback = enable != 0;
+	return w->failed ? setError(B2HIP_ERR_HIP, w->failedWhy) : B2HIP_OK;
+}
+
 int b2hip_step_end(b2hip_world* w)
 {
 	if (int rc = checkUsable(w, "b2hip_step_end", false)) return rc;
@@ -4046,6 +4102,8 @@ int b2hip_step(b2hip_world* w, float dt, int velocity_iterations, int position_i
 int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state* out)
 {
 	if (!w || !out || first < 0 || count < 0 || first + count > (int)w->bodies.size()) return setError(B2HIP_ERR_INVALID, "bad range");
+	ensureRows(w);
+	if (w->failed) return setError(B2HIP_ERR_INVALID, "b2hip_get_body_states: the world is in a failed state (" + w->failedWhy + ")");
 	for (int i = 0; i < count; ++i)
 	{
 		const HostBody& b = w->bodies[first + i];
@@ -4169,6 +4227,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	if (!w || !needed || (cap > 0 && !buffer)) return setError(B2HIP_ERR_INVALID, "null argument");
 	if (int rcu = checkUsable(w, "b2hip_save_snapshot", true)) return rcu;
 	DEVICE_GUARD(w);
+	ensureRows(w); // (the snapshot carries the host's mirror)
 	int rc = flushEdits(w); // everything the host has created or edited is on the device now
 	if (rc) return rc;
 	rc = applyPendingFilters(w); // ... including the re-filter flags of joints created / destroyed since the last step
@@ -4324,7 +4383,8 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	};
 	if (!inRange(sHead, -1, (long long)np) || !inRange(sNext, -1, (long long)np)) return corrupt("per-body proxy lists");
 	if (!inRange(sBlk, 0, MAX_BLOCKS + 1) || ds.c.nBlocks < 0 || ds.c.nBlocks > MAX_BLOCKS) return corrupt("block partition");
-	if (!inRange(sPBody, 0, (long long)nb) || !inRange(sPShape, 0, (long long)nS)) return corrupt("proxy table");
+	// (the proxy of a destroyed fixture stays in the table with body -1)
+	if (!inRange(sPBody, -1, (long long)nb) || !inRange(sPShape, 0, (long long)nS)) return corrupt("proxy table");
 	if (!inRange(sToi, 0, (long long)nC) || !inRange(sMoves, 0, (long long)np)) return corrupt("TOI order / move buffer");
 	if (!inRange(cColor, -1, MAX_COLORS) || !inRange(cMgr, -1, (long long)std::max<size_t>(nT, 1))) return corrupt("contact colour / TOI slot");
 	for (size_t i = 0; i < nC; ++i)

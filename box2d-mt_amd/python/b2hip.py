@@ -184,6 +184,7 @@ def _configure(L, optional_ok=False):
         "b2hip_set_awake": [C.c_void_p, C.c_int, C.c_int],
         "b2hip_fixture_set_sensor": [C.c_void_p, C.c_int, C.c_int],
         "b2hip_fixture_refilter": [C.c_void_p, C.c_int],
+        "b2hip_set_lazy_readback": [C.c_void_p, C.c_int],
     }
     for name, argtypes in sigs.items():
         try:
@@ -441,6 +442,10 @@ class World:
 
     def set_velocity(self, body, velocity=(0.0, 0.0), omega=0.0):
         _check(self.L.b2hip_set_velocity(self.p, body, velocity[0], velocity[1], omega))
+
+    def set_lazy_readback(self, enable=True):
+        """The 40 B per body of a step's read-back stay in HBM until body_states() (or an edit) asks for them."""
+        _check(self.L.b2hip_set_lazy_readback(self.p, int(enable)))
 
     def step(self, dt=1.0 / 60.0, vel_iters=8, pos_iters=3):
         _check(self.L.b2hip_step(self.p, dt, vel_iters, pos_iters))

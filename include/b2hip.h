@@ -606,6 +606,14 @@ int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
 int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed);
 int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world** out);
 
+/* The state read-back of a step (40 B per body, the reference's b2Body members the user reads between steps, b2Body.h:126-131
+ * GetTransform / GetPosition / GetAngle / velocities). Default (0): every step ends with it - b2hip_step returns with the rows on
+ * the host. Lazy (1): a step ends with the counters only and the rows stay in HBM until the first call that needs a body's
+ * state (b2hip_get_body_states, an edit of a body, a snapshot) fetches them, once; a caller that steps several times between
+ * looks - or never looks, a batch run that reads the last state only - does not pay 40 MB of PCIe per step at 1 M bodies.
+ * Results are the same bit for bit. B2HIP_LAZY_READBACK=1 in the environment sets it for every world created afterwards. */
+int b2hip_set_lazy_readback(b2hip_world* w, int enable);
+
 /* 13 floats in b2Profile declaration order (b2TimeStep.h:25-40), milliseconds, from HIP events. */
 int b2hip_get_profile(b2hip_world* w, float ms[13]);
 int b2hip_get_counters(b2hip_world* w, b2hip_counters* out);

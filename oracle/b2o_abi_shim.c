@@ -323,6 +323,14 @@ int b2hip_get_toi_callbacks(b2hip_world* w, int cap, b2hip_toi_callback* out)
 	return b2o_get_toi_callbacks(w->o, cap, (b2o_toi_callback*)out); /* same layout */
 }
 
+/* (a CPU world has nothing to read back: accepted, no effect) */
+int b2hip_set_lazy_readback(b2hip_world* w, int enable)
+{
+	(void)w;
+	(void)enable;
+	return 0;
+}
+
 int b2hip_enable_post_solve(b2hip_world* w, int enable)
 {
 	b2o_enable_post_solve(w->o, enable);

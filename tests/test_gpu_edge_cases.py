@@ -483,3 +483,54 @@ def test_dense_start_grows_the_pair_buffer(monkeypatch):
         assert np.array_equal(a.bodies().view(np.uint32), o.bodies().view(np.uint32)), "step %d" % s
     a.close()
     o.close()
+
+
+def test_lazy_readback_gives_the_same_states(libs):
+    """b2hip_set_lazy_readback: the rows of a step stay on the device until somebody asks. A stack that is pushed, woken and
+    grown between steps (edits pull single bodies; new bodies make the host's mirror grow) is read every 7th step only - and
+    must be what the oracle has, bit for bit; so must a snapshot taken while rows are outstanding, and the world after the
+    mode is switched off again."""
+    a, b = both(libs, continuous=True)
+    a.set_lazy_readback(True)
+    b.set_lazy_readback(True)  # (the shim accepts and ignores it)
+    ids = {}
+    for w in (a, b):
+        g = w.create_body(b2hip.STATIC, (0.0, -1.0))
+        w.create_fixture(g, b2hip.box_shape(40.0, 1.0))
+        ids[w] = []
+        for i in range(40):
+            d = w.create_body(b2hip.DYNAMIC, (-15.0 + 0.8 * (i % 20), 0.5 + 1.01 * (i // 20)))
+            w.create_fixture(d, b2hip.box_shape(0.4, 0.5) if i % 3 else b2hip.circle_shape(0.4), density=1.0)
+            ids[w].append(d)
+
+    def between(s, w):
+        if s % 5 == 2:
+            w.apply_force(ids[w][s % 40], (20.0, 5.0), torque=1.0)          # pulls one row (the fetch), edits it
+        if s % 11 == 4:
+            w.set_velocity(ids[w][(3 * s) % 40], (0.0, 3.0), omega=-2.0)
+        if s in (30, 31, 90):                                                # the mirror grows with rows outstanding
+            for k in range(30 if s == 90 else 3):
+                d = w.create_body(b2hip.DYNAMIC, (-10.0 + 0.7 * k, 6.0 + 0.01 * s))
+                w.create_fixture(d, b2hip.box_shape(0.3, 0.3), density=2.0)
+                ids[w].append(d)
+        if s == 60:
+            w.destroy_body(ids[w][5])
+
+    for s in range(140):
+        between(s, a)
+        between(s, b)
+        a.step()
+        b.step()
+        if s % 7 == 6 or s in (30, 31, 32, 90, 91):
+            same(a, b, "lazy read-back, step %d" % s, skip=(ids[a][5],) if s >= 60 else ())
+        if s == 100:
+            blob = a.save_snapshot()  # (rows outstanding: the snapshot fetches them)
+            c = b2hip.World.from_snapshot(blob, library=libs[0])
+            same(c, b, "snapshot of a lazy world", skip=(ids[a][5],))
+            c.close()
+    a.set_lazy_readback(False)
+    for s in range(140, 150):
+        a.step()
+        b.step()
+    same(a, b, "lazy read-back switched off", skip=(ids[a][5],))
+    a.close(); b.close()
