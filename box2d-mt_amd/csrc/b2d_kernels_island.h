@@ -305,6 +305,8 @@ __global__ __launch_bounds__(256) void k_island_count(DW W)
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
+	__shared__ BlockHot s_hot; // (the workgroup's count for the first root it meets: b2d_wave.h)
+	blockHotInit(&s_hot);
 	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
 		const int i = base + threadIdx.x;
@@ -317,8 +319,9 @@ __global__ __launch_bounds__(256) void k_island_count(DW W)
 			valid = (W.b_flags[b] & BF_TYPE_MASK) != BT_STATIC;
 			if (valid) root = W.parent[b];
 		}
-		waveAtomicAddInt(W.rootContacts, root, 1, valid);
+		blockHotAddInt(&s_hot, W.rootContacts, root, 1, valid);
 	}
+	blockHotFlush(&s_hot, W.rootContacts);
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
 	{
 		const RevoluteJoint& jn = W.joints[j];
@@ -524,23 +527,29 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub)
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
-		if (!contactSolid(C.flags[i])) continue;
-		int4 ids = C.ids[i];
-		bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
-		bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-		int b = nsA ? ids.z : ids.w;
-		if (!nsA && !nsB) continue;
-		int tier = W.rootIsland[W.parent[b]];
+		const int i = base + (int)threadIdx.x;
+		int4 ids = make_int4(0, 0, 0, 0);
+		bool nsA = false, nsB = false;
+		int tier = ROOT_NONE;
+		if (i < n && contactSolid(C.flags[i]))
+		{
+			ids = C.ids[i];
+			nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
+			nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
+			if (nsA || nsB) tier = W.rootIsland[W.parent[nsA ? ids.z : ids.w]];
+		}
 		if (tier == ROOT_SMALL)
 		{
 			if (nsA) W.adj[W.adjStart[ids.z] + atomicAdd(&W.adjCursor[ids.z], 1)] = i;
 			if (nsB) W.adj[W.adjStart[ids.w] + atomicAdd(&W.adjCursor[ids.w], 1)] = i;
 		}
-		else if (tier == ROOT_LARGE)
+		// the large islands' contact list: one cursor for the whole world - a slot per workgroup and iteration, not per wave
+		// (the settled Tumbler: 32 000 atomics on that word, 200 us; b2d_wave.h)
+		const int k = blockAlloc(&S->c.nLContacts, tier == ROOT_LARGE);
+		if (tier == ROOT_LARGE)
 		{
-			int k = atomicAdd(&S->c.nLContacts, 1);
 			W.li_contacts[k] = i;
 			// a body without a home block is offered the block of its neighbour (the highest one, if several do: deterministic)
 			if (nsA && nsB)
