@@ -289,6 +289,7 @@ struct b2hip_world
 	bool adoptPasses = false;    // the last step had orphan constraints (or made a partition): run k_block_adopt this step
 	bool traceLaunches = false;  // B2HIP_TRACE_LAUNCHES=1 (with B2HIP_DEBUG): every kernel's name before the stream is drained behind it
 	bool tracePartition = false; // B2HIP_TRACE_PARTITION=1: why a partition was made, on stderr
+	bool blocksTooBig = false;   // the large islands hold more constraints than any block solver takes: no partition (phaseSolve)
 	bool noSweepBlocks = false;  // B2HIP_NO_SWEEP_BLOCKS=1: jointed / hub islands stay on the launch-per-colour kernels
 	int dfWipedAt = 0;           // dfEpoch >> 14 at the last wipe of the hand-over rows
 	int sweepSteps = 0;          // steps whose large islands went through k_blocks_sweep
@@ -1588,14 +1589,45 @@ static int phaseSolve(b2hip_world* w)
 	// (newcomers without a home block: from the next step on k_block_adopt hands blocks further, for a while)
 	if (c.nOrphanRows > 0) w->adoptSticky = 16; else if (w->adoptSticky > 0) w->adoptSticky -= 1;
 	w->adoptPasses = w->adoptSticky > 0;
+	const bool plainIslands = d.nJoints == 0 && c.maxDegree <= HUB_DEGREE;
+	// ---- large islands that no block solver can take: more constraints than the blocks that fit the device together hold
+	// (1024-lane blocks of ~750 rows: ~190 000; the settled 100 000-box Tumbler has 350 000). They run launch per colour
+	// whatever happens - and a partition would only cost them: it splits the colours into two ranges (interior / cut), 27
+	// colours in use where one range needs 18, and every colour is a launch of every sweep (Tumbler: 6.1 -> 5.2 ms per step).
+	// So the partition is dissolved (all constraints are one class again, coloured afresh once) until the islands have shrunk.
+	{
+		const int cap1024 = plainIslands ? w->blocksMaxWG : w->sweepMaxWG[2];
+		const bool was = w->blocksTooBig;
+		if (!w->blocksTooBig && cap1024 > 0 && c.nLContacts > 800 * cap1024) w->blocksTooBig = true;
+		else if (w->blocksTooBig && c.nLContacts < 650 * cap1024) w->blocksTooBig = false;
+		if (w->blocksTooBig && c.nBlocks > 0 && forceLarge != 2 && !w->noBlocks)
+		{
+			if (w->tracePartition) fprintf(stderr, "[b2hip] partition dissolved: %d constraints in large islands, %d blocks of %d lanes (room for %d)\n", c.nLContacts, c.nBlocks, c.blkLanes, cap1024);
+			const size_t nbAll = w->bodies.size();
+			HIP_TRY(hipMemsetAsync(w->b_blk1.p, 0, nbAll * sizeof(int), w->stream));
+			HIP_TRY(hipMemsetAsync(w->b_adopt.p, 0, nbAll * sizeof(int), w->stream));
+			HIP_TRY(hipMemsetAsync(w->b_adoptStage.p, 0, 3 * nbAll * sizeof(int), w->stream));
+			HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nBlocks, 0, sizeof(int), w->stream));
+			d.serialOrphans = 0; // (no body has a home block now: nothing is an orphan)
+			// the colour census again, under the one class (as after a new partition), then every colour afresh
+			LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
+			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr);
+			rc = readState(w);
+			if (rc) return rc;
+			c = w->h_dstate->c;
+			c.needRecolor = 1;
+			colorSmallQueued = false;
+		}
+		(void)was;
+	}
 	// (from the next step on: in islands with joints / hubs the constraints of such newcomers are swept in order instead)
-	w->serialOrphansNext = (forceLarge != 2 && !w->noBlocks && !w->noSweepBlocks && c.nBlocks > 0 && (d.nJoints > 0 || c.maxDegree > HUB_DEGREE)) ? 1 : 0;
+	w->serialOrphansNext = (forceLarge != 2 && !w->noBlocks && !w->noSweepBlocks && !w->blocksTooBig && c.nBlocks > 0 && (d.nJoints > 0 || c.maxDegree > HUB_DEGREE)) ? 1 : 0;
 	// ---- block partition of the large islands: (re)made when bodies without a home block joined, when a block outgrew a
 	// workgroup, or when too many constraints cross block boundaries (the pile has moved since the partition was made)
 	// (islands with joints or hub bodies are partitioned too: k_blocks_sweep does their contact sweeps block-wise, one launch
 	// per sweep, between the joint walks and the hub sweeps)
-	const bool plainIslands = d.nJoints == 0 && c.maxDegree <= HUB_DEGREE;
-	const bool blockShape = forceLarge != 2 && !w->noBlocks && c.nLIslands > 0 && (plainIslands || !w->noSweepBlocks) &&
+	const bool blockShape = forceLarge != 2 && !w->noBlocks && !w->blocksTooBig && c.nLIslands > 0 && (plainIslands || !w->noSweepBlocks) &&
 		(sp.warmStarting ? 1 : 0) + sp.velIters > 0 && w->blocksMaxWG > 0;
 	if (blockShape && c.partitionCooldown == 0)
 	{
@@ -4179,7 +4211,7 @@ struct SnapHeader
 	uint32_t stateCount, cur;
 	int32_t nextNode, leafCount, lastContacts, newFixture;
 	float inv_dt0, cellSize;
-	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bits 8..15 adoptSticky, 16..23 largeHintSteps (what the next island build is told)
+	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bit 1 blocksTooBig, bits 8..15 adoptSticky, 16..23 largeHintSteps (what the next island build is told)
 };
 const uint32_t kSnapVersion = 4;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
@@ -4252,7 +4284,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
 	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
 	h.eventsOn = w->eventsOn ? 1 : 0;
-	h.solverHints = (w->serialOrphansNext ? 1 : 0) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16);
+	h.solverHints = (w->serialOrphansNext ? 1 : 0) | (w->blocksTooBig ? 2 : 0) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16);
 	SnapWriter o;
 	o.host(&h, sizeof(h));
 	o.host(&w->def, sizeof(w->def));
@@ -4470,6 +4502,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	w->inv_dt0 = h.inv_dt0;
 	w->eventsOn = h.eventsOn != 0;
 	w->serialOrphansNext = h.solverHints & 1;
+	w->blocksTooBig = (h.solverHints & 2) != 0;
 	w->adoptSticky = (h.solverHints >> 8) & 0xff;
 	w->largeHintSteps = (h.solverHints >> 16) & 0xff;
 	w->adoptPasses = w->adoptSticky > 0;
