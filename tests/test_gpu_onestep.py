@@ -173,8 +173,8 @@ def one_step_deviation(b, o):
 #                step  61: pos 8.4e-5 angle 0.016 vel 2.0e-3 spin 0.52 | step 131: pos 1.43e-4 angle 0.033 vel 3.4e-3 spin 0.53, 33 of 30 858 contacts
 #                step 246: pos 1.13e-4 (|dp| 1.7 cm, p99 1.0 cm, median 1.4 mm) angle 0.023 vel 5.6e-4 (|dv| 0.09 m/s) spin 0.095, 11 of 30 564 contacts
 #                step 301: pos 1.07e-4 (|dp| 1.6 cm, median 2.2 mm) angle 0.022 vel 2.0e-3 (|dv| 0.30 m/s) spin 0.25, 18 of 29 936 contacts
-#   pyramid30    at rest: pos 3.3e-4 angle 5e-3 vel 3e-4 spin 0.014, contact set equal
-#   tumbler2000  pos 7e-4 angle 0.065 vel 0.048 spin 3.0, 36 of 16 076 contacts
+#   pyramid30    at rest: pos 3.3e-4 angle 5.8e-3 vel 3.4e-4 spin 0.014, contact set equal
+#   tumbler2000  pos 5.4e-4 angle 0.057 vel 0.038 spin 3.7, 43 of 22 363 contacts
 #   cars60       pos 9e-8 angle 7e-5 vel 2e-6 spin 4e-3, contact set equal
 SCENES = {
     # steps 245 and 300 are the state bench.py times: the pile settled for 240 steps + the driver's 5 warm-up steps, and the
@@ -182,8 +182,8 @@ SCENES = {
     "pyramid141": (build_pyramid, 141, (20, 60, 130, 245, 300), True,
                    {0: (2.2e-4, 0.05, 5.1e-3, 0.8, 1.6e-3), 240: (1.7e-4, 0.035, 3.1e-3, 0.38, 9e-4)},
                    {0: (0.033, 0.81), 240: (0.026, 0.46)}),
-    "pyramid30_at_rest": (build_pyramid, 30, (200, 300), True, (7e-4, 0.012, 7e-4, 0.03, 0.0), None),
-    "tumbler2000": (build_tumbler, 2000, (40, 100), False, (1.5e-3, 0.13, 0.1, 6.0, 5e-3), None),
+    "pyramid30_at_rest": (build_pyramid, 30, (200, 300), True, (5e-4, 9e-3, 5.1e-4, 0.021, 0.0), None),
+    "tumbler2000": (build_tumbler, 2000, (40, 100), False, (8.5e-4, 0.09, 0.06, 5.6, 3e-3), None),
     "cars60": (build_cars, 60, (30, 90), True, (1e-6, 2e-4, 1e-5, 1e-2, 0.0), None),
 }
 
