@@ -229,3 +229,7 @@ static void Summarise(Test* t, double* out6)
 		}
 	}
 }
+
+// (for drivers that want every scene: the registry's size and names)
+extern "C" int testbed_entry_count() { return (int)(sizeof(kEntries) / sizeof(kEntries[0])); }
+extern "C" const char* testbed_entry_name(int i) { return i >= 0 && i < testbed_entry_count() ? kEntries[i].name : ""; }

@@ -10,11 +10,17 @@ int b2h_get_events_ex(b2h_world* h, int cap, int* out);
 void b2h_set_filter(b2h_world* h, int enable);
 int b2h_body_count(b2h_world* h);
 int b2h_contact_count(b2h_world* h);
+int b2h_query_aabb(b2h_world* h, float lx, float ly, float ux, float uy, int cap, int* out);
+int b2h_raycast_closest(b2h_world* h, float x1, float y1, float x2, float y2, float* out7);
+void b2h_tree_stats(b2h_world* h, float* out4);
+int b2h_joint_reactions(b2h_world* h, float inv_dt, int cap, float* out);
+int b2h_probe_dynamic_tree(unsigned seed, int count, int ops, float* out3);
 }
 int main()
 {
-	// every harness scene family, life cycle last (12), with the recording listener and the user filter on
-	const int scenes[][3] = { {0,0,0}, {1,12,2}, {2,8,0}, {3,300,40}, {4,40,5}, {5,200,0}, {6,6,6}, {7,60,6}, {8,80,0}, {9,40,10}, {10,100,6}, {11,100,5}, {12,48,0} };
+	// every harness scene family (12 life cycle, 13 chain shapes), with the recording listener and the user filter on; queries,
+	// ray casts, tree statistics (the host's shadow b2DynamicTree) and joint reactions every 20th step
+	const int scenes[][3] = { {0,0,0}, {1,12,2}, {2,8,0}, {3,300,40}, {4,40,5}, {5,200,0}, {6,6,6}, {7,60,6}, {8,80,0}, {9,40,10}, {10,100,6}, {11,100,5}, {12,48,0}, {13,70,0} };
 	std::vector<int> ev(10 << 18);
 	for (auto& s : scenes)
 	{
@@ -29,11 +35,27 @@ int main()
 			{
 				b2h_step(w, 1, 1.0f / 60.0f, 8, 3);
 				total += b2h_get_events_ex(w, 1 << 18, ev.data());
+				if (k % 20 == 19)
+				{
+					int hits[256];
+					float out7[7], stats[4];
+					std::vector<float> reac(4 * 4096);
+					b2h_query_aabb(w, -10.0f + k * 0.1f, -1.0f, 10.0f, 12.0f, 256, hits);
+					b2h_raycast_closest(w, -30.0f, 0.5f + 0.05f * k, 30.0f, 1.0f, out7);
+					b2h_tree_stats(w, stats);
+					b2h_joint_reactions(w, 60.0f, 4096, reac.data());
+				}
 			}
 			printf("scene %d flags %d: %d bodies %d contacts %ld callbacks\n", s[0], flags, b2h_body_count(w), b2h_contact_count(w), total);
 			fflush(stdout);
 			b2h_destroy(w);
 		}
+	}
+	for (unsigned seed = 1; seed <= 3; ++seed)
+	{
+		float out3[3];
+		const int bad = b2h_probe_dynamic_tree(seed, 400, 4000, out3);
+		printf("dynamic tree, seed %u: %d mismatches against brute force, height %g\n", seed, bad, out3[0]);
 	}
 	return 0;
 }
