@@ -473,6 +473,8 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.toiUnsafe = 0;
 		c.nToiGroups = 0;
 		c.nToiMoved = 0;
+		c.nToiNewPairs = 0;
+		c.nToiChainCreated = 0;
 		c.nPreSolve = 0;
 		c.nPostSolve = 0;
 		c.nFilterList = 0;

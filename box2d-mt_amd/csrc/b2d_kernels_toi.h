@@ -26,6 +26,7 @@
 #define TOI_RECOMP_MAX 512
 #define TOI_WOKEN_MAX 256
 #define TOI_EVENTS_MAX 100000
+#define TOI_NEWPAIR_MAX 256      // new pairs the parallel chains may leave for their close-out to create (more: serial loop)
 #define TOI_MOVED_ALL_MAX 32768  // proxies re-inserted during one TOI phase (their grid bins are stale): DW::toiMoved
 
 // Flags are updated with L2 atomics (wake-ups, claims, invalidation) inside the event loop; a plain load could

@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 		{
 			S->c.nToiEvents = 0;
 			S->c.nToiMoved = 0;
+			S->c.nToiNewPairs = 0;
+			S->c.nToiChainCreated = 0;
 			// (the serial replay of tied components may have created contacts)
 			S->c.nContacts = S->c.nContactsSnap;
 			S->c.nToiOrder = S->c.nToiOrderSnap;
@@ -253,6 +255,8 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 		}
 		const int minIdx = bestI;
 		const float minAlpha = bestI >= 0 ? __uint_as_float(bestA) : 1.0f;
+		const uint32_t evAlphaBits = bestA;        // this event's place in the reference's global order (b2Contact::ToiLessThan)
+		const unsigned long long evKey = bestK;
 		if (minIdx < 0 || 1.0f - 10.0f * B2D_EPSILON < minAlpha) break;
 		if (s_unsafe) break;
 		if (s_events >= CHAIN_EVENTS_MAX)
@@ -576,7 +580,31 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 					if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
 					if (!filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
 					if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return;
-					atomicOr(&s_unsafe, TOI_UNSAFE_PAIR);
+					// A new pair. The reference creates its contact now (b2World.cpp:1015, FindNewContacts after every sub-step),
+					// and creation ORDER is global - but a contact between D and another moving, non-bullet, awake body takes no
+					// part in the rest of the phase: sub-step islands leave such contacts out (b2World.cpp:905-912), it is no TOI
+					// candidate, nobody updates it before the next Collide. So it is only noted, with the key of this event; the
+					// chains' close-out (toiChainsEnd) creates what was noted in event order. Anything else stays a case for
+					// the serial loop: a static / kinematic / bullet partner (D's later events would use the contact), a sleeper.
+					const uint32_t fq = ldFlags(&W.b_flags[bodyQ]);
+					const bool inert = (fq & BF_TYPE_MASK) == BT_DYNAMIC && (fq & (BF_BULLET | BF_AWAKE | BF_ACTIVE)) == (BF_AWAKE | BF_ACTIVE);
+					if (!inert || W.noChainCreate)
+					{
+						atomicOr(&s_unsafe, TOI_UNSAFE_PAIR);
+						return;
+					}
+					const int k = atomicAdd(&S->c.nToiNewPairs, 1);
+					if (k >= TOI_NEWPAIR_MAX)
+					{
+						atomicOr(&s_unsafe, TOI_UNSAFE_CAPACITY);
+						return;
+					}
+					int* ent = W.toiNew + 8 * (size_t)k;
+					b2dStoreAgentI(&ent[0], (int)evAlphaBits);
+					b2dStoreAgentI(&ent[1], (int)(uint32_t)(evKey >> 32));
+					b2dStoreAgentI(&ent[2], (int)(uint32_t)evKey);
+					b2dStoreAgentI(&ent[3], lo);
+					b2dStoreAgentI(&ent[4], hi);
 				});
 			}
 		}
@@ -660,6 +688,116 @@ __device__ __forceinline__ void toiChainsEnd(const DW& W)
 	}
 	__syncthreads();
 	for (int g = threadIdx.x; g < nG; g += blockDim.x) W.b_toiGroup[W.toiGroups[g]] = 0;
+	// ---- the contacts the chains noted (pairs of two moving bodies), created in the reference's order: by event (alpha,
+	// proxy ids of the event's contact), within an event by the pair's proxy ids (b2ContactManager::FindNewContacts sorts its
+	// pairs); a pair noted twice - by a later event of the same body, or from the other side - exists from its first event on.
+	// (Two chains that both moved towards each other were caught above: their hulls overlap without a contact.)
+	const int nNoted = b2dLoadAgentI(&S->c.nToiNewPairs);
+	if (nNoted > 0 && nNoted <= TOI_NEWPAIR_MAX && b2dLoadAgentI(&S->c.toiUnsafe) == 0)
+	{
+		const ContactArrays& C = W.ca[S->cur];
+		__shared__ int s_first[TOI_NEWPAIR_MAX], s_rank[TOI_NEWPAIR_MAX];
+		__shared__ int s_created;
+		if (threadIdx.x == 0) s_created = 0;
+		auto entry = [&](int i, uint32_t* alpha, unsigned long long* ev, unsigned long long* pair, int* lo, int* hi)
+		{
+			const int* ent = W.toiNew + 8 * (size_t)i;
+			*alpha = (uint32_t)b2dLoadAgentI(&ent[0]);
+			*ev = ((unsigned long long)(uint32_t)b2dLoadAgentI(&ent[1]) << 32) | (uint32_t)b2dLoadAgentI(&ent[2]);
+			*lo = b2dLoadAgentI(&ent[3]);
+			*hi = b2dLoadAgentI(&ent[4]);
+			*pair = ((unsigned long long)(uint32_t)W.p_key[*lo] << 32) | (uint32_t)W.p_key[*hi];
+		};
+		auto before = [](uint32_t a1, unsigned long long e1, unsigned long long p1, uint32_t a2, unsigned long long e2, unsigned long long p2)
+		{
+			if (a1 != a2) return a1 < a2;
+			if (e1 != e2) return e1 < e2;
+			return p1 < p2;
+		};
+		__syncthreads();
+		for (int i = threadIdx.x; i < nNoted; i += blockDim.x)
+		{
+			uint32_t ai; unsigned long long ei, pi; int loi, hii;
+			entry(i, &ai, &ei, &pi, &loi, &hii);
+			int first = 1;
+			for (int j = 0; j < nNoted; ++j)
+			{
+				if (j == i) continue;
+				uint32_t aj; unsigned long long ej, pj; int loj, hij;
+				entry(j, &aj, &ej, &pj, &loj, &hij);
+				if (pj != pi) continue;
+				// the same pair: the note of the earlier event stands (identical notes: the lower index)
+				if (before(aj, ej, pj, ai, ei, pi) || (aj == ai && ej == ei && j < i)) first = 0;
+			}
+			s_first[i] = first;
+			if (first) atomicAdd(&s_created, 1);
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < nNoted; i += blockDim.x)
+		{
+			if (!s_first[i]) continue;
+			uint32_t ai; unsigned long long ei, pi; int loi, hii;
+			entry(i, &ai, &ei, &pi, &loi, &hii);
+			int rank = 0;
+			for (int j = 0; j < nNoted; ++j)
+			{
+				if (!s_first[j] || j == i) continue;
+				uint32_t aj; unsigned long long ej, pj; int loj, hij;
+				entry(j, &aj, &ej, &pj, &loj, &hij);
+				if (before(aj, ej, pj, ai, ei, pi)) ++rank;
+			}
+			s_rank[i] = rank;
+		}
+		__syncthreads();
+		const int base = S->c.nContacts;
+		if (base + s_created > W.capContacts)
+		{
+			// (b2hip_step_end undoes the phase from its snapshot, grows the array and runs the phase again)
+			if (threadIdx.x == 0) atomicOr(&S->c.overflow, 1);
+		}
+		else
+		{
+			for (int i = threadIdx.x; i < nNoted; i += blockDim.x)
+			{
+				if (!s_first[i]) continue;
+				uint32_t ai; unsigned long long ei, pi; int pA, pB;
+				entry(i, &ai, &ei, &pi, &pA, &pB);
+				// OnContactCreate (b2ContactManager.cpp:507-564), as k_create_contacts does it
+				if (b2dContactSwap(W.shapes[W.p_shape[pA]].type, W.shapes[W.p_shape[pB]].type) == 1)
+				{
+					const int t = pA;
+					pA = pB;
+					pB = t;
+				}
+				const int dst = base + s_rank[i];
+				const int bodyA = W.p_body[pA], bodyB = W.p_body[pB];
+				const bool sensor = ((W.p_filter1[pA] | W.p_filter1[pB]) & PF_SENSOR) != 0;
+				const float2 mA = W.p_mat[pA], mB = W.p_mat[pB];
+				C.ids[dst] = make_int4(pA, pB, bodyA, bodyB);
+				C.key[dst] = pi;
+				C.flags[dst] = CF_ENABLED | (sensor ? CF_SENSOR : 0u); // (two dynamic bodies, no bullet: not a TOI candidate)
+				C.mat[dst] = make_float4(b2dSqrt(mA.x * mB.x), mA.y > mB.y ? mA.y : mB.y, 0.0f, 1.0f);
+				C.man0[dst] = make_float4(0, 0, 0, 0);
+				C.man1[dst] = make_float4(0, 0, 0, 0);
+				C.imp[dst] = make_float4(0, 0, 0, 0);
+				C.man3[dst] = make_int4(0, 0, 0, 0);
+				C.color[dst] = -1;
+				C.mgr[dst] = -1;
+				if (!sensor)
+				{
+					// SetAwake(true) on both (:525-529): both are awake (the chains note no pair with a sleeper); the timers restart
+					W.b_pos[bodyA].w = 0.0f;
+					W.b_pos[bodyB].w = 0.0f;
+				}
+			}
+			__syncthreads();
+			if (threadIdx.x == 0)
+			{
+				S->c.nContacts = base + s_created;
+				S->c.nToiChainCreated = s_created;
+			}
+		}
+	}
 }
 
 __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp, int haveGrid)

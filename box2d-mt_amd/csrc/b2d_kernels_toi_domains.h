@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void k_toi_dom_init(DW W)
 	{
 		W.st->c.nToiDomains = 0;
 		W.st->c.nToiMoved = 0;
+		W.st->c.nToiNewPairs = 0;
 		W.st->c.nToiPartial = 0;
 	}
 }

@@ -126,6 +126,8 @@ struct Counters
 	int toiUnsafe;       // the parallel TOI chains met a case only the serial event loop reproduces (bits: b2d_kernels_toi_chains.h)
 	int nToiGroups;      // dynamic bodies with a pending impact
 	int nToiMoved;       // proxies re-inserted by the TOI chains / components
+	int nToiNewPairs;    // pairs the chains found between two moving bodies (created in event order when the chains are done)
+	int nToiChainCreated; // contacts that close-out created in this step
 	uint32_t cellExtBits; // float bits of the largest fat-AABB extent among the grid-sized proxies, see gridCellSize()
 	int nToiDomains;     // components with a pending impact
 	int nToiPartial;     // pending impacts of the components that are replayed serially (DW::toiDomList)
@@ -412,6 +414,8 @@ struct DW
 	int* toiGroupCount;  // per chain: contacts gathered for it
 	int* toiGroupList;   // per chain: CHAIN_ADJ_MAX contact indices
 	int* toiMoved;       // proxies re-inserted by the chains
+	int noChainCreate;   // B2HIP_TOI_NO_CHAIN_CREATE=1: every new pair a chain meets sends the phase to the serial loop (comparison)
+	int* toiNew;         // TOI_NEWPAIR_MAX x 8 ints: pairs found by the chains (alpha bits, event key hi / lo, proxy lo / hi)
 	float4* snapBody;    // 5 rows per body: pos, pos0, vel, xf, flags (state before the chains)
 	float4* snapFat;     // fat AABBs before the chains
 

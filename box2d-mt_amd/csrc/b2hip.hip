@@ -188,7 +188,7 @@ struct b2hip_world
 	DevArray<int> p_body, p_shape, p_key, p_filter1;
 	DevArray<uint32_t> p_filter0;
 	DevArray<float2> p_mat;
-	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiGroupCount, toiGroupList, toiMoved, toiParent, toiDomOf, toiDomRoot, toiDomCount, toiDomBase, toiDomFill, toiDomList, toiDomFailed, toiDomEvents;
+	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiGroupCount, toiGroupList, toiMoved, toiNew, toiParent, toiDomOf, toiDomRoot, toiDomCount, toiDomBase, toiDomFill, toiDomList, toiDomFailed, toiDomEvents;
 	DevArray<float4> toiHull;
 	DevArray<float4> snapBody, snapFat;
 	DevArray<ShapeRec> d_shapes;
@@ -289,6 +289,8 @@ struct b2hip_world
 	bool adoptPasses = false;    // the last step had orphan constraints (or made a partition): run k_block_adopt this step
 	bool traceLaunches = false;  // B2HIP_TRACE_LAUNCHES=1 (with B2HIP_DEBUG): every kernel's name before the stream is drained behind it
 	bool tracePartition = false; // B2HIP_TRACE_PARTITION=1: why a partition was made, on stderr
+	int toiGridRetries = 0;      // steps whose chains were run again with the hash grid instead of serially
+	int toiChainContacts = 0;    // contacts created by the close-out of the parallel TOI chains since the world was made
 	bool blocksTooBig = false;   // the large islands hold more constraints than any block solver takes: no partition (phaseSolve)
 	bool noSweepBlocks = false;  // B2HIP_NO_SWEEP_BLOCKS=1: jointed / hub islands stay on the launch-per-colour kernels
 	int dfWipedAt = 0;           // dfEpoch >> 14 at the last wipe of the hand-over rows
@@ -329,6 +331,7 @@ struct b2hip_world
 	int* constsUploadedAt = nullptr;
 	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
+	bool toiChainsHadGrid = false; // the chains of this step ran with the grid (else a moved proxy is all "unsafe" means)
 	bool toiSnapshotTaken = false; // this step's TOI phase saved the state it started from (k_toi_snapshot)
 	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false, toiNoDomains = false;
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
@@ -810,7 +813,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(scanFlags, std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 8);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
-	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
+	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiNew, 8 * TOI_NEWPAIR_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	{
 		// listener bridge buffers: contact-sized only while the callback that needs them is installed
 		const size_t nPre = hasPreSolve(w) ? cc : 1, nPost = w->postSolveOn ? cc : 1, nFil = hasFilter(w) ? cc : 1;
@@ -899,7 +902,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.stateOut = w->stateOut.p;
 	d.b_proxyHead = w->b_proxyHead.p; d.p_next = w->p_next.p; d.toiList = w->toiList.p;
 	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
-	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p; d.toiParent = w->toiParent.p; d.toiDomOf = w->toiDomOf.p; d.toiDomRoot = w->toiDomRoot.p; d.toiDomCount = w->toiDomCount.p; d.toiDomBase = w->toiDomBase.p; d.toiDomFill = w->toiDomFill.p; d.toiDomFailed = w->toiDomFailed.p; d.toiDomEvents = w->toiDomEvents.p; d.toiDomList = w->toiDomList.p; d.toiHull = w->toiHull.p;
+	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p; d.toiNew = w->toiNew.p; d.toiParent = w->toiParent.p; d.toiDomOf = w->toiDomOf.p; d.toiDomRoot = w->toiDomRoot.p; d.toiDomCount = w->toiDomCount.p; d.toiDomBase = w->toiDomBase.p; d.toiDomFill = w->toiDomFill.p; d.toiDomFailed = w->toiDomFailed.p; d.toiDomEvents = w->toiDomEvents.p; d.toiDomList = w->toiDomList.p; d.toiHull = w->toiHull.p;
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.b_adoptStage = w->b_adoptStage.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p; d.blkBodyCount = w->blkBodyCount.p; d.blkBodyCursor = w->blkBodyCursor.p;
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
@@ -2087,6 +2090,7 @@ static int phaseToi(b2hip_world* w)
 	}
 	LAUNCH(w, k_toi_chains, 1024, CHAIN_LANES, d, w->sp, haveGrid);
 	// (k_toi_clear's work is done by k_end_step, which follows)
+	w->toiChainsHadGrid = haveGrid != 0;
 	w->toiChains = true;
 	w->toiSpeculative = true;
 	return 0;
@@ -2149,6 +2153,7 @@ static int phaseToiSync(b2hip_world* w)
 		}
 		LAUNCH(w, k_toi_chains, std::min(groups, 1024), CHAIN_LANES, d, w->sp, haveGrid);
 			LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+		w->toiChainsHadGrid = haveGrid != 0;
 		w->toiChains = true;
 		return 0;
 	}
@@ -2175,6 +2180,7 @@ static int phaseToiSync(b2hip_world* w)
 		LAUNCH(w, k_toi_dom_rollback, gridFor(std::max(std::max(d.nBodies, d.nProxies), d.capContacts)), 256, d);
 		LAUNCH(w, k_toi_loop_partial, 1, TOI_LANES, d, w->sp);
 		LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+		w->toiChainsHadGrid = true; // (the components always have it)
 		w->toiChains = true;
 		return 0;
 	}
@@ -2404,6 +2410,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverMailbox = getenv("B2HIP_SOLVER_MAILBOX") != nullptr; // pushed hand-offs for every constraint (k_solve_mailbox) instead of k_solve_blocks
 	w->noSweepBlocks = getenv("B2HIP_NO_SWEEP_BLOCKS") != nullptr;
 	w->tracePartition = getenv("B2HIP_TRACE_PARTITION") != nullptr;
+	w->dw.noChainCreate = getenv("B2HIP_TOI_NO_CHAIN_CREATE") != nullptr ? 1 : 0;
 	w->traceLaunches = getenv("B2HIP_TRACE_LAUNCHES") != nullptr;
 	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
 	w->blockLanes = 0; // chosen per partition (see phaseSolve); B2HIP_BLOCK_LANES = 256 | 512 | 1024 forces one size
@@ -2509,7 +2516,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
 	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release(); w->hubRowOf.release(); w->hubList.release(); w->hubDelta.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
-	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
+	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiNew.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
@@ -3866,6 +3873,25 @@ static int stepEndImpl(b2hip_world* w)
 	{
 		// a chain met an order-dependent case: back to the state before the chains, then the reference's serial order
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		if (w->h_dstate->c.toiUnsafe == 4 /* TOI_UNSAFE_PAIR */ && !w->toiChainsHadGrid && !w->dw.noChainCreate)
+		{
+			// ... unless all that happened is that a chain moved a proxy out of its fat AABB while the hash grid was not kept
+			// up (nothing had moved for 16 steps): the chains once more, with the grid - most such moves find nothing, or a
+			// pair the chains' close-out can create itself. (The serial loop costs ~50 us per event: 15 ms for the 290 resting
+			// impacts of a 50 000-box pyramid; this costs a second first pass.)
+			w->toiGridSticky = 16;
+			w->toiChains = false;
+			w->toiSpeculative = false;
+			rc = phaseToiSync(w);
+			if (rc) return rc;
+			rc = downloadState(w, -1);
+			if (rc) return rc;
+			w->toiGridRetries += 1;
+			if (w->toiChains && w->h_dstate->c.toiUnsafe != 0) LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		}
+	}
+	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
+	{
 		if (getenv("B2HIP_TOI_WHY")) fprintf(stderr, "b2hip: TOI fallback to the serial loop, unsafe bits 0x%x (1 partner, 2 woke, 4 new pair, 8 capacity, 16 moved proxies), %d pending, %d components\n", w->h_dstate->c.toiUnsafe, w->h_dstate->c.nToiList, w->h_dstate->c.nToiDomains);
 		rc = toiSerial(w);
 		if (rc) return rc;
@@ -4019,6 +4045,7 @@ static int stepEndImpl(b2hip_world* w)
 	w->last.nHubRows = c.nHubRows;
 	w->last.hubRounds = c.hubRounds;
 	w->last.hubSerialChunks = c.hubSerialChunks;
+	w->toiChainContacts += c.nToiChainCreated;
 	if (w->toiRan)
 	{
 		w->last.toiUnsafe = c.toiUnsafe;
@@ -4993,6 +5020,7 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->hub_constraints = w->last.nHubRows;
 	out->hub_fixpoint_rounds = w->last.hubRounds;
 	out->hub_serial_chunks = w->last.hubSerialChunks;
+	out->toi_chain_contacts = w->toiChainContacts;
 	return 0;
 }
 

@@ -318,6 +318,7 @@ typedef struct b2hip_counters
 	int32_t hub_constraints;         /* hub constraints in the last step */
 	int32_t hub_fixpoint_rounds;     /* rounds of the fixed-point form of that sweep in the last step (all sweeps) */
 	int32_t hub_serial_chunks;       /* chunks of 64 hub constraints swept lane after lane instead */
+	int32_t toi_chain_contacts;      /* contacts (since creation) the parallel TOI chains left for their close-out to create in event order */
 } b2hip_counters;
 
 const char* b2hip_last_error(void);

@@ -85,6 +85,43 @@ def test_ccd_side_by_side_with_c_oracle(amd, oracle, exact_mode, scene, p0, p1, 
     assert np.array_equal(ma.view(np.uint32), mo.view(np.uint32))
 
 
+def test_ccd_chains_create_contacts_between_moving_bodies_in_event_order(amd, default_mode, monkeypatch):
+    """A box that lands on the ground through a TOI event next to others: its re-inserted proxy finds a NEW pair with a
+    neighbour. The reference creates that contact inside the sub-step; the parallel chains note it (two moving, non-bullet
+    bodies: the contact takes no part in the rest of the phase) and their close-out creates what was noted in the reference's
+    order - event by event, pairs by proxy ids - instead of sending the whole phase to the serial loop. The serial loop IS the
+    reference's order (pinned against the oracle by the tests above), so: the same world with the hand-over switched off
+    (B2HIP_TOI_NO_CHAIN_CREATE=1: such steps are replayed serially) must give the same bits - states every step, contact
+    ARRAY order and manifolds every tenth (the order is what later steps depend on)."""
+    import b2hip
+
+    def run(no_chain_create):
+        if no_chain_create:
+            monkeypatch.setenv("B2HIP_TOI_NO_CHAIN_CREATE", "1")
+        else:
+            monkeypatch.delenv("B2HIP_TOI_NO_CHAIN_CREATE", raising=False)
+        w = amd.world(bh.RAIN, 1500, 0, seed=7, flags=CCD)
+        out = []
+        for s in range(300):
+            w.step(1)
+            h = [bh.fnv1a64(w.bodies()), w.contact_count]
+            if s % 10 == 9:
+                ids, flags, man = w.contacts()
+                h += [bh.fnv1a64(ids), bh.fnv1a64(flags), bh.fnv1a64(man)]
+            out.append(tuple(h))
+        ctr = b2hip.Counters()
+        b2hip.lib().b2hip_get_counters(C.c_void_p(w.device_world()), C.byref(ctr))
+        w.close()
+        return out, ctr.toi_chain_contacts, ctr.toi_serial_fallbacks
+
+    a, created, fallbacks = run(False)
+    b, created_b, fallbacks_b = run(True)
+    assert created > 0, "the chains never left a contact to their close-out: the test is vacuous"
+    assert created_b == 0 and fallbacks_b > fallbacks
+    first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), None)
+    assert first is None, "close-out creation and serial replay diverge at step %s" % first
+
+
 def test_ccd_keeps_projectiles_inside_on_device(amd, default_mode):
     """The point of the TOI phase: no projectile tunnels through the 0.1-wide walls; with it off many do."""
     def escaped(flags):
