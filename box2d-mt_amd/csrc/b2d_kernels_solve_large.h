@@ -86,6 +86,17 @@ __device__ __forceinline__ bool constraintIsCut(const DW& W, int bodyA, bool nsA
 {
 	return nsA && nsB && effBlk(W, bodyA) != effBlk(W, bodyB);
 }
+// Colours a constraint may not KEEP from one step to the next. On top of colorClassMask: an interior constraint in the upper
+// range is a leftover - it was a cut constraint until its two bodies came to share a block (a new partition: the 50 086-box
+// pyramid makes one every few steps) - and would go on being handed over through memory for no reason: after 84 partitions
+// 105 000 of that pile's 135 000 constraints sat in the upper range although 15 000 were cut (k_solve_blocks 549 us).
+// It gives the colour up and takes the lowest free one again (in the rare case that this is an upper colour once more - both
+// bodies holding 32 others - it does so every step: correct, merely busy).
+__device__ __forceinline__ uint64_t colorStaleMask(bool cut)
+{
+	const uint64_t lower = (1ull << CUT_COLOR_BASE) - 1ull, hub = 1ull << HUB_COLOR;
+	return (cut ? lower : ~lower) | hub;
+}
 // Colours a constraint of this class may NOT take. A cut constraint must sit in the upper range (k_solve_blocks hands the
 // bodies of upper-range constraints over through memory, and only those). An interior constraint takes the lowest free
 // colour, which lies in the lower range unless one of its bodies already holds 32 colours; it may spill into the upper
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		int4 ids = C.ids[i];
 		const unsigned long long bit = 1ull << col;
 		const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-		if (bit & colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))
+		if (bit & colorStaleMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))
 		{
 			// the constraint changed class (a body moved to another block, a new partition): its colour is void
 			C.color[i] = -1;
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 				}
 			}
 			col = C.color[ci];
-			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
+			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorStaleMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
 			if (hubA || hubB)
 			{
 				// a hub constraint owns no colour (and reserves none from the next step on)
