@@ -289,6 +289,7 @@ struct b2hip_world
 	bool adoptPasses = false;    // the last step had orphan constraints (or made a partition): run k_block_adopt this step
 	bool traceLaunches = false;  // B2HIP_TRACE_LAUNCHES=1 (with B2HIP_DEBUG): every kernel's name before the stream is drained behind it
 	bool tracePartition = false; // B2HIP_TRACE_PARTITION=1: why a partition was made, on stderr
+	int pairsLargeSticky = 0;    // steps for which the pair update still reads its pair count back before it sorts
 	int toiGridRetries = 0;      // steps whose chains were run again with the hash grid instead of serially
 	int toiChainContacts = 0;    // contacts created by the close-out of the parallel TOI chains since the world was made
 	bool blocksTooBig = false;   // the large islands hold more constraints than any block solver takes: no partition (phaseSolve)
@@ -1380,6 +1381,11 @@ static int findNewContactsGraph(b2hip_world* w)
 {
 	// (a user contact filter is asked on the host in the middle of the update: synchronous, no graph)
 	if (hasFilter(w)) return findNewContacts(w, true);
+	// A scene that creates more pairs per step than the optimistic counting path ranks (the settled 50 086-box pyramid and the
+	// 100 000-box Tumbler: ~25 000 and ~150 000 new fat-AABB pairs per step) would find that out at the end of the step, sort
+	// with the radix path then - and run the TOI phase and the read-back a second time, every step. While that has happened
+	// lately the host looks at the pair count right after the search instead (one small read-back) and takes the right path.
+	if (w->pairsLargeSticky > 0) return findNewContacts(w, true);
 	return runSegment(w, w->segPairs, 3, [w]() -> int { return findNewContacts(w, false); });
 }
 
@@ -1429,8 +1435,10 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 			rc = growPairBuffers(w);
 			return rc ? rc : 1;
 		}
-		if (w->h_dstate->c.nMoves == 0) return 0;
+		if (w->h_dstate->c.nMoves == 0) { if (w->pairsLargeSticky > 0) w->pairsLargeSticky -= 1; return 0; }
 		large = w->h_dstate->c.nPairs > COUNT_RANK_MAX;
+		if (large) w->pairsLargeSticky = 16;
+		else if (w->pairsLargeSticky > 0) w->pairsLargeSticky -= 1;
 	}
 	return runSortAndCreate(w, large);
 }
@@ -3830,6 +3838,7 @@ static int stepEndImpl(b2hip_world* w)
 	{
 		if (w->h_dstate->c.nPairs > COUNT_RANK_MAX || pairOverflow)
 		{
+			w->pairsLargeSticky = 16; // (the next steps ask for the pair count right after the search: findNewContactsGraph)
 			const bool redoToi = w->toiSpeculative;
 			if (redoToi && w->h_dstate->c.nToiList > 0)
 			{
