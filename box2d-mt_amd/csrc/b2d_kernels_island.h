@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		W.parent[i] = i;
-		W.rootSeed[i] = 0x7fffffff;
-		W.rootBodies[i] = 0;
+		// (rootSeed / rootBodies start with the body's OWN contribution, below: a body that stays its own root - 97 % of the
+		// bodies of the 1 M field - then sends no atomic at all in k_island_flatten; only members add to their root)
 		W.rootContacts[i] = 0;
 		W.rootJoints[i] = 0;
 		W.rootIsland[i] = ROOT_NONE;
@@ -201,6 +201,10 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 			W.b_wake[i] = 0;
 		}
 		W.b_flags[i] = f;
+		const bool member = (f & BF_TYPE_MASK) != BT_STATIC && (f & BF_ACTIVE) != 0;
+		W.rootBodies[i] = member ? 1 : 0;
+		// seeds are taken in m_nonStaticBodies order (b2World.cpp:1207-1221): first awake, active body
+		W.rootSeed[i] = member && (f & BF_AWAKE) != 0 ? W.b_order[i] : 0x7fffffff;
 	}
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x) W.joints[j].islandFlag = 0;
 	if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -293,9 +297,10 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 			}
 			if (waveLane() == 0 && dg > 0) atomicMax(&W.st->c.maxDegree, dg);
 		}
-		waveAtomicAddInt(W.rootBodies, r, 1, valid);
-		// seeds are taken in m_nonStaticBodies order (b2World.cpp:1207-1221): first awake, active body
-		waveAtomicMinInt(W.rootSeed, r, valid ? W.b_order[i] : 0, valid && (f & BF_AWAKE) != 0);
+		// (a root has counted itself and offered its own seed in k_island_init: only the other members add to it)
+		const bool other = valid && r != i;
+		waveAtomicAddInt(W.rootBodies, r, 1, other);
+		waveAtomicMinInt(W.rootSeed, r, other ? W.b_order[i] : 0, other && (f & BF_AWAKE) != 0);
 	}
 }
 

@@ -434,7 +434,7 @@ def test_config_3_at_full_size_properties_and_determinism(amd, oracle, default_m
         assert r.max() <= np.sqrt(2.0) * (S + 0.5) + 0.25, "step %d: a box left the container (r = %.2f)" % (step, r.max())
         # the container (body 1) turns at 0.05 pi rad/s about its pin
         assert abs(ba[1, 5] - 0.05 * np.pi) < 1e-3 and abs(ba[1, 2] - 0.05 * np.pi * step / 60.0) < 2e-3, "step %d: container %s" % (step, ba[1])
-        assert 0 <= ca <= 16 * n
+        assert 0 <= ca <= 64 * n  # (fat-AABB pairs: the falling grid passes through ~50 per box around step 240)
     assert a[-1][1] > 50000, "the pile has not formed: %d contacts" % a[-1][1]
 
 
