@@ -292,6 +292,7 @@ struct b2hip_world
 	int pairsLargeSticky = 0;    // steps for which the pair update still reads its pair count back before it sorts
 	int toiGridRetries = 0;      // steps whose chains were run again with the hash grid instead of serially
 	int toiChainContacts = 0;    // contacts created by the close-out of the parallel TOI chains since the world was made
+	int recolorCountdown = 0;    // ... and steps until such islands are coloured afresh (phaseSolve)
 	bool blocksTooBig = false;   // the large islands hold more constraints than any block solver takes: no partition (phaseSolve)
 	bool noSweepBlocks = false;  // B2HIP_NO_SWEEP_BLOCKS=1: jointed / hub islands stay on the launch-per-colour kernels
 	int dfWipedAt = 0;           // dfEpoch >> 14 at the last wipe of the hand-over rows
@@ -1631,6 +1632,20 @@ static int phaseSolve(b2hip_world* w)
 			colorSmallQueued = false;
 		}
 		(void)was;
+		// Without a partition every colour is a launch of every sweep, and colours handed out one new contact at a time creep
+		// up (24 in use on the settled Tumbler where a colouring from scratch needs 19 - five colours are 0.3 ms of its step):
+		// every 64th step the island is coloured afresh.
+		if (w->blocksTooBig && forceLarge != 2 && !w->noBlocks && c.nLIslands > 0)
+		{
+			if (w->recolorCountdown <= 0)
+			{
+				c.needRecolor = 1;
+				colorSmallQueued = false;
+				w->recolorCountdown = 64;
+			}
+			w->recolorCountdown -= 1;
+		}
+		else w->recolorCountdown = 0;
 	}
 	// (from the next step on: in islands with joints / hubs the constraints of such newcomers are swept in order instead)
 	w->serialOrphansNext = (forceLarge != 2 && !w->noBlocks && !w->noSweepBlocks && !w->blocksTooBig && c.nBlocks > 0 && (d.nJoints > 0 || c.maxDegree > HUB_DEGREE)) ? 1 : 0;
@@ -4247,7 +4262,7 @@ struct SnapHeader
 	uint32_t stateCount, cur;
 	int32_t nextNode, leafCount, lastContacts, newFixture;
 	float inv_dt0, cellSize;
-	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bit 1 blocksTooBig, bits 8..15 adoptSticky, 16..23 largeHintSteps (what the next island build is told)
+	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bit 1 blocksTooBig, bits 8..15 adoptSticky, 16..23 largeHintSteps, 24..30 recolorCountdown (what the next island build is told)
 };
 const uint32_t kSnapVersion = 4;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
@@ -4320,7 +4335,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
 	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
 	h.eventsOn = w->eventsOn ? 1 : 0;
-	h.solverHints = (w->serialOrphansNext ? 1 : 0) | (w->blocksTooBig ? 2 : 0) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16);
+	h.solverHints = (w->serialOrphansNext ? 1 : 0) | (w->blocksTooBig ? 2 : 0) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16) | ((w->recolorCountdown & 0x7f) << 24);
 	SnapWriter o;
 	o.host(&h, sizeof(h));
 	o.host(&w->def, sizeof(w->def));
@@ -4541,6 +4556,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	w->blocksTooBig = (h.solverHints & 2) != 0;
 	w->adoptSticky = (h.solverHints >> 8) & 0xff;
 	w->largeHintSteps = (h.solverHints >> 16) & 0xff;
+	w->recolorCountdown = (h.solverHints >> 24) & 0x7f;
 	w->adoptPasses = w->adoptSticky > 0;
 	rc = ensureCapacity(w, nC);
 	if (rc) return fail(rc);
