@@ -29,7 +29,7 @@
 #ifndef B2D_KERNELS_SOLVE_BLOCKS_H
 #define B2D_KERNELS_SOLVE_BLOCKS_H
 
-#include "b2d_kernels_solve_dataflow.h"
+#include "b2d_handover.h"
 
 // ---- exclusive scan + maximum of up to 1024 ints held one per lane (1024-lane workgroup) -------------------------------------
 __device__ __forceinline__ int blockScan1024(int v, int* s_buf /* [2 * 1024] */, int* total, int* maximum)

@@ -30,8 +30,10 @@
 // used by tests/test_gpu_parity.py::test_block_solver_matches_launch_per_colour). The product has two large-island
 // solvers: k_solve_blocks and, where it does not apply (joints, hubs, exact-order mode, a partition that does not fit),
 // the launch-per-colour kernels.
-#include "b2d_kernels_solve_dataflow.h"
-#include "b2d_kernels_solve_mailbox.h"
+#include "b2d_handover.h"
+#ifdef B2HIP_VALIDATION_SOLVERS
+#include "../validation_src/b2d_validation_solvers.h"
+#endif
 #ifdef B2HIP_VALIDATION_SOLVERS
 #define B2HIP_HAVE_VALIDATION_SOLVERS 1
 #else
@@ -796,7 +798,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, nb * DF_RANKS); ENS(dfInbox, 2 * cc); ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, B2HIP_HAVE_VALIDATION_SOLVERS ? nb * 32 : 1); ENS(dfInbox, B2HIP_HAVE_VALIDATION_SOLVERS ? 2 * cc : 1); /* (mailbox tables of the test build's k_solve_mailbox: DF_RANKS = 32 slots per body) */ ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -1860,7 +1862,7 @@ static int phaseSolve(b2hip_world* w)
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
 		if (useResident)
 		{
-			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (b2d_kernels_solve_persist.h)
+			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (validation_src/b2d_validation_solvers.h)
 			// (the barrier words were zeroed by k_step_begin: one resident launch per step)
 			if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; w->ktKind = useBlocks ? 4 : 3; }
 			const int nColorsArg = colorsOnDevice ? -1 : nColors; // -1: read Counters::nColors on the device

@@ -443,7 +443,7 @@ def test_block_solver_matches_launch_per_colour(amd, default_mode):
     bodies handed over through memory) must reproduce the launch-per-colour solver bit for bit - same partition, same
     colours, same sweep structure, same arithmetic - and so must the three earlier resident solvers (pushed mailboxes,
     polled body rows, grid barrier per colour), which live only in the test build of the library
-    (box2d-mt_amd/validation/, -DB2HIP_VALIDATION_SOLVERS). Multi-block islands (Pyramid 90: 4 095 boxes, Pyramid 141: the
+    (sources box2d-mt_amd/validation_src/, built into box2d-mt_amd/validation/, -DB2HIP_VALIDATION_SOLVERS). Multi-block islands (Pyramid 90: 4 095 boxes, Pyramid 141: the
     bench workload), single-block ones (Pyramid 40) and a dense field whose islands come and go."""
     import ctypes as C
     import b2hip
