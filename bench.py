@@ -278,7 +278,17 @@ def main():
         raw.L = hipL
         sharded = sharding.ShardedWorld(raw, dist=dist, device=torch.device("cuda", local_rank))
         if dist.get_backend() == "nccl":
-            sharded.connect_rccl()
+            # the library's own RCCL communicator on the world's stream; if it cannot be had (librccl not found ...) - on every
+            # rank alike - the exchange falls back to torch.distributed's all-gather between the phase calls
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            try:
+                sharded.connect_rccl()
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("bench.py: b2hip_shard_connect failed on rank %d (%s): torch.distributed all-gather instead\n" % (rank, e))
+                ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and sharded.connected:
+                raise RuntimeError("b2hip_shard_connect succeeded on some ranks only")
         step_world = lambda n=1: [sharded.step(1.0 / 60.0, w.vel_iters, w.pos_iters) for _ in range(n)]
     else:
         step_world = lambda n=1: w.step(n)
@@ -510,7 +520,9 @@ def main():
             line["extra_configs"] = extras
         if sharded is not None:
             line["exchange_bytes_per_step"] = exchange_bytes
-            line["exchange"] = "one all-gather per step of owner-sized slabs (records of the islands each rank solved), RCCL on the world's stream from inside the library, inside the timed region"
+            line["exchange"] = ("one all-gather per step of owner-sized slabs (records of the islands each rank solved), " +
+                                ("RCCL on the world's stream from inside the library" if sharded.connected else "torch.distributed between the phase calls (the library's own RCCL connection could not be made)") +
+                                ", inside the timed region")
         if roof is not None:
             line["roofline"] = roof
         if exact_order is not None:
