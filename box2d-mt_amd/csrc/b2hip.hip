@@ -1349,9 +1349,10 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		int2* vin = d.pairProxy;
 		int2* vout = d.pairProxy2;
 		const int tilesCap = d.capPairs / RADIX_TILE + 1;
+		// (the length of the histogram matrix depends on the pair count only: once per sort, not once per pass)
+		LAUNCH(w, k_radix_count, 1, 1, &d.st->c.nPairs, 0, w->consts.p + 2);
 		for (size_t p = 0; p < shifts.size(); ++p)
 		{
-			LAUNCH(w, k_radix_count, 1, 1, &d.st->c.nPairs, 0, w->consts.p + 2);
 			LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, &d.st->c.nPairs, 0, shifts[p], tilesCap);
 			deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanCtx, w->consts.p + 2, 256 * tilesCap);
 			LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, &d.st->c.nPairs, 0, shifts[p]);
@@ -1490,9 +1491,9 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	for (int sft = 0; sft < 32; sft += 8) shifts.push_back(32 + sft);
 	const int tilesCap = d.capPairs / RADIX_TILE + 1;
 	const int* nPtr = &d.st->c.nLBodies;
+	LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
 	for (size_t p = 0; p < shifts.size(); ++p)
 	{
-		LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
 		LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, nPtr, 0, shifts[p], tilesCap);
 		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanCtx, w->consts.p + 2, 256 * tilesCap);
 		LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, nPtr, 0, shifts[p]);
