@@ -30,6 +30,10 @@ ENTRIES = [
     ("Vehicles (wheel, rope, friction, motor, mouse)", H.VEHICLES, dict(p0=200, p1=6, seed=3, flags=CCD), 300, True),
     ("Tumbler 20", H.TUMBLER, dict(p0=20, p1=0, flags=H.F_SLEEP | H.F_WARM), 200, True),
     ("Tumbler 100", H.TUMBLER, dict(p0=100, p1=0, flags=H.F_SLEEP | H.F_WARM), 120, False),
+    ("Chains (b2ChainShape terrain)", H.CHAINS, dict(p0=70, p1=0, seed=21, flags=CCD), 240, True),
+    ("Life cycle (edits between steps)", H.LIFECYCLE, dict(p0=48, p1=0, seed=5, flags=CCD), 200, True),
+    ("Pyramid 316 (config 4's share)", H.PYRAMID, dict(p0=316, p1=1, flags=CCD), 340, False),
+    ("Tumbler 316 (config 3)", H.TUMBLER, dict(p0=316, p1=0, flags=H.F_SLEEP | H.F_WARM), 160, False),
 ]
 COLS = ["step", "broadphase", "broadphaseFindContacts", "broadphaseSyncFixtures", "collide", "solve", "solveTraversal",
         "solveInit", "solvePosition", "solveVelocity", "solveTOI", "solveTOIFindMinContact", "locking"]
