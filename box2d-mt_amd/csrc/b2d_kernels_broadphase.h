@@ -61,28 +61,53 @@ __device__ __forceinline__ uint32_t cellHash(int ix, int iy, uint32_t mask)
 	return h & mask;
 }
 
-// The cell of the hashed grid. DW::cellSize is sized from the fixtures as they were created; fat AABBs of fast bodies
-// stretch (b2DynamicTree::MoveProxy adds twice the displacement), and a proxy wider than a cell takes the brute-force
-// "large proxy" path: thousands of falling boxes did in the Tumbler. So the cell follows the widest proxy of this pair
-// update (k_bp_clear reduces it into Counters::cellExtBits), capped at 4 x the static size - beyond that a proxy is an
-// outlier (a ground box) and stays on the large path. The pair SET does not depend on the cell.
-__device__ __forceinline__ float gridCellSize(const DW& W)
+// The geometry of the hashed grid. gridLimit: the widest proxy that goes through the grid at all. DW::cellSize is sized from the
+// fixtures as they were created; fat AABBs of fast bodies stretch (b2DynamicTree::MoveProxy adds twice the displacement), and
+// a proxy wider than the limit takes the brute-force "large proxy" path: thousands of falling boxes did in the Tumbler. So
+// the limit follows the widest proxy of this pair update (k_bp_clear reduces it into Counters::cellExtBits), capped at 4 x
+// the static size - beyond that a proxy is an outlier (a ground box) and stays on the large path.
+// gridCell: the cell is the limit, or - in dense scenes (DW::gridHalf) - half of it. Proxies are binned by the cell of their
+// centre, so every partner of a box `a` has its centre inside `a` grown by half the limit (gridWindow); with a cell as wide
+// as the limit that window is 3 x 3 cells = 9 limit^2 of candidates for every proxy, however small - 355 per moved proxy on
+// the settled Tumbler, where the pair search runs at 12 G candidates per second whatever its form. Half cells make the
+// window follow the proxy - 4-5 cells a side, (extent + 1.5 limit)^2: Tumbler 730 -> 590 us, Pyramid 316 237 -> 207 us - but
+// cost a sparse scene more cells to look up than candidates to save (1 M field: 370 -> 500 us). The host switches on the
+// candidates per moved proxy of the previous update (Counters::candRounds). The pair SET does not depend on any of this.
+__device__ __forceinline__ float gridLimit(const DW& W)
 {
 	const float dyn = 1.05f * __uint_as_float(W.st->c.cellExtBits);
 	return dyn > W.cellSize ? dyn : W.cellSize;
 }
+__device__ __forceinline__ float gridCell(const DW& W) { return W.gridHalf ? 0.5f * gridLimit(W) : gridLimit(W); }
 
 __device__ __forceinline__ bool proxyIsLarge(const DW& W, float4 a)
 {
-	const float cell = gridCellSize(W);
-	return (a.z - a.x) > cell || (a.w - a.y) > cell;
+	const float limit = gridLimit(W);
+	return (a.z - a.x) > limit || (a.w - a.y) > limit;
 }
 
 __device__ __forceinline__ void proxyCell(const DW& W, float4 a, int* ix, int* iy)
 {
-	const float inv = 1.0f / gridCellSize(W);
+	const float inv = 1.0f / gridCell(W);
 	*ix = (int)floorf(0.5f * (a.x + a.z) * inv);
 	*iy = (int)floorf(0.5f * (a.y + a.w) * inv);
+}
+
+// The cells that can hold a partner of `a`: [ix0, ix0 + nx) x [iy0, iy0 + ny). false: degenerate or absurdly large (NaN, a
+// box of kilometres): the caller looks at everything.
+#define GRID_WINDOW_MAX 36 // cells of the window of a grid-sized proxy: at most 6 x 6 (extent <= limit = 2 cells, + 1 either side, + rounding)
+__device__ __forceinline__ bool gridWindow(const DW& W, float4 a, int* ix0, int* iy0, int* nx, int* ny)
+{
+	const float limit = gridLimit(W), inv = 1.0f / gridCell(W), half = 0.5f * limit;
+	const float fx0 = floorf((a.x - half) * inv), fx1 = floorf((a.z + half) * inv);
+	const float fy0 = floorf((a.y - half) * inv), fy1 = floorf((a.w + half) * inv);
+	const float cells = (fx1 - fx0 + 1.0f) * (fy1 - fy0 + 1.0f);
+	if (!(cells >= 1.0f && cells <= 4096.0f)) return false;
+	*ix0 = (int)fx0;
+	*iy0 = (int)fy0;
+	*nx = (int)(fx1 - fx0) + 1;
+	*ny = (int)(fy1 - fy0) + 1;
+	return true;
 }
 
 // force = 1: rebuild the grid although the move buffer is empty (the TOI phase queries it and needs it to reflect
@@ -191,6 +216,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	const int lane = (int)(threadIdx.x & 63u);
 	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
+	int rounds = 0;
 	for (int k = waveId; k < nm; k += nWaves)
 	{
 		const int p = W.moveBuf[k];
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 		}
 		const int excl = incl - cnt;
 		const int total = __shfl(incl, 8);
+		rounds += (total + 63) >> 6;
 		for (int base = 0; base < total; base += 64)
 		{
 			const int idx = base + lane;
@@ -247,6 +274,84 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
+	if (lane == 0 && rounds > 0) atomicAdd(&S->c.candRounds[waveId & 31], rounds);
+}
+
+
+// The same with half cells (DW::gridHalf): lane c owns cell c of the proxy's window (gridWindow).
+// One WAVE per moved SMALL proxy. The candidates of its 3x3 cell neighbourhood are flattened into one
+// index space so that 64 candidates are fetched and tested at once (the per-candidate chain
+// item -> fat AABB -> filters -> hash probe is then paid once per wave, not once per candidate).
+__global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const int nm = S->c.nMoves < W.capMoves ? S->c.nMoves : W.capMoves;
+	const int nLarge = S->c.nLargeProxies;
+	const int lane = (int)(threadIdx.x & 63u);
+	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
+	int rounds = 0;
+	for (int k = waveId; k < nm; k += nWaves)
+	{
+		const int p = W.moveBuf[k];
+		if (p < 0 || W.p_body[p] < 0) continue;
+		const float4 a4 = W.p_fat[p];
+		if (proxyIsLarge(W, a4))
+		{
+			// (for k_find_pairs_large; the list is as long as the move buffer)
+			if (lane == 0) W.largeMoves[atomicAdd(&S->c.nLargeMoves, 1)] = p;
+			continue;
+		}
+		AABB a;
+		a.lo = v2(a4.x, a4.y);
+		a.hi = v2(a4.z, a4.w);
+		// the window of this proxy: lane c owns cell c of it; cells that hash to a bucket already seen are dropped. Full cells:
+		// always the 3 x 3 neighbourhood of the centre's cell; half cells: what gridWindow says (at most GRID_WINDOW_MAX)
+		int wx0 = 0, wy0 = 0, wnx = 1, wny = 1;
+		(void)gridWindow(W, a4, &wx0, &wy0, &wnx, &wny); // (a grid-sized proxy: always a window of a few cells)
+		const int nCells = wnx * wny < GRID_WINDOW_MAX ? wnx * wny : GRID_WINDOW_MAX;
+		uint32_t h = lane < nCells ? cellHash(wx0 + lane % wnx, wy0 + lane / wnx, W.gridMask) : 0xffffffffu;
+		bool dup = false;
+		for (int j = 0; j < nCells; ++j)
+		{
+			uint32_t hj = (uint32_t)__shfl((int)h, j);
+			if (j < lane && lane < nCells && hj == h) dup = true;
+		}
+		const int cnt = (lane < nCells && !dup) ? W.gridCount[h] : 0;
+		const int start = lane < nCells ? W.gridStart[h] : 0;
+		int incl = cnt;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			int v = __shfl_up(incl, off);
+			if (lane >= off) incl += v;
+		}
+		const int excl = incl - cnt;
+		const int total = __shfl(incl, 63);
+		rounds += (total + 63) >> 6;
+		for (int base = 0; base < total; base += 64)
+		{
+			const int idx = base + lane;
+			const bool valid = idx < total;
+			int t = -1;
+			for (int c = 0; c < nCells; ++c)
+			{
+				const int ec = __shfl(excl, c), cc = __shfl(cnt, c), sc = __shfl(start, c);
+				if (valid && idx >= ec && idx < ec + cc) t = sc + (idx - ec);
+			}
+			if (t >= 0)
+			{
+				const int q = W.gridItems[t];
+				if (q != p && b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
+			}
+		}
+		for (int t = lane; t < nLarge; t += 64)
+		{
+			const int q = W.largeProxies[t];
+			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
+		}
+	}
+	if (lane == 0 && rounds > 0) atomicAdd(&S->c.candRounds[waveId & 31], rounds);
 }
 
 // Moved LARGE proxies (listed by k_find_pairs_small): brute force over every proxy, a workgroup per (proxy, slice of 1024

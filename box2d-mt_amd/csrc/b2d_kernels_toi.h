@@ -50,23 +50,19 @@ __device__ __forceinline__ Sweep loadSweep(const DW& W, int body)
 }
 
 // Candidate partners of a re-inserted proxy: every proxy whose fat AABB can overlap `a`, found through the hash grid
-// (proxies are binned by the cell of their centre and are at most one cell wide, so the centres of all partners lie in
-// `a` grown by half a cell), plus the proxies that are wider than a cell, plus the proxies whose fat AABB changed since the
+// (proxies are binned by the cell of their centre and are at most gridLimit wide, so the centres of all partners lie in
+// `a` grown by half that limit: gridWindow), plus the proxies that are wider than a cell, plus the proxies whose fat AABB changed since the
 // grid was built (`moved`: their bin is stale). f(q) may be called more than once for the same q.
 template <typename F>
 __device__ __forceinline__ void toiForEachCandidate(const DW& W, AABB a, int lane, int nLanes, const int* moved, int nMoved, F f)
 {
-	const float cell = gridCellSize(W), inv = 1.0f / cell;
-	const float half = 0.5f * cell;
-	const float fx0 = floorf((a.lo.x - half) * inv), fx1 = floorf((a.hi.x + half) * inv);
-	const float fy0 = floorf((a.lo.y - half) * inv), fy1 = floorf((a.hi.y + half) * inv);
-	const float cells = (fx1 - fx0 + 1.0f) * (fy1 - fy0 + 1.0f);
-	if (!(cells >= 1.0f && cells <= 4096.0f))
+	int ix0, iy0, nx, ny;
+	if (!gridWindow(W, make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y), &ix0, &iy0, &nx, &ny))
 	{
 		for (int q = lane; q < W.nProxies; q += nLanes) f(q); // degenerate or huge query: look at everything
 		return;
 	}
-	const int ix0 = (int)fx0, iy0 = (int)fy0, nx = (int)(fx1 - fx0) + 1, nCells = (int)cells;
+	const int nCells = nx * ny;
 	for (int c = lane; c < nCells; c += nLanes)
 	{
 		const uint32_t h = cellHash(ix0 + c % nx, iy0 + c / nx, W.gridMask);

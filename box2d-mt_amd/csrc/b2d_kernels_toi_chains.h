@@ -830,10 +830,12 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 		S->c.nLargeMoves = 0;
 		S->c.nPairs = 0;
 		S->c.nNewContacts = 0;
+		S->c.nMovesSeen = S->c.nMoves;
 	}
+	if (blockIdx.x == 0 && threadIdx.x < 32) S->c.candRounds[threadIdx.x] = 0;
 	if (S->c.nMoves == 0) return;
 	const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-	// widest proxy that should still go through the grid (see gridCellSize): complete when this kernel ends
+	// widest proxy that should still go through the grid (see gridLimit): complete when this kernel ends
 	{
 		const float cap = 4.0f * W.cellSize;
 		float ext = 0.0f;

@@ -100,6 +100,9 @@ struct Counters
 	int nDestroy;        // marked by collide this step
 	int nTouching;
 	int nMoves;          // entries of the move buffer
+	int nMovesSeen;      // ... as the last pair update found it
+	int candRounds[32];  // rounds of 64 candidates the pair search of that update went through (spread over 32 words; the host
+	                     // picks the grid's cell - full or half the limit - for the next step from candidates per moved proxy)
 	int nPairs;          // candidate pairs emitted by the pair finder
 	int nNewContacts;    // unique new contacts created
 	int nRoots;
@@ -128,7 +131,7 @@ struct Counters
 	int nToiMoved;       // proxies re-inserted by the TOI chains / components
 	int nToiNewPairs;    // pairs the chains found between two moving bodies (created in event order when the chains are done)
 	int nToiChainCreated; // contacts that close-out created in this step
-	uint32_t cellExtBits; // float bits of the largest fat-AABB extent among the grid-sized proxies, see gridCellSize()
+	uint32_t cellExtBits; // float bits of the largest fat-AABB extent among the grid-sized proxies, see gridLimit()
 	int nToiDomains;     // components with a pending impact
 	int nToiPartial;     // pending impacts of the components that are replayed serially (DW::toiDomList)
 	int nContactsSnap, nToiOrderSnap; // contact count / TOI slot count when k_toi_snapshot was taken
@@ -414,6 +417,7 @@ struct DW
 	int* toiGroupCount;  // per chain: contacts gathered for it
 	int* toiGroupList;   // per chain: CHAIN_ADJ_MAX contact indices
 	int* toiMoved;       // proxies re-inserted by the chains
+	int gridHalf;        // the grid's cell is half the limit (dense scenes) instead of the limit itself (b2d_kernels_broadphase.h: gridCell)
 	int noChainCreate;   // B2HIP_TOI_NO_CHAIN_CREATE=1: every new pair a chain meets sends the phase to the serial loop (comparison)
 	int* toiNew;         // TOI_NEWPAIR_MAX x 8 ints: pairs found by the chains (alpha bits, event key hi / lo, proxy lo / hi)
 	float4* snapBody;    // 5 rows per body: pos, pos0, vel, xf, flags (state before the chains)

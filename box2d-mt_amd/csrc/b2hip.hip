@@ -291,6 +291,8 @@ struct b2hip_world
 	bool adoptPasses = false;    // the last step had orphan constraints (or made a partition): run k_block_adopt this step
 	bool traceLaunches = false;  // B2HIP_TRACE_LAUNCHES=1 (with B2HIP_DEBUG): every kernel's name before the stream is drained behind it
 	bool tracePartition = false; // B2HIP_TRACE_PARTITION=1: why a partition was made, on stderr
+	bool gridHalf = false;       // the hash grid's cell is half the limit: chosen from the candidates per moved proxy of the last pair update
+	bool gridForced = false;     // B2HIP_GRID_HALF=0 / 1 fixes it
 	int pairsLargeSticky = 0;    // steps for which the pair update still reads its pair count back before it sorts
 	int toiGridRetries = 0;      // steps whose chains were run again with the hash grid instead of serially
 	int toiChainContacts = 0;    // contacts created by the close-out of the parallel TOI chains since the world was made
@@ -1426,7 +1428,8 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanCtx, w->consts.p + 1, (int)(d.gridMask + 1));
 	LAUNCH(w, k_grid_fill, gridFor(d.nProxies), 256, d, 0);
 	if (int rk = ktBracket(w, 4, 7)) return rk;
-	LAUNCH(w, k_find_pairs_small, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
+	if (d.gridHalf) LAUNCH(w, k_find_pairs_window, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
+	else LAUNCH(w, k_find_pairs_small, gridFor((size_t)d.capMoves * 64, 256, 2048), 256, d);
 	if (int rk = ktBracket(w, 4, 7)) return rk;
 	LAUNCH(w, k_find_pairs_large, 1024, 256, d);
 	bool large = false;
@@ -2436,6 +2439,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->solverMailbox = getenv("B2HIP_SOLVER_MAILBOX") != nullptr; // pushed hand-offs for every constraint (k_solve_mailbox) instead of k_solve_blocks
 	w->noSweepBlocks = getenv("B2HIP_NO_SWEEP_BLOCKS") != nullptr;
 	w->tracePartition = getenv("B2HIP_TRACE_PARTITION") != nullptr;
+	if (const char* e = getenv("B2HIP_GRID_HALF")) { w->gridForced = true; w->gridHalf = atoi(e) != 0; w->dw.gridHalf = w->gridHalf ? 1 : 0; }
 	w->dw.noChainCreate = getenv("B2HIP_TOI_NO_CHAIN_CREATE") != nullptr ? 1 : 0;
 	w->traceLaunches = getenv("B2HIP_TRACE_LAUNCHES") != nullptr;
 	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
@@ -4056,6 +4060,15 @@ static int stepEndImpl(b2hip_world* w)
 	w->lastContacts = c.nContacts;
 	w->last.nContacts = c.nContacts;
 	w->last.nMoves = c.nMoves;
+	if (c.nMovesSeen > 256 && !w->gridForced)
+	{
+		// the grid's cell for the next step, from what this step's pair search went through (b2d_kernels_broadphase.h: gridCell)
+		long long rounds = 0;
+		for (int k = 0; k < 32; ++k) rounds += c.candRounds[k];
+		const double perProxy = 64.0 * (double)rounds / (double)c.nMovesSeen;
+		if (perProxy > 128.0) w->gridHalf = true; else if (perProxy < 48.0) w->gridHalf = false;
+		w->dw.gridHalf = w->gridHalf ? 1 : 0; // (between steps: every kernel of the next step sees the same geometry)
+	}
 	w->last.nNewContacts = c.nNewContacts;
 	w->last.nPairs = c.nPairs;
 	w->last.overflow = c.overflow;
