@@ -629,3 +629,34 @@ def test_host_device_handshakes_do_not_change_the_results(amd, default_mode, mon
             other, _ = run(scene, steps, env, **kw)
             first = next((i for i in range(steps) if base[i] != other[i]), None)
             assert first is None, "scene %d with %s differs from the default at step %d" % (scene, env, first)
+
+
+def test_grid_cell_geometry_does_not_change_the_pairs(amd, default_mode, monkeypatch):
+    """The broad-phase grid bins proxies by the cell of their centre; the cell is the widest grid-sized proxy, or - in dense
+    scenes, chosen per step - half of it with a search window per proxy (k_find_pairs_window, gridWindow; the TOI paths'
+    candidate walks use the same window). The pair SET must not depend on that choice: the same worlds with the geometry fixed
+    either way (B2HIP_GRID_HALF=0 / 1) and left to the heuristic give the same states and contact counts every step - the
+    Tumbler (dense; every box moves; large walls), a field with bullets (TOI components and chains re-insert proxies through
+    the grid) and a pyramid with continuous physics."""
+    ccd = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
+
+    def run(scene, steps, half, **kw):
+        if half is None:
+            monkeypatch.delenv("B2HIP_GRID_HALF", raising=False)
+        else:
+            monkeypatch.setenv("B2HIP_GRID_HALF", half)
+        w = amd.world(scene, **kw)
+        out = []
+        for _ in range(steps):
+            w.step(1)
+            out.append((bh.fnv1a64(w.bodies()), w.contact_count))
+        w.close()
+        return out
+
+    for scene, steps, kw in [(bh.TUMBLER, 120, dict(p0=60)), (bh.FIELD, 60, dict(p0=3000, p1=400, f0=60.0, f1=3.0, seed=11, flags=ccd)),
+                             (bh.PYRAMID, 100, dict(p0=50, flags=ccd)), (bh.BULLETS, 120, dict(p0=150, p1=8, seed=3, flags=ccd))]:
+        full = run(scene, steps, "0", **kw)
+        for half in ("1", None):
+            other = run(scene, steps, half, **kw)
+            first = next((i for i in range(steps) if full[i] != other[i]), None)
+            assert first is None, "scene %d: grid geometry %s differs from full cells at step %d" % (scene, half, first)
