@@ -150,10 +150,24 @@ __device__ __forceinline__ void colorCheckBegin(const DW& W)
 
 // Home block (+ 1) of a body this step: its own, or the one a neighbour offered it in k_island_edges (a body that joins a
 // partitioned island is adopted by the block next to it; k_block_census makes that permanent). 0 = none.
+// An offer of block `blk` (1 .. MAX_BLOCKS) to `body`: the offers of a body's neighbours are combined with atomicMax, and
+// the winner should not be "the highest block id" - newcomers of a whole region then pile into one block (Pyramid 316 shedding
+// boxes: a block gained 200 rows in a step and the partition was remade every fifth step) - so an offer carries a hash of
+// (block, body) above the block id: which neighbour's block wins is fixed but spread evenly. Decode with adoptBlock().
+__device__ __forceinline__ int adoptOffer(int blk, int body)
+{
+	uint32_t h = (uint32_t)blk * 2654435761u ^ (uint32_t)body * 40503u;
+	h ^= h >> 15;
+	h *= 0x2c1b3c6du;
+	h ^= h >> 12;
+	return (int)(((h & 0xfffffu) << 11) | (uint32_t)blk); // (20 bits of order, 11 bits of block id: positive)
+}
+__device__ __forceinline__ int adoptBlock(int offer) { return offer & 0x7ff; }
+
 __device__ __forceinline__ int effBlk(const DW& W, int body)
 {
 	const int b = W.b_blk1[body];
-	return b ? b : W.b_adopt[body];
+	return b ? b : adoptBlock(W.b_adopt[body]);
 }
 
 __global__ __launch_bounds__(256) void k_island_init(DW W)
@@ -556,20 +570,37 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub)
 		if (tier == ROOT_LARGE)
 		{
 			W.li_contacts[k] = i;
-			// a body without a home block is offered the block of its neighbour (the highest one, if several do: deterministic)
+			// a body without a home block is offered the block of its neighbour (if several do: the one whose offer ranks highest, adoptOffer)
+			if (nsA != nsB)
+			{
+				// A body without a home block that touches only static bodies gets no offer from anybody (a box the pile shed and
+				// that landed on the ground): its constraints would be orphans and the whole partition would be remade for it. It
+				// takes a block by its own id - the constraint with the static body is interior wherever the body lives - as an
+				// offer of the lowest rank, so that any neighbour's offer still wins.
+				const int D = nsA ? ids.z : ids.w;
+				const int nb = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS;
+				if (nb > 0 && W.b_blk1[D] == 0)
+				{
+					const int offer = 1 + (int)(((uint32_t)D * 2654435761u >> 8) % (uint32_t)nb); // (rank bits 0)
+					atomicMax(&W.b_adopt[D], offer);
+					for (int q = 0; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + D], offer);
+				}
+			}
 			if (nsA && nsB)
 			{
 				// (the offers also go to the three stage buffers of k_block_adopt, which hands blocks on to bodies further away)
 				const int ba = W.b_blk1[ids.z], bb = W.b_blk1[ids.w];
 				if (ba == 0 && bb != 0)
 				{
-					atomicMax(&W.b_adopt[ids.z], bb);
-					for (int q = 0; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.z], bb);
+					const int offer = adoptOffer(bb, ids.z);
+					atomicMax(&W.b_adopt[ids.z], offer);
+					for (int q = 0; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.z], offer);
 				}
 				if (bb == 0 && ba != 0)
 				{
-					atomicMax(&W.b_adopt[ids.w], ba);
-					for (int q = 0; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.w], ba);
+					const int offer = adoptOffer(ba, ids.w);
+					atomicMax(&W.b_adopt[ids.w], offer);
+					for (int q = 0; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.w], offer);
 				}
 			}
 		}
@@ -601,17 +632,20 @@ __global__ __launch_bounds__(256) void k_block_adopt(DW W, int stage)
 	{
 		const int4 ids = C.ids[W.li_contacts[k]];
 		if ((W.b_flags[ids.z] & BF_TYPE_MASK) == BT_STATIC || (W.b_flags[ids.w] & BF_TYPE_MASK) == BT_STATIC) continue;
-		const int ba = W.b_blk1[ids.z] ? W.b_blk1[ids.z] : known[ids.z];
-		const int bb = W.b_blk1[ids.w] ? W.b_blk1[ids.w] : known[ids.w];
-		if (W.b_blk1[ids.z] == 0 && bb != 0 && bb > ba)
+		// (what each end knows so far: its home block, or the block of the best offer it has had up to the stage before)
+		const int ba = W.b_blk1[ids.z] ? W.b_blk1[ids.z] : adoptBlock(known[ids.z]);
+		const int bb = W.b_blk1[ids.w] ? W.b_blk1[ids.w] : adoptBlock(known[ids.w]);
+		if (W.b_blk1[ids.z] == 0 && bb != 0 && bb != ba)
 		{
-			atomicMax(&W.b_adopt[ids.z], bb);
-			for (int q = stage + 1; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.z], bb);
+			const int offer = adoptOffer(bb, ids.z);
+			atomicMax(&W.b_adopt[ids.z], offer);
+			for (int q = stage + 1; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.z], offer);
 		}
-		if (W.b_blk1[ids.w] == 0 && ba != 0 && ba > bb)
+		if (W.b_blk1[ids.w] == 0 && ba != 0 && ba != bb)
 		{
-			atomicMax(&W.b_adopt[ids.w], ba);
-			for (int q = stage + 1; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.w], ba);
+			const int offer = adoptOffer(ba, ids.w);
+			atomicMax(&W.b_adopt[ids.w], offer);
+			for (int q = stage + 1; q < 3; ++q) atomicMax(&W.b_adoptStage[(size_t)q * W.nBodies + ids.w], offer);
 		}
 	}
 }
