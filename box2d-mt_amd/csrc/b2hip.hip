@@ -1677,11 +1677,7 @@ static int phaseSolve(b2hip_world* w)
 		// many blocks again still fit the device together)
 		{
 			const int cap = plainIslands ? w->blocksMaxWG : (lanes == 512 ? w->sweepMaxWG[1] : (lanes == BLOCK_LANES ? w->sweepMaxWG[2] : w->sweepMaxWG[0]));
-			if (c.nBlocks > 0 && c.partitionAge < 16)
-			{
-				if (c.nBlocks * 3 / 2 + 8 <= cap) target = target * 2 / 3;
-				else if (c.nBlocks * 6 / 5 + 8 <= cap) target = target * 5 / 6; // (what room there is: Pyramid 316 has 180 blocks of 248)
-			}
+			if (c.nBlocks > 0 && c.partitionAge < 16 && c.nBlocks * 3 / 2 + 8 <= cap) target = target * 2 / 3;
 			if (w->tracePartition) fprintf(stderr, "[b2hip] capacity for %d-lane blocks: %d\n", lanes, cap);
 		}
 		for (int attempt = 0; need && attempt < 3; ++attempt)
