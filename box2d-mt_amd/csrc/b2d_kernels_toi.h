@@ -230,6 +230,28 @@ __device__ __forceinline__ void toiLogUpdate(const DW& W, const ContactArrays& C
 	W.toiLog[slot] = r;
 }
 
+// What the host's PreSolve answered for the Update logged at `slot` (DW::toiVerdict, see b2hip.hip: toiPreSolveRound): the
+// contact's material as the callback left it is stored, the return value says whether the callback switched the contact off
+// (b2Contact::SetEnabled(false), b2Contact.h:117-123). Slots at or above DW::nToiVerdict have not been asked yet.
+__device__ __forceinline__ bool toiVerdictDisabled(const DW& W, int slot)
+{
+	if (W.toiVerdict == nullptr || slot < 0 || slot >= W.nToiVerdict) return false;
+	return (W.toiVerdict[slot].x & 3) == 3;
+}
+
+__device__ __forceinline__ bool toiVerdictApply(const DW& W, const ContactArrays& C, int slot, int contact)
+{
+	if (W.toiVerdict == nullptr || slot < 0 || slot >= W.nToiVerdict) return false;
+	const int4 v = W.toiVerdict[slot];
+	if ((v.x & 1) == 0) return false;
+	float4 m = C.mat[contact];
+	m.x = __int_as_float(v.y);
+	m.y = __int_as_float(v.z);
+	m.z = __int_as_float(v.w);
+	C.mat[contact] = m;
+	return (v.x & 2) != 0;
+}
+
 __device__ __forceinline__ void toiEvaluate(const DW& W, const ContactArrays& C, int i, int4 ids, Xf xfA, Xf xfB, ToiUpdate* u)
 {
 	const int4 m3 = C.man3[i];
@@ -476,7 +498,13 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			u.wasTouching = (ldFlags(&C.flags[minIdx]) & CF_TOUCHING) != 0;
 			toiEvaluate(W, C, minIdx, minIds, xfA, xfB, &u);
 			toiCommitUpdate(C, minIdx, u);
-			if (W.toiLog != nullptr) toiLogUpdate(W, C, s_logCursor++, minIdx, minIds, u);
+			bool switchedOff = false; // (by the listener's PreSolve, asked in an earlier round of this phase)
+			if (W.toiLog != nullptr)
+			{
+				const int slot = s_logCursor++;
+				toiLogUpdate(W, C, slot, minIdx, minIds, u);
+				if (u.touching && W.preSolveOn) switchedOff = toiVerdictApply(W, C, slot, minIdx);
+			}
 			uint32_t f = ldFlags(&C.flags[minIdx]);
 			const uint32_t cnt = ((f & CF_TOI_COUNT_MASK) >> CF_TOI_COUNT_SHIFT) + 1u;
 			f = (f & ~(CF_TOI | CF_TOI_COUNT_MASK)) | (cnt << CF_TOI_COUNT_SHIFT);
@@ -485,9 +513,9 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				wake(seedA);
 				wake(seedB);
 			}
-			if (!u.touching)
+			if (!u.touching || switchedOff)
 			{
-				// not solid: disable the contact and restore the sweeps (xf was derived from the same c, a)
+				// not solid (b2World.cpp:873-881): disable the contact and restore the sweeps (xf was derived from the same c, a)
 				f &= ~CF_ENABLED;
 				s_solid = 0;
 			}
@@ -611,8 +639,15 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				for (int j = 0; j < nK; ++j) inIsland = inIsland || s_contacts[j] == cd.contact;
 				if (inIsland) continue;
 				cd.info |= 4; // visited: its update is committed
-				if (W.toiLog != nullptr) cd.info |= (s_logCursor++) << 8; // (... and its listener calls logged, in this order)
-				if (cd.info & 1)
+				bool switchedOff = false;
+				if (W.toiLog != nullptr)
+				{
+					const int slot = s_logCursor++; // (... and its listener calls logged, in this order)
+					cd.info |= slot << 8;
+					// a contact its PreSolve switched off stays out of the sub-step's island, its partner where it was (b2World.cpp:948-954)
+					switchedOff = (cd.info & 1) != 0 && W.preSolveOn && toiVerdictDisabled(W, slot);
+				}
+				if ((cd.info & 1) && !switchedOff)
 				{
 					s_contacts[nK++] = cd.contact;
 					bool bodyIn = false;
@@ -635,7 +670,11 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			if (info & 4)
 			{
 				toiCommitUpdate(C, myContact, upd);
-				if (W.toiLog != nullptr) toiLogUpdate(W, C, info >> 8, myContact, C.ids[myContact], upd);
+				if (W.toiLog != nullptr)
+				{
+					toiLogUpdate(W, C, info >> 8, myContact, C.ids[myContact], upd);
+					if (upd.touching && W.preSolveOn && toiVerdictApply(W, C, info >> 8, myContact)) atomicAnd(&C.flags[myContact], ~CF_ENABLED);
+				}
 				if (upd.touching != upd.wasTouching)
 				{
 					const int4 ids = C.ids[myContact];

@@ -380,6 +380,8 @@ struct DW
 	PostSolveRec* postRecs;
 	ToiLogRec* toiLog;      // listener calls from TOI sub-steps, in call order (null: no listener)
 	int capToiLog;
+	const int4* toiVerdict; // what the listener's PreSolve answered for the Updates logged so far in this phase: x bit0 asked,
+	int nToiVerdict;        // bit1 switched the contact off, yzw friction / restitution / tangent speed (bits); [0, nToiVerdict)
 	int* filterList;     // contact indices flagged CF_FILTER (listed for the user's filter before Collide)
 
 	// ---- broad-phase ------------------------------------------------------------------------

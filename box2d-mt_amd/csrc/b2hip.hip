@@ -226,6 +226,7 @@ struct b2hip_world
 	std::vector<b2hip_contact_event> events; // of the last step, in delivery order
 	std::vector<b2hip_toi_callback> toiCallbacks; // listener calls of the last step's TOI sub-steps, in call order
 	DevArray<ToiLogRec> toiLog;
+	DevArray<int4> toiVerdict; // PreSolve answers for the TOI phase's log slots (DW::toiVerdict)
 	DevArray<int> uncolList, compactList, hubRowOf, hubList;
 	DevArray<float4> hubDelta;
 	DevArray<int> rootDone;
@@ -294,6 +295,7 @@ struct b2hip_world
 	bool gridHalf = false;       // the hash grid's cell is half the limit: chosen from the candidates per moved proxy of the last pair update
 	bool gridForced = false;     // B2HIP_GRID_HALF=0 / 1 fixes it
 	int pairsLargeSticky = 0;    // steps for which the pair update still reads its pair count back before it sorts
+	int toiPreSolveReruns = 0; // runs of the TOI phase repeated because a PreSolve changed its contact inside a sub-step
 	int toiGridRetries = 0;      // steps whose chains were run again with the hash grid instead of serially
 	int toiChainContacts = 0;    // contacts created by the close-out of the parallel TOI chains since the world was made
 	int recolorCountdown = 0;    // ... and steps until such islands are coloured afresh (phaseSolve)
@@ -339,6 +341,7 @@ struct b2hip_world
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
 	bool toiChainsHadGrid = false; // the chains of this step ran with the grid (else a moved proxy is all "unsafe" means)
 	bool toiSnapshotTaken = false; // this step's TOI phase saved the state it started from (k_toi_snapshot)
+	std::vector<int4> toiVerdicts; // this step's PreSolve answers per TOI log slot (the device's copy: DW::toiVerdict)
 	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false, toiNoDomains = false;
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
@@ -826,6 +829,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		ENS(pre_o0, nPre); ENS(pre_o1, nPre); ENS(pre_oimp, nPre); ENS(pre_o3, nPre); ENS(preRecs, nPre);
 		ENS(postRecs, nPost); ENS(filterList, nFil);
 		ENS(toiLog, listenerOn(w) && w->def.continuous ? cc : 1);
+		ENS(toiVerdict, hasPreSolve(w) && w->def.continuous ? cc : 1);
 		ENS(hostList, std::max<size_t>(std::max(4 * nPre, nFil), hasFilter(w) ? capPairs : 1)); // (PreSolve material edits: 4 words each)
 	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2); ENS(blkBodyCount, MAX_BLOCKS + 2); ENS(blkBodyCursor, MAX_BLOCKS + 2);
@@ -917,6 +921,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.preRecs = w->preRecs.p; d.postRecs = w->postRecs.p; d.filterList = w->filterList.p;
 	d.toiLog = listenerOn(w) && w->def.continuous ? w->toiLog.p : nullptr;
 	d.capToiLog = (int)std::min<size_t>(w->toiLog.cap, 0x7fffff);
+	d.toiVerdict = hasPreSolve(w) && w->def.continuous ? w->toiVerdict.p : nullptr;
+	d.nToiVerdict = std::min((int)w->toiVerdicts.size(), (int)std::min<size_t>(w->toiVerdict.cap, 0x7fffff));
 	return 0;
 }
 
@@ -2213,6 +2219,12 @@ static int phaseToiSync(b2hip_world* w)
 		w->toiChains = true;
 		return 0;
 	}
+	if (hasPreSolve(w) && !w->toiSnapshotTaken)
+	{
+		// a PreSolve called from a sub-step may change that sub-step (toiPreSolveRounds): the phase must be able to start over
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+		w->toiSnapshotTaken = true;
+	}
 	return toiSerial(w);
 }
 
@@ -2555,7 +2567,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->d_editOps.release();
 	w->b_order.release(); w->orderBody.release(); w->bigRoots.release();
 	w->pre_o0.release(); w->pre_o1.release(); w->pre_oimp.release(); w->pre_o3.release(); w->preRecs.release();
-	w->postRecs.release(); w->filterList.release(); w->hostList.release(); w->toiLog.release();
+	w->postRecs.release(); w->filterList.release(); w->hostList.release(); w->toiLog.release(); w->toiVerdict.release();
 	w->b_blk1.release(); w->b_adopt.release(); w->b_adoptStage.release(); w->blkRows.release(); w->blkRowStart.release(); w->blkCursor.release(); w->blkBodyCount.release(); w->blkBodyCursor.release();
 	w->blkBodyStart.release(); w->blkBodies.release(); w->rowColor.release(); w->b_cutv.release();
 	w->pairFirst.release(); w->pairRank.release(); w->scanTmp.release(); w->radixHist.release(); w->radixHistScan.release();
@@ -3825,6 +3837,8 @@ static int solveToiImpl(b2hip_world* w)
 	w->toiChains = false;
 	w->toiSpeculative = false;
 	w->toiSnapshotTaken = false;
+	w->toiVerdicts.clear();
+	w->dw.nToiVerdict = 0;
 	w->last.nToiList = w->last.nToiCalls = w->last.nToiEvents = 0;
 	if (w->def.continuous && w->sp.dt > 0.0f)
 	{
@@ -3842,6 +3856,139 @@ int b2hip_solve_toi(b2hip_world* w)
 	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_solve_toi outside a step");
 	DEVICE_GUARD(w);
 	return stepFailed(w, solveToiImpl(w));
+}
+
+static int uploadToiVerdicts(b2hip_world* w);
+
+// A contact created inside a TOI sub-step did not fit the array (whatever path ran last, fallbacks included): never a
+// silent drop. With the snapshot of this step's TOI phase at hand the phase is undone, the array doubled and the phase
+// run again; without one (serial-only mode) it is an error.
+static int settleToiOverflow(b2hip_world* w)
+{
+	int rc = 0;
+	for (int attempt = 0; (w->h_dstate->c.overflow & 1) != 0; ++attempt)
+	{
+		if (!w->toiSnapshotTaken || attempt == 3) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step");
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		rc = ensureCapacity(w, 2 * (size_t)w->dw.capContacts);
+		if (rc) return rc;
+		rc = uploadToiVerdicts(w);
+		if (rc) return rc;
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+		w->toiChains = false;
+		w->toiSpeculative = false;
+		rc = phaseToiSync(w);
+		if (rc) return rc;
+		if (w->toiChains)
+		{
+			// (the parallel paths report through toiUnsafe: take their serial fallback here as well)
+			rc = downloadState(w, -1);
+			if (rc) return rc;
+			if (w->h_dstate->c.toiUnsafe != 0)
+			{
+				LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+				rc = toiSerial(w);
+				if (rc) return rc;
+				w->toiFallbacks += 1;
+			}
+		}
+		rc = downloadState(w, -1);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+// The answers collected so far go to the device before the phase runs again (DW::toiVerdict, DW::nToiVerdict).
+static int uploadToiVerdicts(b2hip_world* w)
+{
+	const size_t n = std::min(w->toiVerdicts.size(), w->toiVerdict.cap);
+	w->dw.nToiVerdict = w->dw.toiVerdict != nullptr ? (int)n : 0;
+	if (w->dw.nToiVerdict > 0) HIP_TRY(hipMemcpyAsync((void*)w->toiVerdict.p, w->toiVerdicts.data(), n * sizeof(int4), hipMemcpyHostToDevice, w->stream));
+	return 0;
+}
+
+static void toiCallbackFromLog(const ToiLogRec& r, b2hip_toi_callback* cb)
+{
+	memset(cb, 0, sizeof(*cb));
+	cb->kind = r.info.x;
+	cb->contact_index = r.info.y;
+	cb->fixture_a = r.info.z;
+	cb->fixture_b = r.info.w;
+	toManifold(&cb->old_manifold, r.o0, r.o1, r.oimp, r.o3);
+	toManifold(&cb->manifold, r.n0, r.n1, r.nimp, r.n3);
+	cb->material.friction = r.mat.x;
+	cb->material.restitution = r.mat.y;
+	cb->material.tangent_speed = r.mat.z;
+}
+
+// b2ContactListener::PreSolve from INSIDE the TOI sub-steps (b2World.cpp:866,946 -> b2Contact::Update -> b2Contact.cpp:283-297).
+// The reference calls it in the middle of its event loop, and what it does to the contact changes that sub-step: a contact
+// switched off keeps the sweeps of its bodies and stays out of the sub-step's island (b2World.cpp:873-881, 948-954), an
+// edited material is what the sub-step's solver reads. The event loop here is one kernel, so the phase is run to its end,
+// its log (DW::toiLog: the Updates in the reference's call order) read, and PreSolve called for the logged Updates in
+// order - each exactly once. An answer that changes nothing needs nothing. The first one that does (SetEnabled(false), or a
+// material word that differs) makes everything after it void: the phase goes back to its snapshot and runs again with the
+// answers so far on the device (the loop applies them at the same log slots - it is deterministic, so the log repeats
+// itself up to there), and the calls go on behind the slot that was answered. One extra run of the phase per changing answer.
+static int toiPreSolveRounds(b2hip_world* w, std::vector<ToiLogRec>& recs)
+{
+	int asked = 0; // log slots whose PreSolve has been called
+	for (int round = 0;; ++round)
+	{
+		const int n = std::min(w->h_dstate->c.nToiLog, w->dw.capToiLog);
+		recs.resize((size_t)std::max(n, 0));
+		if (n > 0) HIP_TRY(hipMemcpy((void*)recs.data(), w->toiLog.p, (size_t)n * sizeof(ToiLogRec), hipMemcpyDeviceToHost));
+		if (!hasPreSolve(w) || w->dw.toiVerdict == nullptr) return 0;
+		bool again = false;
+		for (int k = asked; k < n && !again; ++k)
+		{
+			const ToiLogRec& r = recs[(size_t)k];
+			int4 v = make_int4(0, 0, 0, 0);
+			if (r.info.x & 4)
+			{
+				b2hip_toi_callback cb;
+				toiCallbackFromLog(r, &cb);
+				b2hip_pre_solve_record rec;
+				rec.contact_index = cb.contact_index;
+				rec.fixture_a = cb.fixture_a;
+				rec.fixture_b = cb.fixture_b;
+				rec.enabled = 1;
+				rec.old_manifold = cb.old_manifold;
+				rec.manifold = cb.manifold;
+				rec.material = cb.material;
+				// (world edits made from the callback are taken like edits between steps: they reach the device before the next step)
+				w->callbackWindow = true;
+				if (w->preSolveBatchFn) w->preSolveBatchFn(w->preSolveUser, 1, &rec);
+				else rec.enabled = w->preSolveFn(w->preSolveUser, rec.contact_index, rec.fixture_a, rec.fixture_b, &rec.old_manifold, &rec.manifold, &rec.material) ? 1 : 0;
+				w->callbackWindow = false;
+				int bits[3];
+				memcpy(bits, &rec.material, sizeof(bits));
+				v = make_int4(1 | (rec.enabled ? 0 : 2), bits[0], bits[1], bits[2]);
+				again = !rec.enabled || memcmp(&rec.material.friction, &r.mat.x, 4) != 0 || memcmp(&rec.material.restitution, &r.mat.y, 4) != 0 ||
+					memcmp(&rec.material.tangent_speed, &r.mat.z, 4) != 0;
+			}
+			w->toiVerdicts.push_back(v);
+			asked = k + 1;
+		}
+		if (!again) return 0;
+		if (!w->toiSnapshotTaken) return setError(B2HIP_ERR_INVALID, "PreSolve changed a contact inside a TOI sub-step, and the phase kept no snapshot");
+		if (round >= w->dw.capToiLog) return setError(B2HIP_ERR_INVALID, "TOI PreSolve rounds do not end");
+		// (the host mirror of an edited body was refreshed from the state that is about to be taken back)
+		if (!w->dirtyList.empty() || !w->editOps.empty() || !w->proxyEdits.empty() || !w->pendingMoves.empty())
+			return setError(B2HIP_ERR_INVALID, "a PreSolve inside a TOI sub-step edited the world AND changed its contact: not supported");
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		int rc = uploadToiVerdicts(w);
+		if (rc) return rc;
+		w->toiChains = false;
+		w->toiSpeculative = false;
+		rc = phaseToiSync(w);
+		if (rc) return rc;
+		rc = downloadState(w, -1);
+		if (rc) return rc;
+		rc = settleToiOverflow(w);
+		if (rc) return rc;
+		w->toiPreSolveReruns += 1;
+	}
 }
 
 static int stepEndImpl(b2hip_world* w)
@@ -3931,36 +4078,8 @@ static int stepEndImpl(b2hip_world* w)
 		rc = downloadState(w, -1);
 		if (rc) return rc;
 	}
-	// A contact created inside a TOI sub-step did not fit the array (whatever path ran last, fallbacks included): never a
-	// silent drop. With the snapshot of this step's TOI phase at hand the phase is undone, the array doubled and the phase
-	// run again; without one (serial-only mode) it is an error.
-	for (int attempt = 0; (w->h_dstate->c.overflow & 1) != 0; ++attempt)
-	{
-		if (!w->toiSnapshotTaken || attempt == 3) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step");
-		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
-		rc = ensureCapacity(w, 2 * (size_t)w->dw.capContacts);
-		if (rc) return rc;
-		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
-		w->toiChains = false;
-		w->toiSpeculative = false;
-		rc = phaseToiSync(w);
-		if (rc) return rc;
-		if (w->toiChains)
-		{
-			// (the parallel paths report through toiUnsafe: take their serial fallback here as well)
-			rc = downloadState(w, -1);
-			if (rc) return rc;
-			if (w->h_dstate->c.toiUnsafe != 0)
-			{
-				LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
-				rc = toiSerial(w);
-				if (rc) return rc;
-				w->toiFallbacks += 1;
-			}
-		}
-		rc = downloadState(w, -1);
-		if (rc) return rc;
-	}
+	rc = settleToiOverflow(w);
+	if (rc) return rc;
 	w->postSolve.clear();
 	if (w->postSolveOn)
 	{
@@ -3989,28 +4108,16 @@ static int stepEndImpl(b2hip_world* w)
 	w->toiCallbacks.clear();
 	if (w->dw.toiLog != nullptr)
 	{
-		const int n = std::min(w->h_dstate->c.nToiLog, w->dw.capToiLog);
-		if (n > 0)
+		std::vector<ToiLogRec> recs;
+		rc = toiPreSolveRounds(w, recs);
+		if (rc) return rc;
+		for (size_t k = 0; k < recs.size(); ++k)
 		{
-			std::vector<ToiLogRec> recs((size_t)n);
-			HIP_TRY(hipMemcpy((void*)recs.data(), w->toiLog.p, (size_t)n * sizeof(ToiLogRec), hipMemcpyDeviceToHost));
-			for (int k = 0; k < n; ++k)
-			{
-				const ToiLogRec& r = recs[k];
-				if (r.info.x == 0) continue; // (an Update that called nothing: the contact neither touched before nor after)
-				b2hip_toi_callback cb;
-				memset(&cb, 0, sizeof(cb));
-				cb.kind = r.info.x;
-				cb.contact_index = r.info.y;
-				cb.fixture_a = r.info.z;
-				cb.fixture_b = r.info.w;
-				toManifold(&cb.old_manifold, r.o0, r.o1, r.oimp, r.o3);
-				toManifold(&cb.manifold, r.n0, r.n1, r.nimp, r.n3);
-				cb.material.friction = r.mat.x;
-				cb.material.restitution = r.mat.y;
-				cb.material.tangent_speed = r.mat.z;
-				w->toiCallbacks.push_back(cb);
-			}
+			b2hip_toi_callback cb;
+			toiCallbackFromLog(recs[k], &cb);
+			cb.kind &= ~4; // (PreSolve has been called: toiPreSolveRounds)
+			if (cb.kind == 0) continue; // (an Update that called nothing else: the contact neither began nor ended)
+			w->toiCallbacks.push_back(cb);
 		}
 	}
 	w->events.clear();
@@ -5062,6 +5169,7 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->hub_fixpoint_rounds = w->last.hubRounds;
 	out->hub_serial_chunks = w->last.hubSerialChunks;
 	out->toi_chain_contacts = w->toiChainContacts;
+	out->toi_pre_solve_reruns = w->toiPreSolveReruns;
 	return 0;
 }
 

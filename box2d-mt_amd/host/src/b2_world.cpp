@@ -735,7 +735,8 @@ void b2World::DeliverPostSolve()
 // The listener calls the reference makes from inside its TOI sub-steps (b2World.cpp:866,946: contact->Update(listener);
 // b2Island.cpp:527: Report), replayed from the step's log in the reference's call order, after the Collide and Solve callbacks
 // like there. The sub-steps run on one thread in the reference: immediate and deferred form are called back to back, threadId 0.
-// (They are replayed after the fact: a PreSolve here cannot disable its contact for the sub-step that called it.)
+// (PreSolve is not among them: the step itself calls it - through PreSolveBatchTrampoline, one record at a time - where the
+// reference's sub-step does, because its answer changes that sub-step; include/b2hip.h, b2hip_toi_callback.)
 void b2World::DeliverToiCallbacks()
 {
 	if (!m_hip || !m_contactListener) return;

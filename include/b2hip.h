@@ -319,6 +319,7 @@ typedef struct b2hip_counters
 	int32_t hub_fixpoint_rounds;     /* rounds of the fixed-point form of that sweep in the last step (all sweeps) */
 	int32_t hub_serial_chunks;       /* chunks of 64 hub constraints swept lane after lane instead */
 	int32_t toi_chain_contacts;      /* contacts (since creation) the parallel TOI chains left for their close-out to create in event order */
+	int32_t toi_pre_solve_reruns;    /* runs of the TOI phase (since creation) repeated because a PreSolve changed its contact inside a sub-step */
 } b2hip_counters;
 
 const char* b2hip_last_error(void);
@@ -524,9 +525,16 @@ int b2hip_set_pre_solve_batch(b2hip_world* w, b2hip_pre_solve_batch_fn fn, void*
  *   bit0 BeginContact, bit1 EndContact, bit2 PreSolve(old_manifold), bit3 PostSolve (manifold.normal_impulse / tangent_impulse
  *   = the sub-step solver's impulses, manifold.point_count = its point count).
  * Recorded while begin / end events, a PreSolve function or PostSolve records are switched on (each kind only if its
- * callback is), and the TOI phase then runs through the serial event loop (the order IS the serial order). The records
- * are made after the fact: what a PreSolve does to its contact (SetEnabled, SetFriction ...) cannot reach the sub-step
- * that called it. */
+ * callback is), and the TOI phase then runs through the serial event loop (the order IS the serial order).
+ * PreSolve is the exception, because what it does to its contact - a zero return (b2Contact::SetEnabled(false)), an edited
+ * material - changes the sub-step that called it (b2World.cpp:873-881, 948-954: a contact switched off keeps the sweeps of
+ * its bodies and stays out of the sub-step's island): the function installed with b2hip_set_pre_solve /
+ * b2hip_set_pre_solve_batch (one record per call) is called BY THE STEP for every such Update, in the reference's order,
+ * each exactly once, and its answer acts where the reference's does. The device's event loop is one kernel: an answer that
+ * changes its contact sends the phase back to its snapshot for another run with the answers so far (one extra run per
+ * changing answer, b2hip_counters.toi_pre_solve_reruns). World edits made from such a call reach the device before the next
+ * step; a call that edits the world AND changes its contact is refused (B2HIP_ERR_INVALID). bit2 therefore never shows in
+ * the records read here. */
 typedef struct b2hip_toi_callback
 {
 	int32_t kind;

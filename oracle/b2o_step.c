@@ -2266,6 +2266,32 @@ static void contact_update_st(b2o_world* w, contact_t* c)
 		if (w->eventsOn && wasTouching && !touching) kind |= 2;
 		if ((w->preSolveFn != NULL || w->preSolveBatchFn != NULL) && touching) kind |= 4;
 		if (w->eventsOn) c->reported = touching;
+		if (kind & 4)
+		{
+			/* PreSolve is called where the reference calls it (b2Contact.cpp:283-297, from the Update of the sub-step): what it
+			 * does to the contact - SetEnabled(false), SetFriction / SetRestitution / SetTangentSpeed - acts on this sub-step
+			 * (b2World.cpp:873,948: a disabled contact keeps the sweeps and stays out of the sub-step's island). The log keeps
+			 * the calls that change nothing: begin / end / PostSolve. */
+			b2o_pre_solve_record rec;
+			int* rank = contact_ranks(w);
+			rec.contact_index = rank[c - w->contacts];
+			free(rank);
+			rec.fixture_a = c->fixtureA;
+			rec.fixture_b = c->fixtureB;
+			rec.enabled = 1;
+			fill_manifold(&rec.old_manifold, &c->oldm);
+			fill_manifold(&rec.manifold, &c->m);
+			rec.material.friction = c->friction;
+			rec.material.restitution = c->restitution;
+			rec.material.tangent_speed = c->tangentSpeed;
+			if (w->preSolveBatchFn) w->preSolveBatchFn(w->preSolveUser, 1, &rec);
+			else rec.enabled = w->preSolveFn(w->preSolveUser, rec.contact_index, rec.fixture_a, rec.fixture_b, &rec.old_manifold, &rec.manifold, &rec.material) != 0;
+			if (!rec.enabled) c->flags &= ~CF_ENABLED;
+			c->friction = rec.material.friction;
+			c->restitution = rec.material.restitution;
+			c->tangentSpeed = rec.material.tangent_speed;
+			kind &= ~4;
+		}
 		if (kind)
 		{
 			b2o_toi_callback* r = toi_log_push(w);

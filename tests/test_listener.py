@@ -68,6 +68,30 @@ def test_oracle_listener_and_filter_match_the_reference(ref, oracle, name, scene
     b.close()
 
 
+CCD_CASES = [("bullets", bh.BULLETS, 20, 4, 1, 120), ("field", bh.FIELD, 300, 40, 5, 80), ("rain", bh.RAIN, 120, 0, 4, 150),
+             ("piles", bh.PILES, 25, 5, 6, 140)]
+
+
+@pytest.mark.parametrize("name,scene,p0,p1,seed,steps", CCD_CASES)
+@pytest.mark.parametrize("variant", ["disable", "material"])
+def test_oracle_presolve_acts_inside_the_toi_substep_that_called_it(ref, oracle, name, scene, p0, p1, seed, steps, variant):
+    """Continuous physics on: b2Contact::Update calls PreSolve from INSIDE b2World::StepSolveTOI (b2World.cpp:866,946), and a
+    contact the callback switches off there keeps the sweeps of its bodies and stays out of the sub-step's island
+    (b2World.cpp:873-881, 948-954); a material it edits is what the sub-step's solver reads. The same listener on the real
+    reference build and on the drop-in layer over the oracle: every callback of every step and the body states, bit for bit.
+    (With the calls replayed after the step - rounds 2 and 3 until this test - every one of these eight runs diverged from
+    the reference within 75 steps.)"""
+    flags = bh.DEFAULT_FLAGS | bh.F_CONTINUOUS
+    a = ref.world(scene, p0, p1, seed=seed, flags=flags)
+    b = oracle.world(scene, p0, p1, seed=seed, flags=flags)
+    seen, disabled = run_pair(a, b, steps, MODES[variant], False, name + "/ccd/" + variant)
+    assert seen[2] > 0 and seen[3] > 0
+    if variant == "disable":
+        assert disabled > 0
+    a.close()
+    b.close()
+
+
 def test_material_edits_change_the_motion(oracle):
     """the conveyor-belt rule really moves things (else the material variant above proves nothing)"""
     a = oracle.world(bh.PILES, 25, 5, seed=6)
@@ -101,6 +125,29 @@ def test_device_listener_and_filter_match_the_oracle(amd, oracle, monkeypatch, n
     b = oracle.world(scene, p0, p1, seed=seed)
     seen, disabled = run_pair(a, b, steps, MODES[variant], variant == "filter", name + "/" + variant)
     assert seen[2] > 0 and seen[3] > 0
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scene,p0,p1,seed,steps", CCD_CASES)
+@pytest.mark.parametrize("variant", ["disable", "material"])
+def test_device_presolve_acts_inside_the_toi_substep_that_called_it(amd, oracle, monkeypatch, name, scene, p0, p1, seed, steps, variant):
+    """The device's event loop is one kernel: the step calls PreSolve for the logged Updates in order, and the first answer
+    that changes its contact sends the phase back to its snapshot for another run with the answers so far (b2hip.hip:
+    toiPreSolveRounds). Callbacks (each exactly once) and states equal the oracle's, which calls PreSolve inline as the
+    reference does; the counter proves that phases were in fact run again."""
+    import ctypes as C
+    import b2hip
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    flags = bh.DEFAULT_FLAGS | bh.F_CONTINUOUS
+    a = amd.world(scene, p0, p1, seed=seed, flags=flags)
+    b = oracle.world(scene, p0, p1, seed=seed, flags=flags)
+    seen, disabled = run_pair(a, b, steps, MODES[variant], False, name + "/ccd/" + variant)
+    assert seen[2] > 0 and seen[3] > 0
+    ctr = b2hip.Counters()
+    b2hip.lib().b2hip_get_counters(C.c_void_p(a.device_world()), C.byref(ctr))
+    assert ctr.toi_pre_solve_reruns > 0, "no PreSolve answer ever changed a TOI sub-step: the test is vacuous"
     a.close()
     b.close()
 

@@ -13,10 +13,11 @@ compile: tools/testbed_compile_check.sh says 61 of 62).
   GPU : the three TestPassed predicates pass on the product; the others run finite and, in exact-order mode, reproduce
         the oracle-backed run step for step
 The listener calls the reference makes from inside its TOI sub-steps (b2World.cpp:866,946, b2Island.cpp:398-530) are
-delivered too, after the fact (b2hip_get_toi_callbacks): TunnelingTest (edits the world from them) and Breakable (reads the
-landing impulse from a sub-step's PostSolve) follow the reference step for step. ONE scene needs a callback to act INSIDE
-the sub-step that makes it - ConveyorBelt sets the belt's tangent speed from the PreSolve of the landing sub-step, whose own
-solver already uses it: here the belt starts a step later. It runs and stays finite; its trace is not compared. ManyBodies 1-5 (10 000 - 50 000 bodies) are compared on the GPU
+delivered too: begin / end / PostSolve after the step in call order (b2hip_get_toi_callbacks), PreSolve by the step itself
+where the sub-step calls it, because its answer changes that sub-step (include/b2hip.h, b2hip_toi_callback). TunnelingTest
+(edits the world from them), Breakable (reads the landing impulse from a sub-step's PostSolve) and ConveyorBelt (sets the
+belt's tangent speed from the PreSolve of the landing sub-step, whose own solver already uses it) follow the reference step
+for step. ManyBodies 1-5 (10 000 - 50 000 bodies) are compared on the GPU
 against the reference-order run only through their smaller sibling ManyBodies6 (the C oracle's broad-phase is brute force).
 """
 import ctypes as C
@@ -50,7 +51,7 @@ def all_entries():
     return re.findall(r'\{ "(\w+)", ', open(os.path.join(ROOT, "tests", "testbed", "scenes_main.cpp")).read())
 
 
-TOI_LISTENER_SCENES = ("ConveyorBelt",)
+TOI_LISTENER_SCENES = ()  # (round 3: ConveyorBelt needed PreSolve to act inside the sub-step that calls it; it does now)
 BIG_SCENES = ("ManyBodies1", "ManyBodies2", "ManyBodies3", "ManyBodies4", "ManyBodies5")
 LONG = {"SleepCollideTest": 700, "Tumbler": 300, "QueryTest": 1, "SleepCollidePerf": 120, "TunnelingTest": 900}
 CPU_SCENES = [(n, LONG.get(n, 200)) for n in all_entries() if n not in TOI_LISTENER_SCENES and n not in BIG_SCENES]
