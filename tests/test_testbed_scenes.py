@@ -51,10 +51,9 @@ def all_entries():
     return re.findall(r'\{ "(\w+)", ', open(os.path.join(ROOT, "tests", "testbed", "scenes_main.cpp")).read())
 
 
-TOI_LISTENER_SCENES = ()  # (round 3: ConveyorBelt needed PreSolve to act inside the sub-step that calls it; it does now)
 BIG_SCENES = ("ManyBodies1", "ManyBodies2", "ManyBodies3", "ManyBodies4", "ManyBodies5")
 LONG = {"SleepCollideTest": 700, "Tumbler": 300, "QueryTest": 1, "SleepCollidePerf": 120, "TunnelingTest": 900}
-CPU_SCENES = [(n, LONG.get(n, 200)) for n in all_entries() if n not in TOI_LISTENER_SCENES and n not in BIG_SCENES]
+CPU_SCENES = [(n, LONG.get(n, 200)) for n in all_entries() if n not in BIG_SCENES]
 
 
 @pytest.mark.parametrize("name,steps", CPU_SCENES)
@@ -86,13 +85,7 @@ def test_reference_test_passed_predicates_on_the_gpu(name, steps):
 
 def test_every_testbed_entry_is_covered():
     names = all_entries()
-    assert len(names) == 64 and len(CPU_SCENES) == 64 - len(TOI_LISTENER_SCENES) - len(BIG_SCENES)
-
-
-@pytest.mark.parametrize("name", TOI_LISTENER_SCENES)
-def test_scenes_that_need_toi_sub_step_callbacks_run_finite(name):
-    res, t = trace(load("oracle"), name, 200)
-    assert (t[:, 4] == 1.0).all() and t[-1, 0] > 0
+    assert len(names) == 64 and len(CPU_SCENES) == 64 - len(BIG_SCENES)
 
 
 @pytest.mark.gpu
