@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void k_presolve_gather(DW W)
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		if (!W.keepFlag[i] || (C.flags[i] & CF_PRESOLVE) == 0) continue;
+		C.flags[i] &= ~CF_PRESOLVE_OFF; // (set again by k_presolve_disable if this call switches the contact off)
 		const int e = atomicAdd(&S->c.nPreSolve, 1);
 		if (e >= W.capContacts) continue;
 		const int4 ids = C.ids[i];
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void k_presolve_disable(DW W, const int* list,
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
 	{
 		const int j = list[k];
-		if (j >= 0 && j < W.st->c.nContacts) C.flags[j] &= ~CF_ENABLED;
+		if (j >= 0 && j < W.st->c.nContacts) C.flags[j] = (C.flags[j] & ~CF_ENABLED) | CF_PRESOLVE_OFF;
 	}
 }
 

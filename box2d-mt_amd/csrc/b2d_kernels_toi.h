@@ -211,13 +211,15 @@ struct ToiUpdate
 // The listener calls b2Contact::Update makes (b2Contact.cpp:253-297) as ONE log record: BeginContact when the contact starts
 // touching, EndContact when it stops, PreSolve while it touches (TOI candidates are never sensors). `slot` is the record's
 // place in DW::toiLog - the call order of the reference. The reported state (CF_REPORTED) follows what was logged.
-__device__ __forceinline__ void toiLogUpdate(const DW& W, const ContactArrays& C, int slot, int contact, int4 ids, const ToiUpdate& u)
+// assumedOff: the sub-step went on as if this Update's PreSolve had switched the contact off (toiPreSolveOutcome): bit 4 of
+// the record's kind, so that the host can tell whether the answer it gets now changes anything.
+__device__ __forceinline__ void toiLogUpdate(const DW& W, const ContactArrays& C, int slot, int contact, int4 ids, const ToiUpdate& u, bool assumedOff)
 {
 	if (W.toiLog == nullptr || slot < 0 || slot >= W.capToiLog) return;
 	int kind = 0;
 	if (W.eventsOn && !u.wasTouching && u.touching) kind |= 1;
 	if (W.eventsOn && u.wasTouching && !u.touching) kind |= 2;
-	if (W.preSolveOn && u.touching) kind |= 4;
+	if (W.preSolveOn && u.touching) kind |= 4 | (assumedOff ? 16 : 0);
 	if (W.eventsOn)
 	{
 		if (u.touching) atomicOr(&C.flags[contact], CF_REPORTED); else atomicAnd(&C.flags[contact], ~CF_REPORTED);
@@ -230,25 +232,34 @@ __device__ __forceinline__ void toiLogUpdate(const DW& W, const ContactArrays& C
 	W.toiLog[slot] = r;
 }
 
-// What the host's PreSolve answered for the Update logged at `slot` (DW::toiVerdict, see b2hip.hip: toiPreSolveRound): the
-// contact's material as the callback left it is stored, the return value says whether the callback switched the contact off
-// (b2Contact::SetEnabled(false), b2Contact.h:117-123). Slots at or above DW::nToiVerdict have not been asked yet.
-__device__ __forceinline__ bool toiVerdictDisabled(const DW& W, int slot)
+// What the host's PreSolve answered for the Update logged at `slot` (DW::toiVerdict, see b2hip.hip: toiPreSolveRounds): the
+// contact's material as the callback left it, and whether the callback switched the contact off (b2Contact::SetEnabled(false),
+// b2Contact.h:117-123). Slots at or above DW::nToiVerdict have not been asked yet: there the sub-step ASSUMES the answer
+// the listener gave for this contact the last time (CF_PRESOLVE_OFF, kept by the Collide phase's PreSolve and by the answers
+// applied here) and says so in its log record - a listener that keeps answering the same costs no second run of the phase.
+__device__ __forceinline__ bool toiPreSolveAsked(const DW& W, int slot)
 {
-	if (W.toiVerdict == nullptr || slot < 0 || slot >= W.nToiVerdict) return false;
-	return (W.toiVerdict[slot].x & 3) == 3;
+	return W.toiVerdict != nullptr && slot >= 0 && slot < W.nToiVerdict && (W.toiVerdict[slot].x & 1) != 0;
 }
 
-__device__ __forceinline__ bool toiVerdictApply(const DW& W, const ContactArrays& C, int slot, int contact)
+// (read-only form for the order-defining walk, which runs before the lanes commit their Updates)
+__device__ __forceinline__ bool toiPreSolveOff(const DW& W, const ContactArrays& C, int slot, int contact)
 {
-	if (W.toiVerdict == nullptr || slot < 0 || slot >= W.nToiVerdict) return false;
+	if (toiPreSolveAsked(W, slot)) return (W.toiVerdict[slot].x & 2) != 0;
+	return (ldFlags(&C.flags[contact]) & CF_PRESOLVE_OFF) != 0;
+}
+
+// (committing form: an answer's material and its off state go to the contact; CF_ENABLED is the caller's)
+__device__ __forceinline__ bool toiPreSolveOutcome(const DW& W, const ContactArrays& C, int slot, int contact)
+{
+	if (!toiPreSolveAsked(W, slot)) return (ldFlags(&C.flags[contact]) & CF_PRESOLVE_OFF) != 0;
 	const int4 v = W.toiVerdict[slot];
-	if ((v.x & 1) == 0) return false;
 	float4 m = C.mat[contact];
 	m.x = __int_as_float(v.y);
 	m.y = __int_as_float(v.z);
 	m.z = __int_as_float(v.w);
 	C.mat[contact] = m;
+	if (v.x & 2) atomicOr(&C.flags[contact], CF_PRESOLVE_OFF); else atomicAnd(&C.flags[contact], ~CF_PRESOLVE_OFF);
 	return (v.x & 2) != 0;
 }
 
@@ -502,8 +513,9 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			if (W.toiLog != nullptr)
 			{
 				const int slot = s_logCursor++;
-				toiLogUpdate(W, C, slot, minIdx, minIds, u);
-				if (u.touching && W.preSolveOn) switchedOff = toiVerdictApply(W, C, slot, minIdx);
+				const bool assumedOff = u.touching && W.preSolveOn && !toiPreSolveAsked(W, slot) && toiPreSolveOff(W, C, slot, minIdx);
+				toiLogUpdate(W, C, slot, minIdx, minIds, u, assumedOff);
+				if (u.touching && W.preSolveOn) switchedOff = toiPreSolveOutcome(W, C, slot, minIdx);
 			}
 			uint32_t f = ldFlags(&C.flags[minIdx]);
 			const uint32_t cnt = ((f & CF_TOI_COUNT_MASK) >> CF_TOI_COUNT_SHIFT) + 1u;
@@ -645,7 +657,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 					const int slot = s_logCursor++; // (... and its listener calls logged, in this order)
 					cd.info |= slot << 8;
 					// a contact its PreSolve switched off stays out of the sub-step's island, its partner where it was (b2World.cpp:948-954)
-					switchedOff = (cd.info & 1) != 0 && W.preSolveOn && toiVerdictDisabled(W, slot);
+					switchedOff = (cd.info & 1) != 0 && W.preSolveOn && toiPreSolveOff(W, C, slot, cd.contact);
 				}
 				if ((cd.info & 1) && !switchedOff)
 				{
@@ -672,8 +684,10 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				toiCommitUpdate(C, myContact, upd);
 				if (W.toiLog != nullptr)
 				{
-					toiLogUpdate(W, C, info >> 8, myContact, C.ids[myContact], upd);
-					if (upd.touching && W.preSolveOn && toiVerdictApply(W, C, info >> 8, myContact)) atomicAnd(&C.flags[myContact], ~CF_ENABLED);
+					const int slot = info >> 8;
+					const bool assumedOff = upd.touching && W.preSolveOn && !toiPreSolveAsked(W, slot) && toiPreSolveOff(W, C, slot, myContact);
+					toiLogUpdate(W, C, slot, myContact, C.ids[myContact], upd, assumedOff);
+					if (upd.touching && W.preSolveOn && toiPreSolveOutcome(W, C, slot, myContact)) atomicAnd(&C.flags[myContact], ~CF_ENABLED);
 				}
 				if (upd.touching != upd.wasTouching)
 				{

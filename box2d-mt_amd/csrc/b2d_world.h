@@ -43,6 +43,7 @@
 #define CF_PRESOLVE 0x800u      // updated by this step's Collide, touching, not a sensor: b2ContactListener::PreSolve is due (b2Contact.cpp:283)
 #define CF_VC_ONE_POINT 0x10000u // the solver's conditioning guard dropped the second manifold point this step (b2ContactSolver.cpp:230-247)
 #define CF_USER_REJECT 0x20000u  // the user's contact filter refused this contact at its re-filtering (b2ContactManager.cpp:195-203)
+#define CF_PRESOLVE_OFF 0x40000u  // the listener's last PreSolve switched this contact off: what a TOI sub-step assumes until it has been asked
 #define CF_TOI_COUNT_SHIFT 12  // bits 12..15: m_toiCount (0..9)
 #define CF_TOI_COUNT_MASK 0xf000u
 #define CF_TOI_STATE_MASK (CF_TOI | CF_TOI_LISTED | CF_TOI_PENDING | CF_TOI_COUNT_MASK)

@@ -3926,8 +3926,9 @@ static void toiCallbackFromLog(const ToiLogRec& r, b2hip_toi_callback* cb)
 // switched off keeps the sweeps of its bodies and stays out of the sub-step's island (b2World.cpp:873-881, 948-954), an
 // edited material is what the sub-step's solver reads. The event loop here is one kernel, so the phase is run to its end,
 // its log (DW::toiLog: the Updates in the reference's call order) read, and PreSolve called for the logged Updates in
-// order - each exactly once. An answer that changes nothing needs nothing. The first one that does (SetEnabled(false), or a
-// material word that differs) makes everything after it void: the phase goes back to its snapshot and runs again with the
+// order - each exactly once. An answer that changes nothing needs nothing: the contact stays on (or off, where the sub-step
+// assumed the listener's last answer for this contact: CF_PRESOLVE_OFF, toiPreSolveOutcome) and its material as it was. The
+// first one that does makes everything after it void: the phase goes back to its snapshot and runs again with the
 // answers so far on the device (the loop applies them at the same log slots - it is deterministic, so the log repeats
 // itself up to there), and the calls go on behind the slot that was answered. One extra run of the phase per changing answer.
 static int toiPreSolveRounds(b2hip_world* w, std::vector<ToiLogRec>& recs)
@@ -3964,7 +3965,9 @@ static int toiPreSolveRounds(b2hip_world* w, std::vector<ToiLogRec>& recs)
 				int bits[3];
 				memcpy(bits, &rec.material, sizeof(bits));
 				v = make_int4(1 | (rec.enabled ? 0 : 2), bits[0], bits[1], bits[2]);
-				again = !rec.enabled || memcmp(&rec.material.friction, &r.mat.x, 4) != 0 || memcmp(&rec.material.restitution, &r.mat.y, 4) != 0 ||
+				// (bit 4 of the kind: the sub-step went on as if the contact had been switched off - the listener's last answer)
+				const bool assumedOff = (r.info.x & 16) != 0;
+				again = (rec.enabled != 0) == assumedOff || memcmp(&rec.material.friction, &r.mat.x, 4) != 0 || memcmp(&rec.material.restitution, &r.mat.y, 4) != 0 ||
 					memcmp(&rec.material.tangent_speed, &r.mat.z, 4) != 0;
 			}
 			w->toiVerdicts.push_back(v);
@@ -4115,7 +4118,7 @@ static int stepEndImpl(b2hip_world* w)
 		{
 			b2hip_toi_callback cb;
 			toiCallbackFromLog(recs[k], &cb);
-			cb.kind &= ~4; // (PreSolve has been called: toiPreSolveRounds)
+			cb.kind &= ~(4 | 16); // (PreSolve has been called: toiPreSolveRounds)
 			if (cb.kind == 0) continue; // (an Update that called nothing else: the contact neither began nor ended)
 			w->toiCallbacks.push_back(cb);
 		}
