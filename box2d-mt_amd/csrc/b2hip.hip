@@ -3869,6 +3869,9 @@ static int settleToiOverflow(b2hip_world* w)
 	for (int attempt = 0; (w->h_dstate->c.overflow & 1) != 0; ++attempt)
 	{
 		if (!w->toiSnapshotTaken || attempt == 3) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step");
+		// (edits can only be pending here if a PreSolve called from a sub-step made them: toiPreSolveRounds)
+		if (!w->dirtyList.empty() || !w->editOps.empty() || !w->proxyEdits.empty() || !w->pendingMoves.empty())
+			return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step whose PreSolve edited the world");
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
 		rc = ensureCapacity(w, 2 * (size_t)w->dw.capContacts);
 		if (rc) return rc;
