@@ -75,6 +75,10 @@ b2o_world* b2o_world_create(float gx, float gy, int allow_sleep, int warm_starti
 void b2o_world_destroy(b2o_world* w);
 void b2o_set_gravity(b2o_world* w, float gx, float gy);
 void b2o_set_flags(b2o_world* w, int allow_sleep, int warm_starting, int continuous);
+/* b2World::SetSubStepping (b2World.h:183; b2World.cpp:1082-1086, 1668): one TOI event per step call, the island solve only
+ * in the call that starts a step */
+void b2o_set_sub_stepping(b2o_world* w, int flag);
+int b2o_step_complete(const b2o_world* w);
 int b2o_create_body(b2o_world* w, const b2o_body_def* def);
 int b2o_create_fixture(b2o_world* w, int body, const b2o_fixture_def* def, const b2o_shape* shape);
 int b2o_create_revolute_joint(b2o_world* w, int bodyA, int bodyB, const float* anchors4, float referenceAngle,

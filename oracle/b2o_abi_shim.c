@@ -40,8 +40,9 @@ int b2hip_set_gravity(b2hip_world* w, float gx, float gy) { b2o_set_gravity(w->o
 
 int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int continuous, int sub_stepping)
 {
-	w->sub_stepping = sub_stepping; /* not restated either: a step is refused while it is on, like the product does */
+	w->sub_stepping = sub_stepping;
 	b2o_set_flags(w->o, allow_sleep, warm_starting, continuous);
+	b2o_set_sub_stepping(w->o, sub_stepping);
 	return 0;
 }
 
@@ -195,7 +196,6 @@ int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega
 
 int b2hip_step(b2hip_world* w, float dt, int vi, int pi)
 {
-	if (w->sub_stepping) return -4; /* B2HIP_ERR_UNSUPPORTED */
 	b2o_step(w->o, dt, vi, pi);
 	return 0;
 }
@@ -228,7 +228,7 @@ int b2hip_get_contact_events(b2hip_world* w, int cap, b2hip_contact_event* out)
 	return b2o_get_contact_events(w->o, cap, (b2o_contact_event*)out); /* identical layout */
 }
 
-int b2hip_step_begin(b2hip_world* w, float dt, int vi, int pi) { if (w->sub_stepping) return -4; b2o_step_begin(w->o, dt, vi, pi); return 0; }
+int b2hip_step_begin(b2hip_world* w, float dt, int vi, int pi) { b2o_step_begin(w->o, dt, vi, pi); return 0; }
 int b2hip_collide(b2hip_world* w) { b2o_phase_collide(w->o); return 0; }
 int b2hip_solve(b2hip_world* w) { b2o_phase_solve(w->o); return 0; }
 int b2hip_sync_fixtures(b2hip_world* w) { b2o_phase_sync_fixtures(w->o); return 0; }

@@ -144,6 +144,7 @@ struct b2o_world
 	b2o_should_collide_fn filterFn; void* filterUser;
 	b2o_pre_solve_fn preSolveFn; void* preSolveUser;
 	b2o_pre_solve_batch_fn preSolveBatchFn;
+	int subStepping, stepComplete; /* b2World::m_subStepping, m_stepComplete (b2World.cpp:462-464) */
 	b2o_toi_callback* toiLog; int nToiLog, capToiLog; /* listener calls of this step's TOI sub-steps (contact_index = slot until read) */
 	int postSolveOn;
 	b2o_contact_impulse* postSolve; int nPostSolve, capPostSolve;
@@ -169,8 +170,13 @@ b2o_world* b2o_world_create(float gx, float gy, int allow_sleep, int warm_starti
 	w->allowSleep = allow_sleep;
 	w->warmStarting = warm_starting;
 	w->continuous = continuous;
+	w->stepComplete = 1;
 	return w;
 }
+
+/* b2World::SetSubStepping (b2World.h:183) */
+void b2o_set_sub_stepping(b2o_world* w, int flag) { w->subStepping = flag != 0; }
+int b2o_step_complete(const b2o_world* w) { return w->stepComplete; }
 
 void b2o_world_destroy(b2o_world* w)
 {
@@ -2540,15 +2546,26 @@ static void step_solve_toi(b2o_world* w, float dt, int velIters, int minSlot, fl
 /* b2World::SolveTOI (b2World.cpp:1026-1093) + ClearPostSolveTOI (:1467-1523) */
 static void solve_toi(b2o_world* w, float dt, int velIters)
 {
-	int clearPost = 0, first = 1;
+	/* (b2World.cpp:1045: flags were modified by a previous sub-step if the step is not complete) */
+	int clearPost = w->stepComplete == 0, first = w->stepComplete;
 	for (;;)
 	{
 		float minAlpha = 1.0f;
 		int minSlot = find_min_toi(w, &minAlpha);
 		if (first && minSlot >= 0) clearPost = 1;
 		first = 0;
-		if (minSlot < 0 || 1.0f - 10.0f * B2O_EPSILON < minAlpha) break;
+		if (minSlot < 0 || 1.0f - 10.0f * B2O_EPSILON < minAlpha)
+		{
+			w->stepComplete = 1;
+			break;
+		}
 		step_solve_toi(w, dt, velIters, minSlot, minAlpha);
+		/* b2World::SetSubStepping (b2World.cpp:1082-1086): one TOI event per Step call; the flags and sweeps stay as they are */
+		if (w->subStepping)
+		{
+			w->stepComplete = 0;
+			return;
+		}
 	}
 	if (!clearPost) return;
 	for (int i = 0; i < w->nContactSlots; ++i)
@@ -2678,12 +2695,13 @@ void b2o_phase_collide(b2o_world* w)
 }
 void b2o_phase_solve(b2o_world* w)
 {
+	if (!w->stepComplete) return; /* b2World.cpp:1668 */
 	if (w->stepDt > 0.0f) solve_islands(w, w->stepDt, w->inv_dt0 * w->stepDt, w->stepVelIters, w->stepPosIters);
 }
-void b2o_phase_sync_fixtures(b2o_world* w) { if (w->stepDt > 0.0f) synchronize_fixtures(w); }
+void b2o_phase_sync_fixtures(b2o_world* w) { if (w->stepComplete && w->stepDt > 0.0f) synchronize_fixtures(w); }
 void b2o_phase_find_new_contacts(b2o_world* w)
 {
-	if (w->stepDt > 0.0f)
+	if (w->stepComplete && w->stepDt > 0.0f)
 	{
 		find_new_contacts(w);
 		clear_post_solve(w);
@@ -2822,7 +2840,7 @@ void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 	if (w->eventsOn && w->continuous && dt > 0.0f) collect_contact_events(w);
 	float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
 	float dtRatio = w->inv_dt0 * dt;
-	if (dt > 0.0f) solve(w, dt, dtRatio, velIters, posIters);
+	if (w->stepComplete && dt > 0.0f) solve(w, dt, dtRatio, velIters, posIters); /* b2World.cpp:1668 */
 	if (w->continuous && dt > 0.0f) solve_toi(w, dt, velIters);
 	if (dt > 0.0f) w->inv_dt0 = inv_dt;
 	for (int i = 0; i < w->nBodies; ++i)

@@ -84,6 +84,39 @@ def test_oracle_all_callbacks_with_continuous_physics_match_the_reference(ref, o
     b.close()
 
 
+SUBSTEP_CASES = [("bullets", bh.BULLETS, 20, 4, 1, 400), ("field", bh.FIELD, 300, 40, 5, 300), ("rain", bh.RAIN, 120, 0, 4, 400),
+                 ("piles", bh.PILES, 25, 5, 6, 300), ("pyramid", bh.PYRAMID, 9, 1, 1, 300)]
+
+
+@pytest.mark.parametrize("name,scene,p0,p1,seed,steps", SUBSTEP_CASES)
+@pytest.mark.parametrize("listener", [False, True])
+def test_oracle_sub_stepping_matches_the_reference(ref, oracle, name, scene, p0, p1, seed, steps, listener):
+    """b2World::SetSubStepping (b2World.h:183): a Step call solves ONE TOI event and returns with m_stepComplete false
+    (b2World.cpp:1082-1086); the calls that follow run Collide and the next event, but no island solve (b2World.cpp:1668),
+    until no event is left and the TOI flags are cleared (ClearPostSolveTOI, :1467-1504). Body states, contact counts and -
+    with the recording listener - every callback of every call, against the reference build."""
+    flags = bh.DEFAULT_FLAGS | bh.F_CONTINUOUS | bh.F_SUBSTEP
+    a = ref.world(scene, p0, p1, seed=seed, flags=flags)
+    b = oracle.world(scene, p0, p1, seed=seed, flags=flags)
+    if listener:
+        a.record_events(mode=7)
+        b.record_events(mode=7)
+    still = 0
+    for s in range(steps):
+        before = b.bodies().copy()
+        a.step(1)
+        b.step(1)
+        assert a.contact_count == b.contact_count, "step %d" % s
+        assert np.array_equal(a.bodies().view(np.uint32), b.bodies().view(np.uint32)), "step %d" % s
+        if listener:
+            assert sorted(map(tuple, a.events_ex().tolist())) == sorted(map(tuple, b.events_ex().tolist())), "step %d" % s
+        # (a call that only continues a step moves the bodies of one TOI island and nothing else)
+        still += int((b.bodies()[:, :3] == before[:, :3]).all(axis=1).sum() > 0.5 * len(before))
+    assert still > 0, "no call ever continued an incomplete step: sub-stepping is not exercised"
+    a.close()
+    b.close()
+
+
 def test_events_off_by_default_and_after_removal(oracle):
     w = oracle.world(bh.PILES, 10, 4, seed=3)
     w.step(30)
