@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	const int tid = (int)threadIdx.x;
 	__shared__ __attribute__((aligned(16))) float s_out[2560];
 	__shared__ int s_last;
-	const bool toiEvents = S->c.nToiEvents != 0;
+	// (ClearPostSolveTOI only when the step is complete; sub-stepping: also for what earlier calls of the step touched)
+	const bool toiEvents = (S->c.nToiEvents != 0 || W.toiContinue != 0) && S->c.toiIncomplete == 0;
 	bool skipRows = false;
 	const bool storeRows = mode != END_STEP_LAZY, houseKeeping = mode != END_STEP_ROWS;
 	if (mode == END_STEP_SKIP_IF_REDO)

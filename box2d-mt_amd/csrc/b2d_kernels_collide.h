@@ -471,6 +471,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.toiBase = 0;
 		c.toiOverflow = 0;
 		c.nToiLog = 0;
+		c.toiIncomplete = 0;
 		c.toiUnsafe = 0;
 		c.nToiGroups = 0;
 		c.nToiMoved = 0;
@@ -481,6 +482,22 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.nFilterList = 0;
 	}
 	if (t < 32) bar[t] = 0;
+}
+
+// The wake requests Collide gathered (ConsumeAwakes, b2Contact::Destroy) are normally applied by the island build that
+// follows (k_island_init). A call that continues an open step (sub-stepping) has no island build: applied here.
+__global__ __launch_bounds__(256) void k_wake_apply(DW W)
+{
+	b2dPhaseStamp(W);
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		if (W.b_wake[i])
+		{
+			W.b_flags[i] |= BF_AWAKE;
+			W.b_pos[i].w = 0.0f;
+			W.b_wake[i] = 0;
+		}
+	}
 }
 
 // b2World::CreateJoint / DestroyJoint (b2World.cpp:716-732, 833-845): contacts between the two bodies of a joint that does

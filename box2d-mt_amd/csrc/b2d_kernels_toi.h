@@ -102,6 +102,24 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
 	int calls = 0;
+	if (W.toiContinue)
+	{
+		// a call that continues a step (sub-stepping): the impacts earlier calls found stay (b2World.cpp:1041-1045), only the
+		// pending list is made again; what has no valid impact is computed by the event loop in the reference's order
+		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		{
+			const uint32_t flags = C.flags[i] & ~(CF_TOI_LISTED | CF_TOI_PENDING);
+			const bool listed = (flags & CF_TOI) != 0 && C.mat[i].w < 1.0f;
+			if (listed)
+			{
+				const int k = atomicAdd(&S->c.nToiList, 1);
+				if (k < W.capContacts) W.toiList[k] = i;
+			}
+			C.flags[i] = flags | (listed ? CF_TOI_LISTED : 0u);
+		}
+		if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S->c.toiUnsafe, 1); // (never the parallel chains)
+		return;
+	}
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		uint32_t flags = C.flags[i] & ~CF_TOI_STATE_MASK;
@@ -176,7 +194,10 @@ __global__ __launch_bounds__(256) void k_toi_adj_fill(DW W)
 __global__ __launch_bounds__(256) void k_toi_clear(DW W)
 {
 	b2dPhaseStamp(W);
-	if (W.st->c.nToiEvents == 0) return;
+	// (ClearPostSolveTOI, b2World.cpp:1467-1504: when the step is complete, and only if anything was touched - by this call
+	// or, sub-stepping, by the calls before it)
+	if (W.st->c.toiIncomplete != 0) return;
+	if (W.st->c.nToiEvents == 0 && !W.toiContinue) return;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
 		W.b_pos0[i].w = 0.0f;
@@ -361,6 +382,8 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 	const int listCap = DOMAIN ? W.toiDomCount[domain] : W.capContacts;
 	const int myRoot = DOMAIN ? W.toiDomRoot[domain] : -1;
 	__shared__ int s_unsafe, s_failed, s_movedLocal[TOI_DOM_MOVED_LOCAL], s_nMovedLocal;
+	__shared__ int s_incomplete; // the call ends after its event cap with the step unfinished (sub-stepping)
+	__shared__ int s_stepCalls;  // b2World::StepSolveTOI calls of this launch (solid or not: the cap counts calls)
 
 	__shared__ int s_nC, s_nL, s_events, s_calls, s_overflow;
 	__shared__ int s_logCursor; // next free record of DW::toiLog (listener calls of the sub-steps, in call order)
@@ -405,8 +428,27 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		s_overflow = 0;
 		s_toiOrder = S->c.nToiOrder;
 		s_nMovedAll = partial ? (S->c.nToiMoved < TOI_MOVED_ALL_MAX ? S->c.nToiMoved : TOI_MOVED_ALL_MAX) : 0;
+		s_nRecomp = 0;
+		s_incomplete = 0;
+		s_stepCalls = 0;
 	}
 	__syncthreads();
+	// A call that continues a step (b2World::SetSubStepping, b2World.cpp:1041-1086: m_stepComplete false): nothing was computed
+	// by a first pass - the impacts found by earlier calls are still valid (CF_TOI), the contacts of the bodies the last
+	// event displaced, the contacts it created and whatever Collide made eligible since are not. The single-threaded
+	// FindMinToiContact computes them on its way through the contact array: all of them form the first batch here.
+	if (!DOMAIN && !partial && W.toiContinue)
+	{
+		for (int c = tid; c < s_nC; c += TOI_LANES)
+		{
+			const uint32_t flags = ldFlags(&C.flags[c]);
+			if ((flags & (CF_TOI | CF_TOI_PENDING)) != 0 || !toiEligible(W, flags, C.ids[c])) continue;
+			atomicOr(&C.flags[c], CF_TOI_PENDING);
+			const int k = atomicAdd(&s_nRecomp, 1);
+			if (k < TOI_RECOMP_MAX) s_recomp[k] = c; else atomicOr(&s_overflow, 8);
+		}
+		__syncthreads();
+	}
 
 	// SetAwake(true) (b2Body.h:690-718) + remember bodies that were asleep: their dormant contacts become eligible
 	auto wake = [&](int body)
@@ -430,6 +472,125 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 #define TOI_T(k) do { if (tid == 0) { const unsigned long long now = wall_clock64(); s_t[k] += now - tPrev; tPrev = now; } } while (0)
 	for (;;)
 	{
+		// ---- the impacts FindMinToiContact has to (re)compute before it can look for the minimum (b2World.cpp:1525-1611: a
+		// contact without e_toiFlag): collected at the end of the previous event, or - in a call that continues a step
+		// (sub-stepping) - by the scan above
+		{
+			const int nRecomp = s_nRecomp < TOI_RECOMP_MAX ? s_nRecomp : TOI_RECOMP_MAX;
+			// Put the sweeps of each pair on the same interval (b2World.cpp:385-396): the lagging body advances to
+			// the other's alpha0. A body can meet partners at different times within one pass, so the advances are
+			// replayed in the reference's visiting order: the slot order of its contact array (ContactArrays::mgr).
+			for (int r = tid; r < nRecomp; r += TOI_LANES) s_rSlot[r] = C.mgr[s_recomp[r]];
+			__syncthreads();
+			for (int r = tid; r < nRecomp; r += TOI_LANES)
+			{
+				const int m = s_rSlot[r];
+				int rank = 0;
+				for (int j = 0; j < nRecomp; ++j) rank += s_rSlot[j] < m ? 1 : 0;
+				s_rSorted[rank] = s_recomp[r];
+			}
+			__syncthreads();
+			for (int r = tid; r < nRecomp; r += TOI_LANES)
+			{
+				const int4 ids = C.ids[s_rSorted[r]];
+				s_flatBody[2 * r] = ids.z;
+				s_flatBody[2 * r + 1] = ids.w;
+			}
+			if (tid == 0) s_nAdv = 0;
+			__syncthreads();
+			for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
+			{
+				const int b = s_flatBody[q];
+				int first = q;
+				for (int j = 0; j < q; ++j)
+				{
+					if (s_flatBody[j] == b)
+					{
+						first = j;
+						break;
+					}
+				}
+				s_flatFirst[q] = first;
+				if (first == q) s_flatAlpha[q] = W.b_pos0[b].w;
+			}
+			__syncthreads();
+			if (tid == 0)
+			{
+				int nAdv = 0;
+				for (int r = 0; r < nRecomp; ++r)
+				{
+					const int fa = s_flatFirst[2 * r], fb = s_flatFirst[2 * r + 1];
+					if (DOMAIN)
+					{
+						// a static partner is always level with or behind the body it is paired with here (every body of the mini
+						// island was advanced to the event time, and event times never decrease): advancing it changes nothing
+						const bool stA = (ldFlags(&W.b_flags[s_flatBody[fa]]) & BF_TYPE_MASK) == BT_STATIC;
+						const bool stB = (ldFlags(&W.b_flags[s_flatBody[fb]]) & BF_TYPE_MASK) == BT_STATIC;
+						if (stA || stB) continue;
+					}
+					const float aA = s_flatAlpha[fa], aB = s_flatAlpha[fb];
+					if (aA < aB)
+					{
+						s_advFlat[nAdv] = fa;
+						s_advAlpha[nAdv++] = aB;
+						s_flatAlpha[fa] = aB;
+					}
+					else if (aB < aA)
+					{
+						s_advFlat[nAdv] = fb;
+						s_advAlpha[nAdv++] = aA;
+						s_flatAlpha[fb] = aA;
+					}
+				}
+				s_nAdv = nAdv;
+			}
+			__syncthreads();
+			for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
+			{
+				if (s_flatFirst[q] != q) continue;
+				const int nAdv = s_nAdv;
+				bool any = false;
+				Sweep sw;
+				for (int k = 0; k < nAdv; ++k)
+				{
+					if (s_advFlat[k] != q) continue;
+					if (!any) sw = loadSweep(W, s_flatBody[q]);
+					any = true;
+					b2dSweepAdvance(sw, s_advAlpha[k]);
+				}
+				if (any) W.b_pos0[s_flatBody[q]] = make_float4(sw.c0.x, sw.c0.y, sw.a0, sw.alpha0);
+			}
+			__syncthreads();
+			for (int r = tid; r < nRecomp; r += TOI_LANES)
+			{
+				const int c = s_rSorted[r];
+				const int4 ids = C.ids[c];
+				Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
+				if (DOMAIN)
+				{
+					if ((ldFlags(&W.b_flags[ids.z]) & BF_TYPE_MASK) == BT_STATIC) sA.alpha0 = sB.alpha0;
+					else if ((ldFlags(&W.b_flags[ids.w]) & BF_TYPE_MASK) == BT_STATIC) sB.alpha0 = sA.alpha0;
+				}
+				const float alpha = computeToi(W, ids, sA, sB);
+				atomicAdd(&s_calls, 1);
+				float4 mat = C.mat[c];
+				mat.w = alpha;
+				C.mat[c] = mat;
+				uint32_t flags = (ldFlags(&C.flags[c]) & ~CF_TOI_PENDING) | CF_TOI;
+				if (alpha < 1.0f && (flags & CF_TOI_LISTED) == 0)
+				{
+					flags |= CF_TOI_LISTED;
+					const int k = atomicAdd(&s_nL, 1);
+					if (k < listCap) list[k] = c; else atomicOr(&s_overflow, 16);
+				}
+				C.flags[c] = flags;
+			}
+			__syncthreads();
+			if (tid == 0 && s_nL > listCap) s_nL = listCap;
+			__syncthreads();
+			if (tid == 0) s_nRecomp = 0;
+			__syncthreads();
+		}
 		// ---- FindMinToiContact: lexicographic min of (alpha, proxyLow, proxyHigh) over the pending list ----
 		{
 			uint32_t bestA = 0xffffffffu;
@@ -495,11 +656,11 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		if (tid == 0)
 		{
 			s_nWoken = 0;
+			s_stepCalls += 1;
 			s_nCand = 0;
 			s_nMoves = 0;
 			s_nPairs = 0;
 			s_nNew = 0;
-			s_nRecomp = 0;
 			Sweep a = loadSweep(W, seedA), b = loadSweep(W, seedB);
 			b2dSweepAdvance(a, minAlpha); a.c = a.c0; a.a = a.a0;
 			b2dSweepAdvance(b, minAlpha); b.c = b.c0; b.a = b.a0;
@@ -1116,6 +1277,14 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		}
 		__syncthreads();
 		TOI_T(8);
+		// b2World::SetSubStepping (b2World.cpp:1082-1086): the call ends after its event, the step stays open - the next call
+		// finds what has to be recomputed by itself (m_stepComplete = false)
+		if (!DOMAIN && !partial && W.toiEventCap > 0 && s_stepCalls >= W.toiEventCap)
+		{
+			if (tid == 0) s_incomplete = 1;
+			__syncthreads();
+			break;
+		}
 		// ---- contacts that the next FindMinToiContact would have to (re)compute ----------------------------------------
 		const int nWoken = s_nWoken < TOI_WOKEN_MAX ? s_nWoken : TOI_WOKEN_MAX;
 		for (int bi = 0; bi < nB + nWoken; ++bi)
@@ -1138,118 +1307,6 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				if (k < TOI_RECOMP_MAX) s_recomp[k] = c; else atomicOr(&s_overflow, 8);
 			}
 		}
-		__syncthreads();
-		const int nRecomp = s_nRecomp < TOI_RECOMP_MAX ? s_nRecomp : TOI_RECOMP_MAX;
-		// Put the sweeps of each pair on the same interval (b2World.cpp:385-396): the lagging body advances to
-		// the other's alpha0. A body can meet partners at different times within one pass, so the advances are
-		// replayed in the reference's visiting order: the slot order of its contact array (ContactArrays::mgr).
-		for (int r = tid; r < nRecomp; r += TOI_LANES) s_rSlot[r] = C.mgr[s_recomp[r]];
-		__syncthreads();
-		for (int r = tid; r < nRecomp; r += TOI_LANES)
-		{
-			const int m = s_rSlot[r];
-			int rank = 0;
-			for (int j = 0; j < nRecomp; ++j) rank += s_rSlot[j] < m ? 1 : 0;
-			s_rSorted[rank] = s_recomp[r];
-		}
-		__syncthreads();
-		for (int r = tid; r < nRecomp; r += TOI_LANES)
-		{
-			const int4 ids = C.ids[s_rSorted[r]];
-			s_flatBody[2 * r] = ids.z;
-			s_flatBody[2 * r + 1] = ids.w;
-		}
-		if (tid == 0) s_nAdv = 0;
-		__syncthreads();
-		for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
-		{
-			const int b = s_flatBody[q];
-			int first = q;
-			for (int j = 0; j < q; ++j)
-			{
-				if (s_flatBody[j] == b)
-				{
-					first = j;
-					break;
-				}
-			}
-			s_flatFirst[q] = first;
-			if (first == q) s_flatAlpha[q] = W.b_pos0[b].w;
-		}
-		__syncthreads();
-		if (tid == 0)
-		{
-			int nAdv = 0;
-			for (int r = 0; r < nRecomp; ++r)
-			{
-				const int fa = s_flatFirst[2 * r], fb = s_flatFirst[2 * r + 1];
-				if (DOMAIN)
-				{
-					// a static partner is always level with or behind the body it is paired with here (every body of the mini
-					// island was advanced to the event time, and event times never decrease): advancing it changes nothing
-					const bool stA = (ldFlags(&W.b_flags[s_flatBody[fa]]) & BF_TYPE_MASK) == BT_STATIC;
-					const bool stB = (ldFlags(&W.b_flags[s_flatBody[fb]]) & BF_TYPE_MASK) == BT_STATIC;
-					if (stA || stB) continue;
-				}
-				const float aA = s_flatAlpha[fa], aB = s_flatAlpha[fb];
-				if (aA < aB)
-				{
-					s_advFlat[nAdv] = fa;
-					s_advAlpha[nAdv++] = aB;
-					s_flatAlpha[fa] = aB;
-				}
-				else if (aB < aA)
-				{
-					s_advFlat[nAdv] = fb;
-					s_advAlpha[nAdv++] = aA;
-					s_flatAlpha[fb] = aA;
-				}
-			}
-			s_nAdv = nAdv;
-		}
-		__syncthreads();
-		for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
-		{
-			if (s_flatFirst[q] != q) continue;
-			const int nAdv = s_nAdv;
-			bool any = false;
-			Sweep sw;
-			for (int k = 0; k < nAdv; ++k)
-			{
-				if (s_advFlat[k] != q) continue;
-				if (!any) sw = loadSweep(W, s_flatBody[q]);
-				any = true;
-				b2dSweepAdvance(sw, s_advAlpha[k]);
-			}
-			if (any) W.b_pos0[s_flatBody[q]] = make_float4(sw.c0.x, sw.c0.y, sw.a0, sw.alpha0);
-		}
-		__syncthreads();
-		for (int r = tid; r < nRecomp; r += TOI_LANES)
-		{
-			const int c = s_rSorted[r];
-			const int4 ids = C.ids[c];
-			Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
-			if (DOMAIN)
-			{
-				if ((ldFlags(&W.b_flags[ids.z]) & BF_TYPE_MASK) == BT_STATIC) sA.alpha0 = sB.alpha0;
-				else if ((ldFlags(&W.b_flags[ids.w]) & BF_TYPE_MASK) == BT_STATIC) sB.alpha0 = sA.alpha0;
-			}
-			const float alpha = computeToi(W, ids, sA, sB);
-			atomicAdd(&s_calls, 1);
-			float4 mat = C.mat[c];
-			mat.w = alpha;
-			C.mat[c] = mat;
-			uint32_t flags = (ldFlags(&C.flags[c]) & ~CF_TOI_PENDING) | CF_TOI;
-			if (alpha < 1.0f && (flags & CF_TOI_LISTED) == 0)
-			{
-				flags |= CF_TOI_LISTED;
-				const int k = atomicAdd(&s_nL, 1);
-				if (k < listCap) list[k] = c; else atomicOr(&s_overflow, 16);
-			}
-			C.flags[c] = flags;
-		}
-		__syncthreads();
-		if (tid == 0 && s_nL > listCap) s_nL = listCap;
 		__syncthreads();
 		TOI_T(9);
 	}
@@ -1278,6 +1335,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			S->c.toiOverflow = s_overflow | (s_logCursor > W.capToiLog && W.toiLog != nullptr ? 64 : 0);
 			S->c.nToiOrder = s_toiOrder;
 			S->c.nToiLog = s_logCursor < W.capToiLog ? s_logCursor : W.capToiLog;
+			if (!partial) S->c.toiIncomplete = s_incomplete;
 		}
 	}
 }

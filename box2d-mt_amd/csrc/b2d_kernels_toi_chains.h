@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 			S->c.nToiNewPairs = 0;
 			S->c.nToiChainCreated = 0;
 			S->c.nToiLog = 0;
+			S->c.toiIncomplete = 0;
 			// (the serial replay of tied components may have created contacts)
 			S->c.nContacts = S->c.nContactsSnap;
 			S->c.nToiOrder = S->c.nToiOrderSnap;

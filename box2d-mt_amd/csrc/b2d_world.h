@@ -124,6 +124,7 @@ struct Counters
 	int nToiCalls;       // b2TimeOfImpact evaluations this step
 	int toiBase;         // contact count when the TOI adjacency was built (later contacts form the tail)
 	int nToiLog;         // records in DW::toiLog this step
+	int toiIncomplete;   // the TOI phase ended at its event cap (sub-stepping): the step is not complete (b2World::m_stepComplete)
 	int toiOverflow;     // bit0 candidates, bit1 moves, bit2 pairs, bit3 recompute list, bit4 TOI list
 	int nToiOrder;       // persistent: TOI-candidate contacts alive (b2ContactManager::m_toiCount)
 	int nToiDestroy;     // TOI candidates destroyed by the running collide
@@ -381,6 +382,8 @@ struct DW
 	PostSolveRec* postRecs;
 	ToiLogRec* toiLog;      // listener calls from TOI sub-steps, in call order (null: no listener)
 	int capToiLog;
+	int toiEventCap;     // b2World::SetSubStepping: events per call (0: no cap)
+	int toiContinue;     // this call continues a step an earlier call left incomplete (no island solve, no first pass)
 	const int4* toiVerdict; // what the listener's PreSolve answered for the Updates logged so far in this phase: x bit0 asked,
 	int nToiVerdict;        // bit1 switched the contact off, yzw friction / restitution / tangent speed (bits); [0, nToiVerdict)
 	int* filterList;     // contact indices flagged CF_FILTER (listed for the user's filter before Collide)

@@ -342,6 +342,10 @@ struct b2hip_world
 	bool toiChainsHadGrid = false; // the chains of this step ran with the grid (else a moved proxy is all "unsafe" means)
 	bool toiSnapshotTaken = false; // this step's TOI phase saved the state it started from (k_toi_snapshot)
 	std::vector<int4> toiVerdicts; // this step's PreSolve answers per TOI log slot (the device's copy: DW::toiVerdict)
+	// b2World::SetSubStepping (b2World.h:183; b2World.cpp:1082-1086, 1668): with the flag on a step call solves one TOI event
+	// and leaves the step open; the calls that follow run Collide and the next event but no island solve, until no event is left
+	bool stepComplete = true;  // b2World::m_stepComplete
+	bool stepSolves = true;    // this call runs Solve (it started from a complete step)
 	bool toiCountersFresh = false, toiSpeculative = false, toiSyncOnly = false, toiNoDomains = false;
 	bool toiRan, toiEventValid, toiChains, toiSerialOnly, kernelTimingLaunches, solverBarriers, colorSmallPending;
 	bool useGraphs;              // replay the host-decision-free launch sequences as hipGraphs (B2HIP_GRAPHS=1)
@@ -2095,7 +2099,7 @@ static int phaseToiSync(b2hip_world* w);
 // contacts, and the synchronous phase). One read-back and ~45 us less per step with continuous physics on.
 static int phaseToi(b2hip_world* w)
 {
-	if (w->toiSerialOnly || w->toiSyncOnly || listenerOn(w)) return phaseToiSync(w);
+	if (w->toiSerialOnly || w->toiSyncOnly || listenerOn(w) || w->dw.toiEventCap > 0 || w->dw.toiContinue) return phaseToiSync(w);
 	if (w->toiSyncSticky > 0)
 	{
 		// the serial loop was needed recently (bullets, kinematic partners, contact-creating events): decide from the
@@ -2166,10 +2170,13 @@ static int phaseToiSync(b2hip_world* w)
 	w->last.nToiList = w->h_dstate->c.nToiList;
 	w->last.nToiCalls = w->h_dstate->c.nToiCalls;
 	w->last.nToiEvents = 0;
-	if (w->h_dstate->c.nToiList == 0) return 0;
+	// (sub-stepping: one event per call in the reference's serial order; a call that continues a step has impacts to compute
+	// even when nothing is pending yet - the event loop's first batch)
+	const bool subStepped = d.toiEventCap > 0 || d.toiContinue != 0;
+	if (w->h_dstate->c.nToiList == 0 && !d.toiContinue) return 0;
 	if (w->h_dstate->c.nToiList > d.capContacts) return setError(B2HIP_ERR_CAPACITY, "TOI list overflow");
 	w->toiRan = true;
-	if (w->h_dstate->c.toiUnsafe == 0 && !w->toiSerialOnly && !listenerOn(w))
+	if (w->h_dstate->c.toiUnsafe == 0 && !w->toiSerialOnly && !listenerOn(w) && !subStepped)
 	{
 		// every pending impact pairs a dynamic body with a static one: one wave per dynamic body, verified afterwards
 		// (b2hip_step_end falls back to the serial loop from the snapshot if a chain met a case that is order dependent)
@@ -2192,7 +2199,7 @@ static int phaseToiSync(b2hip_world* w)
 		w->toiChains = true;
 		return 0;
 	}
-	if (!w->toiSerialOnly && !w->toiNoDomains && !listenerOn(w))
+	if (!w->toiSerialOnly && !w->toiNoDomains && !listenerOn(w) && !subStepped)
 	{
 		// bullets / kinematic partners: the event loop runs per connected component of the contact graph, side by side
 		// (b2d_kernels_toi_domains.h); b2hip_step_end falls back to the serial loop from the snapshot if a component met
@@ -3183,6 +3190,9 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 		w->ktKind = 0;
 	}
 	w->stepActive = true;
+	w->stepSolves = w->stepComplete;
+	w->dw.toiContinue = w->stepComplete ? 0 : 1;
+	w->dw.toiEventCap = w->def.sub_stepping ? 1 : 0;
 	// zero the per-step counters (keep nContacts / nMoves / cur)
 	Counters zero;
 	memset(&zero, 0, sizeof(zero));
@@ -3618,10 +3628,6 @@ int b2hip_step_begin(b2hip_world* w, float dt, int velocity_iterations, int posi
 {
 	if (int rc = checkUsable(w, "b2hip_step_begin", false)) return rc;
 	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_begin inside a step (finish it with b2hip_step_end)");
-	// b2World::SetSubStepping (b2World.h:183, b2World.cpp:1082: one TOI event per Step call, the step finished over several
-	// calls) is not implemented. A world that has it switched on is REFUSED a step - stepping it as if the flag were off would
-	// silently give other results than the reference. The world is untouched and steps again once the flag is cleared.
-	if (w->def.sub_stepping) return setError(B2HIP_ERR_UNSUPPORTED, "sub-stepping (b2World::SetSubStepping) is not implemented: the step was refused, clear the flag to step");
 	DEVICE_GUARD(w);
 	return stepFailed(w, stepBeginImpl(w, dt, velocity_iterations, position_iterations));
 }
@@ -3765,7 +3771,7 @@ static int shardExchangeOnStream(b2hip_world* w);
 
 static int solveImpl(b2hip_world* w)
 {
-	if (w->sp.dt > 0.0f)
+	if (w->sp.dt > 0.0f && w->stepSolves) // (b2World.cpp:1668: m_stepComplete && step.dt > 0)
 	{
 		int rc = phaseSolve(w);
 		if (rc) return rc;
@@ -3778,9 +3784,11 @@ static int solveImpl(b2hip_world* w)
 	}
 	else
 	{
+		// (a call that continues an open step: no island build to apply the wake-ups Collide asked for)
+		if (w->sp.dt > 0.0f) LAUNCH(w, k_wake_apply, gridFor(w->dw.nBodies), 256, w->dw);
 		for (int k = 4; k <= 8; ++k) stampPhase(w, k);
 	}
-	if (w->postSolveOn && w->sp.dt > 0.0f) LAUNCH(w, k_postsolve_gather, gridFor(w->dw.capContacts), 256, w->dw);
+	if (w->postSolveOn && w->sp.dt > 0.0f && w->stepSolves) LAUNCH(w, k_postsolve_gather, gridFor(w->dw.capContacts), 256, w->dw);
 	stampPhase(w, 3);
 	return 0;
 }
@@ -3795,7 +3803,7 @@ int b2hip_solve(b2hip_world* w)
 
 static int syncFixturesImpl(b2hip_world* w)
 {
-	if (w->sp.dt > 0.0f)
+	if (w->sp.dt > 0.0f && w->stepSolves)
 	{
 		int rc = phaseSyncFixtures(w);
 		if (rc) return rc;
@@ -3814,7 +3822,7 @@ int b2hip_sync_fixtures(b2hip_world* w)
 
 static int findNewContactsImpl(b2hip_world* w)
 {
-	if (w->sp.dt > 0.0f)
+	if (w->sp.dt > 0.0f && w->stepSolves)
 	{
 		int rc = findNewContactsGraph(w);
 		if (rc) return rc;
@@ -4009,7 +4017,7 @@ static int stepEndImpl(b2hip_world* w)
 	const bool pairOverflow = (w->h_dstate->c.overflow & 2) != 0 || ((w->h_dstate->c.overflow & 1) != 0 && w->h_dstate->c.nMoves != 0);
 	if ((w->h_dstate->c.overflow & 1) != 0 && !pairOverflow) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step");
 	if (pairOverflow && w->sp.dt <= 0.0f) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
-	if ((w->h_dstate->c.nMoves != 0 || pairOverflow) && w->sp.dt > 0.0f)
+	if ((w->h_dstate->c.nMoves != 0 || pairOverflow) && w->sp.dt > 0.0f && w->stepSolves)
 	{
 		if (w->h_dstate->c.nPairs > COUNT_RANK_MAX || pairOverflow)
 		{
@@ -4208,6 +4216,8 @@ static int stepEndImpl(b2hip_world* w)
 		if (c.toiOverflow) return setError(B2HIP_ERR_CAPACITY, "TOI event scratch overflow (flags " + std::to_string(c.toiOverflow) + ")");
 	}
 	if (w->sp.dt > 0.0f) w->inv_dt0 = w->sp.inv_dt;
+	// b2World::m_stepComplete (b2World.cpp:1072, 1084): only SolveTOI changes it
+	if (w->def.continuous && w->sp.dt > 0.0f) w->stepComplete = c.toiIncomplete == 0;
 	w->stepActive = false;
 
 	// b2Profile from events (milliseconds)
@@ -4391,7 +4401,7 @@ struct SnapHeader
 	uint32_t stateCount, cur;
 	int32_t nextNode, leafCount, lastContacts, newFixture;
 	float inv_dt0, cellSize;
-	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bit 1 blocksTooBig, bits 8..15 adoptSticky, 16..23 largeHintSteps, 24..30 recolorCountdown (what the next island build is told)
+	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bit 1 blocksTooBig, bit 2 step incomplete (sub-stepping), bits 8..15 adoptSticky, 16..23 largeHintSteps, 24..30 recolorCountdown (what the next island build is told)
 };
 const uint32_t kSnapVersion = 4;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
@@ -4464,7 +4474,7 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
 	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
 	h.eventsOn = w->eventsOn ? 1 : 0;
-	h.solverHints = (w->serialOrphansNext ? 1 : 0) | (w->blocksTooBig ? 2 : 0) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16) | ((w->recolorCountdown & 0x7f) << 24);
+	h.solverHints = (w->serialOrphansNext ? 1 : 0) | (w->blocksTooBig ? 2 : 0) | (w->stepComplete ? 0 : 4) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16) | ((w->recolorCountdown & 0x7f) << 24);
 	SnapWriter o;
 	o.host(&h, sizeof(h));
 	o.host(&w->def, sizeof(w->def));
@@ -4683,6 +4693,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	w->eventsOn = h.eventsOn != 0;
 	w->serialOrphansNext = h.solverHints & 1;
 	w->blocksTooBig = (h.solverHints & 2) != 0;
+	w->stepComplete = (h.solverHints & 4) == 0;
 	w->adoptSticky = (h.solverHints >> 8) & 0xff;
 	w->largeHintSteps = (h.solverHints >> 16) & 0xff;
 	w->recolorCountdown = (h.solverHints >> 24) & 0x7f;

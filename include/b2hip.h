@@ -90,7 +90,8 @@ typedef struct b2hip_world_def
 	int allow_sleep;      /* b2World::SetAllowSleeping      default 1 */
 	int warm_starting;    /* b2World::SetWarmStarting       default 1 */
 	int continuous;       /* b2World::SetContinuousPhysics  default 1 in the reference; continuous collision (TOI) runs on the device: b2hip_solve_toi */
-	int sub_stepping;     /* b2World::SetSubStepping        default 0 ; not implemented: while it is on, b2hip_step* refuses to step (B2HIP_ERR_UNSUPPORTED) */
+	int sub_stepping;     /* b2World::SetSubStepping        default 0 ; a step call solves ONE TOI event and leaves the step open; the calls that
+	                       *   follow run Collide and the next event, no island solve, until no event is left (b2World.cpp:1082-1086, 1668) */
 	int auto_clear_forces;/* b2World::SetAutoClearForces    default 1 */
 	int device;           /* HIP device ordinal, -1 = current */
 } b2hip_world_def;

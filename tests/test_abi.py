@@ -66,23 +66,27 @@ def test_product_does_not_link_the_oracle():
 
 
 @pytest.mark.gpu
-def test_sub_stepping_is_refused_not_ignored():
-    """b2World::SetSubStepping (b2World.h:183) is not implemented: a world with the flag on must refuse to step, loudly, and
-    step again once the flag is cleared (never step as if the flag were off)."""
+def test_sub_stepping_solves_one_toi_event_per_call():
+    """b2World::SetSubStepping (b2World.h:183; b2World.cpp:1082-1086, 1668): with the flag on, a step call that finds a TOI
+    event solves that one event and leaves the step open; the next call runs no island solve - a body in free fall far away
+    does not move during it - and a call that finds no event left closes the step, after which bodies are integrated again.
+    (Parity with the oracle and the reference build: tests/test_events.py.)"""
     import b2hip
     w = b2hip.World(continuous=True)
-    g = w.create_body(b2hip.STATIC, (0.0, -1.0))
-    w.create_fixture(g, b2hip.box_shape(10.0, 1.0))
-    b = w.create_body(b2hip.DYNAMIC, (0.0, 3.0))
-    w.create_fixture(b, b2hip.box_shape(0.5, 0.5), density=1.0)
-    w.step()
-    before = w.body_states().copy()
+    g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+    w.create_fixture(g, b2hip.box_shape(20.0, 0.05))
+    fast = w.create_body(b2hip.DYNAMIC, (0.0, 3.0), velocity=(0.0, -60.0))      # reaches the platform through a TOI event
+    w.create_fixture(fast, b2hip.box_shape(0.1, 0.1), density=1.0)
+    free = w.create_body(b2hip.DYNAMIC, (50.0, 100.0))                           # far from everything: only Solve moves it
+    w.create_fixture(free, b2hip.box_shape(0.1, 0.1), density=1.0)
     w.set_flags(continuous=True, sub_stepping=True)
-    with pytest.raises(b2hip.B2HipError) as err:
+    heights, continued = [], 0
+    for _ in range(12):
         w.step()
-    assert "sub-stepping" in str(err.value)
-    assert w.body_states().tobytes() == before.tobytes()  # the refused step changed nothing
-    w.set_flags(continuous=True, sub_stepping=False)
-    w.step()
-    assert w.body_states()["py"][b] < before["py"][b]
+        heights.append(float(w.body_states()["py"][free]))
+        if len(heights) > 1 and heights[-1] == heights[-2]:
+            continued += 1
+    assert continued > 0, "no call ever continued an open step (the free body fell in every call): %s" % heights
+    assert heights[-1] < heights[0], "the step never completed again"
+    assert float(w.body_states()["py"][fast]) > 0.1, "the fast box went through the platform"
     w.close()

@@ -117,6 +117,31 @@ def test_oracle_sub_stepping_matches_the_reference(ref, oracle, name, scene, p0,
     b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scene,p0,p1,seed,steps", SUBSTEP_CASES)
+@pytest.mark.parametrize("listener", [False, True])
+def test_device_sub_stepping_matches_the_oracle(amd, oracle, monkeypatch, name, scene, p0, p1, seed, steps, listener):
+    """The device's form of it: the serial event loop with a cap of one StepSolveTOI call per launch; a call that continues a
+    step makes no first pass - the impacts earlier calls found stay valid, the others are the event loop's first batch, in
+    the reference's slot order (b2d_kernels_toi.h). Exact-order mode, bit for bit, callbacks included."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    flags = bh.DEFAULT_FLAGS | bh.F_CONTINUOUS | bh.F_SUBSTEP
+    a = amd.world(scene, p0, p1, seed=seed, flags=flags)
+    b = oracle.world(scene, p0, p1, seed=seed, flags=flags)
+    if listener:
+        a.record_events(mode=7)
+        b.record_events(mode=7)
+    for s in range(steps):
+        a.step(1)
+        b.step(1)
+        assert a.contact_count == b.contact_count, "step %d" % s
+        assert np.array_equal(a.bodies().view(np.uint32), b.bodies().view(np.uint32)), "step %d" % s
+        if listener:
+            assert sorted(map(tuple, a.events_ex().tolist())) == sorted(map(tuple, b.events_ex().tolist())), "step %d" % s
+    a.close()
+    b.close()
+
+
 def test_events_off_by_default_and_after_removal(oracle):
     w = oracle.world(bh.PILES, 10, 4, seed=3)
     w.step(30)
