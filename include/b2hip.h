@@ -72,7 +72,7 @@ typedef enum b2hip_status
 	B2HIP_ERR_INVALID = -1,     /* bad argument / unknown id */
 	B2HIP_ERR_HIP = -2,         /* a HIP runtime call failed */
 	B2HIP_ERR_NO_DEVICE = -3,   /* no usable gfx950 device */
-	B2HIP_ERR_UNSUPPORTED = -4, /* feature outside the device path: a step asked of a world with sub-stepping on is refused */
+	B2HIP_ERR_UNSUPPORTED = -4, /* feature outside the device path */
 	B2HIP_ERR_CAPACITY = -5     /* a device buffer overflowed and could not be regrown */
 } b2hip_status;
 

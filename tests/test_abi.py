@@ -90,3 +90,26 @@ def test_sub_stepping_solves_one_toi_event_per_call():
     assert heights[-1] < heights[0], "the step never completed again"
     assert float(w.body_states()["py"][fast]) > 0.1, "the fast box went through the platform"
     w.close()
+
+
+@pytest.mark.gpu
+def test_an_open_sub_stepped_step_survives_a_snapshot():
+    """m_stepComplete travels with the world (b2hip_save_snapshot): a world saved between two calls of one sub-stepped step
+    continues that step after loading, call for call like the world it was taken from."""
+    import b2hip
+    w = b2hip.World(continuous=True)
+    g = w.create_body(b2hip.STATIC, (0.0, 0.0))
+    w.create_fixture(g, b2hip.box_shape(20.0, 0.05))
+    for k in range(6):
+        b = w.create_body(b2hip.DYNAMIC, (-5.0 + 2.0 * k, 3.0 + 0.1 * k), velocity=(1.0 * k, -60.0))
+        w.create_fixture(b, b2hip.box_shape(0.1, 0.1), density=1.0)
+    w.set_flags(continuous=True, sub_stepping=True)
+    w.step()
+    w.step()  # (six impacts pending after the first call: this one continues the step)
+    w2 = b2hip.World.from_snapshot(w.save_snapshot())
+    for k in range(14):
+        w.step()
+        w2.step()
+        assert w.body_states().tobytes() == w2.body_states().tobytes(), "call %d after the snapshot" % k
+    w.close()
+    w2.close()
