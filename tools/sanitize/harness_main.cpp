@@ -26,7 +26,8 @@ int main()
 	{
 		// (flags 7: continuous physics on; modes 15 / 23: the listener's PreSolve switches contacts off / edits their material -
 		// from inside TOI sub-steps as well)
-		const int runs[][2] = { {6, 7}, {7, 7}, {7, 15}, {7, 23} };
+		// (flags 15: ... and b2World::SetSubStepping - one TOI event per call)
+		const int runs[][2] = { {6, 7}, {7, 7}, {7, 15}, {7, 23}, {15, 7}, {15, 15} };
 		for (auto& run : runs)
 		{
 			const int flags = run[0];
