@@ -1189,6 +1189,8 @@ static int flushEdits(b2hip_world* w)
 			HIP_TRY(hipMemcpy(w->p_key.p + id, &key, sizeof(int), hipMemcpyHostToDevice)); // (a re-activated body's proxies have new ids)
 			HIP_TRY(hipMemcpy(w->p_filter0.p + id, &f0, sizeof(uint32_t), hipMemcpyHostToDevice));
 			HIP_TRY(hipMemcpy(w->p_filter1.p + id, &f1, sizeof(int), hipMemcpyHostToDevice));
+			const float2 mat = make_float2(f.friction, f.restitution); // (b2Fixture::SetFriction / SetRestitution: for contacts created from now on)
+			HIP_TRY(hipMemcpy(w->p_mat.p + id, &mat, sizeof(float2), hipMemcpyHostToDevice));
 		}
 		w->proxyEdits.clear();
 		w->fatEdits.clear();
@@ -3609,6 +3611,103 @@ int b2hip_fixture_set_filter(b2hip_world* w, int fixture, uint16_t category_bits
 	f.groupIndex = group_index;
 	w->proxyEdits.push_back(fixture);
 	return b2hip_fixture_refilter(w, fixture);
+}
+
+// b2Fixture::SetDensity / SetFriction / SetRestitution (b2Fixture.h:306-334): plain values - the density is read by the next
+// ResetMassData, friction and restitution by the contacts created from now on (existing contacts keep their mixture)
+int b2hip_fixture_set_material(b2hip_world* w, int fixture, float density, float friction, float restitution)
+{
+	if (int rc = checkFixture(w, fixture, "b2hip_fixture_set_material")) return rc;
+	HostFixture& f = w->fixtures[fixture];
+	f.density = density;
+	f.friction = friction;
+	f.restitution = restitution;
+	w->proxyEdits.push_back(fixture);
+	return B2HIP_OK;
+}
+
+// b2Body::SetLinearDamping / SetAngularDamping / SetGravityScale (b2Body.h:620-648): read by the next Solve
+int b2hip_set_body_damping(b2hip_world* w, int body, float linear_damping, float angular_damping, float gravity_scale)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_body_damping")) return rc;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	b.linearDamping = linear_damping;
+	b.angularDamping = angular_damping;
+	b.gravityScale = gravity_scale;
+	return B2HIP_OK;
+}
+
+// b2Body::SetFixedRotation (b2Body.cpp:546-565): the flag, no spin, mass data again
+int b2hip_set_fixed_rotation(b2hip_world* w, int body, int flag)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_fixed_rotation")) return rc;
+	HostBody& probe = w->bodies[body];
+	if (((probe.flags & BF_FIXEDROT) != 0) == (flag != 0)) return B2HIP_OK;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (flag) b.flags |= BF_FIXEDROT; else b.flags &= ~BF_FIXEDROT;
+	b.w = 0.0f;
+	resetMassData(w, b);
+	b.resetSweep = 1;
+	return B2HIP_OK;
+}
+
+// b2Body::SetSleepingAllowed (b2Body.h:674-688): a body that may not sleep is woken
+int b2hip_set_sleeping_allowed(b2hip_world* w, int body, int flag)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_sleeping_allowed")) return rc;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (flag) b.flags |= BF_AUTOSLEEP;
+	else
+	{
+		b.flags &= ~BF_AUTOSLEEP;
+		if ((b.flags & BF_AWAKE) == 0)
+		{
+			b.flags |= BF_AWAKE;
+			b.sleepTime = 0.0f;
+		}
+	}
+	return B2HIP_OK;
+}
+
+// b2Body::SetMassData (b2Body.cpp:387-424); mass_data == NULL: b2Body::ResetMassData (b2Body.cpp:310-385)
+int b2hip_set_mass_data(b2hip_world* w, int body, const b2hip_mass_data* md)
+{
+	if (int rc = checkBody(w, body, "b2hip_set_mass_data")) return rc;
+	markDirty(w, body);
+	HostBody& b = w->bodies[body];
+	if (md == nullptr)
+	{
+		resetMassData(w, b);
+		b.resetSweep = 1;
+		return B2HIP_OK;
+	}
+	if (b.type != B2HIP_DYNAMIC_BODY) return B2HIP_OK;
+	b.invMass = 0.0f;
+	b.I = 0.0f;
+	b.invI = 0.0f;
+	b.mass = md->mass;
+	if (b.mass <= 0.0f) b.mass = 1.0f;
+	b.invMass = 1.0f / b.mass;
+	const V2 center = v2(md->local_center[0], md->local_center[1]);
+	if (md->inertia > 0.0f && (b.flags & BF_FIXEDROT) == 0)
+	{
+		b.I = md->inertia - b.mass * b2dDot(center, center);
+		b.invI = 1.0f / b.I;
+	}
+	const V2 oldCenter = v2(b.cx, b.cy);
+	b.lcx = center.x;
+	b.lcy = center.y;
+	const V2 c = b2dMulXV(hostXf(b), center);
+	b.c0x = b.cx = c.x;
+	b.c0y = b.cy = c.y;
+	const V2 dv = b2dCrossSV(b.w, c - oldCenter);
+	b.vx += dv.x;
+	b.vy += dv.y;
+	b.resetSweep = 1;
+	return B2HIP_OK;
 }
 
 int b2hip_joint_set_spring(b2hip_world* w, int joint, float frequency_hz, float damping_ratio)

@@ -163,6 +163,7 @@ void b2h_step(b2h_world* h, int steps, float dt, int velIters, int posIters)
 			const float t = 0.04f * (float)h->scene.servoStep;
 			static_cast<b2MouseJoint*>(h->scene.drag)->SetTarget(b2Vec2(10.5f + 4.0f * sinf(t), 5.0f + 2.0f * sinf(2.0f * t + 1.0f)));
 		}
+		if (h->scene.props) b2h::PropsEdits(h->scene, h->world);
 		if (h->scene.lifecycle)
 		{
 			const size_t before = h->scene.bodies.size();

@@ -87,6 +87,10 @@ enum SceneId
 	e_chains = 13,       // p0 = falling bodies (every fourth a bullet) ; chain shapes: a closed loop (an arena with a bumpy floor), an
 	                     //   open chain with ghost vertices set by hand (a ramp), one without, and a short chain on a kinematic
 	                     //   body that travels to and fro: b2ChainAndCircleContact / b2ChainAndPolygonContact, one proxy per child
+	e_props = 14,        // p0 = falling bodies (the rain scene) ; a scripted tour of the body / fixture PROPERTY setters between steps:
+	                     //   SetLinearDamping, SetAngularDamping, SetGravityScale, SetFixedRotation, SetSleepingAllowed, SetMassData,
+	                     //   ResetMassData after b2Fixture::SetDensity, b2Fixture::SetFriction / SetRestitution, and
+	                     //   GetLinearVelocityFromLocalPoint feeding an impulse; see PropsEdits
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -111,10 +115,12 @@ struct Scene
 	b2Joint* slowDrag;  // lifecycle scene: mouse joint with a slowly moving target
 	b2Joint* spring;    // lifecycle scene: wheel joint whose spring is retuned
 	uint32_t lifecycleSeed;
+	bool props;         // the step loop runs PropsEdits before every step
+	int propsStep;
 	bool sliderBounces; // joint is a prismatic motor slider whose motor is reversed by the step loop at either limit
 	float dtDefault;
 	int velIters, posIters;
-	Scene() : joint(NULL), drag(NULL), servoStep(0), lifecycle(false), lifecycleStep(0), slowDrag(NULL), spring(NULL), lifecycleSeed(1), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
+	Scene() : joint(NULL), drag(NULL), servoStep(0), lifecycle(false), lifecycleStep(0), slowDrag(NULL), spring(NULL), lifecycleSeed(1), props(false), propsStep(0), sliderBounces(false), dtDefault(1.0f / 60.0f), velIters(8), posIters(3) {}
 };
 
 inline b2Body* AddBody(Scene& s, b2World* w, const b2BodyDef& bd)
@@ -1271,6 +1277,56 @@ inline void BuildLifecycle(Scene& s, b2World* w, int count, uint32_t seed)
 
 // The script. `first` = index of the first heap body in s.bodies (1), `count` = heap bodies. Destroyed bodies leave a NULL
 // in s.bodies (indices stay what they were); bodies created later are appended.
+// The property setters of b2Body / b2Fixture between steps (b2Body.h:620-688, b2Body.cpp:310-424, 546-565; b2Fixture.h:306-334),
+// on the bodies of the rain scene, by body index so that every backend edits the same bodies.
+inline void PropsEdits(Scene& s, b2World* w)
+{
+	(void)w;
+	const int step = s.propsStep++;
+	const int count = (int)s.bodies.size();
+	for (int i = 1; i < count; ++i)
+	{
+		b2Body* b = s.bodies[(size_t)i];
+		if (b == NULL || b->GetType() != b2_dynamicBody) continue;
+		if (step == 10 && i % 5 == 0) { b->SetLinearDamping(0.8f); b->SetAngularDamping(1.5f); }
+		if (step == 20 && i % 7 == 1) b->SetGravityScale(-0.3f);
+		if (step == 20 && i % 7 == 2) b->SetGravityScale(2.0f);
+		if (step == 30 && i % 4 == 2) b->SetFixedRotation(true);
+		if (step == 50 && i % 6 == 3)
+		{
+			for (b2Fixture* f = b->GetFixtureList(); f; f = f->GetNext()) f->SetDensity(5.0f * f->GetDensity() + 0.5f);
+			b->ResetMassData();
+		}
+		if (step == 60 && i % 9 == 4)
+		{
+			b2MassData md;
+			md.mass = 3.0f;
+			md.center.Set(0.1f, 0.05f);
+			md.I = 0.8f;
+			b->SetMassData(&md);
+		}
+		if (step == 70 && i % 3 == 0) b->SetSleepingAllowed(false);
+		if (step == 70 && i % 2 == 0)
+		{
+			for (b2Fixture* f = b->GetFixtureList(); f; f = f->GetNext()) { f->SetFriction(0.9f); f->SetRestitution(0.6f); }
+		}
+		if (step == 90 && i % 8 == 2) b->SetFixedRotation(false);
+		if (step == 90 && i % 7 == 1) b->SetGravityScale(1.0f);
+		if (step == 110 && i % 6 == 0) b->SetSleepingAllowed(true);
+		if (step % 15 == 7 && i % 11 == 5)
+		{
+			// a drag against the velocity of an off-centre point of the body
+			const b2Vec2 v = b->GetLinearVelocityFromLocalPoint(b2Vec2(0.2f, 0.1f));
+			b->ApplyLinearImpulseToCenter(-0.1f * b->GetMass() * v, true);
+		}
+	}
+	if (step == 80)
+	{
+		// the ground's material, for the contacts made from now on
+		for (b2Fixture* f = s.bodies[0]->GetFixtureList(); f; f = f->GetNext()) { f->SetFriction(0.05f); f->SetRestitution(0.3f); }
+	}
+}
+
 inline void LifecycleEdits(Scene& s, b2World* w)
 {
 	const int step = s.lifecycleStep++;
@@ -1492,6 +1548,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	case e_vehicles: BuildVehicles(s, w, p.p0, p.p1, p.seed); break;
 	case e_lifecycle: BuildLifecycle(s, w, p.p0, p.seed); break;
 	case e_chains: BuildChains(s, w, p.p0, p.seed); break;
+	case e_props: BuildRain(s, w, p.p0, p.seed); s.props = true; break;
 	default: break;
 	}
 }

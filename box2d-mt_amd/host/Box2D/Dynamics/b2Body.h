@@ -94,6 +94,21 @@ public:
 	float32 GetMass() const;
 	float32 GetInertia() const;
 	void GetMassData(b2MassData* data) const;
+	/// b2Body.cpp:387-424 (dynamic bodies only; a no-op while the world is locked) and b2Body.cpp:310-385
+	void SetMassData(const b2MassData* data);
+	void ResetMassData();
+	/// b2Body.h:620-648, b2Body.cpp:546-565, b2Body.h:674-688
+	void SetLinearDamping(float32 linearDamping);
+	void SetAngularDamping(float32 angularDamping);
+	void SetGravityScale(float32 scale);
+	void SetFixedRotation(bool flag);
+	void SetSleepingAllowed(bool flag);
+	/// b2Body.h:586-594: velocity of a point attached to the body
+	b2Vec2 GetLinearVelocityFromWorldPoint(const b2Vec2& worldPoint) const
+	{
+		return GetLinearVelocity() + b2Cross(GetAngularVelocity(), worldPoint - GetWorldCenter());
+	}
+	b2Vec2 GetLinearVelocityFromLocalPoint(const b2Vec2& localPoint) const { return GetLinearVelocityFromWorldPoint(GetWorldPoint(localPoint)); }
 
 	b2Vec2 GetWorldPoint(const b2Vec2& localPoint) const { return b2Mul(GetTransform(), localPoint); }
 	b2Vec2 GetWorldVector(const b2Vec2& localVector) const { return b2Mul(GetTransform().q, localVector); }

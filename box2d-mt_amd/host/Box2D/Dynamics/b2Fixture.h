@@ -80,6 +80,13 @@ public:
 	float32 GetDensity() const { return m_density; }
 	float32 GetFriction() const { return m_friction; }
 	float32 GetRestitution() const { return m_restitution; }
+	/// b2Fixture.h:306-334: the density takes effect at the next b2Body::ResetMassData, friction and restitution in contacts
+	/// created from now on (existing contacts keep their mixture)
+	void SetDensity(float32 density);
+	void SetFriction(float32 friction);
+	void SetRestitution(float32 restitution);
+	/// b2Fixture.h:296-299
+	bool RayCast(b2RayCastOutput* output, const b2RayCastInput& input, int32 childIndex) const;
 	/// Fat AABB of the fixture's proxy as the device broad-phase holds it.
 	const b2AABB& GetAABB(int32 childIndex) const;
 	/// Device id (index into the proxy arrays in HBM).

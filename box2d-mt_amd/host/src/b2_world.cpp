@@ -1389,6 +1389,29 @@ void b2Fixture::SetSensor(bool sensor)
 	m_body->m_world->TouchState(m_body->m_id); // (SetSensor wakes its body)
 }
 
+void b2Fixture::SetDensity(float32 density)
+{
+	m_density = density;
+	for (int32 child = 0; child < m_childCount; ++child) b2hip_fixture_set_material(m_body->GetWorld()->GetDeviceWorld(), m_id + child, m_density, m_friction, m_restitution);
+}
+
+void b2Fixture::SetFriction(float32 friction)
+{
+	m_friction = friction;
+	for (int32 child = 0; child < m_childCount; ++child) b2hip_fixture_set_material(m_body->GetWorld()->GetDeviceWorld(), m_id + child, m_density, m_friction, m_restitution);
+}
+
+void b2Fixture::SetRestitution(float32 restitution)
+{
+	m_restitution = restitution;
+	for (int32 child = 0; child < m_childCount; ++child) b2hip_fixture_set_material(m_body->GetWorld()->GetDeviceWorld(), m_id + child, m_density, m_friction, m_restitution);
+}
+
+bool b2Fixture::RayCast(b2RayCastOutput* output, const b2RayCastInput& input, int32 childIndex) const
+{
+	return m_shape->RayCast(output, input, m_body->GetTransform(), childIndex);
+}
+
 void b2Fixture::SetThickShape(bool flag)
 {
 	if (flag == m_isThickShape) return;
@@ -1417,6 +1440,58 @@ void b2Body::GetMassData(b2MassData* data) const
 	data->mass = md.mass;
 	data->I = md.inertia;
 	data->center.Set(md.local_center[0], md.local_center[1]);
+}
+
+void b2Body::SetMassData(const b2MassData* data)
+{
+	if (m_world->IsLocked() || data == nullptr) return;
+	b2hip_mass_data md;
+	memset(&md, 0, sizeof(md));
+	md.mass = data->mass;
+	md.inertia = data->I;
+	md.local_center[0] = data->center.x;
+	md.local_center[1] = data->center.y;
+	b2hip_set_mass_data(m_world->m_hip, m_id, &md);
+	m_world->TouchState(m_id);
+}
+
+void b2Body::ResetMassData()
+{
+	b2hip_set_mass_data(m_world->m_hip, m_id, nullptr);
+	m_world->TouchState(m_id);
+}
+
+void b2Body::SetLinearDamping(float32 linearDamping)
+{
+	m_linearDamping = linearDamping;
+	b2hip_set_body_damping(m_world->m_hip, m_id, m_linearDamping, m_angularDamping, m_gravityScale);
+}
+
+void b2Body::SetAngularDamping(float32 angularDamping)
+{
+	m_angularDamping = angularDamping;
+	b2hip_set_body_damping(m_world->m_hip, m_id, m_linearDamping, m_angularDamping, m_gravityScale);
+}
+
+void b2Body::SetGravityScale(float32 scale)
+{
+	m_gravityScale = scale;
+	b2hip_set_body_damping(m_world->m_hip, m_id, m_linearDamping, m_angularDamping, m_gravityScale);
+}
+
+void b2Body::SetFixedRotation(bool flag)
+{
+	if (m_fixedRotation == flag) return;
+	m_fixedRotation = flag;
+	b2hip_set_fixed_rotation(m_world->m_hip, m_id, flag ? 1 : 0);
+	m_world->TouchState(m_id);
+}
+
+void b2Body::SetSleepingAllowed(bool flag)
+{
+	m_allowSleep = flag;
+	b2hip_set_sleeping_allowed(m_world->m_hip, m_id, flag ? 1 : 0);
+	m_world->TouchState(m_id);
 }
 
 // ---- b2Fixture ------------------------------------------------------------------------------------

@@ -404,6 +404,14 @@ int b2hip_fixture_set_sensor(b2hip_world* w, int fixture, int is_sensor);
 int b2hip_fixture_set_thick(b2hip_world* w, int fixture, int thick_shape);
 int b2hip_fixture_set_filter(b2hip_world* w, int fixture, uint16_t category_bits, uint16_t mask_bits, int16_t group_index);
 int b2hip_fixture_refilter(b2hip_world* w, int fixture);
+/* b2Fixture::SetDensity / SetFriction / SetRestitution (b2Fixture.h:306-334): the density is read by the next ResetMassData
+ * (b2hip_set_mass_data(w, body, NULL)), friction and restitution by contacts created from now on. */
+int b2hip_fixture_set_material(b2hip_world* w, int fixture, float density, float friction, float restitution);
+/* b2Body::SetLinearDamping / SetAngularDamping / SetGravityScale (b2Body.h:620-648) */
+int b2hip_set_body_damping(b2hip_world* w, int body, float linear_damping, float angular_damping, float gravity_scale);
+/* b2Body::SetFixedRotation (b2Body.cpp:546-565) and b2Body::SetSleepingAllowed (b2Body.h:674-688) */
+int b2hip_set_fixed_rotation(b2hip_world* w, int body, int flag);
+int b2hip_set_sleeping_allowed(b2hip_world* w, int body, int flag);
 /* b2WheelJoint / b2DistanceJoint / b2WeldJoint / b2MouseJoint ::SetFrequency / SetSpringFrequencyHz + SetDampingRatio
  * (e.g. b2WheelJoint.h:125-131): plain member writes, nobody is woken */
 int b2hip_joint_set_spring(b2hip_world* w, int joint, float frequency_hz, float damping_ratio);
@@ -414,6 +422,9 @@ int b2hip_fixture_is_destroyed(const b2hip_world* w, int fixture);
 int b2hip_body_count(const b2hip_world* w);
 int b2hip_fixture_count(const b2hip_world* w);
 int b2hip_get_mass_data(const b2hip_world* w, int body, b2hip_mass_data* out);
+/* b2Body::SetMassData (b2Body.cpp:387-424: dynamic bodies only; `inertia` about the body origin); mass_data == NULL:
+ * b2Body::ResetMassData (b2Body.cpp:310-385: from the fixtures' shapes and densities). */
+int b2hip_set_mass_data(b2hip_world* w, int body, const b2hip_mass_data* mass_data);
 
 /* Force / impulse staging between steps (b2Body::ApplyForceToCenter, ApplyTorque, SetLinearVelocity ...). */
 int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque, int wake);

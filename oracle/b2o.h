@@ -148,6 +148,11 @@ void b2o_set_type(b2o_world* w, int body, int type);       /* b2Body::SetType (b
 void b2o_set_bullet(b2o_world* w, int body, int bullet);
 void b2o_apply_linear_impulse(b2o_world* w, int body, float ix, float iy, float px, float py, int to_center, int wake);
 void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake);
+void b2o_set_body_damping(b2o_world* w, int body, float linear_damping, float angular_damping, float gravity_scale);
+void b2o_set_fixed_rotation(b2o_world* w, int body, int flag);
+void b2o_set_sleeping_allowed(b2o_world* w, int body, int flag);
+void b2o_set_mass_data(b2o_world* w, int body, int set, float mass, float inertia, float cx, float cy);
+void b2o_fixture_set_material(b2o_world* w, int fixture, float density, float friction, float restitution);
 void b2o_fixture_set_sensor(b2o_world* w, int fixture, int is_sensor);
 void b2o_fixture_set_thick(b2o_world* w, int fixture, int thick);
 void b2o_fixture_refilter(b2o_world* w, int fixture);

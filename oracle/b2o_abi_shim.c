@@ -251,6 +251,16 @@ int b2hip_set_awake(b2hip_world* w, int body, int awake) { b2o_set_awake(w->o, b
 int b2hip_set_active(b2hip_world* w, int body, int active) { b2o_set_active(w->o, body, active); return 0; }
 int b2hip_set_type(b2hip_world* w, int body, int type) { b2o_set_type(w->o, body, type); return 0; }
 int b2hip_set_bullet(b2hip_world* w, int body, int bullet) { b2o_set_bullet(w->o, body, bullet); return 0; }
+int b2hip_set_body_damping(b2hip_world* w, int body, float l, float a, float g) { b2o_set_body_damping(w->o, body, l, a, g); return 0; }
+int b2hip_set_fixed_rotation(b2hip_world* w, int body, int flag) { b2o_set_fixed_rotation(w->o, body, flag); return 0; }
+int b2hip_set_sleeping_allowed(b2hip_world* w, int body, int flag) { b2o_set_sleeping_allowed(w->o, body, flag); return 0; }
+int b2hip_set_mass_data(b2hip_world* w, int body, const b2hip_mass_data* md)
+{
+	if (md) b2o_set_mass_data(w->o, body, 1, md->mass, md->inertia, md->local_center[0], md->local_center[1]);
+	else b2o_set_mass_data(w->o, body, 0, 0.0f, 0.0f, 0.0f, 0.0f);
+	return 0;
+}
+int b2hip_fixture_set_material(b2hip_world* w, int fixture, float d, float f, float r) { b2o_fixture_set_material(w->o, fixture, d, f, r); return 0; }
 int b2hip_apply_linear_impulse(b2hip_world* w, int body, float ix, float iy, float px, float py, int wake)
 {
 	b2o_apply_linear_impulse(w->o, body, ix, iy, px, py, 0, wake);

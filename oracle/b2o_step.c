@@ -3263,6 +3263,74 @@ void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake)
 }
 
 /* b2Fixture::SetSensor / SetThickShape / Refilter / SetFilterData (b2Fixture.cpp:180-257) */
+/* b2Body::SetLinearDamping / SetAngularDamping / SetGravityScale (b2Body.h:620-648) */
+void b2o_set_body_damping(b2o_world* w, int body, float linearDamping, float angularDamping, float gravityScale)
+{
+	body_t* b = &w->bodies[body];
+	b->linearDamping = linearDamping;
+	b->angularDamping = angularDamping;
+	b->gravityScale = gravityScale;
+}
+
+/* b2Body::SetFixedRotation (b2Body.cpp:546-565) */
+void b2o_set_fixed_rotation(b2o_world* w, int body, int flag)
+{
+	body_t* b = &w->bodies[body];
+	if (((b->flags & BF_FIXEDROT) != 0) == (flag != 0)) return;
+	if (flag) b->flags |= BF_FIXEDROT; else b->flags &= ~BF_FIXEDROT;
+	b->w = 0.0f;
+	reset_mass(w, b);
+}
+
+/* b2Body::SetSleepingAllowed (b2Body.h:674-688) */
+void b2o_set_sleeping_allowed(b2o_world* w, int body, int flag)
+{
+	body_t* b = &w->bodies[body];
+	if (flag) b->flags |= BF_AUTOSLEEP;
+	else
+	{
+		b->flags &= ~BF_AUTOSLEEP;
+		set_awake(b);
+	}
+}
+
+/* b2Body::SetMassData (b2Body.cpp:387-424); set == 0: b2Body::ResetMassData */
+void b2o_set_mass_data(b2o_world* w, int body, int set, float mass, float inertia, float cx, float cy)
+{
+	body_t* b = &w->bodies[body];
+	if (!set)
+	{
+		reset_mass(w, b);
+		return;
+	}
+	if (b->type != 2) return;
+	b->invMass = 0.0f;
+	b->I = 0.0f;
+	b->invI = 0.0f;
+	b->mass = mass;
+	if (b->mass <= 0.0f) b->mass = 1.0f;
+	b->invMass = 1.0f / b->mass;
+	vec2 center = v_make(cx, cy);
+	if (inertia > 0.0f && (b->flags & BF_FIXEDROT) == 0)
+	{
+		b->I = inertia - b->mass * v_dot(center, center);
+		b->invI = 1.0f / b->I;
+	}
+	vec2 oldCenter = b->c;
+	b->localCenter = center;
+	b->c0 = b->c = xf_mul(b->xf, center);
+	b->v = v_add(b->v, v_cross_sv(b->w, v_sub(b->c, oldCenter)));
+}
+
+/* b2Fixture::SetDensity / SetFriction / SetRestitution (b2Fixture.h:306-334) */
+void b2o_fixture_set_material(b2o_world* w, int fixture, float density, float friction, float restitution)
+{
+	fixture_t* f = &w->fixtures[fixture];
+	f->density = density;
+	f->friction = friction;
+	f->restitution = restitution;
+}
+
 void b2o_fixture_set_sensor(b2o_world* w, int fixture, int isSensor)
 {
 	fixture_t* f = &w->fixtures[fixture];

@@ -17,7 +17,7 @@ ORACLE_LIB = os.path.join(ROOT, "oracle", "libb2oracle_harness.so")
 VALIDATION_LIB = os.path.join(ROOT, "box2d-mt_amd", "validation", "libb2amd_harness_validation.so")
 VALIDATION_CAPI = os.path.join(ROOT, "box2d-mt_amd", "validation", "libb2hip_validation.so")
 
-HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS, SENSORS, ROPES, MACHINES, VEHICLES, LIFECYCLE, CHAINS = range(14)
+HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS, SENSORS, ROPES, MACHINES, VEHICLES, LIFECYCLE, CHAINS, PROPS = range(15)
 F_CONTINUOUS, F_SLEEP, F_WARM, F_SUBSTEP = 1, 2, 4, 8
 DEFAULT_FLAGS = F_SLEEP | F_WARM  # CCD off unless a test asks for it
 

@@ -95,3 +95,50 @@ def test_device_life_cycle_matches_the_oracle(amd, oracle, monkeypatch, count, s
     compare(a, b, STEPS, "device (%s) vs oracle" % mode)  # (device and oracle share the bridge's definition: callbacks compared with CCD on as well)
     a.close()
     b.close()
+
+
+# ---- the property setters (b2Body.h:620-688, b2Body.cpp:310-424, 546-565; b2Fixture.h:306-334) ---------------------------------
+# box2d-mt_amd/harness/scenes.h: PropsEdits - on the rain scene, between steps: SetLinearDamping / SetAngularDamping,
+# SetGravityScale, SetFixedRotation on and off, b2Fixture::SetDensity + ResetMassData, SetMassData, SetSleepingAllowed off and
+# on, b2Fixture::SetFriction / SetRestitution (bodies and ground: contacts made afterwards), GetLinearVelocityFromLocalPoint
+# feeding an impulse.
+PROPS_CASES = [(120, 4, bh.DEFAULT_FLAGS), (60, 9, bh.DEFAULT_FLAGS | bh.F_CONTINUOUS)]
+
+
+def compare_props(a, b, steps, what):
+    for s in range(steps):
+        a.step(1)
+        b.step(1)
+        A, B = a.bodies(), b.bodies()
+        assert a.contact_count == b.contact_count, "%s: contact count at step %d" % (what, s)
+        assert np.array_equal(A.view(np.uint32), B.view(np.uint32)), "%s: body states differ at step %d (bodies %s)" % (
+            what, s, np.nonzero((A.view(np.uint32) != B.view(np.uint32)).any(axis=1))[0][:8])
+        if s % 20 == 19:
+            ia, fa, ma = a.contacts()
+            ib, fb, mb = b.contacts()
+            assert np.array_equal(ia, ib) and np.array_equal(fa, fb), "%s: contact set at step %d" % (what, s)
+            assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)), "%s: manifolds at step %d" % (what, s)
+    return a.bodies()
+
+
+@pytest.mark.parametrize("count,seed,flags", PROPS_CASES)
+def test_oracle_property_setters_match_the_reference(ref, oracle, count, seed, flags):
+    a = ref.world(bh.PROPS, count, 0, seed=seed, flags=flags)
+    b = oracle.world(bh.PROPS, count, 0, seed=seed, flags=flags)
+    edited = compare_props(a, b, 200, "reference vs oracle")
+    plain = ref.world(bh.RAIN, count, 0, seed=seed, flags=flags)
+    plain.step(200)
+    assert not np.array_equal(edited, plain.bodies()), "the edits changed nothing: test is vacuous"
+    for w in (a, b, plain):
+        w.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count,seed,flags", PROPS_CASES)
+def test_device_property_setters_match_the_oracle(amd, oracle, monkeypatch, count, seed, flags):
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")  # (the heap on the ground may exceed the in-LDS solver: reference order everywhere)
+    a = amd.world(bh.PROPS, count, 0, seed=seed, flags=flags)
+    b = oracle.world(bh.PROPS, count, 0, seed=seed, flags=flags)
+    compare_props(a, b, 200, "device vs oracle")
+    a.close()
+    b.close()
