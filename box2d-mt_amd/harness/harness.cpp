@@ -898,5 +898,21 @@ int b2h_joint_reactions(b2h_world* h, float inv_dt, int cap, float* out)
 	return (int)joints.size();
 }
 
+// b2Joint::GetAnchorA / GetAnchorB of every joint, in creation order: rows of 4 floats; returns the joint count
+int b2h_joint_anchors(b2h_world* h, int cap, float* out)
+{
+	std::vector<b2Joint*> joints;
+	for (b2Joint* j = h->world->GetJointList(); j; j = j->GetNext()) joints.push_back(j);
+	std::reverse(joints.begin(), joints.end());
+	for (size_t i = 0; i < joints.size() && (int)i < cap; ++i)
+	{
+		const b2Vec2 a = joints[i]->GetAnchorA(), b = joints[i]->GetAnchorB();
+		out[4 * i] = a.x;
+		out[4 * i + 1] = a.y;
+		out[4 * i + 2] = b.x;
+		out[4 * i + 3] = b.y;
+	}
+	return (int)joints.size();
+}
 
 } // extern "C"

@@ -70,12 +70,21 @@ public:
 	b2Vec2 GetReactionForce(float32 inv_dt) const;
 	float32 GetReactionTorque(float32 inv_dt) const;
 	bool IsActive() const;
+	/// The anchor points in world coordinates (pure virtual in the reference, one pair per joint type: the bodies' local
+	/// anchors; the mouse joint's target and its hold on bodyB, b2MouseJoint.cpp:200-208; the body origins for the motor
+	/// joint, b2MotorJoint.cpp:212-220; the second anchors of its two joints for the gear, b2GearJoint.cpp:371-379).
+	b2Vec2 GetAnchorA() const;
+	b2Vec2 GetAnchorB() const;
 
 protected:
 	friend class b2World;
 	float32 MotorReaction(float32 inv_dt) const; // the motor's share (GetMotorTorque / GetMotorForce of the types that have one)
 	b2Joint(const b2JointDef* def) : m_type(def->type), m_prev(nullptr), m_next(nullptr), m_bodyA(def->bodyA),
-		m_bodyB(def->bodyB), m_collideConnected(def->collideConnected), m_userData(def->userData), m_id(-1) {}
+		m_bodyB(def->bodyB), m_collideConnected(def->collideConnected), m_userData(def->userData), m_id(-1), m_anchorKind(0)
+	{
+		m_anchorA.SetZero();
+		m_anchorB.SetZero();
+	}
 
 	b2JointType m_type;
 	b2Joint* m_prev;
@@ -85,6 +94,9 @@ protected:
 	bool m_collideConnected;
 	void* m_userData;
 	int32 m_id;
+	// GetAnchorA / B: local anchors on the two bodies (kind 0), the mouse joint (1: A is the target), body origins (2)
+	b2Vec2 m_anchorA, m_anchorB;
+	int32 m_anchorKind;
 };
 
 #endif

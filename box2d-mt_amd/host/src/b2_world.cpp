@@ -451,12 +451,46 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 		return nullptr;
 	}
 	j->m_id = id;
+	switch (def->type)
+	{
+	case e_revoluteJoint: j->m_anchorA = static_cast<const b2RevoluteJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2RevoluteJointDef*>(def)->localAnchorB; break;
+	case e_prismaticJoint: j->m_anchorA = static_cast<const b2PrismaticJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2PrismaticJointDef*>(def)->localAnchorB; break;
+	case e_distanceJoint: j->m_anchorA = static_cast<const b2DistanceJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2DistanceJointDef*>(def)->localAnchorB; break;
+	case e_pulleyJoint: j->m_anchorA = static_cast<const b2PulleyJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2PulleyJointDef*>(def)->localAnchorB; break;
+	case e_wheelJoint: j->m_anchorA = static_cast<const b2WheelJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2WheelJointDef*>(def)->localAnchorB; break;
+	case e_weldJoint: j->m_anchorA = static_cast<const b2WeldJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2WeldJointDef*>(def)->localAnchorB; break;
+	case e_frictionJoint: j->m_anchorA = static_cast<const b2FrictionJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2FrictionJointDef*>(def)->localAnchorB; break;
+	case e_ropeJoint: j->m_anchorA = static_cast<const b2RopeJointDef*>(def)->localAnchorA; j->m_anchorB = static_cast<const b2RopeJointDef*>(def)->localAnchorB; break;
+	case e_mouseJoint:
+		j->m_anchorKind = 1;
+		j->m_anchorB = b2MulT(def->bodyB->GetTransform(), static_cast<const b2MouseJointDef*>(def)->target); // (b2MouseJoint.cpp:40)
+		break;
+	case e_motorJoint: j->m_anchorKind = 2; break;
+	case e_gearJoint:
+		j->m_anchorA = static_cast<const b2GearJointDef*>(def)->joint1->m_anchorB; // (b2GearJoint.cpp:67,76 and :99,108)
+		j->m_anchorB = static_cast<const b2GearJointDef*>(def)->joint2->m_anchorB;
+		break;
+	default: break;
+	}
 	j->m_prev = nullptr;
 	j->m_next = m_jointList;
 	if (m_jointList) m_jointList->m_prev = j;
 	m_jointList = j;
 	++m_jointCount;
 	return j;
+}
+
+b2Vec2 b2Joint::GetAnchorA() const
+{
+	if (m_anchorKind == 1) return static_cast<const b2MouseJoint*>(this)->GetTarget();
+	if (m_anchorKind == 2) return m_bodyA->GetPosition();
+	return m_bodyA->GetWorldPoint(m_anchorA);
+}
+
+b2Vec2 b2Joint::GetAnchorB() const
+{
+	if (m_anchorKind == 2) return m_bodyB->GetPosition();
+	return m_bodyB->GetWorldPoint(m_anchorB);
 }
 
 void b2World::DestroyJoint(b2Joint* j)

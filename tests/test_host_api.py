@@ -186,3 +186,24 @@ def test_joint_reaction_forces_match_the_reference_build(oracle, ref, scene, p0,
     assert busy > 0
     a.close()
     r.close()
+
+
+@pytest.mark.parametrize("scene,p0,p1,seed", [(bh.MACHINES, 40, 4, 3), (bh.VEHICLES, 40, 3, 3), (bh.ROPES, 30, 8, 9), (bh.LIFECYCLE, 36, 0, 2)])
+def test_joint_anchors_match_the_reference_build(oracle, ref, scene, p0, p1, seed):
+    """b2Joint::GetAnchorA / GetAnchorB (pure virtual in the reference, one pair per joint type - the mouse joint's target, the
+    motor joint's body origins and the gear joint's borrowed anchors among them) of every joint every tenth step, bitwise."""
+    for h in (oracle, ref):
+        h.lib.b2h_joint_anchors.argtypes = [C.c_void_p, C.c_int, _fp]
+    a, r = oracle.world(scene, p0, p1, seed=seed), ref.world(scene, p0, p1, seed=seed)
+    oa, orr = np.zeros((256, 4), np.float32), np.zeros((256, 4), np.float32)
+    for s in range(100):
+        a.step(1)
+        r.step(1)
+        if s % 10 != 9:
+            continue
+        na = a.L.b2h_joint_anchors(a.ptr, 256, fptr(oa))
+        nr = r.L.b2h_joint_anchors(r.ptr, 256, fptr(orr))
+        assert na == nr and na > 0
+        assert np.array_equal(oa[:na].view(np.uint32), orr[:nr].view(np.uint32)), "step %d: joint %s" % (s, np.nonzero((oa[:na] != orr[:nr]).any(axis=1))[0][:5])
+    a.close()
+    r.close()
