@@ -915,4 +915,29 @@ int b2h_joint_anchors(b2h_world* h, int cap, float* out)
 	return (int)joints.size();
 }
 
+// b2Body::GetJointList of every body: per body the number of joints and, in list order, the index of the body on the other
+// side of each (up to 4 per body; -1 pads): rows of 5 ints; returns the body count
+int b2h_body_joint_lists(b2h_world* h, int cap, int* out)
+{
+	const int n = (int)h->scene.bodies.size();
+	for (int i = 0; i < n && i < cap; ++i)
+	{
+		int* row = out + 5 * i;
+		row[0] = 0;
+		for (int k = 1; k < 5; ++k) row[k] = -1;
+		b2Body* b = h->scene.bodies[(size_t)i];
+		if (b == NULL) continue;
+		for (b2JointEdge* e = b->GetJointList(); e; e = e->next)
+		{
+			if (row[0] < 4)
+			{
+				std::map<const b2Body*, int>::const_iterator it = h->bodyIndex.find(e->other);
+				row[1 + row[0]] = it != h->bodyIndex.end() ? it->second : -2;
+			}
+			row[0] += 1;
+		}
+	}
+	return n;
+}
+
 } // extern "C"

@@ -97,6 +97,8 @@ protected:
 	// GetAnchorA / B: local anchors on the two bodies (kind 0), the mouse joint (1: A is the target), body origins (2)
 	b2Vec2 m_anchorA, m_anchorB;
 	int32 m_anchorKind;
+	// nodes of the two bodies' joint lists (b2Body::GetJointList, b2Joint.h:73-79, b2World.cpp:258-270)
+	b2JointEdge m_edgeA, m_edgeB;
 };
 
 #endif

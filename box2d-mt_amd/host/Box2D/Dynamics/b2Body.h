@@ -14,6 +14,7 @@ class b2World;
 struct b2FixtureDef;
 struct b2JointEdge;
 struct b2ContactEdge;
+struct b2JointEdge;
 
 enum b2BodyType
 {
@@ -91,6 +92,9 @@ public:
 	/// The body's contact edges, newest contact first (b2Body.h:431-436); valid until the next Step or edit.
 	b2ContactEdge* GetContactList();
 	const b2ContactEdge* GetContactList() const { return const_cast<b2Body*>(this)->GetContactList(); }
+	/// The joints attached to this body, newest first (b2Body.h:426-429)
+	b2JointEdge* GetJointList() { return m_jointList; }
+	const b2JointEdge* GetJointList() const { return m_jointList; }
 	float32 GetMass() const;
 	float32 GetInertia() const;
 	void GetMassData(b2MassData* data) const;
@@ -154,6 +158,7 @@ private:
 	b2Body* m_prev;
 	b2Body* m_next;
 	b2Fixture* m_fixtureList;
+	b2JointEdge* m_jointList;
 	int32 m_fixtureCount;
 	void* m_userData;
 	// caches for the reference-returning getters (filled from the world's host mirror)

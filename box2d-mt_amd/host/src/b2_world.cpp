@@ -472,6 +472,19 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 		break;
 	default: break;
 	}
+	// the bodies' joint lists (b2World.cpp:258-270); a gear's bodies are the second bodies of its two joints
+	j->m_edgeA.joint = j;
+	j->m_edgeA.other = j->m_bodyB;
+	j->m_edgeA.prev = nullptr;
+	j->m_edgeA.next = j->m_bodyA->m_jointList;
+	if (j->m_bodyA->m_jointList) j->m_bodyA->m_jointList->prev = &j->m_edgeA;
+	j->m_bodyA->m_jointList = &j->m_edgeA;
+	j->m_edgeB.joint = j;
+	j->m_edgeB.other = j->m_bodyA;
+	j->m_edgeB.prev = nullptr;
+	j->m_edgeB.next = j->m_bodyB->m_jointList;
+	if (j->m_bodyB->m_jointList) j->m_bodyB->m_jointList->prev = &j->m_edgeB;
+	j->m_bodyB->m_jointList = &j->m_edgeB;
 	j->m_prev = nullptr;
 	j->m_next = m_jointList;
 	if (m_jointList) m_jointList->m_prev = j;
@@ -504,6 +517,13 @@ void b2World::DestroyJoint(b2Joint* j)
 	if (j->m_prev) j->m_prev->m_next = j->m_next;
 	if (j->m_next) j->m_next->m_prev = j->m_prev;
 	if (j == m_jointList) m_jointList = j->m_next;
+	// (b2World.cpp:304-333)
+	if (j->m_edgeA.prev) j->m_edgeA.prev->next = j->m_edgeA.next;
+	if (j->m_edgeA.next) j->m_edgeA.next->prev = j->m_edgeA.prev;
+	if (&j->m_edgeA == j->m_bodyA->m_jointList) j->m_bodyA->m_jointList = j->m_edgeA.next;
+	if (j->m_edgeB.prev) j->m_edgeB.prev->next = j->m_edgeB.next;
+	if (j->m_edgeB.next) j->m_edgeB.next->prev = j->m_edgeB.prev;
+	if (&j->m_edgeB == j->m_bodyB->m_jointList) j->m_bodyB->m_jointList = j->m_edgeB.next;
 	--m_jointCount;
 	j->~b2Joint();
 	b2Free(j);
@@ -1132,6 +1152,7 @@ b2Body::b2Body(const b2BodyDef* bd, b2World* world, int32 id)
 	m_prev = nullptr;
 	m_next = nullptr;
 	m_fixtureList = nullptr;
+	m_jointList = nullptr;
 	m_fixtureCount = 0;
 	m_userData = bd->userData;
 }

@@ -207,3 +207,26 @@ def test_joint_anchors_match_the_reference_build(oracle, ref, scene, p0, p1, see
         assert np.array_equal(oa[:na].view(np.uint32), orr[:nr].view(np.uint32)), "step %d: joint %s" % (s, np.nonzero((oa[:na] != orr[:nr]).any(axis=1))[0][:5])
     a.close()
     r.close()
+
+
+@pytest.mark.parametrize("scene,p0,p1,seed", [(bh.MACHINES, 40, 4, 3), (bh.VEHICLES, 40, 3, 3), (bh.ROPES, 30, 8, 9), (bh.LIFECYCLE, 36, 0, 2)])
+def test_body_joint_lists_match_the_reference_build(oracle, ref, scene, p0, p1, seed):
+    """b2Body::GetJointList (b2Body.h:426-429): every body's joint edges, newest first, with the body on the other side - after
+    the scene is built and again after joints and bodies have been destroyed (the life-cycle scene destroys bodies with joints
+    on them, the vehicles scene lets its mouse joint go)."""
+    ip = C.POINTER(C.c_int)
+    for h in (oracle, ref):
+        h.lib.b2h_body_joint_lists.argtypes = [C.c_void_p, C.c_int, ip]
+    a, r = oracle.world(scene, p0, p1, seed=seed), ref.world(scene, p0, p1, seed=seed)
+    oa, orr = np.zeros((512, 5), np.int32), np.zeros((512, 5), np.int32)
+    for s in range(200):
+        if s % 50 == 0:
+            na = a.L.b2h_body_joint_lists(a.ptr, 512, oa.ctypes.data_as(ip))
+            nr = r.L.b2h_body_joint_lists(r.ptr, 512, orr.ctypes.data_as(ip))
+            assert na == nr and na > 0
+            assert np.array_equal(oa[:na], orr[:nr]), "step %d: body %s" % (s, np.nonzero((oa[:na] != orr[:nr]).any(axis=1))[0][:5])
+            assert oa[:na, 0].sum() > 0
+        a.step(1)
+        r.step(1)
+    a.close()
+    r.close()
