@@ -202,4 +202,34 @@ __global__ void k_edit_finish(DW W)
 	W.st->c.nDestroy = 0;
 }
 
+// b2World::ShiftOrigin (b2World.cpp:1862-1887): every body's transform and sweep, every proxy's fat AABB
+// (b2DynamicTree::ShiftOrigin, b2DynamicTree.cpp:768-776) and the world-space anchors joints keep (b2MouseJoint::ShiftOrigin,
+// b2PulleyJoint::ShiftOrigin) move by -newOrigin; plain float subtractions, the same bits as the reference's.
+__global__ __launch_bounds__(256) void k_shift_origin(DW W, float ox, float oy)
+{
+	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	for (int i = t0; i < W.nBodies; i += stride)
+	{
+		float4 xf = W.b_xf[i], p = W.b_pos[i], p0 = W.b_pos0[i];
+		xf.x -= ox; xf.y -= oy;
+		p.x -= ox; p.y -= oy;
+		p0.x -= ox; p0.y -= oy;
+		W.b_xf[i] = xf;
+		W.b_pos[i] = p;
+		W.b_pos0[i] = p0;
+	}
+	for (int q = t0; q < W.nProxies; q += stride)
+	{
+		float4 f = W.p_fat[q];
+		f.x -= ox; f.y -= oy; f.z -= ox; f.w -= oy;
+		W.p_fat[q] = f;
+	}
+	for (int j = t0; j < W.nJoints; j += stride)
+	{
+		JointRec& jn = W.joints[j];
+		if (jn.type == B2D_JOINT_MOUSE) { jn.targetA.x -= ox; jn.targetA.y -= oy; }
+		else if (jn.type == B2D_JOINT_PULLEY) { jn.groundAnchorA.x -= ox; jn.groundAnchorA.y -= oy; jn.s1 -= ox; jn.s2 -= oy; }
+	}
+}
+
 #endif

@@ -3710,6 +3710,38 @@ int b2hip_set_mass_data(b2hip_world* w, int body, const b2hip_mass_data* md)
 	return B2HIP_OK;
 }
 
+// b2World::ShiftOrigin (b2World.cpp:1862-1887)
+int b2hip_shift_origin(b2hip_world* w, float x, float y)
+{
+	if (int rcu = checkUsable(w, "b2hip_shift_origin", true)) return rcu;
+	if (w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_shift_origin inside a step");
+	DEVICE_GUARD(w);
+	// every edit made so far goes to the device first: from here on the device state is the one that is shifted
+	int rc = flushEdits(w);
+	if (rc) return rc;
+	rc = applyEditOps(w, true);
+	if (rc) return rc;
+	const int n = std::max(std::max(w->dw.nBodies, w->dw.nProxies), std::max(w->dw.nJoints, 1));
+	LAUNCH(w, k_shift_origin, gridFor(n), 256, w->dw, x, y);
+	// the host's copies: joint records (uploaded again when a setter edits them), fat AABBs, and the body rows - read back
+	for (size_t j = 0; j < w->joints.size(); ++j)
+	{
+		JointRec& jn = w->joints[j];
+		if (jn.type == B2D_JOINT_MOUSE) { jn.targetA.x -= x; jn.targetA.y -= y; }
+		else if (jn.type == B2D_JOINT_PULLEY) { jn.groundAnchorA.x -= x; jn.groundAnchorA.y -= y; jn.s1 -= x; jn.s2 -= y; }
+	}
+	for (size_t f = 0; f < w->fixtures.size(); ++f)
+	{
+		w->fixtures[f].fat[0] -= x; w->fixtures[f].fat[1] -= y;
+		w->fixtures[f].fat[2] -= x; w->fixtures[f].fat[3] -= y;
+	}
+	rc = downloadState(w, 0);
+	if (rc) return rc;
+	w->stateCount = w->bodies.size();
+	++w->mirrorEpoch;
+	return B2HIP_OK;
+}
+
 int b2hip_joint_set_spring(b2hip_world* w, int joint, float frequency_hz, float damping_ratio)
 {
 	if (int rcu = checkUsable(w, "b2hip_joint_set_spring", true)) return rcu;

@@ -90,7 +90,7 @@ enum SceneId
 	e_props = 14,        // p0 = falling bodies (the rain scene) ; a scripted tour of the body / fixture PROPERTY setters between steps:
 	                     //   SetLinearDamping, SetAngularDamping, SetGravityScale, SetFixedRotation, SetSleepingAllowed, SetMassData,
 	                     //   ResetMassData after b2Fixture::SetDensity, b2Fixture::SetFriction / SetRestitution, and
-	                     //   GetLinearVelocityFromLocalPoint feeding an impulse; see PropsEdits
+	                     //   GetLinearVelocityFromLocalPoint feeding an impulse, b2World::ShiftOrigin twice; see PropsEdits
 	e_bullets = 7        // p0 = projectiles (every other one flagged bullet), p1 = stack height ; continuous-collision stress:
 	                     //   thin static walls + edge ground + box stacks hit by fast small bodies
 };
@@ -1281,7 +1281,6 @@ inline void BuildLifecycle(Scene& s, b2World* w, int count, uint32_t seed)
 // on the bodies of the rain scene, by body index so that every backend edits the same bodies.
 inline void PropsEdits(Scene& s, b2World* w)
 {
-	(void)w;
 	const int step = s.propsStep++;
 	const int count = (int)s.bodies.size();
 	for (int i = 1; i < count; ++i)
@@ -1320,6 +1319,9 @@ inline void PropsEdits(Scene& s, b2World* w)
 			b->ApplyLinearImpulseToCenter(-0.1f * b->GetMass() * v, true);
 		}
 	}
+	// b2World::ShiftOrigin (b2World.cpp:1862-1887): bodies and broad-phase boxes move, nothing else changes
+	if (step == 100) w->ShiftOrigin(b2Vec2(3.5f, -1.25f));
+	if (step == 150) w->ShiftOrigin(b2Vec2(-40.0f, 17.0f));
 	if (step == 80)
 	{
 		// the ground's material, for the contacts made from now on

@@ -103,6 +103,22 @@ public:
 	void SetAutoClearForces(bool flag) { m_autoClearForces = flag; }
 	bool GetAutoClearForces() const { return m_autoClearForces; }
 	const b2Profile& GetProfile() const { return m_profile; }
+	/// b2World.cpp:1862-1887: the origin moves to `newOrigin` (a no-op while the world is locked)
+	void ShiftOrigin(const b2Vec2& newOrigin);
+	/// b2World.h:244, 445-448: the time the caller spent waiting for its own locks, reported with the profile
+	void SetLockingTime(float32 ms) { m_profile.locking = ms; }
+	/// b2World.h:220: true while the step runs the listener's *Immediate callbacks and the contact filter on the executor's threads
+	bool IsMtLocked() const { return m_mtLocked; }
+	/// Cost estimates with which the reference sizes its solve tasks (b2World.h:158-168; defaults b2World.cpp:466-469). The
+	/// device sizes its launches from the island census instead: the values are kept for the caller and change nothing.
+	uint32 GetBodyCostScale() const { return m_bodyCost; }
+	uint32 GetContactCostScale() const { return m_contactCost; }
+	uint32 GetJointCostScale() const { return m_jointCost; }
+	void SetBodyCostScale(uint32 bodyCost) { m_bodyCost = bodyCost; }
+	void SetContactCostScale(uint32 contactCost) { m_contactCost = contactCost; }
+	void SetJointCostScale(uint32 jointCost) { m_jointCost = jointCost; }
+	void SetSolveTaskCostThreshold(uint32 cost) { m_solveTaskCostThreshold = cost; }
+	uint32 GetSolveTaskCostThreshold() const { return m_solveTaskCostThreshold; }
 
 	/// The C-ABI world this object wraps (include/b2hip.h).
 	b2hip_world* GetDeviceWorld() { return m_hip; }
@@ -138,6 +154,8 @@ private:
 	b2hip_world* m_hip;
 	b2Vec2 m_gravity;
 	bool m_allowSleep, m_warmStarting, m_continuousPhysics, m_subStepping, m_autoClearForces, m_locked;
+	bool m_mtLocked = false;
+	uint32 m_bodyCost = 1, m_contactCost = 10, m_jointCost = 10, m_solveTaskCostThreshold = 100;
 	b2Body* m_bodyList;
 	b2Joint* m_jointList;
 	int32 m_bodyCount, m_jointCount;

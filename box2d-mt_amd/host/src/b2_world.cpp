@@ -493,6 +493,28 @@ b2Joint* b2World::CreateJoint(const b2JointDef* def)
 	return j;
 }
 
+void b2World::ShiftOrigin(const b2Vec2& newOrigin)
+{
+	if (IsLocked() || !m_hip) return;
+	if (b2hip_shift_origin(m_hip, newOrigin.x, newOrigin.y) != B2HIP_OK)
+	{
+		fprintf(stderr, "b2World::ShiftOrigin: %s\n", b2hip_last_error());
+		return;
+	}
+	for (b2Joint* j = m_jointList; j; j = j->m_next)
+	{
+		if (j->m_type == e_mouseJoint) static_cast<b2MouseJoint*>(j)->m_targetA -= newOrigin;
+		else if (j->m_type == e_pulleyJoint)
+		{
+			static_cast<b2PulleyJoint*>(j)->m_groundAnchorA -= newOrigin;
+			static_cast<b2PulleyJoint*>(j)->m_groundAnchorB -= newOrigin;
+		}
+	}
+	m_statesValid = false;
+	m_contactsValid = false;
+	m_fatValid = false;
+}
+
 b2Vec2 b2Joint::GetAnchorA() const
 {
 	if (m_anchorKind == 1) return static_cast<const b2MouseJoint*>(this)->GetTarget();
@@ -614,9 +636,11 @@ struct CallbackRange : public b2RangeTask
 void b2World::RunOnExecutor(uint32 count, void (*fn)(void* ctx, uint32 index, uint32 threadId), void* ctx)
 {
 	if (count == 0) return;
+	m_mtLocked = true; // (b2World::SetMtLock around the reference's collide / solve tasks)
 	if (m_stepExecutor == nullptr || m_stepExecutor->GetThreadCount() < 2 || count < 2)
 	{
 		for (uint32 i = 0; i < count; ++i) fn(ctx, i, 0);
+		m_mtLocked = false;
 		return;
 	}
 	CallbackRange task;
@@ -624,6 +648,7 @@ void b2World::RunOnExecutor(uint32 count, void (*fn)(void* ctx, uint32 index, ui
 	task.ctx = ctx;
 	task.SetRange(b2RangeTaskRange(0, count));
 	b2ExecuteRangeTask(*m_stepExecutor, task);
+	m_mtLocked = false;
 }
 
 // b2ContactFilter::ShouldCollide(fixtureA, fixtureB, threadId) for every pair of one decision point, from the worker threads

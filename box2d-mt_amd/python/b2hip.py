@@ -138,6 +138,9 @@ def _configure(L, optional_ok=False):
         "b2hip_world_create": [C.POINTER(WorldDef), C.POINTER(C.c_void_p)],
         "b2hip_world_destroy": [C.c_void_p],
         "b2hip_set_gravity": [C.c_void_p, C.c_float, C.c_float],
+        "b2hip_shift_origin": [C.c_void_p, C.c_float, C.c_float],
+        "b2hip_set_body_damping": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
+        "b2hip_fixture_set_material": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float],
         "b2hip_set_flags": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
         "b2hip_create_body": [C.c_void_p, C.POINTER(BodyDef)],
         "b2hip_create_fixture": [C.c_void_p, C.c_int, C.POINTER(FixtureDef), C.POINTER(Shape)],
@@ -409,6 +412,9 @@ class World:
 
     def destroy_fixture(self, fixture):
         _check(self.L.b2hip_destroy_fixture(self.p, fixture))
+
+    def shift_origin(self, x, y):
+        _check(self.L.b2hip_shift_origin(self.p, x, y))
 
     def set_bullet(self, body, flag=True):
         _check(self.L.b2hip_set_bullet(self.p, body, int(flag)))

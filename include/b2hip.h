@@ -330,6 +330,9 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out);
 void b2hip_world_destroy(b2hip_world* w);
 
 int b2hip_set_gravity(b2hip_world* w, float gx, float gy);
+/* b2World::ShiftOrigin (b2World.cpp:1862-1887): bodies, broad-phase boxes and the world-space anchors of mouse and pulley
+ * joints move by -(x, y); between steps only. */
+int b2hip_shift_origin(b2hip_world* w, float x, float y);
 int b2hip_set_flags(b2hip_world* w, int allow_sleep, int warm_starting, int continuous, int sub_stepping);
 
 /* Returns the new body / fixture / joint id (>= 0) or a negative status. */

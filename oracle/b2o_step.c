@@ -3263,6 +3263,34 @@ void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake)
 }
 
 /* b2Fixture::SetSensor / SetThickShape / Refilter / SetFilterData (b2Fixture.cpp:180-257) */
+/* b2World::ShiftOrigin (b2World.cpp:1862-1887; b2DynamicTree.cpp:768-776; b2MouseJoint / b2PulleyJoint::ShiftOrigin) */
+void b2o_shift_origin(b2o_world* w, float x, float y)
+{
+	vec2 o = v_make(x, y);
+	for (int i = 0; i < w->nBodies; ++i)
+	{
+		body_t* b = &w->bodies[i];
+		b->xf.p = v_sub(b->xf.p, o);
+		b->c0 = v_sub(b->c0, o);
+		b->c = v_sub(b->c, o);
+	}
+	for (int f = 0; f < w->nFixtures; ++f)
+	{
+		fixture_t* fx = &w->fixtures[f];
+		fx->fat[0] -= x; fx->fat[1] -= y; fx->fat[2] -= x; fx->fat[3] -= y;
+	}
+	for (int j = 0; j < w->nJoints; ++j)
+	{
+		revolute_t* jn = &w->joints[j];
+		if (jn->type == B2O_JOINT_MOUSE) jn->localAnchorA = v_sub(jn->localAnchorA, o);
+		else if (jn->type == B2O_JOINT_PULLEY)
+		{
+			jn->groundAnchorA = v_sub(jn->groundAnchorA, o);
+			jn->groundAnchorB = v_sub(jn->groundAnchorB, o);
+		}
+	}
+}
+
 /* b2Body::SetLinearDamping / SetAngularDamping / SetGravityScale (b2Body.h:620-648) */
 void b2o_set_body_damping(b2o_world* w, int body, float linearDamping, float angularDamping, float gravityScale)
 {

@@ -84,3 +84,50 @@ def test_device_refuses_a_toi_presolve_that_edits_the_world_and_changes_its_cont
     assert rc == 0 and calls > 0 and lowest > 0.1  # (an edit alone is fine)
     _, calls, rc = drop_on_platform(L, 0, edit=lambda w, box: w.set_bullet(box, True))
     assert rc != 0 and b"PreSolve" in L.b2hip_last_error()
+
+
+# ---- b2World::ShiftOrigin through the bare ABI: the world-space anchors joints keep (b2MouseJoint / b2PulleyJoint::ShiftOrigin) ----
+def shifted_joints(L, shift_at, steps=90):
+    w = b2hip.World(gravity=(0.0, -10.0), library=L)
+    ground = w.create_body(b2hip.STATIC, position=(0.0, 0.0))
+    w.create_fixture(ground, b2hip.box_shape(30.0, 0.5))
+    a = w.create_body(b2hip.DYNAMIC, position=(-3.0, 4.0))
+    w.create_fixture(a, b2hip.box_shape(0.5, 0.5), density=1.0)
+    b = w.create_body(b2hip.DYNAMIC, position=(3.0, 5.0))
+    w.create_fixture(b, b2hip.box_shape(0.5, 0.5), density=3.0)
+    w.create_pulley_joint(a, b, (-3.0, 9.0), (3.0, 9.0), anchor_a=(0.0, 0.5), anchor_b=(0.0, 0.5), length_a=4.5, length_b=3.5, ratio=1.5)
+    c = w.create_body(b2hip.DYNAMIC, position=(8.0, 3.0))
+    w.create_fixture(c, b2hip.circle_shape(0.4), density=1.0)
+    w.create_mouse_joint(ground, c, (8.0, 3.0), 500.0)
+    total = np.zeros(2, np.float32)
+    rows = []
+    for s in range(steps):
+        if s in shift_at:
+            o = np.float32(shift_at[s])
+            w.shift_origin(float(o[0]), float(o[1]))
+            total += o
+        w.step()
+        rows.append(w.bodies8().copy())
+    w.close()
+    return np.array(rows), total
+
+
+def check_shift(L):
+    plain, _ = shifted_joints(L, {})
+    moved, total = shifted_joints(L, {30: (10.0, -4.0), 60: (-2.5, 1.25)})
+    assert np.array_equal(plain[:30], moved[:30])
+    # velocities do not notice the shift (the joints' anchors moved with the bodies), positions differ by it to rounding
+    assert np.allclose(moved[-1, :, 3:6], plain[-1, :, 3:6], atol=2e-3), "the joints' world anchors did not move with the origin"
+    assert np.allclose(moved[-1, :, :2] + total, plain[-1, :, :2], atol=2e-3)
+    return moved
+
+
+def test_oracle_abi_shift_origin_moves_joint_anchors():
+    check_shift(b2hip.load(bh.ORACLE_LIB, optional_ok=True))
+
+
+@pytest.mark.gpu
+def test_device_abi_shift_origin_matches_the_oracle():
+    a = check_shift(b2hip.lib())
+    b = check_shift(b2hip.load(bh.ORACLE_LIB, optional_ok=True))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
