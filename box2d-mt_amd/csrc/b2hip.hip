@@ -3710,6 +3710,37 @@ int b2hip_set_mass_data(b2hip_world* w, int body, const b2hip_mass_data* md)
 	return B2HIP_OK;
 }
 
+// The scalar setters of the joint classes: plain assignments in the reference (b2DistanceJoint.h:117, b2RopeJoint.h:80,
+// b2FrictionJoint.cpp:206-228, b2MotorJoint.cpp:222-251, b2MouseJoint.cpp:48-76, b2GearJoint.cpp:402-406)
+int b2hip_joint_set_param(b2hip_world* w, int joint, int param, float value)
+{
+	if (int rcu = checkUsable(w, "b2hip_joint_set_param", true)) return rcu;
+	if (joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	JointRec& j = w->joints[joint];
+	const int t = j.type;
+	int kind = 0;
+	if (param == B2HIP_JOINT_LENGTH && (t == B2D_JOINT_DISTANCE || t == B2D_JOINT_ROPE)) { j.length = value; kind = 2; }
+	else if (param == B2HIP_JOINT_MAX_FORCE && (t == B2D_JOINT_FRICTION || t == B2D_JOINT_MOTOR || t == B2D_JOINT_MOUSE)) j.maxForce = value;
+	else if (param == B2HIP_JOINT_MAX_TORQUE && (t == B2D_JOINT_FRICTION || t == B2D_JOINT_MOTOR)) j.maxTorque = value;
+	else if (param == B2HIP_JOINT_RATIO && t == B2D_JOINT_GEAR)
+	{
+		// (a gear's definition lives in its own record, GearRec; JointRec::enableLimit is its index there)
+		const int gi = j.enableLimit;
+		if (gi < 0 || gi >= (int)w->gears.size()) return setError(B2HIP_ERR_INVALID, "gear record missing");
+		w->gears[(size_t)gi].ratio = value;
+		if ((size_t)gi < w->upGears)
+		{
+			DEVICE_GUARD(w);
+			HIP_TRY(hipMemcpy((char*)(w->d_gears.p + gi) + offsetof(GearRec, ratio), &value, sizeof(float), hipMemcpyHostToDevice));
+		}
+		return B2HIP_OK;
+	}
+	else if (param == B2HIP_JOINT_CORRECTION_FACTOR && t == B2D_JOINT_MOTOR) j.correctionFactor = value;
+	else return setError(B2HIP_ERR_INVALID, "b2hip_joint_set_param: the joint's type has no such parameter");
+	w->jointEdits.push_back(std::make_pair(joint, kind));
+	return B2HIP_OK;
+}
+
 // b2World::ShiftOrigin (b2World.cpp:1862-1887)
 int b2hip_shift_origin(b2hip_world* w, float x, float y)
 {

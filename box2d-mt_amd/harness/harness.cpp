@@ -940,4 +940,81 @@ int b2h_body_joint_lists(b2h_world* h, int cap, int* out)
 	return n;
 }
 
+// The scalar setters of the joint classes, applied to every joint of the world by type (b2DistanceJoint::SetLength /
+// SetFrequency / SetDampingRatio, b2FrictionJoint::SetMaxForce / SetMaxTorque, b2GearJoint::SetRatio, b2MotorJoint::SetMaxForce /
+// SetMaxTorque / SetCorrectionFactor, b2MouseJoint::SetMaxForce / SetFrequency / SetDampingRatio, b2RopeJoint::SetMaxLength,
+// b2WeldJoint::SetFrequency / SetDampingRatio); returns the number of joints retuned
+int b2h_retune_joints(b2h_world* h, int round)
+{
+	int n = 0;
+	const float k = 1.0f + 0.05f * (float)round;
+	for (b2Joint* j = h->world->GetJointList(); j; j = j->GetNext())
+	{
+		++n;
+		switch (j->GetType())
+		{
+		case e_distanceJoint:
+		{
+			b2DistanceJoint* d = static_cast<b2DistanceJoint*>(j);
+			d->SetLength(d->GetLength() * k);
+			d->SetFrequency(d->GetFrequency() + 1.0f);
+			d->SetDampingRatio(b2Min(1.0f, d->GetDampingRatio() + 0.1f));
+			break;
+		}
+		case e_frictionJoint:
+		{
+			b2FrictionJoint* f = static_cast<b2FrictionJoint*>(j);
+			f->SetMaxForce(0.5f * f->GetMaxForce());
+			f->SetMaxTorque(0.5f * f->GetMaxTorque());
+			break;
+		}
+		case e_gearJoint: static_cast<b2GearJoint*>(j)->SetRatio(1.1f * static_cast<b2GearJoint*>(j)->GetRatio()); break;
+		case e_motorJoint:
+		{
+			b2MotorJoint* m = static_cast<b2MotorJoint*>(j);
+			m->SetMaxForce(0.7f * m->GetMaxForce());
+			m->SetMaxTorque(0.7f * m->GetMaxTorque());
+			m->SetCorrectionFactor(0.5f * m->GetCorrectionFactor());
+			break;
+		}
+		case e_mouseJoint:
+		{
+			b2MouseJoint* m = static_cast<b2MouseJoint*>(j);
+			m->SetMaxForce(0.8f * m->GetMaxForce());
+			m->SetFrequency(m->GetFrequency() + 0.5f);
+			m->SetDampingRatio(0.9f * m->GetDampingRatio());
+			break;
+		}
+		case e_ropeJoint: static_cast<b2RopeJoint*>(j)->SetMaxLength(0.9f * static_cast<b2RopeJoint*>(j)->GetMaxLength()); break;
+		case e_weldJoint:
+		{
+			b2WeldJoint* wj = static_cast<b2WeldJoint*>(j);
+			wj->SetFrequency(wj->GetFrequency() + 2.0f);
+			wj->SetDampingRatio(0.5f);
+			break;
+		}
+		default: --n; break;
+		}
+	}
+	return n;
+}
+
+// b2WheelJoint::GetJointTranslation / GetJointLinearSpeed / GetJointAngle / GetJointAngularSpeed of every wheel joint, in
+// creation order: rows of 4 floats; returns the number of wheel joints
+int b2h_wheel_states(b2h_world* h, int cap, float* out)
+{
+	std::vector<b2Joint*> joints;
+	for (b2Joint* j = h->world->GetJointList(); j; j = j->GetNext()) if (j->GetType() == e_wheelJoint) joints.push_back(j);
+	std::reverse(joints.begin(), joints.end());
+	for (size_t i = 0; i < joints.size() && (int)i < cap; ++i)
+	{
+		const b2WheelJoint* wj = static_cast<const b2WheelJoint*>(joints[i]);
+		out[4 * i] = wj->GetJointTranslation();
+		out[4 * i + 1] = wj->GetJointLinearSpeed();
+		out[4 * i + 2] = wj->GetJointAngle();
+		out[4 * i + 3] = wj->GetJointAngularSpeed();
+	}
+	return (int)joints.size();
+}
+
 } // extern "C"

@@ -33,6 +33,10 @@ public:
 	const b2Vec2& GetLocalAnchorA() const { return m_localAnchorA; }
 	const b2Vec2& GetLocalAnchorB() const { return m_localAnchorB; }
 	float32 GetLength() const { return m_length; }
+	/// b2DistanceJoint.h:117-131 (plain assignments, read by the next step)
+	void SetLength(float32 length);
+	void SetFrequency(float32 hz);
+	void SetDampingRatio(float32 ratio);
 	float32 GetFrequency() const { return m_frequencyHz; }
 	float32 GetDampingRatio() const { return m_dampingRatio; }
 

@@ -30,6 +30,8 @@ public:
 	const b2Vec2& GetLocalAnchorB() const { return m_localAnchorB; }
 	float32 GetMaxForce() const { return m_maxForce; }
 	float32 GetMaxTorque() const { return m_maxTorque; }
+	void SetMaxForce(float32 force);   // b2FrictionJoint.cpp:206-228
+	void SetMaxTorque(float32 torque);
 
 protected:
 	friend class b2World;

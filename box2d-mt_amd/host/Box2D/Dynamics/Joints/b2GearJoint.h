@@ -26,6 +26,7 @@ public:
 	b2Joint* GetJoint1() { return m_joint1; }
 	b2Joint* GetJoint2() { return m_joint2; }
 	float32 GetRatio() const { return m_ratio; }
+	void SetRatio(float32 ratio);      // b2GearJoint.cpp:402-406
 
 protected:
 	friend class b2World;

@@ -34,6 +34,9 @@ public:
 	float32 GetMaxForce() const { return m_maxForce; }
 	float32 GetMaxTorque() const { return m_maxTorque; }
 	float32 GetCorrectionFactor() const { return m_correctionFactor; }
+	void SetMaxForce(float32 force);   // b2MotorJoint.cpp:222-251
+	void SetMaxTorque(float32 torque);
+	void SetCorrectionFactor(float32 factor);
 	void SetLinearOffset(const b2Vec2& linearOffset);
 	void SetAngularOffset(float32 angularOffset);
 

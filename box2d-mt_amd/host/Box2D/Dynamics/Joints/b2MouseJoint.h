@@ -30,6 +30,9 @@ public:
 	float32 GetMaxForce() const { return m_maxForce; }
 	float32 GetFrequency() const { return m_frequencyHz; }
 	float32 GetDampingRatio() const { return m_dampingRatio; }
+	void SetMaxForce(float32 force);   // b2MouseJoint.cpp:48-76
+	void SetFrequency(float32 hz);
+	void SetDampingRatio(float32 ratio);
 
 protected:
 	friend class b2World;

@@ -25,6 +25,7 @@ public:
 	const b2Vec2& GetLocalAnchorA() const { return m_localAnchorA; }
 	const b2Vec2& GetLocalAnchorB() const { return m_localAnchorB; }
 	float32 GetMaxLength() const { return m_maxLength; }
+	void SetMaxLength(float32 length) ; // b2RopeJoint.h:80
 
 protected:
 	friend class b2World;

@@ -34,6 +34,8 @@ public:
 	float32 GetReferenceAngle() const { return m_referenceAngle; }
 	float32 GetFrequency() const { return m_frequencyHz; }
 	float32 GetDampingRatio() const { return m_dampingRatio; }
+	void SetFrequency(float32 hz);     // b2WeldJoint.h:80-86
+	void SetDampingRatio(float32 ratio);
 
 protected:
 	friend class b2World;

@@ -43,6 +43,11 @@ public:
 	float32 GetMotorSpeed() const { return m_motorSpeed; }
 	float32 GetMaxMotorTorque() const { return m_maxMotorTorque; }
 	float32 GetSpringFrequencyHz() const { return m_frequencyHz; }
+	/// b2WheelJoint.cpp:350-397: from the bodies' current states
+	float32 GetJointTranslation() const;
+	float32 GetJointLinearSpeed() const;
+	float32 GetJointAngle() const;
+	float32 GetJointAngularSpeed() const;
 	float32 GetSpringDampingRatio() const { return m_dampingRatio; }
 	void EnableMotor(bool flag);
 	void SetMotorSpeed(float32 speed);

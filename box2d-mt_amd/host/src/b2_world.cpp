@@ -1712,6 +1712,27 @@ float32 b2PrismaticJoint::GetJointSpeed() const
 	return b2Dot(d, b2Cross(wA, axis)) + b2Dot(axis, vB + b2Cross(wB, rB) - vA - b2Cross(wA, rA));
 }
 
+float32 b2WheelJoint::GetJointTranslation() const
+{
+	b2Vec2 d = m_bodyB->GetWorldPoint(m_localAnchorB) - m_bodyA->GetWorldPoint(m_localAnchorA);
+	return b2Dot(d, m_bodyA->GetWorldVector(m_localAxisA));
+}
+
+float32 b2WheelJoint::GetJointLinearSpeed() const
+{
+	const b2Rot qA = m_bodyA->GetTransform().q, qB = m_bodyB->GetTransform().q;
+	b2Vec2 rA = b2Mul(qA, m_localAnchorA - m_bodyA->GetLocalCenter());
+	b2Vec2 rB = b2Mul(qB, m_localAnchorB - m_bodyB->GetLocalCenter());
+	b2Vec2 d = (m_bodyB->GetWorldCenter() + rB) - (m_bodyA->GetWorldCenter() + rA);
+	b2Vec2 axis = b2Mul(qA, m_localAxisA);
+	b2Vec2 vA = m_bodyA->GetLinearVelocity(), vB = m_bodyB->GetLinearVelocity();
+	float32 wA = m_bodyA->GetAngularVelocity(), wB = m_bodyB->GetAngularVelocity();
+	return b2Dot(d, b2Cross(wA, axis)) + b2Dot(axis, vB + b2Cross(wB, rB) - vA - b2Cross(wA, rA));
+}
+
+float32 b2WheelJoint::GetJointAngle() const { return m_bodyB->GetAngle() - m_bodyA->GetAngle(); }
+float32 b2WheelJoint::GetJointAngularSpeed() const { return m_bodyB->GetAngularVelocity() - m_bodyA->GetAngularVelocity(); }
+
 void b2WheelJointDef::Initialize(b2Body* bA, b2Body* bB, const b2Vec2& anchor, const b2Vec2& axis)
 {
 	bodyA = bA;
@@ -1728,6 +1749,25 @@ void b2WheelJoint::PushMotor()
 void b2WheelJoint::EnableMotor(bool flag) { m_enableMotor = flag; PushMotor(); }
 void b2WheelJoint::SetMotorSpeed(float32 speed) { m_motorSpeed = speed; PushMotor(); }
 void b2WheelJoint::SetMaxMotorTorque(float32 torque) { m_maxMotorTorque = torque; PushMotor(); }
+// ---- the scalar setters of the other joint classes: plain assignments in the reference, one C-ABI call each ------------------
+#define B2_JOINT_DEVICE (m_bodyA->GetWorld()->GetDeviceWorld())
+void b2DistanceJoint::SetLength(float32 length) { m_length = length; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_LENGTH, length); }
+void b2DistanceJoint::SetFrequency(float32 hz) { m_frequencyHz = hz; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
+void b2DistanceJoint::SetDampingRatio(float32 ratio) { m_dampingRatio = ratio; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
+void b2FrictionJoint::SetMaxForce(float32 force) { m_maxForce = force; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_MAX_FORCE, force); }
+void b2FrictionJoint::SetMaxTorque(float32 torque) { m_maxTorque = torque; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_MAX_TORQUE, torque); }
+void b2GearJoint::SetRatio(float32 ratio) { m_ratio = ratio; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_RATIO, ratio); }
+void b2MotorJoint::SetMaxForce(float32 force) { m_maxForce = force; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_MAX_FORCE, force); }
+void b2MotorJoint::SetMaxTorque(float32 torque) { m_maxTorque = torque; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_MAX_TORQUE, torque); }
+void b2MotorJoint::SetCorrectionFactor(float32 factor) { m_correctionFactor = factor; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_CORRECTION_FACTOR, factor); }
+void b2MouseJoint::SetMaxForce(float32 force) { m_maxForce = force; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_MAX_FORCE, force); }
+void b2MouseJoint::SetFrequency(float32 hz) { m_frequencyHz = hz; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
+void b2MouseJoint::SetDampingRatio(float32 ratio) { m_dampingRatio = ratio; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
+void b2RopeJoint::SetMaxLength(float32 length) { m_maxLength = length; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_LENGTH, length); }
+void b2WeldJoint::SetFrequency(float32 hz) { m_frequencyHz = hz; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
+void b2WeldJoint::SetDampingRatio(float32 ratio) { m_dampingRatio = ratio; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
+#undef B2_JOINT_DEVICE
+
 void b2WheelJoint::SetSpringFrequencyHz(float32 hz)
 {
 	m_frequencyHz = hz;

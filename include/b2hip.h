@@ -418,6 +418,12 @@ int b2hip_set_sleeping_allowed(b2hip_world* w, int body, int flag);
 /* b2WheelJoint / b2DistanceJoint / b2WeldJoint / b2MouseJoint ::SetFrequency / SetSpringFrequencyHz + SetDampingRatio
  * (e.g. b2WheelJoint.h:125-131): plain member writes, nobody is woken */
 int b2hip_joint_set_spring(b2hip_world* w, int joint, float frequency_hz, float damping_ratio);
+/* The plain scalar setters of the joint classes (assignments in the reference, no wake-up): b2DistanceJoint::SetLength,
+ * b2RopeJoint::SetMaxLength (LENGTH); b2FrictionJoint / b2MotorJoint / b2MouseJoint::SetMaxForce (MAX_FORCE);
+ * b2FrictionJoint / b2MotorJoint::SetMaxTorque (MAX_TORQUE); b2GearJoint::SetRatio (RATIO);
+ * b2MotorJoint::SetCorrectionFactor (CORRECTION_FACTOR). A parameter the joint's type does not have: B2HIP_ERR_INVALID. */
+enum { B2HIP_JOINT_LENGTH = 0, B2HIP_JOINT_MAX_FORCE = 1, B2HIP_JOINT_MAX_TORQUE = 2, B2HIP_JOINT_RATIO = 3, B2HIP_JOINT_CORRECTION_FACTOR = 4 };
+int b2hip_joint_set_param(b2hip_world* w, int joint, int param, float value);
 /* 1 if the id names a body / fixture that has been destroyed */
 int b2hip_body_is_destroyed(const b2hip_world* w, int body);
 int b2hip_fixture_is_destroyed(const b2hip_world* w, int fixture);

@@ -3263,6 +3263,21 @@ void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake)
 }
 
 /* b2Fixture::SetSensor / SetThickShape / Refilter / SetFilterData (b2Fixture.cpp:180-257) */
+/* the scalar setters of the joint classes (plain assignments: b2DistanceJoint.h:117, b2RopeJoint.h:80, b2FrictionJoint.cpp:206-228,
+ * b2MotorJoint.cpp:222-251, b2MouseJoint.cpp:48-76, b2GearJoint.cpp:402-406); param as in include/b2hip.h */
+int b2o_joint_set_param(b2o_world* w, int joint, int param, float value)
+{
+	revolute_t* j = &w->joints[joint];
+	const int t = j->type;
+	if (param == 0 && (t == B2O_JOINT_DISTANCE || t == B2O_JOINT_ROPE)) j->length = value;
+	else if (param == 1 && (t == B2O_JOINT_FRICTION || t == B2O_JOINT_MOTOR || t == B2O_JOINT_MOUSE)) j->maxForce = value;
+	else if (param == 2 && (t == B2O_JOINT_FRICTION || t == B2O_JOINT_MOTOR)) j->maxTorque = value;
+	else if (param == 3 && t == B2O_JOINT_GEAR) j->ratio = value;
+	else if (param == 4 && t == B2O_JOINT_MOTOR) j->correctionFactor = value;
+	else return -1;
+	return 0;
+}
+
 /* b2World::ShiftOrigin (b2World.cpp:1862-1887; b2DynamicTree.cpp:768-776; b2MouseJoint / b2PulleyJoint::ShiftOrigin) */
 void b2o_shift_origin(b2o_world* w, float x, float y)
 {

@@ -230,3 +230,52 @@ def test_body_joint_lists_match_the_reference_build(oracle, ref, scene, p0, p1, 
         r.step(1)
     a.close()
     r.close()
+
+
+RETUNE_CASES = [(bh.MACHINES, 40, 4, 3), (bh.VEHICLES, 40, 3, 3), (bh.ROPES, 30, 8, 9)]
+
+
+def run_retuned(a, b, what):
+    for h in (a, b):
+        h.L.b2h_retune_joints.argtypes = [C.c_void_p, C.c_int]
+        h.L.b2h_wheel_states.argtypes = [C.c_void_p, C.c_int, _fp]
+    wa, wb = np.zeros((64, 4), np.float32), np.zeros((64, 4), np.float32)
+    retuned = 0
+    for s in range(160):
+        if s in (20, 60, 100):
+            na, nb = a.L.b2h_retune_joints(a.ptr, s // 20), b.L.b2h_retune_joints(b.ptr, s // 20)
+            assert na == nb
+            retuned += na
+        a.step(1)
+        b.step(1)
+        assert np.array_equal(a.bodies().view(np.uint32), b.bodies().view(np.uint32)), "%s: body states differ at step %d" % (what, s)
+        if s % 10 == 9:
+            ka, kb = a.L.b2h_wheel_states(a.ptr, 64, fptr(wa)), b.L.b2h_wheel_states(b.ptr, 64, fptr(wb))
+            assert ka == kb and np.array_equal(wa[:ka].view(np.uint32), wb[:kb].view(np.uint32)), "%s: wheel joint getters at step %d" % (what, s)
+    assert retuned > 0
+    return a.bodies()
+
+
+@pytest.mark.parametrize("scene,p0,p1,seed", RETUNE_CASES)
+def test_joint_scalar_setters_match_the_reference_build(oracle, ref, scene, p0, p1, seed):
+    """b2DistanceJoint::SetLength / SetFrequency / SetDampingRatio, b2FrictionJoint::SetMaxForce / SetMaxTorque, b2GearJoint::SetRatio,
+    b2MotorJoint::SetMaxForce / SetMaxTorque / SetCorrectionFactor, b2MouseJoint::SetMaxForce / SetFrequency / SetDampingRatio,
+    b2RopeJoint::SetMaxLength, b2WeldJoint::SetFrequency / SetDampingRatio applied three times to every joint of the three joint
+    scenes (box2d-mt_amd/harness/harness.cpp: b2h_retune_joints), and the wheel joints' GetJointTranslation / LinearSpeed /
+    Angle / AngularSpeed: states and getters bitwise against the reference build; the retuning changes the motion."""
+    a, r = oracle.world(scene, p0, p1, seed=seed), ref.world(scene, p0, p1, seed=seed)
+    tuned = run_retuned(a, r, "oracle vs reference")
+    plain = ref.world(scene, p0, p1, seed=seed)
+    plain.step(160)
+    assert not np.array_equal(tuned, plain.bodies())
+    for w in (a, r, plain):
+        w.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,p0,p1,seed", RETUNE_CASES)
+def test_device_joint_scalar_setters_match_the_oracle(amd, oracle, scene, p0, p1, seed):
+    a, b = amd.world(scene, p0, p1, seed=seed), oracle.world(scene, p0, p1, seed=seed)
+    run_retuned(a, b, "device vs oracle")
+    a.close()
+    b.close()
