@@ -3086,6 +3086,22 @@ int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lo
 	return 0;
 }
 
+// b2RopeJoint::GetLimitState (b2RopeJoint.h:84) and the limit state of revolute / prismatic joints: the solver's, from the
+// device record; 0 inactive, 1 at lower, 2 at upper, 3 equal (b2LimitState, b2Joint.h:58-64); negative: error
+int b2hip_get_joint_limit_state(b2hip_world* w, int joint)
+{
+	if (int rcu = checkUsable(w, "b2hip_get_joint_limit_state", true)) return rcu;
+	if (joint < 0 || joint >= (int)w->joints.size()) return setError(B2HIP_ERR_INVALID, "bad joint id");
+	DEVICE_GUARD(w);
+	int state = w->joints[joint].limitState;
+	if ((size_t)joint < w->upJoints && w->d_joints.p != nullptr)
+	{
+		HIP_TRY(hipMemcpyAsync(&state, (const char*)(w->d_joints.p + joint) + offsetof(JointRec, limitState), sizeof(int), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	}
+	return state;
+}
+
 int b2hip_get_joint_reaction(b2hip_world* w, int joint, float inv_dt, float out4[4])
 {
 	if (int rcu = checkUsable(w, "b2hip_get_joint_reaction", true)) return rcu;

@@ -1017,4 +1017,14 @@ int b2h_wheel_states(b2h_world* h, int cap, float* out)
 	return (int)joints.size();
 }
 
+// b2RopeJoint::GetLimitState of every rope joint, in creation order; returns their number
+int b2h_rope_states(b2h_world* h, int cap, int* out)
+{
+	std::vector<b2Joint*> joints;
+	for (b2Joint* j = h->world->GetJointList(); j; j = j->GetNext()) if (j->GetType() == e_ropeJoint) joints.push_back(j);
+	std::reverse(joints.begin(), joints.end());
+	for (size_t i = 0; i < joints.size() && (int)i < cap; ++i) out[i] = (int)static_cast<const b2RopeJoint*>(joints[i])->GetLimitState();
+	return (int)joints.size();
+}
+
 } // extern "C"

@@ -26,6 +26,7 @@ public:
 	const b2Vec2& GetLocalAnchorB() const { return m_localAnchorB; }
 	float32 GetMaxLength() const { return m_maxLength; }
 	void SetMaxLength(float32 length) ; // b2RopeJoint.h:80
+	b2LimitState GetLimitState() const; // b2RopeJoint.h:84: e_atUpperLimit while the rope is taut (the last step's solver state)
 
 protected:
 	friend class b2World;

@@ -1764,6 +1764,11 @@ void b2MouseJoint::SetMaxForce(float32 force) { m_maxForce = force; b2hip_joint_
 void b2MouseJoint::SetFrequency(float32 hz) { m_frequencyHz = hz; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
 void b2MouseJoint::SetDampingRatio(float32 ratio) { m_dampingRatio = ratio; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
 void b2RopeJoint::SetMaxLength(float32 length) { m_maxLength = length; b2hip_joint_set_param(B2_JOINT_DEVICE, m_id, B2HIP_JOINT_LENGTH, length); }
+b2LimitState b2RopeJoint::GetLimitState() const
+{
+	const int state = b2hip_get_joint_limit_state(B2_JOINT_DEVICE, m_id);
+	return state >= 0 ? (b2LimitState)state : e_inactiveLimit;
+}
 void b2WeldJoint::SetFrequency(float32 hz) { m_frequencyHz = hz; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
 void b2WeldJoint::SetDampingRatio(float32 ratio) { m_dampingRatio = ratio; b2hip_joint_set_spring(B2_JOINT_DEVICE, m_id, m_frequencyHz, m_dampingRatio); }
 #undef B2_JOINT_DEVICE

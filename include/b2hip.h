@@ -367,6 +367,9 @@ int b2hip_joint_set_limits(b2hip_world* w, int joint, int enable_limit, float lo
  * (b2Joint.h:129-133; per type: b2RevoluteJoint.cpp:439-456, b2PrismaticJoint.cpp:502-510,618-621, ...).
  * out4 = force.x, force.y, torque, motor. One small device read per call (between steps). */
 int b2hip_get_joint_reaction(b2hip_world* w, int joint, float inv_dt, float out4[4]);
+/* b2RopeJoint::GetLimitState (b2RopeJoint.h:84; also the limit state of revolute / prismatic joints): 0 inactive, 1 at lower,
+ * 2 at upper, 3 equal limits (b2LimitState, b2Joint.h:58-64) as the last step's solver left it; negative = error code. */
+int b2hip_get_joint_limit_state(b2hip_world* w, int joint);
 
 /* ---- Life cycle and mutators between steps (all refused inside a step, like the reference's locked world) -------------------
  * Ids are never reused: a destroyed body / fixture keeps its id (every getter reports it as destroyed), so ids handed

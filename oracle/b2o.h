@@ -149,6 +149,7 @@ void b2o_set_bullet(b2o_world* w, int body, int bullet);
 void b2o_apply_linear_impulse(b2o_world* w, int body, float ix, float iy, float px, float py, int to_center, int wake);
 void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake);
 void b2o_shift_origin(b2o_world* w, float x, float y);
+int b2o_get_joint_limit_state(const b2o_world* w, int joint);
 int b2o_joint_set_param(b2o_world* w, int joint, int param, float value);
 void b2o_set_body_damping(b2o_world* w, int body, float linear_damping, float angular_damping, float gravity_scale);
 void b2o_set_fixed_rotation(b2o_world* w, int body, int flag);

@@ -251,6 +251,7 @@ int b2hip_set_awake(b2hip_world* w, int body, int awake) { b2o_set_awake(w->o, b
 int b2hip_set_active(b2hip_world* w, int body, int active) { b2o_set_active(w->o, body, active); return 0; }
 int b2hip_set_type(b2hip_world* w, int body, int type) { b2o_set_type(w->o, body, type); return 0; }
 int b2hip_set_bullet(b2hip_world* w, int body, int bullet) { b2o_set_bullet(w->o, body, bullet); return 0; }
+int b2hip_get_joint_limit_state(b2hip_world* w, int joint) { return b2o_get_joint_limit_state(w->o, joint); }
 int b2hip_joint_set_param(b2hip_world* w, int joint, int param, float value) { return b2o_joint_set_param(w->o, joint, param, value) ? -1 : 0; }
 int b2hip_shift_origin(b2hip_world* w, float x, float y) { b2o_shift_origin(w->o, x, y); return 0; }
 int b2hip_set_body_damping(b2hip_world* w, int body, float l, float a, float g) { b2o_set_body_damping(w->o, body, l, a, g); return 0; }

@@ -3263,6 +3263,8 @@ void b2o_apply_angular_impulse(b2o_world* w, int body, float impulse, int wake)
 }
 
 /* b2Fixture::SetSensor / SetThickShape / Refilter / SetFilterData (b2Fixture.cpp:180-257) */
+int b2o_get_joint_limit_state(const b2o_world* w, int joint) { return w->joints[joint].limitState; }
+
 /* the scalar setters of the joint classes (plain assignments: b2DistanceJoint.h:117, b2RopeJoint.h:80, b2FrictionJoint.cpp:206-228,
  * b2MotorJoint.cpp:222-251, b2MouseJoint.cpp:48-76, b2GearJoint.cpp:402-406); param as in include/b2hip.h */
 int b2o_joint_set_param(b2o_world* w, int joint, int param, float value)

@@ -240,6 +240,10 @@ def run_retuned(a, b, what):
         h.L.b2h_retune_joints.argtypes = [C.c_void_p, C.c_int]
         h.L.b2h_wheel_states.argtypes = [C.c_void_p, C.c_int, _fp]
     wa, wb = np.zeros((64, 4), np.float32), np.zeros((64, 4), np.float32)
+    ip = C.POINTER(C.c_int)
+    for h in (a, b):
+        h.L.b2h_rope_states.argtypes = [C.c_void_p, C.c_int, ip]
+    ra, rb = np.zeros(64, np.int32), np.zeros(64, np.int32)
     retuned = 0
     for s in range(160):
         if s in (20, 60, 100):
@@ -252,6 +256,8 @@ def run_retuned(a, b, what):
         if s % 10 == 9:
             ka, kb = a.L.b2h_wheel_states(a.ptr, 64, fptr(wa)), b.L.b2h_wheel_states(b.ptr, 64, fptr(wb))
             assert ka == kb and np.array_equal(wa[:ka].view(np.uint32), wb[:kb].view(np.uint32)), "%s: wheel joint getters at step %d" % (what, s)
+            ka, kb = a.L.b2h_rope_states(a.ptr, 64, ra.ctypes.data_as(ip)), b.L.b2h_rope_states(b.ptr, 64, rb.ctypes.data_as(ip))
+            assert ka == kb and np.array_equal(ra[:ka], rb[:kb]), "%s: rope joint limit states at step %d" % (what, s)
     assert retuned > 0
     return a.bodies()
 
