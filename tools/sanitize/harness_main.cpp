@@ -15,12 +15,17 @@ int b2h_raycast_closest(b2h_world* h, float x1, float y1, float x2, float y2, fl
 void b2h_tree_stats(b2h_world* h, float* out4);
 int b2h_joint_reactions(b2h_world* h, float inv_dt, int cap, float* out);
 int b2h_probe_dynamic_tree(unsigned seed, int count, int ops, float* out3);
+int b2h_retune_joints(b2h_world* h, int round);
+int b2h_joint_anchors(b2h_world* h, int cap, float* out);
+int b2h_body_joint_lists(b2h_world* h, int cap, int* out);
+int b2h_wheel_states(b2h_world* h, int cap, float* out);
+int b2h_rope_states(b2h_world* h, int cap, int* out);
 }
 int main()
 {
 	// every harness scene family (12 life cycle, 13 chain shapes), with the recording listener and the user filter on; queries,
 	// ray casts, tree statistics (the host's shadow b2DynamicTree) and joint reactions every 20th step
-	const int scenes[][3] = { {0,0,0}, {1,12,2}, {2,8,0}, {3,300,40}, {4,40,5}, {5,200,0}, {6,6,6}, {7,60,6}, {8,80,0}, {9,40,10}, {10,100,6}, {11,100,5}, {12,48,0}, {13,70,0} };
+	const int scenes[][3] = { {0,0,0}, {1,12,2}, {2,8,0}, {3,300,40}, {4,40,5}, {5,200,0}, {6,6,6}, {7,60,6}, {8,80,0}, {9,40,10}, {10,100,6}, {11,100,5}, {12,48,0}, {13,70,0}, {14,80,0} };
 	std::vector<int> ev(10 << 18);
 	for (auto& s : scenes)
 	{
@@ -49,6 +54,13 @@ int main()
 					b2h_raycast_closest(w, -30.0f, 0.5f + 0.05f * k, 30.0f, 1.0f, out7);
 					b2h_tree_stats(w, stats);
 					b2h_joint_reactions(w, 60.0f, 4096, reac.data());
+					// (late round 3: joint setters / getters, anchors, per-body joint lists)
+					std::vector<int> lists(5 * 8192);
+					b2h_joint_anchors(w, 4096, reac.data());
+					b2h_body_joint_lists(w, 8192, lists.data());
+					b2h_wheel_states(w, 1024, reac.data());
+					b2h_rope_states(w, 1024, lists.data());
+					if (k % 60 == 59) b2h_retune_joints(w, k / 60);
 				}
 			}
 			printf("scene %d flags %d listener mode %d: %d bodies %d contacts %ld callbacks\n", s[0], flags, run[1], b2h_body_count(w), b2h_contact_count(w), total);
