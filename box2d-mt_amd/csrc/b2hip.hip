@@ -3679,11 +3679,8 @@ int b2hip_set_sleeping_allowed(b2hip_world* w, int body, int flag)
 	else
 	{
 		b.flags &= ~BF_AUTOSLEEP;
-		if ((b.flags & BF_AWAKE) == 0)
-		{
-			b.flags |= BF_AWAKE;
-			b.sleepTime = 0.0f;
-		}
+		b.flags |= BF_AWAKE; // SetAwake(true) (b2Body.h:690-718): the sleep timer restarts whether or not the body slept
+		b.sleepTime = 0.0f;
 	}
 	return B2HIP_OK;
 }
