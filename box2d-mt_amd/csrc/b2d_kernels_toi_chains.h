@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 	const ContactArrays& A = W.ca[S->cur];
 	const ContactArrays& B = W.ca[1 - S->cur];
 	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-	if (!restore && S->c.nToiList == 0) return; // launched before the host knows whether any impact is pending
+	// (launched before the host knows whether any impact is pending. A call that CONTINUES a sub-stepped step has events to
+	// run although nothing is pending yet - the event loop's first batch computes the impacts - so its snapshot is always due:
+	// a PreSolve answer from that call's sub-step otherwise took the phase back to an EARLIER call's snapshot, materials included.)
+	if (!restore && S->c.nToiList == 0 && !W.toiContinue) return;
 	if (!restore)
 	{
 		toiSnapshotSave(W);

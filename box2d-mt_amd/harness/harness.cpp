@@ -466,6 +466,19 @@ int b2h_raycast_closest(b2h_world* h, float x1, float y1, float x2, float y2, fl
 //             then per point (2x): localPoint.xy, normalImpulse, tangentImpulse, id.key (bit pattern as float)
 // Returns the number of contacts written (<= cap). Order is the list order of the backend and is
 // NOT comparable between backends: sort by ids on the caller's side.
+// The mixed material of every contact, in b2h_get_contacts' order: friction, restitution, tangent speed (b2Contact.h:40-50,157).
+int b2h_get_contact_materials(b2h_world* h, int cap, float* out)
+{
+	int n = 0;
+	for (const b2Contact* c = h->world->GetContactList(); c && n < cap; c = c->GetNext(), ++n)
+	{
+		out[3 * n + 0] = c->GetFriction();
+		out[3 * n + 1] = c->GetRestitution();
+		out[3 * n + 2] = c->GetTangentSpeed();
+	}
+	return n;
+}
+
 int b2h_get_contacts(b2h_world* h, int cap, int* ids, int* flags, float* manifold)
 {
 	int n = 0;

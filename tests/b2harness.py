@@ -234,6 +234,20 @@ class World:
         order = np.lexsort((ids[:, 3], ids[:, 2], ids[:, 1], ids[:, 0]))
         return ids[order], flags[order], man[order]
 
+    def contact_materials(self):
+        """(ids[n,4], material[n,3]: friction, restitution, tangent speed) of every contact, sorted by ids."""
+        cap = max(self.contact_count, 1)
+        ids = np.zeros((cap, 4), np.int32)
+        flags = np.zeros(cap, np.int32)
+        man = np.zeros((cap, 16), np.float32)
+        mat = np.zeros((cap, 3), np.float32)
+        n = self.L.b2h_get_contacts(self.ptr, cap, _iptr(ids), _iptr(flags), _fptr(man))
+        self.L.b2h_get_contact_materials.argtypes = [C.c_void_p, C.c_int, _fp]
+        self.L.b2h_get_contact_materials(self.ptr, cap, _fptr(mat))
+        ids, mat = ids[:n], mat[:n]
+        order = np.lexsort((ids[:, 3], ids[:, 2], ids[:, 1], ids[:, 0]))
+        return ids[order], mat[order]
+
     def device_world(self):
         """b2hip_world* behind the drop-in b2World (AMD backend only), for the C-ABI measurement hooks."""
         self.L.b2h_device_world.restype = C.c_void_p

@@ -142,6 +142,38 @@ def test_device_sub_stepping_matches_the_oracle(amd, oracle, monkeypatch, name, 
     b.close()
 
 
+# The worlds of `tools/gpu_toi_presolve_campaign.py 7 12 substep` whose listener edits materials (mode 23). Round 3 shipped
+# with three of them diverging from the oracle after 90 - 130 calls: a call that continues a sub-stepped step with nothing
+# pending yet skipped its TOI snapshot (k_toi_snapshot looked at nToiList only), so a PreSolve answer from that call's
+# sub-step took the phase back to an EARLIER call's snapshot - the Collide phase's material edits of the call were lost.
+SUBSTEP_MATERIAL_CASES = [(500, 132, 0.0, 2.0, 5783), (500, 60, 60.0, 0.0, 2851), (500, 20, 120.0, 2.0, 1315), (500, 119, 120.0, 2.0, 8076)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,bullets,arena,rmax,seed", SUBSTEP_MATERIAL_CASES)
+def test_device_sub_stepping_with_a_material_editing_presolve_matches_the_oracle(amd, oracle, monkeypatch, n, bullets, arena, rmax, seed):
+    """b2World::SetSubStepping (b2World.cpp:1082-1086, 1668) together with a PreSolve that edits the contact's mixed material
+    inside TOI sub-steps (b2Contact.h:40-50): states, callbacks AND every contact's material, bit for bit, 240 calls."""
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    flags = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM | bh.F_SUBSTEP
+    kw = dict(p0=n, p1=bullets, f0=arena, f1=rmax, seed=seed, flags=flags)
+    a = amd.world(bh.FIELD, **kw)
+    b = oracle.world(bh.FIELD, **kw)
+    a.record_events(mode=23)
+    b.record_events(mode=23)
+    for s in range(240):
+        a.step(1)
+        b.step(1)
+        assert a.contact_count == b.contact_count, "call %d" % s
+        assert np.array_equal(a.bodies().view(np.uint32), b.bodies().view(np.uint32)), "call %d" % s
+        assert sorted(map(tuple, a.events_ex().tolist())) == sorted(map(tuple, b.events_ex().tolist())), "call %d" % s
+        ia, ma = a.contact_materials()
+        ib, mb = b.contact_materials()
+        assert np.array_equal(ia, ib) and np.array_equal(ma.view(np.uint32), mb.view(np.uint32)), "materials, call %d" % s
+    a.close()
+    b.close()
+
+
 def test_events_off_by_default_and_after_removal(oracle):
     w = oracle.world(bh.PILES, 10, 4, seed=3)
     w.step(30)
