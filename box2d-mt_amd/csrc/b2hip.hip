@@ -4126,6 +4126,13 @@ static int toiPreSolveRounds(b2hip_world* w, std::vector<ToiLogRec>& recs)
 		recs.resize((size_t)std::max(n, 0));
 		if (n > 0) HIP_TRY(hipMemcpy((void*)recs.data(), w->toiLog.p, (size_t)n * sizeof(ToiLogRec), hipMemcpyDeviceToHost));
 		if (!hasPreSolve(w) || w->dw.toiVerdict == nullptr) return 0;
+		// (the log itself was cut short: no listener call from a truncated log - the step fails with the capacity error below)
+		if (w->h_dstate->c.toiOverflow & 64) return 0;
+		// The callbacks below may edit bodies (callbackWindow). h_state holds the state AFTER this step's phases by now, but the
+		// mirror's epoch is only advanced at the very end of the step (refreshMirror): a body the host had touched before the
+		// step (a force applied every frame) would not be pulled again and the edit would land on - and later upload - its
+		// pre-step row. The read-back that just happened is the mirror from here on.
+		if (n > asked) refreshMirror(w);
 		bool again = false;
 		for (int k = asked; k < n && !again; ++k)
 		{
@@ -4951,7 +4958,8 @@ int b2hip_get_contacts(b2hip_world* w, int cap, b2hip_contact* out)
 int b2hip_set_shard(b2hip_world* w, int rank, int count)
 {
 	if (int rcu = checkUsable(w, "b2hip_set_shard", true)) return rcu;
-	if (count < 1 || rank < 0 || rank >= count) return setError(B2HIP_ERR_INVALID, "bad shard rank / count");
+	// (the island census keeps one counter per rank: Counters::shardBodies[SHARD_MAX_RANKS] ...)
+	if (count < 1 || count > SHARD_MAX_RANKS || rank < 0 || rank >= count) return setError(B2HIP_ERR_INVALID, "bad rank / count (at most 8 ranks)");
 	w->dw.shardRank = rank;
 	w->dw.shardCount = count;
 	return B2HIP_OK;

@@ -235,7 +235,12 @@ int b2hip_sync_fixtures(b2hip_world* w) { b2o_phase_sync_fixtures(w->o); return 
 int b2hip_find_new_contacts(b2hip_world* w) { b2o_phase_find_new_contacts(w->o); return 0; }
 int b2hip_solve_toi(b2hip_world* w) { b2o_phase_solve_toi(w->o); return 0; }
 int b2hip_step_end(b2hip_world* w) { b2o_step_end(w->o); return 0; }
-int b2hip_set_shard(b2hip_world* w, int rank, int count) { b2o_set_shard(w->o, rank, count); return 0; }
+int b2hip_set_shard(b2hip_world* w, int rank, int count)
+{
+	if (count < 1 || count > 8 || rank < 0 || rank >= count) return -1; /* B2HIP_ERR_INVALID: at most 8 ranks (the product's census arrays) */
+	b2o_set_shard(w->o, rank, count);
+	return 0;
+}
 int b2hip_shard_slab_words(b2hip_world* w, size_t* words_per_rank, int ranks)
 {
 	for (int r = 0; r < ranks; ++r) words_per_rank[r] = b2o_shard_slab_words(w->o, r);

@@ -156,6 +156,41 @@ def one_step_deviation(b, o):
     return dev
 
 
+def solution_quality(w):
+    """What a Gauss-Seidel solution of the step's contact problem is judged by, whatever order produced it: the deepest
+    penetration left (the position solver's own criterion: separation of the manifold points, b2ContactSolver.cpp:620-673, from
+    the body poses and the manifolds as they stand after the step), the summed normal impulse (what carries the pile's
+    weight), the kinetic energy of the moving bodies (density-5 unit boxes: m = 5, I = 5 / 6) and the number of touching
+    contacts. Polygon / edge manifolds only (the pyramid)."""
+    s, c = w.body_states(), w.contacts()
+    c = c[((c["flags"] & 1) != 0) & (c["point_count"] > 0)]
+    qs, qc = np.sin(s["angle"].astype(np.float64)), np.cos(s["angle"].astype(np.float64))
+    px, py = s["px"].astype(np.float64), s["py"].astype(np.float64)
+
+    def to_world(body, lx, ly):
+        return px[body] + qc[body] * lx - qs[body] * ly, py[body] + qs[body] * lx + qc[body] * ly
+
+    face_a = c["manifold_type"] == 1  # e_faceA; 2: e_faceB (b2Collision.h:96-101)
+    ref = np.where(face_a, c["body_a"], c["body_b"])
+    inc = np.where(face_a, c["body_b"], c["body_a"])
+    nx = qc[ref] * c["local_normal"][:, 0] - qs[ref] * c["local_normal"][:, 1]
+    ny = qs[ref] * c["local_normal"][:, 0] + qc[ref] * c["local_normal"][:, 1]
+    plx, ply = to_world(ref, c["local_point"][:, 0], c["local_point"][:, 1])
+    sep = np.full(len(c), np.inf)
+    for k in range(2):
+        has = c["point_count"] > k
+        cx, cy = to_world(inc, c["point_local"][:, k, 0], c["point_local"][:, k, 1])
+        d = (cx - plx) * nx + (cy - ply) * ny - 0.02  # (two polygon radii, b2_polygonRadius = 2 b2_linearSlop)
+        sep = np.where(has, np.minimum(sep, d), sep)
+    dyn = (s["flags"] & 3) == 2
+    ke = float((0.5 * 5.0 * (s["vx"][dyn].astype(np.float64) ** 2 + s["vy"][dyn].astype(np.float64) ** 2) + 0.5 * (5.0 / 6.0) * s["w"][dyn].astype(np.float64) ** 2).sum())
+    pen = -sep[np.isfinite(sep)]
+    return {"penetration_max": float(pen.max()) if pen.size else 0.0, "penetration_p99": float(np.percentile(pen, 99)) if pen.size else 0.0,
+            "penetration_mean": float(np.maximum(pen, 0.0).mean()) if pen.size else 0.0,
+            "impulse_sum": float(c["normal_impulse"].astype(np.float64).sum()), "kinetic_energy": ke, "touching": int(len(c)),
+            "speed_max": float(np.sqrt(s["vx"][dyn] ** 2 + s["vy"][dyn] ** 2).max())}
+
+
 # name: (builder, size, steps at which a one-step comparison is made, continuous physics,
 #        bounds on (pos / scale, angle [rad], vel / scale, spin [rad/s], fraction of the contact set that may differ),
 #        absolute bounds on (|dp| [m], |dv| [m/s]) - what the relative figures mean for one body)
@@ -188,7 +223,12 @@ SCENES = {
 }
 
 
-def run_scene(libs, name, report=None):
+# The coloured solver over the window bench.py times: from the identical state at step 245 the default-mode
+# world and the oracle (reference order) each run on for QUALITY_STEPS steps; see test_coloured_solver_solution_quality_...
+QUALITY_FROM, QUALITY_STEPS = 245, 55
+
+
+def run_scene(libs, name, report=None, quality=None):
     builder, size, ks, continuous = SCENES[name][:4]
     os.environ["B2HIP_FORCE_LARGE"] = "2"  # read at world creation: every island in the reference's constraint order
     try:
@@ -200,17 +240,29 @@ def run_scene(libs, name, report=None):
     builder(o, size)
     step = 0
     out = []
-    for k in ks:
-        while step < k:
-            a.step()
-            o.step()
-            step += 1
-        bitwise_same(a, o, "%s step %d" % (name, step))
-        blob = a.save_snapshot()
-        b = b2hip.World.from_snapshot(blob, library=libs[0])  # default mode: B2HIP_FORCE_LARGE is not set any more
+    q = None  # the default-mode world that runs on from QUALITY_FROM beside the oracle
+    q_left = 0
+
+    def advance():
+        nonlocal step, q_left
         a.step()
         o.step()
         step += 1
+        if q is not None and q_left > 0:
+            q.step()
+            q_left -= 1
+            quality.append((step, solution_quality(q), solution_quality(o)))
+
+    for k in ks:
+        while step < k:
+            advance()
+        bitwise_same(a, o, "%s step %d" % (name, step))
+        blob = a.save_snapshot()
+        b = b2hip.World.from_snapshot(blob, library=libs[0])  # default mode: B2HIP_FORCE_LARGE is not set any more
+        if quality is not None and k == QUALITY_FROM:
+            q = b2hip.World.from_snapshot(blob, library=libs[0])
+            q_left = QUALITY_STEPS
+        advance()
         bitwise_same(a, o, "%s step %d" % (name, step))
         b.step()
         # exact whatever the visiting order: the islands of the step just solved (built from identical inputs)
@@ -222,9 +274,44 @@ def run_scene(libs, name, report=None):
         if report is not None:
             report.append((name, step, dev))
         b.close()
+    if q is not None:
+        q.close()
     a.close()
     o.close()
     return out
+
+
+def check_solution_quality(quality):
+    """Steps 246 .. 300 of config 2 - the window the driver's bench run times - in the coloured order (device, default mode)
+    and in the reference's order (oracle), both started from the bit-identical state at step 245. The trajectories part
+    (a reordered Gauss-Seidel sweep is a different, equally valid iteration: DESIGN.md section 3), so what is bounded is
+    the QUALITY of the solution each delivers, as window means, device <= 1.1 x reference:
+      deepest and 99th-percentile penetration left after the step, kinetic energy, top speed;
+    and within 10 % either way: summed normal impulse (the pile's weight is carried), touching contacts.
+    Measured on MI355X (round 4, profiles/r04_solution_quality_pyramid141.txt - the per-step table this function writes):
+    window means device / reference: deepest penetration 0.2028 / 0.1997 m (1.016; the pile is not a solved one at 8 / 3
+    iterations in either order), p99 penetration 1.002, mean penetration 0.999, summed normal impulse 1.005, kinetic energy
+    0.993, touching contacts 19 807 / 19 782 (1.001), top speed 17.874 / 17.874 m/s (1.000)."""
+    assert len(quality) == QUALITY_STEPS
+    keys = ("penetration_max", "penetration_p99", "penetration_mean", "impulse_sum", "kinetic_energy", "touching", "speed_max")
+    dev = {k: np.array([d[k] for _, d, _ in quality], np.float64) for k in keys}
+    ref = {k: np.array([r[k] for _, _, r in quality], np.float64) for k in keys}
+    lines = ["step  " + "  ".join("%s(dev/ref)" % k for k in keys)]
+    for (step, d, r) in quality:
+        lines.append("%4d  " % step + "  ".join("%.5g/%.5g" % (d[k], r[k]) for k in keys))
+    report = "\n".join(lines)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "solution_quality_pyramid141.txt"), "w") as f:
+            f.write(report + "\n")
+    for k in ("penetration_max", "penetration_p99", "penetration_mean", "kinetic_energy", "speed_max"):
+        assert dev[k].mean() <= 1.1 * ref[k].mean() + 1e-9, "coloured order: window mean of %s %.5g against the reference order's %.5g\n%s" % (k, dev[k].mean(), ref[k].mean(), report)
+    for k in ("impulse_sum", "touching"):
+        ratio = dev[k].mean() / ref[k].mean()
+        assert 0.9 <= ratio <= 1.1, "coloured order: window mean of %s is %.3f x the reference order's\n%s" % (k, ratio, report)
+    # the solver's own acceptance level, every step: b2_maxLinearCorrection-limited piles aside, the deepest point stays within
+    # a few slops of where the reference order leaves it
+    assert dev["penetration_max"].max() <= 1.1 * ref["penetration_max"].max() + 0.005, report
 
 
 @pytest.mark.parametrize("name", list(SCENES))
@@ -234,7 +321,11 @@ def test_default_solver_one_step_from_identical_state(libs, name):
             return table
         return table[max(k for k in table if k <= step)]
 
-    for dev in run_scene(libs, name):
+    quality = [] if name == "pyramid141" else None
+    devs = run_scene(libs, name, quality=quality)
+    if quality is not None:
+        check_solution_quality(quality)
+    for dev in devs:
         where = "%s step %d" % (name, dev["step"])
         bounds = pick(SCENES[name][4], dev["step"])
         absolute = pick(SCENES[name][5], dev["step"])

@@ -22,8 +22,10 @@ import b2hip
 PRE_SOLVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float * 3))
 
 
-def drop_on_platform(L, answer, edit=None, steps=40):
-    """-> ((lowest height the box reached, its slowest downward speed), number of PreSolve calls, rc of the first failing step or 0)"""
+def drop_on_platform(L, answer, edit=None, steps=40, force=None, rows=None):
+    """-> ((lowest height the box reached, its slowest downward speed), number of PreSolve calls, rc of the first failing step or 0)
+    force: applied to the box before every step (the host touches the body's row every frame); rows: list that receives the
+    box's state after every step."""
     w = b2hip.World(gravity=(0.0, -10.0), continuous=True, library=L)
     ground = w.create_body(b2hip.STATIC, position=(0.0, 0.0))
     w.create_fixture(ground, b2hip.box_shape(20.0, 0.05))          # the platform: 0.1 thick
@@ -42,10 +44,14 @@ def drop_on_platform(L, answer, edit=None, steps=40):
     assert L.b2hip_set_pre_solve(w.p, C.cast(fn, C.c_void_p), None) == 0
     lowest, slowest, rc = 1e9, -1e9, 0
     for _ in range(steps):
+        if force is not None:
+            w.apply_force(box, force)
         rc = L.b2hip_step(w.p, C.c_float(1.0 / 60.0), 8, 3)
         if rc != 0:
             break
         row = w.bodies8()[box]
+        if rows is not None:
+            rows.append(row.copy())
         lowest, slowest = min(lowest, float(row[1])), max(slowest, float(row[4]))
     L.b2hip_set_pre_solve(w.p, None, None)
     w.close()
@@ -84,6 +90,28 @@ def test_device_refuses_a_toi_presolve_that_edits_the_world_and_changes_its_cont
     assert rc == 0 and calls > 0 and lowest > 0.1  # (an edit alone is fine)
     _, calls, rc = drop_on_platform(L, 0, edit=lambda w, box: w.set_bullet(box, True))
     assert rc != 0 and b"PreSolve" in L.b2hip_last_error()
+
+
+def forced_box_edited_from_the_sub_step(L):
+    rows = []
+    (lowest, _), calls, rc = drop_on_platform(L, 1, edit=lambda w, box: w.set_bullet(box, True), force=(0.25, 0.0), rows=rows)
+    assert rc == 0 and calls > 0 and lowest > 0.1
+    return np.array(rows)
+
+
+def test_oracle_abi_forced_box_edited_from_the_sub_step():
+    rows = forced_box_edited_from_the_sub_step(b2hip.load(bh.ORACLE_LIB, optional_ok=True))
+    assert (np.diff(rows[:, 0]) > 0).all(), "the sideways force must move the box steadily"
+
+
+@pytest.mark.gpu
+def test_device_edit_from_a_toi_presolve_lands_on_the_fresh_row():
+    """a body the host touches every frame (apply_force: its host row is 'current' for the epoch of the last
+    read-back) and that a PreSolve called from a TOI sub-step edits: the edit must land on the row of THIS step's read-back,
+    not on the pre-step row - which the next upload would have written back, the box jumping back one step."""
+    a = forced_box_edited_from_the_sub_step(b2hip.lib())
+    b = forced_box_edited_from_the_sub_step(b2hip.load(bh.ORACLE_LIB, optional_ok=True))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "first difference at step %d" % int(np.nonzero((a != b).any(axis=1))[0][0])
 
 
 # ---- b2World::ShiftOrigin through the bare ABI: the world-space anchors joints keep (b2MouseJoint / b2PulleyJoint::ShiftOrigin) ----
