@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	{
 		const int p = W.moveBuf[k];
 		if (p < 0 || W.p_body[p] < 0) continue;
+		// (a spatially sharded world: every rank searches for the proxies ITS bodies moved; b2d_kernels_spatial.h, E2)
+		if (W.spatial && (W.b_flags[W.p_body[p]] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[W.p_body[p]] != (uint8_t)W.shardRank) continue;
 		const float4 a4 = W.p_fat[p];
 		if (proxyIsLarge(W, a4))
 		{
@@ -296,6 +298,8 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 	{
 		const int p = W.moveBuf[k];
 		if (p < 0 || W.p_body[p] < 0) continue;
+		// (a spatially sharded world: every rank searches for the proxies ITS bodies moved; b2d_kernels_spatial.h, E2)
+		if (W.spatial && (W.b_flags[W.p_body[p]] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[W.p_body[p]] != (uint8_t)W.shardRank) continue;
 		const float4 a4 = W.p_fat[p];
 		if (proxyIsLarge(W, a4))
 		{

@@ -177,6 +177,11 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 			{
 				keep = 0;
 			}
+			else if (flags & CF_FOREIGN)
+			{
+				// a spatially sharded world: the bodies are another rank's, which evaluates the manifold; here the contact only
+				// keeps existing (the overlap test above is structure: every rank destroys the same contacts)
+			}
 			else
 			{
 				// b2Contact::UpdateImpl (b2Contact.cpp:173-298)
@@ -282,13 +287,13 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 			if (flags & CF_TOI_CANDIDATE) b2dStoreAgentI(&W.toiDestroyList[atomicAdd(&S->c.nToiDestroy, 1)], i); // (read by the last workgroup)
 			// b2Contact::Destroy (b2Contact.cpp:100-113): wake both bodies if the manifold had points
 			int pc = C.man3[i].w;
-			if (pc > 0 && (flags & CF_SENSOR) == 0)
+			if (pc > 0 && (flags & (CF_SENSOR | CF_FOREIGN)) == 0) // (a foreign contact's point count is not maintained: its owner wakes the bodies)
 			{
 				W.b_wake[bodyA] = 1;
 				W.b_wake[bodyB] = 1;
 			}
 		}
-		else if ((flags & CF_TOUCHING) != 0)
+		else if ((flags & (CF_TOUCHING | CF_FOREIGN)) == CF_TOUCHING)
 		{
 			++nTouch;
 		}
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void k_contact_events(DW W)
 	{
 		const uint32_t flags = C.flags[i];
 		const bool touching = (flags & CF_TOUCHING) != 0, reported = (flags & CF_REPORTED) != 0;
-		if (touching == reported) continue;
+		if (touching == reported || (flags & CF_FOREIGN) != 0) continue;
 		C.flags[i] = flags ^ CF_REPORTED;
 		const int e = atomicAdd(&S->c.nEvents, 1);
 		if (e < W.capContacts)

@@ -30,7 +30,8 @@ __device__ __forceinline__ int shardHashOwner(int root, int shardCount)
 __device__ __forceinline__ bool contactSolid(uint32_t flags)
 {
 	// b2World.cpp:1261-1273: enabled, touching, not a sensor
-	return (flags & (CF_ENABLED | CF_TOUCHING | CF_SENSOR | CF_DESTROY)) == (CF_ENABLED | CF_TOUCHING);
+	// (CF_FOREIGN: a spatially sharded world - the contact's bodies are another rank's, its touching bit is not maintained here)
+	return (flags & (CF_ENABLED | CF_TOUCHING | CF_SENSOR | CF_DESTROY | CF_FOREIGN)) == (CF_ENABLED | CF_TOUCHING);
 }
 
 __device__ __forceinline__ int ufFind(int* parent, int i)
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 			W.b_wake[i] = 0;
 		}
 		W.b_flags[i] = f;
-		const bool member = (f & BF_TYPE_MASK) != BT_STATIC && (f & BF_ACTIVE) != 0;
+		// (a spatially sharded world: another rank's body is in none of OUR islands - b2d_kernels_spatial.h)
+		const bool member = (f & BF_TYPE_MASK) != BT_STATIC && (f & BF_ACTIVE) != 0 && !(W.spatial && W.b_owner[i] != (uint8_t)W.shardRank);
 		W.rootBodies[i] = member ? 1 : 0;
 		// seeds are taken in m_nonStaticBodies order (b2World.cpp:1207-1221): first awake, active body
 		W.rootSeed[i] = member && (f & BF_AWAKE) != 0 ? W.b_order[i] : 0x7fffffff;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256) void k_island_union(DW W)
 		if (((W.b_flags[jn.bodyA] & W.b_flags[jn.bodyB]) & BF_ACTIVE) == 0) continue;
 		bool nsA = (W.b_flags[jn.bodyA] & BF_TYPE_MASK) != BT_STATIC;
 		bool nsB = (W.b_flags[jn.bodyB] & BF_TYPE_MASK) != BT_STATIC;
+		if (W.spatial && ((nsA && W.b_owner[jn.bodyA] != (uint8_t)W.shardRank) || (nsB && W.b_owner[jn.bodyB] != (uint8_t)W.shardRank))) continue;
 		if (nsA && nsB) ufUnion(W.parent, jn.bodyA, jn.bodyB);
 	}
 }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 		const int i = base + threadIdx.x;
 		bool valid = i < n;
 		uint32_t f = valid ? W.b_flags[i] : 0u;
-		valid = valid && (f & BF_TYPE_MASK) != BT_STATIC && (f & BF_ACTIVE) != 0;
+		valid = valid && (f & BF_TYPE_MASK) != BT_STATIC && (f & BF_ACTIVE) != 0 && !(W.spatial && W.b_owner[i] != (uint8_t)W.shardRank);
 		int r = 0;
 		if (valid)
 		{
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 					++nFree;
 				}
 				else
-				if (W.shardCount > 1)
+				if (W.shardCount > 1 && !W.spatial) // (island-owner sharding; spatial ownership has sorted the islands out already)
 				{
 					// islands are dealt over the ranks: the big ones one by one (k_shard_big), the others by a hash of their root
 					big = nb > SHARD_BIG_BODIES && forceLarge != 2;

@@ -88,7 +88,7 @@ __device__ __forceinline__ float computeToi(const DW& W, int4 ids, const Sweep& 
 // IsMinToiCandidate (b2Contact.h:403-418) + !e_inactiveFlag: may this contact take part in the arg-min?
 __device__ __forceinline__ bool toiEligible(const DW& W, uint32_t flags, int4 ids)
 {
-	if ((flags & CF_TOI_CANDIDATE) == 0 || (flags & CF_ENABLED) == 0) return false;
+	if ((flags & CF_TOI_CANDIDATE) == 0 || (flags & CF_ENABLED) == 0 || (flags & CF_FOREIGN) != 0) return false;
 	if ((int)((flags & CF_TOI_COUNT_MASK) >> CF_TOI_COUNT_SHIFT) > B2D_MAX_SUB_STEPS) return false;
 	return bodyActiveForContact(ldFlags(&W.b_flags[ids.z])) || bodyActiveForContact(ldFlags(&W.b_flags[ids.w]));
 }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 		{
 			const uint32_t flags = C.flags[i] & ~(CF_TOI_LISTED | CF_TOI_PENDING);
-			const bool listed = (flags & CF_TOI) != 0 && C.mat[i].w < 1.0f;
+			const bool listed = (flags & (CF_TOI | CF_FOREIGN)) == CF_TOI && C.mat[i].w < 1.0f;
 			if (listed)
 			{
 				const int k = atomicAdd(&S->c.nToiList, 1);

@@ -44,6 +44,8 @@
 #define CF_VC_ONE_POINT 0x10000u // the solver's conditioning guard dropped the second manifold point this step (b2ContactSolver.cpp:230-247)
 #define CF_USER_REJECT 0x20000u  // the user's contact filter refused this contact at its re-filtering (b2ContactManager.cpp:195-203)
 #define CF_PRESOLVE_OFF 0x40000u  // the listener's last PreSolve switched this contact off: what a TOI sub-step assumes until it has been asked
+#define CF_FOREIGN 0x80000u      // spatially sharded world: the bodies of this contact belong to another rank - the contact exists here (same
+                                 // slot on every rank) but its manifold, impulses and touching bit are not maintained (b2d_kernels_spatial.h)
 #define CF_TOI_COUNT_SHIFT 12  // bits 12..15: m_toiCount (0..9)
 #define CF_TOI_COUNT_MASK 0xf000u
 #define CF_TOI_STATE_MASK (CF_TOI | CF_TOI_LISTED | CF_TOI_PENDING | CF_TOI_COUNT_MASK)
@@ -180,6 +182,14 @@ struct Counters
 	int edgesBlocksDone;   // ... of k_island_edges (the last one publishes the census when it is the island build's last kernel)
 	int nFreeIslands;    // one-body islands without contacts or joints, stepped by k_island_classify itself
 	int nSmallJointed;   // small islands of this step that hold joints (none: the lean k_solve_small runs)
+	// spatially sharded worlds (b2d_kernels_spatial.h)
+	int nStraddle;       // contacts between non-static bodies of different owners (k_sp_flag_contacts): resolved before anybody updates them
+	int nStraddleJoints; // ... joints
+	int nResolve;        // components the running resolution merges
+	int nMigrated;       // bodies whose owner the last resolution changed
+	int spContacts[SHARD_MAX_RANKS], spJoints[SHARD_MAX_RANKS]; // contact / joint records every rank ships in the running resolution
+	int spBodies[SHARD_MAX_RANKS], spProxies[SHARD_MAX_RANKS];  // non-static bodies and their proxies per owner (k_sp_owner_census)
+	int spToiCreated;    // contacts this rank's TOI phase created (the tail of its contact array until the ranks have merged their tails)
 };
 
 // What b2ContactListener::PreSolve is told about one contact (gathered after Collide, before the compaction of destroyed
@@ -371,6 +381,14 @@ struct DW
 	// it owns and takes the others' results from one exchange per step
 	int shardRank, shardCount;
 	int* bigRoots;       // roots of the islands with more than SHARD_BIG_BODIES bodies (dealt over the ranks in root-id order)
+	// ... or by spatial ownership (b2d_kernels_spatial.h): work and contact content partitioned by the owner of the bodies
+	int spatial;         // 1: DW::b_owner decides who evaluates, solves and moves a body and its contacts
+	uint8_t* b_owner;    // per body: the rank that owns it (the same table on every rank; static bodies: unused)
+	uint8_t* spNewOwner; // per body: its owner after the running resolution
+	int* spStraddle;     // contact indices of Counters::nStraddle
+	int capStraddle;
+	int* spCount;        // per component under resolution: bodies per owner [SP_RESOLVE_MAX][SHARD_MAX_RANKS]
+	int* spTarget;       // per component under resolution: its new owner
 	// listener / filter bridge (include/b2hip.h: b2hip_set_contact_filter, b2hip_set_pre_solve, b2hip_enable_post_solve)
 	int userFilter;      // a user contact filter is installed: the built-in category / mask / group rule is not applied
 	int preSolveOn, postSolveOn;

@@ -42,6 +42,7 @@
 #include "b2d_kernels_solve_blocks.h"
 #include "b2d_kernels_edit.h"
 #include "b2d_kernels_shard.h"
+#include "b2d_kernels_spatial.h"
 #include "b2d_scan.h"
 #include "b2d_shape_geom.h"
 
@@ -241,6 +242,23 @@ struct b2hip_world
 	DevArray<int> shardSend, shardRecv; // this rank's slab / all ranks' slabs
 	size_t shardExchangeBytes = 0;
 	bool shardLoopback = false;  // B2HIP_SHARD_LOOPBACK=1: a communicator of ONE rank still runs export -> ncclAllGather -> import (self-test on a one-GPU box)
+	// spatial ownership (b2d_kernels_spatial.h; b2hip_shard_spatial)
+	bool spatial = false;
+	DevArray<uint8_t> b_owner, spNewOwner;
+	DevArray<int> spStraddle, spCount, spTarget, spSend, spRecv;
+	std::vector<uint8_t> spOwners; // the owner table as the host last knew it (assignment; refreshed after every resolution)
+	bool spOwnersDirty = false;    // owners assigned / bodies created since the table was uploaded
+	float spBounds[SHARD_MAX_RANKS + 1] = {0}; // strips along x the owners were dealt by (bodies created later fall into them)
+	b2hip_all_gather_fn gatherFn = nullptr; // the caller's all-gather (gloo, tests); null with a connected RCCL communicator
+	void* gatherUser = nullptr;
+	int* spHost = nullptr;          // pinned staging of the caller's all-gather
+	size_t spHostWords = 0;
+	int spPairCap = 16384, spToiBodyCap = 1024, spToiProxyCap = 2048;
+	int spOwned[SHARD_MAX_RANKS] = {0}, spOwnedProxies[SHARD_MAX_RANKS] = {0};
+	long long spMigratedTotal = 0, spResolves = 0, spPairsSent = 0;
+	size_t spBytesStep = 0;         // bytes this rank received in the exchanges of the last step
+	int spContactsBeforeToi = 0;
+	size_t spUp = 0;                // bodies the device's owner table covers
 	DevArray<int> scanFlags;     // status words of the single-pass scans (b2d_scan.h)
 	ScanFlags scanCtx;           // ... with their epoch and the abort word (refreshed by ensureCapacity)
 	DevArray<float> stateOut;
@@ -838,6 +856,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2); ENS(blkBodyCount, MAX_BLOCKS + 2); ENS(blkBodyCursor, MAX_BLOCKS + 2);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
+	ENS(b_owner, w->spatial ? nb : 1); ENS(spNewOwner, w->spatial ? nb : 1); ENS(spStraddle, w->spatial ? std::max<size_t>(w->spStraddle.cap, 4096) : 1);
+	ENS(spCount, w->spatial ? (size_t)SP_RESOLVE_MAX * SHARD_MAX_RANKS : 1); ENS(spTarget, w->spatial ? SP_RESOLVE_MAX : 1);
 	ENS(stateOut, 12 * nb + sizeof(DState) / sizeof(float) + 4); // (+ the counters, behind the rows: one copy to the host per step)
 	ENS(consts, 16);
 	ENS(gridBar, 32);
@@ -920,6 +940,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.b_adoptStage = w->b_adoptStage.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p; d.blkBodyCount = w->blkBodyCount.p; d.blkBodyCursor = w->blkBodyCursor.p;
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
+	d.spatial = w->spatial ? 1 : 0; d.b_owner = w->b_owner.p; d.spNewOwner = w->spNewOwner.p; d.spStraddle = w->spStraddle.p;
+	d.capStraddle = (int)w->spStraddle.cap; d.spCount = w->spCount.p; d.spTarget = w->spTarget.p;
 	d.userFilter = hasFilter(w) ? 1 : 0; d.preSolveOn = hasPreSolve(w) ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
 	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
 	d.preRecs = w->preRecs.p; d.postRecs = w->postRecs.p; d.filterList = w->filterList.p;
@@ -1289,6 +1311,13 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 // ------------------------------------------------------------------------------------------------
 // Phases
 // ------------------------------------------------------------------------------------------------
+// spatially sharded worlds (defined behind the RCCL section; b2d_kernels_spatial.h)
+static int spExchangeState(b2hip_world* w, int mode);
+static int spExchangePairs(b2hip_world* w);
+static int spResolve(b2hip_world* w);
+static int spAfterToi(b2hip_world* w);
+static int spBeginStep(b2hip_world* w);
+
 static int radixBits(int maxKey)
 {
 	int bits = 1;
@@ -1398,7 +1427,7 @@ static int findNewContactsOnce(b2hip_world* w, bool sync);
 static int findNewContactsGraph(b2hip_world* w)
 {
 	// (a user contact filter is asked on the host in the middle of the update: synchronous, no graph)
-	if (hasFilter(w)) return findNewContacts(w, true);
+	if (hasFilter(w) || w->spatial) return findNewContacts(w, true);
 	// A scene that creates more pairs per step than the optimistic counting path ranks (the settled 50 086-box pyramid and the
 	// 100 000-box Tumbler: ~25 000 and ~150 000 new fat-AABB pairs per step) would find that out at the end of the step, sort
 	// with the radix path then - and run the TOI phase and the read-back a second time, every step. While that has happened
@@ -1445,6 +1474,20 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 	if (int rk = ktBracket(w, 4, 7)) return rk;
 	LAUNCH(w, k_find_pairs_large, 1024, 256, d);
 	bool large = false;
+	if (w->spatial)
+	{
+		// E2: every rank searched for the proxies ITS bodies moved; all ranks order and create the union
+		int rc = spExchangePairs(w);
+		if (rc) return rc;
+		rc = readState(w);
+		if (rc) return rc;
+		if (w->h_dstate->c.overflow & 3) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow in a spatially sharded world");
+		large = w->h_dstate->c.nPairs > COUNT_RANK_MAX;
+		rc = runSortAndCreate(w, large);
+		if (rc) return rc;
+		// E3: a new contact may join components of different owners
+		return spResolve(w);
+	}
 	if (sync)
 	{
 		int rc = readState(w);
@@ -1558,7 +1601,7 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge, sp);
-		if (d.shardCount > 1) LAUNCH(w, k_shard_big, 1, 1024, d); // the big islands of a sharded world, dealt over the ranks
+		if (d.shardCount > 1 && !d.spatial) LAUNCH(w, k_shard_big, 1, 1024, d); // the big islands of a sharded world, dealt over the ranks
 		{
 			int blocks = (d.nBodies + SCAN_TILE - 1) / SCAN_TILE;
 			if (blocks < 1) blocks = 1;
@@ -2085,7 +2128,7 @@ static int toiSerial(b2hip_world* w)
 	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
 	LAUNCH(w, k_toi_loop, 1, TOI_LANES, d, w->sp);
-	LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+	if (!w->spatial) LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d); // (spatial worlds: k_end_step does it, behind the exchange)
 	w->toiChains = false;
 	return 0;
 }
@@ -2101,7 +2144,7 @@ static int phaseToiSync(b2hip_world* w);
 // contacts, and the synchronous phase). One read-back and ~45 us less per step with continuous physics on.
 static int phaseToi(b2hip_world* w)
 {
-	if (w->toiSerialOnly || w->toiSyncOnly || listenerOn(w) || w->dw.toiEventCap > 0 || w->dw.toiContinue) return phaseToiSync(w);
+	if (w->toiSerialOnly || w->toiSyncOnly || listenerOn(w) || w->dw.toiEventCap > 0 || w->dw.toiContinue || w->spatial) return phaseToiSync(w);
 	if (w->toiSyncSticky > 0)
 	{
 		// the serial loop was needed recently (bullets, kinematic partners, contact-creating events): decide from the
@@ -2172,6 +2215,7 @@ static int phaseToiSync(b2hip_world* w)
 	w->last.nToiList = w->h_dstate->c.nToiList;
 	w->last.nToiCalls = w->h_dstate->c.nToiCalls;
 	w->last.nToiEvents = 0;
+	w->spContactsBeforeToi = w->h_dstate->c.nContacts;
 	// (sub-stepping: one event per call in the reference's serial order; a call that continues a step has impacts to compute
 	// even when nothing is pending yet - the event loop's first batch)
 	const bool subStepped = d.toiEventCap > 0 || d.toiContinue != 0;
@@ -2196,7 +2240,7 @@ static int phaseToiSync(b2hip_world* w)
 			if (rc) return rc;
 		}
 		LAUNCH(w, k_toi_chains, std::min(groups, 1024), CHAIN_LANES, d, w->sp, haveGrid);
-			LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+		if (!w->spatial) LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
 		w->toiChainsHadGrid = haveGrid != 0;
 		w->toiChains = true;
 		return 0;
@@ -2223,14 +2267,15 @@ static int phaseToiSync(b2hip_world* w)
 		// components tied together by a new contact: back to the snapshot, then the serial loop over just those
 		LAUNCH(w, k_toi_dom_rollback, gridFor(std::max(std::max(d.nBodies, d.nProxies), d.capContacts)), 256, d);
 		LAUNCH(w, k_toi_loop_partial, 1, TOI_LANES, d, w->sp);
-		LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
+		if (!w->spatial) LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
 		w->toiChainsHadGrid = true; // (the components always have it)
 		w->toiChains = true;
 		return 0;
 	}
-	if (hasPreSolve(w) && !w->toiSnapshotTaken)
+	if ((hasPreSolve(w) || w->spatial) && !w->toiSnapshotTaken)
 	{
 		// a PreSolve called from a sub-step may change that sub-step (toiPreSolveRounds): the phase must be able to start over
+		// (a spatially sharded world sends the other ranks what differs from this snapshot: spAfterToi)
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
 		w->toiSnapshotTaken = true;
 	}
@@ -2334,6 +2379,7 @@ static int addJoint(b2hip_world* w, const JointRec& j)
 {
 	if (int rcu = checkUsable(w, "b2hip_create_joint", true)) return rcu;
 	w->joints.push_back(j);
+	if (w->spatial) w->spOwnersDirty = true; // (a joint may join bodies of different owners: resolved at the next step)
 	// b2World::CreateJoint (b2World.cpp:716-732): contacts between the two bodies are re-filtered
 	if (j.collideConnected == 0) w->pendingFilter.push_back(std::make_pair(j.bodyA, j.bodyB));
 	return (int)w->joints.size() - 1;
@@ -2674,6 +2720,7 @@ int b2hip_create_body(b2hip_world* w, const b2hip_body_def* def)
 		w->orderDirty = true;
 	}
 	w->bodies.push_back(b);
+	if (w->spatial) w->spOwnersDirty = true; // (the new body falls into the strip of its x at the next step)
 	w->dirtyList.push_back((int)w->bodies.size() - 1);
 	return (int)w->bodies.size() - 1;
 }
@@ -3222,6 +3269,12 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	if (rc) return rc;
 	rc = applyEditOps(w, false); // (after k_step_begin: the end events of destroyed contacts belong to this step's list)
 	if (rc) return rc;
+	if (w->spatial)
+	{
+		if (listenerOn(w) || hasFilter(w) || w->def.sub_stepping) return setError(B2HIP_ERR_UNSUPPORTED, "contact listeners, filters and sub-stepping are not supported in a spatially sharded world");
+		rc = spBeginStep(w);
+		if (rc) return rc;
+	}
 	stampPhase(w, 0);
 	// b2World.cpp:1628-1639: new fixtures -> find their contacts before colliding
 	if (w->newFixture)
@@ -3951,7 +4004,7 @@ static int solveImpl(b2hip_world* w)
 		int rc = phaseSolve(w);
 		if (rc) return rc;
 		// a connected sharded world (b2hip_shard_connect): the islands the other ranks solved arrive here, on the stream
-		if (w->shardComm != nullptr && (w->dw.shardCount > 1 || w->shardLoopback))
+		if (w->shardComm != nullptr && !w->spatial && (w->dw.shardCount > 1 || w->shardLoopback))
 		{
 			rc = shardExchangeOnStream(w);
 			if (rc) return rc;
@@ -3982,6 +4035,8 @@ static int syncFixturesImpl(b2hip_world* w)
 	{
 		int rc = phaseSyncFixtures(w);
 		if (rc) return rc;
+		// E1: what the other ranks' bodies did in Solve, and the fat AABBs their SynchronizeFixtures moved
+		if (w->spatial) { rc = spExchangeState(w, 0); if (rc) return rc; }
 	}
 	stampPhase(w, 9);
 	return 0;
@@ -4027,6 +4082,8 @@ static int solveToiImpl(b2hip_world* w)
 	{
 		int rc = phaseToi(w);
 		if (rc) return rc;
+		// E4: the other ranks' TOI events (after this rank's phase has settled: fallbacks run here, not at the step's end)
+		if (w->spatial) { rc = spAfterToi(w); if (rc) return rc; }
 	}
 	stampPhase(w, 12);
 	w->toiEventValid = true;
@@ -5091,6 +5148,381 @@ int b2hip_shard_exchange_bytes(b2hip_world* w, size_t* bytes)
 {
 	if (!w || !bytes) return setError(B2HIP_ERR_INVALID, "null argument");
 	*bytes = w->shardExchangeBytes;
+	return B2HIP_OK;
+}
+
+// ---- spatial ownership (b2d_kernels_spatial.h) ----------------------------------------------------------------------------------
+// The all-gather of `words` ints per rank from w->spSend into w->spRecv: RCCL on the world's stream when the world is
+// connected, else the caller's collective over pinned host memory.
+static int spAllGather(b2hip_world* w, size_t words)
+{
+	const int ranks = w->dw.shardCount;
+	w->spBytesStep += 4 * words * (size_t)(ranks - 1);
+	if (w->shardComm != nullptr)
+	{
+		RCCL_TRY(g_rccl.allGather(w->spSend.p, w->spRecv.p, words, ncclInt32, (ncclComm_t)w->shardComm, w->stream));
+		return 0;
+	}
+	if (!w->gatherFn) return setError(B2HIP_ERR_INVALID, "a spatially sharded world needs b2hip_shard_connect or b2hip_set_shard_gather");
+	const size_t need = words * (size_t)(ranks + 1);
+	if (w->spHostWords < need)
+	{
+		if (w->spHost) (void)hipHostFree(w->spHost);
+		w->spHost = nullptr;
+		w->spHostWords = 2 * need;
+		HIP_TRY(hipHostMalloc((void**)&w->spHost, w->spHostWords * sizeof(int), hipHostMallocDefault));
+	}
+	HIP_TRY(hipMemcpyAsync(w->spHost, w->spSend.p, words * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	if (w->gatherFn(w->gatherUser, w->spHost, words * sizeof(int), w->spHost + words) != 0) return setError(B2HIP_ERR_INVALID, "the caller's all-gather failed");
+	HIP_TRY(hipMemcpyAsync(w->spRecv.p, w->spHost + words, words * (size_t)ranks * sizeof(int), hipMemcpyHostToDevice, w->stream));
+	return 0;
+}
+
+static int spEnsureSlabs(b2hip_world* w, size_t words)
+{
+	int rc = w->spSend.ensure(words, w->stream, false, false);
+	if (rc) return rc;
+	return w->spRecv.ensure(words * (size_t)w->dw.shardCount, w->stream, false, false);
+}
+
+// the headers of all ranks' slabs, on the host (one small copy + synchronisation)
+static int spReadHeaders(b2hip_world* w, size_t strideWords, int (*hdr)[SP_HEADER_WORDS])
+{
+	for (int r = 0; r < w->dw.shardCount; ++r)
+		HIP_TRY(hipMemcpyAsync(hdr[r], w->spRecv.p + (size_t)r * strideWords, SP_HEADER_WORDS * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	return 0;
+}
+
+// E1 (mode 0, behind SynchronizeFixtures) and E4 (mode 1, behind SolveTOI). E1 is sized from the owner census every rank
+// keeps of every rank - no size exchange, nothing for the host to wait for; E4 is small (the bodies TOI events advanced) and
+// sized by a capacity every rank grows alike when any rank's header says it did not fit.
+static int spExchangeState(b2hip_world* w, int mode)
+{
+	const int ranks = w->dw.shardCount;
+	if (ranks < 2) return 0;
+	DW& d = w->dw;
+	for (int attempt = 0; attempt < 8; ++attempt)
+	{
+		int capB = 1, capP = 1;
+		if (mode == 0) for (int r = 0; r < ranks; ++r) { capB = std::max(capB, w->spOwned[r]); capP = std::max(capP, w->spOwnedProxies[r]); }
+		else { capB = w->spToiBodyCap; capP = w->spToiProxyCap; }
+		const size_t words = SP_HEADER_WORDS + (size_t)capB * SP_BODY_WORDS + (size_t)capP * SP_PROXY_WORDS;
+		int rc = spEnsureSlabs(w, words);
+		if (rc) return rc;
+		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
+		if (mode == 0 || w->toiSnapshotTaken)
+			LAUNCH(w, k_sp_export_state, gridFor(std::max(d.nBodies, d.capMoves)), 256, d, w->spSend.p, mode, capB, capP);
+		if (mode == 1)
+		{
+			// (the contacts this rank's TOI phase created: the other ranks must hear of them - header word 5)
+			HIP_TRY(hipMemcpyAsync(w->spSend.p + 5, &w->d_state.p->c.spToiCreated, sizeof(int), hipMemcpyDeviceToDevice, w->stream));
+		}
+		rc = spAllGather(w, words);
+		if (rc) return rc;
+		if (mode == 1)
+		{
+			int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
+			rc = spReadHeaders(w, words, hdr);
+			if (rc) return rc;
+			int needB = 0, needP = 0, created = 0;
+			for (int r = 0; r < ranks; ++r) { needB = std::max(needB, hdr[r][0]); needP = std::max(needP, hdr[r][1]); created += hdr[r][5]; }
+			if (created != 0)
+				return setError(B2HIP_ERR_UNSUPPORTED, "a TOI sub-step created a contact in a spatially sharded world (the ranks' contact arrays would part): not built yet");
+			if (needB > capB || needP > capP)
+			{
+				// (every rank reads the same headers and grows alike)
+				while (w->spToiBodyCap < needB) w->spToiBodyCap *= 2;
+				while (w->spToiProxyCap < needP) w->spToiProxyCap *= 2;
+				HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+				continue;
+			}
+		}
+		LAUNCH(w, k_sp_import_state, gridFor(std::max(capB, capP)), 256, d, (const int*)w->spRecv.p, words, capB);
+		return 0;
+	}
+	return setError(B2HIP_ERR_CAPACITY, "the TOI exchange of a spatially sharded world did not fit");
+}
+
+// E2: this rank's new pairs out, everybody's in (behind ours in the pair buffer; Counters::nPairs counts all of them)
+static int spExchangePairs(b2hip_world* w)
+{
+	const int ranks = w->dw.shardCount;
+	if (ranks < 2) return 0;
+	DW& d = w->dw;
+	for (int attempt = 0; attempt < 12; ++attempt)
+	{
+		const size_t words = SP_HEADER_WORDS + (size_t)w->spPairCap * SP_PAIR_WORDS;
+		int rc = spEnsureSlabs(w, words);
+		if (rc) return rc;
+		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
+		LAUNCH(w, k_sp_export_pairs, gridFor(w->spPairCap), 256, d, w->spSend.p, w->spPairCap);
+		rc = spAllGather(w, words);
+		if (rc) return rc;
+		int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
+		rc = spReadHeaders(w, words, hdr);
+		if (rc) return rc;
+		int most = 0;
+		long long total = 0;
+		for (int r = 0; r < ranks; ++r)
+		{
+			if (hdr[r][5] & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow on a rank of a spatially sharded world");
+			most = std::max(most, hdr[r][2]);
+			total += hdr[r][2];
+		}
+		if (most > w->spPairCap)
+		{
+			while (w->spPairCap < most) w->spPairCap *= 2;
+			continue;
+		}
+		if (total > (long long)d.capPairs)
+		{
+			// (the union does not fit the pair buffer: every rank grows it alike and keeps its own pairs)
+			w->pairCapHint = (size_t)total + 4096;
+			rc = ensureCapacity(w, (size_t)w->lastContacts);
+			if (rc) return rc;
+		}
+		w->spPairsSent += hdr[d.shardRank][2];
+		LAUNCH(w, k_sp_import_pairs, gridFor(w->spPairCap), 256, w->dw, (const int*)w->spRecv.p, words, w->spPairCap);
+		LAUNCH(w, k_sp_import_pairs_commit, 1, 1, w->dw, (const int*)w->spRecv.p, words, w->spPairCap);
+		return 0;
+	}
+	return setError(B2HIP_ERR_CAPACITY, "the pair exchange of a spatially sharded world did not fit");
+}
+
+// who owns how much (every rank counts every rank: the hosts size E1 from it)
+static int spOwnerCensus(b2hip_world* w)
+{
+	HIP_TRY(hipMemsetAsync(w->d_state.p->c.spBodies, 0, 2 * SHARD_MAX_RANKS * sizeof(int), w->stream));
+	LAUNCH(w, k_sp_owner_census, gridFor(w->dw.nBodies), 256, w->dw);
+	int rc = readState(w);
+	if (rc) return rc;
+	for (int r = 0; r < SHARD_MAX_RANKS; ++r) { w->spOwned[r] = w->h_dstate->c.spBodies[r]; w->spOwnedProxies[r] = w->h_dstate->c.spProxies[r]; }
+	return 0;
+}
+
+// E3. CF_FOREIGN of every contact from the owner table; contacts (and joints) that join bodies of different owners make
+// their components merge under the owner that holds most of the bodies, and the losers ship the content.
+static int spResolve(b2hip_world* w)
+{
+	const int ranks = w->dw.shardCount;
+	DW& d = w->dw;
+	for (int round = 0; round < 4; ++round)
+	{
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nStraddle, 0, 4 * sizeof(int), w->stream)); // nStraddle, nStraddleJoints, nResolve, nMigrated
+		LAUNCH(w, k_sp_flag_contacts, gridFor(d.capContacts), 256, d);
+		if (d.nJoints > 0) LAUNCH(w, k_sp_flag_joints, gridFor(d.nJoints), 256, d);
+		int rc = readState(w);
+		if (rc) return rc;
+		const Counters& c0 = w->h_dstate->c;
+		if (c0.nStraddle == 0 && c0.nStraddleJoints == 0) return 0;
+		if (ranks < 2) return setError(B2HIP_ERR_INVALID, "owners other than this rank in a world of one rank");
+		if (round == 3) break;
+		if (c0.nStraddle > d.capStraddle)
+		{
+			rc = w->spStraddle.ensure((size_t)c0.nStraddle, w->stream, false, false);
+			if (rc) return rc;
+			d.spStraddle = w->spStraddle.p;
+			d.capStraddle = (int)w->spStraddle.cap;
+			continue;
+		}
+		// components of the replicated structure (contacts between non-static bodies, joints), then the rows of those to merge
+		LAUNCH(w, k_toi_dom_init, gridFor(d.nBodies), 256, d);
+		LAUNCH(w, k_toi_dom_union, gridFor(d.capContacts), 256, d);
+		if (d.nJoints > 0) LAUNCH(w, k_sp_union_joints, gridFor(d.nJoints), 256, d);
+		LAUNCH(w, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
+		HIP_TRY(hipMemsetAsync(w->d_state.p->c.spContacts, 0, 2 * SHARD_MAX_RANKS * sizeof(int), w->stream));
+		LAUNCH(w, k_sp_resolve_mark, gridFor(c0.nStraddle + d.nJoints), 256, d);
+		LAUNCH(w, k_sp_resolve_count, gridFor(d.nBodies), 256, d);
+		LAUNCH(w, k_sp_resolve_pick, gridFor(SP_RESOLVE_MAX), 256, d);
+		LAUNCH(w, k_sp_content_census, gridFor(std::max(d.capContacts, d.nJoints)), 256, d);
+		rc = readState(w);
+		if (rc) return rc;
+		const Counters& c1 = w->h_dstate->c;
+		if (c1.overflow & 1024) return setError(B2HIP_ERR_CAPACITY, "more than 65 536 components to merge in one resolution of a spatially sharded world");
+		int capC = 1, capJ = 1;
+		for (int r = 0; r < ranks; ++r) { capC = std::max(capC, c1.spContacts[r]); capJ = std::max(capJ, c1.spJoints[r]); }
+		const size_t words = SP_HEADER_WORDS + (size_t)capC * SP_CONTENT_WORDS + (size_t)capJ * SP_JOINT_WORDS;
+		rc = spEnsureSlabs(w, words);
+		if (rc) return rc;
+		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
+		LAUNCH(w, k_sp_export_content, gridFor(std::max(d.capContacts, d.nJoints)), 256, d, w->spSend.p, capC);
+		rc = spAllGather(w, words);
+		if (rc) return rc;
+		LAUNCH(w, k_sp_apply_owners, gridFor(d.nBodies), 256, d);
+		LAUNCH(w, k_sp_import_content, gridFor(std::max(capC, capJ)), 256, d, (const int*)w->spRecv.p, words, capC);
+		LAUNCH(w, k_sp_commit_owners, gridFor(d.nBodies), 256, d);
+		rc = spOwnerCensus(w);
+		if (rc) return rc;
+		w->spMigratedTotal += w->h_dstate->c.nMigrated;
+		w->spResolves += 1;
+		w->spOwnersDirty = false;
+		w->spOwners.clear(); // (the host's copy is stale: b2hip_get_body_owners reads the device's)
+	}
+	return setError(B2HIP_ERR_INVALID, "straddling contacts remain after a resolution of a spatially sharded world");
+}
+
+// Behind SolveTOI: this rank's phase is settled here (the fallbacks b2hip_step_end would run), then E4.
+static int spAfterToi(b2hip_world* w)
+{
+	int rc = readState(w);
+	if (rc) return rc;
+	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
+	{
+		// a parallel path met an order-dependent case: back to the state before it, then the reference's serial order
+		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		rc = toiSerial(w);
+		if (rc) return rc;
+		w->toiFallbacks += 1;
+		rc = readState(w);
+		if (rc) return rc;
+	}
+	w->toiChains = false;
+	w->toiSpeculative = false;
+	if (w->h_dstate->c.overflow & 1) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step of a spatially sharded world");
+	const int created = w->h_dstate->c.nContacts - w->spContactsBeforeToi;
+	HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.spToiCreated, &created, sizeof(int), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream)); // (`created` is a local)
+	return spExchangeState(w, 1);
+}
+
+static uint8_t spStripOf(const b2hip_world* w, float x)
+{
+	int r = 0;
+	while (r + 1 < w->dw.shardCount && x >= w->spBounds[r + 1]) ++r;
+	return (uint8_t)r;
+}
+
+// The owner table reaches the device (assignment, bodies created since), and whatever straddles is resolved before Collide.
+static int spBeginStep(b2hip_world* w)
+{
+	w->spBytesStep = 0;
+	if (!w->spOwnersDirty) return 0;
+	const size_t nb = w->bodies.size();
+	if (w->spOwners.size() != nb)
+	{
+		// bodies created since the table was last known here: the device's table for the old ones, the strips for the new
+		std::vector<uint8_t> cur(nb, 0);
+		size_t covered = 0;
+		if (w->spOwners.empty())
+		{
+			covered = std::min(w->spUp, nb);
+			if (covered) HIP_TRY(hipMemcpy(cur.data(), w->b_owner.p, covered, hipMemcpyDeviceToHost));
+		}
+		else
+		{
+			covered = std::min(w->spOwners.size(), nb);
+			memcpy(cur.data(), w->spOwners.data(), covered);
+		}
+		for (size_t i = covered; i < nb; ++i) cur[i] = w->bodies[i].type == B2HIP_STATIC_BODY ? 0 : spStripOf(w, w->bodies[i].cx);
+		w->spOwners.swap(cur);
+	}
+	HIP_TRY(hipMemcpyAsync(w->b_owner.p, w->spOwners.data(), nb, hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	w->spUp = nb;
+	int rc = spOwnerCensus(w);
+	if (rc) return rc;
+	rc = spResolve(w); // (clears the host's copy if owners changed)
+	if (rc) return rc;
+	w->spOwnersDirty = false;
+	return 0;
+}
+
+int b2hip_set_shard_gather(b2hip_world* w, b2hip_all_gather_fn fn, void* user)
+{
+	if (int rcu = checkUsable(w, "b2hip_set_shard_gather", true)) return rcu;
+	w->gatherFn = fn;
+	w->gatherUser = user;
+	return B2HIP_OK;
+}
+
+int b2hip_shard_spatial(b2hip_world* w, int rank, int count, const uint8_t* owners)
+{
+	if (int rcu = checkUsable(w, "b2hip_shard_spatial", true)) return rcu;
+	if (count < 1 || count > SHARD_MAX_RANKS || rank < 0 || rank >= count) return setError(B2HIP_ERR_INVALID, "bad rank / count (at most 8 ranks)");
+	if (listenerOn(w) || hasFilter(w) || w->def.sub_stepping) return setError(B2HIP_ERR_UNSUPPORTED, "contact listeners, filters and sub-stepping are not supported in a spatially sharded world");
+	DEVICE_GUARD(w);
+	const size_t nb = w->bodies.size();
+	w->spOwners.assign(nb, 0);
+	if (owners)
+	{
+		for (size_t i = 0; i < nb; ++i)
+		{
+			if (w->bodies[i].type != B2HIP_STATIC_BODY && owners[i] >= count) return setError(B2HIP_ERR_INVALID, "owner out of range");
+			w->spOwners[i] = owners[i] < count ? owners[i] : 0;
+		}
+		for (int r = 0; r <= count; ++r) w->spBounds[r] = 0.0f;
+	}
+	else
+	{
+		// strips of equal body count along x (positions as the host knows them: the same on every rank)
+		std::vector<std::pair<float, int> > xs;
+		for (size_t i = 0; i < nb; ++i)
+		{
+			if (w->bodies[i].type == B2HIP_STATIC_BODY || w->bodies[i].dead) continue;
+			pullBody(w, (int)i);
+			xs.push_back(std::make_pair(w->bodies[i].cx, (int)i));
+		}
+		std::sort(xs.begin(), xs.end());
+		w->spBounds[0] = -3.0e38f;
+		for (int r = 1; r < count; ++r) w->spBounds[r] = xs.empty() ? 0.0f : xs[std::min(xs.size() - 1, xs.size() * (size_t)r / (size_t)count)].first;
+		for (int r = count; r <= SHARD_MAX_RANKS; ++r) w->spBounds[r] = 3.0e38f;
+		w->dw.shardCount = count;
+		for (size_t k = 0; k < xs.size(); ++k) w->spOwners[(size_t)xs[k].second] = spStripOf(w, xs[k].first);
+	}
+	w->spatial = true;
+	w->spOwnersDirty = true;
+	w->dw.shardRank = rank;
+	w->dw.shardCount = count;
+	w->spMigratedTotal = 0;
+	w->spResolves = 0;
+	w->spPairsSent = 0;
+	return B2HIP_OK;
+}
+
+int b2hip_get_body_owners(b2hip_world* w, int cap, uint8_t* owners)
+{
+	if (int rcu = checkUsable(w, "b2hip_get_body_owners", true)) return rcu;
+	if (!w->spatial || !owners) return setError(B2HIP_ERR_INVALID, "not a spatially sharded world");
+	DEVICE_GUARD(w);
+	const size_t nb = std::min((size_t)std::max(cap, 0), w->bodies.size());
+	if (w->spOwnersDirty) { memcpy(owners, w->spOwners.data(), std::min(nb, w->spOwners.size())); return (int)nb; }
+	HIP_TRY(hipMemcpy(owners, w->b_owner.p, nb, hipMemcpyDeviceToHost));
+	return (int)nb;
+}
+
+int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out)
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	memset(out, 0, sizeof(*out));
+	out->rank = w->dw.shardRank;
+	out->count = w->dw.shardCount;
+	if (!w->spatial) return B2HIP_OK;
+	out->owned_bodies = w->spOwned[w->dw.shardRank];
+	out->owned_proxies = w->spOwnedProxies[w->dw.shardRank];
+	out->islands_solved = w->last.nIslands;
+	out->constraint_rows = w->last.nSContacts + w->last.nLContacts;
+	out->migrated_bodies = w->spMigratedTotal;
+	out->resolutions = w->spResolves;
+	out->bytes_received_last_step = (int64_t)w->spBytesStep;
+	out->pairs_sent = w->spPairsSent;
+	// contacts whose content this rank maintains
+	if (!w->stepActive)
+	{
+		DEVICE_GUARD(w);
+		const int n = w->lastContacts;
+		if (n > 0)
+		{
+			std::vector<uint32_t> f((size_t)n);
+			int cur = 0;
+			HIP_TRY(hipMemcpy(&cur, &w->d_state.p->cur, sizeof(int), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(f.data(), w->c_flags[cur].p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+			int own = 0;
+			for (int i = 0; i < n; ++i) own += (f[(size_t)i] & CF_FOREIGN) ? 0 : 1;
+			out->owned_contacts = own;
+		}
+	}
 	return B2HIP_OK;
 }
 

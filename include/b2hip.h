@@ -611,6 +611,47 @@ int b2hip_shard_connect(b2hip_world* w, const void* id128, int rank, int count);
 /* bytes the last step's all-gather moved into this rank (count x stride x 4) */
 int b2hip_shard_exchange_bytes(b2hip_world* w, size_t* bytes);
 
+/* ---- ... or by SPATIAL OWNERSHIP (round 4; SURVEY.md section 8e: "persistent ownership by spatial cell -> GPU"; the reference
+ * partitions the same phases over its threads: b2CollideTask b2World.cpp:100, b2BroadphaseSyncFixturesTask :120,
+ * b2BroadphaseFindNewContactsTask :142, islands :1236-1241) -------------------------------------------------------------------
+ * Every rank builds the SAME world with the same calls; ids mean the same everywhere. Every non-static body has one OWNER.
+ * A rank evaluates manifolds, builds islands, solves, synchronises fixtures, searches pairs and runs TOI events for the
+ * bodies it owns only; what it keeps of the others is the replicated tables of section 8e (pose / velocity rows, fat AABBs)
+ * and the structure of the contact array (which contacts exist, in which order - so that every order the reference's
+ * results depend on stays the unsharded world's). Per step it receives: the rows and fat AABBs of the bodies the others
+ * moved (after Solve and after SolveTOI) and the new pairs the others found; when a new contact joins bodies of different
+ * owners, the smaller side's connected component migrates (contact and joint content is shipped once).
+ * Results are bit-identical to the unsharded world in every mode whose island solve is (reference-order tier, exact-order
+ * mode); large islands in the coloured order stay in their parity class (the block partition is a rank's own).
+ *
+ *   b2hip_shard_spatial(world, rank, count, owners): between steps, once the bodies exist. owners[b2hip_body_count] = owning
+ *     rank per body (static bodies: ignored), or NULL: strips of equal body count along x. The same on every rank.
+ *     Bodies created later fall into the strip of their x. Contacts and joints that join bodies of different owners are
+ *     resolved at the next step (the component goes to the rank that owns most of it).
+ *   the collective: b2hip_shard_connect (RCCL, as above), or b2hip_set_shard_gather: `fn(user, send, bytes, recv)` must
+ *     place every rank's `bytes` bytes at recv + rank * bytes on every rank (an all-gather over HOST memory; gloo in the
+ *     CPU tests, a thread barrier in the one-process GPU tests) and return 0.
+ *   b2hip_get_shard_stats: what this rank owns and what the exchanges moved.
+ * Not supported in a spatially sharded world (refused with B2HIP_ERR_UNSUPPORTED): contact listeners / filters, sub-stepping. */
+typedef int (*b2hip_all_gather_fn)(void* user, const void* send, size_t bytes, void* recv);
+typedef struct b2hip_shard_stats
+{
+	int32_t rank, count;
+	int32_t owned_bodies, owned_proxies;     /* non-static bodies this rank owns, and their proxies */
+	int32_t owned_contacts;                  /* contacts whose content this rank maintains (the others are structure only) */
+	int32_t islands_solved;                  /* islands of the last step (this rank's) */
+	int32_t constraint_rows;                 /* solid contacts in this rank's islands in the last step */
+	int64_t migrated_bodies;                 /* bodies that changed owner since the world was sharded */
+	int64_t resolutions;                     /* times a straddling contact / joint made components merge */
+	int64_t bytes_received_last_step;        /* all exchanges of the last step */
+	int64_t pairs_sent;                      /* new pairs this rank found and sent, since the world was sharded */
+} b2hip_shard_stats;
+int b2hip_shard_spatial(b2hip_world* w, int rank, int count, const uint8_t* owners);
+int b2hip_set_shard_gather(b2hip_world* w, b2hip_all_gather_fn fn, void* user);
+int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out);
+/* the owner table as it stands (owners[b2hip_body_count]); between steps */
+int b2hip_get_body_owners(b2hip_world* w, int cap, uint8_t* owners);
+
 /* Island label per body for the last step: -1 = not solved (asleep / static), else the smallest body id
  * of the island (island membership is compared as a set partition). */
 int b2hip_get_island_labels(b2hip_world* w, int cap, int32_t* out);

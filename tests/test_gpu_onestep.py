@@ -215,7 +215,8 @@ SCENES = {
     # steps 245 and 300 are the state bench.py times: the pile settled for 240 steps + the driver's 5 warm-up steps, and the
     # default 300th step; bounds by first step they apply from
     "pyramid141": (build_pyramid, 141, (20, 60, 130, 245, 300), True,
-                   {0: (2.2e-4, 0.05, 5.1e-3, 0.8, 1.6e-3), 240: (1.7e-4, 0.035, 3.1e-3, 0.38, 9e-4)},
+                   # (steps 21 and 61: north_star's 1e-4 of the scene scale is met and asserted as such)
+                   {0: (1.0e-4, 0.05, 5.1e-3, 0.8, 1.6e-3), 100: (2.2e-4, 0.05, 5.1e-3, 0.8, 1.6e-3), 240: (1.7e-4, 0.035, 3.1e-3, 0.38, 9e-4)},
                    {0: (0.033, 0.81), 240: (0.026, 0.46)}),
     "pyramid30_at_rest": (build_pyramid, 30, (200, 300), True, (5e-4, 9e-3, 5.1e-4, 0.021, 0.0), None),
     "tumbler2000": (build_tumbler, 2000, (40, 100), False, (8.5e-4, 0.09, 0.06, 5.6, 3e-3), None),
