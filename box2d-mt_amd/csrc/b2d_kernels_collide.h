@@ -485,6 +485,8 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.nPreSolve = 0;
 		c.nPostSolve = 0;
 		c.nFilterList = 0;
+		c.spToiCreated = 0;
+		c.spToiStraddle = 0;
 	}
 	if (t < 32) bar[t] = 0;
 }

@@ -36,6 +36,12 @@
 #define SP_JOINT_WORDS 6       // as SHARD_JOINT_WORDS
 #define SP_RESOLVE_MAX 65536   // components one resolution can merge
 
+__device__ __forceinline__ bool spSameBits(float4 a, float4 b)
+{
+	return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+		__float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
+}
+
 __device__ __forceinline__ bool spForeignBody(const DW& W, int body)
 {
 	return W.spatial && (W.b_flags[body] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[body] != (uint8_t)W.shardRank;
@@ -71,8 +77,8 @@ __global__ __launch_bounds__(256) void k_sp_flag_contacts(DW W)
 
 // ---- E1 / E4: state rows and fat AABBs --------------------------------------------------------------------------------------
 // mode 0: after Solve + SynchronizeFixtures - the bodies this rank stepped (BF_ISLAND: in an island, free bodies included) and
-// the proxies its SynchronizeFixtures moved (the move buffer); mode 1: after SolveTOI - the bodies TOI events advanced
-// (alpha0 != 0 until k_toi_clear) and all their proxies. Records carry their ids; the header their counts.
+// the proxies its SynchronizeFixtures moved (the move buffer); mode 1: after SolveTOI - the bodies and proxies this rank's TOI
+// phase changed: whatever differs from the snapshot the phase started from. Records carry their ids; the header their counts.
 __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mode, int capBodies, int capProxies)
 {
 	b2dPhaseStamp(W);
@@ -85,11 +91,22 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 		const uint32_t f = W.b_flags[i];
 		if ((f & BF_TYPE_MASK) == BT_STATIC || W.b_owner[i] != (uint8_t)W.shardRank) continue;
 		const float4 p0 = W.b_pos0[i];
-		if (mode == 0 ? (f & BF_ISLAND) == 0 : p0.w == 0.0f) continue;
-		const int k = atomicAdd(&hdr[0], 1);
-		if (k >= capBodies) { atomicOr(&S->c.overflow, 512); continue; }
-		int* o = ob + (size_t)k * SP_BODY_WORDS;
 		const float4 p = W.b_pos[i], v = W.b_vel[i], xf = W.b_xf[i];
+		if (mode == 0)
+		{
+			if ((f & BF_ISLAND) == 0) continue;
+		}
+		else
+		{
+			// what this rank's TOI phase changed: whatever differs from the snapshot the phase started from (k_toi_snapshot)
+			const float4 s0 = W.snapBody[5 * (size_t)i + 0], s1 = W.snapBody[5 * (size_t)i + 1], s2 = W.snapBody[5 * (size_t)i + 2], s3 = W.snapBody[5 * (size_t)i + 3];
+			const uint32_t sf = __float_as_uint(W.snapBody[5 * (size_t)i + 4].x);
+			const bool same = spSameBits(p, s0) && spSameBits(p0, s1) && spSameBits(v, s2) && spSameBits(xf, s3) && ((f ^ sf) & BF_AWAKE) == 0;
+			if (same) continue;
+		}
+		const int k = atomicAdd(&hdr[0], 1);
+		if (k >= capBodies) { continue; } // (the header keeps the true count: the hosts grow the slab and repeat)
+		int* o = ob + (size_t)k * SP_BODY_WORDS;
 		o[0] = i;
 		o[1] = __float_as_int(p.x); o[2] = __float_as_int(p.y); o[3] = __float_as_int(p.z); o[4] = __float_as_int(p.w);
 		o[5] = __float_as_int(p0.x); o[6] = __float_as_int(p0.y); o[7] = __float_as_int(p0.z); o[8] = __float_as_int(p0.w);
@@ -100,10 +117,11 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 		{
 			for (int q = W.b_proxyHead[i]; q >= 0; q = W.p_next[q])
 			{
-				const int kp = atomicAdd(&hdr[1], 1);
-				if (kp >= capProxies) { atomicOr(&S->c.overflow, 512); continue; }
-				int* r = op + (size_t)kp * SP_PROXY_WORDS;
 				const float4 fat = W.p_fat[q];
+				if (spSameBits(fat, W.snapFat[q])) continue;
+				const int kp = atomicAdd(&hdr[1], 1);
+				if (kp >= capProxies) { continue; }
+				int* r = op + (size_t)kp * SP_PROXY_WORDS;
 				r[0] = q;
 				r[1] = __float_as_int(fat.x); r[2] = __float_as_int(fat.y); r[3] = __float_as_int(fat.z); r[4] = __float_as_int(fat.w);
 			}
@@ -143,7 +161,8 @@ __global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, si
 			const int i = o[0];
 			if (i < 0 || i >= W.nBodies) continue;
 			W.b_pos[i] = make_float4(__int_as_float(o[1]), __int_as_float(o[2]), __int_as_float(o[3]), __int_as_float(o[4]));
-			W.b_pos0[i] = make_float4(__int_as_float(o[5]), __int_as_float(o[6]), __int_as_float(o[7]), __int_as_float(o[8]));
+			// (alpha0 = 0: what the owner's sweep holds once its step has ended - k_end_step resets the sweeps TOI events advanced)
+			W.b_pos0[i] = make_float4(__int_as_float(o[5]), __int_as_float(o[6]), __int_as_float(o[7]), 0.0f);
 			W.b_vel[i] = make_float4(__int_as_float(o[9]), __int_as_float(o[10]), __int_as_float(o[11]), 0.0f);
 			W.b_xf[i] = make_float4(__int_as_float(o[13]), __int_as_float(o[14]), __int_as_float(o[15]), __int_as_float(o[16]));
 			uint32_t f = W.b_flags[i];
@@ -504,6 +523,152 @@ __global__ __launch_bounds__(256) void k_sp_import_content(DW W, const int* in, 
 			jn.motorImpulse = __int_as_float(o[4]);
 			jn.limitState = o[5];
 		}
+	}
+}
+
+// ---- contacts created inside the TOI phases ----------------------------------------------------------------------------------
+// Every rank's event loop appended the contacts ITS events created behind the array all ranks shared when the phase began
+// (index `base` on): in the order of its own events, which is the reference's order restricted to its bodies. The reference's
+// array holds the contacts of all events in the order of the events - (alpha, proxy ids of the event's contact,
+// b2Contact::ToiLessThan), inside an event by the pair's proxy ids (b2ContactManager::FindNewContacts sorts them) - so the
+// tails are merged in that order on every rank: a rank's own contacts move (content and all), the others' are created
+// (structure only), and the TOI slots (b2Contact::m_managerIndex: AddToContactArray hands them out in creation order) are
+// dealt again in the merged order. The descriptors travel with E4: SP_TAIL_WORDS per contact.
+#define SP_TAIL_WORDS 6        // alpha bits, event key hi, lo, proxy lo, proxy hi (key order), index in the creating rank's tail
+#define SP_TAIL_MAX 4096       // contacts all ranks together may create inside one TOI phase
+
+__global__ __launch_bounds__(256) void k_sp_export_tail(DW W, int* out, int base, int capTail)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	const int n = S->c.nContacts - base;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n && k < capTail; k += gridDim.x * blockDim.x)
+	{
+		const int4 key = W.spTailKey[base + k];
+		const int4 ids = C.ids[base + k];
+		const bool swap = W.p_key[ids.x] > W.p_key[ids.y];
+		int* o = out + (size_t)k * SP_TAIL_WORDS;
+		o[0] = key.x; o[1] = key.y; o[2] = key.z;
+		o[3] = swap ? ids.y : ids.x;
+		o[4] = swap ? ids.x : ids.y;
+		o[5] = k;
+	}
+}
+
+// One workgroup. in: all ranks' slabs (header word 5 = contacts created, descriptors at `tailAt` words into the slab).
+__global__ __launch_bounds__(1024) void k_sp_merge_tails(DW W, const int* in, size_t strideWords, size_t tailAt, int base, int toiOrderBase)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	const ContactArrays& T = W.ca[1 - S->cur]; // (scratch between compactions: this rank's tail is parked here while it moves)
+	__shared__ int s_start[SHARD_MAX_RANKS + 1];
+	__shared__ int s_cand[SP_TAIL_MAX];
+	__shared__ int s_dst[SP_TAIL_MAX];
+	const int tid = (int)threadIdx.x;
+	if (tid == 0)
+	{
+		int at = 0;
+		for (int r = 0; r < W.shardCount; ++r) { s_start[r] = at; at += in[(size_t)r * strideWords + 5]; }
+		s_start[W.shardCount] = at;
+	}
+	__syncthreads();
+	const int total = s_start[W.shardCount];
+	if (total == 0) return;
+	if (total > SP_TAIL_MAX || base + total > W.capContacts) { if (tid == 0) atomicOr(&S->c.overflow, 2048); return; }
+	auto entry = [&](int e, int* r) -> const int*
+	{
+		int rr = 0;
+		while (e >= s_start[rr + 1]) ++rr;
+		*r = rr;
+		return in + (size_t)rr * strideWords + tailAt + (size_t)(e - s_start[rr]) * SP_TAIL_WORDS;
+	};
+	// park this rank's tail
+	const int mine = in[(size_t)W.shardRank * strideWords + 5];
+	for (int k = tid; k < mine; k += 1024)
+	{
+		const int i = base + k;
+		T.ids[i] = C.ids[i]; T.key[i] = C.key[i]; T.flags[i] = C.flags[i]; T.mat[i] = C.mat[i]; T.man0[i] = C.man0[i];
+		T.man1[i] = C.man1[i]; T.imp[i] = C.imp[i]; T.man3[i] = C.man3[i]; T.color[i] = C.color[i]; T.mgr[i] = C.mgr[i];
+	}
+	__syncthreads();
+	// the merged order: rank of every entry by (alpha, event key, pair key); equal keys cannot come from two ranks (an event
+	// belongs to one rank; a pair created twice would straddle, which is refused)
+	for (int e = tid; e < total; e += 1024)
+	{
+		int r;
+		const int* o = entry(e, &r);
+		const uint32_t a = (uint32_t)o[0];
+		const unsigned long long ev = ((unsigned long long)(uint32_t)o[1] << 32) | (uint32_t)o[2];
+		const unsigned long long pk = ((unsigned long long)(uint32_t)W.p_key[o[3]] << 32) | (uint32_t)W.p_key[o[4]];
+		int rank = 0;
+		for (int j = 0; j < total; ++j)
+		{
+			if (j == e) continue;
+			int rj;
+			const int* q = entry(j, &rj);
+			const uint32_t aj = (uint32_t)q[0];
+			const unsigned long long evj = ((unsigned long long)(uint32_t)q[1] << 32) | (uint32_t)q[2];
+			const unsigned long long pkj = ((unsigned long long)(uint32_t)W.p_key[q[3]] << 32) | (uint32_t)W.p_key[q[4]];
+			const bool before = aj != a ? aj < a : (evj != ev ? evj < ev : (pkj != pk ? pkj < pk : j < e));
+			if (before) ++rank;
+		}
+		s_dst[e] = rank;
+	}
+	__syncthreads();
+	for (int e = tid; e < total; e += 1024)
+	{
+		int r;
+		const int* o = entry(e, &r);
+		const int dst = base + s_dst[e];
+		int pA = o[3], pB = o[4];
+		if (b2dContactSwap(W.shapes[W.p_shape[pA]].type, W.shapes[W.p_shape[pB]].type) == 1) { const int t = pA; pA = pB; pB = t; }
+		const int bodyA = W.p_body[pA], bodyB = W.p_body[pB];
+		bool cand;
+		if (r == W.shardRank)
+		{
+			const int src = base + o[5];
+			C.ids[dst] = T.ids[src]; C.key[dst] = T.key[src]; C.flags[dst] = T.flags[src]; C.mat[dst] = T.mat[src]; C.man0[dst] = T.man0[src];
+			C.man1[dst] = T.man1[src]; C.imp[dst] = T.imp[src]; C.man3[dst] = T.man3[src]; C.color[dst] = T.color[src];
+			cand = (T.flags[src] & CF_TOI_CANDIDATE) != 0;
+		}
+		else
+		{
+			// OnContactCreate (b2ContactManager.cpp:507-564) as k_create_contacts does it; the bodies' wake-up came with their rows
+			const bool sensor = ((W.p_filter1[pA] | W.p_filter1[pB]) & PF_SENSOR) != 0;
+			cand = isToiCandidate(W, pA, pB, bodyA, bodyB);
+			const float2 mA = W.p_mat[pA], mB = W.p_mat[pB];
+			C.ids[dst] = make_int4(pA, pB, bodyA, bodyB);
+			C.key[dst] = ((uint64_t)(uint32_t)W.p_key[o[3]] << 32) | (uint32_t)W.p_key[o[4]];
+			C.flags[dst] = CF_ENABLED | (sensor ? CF_SENSOR : 0u) | (cand ? CF_TOI_CANDIDATE : 0u) | CF_FOREIGN;
+			C.mat[dst] = make_float4(b2dSqrt(mA.x * mB.x), mA.y > mB.y ? mA.y : mB.y, 0.0f, 1.0f);
+			C.man0[dst] = make_float4(0, 0, 0, 0);
+			C.man1[dst] = make_float4(0, 0, 0, 0);
+			C.imp[dst] = make_float4(0, 0, 0, 0);
+			C.man3[dst] = make_int4(0, 0, 0, 0);
+			C.color[dst] = -1;
+		}
+		C.mgr[dst] = -1;
+		s_cand[s_dst[e]] = cand ? 1 : 0;
+	}
+	__syncthreads();
+	// b2ContactManager::AddToContactArray: the new TOI candidates take the next slots in (merged) creation order
+	for (int g = tid; g < total; g += 1024)
+	{
+		if (!s_cand[g]) continue;
+		int before = 0;
+		for (int j = 0; j < g; ++j) before += s_cand[j];
+		C.mgr[base + g] = toiOrderBase + before;
+		W.toiPos2c[toiOrderBase + before] = base + g;
+	}
+	__syncthreads();
+	if (tid == 0)
+	{
+		int cands = 0;
+		for (int j = 0; j < total; ++j) cands += s_cand[j];
+		S->c.nContacts = base + total;
+		S->c.nToiOrder = toiOrderBase + cands;
 	}
 }
 

@@ -1212,6 +1212,15 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			C.ids[dst] = make_int4(pA, pB, bodyA, bodyB);
 			C.key[dst] = s_pairs[i].key;
 			C.flags[dst] = flags;
+			if (W.spatial)
+			{
+				// the event that created it: its place in the creation order of ALL ranks (b2d_kernels_spatial.h: k_sp_merge_tails)
+				const uint64_t evKey = C.key[minIdx];
+				W.spTailKey[dst] = make_int4((int)__float_as_uint(minAlpha), (int)(uint32_t)(evKey >> 32), (int)(uint32_t)evKey, 0);
+				const uint32_t tA = ldFlags(&W.b_flags[bodyA]) & BF_TYPE_MASK, tB = ldFlags(&W.b_flags[bodyB]) & BF_TYPE_MASK;
+				if ((tA != BT_STATIC && W.b_owner[bodyA] != (uint8_t)W.shardRank) || (tB != BT_STATIC && W.b_owner[bodyB] != (uint8_t)W.shardRank))
+					atomicAdd(&S->c.spToiStraddle, 1);
+			}
 			C.mat[dst] = make_float4(b2dSqrt(mA.x * mB.x), mA.y > mB.y ? mA.y : mB.y, 0.0f, 1.0f);
 			C.man0[dst] = make_float4(0, 0, 0, 0);
 			C.man1[dst] = make_float4(0, 0, 0, 0);

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 			S->c.nToiChainCreated = 0;
 			S->c.nToiLog = 0;
 			S->c.toiIncomplete = 0;
+			S->c.spToiStraddle = 0;
 			// (the serial replay of tied components may have created contacts)
 			S->c.nContacts = S->c.nContactsSnap;
 			S->c.nToiOrder = S->c.nToiOrderSnap;
@@ -780,6 +781,11 @@ __device__ __forceinline__ void toiChainsEnd(const DW& W)
 				const float2 mA = W.p_mat[pA], mB = W.p_mat[pB];
 				C.ids[dst] = make_int4(pA, pB, bodyA, bodyB);
 				C.key[dst] = pi;
+				if (W.spatial)
+				{
+					W.spTailKey[dst] = make_int4((int)ai, (int)(uint32_t)(ei >> 32), (int)(uint32_t)ei, 0);
+					if (W.b_owner[bodyA] != (uint8_t)W.shardRank || W.b_owner[bodyB] != (uint8_t)W.shardRank) atomicAdd(&S->c.spToiStraddle, 1);
+				}
 				C.flags[dst] = CF_ENABLED | (sensor ? CF_SENSOR : 0u); // (two dynamic bodies, no bullet: not a TOI candidate)
 				C.mat[dst] = make_float4(b2dSqrt(mA.x * mB.x), mA.y > mB.y ? mA.y : mB.y, 0.0f, 1.0f);
 				C.man0[dst] = make_float4(0, 0, 0, 0);

@@ -190,6 +190,7 @@ struct Counters
 	int spContacts[SHARD_MAX_RANKS], spJoints[SHARD_MAX_RANKS]; // contact / joint records every rank ships in the running resolution
 	int spBodies[SHARD_MAX_RANKS], spProxies[SHARD_MAX_RANKS];  // non-static bodies and their proxies per owner (k_sp_owner_census)
 	int spToiCreated;    // contacts this rank's TOI phase created (the tail of its contact array until the ranks have merged their tails)
+	int spToiStraddle;   // ... of them with a body of another rank (an event reached over an ownership boundary: refused)
 };
 
 // What b2ContactListener::PreSolve is told about one contact (gathered after Collide, before the compaction of destroyed
@@ -389,6 +390,8 @@ struct DW
 	int capStraddle;
 	int* spCount;        // per component under resolution: bodies per owner [SP_RESOLVE_MAX][SHARD_MAX_RANKS]
 	int* spTarget;       // per component under resolution: its new owner
+	int4* spTailKey;     // per contact created inside a TOI phase: (alpha bits, event key hi, lo, -) of the event that created it -
+	                     // the reference's creation order across ranks (k_sp_merge_tails)
 	// listener / filter bridge (include/b2hip.h: b2hip_set_contact_filter, b2hip_set_pre_solve, b2hip_enable_post_solve)
 	int userFilter;      // a user contact filter is installed: the built-in category / mask / group rule is not applied
 	int preSolveOn, postSolveOn;

@@ -257,7 +257,8 @@ struct b2hip_world
 	int spOwned[SHARD_MAX_RANKS] = {0}, spOwnedProxies[SHARD_MAX_RANKS] = {0};
 	long long spMigratedTotal = 0, spResolves = 0, spPairsSent = 0;
 	size_t spBytesStep = 0;         // bytes this rank received in the exchanges of the last step
-	int spContactsBeforeToi = 0;
+	int spContactsBeforeToi = 0, spToiOrderBefore = 0, spTailCap = 256;
+	DevArray<int4> spTailKey;
 	size_t spUp = 0;                // bodies the device's owner table covers
 	DevArray<int> scanFlags;     // status words of the single-pass scans (b2d_scan.h)
 	ScanFlags scanCtx;           // ... with their epoch and the abort word (refreshed by ensureCapacity)
@@ -858,6 +859,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
 	ENS(b_owner, w->spatial ? nb : 1); ENS(spNewOwner, w->spatial ? nb : 1); ENS(spStraddle, w->spatial ? std::max<size_t>(w->spStraddle.cap, 4096) : 1);
 	ENS(spCount, w->spatial ? (size_t)SP_RESOLVE_MAX * SHARD_MAX_RANKS : 1); ENS(spTarget, w->spatial ? SP_RESOLVE_MAX : 1);
+	ENS(spTailKey, w->spatial ? capContacts : 1);
 	ENS(stateOut, 12 * nb + sizeof(DState) / sizeof(float) + 4); // (+ the counters, behind the rows: one copy to the host per step)
 	ENS(consts, 16);
 	ENS(gridBar, 32);
@@ -941,7 +943,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.b_adoptStage = w->b_adoptStage.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p; d.blkBodyCount = w->blkBodyCount.p; d.blkBodyCursor = w->blkBodyCursor.p;
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
 	d.spatial = w->spatial ? 1 : 0; d.b_owner = w->b_owner.p; d.spNewOwner = w->spNewOwner.p; d.spStraddle = w->spStraddle.p;
-	d.capStraddle = (int)w->spStraddle.cap; d.spCount = w->spCount.p; d.spTarget = w->spTarget.p;
+	d.capStraddle = (int)w->spStraddle.cap; d.spCount = w->spCount.p; d.spTarget = w->spTarget.p; d.spTailKey = w->spTailKey.p;
 	d.userFilter = hasFilter(w) ? 1 : 0; d.preSolveOn = hasPreSolve(w) ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
 	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
 	d.preRecs = w->preRecs.p; d.postRecs = w->postRecs.p; d.filterList = w->filterList.p;
@@ -2216,6 +2218,7 @@ static int phaseToiSync(b2hip_world* w)
 	w->last.nToiCalls = w->h_dstate->c.nToiCalls;
 	w->last.nToiEvents = 0;
 	w->spContactsBeforeToi = w->h_dstate->c.nContacts;
+	w->spToiOrderBefore = w->h_dstate->c.nToiOrder;
 	// (sub-stepping: one event per call in the reference's serial order; a call that continues a step has impacts to compute
 	// even when nothing is pending yet - the event loop's first batch)
 	const bool subStepped = d.toiEventCap > 0 || d.toiContinue != 0;
@@ -5203,12 +5206,13 @@ static int spExchangeState(b2hip_world* w, int mode)
 	const int ranks = w->dw.shardCount;
 	if (ranks < 2) return 0;
 	DW& d = w->dw;
-	for (int attempt = 0; attempt < 8; ++attempt)
+	for (int attempt = 0; attempt < 12; ++attempt)
 	{
-		int capB = 1, capP = 1;
+		int capB = 1, capP = 1, capT = 0;
 		if (mode == 0) for (int r = 0; r < ranks; ++r) { capB = std::max(capB, w->spOwned[r]); capP = std::max(capP, w->spOwnedProxies[r]); }
-		else { capB = w->spToiBodyCap; capP = w->spToiProxyCap; }
-		const size_t words = SP_HEADER_WORDS + (size_t)capB * SP_BODY_WORDS + (size_t)capP * SP_PROXY_WORDS;
+		else { capB = w->spToiBodyCap; capP = w->spToiProxyCap; capT = w->spTailCap; }
+		const size_t tailAt = SP_HEADER_WORDS + (size_t)capB * SP_BODY_WORDS + (size_t)capP * SP_PROXY_WORDS;
+		const size_t words = tailAt + (size_t)capT * SP_TAIL_WORDS;
 		int rc = spEnsureSlabs(w, words);
 		if (rc) return rc;
 		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
@@ -5216,30 +5220,48 @@ static int spExchangeState(b2hip_world* w, int mode)
 			LAUNCH(w, k_sp_export_state, gridFor(std::max(d.nBodies, d.capMoves)), 256, d, w->spSend.p, mode, capB, capP);
 		if (mode == 1)
 		{
-			// (the contacts this rank's TOI phase created: the other ranks must hear of them - header word 5)
-			HIP_TRY(hipMemcpyAsync(w->spSend.p + 5, &w->d_state.p->c.spToiCreated, sizeof(int), hipMemcpyDeviceToDevice, w->stream));
+			// the contacts this rank's TOI phase created (behind the array all ranks shared when the phase began): their
+			// descriptors, for the merge of the tails; header words 5 and 6 = how many, how many of them with another rank's body
+			HIP_TRY(hipMemcpyAsync(w->spSend.p + 5, &w->d_state.p->c.spToiCreated, 2 * sizeof(int), hipMemcpyDeviceToDevice, w->stream));
+			LAUNCH(w, k_sp_export_tail, gridFor(capT), 256, d, w->spSend.p + tailAt, w->spContactsBeforeToi, capT);
 		}
 		rc = spAllGather(w, words);
 		if (rc) return rc;
+		int created = 0;
 		if (mode == 1)
 		{
 			int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
 			rc = spReadHeaders(w, words, hdr);
 			if (rc) return rc;
-			int needB = 0, needP = 0, created = 0;
-			for (int r = 0; r < ranks; ++r) { needB = std::max(needB, hdr[r][0]); needP = std::max(needP, hdr[r][1]); created += hdr[r][5]; }
-			if (created != 0)
-				return setError(B2HIP_ERR_UNSUPPORTED, "a TOI sub-step created a contact in a spatially sharded world (the ranks' contact arrays would part): not built yet");
-			if (needB > capB || needP > capP)
+			int needB = 0, needP = 0, needT = 0, straddle = 0;
+			for (int r = 0; r < ranks; ++r)
+			{
+				needB = std::max(needB, hdr[r][0]); needP = std::max(needP, hdr[r][1]); needT = std::max(needT, hdr[r][5]);
+				created += hdr[r][5];
+				straddle += hdr[r][6];
+			}
+			if (straddle != 0)
+				return setError(B2HIP_ERR_UNSUPPORTED, "a TOI sub-step of a spatially sharded world created a contact with a body of another rank (an event reached over an ownership boundary)");
+			if (created > SP_TAIL_MAX) return setError(B2HIP_ERR_CAPACITY, "more than 4 096 contacts created inside one TOI phase of a spatially sharded world");
+			if (needB > capB || needP > capP || needT > capT)
 			{
 				// (every rank reads the same headers and grows alike)
 				while (w->spToiBodyCap < needB) w->spToiBodyCap *= 2;
 				while (w->spToiProxyCap < needP) w->spToiProxyCap *= 2;
-				HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+				while (w->spTailCap < needT) w->spTailCap *= 2;
 				continue;
 			}
 		}
 		LAUNCH(w, k_sp_import_state, gridFor(std::max(capB, capP)), 256, d, (const int*)w->spRecv.p, words, capB);
+		if (created > 0)
+		{
+			rc = ensureCapacity(w, (size_t)w->spContactsBeforeToi + (size_t)created);
+			if (rc) return rc;
+			LAUNCH(w, k_sp_merge_tails, 1, 1024, w->dw, (const int*)w->spRecv.p, words, tailAt, w->spContactsBeforeToi, w->spToiOrderBefore);
+			rc = spResolve(w); // (CF_FOREIGN of the merged tail; nothing straddles - the phases would have said so)
+			if (rc) return rc;
+			if (w->h_dstate->c.overflow & 2048) return setError(B2HIP_ERR_CAPACITY, "the merge of the TOI tails of a spatially sharded world did not fit");
+		}
 		return 0;
 	}
 	return setError(B2HIP_ERR_CAPACITY, "the TOI exchange of a spatially sharded world did not fit");
@@ -5381,8 +5403,8 @@ static int spAfterToi(b2hip_world* w)
 	w->toiChains = false;
 	w->toiSpeculative = false;
 	if (w->h_dstate->c.overflow & 1) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step of a spatially sharded world");
-	const int created = w->h_dstate->c.nContacts - w->spContactsBeforeToi;
-	HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.spToiCreated, &created, sizeof(int), hipMemcpyHostToDevice, w->stream));
+	int created[2] = { w->h_dstate->c.nContacts - w->spContactsBeforeToi, w->h_dstate->c.spToiStraddle };
+	HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.spToiCreated, created, 2 * sizeof(int), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream)); // (`created` is a local)
 	return spExchangeState(w, 1);
 }

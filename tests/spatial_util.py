@@ -92,5 +92,6 @@ class SpatialRanks:
 
     def owners(self, r, n):
         out = np.zeros(n, np.uint8)
-        assert self.L.b2hip_get_body_owners(C.c_void_p(self.worlds[r][1]), n, out.ctypes.data_as(C.c_void_p)) == n
+        got = self.L.b2hip_get_body_owners(C.c_void_p(self.worlds[r][1]), n, out.ctypes.data_as(C.c_void_p))
+        assert got >= 0, self.L.b2hip_last_error()
         return out
