@@ -31,6 +31,7 @@
 #define SP_HEADER_WORDS 8      // slab header: [0] bodies, [1] proxies, [2] pairs, [3] contacts, [4] joints, [5] flags, [6..7] -
 #define SP_BODY_WORDS 17       // id, pos xyzw, pos0 xyzw, vel xyz, awake, xf xyzw
 #define SP_PROXY_WORDS 5       // id, fat AABB
+#define SP_TOI_PROXY_WORDS 9   // E4: id, fat AABB, the fat AABB the TOI phase began with (where the proxy has been: k_sp_toi_conflicts)
 #define SP_PAIR_WORDS 4        // key hi, key lo, proxy lo, proxy hi
 #define SP_CONTENT_WORDS 24    // contact index, flags, mat xyzw, man0 xyzw, man1 xyzw, imp xyzw, man3 xyzw, colour(-1), -
 #define SP_JOINT_WORDS 6       // as SHARD_JOINT_WORDS
@@ -121,9 +122,11 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 				if (spSameBits(fat, W.snapFat[q])) continue;
 				const int kp = atomicAdd(&hdr[1], 1);
 				if (kp >= capProxies) { continue; }
-				int* r = op + (size_t)kp * SP_PROXY_WORDS;
+				int* r = op + (size_t)kp * SP_TOI_PROXY_WORDS;
+				const float4 was = W.snapFat[q];
 				r[0] = q;
 				r[1] = __float_as_int(fat.x); r[2] = __float_as_int(fat.y); r[3] = __float_as_int(fat.z); r[4] = __float_as_int(fat.w);
+				r[5] = __float_as_int(was.x); r[6] = __float_as_int(was.y); r[7] = __float_as_int(was.z); r[8] = __float_as_int(was.w);
 			}
 		}
 	}
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 	}
 }
 
-__global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, size_t strideWords, int capBodies)
+__global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, size_t strideWords, int capBodies, int proxyWords)
 {
 	b2dPhaseStamp(W);
 	for (int r = 0; r < W.shardCount; ++r)
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, si
 		}
 		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nP; k += gridDim.x * blockDim.x)
 		{
-			const int* o = ip + (size_t)k * SP_PROXY_WORDS;
+			const int* o = ip + (size_t)k * proxyWords;
 			const int q = o[0];
 			if (q < 0 || q >= W.nProxies) continue;
 			W.p_fat[q] = make_float4(__int_as_float(o[1]), __int_as_float(o[2]), __int_as_float(o[3]), __int_as_float(o[4]));
@@ -303,16 +306,17 @@ __global__ __launch_bounds__(256) void k_sp_flag_joints(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_sp_resolve_mark(DW W)
+__global__ __launch_bounds__(256) void k_sp_resolve_mark(DW W, const int2* virt, int nVirt)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int n = S->c.nStraddle < W.capStraddle ? S->c.nStraddle : W.capStraddle;
-	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n + W.nJoints; k += gridDim.x * blockDim.x)
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n + W.nJoints + nVirt; k += gridDim.x * blockDim.x)
 	{
 		int body = -1;
 		if (k < n) body = C.ids[W.spStraddle[k]].z;
+		else if (k >= n + W.nJoints) body = virt[k - n - W.nJoints].x;
 		else
 		{
 			const JointRec& jn = W.joints[k - n];
@@ -554,6 +558,75 @@ __global__ __launch_bounds__(256) void k_sp_export_tail(DW W, int* out, int base
 		o[4] = swap ? ids.x : ids.y;
 		o[5] = k;
 	}
+}
+
+// A TOI event that reached over an ownership boundary (a contact created inside a sub-step with a body of another rank): the
+// phase is taken back on every rank, the components of such pairs merge as if the contact existed (the pairs are "virtual
+// edges" of the resolution: DW::spVirt), and the phase runs again - the pair then lies inside one rank.
+// ... and two proxies that events of DIFFERENT ranks moved so that they came to overlap: in the unsharded world the later of
+// the two events finds the pair and creates its contact inside the phase; here neither rank saw the other's move. Every
+// rank has every rank's E4 records, so every rank finds the same conflicts: boxes = where a proxy has been in the phase (the
+// hull of the box it began with and the one it ended with). A conflict is a virtual edge like a straddling tail contact
+// (no contact can exist between the two bodies yet: they would have one owner).
+__global__ __launch_bounds__(256) void k_sp_tail_pairs(DW W, const int* in, size_t strideWords, size_t tailAt, int capBodies, int capProxies, int2* out, int* nOut)
+{
+	b2dPhaseStamp(W);
+	{
+		// cross-rank overlaps of moved proxies: record (r, k) against every record of the ranks behind r
+		int start[SHARD_MAX_RANKS + 1];
+		int at = 0;
+		for (int r = 0; r < W.shardCount; ++r) { start[r] = at; const int n = in[(size_t)r * strideWords + 1]; at += n < capProxies ? n : capProxies; }
+		start[W.shardCount] = at;
+		const size_t proxAt = SP_HEADER_WORDS + (size_t)capBodies * SP_BODY_WORDS;
+		auto rec = [&](int e, int* r) -> const int*
+		{
+			int rr = 0;
+			while (e >= start[rr + 1]) ++rr;
+			*r = rr;
+			return in + (size_t)rr * strideWords + proxAt + (size_t)(e - start[rr]) * SP_TOI_PROXY_WORDS;
+		};
+		for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < at; e += gridDim.x * blockDim.x)
+		{
+			int re;
+			const int* a = rec(e, &re);
+			const float ax0 = fminf(__int_as_float(a[1]), __int_as_float(a[5])), ay0 = fminf(__int_as_float(a[2]), __int_as_float(a[6]));
+			const float ax1 = fmaxf(__int_as_float(a[3]), __int_as_float(a[7])), ay1 = fmaxf(__int_as_float(a[4]), __int_as_float(a[8]));
+			const int bodyA = W.p_body[a[0]];
+			for (int j = start[re + 1]; j < at; ++j)
+			{
+				int rj;
+				const int* b = rec(j, &rj);
+				const float bx0 = fminf(__int_as_float(b[1]), __int_as_float(b[5])), by0 = fminf(__int_as_float(b[2]), __int_as_float(b[6]));
+				const float bx1 = fmaxf(__int_as_float(b[3]), __int_as_float(b[7])), by1 = fmaxf(__int_as_float(b[4]), __int_as_float(b[8]));
+				// b2TestOverlap (b2Collision.h:273-286): separated iff a gap is positive
+				if (bx0 - ax1 > 0.0f || by0 - ay1 > 0.0f || ax0 - bx1 > 0.0f || ay0 - by1 > 0.0f) continue;
+				const int bodyB = W.p_body[b[0]];
+				if (bodyA == bodyB || W.b_owner[bodyA] == W.b_owner[bodyB]) continue;
+				const int k = atomicAdd(nOut, 1);
+				if (k < SP_TAIL_MAX) out[k] = make_int2(bodyA, bodyB);
+			}
+		}
+	}
+	for (int r = 0; r < W.shardCount; ++r)
+	{
+		const int* slab = in + (size_t)r * strideWords;
+		const int n = slab[5];
+		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+		{
+			const int* o = slab + tailAt + (size_t)k * SP_TAIL_WORDS;
+			const int bA = W.p_body[o[3]], bB = W.p_body[o[4]];
+			const bool nsA = (W.b_flags[bA] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[bB] & BF_TYPE_MASK) != BT_STATIC;
+			if (!nsA || !nsB || W.b_owner[bA] == W.b_owner[bB]) continue;
+			const int slot = atomicAdd(nOut, 1);
+			if (slot < SP_TAIL_MAX) out[slot] = make_int2(bA, bB);
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sp_union_virtual(DW W, const int2* pairs, int n)
+{
+	b2dPhaseStamp(W);
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) ufUnion(W.toiParent, pairs[k].x, pairs[k].y);
 }
 
 // One workgroup. in: all ranks' slabs (header word 5 = contacts created, descriptors at `tailAt` words into the slab).

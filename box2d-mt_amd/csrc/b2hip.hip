@@ -259,6 +259,8 @@ struct b2hip_world
 	size_t spBytesStep = 0;         // bytes this rank received in the exchanges of the last step
 	int spContactsBeforeToi = 0, spToiOrderBefore = 0, spTailCap = 256;
 	DevArray<int4> spTailKey;
+	DevArray<int2> spVirt;          // body pairs a TOI event would have joined over an ownership boundary (k_sp_tail_pairs)
+	long long spToiRedos = 0;
 	size_t spUp = 0;                // bodies the device's owner table covers
 	DevArray<int> scanFlags;     // status words of the single-pass scans (b2d_scan.h)
 	ScanFlags scanCtx;           // ... with their epoch and the abort word (refreshed by ensureCapacity)
@@ -859,7 +861,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
 	ENS(b_owner, w->spatial ? nb : 1); ENS(spNewOwner, w->spatial ? nb : 1); ENS(spStraddle, w->spatial ? std::max<size_t>(w->spStraddle.cap, 4096) : 1);
 	ENS(spCount, w->spatial ? (size_t)SP_RESOLVE_MAX * SHARD_MAX_RANKS : 1); ENS(spTarget, w->spatial ? SP_RESOLVE_MAX : 1);
-	ENS(spTailKey, w->spatial ? capContacts : 1);
+	ENS(spTailKey, w->spatial ? capContacts : 1); ENS(spVirt, w->spatial ? SP_TAIL_MAX + 1 : 1);
 	ENS(stateOut, 12 * nb + sizeof(DState) / sizeof(float) + 4); // (+ the counters, behind the rows: one copy to the host per step)
 	ENS(consts, 16);
 	ENS(gridBar, 32);
@@ -1316,7 +1318,7 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 // spatially sharded worlds (defined behind the RCCL section; b2d_kernels_spatial.h)
 static int spExchangeState(b2hip_world* w, int mode);
 static int spExchangePairs(b2hip_world* w);
-static int spResolve(b2hip_world* w);
+static int spResolve(b2hip_world* w, int nVirt = 0);
 static int spAfterToi(b2hip_world* w);
 static int spBeginStep(b2hip_world* w);
 
@@ -4086,7 +4088,16 @@ static int solveToiImpl(b2hip_world* w)
 		int rc = phaseToi(w);
 		if (rc) return rc;
 		// E4: the other ranks' TOI events (after this rank's phase has settled: fallbacks run here, not at the step's end)
-		if (w->spatial) { rc = spAfterToi(w); if (rc) return rc; }
+		for (int attempt = 0; w->spatial; ++attempt)
+		{
+			rc = spAfterToi(w);
+			if (rc <= 0) { if (rc) return rc; break; }
+			// (1: an event reached over an ownership boundary - the phase was taken back and the owners merged: once more)
+			if (attempt == 8) return setError(B2HIP_ERR_INVALID, "the TOI phase of a spatially sharded world keeps reaching over ownership boundaries");
+			w->toiRan = false; w->toiChains = false; w->toiSpeculative = false; w->toiSnapshotTaken = false; w->toiCountersFresh = false;
+			rc = phaseToi(w);
+			if (rc) return rc;
+		}
 	}
 	stampPhase(w, 12);
 	w->toiEventValid = true;
@@ -5211,7 +5222,8 @@ static int spExchangeState(b2hip_world* w, int mode)
 		int capB = 1, capP = 1, capT = 0;
 		if (mode == 0) for (int r = 0; r < ranks; ++r) { capB = std::max(capB, w->spOwned[r]); capP = std::max(capP, w->spOwnedProxies[r]); }
 		else { capB = w->spToiBodyCap; capP = w->spToiProxyCap; capT = w->spTailCap; }
-		const size_t tailAt = SP_HEADER_WORDS + (size_t)capB * SP_BODY_WORDS + (size_t)capP * SP_PROXY_WORDS;
+		const int proxyWords = mode == 0 ? SP_PROXY_WORDS : SP_TOI_PROXY_WORDS;
+		const size_t tailAt = SP_HEADER_WORDS + (size_t)capB * SP_BODY_WORDS + (size_t)capP * proxyWords;
 		const size_t words = tailAt + (size_t)capT * SP_TAIL_WORDS;
 		int rc = spEnsureSlabs(w, words);
 		if (rc) return rc;
@@ -5230,6 +5242,12 @@ static int spExchangeState(b2hip_world* w, int mode)
 		int created = 0;
 		if (mode == 1)
 		{
+			// what no rank could see by itself: contacts created over an ownership boundary, proxies of different ranks' events
+			// that came to overlap (k_sp_tail_pairs: every rank finds the same list in the same records)
+			HIP_TRY(hipMemsetAsync(w->spVirt.p + SP_TAIL_MAX, 0, sizeof(int), w->stream)); // (the count lives behind the pairs)
+			LAUNCH(w, k_sp_tail_pairs, gridFor(std::max(capP * ranks, capT)), 256, d, (const int*)w->spRecv.p, words, tailAt, capB, capP, w->spVirt.p, (int*)(w->spVirt.p + SP_TAIL_MAX));
+			int nVirt = 0;
+			HIP_TRY(hipMemcpyAsync(&nVirt, w->spVirt.p + SP_TAIL_MAX, sizeof(int), hipMemcpyDeviceToHost, w->stream));
 			int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
 			rc = spReadHeaders(w, words, hdr);
 			if (rc) return rc;
@@ -5240,9 +5258,6 @@ static int spExchangeState(b2hip_world* w, int mode)
 				created += hdr[r][5];
 				straddle += hdr[r][6];
 			}
-			if (straddle != 0)
-				return setError(B2HIP_ERR_UNSUPPORTED, "a TOI sub-step of a spatially sharded world created a contact with a body of another rank (an event reached over an ownership boundary)");
-			if (created > SP_TAIL_MAX) return setError(B2HIP_ERR_CAPACITY, "more than 4 096 contacts created inside one TOI phase of a spatially sharded world");
 			if (needB > capB || needP > capP || needT > capT)
 			{
 				// (every rank reads the same headers and grows alike)
@@ -5251,8 +5266,21 @@ static int spExchangeState(b2hip_world* w, int mode)
 				while (w->spTailCap < needT) w->spTailCap *= 2;
 				continue;
 			}
+			if (straddle != 0 && nVirt == 0) return setError(B2HIP_ERR_INVALID, "a rank of a spatially sharded world reported a TOI contact over an ownership boundary that no descriptor shows");
+			if (nVirt > 0)
+			{
+				// an event reached over an ownership boundary: every rank takes its phase back, the components of such pairs
+				// merge as if the contact existed, and the phase runs again (the pair lies inside one rank then)
+				if (nVirt > SP_TAIL_MAX) return setError(B2HIP_ERR_CAPACITY, "more than 4 096 TOI conflicts between the ranks of a spatially sharded world");
+				if (w->toiSnapshotTaken) LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 1);
+				rc = spResolve(w, nVirt);
+				if (rc) return rc;
+				w->spToiRedos += 1;
+				return 1;
+			}
+			if (created > SP_TAIL_MAX) return setError(B2HIP_ERR_CAPACITY, "more than 4 096 contacts created inside one TOI phase of a spatially sharded world");
 		}
-		LAUNCH(w, k_sp_import_state, gridFor(std::max(capB, capP)), 256, d, (const int*)w->spRecv.p, words, capB);
+		LAUNCH(w, k_sp_import_state, gridFor(std::max(capB, capP)), 256, d, (const int*)w->spRecv.p, words, capB, proxyWords);
 		if (created > 0)
 		{
 			rc = ensureCapacity(w, (size_t)w->spContactsBeforeToi + (size_t)created);
@@ -5326,7 +5354,7 @@ static int spOwnerCensus(b2hip_world* w)
 
 // E3. CF_FOREIGN of every contact from the owner table; contacts (and joints) that join bodies of different owners make
 // their components merge under the owner that holds most of the bodies, and the losers ship the content.
-static int spResolve(b2hip_world* w)
+static int spResolve(b2hip_world* w, int nVirt)
 {
 	const int ranks = w->dw.shardCount;
 	DW& d = w->dw;
@@ -5338,7 +5366,7 @@ static int spResolve(b2hip_world* w)
 		int rc = readState(w);
 		if (rc) return rc;
 		const Counters& c0 = w->h_dstate->c;
-		if (c0.nStraddle == 0 && c0.nStraddleJoints == 0) return 0;
+		if (c0.nStraddle == 0 && c0.nStraddleJoints == 0 && nVirt == 0) return 0;
 		if (ranks < 2) return setError(B2HIP_ERR_INVALID, "owners other than this rank in a world of one rank");
 		if (round == 3) break;
 		if (c0.nStraddle > d.capStraddle)
@@ -5353,9 +5381,11 @@ static int spResolve(b2hip_world* w)
 		LAUNCH(w, k_toi_dom_init, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_toi_dom_union, gridFor(d.capContacts), 256, d);
 		if (d.nJoints > 0) LAUNCH(w, k_sp_union_joints, gridFor(d.nJoints), 256, d);
+		if (nVirt > 0) LAUNCH(w, k_sp_union_virtual, gridFor(nVirt), 256, d, (const int2*)w->spVirt.p, nVirt);
 		LAUNCH(w, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
 		HIP_TRY(hipMemsetAsync(w->d_state.p->c.spContacts, 0, 2 * SHARD_MAX_RANKS * sizeof(int), w->stream));
-		LAUNCH(w, k_sp_resolve_mark, gridFor(c0.nStraddle + d.nJoints), 256, d);
+		LAUNCH(w, k_sp_resolve_mark, gridFor(c0.nStraddle + d.nJoints + nVirt), 256, d, (const int2*)w->spVirt.p, nVirt);
+		nVirt = 0; // (merged now: the rounds after this one look at real contacts and joints only)
 		LAUNCH(w, k_sp_resolve_count, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_sp_resolve_pick, gridFor(SP_RESOLVE_MAX), 256, d);
 		LAUNCH(w, k_sp_content_census, gridFor(std::max(d.capContacts, d.nJoints)), 256, d);
@@ -5529,6 +5559,7 @@ int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out)
 	out->resolutions = w->spResolves;
 	out->bytes_received_last_step = (int64_t)w->spBytesStep;
 	out->pairs_sent = w->spPairsSent;
+	out->toi_redos = w->spToiRedos;
 	// contacts whose content this rank maintains
 	if (!w->stepActive)
 	{

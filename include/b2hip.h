@@ -645,6 +645,7 @@ typedef struct b2hip_shard_stats
 	int64_t resolutions;                     /* times a straddling contact / joint made components merge */
 	int64_t bytes_received_last_step;        /* all exchanges of the last step */
 	int64_t pairs_sent;                      /* new pairs this rank found and sent, since the world was sharded */
+	int64_t toi_redos;                       /* TOI phases run again because an event reached over an ownership boundary */
 } b2hip_shard_stats;
 int b2hip_shard_spatial(b2hip_world* w, int rank, int count, const uint8_t* owners);
 int b2hip_set_shard_gather(b2hip_world* w, b2hip_all_gather_fn fn, void* user);

@@ -14,7 +14,7 @@ class ShardStats(C.Structure):
     _fields_ = [("rank", C.c_int32), ("count", C.c_int32), ("owned_bodies", C.c_int32), ("owned_proxies", C.c_int32),
                 ("owned_contacts", C.c_int32), ("islands_solved", C.c_int32), ("constraint_rows", C.c_int32), ("pad", C.c_int32),
                 ("migrated_bodies", C.c_int64), ("resolutions", C.c_int64), ("bytes_received_last_step", C.c_int64),
-                ("pairs_sent", C.c_int64)]
+                ("pairs_sent", C.c_int64), ("toi_redos", C.c_int64)]
 
 
 class ThreadGather:

@@ -1,0 +1,123 @@
+"""One world over N ranks by SPATIAL OWNERSHIP (include/b2hip.h: b2hip_shard_spatial; box2d-mt_amd/csrc/b2d_kernels_spatial.h)
+against the unsharded world, on the GPU: N ranks in ONE process (one world per rank on the same device, one thread per
+rank, an all-gather over host memory: tests/spatial_util.py). The multi-process form of the same protocol runs over gloo
+on the CPU (tests/test_spatial_gloo.py, on the oracle's shim).
+
+What is pinned:
+  * every rank's copy of EVERY body equals the unsharded world bit for bit after every step, contact counts included -
+    fields of free bodies with bullets (continuous physics on: TOI events, contacts created inside sub-steps and merged over
+    the ranks, components migrating over strip boundaries), piles, rain, jointed vehicles, four pyramids (one per rank) in
+    exact-order mode;
+  * what a rank owns and maintains is its share: bodies, contacts with content, constraint rows ~ 1 / N;
+  * an event that reaches over an ownership boundary is caught and the phase redone (the dense bullets scene).
+Reference: the reference guarantees results independent of the worker count (README.md:161-175, TestMT.cpp:91-110); its own
+partition of these phases: b2World.cpp:100-160, 1236-1241.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import b2harness as bh
+import b2hip
+from spatial_util import SpatialRanks
+
+pytestmark = pytest.mark.gpu
+
+CCD = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
+PLAIN = bh.F_SLEEP | bh.F_WARM
+
+
+def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, seed=3, compare=True):
+    if exact:
+        monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    else:
+        monkeypatch.delenv("B2HIP_FORCE_LARGE", raising=False)
+    L = b2hip.lib()
+    ref = amd.world(scene, p0, p1, seed=seed, flags=flags)
+    ws = [amd.world(scene, p0, p1, seed=seed, flags=flags) for _ in range(ranks)]
+    sr = SpatialRanks(L, [(w, w.device_world()) for w in ws])
+    for s in range(steps):
+        ref.step(1)
+        sr.step()
+        rb = ref.bodies().view(np.uint32)
+        first = ws[0].bodies().view(np.uint32)
+        for r, w in enumerate(ws):
+            wb = w.bodies().view(np.uint32)
+            assert w.contact_count == ref.contact_count, "step %d rank %d: %d contacts, the unsharded world has %d" % (s + 1, r, w.contact_count, ref.contact_count)
+            assert np.array_equal(wb, first), "step %d: rank %d and rank 0 hold different worlds" % (s + 1, r)
+            if compare:
+                bad = np.nonzero((wb != rb).any(axis=1))[0]
+                assert bad.size == 0, "step %d rank %d: %d bodies differ from the unsharded world (first %s)" % (s + 1, r, bad.size, bad[:8].tolist())
+    stats = [sr.stats(r) for r in range(ranks)]
+    nonstatic = int((ref.bodies()[:, 7] != 0).sum())
+    contacts = ref.contact_count
+    for w in ws:
+        w.close()
+    ref.close()
+    return stats, nonstatic, contacts, sr
+
+
+@pytest.mark.parametrize("name,scene,p0,p1,ranks,steps,flags,exact", [
+    ("field with bullets, 2 ranks", bh.FIELD, 3000, 300, 2, 80, CCD, False),
+    ("field with bullets, 4 ranks", bh.FIELD, 3000, 300, 4, 80, CCD, False),
+    ("field 20 000 / 2 000 bullets, 4 ranks", bh.FIELD, 20000, 2000, 4, 30, CCD, False),
+    ("4 pyramids, 2 ranks, exact order", bh.PYRAMID, 20, 4, 2, 100, CCD, True),
+    ("4 pyramids, 4 ranks, exact order", bh.PYRAMID, 20, 4, 4, 100, CCD, True),
+    ("rain, 3 ranks", bh.RAIN, 800, 0, 3, 200, CCD, False),
+    ("piles, 4 ranks", bh.PILES, 100, 8, 4, 150, CCD, False),
+    ("vehicles (wheel / rope / motor / mouse joints), 2 ranks", bh.VEHICLES, 30, 2, 2, 150, CCD, False),
+    ("machines (prismatic / weld / gear / pulley joints), 2 ranks", bh.MACHINES, 30, 3, 2, 120, CCD, False),
+    ("tumbler (hub body + motor joint: one component), 2 ranks", bh.TUMBLER, 20, 0, 2, 80, PLAIN, False),
+])
+def test_sharded_world_is_the_unsharded_world_bit_for_bit(amd, monkeypatch, name, scene, p0, p1, ranks, steps, flags, exact):
+    stats, nonstatic, contacts, _ = run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch)
+    assert sum(st.owned_bodies for st in stats) == nonstatic, "every non-static body has exactly one owner"
+    assert sum(st.owned_contacts for st in stats) <= contacts  # (a contact between two static-only ... has none; the rest one)
+
+
+def test_an_event_over_an_ownership_boundary_is_caught_and_the_phase_redone(amd, monkeypatch):
+    """A dense box of bullets: TOI sub-steps create contacts with bodies of the other rank. Every rank takes its phase back,
+    the components merge as if the contact existed, the phase runs again (b2hip.hip: spExchangeState) - same bits."""
+    stats, _, _, _ = run_sharded(amd, bh.BULLETS, 60, 6, 2, 120, CCD, False, monkeypatch)
+    assert stats[0].toi_redos >= 1, "the scene no longer reaches over a boundary: the test is vacuous"
+
+
+def test_a_rank_holds_and_solves_its_share(amd, monkeypatch):
+    """Work and content per rank ~ 1 / N (b2hip_get_shard_stats): a field of 20 000 free bodies over 4 ranks, and 4 pyramids
+    over 4 ranks. (The id tables - body rows, fat AABBs, the structure of the contact array - are replicated, as SURVEY
+    section 8e prescribes: every order the results depend on stays the unsharded world's.)"""
+    stats, nonstatic, contacts, _ = run_sharded(amd, bh.FIELD, 20000, 2000, 4, 30, CCD, False, monkeypatch)
+    for st in stats:
+        assert 0.8 * nonstatic / 4 <= st.owned_bodies <= 1.2 * nonstatic / 4, "rank %d owns %d of %d bodies" % (st.rank, st.owned_bodies, nonstatic)
+        assert st.owned_contacts <= 0.4 * contacts, "rank %d maintains %d of %d contacts" % (st.rank, st.owned_contacts, contacts)
+        assert st.islands_solved <= 0.3 * nonstatic
+    stats, nonstatic, contacts, _ = run_sharded(amd, bh.PYRAMID, 20, 4, 4, 60, CCD, True, monkeypatch)
+    for st in stats:
+        assert st.owned_bodies == 210 and st.islands_solved == 1, "one pyramid per rank (rank %d: %d bodies, %d islands)" % (st.rank, st.owned_bodies, st.islands_solved)
+        assert st.owned_contacts <= 0.26 * contacts
+        assert st.migrated_bodies == 0
+
+
+def test_default_mode_large_islands_stay_in_their_parity_class(amd, monkeypatch):
+    """Four pyramids of 40 rows over 4 ranks in the DEFAULT mode: each pile is a large island, solved in the coloured order,
+    whose block partition is the owning rank's own - the same parity class as the unsharded world (tests/test_gpu_onestep.py),
+    not the same bits. Pinned: all ranks hold the same world, contact counts follow the unsharded world's, the piles stand."""
+    monkeypatch.delenv("B2HIP_FORCE_LARGE", raising=False)
+    L = b2hip.lib()
+    ref = amd.world(bh.PYRAMID, 40, 4, seed=3, flags=CCD)
+    ws = [amd.world(bh.PYRAMID, 40, 4, seed=3, flags=CCD) for _ in range(4)]
+    sr = SpatialRanks(L, [(w, w.device_world()) for w in ws])
+    for s in range(150):
+        ref.step(1)
+        sr.step()
+        first = ws[0].bodies().view(np.uint32)
+        for w in ws[1:]:
+            assert np.array_equal(w.bodies().view(np.uint32), first), "step %d: the ranks hold different worlds" % (s + 1)
+        assert abs(ws[0].contact_count - ref.contact_count) <= 0.01 * ref.contact_count + 4
+    a, b = ws[0].bodies(), ref.bodies()
+    scale = np.abs(b[:, :2]).max()
+    assert np.isfinite(a).all() and np.abs(a[:, :2] - b[:, :2]).max() / scale < 2e-2
+    for w in ws:
+        w.close()
+    ref.close()

@@ -41,5 +41,5 @@ print("%s %d %d over %d ranks, %d steps (%s%s): %s in %.1f s; gathers %d, %.2f M
       "BITWISE EQUAL to the unsharded world on every rank" if bad is None else "MISMATCH at step %d" % bad, time.time() - t0, sr.gather.calls, sr.gather.bytes / 1e6))
 for r in range(ranks):
     st = sr.stats(r)
-    print("  rank %d: owns %d bodies %d proxies %d contacts; islands %d rows %d; migrated %d in %d resolutions; pairs sent %d; %.1f KB received last step" % (
-        r, st.owned_bodies, st.owned_proxies, st.owned_contacts, st.islands_solved, st.constraint_rows, st.migrated_bodies, st.resolutions, st.pairs_sent, st.bytes_received_last_step / 1e3))
+    print("  rank %d: owns %d bodies %d proxies %d contacts; islands %d rows %d; migrated %d in %d resolutions; pairs sent %d; TOI phases redone %d; %.1f KB received last step" % (
+        r, st.owned_bodies, st.owned_proxies, st.owned_contacts, st.islands_solved, st.constraint_rows, st.migrated_bodies, st.resolutions, st.pairs_sent, st.toi_redos, st.bytes_received_last_step / 1e3))
