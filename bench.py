@@ -108,6 +108,22 @@ def attach_committed_traffic(roof, workload_key):
         roof["traffic_GBps"] = hit[0] / (1e-6 * roof["mean_launch_us"]) / 1e9
 
 
+class _ShardStats(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("count", C.c_int32), ("owned_bodies", C.c_int32), ("owned_proxies", C.c_int32),
+                ("owned_contacts", C.c_int32), ("islands_solved", C.c_int32), ("constraint_rows", C.c_int32), ("pad", C.c_int32),
+                ("migrated_bodies", C.c_int64), ("resolutions", C.c_int64), ("bytes_received_last_step", C.c_int64),
+                ("pairs_sent", C.c_int64), ("toi_redos", C.c_int64)]
+
+
+def shard_stats(hipL, dev):
+    """b2hip_get_shard_stats of a spatially sharded world, as a dict"""
+    st = _ShardStats()
+    hipL.b2hip_get_shard_stats.argtypes = [C.c_void_p, C.POINTER(_ShardStats)]
+    if hipL.b2hip_get_shard_stats(dev, C.byref(st)) != 0:
+        return None
+    return {n: int(getattr(st, n)) for n, _ in _ShardStats._fields_ if n != "pad"}
+
+
 def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, roof_mode, workload_key, seed=3):
     """One of the other BASELINE configs on this GPU, short: settle (the window is stated in the entry), then `steps` timed
     steps (read-back included), then a roofline pass over the configuration's dominant bandwidth kernel."""
@@ -278,8 +294,15 @@ def main():
         raw = _Raw()
         raw.p = C.c_void_p(w.device_world())
         raw.L = hipL
-        sharded = sharding.ShardedWorld(raw, dist=dist, device=torch.device("cuda", local_rank))
-        if dist.get_backend() == "nccl":
+        if os.environ.get("B2_BENCH_SHARD", "spatial") == "spatial":
+            # round 4: spatial ownership (include/b2hip.h: b2hip_shard_spatial) - rank r owns the bodies of strip r along x
+            # (= pyramid r), evaluates, solves and moves those only; the library exchanges rows / pairs inside b2hip_step over
+            # its own RCCL communicator (gloo: an all-gather of host memory). B2_BENCH_SHARD=island: round 3's replicated form.
+            sharded = sharding.SpatialWorld(raw, dist=dist, device=torch.device("cuda", local_rank))
+            sharded.exchange_bytes = 0
+        else:
+            sharded = sharding.ShardedWorld(raw, dist=dist, device=torch.device("cuda", local_rank))
+        if isinstance(sharded, sharding.ShardedWorld) and dist.get_backend() == "nccl":
             # the library's own RCCL communicator on the world's stream; if it cannot be had (librccl not found ...) - on every
             # rank alike - the exchange falls back to torch.distributed's all-gather between the phase calls
             ok = torch.ones(1, dtype=torch.int32, device="cuda")
@@ -441,9 +464,13 @@ def main():
                 raw4 = _Raw()
                 raw4.p = C.c_void_p(w4.device_world())
                 raw4.L = hipL
-                s4 = sharding.ShardedWorld(raw4, dist=dist, device=torch.device("cuda", local_rank))
-                if dist.get_backend() == "nccl":
-                    s4.connect_rccl()
+                if isinstance(sharded, sharding.SpatialWorld):
+                    s4 = sharding.SpatialWorld(raw4, dist=dist, device=torch.device("cuda", local_rank))
+                    s4.exchange_bytes = 0
+                else:
+                    s4 = sharding.ShardedWorld(raw4, dist=dist, device=torch.device("cuda", local_rank))
+                    if dist.get_backend() == "nccl":
+                        s4.connect_rccl()
                 for _ in range(60):
                     s4.step(1.0 / 60.0, w4.vel_iters, w4.pos_iters)
                 barrier()
@@ -454,7 +481,8 @@ def main():
                 el = torch.tensor([time.perf_counter() - t4], dtype=torch.float64, device="cuda")
                 dist.all_reduce(el, op=dist.ReduceOp.MAX)
                 ms = 1000.0 * float(el.item()) / 20
-                extras.append({"workload": "config 4: %d disjoint pyramids of 316 rows (50 086 boxes each) in one world sharded by island over %d GPUs, CCD on" % (world_size, world_size),
+                extras.append({"workload": "config 4: %d disjoint pyramids of 316 rows (50 086 boxes each) in one world sharded %s over %d GPUs, CCD on" % (world_size, "by spatial ownership" if isinstance(s4, sharding.SpatialWorld) else "by island", world_size),
+                               "shard_stats_rank0": shard_stats(hipL, raw4.p),
                                "bodies": w4.body_count, "settle_steps": 60, "timed_steps": 20, "ms_per_step": ms,
                                "world_steps_per_s": 1000.0 / ms, "island_steps_per_s_all_ranks": world_size * 1000.0 / ms,
                                "exchange_bytes_per_step": s4.exchange_bytes})
@@ -482,6 +510,11 @@ def main():
 
     contacts = w.contact_count
     gather_ms = None
+    spatial_stats = None
+    if sharded is not None:
+        import sharding as _sh
+        if isinstance(sharded, _sh.SpatialWorld):
+            spatial_stats = shard_stats(hipL, C.c_void_p(w.device_world()))
     exchange_bytes = sharded.exchange_bytes if sharded is not None else 0
     w.close()
 
@@ -520,7 +553,11 @@ def main():
                              "ms_per_step_max": float(settle_ms.max())}
         if extras is not None:
             line["extra_configs"] = extras
-        if sharded is not None:
+        if sharded is not None and spatial_stats is not None:
+            line["sharding"] = "spatial ownership (b2hip_shard_spatial): a rank evaluates, solves and moves the bodies of its strip; rows / fat AABBs of moved bodies, new pairs and migrating components travel by all-gather " + ("over the library's own RCCL communicator on the world's stream" if sharded.connected else "over torch.distributed (host memory)") + ", inside the timed region"
+            line["shard_stats_rank0"] = spatial_stats
+            line["exchange_bytes_per_step"] = spatial_stats["bytes_received_last_step"]
+        elif sharded is not None:
             line["exchange_bytes_per_step"] = exchange_bytes
             line["exchange"] = ("one all-gather per step of owner-sized slabs (records of the islands each rank solved), " +
                                 ("RCCL on the world's stream from inside the library" if sharded.connected else "torch.distributed between the phase calls (the library's own RCCL connection could not be made)") +

@@ -97,3 +97,66 @@ class ShardedWorld:
         self._check(L.b2hip_find_new_contacts(p))
         self._check(L.b2hip_solve_toi(p))
         self._check(L.b2hip_step_end(p))
+
+
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class SpatialWorld:
+    """One world over the ranks of torch.distributed by SPATIAL OWNERSHIP (include/b2hip.h: b2hip_shard_spatial;
+    box2d-mt_amd/csrc/b2d_kernels_spatial.h): every rank builds the same world, owns the bodies of its strip along x, and
+    evaluates / solves / moves those only; the library exchanges what the others need inside b2hip_step - over RCCL on the
+    world's own stream (`nccl` backend: b2hip_shard_connect), or through an all-gather of host memory that this class hands
+    it (`gloo`: the CPU tests over the oracle's shim, functional runs of several ranks on one GPU)."""
+
+    def __init__(self, world, dist, owners=None, device="cpu"):
+        self.w = world
+        self.L = world.L
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.size = dist.get_world_size() if dist is not None else 1
+        L = self.L
+        L.b2hip_shard_spatial.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.b2hip_set_shard_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.connected = False
+        self.gathers = 0
+        self.gather_bytes = 0
+        if dist is not None and self.size > 1 and dist.get_backend() == "nccl":
+            s = ShardedWorld.__new__(ShardedWorld)  # (only for its RCCL hand-shake: rank 0's id broadcast, every rank connects)
+            s.w, s.L, s.dist, s.device, s.rank, s.size, s.connected = world, L, dist, device, self.rank, self.size, False
+            s.connect_rccl()
+            self.connected = True
+        else:
+            self._cb = GATHER_FN(self._gather)
+            rc = L.b2hip_set_shard_gather(world.p, C.cast(self._cb, C.c_void_p), None)
+            if rc < 0:
+                raise RuntimeError("b2hip error %d: %s" % (rc, L.b2hip_last_error().decode()))
+        own = None
+        if owners is not None:
+            import numpy as np
+            self._owners = np.ascontiguousarray(owners, np.uint8)
+            own = self._owners.ctypes.data_as(C.c_void_p)
+        rc = L.b2hip_shard_spatial(world.p, self.rank, self.size, own)
+        if rc < 0:
+            raise RuntimeError("b2hip error %d: %s" % (rc, L.b2hip_last_error().decode()))
+
+    def _gather(self, user, send, nbytes, recv):
+        import numpy as np
+        import torch
+        try:
+            self.gathers += 1
+            self.gather_bytes += nbytes * self.size
+            src = torch.from_numpy(np.ctypeslib.as_array((C.c_ubyte * nbytes).from_address(send)))
+            dst = torch.from_numpy(np.ctypeslib.as_array((C.c_ubyte * (nbytes * self.size)).from_address(recv)))
+            if self.dist is None or self.size == 1:
+                dst[:nbytes] = src
+            else:
+                self.dist.all_gather_into_tensor(dst, src)
+            return 0
+        except Exception:  # noqa: BLE001 (reported by the library as a failed collective)
+            return 1
+
+    def step(self, dt=1.0 / 60.0, vel_iters=8, pos_iters=3):
+        rc = self.L.b2hip_step(self.w.p, C.c_float(dt), vel_iters, pos_iters)
+        if rc < 0:
+            raise RuntimeError("b2hip error %d: %s" % (rc, self.L.b2hip_last_error().decode()))
