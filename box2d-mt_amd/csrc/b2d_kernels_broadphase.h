@@ -686,6 +686,13 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 			o[9] = p.w;
 		}
 		if (!storeRows) continue; // (uniform over the workgroup: every lane leaves the tile before its barriers)
+		// a spatially sharded world with the lean exchange: the rows of another rank's bodies are not kept up to date here -
+		// a tile that holds none of ours stays as it is in the host's buffer (b2d_kernels_spatial.h)
+		if (W.spatial && !W.spFullRows)
+		{
+			const bool mine = i < n && ((W.b_flags[i] & BF_TYPE_MASK) == BT_STATIC || W.b_owner[i] == (uint8_t)W.shardRank);
+			if (!__syncthreads_or(mine ? 1 : 0)) continue;
+		}
 		__syncthreads();
 		const int cnt = (n - base < 256 ? n - base : 256) * 10; // floats of this tile; base * 40 bytes is 16-byte aligned
 		float* dst = out + (size_t)base * 10;

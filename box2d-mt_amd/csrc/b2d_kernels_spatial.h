@@ -93,9 +93,13 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 		if ((f & BF_TYPE_MASK) == BT_STATIC || W.b_owner[i] != (uint8_t)W.shardRank) continue;
 		const float4 p0 = W.b_pos0[i];
 		const float4 p = W.b_pos[i], v = W.b_vel[i], xf = W.b_xf[i];
+		const uint8_t awakeNow = (f & BF_AWAKE) ? 1 : 0;
+		bool rowDue = true;
 		if (mode == 0)
 		{
 			if ((f & BF_ISLAND) == 0) continue;
+			// lean: the others' work needs this body's awake bit (the Collide rule for their copies of our contacts), not its row
+			rowDue = W.spFullRows || awakeNow != W.spAwake[i];
 		}
 		else
 		{
@@ -104,9 +108,12 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 			const uint32_t sf = __float_as_uint(W.snapBody[5 * (size_t)i + 4].x);
 			const bool same = spSameBits(p, s0) && spSameBits(p0, s1) && spSameBits(v, s2) && spSameBits(xf, s3) && ((f ^ sf) & BF_AWAKE) == 0;
 			if (same) continue;
+			rowDue = W.spFullRows || awakeNow != W.spAwake[i];
 		}
+		if (rowDue)
+		{
 		const int k = atomicAdd(&hdr[0], 1);
-		if (k >= capBodies) { continue; } // (the header keeps the true count: the hosts grow the slab and repeat)
+		if (k < capBodies) { // (the header keeps the true count: the hosts grow the slab and repeat; k_sp_mark_sent when it has arrived)
 		int* o = ob + (size_t)k * SP_BODY_WORDS;
 		o[0] = i;
 		o[1] = __float_as_int(p.x); o[2] = __float_as_int(p.y); o[3] = __float_as_int(p.z); o[4] = __float_as_int(p.w);
@@ -114,6 +121,8 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 		o[9] = __float_as_int(v.x); o[10] = __float_as_int(v.y); o[11] = __float_as_int(v.z);
 		o[12] = (f & BF_AWAKE) ? 1 : 0;
 		o[13] = __float_as_int(xf.x); o[14] = __float_as_int(xf.y); o[15] = __float_as_int(xf.z); o[16] = __float_as_int(xf.w);
+		}
+		}
 		if (mode == 1)
 		{
 			for (int q = W.b_proxyHead[i]; q >= 0; q = W.p_next[q])
@@ -148,6 +157,18 @@ __global__ __launch_bounds__(256) void k_sp_export_state(DW W, int* out, int mod
 	}
 }
 
+// (behind an exchange that fitted: the other ranks hold the awake bit of every body this rank owns)
+__global__ __launch_bounds__(256) void k_sp_mark_sent(DW W)
+{
+	b2dPhaseStamp(W);
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		const uint32_t f = W.b_flags[i];
+		if ((f & BF_TYPE_MASK) == BT_STATIC || W.b_owner[i] != (uint8_t)W.shardRank) continue;
+		W.spAwake[i] = (f & BF_AWAKE) ? 1 : 0;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, size_t strideWords, int capBodies, int proxyWords)
 {
 	b2dPhaseStamp(W);
@@ -177,6 +198,7 @@ __global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, si
 				W.b_force[i] = make_float4(0, 0, 0, 0);
 			}
 			W.b_flags[i] = f;
+			W.spAwake[i] = o[12] ? 1 : 0;
 		}
 		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nP; k += gridDim.x * blockDim.x)
 		{
@@ -403,9 +425,16 @@ __global__ __launch_bounds__(256) void k_sp_content_census(DW W)
 		const int from = W.b_owner[body];
 		if (spNewOwner(W, body) != from) atomicAdd(&S->c.spJoints[from], 1);
 	}
+	// (the rows of the bodies that leave a rank: with the lean exchange nobody else holds them)
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		if ((W.b_flags[i] & BF_TYPE_MASK) == BT_STATIC) continue;
+		const int from = W.b_owner[i];
+		if (spNewOwner(W, i) != from) atomicAdd(&S->c.spMigBodies[from], 1);
+	}
 }
 
-__global__ __launch_bounds__(256) void k_sp_export_content(DW W, int* out, int capContacts)
+__global__ __launch_bounds__(256) void k_sp_export_content(DW W, int* out, int capContacts, int capJoints)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -414,6 +443,21 @@ __global__ __launch_bounds__(256) void k_sp_export_content(DW W, int* out, int c
 	const int me = W.shardRank;
 	int* oc = out + SP_HEADER_WORDS;
 	int* oj = oc + (size_t)capContacts * SP_CONTENT_WORDS;
+	int* ob = oj + (size_t)capJoints * SP_JOINT_WORDS;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		const uint32_t f = W.b_flags[i];
+		if ((f & BF_TYPE_MASK) == BT_STATIC || W.b_owner[i] != me || spNewOwner(W, i) == me) continue;
+		const int k = atomicAdd(&out[0], 1);
+		int* o = ob + (size_t)k * SP_BODY_WORDS;
+		const float4 p = W.b_pos[i], p0 = W.b_pos0[i], v = W.b_vel[i], xf = W.b_xf[i];
+		o[0] = i;
+		o[1] = __float_as_int(p.x); o[2] = __float_as_int(p.y); o[3] = __float_as_int(p.z); o[4] = __float_as_int(p.w);
+		o[5] = __float_as_int(p0.x); o[6] = __float_as_int(p0.y); o[7] = __float_as_int(p0.z); o[8] = __float_as_int(p0.w);
+		o[9] = __float_as_int(v.x); o[10] = __float_as_int(v.y); o[11] = __float_as_int(v.z);
+		o[12] = (f & BF_AWAKE) ? 1 : 0;
+		o[13] = __float_as_int(xf.x); o[14] = __float_as_int(xf.y); o[15] = __float_as_int(xf.z); o[16] = __float_as_int(xf.w);
+	}
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		const int4 ids = C.ids[i];
@@ -488,7 +532,7 @@ __global__ __launch_bounds__(256) void k_sp_commit_owners(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_sp_import_content(DW W, const int* in, size_t strideWords, int capContacts)
+__global__ __launch_bounds__(256) void k_sp_import_content(DW W, const int* in, size_t strideWords, int capContacts, int capJoints)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -497,9 +541,26 @@ __global__ __launch_bounds__(256) void k_sp_import_content(DW W, const int* in, 
 	{
 		if (r == W.shardRank) continue;
 		const int* slab = in + (size_t)r * strideWords;
-		const int nC = slab[3] < capContacts ? slab[3] : capContacts, nJ = slab[4];
+		const int nC = slab[3] < capContacts ? slab[3] : capContacts, nJ = slab[4], nB = slab[0];
 		const int* ic = slab + SP_HEADER_WORDS;
 		const int* ij = ic + (size_t)capContacts * SP_CONTENT_WORDS;
+		const int* ib = ij + (size_t)capJoints * SP_JOINT_WORDS;
+		// the rows of the bodies that changed owner (every rank takes them: whoever gains the body needs them, the others' copies
+		// are simply brought up to date)
+		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nB; k += gridDim.x * blockDim.x)
+		{
+			const int* o = ib + (size_t)k * SP_BODY_WORDS;
+			const int i = o[0];
+			if (i < 0 || i >= W.nBodies) continue;
+			W.b_pos[i] = make_float4(__int_as_float(o[1]), __int_as_float(o[2]), __int_as_float(o[3]), __int_as_float(o[4]));
+			W.b_pos0[i] = make_float4(__int_as_float(o[5]), __int_as_float(o[6]), __int_as_float(o[7]), __int_as_float(o[8]));
+			W.b_vel[i] = make_float4(__int_as_float(o[9]), __int_as_float(o[10]), __int_as_float(o[11]), 0.0f);
+			W.b_xf[i] = make_float4(__int_as_float(o[13]), __int_as_float(o[14]), __int_as_float(o[15]), __int_as_float(o[16]));
+			uint32_t f = W.b_flags[i];
+			f = o[12] ? (f | BF_AWAKE) : (f & ~BF_AWAKE);
+			W.b_flags[i] = f;
+			W.spAwake[i] = o[12] ? 1 : 0;
+		}
 		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nC; k += gridDim.x * blockDim.x)
 		{
 			const int* o = ic + (size_t)k * SP_CONTENT_WORDS;

@@ -188,6 +188,7 @@ struct Counters
 	int nResolve;        // components the running resolution merges
 	int nMigrated;       // bodies whose owner the last resolution changed
 	int spContacts[SHARD_MAX_RANKS], spJoints[SHARD_MAX_RANKS]; // contact / joint records every rank ships in the running resolution
+	int spMigBodies[SHARD_MAX_RANKS];                           // ... body rows (the bodies that leave it)
 	int spBodies[SHARD_MAX_RANKS], spProxies[SHARD_MAX_RANKS];  // non-static bodies and their proxies per owner (k_sp_owner_census)
 	int spToiCreated;    // contacts this rank's TOI phase created (the tail of its contact array until the ranks have merged their tails)
 	int spToiStraddle;   // ... of them with a body of another rank (an event reached over an ownership boundary: refused)
@@ -386,6 +387,9 @@ struct DW
 	int spatial;         // 1: DW::b_owner decides who evaluates, solves and moves a body and its contacts
 	uint8_t* b_owner;    // per body: the rank that owns it (the same table on every rank; static bodies: unused)
 	uint8_t* spNewOwner; // per body: its owner after the running resolution
+	uint8_t* spAwake;    // per body: the awake bit the other ranks hold for it (lean exchange: a row travels when it changes)
+	int spFullRows;      // 1: E1 / E4 carry the rows of every body a rank moved (every rank holds the whole world's state: tests,
+	                     // callers that read any body anywhere); 0: only what the others' work needs - fat AABBs, awake bits
 	int* spStraddle;     // contact indices of Counters::nStraddle
 	int capStraddle;
 	int* spCount;        // per component under resolution: bodies per owner [SP_RESOLVE_MAX][SHARD_MAX_RANKS]

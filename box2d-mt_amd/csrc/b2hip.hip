@@ -244,7 +244,9 @@ struct b2hip_world
 	bool shardLoopback = false;  // B2HIP_SHARD_LOOPBACK=1: a communicator of ONE rank still runs export -> ncclAllGather -> import (self-test on a one-GPU box)
 	// spatial ownership (b2d_kernels_spatial.h; b2hip_shard_spatial)
 	bool spatial = false;
-	DevArray<uint8_t> b_owner, spNewOwner;
+	DevArray<uint8_t> b_owner, spNewOwner, spAwake;
+	bool spFullRows = false;       // B2HIP_SHARD_FULL_ROWS=1 / b2hip_shard_full_rows: every rank holds every body's current row
+	int spRowCap = 1024, spProxyCap = 4096; // lean E1: records per rank (grown alike on every rank when a header says so)
 	DevArray<int> spStraddle, spCount, spTarget, spSend, spRecv;
 	std::vector<uint8_t> spOwners; // the owner table as the host last knew it (assignment; refreshed after every resolution)
 	bool spOwnersDirty = false;    // owners assigned / bodies created since the table was uploaded
@@ -253,11 +255,11 @@ struct b2hip_world
 	void* gatherUser = nullptr;
 	int* spHost = nullptr;          // pinned staging of the caller's all-gather
 	size_t spHostWords = 0;
-	int spPairCap = 16384, spToiBodyCap = 1024, spToiProxyCap = 2048;
+	int spPairCap = 2048, spToiBodyCap = 256, spToiProxyCap = 512; // (records per rank; grown alike on every rank when a header says so)
 	int spOwned[SHARD_MAX_RANKS] = {0}, spOwnedProxies[SHARD_MAX_RANKS] = {0};
 	long long spMigratedTotal = 0, spResolves = 0, spPairsSent = 0;
 	size_t spBytesStep = 0;         // bytes this rank received in the exchanges of the last step
-	int spContactsBeforeToi = 0, spToiOrderBefore = 0, spTailCap = 256;
+	int spContactsBeforeToi = 0, spToiOrderBefore = 0, spTailCap = 64;
 	DevArray<int4> spTailKey;
 	DevArray<int2> spVirt;          // body pairs a TOI event would have joined over an ownership boundary (k_sp_tail_pairs)
 	long long spToiRedos = 0;
@@ -859,7 +861,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	}
 	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, MAX_BLOCKS + 2); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, MAX_BLOCKS + 2); ENS(blkBodyCount, MAX_BLOCKS + 2); ENS(blkBodyCursor, MAX_BLOCKS + 2);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
-	ENS(b_owner, w->spatial ? nb : 1); ENS(spNewOwner, w->spatial ? nb : 1); ENS(spStraddle, w->spatial ? std::max<size_t>(w->spStraddle.cap, 4096) : 1);
+	ENS(b_owner, w->spatial ? nb : 1); ENS(spNewOwner, w->spatial ? nb : 1); ENS(spAwake, w->spatial ? nb : 1); ENS(spStraddle, w->spatial ? std::max<size_t>(w->spStraddle.cap, 4096) : 1);
 	ENS(spCount, w->spatial ? (size_t)SP_RESOLVE_MAX * SHARD_MAX_RANKS : 1); ENS(spTarget, w->spatial ? SP_RESOLVE_MAX : 1);
 	ENS(spTailKey, w->spatial ? capContacts : 1); ENS(spVirt, w->spatial ? SP_TAIL_MAX + 1 : 1);
 	ENS(stateOut, 12 * nb + sizeof(DState) / sizeof(float) + 4); // (+ the counters, behind the rows: one copy to the host per step)
@@ -944,7 +946,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.b_adoptStage = w->b_adoptStage.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p; d.blkBodyCount = w->blkBodyCount.p; d.blkBodyCursor = w->blkBodyCursor.p;
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
-	d.spatial = w->spatial ? 1 : 0; d.b_owner = w->b_owner.p; d.spNewOwner = w->spNewOwner.p; d.spStraddle = w->spStraddle.p;
+	d.spatial = w->spatial ? 1 : 0; d.b_owner = w->b_owner.p; d.spNewOwner = w->spNewOwner.p; d.spAwake = w->spAwake.p; d.spFullRows = w->spFullRows ? 1 : 0; d.spStraddle = w->spStraddle.p;
 	d.capStraddle = (int)w->spStraddle.cap; d.spCount = w->spCount.p; d.spTarget = w->spTarget.p; d.spTailKey = w->spTailKey.p;
 	d.userFilter = hasFilter(w) ? 1 : 0; d.preSolveOn = hasPreSolve(w) ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
 	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
@@ -5220,7 +5222,14 @@ static int spExchangeState(b2hip_world* w, int mode)
 	for (int attempt = 0; attempt < 12; ++attempt)
 	{
 		int capB = 1, capP = 1, capT = 0;
-		if (mode == 0) for (int r = 0; r < ranks; ++r) { capB = std::max(capB, w->spOwned[r]); capP = std::max(capP, w->spOwnedProxies[r]); }
+		bool exactFit = false; // (sized from the owner census every rank keeps of every rank: nothing can overflow, no header to read)
+		if (mode == 0)
+		{
+			int mostB = 1, mostP = 1;
+			for (int r = 0; r < ranks; ++r) { mostB = std::max(mostB, w->spOwned[r]); mostP = std::max(mostP, w->spOwnedProxies[r]); }
+			if (w->spFullRows) { capB = mostB; capP = mostP; exactFit = true; }
+			else { capB = std::min(w->spRowCap, mostB); capP = std::min(w->spProxyCap, mostP); exactFit = capB == mostB && capP == mostP; }
+		}
 		else { capB = w->spToiBodyCap; capP = w->spToiProxyCap; capT = w->spTailCap; }
 		const int proxyWords = mode == 0 ? SP_PROXY_WORDS : SP_TOI_PROXY_WORDS;
 		const size_t tailAt = SP_HEADER_WORDS + (size_t)capB * SP_BODY_WORDS + (size_t)capP * proxyWords;
@@ -5280,7 +5289,23 @@ static int spExchangeState(b2hip_world* w, int mode)
 			}
 			if (created > SP_TAIL_MAX) return setError(B2HIP_ERR_CAPACITY, "more than 4 096 contacts created inside one TOI phase of a spatially sharded world");
 		}
+		if (mode == 0 && !exactFit)
+		{
+			int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
+			rc = spReadHeaders(w, words, hdr);
+			if (rc) return rc;
+			int needB = 0, needP = 0;
+			for (int r = 0; r < ranks; ++r) { needB = std::max(needB, hdr[r][0]); needP = std::max(needP, hdr[r][1]); }
+			if (needB > capB || needP > capP)
+			{
+				// (an export that did not fit has not marked its rows as sent: k_sp_export_state checks the capacity first)
+				while (w->spRowCap < needB) w->spRowCap *= 2;
+				while (w->spProxyCap < needP) w->spProxyCap *= 2;
+				continue;
+			}
+		}
 		LAUNCH(w, k_sp_import_state, gridFor(std::max(capB, capP)), 256, d, (const int*)w->spRecv.p, words, capB, proxyWords);
+		if (!w->spFullRows) LAUNCH(w, k_sp_mark_sent, gridFor(d.nBodies), 256, d);
 		if (created > 0)
 		{
 			rc = ensureCapacity(w, (size_t)w->spContactsBeforeToi + (size_t)created);
@@ -5383,27 +5408,27 @@ static int spResolve(b2hip_world* w, int nVirt)
 		if (d.nJoints > 0) LAUNCH(w, k_sp_union_joints, gridFor(d.nJoints), 256, d);
 		if (nVirt > 0) LAUNCH(w, k_sp_union_virtual, gridFor(nVirt), 256, d, (const int2*)w->spVirt.p, nVirt);
 		LAUNCH(w, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
-		HIP_TRY(hipMemsetAsync(w->d_state.p->c.spContacts, 0, 2 * SHARD_MAX_RANKS * sizeof(int), w->stream));
+		HIP_TRY(hipMemsetAsync(w->d_state.p->c.spContacts, 0, 3 * SHARD_MAX_RANKS * sizeof(int), w->stream));
 		LAUNCH(w, k_sp_resolve_mark, gridFor(c0.nStraddle + d.nJoints + nVirt), 256, d, (const int2*)w->spVirt.p, nVirt);
 		nVirt = 0; // (merged now: the rounds after this one look at real contacts and joints only)
 		LAUNCH(w, k_sp_resolve_count, gridFor(d.nBodies), 256, d);
 		LAUNCH(w, k_sp_resolve_pick, gridFor(SP_RESOLVE_MAX), 256, d);
-		LAUNCH(w, k_sp_content_census, gridFor(std::max(d.capContacts, d.nJoints)), 256, d);
+		LAUNCH(w, k_sp_content_census, gridFor(std::max(std::max(d.capContacts, d.nJoints), d.nBodies)), 256, d);
 		rc = readState(w);
 		if (rc) return rc;
 		const Counters& c1 = w->h_dstate->c;
 		if (c1.overflow & 1024) return setError(B2HIP_ERR_CAPACITY, "more than 65 536 components to merge in one resolution of a spatially sharded world");
-		int capC = 1, capJ = 1;
-		for (int r = 0; r < ranks; ++r) { capC = std::max(capC, c1.spContacts[r]); capJ = std::max(capJ, c1.spJoints[r]); }
-		const size_t words = SP_HEADER_WORDS + (size_t)capC * SP_CONTENT_WORDS + (size_t)capJ * SP_JOINT_WORDS;
+		int capC = 1, capJ = 1, capM = 1;
+		for (int r = 0; r < ranks; ++r) { capC = std::max(capC, c1.spContacts[r]); capJ = std::max(capJ, c1.spJoints[r]); capM = std::max(capM, c1.spMigBodies[r]); }
+		const size_t words = SP_HEADER_WORDS + (size_t)capC * SP_CONTENT_WORDS + (size_t)capJ * SP_JOINT_WORDS + (size_t)capM * SP_BODY_WORDS;
 		rc = spEnsureSlabs(w, words);
 		if (rc) return rc;
 		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
-		LAUNCH(w, k_sp_export_content, gridFor(std::max(d.capContacts, d.nJoints)), 256, d, w->spSend.p, capC);
+		LAUNCH(w, k_sp_export_content, gridFor(std::max(std::max(d.capContacts, d.nJoints), d.nBodies)), 256, d, w->spSend.p, capC, capJ);
 		rc = spAllGather(w, words);
 		if (rc) return rc;
 		LAUNCH(w, k_sp_apply_owners, gridFor(d.nBodies), 256, d);
-		LAUNCH(w, k_sp_import_content, gridFor(std::max(capC, capJ)), 256, d, (const int*)w->spRecv.p, words, capC);
+		LAUNCH(w, k_sp_import_content, gridFor(std::max(std::max(capC, capJ), capM)), 256, d, (const int*)w->spRecv.p, words, capC, capJ);
 		LAUNCH(w, k_sp_commit_owners, gridFor(d.nBodies), 256, d);
 		rc = spOwnerCensus(w);
 		if (rc) return rc;
@@ -5524,6 +5549,7 @@ int b2hip_shard_spatial(b2hip_world* w, int rank, int count, const uint8_t* owne
 		for (size_t k = 0; k < xs.size(); ++k) w->spOwners[(size_t)xs[k].second] = spStripOf(w, xs[k].first);
 	}
 	w->spatial = true;
+	w->spFullRows = getenv("B2HIP_SHARD_FULL_ROWS") != nullptr && atoi(getenv("B2HIP_SHARD_FULL_ROWS")) != 0;
 	w->spOwnersDirty = true;
 	w->dw.shardRank = rank;
 	w->dw.shardCount = count;

@@ -28,11 +28,17 @@ CCD = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
 PLAIN = bh.F_SLEEP | bh.F_WARM
 
 
-def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, seed=3, compare=True):
+def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, seed=3, compare=True, full=True):
+    """full: every rank holds the current row of every body (B2HIP_SHARD_FULL_ROWS=1) and is compared whole; else the lean
+    exchange of the default - a rank answers for the bodies it owns, the world is the union of the owners' rows."""
     if exact:
         monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
     else:
         monkeypatch.delenv("B2HIP_FORCE_LARGE", raising=False)
+    if full:
+        monkeypatch.setenv("B2HIP_SHARD_FULL_ROWS", "1")
+    else:
+        monkeypatch.delenv("B2HIP_SHARD_FULL_ROWS", raising=False)
     L = b2hip.lib()
     ref = amd.world(scene, p0, p1, seed=seed, flags=flags)
     ws = [amd.world(scene, p0, p1, seed=seed, flags=flags) for _ in range(ranks)]
@@ -40,15 +46,26 @@ def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, see
     for s in range(steps):
         ref.step(1)
         sr.step()
-        rb = ref.bodies().view(np.uint32)
+        rbf = ref.bodies()
+        rb = rbf.view(np.uint32)
         first = ws[0].bodies().view(np.uint32)
+        claimed = np.zeros(len(rb), np.int32)
         for r, w in enumerate(ws):
             wb = w.bodies().view(np.uint32)
             assert w.contact_count == ref.contact_count, "step %d rank %d: %d contacts, the unsharded world has %d" % (s + 1, r, w.contact_count, ref.contact_count)
-            assert np.array_equal(wb, first), "step %d: rank %d and rank 0 hold different worlds" % (s + 1, r)
+            if full:
+                assert np.array_equal(wb, first), "step %d: rank %d and rank 0 hold different worlds" % (s + 1, r)
+                mine = np.ones(len(rb), bool)
+            else:
+                own = sr.owners(r, len(rb))
+                mine = (own == r) & (rbf[:, 7] != 0)
+                claimed += mine
+                mine |= rbf[:, 7] == 0
             if compare:
-                bad = np.nonzero((wb != rb).any(axis=1))[0]
+                bad = np.nonzero((wb != rb).any(axis=1) & mine)[0]
                 assert bad.size == 0, "step %d rank %d: %d bodies differ from the unsharded world (first %s)" % (s + 1, r, bad.size, bad[:8].tolist())
+        if not full:
+            assert (claimed[rbf[:, 7] != 0] == 1).all(), "step %d: a body without an owner, or with two" % (s + 1)
     stats = [sr.stats(r) for r in range(ranks)]
     nonstatic = int((ref.bodies()[:, 7] != 0).sum())
     contacts = ref.contact_count
@@ -74,6 +91,20 @@ def test_sharded_world_is_the_unsharded_world_bit_for_bit(amd, monkeypatch, name
     stats, nonstatic, contacts, _ = run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch)
     assert sum(st.owned_bodies for st in stats) == nonstatic, "every non-static body has exactly one owner"
     assert sum(st.owned_contacts for st in stats) <= contacts  # (a contact between two static-only ... has none; the rest one)
+
+
+@pytest.mark.parametrize("name,scene,p0,p1,ranks,steps,flags,exact", [
+    ("field with bullets, 4 ranks", bh.FIELD, 3000, 300, 4, 80, CCD, False),
+    ("4 pyramids, 4 ranks, exact order", bh.PYRAMID, 20, 4, 4, 100, CCD, True),
+    ("rain, 3 ranks", bh.RAIN, 800, 0, 3, 200, CCD, False),
+    ("bullets (events over ownership boundaries), 2 ranks", bh.BULLETS, 60, 6, 2, 120, CCD, False),
+    ("vehicles, 2 ranks", bh.VEHICLES, 30, 2, 2, 150, CCD, False),
+])
+def test_lean_exchange_every_rank_answers_for_its_own_bodies(amd, monkeypatch, name, scene, p0, p1, ranks, steps, flags, exact):
+    """The default exchange: only what the other ranks' WORK needs travels every step - the fat AABBs of moved proxies, awake
+    bits that changed, new pairs - and a body's row travels when the body changes owner. A rank then answers for the bodies it
+    owns: the union of the owners' rows is the unsharded world, bit for bit, every step; every body has exactly one owner."""
+    run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, full=False)
 
 
 def test_an_event_over_an_ownership_boundary_is_caught_and_the_phase_redone(amd, monkeypatch):
