@@ -134,6 +134,36 @@ __global__ __launch_bounds__(256) void k_collide(DW W)
 	{
 		int4 ids = C.ids[i];
 		uint32_t flags = C.flags[i];
+		if (flags & CF_FOREIGN)
+		{
+			// a spatially sharded world: the bodies are another rank's, which evaluates the manifold. Here the contact only keeps
+			// existing - the structural half of b2ContactManager::Collide (:177-230), the same on every rank: the re-filter, the
+			// "both bodies asleep" skip, the fat-AABB test (else destroy)
+			int keepF = 1;
+			if (flags & CF_FILTER)
+			{
+				const bool ok = bodiesShouldCollide(W, ids.w, ids.z) &&
+					filterShouldCollide(W.p_filter0[ids.x], W.p_filter1[ids.x], W.p_filter0[ids.y], W.p_filter1[ids.y]);
+				if (!ok) keepF = 0; else flags &= ~CF_FILTER;
+			}
+			if (keepF && (bodyActiveForContact(W.b_flags[ids.z]) || bodyActiveForContact(W.b_flags[ids.w])))
+			{
+				const float4 fA = W.p_fat[ids.x], fB = W.p_fat[ids.y];
+				AABB boxA, boxB;
+				boxA.lo = v2(fA.x, fA.y); boxA.hi = v2(fA.z, fA.w);
+				boxB.lo = v2(fB.x, fB.y); boxB.hi = v2(fB.z, fB.w);
+				if (!b2dAabbOverlap(boxA, boxB)) keepF = 0;
+			}
+			if (!keepF)
+			{
+				flags |= CF_DESTROY;
+				++nDestroy;
+				if (flags & CF_TOI_CANDIDATE) b2dStoreAgentI(&W.toiDestroyList[atomicAdd(&S->c.nToiDestroy, 1)], i);
+			}
+			C.flags[i] = flags;
+			W.keepFlag[i] = keepF;
+			continue;
+		}
 		// Everything the update of a live contact reads is fetched in TWO rounds - what hangs on the contact index with the
 		// ids, what hangs on the ids right after - instead of level by level behind the tests that need it (flags, then fat
 		// AABBs, then the old manifold and the shape indices, then shapes and transforms: five dependent round trips in front
@@ -546,14 +576,19 @@ __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 		if (W.keepFlag[i])
 		{
 			int j = W.keepScan[i];
+			const uint32_t fl = A.flags[i];
 			B.ids[j] = A.ids[i];
 			B.key[j] = A.key[i];
-			B.flags[j] = A.flags[i];
-			B.mat[j] = A.mat[i];
-			B.man0[j] = A.man0[i];
-			B.man1[j] = A.man1[i];
-			B.imp[j] = A.imp[i];
-			B.man3[j] = A.man3[i];
+			B.flags[j] = fl;
+			if ((fl & CF_FOREIGN) == 0)
+			{
+				// (another rank's contact: only its place in the array is kept here - b2d_kernels_spatial.h)
+				B.mat[j] = A.mat[i];
+				B.man0[j] = A.man0[i];
+				B.man1[j] = A.man1[i];
+				B.imp[j] = A.imp[i];
+				B.man3[j] = A.man3[i];
+			}
 			B.color[j] = A.color[i];
 			const int m = A.mgr[i];
 			B.mgr[j] = m;

@@ -77,8 +77,10 @@ __device__ __forceinline__ void toiSnapshotSave(const DW& W)
 		S->c.nContactsSnap = S->c.nContacts;
 		S->c.nToiOrderSnap = S->c.nToiOrder;
 	}
+	// (a spatially sharded world: the phase touches this rank's bodies, their proxies and contacts only - b2d_kernels_spatial.h)
 	for (int i = t0; i < W.nBodies; i += stride)
 	{
+		if (W.spatial && (W.b_flags[i] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[i] != (uint8_t)W.shardRank) continue;
 		W.snapBody[5 * (size_t)i + 0] = W.b_pos[i];
 		W.snapBody[5 * (size_t)i + 1] = W.b_pos0[i];
 		W.snapBody[5 * (size_t)i + 2] = W.b_vel[i];
@@ -88,6 +90,7 @@ __device__ __forceinline__ void toiSnapshotSave(const DW& W)
 	for (int p = t0; p < W.nProxies; p += stride) W.snapFat[p] = W.p_fat[p];
 	for (int i = t0; i < nC; i += stride)
 	{
+		if (A.flags[i] & CF_FOREIGN) continue;
 		B.flags[i] = A.flags[i];
 		B.mat[i] = A.mat[i];
 		B.man0[i] = A.man0[i];
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 	{
 		for (int i = t0; i < W.nBodies; i += stride)
 		{
+			if (W.spatial && (W.b_flags[i] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[i] != (uint8_t)W.shardRank) continue;
 			W.b_pos[i] = W.snapBody[5 * (size_t)i + 0];
 			W.b_pos0[i] = W.snapBody[5 * (size_t)i + 1];
 			W.b_vel[i] = W.snapBody[5 * (size_t)i + 2];
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 		for (int p = t0; p < W.nProxies; p += stride) W.p_fat[p] = W.snapFat[p];
 		for (int i = t0; i < nC; i += stride)
 		{
+			if (A.flags[i] & CF_FOREIGN) continue;
 			A.flags[i] = B.flags[i];
 			A.mat[i] = B.mat[i];
 			A.man0[i] = B.man0[i];

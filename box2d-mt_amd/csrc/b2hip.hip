@@ -246,7 +246,8 @@ struct b2hip_world
 	bool spatial = false;
 	DevArray<uint8_t> b_owner, spNewOwner, spAwake;
 	bool spFullRows = false;       // B2HIP_SHARD_FULL_ROWS=1 / b2hip_shard_full_rows: every rank holds every body's current row
-	int spRowCap = 1024, spProxyCap = 4096; // lean E1: records per rank (grown alike on every rank when a header says so)
+	int spRowCap = 1024, spProxyCap = 4096;
+	int spIdle[6] = {0, 0, 0, 0, 0, 0}; // exchanges in a row in which a capacity was four times what any rank needed (spCapDecay) // lean E1: records per rank (grown alike on every rank when a header says so)
 	DevArray<int> spStraddle, spCount, spTarget, spSend, spRecv;
 	std::vector<uint8_t> spOwners; // the owner table as the host last knew it (assignment; refreshed after every resolution)
 	bool spOwnersDirty = false;    // owners assigned / bodies created since the table was uploaded
@@ -262,6 +263,12 @@ struct b2hip_world
 	int spContactsBeforeToi = 0, spToiOrderBefore = 0, spTailCap = 64;
 	DevArray<int4> spTailKey;
 	DevArray<int2> spVirt;          // body pairs a TOI event would have joined over an ownership boundary (k_sp_tail_pairs)
+	// measurement hook (b2hip_shard_tape): the results of this rank's collectives kept in device memory / taken from another
+	// world's tape instead of a collective - one rank of a sharded world stepped alone on one GPU (tools/gpu_spatial_share.py)
+	bool spTapeRecord = false;
+	std::vector<std::pair<int*, size_t> > spTape;
+	b2hip_world* spTapeFrom = nullptr;
+	size_t spTapeCursor = 0;
 	long long spToiRedos = 0;
 	size_t spUp = 0;                // bodies the device's owner table covers
 	DevArray<int> scanFlags;     // status words of the single-pass scans (b2d_scan.h)
@@ -2597,6 +2604,12 @@ void b2hip_world_destroy(b2hip_world* w)
 	if (w->shardComm != nullptr && g_rcclDestroy != nullptr) g_rcclDestroy(w->shardComm);
 	w->shardComm = nullptr;
 	w->shardSend.release(); w->shardRecv.release();
+	w->b_owner.release(); w->spNewOwner.release(); w->spAwake.release(); w->spStraddle.release(); w->spCount.release(); w->spTarget.release();
+	w->spSend.release(); w->spRecv.release(); w->spTailKey.release(); w->spVirt.release();
+	if (w->spHost) (void)hipHostFree(w->spHost);
+	w->spHost = nullptr;
+	for (size_t k = 0; k < w->spTape.size(); ++k) (void)hipFree(w->spTape[k].first);
+	w->spTape.clear();
 	w->d_state.release();
 	w->b_pos.release(); w->b_pos0.release(); w->b_vel.release(); w->b_xf.release(); w->b_mass.release(); w->b_damp.release();
 	w->b_force.release(); w->b_flags.release(); w->b_wake.release();
@@ -5174,6 +5187,19 @@ static int spAllGather(b2hip_world* w, size_t words)
 {
 	const int ranks = w->dw.shardCount;
 	w->spBytesStep += 4 * words * (size_t)(ranks - 1);
+	if (w->spTapeFrom != nullptr)
+	{
+		// (replay: what the collective delivered in the recorded run, device to device on the world's stream)
+		const std::vector<std::pair<int*, size_t> >& tape = w->spTapeFrom->spTape;
+		if (w->spTapeCursor >= tape.size() || tape[w->spTapeCursor].second != words * (size_t)ranks)
+			return setError(B2HIP_ERR_INVALID, "the replayed run leaves the recorded one (collective " + std::to_string(w->spTapeCursor) + ")");
+		HIP_TRY(hipMemcpyAsync(w->spRecv.p, tape[w->spTapeCursor].first, words * (size_t)ranks * sizeof(int), hipMemcpyDeviceToDevice, w->stream));
+		// (this rank's own slab as it is NOW: record order inside a slab is not deterministic - atomics - and later kernels may
+		// index into both)
+		HIP_TRY(hipMemcpyAsync(w->spRecv.p + (size_t)w->dw.shardRank * words, w->spSend.p, words * sizeof(int), hipMemcpyDeviceToDevice, w->stream));
+		w->spTapeCursor += 1;
+		return 0;
+	}
 	if (w->shardComm != nullptr)
 	{
 		RCCL_TRY(g_rccl.allGather(w->spSend.p, w->spRecv.p, words, ncclInt32, (ncclComm_t)w->shardComm, w->stream));
@@ -5192,6 +5218,13 @@ static int spAllGather(b2hip_world* w, size_t words)
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	if (w->gatherFn(w->gatherUser, w->spHost, words * sizeof(int), w->spHost + words) != 0) return setError(B2HIP_ERR_INVALID, "the caller's all-gather failed");
 	HIP_TRY(hipMemcpyAsync(w->spRecv.p, w->spHost + words, words * (size_t)ranks * sizeof(int), hipMemcpyHostToDevice, w->stream));
+	if (w->spTapeRecord)
+	{
+		int* keep = nullptr;
+		HIP_TRY(hipMalloc((void**)&keep, words * (size_t)ranks * sizeof(int)));
+		HIP_TRY(hipMemcpyAsync(keep, w->spRecv.p, words * (size_t)ranks * sizeof(int), hipMemcpyDeviceToDevice, w->stream));
+		w->spTape.push_back(std::make_pair(keep, words * (size_t)ranks));
+	}
 	return 0;
 }
 
@@ -5209,6 +5242,15 @@ static int spReadHeaders(b2hip_world* w, size_t strideWords, int (*hdr)[SP_HEADE
 		HIP_TRY(hipMemcpyAsync(hdr[r], w->spRecv.p + (size_t)r * strideWords, SP_HEADER_WORDS * sizeof(int), hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	return 0;
+}
+
+// A slab capacity grows when a header says it was too small and shrinks again when it has been four times too large for 16
+// exchanges in a row (the burst of the first steps - every proxy new, tens of thousands of pairs - would otherwise size every
+// later collective). Every rank reads the same headers: the capacities stay equal on all ranks.
+static void spCapDecay(int* cap, int* idle, int need, int floor)
+{
+	if (4 * need < *cap && *cap > floor) { if (++*idle >= 16) { *cap = std::max(floor, *cap / 2); *idle = 0; } }
+	else *idle = 0;
 }
 
 // E1 (mode 0, behind SynchronizeFixtures) and E4 (mode 1, behind SolveTOI). E1 is sized from the owner census every rank
@@ -5288,6 +5330,9 @@ static int spExchangeState(b2hip_world* w, int mode)
 				return 1;
 			}
 			if (created > SP_TAIL_MAX) return setError(B2HIP_ERR_CAPACITY, "more than 4 096 contacts created inside one TOI phase of a spatially sharded world");
+			spCapDecay(&w->spToiBodyCap, &w->spIdle[2], needB, 256);
+			spCapDecay(&w->spToiProxyCap, &w->spIdle[3], needP, 512);
+			spCapDecay(&w->spTailCap, &w->spIdle[4], needT, 64);
 		}
 		if (mode == 0 && !exactFit)
 		{
@@ -5303,6 +5348,8 @@ static int spExchangeState(b2hip_world* w, int mode)
 				while (w->spProxyCap < needP) w->spProxyCap *= 2;
 				continue;
 			}
+			spCapDecay(&w->spRowCap, &w->spIdle[0], needB, 1024);
+			spCapDecay(&w->spProxyCap, &w->spIdle[1], needP, 4096);
 		}
 		LAUNCH(w, k_sp_import_state, gridFor(std::max(capB, capP)), 256, d, (const int*)w->spRecv.p, words, capB, proxyWords);
 		if (!w->spFullRows) LAUNCH(w, k_sp_mark_sent, gridFor(d.nBodies), 256, d);
@@ -5359,8 +5406,10 @@ static int spExchangePairs(b2hip_world* w)
 			if (rc) return rc;
 		}
 		w->spPairsSent += hdr[d.shardRank][2];
-		LAUNCH(w, k_sp_import_pairs, gridFor(w->spPairCap), 256, w->dw, (const int*)w->spRecv.p, words, w->spPairCap);
-		LAUNCH(w, k_sp_import_pairs_commit, 1, 1, w->dw, (const int*)w->spRecv.p, words, w->spPairCap);
+		const int capNow = w->spPairCap;
+		spCapDecay(&w->spPairCap, &w->spIdle[5], most, 2048);
+		LAUNCH(w, k_sp_import_pairs, gridFor(capNow), 256, w->dw, (const int*)w->spRecv.p, words, capNow);
+		LAUNCH(w, k_sp_import_pairs_commit, 1, 1, w->dw, (const int*)w->spRecv.p, words, capNow);
 		return 0;
 	}
 	return setError(B2HIP_ERR_CAPACITY, "the pair exchange of a spatially sharded world did not fit");
@@ -5445,13 +5494,37 @@ static int spAfterToi(b2hip_world* w)
 {
 	int rc = readState(w);
 	if (rc) return rc;
+	// (what b2hip_step_end does for an unsharded world's parallel TOI paths - the grid's stickiness, the second run of the
+	// chains with the grid, the serial replay - happens here, before the exchange: the other ranks get the settled result)
+	if (w->toiChains)
+	{
+		if (w->h_dstate->c.nToiMoved > 0) w->toiGridSticky = 16;
+		else if (w->toiGridSticky > 0) w->toiGridSticky -= 1;
+	}
 	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
 	{
-		// a parallel path met an order-dependent case: back to the state before it, then the reference's serial order
 		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		if (w->h_dstate->c.toiUnsafe == 4 /* TOI_UNSAFE_PAIR */ && !w->toiChainsHadGrid && !w->dw.noChainCreate)
+		{
+			// a chain moved a proxy out of its fat AABB while the hash grid was not kept up: the chains once more, with the grid
+			w->toiGridSticky = 16;
+			w->toiChains = false;
+			w->toiCountersFresh = false;
+			rc = phaseToiSync(w);
+			if (rc) return rc;
+			rc = readState(w);
+			if (rc) return rc;
+			w->toiGridRetries += 1;
+			if (w->toiChains && w->h_dstate->c.toiUnsafe != 0) LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+		}
+	}
+	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
+	{
+		// an order-dependent case: the state before the parallel path is back (above), now the reference's serial order
 		rc = toiSerial(w);
 		if (rc) return rc;
 		w->toiFallbacks += 1;
+		w->toiSyncSticky = 16;
 		rc = readState(w);
 		if (rc) return rc;
 	}
@@ -5504,6 +5577,16 @@ static int spBeginStep(b2hip_world* w)
 	if (rc) return rc;
 	w->spOwnersDirty = false;
 	return 0;
+}
+
+int b2hip_shard_tape(b2hip_world* w, int mode, b2hip_world* from)
+{
+	if (int rcu = checkUsable(w, "b2hip_shard_tape", true)) return rcu;
+	if (mode == 2 && (!from || from == w)) return setError(B2HIP_ERR_INVALID, "replay needs the world that recorded");
+	w->spTapeRecord = mode == 1;
+	w->spTapeFrom = mode == 2 ? from : nullptr;
+	w->spTapeCursor = 0;
+	return B2HIP_OK;
 }
 
 int b2hip_set_shard_gather(b2hip_world* w, b2hip_all_gather_fn fn, void* user)

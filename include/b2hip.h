@@ -650,6 +650,10 @@ typedef struct b2hip_shard_stats
 int b2hip_shard_spatial(b2hip_world* w, int rank, int count, const uint8_t* owners);
 int b2hip_set_shard_gather(b2hip_world* w, b2hip_all_gather_fn fn, void* user);
 int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out);
+/* Measurement hook (tools/gpu_spatial_share.py): mode 1 - keep the result of every collective of `w` in device memory; mode 2 -
+ * `w` takes its collectives' results from the tape of `from` (a world of the same rank that recorded the same run) instead
+ * of running a collective: one rank of a sharded world stepped alone on one GPU; mode 0 - off. */
+int b2hip_shard_tape(b2hip_world* w, int mode, b2hip_world* from);
 /* the owner table as it stands (owners[b2hip_body_count]); between steps */
 int b2hip_get_body_owners(b2hip_world* w, int cap, uint8_t* owners);
 

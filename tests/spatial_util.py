@@ -26,11 +26,16 @@ class ThreadGather:
         self.barrier = threading.Barrier(n, timeout=timeout)
         self.calls = 0
         self.bytes = 0
+        # the ranks share ONE device here: they take turns on it (a rank's stream is idle when its all-gather is called and
+        # when its step returns), so that a kernel whose workgroups must all be resident - the block solver - has the device
+        # to itself as it would on a rank's own GPU
+        self.device = threading.Lock()
 
     def callback(self, rank):
         def fn(user, send, nbytes, recv):
             try:
                 self.slots[rank] = C.string_at(send, nbytes)
+                self.device.release()
                 self.barrier.wait()
                 for r in range(self.n):
                     C.memmove(recv + r * nbytes, self.slots[r], nbytes)
@@ -38,6 +43,7 @@ class ThreadGather:
                     self.calls += 1
                     self.bytes += nbytes * self.n
                 self.barrier.wait()
+                self.device.acquire()
                 return 0
             except Exception:  # (a broken barrier: another rank failed)
                 return 1
@@ -70,11 +76,17 @@ class SpatialRanks:
         errs = [None] * self.n
 
         def run(r):
+            self.gather.device.acquire()
             try:
                 (fn or (lambda _r, s: s.step(1)))(r, self.worlds[r][0])
             except BaseException as e:  # noqa: B902
                 errs[r] = e
                 self.gather.barrier.abort()
+            finally:
+                try:
+                    self.gather.device.release()
+                except RuntimeError:
+                    pass
 
         ts = [threading.Thread(target=run, args=(r,)) for r in range(self.n)]
         for t in ts:
