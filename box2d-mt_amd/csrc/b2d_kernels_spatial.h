@@ -227,6 +227,11 @@ __global__ __launch_bounds__(256) void k_sp_export_pairs(DW W, int* out, int cap
 	{
 		const uint64_t key = W.pairKey[i];
 		const int2 pr = W.pairProxy[i];
+		{
+			// (a pair that will join bodies of different owners: the hosts learn from the headers whether a resolution is due)
+			const int bA = W.p_body[pr.x], bB = W.p_body[pr.y];
+			if ((W.b_flags[bA] & BF_TYPE_MASK) != BT_STATIC && (W.b_flags[bB] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bA] != W.b_owner[bB]) atomicAdd(&out[6], 1);
+		}
 		int* o = op + (size_t)i * SP_PAIR_WORDS;
 		o[0] = (int)(uint32_t)(key >> 32);
 		o[1] = (int)(uint32_t)key;
@@ -602,12 +607,20 @@ __global__ __launch_bounds__(256) void k_sp_import_content(DW W, const int* in, 
 #define SP_TAIL_WORDS 6        // alpha bits, event key hi, lo, proxy lo, proxy hi (key order), index in the creating rank's tail
 #define SP_TAIL_MAX 4096       // contacts all ranks together may create inside one TOI phase
 
-__global__ __launch_bounds__(256) void k_sp_export_tail(DW W, int* out, int base, int capTail)
+__global__ __launch_bounds__(256) void k_sp_export_tail(DW W, int* out, int* hdr, int base, int capTail, int chains)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	const int n = S->c.nContacts - base;
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		// what the host would have read back before the exchange: it reads every rank's header behind it anyway
+		hdr[4] = S->c.nToiMoved;
+		hdr[5] = n;
+		hdr[6] = S->c.spToiStraddle;
+		hdr[7] = (chains ? S->c.toiUnsafe : 0) | ((S->c.overflow & 1) ? 0x40000000 : 0);
+	}
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n && k < capTail; k += gridDim.x * blockDim.x)
 	{
 		const int4 key = W.spTailKey[base + k];

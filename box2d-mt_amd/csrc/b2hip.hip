@@ -261,6 +261,8 @@ struct b2hip_world
 	long long spMigratedTotal = 0, spResolves = 0, spPairsSent = 0;
 	size_t spBytesStep = 0;         // bytes this rank received in the exchanges of the last step
 	int spContactsBeforeToi = 0, spToiOrderBefore = 0, spTailCap = 64;
+	int spToiUnsafe = 0;            // this rank's Counters::toiUnsafe as its E4 header showed it
+	bool spToiSettled = false;      // this step's phase has been through its fallback already
 	DevArray<int4> spTailKey;
 	DevArray<int2> spVirt;          // body pairs a TOI event would have joined over an ownership boundary (k_sp_tail_pairs)
 	// measurement hook (b2hip_shard_tape): the results of this rank's collectives kept in device memory / taken from another
@@ -1326,7 +1328,7 @@ static int applyEditOps(b2hip_world* w, bool betweenSteps)
 // ------------------------------------------------------------------------------------------------
 // spatially sharded worlds (defined behind the RCCL section; b2d_kernels_spatial.h)
 static int spExchangeState(b2hip_world* w, int mode);
-static int spExchangePairs(b2hip_world* w);
+static int spExchangePairs(b2hip_world* w, long long* totalPairs, int* straddling);
 static int spResolve(b2hip_world* w, int nVirt = 0);
 static int spAfterToi(b2hip_world* w);
 static int spBeginStep(b2hip_world* w);
@@ -1489,16 +1491,24 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 	bool large = false;
 	if (w->spatial)
 	{
-		// E2: every rank searched for the proxies ITS bodies moved; all ranks order and create the union
-		int rc = spExchangePairs(w);
+		// E2: every rank searched for the proxies ITS bodies moved; all ranks order and create the union. The headers of the
+		// slabs tell every host what it needs to go on (one synchronisation): the size of the union -> the ordering path, and
+		// whether a new pair joins bodies of different owners
+		long long total = 0;
+		int straddle = 0;
+		int rc = spExchangePairs(w, &total, &straddle);
 		if (rc) return rc;
-		rc = readState(w);
-		if (rc) return rc;
-		if (w->h_dstate->c.overflow & 3) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow in a spatially sharded world");
-		large = w->h_dstate->c.nPairs > COUNT_RANK_MAX;
+		large = total > COUNT_RANK_MAX;
 		rc = runSortAndCreate(w, large);
 		if (rc) return rc;
-		// E3: a new contact may join components of different owners
+		if (straddle == 0)
+		{
+			// CF_FOREIGN of the new contacts (nothing straddles: no resolution, nothing to read back)
+			HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nStraddle, 0, 4 * sizeof(int), w->stream));
+			LAUNCH(w, k_sp_flag_contacts, gridFor(d.capContacts), 256, d);
+			return 0;
+		}
+		// E3: a new contact joins components of different owners
 		return spResolve(w);
 	}
 	if (sync)
@@ -5285,8 +5295,7 @@ static int spExchangeState(b2hip_world* w, int mode)
 		{
 			// the contacts this rank's TOI phase created (behind the array all ranks shared when the phase began): their
 			// descriptors, for the merge of the tails; header words 5 and 6 = how many, how many of them with another rank's body
-			HIP_TRY(hipMemcpyAsync(w->spSend.p + 5, &w->d_state.p->c.spToiCreated, 2 * sizeof(int), hipMemcpyDeviceToDevice, w->stream));
-			LAUNCH(w, k_sp_export_tail, gridFor(capT), 256, d, w->spSend.p + tailAt, w->spContactsBeforeToi, capT);
+			LAUNCH(w, k_sp_export_tail, gridFor(capT), 256, d, w->spSend.p + tailAt, w->spSend.p, w->spContactsBeforeToi, capT, w->toiChains ? 1 : 0);
 		}
 		rc = spAllGather(w, words);
 		if (rc) return rc;
@@ -5303,6 +5312,22 @@ static int spExchangeState(b2hip_world* w, int mode)
 			rc = spReadHeaders(w, words, hdr);
 			if (rc) return rc;
 			int needB = 0, needP = 0, needT = 0, straddle = 0;
+			{
+				// this rank's own phase, as its header shows it (what a read-back before the exchange would have said)
+				const int* mine = hdr[d.shardRank];
+				if (mine[7] & 0x40000000) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step of a spatially sharded world");
+				if (w->toiChains)
+				{
+					if (mine[4] > 0) w->toiGridSticky = 16;
+					else if (w->toiGridSticky > 0 && !w->spToiSettled) w->toiGridSticky -= 1;
+				}
+				w->spToiUnsafe = mine[7] & 0x3fffffff;
+				bool any = false;
+				for (int r = 0; r < ranks; ++r) any = any || (hdr[r][7] & 0x3fffffff) != 0;
+				// (a parallel TOI path of some rank met an order-dependent case: that rank settles its phase - serially - and
+				// everybody exchanges again; nothing of this exchange has been imported)
+				if (any) return 2;
+			}
 			for (int r = 0; r < ranks; ++r)
 			{
 				needB = std::max(needB, hdr[r][0]); needP = std::max(needP, hdr[r][1]); needT = std::max(needT, hdr[r][5]);
@@ -5368,10 +5393,18 @@ static int spExchangeState(b2hip_world* w, int mode)
 }
 
 // E2: this rank's new pairs out, everybody's in (behind ours in the pair buffer; Counters::nPairs counts all of them)
-static int spExchangePairs(b2hip_world* w)
+static int spExchangePairs(b2hip_world* w, long long* totalPairs, int* straddling)
 {
 	const int ranks = w->dw.shardCount;
-	if (ranks < 2) return 0;
+	*totalPairs = 0;
+	*straddling = 0;
+	if (ranks < 2)
+	{
+		int rc = readState(w);
+		if (rc) return rc;
+		*totalPairs = w->h_dstate->c.nPairs;
+		return 0;
+	}
 	DW& d = w->dw;
 	for (int attempt = 0; attempt < 12; ++attempt)
 	{
@@ -5385,13 +5418,14 @@ static int spExchangePairs(b2hip_world* w)
 		int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
 		rc = spReadHeaders(w, words, hdr);
 		if (rc) return rc;
-		int most = 0;
+		int most = 0, strad = 0;
 		long long total = 0;
 		for (int r = 0; r < ranks; ++r)
 		{
-			if (hdr[r][5] & 2) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow on a rank of a spatially sharded world");
+			if (hdr[r][5] & 3) return setError(B2HIP_ERR_CAPACITY, "pair buffer / contact array overflow on a rank of a spatially sharded world");
 			most = std::max(most, hdr[r][2]);
 			total += hdr[r][2];
+			strad += hdr[r][6];
 		}
 		if (most > w->spPairCap)
 		{
@@ -5406,6 +5440,8 @@ static int spExchangePairs(b2hip_world* w)
 			if (rc) return rc;
 		}
 		w->spPairsSent += hdr[d.shardRank][2];
+		*totalPairs = total;
+		*straddling = strad;
 		const int capNow = w->spPairCap;
 		spCapDecay(&w->spPairCap, &w->spIdle[5], most, 2048);
 		LAUNCH(w, k_sp_import_pairs, gridFor(capNow), 256, w->dw, (const int*)w->spRecv.p, words, capNow);
@@ -5492,49 +5528,40 @@ static int spResolve(b2hip_world* w, int nVirt)
 // Behind SolveTOI: this rank's phase is settled here (the fallbacks b2hip_step_end would run), then E4.
 static int spAfterToi(b2hip_world* w)
 {
-	int rc = readState(w);
-	if (rc) return rc;
 	// (what b2hip_step_end does for an unsharded world's parallel TOI paths - the grid's stickiness, the second run of the
-	// chains with the grid, the serial replay - happens here, before the exchange: the other ranks get the settled result)
-	if (w->toiChains)
+	// chains with the grid, the serial replay - happens here, before the other ranks take this rank's result: the counters
+	// that decide it travel in this rank's own header, so the usual step costs no read-back of its own)
+	w->spToiSettled = false;
+	for (int attempt = 0; attempt < 6; ++attempt)
 	{
-		if (w->h_dstate->c.nToiMoved > 0) w->toiGridSticky = 16;
-		else if (w->toiGridSticky > 0) w->toiGridSticky -= 1;
-	}
-	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
-	{
-		LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
-		if (w->h_dstate->c.toiUnsafe == 4 /* TOI_UNSAFE_PAIR */ && !w->toiChainsHadGrid && !w->dw.noChainCreate)
+		int rc = spExchangeState(w, 1);
+		if (rc != 2) { w->toiChains = false; w->toiSpeculative = false; return rc; }
+		if (w->toiChains && w->spToiUnsafe != 0)
 		{
-			// a chain moved a proxy out of its fat AABB while the hash grid was not kept up: the chains once more, with the grid
-			w->toiGridSticky = 16;
-			w->toiChains = false;
-			w->toiCountersFresh = false;
-			rc = phaseToiSync(w);
-			if (rc) return rc;
-			rc = readState(w);
-			if (rc) return rc;
-			w->toiGridRetries += 1;
-			if (w->toiChains && w->h_dstate->c.toiUnsafe != 0) LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+			LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
+			bool serial = true;
+			if (w->spToiUnsafe == 4 /* TOI_UNSAFE_PAIR */ && !w->toiChainsHadGrid && !w->dw.noChainCreate)
+			{
+				// a chain moved a proxy out of its fat AABB while the hash grid was not kept up: the chains once more, with the grid
+				w->toiGridSticky = 16;
+				w->toiChains = false;
+				w->toiCountersFresh = false;
+				rc = phaseToiSync(w);
+				if (rc) return rc;
+				w->toiGridRetries += 1;
+				serial = false; // (its outcome comes with the next exchange's headers)
+			}
+			if (serial)
+			{
+				rc = toiSerial(w); // (toiChains = false: nothing left to be unsafe about)
+				if (rc) return rc;
+				w->toiFallbacks += 1;
+				w->toiSyncSticky = 16;
+			}
+			w->spToiSettled = true;
 		}
 	}
-	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
-	{
-		// an order-dependent case: the state before the parallel path is back (above), now the reference's serial order
-		rc = toiSerial(w);
-		if (rc) return rc;
-		w->toiFallbacks += 1;
-		w->toiSyncSticky = 16;
-		rc = readState(w);
-		if (rc) return rc;
-	}
-	w->toiChains = false;
-	w->toiSpeculative = false;
-	if (w->h_dstate->c.overflow & 1) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step of a spatially sharded world");
-	int created[2] = { w->h_dstate->c.nContacts - w->spContactsBeforeToi, w->h_dstate->c.spToiStraddle };
-	HIP_TRY(hipMemcpyAsync(&w->d_state.p->c.spToiCreated, created, 2 * sizeof(int), hipMemcpyHostToDevice, w->stream));
-	HIP_TRY(hipStreamSynchronize(w->stream)); // (`created` is a local)
-	return spExchangeState(w, 1);
+	return setError(B2HIP_ERR_INVALID, "the TOI phases of a spatially sharded world do not settle");
 }
 
 static uint8_t spStripOf(const b2hip_world* w, float x)
