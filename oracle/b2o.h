@@ -137,6 +137,12 @@ void b2o_set_shard(b2o_world* w, int rank, int count);
 size_t b2o_shard_slab_words(const b2o_world* w, int rank); /* of ANY rank: every rank counts all during its island build */
 void b2o_shard_export(const b2o_world* w, int32_t* slab);
 void b2o_shard_import(b2o_world* w, const int32_t* all_slabs, size_t stride_words);
+/* spatial ownership (include/b2hip.h: b2hip_shard_spatial): the protocol of box2d-mt_amd/csrc/b2d_kernels_spatial.h, serially */
+int b2o_shard_spatial(b2o_world* w, int rank, int count, const unsigned char* owners);
+void b2o_set_shard_gather(b2o_world* w, int (*fn)(void*, const void*, size_t, void*), void* user);
+int b2o_spatial_failed(const b2o_world* w);
+int b2o_get_body_owners(const b2o_world* w, int cap, unsigned char* out);
+void b2o_get_shard_stats(const b2o_world* w, int32_t* out8, long long* out4);
 
 /* life cycle and mutators between steps (semantics and reference lines: include/b2hip.h) */
 void b2o_destroy_body(b2o_world* w, int body);

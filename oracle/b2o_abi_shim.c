@@ -197,7 +197,9 @@ int b2hip_set_velocity(b2hip_world* w, int body, float vx, float vy, float omega
 int b2hip_step(b2hip_world* w, float dt, int vi, int pi)
 {
 	b2o_step(w->o, dt, vi, pi);
-	return 0;
+	/* (a spatially sharded world: a failed collective, or a TOI sub-step that created a contact - the merge of such contacts over
+	 * the ranks is the product's, this shim does not restate it) */
+	return b2o_spatial_failed(w->o) ? -4 : 0;
 }
 
 int b2hip_get_body_states(b2hip_world* w, int first, int count, b2hip_body_state* out)
@@ -241,6 +243,21 @@ int b2hip_set_shard(b2hip_world* w, int rank, int count)
 	b2o_set_shard(w->o, rank, count);
 	return 0;
 }
+/* spatial ownership: the same entry points as the product (include/b2hip.h) */
+int b2hip_shard_spatial(b2hip_world* w, int rank, int count, const uint8_t* owners) { return b2o_shard_spatial(w->o, rank, count, owners); }
+int b2hip_set_shard_gather(b2hip_world* w, b2hip_all_gather_fn fn, void* user) { b2o_set_shard_gather(w->o, fn, user); return 0; }
+int b2hip_get_body_owners(b2hip_world* w, int cap, uint8_t* owners) { return b2o_get_body_owners(w->o, cap, owners); }
+int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out)
+{
+	int32_t a[8];
+	long long b[4];
+	memset(out, 0, sizeof(*out));
+	b2o_get_shard_stats(w->o, a, b);
+	out->rank = a[0]; out->count = a[1]; out->owned_bodies = a[2]; out->owned_proxies = a[3]; out->owned_contacts = a[4];
+	out->migrated_bodies = b[0]; out->resolutions = b[1]; out->bytes_received_last_step = b[2];
+	return 0;
+}
+int b2hip_shard_tape(b2hip_world* w, int mode, b2hip_world* from) { (void)w; (void)mode; (void)from; return -4; }
 int b2hip_shard_slab_words(b2hip_world* w, size_t* words_per_rank, int ranks)
 {
 	for (int r = 0; r < ranks; ++r) words_per_rank[r] = b2o_shard_slab_words(w->o, r);

@@ -138,6 +138,16 @@ struct b2o_world
 	unsigned char* contactOwned; int capContactOwned; /* per contact slot */
 	unsigned char* jointOwned; int capJointOwned;
 	float stepDt; int stepVelIters, stepPosIters;     /* parameters of the running step (phase entry points) */
+	/* spatial ownership (include/b2hip.h: b2hip_shard_spatial; the protocol of box2d-mt_amd/csrc/b2d_kernels_spatial.h restated
+	 * serially: every rank keeps the whole structure - bodies, proxies, contact slots - and evaluates, solves and moves the
+	 * bodies it owns; rows / fat AABBs of moved bodies and new pairs are all-gathered, components that a new contact joins
+	 * over an ownership boundary migrate) */
+	int spatial;
+	unsigned char* owner; int capOwner;
+	int (*gatherFn)(void* user, const void* send, size_t bytes, void* recv); void* gatherUser;
+	float spBounds[9];
+	long long spMigrated, spResolves, spBytes;
+	int spOwnersDirty, spFailed;
 	/* m_nonStaticBodies (b2World.cpp:573, 662-667): island seeds are taken in this order */
 	int* nonStatic; int nNonStatic, capNonStatic;
 	/* the other listener callbacks and the user contact filter (same protocol as include/b2hip.h) */
@@ -897,13 +907,22 @@ static void push_event(b2o_world* w, const contact_t* c, int kind, int index)
 	w->nEvents++;
 }
 
+static int sp_foreign_body(const b2o_world* w, int bi)
+{
+	return w->spatial && w->bodies[bi].type != 0 && w->owner[bi] != (unsigned char)w->shardRank;
+}
+static int sp_foreign_contact(const b2o_world* w, const contact_t* c)
+{
+	return w->spatial && (sp_foreign_body(w, c->bodyA) || sp_foreign_body(w, c->bodyB));
+}
 static void destroy_contact(b2o_world* w, int slot)
 {
 	contact_t* c = &w->contacts[slot];
 	/* b2ContactManager::Destroy (b2ContactManager.cpp:104-107): a touching contact ends when it is destroyed */
 	if (w->eventsOn && c->reported) push_event(w, c, 1, -1);
 	c->reported = 0;
-	if (c->m.pointCount > 0 && !w->fixtures[c->fixtureA].isSensor && !w->fixtures[c->fixtureB].isSensor)
+	/* (a foreign contact's point count is not maintained here: its owner wakes the bodies) */
+	if (c->m.pointCount > 0 && !w->fixtures[c->fixtureA].isSensor && !w->fixtures[c->fixtureB].isSensor && !sp_foreign_contact(w, c))
 	{
 		set_awake(&w->bodies[c->bodyA]);
 		set_awake(&w->bodies[c->bodyB]);
@@ -1085,6 +1104,9 @@ static void deliver_pre_solve(b2o_world* w)
 }
 
 /* b2ContactManager::Collide (:177-230) + FinishCollide (:388-439: destroys sorted by proxy ids) */
+static void sp_exchange_state(b2o_world* w, int afterToi);
+static void sp_resolve(b2o_world* w);
+
 static void collide(b2o_world* w)
 {
 	int nSlots = w->nContactSlots;
@@ -1117,6 +1139,9 @@ static void collide(b2o_world* w)
 			destroys[nDestroy++] = i;
 			continue;
 		}
+		/* (a spatially sharded world: the bodies are another rank's, which evaluates the manifold; here the contact only keeps
+		 * existing - the tests above are structure, the same on every rank) */
+		if (sp_foreign_contact(w, c)) continue;
 		int wasTouching = (c->flags & CF_TOUCHING) != 0;
 		contact_update(w, c);
 		int sensor = fA->isSensor || fB->isSensor;
@@ -1146,9 +1171,11 @@ static int pair_cmp(const void* a, const void* b)
 
 /* b2BroadPhase::UpdatePairs (b2BroadPhase.h:211-267) + b2ContactManager::AddPair (:237-312) +
  * FinishFindNewContacts (:366-386) */
+static void sp_exchange_pairs(b2o_world* w, pair_t** pairs, int* n, int* cap);
+
 static void find_new_contacts(b2o_world* w)
 {
-	if (w->nMoves == 0) return;
+	if (w->nMoves == 0 && !(w->spatial && w->shardCount > 1)) return; /* (every rank of a sharded world takes part in the exchange) */
 	int cap = 1024, n = 0;
 	pair_t* pairs = (pair_t*)malloc(sizeof(pair_t) * (size_t)cap);
 	for (int k = 0; k < w->nMoves; ++k)
@@ -1156,6 +1183,7 @@ static void find_new_contacts(b2o_world* w)
 		int p = w->moves[k];
 		const fixture_t* fp = &w->fixtures[p];
 		if (fp->dead) continue;
+		if (sp_foreign_body(w, fp->body)) continue; /* every rank searches for the proxies ITS bodies moved */
 		for (int q = 0; q < w->nFixtures; ++q)
 		{
 			if (q == p) continue;
@@ -1173,6 +1201,7 @@ static void find_new_contacts(b2o_world* w)
 			pairs[n++] = pr;
 		}
 	}
+	if (w->spatial && w->shardCount > 1) sp_exchange_pairs(w, &pairs, &n, &cap); /* all ranks order and create the union */
 	qsort(pairs, (size_t)n, sizeof(pair_t), pair_cmp);
 	int prevLo = -1, prevHi = -1;
 	for (int i = 0; i < n; ++i)
@@ -1202,6 +1231,7 @@ static void find_new_contacts(b2o_world* w)
 	}
 	free(pairs);
 	w->nMoves = 0;
+	if (w->spatial) sp_resolve(w); /* a new contact may join components of different owners */
 }
 
 /* b2Body::SynchronizeFixtures (b2Body.cpp:475-489) + b2Fixture::Synchronize (b2Fixture.cpp:143-163) +
@@ -1986,7 +2016,7 @@ static void mark_owned(b2o_world* w, const int* bodies, int nb, const int* conta
 static void solve_islands(b2o_world* w, float h, float dtRatio, int velIters, int posIters)
 {
 	int nb = w->nBodies;
-	const int sharded = w->shardCount > 1;
+	const int sharded = w->shardCount > 1 && !w->spatial;
 	pending_island* pending = NULL;
 	int nPending = 0, capPending = 0;
 	GROW(w->bodyOwned, w->capBodyOwned, w->nBodies + 1, unsigned char);
@@ -2012,6 +2042,7 @@ static void solve_islands(b2o_world* w, float h, float dtRatio, int velIters, in
 		if (seed->type == 0) continue;
 		if (seed->flags & BF_ISLAND) continue;
 		if ((seed->flags & BF_AWAKE) == 0 || (seed->flags & BF_ACTIVE) == 0) continue;
+		if (sp_foreign_body(w, seedIdx)) continue; /* (another rank's: its whole component is) */
 		int bodyCount = 0, contactCount = 0, jointCount = 0, sp = 0;
 		stack[sp++] = seedIdx;
 		seed->flags |= BF_ISLAND;
@@ -2228,6 +2259,7 @@ static int find_min_toi(b2o_world* w, float* alphaOut)
 		contact_t* c = &w->contacts[slot];
 		if (!body_active_for_contact(&w->bodies[c->bodyA]) && !body_active_for_contact(&w->bodies[c->bodyB])) continue;
 		if ((c->flags & CF_ENABLED) == 0 || c->toiCount > B2O_MAX_SUB_STEPS) continue; /* IsMinToiCandidate */
+		if (sp_foreign_contact(w, c)) continue;
 		float alpha = compute_toi(w, c);
 		int less;
 		if (minContact < 0) less = 1;
@@ -2676,8 +2708,10 @@ static void finish_post_solve(b2o_world* w)
 
 /* ---- the phases of a step as separate entry points (same sequence as b2o_step; the sharded driver exchanges the solved
  * islands between b2o_phase_solve and b2o_phase_sync_fixtures) ---------------------------------------------------------- */
+static void sp_begin_step(b2o_world* w);
 void b2o_step_begin(b2o_world* w, float dt, int velIters, int posIters)
 {
+	if (w->spatial) sp_begin_step(w);
 	w->nEvents = 0;
 	w->nPostSolve = 0;
 	w->nToiLog = 0;
@@ -2698,7 +2732,14 @@ void b2o_phase_solve(b2o_world* w)
 	if (!w->stepComplete) return; /* b2World.cpp:1668 */
 	if (w->stepDt > 0.0f) solve_islands(w, w->stepDt, w->inv_dt0 * w->stepDt, w->stepVelIters, w->stepPosIters);
 }
-void b2o_phase_sync_fixtures(b2o_world* w) { if (w->stepComplete && w->stepDt > 0.0f) synchronize_fixtures(w); }
+void b2o_phase_sync_fixtures(b2o_world* w)
+{
+	if (w->stepComplete && w->stepDt > 0.0f)
+	{
+		synchronize_fixtures(w);
+		if (w->spatial) sp_exchange_state(w, 0);
+	}
+}
 void b2o_phase_find_new_contacts(b2o_world* w)
 {
 	if (w->stepComplete && w->stepDt > 0.0f)
@@ -2707,7 +2748,21 @@ void b2o_phase_find_new_contacts(b2o_world* w)
 		clear_post_solve(w);
 	}
 }
-void b2o_phase_solve_toi(b2o_world* w) { if (w->continuous && w->stepDt > 0.0f) solve_toi(w, w->stepDt, w->stepVelIters); }
+void b2o_phase_solve_toi(b2o_world* w)
+{
+	if (w->continuous && w->stepDt > 0.0f)
+	{
+		const uint64_t seq0 = w->nextSeq;
+		solve_toi(w, w->stepDt, w->stepVelIters);
+		if (w->spatial)
+		{
+			/* (the merge of contacts created inside TOI sub-steps over the ranks is the product's: k_sp_merge_tails; this shim
+			 * covers worlds whose events create none and says so otherwise) */
+			if (w->nextSeq != seq0) w->spFailed = 1;
+			sp_exchange_state(w, 1);
+		}
+	}
+}
 void b2o_step_end(b2o_world* w)
 {
 	if (w->stepDt > 0.0f) w->inv_dt0 = 1.0f / w->stepDt;
@@ -2828,6 +2883,18 @@ void b2o_shard_import(b2o_world* w, const int32_t* in, size_t strideWords)
 
 void b2o_step(b2o_world* w, float dt, int velIters, int posIters)
 {
+	if (w->spatial)
+	{
+		/* (the exchanges of a spatially sharded world hang on the phase entry points) */
+		b2o_step_begin(w, dt, velIters, posIters);
+		b2o_phase_collide(w);
+		b2o_phase_solve(w);
+		b2o_phase_sync_fixtures(w);
+		b2o_phase_find_new_contacts(w);
+		b2o_phase_solve_toi(w);
+		b2o_step_end(w);
+		return;
+	}
 	w->nEvents = 0;
 	w->nPostSolve = 0;
 	if (w->newFixture)
@@ -3422,3 +3489,423 @@ void b2o_joint_set_spring(b2o_world* w, int joint, float frequencyHz, float damp
 
 int b2o_body_is_destroyed(const b2o_world* w, int body) { return w->bodies[body].dead; }
 int b2o_fixture_is_destroyed(const b2o_world* w, int fixture) { return w->fixtures[fixture].dead; }
+
+
+/* ---- spatial ownership (see struct b2o_world::spatial) ------------------------------------------------------------------------
+ * A serial restatement of the protocol of box2d-mt_amd/csrc/b2d_kernels_spatial.h, for the multi-process CPU tests (gloo):
+ * E1 / E4 rows and fat AABBs of the bodies a rank moved (full rows: every rank holds every body's state), E2 new pairs, E3
+ * migration of components that a new contact or joint joins over an ownership boundary. Contacts are named by their slot
+ * (every rank creates and destroys the same contacts in the same order, so the slots agree). Not restated: the merge of
+ * contacts created INSIDE TOI sub-steps over the ranks (k_sp_merge_tails) - a step in which an event creates one fails. */
+#define SP_BODY_WORDS 18
+static int32_t sp_fb(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+static float sp_bf(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+
+/* all-gather of a variable number of words per rank: the counts first, then slabs of the largest count. Returns a buffer of
+ * shardCount * (*stride) words (caller frees) and every rank's count. */
+static int32_t* sp_gather(b2o_world* w, const int32_t* send, int words, int* counts, int* stride)
+{
+	const int n = w->shardCount;
+	int32_t mine = words;
+	int32_t* all = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+	if (w->gatherFn == NULL || w->gatherFn(w->gatherUser, &mine, sizeof(mine), all) != 0) { w->spFailed = 1; for (int r = 0; r < n; ++r) all[r] = r == w->shardRank ? words : 0; }
+	int most = 1;
+	for (int r = 0; r < n; ++r) { counts[r] = all[r]; if (all[r] > most) most = all[r]; }
+	free(all);
+	int32_t* pad = (int32_t*)calloc((size_t)most, sizeof(int32_t));
+	if (words > 0) memcpy(pad, send, sizeof(int32_t) * (size_t)words);
+	int32_t* recv = (int32_t*)calloc((size_t)most * (size_t)n, sizeof(int32_t));
+	if (w->gatherFn == NULL || w->gatherFn(w->gatherUser, pad, sizeof(int32_t) * (size_t)most, recv) != 0) w->spFailed = 1;
+	w->spBytes += (long long)sizeof(int32_t) * most * (n - 1);
+	free(pad);
+	*stride = most;
+	return recv;
+}
+
+static void sp_body_record(const body_t* b, int id, int32_t* o)
+{
+	o[0] = id;
+	o[1] = sp_fb(b->xf.p.x); o[2] = sp_fb(b->xf.p.y); o[3] = sp_fb(b->xf.q.s); o[4] = sp_fb(b->xf.q.c);
+	o[5] = sp_fb(b->c0.x); o[6] = sp_fb(b->c0.y); o[7] = sp_fb(b->c.x); o[8] = sp_fb(b->c.y);
+	o[9] = sp_fb(b->a0); o[10] = sp_fb(b->a); o[11] = 0; /* (alpha0 is 0 once the owner's step has ended) */
+	o[12] = sp_fb(b->v.x); o[13] = sp_fb(b->v.y); o[14] = sp_fb(b->w); o[15] = sp_fb(b->sleepTime);
+	o[16] = (b->flags & BF_AWAKE) ? 1 : 0;
+	o[17] = 0;
+}
+static void sp_body_apply(b2o_world* w, const int32_t* o)
+{
+	body_t* b = &w->bodies[o[0]];
+	b->xf.p = v_make(sp_bf(o[1]), sp_bf(o[2])); b->xf.q.s = sp_bf(o[3]); b->xf.q.c = sp_bf(o[4]);
+	b->c0 = v_make(sp_bf(o[5]), sp_bf(o[6])); b->c = v_make(sp_bf(o[7]), sp_bf(o[8]));
+	b->a0 = sp_bf(o[9]); b->a = sp_bf(o[10]); b->alpha0 = 0.0f;
+	b->v = v_make(sp_bf(o[12]), sp_bf(o[13])); b->w = sp_bf(o[14]); b->sleepTime = sp_bf(o[15]);
+	if (o[16]) b->flags |= BF_AWAKE;
+	else
+	{
+		b->flags &= ~BF_AWAKE;
+		b->force = v_make(0.0f, 0.0f);
+		b->torque = 0.0f;
+	}
+}
+
+/* E1 (behind SynchronizeFixtures: the bodies that were in an island) / E4 (behind SolveTOI: every body this rank owns - the
+ * shim keeps no snapshot to tell which ones the events touched) with the fat AABBs of their fixtures.
+ * layout: [nBodies][body records][fixture id, fat x 4]... */
+static void sp_exchange_state(b2o_world* w, int afterToi)
+{
+	if (w->shardCount < 2) return;
+	int cap = 1024, n = 1;
+	int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+	int nb = 0;
+	for (int pass = 0; pass < 2; ++pass)
+	{
+		for (int i = 0; i < w->nBodies; ++i)
+		{
+			const body_t* b = &w->bodies[i];
+			if (b->type == 0 || b->dead || w->owner[i] != (unsigned char)w->shardRank) continue;
+			if (!afterToi && (b->flags & BF_ISLAND) == 0) continue;
+			if (pass == 0)
+			{
+				GROW(out, cap, n + SP_BODY_WORDS, int32_t);
+				sp_body_record(b, i, out + n);
+				n += SP_BODY_WORDS;
+				++nb;
+			}
+			else
+			{
+				for (int f = b->fixtureHead; f >= 0; f = w->fixtures[f].nextInBody)
+				{
+					const fixture_t* fx = &w->fixtures[f];
+					if (fx->proxyId < 0 || fx->dead) continue;
+					GROW(out, cap, n + 5, int32_t);
+					out[n] = f;
+					for (int k = 0; k < 4; ++k) out[n + 1 + k] = sp_fb(fx->fat[k]);
+					n += 5;
+				}
+			}
+		}
+	}
+	out[0] = nb;
+	int counts[8], stride = 0;
+	int32_t* in = sp_gather(w, out, n, counts, &stride);
+	for (int r = 0; r < w->shardCount; ++r)
+	{
+		if (r == w->shardRank) continue;
+		const int32_t* o = in + (size_t)r * (size_t)stride;
+		const int bodies = o[0];
+		const int32_t* q = o + 1;
+		for (int k = 0; k < bodies; ++k, q += SP_BODY_WORDS) sp_body_apply(w, q);
+		for (; q + 5 <= o + counts[r]; q += 5)
+		{
+			fixture_t* fx = &w->fixtures[q[0]];
+			for (int k = 0; k < 4; ++k) fx->fat[k] = sp_bf(q[1 + k]);
+		}
+	}
+	free(in);
+	free(out);
+}
+
+/* E2: the candidate pairs of this rank's moved proxies out, everybody's in (the sort that follows drops the duplicates) */
+static void sp_exchange_pairs(b2o_world* w, pair_t** pairs, int* n, int* cap)
+{
+	int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)(2 * *n + 1));
+	for (int i = 0; i < *n; ++i) { out[2 * i] = (*pairs)[i].fLo; out[2 * i + 1] = (*pairs)[i].fHi; }
+	int counts[8], stride = 0;
+	int32_t* in = sp_gather(w, out, 2 * *n, counts, &stride);
+	for (int r = 0; r < w->shardCount; ++r)
+	{
+		if (r == w->shardRank) continue;
+		const int32_t* o = in + (size_t)r * (size_t)stride;
+		for (int k = 0; k + 1 < counts[r]; k += 2)
+		{
+			if (*n == *cap)
+			{
+				*cap *= 2;
+				*pairs = (pair_t*)realloc(*pairs, sizeof(pair_t) * (size_t)*cap);
+			}
+			pair_t pr;
+			pr.fLo = o[k]; pr.fHi = o[k + 1];
+			pr.lo = w->fixtures[pr.fLo].proxyId; pr.hi = w->fixtures[pr.fHi].proxyId;
+			(*pairs)[(*n)++] = pr;
+		}
+	}
+	free(in);
+	free(out);
+}
+
+static int sp_find(int* parent, int i)
+{
+	while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; }
+	return i;
+}
+static void sp_union(int* parent, int a, int b)
+{
+	a = sp_find(parent, a); b = sp_find(parent, b);
+	if (a == b) return;
+	if (a < b) parent[b] = a; else parent[a] = b;
+}
+
+/* E3: contacts / joints that join non-static bodies of different owners make their components (over ALL existing contacts
+ * between non-static bodies, and joints) merge under the owner that holds most of the bodies - every rank computes the
+ * same from the replicated structure - and the losers ship the content of what they maintained. */
+static void sp_resolve(b2o_world* w)
+{
+	int straddle = 0;
+	for (int s = 0; s < w->nContactSlots && !straddle; ++s)
+	{
+		const contact_t* c = &w->contacts[s];
+		if (c->alive && w->bodies[c->bodyA].type != 0 && w->bodies[c->bodyB].type != 0 && w->owner[c->bodyA] != w->owner[c->bodyB]) straddle = 1;
+	}
+	for (int j = 0; j < w->nJoints && !straddle; ++j)
+	{
+		const revolute_t* jn = &w->joints[j];
+		if (jn->type >= 0 && w->bodies[jn->bodyA].type != 0 && w->bodies[jn->bodyB].type != 0 && w->owner[jn->bodyA] != w->owner[jn->bodyB]) straddle = 1;
+	}
+	if (!straddle) return;
+	const int nb = w->nBodies, R = w->shardCount;
+	int* parent = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
+	for (int i = 0; i < nb; ++i) parent[i] = i;
+	for (int s = 0; s < w->nContactSlots; ++s)
+	{
+		const contact_t* c = &w->contacts[s];
+		if (c->alive && w->bodies[c->bodyA].type != 0 && w->bodies[c->bodyB].type != 0) sp_union(parent, c->bodyA, c->bodyB);
+	}
+	for (int j = 0; j < w->nJoints; ++j)
+	{
+		const revolute_t* jn = &w->joints[j];
+		if (jn->type < 0) continue;
+		const int nsA = w->bodies[jn->bodyA].type != 0, nsB = w->bodies[jn->bodyB].type != 0;
+		if (nsA && nsB) sp_union(parent, jn->bodyA, jn->bodyB);
+		if (jn->type == B2O_JOINT_GEAR)
+		{
+			const int others[2] = { jn->bodyC, jn->bodyD };
+			for (int k = 0; k < 2; ++k)
+			{
+				if (others[k] < 0 || w->bodies[others[k]].type == 0) continue;
+				if (nsA) sp_union(parent, jn->bodyA, others[k]); else if (nsB) sp_union(parent, jn->bodyB, others[k]);
+			}
+		}
+	}
+	/* components that hold a straddling contact / joint: bodies per owner, then the new owner */
+	int* count = (int*)calloc((size_t)(nb + 1) * (size_t)R, sizeof(int));
+	unsigned char* marked = (unsigned char*)calloc((size_t)nb + 1, 1);
+	for (int s = 0; s < w->nContactSlots; ++s)
+	{
+		const contact_t* c = &w->contacts[s];
+		if (c->alive && w->bodies[c->bodyA].type != 0 && w->bodies[c->bodyB].type != 0 && w->owner[c->bodyA] != w->owner[c->bodyB]) marked[sp_find(parent, c->bodyA)] = 1;
+	}
+	for (int j = 0; j < w->nJoints; ++j)
+	{
+		const revolute_t* jn = &w->joints[j];
+		if (jn->type >= 0 && w->bodies[jn->bodyA].type != 0 && w->bodies[jn->bodyB].type != 0 && w->owner[jn->bodyA] != w->owner[jn->bodyB]) marked[sp_find(parent, jn->bodyA)] = 1;
+	}
+	for (int i = 0; i < nb; ++i)
+	{
+		if (w->bodies[i].type == 0) continue;
+		const int root = sp_find(parent, i);
+		if (marked[root]) count[(size_t)root * (size_t)R + w->owner[i]] += 1;
+	}
+	unsigned char* newOwner = (unsigned char*)malloc((size_t)nb + 1);
+	for (int i = 0; i < nb; ++i)
+	{
+		newOwner[i] = w->owner[i];
+		if (w->bodies[i].type == 0) continue;
+		const int root = sp_find(parent, i);
+		if (!marked[root]) continue;
+		int best = 0;
+		for (int r = 1; r < R; ++r) if (count[(size_t)root * (size_t)R + r] > count[(size_t)root * (size_t)R + best]) best = r;
+		newOwner[i] = (unsigned char)best;
+	}
+	/* what this rank loses: [nBodies, nContacts, nJoints] body records, contact content (slot, flags, 16 manifold words,
+	 * friction, restitution, tangent speed, toi, toiCount, new owner), joint records (id, 4 impulses, limit state) */
+	int cap = 1024, n = 3, cb = 0, cc = 0, cj = 0;
+	int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+	const int me = w->shardRank;
+	for (int i = 0; i < nb; ++i)
+	{
+		if (w->bodies[i].type == 0 || w->owner[i] != me || newOwner[i] == me) continue;
+		GROW(out, cap, n + SP_BODY_WORDS, int32_t);
+		sp_body_record(&w->bodies[i], i, out + n);
+		out[n + 11] = sp_fb(w->bodies[i].alpha0);
+		out[n + 17] = newOwner[i];
+		n += SP_BODY_WORDS;
+		++cb;
+		w->spMigrated += 1;
+	}
+	for (int s = 0; s < w->nContactSlots; ++s)
+	{
+		const contact_t* c = &w->contacts[s];
+		if (!c->alive) continue;
+		const int nsA = w->bodies[c->bodyA].type != 0, nsB = w->bodies[c->bodyB].type != 0;
+		if (!nsA && !nsB) continue;
+		if (nsA && nsB && w->owner[c->bodyA] != w->owner[c->bodyB]) continue; /* (straddling: nobody has content for it yet) */
+		const int body = nsA ? c->bodyA : c->bodyB;
+		if (w->owner[body] != me || newOwner[body] == me) continue;
+		GROW(out, cap, n + 24, int32_t);
+		int32_t* o = out + n;
+		o[0] = s; o[1] = (int32_t)c->flags;
+		memcpy(o + 2, &c->m, sizeof(manifold)); /* 16 words */
+		o[18] = sp_fb(c->friction); o[19] = sp_fb(c->restitution); o[20] = sp_fb(c->tangentSpeed); o[21] = sp_fb(c->toi);
+		o[22] = c->toiCount; o[23] = newOwner[body];
+		n += 24;
+		++cc;
+	}
+	for (int j = 0; j < w->nJoints; ++j)
+	{
+		const revolute_t* jn = &w->joints[j];
+		if (jn->type < 0) continue;
+		const int nsA = w->bodies[jn->bodyA].type != 0, nsB = w->bodies[jn->bodyB].type != 0;
+		if (!nsA && !nsB) continue;
+		if (nsA && nsB && w->owner[jn->bodyA] != w->owner[jn->bodyB]) continue;
+		const int body = nsA ? jn->bodyA : jn->bodyB;
+		if (w->owner[body] != me || newOwner[body] == me) continue;
+		GROW(out, cap, n + 6, int32_t);
+		int32_t* o = out + n;
+		o[0] = j;
+		o[1] = sp_fb(jn->impulse[0]);
+		o[2] = sp_fb(jn->type == B2O_JOINT_WHEEL ? jn->springImpulse : jn->impulse[1]);
+		o[3] = sp_fb(jn->impulse[2]);
+		o[4] = sp_fb(jn->motorImpulse);
+		o[5] = jn->limitState;
+		n += 6;
+		++cj;
+	}
+	out[0] = cb; out[1] = cc; out[2] = cj;
+	int counts[8], stride = 0;
+	int32_t* in = sp_gather(w, out, n, counts, &stride);
+	for (int r = 0; r < R; ++r)
+	{
+		if (r == me) continue;
+		const int32_t* o = in + (size_t)r * (size_t)stride;
+		const int rb = o[0], rc = o[1], rj = o[2];
+		const int32_t* q = o + 3;
+		for (int k = 0; k < rb; ++k, q += SP_BODY_WORDS)
+		{
+			sp_body_apply(w, q);
+			w->bodies[q[0]].alpha0 = sp_bf(q[11]);
+		}
+		for (int k = 0; k < rc; ++k, q += 24)
+		{
+			if (q[23] != me) continue;
+			contact_t* c = &w->contacts[q[0]];
+			/* (the structural bits are equal on every rank: the TOI-candidate bit, the filter bit; the rest is content) */
+			c->flags = (uint32_t)q[1];
+			memcpy(&c->m, q + 2, sizeof(manifold));
+			c->friction = sp_bf(q[18]); c->restitution = sp_bf(q[19]); c->tangentSpeed = sp_bf(q[20]); c->toi = sp_bf(q[21]);
+			c->toiCount = q[22];
+		}
+		for (int k = 0; k < rj; ++k, q += 6)
+		{
+			revolute_t* jn = &w->joints[q[0]];
+			jn->impulse[0] = sp_bf(q[1]);
+			if (jn->type == B2O_JOINT_WHEEL) jn->springImpulse = sp_bf(q[2]); else jn->impulse[1] = sp_bf(q[2]);
+			jn->impulse[2] = sp_bf(q[3]);
+			jn->motorImpulse = sp_bf(q[4]);
+			jn->limitState = q[5];
+		}
+	}
+	memcpy(w->owner, newOwner, (size_t)nb);
+	w->spResolves += 1;
+	free(in); free(out); free(newOwner); free(marked); free(count); free(parent);
+}
+
+static unsigned char sp_strip_of(const b2o_world* w, float x)
+{
+	int r = 0;
+	while (r + 1 < w->shardCount && x >= w->spBounds[r + 1]) ++r;
+	return (unsigned char)r;
+}
+
+static void sp_begin_step(b2o_world* w)
+{
+	w->spBytes = 0;
+	if (w->capOwner < w->nBodies)
+	{
+		/* bodies created since the world was sharded fall into the strip of their x */
+		const int old = w->capOwner;
+		w->owner = (unsigned char*)realloc(w->owner, (size_t)w->nBodies + 64);
+		for (int i = old; i < w->nBodies; ++i) w->owner[i] = w->bodies[i].type == 0 ? 0 : sp_strip_of(w, w->bodies[i].c.x);
+		w->capOwner = w->nBodies;
+		w->spOwnersDirty = 1;
+	}
+	if (w->spOwnersDirty)
+	{
+		sp_resolve(w);
+		w->spOwnersDirty = 0;
+	}
+}
+
+typedef struct { float x; int i; } sp_xi;
+static int sp_xi_cmp(const void* a, const void* b)
+{
+	const sp_xi* p = (const sp_xi*)a;
+	const sp_xi* q = (const sp_xi*)b;
+	if (p->x != q->x) return p->x < q->x ? -1 : 1;
+	return p->i < q->i ? -1 : (p->i > q->i ? 1 : 0);
+}
+
+int b2o_shard_spatial(b2o_world* w, int rank, int count, const unsigned char* owners)
+{
+	if (count < 1 || count > 8 || rank < 0 || rank >= count) return -1;
+	w->shardRank = rank;
+	w->shardCount = count;
+	w->owner = (unsigned char*)realloc(w->owner, (size_t)w->nBodies + 64);
+	w->capOwner = w->nBodies;
+	memset(w->owner, 0, (size_t)w->nBodies + 64);
+	if (owners)
+	{
+		for (int i = 0; i < w->nBodies; ++i) w->owner[i] = w->bodies[i].type != 0 && owners[i] < count ? owners[i] : 0;
+		for (int r = 0; r <= 8; ++r) w->spBounds[r] = 0.0f;
+	}
+	else
+	{
+		/* strips of equal body count along x (the rule of b2hip_shard_spatial) */
+		sp_xi* xs = (sp_xi*)malloc(sizeof(sp_xi) * (size_t)(w->nBodies + 1));
+		int n = 0;
+		for (int i = 0; i < w->nBodies; ++i)
+		{
+			if (w->bodies[i].type == 0 || w->bodies[i].dead) continue;
+			xs[n].x = w->bodies[i].c.x; xs[n].i = i; ++n;
+		}
+		qsort(xs, (size_t)n, sizeof(sp_xi), sp_xi_cmp);
+		w->spBounds[0] = -3.0e38f;
+		for (int r = 1; r < count; ++r)
+		{
+			size_t k = (size_t)n * (size_t)r / (size_t)count;
+			if (n > 0 && k > (size_t)n - 1) k = (size_t)n - 1;
+			w->spBounds[r] = n > 0 ? xs[k].x : 0.0f;
+		}
+		for (int r = count; r <= 8; ++r) w->spBounds[r] = 3.0e38f;
+		for (int k = 0; k < n; ++k) w->owner[xs[k].i] = sp_strip_of(w, xs[k].x);
+		free(xs);
+	}
+	w->spatial = 1;
+	w->spOwnersDirty = 1;
+	w->spMigrated = 0;
+	w->spResolves = 0;
+	w->spFailed = 0;
+	return 0;
+}
+
+void b2o_set_shard_gather(b2o_world* w, int (*fn)(void*, const void*, size_t, void*), void* user) { w->gatherFn = fn; w->gatherUser = user; }
+int b2o_spatial_failed(const b2o_world* w) { return w->spFailed; }
+int b2o_get_body_owners(const b2o_world* w, int cap, unsigned char* out)
+{
+	if (!w->spatial) return -1;
+	const int n = cap < w->nBodies ? cap : w->nBodies;
+	for (int i = 0; i < n; ++i) out[i] = i < w->capOwner ? w->owner[i] : 0;
+	return n;
+}
+void b2o_get_shard_stats(const b2o_world* w, int32_t* out8, long long* out4)
+{
+	int bodies = 0, proxies = 0, contacts = 0;
+	for (int i = 0; i < w->nBodies && w->spatial; ++i)
+	{
+		if (w->bodies[i].type == 0 || w->bodies[i].dead || w->owner[i] != (unsigned char)w->shardRank) continue;
+		++bodies;
+		for (int f = w->bodies[i].fixtureHead; f >= 0; f = w->fixtures[f].nextInBody) if (w->fixtures[f].proxyId >= 0) ++proxies;
+	}
+	for (int s = 0; s < w->nContactSlots && w->spatial; ++s) if (w->contacts[s].alive && !sp_foreign_contact(w, &w->contacts[s])) ++contacts;
+	out8[0] = w->shardRank; out8[1] = w->shardCount; out8[2] = bodies; out8[3] = proxies; out8[4] = contacts; out8[5] = 0; out8[6] = 0; out8[7] = 0;
+	out4[0] = w->spMigrated; out4[1] = w->spResolves; out4[2] = w->spBytes; out4[3] = 0;
+}
