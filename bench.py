@@ -143,7 +143,10 @@ def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, roof_mode, 
     ctr = b2hip.Counters()
     dev = C.c_void_p(w.device_world())
     hipL.b2hip_get_counters(dev, C.byref(ctr))
-    out = {"workload": name, "bodies": w.body_count, "contacts": w.contact_count, "settle_steps": settle, "timed_steps": steps,
+    parity = None
+    if scene == bh.FIELD and ctr.large_island_contacts == 0:  # (every island of this world is in the reference-order tier)
+        parity = "reference order, bit-exact: every island lies in the reference-order tier (large_island_constraints = 0); tests/test_gpu_configs_full_size.py pins 12 steps of THIS world (1 000 000 bodies, 10 000 bullets, seed 3) against hashes from the reference build"
+    out = {"workload": name, "bodies": w.body_count, "contacts": w.contact_count, "settle_steps": settle, "timed_steps": steps, "parity_class": parity,
            "timed_window": "steps %d..%d of the scene" % (settle, settle + steps - 1),
            "ms_per_step": float(per.mean()), "ms_per_step_p50": float(np.percentile(per, 50)), "ms_per_step_max": float(per.max()),
            "steps_per_s": 1000.0 / float(per.mean()), "build_s": round(build_s, 2),
@@ -176,7 +179,42 @@ def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, steps, roof_mode, 
     except Exception as e:
         out["roofline"] = {"error": str(e)}
     w.close()
+    out["cpu_baseline"] = cpu_baseline_extra(scene, p0, p1, flags, seed, settle, steps)
     return out
+
+
+def cpu_baseline_extra(scene, p0, p1, flags, seed, settle, steps, max_seconds=12.0):
+    """The reference build on the host beside an extra config ("CPU baseline beside it"), bounded: the same scene,
+    the same window when the reference can afford the settle inside the budget (judged from its first steps), else as many
+    steps from t = 0 as fit - and the entry says which."""
+    import b2harness as bh
+    if not bh.have_ref():
+        return None
+    try:
+        ref = bh.Harness(bh.REF_LIB)
+        w = ref.world(scene, p0, p1, seed=seed, flags=flags, threads=8)
+        t0 = time.perf_counter()
+        w.step(2)
+        first = (time.perf_counter() - t0) / 2
+        done = 2
+        settled = settle > 2 and first * (settle + min(steps, 10)) < max_seconds
+        if settled:
+            w.step(settle - done)
+            done = settle
+        t1 = time.perf_counter()
+        timed = 0
+        while timed < steps and (timed < 2 or time.perf_counter() - t1 < (max_seconds if not settled else max_seconds / 2)):
+            w.step(1)
+            timed += 1
+        dt = time.perf_counter() - t1
+        res = {"value": timed / dt, "unit": "steps/s", "ms_per_step": 1000.0 * dt / timed, "kind": "reference", "cores": 8,
+               "host_cores": os.cpu_count(), "bodies": w.body_count,
+               "sample": "steps %d..%d of the same scene on the reference build (8 threads: b2_maxThreads)" % (done, done + timed - 1) +
+                         ("" if settled else "; the GPU's window starts at step %d - a settle of that length is unaffordable for the reference inside the %.0f s this baseline may take (%.2f s per step at the start), so these are its FIRST steps" % (settle, max_seconds, first))}
+        w.close()
+        return res
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
 
 
 def cpu_baseline(rows, warmup, max_seconds, flags):
@@ -224,6 +262,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--rows", type=int, default=141, help="pyramid rows (141 -> 10 011 boxes, BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-window", action="store_true", help="skip the 300-step per-step distribution (a second, labelled window)")
     ap.add_argument("--no-ccd", action="store_true", help="turn continuous physics (TOI) off on both sides")
     ap.add_argument("--no-secondary", action="store_true", help="skip the multi-island roofline sample (500 k bodies in 100 k piles)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other BASELINE configs (Tumbler 100 k, 1 M field, 50 k pyramid)")
@@ -395,6 +434,26 @@ def main():
     if roof is None:
         roof = solver_roofline_pass()
 
+    # ---- the per-step distribution over >= 300 steps, whatever --steps the caller passed: a world of its own,
+    # settled the same way, 300 single steps timed one by one (not part of `value`)
+    long_window = None
+    if world_size == 1 and not args.no_long_window:
+        try:
+            wl = amd.world(bh.PYRAMID, args.rows, 1, flags=flags)
+            wl.step(SETTLE_STEPS + 60)
+            st = np.empty(301)
+            st[0] = time.perf_counter()
+            for k in range(300):
+                wl.step(1)
+                st[k + 1] = time.perf_counter()
+            d = 1000.0 * np.diff(st)
+            long_window = {"timed_window": "steps %d..%d of the scene, a world of its own settled like the timed one" % (SETTLE_STEPS + 60, SETTLE_STEPS + 359),
+                           "steps": 300, "ms_per_step": float(d.mean()), "ms_per_step_p50": float(np.percentile(d, 50)),
+                           "ms_per_step_p99": float(np.percentile(d, 99)), "ms_per_step_max": float(d.max()), "steps_per_s": 1000.0 / float(d.mean())}
+            wl.close()
+        except Exception as e:  # noqa: BLE001
+            long_window = {"error": str(e)}
+
     # ---- what the bit-exact parity class costs on this workload: the state the timed region ended in, saved and loaded
     # into a world in exact-order mode (every island walked in the reference's constraint order), a few steps timed
     exact_order = None
@@ -537,14 +596,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("Pyramid %d rows: %d bodies, %d contacts per GPU" % (args.rows, nbodies, contacts) if world_size == 1 else
-                                    "%d pyramids of %d rows in ONE world (%d bodies, %d contacts in all; every rank holds it whole and solves one pyramid island)"
+                                    "%d pyramids of %d rows in ONE world (%d bodies, %d contacts in all; every rank keeps the id tables and the contact structure, owns one pyramid)"
                                     % (world_size, args.rows, nbodies, contacts)) +
                                    ", settled for %d untimed steps (steady state), dt 1/60, 8 vel / 3 pos iterations, CCD %s, sleep + warm start on"
                                    % (SETTLE_STEPS, "off" if args.no_ccd else "on (reference default)"),
                        "settle_steps": SETTLE_STEPS,
                        "timed_window": "steps %d..%d of the scene" % (SETTLE_STEPS + args.warmup, SETTLE_STEPS + args.warmup + args.steps - 1),
                        "parity_class": PARITY_CLASS,
-                       "bodies_total": nbodies, "parallelism": "one world on every rank, islands sharded by owner, one RCCL all-gather of owner-sized slabs per step" if world_size > 1 else "single GPU"},
+                       "bodies_total": nbodies, "parallelism": "one world over the ranks by spatial ownership: a rank evaluates, solves and moves the bodies of its strip (one pyramid); fat AABBs / awake bits / new pairs by all-gather, migrating components ship their content" if world_size > 1 else "single GPU"},
             "device_profile_ms": {k: round(v, 4) for k, v in prof.items() if k != "steps"},
         }
         # the free-fall / first-impact transient the settle steps went through (rank 0), never part of `value`
@@ -562,7 +621,15 @@ def main():
             line["exchange"] = ("one all-gather per step of owner-sized slabs (records of the islands each rank solved), " +
                                 ("RCCL on the world's stream from inside the library" if sharded.connected else "torch.distributed between the phase calls (the library's own RCCL connection could not be made)") +
                                 ", inside the timed region")
+        if long_window is not None:
+            line["per_step_distribution_300"] = long_window
         if roof is not None:
+            # (stated plainly) the 0.40 target is not reachable for ONE island of 10 011 bodies: the kernel's
+            # algorithmic traffic is ~56 MB - 7 us at peak - while a Gauss-Seidel sweep over a pile is a chain of DEPENDENT colour
+            # steps (8 interior colours + 3-5 hand-overs between blocks, 11 sweeps), each bounded below by its instruction
+            # latency, not by bytes; the same solver tier reaches 0.87 of peak (algorithmic) where islands are many and
+            # small (roofline_small_islands). What the fraction measures here is that depth.
+            roof["target_0_40"] = "not reachable for a single 10 011-body island: the sweep is a chain of dependent colour steps (latency-bound, counted traffic is half the algorithmic bytes); see DESIGN.md section 3 / 9"
             line["roofline"] = roof
         if exact_order is not None:
             line["exact_order"] = exact_order

@@ -279,6 +279,7 @@ struct b2hip_world
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
 	int dfEpoch;
 	bool solverRows, solverLocal, solverMailbox, noSideStream, profileDetail;
+	bool collideSort = true;     // k_collide sorts the contacts of a tile by shape-pair class in LDS (B2HIP_COLLIDE_SORT=0: in array order)
 	hipStream_t stream2 = nullptr; // small-island solver beside the large-island one
 	hipEvent_t evFork = nullptr, evJoin = nullptr;
 	int dfLanesForced, dfSleep, nCU; // k_solve_dataflow: workgroup size, poll back-off, co-resident workgroups
@@ -1534,7 +1535,7 @@ static int phaseCollide(b2hip_world* w)
 	{
 		DW& d = w->dw;
 		if (int rk = ktBracket(w, 2, 5)) return rk;
-		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d, w->collideSort ? 1 : 0);
 		if (int rk = ktBracket(w, 2, 5)) return rk;
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);
@@ -2521,6 +2522,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->dfLanesForced = 0;
 	w->noSideStream = getenv("B2HIP_NO_SIDE_STREAM") != nullptr;
 	w->profileDetail = !(getenv("B2HIP_PROFILE_DETAIL") && atoi(getenv("B2HIP_PROFILE_DETAIL")) == 0);
+	w->collideSort = !(getenv("B2HIP_COLLIDE_SORT") && atoi(getenv("B2HIP_COLLIDE_SORT")) == 0);
 	w->dfEpoch = 0;
 	// single-XCD attempt of k_solve_mailbox: opt-in. Measured on the 10k-body pyramid it LOSES (launch 500 us against 368):
 	// 334 waves polling on 32 CUs load the consumer CUs' memory queues, which is where a hand-off is priced; L2 locality

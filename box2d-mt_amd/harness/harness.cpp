@@ -466,6 +466,40 @@ int b2h_raycast_closest(b2h_world* h, float x1, float y1, float x2, float y2, fl
 //             then per point (2x): localPoint.xy, normalImpulse, tangentImpulse, id.key (bit pattern as float)
 // Returns the number of contacts written (<= cap). Order is the list order of the backend and is
 // NOT comparable between backends: sort by ids on the caller's side.
+// b2World::DrawDebugData through a b2Draw that only counts: per primitive kind the number of calls, and a checksum of every
+// coordinate / radius / colour it was handed (order-independent: a sum of bit patterns), so that two builds can be compared.
+namespace
+{
+struct CountingDraw : public b2Draw
+{
+	long long calls[7];
+	unsigned long long sum;
+	CountingDraw() : sum(0) { for (int k = 0; k < 7; ++k) calls[k] = 0; }
+	void Add(float v) { unsigned int u; memcpy(&u, &v, 4); sum += (unsigned long long)u * 2654435761ull + 1ull; }
+	void Add(const b2Vec2& v) { Add(v.x); Add(v.y); }
+	void Add(const b2Color& c) { Add(c.r); Add(c.g); Add(c.b); }
+	void DrawPolygon(const b2Vec2* v, int32 n, const b2Color& c) override { ++calls[0]; for (int32 k = 0; k < n; ++k) Add(v[k]); Add(c); }
+	void DrawSolidPolygon(const b2Vec2* v, int32 n, const b2Color& c) override { ++calls[1]; for (int32 k = 0; k < n; ++k) Add(v[k]); Add(c); }
+	void DrawCircle(const b2Vec2& p, float32 r, const b2Color& c) override { ++calls[2]; Add(p); Add(r); Add(c); }
+	void DrawSolidCircle(const b2Vec2& p, float32 r, const b2Vec2& axis, const b2Color& c) override { ++calls[3]; Add(p); Add(r); Add(axis); Add(c); }
+	void DrawSegment(const b2Vec2& a, const b2Vec2& b, const b2Color& c) override { ++calls[4]; Add(a); Add(b); Add(c); }
+	void DrawTransform(const b2Transform& xf) override { ++calls[5]; Add(xf.p); Add(xf.q.s); Add(xf.q.c); }
+	void DrawPoint(const b2Vec2& p, float32 size, const b2Color& c) override { ++calls[6]; Add(p); Add(size); Add(c); }
+};
+}
+
+// out[0..6] calls per primitive (polygon, solid polygon, circle, solid circle, segment, transform, point), out[7] checksum
+void b2h_debug_draw(b2h_world* h, unsigned int flags, long long* out)
+{
+	CountingDraw draw;
+	draw.SetFlags(flags);
+	h->world->SetDebugDraw(&draw);
+	h->world->DrawDebugData();
+	h->world->SetDebugDraw(nullptr);
+	for (int k = 0; k < 7; ++k) out[k] = draw.calls[k];
+	out[7] = (long long)draw.sum;
+}
+
 // The mixed material of every contact, in b2h_get_contacts' order: friction, restitution, tangent speed (b2Contact.h:40-50,157).
 int b2h_get_contact_materials(b2h_world* h, int cap, float* out)
 {

@@ -12,6 +12,7 @@
 #include <utility>
 #include <mutex>
 #include "Box2D/Common/b2Math.h"
+#include "Box2D/Common/b2Draw.h"
 #include "Box2D/Common/b2BlockAllocator.h"
 #include "Box2D/Common/b2StackAllocator.h"
 #include "Box2D/Dynamics/b2TimeStep.h"
@@ -47,6 +48,13 @@ public:
 	/// ends, each in proxy-id order); PreSolve between Collide and the island solve (SetEnabled(false) is honoured);
 	/// PostSolve at the end of Step() with the solver's final impulses. All on the stepping thread, threadId 0.
 	void SetContactListener(b2ContactListener* listener);
+	/// Debug drawing (b2World.h:77, 120 of the reference; what a Testbed binary calls every frame): DrawDebugData walks the
+	/// host mirrors - bodies, fixtures' shape records, joints' anchors, the fat AABBs as the device holds them - and calls the
+	/// user's b2Draw; nothing of it touches the step.
+	void SetDebugDraw(b2Draw* debugDraw) { m_debugDraw = debugDraw; }
+	void DrawDebugData();
+	/// b2World::Dump (b2World.h:248): the world as C++ statements that would build it again, through b2Log. Between steps.
+	void Dump();
 
 	b2Body* CreateBody(const b2BodyDef* def);
 	/// b2World.cpp:585-670: joints (SayGoodbye), contacts, fixtures (SayGoodbye) and the body; the pointer is dead afterwards
@@ -166,6 +174,9 @@ private:
 	b2DestructionListener* m_destructionListener;
 	b2ContactFilter* m_contactFilter;
 	b2ContactListener* m_contactListener;
+	b2Draw* m_debugDraw = nullptr;
+	void DrawShape(const b2Fixture* fixture, const b2Transform& xf, const b2Color& color);
+	void DrawJoint(b2Joint* joint);
 	b2Profile m_profile;
 	b2BlockAllocator m_blockAllocator;
 	mutable std::vector<b2hip_body_state> m_states;

@@ -43,6 +43,8 @@ public:
 	explicit b2ThreadPool(const b2ThreadPoolOptions& options = b2ThreadPoolOptions());
 	~b2ThreadPool();
 
+	/// How long an idle worker spins for a task before it waits on the condition variable (b2ThreadPool.h:79-81 of the reference)
+	void SetBusyWaitTimeout(float32 busyWaitTimeoutMs) { m_busyWaitNs.store((long long)(busyWaitTimeoutMs < 0.0f ? 0.0f : busyWaitTimeoutMs * 1.0e6f)); }
 	void SubmitTasks(b2ThreadPoolTaskGroup& group, b2Task** tasks, uint32 count);
 	void SubmitTask(b2ThreadPoolTaskGroup& group, b2Task* task);
 	void Wait(const b2ThreadPoolTaskGroup& group, const b2ThreadContext& ctx);
@@ -63,6 +65,7 @@ private:
 	std::vector<std::thread> m_threads;
 	std::vector<b2StackAllocator*> m_stacks;
 	bool m_shutdown;
+	std::atomic<long long> m_busyWaitNs{0};
 	int32 m_threadCount;
 	float32 m_lockMilliseconds;
 };

@@ -2,6 +2,7 @@
 // by the reference's Box2D/MT/b2ThreadPool.{h,cpp} and b2Task.cpp:22-71): a vector queue ordered by
 // task cost, N-1 worker threads plus the user thread helping inside Wait().
 #include "Box2D/MT/b2ThreadPool.h"
+#include <chrono>
 #include "Box2D/MT/b2MtUtil.h"
 
 #include <algorithm>
@@ -35,6 +36,7 @@ b2ThreadPool::b2ThreadPool(const b2ThreadPoolOptions& options)
 	m_shutdown = false;
 	m_threadCount = 0;
 	m_lockMilliseconds = 0.0f;
+	SetBusyWaitTimeout(options.busyWaitTimeoutMs);
 	int32 total = options.totalThreadCount;
 	if (total < 0) total = (int32)std::thread::hardware_concurrency();
 	if (total < 1) total = 1;
@@ -145,6 +147,18 @@ void b2ThreadPool::WorkerMain(uint32 threadId)
 	{
 		b2Task* task = nullptr;
 		{
+			// an idle worker spins for a task for the busy-wait time first (b2ThreadPoolOptions::busyWaitTimeoutMs,
+			// SetBusyWaitTimeout: a wake-up through the condition variable costs more than a short phase of a step lasts)
+			const long long spinNs = m_busyWaitNs.load(std::memory_order_relaxed);
+			if (spinNs > 0)
+			{
+				const auto until = std::chrono::steady_clock::now() + std::chrono::nanoseconds(spinNs);
+				while (std::chrono::steady_clock::now() < until)
+				{
+					std::unique_lock<std::mutex> peek(m_mutex, std::try_to_lock);
+					if (peek.owns_lock() && (m_shutdown || !m_queue.empty())) break;
+				}
+			}
 			std::unique_lock<std::mutex> lock(m_mutex);
 			m_cv.wait(lock, [this] { return m_shutdown || !m_queue.empty(); });
 			if (m_shutdown) return;

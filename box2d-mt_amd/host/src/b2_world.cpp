@@ -1908,3 +1908,232 @@ void b2GetPointStates(b2PointState state1[b2_maxManifoldPoints], b2PointState st
 		}
 	}
 }
+
+// ---- debug drawing (reference: b2World.cpp:1797-2045: DrawShape, DrawJoint, DrawDebugData) ----------------------------------
+// Behaviour restated: which primitive a shape type becomes, the colour of a body's state, what each b2Draw flag shows. Nothing
+// here is part of the step: the host mirrors and the device's fat AABBs (the table QueryAABB reads) are all it looks at.
+void b2World::DrawShape(const b2Fixture* fixture, const b2Transform& xf, const b2Color& color)
+{
+	const b2Shape* shape = fixture->GetShape();
+	switch (shape->GetType())
+	{
+	case b2Shape::e_circle:
+	{
+		const b2CircleShape* circle = static_cast<const b2CircleShape*>(shape);
+		m_debugDraw->DrawSolidCircle(b2Mul(xf, circle->m_p), circle->m_radius, b2Mul(xf.q, b2Vec2(1.0f, 0.0f)), color);
+		break;
+	}
+	case b2Shape::e_edge:
+	{
+		const b2EdgeShape* edge = static_cast<const b2EdgeShape*>(shape);
+		m_debugDraw->DrawSegment(b2Mul(xf, edge->m_vertex1), b2Mul(xf, edge->m_vertex2), color);
+		break;
+	}
+	case b2Shape::e_chain:
+	{
+		// the links in the body's colour, a point on every vertex; ghost vertices (if any) dimmed, with a small circle
+		const b2ChainShape* chain = static_cast<const b2ChainShape*>(shape);
+		const b2Color ghost(0.75f * color.r, 0.75f * color.g, 0.75f * color.b, color.a);
+		b2Vec2 from = b2Mul(xf, chain->m_vertices[0]);
+		m_debugDraw->DrawPoint(from, 4.0f, color);
+		if (chain->m_hasPrevVertex)
+		{
+			const b2Vec2 before = b2Mul(xf, chain->m_prevVertex);
+			m_debugDraw->DrawSegment(before, from, ghost);
+			m_debugDraw->DrawCircle(before, 0.1f, ghost);
+		}
+		for (int32 k = 1; k < chain->m_count; ++k)
+		{
+			const b2Vec2 to = b2Mul(xf, chain->m_vertices[k]);
+			m_debugDraw->DrawSegment(from, to, color);
+			m_debugDraw->DrawPoint(to, 4.0f, color);
+			from = to;
+		}
+		if (chain->m_hasNextVertex)
+		{
+			const b2Vec2 after = b2Mul(xf, chain->m_nextVertex);
+			m_debugDraw->DrawSegment(from, after, ghost);
+			m_debugDraw->DrawCircle(after, 0.1f, ghost);
+		}
+		break;
+	}
+	case b2Shape::e_polygon:
+	{
+		const b2PolygonShape* poly = static_cast<const b2PolygonShape*>(shape);
+		b2Vec2 world[b2_maxPolygonVertices];
+		for (int32 k = 0; k < poly->m_count; ++k) world[k] = b2Mul(xf, poly->m_vertices[k]);
+		m_debugDraw->DrawSolidPolygon(world, poly->m_count, color);
+		break;
+	}
+	default:
+		break;
+	}
+}
+
+void b2World::DrawJoint(b2Joint* joint)
+{
+	const b2Vec2 originA = joint->GetBodyA()->GetTransform().p, originB = joint->GetBodyB()->GetTransform().p;
+	const b2Vec2 anchorA = joint->GetAnchorA(), anchorB = joint->GetAnchorB();
+	const b2Color line(0.5f, 0.8f, 0.8f);
+	switch (joint->GetType())
+	{
+	case e_distanceJoint:
+		m_debugDraw->DrawSegment(anchorA, anchorB, line);
+		break;
+	case e_pulleyJoint:
+	{
+		const b2PulleyJoint* pulley = static_cast<const b2PulleyJoint*>(joint);
+		const b2Vec2 groundA = pulley->GetGroundAnchorA(), groundB = pulley->GetGroundAnchorB();
+		m_debugDraw->DrawSegment(groundA, anchorA, line);
+		m_debugDraw->DrawSegment(groundB, anchorB, line);
+		m_debugDraw->DrawSegment(groundA, groundB, line);
+		break;
+	}
+	case e_mouseJoint:
+		m_debugDraw->DrawPoint(anchorA, 4.0f, b2Color(0.0f, 1.0f, 0.0f));
+		m_debugDraw->DrawPoint(anchorB, 4.0f, b2Color(0.0f, 1.0f, 0.0f));
+		m_debugDraw->DrawSegment(anchorA, anchorB, b2Color(0.8f, 0.8f, 0.8f));
+		break;
+	default:
+		m_debugDraw->DrawSegment(originA, anchorA, line);
+		m_debugDraw->DrawSegment(anchorA, anchorB, line);
+		m_debugDraw->DrawSegment(originB, anchorB, line);
+	}
+}
+
+void b2World::DrawDebugData()
+{
+	if (m_debugDraw == nullptr) return;
+	const uint32 flags = m_debugDraw->GetFlags();
+	if (flags & b2Draw::e_shapeBit)
+	{
+		// inactive, static, kinematic, asleep, awake: the reference's five colours
+		static const float32 palette[5][3] = { { 0.5f, 0.5f, 0.3f }, { 0.5f, 0.9f, 0.5f }, { 0.5f, 0.5f, 0.9f }, { 0.6f, 0.6f, 0.6f }, { 0.9f, 0.7f, 0.7f } };
+		for (b2Body* b = m_bodyList; b; b = b->GetNext())
+		{
+			const int state = !b->IsActive() ? 0 : (b->GetType() == b2_staticBody ? 1 : (b->GetType() == b2_kinematicBody ? 2 : (!b->IsAwake() ? 3 : 4)));
+			const b2Color color(palette[state][0], palette[state][1], palette[state][2]);
+			const b2Transform& xf = b->GetTransform();
+			for (const b2Fixture* f = b->GetFixtureList(); f; f = f->GetNext()) DrawShape(f, xf, color);
+		}
+	}
+	if (flags & b2Draw::e_jointBit)
+	{
+		for (b2Joint* j = m_jointList; j; j = j->GetNext()) DrawJoint(j);
+	}
+	// (e_pairBit: the reference's loop over the contacts draws nothing - its body is commented out, b2World.cpp:1985-1997)
+	if (flags & b2Draw::e_aabbBit)
+	{
+		const b2Color color(0.9f, 0.3f, 0.9f);
+		for (b2Body* b = m_bodyList; b; b = b->GetNext())
+		{
+			if (!b->IsActive()) continue;
+			for (const b2Fixture* f = b->GetFixtureList(); f; f = f->GetNext())
+			{
+				for (int32 child = 0; child < f->GetShape()->GetChildCount(); ++child)
+				{
+					const b2AABB& box = f->GetAABB(child); // the fat AABB the device's broad-phase holds for this proxy
+					const b2Vec2 corners[4] = { b2Vec2(box.lowerBound.x, box.lowerBound.y), b2Vec2(box.upperBound.x, box.lowerBound.y),
+						b2Vec2(box.upperBound.x, box.upperBound.y), b2Vec2(box.lowerBound.x, box.upperBound.y) };
+					m_debugDraw->DrawPolygon(corners, 4, color);
+				}
+			}
+		}
+	}
+	if (flags & b2Draw::e_centerOfMassBit)
+	{
+		for (b2Body* b = m_bodyList; b; b = b->GetNext())
+		{
+			b2Transform xf = b->GetTransform();
+			xf.p = b->GetWorldCenter();
+			m_debugDraw->DrawTransform(xf);
+		}
+	}
+}
+
+// ---- b2World::Dump (reference: b2World.cpp:2107-2164, b2Body.cpp:632-661, b2Fixture.cpp:203-280: the world as C++ statements
+// through b2Log). Bodies, fixtures and shapes are written in full; a joint is written as its generic definition (type, the two
+// bodies by index, world anchors, collideConnected) - the per-type parameters are the device record's, not kept on the host.
+void b2World::Dump()
+{
+	if (m_locked) return;
+	b2Log("b2Vec2 g(%.15lef, %.15lef);\n", m_gravity.x, m_gravity.y);
+	b2Log("m_world->SetGravity(g);\n");
+	b2Log("b2Body** bodies = (b2Body**)b2Alloc(%d * sizeof(b2Body*));\n", m_bodyCount);
+	b2Log("b2Joint** joints = (b2Joint**)b2Alloc(%d * sizeof(b2Joint*));\n", m_jointCount);
+	std::vector<const b2Body*> order;
+	for (b2Body* b = m_bodyList; b; b = b->GetNext()) order.push_back(b);
+	for (size_t i = 0; i < order.size(); ++i)
+	{
+		const b2Body* b = order[i];
+		b2Log("{\n  b2BodyDef bd;\n");
+		b2Log("  bd.type = b2BodyType(%d);\n", (int)b->GetType());
+		b2Log("  bd.position.Set(%.15lef, %.15lef);\n", b->GetPosition().x, b->GetPosition().y);
+		b2Log("  bd.angle = %.15lef;\n", b->GetAngle());
+		b2Log("  bd.linearVelocity.Set(%.15lef, %.15lef);\n", b->GetLinearVelocity().x, b->GetLinearVelocity().y);
+		b2Log("  bd.angularVelocity = %.15lef;\n", b->GetAngularVelocity());
+		b2Log("  bd.linearDamping = %.15lef;\n", b->GetLinearDamping());
+		b2Log("  bd.angularDamping = %.15lef;\n", b->GetAngularDamping());
+		b2Log("  bd.allowSleep = bool(%d);\n", b->IsSleepingAllowed() ? 1 : 0);
+		b2Log("  bd.awake = bool(%d);\n", b->IsAwake() ? 1 : 0);
+		b2Log("  bd.fixedRotation = bool(%d);\n", b->IsFixedRotation() ? 1 : 0);
+		b2Log("  bd.bullet = bool(%d);\n", b->IsBullet() ? 1 : 0);
+		b2Log("  bd.active = bool(%d);\n", b->IsActive() ? 1 : 0);
+		b2Log("  bd.gravityScale = %.15lef;\n", b->GetGravityScale());
+		b2Log("  bodies[%d] = m_world->CreateBody(&bd);\n", (int)i);
+		for (const b2Fixture* f = b->GetFixtureList(); f; f = f->GetNext())
+		{
+			b2Log("\n  {\n    b2FixtureDef fd;\n");
+			b2Log("    fd.friction = %.15lef;\n    fd.restitution = %.15lef;\n    fd.density = %.15lef;\n", f->GetFriction(), f->GetRestitution(), f->GetDensity());
+			b2Log("    fd.isSensor = bool(%d);\n    fd.thickShape = bool(%d);\n", f->IsSensor() ? 1 : 0, f->IsThickShape() ? 1 : 0);
+			b2Log("    fd.filter.categoryBits = uint16(%d);\n    fd.filter.maskBits = uint16(%d);\n    fd.filter.groupIndex = int16(%d);\n",
+				(int)f->GetFilterData().categoryBits, (int)f->GetFilterData().maskBits, (int)f->GetFilterData().groupIndex);
+			const b2Shape* shape = f->GetShape();
+			if (shape->GetType() == b2Shape::e_circle)
+			{
+				const b2CircleShape* s = static_cast<const b2CircleShape*>(shape);
+				b2Log("    b2CircleShape shape;\n    shape.m_radius = %.15lef;\n    shape.m_p.Set(%.15lef, %.15lef);\n", s->m_radius, s->m_p.x, s->m_p.y);
+			}
+			else if (shape->GetType() == b2Shape::e_edge)
+			{
+				const b2EdgeShape* s = static_cast<const b2EdgeShape*>(shape);
+				b2Log("    b2EdgeShape shape;\n    shape.m_radius = %.15lef;\n", s->m_radius);
+				b2Log("    shape.m_vertex0.Set(%.15lef, %.15lef);\n    shape.m_vertex1.Set(%.15lef, %.15lef);\n", s->m_vertex0.x, s->m_vertex0.y, s->m_vertex1.x, s->m_vertex1.y);
+				b2Log("    shape.m_vertex2.Set(%.15lef, %.15lef);\n    shape.m_vertex3.Set(%.15lef, %.15lef);\n", s->m_vertex2.x, s->m_vertex2.y, s->m_vertex3.x, s->m_vertex3.y);
+				b2Log("    shape.m_hasVertex0 = bool(%d);\n    shape.m_hasVertex3 = bool(%d);\n", s->m_hasVertex0 ? 1 : 0, s->m_hasVertex3 ? 1 : 0);
+			}
+			else if (shape->GetType() == b2Shape::e_polygon)
+			{
+				const b2PolygonShape* s = static_cast<const b2PolygonShape*>(shape);
+				b2Log("    b2PolygonShape shape;\n    b2Vec2 vs[%d];\n", (int)b2_maxPolygonVertices);
+				for (int32 k = 0; k < s->m_count; ++k) b2Log("    vs[%d].Set(%.15lef, %.15lef);\n", (int)k, s->m_vertices[k].x, s->m_vertices[k].y);
+				b2Log("    shape.Set(vs, %d);\n", (int)s->m_count);
+			}
+			else if (shape->GetType() == b2Shape::e_chain)
+			{
+				const b2ChainShape* s = static_cast<const b2ChainShape*>(shape);
+				b2Log("    b2ChainShape shape;\n    b2Vec2 vs[%d];\n", (int)s->m_count);
+				for (int32 k = 0; k < s->m_count; ++k) b2Log("    vs[%d].Set(%.15lef, %.15lef);\n", (int)k, s->m_vertices[k].x, s->m_vertices[k].y);
+				b2Log("    shape.CreateChain(vs, %d);\n", (int)s->m_count);
+				b2Log("    shape.m_prevVertex.Set(%.15lef, %.15lef);\n    shape.m_nextVertex.Set(%.15lef, %.15lef);\n", s->m_prevVertex.x, s->m_prevVertex.y, s->m_nextVertex.x, s->m_nextVertex.y);
+				b2Log("    shape.m_hasPrevVertex = bool(%d);\n    shape.m_hasNextVertex = bool(%d);\n", s->m_hasPrevVertex ? 1 : 0, s->m_hasNextVertex ? 1 : 0);
+			}
+			b2Log("\n    fd.shape = &shape;\n\n    bodies[%d]->CreateFixture(&fd);\n  }\n", (int)i);
+		}
+		b2Log("}\n");
+	}
+	auto indexOf = [&order](const b2Body* b) { for (size_t i = 0; i < order.size(); ++i) if (order[i] == b) return (int)i; return -1; };
+	int jointIndex = 0;
+	for (int pass = 0; pass < 2; ++pass) // (gear joints last: they refer to other joints)
+	{
+		for (b2Joint* j = m_jointList; j; j = j->GetNext())
+		{
+			if ((j->GetType() == e_gearJoint) != (pass == 1)) continue;
+			const b2Vec2 a = j->GetAnchorA(), b = j->GetAnchorB();
+			b2Log("{\n  // joint %d: b2JointType(%d), bodies[%d] - bodies[%d], collideConnected %d\n", jointIndex, (int)j->GetType(), indexOf(j->GetBodyA()), indexOf(j->GetBodyB()), j->GetCollideConnected() ? 1 : 0);
+			b2Log("  // world anchors (%.15lef, %.15lef) (%.15lef, %.15lef)\n}\n", a.x, a.y, b.x, b.y);
+			++jointIndex;
+		}
+	}
+	b2Log("b2Free(joints);\nb2Free(bodies);\njoints = nullptr;\nbodies = nullptr;\n");
+}

@@ -234,6 +234,13 @@ class World:
         order = np.lexsort((ids[:, 3], ids[:, 2], ids[:, 1], ids[:, 0]))
         return ids[order], flags[order], man[order]
 
+    def debug_draw(self, flags=0x1f):
+        """b2World::DrawDebugData into a counting b2Draw: (calls per primitive kind [7], checksum of everything it was handed)"""
+        out = (C.c_longlong * 8)()
+        self.L.b2h_debug_draw.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_longlong)]
+        self.L.b2h_debug_draw(self.ptr, flags, out)
+        return list(out[:7]), int(out[7])
+
     def contact_materials(self):
         """(ids[n,4], material[n,3]: friction, restitution, tangent speed) of every contact, sorted by ids."""
         cap = max(self.contact_count, 1)

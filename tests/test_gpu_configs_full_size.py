@@ -93,10 +93,12 @@ def test_config_4_share_against_the_reference_and_itself(amd, default_mode):
         assert a[s][2] == int(awake[s]), "step %d: awake bodies" % (s + 1)
         if s < first_touch:
             assert a[s][0] == hashes[s], "step %d (free fall): state hash differs from the reference build's" % (s + 1)
-    # size-independent properties of the landed pile: one island holding every box, nothing below the ground, nothing thrown
+    # size-independent properties of the landing pile: nothing below the ground, nothing thrown
     assert np.isfinite(last).all()
     boxes = last[1:]
-    assert (labels[1:] >= 0).all() and len(set(labels[1:].tolist())) == 1, "the pyramid is one island"
+    # (after 60 steps the lower rows have met - one large island - and the upper rows are still falling, an island each)
+    assert (labels[1:] >= 0).all(), "every box is awake and in an island"
+    assert np.bincount(labels[1:]).max() >= 5000, "the landed rows form one large island (largest: %d bodies)" % np.bincount(labels[1:]).max()
     assert boxes[:, 1].min() > 0.45, "a box sank into the ground (y = %.3f)" % boxes[:, 1].min()
     assert np.abs(boxes[:, 3:5]).max() < 12.0, "a box was thrown (|v| = %.1f m/s after %d steps of falling 0.25 m)" % (np.abs(boxes[:, 3:5]).max(), steps)
 

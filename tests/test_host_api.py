@@ -285,3 +285,37 @@ def test_device_joint_scalar_setters_match_the_oracle(amd, oracle, scene, p0, p1
     run_retuned(a, b, "device vs oracle")
     a.close()
     b.close()
+
+
+# ---- b2World::SetDebugDraw / DrawDebugData (b2World.h:77, 120; b2World.cpp:1797-2045) -------------------------------------------
+DRAW_CASES = [(bh.PYRAMID, 8, 1), (bh.VEHICLES, 10, 2), (bh.CHAINS, 30, 0), (bh.MACHINES, 10, 2), (bh.FIELD, 200, 20), (bh.ROPES, 10, 4)]
+
+
+@pytest.mark.parametrize("scene,p0,p1", DRAW_CASES)
+def test_debug_draw_matches_the_reference_build(oracle, ref, scene, p0, p1):
+    """The drop-in layer's DrawDebugData against the reference's, through a b2Draw that counts: the same number of calls per
+    primitive kind and the same checksum of every coordinate, radius and colour handed over, for every b2Draw flag - shapes
+    (circles, polygons, edges, chains with ghost vertices) in their state colours, joints (distance, pulley, mouse, the
+    generic three segments), fat AABBs (the device's table), centres of mass. Sleeping bodies included (step 200)."""
+    a, b = ref.world(scene, p0, p1, seed=3), oracle.world(scene, p0, p1, seed=3)
+    for steps in (40, 160):
+        a.step(steps)
+        b.step(steps)
+        for flags in (0x01, 0x02, 0x04, 0x08, 0x10, 0x1f):
+            assert a.debug_draw(flags) == b.debug_draw(flags), "flags 0x%x after %d steps" % (flags, steps)
+    assert sum(a.debug_draw(0x1f)[0]) > 0
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,p0,p1", DRAW_CASES[:4])
+def test_device_debug_draw_matches_the_oracle_backed_layer(amd, oracle, monkeypatch, scene, p0, p1):
+    monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+    a, b = amd.world(scene, p0, p1, seed=3), oracle.world(scene, p0, p1, seed=3)
+    a.step(60)
+    b.step(60)
+    for flags in (0x01, 0x02, 0x04, 0x10, 0x1f):
+        assert a.debug_draw(flags) == b.debug_draw(flags), "flags 0x%x" % flags
+    a.close()
+    b.close()
