@@ -85,36 +85,64 @@ __device__ __forceinline__ bool isToiCandidate(const DW& W, int proxyA, int prox
 // b2World::FindMinToiContact re-synchronises sweeps, so it is mirrored here: ContactArrays::mgr is the slot,
 // toiPos2c its inverse. Few candidates die per step; one lane replays the removals.
 #define TOI_ORDER_SORT_MAX 2048
-// Run by the last workgroup of k_collide (256 lanes; it was a launch of its own behind it).
-__device__ __forceinline__ void toiOrderDestroy(const DW& W)
+// Run by the last workgroup of k_collide (256 lanes; it was a launch of its own behind it). Everything the replay reads more
+// than once is in LDS first - the keys (the ranking compares every pair), the slots of the dying contacts, the TAIL of the slot
+// table (the only entries a removal can move) - and the one lane that replays the removals in order reads LDS only; its
+// stores to the tables are fire and forget. (Round 4: with the keys fetched from memory inside the ranking loop and the
+// replay chasing three dependent loads per removal, this tail was most of k_collide's 220 us on the 1 M-body field, where
+// the bullets' fat AABBs make and break ~100 candidate contacts per step - not the evaluation of the manifolds.)
+#define TOI_ORDER_SCRATCH_BYTES (TOI_ORDER_SORT_MAX * (8 + 4 * 4))
+__device__ __forceinline__ void toiOrderDestroy(const DW& W, void* scratch)
 {
 	DState* S = W.st;
 	const int n = __hip_atomic_load(&S->c.nToiDestroy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	if (n == 0) return;
 	const ContactArrays& C = W.ca[S->cur];
-	__shared__ int s_sorted[TOI_ORDER_SORT_MAX];
+	uint64_t* s_key = (uint64_t*)scratch;
+	int* s_sorted = (int*)(s_key + TOI_ORDER_SORT_MAX);   // dying contacts in key order
+	int* s_slot = s_sorted + TOI_ORDER_SORT_MAX;          // ... their slots (kept up to date while earlier removals move them)
+	int* s_tail = s_slot + TOI_ORDER_SORT_MAX;            // contact in slot base + t
+	int* s_tailJ = s_tail + TOI_ORDER_SORT_MAX;           // ... its place in s_sorted if it is dying itself, else -1
 	const int m = n < TOI_ORDER_SORT_MAX ? n : TOI_ORDER_SORT_MAX;
+	const int count0 = S->c.nToiOrder;
+	const int base = count0 - m > 0 ? count0 - m : 0;
+	for (int i = threadIdx.x; i < m; i += blockDim.x) s_key[i] = C.key[b2dLoadAgentI(&W.toiDestroyList[i])];
+	__syncthreads();
 	// rank by key (keys are unique)
 	for (int i = threadIdx.x; i < m; i += blockDim.x)
 	{
-		const int ci = b2dLoadAgentI(&W.toiDestroyList[i]);
-		const uint64_t key = C.key[ci];
+		const uint64_t key = s_key[i];
 		int rank = 0;
-		for (int j = 0; j < m; ++j) rank += C.key[b2dLoadAgentI(&W.toiDestroyList[j])] < key ? 1 : 0;
+		for (int j = 0; j < m; ++j) rank += s_key[j] < key ? 1 : 0;
+		const int ci = b2dLoadAgentI(&W.toiDestroyList[i]);
 		s_sorted[rank] = ci;
+		s_slot[rank] = C.mgr[ci];
+	}
+	for (int t = threadIdx.x; t < count0 - base; t += blockDim.x) s_tail[t] = W.toiPos2c[base + t];
+	__syncthreads();
+	for (int t = threadIdx.x; t < count0 - base; t += blockDim.x)
+	{
+		const int c = s_tail[t];
+		int j = -1;
+		// (k_collide has set CF_DESTROY on every dying contact and its stores have landed: this is the last workgroup)
+		if (b2dLoadAgentI((const int*)&C.flags[c]) & (int)CF_DESTROY)
+			for (int q = 0; q < m; ++q) if (s_sorted[q] == c) { j = q; break; }
+		s_tailJ[t] = j;
 	}
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		int count = S->c.nToiOrder;
+		int count = count0;
 		for (int k = 0; k < m; ++k)
 		{
 			const int ci = s_sorted[k];
-			const int slot = C.mgr[ci];
+			const int slot = s_slot[k];
 			--count;
-			const int last = W.toiPos2c[count];
+			const int last = s_tail[count - base], lastJ = s_tailJ[count - base];
 			W.toiPos2c[slot] = last;
 			C.mgr[last] = slot;
+			if (slot >= base) { s_tail[slot - base] = last; s_tailJ[slot - base] = lastJ; }
+			if (lastJ >= 0) s_slot[lastJ] = slot;
 			C.mgr[ci] = -1;
 		}
 		S->c.nToiOrder = count;
@@ -153,6 +181,12 @@ __device__ __forceinline__ int collideClassKey(const DW& W, const ContactArrays&
 	return 59;
 }
 
+// STAGE: the two shape records of a lane's contact are copied into LDS with wide loads before the manifold is evaluated from
+// them. A world whose bodies share a few shape records (a box scene: one) reads them through the caches at the kernel's full
+// rate; a world where every body has a record of its own (the 1 M-body field: a million radii and n-gons) pays for every
+// vertex the SAT loops touch with a load instruction whose 64 lanes hit 64 different lines - ~200 such instructions per
+// wave against the 20 that fetch both records whole. The host picks the instantiation by the number of distinct records.
+template <int STAGE>
 __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 {
 	b2dPhaseStamp(W);
@@ -162,6 +196,10 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 	int nDestroy = 0, nTouch = 0;
 	__shared__ int s_bin[64];
 	__shared__ int s_perm[256];
+	// (152-byte records side by side: lanes read the same member 38 words apart - a two-way bank conflict at worst)
+	// (... and, once the contacts are done, the scratch of the last workgroup's toiOrderDestroy)
+	__shared__ __attribute__((aligned(16))) unsigned char s_raw[STAGE ? (512 * sizeof(ShapeRec) > TOI_ORDER_SCRATCH_BYTES ? 512 * sizeof(ShapeRec) : TOI_ORDER_SCRATCH_BYTES) : TOI_ORDER_SCRATCH_BYTES];
+	ShapeRec* const s_shape = (ShapeRec*)s_raw;
 	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
 		int i = base + (int)threadIdx.x;
@@ -305,6 +343,18 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 				{
 					const ShapeRec* sA = W.shapes + shapeA;
 					const ShapeRec* sB = W.shapes + shapeB;
+					if (STAGE)
+					{
+						static_assert(sizeof(ShapeRec) % 8 == 0, "ShapeRec is copied in 8-byte pieces");
+						const float2* gA = (const float2*)sA;
+						const float2* gB = (const float2*)sB;
+						float2* lA = (float2*)&s_shape[2 * threadIdx.x];
+						float2* lB = (float2*)&s_shape[2 * threadIdx.x + 1];
+#pragma unroll
+						for (int q = 0; q < (int)(sizeof(ShapeRec) / 8); ++q) { lA[q] = gA[q]; lB[q] = gB[q]; }
+						sA = &s_shape[2 * threadIdx.x];
+						sB = &s_shape[2 * threadIdx.x + 1];
+					}
 					// stale fields survive an early-out exactly like the reference's persistent manifold
 					o0s = o0;
 					o1s = o1;
@@ -392,7 +442,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 	if (nDestroy) atomicAdd(&S->c.nDestroy, nDestroy);
 	if (nTouch) atomicAdd(&S->c.nTouching, nTouch);
 	// the last workgroup to finish: the TOI candidates destroyed by this pass leave the manager's slot order
-	if (b2dLastBlockArrive(&S->c.collideBlocksDone)) toiOrderDestroy(W);
+	if (b2dLastBlockArrive(&S->c.collideBlocksDone)) toiOrderDestroy(W, s_raw);
 }
 
 // b2World::CreateJoint with collideConnected == false flags the contacts between the two bodies for

@@ -279,7 +279,8 @@ struct b2hip_world
 	DevArray<int> gridBar;       // grid barrier state of the persistent solver
 	int dfEpoch;
 	bool solverRows, solverLocal, solverMailbox, noSideStream, profileDetail;
-	bool collideSort = true;     // k_collide sorts the contacts of a tile by shape-pair class in LDS (B2HIP_COLLIDE_SORT=0: in array order)
+	int collideStage = -1;       // B2HIP_COLLIDE_STAGE=0 / 1: never / always stage the shape records through LDS (default: by the record count)
+	int collideSortEnv = -1;     // B2HIP_COLLIDE_SORT=0 / 1: k_collide never / always sorts the contacts of a tile by shape-pair class in LDS
 	hipStream_t stream2 = nullptr; // small-island solver beside the large-island one
 	hipEvent_t evFork = nullptr, evJoin = nullptr;
 	int dfLanesForced, dfSleep, nCU; // k_solve_dataflow: workgroup size, poll back-off, co-resident workgroups
@@ -1535,7 +1536,15 @@ static int phaseCollide(b2hip_world* w)
 	{
 		DW& d = w->dw;
 		if (int rk = ktBracket(w, 2, 5)) return rk;
-		LAUNCH(w, k_collide, gridFor(d.capContacts), 256, d, w->collideSort ? 1 : 0);
+		// (shape records staged through LDS where the world holds many distinct ones: b2d_kernels_collide.h)
+		// Measured (tools/gpu_collide_variants.py, profiles/r04_collide_variants.txt): on the 1 M-body field (a record per body,
+		// circles / boxes / n-gons mixed) staging + sorting a tile by shape-pair class 133 -> 124 us; on the 100 000-box Tumbler
+		// (one record, one class) the sort costs 2 % - so both follow the number of distinct records unless the environment says otherwise.
+		const bool many = w->shapes.size() > 4096;
+		const bool stage = w->collideStage < 0 ? many : w->collideStage != 0;
+		const int sort = w->collideSortEnv < 0 ? (many ? 1 : 0) : (w->collideSortEnv != 0 ? 1 : 0);
+		if (stage) LAUNCH(w, k_collide<1>, gridFor(d.capContacts), 256, d, sort);
+		else LAUNCH(w, k_collide<0>, gridFor(d.capContacts), 256, d, sort);
 		if (int rk = ktBracket(w, 2, 5)) return rk;
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);
@@ -2522,7 +2531,8 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->dfLanesForced = 0;
 	w->noSideStream = getenv("B2HIP_NO_SIDE_STREAM") != nullptr;
 	w->profileDetail = !(getenv("B2HIP_PROFILE_DETAIL") && atoi(getenv("B2HIP_PROFILE_DETAIL")) == 0);
-	w->collideSort = !(getenv("B2HIP_COLLIDE_SORT") && atoi(getenv("B2HIP_COLLIDE_SORT")) == 0);
+	w->collideSortEnv = getenv("B2HIP_COLLIDE_SORT") ? atoi(getenv("B2HIP_COLLIDE_SORT")) : -1;
+	w->collideStage = getenv("B2HIP_COLLIDE_STAGE") ? atoi(getenv("B2HIP_COLLIDE_STAGE")) : -1;
 	w->dfEpoch = 0;
 	// single-XCD attempt of k_solve_mailbox: opt-in. Measured on the 10k-body pyramid it LOSES (launch 500 us against 368):
 	// 334 waves polling on 32 CUs load the consumer CUs' memory queues, which is where a hand-off is priced; L2 locality
@@ -3236,6 +3246,11 @@ int b2hip_apply_force(b2hip_world* w, int body, float fx, float fy, float torque
 	if (w->bodies[body].type != B2HIP_DYNAMIC_BODY) return 0;
 	markDirty(w, body);
 	HostBody& b = w->bodies[body];
+	// (a row that was already dirty - an edit from a callback of the last step - has not been through pullBody: the forces it
+	// holds are the last step's, which the step cleared on the device, and its epoch must say that THIS force is new; else a
+	// later pull of the same step - a PreSolve edit - takes the force for a stale one and drops it)
+	if (w->def.auto_clear_forces && b.forceEpoch != w->stepEpoch) { b.fx = b.fy = b.torque = 0.0f; }
+	b.forceEpoch = w->stepEpoch;
 	if (wake && (b.flags & BF_AWAKE) == 0)
 	{
 		b.flags |= BF_AWAKE;

@@ -135,6 +135,7 @@ def test_default_mode_large_islands_stay_in_their_parity_class(amd, monkeypatch)
     whose block partition is the owning rank's own - the same parity class as the unsharded world (tests/test_gpu_onestep.py),
     not the same bits. Pinned: all ranks hold the same world, contact counts follow the unsharded world's, the piles stand."""
     monkeypatch.delenv("B2HIP_FORCE_LARGE", raising=False)
+    monkeypatch.setenv("B2HIP_SHARD_FULL_ROWS", "1")  # (every rank holds every body's row: the ranks are compared whole)
     L = b2hip.lib()
     ref = amd.world(bh.PYRAMID, 40, 4, seed=3, flags=CCD)
     ws = [amd.world(bh.PYRAMID, 40, 4, seed=3, flags=CCD) for _ in range(4)]

@@ -46,6 +46,14 @@ def trace(L, name, steps):
     return res, out
 
 
+def trace_hash(L, name, steps):
+    """FNV-1a of every body's full state (position, angle, velocities, awake, type: bit patterns) after every step"""
+    out = np.zeros(steps, np.uint64)
+    L.testbed_trace_hash.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    res = L.testbed_trace_hash(name.encode(), steps, out.ctypes.data)
+    return res, out
+
+
 def all_entries():
     import re
     return re.findall(r'\{ "(\w+)", ', open(os.path.join(ROOT, "tests", "testbed", "scenes_main.cpp")).read())
@@ -64,6 +72,11 @@ def test_reference_scenes_on_the_drop_in_layer_match_the_reference(name, steps):
     bad = np.nonzero((ta != tb).any(axis=1))[0]
     assert bad.size == 0, "%s: summaries differ first at step %d: %s vs %s" % (name, bad[0], ta[bad[0]], tb[bad[0]])
     assert ta[-1, 4] == 1.0 and ta[-1, 0] > 0
+    # ... and the full body state, bit for bit, after every step (the summaries are sums)
+    _, ha = trace_hash(load("ref"), name, steps)
+    _, hb = trace_hash(load("oracle"), name, steps)
+    bad = np.nonzero(ha != hb)[0]
+    assert bad.size == 0, "%s: body-state bits differ first at step %d" % (name, bad[0])
 
 
 def test_tunneling_test_predicate_on_the_drop_in_layer():
@@ -97,6 +110,10 @@ def test_reference_scenes_on_the_gpu_match_the_oracle_backed_run(name, steps, mo
     assert ra == rb
     bad = np.nonzero((ta != tb).any(axis=1))[0]
     assert bad.size == 0, "%s: summaries differ first at step %d: %s vs %s" % (name, bad[0], ta[bad[0]], tb[bad[0]])
+    _, ha = trace_hash(load("amd"), name, steps)
+    _, hb = trace_hash(load("oracle"), name, steps)
+    bad = np.nonzero(ha != hb)[0]
+    assert bad.size == 0, "%s: body-state bits differ first at step %d" % (name, bad[0])
 
 
 @pytest.mark.gpu

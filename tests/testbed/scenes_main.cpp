@@ -164,6 +164,38 @@ int testbed_trace(const char* name, int steps, double* trace)
 	return -1;
 }
 
+// The FULL state after every step as one number: FNV-1a over the bit patterns of position, angle, velocities of every body in
+// world order, with its awake flag and type - what two backends must agree on bit for bit (the six summary figures are sums).
+int testbed_trace_hash(const char* name, int steps, unsigned long long* hashes)
+{
+	for (const Entry& e : kEntries)
+	{
+		if (strcmp(e.name, name) != 0) continue;
+		srand(0);
+		Test* t = e.create();
+		Settings settings;
+		for (int i = 0; i < steps; ++i)
+		{
+			t->Step(&settings);
+			unsigned long long h = 1469598103934665603ull;
+			for (b2Body* b = t->GetWorld()->GetBodyList(); b; b = b->GetNext())
+			{
+				const float v[6] = { b->GetPosition().x, b->GetPosition().y, b->GetAngle(), b->GetLinearVelocity().x, b->GetLinearVelocity().y, b->GetAngularVelocity() };
+				unsigned int w[8];
+				memcpy(w, v, sizeof(v));
+				w[6] = b->IsAwake() ? 1u : 0u;
+				w[7] = (unsigned int)b->GetType();
+				for (int k = 0; k < 8; ++k) for (int q = 0; q < 4; ++q) h = (h ^ ((w[k] >> (8 * q)) & 0xffu)) * 1099511628211ull;
+			}
+			hashes[i] = h;
+		}
+		const int res = (int)t->TestPassed();
+		delete t;
+		return res;
+	}
+	return -1;
+}
+
 // Debugging aid: the body list (world order) after `steps` steps: x, y, angle, vx, vy, w, awake, type per body. Returns the
 // body count (at most cap rows are written).
 int testbed_states(const char* name, int steps, double* rows8, int cap)
