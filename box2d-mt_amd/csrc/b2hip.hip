@@ -25,20 +25,11 @@
 #include "../../include/b2hip.h"
 #include "b2d_kernels_toi_chains.h"
 #include "b2d_kernels_toi_domains.h"
-// The three earlier resident large-island solvers (grid barrier per colour, polled body rows, pushed mailboxes) are kept
-// for cross-checks only: built with -DB2HIP_VALIDATION_SOLVERS (make -C box2d-mt_amd validation -> libb2hip_validation.so,
-// used by tests/test_gpu_parity.py::test_block_solver_matches_launch_per_colour). The product has two large-island
-// solvers: k_solve_blocks and, where it does not apply (joints, hubs, exact-order mode, a partition that does not fit),
-// the launch-per-colour kernels.
+// (The three earlier resident large-island solvers of rounds 1 - 2 - grid barrier per colour, polled body rows, pushed
+// mailboxes - lived on as a test build until round 3 and were removed in round 4: k_solve_blocks / k_blocks_sweep are
+// cross-checked against the launch-per-colour kernels, tests/test_gpu_parity.py. What is left of them compiles out.)
 #include "b2d_handover.h"
-#ifdef B2HIP_VALIDATION_SOLVERS
-#include "../validation_src/b2d_validation_solvers.h"
-#endif
-#ifdef B2HIP_VALIDATION_SOLVERS
-#define B2HIP_HAVE_VALIDATION_SOLVERS 1
-#else
 #define B2HIP_HAVE_VALIDATION_SOLVERS 0
-#endif
 #include "b2d_kernels_solve_blocks.h"
 #include "b2d_kernels_edit.h"
 #include "b2d_kernels_shard.h"

@@ -13,9 +13,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libb2ref_harness.so")
 AMD_LIB = os.path.join(ROOT, "box2d-mt_amd", "libb2amd_harness.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libb2oracle_harness.so")
-# test build of the product with the three earlier resident large-island solvers compiled in (make -C box2d-mt_amd validation)
-VALIDATION_LIB = os.path.join(ROOT, "box2d-mt_amd", "validation", "libb2amd_harness_validation.so")
-VALIDATION_CAPI = os.path.join(ROOT, "box2d-mt_amd", "validation", "libb2hip_validation.so")
 
 HELLO, PYRAMID, TUMBLER, FIELD, PILES, RAIN, CIRCLE_STACK, BULLETS, SENSORS, ROPES, MACHINES, VEHICLES, LIFECYCLE, CHAINS, PROPS = range(15)
 F_CONTINUOUS, F_SLEEP, F_WARM, F_SUBSTEP = 1, 2, 4, 8

@@ -123,3 +123,23 @@ def test_reference_scenes_run_in_default_mode(name, steps):
     assert res in (NONE, PASS)
     assert (t[:, 4] == 1.0).all(), "non-finite body state"
     assert t[-1, 0] > 0
+
+
+# ---- ManyBodies1 .. 5 (10 000 - 50 000 bodies) directly against traces of the reference build -----------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BIG_SCENES)
+def test_many_bodies_1_to_5_on_the_gpu_match_the_reference_trace(name, monkeypatch):
+    """The reference's own large Testbed scenes, unmodified, on the product in its DEFAULT mode against traces generated
+    from the reference build in the container (tests/golden/testbed_big.npz, tests/golden/make_golden_testbed.py: the C
+    oracle's brute-force broad-phase cannot follow at these sizes): the six summaries and the hash of every body's full
+    state, step for step. (These fields are sparse: their islands stay in the reference-order tier.)"""
+    monkeypatch.delenv("B2HIP_FORCE_LARGE", raising=False)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "testbed_big.npz"))
+    want_s, want_h = g[name + "/summaries"], g[name + "/hashes"]
+    steps = len(want_h)
+    _, got_s = trace(load("amd"), name, steps)
+    _, got_h = trace_hash(load("amd"), name, steps)
+    bad = np.nonzero((got_s != want_s).any(axis=1))[0]
+    assert bad.size == 0, "%s: summaries differ from the reference build first at step %d: %s vs %s" % (name, bad[0], got_s[bad[0]], want_s[bad[0]])
+    bad = np.nonzero(got_h != want_h)[0]
+    assert bad.size == 0, "%s: body-state bits differ from the reference build first at step %d" % (name, bad[0])
