@@ -12,6 +12,7 @@ scene parameters that produced them. Fixtures are data; no reference source text
                       the device must reproduce these hashes bit for bit in its DEFAULT mode.
   config4_pyramid316  one 316-row pyramid (50 086 boxes: one GPU's share of config 4): contact counts while it comes down.
   config3_tumbler316  99 856 boxes in the revolving container, continuous physics off: contact counts of the first steps.
+  config4_4pyramids316  four such pyramids in one world (200 344 boxes): config 4 as BASELINE.json states it.
 """
 import os
 import sys
@@ -29,13 +30,21 @@ SCENES = [
     ("config5_field1m", bh.FIELD, 1000000, 10000, 3, CCD, 12),
     ("config4_pyramid316", bh.PYRAMID, 316, 1, 3, CCD, 60),
     ("config3_tumbler316", bh.TUMBLER, 316, 0, 3, bh.F_SLEEP | bh.F_WARM, 30),
+    # config 4 as stated: four disjoint 316-row pyramids in ONE world (what the 4 ranks of tests/test_gpu_spatial.py share)
+    ("config4_4pyramids316", bh.PYRAMID, 316, 4, 3, CCD, 40),
 ]
 
 
 def main():
     ref = bh.Harness(bh.REF_LIB)
     out = {}
+    path = os.path.join(HERE, "config_scale.npz")
+    if os.path.exists(path) and "--all" not in sys.argv:
+        old = np.load(path)
+        out = {k: old[k] for k in old.files}  # (scenes already in the file are kept: `--all` regenerates everything)
     for name, sc, p0, p1, seed, flags, steps in SCENES:
+        if name + "/hashes" in out:
+            continue
         t0 = time.time()
         w = ref.world(sc, p0, p1, seed=seed, flags=flags, threads=8)
         counts = np.zeros(steps, np.int32)

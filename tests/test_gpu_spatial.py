@@ -153,3 +153,84 @@ def test_default_mode_large_islands_stay_in_their_parity_class(amd, monkeypatch)
     for w in ws:
         w.close()
     ref.close()
+
+
+# ---- BASELINE configs 4 and 5 in their multi-GPU form, at FULL size, against traces of the reference build ------------------------
+GOLD_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_scale.npz")
+
+
+def _assemble(ws, sr, nb, static_mask):
+    """the world as its owners hold it: every body's row from the rank that owns it (static bodies from rank 0)"""
+    rows = ws[0].bodies().copy()
+    own = sr.owners(0, nb)
+    claimed = static_mask.copy()
+    for r, w in enumerate(ws):
+        mine = (own == r) & ~static_mask
+        if r > 0:
+            rows[mine] = w.bodies()[mine]
+        claimed |= mine
+    assert claimed.all()
+    return rows
+
+
+def test_config_5_over_8_ranks_at_full_size_is_the_reference_bit_for_bit(amd, monkeypatch):
+    """BASELINE config 5 as stated - 1 000 000 bodies + 10 000 bullets, continuous physics on, over EIGHT ranks - in the
+    default mode with the default (lean) exchange: the world assembled from its owners' rows reproduces the trace of the
+    reference build (tests/golden/config_scale.npz: contact count, awake count, the hash of all 8 000 008 state words) after
+    every step. Eight ranks in one process on one GPU (tests/spatial_util.py); the collective is a barrier."""
+    monkeypatch.delenv("B2HIP_FORCE_LARGE", raising=False)
+    monkeypatch.delenv("B2HIP_SHARD_FULL_ROWS", raising=False)
+    g = np.load(GOLD_PATH)
+    sc, p0, p1, seed, steps, flags = (int(x) for x in g["config5_field1m/params"])
+    counts, awake, hashes = g["config5_field1m/contact_counts"], g["config5_field1m/awake"], g["config5_field1m/hashes"]
+    ranks = 8
+    ws = [amd.world(sc, p0, p1, seed=seed, flags=flags) for _ in range(ranks)]
+    sr = SpatialRanks(b2hip.lib(), [(w, w.device_world()) for w in ws])
+    nb = ws[0].body_count
+    static_mask = ws[0].bodies()[:, 7] == 0
+    for s in range(min(steps, 8)):
+        sr.step()
+        rows = _assemble(ws, sr, nb, static_mask)
+        for w in ws:
+            assert w.contact_count == int(counts[s]), "step %d: %d contacts, the reference has %d" % (s + 1, w.contact_count, counts[s])
+        assert int((rows[:, 6] != 0).sum()) == int(awake[s]), "step %d: awake bodies" % (s + 1)
+        assert bh.fnv1a64(rows) == hashes[s], "step %d: the state the 8 ranks hold differs from the reference build's" % (s + 1)
+    stats = [sr.stats(r) for r in range(ranks)]
+    nonstatic = int((~static_mask).sum())
+    assert sum(st.owned_bodies for st in stats) == nonstatic
+    for st in stats:
+        assert 0.8 * nonstatic / ranks <= st.owned_bodies <= 1.2 * nonstatic / ranks, "rank %d owns %d of %d bodies" % (st.rank, st.owned_bodies, nonstatic)
+        assert st.owned_contacts <= 0.25 * int(counts[0]) + 1000
+    assert sum(st.migrated_bodies for st in stats) > 0, "no body ever crossed a strip boundary"
+    for w in ws:
+        w.close()
+
+
+def test_config_4_over_4_ranks_at_full_size_against_the_reference(amd, monkeypatch):
+    """BASELINE config 4 as stated - four disjoint 316-row pyramids (200 344 boxes) in one world over FOUR ranks, one pyramid
+    each - in the default mode: bit for bit the reference build's trace while the rows fall (nothing is solved before they
+    meet at step 13), the reference's contact counts for all 40 steps, one pyramid and a quarter of the contact content per rank."""
+    monkeypatch.delenv("B2HIP_FORCE_LARGE", raising=False)
+    monkeypatch.delenv("B2HIP_SHARD_FULL_ROWS", raising=False)
+    g = np.load(GOLD_PATH)
+    sc, p0, p1, seed, steps, flags = (int(x) for x in g["config4_4pyramids316/params"])
+    counts, awake, hashes = g["config4_4pyramids316/contact_counts"], g["config4_4pyramids316/awake"], g["config4_4pyramids316/hashes"]
+    ranks = 4
+    ws = [amd.world(sc, p0, p1, seed=seed, flags=flags) for _ in range(ranks)]
+    sr = SpatialRanks(b2hip.lib(), [(w, w.device_world()) for w in ws])
+    nb = ws[0].body_count
+    static_mask = ws[0].bodies()[:, 7] == 0
+    for s in range(steps):
+        sr.step()
+        for w in ws:
+            assert abs(w.contact_count - int(counts[s])) <= 1e-4 * counts[s], "step %d: %d contacts, the reference has %d" % (s + 1, w.contact_count, counts[s])
+        if s < 12:
+            rows = _assemble(ws, sr, nb, static_mask)
+            assert bh.fnv1a64(rows) == hashes[s], "step %d (free fall): the state the 4 ranks hold differs from the reference build's" % (s + 1)
+    stats = [sr.stats(r) for r in range(ranks)]
+    for st in stats:
+        assert st.owned_bodies == 316 * 317 // 2, "one pyramid per rank (rank %d owns %d bodies)" % (st.rank, st.owned_bodies)
+        assert st.owned_contacts <= 0.26 * int(counts[-1])
+        assert st.migrated_bodies == 0
+    for w in ws:
+        w.close()

@@ -48,5 +48,10 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_field -- p
 python3 tools/trace_steady.py /tmp/prof_field 10 > $OUT/field1m_steady_state_per_step.txt
 timeout 100 python3 tools/gpu_floor.py 3000 1 > $OUT/floor.txt 2>&1; timeout 100 python3 tools/gpu_floor.py 3000 0 >> $OUT/floor.txt 2>&1
 timeout 300 python3 tools/gpu_lazy_field.py > $OUT/lazy_readback_field1m.txt 2>&1
+# round 4: what ONE rank of a spatially sharded world pays (recorded over 4 in-process ranks, rank 0 replayed alone), and
+# k_collide on the 1 M field (PMC traffic of the field run above covers it: pmc_field_*.csv list every kernel)
+timeout 900 python3 tools/gpu_spatial_share.py 316 4 320 40 > $OUT/spatial_share.txt 2>&1
+timeout 600 python3 tools/gpu_spatial_share.py 141 4 245 40 >> $OUT/spatial_share.txt 2>&1
+python3 tools/pmc_traffic_json.py $OUT k_collide field1000000_collide $OUT/pmc_field_fetch_size.csv $OUT/pmc_field_write_size.csv > $OUT/field_collide_pmc_traffic.json 2>/dev/null
 head -3 $OUT/pmc_fetch_size.csv; head -3 $OUT/pmc_write_size.csv; head -4 $OUT/steady_state_per_step.txt; cat $OUT/pmc_traffic.json $OUT/piles_pmc_traffic.json $OUT/tumbler_pmc_traffic.json $OUT/field_pmc_traffic.json $OUT/floor.txt
 python3 tools/print_bench.py $OUT/bench.json
