@@ -182,6 +182,15 @@ __device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q
 {
 	const int bodyP = W.p_body[p], bodyQ = W.p_body[q];
 	if (bodyP == bodyQ) return;
+	if (W.spatial)
+	{
+		// a spatially sharded world: a rank emits the pairs one of ITS bodies takes part in (a moved static proxy - a host edit
+		// every rank made - is searched by every rank: its pair with another rank's body is that rank's to emit). The hash set
+		// of existing contacts then only needs this rank's own contacts (k_bp_build).
+		const bool mineP = (W.b_flags[bodyP] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyP] == (uint8_t)W.shardRank;
+		const bool mineQ = (W.b_flags[bodyQ] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyQ] == (uint8_t)W.shardRank;
+		if (!mineP && !mineQ) return;
+	}
 	const int keyP = W.p_key[p], keyQ = W.p_key[q];
 	const int lo = keyP < keyQ ? p : q;
 	const int hi = keyP < keyQ ? q : p;

@@ -725,26 +725,39 @@ __device__ __forceinline__ uint32_t hashKey(uint64_t k)
 	return (uint32_t)k;
 }
 
+// The part of the table a pair update uses: sized for the LIVE contacts (at most 25 % load), not for the array's capacity -
+// the table is cleared every update, and the capacity of a world that once saw a burst of pairs (the 1 M-body field:
+// 16 M slots, 128 MB) cost 120 us of clearing per step for 130 000 keys. Every kernel of one update (clear, build, the
+// pair search) derives the same mask from Counters::nContacts, which only the update's own commit changes.
+__device__ __forceinline__ uint32_t htLiveMask(const DW& W)
+{
+	const uint32_t want = 4u * (uint32_t)W.st->c.nContacts + 1024u;
+	uint32_t m = 0xffffffffu >> __clz((int)(want | 1u)); // next power of two above `want`, minus one
+	return m < W.htMask ? m : W.htMask;
+}
+
 __device__ __forceinline__ void htInsert(const DW& W, uint64_t key)
 {
-	uint32_t h = hashKey(key) & W.htMask;
+	const uint32_t mask = htLiveMask(W);
+	uint32_t h = hashKey(key) & mask;
 	for (;;)
 	{
 		unsigned long long old = atomicCAS((unsigned long long*)&W.ht_keys[h], 0ull, (unsigned long long)key);
 		if (old == 0ull || old == key) return;
-		h = (h + 1) & W.htMask;
+		h = (h + 1) & mask;
 	}
 }
 
 __device__ __forceinline__ bool htContains(const DW& W, uint64_t key)
 {
-	uint32_t h = hashKey(key) & W.htMask;
+	const uint32_t mask = htLiveMask(W);
+	uint32_t h = hashKey(key) & mask;
 	for (;;)
 	{
 		uint64_t v = W.ht_keys[h];
 		if (v == key) return true;
 		if (v == 0) return false;
-		h = (h + 1) & W.htMask;
+		h = (h + 1) & mask;
 	}
 }
 
@@ -752,7 +765,7 @@ __global__ __launch_bounds__(256) void k_ht_clear(DW W)
 {
 	b2dPhaseStamp(W);
 	if (W.st->c.nMoves == 0) return;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= W.htMask; i += gridDim.x * blockDim.x)
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, live = htLiveMask(W); i <= live; i += gridDim.x * blockDim.x)
 	{
 		W.ht_keys[i] = 0;
 	}

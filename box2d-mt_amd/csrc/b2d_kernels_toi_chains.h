@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 		W.gridCount[i] = 0;
 		W.gridCursor[i] = 0;
 	}
-	for (uint32_t i = t0; i <= W.htMask; i += stride) W.ht_keys[i] = 0;
+	for (uint32_t i = t0, live = htLiveMask(W); i <= live; i += stride) W.ht_keys[i] = 0; // (the part this update uses)
 }
 
 __global__ __launch_bounds__(256) void k_bp_build(DW W)
@@ -881,7 +881,8 @@ __global__ __launch_bounds__(256) void k_bp_build(DW W)
 	const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
 	const int nC = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
-	for (int i = t0; i < nC; i += stride) htInsert(W, C.key[i] + 1ull);
+	// (the pair search asks the set only about pairs of this rank's bodies: another rank's contacts stay out - tryEmitPair)
+	for (int i = t0; i < nC; i += stride) if ((C.flags[i] & CF_FOREIGN) == 0) htInsert(W, C.key[i] + 1ull);
 	const int n = W.nProxies;
 	for (int p = t0; p < n; p += stride)
 	{

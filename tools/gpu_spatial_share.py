@@ -7,22 +7,37 @@ item 2: "a one-GPU proxy run showing a rank's step for config 4 <= 1.15 x a one-
      clock of its timed steps is a rank's step, the exchange being a host round trip (D2H of its slab, H2D of all slabs) in
      place of RCCL over xGMI;
   3. the same steps of a world that holds ONE pyramid, unsharded.
-usage: gpu_spatial_share.py <rows> <pyramids = ranks> <settle> <timed>   (CCD on, default mode)"""
+usage: gpu_spatial_share.py <rows> <pyramids = ranks> <settle> <timed>   (CCD on, default mode)
+       gpu_spatial_share.py field <bodies> <bullets> <ranks> <settle> <timed>   (config 5: the field over `ranks` strips; part 3 is
+       then the whole field on one GPU, unsharded)"""
 import os, sys, time, ctypes as C, threading
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
 import b2harness as H, b2hip
 import spatial_util as SU
-rows, ranks, settle, timed = (int(a) for a in sys.argv[1:5])
+FIELD = sys.argv[1] == "field"
+if FIELD:
+    bodies, bullets, ranks, settle, timed = (int(a) for a in sys.argv[2:7])
+    rows = bodies
+else:
+    rows, ranks, settle, timed = (int(a) for a in sys.argv[1:5])
 amd = H.Harness(H.AMD_LIB); L = b2hip.lib()
 flags = H.F_SLEEP | H.F_WARM | H.F_CONTINUOUS
+
+
+def make(count):
+    """the world: `count` pyramids, or the field (count is ignored: the ranks share ONE field)"""
+    return amd.world(H.FIELD, bodies, bullets, seed=3, flags=flags) if FIELD else amd.world(H.PYRAMID, rows, count, seed=3, flags=flags)
+
+
+WHAT = ("the field of %d bodies / %d bullets" % (bodies, bullets)) if FIELD else "%d pyramids of %d rows" % (ranks, rows)
 L.b2hip_shard_spatial.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 L.b2hip_set_shard_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 
 # ---- 1. record ------------------------------------------------------------------------------------------------------------
 L.b2hip_shard_tape.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-ws = [amd.world(H.PYRAMID, rows, ranks, seed=3, flags=flags) for _ in range(ranks)]
+ws = [make(ranks) for _ in range(ranks)]
 sr = SU.SpatialRanks(L, [(w, w.device_world()) for w in ws])
 assert L.b2hip_shard_tape(C.c_void_p(ws[0].device_world()), 1, None) == 0  # rank 0 keeps what its collectives delivered (device memory)
 t0 = time.time()
@@ -35,12 +50,12 @@ st = [sr.stats(r) for r in range(ranks)]
 nb = ws[0].body_count
 own_end = sr.owners(0, nb)
 hash_end = H.fnv1a64(ws[0].bodies()[own_end == 0])
-print("recorded %d steps of %d pyramids of %d rows over %d ranks in %.1f s: %d collectives, %.1f MB; rank 0 owns %d bodies, %d contacts with content, %d rows of %d contacts in the world" % (
-    settle + timed, ranks, rows, ranks, time.time() - t0, sr.gather.calls, sr.gather.bytes / 1e6, st[0].owned_bodies, st[0].owned_contacts, st[0].constraint_rows, ws[0].contact_count), flush=True)
+print("recorded %d steps of %s over %d ranks in %.1f s: %d collectives, %.1f MB; rank 0 owns %d bodies, %d contacts with content, %d rows of %d contacts in the world" % (
+    settle + timed, WHAT, ranks, time.time() - t0, sr.gather.calls, sr.gather.bytes / 1e6, st[0].owned_bodies, st[0].owned_contacts, st[0].constraint_rows, ws[0].contact_count), flush=True)
 for w in ws[1:]: w.close()
 
 # ---- 2. replay: rank 0 alone ------------------------------------------------------------------------------------------------
-w0 = amd.world(H.PYRAMID, rows, ranks, seed=3, flags=flags)
+w0 = make(ranks)
 assert L.b2hip_shard_spatial(C.c_void_p(w0.device_world()), 0, ranks, None) == 0
 assert L.b2hip_shard_tape(C.c_void_p(w0.device_world()), 2, C.c_void_p(ws[0].device_world())) == 0
 w0.step(settle)
@@ -62,27 +77,30 @@ print("   device profile of rank 0 (ms per step):", {k: round(v, 4) for k, v in 
 w0.close()
 ws[0].close()
 
-# ---- 3. one pyramid, unsharded ------------------------------------------------------------------------------------------------
-w1 = amd.world(H.PYRAMID, rows, 1, seed=3, flags=flags)
-w1.step(settle)
-w1.reset_profile()
-stamps = [time.perf_counter()]
-for s in range(timed):
-    w1.step(1)
-    stamps.append(time.perf_counter())
-one = 1000.0 * np.diff(stamps)
-print("one pyramid of %d rows, unsharded, same steps: %.3f ms per step (p50 %.3f)  ->  a rank of the %d-pyramid world pays %.2f x (p50 %.2f x)" % (
-    rows, one.mean(), np.percentile(one, 50), ranks, per.mean() / one.mean(), np.percentile(per, 50) / np.percentile(one, 50)), flush=True)
-print("   device profile (ms per step):", {k: round(v, 4) for k, v in w1.profile().items() if k != "steps"})
-w1.close()
+# ---- 3. one rank's share as a world of its own (one pyramid), unsharded --------------------------------------------------------------
+if not FIELD:
+    w1 = make(1)
+    w1.step(settle)
+    w1.reset_profile()
+    stamps = [time.perf_counter()]
+    for s in range(timed):
+        w1.step(1)
+        stamps.append(time.perf_counter())
+    one = 1000.0 * np.diff(stamps)
+    print("one pyramid of %d rows, unsharded, same steps: %.3f ms per step (p50 %.3f)  ->  a rank of the %d-pyramid world pays %.2f x (p50 %.2f x)" % (
+        rows, one.mean(), np.percentile(one, 50), ranks, per.mean() / one.mean(), np.percentile(per, 50) / np.percentile(one, 50)), flush=True)
+    print("   device profile (ms per step):", {k: round(v, 4) for k, v in w1.profile().items() if k != "steps"})
+    w1.close()
 
-# ---- 4. the whole N-pyramid world on one GPU, unsharded (what sharding has to beat) ---------------------------------------------
-wN = amd.world(H.PYRAMID, rows, ranks, seed=3, flags=flags)
+# ---- 4. the whole world on one GPU, unsharded (what sharding has to beat) ----------------------------------------------------------
+wN = make(ranks)
 wN.step(settle)
+wN.reset_profile()
 stamps = [time.perf_counter()]
 for s in range(timed):
     wN.step(1)
     stamps.append(time.perf_counter())
 allN = 1000.0 * np.diff(stamps)
-print("%d pyramids in one unsharded world on one GPU: %.3f ms per step" % (ranks, allN.mean()))
+print("%s in one unsharded world on one GPU: %.3f ms per step  ->  %d ranks at %.3f ms each: %.2f x" % (WHAT, allN.mean(), ranks, per.mean(), allN.mean() / per.mean()))
+print("   device profile (ms per step):", {k: round(v, 4) for k, v in wN.profile().items() if k != "steps"})
 wN.close()
