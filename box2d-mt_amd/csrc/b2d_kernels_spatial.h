@@ -824,14 +824,25 @@ __global__ __launch_bounds__(256) void k_sp_owner_census(DW W)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
+	// (a workgroup counts in LDS and sends one atomic per rank and counter: a million bodies on sixteen words is otherwise
+	// a million same-address atomics - 5 ms of the 1 M-body field's resolution)
+	__shared__ int s_bodies[SHARD_MAX_RANKS], s_proxies[SHARD_MAX_RANKS];
+	if (threadIdx.x < SHARD_MAX_RANKS) { s_bodies[threadIdx.x] = 0; s_proxies[threadIdx.x] = 0; }
+	__syncthreads();
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
 	{
 		if ((W.b_flags[i] & BF_TYPE_MASK) == BT_STATIC) continue;
 		const int o = W.b_owner[i];
 		int np = 0;
 		for (int q = W.b_proxyHead[i]; q >= 0; q = W.p_next[q]) ++np;
-		atomicAdd(&S->c.spBodies[o], 1);
-		atomicAdd(&S->c.spProxies[o], np);
+		atomicAdd(&s_bodies[o], 1);
+		atomicAdd(&s_proxies[o], np);
+	}
+	__syncthreads();
+	if (threadIdx.x < SHARD_MAX_RANKS)
+	{
+		if (s_bodies[threadIdx.x]) atomicAdd(&S->c.spBodies[threadIdx.x], s_bodies[threadIdx.x]);
+		if (s_proxies[threadIdx.x]) atomicAdd(&S->c.spProxies[threadIdx.x], s_proxies[threadIdx.x]);
 	}
 }
 

@@ -5262,12 +5262,12 @@ static int spReadHeaders(b2hip_world* w, size_t strideWords, int (*hdr)[SP_HEADE
 	return 0;
 }
 
-// A slab capacity grows when a header says it was too small and shrinks again when it has been four times too large for 16
-// exchanges in a row (the burst of the first steps - every proxy new, tens of thousands of pairs - would otherwise size every
+// A slab capacity grows when a header says it was too small and is halved again when it has been more than twice what any
+// rank needed for 4 exchanges in a row (the burst of the first steps - every proxy new, tens of thousands of pairs - would otherwise size every
 // later collective). Every rank reads the same headers: the capacities stay equal on all ranks.
 static void spCapDecay(int* cap, int* idle, int need, int floor)
 {
-	if (4 * need < *cap && *cap > floor) { if (++*idle >= 16) { *cap = std::max(floor, *cap / 2); *idle = 0; } }
+	if (2 * need < *cap && *cap > floor) { if (++*idle >= 4) { *cap = std::max(floor, *cap / 2); *idle = 0; } }
 	else *idle = 0;
 }
 

@@ -77,6 +77,9 @@ print("   device profile of rank 0 (ms per step):", {k: round(v, 4) for k, v in 
 w0.close()
 ws[0].close()
 
+if os.environ.get("B2_SHARE_REPLAY_ONLY") == "1":
+    sys.exit(0)  # (under rocprofv3: the replayed rank's steps are the last ones in the trace -> tools/trace_steady.py)
+
 # ---- 3. one rank's share as a world of its own (one pyramid), unsharded --------------------------------------------------------------
 if not FIELD:
     w1 = make(1)
