@@ -12,37 +12,64 @@
 #include "b2d_kernels_solve_large.h"
 
 // b2ContactManager::SynchronizeFixtures (:315-364) + FinishSynchronizeFixtures (:441-452) +
-// b2DynamicTree::MoveProxy, one lane per proxy.
+// b2DynamicTree::MoveProxy, one lane per proxy. The proxies that left their fat AABB are collected per workgroup (a tile of
+// SYNC_TILE proxies, the list in LDS) and take their places in the move buffer with ONE atomic on its counter: in a world
+// where everything moves (the 1 M-body field: 600 000 moved proxies per step) one atomic per wave was 16 000 on the same
+// word, ~10 ns each - most of the kernel's 215 us. (The order of the move buffer has no meaning: the pairs are sorted.)
+#define SYNC_TILE 1024
 __global__ __launch_bounds__(256) void k_sync_fixtures(DW W)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = W.nProxies;
-	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
+	const int tid = (int)threadIdx.x;
+	__shared__ int s_list[SYNC_TILE];
+	__shared__ int s_cnt, s_base;
+	for (int base = blockIdx.x * SYNC_TILE; base < n; base += gridDim.x * SYNC_TILE)
 	{
-		const int body = W.p_body[p];
-		if (body < 0) continue;
-		uint32_t f = W.b_flags[body];
-		// If a body was not in an island then it did not move.
-		if ((f & BF_ISLAND) == 0) continue;
-		float4 m = W.b_mass[body];
-		float4 p0 = W.b_pos0[body];
-		Xf xf1 = b2dXfFromSweep(v2(p0.x, p0.y), p0.z, v2(m.z, m.w));
-		Xf xf2 = loadXf(W.b_xf, body);
-		const ShapeRec* shape = W.shapes + W.p_shape[p];
-		AABB aabb = b2dAabbCombine(b2dShapeAABB(shape, xf1), b2dShapeAABB(shape, xf2));
-		AABB fat = loadAabb(W.p_fat, p);
-		if (b2dAabbContains(fat, aabb)) continue;
-		V2 displacement = xf2.p - xf1.p;
-		AABB b = aabb;
-		b.lo = v2(b.lo.x - B2D_AABB_EXTENSION, b.lo.y - B2D_AABB_EXTENSION);
-		b.hi = v2(b.hi.x + B2D_AABB_EXTENSION, b.hi.y + B2D_AABB_EXTENSION);
-		V2 d = B2D_AABB_MULTIPLIER * displacement;
-		if (d.x < 0.0f) b.lo.x += d.x; else b.hi.x += d.x;
-		if (d.y < 0.0f) b.lo.y += d.y; else b.hi.y += d.y;
-		W.p_fat[p] = make_float4(b.lo.x, b.lo.y, b.hi.x, b.hi.y);
-		int k = atomicAdd(&S->c.nMoves, 1);
-		if (k < W.capMoves) W.moveBuf[k] = p; else atomicOr(&S->c.overflow, 8);
+		if (tid == 0) s_cnt = 0;
+		__syncthreads();
+		for (int j = 0; j < SYNC_TILE / 256; ++j)
+		{
+			const int p = base + j * 256 + tid;
+			if (p >= n) break;
+			const int body = W.p_body[p];
+			if (body < 0) continue;
+			uint32_t f = W.b_flags[body];
+			// If a body was not in an island then it did not move.
+			if ((f & BF_ISLAND) == 0) continue;
+			float4 m = W.b_mass[body];
+			float4 p0 = W.b_pos0[body];
+			Xf xf1 = b2dXfFromSweep(v2(p0.x, p0.y), p0.z, v2(m.z, m.w));
+			Xf xf2 = loadXf(W.b_xf, body);
+			const ShapeRec* shape = W.shapes + W.p_shape[p];
+			AABB aabb = b2dAabbCombine(b2dShapeAABB(shape, xf1), b2dShapeAABB(shape, xf2));
+			AABB fat = loadAabb(W.p_fat, p);
+			if (b2dAabbContains(fat, aabb)) continue;
+			V2 displacement = xf2.p - xf1.p;
+			AABB b = aabb;
+			b.lo = v2(b.lo.x - B2D_AABB_EXTENSION, b.lo.y - B2D_AABB_EXTENSION);
+			b.hi = v2(b.hi.x + B2D_AABB_EXTENSION, b.hi.y + B2D_AABB_EXTENSION);
+			V2 d = B2D_AABB_MULTIPLIER * displacement;
+			if (d.x < 0.0f) b.lo.x += d.x; else b.hi.x += d.x;
+			if (d.y < 0.0f) b.lo.y += d.y; else b.hi.y += d.y;
+			W.p_fat[p] = make_float4(b.lo.x, b.lo.y, b.hi.x, b.hi.y);
+			s_list[atomicAdd(&s_cnt, 1)] = p;
+		}
+		__syncthreads();
+		const int cnt = s_cnt;
+		if (tid == 0 && cnt > 0) s_base = atomicAdd(&S->c.nMoves, cnt);
+		__syncthreads();
+		if (cnt > 0)
+		{
+			const int at = s_base;
+			for (int k = tid; k < cnt; k += 256)
+			{
+				if (at + k < W.capMoves) W.moveBuf[at + k] = s_list[k];
+				else atomicOr(&S->c.overflow, 8);
+			}
+		}
+		__syncthreads();
 	}
 }
 
@@ -654,18 +681,29 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 #define END_STEP_SKIP_IF_REDO 1
 #define END_STEP_LAZY 2
 #define END_STEP_ROWS 3
-__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq, int mode)
+// The rows travel where they differ from what the host's buffer holds: `shadow` is the device's copy of it (rowMode 2: a row
+// is stored - to both - only if it differs from its shadow; 1: all rows are stored and the shadow is written afresh; 0: no
+// shadow, `out` receives every row). A world at rest sends nothing.
+// mode END_STEP_EARLY: the rows only, no house-keeping, no counters, nothing published - launched behind SynchronizeFixtures on
+// a stream of its own with the shadow as `out` (b2hip.hip: startEarlyRows), followed by a copy of the shadow to the host that
+// runs while the pair update and the TOI phase do; the launch at the end of the step then sends what the TOI phase changed
+// since. Whatever the early launch read while TOI events were already moving bodies is either final or differs from the
+// final row and is sent again: host buffer and shadow always hold the same words.
+#define END_STEP_EARLY 4
+#define END_STEP_TILE_ROWS 16 // (more changed rows than this in a tile of 256: the tile leaves whole, as coalesced 16-byte stores)
+__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq, int mode, float* shadow, int rowMode)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = W.nBodies;
 	const int tid = (int)threadIdx.x;
 	__shared__ __attribute__((aligned(16))) float s_out[2560];
+	__shared__ int s_chg[256];
 	__shared__ int s_last;
 	// (ClearPostSolveTOI only when the step is complete; sub-stepping: also for what earlier calls of the step touched)
 	const bool toiEvents = (S->c.nToiEvents != 0 || W.toiContinue != 0) && S->c.toiIncomplete == 0;
 	bool skipRows = false;
-	const bool storeRows = mode != END_STEP_LAZY, houseKeeping = mode != END_STEP_ROWS;
+	const bool storeRows = mode != END_STEP_LAZY, houseKeeping = mode != END_STEP_ROWS && mode != END_STEP_EARLY;
 	if (mode == END_STEP_SKIP_IF_REDO)
 	{
 		const int ov = S->c.overflow, moves = S->c.nMoves;
@@ -694,21 +732,88 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 			o[8] = __uint_as_float(f & 0x7fu);
 			o[9] = p.w;
 		}
-		if (!storeRows) continue; // (uniform over the workgroup: every lane leaves the tile before its barriers)
-		// a spatially sharded world with the lean exchange: the rows of another rank's bodies are not kept up to date here -
-		// a tile that holds none of ours stays as it is in the host's buffer (b2d_kernels_spatial.h)
-		if (W.spatial && !W.spFullRows)
+		if (W.spatial && !W.spFullRows && houseKeeping && W.spOwnOut != nullptr)
 		{
-			const bool mine = i < n && ((W.b_flags[i] & BF_TYPE_MASK) == BT_STATIC || W.b_owner[i] == (uint8_t)W.shardRank);
-			if (!__syncthreads_or(mine ? 1 : 0)) continue;
+			// a spatially sharded world with the lean exchange: this rank answers for the bodies it OWNS - their rows go to the
+			// host packed (id + row, one contiguous run per wave), the table of all rows stays on the device until somebody asks
+			// (as with the read-back on demand). Ownership need not follow the body ids: 1 / N of the rows cross PCIe, not all.
+			const bool mine = i < n && (W.b_flags[i] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[i] == (uint8_t)W.shardRank;
+			const unsigned long long m = __ballot(mine);
+			// (one atomic per tile, not per wave: see k_sync_fixtures)
+			if (waveLane() == 0) s_chg[tid >> 6] = __popcll(m);
+			__syncthreads();
+			if (tid == 0)
+			{
+				const int c0 = s_chg[0], c1 = s_chg[1], c2 = s_chg[2], c3 = s_chg[3];
+				const int at = c0 + c1 + c2 + c3 > 0 ? atomicAdd(&S->c.spOwnRows, c0 + c1 + c2 + c3) : 0;
+				s_chg[0] = at; s_chg[1] = at + c0; s_chg[2] = at + c0 + c1; s_chg[3] = at + c0 + c1 + c2;
+			}
+			__syncthreads();
+			if (mine)
+			{
+				const int k = s_chg[tid >> 6] + __popcll(m & ((1ull << waveLane()) - 1ull));
+				if (k < W.spOwnCap)
+				{
+					int* q = W.spOwnOut + (size_t)k * 11;
+					const float* o = s_out + tid * 10;
+					q[0] = i;
+					for (int c = 0; c < 10; ++c) q[1 + c] = __float_as_int(o[c]);
+				}
+			}
+			__syncthreads(); // (s_chg serves the row comparison next)
 		}
+		if (!storeRows) continue; // (uniform over the workgroup: every lane leaves the tile before its barriers)
+		s_chg[tid] = 0;
 		__syncthreads();
 		const int cnt = (n - base < 256 ? n - base : 256) * 10; // floats of this tile; base * 40 bytes is 16-byte aligned
 		float* dst = out + (size_t)base * 10;
-		for (int q = tid; q < cnt / 4; q += 256) ((float4*)dst)[q] = ((const float4*)s_out)[q];
-		for (int q = (cnt / 4) * 4 + tid; q < cnt; q += 256) dst[q] = s_out[q];
+		float* sh = shadow + (size_t)base * 10;
+		bool whole = true;
+		if (rowMode == 2)
+		{
+			// which rows differ from what the host holds: the shadow tile is read as it is laid out (16 bytes per lane), a chunk
+			// that differs marks the one or two rows it overlaps
+			for (int q = tid; q < cnt / 4; q += 256)
+			{
+				const float4 a = ((const float4*)s_out)[q], b = ((const float4*)sh)[q];
+				if (__float_as_uint(a.x) != __float_as_uint(b.x) || __float_as_uint(a.y) != __float_as_uint(b.y) ||
+					__float_as_uint(a.z) != __float_as_uint(b.z) || __float_as_uint(a.w) != __float_as_uint(b.w))
+				{
+					s_chg[(4 * q) / 10] = 1;
+					s_chg[(4 * q + 3) / 10] = 1;
+				}
+			}
+			for (int q = (cnt / 4) * 4 + tid; q < cnt; q += 256) if (__float_as_uint(s_out[q]) != __float_as_uint(sh[q])) s_chg[q / 10] = 1;
+			__syncthreads();
+			const int nChanged = __syncthreads_count(s_chg[tid]);
+			if (nChanged == 0) continue; // (uniform; the next tile's first barrier stands between these reads and its writes)
+			whole = nChanged > END_STEP_TILE_ROWS;
+			if (!whole && s_chg[tid])
+			{
+				// a few rows of the tile: each on its own (40 bytes, 8-byte aligned)
+				const float2* o2 = (const float2*)(s_out + tid * 10);
+				float2* d2 = (float2*)(out + (size_t)i * 10);
+				float2* h2 = (float2*)(shadow + (size_t)i * 10);
+				for (int c = 0; c < 5; ++c) { const float2 v = o2[c]; d2[c] = v; h2[c] = v; }
+			}
+		}
+		if (whole)
+		{
+			for (int q = tid; q < cnt / 4; q += 256)
+			{
+				const float4 v = ((const float4*)s_out)[q];
+				((float4*)dst)[q] = v;
+				if (rowMode != 0) ((float4*)sh)[q] = v;
+			}
+			for (int q = (cnt / 4) * 4 + tid; q < cnt; q += 256)
+			{
+				dst[q] = s_out[q];
+				if (rowMode != 0) sh[q] = s_out[q];
+			}
+		}
 		__syncthreads();
 	}
+	if (mode == END_STEP_EARLY) return; // (the rows were all: the launch at the end of the step publishes)
 	// ---- the last workgroup: counters, then the sequence number ---------------------------------------------------------
 	// (every wave's stores have left; ONE system-scope fence per workgroup - a fence writes the L2 back - then arrive)
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -736,7 +841,11 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	for (int k = tid; k < (int)(offsetof(DState, pubSeq) / 16); k += 256) tail[k] = b2dLoadAgent4(&src[k]);
 	__threadfence_system();
 	__syncthreads();
-	if (tid == 0) __hip_atomic_store(&((DState*)tail)->pubSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	if (tid == 0)
+	{
+		S->c.spOwnRows = 0; // (the packed rows of a spatially sharded world: counted afresh by the next read-back)
+		__hip_atomic_store(&((DState*)tail)->pubSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 #endif

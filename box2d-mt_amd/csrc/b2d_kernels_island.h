@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 				const int o = __shfl_xor(dg, off);
 				dg = o > dg ? o : dg;
 			}
-			if (waveLane() == 0 && dg > 0) atomicMax(&W.st->c.maxDegree, dg);
+			if (waveLane() == 0 && dg > 0) atomicMaxIfAbove(&W.st->c.maxDegree, dg);
 		}
 		// (a root has counted itself and offered its own seed in k_island_init: only the other members add to it)
 		const bool other = valid && r != i;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 					W.rootIsland[i] = ROOT_SMALL;
 					if (nj > 0) atomicAdd(&S->c.nSmallJointed, 1);
 					in = make_int4(nb, nc, w, 1);
-					atomicMax(&S->c.maxSmallW, w);
+					atomicMaxIfAbove(&S->c.maxSmallW, w);
 				}
 				else
 				{
@@ -478,14 +478,8 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 		}
 		W.rootScanIn[i] = in;
 	}
-	// (one add per wave: a million single-body islands adding to one word serialise in L2)
-	nIslands = waveSumInt(nIslands);
-	nFree = waveSumInt(nFree);
-	if (waveLane() == 0)
-	{
-		if (nIslands) atomicAdd(&S->c.nIslands, nIslands);
-		if (nFree) atomicAdd(&S->c.nFreeIslands, nFree);
-	}
+	// (one add per workgroup: a million single-body islands adding to one word serialise in L2)
+	blockAtomicAddInt2(&S->c.nIslands, nIslands, &S->c.nFreeIslands, nFree);
 }
 
 __global__ __launch_bounds__(256) void k_island_assign(DW W)

@@ -846,4 +846,18 @@ __global__ __launch_bounds__(256) void k_sp_owner_census(DW W)
 	}
 }
 
+// The headers of all ranks' slabs (and, for E4, the count of conflicts k_sp_tail_pairs found) to the host in one go: one wave
+// writes them into pinned memory, the sequence number last - the host polls it (b2hip.hip: spReadHeaders), as it does for the
+// state read-back. Replaces one small copy per rank and a stream synchronisation per exchange.
+__global__ __launch_bounds__(64) void k_sp_collect_headers(const int* __restrict__ recv, size_t strideWords, int ranks, const int* __restrict__ extra, int* out, int seq)
+{
+	const int tid = (int)threadIdx.x;
+	for (int k = tid; k < ranks * SP_HEADER_WORDS; k += 64)
+		out[2 + k] = recv[(size_t)(k / SP_HEADER_WORDS) * strideWords + (size_t)(k % SP_HEADER_WORDS)];
+	if (tid == 0) out[1] = extra ? *extra : 0;
+	__threadfence_system();
+	__syncthreads();
+	if (tid == 0) __hip_atomic_store(&out[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #endif

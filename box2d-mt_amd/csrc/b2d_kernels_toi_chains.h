@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 			if (e <= cap && e > ext) ext = e;
 		}
 		for (int off = 32; off > 0; off >>= 1) ext = fmaxf(ext, __shfl_xor(ext, off));
-		if ((threadIdx.x & 63u) == 0 && ext > 0.0f) atomicMax(&S->c.cellExtBits, __float_as_uint(ext));
+		if ((threadIdx.x & 63u) == 0 && ext > 0.0f) atomicMaxIfAbove(&S->c.cellExtBits, __float_as_uint(ext));
 	}
 	for (uint32_t i = t0; i <= W.gridMask; i += stride)
 	{

@@ -85,6 +85,40 @@ B2D_WAVE_ATOMIC(waveAtomicMaxU32, uint32_t, waveMaxU32, 0u, atomicMax)
 B2D_WAVE_ATOMIC(waveAtomicMinU32, uint32_t, waveMinU32, 0xffffffffu, atomicMin)
 #undef B2D_WAVE_ATOMIC
 
+// Counters every lane of a kernel adds to (island and contact censuses): ONE atomic per workgroup. Same-address atomics are
+// served one after the other in L2, ~6-10 ns each - one per wave of a pass over a million bodies is 16 000 of them, 100 us
+// and more, longer than the pass itself. Every lane of the workgroup must call (barriers inside).
+__device__ __forceinline__ void blockAtomicAddInt2(int* a0, int v0, int* a1, int v1)
+{
+	__shared__ int s_sum[2];
+	if (threadIdx.x == 0) { s_sum[0] = 0; s_sum[1] = 0; }
+	__syncthreads();
+	v0 = waveSumInt(v0);
+	v1 = waveSumInt(v1);
+	if (waveLane() == 0)
+	{
+		if (v0) atomicAdd(&s_sum[0], v0);
+		if (v1) atomicAdd(&s_sum[1], v1);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		if (s_sum[0]) atomicAdd(a0, s_sum[0]);
+		if (s_sum[1]) atomicAdd(a1, s_sum[1]);
+	}
+}
+
+// A running maximum many waves offer to: most offers do not raise it - look first (a plain load), add to the queue of the
+// word's atomics only then. (The value only grows while the kernel runs: a stale read can cost an atomic, never lose a maximum.)
+__device__ __forceinline__ void atomicMaxIfAbove(int* addr, int v)
+{
+	if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, v);
+}
+__device__ __forceinline__ void atomicMaxIfAbove(uint32_t* addr, uint32_t v)
+{
+	if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, v);
+}
+
 // A workgroup's running sum for ONE hot key, kept in LDS across the iterations of a grid-stride loop: a single island of
 // 350 000 constraints among 2 M contacts (the settled 100 000-box Tumbler) still sends one atomic per wave and iteration to
 // the same word - 32 000 of them, ~6.5 ns each in L2: k_island_count 214 us for 80 MB of reads. The first key a workgroup

@@ -192,6 +192,7 @@ struct Counters
 	int spBodies[SHARD_MAX_RANKS], spProxies[SHARD_MAX_RANKS];  // non-static bodies and their proxies per owner (k_sp_owner_census)
 	int spToiCreated;    // contacts this rank's TOI phase created (the tail of its contact array until the ranks have merged their tails)
 	int spToiStraddle;   // ... of them with a body of another rank (an event reached over an ownership boundary: refused)
+	int spOwnRows;       // rows k_end_step packed into DW::spOwnOut this step (the bodies this rank owns)
 };
 
 // What b2ContactListener::PreSolve is told about one contact (gathered after Collide, before the compaction of destroyed
@@ -394,6 +395,8 @@ struct DW
 	int capStraddle;
 	int* spCount;        // per component under resolution: bodies per owner [SP_RESOLVE_MAX][SHARD_MAX_RANKS]
 	int* spTarget;       // per component under resolution: its new owner
+	int* spOwnOut;       // pinned host memory: the rows of the bodies this rank owns, packed (11 words: id + b2hip_body_state), lean exchange
+	int spOwnCap;
 	int4* spTailKey;     // per contact created inside a TOI phase: (alpha bits, event key hi, lo, -) of the event that created it -
 	                     // the reference's creation order across ranks (k_sp_merge_tails)
 	// listener / filter bridge (include/b2hip.h: b2hip_set_contact_filter, b2hip_set_pre_solve, b2hip_enable_post_solve)

@@ -246,6 +246,12 @@ struct b2hip_world
 	b2hip_all_gather_fn gatherFn = nullptr; // the caller's all-gather (gloo, tests); null with a connected RCCL communicator
 	void* gatherUser = nullptr;
 	int* spHost = nullptr;          // pinned staging of the caller's all-gather
+	int* spHdrHost = nullptr;       // pinned: [0] sequence number, [1] extra word, [2..] the headers of all ranks' slabs (spReadHeaders)
+	int* spHdrDev = nullptr;
+	int spHdrSeq = 0;
+	int* spOwnHost = nullptr;       // pinned: the packed rows of this rank's bodies (id + b2hip_body_state), written by k_end_step
+	int* spOwnDev = nullptr;        // ... its device address
+	size_t spOwnCapRows = 0;
 	size_t spHostWords = 0;
 	int spPairCap = 2048, spToiBodyCap = 256, spToiProxyCap = 512; // (records per rank; grown alike on every rank when a header says so)
 	int spOwned[SHARD_MAX_RANKS] = {0}, spOwnedProxies[SHARD_MAX_RANKS] = {0};
@@ -347,6 +353,17 @@ struct b2hip_world
 	// is asked for (rowsPending: h_state's rows are older than the device's; fetched once, by whoever asks first)
 	bool lazyReadback = false;
 	std::atomic<bool> rowsPending{false};
+	// The rows travel only where they differ from what the host's buffer holds: stateOut is the device's copy of h_state's rows
+	// (k_end_step, rowMode), valid while these three are what they were when it was last written in full.
+	const float* shadowDev = nullptr;
+	const float* shadowHost = nullptr;
+	size_t shadowRows = 0;
+	// ... which lets most of a large world's rows leave early, behind SynchronizeFixtures, on a stream of their own while the
+	// pair update and the TOI phase run (startEarlyRows); the launch at the end of the step sends what changed since.
+	hipStream_t rowStream = nullptr;
+	hipEvent_t rowFork = nullptr, rowJoin = nullptr;
+	bool rowsEarlyPending = false;
+	int earlyRowsMin = 65536;       // bodies from which the early launch pays (B2HIP_EARLY_ROWS_MIN; 0 = never)
 	std::mutex rowsMutex;
 	bool blocksThisStep = false; // the large islands of this step went through k_solve_blocks
 
@@ -950,6 +967,15 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.blkBodyStart = w->blkBodyStart.p; d.blkBodies = w->blkBodies.p; d.rowColor = w->rowColor.p; d.b_cutv = w->b_cutv.p;
 	d.spatial = w->spatial ? 1 : 0; d.b_owner = w->b_owner.p; d.spNewOwner = w->spNewOwner.p; d.spAwake = w->spAwake.p; d.spFullRows = w->spFullRows ? 1 : 0; d.spStraddle = w->spStraddle.p;
 	d.capStraddle = (int)w->spStraddle.cap; d.spCount = w->spCount.p; d.spTarget = w->spTarget.p; d.spTailKey = w->spTailKey.p;
+	if (w->spatial && w->spOwnCapRows < nb)
+	{
+		if (w->spOwnHost) { HIP_TRY(hipStreamSynchronize(s)); (void)hipHostFree(w->spOwnHost); }
+		w->spOwnHost = nullptr;
+		w->spOwnCapRows = 2 * nb;
+		HIP_TRY(hipHostMalloc((void**)&w->spOwnHost, w->spOwnCapRows * 11 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostGetDevicePointer((void**)&w->spOwnDev, w->spOwnHost, 0));
+	}
+	d.spOwnOut = w->spatial ? w->spOwnDev : nullptr; d.spOwnCap = (int)w->spOwnCapRows;
 	d.userFilter = hasFilter(w) ? 1 : 0; d.preSolveOn = hasPreSolve(w) ? 1 : 0; d.postSolveOn = w->postSolveOn ? 1 : 0;
 	d.pre_o0 = w->pre_o0.p; d.pre_o1 = w->pre_o1.p; d.pre_oimp = w->pre_oimp.p; d.pre_o3 = w->pre_o3.p;
 	d.preRecs = w->preRecs.p; d.postRecs = w->postRecs.p; d.filterList = w->filterList.p;
@@ -2120,7 +2146,7 @@ static int phaseSyncFixtures(b2hip_world* w)
 {
 	DW& d = w->dw;
 	if (int rk = ktBracket(w, 3, 6)) return rk;
-	LAUNCH(w, k_sync_fixtures, gridFor(d.nProxies), 256, d);
+	LAUNCH(w, k_sync_fixtures, gridFor(((size_t)d.nProxies + 3) / 4), 256, d); // (SYNC_TILE proxies per workgroup and round)
 	if (int rk = ktBracket(w, 3, 6)) return rk;
 	return 0;
 }
@@ -2318,12 +2344,61 @@ static int awaitState(b2hip_world* w, size_t nb)
 	return 0;
 }
 
+static inline bool shadowValid(const b2hip_world* w)
+{
+	return w->shadowDev != nullptr && w->shadowDev == w->stateOut.p && w->shadowHost == w->h_state && w->shadowRows == (size_t)w->dw.nBodies;
+}
+static inline void shadowWritten(b2hip_world* w)
+{
+	w->shadowDev = w->stateOut.p;
+	w->shadowHost = w->h_state;
+	w->shadowRows = (size_t)w->dw.nBodies;
+}
+
+// Behind SynchronizeFixtures the rows of all bodies but those the TOI phase will still move are final: a large world sends
+// them now, on a second stream, under the pair update and the TOI phase (40 bytes per body over PCIe: 0.75 ms for a million
+// bodies, the longest single item of that step), and k_end_step sends the rows that changed since (its shadow comparison).
+static int startEarlyRows(b2hip_world* w)
+{
+	DW& d = w->dw;
+	const bool lazy = w->lazyReadback || (w->spatial && !w->spFullRows);
+	if (w->earlyRowsMin <= 0 || d.nBodies < w->earlyRowsMin || w->noStatePoll || lazy || w->rowsEarlyPending || w->debugSync || w->debugTrace) return 0;
+	if (!w->rowStream)
+	{
+		HIP_TRY(hipStreamCreateWithFlags(&w->rowStream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&w->rowFork, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&w->rowJoin, hipEventDisableTiming));
+	}
+	HIP_TRY(hipEventRecord(w->rowFork, w->stream));
+	HIP_TRY(hipStreamWaitEvent(w->rowStream, w->rowFork, 0));
+	// The rows are gathered into the device's copy (stateOut: ~30 us for a million bodies) and leave from there by a copy - the
+	// DMA engine's, which does not stand in the way of the kernels running meanwhile. (Stores from a kernel straight into host
+	// memory, as k_end_step's are, do: with enough of them in flight to fill the link, the pair update beside them ran 1.5 x
+	// slower - measured, 1 M bodies: 3.77 ms per step without the early launch, 3.29 at best with such a kernel, 3.11 with the copy.)
+	DW dEarly = d;
+	dEarly.stampMask = 0u; // (the phase stamps belong to the main stream's next kernel)
+	hipLaunchKernelGGL(k_end_step, dim3(gridFor(d.nBodies)), dim3(256), 0, w->rowStream, dEarly, 0, (const int*)nullptr, w->stateOut.p, 0, END_STEP_EARLY, (float*)nullptr, 0);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, (size_t)d.nBodies * 10 * sizeof(float), hipMemcpyDeviceToHost, w->rowStream));
+	HIP_TRY(hipEventRecord(w->rowJoin, w->rowStream));
+	shadowWritten(w);
+	w->rowsEarlyPending = true;
+	return 0;
+}
+
 static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 {
 	DW& d = w->dw;
 	const size_t nb = w->bodies.size();
+	if (w->rowsEarlyPending)
+	{
+		HIP_TRY(hipStreamWaitEvent(w->stream, w->rowJoin, 0));
+		w->rowsEarlyPending = false;
+	}
 	// (lazy: every read-back of a step end leaves the rows where they are; a read-back outside a step is a full one)
-	const bool lazy = w->lazyReadback && w->stepActive && !w->noStatePoll;
+	// (... and so does a spatially sharded world with the lean exchange: the rows of the bodies THIS rank owns go to the host
+	// packed - k_end_step, DW::spOwnOut - the table of all rows on demand)
+	const bool lazy = (w->lazyReadback || (w->spatial && !w->spFullRows)) && w->stepActive && !w->noStatePoll;
 	w->rowsPending.store(lazy, std::memory_order_release);
 	w->stateSeq = (w->stateSeq + 1) & 0x3fffffff;
 	if (w->stateSeq == 0) w->stateSeq = 1;
@@ -2332,15 +2407,20 @@ static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 	if (w->noStatePoll)
 	{
 		// B2HIP_NO_STATE_POLL=1, for comparison: into the device staging array, one copy, stream synchronisation
-		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq, 0);
+		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq, 0, (float*)nullptr, 0);
 		HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, B2D_STATE_TAIL(nb) * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 		memcpy(w->h_dstate, w->h_state + B2D_STATE_TAIL(nb), offsetof(DState, pubSeq));
+		w->shadowDev = nullptr; // (the staging array is the shadow's memory)
 		return 0;
 	}
+	const int rowMode = shadowValid(w) ? 2 : 1;
 	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq,
-		lazy ? END_STEP_LAZY : skipRowsIfRedo ? END_STEP_SKIP_IF_REDO : END_STEP_FULL);
-	return awaitState(w, nb);
+		lazy ? END_STEP_LAZY : skipRowsIfRedo ? END_STEP_SKIP_IF_REDO : END_STEP_FULL, w->stateOut.p, rowMode);
+	const int rc = awaitState(w, nb);
+	// (rowsSkipped: 0 - the rows were stored; the shadow of a full write is valid from here on)
+	if (rc == 0 && rowMode == 1 && w->h_dstate->c.rowsSkipped == 0) shadowWritten(w);
+	return rc;
 }
 
 // The rows a lazy step end left on the device (b2hip_set_lazy_readback), fetched when the first caller asks for a body's
@@ -2353,8 +2433,11 @@ static int fetchRows(b2hip_world* w)
 	w->stateSeq = (w->stateSeq + 1) & 0x3fffffff;
 	if (w->stateSeq == 0) w->stateSeq = 1;
 	((DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq = 0;
-	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0, (const int*)nullptr, w->d_hstate, w->stateSeq, END_STEP_ROWS);
-	return pollPublished(w, (volatile const int*)&((const DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq, w->stateSeq, "lazy state read-back");
+	const int rowMode = shadowValid(w) ? 2 : 1;
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0, (const int*)nullptr, w->d_hstate, w->stateSeq, END_STEP_ROWS, w->stateOut.p, rowMode);
+	const int rc = pollPublished(w, (volatile const int*)&((const DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq, w->stateSeq, "lazy state read-back");
+	if (rc == 0 && rowMode == 1) shadowWritten(w);
+	return rc;
 }
 
 static void ensureRows(b2hip_world* w)
@@ -2597,6 +2680,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->noCensusPoll = getenv("B2HIP_NO_CENSUS_POLL") && atoi(getenv("B2HIP_NO_CENSUS_POLL"));
 	w->noStatePoll = getenv("B2HIP_NO_STATE_POLL") && atoi(getenv("B2HIP_NO_STATE_POLL"));
 	w->lazyReadback = getenv("B2HIP_LAZY_READBACK") && atoi(getenv("B2HIP_LAZY_READBACK"));
+	if (getenv("B2HIP_EARLY_ROWS_MIN")) w->earlyRowsMin = atoi(getenv("B2HIP_EARLY_ROWS_MIN"));
 	int rc = ensureCapacity(w, 0);
 	if (rc == 0 && hipStreamSynchronize(w->stream) != hipSuccess) rc = setError(B2HIP_ERR_HIP, "stream sync failed");
 	if (rc)
@@ -2614,6 +2698,14 @@ void b2hip_world_destroy(b2hip_world* w)
 	if (!w) return;
 	DEVICE_GUARD(w);
 	if (w->stream) (void)hipStreamSynchronize(w->stream);
+	if (w->rowStream)
+	{
+		(void)hipStreamSynchronize(w->rowStream);
+		(void)hipStreamDestroy(w->rowStream);
+		(void)hipEventDestroy(w->rowFork);
+		(void)hipEventDestroy(w->rowJoin);
+		w->rowStream = nullptr;
+	}
 	if (w->shardComm != nullptr && g_rcclDestroy != nullptr) g_rcclDestroy(w->shardComm);
 	w->shardComm = nullptr;
 	w->shardSend.release(); w->shardRecv.release();
@@ -2621,6 +2713,10 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->spSend.release(); w->spRecv.release(); w->spTailKey.release(); w->spVirt.release();
 	if (w->spHost) (void)hipHostFree(w->spHost);
 	w->spHost = nullptr;
+	if (w->spOwnHost) (void)hipHostFree(w->spOwnHost);
+	w->spOwnHost = nullptr;
+	if (w->spHdrHost) (void)hipHostFree(w->spHdrHost);
+	w->spHdrHost = nullptr;
 	for (size_t k = 0; k < w->spTape.size(); ++k) (void)hipFree(w->spTape[k].first);
 	w->spTape.clear();
 	w->d_state.release();
@@ -4075,6 +4171,8 @@ static int syncFixturesImpl(b2hip_world* w)
 		if (rc) return rc;
 		// E1: what the other ranks' bodies did in Solve, and the fat AABBs their SynchronizeFixtures moved
 		if (w->spatial) { rc = spExchangeState(w, 0); if (rc) return rc; }
+		rc = startEarlyRows(w);
+		if (rc) return rc;
 	}
 	stampPhase(w, 9);
 	return 0;
@@ -4988,6 +5086,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	if (rc) return fail(rc);
 	if (nM > w->moveBuf.cap || nC > (size_t)w->dw.capContacts || (size_t)h.stateCount * 10 > w->h_stateCap) return fail(corrupt("counts exceed the buffers sized for them"));
 	if (h.stateCount) memcpy(w->h_state, stateAt, (size_t)h.stateCount * 10 * sizeof(float));
+	w->shadowDev = nullptr; // (the host's rows are the snapshot's now, not what the device last sent)
 	w->stateCount = h.stateCount;
 	*w->h_dstate = ds;
 #define SNAP_UP(arr, s) do { if ((s).bytes && hipMemcpy(w->arr.p, (s).p, (s).bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (" #arr ")")); } while (0)
@@ -5205,6 +5304,9 @@ static int spAllGather(b2hip_world* w, size_t words)
 {
 	const int ranks = w->dw.shardCount;
 	w->spBytesStep += 4 * words * (size_t)(ranks - 1);
+	static const bool trace = getenv("B2HIP_SHARD_TRACE") && atoi(getenv("B2HIP_SHARD_TRACE"));
+	if (trace && w->dw.shardRank == 0) fprintf(stderr, "[b2hip] step %lld: all-gather of %zu words per rank (caps: rows %d proxies %d pairs %d toi %d / %d / %d)\n",
+		(long long)w->stepEpoch, words, w->spRowCap, w->spProxyCap, w->spPairCap, w->spToiBodyCap, w->spToiProxyCap, w->spTailCap);
 	if (w->spTapeFrom != nullptr)
 	{
 		// (replay: what the collective delivered in the recorded run, device to device on the world's stream)
@@ -5254,11 +5356,21 @@ static int spEnsureSlabs(b2hip_world* w, size_t words)
 }
 
 // the headers of all ranks' slabs, on the host (one small copy + synchronisation)
-static int spReadHeaders(b2hip_world* w, size_t strideWords, int (*hdr)[SP_HEADER_WORDS])
+static int spReadHeaders(b2hip_world* w, size_t strideWords, int (*hdr)[SP_HEADER_WORDS], const int* extraDev = nullptr, int* extra = nullptr)
 {
-	for (int r = 0; r < w->dw.shardCount; ++r)
-		HIP_TRY(hipMemcpyAsync(hdr[r], w->spRecv.p + (size_t)r * strideWords, SP_HEADER_WORDS * sizeof(int), hipMemcpyDeviceToHost, w->stream));
-	HIP_TRY(hipStreamSynchronize(w->stream));
+	const int ranks = w->dw.shardCount;
+	if (!w->spHdrHost)
+	{
+		HIP_TRY(hipHostMalloc((void**)&w->spHdrHost, (2 + SHARD_MAX_RANKS * SP_HEADER_WORDS) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostGetDevicePointer((void**)&w->spHdrDev, w->spHdrHost, 0));
+		w->spHdrHost[0] = 0;
+	}
+	w->spHdrSeq = (w->spHdrSeq + 1) & 0x3fffffff;
+	if (w->spHdrSeq == 0) w->spHdrSeq = 1;
+	LAUNCH(w, k_sp_collect_headers, 1, 64, (const int*)w->spRecv.p, strideWords, ranks, extraDev, w->spHdrDev, w->spHdrSeq);
+	if (int rc = pollPublished(w, (volatile const int*)&w->spHdrHost[0], w->spHdrSeq, "exchange headers of a spatially sharded world")) return rc;
+	memcpy(hdr, w->spHdrHost + 2, (size_t)ranks * SP_HEADER_WORDS * sizeof(int));
+	if (extra) *extra = w->spHdrHost[1];
 	return 0;
 }
 
@@ -5267,7 +5379,18 @@ static int spReadHeaders(b2hip_world* w, size_t strideWords, int (*hdr)[SP_HEADE
 // later collective). Every rank reads the same headers: the capacities stay equal on all ranks.
 static void spCapDecay(int* cap, int* idle, int need, int floor)
 {
-	if (2 * need < *cap && *cap > floor) { if (++*idle >= 4) { *cap = std::max(floor, *cap / 2); *idle = 0; } }
+	// (four exchanges in a row that used less than half: down to twice the last need - a burst, all rows of a rank in the
+	// first step, must not be paid for in every slab of the next thirty steps)
+	if (2 * need < *cap && *cap > floor)
+	{
+		if (++*idle >= 4)
+		{
+			int c = floor;
+			while (c < 2 * need) c *= 2;
+			*cap = std::min(*cap, c);
+			*idle = 0;
+		}
+	}
 	else *idle = 0;
 }
 
@@ -5288,7 +5411,9 @@ static int spExchangeState(b2hip_world* w, int mode)
 			int mostB = 1, mostP = 1;
 			for (int r = 0; r < ranks; ++r) { mostB = std::max(mostB, w->spOwned[r]); mostP = std::max(mostP, w->spOwnedProxies[r]); }
 			if (w->spFullRows) { capB = mostB; capP = mostP; exactFit = true; }
-			else { capB = std::min(w->spRowCap, mostB); capP = std::min(w->spProxyCap, mostP); exactFit = capB == mostB && capP == mostP; }
+			// (lean: the capacities follow the need the headers report - also DOWN, which is why the headers are read even when
+			// the slab could hold everything a rank owns)
+			else { capB = std::min(w->spRowCap, mostB); capP = std::min(w->spProxyCap, mostP); }
 		}
 		else { capB = w->spToiBodyCap; capP = w->spToiProxyCap; capT = w->spTailCap; }
 		const int proxyWords = mode == 0 ? SP_PROXY_WORDS : SP_TOI_PROXY_WORDS;
@@ -5315,9 +5440,8 @@ static int spExchangeState(b2hip_world* w, int mode)
 			HIP_TRY(hipMemsetAsync(w->spVirt.p + SP_TAIL_MAX, 0, sizeof(int), w->stream)); // (the count lives behind the pairs)
 			LAUNCH(w, k_sp_tail_pairs, gridFor(std::max(capP * ranks, capT)), 256, d, (const int*)w->spRecv.p, words, tailAt, capB, capP, w->spVirt.p, (int*)(w->spVirt.p + SP_TAIL_MAX));
 			int nVirt = 0;
-			HIP_TRY(hipMemcpyAsync(&nVirt, w->spVirt.p + SP_TAIL_MAX, sizeof(int), hipMemcpyDeviceToHost, w->stream));
 			int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
-			rc = spReadHeaders(w, words, hdr);
+			rc = spReadHeaders(w, words, hdr, (const int*)(w->spVirt.p + SP_TAIL_MAX), &nVirt);
 			if (rc) return rc;
 			int needB = 0, needP = 0, needT = 0, straddle = 0;
 			{
@@ -5686,6 +5810,20 @@ int b2hip_get_body_owners(b2hip_world* w, int cap, uint8_t* owners)
 	if (w->spOwnersDirty) { memcpy(owners, w->spOwners.data(), std::min(nb, w->spOwners.size())); return (int)nb; }
 	HIP_TRY(hipMemcpy(owners, w->b_owner.p, nb, hipMemcpyDeviceToHost));
 	return (int)nb;
+}
+
+int b2hip_get_own_body_states(b2hip_world* w, int cap, int32_t* ids, b2hip_body_state* out)
+{
+	if (int rcu = checkUsable(w, "b2hip_get_own_body_states", true)) return rcu;
+	if (!w->spatial || w->spFullRows || !w->spOwnHost) return setError(B2HIP_ERR_INVALID, "not a spatially sharded world with the lean exchange");
+	const int n = std::min(std::min(w->h_dstate->c.spOwnRows, (int)w->spOwnCapRows), std::max(cap, 0));
+	for (int k = 0; k < n; ++k)
+	{
+		const int* q = w->spOwnHost + (size_t)k * 11;
+		if (ids) ids[k] = q[0];
+		if (out) memcpy(&out[k], q + 1, 10 * sizeof(int));
+	}
+	return n;
 }
 
 int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out)

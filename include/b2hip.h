@@ -654,6 +654,10 @@ int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out);
  * `w` takes its collectives' results from the tape of `from` (a world of the same rank that recorded the same run) instead
  * of running a collective: one rank of a sharded world stepped alone on one GPU; mode 0 - off. */
 int b2hip_shard_tape(b2hip_world* w, int mode, b2hip_world* from);
+/* Lean exchange (the default): the rows of the bodies THIS rank owns as the last step left them, packed - what the step
+ * brought to the host (1 / N of the table crosses PCIe; the table of all rows stays on the device until b2hip_get_body_states
+ * asks for it, as with b2hip_set_lazy_readback). ids[k] = body, out[k] = its state; returns the number of rows (at most cap). */
+int b2hip_get_own_body_states(b2hip_world* w, int cap, int32_t* ids, b2hip_body_state* out);
 /* the owner table as it stands (owners[b2hip_body_count]); between steps */
 int b2hip_get_body_owners(b2hip_world* w, int cap, uint8_t* owners);
 

@@ -258,6 +258,7 @@ int b2hip_get_shard_stats(b2hip_world* w, b2hip_shard_stats* out)
 	return 0;
 }
 int b2hip_shard_tape(b2hip_world* w, int mode, b2hip_world* from) { (void)w; (void)mode; (void)from; return -4; }
+int b2hip_get_own_body_states(b2hip_world* w, int cap, int32_t* ids, b2hip_body_state* out) { (void)w; (void)cap; (void)ids; (void)out; return -1; /* (this shim always exchanges full rows) */ }
 int b2hip_shard_slab_words(b2hip_world* w, size_t* words_per_rank, int ranks)
 {
 	for (int r = 0; r < ranks; ++r) words_per_rank[r] = b2o_shard_slab_words(w->o, r);

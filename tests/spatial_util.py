@@ -107,3 +107,12 @@ class SpatialRanks:
         got = self.L.b2hip_get_body_owners(C.c_void_p(self.worlds[r][1]), n, out.ctypes.data_as(C.c_void_p))
         assert got >= 0, self.L.b2hip_last_error()
         return out
+
+    def own_rows(self, r, n):
+        """(ids, rows[k, 10] as uint32): the packed rows of rank r's bodies as the last step brought them to the host"""
+        ids = np.zeros(n, np.int32)
+        rows = np.zeros((n, 10), np.uint32)
+        self.L.b2hip_get_own_body_states.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        got = self.L.b2hip_get_own_body_states(C.c_void_p(self.worlds[r][1]), n, ids.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p))
+        assert got >= 0, self.L.b2hip_last_error()
+        return ids[:got], rows[:got]

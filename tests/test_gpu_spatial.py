@@ -48,6 +48,7 @@ def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, see
         sr.step()
         rbf = ref.bodies()
         rb = rbf.view(np.uint32)
+        packed = None if full else [sr.own_rows(r, len(rb)) for r in range(ranks)]
         first = ws[0].bodies().view(np.uint32)
         claimed = np.zeros(len(rb), np.int32)
         for r, w in enumerate(ws):
@@ -60,6 +61,11 @@ def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, see
                 own = sr.owners(r, len(rb))
                 mine = (own == r) & (rbf[:, 7] != 0)
                 claimed += mine
+                # (what the step itself brought to the host: the packed rows of the rank's own bodies - read BEFORE the table
+                # of all rows is asked for; position, angle and velocities are columns 0-5 of both)
+                ids, rows = packed[r]
+                assert np.array_equal(np.sort(ids), np.nonzero(mine)[0]), "step %d rank %d: the packed rows are not the rank's bodies" % (s + 1, r)
+                assert np.array_equal(rows[:, :6], rb[ids, :6]), "step %d rank %d: a packed row differs from the unsharded world" % (s + 1, r)
                 mine |= rbf[:, 7] == 0
             if compare:
                 bad = np.nonzero((wb != rb).any(axis=1) & mine)[0]
