@@ -25,11 +25,13 @@ __global__ __launch_bounds__(256) void k_sync_fixtures(DW W)
 	const int tid = (int)threadIdx.x;
 	__shared__ int s_list[SYNC_TILE];
 	__shared__ int s_cnt, s_base;
-	for (int base = blockIdx.x * SYNC_TILE; base < n; base += gridDim.x * SYNC_TILE)
+	// (a small world keeps one proxy per lane - 10 000 proxies in tiles of 1 024 would be ten workgroups on 256 CUs)
+	const int perLane = n >= 262144 ? SYNC_TILE / 256 : 1, tile = 256 * perLane;
+	for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile)
 	{
 		if (tid == 0) s_cnt = 0;
 		__syncthreads();
-		for (int j = 0; j < SYNC_TILE / 256; ++j)
+		for (int j = 0; j < perLane; ++j)
 		{
 			const int p = base + j * 256 + tid;
 			if (p >= n) break;
@@ -273,31 +275,37 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 		proxyCell(W, a4, &ix, &iy);
 		// lanes 0..8 own one neighbour cell each; cells that hash to an already seen bucket are dropped
 		uint32_t h = lane < 9 ? cellHash(ix + (lane % 3) - 1, iy + (lane / 3) - 1, W.gridMask) : 0xffffffffu;
+		// (lane indices known at compile time: v_readlane - a scalar read of one lane - instead of a trip through the LDS
+		// crossbar per value; the kernel issues ~50 of these per proxy and is bound by them in sparse scenes)
 		bool dup = false;
-		for (int j = 0; j < 9; ++j)
+#pragma unroll
+		for (int j = 0; j < 8; ++j)
 		{
-			uint32_t hj = (uint32_t)__shfl((int)h, j);
+			const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
 			if (j < lane && lane < 9 && hj == h) dup = true;
 		}
 		const int cnt = (lane < 9 && !dup) ? W.gridCount[h] : 0;
 		const int start = lane < 9 ? W.gridStart[h] : 0;
-		int incl = cnt;
-		for (int off = 1; off < 16; off <<= 1)
+		int ecs[9], ccs[9], scs[9];
+		int total = 0;
+#pragma unroll
+		for (int c = 0; c < 9; ++c)
 		{
-			int v = __shfl_up(incl, off);
-			if (lane >= off) incl += v;
+			ccs[c] = __builtin_amdgcn_readlane(cnt, c);
+			scs[c] = __builtin_amdgcn_readlane(start, c);
+			ecs[c] = total;
+			total += ccs[c];
 		}
-		const int excl = incl - cnt;
-		const int total = __shfl(incl, 8);
 		rounds += (total + 63) >> 6;
 		for (int base = 0; base < total; base += 64)
 		{
 			const int idx = base + lane;
 			const bool valid = idx < total;
 			int t = -1;
+#pragma unroll
 			for (int c = 0; c < 9; ++c)
 			{
-				const int ec = __shfl(excl, c), cc = __shfl(cnt, c), sc = __shfl(start, c);
+				const int ec = ecs[c], cc = ccs[c], sc = scs[c];
 				if (valid && idx >= ec && idx < ec + cc) t = sc + (idx - ec);
 			}
 			if (t >= 0)
@@ -353,9 +361,10 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 		const int nCells = wnx * wny < GRID_WINDOW_MAX ? wnx * wny : GRID_WINDOW_MAX;
 		uint32_t h = lane < nCells ? cellHash(wx0 + lane % wnx, wy0 + lane / wnx, W.gridMask) : 0xffffffffu;
 		bool dup = false;
-		for (int j = 0; j < nCells; ++j)
+		// (j, c below: the same for all lanes - v_readlane, not a trip through the LDS crossbar; see k_find_pairs_small)
+		for (int j = 0; j + 1 < nCells; ++j)
 		{
-			uint32_t hj = (uint32_t)__shfl((int)h, j);
+			const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
 			if (j < lane && lane < nCells && hj == h) dup = true;
 		}
 		const int cnt = (lane < nCells && !dup) ? W.gridCount[h] : 0;
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 			int t = -1;
 			for (int c = 0; c < nCells; ++c)
 			{
-				const int ec = __shfl(excl, c), cc = __shfl(cnt, c), sc = __shfl(start, c);
+				const int ec = __builtin_amdgcn_readlane(excl, c), cc = __builtin_amdgcn_readlane(cnt, c), sc = __builtin_amdgcn_readlane(start, c);
 				if (valid && idx >= ec && idx < ec + cc) t = sc + (idx - ec);
 			}
 			if (t >= 0)

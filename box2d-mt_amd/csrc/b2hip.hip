@@ -362,7 +362,7 @@ struct b2hip_world
 	// pair update and the TOI phase run (startEarlyRows); the launch at the end of the step sends what changed since.
 	hipStream_t rowStream = nullptr;
 	hipEvent_t rowFork = nullptr, rowJoin = nullptr;
-	bool rowsEarlyPending = false;
+	bool rowsForked = false, rowsEarlyPending = false;
 	int earlyRowsMin = 65536;       // bodies from which the early launch pays (B2HIP_EARLY_ROWS_MIN; 0 = never)
 	std::mutex rowsMutex;
 	bool blocksThisStep = false; // the large islands of this step went through k_solve_blocks
@@ -1307,6 +1307,7 @@ static int applyPendingFilters(b2hip_world* w)
 // Applies the queued contact-array ops (b2d_kernels_edit.h) in call order, then compacts the contact array if contacts
 // were destroyed. Called by the step right after its counters are zeroed, and by whoever reads the contacts between steps.
 static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo = false);
+static int startEarlyRows(b2hip_world* w);
 
 static int applyEditOps(b2hip_world* w, bool betweenSteps)
 {
@@ -1532,7 +1533,9 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 	}
 	if (sync)
 	{
-		int rc = readState(w);
+		int rc = startEarlyRows(w); // (before the host waits for the pair count)
+		if (rc) return rc;
+		rc = readState(w);
 		if (rc) return rc;
 		if (w->h_dstate->c.overflow & 3)
 		{
@@ -2146,7 +2149,7 @@ static int phaseSyncFixtures(b2hip_world* w)
 {
 	DW& d = w->dw;
 	if (int rk = ktBracket(w, 3, 6)) return rk;
-	LAUNCH(w, k_sync_fixtures, gridFor(((size_t)d.nProxies + 3) / 4), 256, d); // (SYNC_TILE proxies per workgroup and round)
+	LAUNCH(w, k_sync_fixtures, gridFor(d.nProxies >= 262144 ? ((size_t)d.nProxies + 3) / 4 : (size_t)d.nProxies), 256, d); // (SYNC_TILE proxies per workgroup and round in a large world)
 	if (int rk = ktBracket(w, 3, 6)) return rk;
 	return 0;
 }
@@ -2358,11 +2361,14 @@ static inline void shadowWritten(b2hip_world* w)
 // Behind SynchronizeFixtures the rows of all bodies but those the TOI phase will still move are final: a large world sends
 // them now, on a second stream, under the pair update and the TOI phase (40 bytes per body over PCIe: 0.75 ms for a million
 // bodies, the longest single item of that step), and k_end_step sends the rows that changed since (its shadow comparison).
-static int startEarlyRows(b2hip_world* w)
+// (two halves: the point on the main stream from which the rows may be read is marked right behind SynchronizeFixtures; the
+// launches on the second stream are issued once the host has queued the pair search - or the main stream would wait for
+// the host to get through these calls)
+static int forkEarlyRows(b2hip_world* w)
 {
 	DW& d = w->dw;
 	const bool lazy = w->lazyReadback || (w->spatial && !w->spFullRows);
-	if (w->earlyRowsMin <= 0 || d.nBodies < w->earlyRowsMin || w->noStatePoll || lazy || w->rowsEarlyPending || w->debugSync || w->debugTrace) return 0;
+	if (w->earlyRowsMin <= 0 || d.nBodies < w->earlyRowsMin || w->noStatePoll || lazy || w->rowsEarlyPending || w->rowsForked || w->debugSync || w->debugTrace) return 0;
 	if (!w->rowStream)
 	{
 		HIP_TRY(hipStreamCreateWithFlags(&w->rowStream, hipStreamNonBlocking));
@@ -2370,6 +2376,15 @@ static int startEarlyRows(b2hip_world* w)
 		HIP_TRY(hipEventCreateWithFlags(&w->rowJoin, hipEventDisableTiming));
 	}
 	HIP_TRY(hipEventRecord(w->rowFork, w->stream));
+	w->rowsForked = true;
+	return 0;
+}
+
+static int startEarlyRows(b2hip_world* w)
+{
+	DW& d = w->dw;
+	if (!w->rowsForked) return 0;
+	w->rowsForked = false;
 	HIP_TRY(hipStreamWaitEvent(w->rowStream, w->rowFork, 0));
 	// The rows are gathered into the device's copy (stateOut: ~30 us for a million bodies) and leave from there by a copy - the
 	// DMA engine's, which does not stand in the way of the kernels running meanwhile. (Stores from a kernel straight into host
@@ -2390,6 +2405,7 @@ static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 {
 	DW& d = w->dw;
 	const size_t nb = w->bodies.size();
+	w->rowsForked = false; // (marked, never launched: a step without a pair update)
 	if (w->rowsEarlyPending)
 	{
 		HIP_TRY(hipStreamWaitEvent(w->stream, w->rowJoin, 0));
@@ -4171,7 +4187,7 @@ static int syncFixturesImpl(b2hip_world* w)
 		if (rc) return rc;
 		// E1: what the other ranks' bodies did in Solve, and the fat AABBs their SynchronizeFixtures moved
 		if (w->spatial) { rc = spExchangeState(w, 0); if (rc) return rc; }
-		rc = startEarlyRows(w);
+		rc = forkEarlyRows(w);
 		if (rc) return rc;
 	}
 	stampPhase(w, 9);
@@ -4191,6 +4207,8 @@ static int findNewContactsImpl(b2hip_world* w)
 	if (w->sp.dt > 0.0f && w->stepSolves)
 	{
 		int rc = findNewContactsGraph(w);
+		if (rc) return rc;
+		rc = startEarlyRows(w); // (if the pair update has not sent them off itself)
 		if (rc) return rc;
 	}
 	stampPhase(w, 10);
