@@ -708,6 +708,7 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	const int tid = (int)threadIdx.x;
 	__shared__ __attribute__((aligned(16))) float s_out[2560];
 	__shared__ int s_chg[256];
+	__shared__ int s_pack[256 * 11];
 	__shared__ int s_last;
 	// (ClearPostSolveTOI only when the step is complete; sub-stepping: also for what earlier calls of the step touched)
 	const bool toiEvents = (S->c.nToiEvents != 0 || W.toiContinue != 0) && S->c.toiIncomplete == 0;
@@ -744,30 +745,36 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 		if (W.spatial && !W.spFullRows && houseKeeping && W.spOwnOut != nullptr)
 		{
 			// a spatially sharded world with the lean exchange: this rank answers for the bodies it OWNS - their rows go to the
-			// host packed (id + row, one contiguous run per wave), the table of all rows stays on the device until somebody asks
-			// (as with the read-back on demand). Ownership need not follow the body ids: 1 / N of the rows cross PCIe, not all.
+			// host packed (id + row), the table of all rows stays on the device until somebody asks (as with the read-back on
+			// demand). Ownership need not follow the body ids: 1 / N of the rows cross PCIe, not all. One atomic per tile takes
+			// the tile's place in the list (not one per wave: see k_sync_fixtures); the tile's rows are packed in LDS and leave
+			// as ONE contiguous run of words (eleven 4-byte stores per lane into host memory were 150 us for the 50 000 bodies
+			// of a rank of config 4).
 			const bool mine = i < n && (W.b_flags[i] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[i] == (uint8_t)W.shardRank;
 			const unsigned long long m = __ballot(mine);
-			// (one atomic per tile, not per wave: see k_sync_fixtures)
 			if (waveLane() == 0) s_chg[tid >> 6] = __popcll(m);
 			__syncthreads();
 			if (tid == 0)
 			{
 				const int c0 = s_chg[0], c1 = s_chg[1], c2 = s_chg[2], c3 = s_chg[3];
-				const int at = c0 + c1 + c2 + c3 > 0 ? atomicAdd(&S->c.spOwnRows, c0 + c1 + c2 + c3) : 0;
-				s_chg[0] = at; s_chg[1] = at + c0; s_chg[2] = at + c0 + c1; s_chg[3] = at + c0 + c1 + c2;
+				s_chg[0] = 0; s_chg[1] = c0; s_chg[2] = c0 + c1; s_chg[3] = c0 + c1 + c2;
+				s_chg[4] = c0 + c1 + c2 + c3;
+				s_chg[5] = s_chg[4] > 0 ? atomicAdd(&S->c.spOwnRows, s_chg[4]) : 0;
 			}
 			__syncthreads();
 			if (mine)
 			{
-				const int k = s_chg[tid >> 6] + __popcll(m & ((1ull << waveLane()) - 1ull));
-				if (k < W.spOwnCap)
-				{
-					int* q = W.spOwnOut + (size_t)k * 11;
-					const float* o = s_out + tid * 10;
-					q[0] = i;
-					for (int c = 0; c < 10; ++c) q[1 + c] = __float_as_int(o[c]);
-				}
+				int* q = s_pack + (s_chg[tid >> 6] + __popcll(m & ((1ull << waveLane()) - 1ull))) * 11;
+				const float* o = s_out + tid * 10;
+				q[0] = i;
+				for (int c = 0; c < 10; ++c) q[1 + c] = __float_as_int(o[c]);
+			}
+			__syncthreads();
+			{
+				const int total = s_chg[4], at = s_chg[5];
+				const int fit = at + total <= W.spOwnCap ? total : (W.spOwnCap > at ? W.spOwnCap - at : 0);
+				int* dstp = W.spOwnOut + (size_t)at * 11;
+				for (int q = tid; q < fit * 11; q += 256) dstp[q] = s_pack[q];
 			}
 			__syncthreads(); // (s_chg serves the row comparison next)
 		}
