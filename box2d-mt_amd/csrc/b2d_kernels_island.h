@@ -422,7 +422,8 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 				int w = nb > nc ? nb : nc;
 				if (w < 1) w = 1;
 				bool mine = true, big = false;
-				if (nb == 1 && nc == 0 && nj == 0 && forceLarge != 2 && !W.noFreeBodies)
+				const bool isFree = nb == 1 && nc == 0 && nj == 0 && forceLarge != 2 && !W.noFreeBodies;
+				if (isFree)
 				{
 					// (in a sharded world every rank steps these itself: nothing to exchange)
 					freeBodyStep(W, sp, i);
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 						if (nj) atomicAdd(&S->c.shardJoints[owner], nj);
 					}
 				}
-				if (W.rootIsland[i] == ROOT_FREE)
+				if (isFree) // (not a load of the word just stored: the wave would wait for the store to come back)
 				{
 				}
 				else if (big)
