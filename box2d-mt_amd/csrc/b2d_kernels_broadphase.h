@@ -202,7 +202,11 @@ __global__ __launch_bounds__(256) void k_grid_fill(DW W, int force)
 		int ix, iy;
 		proxyCell(W, a, &ix, &iy);
 		uint32_t h = cellHash(ix, iy, W.gridMask);
-		W.gridItems[W.gridStart[h] + atomicAdd(&W.gridCursor[h], 1)] = p;
+		// (the box travels with the item: the pair search tests a candidate without a second, dependent load - its time is the
+		// chain of loads per moved proxy, and cell by cell the boxes lie together)
+		const int slot = W.gridStart[h] + atomicAdd(&W.gridCursor[h], 1);
+		W.gridItems[slot] = p;
+		W.gridFat[slot] = a;
 	}
 }
 
@@ -255,13 +259,18 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
+	int pAhead = waveId < nm ? W.moveBuf[waveId] : -1;
 	for (int k = waveId; k < nm; k += nWaves)
 	{
-		const int p = W.moveBuf[k];
-		if (p < 0 || W.p_body[p] < 0) continue;
+		// (the next round's proxy is asked for now; this round's body and box in one go)
+		const int p = pAhead;
+		pAhead = k + nWaves < nm ? W.moveBuf[k + nWaves] : -1;
+		const int pSafe = p < 0 ? 0 : p;
+		const int bodyOfP = W.p_body[pSafe];
+		const float4 a4 = W.p_fat[pSafe];
+		if (p < 0 || bodyOfP < 0) continue;
 		// (a spatially sharded world: every rank searches for the proxies ITS bodies moved; b2d_kernels_spatial.h, E2)
-		if (W.spatial && (W.b_flags[W.p_body[p]] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[W.p_body[p]] != (uint8_t)W.shardRank) continue;
-		const float4 a4 = W.p_fat[p];
+		if (W.spatial && (W.b_flags[bodyOfP] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyOfP] != (uint8_t)W.shardRank) continue;
 		if (proxyIsLarge(W, a4))
 		{
 			// (for k_find_pairs_large; the list is as long as the move buffer)
@@ -311,7 +320,11 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 			if (t >= 0)
 			{
 				const int q = W.gridItems[t];
-				if (q != p && b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
+				const float4 fq = W.gridFat[t];
+				AABB bq;
+				bq.lo = v2(fq.x, fq.y);
+				bq.hi = v2(fq.z, fq.w);
+				if (q != p && b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, q);
 			}
 		}
 		for (int t = lane; t < nLarge; t += 64)
@@ -338,13 +351,18 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
+	int pAhead = waveId < nm ? W.moveBuf[waveId] : -1;
 	for (int k = waveId; k < nm; k += nWaves)
 	{
-		const int p = W.moveBuf[k];
-		if (p < 0 || W.p_body[p] < 0) continue;
+		// (the next round's proxy is asked for now; this round's body and box in one go)
+		const int p = pAhead;
+		pAhead = k + nWaves < nm ? W.moveBuf[k + nWaves] : -1;
+		const int pSafe = p < 0 ? 0 : p;
+		const int bodyOfP = W.p_body[pSafe];
+		const float4 a4 = W.p_fat[pSafe];
+		if (p < 0 || bodyOfP < 0) continue;
 		// (a spatially sharded world: every rank searches for the proxies ITS bodies moved; b2d_kernels_spatial.h, E2)
-		if (W.spatial && (W.b_flags[W.p_body[p]] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[W.p_body[p]] != (uint8_t)W.shardRank) continue;
-		const float4 a4 = W.p_fat[p];
+		if (W.spatial && (W.b_flags[bodyOfP] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyOfP] != (uint8_t)W.shardRank) continue;
 		if (proxyIsLarge(W, a4))
 		{
 			// (for k_find_pairs_large; the list is as long as the move buffer)
@@ -391,7 +409,11 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 			if (t >= 0)
 			{
 				const int q = W.gridItems[t];
-				if (q != p && b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
+				const float4 fq = W.gridFat[t];
+				AABB bq;
+				bq.lo = v2(fq.x, fq.y);
+				bq.hi = v2(fq.z, fq.w);
+				if (q != p && b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, q);
 			}
 		}
 		for (int t = lane; t < nLarge; t += 64)
@@ -837,11 +859,12 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	if (tid == 0)
 	{
 		__threadfence_system();
-		s_last = atomicAdd(&S->c.endBlocksDone, 1) == (int)gridDim.x - 1 ? 1 : 0;
+		// (two-level arrival: 2 048 atomics on one word were 60 us of a million-body step's last kernel; b2d_world.h)
+		unsigned t0 = 0u, t1 = 0u;
+		s_last = b2dTreeArrive(W.arriveTree + (size_t)ARRIVE_END_STEP * TREE_WORDS, 0u, 0u, &t0, &t1) ? 1 : 0;
 	}
 	__syncthreads();
 	if (!s_last) return;
-	if (tid == 0) S->c.endBlocksDone = 0;
 	// (the solver's phase stamps travel with the counters)
 	if (bar != nullptr && tid < 6) S->stamps[tid] = bar[8 + tid];
 	if (tid == 0)

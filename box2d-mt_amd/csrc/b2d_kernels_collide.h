@@ -439,10 +439,39 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 		C.flags[i] = flags;
 		W.keepFlag[i] = keep;
 	}
-	if (nDestroy) atomicAdd(&S->c.nDestroy, nDestroy);
-	if (nTouch) atomicAdd(&S->c.nTouching, nTouch);
-	// the last workgroup to finish: the TOI candidates destroyed by this pass leave the manager's slot order
-	if (b2dLastBlockArrive(&S->c.collideBlocksDone)) toiOrderDestroy(W, s_raw);
+	// the census of the pass (destroyed, touching) travels with the arrival of the workgroups (b2d_world.h: b2dTreeArrive -
+	// one atomic per WAVE on each of the two counters was 2 x 2 000 atomics on one word for the 128 000 contacts of the 1 M
+	// field, served one after the other); the last workgroup to finish adds the totals, and:
+	// the TOI candidates destroyed by this pass leave the manager's slot order
+	{
+		__shared__ int s_census[2];
+		if (threadIdx.x == 0) { s_census[0] = 0; s_census[1] = 0; }
+		__syncthreads();
+		nDestroy = waveSumInt(nDestroy);
+		nTouch = waveSumInt(nTouch);
+		if (waveLane() == 0)
+		{
+			if (nDestroy) atomicAdd(&s_census[0], nDestroy);
+			if (nTouch) atomicAdd(&s_census[1], nTouch);
+		}
+		__syncthreads();
+		const bool fit = (unsigned)W.capContacts <= TREE_SUM_MAX;
+		if (!fit && threadIdx.x == 0)
+		{
+			if (s_census[0]) atomicAdd(&S->c.nDestroy, s_census[0]);
+			if (s_census[1]) atomicAdd(&S->c.nTouching, s_census[1]);
+		}
+		unsigned t0 = 0u, t1 = 0u;
+		if (b2dLastBlockArrive(W, ARRIVE_COLLIDE, fit ? (unsigned)s_census[0] : 0u, fit ? (unsigned)s_census[1] : 0u, &t0, &t1))
+		{
+			if (threadIdx.x == 0)
+			{
+				if (t0) atomicAdd(&S->c.nDestroy, (int)t0);
+				if (t1) atomicAdd(&S->c.nTouching, (int)t1);
+			}
+			toiOrderDestroy(W, s_raw);
+		}
+	}
 }
 
 // b2World::CreateJoint with collideConnected == false flags the contacts between the two bodies for
@@ -628,6 +657,9 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.spToiStraddle = 0;
 	}
 	if (t < 32) bar[t] = 0;
+	// (the arrival trees are all zero between launches - whoever completes a word puts it back; a launch that died halfway
+	// in a failed step must not leave the next step's close-outs without their last workgroup)
+	for (int k = t; k < ARRIVE_SITES * TREE_WORDS; k += (int)blockDim.x) W.arriveTree[k] = 0ull;
 }
 
 // The wake requests Collide gathered (ConsumeAwakes, b2Contact::Destroy) are normally applied by the island build that
@@ -707,7 +739,7 @@ __global__ __launch_bounds__(256) void k_compact_contacts(DW W)
 	// the workgroup that finishes last switches the buffers (was a kernel of its own): everybody has read the count and
 	// the live half by then
 	// (no fence: the last workgroup reads nothing the others wrote - a fence per workgroup writes the L2 back 256 times)
-	if (b2dLastBlockArrive(&S->c.compactBlocksDone) && threadIdx.x == 0)
+	if (b2dLastBlockArrive(W, ARRIVE_COMPACT) && threadIdx.x == 0)
 	{
 		S->c.nContacts = W.keepScan[n];
 		S->cur = 1 - S->cur;

@@ -479,8 +479,9 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 		}
 		W.rootScanIn[i] = in;
 	}
-	// (one add per workgroup: a million single-body islands adding to one word serialise in L2)
-	blockAtomicAddInt2(&S->c.nIslands, nIslands, &S->c.nFreeIslands, nFree);
+	// (the census travels with the arrival of the workgroups: even one add per workgroup and counter - 4 096 atomics on two
+	// words - was 120 of this kernel's 205 us on the 1 M field; b2d_world.h: b2dTreeArrive)
+	b2dBlockTreeAdd2(W, ARRIVE_CLASSIFY, &S->c.nIslands, nIslands, &S->c.nFreeIslands, nFree, (unsigned)W.nBodies <= TREE_SUM_MAX);
 }
 
 __global__ __launch_bounds__(256) void k_island_assign(DW W)
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub)
 		}
 	}
 	// (the counters the census consists of are atomics' results: nothing of this workgroup's plain stores is read there)
-	if (pub != nullptr && b2dLastBlockArrive(&S->c.edgesBlocksDone)) b2dPublishCensus(W, pub);
+	if (pub != nullptr && b2dLastBlockArrive(W, ARRIVE_EDGES)) b2dPublishCensus(W, pub);
 }
 
 // The census published by a launch of its own (the island build ends with another kernel than the two that can do it).

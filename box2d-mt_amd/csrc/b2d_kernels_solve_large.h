@@ -274,19 +274,23 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	// nUncolored: constraints without a colour yet -> incremental rounds on top of the existing masks
 	if (bad) atomicOr(&S->c.needRecolor, 1);
 	if (uncolored) atomicAdd(&S->c.nUncolored, uncolored);
-	if (maxColor) atomicMax(&S->c.nColors, maxColor);
-	// wave-combined: one atomic per wave and word instead of one per row
+	// wave-combined, and only what would CHANGE the word (the maximum and the masks only grow while this kernel runs; a load
+	// past the L2 first): one atomic per wave on each of the three words was 16 000 atomics, served one after the other, for
+	// the 350 000 constraints of the settled Tumbler - most of this kernel's 209 us
 	for (int off = 32; off > 0; off >>= 1)
 	{
 		usedLo |= (uint32_t)__shfl_xor((int)usedLo, off);
 		usedHi |= (uint32_t)__shfl_xor((int)usedHi, off);
+		const int om = __shfl_xor(maxColor, off);
+		maxColor = om > maxColor ? om : maxColor;
 	}
 	orphanRows = waveSumInt(orphanRows);
 	cutRows = waveSumInt(cutRows);
 	if (waveLane() == 0)
 	{
-		if (usedLo) atomicOr(&S->c.colorMaskLo, usedLo);
-		if (usedHi) atomicOr(&S->c.colorMaskHi, usedHi);
+		if (maxColor) atomicMaxIfAbove(&S->c.nColors, maxColor);
+		if (usedLo & ~__hip_atomic_load(&S->c.colorMaskLo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&S->c.colorMaskLo, usedLo);
+		if (usedHi & ~__hip_atomic_load(&S->c.colorMaskHi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&S->c.colorMaskHi, usedHi);
 		if (orphanRows) atomicAdd(&s_sums[0], orphanRows);
 		if (cutRows) atomicAdd(&s_sums[1], cutRows);
 	}
@@ -298,8 +302,21 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	}
 	if (threadIdx.x == 0)
 	{
-		if (s_sums[0]) atomicAdd(&S->c.nOrphanRows, s_sums[0]);
-		if (s_sums[1]) atomicAdd(&S->c.nCutRows, s_sums[1]);
+		// (carried by the arrival of the workgroups: b2d_world.h)
+		if ((unsigned)W.capContacts <= TREE_SUM_MAX)
+		{
+			unsigned t0 = 0u, t1 = 0u;
+			if (b2dTreeArrive(W.arriveTree + (size_t)ARRIVE_COLOR_CHECK * TREE_WORDS, (unsigned)s_sums[0], (unsigned)s_sums[1], &t0, &t1))
+			{
+				if (t0) atomicAdd(&S->c.nOrphanRows, (int)t0);
+				if (t1) atomicAdd(&S->c.nCutRows, (int)t1);
+			}
+		}
+		else
+		{
+			if (s_sums[0]) atomicAdd(&S->c.nOrphanRows, s_sums[0]);
+			if (s_sums[1]) atomicAdd(&S->c.nCutRows, s_sums[1]);
+		}
 	}
 	// the home bodies of every block, counted for k_block_census; an adoption (b_adopt: a neighbour's block, offered by
 	// k_island_edges / k_block_adopt) becomes the body's own block (small worlds: k_block_census does it itself)
@@ -1323,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_large_position(DW W, int color)
 			if (r.nsA) W.b_pos[r.bodyA] = make_float4(pA.c.x, pA.c.y, pA.a, pa.w);
 			if (r.nsB) W.b_pos[r.bodyB] = make_float4(pB.c.x, pB.c.y, pB.a, pb.w);
 		}
-		waveAtomicMaxU32(W.rootPen, r.root, floatBits(0.0f - minSep), valid);
+		waveAtomicMaxU32Guarded(W.rootPen, r.root, floatBits(0.0f - minSep), valid);
 	}
 }
 

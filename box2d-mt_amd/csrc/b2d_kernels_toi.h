@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 		}
 		C.flags[i] = flags;
 	}
-	if (calls) atomicAdd(&S->c.nToiCalls, calls);
+	// (one add for the launch, carried by the arrival of the workgroups: b2d_world.h)
+	b2dBlockTreeAdd2(W, ARRIVE_TOI_FIRST, &S->c.nToiCalls, calls, &S->c.nToiCalls, 0, (unsigned)W.capContacts <= TREE_SUM_MAX);
 }
 
 // ---- adjacency of ALL contacts by non-static body (the island CSR only holds solid touching ones) ----

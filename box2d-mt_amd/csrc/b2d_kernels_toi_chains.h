@@ -830,7 +830,7 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp,
 		}
 	}
 	// the last workgroup to finish closes the phase
-	if (b2dLastBlockArrive(&S->c.chainBlocksDone)) toiChainsEnd(W);
+	if (b2dLastBlockArrive(W, ARRIVE_CHAINS)) toiChainsEnd(W);
 }
 
 // ---- fused front of the pair update: (hash table of contact keys + spatial grid) cleared, then built -----------------

@@ -60,7 +60,9 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v)
 // Tumbler: 35 000 of 100 000 bodies on one root, spread over every wave) no longer send one atomic per lane to that root
 // (measured there: k_island_flatten 192 us, nearly all of it the same-address queue in L2).
 // Integer sums / minima / maxima do not depend on the order of combination: the results are the same bits either way.
-#define B2D_WAVE_ATOMIC(NAME, T, REDUCE, IDENTITY, ATOMIC)                                         \
+// WORTH(slot, value): minima / maxima look first (a load past the L2) and join the queue of the word's atomics only if they
+// would change it - the words only move one way while a kernel runs, a stale read costs an atomic, never a result.
+#define B2D_WAVE_ATOMIC(NAME, T, REDUCE, IDENTITY, ATOMIC, WORTH)                                  \
 	__device__ __forceinline__ void NAME(T* base, int key, T val, bool valid)                      \
 	{                                                                                              \
 		const int lane = waveLane();                                                               \
@@ -73,16 +75,20 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v)
 			const int k0 = __shfl(key, leader);                                                    \
 			const bool mine = pending && key == k0;                                                \
 			const T s = REDUCE(mine ? val : (T)(IDENTITY));                                        \
-			if (lane == leader) ATOMIC(&base[k0], s);                                              \
+			if (lane == leader && WORTH(&base[k0], s)) ATOMIC(&base[k0], s);                       \
 			pending = pending && !mine;                                                            \
 		}                                                                                          \
-		if (pending) ATOMIC(&base[key], val);                                                      \
+		if (pending && WORTH(&base[key], val)) ATOMIC(&base[key], val);                            \
 	}
 
-B2D_WAVE_ATOMIC(waveAtomicAddInt, int, waveSumInt, 0, atomicAdd)
-B2D_WAVE_ATOMIC(waveAtomicMinInt, int, waveMinInt, 0x7fffffff, atomicMin)
-B2D_WAVE_ATOMIC(waveAtomicMaxU32, uint32_t, waveMaxU32, 0u, atomicMax)
-B2D_WAVE_ATOMIC(waveAtomicMinU32, uint32_t, waveMinU32, 0xffffffffu, atomicMin)
+#define B2D_WORTH_ALWAYS(P, V) true
+#define B2D_WORTH_BELOW(P, V) ((V) < __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#define B2D_WORTH_ABOVE(P, V) ((V) > __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+B2D_WAVE_ATOMIC(waveAtomicAddInt, int, waveSumInt, 0, atomicAdd, B2D_WORTH_ALWAYS)
+B2D_WAVE_ATOMIC(waveAtomicMinInt, int, waveMinInt, 0x7fffffff, atomicMin, B2D_WORTH_BELOW)
+B2D_WAVE_ATOMIC(waveAtomicMaxU32, uint32_t, waveMaxU32, 0u, atomicMax, B2D_WORTH_ALWAYS) // (inside the resident solvers: fire and forget, no load to wait for)
+B2D_WAVE_ATOMIC(waveAtomicMaxU32Guarded, uint32_t, waveMaxU32, 0u, atomicMax, B2D_WORTH_ABOVE) // (launch per colour: the launch ends when the word's queue has drained)
+B2D_WAVE_ATOMIC(waveAtomicMinU32, uint32_t, waveMinU32, 0xffffffffu, atomicMin, B2D_WORTH_BELOW)
 #undef B2D_WAVE_ATOMIC
 
 // Counters every lane of a kernel adds to (island and contact censuses): ONE atomic per workgroup. Same-address atomics are

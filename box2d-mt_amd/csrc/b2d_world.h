@@ -12,6 +12,7 @@
 
 #include "b2d_solver.h"
 #include "b2d_joint.h"
+#include "b2d_wave.h"
 
 // body flag bits (device). Bits 0-1 hold the b2BodyType.
 #define BF_TYPE_MASK 0x3u
@@ -421,7 +422,9 @@ struct DW
 	int* gridCount;      // per hash cell
 	int* gridStart;
 	int* gridCursor;
+	unsigned long long* arriveTree; // ARRIVE_SITES two-level arrival trees (b2dTreeArrive), all words 0 between launches
 	int* gridItems;      // proxy indices grouped by cell
+	float4* gridFat;     // ... and their fat AABBs as k_grid_fill found them (the pair search's copy: the TOI phase moves p_fat)
 	int* largeProxies;   // proxies larger than a cell
 	int* largeMoves;     // ... those of them in the move buffer
 	uint64_t* pairKey;   // candidate pairs: key
@@ -500,21 +503,103 @@ __device__ __forceinline__ float4 b2dLoadAgent4(const float4* p)
 	asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
 	return make_float4(r.x, r.y, r.z, r.w);
 }
+// ---- arrival of the workgroups of a launch ------------------------------------------------------------------------------
+// "The workgroup that finishes last does the close-out" and "every workgroup adds its count to a counter" both need one
+// atomic per workgroup on ONE word. On this part such atomics are executed at the memory side (the eight XCDs' L2s are not
+// coherent with one another), one after the other, ~30 ns each: measured with k_island_classify on a million bodies - 78 us
+// without its two census adds, 88 us with 512 workgroups, 205 us with 2 048, 325 us with 8 192. So the workgroups arrive in
+// two levels: workgroup b at slot b % 32 (32 words on 32 different 128-byte lines: 32 queues side by side), and the one that
+// completes its slot's count carries the slot's totals on to the root word. The longest queue is gridDim / 32 + 32 atomics
+// instead of gridDim. One 64-bit word holds the count (bits 48+) and two 24-bit sums, so a census travels with the arrival;
+// whoever completes a word puts it back to 0 - nobody else touches it again in this launch.
+#define TREE_GROUPS 32
+#define TREE_STRIDE 16 // 64-bit words between two slots: 128 bytes
+#define TREE_WORDS ((TREE_GROUPS + 1) * TREE_STRIDE)
+#define TREE_SUM_MAX 0xffffffu // (callers whose sums may exceed this use plain atomics instead: see treeSumsFit)
+#define ARRIVE_COLLIDE 0
+#define ARRIVE_COMPACT 1
+#define ARRIVE_EDGES 2
+#define ARRIVE_CHAINS 3
+#define ARRIVE_END_STEP 4
+#define ARRIVE_CLASSIFY 5
+#define ARRIVE_TOI_FIRST 6
+#define ARRIVE_COLOR_CHECK 7
+#define ARRIVE_SITES 8
+// ONE thread per workgroup, every workgroup of the (one-dimensional) grid exactly once. True in the workgroup that arrives
+// last, with the sums of all workgroups' v0 / v1.
+__device__ __forceinline__ bool b2dTreeArrive(unsigned long long* tree, unsigned v0, unsigned v1, unsigned* t0, unsigned* t1)
+{
+	const unsigned nb = gridDim.x;
+	const unsigned groups = nb < TREE_GROUPS ? nb : TREE_GROUPS;
+	const unsigned g = blockIdx.x % groups;
+	const unsigned members = nb / groups + (g < nb % groups ? 1u : 0u);
+	const unsigned long long one = 1ull << 48;
+	unsigned long long* slot = tree + (size_t)g * TREE_STRIDE;
+	const unsigned long long add = one | ((unsigned long long)(v1 & TREE_SUM_MAX) << 24) | (unsigned long long)(v0 & TREE_SUM_MAX);
+	unsigned long long seen = __hip_atomic_fetch_add(slot, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+	if ((unsigned)(seen >> 48) != members) return false;
+	__hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	unsigned long long* root = tree + (size_t)TREE_GROUPS * TREE_STRIDE;
+	const unsigned long long add2 = one | (seen & 0xffffffffffffull);
+	seen = __hip_atomic_fetch_add(root, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add2;
+	if ((unsigned)(seen >> 48) != groups) return false;
+	__hip_atomic_store(root, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	*t0 = (unsigned)(seen & TREE_SUM_MAX);
+	*t1 = (unsigned)((seen >> 24) & TREE_SUM_MAX);
+	return true;
+}
+
 // Every thread of the workgroup calls it at the end of its work; true in the workgroup that arrived last (all of them
-// have then completed the stores they made before arriving). `counter` goes back to 0 for the next launch.
-__device__ __forceinline__ bool b2dLastBlockArrive(int* counter)
+// have then completed the stores they made before arriving). v0 / v1: this WORKGROUP's contribution to two sums (the value
+// thread 0 passes counts), delivered in *t0 / *t1 to the elected workgroup (all its threads).
+__device__ __forceinline__ bool b2dLastBlockArrive(const DW& W, int site, unsigned v0 = 0u, unsigned v1 = 0u, unsigned* t0 = nullptr, unsigned* t1 = nullptr)
 {
 	__shared__ int s_lastBlock;
+	__shared__ unsigned s_treeSums[2];
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		s_lastBlock = prev == (int)gridDim.x - 1 ? 1 : 0;
-		if (s_lastBlock) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		unsigned a = 0u, b = 0u;
+		s_lastBlock = b2dTreeArrive(W.arriveTree + (size_t)site * TREE_WORDS, v0, v1, &a, &b) ? 1 : 0;
+		s_treeSums[0] = a;
+		s_treeSums[1] = b;
 	}
 	__syncthreads();
+	if (t0) *t0 = s_treeSums[0];
+	if (t1) *t1 = s_treeSums[1];
 	return s_lastBlock != 0;
+}
+
+// Two counters every lane of a kernel adds to at its end (a census): summed over the workgroup, carried by the arrival tree,
+// added to the counters by the workgroup that arrives last. Nothing else may write the two counters in this launch. Every
+// lane of every workgroup calls. fit = the sums stay below 2^24 (the caller's bound: bodies, contacts); else plain atomics.
+__device__ __forceinline__ void b2dBlockTreeAdd2(const DW& W, int site, int* c0, int v0, int* c1, int v1, bool fit)
+{
+	__shared__ int s_treeAdd[2];
+	if (threadIdx.x == 0) { s_treeAdd[0] = 0; s_treeAdd[1] = 0; }
+	__syncthreads();
+	v0 = waveSumInt(v0);
+	v1 = waveSumInt(v1);
+	if (waveLane() == 0)
+	{
+		if (v0) atomicAdd(&s_treeAdd[0], v0);
+		if (v1) atomicAdd(&s_treeAdd[1], v1);
+	}
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	if (!fit)
+	{
+		if (s_treeAdd[0]) atomicAdd(c0, s_treeAdd[0]);
+		if (s_treeAdd[1]) atomicAdd(c1, s_treeAdd[1]);
+		return;
+	}
+	unsigned t0 = 0u, t1 = 0u;
+	if (b2dTreeArrive(W.arriveTree + (size_t)site * TREE_WORDS, (unsigned)s_treeAdd[0], (unsigned)s_treeAdd[1], &t0, &t1))
+	{
+		if (t0) atomicAdd(c0, (int)t0);
+		if (t1) atomicAdd(c1, (int)t1);
+	}
 }
 
 // The island census for the host, which is polling for it (b2hip.hip: awaitCensus): every counter goes straight into the

@@ -224,6 +224,8 @@ struct b2hip_world
 	DevArray<int> rootDone;
 	DevArray<float> lc;
 	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies, largeMoves;
+	DevArray<float4> gridFat;
+	DevArray<unsigned long long> arriveTree;
 	DevArray<uint64_t> pairKey, pairKey2;
 	DevArray<int2> pairProxy, pairProxy2;
 	DevArray<int> pairFirst, pairRank;
@@ -857,7 +859,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	}
 	ENS(moveBuf, 2 * np + 64);
 	const size_t gridSize = (size_t)nextPow2(2 * np);
-	ENS(gridCount, gridSize); ENS(gridStart, gridSize + 2); ENS(gridCursor, gridSize); ENS(gridItems, np); ENS(largeProxies, np); ENS(largeMoves, 2 * np + 64);
+	ENS(gridCount, gridSize); ENS(gridStart, gridSize + 2); ENS(gridCursor, gridSize); ENS(gridItems, np); ENS(gridFat, np); ENS(arriveTree, (size_t)ARRIVE_SITES * TREE_WORDS); ENS(largeProxies, np); ENS(largeMoves, 2 * np + 64);
 	ENS(pairKey, capPairs); ENS(pairKey2, capPairs); ENS(pairProxy, capPairs); ENS(pairProxy2, capPairs);
 	ENS(pairFirst, capPairs + 1); ENS(pairRank, capPairs + 2);
 	const size_t maxScanN = std::max(std::max(nb + 2, gridSize + 2), std::max(cc + 2, capPairs + 2));
@@ -954,7 +956,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.hubDelta = w->hubDelta.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
-	d.gridItems = w->gridItems.p; d.largeProxies = w->largeProxies.p; d.largeMoves = w->largeMoves.p;
+	d.gridItems = w->gridItems.p; d.gridFat = w->gridFat.p; d.arriveTree = w->arriveTree.p; d.largeProxies = w->largeProxies.p; d.largeMoves = w->largeMoves.p;
 	d.pairKey = w->pairKey.p; d.pairProxy = w->pairProxy.p; d.pairKey2 = w->pairKey2.p; d.pairProxy2 = w->pairProxy2.p;
 	d.pairFirst = w->pairFirst.p; d.pairRank = w->pairRank.p;
 	d.scanTmp = w->scanTmp.p; d.radixHist = w->radixHist.p; d.keepFlag = w->keepFlag.p; d.keepScan = w->keepScan.p;
@@ -2761,7 +2763,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiNew.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
-	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release();
+	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release(); w->gridFat.release(); w->arriveTree.release();
 	w->largeProxies.release(); w->largeMoves.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
 	w->filterPairs.release();
 	w->d_editOps.release();
