@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 
 // The event chain of one dynamic body: b2World::SolveTOI restricted to the contacts of D (all with static partners).
 // haveGrid = 0: the hash grid was not rebuilt for this phase, so a proxy leaving its fat AABB sends the phase to the serial loop.
-__device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, int haveGrid, int group)
+__device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, int haveGrid, int group, int* census)
 {
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
@@ -650,8 +650,9 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 	__syncthreads();
 	if (lane == 0)
 	{
-		if (s_events) atomicAdd(&S->c.nToiEvents, s_events);
-		if (s_calls) atomicAdd(&S->c.nToiCalls, s_calls);
+		// (events and calls: summed by the workgroup over its chains and carried by its arrival - k_toi_chains)
+		census[0] += s_events;
+		census[1] += s_calls;
 		if (s_unsafe) atomicOr(&S->c.toiUnsafe, s_unsafe);
 	}
 }
@@ -820,17 +821,30 @@ __global__ __launch_bounds__(CHAIN_LANES) void k_toi_chains(DW W, StepParams sp,
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
+	__shared__ int s_chainCensus[2];
+	if (threadIdx.x == 0) { s_chainCensus[0] = 0; s_chainCensus[1] = 0; }
+	__syncthreads();
 	if ((S->c.toiUnsafe & (TOI_UNSAFE_PARTNER | TOI_UNSAFE_CAPACITY)) == 0)
 	{
 		const int nGroups = S->c.nToiGroups < TOI_GROUPS_MAX ? S->c.nToiGroups : TOI_GROUPS_MAX;
 		for (int group = blockIdx.x; group < nGroups; group += gridDim.x)
 		{
-			toiChainRun(W, sp, haveGrid, group);
+			toiChainRun(W, sp, haveGrid, group, s_chainCensus);
 			__syncthreads();
 		}
 	}
-	// the last workgroup to finish closes the phase
-	if (b2dLastBlockArrive(W, ARRIVE_CHAINS)) toiChainsEnd(W);
+	// the last workgroup to finish adds the census the arrivals carried (two atomics per chain on the two counters before)
+	// and closes the phase
+	unsigned events = 0u, calls = 0u;
+	if (b2dLastBlockArrive(W, ARRIVE_CHAINS, (unsigned)s_chainCensus[0], (unsigned)s_chainCensus[1], &events, &calls))
+	{
+		if (threadIdx.x == 0)
+		{
+			if (events) atomicAdd(&S->c.nToiEvents, (int)events);
+			if (calls) atomicAdd(&S->c.nToiCalls, (int)calls);
+		}
+		toiChainsEnd(W);
+	}
 }
 
 // ---- fused front of the pair update: (hash table of contact keys + spatial grid) cleared, then built -----------------

@@ -82,10 +82,16 @@ def test_slowly_dragged_body_stays_awake(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("count,seed,flags", CASES)
-@pytest.mark.parametrize("mode", ["exact", "default"])
+@pytest.mark.parametrize("mode", ["exact", "default", "exact, rows sent early"])
 def test_device_life_cycle_matches_the_oracle(amd, oracle, monkeypatch, count, seed, flags, mode):
-    if mode == "exact":
+    monkeypatch.delenv("B2HIP_EARLY_ROWS_MIN", raising=False)
+    if mode.startswith("exact"):
         monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
+        # (what worlds of 65 536 bodies and more do: the rows leave behind SynchronizeFixtures by DMA on a second stream, the end
+        # of the step sends what changed since - here under bodies, fixtures and joints created and destroyed between steps,
+        # SetTransform / SetAwake / SetActive / SetType edits and TOI events, which all have to reach the host's rows)
+        if mode != "exact":
+            monkeypatch.setenv("B2HIP_EARLY_ROWS_MIN", "1")
     else:
         monkeypatch.setenv("B2HIP_SMALL_MAX_W", "512")
         # the heap is one island of a few hundred contacts: the exact-order in-LDS solver at its 512-row limit takes it, and the
