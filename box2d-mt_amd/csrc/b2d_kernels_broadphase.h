@@ -333,7 +333,9 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
-	if (lane == 0 && rounds > 0) atomicAdd(&S->c.candRounds[waveId & 31], rounds);
+	// (the candidate census for the host's choice of the cell: one atomic per wave on the 32 words of ONE line was 8 192
+	// atomics at the end of the kernel, ~5 ns each - carried by the arrival of the workgroups instead, b2d_world.h)
+	b2dBlockTreeAdd2(W, ARRIVE_PAIRS, &S->c.candRounds[0], lane == 0 ? rounds : 0, &S->c.candRounds[1], 0, (unsigned)W.capMoves <= (TREE_SUM_MAX >> 3));
 }
 
 
@@ -433,7 +435,9 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
-	if (lane == 0 && rounds > 0) atomicAdd(&S->c.candRounds[waveId & 31], rounds);
+	// (the candidate census for the host's choice of the cell: one atomic per wave on the 32 words of ONE line was 8 192
+	// atomics at the end of the kernel, ~5 ns each - carried by the arrival of the workgroups instead, b2d_world.h)
+	b2dBlockTreeAdd2(W, ARRIVE_PAIRS, &S->c.candRounds[0], lane == 0 ? rounds : 0, &S->c.candRounds[1], 0, (unsigned)W.capMoves <= (TREE_SUM_MAX >> 3));
 }
 
 // Moved LARGE proxies (listed by k_find_pairs_small): brute force over every proxy, a workgroup per (proxy, slice of 1024

@@ -114,8 +114,8 @@ __device__ __forceinline__ void colorCheckBegin(const DW& W)
 {
 	if (threadIdx.x <= MAX_COLORS)
 	{
-		W.colorCount[threadIdx.x] = 0;
-		W.colorCursor[threadIdx.x] = 0;
+		W.colorCount[colorSlot(threadIdx.x)] = 0;
+		W.colorCursor[colorSlot(threadIdx.x)] = 0;
 	}
 	if (threadIdx.x == 0)
 	{

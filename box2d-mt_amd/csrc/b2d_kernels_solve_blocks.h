@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void k_color_recheck_begin(DW W)
 	}
 	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS)
 	{
-		W.colorCount[threadIdx.x] = 0;
-		W.colorCursor[threadIdx.x] = 0;
+		W.colorCount[colorSlot(threadIdx.x)] = 0;
+		W.colorCursor[colorSlot(threadIdx.x)] = 0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{

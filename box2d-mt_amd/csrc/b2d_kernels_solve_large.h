@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void k_color_begin(DW W)
 	}
 	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS)
 	{
-		if (threadIdx.x != HUB_COLOR) W.colorCount[threadIdx.x] = 0;
-		W.colorCursor[threadIdx.x] = 0;
+		if (threadIdx.x != HUB_COLOR) W.colorCount[colorSlot(threadIdx.x)] = 0;
+		W.colorCursor[colorSlot(threadIdx.x)] = 0;
 	}
 	// a full recolour forgets every stored colour (also those of non-touching contacts)
 	{
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_color_begin(DW W)
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
-		S->c.nUncolored = n - W.colorCount[HUB_COLOR];
+		S->c.nUncolored = n - W.colorCount[colorSlot(HUB_COLOR)];
 		S->c.colorRounds = 0;
 		S->c.nColors = 0;
 		S->c.colorMaskLo = S->c.colorMaskHi = 0u;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			}
 			W.li_color[s] = col;
 		}
-		(void)blockKeyedAlloc65(W.colorCount, col < 0 ? 0 : col, valid && col >= 0, false);
+		(void)blockKeyedAlloc65(W.colorCount, col < 0 ? 0 : col, valid && col >= 0, false, true);
 	}
 	// needRecolor bit0: two constraints on one body share a colour -> colour everything again;
 	// nUncolored: constraints without a colour yet -> incremental rounds on top of the existing masks
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 		if (nsB) { W.bodyColorMask[ids.w] |= bit; W.bodyClaim[ids.w] = 0; }
 		W.li_color[s] = color;
 		C.color[ci] = color;
-		atomicAdd(&W.colorCount[color], 1);
+		atomicAdd(&W.colorCount[colorSlot(color)], 1);
 		atomicMax(&S->c.nColors, color + 1);
 		noteColorUsed(S, color);
 		++colored;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead)
 			if (nsB) atomicAnd((unsigned long long*)&W.bodyColorMask[ids.w], ~bit);
 			W.li_color[s] = -1;
 			C.color[ci] = -1;
-			atomicSub(&W.colorCount[c], 1);
+			atomicSub(&W.colorCount[colorSlot(c)], 1);
 			W.uncolList[slot] = s;
 		}
 	}
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead)
 			if (B >= 0) { atomicOr((unsigned long long*)&W.bodyColorMask[B], bit); __hip_atomic_store(&W.bodyClaim[B], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 			W.li_color[it_s[j]] = color;
 			C.color[it_ci[j]] = color;
-			atomicAdd(&W.colorCount[color], 1);
+			atomicAdd(&W.colorCount[colorSlot(color)], 1);
 			atomicMax(&s_maxColor, color + 1);
 			noteColorUsed(S, color);
 			it_open[j] = false;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead)
 	{
 		int nc = S->c.nColors > s_maxColor ? S->c.nColors : s_maxColor;
 		if (nc > MAX_COLORS) nc = MAX_COLORS;
-		while (nc > 0 && __hip_atomic_load(&W.colorCount[nc - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) --nc;
+		while (nc > 0 && __hip_atomic_load(&W.colorCount[colorSlot(nc - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) --nc;
 		S->c.nColors = nc;
 		S->c.nUncolored = s_left;
 		S->c.colorRounds += 1;
@@ -553,9 +553,9 @@ __global__ void k_color_scan(DW W)
 		for (int c = 0; c <= nc; ++c)
 		{
 			W.colorStart[c] = run;
-			if (c < nc) run += W.colorCount[c];
+			if (c < nc) run += W.colorCount[colorSlot(c)];
 		}
-		W.st->c.nHubRows = W.colorCount[HUB_COLOR];
+		W.st->c.nHubRows = W.colorCount[colorSlot(HUB_COLOR)];
 	}
 }
 
@@ -571,8 +571,8 @@ __global__ __launch_bounds__(256) void k_exact_begin(DW W)
 	const int n = S->c.nSContacts;
 	for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n; c += gridDim.x * blockDim.x)
 	{
-		W.colorCount[c] = 0;
-		W.colorCursor[c] = 0;
+		W.colorCount[colorSlot(c)] = 0;
+		W.colorCursor[colorSlot(c)] = 0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.nColors = 0;
 }
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_exact_convert(DW W)
 		W.li_contacts[j] = W.si_contacts[j];
 		const int color = W.si_level[j] - 1;
 		W.li_color[j] = color;
-		atomicAdd(&W.colorCount[color], 1);
+		atomicAdd(&W.colorCount[colorSlot(color)], 1);
 		atomicMax(&S->c.nColors, color + 1);
 	}
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nB; k += gridDim.x * blockDim.x)
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 		else
 		{
 			// (exact-order mode has one group per dependency level, possibly thousands: keys beyond the LDS histogram)
-			const int slot = S->c.nColors > MAX_COLORS ? waveKeyedAlloc(W.colorCursor, color, valid) : blockKeyedAlloc65(W.colorCursor, color, valid, true);
+			const int slot = S->c.nColors > MAX_COLORS ? waveKeyedAlloc(W.colorCursor, colorSlot(color), valid) : blockKeyedAlloc65(W.colorCursor, color, valid, true, true);
 			p = W.colorStart[color] + slot;
 		}
 		if (valid && p >= 0)
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_hub_fill(DW W)
 		else if (f) W.hubList[(W.keepScan[n] & 0xfffff) + (W.keepScan[i] >> 20)] = W.hubRowOf[i];
 	}
 	// (k_color_scan sets this for the launch-per-colour layout; with rows grouped by block it is not run)
-	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.nHubRows = W.colorCount[HUB_COLOR];
+	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.nHubRows = W.colorCount[colorSlot(HUB_COLOR)];
 }
 
 // One constraint of a hub chunk, evaluated from the hub row `hubIn` the lane assumes it will meet at its turn. Works on

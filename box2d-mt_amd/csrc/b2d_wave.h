@@ -239,7 +239,15 @@ __device__ __forceinline__ int waveKeyedAllocOnce(int* counter, int key, bool va
 // per key that occurs, all of them in flight together (waveKeyedAlloc pays one atomic round trip per distinct key and
 // wave, one after the other: seven colours on the 10k-body pyramid made k_color_fill 24 us). Every thread of the
 // workgroup must call it (it contains barriers). `fetch` = false: only count (no slot returned).
-__device__ __forceinline__ int blockKeyedAlloc65(int* counter, int key, bool valid, bool fetch)
+// Counters indexed by a colour (colorCount, colorCursor): the first 65 - what a block partition or a settled world uses - lie
+// on 65 different 128-byte lines; atomics on different WORDS of one line still queue (5 ns each against 11 on one word,
+// tools/microbench/atomic_cost.hip), and k_color_check / k_color_fill send ~20 per workgroup and round to these arrays.
+// Colours beyond 64 (exact-order mode: dependency levels, thousands of them) follow densely.
+#define COLOR_SLOT_STRIDE 32
+#define COLOR_SLOT_PADDED 65
+__host__ __device__ __forceinline__ int colorSlot(int c) { return c < COLOR_SLOT_PADDED ? c * COLOR_SLOT_STRIDE : COLOR_SLOT_PADDED * COLOR_SLOT_STRIDE + (c - COLOR_SLOT_PADDED); }
+
+__device__ __forceinline__ int blockKeyedAlloc65(int* counter, int key, bool valid, bool fetch, bool slotted = false)
 {
 	__shared__ int s_cnt[65], s_base[65];
 	__syncthreads(); // a previous call's readers are done
@@ -253,8 +261,9 @@ __device__ __forceinline__ int blockKeyedAlloc65(int* counter, int key, bool val
 		const int c = s_cnt[threadIdx.x];
 		if (c > 0)
 		{
-			if (fetch) s_base[threadIdx.x] = atomicAdd(&counter[threadIdx.x], c);
-			else atomicAdd(&counter[threadIdx.x], c);
+			int* word = &counter[slotted ? colorSlot((int)threadIdx.x) : (int)threadIdx.x];
+			if (fetch) s_base[threadIdx.x] = atomicAdd(word, c);
+			else atomicAdd(word, c);
 		}
 	}
 	if (!fetch) return 0;

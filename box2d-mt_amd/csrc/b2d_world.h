@@ -524,7 +524,8 @@ __device__ __forceinline__ float4 b2dLoadAgent4(const float4* p)
 #define ARRIVE_CLASSIFY 5
 #define ARRIVE_TOI_FIRST 6
 #define ARRIVE_COLOR_CHECK 7
-#define ARRIVE_SITES 8
+#define ARRIVE_PAIRS 8
+#define ARRIVE_SITES 9
 // ONE thread per workgroup, every workgroup of the (one-dimensional) grid exactly once. True in the workgroup that arrives
 // last, with the sums of all workgroups' v0 / v1.
 __device__ __forceinline__ bool b2dTreeArrive(unsigned long long* tree, unsigned v0, unsigned v1, unsigned* t0, unsigned* t1)

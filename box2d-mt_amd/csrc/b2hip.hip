@@ -850,7 +850,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(si_bodies, nb); ENS(si_contacts, cc); ENS(si_level, cc); ENS(si_stack, nb); ENS(si_lastLevel, nb);
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
-	ENS(colorCount, cc + 2); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2); ENS(li_sorted, cc); ENS(li_ref, cc);
+	ENS(colorCount, cc + 2 + COLOR_SLOT_PADDED * COLOR_SLOT_STRIDE); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2 + COLOR_SLOT_PADDED * COLOR_SLOT_STRIDE); ENS(li_sorted, cc); ENS(li_ref, cc); // (colorSlot: the first 65 colour counters on a line each)
 	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, B2HIP_HAVE_VALIDATION_SOLVERS ? nb * 32 : 1); ENS(dfInbox, B2HIP_HAVE_VALIDATION_SOLVERS ? 2 * cc : 1); /* (mailbox tables of the test build's k_solve_mailbox: DF_RANKS = 32 slots per body) */ ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
@@ -6083,7 +6083,14 @@ int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
 	case 9: src = w->dbgVel.p; break;
 	case 10: src = w->dbgLi.p; elem = 4; break;
 	case 11: src = w->gridBar.p; elem = 4; break;
-	case 12: src = w->colorCount.p; elem = 4; break;
+	case 12:
+	{
+		// (the colour census: counter c at colorSlot(c) - the first 65 a 128-byte line apart)
+		if (first < 0 || count < 0 || first + count > COLOR_SLOT_PADDED) return setError(B2HIP_ERR_INVALID, "colour census: [0, 65)");
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		if (count > 0) HIP_TRY(hipMemcpy2D(out, sizeof(int), w->colorCount.p + colorSlot(first), COLOR_SLOT_STRIDE * sizeof(int), sizeof(int), (size_t)count, hipMemcpyDeviceToHost));
+		return 0;
+	}
 	case 13: src = w->bodyColorMask.p; elem = 8; break;
 	case 14: src = w->deg.p; elem = 4; break;
 	case 15: src = w->hubList.p; elem = 4; break;

@@ -4,6 +4,7 @@
 //   mode 0: nothing          mode 1: one non-returning atomicAdd on one word      mode 2: the same, returning (the value is used)
 //   mode 3: two-level arrival (slot b % 32, the completing workgroup goes on to the root: b2d_world.h)
 //   mode 4: one atomicAdd per WAVE on one word
+//   mode 5: one add per workgroup on word b % 32 of ONE 128-byte line     mode 6: on word b % 32 of 32 different lines
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -21,6 +22,8 @@ __global__ __launch_bounds__(256) void k_probe(const float4* in, float* out, int
 	if (mode == 4) { if ((threadIdx.x & 63) == 0) atomicAdd(word, 1); return; }
 	__syncthreads();
 	if (threadIdx.x != 0) return;
+	if (mode == 5) { atomicAdd(word + 64 + (blockIdx.x & 31), 1); return; }
+	if (mode == 6) { atomicAdd(word + 128 + 32 * (blockIdx.x & 31), 1); return; }
 	if (mode == 1) atomicAdd(word, 1);
 	else if (mode == 2) { const int k = atomicAdd(word, 1); if (k == 0x7fffffff) out[1] = 1.0f; }
 	else if (mode == 3)
@@ -46,22 +49,22 @@ int main()
 	float4* in; float* out; int* word; unsigned long long* tree;
 	CHECK(hipMalloc(&in, (size_t)n * sizeof(float4)));
 	CHECK(hipMalloc(&out, 64));
-	CHECK(hipMalloc(&word, 256));
+	CHECK(hipMalloc(&word, 8192));
 	CHECK(hipMalloc(&tree, 33 * 16 * 8));
 	CHECK(hipMemset(in, 0, (size_t)n * sizeof(float4)));
-	CHECK(hipMemset(word, 0, 256));
+	CHECK(hipMemset(word, 0, 8192));
 	CHECK(hipMemset(tree, 0, 33 * 16 * 8));
 	hipEvent_t a, b;
 	CHECK(hipEventCreate(&a));
 	CHECK(hipEventCreate(&b));
-	const char* names[5] = { "no atomic", "1 add / workgroup", "1 returning add / workgroup", "two-level arrival", "1 add / wave" };
+	const char* names[7] = { "no atomic", "1 add / workgroup", "1 returning add / workgroup", "two-level arrival", "1 add / wave", "32 words of one line", "32 words on 32 lines" };
 	printf("%-10s", "workgroups");
-	for (int m = 0; m < 5; ++m) printf(" %28s", names[m]);
+	for (int m = 0; m < 7; ++m) printf(" %28s", names[m]);
 	printf("   (us per launch, mean of 50; 64 MB streamed per launch)\n");
 	for (int grid : { 256, 512, 1024, 2048, 4096, 8192, 16384 })
 	{
 		printf("%-10d", grid);
-		for (int mode = 0; mode < 5; ++mode)
+		for (int mode = 0; mode < 7; ++mode)
 		{
 			for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(256), 0, 0, in, out, n, mode, word, tree);
 			CHECK(hipDeviceSynchronize());
