@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 	if (blockIdx.x == 0) colorCheckBegin(W);
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_BLOCKS + 1; i += gridDim.x * blockDim.x)
 	{
-		W.blkRows[i] = 0;
-		W.blkCursor[i] = 0;
+		W.blkRows[(size_t)i * BLK_SLOT] = 0;
+		W.blkCursor[(size_t)i * BLK_SLOT] = 0;
 		W.blkBodyCount[i] = 0;
 		W.blkBodyCursor[i] = 0;
 	}

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 	const int t = threadIdx.x;
 	const int nb = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS;
 	int total = 0, mx = 0;
-	const int rows = t < nb ? W.blkRows[t] : 0;
+	const int rows = t < nb ? W.blkRows[(size_t)t * BLK_SLOT] : 0;
 	const int rowStart = blockScan1024(rows, s_buf, &total, &mx);
 	if (t < nb) W.blkRowStart[t] = rowStart;
 	if (t == 0)
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256) void k_color_recheck_begin(DW W)
 	}
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_BLOCKS + 1; i += gridDim.x * blockDim.x)
 	{
-		W.blkRows[i] = 0;
-		W.blkCursor[i] = 0;
+		W.blkRows[(size_t)i * BLK_SLOT] = 0;
+		W.blkCursor[(size_t)i * BLK_SLOT] = 0;
 		W.blkBodyCount[i] = 0;
 		W.blkBodyCursor[i] = 0;
 	}

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	for (int i = threadIdx.x; i < MAX_BLOCKS; i += blockDim.x)
 	{
 		const int v = s_blkRows[i];
-		if (v) atomicAdd(&W.blkRows[i], v);
+		if (v) atomicAdd(&W.blkRows[(size_t)i * BLK_SLOT], v);
 	}
 	if (threadIdx.x == 0)
 	{
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 			if (valid && color == HUB_COLOR) owner = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS; // the segment behind the last block
 			const bool placed = valid && owner >= 0 && owner <= MAX_BLOCKS;
 			if (!placed) owner = 0;
-			const int slot = waveKeyedAllocOnce(W.blkCursor, owner, placed, 11); // (owner <= MAX_BLOCKS = 1024)
+			const int slot = waveKeyedAllocOnce(W.blkCursor, owner, placed, 11, BLK_SLOT); // (owner <= MAX_BLOCKS = 1024)
 			p = W.blkRowStart[owner] + slot;
 			if (placed) W.rowColor[p] = color;
 			else if (valid) p = -1;

@@ -218,7 +218,7 @@ __device__ __forceinline__ int waveKeyedAlloc(int* counter, int key, bool valid)
 // the group, and all those atomics are in flight together. waveKeyedAlloc pays one round trip per distinct key, one after
 // the other - k_color_fill hands rows to blocks in arrival order of the island's contact list, ~60 different blocks in a
 // wave of the 50 086-box pyramid: 99 us. `keyBits`: keys are below 1 << keyBits.
-__device__ __forceinline__ int waveKeyedAllocOnce(int* counter, int key, bool valid, int keyBits)
+__device__ __forceinline__ int waveKeyedAllocOnce(int* counter, int key, bool valid, int keyBits, int stride = 1)
 {
 	const int lane = waveLane();
 	unsigned long long peers = __ballot(valid);
@@ -230,7 +230,7 @@ __device__ __forceinline__ int waveKeyedAllocOnce(int* counter, int key, bool va
 	if (!valid) peers = 0ull;
 	const int leader = peers ? __ffsll((long long)peers) - 1 : lane;
 	int base = 0;
-	if (valid && lane == leader) base = atomicAdd(&counter[key], __popcll(peers));
+	if (valid && lane == leader) base = atomicAdd(&counter[(size_t)key * stride], __popcll(peers));
 	base = __shfl(base, leader);
 	return valid ? base + __popcll(peers & ((1ull << lane) - 1ull)) : 0;
 }

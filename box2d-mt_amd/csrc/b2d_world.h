@@ -82,6 +82,7 @@
 #define ROOT_PEN_SLOTS 5          // penetration maxima of the block solver's position iterations in flight (b2d_kernels_solve_blocks.h)
 #define BLOCK_MAX_BODIES 1024    // home bodies a block can hold (LDS rows)
 #define MAX_BLOCKS 1024          // blocks of one partition
+#define BLK_SLOT 32              // ints between two blocks' counters in blkRows / blkCursor: a 128-byte line each (atomics on words of one line queue)
 #define BLOCK_TARGET_DEG 1500    // a block is closed when the contact degrees of its bodies add up to this (rows ~ half of it)
 
 struct ContactArrays
