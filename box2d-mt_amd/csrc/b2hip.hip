@@ -1412,7 +1412,10 @@ static int userFilterPairs(b2hip_world* w, const int2* proxies)
 // b2World::FindNewContacts. `sync` = the host may block on the pair count to pick the sort path
 // (top-of-step call after fixtures were added); otherwise the small path runs optimistically and
 // the caller checks Counters::nPairs at the end-of-step read-back.
-static int runSortAndCreate(b2hip_world* w, bool largePath)
+// knownPairs: the candidate pairs in the buffer where the host has just read the count (-1: unknown) - the radix passes then
+// launch and scan for that many tiles, not for the buffer's capacity (a rank of a sharded world keeps buffers of the whole
+// world's size: eleven scans per step took the three-kernel form for 25 000 pairs)
+static int runSortAndCreate(b2hip_world* w, bool largePath, long long knownPairs = -1)
 {
 	DW& d = w->dw;
 	const uint64_t* sortedKeys = d.pairKey;
@@ -1428,7 +1431,8 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		uint64_t* kout = d.pairKey2;
 		int2* vin = d.pairProxy;
 		int2* vout = d.pairProxy2;
-		const int tilesCap = d.capPairs / RADIX_TILE + 1;
+		int tilesCap = d.capPairs / RADIX_TILE + 1;
+		if (knownPairs >= 0) tilesCap = (int)std::min<long long>(tilesCap, knownPairs / RADIX_TILE + 2);
 		// (the length of the histogram matrix depends on the pair count only: once per sort, not once per pass)
 		LAUNCH(w, k_radix_count, 1, 1, &d.st->c.nPairs, 0, w->consts.p + 2);
 		for (size_t p = 0; p < shifts.size(); ++p)
@@ -1443,7 +1447,8 @@ static int runSortAndCreate(b2hip_world* w, bool largePath)
 		sortedProxies = vin;
 		LAUNCH(w, k_pairs_sorted_first, gridFor(d.capPairs), 256, d, sortedKeys, w->consts.p + 3);
 		if (hasFilter(w)) { int rcf = userFilterPairs(w, sortedProxies); if (rcf) return rcf; }
-		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanCtx, w->consts.p + 3, d.capPairs);
+		deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanCtx, w->consts.p + 3,
+			knownPairs >= 0 ? (int)std::min<long long>(d.capPairs, knownPairs + 2) : d.capPairs);
 		LAUNCH(w, k_pairs_sorted_total, 1, 1, d, w->consts.p + 3);
 	}
 	else
@@ -1521,7 +1526,7 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 		int rc = spExchangePairs(w, &total, &straddle);
 		if (rc) return rc;
 		large = total > COUNT_RANK_MAX;
-		rc = runSortAndCreate(w, large);
+		rc = runSortAndCreate(w, large, total);
 		if (rc) return rc;
 		if (straddle == 0)
 		{
@@ -1549,7 +1554,7 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 		if (large) w->pairsLargeSticky = 16;
 		else if (w->pairsLargeSticky > 0) w->pairsLargeSticky -= 1;
 	}
-	return runSortAndCreate(w, large);
+	return runSortAndCreate(w, large, sync ? (long long)w->h_dstate->c.nPairs : -1);
 }
 
 static int phaseCollide(b2hip_world* w)
@@ -2264,7 +2269,7 @@ static int phaseToiSync(b2hip_world* w)
 			continue;
 		}
 		if (pass == 1 || w->h_dstate->c.nMoves == 0 || w->h_dstate->c.nPairs <= COUNT_RANK_MAX) break;
-		rc = runSortAndCreate(w, true);
+		rc = runSortAndCreate(w, true, w->h_dstate->c.nPairs);
 		if (rc) return rc;
 	}
 	w->last.nToiList = w->h_dstate->c.nToiList;
@@ -4438,7 +4443,7 @@ static int stepEndImpl(b2hip_world* w)
 				if (rc) return rc;
 				rc = findNewContacts(w, true);
 			}
-			else rc = runSortAndCreate(w, true);
+			else rc = runSortAndCreate(w, true, w->h_dstate->c.nPairs);
 			if (rc) return rc;
 			if (redoToi)
 			{
