@@ -121,12 +121,27 @@ class SpatialWorld:
         self.connected = False
         self.gathers = 0
         self.gather_bytes = 0
+        self._group = None
         if dist is not None and self.size > 1 and dist.get_backend() == "nccl":
+            import torch
             s = ShardedWorld.__new__(ShardedWorld)  # (only for its RCCL hand-shake: rank 0's id broadcast, every rank connects)
             s.w, s.L, s.dist, s.device, s.rank, s.size, s.connected = world, L, dist, device, self.rank, self.size, False
-            s.connect_rccl()
-            self.connected = True
-        else:
+            why = ""
+            try:
+                s.connect_rccl()
+            except Exception as e:  # noqa: BLE001
+                why = str(e)
+            # (the library's own communicator cannot be had - librccl not found ... - on every rank alike: the exchange goes
+            # through an all-gather of host memory over a gloo group instead; a rank on its own with the problem is an error)
+            ok = torch.tensor([0 if why else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+            if int(ok.item()) == self.size:
+                self.connected = True
+            elif int(ok.item()) == 0:
+                self._group = dist.new_group(backend="gloo")
+            else:
+                raise RuntimeError("b2hip_shard_connect failed on some ranks only: %s" % why)
+        if not self.connected:
             self._cb = GATHER_FN(self._gather)
             rc = L.b2hip_set_shard_gather(world.p, C.cast(self._cb, C.c_void_p), None)
             if rc < 0:
@@ -151,7 +166,7 @@ class SpatialWorld:
             if self.dist is None or self.size == 1:
                 dst[:nbytes] = src
             else:
-                self.dist.all_gather_into_tensor(dst, src)
+                self.dist.all_gather_into_tensor(dst, src, group=self._group)
             return 0
         except Exception:  # noqa: BLE001 (reported by the library as a failed collective)
             return 1
