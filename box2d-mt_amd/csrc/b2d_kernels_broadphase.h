@@ -765,7 +765,9 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 			uint32_t f = W.b_flags[i];
 			if (clearForces && houseKeeping) W.b_force[i] = make_float4(0, 0, 0, 0);
 			// b2ClearBodySolveTOIFlags (b2World.cpp:239-259, k_toi_clear): sweeps go back to alpha0 = 0 for the next step
-			if (toiEvents && houseKeeping) W.b_pos0[i].w = 0.0f;
+			// (only where an event advanced the sweep: a 4-byte store into every 16-byte element is a read-modify-write of every
+			// line at the memory - 37 us of this kernel's 140 on a million bodies, against 16 MB read)
+			if (toiEvents && houseKeeping && W.b_pos0[i].w != 0.0f) W.b_pos0[i].w = 0.0f;
 			float4 xf = W.b_xf[i], p = W.b_pos[i], v = W.b_vel[i];
 			float* o = s_out + tid * 10; // (filled in every mode: cheaper than a second predicate around ten LDS stores)
 			o[0] = xf.x;
@@ -816,53 +818,54 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 			__syncthreads(); // (s_chg serves the row comparison next)
 		}
 		if (!storeRows) continue; // (uniform over the workgroup: every lane leaves the tile before its barriers)
-		s_chg[tid] = 0;
-		__syncthreads();
 		const int cnt = (n - base < 256 ? n - base : 256) * 10; // floats of this tile; base * 40 bytes is 16-byte aligned
 		float* dst = out + (size_t)base * 10;
 		float* sh = shadow + (size_t)base * 10;
 		bool whole = true;
 		if (rowMode == 2)
 		{
-			// which rows differ from what the host holds: the shadow tile is read as it is laid out (16 bytes per lane), a chunk
-			// that differs marks the one or two rows it overlaps
-			for (int q = tid; q < cnt / 4; q += 256)
+			// does this lane's row differ from what the host holds? Its own ten words (still in its part of s_out) against its
+			// shadow row, 8 bytes at a time - no pass through LDS, no barrier but the one that counts the tile's changed rows
+			bool changed = false;
+			if (i < n)
 			{
-				const float4 a = ((const float4*)s_out)[q], b = ((const float4*)sh)[q];
-				if (__float_as_uint(a.x) != __float_as_uint(b.x) || __float_as_uint(a.y) != __float_as_uint(b.y) ||
-					__float_as_uint(a.z) != __float_as_uint(b.z) || __float_as_uint(a.w) != __float_as_uint(b.w))
+				const float2* o2 = (const float2*)(s_out + tid * 10);
+				const float2* h2 = (const float2*)(shadow + (size_t)i * 10);
+#pragma unroll
+				for (int c = 0; c < 5; ++c)
 				{
-					s_chg[(4 * q) / 10] = 1;
-					s_chg[(4 * q + 3) / 10] = 1;
+					const float2 a = o2[c], b = h2[c];
+					changed = changed || __float_as_uint(a.x) != __float_as_uint(b.x) || __float_as_uint(a.y) != __float_as_uint(b.y);
 				}
 			}
-			for (int q = (cnt / 4) * 4 + tid; q < cnt; q += 256) if (__float_as_uint(s_out[q]) != __float_as_uint(sh[q])) s_chg[q / 10] = 1;
-			__syncthreads();
-			const int nChanged = __syncthreads_count(s_chg[tid]);
-			if (nChanged == 0) continue; // (uniform; the next tile's first barrier stands between these reads and its writes)
+			const int nChanged = __syncthreads_count(changed ? 1 : 0);
+			if (nChanged == 0) continue; // (uniform)
 			whole = nChanged > END_STEP_TILE_ROWS;
-			if (!whole && s_chg[tid])
+			if (!whole)
 			{
-				// a few rows of the tile: each on its own (40 bytes, 8-byte aligned)
-				const float2* o2 = (const float2*)(s_out + tid * 10);
-				float2* d2 = (float2*)(out + (size_t)i * 10);
-				float2* h2 = (float2*)(shadow + (size_t)i * 10);
-				for (int c = 0; c < 5; ++c) { const float2 v = o2[c]; d2[c] = v; h2[c] = v; }
+				if (changed)
+				{
+					// a few rows of the tile: each on its own (40 bytes, 8-byte aligned)
+					const float2* o2 = (const float2*)(s_out + tid * 10);
+					float2* d2 = (float2*)(out + (size_t)i * 10);
+					float2* h2 = (float2*)(shadow + (size_t)i * 10);
+					for (int c = 0; c < 5; ++c) { const float2 v = o2[c]; d2[c] = v; h2[c] = v; }
+				}
+				continue; // (uniform; every lane read its own part of s_out only)
 			}
 		}
-		if (whole)
+		else __syncthreads();
+		// the whole tile, as it lies in LDS: contiguous 16-byte stores (the barrier above made every lane's row visible)
+		for (int q = tid; q < cnt / 4; q += 256)
 		{
-			for (int q = tid; q < cnt / 4; q += 256)
-			{
-				const float4 v = ((const float4*)s_out)[q];
-				((float4*)dst)[q] = v;
-				if (rowMode != 0) ((float4*)sh)[q] = v;
-			}
-			for (int q = (cnt / 4) * 4 + tid; q < cnt; q += 256)
-			{
-				dst[q] = s_out[q];
-				if (rowMode != 0) sh[q] = s_out[q];
-			}
+			const float4 v = ((const float4*)s_out)[q];
+			((float4*)dst)[q] = v;
+			if (rowMode != 0) ((float4*)sh)[q] = v;
+		}
+		for (int q = (cnt / 4) * 4 + tid; q < cnt; q += 256)
+		{
+			dst[q] = s_out[q];
+			if (rowMode != 0) sh[q] = s_out[q];
 		}
 		__syncthreads();
 	}
