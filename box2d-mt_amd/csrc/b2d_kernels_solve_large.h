@@ -175,8 +175,9 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	uint32_t usedLo = 0u, usedHi = 0u;
 	__shared__ int s_blkRows[MAX_BLOCKS];
 	__shared__ int s_sums[2];
+	__shared__ int s_compact[2]; // [0] rows of the compaction class in this round, [1] their first place in the list
 	for (int i = threadIdx.x; i < MAX_BLOCKS; i += blockDim.x) s_blkRows[i] = 0;
-	if (threadIdx.x < 2) s_sums[threadIdx.x] = 0;
+	if (threadIdx.x < 2) { s_sums[threadIdx.x] = 0; s_compact[threadIdx.x] = 0; }
 	__syncthreads();
 	// (1) every touching contact that owns a colour - large island or not, asleep or not - reserves it on its bodies.
 	// A contact that stopped touching gives its colour back: reservations of idle neighbours (a pyramid box has two of
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		const int s = base + threadIdx.x;
 		const bool valid = s < n;
 		int col = -1;
+		int compactRank = -1;
 		if (valid)
 		{
 			const int ci = W.li_contacts[s];
@@ -259,16 +261,30 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			{
 				if (col + 1 > maxColor) maxColor = col + 1;
 				if (col < 32) usedLo |= 1u << col; else usedHi |= 1u << (col - 32);
-				if (col == S->c.compactClass && col > 0)
-				{
-					// candidates of this step's compaction class (k_color_small moves them down if a lower colour is free)
-					const int u = atomicAdd(&S->c.nCompact, 1);
-					if (u < COLOR_SMALL_MAX) W.compactList[u] = s;
-				}
+				// candidates of this step's compaction class (k_color_small moves them down if a lower colour is free): listed below
+				compactRank = (col == S->c.compactClass && col > 0) ? atomicAdd(&s_compact[0], 1) : -1;
 			}
 			W.li_color[s] = col;
 		}
 		(void)blockKeyedAlloc65(W.colorCount, col < 0 ? 0 : col, valid && col >= 0, false, true);
+		// The class under compaction takes its places in the list with ONE atomic per workgroup and round. (One per row - the
+		// value is needed - was a queue of 7 000 returning atomics on one word for Pyramid 316, 18 000 for the Tumbler: each
+		// workgroup's round waited 60 - 85 us in it. The list holds COLOR_SMALL_MAX rows; once the count is past that the
+		// class is not compacted this step - k_color_small - and only "more than that" matters: the adds stop.)
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			const int cnt = s_compact[0];
+			s_compact[1] = COLOR_SMALL_MAX;
+			if (cnt > 0 && __hip_atomic_load(&S->c.nCompact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= COLOR_SMALL_MAX) s_compact[1] = atomicAdd(&S->c.nCompact, cnt);
+			s_compact[0] = 0;
+		}
+		__syncthreads();
+		if (compactRank >= 0)
+		{
+			const int u = s_compact[1] + compactRank;
+			if (u < COLOR_SMALL_MAX) W.compactList[u] = s;
+		}
 	}
 	// needRecolor bit0: two constraints on one body share a colour -> colour everything again;
 	// nUncolored: constraints without a colour yet -> incremental rounds on top of the existing masks
