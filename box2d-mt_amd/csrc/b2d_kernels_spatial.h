@@ -169,9 +169,19 @@ __global__ __launch_bounds__(256) void k_sp_mark_sent(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, size_t strideWords, int capBodies, int proxyWords)
+// markSent: the lean exchange's k_sp_mark_sent in the same launch (this rank's OWN bodies; the records below are other ranks').
+__global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, size_t strideWords, int capBodies, int proxyWords, int markSent)
 {
 	b2dPhaseStamp(W);
+	if (markSent)
+	{
+		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+		{
+			const uint32_t f = W.b_flags[i];
+			if ((f & BF_TYPE_MASK) == BT_STATIC || W.b_owner[i] != (uint8_t)W.shardRank) continue;
+			W.spAwake[i] = (f & BF_AWAKE) ? 1 : 0;
+		}
+	}
 	for (int r = 0; r < W.shardCount; ++r)
 	{
 		if (r == W.shardRank) continue;

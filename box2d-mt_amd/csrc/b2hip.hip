@@ -5533,8 +5533,8 @@ static int spExchangeState(b2hip_world* w, int mode)
 			spCapDecay(&w->spRowCap, &w->spIdle[0], needB, 1024);
 			spCapDecay(&w->spProxyCap, &w->spIdle[1], needP, 4096);
 		}
-		LAUNCH(w, k_sp_import_state, gridFor(std::max(capB, capP)), 256, d, (const int*)w->spRecv.p, words, capB, proxyWords);
-		if (!w->spFullRows) LAUNCH(w, k_sp_mark_sent, gridFor(d.nBodies), 256, d);
+		// (+ what was sent is marked as sent, now that the exchange has gone through: the lean form's k_sp_mark_sent, same launch)
+		LAUNCH(w, k_sp_import_state, gridFor(std::max(std::max(capB, capP), w->spFullRows ? 1 : d.nBodies)), 256, d, (const int*)w->spRecv.p, words, capB, proxyWords, w->spFullRows ? 0 : 1);
 		if (created > 0)
 		{
 			rc = ensureCapacity(w, (size_t)w->spContactsBeforeToi + (size_t)created);
