@@ -170,9 +170,12 @@ __global__ __launch_bounds__(256) void k_sp_mark_sent(DW W)
 }
 
 // markSent: the lean exchange's k_sp_mark_sent in the same launch (this rank's OWN bodies; the records below are other ranks').
-__global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, size_t strideWords, int capBodies, int proxyWords, int markSent)
+// sendHdr: the header of this rank's send slab, wiped for the next exchange's export (the all-gather has read it: it ran
+// before this launch on the stream) - a fill launch less per exchange.
+__global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, size_t strideWords, int capBodies, int proxyWords, int markSent, int* sendHdr)
 {
 	b2dPhaseStamp(W);
+	if (blockIdx.x == 0 && threadIdx.x < SP_HEADER_WORDS) sendHdr[threadIdx.x] = 0;
 	if (markSent)
 	{
 		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
@@ -285,9 +288,10 @@ __global__ __launch_bounds__(256) void k_sp_import_pairs(DW W, const int* in, si
 	}
 }
 // (a launch of its own behind the import: every workgroup of the import reads the old count)
-__global__ void k_sp_import_pairs_commit(DW W, const int* in, size_t strideWords, int capPairsSlab)
+__global__ void k_sp_import_pairs_commit(DW W, const int* in, size_t strideWords, int capPairsSlab, int* sendHdr)
 {
 	DState* S = W.st;
+	for (int k = 0; k < SP_HEADER_WORDS; ++k) sendHdr[k] = 0; // (for the next exchange's export: k_sp_import_state)
 	int at = S->c.nPairs;
 	for (int r = 0; r < W.shardCount; ++r)
 		if (r != W.shardRank) at += in[(size_t)r * strideWords + 2] < capPairsSlab ? in[(size_t)r * strideWords + 2] : capPairsSlab;
@@ -617,8 +621,9 @@ __global__ __launch_bounds__(256) void k_sp_import_content(DW W, const int* in, 
 #define SP_TAIL_WORDS 6        // alpha bits, event key hi, lo, proxy lo, proxy hi (key order), index in the creating rank's tail
 #define SP_TAIL_MAX 4096       // contacts all ranks together may create inside one TOI phase
 
-__global__ __launch_bounds__(256) void k_sp_export_tail(DW W, int* out, int* hdr, int base, int capTail, int chains)
+__global__ __launch_bounds__(256) void k_sp_export_tail(DW W, int* out, int* hdr, int base, int capTail, int chains, int* virtCount)
 {
+	if (blockIdx.x == 0 && threadIdx.x == 0) *virtCount = 0; // (k_sp_tail_pairs counts into it, behind the all-gather)
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];

@@ -248,6 +248,7 @@ struct b2hip_world
 	b2hip_all_gather_fn gatherFn = nullptr; // the caller's all-gather (gloo, tests); null with a connected RCCL communicator
 	void* gatherUser = nullptr;
 	int* spHost = nullptr;          // pinned staging of the caller's all-gather
+	const int* spSendWiped = nullptr; // == spSend.p: its header has been wiped by the last import launch (spPrepareSend)
 	int* spHdrHost = nullptr;       // pinned: [0] sequence number, [1] extra word, [2..] the headers of all ranks' slabs (spReadHeaders)
 	int* spHdrDev = nullptr;
 	int spHdrSeq = 0;
@@ -5380,6 +5381,16 @@ static int spEnsureSlabs(b2hip_world* w, size_t words)
 	return w->spRecv.ensure(words * (size_t)w->dw.shardCount, w->stream, false, false);
 }
 
+// The header of the send slab is zero before an export counts into it: wiped by the import kernel of the exchange before
+// (spSendWiped: by which launch, for which buffer), by a fill otherwise (first exchange, a slab that grew, an exchange that
+// was repeated or left before its import).
+static int spPrepareSend(b2hip_world* w)
+{
+	if (w->spSendWiped != w->spSend.p) HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
+	w->spSendWiped = nullptr;
+	return 0;
+}
+
 // the headers of all ranks' slabs, on the host (one small copy + synchronisation)
 static int spReadHeaders(b2hip_world* w, size_t strideWords, int (*hdr)[SP_HEADER_WORDS], const int* extraDev = nullptr, int* extra = nullptr)
 {
@@ -5446,14 +5457,15 @@ static int spExchangeState(b2hip_world* w, int mode)
 		const size_t words = tailAt + (size_t)capT * SP_TAIL_WORDS;
 		int rc = spEnsureSlabs(w, words);
 		if (rc) return rc;
-		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
+		rc = spPrepareSend(w);
+		if (rc) return rc;
 		if (mode == 0 || w->toiSnapshotTaken)
 			LAUNCH(w, k_sp_export_state, gridFor(std::max(d.nBodies, d.capMoves)), 256, d, w->spSend.p, mode, capB, capP);
 		if (mode == 1)
 		{
 			// the contacts this rank's TOI phase created (behind the array all ranks shared when the phase began): their
 			// descriptors, for the merge of the tails; header words 5 and 6 = how many, how many of them with another rank's body
-			LAUNCH(w, k_sp_export_tail, gridFor(capT), 256, d, w->spSend.p + tailAt, w->spSend.p, w->spContactsBeforeToi, capT, w->toiChains ? 1 : 0);
+			LAUNCH(w, k_sp_export_tail, gridFor(capT), 256, d, w->spSend.p + tailAt, w->spSend.p, w->spContactsBeforeToi, capT, w->toiChains ? 1 : 0, (int*)(w->spVirt.p + SP_TAIL_MAX));
 		}
 		rc = spAllGather(w, words);
 		if (rc) return rc;
@@ -5462,7 +5474,7 @@ static int spExchangeState(b2hip_world* w, int mode)
 		{
 			// what no rank could see by itself: contacts created over an ownership boundary, proxies of different ranks' events
 			// that came to overlap (k_sp_tail_pairs: every rank finds the same list in the same records)
-			HIP_TRY(hipMemsetAsync(w->spVirt.p + SP_TAIL_MAX, 0, sizeof(int), w->stream)); // (the count lives behind the pairs)
+			// (the count lives behind the pairs; k_sp_export_tail has wiped it)
 			LAUNCH(w, k_sp_tail_pairs, gridFor(std::max(capP * ranks, capT)), 256, d, (const int*)w->spRecv.p, words, tailAt, capB, capP, w->spVirt.p, (int*)(w->spVirt.p + SP_TAIL_MAX));
 			int nVirt = 0;
 			int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
@@ -5534,7 +5546,8 @@ static int spExchangeState(b2hip_world* w, int mode)
 			spCapDecay(&w->spProxyCap, &w->spIdle[1], needP, 4096);
 		}
 		// (+ what was sent is marked as sent, now that the exchange has gone through: the lean form's k_sp_mark_sent, same launch)
-		LAUNCH(w, k_sp_import_state, gridFor(std::max(std::max(capB, capP), w->spFullRows ? 1 : d.nBodies)), 256, d, (const int*)w->spRecv.p, words, capB, proxyWords, w->spFullRows ? 0 : 1);
+		LAUNCH(w, k_sp_import_state, gridFor(std::max(std::max(capB, capP), w->spFullRows ? 1 : d.nBodies)), 256, d, (const int*)w->spRecv.p, words, capB, proxyWords, w->spFullRows ? 0 : 1, w->spSend.p);
+		w->spSendWiped = w->spSend.p;
 		if (created > 0)
 		{
 			rc = ensureCapacity(w, (size_t)w->spContactsBeforeToi + (size_t)created);
@@ -5568,7 +5581,8 @@ static int spExchangePairs(b2hip_world* w, long long* totalPairs, int* straddlin
 		const size_t words = SP_HEADER_WORDS + (size_t)w->spPairCap * SP_PAIR_WORDS;
 		int rc = spEnsureSlabs(w, words);
 		if (rc) return rc;
-		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
+		rc = spPrepareSend(w);
+		if (rc) return rc;
 		LAUNCH(w, k_sp_export_pairs, gridFor(w->spPairCap), 256, d, w->spSend.p, w->spPairCap);
 		rc = spAllGather(w, words);
 		if (rc) return rc;
@@ -5602,7 +5616,8 @@ static int spExchangePairs(b2hip_world* w, long long* totalPairs, int* straddlin
 		const int capNow = w->spPairCap;
 		spCapDecay(&w->spPairCap, &w->spIdle[5], most, 2048);
 		LAUNCH(w, k_sp_import_pairs, gridFor(capNow), 256, w->dw, (const int*)w->spRecv.p, words, capNow);
-		LAUNCH(w, k_sp_import_pairs_commit, 1, 1, w->dw, (const int*)w->spRecv.p, words, capNow);
+		LAUNCH(w, k_sp_import_pairs_commit, 1, 1, w->dw, (const int*)w->spRecv.p, words, capNow, w->spSend.p);
+		w->spSendWiped = w->spSend.p;
 		return 0;
 	}
 	return setError(B2HIP_ERR_CAPACITY, "the pair exchange of a spatially sharded world did not fit");
@@ -5665,7 +5680,8 @@ static int spResolve(b2hip_world* w, int nVirt)
 		const size_t words = SP_HEADER_WORDS + (size_t)capC * SP_CONTENT_WORDS + (size_t)capJ * SP_JOINT_WORDS + (size_t)capM * SP_BODY_WORDS;
 		rc = spEnsureSlabs(w, words);
 		if (rc) return rc;
-		HIP_TRY(hipMemsetAsync(w->spSend.p, 0, SP_HEADER_WORDS * sizeof(int), w->stream));
+		rc = spPrepareSend(w);
+		if (rc) return rc;
 		LAUNCH(w, k_sp_export_content, gridFor(std::max(std::max(d.capContacts, d.nJoints), d.nBodies)), 256, d, w->spSend.p, capC, capJ);
 		rc = spAllGather(w, words);
 		if (rc) return rc;
