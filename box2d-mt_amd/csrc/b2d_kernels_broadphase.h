@@ -259,15 +259,25 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
-	int pAhead = waveId < nm ? W.moveBuf[waveId] : -1;
+	// The search is a chain of dependent loads per moved proxy - proxy, its body and box, cell headers, items, and the large
+	// proxies with their boxes - and the kernel's time is that chain times the proxies a wave goes through. So: the large
+	// proxies (walls, the ground: a handful) are fetched ONCE per wave, lane t keeping the t-th; the proxy of the round after
+	// next and the body and box of the next round are asked for while this round works.
+	const int largeQ = lane < nLarge ? W.largeProxies[lane] : -1;
+	const float4 largeFat = largeQ >= 0 ? W.p_fat[largeQ] : make_float4(0, 0, 0, 0);
+	int pNext = waveId < nm ? W.moveBuf[waveId] : -1;
+	int pAhead = waveId + nWaves < nm ? W.moveBuf[waveId + nWaves] : -1;
+	int bodyNext = W.p_body[pNext < 0 ? 0 : pNext];
+	float4 fatNext = W.p_fat[pNext < 0 ? 0 : pNext];
 	for (int k = waveId; k < nm; k += nWaves)
 	{
-		// (the next round's proxy is asked for now; this round's body and box in one go)
-		const int p = pAhead;
-		pAhead = k + nWaves < nm ? W.moveBuf[k + nWaves] : -1;
-		const int pSafe = p < 0 ? 0 : p;
-		const int bodyOfP = W.p_body[pSafe];
-		const float4 a4 = W.p_fat[pSafe];
+		const int p = pNext;
+		const int bodyOfP = bodyNext;
+		const float4 a4 = fatNext;
+		pNext = pAhead;
+		pAhead = k + 2 * nWaves < nm ? W.moveBuf[k + 2 * nWaves] : -1;
+		bodyNext = W.p_body[pNext < 0 ? 0 : pNext];
+		fatNext = W.p_fat[pNext < 0 ? 0 : pNext];
 		if (p < 0 || bodyOfP < 0) continue;
 		// (a spatially sharded world: every rank searches for the proxies ITS bodies moved; b2d_kernels_spatial.h, E2)
 		if (W.spatial && (W.b_flags[bodyOfP] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyOfP] != (uint8_t)W.shardRank) continue;
@@ -327,7 +337,14 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 				if (q != p && b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, q);
 			}
 		}
-		for (int t = lane; t < nLarge; t += 64)
+		if (largeQ >= 0)
+		{
+			AABB bq;
+			bq.lo = v2(largeFat.x, largeFat.y);
+			bq.hi = v2(largeFat.z, largeFat.w);
+			if (b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, largeQ);
+		}
+		for (int t = 64 + lane; t < nLarge; t += 64) // (more than a wave holds: the rest as before)
 		{
 			const int q = W.largeProxies[t];
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
@@ -353,15 +370,25 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
-	int pAhead = waveId < nm ? W.moveBuf[waveId] : -1;
+	// The search is a chain of dependent loads per moved proxy - proxy, its body and box, cell headers, items, and the large
+	// proxies with their boxes - and the kernel's time is that chain times the proxies a wave goes through. So: the large
+	// proxies (walls, the ground: a handful) are fetched ONCE per wave, lane t keeping the t-th; the proxy of the round after
+	// next and the body and box of the next round are asked for while this round works.
+	const int largeQ = lane < nLarge ? W.largeProxies[lane] : -1;
+	const float4 largeFat = largeQ >= 0 ? W.p_fat[largeQ] : make_float4(0, 0, 0, 0);
+	int pNext = waveId < nm ? W.moveBuf[waveId] : -1;
+	int pAhead = waveId + nWaves < nm ? W.moveBuf[waveId + nWaves] : -1;
+	int bodyNext = W.p_body[pNext < 0 ? 0 : pNext];
+	float4 fatNext = W.p_fat[pNext < 0 ? 0 : pNext];
 	for (int k = waveId; k < nm; k += nWaves)
 	{
-		// (the next round's proxy is asked for now; this round's body and box in one go)
-		const int p = pAhead;
-		pAhead = k + nWaves < nm ? W.moveBuf[k + nWaves] : -1;
-		const int pSafe = p < 0 ? 0 : p;
-		const int bodyOfP = W.p_body[pSafe];
-		const float4 a4 = W.p_fat[pSafe];
+		const int p = pNext;
+		const int bodyOfP = bodyNext;
+		const float4 a4 = fatNext;
+		pNext = pAhead;
+		pAhead = k + 2 * nWaves < nm ? W.moveBuf[k + 2 * nWaves] : -1;
+		bodyNext = W.p_body[pNext < 0 ? 0 : pNext];
+		fatNext = W.p_fat[pNext < 0 ? 0 : pNext];
 		if (p < 0 || bodyOfP < 0) continue;
 		// (a spatially sharded world: every rank searches for the proxies ITS bodies moved; b2d_kernels_spatial.h, E2)
 		if (W.spatial && (W.b_flags[bodyOfP] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyOfP] != (uint8_t)W.shardRank) continue;
@@ -429,7 +456,14 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 				if (q != p && b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, q);
 			}
 		}
-		for (int t = lane; t < nLarge; t += 64)
+		if (largeQ >= 0)
+		{
+			AABB bq;
+			bq.lo = v2(largeFat.x, largeFat.y);
+			bq.hi = v2(largeFat.z, largeFat.w);
+			if (b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, largeQ);
+		}
+		for (int t = 64 + lane; t < nLarge; t += 64) // (more than a wave holds: the rest as before)
 		{
 			const int q = W.largeProxies[t];
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
