@@ -246,6 +246,40 @@ __device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q
 	}
 }
 
+// The candidates whose boxes overlap are put aside - (proxy, candidate) in a list per wave in LDS - and go through the filters
+// (tryEmitPair: keys, hash probe of the existing contacts, body and fixture rules, shape types - a chain of a dozen gathers)
+// 64 at a time with every lane busy, instead of where they turn up: a dense window is five or six rounds of 64 candidates
+// with a few hits each, a sparse scene has a hit every second proxy - the chain ran once per round / proxy for those few
+// lanes (Tumbler: pair update 1.50 -> 1.17 ms with the list per window; then per wave across proxies).
+struct PairHits
+{
+	int2* list; // [64] of this wave
+	int n;
+};
+__device__ __forceinline__ void pairHitsFlush(const DW& W, DState* S, PairHits& h, int lane)
+{
+	if (h.n == 0) return;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	if (lane < h.n)
+	{
+		const int2 pq = h.list[lane];
+		tryEmitPair(W, S, pq.x, pq.y);
+	}
+	__builtin_amdgcn_wave_barrier(); // (the list is written again)
+	h.n = 0;
+}
+__device__ __forceinline__ void pairHitsAdd(const DW& W, DState* S, PairHits& h, int lane, bool hit, int p, int q)
+{
+	const unsigned long long hm = __ballot(hit);
+	if (hm == 0ull) return;
+	const int more = (int)__popcll(hm);
+	if (h.n + more > 64) pairHitsFlush(W, S, h, lane);
+	if (hit) h.list[h.n + (int)__popcll(hm & ((1ull << lane) - 1ull))] = make_int2(p, q);
+	h.n += more;
+}
+
 // One WAVE per moved SMALL proxy. The candidates of its 3x3 cell neighbourhood are flattened into one
 // index space so that 64 candidates are fetched and tested at once (the per-candidate chain
 // item -> fat AABB -> filters -> hash probe is then paid once per wave, not once per candidate).
@@ -259,6 +293,10 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
+	__shared__ int2 s_hits[4][64];
+	PairHits hits;
+	hits.list = s_hits[threadIdx.x >> 6];
+	hits.n = 0;
 	// The search is a chain of dependent loads per moved proxy - proxy, its body and box, cell headers, items, and the large
 	// proxies with their boxes - and the kernel's time is that chain times the proxies a wave goes through. So: the large
 	// proxies (walls, the ground: a handful) are fetched ONCE per wave, lane t keeping the t-th; the proxy of the round after
@@ -327,22 +365,24 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 				const int ec = ecs[c], cc = ccs[c], sc = scs[c];
 				if (valid && idx >= ec && idx < ec + cc) t = sc + (idx - ec);
 			}
+			bool hit = false;
+			int q = -1;
 			if (t >= 0)
 			{
-				const int q = W.gridItems[t];
+				q = W.gridItems[t];
 				const float4 fq = W.gridFat[t];
 				AABB bq;
 				bq.lo = v2(fq.x, fq.y);
 				bq.hi = v2(fq.z, fq.w);
-				if (q != p && b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, q);
+				hit = q != p && b2dAabbOverlap(a, bq);
 			}
+			pairHitsAdd(W, S, hits, lane, hit, p, q);
 		}
-		if (largeQ >= 0)
 		{
 			AABB bq;
 			bq.lo = v2(largeFat.x, largeFat.y);
 			bq.hi = v2(largeFat.z, largeFat.w);
-			if (b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, largeQ);
+			pairHitsAdd(W, S, hits, lane, largeQ >= 0 && b2dAabbOverlap(a, bq), p, largeQ);
 		}
 		for (int t = 64 + lane; t < nLarge; t += 64) // (more than a wave holds: the rest as before)
 		{
@@ -350,6 +390,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
+	pairHitsFlush(W, S, hits, lane);
 	// (the candidate census for the host's choice of the cell: one atomic per wave on the 32 words of ONE line was 8 192
 	// atomics at the end of the kernel, ~5 ns each - carried by the arrival of the workgroups instead, b2d_world.h)
 	b2dBlockTreeAdd2(W, ARRIVE_PAIRS, &S->c.candRounds[0], lane == 0 ? rounds : 0, &S->c.candRounds[1], 0, (unsigned)W.capMoves <= (TREE_SUM_MAX >> 3));
@@ -370,6 +411,10 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 	const int waveId = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
+	__shared__ int2 s_hits[4][64];
+	PairHits hits;
+	hits.list = s_hits[threadIdx.x >> 6];
+	hits.n = 0;
 	// The search is a chain of dependent loads per moved proxy - proxy, its body and box, cell headers, items, and the large
 	// proxies with their boxes - and the kernel's time is that chain times the proxies a wave goes through. So: the large
 	// proxies (walls, the ground: a handful) are fetched ONCE per wave, lane t keeping the t-th; the proxy of the round after
@@ -446,22 +491,24 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 				const int ec = __shfl(excl, c), sc = __shfl(start, c);
 				if (valid) t = sc + (idx - ec);
 			}
+			bool hit = false;
+			int q = -1;
 			if (t >= 0)
 			{
-				const int q = W.gridItems[t];
+				q = W.gridItems[t];
 				const float4 fq = W.gridFat[t];
 				AABB bq;
 				bq.lo = v2(fq.x, fq.y);
 				bq.hi = v2(fq.z, fq.w);
-				if (q != p && b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, q);
+				hit = q != p && b2dAabbOverlap(a, bq);
 			}
+			pairHitsAdd(W, S, hits, lane, hit, p, q);
 		}
-		if (largeQ >= 0)
 		{
 			AABB bq;
 			bq.lo = v2(largeFat.x, largeFat.y);
 			bq.hi = v2(largeFat.z, largeFat.w);
-			if (b2dAabbOverlap(a, bq)) tryEmitPair(W, S, p, largeQ);
+			pairHitsAdd(W, S, hits, lane, largeQ >= 0 && b2dAabbOverlap(a, bq), p, largeQ);
 		}
 		for (int t = 64 + lane; t < nLarge; t += 64) // (more than a wave holds: the rest as before)
 		{
@@ -469,6 +516,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
+	pairHitsFlush(W, S, hits, lane);
 	// (the candidate census for the host's choice of the cell: one atomic per wave on the 32 words of ONE line was 8 192
 	// atomics at the end of the kernel, ~5 ns each - carried by the arrival of the workgroups instead, b2d_world.h)
 	b2dBlockTreeAdd2(W, ARRIVE_PAIRS, &S->c.candRounds[0], lane == 0 ? rounds : 0, &S->c.candRounds[1], 0, (unsigned)W.capMoves <= (TREE_SUM_MAX >> 3));
