@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 			ecs[c] = total;
 			total += ccs[c];
 		}
-		rounds += (total + 63) >> 6;
+		{ const int r = (total + 63) >> 6; rounds += r < 8 ? r : 8; } // (at most 8 per proxy enter the census: its 24-bit field in the arrival word holds 8 x capMoves - ADVICE round 4; the host only asks whether the mean is above ~2)
 		for (int base = 0; base < total; base += 64)
 		{
 			const int idx = base + lane;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 		}
 		const int excl = incl - cnt;
 		const int total = __shfl(incl, 63);
-		rounds += (total + 63) >> 6;
+		{ const int r = (total + 63) >> 6; rounds += r < 8 ? r : 8; } // (at most 8 per proxy enter the census: its 24-bit field in the arrival word holds 8 x capMoves - ADVICE round 4; the host only asks whether the mean is above ~2)
 		for (int base = 0; base < total; base += 64)
 		{
 			const int idx = base + lane;

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		W.bodyClaim[i] = 0;
 		W.bodyColorMask[i] = 0;
 		W.bodyActive[i] = 0;
+		W.bodyRest[i] = 0;
 		W.b_adopt[i] = 0;
 		for (int q = 0; q < 3; ++q) W.b_adoptStage[(size_t)q * W.nBodies + i] = 0;
 		uint32_t f = W.b_flags[i] & ~(BF_ISLAND | BF_LARGE);
@@ -232,6 +233,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.posItersLarge = 0;
 		S->c.maxSmallW = 0;
 		S->c.maxDegree = 0;
+		W.hubMeta[0] = 0ull; // (the primary hub of this step: k_island_flatten)
+		S->c.hubEpoch += 1;
 		S->c.chunkW = SMALL_ISLAND_MAX_W;
 		S->c.partitionAge += 1;
 		if (S->c.partitionCooldown > 0) S->c.partitionCooldown -= 1;
@@ -305,14 +308,23 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 			__hip_atomic_store(&W.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		{
-			// census of the largest contact degree (k_island_union counted deg[])
-			int dg = valid ? W.deg[i] : 0;
+			// census of the largest contact degree (k_island_union counted deg[]) - and WHOSE it is when it makes a hub: the
+			// primary hub, whose constraints k_sweep_end takes as one fixed point (ties: the higher body id)
+			int dg = valid ? W.deg[i] : 0, who = valid ? i : -1;
 			for (int off = 32; off > 0; off >>= 1)
 			{
-				const int o = __shfl_xor(dg, off);
-				dg = o > dg ? o : dg;
+				const int o = __shfl_xor(dg, off), ow = __shfl_xor(who, off);
+				if (o > dg || (o == dg && ow > who)) { dg = o; who = ow; }
 			}
-			if (waveLane() == 0 && dg > 0) atomicMaxIfAbove(&W.st->c.maxDegree, dg);
+			if (waveLane() == 0 && dg > 0)
+			{
+				atomicMaxIfAbove(&W.st->c.maxDegree, dg);
+				if (dg > HUB_DEGREE)
+				{
+					const unsigned long long key = ((unsigned long long)(uint32_t)dg << 32) | (unsigned long long)(uint32_t)who;
+					if (key > __hip_atomic_load(&W.hubMeta[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&W.hubMeta[0], key);
+				}
+			}
 		}
 		// (a root has counted itself and offered its own seed in k_island_init: only the other members add to it)
 		const bool other = valid && r != i;

@@ -153,6 +153,8 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 		}
 	}
 	if (t == 0) S->gapClock[0] = wall_clock64();
+	// (the colour census k_color_check has just taken goes home with the counters: the host picks k_sweep_end's tail colours from it)
+	if (t < MAX_COLORS) S->c.colorRows[t] = t == HUB_COLOR ? 0 : __hip_atomic_load(&W.colorCount[colorSlot(t)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	// the island build ends here and the host is waiting for its census to size the solver launches
 	if (pub != nullptr) b2dPublishCensus(W, pub);
 }

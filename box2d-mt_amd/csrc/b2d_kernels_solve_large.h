@@ -624,7 +624,8 @@ __global__ __launch_bounds__(256) void k_exact_convert(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_color_fill(DW W)
+// `restFirst`: the colours from this one up are swept by k_large_rest this step - their bits go into DW::bodyRest (64: none)
+__global__ __launch_bounds__(256) void k_color_fill(DW W, int restFirst)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -668,8 +669,25 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W)
 		if (valid && p >= 0)
 		{
 			W.li_sorted[p] = s;
-			if (color == HUB_COLOR) W.hubRowOf[ci] = p;
+			if (color == HUB_COLOR)
+			{
+				W.hubRowOf[ci] = p;
+				// the lowest contact index among the primary hub's constraints with this partner (k_hub_flag: a partner's later
+				// constraints with the hub - a box in a corner touches two walls - cannot join the one fixed point of k_sweep_end)
+				if (W.hubWide)
+				{
+					const int hubP = (int)(uint32_t)(W.hubMeta[0] & 0xffffffffull);
+					const bool pA = nsA && ids.z == hubP, pB = nsB && ids.w == hubP;
+					if (W.hubMeta[0] != 0ull && pA != pB && (pA ? nsB : nsA))
+						atomicMax(&W.hubFirst[pA ? ids.w : ids.z], ((unsigned long long)(uint32_t)S->c.hubEpoch << 32) | (unsigned long long)(0xffffffffu - (uint32_t)ci));
+				}
+			}
 			W.li_ref[p] = make_int4(ci, nsA ? ids.z : -(ids.z + 1), nsB ? ids.w : -(ids.w + 1), W.parent[nsA ? ids.z : ids.w]);
+			if (color >= restFirst && color != HUB_COLOR && S->c.nColors <= MAX_COLORS)
+			{
+				if (nsA) atomicOr((unsigned long long*)&W.bodyRest[ids.z], 1ull << color);
+				if (nsB) atomicOr((unsigned long long*)&W.bodyRest[ids.w], 1ull << color);
+			}
 			// the upper-range colours of every body (its hand-overs through memory in k_solve_blocks, in this order)
 			if (color >= CUT_COLOR_BASE && color != HUB_COLOR && S->c.nColors <= MAX_COLORS)
 			{
@@ -750,6 +768,25 @@ __global__ __launch_bounds__(256) void k_hub_flag(DW W)
 			{
 				// a hub's constraints first (in contact order), then the others that are swept in order: two counts in one word
 				// (the scan that follows ranks both)
+				if (W.hubWide)
+				{
+					// first the constraints of the PRIMARY hub that one fixed point can take (k_sweep_end): the partner is no hub
+					// itself and this is its first constraint with the hub; then everything else that is swept in order
+					const unsigned long long meta = W.hubMeta[0];
+					const int hubP = (int)(uint32_t)(meta & 0xffffffffull);
+					const bool pA = nsA && ids.z == hubP, pB = nsB && ids.w == hubP;
+					bool wide = meta != 0ull && pA != pB;
+					if (wide)
+					{
+						const int other = pA ? ids.w : ids.z;
+						const bool otherNs = pA ? nsB : nsA;
+						if (otherNs && W.deg[other] > HUB_DEGREE) wide = false;
+						if (otherNs && W.hubFirst[other] != (((unsigned long long)(uint32_t)S->c.hubEpoch << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i))) wide = false;
+					}
+					if (wide) f = 1;
+					else if (rowIsSerial(W, nsA, ids.z, nsB, ids.w)) f = 1 << 20;
+				}
+				else
 				if (rowIsHubs(W, nsA, ids.z, nsB, ids.w)) f = 1;
 				else if (rowIsSerial(W, nsA, ids.z, nsB, ids.w)) f = 1 << 20;
 			}
@@ -770,7 +807,11 @@ __global__ __launch_bounds__(256) void k_hub_fill(DW W)
 		else if (f) W.hubList[(W.keepScan[n] & 0xfffff) + (W.keepScan[i] >> 20)] = W.hubRowOf[i];
 	}
 	// (k_color_scan sets this for the launch-per-colour layout; with rows grouped by block it is not run)
-	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.nHubRows = W.colorCount[colorSlot(HUB_COLOR)];
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		S->c.nHubRows = W.colorCount[colorSlot(HUB_COLOR)];
+		S->c.nHubWide = W.hubWide ? (W.keepScan[n] & 0xfffff) : 0;
+	}
 }
 
 // One constraint of a hub chunk, evaluated from the hub row `hubIn` the lane assumes it will meet at its turn. Works on
@@ -845,8 +886,9 @@ __device__ __forceinline__ HubTrial hubEvaluate(int mode, ContactConstraint& cc,
 // for any NW (tests/test_gpu_parity.py::test_hub_sweep_is_the_same_for_any_number_of_waves).
 #define HUB_DIRTY_WORDS 2048
 
+// `first`: the sweep covers rows [first, nHubRows) of hubList (k_sweep_end takes the rows before that as one fixed point).
 template <int NW>
-__device__ __forceinline__ void hubSweep(const DW& W, int mode, int useGuess)
+__device__ __forceinline__ void hubSweep(const DW& W, int mode, int useGuess, int first = 0)
 {
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
@@ -880,10 +922,10 @@ __device__ __forceinline__ void hubSweep(const DW& W, int mode, int useGuess)
 	int carryBody = -1;
 	float4 carry = make_float4(0, 0, 0, 0);
 	int statRounds = 0, statSerial = 0;
-	const int nChunks = (n + 63) / 64;
+	const int nChunks = n > first ? (n - first + 63) / 64 : 0;
 	for (int chunk = wave; chunk < nChunks; chunk += NW)
 	{
-		const int base = chunk * 64;
+		const int base = first + chunk * 64;
 		const int k = base + lane;
 		const bool have = k < n;
 		LargeRef r;
@@ -1167,11 +1209,12 @@ __device__ __forceinline__ void hubSweep(const DW& W, int mode, int useGuess)
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_large_hub(DW W, int mode, int useGuess)
+__global__ __launch_bounds__(64 * NW) void k_large_hub(DW W, int mode, int useGuess, int behindWide)
 {
 	b2dPhaseStamp(W);
 	if (mode == 2 && W.st->c.allLargeDone) return;
-	hubSweep<NW>(W, mode, useGuess);
+	// (behindWide: only the rows k_sweep_end's one fixed point left - those behind Counters::nHubWide)
+	hubSweep<NW>(W, mode, useGuess, behindWide ? W.st->c.nHubWide : 0);
 }
 
 __global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void k_sp_export_tail(DW W, int* out, int* hdr
 // rank has every rank's E4 records, so every rank finds the same conflicts: boxes = where a proxy has been in the phase (the
 // hull of the box it began with and the one it ended with). A conflict is a virtual edge like a straddling tail contact
 // (no contact can exist between the two bodies yet: they would have one owner).
-__global__ __launch_bounds__(256) void k_sp_tail_pairs(DW W, const int* in, size_t strideWords, size_t tailAt, int capBodies, int capProxies, int2* out, int* nOut)
+__global__ __launch_bounds__(256) void k_sp_tail_pairs(DW W, const int* in, size_t strideWords, size_t tailAt, int capBodies, int capProxies, int capTail, int2* out, int* nOut)
 {
 	b2dPhaseStamp(W);
 	{
@@ -699,10 +699,13 @@ __global__ __launch_bounds__(256) void k_sp_tail_pairs(DW W, const int* in, size
 	for (int r = 0; r < W.shardCount; ++r)
 	{
 		const int* slab = in + (size_t)r * strideWords;
-		const int n = slab[5];
+		// (header word 5 is the rank's TRUE count - the host grows capTail from it and repeats the exchange; the slab holds
+		// capTail descriptors, what lies behind them is the next rank's slab: ADVICE round 4)
+		const int n = slab[5] < capTail ? slab[5] : capTail;
 		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
 		{
 			const int* o = slab + tailAt + (size_t)k * SP_TAIL_WORDS;
+			if ((unsigned)o[3] >= (unsigned)W.nProxies || (unsigned)o[4] >= (unsigned)W.nProxies) continue; // (ids from another rank's slab: checked like the import kernels')
 			const int bA = W.p_body[o[3]], bB = W.p_body[o[4]];
 			const bool nsA = (W.b_flags[bA] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[bB] & BF_TYPE_MASK) != BT_STATIC;
 			if (!nsA || !nsB || W.b_owner[bA] == W.b_owner[bB]) continue;

@@ -151,6 +151,9 @@ struct Counters
 	int compactTick;     // persistent: steps, for the slow beat of an idle colouring
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
 	int nHubRows;        // hub constraints of this step
+	int nHubWide;        // ... the first so many of hubList are constraints of the PRIMARY hub with different non-hub partners: one fixed point (k_sweep_end)
+	int hubEpoch;        // persistent: steps counted for the tags of DW::hubFirst
+	int colorRows[MAX_COLORS]; // census of the large-island constraints by colour as k_color_check found it (the host picks the tail colours of k_sweep_end from it)
 	int hubRounds;       // fixed-point rounds k_large_hub ran this step (all sweeps, all chunks)
 	int hubSerialChunks; // chunks of 64 hub rows it solved lane after lane instead
 	int chunkLanes;      // workgroup size of the small-island solver chosen for this step (TINY_CHUNK_LANES or SMALL_CHUNK_LANES)
@@ -353,11 +356,15 @@ struct DW
 	int* hubRowOf;       // per contact: its constraint row if it is a hub constraint this step
 	float4* hubDelta;    // per hub constraint (hubList order): the change it made to its hub's row in the last sweep (k_large_hub's first guess)
 	int* hubList;        // hub constraint rows in contact-index order (the deterministic visiting order of k_large_hub)
+	unsigned long long* hubMeta;  // [0] the primary hub of this step: (its degree << 32) | body id, 0 = no hub (k_island_flatten)
+	unsigned long long* hubFirst; // per body: (Counters::hubEpoch << 32) | ~(lowest contact index among its constraints with the primary hub)
+	int hubWide;         // 1: hubList starts with the rows k_sweep_end takes as one fixed point (Counters::nHubWide); 0: k_large_hub's order (B2HIP_HUB_WIDE=0)
 	int* li_sorted;      // large contact slots grouped by colour
 	int4* li_ref;        // per colour-sorted row: contact index, bodyA, bodyB (static bodies as -(id+1)), island root
 	uint32_t* bodyClaim;
 	uint64_t* bodyColorMask;
 	uint64_t* bodyActive;   // per body: colours of its constraints in THIS step's large-island solve (dataflow solver)
+	uint64_t* bodyRest;     // per body: the REST colours (>= k_color_fill's restFirst) among its constraints of this step (k_large_rest)
 	int eventsOn;           // contact events requested by the host (b2hip_enable_contact_events)
 	unsigned long long* evKey; // per event: proxy-key pair of the contact (the reference's deferred-callback sort key)
 	int4* evInfo;           // per event: (fixtureA, fixtureB, kind 0 = begin / 1 = end, contact index or -1 if destroyed)

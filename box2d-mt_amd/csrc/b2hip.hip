@@ -31,6 +31,7 @@
 #include "b2d_handover.h"
 #define B2HIP_HAVE_VALIDATION_SOLVERS 0
 #include "b2d_kernels_solve_blocks.h"
+#include "b2d_kernels_sweep_end.h"
 #include "b2d_kernels_edit.h"
 #include "b2d_kernels_shard.h"
 #include "b2d_kernels_spatial.h"
@@ -209,7 +210,7 @@ struct b2hip_world
 		si_stack, si_lastLevel, b_slot, b_island, chunkFirst;
 	DevArray<int> li_bodies, li_contacts, li_roots, li_color, colorCount, colorStart, colorCursor, li_sorted;
 	DevArray<uint32_t> bodyClaim, rootPen, rootSleepMin;
-	DevArray<uint64_t> bodyColorMask, bodyActive;
+	DevArray<uint64_t> bodyColorMask, bodyActive, bodyRest;
 	DevArray<float4> b_posv, dfInbox;
 	DevArray<int> dfRank;
 	DevArray<unsigned long long> evKey;
@@ -221,6 +222,7 @@ struct b2hip_world
 	DevArray<int4> toiVerdict; // PreSolve answers for the TOI phase's log slots (DW::toiVerdict)
 	DevArray<int> uncolList, compactList, hubRowOf, hubList;
 	DevArray<float4> hubDelta;
+	DevArray<unsigned long long> hubMeta, hubFirst;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
 	DevArray<int> moveBuf, gridCount, gridStart, gridCursor, gridItems, largeProxies, largeMoves;
@@ -320,6 +322,18 @@ struct b2hip_world
 	int blocksMaxWG = 0;         // co-resident workgroups of k_solve_blocks on this device (0 = do not use it)
 	int sweepMaxWG[3] = { 0, 0, 0 }; // ... of k_blocks_sweep<256 / 512 / 1024>
 	int hubWaves = 8;            // waves of k_large_hub (B2HIP_HUB_WAVES=1: one)
+	bool sweepEnd = true;        // k_sweep_end closes every sweep of the launch-per-colour solver (B2HIP_NO_SWEEP_END=1: round 4's launches)
+	bool sweepTail = true;       // ... and takes the small colours (B2HIP_NO_TAIL=1: a launch per colour)
+	int tailRowsMax = 1024;      // a colour with at most this many rows in the step's census is a tail colour (B2HIP_TAIL_ROWS): one
+	                             // round of the workgroup. Measured on the settled Tumbler (profiles/r05_b): a round costs the
+	                             // workgroup ~4.5 us - the same chain of dependent loads a launch pays - so a colour of 8 000
+	                             // rows is 9 rounds = 40 us against 5.8 us as a launch of its own (tail colours up to 8 192 rows:
+	                             // 4.94 ms per step; none: 3.87; round 4's launches: 4.57)
+	bool restFlow = true;        // the small colours of a sweep as data flow per body in one launch (k_large_rest; B2HIP_NO_REST=1: launches / tail)
+	int restRowsMax = 16384;     // ... the highest colours that hold at most this many rows together (B2HIP_REST_ROWS)
+	int lastTailFirst = 0, lastRestFirst = 0, lastSweepLaunches = 0; // diagnostics of the last step
+	long long launchCount = 0;   // kernels launched on the main stream so far (LAUNCH)
+	long long familyLaunchesAtStart = 0; int familyLaunches = 0; // ... by the large-island solver family in the last step (timing mode 5)
 	int largeHintSteps = 120;    // > 0: the world has had large islands lately (k_color_check / k_block_census run with the island build)
 	int serialOrphansNext = 0;   // DW::serialOrphans of the next step
 	int adoptSticky = 0;
@@ -651,6 +665,7 @@ static inline void stampsTaken(b2hip_world* w, const A&, const R&...)
 	do                                                                                        \
 	{                                                                                         \
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__);     \
+		(w)->launchCount += 1;                                                                \
 		stampsTaken((w), __VA_ARGS__);                                                        \
 		hipError_t _le = hipGetLastError();                                                   \
 		if (_le != hipSuccess) return setError(B2HIP_ERR_HIP, std::string(#kernel) + " launch: " + hipGetErrorString(_le)); \
@@ -852,7 +867,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2 + COLOR_SLOT_PADDED * COLOR_SLOT_STRIDE); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2 + COLOR_SLOT_PADDED * COLOR_SLOT_STRIDE); ENS(li_sorted, cc); ENS(li_ref, cc); // (colorSlot: the first 65 colour counters on a line each)
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(b_posv, nb); ENS(dfRank, B2HIP_HAVE_VALIDATION_SOLVERS ? nb * 32 : 1); ENS(dfInbox, B2HIP_HAVE_VALIDATION_SOLVERS ? 2 * cc : 1); /* (mailbox tables of the test build's k_solve_mailbox: DF_RANKS = 32 slots per body) */ ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(bodyRest, nb); ENS(b_posv, nb); ENS(dfRank, B2HIP_HAVE_VALIDATION_SOLVERS ? nb * 32 : 1); ENS(dfInbox, B2HIP_HAVE_VALIDATION_SOLVERS ? 2 * cc : 1); /* (mailbox tables of the test build's k_solve_mailbox: DF_RANKS = 32 slots per body) */ ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(hubMeta, 8); ENS(hubFirst, nb); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -923,6 +938,17 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.noFreeBodies = getenv("B2HIP_NO_FREE_BODIES") && atoi(getenv("B2HIP_NO_FREE_BODIES")) ? 1 : 0;
 	d.hubSerial = getenv("B2HIP_HUB_SERIAL") && atoi(getenv("B2HIP_HUB_SERIAL")) ? 1 : 0;
 	w->hubWaves = getenv("B2HIP_HUB_WAVES") && atoi(getenv("B2HIP_HUB_WAVES")) == 1 ? 1 : 8; // (1: the one-wave form, for comparison)
+	// The end of a sweep over islands that run launch per colour - tail colours, hub rows, joints, the verdict of a position
+	// iteration - in one single-workgroup launch (k_sweep_end). B2HIP_NO_SWEEP_END=1: the launches of round 4 (k_large_hub,
+	// k_large_joints, k_large_pos_end); B2HIP_NO_TAIL=1: every colour a launch of its own; B2HIP_HUB_WIDE=0: the hub rows in
+	// k_large_hub's order and scheme (chunks of 64) inside k_sweep_end - what the comparisons in tests/ use. Asking for a
+	// number of hub waves or the serial hub sweep means k_large_hub.
+	w->sweepEnd = !(getenv("B2HIP_NO_SWEEP_END") && atoi(getenv("B2HIP_NO_SWEEP_END"))) && !getenv("B2HIP_HUB_WAVES");
+	w->sweepTail = w->sweepEnd && !(getenv("B2HIP_NO_TAIL") && atoi(getenv("B2HIP_NO_TAIL")));
+	w->restFlow = w->sweepEnd && !(getenv("B2HIP_NO_REST") && atoi(getenv("B2HIP_NO_REST")));
+	w->restRowsMax = getenv("B2HIP_REST_ROWS") ? std::min(atoi(getenv("B2HIP_REST_ROWS")), REST_ROWS_MAX - COLOR_SMALL_MAX) : 16384;
+	w->tailRowsMax = getenv("B2HIP_TAIL_ROWS") ? atoi(getenv("B2HIP_TAIL_ROWS")) : SWEEP_END_LANES;
+	d.hubWide = (w->sweepEnd && !d.hubSerial && !(getenv("B2HIP_HUB_WIDE") && atoi(getenv("B2HIP_HUB_WIDE")) == 0)) ? 1 : 0;
 	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
 	d.capContacts = (int)cc;
 	d.capPairs = (int)w->pairKey.cap;
@@ -954,7 +980,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.hubDelta = w->hubDelta.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.bodyRest = w->bodyRest.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.hubDelta = w->hubDelta.p; d.hubMeta = w->hubMeta.p; d.hubFirst = w->hubFirst.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.gridFat = w->gridFat.p; d.arriveTree = w->arriveTree.p; d.largeProxies = w->largeProxies.p; d.largeMoves = w->largeMoves.p;
@@ -1919,6 +1945,7 @@ static int phaseSolve(b2hip_world* w)
 		d.blockSort = (useBlocks || useSweep) ? 1 : 0;
 		const bool useResident = usePersistent && (useBlocks || B2HIP_HAVE_VALIDATION_SOLVERS);
 		bool colorsOnDevice = false;
+		bool censusVoid = false;
 		if (!exactLarge && (c.needRecolor || c.nUncolored > 0 || c.nCompact > 0))
 		{
 			if (!c.needRecolor && c.nUncolored <= COLOR_SMALL_MAX)
@@ -1944,6 +1971,7 @@ static int phaseSolve(b2hip_world* w)
 			{
 			// a colour clash on some body -> colour the large islands from scratch; otherwise only the
 			// constraints that have no colour yet join the Jones-Plassmann rounds (existing masks stay)
+			censusVoid = true; // (thousands of constraints get their colours now: the colour census of this step is history)
 			int uncolored = c.nUncolored;
 			if (c.needRecolor)
 			{
@@ -1968,7 +1996,26 @@ static int phaseSolve(b2hip_world* w)
 			}
 		}
 		if (!d.blockSort) LAUNCH(w, k_color_scan, 1, 1, d); // (segments by colour: the block solvers sort their rows themselves)
-		LAUNCH(w, k_color_fill, gC, 256, d);
+		// ---- the end of every sweep without a launch per colour (b2d_kernels_sweep_end.h). The REST colours - from the highest
+		// colour down while this step's colour census (k_color_check, published with the island census) keeps them below
+		// restRowsMax rows together - are swept by ONE launch of k_large_rest, as data flow per body; k_color_fill notes them
+		// on their bodies. Which colours are "rest" changes nothing in the result (the order on every body is the launches'):
+		// a launch-count matter. Not on a step that colours afresh: its census is void.
+		const bool useSweepEnd = w->sweepEnd && !exactLarge && !w->debugTrace;
+		int restFirst = 0x7fffffff; // (none)
+		if (useSweepEnd && w->restFlow && !d.blockSort && !c.needRecolor && !censusVoid && nColors > 0 && nColors < MAX_COLORS)
+		{
+			long long sum = 0;
+			int t = nColors;
+			while (t > 0 && sum + c.colorRows[t - 1] <= (long long)w->restRowsMax)
+			{
+				sum += c.colorRows[t - 1];
+				t -= 1;
+			}
+			if (nColors - t >= 2) restFirst = t;
+		}
+		w->lastRestFirst = restFirst < nColors ? restFirst : nColors;
+		LAUNCH(w, k_color_fill, gC, 256, d, restFirst < MAX_COLORS ? restFirst : MAX_COLORS);
 		if (hasHubs)
 		{
 			// the hub constraints in contact-index order (deterministic whatever the atomics of k_color_fill did)
@@ -2042,6 +2089,9 @@ static int phaseSolve(b2hip_world* w)
 			HIP_TRY(hipMemcpyAsync(w->dbgLi.p, w->li_bodies.p, nb * 4, hipMemcpyDeviceToDevice, w->stream));
 			HIP_TRY(hipMemcpyAsync(w->dbgLi.p + nb, &w->d_state.p->c, 64 * 4 > sizeof(Counters) ? sizeof(Counters) : 64 * 4, hipMemcpyDeviceToDevice, w->stream));
 		}
+		// (timing mode 5: ONE event pair around the whole large-island solver family of the launch-per-colour path - integrate,
+		// constraint set-up, every sweep, impulses stored, positions, write-back and sleep)
+		if (w->kernelTiming == 5) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 8; w->familyLaunchesAtStart = w->launchCount; }
 		LAUNCH(w, k_large_integrate, gB, 256, d, sp);
 		if (w->debugTrace) HIP_TRY(hipMemcpyAsync(w->dbgVel.p, w->b_vel.p, w->bodies.size() * 16, hipMemcpyDeviceToDevice, w->stream));
 		TRACE("integrate");
@@ -2068,31 +2118,110 @@ static int phaseSolve(b2hip_world* w)
 			return 0;
 		};
 		// the hub sweeps: eight waves that fetch their chunks of hub constraints ahead of their turn (one wave on request)
-		auto hubSweepLaunch = [&](int mode, int useGuess) -> int
+		auto hubSweepLaunch = [&](int mode, int useGuess, int behindWide = 0) -> int
 		{
-			if (w->hubWaves == 1) LAUNCH(w, k_large_hub<1>, 1, 64, d, mode, useGuess);
-			else LAUNCH(w, k_large_hub<8>, 1, 512, d, mode, useGuess);
+			if (w->hubWaves == 1) LAUNCH(w, k_large_hub<1>, 1, 64, d, mode, useGuess, behindWide);
+			else LAUNCH(w, k_large_hub<8>, 1, 512, d, mode, useGuess, behindWide);
 			return 0;
 		};
 		if (useSweep) w->sweepSteps += 1;
+		// ---- the end of every sweep in ONE single-workgroup launch (b2d_kernels_sweep_end.h): the tail colours - those this
+		// step's colour census (k_color_check, published with the island census) found small, from the highest colour down -
+		// the hub rows, the joint walk, the verdict of a position iteration. Which colours are "tail" changes nothing in the
+		// result (k_sweep_end does k_large_velocity's / k_large_position's arithmetic row for row): a pure launch-count matter.
+		const bool useRest = useSweepEnd && restFirst < nColors;
+		int tailFirst = useRest ? restFirst : nColors;
+		if (useSweepEnd && w->sweepTail && !useRest && !useSweep && !c.needRecolor && !censusVoid && nColors <= MAX_COLORS)
+		{
+			long long sum = 0;
+			while (tailFirst > 0 && c.colorRows[tailFirst - 1] <= w->tailRowsMax && sum + c.colorRows[tailFirst - 1] <= 8ll * w->tailRowsMax)
+			{
+				sum += c.colorRows[tailFirst - 1];
+				tailFirst -= 1;
+			}
+		}
+		bool tailAny = false;
+		for (int col = tailFirst; col < nColors && !useRest; ++col) tailAny = tailAny || colorUsed(col);
+		// (every launch of k_large_rest tags its hand-over rows with an epoch of its own, like k_blocks_sweep)
+		auto restLaunch = [&](int mode) -> int
+		{
+			if (!useRest) return 0;
+			if ((w->dfEpoch >> 14) != w->dfWipedAt)
+			{
+				HIP_TRY(hipMemsetAsync(w->b_cutv.p, 0, w->b_cutv.cap * sizeof(float4), w->stream));
+				HIP_TRY(hipMemsetAsync(w->b_posv.p, 0, w->b_posv.cap * sizeof(float4), w->stream));
+				w->dfWipedAt = w->dfEpoch >> 14;
+			}
+			long long rows = 0;
+			for (int col = restFirst; col < nColors && col < MAX_COLORS; ++col) rows += c.colorRows[col];
+			// (the census is this step's before k_color_small handed out its colours - at most COLOR_SMALL_MAX rows more)
+			const int gR = (int)((rows + COLOR_SMALL_MAX + 255) / 256);
+			if (mode == 0) LAUNCH(w, k_large_rest<0>, gR, 256, d, restFirst, nColors, w->gridBar.p, w->dfEpoch);
+			else if (mode == 1) LAUNCH(w, k_large_rest<1>, gR, 256, d, restFirst, nColors, w->gridBar.p, w->dfEpoch);
+			else LAUNCH(w, k_large_rest<2>, gR, 256, d, restFirst, nColors, w->gridBar.p, w->dfEpoch);
+			w->dfEpoch += 1;
+			return 0;
+		};
+		w->lastTailFirst = tailFirst;
+		w->lastSweepLaunches = 0;
+		const int bigEnd = useSweep ? 0 : tailFirst; // colours [0, bigEnd) are launches of their own
+		// The hub rows the one fixed point cannot take are swept lane after lane inside k_sweep_end - a handful on the Tumbler
+		// (boxes in the corners). An island that kept many of them in the LAST step (several hubs, constraints swept in order for
+		// lack of a home block; the census still carries that step's counts) gets k_large_hub's eight prefetching waves for
+		// them: k_sweep_end up to the fixed point, k_large_hub, k_sweep_end for what follows the hub rows. (Either way a valid
+		// sweep; which one is decided from counters a snapshot carries, so a loaded world decides alike.)
+		const bool leftoverApart = useSweepEnd && hasHubs && d.hubWide && c.nHubRows - c.nHubWide > SE_LEFT_INLINE_MAX;
+		auto sweepEndOne = [&](int mode, int tf, int te, int what) -> int
+		{
+			if (mode == 0) LAUNCH(w, k_sweep_end<0>, 1, SWEEP_END_LANES, d, sp, tf, te, what);
+			else if (mode == 1) LAUNCH(w, k_sweep_end<1>, 1, SWEEP_END_LANES, d, sp, tf, te, what);
+			else LAUNCH(w, k_sweep_end<2>, 1, SWEEP_END_LANES, d, sp, tf, te, what);
+			w->lastSweepLaunches += 1;
+			return 0;
+		};
+		auto sweepEndLaunch = [&](int mode, int what) -> int
+		{
+			if (!what && !tailAny) return 0;
+			const int tf = (useSweep || useRest) ? 0 : tailFirst, te = (useSweep || useRest) ? 0 : nColors;
+			if (leftoverApart && (what & SE_HUB))
+			{
+				int rcl = sweepEndOne(mode, tf, te, (what & (SE_HUB | SE_GUESS)) | SE_HUB_WIDE_ONLY);
+				if (rcl) return rcl;
+				rcl = hubSweepLaunch(mode, (what & SE_GUESS) ? 1 : 0, 1);
+				if (rcl) return rcl;
+				const int rest = what & ~(SE_HUB | SE_GUESS);
+				return rest ? sweepEndOne(mode, 0, 0, rest) : 0;
+			}
+			return sweepEndOne(mode, tf, te, what);
+		};
 		if (sp.warmStarting)
 		{
 			if (useSweep) { rc = sweep(0); if (rc) return rc; }
 			else
 			{
-				for (int col = 0; col < nColors; ++col)
+				for (int col = 0; col < bigEnd; ++col)
 					if (colorUsed(col)) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
+				rc = restLaunch(0);
+				if (rc) return rc;
 			}
-			if (hasHubs) { rc = hubSweepLaunch(0, 0); if (rc) return rc; }
+			if (useSweepEnd)
+			{
+				// (b2Island.cpp:256-268: the joints' InitVelocityConstraints follows the contacts' warm start; the first velocity
+				// iteration then begins with the joints)
+				rc = sweepEndLaunch(0, (hasHubs ? SE_HUB : 0) | (hasJoints ? SE_JOINTS_INIT | (sp.velIters > 0 ? SE_JOINTS_VEL : 0) : 0));
+				if (rc) return rc;
+			}
+			else if (hasHubs) { rc = hubSweepLaunch(0, 0); if (rc) return rc; }
 		}
 		TRACE("warmstart");
-		if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 0);
+		if (hasJoints && !(useSweepEnd && sp.warmStarting)) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 0);
 		for (int it = 0; it < sp.velIters; ++it)
 		{
-			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 1);
+			// (with k_sweep_end the joint walk of iteration it is the last act of the sweep before it)
+			if (hasJoints && !(useSweepEnd && (it > 0 || sp.warmStarting))) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 1);
 			if (useSweep) { rc = sweep(1); if (rc) return rc; }
 			else
-			for (int col = 0; col < nColors; ++col)
+			for (int col = 0; col < bigEnd; ++col)
 			{
 				if (!colorUsed(col)) continue;
 				if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
@@ -2100,7 +2229,13 @@ static int phaseSolve(b2hip_world* w)
 				if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; }
 				if (w->debugTrace) TRACE(("vel" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
-			if (hasHubs) { rc = hubSweepLaunch(1, it > 0 ? 1 : 0); if (rc) return rc; }
+			if (!useSweep) { rc = restLaunch(1); if (rc) return rc; }
+			if (useSweepEnd)
+			{
+				rc = sweepEndLaunch(1, (hasHubs ? SE_HUB | (it > 0 ? SE_GUESS : 0) : 0) | (hasJoints && it + 1 < sp.velIters ? SE_JOINTS_VEL : 0));
+				if (rc) return rc;
+			}
+			else if (hasHubs) { rc = hubSweepLaunch(1, it > 0 ? 1 : 0); if (rc) return rc; }
 		}
 		LAUNCH(w, k_large_store_impulses, gC, 256, d);
 		TRACE("store_impulses");
@@ -2108,23 +2243,33 @@ static int phaseSolve(b2hip_world* w)
 		TRACE("integrate_positions");
 		for (int it = 0; it < sp.posIters; ++it)
 		{
-			LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
+			if (!useSweepEnd || it == 0) LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
 			if (useSweep) { rc = sweep(2); if (rc) return rc; }
 			else
-			for (int col = 0; col < nColors; ++col)
+			for (int col = 0; col < bigEnd; ++col)
 			{
 				if (!colorUsed(col)) continue;
 				LAUNCH(w, k_large_position, gK, 256, d, col);
 				if (w->debugTrace) TRACE(("pos" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
-			if (hasHubs) { rc = hubSweepLaunch(2, it > 0 ? 1 : 0); if (rc) return rc; }
-			if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
-			LAUNCH(w, k_large_pos_end, 1, 256, d);
+			if (!useSweep) { rc = restLaunch(2); if (rc) return rc; }
+			if (useSweepEnd)
+			{
+				rc = sweepEndLaunch(2, (hasHubs ? SE_HUB | (it > 0 ? SE_GUESS : 0) : 0) | (hasJoints ? SE_JOINTS_POS : 0) | SE_POS_END | (it + 1 < sp.posIters ? SE_POS_BEGIN : 0));
+				if (rc) return rc;
+			}
+			else
+			{
+				if (hasHubs) { rc = hubSweepLaunch(2, it > 0 ? 1 : 0); if (rc) return rc; }
+				if (hasJoints) LAUNCH(w, k_large_joints, gJ, 64, d, sp, 2);
+				LAUNCH(w, k_large_pos_end, 1, 256, d);
+			}
 		}
 		}
 		LAUNCH(w, k_large_finalize, gB, 256, d, sp);
 		TRACE("finalize");
 		LAUNCH(w, k_large_sleep, gB, 256, d, sp);
+		if (w->kernelTiming == 5 && w->ktKind == 8) { w->familyLaunches = (int)(w->launchCount - w->familyLaunchesAtStart); rc = ktRecord(w); if (rc) return rc; }
 		TRACE("sleep");
 		if (sideStream) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
 		stampPhase(w, 8);
@@ -2377,6 +2522,9 @@ static int forkEarlyRows(b2hip_world* w)
 	DW& d = w->dw;
 	const bool lazy = w->lazyReadback || (w->spatial && !w->spFullRows);
 	if (w->earlyRowsMin <= 0 || d.nBodies < w->earlyRowsMin || w->noStatePoll || lazy || w->rowsEarlyPending || w->rowsForked || w->debugSync || w->debugTrace) return 0;
+	// (a user contact filter is called by the pair update while the copy would be running: a ShouldCollide that reads a body
+	// - pullBody reads h_state - could see a row half old, half new. No early rows then: ADVICE round 4.)
+	if (hasFilter(w)) return 0;
 	if (!w->rowStream)
 	{
 		HIP_TRY(hipStreamCreateWithFlags(&w->rowStream, hipStreamNonBlocking));
@@ -2764,7 +2912,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
-	w->bodyActive.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release(); w->hubRowOf.release(); w->hubList.release(); w->hubDelta.release();
+	w->bodyActive.release(); w->bodyRest.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release(); w->hubRowOf.release(); w->hubList.release(); w->hubDelta.release(); w->hubMeta.release(); w->hubFirst.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiNew.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
@@ -4692,6 +4840,12 @@ static int stepEndImpl(b2hip_world* w)
 		else if (w->ktKind == 6) w->ktBytes = (double)w->ktUnitsA * 250.0;
 		else if (w->ktKind == 7) w->ktBytes = (double)w->ktUnitsA * 16.0 + (double)w->ktUnitsB * 8.0;
 		else if (w->ktKind == 1) w->ktBytes = (double)w->last.nLContacts * 220.0 * w->sp.velIters;
+		else if (w->ktKind == 8)
+		{
+			// the whole family: SURVEY 8d's solver figure for the large islands, position iterations as executed
+			w->ktBytes = (double)w->last.nLContacts * (w->sp.velIters * 220.0 + w->last.posItersLarge * 136.0 + 488.0) + (double)w->last.nLBodies * 240.0;
+			w->ktLaunches = w->familyLaunches;
+		}
 		else if (w->ktKind == 3 || w->ktKind == 4) w->ktBytes = (double)w->last.nLContacts * (w->sp.velIters * 220.0 + w->last.posItersLarge * 136.0 + 488.0) + (double)w->last.nLBodies * 240.0;
 		else w->ktBytes = (double)w->last.nSContacts * (w->sp.velIters * 220.0 + w->sp.posIters * 136.0 + 488.0) + (double)w->last.nSBodies * 240.0;
 	}
@@ -5475,7 +5629,7 @@ static int spExchangeState(b2hip_world* w, int mode)
 			// what no rank could see by itself: contacts created over an ownership boundary, proxies of different ranks' events
 			// that came to overlap (k_sp_tail_pairs: every rank finds the same list in the same records)
 			// (the count lives behind the pairs; k_sp_export_tail has wiped it)
-			LAUNCH(w, k_sp_tail_pairs, gridFor(std::max(capP * ranks, capT)), 256, d, (const int*)w->spRecv.p, words, tailAt, capB, capP, w->spVirt.p, (int*)(w->spVirt.p + SP_TAIL_MAX));
+			LAUNCH(w, k_sp_tail_pairs, gridFor(std::max(capP * ranks, capT)), 256, d, (const int*)w->spRecv.p, words, tailAt, capB, capP, capT, w->spVirt.p, (int*)(w->spVirt.p + SP_TAIL_MAX));
 			int nVirt = 0;
 			int hdr[SHARD_MAX_RANKS][SP_HEADER_WORDS];
 			rc = spReadHeaders(w, words, hdr, (const int*)(w->spVirt.p + SP_TAIL_MAX), &nVirt);
@@ -5591,12 +5745,26 @@ static int spExchangePairs(b2hip_world* w, long long* totalPairs, int* straddlin
 		if (rc) return rc;
 		int most = 0, strad = 0;
 		long long total = 0;
+		bool overflowed = false;
 		for (int r = 0; r < ranks; ++r)
 		{
-			if (hdr[r][5] & 3) return setError(B2HIP_ERR_CAPACITY, "pair buffer / contact array overflow on a rank of a spatially sharded world");
+			overflowed = overflowed || (hdr[r][5] & 3) != 0;
 			most = std::max(most, hdr[r][2]);
 			total += hdr[r][2];
 			strad += hdr[r][6];
+		}
+		if (overflowed)
+		{
+			// A rank's search did not fit its pair buffer (a dense start: every proxy is new). The unsharded world recovers from
+			// that (growPairBuffers: size the buffer from the true count, clear the flag, search again) and so does this one: every
+			// rank reads the same headers, so all of them grow alike - room for the union - and all of them search again
+			// (findNewContacts repeats on 1; the collectives stay in step). ADVICE round 4.
+			w->pairCapHint = std::max(w->pairCapHint, 2 * (size_t)total + 4096);
+			rc = ensureCapacity(w, (size_t)w->lastContacts + 1024);
+			if (rc) return rc;
+			HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
+			w->spSendWiped = nullptr; // (this slab was filled and never imported: wiped again before the next export)
+			return 1;
 		}
 		if (most > w->spPairCap)
 		{
@@ -5640,7 +5808,7 @@ static int spResolve(b2hip_world* w, int nVirt)
 {
 	const int ranks = w->dw.shardCount;
 	DW& d = w->dw;
-	for (int round = 0; round < 4; ++round)
+	for (int round = 0, grown = 0; round < 4; ++round)
 	{
 		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.nStraddle, 0, 4 * sizeof(int), w->stream)); // nStraddle, nStraddleJoints, nResolve, nMigrated
 		LAUNCH(w, k_sp_flag_contacts, gridFor(d.capContacts), 256, d);
@@ -5657,6 +5825,9 @@ static int spResolve(b2hip_world* w, int nVirt)
 			if (rc) return rc;
 			d.spStraddle = w->spStraddle.p;
 			d.capStraddle = (int)w->spStraddle.cap;
+			// (growing the list is not a round of the resolution: ADVICE round 4)
+			if (++grown > 8) return setError(B2HIP_ERR_CAPACITY, "the list of straddling contacts of a spatially sharded world keeps growing");
+			round -= 1;
 			continue;
 		}
 		// components of the replicated structure (contacts between non-static bodies, joints), then the rows of those to merge
@@ -5709,11 +5880,13 @@ static int spAfterToi(b2hip_world* w)
 	{
 		int rc = spExchangeState(w, 1);
 		if (rc != 2) { w->toiChains = false; w->toiSpeculative = false; return rc; }
-		if (w->toiChains && w->spToiUnsafe != 0)
+		// (whichever parallel path this rank's phase took: unsafe with toiChains false - the components - used to do nothing
+		// here for six exchanges and then fail the step)
+		if (w->spToiUnsafe != 0)
 		{
 			LAUNCH(w, k_toi_snapshot, gridFor(std::max(w->dw.nBodies, w->dw.capContacts)), 256, w->dw, 1);
 			bool serial = true;
-			if (w->spToiUnsafe == 4 /* TOI_UNSAFE_PAIR */ && !w->toiChainsHadGrid && !w->dw.noChainCreate)
+			if (w->toiChains && w->spToiUnsafe == 4 /* TOI_UNSAFE_PAIR */ && !w->toiChainsHadGrid && !w->dw.noChainCreate)
 			{
 				// a chain moved a proxy out of its fat AABB while the hash grid was not kept up: the chains once more, with the grid
 				w->toiGridSticky = 16;
@@ -6216,7 +6389,7 @@ int b2hip_set_kernel_timing_units(b2hip_world* w, long long units_a, long long u
 int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* total_ms, int* launches, double* algorithmic_bytes)
 {
 	if (!w) return setError(B2HIP_ERR_INVALID, "null world");
-	const char* n = w->ktKind == 5 ? "k_collide" : w->ktKind == 6 ? "k_sync_fixtures" : w->ktKind == 7 ? "k_find_pairs_small" : w->ktKind == 4 ? "k_solve_blocks" : w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : (w->solverRows ? "k_solve_dataflow" : "k_solve_mailbox")) : ""));
+	const char* n = w->ktKind == 8 ? "large-island solver family (k_large_integrate / init / velocity / rest / k_sweep_end / position / store_impulses / finalize / sleep)" : w->ktKind == 5 ? "k_collide" : w->ktKind == 6 ? "k_sync_fixtures" : w->ktKind == 7 ? "k_find_pairs_small" : w->ktKind == 4 ? "k_solve_blocks" : w->ktKind == 1 ? "k_large_velocity" : (w->ktKind == 2 ? "k_solve_small" : (w->ktKind == 3 ? (w->solverBarriers ? "k_solve_persistent" : (w->solverRows ? "k_solve_dataflow" : "k_solve_mailbox")) : ""));
 	if (name && name_cap > 0)
 	{
 		strncpy(name, n, (size_t)name_cap - 1);

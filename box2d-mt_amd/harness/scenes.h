@@ -63,7 +63,7 @@ enum SceneId
 	e_helloWorld = 0,
 	e_pyramid = 1,       // p0 = rows, p1 = number of pyramids (side by side); f0 = shard index, f1 = shard count
 	                     //   (f1 >= 2: build only the pyramids k with k % f1 == f0, at the positions of the full scene)
-	e_tumbler = 2,       // p0 = boxes per side of the pre-placed grid, p1 = unused ; f0 = half size S (0 -> auto)
+	e_tumbler = 2,       // p0 = boxes per side of the pre-placed grid, p1 = containers side by side (0 / 1: one) ; f0 = half size S (0 -> auto)
 	e_field = 3,         // p0 = bodies, p1 = bullet count ; f0 = arena half length R (0 -> auto density), f1 = max radius
 	e_piles = 4,         // p0 = piles, p1 = boxes per pile
 	e_rain = 5,          // p0 = bodies (mixed circles / boxes / polygons dropped on a box ground)
@@ -198,7 +198,10 @@ inline void BuildPyramid(Scene& s, b2World* w, int rows, int count, int shard = 
 }
 
 // Hollow square container driven by a revolute motor, n*n small boxes pre-placed on a grid.
-inline void BuildTumbler(Scene& s, b2World* w, int n, float S)
+// `count` containers side by side (0 / 1: the Testbed's one), each pinned to the shared ground body by its own motor joint
+// and filled with its own n x n boxes; `count` > 1 is the N-GPU form of config 3: one container per rank of a world sharded
+// by spatial ownership, bodies created container after container.
+inline void BuildTumbler(Scene& s, b2World* w, int n, float S, int count = 1)
 {
 	w->SetGravity(b2Vec2(0.0f, -10.0f));
 	const float pitch = 0.3f;
@@ -207,50 +210,56 @@ inline void BuildTumbler(Scene& s, b2World* w, int n, float S)
 		S = 0.5f * pitch * (float)n + 1.0f;
 		if (S < 10.0f) S = 10.0f;
 	}
+	if (count < 1) count = 1;
 	b2Body* ground;
 	{
 		b2BodyDef bd;
 		ground = AddBody(s, w, bd);
 	}
+	for (int t = 0; t < count; ++t)
 	{
-		b2BodyDef bd;
-		bd.type = b2_dynamicBody;
-		bd.allowSleep = false;
-		bd.position.Set(0.0f, S);
-		b2Body* body = AddBody(s, w, bd);
-		b2PolygonShape shape;
-		shape.SetAsBox(0.5f, S, b2Vec2(S, 0.0f), 0.0f);
-		body->CreateFixture(&shape, 5.0f);
-		shape.SetAsBox(0.5f, S, b2Vec2(-S, 0.0f), 0.0f);
-		body->CreateFixture(&shape, 5.0f);
-		shape.SetAsBox(S, 0.5f, b2Vec2(0.0f, S), 0.0f);
-		body->CreateFixture(&shape, 5.0f);
-		shape.SetAsBox(S, 0.5f, b2Vec2(0.0f, -S), 0.0f);
-		body->CreateFixture(&shape, 5.0f);
-
-		b2RevoluteJointDef jd;
-		jd.bodyA = ground;
-		jd.bodyB = body;
-		jd.localAnchorA.Set(0.0f, S);
-		jd.localAnchorB.Set(0.0f, 0.0f);
-		jd.referenceAngle = 0.0f;
-		jd.motorSpeed = 0.05f * b2_pi;
-		jd.maxMotorTorque = 1e8f;
-		jd.enableMotor = true;
-		s.joint = w->CreateJoint(&jd);
-	}
-	b2PolygonShape box;
-	box.SetAsBox(0.125f, 0.125f);
-	float start = -0.5f * pitch * (float)(n - 1);
-	for (int i = 0; i < n; ++i)
-	{
-		for (int j = 0; j < n; ++j)
+		const float x0 = (float)t * (2.0f * S + 4.0f);
 		{
 			b2BodyDef bd;
 			bd.type = b2_dynamicBody;
-			bd.position.Set(start + pitch * (float)j, S + start + pitch * (float)i);
+			bd.allowSleep = false;
+			bd.position.Set(x0, S);
 			b2Body* body = AddBody(s, w, bd);
-			body->CreateFixture(&box, 1.0f);
+			b2PolygonShape shape;
+			shape.SetAsBox(0.5f, S, b2Vec2(S, 0.0f), 0.0f);
+			body->CreateFixture(&shape, 5.0f);
+			shape.SetAsBox(0.5f, S, b2Vec2(-S, 0.0f), 0.0f);
+			body->CreateFixture(&shape, 5.0f);
+			shape.SetAsBox(S, 0.5f, b2Vec2(0.0f, S), 0.0f);
+			body->CreateFixture(&shape, 5.0f);
+			shape.SetAsBox(S, 0.5f, b2Vec2(0.0f, -S), 0.0f);
+			body->CreateFixture(&shape, 5.0f);
+
+			b2RevoluteJointDef jd;
+			jd.bodyA = ground;
+			jd.bodyB = body;
+			jd.localAnchorA.Set(x0, S);
+			jd.localAnchorB.Set(0.0f, 0.0f);
+			jd.referenceAngle = 0.0f;
+			jd.motorSpeed = 0.05f * b2_pi;
+			jd.maxMotorTorque = 1e8f;
+			jd.enableMotor = true;
+			b2Joint* joint = w->CreateJoint(&jd);
+			if (t == 0) s.joint = joint;
+		}
+		b2PolygonShape box;
+		box.SetAsBox(0.125f, 0.125f);
+		float start = -0.5f * pitch * (float)(n - 1);
+		for (int i = 0; i < n; ++i)
+		{
+			for (int j = 0; j < n; ++j)
+			{
+				b2BodyDef bd;
+				bd.type = b2_dynamicBody;
+				bd.position.Set(x0 + start + pitch * (float)j, S + start + pitch * (float)i);
+				b2Body* body = AddBody(s, w, bd);
+				body->CreateFixture(&box, 1.0f);
+			}
 		}
 	}
 }
@@ -1538,7 +1547,7 @@ inline void BuildScene(Scene& s, b2World* w, const SceneParams& p)
 	{
 	case e_helloWorld: BuildHelloWorld(s, w); break;
 	case e_pyramid: BuildPyramid(s, w, p.p0, p.p1, (int)p.f0, p.f1 >= 2.0f ? (int)p.f1 : 1); break;
-	case e_tumbler: BuildTumbler(s, w, p.p0, p.f0); break;
+	case e_tumbler: BuildTumbler(s, w, p.p0, p.f0, p.p1); break;
 	case e_field: BuildField(s, w, p.p0, p.p1, p.f0, p.f1, p.seed); break;
 	case e_piles: BuildPiles(s, w, p.p0, p.p1, p.seed); break;
 	case e_rain: BuildRain(s, w, p.p0, p.seed); break;
