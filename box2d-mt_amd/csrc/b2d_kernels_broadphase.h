@@ -692,7 +692,14 @@ __global__ __launch_bounds__(256) void k_create_contacts(DW W, const uint64_t* k
 		const int bodyA = W.p_body[pA], bodyB = W.p_body[pB];
 		const bool sensor = ((W.p_filter1[pA] | W.p_filter1[pB]) & PF_SENSOR) != 0;
 		uint32_t flags = CF_ENABLED | (sensor ? CF_SENSOR : 0u);
-		if (isToiCandidate(W, pA, pB, bodyA, bodyB)) flags |= CF_TOI_CANDIDATE;
+		if (isToiCandidate(W, pA, pB, bodyA, bodyB))
+		{
+			flags |= CF_TOI_CANDIDATE;
+			// (listed for k_toi_order_create: few or none of an update's new contacts are TOI candidates as a rule - none of the
+			// Tumbler's 150 000 per step - and one workgroup ballot-ranking all of them to find that out was 94 us of its step)
+			const int k = atomicAdd(&S->c.nNewToiCand, 1);
+			if (k < TOI_NEW_LIST_MAX) W.toiNewList[k] = dst;
+		}
 		float2 mA = W.p_mat[pA], mB = W.p_mat[pB];
 		// b2MixFriction / b2MixRestitution (b2Contact.h:40-50)
 		float friction = b2dSqrt(mA.x * mB.x);
@@ -741,7 +748,30 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 	DState* S = W.st;
 	const bool blocked = createBlocked(W, S, smallPath);
 	const int nNew = blocked ? 0 : S->c.nNewContacts;
-	if (nNew > 0)
+	const int nCand = blocked ? 0 : S->c.nNewToiCand; // (counted and listed by k_create_contacts)
+	if (nNew > 0 && nCand > 0 && nCand <= TOI_NEW_LIST_MAX)
+	{
+		// the candidates among the new contacts take their slots in creation order = index order: rank by index (the list is in
+		// the order of the atomics that filled it)
+		__shared__ int s_idx[TOI_NEW_LIST_MAX];
+		const ContactArrays& C = W.ca[S->cur];
+		const int tid = (int)threadIdx.x;
+		const int count0 = S->c.nToiOrder;
+		const int mine = tid < nCand ? W.toiNewList[tid] : 0x7fffffff;
+		s_idx[tid] = mine;
+		__syncthreads();
+		if (tid < nCand)
+		{
+			int rank = 0;
+			for (int k = 0; k < nCand; ++k) rank += s_idx[k] < mine ? 1 : 0;
+			const int slot = count0 + rank;
+			C.mgr[mine] = slot;
+			W.toiPos2c[slot] = mine;
+		}
+		__syncthreads();
+		if (tid == 0) S->c.nToiOrder = count0 + nCand;
+	}
+	else if (nNew > 0 && nCand > 0)
 	{
 		const int base = S->c.nContacts;
 		const int cap = W.capContacts;
@@ -791,6 +821,7 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 			S->c.nContacts = S->c.nContacts + S->c.nNewContacts;
 			S->c.nMoves = 0;
 		}
+		S->c.nNewToiCand = 0;
 	}
 }
 

@@ -639,6 +639,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.cellExtBits = 0;
 		c.nEvents = 0;
 		c.nToiList = 0;
+		c.nNewToiCand = 0;
 		c.nToiEvents = 0;
 		c.nToiCalls = 0;
 		c.toiBase = 0;

@@ -273,9 +273,13 @@ __global__ __launch_bounds__(256) void k_island_union(DW W)
 		const int pb = __hip_atomic_load(&W.parent[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		bool nsA = (bfA & BF_TYPE_MASK) != BT_STATIC;
 		bool nsB = (bfB & BF_TYPE_MASK) != BT_STATIC;
-		if (nsA) atomicAdd(&W.deg[ids.z], 1);
-		if (nsB) atomicAdd(&W.deg[ids.w], 1);
+		// (the count a body's atomic returns is the contact's place in the body's adjacency segment: k_island_edges fills the
+		// segments with plain stores - for every body, large islands included: k_color_masks walks them)
+		int2 slot = make_int2(-1, -1);
+		if (nsA) slot.x = atomicAdd(&W.deg[ids.z], 1);
+		if (nsB) slot.y = atomicAdd(&W.deg[ids.w], 1);
 		if (nsA && nsB) ufUnionFrom(W.parent, ids.z, ids.w, pa, pb);
+		W.adjSlot[i] = slot;
 	}
 	// joints connect bodies too (b2World.cpp:1292-1318)
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
@@ -570,10 +574,13 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub)
 			nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
 			if (nsA || nsB) tier = W.rootIsland[W.parent[nsA ? ids.z : ids.w]];
 		}
-		if (tier == ROOT_SMALL)
+		if (nsA || nsB)
 		{
-			if (nsA) W.adj[W.adjStart[ids.z] + atomicAdd(&W.adjCursor[ids.z], 1)] = i;
-			if (nsB) W.adj[W.adjStart[ids.w] + atomicAdd(&W.adjCursor[ids.w], 1)] = i;
+			// every body's solid contacts, grouped by body (the places were handed out by k_island_union's degree count): the DFS
+			// of the small islands and the colour masks of all bodies read them
+			const int2 slot = W.adjSlot[i];
+			if (nsA) W.adj[W.adjStart[ids.z] + slot.x] = i;
+			if (nsB) W.adj[W.adjStart[ids.w] + slot.y] = i;
 		}
 		// the large islands' contact list: one cursor for the whole world - a slot per workgroup and iteration, not per wave
 		// (the settled Tumbler: 32 000 atomics on that word, 200 us; b2d_wave.h)
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(64) void k_island_dfs(DW W)
 			W.si_lastLevel[slot] = 0;
 			++nb;
 			const int s = W.adjStart[b];
-			const int e = s + W.adjCursor[b];
+			const int e = s + W.deg[b];
 			// the contact list is newest first (b2ContactManager.cpp:531-553) == descending index
 			for (int k = s + 1; k < e; ++k)
 			{

@@ -201,16 +201,9 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			C.color[i] = -1;
 			continue;
 		}
-		if (nsA)
-		{
-			unsigned long long old = atomicOr((unsigned long long*)&W.bodyColorMask[ids.z], bit);
-			if (old & bit) bad = 1;
-		}
-		if (nsB)
-		{
-			unsigned long long old = atomicOr((unsigned long long*)&W.bodyColorMask[ids.w], bit);
-			if (old & bit) bad = 1;
-		}
+		// (the reservation on the bodies - DW::bodyColorMask - is made body by body, by k_color_masks behind this kernel: two
+		// returning 64-bit atomics per touching contact here were 800 000 on the 50 086-box pyramid and 740 000 on the Tumbler,
+		// served at the memory side's ~8 per ns - most of this kernel's 115 - 145 us)
 	}
 	// (2) census of the large-island constraints by colour
 	const int n = S->c.nLContacts;
@@ -353,6 +346,40 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			if (e > 0) atomicAdd(&W.blkBodyCount[e - 1], 1);
 		}
 	}
+}
+
+// The colours reserved on every body: the OR of the colours its solid contacts own (k_color_check has just voided what may not
+// be kept), read from the body's adjacency segment and stored with a plain store. Two contacts of one body with the same
+// colour -> Counters::needRecolor, as the returning atomics of round 4's k_color_check found them. (A touching contact that
+// a PreSolve switched off for this step is not solid: it keeps its colour but reserves nothing this step; should a new
+// contact take that colour meanwhile, the clash is found here next step and the island is coloured afresh.)
+__global__ __launch_bounds__(256) void k_color_masks(DW W)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	int bad = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		if ((W.b_flags[i] & BF_TYPE_MASK) == BT_STATIC) continue;
+		const int d = W.deg[i];
+		unsigned long long mask = 0ull;
+		// (a hub's constraints own no colour: k_color_check keeps them colourless)
+		if (d > 0 && d <= HUB_DEGREE)
+		{
+			const int s = W.adjStart[i];
+			for (int k = 0; k < d; ++k)
+			{
+				const int col = C.color[W.adj[s + k]];
+				if (col < 0 || col >= MAX_COLORS || col == HUB_COLOR) continue;
+				const unsigned long long bit = 1ull << col;
+				if (mask & bit) bad = 1;
+				mask |= bit;
+			}
+		}
+		W.bodyColorMask[i] = mask;
+	}
+	if (bad) atomicOr(&S->c.needRecolor, 1);
 }
 
 __global__ __launch_bounds__(256) void k_color_claim(DW W)

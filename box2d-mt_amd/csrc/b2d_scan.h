@@ -10,7 +10,9 @@
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 4
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
-#define SCAN_CHAIN_MAX_TILES 256 // single-pass scan up to 256 K elements, three kernels beyond
+#define SCAN_CHAIN_MAX_TILES 256 // single-pass scan up to 256 tiles: 256 K elements in tiles of 1 024, 1 M in tiles of 4 096; three kernels beyond
+#define SCAN_ITEMS_WIDE 16
+#define SCAN_TILE_WIDE (SCAN_THREADS * SCAN_ITEMS_WIDE)
 
 __device__ __forceinline__ int scanAdd(int a, int b) { return a + b; }
 __device__ __forceinline__ int4 scanAdd(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -168,15 +170,19 @@ __device__ __forceinline__ int4 scanWaveSum(int4 v)
 #define SCAN_SPIN_MAX (1u << 23)
 #define SCAN_ABORT_BIT 256
 
-template <typename T>
+// ITEMS per thread: 4 (tiles of 1 024 elements) up to 256 K elements; 16 (tiles of 4 096) up to 1 M - the look-back is a chain
+// over the TILES, so a million-element scan (the body and grid tables of BASELINE config 5, the tables of a rank of a sharded
+// world) is as short a chain as a 256 K one and still one launch instead of three.
+template <typename T, int ITEMS>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict__ in, T* __restrict__ out, T* work, int* flags, int cap, const int* nPtr, unsigned epoch,
 	int* abortWord)
 {
+	constexpr int TILE = SCAN_THREADS * ITEMS;
 	__shared__ T lds[2 * SCAN_THREADS];
 	__shared__ T s_prefix;
 	const int n = *nPtr;
 	const int tile = blockIdx.x;
-	const int base = tile * SCAN_TILE;
+	const int base = tile * TILE;
 	if (n == 0)
 	{
 		if (tile == 0 && threadIdx.x == 0)
@@ -188,12 +194,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 		return;
 	}
 	if (base >= n) return;
-	T v[SCAN_ITEMS];
+	T v[ITEMS];
 	T sum;
 	scanZero(sum);
-	for (int k = 0; k < SCAN_ITEMS; ++k)
+	for (int k = 0; k < ITEMS; ++k)
 	{
-		const int i = base + threadIdx.x * SCAN_ITEMS + k;
+		const int i = base + threadIdx.x * ITEMS + k;
 		scanZero(v[k]);
 		if (i < n) v[k] = in[i];
 		sum = scanAdd(sum, v[k]);
@@ -259,9 +265,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const T* __restrict
 	}
 	__syncthreads();
 	T run = scanAdd(s_prefix, excl);
-	for (int k = 0; k < SCAN_ITEMS; ++k)
+	for (int k = 0; k < ITEMS; ++k)
 	{
-		const int i = base + threadIdx.x * SCAN_ITEMS + k;
+		const int i = base + threadIdx.x * ITEMS + k;
 		if (i < n) out[i] = run;
 		run = scanAdd(run, v[k]);
 		if (i == n - 1) out[n] = run;
@@ -286,9 +292,10 @@ static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, 
 	int* flags = sf.words;
 	int blocks = (capN + SCAN_TILE - 1) / SCAN_TILE;
 	if (blocks < 1) blocks = 1;
+	const int blocksWide = (capN + SCAN_TILE_WIDE - 1) / SCAN_TILE_WIDE;
 	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
 	(void)hipStreamIsCapturing(stream, &capturing);
-	if (capturing != hipStreamCaptureStatusNone || blocks > SCAN_CHAIN_MAX_TILES)
+	if (capturing != hipStreamCaptureStatusNone || blocksWide > SCAN_CHAIN_MAX_TILES)
 	{
 		// a captured launch would replay its epoch, and past a few hundred tiles the look-back chain costs more than the two
 		// launches it saves (1.4 M elements: 25 us against 15): the three-kernel form (reduce, scan of the tile sums, final)
@@ -303,7 +310,10 @@ static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, 
 		sf.epoch = 0u;
 	}
 	const unsigned epoch = ++sf.epoch;
-	hipLaunchKernelGGL(k_scan_chain<T>, dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, flags, blocks + 4, nPtr, epoch, sf.abortWord);
+	if (blocks <= SCAN_CHAIN_MAX_TILES)
+		hipLaunchKernelGGL((k_scan_chain<T, SCAN_ITEMS>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, in, out, work, flags, blocks + 4, nPtr, epoch, sf.abortWord);
+	else
+		hipLaunchKernelGGL((k_scan_chain<T, SCAN_ITEMS_WIDE>), dim3(blocksWide), dim3(SCAN_THREADS), 0, stream, in, out, work, flags, blocksWide + 4, nPtr, epoch, sf.abortWord);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@
 #define HUB_COLOR (MAX_COLORS - 1) // row group of the hub constraints
 #define CENSUS_WG_MAX_BODIES 16384 // large-island bodies up to this many are grouped by block by k_block_census itself (one workgroup)
 #define COLOR_SMALL_MAX 4096     // uncoloured constraints up to this many are coloured by one workgroup without a host round trip
+#define TOI_NEW_LIST_MAX 1024     // new TOI candidates of one pair update up to this many are ranked from a list (k_toi_order_create)
 #define COUNT_RANK_MAX 4096      // new-pair sets up to this size are ranked by counting, above by radix sort
 #define SHARD_BIG_BODIES 4096    // islands above this size are dealt over the ranks one by one (in root-id order), smaller ones by a hash of their root
 #define SHARD_BIG_MAX 1024       // ... at most this many per step (more: they fall back to the hash)
@@ -132,6 +133,7 @@ struct Counters
 	int toiOverflow;     // bit0 candidates, bit1 moves, bit2 pairs, bit3 recompute list, bit4 TOI list
 	int nToiOrder;       // persistent: TOI-candidate contacts alive (b2ContactManager::m_toiCount)
 	int nToiDestroy;     // TOI candidates destroyed by the running collide
+	int nNewToiCand;     // TOI candidates among the contacts the running pair update creates (k_create_contacts lists them in DW::toiNewList)
 	int toiUnsafe;       // the parallel TOI chains met a case only the serial event loop reproduces (bits: b2d_kernels_toi_chains.h)
 	int nToiGroups;      // dynamic bodies with a pending impact
 	int nToiMoved;       // proxies re-inserted by the TOI chains / components
@@ -329,6 +331,7 @@ struct DW
 	int* adjStart;       // exclusive scan of deg
 	int* adjCursor;
 	int* adj;            // contact indices grouped by body
+	int2* adjSlot;       // per contact: its place in the adjacency segments of its two bodies (k_island_union), -1 for a static body
 	// small islands
 	int* si_root;        // [nSIslands]
 	int* si_bodyStart;   // [nSIslands + 1]
@@ -446,6 +449,7 @@ struct DW
 	int* toiList;        // contact indices whose cached TOI is < 1
 	int* toiPos2c;       // slot of the reference's TOI partition -> contact index (inverse of ContactArrays::mgr)
 	int* toiDestroyList; // TOI candidates marked for destruction by collide
+	int* toiNewList;     // TOI candidates among the new contacts of the running pair update (contact indices, at most TOI_NEW_LIST_MAX listed)
 	int* b_toiGroup;     // per body: chain index + 1 while it owns a TOI chain
 	int* toiGroups;      // dynamic bodies with a pending impact
 	// TOI components (b2d_kernels_toi_domains.h): connected components of {non-static bodies, contacts between them}

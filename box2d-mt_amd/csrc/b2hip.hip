@@ -183,7 +183,7 @@ struct b2hip_world
 	DevArray<int> p_body, p_shape, p_key, p_filter1;
 	DevArray<uint32_t> p_filter0;
 	DevArray<float2> p_mat;
-	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, b_toiGroup, toiGroups, toiGroupCount, toiGroupList, toiMoved, toiNew, toiParent, toiDomOf, toiDomRoot, toiDomCount, toiDomBase, toiDomFill, toiDomList, toiDomFailed, toiDomEvents;
+	DevArray<int> b_proxyHead, p_next, toiList, toiPos2c, toiDestroyList, toiNewList, b_toiGroup, toiGroups, toiGroupCount, toiGroupList, toiMoved, toiNew, toiParent, toiDomOf, toiDomRoot, toiDomCount, toiDomBase, toiDomFill, toiDomList, toiDomFailed, toiDomEvents;
 	DevArray<float4> toiHull;
 	DevArray<float4> snapBody, snapFat;
 	DevArray<ShapeRec> d_shapes;
@@ -205,6 +205,7 @@ struct b2hip_world
 	size_t upGears = 0;
 	std::vector<std::pair<int, int> > jointEdits;    // (joint, 1 = also clear the limit impulse, 2 = also the anchors / offsets): members changed by a setter
 	DevArray<int> parent, rootSeed, rootBodies, rootContacts, rootJoints, rootIsland, deg, adjStart, adjCursor, adj;
+	DevArray<int2> adjSlot;
 	DevArray<int4> rootScanIn, rootScanOut;
 	DevArray<int> si_root, si_bodyStart, si_contactStart, si_wStart, si_maxLevel, si_bodies, si_contacts, si_level,
 		si_stack, si_lastLevel, b_slot, b_island, chunkFirst;
@@ -329,8 +330,14 @@ struct b2hip_world
 	                             // workgroup ~4.5 us - the same chain of dependent loads a launch pays - so a colour of 8 000
 	                             // rows is 9 rounds = 40 us against 5.8 us as a launch of its own (tail colours up to 8 192 rows:
 	                             // 4.94 ms per step; none: 3.87; round 4's launches: 4.57)
+	int recolorSlack = 2;        // colour afresh when the colours in use exceed the last fresh colouring's by more than this (B2HIP_RECOLOR_SLACK; -1: every 64th step as in round 4)
+	int freshColors = 0;         // colours the last colouring from scratch of a partition-less world needed (0: none yet); in the snapshot's hints
+	bool freshColorsPending = false;
 	bool restFlow = true;        // the small colours of a sweep as data flow per body in one launch (k_large_rest; B2HIP_NO_REST=1: launches / tail)
-	int restRowsMax = 16384;     // ... the highest colours that hold at most this many rows together (B2HIP_REST_ROWS)
+	int restRowsMax = 65536;     // ... the highest colours that hold at most this many rows together (B2HIP_REST_ROWS). Measured on the
+	                             // settled Tumbler (profiles/r05_i_rest_rows_sweep.txt: the solver family per step, 21 colours): none 2.06 ms /
+	                             // 260 launches per step; 16 384 rows 2.01 / 236; 50 000 1.89 / 188; 80 000 1.86 / 164; 180 000 1.88 / 116 -
+	                             // a hop costs more the more lanes poll
 	int lastTailFirst = 0, lastRestFirst = 0, lastSweepLaunches = 0; // diagnostics of the last step
 	long long launchCount = 0;   // kernels launched on the main stream so far (LAUNCH)
 	long long familyLaunchesAtStart = 0; int familyLaunches = 0; // ... by the large-island solver family in the last step (timing mode 5)
@@ -860,7 +867,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		}
 	}
 	ENS(parent, nb); ENS(rootSeed, nb); ENS(rootBodies, nb); ENS(rootContacts, nb); ENS(rootJoints, nb); ENS(rootIsland, nb);
-	ENS(deg, nb + 1); ENS(adjStart, nb + 2); ENS(adjCursor, nb); ENS(adj, 2 * cc);
+	ENS(deg, nb + 1); ENS(adjStart, nb + 2); ENS(adjCursor, nb); ENS(adj, 2 * cc); ENS(adjSlot, cc);
 	ENS(rootScanIn, nb + 1); ENS(rootScanOut, nb + 2);
 	ENS(si_root, nb + 1); ENS(si_bodyStart, nb + 2); ENS(si_contactStart, nb + 2); ENS(si_wStart, nb + 2); ENS(si_maxLevel, nb + 1);
 	ENS(si_bodies, nb); ENS(si_contacts, cc); ENS(si_level, cc); ENS(si_stack, nb); ENS(si_lastLevel, nb);
@@ -885,7 +892,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(scanTmp4, 3 * (maxScanN / SCAN_TILE + 8));
 	ENS(scanFlags, std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 8);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
-	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc);
+	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc); ENS(toiNewList, TOI_NEW_LIST_MAX);
 	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiNew, 8 * TOI_NEWPAIR_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
 	{
 		// listener bridge buffers: contact-sized only while the callback that needs them is installed
@@ -945,8 +952,9 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	// number of hub waves or the serial hub sweep means k_large_hub.
 	w->sweepEnd = !(getenv("B2HIP_NO_SWEEP_END") && atoi(getenv("B2HIP_NO_SWEEP_END"))) && !getenv("B2HIP_HUB_WAVES");
 	w->sweepTail = w->sweepEnd && !(getenv("B2HIP_NO_TAIL") && atoi(getenv("B2HIP_NO_TAIL")));
+	w->recolorSlack = getenv("B2HIP_RECOLOR_SLACK") ? atoi(getenv("B2HIP_RECOLOR_SLACK")) : 2;
 	w->restFlow = w->sweepEnd && !(getenv("B2HIP_NO_REST") && atoi(getenv("B2HIP_NO_REST")));
-	w->restRowsMax = getenv("B2HIP_REST_ROWS") ? std::min(atoi(getenv("B2HIP_REST_ROWS")), REST_ROWS_MAX - COLOR_SMALL_MAX) : 16384;
+	w->restRowsMax = getenv("B2HIP_REST_ROWS") ? std::min(atoi(getenv("B2HIP_REST_ROWS")), REST_ROWS_MAX - COLOR_SMALL_MAX) : 65536;
 	w->tailRowsMax = getenv("B2HIP_TAIL_ROWS") ? atoi(getenv("B2HIP_TAIL_ROWS")) : SWEEP_END_LANES;
 	d.hubWide = (w->sweepEnd && !d.hubSerial && !(getenv("B2HIP_HUB_WIDE") && atoi(getenv("B2HIP_HUB_WIDE")) == 0)) ? 1 : 0;
 	if (const char* e = getenv("B2HIP_SMALL_MAX_W")) d.smallMaxW = std::max(1, std::min((int)SMALL_ISLAND_MAX_W, atoi(e)));
@@ -973,7 +981,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.rootJointCursor = w->rootJointCursor.p; d.lj_list = w->lj_list.p; d.rootJointOkay = w->rootJointOkay.p;
 	d.parent = w->parent.p; d.rootSeed = w->rootSeed.p; d.rootBodies = w->rootBodies.p; d.rootContacts = w->rootContacts.p;
 	d.rootJoints = w->rootJoints.p; d.rootScanIn = w->rootScanIn.p; d.rootScanOut = w->rootScanOut.p; d.rootIsland = w->rootIsland.p;
-	d.deg = w->deg.p; d.adjStart = w->adjStart.p; d.adjCursor = w->adjCursor.p; d.adj = w->adj.p;
+	d.deg = w->deg.p; d.adjStart = w->adjStart.p; d.adjCursor = w->adjCursor.p; d.adj = w->adj.p; d.adjSlot = w->adjSlot.p;
 	d.si_root = w->si_root.p; d.si_bodyStart = w->si_bodyStart.p; d.si_contactStart = w->si_contactStart.p; d.si_wStart = w->si_wStart.p;
 	d.si_maxLevel = w->si_maxLevel.p; d.si_bodies = w->si_bodies.p; d.si_contacts = w->si_contacts.p; d.si_level = w->si_level.p;
 	d.si_stack = w->si_stack.p; d.si_lastLevel = w->si_lastLevel.p; d.b_slot = w->b_slot.p; d.b_island = w->b_island.p;
@@ -989,7 +997,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.scanTmp = w->scanTmp.p; d.radixHist = w->radixHist.p; d.keepFlag = w->keepFlag.p; d.keepScan = w->keepScan.p;
 	d.stateOut = w->stateOut.p;
 	d.b_proxyHead = w->b_proxyHead.p; d.p_next = w->p_next.p; d.toiList = w->toiList.p;
-	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p;
+	d.toiPos2c = w->toiPos2c.p; d.toiDestroyList = w->toiDestroyList.p; d.toiNewList = w->toiNewList.p;
 	d.b_toiGroup = w->b_toiGroup.p; d.toiGroups = w->toiGroups.p; d.toiGroupCount = w->toiGroupCount.p; d.toiGroupList = w->toiGroupList.p; d.toiMoved = w->toiMoved.p; d.toiNew = w->toiNew.p; d.toiParent = w->toiParent.p; d.toiDomOf = w->toiDomOf.p; d.toiDomRoot = w->toiDomRoot.p; d.toiDomCount = w->toiDomCount.p; d.toiDomBase = w->toiDomBase.p; d.toiDomFill = w->toiDomFill.p; d.toiDomFailed = w->toiDomFailed.p; d.toiDomEvents = w->toiDomEvents.p; d.toiDomList = w->toiDomList.p; d.toiHull = w->toiHull.p;
 	d.snapBody = w->snapBody.p; d.snapFat = w->snapFat.p;
 	d.b_blk1 = w->b_blk1.p; d.b_adopt = w->b_adopt.p; d.b_adoptStage = w->b_adoptStage.p; d.blkRows = w->blkRows.p; d.blkRowStart = w->blkRowStart.p; d.blkCursor = w->blkCursor.p; d.blkBodyCount = w->blkBodyCount.p; d.blkBodyCursor = w->blkBodyCursor.p;
@@ -1650,6 +1658,7 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	LAUNCH(w, k_part_assign, gridFor(d.nBodies), 256, d, vin, d.pairRank);
 	LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_color_masks, gridFor(d.nBodies), 256, d);
 	LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr);
 	return 0;
 }
@@ -1710,6 +1719,7 @@ static int phaseSolve(b2hip_world* w)
 		if (largeHint)
 		{
 			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_color_masks, gridFor(d.nBodies), 256, d);
 			LAUNCH(w, k_block_census, 1, 1024, d, pubBy == 1 ? w->d_pub : (DState*)nullptr);
 		}
 		if (pubBy == 3) LAUNCH(w, k_publish_census, 1, 256, d, w->d_pub);
@@ -1738,6 +1748,7 @@ static int phaseSolve(b2hip_world* w)
 		{
 			// the first large island after a while: run what was skipped, look again
 			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_color_masks, gridFor(d.nBodies), 256, d);
 			LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr);
 			rc = readState(w);
 			if (rc) return rc;
@@ -1772,6 +1783,7 @@ static int phaseSolve(b2hip_world* w)
 			// the colour census again, under the one class (as after a new partition), then every colour afresh
 			LAUNCH(w, k_color_recheck_begin, gridFor(d.nBodies), 256, d);
 			LAUNCH(w, k_color_check, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_color_masks, gridFor(d.nBodies), 256, d);
 			LAUNCH(w, k_block_census, 1, 1024, d, (DState*)nullptr);
 			rc = readState(w);
 			if (rc) return rc;
@@ -1783,17 +1795,25 @@ static int phaseSolve(b2hip_world* w)
 		// Without a partition every colour is a launch of every sweep, and colours handed out one new contact at a time creep
 		// up (24 in use on the settled Tumbler where a colouring from scratch needs 19 - five colours are 0.3 ms of its step):
 		// every 64th step the island is coloured afresh.
+		// (round 5: ... if they HAVE crept up - more than two colours above what the last colouring from scratch needed; the
+		// top colours of a sweep are hops of k_large_rest now, ~2.5 us each, and a colouring from scratch is 5 ms of claim /
+		// resolve rounds with read-backs: the settled Tumbler's step 64, 128, ... took 9 - 11 ms against 4)
 		if (w->blocksTooBig && forceLarge != 2 && !w->noBlocks && c.nLIslands > 0)
 		{
 			if (w->recolorCountdown <= 0)
 			{
-				c.needRecolor = 1;
-				colorSmallQueued = false;
-				w->recolorCountdown = 64;
+				if (w->freshColors <= 0 || c.nColors > w->freshColors + w->recolorSlack)
+				{
+					c.needRecolor = 1;
+					colorSmallQueued = false;
+					w->freshColorsPending = true;
+					w->recolorCountdown = 64;
+				}
+				else w->recolorCountdown = 16;
 			}
 			w->recolorCountdown -= 1;
 		}
-		else w->recolorCountdown = 0;
+		else { w->recolorCountdown = 0; w->freshColors = 0; }
 	}
 	// (from the next step on: in islands with joints / hubs the constraints of such newcomers are swept in order instead)
 	w->serialOrphansNext = (forceLarge != 2 && !w->noBlocks && !w->noSweepBlocks && !w->blocksTooBig && c.nBlocks > 0 && (d.nJoints > 0 || c.maxDegree > HUB_DEGREE)) ? 1 : 0;
@@ -1993,6 +2013,7 @@ static int phaseSolve(b2hip_world* w)
 				if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
 				batch = 8;
 			}
+			if (w->freshColorsPending) { w->freshColors = nColors < 63 ? nColors : 63; w->freshColorsPending = false; }
 			}
 		}
 		if (!d.blockSort) LAUNCH(w, k_color_scan, 1, 1, d); // (segments by colour: the block solvers sort their rows themselves)
@@ -2905,7 +2926,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->jadjStart.release(); w->jadj.release(); w->rootJointStart.release(); w->rootJointCursor.release();
 	w->lj_list.release(); w->rootJointOkay.release();
 	w->parent.release(); w->rootSeed.release(); w->rootBodies.release(); w->rootContacts.release(); w->rootJoints.release();
-	w->rootIsland.release(); w->deg.release(); w->adjStart.release(); w->adjCursor.release(); w->adj.release();
+	w->rootIsland.release(); w->deg.release(); w->adjStart.release(); w->adjCursor.release(); w->adj.release(); w->adjSlot.release();
 	w->rootScanIn.release(); w->rootScanOut.release();
 	w->si_root.release(); w->si_bodyStart.release(); w->si_contactStart.release(); w->si_wStart.release(); w->si_maxLevel.release();
 	w->si_bodies.release(); w->si_contacts.release(); w->si_level.release(); w->si_stack.release(); w->si_lastLevel.release();
@@ -2913,7 +2934,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
 	w->bodyActive.release(); w->bodyRest.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release(); w->hubRowOf.release(); w->hubList.release(); w->hubDelta.release(); w->hubMeta.release(); w->hubFirst.release();
-	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release();
+	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release(); w->toiNewList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiNew.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
 	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
@@ -4965,9 +4986,9 @@ struct SnapHeader
 	uint32_t stateCount, cur;
 	int32_t nextNode, leafCount, lastContacts, newFixture;
 	float inv_dt0, cellSize;
-	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bit 1 blocksTooBig, bit 2 step incomplete (sub-stepping), bits 8..15 adoptSticky, 16..23 largeHintSteps, 24..30 recolorCountdown (what the next island build is told)
+	int32_t eventsOn, solverHints; // solverHints: bit 0 serialOrphansNext, bit 1 blocksTooBig, bit 2 step incomplete (sub-stepping), bits 3..7 + 31 freshColors, bits 8..15 adoptSticky, 16..23 largeHintSteps, 24..30 recolorCountdown (what the next island build is told)
 };
-const uint32_t kSnapVersion = 4;
+const uint32_t kSnapVersion = 5;
 const char kSnapMagic[8] = { 'B', '2', 'H', 'I', 'P', 'S', 'N', '1' };
 
 struct SnapWriter
@@ -5038,7 +5059,8 @@ int b2hip_save_snapshot(b2hip_world* w, void* buffer, size_t cap, size_t* needed
 	h.nextNode = w->nextNode; h.leafCount = w->leafCount; h.lastContacts = w->lastContacts; h.newFixture = w->newFixture ? 1 : 0;
 	h.inv_dt0 = w->inv_dt0; h.cellSize = w->dw.cellSize;
 	h.eventsOn = w->eventsOn ? 1 : 0;
-	h.solverHints = (w->serialOrphansNext ? 1 : 0) | (w->blocksTooBig ? 2 : 0) | (w->stepComplete ? 0 : 4) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16) | ((w->recolorCountdown & 0x7f) << 24);
+	h.solverHints = (w->serialOrphansNext ? 1 : 0) | (w->blocksTooBig ? 2 : 0) | (w->stepComplete ? 0 : 4) | ((w->adoptSticky & 0xff) << 8) | ((w->largeHintSteps & 0xff) << 16) | ((w->recolorCountdown & 0x7f) << 24) |
+		((w->freshColors & 0x1f) << 3) | (int32_t)(((uint32_t)(w->freshColors >> 5) & 1u) << 31); // (bits 3..7 and 31: freshColors, 0..63)
 	SnapWriter o;
 	o.host(&h, sizeof(h));
 	o.host(&w->def, sizeof(w->def));
@@ -5261,6 +5283,8 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	w->adoptSticky = (h.solverHints >> 8) & 0xff;
 	w->largeHintSteps = (h.solverHints >> 16) & 0xff;
 	w->recolorCountdown = (h.solverHints >> 24) & 0x7f;
+	w->freshColors = ((h.solverHints >> 3) & 0x1f) | ((int)(((uint32_t)h.solverHints >> 31) & 1u) << 5);
+	w->freshColorsPending = false;
 	w->adoptPasses = w->adoptSticky > 0;
 	rc = ensureCapacity(w, nC);
 	if (rc) return fail(rc);
@@ -5753,14 +5777,18 @@ static int spExchangePairs(b2hip_world* w, long long* totalPairs, int* straddlin
 			total += hdr[r][2];
 			strad += hdr[r][6];
 		}
-		if (overflowed)
+		// (creation is all or nothing, and the unsharded world's way out of a full contact array - the host grows it at the end of
+		// the step and runs the update again - does not exist for a sharded one: room for every candidate pair before anything
+		// is created; the contact structure is replicated, so every rank sees the same need)
+		const bool needContacts = (long long)w->lastContacts + total > (long long)d.capContacts;
+		if (overflowed || needContacts)
 		{
 			// A rank's search did not fit its pair buffer (a dense start: every proxy is new). The unsharded world recovers from
 			// that (growPairBuffers: size the buffer from the true count, clear the flag, search again) and so does this one: every
 			// rank reads the same headers, so all of them grow alike - room for the union - and all of them search again
 			// (findNewContacts repeats on 1; the collectives stay in step). ADVICE round 4.
 			w->pairCapHint = std::max(w->pairCapHint, 2 * (size_t)total + 4096);
-			rc = ensureCapacity(w, (size_t)w->lastContacts + 1024);
+			rc = ensureCapacity(w, (size_t)w->lastContacts + (size_t)total + 1024);
 			if (rc) return rc;
 			HIP_TRY(hipMemsetAsync(&w->d_state.p->c.overflow, 0, sizeof(int), w->stream));
 			w->spSendWiped = nullptr; // (this slab was filled and never imported: wiped again before the next export)
@@ -5778,6 +5806,7 @@ static int spExchangePairs(b2hip_world* w, long long* totalPairs, int* straddlin
 			rc = ensureCapacity(w, (size_t)w->lastContacts);
 			if (rc) return rc;
 		}
+
 		w->spPairsSent += hdr[d.shardRank][2];
 		*totalPairs = total;
 		*straddling = strad;

@@ -218,7 +218,9 @@ inline void BuildTumbler(Scene& s, b2World* w, int n, float S, int count = 1)
 	}
 	for (int t = 0; t < count; ++t)
 	{
-		const float x0 = (float)t * (2.0f * S + 4.0f);
+		// (a container's corners sweep a circle of radius sqrt(2) (S + 0.5): 3 S + 4 between the centres keeps even the fat AABBs
+		// of two revolving neighbours apart - no contact, no shared component, one container per rank for ever)
+		const float x0 = (float)t * (3.0f * S + 4.0f);
 		{
 			b2BodyDef bd;
 			bd.type = b2_dynamicBody;

@@ -1597,7 +1597,8 @@ static void gear_gather(b2o_world* w, const revolute_t* j, const pos_t* position
  * reference's (b2Island.cpp:184-396 solves them in island order): 1 greedy colouring by hashed priority (what the device's
  * coloured solver does), 2 bottom-up by contact height, 3 / 6 greedy colouring with a spatial priority, 4 the reference
  * order's own dependency levels wrapped modulo B2O_ORDER_D (flips about 1 / D of the pairwise precedences), 5 the same on
- * the bottom-up order. Result on Pyramid 141 at steps 245 / 300: DESIGN.md section 3. */
+ * the bottom-up order, 7 the reference's order inside the blocks of a spatial partition (cells of B2O_ORDER_D metres) and a
+ * coloured order on the cut constraints only. Result on Pyramid 141 at steps 245 / 300: DESIGN.md section 3. */
 static const b2o_world* exw;
 static float* exkey;
 static int ex_cmp(const void* a, const void* b)
@@ -1697,6 +1698,54 @@ static void ex_reorder(b2o_world* w, int* ic, int n, int mode, int D)
 		free(rank);
 		free(lev);
 		free(last);
+		for (int i = 0; i < n; ++i) idx[i] = i;
+	}
+	else if (mode == 7)
+	{
+		/* the reference's order INSIDE a block of a spatial partition, a coloured order only on the cut
+		 * constraints. Blocks = square cells of D metres (a body's block: the cell of its centre); a constraint is interior if
+		 * its non-static bodies share a block. Interior constraints of different blocks share no body, so "every block in the
+		 * reference's order" is the reference's order restricted to the interior constraints; the cut constraints follow, greedy
+		 * colours by hashed priority (the device's), colour classes ascending. */
+		const float G = (float)D;
+		float* pri = (float*)malloc(sizeof(float) * n);
+		int* cut = (int*)malloc(sizeof(int) * n);
+		int nCut = 0;
+		for (int i = 0; i < n; ++i)
+		{
+			const contact_t* c = &w->contacts[ic[i]];
+			const body_t* a = &w->bodies[c->bodyA];
+			const body_t* b = &w->bodies[c->bodyB];
+			cut[i] = 0;
+			if (a->type != 0 && b->type != 0)
+			{
+				const int ax = (int)floorf(a->c.x / G), ay = (int)floorf(a->c.y / G), bx = (int)floorf(b->c.x / G), by = (int)floorf(b->c.y / G);
+				cut[i] = ax != bx || ay != by;
+			}
+			nCut += cut[i];
+			pri[i] = (float)(((uint32_t)ic[i] * 2654435761u) >> 8);
+		}
+		exkey = pri;
+		qsort(idx, n, sizeof(int), ex_cmp);
+		uint64_t* used = (uint64_t*)calloc(w->nBodies, sizeof(uint64_t));
+		int maxc = 0;
+		for (int k = 0; k < n; ++k)
+		{
+			const int i = idx[k];
+			if (!cut[i]) continue;
+			const contact_t* c = &w->contacts[ic[i]];
+			const uint64_t m = used[c->bodyA] | used[c->bodyB];
+			int col = 0;
+			while (m & (1ull << col)) ++col;
+			used[c->bodyA] |= 1ull << col;
+			used[c->bodyB] |= 1ull << col;
+			key[i] = 1.0f + (float)col;
+			if (col > maxc) maxc = col;
+		}
+		for (int i = 0; i < n; ++i) if (!cut[i]) key[i] = (float)i / (float)(n + 1);
+		fprintf(stderr, "[ex] mode 7: blocks of %d m, %d of %d constraints cut, %d cut colours\n", D, nCut, n, maxc + 1);
+		free(used); free(pri); free(cut);
+		exkey = key;
 		for (int i = 0; i < n; ++i) idx[i] = i;
 	}
 	qsort(idx, n, sizeof(int), ex_cmp);

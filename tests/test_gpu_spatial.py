@@ -28,7 +28,7 @@ CCD = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
 PLAIN = bh.F_SLEEP | bh.F_WARM
 
 
-def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, seed=3, compare=True, full=True):
+def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, seed=3, compare=True, full=True, f0=0.0, f1=0.0):
     """full: every rank holds the current row of every body (B2HIP_SHARD_FULL_ROWS=1) and is compared whole; else the lean
     exchange of the default - a rank answers for the bodies it owns, the world is the union of the owners' rows."""
     if exact:
@@ -40,8 +40,8 @@ def run_sharded(amd, scene, p0, p1, ranks, steps, flags, exact, monkeypatch, see
     else:
         monkeypatch.delenv("B2HIP_SHARD_FULL_ROWS", raising=False)
     L = b2hip.lib()
-    ref = amd.world(scene, p0, p1, seed=seed, flags=flags)
-    ws = [amd.world(scene, p0, p1, seed=seed, flags=flags) for _ in range(ranks)]
+    ref = amd.world(scene, p0, p1, f0, f1, seed=seed, flags=flags)
+    ws = [amd.world(scene, p0, p1, f0, f1, seed=seed, flags=flags) for _ in range(ranks)]
     sr = SpatialRanks(L, [(w, w.device_world()) for w in ws])
     for s in range(steps):
         ref.step(1)
@@ -240,3 +240,15 @@ def test_config_4_over_4_ranks_at_full_size_against_the_reference(amd, monkeypat
         assert st.migrated_bodies == 0
     for w in ws:
         w.close()
+
+
+def test_a_dense_start_grows_the_pair_buffer_of_a_sharded_world_too(amd, monkeypatch):
+    """1 400 bodies and 450 bullets crammed into a 70 x 70 arena - the first pair update of every rank finds
+    several times more candidate pairs than its buffer was sized for. The unsharded world grows the buffer and searches again
+    (tests/test_gpu_edge_cases.py::test_dense_start_grows_the_pair_buffer); a spatially sharded world used to fail its step with
+    a capacity error. Now every rank reads the overflow in the slab headers, all grow alike and all search again: the same
+    bits as the unsharded world, exact-order mode (the islands are huge)."""
+    # (continuous physics off: with it the first TOI phase of this arena creates more contacts inside sub-steps than the
+    #  4 096 a sharded world merges per phase - SP_TAIL_MAX, a stated limit that is reported as a capacity error)
+    stats, nonstatic, contacts, _ = run_sharded(amd, bh.FIELD, 1406, 456, 2, 3, PLAIN, True, monkeypatch, seed=2623, f0=35.0, f1=2.0)
+    assert contacts > 15000
