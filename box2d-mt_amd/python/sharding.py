@@ -138,6 +138,9 @@ class SpatialWorld:
             if int(ok.item()) == self.size:
                 self.connected = True
             elif int(ok.item()) == 0:
+                # (loud: from here on "RCCL saw N ranks" is false for this world - the exchange is an all-gather of HOST memory)
+                import sys
+                sys.stderr.write("sharding.SpatialWorld: b2hip_shard_connect failed on every rank (%s): the exchange falls back to torch.distributed over gloo - NOT RCCL\n" % why)
                 self._group = dist.new_group(backend="gloo")
             else:
                 raise RuntimeError("b2hip_shard_connect failed on some ranks only: %s" % why)
