@@ -389,9 +389,9 @@ def main():
         """The solver of the timed workload: the launch-per-colour family (mode 5) where that is what runs, else the dominant
         resident solver kernel (mode 1: k_solve_blocks on the pyramid)."""
         try:
-            roof = kernel_roofline(hipL, dev, lambda: step_world(1), 5, ROOF_STEPS)
-            if roof is None:
-                roof = kernel_roofline(hipL, dev, lambda: step_world(1), 1, ROOF_STEPS)
+            # (the mode follows the WORKLOAD, never the outcome: every rank of a sharded world must take the same number of steps -
+            # a fallback to another mode on a rank whose family happened to be empty left the ranks out of step, round 5)
+            roof = kernel_roofline(hipL, dev, lambda: step_world(1), 5 if args.workload == "tumbler" else 1, ROOF_STEPS)
             ctr = b2hip.Counters()
             hipL.b2hip_get_counters(dev, C.byref(ctr))
             if roof is not None:

@@ -709,7 +709,9 @@ int b2hip_step_end(b2hip_world* w)
 	if (int rc = checkUsable(w, "b2hip_step_end", false)) return rc;
 	if (!w->stepActive) return setError(B2HIP_ERR_INVALID, "b2hip_step_end outside a step");
 	DEVICE_GUARD(w);
-	return stepFailed(w, stepEndImpl(w));
+	const int rc = stepFailed(w, stepEndImpl(w));
+	if (w->traceLaunches) { fprintf(stderr, "[b2hip] host: step end returns %d\n", rc); fflush(stderr); }
+	return rc;
 }
 
 int b2hip_step(b2hip_world* w, float dt, int velocity_iterations, int position_iterations)

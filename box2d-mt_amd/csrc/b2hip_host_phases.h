@@ -1233,7 +1233,9 @@ static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 	const int rowMode = shadowValid(w) ? 2 : 1;
 	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq,
 		lazy ? END_STEP_LAZY : skipRowsIfRedo ? END_STEP_SKIP_IF_REDO : END_STEP_FULL, w->stateOut.p, rowMode);
+	if (w->traceLaunches) { fprintf(stderr, "[b2hip] host: awaiting the read-back %d\n", w->stateSeq); fflush(stderr); }
 	const int rc = awaitState(w, nb);
+	if (w->traceLaunches) { fprintf(stderr, "[b2hip] host: read-back %d arrived (rc %d)\n", w->stateSeq, rc); fflush(stderr); }
 	// (rowsSkipped: 0 - the rows were stored; the shadow of a full write is valid from here on)
 	if (rc == 0 && rowMode == 1 && w->h_dstate->c.rowsSkipped == 0) shadowWritten(w);
 	return rc;

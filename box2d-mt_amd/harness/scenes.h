@@ -18,6 +18,7 @@
 
 #include "Box2D/Box2D.h"
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace b2h
@@ -220,7 +221,9 @@ inline void BuildTumbler(Scene& s, b2World* w, int n, float S, int count = 1)
 	{
 		// (a container's corners sweep a circle of radius sqrt(2) (S + 0.5): 3 S + 4 between the centres keeps even the fat AABBs
 		// of two revolving neighbours apart - no contact, no shared component, one container per rank for ever)
-		const float x0 = (float)t * (3.0f * S + 4.0f);
+		// (B2H_TUMBLER_CLOSE=1: 2 S + 4, close enough for the fat AABBs of two revolving neighbours to overlap - a test of
+		// components that merge over an ownership boundary, tests/test_gpu_spatial.py)
+		const float x0 = (float)t * ((getenv("B2H_TUMBLER_CLOSE") ? 2.0f : 3.0f) * S + 4.0f);
 		{
 			b2BodyDef bd;
 			bd.type = b2_dynamicBody;

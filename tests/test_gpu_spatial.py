@@ -252,3 +252,14 @@ def test_a_dense_start_grows_the_pair_buffer_of_a_sharded_world_too(amd, monkeyp
     #  4 096 a sharded world merges per phase - SP_TAIL_MAX, a stated limit that is reported as a capacity error)
     stats, nonstatic, contacts, _ = run_sharded(amd, bh.FIELD, 1406, 456, 2, 3, PLAIN, True, monkeypatch, seed=2623, f0=35.0, f1=2.0)
     assert contacts > 15000
+
+
+def test_two_revolving_containers_that_come_to_touch_merge_under_one_owner(amd, monkeypatch):
+    """Two Tumbler containers 2 S + 4 apart (B2H_TUMBLER_CLOSE=1; bench.py's N > 1 world keeps them 3 S + 4 apart): after ~55
+    steps their fat AABBs overlap, a contact between the two hub bodies exists, and the two components - each a container on a
+    motor joint with its boxes - merge under one owner with everything they hold. Exact-order mode: every rank's world equals
+    the unsharded one bit for bit through the merge, and one rank ends up owning every body."""
+    monkeypatch.setenv("B2H_TUMBLER_CLOSE", "1")
+    stats, nonstatic, contacts, _ = run_sharded(amd, bh.TUMBLER, 12, 2, 2, 150, PLAIN, True, monkeypatch)
+    assert sorted(st.owned_bodies for st in stats) == [0, nonstatic], [st.owned_bodies for st in stats]
+    assert stats[0].migrated_bodies > 0
