@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 		S->c.posItersLarge = 0;
 		S->c.maxSmallW = 0;
 		S->c.maxDegree = 0;
+		S->c.maxDegreePlain = 0;
 		W.hubMeta[0] = 0ull; // (the primary hub of this step: k_island_flatten)
 		S->c.hubEpoch += 1;
 		S->c.chunkW = SMALL_ISLAND_MAX_W;
@@ -320,6 +321,11 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 				const int o = __shfl_xor(dg, off), ow = __shfl_xor(who, off);
 				if (o > dg || (o == dg && ow > who)) { dg = o; who = ow; }
 			}
+			// (... and the busiest body below the hub threshold: what a colouring cannot go under - the host's measure of how far
+			// the colours in use have crept, b2hip_host_phases.h)
+			int dgPlain = valid && W.deg[i] <= HUB_DEGREE ? W.deg[i] : 0;
+			for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(dgPlain, off); dgPlain = o > dgPlain ? o : dgPlain; }
+			if (waveLane() == 0 && dgPlain > 0) atomicMaxIfAbove(&W.st->c.maxDegreePlain, dgPlain);
 			if (waveLane() == 0 && dg > 0)
 			{
 				atomicMaxIfAbove(&W.st->c.maxDegree, dg);

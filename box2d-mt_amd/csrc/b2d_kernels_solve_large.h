@@ -696,9 +696,11 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W, int restFirst)
 		if (valid && p >= 0)
 		{
 			W.li_sorted[p] = s;
+			// (every contact's row and every row's colour: the body-centred warm start gathers a body's rows in colour order)
+			W.hubRowOf[ci] = p;
+			if (!W.blockSort) W.rowColor[p] = color;
 			if (color == HUB_COLOR)
 			{
-				W.hubRowOf[ci] = p;
 				// the lowest contact index among the primary hub's constraints with this partner (k_hub_flag: a partner's later
 				// constraints with the hub - a box in a corner touches two walls - cannot join the one fixed point of k_sweep_end)
 				if (W.hubWide)
@@ -1244,7 +1246,7 @@ __global__ __launch_bounds__(64 * NW) void k_large_hub(DW W, int mode, int useGu
 	hubSweep<NW>(W, mode, useGuess, behindWide ? W.st->c.nHubWide : 0);
 }
 
-__global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)
+__global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp, int warmDeltas)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -1281,6 +1283,89 @@ __global__ __launch_bounds__(256) void k_large_init(DW W, StepParams sp)
 			mB4.x, mB4.y, v2(mB4.z, mB4.w), W.shapes[W.p_shape[ids.y]].radius,
 			pA, vA, pB, vB, sp.warmStarting != 0, sp.dtRatio);
 		lcStore(W, row, cc, 0, LC_WORDS);
+		if (warmDeltas && sp.warmStarting)
+		{
+			// what b2dWarmStart would subtract from body A and add to body B, point by point - the same expressions, so the same
+			// floats: k_large_warm applies them body by body in the order the colour launches would (b2d_solver.h: b2dWarmStart)
+			const float mA = cc.invMassA, iA = cc.invIA, mB = cc.invMassB, iB = cc.invIB;
+			const V2 normal = cc.normal;
+			const V2 tangent = b2dCrossVS(normal, 1.0f);
+			float4 q[4];
+			q[0] = q[1] = q[2] = q[3] = make_float4(0, 0, 0, 0);
+			B2D_FOR_POINTS(j, cc.pointCount)
+			{
+				const V2 P = cc.normalImpulse[j] * normal + cc.tangentImpulse[j] * tangent;
+				const float dwA = iA * b2dCross(cc.rA[j], P);
+				const V2 dvA = mA * P;
+				const float dwB = iB * b2dCross(cc.rB[j], P);
+				const V2 dvB = mB * P;
+				q[j] = make_float4(dvA.x, dvA.y, dwA, 0.0f);
+				q[2 + j] = make_float4(dvB.x, dvB.y, dwB, 0.0f);
+			}
+			q[0].w = __int_as_float(cc.pointCount);
+			q[2].w = __int_as_float(cc.pointCount);
+			float4* dst = W.warmDelta + (size_t)row * 4;
+			dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
+		}
+	}
+}
+
+// The warm start of the launch-per-colour solver in ONE launch, body by body. A warm start only ADDS what the constraints
+// carried over from the last step (b2ContactSolver::WarmStart, b2ContactSolver.cpp:253-291): no constraint reads a velocity, so
+// the only order that matters is the order of the additions ON EVERY BODY - and every body has its adjacency segment and every
+// row its colour, so a lane takes a body, walks its rows in ascending colour (the order the colour launches would have
+// visited it in) and applies the deltas k_large_init stored: the same additions in the same order, the same bits, one launch
+// where a sweep of 12 - 20 launches was. The rows of a hub are left to k_sweep_end (their partners meet them last either way).
+__global__ __launch_bounds__(256) void k_large_warm(DW W)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const int n = S->c.nLBodies;
+	// a lane's rows as keys (colour << 26 | row), sorted in LDS: entry e of lane t at [e * 256 + t] (no bank conflicts);
+	// a body below the hub threshold has at most HUB_DEGREE = 30 rows
+	__shared__ uint32_t s_key[32 * 256];
+	const int t = (int)threadIdx.x;
+	for (int k = blockIdx.x * blockDim.x + t; k < n; k += gridDim.x * blockDim.x)
+	{
+		const int body = W.li_bodies[k];
+		const int d = W.deg[body];
+		if (d <= 0 || d > HUB_DEGREE) continue; // (a hub's rows are all hub rows)
+		const int s = W.adjStart[body];
+		int m = 0;
+		for (int e = 0; e < d; ++e)
+		{
+			const int row = W.hubRowOf[W.adj[s + e]];
+			const int c = W.rowColor[row];
+			if (c < 0 || c >= MAX_COLORS || c == HUB_COLOR) continue; // (the hub's rows: k_sweep_end)
+			// insertion into the sorted prefix (colours of one body are all different)
+			const uint32_t key = ((uint32_t)c << 26) | (uint32_t)row;
+			int j = m;
+			while (j > 0 && s_key[(j - 1) * 256 + t] > key) { s_key[j * 256 + t] = s_key[(j - 1) * 256 + t]; --j; }
+			s_key[j * 256 + t] = key;
+			++m;
+		}
+		float4 v4 = W.b_vel[body];
+		V2 v = v2(v4.x, v4.y);
+		float w = v4.z;
+		for (int e = 0; e < m; ++e)
+		{
+			const int row = (int)(s_key[e * 256 + t] & 0x3ffffffu);
+			const bool sideA = W.li_ref[row].y == body;
+			const float4* q = W.warmDelta + (size_t)row * 4 + (sideA ? 0 : 2);
+			const float4 q0 = q[0], q1 = q[1];
+			const int pc = __float_as_int(q0.w);
+			if (sideA)
+			{
+				if (pc > 0) { w -= q0.z; v -= v2(q0.x, q0.y); }
+				if (pc > 1) { w -= q1.z; v -= v2(q1.x, q1.y); }
+			}
+			else
+			{
+				if (pc > 0) { w += q0.z; v += v2(q0.x, q0.y); }
+				if (pc > 1) { w += q1.z; v += v2(q1.x, q1.y); }
+			}
+		}
+		W.b_vel[body] = make_float4(v.x, v.y, w, 0.0f);
 	}
 }
 

@@ -5,12 +5,15 @@
 // they hold: DESIGN.md section 4). Measured on that island (profiles/r05_a): 19 colours whose census falls off steeply -
 // 41 000, 40 600, ... 8 300, 5 600, 3 400, 1 800, 760, 224, 59, 11 rows - then the hub's 900 constraints swept by one
 // workgroup in 15 chained chunks (82 us), then one lane walking the island's joints: 21 launches per sweep, 12 sweeps per step.
-// Everything behind the big colours has no use for 256 CUs; this kernel does it in one workgroup of 1024 lanes with workgroup
-// barriers where the launches had kernel boundaries:
+// Everything behind the big colours has no use for 256 CUs; this kernel does it in one workgroup of 512 lanes with workgroup
+// barriers where the launches had kernel boundaries (512, not 1024: a 1024-lane workgroup caps a lane at 128 registers, the
+// velocity solve of the hub's fixed point needs ~166 and spilled inside its rounds - measured with the kernel's own stamps,
+// B2HIP_SWEEP_STAMPS=1: the fixed point over the Tumbler's 900 rows 34.5 us as one pass of 1024 lanes, 21.5 us as two passes
+// of 512, 28.7 us as four of 256):
 //   A  the TAIL colours (those the host found small in this step's census), colour after colour - the arithmetic of
 //      k_large_velocity / k_large_position row for row, so the result is the launch-per-colour one bit for bit;
-//   B  the hub's constraints as ONE fixed point over up to 1024 lanes (the chunks of 64 of k_large_hub were a chain of
-//      fixed points; b2d_kernels_solve_large.h explains the scheme), prefix sums over the workgroup through LDS;
+//   B  the hub's constraints as fixed points over 512 lanes at a time (the chunks of 64 of k_large_hub were a chain of 15
+//      fixed points, now of two; b2d_kernels_solve_large.h explains the scheme), prefix sums over the workgroup through LDS;
 //   C  the hub rows B cannot take (a partner that occurs twice, a second hub, constraints swept in order for lack of a home
 //      block) by one wave, turn by turn or chunk-wise: hubSweep<1> over the rest of the list;
 //   D  what the host launched between two sweeps anyway: the island's joints (k_large_joints), the verdict of a position
@@ -22,7 +25,7 @@
 
 #include "b2d_handover.h"
 
-#define SWEEP_END_LANES 1024
+#define SWEEP_END_LANES 512
 #define SWEEP_END_WAVES (SWEEP_END_LANES / 64)
 // what a launch does behind its tail colours (bits of `what`)
 #define SE_HUB 1          // the hub rows (B, C)
@@ -196,7 +199,7 @@ __device__ __forceinline__ void sweepEndColour(const DW& W, const ContactArrays&
 	}
 }
 
-// ---- B: up to 1024 rows of the PRIMARY hub as one fixed point ------------------------------------------------------------
+// ---- B: up to SWEEP_END_LANES rows of the PRIMARY hub as one fixed point ------------------------------------------------------------
 // Rows [first, first + cnt) of hubList: constraints between the primary hub (the body with the most solid contacts:
 // DW::hubMeta[0]) and `cnt` DIFFERENT partners, none of them a hub (k_hub_flag sorts the others out). The sequential sweep
 // in list order is the fixed point of "every lane evaluates its constraint from the hub row it assumes it will meet": lane k's
@@ -415,12 +418,16 @@ __device__ __forceinline__ void sweepEndJoints(const DW& W, const StepParams& sp
 }
 
 template <int MODE>
-__global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams sp, int tailFirst, int tailEnd, int what)
+__global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams sp, int tailFirst, int tailEnd, int what, int* stampBar)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (MODE == 2 && S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];
+	// (B2HIP_SWEEP_STAMPS=1: where a velocity launch's time goes - 10 ns ticks since its start at the end of A, B, C, D in the
+	// words the block solver's stamps use; they come home with the read-back as DState::stamps: tools/gpu_tumbler_probe.py)
+	const unsigned long long t0 = (stampBar != nullptr && MODE == 1) ? wall_clock64() : 0ull;
+#define SE_STAMP(k) do { if (stampBar != nullptr && MODE == 1 && threadIdx.x == 0) stampBar[8 + (k)] = (int)(wall_clock64() - t0); } while (0)
 	// ---- A
 	for (int col = tailFirst; col < tailEnd; ++col)
 	{
@@ -429,6 +436,7 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 		sweepEndColour<MODE>(W, C, begin, end);
 		__syncthreads(); // (rows written by this workgroup, read by this workgroup: one CU, one L1)
 	}
+	SE_STAMP(0);
 	if (what & SE_HUB)
 	{
 		const int nRows = S->c.nHubRows;
@@ -452,6 +460,7 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 			}
 			__syncthreads();
 		}
+		SE_STAMP(1);
 		// ---- C
 		if (nWide < nRows)
 		{
@@ -462,10 +471,13 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 			}
 		}
 	}
+	SE_STAMP(2);
 	// ---- D
 	if (what & SE_JOINTS_INIT) { sweepEndJoints(W, sp, 0); __syncthreads(); }
 	if (what & SE_JOINTS_VEL) { sweepEndJoints(W, sp, 1); __syncthreads(); }
 	if (what & SE_JOINTS_POS) { sweepEndJoints(W, sp, 2); __syncthreads(); }
+	SE_STAMP(3);
+#undef SE_STAMP
 	if (what & SE_POS_END)
 	{
 		// (k_large_pos_end: per-island early out, b2Island.cpp:329-334)

@@ -879,12 +879,20 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 		for (int off = 32; off > 0; off >>= 1) ext = fmaxf(ext, __shfl_xor(ext, off));
 		if ((threadIdx.x & 63u) == 0 && ext > 0.0f) atomicMaxIfAbove(&S->c.cellExtBits, __float_as_uint(ext));
 	}
-	for (uint32_t i = t0; i <= W.gridMask; i += stride)
+	// (16 bytes per lane and store: the tables are powers of two of at least 64 entries, 256-byte aligned - 4-byte stores
+	// were 93 us for the 40 MB of a million-proxy world)
 	{
-		W.gridCount[i] = 0;
-		W.gridCursor[i] = 0;
+		const int4 z = make_int4(0, 0, 0, 0);
+		int4* gc = (int4*)W.gridCount;
+		int4* gu = (int4*)W.gridCursor;
+		for (uint32_t i = t0, n4 = (W.gridMask + 1u) >> 2; i < n4; i += stride)
+		{
+			gc[i] = z;
+			gu[i] = z;
+		}
+		int4* hk = (int4*)W.ht_keys;
+		for (uint32_t i = t0, n2 = (htLiveMask(W) + 1u) >> 1; i < n2; i += stride) hk[i] = z; // (the part this update uses)
 	}
-	for (uint32_t i = t0, live = htLiveMask(W); i <= live; i += stride) W.ht_keys[i] = 0; // (the part this update uses)
 }
 
 __global__ __launch_bounds__(256) void k_bp_build(DW W)

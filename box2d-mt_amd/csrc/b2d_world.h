@@ -152,6 +152,7 @@ struct Counters
 	int compactMoved;    // constraints k_color_small moved down in this step's visit (read by the next step's colorCheckBegin)
 	int compactTick;     // persistent: steps, for the slow beat of an idle colouring
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
+	int maxDegreePlain;  // ... among the bodies that are no hubs (<= HUB_DEGREE): the fewest colours a colouring of their constraints can have
 	int nHubRows;        // hub constraints of this step
 	int nHubWide;        // ... the first so many of hubList are constraints of the PRIMARY hub with different non-hub partners: one fixed point (k_sweep_end)
 	int hubEpoch;        // persistent: steps counted for the tags of DW::hubFirst
@@ -375,6 +376,7 @@ struct DW
 	float4* dfInbox;        // per large-island constraint row: two tagged 16-byte slots (body A, body B)
 	float4* b_posv;         // per body: (c.xy, a, version) rows of the dataflow solver's position phase
 	float* lc;           // large-island constraint rows, field-major: lc[field * capContacts + slot]
+	float4* warmDelta;   // per large-island constraint row: 4 x float4 - what its warm start subtracts from body A (points 0, 1) and adds to body B (k_large_init -> k_large_warm)
 	uint32_t* rootPen;   // per root: max penetration of the running position iteration (bits of -minSeparation)
 	int* rootDone;       // per root: positionSolved
 	uint32_t* rootSleepMin;

@@ -329,6 +329,14 @@ int b2hip_get_kernel_timing(b2hip_world* w, char* name, int name_cap, float* tot
 }
 
 // (diagnostics, not part of include/b2hip.h: the device clock stamps around the mid-step census read-back, in 10 ns ticks)
+// (diagnostics: the six phase stamps of the last step's resident solver - or, with B2HIP_SWEEP_STAMPS=1, of its last k_sweep_end<1>)
+int b2hip_debug_stamps(b2hip_world* w, int out[6])
+{
+	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");
+	for (int k = 0; k < 6; ++k) out[k] = w->h_dstate->stamps[k];
+	return 0;
+}
+
 int b2hip_debug_gap_clocks(b2hip_world* w, unsigned long long out[4])
 {
 	if (!w || !out) return setError(B2HIP_ERR_INVALID, "null argument");

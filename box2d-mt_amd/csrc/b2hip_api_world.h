@@ -251,7 +251,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release(); w->toiNewList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiNew.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
-	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release();
+	w->rootSleepMin.release(); w->bodyColorMask.release(); w->rootDone.release(); w->lc.release(); w->warmDelta.release();
 	w->moveBuf.release(); w->gridCount.release(); w->gridStart.release(); w->gridCursor.release(); w->gridItems.release(); w->gridFat.release(); w->arriveTree.release();
 	w->largeProxies.release(); w->largeMoves.release(); w->pairKey.release(); w->pairKey2.release(); w->pairProxy.release(); w->pairProxy2.release();
 	w->filterPairs.release();

@@ -425,7 +425,10 @@ static int phaseSolve(b2hip_world* w)
 		{
 			if (w->recolorCountdown <= 0)
 			{
-				if (w->freshColors <= 0 || c.nColors > w->freshColors + w->recolorSlack)
+				// (a colouring from scratch lands anywhere between the busiest plain body's degree + 1 and + 8: the measure is the
+				// better of what the last one reached and degree + 3, so that a poor one is not kept as the yardstick)
+				const int yard = std::min(w->freshColors, c.maxDegreePlain + 3);
+				if (w->freshColors <= 0 || w->recolorSlack < 0 || c.nColors > yard + w->recolorSlack)
 				{
 					c.needRecolor = 1;
 					colorSmallQueued = false;
@@ -740,7 +743,10 @@ static int phaseSolve(b2hip_world* w)
 		if (w->debugTrace) HIP_TRY(hipMemcpyAsync(w->dbgVel.p, w->b_vel.p, w->bodies.size() * 16, hipMemcpyDeviceToDevice, w->stream));
 		TRACE("integrate");
 		if (hasJoints && !exactLarge) LAUNCH(w, k_joints_sort, gJ, 64, d);
-		LAUNCH(w, k_large_init, gC, 256, d, sp);
+		// (the warm start body by body in one launch - k_large_warm - where the sweep would be a launch per colour: k_large_init
+		// leaves the deltas for it)
+		const bool bodyWarm = w->bodyWarm && w->sweepEnd && !exactLarge && !w->debugTrace && !useSweep && sp.warmStarting && nColors <= MAX_COLORS;
+		LAUNCH(w, k_large_init, gC, 256, d, sp, bodyWarm ? 1 : 0);
 		TRACE("init");
 		// colours that own no constraint (the partition keeps two colour ranges apart) are not launched
 		const uint64_t colorMask = exactLarge ? ~0ull : ((uint64_t)w->h_dstate->c.colorMaskLo | ((uint64_t)w->h_dstate->c.colorMaskHi << 32));
@@ -817,16 +823,17 @@ static int phaseSolve(b2hip_world* w)
 		const bool leftoverApart = useSweepEnd && hasHubs && d.hubWide && c.nHubRows - c.nHubWide > SE_LEFT_INLINE_MAX;
 		auto sweepEndOne = [&](int mode, int tf, int te, int what) -> int
 		{
-			if (mode == 0) LAUNCH(w, k_sweep_end<0>, 1, SWEEP_END_LANES, d, sp, tf, te, what);
-			else if (mode == 1) LAUNCH(w, k_sweep_end<1>, 1, SWEEP_END_LANES, d, sp, tf, te, what);
-			else LAUNCH(w, k_sweep_end<2>, 1, SWEEP_END_LANES, d, sp, tf, te, what);
+			if (mode == 0) LAUNCH(w, k_sweep_end<0>, 1, SWEEP_END_LANES, d, sp, tf, te, what, w->sweepStamps ? w->gridBar.p : (int*)nullptr);
+			else if (mode == 1) LAUNCH(w, k_sweep_end<1>, 1, SWEEP_END_LANES, d, sp, tf, te, what, w->sweepStamps ? w->gridBar.p : (int*)nullptr);
+			else LAUNCH(w, k_sweep_end<2>, 1, SWEEP_END_LANES, d, sp, tf, te, what, w->sweepStamps ? w->gridBar.p : (int*)nullptr);
 			w->lastSweepLaunches += 1;
 			return 0;
 		};
+		bool noTail = false;
 		auto sweepEndLaunch = [&](int mode, int what) -> int
 		{
-			if (!what && !tailAny) return 0;
-			const int tf = (useSweep || useRest) ? 0 : tailFirst, te = (useSweep || useRest) ? 0 : nColors;
+			if (!what && (!tailAny || noTail)) return 0;
+			const int tf = (useSweep || useRest || noTail) ? 0 : tailFirst, te = (useSweep || useRest || noTail) ? 0 : nColors;
 			if (leftoverApart && (what & SE_HUB))
 			{
 				int rcl = sweepEndOne(mode, tf, te, (what & (SE_HUB | SE_GUESS)) | SE_HUB_WIDE_ONLY);
@@ -841,6 +848,7 @@ static int phaseSolve(b2hip_world* w)
 		if (sp.warmStarting)
 		{
 			if (useSweep) { rc = sweep(0); if (rc) return rc; }
+			else if (bodyWarm) LAUNCH(w, k_large_warm, gB, 256, d);
 			else
 			{
 				for (int col = 0; col < bigEnd; ++col)
@@ -852,7 +860,11 @@ static int phaseSolve(b2hip_world* w)
 			{
 				// (b2Island.cpp:256-268: the joints' InitVelocityConstraints follows the contacts' warm start; the first velocity
 				// iteration then begins with the joints)
-				rc = sweepEndLaunch(0, (hasHubs ? SE_HUB : 0) | (hasJoints ? SE_JOINTS_INIT | (sp.velIters > 0 ? SE_JOINTS_VEL : 0) : 0));
+				const int what0 = (hasHubs ? SE_HUB : 0) | (hasJoints ? SE_JOINTS_INIT | (sp.velIters > 0 ? SE_JOINTS_VEL : 0) : 0);
+				// (after k_large_warm every colour has had its warm start: only what follows the colours is left)
+				noTail = bodyWarm; // (after k_large_warm every colour has had its warm start)
+				rc = sweepEndLaunch(0, what0);
+				noTail = false;
 				if (rc) return rc;
 			}
 			else if (hasHubs) { rc = hubSweepLaunch(0, 0); if (rc) return rc; }

@@ -187,7 +187,7 @@ struct b2hip_world
 	DevArray<ToiLogRec> toiLog;
 	DevArray<int4> toiVerdict; // PreSolve answers for the TOI phase's log slots (DW::toiVerdict)
 	DevArray<int> uncolList, compactList, hubRowOf, hubList;
-	DevArray<float4> hubDelta;
+	DevArray<float4> hubDelta, warmDelta;
 	DevArray<unsigned long long> hubMeta, hubFirst;
 	DevArray<int> rootDone;
 	DevArray<float> lc;
@@ -298,6 +298,8 @@ struct b2hip_world
 	int recolorSlack = 2;        // colour afresh when the colours in use exceed the last fresh colouring's by more than this (B2HIP_RECOLOR_SLACK; -1: every 64th step as in round 4)
 	int freshColors = 0;         // colours the last colouring from scratch of a partition-less world needed (0: none yet); in the snapshot's hints
 	bool freshColorsPending = false;
+	bool sweepStamps = false;    // B2HIP_SWEEP_STAMPS=1: k_sweep_end<1> leaves its phase stamps where the block solver's go (diagnostics)
+	bool bodyWarm = true;        // the warm start of a launch-per-colour solve body by body in one launch (k_large_warm; B2HIP_NO_BODY_WARM=1: a sweep of launches)
 	bool restFlow = true;        // the small colours of a sweep as data flow per body in one launch (k_large_rest; B2HIP_NO_REST=1: launches / tail)
 	int restRowsMax = 65536;     // ... the highest colours that hold at most this many rows together (B2HIP_REST_ROWS). Measured on the
 	                             // settled Tumbler (profiles/r05_i_rest_rows_sweep.txt: the solver family per step, 21 colours): none 2.06 ms /
@@ -845,6 +847,11 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
 		if (rc) return rc;
 	}
+	if (w->warmDelta.cap < 4 * cc)
+	{
+		rc = w->warmDelta.ensure(4 * cc, s, false, false); // (per-step scratch: k_large_init -> k_large_warm)
+		if (rc) return rc;
+	}
 	ENS(moveBuf, 2 * np + 64);
 	const size_t gridSize = (size_t)nextPow2(2 * np);
 	ENS(gridCount, gridSize); ENS(gridStart, gridSize + 2); ENS(gridCursor, gridSize); ENS(gridItems, np); ENS(gridFat, np); ENS(arriveTree, (size_t)ARRIVE_SITES * TREE_WORDS); ENS(largeProxies, np); ENS(largeMoves, 2 * np + 64);
@@ -918,6 +925,8 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	w->sweepEnd = !(getenv("B2HIP_NO_SWEEP_END") && atoi(getenv("B2HIP_NO_SWEEP_END"))) && !getenv("B2HIP_HUB_WAVES");
 	w->sweepTail = w->sweepEnd && !(getenv("B2HIP_NO_TAIL") && atoi(getenv("B2HIP_NO_TAIL")));
 	w->recolorSlack = getenv("B2HIP_RECOLOR_SLACK") ? atoi(getenv("B2HIP_RECOLOR_SLACK")) : 2;
+	w->sweepStamps = getenv("B2HIP_SWEEP_STAMPS") != nullptr;
+	w->bodyWarm = !(getenv("B2HIP_NO_BODY_WARM") && atoi(getenv("B2HIP_NO_BODY_WARM")));
 	w->restFlow = w->sweepEnd && !(getenv("B2HIP_NO_REST") && atoi(getenv("B2HIP_NO_REST")));
 	w->restRowsMax = getenv("B2HIP_REST_ROWS") ? std::min(atoi(getenv("B2HIP_REST_ROWS")), REST_ROWS_MAX - COLOR_SMALL_MAX) : 65536;
 	w->tailRowsMax = getenv("B2HIP_TAIL_ROWS") ? atoi(getenv("B2HIP_TAIL_ROWS")) : SWEEP_END_LANES;
@@ -953,7 +962,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.chunkFirst = w->chunkFirst.p;
 	d.li_bodies = w->li_bodies.p; d.li_contacts = w->li_contacts.p; d.li_roots = w->li_roots.p; d.li_color = w->li_color.p;
 	d.colorCount = w->colorCount.p; d.colorStart = w->colorStart.p; d.colorCursor = w->colorCursor.p; d.li_sorted = w->li_sorted.p; d.li_ref = w->li_ref.p;
-	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.bodyRest = w->bodyRest.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.hubDelta = w->hubDelta.p; d.hubMeta = w->hubMeta.p; d.hubFirst = w->hubFirst.p; d.lc = w->lc.p; d.rootPen = w->rootPen.p;
+	d.bodyClaim = w->bodyClaim.p; d.bodyColorMask = w->bodyColorMask.p; d.bodyActive = w->bodyActive.p; d.bodyRest = w->bodyRest.p; d.b_posv = w->b_posv.p; d.dfRank = w->dfRank.p; d.dfInbox = w->dfInbox.p; d.evKey = w->evKey.p; d.evInfo = w->evInfo.p; d.eventsOn = w->eventsOn ? 1 : 0; d.uncolList = w->uncolList.p; d.compactList = w->compactList.p; d.hubRowOf = w->hubRowOf.p; d.hubList = w->hubList.p; d.hubDelta = w->hubDelta.p; d.hubMeta = w->hubMeta.p; d.hubFirst = w->hubFirst.p; d.lc = w->lc.p; d.warmDelta = w->warmDelta.p; d.rootPen = w->rootPen.p;
 	d.rootDone = w->rootDone.p; d.rootSleepMin = w->rootSleepMin.p;
 	d.moveBuf = w->moveBuf.p; d.gridCount = w->gridCount.p; d.gridStart = w->gridStart.p; d.gridCursor = w->gridCursor.p;
 	d.gridItems = w->gridItems.p; d.gridFat = w->gridFat.p; d.arriveTree = w->arriveTree.p; d.largeProxies = w->largeProxies.p; d.largeMoves = w->largeMoves.p;

@@ -1,7 +1,7 @@
 """GPU tests of the end of a sweep over islands that run launch per colour (box2d-mt_amd/csrc/b2d_kernels_sweep_end.h):
 k_large_rest (the small colours of a sweep as data flow per body, one launch), k_sweep_end (tail colours, the hub rows as ONE
 fixed point, leftover hub rows lane after lane, the joint walk, the verdict of a position iteration - one single-workgroup
-launch). Reference: b2Island::Solve, Box2D/Dynamics/b2Island.cpp:256-336; b2ContactSolver.cpp:293-603, 676-752.
+launch), k_large_warm (the warm start of a launch-per-colour solve body by body, one launch). Reference: b2Island::Solve, Box2D/Dynamics/b2Island.cpp:256-336; b2ContactSolver.cpp:293-603, 676-752.
 
 Bars:
   * everything but the hub's fixed point does the arithmetic of the launches it replaces, in the same order on every body:
@@ -23,7 +23,7 @@ import b2harness as bh
 pytestmark = pytest.mark.gpu
 
 KEYS = ("B2HIP_HUB_SERIAL", "B2HIP_NO_SWEEP_END", "B2HIP_NO_TAIL", "B2HIP_HUB_WIDE", "B2HIP_TAIL_ROWS", "B2HIP_SOLVER_LAUNCHES",
-        "B2HIP_NO_REST", "B2HIP_REST_ROWS", "B2HIP_FORCE_LARGE", "B2HIP_HUB_WAVES")
+        "B2HIP_NO_REST", "B2HIP_REST_ROWS", "B2HIP_FORCE_LARGE", "B2HIP_HUB_WAVES", "B2HIP_NO_BODY_WARM")
 CCD = bh.F_SLEEP | bh.F_WARM | bh.F_CONTINUOUS
 LAUNCHES = {"B2HIP_SOLVER_LAUNCHES": "1"}  # no resident block solver, no k_blocks_sweep: a launch per colour
 
@@ -65,7 +65,8 @@ def test_sweep_end_folding_is_bit_identical_to_the_launches_it_replaces(amd, mon
     base, _ = run(amd, monkeypatch, scene, steps, dict(serial, B2HIP_NO_SWEEP_END="1"), **kw)
     variants = {"default split": {}, "no rest colours, tail colours up to 100 rows": {"B2HIP_NO_REST": "1", "B2HIP_TAIL_ROWS": "100"},
                 "rest colours up to 28 000 rows": {"B2HIP_REST_ROWS": "100000"}, "every colour a tail colour": {"B2HIP_NO_REST": "1", "B2HIP_TAIL_ROWS": "100000"},
-                "no rest, no tail": {"B2HIP_NO_REST": "1", "B2HIP_NO_TAIL": "1"}}
+                "no rest, no tail": {"B2HIP_NO_REST": "1", "B2HIP_NO_TAIL": "1"},
+                "warm start as a sweep of launches": {"B2HIP_NO_BODY_WARM": "1"}}
     for label, env in variants.items():
         other, _ = run(amd, monkeypatch, scene, steps, dict(serial, **env), **kw)
         first = first_diff(base, other)

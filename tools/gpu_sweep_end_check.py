@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "box2d-mt_amd", "python"))
 import b2harness as bh
 amd = bh.Harness(bh.AMD_LIB)
-KEYS = ("B2HIP_HUB_SERIAL", "B2HIP_NO_SWEEP_END", "B2HIP_NO_TAIL", "B2HIP_HUB_WIDE", "B2HIP_TAIL_ROWS", "B2HIP_SOLVER_LAUNCHES", "B2HIP_NO_BLOCKS", "B2HIP_NO_REST", "B2HIP_REST_ROWS")
+KEYS = ("B2HIP_HUB_SERIAL", "B2HIP_NO_SWEEP_END", "B2HIP_NO_TAIL", "B2HIP_HUB_WIDE", "B2HIP_TAIL_ROWS", "B2HIP_SOLVER_LAUNCHES", "B2HIP_NO_BLOCKS", "B2HIP_NO_REST", "B2HIP_REST_ROWS", "B2HIP_NO_BODY_WARM")
 
 
 def run(scene, p0, p1, steps, env, flags=bh.F_SLEEP | bh.F_WARM, seed=3, every=1):
@@ -65,8 +65,8 @@ ok = ok and a == b
 if len(sys.argv) < 2:
     import ctypes as C, b2hip
     L = b2hip.lib()
-    for env in ({}, {"B2HIP_REST_ROWS": "28000"}, {"B2HIP_REST_ROWS": "50000"}, {"B2HIP_REST_ROWS": "75000"}, {"B2HIP_REST_ROWS": "110000"}, {"B2HIP_REST_ROWS": "150000"},
-                {"B2HIP_NO_REST": "1"}, {"B2HIP_NO_SWEEP_END": "1"}):
+    for env in ({}, {"B2HIP_REST_ROWS": "16384"},
+                {"B2HIP_NO_BODY_WARM": "1"}, {"B2HIP_NO_REST": "1"}, {"B2HIP_NO_SWEEP_END": "1"}):
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(env)

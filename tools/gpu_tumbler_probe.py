@@ -48,5 +48,13 @@ if nh > 0:
         p = partner[k:k + 64][pdyn[k:k + 64]]
         if len(np.unique(p)) != len(p): bad += 1
     print("chunks %d, with a duplicate partner inside %d" % ((nh + 63) // 64, bad))
+if os.environ.get("B2HIP_SWEEP_STAMPS"):
+    st = (C.c_int * 6)()
+    L.b2hip_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    acc = np.zeros(4)
+    for _ in range(10):
+        w.step(1); L.b2hip_debug_stamps(dev, st); acc += np.array(list(st)[:4])
+    acc *= 0.01 / 10  # 10 ns ticks -> us
+    print("k_sweep_end<1> (last velocity sweep of a step, mean of 10 steps), us since its start: tail colours done %.1f, hub fixed point done %.1f, leftover rows done %.1f, joints done %.1f" % tuple(acc))
 print({k: round(v, 3) for k, v in w.profile().items() if v and k != "steps"})
 w.close()
