@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k_sync_fixtures(DW W)
 	__shared__ int s_cnt, s_base;
 	// (a small world keeps one proxy per lane - 10 000 proxies in tiles of 1 024 would be ten workgroups on 256 CUs)
 	const int perLane = n >= 262144 ? SYNC_TILE / 256 : 1, tile = 256 * perLane;
+	if (blockIdx.x == 0 && tid == 0) S->c.gridFresh = 0; // (boxes move: whatever grid there is is stale until the next pair update)
 	for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile)
 	{
 		if (tid == 0) s_cnt = 0;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void k_grid_clear(DW W, int force)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
+	if (force && S->c.gridFresh && !W.spatial) return; // (this step's pair update built it, nothing has moved since)
 	// always reset the pair census, also when nothing moved: the ordering / creation kernels that
 	// follow key off nPairs and must see 0 then
 	if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DW W, int force)
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0 && !force) return;
+	if (force && S->c.gridFresh && !W.spatial) return;
 	const int n = W.nProxies;
 	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
 	{
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(256) void k_grid_fill(DW W, int force)
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0 && !force) return;
+	if (force && S->c.gridFresh && !W.spatial) return;
 	const int n = W.nProxies;
 	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
 	{
@@ -733,9 +737,14 @@ __global__ __launch_bounds__(256) void k_create_finish(DW W, int smallPath)
 	{
 		if (W.b_wake[i])
 		{
-			W.b_flags[i] |= BF_AWAKE;
-			W.b_pos[i].w = 0.0f;
 			W.b_wake[i] = 0;
+			// (most bodies that get a new contact are awake with their timer at zero: nothing to write, and no mark on their row -
+			// a moving field makes contacts for a tenth of its bodies per step, spread over every tile of the read-back)
+			const uint32_t f = W.b_flags[i];
+			if ((f & BF_AWAKE) != 0 && W.b_pos[i].w == 0.0f) continue;
+			W.b_flags[i] = f | BF_AWAKE;
+			W.b_pos[i].w = 0.0f;
+			W.b_rowDirty[i] = 1;
 		}
 	}
 }
@@ -850,7 +859,12 @@ __global__ __launch_bounds__(1024) void k_toi_order_create(DW W, int smallPath)
 // final row and is sent again: host buffer and shadow always hold the same words.
 #define END_STEP_EARLY 4
 #define END_STEP_TILE_ROWS 16 // (more changed rows than this in a tile of 256: the tile leaves whole, as coalesced 16-byte stores)
-__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq, int mode, float* shadow, int rowMode)
+// marks (with rowMode 2, behind an early launch of this step): 1 - only tiles with a body whose row was written since
+// SynchronizeFixtures are looked at (DW::b_rowDirty, set by whoever writes such a row: contact creation's wake-ups, the TOI
+// phase; the compare of a million untouched rows with their shadow was 90 us of config 5's step); 2 - every tile is compared
+// as with 0 and a row that differs without a mark raises Counters::overflow bit 12 (B2HIP_ROW_MARKS_CHECK=1: the proof that
+// the marks are complete). Every launch but the early one clears the marks it saw.
+__global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const int* bar, float* out, int seq, int mode, float* shadow, int rowMode, int marks)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -863,6 +877,7 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	// (ClearPostSolveTOI only when the step is complete; sub-stepping: also for what earlier calls of the step touched)
 	const bool toiEvents = (S->c.nToiEvents != 0 || W.toiContinue != 0) && S->c.toiIncomplete == 0;
 	bool skipRows = false;
+	int stored = 0; // (this lane has stored towards the host: the workgroup's fence below)
 	const bool storeRows = mode != END_STEP_LAZY, houseKeeping = mode != END_STEP_ROWS && mode != END_STEP_EARLY;
 	if (mode == END_STEP_SKIP_IF_REDO)
 	{
@@ -873,9 +888,21 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	for (int base = blockIdx.x * 256; base < n && !skipRows; base += gridDim.x * 256)
 	{
 		const int i = base + tid;
+		int mark = 0;
+		if (mode != END_STEP_EARLY)
+		{
+			if (i < n)
+			{
+				mark = W.b_rowDirty[i];
+				if (mark) W.b_rowDirty[i] = 0;
+			}
+			if (marks == 1 && __syncthreads_or(mark) == 0) continue; // (uniform: nobody wrote a row of this tile since the early launch read it)
+			if (marks == 1 && tid == 0) atomicAdd(&S->c.endBlocksDone, 1);
+		}
 		if (i < n)
 		{
 			uint32_t f = W.b_flags[i];
+			if (marks == 2 && !mark && W.b_pos0[i].w != 0.0f) atomicOr(&S->c.overflow, 0x1000);
 			if (clearForces && houseKeeping) W.b_force[i] = make_float4(0, 0, 0, 0);
 			// b2ClearBodySolveTOIFlags (b2World.cpp:239-259, k_toi_clear): sweeps go back to alpha0 = 0 for the next step
 			// (only where an event advanced the sweep: a 4-byte store into every 16-byte element is a read-modify-write of every
@@ -950,6 +977,7 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 					const float2 a = o2[c], b = h2[c];
 					changed = changed || __float_as_uint(a.x) != __float_as_uint(b.x) || __float_as_uint(a.y) != __float_as_uint(b.y);
 				}
+				if (marks == 2 && changed && !mark) atomicOr(&S->c.overflow, 0x1000);
 			}
 			const int nChanged = __syncthreads_count(changed ? 1 : 0);
 			if (nChanged == 0) continue; // (uniform)
@@ -963,12 +991,14 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 					float2* d2 = (float2*)(out + (size_t)i * 10);
 					float2* h2 = (float2*)(shadow + (size_t)i * 10);
 					for (int c = 0; c < 5; ++c) { const float2 v = o2[c]; d2[c] = v; h2[c] = v; }
+					stored = 1;
 				}
 				continue; // (uniform; every lane read its own part of s_out only)
 			}
 		}
 		else __syncthreads();
 		// the whole tile, as it lies in LDS: contiguous 16-byte stores (the barrier above made every lane's row visible)
+		stored = 1;
 		for (int q = tid; q < cnt / 4; q += 256)
 		{
 			const float4 v = ((const float4*)s_out)[q];
@@ -985,11 +1015,14 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	if (mode == END_STEP_EARLY) return; // (the rows were all: the launch at the end of the step publishes)
 	// ---- the last workgroup: counters, then the sequence number ---------------------------------------------------------
 	// (every wave's stores have left; ONE system-scope fence per workgroup - a fence writes the L2 back - then arrive)
+	// (... and only for a workgroup that HAS stored towards the host: behind an early launch most workgroups find no marked
+	// row, and two thousand write-backs of the L2s in a row were 60 us of a kernel that had 4 MB to read)
+	if (W.spatial && !W.spFullRows) stored = 1; // (the packed rows of a sharded world)
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
+	const int anyStored = __syncthreads_or(stored);
 	if (tid == 0)
 	{
-		__threadfence_system();
+		if (anyStored) __threadfence_system();
 		// (two-level arrival: 2 048 atomics on one word were 60 us of a million-body step's last kernel; b2d_world.h)
 		unsigned t0 = 0u, t1 = 0u;
 		s_last = b2dTreeArrive(W.arriveTree + (size_t)ARRIVE_END_STEP * TREE_WORDS, 0u, 0u, &t0, &t1) ? 1 : 0;
@@ -1014,6 +1047,7 @@ __global__ __launch_bounds__(256) void k_end_step(DW W, int clearForces, const i
 	if (tid == 0)
 	{
 		S->c.spOwnRows = 0; // (the packed rows of a spatially sharded world: counted afresh by the next read-back)
+		S->c.endBlocksDone = 0;
 		__hip_atomic_store(&((DState*)tail)->pubSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }

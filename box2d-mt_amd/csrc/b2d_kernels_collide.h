@@ -92,6 +92,14 @@ __device__ __forceinline__ bool isToiCandidate(const DW& W, int proxyA, int prox
 // replay chasing three dependent loads per removal, this tail was most of k_collide's 220 us on the 1 M-body field, where
 // the bullets' fat AABBs make and break ~100 candidate contacts per step - not the evaluation of the manifolds.)
 #define TOI_ORDER_SCRATCH_BYTES (TOI_ORDER_SORT_MAX * (8 + 4 * 4))
+// More dying candidates than the LDS tables hold (a dense start: 450 bullets in a crowd break 5 000 candidate contacts in one
+// step; until round 5 the surplus was flagged in Counters::overflow bit 4 and the slot table left inconsistent - harmless
+// while nothing but the re-synchronisation order read it, wrong results once k_toi_first walks it): the removals are
+// replayed in CHUNKS of TOI_ORDER_SORT_MAX in key order. A chunk is the replay below applied to the table as the chunks
+// before left it - a tail contact that dies in a LATER chunk is moved like a survivor (its slot is read again when its turn
+// comes), one that died in an earlier chunk is gone. What needs all n at once - the ranks - goes through memory: the keys and
+// the contacts in key order in the pair buffer (idle between the pair updates), a contact's rank in DW::toiList (the TOI
+// phase's list: idle during Collide). n * n / 256 comparisons per lane: milliseconds at n = 20 000, and only then.
 __device__ __forceinline__ void toiOrderDestroy(const DW& W, void* scratch)
 {
 	DState* S = W.st;
@@ -103,51 +111,102 @@ __device__ __forceinline__ void toiOrderDestroy(const DW& W, void* scratch)
 	int* s_slot = s_sorted + TOI_ORDER_SORT_MAX;          // ... their slots (kept up to date while earlier removals move them)
 	int* s_tail = s_slot + TOI_ORDER_SORT_MAX;            // contact in slot base + t
 	int* s_tailJ = s_tail + TOI_ORDER_SORT_MAX;           // ... its place in s_sorted if it is dying itself, else -1
-	const int m = n < TOI_ORDER_SORT_MAX ? n : TOI_ORDER_SORT_MAX;
-	const int count0 = S->c.nToiOrder;
-	const int base = count0 - m > 0 ? count0 - m : 0;
-	for (int i = threadIdx.x; i < m; i += blockDim.x) s_key[i] = C.key[b2dLoadAgentI(&W.toiDestroyList[i])];
-	__syncthreads();
-	// rank by key (keys are unique)
-	for (int i = threadIdx.x; i < m; i += blockDim.x)
+	const bool chunked = n > TOI_ORDER_SORT_MAX;
+	uint64_t* g_key = W.pairKey;                 // (chunked) keys of the dying contacts, list order
+	int* g_sorted = (int*)(W.pairKey + n);       // (chunked) the dying contacts in key order
+	int* g_rank = W.toiList;                     // (chunked) per contact: its rank among the dying
+	if (chunked)
 	{
-		const uint64_t key = s_key[i];
-		int rank = 0;
-		for (int j = 0; j < m; ++j) rank += s_key[j] < key ? 1 : 0;
-		const int ci = b2dLoadAgentI(&W.toiDestroyList[i]);
-		s_sorted[rank] = ci;
-		s_slot[rank] = C.mgr[ci];
+		if ((size_t)n * 3 > (size_t)W.capPairs * 2 || n > W.capContacts)
+		{
+			// (no room for the tables: the host fails the step - b2hip_step_end)
+			if (threadIdx.x == 0) { atomicOr(&S->c.overflow, 16); S->c.nToiDestroy = 0; }
+			return;
+		}
+		for (int i = threadIdx.x; i < n; i += blockDim.x) g_key[i] = C.key[b2dLoadAgentI(&W.toiDestroyList[i])];
+		__threadfence();
+		__syncthreads();
+		for (int i = threadIdx.x; i < n; i += blockDim.x)
+		{
+			const uint64_t key = g_key[i];
+			int rank = 0;
+			for (int j = 0; j < n; ++j) rank += g_key[j] < key ? 1 : 0; // (every lane the same word: one fetch per wave)
+			const int ci = b2dLoadAgentI(&W.toiDestroyList[i]);
+			g_sorted[rank] = ci;
+			g_rank[ci] = rank;
+		}
+		__threadfence();
+		__syncthreads();
 	}
-	for (int t = threadIdx.x; t < count0 - base; t += blockDim.x) s_tail[t] = W.toiPos2c[base + t];
-	__syncthreads();
-	for (int t = threadIdx.x; t < count0 - base; t += blockDim.x)
+	int count = S->c.nToiOrder;
+	for (int c0 = 0; c0 < n; c0 += TOI_ORDER_SORT_MAX)
 	{
-		const int c = s_tail[t];
-		int j = -1;
-		// (k_collide has set CF_DESTROY on every dying contact and its stores have landed: this is the last workgroup)
-		if (b2dLoadAgentI((const int*)&C.flags[c]) & (int)CF_DESTROY)
-			for (int q = 0; q < m; ++q) if (s_sorted[q] == c) { j = q; break; }
-		s_tailJ[t] = j;
+		const int m = n - c0 < TOI_ORDER_SORT_MAX ? n - c0 : TOI_ORDER_SORT_MAX;
+		const int count0 = count;
+		const int base = count0 - m > 0 ? count0 - m : 0;
+		if (!chunked)
+		{
+			for (int i = threadIdx.x; i < m; i += blockDim.x) s_key[i] = C.key[b2dLoadAgentI(&W.toiDestroyList[i])];
+			__syncthreads();
+			// rank by key (keys are unique)
+			for (int i = threadIdx.x; i < m; i += blockDim.x)
+			{
+				const uint64_t key = s_key[i];
+				int rank = 0;
+				for (int j = 0; j < m; ++j) rank += s_key[j] < key ? 1 : 0;
+				const int ci = b2dLoadAgentI(&W.toiDestroyList[i]);
+				s_sorted[rank] = ci;
+				s_slot[rank] = C.mgr[ci];
+			}
+		}
+		else
+		{
+			// (what lane 0 stored in the chunk before is read past this CU's L1: the lines may sit there from that chunk's loads)
+			for (int i = threadIdx.x; i < m; i += blockDim.x)
+			{
+				const int ci = g_sorted[c0 + i];
+				s_sorted[i] = ci;
+				s_slot[i] = b2dLoadAgentI(&C.mgr[ci]);
+			}
+		}
+		for (int t = threadIdx.x; t < count0 - base; t += blockDim.x) s_tail[t] = b2dLoadAgentI(&W.toiPos2c[base + t]);
+		__syncthreads();
+		for (int t = threadIdx.x; t < count0 - base; t += blockDim.x)
+		{
+			const int c = s_tail[t];
+			int j = -1;
+			// (k_collide has set CF_DESTROY on every dying contact and its stores have landed: this is the last workgroup)
+			if (b2dLoadAgentI((const int*)&C.flags[c]) & (int)CF_DESTROY)
+			{
+				if (!chunked) { for (int q = 0; q < m; ++q) if (s_sorted[q] == c) { j = q; break; } }
+				else { const int r = g_rank[c]; if (r >= c0 && r < c0 + m) j = r - c0; }
+			}
+			s_tailJ[t] = j;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			for (int k = 0; k < m; ++k)
+			{
+				const int ci = s_sorted[k];
+				const int slot = s_slot[k];
+				--count;
+				const int last = s_tail[count - base], lastJ = s_tailJ[count - base];
+				W.toiPos2c[slot] = last;
+				C.mgr[last] = slot;
+				if (slot >= base) { s_tail[slot - base] = last; s_tailJ[slot - base] = lastJ; }
+				if (lastJ >= 0) s_slot[lastJ] = slot;
+				C.mgr[ci] = -1;
+			}
+			__threadfence();
+		}
+		count = count0 - m; // (every lane keeps count: m removals)
+		__syncthreads();
 	}
-	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		int count = count0;
-		for (int k = 0; k < m; ++k)
-		{
-			const int ci = s_sorted[k];
-			const int slot = s_slot[k];
-			--count;
-			const int last = s_tail[count - base], lastJ = s_tailJ[count - base];
-			W.toiPos2c[slot] = last;
-			C.mgr[last] = slot;
-			if (slot >= base) { s_tail[slot - base] = last; s_tailJ[slot - base] = lastJ; }
-			if (lastJ >= 0) s_slot[lastJ] = slot;
-			C.mgr[ci] = -1;
-		}
 		S->c.nToiOrder = count;
 		S->c.nToiDestroy = 0;
-		if (n > TOI_ORDER_SORT_MAX) atomicOr(&S->c.overflow, 16);
 	}
 }
 
@@ -637,6 +696,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		(&c.nPairs)[1] = 0;
 		c.overflow = 0;
 		c.cellExtBits = 0;
+		c.gridFresh = 0;
 		c.nEvents = 0;
 		c.nToiList = 0;
 		c.nNewToiCand = 0;

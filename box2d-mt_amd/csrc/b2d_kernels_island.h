@@ -300,6 +300,12 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 {
 	b2dPhaseStamp(W);
 	const int n = W.nBodies;
+	// census of the largest contact degree (k_island_union counted deg[]) - and WHOSE it is when it makes a hub: the primary
+	// hub, whose constraints k_sweep_end takes as one fixed point (ties: the higher body id) - and the busiest body below the
+	// hub threshold: what a colouring cannot go under (the host's measure of how far the colours in use have crept,
+	// b2hip_host_phases.h). Kept per lane over the loop and offered ONCE per workgroup: an offer is a load past the L2 of a
+	// word every workgroup looks at (two such loads per wave and round were 40 us of this kernel on a million bodies).
+	int dg = 0, who = -1, dgPlain = 0;
 	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
 		const int i = base + threadIdx.x;
@@ -311,35 +317,41 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 		{
 			r = ufFindReadOnly(W.parent, i);
 			__hip_atomic_store(&W.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		{
-			// census of the largest contact degree (k_island_union counted deg[]) - and WHOSE it is when it makes a hub: the
-			// primary hub, whose constraints k_sweep_end takes as one fixed point (ties: the higher body id)
-			int dg = valid ? W.deg[i] : 0, who = valid ? i : -1;
-			for (int off = 32; off > 0; off >>= 1)
-			{
-				const int o = __shfl_xor(dg, off), ow = __shfl_xor(who, off);
-				if (o > dg || (o == dg && ow > who)) { dg = o; who = ow; }
-			}
-			// (... and the busiest body below the hub threshold: what a colouring cannot go under - the host's measure of how far
-			// the colours in use have crept, b2hip_host_phases.h)
-			int dgPlain = valid && W.deg[i] <= HUB_DEGREE ? W.deg[i] : 0;
-			for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(dgPlain, off); dgPlain = o > dgPlain ? o : dgPlain; }
-			if (waveLane() == 0 && dgPlain > 0) atomicMaxIfAbove(&W.st->c.maxDegreePlain, dgPlain);
-			if (waveLane() == 0 && dg > 0)
-			{
-				atomicMaxIfAbove(&W.st->c.maxDegree, dg);
-				if (dg > HUB_DEGREE)
-				{
-					const unsigned long long key = ((unsigned long long)(uint32_t)dg << 32) | (unsigned long long)(uint32_t)who;
-					if (key > __hip_atomic_load(&W.hubMeta[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&W.hubMeta[0], key);
-				}
-			}
+			const int d = W.deg[i];
+			if (d > dg || (d == dg && i > who)) { dg = d; who = i; }
+			if (d <= HUB_DEGREE && d > dgPlain) dgPlain = d;
 		}
 		// (a root has counted itself and offered its own seed in k_island_init: only the other members add to it)
 		const bool other = valid && r != i;
 		waveAtomicAddInt(W.rootBodies, r, 1, other);
 		waveAtomicMinInt(W.rootSeed, r, other ? W.b_order[i] : 0, other && (f & BF_AWAKE) != 0);
+	}
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const int o = __shfl_xor(dg, off), ow = __shfl_xor(who, off), op = __shfl_xor(dgPlain, off);
+		if (o > dg || (o == dg && ow > who)) { dg = o; who = ow; }
+		dgPlain = op > dgPlain ? op : dgPlain;
+	}
+	__shared__ int s_dg[4], s_who[4], s_plain[4];
+	if (waveLane() == 0) { s_dg[threadIdx.x >> 6] = dg; s_who[threadIdx.x >> 6] = who; s_plain[threadIdx.x >> 6] = dgPlain; }
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		for (int k = 1; k < 4; ++k)
+		{
+			if (s_dg[k] > dg || (s_dg[k] == dg && s_who[k] > who)) { dg = s_dg[k]; who = s_who[k]; }
+			dgPlain = s_plain[k] > dgPlain ? s_plain[k] : dgPlain;
+		}
+		if (dgPlain > 0) atomicMaxIfAbove(&W.st->c.maxDegreePlain, dgPlain);
+		if (dg > 0)
+		{
+			atomicMaxIfAbove(&W.st->c.maxDegree, dg);
+			if (dg > HUB_DEGREE)
+			{
+				const unsigned long long key = ((unsigned long long)(uint32_t)dg << 32) | (unsigned long long)(uint32_t)who;
+				if (key > __hip_atomic_load(&W.hubMeta[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&W.hubMeta[0], key);
+			}
+		}
 	}
 }
 

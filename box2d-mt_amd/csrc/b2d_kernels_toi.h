@@ -6,7 +6,7 @@
 // contacts), solve it, re-sync its proxies, create the contacts that movement produced, recompute the
 // invalidated impacts, repeat (StepSolveTOI :851-1024).
 //
-// Mapping here: (1) is k_toi_first, one lane per contact over the whole contact array. (2) runs inside
+// Mapping here: (1) is k_toi_first, one lane per TOI-candidate contact (the manager's slot table). (2) runs inside
 // ONE persistent workgroup (k_toi_loop) so that an event costs no launch and no host round trip; inside
 // an event everything that commutes is done by all lanes (candidate manifolds, proxy re-sync, pair
 // search, impact recomputation) and only the order-defining decisions (which candidate enters the
@@ -120,8 +120,16 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 		if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S->c.toiUnsafe, 1); // (never the parallel chains)
 		return;
 	}
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	// Only TOI candidates can be eligible or carry TOI state (CF_TOI_STATE_MASK: set below and by the event loops for eligible
+	// contacts only, wiped by k_edit_* when a contact stops being a candidate), and the candidates are listed: the manager's slot
+	// table (DW::toiPos2c[0, nToiOrder), kept by toiOrderDestroy / k_toi_order_create / the edits). A lane per SLOT instead of a
+	// lane per contact: the million-body field has 1.2 M contacts and ~40 000 candidates, whose evaluations - thousands of
+	// instructions each - were spread one or two to a wave over every wave of the launch (113 us); now they sit side by side.
+	const int nSlots = S->c.nToiOrder < W.capContacts ? S->c.nToiOrder : W.capContacts;
+	(void)n;
+	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nSlots; s += gridDim.x * blockDim.x)
 	{
+		const int i = W.toiPos2c[s];
 		uint32_t flags = C.flags[i] & ~CF_TOI_STATE_MASK;
 		const int4 ids = C.ids[i];
 		if (toiEligible(W, flags, ids))
@@ -348,6 +356,7 @@ __device__ __forceinline__ Sweep advancedSweep(const DW& W, int body, float alph
 __device__ __forceinline__ void storeAdvanced(const DW& W, int body, const Sweep& s)
 {
 	const float sleepTime = W.b_pos[body].w;
+	W.b_rowDirty[body] = 1;
 	W.b_pos0[body] = make_float4(s.c0.x, s.c0.y, s.a0, s.alpha0);
 	W.b_pos[body] = make_float4(s.c.x, s.c.y, s.a, sleepTime);
 	const Xf xf = b2dXfFromSweep(s.c, s.a, s.localCenter);
@@ -456,6 +465,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 	{
 		const uint32_t old = atomicOr(&W.b_flags[body], BF_AWAKE);
 		W.b_pos[body].w = 0.0f;
+		W.b_rowDirty[body] = 1;
 		if ((old & BF_AWAKE) == 0)
 		{
 			// (a woken body resting on a static one would read that body's alpha0, which other components also advance)
@@ -559,7 +569,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 					any = true;
 					b2dSweepAdvance(sw, s_advAlpha[k]);
 				}
-				if (any) W.b_pos0[s_flatBody[q]] = make_float4(sw.c0.x, sw.c0.y, sw.a0, sw.alpha0);
+				if (any) { W.b_pos0[s_flatBody[q]] = make_float4(sw.c0.x, sw.c0.y, sw.a0, sw.alpha0); W.b_rowDirty[s_flatBody[q]] = 1; }
 			}
 			__syncthreads();
 			for (int r = tid; r < nRecomp; r += TOI_LANES)
@@ -986,7 +996,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		{
 			const int b = s_bodies[tid];
 			const float4 p = s_pos[tid];
-			if (!DOMAIN || (ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) != BT_STATIC) W.b_pos0[b] = make_float4(p.x, p.y, p.z, minAlpha);
+			if (!DOMAIN || (ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) != BT_STATIC) { W.b_pos0[b] = make_float4(p.x, p.y, p.z, minAlpha); W.b_rowDirty[b] = 1; }
 		}
 		if (ci >= 0) initConstraint();
 		TOI_WAVE_SYNC();
@@ -1038,6 +1048,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			const float sleepTime = W.b_pos[b].w;
 			W.b_pos[b] = make_float4(c.x, c.y, a, sleepTime);
 			W.b_vel[b] = make_float4(vv.x, vv.y, w, 0.0f);
+			W.b_rowDirty[b] = 1;
 			const Xf xf = b2dXfFromSweep(c, a, v2(m.z, m.w));
 			W.b_xf[b] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
 		}
@@ -1321,6 +1332,9 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		TOI_T(9);
 	}
 	if (!DOMAIN && !partial && tid < 12) W.hubList[tid] = (int)s_t[tid];
+	// (diagnostics: a component's phase ticks, events, TOI calls and pending contacts in 16 words behind those - tools/gpu_toi_domains_probe.py)
+	if (DOMAIN && tid < 15 && 16 + 16 * (domain + 1) <= W.capContacts)
+		W.hubList[16 + 16 * domain + tid] = tid < 12 ? (int)s_t[tid] : tid == 12 ? s_events : tid == 13 ? s_calls : s_nL;
 #undef TOI_T
 
 	if (tid == 0)

@@ -100,6 +100,23 @@ __device__ __forceinline__ void toiSnapshotSave(const DW& W)
 	}
 }
 
+// What k_toi_first wrote while the snapshot was being taken beside it: flags and time of impact of the TOI candidates.
+__global__ __launch_bounds__(256) void k_toi_snap_cands(DW W)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const ContactArrays& A = W.ca[S->cur];
+	const ContactArrays& B = W.ca[1 - S->cur];
+	const int nSlots = S->c.nToiOrder < W.capContacts ? S->c.nToiOrder : W.capContacts;
+	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nSlots; s += gridDim.x * blockDim.x)
+	{
+		const int i = W.toiPos2c[s];
+		if (A.flags[i] & CF_FOREIGN) continue;
+		B.flags[i] = A.flags[i];
+		B.mat[i] = A.mat[i];
+	}
+}
+
 // The contacts of every chain body, gathered in one pass over the contact array (b_toiGroup = chain index + 1).
 // withSnapshot: the state the chains may touch is saved by the same launch (k_toi_snapshot, restore = 0, was one more).
 __global__ __launch_bounds__(256) void k_toi_group_contacts(DW W, int withSnapshot)
@@ -124,7 +141,8 @@ __global__ __launch_bounds__(256) void k_toi_group_contacts(DW W, int withSnapsh
 	}
 }
 
-// restore = 0: toiSnapshotSave as a launch of its own; 1: everything back.
+// restore = 0: toiSnapshotSave as a launch of its own; 1: everything back; 2: saved whether or not an impact is pending - the
+// launch runs BESIDE k_toi_first, which finds that out (b2hip_host_phases.h: phaseToiSync; k_toi_snap_cands completes it).
 __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 {
 	b2dPhaseStamp(W);
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 	// run although nothing is pending yet - the event loop's first batch computes the impacts - so its snapshot is always due:
 	// a PreSolve answer from that call's sub-step otherwise took the phase back to an EARLIER call's snapshot, materials included.)
 	if (!restore && S->c.nToiList == 0 && !W.toiContinue) return;
-	if (!restore)
+	if (restore != 1)
 	{
 		toiSnapshotSave(W);
 	}
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(256) void k_toi_snapshot(DW W, int restore)
 			W.b_vel[i] = W.snapBody[5 * (size_t)i + 2];
 			W.b_xf[i] = W.snapBody[5 * (size_t)i + 3];
 			W.b_flags[i] = __float_as_uint(W.snapBody[5 * (size_t)i + 4].x);
+			W.b_rowDirty[i] = 1; // (whatever the phase made of the row: the read-back compares it again)
 			W.b_toiGroup[i] = 0;
 		}
 		for (int p = t0; p < W.nProxies; p += stride) W.p_fat[p] = W.snapFat[p];
@@ -216,6 +235,7 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 	{
 		const uint32_t old = atomicOr(&W.b_flags[body], BF_AWAKE);
 		W.b_pos[body].w = 0.0f;
+		W.b_rowDirty[body] = 1;
 		if ((old & BF_AWAKE) == 0 && (old & BF_TYPE_MASK) != BT_STATIC) atomicOr(&s_unsafe, TOI_UNSAFE_WOKE);
 	};
 	// static partners are always in sync with D (see the header): give both sweeps D's alpha0
@@ -495,6 +515,7 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 		{
 			const float4 p = s_pos[lane];
 			W.b_pos0[D] = make_float4(p.x, p.y, p.z, minAlpha);
+			W.b_rowDirty[D] = 1;
 		}
 		if (ci >= 0) initConstraint();
 		__syncthreads();
@@ -524,6 +545,7 @@ __device__ __forceinline__ void toiChainRun(const DW& W, const StepParams& sp, i
 			const float sleepTime = W.b_pos[D].w;
 			W.b_pos[D] = make_float4(c.x, c.y, a, sleepTime);
 			W.b_vel[D] = make_float4(vv.x, vv.y, w, 0.0f);
+			W.b_rowDirty[D] = 1;
 			const Xf xf = b2dXfFromSweep(c, a, v2(massD.z, massD.w));
 			W.b_xf[D] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
 		}
@@ -805,6 +827,8 @@ __device__ __forceinline__ void toiChainsEnd(const DW& W)
 					// SetAwake(true) on both (:525-529): both are awake (the chains note no pair with a sleeper); the timers restart
 					W.b_pos[bodyA].w = 0.0f;
 					W.b_pos[bodyB].w = 0.0f;
+					W.b_rowDirty[bodyA] = 1;
+					W.b_rowDirty[bodyB] = 1;
 				}
 			}
 			__syncthreads();
@@ -861,6 +885,7 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 		S->c.nPairs = 0;
 		S->c.nNewContacts = 0;
 		S->c.nMovesSeen = S->c.nMoves;
+		S->c.gridFresh = S->c.nMoves != 0 ? 1 : 0; // (this update builds the grid from every proxy's box: k_bp_build, k_grid_fill)
 	}
 	if (blockIdx.x == 0 && threadIdx.x < 32) S->c.candRounds[threadIdx.x] = 0;
 	if (S->c.nMoves == 0) return;

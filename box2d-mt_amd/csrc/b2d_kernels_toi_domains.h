@@ -173,6 +173,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_domains(DW W, StepParams sp)
 	DState* S = W.st;
 	if (S->c.toiUnsafe & TOI_UNSAFE_CAPACITY) return;
 	const int n = S->c.nToiDomains < TOI_DOMAINS_MAX ? S->c.nToiDomains : TOI_DOMAINS_MAX;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && W.capContacts > 16) W.hubList[12] = n; // (diagnostics: how many rows behind word 16 are this step's)
 	for (int d = blockIdx.x; d < n; d += gridDim.x)
 	{
 		toiLoopRun<true>(W, sp, d, 0);
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256) void k_toi_dom_rollback(DW W)
 		W.b_vel[i] = W.snapBody[5 * (size_t)i + 2];
 		W.b_xf[i] = W.snapBody[5 * (size_t)i + 3];
 		W.b_flags[i] = __float_as_uint(W.snapBody[5 * (size_t)i + 4].x);
+		W.b_rowDirty[i] = 1;
 	}
 	for (int p = t0; p < W.nProxies; p += stride)
 	{

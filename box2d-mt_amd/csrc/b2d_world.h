@@ -153,6 +153,7 @@ struct Counters
 	int compactTick;     // persistent: steps, for the slow beat of an idle colouring
 	int maxDegree;       // largest number of solid touching contacts on one non-static body this step
 	int maxDegreePlain;  // ... among the bodies that are no hubs (<= HUB_DEGREE): the fewest colours a colouring of their constraints can have
+	int gridFresh;       // the hash grid holds every proxy's fat AABB as of now: built by this step's pair update (k_bp_clear / k_bp_build), nothing has moved a proxy since (k_step_begin, k_sync_fixtures reset it) - the TOI phase then queries it as it is
 	int nHubRows;        // hub constraints of this step
 	int nHubWide;        // ... the first so many of hubList are constraints of the PRIMARY hub with different non-hub partners: one fixed point (k_sweep_end)
 	int hubEpoch;        // persistent: steps counted for the tags of DW::hubFirst
@@ -183,7 +184,7 @@ struct Counters
 	int nRemoteIslands;  // islands of this step that another rank solves
 	int nSerialOrphans;  // constraints swept in order this step because a body of theirs has no home block (rowIsSerial)
 	int compactBlocksDone; // workgroups of k_compact_contacts that have finished (the last one switches the contact buffers)
-	int endBlocksDone;     // ... of k_end_step (the last one appends the counters to the read-back)
+	int endBlocksDone;     // tiles of 256 bodies the last marks-driven k_end_step looked at (diagnostics; its last workgroup puts it back to 0 behind the read-back)
 	int rowsSkipped;       // k_end_step left the state rows out: the host will finish the pair update and read back again
 	int collideBlocksDone; // ... of k_collide (the last one runs toiOrderDestroy)
 	int chainBlocksDone;   // ... of k_toi_chains (the last one runs toiChainsEnd)
@@ -376,6 +377,7 @@ struct DW
 	float4* dfInbox;        // per large-island constraint row: two tagged 16-byte slots (body A, body B)
 	float4* b_posv;         // per body: (c.xy, a, version) rows of the dataflow solver's position phase
 	float* lc;           // large-island constraint rows, field-major: lc[field * capContacts + slot]
+	int* b_rowDirty;        // per body: its read-back row (or its sweep's alpha0) was written behind SynchronizeFixtures - by contact creation's wake-ups or the TOI phase; k_end_step looks at these bodies only when the rows left early (b2hip_host_phases.h: startEarlyRows) and clears the marks
 	float4* warmDelta;   // per large-island constraint row: 4 x float4 - what its warm start subtracts from body A (points 0, 1) and adds to body B (k_large_init -> k_large_warm)
 	uint32_t* rootPen;   // per root: max penetration of the running position iteration (bits of -minSeparation)
 	int* rootDone;       // per root: positionSolved

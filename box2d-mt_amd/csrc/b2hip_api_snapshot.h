@@ -324,6 +324,7 @@ int b2hip_load_snapshot(const void* buffer, size_t size, int device, b2hip_world
 	if (hipMemcpy(w->d_state.p, &ds, sizeof(DState), hipMemcpyHostToDevice) != hipSuccess) return fail(setError(B2HIP_ERR_HIP, "snapshot upload failed (state block)"));
 	w->pubSeq = ds.pubCount; // (the device numbers its census publications; the host counts along)
 	SNAP_UP(b_pos, sPos); SNAP_UP(b_pos0, sPos0); SNAP_UP(b_vel, sVel); SNAP_UP(b_xf, sXf); SNAP_UP(b_mass, sMass); SNAP_UP(b_damp, sDamp);
+	w->forceOnDevice = true; w->rowsWentEarly = false;
 	SNAP_UP(b_force, sForce); SNAP_UP(b_flags, sFlags); SNAP_UP(b_wake, sWake); SNAP_UP(b_proxyHead, sHead); SNAP_UP(b_blk1, sBlk);
 	SNAP_UP(p_fat, sFat); SNAP_UP(p_body, sPBody); SNAP_UP(p_shape, sPShape); SNAP_UP(p_key, sPKey); SNAP_UP(p_filter0, sF0); SNAP_UP(p_filter1, sF1);
 	SNAP_UP(p_mat, sPMat); SNAP_UP(p_next, sNext);

@@ -416,6 +416,7 @@ static int stepEndImpl(b2hip_world* w)
 	// bit 1: candidate-pair buffer; bit 0 with moves still buffered: the new contacts did not fit and creation was skipped
 	// as a whole (createBlocked) - both are cured by growing and running the pair update again. Bit 0 without buffered
 	// moves comes from a contact created inside a TOI sub-step: that one is lost.
+	if (w->h_dstate->c.overflow & 16) return setError(B2HIP_ERR_CAPACITY, "more TOI-candidate contacts destroyed in one step than the pair buffer has room to order (toiOrderDestroy)");
 	const bool pairOverflow = (w->h_dstate->c.overflow & 2) != 0 || ((w->h_dstate->c.overflow & 1) != 0 && w->h_dstate->c.nMoves != 0);
 	if ((w->h_dstate->c.overflow & 1) != 0 && !pairOverflow) return setError(B2HIP_ERR_CAPACITY, "contact array full during a TOI sub-step");
 	if (pairOverflow && w->sp.dt <= 0.0f) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");

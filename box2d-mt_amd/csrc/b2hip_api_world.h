@@ -228,7 +228,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->spTape.clear();
 	w->d_state.release();
 	w->b_pos.release(); w->b_pos0.release(); w->b_vel.release(); w->b_xf.release(); w->b_mass.release(); w->b_damp.release();
-	w->b_force.release(); w->b_flags.release(); w->b_wake.release();
+	w->b_force.release(); w->b_flags.release(); w->b_wake.release(); w->b_rowDirty.release();
 	w->p_fat.release(); w->p_body.release(); w->p_shape.release(); w->p_key.release(); w->p_filter0.release(); w->p_filter1.release();
 	w->p_mat.release(); w->d_shapes.release();
 	for (int k = 0; k < 2; ++k)

@@ -964,18 +964,29 @@ static int phaseSyncFixtures(b2hip_world* w)
 }
 
 // The serial event loop walks contacts by body (CSR) and searches new pairs through the hash grid.
-static int toiBuildIndexes(b2hip_world* w, bool csr)
+static int toiBuildAdjacency(b2hip_world* w, hipStream_t s)
+{
+	DW& d = w->dw;
+	LAUNCH_ON(w, s, k_toi_adj_clear, gridFor(d.nBodies + 1), 256, d);
+	LAUNCH_ON(w, s, k_toi_adj_count, gridFor(d.capContacts), 256, d);
+	deviceExclusiveScan<int>(s, d.deg, d.adjStart, d.scanTmp, w->scanCtx, w->consts.p + 4, d.nBodies + 1);
+	LAUNCH_ON(w, s, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
+	return 0;
+}
+
+static int toiBuildIndexes(b2hip_world* w, bool csr, bool gridKnownFresh = false)
 {
 	DW& d = w->dw;
 	if (csr)
 	{
-		LAUNCH(w, k_toi_adj_clear, gridFor(d.nBodies + 1), 256, d);
-		LAUNCH(w, k_toi_adj_count, gridFor(d.capContacts), 256, d);
-		deviceExclusiveScan<int>(w->stream, d.deg, d.adjStart, d.scanTmp, w->scanCtx, w->consts.p + 4, d.nBodies + 1);
-		LAUNCH(w, k_toi_adj_fill, gridFor(d.capContacts), 256, d);
+		int rc = toiBuildAdjacency(w, w->stream);
+		if (rc) return rc;
 	}
 	// make the grid reflect every fat AABB as of now (the end-of-step pair update skips the rebuild when nothing
-	// moved, and TOI moves of earlier steps never enter the move buffer)
+	// moved, and TOI moves of earlier steps never enter the move buffer) - unless this step's pair update has just built it
+	// from every proxy's box and nothing moved one since (Counters::gridFresh; the kernels below check it themselves, the
+	// host saves their launches when the read-back it already has says so: 128 us of a million-proxy world's step)
+	if (gridKnownFresh && !w->spatial) return 0;
 	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
 	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
 	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanCtx, w->consts.p + 1, (int)(d.gridMask + 1));
@@ -986,7 +997,8 @@ static int toiBuildIndexes(b2hip_world* w, bool csr)
 static int toiSerial(b2hip_world* w)
 {
 	DW& d = w->dw;
-	int rc = toiBuildIndexes(w, true);
+	// (every caller has read this step's counters back since the pair update: phaseToiSync, the fall-backs of b2hip_step_end)
+	int rc = toiBuildIndexes(w, true, w->h_dstate->c.gridFresh != 0);
 	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
 	LAUNCH(w, k_toi_loop, 1, TOI_LANES, d, w->sp);
@@ -998,6 +1010,14 @@ static int toiSerial(b2hip_world* w)
 // b2World::SolveTOI (b2World.cpp:1026-1093). The first arg-min pass runs over the whole contact array; the
 // event loop only runs (one persistent workgroup) when some impact lies inside the step.
 static int phaseToiSync(b2hip_world* w);
+
+// k_toi_first takes a lane per TOI candidate (grid-stride over the manager's slot table): sized from the candidate count of
+// the last read-back, generously - a wrong guess only makes the lanes loop.
+static inline int toiFirstGrid(b2hip_world* w)
+{
+	const size_t hint = (size_t)std::max(w->h_dstate->c.nToiOrder, 0);
+	return gridFor(std::min<size_t>((size_t)w->dw.capContacts, std::max<size_t>(2 * hint + 4096, 65536)));
+}
 
 // The phase without a host round trip: k_toi_first, then the chain kernels at once. Each of them leaves immediately if no
 // impact is pending (or if k_toi_first saw a bullet / kinematic partner: toiUnsafe), so the host learns the outcome from
@@ -1024,7 +1044,7 @@ static int phaseToi(b2hip_world* w)
 		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
 	}
 	w->toiCountersFresh = false;
-	LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_toi_first, toiFirstGrid(w), 256, d);
 	const int haveGrid = w->toiGridSticky > 0 ? 1 : 0;
 	LAUNCH(w, k_toi_groups_begin, gridFor(std::min(d.capContacts, 1 << 16)), 256, d);
 	LAUNCH(w, k_toi_group_contacts, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 1); // (+ the snapshot)
@@ -1048,8 +1068,36 @@ static int phaseToiSync(b2hip_world* w)
 	// one read-back serves both questions: did the optimistic small-sort path of the end-of-step pair update
 	// apply (else finish it first: the TOI phase must see every contact), and is any impact pending
 	int rc = 0;
+	// While the component-wise event loops have been in use (bullets: config 5), what they need besides the first pass - the
+	// snapshot (230 MB for a million bodies: bandwidth), the adjacency of all contacts and the components (a dozen short
+	// launches: latency) - does not wait for it: none of that reads what k_toi_first writes except the candidates' flags and
+	// impact times, which k_toi_snap_cands copies afterwards. It runs on the side stream (idle behind Solve) beside
+	// k_toi_first - a few heavy lanes, ~120 us - and the host's look at its census: ~180 us of the step's critical path.
+	// Void if the pair update has to be finished first (the contact array grows under it): then everything is done again below.
+	bool aside = false;
+	if (w->toiDomainsSticky > 0 && w->toiCountersFresh && !w->spatial && w->stream2 != nullptr && !w->noSideStream && !w->debugSync && !w->debugTrace &&
+		!w->toiSnapshotTaken && !w->toiSerialOnly && !w->toiNoDomains && !listenerOn(w) && d.toiEventCap == 0 && !d.toiContinue)
+	{
+		HIP_TRY(hipEventRecord(w->evFork, w->stream));
+		HIP_TRY(hipStreamWaitEvent(w->stream2, w->evFork, 0));
+		LAUNCH_ON(w, w->stream2, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 2);
+		rc = toiBuildAdjacency(w, w->stream2);
+		if (rc) return rc;
+		LAUNCH_ON(w, w->stream2, k_toi_dom_init, gridFor(d.nBodies), 256, d);
+		LAUNCH_ON(w, w->stream2, k_toi_dom_union, gridFor(d.capContacts), 256, d);
+		LAUNCH_ON(w, w->stream2, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
+		HIP_TRY(hipEventRecord(w->evJoin, w->stream2));
+		aside = true;
+	}
+	bool asideValid = aside;
 	for (int pass = 0; pass < 2; ++pass)
 	{
+		if (pass == 1 && aside)
+		{
+			// (the contact array is about to change, or has: the side stream's work is void - and must have ended)
+			HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
+			asideValid = false;
+		}
 		if (pass == 1 || !w->toiCountersFresh)
 		{
 			// (the first pass of a step starts from the zeros of k_step_begin)
@@ -1057,13 +1105,14 @@ static int phaseToiSync(b2hip_world* w)
 			HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int) * 3, w->stream));
 		}
 		w->toiCountersFresh = false;
-		LAUNCH(w, k_toi_first, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_toi_first, toiFirstGrid(w), 256, d);
 		rc = readState(w);
 		if (rc) return rc;
 		if (w->h_dstate->c.overflow & 3)
 		{
 			// the end-of-step pair update overflowed its buffer (or the contact array): grow, run the whole update again, look again
 			if (pass == 1) return setError(B2HIP_ERR_CAPACITY, "pair buffer overflow");
+			if (aside && asideValid) { HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0)); asideValid = false; }
 			rc = growPairBuffers(w);
 			if (rc) return rc;
 			rc = findNewContacts(w, true);
@@ -1071,9 +1120,13 @@ static int phaseToiSync(b2hip_world* w)
 			continue;
 		}
 		if (pass == 1 || w->h_dstate->c.nMoves == 0 || w->h_dstate->c.nPairs <= COUNT_RANK_MAX) break;
+		if (aside && asideValid) { HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0)); asideValid = false; }
 		rc = runSortAndCreate(w, true, w->h_dstate->c.nPairs);
 		if (rc) return rc;
 	}
+	// (whatever follows writes what the side stream reads: it has had ~200 us, the wait is a formality)
+	if (aside) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
+	if (w->toiDomainsSticky > 0) w->toiDomainsSticky -= 1;
 	w->last.nToiList = w->h_dstate->c.nToiList;
 	w->last.nToiCalls = w->h_dstate->c.nToiCalls;
 	w->last.nToiEvents = 0;
@@ -1099,7 +1152,7 @@ static int phaseToiSync(b2hip_world* w)
 		w->toiSnapshotTaken = true;
 		if (haveGrid)
 		{
-			rc = toiBuildIndexes(w, false);
+			rc = toiBuildIndexes(w, false, w->h_dstate->c.gridFresh != 0);
 			if (rc) return rc;
 		}
 		LAUNCH(w, k_toi_chains, std::min(groups, 1024), CHAIN_LANES, d, w->sp, haveGrid);
@@ -1113,17 +1166,33 @@ static int phaseToiSync(b2hip_world* w)
 		// bullets / kinematic partners: the event loop runs per connected component of the contact graph, side by side
 		// (b2d_kernels_toi_domains.h); b2hip_step_end falls back to the serial loop from the snapshot if a component met
 		// something that couples it to another one
-		rc = toiBuildIndexes(w, true);
+		// The snapshot (230 MB for a million bodies: bandwidth) runs on the side stream beside the dozen short launches that build
+		// the adjacency and the components (latency): nothing they write is anything it reads, the stream is drained (readState
+		// above), and the side stream is idle behind Solve. The event loops wait for it.
+		w->toiDomainsSticky = 16;
+		const bool snapAside = !asideValid && w->stream2 != nullptr && !w->noSideStream && !w->debugSync && !w->debugTrace;
+		if (snapAside)
+		{
+			LAUNCH_ON(w, w->stream2, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+			HIP_TRY(hipEventRecord(w->evJoin, w->stream2));
+		}
+		// (asideValid: snapshot, adjacency and components are there - the grid, if this step's pair update has not left one)
+		rc = toiBuildIndexes(w, !asideValid, w->h_dstate->c.gridFresh != 0);
 		if (rc) return rc;
-		LAUNCH(w, k_toi_dom_init, gridFor(d.nBodies), 256, d);
-		LAUNCH(w, k_toi_dom_union, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
+		if (!asideValid)
+		{
+			LAUNCH(w, k_toi_dom_init, gridFor(d.nBodies), 256, d);
+			LAUNCH(w, k_toi_dom_union, gridFor(d.capContacts), 256, d);
+			LAUNCH(w, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
+		}
 		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int), w->stream)); // (k_toi_first's "not chains" bit)
 		LAUNCH(w, k_toi_dom_mark, gridFor(w->h_dstate->c.nToiList), 256, d);
 		LAUNCH(w, k_toi_dom_count, gridFor(d.capContacts), 256, d);
 		LAUNCH(w, k_toi_dom_scan, 1, 1024, d);
 		LAUNCH(w, k_toi_dom_fill, gridFor(w->h_dstate->c.nToiList), 256, d);
-		LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+		if (asideValid) LAUNCH(w, k_toi_snap_cands, toiFirstGrid(w), 256, d);
+		else if (snapAside) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
+		else LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
 		w->toiSnapshotTaken = true;
 		LAUNCH(w, k_toi_domains, std::min(w->h_dstate->c.nToiList, 2048), TOI_LANES, d, w->sp);
 		LAUNCH(w, k_toi_domains_end, std::min(std::max(w->h_dstate->c.nToiList, 1), 1024), 256, d);
@@ -1204,12 +1273,13 @@ static int startEarlyRows(b2hip_world* w)
 	// slower - measured, 1 M bodies: 3.77 ms per step without the early launch, 3.29 at best with such a kernel, 3.11 with the copy.)
 	DW dEarly = d;
 	dEarly.stampMask = 0u; // (the phase stamps belong to the main stream's next kernel)
-	hipLaunchKernelGGL(k_end_step, dim3(gridFor(d.nBodies)), dim3(256), 0, w->rowStream, dEarly, 0, (const int*)nullptr, w->stateOut.p, 0, END_STEP_EARLY, (float*)nullptr, 0);
+	hipLaunchKernelGGL(k_end_step, dim3(gridFor(d.nBodies)), dim3(256), 0, w->rowStream, dEarly, 0, (const int*)nullptr, w->stateOut.p, 0, END_STEP_EARLY, (float*)nullptr, 0, 0);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, (size_t)d.nBodies * 10 * sizeof(float), hipMemcpyDeviceToHost, w->rowStream));
 	HIP_TRY(hipEventRecord(w->rowJoin, w->rowStream));
 	shadowWritten(w);
 	w->rowsEarlyPending = true;
+	w->rowsWentEarly = true;
 	return 0;
 }
 
@@ -1235,7 +1305,9 @@ static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 	if (w->noStatePoll)
 	{
 		// B2HIP_NO_STATE_POLL=1, for comparison: into the device staging array, one copy, stream synchronisation
-		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq, 0, (float*)nullptr, 0);
+		LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->stateOut.p, w->stateSeq, 0, (float*)nullptr, 0, 0);
+		w->rowsWentEarly = false;
+		if (clear) w->forceOnDevice = false;
 		HIP_TRY(hipMemcpyAsync(w->h_state, w->stateOut.p, B2D_STATE_TAIL(nb) * sizeof(float) + sizeof(DState), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 		memcpy(w->h_dstate, w->h_state + B2D_STATE_TAIL(nb), offsetof(DState, pubSeq));
@@ -1243,13 +1315,23 @@ static int downloadState(b2hip_world* w, int clearForces, bool skipRowsIfRedo)
 		return 0;
 	}
 	const int rowMode = shadowValid(w) ? 2 : 1;
+	// The first read-back behind this step's early launch looks only at the tiles somebody has written a row of since
+	// (DW::b_rowDirty) - unless it has forces to clear in every tile, or sweeps to reset that earlier calls of a sub-stepped
+	// step advanced. Any later read-back of the step (fall-backs, a finished pair update) compares every row again.
+	const bool clearing = clear && w->forceOnDevice;
+	if (w->traceLaunches) fprintf(stderr, "[b2hip] host: read-back: rows went early %d, row mode %d, lazy %d, clearing %d (clear %d), marks %d\n", (int)w->rowsWentEarly, rowMode, (int)lazy, (int)clearing, clear, w->rowMarks);
+	const int marks = (w->rowsWentEarly && rowMode == 2 && !lazy && !w->spatial && !clearing && !d.toiContinue && d.toiEventCap == 0) ? w->rowMarks : 0;
+	w->rowsWentEarly = false;
 	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, clear, (const int*)w->gridBar.p, w->d_hstate, w->stateSeq,
-		lazy ? END_STEP_LAZY : skipRowsIfRedo ? END_STEP_SKIP_IF_REDO : END_STEP_FULL, w->stateOut.p, rowMode);
+		lazy ? END_STEP_LAZY : skipRowsIfRedo ? END_STEP_SKIP_IF_REDO : END_STEP_FULL, w->stateOut.p, rowMode, marks);
 	if (w->traceLaunches) { fprintf(stderr, "[b2hip] host: awaiting the read-back %d\n", w->stateSeq); fflush(stderr); }
 	const int rc = awaitState(w, nb);
-	if (w->traceLaunches) { fprintf(stderr, "[b2hip] host: read-back %d arrived (rc %d)\n", w->stateSeq, rc); fflush(stderr); }
+	if (w->traceLaunches) { fprintf(stderr, "[b2hip] host: read-back %d arrived (rc %d), marked tiles %d of %d\n", w->stateSeq, rc, w->h_dstate->c.endBlocksDone, (d.nBodies + 255) / 256); fflush(stderr); }
 	// (rowsSkipped: 0 - the rows were stored; the shadow of a full write is valid from here on)
 	if (rc == 0 && rowMode == 1 && w->h_dstate->c.rowsSkipped == 0) shadowWritten(w);
+	// (the forces are cleared row by row inside the tile loop: not when the rows were skipped)
+	if (rc == 0 && clear && w->h_dstate->c.rowsSkipped != 1) w->forceOnDevice = false;
+	if (rc == 0 && (w->h_dstate->c.overflow & 0x1000)) return setError(B2HIP_ERR_INVALID, "B2HIP_ROW_MARKS_CHECK: a body's read-back row changed behind the early launch without a mark (DW::b_rowDirty)");
 	return rc;
 }
 
@@ -1264,7 +1346,7 @@ static int fetchRows(b2hip_world* w)
 	if (w->stateSeq == 0) w->stateSeq = 1;
 	((DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq = 0;
 	const int rowMode = shadowValid(w) ? 2 : 1;
-	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0, (const int*)nullptr, w->d_hstate, w->stateSeq, END_STEP_ROWS, w->stateOut.p, rowMode);
+	LAUNCH(w, k_end_step, gridFor(d.nBodies), 256, d, 0, (const int*)nullptr, w->d_hstate, w->stateSeq, END_STEP_ROWS, w->stateOut.p, rowMode, 0);
 	const int rc = pollPublished(w, (volatile const int*)&((const DState*)(w->h_state + B2D_STATE_TAIL(nb)))->pubSeq, w->stateSeq, "lazy state read-back");
 	if (rc == 0 && rowMode == 1) shadowWritten(w);
 	return rc;

@@ -143,7 +143,7 @@ struct b2hip_world
 	DevArray<DState> d_state;
 	DevArray<float4> b_pos, b_pos0, b_vel, b_xf, b_mass, b_damp, b_force;
 	DevArray<uint32_t> b_flags;
-	DevArray<int> b_wake;
+	DevArray<int> b_wake, b_rowDirty;
 	DevArray<float4> p_fat;
 	DevArray<int> p_body, p_shape, p_key, p_filter1;
 	DevArray<uint32_t> p_filter0;
@@ -298,6 +298,10 @@ struct b2hip_world
 	int recolorSlack = 2;        // colour afresh when the colours in use exceed the last fresh colouring's by more than this (B2HIP_RECOLOR_SLACK; -1: every 64th step as in round 4)
 	int freshColors = 0;         // colours the last colouring from scratch of a partition-less world needed (0: none yet); in the snapshot's hints
 	bool freshColorsPending = false;
+	bool forceOnDevice = true;   // some body's force / torque row on the device may be non-zero (set by uploads, reset by a clearing read-back): the
+	                             // read-back of a large world skips untouched tiles only when there is nothing to clear in them
+	int rowMarks = 1;            // the read-back behind an early launch looks at marked tiles only (DW::b_rowDirty; B2HIP_NO_ROW_MARKS=1: compares every row; B2HIP_ROW_MARKS_CHECK=1: compares every row AND fails the step if an unmarked one differs)
+	bool rowsWentEarly = false;  // this step's rows left behind SynchronizeFixtures (startEarlyRows): the shadow is that state
 	bool sweepStamps = false;    // B2HIP_SWEEP_STAMPS=1: k_sweep_end<1> leaves its phase stamps where the block solver's go (diagnostics)
 	bool bodyWarm = true;        // the warm start of a launch-per-colour solve body by body in one launch (k_large_warm; B2HIP_NO_BODY_WARM=1: a sweep of launches)
 	bool restFlow = true;        // the small colours of a sweep as data flow per body in one launch (k_large_rest; B2HIP_NO_REST=1: launches / tail)
@@ -372,6 +376,7 @@ struct b2hip_world
 	int* constsUploadedAt = nullptr;
 	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
+	int toiDomainsSticky = 0; // steps for which the component-wise event loops' preparations start beside k_toi_first (phaseToiSync)
 	bool toiChainsHadGrid = false; // the chains of this step ran with the grid (else a moved proxy is all "unsafe" means)
 	bool toiSnapshotTaken = false; // this step's TOI phase saved the state it started from (k_toi_snapshot)
 	std::vector<int4> toiVerdicts; // this step's PreSolve answers per TOI log slot (the device's copy: DW::toiVerdict)
@@ -807,7 +812,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 #define ENS(arr, n) do { rc = w->arr.ensure((n), s); if (rc) return rc; } while (0)
 	ENS(d_state, 1);
 	ENS(b_pos, nb); ENS(b_pos0, nb); ENS(b_vel, nb); ENS(b_xf, nb); ENS(b_mass, nb); ENS(b_damp, nb); ENS(b_force, nb);
-	ENS(b_flags, nb); ENS(b_wake, nb); ENS(b_order, nb); ENS(orderBody, nb); ENS(bigRoots, SHARD_BIG_MAX);
+	ENS(b_flags, nb); ENS(b_wake, nb); ENS(b_rowDirty, nb); ENS(b_order, nb); ENS(orderBody, nb); ENS(bigRoots, SHARD_BIG_MAX);
 	ENS(p_fat, np); ENS(p_body, np); ENS(p_shape, np); ENS(p_key, np); ENS(p_filter0, np); ENS(p_filter1, np); ENS(p_mat, np);
 	ENS(b_proxyHead, nb); ENS(p_next, np);
 	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
@@ -926,6 +931,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	w->sweepTail = w->sweepEnd && !(getenv("B2HIP_NO_TAIL") && atoi(getenv("B2HIP_NO_TAIL")));
 	w->recolorSlack = getenv("B2HIP_RECOLOR_SLACK") ? atoi(getenv("B2HIP_RECOLOR_SLACK")) : 2;
 	w->sweepStamps = getenv("B2HIP_SWEEP_STAMPS") != nullptr;
+	w->rowMarks = (getenv("B2HIP_ROW_MARKS_CHECK") && atoi(getenv("B2HIP_ROW_MARKS_CHECK"))) ? 2 : (getenv("B2HIP_NO_ROW_MARKS") && atoi(getenv("B2HIP_NO_ROW_MARKS"))) ? 0 : 1;
 	w->bodyWarm = !(getenv("B2HIP_NO_BODY_WARM") && atoi(getenv("B2HIP_NO_BODY_WARM")));
 	w->restFlow = w->sweepEnd && !(getenv("B2HIP_NO_REST") && atoi(getenv("B2HIP_NO_REST")));
 	w->restRowsMax = getenv("B2HIP_REST_ROWS") ? std::min(atoi(getenv("B2HIP_REST_ROWS")), REST_ROWS_MAX - COLOR_SMALL_MAX) : 65536;
@@ -938,7 +944,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	d.htMask = (uint32_t)(w->ht_keys.cap - 1);
 	d.gridMask = (uint32_t)(gridSize - 1);
 	d.b_pos = w->b_pos.p; d.b_pos0 = w->b_pos0.p; d.b_vel = w->b_vel.p; d.b_xf = w->b_xf.p; d.b_mass = w->b_mass.p;
-	d.b_damp = w->b_damp.p; d.b_force = w->b_force.p; d.b_flags = w->b_flags.p; d.b_wake = w->b_wake.p;
+	d.b_damp = w->b_damp.p; d.b_force = w->b_force.p; d.b_flags = w->b_flags.p; d.b_wake = w->b_wake.p; d.b_rowDirty = w->b_rowDirty.p;
 	d.b_order = w->b_order.p; d.orderBody = w->orderBody.p; d.bigRoots = w->bigRoots.p;
 	d.p_fat = w->p_fat.p; d.p_body = w->p_body.p; d.p_shape = w->p_shape.p; d.p_key = w->p_key.p;
 	d.p_filter0 = w->p_filter0.p; d.p_filter1 = w->p_filter1.p; d.p_mat = w->p_mat.p; d.shapes = w->d_shapes.p;
@@ -1026,6 +1032,7 @@ static int flushEdits(b2hip_world* w)
 			mass.push_back(make_float4(b.invMass, b.invI, b.lcx, b.lcy));
 			damp.push_back(make_float4(b.linearDamping, b.angularDamping, b.gravityScale, 0.0f));
 			force.push_back(make_float4(b.fx, b.fy, b.torque, 0.0f));
+			if (b.fx != 0.0f || b.fy != 0.0f || b.torque != 0.0f) w->forceOnDevice = true;
 			flags.push_back((b.flags & ~BF_TYPE_MASK) | (uint32_t)b.type);
 			b.dirty = false;
 			++j;

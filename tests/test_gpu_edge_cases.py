@@ -470,13 +470,16 @@ def test_edits_on_a_body_with_more_contacts_than_one_edit_pass(libs):
 def test_dense_start_grows_the_pair_buffer(monkeypatch):
     """1 400 bodies and 450 bullets crammed into a 70 x 70 arena: the first pair update finds several times more candidate
     pairs than the buffer was sized for (21 000 contacts on step one). The buffers grow and the search runs again - no
-    capacity error - and the result is still the oracle's, bit for bit (exact-order mode: the islands are huge)."""
+    capacity error - and the result is still the oracle's, bit for bit (exact-order mode: the islands are huge).
+    Step 1 destroys 5 600 contacts, more TOI candidates among them than the LDS tables of toiOrderDestroy hold (2 048): the
+    removals are replayed in chunks (b2d_kernels_collide.h), and k_toi_first - which walks the manager's slot table since
+    round 5 - finds every candidate in steps 2 - 4 (until round 5 the surplus left the table inconsistent, unnoticed)."""
     import b2harness as bh
     monkeypatch.setenv("B2HIP_FORCE_LARGE", "2")
     amd, orc = bh.Harness(bh.AMD_LIB), bh.Harness(bh.ORACLE_LIB)
     kw = dict(p0=1406, p1=456, f0=35.0, f1=2.0, seed=2623, flags=bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM)
     a, o = amd.world(bh.FIELD, **kw), orc.world(bh.FIELD, **kw)
-    for s in range(3):
+    for s in range(5):
         a.step(1)
         o.step(1)
         assert a.contact_count == o.contact_count and a.contact_count > 15000, "step %d" % s
