@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = W.nBodies;
-	int nIslands = 0, nFree = 0;
+	int nIslands = 0, nFree = 0, maxW = 0;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		int4 in = make_int4(0, 0, 0, 0);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 					W.rootIsland[i] = ROOT_SMALL;
 					if (nj > 0) atomicAdd(&S->c.nSmallJointed, 1);
 					in = make_int4(nb, nc, w, 1);
-					atomicMaxIfAbove(&S->c.maxSmallW, w);
+					maxW = w > maxW ? w : maxW; // (offered once per workgroup, below)
 				}
 				else
 				{
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256) void k_island_classify(DW W, int forceLarge, S
 	}
 	// (the census travels with the arrival of the workgroups: even one add per workgroup and counter - 4 096 atomics on two
 	// words - was 120 of this kernel's 205 us on the 1 M field; b2d_world.h: b2dTreeArrive)
+	blockAtomicMaxIfAbove(&S->c.maxSmallW, maxW);
 	b2dBlockTreeAdd2(W, ARRIVE_CLASSIFY, &S->c.nIslands, nIslands, &S->c.nFreeIslands, nFree, (unsigned)W.nBodies <= TREE_SUM_MAX);
 }
 

@@ -381,7 +381,7 @@ __device__ __forceinline__ void storeAdvanced(const DW& W, int body, const Sweep
 // k_toi_dom_rollback): its pending list is DW::toiDomList[0, nToiPartial), the proxies the finished components moved
 // are already in DW::toiMoved, and a contact created with a body of a finished component means that component did not
 // see it in time: Counters::toiUnsafe, and the whole phase is redone serially.
-template <bool DOMAIN>
+template <bool DOMAIN, int LANES>
 __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, int domain, int partial)
 {
 	DState* S = W.st;
@@ -399,9 +399,9 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 	__shared__ int s_logCursor; // next free record of DW::toiLog (listener calls of the sub-steps, in call order)
 	__shared__ int s_minIdx;
 	__shared__ float s_minAlpha;
-	__shared__ unsigned long long s_best[TOI_LANES];
-	__shared__ uint32_t s_bestAlpha[TOI_LANES];
-	__shared__ int s_bestIdx[TOI_LANES];
+	__shared__ unsigned long long s_best[LANES];
+	__shared__ uint32_t s_bestAlpha[LANES];
+	__shared__ int s_bestIdx[LANES];
 	__shared__ int s_solid;
 	__shared__ int s_bodies[B2D_MAX_TOI_BODIES], s_nBodies;
 	__shared__ int s_contacts[B2D_MAX_TOI_CONTACTS], s_nContacts;
@@ -449,7 +449,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 	// FindMinToiContact computes them on its way through the contact array: all of them form the first batch here.
 	if (!DOMAIN && !partial && W.toiContinue)
 	{
-		for (int c = tid; c < s_nC; c += TOI_LANES)
+		for (int c = tid; c < s_nC; c += LANES)
 		{
 			const uint32_t flags = ldFlags(&C.flags[c]);
 			if ((flags & (CF_TOI | CF_TOI_PENDING)) != 0 || !toiEligible(W, flags, C.ids[c])) continue;
@@ -491,9 +491,9 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			// Put the sweeps of each pair on the same interval (b2World.cpp:385-396): the lagging body advances to
 			// the other's alpha0. A body can meet partners at different times within one pass, so the advances are
 			// replayed in the reference's visiting order: the slot order of its contact array (ContactArrays::mgr).
-			for (int r = tid; r < nRecomp; r += TOI_LANES) s_rSlot[r] = C.mgr[s_recomp[r]];
+			for (int r = tid; r < nRecomp; r += LANES) s_rSlot[r] = C.mgr[s_recomp[r]];
 			__syncthreads();
-			for (int r = tid; r < nRecomp; r += TOI_LANES)
+			for (int r = tid; r < nRecomp; r += LANES)
 			{
 				const int m = s_rSlot[r];
 				int rank = 0;
@@ -501,7 +501,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				s_rSorted[rank] = s_recomp[r];
 			}
 			__syncthreads();
-			for (int r = tid; r < nRecomp; r += TOI_LANES)
+			for (int r = tid; r < nRecomp; r += LANES)
 			{
 				const int4 ids = C.ids[s_rSorted[r]];
 				s_flatBody[2 * r] = ids.z;
@@ -509,7 +509,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			}
 			if (tid == 0) s_nAdv = 0;
 			__syncthreads();
-			for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
+			for (int q = tid; q < 2 * nRecomp; q += LANES)
 			{
 				const int b = s_flatBody[q];
 				int first = q;
@@ -556,7 +556,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				s_nAdv = nAdv;
 			}
 			__syncthreads();
-			for (int q = tid; q < 2 * nRecomp; q += TOI_LANES)
+			for (int q = tid; q < 2 * nRecomp; q += LANES)
 			{
 				if (s_flatFirst[q] != q) continue;
 				const int nAdv = s_nAdv;
@@ -572,7 +572,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 				if (any) { W.b_pos0[s_flatBody[q]] = make_float4(sw.c0.x, sw.c0.y, sw.a0, sw.alpha0); W.b_rowDirty[s_flatBody[q]] = 1; }
 			}
 			__syncthreads();
-			for (int r = tid; r < nRecomp; r += TOI_LANES)
+			for (int r = tid; r < nRecomp; r += LANES)
 			{
 				const int c = s_rSorted[r];
 				const int4 ids = C.ids[c];
@@ -608,7 +608,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			unsigned long long bestK = ~0ull;
 			int bestI = -1;
 			const int nL = s_nL;
-			for (int k = tid; k < nL; k += TOI_LANES)
+			for (int k = tid; k < nL; k += LANES)
 			{
 				const int i = list[k];
 				const uint32_t flags = ldFlags(&C.flags[i]);
@@ -627,7 +627,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			s_best[tid] = bestK;
 			s_bestIdx[tid] = bestI;
 			__syncthreads();
-			for (int off = TOI_LANES / 2; off > 0; off >>= 1)
+			for (int off = LANES / 2; off > 0; off >>= 1)
 			{
 				if (tid < off)
 				{
@@ -734,7 +734,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			if ((fX & BF_TYPE_MASK) != BT_DYNAMIC) continue;
 			const int e0 = W.adjStart[X], e1 = W.adjStart[X + 1];
 			const int nTail = s_nC - nC0;
-			for (int e = tid; e < (e1 - e0) + nTail; e += TOI_LANES)
+			for (int e = tid; e < (e1 - e0) + nTail; e += LANES)
 			{
 				int c;
 				if (e < e1 - e0) c = W.adj[e0 + e];
@@ -759,7 +759,11 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			}
 		}
 		__syncthreads();
-		const int nCand = s_nCand < TOI_CAND_MAX ? s_nCand : TOI_CAND_MAX;
+		// (one lane per candidate below: a narrow workgroup - the components' single wave - takes as many as it has lanes, more
+		// is a capacity cut like any other: the serial loop's 512 lanes get the phase)
+		const int candCap = TOI_CAND_MAX < LANES ? TOI_CAND_MAX : LANES;
+		if (tid == 0 && s_nCand > candCap) s_overflow |= 1;
+		const int nCand = s_nCand < candCap ? s_nCand : candCap;
 		// order: seed A's list first, each list newest contact first
 		if (tid < nCand)
 		{
@@ -1121,7 +1125,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			const int p = s_moves[mI];
 			const AABB fp = loadAabb(W.p_fat, p);
 			const int bodyP = W.p_body[p];
-			toiForEachCandidate(W, fp, tid, TOI_LANES, movedList, nMovedAll, [&](int q)
+			toiForEachCandidate(W, fp, tid, LANES, movedList, nMovedAll, [&](int q)
 			{
 				const int bodyQ = W.p_body[q];
 				if (bodyQ < 0 || p == q || bodyP == bodyQ) return;
@@ -1169,7 +1173,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			break;
 		}
 		const int nPairs = s_nPairs < TOI_PAIRS_MAX ? s_nPairs : TOI_PAIRS_MAX;
-		for (int i = tid; i < nPairs; i += TOI_LANES)
+		for (int i = tid; i < nPairs; i += LANES)
 		{
 			const uint64_t key = s_pairs[i].key;
 			int first = 1;
@@ -1177,7 +1181,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			s_pairFirst[i] = first;
 		}
 		__syncthreads();
-		for (int i = tid; i < nPairs; i += TOI_LANES)
+		for (int i = tid; i < nPairs; i += LANES)
 		{
 			const uint64_t key = s_pairs[i].key;
 			int rank = 0;
@@ -1188,7 +1192,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		__syncthreads();
 		// OnContactCreate (b2ContactManager.cpp:507-564), in (proxyLow, proxyHigh) order at the end of the array
 		const int base = s_nC;
-		for (int i = tid; i < nPairs; i += TOI_LANES)
+		for (int i = tid; i < nPairs; i += LANES)
 		{
 			if (!s_pairFirst[i]) continue;
 			const int dst = base + s_pairRank[i];
@@ -1248,7 +1252,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 		}
 		__syncthreads();
 		// b2ContactManager::AddToContactArray: new TOI candidates take the next slots in creation order
-		for (int i = tid; i < nPairs; i += TOI_LANES)
+		for (int i = tid; i < nPairs; i += LANES)
 		{
 			if (!s_pairFirst[i] || !s_pairCand[i] || base + s_pairRank[i] >= W.capContacts) continue;
 			int before = 0;
@@ -1283,7 +1287,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			const int b = s_bodies[bi];
 			if ((ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) != BT_DYNAMIC) continue;
 			const int e0 = W.adjStart[b], e1 = W.adjStart[b + 1];
-			for (int e = tid; e < (e1 - e0) + nTail; e += TOI_LANES)
+			for (int e = tid; e < (e1 - e0) + nTail; e += LANES)
 			{
 				int c;
 				if (e < e1 - e0) c = W.adj[e0 + e];
@@ -1313,7 +1317,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 			const int b = bi < nB ? s_bodies[bi] : s_woken[bi - nB];
 			if ((ldFlags(&W.b_flags[b]) & BF_TYPE_MASK) == BT_STATIC) continue;
 			const int e0 = W.adjStart[b], e1 = W.adjStart[b + 1];
-			for (int e = tid; e < (e1 - e0) + nTail; e += TOI_LANES)
+			for (int e = tid; e < (e1 - e0) + nTail; e += LANES)
 			{
 				int c;
 				if (e < e1 - e0) c = W.adj[e0 + e];
@@ -1368,7 +1372,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 __global__ __launch_bounds__(TOI_LANES) void k_toi_loop(DW W, StepParams sp)
 {
 	b2dPhaseStamp(W);
-	toiLoopRun<false>(W, sp, 0, 0);
+	toiLoopRun<false, TOI_LANES>(W, sp, 0, 0);
 }
 
 // The components that met a new contact (or each other), replayed in the reference's global order by one workgroup.
@@ -1376,7 +1380,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_loop_partial(DW W, StepParams
 {
 	b2dPhaseStamp(W);
 	if (W.st->c.nToiPartial == 0 || W.st->c.toiUnsafe != 0) return;
-	toiLoopRun<false>(W, sp, 0, 1);
+	toiLoopRun<false, TOI_LANES>(W, sp, 0, 1);
 }
 
 #endif

@@ -901,8 +901,8 @@ __global__ __launch_bounds__(256) void k_bp_clear(DW W)
 			const float e = fmaxf(a.z - a.x, a.w - a.y);
 			if (e <= cap && e > ext) ext = e;
 		}
-		for (int off = 32; off > 0; off >>= 1) ext = fmaxf(ext, __shfl_xor(ext, off));
-		if ((threadIdx.x & 63u) == 0 && ext > 0.0f) atomicMaxIfAbove(&S->c.cellExtBits, __float_as_uint(ext));
+		// (a positive float's bits order like the float: one offer per workgroup, b2d_wave.h)
+		blockAtomicMaxIfAbove((int*)&S->c.cellExtBits, ext > 0.0f ? (int)__float_as_uint(ext) : 0);
 	}
 	// (16 bytes per lane and store: the tables are powers of two of at least 64 entries, 256-byte aligned - 4-byte stores
 	// were 93 us for the 40 MB of a million-proxy world)

@@ -167,7 +167,13 @@ __global__ __launch_bounds__(256) void k_toi_dom_fill(DW W)
 }
 
 // The event loop of every component with a pending impact, one workgroup each (a fixed grid takes them in turn).
-__global__ __launch_bounds__(TOI_LANES) void k_toi_domains(DW W, StepParams sp)
+// LANES = 64: one wave per component. A component of config 5 is a bullet and what it hits - one or two pending impacts, a
+// handful of candidate contacts - and an event is ~50 dependent stages with a workgroup barrier between them: with eight waves
+// every barrier is a rendezvous, with one the compiler drops it (a workgroup no wider than a wave needs none). The loop takes
+// at most LANES candidate contacts per event then (one lane each); a component that has more is a capacity cut - the serial
+// loop gets the phase, and the host launches the wide form for a while (b2hip_host_phases.h).
+template <int LANES>
+__global__ __launch_bounds__(LANES) void k_toi_domains(DW W, StepParams sp)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(TOI_LANES) void k_toi_domains(DW W, StepParams sp)
 	if (blockIdx.x == 0 && threadIdx.x == 0 && W.capContacts > 16) W.hubList[12] = n; // (diagnostics: how many rows behind word 16 are this step's)
 	for (int d = blockIdx.x; d < n; d += gridDim.x)
 	{
-		toiLoopRun<true>(W, sp, d, 0);
+		toiLoopRun<true, LANES>(W, sp, d, 0);
 		__syncthreads();
 	}
 }

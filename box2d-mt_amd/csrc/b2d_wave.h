@@ -125,6 +125,23 @@ __device__ __forceinline__ void atomicMaxIfAbove(uint32_t* addr, uint32_t v)
 	if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, v);
 }
 
+// ... and once per WORKGROUP where every lane has a candidate (kept in a register over the kernel's loop): even the look is a
+// load past the L2 of one word that every wave of the launch wants - 32 000 of them were 80 of k_island_flatten's 99 us on a
+// million bodies (round 5). Every thread of the workgroup calls it, once, at the end; values <= 0 are no offer.
+__device__ __forceinline__ void blockAtomicMaxIfAbove(int* addr, int v)
+{
+	__shared__ int s_blockMax[16];
+	for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+	if ((threadIdx.x & 63u) == 0) s_blockMax[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		const int nw = (int)((blockDim.x + 63u) >> 6);
+		for (int k = 1; k < nw; ++k) v = s_blockMax[k] > v ? s_blockMax[k] : v;
+		if (v > 0) atomicMaxIfAbove(addr, v);
+	}
+}
+
 // A workgroup's running sum for ONE hot key, kept in LDS across the iterations of a grid-stride loop: a single island of
 // 350 000 constraints among 2 M contacts (the settled 100 000-box Tumbler) still sends one atomic per wave and iteration to
 // the same word - 32 000 of them, ~6.5 ns each in L2: k_island_count 214 us for 80 MB of reads. The first key a workgroup

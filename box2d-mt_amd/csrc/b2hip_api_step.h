@@ -488,6 +488,8 @@ static int stepEndImpl(b2hip_world* w)
 	if (w->toiChains && w->h_dstate->c.toiUnsafe != 0)
 	{
 		if (getenv("B2HIP_TOI_WHY")) fprintf(stderr, "b2hip: TOI fallback to the serial loop, unsafe bits 0x%x (1 partner, 2 woke, 4 new pair, 8 capacity, 16 moved proxies), %d pending, %d components\n", w->h_dstate->c.toiUnsafe, w->h_dstate->c.nToiList, w->h_dstate->c.nToiDomains);
+		// (a capacity cut - possibly more candidate contacts in one event than the narrow component loops have lanes: the wide form next time)
+		if (w->h_dstate->c.toiUnsafe & 8) w->toiDomWide = 64;
 		rc = toiSerial(w);
 		if (rc) return rc;
 		w->toiFallbacks += 1;

@@ -1080,12 +1080,14 @@ static int phaseToiSync(b2hip_world* w)
 	{
 		HIP_TRY(hipEventRecord(w->evFork, w->stream));
 		HIP_TRY(hipStreamWaitEvent(w->stream2, w->evFork, 0));
-		LAUNCH_ON(w, w->stream2, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 2);
+		// (the short launches first: the snapshot's bandwidth then falls into the tail of k_toi_first and the host's look at its
+		// census - beside its start it took the first pass from 120 to 220 us: loaded latency)
 		rc = toiBuildAdjacency(w, w->stream2);
 		if (rc) return rc;
 		LAUNCH_ON(w, w->stream2, k_toi_dom_init, gridFor(d.nBodies), 256, d);
 		LAUNCH_ON(w, w->stream2, k_toi_dom_union, gridFor(d.capContacts), 256, d);
 		LAUNCH_ON(w, w->stream2, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
+		LAUNCH_ON(w, w->stream2, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 2);
 		HIP_TRY(hipEventRecord(w->evJoin, w->stream2));
 		aside = true;
 	}
@@ -1194,7 +1196,12 @@ static int phaseToiSync(b2hip_world* w)
 		else if (snapAside) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
 		else LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
 		w->toiSnapshotTaken = true;
-		LAUNCH(w, k_toi_domains, std::min(w->h_dstate->c.nToiList, 2048), TOI_LANES, d, w->sp);
+		if (w->toiDomWide > 0 || w->toiDomWideOnly)
+		{
+			LAUNCH(w, k_toi_domains<TOI_LANES>, std::min(w->h_dstate->c.nToiList, 2048), TOI_LANES, d, w->sp);
+			if (w->toiDomWide > 0) w->toiDomWide -= 1;
+		}
+		else LAUNCH(w, k_toi_domains<64>, std::min(w->h_dstate->c.nToiList, 2048), 64, d, w->sp);
 		LAUNCH(w, k_toi_domains_end, std::min(std::max(w->h_dstate->c.nToiList, 1), 1024), 256, d);
 		// components tied together by a new contact: back to the snapshot, then the serial loop over just those
 		LAUNCH(w, k_toi_dom_rollback, gridFor(std::max(std::max(d.nBodies, d.nProxies), d.capContacts)), 256, d);

@@ -376,6 +376,8 @@ struct b2hip_world
 	int* constsUploadedAt = nullptr;
 	int toiSyncSticky = 0; // steps for which the TOI phase decides from a read-back again (see phaseToi)
 	int toiGridSticky = 0; // steps for which the TOI chains still get a rebuilt hash grid
+	int toiDomWide = 0;       // steps for which the components' event loops get 512 lanes again (one of them met more candidate contacts than a wave has lanes)
+	bool toiDomWideOnly = false; // B2HIP_TOI_DOM_WIDE=1: always (comparison)
 	int toiDomainsSticky = 0; // steps for which the component-wise event loops' preparations start beside k_toi_first (phaseToiSync)
 	bool toiChainsHadGrid = false; // the chains of this step ran with the grid (else a moved proxy is all "unsafe" means)
 	bool toiSnapshotTaken = false; // this step's TOI phase saved the state it started from (k_toi_snapshot)
