@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_grid_clear(DW W, int force)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
-	if (force && S->c.gridFresh && !W.spatial) return; // (this step's pair update built it, nothing has moved since)
+	if (force && S->c.gridFresh) return; // (this step's pair update built it, nothing has moved since)
 	// always reset the pair census, also when nothing moved: the ordering / creation kernels that
 	// follow key off nPairs and must see 0 then
 	if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_grid_count(DW W, int force)
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0 && !force) return;
-	if (force && S->c.gridFresh && !W.spatial) return;
+	if (force && S->c.gridFresh) return;
 	const int n = W.nProxies;
 	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
 	{
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_grid_fill(DW W, int force)
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (S->c.nMoves == 0 && !force) return;
-	if (force && S->c.gridFresh && !W.spatial) return;
+	if (force && S->c.gridFresh) return;
 	const int n = W.nProxies;
 	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
 	{

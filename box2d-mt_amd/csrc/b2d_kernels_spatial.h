@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void k_sp_import_state(DW W, const int* in, si
 {
 	b2dPhaseStamp(W);
 	if (blockIdx.x == 0 && threadIdx.x < SP_HEADER_WORDS) sendHdr[threadIdx.x] = 0;
+	if (blockIdx.x == 0 && threadIdx.x == 0) W.st->c.gridFresh = 0; // (other ranks' boxes arrive: the grid is stale until a pair update builds it again)
 	if (markSent)
 	{
 		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)

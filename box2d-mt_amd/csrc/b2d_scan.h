@@ -317,53 +317,63 @@ static inline void deviceExclusiveScan(hipStream_t stream, const T* in, T* out, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stable LSD radix sort of (uint64 key, int2 payload), 8 bits per pass.
+// Stable LSD radix sort of (uint64 key, int2 payload), up to RADIX_BITS = 11 bits per pass (round 5; 8 before: the pair
+// update's keys are two proxy keys of 17 - 21 bits - six passes of three launches each, every one a dependent launch of a
+// step that is priced by those; now four).
 // Per pass: (1) per-tile digit histogram, (2) scan of the digit-major histogram matrix,
 // (3) stable scatter using wave64 ballots to rank equal digits inside a wave.
 #define RADIX_THREADS 256
 #define RADIX_ITEMS 8
 #define RADIX_TILE (RADIX_THREADS * RADIX_ITEMS)
+#define RADIX_BITS 11
+#define RADIX_DIGITS (1 << RADIX_BITS)
 
+// `width` <= RADIX_BITS: the bits this pass looks at (the digit is (key >> shift) & ((1 << width) - 1); all RADIX_DIGITS rows of
+// the matrix are written, the unused ones with zeros)
 __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(const uint64_t* __restrict__ keys, int* __restrict__ hist,
-	const int* nPtr, int minN, int shift, int numTilesCap)
+	const int* nPtr, int minN, int shift, int width, int numTilesCap)
 {
-	__shared__ int lh[256];
+	__shared__ int lh[RADIX_DIGITS];
 	int n = *nPtr;
 	if (n <= minN) return;
 	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
 	int tile = blockIdx.x;
 	if (tile >= numTiles) return;
-	lh[threadIdx.x] = 0;
+	for (int q = threadIdx.x; q < RADIX_DIGITS; q += RADIX_THREADS) lh[q] = 0;
 	__syncthreads();
+	const uint32_t mask = (1u << width) - 1u;
 	int base = tile * RADIX_TILE;
 	for (int k = 0; k < RADIX_ITEMS; ++k)
 	{
 		int i = base + k * RADIX_THREADS + threadIdx.x;
 		if (i < n)
 		{
-			int d = (int)((keys[i] >> shift) & 0xffu);
+			int d = (int)((uint32_t)(keys[i] >> shift) & mask);
 			atomicAdd(&lh[d], 1);
 		}
 	}
 	__syncthreads();
 	// digit-major so that a plain scan yields global offsets
-	hist[threadIdx.x * numTiles + tile] = lh[threadIdx.x];
+	for (int q = threadIdx.x; q < RADIX_DIGITS; q += RADIX_THREADS) hist[q * numTiles + tile] = lh[q];
 	(void)numTilesCap;
 }
 
-// histCount = 256 * numTiles, written to device memory for the scan utility
+// histCount = RADIX_DIGITS * numTiles, written to device memory for the scan utility
 __global__ void k_radix_count(const int* nPtr, int minN, int* histCount)
 {
 	int n = *nPtr;
 	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
-	*histCount = (n <= minN) ? 0 : 256 * numTiles;
+	*histCount = (n <= minN) ? 0 : RADIX_DIGITS * numTiles;
 }
 
 __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(const uint64_t* __restrict__ keysIn, const int2* __restrict__ valsIn,
-	uint64_t* __restrict__ keysOut, int2* __restrict__ valsOut, const int* __restrict__ histScan, const int* nPtr, int minN, int shift)
+	uint64_t* __restrict__ keysOut, int2* __restrict__ valsOut, const int* __restrict__ histScan, const int* nPtr, int minN, int shift, int width)
 {
-	__shared__ int waveCount[4][256]; // per wave digit counts of the current round
-	__shared__ int digitBase[256];    // running global offset per digit for this tile
+	// per wave: how many of the current round's keys of the three waves before it carry a digit - only the digits that OCCUR in
+	// the round are touched (a round is 256 keys: at most 256 of the 2 048 counters), set by the first lane of a digit group
+	// and taken back by it after the round
+	__shared__ int waveCount[4][RADIX_DIGITS];
+	__shared__ int digitBase[RADIX_DIGITS]; // running global offset per digit for this tile
 	int n = *nPtr;
 	if (n <= minN) return;
 	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
@@ -372,19 +382,35 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(const uint64_t*
 	int tid = threadIdx.x;
 	int lane = tid & 63;
 	int wave = tid >> 6;
-	digitBase[tid] = histScan[tid * numTiles + tile];
+	for (int q = tid; q < RADIX_DIGITS; q += RADIX_THREADS)
+	{
+		digitBase[q] = histScan[q * numTiles + tile];
+		waveCount[0][q] = 0; waveCount[1][q] = 0; waveCount[2][q] = 0; waveCount[3][q] = 0;
+	}
+	__syncthreads();
+	const uint32_t mask = (1u << width) - 1u;
 	int base = tile * RADIX_TILE;
+	// (all of the tile's keys and payloads first: eight independent loads in flight, not one load's latency in front of every
+	// round - the kernel moves 2 MB and was 16 us of dependent steps)
+	uint64_t keyR[RADIX_ITEMS];
+	int2 valR[RADIX_ITEMS];
+#pragma unroll
 	for (int k = 0; k < RADIX_ITEMS; ++k)
 	{
-		for (int w = 0; w < 4; ++w) waveCount[w][tid] = 0;
-		__syncthreads();
+		const int i = base + k * RADIX_THREADS + tid;
+		keyR[k] = i < n ? keysIn[i] : 0;
+		valR[k] = i < n ? valsIn[i] : make_int2(0, 0);
+	}
+#pragma unroll
+	for (int k = 0; k < RADIX_ITEMS; ++k)
+	{
 		int i = base + k * RADIX_THREADS + tid;
 		bool valid = i < n;
-		uint64_t key = valid ? keysIn[i] : 0;
-		int d = valid ? (int)((key >> shift) & 0xffu) : -1;
+		uint64_t key = keyR[k];
+		int d = valid ? (int)((uint32_t)(key >> shift) & mask) : -1;
 		// lanes of this wave holding the same digit
 		unsigned long long peers = __ballot(valid);
-		for (int b = 0; b < 8; ++b)
+		for (int b = 0; b < RADIX_BITS; ++b)
 		{
 			unsigned long long m = __ballot(valid && ((d >> b) & 1));
 			peers &= ((d >> b) & 1) ? m : ~m;
@@ -392,21 +418,31 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(const uint64_t*
 		if (!valid) peers = 0;
 		unsigned long long lower = peers & ((1ull << lane) - 1ull);
 		int rankInWave = __popcll(lower);
-		if (valid && lower == 0)
-		{
-			waveCount[wave][d] = __popcll(peers); // first lane of each digit group
-		}
+		const bool first = valid && lower == 0; // first lane of each digit group
+		const int groupSize = __popcll(peers);
+		if (first) waveCount[wave][d] = groupSize;
 		__syncthreads();
+		int total = 0;
 		if (valid)
 		{
 			int off = digitBase[d];
 			for (int w = 0; w < wave; ++w) off += waveCount[w][d];
 			int dst = off + rankInWave;
 			keysOut[dst] = key;
-			valsOut[dst] = valsIn[i];
+			valsOut[dst] = valR[k];
+			if (first) total = waveCount[0][d] + waveCount[1][d] + waveCount[2][d] + waveCount[3][d];
 		}
 		__syncthreads();
-		digitBase[tid] += waveCount[0][tid] + waveCount[1][tid] + waveCount[2][tid] + waveCount[3][tid];
+		// the digit's running offset moves on by the round's keys with that digit: added once per digit - by the first lane of
+		// the digit's group in the LOWEST wave that has the digit - and the round's counters go back to zero
+		if (first)
+		{
+			bool lowest = true;
+			for (int w = 0; w < wave; ++w) lowest = lowest && waveCount[w][d] == 0;
+			if (lowest) digitBase[d] += total;
+		}
+		__syncthreads();
+		if (first) waveCount[wave][d] = 0;
 		__syncthreads();
 	}
 }

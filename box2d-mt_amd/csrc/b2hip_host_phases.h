@@ -20,6 +20,36 @@ static int radixBits(int maxKey)
 	return bits;
 }
 
+// The passes of a stable LSD sort over bits [first, first + bits) of the keys: (shift, width) pairs of at most RADIX_BITS bits
+// each, as few as cover the range, of (almost) equal width.
+static void radixPasses(int first, int bits, std::vector<std::pair<int, int>>& out)
+{
+	const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+	for (int p = 0, at = 0; p < passes; ++p)
+	{
+		const int width = (bits - at + (passes - p) - 1) / (passes - p);
+		out.push_back(std::make_pair(first + at, width));
+		at += width;
+	}
+}
+
+// keys / payloads in (kin, vin), *nPtr of them; sorted by the bits the passes name; which buffers hold the result comes back in kin / vin
+static int radixSort(b2hip_world* w, uint64_t*& kin, uint64_t*& kout, int2*& vin, int2*& vout, const int* nPtr, int tilesCap, const std::vector<std::pair<int, int>>& passes)
+{
+	DW& d = w->dw;
+	// (the length of the histogram matrix depends on the count only: once per sort, not once per pass)
+	LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
+	for (size_t p = 0; p < passes.size(); ++p)
+	{
+		LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, nPtr, 0, passes[p].first, passes[p].second, tilesCap);
+		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanCtx, w->consts.p + 2, RADIX_DIGITS * tilesCap);
+		LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, nPtr, 0, passes[p].first, passes[p].second);
+		std::swap(kin, kout);
+		std::swap(vin, vout);
+	}
+	return 0;
+}
+
 // Uploads `list` and runs `kernel(d, list, count)` (contacts to disable / reject, candidate pairs to drop)
 template <typename K>
 static int applyHostList(b2hip_world* w, K kernel, const std::vector<int>& list)
@@ -82,25 +112,16 @@ static int runSortAndCreate(b2hip_world* w, bool largePath, long long knownPairs
 	{
 		// LSD radix sort on the two key halves
 		int bits = radixBits(w->nextNode + 1);
-		std::vector<int> shifts;
-		for (int sft = 0; sft < bits; sft += 8) shifts.push_back(sft);
-		for (int sft = 0; sft < bits; sft += 8) shifts.push_back(32 + sft);
+		std::vector<std::pair<int, int>> passes;
+		radixPasses(0, bits, passes);
+		radixPasses(32, bits, passes);
 		uint64_t* kin = d.pairKey;
 		uint64_t* kout = d.pairKey2;
 		int2* vin = d.pairProxy;
 		int2* vout = d.pairProxy2;
 		int tilesCap = d.capPairs / RADIX_TILE + 1;
 		if (knownPairs >= 0) tilesCap = (int)std::min<long long>(tilesCap, knownPairs / RADIX_TILE + 2);
-		// (the length of the histogram matrix depends on the pair count only: once per sort, not once per pass)
-		LAUNCH(w, k_radix_count, 1, 1, &d.st->c.nPairs, 0, w->consts.p + 2);
-		for (size_t p = 0; p < shifts.size(); ++p)
-		{
-			LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, &d.st->c.nPairs, 0, shifts[p], tilesCap);
-			deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanCtx, w->consts.p + 2, 256 * tilesCap);
-			LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, &d.st->c.nPairs, 0, shifts[p]);
-			std::swap(kin, kout);
-			std::swap(vin, vout);
-		}
+		if (int rcs = radixSort(w, kin, kout, vin, vout, &d.st->c.nPairs, tilesCap, passes)) return rcs;
 		sortedKeys = kin;
 		sortedProxies = vin;
 		LAUNCH(w, k_pairs_sorted_first, gridFor(d.capPairs), 256, d, sortedKeys, w->consts.p + 3);
@@ -261,21 +282,13 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	int2* vout = d.pairProxy2;
 	LAUNCH(w, k_part_keys, gridFor(d.nBodies), 256, d, kin, vin);
 	// LSD radix sort: the body-id bits, then the 32 Morton bits (the pair buffers hold at least 8 entries per proxy)
-	std::vector<int> shifts;
+	std::vector<std::pair<int, int>> passes;
 	const int idBits = radixBits(d.nBodies + 1);
-	for (int sft = 0; sft < idBits; sft += 8) shifts.push_back(sft);
-	for (int sft = 0; sft < 32; sft += 8) shifts.push_back(32 + sft);
+	radixPasses(0, idBits, passes);
+	radixPasses(32, 32, passes);
 	const int tilesCap = d.capPairs / RADIX_TILE + 1;
 	const int* nPtr = &d.st->c.nLBodies;
-	LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
-	for (size_t p = 0; p < shifts.size(); ++p)
-	{
-		LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, nPtr, 0, shifts[p], tilesCap);
-		deviceExclusiveScan<int>(w->stream, d.radixHist, w->radixHistScan.p, d.scanTmp, w->scanCtx, w->consts.p + 2, 256 * tilesCap);
-		LAUNCH(w, k_radix_scatter, tilesCap, RADIX_THREADS, kin, vin, kout, vout, w->radixHistScan.p, nPtr, 0, shifts[p]);
-		std::swap(kin, kout);
-		std::swap(vin, vout);
-	}
+	if (int rcs = radixSort(w, kin, kout, vin, vout, nPtr, tilesCap, passes)) return rcs;
 	LAUNCH(w, k_part_weights, gridFor(d.nBodies), 256, d, vin, d.pairFirst);
 	deviceExclusiveScan<int>(w->stream, d.pairFirst, d.pairRank, d.scanTmp, w->scanCtx, nPtr, d.nBodies);
 	LAUNCH(w, k_part_assign, gridFor(d.nBodies), 256, d, vin, d.pairRank);
@@ -986,7 +999,7 @@ static int toiBuildIndexes(b2hip_world* w, bool csr, bool gridKnownFresh = false
 	// moved, and TOI moves of earlier steps never enter the move buffer) - unless this step's pair update has just built it
 	// from every proxy's box and nothing moved one since (Counters::gridFresh; the kernels below check it themselves, the
 	// host saves their launches when the read-back it already has says so: 128 us of a million-proxy world's step)
-	if (gridKnownFresh && !w->spatial) return 0;
+	if (gridKnownFresh) return 0;
 	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
 	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
 	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanCtx, w->consts.p + 1, (int)(d.gridMask + 1));

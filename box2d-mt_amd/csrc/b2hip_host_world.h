@@ -866,10 +866,10 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(pairFirst, capPairs + 1); ENS(pairRank, capPairs + 2);
 	const size_t maxScanN = std::max(std::max(nb + 2, gridSize + 2), std::max(cc + 2, capPairs + 2));
 	const size_t radixTiles = capPairs / RADIX_TILE + 2;
-	ENS(radixHist, 256 * radixTiles + 2); ENS(radixHistScan, 256 * radixTiles + 4);
-	ENS(scanTmp, 3 * (std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 8));
+	ENS(radixHist, RADIX_DIGITS * radixTiles + 2); ENS(radixHistScan, RADIX_DIGITS * radixTiles + 4);
+	ENS(scanTmp, 3 * (std::max(maxScanN, RADIX_DIGITS * radixTiles) / SCAN_TILE + 8));
 	ENS(scanTmp4, 3 * (maxScanN / SCAN_TILE + 8));
-	ENS(scanFlags, std::max(maxScanN, 256 * radixTiles) / SCAN_TILE + 8);
+	ENS(scanFlags, std::max(maxScanN, RADIX_DIGITS * radixTiles) / SCAN_TILE + 8);
 	ENS(keepFlag, cc + 1); ENS(keepScan, cc + 2);
 	ENS(toiList, cc); ENS(toiPos2c, cc); ENS(toiDestroyList, cc); ENS(toiNewList, TOI_NEW_LIST_MAX);
 	ENS(b_toiGroup, nb); ENS(toiGroups, nb); ENS(toiGroupCount, std::min<size_t>(nb, TOI_GROUPS_MAX)); ENS(toiGroupList, std::min<size_t>(nb, TOI_GROUPS_MAX) * CHAIN_ADJ_MAX); ENS(toiMoved, TOI_MOVED_ALL_MAX); ENS(toiNew, 8 * TOI_NEWPAIR_MAX); ENS(toiParent, nb); ENS(toiDomOf, nb); ENS(toiDomRoot, TOI_DOMAINS_MAX); ENS(toiDomCount, TOI_DOMAINS_MAX); ENS(toiDomBase, TOI_DOMAINS_MAX); ENS(toiDomFill, TOI_DOMAINS_MAX); ENS(toiDomFailed, TOI_DOMAINS_MAX); ENS(toiDomEvents, TOI_DOMAINS_MAX); ENS(toiDomList, cc); ENS(toiHull, np); ENS(snapBody, 5 * nb); ENS(snapFat, np);
