@@ -641,8 +641,10 @@ __global__ __launch_bounds__(256) void k_pairs_sorted_first(DW W, const uint64_t
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nPairs < W.capPairs ? S->c.nPairs : W.capPairs;
-	if (blockIdx.x == 0 && threadIdx.x == 0) *nOut = n > COUNT_RANK_MAX ? n : 0;
-	if (n <= COUNT_RANK_MAX) return;
+	// (any count: the radix path is also what a world takes that has been sorting large sets lately, without looking at the
+	// count first - findNewContactsGraph; until round 5 a set the counting path could have ranked was left alone here)
+	if (blockIdx.x == 0 && threadIdx.x == 0) *nOut = n;
+	if (n <= 0) return;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 	{
 		W.pairFirst[i] = (i == 0 || keys[i - 1] != keys[i]) ? 1 : 0;
@@ -662,6 +664,8 @@ __global__ void k_pairs_sorted_total(DW W, const int* n2)
 __device__ __forceinline__ bool createBlocked(const DW& W, const DState* S, int smallPath)
 {
 	if (smallPath && S->c.nPairs > COUNT_RANK_MAX) return true;
+	// (the pair buffer overflowed, or the radix passes were queued for fewer pairs than there are: the host runs the update again)
+	if (!smallPath && (S->c.overflow & 2) != 0) return true;
 	return S->c.nContacts + S->c.nNewContacts > W.capContacts;
 }
 

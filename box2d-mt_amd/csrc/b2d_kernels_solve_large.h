@@ -1485,6 +1485,8 @@ __global__ __launch_bounds__(256) void k_large_position(DW W, int color)
 	if (S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];
 	const int begin = W.colorStart[color], end = W.colorStart[color + 1];
+	BlockMaxU32 pen;
+	pen.key = -1; pen.val = 0u;
 	for (int base = begin + blockIdx.x * blockDim.x; base < end; base += gridDim.x * blockDim.x)
 	{
 		const int row = base + threadIdx.x;
@@ -1511,8 +1513,9 @@ __global__ __launch_bounds__(256) void k_large_position(DW W, int color)
 			if (r.nsA) W.b_pos[r.bodyA] = make_float4(pA.c.x, pA.c.y, pA.a, pa.w);
 			if (r.nsB) W.b_pos[r.bodyB] = make_float4(pB.c.x, pB.c.y, pB.a, pb.w);
 		}
-		waveAtomicMaxU32Guarded(W.rootPen, r.root, floatBits(0.0f - minSep), valid);
+		blockMaxU32Offer(pen, W.rootPen, r.root, floatBits(0.0f - minSep), valid);
 	}
+	blockMaxU32Flush(pen, W.rootPen);
 }
 
 // After all colours of one position iteration: per-island early out (b2Island.cpp:329-334).

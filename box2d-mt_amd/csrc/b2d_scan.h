@@ -337,6 +337,7 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(const uint64_t* __
 	int n = *nPtr;
 	if (n <= minN) return;
 	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+	if (numTiles > (int)gridDim.x) numTiles = (int)gridDim.x; // (a sort sized for fewer keys than there are: k_radix_count has flagged it)
 	int tile = blockIdx.x;
 	if (tile >= numTiles) return;
 	for (int q = threadIdx.x; q < RADIX_DIGITS; q += RADIX_THREADS) lh[q] = 0;
@@ -359,10 +360,18 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(const uint64_t* __
 }
 
 // histCount = RADIX_DIGITS * numTiles, written to device memory for the scan utility
-__global__ void k_radix_count(const int* nPtr, int minN, int* histCount)
+// tilesCap: the tiles the launches of this sort were sized for. A sort that was queued without the host having seen the count
+// (the pair update of a world that has been sorting with the radix passes lately) may meet more: the passes then cover a part
+// only and `overflow` gets `overflowBit` - whoever consumes the result looks at it (createBlocked).
+__global__ void k_radix_count(const int* nPtr, int minN, int* histCount, int tilesCap, int* overflow, int overflowBit)
 {
 	int n = *nPtr;
 	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+	if (numTiles > tilesCap)
+	{
+		if (overflow != nullptr) atomicOr(overflow, overflowBit);
+		numTiles = tilesCap;
+	}
 	*histCount = (n <= minN) ? 0 : RADIX_DIGITS * numTiles;
 }
 
@@ -377,6 +386,7 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(const uint64_t*
 	int n = *nPtr;
 	if (n <= minN) return;
 	int numTiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+	if (numTiles > (int)gridDim.x) { numTiles = (int)gridDim.x; n = numTiles * RADIX_TILE; } // (see k_radix_hist)
 	int tile = blockIdx.x;
 	if (tile >= numTiles) return;
 	int tid = threadIdx.x;

@@ -91,6 +91,64 @@ B2D_WAVE_ATOMIC(waveAtomicMaxU32Guarded, uint32_t, waveMaxU32, 0u, atomicMax, B2
 B2D_WAVE_ATOMIC(waveAtomicMinU32, uint32_t, waveMinU32, 0xffffffffu, atomicMin, B2D_WORTH_BELOW)
 #undef B2D_WAVE_ATOMIC
 
+// A maximum per key that (nearly) every lane of a launch offers to the SAME key - the penetration of the one large island a
+// colour launch works on (DW::rootPen): kept per lane over the kernel's loop (blockMaxU32Offer) and offered once per
+// WORKGROUP at its end (blockMaxU32Flush) when all its lanes hold one key - else wave by wave as before. One look past the
+// L2 per wave was 640 of them on one word at the end of every position launch. Every thread calls both, convergently.
+struct BlockMaxU32
+{
+	int key;      // -1: nothing yet
+	uint32_t val;
+};
+__device__ __forceinline__ void blockMaxU32Offer(BlockMaxU32& run, uint32_t* base, int key, uint32_t val, bool valid)
+{
+	// (a lane that meets a second key sends the first one on its way - a launch over several islands)
+	const bool other = valid && run.key >= 0 && run.key != key;
+	if (__ballot(other) != 0ull) waveAtomicMaxU32Guarded(base, run.key, run.val, other);
+	if (valid)
+	{
+		if (run.key != key) { run.key = key; run.val = val; }
+		else run.val = val > run.val ? val : run.val;
+	}
+}
+__device__ __forceinline__ void blockMaxU32Flush(const BlockMaxU32& run, uint32_t* base)
+{
+	__shared__ int s_k[16];
+	__shared__ uint32_t s_v[16];
+	__shared__ int s_one;
+	const bool have = run.key >= 0;
+	const unsigned long long pm = __ballot(have);
+	int k0 = -1;
+	uint32_t m = 0u;
+	bool uniform = true;
+	if (pm != 0ull)
+	{
+		k0 = __shfl(run.key, __ffsll((long long)pm) - 1);
+		uniform = __ballot(have && run.key != k0) == 0ull;
+		m = waveMaxU32(have && run.key == k0 ? run.val : 0u);
+	}
+	if (waveLane() == 0) { s_k[threadIdx.x >> 6] = uniform ? k0 : -2; s_v[threadIdx.x >> 6] = m; }
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		const int nw = (int)((blockDim.x + 63u) >> 6);
+		int k = -1;
+		uint32_t v = 0u;
+		bool one = true;
+		for (int q = 0; q < nw; ++q)
+		{
+			if (s_k[q] == -1) continue;
+			if (s_k[q] == -2 || (k >= 0 && s_k[q] != k)) { one = false; break; }
+			k = s_k[q];
+			v = s_v[q] > v ? s_v[q] : v;
+		}
+		s_one = one ? 1 : 0;
+		if (one && k >= 0 && v > __hip_atomic_load(&base[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&base[k], v);
+	}
+	__syncthreads();
+	if (!s_one) waveAtomicMaxU32Guarded(base, run.key, run.val, have);
+}
+
 // Counters every lane of a kernel adds to (island and contact censuses): ONE atomic per workgroup. Same-address atomics are
 // served one after the other in L2, ~6-10 ns each - one per wave of a pass over a million bodies is 16 000 of them, 100 us
 // and more, longer than the pass itself. Every lane of the workgroup must call (barriers inside).

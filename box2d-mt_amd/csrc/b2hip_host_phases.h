@@ -34,11 +34,11 @@ static void radixPasses(int first, int bits, std::vector<std::pair<int, int>>& o
 }
 
 // keys / payloads in (kin, vin), *nPtr of them; sorted by the bits the passes name; which buffers hold the result comes back in kin / vin
-static int radixSort(b2hip_world* w, uint64_t*& kin, uint64_t*& kout, int2*& vin, int2*& vout, const int* nPtr, int tilesCap, const std::vector<std::pair<int, int>>& passes)
+static int radixSort(b2hip_world* w, uint64_t*& kin, uint64_t*& kout, int2*& vin, int2*& vout, const int* nPtr, int tilesCap, const std::vector<std::pair<int, int>>& passes, int overflowBit = 0)
 {
 	DW& d = w->dw;
 	// (the length of the histogram matrix depends on the count only: once per sort, not once per pass)
-	LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2);
+	LAUNCH(w, k_radix_count, 1, 1, nPtr, 0, w->consts.p + 2, tilesCap, overflowBit ? &d.st->c.overflow : (int*)nullptr, overflowBit);
 	for (size_t p = 0; p < passes.size(); ++p)
 	{
 		LAUNCH(w, k_radix_hist, tilesCap, RADIX_THREADS, kin, d.radixHist, nPtr, 0, passes[p].first, passes[p].second, tilesCap);
@@ -153,6 +153,10 @@ static int findNewContactsGraph(b2hip_world* w)
 	// 100 000-box Tumbler: ~25 000 and ~150 000 new fat-AABB pairs per step) would find that out at the end of the step, sort
 	// with the radix path then - and run the TOI phase and the read-back a second time, every step. While that has happened
 	// lately the host looks at the pair count right after the search instead (one small read-back) and takes the right path.
+	// (Not looking at all - the radix passes queued behind the search for twice the last update's count, checking the size
+	// themselves - was built and measured in round 5, same box, same states: Tumbler 3.49 against 3.50 ms, Pyramid 316 1.37
+	// against 1.39, and the 1 M field 2.6 against 2.2: its updates alternate between 3 000 and 150 000 pairs, every second guess
+	// was too small and the update ran twice. The gaps a kernel trace shows behind this read-back are the profiler's.)
 	if (w->pairsLargeSticky > 0) return findNewContacts(w, true);
 	return runSegment(w, w->segPairs, 3, [w]() -> int { return findNewContacts(w, false); });
 }

@@ -183,6 +183,33 @@ def test_ccd_components_run_side_by_side_and_stay_bit_exact(amd, oracle, default
         w.close()
 
 
+@pytest.mark.parametrize("env", [{"B2HIP_TOI_DOM_WIDE": "1"}, {"B2HIP_NO_SIDE_STREAM": "1"},
+                                 {"B2HIP_EARLY_ROWS_MIN": "1", "B2HIP_ROW_MARKS_CHECK": "1"}, {"B2HIP_EARLY_ROWS_MIN": "1"},
+                                 {"B2HIP_EARLY_ROWS_MIN": "1", "B2HIP_NO_ROW_MARKS": "1"}],
+                         ids=["wide component loops", "no side stream", "early rows + marks checked", "early rows + marks", "early rows, every row compared"])
+def test_ccd_component_path_variants_are_bit_exact(amd, oracle, default_mode, monkeypatch, env):
+    """Round 5's forms of the component path against the oracle, every step, on the field of the test above: the event
+    loops on one wave per component (default) and on 512 lanes (B2HIP_TOI_DOM_WIDE); snapshot / adjacency / components on the
+    side stream beside k_toi_first (default from the second step with events on) and on the main stream; the read-back behind
+    an early launch of the rows - forced on this small world with B2HIP_EARLY_ROWS_MIN - looking at marked tiles only
+    (DW::b_rowDirty), with the marks CHECKED (a row that differs from the early launch's without a mark fails the step:
+    b2hip_host_phases.h, downloadState), and comparing every row."""
+    kw = dict(p0=2500, p1=300, f0=0.0, f1=0.0, seed=11, flags=CCD)
+    o = oracle.world(bh.FIELD, **kw)
+    want = []
+    for _ in range(20):
+        o.step(1)
+        want.append((bh.fnv1a64(o.bodies()), o.contact_count))
+    o.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = amd.world(bh.FIELD, **kw)
+    for s in range(20):
+        w.step(1)
+        assert (bh.fnv1a64(w.bodies()), w.contact_count) == want[s], "step %d differs (%s)" % (s, env)
+    w.close()
+
+
 def test_ccd_at_scale_matches_reference_trace(amd, default_mode):
     """30 000 free bodies with 3 000 bullets, 30 steps: per-step contact counts and full-state hashes recorded from the
     reference build (tests/golden/toi_scale.npz). Hundreds of TOI events per step go through the per-component path."""
