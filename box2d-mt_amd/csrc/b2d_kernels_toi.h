@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 					if (foreign && (ldFlags(&W.b_flags[bodyQ]) & BF_TYPE_MASK) != BT_STATIC)
 					{
 						const int d2 = W.toiDomOf[W.toiParent[bodyQ]] - 1;
-						if (d2 >= 0) W.toiDomFailed[d2] = 1;
+						if (d2 >= 0) { W.toiDomFailed[d2] = 1; S->c.toiAnyFailed = 1; }
 					}
 					s_failed = 1;
 				}
@@ -1345,7 +1345,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 	{
 		if (DOMAIN)
 		{
-			if (s_failed) W.toiDomFailed[domain] = 1;
+			if (s_failed) { W.toiDomFailed[domain] = 1; S->c.toiAnyFailed = 1; }
 			W.toiDomEvents[domain] = s_events;
 			if (s_events) atomicAdd(&S->c.nToiEvents, s_events);
 			if (s_calls) atomicAdd(&S->c.nToiCalls, s_calls);

@@ -142,6 +142,7 @@ struct Counters
 	uint32_t cellExtBits; // float bits of the largest fat-AABB extent among the grid-sized proxies, see gridLimit()
 	int nToiDomains;     // components with a pending impact
 	int nToiPartial;     // pending impacts of the components that are replayed serially (DW::toiDomList)
+	int toiAnyFailed;    // some component of this phase has to be replayed serially (DW::toiDomFailed has a 1): k_toi_dom_rollback has work
 	int nContactsSnap, nToiOrderSnap; // contact count / TOI slot count when k_toi_snapshot was taken
 	int nEvents;         // contact events of this step (DW::evKey / evInfo), see k_contact_events
 	int nUncolList;      // entries of DW::uncolList (large-island constraints without a colour)

@@ -290,7 +290,7 @@ static int partitionLargeIslands(b2hip_world* w, int targetDeg)
 	const int idBits = radixBits(d.nBodies + 1);
 	radixPasses(0, idBits, passes);
 	radixPasses(32, 32, passes);
-	const int tilesCap = d.capPairs / RADIX_TILE + 1;
+	const int tilesCap = std::min(d.capPairs / RADIX_TILE + 1, d.nBodies / RADIX_TILE + 2); // (at most every body)
 	const int* nPtr = &d.st->c.nLBodies;
 	if (int rcs = radixSort(w, kin, kout, vin, vout, nPtr, tilesCap, passes)) return rcs;
 	LAUNCH(w, k_part_weights, gridFor(d.nBodies), 256, d, vin, d.pairFirst);
@@ -1003,7 +1003,8 @@ static int toiBuildIndexes(b2hip_world* w, bool csr, bool gridKnownFresh = false
 	// moved, and TOI moves of earlier steps never enter the move buffer) - unless this step's pair update has just built it
 	// from every proxy's box and nothing moved one since (Counters::gridFresh; the kernels below check it themselves, the
 	// host saves their launches when the read-back it already has says so: 128 us of a million-proxy world's step)
-	if (gridKnownFresh) return 0;
+	// (a sharded rank launches them anyway: other ranks' boxes may have arrived since the host last looked - the kernels know)
+	if (gridKnownFresh && !w->spatial) return 0;
 	LAUNCH(w, k_grid_clear, gridFor(d.gridMask + 1), 256, d, 1);
 	LAUNCH(w, k_grid_count, gridFor(d.nProxies), 256, d, 1);
 	deviceExclusiveScan<int>(w->stream, d.gridCount, d.gridStart, d.scanTmp, w->scanCtx, w->consts.p + 1, (int)(d.gridMask + 1));
