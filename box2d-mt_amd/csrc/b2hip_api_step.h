@@ -459,6 +459,18 @@ static int stepEndImpl(b2hip_world* w)
 		w->toiRan = tc.nToiList > 0;
 		if (tc.nToiList == 0) w->toiChains = false;
 	}
+	if (w->toiSpecDomains)
+	{
+		// the component path was queued without its census (phaseToi): the hints for the next step, and the one assumption
+		w->toiSpecDomains = false;
+		w->lastToiList = w->h_dstate->c.nToiList;
+		w->gridFreshLast = w->h_dstate->c.gridFresh != 0;
+		if (w->h_dstate->c.nToiList > 0) w->toiDomainsSticky = 16;
+		else if (w->toiDomainsSticky > 0) w->toiDomainsSticky -= 1;
+		// (the event loops searched a grid that this step's pair update had NOT rebuilt - nothing moved, the first step in
+		// many: as with any order-dependent case, back to the snapshot and the serial loop, which builds its own)
+		if (w->toiChains && w->toiSpecGridAssumed && w->h_dstate->c.gridFresh == 0) w->h_dstate->c.toiUnsafe |= 0x80;
+	}
 	if (w->toiChains)
 	{
 		if (w->h_dstate->c.nToiMoved > 0) w->toiGridSticky = 16;

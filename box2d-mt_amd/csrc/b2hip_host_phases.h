@@ -1029,6 +1029,62 @@ static int toiSerial(b2hip_world* w)
 // event loop only runs (one persistent workgroup) when some impact lies inside the step.
 static int phaseToiSync(b2hip_world* w);
 
+// What the component-wise event loops need besides the first pass, on the side stream beside it (see phaseToiSync).
+static inline bool toiAsideWanted(const b2hip_world* w)
+{
+	return w->toiDomainsSticky > 0 && w->toiCountersFresh && !w->spatial && w->stream2 != nullptr && !w->noSideStream && !w->debugSync && !w->debugTrace &&
+		!w->toiSnapshotTaken && !w->toiSerialOnly && !w->toiNoDomains && !listenerOn(w) && w->dw.toiEventCap == 0 && !w->dw.toiContinue;
+}
+static int toiAsideLaunch(b2hip_world* w)
+{
+	DW& d = w->dw;
+	HIP_TRY(hipEventRecord(w->evFork, w->stream));
+	HIP_TRY(hipStreamWaitEvent(w->stream2, w->evFork, 0));
+	// (the short launches first: the snapshot's bandwidth then falls into the tail of k_toi_first and the host's look at its
+	// census - beside its start it took the first pass from 120 to 220 us: loaded latency)
+	int rc = toiBuildAdjacency(w, w->stream2);
+	if (rc) return rc;
+	LAUNCH_ON(w, w->stream2, k_toi_dom_init, gridFor(d.nBodies), 256, d);
+	LAUNCH_ON(w, w->stream2, k_toi_dom_union, gridFor(d.capContacts), 256, d);
+	LAUNCH_ON(w, w->stream2, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
+	LAUNCH_ON(w, w->stream2, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 2);
+	HIP_TRY(hipEventRecord(w->evJoin, w->stream2));
+	return 0;
+}
+
+static inline int toiFirstGrid(b2hip_world* w);
+
+// The component path behind the first pass, its components and its snapshot: pending lists per component, the event loops, the
+// cross-component check, what has to be taken back and replayed serially. pending: the pending impacts (the host's count, or
+// its guess: every kernel strides). snapshot: 0 - taken here; 1 - taken beside the first pass, the candidates' part copied
+// here; 2 - running on the side stream, waited for here.
+static int toiDomainLaunches(b2hip_world* w, int pending, int snapshot)
+{
+	DW& d = w->dw;
+	pending = std::max(pending, 1);
+	LAUNCH(w, k_toi_dom_mark, gridFor(pending), 256, d);
+	LAUNCH(w, k_toi_dom_count, gridFor(d.capContacts), 256, d);
+	LAUNCH(w, k_toi_dom_scan, 1, 1024, d);
+	LAUNCH(w, k_toi_dom_fill, gridFor(pending), 256, d);
+	if (snapshot == 1) LAUNCH(w, k_toi_snap_cands, toiFirstGrid(w), 256, d);
+	else if (snapshot == 2) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
+	else LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
+	w->toiSnapshotTaken = true;
+	if (w->toiDomWide > 0 || w->toiDomWideOnly)
+	{
+		LAUNCH(w, k_toi_domains<TOI_LANES>, std::min(pending, 2048), TOI_LANES, d, w->sp);
+		if (w->toiDomWide > 0) w->toiDomWide -= 1;
+	}
+	else LAUNCH(w, k_toi_domains<64>, std::min(pending, 2048), 64, d, w->sp);
+	LAUNCH(w, k_toi_domains_end, std::min(pending, 1024), 256, d);
+	// components tied together by a new contact: back to the snapshot, then the serial loop over just those
+	LAUNCH(w, k_toi_dom_rollback, gridFor(std::max(std::max(d.nBodies, d.nProxies), d.capContacts)), 256, d);
+	LAUNCH(w, k_toi_loop_partial, 1, TOI_LANES, d, w->sp);
+	w->toiChainsHadGrid = true; // (the components always have it)
+	w->toiChains = true;
+	return 0;
+}
+
 // k_toi_first takes a lane per TOI candidate (grid-stride over the manager's slot table): sized from the candidate count of
 // the last read-back, generously - a wrong guess only makes the lanes loop.
 static inline int toiFirstGrid(b2hip_world* w)
@@ -1045,6 +1101,30 @@ static inline int toiFirstGrid(b2hip_world* w)
 static int phaseToi(b2hip_world* w)
 {
 	if (w->toiSerialOnly || w->toiSyncOnly || listenerOn(w) || w->dw.toiEventCap > 0 || w->dw.toiContinue || w->spatial) return phaseToiSync(w);
+	if (toiAsideWanted(w) && w->lastToiList > 0 && !w->noToiSpecDomains)
+	{
+		// The component path without the look at the first pass's census (round 5): while it has been the path of the last
+		// steps, its launches are queued behind k_toi_first at once, sized from the last step's pending count (they stride);
+		// every one of them leaves if nothing is pending. What the census would have told - the pair update unfinished, nothing
+		// pending, a capacity cut - b2hip_step_end learns from the read-back it makes anyway and settles as it does for the
+		// speculative chains; the one thing assumed - that the pair update of THIS step has left the grid fresh, as it had
+		// the step before - is checked there too (Counters::gridFresh), and a wrong guess is a serial replay from the snapshot.
+		DW& d = w->dw;
+		int rc = toiAsideLaunch(w);
+		if (rc) return rc;
+		w->toiCountersFresh = false;
+		LAUNCH(w, k_toi_first, toiFirstGrid(w), 256, d);
+		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int), w->stream)); // (k_toi_first's "not chains" bit)
+		HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
+		if (!w->gridFreshLast) { rc = toiBuildIndexes(w, false, false); if (rc) return rc; }
+		rc = toiDomainLaunches(w, 2 * w->lastToiList + 256, 1);
+		if (rc) return rc;
+		// (k_toi_clear's work is done by k_end_step, which follows)
+		w->toiSpeculative = true;
+		w->toiSpecDomains = true;
+		w->toiSpecGridAssumed = w->gridFreshLast;
+		return 0;
+	}
 	if (w->toiSyncSticky > 0)
 	{
 		// the serial loop was needed recently (bullets, kinematic partners, contact-creating events): decide from the
@@ -1093,20 +1173,10 @@ static int phaseToiSync(b2hip_world* w)
 	// k_toi_first - a few heavy lanes, ~120 us - and the host's look at its census: ~180 us of the step's critical path.
 	// Void if the pair update has to be finished first (the contact array grows under it): then everything is done again below.
 	bool aside = false;
-	if (w->toiDomainsSticky > 0 && w->toiCountersFresh && !w->spatial && w->stream2 != nullptr && !w->noSideStream && !w->debugSync && !w->debugTrace &&
-		!w->toiSnapshotTaken && !w->toiSerialOnly && !w->toiNoDomains && !listenerOn(w) && d.toiEventCap == 0 && !d.toiContinue)
+	if (toiAsideWanted(w))
 	{
-		HIP_TRY(hipEventRecord(w->evFork, w->stream));
-		HIP_TRY(hipStreamWaitEvent(w->stream2, w->evFork, 0));
-		// (the short launches first: the snapshot's bandwidth then falls into the tail of k_toi_first and the host's look at its
-		// census - beside its start it took the first pass from 120 to 220 us: loaded latency)
-		rc = toiBuildAdjacency(w, w->stream2);
+		rc = toiAsideLaunch(w);
 		if (rc) return rc;
-		LAUNCH_ON(w, w->stream2, k_toi_dom_init, gridFor(d.nBodies), 256, d);
-		LAUNCH_ON(w, w->stream2, k_toi_dom_union, gridFor(d.capContacts), 256, d);
-		LAUNCH_ON(w, w->stream2, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
-		LAUNCH_ON(w, w->stream2, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 2);
-		HIP_TRY(hipEventRecord(w->evJoin, w->stream2));
 		aside = true;
 	}
 	bool asideValid = aside;
@@ -1206,27 +1276,11 @@ static int phaseToiSync(b2hip_world* w)
 			LAUNCH(w, k_toi_dom_flatten, gridFor(d.nBodies), 256, d);
 		}
 		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int), w->stream)); // (k_toi_first's "not chains" bit)
-		LAUNCH(w, k_toi_dom_mark, gridFor(w->h_dstate->c.nToiList), 256, d);
-		LAUNCH(w, k_toi_dom_count, gridFor(d.capContacts), 256, d);
-		LAUNCH(w, k_toi_dom_scan, 1, 1024, d);
-		LAUNCH(w, k_toi_dom_fill, gridFor(w->h_dstate->c.nToiList), 256, d);
-		if (asideValid) LAUNCH(w, k_toi_snap_cands, toiFirstGrid(w), 256, d);
-		else if (snapAside) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
-		else LAUNCH(w, k_toi_snapshot, gridFor(std::max(d.nBodies, d.capContacts)), 256, d, 0);
-		w->toiSnapshotTaken = true;
-		if (w->toiDomWide > 0 || w->toiDomWideOnly)
-		{
-			LAUNCH(w, k_toi_domains<TOI_LANES>, std::min(w->h_dstate->c.nToiList, 2048), TOI_LANES, d, w->sp);
-			if (w->toiDomWide > 0) w->toiDomWide -= 1;
-		}
-		else LAUNCH(w, k_toi_domains<64>, std::min(w->h_dstate->c.nToiList, 2048), 64, d, w->sp);
-		LAUNCH(w, k_toi_domains_end, std::min(std::max(w->h_dstate->c.nToiList, 1), 1024), 256, d);
-		// components tied together by a new contact: back to the snapshot, then the serial loop over just those
-		LAUNCH(w, k_toi_dom_rollback, gridFor(std::max(std::max(d.nBodies, d.nProxies), d.capContacts)), 256, d);
-		LAUNCH(w, k_toi_loop_partial, 1, TOI_LANES, d, w->sp);
+		w->lastToiList = w->h_dstate->c.nToiList;
+		w->gridFreshLast = w->h_dstate->c.gridFresh != 0;
+		rc = toiDomainLaunches(w, w->h_dstate->c.nToiList, asideValid ? 1 : snapAside ? 2 : 0);
+		if (rc) return rc;
 		if (!w->spatial) LAUNCH(w, k_toi_clear, gridFor(d.nBodies), 256, d);
-		w->toiChainsHadGrid = true; // (the components always have it)
-		w->toiChains = true;
 		return 0;
 	}
 	if ((hasPreSolve(w) || w->spatial) && !w->toiSnapshotTaken)

@@ -183,14 +183,15 @@ def test_ccd_components_run_side_by_side_and_stay_bit_exact(amd, oracle, default
         w.close()
 
 
-@pytest.mark.parametrize("env", [{"B2HIP_TOI_DOM_WIDE": "1"}, {"B2HIP_NO_SIDE_STREAM": "1"},
+@pytest.mark.parametrize("env", [{"B2HIP_TOI_DOM_WIDE": "1"}, {"B2HIP_NO_SIDE_STREAM": "1"}, {"B2HIP_TOI_NO_SPEC_DOMAINS": "1"},
                                  {"B2HIP_EARLY_ROWS_MIN": "1", "B2HIP_ROW_MARKS_CHECK": "1"}, {"B2HIP_EARLY_ROWS_MIN": "1"},
                                  {"B2HIP_EARLY_ROWS_MIN": "1", "B2HIP_NO_ROW_MARKS": "1"}],
-                         ids=["wide component loops", "no side stream", "early rows + marks checked", "early rows + marks", "early rows, every row compared"])
+                         ids=["wide component loops", "no side stream", "census first", "early rows + marks checked", "early rows + marks", "early rows, every row compared"])
 def test_ccd_component_path_variants_are_bit_exact(amd, oracle, default_mode, monkeypatch, env):
     """Round 5's forms of the component path against the oracle, every step, on the field of the test above: the event
     loops on one wave per component (default) and on 512 lanes (B2HIP_TOI_DOM_WIDE); snapshot / adjacency / components on the
-    side stream beside k_toi_first (default from the second step with events on) and on the main stream; the read-back behind
+    side stream beside k_toi_first (default from the second step with events on) and on the main stream; the whole path queued
+    behind k_toi_first without a look at its census (default while the path has been in use) and after that look; the read-back behind
     an early launch of the rows - forced on this small world with B2HIP_EARLY_ROWS_MIN - looking at marked tiles only
     (DW::b_rowDirty), with the marks CHECKED (a row that differs from the early launch's without a mark fails the step:
     b2hip_host_phases.h, downloadState), and comparing every row."""
