@@ -161,6 +161,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->toiSyncOnly = getenv("B2HIP_TOI_SYNC") != nullptr;
 	w->toiDomWideOnly = getenv("B2HIP_TOI_DOM_WIDE") != nullptr;
 	w->noToiSpecDomains = getenv("B2HIP_TOI_NO_SPEC_DOMAINS") != nullptr;
+	w->debugAssumeFreshGrid = getenv("B2HIP_DEBUG_ASSUME_FRESH_GRID") != nullptr;
 	w->toiNoDomains = getenv("B2HIP_TOI_NO_DOMAINS") != nullptr; // bullets / kinematic partners through the serial loop only // decide chains / serial loop from a read-back after k_toi_first (the older flow)
 	w->toiFallbacks = 0;
 	for (int i = 0; i < 13; ++i) w->ev[i] = nullptr;

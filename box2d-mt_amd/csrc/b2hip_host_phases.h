@@ -1116,13 +1116,17 @@ static int phaseToi(b2hip_world* w)
 		LAUNCH(w, k_toi_first, toiFirstGrid(w), 256, d);
 		HIP_TRY(hipMemsetAsync(&w->d_state.p->c.toiUnsafe, 0, sizeof(int), w->stream)); // (k_toi_first's "not chains" bit)
 		HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
-		if (!w->gridFreshLast) { rc = toiBuildIndexes(w, false, false); if (rc) return rc; }
+		// (B2HIP_DEBUG_ASSUME_FRESH_GRID=1, for the tests: the assumption is made whatever the last step said, and the device is
+		// told the grid is stale - every such step takes the wrong-guess path of b2hip_step_end)
+		const bool assumeFresh = w->gridFreshLast || w->debugAssumeFreshGrid;
+		if (w->debugAssumeFreshGrid) HIP_TRY(hipMemsetAsync(&w->d_state.p->c.gridFresh, 0, sizeof(int), w->stream));
+		if (!assumeFresh) { rc = toiBuildIndexes(w, false, false); if (rc) return rc; }
 		rc = toiDomainLaunches(w, 2 * w->lastToiList + 256, 1);
 		if (rc) return rc;
 		// (k_toi_clear's work is done by k_end_step, which follows)
 		w->toiSpeculative = true;
 		w->toiSpecDomains = true;
-		w->toiSpecGridAssumed = w->gridFreshLast;
+		w->toiSpecGridAssumed = assumeFresh;
 		return 0;
 	}
 	if (w->toiSyncSticky > 0)

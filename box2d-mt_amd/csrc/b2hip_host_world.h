@@ -379,6 +379,7 @@ struct b2hip_world
 	int lastToiList = 0;      // pending impacts of the last step that took the component path (sizes the speculative launches)
 	bool gridFreshLast = false; // ... and whether its pair update had left the grid fresh (what the speculative flow assumes of the next)
 	bool toiSpecDomains = false, toiSpecGridAssumed = false; // this step's TOI phase was queued without the census (phaseToi) / assuming a fresh grid
+	bool debugAssumeFreshGrid = false; // B2HIP_DEBUG_ASSUME_FRESH_GRID=1 (tests: the speculative component path's wrong-guess handling)
 	bool noToiSpecDomains = false; // B2HIP_TOI_NO_SPEC_DOMAINS=1: always look at the census first (phaseToiSync)
 	int toiDomWide = 0;       // steps for which the components' event loops get 512 lanes again (one of them met more candidate contacts than a wave has lanes)
 	bool toiDomWideOnly = false; // B2HIP_TOI_DOM_WIDE=1: always (comparison)

@@ -211,6 +211,32 @@ def test_ccd_component_path_variants_are_bit_exact(amd, oracle, default_mode, mo
     w.close()
 
 
+def test_ccd_speculative_component_path_survives_a_wrong_guess(amd, oracle, default_mode, monkeypatch):
+    """The component path queued without its census (phaseToi) assumes that this step's pair update left the hash grid fresh,
+    as the last step's had, and b2hip_step_end checks it. B2HIP_DEBUG_ASSUME_FRESH_GRID=1 makes every such step a wrong guess
+    (the device is told the grid is stale): each goes back to the snapshot and through the serial loop - and the states stay
+    the oracle's, bit for bit, with the fall-backs counted."""
+    hip = C.CDLL(os.path.join(ROOT, "box2d-mt_amd", "libb2hip.so"))
+    import b2hip
+    kw = dict(p0=2500, p1=300, f0=0.0, f1=0.0, seed=11, flags=CCD)
+    o = oracle.world(bh.FIELD, **kw)
+    want = []
+    for _ in range(14):
+        o.step(1)
+        want.append((bh.fnv1a64(o.bodies()), o.contact_count))
+    o.close()
+    monkeypatch.setenv("B2HIP_DEBUG_ASSUME_FRESH_GRID", "1")
+    w = amd.world(bh.FIELD, **kw)
+    dev = C.c_void_p(w.device_world())
+    for s in range(14):
+        w.step(1)
+        assert (bh.fnv1a64(w.bodies()), w.contact_count) == want[s], "step %d differs" % s
+    ctr = b2hip.Counters()
+    assert hip.b2hip_get_counters(dev, C.byref(ctr)) == 0
+    assert ctr.toi_serial_fallbacks >= 8, "the wrong-guess path was not taken (%d fall-backs)" % ctr.toi_serial_fallbacks
+    w.close()
+
+
 def test_ccd_at_scale_matches_reference_trace(amd, default_mode):
     """30 000 free bodies with 3 000 bullets, 30 steps: per-step contact counts and full-state hashes recorded from the
     reference build (tests/golden/toi_scale.npz). Hundreds of TOI events per step go through the per-component path."""
