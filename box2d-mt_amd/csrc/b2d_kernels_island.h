@@ -165,10 +165,26 @@ __device__ __forceinline__ int adoptOffer(int blk, int body)
 }
 __device__ __forceinline__ int adoptBlock(int offer) { return offer & 0x7ff; }
 
+// A body of a large island that NO neighbour could offer a block - it landed on other newcomers, further from any block
+// than k_block_adopt hands blocks on - takes one by its own id, as the newcomers that touch only the ground have since round 3
+// (k_island_edges): its constraints are cut constraints wherever its neighbours live, a handful of hand-overs through
+// memory. Until round 5 such a body's constraints were "orphans" and the whole island was partitioned again for them -
+// radix passes, a colour check of every contact, a dozen claim / resolve rounds with read-backs, ~1 ms: the settled 50 086-box
+// pyramid, whose rim sheds boxes onto a debris field all the time, did that every second step (`B2HIP_TRACE_PARTITION=1`).
 __device__ __forceinline__ int effBlk(const DW& W, int body)
 {
 	const int b = W.b_blk1[body];
-	return b ? b : adoptBlock(W.b_adopt[body]);
+	if (b) return b;
+	const int o = adoptBlock(W.b_adopt[body]);
+	if (o || W.noOwnIdBlocks) return o;
+	if ((W.b_flags[body] & BF_LARGE) == 0) return 0;
+	// (plain islands only - no joints, no hubs: what k_solve_blocks takes. Islands with joints or hubs go sweep by sweep through
+	// k_blocks_sweep, which sweeps such newcomers' constraints in order with the hub rows - DW::serialOrphans - and never made
+	// a partition for them; handing them blocks there instead ran MultithreadDemo's growing pile into the sweep kernel's spin
+	// limit, not looked into)
+	if (W.nJoints != 0 || W.st->c.maxDegree > HUB_DEGREE) return 0;
+	const int nb = W.st->c.nBlocks < MAX_BLOCKS ? W.st->c.nBlocks : MAX_BLOCKS;
+	return nb > 0 ? 1 + (int)(((uint32_t)body * 2654435761u >> 8) % (uint32_t)nb) : 0;
 }
 
 __global__ __launch_bounds__(256) void k_island_init(DW W)

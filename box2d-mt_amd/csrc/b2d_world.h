@@ -472,6 +472,7 @@ struct DW
 	int* toiGroupList;   // per chain: CHAIN_ADJ_MAX contact indices
 	int* toiMoved;       // proxies re-inserted by the chains
 	int gridHalf;        // the grid's cell is half the limit (dense scenes) instead of the limit itself (b2d_kernels_broadphase.h: gridCell)
+	int noOwnIdBlocks;   // B2HIP_NO_OWN_ID_BLOCKS=1: a large-island body without a block or an offer stays an orphan (round 4: the island is partitioned again)
 	int noChainCreate;   // B2HIP_TOI_NO_CHAIN_CREATE=1: every new pair a chain meets sends the phase to the serial loop (comparison)
 	int* toiNew;         // TOI_NEWPAIR_MAX x 8 ints: pairs found by the chains (alpha bits, event key hi / lo, proxy lo / hi)
 	float4* snapBody;    // 5 rows per body: pos, pos0, vel, xf, flags (state before the chains)
