@@ -176,11 +176,16 @@ def cpu_baseline_window(scene, p0, p1, flags, seed, first, steps, max_seconds, t
         t00 = time.perf_counter()
         w = ref.world(scene, p0, p1, seed=seed, flags=flags, threads=threads)
         build_s = time.perf_counter() - t00
+        # (the first step builds the reference's broad-phase tree - 5 s for a million proxies - and says nothing about the others:
+        # the window is judged from the second)
         t0 = time.perf_counter()
-        w.step(2)
-        two = (time.perf_counter() - t0) / 2
+        w.step(1)
+        one = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        w.step(1)
+        two = time.perf_counter() - t0
         done = 2
-        reach = first > 2 and two * (first + min(steps, 10)) < max_seconds
+        reach = first > 2 and one + two * (first + min(steps, 10) - 1) < max_seconds
         if reach:
             w.step(first - done)
             done = first
@@ -214,7 +219,7 @@ def gpu_window(amd, scene, p0, p1, flags, seed, first, steps):
     return out
 
 
-def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, roof_modes, workload_key, cpu_first, cpu_seconds, seed=3, long_steps=300, exact_order=False, parity=None):
+def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, roof_modes, workload_key, cpu_first, cpu_seconds, seed=3, long_steps=300, exact_order=False, parity=None, cpu_budget=1.0):
     """One of the other BASELINE configs on this GPU: settle (the window is stated in the entry), `long_steps` single steps
     timed one by one (read-back included: mean / p50 / p99), then roofline passes - the configuration's SOLVER kernel first
     (mode 1; mode 5 where the solver is a launch-per-colour family), then its dominant bandwidth kernel - and the CPU baseline."""
@@ -248,7 +253,9 @@ def time_extra(amd, hipL, name, scene, p0, p1, flags, settle, roof_modes, worklo
     if exact_order:
         out["exact_order"] = exact_order_cost(hipL, w)
     w.close()
-    cb = cpu_baseline_window(scene, p0, p1, flags, seed, cpu_first, 20, cpu_seconds)
+    # (cpu_budget: the 1 M field's reference needs ~45 s to reach the window the GPU is timed in - 1.2 s per step - and gets them:
+    # same scene, same window on both sides)
+    cb = cpu_baseline_window(scene, p0, p1, flags, seed, cpu_first, 20, cpu_seconds * cpu_budget)
     if cb is not None and "error" not in cb and cb["window"][0] != settle:
         try:
             cb["gpu_same_window"] = gpu_window(amd, scene, p0, p1, flags, seed, cb["window"][0], cb["window"][1] - cb["window"][0] + 1)
@@ -491,7 +498,7 @@ def main():
                 jobs.append(dict(name="config 3: Tumbler 316 x 316 = 99 856 boxes in a revolving container, CCD off (Tumbler.h)", scene=bh.TUMBLER, p0=316, p1=0, flags=bh.F_SLEEP | bh.F_WARM,
                                  settle=SETTLE["tumbler"], roof_modes=[("roofline", 5), ("roofline_collide", 2)], workload_key="tumbler316", cpu_first=60, parity=PARITY_TUMBLER, seed=1))
             jobs.append(dict(name="config 5 on ONE GPU: 1 M mixed circles + boxes random field, 10 000 bullets, CCD on", scene=bh.FIELD, p0=1000000, p1=10000, flags=ccd,
-                             settle=SETTLE["field"], roof_modes=[("roofline", 1), ("roofline_sync_fixtures", 3)], workload_key="field1000000", cpu_first=SETTLE["field"], long_steps=300))
+                             settle=SETTLE["field"], roof_modes=[("roofline", 1), ("roofline_sync_fixtures", 3)], workload_key="field1000000", cpu_first=SETTLE["field"], long_steps=300, cpu_budget=6.0))
             jobs.append(dict(name="config 4, one GPU's share: Pyramid 316 rows = 50 086 boxes, CCD on", scene=bh.PYRAMID, p0=316, p1=1, flags=ccd,
                              settle=SETTLE["pyramid316"], roof_modes=[("roofline", 1)], workload_key="pyramid316", cpu_first=60))
         for job in jobs:
