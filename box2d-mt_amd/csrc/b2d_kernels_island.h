@@ -176,13 +176,13 @@ __device__ __forceinline__ int effBlk(const DW& W, int body)
 	const int b = W.b_blk1[body];
 	if (b) return b;
 	const int o = adoptBlock(W.b_adopt[body]);
-	if (o || W.noOwnIdBlocks) return o;
+	if (o || W.noOwnIdBlocks > 0) return o;
 	if ((W.b_flags[body] & BF_LARGE) == 0) return 0;
 	// (plain islands only - no joints, no hubs: what k_solve_blocks takes. Islands with joints or hubs go sweep by sweep through
 	// k_blocks_sweep, which sweeps such newcomers' constraints in order with the hub rows - DW::serialOrphans - and never made
 	// a partition for them; handing them blocks there instead ran MultithreadDemo's growing pile into the sweep kernel's spin
 	// limit, not looked into)
-	if (W.nJoints != 0 || W.st->c.maxDegree > HUB_DEGREE) return 0;
+	if ((W.nJoints != 0 || W.st->c.maxDegree > HUB_DEGREE) && W.noOwnIdBlocks >= 0) return 0; // (noOwnIdBlocks -1, B2HIP_OWN_ID_BLOCKS_ALL=1: everywhere - the experiment)
 	const int nb = W.st->c.nBlocks < MAX_BLOCKS ? W.st->c.nBlocks : MAX_BLOCKS;
 	return nb > 0 ? 1 + (int)(((uint32_t)body * 2654435761u >> 8) % (uint32_t)nb) : 0;
 }

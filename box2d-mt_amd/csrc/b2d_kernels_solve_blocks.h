@@ -318,7 +318,7 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	if (nR > LANES || nB > BLOCK_MAX_BODIES || nB > LANES)
 	{
 		// the host checked the census before choosing this kernel: cannot happen, fail loudly
-		if (tid == 0) { stcI(&bar[4], 1); atomicOr(gb.overflow, 64); }
+		if (tid == 0) { stcI(&bar[4], 1); atomicOr(gb.overflow, 64 | 0x2000); } // (0x2000: a block holds more than a workgroup takes - not a wait that timed out)
 		nR = nR > LANES ? LANES : nR;
 		nB = 0;
 	}
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(LANES) void k_blocks_sweep(DW W, StepParams sp, int
 	int nB = W.blkBodyStart[blk + 1] - bodyStart;
 	if (nR > LANES || nB > BLOCK_MAX_BODIES || nB > LANES)
 	{
-		if (tid == 0) { stcI(&bar[4], 1); atomicOr(&S->c.overflow, 64); }
+		if (tid == 0) { stcI(&bar[4], 1); atomicOr(&S->c.overflow, 64 | 0x2000); }
 		nR = nR > LANES ? LANES : nR;
 		nB = 0;
 	}

@@ -617,7 +617,8 @@ static int stepEndImpl(b2hip_world* w)
 		if (c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
 		if (c.nUncolored != 0) return setError(B2HIP_ERR_CAPACITY, "incremental colouring did not converge");
 	}
-	if (c.overflow & 64) return setError(B2HIP_ERR_HIP, "grid barrier of k_solve_persistent timed out (a workgroup was not resident)");
+	if ((c.overflow & 0x2040) == 0x2040) return setError(B2HIP_ERR_CAPACITY, "a block of the large-island partition holds more rows or home bodies than its workgroup takes (the census the host partitions by did not see them)");
+	if (c.overflow & 64) return setError(B2HIP_ERR_HIP, "a wait inside a resident large-island solver timed out (a workgroup was not resident, or a hand-over never came)");
 	if (c.overflow & SCAN_ABORT_BIT) return setError(B2HIP_ERR_HIP, "a single-pass scan gave up waiting for a predecessor tile (k_scan_chain look-back)");
 	w->last.posItersLarge = c.posItersLarge;
 	w->last.nHubRows = c.nHubRows;

@@ -125,7 +125,7 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->tracePartition = getenv("B2HIP_TRACE_PARTITION") != nullptr;
 	if (const char* e = getenv("B2HIP_GRID_HALF")) { w->gridForced = true; w->gridHalf = atoi(e) != 0; w->dw.gridHalf = w->gridHalf ? 1 : 0; }
 	w->dw.noChainCreate = getenv("B2HIP_TOI_NO_CHAIN_CREATE") != nullptr ? 1 : 0;
-	w->dw.noOwnIdBlocks = getenv("B2HIP_NO_OWN_ID_BLOCKS") != nullptr ? 1 : 0;
+	w->dw.noOwnIdBlocks = getenv("B2HIP_NO_OWN_ID_BLOCKS") != nullptr ? 1 : getenv("B2HIP_OWN_ID_BLOCKS_ALL") != nullptr ? -1 : 0;
 	w->traceLaunches = getenv("B2HIP_TRACE_LAUNCHES") != nullptr;
 	w->noBlocks = getenv("B2HIP_NO_BLOCKS") != nullptr;           // no block partition at all (colours as before it existed)
 	w->blockLanes = 0; // chosen per partition (see phaseSolve); B2HIP_BLOCK_LANES = 256 | 512 | 1024 forces one size
