@@ -152,6 +152,19 @@ __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, in
 		++spins;
 		if (spins > DATAFLOW_SPIN_MAX || ((spins & 1023) == 0 && __any(ldcI(&bar[4]) != 0)))
 		{
+			// (post mortem, B2HIP_HANDOVER_WHY=1: the first lane that gave up on its OWN count leaves what it waited for - the rows'
+			// addresses in 16-byte units, the versions it needed and the ones it last saw - in bar[24..31])
+			if (pending && spins > DATAFLOW_SPIN_MAX && atomicCAS(&bar[24], 0, 1) == 0)
+			{
+				f4v ra = { 0.0f, 0.0f, 0.0f, 0.0f }, rb = ra;
+				if (rowA) ra = ldRow(rowA);
+				if (rowB) rb = ldRow(rowB);
+				bar[25] = needA; bar[26] = __float_as_int(ra.w);
+				bar[27] = needB; bar[28] = __float_as_int(rb.w);
+				bar[29] = rowA ? (int)(uint32_t)((uintptr_t)rowA >> 4) : -1;
+				bar[30] = rowB ? (int)(uint32_t)((uintptr_t)rowB >> 4) : -1;
+				bar[31] = (int)blockIdx.x * 4096 + (int)threadIdx.x;
+			}
 			stcI(&bar[4], 1);
 			atomicOr(overflow, 64);
 			return false;

@@ -697,6 +697,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.overflow = 0;
 		c.cellExtBits = 0;
 		c.gridFresh = 0;
+		W.st->dbgCensus[0] = 0;
 		c.nEvents = 0;
 		c.nToiList = 0;
 		c.nNewToiCand = 0;

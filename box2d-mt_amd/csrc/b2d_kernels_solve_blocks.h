@@ -119,6 +119,13 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 					W.b_blk1[body[u]] = e[u];
 					atomicAdd(&s_cnt[e[u] - 1], 1);
 				}
+				else if (body[u] >= 0 && atomicCAS(&S->dbgCensus[0], 0, body[u] + 1) == 0)
+				{
+					S->dbgCensus[1] = e[u]; S->dbgCensus[2] = W.b_blk1[body[u]]; S->dbgCensus[3] = W.b_adopt[body[u]];
+					const uint32_t hx = (uint32_t)body[u] * 2654435761u >> 8;
+					const int nbx = W.st->c.nBlocks;
+					S->dbgCensus[4] = (int)hx; S->dbgCensus[5] = nbx; S->dbgCensus[6] = (int)(hx % (uint32_t)nbx); S->dbgCensus[7] = effBlk(W, body[u]);
+				}
 			}
 		}
 		__syncthreads();

@@ -251,6 +251,7 @@ struct DState
 	unsigned long long phaseClock[16];
 	int pubCount;        // publications of the census so far (b2dPublishCensus; the host counts along)
 	// (host copies only: the number of the publication / read-back this copy is; what lies before it is copied in 16-byte pieces)
+	int dbgCensus[8];    // (diagnostics, B2HIP_HANDOVER_WHY: the first large-island body k_block_census found without a block, and why)
 	alignas(16) int pubSeq;
 	int pubPad[3];
 };

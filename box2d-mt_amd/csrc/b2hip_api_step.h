@@ -263,6 +263,91 @@ int b2hip_solve_toi(b2hip_world* w)
 
 static int uploadToiVerdicts(b2hip_world* w);
 
+// B2HIP_HANDOVER_WHY=1: what the lane that gave up first was waiting for (b2d_handover.h: dataflowRun), and every constraint
+// row of the large islands that touches either of its two bodies - colour, the block segment it was placed in, the bodies'
+// home blocks and cut-colour masks - to stderr. Diagnostics for the block solvers' hand-over protocol.
+static void handoverPostMortem(b2hip_world* w)
+{
+	(void)hipStreamSynchronize(w->stream);
+	int bar[32];
+	if (hipMemcpy(bar, w->gridBar.p, sizeof(bar), hipMemcpyDeviceToHost) != hipSuccess || bar[24] == 0) { fprintf(stderr, "[b2hip] hand-over post mortem: no record\n"); return; }
+	const Counters& c = w->h_dstate->c;
+	auto bodyOf = [&](int unit) -> int
+	{
+		if (unit == -1) return -1;
+		const float4* bases[2] = { w->b_cutv.p, w->b_posv.p };
+		for (int k = 0; k < 2; ++k)
+		{
+			const uint32_t b0 = (uint32_t)((uintptr_t)bases[k] >> 4);
+			const uint32_t d = (uint32_t)unit - b0;
+			if (d < (uint32_t)w->bodies.size()) return (int)d;
+		}
+		return -2;
+	};
+	{
+		DState ds;
+		if (hipMemcpy(&ds, w->d_state.p, sizeof(DState), hipMemcpyDeviceToHost) == hipSuccess && ds.dbgCensus[0] != 0)
+			fprintf(stderr, "[b2hip]   k_block_census left body %d without a block: effBlk %d, b_blk1 %d, offer 0x%x, hash 0x%x, blocks %d, hash mod blocks %d, effBlk again %d\n", ds.dbgCensus[0] - 1, ds.dbgCensus[1], ds.dbgCensus[2], ds.dbgCensus[3], ds.dbgCensus[4], ds.dbgCensus[5], ds.dbgCensus[6], ds.dbgCensus[7]);
+	}
+	const int bodyA = bodyOf(bar[29]), bodyB = bodyOf(bar[30]);
+	fprintf(stderr, "[b2hip] hand-over post mortem: workgroup %d lane %d waited for body %d at version 0x%x (saw 0x%x) and body %d at 0x%x (saw 0x%x); %d blocks of %d lanes, %d large-island constraints, %d colours\n",
+		bar[31] / 4096, bar[31] % 4096, bodyA, bar[25], bar[26], bodyB, bar[27], bar[28], c.nBlocks, c.blkLanes, c.nLContacts, c.nColors);
+	const int n = c.nLContacts;
+	if (n <= 0) return;
+	std::vector<int4> ref((size_t)n);
+	std::vector<int> col((size_t)n), rowStart((size_t)MAX_BLOCKS + 2), blk1(w->bodies.size()), adopt(w->bodies.size());
+	std::vector<unsigned long long> act(w->bodies.size());
+	(void)hipMemcpy(ref.data(), w->li_ref.p, (size_t)n * sizeof(int4), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(col.data(), w->rowColor.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(rowStart.data(), w->blkRowStart.p, rowStart.size() * sizeof(int), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(blk1.data(), w->b_blk1.p, blk1.size() * sizeof(int), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(adopt.data(), w->b_adopt.p, adopt.size() * sizeof(int), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(act.data(), w->bodyActive.p, act.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+	std::vector<uint32_t> flags(w->bodies.size());
+	std::vector<int> deg(w->bodies.size());
+	(void)hipMemcpy(flags.data(), w->b_flags.p, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(deg.data(), w->deg.p, deg.size() * sizeof(int), hipMemcpyDeviceToHost);
+	std::vector<int> lib((size_t)std::max(c.nLBodies, 1));
+	(void)hipMemcpy(lib.data(), w->li_bodies.p, lib.size() * sizeof(int), hipMemcpyDeviceToHost);
+	{
+		int zero = 0, first = -1;
+		for (int k = 0; k < c.nLBodies; ++k) if (blk1[(size_t)lib[(size_t)k]] == 0) { if (first < 0) first = lib[(size_t)k]; ++zero; }
+		std::vector<int> bstart((size_t)MAX_BLOCKS + 2);
+		(void)hipMemcpy(bstart.data(), w->blkBodyStart.p, bstart.size() * sizeof(int), hipMemcpyDeviceToHost);
+		fprintf(stderr, "[b2hip]   %d of the %d large-island bodies have no home block (the first: %d); home bodies listed by the census: %d; bodies in the world %zu, joints %d, busiest body %d contacts\n",
+			zero, c.nLBodies, first, bstart[(size_t)std::min(c.nBlocks, MAX_BLOCKS)], w->bodies.size(), w->dw.nJoints, c.maxDegree);
+	}
+	auto describe = [&](int body)
+	{
+		int at = -1;
+		for (int k = 0; k < c.nLBodies; ++k) if (lib[(size_t)k] == body) at = k;
+		const int nbk = c.nBlocks < MAX_BLOCKS ? c.nBlocks : MAX_BLOCKS;
+		fprintf(stderr, "[b2hip]       (place in the list of large-island bodies: %d of %d; a block by its own id would be %d)\n", at, c.nLBodies, nbk > 0 ? 1 + (int)(((uint32_t)body * 2654435761u >> 8) % (uint32_t)nbk) : 0);
+		fprintf(stderr, "[b2hip]       body %d: flags 0x%x (type %u, large %d, awake %d), degree %d, home block %d, offer 0x%x, cut-colour mask 0x%llx\n", body, flags[(size_t)body], flags[(size_t)body] & BF_TYPE_MASK,
+			(flags[(size_t)body] & BF_LARGE) ? 1 : 0, (flags[(size_t)body] & BF_AWAKE) ? 1 : 0, deg[(size_t)body], blk1[(size_t)body], adopt[(size_t)body], act[(size_t)body]);
+	};
+	for (int which = 0; which < 2; ++which)
+	{
+		const int body = which ? bodyB : bodyA;
+		if (body < 0) continue;
+		fprintf(stderr, "[b2hip]   body %d: home block %d, offer 0x%x, cut-colour mask 0x%llx (%d cut constraints expected)\n", body, blk1[(size_t)body], adopt[(size_t)body], act[(size_t)body], __builtin_popcountll(act[(size_t)body]));
+		for (int row = 0; row < n; ++row)
+		{
+			const int4 q = ref[(size_t)row];
+			const int a = q.y >= 0 ? q.y : -(q.y + 1), b = q.z >= 0 ? q.z : -(q.z + 1);
+			if ((q.y >= 0 && a == body) || (q.z >= 0 && b == body))
+			{
+				int seg = -1;
+				for (int k = 0; k <= c.nBlocks && k <= MAX_BLOCKS; ++k) if (row >= rowStart[(size_t)k] && row < rowStart[(size_t)k + 1]) seg = k;
+				fprintf(stderr, "[b2hip]     row %d colour %d in the segment of block %d: contact %d, bodies %d%s (block %d) / %d%s (block %d)\n", row, col[(size_t)row], seg + 1, q.x,
+					a, q.y >= 0 ? "" : " static", q.y >= 0 ? blk1[(size_t)a] : 0, b, q.z >= 0 ? "" : " static", q.z >= 0 ? blk1[(size_t)b] : 0);
+				if (q.y >= 0) describe(a);
+				if (q.z >= 0) describe(b);
+			}
+		}
+	}
+}
+
 // A contact created inside a TOI sub-step did not fit the array (whatever path ran last, fallbacks included): never a
 // silent drop. With the snapshot of this step's TOI phase at hand the phase is undone, the array doubled and the phase
 // run again; without one (serial-only mode) it is an error.
@@ -618,7 +703,11 @@ static int stepEndImpl(b2hip_world* w)
 		if (c.nUncolored != 0) return setError(B2HIP_ERR_CAPACITY, "incremental colouring did not converge");
 	}
 	if ((c.overflow & 0x2040) == 0x2040) return setError(B2HIP_ERR_CAPACITY, "a block of the large-island partition holds more rows or home bodies than its workgroup takes (the census the host partitions by did not see them)");
-	if (c.overflow & 64) return setError(B2HIP_ERR_HIP, "a wait inside a resident large-island solver timed out (a workgroup was not resident, or a hand-over never came)");
+	if (c.overflow & 64)
+	{
+		if (getenv("B2HIP_HANDOVER_WHY")) handoverPostMortem(w);
+		return setError(B2HIP_ERR_HIP, "a wait inside a resident large-island solver timed out (a workgroup was not resident, or a hand-over never came)");
+	}
 	if (c.overflow & SCAN_ABORT_BIT) return setError(B2HIP_ERR_HIP, "a single-pass scan gave up waiting for a predecessor tile (k_scan_chain look-back)");
 	w->last.posItersLarge = c.posItersLarge;
 	w->last.nHubRows = c.nHubRows;
