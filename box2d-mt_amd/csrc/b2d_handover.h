@@ -119,7 +119,12 @@ __device__ __forceinline__ void stRow(float4* p, float x, float y, float z, int 
 	v.y = y;
 	v.z = z;
 	v.w = __int_as_float(version);
-	asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+	// (s_nop 1: a store of more than 8 bytes reads its data registers late, and a VALU write to them within the next two
+	// instructions can reach the store first. The compiler's hazard pass keeps that distance for its own stores; an
+	// instruction inside an asm statement is invisible to it. k_solve_blocks once had `global_store_dwordx4 v[.], v[4:7]` /
+	// `s_or_b64 exec` / `v_mad_u64_u32 v[4:5]`: a hand-over row with words of the next address computation in it, now and
+	// then - the bench scene stopped repeating bit for bit (round 5; tools/asm_store_hazard.py looks for the pattern).)
+	asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ void atomicOr64(uint64_t* p, uint64_t v)

@@ -165,20 +165,6 @@ __device__ __forceinline__ int adoptOffer(int blk, int body)
 }
 __device__ __forceinline__ int adoptBlock(int offer) { return offer & 0x7ff; }
 
-// The block (+ 1) a body takes by its own id: hash(body) mod blocks. The remainder goes by way of a float quotient with BOTH
-// corrections, not through `%`: with a divisor the compiler knows to be small it expands `%` into its 24-bit form, and
-// inside k_block_census that form returned 0xffffff for x = 0xc1f9f3, nb = 11 (a quotient one too large, the remainder - 1,
-// uncorrected) where the same expression in k_color_check and k_color_fill returned 10 - one body of 622 was home in no
-// block, its neighbour's cut constraint waited for a hand-over that never came (found with B2HIP_HANDOVER_WHY, round 5).
-__device__ __forceinline__ int ownIdBlock(int body, int nb)
-{
-	const uint32_t x = (uint32_t)body * 2654435761u >> 8; // (< 2^24: exact as a float)
-	const uint32_t q = (uint32_t)((float)x / (float)nb);
-	int r = (int)x - (int)(q * (uint32_t)nb);
-	if (r < 0) r += nb; else if (r >= nb) r -= nb;
-	return 1 + r;
-}
-
 // A body of a large island that NO neighbour could offer a block - it landed on other newcomers, further from any block
 // than k_block_adopt hands blocks on - takes one by its own id, as the newcomers that touch only the ground have since round 3
 // (k_island_edges): its constraints are cut constraints wherever its neighbours live, a handful of hand-overs through

@@ -23,6 +23,21 @@
 #endif
 
 // --- tuning constants (Box2D/Common/b2Settings.h:47-174) -------------------------------------
+// (in this header so that the CPU build can check it exhaustively: tests/test_device_math_cpu.py)
+// The block (+ 1) a body takes by its own id: hash(body) mod blocks. The remainder goes by way of a float quotient with BOTH
+// corrections, not through `%`: with a divisor the compiler knows to be small it expands `%` into its 24-bit form, and
+// inside k_block_census that form returned 0xffffff for x = 0xc1f9f3, nb = 11 (a quotient one too large, the remainder - 1,
+// uncorrected) where the same expression in k_color_check and k_color_fill returned 10 - one body of 622 was home in no
+// block, its neighbour's cut constraint waited for a hand-over that never came (found with B2HIP_HANDOVER_WHY, round 5).
+B2D_HD int ownIdBlock(int body, int nb)
+{
+	const uint32_t x = (uint32_t)body * 2654435761u >> 8; // (< 2^24: exact as a float)
+	const uint32_t q = (uint32_t)((float)x / (float)nb);
+	int r = (int)x - (int)(q * (uint32_t)nb);
+	if (r < 0) r += nb; else if (r >= nb) r -= nb;
+	return 1 + r;
+}
+
 #define B2D_EPSILON 1.192092896e-07f
 #define B2D_MAXFLOAT 3.402823466e+38f
 #define B2D_PI 3.14159265359f

@@ -513,7 +513,8 @@ __device__ __forceinline__ void b2dStoreAgent4(float4* p, float4 v)
 	typedef float f4 __attribute__((ext_vector_type(4)));
 	f4 q;
 	q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
-	asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(q) : "memory");
+	// (s_nop 1: the store's data registers must not be written by the next two instructions - see stRow in b2d_handover.h)
+	asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(q) : "memory");
 }
 __device__ __forceinline__ float4 b2dLoadAgent4(const float4* p)
 {

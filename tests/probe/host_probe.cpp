@@ -109,6 +109,29 @@ void probe_distance(int countA, const float* vertsA, float radiusA, const float*
 	out6[5] = (float)out.iterations;
 }
 
+// ownIdBlock (b2d_math.h) against the integer remainder: every block count up to `nbMax`, every `stride`-th body id below
+// `bodies` plus the ids whose hash lies at the very top of its 24 bits; returns the number of mismatches
+long probe_own_id_block_check(int nbMax, unsigned bodies, unsigned stride)
+{
+	long bad = 0;
+	for (int nb = 1; nb <= nbMax; ++nb)
+	{
+		for (unsigned body = 0; body < bodies; body += stride)
+		{
+			const unsigned x = body * 2654435761u >> 8;
+			if (ownIdBlock((int)body, nb) != 1 + (int)(x % (unsigned)nb)) ++bad;
+		}
+	}
+	// (x * rcp(nb) rounds up past an integer only near the top of the 24 bits: all ids whose hash is there)
+	for (unsigned body = 0; body < bodies; ++body)
+	{
+		const unsigned x = body * 2654435761u >> 8;
+		if (x < 0xf00000u) continue;
+		for (int nb = 1; nb <= nbMax; ++nb) if (ownIdBlock((int)body, nb) != 1 + (int)(x % (unsigned)nb)) ++bad;
+	}
+	return bad;
+}
+
 void probe_toi(int countA, const float* vertsA, float radiusA, const float* sweepA9, int countB, const float* vertsB,
 	float radiusB, const float* sweepB9, float tMax, float* out2)
 {

@@ -113,3 +113,20 @@ def test_an_open_sub_stepped_step_survives_a_snapshot():
         assert w.body_states().tobytes() == w2.body_states().tobytes(), "call %d after the snapshot" % k
     w.close()
     w2.close()
+
+
+def test_no_wide_store_has_its_data_registers_overwritten_too_soon():
+    """The gfx950 code of the built library: no dwordx3/x4 store with a VALU write to its data registers inside the next
+    two issue slots. The compiler keeps that distance for its own stores, not for the sc1 hand-over stores written as
+    asm statements (they carry an s_nop 1) - one such pair in k_solve_blocks made the bench scene's runs differ, round 5
+    (tools/asm_store_hazard.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_store_hazard as hz
+    if not os.path.exists(hz.OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not present")
+    if not os.path.exists(LIB):
+        pytest.fail("libb2hip.so missing: run __graft_entry__.build()")
+    stores, found = hz.scan(hz.disassemble(LIB))
+    assert stores > 0
+    assert found == []

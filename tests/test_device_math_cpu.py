@@ -83,3 +83,14 @@ def test_device_toi_header_matches_golden():
                     C.c_float(1.0), out.ctypes.data_as(fp))
         bad += not np.array_equal(out.view(np.uint32), v["t_out"][i].view(np.uint32))
     assert bad == 0
+
+
+def test_own_id_block_is_the_exact_remainder():
+    """ownIdBlock (b2d_math.h): hash(body) mod blocks + 1 by way of a float quotient with both corrections - the compiler's own
+    24-bit expansion of `%` on the GPU returned 0xffffff for 0xc1f9f3 % 11 inside one kernel (round 5: a body of a jointed
+    pile was home in no block). Checked against the integer remainder for every block count up to 1 024 over a stride of body
+    ids and every id of the first 2 M whose hash lies in the top sixteenth of its 24 bits."""
+    P = pu.build_probe()
+    P.probe_own_id_block_check.restype = C.c_long
+    assert P.probe_own_id_block_check(C.c_int(1024), C.c_uint(2000000), C.c_uint(257)) == 0
+
