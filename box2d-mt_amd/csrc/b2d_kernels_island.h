@@ -821,6 +821,15 @@ __global__ __launch_bounds__(256) void k_joints_fill(DW W)
 		const int root = W.parent[b];
 		if (W.rootIsland[root] != ROOT_LARGE) continue;
 		W.lj_list[W.rootJointStart[root] + atomicAdd(&W.rootJointCursor[root], 1)] = j;
+		// the bodies of a large island's joint are touched by the workgroup that walks the joints behind the colours of a sweep:
+		// in a fused launch (k_rest_hub) their last rest row hands them on to it (REST_SERIAL_BIT = bit HUB_COLOR of DW::bodyRest,
+		// wiped by k_island_init)
+		{
+			int ids[4] = { jn.bodyA, jn.bodyB, -1, -1 };
+			if (jn.type == B2D_JOINT_GEAR) { const GearRec& g = W.gears[jn.enableLimit]; ids[2] = g.bodyC; ids[3] = g.bodyD; }
+			for (int q = 0; q < 4; ++q)
+				if (ids[q] >= 0 && (W.b_flags[ids[q]] & BF_TYPE_MASK) != BT_STATIC) atomicOr((unsigned long long*)&W.bodyRest[ids[q]], 1ull << HUB_COLOR);
+		}
 	}
 }
 

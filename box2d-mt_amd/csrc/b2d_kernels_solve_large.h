@@ -445,13 +445,42 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 // the ones the grid-wide rounds would hand out.
 // `queuedAhead`: launched behind the census before the host has read it (it runs while the host sizes the solver launches):
 // only if the partition is certain to stay (b2dPartitionSettled), else the host launches it again in its usual place.
-__global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead)
+// (round 6) ... or if no partition CAN be made this step: the large islands hold more constraints than the block solvers take
+// (`aheadMinRows` > 0: the host's threshold for staying in that state, b2hip_host_phases.h: blocksTooBig) and no partition
+// exists. Such a world runs launch per colour, where the host needs the final colour count: the kernel publishes the state
+// behind its work (`pub`, like the census) and the host polls instead of copying and synchronising - on the settled 100 000-box
+// Tumbler the early return + the host's second launch + the copy were ~60 us of device idle per step.
+__host__ __device__ inline bool b2dColorAheadNoPartition(const Counters& c, int aheadMinRows)
+{
+	return aheadMinRows > 0 && c.nBlocks == 0 && c.nLContacts >= aheadMinRows;
+}
+__device__ __forceinline__ void colorSmallBody(const DW& W);
+__global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead, int aheadMinRows, DState* pub)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	if (threadIdx.x == 0) S->gapClock[2] = wall_clock64();
-	if (queuedAhead && !b2dPartitionSettled(S->c)) return;
-	if (S->c.nUncolList > COLOR_SMALL_MAX || S->c.needRecolor) return;
+	bool run = true, publish = pub != nullptr;
+	if (queuedAhead)
+	{
+		const bool noPart = b2dColorAheadNoPartition(S->c, aheadMinRows);
+		run = b2dPartitionSettled(S->c) || noPart;
+		publish = publish && noPart; // (the host evaluates the same function on the same counters: it knows what to wait for)
+	}
+	if (S->c.nUncolList > COLOR_SMALL_MAX || S->c.needRecolor) run = false;
+	if (run) colorSmallBody(W);
+	if (publish)
+	{
+		__syncthreads();
+		// the census by colour as it stands now (the host sizes the colour launches and picks the rest colours from it)
+		if (run && threadIdx.x < MAX_COLORS) S->c.colorRows[threadIdx.x] = threadIdx.x == HUB_COLOR ? 0 : __hip_atomic_load(&W.colorCount[colorSlot(threadIdx.x)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+		b2dPublishCensus(W, pub);
+	}
+}
+__device__ __forceinline__ void colorSmallBody(const DW& W)
+{
+	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	__shared__ int s_left, s_colored, s_maxColor, s_n;
 	if (threadIdx.x == 0)
@@ -712,6 +741,13 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W, int restFirst)
 				}
 			}
 			W.li_ref[p] = make_int4(ci, nsA ? ids.z : -(ids.z + 1), nsB ? ids.w : -(ids.w + 1), W.parent[nsA ? ids.z : ids.w]);
+			// a hub row's bodies are touched by the workgroup that sweeps the hub rows behind the colours: in a fused launch
+			// (k_rest_hub) their last rest row hands them on to it (REST_SERIAL_BIT = this bit)
+			if (color == HUB_COLOR && restFirst < MAX_COLORS)
+			{
+				if (nsA) atomicOr((unsigned long long*)&W.bodyRest[ids.z], 1ull << HUB_COLOR);
+				if (nsB) atomicOr((unsigned long long*)&W.bodyRest[ids.w], 1ull << HUB_COLOR);
+			}
 			if (color >= restFirst && color != HUB_COLOR && S->c.nColors <= MAX_COLORS)
 			{
 				if (nsA) atomicOr((unsigned long long*)&W.bodyRest[ids.z], 1ull << color);
@@ -840,6 +876,145 @@ __global__ __launch_bounds__(256) void k_hub_fill(DW W)
 	{
 		S->c.nHubRows = W.colorCount[colorSlot(HUB_COLOR)];
 		S->c.nHubWide = W.hubWide ? (W.keepScan[n] & 0xfffff) : 0;
+	}
+}
+
+// The ORDER in which the primary hub meets its partners (round 6): by the partner's highest colour, ascending (ties: contact
+// index, the order k_hub_fill left). A hub row comes last on its partner - behind the partner's highest colour - so in a sweep
+// the partners become ready for the hub in exactly this order: the rows of the first colours' partners can be swept while the
+// last colours of the sweep (the REST rows, in the same launch: k_rest_hub) are still on their way. A fixed rule over the
+// colouring: it does not depend on which colours a step sweeps as launches and which as rest rows.
+// One workgroup: a stable counting sort of hubList[0, n) by 64 keys, through DW::keepFlag (free behind k_hub_fill).
+// `allHubs`: the list's first segment holds the rows of ALL hubs (B2HIP_HUB_WIDE=0 with B2HIP_HUB_ORDER=1: the comparison
+// runs of tests/test_gpu_sweep_end.py); the partner is the body of lower degree then.
+#define HUB_ORDER_MAX 65536
+__global__ __launch_bounds__(1024) void k_hub_order(DW W, int allHubs)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const int n = allHubs ? (W.keepScan[S->c.nContacts] & 0xfffff) : S->c.nHubWide;
+	if (n <= 1 || n > HUB_ORDER_MAX) return; // (uniform; beyond the limit the rows keep contact order: any order is a valid sweep)
+	__shared__ int s_cnt[64], s_start[64], s_run[64];
+	__shared__ int s_wcnt[16][64];
+	const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+	if (t < 64) { s_cnt[t] = 0; s_run[t] = 0; }
+	for (int i = t; i < 16 * 64; i += 1024) (&s_wcnt[0][0])[i] = 0;
+	__syncthreads();
+	auto keyOf = [&](int row) -> int
+	{
+		const int4 q = W.li_ref[row];
+		const bool nsA = q.y >= 0, nsB = q.z >= 0;
+		const int a = nsA ? q.y : -(q.y + 1), b = nsB ? q.z : -(q.z + 1);
+		// the partner: the body that is not the hub (of two hubs: the one of lower degree)
+		int partner = -1;
+		if (nsA && nsB) partner = W.deg[a] <= W.deg[b] ? a : b;
+		else if (nsA || nsB) partner = -1; // (the hub against a static body: ready at once)
+		if (partner < 0) return 0;
+		const unsigned long long m = W.bodyColorMask[partner] & ~(1ull << HUB_COLOR);
+		return m == 0ull ? 0 : 64 - __clzll((long long)m); // 1 + the highest colour, <= 63
+	};
+	for (int k = t; k < n; k += 1024) atomicAdd(&s_cnt[keyOf(W.hubList[k])], 1);
+	__syncthreads();
+	if (t == 0)
+	{
+		int run = 0;
+		for (int b = 0; b < 64; ++b) { s_start[b] = run; run += s_cnt[b]; }
+	}
+	__syncthreads();
+	for (int base = 0; base < n; base += 1024) // (uniform)
+	{
+		const int k = base + t;
+		const bool have = k < n;
+		const int row = have ? W.hubList[k] : 0;
+		const int key = have ? keyOf(row) : -1;
+		// my rank among the lanes of this wave with my key, and the wave's count per key
+		int rankW = 0;
+		unsigned long long todo = __ballot(have);
+		while (todo != 0ull)
+		{
+			const int src = __ffsll((long long)todo) - 1;
+			const int k0 = __shfl(key, src);
+			const unsigned long long m = __ballot(have && key == k0);
+			if (have && key == k0) rankW = __popcll(m & ((1ull << lane) - 1ull));
+			if (lane == src) s_wcnt[wave][k0] = __popcll(m);
+			todo &= ~m;
+		}
+		__syncthreads();
+		if (have)
+		{
+			int before = 0;
+			for (int w2 = 0; w2 < wave; ++w2) before += s_wcnt[w2][key];
+			W.keepFlag[s_start[key] + s_run[key] + before + rankW] = row;
+		}
+		__syncthreads();
+		if (t < 64)
+		{
+			int tot = 0;
+			for (int w2 = 0; w2 < 16; ++w2) { tot += s_wcnt[w2][t]; s_wcnt[w2][t] = 0; }
+			s_run[t] += tot;
+		}
+		__syncthreads();
+	}
+	__syncthreads();
+	// The constraints change PLACES among the rows they hold, so that the k-th of the new order sits in the k-th lowest of
+	// those rows: the fixed point's lanes read consecutive rows again (field-major rows: 36 coalesced loads per wave - through
+	// a permuted list every one of them touched a dozen lines, +10 us per pass of 512). Nothing has read the rows' content
+	// yet (k_large_init fills them behind this kernel); what names a row - li_ref, hubRowOf - moves with the constraint.
+	// keepFlag[0, n): the rows in the new order; keepScan[0, n) (free like keepFlag): their references, saved before any is overwritten.
+	int4* const refs = (int4*)W.keepScan; // (n <= HUB_ORDER_MAX int4 = 1 MB: capContacts ints hold that from 262 144 contacts on)
+	const bool room = (size_t)W.capContacts * sizeof(int) >= (size_t)n * sizeof(int4) + 64;
+	if (!room)
+	{
+		for (int k = t; k < n; k += 1024) W.hubList[k] = W.keepFlag[k];
+		return;
+	}
+	for (int k = t; k < n; k += 1024) refs[k] = W.li_ref[W.keepFlag[k]];
+	__syncthreads();
+	// the rows of the segment in ascending order: hubList still holds them in contact order, which is ascending in the row
+	// only by accident (k_color_fill hands the places out by atomics) - rank them by a count over the list
+	__shared__ int s_lo, s_hi;
+	if (t == 0) { s_lo = 0x7fffffff; s_hi = -1; }
+	__syncthreads();
+	for (int k = t; k < n; k += 1024) { atomicMin(&s_lo, W.hubList[k]); atomicMax(&s_hi, W.hubList[k]); }
+	__syncthreads();
+	const int lo = s_lo, span = s_hi - s_lo + 1;
+	// (a bitmap over [lo, hi] in keepFlag behind the list; the rows of one colour segment: span is n plus the handful of
+	// leftover rows that share the segment)
+	int* const bits = W.keepFlag + n;
+	if ((size_t)n + (size_t)span + 1024 > (size_t)W.capContacts)
+	{
+		for (int k = t; k < n; k += 1024) W.hubList[k] = W.keepFlag[k];
+		return;
+	}
+	for (int i = t; i < span; i += 1024) bits[i] = 0;
+	__syncthreads();
+	for (int k = t; k < n; k += 1024) bits[W.hubList[k] - lo] = 1;
+	__syncthreads();
+	__shared__ int s_base, s_wsum[16];
+	if (t == 0) s_base = 0;
+	__syncthreads();
+	for (int b0 = 0; b0 < span; b0 += 1024) // (uniform)
+	{
+		const int i = b0 + t;
+		const int f = i < span ? bits[i] : 0;
+		const unsigned long long m = __ballot(f != 0);
+		if (lane == 0) s_wsum[wave] = __popcll(m);
+		__syncthreads();
+		int before = s_base;
+		for (int w2 = 0; w2 < wave; ++w2) before += s_wsum[w2];
+		const int rank = before + __popcll(m & ((1ull << lane) - 1ull));
+		if (f)
+		{
+			// the rank-th lowest row takes the rank-th constraint of the new order
+			const int row = lo + i;
+			const int4 q = refs[rank];
+			W.li_ref[row] = q;
+			W.hubRowOf[q.x] = row;
+			W.hubList[rank] = row;
+		}
+		__syncthreads();
+		if (t == 0) { int tot = 0; for (int w2 = 0; w2 < 16; ++w2) tot += s_wsum[w2]; s_base += tot; }
+		__syncthreads();
 	}
 }
 

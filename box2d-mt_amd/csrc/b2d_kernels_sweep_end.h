@@ -51,12 +51,17 @@
 // All workgroups of the launch must be resident together (the host keeps the rest rows below REST_ROWS_MAX: 768 workgroups
 // of 256 lanes, three per CU).
 #define REST_ROWS_MAX 196608
+// A body that the hub workgroup of a fused launch (k_rest_hub below) touches - a partner of a hub row, a body of a joint of a
+// large island - carries this bit in DW::bodyRest (k_color_fill, k_joints_fill; HUB_COLOR is never a rest colour). In a fused
+// launch the LAST rest row of such a body hands its row on like the others (a tagged row) instead of writing the body table:
+// the hub workgroup waits for that tag, puts the row into the table itself and goes on from there - so the table row of such
+// a body has ONE writer per launch, and the hub's rows, the joints and the verdict need no launch of their own.
+#define REST_SERIAL_BIT (1ull << HUB_COLOR)
+// `wg` of `nWG` workgroups of blockDim.x lanes sweep the rest rows; `serialTagged`: a fused launch (see REST_SERIAL_BIT)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_large_rest(DW W, int restFirst, int nColors, int* bar, int epoch)
+__device__ __forceinline__ bool restSweepRows(const DW& W, int restFirst, int nColors, int* bar, int epoch, int wg, int nWG, bool serialTagged)
 {
-	b2dPhaseStamp(W);
 	DState* S = W.st;
-	if (MODE == 2 && S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];
 	const int begin = W.colorStart[restFirst], end = W.colorStart[nColors];
 	const int tag = (epoch & 0x7fff) << 16;
@@ -66,10 +71,10 @@ __global__ __launch_bounds__(256) void k_large_rest(DW W, int restFirst, int nCo
 	// rows begin + its index, + the grid size, ... in turn. That cannot deadlock: a row only waits for rows of lower colours,
 	// i.e. of lower index (the rows are sorted by colour), and those are taken earlier by their lanes or are being waited for
 	// by lanes that are running - the lowest unfinished row can always go ahead.
-	const int stride = (int)(gridDim.x * blockDim.x);
+	const int stride = (int)(nWG * blockDim.x);
 	for (int base = begin; base < end; base += stride) // (uniform: every lane of the launch makes the same trips)
 	{
-		const int row = base + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+		const int row = base + (int)(wg * blockDim.x + threadIdx.x);
 		const bool have = row < end;
 		LargeRef r;
 		r.ci = 0; r.bodyA = 0; r.bodyB = 0; r.root = 0; r.nsA = false; r.nsB = false;
@@ -77,6 +82,7 @@ __global__ __launch_bounds__(256) void k_large_rest(DW W, int restFirst, int nCo
 		memset(&cc, 0, sizeof(cc));
 		bool active = have;
 		int rankA = 0, degA = 0, rankB = 0, degB = 0;
+		bool tagLastA = false, tagLastB = false;
 		float4 startA = make_float4(0, 0, 0, 0), startB = startA;
 		if (have)
 		{
@@ -98,8 +104,8 @@ __global__ __launch_bounds__(256) void k_large_rest(DW W, int restFirst, int nCo
 				if (r.nsB) startB = rows[r.bodyB];
 			}
 			const unsigned long long below = (1ull << col) - 1ull;
-			if (r.nsA) { const unsigned long long m = W.bodyRest[r.bodyA]; degA = __popcll(m); rankA = __popcll(m & below); }
-			if (r.nsB) { const unsigned long long m = W.bodyRest[r.bodyB]; degB = __popcll(m); rankB = __popcll(m & below); }
+			if (r.nsA) { const unsigned long long m = W.bodyRest[r.bodyA]; degA = __popcll(m & ~REST_SERIAL_BIT); rankA = __popcll(m & below); tagLastA = serialTagged && (m & REST_SERIAL_BIT) != 0ull; }
+			if (r.nsB) { const unsigned long long m = W.bodyRest[r.bodyB]; degB = __popcll(m & ~REST_SERIAL_BIT); rankB = __popcll(m & below); tagLastB = serialTagged && (m & REST_SERIAL_BIT) != 0ull; }
 		}
 		const bool nsA = have && r.nsA, nsB = have && r.nsB;
 		// (rank 0: nothing to wait for - the row comes from the body table)
@@ -133,13 +139,23 @@ __global__ __launch_bounds__(256) void k_large_rest(DW W, int restFirst, int nCo
 				qb = make_float4(vB.v.x, vB.v.y, vB.w, 0.0f);
 			}
 			// the body's last rest row puts it back into the body table (for the launches that follow), the others hand it on
-			if (nsA) { if (rankA + 1 < degA) stRow(xA, qa.x, qa.y, qa.z, needA + 1); else rows[r.bodyA] = qa; }
-			if (nsB) { if (rankB + 1 < degB) stRow(xB, qb.x, qb.y, qb.z, needB + 1); else rows[r.bodyB] = qb; }
+			// (... to the hub workgroup of a fused launch, if that is who touches the body next: REST_SERIAL_BIT)
+			if (nsA) { if (rankA + 1 < degA || tagLastA) stRow(xA, qa.x, qa.y, qa.z, needA + 1); else rows[r.bodyA] = qa; }
+			if (nsB) { if (rankB + 1 < degB || tagLastB) stRow(xB, qb.x, qb.y, qb.z, needB + 1); else rows[r.bodyB] = qb; }
 		});
-		if (!ok) return;
+		if (!ok) return false;
 		if (MODE == 1 && have && active) lcStore(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
 		if (MODE == 2) waveAtomicMaxU32Guarded(W.rootPen, r.root, floatBits(0.0f - minSep), have && active);
 	}
+	return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_large_rest(DW W, int restFirst, int nColors, int* bar, int epoch)
+{
+	b2dPhaseStamp(W);
+	if (MODE == 2 && W.st->c.allLargeDone) return;
+	(void)restSweepRows<MODE>(W, restFirst, nColors, bar, epoch, (int)blockIdx.x, (int)gridDim.x, false);
 }
 
 // ---- A: one tail colour -------------------------------------------------------------------------------------------------
@@ -199,6 +215,106 @@ __device__ __forceinline__ void sweepEndColour(const DW& W, const ContactArrays&
 	}
 }
 
+// ---- the hub workgroup of a FUSED launch (k_rest_hub): what it waits for ----------------------------------------------------
+// The rest rows of this sweep run in the other workgroups of the same launch. A body the hub workgroup touches (REST_SERIAL_BIT)
+// that has rest rows arrives as a tagged row from the last of them: wait for that tag, put the row into the body table, go
+// on as k_sweep_end would behind a k_large_rest launch - the same arithmetic in the same order on every body, the same bits.
+#define REST_SETTLED 0x4000 // (on top of a tag: ranks stay below 64)
+struct RestJoin
+{
+	int* bar;        // grid barrier words: [4] abort, [5] workgroups of fused launches that have finished their rest rows
+	int tag;         // (epoch & 0x7fff) << 16 of this launch
+	int arriveNeed;  // MODE 2: the verdict waits until bar[5] has reached this
+};
+
+template <int MODE>
+__device__ __forceinline__ bool restSettleBody(const DW& W, const RestJoin& rj, int body)
+{
+	const unsigned long long m = W.bodyRest[body];
+	if ((m & REST_SERIAL_BIT) == 0ull) return true; // (not ours to wait for: a static body, or a launch that is not fused)
+	const int d = __popcll(m & ~REST_SERIAL_BIT);
+	if (d == 0) return true; // (no rest rows: the colour launches left the row in the table)
+	float4* const rows = MODE == 2 ? W.b_pos : W.b_vel;
+	const float4* const x = (MODE == 2 ? W.b_posv : W.b_cutv) + body;
+	const int need = rj.tag + d;
+	int spins = 0;
+	for (;;)
+	{
+		const f4v r = ldRow(x);
+		if (__float_as_int(r.w) == need)
+		{
+			// (several lanes may settle one body at once - a body in two leftover rows, in two joints: the same value)
+			rows[body] = make_float4(r.x, r.y, r.z, MODE == 2 ? rows[body].w : 0.0f);
+			// ... and nobody settles it a second time: the table row is the hub workgroup's from here on (a partner's first row
+			// with the hub is swept by the fixed point, its second one with the leftovers, later)
+			stRow(const_cast<float4*>(x), r.x, r.y, r.z, need + REST_SETTLED);
+			return true;
+		}
+		if (__float_as_int(r.w) == need + REST_SETTLED) return true;
+		if (++spins > DATAFLOW_SPIN_MAX || ((spins & 1023) == 0 && ldcI(&rj.bar[4]) != 0)) return false;
+		__builtin_amdgcn_s_sleep(1);
+	}
+}
+
+// The bodies of the hub rows [first, first + cnt) of hubList / of the joints of the large islands, settled. All lanes of the
+// workgroup call; false: a wait was abandoned and every lane leaves. Called right before the rows / joints are swept: the
+// hub rows are in the order in which their partners become ready (k_hub_order), so the first pass of the fixed point runs
+// while the partners of the last one are still being worked on by the rest rows.
+__device__ __forceinline__ bool restSettleVote(const DW& W, const RestJoin& rj, bool ok)
+{
+	const int bad = __syncthreads_or(ok ? 0 : 1);
+	if (bad && threadIdx.x == 0)
+	{
+		stcI(&rj.bar[4], 1);
+		atomicOr(&W.st->c.overflow, 64);
+	}
+	return bad == 0;
+}
+template <int MODE>
+__device__ __forceinline__ bool restSettleHubRows(const DW& W, const ContactArrays& C, const RestJoin& rj, int first, int cnt)
+{
+	bool ok = true;
+	for (int k = first + (int)threadIdx.x; k < first + cnt; k += SWEEP_END_LANES)
+	{
+		const LargeRef r = largeRef(W, C, W.hubList[k]);
+		if (MODE == 2 && W.rootDone[r.root]) continue; // (a closed island's rows do not run: nothing is handed on)
+		if (r.nsA) ok = restSettleBody<MODE>(W, rj, r.bodyA) && ok;
+		if (r.nsB) ok = restSettleBody<MODE>(W, rj, r.bodyB) && ok;
+	}
+	return restSettleVote(W, rj, ok);
+}
+template <int MODE>
+__device__ __forceinline__ bool restSettleJoints(const DW& W, const RestJoin& rj)
+{
+	DState* S = W.st;
+	bool ok = true;
+	if (W.nJoints > 0)
+	{
+		const int n = S->c.nLIslands;
+		for (int k = (int)threadIdx.x; k < n; k += SWEEP_END_LANES)
+		{
+			const int root = W.li_roots[k];
+			const int nj = W.rootJoints[root];
+			if (nj == 0) continue;
+			if (MODE == 2 && W.rootDone[root]) continue;
+			const int start = W.rootJointStart[root];
+			for (int t = 0; t < nj; ++t)
+			{
+				const JointRec* j = &W.joints[W.lj_list[start + t]];
+				ok = restSettleBody<MODE>(W, rj, j->bodyA) && ok;
+				ok = restSettleBody<MODE>(W, rj, j->bodyB) && ok;
+				if (j->type == B2D_JOINT_GEAR)
+				{
+					const GearRec* g = &W.gears[j->enableLimit];
+					ok = restSettleBody<MODE>(W, rj, g->bodyC) && ok;
+					ok = restSettleBody<MODE>(W, rj, g->bodyD) && ok;
+				}
+			}
+		}
+	}
+	return restSettleVote(W, rj, ok);
+}
+
 // ---- B: up to SWEEP_END_LANES rows of the PRIMARY hub as one fixed point ------------------------------------------------------------
 // Rows [first, first + cnt) of hubList: constraints between the primary hub (the body with the most solid contacts:
 // DW::hubMeta[0]) and `cnt` DIFFERENT partners, none of them a hub (k_hub_flag sorts the others out). The sequential sweep
@@ -209,7 +325,7 @@ __device__ __forceinline__ void sweepEndColour(const DW& W, const ContactArrays&
 // |changes|) per component: the rounding a sum over that many terms carries anyway.
 // All lanes of the workgroup call. Returns the hub row behind the last row (every lane).
 template <int MODE>
-__device__ __forceinline__ float4 hubWidePass(const DW& W, const ContactArrays& C, int hubBody, float4 u0, int first, int cnt, int useGuess, int* roundsOut)
+__device__ __forceinline__ float4 hubWidePass(const DW& W, const ContactArrays& C, int hubBody, float4 u0, int first, int cnt, int useGuess, int* roundsOut, const RestJoin* rj, bool* okOut)
 {
 	__shared__ float s_tot[2][SWEEP_END_WAVES][6]; // per wave: sums of the changes (x, y, z) and of their magnitudes
 	__shared__ float4 s_hubOut;
@@ -238,14 +354,22 @@ __device__ __forceinline__ float4 hubWidePass(const DW& W, const ContactArrays& 
 			active = W.rootDone[r.root] == 0;
 			lcLoad(W, row, cc, LC_MASS_FIRST, LC_MASS_FIRST + 4);
 			lcLoad(W, row, cc, LC_POS_FIRST, LC_WORDS);
-			other = rows[otherBody]; // static partners have a position too
 		}
-		else
-		{
-			lcLoad(W, row, cc, 0, LC_VEL_WORDS);
-			if (otherDynamic) other = rows[otherBody];
-		}
+		else lcLoad(W, row, cc, 0, LC_VEL_WORDS);
 		if (useGuess) guess = W.hubDelta[k];
+	}
+	if (rj != nullptr)
+	{
+		// fused launch: the partner may still be on its way through the rest rows (the constraint's own words, asked for above,
+		// arrive meanwhile). Settled = its row is in the body table, written by this lane: the load below sees it.
+		bool ok = true;
+		if (have && active && otherDynamic) ok = restSettleBody<MODE>(W, *rj, otherBody);
+		if (!restSettleVote(W, *rj, ok)) { *okOut = false; return u0; }
+	}
+	if (have)
+	{
+		if (MODE == 2) other = rows[otherBody]; // static partners have a position too
+		else if (otherDynamic) other = rows[otherBody];
 	}
 	const float imp0[4] = { cc.normalImpulse[0], cc.tangentImpulse[0], cc.normalImpulse[1], cc.tangentImpulse[1] };
 	// exclusive prefix over the workgroup of (dx, dy, dz), in a fixed order: a shuffle tree inside the wave, the waves' totals
@@ -417,13 +541,14 @@ __device__ __forceinline__ void sweepEndJoints(const DW& W, const StepParams& sp
 	}
 }
 
+// What one k_sweep_end launch does (a workgroup of SWEEP_END_LANES lanes); `rj`: as the hub workgroup of a fused launch.
 template <int MODE>
-__global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams sp, int tailFirst, int tailEnd, int what, int* stampBar)
+__device__ __forceinline__ void sweepEndBody(const DW& W, const StepParams& sp, int tailFirst, int tailEnd, int what, int* stampBar, const RestJoin* rj)
 {
-	b2dPhaseStamp(W);
 	DState* S = W.st;
-	if (MODE == 2 && S->c.allLargeDone) return;
 	const ContactArrays& C = W.ca[S->cur];
+	// (fused launch: whatever this launch goes on to do, EVERY body that carries REST_SERIAL_BIT is settled below - it was
+	// handed on instead of written to the table - the hub rows' bodies pass by pass, the joints' before the joint walk)
 	// (B2HIP_SWEEP_STAMPS=1: where a velocity launch's time goes - 10 ns ticks since its start at the end of A, B, C, D in the
 	// words the block solver's stamps use; they come home with the read-back as DState::stamps: tools/gpu_tumbler_probe.py)
 	const unsigned long long t0 = (stampBar != nullptr && MODE == 1) ? wall_clock64() : 0ull;
@@ -451,7 +576,9 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 			for (int first = 0; first < nWide; first += SWEEP_END_LANES)
 			{
 				const int cnt = nWide - first < SWEEP_END_LANES ? nWide - first : SWEEP_END_LANES;
-				u = hubWidePass<MODE>(W, C, hubBody, u, first, cnt, (what & SE_GUESS) ? 1 : 0, &rounds);
+				bool okPass = true;
+				u = hubWidePass<MODE>(W, C, hubBody, u, first, cnt, (what & SE_GUESS) ? 1 : 0, &rounds, rj, &okPass);
+				if (!okPass) return; // (uniform: the vote of the whole workgroup)
 			}
 			if (threadIdx.x == 0)
 			{
@@ -464,6 +591,7 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 		// ---- C
 		if (nWide < nRows)
 		{
+			if (rj != nullptr && !restSettleHubRows<MODE>(W, C, *rj, nWide, nRows - nWide)) return;
 			if (!(what & SE_HUB_WIDE_ONLY))
 			{
 				if (threadIdx.x < 64) hubLeftover<MODE>(W, C, nWide, nRows);
@@ -472,6 +600,12 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 		}
 	}
 	SE_STAMP(2);
+	if (rj != nullptr)
+	{
+		// (a fused launch that sweeps no hub rows - an island with joints only, or B2HIP_HUB_WIDE... - still settles them all)
+		if (!(what & SE_HUB) && !restSettleHubRows<MODE>(W, C, *rj, 0, S->c.nHubRows)) return;
+		if (!restSettleJoints<MODE>(W, *rj)) return;
+	}
 	// ---- D
 	if (what & SE_JOINTS_INIT) { sweepEndJoints(W, sp, 0); __syncthreads(); }
 	if (what & SE_JOINTS_VEL) { sweepEndJoints(W, sp, 1); __syncthreads(); }
@@ -483,6 +617,24 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 		// (k_large_pos_end: per-island early out, b2Island.cpp:329-334)
 		__shared__ int s_open;
 		if (threadIdx.x == 0) s_open = 0;
+		if (rj != nullptr)
+		{
+			// the verdict is over ALL rows of the iteration: the rest rows' workgroups have offered their penetration maxima
+			// (atomics past the L2) before they arrive
+			__shared__ int s_joined;
+			if (threadIdx.x == 0)
+			{
+				int spins = 0, okj = 1;
+				while (ldcI(&rj->bar[5]) < rj->arriveNeed)
+				{
+					if (++spins > PERSIST_SPIN_MAX || ldcI(&rj->bar[4]) != 0) { stcI(&rj->bar[4], 1); atomicOr(&S->c.overflow, 64); okj = 0; break; }
+					__builtin_amdgcn_s_sleep(1);
+				}
+				s_joined = okj;
+			}
+			__syncthreads();
+			if (!s_joined) return;
+		}
 		__syncthreads();
 		const int n = S->c.nLIslands;
 		int open = 0;
@@ -513,6 +665,47 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams 
 			}
 		}
 	}
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SWEEP_END_LANES) void k_sweep_end(DW W, StepParams sp, int tailFirst, int tailEnd, int what, int* stampBar)
+{
+	b2dPhaseStamp(W);
+	if (MODE == 2 && W.st->c.allLargeDone) return;
+	sweepEndBody<MODE>(W, sp, tailFirst, tailEnd, what, stampBar, nullptr);
+}
+
+// ---- k_large_rest and k_sweep_end in ONE launch (round 6) ---------------------------------------------------------------------
+// On the settled 100 000-box Tumbler a velocity sweep ended with k_large_rest (~28 us: chains of tagged rows, most CUs idle)
+// and then k_sweep_end (~32 us: ONE workgroup, 255 CUs idle) - 60 of the sweep's ~120 us in two launches that use the device
+// one after the other although almost nothing of the second depends on the first: the hub's ~900 partners are boxes at the
+// container's walls, few of which carry rest colours at all. Here the LAST workgroup of the launch is k_sweep_end's (it is
+// dispatched last: the rest rows' workgroups never wait for it), the others sweep the rest rows; what the hub workgroup needs
+// of them arrives as tagged rows (RestJoin, REST_SERIAL_BIT). Same arithmetic, same order on every body: the bits of the two
+// launches (tests/test_gpu_sweep_end.py). MODE 2: the verdict of the iteration waits for every rest workgroup's arrival.
+template <int MODE>
+__global__ __launch_bounds__(SWEEP_END_LANES) void k_rest_hub(DW W, StepParams sp, int restFirst, int nColors, int what, int* bar, int epoch, int arriveNeed, int* stampBar)
+{
+	b2dPhaseStamp(W);
+	if (MODE == 2 && W.st->c.allLargeDone) return;
+	const int nRest = (int)gridDim.x - 1;
+	if ((int)blockIdx.x < nRest)
+	{
+		const bool ok = restSweepRows<MODE>(W, restFirst, nColors, bar, epoch, (int)blockIdx.x, nRest, true);
+		if (MODE == 2)
+		{
+			// (this workgroup's penetration maxima are on their way past the L2: drained before it counts as arrived)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+			if (ok && threadIdx.x == 0) __hip_atomic_fetch_add(&bar[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		return;
+	}
+	RestJoin rj;
+	rj.bar = bar;
+	rj.tag = (epoch & 0x7fff) << 16;
+	rj.arriveNeed = arriveNeed;
+	sweepEndBody<MODE>(W, sp, 0, 0, what, stampBar, &rj);
 }
 
 #endif

@@ -220,6 +220,7 @@ int b2hip_debug_read(b2hip_world* w, int which, int first, int count, void* out)
 	case 18: src = w->li_ref.p; break;
 	case 19: src = w->rowColor.p; elem = 4; break;
 	case 20: src = w->blkRowStart.p; elem = 4; break;
+	case 21: src = w->bodyRest.p; elem = 8; break;
 	default: return setError(B2HIP_ERR_INVALID, "bad array id");
 	}
 	HIP_TRY(hipMemcpy(out, (const char*)src + (size_t)first * elem, (size_t)count * elem, hipMemcpyDeviceToHost));

@@ -154,6 +154,22 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 			}
 		}
 	}
+	{
+		// the workgroups of k_large_rest / k_rest_hub wait for one another's rows: all of a launch must be resident together
+		// (the grid was sized from the colour census alone)
+		int devId = 0, r1 = 0, r2 = 0, f1 = 0, f2 = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&devId) == hipSuccess && hipGetDeviceProperties(&prop, devId) == hipSuccess)
+		{
+			const int cus = std::max(1, prop.multiProcessorCount - 8);
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r1, k_large_rest<1>, 256, 0) == hipSuccess &&
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&r2, k_large_rest<2>, 256, 0) == hipSuccess && r1 > 0 && r2 > 0)
+				w->restMaxWG = std::min(r1, r2) * cus;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&f1, k_rest_hub<1>, SWEEP_END_LANES, 0) == hipSuccess &&
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&f2, k_rest_hub<2>, SWEEP_END_LANES, 0) == hipSuccess && f1 > 0 && f2 > 0)
+				w->restHubMaxWG = std::min(f1, f2) * cus;
+		}
+	}
 	w->dfSleep = 1;
 	if (const char* e = getenv("B2HIP_DF_LANES")) w->dfLanesForced = std::max(64, std::min(256, atoi(e) / 64 * 64));
 	if (const char* e = getenv("B2HIP_DF_SLEEP")) w->dfSleep = atoi(e);
@@ -909,6 +925,7 @@ static int stepBeginImpl(b2hip_world* w, float dt, int velocity_iterations, int 
 	// (b2Profile::step: from the start of this kernel to the end of k_end_step, slots 14 and 13)
 	w->dw.stampMask = 1u << 14;
 	LAUNCH(w, k_step_begin, 1, 64, w->dw, w->gridBar.p);
+	w->restArrived = 0; // (bar[5] starts the step at 0)
 	w->toiCountersFresh = true;
 	rc = applyPendingFilters(w);
 	if (rc) return rc;

@@ -369,15 +369,27 @@ static int phaseSolve(b2hip_world* w)
 
 	// the host needs the island census to size the solver launches
 	bool colorSmallQueued = false;
+	bool colorAheadPublished = false; // the queued k_color_small ran in its no-partition mode and publishes the state behind it
+	int aheadMinRows = 0;
 	if (poll)
 	{
 		w->pubSeq = (w->pubSeq + 1) & 0x3fffffff; // (the device counts its publications the same way: DState::pubCount)
 		// what the host would launch next in the usual case (a few new contacts on a settled pile to colour, a colour class to
 		// compact) goes behind the census at once and runs while the host is busy with it; the kernel looks at the same
 		// counters and returns if the case is another one
-		if (largeHint && forceLarge != 2) { LAUNCH(w, k_color_small, 1, 1024, d, 1); colorSmallQueued = true; }
+		// (round 6: ... and where no partition can be made this step - the large islands are beyond what the block solvers take,
+		// the host's own hysteresis below - the queued launch runs too and PUBLISHES what it leaves: the launch-per-colour path
+		// polls that instead of a copy + synchronise)
+		aheadMinRows = (forceLarge != 2 && !w->colorAheadOff) ? (w->noBlocks ? 1 : (w->blocksTooBig ? 650 * std::max(w->blocksMaxWG, w->sweepMaxWG[2]) : 0)) : 0;
+		if (largeHint && forceLarge != 2) { LAUNCH(w, k_color_small, 1, 1024, d, 1, aheadMinRows, w->d_pub); colorSmallQueued = true; }
 		rc = awaitCensus(w);
-		if (rc == 0 && !b2dPartitionSettled(w->h_dstate->c)) colorSmallQueued = false; // (it saw the same and returned)
+		if (rc == 0)
+		{
+			const bool settled = b2dPartitionSettled(w->h_dstate->c);
+			colorAheadPublished = colorSmallQueued && b2dColorAheadNoPartition(w->h_dstate->c, aheadMinRows);
+			if (colorAheadPublished) w->pubSeq = (w->pubSeq + 1) & 0x3fffffff; // (its publication is on its way: the next one to wait for)
+			if (!settled && !colorAheadPublished) colorSmallQueued = false; // (it saw the same and returned)
+		}
 	}
 	else rc = readState(w);
 	if (rc) return rc;
@@ -399,7 +411,7 @@ static int phaseSolve(b2hip_world* w)
 	else if (w->largeHintSteps > 0) w->largeHintSteps -= 1;
 	// (newcomers without a home block: from the next step on k_block_adopt hands blocks further, for a while)
 	if (c.nOrphanRows > 0) w->adoptSticky = 16; else if (w->adoptSticky > 0) w->adoptSticky -= 1;
-	w->adoptPasses = w->adoptSticky > 0;
+	w->adoptPasses = w->adoptSticky > 0 && !(w->blocksTooBig && c.nBlocks == 0); // (no partition, none to come: nobody has a block to hand on)
 	const bool plainIslands = d.nJoints == 0 && c.maxDegree <= HUB_DEGREE;
 	// ---- large islands that no block solver can take: more constraints than the blocks that fit the device together hold
 	// (1024-lane blocks of ~750 rows: ~190 000; the settled 100 000-box Tumbler has 350 000). They run launch per colour
@@ -615,7 +627,14 @@ static int phaseSolve(b2hip_world* w)
 			{
 				// the usual case (a few new contacts on a settled island, a colour class to compact): one workgroup colours
 				// them; the resident solver reads the colour count from the device, the launch-per-colour path reads it back
-				if (!colorSmallQueued) LAUNCH(w, k_color_small, 1, 1024, d, 0); // (else: it went out behind the census)
+				// (the launch-per-colour path needs the colour count: published by the kernel and polled - a copy + synchronise
+				// otherwise, B2HIP_NO_CENSUS_POLL=1)
+				const bool pubColors = poll && !useResident && !w->colorAheadOff;
+				if (!colorSmallQueued)
+				{
+					LAUNCH(w, k_color_small, 1, 1024, d, 0, 0, pubColors ? w->d_pub : (DState*)nullptr); // (else: it went out behind the census)
+					if (pubColors) w->pubSeq = (w->pubSeq + 1) & 0x3fffffff;
+				}
 				if (useResident)
 				{
 					colorsOnDevice = true;
@@ -623,7 +642,13 @@ static int phaseSolve(b2hip_world* w)
 				}
 				else
 				{
-					rc = readState(w);
+					if ((colorSmallQueued && colorAheadPublished) || (!colorSmallQueued && pubColors))
+					{
+						rc = awaitCensus(w);
+						if (rc == 0) c.nColors = w->h_dstate->c.nColors;
+						if (rc == 0) memcpy(c.colorRows, w->h_dstate->c.colorRows, sizeof(c.colorRows));
+					}
+					else rc = readState(w);
 					if (rc) return rc;
 					nColors = w->h_dstate->c.nColors;
 					if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
@@ -686,10 +711,23 @@ static int phaseSolve(b2hip_world* w)
 			LAUNCH(w, k_hub_flag, gridFor(d.capContacts), 256, d);
 			deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 			LAUNCH(w, k_hub_fill, gridFor(d.capContacts), 256, d);
+			// (the hub meets its partners in the order of their highest colour: b2d_kernels_solve_large.h, k_hub_order)
+			if (!w->noHubOrder && (d.hubWide || w->hubOrderAll)) LAUNCH(w, k_hub_order, 1, 1024, d, d.hubWide ? 0 : 1);
 			w->hubSteps += 1;
 		}
 		stampPhase(w, 7);
 		const int gK = gridFor(std::max(nLContacts / std::max(nColors, 1), 1) * 2);
+		// A colour launch is a chain of dependent loads per lane (~4.5 us whatever it holds): a lane that makes a second trip
+		// of the grid-stride loop pays the chain twice - the Tumbler's five biggest colours (41 000 - 42 000 rows against a grid
+		// of 39 000 lanes sized from the MEAN colour) took 8 us instead of 6. Sized per colour from this step's census now
+		// (+ what k_color_small may still add), in workgroups of colorLanes lanes so that the rows spread over all CUs.
+		const int kLanes = w->colorLanes;
+		const bool censusGrid = !exactLarge && nColors > 0 && nColors <= MAX_COLORS && !c.needRecolor && !censusVoid && !w->noCensusGrid;
+		auto gridOfColor = [&](int col) -> int
+		{
+			if (!censusGrid || col < 0 || col >= MAX_COLORS) return gK;
+			return gridFor((size_t)c.colorRows[col] + 512, kLanes, 1 << 16);
+		};
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
 		if (useResident)
 		{
@@ -822,7 +860,9 @@ static int phaseSolve(b2hip_world* w)
 			long long rows = 0;
 			for (int col = restFirst; col < nColors && col < MAX_COLORS; ++col) rows += c.colorRows[col];
 			// (the census is this step's before k_color_small handed out its colours - at most COLOR_SMALL_MAX rows more)
-			const int gR = (int)((rows + COLOR_SMALL_MAX + 255) / 256);
+			int gR = (int)((rows + COLOR_SMALL_MAX + 255) / 256);
+			// (the workgroups wait for one another: no more of them than are resident together - the rest walk in strides)
+			if (w->restMaxWG > 0) gR = std::min(gR, w->restMaxWG);
 			if (mode == 0) LAUNCH(w, k_large_rest<0>, gR, 256, d, restFirst, nColors, w->gridBar.p, w->dfEpoch);
 			else if (mode == 1) LAUNCH(w, k_large_rest<1>, gR, 256, d, restFirst, nColors, w->gridBar.p, w->dfEpoch);
 			else LAUNCH(w, k_large_rest<2>, gR, 256, d, restFirst, nColors, w->gridBar.p, w->dfEpoch);
@@ -843,6 +883,31 @@ static int phaseSolve(b2hip_world* w)
 			if (mode == 0) LAUNCH(w, k_sweep_end<0>, 1, SWEEP_END_LANES, d, sp, tf, te, what, w->sweepStamps ? w->gridBar.p : (int*)nullptr);
 			else if (mode == 1) LAUNCH(w, k_sweep_end<1>, 1, SWEEP_END_LANES, d, sp, tf, te, what, w->sweepStamps ? w->gridBar.p : (int*)nullptr);
 			else LAUNCH(w, k_sweep_end<2>, 1, SWEEP_END_LANES, d, sp, tf, te, what, w->sweepStamps ? w->gridBar.p : (int*)nullptr);
+			w->lastSweepLaunches += 1;
+			return 0;
+		};
+		// ---- k_large_rest and k_sweep_end of one sweep as ONE launch (k_rest_hub, round 6): the rest rows in gF workgroups of
+		// 512 lanes, the hub rows / joints / verdict in one more that waits for what it needs of them as tagged rows. All
+		// workgroups must be resident together (restHubMaxWG: the occupancy query at world creation).
+		const bool fuseHub = useRest && w->restHub && (hasHubs || hasJoints) && !leftoverApart && w->restHubMaxWG > 1;
+		auto restHubLaunch = [&](int mode, int what) -> int
+		{
+			if ((w->dfEpoch >> 14) != w->dfWipedAt)
+			{
+				HIP_TRY(hipMemsetAsync(w->b_cutv.p, 0, w->b_cutv.cap * sizeof(float4), w->stream));
+				HIP_TRY(hipMemsetAsync(w->b_posv.p, 0, w->b_posv.cap * sizeof(float4), w->stream));
+				w->dfWipedAt = w->dfEpoch >> 14;
+			}
+			long long rows = 0;
+			for (int col = restFirst; col < nColors && col < MAX_COLORS; ++col) rows += c.colorRows[col];
+			// (the census is this step's before k_color_small handed out its colours - at most COLOR_SMALL_MAX rows more; a grid
+			// that does not hold every row walks them in strides)
+			int gF = (int)((rows + COLOR_SMALL_MAX + SWEEP_END_LANES - 1) / SWEEP_END_LANES);
+			gF = std::max(1, std::min(gF, w->restHubMaxWG - 1));
+			if (mode == 2) w->restArrived += gF; // (the verdict of a position iteration waits for them: bar[5])
+			if (mode == 1) LAUNCH(w, k_rest_hub<1>, gF + 1, SWEEP_END_LANES, d, sp, restFirst, nColors, what, w->gridBar.p, w->dfEpoch, w->restArrived, w->sweepStamps ? w->gridBar.p : (int*)nullptr);
+			else LAUNCH(w, k_rest_hub<2>, gF + 1, SWEEP_END_LANES, d, sp, restFirst, nColors, what, w->gridBar.p, w->dfEpoch, w->restArrived, (int*)nullptr);
+			w->dfEpoch += 1;
 			w->lastSweepLaunches += 1;
 			return 0;
 		};
@@ -869,7 +934,7 @@ static int phaseSolve(b2hip_world* w)
 			else
 			{
 				for (int col = 0; col < bigEnd; ++col)
-					if (colorUsed(col)) LAUNCH(w, k_large_velocity, gK, 256, d, col, 0);
+					if (colorUsed(col)) LAUNCH(w, k_large_velocity, gridOfColor(col), censusGrid ? kLanes : 256, d, col, 0);
 				rc = restLaunch(0);
 				if (rc) return rc;
 			}
@@ -898,17 +963,22 @@ static int phaseSolve(b2hip_world* w)
 			{
 				if (!colorUsed(col)) continue;
 				if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 1; }
-				LAUNCH(w, k_large_velocity, gK, 256, d, col, 1);
+				LAUNCH(w, k_large_velocity, gridOfColor(col), censusGrid ? kLanes : 256, d, col, 1);
 				if (w->kernelTiming == 1) { rc = ktRecord(w); if (rc) return rc; }
 				if (w->debugTrace) TRACE(("vel" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
-			if (!useSweep) { rc = restLaunch(1); if (rc) return rc; }
-			if (useSweepEnd)
+			const int what1 = (hasHubs ? SE_HUB | (it > 0 ? SE_GUESS : 0) : 0) | (hasJoints && it + 1 < sp.velIters ? SE_JOINTS_VEL : 0);
+			if (fuseHub && !useSweep) { rc = restHubLaunch(1, what1); if (rc) return rc; }
+			else
 			{
-				rc = sweepEndLaunch(1, (hasHubs ? SE_HUB | (it > 0 ? SE_GUESS : 0) : 0) | (hasJoints && it + 1 < sp.velIters ? SE_JOINTS_VEL : 0));
-				if (rc) return rc;
+				if (!useSweep) { rc = restLaunch(1); if (rc) return rc; }
+				if (useSweepEnd)
+				{
+					rc = sweepEndLaunch(1, what1);
+					if (rc) return rc;
+				}
+				else if (hasHubs) { rc = hubSweepLaunch(1, it > 0 ? 1 : 0); if (rc) return rc; }
 			}
-			else if (hasHubs) { rc = hubSweepLaunch(1, it > 0 ? 1 : 0); if (rc) return rc; }
 		}
 		LAUNCH(w, k_large_store_impulses, gC, 256, d);
 		TRACE("store_impulses");
@@ -922,13 +992,15 @@ static int phaseSolve(b2hip_world* w)
 			for (int col = 0; col < bigEnd; ++col)
 			{
 				if (!colorUsed(col)) continue;
-				LAUNCH(w, k_large_position, gK, 256, d, col);
+				LAUNCH(w, k_large_position, gridOfColor(col), censusGrid ? kLanes : 256, d, col);
 				if (w->debugTrace) TRACE(("pos" + std::to_string(it) + "_c" + std::to_string(col)).c_str());
 			}
+			const int what2 = (hasHubs ? SE_HUB | (it > 0 ? SE_GUESS : 0) : 0) | (hasJoints ? SE_JOINTS_POS : 0) | SE_POS_END | (it + 1 < sp.posIters ? SE_POS_BEGIN : 0);
+			if (fuseHub && !useSweep && w->restHub > 1) { rc = restHubLaunch(2, what2); if (rc) return rc; continue; }
 			if (!useSweep) { rc = restLaunch(2); if (rc) return rc; }
 			if (useSweepEnd)
 			{
-				rc = sweepEndLaunch(2, (hasHubs ? SE_HUB | (it > 0 ? SE_GUESS : 0) : 0) | (hasJoints ? SE_JOINTS_POS : 0) | SE_POS_END | (it + 1 < sp.posIters ? SE_POS_BEGIN : 0));
+				rc = sweepEndLaunch(2, what2);
 				if (rc) return rc;
 			}
 			else

@@ -305,6 +305,15 @@ struct b2hip_world
 	bool sweepStamps = false;    // B2HIP_SWEEP_STAMPS=1: k_sweep_end<1> leaves its phase stamps where the block solver's go (diagnostics)
 	bool bodyWarm = true;        // the warm start of a launch-per-colour solve body by body in one launch (k_large_warm; B2HIP_NO_BODY_WARM=1: a sweep of launches)
 	bool restFlow = true;        // the small colours of a sweep as data flow per body in one launch (k_large_rest; B2HIP_NO_REST=1: launches / tail)
+	bool noHubOrder = false;     // B2HIP_NO_HUB_ORDER=1: the hub rows in contact order (round 5)
+	bool hubOrderAll = false;    // B2HIP_HUB_ORDER=1: ... ordered also where every hub row is swept lane after lane (B2HIP_HUB_WIDE=0 / B2HIP_HUB_SERIAL=1: comparison runs)
+	bool colorAheadOff = false;  // B2HIP_NO_COLOR_AHEAD=1: round 5's flow (the queued k_color_small returns where there is no partition, the colour count comes by copy)
+	bool noCensusGrid = false;   // B2HIP_NO_CENSUS_GRID=1: every colour launch sized from the mean colour (round 5)
+	int colorLanes = 256;        // lanes per workgroup of a colour launch (k_large_velocity / k_large_position; B2HIP_COLOR_LANES = 64 | 128 | 256)
+	int restHub = 2;             // k_large_rest + k_sweep_end of a sweep as ONE launch (k_rest_hub; B2HIP_REST_HUB=0: two launches, 1: the velocity sweeps only)
+	int restHubMaxWG = 0;        // co-resident workgroups of k_rest_hub (0: do not use it)
+	int restMaxWG = 0;           // ... of k_large_rest (0: unknown)
+	int restArrived = 0;         // workgroups of this step's fused launches that sweep rest rows (what the verdict of a position iteration waits for: bar[5])
 	int restRowsMax = 65536;     // ... the highest colours that hold at most this many rows together (B2HIP_REST_ROWS). Measured on the
 	                             // settled Tumbler (profiles/r05_i_rest_rows_sweep.txt: the solver family per step, 21 colours): none 2.06 ms /
 	                             // 260 launches per step; 16 384 rows 2.01 / 236; 50 000 1.89 / 188; 80 000 1.86 / 164; 180 000 1.88 / 116 -
@@ -941,6 +950,12 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	w->rowMarks = (getenv("B2HIP_ROW_MARKS_CHECK") && atoi(getenv("B2HIP_ROW_MARKS_CHECK"))) ? 2 : (getenv("B2HIP_NO_ROW_MARKS") && atoi(getenv("B2HIP_NO_ROW_MARKS"))) ? 0 : 1;
 	w->bodyWarm = !(getenv("B2HIP_NO_BODY_WARM") && atoi(getenv("B2HIP_NO_BODY_WARM")));
 	w->restFlow = w->sweepEnd && !(getenv("B2HIP_NO_REST") && atoi(getenv("B2HIP_NO_REST")));
+	w->noHubOrder = getenv("B2HIP_NO_HUB_ORDER") && atoi(getenv("B2HIP_NO_HUB_ORDER"));
+	w->hubOrderAll = getenv("B2HIP_HUB_ORDER") && atoi(getenv("B2HIP_HUB_ORDER"));
+	w->colorAheadOff = getenv("B2HIP_NO_COLOR_AHEAD") && atoi(getenv("B2HIP_NO_COLOR_AHEAD"));
+	w->noCensusGrid = getenv("B2HIP_NO_CENSUS_GRID") && atoi(getenv("B2HIP_NO_CENSUS_GRID"));
+	if (const char* e = getenv("B2HIP_COLOR_LANES")) { const int v = atoi(e); w->colorLanes = v == 64 ? 64 : (v == 128 ? 128 : 256); }
+	w->restHub = getenv("B2HIP_REST_HUB") ? std::max(0, std::min(2, atoi(getenv("B2HIP_REST_HUB")))) : 2;
 	w->restRowsMax = getenv("B2HIP_REST_ROWS") ? std::min(atoi(getenv("B2HIP_REST_ROWS")), REST_ROWS_MAX - COLOR_SMALL_MAX) : 65536;
 	w->tailRowsMax = getenv("B2HIP_TAIL_ROWS") ? atoi(getenv("B2HIP_TAIL_ROWS")) : SWEEP_END_LANES;
 	d.hubWide = (w->sweepEnd && !d.hubSerial && !(getenv("B2HIP_HUB_WIDE") && atoi(getenv("B2HIP_HUB_WIDE")) == 0)) ? 1 : 0;

@@ -51,10 +51,16 @@ if nh > 0:
 if os.environ.get("B2HIP_SWEEP_STAMPS"):
     st = (C.c_int * 6)()
     L.b2hip_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-    acc = np.zeros(4)
+    acc = np.zeros(5)
     for _ in range(10):
-        w.step(1); L.b2hip_debug_stamps(dev, st); acc += np.array(list(st)[:4])
+        w.step(1); L.b2hip_debug_stamps(dev, st); acc += np.array(list(st)[:5])
     acc *= 0.01 / 10  # 10 ns ticks -> us
-    print("k_sweep_end<1> (last velocity sweep of a step, mean of 10 steps), us since its start: tail colours done %.1f, hub fixed point done %.1f, leftover rows done %.1f, joints done %.1f" % tuple(acc))
+    print("k_sweep_end<1> / the hub workgroup of k_rest_hub<1> (last velocity sweep of a step, mean of 10 steps), us since its start: tail colours done %.1f, hub fixed point done %.1f, leftover rows done %.1f, joints done %.1f; bodies handed over by the rest rows settled %.1f" % tuple(acc))
+    bodyRest = np.zeros(nb, np.uint64)
+    if nh > 0 and L.b2hip_debug_read(dev, 21, 0, nb, bodyRest.ctypes.data) == 0:
+        bit = np.uint64(1) << np.uint64(63)
+        serial = (bodyRest & bit) != 0
+        restdeg = np.array([bin(int(x) & ((1 << 63) - 1)).count("1") for x in bodyRest])
+        print("bodies with the serial bit %d, of them with rest rows %d (histogram of their rest rows: %s)" % (int(serial.sum()), int((serial & (restdeg > 0)).sum()), np.bincount(restdeg[serial]).tolist()))
 print({k: round(v, 3) for k, v in w.profile().items() if v and k != "steps"})
 w.close()
