@@ -5,7 +5,8 @@ A "step" is one full Step(1/60 s, 8 velocity / 3 position iterations) of the wor
 body-state read-back. BASELINE.json quotes its metric on several configurations; the N = 1 workload is the
 LARGEST one it assigns to a single GPU - configs[2], "Tumbler 100k bodies, CCD off, 1 x MI355X": 316 x 316 = 99 856 boxes in a
 revolving container that hangs on a motorised revolute joint (Testbed/Tests/Tumbler.h:31-87, scaled as SURVEY.md 8d says) -
-measured in its SETTLED state: the boxes start on a grid that fills the container and have come down after ~400 steps, so the
+measured in its SETTLED state: the boxes start on a grid that fills the container, have come down after ~400 steps and slosh
+until ~700 (the step time follows the contact count: SETTLE below), so the
 scene is stepped for SETTLE[...] untimed steps as part of building the workload whatever --warmup says (that transient is
 reported separately), then --warmup untimed steps, then exactly --steps timed steps. The other configurations are
 `extra_configs` of the same line (config 2 = Pyramid 141, config 4's per-GPU share = Pyramid 316, config 5 on ONE GPU = the
@@ -48,7 +49,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 # Settle steps per workload (workload construction, untimed, always): the Tumbler's boxes have come down after ~400 steps; the
 # 141-row pyramid's contact count levels off at step ~200 (SURVEY asks for >= 120); the 316-row pyramid's top row lands at
 # ~240; the field is random from the start.
-SETTLE = {"tumbler": 400, "pyramid141": 240, "pyramid316": 320, "field": 30}
+# (round 6: the Tumbler 700, not 400 - the boxes have come down by step ~400, but the splash they make has not died down: the
+# contact count falls to a minimum of 2.4 M at step ~420, climbs to 3.1 M at ~550 and settles around 2.5 - 2.7 M from step ~700
+# on, and the step time follows it - 3.35 ms at 400..449, 3.96 at 550..599, 3.46 - 3.64 from 700 to 1200
+# (tools/gpu_step_series.py, profiles/r06_tumbler316_step_series.txt). Twenty steps behind step 400 were the cheapest window of
+# the whole run, 12 % below the 300 steps behind them; behind step 700 the timed steps and the 300 that follow agree to ~2 %.)
+SETTLE = {"tumbler": 700, "pyramid141": 240, "pyramid316": 320, "field": 30}
 PARITY_TUMBLER = ("coloured order (launch per colour + k_large_rest + k_sweep_end): one island of ~370 000 constraints, a hub of ~900 "
                   "and a revolute joint; integer results (island membership, awake flags, contact counts against the reference for 30 "
                   "steps: tests/test_gpu_configs_full_size.py) exact; floats differ from the reference by the ORDER dependence of 8 + 3 "
@@ -58,7 +64,7 @@ PARITY_TUMBLER = ("coloured order (launch per colour + k_large_rest + k_sweep_en
 PARITY_PYRAMID = ("coloured order (k_solve_blocks): integer results exact; ONE step from a bit-identical snapshot of the timed state: "
                   "|dp| <= 1.7 cm on 1 m boxes (1.13e-4 of the 150 m scene; median 1-2 mm), |dv| <= 0.30 m/s, 18 of 30 000 contacts differ "
                   "(tests/test_gpu_onestep.py); the bit-exact class is `exact_order`")
-FAMILY_KERNELS = ("k_large_integrate", "k_large_init", "k_large_velocity", "k_large_rest", "k_sweep_end", "k_large_position", "k_large_store_impulses",
+FAMILY_KERNELS = ("k_large_integrate", "k_large_init", "k_large_velocity", "k_large_rest", "k_rest_hub", "k_large_warm", "k_sweep_end", "k_large_position", "k_large_store_impulses",
                   "k_large_integrate_positions", "k_large_pos_begin", "k_large_finalize", "k_large_sleep", "k_large_hub", "k_large_joints", "k_large_pos_end", "k_joints_sort")
 
 

@@ -71,9 +71,10 @@ __device__ __forceinline__ bool gridBarrier(const GridBarrier& gb)
 		else
 		{
 			int spins = 0;
+			const int spinMax = gb.bar[6] != 0 ? gb.bar[6] : PERSIST_SPIN_MAX; // (bar[6]: tests force the time-out, k_step_begin)
 			while (ldcI(&gb.bar[1]) == gen)
 			{
-				if (++spins > PERSIST_SPIN_MAX || ldcI(&gb.bar[4]) != 0)
+				if (++spins > spinMax || ldcI(&gb.bar[4]) != 0)
 				{
 					stcI(&gb.bar[4], 1);
 					atomicOr(gb.overflow, 64);
@@ -138,6 +139,8 @@ template <typename F>
 __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, int needA, const float4* rowB, int needB, int* bar, int* overflow, int pollSleep, F body)
 {
 	int spins = 0;
+	int lastA = 0, lastB = 0; // (the versions the last poll saw: pollSleep >= 4)
+	const int spinMax = bar[6] != 0 ? bar[6] : DATAFLOW_SPIN_MAX; // (bar[6]: tests force the time-out, k_step_begin)
 	while (__any(pending))
 	{
 		if (pending)
@@ -146,6 +149,7 @@ __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, in
 			if (rowA && rowB) ldRow2(rowA, rowB, &ra, &rb);
 			else if (rowA) ra = ldRow(rowA);
 			else if (rowB) rb = ldRow(rowB);
+			lastA = __float_as_int(ra.w); lastB = __float_as_int(rb.w);
 			const bool ready = (!rowA || __float_as_int(ra.w) == needA) && (!rowB || __float_as_int(rb.w) == needB);
 			if (ready)
 			{
@@ -155,11 +159,11 @@ __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, in
 		}
 		// wave-uniform bookkeeping: every lane counts every trip
 		++spins;
-		if (spins > DATAFLOW_SPIN_MAX || ((spins & 1023) == 0 && __any(ldcI(&bar[4]) != 0)))
+		if (spins > spinMax || ((spins & 1023) == 0 && __any(ldcI(&bar[4]) != 0)))
 		{
 			// (post mortem, B2HIP_HANDOVER_WHY=1: the first lane that gave up on its OWN count leaves what it waited for - the rows'
 			// addresses in 16-byte units, the versions it needed and the ones it last saw - in bar[24..31])
-			if (pending && spins > DATAFLOW_SPIN_MAX && atomicCAS(&bar[24], 0, 1) == 0)
+			if (pending && spins > spinMax && atomicCAS(&bar[24], 0, 1) == 0)
 			{
 				f4v ra = { 0.0f, 0.0f, 0.0f, 0.0f }, rb = ra;
 				if (rowA) ra = ldRow(rowA);
@@ -179,6 +183,24 @@ __device__ __forceinline__ bool dataflowRun(bool pending, const float4* rowA, in
 			if (pollSleep == 1) __builtin_amdgcn_s_sleep(1);
 			else if (pollSleep == 2) __builtin_amdgcn_s_sleep(4);
 			else if (pollSleep == 3) __builtin_amdgcn_s_sleep(12);
+			else if (pollSleep >= 4)
+			{
+				// back off by DISTANCE (round 6): the versions count the hand-overs of a body within this launch, so what a lane has
+				// just read says how many are still to come before its turn; the wave sleeps for the nearest of its lanes' turns,
+				// ~(pollSleep - 3) x 0.43 us per hand-over still ahead of it (a hop is ~2.5 us): fewer polls past the L2 per hop
+				int dist = 64;
+				if (pending)
+				{
+					const int da = rowA ? needA - lastA : 0, db = rowB ? needB - lastB : 0;
+					int d = da > db ? da : db;
+					if (d < 1 || d > 63) d = 1; // (another launch's tag: nothing known)
+					dist = d;
+				}
+				for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(dist, off); dist = o < dist ? o : dist; }
+				const int naps = (dist - 1) * (pollSleep - 3);
+				for (int k = 0; k < naps && k < 64; ++k) __builtin_amdgcn_s_sleep(16);
+				__builtin_amdgcn_s_sleep(1);
+			}
 		}
 	}
 	return true;

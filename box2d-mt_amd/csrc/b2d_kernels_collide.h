@@ -718,7 +718,7 @@ __global__ void k_step_begin(DW W, int* bar)
 		c.spToiCreated = 0;
 		c.spToiStraddle = 0;
 	}
-	if (t < 32) bar[t] = 0;
+	if (t < 32) bar[t] = t == 6 ? W.testSpinMax : 0; // ([6]: B2HIP_TEST_SPIN_MAX - the spin limit of every wait between workgroups, 0 = the built-in ones: tests/test_gpu_recovery.py)
 	// (the arrival trees are all zero between launches - whoever completes a word puts it back; a launch that died halfway
 	// in a failed step must not leave the next step's close-outs without their last workgroup)
 	for (int k = t; k < ARRIVE_SITES * TREE_WORDS; k += (int)blockDim.x) W.arriveTree[k] = 0ull;

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 					S->dbgCensus[1] = e[u]; S->dbgCensus[2] = W.b_blk1[body[u]]; S->dbgCensus[3] = W.b_adopt[body[u]];
 					const uint32_t hx = (uint32_t)body[u] * 2654435761u >> 8;
 					const int nbx = W.st->c.nBlocks;
-					S->dbgCensus[4] = (int)hx; S->dbgCensus[5] = nbx; S->dbgCensus[6] = (int)(hx % (uint32_t)nbx); S->dbgCensus[7] = effBlk(W, body[u]);
+					S->dbgCensus[4] = (int)hx; S->dbgCensus[5] = nbx; S->dbgCensus[6] = nbx > 0 ? ownIdBlock(body[u], nbx) - 1 : -1; /* (the solver's own function: the plain % was miscompiled here, round 5) */ S->dbgCensus[7] = effBlk(W, body[u]);
 				}
 			}
 		}
@@ -313,6 +313,15 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 	__shared__ int s_hist[MAX_COLORS], s_colStart[MAX_COLORS + 1];
 	__shared__ unsigned long long s_colMask;
 	if (gtid == 0) { S->c.allLargeDone = 0; S->gapClock[3] = wall_clock64(); }
+	// The colours come from k_color_small, which the host did not wait for: if it ran out of rounds or of colours (round 6:
+	// neither ends the step any more) this kernel must not sweep - a constraint without a colour is in no colour step, and a
+	// neighbour block would wait for its hand-over until the spin limit. Every workgroup reads the same two words and leaves;
+	// the host sees bit 6, puts the state back, finishes the colouring and solves launch by launch (b2hip_host_phases.h).
+	if (S->c.nUncolored != 0 || (S->c.overflow & 4) != 0)
+	{
+		if (gtid == 0) { stcI(&bar[4], 1); atomicOr(gb.overflow, 64); }
+		return;
+	}
 	// (penetration maxima: every slot was wiped by k_island_init)
 	const unsigned long long t0 = wall_clock64();
 #define BLK_STAMP(k) do { if (gtid == 0) bar[8 + (k)] = (int)(wall_clock64() - t0); } while (0)
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(LANES) void k_solve_blocks(DW W, StepParams sp, int
 			const int need = (g + 1) * gb.nWG;
 			while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) // (what follows reads past the L2: ldc*)
 			{
-				if (++spins > PERSIST_SPIN_MAX || ldcI(&bar[4]) != 0)
+				if (++spins > (bar[6] != 0 ? bar[6] : PERSIST_SPIN_MAX) || ldcI(&bar[4]) != 0)
 				{
 					stcI(&bar[4], 1);
 					atomicOr(gb.overflow, 64);

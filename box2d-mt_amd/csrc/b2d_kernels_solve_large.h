@@ -105,6 +105,14 @@ __device__ __forceinline__ uint64_t colorClassMask(bool cut)
 {
 	return (cut ? COLOR_INTERIOR_BITS : 0ull) | (1ull << HUB_COLOR);
 }
+// (tests/test_gpu_recovery.py: B2HIP_TEST_MAX_COLORS = N leaves the colours [0, N) of each range - a pile then runs out of
+// colours on its busiest bodies, as a world with 64 different ones on two bodies would)
+__device__ __forceinline__ uint64_t colorTestMask(const DW& W)
+{
+	if (W.testMaxColors <= 0 || W.testMaxColors >= CUT_COLOR_BASE) return 0ull;
+	const uint64_t keep = (1ull << W.testMaxColors) - 1ull;
+	return ~(keep | (keep << CUT_COLOR_BASE));
+}
 __device__ __forceinline__ void noteColorUsed(DState* S, int color)
 {
 	if (color < 32) atomicOr(&S->c.colorMaskLo, 1u << color);
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void k_color_resolve(DW W)
 		if (nsB && __hip_atomic_load(&W.bodyClaim[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
 		if (!win) continue;
 		// this lane is the only winner on both bodies this round: plain read-modify-write is safe
-		uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
+		uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)) | colorTestMask(W);
 		if (nsA) used |= W.bodyColorMask[ids.z];
 		if (nsB) used |= W.bodyColorMask[ids.w];
 		int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
@@ -506,7 +514,7 @@ __device__ __forceinline__ void colorSmallBody(const DW& W)
 			const int4 ids = C.ids[ci];
 			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
 			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-			uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
+			uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)) | colorTestMask(W);
 			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (used == ~0ull || __ffsll((long long)~used) - 1 >= c) continue;
@@ -555,11 +563,12 @@ __device__ __forceinline__ void colorSmallBody(const DW& W)
 			it_a[j] = nsA ? ids.z : -1;
 			it_b[j] = nsB ? ids.w : -1;
 			it_pr[j] = colorPriority(ci);
-			it_class[j] = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB));
+			it_class[j] = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)) | colorTestMask(W);
 		}
 	}
 	__syncthreads();
-	for (int round = 0; round < 4 * MAX_COLORS && s_left > 0; ++round)
+	const int maxRounds = W.testColorRounds > 0 ? W.testColorRounds : 4 * MAX_COLORS; // (B2HIP_TEST_COLOR_ROUNDS: tests of the fall-back to the grid-wide rounds)
+	for (int round = 0; round < maxRounds && s_left > 0; ++round)
 	{
 		if (threadIdx.x == 0) s_colored = 0;
 #pragma unroll
@@ -854,6 +863,10 @@ __global__ __launch_bounds__(256) void k_hub_flag(DW W)
 				else
 				if (rowIsHubs(W, nsA, ids.z, nsB, ids.w)) f = 1;
 				else if (rowIsSerial(W, nsA, ids.z, nsB, ids.w)) f = 1 << 20;
+				// a constraint that found NO colour free on its two bodies (Counters::overflow bit 2; it sits in the hub group, its
+				// stored colour says so - a hub's own constraints store none) is swept in order with the hub rows this step (round 6:
+				// the step used to fail with "more than 64 constraint colours on one body") and asks for a colour again next step
+				if (f == 0 && C.color[i] == HUB_COLOR) f = 1 << 20;
 			}
 		}
 		W.keepFlag[i] = f;

@@ -48,8 +48,10 @@
 // one writes the body table. A chain is as long as a body has rest colours - a few hops of ~3 us where the launches were
 // 6 us each - and chains of different bodies do not wait for one another. The same arithmetic in the same order on every
 // body as the launches: the same bits (tests/test_gpu_sweep_end.py).
-// All workgroups of the launch must be resident together (the host keeps the rest rows below REST_ROWS_MAX: 768 workgroups
-// of 256 lanes, three per CU).
+// The workgroups of the launch wait for one another: a lane on a later trip of the stride loop may wait for a first-trip row
+// of a workgroup with a HIGHER index only if that workgroup is running, so ALL workgroups of the launch must be resident
+// together. The host clamps the grid to the occupancy query times the CUs (restMaxWG, restHubMaxWG: b2hip_api_world.h;
+// ADVICE round 5) and lets the rows beyond it be walked in strides.
 #define REST_ROWS_MAX 196608
 // A body that the hub workgroup of a fused launch (k_rest_hub below) touches - a partner of a hub row, a body of a joint of a
 // large island - carries this bit in DW::bodyRest (k_color_fill, k_joints_fill; HUB_COLOR is never a rest colour). In a fused
@@ -113,7 +115,7 @@ __device__ __forceinline__ bool restSweepRows(const DW& W, int restFirst, int nC
 		float4* const xB = nsB ? &xch[r.bodyB] : nullptr;
 		const int needA = tag + rankA, needB = tag + rankB;
 		float minSep = 0.0f;
-		const bool ok = dataflowRun(have && active, (nsA && rankA > 0) ? xA : nullptr, needA, (nsB && rankB > 0) ? xB : nullptr, needB, bar, &S->c.overflow, 1, [&](f4v ra, f4v rb)
+		const bool ok = dataflowRun(have && active, (nsA && rankA > 0) ? xA : nullptr, needA, (nsB && rankB > 0) ? xB : nullptr, needB, bar, &S->c.overflow, W.restPoll, [&](f4v ra, f4v rb)
 		{
 			float4 qa = startA, qb = startB;
 			if (nsA && rankA > 0) qa = make_float4(ra.x, ra.y, ra.z, startA.w);
@@ -251,7 +253,7 @@ __device__ __forceinline__ bool restSettleBody(const DW& W, const RestJoin& rj, 
 			return true;
 		}
 		if (__float_as_int(r.w) == need + REST_SETTLED) return true;
-		if (++spins > DATAFLOW_SPIN_MAX || ((spins & 1023) == 0 && ldcI(&rj.bar[4]) != 0)) return false;
+		if (++spins > (rj.bar[6] != 0 ? rj.bar[6] : DATAFLOW_SPIN_MAX) || ((spins & 1023) == 0 && ldcI(&rj.bar[4]) != 0)) return false;
 		__builtin_amdgcn_s_sleep(1);
 	}
 }
@@ -627,7 +629,7 @@ __device__ __forceinline__ void sweepEndBody(const DW& W, const StepParams& sp, 
 				int spins = 0, okj = 1;
 				while (ldcI(&rj->bar[5]) < rj->arriveNeed)
 				{
-					if (++spins > PERSIST_SPIN_MAX || ldcI(&rj->bar[4]) != 0) { stcI(&rj->bar[4], 1); atomicOr(&S->c.overflow, 64); okj = 0; break; }
+					if (++spins > (rj->bar[6] != 0 ? rj->bar[6] : PERSIST_SPIN_MAX) || ldcI(&rj->bar[4]) != 0) { stcI(&rj->bar[4], 1); atomicOr(&S->c.overflow, 64); okj = 0; break; }
 					__builtin_amdgcn_s_sleep(1);
 				}
 				s_joined = okj;
@@ -706,6 +708,103 @@ __global__ __launch_bounds__(SWEEP_END_LANES) void k_rest_hub(DW W, StepParams s
 	rj.tag = (epoch & 0x7fff) << 16;
 	rj.arriveNeed = arriveNeed;
 	sweepEndBody<MODE>(W, sp, 0, 0, what, stampBar, &rj);
+}
+
+// ---- a solve that can be run again (round 6; b2hip_host_phases.h: runLarge) ----------------------------------------------------------
+// What the large-island solver CHANGES, saved before its first launch and put back if a wait between its workgroups timed
+// out: the rows of the large islands' bodies (position + sleep time, sweep start, velocity, transform, flags, force), the
+// impulses and flags of their contacts, their joints (accumulated impulses, per-step scratch). Everything else the solver
+// touches is scratch that its launches fill before they read it (constraint rows, warm-start deltas, exchange rows - tagged
+// with an epoch the next launch does not share) or is reset by k_solver_recover_reset. The small islands are somebody else's:
+// their solver runs beside this one on the side stream and keeps what it wrote.
+// dir 0: save, 1: restore.
+__global__ __launch_bounds__(256) void k_solver_snapshot(DW W, int dir)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	const int nB = S->c.nLBodies, nC = S->c.nLContacts, nI = S->c.nLIslands;
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nB; k += gridDim.x * blockDim.x)
+	{
+		const int body = W.li_bodies[k];
+		float4* const s = W.solveSnapBody + (size_t)k * 6;
+		if (dir == 0)
+		{
+			s[0] = W.b_pos[body]; s[1] = W.b_pos0[body]; s[2] = W.b_vel[body]; s[3] = W.b_xf[body]; s[4] = W.b_force[body];
+			s[5] = make_float4(__uint_as_float(W.b_flags[body]), 0.0f, 0.0f, 0.0f);
+		}
+		else
+		{
+			W.b_pos[body] = s[0]; W.b_pos0[body] = s[1]; W.b_vel[body] = s[2]; W.b_xf[body] = s[3]; W.b_force[body] = s[4];
+			W.b_flags[body] = __float_as_uint(s[5].x);
+		}
+	}
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nC; k += gridDim.x * blockDim.x)
+	{
+		const int ci = W.li_contacts[k];
+		if (dir == 0) { W.solveSnapImp[k] = C.imp[ci]; W.solveSnapCFlags[k] = C.flags[ci]; }
+		else { C.imp[ci] = W.solveSnapImp[k]; C.flags[ci] = W.solveSnapCFlags[k]; }
+	}
+	// the joints of the large islands (lj_list, island by island), and the gear records some of them own
+	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nI; k += gridDim.x * blockDim.x)
+	{
+		const int root = W.li_roots[k];
+		const int nj = W.rootJoints[root], start = W.rootJointStart[root];
+		for (int t = 0; t < nj; ++t)
+		{
+			const int j = W.lj_list[start + t];
+			if (dir == 0) W.solveSnapJoints[j] = W.joints[j]; else W.joints[j] = W.solveSnapJoints[j];
+			if (W.joints[j].type == B2D_JOINT_GEAR)
+			{
+				const int g = W.joints[j].enableLimit;
+				if (dir == 0) W.solveSnapGears[g] = W.gears[g]; else W.gears[g] = W.solveSnapGears[g];
+			}
+		}
+	}
+}
+
+// The overflow word of the step so far, to mapped host memory: word[0] the flags, word[1] the number of this publication,
+// word[2] the constraints still without a colour (a resident solver reads the colours on the device).
+__global__ void k_solver_status(DW W, int* word, int seq)
+{
+	b2dPhaseStamp(W);
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		const int flags = __hip_atomic_load(&W.st->c.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(&word[0], flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&word[2], W.st->c.nUncolored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&word[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+// Before the solve runs a second time: the timed-out wait forgotten (overflow bit 6 and its qualifier, the barrier words),
+// the per-step solver scratch as k_island_init / the solver's own first kernels would find it.
+__global__ __launch_bounds__(256) void k_solver_recover_reset(DW W, int* bar)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W.nBodies; i += gridDim.x * blockDim.x)
+	{
+		for (int k = 0; k < ROOT_PEN_SLOTS; ++k) W.rootPen[(size_t)k * W.nBodies + i] = 0;
+		W.rootDone[i] = 0;
+		W.rootSleepMin[i] = 0x7f7fffffu;
+		W.rootJointOkay[i] = 1;
+		W.bodyRest[i] = 0;
+		W.bodyActive[i] = 0;
+	}
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_BLOCKS + 1; i += gridDim.x * blockDim.x)
+	{
+		W.blkCursor[(size_t)i * BLK_SLOT] = 0;
+		W.blkBodyCursor[i] = 0;
+	}
+	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS) W.colorCursor[colorSlot(threadIdx.x)] = 0;
+	if (blockIdx.x == 0 && threadIdx.x < 32) bar[threadIdx.x] = 0;
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		atomicAnd(&S->c.overflow, ~(64 | 0x2000));
+		S->c.allLargeDone = 0;
+		S->c.posItersLarge = 0;
+	}
 }
 
 #endif

@@ -185,19 +185,23 @@ __device__ __forceinline__ void atomicMaxIfAbove(uint32_t* addr, uint32_t v)
 
 // ... and once per WORKGROUP where every lane has a candidate (kept in a register over the kernel's loop): even the look is a
 // load past the L2 of one word that every wave of the launch wants - 32 000 of them were 80 of k_island_flatten's 99 us on a
-// million bodies (round 5). Every thread of the workgroup calls it, once, at the end; values <= 0 are no offer.
+// million bodies (round 5). EVERY thread of the workgroup calls it, convergently (a caller that leaves early must do so
+// uniformly, before the call: k_bp_clear's `nMoves == 0`); workgroups of whole waves, at most 16 of them; values <= 0 are no
+// offer. The scratch is shared by all calls of a kernel: the trailing barrier makes a second call safe.
 __device__ __forceinline__ void blockAtomicMaxIfAbove(int* addr, int v)
 {
 	__shared__ int s_blockMax[16];
 	for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
-	if ((threadIdx.x & 63u) == 0) s_blockMax[threadIdx.x >> 6] = v;
+	if ((threadIdx.x & 63u) == 0) s_blockMax[(threadIdx.x >> 6) & 15u] = v;
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		const int nw = (int)((blockDim.x + 63u) >> 6);
+		int nw = (int)((blockDim.x + 63u) >> 6);
+		nw = nw > 16 ? 16 : nw;
 		for (int k = 1; k < nw; ++k) v = s_blockMax[k] > v ? s_blockMax[k] : v;
 		if (v > 0) atomicMaxIfAbove(addr, v);
 	}
+	__syncthreads();
 }
 
 // A workgroup's running sum for ONE hot key, kept in LDS across the iterations of a grid-stride loop: a single island of

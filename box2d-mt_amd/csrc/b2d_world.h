@@ -275,6 +275,9 @@ struct DW
 	int capContacts, capPairs, capMoves;
 	int serialOrphans;    // 1: constraints of bodies without a home block are swept in order with the hub constraints
 	int noFreeBodies;     // B2HIP_NO_FREE_BODIES=1: one-body islands go through the small-island solver like any other
+	int testMaxColors, testColorRounds; // B2HIP_TEST_MAX_COLORS / B2HIP_TEST_COLOR_ROUNDS: fewer colours per range / rounds of k_color_small than the built-in limits (tests of the recoveries)
+	int testSpinMax;      // B2HIP_TEST_SPIN_MAX: the spin limit of the waits between workgroups (0: PERSIST_SPIN_MAX / DATAFLOW_SPIN_MAX) - forces the time-out the recovery path exists for
+	int restPoll;         // how the rest rows wait (dataflowRun's pollSleep): 1 short naps (round 5), >= 4 back off by distance (B2HIP_REST_POLL)
 	int hubSerial;        // B2HIP_HUB_SERIAL=1: hub rows lane after lane only (validation of the fixed-point path)
 	int smallMaxW;        // islands up to this size take the exact-order in-LDS solver (default TINY_ISLAND_MAX_W = 128; B2HIP_SMALL_MAX_W up to 512)
 	int bigChunks;        // 1: always use 1024-lane chunks for the small-island solver (B2HIP_BIG_CHUNKS)
@@ -371,6 +374,9 @@ struct DW
 	uint32_t* bodyClaim;
 	uint64_t* bodyColorMask;
 	uint64_t* bodyActive;   // per body: colours of its constraints in THIS step's large-island solve (dataflow solver)
+	float4* solveSnapBody;  // what k_solver_snapshot keeps of the large islands' bodies (6 rows each), ...
+	float4* solveSnapImp; uint32_t* solveSnapCFlags; // ... of their contacts (impulses, flags) ...
+	struct JointRec* solveSnapJoints; struct GearRec* solveSnapGears; // ... and of their joints
 	uint64_t* bodyRest;     // per body: the REST colours (>= k_color_fill's restFirst) among its constraints of this step (k_large_rest)
 	int eventsOn;           // contact events requested by the host (b2hip_enable_contact_events)
 	unsigned long long* evKey; // per event: proxy-key pair of the contact (the reference's deferred-callback sort key)

@@ -286,6 +286,7 @@ int b2hip_get_counters(b2hip_world* w, b2hip_counters* out)
 	out->hub_serial_chunks = w->last.hubSerialChunks;
 	out->toi_chain_contacts = w->toiChainContacts;
 	out->toi_pre_solve_reruns = w->toiPreSolveReruns;
+	out->solver_recoveries = w->solverRecoveries + w->colorRecoveries;
 	return 0;
 }
 

@@ -322,7 +322,7 @@ static void handoverPostMortem(b2hip_world* w)
 		int at = -1;
 		for (int k = 0; k < c.nLBodies; ++k) if (lib[(size_t)k] == body) at = k;
 		const int nbk = c.nBlocks < MAX_BLOCKS ? c.nBlocks : MAX_BLOCKS;
-		fprintf(stderr, "[b2hip]       (place in the list of large-island bodies: %d of %d; a block by its own id would be %d)\n", at, c.nLBodies, nbk > 0 ? 1 + (int)(((uint32_t)body * 2654435761u >> 8) % (uint32_t)nbk) : 0);
+		fprintf(stderr, "[b2hip]       (place in the list of large-island bodies: %d of %d; a block by its own id would be %d)\n", at, c.nLBodies, nbk > 0 ? ownIdBlock(body, nbk) : 0);
 		fprintf(stderr, "[b2hip]       body %d: flags 0x%x (type %u, large %d, awake %d), degree %d, home block %d, offer 0x%x, cut-colour mask 0x%llx\n", body, flags[(size_t)body], flags[(size_t)body] & BF_TYPE_MASK,
 			(flags[(size_t)body] & BF_LARGE) ? 1 : 0, (flags[(size_t)body] & BF_AWAKE) ? 1 : 0, deg[(size_t)body], blk1[(size_t)body], adopt[(size_t)body], act[(size_t)body]);
 	};
@@ -528,6 +528,9 @@ static int stepEndImpl(b2hip_world* w)
 			{
 				w->toiChains = false;
 				w->toiSpeculative = false;
+				// (the redone phase is judged on its own: not by what the speculative launch assumed of the grid - ADVICE round 5)
+				w->toiSpecDomains = false;
+				w->toiSpecGridAssumed = false;
 				rc = phaseToiSync(w);
 				if (rc) return rc;
 			}
@@ -574,6 +577,8 @@ static int stepEndImpl(b2hip_world* w)
 			w->toiGridSticky = 16;
 			w->toiChains = false;
 			w->toiSpeculative = false;
+			w->toiSpecDomains = false;
+			w->toiSpecGridAssumed = false;
 			rc = phaseToiSync(w);
 			if (rc) return rc;
 			rc = downloadState(w, -1);

@@ -204,6 +204,14 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 		return setError(B2HIP_ERR_HIP, "hipHostMalloc (coherent) failed");
 	}
 	memset(w->h_pub, 0, sizeof(DState));
+	w->recoverOn = !(getenv("B2HIP_NO_RECOVER") && atoi(getenv("B2HIP_NO_RECOVER")));
+	if (hipHostMalloc((void**)&w->h_solverWord, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+		hipHostGetDevicePointer((void**)&w->d_solverWord, w->h_solverWord, 0) != hipSuccess)
+	{
+		b2hip_world_destroy(w);
+		return setError(B2HIP_ERR_HIP, "hipHostMalloc (coherent) failed");
+	}
+	memset(w->h_solverWord, 0, 64);
 	w->noCensusPoll = getenv("B2HIP_NO_CENSUS_POLL") && atoi(getenv("B2HIP_NO_CENSUS_POLL"));
 	w->noStatePoll = getenv("B2HIP_NO_STATE_POLL") && atoi(getenv("B2HIP_NO_STATE_POLL"));
 	w->lazyReadback = getenv("B2HIP_LAZY_READBACK") && atoi(getenv("B2HIP_LAZY_READBACK"));
@@ -267,7 +275,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	w->b_slot.release(); w->b_island.release(); w->chunkFirst.release();
 	w->li_bodies.release(); w->li_contacts.release(); w->li_roots.release(); w->li_color.release(); w->colorCount.release();
 	w->colorStart.release(); w->colorCursor.release(); w->li_sorted.release(); w->bodyClaim.release(); w->rootPen.release();
-	w->bodyActive.release(); w->bodyRest.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release(); w->hubRowOf.release(); w->hubList.release(); w->hubDelta.release(); w->hubMeta.release(); w->hubFirst.release();
+	w->bodyActive.release(); w->bodyRest.release(); w->b_posv.release(); w->dfRank.release(); w->dfInbox.release(); w->evKey.release(); w->evInfo.release(); w->uncolList.release(); w->compactList.release(); w->gridBar.release(); w->hubRowOf.release(); w->hubList.release(); w->hubDelta.release(); w->hubMeta.release(); w->hubFirst.release(); w->solveSnapBody.release(); w->solveSnapImp.release(); w->solveSnapCFlags.release(); w->solveSnapJoints.release(); w->solveSnapGears.release();
 	w->b_proxyHead.release(); w->p_next.release(); w->toiList.release(); w->toiPos2c.release(); w->toiDestroyList.release(); w->toiNewList.release();
 	w->b_toiGroup.release(); w->toiGroups.release(); w->toiGroupCount.release(); w->toiGroupList.release(); w->toiMoved.release(); w->toiNew.release(); w->toiParent.release(); w->toiDomOf.release(); w->toiDomRoot.release(); w->toiDomCount.release(); w->toiDomBase.release(); w->toiDomFill.release(); w->toiDomFailed.release(); w->toiDomEvents.release(); w->toiDomList.release(); w->toiHull.release(); w->snapBody.release(); w->snapFat.release();
 	w->c_mgr[0].release(); w->c_mgr[1].release(); w->dbgPreVel.release(); w->dbgVel.release(); w->dbgLi.release();
@@ -286,6 +294,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
 	if (w->h_pub) (void)hipHostFree(w->h_pub);
+	if (w->h_solverWord) (void)hipHostFree(w->h_solverWord);
 	for (int i = 0; i < 13; ++i)
 		if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);
 	for (size_t i = 0; i < w->ktEvents.size(); ++i) (void)hipEventDestroy(w->ktEvents[i]);

@@ -523,7 +523,7 @@ static int phaseSolve(b2hip_world* w)
 
 	stampPhase(w, 4);
 	const bool exactLarge = forceLarge == 2;
-	const bool hasHubs = !exactLarge && (c.maxDegree > HUB_DEGREE || c.nSerialOrphans > 0); // (anything for k_large_hub)
+	bool hasHubs = !exactLarge && (c.maxDegree > HUB_DEGREE || c.nSerialOrphans > 0); // (anything for k_large_hub)
 	// Small and large islands share nothing (different bodies, contacts, island tables): when both tiers are present the
 	// small-island chain (DFS order, chunking, k_solve_small) runs on a side stream beside the large-island solver and
 	// joins before SynchronizeFixtures. With a handful of small islands that chain is one or two workgroups of big kernels
@@ -606,21 +606,23 @@ static int phaseSolve(b2hip_world* w)
 		const int persistLanes = w->solverBarriers ? PERSIST_LANES : dfLanes;
 		const int persistWG = (nLContacts + persistLanes - 1) / persistLanes;
 		const int persistMaxWG = w->persistMaxWG * (PERSIST_LANES / persistLanes);
-		const bool usePersistent = !exactLarge && !hasJoints && !hasHubs && !w->debugTrace && !w->kernelTimingLaunches &&
+		bool usePersistent = !exactLarge && !hasJoints && !hasHubs && !w->debugTrace && !w->kernelTimingLaunches &&
 			persistMaxWG > 0 && persistWG <= persistMaxWG;
 		// the block solver (bodies in LDS, one workgroup per block of the partition): whenever the partition fits
 		const bool partitionFits = blockShape && c.nBlocks > 0 && c.nOrphanRows == 0 && c.blkMaxRows <= c.blkLanes && c.blkMaxBodies <= c.blkLanes;
-		const bool useBlocks = usePersistent && partitionFits && plainIslands && !w->solverBarriers && !w->solverRows && !w->solverMailbox &&
+		bool useBlocks = usePersistent && partitionFits && plainIslands && !w->solverBarriers && !w->solverRows && !w->solverMailbox &&
 			c.nBlocks <= w->blocksMaxWG &&
 			(sp.velIters + 2) * (MAX_COLORS + 1) < 65536 && (sp.posIters + 1) * (MAX_COLORS + 1) < 65536;
 		// one launch per sweep over the same blocks for islands that need joint walks / hub sweeps in between
 		const int sweepMaxWG = c.blkLanes == 512 ? w->sweepMaxWG[1] : (c.blkLanes == BLOCK_LANES ? w->sweepMaxWG[2] : w->sweepMaxWG[0]);
-		const bool useSweep = !useBlocks && !exactLarge && partitionFits && !plainIslands && !w->debugTrace && !w->kernelTimingLaunches &&
+		bool useSweep = !useBlocks && !exactLarge && partitionFits && !plainIslands && !w->debugTrace && !w->kernelTimingLaunches &&
 			c.nBlocks <= sweepMaxWG;
 		d.blockSort = (useBlocks || useSweep) ? 1 : 0;
-		const bool useResident = usePersistent && (useBlocks || B2HIP_HAVE_VALIDATION_SOLVERS);
+		bool useResident = usePersistent && (useBlocks || B2HIP_HAVE_VALIDATION_SOLVERS);
 		bool colorsOnDevice = false;
 		bool censusVoid = false;
+		bool colorSpill = false; // some constraint found no free colour this step: it sits in the hub group and is swept in order
+		bool roundsToo = false;  // the grid-wide colouring rounds run (asked for by the census, or to finish what k_color_small left)
 		if (!exactLarge && (c.needRecolor || c.nUncolored > 0 || c.nCompact > 0))
 		{
 			if (!c.needRecolor && c.nUncolored <= COLOR_SMALL_MAX)
@@ -651,11 +653,21 @@ static int phaseSolve(b2hip_world* w)
 					else rc = readState(w);
 					if (rc) return rc;
 					nColors = w->h_dstate->c.nColors;
-					if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
-					if (w->h_dstate->c.nUncolored != 0) return setError(B2HIP_ERR_CAPACITY, "incremental colouring did not converge");
+					// (round 6: neither ends the step any more. A constraint without a free colour on its two bodies is swept in order
+					// with the hub rows - k_hub_flag; rounds that did not converge are finished by the grid-wide rounds below)
+					if (w->h_dstate->c.overflow & 4) { if (!w->recoverOn) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body"); colorSpill = true; }
+					if (w->h_dstate->c.nUncolored != 0)
+					{
+						if (!w->recoverOn) return setError(B2HIP_ERR_CAPACITY, "incremental colouring did not converge");
+						roundsToo = true;
+						c.nUncolored = w->h_dstate->c.nUncolored;
+						w->colorRecoveries += 1;
+						if (getenv("B2HIP_TRACE_RECOVERY")) fprintf(stderr, "[b2hip] k_color_small left %d constraints without a colour: the grid-wide rounds finish\n", c.nUncolored);
+					}
 				}
 			}
-			else
+			else roundsToo = true;
+			if (roundsToo)
 			{
 			// a colour clash on some body -> colour the large islands from scratch; otherwise only the
 			// constraints that have no colour yet join the Jones-Plassmann rounds (existing masks stay)
@@ -678,12 +690,35 @@ static int phaseSolve(b2hip_world* w)
 				if (rc) return rc;
 				uncolored = w->h_dstate->c.nUncolored;
 				nColors = w->h_dstate->c.nColors;
-				if (w->h_dstate->c.overflow & 4) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body");
+				if (w->h_dstate->c.overflow & 4) { if (!w->recoverOn) return setError(B2HIP_ERR_CAPACITY, "more than 64 constraint colours on one body"); colorSpill = true; }
 				batch = 8;
 			}
 			if (w->freshColorsPending) { w->freshColors = nColors < 63 ? nColors : 63; w->freshColorsPending = false; }
 			}
 		}
+		if (colorSpill) w->colorRecoveries += 1;
+		// (a constraint without a colour carries HUB_COLOR: the colours to launch end below it)
+		if (!exactLarge && nColors > HUB_COLOR) nColors = HUB_COLOR;
+		// ---- the row layout and the solver proper, as ONE unit that can run a second time in its SAFE form (round 6, VERDICT r05
+		// item 5): b2World::Step has no failure path (b2World.cpp:1613-1710), and a wait between workgroups that times out - a
+		// co-tenant on the device, a workgroup that was not resident - used to fail the step and leave a dead world. The unit
+		// saves what the solver changes (k_solver_snapshot: rows of the large islands' bodies, impulses and flags of their
+		// contacts, their joints) before its first solver launch; behind its last one a one-lane kernel publishes the overflow
+		// word, the host looks at it (a poll of mapped memory: ~5 us with the next launch's latency - only where the unit used a
+		// kernel whose workgroups wait for one another), and on a timed-out wait puts the saved state back and runs the unit
+		// again on the plain path: rows by colour, a launch per colour, tail colours and hub rows in k_sweep_end's ONE workgroup -
+		// nothing in it waits for another workgroup. Same colouring, same arithmetic, same order on every body: the bits the
+		// fast path would have produced (tests/test_gpu_recovery.py).
+		bool waitsBetweenWorkgroups = false;
+		auto runLarge = [&](const bool safe) -> int
+		{
+		if (safe)
+		{
+			usePersistent = useBlocks = useSweep = useResident = false;
+			colorsOnDevice = false;
+			d.blockSort = 0;
+		}
+		if (colorSpill) hasHubs = true; // (k_hub_flag lists the constraints that found no colour)
 		if (!d.blockSort) LAUNCH(w, k_color_scan, 1, 1, d); // (segments by colour: the block solvers sort their rows themselves)
 		// ---- the end of every sweep without a launch per colour (b2d_kernels_sweep_end.h). The REST colours - from the highest
 		// colour down while this step's colour census (k_color_check, published with the island census) keeps them below
@@ -692,7 +727,7 @@ static int phaseSolve(b2hip_world* w)
 		// a launch-count matter. Not on a step that colours afresh: its census is void.
 		const bool useSweepEnd = w->sweepEnd && !exactLarge && !w->debugTrace;
 		int restFirst = 0x7fffffff; // (none)
-		if (useSweepEnd && w->restFlow && !d.blockSort && !c.needRecolor && !censusVoid && nColors > 0 && nColors < MAX_COLORS)
+		if (useSweepEnd && w->restFlow && !safe && !d.blockSort && !c.needRecolor && !censusVoid && nColors > 0 && nColors < MAX_COLORS)
 		{
 			long long sum = 0;
 			int t = nColors;
@@ -729,6 +764,8 @@ static int phaseSolve(b2hip_world* w)
 			return gridFor((size_t)c.colorRows[col] + 512, kLanes, 1 << 16);
 		};
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
+		waitsBetweenWorkgroups = useResident || useSweep || (useSweepEnd && restFirst < nColors);
+		if (!safe && w->recoverOn && waitsBetweenWorkgroups) LAUNCH(w, k_solver_snapshot, gridFor(std::max(nLBodies, nLContacts)), 256, d, 0);
 		if (useResident)
 		{
 			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (validation_src/b2d_validation_solvers.h)
@@ -793,7 +830,7 @@ static int phaseSolve(b2hip_world* w)
 		}
 		// (timing mode 5: ONE event pair around the whole large-island solver family of the launch-per-colour path - integrate,
 		// constraint set-up, every sweep, impulses stored, positions, write-back and sleep)
-		if (w->kernelTiming == 5) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 8; w->familyLaunchesAtStart = w->launchCount; }
+		if (w->kernelTiming == 5 && !safe) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 8; w->familyLaunchesAtStart = w->launchCount; }
 		LAUNCH(w, k_large_integrate, gB, 256, d, sp);
 		if (w->debugTrace) HIP_TRY(hipMemcpyAsync(w->dbgVel.p, w->b_vel.p, w->bodies.size() * 16, hipMemcpyDeviceToDevice, w->stream));
 		TRACE("integrate");
@@ -1014,7 +1051,59 @@ static int phaseSolve(b2hip_world* w)
 		LAUNCH(w, k_large_finalize, gB, 256, d, sp);
 		TRACE("finalize");
 		LAUNCH(w, k_large_sleep, gB, 256, d, sp);
+		return 0;
+		};
+		rc = runLarge(false);
+		if (rc) return rc;
 		if (w->kernelTiming == 5 && w->ktKind == 8) { w->familyLaunches = (int)(w->launchCount - w->familyLaunchesAtStart); rc = ktRecord(w); if (rc) return rc; }
+		if (w->recoverOn && waitsBetweenWorkgroups)
+		{
+			// did every wait come to its end? (the overflow word, published by one lane behind the solver; polled)
+			w->solverSeq = (w->solverSeq + 1) & 0x7fff;
+			LAUNCH(w, k_solver_status, 1, 64, d, w->d_solverWord, w->solverSeq);
+			rc = pollPublished(w, (volatile const int*)&w->h_solverWord[1], w->solverSeq, "solver status");
+			if (rc) return rc;
+			const int flags = w->h_solverWord[0];
+			// (a resident solver read the colours on the device: were they complete?)
+			const bool colorsBad = colorsOnDevice && ((flags & 4) != 0 || w->h_solverWord[2] != 0);
+			if (colorsOnDevice) w->colorSmallPending = false; // (looked at here)
+			if ((flags & 64) || colorsBad)
+			{
+				if (w->tracePartition || getenv("B2HIP_TRACE_RECOVERY")) fprintf(stderr, "[b2hip] a wait between workgroups of the large-island solver timed out (overflow 0x%x): saved state back, the solve once more launch by launch\n", flags);
+				LAUNCH(w, k_solver_snapshot, gridFor(std::max(nLBodies, nLContacts)), 256, d, 1);
+				LAUNCH(w, k_solver_recover_reset, gridFor(d.nBodies), 256, d, w->gridBar.p);
+				w->restArrived = 0;
+				rc = readState(w);
+				if (rc) return rc;
+				if (colorsBad)
+				{
+					if (getenv("B2HIP_TRACE_RECOVERY")) fprintf(stderr, "[b2hip] the resident solver ran on an incomplete colouring (overflow 0x%x, %d without a colour): colouring finished, the solve once more\n", flags, w->h_solverWord[2]);
+					// finish the colouring first: the grid-wide rounds over what k_color_small left open
+					int uncolored = w->h_dstate->c.nUncolored;
+					while (uncolored > 0)
+					{
+						for (int r = 0; r < 8; ++r)
+						{
+							LAUNCH(w, k_color_claim, gC, 256, d);
+							LAUNCH(w, k_color_resolve, gC, 256, d);
+						}
+						rc = readState(w);
+						if (rc) return rc;
+						uncolored = w->h_dstate->c.nUncolored;
+					}
+					if (w->h_dstate->c.overflow & 4) colorSpill = true;
+					censusVoid = true;
+					w->colorRecoveries += 1;
+				}
+				nColors = w->h_dstate->c.nColors;
+				if (nColors > HUB_COLOR) nColors = HUB_COLOR;
+				c.nColors = nColors;
+				memcpy(c.colorRows, w->h_dstate->c.colorRows, sizeof(c.colorRows));
+				if (flags & 64) w->solverRecoveries += 1;
+				rc = runLarge(true);
+				if (rc) return rc;
+			}
+		}
 		TRACE("sleep");
 		if (sideStream) HIP_TRY(hipStreamWaitEvent(w->stream, w->evJoin, 0));
 		stampPhase(w, 8);

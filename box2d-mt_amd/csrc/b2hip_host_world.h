@@ -160,8 +160,9 @@ struct b2hip_world
 	DevArray<int> c_color[2], c_mgr[2];
 	DevArray<int4> li_ref;
 	DevArray<uint64_t> ht_keys;
-	DevArray<RevoluteJoint> d_joints;
-	DevArray<GearRec> d_gears;
+	DevArray<RevoluteJoint> d_joints, solveSnapJoints;
+	DevArray<GearRec> d_gears, solveSnapGears;
+	DevArray<float4> solveSnapBody, solveSnapImp; DevArray<uint32_t> solveSnapCFlags; // k_solver_snapshot (b2d_kernels_sweep_end.h)
 	DevArray<int> jadjStart, jadj, rootJointStart, rootJointCursor, lj_list, rootJointOkay;
 	std::vector<std::pair<int, int> > pendingFilter; // body pairs whose contacts must be re-filtered (new joint)
 	int nMouseJoints = 0;
@@ -310,6 +311,13 @@ struct b2hip_world
 	bool colorAheadOff = false;  // B2HIP_NO_COLOR_AHEAD=1: round 5's flow (the queued k_color_small returns where there is no partition, the colour count comes by copy)
 	bool noCensusGrid = false;   // B2HIP_NO_CENSUS_GRID=1: every colour launch sized from the mean colour (round 5)
 	int colorLanes = 256;        // lanes per workgroup of a colour launch (k_large_velocity / k_large_position; B2HIP_COLOR_LANES = 64 | 128 | 256)
+	bool recoverOn = true;       // a timed-out wait between workgroups of the large-island solver is recovered from (saved state back, the
+	                             // solve once more launch by launch; B2HIP_NO_RECOVER=1: the step fails as in round 5)
+	int* h_solverWord = nullptr; // mapped host memory: [0] the overflow word behind the solver, [1] the publication's number (k_solver_status)
+	int* d_solverWord = nullptr;
+	int solverSeq = 0;
+	int colorRecoveries = 0;     // steps whose colouring ran out of colours / of rounds and went on (swept in order / finished by the grid-wide rounds)
+	int solverRecoveries = 0;    // solves run a second time so far (b2hip_get_counters: solver_recoveries)
 	int restHub = 2;             // k_large_rest + k_sweep_end of a sweep as ONE launch (k_rest_hub; B2HIP_REST_HUB=0: two launches, 1: the velocity sweeps only)
 	int restHubMaxWG = 0;        // co-resident workgroups of k_rest_hub (0: do not use it)
 	int restMaxWG = 0;           // ... of k_large_rest (0: unknown)
@@ -834,6 +842,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(d_shapes, std::max<size_t>(w->shapes.size(), 1));
 	ENS(d_joints, std::max<size_t>(w->joints.size(), 1));
 	ENS(d_gears, std::max<size_t>(w->gears.size(), 1));
+	ENS(solveSnapJoints, w->recoverOn ? std::max<size_t>(w->joints.size(), 1) : 1); ENS(solveSnapGears, w->recoverOn ? std::max<size_t>(w->gears.size(), 1) : 1);
 	ENS(jadjStart, nb + 2); ENS(jadj, 2 * w->joints.size() + 2); ENS(rootJointStart, nb + 2); ENS(rootJointCursor, nb);
 	ENS(lj_list, w->joints.size() + 2); ENS(rootJointOkay, nb);
 	const size_t capPairs = std::max<size_t>(std::max<size_t>(8 * np + 4096, w->pairKey.cap), w->pairCapHint);
@@ -862,7 +871,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	ENS(b_slot, nb); ENS(b_island, nb); ENS(chunkFirst, (nb + cc) / (TINY_CHUNK_LANES / 2) + 4);
 	ENS(li_bodies, nb); ENS(li_contacts, cc); ENS(li_roots, nb); ENS(li_color, cc);
 	ENS(colorCount, cc + 2 + COLOR_SLOT_PADDED * COLOR_SLOT_STRIDE); ENS(colorStart, cc + 2); ENS(colorCursor, cc + 2 + COLOR_SLOT_PADDED * COLOR_SLOT_STRIDE); ENS(li_sorted, cc); ENS(li_ref, cc); // (colorSlot: the first 65 colour counters on a line each)
-	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(bodyRest, nb); ENS(b_posv, nb); ENS(dfRank, B2HIP_HAVE_VALIDATION_SOLVERS ? nb * 32 : 1); ENS(dfInbox, B2HIP_HAVE_VALIDATION_SOLVERS ? 2 * cc : 1); /* (mailbox tables of the test build's k_solve_mailbox: DF_RANKS = 32 slots per body) */ ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(hubMeta, 8); ENS(hubFirst, nb); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
+	ENS(bodyClaim, nb); ENS(bodyColorMask, nb); ENS(bodyActive, nb); ENS(bodyRest, nb); ENS(b_posv, nb); ENS(dfRank, B2HIP_HAVE_VALIDATION_SOLVERS ? nb * 32 : 1); ENS(dfInbox, B2HIP_HAVE_VALIDATION_SOLVERS ? 2 * cc : 1); /* (mailbox tables of the test build's k_solve_mailbox: DF_RANKS = 32 slots per body) */ ENS(evKey, cc); ENS(evInfo, cc); ENS(uncolList, COLOR_SMALL_MAX); ENS(compactList, COLOR_SMALL_MAX); ENS(hubRowOf, cc); ENS(hubList, cc); ENS(hubDelta, cc); ENS(hubMeta, 8); ENS(hubFirst, nb); ENS(solveSnapBody, w->recoverOn ? 6 * nb : 1); ENS(solveSnapImp, w->recoverOn ? cc : 1); ENS(solveSnapCFlags, w->recoverOn ? cc : 1); ENS(rootPen, ROOT_PEN_SLOTS * nb); ENS(rootDone, nb); ENS(rootSleepMin, nb);
 	if (w->lc.cap < (size_t)LC_WORDS * cc)
 	{
 		rc = w->lc.ensure((size_t)LC_WORDS * cc, s, false, false);
@@ -936,6 +945,10 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	// or contacts) are walked in the reference's order, bit-exact; B2HIP_SMALL_MAX_W (<= 512) moves the line.
 	d.smallMaxW = TINY_ISLAND_MAX_W;
 	d.noFreeBodies = getenv("B2HIP_NO_FREE_BODIES") && atoi(getenv("B2HIP_NO_FREE_BODIES")) ? 1 : 0;
+	d.testMaxColors = getenv("B2HIP_TEST_MAX_COLORS") ? atoi(getenv("B2HIP_TEST_MAX_COLORS")) : 0;
+	d.testColorRounds = getenv("B2HIP_TEST_COLOR_ROUNDS") ? atoi(getenv("B2HIP_TEST_COLOR_ROUNDS")) : 0;
+	d.testSpinMax = getenv("B2HIP_TEST_SPIN_MAX") ? std::max(0, atoi(getenv("B2HIP_TEST_SPIN_MAX"))) : 0;
+	d.restPoll = getenv("B2HIP_REST_POLL") ? std::max(1, std::min(16, atoi(getenv("B2HIP_REST_POLL")))) : 1;
 	d.hubSerial = getenv("B2HIP_HUB_SERIAL") && atoi(getenv("B2HIP_HUB_SERIAL")) ? 1 : 0;
 	w->hubWaves = getenv("B2HIP_HUB_WAVES") && atoi(getenv("B2HIP_HUB_WAVES")) == 1 ? 1 : 8; // (1: the one-wave form, for comparison)
 	// The end of a sweep over islands that run launch per colour - tail colours, hub rows, joints, the verdict of a position
@@ -977,7 +990,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		d.ca[k].color = w->c_color[k].p; d.ca[k].mgr = w->c_mgr[k].p;
 	}
 	d.ht_keys = w->ht_keys.p;
-	d.joints = w->d_joints.p;
+	d.joints = w->d_joints.p; d.solveSnapJoints = w->solveSnapJoints.p; d.solveSnapGears = w->solveSnapGears.p; d.solveSnapBody = w->solveSnapBody.p; d.solveSnapImp = w->solveSnapImp.p; d.solveSnapCFlags = w->solveSnapCFlags.p;
 	d.gears = w->d_gears.p;
 	d.jadjStart = w->jadjStart.p; d.jadj = w->jadj.p; d.rootJointStart = w->rootJointStart.p;
 	d.rootJointCursor = w->rootJointCursor.p; d.lj_list = w->lj_list.p; d.rootJointOkay = w->rootJointOkay.p;

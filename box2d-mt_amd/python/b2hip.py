@@ -114,7 +114,7 @@ class Counters(C.Structure):
         "colors", "moved_proxies", "new_contacts", "destroyed_contacts", "solver_chunks",
         "pos_iterations_large", "overflow_flags", "toi_events", "toi_calls", "toi_pending_first_pass", "toi_serial_fallbacks",
         "blocks", "cut_constraints", "block_max_rows", "partitions", "block_solver_steps", "free_islands", "sweep_solver_steps",
-        "hub_constraints", "hub_fixpoint_rounds", "hub_serial_chunks", "toi_chain_contacts", "toi_pre_solve_reruns")]
+        "hub_constraints", "hub_fixpoint_rounds", "hub_serial_chunks", "toi_chain_contacts", "toi_pre_solve_reruns", "solver_recoveries")]
 
 
 BODY_STATE_DTYPE = np.dtype([("px", "f4"), ("py", "f4"), ("angle", "f4"), ("vx", "f4"), ("vy", "f4"), ("w", "f4"),

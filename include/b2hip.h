@@ -321,6 +321,9 @@ typedef struct b2hip_counters
 	int32_t hub_serial_chunks;       /* chunks of 64 hub constraints swept lane after lane instead */
 	int32_t toi_chain_contacts;      /* contacts (since creation) the parallel TOI chains left for their close-out to create in event order */
 	int32_t toi_pre_solve_reruns;    /* runs of the TOI phase (since creation) repeated because a PreSolve changed its contact inside a sub-step */
+	int32_t solver_recoveries;       /* large-island solves (since creation) run a second time, launch by launch, because a wait between the
+	                                    workgroups of a resident / data-flow solver kernel timed out, or whose colouring ran out of colours (such constraints are
+	                                    swept in order) or of rounds (finished grid-wide); the step itself succeeds (B2HIP_NO_RECOVER=1: it fails as before) */
 } b2hip_counters;
 
 const char* b2hip_last_error(void);

@@ -1,0 +1,69 @@
+"""GPU tests of the windows bench.py TIMES: the default mode - coloured order on the large islands - run to
+the settled state of BASELINE configs 3, 4 (one share) and 2 and compared with aggregates of the REFERENCE BUILD's run to the
+same steps (tests/golden/settled_windows.npz, made by tests/golden/make_golden_settled.py from oracle/_ref).
+
+By step 700 of the Tumbler (320 of Pyramid 316, 240 of Pyramid 141) the device's trajectory and the reference's have long parted:
+a reordered Gauss-Seidel sweep is a different, equally valid iteration, and a pile of 100 000 boxes multiplies any difference by
+~1.6 per step while it moves (tools/gpu_r06_lockstep.py). What any valid order must deliver is the same PILE: as many contacts,
+as many of them touching, the same penetration left by 8 + 3 iterations, the same weight carried, the same energy and speeds,
+the container where its motor puts it. Bounds, on window means over 16 samples (every 4th step of 61):
+  * contact count, touching contacts, summed normal impulse, mean speed, kinetic energy: within 2 % of the reference's
+    (measured: see the table the test writes to gpurun_out/settled_windows_<scene>.txt; the committed copy is in profiles/);
+  * penetration (p99, mean): the device's <= 1.02 x the reference's (a better solution is no failure) ...
+  * extremes of a single body / point (deepest penetration, top speed): <= 1.25 x - one sample of an extreme value;
+  * the container's angle: within 1e-3 rad at every sample (a motor with torque to spare: the same angle whatever the pile does).
+Run-to-run determinism of the same window is asserted in tests/test_gpu_configs_full_size.py and test_gpu_sweep_end.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import b2harness as bh
+import quality_util as qu
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "settled_windows.npz")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# key: (lower bound, upper bound) of device window mean / reference window mean
+RATIO_BOUNDS = {"contacts": (0.98, 1.02), "touching": (0.98, 1.02), "impulse_sum": (0.98, 1.02), "speed_mean": (0.98, 1.02),
+                "kinetic_energy": (0.98, 1.02), "penetration_p99": (0.0, 1.02), "penetration_mean": (0.0, 1.02),
+                "penetration_max": (0.0, 1.25), "speed_max": (0.0, 1.25)}
+# per scene overrides, each with the measurement that asks for it (profiles/r06_settled_windows_*.txt)
+OVERRIDES = {}
+
+
+@pytest.mark.parametrize("name", ["config2_pyramid141", "config4_pyramid316", "config3_tumbler316"])
+def test_settled_window_matches_the_reference_builds_aggregates(amd, name):
+    g = np.load(GOLDEN)
+    sc, p0, p1, seed, flags, first, last, every = (int(v) for v in g[name + "/params"])
+    keys = [str(k) for k in g[name + "/keys"]]
+    ref = g[name + "/table"]
+    w = amd.world(sc, p0, p1, seed=seed, flags=flags)
+    w.step(first)
+    steps, dev = qu.window(w, first, last, every)
+    w.close()
+    assert list(steps) == list(g[name + "/steps"])
+    assert np.isfinite(dev).all()
+    lines = ["%s: device (default mode) / reference build, samples at steps %d..%d every %d" % (name, first, last, every),
+             "step  " + "  ".join(keys)]
+    for i, s in enumerate(steps):
+        lines.append("%4d  " % s + "  ".join("%.6g/%.6g" % (dev[i, j], ref[i, j]) for j in range(len(keys))))
+    dm, rm = dev.mean(axis=0), ref.mean(axis=0)
+    lines.append("mean  " + "  ".join("%.6g/%.6g (%.4f)" % (dm[j], rm[j], dm[j] / rm[j] if rm[j] else 1.0) for j in range(len(keys))))
+    report = "\n".join(lines)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "settled_windows_%s.txt" % name), "w") as f:
+            f.write(report + "\n")
+    bounds = dict(RATIO_BOUNDS, **OVERRIDES.get(name, {}))
+    for j, k in enumerate(keys):
+        if k == "angle_body1":
+            if sc == bh.TUMBLER:
+                assert np.abs(dev[:, j] - ref[:, j]).max() < 1e-3, "%s: the container's angle\n%s" % (name, report)
+            continue
+        lo, hi = bounds[k]
+        ratio = dm[j] / rm[j] if rm[j] else 1.0
+        assert lo <= ratio <= hi, "%s: window mean of %s is %.4f x the reference build's (bounds %.2f .. %.2f)\n%s" % (name, k, ratio, lo, hi, report)

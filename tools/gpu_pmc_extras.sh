@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; OUT=gpurun_out/r05_u; rm -rf $OUT; mkdir -p $OUT
+set -u
+cd "${GRAFT_REPO_ROOT:?}" || exit 1; export TMPDIR=/tmp; OUT=gpurun_out/r05_u; rm -rf "$OUT"; mkdir -p "$OUT"
 for spec in "pyramid316 1 316 1 340 ccd k_solve_blocks" "field1000000 3 1000000 10000 50 ccd k_solve_small"; do
   set -- $spec
   for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -2,11 +2,13 @@
 # Round 5, final set: GPU suite, bench line, the headline workload under rocprofv3 (kernel stats + PMC traffic of the solver
 # family), settled-window budgets of configs 3 / 4-share / 5 / 2, the component-wise TOI loops' phase budget, the one-GPU proxy
 # of a spatially sharded rank. usage: tools/gpu_r05_final.sh <tag> [notests]
-cd $GRAFT_REPO_ROOT
+set -u
+: "${1:?usage: gpu_r05_final.sh <tag> [notests]}"
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
-OUT=gpurun_out/$1
-rm -rf $OUT; mkdir -p $OUT
-if [ "$2" != "notests" ]; then
+OUT="gpurun_out/$1"
+rm -rf "$OUT"; mkdir -p "$OUT"
+if [ "${2:-}" != "notests" ]; then
   timeout 1500 python3 -m pytest tests -q -m gpu > $OUT/pytest_gpu.txt 2>&1
   grep -a "passed\|failed" $OUT/pytest_gpu.txt | tail -2
   timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt

@@ -1,10 +1,12 @@
 #!/bin/bash
 # Round 5: kernel trace + PMC traffic of the headline workload (config 3, the settled Tumbler) and the N = 2 bench path on one GPU.
 # usage: tools/gpu_r05_profile.sh <tag>
-cd $GRAFT_REPO_ROOT
+set -u
+: "${1:?usage: gpu_r05_profile.sh <tag>}"
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
-OUT=gpurun_out/$1
-rm -rf $OUT; mkdir -p $OUT
+OUT="gpurun_out/$1"
+rm -rf "$OUT"; mkdir -p "$OUT"
 ( export B2_BENCH_SHARE_GPU=1 B2_BENCH_BACKEND=gloo; timeout 900 python3 bench.py --gpus 2 --steps 10 --warmup 5 --tumbler 100 --no-extras --no-secondary > $OUT/bench_n2_shared_gpu_gloo.json 2> $OUT/bench_n2.err; echo "n2 rc=$?" )
 tail -3 $OUT/bench_n2.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-extras --no-long-window > $OUT/stats.log 2>&1
