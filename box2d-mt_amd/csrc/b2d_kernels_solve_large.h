@@ -49,10 +49,28 @@ __device__ __forceinline__ void lcLoad(const DW& W, int row, ContactConstraint& 
 }
 
 // ---- bodies --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_large_integrate(DW W, StepParams sp)
+// `sortJoints`: ... and every large island's joint list put in ascending joint order (k_joints_sort's loop, one lane per
+// island: a launch of its own in the chain before round 6).
+__global__ __launch_bounds__(256) void k_large_integrate(DW W, StepParams sp, int sortJoints)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
+	if (sortJoints)
+	{
+		const int nI = S->c.nLIslands;
+		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nI; k += gridDim.x * blockDim.x)
+		{
+			const int root = W.li_roots[k];
+			const int s0 = W.rootJointStart[root], e = s0 + W.rootJoints[root];
+			for (int a = s0 + 1; a < e; ++a)
+			{
+				const int v = W.lj_list[a];
+				int b = a - 1;
+				while (b >= s0 && W.lj_list[b] > v) { W.lj_list[b + 1] = W.lj_list[b]; --b; }
+				W.lj_list[b + 1] = v;
+			}
+		}
+	}
 	const int n = S->c.nLBodies;
 	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
 	{
@@ -1664,6 +1682,58 @@ __global__ __launch_bounds__(256) void k_large_pos_begin(DW W)
 		W.rootPen[W.li_roots[k]] = 0;
 		W.rootJointOkay[W.li_roots[k]] = 1;
 	}
+}
+
+// Between the last velocity sweep and the first position iteration, in ONE launch (round 6: three launches of ~5, ~17 and ~5 us
+// in a chain of dependent launches): k_large_store_impulses (rows), k_large_integrate_positions (bodies), k_large_pos_begin
+// (islands) - three loops over different things, none of which reads what another writes.
+__global__ __launch_bounds__(256) void k_large_after_velocity(DW W, StepParams sp)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	{
+		const int n = S->c.nLContacts;
+		for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x)
+		{
+			const int ci = W.li_ref[row].x;
+			ContactConstraint cc;
+			memset(&cc, 0, sizeof(cc));
+			lcLoad(W, row, cc, LC_IMP_FIRST, LC_IMP_FIRST + 4);
+			lcLoad(W, row, cc, 35, 36);
+			if (W.postSolveOn)
+			{
+				lcLoad(W, row, cc, LC_WORDS - 1, LC_WORDS); // pcPointCount: the manifold's own count
+				if (cc.pointCount < cc.pcPointCount) C.flags[ci] |= CF_VC_ONE_POINT;
+			}
+			float4 im = C.imp[ci];
+			if (cc.pointCount > 0) { im.x = cc.normalImpulse[0]; im.y = cc.tangentImpulse[0]; }
+			if (cc.pointCount > 1) { im.z = cc.normalImpulse[1]; im.w = cc.tangentImpulse[1]; }
+			C.imp[ci] = im;
+		}
+	}
+	{
+		const int n = S->c.nLBodies;
+		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+		{
+			const int body = W.li_bodies[k];
+			float4 p = W.b_pos[body], v = W.b_vel[body];
+			V2 c = v2(p.x, p.y), vv = v2(v.x, v.y);
+			float a = p.z, w = v.z;
+			b2dIntegratePosition(&c, &a, &vv, &w, sp.dt);
+			W.b_pos[body] = make_float4(c.x, c.y, a, p.w);
+			W.b_vel[body] = make_float4(vv.x, vv.y, w, 0.0f);
+		}
+	}
+	{
+		const int n = S->c.nLIslands;
+		for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+		{
+			W.rootPen[W.li_roots[k]] = 0;
+			W.rootJointOkay[W.li_roots[k]] = 1;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) S->c.allLargeDone = 0;
 }
 
 __global__ __launch_bounds__(256) void k_large_position(DW W, int color)

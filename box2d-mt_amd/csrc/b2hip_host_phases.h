@@ -421,8 +421,15 @@ static int phaseSolve(b2hip_world* w)
 	{
 		const int cap1024 = plainIslands ? w->blocksMaxWG : w->sweepMaxWG[2];
 		const bool was = w->blocksTooBig;
-		if (!w->blocksTooBig && cap1024 > 0 && c.nLContacts > 800 * cap1024) w->blocksTooBig = true;
-		else if (w->blocksTooBig && c.nLContacts < 650 * cap1024) w->blocksTooBig = false;
+		// (round 6: islands with joints / hubs leave the block sweeps much earlier - k_blocks_sweep is a launch per sweep whose
+		// cut constraints go from workgroup to workgroup through memory, ~45 us per sweep with 256-lane blocks but ~78 us with the
+		// 1024-lane blocks an island above ~60 000 constraints needs, while launch per colour with the top colours as rest
+		// rows and the hub in the same launch has come down to ~70 us there: the Tumbler with 10 000 boxes 1.19 ms per step in
+		// blocks against 1.45 without, with 22 500 boxes 1.92 against 1.61 (profiles/r06_sweep_blocks_crossover.txt))
+		const long long tooBigAt = plainIslands ? 800ll * cap1024 : std::min<long long>(800ll * cap1024, w->sweepRowsMax);
+		const long long fitsAgainAt = plainIslands ? 650ll * cap1024 : std::min<long long>(650ll * cap1024, (long long)w->sweepRowsMax * 13 / 16);
+		if (!w->blocksTooBig && cap1024 > 0 && c.nLContacts > tooBigAt) w->blocksTooBig = true;
+		else if (w->blocksTooBig && c.nLContacts < fitsAgainAt) w->blocksTooBig = false;
 		if (w->blocksTooBig && c.nBlocks > 0 && forceLarge != 2 && !w->noBlocks)
 		{
 			if (w->tracePartition) fprintf(stderr, "[b2hip] partition dissolved: %d constraints in large islands, %d blocks of %d lanes (room for %d)\n", c.nLContacts, c.nBlocks, c.blkLanes, cap1024);
@@ -831,10 +838,11 @@ static int phaseSolve(b2hip_world* w)
 		// (timing mode 5: ONE event pair around the whole large-island solver family of the launch-per-colour path - integrate,
 		// constraint set-up, every sweep, impulses stored, positions, write-back and sleep)
 		if (w->kernelTiming == 5 && !safe) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 8; w->familyLaunchesAtStart = w->launchCount; }
-		LAUNCH(w, k_large_integrate, gB, 256, d, sp);
+		const bool sortInIntegrate = hasJoints && !exactLarge && !w->debugTrace;
+		LAUNCH(w, k_large_integrate, gB, 256, d, sp, sortInIntegrate ? 1 : 0);
 		if (w->debugTrace) HIP_TRY(hipMemcpyAsync(w->dbgVel.p, w->b_vel.p, w->bodies.size() * 16, hipMemcpyDeviceToDevice, w->stream));
 		TRACE("integrate");
-		if (hasJoints && !exactLarge) LAUNCH(w, k_joints_sort, gJ, 64, d);
+		if (hasJoints && !exactLarge && !sortInIntegrate) LAUNCH(w, k_joints_sort, gJ, 64, d);
 		// (the warm start body by body in one launch - k_large_warm - where the sweep would be a launch per colour: k_large_init
 		// leaves the deltas for it)
 		const bool bodyWarm = w->bodyWarm && w->sweepEnd && !exactLarge && !w->debugTrace && !useSweep && sp.warmStarting && nColors <= MAX_COLORS;
@@ -1017,13 +1025,19 @@ static int phaseSolve(b2hip_world* w)
 				else if (hasHubs) { rc = hubSweepLaunch(1, it > 0 ? 1 : 0); if (rc) return rc; }
 			}
 		}
-		LAUNCH(w, k_large_store_impulses, gC, 256, d);
-		TRACE("store_impulses");
-		LAUNCH(w, k_large_integrate_positions, gB, 256, d, sp);
-		TRACE("integrate_positions");
+		// (one launch for the three: k_large_after_velocity; apart where a trace wants to see each)
+		const bool afterFused = !w->debugTrace && sp.posIters > 0;
+		if (afterFused) LAUNCH(w, k_large_after_velocity, gridFor(std::max(nLContacts, nLBodies)), 256, d, sp);
+		else
+		{
+			LAUNCH(w, k_large_store_impulses, gC, 256, d);
+			TRACE("store_impulses");
+			LAUNCH(w, k_large_integrate_positions, gB, 256, d, sp);
+			TRACE("integrate_positions");
+		}
 		for (int it = 0; it < sp.posIters; ++it)
 		{
-			if (!useSweepEnd || it == 0) LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
+			if ((!useSweepEnd || it == 0) && !(afterFused && it == 0)) LAUNCH(w, k_large_pos_begin, gridFor(nLIslands), 256, d);
 			if (useSweep) { rc = sweep(2); if (rc) return rc; }
 			else
 			for (int col = 0; col < bigEnd; ++col)

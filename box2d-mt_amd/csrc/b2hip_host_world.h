@@ -318,6 +318,7 @@ struct b2hip_world
 	int solverSeq = 0;
 	int colorRecoveries = 0;     // steps whose colouring ran out of colours / of rounds and went on (swept in order / finished by the grid-wide rounds)
 	int solverRecoveries = 0;    // solves run a second time so far (b2hip_get_counters: solver_recoveries)
+	int sweepRowsMax = 60000;    // islands with joints / hubs above this many constraints run launch per colour, not k_blocks_sweep (B2HIP_SWEEP_ROWS_MAX)
 	int restHub = 2;             // k_large_rest + k_sweep_end of a sweep as ONE launch (k_rest_hub; B2HIP_REST_HUB=0: two launches, 1: the velocity sweeps only)
 	int restHubMaxWG = 0;        // co-resident workgroups of k_rest_hub (0: do not use it)
 	int restMaxWG = 0;           // ... of k_large_rest (0: unknown)
@@ -968,6 +969,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	w->colorAheadOff = getenv("B2HIP_NO_COLOR_AHEAD") && atoi(getenv("B2HIP_NO_COLOR_AHEAD"));
 	w->noCensusGrid = getenv("B2HIP_NO_CENSUS_GRID") && atoi(getenv("B2HIP_NO_CENSUS_GRID"));
 	if (const char* e = getenv("B2HIP_COLOR_LANES")) { const int v = atoi(e); w->colorLanes = v == 64 ? 64 : (v == 128 ? 128 : 256); }
+	if (getenv("B2HIP_SWEEP_ROWS_MAX")) w->sweepRowsMax = std::max(1, atoi(getenv("B2HIP_SWEEP_ROWS_MAX")));
 	w->restHub = getenv("B2HIP_REST_HUB") ? std::max(0, std::min(2, atoi(getenv("B2HIP_REST_HUB")))) : 2;
 	w->restRowsMax = getenv("B2HIP_REST_ROWS") ? std::min(atoi(getenv("B2HIP_REST_ROWS")), REST_ROWS_MAX - COLOR_SMALL_MAX) : 65536;
 	w->tailRowsMax = getenv("B2HIP_TAIL_ROWS") ? atoi(getenv("B2HIP_TAIL_ROWS")) : SWEEP_END_LANES;
