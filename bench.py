@@ -64,7 +64,7 @@ PARITY_TUMBLER = ("coloured order (launch per colour + k_large_rest + k_sweep_en
 PARITY_PYRAMID = ("coloured order (k_solve_blocks): integer results exact; ONE step from a bit-identical snapshot of the timed state: "
                   "|dp| <= 1.7 cm on 1 m boxes (1.13e-4 of the 150 m scene; median 1-2 mm), |dv| <= 0.30 m/s, 18 of 30 000 contacts differ "
                   "(tests/test_gpu_onestep.py); the bit-exact class is `exact_order`")
-FAMILY_KERNELS = ("k_large_integrate", "k_large_init", "k_large_velocity", "k_large_rest", "k_rest_hub", "k_large_warm", "k_sweep_end", "k_large_position", "k_large_store_impulses",
+FAMILY_KERNELS = ("k_large_integrate", "k_large_init", "k_large_velocity", "k_large_rest", "k_rest_hub", "k_large_warm", "k_sweep_end", "k_large_position", "k_large_store_impulses", "k_large_after_velocity",
                   "k_large_integrate_positions", "k_large_pos_begin", "k_large_finalize", "k_large_sleep", "k_large_hub", "k_large_joints", "k_large_pos_end", "k_joints_sort")
 
 

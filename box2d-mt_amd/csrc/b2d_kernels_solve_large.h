@@ -194,6 +194,11 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
+	// (round 6) a world WITHOUT a partition - the settled Tumbler, whose island is beyond what the block solvers take - has no
+	// home blocks: effBlk is 0 for every body (b_blk1 and b_adopt were wiped when the partition was dissolved), no constraint
+	// is cut, every one is an "orphan". Said once here instead of found out by three or four gathers per body and constraint.
+	const bool noPart = S->c.nBlocks == 0;
+	auto isCut = [&](int bodyA, bool nsA, int bodyB, bool nsB) -> bool { return noPart ? false : constraintIsCut(W, bodyA, nsA, bodyB, nsB); };
 	int bad = 0;
 	int uncolored = 0;
 	int maxColor = 0;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		int4 ids = C.ids[i];
 		const unsigned long long bit = 1ull << col;
 		const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-		if (bit & colorStaleMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))
+		if (bit & colorStaleMask(isCut(ids.z, nsA, ids.w, nsB)))
 		{
 			// the constraint changed class (a body moved to another block, a new partition): its colour is void
 			C.color[i] = -1;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			{
 				// block census: the row belongs to the home block of its first non-static body (counted in LDS: ten
 				// thousand rows adding to a few dozen words of memory serialise in L2)
-				const int blkA = nsA ? effBlk(W, ids.z) : 0, blkB = nsB ? effBlk(W, ids.w) : 0;
+				const int blkA = (nsA && !noPart) ? effBlk(W, ids.z) : 0, blkB = (nsB && !noPart) ? effBlk(W, ids.w) : 0;
 				// (a hub's constraints belong to no block: k_large_hub sweeps them, in a segment of their own behind the blocks' rows)
 				const int owner = nsA ? blkA : blkB;
 				if (!hubA && !hubB)
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 				}
 			}
 			col = C.color[ci];
-			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorStaleMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
+			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorStaleMask(isCut(ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
 			if (hubA || hubB)
 			{
 				// a hub constraint owns no colour (and reserves none from the next step on)
@@ -499,11 +504,13 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead, int
 	{
 		__syncthreads();
 		// the census by colour as it stands now (the host sizes the colour launches and picks the rest colours from it)
-		if (run && threadIdx.x < MAX_COLORS) S->c.colorRows[threadIdx.x] = threadIdx.x == HUB_COLOR ? 0 : __hip_atomic_load(&W.colorCount[colorSlot(threadIdx.x)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (run && threadIdx.x < MAX_COLORS) S->c.colorRows[threadIdx.x] = threadIdx.x == HUB_COLOR ? 0 : __hip_atomic_load(&W.colorCount[colorSlot(threadIdx.x)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (workgroup scope like the adds above: this XCD's L2 holds them)
 		__syncthreads();
 		b2dPublishCensus(W, pub);
 	}
 }
+// (round 6: ONE workgroup runs this - its atomics and its looks at the masks and claims carry workgroup scope: they are served
+// by this XCD's L2 instead of going past it, ~0.3 us a round trip instead of 1 - 2, and a round is eight of them in a row)
 __device__ __forceinline__ void colorSmallBody(const DW& W)
 {
 	DState* S = W.st;
@@ -533,17 +540,17 @@ __device__ __forceinline__ void colorSmallBody(const DW& W)
 			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
 			const bool nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
 			uint64_t used = colorClassMask(constraintIsCut(W, ids.z, nsA, ids.w, nsB)) | colorTestMask(W);
-			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (nsA) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (nsB) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			if (used == ~0ull || __ffsll((long long)~used) - 1 >= c) continue;
 			const int slot = atomicAdd(&s_n, 1);
 			if (slot >= COLOR_SMALL_MAX) continue;
 			const unsigned long long bit = 1ull << c;
-			if (nsA) atomicAnd((unsigned long long*)&W.bodyColorMask[ids.z], ~bit);
-			if (nsB) atomicAnd((unsigned long long*)&W.bodyColorMask[ids.w], ~bit);
+			if (nsA) (void)__hip_atomic_fetch_and((unsigned long long*)&W.bodyColorMask[ids.z], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (nsB) (void)__hip_atomic_fetch_and((unsigned long long*)&W.bodyColorMask[ids.w], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			W.li_color[s] = -1;
 			C.color[ci] = -1;
-			atomicSub(&W.colorCount[colorSlot(c)], 1);
+			(void)__hip_atomic_fetch_add(&W.colorCount[colorSlot(c)], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			W.uncolList[slot] = s;
 		}
 	}
@@ -593,8 +600,8 @@ __device__ __forceinline__ void colorSmallBody(const DW& W)
 		for (int j = 0; j < PER; ++j)
 		{
 			if (!it_open[j]) continue;
-			if (it_a[j] >= 0) atomicMax(&W.bodyClaim[it_a[j]], it_pr[j]);
-			if (it_b[j] >= 0) atomicMax(&W.bodyClaim[it_b[j]], it_pr[j]);
+			if (it_a[j] >= 0) (void)__hip_atomic_fetch_max(&W.bodyClaim[it_a[j]], it_pr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (it_b[j] >= 0) (void)__hip_atomic_fetch_max(&W.bodyClaim[it_b[j]], it_pr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		__syncthreads();
 		int colored = 0;
@@ -605,20 +612,20 @@ __device__ __forceinline__ void colorSmallBody(const DW& W)
 			const int A = it_a[j], B = it_b[j];
 			const uint32_t pr = it_pr[j];
 			bool win = true;
-			if (A >= 0 && __hip_atomic_load(&W.bodyClaim[A], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
-			if (B >= 0 && __hip_atomic_load(&W.bodyClaim[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr) win = false;
+			if (A >= 0 && __hip_atomic_load(&W.bodyClaim[A], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pr) win = false;
+			if (B >= 0 && __hip_atomic_load(&W.bodyClaim[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pr) win = false;
 			if (!win) continue;
 			uint64_t used = it_class[j];
-			if (A >= 0) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[A], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (B >= 0) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (A >= 0) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[A], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (B >= 0) used |= __hip_atomic_load((unsigned long long*)&W.bodyColorMask[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			const int color = used == ~0ull ? MAX_COLORS - 1 : __ffsll((long long)~used) - 1;
 			if (used == ~0ull) atomicOr(&S->c.overflow, 4);
 			const unsigned long long bit = 1ull << color;
-			if (A >= 0) { atomicOr((unsigned long long*)&W.bodyColorMask[A], bit); __hip_atomic_store(&W.bodyClaim[A], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-			if (B >= 0) { atomicOr((unsigned long long*)&W.bodyColorMask[B], bit); __hip_atomic_store(&W.bodyClaim[B], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			if (A >= 0) { (void)__hip_atomic_fetch_or((unsigned long long*)&W.bodyColorMask[A], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&W.bodyClaim[A], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+			if (B >= 0) { (void)__hip_atomic_fetch_or((unsigned long long*)&W.bodyColorMask[B], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&W.bodyClaim[B], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 			W.li_color[it_s[j]] = color;
 			C.color[it_ci[j]] = color;
-			atomicAdd(&W.colorCount[colorSlot(color)], 1);
+			(void)__hip_atomic_fetch_add(&W.colorCount[colorSlot(color)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			atomicMax(&s_maxColor, color + 1);
 			noteColorUsed(S, color);
 			it_open[j] = false;
@@ -633,7 +640,7 @@ __device__ __forceinline__ void colorSmallBody(const DW& W)
 	{
 		int nc = S->c.nColors > s_maxColor ? S->c.nColors : s_maxColor;
 		if (nc > MAX_COLORS) nc = MAX_COLORS;
-		while (nc > 0 && __hip_atomic_load(&W.colorCount[colorSlot(nc - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) --nc;
+		while (nc > 0 && __hip_atomic_load(&W.colorCount[colorSlot(nc - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) --nc;
 		S->c.nColors = nc;
 		S->c.nUncolored = s_left;
 		S->c.colorRounds += 1;
@@ -643,6 +650,26 @@ __device__ __forceinline__ void colorSmallBody(const DW& W)
 __global__ void k_color_scan(DW W)
 {
 	b2dPhaseStamp(W);
+	// (the usual case - at most MAX_COLORS groups: one wave, a shuffle scan; the serial walk below was 64 dependent loads, ~14 us
+	// in the chain of launches before the solver)
+	if (W.st->c.nColors <= MAX_COLORS)
+	{
+		if (blockIdx.x == 0 && threadIdx.x < 64)
+		{
+			const int c = (int)threadIdx.x;
+			const int cnt = c < MAX_COLORS ? W.colorCount[colorSlot(c)] : 0;
+			int incl = cnt;
+			for (int off = 1; off < 64; off <<= 1)
+			{
+				const int o = __shfl_up(incl, off);
+				if (c >= off) incl += o;
+			}
+			W.colorStart[c] = incl - cnt;
+			if (c == 63) W.colorStart[64] = incl;
+			if (c == HUB_COLOR) W.st->c.nHubRows = cnt;
+		}
+		return;
+	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		// all MAX_COLORS groups: the regular colours [0, nColors) first, the hub group (HUB_COLOR) last

@@ -726,7 +726,7 @@ static int phaseSolve(b2hip_world* w)
 			d.blockSort = 0;
 		}
 		if (colorSpill) hasHubs = true; // (k_hub_flag lists the constraints that found no colour)
-		if (!d.blockSort) LAUNCH(w, k_color_scan, 1, 1, d); // (segments by colour: the block solvers sort their rows themselves)
+		if (!d.blockSort) LAUNCH(w, k_color_scan, 1, 64, d); // (segments by colour: the block solvers sort their rows themselves)
 		// ---- the end of every sweep without a launch per colour (b2d_kernels_sweep_end.h). The REST colours - from the highest
 		// colour down while this step's colour census (k_color_check, published with the island census) keeps them below
 		// restRowsMax rows together - are swept by ONE launch of k_large_rest, as data flow per body; k_color_fill notes them

@@ -5,7 +5,7 @@ N steps (a step begins with k_step_begin) are added up and divided by N.
 usage: pmc_family_json.py <fetch dir> <write dir> <workload key> <steps>"""
 import csv, glob, json, sys, collections
 fetch_dir, write_dir, workload, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-FAMILY = ("k_large_integrate", "k_large_init", "k_large_velocity", "k_large_rest", "k_rest_hub", "k_large_warm", "k_sweep_end", "k_large_position", "k_large_store_impulses",
+FAMILY = ("k_large_integrate", "k_large_init", "k_large_velocity", "k_large_rest", "k_rest_hub", "k_large_warm", "k_sweep_end", "k_large_position", "k_large_store_impulses", "k_large_after_velocity",
           "k_large_integrate_positions", "k_large_pos_begin", "k_large_finalize", "k_large_sleep", "k_large_hub", "k_large_joints", "k_large_pos_end", "k_joints_sort")
 
 
