@@ -486,7 +486,7 @@ __host__ __device__ inline bool b2dColorAheadNoPartition(const Counters& c, int 
 	return aheadMinRows > 0 && c.nBlocks == 0 && c.nLContacts >= aheadMinRows;
 }
 __device__ __forceinline__ void colorSmallBody(const DW& W);
-__global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead, int aheadMinRows, DState* pub)
+__global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead, int aheadMinRows, DState* pub, int pubSeq)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(1024) void k_color_small(DW W, int queuedAhead, int
 		// the census by colour as it stands now (the host sizes the colour launches and picks the rest colours from it)
 		if (run && threadIdx.x < MAX_COLORS) S->c.colorRows[threadIdx.x] = threadIdx.x == HUB_COLOR ? 0 : __hip_atomic_load(&W.colorCount[colorSlot(threadIdx.x)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (workgroup scope like the adds above: this XCD's L2 holds them)
 		__syncthreads();
-		b2dPublishCensus(W, pub);
+		b2dPublishCensus(W, pub, pubSeq); // (a buffer and a count of its own: b2d_world.h)
 	}
 }
 // (round 6: ONE workgroup runs this - its atomics and its looks at the masks and claims carry workgroup scope: they are served

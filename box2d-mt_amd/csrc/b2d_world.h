@@ -633,7 +633,10 @@ __device__ __forceinline__ void b2dBlockTreeAdd2(const DW& W, int site, int* c0,
 // pinned host copy `pub`, the number of this publication last. Called by ALL threads of one workgroup, after everything
 // the counters depend on (the island build's last kernel, its last workgroup). Cheaper than a copy behind the kernel plus
 // a stream synchronisation, and the stream can go on (k_color_small is already queued) while the host decides.
-__device__ __forceinline__ void b2dPublishCensus(const DW& W, DState* pub)
+// `seqGiven` >= 0: the publication's number comes from the host (a SECOND buffer with a count of its own: the state behind
+// k_color_small - two publications into one buffer within a few microseconds raced with the host, which polls for the
+// first one's number and copies the buffer: round 6, a step in a few hundred failed with "census was not published").
+__device__ __forceinline__ void b2dPublishCensus(const DW& W, DState* pub, int seqGiven = -1)
 {
 	DState* S = W.st;
 	// (what lane 0 has just stored into the counters with ordinary stores is written back before anybody reads it past the L2)
@@ -649,8 +652,12 @@ __device__ __forceinline__ void b2dPublishCensus(const DW& W, DState* pub)
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		const int seq = (S->pubCount + 1) & 0x3fffffff;
-		S->pubCount = seq;
+		int seq = seqGiven;
+		if (seqGiven < 0)
+		{
+			seq = (S->pubCount + 1) & 0x3fffffff;
+			S->pubCount = seq;
+		}
 		__hip_atomic_store(&pub->pubSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }

@@ -17,6 +17,7 @@
 #include <rccl/rccl.h> // (types only: the library is opened with dlopen by b2hip_shard_connect)
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <string>

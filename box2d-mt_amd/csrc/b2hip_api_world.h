@@ -204,6 +204,13 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 		return setError(B2HIP_ERR_HIP, "hipHostMalloc (coherent) failed");
 	}
 	memset(w->h_pub, 0, sizeof(DState));
+	if (hipHostMalloc((void**)&w->h_pub2, sizeof(DState), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+		hipHostGetDevicePointer((void**)&w->d_pub2, w->h_pub2, 0) != hipSuccess)
+	{
+		b2hip_world_destroy(w);
+		return setError(B2HIP_ERR_HIP, "hipHostMalloc (coherent) failed");
+	}
+	memset(w->h_pub2, 0, sizeof(DState));
 	w->recoverOn = !(getenv("B2HIP_NO_RECOVER") && atoi(getenv("B2HIP_NO_RECOVER")));
 	if (hipHostMalloc((void**)&w->h_solverWord, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
 		hipHostGetDevicePointer((void**)&w->d_solverWord, w->h_solverWord, 0) != hipSuccess)
@@ -294,6 +301,7 @@ void b2hip_world_destroy(b2hip_world* w)
 	if (w->h_state) (void)hipHostFree(w->h_state);
 	if (w->h_dstate) (void)hipHostFree(w->h_dstate);
 	if (w->h_pub) (void)hipHostFree(w->h_pub);
+	if (w->h_pub2) (void)hipHostFree(w->h_pub2);
 	if (w->h_solverWord) (void)hipHostFree(w->h_solverWord);
 	for (int i = 0; i < 13; ++i)
 		if (w->ev[i]) (void)hipEventDestroy(w->ev[i]);

@@ -381,13 +381,13 @@ static int phaseSolve(b2hip_world* w)
 		// the host's own hysteresis below - the queued launch runs too and PUBLISHES what it leaves: the launch-per-colour path
 		// polls that instead of a copy + synchronise)
 		aheadMinRows = (forceLarge != 2 && !w->colorAheadOff) ? (w->noBlocks ? 1 : (w->blocksTooBig ? 650 * std::max(w->blocksMaxWG, w->sweepMaxWG[2]) : 0)) : 0;
-		if (largeHint && forceLarge != 2) { LAUNCH(w, k_color_small, 1, 1024, d, 1, aheadMinRows, w->d_pub); colorSmallQueued = true; }
+		if (largeHint && forceLarge != 2) { LAUNCH(w, k_color_small, 1, 1024, d, 1, aheadMinRows, w->d_pub2, (w->pubSeq2 + 1) & 0x3fffffff); colorSmallQueued = true; }
 		rc = awaitCensus(w);
 		if (rc == 0)
 		{
 			const bool settled = b2dPartitionSettled(w->h_dstate->c);
 			colorAheadPublished = colorSmallQueued && b2dColorAheadNoPartition(w->h_dstate->c, aheadMinRows);
-			if (colorAheadPublished) w->pubSeq = (w->pubSeq + 1) & 0x3fffffff; // (its publication is on its way: the next one to wait for)
+			if (colorAheadPublished) w->pubSeq2 = (w->pubSeq2 + 1) & 0x3fffffff; // (its publication is on its way, with this number)
 			if (!settled && !colorAheadPublished) colorSmallQueued = false; // (it saw the same and returned)
 		}
 	}
@@ -641,8 +641,8 @@ static int phaseSolve(b2hip_world* w)
 				const bool pubColors = poll && !useResident && !w->colorAheadOff;
 				if (!colorSmallQueued)
 				{
-					LAUNCH(w, k_color_small, 1, 1024, d, 0, 0, pubColors ? w->d_pub : (DState*)nullptr); // (else: it went out behind the census)
-					if (pubColors) w->pubSeq = (w->pubSeq + 1) & 0x3fffffff;
+					if (pubColors) w->pubSeq2 = (w->pubSeq2 + 1) & 0x3fffffff;
+					LAUNCH(w, k_color_small, 1, 1024, d, 0, 0, pubColors ? w->d_pub2 : (DState*)nullptr, w->pubSeq2); // (else: it went out behind the census)
 				}
 				if (useResident)
 				{
@@ -653,7 +653,7 @@ static int phaseSolve(b2hip_world* w)
 				{
 					if ((colorSmallQueued && colorAheadPublished) || (!colorSmallQueued && pubColors))
 					{
-						rc = awaitCensus(w);
+						rc = awaitColors(w);
 						if (rc == 0) c.nColors = w->h_dstate->c.nColors;
 						if (rc == 0) memcpy(c.colorRows, w->h_dstate->c.colorRows, sizeof(c.colorRows));
 					}

@@ -357,6 +357,9 @@ struct b2hip_world
 	int stateSeq = 0;            // sequence number of the last read-back asked for (awaitState)
 	size_t h_stateCap;
 	DState* h_dstate;
+	DState* h_pub2 = nullptr;    // ... and where k_color_small publishes the state behind the colouring (a buffer and a count of its own: pubSeq2)
+	DState* d_pub2 = nullptr;
+	int pubSeq2 = 0;
 	DState* h_pub = nullptr;     // where k_block_census publishes the island census (pinned, coherent); polled by awaitCensus
 	DState* d_pub = nullptr;     // ... its device address
 	int pubSeq = 0;
@@ -820,8 +823,20 @@ static int pollPublished(b2hip_world* w, volatile const int* seq, int want, cons
 	return 0;
 }
 
+// The state behind k_color_small (published into the second buffer with the number the host gave it).
+static int awaitColors(b2hip_world* w)
+{
+	if (int rc = pollPublished(w, (volatile const int*)&w->h_pub2->pubSeq, w->pubSeq2, "colour state")) return rc;
+	memcpy(w->h_dstate, w->h_pub2, offsetof(DState, pubSeq));
+	return 0;
+}
+
 static int awaitCensus(b2hip_world* w)
 {
+	// (B2HIP_TEST_POLL_DELAY_US: the host comes late to its poll - what a descheduled thread does to it now and then;
+	// tests/test_gpu_recovery.py: a second publication must not have overwritten the first by then)
+	static const int delayUs = getenv("B2HIP_TEST_POLL_DELAY_US") ? atoi(getenv("B2HIP_TEST_POLL_DELAY_US")) : 0;
+	if (delayUs > 0) std::this_thread::sleep_for(std::chrono::microseconds(delayUs));
 	if (int rc = pollPublished(w, (volatile const int*)&w->h_pub->pubSeq, w->pubSeq, "island census")) return rc;
 	memcpy(w->h_dstate, w->h_pub, offsetof(DState, pubSeq));
 	return 0;

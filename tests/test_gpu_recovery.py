@@ -27,7 +27,7 @@ import b2hip
 pytestmark = pytest.mark.gpu
 
 KEYS = ("B2HIP_TEST_SPIN_MAX", "B2HIP_TEST_MAX_COLORS", "B2HIP_TEST_COLOR_ROUNDS", "B2HIP_NO_RECOVER", "B2HIP_SOLVER_LAUNCHES", "B2HIP_NO_REST",
-        "B2HIP_HUB_SERIAL", "B2HIP_NO_SWEEP_BLOCKS", "B2HIP_REST_HUB")
+        "B2HIP_HUB_SERIAL", "B2HIP_NO_SWEEP_BLOCKS", "B2HIP_REST_HUB", "B2HIP_NO_BLOCKS")
 CCD = bh.F_SLEEP | bh.F_WARM | bh.F_CONTINUOUS
 
 
@@ -116,3 +116,16 @@ def test_colouring_that_runs_out_goes_on(amd, monkeypatch, env, what, launches):
     boxes = sa[sa[:, 7] == 2]
     assert boxes[:, 1].min() > 0.3 and boxes[:, 1].max() < 1.05 * sr[:, 1].max() + 0.5, (boxes[:, 1].min(), boxes[:, 1].max(), sr[:, 1].max())
     assert abs(ca.contacts - cr.contacts) <= 0.02 * cr.contacts
+
+
+def test_a_host_that_polls_late_still_gets_the_census(amd, monkeypatch):
+    """A world without a partition publishes twice per step: the island census (k_block_census) and, a few microseconds to
+    ~80 us later, the state behind k_color_small. Into ONE buffer with ONE count (as first built in round 6) a host that
+    reached its poll late found the second number where it waited for the first - "island census was not published", one
+    step in a few hundred on a busy box. Two buffers, two counts now; here the host is MADE late (the delay is read once per
+    process, so this test only proves something in a process that has not polled before - it still must pass in any)."""
+    monkeypatch.setenv("B2HIP_TEST_POLL_DELAY_US", "300")
+    late, s1, _ = run(amd, monkeypatch, bh.TUMBLER, 80, {"B2HIP_NO_BLOCKS": "1"}, p0=60)
+    monkeypatch.delenv("B2HIP_TEST_POLL_DELAY_US", raising=False)
+    again, s2, _ = run(amd, monkeypatch, bh.TUMBLER, 80, {"B2HIP_NO_BLOCKS": "1"}, p0=60)
+    assert np.isfinite(s1).all() and late == again
