@@ -1076,6 +1076,103 @@ __global__ __launch_bounds__(1024) void k_hub_order(DW W, int allHubs)
 	}
 }
 
+// ---- the hub list in ONE single-workgroup launch (round 6) -------------------------------------------------------------------------
+// k_hub_flag (a pass over EVERY contact) + an exclusive scan of 2.6 M flags (three launches) + k_hub_fill + k_hub_order were
+// 56 us of the Tumbler's step for a list of ~950 rows that already lie together: the rows of the hub group are one segment
+// of the row array (k_color_fill put them there, in the order its atomics happened to run). This kernel sorts that segment in
+// place by (class, partner's highest colour, contact index) - a rank sort: every row counts the keys below its own, the keys
+// in LDS - and writes the list, the counts and what names a row (li_ref, hubRowOf) for the new places: hubList[k] = first + k.
+//   class 0: what the fixed point of k_sweep_end takes (`wide`: the primary hub's constraint with a partner that is no hub and
+//            meets the hub here for the first time) or, without it, every constraint of a hub; class 1: everything else that
+//            is swept in order. The same predicates as k_hub_flag's, the same lists in the same order as k_hub_fill + k_hub_order.
+//   `ordered`: class 0 by the partner's highest colour (k_hub_order's rule), else by contact index alone.
+// Lists longer than HUB_BUILD_LDS rows keep their keys in memory (slow: n^2 / 1024 looks per lane - the host sends worlds whose
+// last step had that many hub rows through the four launches instead).
+#define HUB_BUILD_LDS 4096
+__global__ __launch_bounds__(1024) void k_hub_build(DW W, int wideMode, int ordered, int blockSort)
+{
+	b2dPhaseStamp(W);
+	DState* S = W.st;
+	const ContactArrays& C = W.ca[S->cur];
+	const int n = W.colorCount[colorSlot(HUB_COLOR)];
+	int first = 0;
+	if (blockSort) { const int nb = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS; first = W.blkRowStart[nb]; }
+	else first = W.colorStart[HUB_COLOR];
+	const int t = (int)threadIdx.x;
+	__shared__ unsigned long long s_key[HUB_BUILD_LDS];
+	__shared__ int s_wide;
+	if (t == 0) s_wide = 0;
+	if (n <= 0 || (size_t)n * 4 > (size_t)W.capContacts)
+	{
+		// (nothing to list - or a hub with more than a quarter of all contacts, beyond the scratch: the rows stay where they are)
+		if (t == 0) { S->c.nHubRows = n > 0 ? n : 0; S->c.nHubWide = 0; }
+		for (int k = t; k < n; k += 1024) W.hubList[k] = first + k;
+		return;
+	}
+	const bool inLds = n <= HUB_BUILD_LDS;
+	unsigned long long* const keys = inLds ? s_key : (unsigned long long*)W.keepScan;
+	int4* const refs = (int4*)W.keepFlag;
+	const unsigned long long meta = W.hubMeta[0];
+	const int hubP = (int)(uint32_t)(meta & 0xffffffffull);
+	__syncthreads();
+	for (int j = t; j < n; j += 1024)
+	{
+		const int4 q = W.li_ref[first + j];
+		const int ci = q.x;
+		const bool nsA = q.y >= 0, nsB = q.z >= 0;
+		const int a = nsA ? q.y : -(q.y + 1), b = nsB ? q.z : -(q.z + 1);
+		int cls = 1;
+		int partner = -1;
+		if (wideMode)
+		{
+			const bool pA = nsA && a == hubP, pB = nsB && b == hubP;
+			bool wide = meta != 0ull && pA != pB;
+			if (wide)
+			{
+				const int other = pA ? b : a;
+				const bool otherNs = pA ? nsB : nsA;
+				if (otherNs && W.deg[other] > HUB_DEGREE) wide = false;
+				if (otherNs && W.hubFirst[other] != (((unsigned long long)(uint32_t)S->c.hubEpoch << 32) | (unsigned long long)(0xffffffffu - (uint32_t)ci))) wide = false;
+				if (wide && otherNs) partner = other;
+			}
+			cls = wide ? 0 : 1;
+		}
+		else
+		{
+			cls = rowIsHubs(W, nsA, a, nsB, b) ? 0 : 1;
+			if (cls == 0 && nsA && nsB) partner = W.deg[a] <= W.deg[b] ? a : b;
+		}
+		int hi = 0;
+		if (ordered && cls == 0 && partner >= 0)
+		{
+			const unsigned long long m = W.bodyColorMask[partner] & ~(1ull << HUB_COLOR);
+			hi = m == 0ull ? 0 : 64 - __clzll((long long)m);
+		}
+		if (cls == 0) atomicAdd(&s_wide, 1);
+		keys[j] = ((unsigned long long)cls << 62) | ((unsigned long long)hi << 40) | (unsigned long long)(uint32_t)ci;
+		refs[j] = q;
+	}
+	__threadfence_block();
+	__syncthreads();
+	for (int j = t; j < n; j += 1024)
+	{
+		const unsigned long long mine = keys[j];
+		int rank = 0;
+		for (int k = 0; k < n; ++k) rank += keys[k] < mine ? 1 : 0; // (every lane reads the same word: a broadcast)
+		const int4 q = refs[j];
+		const int row = first + rank;
+		W.li_ref[row] = q;
+		W.hubRowOf[q.x] = row;
+		W.hubList[rank] = row;
+	}
+	if (t == 0)
+	{
+		S->c.nHubRows = n;
+		S->c.nHubWide = wideMode ? s_wide : 0;
+	}
+	(void)C;
+}
+
 // One constraint of a hub chunk, evaluated from the hub row `hubIn` the lane assumes it will meet at its turn. Works on
 // copies: returns the hub row after the constraint, the partner row and the impulses it would leave.
 struct HubTrial

@@ -747,7 +747,15 @@ static int phaseSolve(b2hip_world* w)
 		}
 		w->lastRestFirst = restFirst < nColors ? restFirst : nColors;
 		LAUNCH(w, k_color_fill, gC, 256, d, restFirst < MAX_COLORS ? restFirst : MAX_COLORS);
-		if (hasHubs)
+		// (round 6: one single-workgroup launch sorts the hub group's segment of the row array in place - k_hub_build - where the
+		// last step's list was short enough for its keys to sit in LDS; the four launches below otherwise)
+		const bool hubBuildOne = hasHubs && !w->noHubBuild && w->last.nHubRows <= HUB_BUILD_LDS;
+		if (hubBuildOne)
+		{
+			LAUNCH(w, k_hub_build, 1, 1024, d, d.hubWide ? 1 : 0, (!w->noHubOrder && (d.hubWide || w->hubOrderAll)) ? 1 : 0, d.blockSort ? 1 : 0);
+			w->hubSteps += 1;
+		}
+		else if (hasHubs)
 		{
 			// the hub constraints in contact-index order (deterministic whatever the atomics of k_color_fill did)
 			LAUNCH(w, k_hub_flag, gridFor(d.capContacts), 256, d);

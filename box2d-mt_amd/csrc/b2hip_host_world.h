@@ -306,6 +306,7 @@ struct b2hip_world
 	bool sweepStamps = false;    // B2HIP_SWEEP_STAMPS=1: k_sweep_end<1> leaves its phase stamps where the block solver's go (diagnostics)
 	bool bodyWarm = true;        // the warm start of a launch-per-colour solve body by body in one launch (k_large_warm; B2HIP_NO_BODY_WARM=1: a sweep of launches)
 	bool restFlow = true;        // the small colours of a sweep as data flow per body in one launch (k_large_rest; B2HIP_NO_REST=1: launches / tail)
+	bool noHubBuild = false;     // B2HIP_NO_HUB_BUILD=1: the hub list by k_hub_flag + scan + k_hub_fill + k_hub_order (four launches) always
 	bool noHubOrder = false;     // B2HIP_NO_HUB_ORDER=1: the hub rows in contact order (round 5)
 	bool hubOrderAll = false;    // B2HIP_HUB_ORDER=1: ... ordered also where every hub row is swept lane after lane (B2HIP_HUB_WIDE=0 / B2HIP_HUB_SERIAL=1: comparison runs)
 	bool colorAheadOff = false;  // B2HIP_NO_COLOR_AHEAD=1: round 5's flow (the queued k_color_small returns where there is no partition, the colour count comes by copy)
@@ -979,6 +980,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 	w->rowMarks = (getenv("B2HIP_ROW_MARKS_CHECK") && atoi(getenv("B2HIP_ROW_MARKS_CHECK"))) ? 2 : (getenv("B2HIP_NO_ROW_MARKS") && atoi(getenv("B2HIP_NO_ROW_MARKS"))) ? 0 : 1;
 	w->bodyWarm = !(getenv("B2HIP_NO_BODY_WARM") && atoi(getenv("B2HIP_NO_BODY_WARM")));
 	w->restFlow = w->sweepEnd && !(getenv("B2HIP_NO_REST") && atoi(getenv("B2HIP_NO_REST")));
+	w->noHubBuild = getenv("B2HIP_NO_HUB_BUILD") && atoi(getenv("B2HIP_NO_HUB_BUILD"));
 	w->noHubOrder = getenv("B2HIP_NO_HUB_ORDER") && atoi(getenv("B2HIP_NO_HUB_ORDER"));
 	w->hubOrderAll = getenv("B2HIP_HUB_ORDER") && atoi(getenv("B2HIP_HUB_ORDER"));
 	w->colorAheadOff = getenv("B2HIP_NO_COLOR_AHEAD") && atoi(getenv("B2HIP_NO_COLOR_AHEAD"));

@@ -23,7 +23,7 @@ import b2harness as bh
 pytestmark = pytest.mark.gpu
 
 KEYS = ("B2HIP_HUB_SERIAL", "B2HIP_NO_SWEEP_END", "B2HIP_NO_TAIL", "B2HIP_HUB_WIDE", "B2HIP_TAIL_ROWS", "B2HIP_SOLVER_LAUNCHES",
-        "B2HIP_NO_REST", "B2HIP_REST_ROWS", "B2HIP_FORCE_LARGE", "B2HIP_HUB_WAVES", "B2HIP_NO_BODY_WARM", "B2HIP_REST_HUB", "B2HIP_HUB_ORDER", "B2HIP_NO_HUB_ORDER")
+        "B2HIP_NO_REST", "B2HIP_REST_ROWS", "B2HIP_FORCE_LARGE", "B2HIP_HUB_WAVES", "B2HIP_NO_BODY_WARM", "B2HIP_REST_HUB", "B2HIP_HUB_ORDER", "B2HIP_NO_HUB_ORDER", "B2HIP_NO_HUB_BUILD")
 CCD = bh.F_SLEEP | bh.F_WARM | bh.F_CONTINUOUS
 LAUNCHES = {"B2HIP_SOLVER_LAUNCHES": "1"}  # no resident block solver, no k_blocks_sweep: a launch per colour
 
@@ -70,7 +70,9 @@ def test_sweep_end_folding_is_bit_identical_to_the_launches_it_replaces(amd, mon
                 # (round 6: by default the rest rows and the end of the sweep are ONE launch, k_rest_hub)
                 "rest rows and end of the sweep as two launches": {"B2HIP_REST_HUB": "0"},
                 "... fused in the velocity sweeps only": {"B2HIP_REST_HUB": "1"},
-                "fused, rest colours up to 100 000 rows": {"B2HIP_REST_ROWS": "100000", "B2HIP_REST_HUB": "2"}}
+                "fused, rest colours up to 100 000 rows": {"B2HIP_REST_ROWS": "100000", "B2HIP_REST_HUB": "2"},
+                # (round 6: by default ONE launch sorts the hub group's segment in place, k_hub_build)
+                "hub list by k_hub_flag + scan + k_hub_fill": {"B2HIP_NO_HUB_BUILD": "1"}}
     for label, env in variants.items():
         other, _ = run(amd, monkeypatch, scene, steps, dict(serial, **env), **kw)
         first = first_diff(base, other)
@@ -88,6 +90,16 @@ def test_hub_rows_as_one_fixed_point_agree_with_the_lane_after_lane_sweep(amd, m
         assert np.isfinite(wide).all()
         d = np.abs(serial[:, :2] - wide[:, :2]).max()
         assert d < 1e-3, "Tumbler %d: the fixed point over the workgroup is %g away from the lane-after-lane sweep after 30 steps" % (n, d)
+
+
+def test_hub_list_in_one_launch_is_the_list_of_the_four_launches(amd, monkeypatch):
+    """k_hub_build against k_hub_flag + scan + k_hub_fill + k_hub_order, with the fixed point over the workgroup (the default):
+    the same rows in the same order, so the same bits."""
+    for n, extra in ((60, {}), (100, LAUNCHES)):
+        a, _ = run(amd, monkeypatch, bh.TUMBLER, 100, dict(extra), p0=n)
+        b, _ = run(amd, monkeypatch, bh.TUMBLER, 100, dict(extra, B2HIP_NO_HUB_BUILD="1"), p0=n)
+        first = first_diff(a, b)
+        assert first is None, "Tumbler %d: the one-launch hub list differs from the four launches' at step %d" % (n, first)
 
 
 def test_default_mode_with_hubs_is_run_to_run_deterministic(amd, monkeypatch):
