@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(1024) void k_hub_build(DW W, int wideMode, int orde
 	if (blockSort) { const int nb = S->c.nBlocks < MAX_BLOCKS ? S->c.nBlocks : MAX_BLOCKS; first = W.blkRowStart[nb]; }
 	else first = W.colorStart[HUB_COLOR];
 	const int t = (int)threadIdx.x;
-	__shared__ unsigned long long s_key[HUB_BUILD_LDS];
+	__shared__ __attribute__((aligned(16))) unsigned long long s_key[HUB_BUILD_LDS + 8];
 	__shared__ int s_wide;
 	if (t == 0) s_wide = 0;
 	if (n <= 0 || (size_t)n * 4 > (size_t)W.capContacts)
@@ -1152,13 +1152,29 @@ __global__ __launch_bounds__(1024) void k_hub_build(DW W, int wideMode, int orde
 		keys[j] = ((unsigned long long)cls << 62) | ((unsigned long long)hi << 40) | (unsigned long long)(uint32_t)ci;
 		refs[j] = q;
 	}
+	// (the keys behind the last one never count: the loop below reads them eight at a time without asking where the list ends)
+	if (inLds && t < 8) s_key[n + t] = ~0ull;
 	__threadfence_block();
 	__syncthreads();
 	for (int j = t; j < n; j += 1024)
 	{
 		const unsigned long long mine = keys[j];
 		int rank = 0;
-		for (int k = 0; k < n; ++k) rank += keys[k] < mine ? 1 : 0; // (every lane reads the same word: a broadcast)
+		if (inLds)
+		{
+			// every lane reads the same words (broadcasts), eight keys per trip in four 16-byte reads that are in flight together: one
+			// key per trip was a chain of ~950 LDS round trips, 40 us for the Tumbler's list
+			typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+			const u64x2* k2 = (const u64x2*)s_key;
+			for (int k = 0; k < n; k += 8)
+			{
+				const u64x2 v0 = k2[(k >> 1) + 0], v1 = k2[(k >> 1) + 1], v2 = k2[(k >> 1) + 2], v3 = k2[(k >> 1) + 3];
+				rank += (v0.x < mine ? 1 : 0) + (v0.y < mine ? 1 : 0) + (v1.x < mine ? 1 : 0) + (v1.y < mine ? 1 : 0)
+					+ (v2.x < mine ? 1 : 0) + (v2.y < mine ? 1 : 0) + (v3.x < mine ? 1 : 0) + (v3.y < mine ? 1 : 0);
+			}
+		}
+		else
+			for (int k = 0; k < n; ++k) rank += keys[k] < mine ? 1 : 0;
 		const int4 q = refs[j];
 		const int row = first + rank;
 		W.li_ref[row] = q;
