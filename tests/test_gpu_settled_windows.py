@@ -35,8 +35,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RATIO_BOUNDS = {"contacts": (0.92, 1.08), "touching": (0.96, 1.04), "impulse_sum": (0.92, 1.08), "speed_mean": (0.94, 1.06),
                 "kinetic_energy": (0.85, 1.15), "penetration_p99": (0.0, 1.05), "penetration_mean": (0.0, 1.05),
                 "penetration_max": (0.0, 1.25), "speed_max": (0.0, 1.25)}
-# per scene overrides, each with the measurement that asks for it (profiles/r06_settled_windows_*.txt)
-OVERRIDES = {}
+# Per scene overrides, each with the measurement that asks for it (profiles/r06_*_settled_windows_*.txt).
+#
+# config3_tumbler316 - THE FIND OF THIS TEST. At steps 700..760 the reference build's pile and the device's are macroscopically
+# different piles: the reference holds 5.38 M contacts of which 712 000 touch, penetration p99 0.237 m / deepest 0.52 m (the boxes
+# are 0.25 m wide); the device 2.6 M / 370 000, p99 0.16 m / deepest 0.22 m. Both fell the same way (contact counts agree to
+# 0.5 % over the first 30 steps, tests/test_gpu_configs_full_size.py; both reach ~5 M contacts at steps 150..300), but from
+# there the device's pile expands again to what a dense packing of 100 000 boxes holds (3.7 touching contacts per box) while the
+# reference's stays compressed (7.1 per box) for as long as it was run (700 steps = 3 hours of the reference build on 8 cores).
+# It is the ORDER, and it grows with the depth of the pile: 8 + 3 Gauss-Seidel iterations cannot carry a pile 250 boxes deep in
+# either order, and the reference's order (the island's depth-first constraint order, one thread) leaves it further from
+# solved than colour order does. Evidence: (1) the 10 000-box Tumbler agrees between the two to 1 - 2 % in contact count over
+# all 700 steps (tools/gpu_step_series.py against the reference build); (2) the 22 500-box Tumbler on the device in the
+# REFERENCE'S order (B2HIP_FORCE_LARGE=2, bit-exact to the reference wherever it is compared) against the device's default
+# mode, step 350: 476 000 contacts / 98 800 touching / p99 0.167 m against 437 000 / 88 200 / 0.157 m - already + 9 - 12 %
+# (profiles/r06_c_order_effect_tumbler150.txt). So: the device's default mode does NOT reproduce the reference's pile at this
+# depth - it leaves LESS penetration - and the bench line says so (`state_vs_reference`): its timed state holds half the
+# contacts the reference's holds at the same step. What is asserted for this scene: the container's angle (exact physics of a
+# motor with torque to spare), a solution no worse than the reference's (penetration), counts between a dense packing's and the
+# reference's, energies and speeds of the same order.
+OVERRIDES = {"config3_tumbler316": {"contacts": (0.40, 1.05), "touching": (0.45, 1.05), "impulse_sum": (0.9, 1.8), "kinetic_energy": (0.8, 1.6),
+                                    "speed_mean": (0.85, 1.4), "speed_max": (0.0, 1.9)}}
 
 
 def _scenes():
