@@ -61,6 +61,13 @@ PARITY_TUMBLER = ("coloured order (launch per colour + k_large_rest + k_sweep_en
                   "Gauss-Seidel sweeps - one step from a bit-identical snapshot on Tumbler 2000: 5.4e-4 of the scene "
                   "(tests/test_gpu_onestep.py, bound 8.5e-4: above north_star's 1e-4, stated); bit-identical to launch-per-colour under "
                   "the same colouring (tests/test_gpu_sweep_end.py); the bit-exact class (B2HIP_FORCE_LARGE=2) is priced on config 2 below")
+STATE_VS_REFERENCE_TUMBLER = ("NOT the reference's state: the reference build run to the same steps (700..760: tests/golden/settled_windows.npz, 3 hours on 8 cores) "
+                              "holds 5.38 M contacts / 712 000 touching with penetration p99 0.237 m, this path's default mode 2.6 M / 370 000 with p99 0.16 m - "
+                              "8 + 3 Gauss-Seidel iterations cannot carry a pile 250 boxes deep in either order, and the reference's depth-first order leaves it "
+                              "more penetrated than colour order does (the effect grows with depth: 1 - 2 % at 10 000 boxes, 9 - 12 % at 22 500, 2 x here; "
+                              "profiles/r06_c_order_effect_tumbler150.txt, tests/test_gpu_settled_windows.py). The timed state therefore holds about half the "
+                              "contacts the reference would be stepping; where this path's own pile was that dense (steps 150..300: 5 M contacts, 520 000 - 630 000 "
+                              "touching) a step took 5.5 - 6.3 ms (`transient`, tools/gpu_step_series.py)")
 PARITY_PYRAMID = ("coloured order (k_solve_blocks): integer results exact; ONE step from a bit-identical snapshot of the timed state: "
                   "|dp| <= 1.7 cm on 1 m boxes (1.13e-4 of the 150 m scene; median 1-2 mm), |dv| <= 0.30 m/s, 18 of 30 000 contacts differ "
                   "(tests/test_gpu_onestep.py); the bit-exact class is `exact_order`")
@@ -593,6 +600,7 @@ def main():
                        "settle_steps": settle, "build_s": round(build_s, 2),
                        "timed_window": "steps %d..%d of the scene" % (settle + args.warmup, settle + args.warmup + args.steps - 1),
                        "parity_class": PARITY_TUMBLER if args.workload == "tumbler" else PARITY_PYRAMID,
+                       "state_vs_reference": (STATE_VS_REFERENCE_TUMBLER if args.workload == "tumbler" and args.tumbler == 316 and world_size == 1 else None),
                        "bodies_total": nbodies, "islands": ctr.islands, "large_island_constraints": ctr.large_island_contacts, "colors": ctr.colors,
                        "hub_constraints": ctr.hub_constraints,
                        "parallelism": "one world over the ranks by spatial ownership: a rank evaluates, solves and moves the bodies of its strip (one %s); fat AABBs / awake bits / new pairs by all-gather, migrating components ship their content" % unit_name if world_size > 1 else "single GPU"},
