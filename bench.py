@@ -610,6 +610,10 @@ def main():
         line["transient"] = {"steps": "0..%d (workload construction, untimed)" % (settle - 1), "ms_per_step": float(settle_ms.mean()),
                              "ms_per_step_p50": float(np.percentile(settle_ms, 50)), "ms_per_step_p99": float(np.percentile(settle_ms, 99)),
                              "ms_per_step_max": float(settle_ms.max())}
+        if args.workload == "tumbler" and settle >= 320:
+            # (the pile at its densest - ~5 M contacts, 520 000 - 630 000 touching: what the REFERENCE's pile still looks like at
+            # step 700, `state_vs_reference`)
+            line["transient"]["steps_200_299_ms_per_step"] = float(settle_ms[200:300].mean())
         if lazy is not None:
             line["ms_per_step_lazy_readback"] = lazy
         if sharded is not None and spatial_stats is not None:

@@ -245,6 +245,13 @@ __device__ __forceinline__ int collideClassKey(const DW& W, const ContactArrays&
 // rate; a world where every body has a record of its own (the 1 M-body field: a million radii and n-gons) pays for every
 // vertex the SAT loops touch with a load instruction whose 64 lanes hit 64 different lines - ~200 such instructions per
 // wave against the 20 that fetch both records whole. The host picks the instantiation by the number of distinct records.
+// (bits, not values: -0 against +0 and NaN payloads are differences too)
+__device__ __forceinline__ bool b2dSameBits4(float4 a, float4 b)
+{
+	return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+		__float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
+}
+
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 {
@@ -450,9 +457,18 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 						// quirk kept: only fixture A's body is woken (b2ContactManager.cpp:472-485)
 						W.b_wake[bodyA] = 1;
 					}
-					C.man0[i] = make_float4(mf.localNormal.x, mf.localNormal.y, mf.localPoint.x, mf.localPoint.y);
-					C.man1[i] = make_float4(mf.p[0].x, mf.p[0].y, mf.p[1].x, mf.p[1].y);
-					C.imp[i] = make_float4(ni[0], ti[0], ni[1], ti[1]);
+					// (round 6) only what CHANGED is stored: five of six contacts of a dense pile are fat-AABB pairs that did not touch
+					// before and do not touch now - their manifold comes out of b2dEvaluate bit for bit as it went in (the early-outs leave
+					// the stale fields alone, as the reference's persistent manifold does), and storing it again was 64 of this kernel's
+					// ~150 written bytes per contact. Compared as bits: what is in memory afterwards is the same either way.
+					{
+						const float4 n0 = make_float4(mf.localNormal.x, mf.localNormal.y, mf.localPoint.x, mf.localPoint.y);
+						const float4 n1 = make_float4(mf.p[0].x, mf.p[0].y, mf.p[1].x, mf.p[1].y);
+						const float4 nI = make_float4(ni[0], ti[0], ni[1], ti[1]);
+						if (!b2dSameBits4(n0, o0)) C.man0[i] = n0;
+						if (!b2dSameBits4(n1, o1)) C.man1[i] = n1;
+						if (!b2dSameBits4(nI, oldImp)) C.imp[i] = nI;
+					}
 				}
 				if (W.preSolveOn && !sensor && touching)
 				{
@@ -463,7 +479,10 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 					W.pre_o3[i] = m3;
 					flags |= CF_PRESOLVE;
 				}
-				C.man3[i] = make_int4((int)mf.id[0], (int)mf.id[1], mf.type, mf.pointCount);
+				{
+					const int4 n3 = make_int4((int)mf.id[0], (int)mf.id[1], mf.type, mf.pointCount);
+					if (n3.x != m3.x || n3.y != m3.y || n3.z != m3.z || n3.w != m3.w) C.man3[i] = n3;
+				}
 				if (touching) flags |= CF_TOUCHING; else flags &= ~CF_TOUCHING;
 			}
 		}
