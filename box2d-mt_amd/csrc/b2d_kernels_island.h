@@ -272,31 +272,80 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_island_union(DW W)
+// The SOLID contacts of a tile of `rounds` x 256 contacts, gathered into LDS (round 6). The island build's three passes over the
+// contacts do their work for the solid ones only - one contact in seven of the settled 100 000-box Tumbler (2.6 M fat-AABB
+// pairs, 370 000 of them touching) - and a lane per contact leaves their waves with nine lanes of 64 walking the
+// union-find trees (chains of dependent loads past the L2) while the rest sit idle: as many waves in flight as for 2.6 M
+// walks. Here a workgroup reads the flags of its tile with `rounds` independent loads per lane, lists the solid contacts in
+// LDS (one LDS atomic per wave and round; which lane gets which contact does not matter to any of the three) and works
+// through the list with full waves. `rounds` is the host's (b2hip_host_phases.h: 8 for millions of contacts, 1 - a lane
+// per contact as before, the list then only squeezes the gaps out of a tile - where that would leave workgroups without work).
+#define SOLID_TILE_ROUNDS_MAX 8
+struct SolidTile
+{
+	int n;
+	int list[SOLID_TILE_ROUNDS_MAX * 256];
+};
+template <bool CLEAR_ISLAND_BIT>
+__device__ __forceinline__ int solidTileGather(const ContactArrays& C, int n, int tileBase, int rounds, SolidTile* t)
+{
+	if (threadIdx.x == 0) t->n = 0;
+	__syncthreads();
+	uint32_t fl[SOLID_TILE_ROUNDS_MAX];
+#pragma unroll
+	for (int k = 0; k < SOLID_TILE_ROUNDS_MAX; ++k)
+	{
+		const int i = tileBase + k * 256 + (int)threadIdx.x;
+		fl[k] = (k < rounds && i < n) ? C.flags[i] : (uint32_t)CF_DESTROY;
+	}
+#pragma unroll
+	for (int k = 0; k < SOLID_TILE_ROUNDS_MAX; ++k)
+	{
+		if (k >= rounds) break;
+		const int i = tileBase + k * 256 + (int)threadIdx.x;
+		// (b2World::Solve clears the island flag of every contact, b2World.cpp:1191-1194: stored where it was set)
+		if (CLEAR_ISLAND_BIT && (fl[k] & CF_ISLAND) != 0 && i < n) C.flags[i] = fl[k] & ~CF_ISLAND;
+		const bool solid = contactSolid(fl[k]);
+		const unsigned long long m = __ballot(solid);
+		int base = 0;
+		if (waveLane() == 0 && m) base = atomicAdd(&t->n, __popcll(m));
+		base = __shfl(base, 0);
+		if (solid) t->list[base + __popcll(m & ((1ull << waveLane()) - 1ull))] = i;
+	}
+	__syncthreads();
+	return t->n;
+}
+
+__global__ __launch_bounds__(256) void k_island_union(DW W, int rounds)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	__shared__ SolidTile s_tile;
+	const int tile = rounds * 256;
+	for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile)
 	{
-		uint32_t flags = C.flags[i] & ~CF_ISLAND;
-		C.flags[i] = flags;
-		if (!contactSolid(flags)) continue;
-		int4 ids = C.ids[i];
-		// (the first level of both walks is fetched together with the body flags: one round trip less in front of the walks)
-		const uint32_t bfA = W.b_flags[ids.z], bfB = W.b_flags[ids.w];
-		const int pa = __hip_atomic_load(&W.parent[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const int pb = __hip_atomic_load(&W.parent[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		bool nsA = (bfA & BF_TYPE_MASK) != BT_STATIC;
-		bool nsB = (bfB & BF_TYPE_MASK) != BT_STATIC;
-		// (the count a body's atomic returns is the contact's place in the body's adjacency segment: k_island_edges fills the
-		// segments with plain stores - for every body, large islands included: k_color_masks walks them)
-		int2 slot = make_int2(-1, -1);
-		if (nsA) slot.x = atomicAdd(&W.deg[ids.z], 1);
-		if (nsB) slot.y = atomicAdd(&W.deg[ids.w], 1);
-		if (nsA && nsB) ufUnionFrom(W.parent, ids.z, ids.w, pa, pb);
-		W.adjSlot[i] = slot;
+		const int m = solidTileGather<true>(C, n, base, rounds, &s_tile);
+		for (int j = threadIdx.x; j < m; j += 256)
+		{
+			const int i = s_tile.list[j];
+			int4 ids = C.ids[i];
+			// (the first level of both walks is fetched together with the body flags: one round trip less in front of the walks)
+			const uint32_t bfA = W.b_flags[ids.z], bfB = W.b_flags[ids.w];
+			const int pa = __hip_atomic_load(&W.parent[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int pb = __hip_atomic_load(&W.parent[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			bool nsA = (bfA & BF_TYPE_MASK) != BT_STATIC;
+			bool nsB = (bfB & BF_TYPE_MASK) != BT_STATIC;
+			// (the count a body's atomic returns is the contact's place in the body's adjacency segment: k_island_edges fills the
+			// segments with plain stores - for every body, large islands included: k_color_masks walks them)
+			int2 slot = make_int2(-1, -1);
+			if (nsA) slot.x = atomicAdd(&W.deg[ids.z], 1);
+			if (nsB) slot.y = atomicAdd(&W.deg[ids.w], 1);
+			if (nsA && nsB) ufUnionFrom(W.parent, ids.z, ids.w, pa, pb);
+			W.adjSlot[i] = slot;
+		}
+		__syncthreads(); // (the list is the next tile's)
 	}
 	// joints connect bodies too (b2World.cpp:1292-1318)
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
@@ -371,27 +420,34 @@ __global__ __launch_bounds__(256) void k_island_flatten(DW W)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_island_count(DW W)
+__global__ __launch_bounds__(256) void k_island_count(DW W, int rounds)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
 	__shared__ BlockHot s_hot; // (the workgroup's count for the first root it meets: b2d_wave.h)
+	__shared__ SolidTile s_tile;
 	blockHotInit(&s_hot);
-	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
+	const int tile = rounds * 256;
+	for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile)
 	{
-		const int i = base + threadIdx.x;
-		bool valid = i < n && contactSolid(C.flags[i]);
-		int root = 0;
-		if (valid)
+		const int m = solidTileGather<false>(C, n, base, rounds, &s_tile);
+		for (int j0 = 0; j0 < m; j0 += 256)
 		{
-			int4 ids = C.ids[i];
-			int b = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC ? ids.z : ids.w;
-			valid = (W.b_flags[b] & BF_TYPE_MASK) != BT_STATIC;
-			if (valid) root = W.parent[b];
+			const int j = j0 + (int)threadIdx.x;
+			bool valid = j < m;
+			int root = 0;
+			if (valid)
+			{
+				int4 ids = C.ids[s_tile.list[j]];
+				int b = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC ? ids.z : ids.w;
+				valid = (W.b_flags[b] & BF_TYPE_MASK) != BT_STATIC;
+				if (valid) root = W.parent[b];
+			}
+			blockHotAddInt(&s_hot, W.rootContacts, root, 1, valid);
 		}
-		blockHotAddInt(&s_hot, W.rootContacts, root, 1, valid);
+		__syncthreads(); // (the list is the next tile's)
 	}
 	blockHotFlush(&s_hot, W.rootContacts);
 	for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W.nJoints; j += gridDim.x * blockDim.x)
@@ -590,19 +646,25 @@ __global__ __launch_bounds__(256) void k_island_assign(DW W)
 
 // Adjacency (small islands) and the large-island contact list. `pub`: this is the last kernel of the island build (no large
 // islands lately, no joints): its last workgroup publishes the census for the host (b2dPublishCensus).
-__global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub)
+__global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub, int rounds)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
 	const int n = S->c.nContacts;
 	const ContactArrays& C = W.ca[S->cur];
-	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
+	__shared__ SolidTile s_tile;
+	const int tile = rounds * 256;
+	for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile)
 	{
-		const int i = base + (int)threadIdx.x;
+	const int m = solidTileGather<false>(C, n, base, rounds, &s_tile);
+	for (int j0 = 0; j0 < m; j0 += 256)
+	{
+		const int j = j0 + (int)threadIdx.x;
+		const int i = j < m ? s_tile.list[j] : 0;
 		int4 ids = make_int4(0, 0, 0, 0);
 		bool nsA = false, nsB = false;
 		int tier = ROOT_NONE;
-		if (i < n && contactSolid(C.flags[i]))
+		if (j < m)
 		{
 			ids = C.ids[i];
 			nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC;
@@ -657,6 +719,8 @@ __global__ __launch_bounds__(256) void k_island_edges(DW W, DState* pub)
 				}
 			}
 		}
+	}
+	__syncthreads(); // (the list is the next tile's)
 	}
 	// (the counters the census consists of are atomics' results: nothing of this workgroup's plain stores is read there)
 	if (pub != nullptr && b2dLastBlockArrive(W, ARRIVE_EDGES)) b2dPublishCensus(W, pub);

@@ -252,6 +252,9 @@ static int phaseCollide(b2hip_world* w)
 		// (one record, one class) the sort costs 2 % - so both follow the number of distinct records unless the environment says otherwise.
 		const bool many = w->shapes.size() > 4096;
 		const bool stage = w->collideStage < 0 ? many : w->collideStage != 0;
+		// (round 6, measured and left out: sorting also by "the old manifold had points" - the pairs that will run the clipping - to
+		// give the one touching contact in six of a dense pile waves of its own: Tumbler 316 3.275 -> 3.338 ms, 1 M field 2.10 -> 2.14:
+		// the kernel is bound by its loads, not by the lanes idling through the long path)
 		const int sort = w->collideSortEnv < 0 ? (many ? 1 : 0) : (w->collideSortEnv != 0 ? 1 : 0);
 		if (stage) LAUNCH(w, k_collide<1>, gridFor(d.capContacts), 256, d, sort);
 		else LAUNCH(w, k_collide<0>, gridFor(d.capContacts), 256, d, sort);
@@ -329,13 +332,19 @@ static int phaseSolve(b2hip_world* w)
 	const bool poll = !w->noCensusPoll;
 	const bool adopt = w->adoptPasses;
 	const int pubBy = !poll ? 0 : (largeHint ? 1 : ((d.nJoints == 0 && !adopt) ? 2 : 3));
-	int rc = runSegment(w, w->segIslands, (2 + 16ull * (uint64_t)forceLarge + (largeHint ? 8ull : 0ull) + 64ull * (uint64_t)pubBy + (adopt ? 512ull : 0ull)) ^ (spHash << 12), [w, forceLarge, sp, largeHint, pubBy, adopt]() -> int
+	// (the passes over the contacts gather the solid ones of a tile of `solidRounds` x 256 contacts in LDS, b2d_kernels_island.h:
+	// tiles as large as leave a thousand workgroups with one each - a lane per contact below 512 000 contacts)
+	int solidRounds = 1;
+	while (solidRounds < SOLID_TILE_ROUNDS_MAX && (long long)w->last.nContacts >= 2ll * solidRounds * 256 * 1024) solidRounds *= 2;
+	if (w->solidRoundsEnv > 0) solidRounds = w->solidRoundsEnv;
+	const int solidIdx = solidRounds >= 8 ? 3 : (solidRounds >= 4 ? 2 : (solidRounds >= 2 ? 1 : 0));
+	int rc = runSegment(w, w->segIslands, (2 + 16ull * (uint64_t)forceLarge + (largeHint ? 8ull : 0ull) + 64ull * (uint64_t)pubBy + (adopt ? 512ull : 0ull) + 1024ull * (uint64_t)solidIdx) ^ (spHash << 12), [w, forceLarge, sp, largeHint, pubBy, adopt, solidRounds]() -> int
 	{
 		DW& d = w->dw;
 		LAUNCH(w, k_island_init, gridFor(d.nBodies), 256, d);
-		LAUNCH(w, k_island_union, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_island_union, gridFor((size_t)(d.capContacts + solidRounds - 1) / solidRounds), 256, d, solidRounds);
 		LAUNCH(w, k_island_flatten, gridFor(d.nBodies), 256, d);
-		LAUNCH(w, k_island_count, gridFor(d.capContacts), 256, d);
+		LAUNCH(w, k_island_count, gridFor((size_t)(d.capContacts + solidRounds - 1) / solidRounds), 256, d, solidRounds);
 		LAUNCH(w, k_island_classify, gridFor(d.nBodies), 256, d, forceLarge, sp);
 		if (d.shardCount > 1 && !d.spatial) LAUNCH(w, k_shard_big, 1, 1024, d); // the big islands of a sharded world, dealt over the ranks
 		{
@@ -350,7 +359,7 @@ static int phaseSolve(b2hip_world* w)
 			deviceExclusiveScan<int>(w->stream, d.rootJoints, d.rootJointStart, d.scanTmp, w->scanCtx, w->consts.p, d.nBodies);
 		}
 		LAUNCH(w, k_island_assign, gridFor(d.nBodies), 256, d);
-		LAUNCH(w, k_island_edges, gridFor(d.capContacts), 256, d, pubBy == 2 ? w->d_pub : (DState*)nullptr);
+		LAUNCH(w, k_island_edges, gridFor((size_t)(d.capContacts + solidRounds - 1) / solidRounds), 256, d, pubBy == 2 ? w->d_pub : (DState*)nullptr, solidRounds);
 		// (a growing pile: hand home blocks on to newcomers up to four contacts away instead of partitioning again)
 		if (adopt)
 			for (int stage = 0; stage < 3; ++stage) LAUNCH(w, k_block_adopt, gridFor(d.capContacts), 256, d, stage);

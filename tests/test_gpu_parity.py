@@ -654,3 +654,34 @@ def test_grid_cell_geometry_does_not_change_the_pairs(amd, default_mode, monkeyp
             other = run(scene, steps, half, **kw)
             first = next((i for i in range(steps) if full[i] != other[i]), None)
             assert first is None, "scene %d: grid geometry %s differs from full cells at step %d" % (scene, half, first)
+
+
+def test_the_island_builds_contact_tiles_do_not_change_the_results(amd, default_mode, monkeypatch):
+    """The island build's three passes over the contacts (k_island_union / count / edges) gather the solid contacts of a tile of
+    rounds x 256 contacts in LDS and work through that list with full waves (b2d_kernels_island.h: solidTileGather); the host
+    picks the rounds by the contact count (8 for the settled 100 000-box Tumbler, 1 below 512 000 contacts). Which lane gets
+    which contact must not matter: the same worlds with the tile fixed at 1, 2, 4 and 8 rounds give the same states and contact
+    counts every step - a growing pile (partitions, adoption), the Tumbler (hub, large island), jointed machines (joints in the
+    union and the count) and a field with bullets (thousands of small islands, TOI sub-steps)."""
+    ccd = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
+
+    def run(scene, steps, rounds, **kw):
+        if rounds is None:
+            monkeypatch.delenv("B2HIP_SOLID_ROUNDS", raising=False)
+        else:
+            monkeypatch.setenv("B2HIP_SOLID_ROUNDS", rounds)
+        w = amd.world(scene, **kw)
+        out = []
+        for _ in range(steps):
+            w.step(1)
+            out.append((bh.fnv1a64(w.bodies()), w.contact_count))
+        w.close()
+        return out
+
+    for scene, steps, kw in [(bh.PYRAMID, 100, dict(p0=50, flags=ccd)), (bh.TUMBLER, 120, dict(p0=60)), (bh.MACHINES, 120, dict(p0=600, p1=6, seed=3)),
+                             (bh.FIELD, 60, dict(p0=3000, p1=400, f0=60.0, f1=3.0, seed=11, flags=ccd))]:
+        one = run(scene, steps, "1", **kw)
+        for rounds in ("2", "4", "8", None):
+            other = run(scene, steps, rounds, **kw)
+            first = next((i for i in range(steps) if one[i] != other[i]), None)
+            assert first is None, "scene %d: tiles of %s rounds differ from a lane per contact at step %d" % (scene, rounds, first)
