@@ -252,8 +252,16 @@ __device__ __forceinline__ bool b2dSameBits4(float4 a, float4 b)
 		__float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
 }
 
-template <int STAGE>
-__global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
+// ORDER: the last workgroup replays the dying TOI candidates (toiOrderDestroy) - no launch for it, but its 48 KB of LDS tables
+// and the 150 registers of the evaluation leave three waves per SIMD. The kernel is bound by the chains of loads in front of
+// the arithmetic (ids -> bodies, proxies, old manifold -> shapes), not by bandwidth or the arithmetic: with the replay in a
+// launch of its own (k_toi_order_destroy) and the registers capped at 128 - four waves per SIMD, 15 values spilled - the
+// 2.6 M contacts of the settled Tumbler take 260 us instead of 348 (the step 3.29 -> 3.20 ms; five waves with 56 spills:
+// 3.25, six: 3.35). The host picks the form by the contact count (b2hip_host_phases.h: phaseCollide).
+template <int STAGE, bool ORDER = true>
+__global__ __launch_bounds__(256) void
+__attribute__((amdgpu_waves_per_eu((!ORDER && !STAGE) ? 4 : 1, (!ORDER && !STAGE) ? 4 : 8)))
+k_collide(DW W, int sortTile)
 {
 	b2dPhaseStamp(W);
 	DState* S = W.st;
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 	__shared__ int s_perm[256];
 	// (152-byte records side by side: lanes read the same member 38 words apart - a two-way bank conflict at worst)
 	// (... and, once the contacts are done, the scratch of the last workgroup's toiOrderDestroy)
-	__shared__ __attribute__((aligned(16))) unsigned char s_raw[STAGE ? (512 * sizeof(ShapeRec) > TOI_ORDER_SCRATCH_BYTES ? 512 * sizeof(ShapeRec) : TOI_ORDER_SCRATCH_BYTES) : TOI_ORDER_SCRATCH_BYTES];
+	__shared__ __attribute__((aligned(16))) unsigned char s_raw[STAGE ? ((512 * sizeof(ShapeRec) > TOI_ORDER_SCRATCH_BYTES || !ORDER) ? 512 * sizeof(ShapeRec) : TOI_ORDER_SCRATCH_BYTES) : (ORDER ? TOI_ORDER_SCRATCH_BYTES : 16)];
 	ShapeRec* const s_shape = (ShapeRec*)s_raw;
 	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
@@ -547,9 +555,16 @@ __global__ __launch_bounds__(256) void k_collide(DW W, int sortTile)
 				if (t0) atomicAdd(&S->c.nDestroy, (int)t0);
 				if (t1) atomicAdd(&S->c.nTouching, (int)t1);
 			}
-			toiOrderDestroy(W, s_raw);
+			if (ORDER) toiOrderDestroy(W, s_raw);
 		}
 	}
+}
+
+// toiOrderDestroy as a launch of its own, behind k_collide<.., false> (one workgroup; returns at once when no candidate died).
+__global__ __launch_bounds__(256) void k_toi_order_destroy(DW W)
+{
+	__shared__ __attribute__((aligned(16))) unsigned char s_raw[TOI_ORDER_SCRATCH_BYTES];
+	toiOrderDestroy(W, s_raw);
 }
 
 // b2World::CreateJoint with collideConnected == false flags the contacts between the two bodies for

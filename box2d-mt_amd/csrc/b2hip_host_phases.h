@@ -242,7 +242,11 @@ static int findNewContactsOnce(b2hip_world* w, bool sync)
 
 static int phaseCollide(b2hip_world* w)
 {
-	return runSegment(w, w->segCollide, 1 + (w->dw.preSolveOn ? 32 : 0), [w]() -> int
+	// (the form of k_collide, b2d_kernels_collide.h: from 262 144 contacts on - a thousand workgroups - the replay of the dying
+	// TOI candidates is a launch of its own and the evaluation runs four waves per SIMD; below, the launch costs more than the
+	// occupancy gives)
+	const bool split = w->collideSplitEnv < 0 ? w->last.nContacts >= 262144 : w->collideSplitEnv != 0;
+	return runSegment(w, w->segCollide, 1 + (w->dw.preSolveOn ? 32 : 0) + (split ? 64 : 0), [w, split]() -> int
 	{
 		DW& d = w->dw;
 		if (int rk = ktBracket(w, 2, 5)) return rk;
@@ -253,11 +257,15 @@ static int phaseCollide(b2hip_world* w)
 		const bool many = w->shapes.size() > 4096;
 		const bool stage = w->collideStage < 0 ? many : w->collideStage != 0;
 		// (round 6, measured and left out: sorting also by "the old manifold had points" - the pairs that will run the clipping - to
-		// give the one touching contact in six of a dense pile waves of its own: Tumbler 316 3.275 -> 3.338 ms, 1 M field 2.10 -> 2.14:
-		// the kernel is bound by its loads, not by the lanes idling through the long path)
+		// give the one touching contact in six of a dense pile waves of its own: Tumbler 316 3.275 -> 3.338 ms, 1 M field 2.10 -> 2.14)
 		const int sort = w->collideSortEnv < 0 ? (many ? 1 : 0) : (w->collideSortEnv != 0 ? 1 : 0);
-		if (stage) LAUNCH(w, k_collide<1>, gridFor(d.capContacts), 256, d, sort);
-		else LAUNCH(w, k_collide<0>, gridFor(d.capContacts), 256, d, sort);
+		if (stage) LAUNCH(w, (k_collide<1, true>), gridFor(d.capContacts), 256, d, sort);
+		else if (split)
+		{
+			LAUNCH(w, (k_collide<0, false>), gridFor(d.capContacts), 256, d, sort);
+			LAUNCH(w, k_toi_order_destroy, 1, 256, d);
+		}
+		else LAUNCH(w, (k_collide<0, true>), gridFor(d.capContacts), 256, d, sort);
 		if (int rk = ktBracket(w, 2, 5)) return rk;
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);

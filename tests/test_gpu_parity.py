@@ -685,3 +685,29 @@ def test_the_island_builds_contact_tiles_do_not_change_the_results(amd, default_
             other = run(scene, steps, rounds, **kw)
             first = next((i for i in range(steps) if one[i] != other[i]), None)
             assert first is None, "scene %d: tiles of %s rounds differ from a lane per contact at step %d" % (scene, rounds, first)
+
+
+def test_the_two_forms_of_k_collide_give_the_same_bits(amd, default_mode, monkeypatch):
+    """k_collide replays the dying TOI candidates in its last workgroup (worlds below 262 144 contacts) or leaves that to a launch
+    of its own and runs four waves per SIMD on 128 registers (b2d_kernels_collide.h: k_collide<0, false> + k_toi_order_destroy).
+    Same arithmetic, same order of the manager's slots afterwards: worlds whose TOI candidates die every step - bullets through
+    a crowd, a field with bullets, the Tumbler's boxes leaving the container's walls - forced into either form give the same
+    states, contact counts and (continuous physics on) the same TOI events step by step."""
+    ccd = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
+
+    def run(scene, steps, split, **kw):
+        monkeypatch.setenv("B2HIP_COLLIDE_SPLIT", split)
+        w = amd.world(scene, **kw)
+        out = []
+        for _ in range(steps):
+            w.step(1)
+            out.append((bh.fnv1a64(w.bodies()), w.contact_count))
+        w.close()
+        return out
+
+    for scene, steps, kw in [(bh.BULLETS, 150, dict(p0=150, p1=8, seed=3, flags=ccd)), (bh.FIELD, 60, dict(p0=3000, p1=400, f0=60.0, f1=3.0, seed=11, flags=ccd)),
+                             (bh.TUMBLER, 120, dict(p0=60)), (bh.TUMBLER, 80, dict(p0=40, flags=ccd))]:
+        inside = run(scene, steps, "0", **kw)
+        own = run(scene, steps, "1", **kw)
+        first = next((i for i in range(steps) if inside[i] != own[i]), None)
+        assert first is None, "scene %d: the replay as a launch of its own differs from the replay inside k_collide at step %d" % (scene, first)
