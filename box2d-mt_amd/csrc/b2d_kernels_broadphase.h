@@ -214,11 +214,12 @@ __global__ __launch_bounds__(256) void k_grid_fill(DW W, int force)
 	}
 }
 
-// b2ContactManager::AddPair filters (:237-312) evaluated before the pair is even stored.
-__device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q)
+// b2ContactManager::AddPair filters (:237-312) evaluated before the pair is even stored: does (p, q) become a pair, and which
+// (key = the two proxy keys, lower first; lo / hi = the proxies in that order)
+__device__ __forceinline__ bool pairPasses(const DW& W, int p, int q, uint64_t* keyOut, int2* proxOut)
 {
 	const int bodyP = W.p_body[p], bodyQ = W.p_body[q];
-	if (bodyP == bodyQ) return;
+	if (bodyP == bodyQ) return false;
 	if (W.spatial)
 	{
 		// a spatially sharded world: a rank emits the pairs one of ITS bodies takes part in (a moved static proxy - a host edit
@@ -226,23 +227,34 @@ __device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q
 		// of existing contacts then only needs this rank's own contacts (k_bp_build).
 		const bool mineP = (W.b_flags[bodyP] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyP] == (uint8_t)W.shardRank;
 		const bool mineQ = (W.b_flags[bodyQ] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyQ] == (uint8_t)W.shardRank;
-		if (!mineP && !mineQ) return;
+		if (!mineP && !mineQ) return false;
 	}
 	const int keyP = W.p_key[p], keyQ = W.p_key[q];
 	const int lo = keyP < keyQ ? p : q;
 	const int hi = keyP < keyQ ? q : p;
 	const uint64_t key = ((uint64_t)(uint32_t)W.p_key[lo] << 32) | (uint32_t)W.p_key[hi];
-	if (htContains(W, key + 1ull)) return;
+	if (htContains(W, key + 1ull)) return false;
 	// bodyB->ShouldCollide(bodyA) with A = lower proxy id
-	if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return;
+	if (!bodiesShouldCollide(W, W.p_body[hi], W.p_body[lo])) return false;
 	// (a user contact filter replaces the built-in rule: it is asked on the host for every pair that gets this far)
-	if (!W.userFilter && !filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return;
-	if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return;
+	if (!W.userFilter && !filterShouldCollide(W.p_filter0[lo], W.p_filter1[lo], W.p_filter0[hi], W.p_filter1[hi])) return false;
+	if (b2dContactSwap(W.shapes[W.p_shape[lo]].type, W.shapes[W.p_shape[hi]].type) < 0) return false;
+	*keyOut = key;
+	*proxOut = make_int2(lo, hi);
+	return true;
+}
+
+// ... and stored at once, a place of the pair buffer per pair (the brute-force search of the large proxies, lists beyond a wave)
+__device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q)
+{
+	uint64_t key;
+	int2 prox;
+	if (!pairPasses(W, p, q, &key, &prox)) return;
 	int k = atomicAdd(&S->c.nPairs, 1);
 	if (k < W.capPairs)
 	{
 		W.pairKey[k] = key;
-		W.pairProxy[k] = make_int2(lo, hi);
+		W.pairProxy[k] = prox;
 	}
 	else
 	{
@@ -250,8 +262,65 @@ __device__ __forceinline__ void tryEmitPair(const DW& W, DState* S, int p, int q
 	}
 }
 
+// The pairs a WAVE of the search kernels has found wait in LDS (round 6) and take their places in the pair buffer PAIR_STAGE_CAP
+// at a time; what is left when the kernel ends goes out with one atomic per workgroup. A place per pair as it turned up - the
+// compiler combines the lanes of a wave, so: one returning atomic per flush of the hit list below - was ~100 000 atomics on
+// ONE word in a step of the settled 100 000-box Tumbler (530 000 pairs: every box moves and finds each new neighbour from both
+// sides), served one after the other at the memory side in ~4 ns each: the 370 us of k_find_pairs_window were that queue.
+// The order of the pair buffer means nothing: it is sorted by key before anything reads it.
+#define PAIR_STAGE_CAP 256
+struct PairStage
+{
+	uint64_t* key; // [PAIR_STAGE_CAP] of this wave
+	int2* prox;
+	int n;
+};
+__device__ __forceinline__ void pairStageStore(const DW& W, DState* S, const PairStage& st, int lane, int base)
+{
+	for (int j = lane; j < st.n; j += 64)
+	{
+		const int k = base + j;
+		if (k < W.capPairs)
+		{
+			W.pairKey[k] = st.key[j];
+			W.pairProxy[k] = st.prox[j];
+		}
+	}
+	if (lane == 0 && base + st.n > W.capPairs) atomicOr(&S->c.overflow, 2);
+}
+__device__ __forceinline__ void pairStageDrain(const DW& W, DState* S, PairStage& st, int lane)
+{
+	if (st.n == 0) return;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	int base = 0;
+	if (lane == 0) base = atomicAdd(&S->c.nPairs, st.n);
+	base = __builtin_amdgcn_readfirstlane(base);
+	pairStageStore(W, S, st, lane, base);
+	__builtin_amdgcn_wave_barrier(); // (the stage is written again)
+	st.n = 0;
+}
+// (every wave of the workgroup, once, at the end of the kernel)
+__device__ __forceinline__ void pairStageFinish(const DW& W, DState* S, PairStage& st, int lane)
+{
+	__shared__ int s_stageCount[16], s_stageBase;
+	const int wv = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63u) >> 6);
+	if (lane == 0) s_stageCount[wv] = st.n;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		int run = 0;
+		for (int q = 0; q < nw; ++q) { const int c = s_stageCount[q]; s_stageCount[q] = run; run += c; }
+		s_stageBase = run > 0 ? atomicAdd(&S->c.nPairs, run) : 0;
+	}
+	__syncthreads();
+	pairStageStore(W, S, st, lane, s_stageBase + s_stageCount[wv]);
+	st.n = 0;
+}
+
 // The candidates whose boxes overlap are put aside - (proxy, candidate) in a list per wave in LDS - and go through the filters
-// (tryEmitPair: keys, hash probe of the existing contacts, body and fixture rules, shape types - a chain of a dozen gathers)
+// (pairPasses: keys, hash probe of the existing contacts, body and fixture rules, shape types - a chain of a dozen gathers)
 // 64 at a time with every lane busy, instead of where they turn up: a dense window is five or six rounds of 64 candidates
 // with a few hits each, a sparse scene has a hit every second proxy - the chain ran once per round / proxy for those few
 // lanes (Tumbler: pair update 1.50 -> 1.17 ms with the list per window; then per wave across proxies).
@@ -260,26 +329,38 @@ struct PairHits
 	int2* list; // [64] of this wave
 	int n;
 };
-__device__ __forceinline__ void pairHitsFlush(const DW& W, DState* S, PairHits& h, int lane)
+__device__ __forceinline__ void pairHitsFlush(const DW& W, DState* S, PairHits& h, PairStage& st, int lane)
 {
 	if (h.n == 0) return;
+	if (st.n + h.n > PAIR_STAGE_CAP) pairStageDrain(W, S, st, lane);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	uint64_t key = 0ull;
+	int2 prox = make_int2(0, 0);
+	bool ok = false;
 	if (lane < h.n)
 	{
 		const int2 pq = h.list[lane];
-		tryEmitPair(W, S, pq.x, pq.y);
+		ok = pairPasses(W, pq.x, pq.y, &key, &prox);
 	}
+	const unsigned long long om = __ballot(ok);
+	if (ok)
+	{
+		const int j = st.n + (int)__popcll(om & ((1ull << lane) - 1ull));
+		st.key[j] = key;
+		st.prox[j] = prox;
+	}
+	st.n += (int)__popcll(om);
 	__builtin_amdgcn_wave_barrier(); // (the list is written again)
 	h.n = 0;
 }
-__device__ __forceinline__ void pairHitsAdd(const DW& W, DState* S, PairHits& h, int lane, bool hit, int p, int q)
+__device__ __forceinline__ void pairHitsAdd(const DW& W, DState* S, PairHits& h, PairStage& st, int lane, bool hit, int p, int q)
 {
 	const unsigned long long hm = __ballot(hit);
 	if (hm == 0ull) return;
 	const int more = (int)__popcll(hm);
-	if (h.n + more > 64) pairHitsFlush(W, S, h, lane);
+	if (h.n + more > 64) pairHitsFlush(W, S, h, st, lane);
 	if (hit) h.list[h.n + (int)__popcll(hm & ((1ull << lane) - 1ull))] = make_int2(p, q);
 	h.n += more;
 }
@@ -298,9 +379,15 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
 	__shared__ int2 s_hits[4][64];
+	__shared__ uint64_t s_stageKey[4][PAIR_STAGE_CAP];
+	__shared__ int2 s_stageProx[4][PAIR_STAGE_CAP];
 	PairHits hits;
 	hits.list = s_hits[threadIdx.x >> 6];
 	hits.n = 0;
+	PairStage stage;
+	stage.key = s_stageKey[threadIdx.x >> 6];
+	stage.prox = s_stageProx[threadIdx.x >> 6];
+	stage.n = 0;
 	// The search is a chain of dependent loads per moved proxy - proxy, its body and box, cell headers, items, and the large
 	// proxies with their boxes - and the kernel's time is that chain times the proxies a wave goes through. So: the large
 	// proxies (walls, the ground: a handful) are fetched ONCE per wave, lane t keeping the t-th; the proxy of the round after
@@ -380,13 +467,13 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 				bq.hi = v2(fq.z, fq.w);
 				hit = q != p && b2dAabbOverlap(a, bq);
 			}
-			pairHitsAdd(W, S, hits, lane, hit, p, q);
+			pairHitsAdd(W, S, hits, stage, lane, hit, p, q);
 		}
 		{
 			AABB bq;
 			bq.lo = v2(largeFat.x, largeFat.y);
 			bq.hi = v2(largeFat.z, largeFat.w);
-			pairHitsAdd(W, S, hits, lane, largeQ >= 0 && b2dAabbOverlap(a, bq), p, largeQ);
+			pairHitsAdd(W, S, hits, stage, lane, largeQ >= 0 && b2dAabbOverlap(a, bq), p, largeQ);
 		}
 		for (int t = 64 + lane; t < nLarge; t += 64) // (more than a wave holds: the rest as before)
 		{
@@ -394,7 +481,8 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
-	pairHitsFlush(W, S, hits, lane);
+	pairHitsFlush(W, S, hits, stage, lane);
+	pairStageFinish(W, S, stage, lane);
 	// (the candidate census for the host's choice of the cell: one atomic per wave on the 32 words of ONE line was 8 192
 	// atomics at the end of the kernel, ~5 ns each - carried by the arrival of the workgroups instead, b2d_world.h)
 	b2dBlockTreeAdd2(W, ARRIVE_PAIRS, &S->c.candRounds[0], lane == 0 ? rounds : 0, &S->c.candRounds[1], 0, (unsigned)W.capMoves <= (TREE_SUM_MAX >> 3));
@@ -416,9 +504,15 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 	const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
 	int rounds = 0;
 	__shared__ int2 s_hits[4][64];
+	__shared__ uint64_t s_stageKey[4][PAIR_STAGE_CAP];
+	__shared__ int2 s_stageProx[4][PAIR_STAGE_CAP];
 	PairHits hits;
 	hits.list = s_hits[threadIdx.x >> 6];
 	hits.n = 0;
+	PairStage stage;
+	stage.key = s_stageKey[threadIdx.x >> 6];
+	stage.prox = s_stageProx[threadIdx.x >> 6];
+	stage.n = 0;
 	// The search is a chain of dependent loads per moved proxy - proxy, its body and box, cell headers, items, and the large
 	// proxies with their boxes - and the kernel's time is that chain times the proxies a wave goes through. So: the large
 	// proxies (walls, the ground: a handful) are fetched ONCE per wave, lane t keeping the t-th; the proxy of the round after
@@ -506,13 +600,13 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 				bq.hi = v2(fq.z, fq.w);
 				hit = q != p && b2dAabbOverlap(a, bq);
 			}
-			pairHitsAdd(W, S, hits, lane, hit, p, q);
+			pairHitsAdd(W, S, hits, stage, lane, hit, p, q);
 		}
 		{
 			AABB bq;
 			bq.lo = v2(largeFat.x, largeFat.y);
 			bq.hi = v2(largeFat.z, largeFat.w);
-			pairHitsAdd(W, S, hits, lane, largeQ >= 0 && b2dAabbOverlap(a, bq), p, largeQ);
+			pairHitsAdd(W, S, hits, stage, lane, largeQ >= 0 && b2dAabbOverlap(a, bq), p, largeQ);
 		}
 		for (int t = 64 + lane; t < nLarge; t += 64) // (more than a wave holds: the rest as before)
 		{
@@ -520,7 +614,8 @@ __global__ __launch_bounds__(256) void k_find_pairs_window(DW W)
 			if (b2dAabbOverlap(a, loadAabb(W.p_fat, q))) tryEmitPair(W, S, p, q);
 		}
 	}
-	pairHitsFlush(W, S, hits, lane);
+	pairHitsFlush(W, S, hits, stage, lane);
+	pairStageFinish(W, S, stage, lane);
 	// (the candidate census for the host's choice of the cell: one atomic per wave on the 32 words of ONE line was 8 192
 	// atomics at the end of the kernel, ~5 ns each - carried by the arrival of the workgroups instead, b2d_world.h)
 	b2dBlockTreeAdd2(W, ARRIVE_PAIRS, &S->c.candRounds[0], lane == 0 ? rounds : 0, &S->c.candRounds[1], 0, (unsigned)W.capMoves <= (TREE_SUM_MAX >> 3));

@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	__shared__ int s_blkRows[MAX_BLOCKS];
 	__shared__ int s_sums[2];
 	__shared__ int s_compact[2]; // [0] rows of the compaction class in this round, [1] their first place in the list
+	__shared__ int s_uncol[2];   // the same for the rows without a colour
 	for (int i = threadIdx.x; i < MAX_BLOCKS; i += blockDim.x) s_blkRows[i] = 0;
-	if (threadIdx.x < 2) { s_sums[threadIdx.x] = 0; s_compact[threadIdx.x] = 0; }
+	if (threadIdx.x < 2) { s_sums[threadIdx.x] = 0; s_compact[threadIdx.x] = 0; s_uncol[threadIdx.x] = 0; }
 	__syncthreads();
 	// (1) every touching contact that owns a colour - large island or not, asleep or not - reserves it on its bodies.
 	// A contact that stopped touching gives its colour back: reservations of idle neighbours (a pyramid box has two of
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		const int s = base + threadIdx.x;
 		const bool valid = s < n;
 		int col = -1;
-		int compactRank = -1;
+		int compactRank = -1, uncolRank = -1;
 		if (valid)
 		{
 			const int ci = W.li_contacts[s];
@@ -277,9 +278,10 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			{
 				++uncolored;
 				col = -1;
-				// short list for the in-kernel incremental colouring (k_color_small)
-				const int u = atomicAdd(&S->c.nUncolList, 1);
-				if (u < COLOR_SMALL_MAX) W.uncolList[u] = s;
+				// short list for the in-kernel incremental colouring (k_color_small): places taken below, one atomic per workgroup
+				// (one per row was a few thousand returning atomics on one word in every step of the settled Tumbler - the contacts that
+				// began to touch - each served in its turn at the memory side: 30 us of its step)
+				uncolRank = atomicAdd(&s_uncol[0], 1);
 			}
 			else if (col != HUB_COLOR)
 			{
@@ -302,8 +304,16 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 			s_compact[1] = COLOR_SMALL_MAX;
 			if (cnt > 0 && __hip_atomic_load(&S->c.nCompact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= COLOR_SMALL_MAX) s_compact[1] = atomicAdd(&S->c.nCompact, cnt);
 			s_compact[0] = 0;
+			const int cu = s_uncol[0];
+			s_uncol[1] = cu > 0 ? atomicAdd(&S->c.nUncolList, cu) : 0;
+			s_uncol[0] = 0;
 		}
 		__syncthreads();
+		if (uncolRank >= 0)
+		{
+			const int u = s_uncol[1] + uncolRank;
+			if (u < COLOR_SMALL_MAX) W.uncolList[u] = s;
+		}
 		if (compactRank >= 0)
 		{
 			const int u = s_compact[1] + compactRank;
