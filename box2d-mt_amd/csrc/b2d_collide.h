@@ -93,10 +93,14 @@ B2D_HD int b2dClipSegmentToLine(ClipVertex vOut[2], const ClipVertex vIn[2], V2 
 }
 
 // b2FindMaxSeparation (b2CollidePolygon.cpp:23-62): first max wins (strict >), inner min strict <.
+// FIXED > 0: both polygons are known to have FIXED vertices (k_collide's path for two staged box records: the loops unroll,
+// the vertex and normal reads are issued together instead of one round trip per loop iteration) - the same operations in the
+// same order as with the counts read from the records.
+template <int FIXED = 0>
 B2D_HD float b2dFindMaxSeparation(int* edgeIndex, const ShapeRec* poly1, Xf xf1, const ShapeRec* poly2, Xf xf2)
 {
-	int count1 = poly1->count;
-	int count2 = poly2->count;
+	const int count1 = FIXED ? FIXED : poly1->count;
+	const int count2 = FIXED ? FIXED : poly2->count;
 	Xf xf = b2dMulTXX(xf2, xf1);
 	int bestIndex = 0;
 	float maxSeparation = -B2D_MAXFLOAT;
@@ -124,9 +128,10 @@ B2D_HD float b2dFindMaxSeparation(int* edgeIndex, const ShapeRec* poly1, Xf xf1,
 }
 
 // b2FindIncidentEdge (b2CollidePolygon.cpp:64-107)
+template <int FIXED = 0>
 B2D_HD void b2dFindIncidentEdge(ClipVertex c[2], const ShapeRec* poly1, Xf xf1, int edge1, const ShapeRec* poly2, Xf xf2)
 {
-	int count2 = poly2->count;
+	const int count2 = FIXED ? FIXED : poly2->count;
 	V2 normal1 = b2dMulTRV(xf2.q, b2dMulRV(xf1.q, poly1->normals[edge1]));
 	int index = 0;
 	float minDot = B2D_MAXFLOAT;
@@ -148,17 +153,18 @@ B2D_HD void b2dFindIncidentEdge(ClipVertex c[2], const ShapeRec* poly1, Xf xf1, 
 }
 
 // b2CollidePolygons (b2CollidePolygon.cpp:116-239)
+template <int FIXED = 0>
 B2D_HD void b2dCollidePolygons(Manifold* m, const ShapeRec* polyA, Xf xfA, const ShapeRec* polyB, Xf xfB)
 {
 	m->pointCount = 0;
 	float totalRadius = polyA->radius + polyB->radius;
 
 	int edgeA = 0;
-	float separationA = b2dFindMaxSeparation(&edgeA, polyA, xfA, polyB, xfB);
+	float separationA = b2dFindMaxSeparation<FIXED>(&edgeA, polyA, xfA, polyB, xfB);
 	if (separationA > totalRadius) return;
 
 	int edgeB = 0;
-	float separationB = b2dFindMaxSeparation(&edgeB, polyB, xfB, polyA, xfA);
+	float separationB = b2dFindMaxSeparation<FIXED>(&edgeB, polyB, xfB, polyA, xfA);
 	if (separationB > totalRadius) return;
 
 	const ShapeRec* poly1;
@@ -190,9 +196,9 @@ B2D_HD void b2dCollidePolygons(Manifold* m, const ShapeRec* polyA, Xf xfA, const
 	}
 
 	ClipVertex incidentEdge[2];
-	b2dFindIncidentEdge(incidentEdge, poly1, xf1, edge1, poly2, xf2);
+	b2dFindIncidentEdge<FIXED>(incidentEdge, poly1, xf1, edge1, poly2, xf2);
 
-	int count1 = poly1->count;
+	const int count1 = FIXED ? FIXED : poly1->count;
 	int iv1 = edge1;
 	int iv2 = edge1 + 1 < count1 ? edge1 + 1 : 0;
 

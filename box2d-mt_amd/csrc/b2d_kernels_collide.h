@@ -274,6 +274,34 @@ k_collide(DW W, int sortTile)
 	// (... and, once the contacts are done, the scratch of the last workgroup's toiOrderDestroy)
 	__shared__ __attribute__((aligned(16))) unsigned char s_raw[STAGE ? ((512 * sizeof(ShapeRec) > TOI_ORDER_SCRATCH_BYTES || !ORDER) ? 512 * sizeof(ShapeRec) : TOI_ORDER_SCRATCH_BYTES) : (ORDER ? TOI_ORDER_SCRATCH_BYTES : 16)];
 	ShapeRec* const s_shape = (ShapeRec*)s_raw;
+	// (sortTile bit 2) the shape records of the workgroup's FIRST contact wait in LDS: a world of boxes has one record, and the
+	// separating-axis loops fetch its vertices and normals one by one - ~50 loads per contact, every one a round trip to the
+	// vector L1 for a value all 64 lanes share, one after the other: that chain, not the bandwidth and not the arithmetic, was
+	// this kernel's time on the 100 000-box Tumbler. A polygon pair whose two records are the staged ones reads LDS instead.
+	__shared__ __attribute__((aligned(16))) ShapeRec s_uni[2];
+	__shared__ int s_uniId[2];
+	const bool uniOn = !STAGE && (sortTile & 4) != 0;
+	sortTile &= 3;
+	if (uniOn)
+	{
+		const int i0 = (int)(blockIdx.x * blockDim.x);
+		int idA = 0, idB = 0;
+		if (i0 < n)
+		{
+			const int4 ids0 = C.ids[i0];
+			idA = W.p_shape[ids0.x];
+			idB = W.p_shape[ids0.y];
+		}
+		static_assert(sizeof(ShapeRec) % 4 == 0, "ShapeRec is copied word by word");
+		constexpr int RW = (int)(sizeof(ShapeRec) / 4);
+		if (threadIdx.x < 2 * RW)
+		{
+			const int which = (int)threadIdx.x / RW, word = (int)threadIdx.x % RW;
+			((uint32_t*)&s_uni[which])[word] = ((const uint32_t*)(W.shapes + (which ? idB : idA)))[word];
+		}
+		if (threadIdx.x == 0) { s_uniId[0] = idA; s_uniId[1] = idB; }
+		__syncthreads();
+	}
 	for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x)
 	{
 		int i = base + (int)threadIdx.x;
@@ -438,7 +466,23 @@ k_collide(DW W, int sortTile)
 					mf.p[1] = v2(o1.z, o1.w);
 					mf.id[0] = oldId0;
 					mf.id[1] = oldId1;
-					b2dEvaluate(&mf, sA, xfA, sB, xfB);
+					bool evaluated = false;
+					if (uniOn)
+					{
+						const int u0 = s_uniId[0], u1 = s_uniId[1];
+						const bool a0 = shapeA == u0, b0 = shapeB == u0;
+						if ((a0 || shapeA == u1) && (b0 || shapeB == u1))
+						{
+							const ShapeRec* lA = &s_uni[a0 ? 0 : 1];
+							const ShapeRec* lB = &s_uni[b0 ? 0 : 1];
+							if (lA->type == B2D_SHAPE_POLYGON && lB->type == B2D_SHAPE_POLYGON && lA->count == 4 && lB->count == 4)
+							{
+								b2dCollidePolygons<4>(&mf, lA, xfA, lB, xfB);
+								evaluated = true;
+							}
+						}
+					}
+					if (!evaluated) b2dEvaluate(&mf, sA, xfA, sB, xfB);
 					touching = mf.pointCount > 0;
 					float ni[2], ti[2];
 					ni[0] = oldImp.x; ti[0] = oldImp.y; ni[1] = oldImp.z; ti[1] = oldImp.w;

@@ -259,13 +259,16 @@ static int phaseCollide(b2hip_world* w)
 		// (round 6, measured and left out: sorting also by "the old manifold had points" - the pairs that will run the clipping - to
 		// give the one touching contact in six of a dense pile waves of its own: Tumbler 316 3.275 -> 3.338 ms, 1 M field 2.10 -> 2.14)
 		const int sort = w->collideSortEnv < 0 ? (many ? 1 : 0) : (w->collideSortEnv != 0 ? 1 : 0);
+		// (bit 2: the records of a workgroup's first contact staged in LDS, two staged 4-gons evaluated with unrolled loops -
+		// b2d_kernels_collide.h; Tumbler 316: 2.95 -> 2.88 ms. B2HIP_COLLIDE_UNI=0: off, the comparison form of the tests)
+		const int uni = w->collideUniOff ? 0 : 4;
 		if (stage) LAUNCH(w, (k_collide<1, true>), gridFor(d.capContacts), 256, d, sort);
 		else if (split)
 		{
-			LAUNCH(w, (k_collide<0, false>), gridFor(d.capContacts), 256, d, sort);
+			LAUNCH(w, (k_collide<0, false>), gridFor(d.capContacts), 256, d, sort | uni);
 			LAUNCH(w, k_toi_order_destroy, 1, 256, d);
 		}
-		else LAUNCH(w, (k_collide<0, true>), gridFor(d.capContacts), 256, d, sort);
+		else LAUNCH(w, (k_collide<0, true>), gridFor(d.capContacts), 256, d, sort | uni);
 		if (int rk = ktBracket(w, 2, 5)) return rk;
 		deviceExclusiveScan<int>(w->stream, d.keepFlag, d.keepScan, d.scanTmp, w->scanCtx, &d.st->c.nContacts, d.capContacts);
 		if (d.preSolveOn) LAUNCH(w, k_presolve_gather, gridFor(d.capContacts), 256, d);

@@ -695,8 +695,9 @@ def test_the_two_forms_of_k_collide_give_the_same_bits(amd, default_mode, monkey
     states, contact counts and (continuous physics on) the same TOI events step by step."""
     ccd = bh.F_CONTINUOUS | bh.F_SLEEP | bh.F_WARM
 
-    def run(scene, steps, split, **kw):
+    def run(scene, steps, split, uni="1", **kw):
         monkeypatch.setenv("B2HIP_COLLIDE_SPLIT", split)
+        monkeypatch.setenv("B2HIP_COLLIDE_UNI", uni)
         w = amd.world(scene, **kw)
         out = []
         for _ in range(steps):
@@ -706,8 +707,14 @@ def test_the_two_forms_of_k_collide_give_the_same_bits(amd, default_mode, monkey
         return out
 
     for scene, steps, kw in [(bh.BULLETS, 150, dict(p0=150, p1=8, seed=3, flags=ccd)), (bh.FIELD, 60, dict(p0=3000, p1=400, f0=60.0, f1=3.0, seed=11, flags=ccd)),
-                             (bh.TUMBLER, 120, dict(p0=60)), (bh.TUMBLER, 80, dict(p0=40, flags=ccd))]:
+                             (bh.TUMBLER, 120, dict(p0=60)), (bh.TUMBLER, 80, dict(p0=40, flags=ccd)), (bh.PILES, 100, dict(p0=40, p1=12, seed=5, flags=ccd))]:
         inside = run(scene, steps, "0", **kw)
         own = run(scene, steps, "1", **kw)
         first = next((i for i in range(steps) if inside[i] != own[i]), None)
         assert first is None, "scene %d: the replay as a launch of its own differs from the replay inside k_collide at step %d" % (scene, first)
+        # (both forms stage the shape records of a workgroup's first contact in LDS and evaluate two staged 4-gons with the
+        # loops unrolled - b2dCollidePolygons<4>: the same operations in the same order as with every record read from memory)
+        for split in ("0", "1"):
+            plain = run(scene, steps, split, uni="0", **kw)
+            first = next((i for i in range(steps) if inside[i] != plain[i]), None)
+            assert first is None, "scene %d: staged shape records differ from records read from memory at step %d (split %s)" % (scene, first, split)
