@@ -394,19 +394,50 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 	// next and the body and box of the next round are asked for while this round works.
 	const int largeQ = lane < nLarge ? W.largeProxies[lane] : -1;
 	const float4 largeFat = largeQ >= 0 ? W.p_fat[largeQ] : make_float4(0, 0, 0, 0);
+	// (round 6: ... and the cell headers of the NEXT round's proxy - count and start of its nine cells - while this round
+	// fetches and tests its candidates: a round is then one round trip, the candidates', not two in a row. The million
+	// proxies of the field are 122 rounds for each of the 8 192 waves the chip holds.)
+	// lanes 0..8 own one neighbour cell each; cells that hash to an already seen bucket are dropped
+	auto cellHeaders = [&](const float4& f, int* cntOut, int* startOut)
+	{
+		int ix, iy;
+		proxyCell(W, f, &ix, &iy);
+		const uint32_t h = lane < 9 ? cellHash(ix + (lane % 3) - 1, iy + (lane / 3) - 1, W.gridMask) : 0xffffffffu;
+		// (lane indices known at compile time: v_readlane - a scalar read of one lane - instead of a trip through the LDS
+		// crossbar per value; the kernel issues ~50 of these per proxy and is bound by them in sparse scenes)
+		bool dup = false;
+#pragma unroll
+		for (int j = 0; j < 8; ++j)
+		{
+			const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
+			if (j < lane && lane < 9 && hj == h) dup = true;
+		}
+		*cntOut = (lane < 9 && !dup) ? W.gridCount[h] : 0;
+		*startOut = lane < 9 ? W.gridStart[h] : 0;
+	};
 	int pNext = waveId < nm ? W.moveBuf[waveId] : -1;
 	int pAhead = waveId + nWaves < nm ? W.moveBuf[waveId + nWaves] : -1;
+	int pAhead2 = waveId + 2 * nWaves < nm ? W.moveBuf[waveId + 2 * nWaves] : -1;
 	int bodyNext = W.p_body[pNext < 0 ? 0 : pNext];
 	float4 fatNext = W.p_fat[pNext < 0 ? 0 : pNext];
+	int bodyAhead = W.p_body[pAhead < 0 ? 0 : pAhead];
+	float4 fatAhead = W.p_fat[pAhead < 0 ? 0 : pAhead];
+	int cntNext = 0, startNext = 0;
+	cellHeaders(fatNext, &cntNext, &startNext);
 	for (int k = waveId; k < nm; k += nWaves)
 	{
 		const int p = pNext;
 		const int bodyOfP = bodyNext;
 		const float4 a4 = fatNext;
+		const int cnt = cntNext, start = startNext;
 		pNext = pAhead;
-		pAhead = k + 2 * nWaves < nm ? W.moveBuf[k + 2 * nWaves] : -1;
-		bodyNext = W.p_body[pNext < 0 ? 0 : pNext];
-		fatNext = W.p_fat[pNext < 0 ? 0 : pNext];
+		bodyNext = bodyAhead;
+		fatNext = fatAhead;
+		pAhead = pAhead2;
+		pAhead2 = k + 3 * nWaves < nm ? W.moveBuf[k + 3 * nWaves] : -1;
+		bodyAhead = W.p_body[pAhead < 0 ? 0 : pAhead];
+		fatAhead = W.p_fat[pAhead < 0 ? 0 : pAhead];
+		cellHeaders(fatNext, &cntNext, &startNext);
 		if (p < 0 || bodyOfP < 0) continue;
 		// (a spatially sharded world: every rank searches for the proxies ITS bodies moved; b2d_kernels_spatial.h, E2)
 		if (W.spatial && (W.b_flags[bodyOfP] & BF_TYPE_MASK) != BT_STATIC && W.b_owner[bodyOfP] != (uint8_t)W.shardRank) continue;
@@ -419,21 +450,6 @@ __global__ __launch_bounds__(256) void k_find_pairs_small(DW W)
 		AABB a;
 		a.lo = v2(a4.x, a4.y);
 		a.hi = v2(a4.z, a4.w);
-		int ix, iy;
-		proxyCell(W, a4, &ix, &iy);
-		// lanes 0..8 own one neighbour cell each; cells that hash to an already seen bucket are dropped
-		uint32_t h = lane < 9 ? cellHash(ix + (lane % 3) - 1, iy + (lane / 3) - 1, W.gridMask) : 0xffffffffu;
-		// (lane indices known at compile time: v_readlane - a scalar read of one lane - instead of a trip through the LDS
-		// crossbar per value; the kernel issues ~50 of these per proxy and is bound by them in sparse scenes)
-		bool dup = false;
-#pragma unroll
-		for (int j = 0; j < 8; ++j)
-		{
-			const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
-			if (j < lane && lane < 9 && hj == h) dup = true;
-		}
-		const int cnt = (lane < 9 && !dup) ? W.gridCount[h] : 0;
-		const int start = lane < 9 ? W.gridStart[h] : 0;
 		int ecs[9], ccs[9], scs[9];
 		int total = 0;
 #pragma unroll

@@ -217,15 +217,23 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	const int nAll = S->c.nContacts;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAll; i += gridDim.x * blockDim.x)
 	{
+		// (colour and flags together - one round trip, not two in a row, for the one contact in seven of a dense pile that owns
+		// a colour; and without a partition nothing is cut: the answer needs neither the ids nor the bodies)
 		const int col = C.color[i];
+		const uint32_t cfl = C.flags[i];
 		if (col < 0 || col >= MAX_COLORS) continue;
-		if ((C.flags[i] & (CF_TOUCHING | CF_SENSOR)) != CF_TOUCHING)
+		if ((cfl & (CF_TOUCHING | CF_SENSOR)) != CF_TOUCHING)
 		{
 			C.color[i] = -1;
 			continue;
 		}
-		int4 ids = C.ids[i];
 		const unsigned long long bit = 1ull << col;
+		if (noPart)
+		{
+			if (bit & colorStaleMask(false)) C.color[i] = -1;
+			continue;
+		}
+		int4 ids = C.ids[i];
 		const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
 		if (bit & colorStaleMask(isCut(ids.z, nsA, ids.w, nsB)))
 		{
@@ -248,10 +256,16 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 		if (valid)
 		{
 			const int ci = W.li_contacts[s];
+			// (what hangs on the contact in one round trip, what hangs on its bodies in the next: the degrees are fetched beside
+			// the body flags, not behind them)
 			const int4 ids = C.ids[ci];
-			const bool nsA = (W.b_flags[ids.z] & BF_TYPE_MASK) != BT_STATIC, nsB = (W.b_flags[ids.w] & BF_TYPE_MASK) != BT_STATIC;
-			const bool hubA = rowIsSerial(W, nsA, ids.z, nsB, ids.w), hubB = false; // (swept in order: see rowIsSerial)
-			if (hubA && !rowIsHubs(W, nsA, ids.z, nsB, ids.w)) atomicAdd(&S->c.nSerialOrphans, 1);
+			const int colStored = C.color[ci];
+			const uint32_t bfA = W.b_flags[ids.z], bfB = W.b_flags[ids.w];
+			const int dgA = W.deg[ids.z], dgB = W.deg[ids.w];
+			const bool nsA = (bfA & BF_TYPE_MASK) != BT_STATIC, nsB = (bfB & BF_TYPE_MASK) != BT_STATIC;
+			const bool isHubs = (nsA && dgA > HUB_DEGREE) || (nsB && dgB > HUB_DEGREE); // (rowIsHubs)
+			const bool hubA = isHubs || (W.serialOrphans && rowIsSerial(W, nsA, ids.z, nsB, ids.w)), hubB = false; // (swept in order: see rowIsSerial)
+			if (hubA && !isHubs) atomicAdd(&S->c.nSerialOrphans, 1);
 			{
 				// block census: the row belongs to the home block of its first non-static body (counted in LDS: ten
 				// thousand rows adding to a few dozen words of memory serialise in L2)
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 					if (nsA && nsB && blkA != blkB) ++cutRows;
 				}
 			}
-			col = C.color[ci];
+			col = colStored;
 			if (col >= 0 && col < MAX_COLORS && ((1ull << col) & colorStaleMask(isCut(ids.z, nsA, ids.w, nsB)))) col = -1; // (voided above)
 			if (hubA || hubB)
 			{
