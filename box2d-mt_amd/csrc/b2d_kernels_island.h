@@ -327,23 +327,28 @@ __global__ __launch_bounds__(256) void k_island_union(DW W, int rounds)
 	for (int base = blockIdx.x * tile; base < n; base += gridDim.x * tile)
 	{
 		const int m = solidTileGather<true>(C, n, base, rounds, &s_tile);
-		for (int j = threadIdx.x; j < m; j += 256)
+		for (int j0 = 0; j0 < m; j0 += 256)
 		{
-			const int i = s_tile.list[j];
-			int4 ids = C.ids[i];
+			const int j = j0 + (int)threadIdx.x;
+			const bool live = j < m;
+			const int i = live ? s_tile.list[j] : 0;
+			int4 ids = live ? C.ids[i] : make_int4(0, 0, 0, 0);
 			// (the first level of both walks is fetched together with the body flags: one round trip less in front of the walks)
 			const uint32_t bfA = W.b_flags[ids.z], bfB = W.b_flags[ids.w];
 			const int pa = __hip_atomic_load(&W.parent[ids.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const int pb = __hip_atomic_load(&W.parent[ids.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			bool nsA = (bfA & BF_TYPE_MASK) != BT_STATIC;
-			bool nsB = (bfB & BF_TYPE_MASK) != BT_STATIC;
+			const bool nsA = live && (bfA & BF_TYPE_MASK) != BT_STATIC;
+			const bool nsB = live && (bfB & BF_TYPE_MASK) != BT_STATIC;
 			// (the count a body's atomic returns is the contact's place in the body's adjacency segment: k_island_edges fills the
-			// segments with plain stores - for every body, large islands included: k_color_masks walks them)
+			// segments with plain stores - for every body, large islands included: k_color_masks walks them. These returning
+			// atomics - 750 000 in a step of the settled Tumbler - are served at the memory side at ~8 per ns and were most of
+			// this kernel's time; neighbouring lanes with the same body share one: b2d_wave.h, waveRunAlloc)
 			int2 slot = make_int2(-1, -1);
-			if (nsA) slot.x = atomicAdd(&W.deg[ids.z], 1);
-			if (nsB) slot.y = atomicAdd(&W.deg[ids.w], 1);
+			const int sa = waveRunAlloc(W.deg, ids.z, nsA), sb = waveRunAlloc(W.deg, ids.w, nsB);
+			if (nsA) slot.x = sa;
+			if (nsB) slot.y = sb;
 			if (nsA && nsB) ufUnionFrom(W.parent, ids.z, ids.w, pa, pb);
-			W.adjSlot[i] = slot;
+			if (live) W.adjSlot[i] = slot;
 		}
 		__syncthreads(); // (the list is the next tile's)
 	}

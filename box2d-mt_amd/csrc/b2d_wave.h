@@ -292,6 +292,29 @@ __device__ __forceinline__ int waveKeyedAlloc(int* counter, int key, bool valid)
 	return result;
 }
 
+// The same for keys that come in RUNS (neighbouring lanes with the same key): the first lane of a run allocates for the run -
+// one atomic per run, all in flight together, no loop over the keys. Equal keys in lanes that are not neighbours simply make
+// two runs. (k_island_union: the solid contacts of a tile in contact order - contacts are created in key order, so the
+// contacts of one fixture sit side by side and a body's degree was counted up one returning atomic at a time.)
+__device__ __forceinline__ int waveRunAlloc(int* counter, int key, bool valid)
+{
+	const int lane = waveLane();
+	const int prevKey = __shfl_up(key, 1);
+	const bool prevValid = (bool)__shfl_up((int)valid, 1);
+	const bool head = valid && (lane == 0 || !prevValid || prevKey != key);
+	// (a run ends where the next head or the next invalid lane is)
+	const unsigned long long breaks = __ballot(head || !valid);
+	const unsigned long long above = lane == 63 ? 0ull : (breaks >> (lane + 1)) << (lane + 1);
+	const int end = above ? __ffsll((long long)above) - 1 : 64; // first lane behind this lane that starts something else
+	const unsigned long long heads = __ballot(head);
+	const unsigned long long below = heads & ((2ull << lane) - 1ull); // heads at or below this lane
+	const int myHead = below ? 63 - __clzll((long long)below) : lane;
+	int base = 0;
+	if (head) base = atomicAdd(&counter[key], end - lane);
+	base = __shfl(base, myHead);
+	return valid ? base + (lane - myHead) : 0;
+}
+
 // The same in ONE atomic round trip whatever the number of distinct keys: the lanes that hold the same key find one another
 // with a ballot per key bit (as the radix sort's scatter ranks equal digits), the first lane of every group allocates for
 // the group, and all those atomics are in flight together. waveKeyedAlloc pays one round trip per distinct key, one after
