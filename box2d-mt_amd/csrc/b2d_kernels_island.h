@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_island_union(DW W, int rounds)
 			// (the count a body's atomic returns is the contact's place in the body's adjacency segment: k_island_edges fills the
 			// segments with plain stores - for every body, large islands included: k_color_masks walks them. Neighbouring lanes
 			// with the same body share one atomic: b2d_wave.h, waveRunAlloc. Not what this kernel waits for, though: issuing all
-			// 750 000 of the settled Tumbler's a second time on a scratch array changed nothing - the walks are.)
+			// 750 000 of the settled Tumbler's a second time on a scratch array changed nothing - docs/KERNEL_NOTES.md.)
 			int2 slot = make_int2(-1, -1);
 			const int sa = waveRunAlloc(W.deg, ids.z, nsA), sb = waveRunAlloc(W.deg, ids.w, nsB);
 			if (nsA) slot.x = sa;
