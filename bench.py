@@ -67,7 +67,7 @@ STATE_VS_REFERENCE_TUMBLER = ("NOT the reference's state: the reference build ru
                               "more penetrated than colour order does (the effect grows with depth: 1 - 2 % at 10 000 boxes, 9 - 12 % at 22 500, 2 x here; "
                               "profiles/r06_c_order_effect_tumbler150.txt, tests/test_gpu_settled_windows.py). The timed state therefore holds about half the "
                               "contacts the reference would be stepping; where this path's own pile was that dense (steps 150..300: 5 M contacts, 520 000 - 630 000 "
-                              "touching) a step took 5.5 - 6.3 ms (`transient`, tools/gpu_step_series.py)")
+                              "touching) a step takes 4.5 - 4.9 ms (`transient.steps_200_299_ms_per_step`, tools/gpu_step_series.py; 5.5 - 6.3 before the second half of round 6)")
 PARITY_PYRAMID = ("coloured order (k_solve_blocks): integer results exact; ONE step from a bit-identical snapshot of the timed state: "
                   "|dp| <= 1.7 cm on 1 m boxes (1.13e-4 of the 150 m scene; median 1-2 mm), |dv| <= 0.30 m/s, 18 of 30 000 contacts differ "
                   "(tests/test_gpu_onestep.py); the bit-exact class is `exact_order`")
