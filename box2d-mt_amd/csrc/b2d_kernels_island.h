@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void k_island_init(DW W)
 	{
 		W.blkRows[(size_t)i * BLK_SLOT] = 0;
 		W.blkCursor[(size_t)i * BLK_SLOT] = 0;
-		W.blkBodyCount[i] = 0;
-		W.blkBodyCursor[i] = 0;
+		W.blkBodyCount[(size_t)i * BLK_SLOT] = 0;
+		W.blkBodyCursor[(size_t)i * BLK_SLOT] = 0;
 	}
 	const int n = W.nBodies;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(1024) void k_block_census(DW W, DState* pub)
 	// (100 000-box Tumbler: 0.15 ms less than this workgroup walking 45 000 bodies).
 	if (S->c.nLBodies > CENSUS_WG_MAX_BODIES)
 	{
-		const int cnt = t < nb ? W.blkBodyCount[t] : 0;
+		const int cnt = t < nb ? W.blkBodyCount[(size_t)t * BLK_SLOT] : 0;
 		const int start = blockScan1024(cnt, s_buf, &total, &mx);
 		if (t < nb) W.blkBodyStart[t] = start;
 		if (t == 0)
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void k_color_recheck_begin(DW W)
 	{
 		W.blkRows[(size_t)i * BLK_SLOT] = 0;
 		W.blkCursor[(size_t)i * BLK_SLOT] = 0;
-		W.blkBodyCount[i] = 0;
-		W.blkBodyCursor[i] = 0;
+		W.blkBodyCount[(size_t)i * BLK_SLOT] = 0;
+		W.blkBodyCursor[(size_t)i * BLK_SLOT] = 0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS)
 	{

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 				e = effBlk(W, body);
 				if (e > 0 && e <= nb) W.b_blk1[body] = e; else e = 0;
 			}
-			if (e > 0) atomicAdd(&W.blkBodyCount[e - 1], 1);
+			if (e > 0) atomicAdd(&W.blkBodyCount[(size_t)(e - 1) * BLK_SLOT], 1);
 		}
 	}
 }
@@ -859,7 +859,10 @@ __global__ __launch_bounds__(256) void k_color_fill(DW W, int restFirst)
 			{
 				// (one atomic per lane, all in flight together: the bodies of a wave belong to many blocks, and handing the slots out
 				// block after block - waveKeyedAlloc - is a round trip per block)
-				const int slot = atomicAdd(&W.blkBodyCursor[e - 1], 1);
+				// (a line per block - BLK_SLOT - like the row counters: 50 000 bodies of the 50 086-box pyramid adding to 130 words on
+				// FOUR lines queued behind one another there, 5 ns each: 64 us of this kernel's 76, and as much of k_color_check's
+				// count, found with a clock around the loop)
+				const int slot = atomicAdd(&W.blkBodyCursor[(size_t)(e - 1) * BLK_SLOT], 1);
 				W.blkBodies[W.blkBodyStart[e - 1] + slot] = body;
 				W.b_slot[body] = slot;
 			}

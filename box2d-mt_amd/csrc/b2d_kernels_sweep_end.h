@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void k_solver_recover_reset(DW W, int* bar)
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_BLOCKS + 1; i += gridDim.x * blockDim.x)
 	{
 		W.blkCursor[(size_t)i * BLK_SLOT] = 0;
-		W.blkBodyCursor[i] = 0;
+		W.blkBodyCursor[(size_t)i * BLK_SLOT] = 0;
 	}
 	if (blockIdx.x == 0 && threadIdx.x <= MAX_COLORS) W.colorCursor[colorSlot(threadIdx.x)] = 0;
 	if (blockIdx.x == 0 && threadIdx.x < 32) bar[threadIdx.x] = 0;

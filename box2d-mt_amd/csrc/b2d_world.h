@@ -397,7 +397,7 @@ struct DW
 	int* blkRows;        // per block: rows it owns this step
 	int* blkRowStart;    // [nBlocks + 1] exclusive scan of blkRows
 	int* blkCursor;      // per block: fill cursor of k_color_fill
-	int* blkBodyCount;   // home bodies per block (counted by k_color_check, scanned by k_block_census)
+	int* blkBodyCount;   // home bodies per block (counted by k_color_check, scanned by k_block_census); [block * BLK_SLOT], like blkRows
 	int* blkBodyCursor;  // ... slots handed out so far (k_color_fill)
 	int* blkBodyStart;   // [nBlocks + 1] home bodies of each block (segments of blkBodies)
 	int* blkBodies;      // large-island bodies grouped by home block

@@ -925,7 +925,7 @@ static int ensureCapacity(b2hip_world* w, size_t needContacts)
 		ENS(toiVerdict, hasPreSolve(w) && w->def.continuous ? cc : 1);
 		ENS(hostList, std::max<size_t>(std::max(4 * nPre, nFil), hasFilter(w) ? capPairs : 1)); // (PreSolve material edits: 4 words each)
 	}
-	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, (size_t)(MAX_BLOCKS + 2) * BLK_SLOT); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, (size_t)(MAX_BLOCKS + 2) * BLK_SLOT); ENS(blkBodyCount, MAX_BLOCKS + 2); ENS(blkBodyCursor, MAX_BLOCKS + 2);
+	ENS(b_blk1, nb); ENS(b_adopt, nb); ENS(b_adoptStage, 3 * nb); ENS(blkRows, (size_t)(MAX_BLOCKS + 2) * BLK_SLOT); ENS(blkRowStart, MAX_BLOCKS + 2); ENS(blkCursor, (size_t)(MAX_BLOCKS + 2) * BLK_SLOT); ENS(blkBodyCount, (size_t)(MAX_BLOCKS + 2) * BLK_SLOT); ENS(blkBodyCursor, (size_t)(MAX_BLOCKS + 2) * BLK_SLOT);
 	ENS(blkBodyStart, MAX_BLOCKS + 2); ENS(blkBodies, nb); ENS(rowColor, cc); ENS(b_cutv, nb);
 	ENS(b_owner, w->spatial ? nb : 1); ENS(spNewOwner, w->spatial ? nb : 1); ENS(spAwake, w->spatial ? nb : 1); ENS(spStraddle, w->spatial ? std::max<size_t>(w->spStraddle.cap, 4096) : 1);
 	ENS(spCount, w->spatial ? (size_t)SP_RESOLVE_MAX * SHARD_MAX_RANKS : 1); ENS(spTarget, w->spatial ? SP_RESOLVE_MAX : 1);
