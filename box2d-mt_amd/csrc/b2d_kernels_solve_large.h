@@ -337,7 +337,10 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 	// needRecolor bit0: two constraints on one body share a colour -> colour everything again;
 	// nUncolored: constraints without a colour yet -> incremental rounds on top of the existing masks
 	if (bad) atomicOr(&S->c.needRecolor, 1);
-	if (uncolored) atomicAdd(&S->c.nUncolored, uncolored);
+	// (nUncolored = nUncolList - the same rows, counted once, by the workgroups' list allocations above; k_color_masks, the
+	// kernel behind this one, copies it. A sum per wave on top was 1 500 more atomics on the line of Counters that every
+	// workgroup of this kernel already queues at: a clock around the sections showed 13 - 45 us per workgroup spent there)
+	(void)uncolored;
 	// wave-combined, and only what would CHANGE the word (the maximum and the masks only grow while this kernel runs; a load
 	// past the L2 first): one atomic per wave on each of the three words was 16 000 atomics, served one after the other, for
 	// the 350 000 constraints of the settled Tumbler - most of this kernel's 209 us
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(256) void k_color_check(DW W)
 __global__ __launch_bounds__(256) void k_color_masks(DW W)
 {
 	b2dPhaseStamp(W);
+	if (blockIdx.x == 0 && threadIdx.x == 0) W.st->c.nUncolored = W.st->c.nUncolList; // (k_color_check's count of the rows without a colour)
 	DState* S = W.st;
 	const ContactArrays& C = W.ca[S->cur];
 	int bad = 0;
