@@ -113,7 +113,6 @@ int b2hip_world_create(const b2hip_world_def* def, b2hip_world** out)
 	w->noSideStream = getenv("B2HIP_NO_SIDE_STREAM") != nullptr;
 	w->profileDetail = !(getenv("B2HIP_PROFILE_DETAIL") && atoi(getenv("B2HIP_PROFILE_DETAIL")) == 0);
 	if (const char* e = getenv("B2HIP_SOLID_ROUNDS")) { const int v = atoi(e); w->solidRoundsEnv = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }
-	w->noPreQueue = getenv("B2HIP_NO_PREQUEUE") && atoi(getenv("B2HIP_NO_PREQUEUE")) != 0;
 	w->collideSplitEnv = getenv("B2HIP_COLLIDE_SPLIT") ? atoi(getenv("B2HIP_COLLIDE_SPLIT")) : -1;
 	w->collideUniOff = getenv("B2HIP_COLLIDE_UNI") && atoi(getenv("B2HIP_COLLIDE_UNI")) == 0;
 	w->collideSortEnv = getenv("B2HIP_COLLIDE_SORT") ? atoi(getenv("B2HIP_COLLIDE_SORT")) : -1;

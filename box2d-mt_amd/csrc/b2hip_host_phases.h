@@ -647,7 +647,6 @@ static int phaseSolve(b2hip_world* w)
 		d.blockSort = (useBlocks || useSweep) ? 1 : 0;
 		bool useResident = usePersistent && (useBlocks || B2HIP_HAVE_VALIDATION_SOLVERS);
 		bool colorsOnDevice = false;
-		bool preSnapshot = false, preIntegrate = false; // (launched ahead of the wait for the colours, below)
 		bool censusVoid = false;
 		bool colorSpill = false; // some constraint found no free colour this step: it sits in the hub group and is swept in order
 		bool roundsToo = false;  // the grid-wide colouring rounds run (asked for by the census, or to finish what k_color_small left)
@@ -674,16 +673,6 @@ static int phaseSolve(b2hip_world* w)
 				{
 					if ((colorSmallQueued && colorAheadPublished) || (!colorSmallQueued && pubColors))
 					{
-						// (round 6) what the solver's front needs of the colours is nothing yet: the saved state for a recovery and the
-						// velocity integration go out BEFORE the host waits - they run behind k_color_small while the host learns the
-						// colours and issues the three or four launches that lay the rows out; behind the wait those launches' ~20 us
-						// of host time met an idle stream every step.
-						if (!useResident && !exactLarge && !w->debugTrace && !w->kernelTiming && !w->kernelTimingLaunches && !w->noPreQueue)
-						{
-							if (w->recoverOn && (useSweep || (w->sweepEnd && w->restFlow))) { LAUNCH(w, k_solver_snapshot, gridFor(std::max(nLBodies, nLContacts)), 256, d, 0); preSnapshot = true; }
-							LAUNCH(w, k_large_integrate, gB, 256, d, sp, hasJoints ? 1 : 0);
-							preIntegrate = true;
-						}
 						rc = awaitColors(w);
 						if (rc == 0) c.nColors = w->h_dstate->c.nColors;
 						if (rc == 0) memcpy(c.colorRows, w->h_dstate->c.colorRows, sizeof(c.colorRows));
@@ -811,7 +800,7 @@ static int phaseSolve(b2hip_world* w)
 		};
 		const int gJ = gridFor(std::max(nLIslands, 1), 64, 1 << 16);
 		waitsBetweenWorkgroups = useResident || useSweep || (useSweepEnd && restFirst < nColors);
-		if (!safe && w->recoverOn && waitsBetweenWorkgroups && !preSnapshot) LAUNCH(w, k_solver_snapshot, gridFor(std::max(nLBodies, nLContacts)), 256, d, 0);
+		if (!safe && w->recoverOn && waitsBetweenWorkgroups) LAUNCH(w, k_solver_snapshot, gridFor(std::max(nLBodies, nLContacts)), 256, d, 0);
 		if (useResident)
 		{
 			// one resident grid for the whole sweep structure; colour boundaries are grid barriers (validation_src/b2d_validation_solvers.h)
@@ -878,7 +867,7 @@ static int phaseSolve(b2hip_world* w)
 		// constraint set-up, every sweep, impulses stored, positions, write-back and sleep)
 		if (w->kernelTiming == 5 && !safe) { rc = ktRecord(w); if (rc) return rc; w->ktKind = 8; w->familyLaunchesAtStart = w->launchCount; }
 		const bool sortInIntegrate = hasJoints && !exactLarge && !w->debugTrace;
-		if (safe || !preIntegrate) LAUNCH(w, k_large_integrate, gB, 256, d, sp, sortInIntegrate ? 1 : 0);
+		LAUNCH(w, k_large_integrate, gB, 256, d, sp, sortInIntegrate ? 1 : 0);
 		if (w->debugTrace) HIP_TRY(hipMemcpyAsync(w->dbgVel.p, w->b_vel.p, w->bodies.size() * 16, hipMemcpyDeviceToDevice, w->stream));
 		TRACE("integrate");
 		if (hasJoints && !exactLarge && !sortInIntegrate) LAUNCH(w, k_joints_sort, gJ, 64, d);

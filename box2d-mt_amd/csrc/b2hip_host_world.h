@@ -250,7 +250,6 @@ struct b2hip_world
 	bool solverRows, solverLocal, solverMailbox, noSideStream, profileDetail;
 	int collideStage = -1;       // B2HIP_COLLIDE_STAGE=0 / 1: never / always stage the shape records through LDS (default: by the record count)
 	int solidRoundsEnv = 0;      // B2HIP_SOLID_ROUNDS=1 / 2 / 4 / 8: the tile of the island build's passes over the contacts (x 256 contacts), else by the contact count
-	bool noPreQueue = false;     // B2HIP_NO_PREQUEUE=1: the recovery snapshot and the velocity integration of a launch-per-colour solve are launched behind the wait for the colours (comparison)
 	int collideSplitEnv = -1;    // B2HIP_COLLIDE_SPLIT=0 / 1: k_collide with the TOI-order replay inside / as a launch of its own (four waves per SIMD), else by the contact count
 	bool collideUniOff = false;  // B2HIP_COLLIDE_UNI=0: k_collide reads every shape record from memory (no staged pair of records)
 	int collideSortEnv = -1;     // B2HIP_COLLIDE_SORT=0 / 1: k_collide never / always sorts the contacts of a tile by shape-pair class in LDS
