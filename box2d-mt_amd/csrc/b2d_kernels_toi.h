@@ -75,6 +75,13 @@ __device__ __forceinline__ void toiForEachCandidate(const DW& W, AABB a, int lan
 }
 
 // b2World::ComputeToi(c, alpha0) (b2World.cpp:401-444): the sweeps are already on the same interval.
+__device__ __forceinline__ float computeToiOf(const GjkProxy& pA, const GjkProxy& pB, const Sweep& sA, const Sweep& sB)
+{
+	float t = 1.0f;
+	const int state = b2dTimeOfImpact(&t, pA, sA, pB, sB, 1.0f);
+	const float alpha0 = sA.alpha0;
+	return state == TOI_TOUCHING ? b2dMin(alpha0 + (1.0f - alpha0) * t, 1.0f) : 1.0f;
+}
 __device__ __forceinline__ float computeToi(const DW& W, int4 ids, const Sweep& sA, const Sweep& sB)
 {
 	const GjkProxy pA = b2dProxy(W.shapes + W.p_shape[ids.x]);
@@ -83,6 +90,21 @@ __device__ __forceinline__ float computeToi(const DW& W, int4 ids, const Sweep& 
 	const int state = b2dTimeOfImpact(&t, pA, sA, pB, sB, 1.0f);
 	const float alpha0 = sA.alpha0;
 	return state == TOI_TOUCHING ? b2dMin(alpha0 + (1.0f - alpha0) * t, 1.0f) : 1.0f;
+}
+
+// ... with the vertices of both shapes copied into `stage` first (LDS, 2 x B2D_MAX_POLY_VERTS of the calling lane): the root
+// finder and its distance iterations read them index by index, hundreds of times - from LDS instead of through the vector L1
+// (k_toi_first on the 1 M field: 204 -> 166 us; the same arithmetic on the same values)
+__device__ __forceinline__ float computeToiStaged(const DW& W, int4 ids, const Sweep& sA, const Sweep& sB, V2* stage)
+{
+	const ShapeRec* rA = W.shapes + W.p_shape[ids.x];
+	const ShapeRec* rB = W.shapes + W.p_shape[ids.y];
+	GjkProxy pA = b2dProxy(rA), pB = b2dProxy(rB);
+#pragma unroll
+	for (int k = 0; k < B2D_MAX_POLY_VERTS; ++k) { stage[k] = rA->verts[k]; stage[B2D_MAX_POLY_VERTS + k] = rB->verts[k]; }
+	pA.verts = stage;
+	pB.verts = stage + B2D_MAX_POLY_VERTS;
+	return computeToiOf(pA, pB, sA, sB);
 }
 
 // IsMinToiCandidate (b2Contact.h:403-418) + !e_inactiveFlag: may this contact take part in the arg-min?
@@ -125,6 +147,11 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 	// table (DW::toiPos2c[0, nToiOrder), kept by toiOrderDestroy / k_toi_order_create / the edits). A lane per SLOT instead of a
 	// lane per contact: the million-body field has 1.2 M contacts and ~40 000 candidates, whose evaluations - thousands of
 	// instructions each - were spread one or two to a wave over every wave of the launch (113 us); now they sit side by side.
+	// (round 6) The vertices of a candidate's two shapes wait in LDS, a lane's own 128 bytes: the root finder and the distance
+	// iterations inside it read them one at a time, index by index, hundreds to thousands of times per candidate - each a
+	// round trip to the vector L1 in a chain (the field's million distinct records: the first touch of each comes from memory)
+	// - and that chain, not the arithmetic, was the kernel's time.
+	__shared__ V2 s_toiVerts[256][2 * B2D_MAX_POLY_VERTS];
 	const int nSlots = S->c.nToiOrder < W.capContacts ? S->c.nToiOrder : W.capContacts;
 	(void)n;
 	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nSlots; s += gridDim.x * blockDim.x)
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(256) void k_toi_first(DW W)
 		if (toiEligible(W, flags, ids))
 		{
 			const Sweep sA = loadSweep(W, ids.z), sB = loadSweep(W, ids.w);
-			const float alpha = computeToi(W, ids, sA, sB);
+			const float alpha = computeToiStaged(W, ids, sA, sB, s_toiVerts[threadIdx.x]);
 			++calls;
 			float4 mat = C.mat[i];
 			mat.w = alpha;
@@ -582,7 +609,7 @@ __device__ __forceinline__ void toiLoopRun(const DW& W, const StepParams& sp, in
 					if ((ldFlags(&W.b_flags[ids.z]) & BF_TYPE_MASK) == BT_STATIC) sA.alpha0 = sB.alpha0;
 					else if ((ldFlags(&W.b_flags[ids.w]) & BF_TYPE_MASK) == BT_STATIC) sB.alpha0 = sA.alpha0;
 				}
-				const float alpha = computeToi(W, ids, sA, sB);
+				const float alpha = computeToi(W, ids, sA, sB); // (staged through LDS as in k_toi_first: measured, no difference to the step - the event loops wait for one another's events, not for this)
 				atomicAdd(&s_calls, 1);
 				float4 mat = C.mat[c];
 				mat.w = alpha;
